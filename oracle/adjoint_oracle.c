@@ -1,0 +1,936 @@
+/*
+ * oracle/adjoint_oracle.c — CPU restatement of the SciMLSensitivity.jl continuous-adjoint hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see adjoint_oracle.h for the parity-pinning statement).  Plain C99.
+ * Every function cites the reference lines (relative to /root/reference) whose behaviour it restates.
+ * It is written for fidelity to the reference's control flow — one trajectory at a time, a generic
+ * ODE integrator with tstops and callbacks, a functor-style adjoint RHS — NOT for speed.
+ *
+ * [upstream-recall] marks behaviour of un-vendored packages (OrdinaryDiffEq / DiffEqCallbacks / QuadGK)
+ * restated from their published algorithms; see SURVEY.md §8c and Appendix A.
+ */
+#include "adjoint_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <float.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_MAXK 7
+
+/* =====================================================================================
+ * 1. Models: f, (df/du)^T lam, (df/dp)^T lam — the user-VJP seam
+ *    vjp(dlam, lam, u, p, t) / vjp_p(dgrad, lam, u, p, t), un-negated
+ *    (src/derivative_wrappers.jl:284-359; test/Core3/user_vjp.jl:14-38)
+ * ===================================================================================== */
+typedef struct {
+    int id, n, np;
+    int dims[4];
+    double *work; /* scratch for big models */
+} orc_model;
+
+static int model_init(orc_model *m, int id, const int dims[4]) {
+    m->id = id; m->work = NULL;
+    for (int i = 0; i < 4; ++i) m->dims[i] = dims ? dims[i] : 0;
+    switch (id) {
+    case ORC_MODEL_LV: case ORC_MODEL_LVT: m->n = 2; m->np = 4; break;
+    case ORC_MODEL_LORENZ: m->n = 3; m->np = 3; break;
+    case ORC_MODEL_LINDIAG: m->n = 2; m->np = 2; break;
+    case ORC_MODEL_FALLMASS: m->n = 2; m->np = 2; break;
+    case ORC_MODEL_MLP: {
+        int d = m->dims[0], H = m->dims[1], B = m->dims[2];
+        if (d <= 0 || H <= 0 || B <= 0) return -1;
+        m->n = d * B; m->np = H * d + H + H * H + H + d * H + d;
+        break; }
+    case ORC_MODEL_BRUSS: {
+        int G = m->dims[0]; if (G <= 1) return -1;
+        m->n = 2 * G * G; m->np = 3; break; }
+    default: return -1;
+    }
+    return 0;
+}
+
+int orc_model_sizes(int model, const int dims[4], int *n, int *np) {
+    orc_model m; if (model_init(&m, model, dims)) return -1;
+    *n = m.n; *np = m.np; return 0;
+}
+
+/* Brusselator forcing term (docs/src/examples/pde/brusselator.md:85) */
+static double bruss_force(double x, double y, double t) {
+    return (((x - 0.3) * (x - 0.3) + (y - 0.6) * (y - 0.6)) <= 0.01 && t >= 1.1) ? 5.0 : 0.0;
+}
+
+static void model_f(const orc_model *m, double *du, const double *u, const double *p, double t) {
+    switch (m->id) {
+    case ORC_MODEL_LV:      /* test/Core3/user_vjp.jl:6-10 */
+        du[0] = p[0] * u[0] - p[1] * u[0] * u[1];
+        du[1] = -p[2] * u[1] + p[3] * u[0] * u[1];
+        break;
+    case ORC_MODEL_LVT:     /* test/Core3/adjoint.jl:8-12 */
+        du[0] = p[0] * u[0] - p[1] * u[0] * u[1] * t;
+        du[1] = -p[2] * u[1] + t * p[3] * u[0] * u[1];
+        break;
+    case ORC_MODEL_LORENZ:  /* test/Core3/adjoint.jl:1160-1166 */
+        du[0] = p[0] * (u[1] - u[0]);
+        du[1] = u[0] * (p[1] - u[2]) - u[1];
+        du[2] = u[0] * u[1] - p[2] * u[2];
+        break;
+    case ORC_MODEL_LINDIAG: /* test/Core1/sparse_adjoint.jl:6-7 */
+        du[0] = p[0] * u[0]; du[1] = p[1] * u[1];
+        break;
+    case ORC_MODEL_FALLMASS:/* test/Core7/physical_ode_regression.jl:20-23 */
+        du[0] = u[1]; du[1] = -p[0];
+        break;
+    case ORC_MODEL_MLP: {
+        /* U is d x B column-major; f(U) = W3 tanh(W2 tanh(W1 U + b1) + b2) + b3 (docs/src/Benchmark.md:62 shape) */
+        int d = m->dims[0], H = m->dims[1], B = m->dims[2];
+        const double *W1 = p, *b1 = W1 + H * d, *W2 = b1 + H, *b2 = W2 + H * H, *W3 = b2 + H, *b3 = W3 + d * H;
+        double *h1 = m->work, *h2 = h1 + H;
+        for (int c = 0; c < B; ++c) {
+            const double *x = u + (size_t)c * d; double *o = du + (size_t)c * d;
+            for (int i = 0; i < H; ++i) { double s = b1[i]; for (int j = 0; j < d; ++j) s += W1[i + j * H] * x[j]; h1[i] = tanh(s); }
+            for (int i = 0; i < H; ++i) { double s = b2[i]; for (int j = 0; j < H; ++j) s += W2[i + j * H] * h1[j]; h2[i] = tanh(s); }
+            for (int i = 0; i < d; ++i) { double s = b3[i]; for (int j = 0; j < H; ++j) s += W3[i + j * d] * h2[j]; o[i] = s; }
+        }
+        break; }
+    case ORC_MODEL_BRUSS: {
+        /* docs/src/examples/pde/brusselator.md:98-112; u[i,j,s] column-major (i fastest); p = (A, B, alpha) */
+        int G = m->dims[0]; double A = p[0], Bc = p[1], alpha = p[2];
+        double dx = 1.0 / (G - 1), adx = alpha / (dx * dx);
+        const double *U = u, *V = u + (size_t)G * G; double *dU = du, *dV = du + (size_t)G * G;
+        for (int j = 0; j < G; ++j) for (int i = 0; i < G; ++i) {
+            int ip = (i + 1) % G, im = (i + G - 1) % G, jp = (j + 1) % G, jm = (j + G - 1) % G;
+            double Uc = U[i + j * G], Vc = V[i + j * G];
+            double LU = U[im + j * G] + U[ip + j * G] + U[i + jp * G] + U[i + jm * G] - 4.0 * Uc;
+            double LV = V[im + j * G] + V[ip + j * G] + V[i + jp * G] + V[i + jm * G] - 4.0 * Vc;
+            dU[i + j * G] = adx * LU + Bc + Uc * Uc * Vc - (A + 1.0) * Uc + bruss_force(i * dx, j * dx, t);
+            dV[i + j * G] = adx * LV + A * Uc - Uc * Uc * Vc;
+        }
+        break; }
+    }
+}
+
+/* dlam = (df/du)^T lam ; dgrad = (df/dp)^T lam ; either output may be NULL ("nothing" = skip,
+ * src/derivative_wrappers.jl:256-267) */
+static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const double *lam, const double *u,
+                      const double *p, double t) {
+    switch (m->id) {
+    case ORC_MODEL_LV:
+        if (dlam) {
+            dlam[0] = (p[0] - p[1] * u[1]) * lam[0] + p[3] * u[1] * lam[1];
+            dlam[1] = -p[1] * u[0] * lam[0] + (-p[2] + p[3] * u[0]) * lam[1];
+        }
+        if (dgrad) {
+            dgrad[0] = u[0] * lam[0]; dgrad[1] = -u[0] * u[1] * lam[0];
+            dgrad[2] = -u[1] * lam[1]; dgrad[3] = u[0] * u[1] * lam[1];
+        }
+        break;
+    case ORC_MODEL_LVT:     /* Jacobian of test/Core3/adjoint.jl:18-25, transposed */
+        if (dlam) {
+            dlam[0] = (p[0] - p[1] * u[1] * t) * lam[0] + t * u[1] * p[3] * lam[1];
+            dlam[1] = -p[1] * u[0] * t * lam[0] + (-p[2] + t * u[0] * p[3]) * lam[1];
+        }
+        if (dgrad) {
+            dgrad[0] = u[0] * lam[0]; dgrad[1] = -u[0] * u[1] * t * lam[0];
+            dgrad[2] = -u[1] * lam[1]; dgrad[3] = t * u[0] * u[1] * lam[1];
+        }
+        break;
+    case ORC_MODEL_LORENZ:
+        if (dlam) {
+            dlam[0] = -p[0] * lam[0] + (p[1] - u[2]) * lam[1] + u[1] * lam[2];
+            dlam[1] = p[0] * lam[0] - lam[1] + u[0] * lam[2];
+            dlam[2] = -u[0] * lam[1] - p[2] * lam[2];
+        }
+        if (dgrad) {
+            dgrad[0] = (u[1] - u[0]) * lam[0]; dgrad[1] = u[0] * lam[1]; dgrad[2] = -u[2] * lam[2];
+        }
+        break;
+    case ORC_MODEL_LINDIAG: /* jac = diag(p), paramjac = diag(u): test/Core1/sparse_adjoint.jl:7-8 */
+        if (dlam) { dlam[0] = p[0] * lam[0]; dlam[1] = p[1] * lam[1]; }
+        if (dgrad) { dgrad[0] = u[0] * lam[0]; dgrad[1] = u[1] * lam[1]; }
+        break;
+    case ORC_MODEL_FALLMASS:
+        if (dlam) { dlam[0] = 0.0; dlam[1] = lam[0]; }
+        if (dgrad) { dgrad[0] = -lam[1]; dgrad[1] = 0.0; }
+        break;
+    case ORC_MODEL_MLP: {
+        int d = m->dims[0], H = m->dims[1], B = m->dims[2];
+        const double *W1 = p, *b1 = W1 + H * d, *W2 = b1 + H, *b2 = W2 + H * H, *W3 = b2 + H;
+        double *h1 = m->work, *h2 = h1 + H, *g2 = h2 + H, *g1 = g2 + H;
+        double *gW1 = dgrad, *gb1 = dgrad ? gW1 + H * d : NULL, *gW2 = dgrad ? gb1 + H : NULL,
+               *gb2 = dgrad ? gW2 + H * H : NULL, *gW3 = dgrad ? gb2 + H : NULL, *gb3 = dgrad ? gW3 + d * H : NULL;
+        if (dgrad) memset(dgrad, 0, sizeof(double) * (size_t)m->np);
+        (void)b2;
+        for (int c = 0; c < B; ++c) {
+            const double *x = u + (size_t)c * d, *l = lam + (size_t)c * d;
+            for (int i = 0; i < H; ++i) { double s = b1[i]; for (int j = 0; j < d; ++j) s += W1[i + j * H] * x[j]; h1[i] = tanh(s); }
+            for (int i = 0; i < H; ++i) { double s = (W2 + H * H)[i]; for (int j = 0; j < H; ++j) s += W2[i + j * H] * h1[j]; h2[i] = tanh(s); }
+            /* backward: out = W3 h2 + b3 */
+            for (int j = 0; j < H; ++j) { double s = 0; for (int i = 0; i < d; ++i) s += W3[i + j * d] * l[i]; g2[j] = s * (1.0 - h2[j] * h2[j]); }
+            for (int j = 0; j < H; ++j) { double s = 0; for (int i = 0; i < H; ++i) s += W2[i + j * H] * g2[i]; g1[j] = s * (1.0 - h1[j] * h1[j]); }
+            if (dlam) for (int j = 0; j < d; ++j) { double s = 0; for (int i = 0; i < H; ++i) s += W1[i + j * H] * g1[i]; dlam[(size_t)c * d + j] = s; }
+            if (dgrad) {
+                for (int j = 0; j < H; ++j) for (int i = 0; i < d; ++i) gW3[i + j * d] += l[i] * h2[j];
+                for (int i = 0; i < d; ++i) gb3[i] += l[i];
+                for (int j = 0; j < H; ++j) for (int i = 0; i < H; ++i) gW2[i + j * H] += g2[i] * h1[j];
+                for (int i = 0; i < H; ++i) gb2[i] += g2[i];
+                for (int j = 0; j < d; ++j) for (int i = 0; i < H; ++i) gW1[i + j * H] += g1[i] * x[j];
+                for (int i = 0; i < H; ++i) gb1[i] += g1[i];
+            }
+        }
+        break; }
+    case ORC_MODEL_BRUSS: {
+        int G = m->dims[0]; double A = p[0], alpha = p[2];
+        double dx = 1.0 / (G - 1), adx = alpha / (dx * dx);
+        size_t GG = (size_t)G * G;
+        const double *U = u, *V = u + GG, *lU = lam, *lV = lam + GG;
+        double gA = 0, gB = 0, gal = 0;
+        for (int j = 0; j < G; ++j) for (int i = 0; i < G; ++i) {
+            int ip = (i + 1) % G, im = (i + G - 1) % G, jp = (j + 1) % G, jm = (j + G - 1) % G;
+            size_t c = i + (size_t)j * G;
+            double Uc = U[c], Vc = V[c];
+            /* the periodic Laplacian is symmetric: (L^T lam) = L lam */
+            double LlU = lU[im + j * G] + lU[ip + j * G] + lU[i + jp * G] + lU[i + jm * G] - 4.0 * lU[c];
+            double LlV = lV[im + j * G] + lV[ip + j * G] + lV[i + jp * G] + lV[i + jm * G] - 4.0 * lV[c];
+            if (dlam) {
+                dlam[c] = adx * LlU + (2.0 * Uc * Vc - (A + 1.0)) * lU[c] + (A - 2.0 * Uc * Vc) * lV[c];
+                dlam[GG + c] = adx * LlV + Uc * Uc * lU[c] - Uc * Uc * lV[c];
+            }
+            if (dgrad) {
+                double LU = U[im + j * G] + U[ip + j * G] + U[i + jp * G] + U[i + jm * G] - 4.0 * Uc;
+                double LV = V[im + j * G] + V[ip + j * G] + V[i + jp * G] + V[i + jm * G] - 4.0 * Vc;
+                gA += -Uc * lU[c] + Uc * lV[c];
+                gB += lU[c];
+                gal += (LU * lU[c] + LV * lV[c]) / (dx * dx);
+            }
+        }
+        if (dgrad) { dgrad[0] = gA; dgrad[1] = gB; dgrad[2] = gal; }
+        (void)t;
+        break; }
+    }
+}
+
+int orc_model_f(int model, const int dims[4], const double *u, const double *p, double t, double *du) {
+    orc_model m; if (model_init(&m, model, dims)) return -1;
+    if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+    model_f(&m, du, u, p, t);
+    free(m.work);
+    return 0;
+}
+int orc_model_vjp(int model, const int dims[4], const double *lam, const double *u, const double *p, double t,
+                  double *dlam, double *dgrad) {
+    orc_model m; if (model_init(&m, model, dims)) return -1;
+    if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+    model_vjp(&m, dlam, dgrad, lam, u, p, t);
+    free(m.work);
+    return 0;
+}
+
+/* =====================================================================================
+ * 2. Steppers and dense output [upstream-recall: OrdinaryDiffEq]
+ * ===================================================================================== */
+/* Tsit5 tableau: Ch. Tsitouras, Comput. Math. Appl. 62 (2011) 770-775; interpolant coefficients as
+ * published with the method.  Self-checked by orc_test_tsit5_order_residual(). */
+static const double TS_C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+static const double TS_A[7][6] = {
+    {0},
+    {0.161},
+    {-0.008480655492356989, 0.335480655492357},
+    {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
+    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
+    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+static const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
+                                -0.1447110071732629, 0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
+/* b_i(theta): b1 = th*(r11 + th*(r12 + th*(r13 + th*r14))), bi = th^2*(ri2 + th*(ri3 + th*ri4)) */
+static const double TS_R[7][4] = {
+    {1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216},
+    {0.0, 0.13169999999999998, -0.2234, 0.1017},
+    {0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253},
+    {0.0, -12.411077166933676, 30.33818863028232, -16.548102889244902},
+    {0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928},
+    {0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661},
+    {0.0, 1.5, -4.0, 2.5}};
+
+static void tsit5_bweights(double th, double b[7]) {
+    b[0] = th * (TS_R[0][0] + th * (TS_R[0][1] + th * (TS_R[0][2] + th * TS_R[0][3])));
+    for (int i = 1; i < 7; ++i) b[i] = th * th * (TS_R[i][1] + th * (TS_R[i][2] + th * TS_R[i][3]));
+}
+
+double orc_test_tsit5_order_residual(void) {
+    /* order conditions through order 5 for (A, b=A[6], c) plus row sums and theta=1 interpolant consistency */
+    double r = 0, s;
+    const double *b = TS_A[6];
+    for (int i = 1; i < 7; ++i) { s = 0; for (int j = 0; j < i; ++j) s += TS_A[i][j]; r = fmax(r, fabs(s - TS_C[i])); }
+    double Ac[7] = {0}, Ac2[7] = {0}, AAc[7] = {0}, Ac3[7] = {0}, AAc2[7] = {0}, AcAc[7] = {0}, AAAc[7] = {0};
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < i && j < 6; ++j) {
+        Ac[i] += TS_A[i][j] * TS_C[j]; Ac2[i] += TS_A[i][j] * TS_C[j] * TS_C[j]; Ac3[i] += TS_A[i][j] * TS_C[j] * TS_C[j] * TS_C[j]; }
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < i && j < 6; ++j) {
+        AAc[i] += TS_A[i][j] * Ac[j]; AAc2[i] += TS_A[i][j] * Ac2[j]; AcAc[i] += TS_A[i][j] * TS_C[j] * Ac[j]; }
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < i && j < 6; ++j) AAAc[i] += TS_A[i][j] * AAc[j];
+    double bb[7]; for (int i = 0; i < 6; ++i) bb[i] = b[i]; bb[6] = 0.0;
+#define SUMB(expr, target) do { s = 0; for (int i = 0; i < 7; ++i) s += bb[i] * (expr); r = fmax(r, fabs(s - (target))); } while (0)
+    SUMB(1.0, 1.0); SUMB(TS_C[i], 0.5); SUMB(TS_C[i] * TS_C[i], 1.0 / 3); SUMB(Ac[i], 1.0 / 6);
+    SUMB(TS_C[i] * TS_C[i] * TS_C[i], 0.25); SUMB(TS_C[i] * Ac[i], 0.125); SUMB(Ac2[i], 1.0 / 12); SUMB(AAc[i], 1.0 / 24);
+    SUMB(TS_C[i] * TS_C[i] * TS_C[i] * TS_C[i], 0.2); SUMB(TS_C[i] * TS_C[i] * Ac[i], 0.1); SUMB(TS_C[i] * Ac2[i], 1.0 / 15);
+    SUMB(TS_C[i] * AAc[i], 1.0 / 30); SUMB(Ac[i] * Ac[i], 1.0 / 20); SUMB(Ac3[i], 1.0 / 20); SUMB(AcAc[i], 1.0 / 40);
+    SUMB(AAc2[i], 1.0 / 60); SUMB(AAAc[i], 1.0 / 120);
+#undef SUMB
+    double w[7]; tsit5_bweights(1.0, w);
+    for (int i = 0; i < 7; ++i) r = fmax(r, fabs(w[i] - bb[i]));
+    /* embedded weights: b - btilde must also sum to 1 and integrate c exactly */
+    s = 0; for (int i = 0; i < 7; ++i) s += TS_BT[i]; r = fmax(r, fabs(s));
+    s = 0; for (int i = 0; i < 7; ++i) s += TS_BT[i] * TS_C[i]; r = fmax(r, fabs(s));
+    return r;
+}
+
+typedef void (*orc_rhs)(double *du, const double *u, double t, void *ctx);
+
+/* one accepted step of a dense solution */
+typedef struct {
+    int n, nk, kind;       /* kind: stepper that produced it */
+    long nsteps, cap;
+    double *t0, *t1;       /* step start / end times */
+    double *u0, *u1;       /* [nsteps][n] */
+    double *k;             /* [nsteps][nk][n]; RK4: k[0]=f(u0,t0), k[1]=f(u1,t1) (FSAL pair) ; Tsit5: 7 stages */
+} orc_dense;
+
+static void dense_init(orc_dense *d, int n, int kind) {
+    memset(d, 0, sizeof(*d)); d->n = n; d->kind = kind; d->nk = (kind == ORC_STEPPER_TSIT5) ? 7 : 2;
+}
+static void dense_free(orc_dense *d) { free(d->t0); free(d->t1); free(d->u0); free(d->u1); free(d->k); memset(d, 0, sizeof(*d)); }
+static void dense_push(orc_dense *d, double t0, double t1, const double *u0, const double *u1, const double *k) {
+    if (d->nsteps == d->cap) {
+        d->cap = d->cap ? 2 * d->cap : 256;
+        d->t0 = (double *)realloc(d->t0, sizeof(double) * d->cap); d->t1 = (double *)realloc(d->t1, sizeof(double) * d->cap);
+        d->u0 = (double *)realloc(d->u0, sizeof(double) * d->cap * d->n); d->u1 = (double *)realloc(d->u1, sizeof(double) * d->cap * d->n);
+        d->k = (double *)realloc(d->k, sizeof(double) * d->cap * d->nk * d->n);
+    }
+    long s = d->nsteps++;
+    d->t0[s] = t0; d->t1[s] = t1;
+    memcpy(d->u0 + s * d->n, u0, sizeof(double) * d->n); memcpy(d->u1 + s * d->n, u1, sizeof(double) * d->n);
+    memcpy(d->k + s * d->nk * d->n, k, sizeof(double) * d->nk * d->n);
+}
+
+/* evaluate one step's continuous extension at time t.
+ * RK4 (no special interpolant) => OrdinaryDiffEq's default 3rd-order Hermite on (u0, f0, u1, f1):
+ *   u(th) = (1-th) u0 + th u1 + th (th-1) [ (1-2th)(u1-u0) + (th-1) h k1 + th h k2 ]   [upstream-recall, SURVEY §8c]
+ * Tsit5 => its own 4th-order interpolant u0 + h sum b_i(th) k_i. */
+static void dense_eval_step(const orc_dense *d, long s, double t, double *y) {
+    int n = d->n; double h = d->t1[s] - d->t0[s]; double th = (h == 0.0) ? 0.0 : (t - d->t0[s]) / h;
+    const double *u0 = d->u0 + s * n, *u1 = d->u1 + s * n, *k = d->k + s * d->nk * n;
+    if (d->kind == ORC_STEPPER_TSIT5) {
+        double b[7]; tsit5_bweights(th, b);
+        for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < 7; ++j) acc += b[j] * k[j * n + i]; y[i] = u0[i] + h * acc; }
+    } else {
+        for (int i = 0; i < n; ++i)
+            y[i] = (1 - th) * u0[i] + th * u1[i] + th * (th - 1) * ((1 - 2 * th) * (u1[i] - u0[i]) + (th - 1) * h * k[i] + th * h * k[n + i]);
+    }
+}
+/* sol(y, t): locate the step by binary search (steps are monotone in either direction) and interpolate.
+ * `hint` caches the last step index (the reference's interpolation also searches from sol.t). */
+static void dense_eval(const orc_dense *d, double t, double *y, long *hint) {
+    long lo = 0, hi = d->nsteps - 1;
+    int fwd = d->nsteps == 0 || d->t1[0] >= d->t0[0];
+    if (hint && *hint >= 0 && *hint < d->nsteps) {
+        long s = *hint; double a = fwd ? d->t0[s] : d->t1[s], b = fwd ? d->t1[s] : d->t0[s];
+        if (t >= a && t <= b) { dense_eval_step(d, s, t, y); return; }
+    }
+    while (lo < hi) {
+        long mid = (lo + hi) / 2;
+        /* continuity=:right : at a shared knot prefer the later (in forward time) step */
+        if (fwd) { if (t >= d->t1[mid]) lo = mid + 1; else hi = mid; }
+        else     { if (t < d->t1[mid]) lo = mid + 1; else hi = mid; }
+    }
+    if (lo > d->nsteps - 1) lo = d->nsteps - 1;
+    if (hint) *hint = lo;
+    dense_eval_step(d, lo, t, y);
+}
+
+/* integrator state handed to post-step callbacks (the `integrator` of DiffEq callbacks) */
+typedef struct orc_integ {
+    int n, nk, kind;
+    double t, tprev, dt, dtcache;
+    double tdir;
+    double *u, *uprev, *k, *tmp, *utilde;
+    double *fsal;
+    orc_rhs rhs; void *ctx;
+    long nrhs, naccept, nreject;
+    int u_modified;
+} orc_integ;
+
+typedef int (*orc_stepcb)(orc_integ *I, void *cbctx); /* returns nonzero if u was modified (=> derivative_discontinuity!) */
+
+typedef struct {
+    int kind; double dt; double abstol, reltol;
+} orc_alg;
+
+/* in-step interpolant of the integrator itself: integrator(curu, t)  [upstream-recall] */
+static void integ_interp(const orc_integ *I, double t, double *y) {
+    int n = I->n; double h = I->t - I->tprev; double th = (t - I->tprev) / h;
+    if (I->kind == ORC_STEPPER_TSIT5) {
+        double b[7]; tsit5_bweights(th, b);
+        for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < 7; ++j) acc += b[j] * I->k[j * n + i]; y[i] = I->uprev[i] + h * acc; }
+    } else {
+        for (int i = 0; i < n; ++i)
+            y[i] = (1 - th) * I->uprev[i] + th * I->u[i] +
+                   th * (th - 1) * ((1 - 2 * th) * (I->u[i] - I->uprev[i]) + (th - 1) * h * I->k[i] + th * h * I->k[n + i]);
+    }
+}
+
+static double scaled_norm(const double *e, const double *a, const double *b, int n, double abstol, double reltol) {
+    double s = 0; for (int i = 0; i < n; ++i) { double sc = abstol + fmax(fabs(a[i]), fabs(b[i])) * reltol; double q = e[i] / sc; s += q * q; }
+    return sqrt(s / n);
+}
+
+/* Hairer-Norsett-Wanner initial step (as used by OrdinaryDiffEq's `ode_determine_initdt`) [upstream-recall] */
+static double initial_dt(orc_integ *I, const orc_alg *alg, double tend) {
+    int n = I->n; double *f0 = I->fsal, *u1 = I->tmp, *f1 = I->utilde;
+    double d0 = 0, d1 = 0;
+    for (int i = 0; i < n; ++i) { double sc = alg->abstol + fabs(I->u[i]) * alg->reltol; d0 += (I->u[i] / sc) * (I->u[i] / sc); d1 += (f0[i] / sc) * (f0[i] / sc); }
+    d0 = sqrt(d0 / n); d1 = sqrt(d1 / n);
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    h0 = fmin(h0, fabs(tend - I->t));
+    for (int i = 0; i < n; ++i) u1[i] = I->u[i] + I->tdir * h0 * f0[i];
+    I->rhs(f1, u1, I->t + I->tdir * h0, I->ctx); I->nrhs++;
+    double d2 = 0;
+    for (int i = 0; i < n; ++i) { double sc = alg->abstol + fabs(I->u[i]) * alg->reltol; double q = (f1[i] - f0[i]) / sc; d2 += q * q; }
+    d2 = sqrt(d2 / n) / h0;
+    double h1 = (fmax(d1, d2) <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+    return fmin(fmin(100 * h0, h1), fabs(tend - I->t));
+}
+
+/*
+ * solve(prob, alg; dt, adaptive, tstops, callback, save_everystep) — the subset the adjoint path uses
+ * (call sites: src/sensitivity_interface.jl:487-491, src/quadrature_adjoint.jl:527-530,
+ *  src/gauss_adjoint.jl:847-851, src/interpolating_adjoint.jl:89-105, 246-251, src/concrete_solve.jl:689-707).
+ * [upstream-recall] fixed-step: dt = min(|dtcache|, |tstop - t|); t snaps to the tstop when within 100 eps;
+ * adaptive Tsit5: PI controller beta1 = 7/50, beta2 = 2/25, gamma = 9/10, qmin = 1/5, qmax = 10.
+ * After a callback modifies u the FSAL derivative is recomputed (derivative_discontinuity!, adjoint_common.jl:818).
+ */
+static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, double tend, const orc_alg *alg,
+                     const double *tstops, int ntstops, orc_stepcb cb, void *cbctx, int cb_at_init,
+                     orc_dense *rec, long *nrhs_out) {
+    orc_integ I; memset(&I, 0, sizeof(I));
+    I.n = n; I.kind = alg->kind; I.nk = (alg->kind == ORC_STEPPER_TSIT5) ? 7 : 2;
+    I.rhs = rhs; I.ctx = ctx; I.t = tstart; I.tprev = tstart; I.tdir = (tend >= tstart) ? 1.0 : -1.0;
+    I.u = u;
+    double *buf = (double *)calloc((size_t)n * (5 + ORC_MAXK + 1), sizeof(double));
+    I.uprev = buf; I.tmp = buf + n; I.utilde = buf + 2 * n; I.fsal = buf + 3 * n; I.k = buf + 4 * n;
+    double *us = buf + (size_t)n * (4 + ORC_MAXK + 1);
+    int adaptive = (alg->kind == ORC_STEPPER_TSIT5);
+    int status = 0;
+    /* tstops sorted along the integration direction; skip those not strictly ahead of tstart */
+    int its = 0;
+    double *ts = (double *)malloc(sizeof(double) * (size_t)(ntstops + 1));
+    int nts = 0;
+    for (int i = 0; i < ntstops; ++i) ts[nts++] = tstops[i];
+    for (int i = 1; i < nts; ++i) { double v = ts[i]; int j = i - 1; while (j >= 0 && I.tdir * ts[j] > I.tdir * v) { ts[j + 1] = ts[j]; --j; } ts[j + 1] = v; }
+    ts[nts++] = tend;
+
+    if (cb && cb_at_init) { /* PresetTimeCallback fires in initialisation when tstart is a preset time [upstream-recall] */
+        memcpy(I.uprev, I.u, sizeof(double) * n);
+        cb(&I, cbctx);
+    }
+    rhs(I.fsal, I.u, I.t, ctx); I.nrhs++;
+    double qold = 1e-4;
+    if (adaptive) I.dt = I.tdir * ((alg->dt > 0) ? alg->dt : initial_dt(&I, alg, tend));
+    else I.dt = I.tdir * fabs(alg->dt);
+    I.dtcache = I.dt;
+    long guard = 0;
+    while (I.tdir * I.t < I.tdir * tend) {
+        if (++guard > 200000000L) { status = -2; break; }
+        while (its < nts && I.tdir * ts[its] <= I.tdir * I.t + 100 * DBL_EPSILON * fmax(fabs(I.t), fabs(ts[its]))) ++its;
+        if (its >= nts) break;
+        double tstop = ts[its];
+        double dt = adaptive ? I.dt : I.dtcache;
+        if (fabs(dt) > fabs(tstop - I.t)) dt = tstop - I.t;
+        /* avoid a sliver step: if the remainder after this step would be within roundoff, land on the tstop */
+        if (fabs((I.t + dt) - tstop) < 100 * DBL_EPSILON * fmax(fabs(I.t + dt), fabs(tstop))) dt = tstop - I.t;
+        memcpy(I.uprev, I.u, sizeof(double) * n);
+        double t = I.t;
+        double *k = I.k;
+        if (!adaptive) {
+            /* classic RK4, stages at t, t+dt/2, t+dt/2, t+dt */
+            double *k2 = I.tmp, *k3 = I.utilde, *k4 = k + n; /* k[1] is overwritten by fsallast below */
+            memcpy(k, I.fsal, sizeof(double) * n);
+            for (int i = 0; i < n; ++i) us[i] = I.uprev[i] + 0.5 * dt * k[i];
+            rhs(k2, us, t + 0.5 * dt, ctx);
+            for (int i = 0; i < n; ++i) us[i] = I.uprev[i] + 0.5 * dt * k2[i];
+            rhs(k3, us, t + 0.5 * dt, ctx);
+            for (int i = 0; i < n; ++i) us[i] = I.uprev[i] + dt * k3[i];
+            rhs(k4, us, t + dt, ctx);
+            for (int i = 0; i < n; ++i) I.u[i] = I.uprev[i] + (dt / 6.0) * (k[i] + 2.0 * (k2[i] + k3[i]) + k4[i]);
+            I.nrhs += 3;
+            double tnew = t + dt;
+            if (fabs(tnew - tstop) < 100 * DBL_EPSILON * fmax(fabs(tnew), fabs(tstop))) tnew = tstop;
+            rhs(k + n, I.u, tnew, ctx); I.nrhs++;               /* fsallast */
+            memcpy(I.fsal, k + n, sizeof(double) * n);
+            I.tprev = t; I.t = tnew; I.naccept++;
+        } else {
+            memcpy(k, I.fsal, sizeof(double) * n);
+            for (int s = 1; s < 7; ++s) {
+                for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < s; ++j) acc += TS_A[s][j] * k[j * n + i]; I.tmp[i] = I.uprev[i] + dt * acc; }
+                if (s < 6) { rhs(k + s * n, I.tmp, t + TS_C[s] * dt, ctx); I.nrhs++; }
+                else { memcpy(I.u, I.tmp, sizeof(double) * n); rhs(k + 6 * n, I.u, t + dt, ctx); I.nrhs++; }
+            }
+            for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < 7; ++j) acc += TS_BT[j] * k[j * n + i]; I.utilde[i] = dt * acc; }
+            double EEst = scaled_norm(I.utilde, I.uprev, I.u, n, alg->abstol, alg->reltol);
+            double q11 = pow(fmax(EEst, 1e-300), 7.0 / 50.0);
+            double q = q11 / pow(qold, 2.0 / 25.0);
+            q = fmax(1.0 / 10.0, fmin(5.0, q / 0.9));
+            if (EEst <= 1.0 || fabs(dt) < 1e-14 * fmax(1.0, fabs(t))) {
+                double tnew = t + dt;
+                if (fabs(tnew - tstop) < 100 * DBL_EPSILON * fmax(fabs(tnew), fabs(tstop))) tnew = tstop;
+                qold = fmax(EEst, 1e-4);
+                memcpy(I.fsal, k + 6 * n, sizeof(double) * n);
+                I.tprev = t; I.t = tnew; I.naccept++;
+                I.dt = dt / q;                       /* step_accept_controller!: next dt from the step actually taken */
+                if (fabs(I.dt) < 1e-14 * fmax(1.0, fabs(tnew))) I.dt = I.tdir * 1e-14 * fmax(1.0, fabs(tnew));
+            } else {
+                memcpy(I.u, I.uprev, sizeof(double) * n);
+                I.dt = dt / fmin(5.0, q11 / 0.9);
+                I.nreject++;
+                continue;
+            }
+        }
+        if (rec) dense_push(rec, I.tprev, I.t, I.uprev, I.u, I.k);
+        if (cb) {
+            I.u_modified = 0;
+            if (cb(&I, cbctx)) { rhs(I.fsal, I.u, I.t, ctx); I.nrhs++; }
+        }
+    }
+    if (nrhs_out) *nrhs_out += I.nrhs;
+    free(ts); free(buf);
+    return status;
+}
+
+/* =====================================================================================
+ * 3. Forward solve (src/concrete_solve.jl:689-770)
+ * ===================================================================================== */
+typedef struct { const orc_model *m; const double *p; } fwd_ctx;
+static void fwd_rhs(double *du, const double *u, double t, void *c) { fwd_ctx *f = (fwd_ctx *)c; model_f(f->m, du, u, f->p, t); }
+
+static orc_alg make_alg(const orc_config *cfg) {
+    orc_alg a; a.kind = cfg->stepper; a.dt = cfg->dt; a.abstol = cfg->abstol > 0 ? cfg->abstol : 1e-6; a.reltol = cfg->reltol > 0 ? cfg->reltol : 1e-3;
+    return a;
+}
+
+/* dense forward solve over [ta, tb] from u0; result in `sol`; u_end returned in u */
+static int forward_dense(const orc_model *m, const orc_config *cfg, const double *p, double ta, double tb, double *u,
+                         double dt_hint, orc_dense *sol, long *nrhs) {
+    fwd_ctx fc = {m, p};
+    orc_alg a = make_alg(cfg); if (dt_hint > 0) a.dt = dt_hint;
+    dense_init(sol, m->n, cfg->stepper);
+    return integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, NULL, NULL, 0, sol, nrhs);
+}
+
+/* =====================================================================================
+ * 4. Adjoint sensitivity functions (the hot-loop body) and callbacks
+ * ===================================================================================== */
+typedef struct {
+    const orc_model *m; const orc_config *cfg; const double *p;
+    int n, np;
+    /* forward solution */
+    const orc_dense *sol; long hint;
+    /* checkpointing (src/interpolating_adjoint.jl:20-27): intervals, cursor, local cpsol */
+    int checkpointing; int nint; double *int_a, *int_b; int cursor; orc_dense cpsol; int cpsol_valid; long cphint;
+    const double *ck_t; const double *ck_u; int nck;   /* stored (non-dense) forward values at checkpoint times */
+    double *y;            /* shared y buffer (S.y) */
+    double *scratch;      /* n + np */
+    /* loss */
+    const double *save_t; int M; const double *dLdu; int cur_time; /* 1-based countdown (adjoint_common.jl:819) */
+    /* Gauss accumulation (src/gauss_adjoint.jl:809) */
+    double *gauss_acc;
+    /* backsolve checkpoint cursor */
+    int bs_cur;
+    long *nrhs;
+    int alg;
+} adj_ctx;
+
+/* stored forward value at checkpoint time c (non-dense `sol(c)` at a saved point) */
+static void ckpt_value(const adj_ctx *A, double c, double *y) {
+    int best = 0; double bd = fabs(A->ck_t[0] - c);
+    for (int i = 1; i < A->nck; ++i) { double d = fabs(A->ck_t[i] - c); if (d < bd) { bd = d; best = i; } }
+    memcpy(y, A->ck_u + (size_t)best * A->n, sizeof(double) * A->n);
+}
+
+/* findcursor: first interval whose end is >= t  (src/interpolating_adjoint.jl:128-132) */
+static int findcursor(const adj_ctx *A, double t) {
+    int lo = 0, hi = A->nint - 1;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (A->int_b[mid] < t) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+static int resolve_interval(adj_ctx *A, int cursor, double dt_hint) {
+    /* prob' = remake(prob, tspan = intervals[cursor], u0 = sol(interval[1])); cpsol' = solve(prob', sol.alg; dt, tols...)
+     * (src/interpolating_adjoint.jl:245-251; first interval eagerly at :88-92) */
+    double *y0 = (double *)malloc(sizeof(double) * A->n);
+    ckpt_value(A, A->int_a[cursor], y0);
+    if (A->cpsol_valid) dense_free(&A->cpsol);
+    int st = forward_dense(A->m, A->cfg, A->p, A->int_a[cursor], A->int_b[cursor], y0, dt_hint, &A->cpsol, A->nrhs);
+    A->cpsol_valid = 1; A->cursor = cursor; A->cphint = -1;
+    free(y0);
+    return st;
+}
+
+/* y <- forward state at t: dense interpolant, or checkpointed re-solve
+ * (split_states, src/interpolating_adjoint.jl:190-277; src/gauss_adjoint.jl:158-217; src/quadrature_adjoint.jl:63-72) */
+static void fetch_y(adj_ctx *A, double t) {
+    if (!A->checkpointing) { dense_eval(A->sol, t, A->y, &A->hint); return; }
+    double a = A->int_a[A->cursor], b = A->int_b[A->cursor];
+    if (!(a <= t && t <= b)) {
+        int c = findcursor(A, t);
+        double dtl = 0;
+        if (A->cpsol_valid && A->cpsol.nsteps > 0) { long s = A->cpsol.nsteps - 1; dtl = fabs(A->cpsol.t1[s] - A->cpsol.t0[s]); }
+        resolve_interval(A, c, dtl);
+    }
+    dense_eval(&A->cpsol, t, A->y, &A->cphint);
+}
+
+/* (S::ODEInterpolatingAdjointSensitivityFunction)(du,u,p,t)  src/interpolating_adjoint.jl:150-174
+ * z = [lam(n); grad(np)] */
+static void rhs_interpolating(double *dz, const double *z, double t, void *c) {
+    adj_ctx *A = (adj_ctx *)c; int n = A->n, np = A->np;
+    fetch_y(A, t);
+    model_vjp(A->m, dz, dz + n, z, A->y, A->p, t);           /* vecjacobian!(dlam, y, lam, p, t, S; dgrad) */
+    for (int i = 0; i < n; ++i) dz[i] *= -1.0;               /* :169 */
+    for (int i = 0; i < np; ++i) dz[n + i] *= -1.0;          /* :170 */
+}
+/* (S::ODEBacksolveSensitivityFunction)(du,u,p,t)  src/backsolve_adjoint.jl:32-61 ; z = [lam; grad; y] (:78-120) */
+static void rhs_backsolve(double *dz, const double *z, double t, void *c) {
+    adj_ctx *A = (adj_ctx *)c; int n = A->n, np = A->np;
+    memcpy(A->y, z + n + np, sizeof(double) * n);             /* copyto!(vec(y), _y) :37-41 */
+    model_vjp(A->m, dz, dz + n, z, A->y, A->p, t);
+    model_f(A->m, dz + n + np, A->y, A->p, t);                /* dy = f(y,p,t), not negated :54 */
+    for (int i = 0; i < n + np; ++i) dz[i] *= -1.0;
+}
+/* Quadrature / Gauss: u = lam only (src/quadrature_adjoint.jl:35-46, src/gauss_adjoint.jl:118-128) */
+static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
+    adj_ctx *A = (adj_ctx *)c; int n = A->n;
+    fetch_y(A, t);
+    model_vjp(A->m, dz, NULL, z, A->y, A->p, t);
+    for (int i = 0; i < n; ++i) dz[i] *= -1.0;
+}
+
+static int time_hits(double t, double target) { return fabs(t - target) <= 100 * DBL_EPSILON * fmax(fabs(t), fabs(target)); }
+
+/* ReverseLossCallback (src/adjoint_common.jl:754-821): lam += dgdu(y, p, t_i, i); counter counts down (:819) */
+static int loss_jump(adj_ctx *A, orc_integ *I) {
+    int n = A->n, np = A->np;
+    if (A->cur_time < 1) return 0;
+    if (!time_hits(I->t, A->save_t[A->cur_time - 1])) return 0;
+    if (A->cfg->no_start && A->alg != ORC_ALG_BACKSOLVE && A->cur_time == 1) return 0;      /* :761 */
+    if (A->alg == ORC_ALG_BACKSOLVE) memcpy(A->y, I->u + n + np, sizeof(double) * n);       /* :765-767 */
+    else {
+        /* the shared y buffer holds the last interpolated value; after a step ending on t_i the last RHS call
+         * (FSAL) was at t_i, so y == sol(t_i).  Refresh explicitly: identical value. */
+        fetch_y(A, I->t);
+    }
+    int idx = A->cur_time - 1;
+    for (int i = 0; i < n; ++i) {
+        double g = (A->cfg->loss_kind == ORC_LOSS_COTANGENT) ? A->dLdu[(size_t)idx * n + i] : (A->y[i] - A->cfg->loss_shift);
+        I->u[i] += g;                                                                        /* :812-813 */
+    }
+    A->cur_time -= 1;
+    return 1;
+}
+
+/* backsolve_checkpoint_callbacks (src/backsolve_adjoint.jl:523-546): y-block <- sol(t) at checkpoint times */
+static int backsolve_ckpt(adj_ctx *A, orc_integ *I) {
+    if (!A->checkpointing || A->bs_cur < 1) return 0;
+    if (!time_hits(I->t, A->ck_t[A->bs_cur - 1])) return 0;
+    memcpy(I->u + A->n + A->np, A->ck_u + (size_t)(A->bs_cur - 1) * A->n, sizeof(double) * A->n);
+    A->bs_cur -= 1;
+    return 1;
+}
+
+/* GaussIntegrand (src/gauss_adjoint.jl:745-759): y = sol(t); out = -(df/dp)^T lam  (+ dgdp: continuous costs out of scope) */
+static void gauss_integrand(adj_ctx *A, double *out, double t, const double *lam) {
+    fetch_y(A, t);
+    model_vjp(A->m, NULL, out, lam, A->y, A->p, t);
+    for (int i = 0; i < A->np; ++i) out[i] = -out[i];
+}
+
+/* IntegratingSumCallback [upstream-recall: DiffEqCallbacks]: after every accepted step, Gauss-Legendre with
+ * n = div(alg_order + 1, 2) nodes (RK4: 2, Tsit5: 3) on [tprev, t] using the integrator's own interpolant;
+ * accumulates  (t - tprev)/2 * sum_i w_i integrand(u(t_i), t_i).  Time runs backward, so with integrand = -f_p^T lam
+ * the running sum equals  int_{t0}^{T} lam^T f_p dt , which is what src/gauss_adjoint.jl:852 returns as `res`
+ * (pinned by the Gauss == Interpolating relation, test/Core3/adjoint.jl:385, 389-394). */
+static void gauss_step(adj_ctx *A, orc_integ *I) {
+    static const double x2[2] = {-0.5773502691896257645, 0.5773502691896257645}, w2[2] = {1.0, 1.0};
+    static const double x3[3] = {-0.7745966692414833770, 0.0, 0.7745966692414833770}, w3[3] = {5.0 / 9, 8.0 / 9, 5.0 / 9};
+    int ng = (I->kind == ORC_STEPPER_TSIT5) ? 3 : 2; const double *x = ng == 3 ? x3 : x2, *w = ng == 3 ? w3 : w2;
+    double half = 0.5 * (I->t - I->tprev), mid = 0.5 * (I->t + I->tprev);
+    double *lam = A->scratch, *out = A->scratch + A->n;
+    for (int g = 0; g < ng; ++g) {
+        double tt = half * x[g] + mid;
+        integ_interp(I, tt, lam);
+        gauss_integrand(A, out, tt, lam);
+        for (int i = 0; i < A->np; ++i) A->gauss_acc[i] += half * w[g] * out[i];
+    }
+}
+
+/* CallbackSet ordering: Gauss: CallbackSet(cb_integrate, cb2_loss) (src/gauss_adjoint.jl:850);
+ * Backsolve: CallbackSet(cb_checkpoint, cb_loss) (src/backsolve_adjoint.jl:545). */
+static int adjoint_step_cb(orc_integ *I, void *c) {
+    adj_ctx *A = (adj_ctx *)c; int mod = 0;
+    if (A->alg == ORC_ALG_GAUSS && I->t != I->tprev) gauss_step(A, I);
+    if (A->alg == ORC_ALG_BACKSOLVE) mod |= backsolve_ckpt(A, I);
+    mod |= loss_jump(A, I);
+    return mod;
+}
+
+/* =====================================================================================
+ * 5. QuadGK [upstream-recall]: adaptive Gauss-Kronrod (7,15), global error heap, Euclidean norm
+ * ===================================================================================== */
+static const double GK_X[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
+                               0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
+                               0.586087235467691130294144838258730, 0.405845151377397166906606412076961,
+                               0.207784955007898467600689403773245, 0.0};
+static const double GK_WK[8] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
+                                0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
+                                0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
+                                0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
+static const double GK_WG[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
+                                0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
+
+typedef void (*orc_integrand)(double *out, double t, void *ctx);
+typedef struct { double a, b, E; double *I; } gk_seg;
+
+static void gk_eval(orc_integrand f, void *ctx, int m, double a, double b, double *I, double *E, double *w1, double *w2, long *nev) {
+    double c = 0.5 * (a + b), h = 0.5 * (b - a);
+    double *Ig = w1 + m; /* w1: fval (m) + Ig (m) */
+    memset(I, 0, sizeof(double) * m); memset(Ig, 0, sizeof(double) * m);
+    for (int j = 0; j < 7; ++j) {
+        f(w1, c - h * GK_X[j], ctx); f(w2, c + h * GK_X[j], ctx);
+        for (int i = 0; i < m; ++i) { double s = w1[i] + w2[i]; I[i] += GK_WK[j] * s; if (j & 1) Ig[i] += GK_WG[j / 2] * s; }
+    }
+    f(w1, c, ctx);
+    for (int i = 0; i < m; ++i) { I[i] += GK_WK[7] * w1[i]; Ig[i] += GK_WG[3] * w1[i]; }
+    double e = 0; for (int i = 0; i < m; ++i) { I[i] *= h; Ig[i] *= h; double d = I[i] - Ig[i]; e += d * d; }
+    *E = sqrt(e); *nev += 15;
+}
+
+static int quadgk_vec(orc_integrand f, void *ctx, int m, double a, double b, double atol, double rtol, double *res, long *nev) {
+    int cap = 64, ns = 0; gk_seg *seg = (gk_seg *)malloc(sizeof(gk_seg) * cap);
+    double *w1 = (double *)malloc(sizeof(double) * 2 * m), *w2 = (double *)malloc(sizeof(double) * m);
+    double *I = (double *)calloc(m, sizeof(double)); double E;
+    seg[0].a = a; seg[0].b = b; seg[0].I = (double *)malloc(sizeof(double) * m);
+    gk_eval(f, ctx, m, a, b, seg[0].I, &seg[0].E, w1, w2, nev); ns = 1;
+    memcpy(I, seg[0].I, sizeof(double) * m); E = seg[0].E;
+    const long maxevals = 10000000L;
+    for (;;) {
+        double nrm = 0; for (int i = 0; i < m; ++i) nrm += I[i] * I[i]; nrm = sqrt(nrm);
+        if (E <= fmax(atol, rtol * nrm) || *nev >= maxevals) break;
+        int worst = 0; for (int s = 1; s < ns; ++s) if (seg[s].E > seg[worst].E) worst = s;
+        gk_seg sw = seg[worst]; double mid = 0.5 * (sw.a + sw.b);
+        if (!(mid > fmin(sw.a, sw.b) && mid < fmax(sw.a, sw.b))) break; /* interval cannot be split further */
+        if (ns + 1 >= cap) { cap *= 2; seg = (gk_seg *)realloc(seg, sizeof(gk_seg) * cap); }
+        gk_seg s1, s2; s1.a = sw.a; s1.b = mid; s2.a = mid; s2.b = sw.b;
+        s1.I = sw.I; s2.I = (double *)malloc(sizeof(double) * m);
+        double *old = (double *)malloc(sizeof(double) * m); memcpy(old, sw.I, sizeof(double) * m);
+        gk_eval(f, ctx, m, s1.a, s1.b, s1.I, &s1.E, w1, w2, nev);
+        gk_eval(f, ctx, m, s2.a, s2.b, s2.I, &s2.E, w1, w2, nev);
+        for (int i = 0; i < m; ++i) I[i] += s1.I[i] + s2.I[i] - old[i];
+        E += s1.E + s2.E - sw.E;
+        free(old);
+        seg[worst] = s1; seg[ns++] = s2;
+    }
+    /* re-sum (QuadGK's `resum`) to limit roundoff */
+    memset(I, 0, sizeof(double) * m);
+    for (int s = 0; s < ns; ++s) for (int i = 0; i < m; ++i) I[i] += seg[s].I[i];
+    memcpy(res, I, sizeof(double) * m);
+    for (int s = 0; s < ns; ++s) free(seg[s].I);
+    free(seg); free(w1); free(w2); free(I);
+    return 0;
+}
+
+static void poly_integrand(double *out, double t, void *ctx) { int d = *(int *)ctx; out[0] = pow(t, d); }
+double orc_test_quadgk_poly(int degree, double a, double b, double atol, double rtol, long *nevals) {
+    double r; long nev = 0; quadgk_vec(poly_integrand, &degree, 1, a, b, atol, rtol, &r, &nev);
+    if (nevals) *nevals = nev; return r;
+}
+
+/* AdjointSensitivityIntegrand (src/quadrature_adjoint.jl:486-502): y = sol(t), lam = adj_sol(t), out = f_p^T lam */
+typedef struct { adj_ctx *A; const orc_dense *adj; long hint; double *lam; } quad_ctx;
+static void quad_integrand(double *out, double t, void *c) {
+    quad_ctx *Q = (quad_ctx *)c; adj_ctx *A = Q->A;
+    fetch_y(A, t);
+    dense_eval(Q->adj, t, Q->lam, &Q->hint);
+    model_vjp(A->m, NULL, out, Q->lam, A->y, A->p, t);
+}
+
+/* =====================================================================================
+ * 6. adjoint_sensitivities(sol, alg; t, dgdu_discrete, sensealg, checkpoints, ...) for one trajectory
+ *    (src/sensitivity_interface.jl:373-526, src/quadrature_adjoint.jl:510-633, src/gauss_adjoint.jl:766-870)
+ * ===================================================================================== */
+static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *u0, const double *p, const double *dLdu,
+                       double *du0, double *dp, double *out, long *nrhs, double *t_fwd, double *t_rev) {
+    int n = m->n, np = m->np, M = cfg->nsave;
+    struct timespec c0, c1, c2;
+    clock_gettime(CLOCK_MONOTONIC, &c0);
+    /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
+    orc_dense sol; double *uend = (double *)malloc(sizeof(double) * n); memcpy(uend, u0, sizeof(double) * n);
+    int st = forward_dense(m, cfg, p, cfg->t0, cfg->t1, uend, 0.0, &sol, nrhs);
+    if (st) { dense_free(&sol); free(uend); return st; }
+    long hint = -1;
+    if (out) for (int i = 0; i < M; ++i) dense_eval(&sol, cfg->save_times[i], out + (size_t)i * n, &hint);
+    /* checkpoints: default = sol.t of the saveat solve = save_times (+ endpoints forced: concrete_solve.jl:695-700) */
+    int nck = 0; double *ck_t = NULL, *ck_u = NULL;
+    int use_ckpt = cfg->checkpointing && cfg->alg != ORC_ALG_QUADRATURE;
+    if (use_ckpt) {
+        int nsrc = cfg->nckpt > 0 ? cfg->nckpt : M; const double *src = cfg->nckpt > 0 ? cfg->checkpoints : cfg->save_times;
+        ck_t = (double *)malloc(sizeof(double) * (nsrc + 2));
+        if (nsrc == 0 || src[0] > cfg->t0) ck_t[nck++] = cfg->t0;
+        for (int i = 0; i < nsrc; ++i) ck_t[nck++] = src[i];
+        if (ck_t[nck - 1] < cfg->t1) ck_t[nck++] = cfg->t1;
+        ck_u = (double *)malloc(sizeof(double) * (size_t)nck * n);
+        for (int i = 0; i < nck; ++i) dense_eval(&sol, ck_t[i], ck_u + (size_t)i * n, &hint);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &c1);
+
+    adj_ctx A; memset(&A, 0, sizeof(A));
+    A.m = m; A.cfg = cfg; A.p = p; A.n = n; A.np = np; A.sol = &sol; A.hint = -1; A.alg = cfg->alg;
+    A.y = (double *)calloc(n, sizeof(double)); A.scratch = (double *)calloc((size_t)n + np, sizeof(double));
+    A.save_t = cfg->save_times; A.M = M; A.dLdu = dLdu; A.cur_time = M; A.nrhs = nrhs;
+    A.ck_t = ck_t; A.ck_u = ck_u; A.nck = nck; A.bs_cur = nck;
+    memcpy(A.y, uend, sizeof(double) * n);
+    if (use_ckpt && cfg->alg != ORC_ALG_BACKSOLVE) {
+        /* intervals = consecutive checkpoint pairs (+ tail up to T) (src/interpolating_adjoint.jl:55-58) */
+        A.checkpointing = 1; A.nint = nck - 1;
+        A.int_a = (double *)malloc(sizeof(double) * A.nint); A.int_b = (double *)malloc(sizeof(double) * A.nint);
+        for (int i = 0; i < A.nint; ++i) { A.int_a[i] = ck_t[i]; A.int_b[i] = ck_t[i + 1]; }
+        resolve_interval(&A, A.nint - 1, 0.0);                      /* eager last-interval re-solve :88-92 */
+    } else if (use_ckpt) {
+        A.checkpointing = 1;
+    }
+
+    /* tstops: loss times (PresetTimeCallback registers them, adjoint_common.jl:848-855) + checkpoints when
+     * checkpointing (sensitivity_interface.jl:484-486; backsolve checkpoint callback is also a PresetTimeCallback) */
+    int nts = 0; double *tst = (double *)malloc(sizeof(double) * (size_t)(M + nck + 1));
+    for (int i = 0; i < M; ++i) tst[nts++] = cfg->save_times[i];
+    for (int i = 0; i < nck; ++i) tst[nts++] = ck_t[i];
+
+    orc_alg alg = make_alg(cfg);
+    int nz; orc_rhs rhs; double *z;
+    switch (cfg->alg) {
+    case ORC_ALG_INTERPOLATING: nz = n + np; rhs = rhs_interpolating; break;           /* z0 = 0 (:412) */
+    case ORC_ALG_BACKSOLVE: nz = 2 * n + np; rhs = rhs_backsolve; break;               /* z0 = [0; 0; y(T)] (:229-231) */
+    default: nz = n; rhs = rhs_lambda_only; break;
+    }
+    z = (double *)calloc(nz, sizeof(double));
+    if (cfg->alg == ORC_ALG_BACKSOLVE) { memcpy(z + n + np, uend, sizeof(double) * n); if (A.bs_cur >= 1 && time_hits(cfg->t1, ck_t[A.bs_cur - 1])) A.bs_cur -= 1; }
+    if (cfg->alg == ORC_ALG_GAUSS) A.gauss_acc = (double *)calloc(np, sizeof(double));
+    orc_dense adjrec; int have_rec = 0;
+    if (cfg->alg == ORC_ALG_QUADRATURE) { dense_init(&adjrec, n, cfg->stepper); have_rec = 1; }
+    int cb_at_init = (M > 0 && time_hits(cfg->t1, cfg->save_times[M - 1]));
+    st = integrate(rhs, &A, nz, z, cfg->t1, cfg->t0, &alg, tst, nts, adjoint_step_cb, &A, cb_at_init, have_rec ? &adjrec : NULL, nrhs);
+
+    /* unpack (src/sensitivity_interface.jl:500-508) */
+    memcpy(du0, z, sizeof(double) * n);
+    if (cfg->alg == ORC_ALG_INTERPOLATING || cfg->alg == ORC_ALG_BACKSOLVE) memcpy(dp, z + n, sizeof(double) * np);
+    else if (cfg->alg == ORC_ALG_GAUSS) memcpy(dp, A.gauss_acc, sizeof(double) * np);
+    else {
+        /* res = sum over loss intervals of quadgk(integrand, t[i], t[i+1]) + end/start corrections
+         * (src/quadrature_adjoint.jl:563-616) */
+        quad_ctx Q; Q.A = &A; Q.adj = &adjrec; Q.hint = -1; Q.lam = (double *)malloc(sizeof(double) * n);
+        double *seg = (double *)malloc(sizeof(double) * np); long nev = 0;
+        double atol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, rtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
+        memset(dp, 0, sizeof(double) * np);
+        if (M == 0) { quadgk_vec(quad_integrand, &Q, np, cfg->t0, cfg->t1, atol, rtol, dp, &nev); }
+        else {
+            if (cfg->save_times[M - 1] != cfg->t1) { quadgk_vec(quad_integrand, &Q, np, cfg->save_times[M - 1], cfg->t1, atol, rtol, seg, &nev); for (int i = 0; i < np; ++i) dp[i] += seg[i]; }
+            for (int i = M - 2; i >= 0; --i) { quadgk_vec(quad_integrand, &Q, np, cfg->save_times[i], cfg->save_times[i + 1], atol, rtol, seg, &nev); for (int j = 0; j < np; ++j) dp[j] += seg[j]; }
+            if (cfg->save_times[0] != cfg->t0) { quadgk_vec(quad_integrand, &Q, np, cfg->t0, cfg->save_times[0], atol, rtol, seg, &nev); for (int i = 0; i < np; ++i) dp[i] += seg[i]; }
+        }
+        if (nrhs) *nrhs += nev;
+        free(seg); free(Q.lam);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &c2);
+    if (t_fwd) *t_fwd += (c1.tv_sec - c0.tv_sec) + 1e-9 * (c1.tv_nsec - c0.tv_nsec);
+    if (t_rev) *t_rev += (c2.tv_sec - c1.tv_sec) + 1e-9 * (c2.tv_nsec - c1.tv_nsec);
+
+    if (have_rec) dense_free(&adjrec);
+    if (A.cpsol_valid) dense_free(&A.cpsol);
+    free(A.int_a); free(A.int_b); free(A.gauss_acc); free(A.y); free(A.scratch);
+    free(z); free(tst); free(ck_t); free(ck_u); free(uend); dense_free(&sol);
+    return st;
+}
+
+int orc_forward(const orc_config *cfg, const double *u0, const double *p, double *out, long *nsteps) {
+    orc_model m; if (model_init(&m, cfg->model, cfg->dims)) return -1;
+    if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+    orc_dense sol; double *u = (double *)malloc(sizeof(double) * m.n); memcpy(u, u0, sizeof(double) * m.n);
+    long nrhs = 0;
+    int st = forward_dense(&m, cfg, p, cfg->t0, cfg->t1, u, 0.0, &sol, &nrhs);
+    long hint = -1;
+    if (!st && out) for (int i = 0; i < cfg->nsave; ++i) dense_eval(&sol, cfg->save_times[i], out + (size_t)i * m.n, &hint);
+    if (nsteps) *nsteps = sol.nsteps;
+    dense_free(&sol); free(u); free(m.work);
+    return st;
+}
+
+int orc_adjoint(const orc_config *cfg, const double *u0, const double *p, const double *dLdu,
+                double *du0, double *dp, double *out, long *nrhs) {
+    orc_model m; if (model_init(&m, cfg->model, cfg->dims)) return -1;
+    if (cfg->loss_kind == ORC_LOSS_COTANGENT && !dLdu && cfg->nsave > 0) return -1;
+    if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+    long nr = 0;
+    int st = adjoint_one(&m, cfg, u0, p, dLdu, du0, dp, out, &nr, NULL, NULL);
+    if (nrhs) *nrhs = nr;
+    free(m.work);
+    return st;
+}
+
+int orc_adjoint_ensemble(const orc_config *cfg, long N, const double *u0, const double *p, int p_shared,
+                         const double *dLdu, double *du0, double *dp, double *out, int nthreads,
+                         double *forward_seconds, double *reverse_seconds) {
+    orc_model m0; if (model_init(&m0, cfg->model, cfg->dims)) return -1;
+    int n = m0.n, np = m0.np, M = cfg->nsave; int status = 0;
+    double tf = 0, tr = 0;
+    if (p_shared) memset(dp, 0, sizeof(double) * np);
+    (void)nthreads;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+    {
+        orc_model m = m0; m.work = NULL;
+        if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+        double *dpl = (double *)calloc(np, sizeof(double)), *dpi = (double *)calloc(np, sizeof(double));
+        double ltf = 0, ltr = 0;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (long i = 0; i < N; ++i) {
+            long nr = 0;
+            int st = adjoint_one(&m, cfg, u0 + (size_t)i * n, p_shared ? p : p + (size_t)i * np,
+                                 dLdu ? dLdu + (size_t)i * M * n : NULL, du0 + (size_t)i * n,
+                                 p_shared ? dpi : dp + (size_t)i * np, out ? out + (size_t)i * M * n : NULL, &nr, &ltf, &ltr);
+            if (st) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+                status = st;
+            }
+            if (p_shared) for (int j = 0; j < np; ++j) dpl[j] += dpi[j];
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            if (p_shared) for (int j = 0; j < np; ++j) dp[j] += dpl[j];
+            if (ltf > tf) tf = ltf;
+            if (ltr > tr) tr = ltr;
+        }
+        free(dpl); free(dpi); free(m.work);
+    }
+    if (forward_seconds) *forward_seconds = tf;
+    if (reverse_seconds) *reverse_seconds = tr;
+    return status;
+}

@@ -1,0 +1,88 @@
+/*
+ * oracle/adjoint_oracle.h — CPU restatement of the SciMLSensitivity.jl continuous-adjoint hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / the timed CPU baseline.  libhipadj (the product) never links or calls it.
+ *
+ * Parity status: the reference is pure Julia and `julia` is absent from this image, so the
+ * reference itself cannot be executed here; its ODE stepping / dense output / quadrature arithmetic
+ * lives in un-vendored packages (OrdinaryDiffEq >= 7, DiffEqCallbacks >= 4.18, QuadGK >= 2.11.3,
+ * /root/reference/Project.toml:71,99-109, no Manifest).  This oracle is therefore pinned on
+ *   (1) the two literal known answers the reference tests hold for this path
+ *       (test/Core7/physical_ode_regression.jl:42-51, test/Core1/sparse_adjoint.jl:32-33),
+ *   (2) the cross-method relations the reference tests assert (test/Core3/adjoint.jl:366-404,
+ *       691-705, 1201-1241; test/Core3/user_vjp.jl:79-113), with scipy DOP853 forward
+ *       sensitivities standing in for ForwardDiff (tests/golden/ + tests/golden/make_golden.py).
+ * Fixed-step RK4 ensembles (BASELINE configs 2/3) are covered by NO reference test:
+ * for those sizes parity is "unpinned" beyond the relations above.
+ */
+#ifndef ADJOINT_ORACLE_H
+#define ADJOINT_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* model ids — shared numbering with include/hipadj.h */
+enum {
+    ORC_MODEL_LV = 0,        /* Lotka-Volterra, 4 params (test/Core1/concrete_solve_derivatives.jl, user_vjp.jl:6-38) */
+    ORC_MODEL_LVT = 1,       /* time-dependent LV `fb` (test/Core3/adjoint.jl:8-12) */
+    ORC_MODEL_LORENZ = 2,    /* Lorenz-63 (test/Core3/adjoint.jl:1160-1166) */
+    ORC_MODEL_LINDIAG = 3,   /* u' = p .* u, n = np = 2 (test/Core1/sparse_adjoint.jl:6-17) */
+    ORC_MODEL_FALLMASS = 4,  /* u' = [u2, -g]  (test/Core7/physical_ode_regression.jl:20-23) */
+    ORC_MODEL_MLP = 5,       /* tanh MLP d->H->H->d applied column-wise to a d x B state */
+    ORC_MODEL_BRUSS = 6      /* 2-D Brusselator, periodic 5-point Laplacian */
+};
+enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3 };
+enum { ORC_STEPPER_RK4 = 0, ORC_STEPPER_TSIT5 = 1 };
+enum { ORC_LOSS_COTANGENT = 0, ORC_LOSS_LSQ_SHIFT = 1 };
+
+typedef struct {
+    int model, alg, stepper;
+    int dims[4];          /* model shape parameters: MLP {d, H, B, 0}; BRUSS {Ngrid, 0,0,0}; else unused */
+    double t0, t1, dt;    /* dt: fixed step (RK4) or initial-step hint (<=0: automatic) for Tsit5 */
+    double abstol, reltol;/* stepper tolerances (Tsit5) used for forward, re-solve and reverse solves */
+    int nsave;            /* M loss / save times (ascending) */
+    const double *save_times;
+    int loss_kind;        /* COTANGENT: dgdu_discrete(out,u,p,t,i) = dLdu[i]  (src/concrete_solve.jl:842-851)
+                             LSQ_SHIFT: out = u - loss_shift               (test/Core3/adjoint.jl:49-51)  */
+    double loss_shift;
+    int checkpointing;    /* sensealg.checkpointing */
+    int nckpt;            /* checkpoint times (ascending); 0 => default = save_times (sol.t of a saveat solve) */
+    const double *checkpoints;
+    double quad_abstol, quad_reltol; /* QuadratureAdjoint(abstol, reltol) */
+    int no_start;         /* suppress the jump at t0 (src/adjoint_common.jl:761) */
+} orc_config;
+
+int orc_model_sizes(int model, const int dims[4], int *n, int *np);
+
+/* forward solve of ONE trajectory; out[M][n] = sol(save_times) (src/concrete_solve.jl:718-727) */
+int orc_forward(const orc_config *cfg, const double *u0, const double *p, double *out, long *nsteps);
+
+/* forward + adjoint of ONE trajectory. dLdu: [M][n] cotangents or NULL (LSQ_SHIFT).
+   du0[n], dp[np] (row vector of src/sensitivity_interface.jl:500-508), out[M][n] (may be NULL). */
+int orc_adjoint(const orc_config *cfg, const double *u0, const double *p, const double *dLdu,
+                double *du0, double *dp, double *out, long *nrhs);
+
+/* ensemble: N independent trajectories (test/Core4/ensembles.jl:13-31), u0[N][n]; p shared [np] or [N][np];
+   dLdu [N][M][n] or NULL; du0[N][n]; dp [np] (sum over trajectories, p_shared) or [N][np]; out [N][M][n] or NULL.
+   skip_forward_timing: returns seconds spent in the reverse passes only through *reverse_seconds. */
+int orc_adjoint_ensemble(const orc_config *cfg, long N, const double *u0, const double *p, int p_shared,
+                         const double *dLdu, double *du0, double *dp, double *out, int nthreads,
+                         double *forward_seconds, double *reverse_seconds);
+
+/* raw model hooks (user-VJP seam, src/derivative_wrappers.jl:284-359) for unit tests */
+int orc_model_f(int model, const int dims[4], const double *u, const double *p, double t, double *du);
+int orc_model_vjp(int model, const int dims[4], const double *lam, const double *u, const double *p, double t,
+                  double *dlam, double *dgrad);
+
+/* adaptive Gauss-Kronrod (7,15) on a polynomial test integrand, for pinning the quadrature rule */
+double orc_test_quadgk_poly(int degree, double a, double b, double atol, double rtol, long *nevals);
+/* Tsit5 tableau self-check: returns max order-condition residual up to order 5 */
+double orc_test_tsit5_order_residual(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
