@@ -1,0 +1,138 @@
+/*
+ * hipadj.h — C ABI of libhipadj: MI355X (gfx950) batched continuous-adjoint sensitivity engine.
+ *
+ * Drop-in boundary: the WHOLE reverse pass of a WHOLE ensemble sits behind
+ * these entry points.  Each entry point names the reference interface it replaces (paths relative to the
+ * SciMLSensitivity.jl tree).  The reference has no FFI of its own (pure Julia); the Julia-side binding a
+ * maintainer would add is the `ccall` stub in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, Float64, caller-owned buffers, row-major as stated per argument.
+ * Every function returns HIPADJ_OK (0) or a negative hipadj_status; nothing throws across the ABI;
+ * hipadj_last_error() gives the message.  A handle is not thread-safe; distinct handles are independent
+ * (the reference gets concurrency from many solves on Julia threads, test/Core4/ensembles.jl:16-20).
+ * There is NO CPU fallback: hipadj_create fails with HIPADJ_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef HIPADJ_H
+#define HIPADJ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPADJ_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    HIPADJ_OK = 0,
+    HIPADJ_ERR_INVALID_ARG = -1,  /* mirrors the reference's `error(...)` on misuse, src/interpolating_adjoint.jl:321-326 */
+    HIPADJ_ERR_NO_DEVICE = -2,
+    HIPADJ_ERR_HIP = -3,
+    HIPADJ_ERR_NONFINITE = -4,    /* a trajectory produced NaN/Inf — the reference's retcode checks */
+    HIPADJ_ERR_STATE = -5,        /* adjoint requested before forward */
+    HIPADJ_ERR_UNSUPPORTED = -6
+} hipadj_status;
+
+/* compile-time model registry: device-inlined f, (df/du)^T lam, (df/dp)^T lam — the reference's user-VJP seam
+ * ODEFunction(f; vjp, vjp_p)  (src/derivative_wrappers.jl:284-359, test/Core3/user_vjp.jl:14-38) */
+typedef enum {
+    HIPADJ_MODEL_LV = 0,       /* Lotka-Volterra n=2 np=4 (test/Core3/user_vjp.jl:6-10) */
+    HIPADJ_MODEL_LVT = 1,      /* time-dependent LV `fb` (test/Core3/adjoint.jl:8-12) */
+    HIPADJ_MODEL_LORENZ = 2,   /* Lorenz-63 n=3 np=3 (test/Core3/adjoint.jl:1160-1166) */
+    HIPADJ_MODEL_LINDIAG = 3,  /* u' = p .* u, n=np=2 (test/Core1/sparse_adjoint.jl:6-8) */
+    HIPADJ_MODEL_FALLMASS = 4, /* u' = [u2, -g] (test/Core7/physical_ode_regression.jl:20-23) */
+    HIPADJ_MODEL_MLP = 5,      /* tanh MLP d->H->H->d on a d x B state; dims = {d, H, B} */
+    HIPADJ_MODEL_BRUSS = 6     /* 2-D Brusselator, dims = {Ngrid} (docs/src/examples/pde/brusselator.md:98-112) */
+} hipadj_model;
+
+/* sensealg — src/sensitivity_algorithms.jl:254-272 (Backsolve), 378-396 (Interpolating), 486-503 (Quadrature),
+ * 591-607 (Gauss) */
+typedef enum {
+    HIPADJ_ALG_INTERPOLATING = 0,
+    HIPADJ_ALG_BACKSOLVE = 1,
+    HIPADJ_ALG_GAUSS = 2,
+    HIPADJ_ALG_QUADRATURE = 3
+} hipadj_alg;
+
+typedef enum { HIPADJ_STEPPER_RK4_FIXED = 0 } hipadj_stepper;
+
+/* how dgdu_discrete(out, u, p, t, i) is evaluated at loss time t_i (src/adjoint_common.jl:771-773) */
+typedef enum {
+    HIPADJ_LOSS_COTANGENT = 0, /* out = dLdu[:, i]   — the AD path, src/concrete_solve.jl:842-851 */
+    HIPADJ_LOSS_LSQ_SHIFT = 1  /* out = u - loss_shift — test/Core3/adjoint.jl:49-51, 1169-1172; fused in-kernel */
+} hipadj_loss;
+
+typedef struct {
+    uint32_t struct_size;      /* = sizeof(hipadj_config); ABI guard */
+    int32_t model;             /* hipadj_model */
+    int32_t alg;               /* hipadj_alg */
+    int32_t stepper;           /* hipadj_stepper */
+    int32_t dims[4];           /* model shape parameters (MLP, BRUSS), else 0 */
+    int64_t ntraj;             /* N trajectories in this handle's shard */
+    double t0, t1, dt;         /* tspan and fixed step; (t1 - t0)/dt must be an integer number of steps S */
+    int32_t nsave;             /* M loss/save times */
+    const double *save_times;  /* [M] ascending, each on the step grid t0 + k*dt (copied at create) */
+    int32_t loss_kind;         /* hipadj_loss */
+    double loss_shift;
+    int32_t checkpointing;     /* sensealg.checkpointing (Backsolve default true: sensitivity_algorithms.jl:260-265) */
+    int32_t ckpt_stride;       /* checkpoint every ckpt_stride steps; 0 => checkpoints = save_times (backsolve_adjoint.jl:132) */
+    double quad_abstol, quad_reltol; /* QuadratureAdjoint(abstol = 1e-6, reltol = 1e-3) */
+    int32_t no_start;          /* suppress the loss jump at t0 (src/adjoint_common.jl:761) */
+    int32_t p_shared;          /* 1: p[np] shared by all trajectories and dp[np] = sum_i dp_i ; 0: p[N][np], dp[N][np] */
+    int32_t device;            /* HIP device ordinal */
+    int32_t time_segments;     /* 0 = automatic; 1 = strictly sequential in time; C > 1 = C time segments per trajectory */
+} hipadj_config;
+
+typedef struct {
+    uint32_t struct_size;
+    int32_t n, np;
+    int64_t ntraj, nsteps;
+    int32_t time_segments;         /* segments actually used by the last adjoint */
+    double forward_ms_last, adjoint_ms_last;      /* device time of the last call (HIP events on the handle stream) */
+    double forward_ms_total, adjoint_ms_total;
+    int64_t forward_calls, adjoint_calls;
+    double adjoint_main_kernel_ms_last, adjoint_main_kernel_ms_total; /* dominant reverse kernel only */
+    double adjoint_algorithmic_bytes; /* per adjoint call, SURVEY.md §8d definition */
+    double vjp_steps;                 /* N * S * 4 per adjoint call (src/derivative_wrappers.jl:256 equivalents) */
+    double workspace_bytes;
+} hipadj_stats;
+
+typedef struct hipadj_handle hipadj_handle;
+
+int hipadj_version(void);
+const char *hipadj_status_string(int status);
+/* message of the last failing call on this handle; handle == NULL: last hipadj_create failure of this thread */
+const char *hipadj_last_error(const hipadj_handle *h);
+/* n and np of a registered model (the reference reads them off u0 / p) */
+int hipadj_model_sizes(int32_t model, const int32_t dims[4], int32_t *n, int32_t *np);
+
+/* Replaces the per-call setup of ODEAdjointProblem + adjointdiffcache (src/interpolating_adjoint.jl:307-451,
+ * src/backsolve_adjoint.jl:123-272, src/adjoint_common.jl:42-469): validates the configuration, allocates the
+ * device workspaces (forward interpolant tiles / checkpoint tiles), creates the stream. */
+int hipadj_create(const hipadj_config *cfg, hipadj_handle **out);
+int hipadj_destroy(hipadj_handle *h);
+
+/* Forward solve of the ensemble — replaces the forward `solve` in _concrete_solve_adjoint
+ * (src/concrete_solve.jl:689-707) and the primal output `out = sol(ts)` (:718-770).
+ * u0 [N][n]; p [np] (p_shared) or [N][np]; out [N][M][n] (may be NULL). Host pointers; synchronous. */
+int hipadj_forward(hipadj_handle *h, const double *u0, const double *p, double *out);
+
+/* Reverse pass — replaces adjoint_sensitivities(sol, alg; t, dgdu_discrete, sensealg, checkpoints)
+ * (src/sensitivity_interface.jl:373-526; Quadrature: src/quadrature_adjoint.jl:510-633; Gauss:
+ * src/gauss_adjoint.jl:766-870), i.e. the pullback body of src/concrete_solve.jl:955-986.
+ * dLdu [N][M][n] cotangents (COTANGENT loss) or NULL (LSQ_SHIFT); du0 [N][n]; dp [np] or [N][np]. */
+int hipadj_adjoint(hipadj_handle *h, const double *dLdu, double *du0, double *dp);
+
+/* Device-pointer variants (same layouts, memory of cfg.device); asynchronous on the handle's stream. */
+int hipadj_forward_dev(hipadj_handle *h, const double *d_u0, const double *d_p, double *d_out);
+int hipadj_adjoint_dev(hipadj_handle *h, const double *d_dLdu, double *d_du0, double *d_dp);
+/* run on the caller's hipStream_t (e.g. torch's current stream); NULL restores the handle's own stream */
+int hipadj_set_stream(hipadj_handle *h, void *hip_stream);
+int hipadj_synchronize(hipadj_handle *h);
+
+int hipadj_get_stats(hipadj_handle *h, hipadj_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPADJ_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libhipadj.so (include/hipadj.h).  Fails loudly when the HIP library is missing:
+there is no CPU or PyTorch fallback behind this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhipadj.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NONFINITE, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+
+MODEL = dict(lv=0, lvt=1, lorenz=2, lindiag=3, fallmass=4, mlp=5, bruss=6)
+ALG = dict(interpolating=0, backsolve=1, gauss=2, quadrature=3)
+LOSS_COTANGENT, LOSS_LSQ_SHIFT = 0, 1
+
+DECLARED_SYMBOLS = (
+    "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
+    "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
+    "hipadj_set_stream", "hipadj_synchronize", "hipadj_get_stats",
+)
+
+
+class HipadjConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("model", C.c_int32), ("alg", C.c_int32), ("stepper", C.c_int32),
+        ("dims", C.c_int32 * 4), ("ntraj", C.c_int64),
+        ("t0", C.c_double), ("t1", C.c_double), ("dt", C.c_double),
+        ("nsave", C.c_int32), ("save_times", C.POINTER(C.c_double)),
+        ("loss_kind", C.c_int32), ("loss_shift", C.c_double),
+        ("checkpointing", C.c_int32), ("ckpt_stride", C.c_int32),
+        ("quad_abstol", C.c_double), ("quad_reltol", C.c_double),
+        ("no_start", C.c_int32), ("p_shared", C.c_int32), ("device", C.c_int32), ("time_segments", C.c_int32),
+    ]
+
+
+class HipadjStats(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n", C.c_int32), ("np", C.c_int32),
+        ("ntraj", C.c_int64), ("nsteps", C.c_int64), ("time_segments", C.c_int32),
+        ("forward_ms_last", C.c_double), ("adjoint_ms_last", C.c_double),
+        ("forward_ms_total", C.c_double), ("adjoint_ms_total", C.c_double),
+        ("forward_calls", C.c_int64), ("adjoint_calls", C.c_int64),
+        ("adjoint_main_kernel_ms_last", C.c_double), ("adjoint_main_kernel_ms_total", C.c_double),
+        ("adjoint_algorithmic_bytes", C.c_double), ("vjp_steps", C.c_double), ("workspace_bytes", C.c_double),
+    ]
+
+
+class HipadjError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"hipadj status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """dlopen libhipadj.so.  Raises (never falls back) when the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the gfx950 extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "This package has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp, vp = C.POINTER(C.c_double), C.c_void_p
+    L.hipadj_version.restype = C.c_int
+    L.hipadj_status_string.restype = C.c_char_p
+    L.hipadj_status_string.argtypes = [C.c_int]
+    L.hipadj_last_error.restype = C.c_char_p
+    L.hipadj_last_error.argtypes = [vp]
+    L.hipadj_model_sizes.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.hipadj_create.argtypes = [C.POINTER(HipadjConfig), C.POINTER(vp)]
+    L.hipadj_destroy.argtypes = [vp]
+    L.hipadj_forward.argtypes = [vp, dp, dp, dp]
+    L.hipadj_adjoint.argtypes = [vp, dp, dp, dp]
+    L.hipadj_forward_dev.argtypes = [vp, vp, vp, vp]
+    L.hipadj_adjoint_dev.argtypes = [vp, vp, vp, vp]
+    L.hipadj_set_stream.argtypes = [vp, vp]
+    L.hipadj_synchronize.argtypes = [vp]
+    L.hipadj_get_stats.argtypes = [vp, C.POINTER(HipadjStats)]
+    _lib = L
+    return L
+
+
+def model_sizes(model, dims=(0, 0, 0, 0)):
+    n, npar = C.c_int32(), C.c_int32()
+    rc = load().hipadj_model_sizes(MODEL[model], (C.c_int32 * 4)(*dims), C.byref(n), C.byref(npar))
+    if rc != OK:
+        raise HipadjError(rc, f"unknown model {model!r} / dims {dims}")
+    return n.value, npar.value

@@ -1,0 +1,363 @@
+// hipadj_api.hip — the C-ABI shared library (include/hipadj.h) over the gfx950 kernel family.
+// Host side only does validation, workspace ownership, launch sequencing and timing; all arithmetic is in
+// hipadj_lane.hpp / hipadj_kernels.hpp.  No CPU fallback exists: without a usable HIP device
+// hipadj_create returns HIPADJ_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hipadj.h"
+#include "hipadj_kernels.hpp"
+#include "hipadj_plan.hpp"
+
+using namespace hipadj;
+
+struct hipadj_handle {
+    hipadj_config cfg{};
+    int n = 0, np = 0;
+    long N = 0, Npad = 0;
+    int S = 0, M = 0, nck = 0, nseg = 1, nq = 0;
+    Geom g{};
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fwd begin/end, adj begin/end, main-kernel begin/end
+    std::vector<double> save_times;
+    std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
+    // device workspaces (owned)
+    double *d_u0 = nullptr, *d_p = nullptr, *d_outT = nullptr, *d_yT = nullptr, *d_ckpt = nullptr, *d_cotT = nullptr;
+    double *d_segbuf = nullptr, *d_dp_traj = nullptr, *d_qres = nullptr, *d_qa = nullptr, *d_qb = nullptr;
+    double *d_io_a = nullptr, *d_du0 = nullptr, *d_dp = nullptr;   // staging for the host-pointer API
+    dbl2 *d_knots = nullptr, *d_adj = nullptr;
+    int *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
+    const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
+    bool have_forward = false, timing_pending_fwd = false, timing_pending_adj = false;
+    double ws_bytes = 0;
+    hipadj_stats st{};
+    std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+extern "C" int hipadj_version(void) { return HIPADJ_VERSION; }
+
+extern "C" const char* hipadj_status_string(int s) {
+    switch (s) {
+    case HIPADJ_OK: return "ok";
+    case HIPADJ_ERR_INVALID_ARG: return "invalid argument";
+    case HIPADJ_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required; there is no CPU fallback)";
+    case HIPADJ_ERR_HIP: return "HIP runtime error";
+    case HIPADJ_ERR_NONFINITE: return "non-finite value in a trajectory's sensitivities";
+    case HIPADJ_ERR_STATE: return "invalid call order (forward solve required first)";
+    case HIPADJ_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char* hipadj_last_error(const hipadj_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int hipadj_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, int32_t* np) {
+    if (!n || !np) return HIPADJ_ERR_INVALID_ARG;
+    return plan_model_sizes(model, dims, n, np);
+}
+
+#define HIPADJ_FAIL(h, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (h)->err = _b; return (code); } while (0)
+#define HIP_TRY(h, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    HIPADJ_FAIL(h, HIPADJ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+
+template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
+    if (count == 0) { *p = nullptr; return HIPADJ_OK; }
+    HIP_TRY(h, hipMalloc((void**)p, count * sizeof(T)));
+    h->ws_bytes += (double)(count * sizeof(T));
+    return HIPADJ_OK;
+}
+#define TRY(expr) do { int _rc = (expr); if (_rc != HIPADJ_OK) return _rc; } while (0)
+
+static void free_all(hipadj_handle* h) {
+    void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
+                    h->d_qb, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_save_of_knot,
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+}
+
+extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
+    if (!out) { g_create_error = "out == NULL"; return HIPADJ_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!cfg) { g_create_error = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
+        auto* h = new hipadj_handle();
+    auto fail = [&](int code) { g_create_error = h->err; free_all(h); delete h; return code; };
+    h->cfg = *cfg; h->cfg.save_times = nullptr;
+    Plan P;
+    { const int prc = make_plan(cfg, P, h->err); if (prc != HIPADJ_OK) return fail(prc); }
+    const int n = P.n, np = P.np; const long S = P.S;
+    h->n = n; h->np = np; h->N = P.N; h->Npad = P.Npad; h->S = P.S; h->M = P.M; h->nck = P.nck; h->nseg = P.nseg; h->nq = P.nq;
+    h->save_times = P.save_times; h->save_of_knot = P.save_of_knot; h->ckpt_of_knot = P.ckpt_of_knot; h->seg_bounds = P.seg_bounds;
+    const bool bs_ckpt = P.bs_ckpt;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { h->err = hipadj_status_string(HIPADJ_ERR_NO_DEVICE); return fail(HIPADJ_ERR_NO_DEVICE); }
+    if (cfg->device < 0 || cfg->device >= ndev) { h->err = "device ordinal out of range"; return fail(HIPADJ_ERR_INVALID_ARG); }
+    auto HT = [&](hipError_t e, const char* what) { if (e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; };
+    if (!HT(hipSetDevice(cfg->device), "hipSetDevice")) return fail(HIPADJ_ERR_HIP);
+    if (!HT(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking), "hipStreamCreate")) return fail(HIPADJ_ERR_HIP);
+    h->stream = h->own_stream;
+    for (auto& e : h->ev) if (!HT(hipEventCreate(&e), "hipEventCreate")) return fail(HIPADJ_ERR_HIP);
+
+    const long Np = h->Npad;
+    int rc = HIPADJ_OK;
+    auto A = [&](int r) { if (rc == HIPADJ_OK) rc = r; };
+    A(dev_alloc(h, &h->d_u0, (size_t)h->N * n));
+    A(dev_alloc(h, &h->d_p, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
+    A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
+    A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
+    if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));
+    if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
+    if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
+    A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
+    A(dev_alloc(h, &h->d_dp_traj, (size_t)np * Np));
+    A(dev_alloc(h, &h->d_io_a, (size_t)h->N * (h->M > 0 ? h->M : 1) * n));
+    A(dev_alloc(h, &h->d_du0, (size_t)h->N * n));
+    A(dev_alloc(h, &h->d_dp, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
+    A(dev_alloc(h, &h->d_save_of_knot, (size_t)S + 1));
+    A(dev_alloc(h, &h->d_ckpt_of_knot, (size_t)S + 1));
+    A(dev_alloc(h, &h->d_seg_bounds, (size_t)h->nseg + 1));
+    A(dev_alloc(h, &h->d_flag, 1));
+    const std::vector<double>&qa = P.qa, &qb = P.qb;
+    if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
+        A(dev_alloc(h, &h->d_adj, (size_t)S * 2 * n * Np));
+        A(dev_alloc(h, &h->d_qres, (size_t)h->nq * np * Np));
+        A(dev_alloc(h, &h->d_qa, (size_t)h->nq)); A(dev_alloc(h, &h->d_qb, (size_t)h->nq));
+    }
+    if (rc != HIPADJ_OK) return fail(rc);
+    bool ok = HT(hipMemcpy(h->d_save_of_knot, h->save_of_knot.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
+              HT(hipMemcpy(h->d_ckpt_of_knot, h->ckpt_of_knot.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
+              HT(hipMemcpy(h->d_seg_bounds, h->seg_bounds.data(), sizeof(int) * (h->nseg + 1), hipMemcpyHostToDevice), "memcpy") &&
+              HT(hipMemset(h->d_flag, 0, sizeof(int)), "memset");
+    if (ok && h->nq > 0) ok = HT(hipMemcpy(h->d_qa, qa.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy") &&
+                              HT(hipMemcpy(h->d_qb, qb.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy");
+    if (!ok) return fail(HIPADJ_ERR_HIP);
+
+    Geom& g = h->g;
+    g.N = h->N; g.Npad = Np; g.S = (int)S; g.M = h->M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
+    g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
+
+    h->st.struct_size = sizeof(hipadj_stats); h->st.n = n; h->st.np = np; h->st.ntraj = h->N; h->st.nsteps = S;
+    h->st.time_segments = h->nseg; h->st.workspace_bytes = h->ws_bytes;
+    // ALGORITHMIC bytes of one reverse pass: knots (u,f) once, cotangents (if read), du0 + dp out
+    double bytes = 0.0;
+    if (cfg->alg == HIPADJ_ALG_BACKSOLVE) bytes = (double)h->N * ((double)h->nck * 8.0 * n + 8.0 * n);
+    else bytes = (double)h->N * (double)(S + 1) * 16.0 * n;
+    if (cfg->alg == HIPADJ_ALG_QUADRATURE) bytes += (double)h->N * (double)S * 2.0 * 32.0 * n;   // dense lambda write + read
+    if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) bytes += (double)h->N * h->M * 8.0 * n;
+    bytes += (double)h->N * 8.0 * (n + np);
+    h->st.adjoint_algorithmic_bytes = bytes;
+    h->st.vjp_steps = (double)h->N * (double)S * 4.0;
+    *out = h;
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_destroy(hipadj_handle* h) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_set_stream(hipadj_handle* h, void* s) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return HIPADJ_OK;
+}
+
+static void harvest_timing(hipadj_handle* h) {
+    float ms = 0.f;
+    if (h->timing_pending_fwd) {
+        if (hipEventSynchronize(h->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) { h->st.forward_ms_last = ms; h->st.forward_ms_total += ms; }
+        h->timing_pending_fwd = false;
+    }
+    if (h->timing_pending_adj) {
+        if (hipEventSynchronize(h->ev[3]) == hipSuccess) {
+            if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) { h->st.adjoint_ms_last = ms; h->st.adjoint_ms_total += ms; }
+            if (hipEventElapsedTime(&ms, h->ev[4], h->ev[5]) == hipSuccess) { h->st.adjoint_main_kernel_ms_last = ms; h->st.adjoint_main_kernel_ms_total += ms; }
+        }
+        h->timing_pending_adj = false;
+    }
+}
+
+extern "C" int hipadj_synchronize(hipadj_handle* h) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    harvest_timing(h);
+    int flag = 0;
+    HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
+        HIPADJ_FAIL(h, HIPADJ_ERR_NONFINITE, "non-finite sensitivities (flag %d): a trajectory diverged", flag);
+    }
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_get_stats(hipadj_handle* h, hipadj_stats* st) {
+    if (!h || !st) return HIPADJ_ERR_INVALID_ARG;
+    if (st->struct_size != sizeof(hipadj_stats)) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_stats.struct_size mismatch");
+    *st = h->st;
+    return HIPADJ_OK;
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------------
+static int launch_transpose_to_soa(hipadj_handle* h, const double* src, double* dst, int C) {
+    dim3 blk(32, 8), grd((unsigned)((h->Npad + 31) / 32), (unsigned)((C + 31) / 32));
+    hipLaunchKernelGGL(k_aos_to_soa, grd, blk, 0, h->stream, src, dst, h->N, h->Npad, C);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+static int launch_transpose_to_aos(hipadj_handle* h, const double* src, double* dst, int C) {
+    dim3 blk(32, 8), grd((unsigned)((h->N + 31) / 32), (unsigned)((C + 31) / 32));
+    hipLaunchKernelGGL(k_soa_to_aos, grd, blk, 0, h->stream, src, dst, h->N, h->Npad, C);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+
+template <class Mo> static int forward_impl(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    dbl2* knots = h->d_knots;
+    double* ck = h->d_ckpt;
+    hipLaunchKernelGGL((k_forward<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, d_u0, d_p, knots, ck,
+                       h->d_ckpt_of_knot, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, h->d_save_of_knot, h->d_yT);
+    HIP_TRY(h, hipGetLastError());
+    if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
+    return HIPADJ_OK;
+}
+
+template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    constexpr int PF = 8;
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    const double* p = h->p_dev_last;
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    hipEvent_t k0 = h->ev[4], k1 = h->ev[5];   // dominant-kernel bracket
+    HIP_TRY(h, hipEventRecord(k0, h->stream));
+    switch (h->cfg.alg) {
+    case HIPADJ_ALG_INTERPOLATING: {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        hipLaunchKernelGGL((k_interp<Mo, PF>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p,
+                           (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(k1, h->stream));
+        hipLaunchKernelGGL((k_compose<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf, d_du0, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    case HIPADJ_ALG_BACKSOLVE:
+        hipLaunchKernelGGL((k_backsolve<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const double*)h->d_yT,
+                           (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
+                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(k1, h->stream));
+        break;
+    case HIPADJ_ALG_GAUSS:
+        hipLaunchKernelGGL((k_gauss<Mo, PF>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
+                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(k1, h->stream));
+        break;
+    case HIPADJ_ALG_QUADRATURE: {
+        hipLaunchKernelGGL((k_quad_adj<Mo, PF>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
+                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(k1, h->stream));
+        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        hipLaunchKernelGGL((k_quad_gk<Mo>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
+                           (const dbl2*)h->d_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    }
+    // dp: shared p => deterministic sum over trajectories; else per-trajectory rows in the caller layout
+    hipLaunchKernelGGL(k_reduce_dp, dim3((unsigned)h->np), dim3(256), 0, h->stream, h->N, h->Npad, (const double*)h->d_dp_traj,
+                       h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
+    HIP_TRY(h, hipGetLastError());
+    if (!h->cfg.p_shared) TRY(launch_transpose_to_aos(h, h->d_dp_traj, d_dp, h->np));
+    { const long cnt = h->N * h->n;
+      hipLaunchKernelGGL(k_scan_finite, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, cnt, (const double*)d_du0, h->d_flag);
+      HIP_TRY(h, hipGetLastError()); }
+    HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+    h->timing_pending_adj = true;
+    return HIPADJ_OK;   // timings are harvested lazily at the next synchronize / call
+}
+
+#define DISPATCH_MODEL(h, fn, ...)                                                         \
+    switch ((h)->cfg.model) {                                                              \
+    case HIPADJ_MODEL_LV: return fn<ModelLV>(__VA_ARGS__);                                 \
+    case HIPADJ_MODEL_LVT: return fn<ModelLVT>(__VA_ARGS__);                               \
+    case HIPADJ_MODEL_LORENZ: return fn<ModelLorenz>(__VA_ARGS__);                         \
+    case HIPADJ_MODEL_LINDIAG: return fn<ModelLinDiag>(__VA_ARGS__);                       \
+    case HIPADJ_MODEL_FALLMASS: return fn<ModelFallMass>(__VA_ARGS__);                     \
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "model %d has no device kernels", (h)->cfg.model); }
+
+static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    DISPATCH_MODEL(h, forward_impl, h, d_u0, d_p, d_out);
+}
+static int adjoint_dispatch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    DISPATCH_MODEL(h, adjoint_impl, h, d_cot, d_du0, d_dp);
+}
+
+extern "C" int hipadj_forward_dev(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!d_u0 || !d_p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    harvest_timing(h);
+    // keep private copies: the adjoint needs p, and u0 may be released by the caller
+    const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
+    if (d_p != h->d_p) HIP_TRY(h, hipMemcpyAsync(h->d_p, d_p, pb, hipMemcpyDeviceToDevice, h->stream));
+    h->p_dev_last = h->d_p;
+    HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    TRY(forward_dispatch(h, d_u0, h->d_p, d_out));
+    HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    h->timing_pending_fwd = true; h->have_forward = true; h->st.forward_calls++;
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double* d_du0, double* d_dp) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!h->have_forward) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_adjoint called before hipadj_forward (the reverse pass consumes the forward solution)");
+    if (!d_du0 || !d_dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !d_dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    harvest_timing(h);
+    TRY(adjoint_dispatch(h, d_dLdu, d_du0, d_dp));
+    h->st.adjoint_calls++;
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* p, double* out) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!u0 || !p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
+    HIP_TRY(h, hipMemcpyAsync(h->d_u0, u0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_p, p, pb, hipMemcpyHostToDevice, h->stream));
+    TRY(hipadj_forward_dev(h, h->d_u0, h->d_p, out ? h->d_io_a : nullptr));
+    if (out && h->M > 0) HIP_TRY(h, hipMemcpyAsync(out, h->d_io_a, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyDeviceToHost, h->stream));
+    return hipadj_synchronize(h);
+}
+
+extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0, double* dp) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!du0 || !dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const bool cot = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0;
+    if (cot && !dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
+    if (cot) HIP_TRY(h, hipMemcpyAsync(h->d_io_a, dLdu, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
+    TRY(hipadj_adjoint_dev(h, cot ? h->d_io_a : nullptr, h->d_du0, h->d_dp));
+    const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
+    HIP_TRY(h, hipMemcpyAsync(du0, h->d_du0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dp, h->d_dp, pb, hipMemcpyDeviceToHost, h->stream));
+    return hipadj_synchronize(h);
+}

@@ -1,0 +1,541 @@
+// hipadj_lane.hpp — per-lane bodies of the lane-per-trajectory kernel family (small-n models).
+//
+// One lane integrates one (trajectory, time-segment) pair.  All state lives in VGPRs (arrays with
+// compile-time extents, loops fully unrolled); the forward solution is streamed from HBM as 16-byte
+// "pair" records laid out [knot][pair][trajectory] so that a wavefront's 64 lanes read 1 KiB contiguous
+// per load instruction.
+//
+// What these bodies restate (reference = SciMLSensitivity.jl, paths relative to its tree):
+//   forward_lane        the forward `solve` of _concrete_solve_adjoint (src/concrete_solve.jl:689-707) with
+//                       fixed-step RK4, saving (u_k, f(u_k)) = the data of the dense Hermite interpolant
+//   interp_lane         (S::ODEInterpolatingAdjointSensitivityFunction)(du,u,p,t)  src/interpolating_adjoint.jl:150-174
+//                       + split_states :190-304 + ReverseLossCallback src/adjoint_common.jl:754-821, stepped by RK4
+//   backsolve_lane      (S::ODEBacksolveSensitivityFunction)  src/backsolve_adjoint.jl:32-61, 78-120 and the
+//                       checkpoint callback :523-546
+//   gauss_lane          (S::ODEGaussAdjointSensitivityFunction) src/gauss_adjoint.jl:118-128 + GaussIntegrand :745-759
+//                       + the IntegratingSumCallback wiring :809-851
+//   quad_adj_lane / quad_gk_lane   src/quadrature_adjoint.jl:35-46, 486-502, 510-616
+//
+// Because the loss times sit on the step grid and both passes use the same fixed dt, every reverse RK4 stage
+// lands on a forward knot (theta = 0 or 1) or on a midpoint (theta = 1/2), where the cubic-Hermite dense output
+//   u(th) = (1-th) u0 + th u1 + th (th-1) [ (1-2th)(u1-u0) + (th-1) h f0 + th h f1 ]
+// collapses to  1/2 (u0 + u1) + h/8 (f0 - f1)   (SURVEY.md Appendix A.8).
+//
+// TIME SEGMENTATION (the MI355X-first part): for Interpolating/Gauss the reverse ODE is LINEAR in
+// (lambda, mu) once y(t) is known, so a time segment [k_lo, k_hi) acts on its incoming state as an affine map
+//   lambda_out = A lambda_in + c_l ,   mu_out = mu_in + B lambda_in + c_m .
+// A lane can therefore integrate a segment WITHOUT knowing its incoming state by carrying n basis columns
+// (A, B) next to the affine column (c, which absorbs the loss jumps); a short second kernel composes the
+// segments.  This multiplies the number of independent lanes by the segment count — the only way to fill
+// 1024 SIMDs from a 10^4-trajectory ensemble whose time loop is inherently serial.
+#pragma once
+
+#include "hipadj_models.hpp"
+
+namespace hipadj {
+
+struct alignas(16) dbl2 { double x, y; };
+
+// geometry shared by all kernels of one handle
+struct Geom {
+    long N;        // trajectories
+    long Npad;     // padded to a multiple of 64 (one wavefront)
+    int S;         // RK4 steps
+    int M;         // loss times
+    double t0, dt;
+    double loss_shift;
+    int loss_kind;     // 0 cotangent, 1 lsq_shift
+    int no_start;
+    int p_shared;
+};
+
+template <class Mo> struct Knot { double u[Mo::N]; double f[Mo::N]; };
+
+// knot k of trajectory i: 2N doubles packed as N pairs
+template <class Mo>
+HIPADJ_HD void load_knot(const dbl2* __restrict__ K, long Npad, int k, long i, Knot<Mo>& kn) {
+    constexpr int N = Mo::N;
+    double v[2 * N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const dbl2 d = K[((long)k * N + j) * Npad + i];
+        v[2 * j] = d.x; v[2 * j + 1] = d.y;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) { kn.u[j] = v[j]; kn.f[j] = v[N + j]; }
+}
+template <class Mo>
+HIPADJ_HD void store_knot(dbl2* __restrict__ K, long Npad, int k, long i, const double (&u)[Mo::N], const double (&f)[Mo::N]) {
+    constexpr int N = Mo::N;
+    double v[2 * N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { v[j] = u[j]; v[N + j] = f[j]; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) { dbl2 d; d.x = v[2 * j]; d.y = v[2 * j + 1]; K[((long)k * N + j) * Npad + i] = d; }
+}
+
+template <class Mo>
+HIPADJ_HD void load_p(const double* __restrict__ p, const Geom& g, long i, double (&pv)[Mo::NP]) {
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * Mo::NP + j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward RK4: u' = f(u,p,t), classic stages at t, t+dt/2, t+dt/2, t+dt; FSAL value f(u_k) is stored with u_k.
+//   knots     [S+1][N pairs][Npad]  or nullptr (Backsolve keeps checkpoints only)
+//   ckpt      [nck][N][Npad] doubles, ckpt_of_knot[k] = checkpoint slot or -1
+//   outT      [M][n][Npad] primal output sol(ts) (SoA; transposed to the caller layout afterwards) or nullptr;
+//             save_of_knot[k] = i or -1
+//   yT        [n][Npad] final state y(T) (Backsolve's z0 = [0; 0; y(T)], src/backsolve_adjoint.jl:229-231) or nullptr
+// ------------------------------------------------------------------------------------------------
+template <class Mo>
+HIPADJ_HD void forward_lane(const Geom& g, long i, const double* __restrict__ u0, const double* __restrict__ p,
+                            dbl2* __restrict__ knots, double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
+                            double* __restrict__ outT, const int* __restrict__ save_of_knot, double* __restrict__ yT) {
+    constexpr int N = Mo::N;
+    double pv[Mo::NP]; load_p<Mo>(p, g, i, pv);
+    double u[N], k1[N], k2[N], k3[N], k4[N], us[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] = u0[i * N + j];
+    const double dt = g.dt;
+    for (int k = 0; k <= g.S; ++k) {
+        const double t = g.t0 + k * dt;
+        Mo::f(k1, u, pv, t);
+        if (knots) store_knot<Mo>(knots, g.Npad, k, i, u, k1);
+        if (ckpt) { const int c = ckpt_of_knot[k]; if (c >= 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) ckpt[((long)c * N + j) * g.Npad + i] = u[j]; } }
+        if (outT) { const int s = save_of_knot[k]; if (s >= 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) outT[((long)s * N + j) * g.Npad + i] = u[j]; } }
+        if (k == g.S) {
+            if (yT) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) yT[(long)j * g.Npad + i] = u[j]; }
+            break;
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) us[j] = u[j] + 0.5 * dt * k1[j];
+        Mo::f(k2, us, pv, t + 0.5 * dt);
+#pragma unroll
+        for (int j = 0; j < N; ++j) us[j] = u[j] + 0.5 * dt * k2[j];
+        Mo::f(k3, us, pv, t + 0.5 * dt);
+#pragma unroll
+        for (int j = 0; j < N; ++j) us[j] = u[j] + dt * k3[j];
+        Mo::f(k4, us, pv, t + dt);
+#pragma unroll
+        for (int j = 0; j < N; ++j) u[j] = u[j] + (dt / 6.0) * (k1[j] + 2.0 * (k2[j] + k3[j]) + k4[j]);
+    }
+}
+
+// loss gradient dgdu_discrete(out, u, p, t_i, i): cotangent column or u - shift
+template <class Mo>
+HIPADJ_HD void loss_grad(const Geom& g, long i, int s, const double* __restrict__ cotT, const double (&y)[Mo::N], double (&gl)[Mo::N]) {
+#pragma unroll
+    for (int j = 0; j < Mo::N; ++j)
+        gl[j] = (g.loss_kind == 0) ? cotT[((long)s * Mo::N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+}
+
+// One reverse RK4 step of NC columns z_c = (lam_c, mu_c) through the interval [t_k, t_{k+1}] (h = -dt):
+//   lam' = -(df/du)^T lam , mu' = -(df/dp)^T lam  with y from the forward Hermite interpolant.
+// WITH_MU = false skips the parameter block (Gauss / Quadrature integrate lambda only).
+template <class Mo, int NC, bool WITH_MU>
+HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&pv)[Mo::NP], double t_lo, double dt,
+                            double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    double ymid[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]);
+    const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double V1[N], V2[N], V3[N], V4[N], ls[N];
+        double W[NP], Wacc[NP];
+        Mo::vjp_u(V1, lam[c], hi.u, pv, t_hi);
+        if (WITH_MU) { Mo::vjp_p(Wacc, lam[c], hi.u, pv, t_hi); }
+#pragma unroll
+        for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V1[j];
+        Mo::vjp_u(V2, ls, ymid, pv, t_mid);
+        if (WITH_MU) { Mo::vjp_p(W, ls, ymid, pv, t_mid);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V2[j];
+        Mo::vjp_u(V3, ls, ymid, pv, t_mid);
+        if (WITH_MU) { Mo::vjp_p(W, ls, ymid, pv, t_mid);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + dt * V3[j];
+        Mo::vjp_u(V4, ls, lo.u, pv, t_lo);
+        if (WITH_MU) { Mo::vjp_p(W, ls, lo.u, pv, t_lo);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) Wacc[j] += W[j]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[c][j] = lam[c][j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+        if (WITH_MU) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[c][j] = mu[c][j] + (dt / 6.0) * Wacc[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// InterpolatingAdjoint over knots k_hi -> k_lo.  Column 0 is the affine column (starts at 0, receives the
+// loss jumps); columns 1..N are basis columns (lambda = e_j) when NC == 1 + N.
+//   top segment (k_hi == S): NC = 1, the jump at T is applied before the first step.
+// The jump at knot k_lo is applied at the end (so segment results chain without double counting).
+// PF = software prefetch distance in knots.
+// ------------------------------------------------------------------------------------------------
+template <class Mo, int NC, int PF>
+HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p,
+                           const dbl2* __restrict__ knots, const double* __restrict__ cotT,
+                           const int* __restrict__ save_of_knot, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[c][j] = (c > 0 && c - 1 == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
+    }
+    Knot<Mo> hi; load_knot<Mo>(knots, g.Npad, k_hi, i, hi);
+    if (k_hi == g.S) {  // PresetTimeCallback fires at initialisation when T is a loss time
+        const int s = save_of_knot[k_hi];
+        if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, hi.u, gl);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; }
+    }
+    Knot<Mo> ring[PF];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) { const int kk = k_hi - 1 - r; load_knot<Mo>(knots, g.Npad, kk > k_lo ? kk : k_lo, i, ring[r]); }
+    for (int kb = k_hi - 1; kb >= k_lo; kb -= PF) {
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int k = kb - r;
+            if (k >= k_lo) {
+                const Knot<Mo> lo = ring[r];
+                const int kn = k - PF;
+                load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[r]);   // prefetch PF knots ahead
+                adj_rk4_step<Mo, NC, true>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
+                const int s = save_of_knot[k];
+                if (s >= 0 && !(g.no_start && s == 0)) {
+                    double gl[N]; loss_grad<Mo>(g, i, s, cotT, lo.u, gl);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+                }
+                hi = lo;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BacksolveAdjoint, sequential in time per trajectory: z = [lam; mu; y], dy = f(y) integrated backward,
+// y overwritten by the stored forward value at every checkpoint knot, loss gradient evaluated at the
+// (possibly just overwritten) backsolved y  (src/adjoint_common.jl:765-767; callback order
+// CallbackSet(checkpoint, loss) src/backsolve_adjoint.jl:545).
+// ------------------------------------------------------------------------------------------------
+template <class Mo>
+HIPADJ_HD void backsolve_lane(const Geom& g, long i, const double* __restrict__ p, const double* __restrict__ yT,
+                              const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
+                              const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                              double (&lam)[Mo::N], double (&mu)[Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+    double y[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { lam[j] = 0.0; y[j] = yT[(long)j * g.Npad + i]; }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[j] = 0.0;
+    const double dt = g.dt;
+    { const int s = save_of_knot[g.S];
+      if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, y, gl);
+#pragma unroll
+          for (int j = 0; j < N; ++j) lam[j] += gl[j]; } }
+    for (int k = g.S - 1; k >= 0; --k) {
+        const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
+        double F1[N], F2[N], F3[N], F4[N], Y[N], ls[N];
+        double V1[N], V2[N], V3[N], V4[N], W[NP], Wacc[NP];
+        // stage 1 at t_hi
+        Mo::f(F1, y, pv, t_hi); Mo::vjp_u(V1, lam, y, pv, t_hi); Mo::vjp_p(Wacc, lam, y, pv, t_hi);
+#pragma unroll
+        for (int j = 0; j < N; ++j) { Y[j] = y[j] - (0.5 * dt) * F1[j]; ls[j] = lam[j] + (0.5 * dt) * V1[j]; }
+        Mo::f(F2, Y, pv, t_mid); Mo::vjp_u(V2, ls, Y, pv, t_mid); Mo::vjp_p(W, ls, Y, pv, t_mid);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { Y[j] = y[j] - (0.5 * dt) * F2[j]; ls[j] = lam[j] + (0.5 * dt) * V2[j]; }
+        Mo::f(F3, Y, pv, t_mid); Mo::vjp_u(V3, ls, Y, pv, t_mid); Mo::vjp_p(W, ls, Y, pv, t_mid);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { Y[j] = y[j] - dt * F3[j]; ls[j] = lam[j] + dt * V3[j]; }
+        Mo::f(F4, Y, pv, t_lo); Mo::vjp_u(V4, ls, Y, pv, t_lo); Mo::vjp_p(W, ls, Y, pv, t_lo);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) Wacc[j] += W[j];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            y[j] = y[j] - (dt / 6.0) * (F1[j] + 2.0 * (F2[j] + F3[j]) + F4[j]);
+            lam[j] = lam[j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[j] = mu[j] + (dt / 6.0) * Wacc[j];
+        if (ckpt) { const int c = ckpt_of_knot[k]; if (c >= 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = ckpt[((long)c * N + j) * g.Npad + i]; } }
+        const int s = save_of_knot[k];
+        if (s >= 0) {
+            double gl[N]; loss_grad<Mo>(g, i, s, cotT, y, gl);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[j] += gl[j];
+        }
+    }
+}
+
+// cubic Hermite at general theta on a step (u0,f0) -> (u1,f1) of signed length h
+template <int N>
+HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double (&f0)[N], const double (&u1)[N], const double (&f1)[N], double (&y)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        y[j] = (1.0 - th) * u0[j] + th * u1[j] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (u1[j] - u0[j]) + (th - 1.0) * h * f0[j] + th * h * f1[j]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GaussAdjoint: lambda-only reverse RK4; after every step a 2-point Gauss-Legendre rule (div(order+1, 2) nodes
+// for RK4) of  -(df/dp)^T lam  over the step, with lambda from the ADJOINT step's Hermite interpolant (FSAL
+// derivatives at both ends) and y from the forward interpolant  (src/gauss_adjoint.jl:745-759, 809-851).
+// Time runs backward, so the accumulated sum equals int_{t0}^{T} lam^T f_p dt.
+// ------------------------------------------------------------------------------------------------
+template <class Mo, int PF>
+HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                          const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                          double (&lamo)[Mo::N], double (&muo)[Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+    double lam[1][N], mu[1][NP];
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+    const double dt = g.dt;
+    Knot<Mo> hi; load_knot<Mo>(knots, g.Npad, g.S, i, hi);
+    { const int s = save_of_knot[g.S];
+      if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, hi.u, gl);
+#pragma unroll
+          for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; } }
+    Knot<Mo> ring[PF];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) { const int kk = g.S - 1 - r; load_knot<Mo>(knots, g.Npad, kk > 0 ? kk : 0, i, ring[r]); }
+    const double xg = 0.5773502691896257645;
+    for (int kb = g.S - 1; kb >= 0; kb -= PF) {
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int k = kb - r;
+            if (k >= 0) {
+                const Knot<Mo> lo = ring[r];
+                const int kn = k - PF;
+                load_knot<Mo>(knots, g.Npad, kn > 0 ? kn : 0, i, ring[r]);
+                const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
+                double lam_hi[N], d_hi[N], d_lo[N], V[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) lam_hi[j] = lam[0][j];
+                Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
+#pragma unroll
+                for (int j = 0; j < N; ++j) d_hi[j] = -V[j];                     // fsalfirst of the adjoint step
+                adj_rk4_step<Mo, 1, false>(hi, lo, pv, t_lo, dt, lam, mu);
+                Mo::vjp_u(V, lam[0], lo.u, pv, t_lo);
+#pragma unroll
+                for (int j = 0; j < N; ++j) d_lo[j] = -V[j];                     // fsallast
+                // Gauss nodes t_g = mid + half*x, half = (t_lo - t_hi)/2 < 0; theta along the adjoint step = (1 + x)/2
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const double x = q == 0 ? -xg : xg;
+                    const double th = 0.5 * (1.0 + x);
+                    double lg[N], yg[N], W[NP];
+                    hermite<N>(th, -dt, lam_hi, d_hi, lam[0], d_lo, lg);
+                    hermite<N>(1.0 - th, dt, lo.u, lo.f, hi.u, hi.f, yg);
+                    Mo::vjp_p(W, lg, yg, pv, t_hi - th * dt);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) mu[0][j] += (0.5 * dt) * W[j];
+                }
+                const int s = save_of_knot[k];
+                if (s >= 0 && !(g.no_start && s == 0)) {
+                    double gl[N]; loss_grad<Mo>(g, i, s, cotT, lo.u, gl);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+                }
+                hi = lo;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) muo[j] = mu[0][j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// QuadratureAdjoint pass 1: lambda-only reverse RK4 "saved densely": per step k (from knot k+1 to k) the record
+//   adj[k] = ( lam_start (post-jump at k+1), dlam_start, lam_end (pre-jump at k), dlam_end )   4N doubles
+// laid out [step][2N pairs][Npad]  (src/quadrature_adjoint.jl:527-530 save_everystep = true).
+// ------------------------------------------------------------------------------------------------
+template <class Mo, int PF>
+HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                             const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                             dbl2* __restrict__ adj, double (&lamo)[Mo::N]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+    double lam[1][N], mu[1][NP];
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+    const double dt = g.dt;
+    Knot<Mo> hi; load_knot<Mo>(knots, g.Npad, g.S, i, hi);
+    { const int s = save_of_knot[g.S];
+      if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, hi.u, gl);
+#pragma unroll
+          for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; } }
+    Knot<Mo> ring[PF];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) { const int kk = g.S - 1 - r; load_knot<Mo>(knots, g.Npad, kk > 0 ? kk : 0, i, ring[r]); }
+    for (int kb = g.S - 1; kb >= 0; kb -= PF) {
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int k = kb - r;
+            if (k >= 0) {
+                const Knot<Mo> lo = ring[r];
+                const int kn = k - PF;
+                load_knot<Mo>(knots, g.Npad, kn > 0 ? kn : 0, i, ring[r]);
+                const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
+                double rec[4 * N], V[N];
+                Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
+#pragma unroll
+                for (int j = 0; j < N; ++j) { rec[j] = lam[0][j]; rec[N + j] = -V[j]; }
+                adj_rk4_step<Mo, 1, false>(hi, lo, pv, t_lo, dt, lam, mu);
+                Mo::vjp_u(V, lam[0], lo.u, pv, t_lo);
+#pragma unroll
+                for (int j = 0; j < N; ++j) { rec[2 * N + j] = lam[0][j]; rec[3 * N + j] = -V[j]; }
+#pragma unroll
+                for (int j = 0; j < 2 * N; ++j) { dbl2 d; d.x = rec[2 * j]; d.y = rec[2 * j + 1]; adj[((long)k * 2 * N + j) * g.Npad + i] = d; }
+                const int s = save_of_knot[k];
+                if (s >= 0 && !(g.no_start && s == 0)) {
+                    double gl[N]; loss_grad<Mo>(g, i, s, cotT, lo.u, gl);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+                }
+                hi = lo;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
+}
+
+// Gauss-Kronrod (7,15) constants (QUADPACK qk15 / QuadGK order 7)
+struct GK15 {
+    static constexpr double X[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
+                                    0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
+                                    0.586087235467691130294144838258730, 0.405845151377397166906606412076961,
+                                    0.207784955007898467600689403773245, 0.0};
+    static constexpr double WK[8] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
+                                     0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
+                                     0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
+                                     0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
+    static constexpr double WG[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
+                                     0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
+};
+
+// AdjointSensitivityIntegrand (src/quadrature_adjoint.jl:486-502): y = sol(t), lam = adj_sol(t), out = f_p^T lam
+template <class Mo>
+HIPADJ_HD void quad_integrand(const Geom& g, long i, const double (&pv)[Mo::NP], const dbl2* __restrict__ knots,
+                              const dbl2* __restrict__ adj, double t, double (&out)[Mo::NP]) {
+    constexpr int N = Mo::N;
+    int k = (int)((t - g.t0) / g.dt);
+    if (k < 0) k = 0;
+    if (k > g.S - 1) k = g.S - 1;
+    // guard against the floor landing one step off because of roundoff in (t - t0)/dt
+    if (t < g.t0 + k * g.dt && k > 0) --k;
+    if (t > g.t0 + (k + 1) * g.dt && k < g.S - 1) ++k;
+    Knot<Mo> lo, hi;
+    load_knot<Mo>(knots, g.Npad, k, i, lo); load_knot<Mo>(knots, g.Npad, k + 1, i, hi);
+    double rec[4 * N];
+#pragma unroll
+    for (int j = 0; j < 2 * N; ++j) { const dbl2 d = adj[((long)k * 2 * N + j) * g.Npad + i]; rec[2 * j] = d.x; rec[2 * j + 1] = d.y; }
+    const double t_lo = g.t0 + k * g.dt;
+    const double thf = (t - t_lo) / g.dt;          // forward theta in [0,1]
+    double y[N], lam[N], l0[N], d0[N], l1[N], d1[N];
+    hermite<N>(thf, g.dt, lo.u, lo.f, hi.u, hi.f, y);
+#pragma unroll
+    for (int j = 0; j < N; ++j) { l0[j] = rec[j]; d0[j] = rec[N + j]; l1[j] = rec[2 * N + j]; d1[j] = rec[3 * N + j]; }
+    hermite<N>(1.0 - thf, -g.dt, l0, d0, l1, d1, lam);   // adjoint step runs t_hi -> t_lo
+    Mo::vjp_p(out, lam, y, pv, t);
+}
+
+template <class Mo>
+HIPADJ_HD double gk15_eval(const Geom& g, long i, const double (&pv)[Mo::NP], const dbl2* __restrict__ knots,
+                           const dbl2* __restrict__ adj, double a, double b, double (&I)[Mo::NP]) {
+    constexpr int NP = Mo::NP;
+    const double c = 0.5 * (a + b), h = 0.5 * (b - a);
+    double Ig[NP], f1[NP], f2[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { I[j] = 0.0; Ig[j] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        quad_integrand<Mo>(g, i, pv, knots, adj, c - h * GK15::X[q], f1);
+        quad_integrand<Mo>(g, i, pv, knots, adj, c + h * GK15::X[q], f2);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { const double s = f1[j] + f2[j]; I[j] += GK15::WK[q] * s; if (q & 1) Ig[j] += GK15::WG[q / 2] * s; }
+    }
+    quad_integrand<Mo>(g, i, pv, knots, adj, c, f1);
+    double e = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        I[j] += GK15::WK[7] * f1[j]; Ig[j] += GK15::WG[3] * f1[j];
+        I[j] *= h; Ig[j] *= h;
+        const double d = I[j] - Ig[j]; e += d * d;
+    }
+    return sqrt(e);
+}
+
+// QuadratureAdjoint pass 2: one lane = one (trajectory, loss interval): quadgk(integrand, t[i], t[i+1]; atol, rtol)
+// — adaptive bisection of the worst segment until E <= max(atol, rtol*|I|)  (src/quadrature_adjoint.jl:580-591).
+// MAXSEG bounds the per-lane segment list (QuadGK itself is bounded by maxevals).
+template <class Mo, int MAXSEG>
+HIPADJ_HD void quad_gk_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                            const dbl2* __restrict__ adj, double a, double b, double atol, double rtol,
+                            double (&res)[Mo::NP]) {
+    constexpr int NP = Mo::NP;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+    double sa[MAXSEG], sb[MAXSEG], sE[MAXSEG], sI[MAXSEG][NP];
+    double I[NP];
+    int ns = 1;
+    sa[0] = a; sb[0] = b;
+    { double I0[NP]; sE[0] = gk15_eval<Mo>(g, i, pv, knots, adj, a, b, I0);
+      for (int j = 0; j < NP; ++j) { sI[0][j] = I0[j]; I[j] = I0[j]; } }
+    double E = sE[0];
+    for (;;) {
+        double nrm = 0.0;
+        for (int j = 0; j < NP; ++j) nrm += I[j] * I[j];
+        nrm = sqrt(nrm);
+        const double tol = atol > rtol * nrm ? atol : rtol * nrm;
+        if (E <= tol || ns + 1 > MAXSEG) break;
+        int w = 0;
+        for (int s = 1; s < ns; ++s) if (sE[s] > sE[w]) w = s;
+        const double wa = sa[w], wb = sb[w], mid = 0.5 * (wa + wb);
+        if (!(mid > (wa < wb ? wa : wb) && mid < (wa < wb ? wb : wa))) break;
+        double I1[NP], I2[NP];
+        const double E1 = gk15_eval<Mo>(g, i, pv, knots, adj, wa, mid, I1);
+        const double E2 = gk15_eval<Mo>(g, i, pv, knots, adj, mid, wb, I2);
+        for (int j = 0; j < NP; ++j) { I[j] += I1[j] + I2[j] - sI[w][j]; sI[w][j] = I1[j]; sI[ns][j] = I2[j]; }
+        E += E1 + E2 - sE[w];
+        sa[w] = wa; sb[w] = mid; sE[w] = E1;
+        sa[ns] = mid; sb[ns] = wb; sE[ns] = E2;
+        ++ns;
+    }
+    for (int j = 0; j < NP; ++j) { double s = 0.0; for (int q = 0; q < ns; ++q) s += sI[q][j]; res[j] = s; }
+}
+
+}  // namespace hipadj

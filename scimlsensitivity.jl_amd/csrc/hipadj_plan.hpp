@@ -1,0 +1,127 @@
+// hipadj_plan.hpp — host-side planning shared by the C-ABI library and the test-only lane emulator:
+// validates a hipadj_config and derives the step grid, the knot -> loss-time / checkpoint maps, the time
+// segmentation and the quadrature interval list.  Pure C++ (no HIP).
+//
+// Reference behaviour restated here:
+//   loss times become tstops of the reverse solve via PresetTimeCallback      src/adjoint_common.jl:848-855
+//   default Backsolve checkpoints = sol.t of the saveat solve                 src/backsolve_adjoint.jl:132
+//   QuadratureAdjoint interval order (end correction, t[i]..t[i+1] descending, start correction)
+//                                                                             src/quadrature_adjoint.jl:563-616
+#pragma once
+#include <cmath>
+#include <string>
+#include <vector>
+#include "../../include/hipadj.h"
+
+namespace hipadj {
+
+struct Plan {
+    int n = 0, np = 0;
+    long N = 0, Npad = 0;
+    int S = 0, M = 0, nck = 0, nseg = 1, nq = 0;
+    std::vector<double> save_times;
+    std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
+    std::vector<double> qa, qb;
+    bool bs_ckpt = false;
+};
+
+inline bool plan_small_model(int m) { return m >= HIPADJ_MODEL_LV && m <= HIPADJ_MODEL_FALLMASS; }
+
+inline int plan_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, int32_t* np) {
+    switch (model) {
+    case HIPADJ_MODEL_LV: case HIPADJ_MODEL_LVT: *n = 2; *np = 4; return HIPADJ_OK;
+    case HIPADJ_MODEL_LORENZ: *n = 3; *np = 3; return HIPADJ_OK;
+    case HIPADJ_MODEL_LINDIAG: case HIPADJ_MODEL_FALLMASS: *n = 2; *np = 2; return HIPADJ_OK;
+    case HIPADJ_MODEL_MLP:
+        if (!dims || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0) return HIPADJ_ERR_INVALID_ARG;
+        *n = dims[0] * dims[2]; *np = dims[1] * dims[0] + dims[1] + dims[1] * dims[1] + dims[1] + dims[0] * dims[1] + dims[0];
+        return HIPADJ_OK;
+    case HIPADJ_MODEL_BRUSS:
+        if (!dims || dims[0] <= 1) return HIPADJ_ERR_INVALID_ARG;
+        *n = 2 * dims[0] * dims[0]; *np = 3; return HIPADJ_OK;
+    default: return HIPADJ_ERR_INVALID_ARG;
+    }
+}
+
+// Number of time segments per trajectory for the linear (Interpolating) reverse pass: enough
+// (trajectory-wave x segment) workgroups to put ~2 waves on each of the 1024 SIMDs of an MI355X, each segment
+// keeping >= 16 steps.  A non-top segment carries 1 + n columns, so segmentation only pays once the added
+// parallelism exceeds that factor.
+inline int plan_auto_segments(long N, int S, int n) {
+    const long waves = (N + 63) / 64;
+    long target = (long)std::ceil(2048.0 / (double)waves);
+    long maxseg = S / 16; if (maxseg < 1) maxseg = 1;
+    if (target > maxseg) target = maxseg;
+    if ((double)target < 1.0 + n) return 1;
+    return (int)target;
+}
+
+inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
+    if (!cfg) { err = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->struct_size != sizeof(hipadj_config)) { err = "hipadj_config.struct_size mismatch (ABI)"; return HIPADJ_ERR_INVALID_ARG; }
+    int32_t n, np;
+    if (plan_model_sizes(cfg->model, cfg->dims, &n, &np) != HIPADJ_OK) { err = "unknown model id or bad dims"; return HIPADJ_ERR_INVALID_ARG; }
+    if (!plan_small_model(cfg->model)) { err = "model not yet available in the gfx950 kernel family (MLP / BRUSS: wave-per-trajectory family pending)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_QUADRATURE) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED) { err = "only fixed-step RK4 runs on the device (adaptive Tsit5 is CPU plumbing in BASELINE config 1)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->ntraj <= 0) { err = "ntraj must be positive"; return HIPADJ_ERR_INVALID_ARG; }
+    if (!(cfg->dt > 0) || !(cfg->t1 > cfg->t0)) { err = "need dt > 0 and t1 > t0"; return HIPADJ_ERR_INVALID_ARG; }
+    const double sreal = (cfg->t1 - cfg->t0) / cfg->dt; const long S = std::lround(sreal);
+    if (S < 1 || std::fabs(sreal - (double)S) > 1e-6 * (double)S || S > 100000000L) { err = "(t1 - t0)/dt must be a positive integer number of steps"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->nsave < 0 || (cfg->nsave > 0 && !cfg->save_times)) { err = "save_times missing"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->time_segments < 0) { err = "time_segments must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->ckpt_stride < 0) { err = "ckpt_stride must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
+    P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = (int)S; P.M = cfg->nsave;
+    P.save_of_knot.assign(S + 1, -1); P.ckpt_of_knot.assign(S + 1, -1);
+    P.save_times.assign(cfg->save_times, cfg->save_times + cfg->nsave);
+    for (int i = 0; i < cfg->nsave; ++i) {
+        const double kr = (cfg->save_times[i] - cfg->t0) / cfg->dt; const long k = std::lround(kr);
+        if (k < 0 || k > S || std::fabs(kr - (double)k) > 1e-6) { err = "save_times must lie on the step grid t0 + k*dt within [t0, t1]"; return HIPADJ_ERR_INVALID_ARG; }
+        if (i > 0 && !(cfg->save_times[i] > cfg->save_times[i - 1])) { err = "save_times must be strictly ascending (duplicate event times are out of scope)"; return HIPADJ_ERR_INVALID_ARG; }
+        P.save_of_knot[k] = i;
+    }
+    // checkpoints: BacksolveAdjoint only.  Interpolating/Gauss checkpointing re-solves, on this fixed grid,
+    // bit-identical knots from the stored values; the dense tiles are kept instead.
+    P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
+    P.nck = 0;
+    if (P.bs_ckpt) {
+        int c = 0;
+        if (cfg->ckpt_stride > 0) { for (long k = 0; k <= S; k += cfg->ckpt_stride) P.ckpt_of_knot[k] = c++; if (P.ckpt_of_knot[S] < 0) P.ckpt_of_knot[S] = c++; }
+        else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }
+        P.nck = c;
+    }
+    P.nseg = 1;
+    if (cfg->alg == HIPADJ_ALG_INTERPOLATING) {
+        P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n) : cfg->time_segments;
+        if (P.nseg > P.S) P.nseg = P.S;
+        if (P.nseg < 1) P.nseg = 1;
+    }
+    // the top segment carries 1 column, the others 1 + n: give the top segment a proportionally longer span
+    {
+        const int C = P.nseg; P.seg_bounds.assign(C + 1, 0);
+        if (C == 1) { P.seg_bounds[1] = (int)S; }
+        else {
+            const double w_top = 1.0 + 0.6 * n;
+            const double unit = (double)S / ((C - 1) + w_top);
+            double acc = 0.0;
+            for (int s = 1; s < C; ++s) { acc += unit; int b = (int)std::lround(acc); if (b <= P.seg_bounds[s - 1]) b = P.seg_bounds[s - 1] + 1; P.seg_bounds[s] = b; }
+            P.seg_bounds[C] = (int)S;
+            for (int s = C - 1; s >= 1; --s) if (P.seg_bounds[s] >= P.seg_bounds[s + 1]) P.seg_bounds[s] = P.seg_bounds[s + 1] - 1;
+        }
+    }
+    P.qa.clear(); P.qb.clear();
+    if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
+        const auto& t = P.save_times;
+        if (t.empty()) { P.qa.push_back(cfg->t0); P.qb.push_back(cfg->t1); }
+        else {
+            if (P.save_of_knot[S] < 0) { P.qa.push_back(t.back()); P.qb.push_back(cfg->t1); }
+            for (int i = (int)t.size() - 2; i >= 0; --i) { P.qa.push_back(t[i]); P.qb.push_back(t[i + 1]); }
+            if (P.save_of_knot[0] < 0) { P.qa.push_back(cfg->t0); P.qb.push_back(t.front()); }
+        }
+    }
+    P.nq = (int)P.qa.size();
+    return HIPADJ_OK;
+}
+
+}  // namespace hipadj

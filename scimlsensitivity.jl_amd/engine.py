@@ -1,0 +1,111 @@
+"""Engine: owner of one hipadj handle (include/hipadj.h).  Host (numpy) and device (torch) entry points.
+torch is used for device memory and streams only."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import HipadjConfig, HipadjStats, HipadjError
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Engine:
+    def __init__(self, model, alg, ntraj, t0, t1, dt, save_times=(), loss_kind=_lib.LOSS_COTANGENT, loss_shift=0.0,
+                 checkpointing=False, ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False,
+                 p_shared=True, device=0, time_segments=0, dims=(0, 0, 0, 0)):
+        L = _lib.load()
+        self._L = L
+        self._save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
+        c = HipadjConfig()
+        c.struct_size = C.sizeof(HipadjConfig)
+        c.model, c.alg, c.stepper = _lib.MODEL[model], _lib.ALG[alg], 0
+        for i in range(4):
+            c.dims[i] = int(dims[i])
+        c.ntraj = int(ntraj)
+        c.t0, c.t1, c.dt = float(t0), float(t1), float(dt)
+        c.nsave = len(self._save)
+        c.save_times = _dptr(self._save) if len(self._save) else None
+        c.loss_kind, c.loss_shift = int(loss_kind), float(loss_shift)
+        c.checkpointing, c.ckpt_stride = int(bool(checkpointing)), int(ckpt_stride)
+        c.quad_abstol, c.quad_reltol = float(quad_abstol), float(quad_reltol)
+        c.no_start, c.p_shared, c.device, c.time_segments = int(bool(no_start)), int(bool(p_shared)), int(device), int(time_segments)
+        self.cfg = c
+        self.model, self.alg = model, alg
+        self.N, self.M = int(ntraj), len(self._save)
+        self.p_shared = bool(p_shared)
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = L.hipadj_create(C.byref(c), C.byref(h))
+        if rc != _lib.OK:
+            raise HipadjError(rc, L.hipadj_last_error(None).decode())
+        self._h = h
+        st = self.stats()
+        self.n, self.np = st["n"], st["np"]
+
+    # ---- lifetime -------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hipadj_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            raise HipadjError(rc, self._L.hipadj_last_error(self._h).decode())
+
+    # ---- host-pointer API -----------------------------------------------------------------------------
+    def forward(self, u0, p, want_out=True):
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        if u0.shape != (self.N, self.n):
+            raise ValueError(f"u0 must be [{self.N}][{self.n}], got {u0.shape}")
+        if p.shape != ((self.np,) if self.p_shared else (self.N, self.np)):
+            raise ValueError(f"p has shape {p.shape}")
+        out = np.empty((self.N, self.M, self.n)) if (want_out and self.M) else None
+        self._check(self._L.hipadj_forward(self._h, _dptr(u0), _dptr(p), _dptr(out) if out is not None else None))
+        return out
+
+    def adjoint(self, dLdu=None):
+        if dLdu is not None:
+            dLdu = np.ascontiguousarray(dLdu, dtype=np.float64)
+            if dLdu.shape != (self.N, self.M, self.n):
+                raise ValueError(f"dLdu must be [{self.N}][{self.M}][{self.n}], got {dLdu.shape}")
+        du0 = np.empty((self.N, self.n))
+        dp = np.empty(self.np if self.p_shared else (self.N, self.np))
+        self._check(self._L.hipadj_adjoint(self._h, _dptr(dLdu) if dLdu is not None else None, _dptr(du0), _dptr(dp)))
+        return du0, dp
+
+    # ---- device-pointer API (torch tensors on cuda:<device>) -------------------------------------------
+    def use_torch_stream(self):
+        import torch
+        self._check(self._L.hipadj_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def forward_dev(self, u0, p, out=None):
+        self._check(self._L.hipadj_forward_dev(self._h, C.c_void_p(u0.data_ptr()), C.c_void_p(p.data_ptr()),
+                                               C.c_void_p(out.data_ptr()) if out is not None else None))
+
+    def adjoint_dev(self, dLdu, du0, dp):
+        self._check(self._L.hipadj_adjoint_dev(self._h, C.c_void_p(dLdu.data_ptr()) if dLdu is not None else None,
+                                               C.c_void_p(du0.data_ptr()), C.c_void_p(dp.data_ptr())))
+
+    def synchronize(self):
+        self._check(self._L.hipadj_synchronize(self._h))
+
+    def stats(self):
+        st = HipadjStats()
+        st.struct_size = C.sizeof(HipadjStats)
+        self._check(self._L.hipadj_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in HipadjStats._fields_}

@@ -1,0 +1,135 @@
+"""Host-side mirror of the reference's entry points for the adjoint hot path.
+
+    solve(ensprob, RK4(); dt, saveat, sensealg, ...)             forward solve that keeps what the reverse pass needs
+                                                                 (src/concrete_solve.jl:689-707)
+    adjoint_sensitivities(sol, alg; t, dgdu_discrete, sensealg)  -> (du0, dp)   (src/sensitivity_interface.jl:373-526)
+    concrete_solve_adjoint(prob, alg, sensealg, u0, p; ...)      -> (out, pullback)  (src/concrete_solve.jl:523-1042)
+    EnsembleAdjoint (torch.autograd.Function)                    outer AD = torch autograd in the role Zygote plays
+                                                                 for the reference
+
+Everything numeric happens behind the C ABI (include/hipadj.h) on the GPU.
+"""
+import numpy as np
+
+from . import _lib
+from .engine import Engine
+from .problems import RK4, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift
+from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
+                                     QuadratureAdjoint, GaussAdjoint, ischeckpointing)
+
+
+def _save_times(tspan, saveat, dt):
+    if saveat is None:
+        return np.zeros(0)
+    if np.isscalar(saveat):
+        m = int(round((tspan[1] - tspan[0]) / saveat))
+        return tspan[0] + saveat * np.arange(m + 1)
+    return np.ascontiguousarray(np.asarray(saveat, dtype=np.float64))
+
+
+def _engine_kwargs(sensealg, checkpoints, dt, t0):
+    kw = {}
+    if isinstance(sensealg, BacksolveAdjoint):
+        kw["checkpointing"] = sensealg.checkpointing
+        if checkpoints is not None and sensealg.checkpointing:
+            ck = np.asarray(checkpoints, dtype=np.float64)
+            ks = np.rint((ck - t0) / dt).astype(np.int64)
+            stride = int(ks[1] - ks[0]) if len(ks) > 1 else 0
+            if len(ks) > 2 and not np.all(np.diff(ks) == stride):
+                raise ValueError("checkpoints must be equally spaced on the step grid (ckpt_stride)")
+            kw["ckpt_stride"] = stride
+    elif isinstance(sensealg, (InterpolatingAdjoint, GaussAdjoint)):
+        kw["checkpointing"] = sensealg.checkpointing
+    elif isinstance(sensealg, QuadratureAdjoint):
+        kw["quad_abstol"], kw["quad_reltol"] = sensealg.abstol, sensealg.reltol
+    return kw
+
+
+def solve(ensprob, alg=RK4(), *, dt, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
+          device=0, time_segments=0, no_start=False, want_out=True):
+    """Forward solve of an EnsembleProblem on the device.  The returned solution owns the device-resident
+    interpolant tiles (Interpolating/Gauss/Quadrature) or checkpoints (Backsolve) the reverse pass consumes.
+    `dgdu_discrete` may be given here already (LsqShift or None = cotangents) because the fused reverse kernel
+    is specialised on it at handle creation."""
+    if not isinstance(alg, RK4):
+        raise ValueError("only fixed-step RK4() runs on the device (adaptive Tsit5 is CPU plumbing, BASELINE config 1)")
+    if not isinstance(sensealg, AbstractAdjointSensitivityAlgorithm):
+        raise TypeError("sensealg must be one of InterpolatingAdjoint/BacksolveAdjoint/GaussAdjoint/QuadratureAdjoint")
+    if isinstance(ensprob, ODEProblem):
+        ensprob = EnsembleProblem(ensprob, ensprob.u0[None, :])
+    prob = ensprob.prob
+    ts = _save_times(prob.tspan, saveat, dt)
+    loss_kind, shift = (_lib.LOSS_LSQ_SHIFT, dgdu_discrete.shift) if isinstance(dgdu_discrete, LsqShift) else (_lib.LOSS_COTANGENT, 0.0)
+    eng = Engine(prob.f, sensealg.name, ensprob.u0.shape[0], prob.tspan[0], prob.tspan[1], dt, save_times=ts,
+                 loss_kind=loss_kind, loss_shift=shift, p_shared=(ensprob.p.ndim == 1), device=device,
+                 time_segments=time_segments, no_start=no_start, dims=prob.dims,
+                 **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0]))
+    out = eng.forward(ensprob.u0, ensprob.p, want_out=want_out)
+    return EnsembleSolution(engine=eng, u=out, t=ts, prob=ensprob, alg=alg, dt=dt,
+                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete))
+
+
+def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, sensealg=None, checkpoints=None, **kwargs):
+    """(du0, dp) for the loss  sum_i l_i(u(t_i))  with dl_i/du = dgdu_discrete at the times `t`
+    (src/sensitivity_interface.jl:373-526).  `dgdu_discrete`: LsqShift(c) or an array [N][M][n] of cotangents
+    (the AD path hands `Delta[:, i]`, src/concrete_solve.jl:842-851).  Returns du0 [N][n] and dp: [np] row
+    (sum over the ensemble when p is shared) or [N][np]."""
+    if kwargs:
+        raise TypeError(f"unsupported keyword(s) {sorted(kwargs)} (continuous costs g/dgdp, callbacks: SURVEY.md §8f)")
+    eng = sol.engine
+    want_alg = (sensealg or sol.extra["sensealg"])
+    if want_alg.name != eng.alg:
+        raise ValueError(f"solution was prepared for sensealg={eng.alg!r}; re-run solve(...; sensealg={want_alg!r})")
+    if t is not None and not (len(t) == len(sol.t) and np.allclose(np.asarray(t, dtype=np.float64), sol.t, rtol=0, atol=1e-12)):
+        raise ValueError("t must equal the save times the forward solve was run with")
+    if isinstance(dgdu_discrete, LsqShift):
+        if eng.cfg.loss_kind != _lib.LOSS_LSQ_SHIFT or eng.cfg.loss_shift != dgdu_discrete.shift:
+            raise ValueError("pass dgdu_discrete=LsqShift(...) to solve(...) as well: the reverse kernel is specialised on it")
+        return eng.adjoint(None)
+    if dgdu_discrete is None:
+        if eng.cfg.loss_kind == _lib.LOSS_LSQ_SHIFT:
+            return eng.adjoint(None)
+        raise ValueError("dgdu_discrete required")
+    if eng.cfg.loss_kind != _lib.LOSS_COTANGENT:
+        raise ValueError("solution was prepared with a fused LsqShift loss; cotangents need dgdu_discrete=None at solve time")
+    return eng.adjoint(np.asarray(dgdu_discrete, dtype=np.float64))
+
+
+def concrete_solve_adjoint(prob, alg, sensealg, u0, p, *, dt, saveat, **kw):
+    """(out, pullback) — the contract of SciMLBase._concrete_solve_adjoint (src/concrete_solve.jl:523-1042):
+    `out` = sol(ts) [N][M][n]; pullback(Delta) -> (du0, dp) runs the reverse pass with Delta as dgdu_discrete."""
+    ens = EnsembleProblem(ODEProblem(prob.f, prob.u0, prob.tspan, np.asarray(p if np.ndim(p) == 1 else prob.p), prob.dims),
+                          np.atleast_2d(u0), np.asarray(p))
+    sol = solve(ens, alg, dt=dt, saveat=saveat, sensealg=sensealg, **kw)
+
+    def pullback(delta):
+        return adjoint_sensitivities(sol, alg, dgdu_discrete=np.asarray(delta, dtype=np.float64).reshape(sol.u.shape))
+    return sol.u, pullback
+
+
+def make_autograd_function():
+    """torch.autograd.Function running forward and reverse passes on device tensors through the C ABI
+    (hipadj_forward_dev / hipadj_adjoint_dev on torch's current stream)."""
+    import torch
+
+    class EnsembleAdjoint(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, u0, p, engine):
+            if not (u0.is_cuda and p.is_cuda and u0.dtype == torch.float64 and p.dtype == torch.float64):
+                raise ValueError("u0 and p must be float64 tensors on the engine's GPU")
+            engine.use_torch_stream()
+            out = torch.empty((engine.N, engine.M, engine.n), dtype=torch.float64, device=u0.device)
+            engine.forward_dev(u0.contiguous(), p.contiguous(), out)
+            ctx.engine = engine
+            return out
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            eng = ctx.engine
+            eng.use_torch_stream()
+            du0 = torch.empty((eng.N, eng.n), dtype=torch.float64, device=grad_out.device)
+            dp = torch.empty((eng.np,) if eng.p_shared else (eng.N, eng.np), dtype=torch.float64, device=grad_out.device)
+            eng.adjoint_dev(grad_out.contiguous(), du0, dp)
+            return du0, dp, None
+
+    return EnsembleAdjoint

@@ -1,0 +1,64 @@
+"""Problem / solver / loss descriptors of the host API (names follow SciMLBase / OrdinaryDiffEq)."""
+from dataclasses import dataclass, field
+import numpy as np
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class RK4:
+    """Fixed-step classic Runge-Kutta 4 (the `alg` handed to solve / adjoint_sensitivities)."""
+
+
+@dataclass
+class ODEProblem:
+    """ODEProblem(f, u0, tspan, p) with `f` a name from the device model registry (include/hipadj.h)."""
+    f: str
+    u0: np.ndarray
+    tspan: tuple
+    p: np.ndarray
+    dims: tuple = (0, 0, 0, 0)
+
+    def __post_init__(self):
+        if self.f not in _lib.MODEL:
+            raise ValueError(f"unknown model {self.f!r}; registered: {sorted(_lib.MODEL)}")
+        self.u0 = np.ascontiguousarray(self.u0, dtype=np.float64)
+        self.p = np.ascontiguousarray(self.p, dtype=np.float64)
+        self.tspan = (float(self.tspan[0]), float(self.tspan[1]))
+
+
+@dataclass
+class EnsembleProblem:
+    """EnsembleProblem(prob; prob_func): N independent trajectories that differ in u0 (and optionally p)
+    (test/Core4/ensembles.jl:13-31).  u0: [N][n]; p: [np] shared or [N][np]."""
+    prob: ODEProblem
+    u0: np.ndarray
+    p: np.ndarray = None
+
+    def __post_init__(self):
+        self.u0 = np.ascontiguousarray(self.u0, dtype=np.float64)
+        if self.u0.ndim != 2:
+            raise ValueError("EnsembleProblem u0 must be [N][n]")
+        self.p = self.prob.p if self.p is None else np.ascontiguousarray(self.p, dtype=np.float64)
+
+
+@dataclass(frozen=True)
+class LsqShift:
+    """dgdu_discrete(out, u, p, t, i) = u - shift  (test/Core3/adjoint.jl:49-51: `out .= -2.0 .+ u`),
+    evaluated inside the reverse kernel."""
+    shift: float = 0.0
+
+
+@dataclass
+class EnsembleSolution:
+    """What the reverse pass needs from the forward solve: the handle owning the device-resident interpolant
+    tiles / checkpoints, plus the primal output at the save times."""
+    engine: object
+    u: np.ndarray                # [N][M][n] = sol(ts)
+    t: np.ndarray                # [M]
+    prob: object
+    alg: object
+    dt: float
+    dense: bool = True
+    retcode: str = "Success"
+    extra: dict = field(default_factory=dict)

@@ -1,0 +1,69 @@
+"""ctypes binding of tests/emu/liblane_emu.so — TEST-ONLY host emulation of the device lane bodies
+(see tests/emu/lane_emu.cpp).  Never imported by the product package."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+sys.path.insert(0, _ROOT)
+_SRC = os.path.join(_HERE, "emu", "lane_emu.cpp")
+_LIB = os.path.join(_HERE, "emu", "liblane_emu.so")
+_CSRC = os.path.join(_ROOT, "scimlsensitivity.jl_amd", "csrc")
+
+
+def build(force=False):
+    deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("hipadj_lane.hpp", "hipadj_models.hpp", "hipadj_plan.hpp")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _LIB, _SRC])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.emu_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shift=0.0, checkpointing=False,
+                ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, p_shared=True, time_segments=1):
+    from scimlsensitivity_jl_amd import _lib as PL
+    save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
+    c = PL.HipadjConfig()
+    c.struct_size = C.sizeof(PL.HipadjConfig)
+    c.model, c.alg, c.stepper = PL.MODEL[model], PL.ALG[alg], 0
+    c.ntraj = ntraj
+    c.t0, c.t1, c.dt = t0, t1, dt
+    c.nsave = len(save)
+    c.save_times = save.ctypes.data_as(C.POINTER(C.c_double)) if len(save) else None
+    c.loss_kind, c.loss_shift = loss_kind, loss_shift
+    c.checkpointing, c.ckpt_stride = int(checkpointing), ckpt_stride
+    c.quad_abstol, c.quad_reltol = quad_abstol, quad_reltol
+    c.no_start, c.p_shared, c.device, c.time_segments = int(no_start), int(p_shared), 0, time_segments
+    c._keep = save
+    return c
+
+
+def forward_adjoint(cfg, n, npar, u0, p, dLdu=None):
+    u0 = np.ascontiguousarray(u0, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    N, M = u0.shape[0], cfg.nsave
+    du0 = np.zeros((N, n))
+    dp = np.zeros(npar if cfg.p_shared else (N, npar))
+    out = np.zeros((N, M, n))
+    P = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    if dLdu is not None:
+        dLdu = np.ascontiguousarray(dLdu, dtype=np.float64)
+    rc = lib().emu_forward_adjoint(C.byref(cfg), P(u0), P(p), P(dLdu), P(du0), P(dp), P(out))
+    if rc:
+        raise RuntimeError(f"emu rc={rc}: {lib().emu_last_error().decode()}")
+    return du0, dp, out

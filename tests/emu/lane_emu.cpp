@@ -1,0 +1,131 @@
+// tests/emu/lane_emu.cpp — TEST-ONLY host emulation of the gfx950 lane bodies.
+//
+// This is NOT a product path and NOT a CPU fallback: libhipadj never contains it, the package never loads
+// it.  It compiles scimlsensitivity.jl_amd/csrc/hipadj_lane.hpp with g++ (HIPADJ_HD -> inline) and loops the
+// per-lane bodies over trajectories exactly as the kernels in hipadj_kernels.hpp do, so that the device
+// arithmetic (RK4 staging, Hermite midpoints, segment composition, Gauss nodes, GK15 bisection) can be
+// compared with the oracle inside the GPU-less build container (`pytest -m "not gpu"`).  The real parity
+// tests (`-m gpu`) go through the C ABI on an MI355X.
+#include <cstring>
+#include <string>
+#include <vector>
+#include <cmath>
+#include "../../scimlsensitivity.jl_amd/csrc/hipadj_lane.hpp"
+#include "../../scimlsensitivity.jl_amd/csrc/hipadj_plan.hpp"
+
+using namespace hipadj;
+
+template <class Mo>
+static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
+               double* du0, double* dp, double* out) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, PF = 8;
+    Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
+    g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
+    const long Np = P.Npad;
+    std::vector<dbl2> knots(cfg->alg != HIPADJ_ALG_BACKSOLVE ? (size_t)(P.S + 1) * N * Np : 0);
+    std::vector<double> ckpt(P.bs_ckpt ? (size_t)P.nck * N * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np);
+    std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0);
+    std::vector<double> dp_traj((size_t)NP * Np, 0.0);
+    for (long i = 0; i < P.N; ++i)
+        forward_lane<Mo>(g, i, u0, p, knots.empty() ? nullptr : knots.data(), ckpt.empty() ? nullptr : ckpt.data(),
+                         P.ckpt_of_knot.data(), outT.data(), P.save_of_knot.data(), yT.data());
+    if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
+    if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
+    const double* cot = cotT.empty() ? nullptr : cotT.data();
+    switch (cfg->alg) {
+    case HIPADJ_ALG_INTERPOLATING: {
+        std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
+        for (int seg = 0; seg < P.nseg; ++seg) for (long i = 0; i < P.N; ++i) {
+            double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
+            if (seg == P.nseg - 1) {
+                double lam[1][N], mu[1][NP];
+                interp_lane<Mo, 1, PF>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
+                for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
+            } else {
+                double lam[NC][N], mu[NC][NP];
+                interp_lane<Mo, NC, PF>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
+                                               for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
+            }
+        }
+        for (long i = 0; i < P.N; ++i) {       // k_compose
+            double lam[N], mu[NP];
+            const double* src = segbuf.data() + (size_t)(P.nseg - 1) * NC * R * Np + i;
+            for (int j = 0; j < N; ++j) lam[j] = src[(size_t)j * Np];
+            for (int j = 0; j < NP; ++j) mu[j] = src[(size_t)(N + j) * Np];
+            for (int s = P.nseg - 2; s >= 0; --s) {
+                src = segbuf.data() + (size_t)s * NC * R * Np + i;
+                double nl[N], nm[NP];
+                for (int j = 0; j < N; ++j) nl[j] = src[(size_t)j * Np];
+                for (int j = 0; j < NP; ++j) nm[j] = mu[j] + src[(size_t)(N + j) * Np];
+                for (int c = 0; c < N; ++c) { for (int j = 0; j < N; ++j) nl[j] += src[((size_t)(c + 1) * R + j) * Np] * lam[c];
+                                              for (int j = 0; j < NP; ++j) nm[j] += src[((size_t)(c + 1) * R + N + j) * Np] * lam[c]; }
+                for (int j = 0; j < N; ++j) lam[j] = nl[j];
+                for (int j = 0; j < NP; ++j) mu[j] = nm[j];
+            }
+            for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+            for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
+        }
+        break; }
+    case HIPADJ_ALG_BACKSOLVE:
+        for (long i = 0; i < P.N; ++i) {
+            double lam[N], mu[NP];
+            backsolve_lane<Mo>(g, i, p, yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
+            for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+            for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
+        }
+        break;
+    case HIPADJ_ALG_GAUSS:
+        for (long i = 0; i < P.N; ++i) {
+            double lam[N], mu[NP];
+            gauss_lane<Mo, PF>(g, i, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+            for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+            for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
+        }
+        break;
+    case HIPADJ_ALG_QUADRATURE: {
+        std::vector<dbl2> adj((size_t)P.S * 2 * N * Np);
+        const double atol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, rtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
+        for (long i = 0; i < P.N; ++i) {
+            double lam[N];
+            quad_adj_lane<Mo, PF>(g, i, p, knots.data(), cot, P.save_of_knot.data(), adj.data(), lam);
+            for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+            double acc[NP]; for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+            for (int q = 0; q < P.nq; ++q) {
+                double res[NP];
+                quad_gk_lane<Mo, 32>(g, i, p, knots.data(), adj.data(), P.qa[q], P.qb[q], atol, rtol, res);
+                for (int j = 0; j < NP; ++j) acc[j] += res[j];
+            }
+            for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = acc[j];
+        }
+        break; }
+    default: return HIPADJ_ERR_INVALID_ARG;
+    }
+    if (cfg->p_shared) { for (int j = 0; j < NP; ++j) { double s = 0; for (long i = 0; i < P.N; ++i) s += dp_traj[(size_t)j * Np + i]; dp[j] = s; } }
+    else for (long i = 0; i < P.N; ++i) for (int j = 0; j < NP; ++j) dp[i * NP + j] = dp_traj[(size_t)j * Np + i];
+    return HIPADJ_OK;
+}
+
+static std::string g_err;
+extern "C" const char* emu_last_error() { return g_err.c_str(); }
+
+extern "C" int emu_plan(const hipadj_config* cfg, int* nseg, int* seg_bounds /*[cap]*/, int cap, int* nck, int* nq) {
+    Plan P; const int rc = make_plan(cfg, P, g_err); if (rc) return rc;
+    *nseg = P.nseg; *nck = P.nck; *nq = P.nq;
+    for (int i = 0; i <= P.nseg && i < cap; ++i) seg_bounds[i] = P.seg_bounds[i];
+    return 0;
+}
+
+extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, const double* p, const double* dLdu,
+                                   double* du0, double* dp, double* out) {
+    Plan P; const int rc = make_plan(cfg, P, g_err); if (rc) return rc;
+    switch (cfg->model) {
+    case HIPADJ_MODEL_LV: return run<ModelLV>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LVT: return run<ModelLVT>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LORENZ: return run<ModelLorenz>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LINDIAG: return run<ModelLinDiag>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_FALLMASS: return run<ModelFallMass>(cfg, P, u0, p, dLdu, du0, dp, out);
+    default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
+    }
+}

@@ -1,0 +1,193 @@
+"""Parity tests proper (`-m gpu`): the HIP path through the C ABI vs the CPU oracle on identical seeded inputs.
+Tolerance: rtol = 1e-6 (Float64), the bar BASELINE.json's north_star states; observed errors are ~1e-13."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+
+
+def lorenz_inputs(N, seed=20240601):
+    rng = np.random.default_rng(seed)
+    return np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)), np.array([10.0, 28.0, 8.0 / 3.0])
+
+
+ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE")]
+
+
+def sensealg_of(sa, name):
+    return {"interpolating": sa.InterpolatingAdjoint(), "backsolve": sa.BacksolveAdjoint(), "gauss": sa.GaussAdjoint(),
+            "quadrature": sa.QuadratureAdjoint()}[name]
+
+
+def test_native_library_is_loaded(sa):
+    sa.load_library()
+    assert any("libhipadj.so" in l for l in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("N", [1, 64, 200])
+def test_lorenz_lsq_matches_oracle(sa, alg, oalg, N):
+    """Lorenz-63, dg = u - 2 at t = 0:0.1:T (test/Core3/adjoint.jl:1157-1172 with a fixed-step solver)."""
+    T, dt = 2.0, 0.01
+    u0, p = lorenz_inputs(N)
+    ts = np.linspace(0, T, 21)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sensealg_of(sa, alg), dgdu_discrete=sa.LsqShift(2.0))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+    ref = O.Problem("LORENZ", alg=oalg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0,
+                    checkpointing=(alg == "backsolve"))
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(sol.u, rout) < RTOL
+    assert rel(du0, rdu0) < RTOL
+    assert rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("model,omodel,u0c,p", [
+    ("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]),
+    ("lvt", "LVT", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]),
+    ("lindiag", "LINDIAG", [1.0, 1.0], [1.0, 2.0]),
+    ("fallmass", "FALLMASS", [1.0, 0.0], [9.81, 1.0]),
+])
+def test_cotangent_path_all_models(sa, alg, oalg, model, omodel, u0c, p):
+    """The AD path: dgdu_discrete = Delta[:, i] (src/concrete_solve.jl:842-851), per-trajectory parameters."""
+    rng = np.random.default_rng(3)
+    N, T, dt = 70, 2.0, 0.02
+    n, npar = sa.model_sizes(model)
+    u0 = np.asarray(u0c) * (1 + 0.05 * rng.standard_normal((N, n)))
+    pp = np.asarray(p) * (1 + 0.05 * rng.standard_normal((N, npar)))
+    ts = np.arange(0, T + 1e-9, 0.1)
+    delta = rng.standard_normal((N, len(ts), n))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model, u0[0], (0, T), pp[0]), u0, pp), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sensealg_of(sa, alg))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem(omodel, alg=oalg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT",
+                    checkpointing=(alg == "backsolve"))
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert dp.shape == (N, npar)
+    assert rel(sol.u, rout) < RTOL
+    assert rel(du0, rdu0) < RTOL
+    assert rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+@pytest.mark.parametrize("segments", [1, 2, 7, 0])
+def test_time_segmentation_is_invisible(sa, segments):
+    """The segmented reverse pass (affine-map composition) reproduces the sequential one (oracle)."""
+    N, T, dt = 130, 4.0, 0.01
+    u0, p = lorenz_inputs(N, seed=5)
+    ts = np.linspace(0, T, 41)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0), time_segments=segments)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+def test_backsolve_checkpoint_stride_and_no_checkpointing(sa):
+    N, T, dt = 64, 1.0, 0.01
+    u0, p = lorenz_inputs(N, seed=9)
+    ts = np.linspace(0, T, 11)
+    for ck, stride, cks in ((True, 20, np.arange(0, 101, 20) * dt), (False, 0, None)):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                       sensealg=sa.BacksolveAdjoint(checkpointing=ck), dgdu_discrete=sa.LsqShift(2.0), checkpoints=cks)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+        ref = O.Problem("LORENZ", alg="BACKSOLVE", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT",
+                        loss_shift=2.0, checkpointing=ck, checkpoints=cks)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+        assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+        sol.engine.close()
+
+
+def test_golden_gradient_lorenz_T2(sa, golden):
+    """HIP path vs the independent scipy forward-sensitivity gradient (dt -> small): the relation the reference
+    tests assert against ForwardDiff (test/Core3/adjoint.jl:691-705)."""
+    g = golden["lorenz_T2"]
+    ts = np.asarray(g["ts"])
+    sol = sa.solve(sa.ODEProblem("lorenz", np.asarray(g["u0"]), (0, 2.0), np.asarray(g["p"])), sa.RK4(), dt=0.0005, saveat=ts,
+                   sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+    assert rel(du0[0], g["du0"]) < 1e-7 and rel(dp, g["dp"]) < 1e-7
+    sol.engine.close()
+
+
+def test_full_size_properties(sa):
+    """BASELINE size (10^4 trajectories, 1000 steps): size-independent properties —
+    linearity of the pullback in the cotangent, and sum-of-shards == whole (the multi-GPU invariant)."""
+    N, T, dt = 10000, 10.0, 0.01
+    u0, p = lorenz_inputs(N)
+    ts = np.linspace(0, T, 101)
+    rng = np.random.default_rng(0)
+    prob = sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0)
+    sol = sa.solve(prob, sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint(), want_out=False)
+    d1 = rng.standard_normal((N, len(ts), 3)); d2 = rng.standard_normal((N, len(ts), 3))
+    a1, b1 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d1)
+    a2, b2 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d2)
+    a3, b3 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=2.0 * d1 - 3.0 * d2)
+    assert rel(a3, 2.0 * a1 - 3.0 * a2) < 1e-9 and rel(b3, 2.0 * b1 - 3.0 * b2) < 1e-9
+    sol.engine.close()
+    # shards: 2 x 5000 trajectories, dp summed on the host == whole-ensemble dp
+    parts = []
+    for lo, hi in (sa.shard_range(N, 0, 2), sa.shard_range(N, 1, 2)):
+        s = sa.solve(sa.EnsembleProblem(prob.prob, u0[lo:hi]), sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint(), want_out=False)
+        parts.append(sa.adjoint_sensitivities(s, sa.RK4(), dgdu_discrete=d1[lo:hi]))
+        s.engine.close()
+    assert rel(np.concatenate([parts[0][0], parts[1][0]]), a1) < 1e-12
+    assert rel(parts[0][1] + parts[1][1], b1) < 1e-10
+    # a bounded oracle sample of the same workload
+    idx = np.arange(0, N, 625)
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT")
+    rdu0, _, _, _ = ref.adjoint_ensemble(u0[idx], p, d1[idx])
+    assert rel(a1[idx], rdu0) < RTOL
+
+
+def test_errors_mirror_reference_misuse(sa):
+    with pytest.raises(sa.HipadjError):
+        sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.03, save_times=[0.5])      # non-integer step count
+    with pytest.raises(sa.HipadjError):
+        sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, save_times=[0.505])    # off-grid loss time
+    e = sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, save_times=[0.5, 1.0])
+    with pytest.raises(sa.HipadjError):
+        e.adjoint(np.zeros((4, 2, 3)))                                                  # reverse before forward
+    e.close()
+
+
+def test_nonfinite_is_reported(sa):
+    u0 = np.full((64, 3), 1e200); p = np.array([10.0, 28.0, 8.0 / 3.0])
+    ts = np.array([1.0])
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, 1.0), p), u0), sa.RK4(), dt=0.01, saveat=ts,
+                   sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    with pytest.raises(sa.HipadjError) as ei:
+        sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+    assert ei.value.status == -4
+    sol.engine.close()
+
+
+def test_torch_autograd_device_path(sa):
+    import torch
+    N, T, dt = 128, 1.0, 0.01
+    u0n, pn = lorenz_inputs(N, seed=11)
+    ts = np.linspace(0, T, 11)
+    eng = sa.Engine("lorenz", "interpolating", N, 0.0, T, dt, save_times=ts)
+    F = sa.make_autograd_function()
+    u0 = torch.tensor(u0n, device="cuda", dtype=torch.float64, requires_grad=True)
+    p = torch.tensor(pn, device="cuda", dtype=torch.float64, requires_grad=True)
+    out = F.apply(u0, p, eng)
+    loss = 0.5 * ((out - 2.0) ** 2).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    eng.synchronize()
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0n, pn)
+    assert rel(u0.grad.cpu().numpy(), rdu0) < RTOL and rel(p.grad.cpu().numpy(), rdp) < RTOL
+    eng.close()
