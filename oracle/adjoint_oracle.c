@@ -524,7 +524,13 @@ static orc_alg make_alg(const orc_config *cfg) {
 static int forward_dense(const orc_model *m, const orc_config *cfg, const double *p, double ta, double tb, double *u,
                          double dt_hint, orc_dense *sol, long *nrhs) {
     fwd_ctx fc = {m, p};
-    orc_alg a = make_alg(cfg); if (dt_hint > 0) a.dt = dt_hint;
+    orc_alg a = make_alg(cfg);
+    /* dt_hint = |last step of the previous cpsol| (src/interpolating_adjoint.jl:249).  For the adaptive stepper it is
+     * the initial-step guess, as in the reference.  For fixed-step RK4 the reference's kwarg would REPLACE the step:
+     * with L = interval length and m = L/dt steps the recursion dt' = L - (m-1) dt amplifies the roundoff of the
+     * snapped last step by (m-1) per interval and the step size degenerates after a few intervals (observed here:
+     * 49^19 * 1e-15).  In exact arithmetic dt' == dt, so the oracle keeps the user's dt for fixed-step re-solves. */
+    if (dt_hint > 0 && cfg->stepper == ORC_STEPPER_TSIT5) a.dt = dt_hint;
     dense_init(sol, m->n, cfg->stepper);
     return integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, NULL, NULL, 0, sol, nrhs);
 }
@@ -753,7 +759,8 @@ static int quadgk_vec(orc_integrand f, void *ctx, int m, double a, double b, dou
 static void poly_integrand(double *out, double t, void *ctx) { int d = *(int *)ctx; out[0] = pow(t, d); }
 double orc_test_quadgk_poly(int degree, double a, double b, double atol, double rtol, long *nevals) {
     double r; long nev = 0; quadgk_vec(poly_integrand, &degree, 1, a, b, atol, rtol, &r, &nev);
-    if (nevals) *nevals = nev; return r;
+    if (nevals) *nevals = nev;
+    return r;
 }
 
 /* AdjointSensitivityIntegrand (src/quadrature_adjoint.jl:486-502): y = sol(t), lam = adj_sol(t), out = f_p^T lam */

@@ -62,6 +62,12 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build the gfx950 extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "This package has no CPU fallback.")
+    # torch ships its own HIP runtime: when torch is going to be used for device memory / streams it must
+    # initialise first, otherwise the process ends up with a second runtime that sees no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     dp, vp = C.POINTER(C.c_double), C.c_void_p
     L.hipadj_version.restype = C.c_int

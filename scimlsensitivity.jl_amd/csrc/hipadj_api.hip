@@ -28,7 +28,7 @@ struct hipadj_handle {
     std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
     // device workspaces (owned)
     double *d_u0 = nullptr, *d_p = nullptr, *d_outT = nullptr, *d_yT = nullptr, *d_ckpt = nullptr, *d_cotT = nullptr;
-    double *d_segbuf = nullptr, *d_dp_traj = nullptr, *d_qres = nullptr, *d_qa = nullptr, *d_qb = nullptr;
+    double *d_segbuf = nullptr, *d_dp_traj = nullptr, *d_qres = nullptr, *d_qa = nullptr, *d_qb = nullptr, *d_partial = nullptr;
     double *d_io_a = nullptr, *d_du0 = nullptr, *d_dp = nullptr;   // staging for the host-pointer API
     dbl2 *d_knots = nullptr, *d_adj = nullptr;
     int *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
@@ -77,7 +77,7 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
 
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
-                    h->d_qb, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_save_of_knot,
+                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -118,6 +118,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
     A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
     A(dev_alloc(h, &h->d_dp_traj, (size_t)np * Np));
+    A(dev_alloc(h, &h->d_partial, (size_t)((h->N + FIN - 1) / FIN) * np));
     A(dev_alloc(h, &h->d_io_a, (size_t)h->N * (h->M > 0 ? h->M : 1) * n));
     A(dev_alloc(h, &h->d_du0, (size_t)h->N * n));
     A(dev_alloc(h, &h->d_dp, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
@@ -239,6 +240,8 @@ template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_co
     constexpr int PF = 8;
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     const double* p = h->p_dev_last;
+    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
+    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;   // per-trajectory dp rows [N][np]
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
     hipEvent_t k0 = h->ev[4], k1 = h->ev[5];   // dominant-kernel bracket
@@ -250,7 +253,8 @@ template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_co
                            (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
-        hipLaunchKernelGGL((k_compose<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf, d_du0, h->d_dp_traj);
+        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(fblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                           d_du0, dp_rows, h->d_partial, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_BACKSOLVE:
@@ -279,14 +283,16 @@ template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_co
         HIP_TRY(h, hipGetLastError());
         break; }
     }
-    // dp: shared p => deterministic sum over trajectories; else per-trajectory rows in the caller layout
-    hipLaunchKernelGGL(k_reduce_dp, dim3((unsigned)h->np), dim3(256), 0, h->stream, h->N, h->Npad, (const double*)h->d_dp_traj,
-                       h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
-    HIP_TRY(h, hipGetLastError());
-    if (!h->cfg.p_shared) TRY(launch_transpose_to_aos(h, h->d_dp_traj, d_dp, h->np));
-    { const long cnt = h->N * h->n;
-      hipLaunchKernelGGL(k_scan_finite, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, cnt, (const double*)d_du0, h->d_flag);
-      HIP_TRY(h, hipGetLastError()); }
+    // finishing stage: NaN/Inf scan + per-workgroup partial sums of mu (Interpolating fused it with the composition)
+    if (h->cfg.alg != HIPADJ_ALG_INTERPOLATING) {
+        hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
+                           (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->cfg.p_shared) {   // dp = sum over trajectories, fixed order
+        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
+        HIP_TRY(h, hipGetLastError());
+    }
     HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
     h->timing_pending_adj = true;
     return HIPADJ_OK;   // timings are harvested lazily at the next synchronize / call

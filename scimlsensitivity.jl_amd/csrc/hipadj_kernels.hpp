@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const doubl
                                                  const int* __restrict__ save_of_knot, double* __restrict__ segbuf) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
-    const int seg = blockIdx.y;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;   // longest (top, 1-column) segment is dispatched first
     if (i >= g.N) return;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
     double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
@@ -60,42 +60,114 @@ __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const doubl
     }
 }
 
+// ---- finishing stage -------------------------------------------------------------------------------------
+// Per 256-thread workgroup: (optionally) compose the segment maps of each trajectory, scan for NaN/Inf (the
+// reference's retcode check), write du0 / per-trajectory dp, and reduce mu over the workgroup's trajectories in a
+// FIXED order (shuffle tree per wave, then waves 0..3) into partial[block][NP]; k_reduce_final then sums the
+// partials in block order => dp is bit-reproducible for a given N.
+constexpr int FIN = 256;
+
+template <int NP>
+__device__ __forceinline__ void block_partial(const double (&mu)[NP], bool valid, double* __restrict__ partial) {
+    __shared__ double sh[FIN / WAVE][NP];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        double v = valid ? mu[j] : 0.0;
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+        if (lane == 0) sh[wv][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NP) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < FIN / WAVE; ++w) t += sh[w][threadIdx.x];
+        partial[(long)blockIdx.x * NP + threadIdx.x] = t;
+    }
+}
+
+__device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.79769313486231570e308; }
+
 // compose the segment maps top -> bottom:  lam <- A lam + c_l ; mu <- mu + B lam + c_m
 template <class Mo>
-__global__ void __launch_bounds__(WAVE) k_compose(Geom g, int nseg, const double* __restrict__ segbuf,
-                                                  double* __restrict__ du0, double* __restrict__ dp_traj) {
+__global__ void __launch_bounds__(FIN) k_compose_finish(Geom g, int nseg, const double* __restrict__ segbuf,
+                                                        double* __restrict__ du0, double* __restrict__ dp_rows,
+                                                        double* __restrict__ partial, int* __restrict__ flag) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
-    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
-    if (i >= g.N) return;
+    const long i = (long)blockIdx.x * FIN + threadIdx.x;
+    const bool valid = i < g.N;
     double lam[N], mu[NP];
-    { const double* __restrict__ src = segbuf + (long)(nseg - 1) * NC * R * g.Npad + i;
 #pragma unroll
-      for (int j = 0; j < N; ++j) lam[j] = src[(long)j * g.Npad];
+    for (int j = 0; j < N; ++j) lam[j] = 0.0;
 #pragma unroll
-      for (int j = 0; j < NP; ++j) mu[j] = src[(long)(N + j) * g.Npad]; }
-    for (int s = nseg - 2; s >= 0; --s) {
-        const double* __restrict__ src = segbuf + (long)s * NC * R * g.Npad + i;
-        double nl[N], nm[NP];
+    for (int j = 0; j < NP; ++j) mu[j] = 0.0;
+    if (valid) {
+        { const double* __restrict__ src = segbuf + (long)(nseg - 1) * NC * R * g.Npad + i;
 #pragma unroll
-        for (int j = 0; j < N; ++j) nl[j] = src[(long)j * g.Npad];
+          for (int j = 0; j < N; ++j) lam[j] = src[(long)j * g.Npad];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) nm[j] = mu[j] + src[(long)(N + j) * g.Npad];
+          for (int j = 0; j < NP; ++j) mu[j] = src[(long)(N + j) * g.Npad]; }
+        for (int s = nseg - 2; s >= 0; --s) {
+            const double* __restrict__ src = segbuf + (long)s * NC * R * g.Npad + i;
+            double nl[N], nm[NP];
 #pragma unroll
-        for (int c = 0; c < N; ++c) {
+            for (int j = 0; j < N; ++j) nl[j] = src[(long)j * g.Npad];
 #pragma unroll
-            for (int j = 0; j < N; ++j) nl[j] += src[((long)(c + 1) * R + j) * g.Npad] * lam[c];
+            for (int j = 0; j < NP; ++j) nm[j] = mu[j] + src[(long)(N + j) * g.Npad];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) nm[j] += src[((long)(c + 1) * R + N + j) * g.Npad] * lam[c];
+            for (int c = 0; c < N; ++c) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) nl[j] += src[((long)(c + 1) * R + j) * g.Npad] * lam[c];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) nm[j] += src[((long)(c + 1) * R + N + j) * g.Npad] * lam[c];
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[j] = nl[j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[j] = nm[j];
         }
+        bool bad = false;
 #pragma unroll
-        for (int j = 0; j < N; ++j) lam[j] = nl[j];
+        for (int j = 0; j < N; ++j) { du0[i * N + j] = lam[j]; bad |= !finite_d(lam[j]); }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) mu[j] = nm[j];
+        for (int j = 0; j < NP; ++j) { bad |= !finite_d(mu[j]); if (dp_rows) dp_rows[i * NP + j] = mu[j]; }
+        if (bad) atomicOr(flag, 1);
     }
+    block_partial<NP>(mu, valid, partial);
+}
+
+// finishing stage for kernels that already wrote du0 [N][n] and dp_traj [NP][Npad]
+template <int N, int NP>
+__global__ void __launch_bounds__(FIN) k_finish(long Ntraj, long Npad, const double* __restrict__ du0,
+                                                const double* __restrict__ dp_traj, double* __restrict__ dp_rows,
+                                                double* __restrict__ partial, int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * FIN + threadIdx.x;
+    const bool valid = i < Ntraj;
+    double mu[NP];
 #pragma unroll
-    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+    for (int j = 0; j < NP; ++j) mu[j] = 0.0;
+    if (valid) {
+        bool bad = false;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
+        for (int j = 0; j < N; ++j) bad |= !finite_d(du0[i * N + j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { mu[j] = dp_traj[(long)j * Npad + i]; bad |= !finite_d(mu[j]); if (dp_rows) dp_rows[i * NP + j] = mu[j]; }
+        if (bad) atomicOr(flag, 1);
+    }
+    block_partial<NP>(mu, valid, partial);
+}
+
+// dp[j] = sum over workgroup partials in block order (one workgroup per parameter)
+__global__ void __launch_bounds__(FIN) k_reduce_final(int nblocks, int np, const double* __restrict__ partial, double* __restrict__ dp) {
+    __shared__ double sh[FIN];
+    const int j = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += FIN) s += partial[(long)b * np + j];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = FIN / 2; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) dp[j] = sh[0];
 }
 
 template <class Mo>
@@ -196,26 +268,6 @@ __global__ void k_soa_to_aos(const double* __restrict__ src, double* __restrict_
         const long i = i0 + r; const int c = c0 + threadIdx.x;
         if (i < N && c < C) dst[i * C + c] = tile[threadIdx.x][r];
     }
-}
-
-// dp[j] = sum_i dp_traj[j][i] — one workgroup per parameter, fixed-order tree => bit-reproducible for a given N.
-// Also scans du0 / dp_traj for NaN/Inf (the reference's retcode check) into *flag.
-__global__ void __launch_bounds__(256) k_reduce_dp(long N, long Npad, const double* __restrict__ dp_traj,
-                                                   double* __restrict__ dp, int* __restrict__ flag) {
-    __shared__ double sh[256];
-    const int j = blockIdx.x;
-    double s = 0.0; int bad = 0;
-    for (long i = threadIdx.x; i < N; i += 256) { const double v = dp_traj[(long)j * Npad + i]; s += v; bad |= !(fabs(v) <= 1.79769313486231570e308); }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
-    if (threadIdx.x == 0 && dp) dp[j] = sh[0];
-    if (bad) atomicOr(flag, 1);
-}
-// dp per trajectory: SoA [np][Npad] -> caller [N][np] handled by k_soa_to_aos.
-__global__ void __launch_bounds__(256) k_scan_finite(long count, const double* __restrict__ v, int* __restrict__ flag) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < count && !(fabs(v[i]) <= 1.79769313486231570e308)) atomicOr(flag, 2);
 }
 
 }  // namespace hipadj

@@ -211,6 +211,9 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
 #pragma unroll
     for (int r = 0; r < PF; ++r) { const int kk = k_hi - 1 - r; load_knot<Mo>(knots, g.Npad, kk > k_lo ? kk : k_lo, i, ring[r]); }
     for (int kb = k_hi - 1; kb >= k_lo; kb -= PF) {
+        int sfl[PF];                                  // loss-time flags of this block: scalar loads issued up front
+#pragma unroll
+        for (int r = 0; r < PF; ++r) { const int k = kb - r; sfl[r] = save_of_knot[k > k_lo ? k : k_lo]; }
 #pragma unroll
         for (int r = 0; r < PF; ++r) {
             const int k = kb - r;
@@ -219,7 +222,7 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
                 const int kn = k - PF;
                 load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[r]);   // prefetch PF knots ahead
                 adj_rk4_step<Mo, NC, true>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
-                const int s = save_of_knot[k];
+                const int s = sfl[r];
                 if (s >= 0 && !(g.no_start && s == 0)) {
                     double gl[N]; loss_grad<Mo>(g, i, s, cotT, lo.u, gl);
 #pragma unroll

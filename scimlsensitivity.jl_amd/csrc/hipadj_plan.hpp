@@ -9,6 +9,7 @@
 //                                                                             src/quadrature_adjoint.jl:563-616
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../include/hipadj.h"
@@ -49,7 +50,9 @@ inline int plan_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, in
 // parallelism exceeds that factor.
 inline int plan_auto_segments(long N, int S, int n) {
     const long waves = (N + 63) / 64;
-    long target = (long)std::ceil(2048.0 / (double)waves);
+    // the segmented kernel needs ~250 VGPRs => 2 resident waves per SIMD => 2048 wave slots on 256 CUs x 4 SIMDs;
+    // floor() keeps the grid within ONE residency round (a partial second round would double the makespan)
+    long target = 2048 / waves;
     long maxseg = S / 16; if (maxseg < 1) maxseg = 1;
     if (target > maxseg) target = maxseg;
     if ((double)target < 1.0 + n) return 1;
@@ -102,7 +105,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         const int C = P.nseg; P.seg_bounds.assign(C + 1, 0);
         if (C == 1) { P.seg_bounds[1] = (int)S; }
         else {
-            const double w_top = 1.0 + 0.6 * n;
+            double w_top = 1.0 + 0.6 * n;             // a 1-column lane advances ~w_top steps per (1+n)-column step
+            if (const char* e = std::getenv("HIPADJ_WTOP")) { const double v = std::atof(e); if (v > 0) w_top = v; }   // tuning hook
             const double unit = (double)S / ((C - 1) + w_top);
             double acc = 0.0;
             for (int s = 1; s < C; ++s) { acc += unit; int b = (int)std::lround(acc); if (b <= P.seg_bounds[s - 1]) b = P.seg_bounds[s - 1] + 1; P.seg_bounds[s] = b; }

@@ -1,0 +1,191 @@
+"""Pins the CPU oracle (oracle/adjoint_oracle.c) before anything is checked against it.
+
+The reference (pure Julia) cannot run here, so the pins are:
+  * the two literal known answers of the reference's tests,
+  * the relations its tests assert between the four algorithms and against an independent gradient
+    (tests/golden/gradients.json — scipy DOP853 forward sensitivities standing in for ForwardDiff),
+  * self-checks of the restated upstream pieces (Tsit5 tableau, GK15 rule, RK4 order).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+ALGS = ["INTERPOLATING", "BACKSOLVE", "GAUSS", "QUADRATURE"]
+LVT = dict(u0=[1.0, 1.0], p=[1.5, 1.0, 3.0, 1.0])
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+
+
+def test_tsit5_tableau_satisfies_order_conditions():
+    assert O.lib().orc_test_tsit5_order_residual() < 1e-13
+
+
+def test_gk15_rule_is_exact_for_low_degree_and_adapts():
+    nev = C.c_long()
+    for deg in (0, 1, 6, 13, 22):
+        v = O.lib().orc_test_quadgk_poly(deg, -1.0, 2.0, 0.0, 1e-13, C.byref(nev))
+        exact = (2.0 ** (deg + 1) - (-1.0) ** (deg + 1)) / (deg + 1)
+        assert abs(v - exact) <= 1e-12 * abs(exact)
+    O.lib().orc_test_quadgk_poly(6, 0.0, 1.0, 0.0, 1e-10, C.byref(nev))
+    assert nev.value == 15                      # degree <= 13: Gauss-7 already exact, no bisection
+
+
+@pytest.mark.parametrize("model,u,p", [("LV", [0.7, 1.3], [1.5, 1.0, 3.0, 1.0]), ("LVT", [0.7, 1.3], [1.5, 1.0, 3.0, 1.0]),
+                                       ("LORENZ", [1.0, -2.0, 15.0], [10.0, 28.0, 8 / 3]), ("LINDIAG", [0.3, 2.0], [1.0, 2.0]),
+                                       ("FALLMASS", [1.0, 0.5], [9.81, 1.0])])
+def test_model_vjps_match_finite_differences(model, u, p):
+    """user-VJP seam (test/Core3/user_vjp.jl:98-114): vjp == J^T lam, vjp_p == paramjac^T lam."""
+    u, p = np.array(u), np.array(p)
+    lam = np.array([0.3, -1.1, 0.7])[: len(u)]
+    t, h = 0.4, 1e-6
+    dlam, dgrad = O.model_vjp(model, lam, u, p, t)
+    J = np.stack([(O.model_f(model, u + h * e, p, t) - O.model_f(model, u - h * e, p, t)) / (2 * h) for e in np.eye(len(u))], axis=1)
+    P = np.stack([(O.model_f(model, u, p + h * e, t) - O.model_f(model, u, p - h * e, t)) / (2 * h) for e in np.eye(len(p))], axis=1)
+    assert np.allclose(dlam, J.T @ lam, rtol=1e-7, atol=1e-8)
+    assert np.allclose(dgrad, P.T @ lam, rtol=1e-7, atol=1e-8)
+
+
+def test_mlp_and_brusselator_vjps_match_finite_differences():
+    rng = np.random.default_rng(0)
+    for model, dims in (("MLP", (2, 5, 3, 0)), ("BRUSS", (4, 0, 0, 0))):
+        n, npar = O.model_sizes(model, dims)
+        u = rng.uniform(0.5, 1.5, n); p = rng.uniform(0.5, 1.5, npar); lam = rng.standard_normal(n)
+        dlam, dgrad = O.model_vjp(model, lam, u, p, 2.0, dims)
+        h = 1e-6
+        for j in rng.choice(n, 4, replace=False):
+            e = np.zeros(n); e[j] = h
+            fd = (O.model_f(model, u + e, p, 2.0, dims) - O.model_f(model, u - e, p, 2.0, dims)) / (2 * h)
+            assert abs(fd @ lam - dlam[j]) < 1e-6 * max(1, abs(dlam[j]))
+        for j in rng.choice(npar, min(4, npar), replace=False):
+            e = np.zeros(npar); e[j] = h
+            fd = (O.model_f(model, u, p + e, 2.0, dims) - O.model_f(model, u, p - e, 2.0, dims)) / (2 * h)
+            assert abs(fd @ lam - dgrad[j]) < 1e-5 * max(1, abs(dgrad[j]))
+
+
+# ---- the reference's literal known answers -------------------------------------------------------------------
+@pytest.mark.parametrize("alg", ALGS)
+def test_falling_mass_literal(alg, golden):
+    """test/Core7/physical_ode_regression.jl:42-51: d/dp sum(position at 0:0.05:2) == [-27.675, 0.0], atol 1e-2."""
+    g = golden["fallmass"]
+    ts = np.asarray(g["ts"])
+    delta = np.zeros((len(ts), 2)); delta[:, 0] = 1.0
+    for stepper, kw in (("TSIT5", dict(dt=0.0, abstol=1e-6, reltol=1e-3)), ("RK4", dict(dt=0.05))):
+        pr = O.Problem("FALLMASS", alg=alg, stepper=stepper, t0=0, t1=2.0, save_times=ts, loss="COTANGENT", **kw)
+        _, dp, _ = pr.adjoint(g["u0"], g["p"], delta)
+        assert np.allclose(dp, g["reference_literal"], atol=g["reference_atol"])
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_diagonal_linear_literal(alg, golden):
+    """test/Core1/sparse_adjoint.jl:32-33: gradient of sum(u(1)) for u' = p.*u equals exp.(p) (tol 1e-3)."""
+    g = golden["lindiag"]
+    pr = O.Problem("LINDIAG", alg=alg, stepper="TSIT5", t0=0, t1=1.0, dt=0.0, abstol=1e-6, reltol=1e-6, save_times=[1.0],
+                   loss="COTANGENT", quad_abstol=1e-6, quad_reltol=1e-6)
+    du0, dp, out = pr.adjoint(g["u0"], g["p"], np.ones((1, 2)))
+    assert np.allclose(out[0], g["reference_literal"], rtol=1e-3)
+    assert np.allclose(dp, g["reference_literal"], rtol=1e-3)
+
+
+# ---- relations asserted by test/Core3/adjoint.jl -------------------------------------------------------------
+@pytest.mark.parametrize("alg", ALGS)
+def test_lvt_all_algorithms_match_forward_sensitivity_gradient(alg, golden):
+    """adjoint == ForwardDiff through the solver (test/Core3/adjoint.jl:366-404, 691-705), rtol 1e-9 there with
+    Tsit5 at 1e-14; here Tsit5 at 1e-12 against scipy DOP853 at 1e-13."""
+    g = golden["lvt"]
+    pr = O.Problem("LVT", alg=alg, stepper="TSIT5", t0=0, t1=10, dt=0.0, abstol=1e-12, reltol=1e-12, save_times=g["ts"],
+                   loss="LSQ_SHIFT", loss_shift=2.0, quad_abstol=1e-12, quad_reltol=1e-12)
+    du0, dp, out = pr.adjoint(g["u0"], g["p"])
+    assert rel(out, g["u"]) < 1e-9
+    assert rel(du0, g["du0"]) < 1e-8 and rel(dp, g["dp"]) < 1e-8
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_lv_sum_loss_concrete_solve_gradient(alg, golden):
+    """test/Core1/concrete_solve_derivatives.jl:106-165: loss = sum(solve(...; saveat = 0.1)) => Delta == 1."""
+    g = golden["lv_sum"]
+    ts = np.asarray(g["ts"])
+    pr = O.Problem("LV", alg=alg, stepper="TSIT5", t0=0, t1=10, dt=0.0, abstol=1e-11, reltol=1e-11, save_times=ts,
+                   loss="COTANGENT", quad_abstol=1e-11, quad_reltol=1e-11)
+    du0, dp, _ = pr.adjoint(g["u0"], g["p"], np.ones((len(ts), 2)))
+    assert rel(du0, g["du0"]) < 1e-7 and rel(dp, g["dp"]) < 1e-7
+
+
+def test_lorenz_backsolve_checkpointed_matches_interpolating(golden):
+    """test/Core3/adjoint.jl:1157-1241: Backsolve (checkpointed) ~ Interpolating, rtol 1e-5 / 1e-4 for coarser
+    checkpoints; un-checkpointed Backsolve is skipped there ('cannot finish')."""
+    g = golden["lorenz"]
+    ts = np.asarray(g["ts"])
+    kw = dict(stepper="TSIT5", t0=0, t1=10, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    du_i, dp_i, _ = O.Problem("LORENZ", alg="INTERPOLATING", **kw).adjoint(g["u0"], g["p"])
+    du_b, dp_b, _ = O.Problem("LORENZ", alg="BACKSOLVE", checkpointing=True, **kw).adjoint(g["u0"], g["p"])
+    du_c, dp_c, _ = O.Problem("LORENZ", alg="BACKSOLVE", checkpointing=True, checkpoints=ts[::2], **kw).adjoint(g["u0"], g["p"])
+    assert rel(du_b, du_i) < 1e-5 and rel(dp_b, dp_i) < 1e-5
+    assert rel(du_c, du_i) < 1e-4 and rel(dp_c, dp_i) < 1e-4
+    # and against the independent gradient (chaotic: looser)
+    assert rel(dp_i, g["dp"]) < 1e-4
+
+
+@pytest.mark.parametrize("alg", ["INTERPOLATING", "GAUSS"])
+def test_checkpointed_interpolating_and_gauss_match_dense(alg, golden):
+    """InterpolatingAdjoint(checkpointing=true) / GaussAdjoint(checkpointing=true) re-solve each checkpoint
+    interval (src/interpolating_adjoint.jl:207-277) and agree with the dense variants (test/Core3/adjoint.jl:366-404)."""
+    g = golden["lvt"]
+    kw = dict(stepper="TSIT5", t0=0, t1=10, dt=0.0, abstol=1e-11, reltol=1e-11, save_times=g["ts"], loss="LSQ_SHIFT", loss_shift=2.0)
+    a = O.Problem("LVT", alg=alg, **kw).adjoint(g["u0"], g["p"])
+    b = O.Problem("LVT", alg=alg, checkpointing=True, **kw).adjoint(g["u0"], g["p"])
+    assert rel(b[0], a[0]) < 1e-7 and rel(b[1], a[1]) < 1e-7
+    # fixed-step RK4 on a grid: the re-solved knots are (to roundoff) the stored ones
+    kw = dict(stepper="RK4", t0=0, t1=10, dt=0.01, save_times=g["ts"], loss="LSQ_SHIFT", loss_shift=2.0)
+    a = O.Problem("LVT", alg=alg, **kw).adjoint(g["u0"], g["p"])
+    b = O.Problem("LVT", alg=alg, checkpointing=True, **kw).adjoint(g["u0"], g["p"])
+    assert rel(b[0], a[0]) < 1e-11 and rel(b[1], a[1]) < 1e-11
+
+
+def test_rk4_gradient_converges_at_fourth_order(golden):
+    g = golden["lorenz_T2"]
+    errs = []
+    for dt in (0.02, 0.01, 0.005):
+        pr = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=2.0, dt=dt, save_times=g["ts"], loss="LSQ_SHIFT", loss_shift=2.0)
+        _, dp, _ = pr.adjoint(g["u0"], g["p"])
+        errs.append(rel(dp, g["dp"]))
+    orders = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert np.all(orders > 3.3), (errs, orders)
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_rk4_four_algorithms_agree_as_dt_shrinks(alg, golden):
+    g = golden["lorenz_T2"]
+    pr = O.Problem("LORENZ", alg=alg, stepper="RK4", t0=0, t1=2.0, dt=0.001, save_times=g["ts"], loss="LSQ_SHIFT", loss_shift=2.0,
+                   checkpointing=(alg == "BACKSOLVE"), quad_abstol=1e-12, quad_reltol=1e-12)
+    du0, dp, _ = pr.adjoint(g["u0"], g["p"])
+    assert rel(du0, g["du0"]) < 1e-8 and rel(dp, g["dp"]) < 1e-8
+
+
+def test_no_start_and_offgrid_and_interior_save_times():
+    """no_start suppresses the jump at t0 (src/adjoint_common.jl:761); loss times need not sit on step ends."""
+    u0, p = [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]
+    ts = np.array([0.0, 0.33, 1.0, 1.7])
+    base = O.Problem("LV", alg="INTERPOLATING", stepper="RK4", t0=0, t1=2.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    du0_a, dp_a, out = base.adjoint(u0, p)
+    ns = O.Problem("LV", alg="INTERPOLATING", stepper="RK4", t0=0, t1=2.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, no_start=True)
+    du0_b, dp_b, _ = ns.adjoint(u0, p)
+    assert np.allclose(du0_a - du0_b, np.array(u0) - 2.0) and np.allclose(dp_a, dp_b)
+    tight = O.Problem("LV", alg="INTERPOLATING", stepper="TSIT5", t0=0, t1=2.0, dt=0.0, abstol=1e-12, reltol=1e-12, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    du0_c, dp_c, _ = tight.adjoint(u0, p)
+    assert rel(dp_a, dp_c) < 1e-6
+
+
+def test_ensemble_sums_shared_parameter_gradient():
+    rng = np.random.default_rng(2)
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((6, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.linspace(0, 1, 11)
+    pr = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=1.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    du0, dp, out, _ = pr.adjoint_ensemble(u0, p, nthreads=2)
+    singles = [pr.adjoint(u0[i], p) for i in range(6)]
+    assert np.allclose(dp, sum(s[1] for s in singles), rtol=1e-13)
+    assert np.allclose(du0, np.stack([s[0] for s in singles]), rtol=1e-14)
