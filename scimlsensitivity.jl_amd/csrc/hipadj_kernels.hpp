@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restri
 }
 
 // segbuf layout: [segment][column][N+NP][Npad]; the top segment only fills column 0.
-template <class Mo, int PF>
+template <class Mo, int PF, int LOSS>
 __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const double* __restrict__ p,
                                                  const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                                                  const int* __restrict__ save_of_knot, double* __restrict__ segbuf) {
@@ -42,14 +42,14 @@ __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const doubl
     double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
     if (seg == sp.nseg - 1) {
         double lam[1][N], mu[1][NP];
-        interp_lane<Mo, 1, PF>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
 #pragma unroll
         for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
 #pragma unroll
         for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
     } else {
         double lam[NC][N], mu[NC][NP];
-        interp_lane<Mo, NC, PF>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        interp_lane<Mo, NC, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, const double* __rest
     for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
 }
 
-template <class Mo, int PF>
+template <class Mo, int PF, int LOSS>
 __global__ void __launch_bounds__(WAVE) k_gauss(Geom g, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                                 const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                                                 double* __restrict__ du0, double* __restrict__ dp_traj) {
@@ -194,14 +194,14 @@ __global__ void __launch_bounds__(WAVE) k_gauss(Geom g, const double* __restrict
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= g.N) return;
     double lam[N], mu[NP];
-    gauss_lane<Mo, PF>(g, i, p, knots, cotT, save_of_knot, lam, mu);
+    gauss_lane<Mo, PF, LOSS>(g, i, p, knots, cotT, save_of_knot, lam, mu);
 #pragma unroll
     for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
 #pragma unroll
     for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
 }
 
-template <class Mo, int PF>
+template <class Mo, int PF, int LOSS>
 __global__ void __launch_bounds__(WAVE) k_quad_adj(Geom g, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                                    const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                                                    dbl2* __restrict__ adj, double* __restrict__ du0) {
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(WAVE) k_quad_adj(Geom g, const double* __restr
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= g.N) return;
     double lam[N];
-    quad_adj_lane<Mo, PF>(g, i, p, knots, cotT, save_of_knot, adj, lam);
+    quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots, cotT, save_of_knot, adj, lam);
 #pragma unroll
     for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
 }
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(WAVE) k_quad_gk(Geom g, const double* __restri
     const int q = blockIdx.y;
     if (i >= g.N) return;
     double res[NP];
-    quad_gk_lane<Mo, 32>(g, i, p, knots, adj, qa[q], qb[q], atol, rtol, res);
+    quad_gk_lane<Mo, 128>(g, i, p, knots, adj, qa[q], qb[q], atol, rtol, res);
 #pragma unroll
     for (int j = 0; j < NP; ++j) qres[((long)q * NP + j) * g.Npad + i] = res[j];
 }

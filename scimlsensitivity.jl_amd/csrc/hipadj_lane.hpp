@@ -181,13 +181,113 @@ HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double
 }
 
 // ------------------------------------------------------------------------------------------------
+// reverse_sweep: streams the forward knots k_hi -> k_lo of trajectory i through `step(hi, lo, k, jump, gl)`.
+//
+// The main loop is STRAIGHT-LINE code per block of PF steps (no branches, no conditional loads), so that hipcc
+// emits counted `s_waitcnt vmcnt(N)` and the PF-deep software prefetch really stays in flight (with a branch
+// per step the compiler falls back to vmcnt(0) and every step eats a full HBM round trip).  Ring slot j holds
+// knot kb - j of the current block; step r uses ring[r] as `lo` and ring[r-1] (the carry for r = 0) as `hi`;
+// a slot is refilled for the next block right after its last use, which gives a prefetch distance of PF - 1
+// steps without register copies.  The loss jump is a select, not a branch:
+//     LOSS == 1 (LSQ_SHIFT): gl = u - shift, computed from the knot just loaded
+//     LOSS == 0 (COTANGENT): gl = Delta[:, s] streamed through a second ring (clamped index on non-loss steps
+//                            => L2 hits, no extra HBM traffic)
+// A final partial block (< PF steps) runs the same body under per-step guards.
+// ------------------------------------------------------------------------------------------------
+template <class Mo, int LOSS>
+HIPADJ_HD void load_cot(const Geom& g, long i, int s, const double* __restrict__ cotT, double (&c)[Mo::N]) {
+    if (LOSS == 0) {
+        const int sc = s > 0 ? s : 0;
+#pragma unroll
+        for (int j = 0; j < Mo::N; ++j) c[j] = cotT[((long)sc * Mo::N + j) * g.Npad + i];
+    } else {
+#pragma unroll
+        for (int j = 0; j < Mo::N; ++j) c[j] = 0.0;
+    }
+}
+
+template <class Mo, int PF, int LOSS, class Init, class Step>
+HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const dbl2* __restrict__ knots,
+                             const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                             Init&& init, Step&& step) {
+    constexpr int N = Mo::N;
+    Knot<Mo> carry; load_knot<Mo>(knots, g.Npad, k_hi, i, carry);
+    if (k_hi == g.S) {   // PresetTimeCallback fires at initialisation when T is a loss time
+        const int s = save_of_knot[k_hi];
+        double gl[N];
+        if (LOSS == 0) {
+            if (s >= 0) load_cot<Mo, LOSS>(g, i, s, cotT, gl);
+            else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) gl[j] = 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) gl[j] = carry.u[j] - g.loss_shift;
+        }
+        init(s >= 0, gl);
+    }
+    Knot<Mo> ring[PF];
+    double cot[PF][N];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+        const int kk = k_hi - 1 - r, kc = kk > k_lo ? kk : k_lo;
+        load_knot<Mo>(knots, g.Npad, kc, i, ring[r]);
+        load_cot<Mo, LOSS>(g, i, LOSS == 0 ? save_of_knot[kc] : 0, cotT, cot[r]);
+    }
+    int kb = k_hi - 1;
+    for (; kb - (PF - 1) >= k_lo; kb -= PF) {
+        int sfl[PF], sfn[PF];       // loss flags of this block and (cotangent prefetch) of the next one: scalar loads up front
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            sfl[r] = save_of_knot[kb - r];
+            const int kn = kb - PF - r;
+            sfn[r] = LOSS == 0 ? save_of_knot[kn > k_lo ? kn : k_lo] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int k = kb - r;
+            const int s = sfl[r];
+            const bool jump = s >= 0 && !(g.no_start && s == 0);
+            double gl[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) gl[j] = LOSS == 0 ? cot[r][j] : (ring[r].u[j] - g.loss_shift);
+            HIPADJ_STEP_FENCE();
+            step(r == 0 ? carry : ring[r > 0 ? r - 1 : 0], ring[r], k, jump, gl);
+            HIPADJ_STEP_FENCE();
+            if (r >= 1) {   // slot r-1 is dead: refill it for the next block (knot kb - PF - (r-1))
+                const int kn = kb - PF - (r - 1);
+                load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[r - 1]);
+                load_cot<Mo, LOSS>(g, i, sfn[r - 1], cotT, cot[r - 1]);
+            }
+        }
+        carry = ring[PF - 1];
+        { const int kn = kb - PF - (PF - 1);
+          load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[PF - 1]);
+          load_cot<Mo, LOSS>(g, i, sfn[PF - 1], cotT, cot[PF - 1]); }
+    }
+    // partial last block: ring[j] already holds knot max(kb - j, k_lo)
+#pragma unroll
+    for (int r = 0; r < PF - 1; ++r) {
+        const int k = kb - r;
+        if (k >= k_lo) {
+            const int s = save_of_knot[k];
+            const bool jump = s >= 0 && !(g.no_start && s == 0);
+            double gl[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) gl[j] = LOSS == 0 ? cot[r][j] : (ring[r].u[j] - g.loss_shift);
+            step(r == 0 ? carry : ring[r > 0 ? r - 1 : 0], ring[r], k, jump, gl);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // InterpolatingAdjoint over knots k_hi -> k_lo.  Column 0 is the affine column (starts at 0, receives the
 // loss jumps); columns 1..N are basis columns (lambda = e_j) when NC == 1 + N.
 //   top segment (k_hi == S): NC = 1, the jump at T is applied before the first step.
 // The jump at knot k_lo is applied at the end (so segment results chain without double counting).
-// PF = software prefetch distance in knots.
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int NC, int PF>
+template <class Mo, int NC, int PF, int LOSS>
 HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p,
                            const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                            const int* __restrict__ save_of_knot, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
@@ -200,38 +300,16 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
 #pragma unroll
         for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
     }
-    Knot<Mo> hi; load_knot<Mo>(knots, g.Npad, k_hi, i, hi);
-    if (k_hi == g.S) {  // PresetTimeCallback fires at initialisation when T is a loss time
-        const int s = save_of_knot[k_hi];
-        if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, hi.u, gl);
+    reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot,
+        [&](bool jump, const double (&gl)[N]) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; }
-    }
-    Knot<Mo> ring[PF];
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        },
+        [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
+            adj_rk4_step<Mo, NC, true>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
 #pragma unroll
-    for (int r = 0; r < PF; ++r) { const int kk = k_hi - 1 - r; load_knot<Mo>(knots, g.Npad, kk > k_lo ? kk : k_lo, i, ring[r]); }
-    for (int kb = k_hi - 1; kb >= k_lo; kb -= PF) {
-        int sfl[PF];                                  // loss-time flags of this block: scalar loads issued up front
-#pragma unroll
-        for (int r = 0; r < PF; ++r) { const int k = kb - r; sfl[r] = save_of_knot[k > k_lo ? k : k_lo]; }
-#pragma unroll
-        for (int r = 0; r < PF; ++r) {
-            const int k = kb - r;
-            if (k >= k_lo) {
-                const Knot<Mo> lo = ring[r];
-                const int kn = k - PF;
-                load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[r]);   // prefetch PF knots ahead
-                adj_rk4_step<Mo, NC, true>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
-                const int s = sfl[r];
-                if (s >= 0 && !(g.no_start && s == 0)) {
-                    double gl[N]; loss_grad<Mo>(g, i, s, cotT, lo.u, gl);
-#pragma unroll
-                    for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
-                }
-                hi = lo;
-            }
-        }
-    }
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,7 +389,7 @@ HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double 
 // derivatives at both ends) and y from the forward interpolant  (src/gauss_adjoint.jl:745-759, 809-851).
 // Time runs backward, so the accumulated sum equals int_{t0}^{T} lam^T f_p dt.
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int PF>
+template <class Mo, int PF, int LOSS>
 HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
                           const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                           double (&lamo)[Mo::N], double (&muo)[Mo::NP]) {
@@ -323,56 +401,39 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, c
 #pragma unroll
     for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
     const double dt = g.dt;
-    Knot<Mo> hi; load_knot<Mo>(knots, g.Npad, g.S, i, hi);
-    { const int s = save_of_knot[g.S];
-      if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, hi.u, gl);
-#pragma unroll
-          for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; } }
-    Knot<Mo> ring[PF];
-#pragma unroll
-    for (int r = 0; r < PF; ++r) { const int kk = g.S - 1 - r; load_knot<Mo>(knots, g.Npad, kk > 0 ? kk : 0, i, ring[r]); }
     const double xg = 0.5773502691896257645;
-    for (int kb = g.S - 1; kb >= 0; kb -= PF) {
+    reverse_sweep<Mo, PF, LOSS>(g, i, 0, g.S, knots, cotT, save_of_knot,
+        [&](bool jump, const double (&gl)[N]) {
 #pragma unroll
-        for (int r = 0; r < PF; ++r) {
-            const int k = kb - r;
-            if (k >= 0) {
-                const Knot<Mo> lo = ring[r];
-                const int kn = k - PF;
-                load_knot<Mo>(knots, g.Npad, kn > 0 ? kn : 0, i, ring[r]);
-                const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
-                double lam_hi[N], d_hi[N], d_lo[N], V[N];
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        },
+        [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
+            const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
+            double lam_hi[N], d_hi[N], d_lo[N], V[N];
 #pragma unroll
-                for (int j = 0; j < N; ++j) lam_hi[j] = lam[0][j];
-                Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
+            for (int j = 0; j < N; ++j) lam_hi[j] = lam[0][j];
+            Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
 #pragma unroll
-                for (int j = 0; j < N; ++j) d_hi[j] = -V[j];                     // fsalfirst of the adjoint step
-                adj_rk4_step<Mo, 1, false>(hi, lo, pv, t_lo, dt, lam, mu);
-                Mo::vjp_u(V, lam[0], lo.u, pv, t_lo);
+            for (int j = 0; j < N; ++j) d_hi[j] = -V[j];                     // fsalfirst of the adjoint step
+            adj_rk4_step<Mo, 1, false>(hi, lo, pv, t_lo, dt, lam, mu);
+            Mo::vjp_u(V, lam[0], lo.u, pv, t_lo);
 #pragma unroll
-                for (int j = 0; j < N; ++j) d_lo[j] = -V[j];                     // fsallast
-                // Gauss nodes t_g = mid + half*x, half = (t_lo - t_hi)/2 < 0; theta along the adjoint step = (1 + x)/2
+            for (int j = 0; j < N; ++j) d_lo[j] = -V[j];                     // fsallast
+            // Gauss nodes t_g = mid + half*x, half = (t_lo - t_hi)/2 < 0; theta along the adjoint step = (1 + x)/2
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const double x = q == 0 ? -xg : xg;
-                    const double th = 0.5 * (1.0 + x);
-                    double lg[N], yg[N], W[NP];
-                    hermite<N>(th, -dt, lam_hi, d_hi, lam[0], d_lo, lg);
-                    hermite<N>(1.0 - th, dt, lo.u, lo.f, hi.u, hi.f, yg);
-                    Mo::vjp_p(W, lg, yg, pv, t_hi - th * dt);
+            for (int q = 0; q < 2; ++q) {
+                const double x = q == 0 ? -xg : xg;
+                const double th = 0.5 * (1.0 + x);
+                double lg[N], yg[N], W[NP];
+                hermite<N>(th, -dt, lam_hi, d_hi, lam[0], d_lo, lg);
+                hermite<N>(1.0 - th, dt, lo.u, lo.f, hi.u, hi.f, yg);
+                Mo::vjp_p(W, lg, yg, pv, t_hi - th * dt);
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) mu[0][j] += (0.5 * dt) * W[j];
-                }
-                const int s = save_of_knot[k];
-                if (s >= 0 && !(g.no_start && s == 0)) {
-                    double gl[N]; loss_grad<Mo>(g, i, s, cotT, lo.u, gl);
-#pragma unroll
-                    for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
-                }
-                hi = lo;
+                for (int j = 0; j < NP; ++j) mu[0][j] += (0.5 * dt) * W[j];
             }
-        }
-    }
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        });
 #pragma unroll
     for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
 #pragma unroll
@@ -384,7 +445,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, c
 //   adj[k] = ( lam_start (post-jump at k+1), dlam_start, lam_end (pre-jump at k), dlam_end )   4N doubles
 // laid out [step][2N pairs][Npad]  (src/quadrature_adjoint.jl:527-530 save_everystep = true).
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int PF>
+template <class Mo, int PF, int LOSS>
 HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
                              const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                              dbl2* __restrict__ adj, double (&lamo)[Mo::N]) {
@@ -396,43 +457,26 @@ HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p
 #pragma unroll
     for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
     const double dt = g.dt;
-    Knot<Mo> hi; load_knot<Mo>(knots, g.Npad, g.S, i, hi);
-    { const int s = save_of_knot[g.S];
-      if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, hi.u, gl);
+    reverse_sweep<Mo, PF, LOSS>(g, i, 0, g.S, knots, cotT, save_of_knot,
+        [&](bool jump, const double (&gl)[N]) {
 #pragma unroll
-          for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; } }
-    Knot<Mo> ring[PF];
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        },
+        [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
+            const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
+            double rec[4 * N], V[N];
+            Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
 #pragma unroll
-    for (int r = 0; r < PF; ++r) { const int kk = g.S - 1 - r; load_knot<Mo>(knots, g.Npad, kk > 0 ? kk : 0, i, ring[r]); }
-    for (int kb = g.S - 1; kb >= 0; kb -= PF) {
+            for (int j = 0; j < N; ++j) { rec[j] = lam[0][j]; rec[N + j] = -V[j]; }
+            adj_rk4_step<Mo, 1, false>(hi, lo, pv, t_lo, dt, lam, mu);
+            Mo::vjp_u(V, lam[0], lo.u, pv, t_lo);
 #pragma unroll
-        for (int r = 0; r < PF; ++r) {
-            const int k = kb - r;
-            if (k >= 0) {
-                const Knot<Mo> lo = ring[r];
-                const int kn = k - PF;
-                load_knot<Mo>(knots, g.Npad, kn > 0 ? kn : 0, i, ring[r]);
-                const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
-                double rec[4 * N], V[N];
-                Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
+            for (int j = 0; j < N; ++j) { rec[2 * N + j] = lam[0][j]; rec[3 * N + j] = -V[j]; }
 #pragma unroll
-                for (int j = 0; j < N; ++j) { rec[j] = lam[0][j]; rec[N + j] = -V[j]; }
-                adj_rk4_step<Mo, 1, false>(hi, lo, pv, t_lo, dt, lam, mu);
-                Mo::vjp_u(V, lam[0], lo.u, pv, t_lo);
+            for (int j = 0; j < 2 * N; ++j) { dbl2 d; d.x = rec[2 * j]; d.y = rec[2 * j + 1]; adj[((long)k * 2 * N + j) * g.Npad + i] = d; }
 #pragma unroll
-                for (int j = 0; j < N; ++j) { rec[2 * N + j] = lam[0][j]; rec[3 * N + j] = -V[j]; }
-#pragma unroll
-                for (int j = 0; j < 2 * N; ++j) { dbl2 d; d.x = rec[2 * j]; d.y = rec[2 * j + 1]; adj[((long)k * 2 * N + j) * g.Npad + i] = d; }
-                const int s = save_of_knot[k];
-                if (s >= 0 && !(g.no_start && s == 0)) {
-                    double gl[N]; loss_grad<Mo>(g, i, s, cotT, lo.u, gl);
-#pragma unroll
-                    for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
-                }
-                hi = lo;
-            }
-        }
-    }
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        });
 #pragma unroll
     for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
 }

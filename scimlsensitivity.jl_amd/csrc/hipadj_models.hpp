@@ -12,6 +12,14 @@
 #else
 #define HIPADJ_HD inline
 #endif
+// Scheduling fence between unrolled RK4 steps (device code only): stops hipcc from hoisting the lambda-independent
+// part of LATER steps (Hermite midpoints of knots that are still in flight) above the current step, which would
+// turn the counted `s_waitcnt vmcnt(N)` of the software prefetch into a full drain once per block.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HIPADJ_STEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HIPADJ_STEP_FENCE() ((void)0)
+#endif
 
 namespace hipadj {
 

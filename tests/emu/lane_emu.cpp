@@ -15,7 +15,7 @@
 
 using namespace hipadj;
 
-template <class Mo>
+template <class Mo, int LOSS>
 static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
                double* du0, double* dp, double* out) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, PF = 8;
@@ -39,12 +39,12 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
             if (seg == P.nseg - 1) {
                 double lam[1][N], mu[1][NP];
-                interp_lane<Mo, 1, PF>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                interp_lane<Mo, 1, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
                 for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
                 for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
             } else {
                 double lam[NC][N], mu[NC][NP];
-                interp_lane<Mo, NC, PF>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                interp_lane<Mo, NC, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
                 for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
             }
@@ -79,7 +79,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     case HIPADJ_ALG_GAUSS:
         for (long i = 0; i < P.N; ++i) {
             double lam[N], mu[NP];
-            gauss_lane<Mo, PF>(g, i, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+            gauss_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
             for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
             for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
         }
@@ -89,12 +89,12 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         const double atol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, rtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
         for (long i = 0; i < P.N; ++i) {
             double lam[N];
-            quad_adj_lane<Mo, PF>(g, i, p, knots.data(), cot, P.save_of_knot.data(), adj.data(), lam);
+            quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot.data(), adj.data(), lam);
             for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
             double acc[NP]; for (int j = 0; j < NP; ++j) acc[j] = 0.0;
             for (int q = 0; q < P.nq; ++q) {
                 double res[NP];
-                quad_gk_lane<Mo, 32>(g, i, p, knots.data(), adj.data(), P.qa[q], P.qb[q], atol, rtol, res);
+                quad_gk_lane<Mo, 128>(g, i, p, knots.data(), adj.data(), P.qa[q], P.qb[q], atol, rtol, res);
                 for (int j = 0; j < NP; ++j) acc[j] += res[j];
             }
             for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = acc[j];
@@ -121,11 +121,11 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
                                    double* du0, double* dp, double* out) {
     Plan P; const int rc = make_plan(cfg, P, g_err); if (rc) return rc;
     switch (cfg->model) {
-    case HIPADJ_MODEL_LV: return run<ModelLV>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_LVT: return run<ModelLVT>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_LORENZ: return run<ModelLorenz>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_LINDIAG: return run<ModelLinDiag>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_FALLMASS: return run<ModelFallMass>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LV: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelLV, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelLV, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LVT: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelLVT, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelLVT, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LORENZ: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelLorenz, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelLorenz, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LINDIAG: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelLinDiag, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelLinDiag, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_FALLMASS: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelFallMass, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelFallMass, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

@@ -1,0 +1,89 @@
+"""CPU-side check of the DEVICE arithmetic: the lane bodies of scimlsensitivity.jl_amd/csrc/hipadj_lane.hpp,
+compiled for the host by tests/emu/lane_emu.cpp (test-only, never shipped), against the oracle on identical
+seeded inputs.  This is not the parity gate (that is tests/test_gpu_parity.py through the C ABI on an MI355X);
+it lets the GPU-less container catch arithmetic regressions in the kernels' source."""
+import numpy as np
+import pytest
+
+import emu as E
+import oracle as O
+
+MODELS = [("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]), ("lvt", "LVT", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]),
+          ("lorenz", "LORENZ", [1.0, 0.0, 0.0], [10.0, 28.0, 8 / 3]), ("lindiag", "LINDIAG", [1.0, 1.0], [1.0, 2.0]),
+          ("fallmass", "FALLMASS", [1.0, 0.0], [9.81, 1.0])]
+ALGS = ["interpolating", "backsolve", "gauss", "quadrature"]
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("model,omodel,u0c,p", MODELS)
+def test_lane_bodies_match_oracle_cotangent(alg, model, omodel, u0c, p):
+    rng = np.random.default_rng(4)
+    N, T, dt = 5, 1.5, 0.01
+    n, npar = len(u0c), len(p)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.03 * rng.standard_normal((N, npar)))
+    ts = np.arange(0, T + 1e-9, 0.1)
+    delta = rng.standard_normal((N, len(ts), n))
+    cfg = E.make_config(model, alg, N, 0.0, T, dt, ts, loss_kind=0, checkpointing=(alg == "backsolve"), p_shared=False)
+    du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+    ref = O.Problem(omodel, alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT",
+                    checkpointing=(alg == "backsolve"))
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+@pytest.mark.parametrize("segments", [1, 2, 3, 9, 33])
+def test_time_segmented_composition_equals_sequential(segments):
+    rng = np.random.default_rng(8)
+    N, T, dt = 3, 3.0, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.linspace(0, T, 31)
+    cfg = E.make_config("lorenz", "interpolating", N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, time_segments=segments)
+    du0, dp, _ = E.forward_adjoint(cfg, 3, 3, u0, p)
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < 1e-11 and rel(dp, rdp) < 1e-11
+
+
+def test_edge_cases_no_save_times_single_step_and_no_start():
+    u0 = np.array([[1.0, 1.0]]); p = np.array([1.5, 1.0, 3.0, 1.0])
+    # one RK4 step, loss at both ends, no_start drops the t0 jump
+    for ns in (False, True):
+        cfg = E.make_config("lv", "interpolating", 1, 0.0, 0.1, 0.1, [0.0, 0.1], loss_kind=1, loss_shift=2.0, no_start=ns)
+        du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
+        ref = O.Problem("LV", alg="INTERPOLATING", stepper="RK4", t0=0, t1=0.1, dt=0.1, save_times=[0.0, 0.1], loss="LSQ_SHIFT", loss_shift=2.0, no_start=ns)
+        rdu0, rdp, _ = ref.adjoint(u0[0], p)
+        assert rel(du0[0], rdu0) < 1e-13 and rel(dp, rdp) < 1e-13
+    # no loss times at all: gradient is exactly zero (empty input)
+    cfg = E.make_config("lv", "gauss", 1, 0.0, 1.0, 0.1, [], loss_kind=1, loss_shift=2.0)
+    du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
+    assert np.all(du0 == 0) and np.all(dp == 0)
+
+
+def test_backsolve_checkpoint_layouts():
+    rng = np.random.default_rng(1)
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((2, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.linspace(0, 1, 11)
+    for ck, stride, cks in ((True, 0, None), (True, 25, np.arange(0, 101, 25) * 0.01), (False, 0, None)):
+        cfg = E.make_config("lorenz", "backsolve", 2, 0.0, 1.0, 0.01, ts, loss_kind=1, loss_shift=2.0, checkpointing=ck, ckpt_stride=stride)
+        du0, dp, _ = E.forward_adjoint(cfg, 3, 3, u0, p)
+        ref = O.Problem("LORENZ", alg="BACKSOLVE", stepper="RK4", t0=0, t1=1.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0,
+                        checkpointing=ck, checkpoints=cks)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+        assert rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+def test_quadrature_adaptive_bisection_matches_oracle_at_tight_tolerance():
+    """coarse dt makes the integrand kinky => GK15 bisects; device and oracle must take the same decisions."""
+    u0 = np.array([[1.0, 0.0, 0.0]]); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.array([0.0, 1.0, 2.0])
+    cfg = E.make_config("lorenz", "quadrature", 1, 0.0, 2.0, 0.05, ts, loss_kind=1, loss_shift=2.0, quad_abstol=1e-12, quad_reltol=1e-12)
+    du0, dp, _ = E.forward_adjoint(cfg, 3, 3, u0, p)
+    ref = O.Problem("LORENZ", alg="QUADRATURE", stepper="RK4", t0=0, t1=2.0, dt=0.05, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0,
+                    quad_abstol=1e-12, quad_reltol=1e-12)
+    rdu0, rdp, _ = ref.adjoint(u0[0], p)
+    assert rel(dp, rdp) < 1e-9
