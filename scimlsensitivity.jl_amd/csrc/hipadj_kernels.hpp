@@ -108,24 +108,39 @@ __global__ void __launch_bounds__(FIN) k_compose_finish(Geom g, int nseg, const 
           for (int j = 0; j < N; ++j) lam[j] = src[(long)j * g.Npad];
 #pragma unroll
           for (int j = 0; j < NP; ++j) mu[j] = src[(long)(N + j) * g.Npad]; }
-        for (int s = nseg - 2; s >= 0; --s) {
-            const double* __restrict__ src = segbuf + (long)s * NC * R * g.Npad + i;
-            double nl[N], nm[NP];
+        // The composition is a short dependent chain per segment, but each segment's map is a fresh set of loads:
+        // fetch CH segments' maps at once (independent loads in flight together), then compose them in order.
+        constexpr int CH = 4;
+        for (int sb = nseg - 2; sb >= 0; sb -= CH) {
+            double m[CH][NC * R];
 #pragma unroll
-            for (int j = 0; j < N; ++j) nl[j] = src[(long)j * g.Npad];
+            for (int q = 0; q < CH; ++q) {
+                const int sq = sb - q > 0 ? sb - q : 0;
+                const double* __restrict__ src = segbuf + (long)sq * NC * R * g.Npad + i;
 #pragma unroll
-            for (int j = 0; j < NP; ++j) nm[j] = mu[j] + src[(long)(N + j) * g.Npad];
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) nl[j] += src[((long)(c + 1) * R + j) * g.Npad] * lam[c];
-#pragma unroll
-                for (int j = 0; j < NP; ++j) nm[j] += src[((long)(c + 1) * R + N + j) * g.Npad] * lam[c];
+                for (int e = 0; e < NC * R; ++e) m[q][e] = src[(long)e * g.Npad];
             }
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[j] = nl[j];
+            for (int q = 0; q < CH; ++q) {
+                if (sb - q >= 0) {
+                    double nl[N], nm[NP];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) mu[j] = nm[j];
+                    for (int j = 0; j < N; ++j) nl[j] = m[q][j];
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) nm[j] = mu[j] + m[q][N + j];
+#pragma unroll
+                    for (int c = 0; c < N; ++c) {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) nl[j] += m[q][(c + 1) * R + j] * lam[c];
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) nm[j] += m[q][(c + 1) * R + N + j] * lam[c];
+                    }
+#pragma unroll
+                    for (int j = 0; j < N; ++j) lam[j] = nl[j];
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) mu[j] = nm[j];
+                }
+            }
         }
         bool bad = false;
 #pragma unroll

@@ -9,7 +9,7 @@ cd $REPO
 echo "== smoke" ; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -8
 echo "== pytest -m gpu" ; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
 echo "== bench" ; timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err ; tail -3 $OUT/bench.err ; cat $OUT/bench.json
-for seg in 1 4 8 13 20 32; do
+for seg in 1 6 13; do
   echo "== bench segments=$seg" ; timeout 300 python bench.py --no-cpu-baseline --segments $seg --steps 30 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['achieved'])"
 done
 cd /tmp ; export TMPDIR=/tmp

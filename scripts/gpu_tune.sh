@@ -11,6 +11,12 @@ echo "== sweep"
 for w in 2.0 2.8 3.5 4.5; do for seg in 6 12 13; do HIPADJ_WTOP=$w one $seg; done; done
 one 1; one 0
 cd /tmp ; export TMPDIR=/tmp
+echo "== kernel trace (auto segments)"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $REPO/bench.py --no-cpu-baseline --steps 20 > /dev/null 2> $OUT/prof.err
+f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1) ; [ -n "$f" ] && python -c "
+import csv,sys
+for r in list(csv.DictReader(open('$f')))[:8]: print(r['Name'][:58].ljust(58), r['Calls'], r['AverageNs'], r['Percentage'])
+"
 for seg in 1 13; do
   echo "== SQ counters segments=$seg"
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq_$seg -o pmc -- python $REPO/bench.py --no-cpu-baseline --segments $seg --steps 5 --warmup 1 > /dev/null 2> $OUT/sq_$seg.err
