@@ -23,7 +23,12 @@ struct hipadj_handle {
     int S = 0, M = 0, nck = 0, nseg = 1, nq = 0;
     Geom g{};
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fwd begin/end, adj begin/end, main-kernel begin/end
+    hipEvent_t ev[2] = {nullptr, nullptr};            // forward begin/end
+    // adjoint timing: a ring of event sets harvested with hipEventQuery, so that back-to-back asynchronous
+    // calls never block the host on the previous call (a blocking harvest serialises launch and execution)
+    static constexpr int NSET = 16;
+    struct EvSet { hipEvent_t a0 = nullptr, a1 = nullptr, k0 = nullptr, k1 = nullptr; bool pending = false; } evs[NSET];
+    int ev_next = 0;
     std::vector<double> save_times;
     std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
     // device workspaces (owned)
@@ -33,7 +38,7 @@ struct hipadj_handle {
     dbl2 *d_knots = nullptr, *d_adj = nullptr;
     int *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
-    bool have_forward = false, timing_pending_fwd = false, timing_pending_adj = false;
+    bool have_forward = false, timing_pending_fwd = false;
     double ws_bytes = 0;
     hipadj_stats st{};
     std::string err;
@@ -81,6 +86,7 @@ static void free_all(hipadj_handle* h) {
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -105,6 +111,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (!HT(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking), "hipStreamCreate")) return fail(HIPADJ_ERR_HIP);
     h->stream = h->own_stream;
     for (auto& e : h->ev) if (!HT(hipEventCreate(&e), "hipEventCreate")) return fail(HIPADJ_ERR_HIP);
+    for (auto& q : h->evs) for (hipEvent_t* e : {&q.a0, &q.a1, &q.k0, &q.k1}) if (!HT(hipEventCreate(e), "hipEventCreate")) return fail(HIPADJ_ERR_HIP);
 
     const long Np = h->Npad;
     int rc = HIPADJ_OK;
@@ -175,26 +182,29 @@ extern "C" int hipadj_set_stream(hipadj_handle* h, void* s) {
     return HIPADJ_OK;
 }
 
-static void harvest_timing(hipadj_handle* h) {
+static void harvest_set(hipadj_handle* h, hipadj_handle::EvSet& q, bool block) {
+    if (!q.pending) return;
+    if (block) { if (hipEventSynchronize(q.a1) != hipSuccess) { q.pending = false; return; } }
+    else if (hipEventQuery(q.a1) != hipSuccess) return;           // still running: look again later
     float ms = 0.f;
-    if (h->timing_pending_fwd) {
-        if (hipEventSynchronize(h->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) { h->st.forward_ms_last = ms; h->st.forward_ms_total += ms; }
+    if (hipEventElapsedTime(&ms, q.a0, q.a1) == hipSuccess) { h->st.adjoint_ms_last = ms; h->st.adjoint_ms_total += ms; }
+    if (hipEventElapsedTime(&ms, q.k0, q.k1) == hipSuccess) { h->st.adjoint_main_kernel_ms_last = ms; h->st.adjoint_main_kernel_ms_total += ms; }
+    q.pending = false;
+}
+static void harvest_timing(hipadj_handle* h, bool block) {
+    float ms = 0.f;
+    if (h->timing_pending_fwd && (block ? hipEventSynchronize(h->ev[1]) : hipEventQuery(h->ev[1])) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) { h->st.forward_ms_last = ms; h->st.forward_ms_total += ms; }
         h->timing_pending_fwd = false;
     }
-    if (h->timing_pending_adj) {
-        if (hipEventSynchronize(h->ev[3]) == hipSuccess) {
-            if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) { h->st.adjoint_ms_last = ms; h->st.adjoint_ms_total += ms; }
-            if (hipEventElapsedTime(&ms, h->ev[4], h->ev[5]) == hipSuccess) { h->st.adjoint_main_kernel_ms_last = ms; h->st.adjoint_main_kernel_ms_total += ms; }
-        }
-        h->timing_pending_adj = false;
-    }
+    for (int j = 0; j < hipadj_handle::NSET; ++j) harvest_set(h, h->evs[(h->ev_next + j) % hipadj_handle::NSET], block);   // oldest first
 }
 
 extern "C" int hipadj_synchronize(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    harvest_timing(h);
+    harvest_timing(h, true);
     int flag = 0;
     HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
@@ -243,8 +253,11 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;   // per-trajectory dp rows [N][np]
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
-    HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
-    hipEvent_t k0 = h->ev[4], k1 = h->ev[5];   // dominant-kernel bracket
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);                   // ring full: only now wait for the oldest call
+    HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
     HIP_TRY(h, hipEventRecord(k0, h->stream));
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: {
@@ -257,13 +270,17 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                            d_du0, dp_rows, h->d_partial, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         break; }
-    case HIPADJ_ALG_BACKSOLVE:
-        hipLaunchKernelGGL((k_backsolve<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const double*)h->d_yT,
+    case HIPADJ_ALG_BACKSOLVE: {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        hipLaunchKernelGGL((k_backsolve<Mo>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
                            (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
-                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj);
+                           (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
-        break;
+        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(fblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                           d_du0, dp_rows, h->d_partial, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        break; }
     case HIPADJ_ALG_GAUSS:
         hipLaunchKernelGGL((k_gauss<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
                            (const double*)h->d_cotT, (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj);
@@ -284,7 +301,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         break; }
     }
     // finishing stage: NaN/Inf scan + per-workgroup partial sums of mu (Interpolating fused it with the composition)
-    if (h->cfg.alg != HIPADJ_ALG_INTERPOLATING) {
+    if (h->cfg.alg != HIPADJ_ALG_INTERPOLATING && h->cfg.alg != HIPADJ_ALG_BACKSOLVE) {
         hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
                            (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag);
         HIP_TRY(h, hipGetLastError());
@@ -293,8 +310,8 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
         HIP_TRY(h, hipGetLastError());
     }
-    HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
-    h->timing_pending_adj = true;
+    HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = true;
     return HIPADJ_OK;   // timings are harvested lazily at the next synchronize / call
 }
 
@@ -322,7 +339,7 @@ extern "C" int hipadj_forward_dev(hipadj_handle* h, const double* d_u0, const do
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!d_u0 || !d_p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    harvest_timing(h);
+    harvest_timing(h, false);
     // keep private copies: the adjoint needs p, and u0 may be released by the caller
     const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
     if (d_p != h->d_p) HIP_TRY(h, hipMemcpyAsync(h->d_p, d_p, pb, hipMemcpyDeviceToDevice, h->stream));
@@ -340,7 +357,7 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
     if (!d_du0 || !d_dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !d_dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    harvest_timing(h);
+    harvest_timing(h, false);
     TRY(adjoint_dispatch(h, d_dLdu, d_du0, d_dp));
     h->st.adjoint_calls++;
     return HIPADJ_OK;

@@ -185,20 +185,36 @@ __global__ void __launch_bounds__(FIN) k_reduce_final(int nblocks, int np, const
     if (threadIdx.x == 0) dp[j] = sh[0];
 }
 
+// BacksolveAdjoint, segmented at checkpoint knots; writes the segment maps like k_interp
 template <class Mo>
-__global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, const double* __restrict__ p, const double* __restrict__ yT,
+__global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ yT,
                                                     const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
                                                     const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                                                    double* __restrict__ du0, double* __restrict__ dp_traj) {
-    constexpr int N = Mo::N, NP = Mo::NP;
+                                                    double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;
     if (i >= g.N) return;
-    double lam[N], mu[NP];
-    backsolve_lane<Mo>(g, i, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
+    if (seg == sp.nseg - 1) {
+        double lam[1][N], mu[1][NP];
+        backsolve_lane<Mo, 1>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
 #pragma unroll
-    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+        for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
+        for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
+    } else {
+        double lam[NC][N], mu[NC][NP];
+        backsolve_lane<Mo, NC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) dst[((long)c * R + j) * g.Npad] = lam[c][j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * g.Npad] = mu[c][j];
+        }
+    }
 }
 
 template <class Mo, int PF, int LOSS>

@@ -318,51 +318,76 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
 // (possibly just overwritten) backsolved y  (src/adjoint_common.jl:765-767; callback order
 // CallbackSet(checkpoint, loss) src/backsolve_adjoint.jl:545).
 // ------------------------------------------------------------------------------------------------
-template <class Mo>
-HIPADJ_HD void backsolve_lane(const Geom& g, long i, const double* __restrict__ p, const double* __restrict__ yT,
-                              const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
-                              const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                              double (&lam)[Mo::N], double (&mu)[Mo::NP]) {
+// Time segmentation: y is re-initialised from the stored forward value at every checkpoint, so a segment whose
+// upper end k_hi is a checkpoint knot (or T) knows its y without the segments above it; (lam, mu) are linear given
+// y, so NC = 1 + N columns carry the segment's affine map exactly as in interp_lane.
+template <class Mo, int NC>
+HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p,
+                              const double* __restrict__ yT, const double* __restrict__ ckpt,
+                              const int* __restrict__ ckpt_of_knot, const double* __restrict__ cotT,
+                              const int* __restrict__ save_of_knot, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
     constexpr int N = Mo::N, NP = Mo::NP;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
     double y[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) { lam[j] = 0.0; y[j] = yT[(long)j * g.Npad + i]; }
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) mu[j] = 0.0;
+        for (int j = 0; j < N; ++j) lam[c][j] = (c > 0 && c - 1 == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
+    }
+    if (k_hi == g.S) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) y[j] = yT[(long)j * g.Npad + i];
+        const int s = save_of_knot[g.S];
+        if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, y, gl);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; }
+    } else {
+        const int c0 = ckpt_of_knot[k_hi];      // the planner only cuts segments at checkpoint knots
+#pragma unroll
+        for (int j = 0; j < N; ++j) y[j] = ckpt[((long)c0 * N + j) * g.Npad + i];
+    }
     const double dt = g.dt;
-    { const int s = save_of_knot[g.S];
-      if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, y, gl);
-#pragma unroll
-          for (int j = 0; j < N; ++j) lam[j] += gl[j]; } }
-    for (int k = g.S - 1; k >= 0; --k) {
+    for (int k = k_hi - 1; k >= k_lo; --k) {
         const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
-        double F1[N], F2[N], F3[N], F4[N], Y[N], ls[N];
-        double V1[N], V2[N], V3[N], V4[N], W[NP], Wacc[NP];
-        // stage 1 at t_hi
-        Mo::f(F1, y, pv, t_hi); Mo::vjp_u(V1, lam, y, pv, t_hi); Mo::vjp_p(Wacc, lam, y, pv, t_hi);
+        double F1[N], F2[N], F3[N], F4[N], Y2[N], Y3[N], Y4[N];
+        Mo::f(F1, y, pv, t_hi);
 #pragma unroll
-        for (int j = 0; j < N; ++j) { Y[j] = y[j] - (0.5 * dt) * F1[j]; ls[j] = lam[j] + (0.5 * dt) * V1[j]; }
-        Mo::f(F2, Y, pv, t_mid); Mo::vjp_u(V2, ls, Y, pv, t_mid); Mo::vjp_p(W, ls, Y, pv, t_mid);
+        for (int j = 0; j < N; ++j) Y2[j] = y[j] - (0.5 * dt) * F1[j];
+        Mo::f(F2, Y2, pv, t_mid);
 #pragma unroll
-        for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+        for (int j = 0; j < N; ++j) Y3[j] = y[j] - (0.5 * dt) * F2[j];
+        Mo::f(F3, Y3, pv, t_mid);
 #pragma unroll
-        for (int j = 0; j < N; ++j) { Y[j] = y[j] - (0.5 * dt) * F2[j]; ls[j] = lam[j] + (0.5 * dt) * V2[j]; }
-        Mo::f(F3, Y, pv, t_mid); Mo::vjp_u(V3, ls, Y, pv, t_mid); Mo::vjp_p(W, ls, Y, pv, t_mid);
+        for (int j = 0; j < N; ++j) Y4[j] = y[j] - dt * F3[j];
+        Mo::f(F4, Y4, pv, t_lo);
 #pragma unroll
-        for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+        for (int c = 0; c < NC; ++c) {
+            double ls[N], V1[N], V2[N], V3[N], V4[N], W[NP], Wacc[NP];
+            Mo::vjp_u(V1, lam[c], y, pv, t_hi); Mo::vjp_p(Wacc, lam[c], y, pv, t_hi);
 #pragma unroll
-        for (int j = 0; j < N; ++j) { Y[j] = y[j] - dt * F3[j]; ls[j] = lam[j] + dt * V3[j]; }
-        Mo::f(F4, Y, pv, t_lo); Mo::vjp_u(V4, ls, Y, pv, t_lo); Mo::vjp_p(W, ls, Y, pv, t_lo);
+            for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V1[j];
+            Mo::vjp_u(V2, ls, Y2, pv, t_mid); Mo::vjp_p(W, ls, Y2, pv, t_mid);
 #pragma unroll
-        for (int j = 0; j < NP; ++j) Wacc[j] += W[j];
+            for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            y[j] = y[j] - (dt / 6.0) * (F1[j] + 2.0 * (F2[j] + F3[j]) + F4[j]);
-            lam[j] = lam[j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+            for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V2[j];
+            Mo::vjp_u(V3, ls, Y3, pv, t_mid); Mo::vjp_p(W, ls, Y3, pv, t_mid);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+#pragma unroll
+            for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + dt * V3[j];
+            Mo::vjp_u(V4, ls, Y4, pv, t_lo); Mo::vjp_p(W, ls, Y4, pv, t_lo);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) Wacc[j] += W[j];
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[c][j] = lam[c][j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[c][j] = mu[c][j] + (dt / 6.0) * Wacc[j];
         }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) mu[j] = mu[j] + (dt / 6.0) * Wacc[j];
+        for (int j = 0; j < N; ++j) y[j] = y[j] - (dt / 6.0) * (F1[j] + 2.0 * (F2[j] + F3[j]) + F4[j]);
         if (ckpt) { const int c = ckpt_of_knot[k]; if (c >= 0) {
 #pragma unroll
             for (int j = 0; j < N; ++j) y[j] = ckpt[((long)c * N + j) * g.Npad + i]; } }
@@ -370,7 +395,7 @@ HIPADJ_HD void backsolve_lane(const Geom& g, long i, const double* __restrict__ 
         if (s >= 0) {
             double gl[N]; loss_grad<Mo>(g, i, s, cotT, y, gl);
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[j] += gl[j];
+            for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
         }
     }
 }

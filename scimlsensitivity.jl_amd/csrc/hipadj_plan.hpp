@@ -95,7 +95,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         P.nck = c;
     }
     P.nseg = 1;
-    if (cfg->alg == HIPADJ_ALG_INTERPOLATING) {
+    const bool seg_alg = cfg->alg == HIPADJ_ALG_INTERPOLATING || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt);
+    if (seg_alg) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n) : cfg->time_segments;
         if (P.nseg > P.S) P.nseg = P.S;
         if (P.nseg < 1) P.nseg = 1;
@@ -113,6 +114,20 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
             P.seg_bounds[C] = (int)S;
             for (int s = C - 1; s >= 1; --s) if (P.seg_bounds[s] >= P.seg_bounds[s + 1]) P.seg_bounds[s] = P.seg_bounds[s + 1] - 1;
         }
+    }
+    if (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.nseg > 1) {
+        // Backsolve segments may only be cut where y is known independently of the segments above: at checkpoint
+        // knots.  Snap every interior bound to the nearest checkpoint knot and drop duplicates.
+        std::vector<int> ck;
+        for (int k = 1; k < (int)S; ++k) if (P.ckpt_of_knot[k] >= 0) ck.push_back(k);
+        std::vector<int> b; b.push_back(0);
+        for (int s = 1; s < P.nseg; ++s) {
+            int best = -1; long bd = 0;
+            for (int k : ck) { const long d = std::labs((long)k - P.seg_bounds[s]); if (best < 0 || d < bd) { best = k; bd = d; } }
+            if (best > b.back()) b.push_back(best);
+        }
+        b.push_back((int)S);
+        P.seg_bounds = b; P.nseg = (int)b.size() - 1;
     }
     P.qa.clear(); P.qb.clear();
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {

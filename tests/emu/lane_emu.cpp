@@ -15,6 +15,30 @@
 
 using namespace hipadj;
 
+template <class Mo>
+static void compose(const Plan& P, const std::vector<double>& segbuf, double* du0, std::vector<double>& dp_traj) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    const long Np = P.Npad;
+        for (long i = 0; i < P.N; ++i) {       // k_compose
+            double lam[N], mu[NP];
+            const double* src = segbuf.data() + (size_t)(P.nseg - 1) * NC * R * Np + i;
+            for (int j = 0; j < N; ++j) lam[j] = src[(size_t)j * Np];
+            for (int j = 0; j < NP; ++j) mu[j] = src[(size_t)(N + j) * Np];
+            for (int s = P.nseg - 2; s >= 0; --s) {
+                src = segbuf.data() + (size_t)s * NC * R * Np + i;
+                double nl[N], nm[NP];
+                for (int j = 0; j < N; ++j) nl[j] = src[(size_t)j * Np];
+                for (int j = 0; j < NP; ++j) nm[j] = mu[j] + src[(size_t)(N + j) * Np];
+                for (int c = 0; c < N; ++c) { for (int j = 0; j < N; ++j) nl[j] += src[((size_t)(c + 1) * R + j) * Np] * lam[c];
+                                              for (int j = 0; j < NP; ++j) nm[j] += src[((size_t)(c + 1) * R + N + j) * Np] * lam[c]; }
+                for (int j = 0; j < N; ++j) lam[j] = nl[j];
+                for (int j = 0; j < NP; ++j) mu[j] = nm[j];
+            }
+            for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+            for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
+        }
+}
+
 template <class Mo, int LOSS>
 static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
                double* du0, double* dp, double* out) {
@@ -49,33 +73,27 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
             }
         }
-        for (long i = 0; i < P.N; ++i) {       // k_compose
-            double lam[N], mu[NP];
-            const double* src = segbuf.data() + (size_t)(P.nseg - 1) * NC * R * Np + i;
-            for (int j = 0; j < N; ++j) lam[j] = src[(size_t)j * Np];
-            for (int j = 0; j < NP; ++j) mu[j] = src[(size_t)(N + j) * Np];
-            for (int s = P.nseg - 2; s >= 0; --s) {
-                src = segbuf.data() + (size_t)s * NC * R * Np + i;
-                double nl[N], nm[NP];
-                for (int j = 0; j < N; ++j) nl[j] = src[(size_t)j * Np];
-                for (int j = 0; j < NP; ++j) nm[j] = mu[j] + src[(size_t)(N + j) * Np];
-                for (int c = 0; c < N; ++c) { for (int j = 0; j < N; ++j) nl[j] += src[((size_t)(c + 1) * R + j) * Np] * lam[c];
-                                              for (int j = 0; j < NP; ++j) nm[j] += src[((size_t)(c + 1) * R + N + j) * Np] * lam[c]; }
-                for (int j = 0; j < N; ++j) lam[j] = nl[j];
-                for (int j = 0; j < NP; ++j) mu[j] = nm[j];
-            }
-            for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
-            for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
-        }
+        compose<Mo>(P, segbuf, du0, dp_traj);
         break; }
-    case HIPADJ_ALG_BACKSOLVE:
-        for (long i = 0; i < P.N; ++i) {
-            double lam[N], mu[NP];
-            backsolve_lane<Mo>(g, i, p, yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
-            for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
-            for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
+    case HIPADJ_ALG_BACKSOLVE: {
+        std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
+        const double* ck = ckpt.empty() ? nullptr : ckpt.data();
+        for (int seg = 0; seg < P.nseg; ++seg) for (long i = 0; i < P.N; ++i) {
+            double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
+            if (seg == P.nseg - 1) {
+                double lam[1][N], mu[1][NP];
+                backsolve_lane<Mo, 1>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
+                for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
+                for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
+            } else {
+                double lam[NC][N], mu[NC][NP];
+                backsolve_lane<Mo, NC>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
+                for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
+                                               for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
+            }
         }
-        break;
+        compose<Mo>(P, segbuf, du0, dp_traj);
+        break; }
     case HIPADJ_ALG_GAUSS:
         for (long i = 0; i < P.N; ++i) {
             double lam[N], mu[NP];

@@ -87,3 +87,20 @@ def test_quadrature_adaptive_bisection_matches_oracle_at_tight_tolerance():
                     quad_abstol=1e-12, quad_reltol=1e-12)
     rdu0, rdp, _ = ref.adjoint(u0[0], p)
     assert rel(dp, rdp) < 1e-9
+
+
+@pytest.mark.parametrize("segments,stride", [(1, 0), (3, 0), (7, 0), (4, 25), (50, 0)])
+def test_backsolve_segmented_at_checkpoints_equals_sequential(segments, stride):
+    """y restarts from the stored value at every checkpoint => checkpoint-aligned segments are independent."""
+    rng = np.random.default_rng(12)
+    N, T, dt = 3, 2.0, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.linspace(0, T, 21)
+    cks = None if stride == 0 else np.arange(0, 201, stride) * dt
+    cfg = E.make_config("lorenz", "backsolve", N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, checkpointing=True,
+                        ckpt_stride=stride, time_segments=segments)
+    du0, dp, _ = E.forward_adjoint(cfg, 3, 3, u0, p)
+    ref = O.Problem("LORENZ", alg="BACKSOLVE", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0,
+                    checkpointing=True, checkpoints=cks)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10

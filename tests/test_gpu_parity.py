@@ -94,6 +94,20 @@ def test_time_segmentation_is_invisible(sa, segments):
     sol.engine.close()
 
 
+@pytest.mark.parametrize("segments", [1, 5, 0])
+def test_backsolve_segmented_at_checkpoints(sa, segments):
+    N, T, dt = 100, 4.0, 0.01
+    u0, p = lorenz_inputs(N, seed=21)
+    ts = np.linspace(0, T, 41)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sa.BacksolveAdjoint(), dgdu_discrete=sa.LsqShift(2.0), time_segments=segments)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+    ref = O.Problem("LORENZ", alg="BACKSOLVE", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, checkpointing=True)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
 def test_backsolve_checkpoint_stride_and_no_checkpointing(sa):
     N, T, dt = 64, 1.0, 0.01
     u0, p = lorenz_inputs(N, seed=9)
