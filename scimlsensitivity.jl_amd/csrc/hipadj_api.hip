@@ -12,6 +12,7 @@
 
 #include "../../include/hipadj.h"
 #include "hipadj_kernels.hpp"
+#include "hipadj_field.hpp"
 #include "hipadj_plan.hpp"
 
 using namespace hipadj;
@@ -36,6 +37,9 @@ struct hipadj_handle {
     double *d_segbuf = nullptr, *d_dp_traj = nullptr, *d_qres = nullptr, *d_qa = nullptr, *d_qb = nullptr, *d_partial = nullptr;
     double *d_io_a = nullptr, *d_du0 = nullptr, *d_dp = nullptr;   // staging for the host-pointer API
     dbl2 *d_knots = nullptr, *d_adj = nullptr;
+    bool field = false;                   // workgroup-per-trajectory family (BRUSS)
+    double *d_fknots = nullptr, *d_fadj = nullptr;
+    FieldGeom fg{};
     int *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
     bool have_forward = false, timing_pending_fwd = false;
@@ -82,7 +86,7 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
 
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
-                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_save_of_knot,
+                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -118,12 +122,18 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     auto A = [&](int r) { if (rc == HIPADJ_OK) rc = r; };
     A(dev_alloc(h, &h->d_u0, (size_t)h->N * n));
     A(dev_alloc(h, &h->d_p, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
-    A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
-    A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
-    if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));
-    if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
-    if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
-    A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
+    h->field = P.field;
+    if (!h->field) {
+        A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
+        A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
+        if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));
+        if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
+        if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
+        A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
+    } else {
+        A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
+        if (cfg->alg == HIPADJ_ALG_QUADRATURE) A(dev_alloc(h, &h->d_fadj, (size_t)h->N * S * 4 * n));
+    }
     A(dev_alloc(h, &h->d_dp_traj, (size_t)np * Np));
     A(dev_alloc(h, &h->d_partial, (size_t)((h->N + FIN - 1) / FIN) * np));
     A(dev_alloc(h, &h->d_io_a, (size_t)h->N * (h->M > 0 ? h->M : 1) * n));
@@ -135,7 +145,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_flag, 1));
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
-        A(dev_alloc(h, &h->d_adj, (size_t)S * 2 * n * Np));
+        if (!h->field) A(dev_alloc(h, &h->d_adj, (size_t)S * 2 * n * Np));
         A(dev_alloc(h, &h->d_qres, (size_t)h->nq * np * Np));
         A(dev_alloc(h, &h->d_qa, (size_t)h->nq)); A(dev_alloc(h, &h->d_qb, (size_t)h->nq));
     }
@@ -151,6 +161,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     Geom& g = h->g;
     g.N = h->N; g.Npad = Np; g.S = (int)S; g.M = h->M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
+    h->fg.N = h->N; h->fg.S = (int)S; h->fg.M = h->M; h->fg.t0 = cfg->t0; h->fg.dt = cfg->dt; h->fg.loss_shift = cfg->loss_shift;
+    h->fg.loss_kind = cfg->loss_kind; h->fg.no_start = cfg->no_start; h->fg.p_shared = cfg->p_shared;
 
     h->st.struct_size = sizeof(hipadj_stats); h->st.n = n; h->st.np = np; h->st.ntraj = h->N; h->st.nsteps = S;
     h->st.time_segments = h->nseg; h->st.workspace_bytes = h->ws_bytes;
@@ -319,6 +331,70 @@ template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_co
     return h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT ? adjoint_impl_l<Mo, 0>(h, d_cot, d_du0, d_dp) : adjoint_impl_l<Mo, 1>(h, d_cot, d_du0, d_dp);
 }
 
+
+// ---- workgroup-per-trajectory family (Brusselator) -----------------------------------------------------
+template <int G> static int field_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    hipLaunchKernelGGL((k_bruss_forward<G>), dim3((unsigned)h->N), dim3(Bruss<G>::T), 0, h->stream, h->fg, d_u0, d_p, h->d_fknots,
+                       (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+template <int G> static int field_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    const double* p = h->p_dev_last;
+    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
+    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);
+    HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    const dim3 grid((unsigned)h->N), blk(Bruss<G>::T);
+    switch (h->cfg.alg) {
+    case HIPADJ_ALG_INTERPOLATING:
+        hipLaunchKernelGGL((k_bruss_adjoint<G, 0>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        break;
+    case HIPADJ_ALG_GAUSS:
+        hipLaunchKernelGGL((k_bruss_adjoint<G, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        break;
+    case HIPADJ_ALG_QUADRATURE: {
+        hipLaunchKernelGGL((k_bruss_quad_adj<G>), grid, blk, 0, h->stream, h->fg, p, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, h->d_fadj, d_du0, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        hipLaunchKernelGGL((k_bruss_quad_gk<G, 128>), dim3((unsigned)h->N, (unsigned)h->nq), blk, 0, h->stream, h->fg, h->Npad, p,
+                           (const double*)h->d_fknots, (const double*)h->d_fadj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
+        HIP_TRY(h, hipGetLastError());
+        const unsigned waves = (unsigned)(h->Npad / WAVE);
+        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg not available for the PDE family");
+    }
+    hipLaunchKernelGGL((k_finish<0, 3>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
+                       (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag);
+    HIP_TRY(h, hipGetLastError());
+    if (h->cfg.p_shared) {
+        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = true;
+    return HIPADJ_OK;
+}
+#define DISPATCH_GRID(h, fn, ...)                                                          \
+    switch ((h)->cfg.dims[0]) {                                                            \
+    case 8: return fn<8>(__VA_ARGS__);                                                     \
+    case 16: return fn<16>(__VA_ARGS__);                                                   \
+    case 32: return fn<32>(__VA_ARGS__);                                                   \
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "unsupported Brusselator grid %d", (h)->cfg.dims[0]); }
+
 #define DISPATCH_MODEL(h, fn, ...)                                                         \
     switch ((h)->cfg.model) {                                                              \
     case HIPADJ_MODEL_LV: return fn<ModelLV>(__VA_ARGS__);                                 \
@@ -329,9 +405,11 @@ template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_co
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "model %d has no device kernels", (h)->cfg.model); }
 
 static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    if (h->field) { DISPATCH_GRID(h, field_forward, h, d_u0, d_p, d_out); }
     DISPATCH_MODEL(h, forward_impl, h, d_u0, d_p, d_out);
 }
 static int adjoint_dispatch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    if (h->field) { DISPATCH_GRID(h, field_adjoint, h, d_cot, d_du0, d_dp); }
     DISPATCH_MODEL(h, adjoint_impl, h, d_cot, d_du0, d_dp);
 }
 

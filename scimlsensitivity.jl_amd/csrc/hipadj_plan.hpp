@@ -24,6 +24,7 @@ struct Plan {
     std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
     std::vector<double> qa, qb;
     bool bs_ckpt = false;
+    bool field = false;      // workgroup-per-trajectory family (hipadj_field.hpp)
 };
 
 inline bool plan_small_model(int m) { return m >= HIPADJ_MODEL_LV && m <= HIPADJ_MODEL_FALLMASS; }
@@ -64,7 +65,12 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->struct_size != sizeof(hipadj_config)) { err = "hipadj_config.struct_size mismatch (ABI)"; return HIPADJ_ERR_INVALID_ARG; }
     int32_t n, np;
     if (plan_model_sizes(cfg->model, cfg->dims, &n, &np) != HIPADJ_OK) { err = "unknown model id or bad dims"; return HIPADJ_ERR_INVALID_ARG; }
-    if (!plan_small_model(cfg->model)) { err = "model not yet available in the gfx950 kernel family (MLP / BRUSS: wave-per-trajectory family pending)"; return HIPADJ_ERR_UNSUPPORTED; }
+    P.field = cfg->model == HIPADJ_MODEL_BRUSS;
+    if (!plan_small_model(cfg->model) && !P.field) { err = "model has no gfx950 kernels yet (MLP: FP64-MFMA family pending)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (P.field) {
+        if (cfg->dims[0] != 8 && cfg->dims[0] != 16 && cfg->dims[0] != 32) { err = "Brusselator grid must be 8, 16 or 32 (one workgroup per trajectory)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "BacksolveAdjoint is not offered for the PDE family: backward diffusion is ill-posed (src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }
+    }
     if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_QUADRATURE) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED) { err = "only fixed-step RK4 runs on the device (adaptive Tsit5 is CPU plumbing in BASELINE config 1)"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->ntraj <= 0) { err = "ntraj must be positive"; return HIPADJ_ERR_INVALID_ARG; }
@@ -95,7 +101,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         P.nck = c;
     }
     P.nseg = 1;
-    const bool seg_alg = cfg->alg == HIPADJ_ALG_INTERPOLATING || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt);
+    const bool seg_alg = !P.field && (cfg->alg == HIPADJ_ALG_INTERPOLATING || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
     if (seg_alg) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n) : cfg->time_segments;
         if (P.nseg > P.S) P.nseg = P.S;

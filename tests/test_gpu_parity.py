@@ -205,3 +205,86 @@ def test_torch_autograd_device_path(sa):
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0n, pn)
     assert rel(u0.grad.cpu().numpy(), rdu0) < RTOL and rel(p.grad.cpu().numpy(), rdp) < RTOL
     eng.close()
+
+
+# ---- workgroup-per-trajectory family: 2-D Brusselator (BASELINE config 5) ---------------------------------
+def bruss_u0(G, N, seed=0):
+    """docs/src/examples/pde/brusselator.md:88-96 initial condition (+ a per-trajectory perturbation)."""
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(0.0, 1.0, G)
+    U = np.zeros((G, G)); V = np.zeros((G, G))
+    for i in range(G):
+        for j in range(G):
+            U[i, j] = 22.0 * (xs[j] * (1 - xs[j])) ** 1.5
+            V[i, j] = 27.0 * (xs[i] * (1 - xs[i])) ** 1.5
+    base = np.concatenate([U.ravel(order="F"), V.ravel(order="F")])
+    return base[None, :] * (1 + 0.01 * rng.standard_normal((N, base.size)))
+
+
+BRUSS_CASES = [(8, 5e-4, 1.2, 1.3, 3), (16, 1e-4, 0.0, 0.02, 2)]
+
+
+@pytest.mark.parametrize("alg,oalg", [a for a in ALGS if a[0] != "backsolve"])
+@pytest.mark.parametrize("G,dt,t0,t1,N", BRUSS_CASES)
+def test_brusselator_lsq_matches_oracle(sa, alg, oalg, G, dt, t0, t1, N):
+    u0 = bruss_u0(G, N); p = np.array([3.4, 1.0, 10.0])
+    S = int(round((t1 - t0) / dt))
+    ts = t0 + dt * np.arange(0, S + 1, S // 4)
+    dims = (G, 0, 0, 0)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("bruss", u0[0], (t0, t1), p, dims), u0), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sensealg_of(sa, alg), dgdu_discrete=sa.LsqShift(2.0))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+    ref = O.Problem("BRUSS", alg=oalg, stepper="RK4", t0=t0, t1=t1, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, dims=dims)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(sol.u, rout) < RTOL
+    assert rel(du0, rdu0) < RTOL
+    assert rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+@pytest.mark.parametrize("alg,oalg", [a for a in ALGS if a[0] != "backsolve"])
+def test_brusselator_cotangent_per_trajectory_params(sa, alg, oalg):
+    G, dt, t0, t1, N = 8, 5e-4, 0.0, 0.05, 4
+    rng = np.random.default_rng(2)
+    u0 = bruss_u0(G, N, seed=3); p = np.array([3.4, 1.0, 10.0]) * (1 + 0.02 * rng.standard_normal((N, 3)))
+    ts = np.array([0.0, 0.02, 0.05])
+    delta = rng.standard_normal((N, len(ts), 2 * G * G))
+    dims = (G, 0, 0, 0)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("bruss", u0[0], (t0, t1), p[0], dims), u0, p), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sensealg_of(sa, alg))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem("BRUSS", alg=oalg, stepper="RK4", t0=t0, t1=t1, dt=dt, save_times=ts, loss="COTANGENT", dims=dims)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+def test_brusselator_config5_shape_quadrature(sa):
+    """BASELINE configs[4]: 32 x 32 grid (n = 2048), QuadratureAdjoint; explicit RK4 at the stability limit
+    dt = 2.5e-5 on a short horizon, checked against the oracle and by linearity of the pullback."""
+    G, dt, t0, t1 = 32, 2.5e-5, 0.0, 0.005
+    u0 = bruss_u0(G, 1); p = np.array([3.4, 1.0, 10.0])
+    ts = np.array([0.0, 0.0025, 0.005])
+    dims = (G, 0, 0, 0)
+    rng = np.random.default_rng(1)
+    d1 = rng.standard_normal((1, 3, 2048)); d2 = rng.standard_normal((1, 3, 2048))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("bruss", u0[0], (t0, t1), p, dims), u0), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10))
+    a1, b1 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d1)
+    a2, b2 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d2)
+    a3, b3 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d1 + 2.0 * d2)
+    assert rel(a3, a1 + 2.0 * a2) < 1e-10 and rel(b3, b1 + 2.0 * b2) < 1e-7
+    ref = O.Problem("BRUSS", alg="QUADRATURE", stepper="RK4", t0=t0, t1=t1, dt=dt, save_times=ts, loss="COTANGENT", dims=dims,
+                    quad_abstol=1e-10, quad_reltol=1e-10)
+    rdu0, rdp, rout = ref.adjoint(u0[0], p, d1[0])
+    assert rel(sol.u[0], rout) < RTOL and rel(a1[0], rdu0) < RTOL and rel(b1, rdp) < RTOL
+    sol.engine.close()
+
+
+def test_brusselator_rejects_backsolve_and_odd_grids(sa):
+    with pytest.raises(sa.HipadjError) as e1:
+        sa.Engine("bruss", "backsolve", 1, 0.0, 0.01, 1e-4, save_times=[0.01], dims=(8, 0, 0, 0))
+    assert e1.value.status == -6
+    with pytest.raises(sa.HipadjError) as e2:
+        sa.Engine("bruss", "interpolating", 1, 0.0, 0.01, 1e-4, save_times=[0.01], dims=(12, 0, 0, 0))
+    assert e2.value.status == -6
