@@ -13,6 +13,7 @@
 #include "../../include/hipadj.h"
 #include "hipadj_kernels.hpp"
 #include "hipadj_field.hpp"
+#include "hipadj_mlp.hpp"
 #include "hipadj_plan.hpp"
 
 using namespace hipadj;
@@ -39,6 +40,10 @@ struct hipadj_handle {
     dbl2 *d_knots = nullptr, *d_adj = nullptr;
     bool field = false;                   // workgroup-per-trajectory family (BRUSS)
     double *d_fknots = nullptr, *d_fadj = nullptr;
+    bool mlp = false; int NQ = 0, ksplit = 1;
+    double *d_w2t = nullptr, *d_ax = nullptr, *d_al = nullptr, *d_ah1 = nullptr, *d_ah2 = nullptr, *d_ag1 = nullptr, *d_ag2 = nullptr;
+    double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
+    MlpGeom mg{};
     FieldGeom fg{};
     int *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
@@ -86,7 +91,7 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
 
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
-                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_save_of_knot,
+                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -123,13 +128,31 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_u0, (size_t)h->N * n));
     A(dev_alloc(h, &h->d_p, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
     h->field = P.field;
-    if (!h->field) {
+    if (!P.field && !P.mlp) {
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
         if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));
         if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
         if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
+    } else if (P.mlp) {
+        h->mlp = true; h->field = false; h->NQ = P.NQ;
+        const size_t Hh = cfg->dims[1], Bb = cfg->dims[2], Q = (size_t)h->N * S * P.NQ, HP = Hh + 16;
+        const long groups = cfg->p_shared ? 1 : h->N;
+        const long nchunks = (long)(Q / groups) * (Bb / 16);
+        h->ksplit = (int)(nchunks < 128 ? nchunks : 128);
+        A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
+        A(dev_alloc(h, &h->d_w2t, (size_t)groups * Hh * Hh));
+        A(dev_alloc(h, &h->d_ax, Q * 16 * Bb)); A(dev_alloc(h, &h->d_al, Q * 16 * Bb));
+        A(dev_alloc(h, &h->d_ah1, Q * HP * Bb)); A(dev_alloc(h, &h->d_ah2, Q * HP * Bb));
+        A(dev_alloc(h, &h->d_ag1, Q * Hh * Bb)); A(dev_alloc(h, &h->d_ag2, Q * Hh * Bb));
+        A(dev_alloc(h, &h->d_c1, (size_t)groups * h->ksplit * Hh * HP));
+        A(dev_alloc(h, &h->d_c2, (size_t)groups * h->ksplit * Hh * 16));
+        A(dev_alloc(h, &h->d_c3, (size_t)groups * h->ksplit * 16 * HP));
+        if (rc == HIPADJ_OK) {   // padding rows (zeros) and the ones rows are written once / by the sweep; zero everything first
+            if (hipMemset(h->d_ax, 0, Q * 16 * Bb * 8) != hipSuccess || hipMemset(h->d_al, 0, Q * 16 * Bb * 8) != hipSuccess ||
+                hipMemset(h->d_ah1, 0, Q * HP * Bb * 8) != hipSuccess || hipMemset(h->d_ah2, 0, Q * HP * Bb * 8) != hipSuccess) { h->err = "hipMemset failed"; rc = HIPADJ_ERR_HIP; }
+        }
     } else {
         A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) A(dev_alloc(h, &h->d_fadj, (size_t)h->N * S * 4 * n));
@@ -163,6 +186,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
     h->fg.N = h->N; h->fg.S = (int)S; h->fg.M = h->M; h->fg.t0 = cfg->t0; h->fg.dt = cfg->dt; h->fg.loss_shift = cfg->loss_shift;
     h->fg.loss_kind = cfg->loss_kind; h->fg.no_start = cfg->no_start; h->fg.p_shared = cfg->p_shared;
+    h->mg.N = h->N; h->mg.B = cfg->dims[2]; h->mg.S = (int)S; h->mg.M = h->M; h->mg.t0 = cfg->t0; h->mg.dt = cfg->dt; h->mg.loss_shift = cfg->loss_shift;
+    h->mg.loss_kind = cfg->loss_kind; h->mg.no_start = cfg->no_start; h->mg.p_shared = cfg->p_shared; h->mg.NQ = P.NQ;
 
     h->st.struct_size = sizeof(hipadj_stats); h->st.n = n; h->st.np = np; h->st.ntraj = h->N; h->st.nsteps = S;
     h->st.time_segments = h->nseg; h->st.workspace_bytes = h->ws_bytes;
@@ -395,6 +420,57 @@ template <int G> static int field_adjoint(hipadj_handle* h, const double* d_cot,
     case 32: return fn<32>(__VA_ARGS__);                                                   \
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "unsupported Brusselator grid %d", (h)->cfg.dims[0]); }
 
+
+// ---- FP64-MFMA family (MLP neural ODE) -----------------------------------------------------------------
+template <int H> static int mlp_forward_launch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    const int groups = h->cfg.p_shared ? 1 : (int)h->N;
+    hipLaunchKernelGGL(k_mlp_transpose_w2, dim3(64, (unsigned)groups), dim3(256), 0, h->stream, H, Mlp<H>::NPAR, H * 2 + H, d_p, h->d_w2t);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL((k_mlp_forward<H>), dim3((unsigned)(h->mg.B / 16), (unsigned)h->N), dim3(64), 0, h->stream, h->mg, d_u0, d_p, (const double*)h->d_w2t,
+                       h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+template <int H> static int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    constexpr int HP = Mlp<H>::HP;
+    const double* p = h->p_dev_last;
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);
+    HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    MlpRec<H> R{h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2};
+    const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), blk(64);
+    if (h->cfg.alg == HIPADJ_ALG_GAUSS)
+        hipLaunchKernelGGL((k_mlp_adjoint<H, 2>), grid, blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
+    else
+        hipLaunchKernelGGL((k_mlp_adjoint<H, 0>), grid, blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+    const long groups = h->cfg.p_shared ? 1 : h->N;
+    const long Qper = (h->N * (long)h->S * h->NQ) / groups;
+    const int B = h->mg.B, ks = h->ksplit;
+    hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL((k_mlp_wgrad<1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL((k_mlp_wreduce<H>), dim3((Mlp<H>::NPAR + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, ks, (const double*)h->d_c1, (const double*)h->d_c2,
+                       (const double*)h->d_c3, d_dp);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = true;
+    return HIPADJ_OK;
+}
+#define DISPATCH_HIDDEN(h, fn, ...)                                                        \
+    switch ((h)->cfg.dims[1]) {                                                            \
+    case 32: return fn<32>(__VA_ARGS__);                                                   \
+    case 128: return fn<128>(__VA_ARGS__);                                                 \
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "unsupported hidden width %d", (h)->cfg.dims[1]); }
+
 #define DISPATCH_MODEL(h, fn, ...)                                                         \
     switch ((h)->cfg.model) {                                                              \
     case HIPADJ_MODEL_LV: return fn<ModelLV>(__VA_ARGS__);                                 \
@@ -406,10 +482,12 @@ template <int G> static int field_adjoint(hipadj_handle* h, const double* d_cot,
 
 static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (h->field) { DISPATCH_GRID(h, field_forward, h, d_u0, d_p, d_out); }
+    if (h->mlp) { DISPATCH_HIDDEN(h, mlp_forward_launch, h, d_u0, d_p, d_out); }
     DISPATCH_MODEL(h, forward_impl, h, d_u0, d_p, d_out);
 }
 static int adjoint_dispatch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     if (h->field) { DISPATCH_GRID(h, field_adjoint, h, d_cot, d_du0, d_dp); }
+    if (h->mlp) { DISPATCH_HIDDEN(h, mlp_adjoint_launch, h, d_cot, d_du0, d_dp); }
     DISPATCH_MODEL(h, adjoint_impl, h, d_cot, d_du0, d_dp);
 }
 

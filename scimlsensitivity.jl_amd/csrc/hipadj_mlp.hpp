@@ -1,0 +1,369 @@
+// hipadj_mlp.hpp — FP64-MFMA kernel family for the neural-ODE case (BASELINE config 4: 3-layer tanh MLP, 128 hidden,
+// 4096-column batch, GaussAdjoint).  Model (oracle/adjoint_oracle.c ORC_MODEL_MLP; docs/src/Benchmark.md:62 shape):
+//     X is d x B (column-major, d = 2),  f(X) = W3 tanh(W2 tanh(W1 X + b1) + b2) + b3   applied column-wise,
+//     p = [W1 (H x d), b1, W2 (H x H), b2, W3 (d x H), b3], all column-major.
+//
+// The batch columns are independent given the weights, so ONE WAVE integrates 16 columns through the whole
+// reverse sweep.  The two H x H contractions per VJP (W2 H1 forward, W2^T G2 backward) run on the matrix cores:
+//     v_mfma_f64_16x16x4_f64:  A[i = l&15][k = l>>4] (one f64 per lane), B[k = l>>4][j = l&15],
+//     C/D: col = l & 15, row = (l >> 4) + 4 * reg   (the f64 map, cdna_hip_programming.md §3)
+// With the batch column on j = l & 15, register r of output tile t holds row 16t + 4r + (l>>4): for fixed r the four
+// lane groups hold FOUR CONSECUTIVE rows, i.e. exactly the B operand of the K-step (t, r) of the next layer.
+// Activations therefore flow layer to layer in registers — no LDS round trip, tanh fused on the accumulator.
+// A operands (16 x 4 blocks of W2 / W2^T) are read straight from L2 (128 KB, shared by every wave); the d-sized
+// contractions (W1, W3) are VALU work plus a two-step cross-lane-group reduction (__shfl_xor 16, 32).
+//
+// Parameter gradient: (df/dp)^T lam = sum over columns of outer products of activations (G2 H1^T, ...).  A lane
+// cannot carry the 17 282 accumulators; instead the sweep writes the weighted activation records
+//     X_q, w Lam_q (16-row padded), H1_q (+ ones row), H2_q (+ ones row), w G1_q, w G2_q     q = quadrature points
+// (Gauss: the two Gauss-Legendre nodes of every step, w = dt/2, src/gauss_adjoint.jl:745-759, 809-851;
+//  Interpolating: the four RK4 stages, w = dt/6, dt/3, dt/3, dt/6, src/interpolating_adjoint.jl:166-172)
+// and k_mlp_wgrad contracts them over (q, column) with MFMA as three split-K NT-GEMMs:
+//     G2 x [H1;1]^T -> dW2, db2      G1 x [X;1]^T -> dW1, db1      [Lam] x [H2;1]^T -> dW3, db3
+// followed by a fixed-order reduction of the split-K partials (bit-reproducible).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "hipadj_lane.hpp"
+
+namespace hipadj {
+
+typedef double mlp_d4 __attribute__((ext_vector_type(4)));
+
+struct MlpGeom {
+    long N;            // trajectories (each with its own d x B state)
+    int B, S, M;
+    double t0, dt, loss_shift;
+    int loss_kind, no_start, p_shared;
+    int NQ;            // quadrature records per step (Gauss 2, Interpolating 4)
+};
+
+template <int H> struct Mlp {
+    static constexpr int D = 2, TT = H / 16;       // row tiles
+    static constexpr int NPAR = H * D + H + H * H + H + D * H + D;
+    static constexpr int HP = H + 16;              // H rows + a 16-row tile whose first row is the ones row
+    static_assert(H % 16 == 0, "hidden width must be a multiple of 16");
+};
+
+template <int H> struct MlpW { const double *W1, *b1, *W2, *b2, *W3, *b3, *W2T; };
+template <int H> __device__ __forceinline__ MlpW<H> mlp_weights(const double* __restrict__ p, const double* __restrict__ w2t, int p_shared, long traj) {
+    constexpr int D = Mlp<H>::D;
+    const double* pp = p_shared ? p : p + traj * Mlp<H>::NPAR;
+    MlpW<H> w; w.W1 = pp; w.b1 = w.W1 + H * D; w.W2 = w.b1 + H; w.b2 = w.W2 + H * H; w.W3 = w.b2 + H; w.b3 = w.W3 + D * H;
+    w.W2T = p_shared ? w2t : w2t + traj * (long)H * H;
+    return w;
+}
+
+// out[t] (+)= Wm (H x H, column-major) . act  with act in the register layout described above.
+// K-step (kt, r) issues TT MFMAs that share one B operand; its TT A operands (16 x 4 blocks of Wm, L2-resident) are
+// fetched ONE K-step ahead and a scheduling fence per K-step keeps hipcc from hoisting all H*H/64 loads to the top
+// (which spilled 7.5 KB per lane at H = 128).
+template <int H>
+__device__ __forceinline__ void mlp_gemm(const double* __restrict__ Wm, const double (&act)[H / 16][4], mlp_d4 (&acc)[H / 16]) {
+    constexpr int TT = H / 16, NK = TT * 4;
+    // uniform base (SGPR pair) + ONE 32-bit lane offset + compile-time constants: the loads use the saddr form and no
+    // per-load 64-bit address VGPRs exist for LICM to hoist out of the time loop (that is what spilled before)
+    unsigned lane_off = (threadIdx.x & 15u) + ((threadIdx.x & 63u) >> 4) * (unsigned)H;
+    asm volatile("" : "+v"(lane_off));   // opaque per call: address arithmetic stays next to its load instead of being
+                                         // hoisted out of the time loop as hundreds of live 64-bit VGPR pairs
+    double a_cur[TT], a_nxt[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) a_cur[t] = Wm[lane_off + (unsigned)(16 * t)];
+#pragma unroll
+    for (int st = 0; st < NK; ++st) {
+        if (st + 1 < NK) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) a_nxt[t] = Wm[lane_off + (unsigned)(16 * t + 4 * (st + 1) * H)];
+        }
+        const double b = act[st / 4][st % 4];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], b, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) a_cur[t] = a_nxt[t];
+    }
+}
+
+__device__ __forceinline__ double group_sum4(double v) {   // sum over the four 16-lane groups (same column j)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// forward pass for the wave's 16 columns: x[D] per lane (column l&15, replicated over the 4 lane groups)
+template <int H>
+__device__ __forceinline__ void mlp_forward(const MlpW<H>& w, const double (&x)[2], double (&h1)[H / 16][4], double (&h2)[H / 16][4], double (&out)[2]) {
+    constexpr int TT = H / 16, D = 2;
+    const unsigned lq = (threadIdx.x & 63u) >> 4;
+    mlp_d4 acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned row = (unsigned)(16 * t + 4 * r) + lq;
+            h1[t][r] = tanh(w.b1[row] + w.W1[row] * x[0] + w.W1[row + (unsigned)H] * x[1]);
+            acc[t][r] = w.b2[row];
+        }
+    }
+    mlp_gemm<H>(w.W2, h1, acc);
+    double o0 = 0.0, o1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned row = (unsigned)(16 * t + 4 * r) + lq;
+            h2[t][r] = tanh(acc[t][r]);
+            o0 += w.W3[row * 2u] * h2[t][r];
+            o1 += w.W3[row * 2u + 1u] * h2[t][r];
+        }
+    }
+    out[0] = w.b3[0] + group_sum4(o0);
+    out[1] = w.b3[1] + group_sum4(o1);
+}
+
+// (df/du)^T lam for the wave's columns, given the activations of the forward pass; g1/g2 are the layer cotangents
+template <int H>
+__device__ __forceinline__ void mlp_backward(const MlpW<H>& w, const double (&lam)[2], const double (&h1)[H / 16][4], const double (&h2)[H / 16][4],
+                                             double (&g1)[H / 16][4], double (&g2)[H / 16][4], double (&dlam)[2]) {
+    constexpr int TT = H / 16, D = 2;
+    const unsigned lq = (threadIdx.x & 63u) >> 4;
+    mlp_d4 acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned row = (unsigned)(16 * t + 4 * r) + lq;
+            g2[t][r] = (w.W3[row * 2u] * lam[0] + w.W3[row * 2u + 1u] * lam[1]) * (1.0 - h2[t][r] * h2[t][r]);
+            acc[t][r] = 0.0;
+        }
+    }
+    mlp_gemm<H>(w.W2T, g2, acc);
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned row = (unsigned)(16 * t + 4 * r) + lq;
+            g1[t][r] = acc[t][r] * (1.0 - h1[t][r] * h1[t][r]);
+            d0 += w.W1[row] * g1[t][r];
+            d1 += w.W1[row + (unsigned)H] * g1[t][r];
+        }
+    }
+    dlam[0] = group_sum4(d0);
+    dlam[1] = group_sum4(d1);
+}
+
+// W2T[i + k*H] = W2[k + i*H]
+__global__ void k_mlp_transpose_w2(int H, int npar, int hd, const double* __restrict__ p, double* __restrict__ w2t) {
+    const long traj = blockIdx.y;
+    const double* W2 = p + traj * npar + hd;   // hd = H*D + H
+    double* o = w2t + traj * (long)H * H;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < H * H; e += gridDim.x * blockDim.x) {
+        const int i = e % H, k = e / H;
+        o[i + (long)k * H] = W2[k + (long)i * H];
+    }
+}
+
+// forward RK4; knots [traj][S+1][2][D][B]  (x_k then f(x_k)); out [traj][M][D*B] in the caller's layout
+template <int H>
+__global__ void __launch_bounds__(64) k_mlp_forward(MlpGeom g, const double* __restrict__ u0, const double* __restrict__ p, const double* __restrict__ w2t,
+                                                    double* __restrict__ knots, double* __restrict__ out, const int* __restrict__ save_of_knot) {
+    constexpr int TT = H / 16, D = 2;
+    const long traj = blockIdx.y;
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool writer = (threadIdx.x >> 4) == 0;
+    const MlpW<H> w = mlp_weights<H>(p, w2t, g.p_shared, traj);
+    const long nB = (long)D * g.B;
+    double x[D], k1[D], k2[D], k3[D], k4[D], xs[D], h1[TT][4], h2[TT][4];
+    x[0] = u0[traj * nB + (long)col * D]; x[1] = u0[traj * nB + (long)col * D + 1];
+    const double dt = g.dt;
+    for (int k = 0; k <= g.S; ++k) {
+        mlp_forward<H>(w, x, h1, h2, k1);
+        if (writer) {
+            double* kn = knots + ((traj * (g.S + 1) + k) * 2) * nB;
+            kn[col] = x[0]; kn[g.B + col] = x[1]; kn[nB + col] = k1[0]; kn[nB + g.B + col] = k1[1];
+            const int s = save_of_knot[k];
+            if (out && s >= 0) { double* o = out + (traj * g.M + s) * nB; o[(long)col * D] = x[0]; o[(long)col * D + 1] = x[1]; }
+        }
+        if (k == g.S) break;
+        xs[0] = x[0] + 0.5 * dt * k1[0]; xs[1] = x[1] + 0.5 * dt * k1[1];
+        mlp_forward<H>(w, xs, h1, h2, k2);
+        xs[0] = x[0] + 0.5 * dt * k2[0]; xs[1] = x[1] + 0.5 * dt * k2[1];
+        mlp_forward<H>(w, xs, h1, h2, k3);
+        xs[0] = x[0] + dt * k3[0]; xs[1] = x[1] + dt * k3[1];
+        mlp_forward<H>(w, xs, h1, h2, k4);
+        x[0] = x[0] + (dt / 6.0) * (k1[0] + 2.0 * (k2[0] + k3[0]) + k4[0]);
+        x[1] = x[1] + (dt / 6.0) * (k1[1] + 2.0 * (k2[1] + k3[1]) + k4[1]);
+    }
+}
+
+// activation records for the weight-gradient GEMMs; q indexes (traj, step, point); all arrays [q][rows][B]
+template <int H> struct MlpRec { double *AX, *AL, *AH1, *AH2, *AG1, *AG2; };
+
+template <int H>
+__device__ __forceinline__ void mlp_record(const MlpRec<H>& R, const MlpGeom& g, long q, int col, double wq, const double (&x)[2], const double (&lam)[2],
+                                           const double (&h1)[H / 16][4], const double (&h2)[H / 16][4], const double (&g1)[H / 16][4], const double (&g2)[H / 16][4]) {
+    constexpr int TT = H / 16, HP = Mlp<H>::HP;
+    const int lq = (threadIdx.x & 63) >> 4;
+    const long B = g.B;
+    if (lq == 0) {
+        double* ax = R.AX + q * 16 * B; double* al = R.AL + q * 16 * B;
+        ax[col] = x[0]; ax[B + col] = x[1]; ax[2 * B + col] = 1.0;
+        al[col] = wq * lam[0]; al[B + col] = wq * lam[1];
+        R.AH1[(q * HP + H) * B + col] = 1.0; R.AH2[(q * HP + H) * B + col] = 1.0;
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = 16 * t + 4 * r + lq;
+            R.AH1[(q * HP + row) * B + col] = h1[t][r];
+            R.AH2[(q * HP + row) * B + col] = h2[t][r];
+            R.AG1[(q * H + row) * B + col] = wq * g1[t][r];
+            R.AG2[(q * H + row) * B + col] = wq * g2[t][r];
+        }
+    }
+}
+
+// reverse sweep: ALG 0 = InterpolatingAdjoint (records at the 4 RK4 stages), ALG 2 = GaussAdjoint (records at the
+// two Gauss-Legendre nodes; lam from the adjoint step's Hermite interpolant, y from the forward one)
+template <int H, int ALG>
+__global__ void __launch_bounds__(64) k_mlp_adjoint(MlpGeom g, const double* __restrict__ p, const double* __restrict__ w2t, const double* __restrict__ knots,
+                                                    const double* __restrict__ cot, const int* __restrict__ save_of_knot, MlpRec<H> R,
+                                                    double* __restrict__ du0, int* __restrict__ flag) {
+    constexpr int TT = H / 16, D = 2;
+    const long traj = blockIdx.y;
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool writer = (threadIdx.x >> 4) == 0;
+    const MlpW<H> w = mlp_weights<H>(p, w2t, g.p_shared, traj);
+    const long nB = (long)D * g.B;
+    const double dt = g.dt;
+    auto knot = [&](int k, double (&xx)[2], double (&ff)[2]) {
+        const double* kn = knots + ((traj * (g.S + 1) + k) * 2) * nB;
+        xx[0] = kn[col]; xx[1] = kn[g.B + col]; ff[0] = kn[nB + col]; ff[1] = kn[nB + g.B + col];
+    };
+    auto jump = [&](int s, const double (&xx)[2], double (&lam)[2]) {
+        if (g.loss_kind == 0) { const double* c = cot + (traj * g.M + s) * nB; lam[0] += c[(long)col * D]; lam[1] += c[(long)col * D + 1]; }
+        else { lam[0] += xx[0] - g.loss_shift; lam[1] += xx[1] - g.loss_shift; }
+    };
+    double lam[D] = {0.0, 0.0}, xh[D], fh[D], xl[D], fl[D];
+    double h1[TT][4], h2[TT][4], g1[TT][4], g2[TT][4], out[D];
+    knot(g.S, xh, fh);
+    { const int s = save_of_knot[g.S]; if (s >= 0) jump(s, xh, lam); }
+    const double xg = 0.5773502691896257645;
+    for (int k = g.S - 1; k >= 0; --k) {
+        knot(k, xl, fl);
+        const long qbase = (traj * g.S + k) * g.NQ;
+        double xm[D], ls[D], V1[D], V2[D], V3[D], V4[D], lam_hi[D] = {lam[0], lam[1]};
+        xm[0] = 0.5 * (xl[0] + xh[0]) + (0.125 * dt) * (fl[0] - fh[0]);
+        xm[1] = 0.5 * (xl[1] + xh[1]) + (0.125 * dt) * (fl[1] - fh[1]);
+        // stage 1 at x_hi
+        mlp_forward<H>(w, xh, h1, h2, out);
+        mlp_backward<H>(w, lam, h1, h2, g1, g2, V1);
+        if (ALG == 0) mlp_record<H>(R, g, qbase + 0, col, dt / 6.0, xh, lam, h1, h2, g1, g2);
+        // stages 2, 3 at the Hermite midpoint (same activations)
+        ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
+        mlp_forward<H>(w, xm, h1, h2, out);
+        mlp_backward<H>(w, ls, h1, h2, g1, g2, V2);
+        if (ALG == 0) mlp_record<H>(R, g, qbase + 1, col, dt / 3.0, xm, ls, h1, h2, g1, g2);
+        ls[0] = lam[0] + 0.5 * dt * V2[0]; ls[1] = lam[1] + 0.5 * dt * V2[1];
+        mlp_backward<H>(w, ls, h1, h2, g1, g2, V3);
+        if (ALG == 0) mlp_record<H>(R, g, qbase + 2, col, dt / 3.0, xm, ls, h1, h2, g1, g2);
+        // stage 4 at x_lo
+        ls[0] = lam[0] + dt * V3[0]; ls[1] = lam[1] + dt * V3[1];
+        mlp_forward<H>(w, xl, h1, h2, out);
+        mlp_backward<H>(w, ls, h1, h2, g1, g2, V4);
+        if (ALG == 0) mlp_record<H>(R, g, qbase + 3, col, dt / 6.0, xl, ls, h1, h2, g1, g2);
+        lam[0] = lam[0] + (dt / 6.0) * (V1[0] + 2.0 * (V2[0] + V3[0]) + V4[0]);
+        lam[1] = lam[1] + (dt / 6.0) * (V1[1] + 2.0 * (V2[1] + V3[1]) + V4[1]);
+        if (ALG == 2) {
+            double V5[D];
+            mlp_backward<H>(w, lam, h1, h2, g1, g2, V5);                   // fsallast at x_lo (activations of stage 4)
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq) {
+                const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
+                double lg[D], yg[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    lg[j] = (1.0 - th) * lam_hi[j] + th * lam[j] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lam[j] - lam_hi[j]) + (th - 1.0) * (-dt) * (-V1[j]) + th * (-dt) * (-V5[j]));
+                    yg[j] = (1.0 - tf) * xl[j] + tf * xh[j] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (xh[j] - xl[j]) + (tf - 1.0) * dt * fl[j] + tf * dt * fh[j]);
+                }
+                double dl[D];
+                mlp_forward<H>(w, yg, h1, h2, out);
+                mlp_backward<H>(w, lg, h1, h2, g1, g2, dl);
+                mlp_record<H>(R, g, qbase + nq, col, 0.5 * dt, yg, lg, h1, h2, g1, g2);
+            }
+        }
+        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) jump(s, xl, lam); }
+        xh[0] = xl[0]; xh[1] = xl[1]; fh[0] = fl[0]; fh[1] = fl[1];
+    }
+    if (writer) {
+        du0[traj * nB + (long)col * D] = lam[0]; du0[traj * nB + (long)col * D + 1] = lam[1];
+        if (!(fabs(lam[0]) <= 1.79769313486231570e308) || !(fabs(lam[1]) <= 1.79769313486231570e308)) atomicOr(flag, 1);
+    }
+}
+
+// split-K NT-GEMM on the records:  Cpart[grp][ks][ra][rb] = sum_{s in K-slice ks} A[ra][s] Bm[rb][s]
+// A: [Q][RA][B], Bm: [Q][RB][B] (RA, RB multiples of 16); samples s = (q, column).  One wave per (A row tile, slice).
+// Within a 16-sample chunk lane (i, g) takes samples 4g..4g+3 (one 32-byte load) for the four K-steps kk = 0..3:
+// K-step kk then contracts samples {4g + kk}, the same assignment for A and B.
+template <int NTB>
+__global__ void __launch_bounds__(64) k_mlp_wgrad(const double* __restrict__ A, const double* __restrict__ Bm, int RA, int RB, long Qper, int B,
+                                                  int ksplit, double* __restrict__ Cpart) {
+    const int ti = blockIdx.x, ks = blockIdx.y; const long grp = blockIdx.z;
+    const int li = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
+    mlp_d4 acc[NTB];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) acc[t] = mlp_d4{0.0, 0.0, 0.0, 0.0};
+    const long chunks_per_q = B / 16, nchunks = Qper * chunks_per_q;
+    const long c0 = nchunks * ks / ksplit, c1 = nchunks * (ks + 1) / ksplit;
+    for (long c = c0; c < c1; ++c) {
+        const long q = grp * Qper + c / chunks_per_q; const int s0 = (int)(c % chunks_per_q) * 16 + 4 * lq;
+        const double* ap = A + (q * RA + 16 * ti + li) * (long)B + s0;
+        const double a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+            if (16 * t < RB) {
+                const double* bp = Bm + (q * RB + 16 * t + li) * (long)B + s0;
+                const double b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    double* cp = Cpart + ((grp * ksplit + ks) * (long)RA) * RB;
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) {
+        if (16 * t < RB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[(long)(16 * ti + lq + 4 * r) * RB + 16 * t + li] = acc[t][r];
+        }
+    }
+}
+
+// dp = fixed-order sum of the split-K partials, scattered into the parameter layout
+//   C1 = G2 x [H1;1]^T (H x HP): dW2[i + m H], db2[i] = C1[i][H];  C2 = G1 x [X;1]^T (H x 16): dW1[i + d H], db1[i] = C2[i][2]
+//   C3 = Lam x [H2;1]^T (16 x HP): dW3[d + m D], db3[d] = C3[d][H]
+template <int H>
+__global__ void __launch_bounds__(256) k_mlp_wreduce(int ksplit, const double* __restrict__ C1, const double* __restrict__ C2, const double* __restrict__ C3,
+                                                     double* __restrict__ dp) {
+    constexpr int D = 2, HP = Mlp<H>::HP, NPAR = Mlp<H>::NPAR;
+    const long grp = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NPAR) return;
+    const double* src; long idx, stride;
+    int o = e;
+    if (o < H * D) { const int i = o % H, d = o / H; src = C2 + grp * ksplit * (long)H * 16; idx = (long)i * 16 + d; stride = (long)H * 16; }
+    else if ((o -= H * D) < H) { src = C2 + grp * ksplit * (long)H * 16; idx = (long)o * 16 + D; stride = (long)H * 16; }
+    else if ((o -= H) < H * H) { const int i = o % H, m = o / H; src = C1 + grp * ksplit * (long)H * HP; idx = (long)i * HP + m; stride = (long)H * HP; }
+    else if ((o -= H * H) < H) { src = C1 + grp * ksplit * (long)H * HP; idx = (long)o * HP + H; stride = (long)H * HP; }
+    else if ((o -= H) < D * H) { const int d = o % D, m = o / D; src = C3 + grp * ksplit * (long)16 * HP; idx = (long)d * HP + m; stride = (long)16 * HP; }
+    else { o -= D * H; src = C3 + grp * ksplit * (long)16 * HP; idx = (long)o * HP + H; stride = (long)16 * HP; }
+    double s = 0.0;
+    for (int k = 0; k < ksplit; ++k) s += src[idx + k * stride];
+    dp[grp * NPAR + e] = s;
+}
+
+}  // namespace hipadj

@@ -25,6 +25,8 @@ struct Plan {
     std::vector<double> qa, qb;
     bool bs_ckpt = false;
     bool field = false;      // workgroup-per-trajectory family (hipadj_field.hpp)
+    bool mlp = false;        // FP64-MFMA family (hipadj_mlp.hpp)
+    int NQ = 0;              // activation records per step (MLP)
 };
 
 inline bool plan_small_model(int m) { return m >= HIPADJ_MODEL_LV && m <= HIPADJ_MODEL_FALLMASS; }
@@ -66,7 +68,15 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     int32_t n, np;
     if (plan_model_sizes(cfg->model, cfg->dims, &n, &np) != HIPADJ_OK) { err = "unknown model id or bad dims"; return HIPADJ_ERR_INVALID_ARG; }
     P.field = cfg->model == HIPADJ_MODEL_BRUSS;
-    if (!plan_small_model(cfg->model) && !P.field) { err = "model has no gfx950 kernels yet (MLP: FP64-MFMA family pending)"; return HIPADJ_ERR_UNSUPPORTED; }
+    P.mlp = cfg->model == HIPADJ_MODEL_MLP;
+    if (!plan_small_model(cfg->model) && !P.field && !P.mlp) { err = "unknown model"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (P.mlp) {
+        if (cfg->dims[0] != 2) { err = "MLP family: state width d must be 2 (docs/src/Benchmark.md:62 shape)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->dims[1] != 32 && cfg->dims[1] != 128) { err = "MLP family: hidden width must be 32 or 128"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->dims[2] % 16 != 0) { err = "MLP family: batch must be a multiple of 16 (one wave per 16 columns)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg != HIPADJ_ALG_GAUSS && cfg->alg != HIPADJ_ALG_INTERPOLATING) { err = "MLP family offers GaussAdjoint and InterpolatingAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
+        P.NQ = cfg->alg == HIPADJ_ALG_GAUSS ? 2 : 4;
+    }
     if (P.field) {
         if (cfg->dims[0] != 8 && cfg->dims[0] != 16 && cfg->dims[0] != 32) { err = "Brusselator grid must be 8, 16 or 32 (one workgroup per trajectory)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "BacksolveAdjoint is not offered for the PDE family: backward diffusion is ill-posed (src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }
@@ -101,7 +111,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         P.nck = c;
     }
     P.nseg = 1;
-    const bool seg_alg = !P.field && (cfg->alg == HIPADJ_ALG_INTERPOLATING || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
+    const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
     if (seg_alg) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n) : cfg->time_segments;
         if (P.nseg > P.S) P.nseg = P.S;

@@ -288,3 +288,77 @@ def test_brusselator_rejects_backsolve_and_odd_grids(sa):
     with pytest.raises(sa.HipadjError) as e2:
         sa.Engine("bruss", "interpolating", 1, 0.0, 0.01, 1e-4, save_times=[0.01], dims=(12, 0, 0, 0))
     assert e2.value.status == -6
+
+
+# ---- FP64-MFMA family: tanh-MLP neural ODE (BASELINE config 4) ----------------------------------------------
+def mlp_params(d, H, seed=1):
+    """weights ~ N(0, 1/fan_in), seed 1; layout [W1 (H x d), b1, W2 (H x H), b2, W3 (d x H), b3], column-major."""
+    rng = np.random.default_rng(seed)
+    W1 = rng.standard_normal((H, d)) / np.sqrt(d); b1 = 0.1 * rng.standard_normal(H)
+    W2 = rng.standard_normal((H, H)) / np.sqrt(H); b2 = 0.1 * rng.standard_normal(H)
+    W3 = rng.standard_normal((d, H)) / np.sqrt(H); b3 = 0.1 * rng.standard_normal(d)
+    return np.concatenate([W1.ravel(order="F"), b1, W2.ravel(order="F"), b2, W3.ravel(order="F"), b3])
+
+
+@pytest.mark.parametrize("alg,oalg", [("gauss", "GAUSS"), ("interpolating", "INTERPOLATING")])
+@pytest.mark.parametrize("H,B,N,shared", [(32, 32, 1, True), (32, 48, 2, False), (128, 16, 1, True)])
+def test_mlp_matches_oracle(sa, alg, oalg, H, B, N, shared):
+    d, T, dt = 2, 0.3, 0.05
+    dims = (d, H, B, 0)
+    rng = np.random.default_rng(4)
+    u0 = rng.standard_normal((N, d * B))
+    p = mlp_params(d, H) if shared else np.stack([mlp_params(d, H, seed=10 + i) for i in range(N)])
+    ts = np.array([0.0, 0.1, 0.2, 0.3])
+    delta = rng.standard_normal((N, len(ts), d * B))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("mlp", u0[0], (0, T), p if shared else p[0], dims), u0, p), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sensealg_of(sa, alg))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem("MLP", alg=oalg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", dims=dims)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(sol.u, rout) < RTOL
+    assert rel(du0, rdu0) < RTOL
+    assert rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+def test_mlp_lsq_loss_gauss(sa):
+    d, H, B, T, dt = 2, 32, 64, 0.2, 0.05
+    dims = (d, H, B, 0)
+    rng = np.random.default_rng(6)
+    u0 = rng.standard_normal((1, d * B)); p = mlp_params(d, H)
+    ts = np.array([0.1, 0.2])
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("mlp", u0[0], (0, T), p, dims), u0), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+    ref = O.Problem("MLP", alg="GAUSS", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, dims=dims)
+    rdu0, rdp, rout = ref.adjoint(u0[0], p)
+    assert rel(sol.u[0], rout) < RTOL and rel(du0[0], rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+def test_mlp_config4_shape_gauss(sa):
+    """BASELINE configs[3]: 3-layer MLP, 128 hidden, 4096-column batch, GaussAdjoint (two RK4 steps so that the
+    single-threaded oracle finishes in seconds) + linearity of the pullback at the same size."""
+    d, H, B, T, dt = 2, 128, 4096, 0.02, 0.01
+    dims = (d, H, B, 0)
+    rng = np.random.default_rng(8)
+    u0 = rng.standard_normal((1, d * B)); p = mlp_params(d, H)
+    ts = np.array([0.02])
+    d1 = rng.standard_normal((1, 1, d * B)); d2 = rng.standard_normal((1, 1, d * B))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("mlp", u0[0], (0, T), p, dims), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sa.GaussAdjoint())
+    a1, b1 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d1)
+    a2, b2 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d2)
+    a3, b3 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d1 - 0.5 * d2)
+    assert rel(a3, a1 - 0.5 * a2) < 1e-10 and rel(b3, b1 - 0.5 * b2) < 1e-9
+    ref = O.Problem("MLP", alg="GAUSS", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", dims=dims)
+    rdu0, rdp, rout = ref.adjoint(u0[0], p, d1[0])
+    assert rel(sol.u[0], rout) < RTOL and rel(a1[0], rdu0) < RTOL and rel(b1, rdp) < RTOL
+    sol.engine.close()
+
+
+def test_mlp_rejects_unsupported(sa):
+    for kw in (dict(alg="quadrature", dims=(2, 32, 32, 0)), dict(alg="gauss", dims=(3, 32, 32, 0)), dict(alg="gauss", dims=(2, 48, 32, 0)),
+               dict(alg="gauss", dims=(2, 32, 24, 0))):
+        with pytest.raises(sa.HipadjError) as e:
+            sa.Engine("mlp", kw["alg"], 1, 0.0, 0.1, 0.05, save_times=[0.1], dims=kw["dims"])
+        assert e.value.status == -6
