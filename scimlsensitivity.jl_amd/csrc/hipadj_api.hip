@@ -39,13 +39,14 @@ struct hipadj_handle {
     double *d_io_a = nullptr, *d_du0 = nullptr, *d_dp = nullptr;   // staging for the host-pointer API
     dbl2 *d_knots = nullptr, *d_adj = nullptr;
     bool field = false;                   // workgroup-per-trajectory family (BRUSS)
+    bool ip_ckpt = false;                 // Interpolating/Gauss checkpointing=true
     double *d_fknots = nullptr, *d_fadj = nullptr;
     bool mlp = false; int NQ = 0, ksplit = 1;
     double *d_w2t = nullptr, *d_ax = nullptr, *d_al = nullptr, *d_ah1 = nullptr, *d_ah2 = nullptr, *d_ag1 = nullptr, *d_ag2 = nullptr;
     double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
     MlpGeom mg{};
     FieldGeom fg{};
-    int *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
+    int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
     bool have_forward = false, timing_pending_fwd = false;
     double ws_bytes = 0;
@@ -91,7 +92,7 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
 
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
-                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_save_of_knot,
+                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_prev_ck, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -111,7 +112,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     const int n = P.n, np = P.np; const long S = P.S;
     h->n = n; h->np = np; h->N = P.N; h->Npad = P.Npad; h->S = P.S; h->M = P.M; h->nck = P.nck; h->nseg = P.nseg; h->nq = P.nq;
     h->save_times = P.save_times; h->save_of_knot = P.save_of_knot; h->ckpt_of_knot = P.ckpt_of_knot; h->seg_bounds = P.seg_bounds;
-    const bool bs_ckpt = P.bs_ckpt;
+    const bool bs_ckpt = P.bs_ckpt || P.ip_ckpt;
+    h->ip_ckpt = P.ip_ckpt;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { h->err = hipadj_status_string(HIPADJ_ERR_NO_DEVICE); return fail(HIPADJ_ERR_NO_DEVICE); }
     if (cfg->device < 0 || cfg->device >= ndev) { h->err = "device ordinal out of range"; return fail(HIPADJ_ERR_INVALID_ARG); }
@@ -131,7 +133,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (!P.field && !P.mlp) {
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
-        if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));
+        if (cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));
         if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
         if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
@@ -164,6 +166,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_dp, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
     A(dev_alloc(h, &h->d_save_of_knot, (size_t)S + 1));
     A(dev_alloc(h, &h->d_ckpt_of_knot, (size_t)S + 1));
+    A(dev_alloc(h, &h->d_prev_ck, (size_t)S + 1));
     A(dev_alloc(h, &h->d_seg_bounds, (size_t)h->nseg + 1));
     A(dev_alloc(h, &h->d_flag, 1));
     const std::vector<double>&qa = P.qa, &qb = P.qb;
@@ -175,6 +178,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (rc != HIPADJ_OK) return fail(rc);
     bool ok = HT(hipMemcpy(h->d_save_of_knot, h->save_of_knot.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
               HT(hipMemcpy(h->d_ckpt_of_knot, h->ckpt_of_knot.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
+              HT(hipMemcpy(h->d_prev_ck, P.prev_ck.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
               HT(hipMemcpy(h->d_seg_bounds, h->seg_bounds.data(), sizeof(int) * (h->nseg + 1), hipMemcpyHostToDevice), "memcpy") &&
               HT(hipMemset(h->d_flag, 0, sizeof(int)), "memset");
     if (ok && h->nq > 0) ok = HT(hipMemcpy(h->d_qa, qa.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy") &&
@@ -193,7 +197,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->st.time_segments = h->nseg; h->st.workspace_bytes = h->ws_bytes;
     // ALGORITHMIC bytes of one reverse pass: knots (u,f) once, cotangents (if read), du0 + dp out
     double bytes = 0.0;
-    if (cfg->alg == HIPADJ_ALG_BACKSOLVE) bytes = (double)h->N * ((double)h->nck * 8.0 * n + 8.0 * n);
+    if (cfg->alg == HIPADJ_ALG_BACKSOLVE || P.ip_ckpt) bytes = (double)h->N * ((double)h->nck * 8.0 * n + 8.0 * n);
     else bytes = (double)h->N * (double)(S + 1) * 16.0 * n;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) bytes += (double)h->N * (double)S * 2.0 * 32.0 * n;   // dense lambda write + read
     if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) bytes += (double)h->N * h->M * 8.0 * n;
@@ -299,6 +303,10 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
+        if (h->ip_ckpt)
+            hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+        else
         hipLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p,
                            (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
@@ -319,6 +327,10 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_GAUSS:
+        if (h->ip_ckpt)
+            hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+                               (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj);
+        else
         hipLaunchKernelGGL((k_gauss<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
                            (const double*)h->d_cotT, (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj);
         HIP_TRY(h, hipGetLastError());

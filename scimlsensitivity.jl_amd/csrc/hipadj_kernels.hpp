@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 #include "hipadj_lane.hpp"
+#include "hipadj_plan.hpp"
 
 namespace hipadj {
 
@@ -58,6 +59,58 @@ __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const doubl
             for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * g.Npad] = mu[c][j];
         }
     }
+}
+
+// checkpointing=true variants: checkpoint tiles in HBM, interval re-solve tile in LDS ([step][component][lane])
+template <class Mo, int LOSS>
+__global__ void __launch_bounds__(WAVE) k_interp_ckpt(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ ckpt,
+                                                      const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
+                                                      const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                                                      double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, KM = HIPADJ_CKPT_KMAX;
+    __shared__ double tile[(KM + 1) * N * WAVE];
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;
+    if (i >= g.N) return;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    const CkptSrc C{ckpt, ckpt_of_knot, prev_ck, tile, WAVE, (int)threadIdx.x};
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
+    if (seg == sp.nseg - 1) {
+        double lam[1][N], mu[1][NP];
+        interp_lane<Mo, 1, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
+    } else {
+        double lam[NC][N], mu[NC][NP];
+        interp_lane<Mo, NC, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) dst[((long)c * R + j) * g.Npad] = lam[c][j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * g.Npad] = mu[c][j];
+        }
+    }
+}
+
+template <class Mo, int LOSS>
+__global__ void __launch_bounds__(WAVE) k_gauss_ckpt(Geom g, const double* __restrict__ p, const double* __restrict__ ckpt,
+                                                     const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
+                                                     const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                                                     double* __restrict__ du0, double* __restrict__ dp_traj) {
+    constexpr int N = Mo::N, NP = Mo::NP, KM = HIPADJ_CKPT_KMAX;
+    __shared__ double tile[(KM + 1) * N * WAVE];
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    if (i >= g.N) return;
+    const CkptSrc C{ckpt, ckpt_of_knot, prev_ck, tile, WAVE, (int)threadIdx.x};
+    double lam[N], mu[NP];
+    gauss_lane<Mo, 1, LOSS, KM>(g, i, p, nullptr, cotT, save_of_knot, lam, mu, &C);
+#pragma unroll
+    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
 }
 
 // ---- finishing stage -------------------------------------------------------------------------------------

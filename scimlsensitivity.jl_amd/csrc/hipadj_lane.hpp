@@ -282,15 +282,98 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
 }
 
 // ------------------------------------------------------------------------------------------------
+// reverse_sweep_ckpt: the checkpointing=true form of InterpolatingAdjoint / GaussAdjoint
+// (CheckpointSolution, src/interpolating_adjoint.jl:20-27, 54-109, 207-277; src/gauss_adjoint.jl:158-217).
+// Only the checkpoint states are kept in HBM.  For every checkpoint interval [ka, kb] (top to bottom) the lane
+// re-integrates the forward problem from the stored u(ka) with the same RK4/dt ("re-solve the interval with
+// sol.alg") into a tile  tile[j][component][lane]  (LDS on the device: 64 lanes x 8 B = conflict-free rows), then
+// walks the interval backward through the same `step` as the dense sweep, with f(u_k) recomputed from the tile.
+// HBM traffic drops from 16n B per step to 8n B per checkpoint; the price is 4 extra f evaluations per step.
+// Segment bounds handed to this sweep are checkpoint knots (the planner guarantees it).
+// ------------------------------------------------------------------------------------------------
+struct CkptSrc {
+    const double* ckpt;          // [nck][N][Npad]
+    const int* ckpt_of_knot;     // [S+1] slot or -1
+    const int* prev_ck;          // [S+1] largest checkpoint knot < k
+    double* tile;                // (KMAX+1) * N * TS doubles
+    int TS, tl;                  // lane stride / lane index inside the tile (64, lane) on the device; (1, 0) on the host
+};
+
+template <class Mo, int KMAX, int LOSS, class Init, class Step>
+HIPADJ_HD void reverse_sweep_ckpt(const Geom& g, long i, int k_lo, int k_hi, const double (&pv)[Mo::NP], const CkptSrc& C,
+                                  const double* __restrict__ cotT, const int* __restrict__ save_of_knot, Init&& init, Step&& step) {
+    constexpr int N = Mo::N;
+    const double dt = g.dt;
+    Knot<Mo> hi;
+    bool have_hi = false;
+    for (int kb = k_hi; kb > k_lo;) {
+        int ka = C.prev_ck[kb]; if (ka < k_lo) ka = k_lo;
+        const int m = kb - ka;
+        // ---- re-solve [ka, kb] forward from the stored checkpoint
+        double u[N], k1[N], k2[N], k3[N], k4[N], us[N];
+        { const int c = C.ckpt_of_knot[ka];
+#pragma unroll
+          for (int j = 0; j < N; ++j) u[j] = C.ckpt[((long)c * N + j) * g.Npad + i]; }
+        for (int q = 0; q <= m; ++q) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) C.tile[((long)q * N + j) * C.TS + C.tl] = u[j];
+            if (q == m) break;
+            const double t = g.t0 + (ka + q) * dt;
+            Mo::f(k1, u, pv, t);
+#pragma unroll
+            for (int j = 0; j < N; ++j) us[j] = u[j] + 0.5 * dt * k1[j];
+            Mo::f(k2, us, pv, t + 0.5 * dt);
+#pragma unroll
+            for (int j = 0; j < N; ++j) us[j] = u[j] + 0.5 * dt * k2[j];
+            Mo::f(k3, us, pv, t + 0.5 * dt);
+#pragma unroll
+            for (int j = 0; j < N; ++j) us[j] = u[j] + dt * k3[j];
+            Mo::f(k4, us, pv, t + dt);
+#pragma unroll
+            for (int j = 0; j < N; ++j) u[j] = u[j] + (dt / 6.0) * (k1[j] + 2.0 * (k2[j] + k3[j]) + k4[j]);
+        }
+        if (!have_hi) {   // top of the sweep: the knot at k_hi comes from this (the last) interval's re-solve
+#pragma unroll
+            for (int j = 0; j < N; ++j) hi.u[j] = u[j];
+            Mo::f(hi.f, hi.u, pv, g.t0 + kb * dt);
+            have_hi = true;
+            if (k_hi == g.S) {
+                const int s = save_of_knot[k_hi];
+                double gl[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? ((s >= 0) ? cotT[((long)s * N + j) * g.Npad + i] : 0.0) : (hi.u[j] - g.loss_shift);
+                init(s >= 0, gl);
+            }
+        }
+        // ---- walk the interval backward
+        for (int k = kb - 1; k >= ka; --k) {
+            Knot<Mo> lo;
+#pragma unroll
+            for (int j = 0; j < N; ++j) lo.u[j] = C.tile[((long)(k - ka) * N + j) * C.TS + C.tl];
+            Mo::f(lo.f, lo.u, pv, g.t0 + k * dt);
+            const int s = save_of_knot[k];
+            const bool jump = s >= 0 && !(g.no_start && s == 0);
+            double gl[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? (jump ? cotT[((long)s * N + j) * g.Npad + i] : 0.0) : (lo.u[j] - g.loss_shift);
+            step(hi, lo, k, jump, gl);
+            hi = lo;
+        }
+        kb = ka;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // InterpolatingAdjoint over knots k_hi -> k_lo.  Column 0 is the affine column (starts at 0, receives the
 // loss jumps); columns 1..N are basis columns (lambda = e_j) when NC == 1 + N.
 //   top segment (k_hi == S): NC = 1, the jump at T is applied before the first step.
 // The jump at knot k_lo is applied at the end (so segment results chain without double counting).
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int NC, int PF, int LOSS>
+template <class Mo, int NC, int PF, int LOSS, int KMAX = 0>
 HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p,
                            const dbl2* __restrict__ knots, const double* __restrict__ cotT,
-                           const int* __restrict__ save_of_knot, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
+                           const int* __restrict__ save_of_knot, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP],
+                           const CkptSrc* ck = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
 #pragma unroll
@@ -300,16 +383,17 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
 #pragma unroll
         for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
     }
-    reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot,
-        [&](bool jump, const double (&gl)[N]) {
+    auto init = [&](bool jump, const double (&gl)[N]) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
-        },
-        [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
-            adj_rk4_step<Mo, NC, true>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
+        for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+    };
+    auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
+        adj_rk4_step<Mo, NC, true>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
-        });
+        for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+    };
+    if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, LOSS>(g, i, k_lo, k_hi, pv, *ck, cotT, save_of_knot, init, step);
+    else reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot, init, step);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,10 +498,10 @@ HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double 
 // derivatives at both ends) and y from the forward interpolant  (src/gauss_adjoint.jl:745-759, 809-851).
 // Time runs backward, so the accumulated sum equals int_{t0}^{T} lam^T f_p dt.
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int PF, int LOSS>
+template <class Mo, int PF, int LOSS, int KMAX = 0>
 HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
                           const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                          double (&lamo)[Mo::N], double (&muo)[Mo::NP]) {
+                          double (&lamo)[Mo::N], double (&muo)[Mo::NP], const CkptSrc* ck = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
     double lam[1][N], mu[1][NP];
@@ -427,12 +511,11 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, c
     for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
     const double dt = g.dt;
     const double xg = 0.5773502691896257645;
-    reverse_sweep<Mo, PF, LOSS>(g, i, 0, g.S, knots, cotT, save_of_knot,
-        [&](bool jump, const double (&gl)[N]) {
+    auto init = [&](bool jump, const double (&gl)[N]) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
-        },
-        [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
+        for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+    };
+    auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
             const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
             double lam_hi[N], d_hi[N], d_lo[N], V[N];
 #pragma unroll
@@ -458,7 +541,9 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, c
             }
 #pragma unroll
             for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
-        });
+    };
+    if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, LOSS>(g, i, 0, g.S, pv, *ck, cotT, save_of_knot, init, step);
+    else reverse_sweep<Mo, PF, LOSS>(g, i, 0, g.S, knots, cotT, save_of_knot, init, step);
 #pragma unroll
     for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
 #pragma unroll

@@ -16,6 +16,8 @@
 
 namespace hipadj {
 
+constexpr int HIPADJ_CKPT_KMAX = 16;   // longest checkpoint interval (steps) the in-kernel re-solve tile holds
+
 struct Plan {
     int n = 0, np = 0;
     long N = 0, Npad = 0;
@@ -24,6 +26,8 @@ struct Plan {
     std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
     std::vector<double> qa, qb;
     bool bs_ckpt = false;
+    bool ip_ckpt = false;    // Interpolating/Gauss with checkpointing=true: checkpoint tiles + in-kernel interval re-solve
+    std::vector<int> prev_ck; // largest checkpoint knot < k
     bool field = false;      // workgroup-per-trajectory family (hipadj_field.hpp)
     bool mlp = false;        // FP64-MFMA family (hipadj_mlp.hpp)
     int NQ = 0;              // activation records per step (MLP)
@@ -103,12 +107,19 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     // checkpoints: BacksolveAdjoint only.  Interpolating/Gauss checkpointing re-solves, on this fixed grid,
     // bit-identical knots from the stored values; the dense tiles are kept instead.
     P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
+    P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing && !P.field && !P.mlp;
     P.nck = 0;
-    if (P.bs_ckpt) {
+    if (P.bs_ckpt || P.ip_ckpt) {
         int c = 0;
         if (cfg->ckpt_stride > 0) { for (long k = 0; k <= S; k += cfg->ckpt_stride) P.ckpt_of_knot[k] = c++; if (P.ckpt_of_knot[S] < 0) P.ckpt_of_knot[S] = c++; }
         else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }
         P.nck = c;
+    }
+    P.prev_ck.assign(S + 1, 0);
+    if (P.ip_ckpt) {
+        int last = 0, longest = 0;
+        for (long k = 1; k <= S; ++k) { P.prev_ck[k] = last; if (P.ckpt_of_knot[k] >= 0) { if ((int)k - last > longest) longest = (int)k - last; last = (int)k; } }
+        if (longest > HIPADJ_CKPT_KMAX) { err = "checkpoint interval longer than 16 steps: the re-solve tile would not fit the LDS budget"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     P.nseg = 1;
     const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
@@ -131,7 +142,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
             for (int s = C - 1; s >= 1; --s) if (P.seg_bounds[s] >= P.seg_bounds[s + 1]) P.seg_bounds[s] = P.seg_bounds[s + 1] - 1;
         }
     }
-    if (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.nseg > 1) {
+    if ((cfg->alg == HIPADJ_ALG_BACKSOLVE || P.ip_ckpt) && P.nseg > 1) {
         // Backsolve segments may only be cut where y is known independently of the segments above: at checkpoint
         // knots.  Snap every interior bound to the nearest checkpoint knot and drop duplicates.
         std::vector<int> ck;

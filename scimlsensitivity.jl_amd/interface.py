@@ -29,17 +29,16 @@ def _save_times(tspan, saveat, dt):
 
 def _engine_kwargs(sensealg, checkpoints, dt, t0):
     kw = {}
-    if isinstance(sensealg, BacksolveAdjoint):
+    if isinstance(sensealg, (BacksolveAdjoint, InterpolatingAdjoint, GaussAdjoint)):
         kw["checkpointing"] = sensealg.checkpointing
         if checkpoints is not None and sensealg.checkpointing:
+            # `checkpoints` of adjoint_sensitivities (default sol.t): must be equally spaced on the step grid here
             ck = np.asarray(checkpoints, dtype=np.float64)
             ks = np.rint((ck - t0) / dt).astype(np.int64)
             stride = int(ks[1] - ks[0]) if len(ks) > 1 else 0
-            if len(ks) > 2 and not np.all(np.diff(ks) == stride):
+            if len(ks) > 2 and not np.all(np.diff(ks)[:-1] == stride):
                 raise ValueError("checkpoints must be equally spaced on the step grid (ckpt_stride)")
             kw["ckpt_stride"] = stride
-    elif isinstance(sensealg, (InterpolatingAdjoint, GaussAdjoint)):
-        kw["checkpointing"] = sensealg.checkpointing
     elif isinstance(sensealg, QuadratureAdjoint):
         kw["quad_abstol"], kw["quad_reltol"] = sensealg.abstol, sensealg.reltol
     return kw

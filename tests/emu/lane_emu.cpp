@@ -46,8 +46,9 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
     const long Np = P.Npad;
-    std::vector<dbl2> knots(cfg->alg != HIPADJ_ALG_BACKSOLVE ? (size_t)(P.S + 1) * N * Np : 0);
-    std::vector<double> ckpt(P.bs_ckpt ? (size_t)P.nck * N * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np);
+    std::vector<dbl2> knots((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) ? (size_t)(P.S + 1) * N * Np : 0);
+    std::vector<double> tile((size_t)(HIPADJ_CKPT_KMAX + 1) * N);
+    std::vector<double> ckpt((P.bs_ckpt || P.ip_ckpt) ? (size_t)P.nck * N * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np);
     std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0);
     std::vector<double> dp_traj((size_t)NP * Np, 0.0);
     for (long i = 0; i < P.N; ++i)
@@ -56,6 +57,8 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
     if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
     const double* cot = cotT.empty() ? nullptr : cotT.data();
+    const CkptSrc CK{ckpt.empty() ? nullptr : ckpt.data(), P.ckpt_of_knot.data(), P.prev_ck.data(), tile.data(), 1, 0};
+    constexpr int KM = HIPADJ_CKPT_KMAX;
     switch (cfg->alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
@@ -63,12 +66,14 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
             if (seg == P.nseg - 1) {
                 double lam[1][N], mu[1][NP];
-                interp_lane<Mo, 1, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                if (P.ip_ckpt) interp_lane<Mo, 1, PF, LOSS, KM>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
+                else interp_lane<Mo, 1, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
                 for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
                 for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
             } else {
                 double lam[NC][N], mu[NC][NP];
-                interp_lane<Mo, NC, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                if (P.ip_ckpt) interp_lane<Mo, NC, PF, LOSS, KM>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
+                else interp_lane<Mo, NC, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
                 for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
             }
@@ -97,7 +102,8 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     case HIPADJ_ALG_GAUSS:
         for (long i = 0; i < P.N; ++i) {
             double lam[N], mu[NP];
-            gauss_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+            if (P.ip_ckpt) gauss_lane<Mo, PF, LOSS, KM>(g, i, p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
+            else gauss_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
             for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
             for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
         }

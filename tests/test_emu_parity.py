@@ -104,3 +104,31 @@ def test_backsolve_segmented_at_checkpoints_equals_sequential(segments, stride):
                     checkpointing=True, checkpoints=cks)
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
     assert rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "gauss"])
+@pytest.mark.parametrize("segments,stride", [(1, 0), (4, 0), (3, 5), (1, 16)])
+def test_checkpointed_interpolating_gauss_resolve_tiles(alg, segments, stride):
+    """checkpointing=true: only checkpoint states are stored; every interval is re-solved into a tile and swept
+    backward (src/interpolating_adjoint.jl:207-277).  Must equal the oracle's checkpointed run (and the dense one)."""
+    rng = np.random.default_rng(14)
+    N, T, dt = 3, 2.0, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.linspace(0, T, 21)
+    cks = None if stride == 0 else np.unique(np.append(np.arange(0, 201, stride), 200)) * dt
+    for loss_kind, delta in ((1, None), (0, rng.standard_normal((N, len(ts), 3)))):
+        cfg = E.make_config("lorenz", alg, N, 0.0, T, dt, ts, loss_kind=loss_kind, loss_shift=2.0, checkpointing=True,
+                            ckpt_stride=stride, time_segments=segments)
+        du0, dp, out = E.forward_adjoint(cfg, 3, 3, u0, p, delta)
+        ref = O.Problem("LORENZ", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts,
+                        loss="LSQ_SHIFT" if loss_kind else "COTANGENT", loss_shift=2.0, checkpointing=True, checkpoints=cks)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+        assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+def test_checkpoint_interval_too_long_is_rejected():
+    import ctypes as C
+    cfg = E.make_config("lorenz", "interpolating", 2, 0.0, 1.0, 0.01, [0.5, 1.0], checkpointing=True)   # 50-step intervals
+    nseg, nck, nq = C.c_int(), C.c_int(), C.c_int(); b = (C.c_int * 8)()
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 8, C.byref(nck), C.byref(nq)) == -6
+    assert "checkpoint interval" in E.lib().emu_last_error().decode()

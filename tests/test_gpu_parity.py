@@ -94,6 +94,29 @@ def test_time_segmentation_is_invisible(sa, segments):
     sol.engine.close()
 
 
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+@pytest.mark.parametrize("segments", [1, 0])
+def test_checkpointed_interpolating_gauss_on_device(sa, alg, oalg, segments):
+    """checkpointing=true: checkpoint tiles in HBM + in-kernel interval re-solve (LDS tile), vs the oracle's
+    CheckpointSolution restatement; also equals the dense variant to roundoff."""
+    N, T, dt = 150, 4.0, 0.01
+    u0, p = lorenz_inputs(N, seed=31)
+    ts = np.linspace(0, T, 41)
+    SA = sa.InterpolatingAdjoint if alg == "interpolating" else sa.GaussAdjoint
+    res, ws = {}, {}
+    for ck in (True, False):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                       sensealg=SA(checkpointing=ck), dgdu_discrete=sa.LsqShift(2.0), time_segments=segments)
+        res[ck] = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+        ws[ck] = sol.engine.stats()["workspace_bytes"]
+        sol.engine.close()
+    assert ws[False] - ws[True] > 0.9 * 401 * 16 * 3 * 192 - 41 * 8 * 3 * 192   # the dense interpolant tiles were never allocated
+    ref = O.Problem("LORENZ", alg=oalg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, checkpointing=True)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(res[True][0], rdu0) < RTOL and rel(res[True][1], rdp) < RTOL
+    assert rel(res[True][0], res[False][0]) < 1e-9 and rel(res[True][1], res[False][1]) < 1e-9
+
+
 @pytest.mark.parametrize("segments", [1, 5, 0])
 def test_backsolve_segmented_at_checkpoints(sa, segments):
     N, T, dt = 100, 4.0, 0.01
