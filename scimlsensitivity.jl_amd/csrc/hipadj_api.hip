@@ -326,16 +326,20 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                            d_du0, dp_rows, h->d_partial, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         break; }
-    case HIPADJ_ALG_GAUSS:
+    case HIPADJ_ALG_GAUSS: {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt)
-            hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
-                               (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj);
+            hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         else
-        hipLaunchKernelGGL((k_gauss<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
-                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj);
+            hipLaunchKernelGGL((k_gauss<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
+                               (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
-        break;
+        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(fblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                           d_du0, dp_rows, h->d_partial, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        break; }
     case HIPADJ_ALG_QUADRATURE: {
         hipLaunchKernelGGL((k_quad_adj<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
                            (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0);
@@ -350,7 +354,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         break; }
     }
     // finishing stage: NaN/Inf scan + per-workgroup partial sums of mu (Interpolating fused it with the composition)
-    if (h->cfg.alg != HIPADJ_ALG_INTERPOLATING && h->cfg.alg != HIPADJ_ALG_BACKSOLVE) {
+    if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
         hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
                            (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag);
         HIP_TRY(h, hipGetLastError());

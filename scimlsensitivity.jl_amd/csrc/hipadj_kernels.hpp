@@ -95,24 +95,6 @@ __global__ void __launch_bounds__(WAVE) k_interp_ckpt(Geom g, SegPlan sp, const 
     }
 }
 
-template <class Mo, int LOSS>
-__global__ void __launch_bounds__(WAVE) k_gauss_ckpt(Geom g, const double* __restrict__ p, const double* __restrict__ ckpt,
-                                                     const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
-                                                     const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                                                     double* __restrict__ du0, double* __restrict__ dp_traj) {
-    constexpr int N = Mo::N, NP = Mo::NP, KM = HIPADJ_CKPT_KMAX;
-    __shared__ double tile[(KM + 1) * N * WAVE];
-    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
-    if (i >= g.N) return;
-    const CkptSrc C{ckpt, ckpt_of_knot, prev_ck, tile, WAVE, (int)threadIdx.x};
-    double lam[N], mu[NP];
-    gauss_lane<Mo, 1, LOSS, KM>(g, i, p, nullptr, cotT, save_of_knot, lam, mu, &C);
-#pragma unroll
-    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
-}
-
 // ---- finishing stage -------------------------------------------------------------------------------------
 // Per 256-thread workgroup: (optionally) compose the segment maps of each trajectory, scan for NaN/Inf (the
 // reference's retcode check), write du0 / per-trajectory dp, and reduce mu over the workgroup's trajectories in a
@@ -270,19 +252,62 @@ __global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, SegPlan sp, const do
     }
 }
 
+template <class Mo, int NC>
+__device__ __forceinline__ void store_segment_map(double* __restrict__ dst, long Npad, const double (&lam)[NC][Mo::N], const double (&mu)[NC][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP, R = N + NP;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) dst[((long)c * R + j) * Npad] = lam[c][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * Npad] = mu[c][j];
+    }
+}
+
+// GaussAdjoint, time-segmented like k_interp (segment maps -> k_compose_finish)
 template <class Mo, int PF, int LOSS>
-__global__ void __launch_bounds__(WAVE) k_gauss(Geom g, const double* __restrict__ p, const dbl2* __restrict__ knots,
+__global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                                 const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                                                double* __restrict__ du0, double* __restrict__ dp_traj) {
-    constexpr int N = Mo::N, NP = Mo::NP;
+                                                double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;
     if (i >= g.N) return;
-    double lam[N], mu[NP];
-    gauss_lane<Mo, PF, LOSS>(g, i, p, knots, cotT, save_of_knot, lam, mu);
-#pragma unroll
-    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
+    if (seg == sp.nseg - 1) {
+        double lam[1][N], mu[1][NP];
+        gauss_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        store_segment_map<Mo, 1>(dst, g.Npad, lam, mu);
+    } else {
+        double lam[NC][N], mu[NC][NP];
+        gauss_lane<Mo, NC, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        store_segment_map<Mo, NC>(dst, g.Npad, lam, mu);
+    }
+}
+
+template <class Mo, int LOSS>
+__global__ void __launch_bounds__(WAVE) k_gauss_ckpt(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ ckpt,
+                                                     const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
+                                                     const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                                                     double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, KM = HIPADJ_CKPT_KMAX;
+    __shared__ double tile[(KM + 1) * N * WAVE];
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;
+    if (i >= g.N) return;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    const CkptSrc C{ckpt, ckpt_of_knot, prev_ck, tile, WAVE, (int)threadIdx.x};
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
+    if (seg == sp.nseg - 1) {
+        double lam[1][N], mu[1][NP];
+        gauss_lane<Mo, 1, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
+        store_segment_map<Mo, 1>(dst, g.Npad, lam, mu);
+    } else {
+        double lam[NC][N], mu[NC][NP];
+        gauss_lane<Mo, NC, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
+        store_segment_map<Mo, NC>(dst, g.Npad, lam, mu);
+    }
 }
 
 template <class Mo, int PF, int LOSS>

@@ -498,17 +498,21 @@ HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double 
 // derivatives at both ends) and y from the forward interpolant  (src/gauss_adjoint.jl:745-759, 809-851).
 // Time runs backward, so the accumulated sum equals int_{t0}^{T} lam^T f_p dt.
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int PF, int LOSS, int KMAX = 0>
-HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
+// Like interp_lane the sweep is linear in (lam, mu) given y(t), so it takes NC columns (affine + basis) and a segment
+// [k_lo, k_hi): the same time segmentation and composition apply.
+template <class Mo, int NC, int PF, int LOSS, int KMAX = 0>
+HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p, const dbl2* __restrict__ knots,
                           const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                          double (&lamo)[Mo::N], double (&muo)[Mo::NP], const CkptSrc* ck = nullptr) {
+                          double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP], const CkptSrc* ck = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
-    double lam[1][N], mu[1][NP];
 #pragma unroll
-    for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+        for (int j = 0; j < N; ++j) lam[c][j] = (c > 0 && c - 1 == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
+    }
     const double dt = g.dt;
     const double xg = 0.5773502691896257645;
     auto init = [&](bool jump, const double (&gl)[N]) {
@@ -516,38 +520,41 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, const double* __restrict__ p, c
         for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
     };
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
-            const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
-            double lam_hi[N], d_hi[N], d_lo[N], V[N];
+        const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
+        double lam_hi[NC][N], d_hi[NC][N], V[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam_hi[j] = lam[0][j];
-            Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
+        for (int c = 0; c < NC; ++c) {
+            Mo::vjp_u(V, lam[c], hi.u, pv, t_hi);
 #pragma unroll
-            for (int j = 0; j < N; ++j) d_hi[j] = -V[j];                     // fsalfirst of the adjoint step
-            adj_rk4_step<Mo, 1, false>(hi, lo, pv, t_lo, dt, lam, mu);
-            Mo::vjp_u(V, lam[0], lo.u, pv, t_lo);
+            for (int j = 0; j < N; ++j) { lam_hi[c][j] = lam[c][j]; d_hi[c][j] = -V[j]; }      // fsalfirst of the adjoint step
+        }
+        adj_rk4_step<Mo, NC, false>(hi, lo, pv, t_lo, dt, lam, mu);
+        // forward state at the two Gauss nodes t_g = mid + half*x, half = (t_lo - t_hi)/2 < 0; theta along the adjoint
+        // step = (1 + x)/2; shared by all columns
+        double yg[2][N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) d_lo[j] = -V[j];                     // fsallast
-            // Gauss nodes t_g = mid + half*x, half = (t_lo - t_hi)/2 < 0; theta along the adjoint step = (1 + x)/2
+        for (int q = 0; q < 2; ++q) hermite<N>(1.0 - 0.5 * (1.0 + (q == 0 ? -xg : xg)), dt, lo.u, lo.f, hi.u, hi.f, yg[q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double d_lo[N];
+            Mo::vjp_u(V, lam[c], lo.u, pv, t_lo);
+#pragma unroll
+            for (int j = 0; j < N; ++j) d_lo[j] = -V[j];                                        // fsallast
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const double x = q == 0 ? -xg : xg;
-                const double th = 0.5 * (1.0 + x);
-                double lg[N], yg[N], W[NP];
-                hermite<N>(th, -dt, lam_hi, d_hi, lam[0], d_lo, lg);
-                hermite<N>(1.0 - th, dt, lo.u, lo.f, hi.u, hi.f, yg);
-                Mo::vjp_p(W, lg, yg, pv, t_hi - th * dt);
+                const double th = 0.5 * (1.0 + (q == 0 ? -xg : xg));
+                double lg[N], W[NP];
+                hermite<N>(th, -dt, lam_hi[c], d_hi[c], lam[c], d_lo, lg);
+                Mo::vjp_p(W, lg, yg[q], pv, t_hi - th * dt);
 #pragma unroll
-                for (int j = 0; j < NP; ++j) mu[0][j] += (0.5 * dt) * W[j];
+                for (int j = 0; j < NP; ++j) mu[c][j] += (0.5 * dt) * W[j];
             }
+        }
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
     };
-    if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, LOSS>(g, i, 0, g.S, pv, *ck, cotT, save_of_knot, init, step);
-    else reverse_sweep<Mo, PF, LOSS>(g, i, 0, g.S, knots, cotT, save_of_knot, init, step);
-#pragma unroll
-    for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) muo[j] = mu[0][j];
+    if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, LOSS>(g, i, k_lo, k_hi, pv, *ck, cotT, save_of_knot, init, step);
+    else reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot, init, step);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -122,7 +122,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (longest > HIPADJ_CKPT_KMAX) { err = "checkpoint interval longer than 16 steps: the re-solve tile would not fit the LDS budget"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     P.nseg = 1;
-    const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
+    const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
     if (seg_alg) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n) : cfg->time_segments;
         if (P.nseg > P.S) P.nseg = P.S;

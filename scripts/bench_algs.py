@@ -23,8 +23,9 @@ def main():
     dev = torch.device("cuda", 0)
     u0 = torch.tensor(u0n, device=dev); p = torch.tensor([10.0, 28.0, 8.0 / 3.0], device=dev, dtype=torch.float64)
     du0 = torch.empty((N, 3), device=dev, dtype=torch.float64); dp = torch.empty(3, device=dev, dtype=torch.float64)
-    for alg, kw in (("interpolating", {}), ("backsolve", dict(checkpointing=True)), ("backsolve", dict(checkpointing=True, time_segments=1)),
-                    ("gauss", {}), ("quadrature", {})):
+    for alg, kw in (("interpolating", {}), ("interpolating", dict(time_segments=1)), ("interpolating", dict(checkpointing=True)),
+                    ("backsolve", dict(checkpointing=True)), ("backsolve", dict(checkpointing=True, time_segments=1)),
+                    ("gauss", {}), ("gauss", dict(time_segments=1)), ("gauss", dict(checkpointing=True)), ("quadrature", {})):
         eng = sa.Engine("lorenz", alg, N, 0.0, 10.0, 0.01, save_times=ts, loss_kind=1, loss_shift=2.0, **kw)
         eng.use_torch_stream()
         eng.forward_dev(u0, p, None)

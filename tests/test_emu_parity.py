@@ -132,3 +132,16 @@ def test_checkpoint_interval_too_long_is_rejected():
     nseg, nck, nq = C.c_int(), C.c_int(), C.c_int(); b = (C.c_int * 8)()
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 8, C.byref(nck), C.byref(nq)) == -6
     assert "checkpoint interval" in E.lib().emu_last_error().decode()
+
+
+@pytest.mark.parametrize("segments", [2, 5, 0])
+def test_gauss_time_segmented_equals_sequential(segments):
+    rng = np.random.default_rng(18)
+    N, T, dt = 3, 3.0, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.linspace(0, T, 31)
+    cfg = E.make_config("lorenz", "gauss", N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, time_segments=segments)
+    du0, dp, _ = E.forward_adjoint(cfg, 3, 3, u0, p)
+    ref = O.Problem("LORENZ", alg="GAUSS", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < 1e-11 and rel(dp, rdp) < 1e-11

@@ -79,6 +79,20 @@ def test_cotangent_path_all_models(sa, alg, oalg, model, omodel, u0c, p):
     sol.engine.close()
 
 
+@pytest.mark.parametrize("segments", [1, 4, 0])
+def test_gauss_time_segmentation_is_invisible(sa, segments):
+    N, T, dt = 130, 4.0, 0.01
+    u0, p = lorenz_inputs(N, seed=6)
+    ts = np.linspace(0, T, 41)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0), time_segments=segments)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+    ref = O.Problem("LORENZ", alg="GAUSS", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
 @pytest.mark.parametrize("segments", [1, 2, 7, 0])
 def test_time_segmentation_is_invisible(sa, segments):
     """The segmented reverse pass (affine-map composition) reproduces the sequential one (oracle)."""
