@@ -100,18 +100,31 @@ def main():
     u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
     p = torch.tensor(p_np, device=dev, dtype=torch.float64)
     du0 = torch.empty((n_local, 3), device=dev, dtype=torch.float64)
-    dp = torch.empty(3, device=dev, dtype=torch.float64)
+    dps = [torch.empty(3, device=dev, dtype=torch.float64) for _ in range(2)]
     eng.forward_dev(u0, p, None)          # forward solve: interpolant tiles now resident in HBM
     torch.cuda.synchronize()
     fwd_ms = None
+    state = {"it": 0, "pending": None}
 
     def step():
+        # reverse pass of this step; the all-reduce of dL/dp (RCCL, its own stream) overlaps the NEXT step's kernels:
+        # dp is double-buffered and the previous step's reduction is only waited for here
+        dp = dps[state["it"] & 1]
         eng.adjoint_dev(None, du0, dp)
         if world > 1:
-            dist.all_reduce(dp, op=dist.ReduceOp.SUM)
+            if state["pending"] is not None:
+                state["pending"].wait()
+            state["pending"] = dist.all_reduce(dp, op=dist.ReduceOp.SUM, async_op=True)
+        state["it"] += 1
+
+    def drain():
+        if state["pending"] is not None:
+            state["pending"].wait()
+            state["pending"] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     eng.synchronize()
     st0 = eng.stats()
@@ -121,6 +134,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
