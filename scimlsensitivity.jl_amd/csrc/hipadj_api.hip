@@ -188,6 +188,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     Geom& g = h->g;
     g.N = h->N; g.Npad = Np; g.S = (int)S; g.M = h->M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
+    g.kmask = -1;
+    if (const char* e = std::getenv("HIPADJ_EXP_KMASK")) g.kmask = std::atoi(e);   // timing experiment only (results are wrong with a mask)
     h->fg.N = h->N; h->fg.S = (int)S; h->fg.M = h->M; h->fg.t0 = cfg->t0; h->fg.dt = cfg->dt; h->fg.loss_shift = cfg->loss_shift;
     h->fg.loss_kind = cfg->loss_kind; h->fg.no_start = cfg->no_start; h->fg.p_shared = cfg->p_shared;
     h->mg.N = h->N; h->mg.B = cfg->dims[2]; h->mg.S = (int)S; h->mg.M = h->M; h->mg.t0 = cfg->t0; h->mg.dt = cfg->dt; h->mg.loss_shift = cfg->loss_shift;
@@ -442,7 +444,7 @@ template <int H> static int mlp_forward_launch(hipadj_handle* h, const double* d
     const int groups = h->cfg.p_shared ? 1 : (int)h->N;
     hipLaunchKernelGGL(k_mlp_transpose_w2, dim3(64, (unsigned)groups), dim3(256), 0, h->stream, H, Mlp<H>::NPAR, H * 2 + H, d_p, h->d_w2t);
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL((k_mlp_forward<H>), dim3((unsigned)(h->mg.B / 16), (unsigned)h->N), dim3(64), 0, h->stream, h->mg, d_u0, d_p, (const double*)h->d_w2t,
+    hipLaunchKernelGGL((k_mlp_forward<H>), dim3((unsigned)(h->mg.B / 16), (unsigned)h->N), dim3(Mlp<H>::NT), 0, h->stream, h->mg, d_u0, d_p, (const double*)h->d_w2t,
                        h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
     HIP_TRY(h, hipGetLastError());
     return HIPADJ_OK;
@@ -456,12 +458,12 @@ template <int H> static int mlp_adjoint_launch(hipadj_handle* h, const double* d
     HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     MlpRec<H> R{h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2};
-    const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), blk(64);
+    const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), blk(64), sweep_blk(Mlp<H>::NT);
     if (h->cfg.alg == HIPADJ_ALG_GAUSS)
-        hipLaunchKernelGGL((k_mlp_adjoint<H, 2>), grid, blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
+        hipLaunchKernelGGL((k_mlp_adjoint<H, 2>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
                            (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
     else
-        hipLaunchKernelGGL((k_mlp_adjoint<H, 0>), grid, blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
+        hipLaunchKernelGGL((k_mlp_adjoint<H, 0>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
                            (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(es.k1, h->stream));

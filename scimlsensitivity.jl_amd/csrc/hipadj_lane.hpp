@@ -47,14 +47,16 @@ struct Geom {
     int loss_kind;     // 0 cotangent, 1 lsq_shift
     int no_start;
     int p_shared;
+    int kmask;         // experiment hook (normally -1): knot index & kmask is what gets loaded — isolates HBM from issue limits
 };
 
 template <class Mo> struct Knot { double u[Mo::N]; double f[Mo::N]; };
 
 // knot k of trajectory i: 2N doubles packed as N pairs
 template <class Mo>
-HIPADJ_HD void load_knot(const dbl2* __restrict__ K, long Npad, int k, long i, Knot<Mo>& kn) {
+HIPADJ_HD void load_knot(const dbl2* __restrict__ K, long Npad, int k, long i, Knot<Mo>& kn, int kmask = -1) {
     constexpr int N = Mo::N;
+    k &= kmask;
     double v[2 * N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -149,34 +151,31 @@ HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double
     const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        double V1[N], V2[N], V3[N], V4[N], ls[N];
-        double W[NP], Wacc[NP];
+        double V1[N], V2[N], V3[N], V4[N], l2[N], l3[N], l4[N];
         Mo::vjp_u(V1, lam[c], hi.u, pv, t_hi);
-        if (WITH_MU) { Mo::vjp_p(Wacc, lam[c], hi.u, pv, t_hi); }
 #pragma unroll
-        for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V1[j];
-        Mo::vjp_u(V2, ls, ymid, pv, t_mid);
-        if (WITH_MU) { Mo::vjp_p(W, ls, ymid, pv, t_mid);
+        for (int j = 0; j < N; ++j) l2[j] = lam[c][j] + (0.5 * dt) * V1[j];
+        Mo::vjp_u(V2, l2, ymid, pv, t_mid);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j]; }
+        for (int j = 0; j < N; ++j) l3[j] = lam[c][j] + (0.5 * dt) * V2[j];
+        Mo::vjp_u(V3, l3, ymid, pv, t_mid);
 #pragma unroll
-        for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V2[j];
-        Mo::vjp_u(V3, ls, ymid, pv, t_mid);
-        if (WITH_MU) { Mo::vjp_p(W, ls, ymid, pv, t_mid);
+        for (int j = 0; j < N; ++j) l4[j] = lam[c][j] + dt * V3[j];
+        Mo::vjp_u(V4, l4, lo.u, pv, t_lo);
+        if (WITH_MU) {
+            // mu' = -(df/dp)^T lam, RK4 weights 1:2:2:1.  (df/dp)^T lam is linear in lam and stages 2 and 3 share the
+            // same y (the Hermite midpoint) and t, so their two VJPs collapse into one on lam_2 + lam_3.
+            double W1[NP], W23[NP], W4[NP], l23[N];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j]; }
+            for (int j = 0; j < N; ++j) l23[j] = l2[j] + l3[j];
+            Mo::vjp_p(W1, lam[c], hi.u, pv, t_hi);
+            Mo::vjp_p(W23, l23, ymid, pv, t_mid);
+            Mo::vjp_p(W4, l4, lo.u, pv, t_lo);
 #pragma unroll
-        for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + dt * V3[j];
-        Mo::vjp_u(V4, ls, lo.u, pv, t_lo);
-        if (WITH_MU) { Mo::vjp_p(W, ls, lo.u, pv, t_lo);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) Wacc[j] += W[j]; }
+            for (int j = 0; j < NP; ++j) mu[c][j] = mu[c][j] + (dt / 6.0) * (W1[j] + 2.0 * W23[j] + W4[j]);
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j) lam[c][j] = lam[c][j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
-        if (WITH_MU) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) mu[c][j] = mu[c][j] + (dt / 6.0) * Wacc[j];
-        }
     }
 }
 
@@ -211,7 +210,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
                              const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                              Init&& init, Step&& step) {
     constexpr int N = Mo::N;
-    Knot<Mo> carry; load_knot<Mo>(knots, g.Npad, k_hi, i, carry);
+    Knot<Mo> carry; load_knot<Mo>(knots, g.Npad, k_hi, i, carry, g.kmask);
     if (k_hi == g.S) {   // PresetTimeCallback fires at initialisation when T is a loss time
         const int s = save_of_knot[k_hi];
         double gl[N];
@@ -232,7 +231,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
 #pragma unroll
     for (int r = 0; r < PF; ++r) {
         const int kk = k_hi - 1 - r, kc = kk > k_lo ? kk : k_lo;
-        load_knot<Mo>(knots, g.Npad, kc, i, ring[r]);
+        load_knot<Mo>(knots, g.Npad, kc, i, ring[r], g.kmask);
         load_cot<Mo, LOSS>(g, i, LOSS == 0 ? save_of_knot[kc] : 0, cotT, cot[r]);
     }
     int kb = k_hi - 1;
@@ -257,13 +256,13 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
             HIPADJ_STEP_FENCE();
             if (r >= 1) {   // slot r-1 is dead: refill it for the next block (knot kb - PF - (r-1))
                 const int kn = kb - PF - (r - 1);
-                load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[r - 1]);
+                load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[r - 1], g.kmask);
                 load_cot<Mo, LOSS>(g, i, sfn[r - 1], cotT, cot[r - 1]);
             }
         }
         carry = ring[PF - 1];
         { const int kn = kb - PF - (PF - 1);
-          load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[PF - 1]);
+          load_knot<Mo>(knots, g.Npad, kn > k_lo ? kn : k_lo, i, ring[PF - 1], g.kmask);
           load_cot<Mo, LOSS>(g, i, sfn[PF - 1], cotT, cot[PF - 1]); }
     }
     // partial last block: ring[j] already holds knot max(kb - j, k_lo)

@@ -3,13 +3,17 @@
 //     X is d x B (column-major, d = 2),  f(X) = W3 tanh(W2 tanh(W1 X + b1) + b2) + b3   applied column-wise,
 //     p = [W1 (H x d), b1, W2 (H x H), b2, W3 (d x H), b3], all column-major.
 //
-// The batch columns are independent given the weights, so ONE WAVE integrates 16 columns through the whole
-// reverse sweep.  The two H x H contractions per VJP (W2 H1 forward, W2^T G2 backward) run on the matrix cores:
+// The batch columns are independent given the weights, so ONE WORKGROUP integrates 16 columns through the whole
+// reverse sweep; its NW = min(4, H/16) waves (one per SIMD of the CU) split the H output rows of every layer, so both
+// the MFMA work and the FP64 tanh work (which dominates: ~150 VALU instructions each) use all four SIMDs.
+// The two H x H contractions per VJP (W2 H1 forward, W2^T G2 backward) run on the matrix cores:
 //     v_mfma_f64_16x16x4_f64:  A[i = l&15][k = l>>4] (one f64 per lane), B[k = l>>4][j = l&15],
 //     C/D: col = l & 15, row = (l >> 4) + 4 * reg   (the f64 map, cdna_hip_programming.md §3)
 // With the batch column on j = l & 15, register r of output tile t holds row 16t + 4r + (l>>4): for fixed r the four
-// lane groups hold FOUR CONSECUTIVE rows, i.e. exactly the B operand of the K-step (t, r) of the next layer.
-// Activations therefore flow layer to layer in registers — no LDS round trip, tanh fused on the accumulator.
+// lane groups hold FOUR CONSECUTIVE rows, i.e. exactly the B operand layout of a K-step of the next layer: a wave
+// writes its rows of the activation to an LDS tile act[row][16] (64 consecutive doubles per store: conflict-free),
+// one s_barrier, and every wave reads its B operands as act[4 st + (l>>4)][l&15] (again 64 consecutive doubles).
+// tanh is fused on the accumulator.  Two barriers per forward / backward pass (activation exchange, d-sized reduction).
 // A operands (16 x 4 blocks of W2 / W2^T) are read straight from L2 (128 KB, shared by every wave); the d-sized
 // contractions (W1, W3) are VALU work plus a two-step cross-lane-group reduction (__shfl_xor 16, 32).
 //
@@ -40,9 +44,12 @@ struct MlpGeom {
 
 template <int H> struct Mlp {
     static constexpr int D = 2, TT = H / 16;       // row tiles
+    static constexpr int NW = TT >= 4 ? 4 : TT;    // waves per workgroup (row split)
+    static constexpr int TW = TT / NW;             // row tiles per wave
+    static constexpr int NT = 64 * NW;             // threads per workgroup
     static constexpr int NPAR = H * D + H + H * H + H + D * H + D;
     static constexpr int HP = H + 16;              // H rows + a 16-row tile whose first row is the ones row
-    static_assert(H % 16 == 0, "hidden width must be a multiple of 16");
+    static_assert(H % 16 == 0 && TT % NW == 0, "hidden width must be a multiple of 16 (and of 64 beyond 48)");
 };
 
 template <int H> struct MlpW { const double *W1, *b1, *W2, *b2, *W3, *b3, *W2T; };
@@ -54,33 +61,35 @@ template <int H> __device__ __forceinline__ MlpW<H> mlp_weights(const double* __
     return w;
 }
 
-// out[t] (+)= Wm (H x H, column-major) . act  with act in the register layout described above.
-// K-step (kt, r) issues TT MFMAs that share one B operand; its TT A operands (16 x 4 blocks of Wm, L2-resident) are
-// fetched ONE K-step ahead and a scheduling fence per K-step keeps hipcc from hoisting all H*H/64 loads to the top
-// (which spilled 7.5 KB per lane at H = 128).
+// LDS of one workgroup: the exchanged activation tile and the cross-wave reduction scratch
+template <int H> struct MlpLds { double act[H * 16]; double red[4][16][2]; };
+
+// acc[t] (+)= rows (16 (t0 + t) .. +15) of  Wm (H x H, column-major) . act   with act read from the LDS tile.
+// The TW A operands of a K-step (16 x 4 blocks of Wm, L2-resident) are fetched ONE K-step ahead; a scheduling fence per
+// K-step keeps hipcc from hoisting all loads to the top, and the lane offset is made opaque per call so that the address
+// arithmetic is not hoisted out of the time loop as hundreds of live 64-bit VGPR pairs (both spilled KBs per lane).
 template <int H>
-__device__ __forceinline__ void mlp_gemm(const double* __restrict__ Wm, const double (&act)[H / 16][4], mlp_d4 (&acc)[H / 16]) {
-    constexpr int TT = H / 16, NK = TT * 4;
-    // uniform base (SGPR pair) + ONE 32-bit lane offset + compile-time constants: the loads use the saddr form and no
-    // per-load 64-bit address VGPRs exist for LICM to hoist out of the time loop (that is what spilled before)
-    unsigned lane_off = (threadIdx.x & 15u) + ((threadIdx.x & 63u) >> 4) * (unsigned)H;
-    asm volatile("" : "+v"(lane_off));   // opaque per call: address arithmetic stays next to its load instead of being
-                                         // hoisted out of the time loop as hundreds of live 64-bit VGPR pairs
-    double a_cur[TT], a_nxt[TT];
+__device__ __forceinline__ void mlp_gemm(const double* __restrict__ Wm, const double* __restrict__ act, int t0, mlp_d4 (&acc)[Mlp<H>::TW]) {
+    constexpr int TW = Mlp<H>::TW, NK = H / 4;
+    const unsigned li = threadIdx.x & 15u, lq = (threadIdx.x & 63u) >> 4;
+    unsigned lane_off = li + lq * (unsigned)H + 16u * (unsigned)t0;
+    asm volatile("" : "+v"(lane_off));
+    const unsigned act_off = lq * 16u + li;
+    double a_cur[TW], a_nxt[TW];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) a_cur[t] = Wm[lane_off + (unsigned)(16 * t)];
+    for (int t = 0; t < TW; ++t) a_cur[t] = Wm[lane_off + (unsigned)(16 * t)];
 #pragma unroll
     for (int st = 0; st < NK; ++st) {
         if (st + 1 < NK) {
 #pragma unroll
-            for (int t = 0; t < TT; ++t) a_nxt[t] = Wm[lane_off + (unsigned)(16 * t + 4 * (st + 1) * H)];
+            for (int t = 0; t < TW; ++t) a_nxt[t] = Wm[lane_off + (unsigned)(16 * t + 4 * (st + 1) * H)];
         }
-        const double b = act[st / 4][st % 4];
+        const double b = act[act_off + (unsigned)(64 * st)];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], b, acc[t], 0, 0, 0);
+        for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], b, acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < TT; ++t) a_cur[t] = a_nxt[t];
+        for (int t = 0; t < TW; ++t) a_cur[t] = a_nxt[t];
     }
 }
 
@@ -90,67 +99,88 @@ __device__ __forceinline__ double group_sum4(double v) {   // sum over the four 
     return v;
 }
 
-// forward pass for the wave's 16 columns: x[D] per lane (column l&15, replicated over the 4 lane groups)
+// cross-wave sum of a per-wave (o0, o1) pair for column l&15; every lane of every wave gets the total
 template <int H>
-__device__ __forceinline__ void mlp_forward(const MlpW<H>& w, const double (&x)[2], double (&h1)[H / 16][4], double (&h2)[H / 16][4], double (&out)[2]) {
-    constexpr int TT = H / 16, D = 2;
-    const unsigned lq = (threadIdx.x & 63u) >> 4;
-    mlp_d4 acc[TT];
+__device__ __forceinline__ void mlp_reduce2(MlpLds<H>& L, double o0, double o1, double (&out)[2]) {
+    constexpr int NW = Mlp<H>::NW;
+    const int wv = threadIdx.x >> 6, li = threadIdx.x & 15;
+    o0 = group_sum4(o0); o1 = group_sum4(o1);
+    if (((threadIdx.x & 63) >> 4) == 0) { L.red[wv][li][0] = o0; L.red[wv][li][1] = o1; }
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int w = 0; w < NW; ++w) { s0 += L.red[w][li][0]; s1 += L.red[w][li][1]; }
+    out[0] = s0; out[1] = s1;
+}
+
+// forward pass for the workgroup's 16 columns: x[D] per lane (column l&15, replicated over lane groups and waves);
+// h1/h2 hold THIS WAVE's rows (tiles t0 .. t0+TW-1) in the MFMA accumulator layout
+template <int H>
+__device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, const double (&x)[2], double (&h1)[Mlp<H>::TW][4], double (&h2)[Mlp<H>::TW][4], double (&out)[2]) {
+    constexpr int TW = Mlp<H>::TW;
+    const unsigned lq = (threadIdx.x & 63u) >> 4, li = threadIdx.x & 15u;
+    const int t0 = (threadIdx.x >> 6) * TW;
+    mlp_d4 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned row = (unsigned)(16 * t + 4 * r) + lq;
+            const unsigned row = (unsigned)(16 * (t0 + t) + 4 * r) + lq;
             h1[t][r] = tanh(w.b1[row] + w.W1[row] * x[0] + w.W1[row + (unsigned)H] * x[1]);
             acc[t][r] = w.b2[row];
+            L.act[row * 16u + li] = h1[t][r];
         }
     }
-    mlp_gemm<H>(w.W2, h1, acc);
+    __syncthreads();
+    mlp_gemm<H>(w.W2, L.act, t0, acc);
     double o0 = 0.0, o1 = 0.0;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < TW; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned row = (unsigned)(16 * t + 4 * r) + lq;
+            const unsigned row = (unsigned)(16 * (t0 + t) + 4 * r) + lq;
             h2[t][r] = tanh(acc[t][r]);
             o0 += w.W3[row * 2u] * h2[t][r];
             o1 += w.W3[row * 2u + 1u] * h2[t][r];
         }
     }
-    out[0] = w.b3[0] + group_sum4(o0);
-    out[1] = w.b3[1] + group_sum4(o1);
+    mlp_reduce2<H>(L, o0, o1, out);      // barrier inside: also orders the act reads above before the next pass's writes
+    out[0] += w.b3[0]; out[1] += w.b3[1];
 }
 
-// (df/du)^T lam for the wave's columns, given the activations of the forward pass; g1/g2 are the layer cotangents
+// (df/du)^T lam for the workgroup's columns, given the activations of the forward pass; g1/g2 are this wave's rows of
+// the layer cotangents
 template <int H>
-__device__ __forceinline__ void mlp_backward(const MlpW<H>& w, const double (&lam)[2], const double (&h1)[H / 16][4], const double (&h2)[H / 16][4],
-                                             double (&g1)[H / 16][4], double (&g2)[H / 16][4], double (&dlam)[2]) {
-    constexpr int TT = H / 16, D = 2;
-    const unsigned lq = (threadIdx.x & 63u) >> 4;
-    mlp_d4 acc[TT];
+__device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, const double (&lam)[2], const double (&h1)[Mlp<H>::TW][4], const double (&h2)[Mlp<H>::TW][4],
+                                             double (&g1)[Mlp<H>::TW][4], double (&g2)[Mlp<H>::TW][4], double (&dlam)[2]) {
+    constexpr int TW = Mlp<H>::TW;
+    const unsigned lq = (threadIdx.x & 63u) >> 4, li = threadIdx.x & 15u;
+    const int t0 = (threadIdx.x >> 6) * TW;
+    mlp_d4 acc[TW];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < TW; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned row = (unsigned)(16 * t + 4 * r) + lq;
+            const unsigned row = (unsigned)(16 * (t0 + t) + 4 * r) + lq;
             g2[t][r] = (w.W3[row * 2u] * lam[0] + w.W3[row * 2u + 1u] * lam[1]) * (1.0 - h2[t][r] * h2[t][r]);
             acc[t][r] = 0.0;
+            L.act[row * 16u + li] = g2[t][r];
         }
     }
-    mlp_gemm<H>(w.W2T, g2, acc);
+    __syncthreads();
+    mlp_gemm<H>(w.W2T, L.act, t0, acc);
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < TW; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned row = (unsigned)(16 * t + 4 * r) + lq;
+            const unsigned row = (unsigned)(16 * (t0 + t) + 4 * r) + lq;
             g1[t][r] = acc[t][r] * (1.0 - h1[t][r] * h1[t][r]);
             d0 += w.W1[row] * g1[t][r];
             d1 += w.W1[row + (unsigned)H] * g1[t][r];
         }
     }
-    dlam[0] = group_sum4(d0);
-    dlam[1] = group_sum4(d1);
+    mlp_reduce2<H>(L, d0, d1, dlam);
 }
 
 // W2T[i + k*H] = W2[k + i*H]
@@ -166,19 +196,20 @@ __global__ void k_mlp_transpose_w2(int H, int npar, int hd, const double* __rest
 
 // forward RK4; knots [traj][S+1][2][D][B]  (x_k then f(x_k)); out [traj][M][D*B] in the caller's layout
 template <int H>
-__global__ void __launch_bounds__(64) k_mlp_forward(MlpGeom g, const double* __restrict__ u0, const double* __restrict__ p, const double* __restrict__ w2t,
-                                                    double* __restrict__ knots, double* __restrict__ out, const int* __restrict__ save_of_knot) {
-    constexpr int TT = H / 16, D = 2;
+__global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_forward(MlpGeom g, const double* __restrict__ u0, const double* __restrict__ p, const double* __restrict__ w2t,
+                                                            double* __restrict__ knots, double* __restrict__ out, const int* __restrict__ save_of_knot) {
+    constexpr int TW = Mlp<H>::TW, D = 2;
+    __shared__ MlpLds<H> L;
     const long traj = blockIdx.y;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
-    const bool writer = (threadIdx.x >> 4) == 0;
+    const bool writer = (threadIdx.x >> 4) == 0;          // wave 0, lane group 0
     const MlpW<H> w = mlp_weights<H>(p, w2t, g.p_shared, traj);
     const long nB = (long)D * g.B;
-    double x[D], k1[D], k2[D], k3[D], k4[D], xs[D], h1[TT][4], h2[TT][4];
+    double x[D], k1[D], k2[D], k3[D], k4[D], xs[D], h1[TW][4], h2[TW][4];
     x[0] = u0[traj * nB + (long)col * D]; x[1] = u0[traj * nB + (long)col * D + 1];
     const double dt = g.dt;
     for (int k = 0; k <= g.S; ++k) {
-        mlp_forward<H>(w, x, h1, h2, k1);
+        mlp_forward<H>(w, L, x, h1, h2, k1);
         if (writer) {
             double* kn = knots + ((traj * (g.S + 1) + k) * 2) * nB;
             kn[col] = x[0]; kn[g.B + col] = x[1]; kn[nB + col] = k1[0]; kn[nB + g.B + col] = k1[1];
@@ -187,11 +218,11 @@ __global__ void __launch_bounds__(64) k_mlp_forward(MlpGeom g, const double* __r
         }
         if (k == g.S) break;
         xs[0] = x[0] + 0.5 * dt * k1[0]; xs[1] = x[1] + 0.5 * dt * k1[1];
-        mlp_forward<H>(w, xs, h1, h2, k2);
+        mlp_forward<H>(w, L, xs, h1, h2, k2);
         xs[0] = x[0] + 0.5 * dt * k2[0]; xs[1] = x[1] + 0.5 * dt * k2[1];
-        mlp_forward<H>(w, xs, h1, h2, k3);
+        mlp_forward<H>(w, L, xs, h1, h2, k3);
         xs[0] = x[0] + dt * k3[0]; xs[1] = x[1] + dt * k3[1];
-        mlp_forward<H>(w, xs, h1, h2, k4);
+        mlp_forward<H>(w, L, xs, h1, h2, k4);
         x[0] = x[0] + (dt / 6.0) * (k1[0] + 2.0 * (k2[0] + k3[0]) + k4[0]);
         x[1] = x[1] + (dt / 6.0) * (k1[1] + 2.0 * (k2[1] + k3[1]) + k4[1]);
     }
@@ -202,21 +233,21 @@ template <int H> struct MlpRec { double *AX, *AL, *AH1, *AH2, *AG1, *AG2; };
 
 template <int H>
 __device__ __forceinline__ void mlp_record(const MlpRec<H>& R, const MlpGeom& g, long q, int col, double wq, const double (&x)[2], const double (&lam)[2],
-                                           const double (&h1)[H / 16][4], const double (&h2)[H / 16][4], const double (&g1)[H / 16][4], const double (&g2)[H / 16][4]) {
-    constexpr int TT = H / 16, HP = Mlp<H>::HP;
-    const int lq = (threadIdx.x & 63) >> 4;
+                                           const double (&h1)[Mlp<H>::TW][4], const double (&h2)[Mlp<H>::TW][4], const double (&g1)[Mlp<H>::TW][4], const double (&g2)[Mlp<H>::TW][4]) {
+    constexpr int TW = Mlp<H>::TW, HP = Mlp<H>::HP;
+    const int lq = (threadIdx.x & 63) >> 4, t0 = (threadIdx.x >> 6) * TW;
     const long B = g.B;
-    if (lq == 0) {
+    if ((threadIdx.x >> 4) == 0) {       // wave 0, lane group 0: the d-sized rows and the ones rows
         double* ax = R.AX + q * 16 * B; double* al = R.AL + q * 16 * B;
         ax[col] = x[0]; ax[B + col] = x[1]; ax[2 * B + col] = 1.0;
         al[col] = wq * lam[0]; al[B + col] = wq * lam[1];
         R.AH1[(q * HP + H) * B + col] = 1.0; R.AH2[(q * HP + H) * B + col] = 1.0;
     }
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < TW; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long row = 16 * t + 4 * r + lq;
+            const long row = 16 * (t0 + t) + 4 * r + lq;
             R.AH1[(q * HP + row) * B + col] = h1[t][r];
             R.AH2[(q * HP + row) * B + col] = h2[t][r];
             R.AG1[(q * H + row) * B + col] = wq * g1[t][r];
@@ -228,13 +259,14 @@ __device__ __forceinline__ void mlp_record(const MlpRec<H>& R, const MlpGeom& g,
 // reverse sweep: ALG 0 = InterpolatingAdjoint (records at the 4 RK4 stages), ALG 2 = GaussAdjoint (records at the
 // two Gauss-Legendre nodes; lam from the adjoint step's Hermite interpolant, y from the forward one)
 template <int H, int ALG>
-__global__ void __launch_bounds__(64) k_mlp_adjoint(MlpGeom g, const double* __restrict__ p, const double* __restrict__ w2t, const double* __restrict__ knots,
+__global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const double* __restrict__ p, const double* __restrict__ w2t, const double* __restrict__ knots,
                                                     const double* __restrict__ cot, const int* __restrict__ save_of_knot, MlpRec<H> R,
                                                     double* __restrict__ du0, int* __restrict__ flag) {
-    constexpr int TT = H / 16, D = 2;
+    constexpr int TW = Mlp<H>::TW, D = 2;
+    __shared__ MlpLds<H> L;
     const long traj = blockIdx.y;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
-    const bool writer = (threadIdx.x >> 4) == 0;
+    const bool writer = (threadIdx.x >> 4) == 0;          // wave 0, lane group 0
     const MlpW<H> w = mlp_weights<H>(p, w2t, g.p_shared, traj);
     const long nB = (long)D * g.B;
     const double dt = g.dt;
@@ -247,7 +279,7 @@ __global__ void __launch_bounds__(64) k_mlp_adjoint(MlpGeom g, const double* __r
         else { lam[0] += xx[0] - g.loss_shift; lam[1] += xx[1] - g.loss_shift; }
     };
     double lam[D] = {0.0, 0.0}, xh[D], fh[D], xl[D], fl[D];
-    double h1[TT][4], h2[TT][4], g1[TT][4], g2[TT][4], out[D];
+    double h1[TW][4], h2[TW][4], g1[TW][4], g2[TW][4], out[D];
     knot(g.S, xh, fh);
     { const int s = save_of_knot[g.S]; if (s >= 0) jump(s, xh, lam); }
     const double xg = 0.5773502691896257645;
@@ -258,27 +290,27 @@ __global__ void __launch_bounds__(64) k_mlp_adjoint(MlpGeom g, const double* __r
         xm[0] = 0.5 * (xl[0] + xh[0]) + (0.125 * dt) * (fl[0] - fh[0]);
         xm[1] = 0.5 * (xl[1] + xh[1]) + (0.125 * dt) * (fl[1] - fh[1]);
         // stage 1 at x_hi
-        mlp_forward<H>(w, xh, h1, h2, out);
-        mlp_backward<H>(w, lam, h1, h2, g1, g2, V1);
+        mlp_forward<H>(w, L, xh, h1, h2, out);
+        mlp_backward<H>(w, L, lam, h1, h2, g1, g2, V1);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 0, col, dt / 6.0, xh, lam, h1, h2, g1, g2);
         // stages 2, 3 at the Hermite midpoint (same activations)
         ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
-        mlp_forward<H>(w, xm, h1, h2, out);
-        mlp_backward<H>(w, ls, h1, h2, g1, g2, V2);
+        mlp_forward<H>(w, L, xm, h1, h2, out);
+        mlp_backward<H>(w, L, ls, h1, h2, g1, g2, V2);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 1, col, dt / 3.0, xm, ls, h1, h2, g1, g2);
         ls[0] = lam[0] + 0.5 * dt * V2[0]; ls[1] = lam[1] + 0.5 * dt * V2[1];
-        mlp_backward<H>(w, ls, h1, h2, g1, g2, V3);
+        mlp_backward<H>(w, L, ls, h1, h2, g1, g2, V3);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 2, col, dt / 3.0, xm, ls, h1, h2, g1, g2);
         // stage 4 at x_lo
         ls[0] = lam[0] + dt * V3[0]; ls[1] = lam[1] + dt * V3[1];
-        mlp_forward<H>(w, xl, h1, h2, out);
-        mlp_backward<H>(w, ls, h1, h2, g1, g2, V4);
+        mlp_forward<H>(w, L, xl, h1, h2, out);
+        mlp_backward<H>(w, L, ls, h1, h2, g1, g2, V4);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 3, col, dt / 6.0, xl, ls, h1, h2, g1, g2);
         lam[0] = lam[0] + (dt / 6.0) * (V1[0] + 2.0 * (V2[0] + V3[0]) + V4[0]);
         lam[1] = lam[1] + (dt / 6.0) * (V1[1] + 2.0 * (V2[1] + V3[1]) + V4[1]);
         if (ALG == 2) {
             double V5[D];
-            mlp_backward<H>(w, lam, h1, h2, g1, g2, V5);                   // fsallast at x_lo (activations of stage 4)
+            mlp_backward<H>(w, L, lam, h1, h2, g1, g2, V5);                   // fsallast at x_lo (activations of stage 4)
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
@@ -289,8 +321,8 @@ __global__ void __launch_bounds__(64) k_mlp_adjoint(MlpGeom g, const double* __r
                     yg[j] = (1.0 - tf) * xl[j] + tf * xh[j] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (xh[j] - xl[j]) + (tf - 1.0) * dt * fl[j] + tf * dt * fh[j]);
                 }
                 double dl[D];
-                mlp_forward<H>(w, yg, h1, h2, out);
-                mlp_backward<H>(w, lg, h1, h2, g1, g2, dl);
+                mlp_forward<H>(w, L, yg, h1, h2, out);
+                mlp_backward<H>(w, L, lg, h1, h2, g1, g2, dl);
                 mlp_record<H>(R, g, qbase + nq, col, 0.5 * dt, yg, lg, h1, h2, g1, g2);
             }
         }

@@ -44,7 +44,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
                double* du0, double* dp, double* out) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, PF = 8;
     Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
-    g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
+    g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1;
     const long Np = P.Npad;
     std::vector<dbl2> knots((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) ? (size_t)(P.S + 1) * N * Np : 0);
     std::vector<double> tile((size_t)(HIPADJ_CKPT_KMAX + 1) * N);
