@@ -46,6 +46,7 @@ struct hipadj_handle {
     double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
     MlpGeom mg{};
     FieldGeom fg{};
+    unsigned* d_ticket = nullptr;
     int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
     bool have_forward = false, timing_pending_fwd = false;
@@ -92,7 +93,7 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
 
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
-                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_prev_ck, h->d_save_of_knot,
+                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -169,6 +170,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_prev_ck, (size_t)S + 1));
     A(dev_alloc(h, &h->d_seg_bounds, (size_t)h->nseg + 1));
     A(dev_alloc(h, &h->d_flag, 1));
+    A(dev_alloc(h, &h->d_ticket, 1));
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
         if (!h->field) A(dev_alloc(h, &h->d_adj, (size_t)S * 2 * n * Np));
@@ -180,7 +182,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
               HT(hipMemcpy(h->d_ckpt_of_knot, h->ckpt_of_knot.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
               HT(hipMemcpy(h->d_prev_ck, P.prev_ck.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
               HT(hipMemcpy(h->d_seg_bounds, h->seg_bounds.data(), sizeof(int) * (h->nseg + 1), hipMemcpyHostToDevice), "memcpy") &&
-              HT(hipMemset(h->d_flag, 0, sizeof(int)), "memset");
+              HT(hipMemset(h->d_flag, 0, sizeof(int)), "memset") && HT(hipMemset(h->d_ticket, 0, sizeof(unsigned)), "memset");
     if (ok && h->nq > 0) ok = HT(hipMemcpy(h->d_qa, qa.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy") &&
                               HT(hipMemcpy(h->d_qb, qb.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy");
     if (!ok) return fail(HIPADJ_ERR_HIP);
@@ -295,6 +297,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
     const double* p = h->p_dev_last;
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;   // per-trajectory dp rows [N][np]
+    double* dp_sum = h->cfg.p_shared ? d_dp : (double*)nullptr;    // dp = sum over trajectories, reduced in-launch by the last-arriving workgroup
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
@@ -314,7 +317,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
         hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(fblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                           d_du0, dp_rows, h->d_partial, h->d_flag);
+                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_BACKSOLVE: {
@@ -325,7 +328,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
         hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(fblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                           d_du0, dp_rows, h->d_partial, h->d_flag);
+                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_GAUSS: {
@@ -339,7 +342,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
         hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(fblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                           d_du0, dp_rows, h->d_partial, h->d_flag);
+                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_QUADRATURE: {
@@ -358,11 +361,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
     // finishing stage: NaN/Inf scan + per-workgroup partial sums of mu (Interpolating fused it with the composition)
     if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
         hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
-                           (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag);
-        HIP_TRY(h, hipGetLastError());
-    }
-    if (h->cfg.p_shared) {   // dp = sum over trajectories, fixed order
-        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
+                           (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipEventRecord(es.a1, h->stream));
@@ -421,12 +420,8 @@ template <int G> static int field_adjoint(hipadj_handle* h, const double* d_cot,
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg not available for the PDE family");
     }
     hipLaunchKernelGGL((k_finish<0, 3>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
-                       (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag);
+                       (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, h->cfg.p_shared ? d_dp : (double*)nullptr);
     HIP_TRY(h, hipGetLastError());
-    if (h->cfg.p_shared) {
-        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
-        HIP_TRY(h, hipGetLastError());
-    }
     HIP_TRY(h, hipEventRecord(es.a1, h->stream));
     es.pending = true;
     return HIPADJ_OK;

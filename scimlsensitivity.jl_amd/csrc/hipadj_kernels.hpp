@@ -124,11 +124,40 @@ __device__ __forceinline__ void block_partial(const double (&mu)[NP], bool valid
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.79769313486231570e308; }
 
+// In-launch final reduction (replaces a separate k_reduce_final launch): the workgroup that draws the last arrival
+// ticket sums all partials in block order.  Placement-independent hand-off per cdna_hip_programming.md §6 G16:
+// plain stores -> __syncthreads -> one lane: agent-scope release + asm vmcnt(0) -> relaxed agent ticket;
+// last arriver: agent-scope acquire -> plain loads.  The counter is reset by the last arriver (zeroed at create).
+template <int NP>
+__device__ __forceinline__ void final_reduce_last_arriver(const double* __restrict__ partial, int nblocks, unsigned* __restrict__ ticket_ctr,
+                                                          double* __restrict__ dp) {
+    __syncthreads();                       // this workgroup's partial[] stores are issued
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)nblocks - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            double s[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) s[j] = 0.0;
+            for (int b = 0; b < nblocks; ++b) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) s[j] += partial[(long)b * NP + j];
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dp[j] = s[j];
+            __hip_atomic_store(ticket_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // compose the segment maps top -> bottom:  lam <- A lam + c_l ; mu <- mu + B lam + c_m
 template <class Mo>
 __global__ void __launch_bounds__(FIN) k_compose_finish(Geom g, int nseg, const double* __restrict__ segbuf,
                                                         double* __restrict__ du0, double* __restrict__ dp_rows,
-                                                        double* __restrict__ partial, int* __restrict__ flag) {
+                                                        double* __restrict__ partial, int* __restrict__ flag,
+                                                        unsigned* __restrict__ ticket_ctr, double* __restrict__ dp_sum) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
     const long i = (long)blockIdx.x * FIN + threadIdx.x;
     const bool valid = i < g.N;
@@ -185,13 +214,15 @@ __global__ void __launch_bounds__(FIN) k_compose_finish(Geom g, int nseg, const 
         if (bad) atomicOr(flag, 1);
     }
     block_partial<NP>(mu, valid, partial);
+    if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
 }
 
 // finishing stage for kernels that already wrote du0 [N][n] and dp_traj [NP][Npad]
 template <int N, int NP>
 __global__ void __launch_bounds__(FIN) k_finish(long Ntraj, long Npad, const double* __restrict__ du0,
                                                 const double* __restrict__ dp_traj, double* __restrict__ dp_rows,
-                                                double* __restrict__ partial, int* __restrict__ flag) {
+                                                double* __restrict__ partial, int* __restrict__ flag,
+                                                unsigned* __restrict__ ticket_ctr, double* __restrict__ dp_sum) {
     const long i = (long)blockIdx.x * FIN + threadIdx.x;
     const bool valid = i < Ntraj;
     double mu[NP];
@@ -206,6 +237,7 @@ __global__ void __launch_bounds__(FIN) k_finish(long Ntraj, long Npad, const dou
         if (bad) atomicOr(flag, 1);
     }
     block_partial<NP>(mu, valid, partial);
+    if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
 }
 
 // dp[j] = sum over workgroup partials in block order (one workgroup per parameter)
