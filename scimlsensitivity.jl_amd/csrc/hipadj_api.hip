@@ -46,8 +46,7 @@ struct hipadj_handle {
     double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
     MlpGeom mg{};
     FieldGeom fg{};
-    unsigned *d_ticket = nullptr, *d_tile_ctr = nullptr;
-    double* d_tile_partial = nullptr;
+    unsigned* d_ticket = nullptr;
     int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
     bool have_forward = false, timing_pending_fwd = false;
@@ -94,7 +93,7 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
 
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
-                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_tile_ctr, h->d_tile_partial, h->d_prev_ck, h->d_save_of_knot,
+                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -162,7 +161,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) A(dev_alloc(h, &h->d_fadj, (size_t)h->N * S * 4 * n));
     }
     A(dev_alloc(h, &h->d_dp_traj, (size_t)np * Np));
-    A(dev_alloc(h, &h->d_partial, (size_t)((h->N + FIN - 1) / FIN) * np));
+    A(dev_alloc(h, &h->d_partial, (size_t)((h->N + FIN / 4 - 1) / (FIN / 4)) * np));
     A(dev_alloc(h, &h->d_io_a, (size_t)h->N * (h->M > 0 ? h->M : 1) * n));
     A(dev_alloc(h, &h->d_du0, (size_t)h->N * n));
     A(dev_alloc(h, &h->d_dp, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
@@ -172,8 +171,6 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_seg_bounds, (size_t)h->nseg + 1));
     A(dev_alloc(h, &h->d_flag, 1));
     A(dev_alloc(h, &h->d_ticket, 1));
-    A(dev_alloc(h, &h->d_tile_ctr, (size_t)(Np / WAVE)));
-    A(dev_alloc(h, &h->d_tile_partial, (size_t)(Np / WAVE) * np));
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
         if (!h->field) A(dev_alloc(h, &h->d_adj, (size_t)S * 2 * n * Np));
@@ -185,8 +182,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
               HT(hipMemcpy(h->d_ckpt_of_knot, h->ckpt_of_knot.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
               HT(hipMemcpy(h->d_prev_ck, P.prev_ck.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy") &&
               HT(hipMemcpy(h->d_seg_bounds, h->seg_bounds.data(), sizeof(int) * (h->nseg + 1), hipMemcpyHostToDevice), "memcpy") &&
-              HT(hipMemset(h->d_flag, 0, sizeof(int)), "memset") && HT(hipMemset(h->d_ticket, 0, sizeof(unsigned)), "memset") &&
-              HT(hipMemset(h->d_tile_ctr, 0, sizeof(unsigned) * (size_t)(Np / WAVE)), "memset");
+              HT(hipMemset(h->d_flag, 0, sizeof(int)), "memset") && HT(hipMemset(h->d_ticket, 0, sizeof(unsigned)), "memset");
     if (ok && h->nq > 0) ok = HT(hipMemcpy(h->d_qa, qa.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy") &&
                               HT(hipMemcpy(h->d_qb, qb.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy");
     if (!ok) return fail(HIPADJ_ERR_HIP);
@@ -302,6 +298,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     const double* p = h->p_dev_last;
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
+    const unsigned cblocks = (unsigned)((h->N + FIN / 4 - 1) / (FIN / 4));   // composition: 4 lanes per trajectory
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;   // per-trajectory dp rows [N][np]
     double* dp_sum = h->cfg.p_shared ? d_dp : (double*)nullptr;    // dp = sum over trajectories, reduced in-launch by the last-arriving workgroup
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
@@ -311,38 +308,46 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
     HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
     HIP_TRY(h, hipEventRecord(k0, h->stream));
-    // segmented algorithms: composition, NaN scan and the dp reduction happen in-launch (segment_epilogue)
-    const SegPlan sp{h->nseg, h->d_seg_bounds};
-    const SegEpilogue E{h->d_segbuf, h->d_tile_ctr, h->d_ticket, h->d_tile_partial, d_du0, dp_rows, dp_sum, h->d_flag};
-    const dim3 sgrid(waves, (unsigned)h->nseg), sblk(WAVE);
     switch (h->cfg.alg) {
-    case HIPADJ_ALG_INTERPOLATING:
+    case HIPADJ_ALG_INTERPOLATING: {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt)
-            hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), sgrid, sblk, 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, E);
+            hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         else
-            hipLaunchKernelGGL((k_interp<Mo, PF, LOSS>), sgrid, sblk, 0, h->stream, h->g, sp, p,
-                               (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, E);
+        hipLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p,
+                           (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
-        break;
-    case HIPADJ_ALG_BACKSOLVE:
-        hipLaunchKernelGGL((k_backsolve<Mo>), sgrid, sblk, 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
+        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    case HIPADJ_ALG_BACKSOLVE: {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        hipLaunchKernelGGL((k_backsolve<Mo>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
                            (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
-                           (const int*)h->d_save_of_knot, E);
+                           (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
-        break;
-    case HIPADJ_ALG_GAUSS:
+        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    case HIPADJ_ALG_GAUSS: {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt)
-            hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), sgrid, sblk, 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, E);
+            hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         else
-            hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), sgrid, sblk, 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
-                               (const double*)h->d_cotT, (const int*)h->d_save_of_knot, E);
+            hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
+                               (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(k1, h->stream));
-        break;
+        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        HIP_TRY(h, hipGetLastError());
+        break; }
     case HIPADJ_ALG_QUADRATURE: {
         hipLaunchKernelGGL((k_quad_adj<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
                            (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0);

@@ -30,154 +30,34 @@ __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restri
     forward_lane<Mo>(g, i, u0, p, knots, ckpt, ckpt_of_knot, outT, save_of_knot, yT);
 }
 
-// ---- time-segmented kernels: segment maps + in-launch composition ---------------------------------------------
-// Every (trajectory tile, segment) wave integrates its segment and publishes the affine map
-//     segbuf[segment][column][N+NP][Npad]           (the top segment only fills column 0)
-// The wave that draws the LAST arrival ticket of its trajectory tile composes the C maps top -> bottom
-//     lam <- A lam + c_l ;  mu <- mu + B lam + c_m
-// right there (no separate composition launch), scans for NaN/Inf (the reference's retcode check), writes du0 / the
-// per-trajectory dp rows and a wave-level partial sum of mu; the tile that draws the last GLOBAL ticket sums the tile
-// partials in tile order => dp is bit-reproducible for a given N whatever the arrival order.
-// Hand-off form (cdna_hip_programming.md §6 G16, "8-byte agent-scope atomics on both sides"): the maps and partials
-// are stored with relaxed agent-scope 8-byte atomic stores (write-through, sc1), every storing wave drains
-// `s_waitcnt vmcnt(0)` before lane 0 takes its relaxed agent-scope ticket, and the composing wave reads with relaxed
-// agent-scope atomic loads (bypass L1).  Placement-independent; counters are reset by the last arriver (zeroed at create).
-__device__ __forceinline__ void st_agent(double* p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_agent(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<double*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-struct SegEpilogue {
-    double* segbuf;
-    unsigned* tile_ctr;      // [ntiles]
-    unsigned* global_ctr;    // [1]
-    double* partial;         // [ntiles][NP]
-    double* du0;             // [N][n]
-    double* dp_rows;         // [N][np] or nullptr (shared p)
-    double* dp_sum;          // [np] or nullptr
-    int* flag;
-};
-
-template <class Mo, int NC>
-__device__ __forceinline__ void segment_epilogue(const Geom& g, int nseg, const SegEpilogue& E, int seg, long i, bool valid,
-                                                 const double (&lam_s)[NC][Mo::N], const double (&mu_s)[NC][Mo::NP]) {
-    constexpr int N = Mo::N, NP = Mo::NP, NCM = 1 + N, R = N + NP;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const unsigned tile = blockIdx.x, ntiles = gridDim.x;
-    {   // publish this segment's map
-        double* dst = E.segbuf + (long)seg * NCM * R * g.Npad + i;
-        if (valid) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) st_agent(dst + ((long)c * R + j) * g.Npad, lam_s[c][j]);
-#pragma unroll
-                for (int j = 0; j < NP; ++j) st_agent(dst + ((long)c * R + N + j) * g.Npad, mu_s[c][j]);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(E.tile_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = __shfl(t, 0, WAVE);
-    if (t != (unsigned)nseg - 1u) return;
-    // ---- last arriver of this trajectory tile: compose
-    double lam[N], mu[NP];
-    {
-        const double* src = E.segbuf + (long)(nseg - 1) * NCM * R * g.Npad + i;
-#pragma unroll
-        for (int j = 0; j < N; ++j) lam[j] = ld_agent(src + (long)j * g.Npad);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) mu[j] = ld_agent(src + (long)(N + j) * g.Npad);
-    }
-    constexpr int CH = 2;     // maps of CH segments in flight together, composed in order (kept small: registers)
-    for (int sb = nseg - 2; sb >= 0; sb -= CH) {
-        double m[CH][NCM * R];
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            const int sq = sb - q > 0 ? sb - q : 0;
-            const double* src = E.segbuf + (long)sq * NCM * R * g.Npad + i;
-#pragma unroll
-            for (int e = 0; e < NCM * R; ++e) m[q][e] = ld_agent(src + (long)e * g.Npad);
-        }
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            if (sb - q >= 0) {
-                double nl[N], nm[NP];
-#pragma unroll
-                for (int j = 0; j < N; ++j) nl[j] = m[q][j];
-#pragma unroll
-                for (int j = 0; j < NP; ++j) nm[j] = mu[j] + m[q][N + j];
-#pragma unroll
-                for (int c = 0; c < N; ++c) {
-#pragma unroll
-                    for (int j = 0; j < N; ++j) nl[j] += m[q][(c + 1) * R + j] * lam[c];
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) nm[j] += m[q][(c + 1) * R + N + j] * lam[c];
-                }
-#pragma unroll
-                for (int j = 0; j < N; ++j) lam[j] = nl[j];
-#pragma unroll
-                for (int j = 0; j < NP; ++j) mu[j] = nm[j];
-            }
-        }
-    }
-    bool bad = false;
-    if (valid) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) { E.du0[i * N + j] = lam[j]; bad |= !(fabs(lam[j]) <= 1.79769313486231570e308); }
-#pragma unroll
-        for (int j = 0; j < NP; ++j) { bad |= !(fabs(mu[j]) <= 1.79769313486231570e308); if (E.dp_rows) E.dp_rows[i * NP + j] = mu[j]; }
-        if (bad) atomicOr(E.flag, 1);
-    }
-    if (lane == 0) __hip_atomic_store(E.tile_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!E.dp_sum) return;
-    // ---- wave partial of mu (fixed shuffle tree), then the last tile sums the partials in tile order
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        double v = valid ? mu[j] : 0.0;
-#pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-        if (lane == 0) st_agent(E.partial + (long)tile * NP + j, v);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned tg = 0;
-    if (lane == 0) tg = __hip_atomic_fetch_add(E.global_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tg = __shfl(tg, 0, WAVE);
-    if (tg != ntiles - 1u) return;
-    if (lane < NP) {
-        double s = 0.0;
-        for (unsigned b = 0; b < ntiles; ++b) s += ld_agent(E.partial + (long)b * NP + lane);
-        E.dp_sum[lane] = s;
-    }
-    if (lane == 0) __hip_atomic_store(E.global_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// common prologue of the segmented kernels: lane -> (trajectory, segment); padded lanes redo the last trajectory
-// (their stores are masked) so that the whole wave reaches the epilogue's shuffles
-#define HIPADJ_SEG_PROLOGUE()                                                                          \
-    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N;                                                  \
-    const long i_raw = (long)blockIdx.x * WAVE + threadIdx.x;                                          \
-    const bool valid = i_raw < g.N;                                                                    \
-    const long i = valid ? i_raw : g.N - 1;                                                            \
-    const int seg = sp.nseg - 1 - (int)blockIdx.y;   /* longest (top, 1-column) segment dispatched first */ \
-    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1]
-
+// segbuf layout: [segment][column][N+NP][Npad]; the top segment only fills column 0.
 template <class Mo, int PF, int LOSS>
 __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const double* __restrict__ p,
                                                  const dbl2* __restrict__ knots, const double* __restrict__ cotT,
-                                                 const int* __restrict__ save_of_knot, SegEpilogue E) {
-    HIPADJ_SEG_PROLOGUE();
+                                                 const int* __restrict__ save_of_knot, double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;   // longest (top, 1-column) segment is dispatched first
+    if (i >= g.N) return;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
     if (seg == sp.nseg - 1) {
         double lam[1][N], mu[1][NP];
         interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
-        segment_epilogue<Mo, 1>(g, sp.nseg, E, seg, i, valid, lam, mu);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
     } else {
         double lam[NC][N], mu[NC][NP];
         interp_lane<Mo, NC, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
-        segment_epilogue<Mo, NC>(g, sp.nseg, E, seg, i, valid, lam, mu);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) dst[((long)c * R + j) * g.Npad] = lam[c][j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * g.Npad] = mu[c][j];
+        }
     }
 }
 
@@ -185,70 +65,33 @@ __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const doubl
 template <class Mo, int LOSS>
 __global__ void __launch_bounds__(WAVE) k_interp_ckpt(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ ckpt,
                                                       const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
-                                                      const double* __restrict__ cotT, const int* __restrict__ save_of_knot, SegEpilogue E) {
-    constexpr int KM = HIPADJ_CKPT_KMAX;
-    __shared__ double tile[(KM + 1) * Mo::N * WAVE];
-    HIPADJ_SEG_PROLOGUE();
+                                                      const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                                                      double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, KM = HIPADJ_CKPT_KMAX;
+    __shared__ double tile[(KM + 1) * N * WAVE];
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;
+    if (i >= g.N) return;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
     const CkptSrc C{ckpt, ckpt_of_knot, prev_ck, tile, WAVE, (int)threadIdx.x};
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
     if (seg == sp.nseg - 1) {
         double lam[1][N], mu[1][NP];
         interp_lane<Mo, 1, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
-        segment_epilogue<Mo, 1>(g, sp.nseg, E, seg, i, valid, lam, mu);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
     } else {
         double lam[NC][N], mu[NC][NP];
         interp_lane<Mo, NC, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
-        segment_epilogue<Mo, NC>(g, sp.nseg, E, seg, i, valid, lam, mu);
-    }
-}
-
-template <class Mo, int PF, int LOSS>
-__global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double* __restrict__ p, const dbl2* __restrict__ knots,
-                                                const double* __restrict__ cotT, const int* __restrict__ save_of_knot, SegEpilogue E) {
-    HIPADJ_SEG_PROLOGUE();
-    if (seg == sp.nseg - 1) {
-        double lam[1][N], mu[1][NP];
-        gauss_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
-        segment_epilogue<Mo, 1>(g, sp.nseg, E, seg, i, valid, lam, mu);
-    } else {
-        double lam[NC][N], mu[NC][NP];
-        gauss_lane<Mo, NC, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
-        segment_epilogue<Mo, NC>(g, sp.nseg, E, seg, i, valid, lam, mu);
-    }
-}
-
-template <class Mo, int LOSS>
-__global__ void __launch_bounds__(WAVE) k_gauss_ckpt(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ ckpt,
-                                                     const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
-                                                     const double* __restrict__ cotT, const int* __restrict__ save_of_knot, SegEpilogue E) {
-    constexpr int KM = HIPADJ_CKPT_KMAX;
-    __shared__ double tile[(KM + 1) * Mo::N * WAVE];
-    HIPADJ_SEG_PROLOGUE();
-    const CkptSrc C{ckpt, ckpt_of_knot, prev_ck, tile, WAVE, (int)threadIdx.x};
-    if (seg == sp.nseg - 1) {
-        double lam[1][N], mu[1][NP];
-        gauss_lane<Mo, 1, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
-        segment_epilogue<Mo, 1>(g, sp.nseg, E, seg, i, valid, lam, mu);
-    } else {
-        double lam[NC][N], mu[NC][NP];
-        gauss_lane<Mo, NC, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
-        segment_epilogue<Mo, NC>(g, sp.nseg, E, seg, i, valid, lam, mu);
-    }
-}
-
-// BacksolveAdjoint, segmented at checkpoint knots
-template <class Mo>
-__global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ yT,
-                                                    const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
-                                                    const double* __restrict__ cotT, const int* __restrict__ save_of_knot, SegEpilogue E) {
-    HIPADJ_SEG_PROLOGUE();
-    if (seg == sp.nseg - 1) {
-        double lam[1][N], mu[1][NP];
-        backsolve_lane<Mo, 1>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
-        segment_epilogue<Mo, 1>(g, sp.nseg, E, seg, i, valid, lam, mu);
-    } else {
-        double lam[NC][N], mu[NC][NP];
-        backsolve_lane<Mo, NC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
-        segment_epilogue<Mo, NC>(g, sp.nseg, E, seg, i, valid, lam, mu);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) dst[((long)c * R + j) * g.Npad] = lam[c][j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * g.Npad] = mu[c][j];
+        }
     }
 }
 
@@ -289,24 +132,154 @@ template <int NP>
 __device__ __forceinline__ void final_reduce_last_arriver(const double* __restrict__ partial, int nblocks, unsigned* __restrict__ ticket_ctr,
                                                           double* __restrict__ dp) {
     __syncthreads();                       // this workgroup's partial[] stores are issued
-    if (threadIdx.x == 0) {
+    if (threadIdx.x >= WAVE) return;       // wave 0 does the hand-off
+    const int lane = threadIdx.x;
+    unsigned t = 0;
+    if (lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == (unsigned)nblocks - 1u) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            double s[NP];
+        t = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    t = __shfl(t, 0, WAVE);
+    if (t != (unsigned)nblocks - 1u) return;
+    if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // lane l sums blocks l, l+64, ... in increasing order, then a fixed shuffle tree: deterministic for a given N
 #pragma unroll
-            for (int j = 0; j < NP; ++j) s[j] = 0.0;
-            for (int b = 0; b < nblocks; ++b) {
+    for (int j = 0; j < NP; ++j) {
+        double v = 0.0;
+        for (int b = lane; b < nblocks; b += WAVE) v += partial[(long)b * NP + j];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) s[j] += partial[(long)b * NP + j];
+        for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+        if (lane == 0) dp[j] = v;
+    }
+    if (lane == 0) __hip_atomic_store(ticket_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Composition of the C segment maps of each trajectory, top -> bottom:  lam <- A lam + c_l ; mu <- mu + B lam + c_m.
+// A plain loop over the maps is a chain of C dependent load rounds (13 us for C = 13).  Instead FOUR lanes share a
+// trajectory: each takes a contiguous quarter of the lower maps, fetches them in ONE round of independent loads and
+// folds them into a single affine map (map o map), the first quarter applying its maps to the top segment's vector;
+// three shuffle hops then push the vector through the other quarters' composed maps.
+template <class Mo>
+__global__ void __launch_bounds__(FIN) k_compose_finish(Geom g, int nseg, const double* __restrict__ segbuf,
+                                                        double* __restrict__ du0, double* __restrict__ dp_rows,
+                                                        double* __restrict__ partial, int* __restrict__ flag,
+                                                        unsigned* __restrict__ ticket_ctr, double* __restrict__ dp_sum) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, CHT = 3;
+    const long i_raw = (long)blockIdx.x * (FIN / 4) + (threadIdx.x >> 2);
+    const int part = threadIdx.x & 3;
+    const bool tvalid = i_raw < g.N;
+    const long i = tvalid ? i_raw : g.N - 1;
+    const int L = nseg - 1;                                  // lower maps, rank 0 = segment nseg-2 ... rank L-1 = segment 0
+    const int r0 = (L * part) / 4, r1 = (L * (part + 1)) / 4;
+    // group map G (identity) or, for part 0, the running vector starting from the top segment's (c_l, c_m)
+    double A[N][N], Bm[NP][N], cl[N], cm[NP];
+#pragma unroll
+    for (int a = 0; a < N; ++a) { cl[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) A[a][b] = (a == b) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int a = 0; a < NP; ++a) { cm[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) Bm[a][b] = 0.0; }
+    if (part == 0) {
+        const double* __restrict__ src = segbuf + (long)(nseg - 1) * NC * R * g.Npad + i;
+#pragma unroll
+        for (int j = 0; j < N; ++j) cl[j] = src[(long)j * g.Npad];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) cm[j] = src[(long)(N + j) * g.Npad];
+    }
+    for (int rb = r0; rb < r1; rb += CHT) {
+        double m[CHT][NC * R];
+#pragma unroll
+        for (int q = 0; q < CHT; ++q) {
+            const int rk = rb + q < r1 ? rb + q : r1 - 1;
+            const double* __restrict__ src = segbuf + (long)(nseg - 2 - rk) * NC * R * g.Npad + i;
+#pragma unroll
+            for (int e = 0; e < NC * R; ++e) m[q][e] = src[(long)e * g.Npad];
+        }
+#pragma unroll
+        for (int q = 0; q < CHT; ++q) {
+            if (rb + q < r1) {
+                // lower map Lm: c_l = m[j], c_m = m[N+j], A[:,c] = m[(c+1)R + j], B[:,c] = m[(c+1)R + N + j]
+                double ncl[N], ncm[NP];
+#pragma unroll
+                for (int j = 0; j < N; ++j) { ncl[j] = m[q][j];
+#pragma unroll
+                    for (int c = 0; c < N; ++c) ncl[j] += m[q][(c + 1) * R + j] * cl[c]; }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { ncm[j] = cm[j] + m[q][N + j];
+#pragma unroll
+                    for (int c = 0; c < N; ++c) ncm[j] += m[q][(c + 1) * R + N + j] * cl[c]; }
+                if (part != 0) {   // full map o map for the quarters that do not know their input vector yet
+                    double nA[N][N], nB[NP][N];
+#pragma unroll
+                    for (int a = 0; a < N; ++a)
+#pragma unroll
+                        for (int b = 0; b < N; ++b) { double v = 0.0;
+#pragma unroll
+                            for (int c = 0; c < N; ++c) v += m[q][(c + 1) * R + a] * A[c][b];
+                            nA[a][b] = v; }
+#pragma unroll
+                    for (int a = 0; a < NP; ++a)
+#pragma unroll
+                        for (int b = 0; b < N; ++b) { double v = Bm[a][b];
+#pragma unroll
+                            for (int c = 0; c < N; ++c) v += m[q][(c + 1) * R + N + a] * A[c][b];
+                            nB[a][b] = v; }
+#pragma unroll
+                    for (int a = 0; a < N; ++a)
+#pragma unroll
+                        for (int b = 0; b < N; ++b) A[a][b] = nA[a][b];
+#pragma unroll
+                    for (int a = 0; a < NP; ++a)
+#pragma unroll
+                        for (int b = 0; b < N; ++b) Bm[a][b] = nB[a][b];
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) cl[j] = ncl[j];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) cm[j] = ncm[j];
             }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) dp[j] = s[j];
-            __hip_atomic_store(ticket_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // push the vector through quarters 1..3: v <- G_q(v)
+    double lam[N], mu[NP];
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[j] = cl[j];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[j] = cm[j];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        double li[N], mi[NP];
+#pragma unroll
+        for (int j = 0; j < N; ++j) li[j] = __shfl(lam[j], (threadIdx.x & ~3) + q - 1, WAVE);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mi[j] = __shfl(mu[j], (threadIdx.x & ~3) + q - 1, WAVE);
+        if (part == q) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { double v = cl[j];
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += A[j][c] * li[c];
+                lam[j] = v; }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { double v = mi[j] + cm[j];
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += Bm[j][c] * li[c];
+                mu[j] = v; }
+        }
+    }
+    const bool owner = tvalid && part == 3;
+    if (owner) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { du0[i * N + j] = lam[j]; bad |= !finite_d(lam[j]); }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { bad |= !finite_d(mu[j]); if (dp_rows) dp_rows[i * NP + j] = mu[j]; }
+        if (bad) atomicOr(flag, 1);
+    }
+    block_partial<NP>(mu, owner, partial);
+    if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
 }
 
 // finishing stage for kernels that already wrote du0 [N][n] and dp_traj [NP][Npad]
@@ -330,6 +303,108 @@ __global__ void __launch_bounds__(FIN) k_finish(long Ntraj, long Npad, const dou
     }
     block_partial<NP>(mu, valid, partial);
     if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
+}
+
+// dp[j] = sum over workgroup partials in block order (one workgroup per parameter)
+__global__ void __launch_bounds__(FIN) k_reduce_final(int nblocks, int np, const double* __restrict__ partial, double* __restrict__ dp) {
+    __shared__ double sh[FIN];
+    const int j = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += FIN) s += partial[(long)b * np + j];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = FIN / 2; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) dp[j] = sh[0];
+}
+
+// BacksolveAdjoint, segmented at checkpoint knots; writes the segment maps like k_interp
+template <class Mo>
+__global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ yT,
+                                                    const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
+                                                    const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                                                    double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;
+    if (i >= g.N) return;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
+    if (seg == sp.nseg - 1) {
+        double lam[1][N], mu[1][NP];
+        backsolve_lane<Mo, 1>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
+    } else {
+        double lam[NC][N], mu[NC][NP];
+        backsolve_lane<Mo, NC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) dst[((long)c * R + j) * g.Npad] = lam[c][j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * g.Npad] = mu[c][j];
+        }
+    }
+}
+
+template <class Mo, int NC>
+__device__ __forceinline__ void store_segment_map(double* __restrict__ dst, long Npad, const double (&lam)[NC][Mo::N], const double (&mu)[NC][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP, R = N + NP;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) dst[((long)c * R + j) * Npad] = lam[c][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * Npad] = mu[c][j];
+    }
+}
+
+// GaussAdjoint, time-segmented like k_interp (segment maps -> k_compose_finish)
+template <class Mo, int PF, int LOSS>
+__global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                                const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                                                double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;
+    if (i >= g.N) return;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
+    if (seg == sp.nseg - 1) {
+        double lam[1][N], mu[1][NP];
+        gauss_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        store_segment_map<Mo, 1>(dst, g.Npad, lam, mu);
+    } else {
+        double lam[NC][N], mu[NC][NP];
+        gauss_lane<Mo, NC, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        store_segment_map<Mo, NC>(dst, g.Npad, lam, mu);
+    }
+}
+
+template <class Mo, int LOSS>
+__global__ void __launch_bounds__(WAVE) k_gauss_ckpt(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ ckpt,
+                                                     const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
+                                                     const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
+                                                     double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, KM = HIPADJ_CKPT_KMAX;
+    __shared__ double tile[(KM + 1) * N * WAVE];
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;
+    if (i >= g.N) return;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    const CkptSrc C{ckpt, ckpt_of_knot, prev_ck, tile, WAVE, (int)threadIdx.x};
+    double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
+    if (seg == sp.nseg - 1) {
+        double lam[1][N], mu[1][NP];
+        gauss_lane<Mo, 1, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
+        store_segment_map<Mo, 1>(dst, g.Npad, lam, mu);
+    } else {
+        double lam[NC][N], mu[NC][NP];
+        gauss_lane<Mo, NC, 1, LOSS, KM>(g, i, k_lo, k_hi, p, nullptr, cotT, save_of_knot, lam, mu, &C);
+        store_segment_map<Mo, NC>(dst, g.Npad, lam, mu);
+    }
 }
 
 template <class Mo, int PF, int LOSS>
