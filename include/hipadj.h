@@ -62,6 +62,12 @@ typedef enum {
     HIPADJ_LOSS_LSQ_SHIFT = 1  /* out = u - loss_shift — test/Core3/adjoint.jl:49-51, 1169-1172; fused in-kernel */
 } hipadj_loss;
 
+/* registry of continuous costs (device-inlined dgdu_continuous / dgdp_continuous) */
+typedef enum {
+    HIPADJ_CCOST_NONE = 0,
+    HIPADJ_CCOST_HALF_SQ_SUM = 1  /* g = (sum(u))^2 / 2, dgdu = sum(u) in every component, dgdp = 0 (test/Core3/adjoint.jl:913-919) */
+} hipadj_cont_cost;
+
 typedef struct {
     uint32_t struct_size;      /* = sizeof(hipadj_config); ABI guard */
     int32_t model;             /* hipadj_model */
@@ -81,6 +87,9 @@ typedef struct {
     int32_t p_shared;          /* 1: p[np] shared by all trajectories and dp[np] = sum_i dp_i ; 0: p[N][np], dp[N][np] */
     int32_t device;            /* HIP device ordinal */
     int32_t time_segments;     /* 0 = automatic; 1 = strictly sequential in time; C > 1 = C time segments per trajectory */
+    int32_t cont_cost;         /* hipadj_cont_cost: continuous cost g(u,p,t) added to the loss as int g dt (accumulate_cost!,
+                                  src/derivative_wrappers.jl:1411-1442; adjoint_sensitivities(...; g, dgdu_continuous)) */
+    int32_t reserved0;
 } hipadj_config;
 
 typedef struct {

@@ -598,6 +598,15 @@ static void fetch_y(adj_ctx *A, double t) {
     dense_eval(&A->cpsol, t, A->y, &A->cphint);
 }
 
+/* accumulate_cost!(dlam, y, p, t, S, dgrad)  src/derivative_wrappers.jl:1411-1442: dlam -= g_u(y,p,t) (dgrad -= g_p: zero for
+ * the registered cost).  Called when the cost has a continuous part (`discrete ||` guard, interpolating_adjoint.jl:172). */
+static void accumulate_cost(const adj_ctx *A, double *dlam) {
+    if (A->cfg->cont_cost == 1) {
+        double s = 0; for (int i = 0; i < A->n; ++i) s += A->y[i];
+        for (int i = 0; i < A->n; ++i) dlam[i] -= s;
+    }
+}
+
 /* (S::ODEInterpolatingAdjointSensitivityFunction)(du,u,p,t)  src/interpolating_adjoint.jl:150-174
  * z = [lam(n); grad(np)] */
 static void rhs_interpolating(double *dz, const double *z, double t, void *c) {
@@ -606,6 +615,7 @@ static void rhs_interpolating(double *dz, const double *z, double t, void *c) {
     model_vjp(A->m, dz, dz + n, z, A->y, A->p, t);           /* vecjacobian!(dlam, y, lam, p, t, S; dgrad) */
     for (int i = 0; i < n; ++i) dz[i] *= -1.0;               /* :169 */
     for (int i = 0; i < np; ++i) dz[n + i] *= -1.0;          /* :170 */
+    accumulate_cost(A, dz);                                  /* :172 */
 }
 /* (S::ODEBacksolveSensitivityFunction)(du,u,p,t)  src/backsolve_adjoint.jl:32-61 ; z = [lam; grad; y] (:78-120) */
 static void rhs_backsolve(double *dz, const double *z, double t, void *c) {
@@ -614,6 +624,7 @@ static void rhs_backsolve(double *dz, const double *z, double t, void *c) {
     model_vjp(A->m, dz, dz + n, z, A->y, A->p, t);
     model_f(A->m, dz + n + np, A->y, A->p, t);                /* dy = f(y,p,t), not negated :54 */
     for (int i = 0; i < n + np; ++i) dz[i] *= -1.0;
+    accumulate_cost(A, dz);                                   /* :59 */
 }
 /* Quadrature / Gauss: u = lam only (src/quadrature_adjoint.jl:35-46, src/gauss_adjoint.jl:118-128) */
 static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
@@ -621,6 +632,7 @@ static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
     fetch_y(A, t);
     model_vjp(A->m, dz, NULL, z, A->y, A->p, t);
     for (int i = 0; i < n; ++i) dz[i] *= -1.0;
+    accumulate_cost(A, dz);                                   /* quadrature_adjoint.jl:44, gauss_adjoint.jl:126 */
 }
 
 static int time_hits(double t, double target) { return fabs(t - target) <= 100 * DBL_EPSILON * fmax(fabs(t), fabs(target)); }

@@ -53,6 +53,8 @@ typedef struct {
     const double *checkpoints;
     double quad_abstol, quad_reltol; /* QuadratureAdjoint(abstol, reltol) */
     int no_start;         /* suppress the jump at t0 (src/adjoint_common.jl:761) */
+    int cont_cost;        /* continuous cost g(u,p,t) added to the loss as int g dt (accumulate_cost!, src/derivative_wrappers.jl:1411-1442):
+                             0 none; 1: g = (sum(u))^2 / 2, dgdu = sum(u) in every component (test/Core3/adjoint.jl:913-919), dgdp = 0 */
 } orc_config;
 
 int orc_model_sizes(int model, const int dims[4], int *n, int *np);

@@ -11,6 +11,7 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NONFINITE, ERR_STATE, ERR_UNSUP
 MODEL = dict(lv=0, lvt=1, lorenz=2, lindiag=3, fallmass=4, mlp=5, bruss=6)
 ALG = dict(interpolating=0, backsolve=1, gauss=2, quadrature=3)
 LOSS_COTANGENT, LOSS_LSQ_SHIFT = 0, 1
+CCOST_NONE, CCOST_HALF_SQ_SUM = 0, 1
 
 DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
@@ -29,6 +30,7 @@ class HipadjConfig(C.Structure):
         ("checkpointing", C.c_int32), ("ckpt_stride", C.c_int32),
         ("quad_abstol", C.c_double), ("quad_reltol", C.c_double),
         ("no_start", C.c_int32), ("p_shared", C.c_int32), ("device", C.c_int32), ("time_segments", C.c_int32),
+        ("cont_cost", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

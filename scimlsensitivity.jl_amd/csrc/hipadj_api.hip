@@ -29,7 +29,7 @@ struct hipadj_handle {
     // adjoint timing: a ring of event sets harvested with hipEventQuery, so that back-to-back asynchronous
     // calls never block the host on the previous call (a blocking harvest serialises launch and execution)
     static constexpr int NSET = 16;
-    struct EvSet { hipEvent_t a0 = nullptr, a1 = nullptr, k0 = nullptr, k1 = nullptr; bool pending = false; } evs[NSET];
+    struct EvSet { hipEvent_t a0 = nullptr, a1 = nullptr, k0 = nullptr, k1 = nullptr; bool pending = false, full = true; } evs[NSET];
     int ev_next = 0;
     std::vector<double> save_times;
     std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
@@ -50,6 +50,8 @@ struct hipadj_handle {
     int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
     bool have_forward = false, timing_pending_fwd = false;
+    int fused_final = 0;                  // 1: dp reduced in-launch by the last-arriving workgroup (HIPADJ_FUSED_FINAL)
+    int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)
     double ws_bytes = 0;
     hipadj_stats st{};
     std::string err;
@@ -191,6 +193,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     g.N = h->N; g.Npad = Np; g.S = (int)S; g.M = h->M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
     g.kmask = -1;
+    if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
+    if (const char* e = std::getenv("HIPADJ_FUSED_FINAL")) h->fused_final = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_EXP_KMASK")) g.kmask = std::atoi(e);   // timing experiment only (results are wrong with a mask)
     h->fg.N = h->N; h->fg.S = (int)S; h->fg.M = h->M; h->fg.t0 = cfg->t0; h->fg.dt = cfg->dt; h->fg.loss_shift = cfg->loss_shift;
     h->fg.loss_kind = cfg->loss_kind; h->fg.no_start = cfg->no_start; h->fg.p_shared = cfg->p_shared;
@@ -229,10 +233,11 @@ extern "C" int hipadj_set_stream(hipadj_handle* h, void* s) {
 
 static void harvest_set(hipadj_handle* h, hipadj_handle::EvSet& q, bool block) {
     if (!q.pending) return;
-    if (block) { if (hipEventSynchronize(q.a1) != hipSuccess) { q.pending = false; return; } }
-    else if (hipEventQuery(q.a1) != hipSuccess) return;           // still running: look again later
+    hipEvent_t last = q.full ? q.a1 : q.k1;
+    if (block) { if (hipEventSynchronize(last) != hipSuccess) { q.pending = false; return; } }
+    else if (hipEventQuery(last) != hipSuccess) return;           // still running: look again later
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, q.a0, q.a1) == hipSuccess) { h->st.adjoint_ms_last = ms; h->st.adjoint_ms_total += ms; }
+    if (q.full && hipEventElapsedTime(&ms, q.a0, q.a1) == hipSuccess) { h->st.adjoint_ms_last = ms; h->st.adjoint_ms_total += ms; }
     if (hipEventElapsedTime(&ms, q.k0, q.k1) == hipSuccess) { h->st.adjoint_main_kernel_ms_last = ms; h->st.adjoint_main_kernel_ms_total += ms; }
     q.pending = false;
 }
@@ -294,20 +299,20 @@ template <class Mo> static int forward_impl(hipadj_handle* h, const double* d_u0
 template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     // software-prefetch depth, chosen so that each kernel keeps 2 waves per SIMD (<= 256 VGPRs): the cotangent ring
     // and the Gauss-node state cost registers
-    constexpr int PF = LOSS == 1 ? 8 : 6, PFG = 4;
+    constexpr int PF = (LOSS & 1) == 1 ? 8 : 6, PFG = 4;   // LOSS here = MODE = discrete-loss kind | (continuous cost << 1)
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     const double* p = h->p_dev_last;
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
     const unsigned cblocks = (unsigned)((h->N + FIN / 4 - 1) / (FIN / 4));   // composition: 4 lanes per trajectory
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;   // per-trajectory dp rows [N][np]
-    double* dp_sum = h->cfg.p_shared ? d_dp : (double*)nullptr;    // dp = sum over trajectories, reduced in-launch by the last-arriving workgroup
+    double* dp_sum = (h->cfg.p_shared && h->fused_final) ? d_dp : (double*)nullptr;   // in-launch last-arriver reduction (optional)
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
     harvest_set(h, es, true);                   // ring full: only now wait for the oldest call
-    HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
-    HIP_TRY(h, hipEventRecord(k0, h->stream));
+    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k0, h->stream));
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
@@ -318,18 +323,18 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         hipLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p,
                            (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(k1, h->stream));
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
                            d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_BACKSOLVE: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
-        hipLaunchKernelGGL((k_backsolve<Mo>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
+        hipLaunchKernelGGL((k_backsolve<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
                            (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
                            (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(k1, h->stream));
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
                            d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
@@ -343,7 +348,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
             hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
                                (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(k1, h->stream));
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
                            d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
@@ -352,7 +357,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         hipLaunchKernelGGL((k_quad_adj<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
                            (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(k1, h->stream));
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
         hipLaunchKernelGGL((k_quad_gk<Mo>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
                            (const dbl2*)h->d_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
@@ -367,15 +372,25 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                            (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
     }
-    HIP_TRY(h, hipEventRecord(es.a1, h->stream));
-    es.pending = true;
+    if (h->cfg.p_shared && !h->fused_final) {   // dp = sum over workgroup partials, fixed order
+        const unsigned nb = h->cfg.alg == HIPADJ_ALG_QUADRATURE ? fblocks : cblocks;
+        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)nb, h->np, (const double*)h->d_partial, d_dp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = h->timing >= 1; es.full = h->timing >= 2;
     return HIPADJ_OK;   // timings are harvested lazily at the next synchronize / call
 }
 
 template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    return h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT ? adjoint_impl_l<Mo, 0>(h, d_cot, d_du0, d_dp) : adjoint_impl_l<Mo, 1>(h, d_cot, d_du0, d_dp);
+    const int mode = (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT ? 0 : 1) | (h->cfg.cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
+    switch (mode) {
+    case 0: return adjoint_impl_l<Mo, 0>(h, d_cot, d_du0, d_dp);
+    case 1: return adjoint_impl_l<Mo, 1>(h, d_cot, d_du0, d_dp);
+    case 2: return adjoint_impl_l<Mo, 2>(h, d_cot, d_du0, d_dp);
+    default: return adjoint_impl_l<Mo, 3>(h, d_cot, d_du0, d_dp);
+    }
 }
-
 
 // ---- workgroup-per-trajectory family (Brusselator) -----------------------------------------------------
 template <int G> static int field_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {

@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(FIN) k_reduce_final(int nblocks, int np, const
 }
 
 // BacksolveAdjoint, segmented at checkpoint knots; writes the segment maps like k_interp
-template <class Mo>
+template <class Mo, int CC>
 __global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ yT,
                                                     const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
                                                     const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
@@ -331,14 +331,14 @@ __global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, SegPlan sp, const do
     double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
     if (seg == sp.nseg - 1) {
         double lam[1][N], mu[1][NP];
-        backsolve_lane<Mo, 1>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+        backsolve_lane<Mo, 1, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
 #pragma unroll
         for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
 #pragma unroll
         for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
     } else {
         double lam[NC][N], mu[NC][NP];
-        backsolve_lane<Mo, NC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+        backsolve_lane<Mo, NC, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll

@@ -138,30 +138,57 @@ HIPADJ_HD void loss_grad(const Geom& g, long i, int s, const double* __restrict_
         gl[j] = (g.loss_kind == 0) ? cotT[((long)s * Mo::N + j) * g.Npad + i] : (y[j] - g.loss_shift);
 }
 
+// continuous cost g(u,p,t) of the registry (accumulate_cost!, src/derivative_wrappers.jl:1411-1442): CC = 1 is the
+// reference test's energy  g = (sum u)^2 / 2  =>  dgdu_j = sum(u) for every j, dgdp = 0  (test/Core3/adjoint.jl:913-919)
+template <class Mo, int CC>
+HIPADJ_HD void cost_grad_u(const double (&y)[Mo::N], double (&gu)[Mo::N]) {
+    double s = 0.0;
+    if (CC == 1) {
+#pragma unroll
+        for (int j = 0; j < Mo::N; ++j) s += y[j];
+    }
+#pragma unroll
+    for (int j = 0; j < Mo::N; ++j) gu[j] = s;
+}
+
 // One reverse RK4 step of NC columns z_c = (lam_c, mu_c) through the interval [t_k, t_{k+1}] (h = -dt):
-//   lam' = -(df/du)^T lam , mu' = -(df/dp)^T lam  with y from the forward Hermite interpolant.
-// WITH_MU = false skips the parameter block (Gauss / Quadrature integrate lambda only).
-template <class Mo, int NC, bool WITH_MU>
+//   lam' = -(df/du)^T lam - g_u , mu' = -(df/dp)^T lam  with y from the forward Hermite interpolant.
+// The cost term g_u does not depend on lam: it only drives the affine column (c = 0).
+// WITH_MU = false skips the parameter block (Quadrature integrates lambda only).
+template <class Mo, int NC, bool WITH_MU, int CC = 0>
 HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&pv)[Mo::NP], double t_lo, double dt,
                             double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
     constexpr int N = Mo::N, NP = Mo::NP;
-    double ymid[N];
+    double ymid[N], gu1[N], gum[N], gu4[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]);
+    if (CC) { cost_grad_u<Mo, CC>(hi.u, gu1); cost_grad_u<Mo, CC>(ymid, gum); cost_grad_u<Mo, CC>(lo.u, gu4); }
     const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         double V1[N], V2[N], V3[N], V4[N], l2[N], l3[N], l4[N];
         Mo::vjp_u(V1, lam[c], hi.u, pv, t_hi);
+        if (CC && c == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) V1[j] += gu1[j]; }
 #pragma unroll
         for (int j = 0; j < N; ++j) l2[j] = lam[c][j] + (0.5 * dt) * V1[j];
         Mo::vjp_u(V2, l2, ymid, pv, t_mid);
+        if (CC && c == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) V2[j] += gum[j]; }
 #pragma unroll
         for (int j = 0; j < N; ++j) l3[j] = lam[c][j] + (0.5 * dt) * V2[j];
         Mo::vjp_u(V3, l3, ymid, pv, t_mid);
+        if (CC && c == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) V3[j] += gum[j]; }
 #pragma unroll
         for (int j = 0; j < N; ++j) l4[j] = lam[c][j] + dt * V3[j];
         Mo::vjp_u(V4, l4, lo.u, pv, t_lo);
+        if (CC && c == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) V4[j] += gu4[j]; }
         if (WITH_MU) {
             // mu' = -(df/dp)^T lam, RK4 weights 1:2:2:1.  (df/dp)^T lam is linear in lam and stages 2 and 3 share the
             // same y (the Hermite midpoint) and t, so their two VJPs collapse into one on lam_2 + lam_3.
@@ -368,12 +395,12 @@ HIPADJ_HD void reverse_sweep_ckpt(const Geom& g, long i, int k_lo, int k_hi, con
 //   top segment (k_hi == S): NC = 1, the jump at T is applied before the first step.
 // The jump at knot k_lo is applied at the end (so segment results chain without double counting).
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int NC, int PF, int LOSS, int KMAX = 0>
+template <class Mo, int NC, int PF, int MODE, int KMAX = 0>   // MODE = discrete-loss kind | (continuous cost << 1)
 HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p,
                            const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                            const int* __restrict__ save_of_knot, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP],
                            const CkptSrc* ck = nullptr) {
-    constexpr int N = Mo::N, NP = Mo::NP;
+    constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -387,7 +414,7 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
         for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
     };
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
-        adj_rk4_step<Mo, NC, true>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
+        adj_rk4_step<Mo, NC, true, CC>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
 #pragma unroll
         for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
     };
@@ -404,7 +431,7 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
 // Time segmentation: y is re-initialised from the stored forward value at every checkpoint, so a segment whose
 // upper end k_hi is a checkpoint knot (or T) knows its y without the segments above it; (lam, mu) are linear given
 // y, so NC = 1 + N columns carry the segment's affine map exactly as in interp_lane.
-template <class Mo, int NC>
+template <class Mo, int NC, int CC = 0>
 HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p,
                               const double* __restrict__ yT, const double* __restrict__ ckpt,
                               const int* __restrict__ ckpt_of_knot, const double* __restrict__ cotT,
@@ -445,23 +472,37 @@ HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const d
 #pragma unroll
         for (int j = 0; j < N; ++j) Y4[j] = y[j] - dt * F3[j];
         Mo::f(F4, Y4, pv, t_lo);
+        double gu1[N], gu2[N], gu3[N], gu4[N];
+        if (CC) { cost_grad_u<Mo, CC>(y, gu1); cost_grad_u<Mo, CC>(Y2, gu2); cost_grad_u<Mo, CC>(Y3, gu3); cost_grad_u<Mo, CC>(Y4, gu4); }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             double ls[N], V1[N], V2[N], V3[N], V4[N], W[NP], Wacc[NP];
             Mo::vjp_u(V1, lam[c], y, pv, t_hi); Mo::vjp_p(Wacc, lam[c], y, pv, t_hi);
+            if (CC && c == 0) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) V1[j] += gu1[j]; }
 #pragma unroll
             for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V1[j];
             Mo::vjp_u(V2, ls, Y2, pv, t_mid); Mo::vjp_p(W, ls, Y2, pv, t_mid);
+            if (CC && c == 0) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) V2[j] += gu2[j]; }
 #pragma unroll
             for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
 #pragma unroll
             for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V2[j];
             Mo::vjp_u(V3, ls, Y3, pv, t_mid); Mo::vjp_p(W, ls, Y3, pv, t_mid);
+            if (CC && c == 0) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) V3[j] += gu3[j]; }
 #pragma unroll
             for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
 #pragma unroll
             for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + dt * V3[j];
             Mo::vjp_u(V4, ls, Y4, pv, t_lo); Mo::vjp_p(W, ls, Y4, pv, t_lo);
+            if (CC && c == 0) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) V4[j] += gu4[j]; }
 #pragma unroll
             for (int j = 0; j < NP; ++j) Wacc[j] += W[j];
 #pragma unroll
@@ -499,11 +540,11 @@ HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double 
 // ------------------------------------------------------------------------------------------------
 // Like interp_lane the sweep is linear in (lam, mu) given y(t), so it takes NC columns (affine + basis) and a segment
 // [k_lo, k_hi): the same time segmentation and composition apply.
-template <class Mo, int NC, int PF, int LOSS, int KMAX = 0>
+template <class Mo, int NC, int PF, int MODE, int KMAX = 0>
 HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p, const dbl2* __restrict__ knots,
                           const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                           double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP], const CkptSrc* ck = nullptr) {
-    constexpr int N = Mo::N, NP = Mo::NP;
+    constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -520,14 +561,15 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
     };
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
         const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
-        double lam_hi[NC][N], d_hi[NC][N], V[N];
+        double lam_hi[NC][N], d_hi[NC][N], V[N], guh[N], gul[N];
+        cost_grad_u<Mo, CC>(hi.u, guh); cost_grad_u<Mo, CC>(lo.u, gul);      // zero when CC == 0
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             Mo::vjp_u(V, lam[c], hi.u, pv, t_hi);
 #pragma unroll
-            for (int j = 0; j < N; ++j) { lam_hi[c][j] = lam[c][j]; d_hi[c][j] = -V[j]; }      // fsalfirst of the adjoint step
+            for (int j = 0; j < N; ++j) { lam_hi[c][j] = lam[c][j]; d_hi[c][j] = -(V[j] + ((CC && c == 0) ? guh[j] : 0.0)); }   // fsalfirst of the adjoint step
         }
-        adj_rk4_step<Mo, NC, false>(hi, lo, pv, t_lo, dt, lam, mu);
+        adj_rk4_step<Mo, NC, false, CC>(hi, lo, pv, t_lo, dt, lam, mu);
         // forward state at the two Gauss nodes t_g = mid + half*x, half = (t_lo - t_hi)/2 < 0; theta along the adjoint
         // step = (1 + x)/2; shared by all columns
         double yg[2][N];
@@ -538,7 +580,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
             double d_lo[N];
             Mo::vjp_u(V, lam[c], lo.u, pv, t_lo);
 #pragma unroll
-            for (int j = 0; j < N; ++j) d_lo[j] = -V[j];                                        // fsallast
+            for (int j = 0; j < N; ++j) d_lo[j] = -(V[j] + ((CC && c == 0) ? gul[j] : 0.0));          // fsallast
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const double th = 0.5 * (1.0 + (q == 0 ? -xg : xg));
@@ -561,11 +603,11 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
 //   adj[k] = ( lam_start (post-jump at k+1), dlam_start, lam_end (pre-jump at k), dlam_end )   4N doubles
 // laid out [step][2N pairs][Npad]  (src/quadrature_adjoint.jl:527-530 save_everystep = true).
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int PF, int LOSS>
+template <class Mo, int PF, int MODE>
 HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
                              const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                              dbl2* __restrict__ adj, double (&lamo)[Mo::N]) {
-    constexpr int N = Mo::N, NP = Mo::NP;
+    constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
     double lam[1][N], mu[1][NP];
 #pragma unroll
@@ -580,14 +622,15 @@ HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p
         },
         [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
             const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
-            double rec[4 * N], V[N];
+            double rec[4 * N], V[N], guh[N], gul[N];
+            cost_grad_u<Mo, CC>(hi.u, guh); cost_grad_u<Mo, CC>(lo.u, gul);      // zero when CC == 0
             Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
 #pragma unroll
-            for (int j = 0; j < N; ++j) { rec[j] = lam[0][j]; rec[N + j] = -V[j]; }
-            adj_rk4_step<Mo, 1, false>(hi, lo, pv, t_lo, dt, lam, mu);
+            for (int j = 0; j < N; ++j) { rec[j] = lam[0][j]; rec[N + j] = -(V[j] + guh[j]); }
+            adj_rk4_step<Mo, 1, false, CC>(hi, lo, pv, t_lo, dt, lam, mu);
             Mo::vjp_u(V, lam[0], lo.u, pv, t_lo);
 #pragma unroll
-            for (int j = 0; j < N; ++j) { rec[2 * N + j] = lam[0][j]; rec[3 * N + j] = -V[j]; }
+            for (int j = 0; j < N; ++j) { rec[2 * N + j] = lam[0][j]; rec[3 * N + j] = -(V[j] + gul[j]); }
 #pragma unroll
             for (int j = 0; j < 2 * N; ++j) { dbl2 d; d.x = rec[2 * j]; d.y = rec[2 * j + 1]; adj[((long)k * 2 * N + j) * g.Npad + i] = d; }
 #pragma unroll

@@ -95,6 +95,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->time_segments < 0) { err = "time_segments must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->ckpt_stride < 0) { err = "ckpt_stride must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->cont_cost != HIPADJ_CCOST_NONE && cfg->cont_cost != HIPADJ_CCOST_HALF_SQ_SUM) { err = "unknown cont_cost"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->cont_cost != HIPADJ_CCOST_NONE && (P.field || P.mlp)) { err = "continuous costs are available for the lane-per-trajectory family only"; return HIPADJ_ERR_UNSUPPORTED; }
     P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = (int)S; P.M = cfg->nsave;
     P.save_of_knot.assign(S + 1, -1); P.ckpt_of_knot.assign(S + 1, -1);
     P.save_times.assign(cfg->save_times, cfg->save_times + cfg->nsave);

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Engine
-from .problems import RK4, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift
+from .problems import RK4, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum
 from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
                                      QuadratureAdjoint, GaussAdjoint, ischeckpointing)
 
@@ -45,11 +45,11 @@ def _engine_kwargs(sensealg, checkpoints, dt, t0):
 
 
 def solve(ensprob, alg=RK4(), *, dt, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
-          device=0, time_segments=0, no_start=False, want_out=True):
+          device=0, time_segments=0, no_start=False, want_out=True, g=None):
     """Forward solve of an EnsembleProblem on the device.  The returned solution owns the device-resident
     interpolant tiles (Interpolating/Gauss/Quadrature) or checkpoints (Backsolve) the reverse pass consumes.
     `dgdu_discrete` may be given here already (LsqShift or None = cotangents) because the fused reverse kernel
-    is specialised on it at handle creation."""
+    is specialised on it at handle creation; likewise the continuous cost `g` (HalfSquaredSum() or None)."""
     if not isinstance(alg, RK4):
         raise ValueError("only fixed-step RK4() runs on the device (adaptive Tsit5 is CPU plumbing, BASELINE config 1)")
     if not isinstance(sensealg, AbstractAdjointSensitivityAlgorithm):
@@ -58,23 +58,27 @@ def solve(ensprob, alg=RK4(), *, dt, saveat=None, sensealg=InterpolatingAdjoint(
         ensprob = EnsembleProblem(ensprob, ensprob.u0[None, :])
     prob = ensprob.prob
     ts = _save_times(prob.tspan, saveat, dt)
+    if g is not None and not isinstance(g, HalfSquaredSum):
+        raise ValueError("g must be a registered continuous cost (HalfSquaredSum()) or None")
     loss_kind, shift = (_lib.LOSS_LSQ_SHIFT, dgdu_discrete.shift) if isinstance(dgdu_discrete, LsqShift) else (_lib.LOSS_COTANGENT, 0.0)
     eng = Engine(prob.f, sensealg.name, ensprob.u0.shape[0], prob.tspan[0], prob.tspan[1], dt, save_times=ts,
                  loss_kind=loss_kind, loss_shift=shift, p_shared=(ensprob.p.ndim == 1), device=device,
-                 time_segments=time_segments, no_start=no_start, dims=prob.dims,
+                 time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_lib.CCOST_HALF_SQ_SUM if g is not None else 0),
                  **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0]))
     out = eng.forward(ensprob.u0, ensprob.p, want_out=want_out)
     return EnsembleSolution(engine=eng, u=out, t=ts, prob=ensprob, alg=alg, dt=dt,
-                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete))
+                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g))
 
 
-def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, sensealg=None, checkpoints=None, **kwargs):
+def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, sensealg=None, checkpoints=None, g=None, **kwargs):
     """(du0, dp) for the loss  sum_i l_i(u(t_i))  with dl_i/du = dgdu_discrete at the times `t`
     (src/sensitivity_interface.jl:373-526).  `dgdu_discrete`: LsqShift(c) or an array [N][M][n] of cotangents
     (the AD path hands `Delta[:, i]`, src/concrete_solve.jl:842-851).  Returns du0 [N][n] and dp: [np] row
     (sum over the ensemble when p is shared) or [N][np]."""
     if kwargs:
-        raise TypeError(f"unsupported keyword(s) {sorted(kwargs)} (continuous costs g/dgdp, callbacks: SURVEY.md §8f)")
+        raise TypeError(f"unsupported keyword(s) {sorted(kwargs)} (dgdp, callbacks: SURVEY.md §8f)")
+    if g is not None and sol.extra.get("g") != g:
+        raise ValueError("pass the continuous cost g to solve(...) as well: the reverse kernel is specialised on it")
     eng = sol.engine
     want_alg = (sensealg or sol.extra["sensealg"])
     if want_alg.name != eng.alg:
@@ -86,7 +90,7 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, senseal
             raise ValueError("pass dgdu_discrete=LsqShift(...) to solve(...) as well: the reverse kernel is specialised on it")
         return eng.adjoint(None)
     if dgdu_discrete is None:
-        if eng.cfg.loss_kind == _lib.LOSS_LSQ_SHIFT:
+        if eng.cfg.loss_kind == _lib.LOSS_LSQ_SHIFT or eng.M == 0:
             return eng.adjoint(None)
         raise ValueError("dgdu_discrete required")
     if eng.cfg.loss_kind != _lib.LOSS_COTANGENT:

@@ -49,6 +49,13 @@ class LsqShift:
     shift: float = 0.0
 
 
+@dataclass(frozen=True)
+class HalfSquaredSum:
+    """Continuous cost g(u, p, t) = (sum(u))^2 / 2 with dgdu_continuous = sum(u) in every component
+    (the `g`/`dg` pair of test/Core3/adjoint.jl:913-919); evaluated inside the reverse kernels
+    (accumulate_cost!, src/derivative_wrappers.jl:1411-1442)."""
+
+
 @dataclass
 class EnsembleSolution:
     """What the reverse pass needs from the forward solve: the handle owning the device-resident interpolant

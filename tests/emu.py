@@ -35,7 +35,7 @@ def lib():
 
 
 def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shift=0.0, checkpointing=False,
-                ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, p_shared=True, time_segments=1):
+                ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, p_shared=True, time_segments=1, cont_cost=0):
     from scimlsensitivity_jl_amd import _lib as PL
     save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
     c = PL.HipadjConfig()
@@ -49,6 +49,7 @@ def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shi
     c.checkpointing, c.ckpt_stride = int(checkpointing), ckpt_stride
     c.quad_abstol, c.quad_reltol = quad_abstol, quad_reltol
     c.no_start, c.p_shared, c.device, c.time_segments = int(no_start), int(p_shared), 0, time_segments
+    c.cont_cost = cont_cost
     c._keep = save
     return c
 

@@ -39,7 +39,7 @@ static void compose(const Plan& P, const std::vector<double>& segbuf, double* du
         }
 }
 
-template <class Mo, int LOSS>
+template <class Mo, int LOSS>   // LOSS = MODE = discrete-loss kind | (continuous cost << 1)
 static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
                double* du0, double* dp, double* out) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, PF = 8;
@@ -87,12 +87,12 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
             if (seg == P.nseg - 1) {
                 double lam[1][N], mu[1][NP];
-                backsolve_lane<Mo, 1>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
+                backsolve_lane<Mo, 1, (LOSS >> 1)>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
                 for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
                 for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
             } else {
                 double lam[NC][N], mu[NC][NP];
-                backsolve_lane<Mo, NC>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
+                backsolve_lane<Mo, NC, (LOSS >> 1)>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
                 for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
             }
@@ -143,6 +143,17 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     return HIPADJ_OK;
 }
 
+template <class Mo>
+static int dispatch_mode(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out) {
+    const int mode = (cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? 0 : 1) | (cfg->cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
+    switch (mode) {
+    case 0: return run<Mo, 0>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case 1: return run<Mo, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case 2: return run<Mo, 2>(cfg, P, u0, p, dLdu, du0, dp, out);
+    default: return run<Mo, 3>(cfg, P, u0, p, dLdu, du0, dp, out);
+    }
+}
+
 static std::string g_err;
 extern "C" const char* emu_last_error() { return g_err.c_str(); }
 
@@ -157,11 +168,11 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
                                    double* du0, double* dp, double* out) {
     Plan P; const int rc = make_plan(cfg, P, g_err); if (rc) return rc;
     switch (cfg->model) {
-    case HIPADJ_MODEL_LV: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelLV, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelLV, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_LVT: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelLVT, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelLVT, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_LORENZ: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelLorenz, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelLorenz, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_LINDIAG: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelLinDiag, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelLinDiag, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_FALLMASS: return cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? run<ModelFallMass, 0>(cfg, P, u0, p, dLdu, du0, dp, out) : run<ModelFallMass, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LV: return dispatch_mode<ModelLV>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LVT: return dispatch_mode<ModelLVT>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LORENZ: return dispatch_mode<ModelLorenz>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_LINDIAG: return dispatch_mode<ModelLinDiag>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_FALLMASS: return dispatch_mode<ModelFallMass>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

@@ -115,6 +115,19 @@ def main():
     out["lindiag"] = dict(u0=[1.0, 1.0], p=[1.0, 2.0], tspan=[0, 1], ts=ts.tolist(), loss="sum(u(T))",
                           reference_literal=np.exp([1.0, 2.0]).tolist(), reference_rtol=1e-3,
                           du0=du0.tolist(), dp=dp.tolist())
+    # continuous cost L = int_0^T (u1 + u2)^2 / 2 dt on the time-dependent LV problem (test/Core3/adjoint.jl:910-1127)
+    p4 = np.array([1.5, 1.0, 3.0, 1.0])
+
+    def rhs_c(t, z):
+        u = z[:2]; S = z[2:14].reshape(2, 6)
+        f_, J, P = lvt(u, p4, t)
+        dS = J @ S; dS[:, 2:] += P
+        return np.concatenate([f_, dS.ravel(), u.sum() * (S[0] + S[1])])
+    S0 = np.zeros((2, 6)); S0[:, :2] = np.eye(2)
+    solc = solve_ivp(rhs_c, (0, 4.0), np.concatenate([[1.0, 1.0], S0.ravel(), np.zeros(6)]), method="DOP853", rtol=1e-13, atol=1e-13)
+    gc = solc.y[14:, -1]
+    out["lvt_continuous"] = dict(u0=[1.0, 1.0], p=p4.tolist(), tspan=[0, 4.0], cost="g = (u1+u2)^2/2", du0=gc[:2].tolist(), dp=gc[2:].tolist())
+
     with open(os.path.join(HERE, "gradients.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k, v in out.items():

@@ -28,7 +28,7 @@ class OrcConfig(C.Structure):
         ("loss_kind", C.c_int), ("loss_shift", C.c_double),
         ("checkpointing", C.c_int), ("nckpt", C.c_int), ("checkpoints", C.POINTER(C.c_double)),
         ("quad_abstol", C.c_double), ("quad_reltol", C.c_double),
-        ("no_start", C.c_int),
+        ("no_start", C.c_int), ("cont_cost", C.c_int),
     ]
 
 
@@ -86,7 +86,7 @@ class Problem:
 
     def __init__(self, model, alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=1.0, dt=0.01, abstol=1e-6,
                  reltol=1e-3, save_times=(), loss="COTANGENT", loss_shift=0.0, checkpointing=False,
-                 checkpoints=None, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, dims=(0, 0, 0, 0)):
+                 checkpoints=None, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, dims=(0, 0, 0, 0), cont_cost=0):
         self.model = model
         self.dims = tuple(dims)
         self.n, self.np = model_sizes(model, dims)
@@ -105,6 +105,7 @@ class Problem:
         c.checkpoints = _p(self._ck) if self._ck is not None else None
         c.quad_abstol, c.quad_reltol = quad_abstol, quad_reltol
         c.no_start = int(no_start)
+        c.cont_cost = int(cont_cost)
         self.cfg = c
 
     @property

@@ -145,3 +145,21 @@ def test_gauss_time_segmented_equals_sequential(segments):
     ref = O.Problem("LORENZ", alg="GAUSS", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
     assert rel(du0, rdu0) < 1e-11 and rel(dp, rdp) < 1e-11
+
+
+@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("segments", [1, 3])
+def test_continuous_cost_accumulate_cost(alg, segments):
+    """accumulate_cost! (src/derivative_wrappers.jl:1411-1442): lam' = -J^T lam - g_u with g = (sum u)^2/2
+    (test/Core3/adjoint.jl:913-919), alone and mixed with a discrete loss (test/Core7/mixed_costs.jl)."""
+    rng = np.random.default_rng(21)
+    N, T, dt = 3, 2.0, 0.01
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    for ts, loss_kind in ((np.zeros(0), 1), (np.linspace(0, T, 11), 1)):
+        cfg = E.make_config("lvt", alg, N, 0.0, T, dt, ts, loss_kind=loss_kind, loss_shift=2.0, checkpointing=(alg == "backsolve"),
+                            ckpt_stride=20, time_segments=segments, cont_cost=1)
+        du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
+        ref = O.Problem("LVT", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0,
+                        checkpointing=(alg == "backsolve"), checkpoints=np.arange(0, 201, 20) * dt, cont_cost=1)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+        assert rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10

@@ -427,3 +427,22 @@ def test_repeated_calls_are_bitwise_reproducible_no_stale_handoff(sa, alg):
     idx = np.arange(0, N, 300)
     rdu0, _, _, _ = ref.adjoint_ensemble(u0[idx], p, d[0][idx])
     assert rel(first[0][0][idx], rdu0) < RTOL
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_continuous_cost_on_device(sa, alg, oalg):
+    """adjoint_sensitivities(...; g, dgdu_continuous): g = (sum u)^2/2 accumulated inside the reverse kernels
+    (accumulate_cost!, src/derivative_wrappers.jl:1411-1442), alone and mixed with a discrete loss."""
+    N, T, dt = 100, 2.0, 0.01
+    rng = np.random.default_rng(23)
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    for ts, dg in ((None, None), (np.linspace(0, T, 11), sa.LsqShift(2.0))):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lvt", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                       sensealg=sensealg_of(sa, alg), dgdu_discrete=dg, g=sa.HalfSquaredSum(),
+                       checkpoints=(np.arange(0, 201, 20) * dt if alg == "backsolve" else None))
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), g=sa.HalfSquaredSum())
+        ref = O.Problem("LVT", alg=oalg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=(ts if ts is not None else []), loss="LSQ_SHIFT",
+                        loss_shift=2.0, checkpointing=(alg == "backsolve"), checkpoints=np.arange(0, 201, 20) * dt, cont_cost=1)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+        assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+        sol.engine.close()

@@ -189,3 +189,14 @@ def test_ensemble_sums_shared_parameter_gradient():
     singles = [pr.adjoint(u0[i], p) for i in range(6)]
     assert np.allclose(dp, sum(s[1] for s in singles), rtol=1e-13)
     assert np.allclose(du0, np.stack([s[0] for s in singles]), rtol=1e-14)
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_continuous_cost_matches_forward_sensitivity_gradient(alg, golden):
+    """dgdu_continuous / g path (accumulate_cost!): adjoint == ForwardDiff of the quadrature of g
+    (test/Core3/adjoint.jl:1099-1144, norm < 1e-8 there)."""
+    g = golden["lvt_continuous"]
+    pr = O.Problem("LVT", alg=alg, stepper="TSIT5", t0=0, t1=4.0, dt=0.0, abstol=1e-12, reltol=1e-12, save_times=[], loss="LSQ_SHIFT",
+                   cont_cost=1, quad_abstol=1e-12, quad_reltol=1e-12)
+    du0, dp, _ = pr.adjoint(g["u0"], g["p"])
+    assert rel(du0, g["du0"]) < 1e-8 and rel(dp, g["dp"]) < 1e-8
