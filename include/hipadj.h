@@ -138,6 +138,9 @@ int hipadj_adjoint_dev(hipadj_handle *h, const double *d_dLdu, double *d_du0, do
 /* run on the caller's hipStream_t (e.g. torch's current stream); NULL restores the handle's own stream */
 int hipadj_set_stream(hipadj_handle *h, void *hip_stream);
 int hipadj_synchronize(hipadj_handle *h);
+/* device timing recorded per adjoint call: 0 none, 1 dominant-kernel bracket (2 events), 2 + whole-call bracket (default).
+ * Each event costs a few microseconds of queue time; throughput-critical callers use 0 or 1. */
+int hipadj_set_timing(hipadj_handle *h, int level);
 
 int hipadj_get_stats(hipadj_handle *h, hipadj_stats *stats);
 

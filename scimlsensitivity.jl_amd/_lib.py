@@ -16,7 +16,7 @@ CCOST_NONE, CCOST_HALF_SQ_SUM = 0, 1
 DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
-    "hipadj_set_stream", "hipadj_synchronize", "hipadj_get_stats",
+    "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
 )
 
 
@@ -86,6 +86,7 @@ def load():
     L.hipadj_adjoint_dev.argtypes = [vp, vp, vp, vp]
     L.hipadj_set_stream.argtypes = [vp, vp]
     L.hipadj_synchronize.argtypes = [vp]
+    L.hipadj_set_timing.argtypes = [vp, C.c_int]
     L.hipadj_get_stats.argtypes = [vp, C.POINTER(HipadjStats)]
     _lib = L
     return L

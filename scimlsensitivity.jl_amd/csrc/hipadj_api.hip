@@ -225,6 +225,12 @@ extern "C" int hipadj_destroy(hipadj_handle* h) {
     return HIPADJ_OK;
 }
 
+extern "C" int hipadj_set_timing(hipadj_handle* h, int level) {
+    if (!h || level < 0 || level > 2) return HIPADJ_ERR_INVALID_ARG;
+    h->timing = level;
+    return HIPADJ_OK;
+}
+
 extern "C" int hipadj_set_stream(hipadj_handle* h, void* s) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     h->stream = s ? (hipStream_t)s : h->own_stream;
@@ -383,7 +389,8 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
 }
 
 template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    const int mode = (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT ? 0 : 1) | (h->cfg.cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
+    // no loss times => no cotangent buffer exists: run the LSQ specialisation (its jump select is never taken)
+    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
     switch (mode) {
     case 0: return adjoint_impl_l<Mo, 0>(h, d_cot, d_du0, d_dp);
     case 1: return adjoint_impl_l<Mo, 1>(h, d_cot, d_du0, d_dp);

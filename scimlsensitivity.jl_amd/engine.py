@@ -102,6 +102,10 @@ class Engine:
         self._check(self._L.hipadj_adjoint_dev(self._h, C.c_void_p(dLdu.data_ptr()) if dLdu is not None else None,
                                                C.c_void_p(du0.data_ptr()), C.c_void_p(dp.data_ptr())))
 
+    def set_timing(self, level):
+        """0: no device events, 1: dominant-kernel bracket only, 2: + whole-call bracket (default)."""
+        self._check(self._L.hipadj_set_timing(self._h, int(level)))
+
     def synchronize(self):
         self._check(self._L.hipadj_synchronize(self._h))
 

@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd $REPO
 echo "== pytest -m gpu" ; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
-one() { python bench.py --no-cpu-baseline --segments $1 --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('seg',d['config']['time_segments'],'wtop','$HIPADJ_WTOP','traj/s %.3e ms/step %.4f kernel_ms %.4f GB/s %.0f e2e_adj_ms %.4f'%(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['achieved'], d['roofline']['end_to_end_adjoint_ms']))"; }
+one() { python bench.py --no-cpu-baseline --segments $1 --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('seg',d['config']['time_segments'],'wtop','$HIPADJ_WTOP','traj/s %.3e ms/step %.4f kernel_ms %.4f GB/s %.0f'%(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['achieved']))"; }
 echo "== sweep"
 for w in 2.0 2.8 3.5 4.5; do for seg in 6 12 13; do HIPADJ_WTOP=$w one $seg; done; done
 one 1; one 0

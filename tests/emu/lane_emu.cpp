@@ -145,7 +145,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
 
 template <class Mo>
 static int dispatch_mode(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out) {
-    const int mode = (cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? 0 : 1) | (cfg->cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
+    const int mode = ((cfg->loss_kind == HIPADJ_LOSS_COTANGENT && P.M > 0) ? 0 : 1) | (cfg->cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
     switch (mode) {
     case 0: return run<Mo, 0>(cfg, P, u0, p, dLdu, du0, dp, out);
     case 1: return run<Mo, 1>(cfg, P, u0, p, dLdu, du0, dp, out);

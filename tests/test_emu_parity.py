@@ -163,3 +163,15 @@ def test_continuous_cost_accumulate_cost(alg, segments):
                         checkpointing=(alg == "backsolve"), checkpoints=np.arange(0, 201, 20) * dt, cont_cost=1)
         rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
         assert rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+def test_no_loss_times_with_cotangent_loss_kind_is_safe():
+    """M = 0 with the cotangent loss kind: there is no cotangent buffer at all; the sweep must not touch it."""
+    u0 = np.array([[1.0, 1.0]]); p = np.array([1.5, 1.0, 3.0, 1.0])
+    for alg in ALGS:
+        cfg = E.make_config("lvt", alg, 1, 0.0, 1.0, 0.01, [], loss_kind=0, cont_cost=1, checkpointing=(alg == "backsolve"), ckpt_stride=10)
+        du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p, None)
+        ref = O.Problem("LVT", alg=alg.upper(), stepper="RK4", t0=0, t1=1.0, dt=0.01, save_times=[], loss="COTANGENT", cont_cost=1,
+                        checkpointing=(alg == "backsolve"), checkpoints=np.arange(0, 101, 10) * 0.01)
+        rdu0, rdp, _ = ref.adjoint(u0[0], p, None)
+        assert rel(du0[0], rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
