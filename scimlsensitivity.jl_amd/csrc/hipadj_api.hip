@@ -144,8 +144,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         h->mlp = true; h->field = false; h->NQ = P.NQ;
         const size_t Hh = cfg->dims[1], Bb = cfg->dims[2], Q = (size_t)h->N * S * P.NQ, HP = Hh + 16;
         const long groups = cfg->p_shared ? 1 : h->N;
-        const long nchunks = (long)(Q / groups) * (Bb / 16);
-        h->ksplit = (int)(nchunks < 128 ? nchunks : 128);
+        const long nslabs = (long)(Q / groups) * ((Bb + 63) / 64);   // weight-gradient GEMMs: 64-sample slabs, 2 workgroups per CU
+        h->ksplit = (int)(nslabs < 512 ? nslabs : 512);
         A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
         A(dev_alloc(h, &h->d_w2t, (size_t)groups * Hh * Hh));
         A(dev_alloc(h, &h->d_ax, Q * 16 * Bb)); A(dev_alloc(h, &h->d_al, Q * 16 * Bb));
@@ -490,12 +490,23 @@ template <int H> static int mlp_adjoint_launch(hipadj_handle* h, const double* d
     const long groups = h->cfg.p_shared ? 1 : h->N;
     const long Qper = (h->N * (long)h->S * h->NQ) / groups;
     const int B = h->mg.B, ks = h->ksplit;
-    hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
-    HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL((k_mlp_wgrad<1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
-    HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
-    HIP_TRY(h, hipGetLastError());
+    if (B % 64 == 0) {
+        const size_t lds1 = (size_t)HP * WG_PITCH * sizeof(double), lds2 = (size_t)16 * WG_PITCH * sizeof(double);
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_wgrad<H / 16 + 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64 * (H / 16)), lds1, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_mlp_wgrad<1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64 * (H / 16)), lds2, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64), lds1, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
+        HIP_TRY(h, hipGetLastError());
+    } else {   // batches that are not a multiple of 64 columns: 16-sample chunks straight from global memory
+        hipLaunchKernelGGL((k_mlp_wgrad_small<H / 16 + 1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_mlp_wgrad_small<1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_mlp_wgrad_small<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
+        HIP_TRY(h, hipGetLastError());
+    }
     hipLaunchKernelGGL((k_mlp_wreduce<H>), dim3((Mlp<H>::NPAR + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, ks, (const double*)h->d_c1, (const double*)h->d_c2,
                        (const double*)h->d_c3, d_dp);
     HIP_TRY(h, hipGetLastError());

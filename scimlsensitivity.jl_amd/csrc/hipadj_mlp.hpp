@@ -44,7 +44,10 @@ struct MlpGeom {
 
 template <int H> struct Mlp {
     static constexpr int D = 2, TT = H / 16;       // row tiles
-    static constexpr int NW = TT >= 4 ? 4 : TT;    // waves per workgroup (row split)
+#ifndef HIPADJ_MLP_MAXW
+#define HIPADJ_MLP_MAXW 8     // 2 waves per SIMD: one wave's tanh (VALU) overlaps the other's MFMAs (measured 14.1 -> 11.8 ms)
+#endif
+    static constexpr int NW = TT >= HIPADJ_MLP_MAXW ? HIPADJ_MLP_MAXW : TT;    // waves per workgroup (row split)
     static constexpr int TW = TT / NW;             // row tiles per wave
     static constexpr int NT = 64 * NW;             // threads per workgroup
     static constexpr int NPAR = H * D + H + H * H + H + D * H + D;
@@ -62,7 +65,7 @@ template <int H> __device__ __forceinline__ MlpW<H> mlp_weights(const double* __
 }
 
 // LDS of one workgroup: the exchanged activation tile and the cross-wave reduction scratch
-template <int H> struct MlpLds { double act[H * 16]; double red[4][16][2]; };
+template <int H> struct MlpLds { double act[H * 16]; double red[Mlp<H>::NW][16][2]; };
 
 // acc[t] (+)= rows (16 (t0 + t) .. +15) of  Wm (H x H, column-major) . act   with act read from the LDS tile.
 // The TW A operands of a K-step (16 x 4 blocks of Wm, L2-resident) are fetched ONE K-step ahead; a scheduling fence per
@@ -336,11 +339,63 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const dou
 }
 
 // split-K NT-GEMM on the records:  Cpart[grp][ks][ra][rb] = sum_{s in K-slice ks} A[ra][s] Bm[rb][s]
-// A: [Q][RA][B], Bm: [Q][RB][B] (RA, RB multiples of 16); samples s = (q, column).  One wave per (A row tile, slice).
-// Within a 16-sample chunk lane (i, g) takes samples 4g..4g+3 (one 32-byte load) for the four K-steps kk = 0..3:
-// K-step kk then contracts samples {4g + kk}, the same assignment for A and B.
+// A: [Q][RA][B], Bm: [Q][RB][B] (RA, RB multiples of 16); samples s = (q, column).
+// One workgroup = RA/16 waves (one per 16-row tile of A) shares the B operand: every iteration the workgroup stages a
+// [RB][64-sample] slab of Bm in LDS with coalesced 16-byte loads (each Bm byte leaves HBM once instead of once per A
+// tile — that re-read was 8x the traffic and the whole cost of the first version), each wave reads its own A rows
+// from global memory and its B fragments from LDS with ds_read_b128 (row pitch 66 doubles: the 16 rows of a fragment
+// land on 16 distinct 16-byte slots).  Within a 16-sample chunk lane (i, g) takes samples 4g..4g+3 for the four
+// K-steps kk = 0..3: K-step kk contracts samples {4g + kk}, the same assignment for A and B.
+constexpr int WG_SAMPLES = 64, WG_PITCH = WG_SAMPLES + 2;
 template <int NTB>
-__global__ void __launch_bounds__(64) k_mlp_wgrad(const double* __restrict__ A, const double* __restrict__ Bm, int RA, int RB, long Qper, int B,
+__global__ void __launch_bounds__(512) k_mlp_wgrad(const double* __restrict__ A, const double* __restrict__ Bm, int RA, int RB, long Qper, int B,
+                                                   int ksplit, double* __restrict__ Cpart) {
+    extern __shared__ __attribute__((aligned(16))) double bt[];       // [RB][WG_PITCH]
+    const int ks = blockIdx.y; const long grp = blockIdx.z;
+    const int ti = threadIdx.x >> 6, li = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
+    const int nthreads = blockDim.x;
+    mlp_d4 acc[NTB];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) acc[t] = mlp_d4{0.0, 0.0, 0.0, 0.0};
+    const long slabs_per_q = B / WG_SAMPLES, nslabs = Qper * slabs_per_q;
+    const long c0 = nslabs * ks / ksplit, c1 = nslabs * (ks + 1) / ksplit;
+    for (long c = c0; c < c1; ++c) {
+        const long q = grp * Qper + c / slabs_per_q; const int s_base = (int)(c % slabs_per_q) * WG_SAMPLES;
+        // stage Bm[q][0..RB)[s_base .. s_base+64) : RB rows x 32 dbl2
+        for (int e = threadIdx.x; e < RB * (WG_SAMPLES / 2); e += nthreads) {
+            const int row = e / (WG_SAMPLES / 2), pr = e % (WG_SAMPLES / 2);
+            const dbl2 v = *reinterpret_cast<const dbl2*>(Bm + (q * RB + row) * (long)B + s_base + 2 * pr);
+            *reinterpret_cast<dbl2*>(bt + row * WG_PITCH + 2 * pr) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c4 = 0; c4 < WG_SAMPLES / 16; ++c4) {
+            const int s0 = 16 * c4 + 4 * lq;
+            const double* ap = A + (q * RA + 16 * ti + li) * (long)B + s_base + s0;
+            const dbl2 a01 = *reinterpret_cast<const dbl2*>(ap), a23 = *reinterpret_cast<const dbl2*>(ap + 2);
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) {
+                const double* bp = bt + (16 * t + li) * WG_PITCH + s0;
+                const dbl2 b01 = *reinterpret_cast<const dbl2*>(bp), b23 = *reinterpret_cast<const dbl2*>(bp + 2);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    double* cp = Cpart + ((grp * ksplit + ks) * (long)RA) * RB;
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cp[(long)(16 * ti + lq + 4 * r) * RB + 16 * t + li] = acc[t][r];
+    }
+}
+
+// fallback for batches that are not a multiple of 64 columns: one wave per (A row tile, K slice), 16-sample chunks
+template <int NTB>
+__global__ void __launch_bounds__(64) k_mlp_wgrad_small(const double* __restrict__ A, const double* __restrict__ Bm, int RA, int RB, long Qper, int B,
                                                   int ksplit, double* __restrict__ Cpart) {
     const int ti = blockIdx.x, ks = blockIdx.y; const long grp = blockIdx.z;
     const int li = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;

@@ -77,7 +77,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (P.mlp) {
         if (cfg->dims[0] != 2) { err = "MLP family: state width d must be 2 (docs/src/Benchmark.md:62 shape)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->dims[1] != 32 && cfg->dims[1] != 128) { err = "MLP family: hidden width must be 32 or 128"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->dims[2] % 16 != 0) { err = "MLP family: batch must be a multiple of 16 (one wave per 16 columns)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->dims[2] % 16 != 0) { err = "MLP family: batch must be a multiple of 16 (one workgroup per 16 columns)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg != HIPADJ_ALG_GAUSS && cfg->alg != HIPADJ_ALG_INTERPOLATING) { err = "MLP family offers GaussAdjoint and InterpolatingAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
         P.NQ = cfg->alg == HIPADJ_ALG_GAUSS ? 2 : 4;
     }

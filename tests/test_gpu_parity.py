@@ -338,7 +338,7 @@ def mlp_params(d, H, seed=1):
 
 
 @pytest.mark.parametrize("alg,oalg", [("gauss", "GAUSS"), ("interpolating", "INTERPOLATING")])
-@pytest.mark.parametrize("H,B,N,shared", [(32, 32, 1, True), (32, 48, 2, False), (128, 16, 1, True)])
+@pytest.mark.parametrize("H,B,N,shared", [(32, 32, 1, True), (32, 48, 2, False), (128, 16, 1, True), (32, 128, 2, False), (128, 64, 2, True)])
 def test_mlp_matches_oracle(sa, alg, oalg, H, B, N, shared):
     d, T, dt = 2, 0.3, 0.05
     dims = (d, H, B, 0)
