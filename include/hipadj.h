@@ -30,7 +30,8 @@ typedef enum {
     HIPADJ_ERR_HIP = -3,
     HIPADJ_ERR_NONFINITE = -4,    /* a trajectory produced NaN/Inf — the reference's retcode checks */
     HIPADJ_ERR_STATE = -5,        /* adjoint requested before forward */
-    HIPADJ_ERR_UNSUPPORTED = -6
+    HIPADJ_ERR_UNSUPPORTED = -6,
+    HIPADJ_ERR_MAXITERS = -7      /* adaptive solve ran out of steps (max_steps) — the reference's ReturnCode.MaxIters */
 } hipadj_status;
 
 /* compile-time model registry: device-inlined f, (df/du)^T lam, (df/dp)^T lam — the reference's user-VJP seam
@@ -54,7 +55,12 @@ typedef enum {
     HIPADJ_ALG_QUADRATURE = 3
 } hipadj_alg;
 
-typedef enum { HIPADJ_STEPPER_RK4_FIXED = 0 } hipadj_stepper;
+typedef enum {
+    HIPADJ_STEPPER_RK4_FIXED = 0,      /* fixed-step classic RK4, cubic-Hermite dense output; loss times on the step grid */
+    HIPADJ_STEPPER_TSIT5_ADAPTIVE = 1  /* adaptive Tsit5 with per-trajectory step control and its own interpolant (the stepper of
+                                          the reference's tests); arbitrary loss times; lane-per-trajectory models;
+                                          Interpolating / Backsolve / Gauss */
+} hipadj_stepper;
 
 /* how dgdu_discrete(out, u, p, t, i) is evaluated at loss time t_i (src/adjoint_common.jl:771-773) */
 typedef enum {
@@ -75,7 +81,8 @@ typedef struct {
     int32_t stepper;           /* hipadj_stepper */
     int32_t dims[4];           /* model shape parameters (MLP, BRUSS), else 0 */
     int64_t ntraj;             /* N trajectories in this handle's shard */
-    double t0, t1, dt;         /* tspan and fixed step; (t1 - t0)/dt must be an integer number of steps S */
+    double t0, t1, dt;         /* tspan; RK4: fixed step, (t1 - t0)/dt must be an integer number of steps S;
+                                  Tsit5: initial step (<= 0: automatic) */
     int32_t nsave;             /* M loss/save times */
     const double *save_times;  /* [M] ascending, each on the step grid t0 + k*dt (copied at create) */
     int32_t loss_kind;         /* hipadj_loss */
@@ -89,7 +96,8 @@ typedef struct {
     int32_t time_segments;     /* 0 = automatic; 1 = strictly sequential in time; C > 1 = C time segments per trajectory */
     int32_t cont_cost;         /* hipadj_cont_cost: continuous cost g(u,p,t) added to the loss as int g dt (accumulate_cost!,
                                   src/derivative_wrappers.jl:1411-1442; adjoint_sensitivities(...; g, dgdu_continuous)) */
-    int32_t reserved0;
+    int32_t max_steps;         /* Tsit5: capacity of the per-trajectory dense solution in accepted steps (0 => 2048) */
+    double abstol, reltol;     /* Tsit5: tolerances of the forward AND reverse solves (src/sensitivity_interface.jl:432 defaults 1e-6 / 1e-3) */
 } hipadj_config;
 
 typedef struct {

@@ -30,7 +30,8 @@ class HipadjConfig(C.Structure):
         ("checkpointing", C.c_int32), ("ckpt_stride", C.c_int32),
         ("quad_abstol", C.c_double), ("quad_reltol", C.c_double),
         ("no_start", C.c_int32), ("p_shared", C.c_int32), ("device", C.c_int32), ("time_segments", C.c_int32),
-        ("cont_cost", C.c_int32), ("reserved0", C.c_int32),
+        ("cont_cost", C.c_int32), ("max_steps", C.c_int32),
+        ("abstol", C.c_double), ("reltol", C.c_double),
     ]
 
 

@@ -1,0 +1,410 @@
+// hipadj_adaptive.hpp — adaptive Tsit5 (5(4) pair, PI step control, own 4th-order interpolant) for the
+// lane-per-trajectory family: per-lane step control, forward dense output in HBM, reverse adjoint sweeps that
+// interpolate the forward solution at arbitrary times.  This is the stepper every reference test uses
+// (`Tsit5()`, test/Core3/adjoint.jl:31-43, 1167; test/Core1/concrete_solve_derivatives.jl) and SURVEY.md §8f rank 1.
+//
+// What is restated (reference = SciMLSensitivity.jl; the stepper itself lives in OrdinaryDiffEq [upstream-recall]):
+//   forward dense solve, out = sol(ts) by interpolation            src/concrete_solve.jl:701-727
+//   Interpolating RHS with y = sol(t) at arbitrary t               src/interpolating_adjoint.jl:150-174, 190-204
+//   Backsolve RHS + checkpoint / loss callbacks at tstops          src/backsolve_adjoint.jl:32-61, 523-546; src/adjoint_common.jl:754-821
+//   Gauss: lambda-only RHS + IntegratingSumCallback with div(order+1, 2) = 3 Gauss-Legendre nodes per accepted step
+//                                                                  src/gauss_adjoint.jl:118-128, 745-759, 809-851
+//   reverse solve reuses alg and tolerances, tstops = loss times   src/sensitivity_interface.jl:484-491
+// The controller arithmetic follows oracle/adjoint_oracle.c `integrate` line by line (Hairer initial step, error norm
+// RMS of err/(abstol + max(|u0|,|u1|) reltol), PI exponents 7/50 and 2/25, gamma 0.9, q in [1/10, 5], tstop clipping
+// with a 100-eps snap), so that device and oracle take the same step sequences up to roundoff.
+//
+// Layout of the forward dense solution (per trajectory a ragged list of accepted steps, trajectory-minor):
+//   rec[(s * RW + w) * Npad + i],  RW = 2 + 8 n :  w = 0 t_start, 1 t_end, 2.. u_start[n], then k_1..k_7 [7][n]
+//   nsteps[i] accepted steps (<= Smax; overflow is reported as HIPADJ_ERR_NONFINITE-class failure through the flag)
+#pragma once
+
+#include "hipadj_lane.hpp"
+
+namespace hipadj {
+
+struct AdaptGeom {
+    long N, Npad;
+    int M, Smax, nck;
+    double t0, t1, dt0, abstol, reltol;
+    double loss_shift;
+    int loss_kind, no_start, p_shared, cont_cost;
+};
+
+// Tsit5 coefficients (Tsitouras 2011); same values as oracle/adjoint_oracle.c (order conditions checked there)
+struct TS5 {
+    static HIPADJ_HD double c(int i) { const double v[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0}; return v[i]; }
+    static HIPADJ_HD double a(int i, int j) {
+        const double v[7][6] = {
+            {0, 0, 0, 0, 0, 0},
+            {0.161, 0, 0, 0, 0, 0},
+            {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+            {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+            {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+            {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0},
+            {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+        return v[i][j];
+    }
+    static HIPADJ_HD double bt(int i) {
+        const double v[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+                             0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
+        return v[i];
+    }
+    static HIPADJ_HD void bweights(double th, double (&b)[7]) {
+        const double r[7][4] = {
+            {1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216},
+            {0.0, 0.13169999999999998, -0.2234, 0.1017},
+            {0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253},
+            {0.0, -12.411077166933676, 30.33818863028232, -16.548102889244902},
+            {0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928},
+            {0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661},
+            {0.0, 1.5, -4.0, 2.5}};
+        b[0] = th * (r[0][0] + th * (r[0][1] + th * (r[0][2] + th * r[0][3])));
+#pragma unroll
+        for (int i = 1; i < 7; ++i) b[i] = th * th * (r[i][1] + th * (r[i][2] + th * r[i][3]));
+    }
+};
+
+HIPADJ_HD double hmax2(double a, double b) { return a > b ? a : b; }
+HIPADJ_HD double hmin2(double a, double b) { return a < b ? a : b; }
+HIPADJ_HD double habs(double a) { return a < 0 ? -a : a; }
+HIPADJ_HD bool time_hits(double t, double target) { return habs(t - target) <= 100.0 * 2.220446049250313e-16 * hmax2(habs(t), habs(target)); }
+
+// continuous extension of one Tsit5 step: y = u0 + h sum_i b_i(theta) k_i
+template <int NZ>
+HIPADJ_HD void tsit5_interp(double th, double h, const double (&u0)[NZ], const double (&k)[7][NZ], double (&y)[NZ]) {
+    double b[7]; TS5::bweights(th, b);
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc += b[j] * k[j][i];
+        y[i] = u0[i] + h * acc;
+    }
+}
+
+// solve(prob, Tsit5(); abstol, reltol, dt, tstops, callback) for a small system held in registers.
+//   rhs(du, u, t); cb(t, tprev, u, uprev, k) is called after every accepted step (and once at the start when
+//   cb_at_init) and returns true when it modified u (=> the FSAL derivative is recomputed, derivative_discontinuity!).
+//   tstops: ntstops times sorted along the integration direction (entries not ahead of t are skipped).
+// Returns the number of accepted steps, or -1 when max_steps was exceeded.
+template <int NZ, class Rhs, class Cb>
+HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, double dt_hint, double abstol, double reltol,
+                              const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps, Rhs&& rhs, Cb&& cb) {
+    const double EPS = 2.220446049250313e-16;
+    const double tdir = tend >= tstart ? 1.0 : -1.0;
+    double t = tstart, tprev = tstart;
+    double uprev[NZ], k[7][NZ], fsal[NZ], tmp[NZ];
+    if (cb_at_init) {
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) uprev[i] = u[i];
+        cb(t, tprev, u, uprev, k);
+    }
+    rhs(fsal, u, t);
+    double dt;
+    if (dt_hint > 0) dt = tdir * dt_hint;
+    else {   // Hairer-Norsett-Wanner initial step
+        double d0 = 0, d1 = 0;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; d0 += (u[i] / sc) * (u[i] / sc); d1 += (fsal[i] / sc) * (fsal[i] / sc); }
+        d0 = sqrt(d0 / NZ); d1 = sqrt(d1 / NZ);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = hmin2(h0, habs(tend - t));
+        double u1[NZ], f1[NZ];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) u1[i] = u[i] + tdir * h0 * fsal[i];
+        rhs(f1, u1, t + tdir * h0);
+        double d2 = 0;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; const double q = (f1[i] - fsal[i]) / sc; d2 += q * q; }
+        d2 = sqrt(d2 / NZ) / h0;
+        const double h1 = (hmax2(d1, d2) <= 1e-15) ? hmax2(1e-6, h0 * 1e-3) : pow(0.01 / hmax2(d1, d2), 1.0 / 5.0);
+        dt = tdir * hmin2(hmin2(100.0 * h0, h1), habs(tend - t));
+    }
+    double qold = 1e-4;
+    int its = 0, naccept = 0, guard = 0;
+    while (tdir * t < tdir * tend) {
+        if (++guard > 16 * max_steps + 64) return -1;
+        // next stop: the first tstop strictly ahead of t (beyond the 100-eps snap), else tend
+        while (its < ntstops && tdir * tstops[its] <= tdir * t + 100.0 * EPS * hmax2(habs(t), habs(tstops[its]))) ++its;
+        double tstop = tend;
+        if (its < ntstops && tdir * tstops[its] < tdir * tend) tstop = tstops[its];
+        double h = dt;
+        if (habs(h) > habs(tstop - t)) h = tstop - t;
+        if (habs((t + h) - tstop) < 100.0 * EPS * hmax2(habs(t + h), habs(tstop))) h = tstop - t;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) { uprev[i] = u[i]; k[0][i] = fsal[i]; }
+#pragma unroll
+        for (int s = 1; s < 7; ++s) {
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < s; ++j) acc += TS5::a(s, j) * k[j][i];
+                tmp[i] = uprev[i] + h * acc;
+            }
+            if (s < 6) rhs(k[s], tmp, t + TS5::c(s) * h);
+            else {
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) u[i] = tmp[i];
+                rhs(k[6], u, t + h);
+            }
+        }
+        double e2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc += TS5::bt(j) * k[j][i];
+            const double sc = abstol + hmax2(habs(uprev[i]), habs(u[i])) * reltol;
+            const double q = h * acc / sc;
+            e2 += q * q;
+        }
+        const double EEst = sqrt(e2 / NZ);
+        const double q11 = pow(hmax2(EEst, 1e-300), 7.0 / 50.0);
+        double q = q11 / pow(qold, 2.0 / 25.0);
+        q = hmax2(1.0 / 10.0, hmin2(5.0, q / 0.9));
+        if (EEst <= 1.0 || habs(h) < 1e-14 * hmax2(1.0, habs(t))) {
+            double tnew = t + h;
+            if (habs(tnew - tstop) < 100.0 * EPS * hmax2(habs(tnew), habs(tstop))) tnew = tstop;
+            qold = hmax2(EEst, 1e-4);
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) fsal[i] = k[6][i];
+            tprev = t; t = tnew; ++naccept;
+            dt = h / q;
+            if (habs(dt) < 1e-14 * hmax2(1.0, habs(tnew))) dt = tdir * 1e-14 * hmax2(1.0, habs(tnew));
+            if (cb(t, tprev, u, uprev, k)) rhs(fsal, u, t);
+            if (naccept > max_steps) return -1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) u[i] = uprev[i];
+            dt = h / hmin2(5.0, q11 / 0.9);
+        }
+    }
+    return naccept;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward dense solve; also out = sol(ts) (outT [M][n][Npad]) and the checkpoint states sol(c_j) (ckpt [nck][n][Npad])
+template <class Mo>
+HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __restrict__ u0, const double* __restrict__ p,
+                                  double* __restrict__ rec, int* __restrict__ nsteps, const double* __restrict__ save_t,
+                                  double* __restrict__ outT, const double* __restrict__ ck_t, double* __restrict__ ckpt,
+                                  double* __restrict__ yT, int* __restrict__ flag) {
+    constexpr int N = Mo::N, RW = 2 + 8 * N;
+    double pv[Mo::NP];
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * Mo::NP + j];
+    double u[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] = u0[i * N + j];
+    int s = 0, ms = 0, mc = 0;
+    bool overflow = false;
+    // points that coincide with t0
+    while (outT && ms < g.M && save_t[ms] <= g.t0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) outT[((long)ms * N + j) * g.Npad + i] = u[j];
+        ++ms; }
+    while (ckpt && mc < g.nck && ck_t[mc] <= g.t0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = u[j];
+        ++mc; }
+    const int na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.Smax,
+        [&](double (&du)[N], const double (&uu)[N], double t) { Mo::f(du, uu, pv, t); },
+        [&](double t, double tprev, double (&un)[N], const double (&up)[N], const double (&k)[7][N]) -> bool {
+            if (s < g.Smax) {
+                if (rec) {
+                    rec[((long)s * RW + 0) * g.Npad + i] = tprev; rec[((long)s * RW + 1) * g.Npad + i] = t;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) rec[((long)s * RW + 2 + j) * g.Npad + i] = up[j];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) rec[((long)s * RW + 2 + N + q * N + j) * g.Npad + i] = k[q][j];
+                }
+            } else overflow = true;
+            ++s;
+            const double h = t - tprev;
+            while (outT && ms < g.M && (save_t[ms] <= t || time_hits(save_t[ms], t))) {
+                double y[N]; tsit5_interp<N>((save_t[ms] - tprev) / h, h, up, k, y);
+#pragma unroll
+                for (int j = 0; j < N; ++j) outT[((long)ms * N + j) * g.Npad + i] = y[j];
+                ++ms; }
+            while (ckpt && mc < g.nck && (ck_t[mc] <= t || time_hits(ck_t[mc], t))) {
+                double y[N]; tsit5_interp<N>((ck_t[mc] - tprev) / h, h, up, k, y);
+#pragma unroll
+                for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = y[j];
+                ++mc; }
+            (void)un;
+            return false;
+        });
+    nsteps[i] = s < g.Smax ? s : g.Smax;
+    if (yT) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) yT[(long)j * g.Npad + i] = u[j]; }
+    if (na < 0 || overflow) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(flag, 4);
+#else
+        *flag |= 4;
+#endif
+    }
+}
+
+// cursor into one trajectory's forward dense solution: the step containing t, cached in registers
+template <class Mo> struct FwdCursor {
+    static constexpr int N = Mo::N, RW = 2 + 8 * Mo::N;
+    const double* rec; long Npad, i; int ns, sc;
+    double ta, tb, u0[Mo::N], k[7][Mo::N];
+    HIPADJ_HD void load(int s) {
+        sc = s;
+        ta = rec[((long)s * RW + 0) * Npad + i]; tb = rec[((long)s * RW + 1) * Npad + i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) u0[j] = rec[((long)s * RW + 2 + j) * Npad + i];
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+#pragma unroll
+            for (int j = 0; j < N; ++j) k[q][j] = rec[((long)s * RW + 2 + N + q * N + j) * Npad + i];
+    }
+    HIPADJ_HD void init(const double* r, long np, long ii, int nsteps) { rec = r; Npad = np; i = ii; ns = nsteps; load(nsteps - 1); }
+    // y = sol(t): the reverse sweep moves mostly downward, so a linear cursor walk replaces the binary search
+    HIPADJ_HD void eval(double t, double (&y)[Mo::N]) {
+        while (t < ta && sc > 0) load(sc - 1);
+        while (t > tb && sc < ns - 1) load(sc + 1);
+        const double h = tb - ta;
+        tsit5_interp<N>((t - ta) / h, h, u0, k, y);
+    }
+};
+
+// reverse sweeps.  ALG: 0 Interpolating (z = [lam; mu]), 1 Backsolve (z = [lam; mu; y]), 2 Gauss (z = lam, mu by quadrature)
+template <class Mo, int ALG, int CC>
+HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __restrict__ p, const double* __restrict__ rec,
+                                  const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
+                                  const double* __restrict__ ck_t, const double* __restrict__ save_t, const double* __restrict__ tstops_desc,
+                                  int ntstops, const double* __restrict__ cotT, double (&lam_out)[Mo::N], double (&mu_out)[Mo::NP], int* __restrict__ flag) {
+    constexpr int N = Mo::N, NP = Mo::NP, NZ = ALG == 0 ? N + NP : (ALG == 1 ? 2 * N + NP : N);
+    double pv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
+    FwdCursor<Mo> cur;
+    if (ALG != 1) cur.init(rec, g.Npad, i, nsteps[i]);
+    double z[NZ];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) z[j] = 0.0;
+    if (ALG == 1) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) z[N + NP + j] = yT[(long)j * g.Npad + i]; }
+    double gacc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) gacc[j] = 0.0;
+    int cur_time = g.M, bs_cur = g.nck;
+    if (ALG == 1 && bs_cur >= 1 && time_hits(g.t1, ck_t[bs_cur - 1])) --bs_cur;
+
+    auto rhs = [&](double (&dz)[NZ], const double (&zz)[NZ], double t) {
+        double y[N], lam[N], dl[N], dg[NP];
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[j] = zz[j];
+        if (ALG == 1) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = zz[N + NP + j];
+        } else cur.eval(t, y);
+        Mo::vjp_u(dl, lam, y, pv, t);
+        double gu[N]; cost_grad_u<Mo, CC>(y, gu);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dz[j] = -dl[j] - gu[j];
+        if (ALG != 2) {
+            Mo::vjp_p(dg, lam, y, pv, t);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dz[N + j] = -dg[j];
+        }
+        if (ALG == 1) {
+            double f[N]; Mo::f(f, y, pv, t);
+#pragma unroll
+            for (int j = 0; j < N; ++j) dz[N + NP + j] = f[j];
+        }
+    };
+    auto cb = [&](double t, double tprev, double (&zz)[NZ], const double (&zp)[NZ], const double (&k)[7][NZ]) -> bool {
+        bool mod = false;
+        if (ALG == 2 && t != tprev) {   // IntegratingSumCallback: 3-point Gauss-Legendre of -(df/dp)^T lam on [tprev, t]
+            const double xg[3] = {-0.7745966692414833770, 0.0, 0.7745966692414833770}, wg[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
+            const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double tt = half * xg[q] + mid;
+                double lg[NZ], y[N], W[NP], lamq[N];
+                tsit5_interp<NZ>((tt - tprev) / h, h, zp, k, lg);
+#pragma unroll
+                for (int j = 0; j < N; ++j) lamq[j] = lg[j];
+                cur.eval(tt, y);
+                Mo::vjp_p(W, lamq, y, pv, tt);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) gacc[j] += half * wg[q] * (-W[j]);
+            }
+        }
+        if (ALG == 1 && ckpt && bs_cur >= 1 && time_hits(t, ck_t[bs_cur - 1])) {   // backsolve_checkpoint_callbacks
+#pragma unroll
+            for (int j = 0; j < N; ++j) zz[N + NP + j] = ckpt[((long)(bs_cur - 1) * N + j) * g.Npad + i];
+            --bs_cur; mod = true;
+        }
+        if (cur_time >= 1 && time_hits(t, save_t[cur_time - 1])) {                   // ReverseLossCallback
+            if (!(g.no_start && ALG != 1 && cur_time == 1)) {
+                double y[N];
+                if (ALG == 1) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) y[j] = zz[N + NP + j];
+                } else cur.eval(t, y);
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    zz[j] += (g.loss_kind == 0) ? cotT[((long)(cur_time - 1) * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+                mod = true;
+            } else mod = false;
+            --cur_time;
+        }
+        return mod;
+    };
+    const bool cb_at_init = g.M > 0 && time_hits(g.t1, save_t[g.M - 1]);
+    const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.Smax, rhs, cb);
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam_out[j] = z[j];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu_out[j] = ALG == 2 ? gacc[j] : z[N + j];
+    if (na < 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(flag, 4);
+#else
+        *flag |= 4;
+#endif
+    }
+}
+
+#if defined(__HIPCC__)
+// one lane = one trajectory; lanes of a wave take their own step sequences (accept/reject and the cursor walks
+// diverge under the exec mask), a wave retires when its slowest trajectory does
+template <class Mo>
+__global__ void __launch_bounds__(64) k_forward_tsit5(AdaptGeom g, const double* __restrict__ u0, const double* __restrict__ p,
+                                                      double* __restrict__ rec, int* __restrict__ nsteps, const double* __restrict__ save_t,
+                                                      double* __restrict__ outT, const double* __restrict__ ck_t, double* __restrict__ ckpt,
+                                                      double* __restrict__ yT, int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    if (i >= g.N) return;
+    forward_tsit5_lane<Mo>(g, i, u0, p, rec, nsteps, save_t, outT, ck_t, ckpt, yT, flag);
+}
+
+template <class Mo, int ALG, int CC>
+__global__ void __launch_bounds__(64) k_adjoint_tsit5(AdaptGeom g, const double* __restrict__ p, const double* __restrict__ rec,
+                                                      const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
+                                                      const double* __restrict__ ck_t, const double* __restrict__ save_t,
+                                                      const double* __restrict__ tstops_desc, int ntstops, const double* __restrict__ cotT,
+                                                      double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    if (i >= g.N) return;
+    double lam[Mo::N], mu[Mo::NP];
+    adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec, nsteps, yT, ckpt, ck_t, save_t, tstops_desc, ntstops, cotT, lam, mu, flag);
+#pragma unroll
+    for (int j = 0; j < Mo::N; ++j) du0[i * Mo::N + j] = lam[j];
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
+}
+#endif
+
+}  // namespace hipadj

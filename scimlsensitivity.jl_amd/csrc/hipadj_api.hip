@@ -14,6 +14,7 @@
 #include "hipadj_kernels.hpp"
 #include "hipadj_field.hpp"
 #include "hipadj_mlp.hpp"
+#include "hipadj_adaptive.hpp"
 #include "hipadj_plan.hpp"
 
 using namespace hipadj;
@@ -46,6 +47,10 @@ struct hipadj_handle {
     double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
     MlpGeom mg{};
     FieldGeom fg{};
+    bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
+    AdaptGeom ag{};
+    double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr;
+    int *d_nsteps = nullptr, ntstops = 0;
     unsigned* d_ticket = nullptr;
     int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
@@ -69,6 +74,7 @@ extern "C" const char* hipadj_status_string(int s) {
     case HIPADJ_ERR_HIP: return "HIP runtime error";
     case HIPADJ_ERR_NONFINITE: return "non-finite value in a trajectory's sensitivities";
     case HIPADJ_ERR_STATE: return "invalid call order (forward solve required first)";
+    case HIPADJ_ERR_MAXITERS: return "adaptive solve exceeded max_steps";
     case HIPADJ_ERR_UNSUPPORTED: return "unsupported configuration";
     default: return "unknown status";
     }
@@ -96,7 +102,7 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
@@ -133,7 +139,30 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_u0, (size_t)h->N * n));
     A(dev_alloc(h, &h->d_p, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
     h->field = P.field;
-    if (!P.field && !P.mlp) {
+    h->adaptive = P.adaptive;
+    if (P.adaptive) {
+        const int RW = 2 + 8 * n;
+        A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
+        A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
+        if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)P.Smax * RW * Np));
+        A(dev_alloc(h, &h->d_nsteps, (size_t)Np));
+        if (P.nck > 0) { A(dev_alloc(h, &h->d_ckpt, (size_t)P.nck * n * Np)); A(dev_alloc(h, &h->d_ck_t, (size_t)P.nck)); }
+        if (h->M > 0) A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
+        h->ntstops = (int)P.tstops_desc.size();
+        if (h->ntstops > 0) A(dev_alloc(h, &h->d_tstops, (size_t)h->ntstops));
+        if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
+        if (rc == HIPADJ_OK) {
+            bool ok2 = true;
+            if (h->M > 0) ok2 = ok2 && HT(hipMemcpy(h->d_save_t, P.save_times.data(), sizeof(double) * h->M, hipMemcpyHostToDevice), "memcpy");
+            if (P.nck > 0) ok2 = ok2 && HT(hipMemcpy(h->d_ck_t, P.ck_times.data(), sizeof(double) * P.nck, hipMemcpyHostToDevice), "memcpy");
+            if (h->ntstops > 0) ok2 = ok2 && HT(hipMemcpy(h->d_tstops, P.tstops_desc.data(), sizeof(double) * h->ntstops, hipMemcpyHostToDevice), "memcpy");
+            if (!ok2) rc = HIPADJ_ERR_HIP;
+        }
+        AdaptGeom& ag = h->ag;
+        ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = P.Smax; ag.nck = P.nck; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
+        ag.abstol = cfg->abstol; ag.reltol = cfg->reltol; ag.loss_shift = cfg->loss_shift; ag.loss_kind = cfg->loss_kind;
+        ag.no_start = cfg->no_start; ag.p_shared = cfg->p_shared; ag.cont_cost = cfg->cont_cost;
+    } else if (!P.field && !P.mlp) {
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
         if (cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));
@@ -205,7 +234,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->st.time_segments = h->nseg; h->st.workspace_bytes = h->ws_bytes;
     // ALGORITHMIC bytes of one reverse pass: knots (u,f) once, cotangents (if read), du0 + dp out
     double bytes = 0.0;
-    if (cfg->alg == HIPADJ_ALG_BACKSOLVE || P.ip_ckpt) bytes = (double)h->N * ((double)h->nck * 8.0 * n + 8.0 * n);
+    if (P.adaptive) bytes = 0.0;   // data-dependent (accepted steps per trajectory): not modelled
+    else if (cfg->alg == HIPADJ_ALG_BACKSOLVE || P.ip_ckpt) bytes = (double)h->N * ((double)h->nck * 8.0 * n + 8.0 * n);
     else bytes = (double)h->N * (double)(S + 1) * 16.0 * n;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) bytes += (double)h->N * (double)S * 2.0 * 32.0 * n;   // dense lambda write + read
     if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) bytes += (double)h->N * h->M * 8.0 * n;
@@ -265,6 +295,7 @@ extern "C" int hipadj_synchronize(hipadj_handle* h) {
     HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
         HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
+        if (flag & 4) HIPADJ_FAIL(h, HIPADJ_ERR_MAXITERS, "adaptive Tsit5 exceeded max_steps = %d accepted steps on at least one trajectory (raise max_steps or loosen tolerances)", h->ag.Smax);
         HIPADJ_FAIL(h, HIPADJ_ERR_NONFINITE, "non-finite sensitivities (flag %d): a trajectory diverged", flag);
     }
     return HIPADJ_OK;
@@ -529,14 +560,61 @@ template <int H> static int mlp_adjoint_launch(hipadj_handle* h, const double* d
     case HIPADJ_MODEL_FALLMASS: return fn<ModelFallMass>(__VA_ARGS__);                     \
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "model %d has no device kernels", (h)->cfg.model); }
 
+// ---- adaptive Tsit5 (hipadj_adaptive.hpp) ------------------------------------------------------------------
+template <class Mo> static int adaptive_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->d_rec, h->d_nsteps,
+                       (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
+    HIP_TRY(h, hipGetLastError());
+    if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
+    return HIPADJ_OK;
+}
+template <class Mo, int ALG, int CC> static int adaptive_adjoint_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
+    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
+                       (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
+                       (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+    hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
+                       (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, (double*)nullptr);
+    HIP_TRY(h, hipGetLastError());
+    if (h->cfg.p_shared) {
+        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = h->timing >= 1; es.full = h->timing >= 2;
+    return HIPADJ_OK;
+}
+template <class Mo> static int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    const bool cc = h->cfg.cont_cost == HIPADJ_CCOST_HALF_SQ_SUM;
+    switch (h->cfg.alg) {
+    case HIPADJ_ALG_INTERPOLATING: return cc ? adaptive_adjoint_l<Mo, 0, 1>(h, d_cot, d_du0, d_dp) : adaptive_adjoint_l<Mo, 0, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_BACKSOLVE: return cc ? adaptive_adjoint_l<Mo, 1, 1>(h, d_cot, d_du0, d_dp) : adaptive_adjoint_l<Mo, 1, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS: return cc ? adaptive_adjoint_l<Mo, 2, 1>(h, d_cot, d_du0, d_dp) : adaptive_adjoint_l<Mo, 2, 0>(h, d_cot, d_du0, d_dp);
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d has no adaptive device kernel", h->cfg.alg);
+    }
+}
+
 static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (h->field) { DISPATCH_GRID(h, field_forward, h, d_u0, d_p, d_out); }
     if (h->mlp) { DISPATCH_HIDDEN(h, mlp_forward_launch, h, d_u0, d_p, d_out); }
+    if (h->adaptive) { DISPATCH_MODEL(h, adaptive_forward, h, d_u0, d_p, d_out); }
     DISPATCH_MODEL(h, forward_impl, h, d_u0, d_p, d_out);
 }
 static int adjoint_dispatch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     if (h->field) { DISPATCH_GRID(h, field_adjoint, h, d_cot, d_du0, d_dp); }
     if (h->mlp) { DISPATCH_HIDDEN(h, mlp_adjoint_launch, h, d_cot, d_du0, d_dp); }
+    if (h->adaptive) { DISPATCH_MODEL(h, adaptive_adjoint, h, d_cot, d_du0, d_dp); }
     DISPATCH_MODEL(h, adjoint_impl, h, d_cot, d_du0, d_dp);
 }
 

@@ -30,6 +30,9 @@ struct Plan {
     std::vector<int> prev_ck; // largest checkpoint knot < k
     bool field = false;      // workgroup-per-trajectory family (hipadj_field.hpp)
     bool mlp = false;        // FP64-MFMA family (hipadj_mlp.hpp)
+    bool adaptive = false;   // adaptive Tsit5 (hipadj_adaptive.hpp)
+    int Smax = 0;            // capacity of the per-trajectory dense solution (adaptive)
+    std::vector<double> ck_times, tstops_desc;   // adaptive: checkpoint times (ascending), reverse tstops (descending)
     int NQ = 0;              // activation records per step (MLP)
 };
 
@@ -86,7 +89,42 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "BacksolveAdjoint is not offered for the PDE family: backward diffusion is ill-posed (src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_QUADRATURE) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
-    if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED) { err = "only fixed-step RK4 runs on the device (adaptive Tsit5 is CPU plumbing in BASELINE config 1)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {
+        // adaptive path: no step grid; arbitrary ascending loss times inside [t0, t1]
+        if (!plan_small_model(cfg->model)) { err = "adaptive Tsit5 is available for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg == HIPADJ_ALG_QUADRATURE) { err = "QuadratureAdjoint with adaptive Tsit5 is not available on the device yet"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg != HIPADJ_ALG_BACKSOLVE && cfg->checkpointing) { err = "checkpointing=true with adaptive Tsit5: Backsolve only (Interpolating/Gauss keep the dense solution)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->ntraj <= 0) { err = "ntraj must be positive"; return HIPADJ_ERR_INVALID_ARG; }
+        if (!(cfg->t1 > cfg->t0)) { err = "need t1 > t0"; return HIPADJ_ERR_INVALID_ARG; }
+        if (!(cfg->abstol > 0) || !(cfg->reltol > 0)) { err = "adaptive Tsit5 needs abstol > 0 and reltol > 0"; return HIPADJ_ERR_INVALID_ARG; }
+        if (cfg->nsave < 0 || (cfg->nsave > 0 && !cfg->save_times)) { err = "save_times missing"; return HIPADJ_ERR_INVALID_ARG; }
+        if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
+        if (cfg->cont_cost != HIPADJ_CCOST_NONE && cfg->cont_cost != HIPADJ_CCOST_HALF_SQ_SUM) { err = "unknown cont_cost"; return HIPADJ_ERR_INVALID_ARG; }
+        if (cfg->max_steps < 0) { err = "max_steps must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
+        P.adaptive = true; P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = 0; P.M = cfg->nsave;
+        P.Smax = cfg->max_steps > 0 ? cfg->max_steps : 2048;
+        P.save_times.assign(cfg->save_times, cfg->save_times + cfg->nsave);
+        for (int i = 0; i < cfg->nsave; ++i) {
+            if (!(cfg->save_times[i] >= cfg->t0 && cfg->save_times[i] <= cfg->t1)) { err = "save_times must lie inside [t0, t1]"; return HIPADJ_ERR_INVALID_ARG; }
+            if (i > 0 && !(cfg->save_times[i] > cfg->save_times[i - 1])) { err = "save_times must be strictly ascending (duplicate event times are out of scope)"; return HIPADJ_ERR_INVALID_ARG; }
+        }
+        P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
+        P.ck_times.clear();
+        if (P.bs_ckpt) {   // default checkpoints = sol.t of the saveat solve: t0, save times, t1 (src/backsolve_adjoint.jl:132)
+            if (P.save_times.empty() || P.save_times.front() > cfg->t0) P.ck_times.push_back(cfg->t0);
+            for (double t : P.save_times) P.ck_times.push_back(t);
+            if (P.ck_times.back() < cfg->t1) P.ck_times.push_back(cfg->t1);
+        }
+        P.nck = (int)P.ck_times.size();
+        // reverse tstops: loss times (PresetTimeCallback) + checkpoint times, descending
+        std::vector<double> ts(P.save_times); ts.insert(ts.end(), P.ck_times.begin(), P.ck_times.end());
+        for (size_t a = 1; a < ts.size(); ++a) { const double v = ts[a]; size_t b = a; while (b > 0 && ts[b - 1] < v) { ts[b] = ts[b - 1]; --b; } ts[b] = v; }
+        P.tstops_desc = ts;
+        P.nseg = 1; P.seg_bounds.assign(2, 0); P.nq = 0;
+        P.save_of_knot.assign(1, -1); P.ckpt_of_knot.assign(1, -1); P.prev_ck.assign(1, 0);
+        return HIPADJ_OK;
+    }
     if (cfg->ntraj <= 0) { err = "ntraj must be positive"; return HIPADJ_ERR_INVALID_ARG; }
     if (!(cfg->dt > 0) || !(cfg->t1 > cfg->t0)) { err = "need dt > 0 and t1 > t0"; return HIPADJ_ERR_INVALID_ARG; }
     const double sreal = (cfg->t1 - cfg->t0) / cfg->dt; const long S = std::lround(sreal);

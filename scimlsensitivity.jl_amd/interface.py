@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's entry points for the adjoint hot path.
 
-    solve(ensprob, RK4(); dt, saveat, sensealg, ...)             forward solve that keeps what the reverse pass needs
+    solve(ensprob, RK4() | Tsit5(); dt, saveat, sensealg, ...)   forward solve that keeps what the reverse pass needs
                                                                  (src/concrete_solve.jl:689-707)
     adjoint_sensitivities(sol, alg; t, dgdu_discrete, sensealg)  -> (du0, dp)   (src/sensitivity_interface.jl:373-526)
     concrete_solve_adjoint(prob, alg, sensealg, u0, p; ...)      -> (out, pullback)  (src/concrete_solve.jl:523-1042)
@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Engine
-from .problems import RK4, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum
+from .problems import RK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum
 from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
                                      QuadratureAdjoint, GaussAdjoint, ischeckpointing)
 
@@ -27,10 +27,14 @@ def _save_times(tspan, saveat, dt):
     return np.ascontiguousarray(np.asarray(saveat, dtype=np.float64))
 
 
-def _engine_kwargs(sensealg, checkpoints, dt, t0):
+def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
     kw = {}
     if isinstance(sensealg, (BacksolveAdjoint, InterpolatingAdjoint, GaussAdjoint)):
         kw["checkpointing"] = sensealg.checkpointing
+        if adaptive:
+            if checkpoints is not None:
+                raise ValueError("Tsit5(): checkpoints default to the save times (sol.t of the saveat solve); custom lists are not wired")
+            return kw
         if checkpoints is not None and sensealg.checkpointing:
             # `checkpoints` of adjoint_sensitivities (default sol.t): must be equally spaced on the step grid here
             ck = np.asarray(checkpoints, dtype=np.float64)
@@ -44,14 +48,22 @@ def _engine_kwargs(sensealg, checkpoints, dt, t0):
     return kw
 
 
-def solve(ensprob, alg=RK4(), *, dt, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
-          device=0, time_segments=0, no_start=False, want_out=True, g=None):
+def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
+          device=0, time_segments=0, no_start=False, want_out=True, g=None, abstol=1e-6, reltol=1e-3, max_steps=0):
     """Forward solve of an EnsembleProblem on the device.  The returned solution owns the device-resident
     interpolant tiles (Interpolating/Gauss/Quadrature) or checkpoints (Backsolve) the reverse pass consumes.
     `dgdu_discrete` may be given here already (LsqShift or None = cotangents) because the fused reverse kernel
-    is specialised on it at handle creation; likewise the continuous cost `g` (HalfSquaredSum() or None)."""
-    if not isinstance(alg, RK4):
-        raise ValueError("only fixed-step RK4() runs on the device (adaptive Tsit5 is CPU plumbing, BASELINE config 1)")
+    is specialised on it at handle creation; likewise the continuous cost `g` (HalfSquaredSum() or None).
+    alg = RK4(): fixed step `dt` (required).  alg = Tsit5(): adaptive, `abstol`/`reltol` are used for the forward AND
+    the reverse solve (src/sensitivity_interface.jl:432), `dt` is the optional initial-step hint, `saveat` may hold
+    arbitrary ascending times, `max_steps` bounds the accepted steps per trajectory (default 2048)."""
+    adaptive = isinstance(alg, Tsit5)
+    if not adaptive and not isinstance(alg, RK4):
+        raise ValueError("alg must be RK4() (fixed step) or Tsit5() (adaptive)")
+    if not adaptive and dt is None:
+        raise ValueError("RK4() needs dt")
+    if dt is None:
+        dt = 0.0
     if not isinstance(sensealg, AbstractAdjointSensitivityAlgorithm):
         raise TypeError("sensealg must be one of InterpolatingAdjoint/BacksolveAdjoint/GaussAdjoint/QuadratureAdjoint")
     if isinstance(ensprob, ODEProblem):
@@ -64,7 +76,8 @@ def solve(ensprob, alg=RK4(), *, dt, saveat=None, sensealg=InterpolatingAdjoint(
     eng = Engine(prob.f, sensealg.name, ensprob.u0.shape[0], prob.tspan[0], prob.tspan[1], dt, save_times=ts,
                  loss_kind=loss_kind, loss_shift=shift, p_shared=(ensprob.p.ndim == 1), device=device,
                  time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_lib.CCOST_HALF_SQ_SUM if g is not None else 0),
-                 **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0]))
+                 stepper=(1 if adaptive else 0), abstol=abstol, reltol=reltol, max_steps=max_steps,
+                 **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive))
     out = eng.forward(ensprob.u0, ensprob.p, want_out=want_out)
     return EnsembleSolution(engine=eng, u=out, t=ts, prob=ensprob, alg=alg, dt=dt,
                             extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g))
@@ -98,7 +111,7 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, senseal
     return eng.adjoint(np.asarray(dgdu_discrete, dtype=np.float64))
 
 
-def concrete_solve_adjoint(prob, alg, sensealg, u0, p, *, dt, saveat, **kw):
+def concrete_solve_adjoint(prob, alg, sensealg, u0, p, *, dt=None, saveat, **kw):
     """(out, pullback) — the contract of SciMLBase._concrete_solve_adjoint (src/concrete_solve.jl:523-1042):
     `out` = sol(ts) [N][M][n]; pullback(Delta) -> (du0, dp) runs the reverse pass with Delta as dgdu_discrete."""
     ens = EnsembleProblem(ODEProblem(prob.f, prob.u0, prob.tspan, np.asarray(p if np.ndim(p) == 1 else prob.p), prob.dims),

@@ -10,6 +10,12 @@ class RK4:
     """Fixed-step classic Runge-Kutta 4 (the `alg` handed to solve / adjoint_sensitivities)."""
 
 
+@dataclass(frozen=True)
+class Tsit5:
+    """Adaptive Tsitouras 5(4) with PI step control and its own 4th-order interpolant — the stepper of the
+    reference's own tests (test/Core3/adjoint.jl:31-43).  Per-trajectory step sequences on the device."""
+
+
 @dataclass
 class ODEProblem:
     """ODEProblem(f, u0, tspan, p) with `f` a name from the device model registry (include/hipadj.h)."""

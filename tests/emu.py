@@ -15,7 +15,7 @@ _CSRC = os.path.join(_ROOT, "scimlsensitivity.jl_amd", "csrc")
 
 
 def build(force=False):
-    deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("hipadj_lane.hpp", "hipadj_models.hpp", "hipadj_plan.hpp")]
+    deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("hipadj_lane.hpp", "hipadj_models.hpp", "hipadj_plan.hpp", "hipadj_adaptive.hpp")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _LIB, _SRC])
     return _LIB
@@ -35,12 +35,13 @@ def lib():
 
 
 def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shift=0.0, checkpointing=False,
-                ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, p_shared=True, time_segments=1, cont_cost=0):
+                ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, p_shared=True, time_segments=1, cont_cost=0,
+                stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0):
     from scimlsensitivity_jl_amd import _lib as PL
     save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
     c = PL.HipadjConfig()
     c.struct_size = C.sizeof(PL.HipadjConfig)
-    c.model, c.alg, c.stepper = PL.MODEL[model], PL.ALG[alg], 0
+    c.model, c.alg, c.stepper = PL.MODEL[model], PL.ALG[alg], stepper
     c.ntraj = ntraj
     c.t0, c.t1, c.dt = t0, t1, dt
     c.nsave = len(save)
@@ -50,6 +51,7 @@ def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shi
     c.quad_abstol, c.quad_reltol = quad_abstol, quad_reltol
     c.no_start, c.p_shared, c.device, c.time_segments = int(no_start), int(p_shared), 0, time_segments
     c.cont_cost = cont_cost
+    c.max_steps, c.abstol, c.reltol = max_steps, abstol, reltol
     c._keep = save
     return c
 

@@ -12,6 +12,7 @@
 #include <cmath>
 #include "../../scimlsensitivity.jl_amd/csrc/hipadj_lane.hpp"
 #include "../../scimlsensitivity.jl_amd/csrc/hipadj_plan.hpp"
+#include "../../scimlsensitivity.jl_amd/csrc/hipadj_adaptive.hpp"
 
 using namespace hipadj;
 
@@ -143,8 +144,53 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     return HIPADJ_OK;
 }
 
+// adaptive Tsit5: loops the lane bodies of hipadj_adaptive.hpp exactly as k_forward_tsit5 / k_adjoint_tsit5 + k_finish do
+template <class Mo, int ALG, int CC>
+static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
+                        double* du0, double* dp, double* out, int* nsteps_out) {
+    constexpr int N = Mo::N, NP = Mo::NP, RW = 2 + 8 * N;
+    AdaptGeom g; g.N = P.N; g.Npad = P.Npad; g.M = P.M; g.Smax = P.Smax; g.nck = P.nck; g.t0 = cfg->t0; g.t1 = cfg->t1; g.dt0 = cfg->dt;
+    g.abstol = cfg->abstol; g.reltol = cfg->reltol; g.loss_shift = cfg->loss_shift; g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start;
+    g.p_shared = cfg->p_shared; g.cont_cost = cfg->cont_cost;
+    const long Np = P.Npad;
+    std::vector<double> rec(ALG != 1 ? (size_t)P.Smax * RW * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np), ckpt((size_t)P.nck * N * Np);
+    std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
+    std::vector<int> nsteps((size_t)Np, 0);
+    int flag = 0;
+    for (long i = 0; i < P.N; ++i)
+        forward_tsit5_lane<Mo>(g, i, u0, p, rec.empty() ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(),
+                               P.ck_times.data(), ckpt.empty() ? nullptr : ckpt.data(), yT.data(), &flag);
+    if (nsteps_out) for (long i = 0; i < P.N; ++i) nsteps_out[i] = nsteps[i];
+    if (flag & 4) return HIPADJ_ERR_MAXITERS;
+    if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
+    if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
+    for (long i = 0; i < P.N; ++i) {
+        double lam[N], mu[NP];
+        adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec.data(), nsteps.data(), yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ck_times.data(),
+                                        P.save_times.data(), P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), lam, mu, &flag);
+        for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+        for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
+    }
+    if (flag & 4) return HIPADJ_ERR_MAXITERS;
+    if (cfg->p_shared) { for (int j = 0; j < NP; ++j) { double s = 0; for (long i = 0; i < P.N; ++i) s += dp_traj[(size_t)j * Np + i]; dp[j] = s; } }
+    else for (long i = 0; i < P.N; ++i) for (int j = 0; j < NP; ++j) dp[i * NP + j] = dp_traj[(size_t)j * Np + i];
+    return HIPADJ_OK;
+}
+
+template <class Mo>
+static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* ns) {
+    const bool cc = cfg->cont_cost == HIPADJ_CCOST_HALF_SQ_SUM;
+    switch (cfg->alg) {
+    case HIPADJ_ALG_INTERPOLATING: return cc ? run_adaptive<Mo, 0, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns) : run_adaptive<Mo, 0, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_BACKSOLVE: return cc ? run_adaptive<Mo, 1, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns) : run_adaptive<Mo, 1, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_GAUSS: return cc ? run_adaptive<Mo, 2, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns) : run_adaptive<Mo, 2, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    default: return HIPADJ_ERR_UNSUPPORTED;
+    }
+}
+
 template <class Mo>
 static int dispatch_mode(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out) {
+    if (P.adaptive) return dispatch_adaptive<Mo>(cfg, P, u0, p, dLdu, du0, dp, out, nullptr);
     const int mode = ((cfg->loss_kind == HIPADJ_LOSS_COTANGENT && P.M > 0) ? 0 : 1) | (cfg->cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
     switch (mode) {
     case 0: return run<Mo, 0>(cfg, P, u0, p, dLdu, du0, dp, out);

@@ -175,3 +175,68 @@ def test_no_loss_times_with_cotangent_loss_kind_is_safe():
                         checkpointing=(alg == "backsolve"), checkpoints=np.arange(0, 101, 10) * 0.01)
         rdu0, rdp, _ = ref.adjoint(u0[0], p, None)
         assert rel(du0[0], rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+# ---- adaptive Tsit5 (hipadj_adaptive.hpp): the stepper of the reference's own tests ---------------------------------
+TS_ALGS = ["interpolating", "backsolve", "gauss"]
+
+
+@pytest.mark.parametrize("alg", TS_ALGS)
+@pytest.mark.parametrize("model,omodel,u0c,p", MODELS)
+def test_tsit5_lane_bodies_match_oracle(alg, model, omodel, u0c, p):
+    """Same controller arithmetic as the oracle => identical step sequences on the host build (no FMA contraction)."""
+    rng = np.random.default_rng(14)
+    N, T = 4, 2.0
+    n, npar = len(u0c), len(p)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.03 * rng.standard_normal((N, npar)))
+    ts = np.array([0.0, 0.13, 0.5, 0.77, 1.0, 1.9, 2.0])          # off any grid
+    delta = rng.standard_normal((N, len(ts), n))
+    ck = alg == "backsolve"
+    cfg = E.make_config(model, alg, N, 0.0, T, 0.0, ts, loss_kind=0, checkpointing=ck, p_shared=False, stepper=1, abstol=1e-8, reltol=1e-7)
+    du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+    ref = O.Problem(omodel, alg=alg.upper(), stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-7, save_times=ts,
+                    loss="COTANGENT", checkpointing=ck)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+@pytest.mark.parametrize("alg", TS_ALGS)
+def test_tsit5_reference_test_setup_lvt_matches_golden(alg):
+    """test/Core3/adjoint.jl:31-51, 366-404: LV `fb`, Tsit5 abstol=reltol=1e-14 (1e-12 here), loss at 0:0.5:10, dg = u - 2,
+    against the scipy DOP853 forward-sensitivity gradient in tests/golden/gradients.json."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gradients.json")))["lvt"]
+    ts = np.asarray(gold["ts"])
+    cfg = E.make_config("lvt", alg, 1, gold["tspan"][0], gold["tspan"][1], 0.0, ts, loss_kind=1, loss_shift=2.0,
+                        checkpointing=(alg == "backsolve"), stepper=1, abstol=1e-12, reltol=1e-12, max_steps=20000)
+    du0, dp, _ = E.forward_adjoint(cfg, 2, 4, np.asarray([gold["u0"]]), np.asarray(gold["p"]))
+    tol = 1e-6 if alg != "backsolve" else 1e-5
+    assert rel(du0[0], np.asarray(gold["du0"])) < tol and rel(dp, np.asarray(gold["dp"])) < tol
+
+
+def test_tsit5_no_start_initial_dt_hint_and_continuous_cost():
+    u0 = np.array([[1.0, 1.0]]); p = np.array([1.5, 1.0, 3.0, 1.0]); ts = [0.0, 0.4, 1.0]
+    for kw, okw in [(dict(no_start=True), dict(no_start=True)), (dict(cont_cost=1), dict(cont_cost=1))]:
+        for alg in TS_ALGS:
+            if alg == "backsolve" and "no_start" in kw:
+                continue
+            cfg = E.make_config("lv", alg, 1, 0.0, 1.0, 0.05, ts, loss_kind=1, loss_shift=2.0, stepper=1, abstol=1e-9, reltol=1e-9, **kw)
+            du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
+            ref = O.Problem("LV", alg=alg.upper(), stepper="TSIT5", t0=0, t1=1.0, dt=0.05, abstol=1e-9, reltol=1e-9, save_times=ts,
+                            loss="LSQ_SHIFT", loss_shift=2.0, **okw)
+            rdu0, rdp, _ = ref.adjoint(u0[0], p)
+            assert rel(du0[0], rdu0) < 1e-11 and rel(dp, rdp) < 1e-11, (kw, alg)
+
+
+def test_tsit5_max_steps_overflow_is_an_error_and_plan_rejections():
+    u0 = np.array([[1.0, 0.0, 0.0]]); p = np.array([10.0, 28.0, 8 / 3])
+    cfg = E.make_config("lorenz", "interpolating", 1, 0.0, 10.0, 0.0, [10.0], loss_kind=1, stepper=1, abstol=1e-10, reltol=1e-10, max_steps=50)
+    with pytest.raises(RuntimeError, match="rc=-7"):
+        E.forward_adjoint(cfg, 3, 3, u0, p)
+    for bad in (dict(alg="quadrature"), dict(alg="interpolating", checkpointing=True), dict(alg="gauss", abstol=0.0),
+                dict(alg="interpolating", ts=[0.5, 0.5]), dict(alg="interpolating", ts=[11.0])):
+        kw = dict(bad); alg = kw.pop("alg"); ts = kw.pop("ts", [1.0])
+        cfg = E.make_config("lorenz", alg, 1, 0.0, 10.0, 0.0, ts, stepper=1, **kw)
+        with pytest.raises(RuntimeError):
+            E.forward_adjoint(cfg, 3, 3, u0, p, np.zeros((1, len(ts), 3)))

@@ -446,3 +446,82 @@ def test_continuous_cost_on_device(sa, alg, oalg):
         rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
         assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
         sol.engine.close()
+
+
+# ---- adaptive Tsit5 on the device (csrc/hipadj_adaptive.hpp) ---------------------------------------------------------
+TS_ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS")]
+
+
+@pytest.mark.parametrize("alg,oalg", TS_ALGS)
+@pytest.mark.parametrize("model,omodel,u0c,p", [
+    ("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]),
+    ("lvt", "LVT", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]),
+    ("lorenz", "LORENZ", [1.0, 0.0, 0.0], [10.0, 28.0, 8 / 3]),
+    ("lindiag", "LINDIAG", [1.0, 1.0], [1.0, 2.0]),
+    ("fallmass", "FALLMASS", [1.0, 0.0], [9.81, 1.0]),
+])
+def test_tsit5_cotangent_all_models(sa, alg, oalg, model, omodel, u0c, p):
+    """Adaptive Tsit5, per-trajectory step control, loss times off any grid, per-trajectory parameters.  Device and
+    oracle run the same controller; FMA contraction perturbs step sizes at roundoff level, a flipped accept/reject
+    decision moves a result by O(tolerance) = 1e-9, far inside the 1e-6 gate."""
+    rng = np.random.default_rng(31)
+    N, T = 70, 2.0
+    n, npar = sa.model_sizes(model)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.05 * rng.standard_normal((N, npar)))
+    ts = np.array([0.0, 0.13, 0.5, 0.77, 1.0, 1.9, 2.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    ck = alg == "backsolve"
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model, u0[0], (0, T), pp[0]), u0, pp), sa.Tsit5(), saveat=ts,
+                   sensealg=sensealg_of(sa, alg), abstol=1e-9, reltol=1e-9)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem(omodel, alg=oalg, stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts,
+                    loss="COTANGENT", checkpointing=ck)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+@pytest.mark.parametrize("alg,oalg", TS_ALGS)
+def test_tsit5_reference_lvt_setup_against_golden(sa, alg, oalg):
+    """BASELINE configs[0] / test/Core3/adjoint.jl:31-51, 366-404 on the device: LV `fb`, Tsit5 with tight tolerances,
+    dg = u - 2 at t = 0:0.5:10, against the DOP853 forward-sensitivity gradient (tests/golden/gradients.json)."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gradients.json")))["lvt"]
+    ts = np.asarray(gold["ts"])
+    u0 = np.asarray([gold["u0"]]); p = np.asarray(gold["p"])
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lvt", u0[0], tuple(gold["tspan"]), p), u0), sa.Tsit5(), saveat=ts,
+                   sensealg=sensealg_of(sa, alg), dgdu_discrete=sa.LsqShift(2.0), abstol=1e-12, reltol=1e-12, max_steps=20000)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+    tol = 1e-6 if alg != "backsolve" else 1e-5       # Backsolve re-integrates y backwards: the reference tests loosen it too (adjoint.jl:371)
+    assert rel(sol.u[0], np.asarray(gold["u"])) < 1e-8
+    assert rel(du0[0], gold["du0"]) < tol and rel(dp, gold["dp"]) < tol
+    sol.engine.close()
+
+
+def test_tsit5_large_ensemble_sampled_against_oracle_and_cross_method(sa):
+    """10^4 Lorenz trajectories with the reference's default tolerances (1e-6 / 1e-3): every lane takes its own step
+    sequence.  A sample is compared with the oracle; Interpolating vs Gauss must agree to solver tolerance."""
+    N, T = 10000, 1.0
+    u0, p = lorenz_inputs(N, seed=77)
+    ts = np.linspace(0, T, 11)
+    res = {}
+    for alg in ("interpolating", "gauss"):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.Tsit5(), saveat=ts,
+                       sensealg=sensealg_of(sa, alg), dgdu_discrete=sa.LsqShift(2.0), abstol=1e-8, reltol=1e-8)
+        res[alg] = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+        sol.engine.close()
+    idx = np.arange(0, N, 157)
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts,
+                    loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0 = np.array([ref.adjoint(u0[i], p)[0] for i in idx])
+    assert rel(res["interpolating"][0][idx], rdu0) < RTOL
+    assert rel(res["gauss"][0], res["interpolating"][0]) < 1e-5 and rel(res["gauss"][1], res["interpolating"][1]) < 1e-5
+
+
+def test_tsit5_max_steps_is_reported(sa):
+    u0, p = lorenz_inputs(64)
+    with pytest.raises(sa.HipadjError) as e:
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, 10.0), p), u0), sa.Tsit5(), saveat=[10.0],
+                       sensealg=sa.InterpolatingAdjoint(), abstol=1e-10, reltol=1e-10, max_steps=50)
+    assert e.value.status == -7
