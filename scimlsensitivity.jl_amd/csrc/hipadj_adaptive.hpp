@@ -15,8 +15,12 @@
 // with a 100-eps snap), so that device and oracle take the same step sequences up to roundoff.
 //
 // Layout of the forward dense solution (per trajectory a ragged list of accepted steps, trajectory-minor):
-//   rec[(s * RW + w) * Npad + i],  RW = 2 + 8 n :  w = 0 t_start, 1 t_end, 2.. u_start[n], then k_1..k_7 [7][n]
-//   nsteps[i] accepted steps (<= Smax; overflow is reported as HIPADJ_ERR_NONFINITE-class failure through the flag)
+//   rec[(s * RW + w) * Npad + i],  RW = 2 + 5 n :  w = 0 t_start, 1 t_end, then c_0..c_4 [5][n], the monomial form of the
+//   Tsit5 continuous extension on the step:  y(theta) = c_0 + theta (c_1 + theta (c_2 + theta (c_3 + theta c_4))),
+//   c_0 = u_start, c_1 = h k_1, c_m = h sum_j r_{j,m-1} k_j.  The 7 stage derivatives are folded into 4 coefficient
+//   vectors when the step is accepted: 35 % fewer bytes per record than (u, k_1..k_7) and a Horner evaluation (4 n FMAs)
+//   per reverse-pass stage instead of the 7-term b_j(theta) sum.
+//   nsteps[i] accepted steps (<= Smax; overflow is reported through flag bit 4 => HIPADJ_ERR_MAXITERS)
 #pragma once
 
 #include "hipadj_lane.hpp"
@@ -81,6 +85,36 @@ HIPADJ_HD void tsit5_interp(double th, double h, const double (&u0)[NZ], const d
         for (int j = 0; j < 7; ++j) acc += b[j] * k[j][i];
         y[i] = u0[i] + h * acc;
     }
+}
+
+// monomial coefficients of the continuous extension of one accepted step (see the layout note above)
+template <int NZ>
+HIPADJ_HD void tsit5_poly(double h, const double (&u0)[NZ], const double (&k)[7][NZ], double (&c)[5][NZ]) {
+    const double r[7][4] = {
+        {1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216},
+        {0.0, 0.13169999999999998, -0.2234, 0.1017},
+        {0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253},
+        {0.0, -12.411077166933676, 30.33818863028232, -16.548102889244902},
+        {0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928},
+        {0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661},
+        {0.0, 1.5, -4.0, 2.5}};
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        c[0][i] = u0[i];
+        c[1][i] = h * k[0][i];
+#pragma unroll
+        for (int m = 1; m < 4; ++m) {
+            double acc = r[0][m] * k[0][i];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) acc += r[j][m] * k[j][i];
+            c[m + 1][i] = h * acc;
+        }
+    }
+}
+template <int NZ>
+HIPADJ_HD void poly_eval(double th, const double (&c)[5][NZ], double (&y)[NZ]) {
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) y[i] = c[0][i] + th * (c[1][i] + th * (c[2][i] + th * (c[3][i] + th * c[4][i])));
 }
 
 // solve(prob, Tsit5(); abstol, reltol, dt, tstops, callback) for a small system held in registers.
@@ -191,7 +225,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                                   double* __restrict__ rec, int* __restrict__ nsteps, const double* __restrict__ save_t,
                                   double* __restrict__ outT, const double* __restrict__ ck_t, double* __restrict__ ckpt,
                                   double* __restrict__ yT, int* __restrict__ flag) {
-    constexpr int N = Mo::N, RW = 2 + 8 * N;
+    constexpr int N = Mo::N, RW = 2 + 5 * N;
     double pv[Mo::NP];
 #pragma unroll
     for (int j = 0; j < Mo::NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * Mo::NP + j];
@@ -212,26 +246,25 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     const int na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.Smax,
         [&](double (&du)[N], const double (&uu)[N], double t) { Mo::f(du, uu, pv, t); },
         [&](double t, double tprev, double (&un)[N], const double (&up)[N], const double (&k)[7][N]) -> bool {
+            const double h = t - tprev;
+            double c[5][N]; tsit5_poly<N>(h, up, k, c);
             if (s < g.Smax) {
                 if (rec) {
                     rec[((long)s * RW + 0) * g.Npad + i] = tprev; rec[((long)s * RW + 1) * g.Npad + i] = t;
 #pragma unroll
-                    for (int j = 0; j < N; ++j) rec[((long)s * RW + 2 + j) * g.Npad + i] = up[j];
+                    for (int m = 0; m < 5; ++m)
 #pragma unroll
-                    for (int q = 0; q < 7; ++q)
-#pragma unroll
-                        for (int j = 0; j < N; ++j) rec[((long)s * RW + 2 + N + q * N + j) * g.Npad + i] = k[q][j];
+                        for (int j = 0; j < N; ++j) rec[((long)s * RW + 2 + m * N + j) * g.Npad + i] = c[m][j];
                 }
             } else overflow = true;
             ++s;
-            const double h = t - tprev;
             while (outT && ms < g.M && (save_t[ms] <= t || time_hits(save_t[ms], t))) {
-                double y[N]; tsit5_interp<N>((save_t[ms] - tprev) / h, h, up, k, y);
+                double y[N]; poly_eval<N>((save_t[ms] - tprev) / h, c, y);
 #pragma unroll
                 for (int j = 0; j < N; ++j) outT[((long)ms * N + j) * g.Npad + i] = y[j];
                 ++ms; }
             while (ckpt && mc < g.nck && (ck_t[mc] <= t || time_hits(ck_t[mc], t))) {
-                double y[N]; tsit5_interp<N>((ck_t[mc] - tprev) / h, h, up, k, y);
+                double y[N]; poly_eval<N>((ck_t[mc] - tprev) / h, c, y);
 #pragma unroll
                 for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = y[j];
                 ++mc; }
@@ -251,28 +284,33 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     }
 }
 
-// cursor into one trajectory's forward dense solution: the step containing t, cached in registers
+// cursor into one trajectory's forward dense solution: the step containing t, its coefficients cached in registers.
+// The walk touches only the step end points (one load per visited step: consecutive steps share an end point);
+// the 5 n coefficients are loaded once per step actually used.
 template <class Mo> struct FwdCursor {
-    static constexpr int N = Mo::N, RW = 2 + 8 * Mo::N;
-    const double* rec; long Npad, i; int ns, sc;
-    double ta, tb, u0[Mo::N], k[7][Mo::N];
-    HIPADJ_HD void load(int s) {
-        sc = s;
-        ta = rec[((long)s * RW + 0) * Npad + i]; tb = rec[((long)s * RW + 1) * Npad + i];
-#pragma unroll
-        for (int j = 0; j < N; ++j) u0[j] = rec[((long)s * RW + 2 + j) * Npad + i];
-#pragma unroll
-        for (int q = 0; q < 7; ++q)
-#pragma unroll
-            for (int j = 0; j < N; ++j) k[q][j] = rec[((long)s * RW + 2 + N + q * N + j) * Npad + i];
+    static constexpr int N = Mo::N, RW = 2 + 5 * Mo::N;
+    const double* rec; long Npad, i; int ns, sc, lc;
+    double ta, tb, c[5][Mo::N];
+    HIPADJ_HD void init(const double* r, long np, long ii, int nsteps) {
+        rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; lc = -1;
+        ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i];
     }
-    HIPADJ_HD void init(const double* r, long np, long ii, int nsteps) { rec = r; Npad = np; i = ii; ns = nsteps; load(nsteps - 1); }
     // y = sol(t): the reverse sweep moves mostly downward, so a linear cursor walk replaces the binary search
     HIPADJ_HD void eval(double t, double (&y)[Mo::N]) {
-        while (t < ta && sc > 0) load(sc - 1);
-        while (t > tb && sc < ns - 1) load(sc + 1);
-        const double h = tb - ta;
-        tsit5_interp<N>((t - ta) / h, h, u0, k, y);
+        while (t < ta && sc > 0) { --sc; tb = ta; ta = rec[((long)sc * RW + 0) * Npad + i]; }
+        while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[((long)sc * RW + 1) * Npad + i]; }
+        if (sc != lc) {
+            lc = sc;
+            long base = ((long)sc * RW + 2) * Npad + i;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(base));   // keep the 5 n addresses local to this load (no hoisting across the unrolled stages)
+#endif
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int j = 0; j < N; ++j) c[m][j] = rec[base + (long)(m * N + j) * Npad];
+        }
+        poly_eval<N>((t - ta) / (tb - ta), c, y);
     }
 };
 

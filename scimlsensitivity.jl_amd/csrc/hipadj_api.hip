@@ -141,7 +141,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->field = P.field;
     h->adaptive = P.adaptive;
     if (P.adaptive) {
-        const int RW = 2 + 8 * n;
+        const int RW = 2 + 5 * n;   // record width, hipadj_adaptive.hpp
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
         if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)P.Smax * RW * Np));
