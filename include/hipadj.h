@@ -43,7 +43,8 @@ typedef enum {
     HIPADJ_MODEL_LINDIAG = 3,  /* u' = p .* u, n=np=2 (test/Core1/sparse_adjoint.jl:6-8) */
     HIPADJ_MODEL_FALLMASS = 4, /* u' = [u2, -g] (test/Core7/physical_ode_regression.jl:20-23) */
     HIPADJ_MODEL_MLP = 5,      /* tanh MLP d->H->H->d on a d x B state; dims = {d, H, B} */
-    HIPADJ_MODEL_BRUSS = 6     /* 2-D Brusselator, dims = {Ngrid} (docs/src/examples/pde/brusselator.md:98-112) */
+    HIPADJ_MODEL_BRUSS = 6,    /* 2-D Brusselator, dims = {Ngrid} (docs/src/examples/pde/brusselator.md:98-112) */
+    HIPADJ_MODEL_USER_BASE = 1000 /* ids >= this come from hipadj_model_register (runtime-compiled right-hand sides) */
 } hipadj_model;
 
 /* sensealg — src/sensitivity_algorithms.jl:254-272 (Backsolve), 378-396 (Interpolating), 486-503 (Quadrature),
@@ -122,6 +123,21 @@ const char *hipadj_status_string(int status);
 const char *hipadj_last_error(const hipadj_handle *h);
 /* n and np of a registered model (the reference reads them off u0 / p) */
 int hipadj_model_sizes(int32_t model, const int32_t dims[4], int32_t *n, int32_t *np);
+
+/* Runtime model ingestion — the reference's ODEFunction(f!; vjp, vjp_p) seam (src/derivative_wrappers.jl:284-359,
+ * test/Core3/user_vjp.jl:14-38, 77): the caller supplies the BODIES of the three device functions as HIP C++ text;
+ * hipadj_create compiles the lane-per-trajectory kernels for them with hiprtc (gfx950) on first use.
+ *   f_body      writes du[0..n)   from  u[0..n), p[0..np), t            (in-place f!(du, u, p, t))
+ *   vjp_u_body  writes out[0..n)  = (df/du)^T lam  from lam, u, p, t    (vjp(dlam, lam, u, p, t), UN-negated)
+ *   vjp_p_body  writes out[0..np) = (df/dp)^T lam  from lam, u, p, t    (vjp_p(dgrad, lam, u, p, t), UN-negated)
+ * All are `double`; local variables and device math functions are allowed; no global memory access.
+ * Limits: 1 <= n <= 8, 1 <= np <= 32.  On success *model_id (>= HIPADJ_MODEL_USER_BASE) is valid for hipadj_config.model
+ * for the lifetime of the process; registering the same name again replaces the sources (new id). */
+int hipadj_model_register(const char *name, int32_t n, int32_t np, const char *f_body, const char *vjp_u_body,
+                          const char *vjp_p_body, int32_t *model_id);
+/* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
+ * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
+int hipadj_model_check(int32_t model_id);
 
 /* Replaces the per-call setup of ODEAdjointProblem + adjointdiffcache (src/interpolating_adjoint.jl:307-451,
  * src/backsolve_adjoint.jl:123-272, src/adjoint_common.jl:42-469): validates the configuration, allocates the

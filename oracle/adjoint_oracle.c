@@ -49,6 +49,8 @@ static int model_init(orc_model *m, int id, const int dims[4]) {
     case ORC_MODEL_BRUSS: {
         int G = m->dims[0]; if (G <= 1) return -1;
         m->n = 2 * G * G; m->np = 3; break; }
+    case ORC_MODEL_ROBER: m->n = 3; m->np = 3; break;
+    case ORC_MODEL_RING: { int r = m->dims[0]; if (r < 2 || r > 8) return -1; m->n = r; m->np = r + 1; break; }
     default: return -1;
     }
     return 0;
@@ -85,6 +87,16 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
     case ORC_MODEL_FALLMASS:/* test/Core7/physical_ode_regression.jl:20-23 */
         du[0] = u[1]; du[1] = -p[0];
         break;
+    case ORC_MODEL_ROBER:   /* Robertson kinetics, test/Core3/adjoint.jl:1434-1441 (`rober`) */
+        du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
+        du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
+        du[2] = p[1] * u[1] * u[1];
+        break;
+    case ORC_MODEL_RING: {  /* synthetic test subject for runtime-registered models (NOT from the reference):
+                               du_i = p_i (u_{i+1} - u_i) + p_n sin(u_{i-1}), indices mod n */
+        int r = m->n;
+        for (int i = 0; i < r; ++i) du[i] = p[i] * (u[(i + 1) % r] - u[i]) + p[r] * sin(u[(i + r - 1) % r]);
+        break; }
     case ORC_MODEL_MLP: {
         /* U is d x B column-major; f(U) = W3 tanh(W2 tanh(W1 U + b1) + b2) + b3 (docs/src/Benchmark.md:62 shape) */
         int d = m->dims[0], H = m->dims[1], B = m->dims[2];
@@ -157,6 +169,28 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
         if (dlam) { dlam[0] = 0.0; dlam[1] = lam[0]; }
         if (dgrad) { dgrad[0] = -lam[1]; dgrad[1] = 0.0; }
         break;
+    case ORC_MODEL_ROBER:
+        if (dlam) {
+            dlam[0] = -p[0] * lam[0] + p[0] * lam[1];
+            dlam[1] = p[2] * u[2] * lam[0] + (-2.0 * p[1] * u[1] - p[2] * u[2]) * lam[1] + 2.0 * p[1] * u[1] * lam[2];
+            dlam[2] = p[2] * u[1] * lam[0] - p[2] * u[1] * lam[1];
+        }
+        if (dgrad) {
+            dgrad[0] = -u[0] * lam[0] + u[0] * lam[1];
+            dgrad[1] = -u[1] * u[1] * lam[1] + u[1] * u[1] * lam[2];
+            dgrad[2] = u[1] * u[2] * lam[0] - u[1] * u[2] * lam[1];
+        }
+        break;
+    case ORC_MODEL_RING: {
+        int r = m->n;
+        if (dlam) for (int j = 0; j < r; ++j)
+            dlam[j] = -p[j] * lam[j] + p[(j + r - 1) % r] * lam[(j + r - 1) % r] + p[r] * cos(u[j]) * lam[(j + 1) % r];
+        if (dgrad) {
+            double s = 0.0;
+            for (int k = 0; k < r; ++k) { dgrad[k] = lam[k] * (u[(k + 1) % r] - u[k]); s += lam[k] * sin(u[(k + r - 1) % r]); }
+            dgrad[r] = s;
+        }
+        break; }
     case ORC_MODEL_MLP: {
         int d = m->dims[0], H = m->dims[1], B = m->dims[2];
         const double *W1 = p, *b1 = W1 + H * d, *W2 = b1 + H, *b2 = W2 + H * H, *W3 = b2 + H;

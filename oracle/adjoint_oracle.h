@@ -32,7 +32,9 @@ enum {
     ORC_MODEL_LINDIAG = 3,   /* u' = p .* u, n = np = 2 (test/Core1/sparse_adjoint.jl:6-17) */
     ORC_MODEL_FALLMASS = 4,  /* u' = [u2, -g]  (test/Core7/physical_ode_regression.jl:20-23) */
     ORC_MODEL_MLP = 5,       /* tanh MLP d->H->H->d applied column-wise to a d x B state */
-    ORC_MODEL_BRUSS = 6      /* 2-D Brusselator, periodic 5-point Laplacian */
+    ORC_MODEL_BRUSS = 6,     /* 2-D Brusselator, periodic 5-point Laplacian */
+    ORC_MODEL_ROBER = 7,     /* Robertson kinetics `rober` (test/Core3/adjoint.jl:1434-1441); checker for runtime-registered models */
+    ORC_MODEL_RING = 8       /* synthetic ring, dims = {n <= 8}, np = n + 1; checker for runtime-registered models with n > 3 */
 };
 enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3 };
 enum { ORC_STEPPER_RK4 = 0, ORC_STEPPER_TSIT5 = 1 };

@@ -6,7 +6,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libhipadj.so")
 
-OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NONFINITE, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NONFINITE, ERR_STATE, ERR_UNSUPPORTED, ERR_MAXITERS = 0, -1, -2, -3, -4, -5, -6, -7
+MODEL_USER_BASE = 1000
 
 MODEL = dict(lv=0, lvt=1, lorenz=2, lindiag=3, fallmass=4, mlp=5, bruss=6)
 ALG = dict(interpolating=0, backsolve=1, gauss=2, quadrature=3)
@@ -17,6 +18,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
+    "hipadj_model_register", "hipadj_model_check",
 )
 
 
@@ -89,6 +91,8 @@ def load():
     L.hipadj_synchronize.argtypes = [vp]
     L.hipadj_set_timing.argtypes = [vp, C.c_int]
     L.hipadj_get_stats.argtypes = [vp, C.POINTER(HipadjStats)]
+    L.hipadj_model_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
+    L.hipadj_model_check.argtypes = [C.c_int32]
     _lib = L
     return L
 
@@ -99,3 +103,19 @@ def model_sizes(model, dims=(0, 0, 0, 0)):
     if rc != OK:
         raise HipadjError(rc, f"unknown model {model!r} / dims {dims}")
     return n.value, npar.value
+
+
+def register_model(name, n, npar, f, vjp, vjp_p, check=False):
+    """hipadj_model_register: runtime ingestion of a right-hand side and its two VJPs (HIP C++ bodies, see include/hipadj.h).
+    Adds `name` to MODEL and returns the model id; check=True compiles for gfx950 immediately (no device needed)."""
+    L = load()
+    mid = C.c_int32()
+    rc = L.hipadj_model_register(name.encode(), int(n), int(npar), f.encode(), vjp.encode(), vjp_p.encode(), C.byref(mid))
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+    if check:
+        rc = L.hipadj_model_check(mid.value)
+        if rc != OK:
+            raise HipadjError(rc, L.hipadj_last_error(None).decode())
+    MODEL[name] = mid.value
+    return mid.value

@@ -415,7 +415,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     }
 }
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 // one lane = one trajectory; lanes of a wave take their own step sequences (accept/reject and the cursor walks
 // diverge under the exec mask), a wave retires when its slowest trajectory does
 template <class Mo>

@@ -16,6 +16,7 @@
 #include "hipadj_mlp.hpp"
 #include "hipadj_adaptive.hpp"
 #include "hipadj_plan.hpp"
+#include "hipadj_user.hpp"
 
 using namespace hipadj;
 
@@ -47,6 +48,9 @@ struct hipadj_handle {
     double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
     MlpGeom mg{};
     FieldGeom fg{};
+    bool user = false;                    // runtime-compiled right-hand side (hipadj_user.hpp)
+    hipModule_t umod = nullptr;
+    hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish
     bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
     AdaptGeom ag{};
     double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr;
@@ -63,6 +67,7 @@ struct hipadj_handle {
 };
 
 static thread_local std::string g_create_error;
+static int user_prepare(hipadj_handle* h);   // hiprtc compilation of the kernels of a runtime-registered model
 
 extern "C" int hipadj_version(void) { return HIPADJ_VERSION; }
 
@@ -97,6 +102,16 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
     h->ws_bytes += (double)(count * sizeof(T));
     return HIPADJ_OK;
 }
+extern "C" int hipadj_model_register(const char* name, int32_t n, int32_t np, const char* f_body, const char* vjp_u_body,
+                                     const char* vjp_p_body, int32_t* model_id) {
+    return user_register(name, n, np, f_body, vjp_u_body, vjp_p_body, model_id, g_create_error);
+}
+
+extern "C" int hipadj_model_check(int32_t model_id) {
+    std::vector<char> code; std::map<std::string, std::string> low;
+    return user_compile(model_id, {"hipadj::k_forward<hipadj::UserModel>", "hipadj::k_interp<hipadj::UserModel, 2, 1>"}, code, low, g_create_error);
+}
+
 #define TRY(expr) do { int _rc = (expr); if (_rc != HIPADJ_OK) return _rc; } while (0)
 
 static void free_all(hipadj_handle* h) {
@@ -104,6 +119,7 @@ static void free_all(hipadj_handle* h) {
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->umod) (void)hipModuleUnload(h->umod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -242,6 +258,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     bytes += (double)h->N * 8.0 * (n + np);
     h->st.adjoint_algorithmic_bytes = bytes;
     h->st.vjp_steps = (double)h->N * (double)S * 4.0;
+    h->user = P.user;
+    if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
     *out = h;
     return HIPADJ_OK;
 }
@@ -560,6 +578,122 @@ template <int H> static int mlp_adjoint_launch(hipadj_handle* h, const double* d
     case HIPADJ_MODEL_FALLMASS: return fn<ModelFallMass>(__VA_ARGS__);                     \
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "model %d has no device kernels", (h)->cfg.model); }
 
+// ---- runtime-compiled models (hipadj_user.hpp) --------------------------------------------------------------
+// Kernel instantiations a handle needs, by configuration.  Prefetch depths shrink with n: the knot ring holds
+// PF x 2n doubles in VGPRs.
+struct UserKernels { std::string forward, main_k, tail, gk; };
+static UserKernels user_kernel_names(const hipadj_handle* h) {
+    const std::string U = "hipadj::UserModel";
+    const int n = h->n, np = h->np;
+    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
+    const int cc = mode >> 1;
+    const int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : (n <= 5 ? 4 : 2), PFG = n <= 3 ? 4 : 2;
+    auto I = [](int v) { return std::to_string(v); };
+    UserKernels k;
+    const std::string finish = "hipadj::k_finish<" + I(n) + ", " + I(np) + ">", compose = "hipadj::k_compose_finish<" + U + ">";
+    if (h->adaptive) {
+        k.forward = "hipadj::k_forward_tsit5<" + U + ">";
+        k.main_k = "hipadj::k_adjoint_tsit5<" + U + ", " + I(h->cfg.alg) + ", " + I(cc) + ">";
+        k.tail = finish;
+        return k;
+    }
+    k.forward = "hipadj::k_forward<" + U + ">";
+    switch (h->cfg.alg) {
+    case HIPADJ_ALG_INTERPOLATING: k.main_k = "hipadj::k_interp<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.tail = compose; break;
+    case HIPADJ_ALG_BACKSOLVE: k.main_k = "hipadj::k_backsolve<" + U + ", " + I(cc) + ">"; k.tail = compose; break;
+    case HIPADJ_ALG_GAUSS: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ">"; k.tail = compose; break;
+    default: k.main_k = "hipadj::k_quad_adj<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.gk = "hipadj::k_quad_gk<" + U + ">"; k.tail = finish; break;
+    }
+    return k;
+}
+
+static int user_prepare(hipadj_handle* h) {
+    const UserKernels k = user_kernel_names(h);
+    std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
+    if (!k.gk.empty()) exprs.push_back(k.gk);
+    std::vector<char> code; std::map<std::string, std::string> low;
+    const int rc = user_compile(h->cfg.model, exprs, code, low, h->err);
+    if (rc != HIPADJ_OK) return rc;
+    HIP_TRY(h, hipModuleLoadData(&h->umod, code.data()));
+    HIP_TRY(h, hipModuleGetFunction(&h->uf_forward, h->umod, low[k.forward].c_str()));
+    HIP_TRY(h, hipModuleGetFunction(&h->uf_main, h->umod, low[k.main_k].c_str()));
+    HIP_TRY(h, hipModuleGetFunction(&h->uf_tail, h->umod, low[k.tail].c_str()));
+    if (!k.gk.empty()) HIP_TRY(h, hipModuleGetFunction(&h->uf_gk, h->umod, low[k.gk].c_str()));
+    return HIPADJ_OK;
+}
+
+// launch of a module kernel; every argument is passed with exactly the parameter type of the kernel
+template <class... Args> static int ulaunch(hipadj_handle* h, hipFunction_t fn, dim3 g, dim3 b, Args... args) {
+    void* ptrs[] = {(void*)&args...};
+    HIP_TRY(h, hipModuleLaunchKernel(fn, g.x, g.y, g.z, b.x, b.y, b.z, 0, h->stream, ptrs, nullptr));
+    return HIPADJ_OK;
+}
+
+static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    double* outT = (d_out && h->M > 0) ? h->d_outT : (double*)nullptr;
+    if (h->adaptive)
+        TRY(ulaunch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->d_rec, h->d_nsteps, (const double*)h->d_save_t, outT,
+                    (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag));
+    else
+        TRY(ulaunch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
+                    (const int*)h->d_save_of_knot, h->d_yT));
+    if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
+    return HIPADJ_OK;
+}
+
+static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    const double* p = h->p_dev_last;
+    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN), cblocks = (unsigned)((h->N + FIN / 4 - 1) / (FIN / 4));
+    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
+    double* no_sum = nullptr;
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    bool composed = false;
+    if (h->adaptive) {
+        TRY(ulaunch(h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
+                    (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, h->ntstops,
+                    (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag));
+    } else {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        const dim3 sgrid(waves, (unsigned)h->nseg);
+        switch (h->cfg.alg) {
+        case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS:
+            TRY(ulaunch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
+            composed = true; break;
+        case HIPADJ_ALG_BACKSOLVE:
+            TRY(ulaunch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+                        (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
+            composed = true; break;
+        default: {
+            TRY(ulaunch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0));
+            const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+            TRY(ulaunch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const dbl2*)h->d_adj, (const double*)h->d_qa,
+                        (const double*)h->d_qb, atol, rtol, h->d_qres));
+            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+            HIP_TRY(h, hipGetLastError());
+            break; }
+        }
+    }
+    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+    if (composed)
+        TRY(ulaunch(h, h->uf_tail, dim3(cblocks), dim3(FIN), h->g, h->nseg, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
+    else
+        TRY(ulaunch(h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)d_du0, (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
+    if (h->cfg.p_shared) {
+        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)(composed ? cblocks : fblocks), h->np, (const double*)h->d_partial, d_dp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = h->timing >= 1; es.full = h->timing >= 2;
+    return HIPADJ_OK;
+}
+
 // ---- adaptive Tsit5 (hipadj_adaptive.hpp) ------------------------------------------------------------------
 template <class Mo> static int adaptive_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
@@ -606,12 +740,14 @@ template <class Mo> static int adaptive_adjoint(hipadj_handle* h, const double* 
 }
 
 static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    if (h->user) return user_forward(h, d_u0, d_p, d_out);
     if (h->field) { DISPATCH_GRID(h, field_forward, h, d_u0, d_p, d_out); }
     if (h->mlp) { DISPATCH_HIDDEN(h, mlp_forward_launch, h, d_u0, d_p, d_out); }
     if (h->adaptive) { DISPATCH_MODEL(h, adaptive_forward, h, d_u0, d_p, d_out); }
     DISPATCH_MODEL(h, forward_impl, h, d_u0, d_p, d_out);
 }
 static int adjoint_dispatch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    if (h->user) return user_adjoint(h, d_cot, d_du0, d_dp);
     if (h->field) { DISPATCH_GRID(h, field_adjoint, h, d_cot, d_du0, d_dp); }
     if (h->mlp) { DISPATCH_HIDDEN(h, mlp_adjoint_launch, h, d_cot, d_du0, d_dp); }
     if (h->adaptive) { DISPATCH_MODEL(h, adaptive_adjoint, h, d_cot, d_du0, d_dp); }

@@ -7,9 +7,13 @@
 // round-robins the HBM streams of neighbouring trajectory tiles over all 8 L2s.
 #pragma once
 
+#if !defined(__HIPCC_RTC__)   // hiprtc (runtime-compiled user models, hipadj_user.hpp) provides the runtime header implicitly
 #include <hip/hip_runtime.h>
+#endif
 #include "hipadj_lane.hpp"
+#if !defined(__HIPCC_RTC__)
 #include "hipadj_plan.hpp"
+#endif
 
 namespace hipadj {
 

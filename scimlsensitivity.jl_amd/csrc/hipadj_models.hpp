@@ -7,7 +7,7 @@
 // Hand-derived; no runtime AD on the device.
 #pragma once
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 #define HIPADJ_HD __host__ __device__ __forceinline__
 #else
 #define HIPADJ_HD inline
@@ -22,6 +22,8 @@
 #endif
 
 namespace hipadj {
+
+constexpr int HIPADJ_CKPT_KMAX = 16;   // longest checkpoint interval (steps) the in-kernel re-solve tile holds
 
 // Lotka-Volterra (test/Core3/user_vjp.jl:6-10): du1 = p1 u1 - p2 u1 u2 ; du2 = -p3 u2 + p4 u1 u2
 struct ModelLV {

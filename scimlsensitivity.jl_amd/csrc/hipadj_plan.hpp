@@ -13,10 +13,9 @@
 #include <string>
 #include <vector>
 #include "../../include/hipadj.h"
+#include "hipadj_models.hpp"
 
 namespace hipadj {
-
-constexpr int HIPADJ_CKPT_KMAX = 16;   // longest checkpoint interval (steps) the in-kernel re-solve tile holds
 
 struct Plan {
     int n = 0, np = 0;
@@ -31,12 +30,17 @@ struct Plan {
     bool field = false;      // workgroup-per-trajectory family (hipadj_field.hpp)
     bool mlp = false;        // FP64-MFMA family (hipadj_mlp.hpp)
     bool adaptive = false;   // adaptive Tsit5 (hipadj_adaptive.hpp)
+    bool user = false;       // runtime-compiled right-hand side (hipadj_user.hpp)
     int Smax = 0;            // capacity of the per-trajectory dense solution (adaptive)
     std::vector<double> ck_times, tstops_desc;   // adaptive: checkpoint times (ascending), reverse tstops (descending)
     int NQ = 0;              // activation records per step (MLP)
 };
 
-inline bool plan_small_model(int m) { return m >= HIPADJ_MODEL_LV && m <= HIPADJ_MODEL_FALLMASS; }
+// runtime-registered models (ids >= HIPADJ_MODEL_USER_BASE, hipadj_user.hpp): sizes come from the registry
+typedef int (*plan_user_sizes_fn)(int32_t model, int32_t* n, int32_t* np);
+inline plan_user_sizes_fn& plan_user_sizes_hook() { static plan_user_sizes_fn f = nullptr; return f; }
+inline bool plan_user_model(int m) { return m >= HIPADJ_MODEL_USER_BASE; }
+inline bool plan_small_model(int m) { return (m >= HIPADJ_MODEL_LV && m <= HIPADJ_MODEL_FALLMASS) || plan_user_model(m); }
 
 inline int plan_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, int32_t* np) {
     switch (model) {
@@ -50,7 +54,9 @@ inline int plan_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, in
     case HIPADJ_MODEL_BRUSS:
         if (!dims || dims[0] <= 1) return HIPADJ_ERR_INVALID_ARG;
         *n = 2 * dims[0] * dims[0]; *np = 3; return HIPADJ_OK;
-    default: return HIPADJ_ERR_INVALID_ARG;
+    default:
+        if (plan_user_model(model) && plan_user_sizes_hook()) return plan_user_sizes_hook()(model, n, np);
+        return HIPADJ_ERR_INVALID_ARG;
     }
 }
 
@@ -58,8 +64,9 @@ inline int plan_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, in
 // (trajectory-wave x segment) workgroups to put ~2 waves on each of the 1024 SIMDs of an MI355X, each segment
 // keeping >= 16 steps.  A non-top segment carries 1 + n columns, so segmentation only pays once the added
 // parallelism exceeds that factor.
-inline int plan_auto_segments(long N, int S, int n) {
+inline int plan_auto_segments(long N, int S, int n, int np = 0) {
     const long waves = (N + 63) / 64;
+    if ((1 + n) * (n + np) > 64) return 1;   // a segment lane holds (1 + n) columns of n + np doubles in VGPRs
     // the segmented kernel needs ~250 VGPRs => 2 resident waves per SIMD => 2048 wave slots on 256 CUs x 4 SIMDs;
     // floor() keeps the grid within ONE residency round (a partial second round would double the makespan)
     long target = 2048 / waves;
@@ -76,6 +83,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (plan_model_sizes(cfg->model, cfg->dims, &n, &np) != HIPADJ_OK) { err = "unknown model id or bad dims"; return HIPADJ_ERR_INVALID_ARG; }
     P.field = cfg->model == HIPADJ_MODEL_BRUSS;
     P.mlp = cfg->model == HIPADJ_MODEL_MLP;
+    P.user = plan_user_model(cfg->model);
     if (!plan_small_model(cfg->model) && !P.field && !P.mlp) { err = "unknown model"; return HIPADJ_ERR_UNSUPPORTED; }
     if (P.mlp) {
         if (cfg->dims[0] != 2) { err = "MLP family: state width d must be 2 (docs/src/Benchmark.md:62 shape)"; return HIPADJ_ERR_UNSUPPORTED; }
@@ -155,6 +163,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }
         P.nck = c;
     }
+    if (P.ip_ckpt && P.user) { err = "checkpointing=true for Interpolating/Gauss is not offered for runtime-compiled models yet"; return HIPADJ_ERR_UNSUPPORTED; }
     P.prev_ck.assign(S + 1, 0);
     if (P.ip_ckpt) {
         int last = 0, longest = 0;
@@ -164,7 +173,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     P.nseg = 1;
     const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
     if (seg_alg) {
-        P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n) : cfg->time_segments;
+        P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n, np) : cfg->time_segments;
+        if ((1 + n) * (n + np) > 64) P.nseg = 1;   // segment lanes would not fit the register file
         if (P.nseg > P.S) P.nseg = P.S;
         if (P.nseg < 1) P.nseg = 1;
     }

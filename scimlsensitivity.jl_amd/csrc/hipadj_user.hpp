@@ -1,0 +1,188 @@
+// hipadj_user.hpp — runtime model ingestion for the lane-per-trajectory kernel family (host side of the library).
+//
+// The reference lets the caller hand in the right-hand side and its two vector-Jacobian products as plain functions,
+//   ODEFunction(f!; vjp = (dlam, lam, u, p, t), vjp_p = (dgrad, lam, u, p, t))       src/derivative_wrappers.jl:284-359
+// (priority vjp_p > paramjac > AD; exercised by test/Core3/user_vjp.jl:14-38, 77).  On the device the same seam is a
+// struct with three inlined static functions (hipadj_models.hpp).  hipadj_model_register stores the three BODIES as HIP
+// C++ text; at hipadj_create the kernels the configuration needs (forward solve, reverse sweep, segment composition /
+// finishing) are instantiated for that struct and compiled for gfx950 with hiprtc from the library's own headers
+// (read from csrc/ next to libhipadj.so), loaded with hipModuleLoadData and launched with hipModuleLaunchKernel.
+// Nothing here is a CPU path: a model that fails to compile fails hipadj_create with the compiler log.
+//
+// hiprtc is bound with dlopen at first use, not at link time: a process that has torch loaded already carries a
+// HIP runtime + hiprtc pair, and binding by soname picks that pair instead of mixing two runtimes.
+#pragma once
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "hipadj_plan.hpp"
+
+namespace hipadj {
+
+struct UserModelSrc {
+    std::string name, f, vjp_u, vjp_p;
+    int n = 0, np = 0;
+};
+
+struct UserRegistry {
+    std::mutex mu;
+    std::vector<UserModelSrc> models;                       // id = HIPADJ_MODEL_USER_BASE + index
+    std::map<std::string, std::vector<char>> code_cache;    // (id | name expressions) -> gfx950 code object
+    std::map<std::string, std::map<std::string, std::string>> lowered_cache;   // same key -> expression -> mangled name
+};
+inline UserRegistry& user_registry() { static UserRegistry r; return r; }
+
+inline int user_model_sizes(int32_t model, int32_t* n, int32_t* np) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) return HIPADJ_ERR_INVALID_ARG;
+    *n = R.models[idx].n; *np = R.models[idx].np;
+    return HIPADJ_OK;
+}
+
+struct RtcApi {
+    void* lib = nullptr;
+    hiprtcResult (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+    hiprtcResult (*AddNameExpression)(hiprtcProgram, const char*) = nullptr;
+    hiprtcResult (*CompileProgram)(hiprtcProgram, int, const char**) = nullptr;
+    hiprtcResult (*GetProgramLogSize)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*GetProgramLog)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*GetLoweredName)(hiprtcProgram, const char*, const char**) = nullptr;
+    hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*GetCode)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
+    std::string err;
+};
+
+inline RtcApi& rtc_api() {
+    static RtcApi A;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
+        for (const char* nm : names) { A.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (A.lib) break; }
+        if (!A.lib) { A.err = "hiprtc not found (libhiprtc.so): runtime-compiled models are unavailable"; return; }
+        auto S = [&](const char* s) { void* p = dlsym(A.lib, s); if (!p && A.err.empty()) A.err = std::string("hiprtc symbol missing: ") + s; return p; };
+        A.CreateProgram = (decltype(A.CreateProgram))S("hiprtcCreateProgram");
+        A.AddNameExpression = (decltype(A.AddNameExpression))S("hiprtcAddNameExpression");
+        A.CompileProgram = (decltype(A.CompileProgram))S("hiprtcCompileProgram");
+        A.GetProgramLogSize = (decltype(A.GetProgramLogSize))S("hiprtcGetProgramLogSize");
+        A.GetProgramLog = (decltype(A.GetProgramLog))S("hiprtcGetProgramLog");
+        A.GetLoweredName = (decltype(A.GetLoweredName))S("hiprtcGetLoweredName");
+        A.GetCodeSize = (decltype(A.GetCodeSize))S("hiprtcGetCodeSize");
+        A.GetCode = (decltype(A.GetCode))S("hiprtcGetCode");
+        A.DestroyProgram = (decltype(A.DestroyProgram))S("hiprtcDestroyProgram");
+    });
+    return A;
+}
+
+// directory holding the library's kernel headers: $HIPADJ_CSRC_DIR, else csrc/ next to libhipadj.so
+inline std::string user_csrc_dir() {
+    if (const char* e = std::getenv("HIPADJ_CSRC_DIR")) return e;
+    Dl_info info;
+    if (dladdr((const void*)&user_csrc_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t k = p.rfind('/');
+        return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/csrc";
+    }
+    return "csrc";
+}
+
+inline bool user_read_file(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::ostringstream ss; ss << f.rdbuf(); out = ss.str();
+    return true;
+}
+
+inline std::string user_model_struct(const UserModelSrc& m) {
+    std::ostringstream o;
+    o << "#include \"hipadj_kernels.hpp\"\n#include \"hipadj_adaptive.hpp\"\n"
+      << "namespace hipadj {\n// runtime-registered model '" << m.name << "'\nstruct UserModel {\n"
+      << "    static constexpr int N = " << m.n << ", NP = " << m.np << ";\n    static constexpr bool TIME_DEP = true;\n"
+      << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+      << "        (void)u; (void)p; (void)t;\n" << m.f << "\n    }\n"
+      << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+      << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_u << "\n    }\n"
+      << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+      << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_p << "\n    }\n};\n}  // namespace hipadj\n";
+    return o.str();
+}
+
+// Compiles (or fetches from the process-wide cache) the code object holding `exprs` for user model `model`.
+// Returns HIPADJ_OK and fills code + lowered names; on failure err carries the hiprtc log.
+inline int user_compile(int32_t model, const std::vector<std::string>& exprs, std::vector<char>& code,
+                        std::map<std::string, std::string>& lowered, std::string& err) {
+    UserRegistry& R = user_registry();
+    UserModelSrc src;
+    std::string key = std::to_string(model);
+    for (const auto& e : exprs) key += "|" + e;
+    {
+        std::lock_guard<std::mutex> lk(R.mu);
+        const int idx = model - HIPADJ_MODEL_USER_BASE;
+        if (idx < 0 || idx >= (int)R.models.size()) { err = "unknown user model id"; return HIPADJ_ERR_INVALID_ARG; }
+        src = R.models[idx];
+        auto it = R.code_cache.find(key);
+        if (it != R.code_cache.end()) { code = it->second; lowered = R.lowered_cache[key]; return HIPADJ_OK; }
+    }
+    RtcApi& A = rtc_api();
+    if (!A.lib || !A.err.empty()) { err = A.err.empty() ? "hiprtc unavailable" : A.err; return HIPADJ_ERR_UNSUPPORTED; }
+    const char* hnames[] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp"};
+    std::string htext[4];
+    const std::string dir = user_csrc_dir();
+    for (int i = 0; i < 4; ++i)
+        if (!user_read_file(dir + "/" + hnames[i], htext[i])) { err = "cannot read kernel header " + dir + "/" + hnames[i] + " (set HIPADJ_CSRC_DIR)"; return HIPADJ_ERR_UNSUPPORTED; }
+    const char* hptr[] = {htext[0].c_str(), htext[1].c_str(), htext[2].c_str(), htext[3].c_str()};
+    const std::string tu = user_model_struct(src);
+    hiprtcProgram prog = nullptr;
+    if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", 4, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
+    for (const auto& e : exprs) A.AddNameExpression(prog, e.c_str());
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const hiprtcResult cr = A.CompileProgram(prog, 3, opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t ls = 0; A.GetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0'); if (ls) A.GetProgramLog(prog, &log[0]);
+        if (log.size() > 4000) log.resize(4000);
+        err = "model '" + src.name + "' failed to compile:\n" + log;
+        A.DestroyProgram(&prog);
+        return HIPADJ_ERR_INVALID_ARG;
+    }
+    lowered.clear();
+    for (const auto& e : exprs) {
+        const char* low = nullptr;
+        if (A.GetLoweredName(prog, e.c_str(), &low) != HIPRTC_SUCCESS || !low) { err = "no lowered name for " + e; A.DestroyProgram(&prog); return HIPADJ_ERR_HIP; }
+        lowered[e] = low;
+    }
+    size_t cs = 0; A.GetCodeSize(prog, &cs);
+    code.assign(cs, 0); A.GetCode(prog, code.data());
+    A.DestroyProgram(&prog);
+    {
+        std::lock_guard<std::mutex> lk(R.mu);
+        R.code_cache[key] = code; R.lowered_cache[key] = lowered;
+    }
+    return HIPADJ_OK;
+}
+
+inline int user_register(const char* name, int32_t n, int32_t np, const char* f, const char* vu, const char* vp, int32_t* id, std::string& err) {
+    if (!name || !f || !vu || !vp || !id) { err = "hipadj_model_register: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+    if (n < 1 || n > 8 || np < 1 || np > 32) { err = "hipadj_model_register: need 1 <= n <= 8 and 1 <= np <= 32 (state and parameters live in VGPRs)"; return HIPADJ_ERR_INVALID_ARG; }
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    UserModelSrc m; m.name = name; m.n = n; m.np = np; m.f = f; m.vjp_u = vu; m.vjp_p = vp;
+    R.models.push_back(m);
+    *id = HIPADJ_MODEL_USER_BASE + (int32_t)R.models.size() - 1;
+    plan_user_sizes_hook() = &user_model_sizes;
+    return HIPADJ_OK;
+}
+
+}  // namespace hipadj

@@ -16,6 +16,19 @@ class Tsit5:
     reference's own tests (test/Core3/adjoint.jl:31-43).  Per-trajectory step sequences on the device."""
 
 
+class DeviceFunction:
+    """ODEFunction(f!; vjp, vjp_p) for the device (src/derivative_wrappers.jl:284-359, test/Core3/user_vjp.jl:77):
+    the three function BODIES as HIP C++ text over `du`/`out`, `u`, `p`, `lam`, `t` (all double), compiled at solve time
+    with hiprtc for gfx950.  Usable wherever a registered model name is: ODEProblem(DeviceFunction(...), u0, tspan, p)."""
+
+    def __init__(self, name, n, np, f, vjp, vjp_p, check=False):
+        self.name, self.n, self.np = name, int(n), int(np)
+        self.id = _lib.register_model(name, n, np, f, vjp, vjp_p, check=check)
+
+    def __repr__(self):
+        return f"DeviceFunction({self.name!r}, n={self.n}, np={self.np}, id={self.id})"
+
+
 @dataclass
 class ODEProblem:
     """ODEProblem(f, u0, tspan, p) with `f` a name from the device model registry (include/hipadj.h)."""
@@ -26,6 +39,8 @@ class ODEProblem:
     dims: tuple = (0, 0, 0, 0)
 
     def __post_init__(self):
+        if isinstance(self.f, DeviceFunction):
+            self.f = self.f.name
         if self.f not in _lib.MODEL:
             raise ValueError(f"unknown model {self.f!r}; registered: {sorted(_lib.MODEL)}")
         self.u0 = np.ascontiguousarray(self.u0, dtype=np.float64)

@@ -137,3 +137,36 @@ def test_shard_ranges_cover_the_ensemble(sa):
         assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
         sizes = [hi - lo for lo, hi in r]
         assert max(sizes) - min(sizes) <= 1
+
+
+# ---- runtime model ingestion (hipadj_model_register / hipadj_model_check): hiprtc compiles for gfx950 without a device
+def test_runtime_model_registration_compiles_for_gfx950_and_reports_errors():
+    import user_models as UM
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.ring(5)
+    mid = _lib.register_model("ring5_cpu_check", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"], check=True)
+    assert mid >= _lib.MODEL_USER_BASE and _lib.model_sizes("ring5_cpu_check") == (5, 6)
+    with pytest.raises(_lib.HipadjError, match="undeclared identifier"):
+        _lib.register_model("broken_rhs", 2, 2, "du[0] = nope; du[1] = 0.0;", "out[0] = 0.0; out[1] = 0.0;", "out[0] = 0.0; out[1] = 0.0;", check=True)
+    for n, npar in ((0, 1), (9, 1), (2, 0), (2, 33)):
+        with pytest.raises(_lib.HipadjError):
+            _lib.register_model("bad_dims", n, npar, "", "", "")
+
+
+def test_runtime_model_plans_like_a_lane_model():
+    """A registered model goes through the same planner: segmentation only while (1+n)(n+np) columns fit the registers."""
+    import emu as E
+    import user_models as UM
+    from scimlsensitivity_jl_amd import _lib
+    import ctypes as C
+    for n, expect_seg in ((4, True), (6, False)):
+        m = UM.ring(n)
+        _lib.register_model(f"ring{n}_plan", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+        cfg = E.make_config(f"ring{n}_plan", "interpolating", 64, 0.0, 10.0, 0.01, [10.0], loss_kind=1, time_segments=0)
+        L = _lib.load()
+        h = C.c_void_p()
+        rc = L.hipadj_create(C.byref(cfg), C.byref(h))
+        # no GPU in the CPU suite: planning succeeded iff the failure is NO_DEVICE (not INVALID_ARG / UNSUPPORTED)
+        assert rc in (_lib.OK, _lib.ERR_NO_DEVICE), L.hipadj_last_error(None)
+        if rc == _lib.OK:
+            L.hipadj_destroy(h)

@@ -525,3 +525,67 @@ def test_tsit5_max_steps_is_reported(sa):
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, 10.0), p), u0), sa.Tsit5(), saveat=[10.0],
                        sensealg=sa.InterpolatingAdjoint(), abstol=1e-10, reltol=1e-10, max_steps=50)
     assert e.value.status == -7
+
+
+# ---- runtime-registered models (hipadj_model_register -> hiprtc -> hipModuleLaunchKernel) -------------------------------
+import user_models as UM
+
+_registered = {}
+
+
+def _device_function(sa, name, m):
+    if name not in _registered:
+        _registered[name] = sa.DeviceFunction(name, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    return _registered[name]
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_runtime_lv_equals_builtin_lv(sa, alg, oalg):
+    """test/Core3/user_vjp.jl:77-113: the user-supplied f / vjp / vjp_p route must give what the built-in route gives."""
+    rng = np.random.default_rng(41)
+    N, T, dt = 130, 2.0, 0.01
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    ts = np.linspace(0, T, 21)
+    res = []
+    for f in ("lv", _device_function(sa, "lv_runtime", UM.LV)):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                       sensealg=sensealg_of(sa, alg), dgdu_discrete=sa.LsqShift(2.0))
+        res.append((sol.u,) + sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0)))
+        sol.engine.close()
+    for a, b in zip(res[0], res[1]):
+        assert rel(b, a) < 1e-13
+
+
+@pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring4", "RING", (4, 0, 0, 0)), ("ring6", "RING", (6, 0, 0, 0))])
+def test_runtime_models_match_oracle(sa, name, omodel, dims, alg, oalg, stepper):
+    """Models the library has never seen: Robertson kinetics (test/Core3/adjoint.jl:1434-1441, mild rates) and the synthetic
+    ring with n = 4 (time-segmented, prefetch depth 4) and n = 6 (too many columns to segment, depth 2)."""
+    if stepper == "tsit5" and alg == "quadrature":
+        pytest.skip("QuadratureAdjoint is not wired for the adaptive path")
+    m = UM.ROBER if name == "rober" else UM.ring(dims[0])
+    f = _device_function(sa, name + "_runtime", m)
+    rng = np.random.default_rng(43)
+    N, T, dt = 70, 2.0, 0.01
+    n, npar = m["n"], m["np"]
+    u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar))
+    ts = np.arange(0, T + 1e-9, 0.25)
+    delta = rng.standard_normal((N, len(ts), n))
+    ck = alg == "backsolve"
+    if stepper == "rk4":
+        salg, kw, okw = sa.RK4(), dict(dt=dt), dict(stepper="RK4", dt=dt)
+    else:
+        salg, kw, okw = sa.Tsit5(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), salg, saveat=ts, sensealg=sensealg_of(sa, alg), **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=delta)
+    ref = O.Problem(omodel, alg=oalg, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=ck, dims=dims, **okw)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+def test_runtime_model_compile_error_surfaces_at_solve(sa):
+    bad = sa.DeviceFunction("broken_at_solve", 2, 2, "du[0] = undefined_symbol; du[1] = 0.0;", "out[0] = 0.0; out[1] = 0.0;", "out[0] = 0.0; out[1] = 0.0;")
+    with pytest.raises(sa.HipadjError, match="failed to compile"):
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem(bad, np.ones(2), (0, 1.0), np.ones(2)), np.ones((4, 2))), sa.RK4(), dt=0.1, saveat=[1.0])

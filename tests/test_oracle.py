@@ -50,6 +50,20 @@ def test_model_vjps_match_finite_differences(model, u, p):
     assert np.allclose(dgrad, P.T @ lam, rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("model,dims", [("ROBER", (0, 0, 0, 0)), ("RING", (2, 0, 0, 0)), ("RING", (4, 0, 0, 0)), ("RING", (7, 0, 0, 0))])
+def test_checker_models_for_runtime_registration_vjps(model, dims):
+    """ORC_MODEL_ROBER (test/Core3/adjoint.jl:1434-1441) and the synthetic ring: the oracle side of the runtime-registered
+    device models (tests/user_models.py); hand VJPs against finite differences."""
+    rng = np.random.default_rng(2)
+    n, npar = O.model_sizes(model, dims)
+    u = rng.uniform(0.3, 1.2, n); p = rng.uniform(0.4, 1.5, npar); lam = rng.standard_normal(n)
+    dlam, dgrad = O.model_vjp(model, lam, u, p, 0.3, dims)
+    h = 1e-6
+    J = np.stack([(O.model_f(model, u + h * e, p, 0.3, dims) - O.model_f(model, u - h * e, p, 0.3, dims)) / (2 * h) for e in np.eye(n)], axis=1)
+    P = np.stack([(O.model_f(model, u, p + h * e, 0.3, dims) - O.model_f(model, u, p - h * e, 0.3, dims)) / (2 * h) for e in np.eye(npar)], axis=1)
+    assert np.allclose(dlam, J.T @ lam, rtol=1e-7, atol=1e-8) and np.allclose(dgrad, P.T @ lam, rtol=1e-7, atol=1e-8)
+
+
 def test_mlp_and_brusselator_vjps_match_finite_differences():
     rng = np.random.default_rng(0)
     for model, dims in (("MLP", (2, 5, 3, 0)), ("BRUSS", (4, 0, 0, 0))):

@@ -1,0 +1,27 @@
+"""HIP C++ bodies of the runtime-registered test models (hipadj_model_register) and their oracle counterparts.
+The oracle implements the same right-hand sides in C (ORC_MODEL_ROBER, ORC_MODEL_RING) as the checker."""
+
+ROBER = dict(  # Robertson kinetics `rober`, test/Core3/adjoint.jl:1434-1441
+    n=3, np=3,
+    f="du[0] = -p[0]*u[0] + p[2]*u[1]*u[2]; du[1] = p[0]*u[0] - p[1]*u[1]*u[1] - p[2]*u[1]*u[2]; du[2] = p[1]*u[1]*u[1];",
+    vjp=("out[0] = -p[0]*lam[0] + p[0]*lam[1];"
+         "out[1] = p[2]*u[2]*lam[0] + (-2.0*p[1]*u[1] - p[2]*u[2])*lam[1] + 2.0*p[1]*u[1]*lam[2];"
+         "out[2] = p[2]*u[1]*lam[0] - p[2]*u[1]*lam[1];"),
+    vjp_p=("out[0] = -u[0]*lam[0] + u[0]*lam[1]; out[1] = -u[1]*u[1]*lam[1] + u[1]*u[1]*lam[2];"
+           "out[2] = u[1]*u[2]*lam[0] - u[1]*u[2]*lam[1];"))
+
+
+def ring(n):
+    """synthetic ring: du_i = p_i (u_{i+1} - u_i) + p_n sin(u_{i-1}), indices mod n; np = n + 1"""
+    f = "".join(f"du[{i}] = p[{i}]*(u[{(i + 1) % n}] - u[{i}]) + p[{n}]*sin(u[{(i - 1) % n}]);" for i in range(n))
+    vjp = "".join(f"out[{j}] = -p[{j}]*lam[{j}] + p[{(j - 1) % n}]*lam[{(j - 1) % n}] + p[{n}]*cos(u[{j}])*lam[{(j + 1) % n}];" for j in range(n))
+    vjp_p = "".join(f"out[{k}] = lam[{k}]*(u[{(k + 1) % n}] - u[{k}]);" for k in range(n))
+    vjp_p += f"out[{n}] = " + " + ".join(f"lam[{k}]*sin(u[{(k - 1) % n}])" for k in range(n)) + ";"
+    return dict(n=n, np=n + 1, f=f, vjp=vjp, vjp_p=vjp_p)
+
+
+LV = dict(  # the built-in `lv` re-entered through the runtime path (test/Core3/user_vjp.jl:6-38)
+    n=2, np=4,
+    f="du[0] = p[0]*u[0] - p[1]*u[0]*u[1]; du[1] = -p[2]*u[1] + p[3]*u[0]*u[1];",
+    vjp="out[0] = (p[0] - p[1]*u[1])*lam[0] + p[3]*u[1]*lam[1]; out[1] = -p[1]*u[0]*lam[0] + (-p[2] + p[3]*u[0])*lam[1];",
+    vjp_p="const double xy = u[0]*u[1]; out[0] = u[0]*lam[0]; out[1] = -xy*lam[0]; out[2] = -u[1]*lam[1]; out[3] = xy*lam[1];")
