@@ -14,6 +14,14 @@
 // RMS of err/(abstol + max(|u0|,|u1|) reltol), PI exponents 7/50 and 2/25, gamma 0.9, q in [1/10, 5], tstop clipping
 // with a 100-eps snap), so that device and oracle take the same step sequences up to roundoff.
 //
+// Register / LDS plan (gfx950).  The seven stage derivatives of a step plus the step's start value (8 x NZ doubles per
+// lane) live in LDS as lane-private columns  ks[(row * NZ + i) * 64 + lane]  (consecutive lanes -> consecutive 8-byte
+// words: conflict-free ds_read_b64/ds_write_b64), NOT in VGPRs.  That lets the stage loop stay ROLLED: one instance of
+// the right-hand side (and of the forward-solution cursor inside it) instead of seven, tableau coefficients fetched with
+// scalar loads instead of ~60 FP64 literals parked in SGPR pairs.  The earlier fully unrolled register version needed
+// 256 VGPRs + up to 256 AGPRs + scratch for NZ >= 9 and produced wrong step sequences on the device for one size
+// (n = 4 Backsolve) although the same source is exact on the host; the rolled version needs far fewer registers.
+//
 // Layout of the forward dense solution (per trajectory a ragged list of accepted steps, trajectory-minor):
 //   rec[(s * RW + w) * Npad + i],  RW = 2 + 5 n :  w = 0 t_start, 1 t_end, then c_0..c_4 [5][n], the monomial form of the
 //   Tsit5 continuous extension on the step:  y(theta) = c_0 + theta (c_1 + theta (c_2 + theta (c_3 + theta c_4))),
@@ -35,7 +43,8 @@ struct AdaptGeom {
     int loss_kind, no_start, p_shared, cont_cost;
 };
 
-// Tsit5 coefficients (Tsitouras 2011); same values as oracle/adjoint_oracle.c (order conditions checked there)
+// Tsit5 coefficients (Tsitouras 2011); same values as oracle/adjoint_oracle.c (order conditions checked there).
+// Tables are indexed at run time (uniform indices -> scalar loads on the device).
 struct TS5 {
     static HIPADJ_HD double c(int i) { const double v[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0}; return v[i]; }
     static HIPADJ_HD double a(int i, int j) {
@@ -54,8 +63,9 @@ struct TS5 {
                              0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
         return v[i];
     }
-    static HIPADJ_HD void bweights(double th, double (&b)[7]) {
-        const double r[7][4] = {
+    // b_j(theta) = theta (r_j0 + theta (r_j1 + theta (r_j2 + theta r_j3))); r_j0 = 0 for j >= 1
+    static HIPADJ_HD double r(int j, int m) {
+        const double v[7][4] = {
             {1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216},
             {0.0, 0.13169999999999998, -0.2234, 0.1017},
             {0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253},
@@ -63,9 +73,10 @@ struct TS5 {
             {0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928},
             {0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661},
             {0.0, 1.5, -4.0, 2.5}};
-        b[0] = th * (r[0][0] + th * (r[0][1] + th * (r[0][2] + th * r[0][3])));
-#pragma unroll
-        for (int i = 1; i < 7; ++i) b[i] = th * th * (r[i][1] + th * (r[i][2] + th * r[i][3]));
+        return v[j][m];
+    }
+    static HIPADJ_HD double b(int j, double th) {
+        return j == 0 ? th * (r(0, 0) + th * (r(0, 1) + th * (r(0, 2) + th * r(0, 3)))) : th * th * (r(j, 1) + th * (r(j, 2) + th * r(j, 3)));
     }
 };
 
@@ -74,42 +85,44 @@ HIPADJ_HD double hmin2(double a, double b) { return a < b ? a : b; }
 HIPADJ_HD double habs(double a) { return a < 0 ? -a : a; }
 HIPADJ_HD bool time_hits(double t, double target) { return habs(t - target) <= 100.0 * 2.220446049250313e-16 * hmax2(habs(t), habs(target)); }
 
-// continuous extension of one Tsit5 step: y = u0 + h sum_i b_i(theta) k_i
-template <int NZ>
-HIPADJ_HD void tsit5_interp(double th, double h, const double (&u0)[NZ], const double (&k)[7][NZ], double (&y)[NZ]) {
-    double b[7]; TS5::bweights(th, b);
+// Stage storage of one lane: rows 0..6 = k_1..k_7 of the current step, row 7 = the step's start value.
+// Device: base = LDS array + lane, stride = 64.  Host emulation: a local array, stride 1.
+constexpr int KS_ROWS = 8, KS_UPREV = 7;
+template <int NZ> struct KStore {
+    double* base; int stride;
+    HIPADJ_HD double get(int row, int i) const { return base[(row * NZ + i) * stride]; }
+    HIPADJ_HD void set(int row, int i, double v) const { base[(row * NZ + i) * stride] = v; }
+};
+
+// y = u_start + h sum_j b_j(theta) k_j : the continuous extension of the step held in K (used for the lambda values at the
+// Gauss nodes; the forward solution is stored in monomial form instead, see tsit5_poly)
+template <int NZ, int NOUT>
+HIPADJ_HD void kstore_interp(const KStore<NZ>& K, double th, double h, double (&y)[NOUT]) {
 #pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-        double acc = 0.0;
+    for (int i = 0; i < NOUT; ++i) y[i] = 0.0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) acc += b[j] * k[j][i];
-        y[i] = u0[i] + h * acc;
+    for (int j = 0; j < 7; ++j) {
+        const double bj = TS5::b(j, th);
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) y[i] += bj * K.get(j, i);
     }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) y[i] = K.get(KS_UPREV, i) + h * y[i];
 }
 
-// monomial coefficients of the continuous extension of one accepted step (see the layout note above)
+// monomial coefficients of the continuous extension of the accepted step held in K (see the layout note above)
 template <int NZ>
-HIPADJ_HD void tsit5_poly(double h, const double (&u0)[NZ], const double (&k)[7][NZ], double (&c)[5][NZ]) {
-    const double r[7][4] = {
-        {1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216},
-        {0.0, 0.13169999999999998, -0.2234, 0.1017},
-        {0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253},
-        {0.0, -12.411077166933676, 30.33818863028232, -16.548102889244902},
-        {0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928},
-        {0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661},
-        {0.0, 1.5, -4.0, 2.5}};
+HIPADJ_HD void tsit5_poly(const KStore<NZ>& K, double h, double (&c)[5][NZ]) {
 #pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-        c[0][i] = u0[i];
-        c[1][i] = h * k[0][i];
+    for (int i = 0; i < NZ; ++i) { c[0][i] = K.get(KS_UPREV, i); c[1][i] = h * K.get(0, i); c[2][i] = 0.0; c[3][i] = 0.0; c[4][i] = 0.0; }
 #pragma unroll
-        for (int m = 1; m < 4; ++m) {
-            double acc = r[0][m] * k[0][i];
+    for (int j = 0; j < 7; ++j) {
+        const double r1 = TS5::r(j, 1), r2 = TS5::r(j, 2), r3 = TS5::r(j, 3);
 #pragma unroll
-            for (int j = 1; j < 7; ++j) acc += r[j][m] * k[j][i];
-            c[m + 1][i] = h * acc;
-        }
+        for (int i = 0; i < NZ; ++i) { const double kj = K.get(j, i); c[2][i] += r1 * kj; c[3][i] += r2 * kj; c[4][i] += r3 * kj; }
     }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) { c[2][i] *= h; c[3][i] *= h; c[4][i] *= h; }
 }
 template <int NZ>
 HIPADJ_HD void poly_eval(double th, const double (&c)[5][NZ], double (&y)[NZ]) {
@@ -117,48 +130,62 @@ HIPADJ_HD void poly_eval(double th, const double (&c)[5][NZ], double (&y)[NZ]) {
     for (int i = 0; i < NZ; ++i) y[i] = c[0][i] + th * (c[1][i] + th * (c[2][i] + th * (c[3][i] + th * c[4][i])));
 }
 
-// solve(prob, Tsit5(); abstol, reltol, dt, tstops, callback) for a small system held in registers.
-//   rhs(du, u, t); cb(t, tprev, u, uprev, k) is called after every accepted step (and once at the start when
-//   cb_at_init) and returns true when it modified u (=> the FSAL derivative is recomputed, derivative_discontinuity!).
-//   tstops: ntstops times sorted along the integration direction (entries not ahead of t are skipped).
+// solve(prob, Tsit5(); abstol, reltol, dt, tstops, callback) for a small system.
+//   rhs(du, u, t); cb(t, tprev, u, K) is called after every accepted step with the step's stages still in K (and once at
+//   the start when cb_at_init) and returns true when it modified u (=> the FSAL derivative is recomputed,
+//   derivative_discontinuity!).  tstops: ntstops times sorted along the integration direction.
 // Returns the number of accepted steps, or -1 when max_steps was exceeded.
 template <int NZ, class Rhs, class Cb>
 HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, double dt_hint, double abstol, double reltol,
-                              const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps, Rhs&& rhs, Cb&& cb) {
+                              const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps,
+                              const KStore<NZ>& K, Rhs&& rhs, Cb&& cb) {
     const double EPS = 2.220446049250313e-16;
     const double tdir = tend >= tstart ? 1.0 : -1.0;
     double t = tstart, tprev = tstart;
-    double uprev[NZ], k[7][NZ], fsal[NZ], tmp[NZ];
+    double w[NZ];
     if (cb_at_init) {
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) uprev[i] = u[i];
-        cb(t, tprev, u, uprev, k);
+        for (int i = 0; i < NZ; ++i) K.set(KS_UPREV, i, u[i]);
+        cb(t, tprev, u, K);
     }
-    rhs(fsal, u, t);
-    double dt;
-    if (dt_hint > 0) dt = tdir * dt_hint;
-    else {   // Hairer-Norsett-Wanner initial step
-        double d0 = 0, d1 = 0;
+#pragma unroll 1
+    for (int j = 1; j < 7; ++j)
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; d0 += (u[i] / sc) * (u[i] / sc); d1 += (fsal[i] / sc) * (fsal[i] / sc); }
-        d0 = sqrt(d0 / NZ); d1 = sqrt(d1 / NZ);
-        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-        h0 = hmin2(h0, habs(tend - t));
-        double u1[NZ], f1[NZ];
-#pragma unroll
-        for (int i = 0; i < NZ; ++i) u1[i] = u[i] + tdir * h0 * fsal[i];
-        rhs(f1, u1, t + tdir * h0);
-        double d2 = 0;
-#pragma unroll
-        for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; const double q = (f1[i] - fsal[i]) / sc; d2 += q * q; }
-        d2 = sqrt(d2 / NZ) / h0;
-        const double h1 = (hmax2(d1, d2) <= 1e-15) ? hmax2(1e-6, h0 * 1e-3) : pow(0.01 / hmax2(d1, d2), 1.0 / 5.0);
-        dt = tdir * hmin2(hmin2(100.0 * h0, h1), habs(tend - t));
-    }
-    double qold = 1e-4;
+        for (int i = 0; i < NZ; ++i) K.set(j, i, 0.0);
+    bool need_k0 = true, first = true;
+    double dt = 0.0, qold = 1e-4;
     int its = 0, naccept = 0, guard = 0;
+#pragma unroll 1
     while (tdir * t < tdir * tend) {
         if (++guard > 16 * max_steps + 64) return -1;
+        if (need_k0) {   // first step, or u was changed by a callback: k_1 = f(u, t)
+            rhs(w, u, t);
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) K.set(0, i, w[i]);
+            need_k0 = false;
+        }
+        if (first) {
+            first = false;
+            if (dt_hint > 0) dt = tdir * dt_hint;
+            else {   // Hairer-Norsett-Wanner initial step; w still holds f(u0)
+                double d0 = 0, d1 = 0;
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; d0 += (u[i] / sc) * (u[i] / sc); d1 += (w[i] / sc) * (w[i] / sc); }
+                d0 = sqrt(d0 / NZ); d1 = sqrt(d1 / NZ);
+                double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                h0 = hmin2(h0, habs(tend - t));
+                double u1[NZ], f1[NZ];
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) u1[i] = u[i] + tdir * h0 * w[i];
+                rhs(f1, u1, t + tdir * h0);
+                double d2 = 0;
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; const double q = (f1[i] - K.get(0, i)) / sc; d2 += q * q; }
+                d2 = sqrt(d2 / NZ) / h0;
+                const double h1 = (hmax2(d1, d2) <= 1e-15) ? hmax2(1e-6, h0 * 1e-3) : pow(0.01 / hmax2(d1, d2), 1.0 / 5.0);
+                dt = tdir * hmin2(hmin2(100.0 * h0, h1), habs(tend - t));
+            }
+        }
         // next stop: the first tstop strictly ahead of t (beyond the 100-eps snap), else tend
         while (its < ntstops && tdir * tstops[its] <= tdir * t + 100.0 * EPS * hmax2(habs(t), habs(tstops[its]))) ++its;
         double tstop = tend;
@@ -167,32 +194,51 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
         if (habs(h) > habs(tstop - t)) h = tstop - t;
         if (habs((t + h) - tstop) < 100.0 * EPS * hmax2(habs(t + h), habs(tstop))) h = tstop - t;
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) { uprev[i] = u[i]; k[0][i] = fsal[i]; }
-#pragma unroll
+        for (int i = 0; i < NZ; ++i) K.set(KS_UPREV, i, u[i]);
+        // Stage loop, rolled: ONE instance of rhs (and of the forward-solution cursor inside it).  The whole zero-padded
+        // tableau row arrives in one batch of scalar loads, then a straight-line 6-term sum: rows j >= s of K hold finite
+        // leftovers that the zero coefficients annihilate (non-finite leftovers are cleared when a step is rejected,
+        // below).  Summation order j = 0, 1, ... is the oracle's.  (Measured alternative: forming the next stage's partial
+        // sum next to rhs to hide the LDS round trip costs 9 x NZ extra FMAs per step and is 8 % slower — with one wave
+        // per CU at N = 10^4 this loop is bound by instruction count, not by latency.)
+#pragma unroll 1
         for (int s = 1; s < 7; ++s) {
 #pragma unroll
-            for (int i = 0; i < NZ; ++i) {
-                double acc = 0.0;
+            for (int i = 0; i < NZ; ++i) w[i] = 0.0;
+            {
+                double as[6];
 #pragma unroll
-                for (int j = 0; j < s; ++j) acc += TS5::a(s, j) * k[j][i];
-                tmp[i] = uprev[i] + h * acc;
-            }
-            if (s < 6) rhs(k[s], tmp, t + TS5::c(s) * h);
-            else {
+                for (int j = 0; j < 6; ++j) as[j] = TS5::a(s, j);
 #pragma unroll
-                for (int i = 0; i < NZ; ++i) u[i] = tmp[i];
-                rhs(k[6], u, t + h);
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) w[i] += as[j] * K.get(j, i);
             }
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) w[i] = K.get(KS_UPREV, i) + h * w[i];
+            double ks[NZ];
+            rhs(ks, w, t + TS5::c(s) * h);
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) K.set(s, i, ks[i]);
         }
+        // w = u_{n+1} (the seventh stage state is the 5th-order solution), K row 6 = f(u_{n+1}) (FSAL)
         double e2 = 0.0;
+        {
+            double err[NZ];
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) {
-            double acc = 0.0;
+            for (int i = 0; i < NZ; ++i) err[i] = 0.0;
 #pragma unroll
-            for (int j = 0; j < 7; ++j) acc += TS5::bt(j) * k[j][i];
-            const double sc = abstol + hmax2(habs(uprev[i]), habs(u[i])) * reltol;
-            const double q = h * acc / sc;
-            e2 += q * q;
+            for (int j = 0; j < 7; ++j) {
+                const double btj = TS5::bt(j);
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) err[i] += btj * K.get(j, i);
+            }
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) {
+                const double sc = abstol + hmax2(habs(K.get(KS_UPREV, i)), habs(w[i])) * reltol;
+                const double q = h * err[i] / sc;
+                e2 += q * q;
+            }
         }
         const double EEst = sqrt(e2 / NZ);
         const double q11 = pow(hmax2(EEst, 1e-300), 7.0 / 50.0);
@@ -203,16 +249,24 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             if (habs(tnew - tstop) < 100.0 * EPS * hmax2(habs(tnew), habs(tstop))) tnew = tstop;
             qold = hmax2(EEst, 1e-4);
 #pragma unroll
-            for (int i = 0; i < NZ; ++i) fsal[i] = k[6][i];
+            for (int i = 0; i < NZ; ++i) u[i] = w[i];
             tprev = t; t = tnew; ++naccept;
             dt = h / q;
             if (habs(dt) < 1e-14 * hmax2(1.0, habs(tnew))) dt = tdir * 1e-14 * hmax2(1.0, habs(tnew));
-            if (cb(t, tprev, u, uprev, k)) rhs(fsal, u, t);
+            if (cb(t, tprev, u, K)) need_k0 = true;
+            else {
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) K.set(0, i, K.get(6, i));   // FSAL
+            }
             if (naccept > max_steps) return -1;
         } else {
+            dt = h / hmin2(5.0, q11 / 0.9);   // u still holds the step's start value
+            if (!(EEst < 1e300)) {            // overflowed stage derivatives must not meet the zero padding of the tableau rows
+#pragma unroll 1
+                for (int j = 1; j < 7; ++j)
 #pragma unroll
-            for (int i = 0; i < NZ; ++i) u[i] = uprev[i];
-            dt = h / hmin2(5.0, q11 / 0.9);
+                    for (int i = 0; i < NZ; ++i) K.set(j, i, 0.0);
+            }
         }
     }
     return naccept;
@@ -224,8 +278,9 @@ template <class Mo>
 HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __restrict__ u0, const double* __restrict__ p,
                                   double* __restrict__ rec, int* __restrict__ nsteps, const double* __restrict__ save_t,
                                   double* __restrict__ outT, const double* __restrict__ ck_t, double* __restrict__ ckpt,
-                                  double* __restrict__ yT, int* __restrict__ flag) {
+                                  double* __restrict__ yT, int* __restrict__ flag, double* kbase, int kstride) {
     constexpr int N = Mo::N, RW = 2 + 5 * N;
+    const KStore<N> K{kbase, kstride};
     double pv[Mo::NP];
 #pragma unroll
     for (int j = 0; j < Mo::NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * Mo::NP + j];
@@ -243,11 +298,11 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
         for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = u[j];
         ++mc; }
-    const int na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.Smax,
+    const int na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.Smax, K,
         [&](double (&du)[N], const double (&uu)[N], double t) { Mo::f(du, uu, pv, t); },
-        [&](double t, double tprev, double (&un)[N], const double (&up)[N], const double (&k)[7][N]) -> bool {
+        [&](double t, double tprev, double (&un)[N], const KStore<N>& KK) -> bool {
             const double h = t - tprev;
-            double c[5][N]; tsit5_poly<N>(h, up, k, c);
+            double c[5][N]; tsit5_poly<N>(KK, h, c);
             if (s < g.Smax) {
                 if (rec) {
                     rec[((long)s * RW + 0) * g.Npad + i] = tprev; rec[((long)s * RW + 1) * g.Npad + i] = t;
@@ -301,10 +356,7 @@ template <class Mo> struct FwdCursor {
         while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[((long)sc * RW + 1) * Npad + i]; }
         if (sc != lc) {
             lc = sc;
-            long base = ((long)sc * RW + 2) * Npad + i;
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(base));   // keep the 5 n addresses local to this load (no hoisting across the unrolled stages)
-#endif
+            const long base = ((long)sc * RW + 2) * Npad + i;
 #pragma unroll
             for (int m = 0; m < 5; ++m)
 #pragma unroll
@@ -315,12 +367,16 @@ template <class Mo> struct FwdCursor {
 };
 
 // reverse sweeps.  ALG: 0 Interpolating (z = [lam; mu]), 1 Backsolve (z = [lam; mu; y]), 2 Gauss (z = lam, mu by quadrature)
+template <class Mo, int ALG> struct AdjNZ { static constexpr int value = ALG == 0 ? Mo::N + Mo::NP : (ALG == 1 ? 2 * Mo::N + Mo::NP : Mo::N); };
+
 template <class Mo, int ALG, int CC>
 HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __restrict__ p, const double* __restrict__ rec,
                                   const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
                                   const double* __restrict__ ck_t, const double* __restrict__ save_t, const double* __restrict__ tstops_desc,
-                                  int ntstops, const double* __restrict__ cotT, double (&lam_out)[Mo::N], double (&mu_out)[Mo::NP], int* __restrict__ flag) {
-    constexpr int N = Mo::N, NP = Mo::NP, NZ = ALG == 0 ? N + NP : (ALG == 1 ? 2 * N + NP : N);
+                                  int ntstops, const double* __restrict__ cotT, double (&lam_out)[Mo::N], double (&mu_out)[Mo::NP], int* __restrict__ flag,
+                                  double* kbase, int kstride) {
+    constexpr int N = Mo::N, NP = Mo::NP, NZ = AdjNZ<Mo, ALG>::value;
+    const KStore<NZ> K{kbase, kstride};
     double pv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
@@ -361,22 +417,21 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             for (int j = 0; j < N; ++j) dz[N + NP + j] = f[j];
         }
     };
-    auto cb = [&](double t, double tprev, double (&zz)[NZ], const double (&zp)[NZ], const double (&k)[7][NZ]) -> bool {
+    auto cb = [&](double t, double tprev, double (&zz)[NZ], const KStore<NZ>& KK) -> bool {
         bool mod = false;
         if (ALG == 2 && t != tprev) {   // IntegratingSumCallback: 3-point Gauss-Legendre of -(df/dp)^T lam on [tprev, t]
-            const double xg[3] = {-0.7745966692414833770, 0.0, 0.7745966692414833770}, wg[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
             const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;
-#pragma unroll
+#pragma unroll 1
             for (int q = 0; q < 3; ++q) {
-                const double tt = half * xg[q] + mid;
-                double lg[NZ], y[N], W[NP], lamq[N];
-                tsit5_interp<NZ>((tt - tprev) / h, h, zp, k, lg);
-#pragma unroll
-                for (int j = 0; j < N; ++j) lamq[j] = lg[j];
+                const double xq = q == 0 ? -0.7745966692414833770 : (q == 1 ? 0.0 : 0.7745966692414833770);
+                const double wq = q == 1 ? 8.0 / 9.0 : 5.0 / 9.0;
+                const double tt = half * xq + mid;
+                double y[N], W[NP], lamq[N];
+                kstore_interp<NZ, N>(KK, (tt - tprev) / h, h, lamq);
                 cur.eval(tt, y);
                 Mo::vjp_p(W, lamq, y, pv, tt);
 #pragma unroll
-                for (int j = 0; j < NP; ++j) gacc[j] += half * wg[q] * (-W[j]);
+                for (int j = 0; j < NP; ++j) gacc[j] += half * wq * (-W[j]);
             }
         }
         if (ALG == 1 && ckpt && bs_cur >= 1 && time_hits(t, ck_t[bs_cur - 1])) {   // backsolve_checkpoint_callbacks
@@ -395,13 +450,13 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 for (int j = 0; j < N; ++j)
                     zz[j] += (g.loss_kind == 0) ? cotT[((long)(cur_time - 1) * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
                 mod = true;
-            } else mod = false;
+            }
             --cur_time;
         }
         return mod;
     };
     const bool cb_at_init = g.M > 0 && time_hits(g.t1, save_t[g.M - 1]);
-    const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.Smax, rhs, cb);
+    const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.Smax, K, rhs, cb);
 #pragma unroll
     for (int j = 0; j < N; ++j) lam_out[j] = z[j];
 #pragma unroll
@@ -417,15 +472,17 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 // one lane = one trajectory; lanes of a wave take their own step sequences (accept/reject and the cursor walks
-// diverge under the exec mask), a wave retires when its slowest trajectory does
+// diverge under the exec mask), a wave retires when its slowest trajectory does.  Stage storage: 8 x NZ x 64 doubles
+// of LDS per wave (NZ = 6: 24.5 KB => 6 waves per CU).
 template <class Mo>
 __global__ void __launch_bounds__(64) k_forward_tsit5(AdaptGeom g, const double* __restrict__ u0, const double* __restrict__ p,
                                                       double* __restrict__ rec, int* __restrict__ nsteps, const double* __restrict__ save_t,
                                                       double* __restrict__ outT, const double* __restrict__ ck_t, double* __restrict__ ckpt,
                                                       double* __restrict__ yT, int* __restrict__ flag) {
+    __shared__ double ks[KS_ROWS * Mo::N * 64];
     const long i = (long)blockIdx.x * 64 + threadIdx.x;
     if (i >= g.N) return;
-    forward_tsit5_lane<Mo>(g, i, u0, p, rec, nsteps, save_t, outT, ck_t, ckpt, yT, flag);
+    forward_tsit5_lane<Mo>(g, i, u0, p, rec, nsteps, save_t, outT, ck_t, ckpt, yT, flag, ks + threadIdx.x, 64);
 }
 
 template <class Mo, int ALG, int CC>
@@ -434,10 +491,11 @@ __global__ void __launch_bounds__(64) k_adjoint_tsit5(AdaptGeom g, const double*
                                                       const double* __restrict__ ck_t, const double* __restrict__ save_t,
                                                       const double* __restrict__ tstops_desc, int ntstops, const double* __restrict__ cotT,
                                                       double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    __shared__ double ks[KS_ROWS * AdjNZ<Mo, ALG>::value * 64];
     const long i = (long)blockIdx.x * 64 + threadIdx.x;
     if (i >= g.N) return;
     double lam[Mo::N], mu[Mo::NP];
-    adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec, nsteps, yT, ckpt, ck_t, save_t, tstops_desc, ntstops, cotT, lam, mu, flag);
+    adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec, nsteps, yT, ckpt, ck_t, save_t, tstops_desc, ntstops, cotT, lam, mu, flag, ks + threadIdx.x, 64);
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) du0[i * Mo::N + j] = lam[j];
 #pragma unroll

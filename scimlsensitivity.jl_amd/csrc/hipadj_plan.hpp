@@ -110,6 +110,10 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
         if (cfg->cont_cost != HIPADJ_CCOST_NONE && cfg->cont_cost != HIPADJ_CCOST_HALF_SQ_SUM) { err = "unknown cont_cost"; return HIPADJ_ERR_INVALID_ARG; }
         if (cfg->max_steps < 0) { err = "max_steps must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
+        {   // the 8 x NZ stage rows of a wave live in LDS (hipadj_adaptive.hpp): 8 * NZ * 64 lanes * 8 B <= 160 KB
+            const int NZ = cfg->alg == HIPADJ_ALG_INTERPOLATING ? n + np : (cfg->alg == HIPADJ_ALG_BACKSOLVE ? 2 * n + np : n);
+            if (8L * NZ * 64 * 8 > 160L * 1024) { err = "adaptive Tsit5: augmented state too large for the LDS stage storage (need 8 * NZ * 512 B <= 160 KB)"; return HIPADJ_ERR_UNSUPPORTED; }
+        }
         P.adaptive = true; P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = 0; P.M = cfg->nsave;
         P.Smax = cfg->max_steps > 0 ? cfg->max_steps : 2048;
         P.save_times.assign(cfg->save_times, cfg->save_times + cfg->nsave);

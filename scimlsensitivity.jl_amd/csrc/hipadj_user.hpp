@@ -147,8 +147,10 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
     hiprtcProgram prog = nullptr;
     if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", 4, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
     for (const auto& e : exprs) A.AddNameExpression(prog, e.c_str());
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    const hiprtcResult cr = A.CompileProgram(prog, 3, opts);
+    std::vector<std::string> optv = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    if (const char* e = std::getenv("HIPADJ_RTC_FLAGS")) { std::istringstream is(e); std::string w; while (is >> w) optv.push_back(w); }   // tuning / debugging hook
+    std::vector<const char*> opts; for (const auto& o : optv) opts.push_back(o.c_str());
+    const hiprtcResult cr = A.CompileProgram(prog, (int)opts.size(), opts.data());
     if (cr != HIPRTC_SUCCESS) {
         size_t ls = 0; A.GetProgramLogSize(prog, &ls);
         std::string log(ls, '\0'); if (ls) A.GetProgramLog(prog, &log[0]);

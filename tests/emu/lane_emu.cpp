@@ -157,9 +157,10 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
     std::vector<int> nsteps((size_t)Np, 0);
     int flag = 0;
+    std::vector<double> kbuf((size_t)KS_ROWS * (2 * N + NP));   // stage storage of one lane (LDS columns on the device), stride 1 here
     for (long i = 0; i < P.N; ++i)
         forward_tsit5_lane<Mo>(g, i, u0, p, rec.empty() ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(),
-                               P.ck_times.data(), ckpt.empty() ? nullptr : ckpt.data(), yT.data(), &flag);
+                               P.ck_times.data(), ckpt.empty() ? nullptr : ckpt.data(), yT.data(), &flag, kbuf.data(), 1);
     if (nsteps_out) for (long i = 0; i < P.N; ++i) nsteps_out[i] = nsteps[i];
     if (flag & 4) return HIPADJ_ERR_MAXITERS;
     if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
@@ -167,7 +168,7 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     for (long i = 0; i < P.N; ++i) {
         double lam[N], mu[NP];
         adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec.data(), nsteps.data(), yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ck_times.data(),
-                                        P.save_times.data(), P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), lam, mu, &flag);
+                                        P.save_times.data(), P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), lam, mu, &flag, kbuf.data(), 1);
         for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
         for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
     }
