@@ -69,10 +69,14 @@ typedef enum {
     HIPADJ_LOSS_LSQ_SHIFT = 1  /* out = u - loss_shift — test/Core3/adjoint.jl:49-51, 1169-1172; fused in-kernel */
 } hipadj_loss;
 
-/* registry of continuous costs (device-inlined dgdu_continuous / dgdp_continuous) */
+/* continuous costs g(u, p, t) with device-inlined dgdu_continuous / dgdp_continuous
+ * (accumulate_cost!, src/derivative_wrappers.jl:1411-1442; AdjointSensitivityIntegrand `out .+= dgdp`, src/quadrature_adjoint.jl:497-500).
+ * GaussAdjoint is offered for costs without a parameter term only: no reference test covers its `+dgdp` (src/gauss_adjoint.jl:755-758). */
 typedef enum {
     HIPADJ_CCOST_NONE = 0,
-    HIPADJ_CCOST_HALF_SQ_SUM = 1  /* g = (sum(u))^2 / 2, dgdu = sum(u) in every component, dgdp = 0 (test/Core3/adjoint.jl:913-919) */
+    HIPADJ_CCOST_HALF_SQ_SUM = 1, /* g = (sum(u))^2 / 2, dgdu = sum(u) in every component, dgdp = 0 (test/Core3/adjoint.jl:913-919) */
+    HIPADJ_CCOST_U1SQ_PLUS_P1 = 2,/* g = u[1]^2 + p[1], dgdu = [2 u1, 0, ...], dgdp = [1, 0, ...] (test/Core7/mixed_costs.jl:46-57) */
+    HIPADJ_CCOST_MODEL = 3        /* the cost attached to a runtime-registered model with hipadj_model_set_cost */
 } hipadj_cont_cost;
 
 typedef struct {
@@ -135,6 +139,10 @@ int hipadj_model_sizes(int32_t model, const int32_t dims[4], int32_t *n, int32_t
  * for the lifetime of the process; registering the same name again replaces the sources (new id). */
 int hipadj_model_register(const char *name, int32_t n, int32_t np, const char *f_body, const char *vjp_u_body,
                           const char *vjp_p_body, int32_t *model_id);
+/* Attaches a continuous cost to a runtime-registered model — dgdu_continuous / dgdp_continuous of adjoint_sensitivities
+ * (src/sensitivity_interface.jl:373-526): dgdu_body writes out[0..n) = dg/du, dgdp_body writes out[0..np) = dg/dp from u, p, t.
+ * Selected per handle with cont_cost = HIPADJ_CCOST_MODEL. */
+int hipadj_model_set_cost(int32_t model_id, const char *dgdu_body, const char *dgdp_body);
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
  * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
 int hipadj_model_check(int32_t model_id);

@@ -632,12 +632,22 @@ static void fetch_y(adj_ctx *A, double t) {
     dense_eval(&A->cpsol, t, A->y, &A->cphint);
 }
 
-/* accumulate_cost!(dlam, y, p, t, S, dgrad)  src/derivative_wrappers.jl:1411-1442: dlam -= g_u(y,p,t) (dgrad -= g_p: zero for
- * the registered cost).  Called when the cost has a continuous part (`discrete ||` guard, interpolating_adjoint.jl:172). */
-static void accumulate_cost(const adj_ctx *A, double *dlam) {
+/* accumulate_cost!(dlam, y, p, t, S, dgrad)  src/derivative_wrappers.jl:1411-1442: dlam -= g_u(y,p,t); dgrad -= g_p(y,p,t) when
+ * the caller hands a parameter block (Interpolating :172, Backsolve :59; Quadrature/Gauss pass none and add g_p in their
+ * integrands).  Called when the cost has a continuous part (`discrete ||` guard, interpolating_adjoint.jl:172).
+ *   cont_cost 1:  g = (sum u)^2 / 2           dgdu_j = sum(u), dgdp = 0        (test/Core3/adjoint.jl:913-919)
+ *   cont_cost 2:  g = u_1^2 + p_1             dgdu = [2 u_1, 0, ...], dgdp = [1, 0, ...]   (test/Core7/mixed_costs.jl:46-57) */
+static void cost_grad_p(const adj_ctx *A, double *gp) {
+    for (int i = 0; i < A->np; ++i) gp[i] = 0.0;
+    if (A->cfg->cont_cost == 2) gp[0] = 1.0;
+}
+static void accumulate_cost(const adj_ctx *A, double *dlam, double *dgrad) {
     if (A->cfg->cont_cost == 1) {
         double s = 0; for (int i = 0; i < A->n; ++i) s += A->y[i];
         for (int i = 0; i < A->n; ++i) dlam[i] -= s;
+    } else if (A->cfg->cont_cost == 2) {
+        dlam[0] -= 2.0 * A->y[0];
+        if (dgrad) dgrad[0] -= 1.0;
     }
 }
 
@@ -649,7 +659,7 @@ static void rhs_interpolating(double *dz, const double *z, double t, void *c) {
     model_vjp(A->m, dz, dz + n, z, A->y, A->p, t);           /* vecjacobian!(dlam, y, lam, p, t, S; dgrad) */
     for (int i = 0; i < n; ++i) dz[i] *= -1.0;               /* :169 */
     for (int i = 0; i < np; ++i) dz[n + i] *= -1.0;          /* :170 */
-    accumulate_cost(A, dz);                                  /* :172 */
+    accumulate_cost(A, dz, dz + n);                          /* :172 */
 }
 /* (S::ODEBacksolveSensitivityFunction)(du,u,p,t)  src/backsolve_adjoint.jl:32-61 ; z = [lam; grad; y] (:78-120) */
 static void rhs_backsolve(double *dz, const double *z, double t, void *c) {
@@ -658,7 +668,7 @@ static void rhs_backsolve(double *dz, const double *z, double t, void *c) {
     model_vjp(A->m, dz, dz + n, z, A->y, A->p, t);
     model_f(A->m, dz + n + np, A->y, A->p, t);                /* dy = f(y,p,t), not negated :54 */
     for (int i = 0; i < n + np; ++i) dz[i] *= -1.0;
-    accumulate_cost(A, dz);                                   /* :59 */
+    accumulate_cost(A, dz, dz + n);                           /* :59 */
 }
 /* Quadrature / Gauss: u = lam only (src/quadrature_adjoint.jl:35-46, src/gauss_adjoint.jl:118-128) */
 static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
@@ -666,7 +676,7 @@ static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
     fetch_y(A, t);
     model_vjp(A->m, dz, NULL, z, A->y, A->p, t);
     for (int i = 0; i < n; ++i) dz[i] *= -1.0;
-    accumulate_cost(A, dz);                                   /* quadrature_adjoint.jl:44, gauss_adjoint.jl:126 */
+    accumulate_cost(A, dz, NULL);                             /* quadrature_adjoint.jl:44, gauss_adjoint.jl:126 */
 }
 
 static int time_hits(double t, double target) { return fabs(t - target) <= 100 * DBL_EPSILON * fmax(fabs(t), fabs(target)); }
@@ -810,12 +820,17 @@ double orc_test_quadgk_poly(int degree, double a, double b, double atol, double 
 }
 
 /* AdjointSensitivityIntegrand (src/quadrature_adjoint.jl:486-502): y = sol(t), lam = adj_sol(t), out = f_p^T lam */
+#define ORC_MAXNP_COST 64
 typedef struct { adj_ctx *A; const orc_dense *adj; long hint; double *lam; } quad_ctx;
 static void quad_integrand(double *out, double t, void *c) {
     quad_ctx *Q = (quad_ctx *)c; adj_ctx *A = Q->A;
     fetch_y(A, t);
     dense_eval(Q->adj, t, Q->lam, &Q->hint);
     model_vjp(A->m, NULL, out, Q->lam, A->y, A->p, t);
+    if (A->cfg->cont_cost == 2) {                                /* out .+= dgdp_cache  (:497-500) */
+        double gp[ORC_MAXNP_COST]; cost_grad_p(A, gp);
+        for (int i = 0; i < A->np; ++i) out[i] += gp[i];
+    }
 }
 
 /* =====================================================================================
@@ -826,6 +841,12 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
                        double *du0, double *dp, double *out, long *nrhs, double *t_fwd, double *t_rev) {
     int n = m->n, np = m->np, M = cfg->nsave;
     struct timespec c0, c1, c2;
+    if (cfg->cont_cost < 0 || cfg->cont_cost > 2) return -6;
+    /* GaussIntegrand adds +dgdp to the NEGATED f_p^T lam (src/gauss_adjoint.jl:755-758) while the sum runs backward in time;
+     * no reference test covers Gauss with dgdp_continuous (test/Core7/mixed_costs.jl, adjoint_param.jl use Backsolve /
+     * Interpolating / Quadrature), so the sign is not restated here */
+    if (cfg->cont_cost == 2 && cfg->alg == ORC_ALG_GAUSS) return -6;
+    if (cfg->cont_cost == 2 && np > ORC_MAXNP_COST) return -6;
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
     orc_dense sol; double *uend = (double *)malloc(sizeof(double) * n); memcpy(uend, u0, sizeof(double) * n);

@@ -7,7 +7,8 @@ from ._lib import HipadjError, model_sizes, load as load_library, LIB_PATH
 from .sensitivity_algorithms import (AbstractSensitivityAlgorithm, AbstractAdjointSensitivityAlgorithm, DeviceVJP,
                                      InterpolatingAdjoint, BacksolveAdjoint, QuadratureAdjoint, GaussAdjoint,
                                      ischeckpointing)
-from .problems import RK4, Tsit5, DeviceFunction, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum
+from .problems import (RK4, Tsit5, DeviceFunction, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum,
+                       FirstStateSquaredPlusFirstParam, ModelCost)
 from .engine import Engine
 from .interface import solve, adjoint_sensitivities, concrete_solve_adjoint, make_autograd_function
 from .distributed import shard_range, allreduce_dp, gather_du0
@@ -19,6 +20,6 @@ __all__ = [
     "HipadjError", "model_sizes", "load_library", "LIB_PATH", "AbstractSensitivityAlgorithm",
     "AbstractAdjointSensitivityAlgorithm", "DeviceVJP", "InterpolatingAdjoint", "BacksolveAdjoint",
     "QuadratureAdjoint", "GaussAdjoint", "ischeckpointing", "RK4", "Tsit5", "DeviceFunction", "ODEProblem", "EnsembleProblem",
-    "EnsembleSolution", "LsqShift", "HalfSquaredSum", "Engine", "solve", "adjoint_sensitivities", "concrete_solve_adjoint",
+    "EnsembleSolution", "LsqShift", "HalfSquaredSum", "FirstStateSquaredPlusFirstParam", "ModelCost", "Engine", "solve", "adjoint_sensitivities", "concrete_solve_adjoint",
     "make_autograd_function", "shard_range", "allreduce_dp", "gather_du0", "build_extension",
 ]

@@ -12,13 +12,13 @@ MODEL_USER_BASE = 1000
 MODEL = dict(lv=0, lvt=1, lorenz=2, lindiag=3, fallmass=4, mlp=5, bruss=6)
 ALG = dict(interpolating=0, backsolve=1, gauss=2, quadrature=3)
 LOSS_COTANGENT, LOSS_LSQ_SHIFT = 0, 1
-CCOST_NONE, CCOST_HALF_SQ_SUM = 0, 1
+CCOST_NONE, CCOST_HALF_SQ_SUM, CCOST_U1SQ_PLUS_P1, CCOST_MODEL = 0, 1, 2, 3
 
 DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_model_check",
+    "hipadj_model_register", "hipadj_model_check", "hipadj_model_set_cost",
 )
 
 
@@ -93,6 +93,7 @@ def load():
     L.hipadj_get_stats.argtypes = [vp, C.POINTER(HipadjStats)]
     L.hipadj_model_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
     L.hipadj_model_check.argtypes = [C.c_int32]
+    L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     _lib = L
     return L
 
@@ -119,3 +120,11 @@ def register_model(name, n, npar, f, vjp, vjp_p, check=False):
             raise HipadjError(rc, L.hipadj_last_error(None).decode())
     MODEL[name] = mid.value
     return mid.value
+
+
+def set_model_cost(model_id, dgdu, dgdp):
+    """hipadj_model_set_cost: attach dgdu_continuous / dgdp_continuous bodies to a runtime-registered model."""
+    L = load()
+    rc = L.hipadj_model_set_cost(int(model_id), dgdu.encode(), dgdp.encode())
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())

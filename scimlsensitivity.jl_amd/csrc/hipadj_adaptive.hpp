@@ -403,11 +403,16 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             for (int j = 0; j < N; ++j) y[j] = zz[N + NP + j];
         } else cur.eval(t, y);
         Mo::vjp_u(dl, lam, y, pv, t);
-        double gu[N]; cost_grad_u<Mo, CC>(y, gu);
+        double gu[N]; cost_grad_u<Mo, CC>(y, pv, t, gu);
 #pragma unroll
         for (int j = 0; j < N; ++j) dz[j] = -dl[j] - gu[j];
         if (ALG != 2) {
             Mo::vjp_p(dg, lam, y, pv, t);
+            if (cost_has_gp<CC>::value) {   // dgrad -= g_p
+                double gp[NP]; cost_grad_p<Mo, CC>(y, pv, t, gp);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) dg[j] += gp[j];
+            }
 #pragma unroll
             for (int j = 0; j < NP; ++j) dz[N + j] = -dg[j];
         }

@@ -107,9 +107,14 @@ extern "C" int hipadj_model_register(const char* name, int32_t n, int32_t np, co
     return user_register(name, n, np, f_body, vjp_u_body, vjp_p_body, model_id, g_create_error);
 }
 
+extern "C" int hipadj_model_set_cost(int32_t model_id, const char* dgdu_body, const char* dgdp_body) {
+    return user_set_cost(model_id, dgdu_body, dgdp_body, g_create_error);
+}
+
 extern "C" int hipadj_model_check(int32_t model_id) {
     std::vector<char> code; std::map<std::string, std::string> low;
-    return user_compile(model_id, {"hipadj::k_forward<hipadj::UserModel>", "hipadj::k_interp<hipadj::UserModel, 2, 1>"}, code, low, g_create_error);
+    return user_compile(model_id, {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 2, 7>" : "hipadj::k_interp<hipadj::UserModel, 2, 1>"},
+                        code, low, g_create_error);
 }
 
 #define TRY(expr) do { int _rc = (expr); if (_rc != HIPADJ_OK) return _rc; } while (0)
@@ -259,6 +264,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->st.adjoint_algorithmic_bytes = bytes;
     h->st.vjp_steps = (double)h->N * (double)S * 4.0;
     h->user = P.user;
+    if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { h->err = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost)"; return fail(HIPADJ_ERR_INVALID_ARG); }
     if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
     *out = h;
     return HIPADJ_OK;
@@ -394,7 +400,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                            d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
         break; }
-    case HIPADJ_ALG_GAUSS: {
+    case HIPADJ_ALG_GAUSS: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt)
             hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
@@ -414,7 +420,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-        hipLaunchKernelGGL((k_quad_gk<Mo>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
+        hipLaunchKernelGGL((k_quad_gk<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
                            (const dbl2*)h->d_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
         HIP_TRY(h, hipGetLastError());
         hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
@@ -439,12 +445,15 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
 
 template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     // no loss times => no cotangent buffer exists: run the LSQ specialisation (its jump select is never taken)
-    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
+    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);   // MODE = loss | cost << 1
     switch (mode) {
     case 0: return adjoint_impl_l<Mo, 0>(h, d_cot, d_du0, d_dp);
     case 1: return adjoint_impl_l<Mo, 1>(h, d_cot, d_du0, d_dp);
     case 2: return adjoint_impl_l<Mo, 2>(h, d_cot, d_du0, d_dp);
-    default: return adjoint_impl_l<Mo, 3>(h, d_cot, d_du0, d_dp);
+    case 3: return adjoint_impl_l<Mo, 3>(h, d_cot, d_du0, d_dp);
+    case 4: return adjoint_impl_l<Mo, 4>(h, d_cot, d_du0, d_dp);
+    case 5: return adjoint_impl_l<Mo, 5>(h, d_cot, d_du0, d_dp);
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "cont_cost %d is not available for compiled-in models", h->cfg.cont_cost);
     }
 }
 
@@ -585,7 +594,7 @@ struct UserKernels { std::string forward, main_k, tail, gk; };
 static UserKernels user_kernel_names(const hipadj_handle* h) {
     const std::string U = "hipadj::UserModel";
     const int n = h->n, np = h->np;
-    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
+    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);
     const int cc = mode >> 1;
     const int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : (n <= 5 ? 4 : 2), PFG = n <= 3 ? 4 : 2;
     auto I = [](int v) { return std::to_string(v); };
@@ -602,7 +611,7 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     case HIPADJ_ALG_INTERPOLATING: k.main_k = "hipadj::k_interp<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.tail = compose; break;
     case HIPADJ_ALG_BACKSOLVE: k.main_k = "hipadj::k_backsolve<" + U + ", " + I(cc) + ">"; k.tail = compose; break;
     case HIPADJ_ALG_GAUSS: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ">"; k.tail = compose; break;
-    default: k.main_k = "hipadj::k_quad_adj<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.gk = "hipadj::k_quad_gk<" + U + ">"; k.tail = finish; break;
+    default: k.main_k = "hipadj::k_quad_adj<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.gk = "hipadj::k_quad_gk<" + U + ", " + I(cc) + ">"; k.tail = finish; break;
     }
     return k;
 }
@@ -730,12 +739,16 @@ template <class Mo, int ALG, int CC> static int adaptive_adjoint_l(hipadj_handle
     return HIPADJ_OK;
 }
 template <class Mo> static int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    const bool cc = h->cfg.cont_cost == HIPADJ_CCOST_HALF_SQ_SUM;
-    switch (h->cfg.alg) {
-    case HIPADJ_ALG_INTERPOLATING: return cc ? adaptive_adjoint_l<Mo, 0, 1>(h, d_cot, d_du0, d_dp) : adaptive_adjoint_l<Mo, 0, 0>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_BACKSOLVE: return cc ? adaptive_adjoint_l<Mo, 1, 1>(h, d_cot, d_du0, d_dp) : adaptive_adjoint_l<Mo, 1, 0>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_GAUSS: return cc ? adaptive_adjoint_l<Mo, 2, 1>(h, d_cot, d_du0, d_dp) : adaptive_adjoint_l<Mo, 2, 0>(h, d_cot, d_du0, d_dp);
-    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d has no adaptive device kernel", h->cfg.alg);
+    switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
+    case HIPADJ_ALG_INTERPOLATING * 4 + 0: return adaptive_adjoint_l<Mo, 0, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_INTERPOLATING * 4 + 1: return adaptive_adjoint_l<Mo, 0, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_INTERPOLATING * 4 + 2: return adaptive_adjoint_l<Mo, 0, 2>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 0: return adaptive_adjoint_l<Mo, 1, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 1: return adaptive_adjoint_l<Mo, 1, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 2: return adaptive_adjoint_l<Mo, 1, 2>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1>(h, d_cot, d_du0, d_dp);
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
     }
 }
 

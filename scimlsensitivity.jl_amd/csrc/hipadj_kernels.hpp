@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(WAVE) k_quad_adj(Geom g, const double* __restr
 }
 
 // one lane per (trajectory, quadrature interval); qres [interval][NP][Npad]
-template <class Mo>
+template <class Mo, int CC = 0>
 __global__ void __launch_bounds__(WAVE) k_quad_gk(Geom g, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                                   const dbl2* __restrict__ adj, const double* __restrict__ qa,
                                                   const double* __restrict__ qb, double atol, double rtol,
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(WAVE) k_quad_gk(Geom g, const double* __restri
     const int q = blockIdx.y;
     if (i >= g.N) return;
     double res[NP];
-    quad_gk_lane<Mo, 128>(g, i, p, knots, adj, qa[q], qb[q], atol, rtol, res);
+    quad_gk_lane<Mo, 128, CC>(g, i, p, knots, adj, qa[q], qb[q], atol, rtol, res);
 #pragma unroll
     for (int j = 0; j < NP; ++j) qres[((long)q * NP + j) * g.Npad + i] = res[j];
 }

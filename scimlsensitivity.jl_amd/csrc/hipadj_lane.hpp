@@ -138,17 +138,35 @@ HIPADJ_HD void loss_grad(const Geom& g, long i, int s, const double* __restrict_
         gl[j] = (g.loss_kind == 0) ? cotT[((long)s * Mo::N + j) * g.Npad + i] : (y[j] - g.loss_shift);
 }
 
-// continuous cost g(u,p,t) of the registry (accumulate_cost!, src/derivative_wrappers.jl:1411-1442): CC = 1 is the
-// reference test's energy  g = (sum u)^2 / 2  =>  dgdu_j = sum(u) for every j, dgdp = 0  (test/Core3/adjoint.jl:913-919)
+// continuous cost g(u,p,t) (accumulate_cost!, src/derivative_wrappers.jl:1411-1442: dlam -= g_u, dgrad -= g_p):
+//   CC = 1  g = (sum u)^2 / 2    dgdu_j = sum(u), dgdp = 0                          (test/Core3/adjoint.jl:913-919)
+//   CC = 2  g = u_1^2 + p_1      dgdu = [2 u_1, 0, ...], dgdp = [1, 0, ...]         (test/Core7/mixed_costs.jl:46-57)
+//   CC = 3  the cost attached to a runtime-registered model: Mo::dgdu / Mo::dgdp    (dgdu_continuous / dgdp_continuous)
+template <int CC> struct cost_has_gp { static constexpr bool value = CC >= 2; };
 template <class Mo, int CC>
-HIPADJ_HD void cost_grad_u(const double (&y)[Mo::N], double (&gu)[Mo::N]) {
-    double s = 0.0;
-    if (CC == 1) {
+HIPADJ_HD void cost_grad_u(const double (&y)[Mo::N], const double (&p)[Mo::NP], double t, double (&gu)[Mo::N]) {
+    if constexpr (CC == 3) { Mo::dgdu(gu, y, p, t); }
+    else {
+        (void)p; (void)t;
+        double s = 0.0;
+        if (CC == 1) {
 #pragma unroll
-        for (int j = 0; j < Mo::N; ++j) s += y[j];
+            for (int j = 0; j < Mo::N; ++j) s += y[j];
+        }
+#pragma unroll
+        for (int j = 0; j < Mo::N; ++j) gu[j] = s;
+        if (CC == 2) gu[0] = 2.0 * y[0];
     }
+}
+template <class Mo, int CC>
+HIPADJ_HD void cost_grad_p(const double (&y)[Mo::N], const double (&p)[Mo::NP], double t, double (&gp)[Mo::NP]) {
+    if constexpr (CC == 3) { Mo::dgdp(gp, y, p, t); }
+    else {
+        (void)y; (void)p; (void)t;
 #pragma unroll
-    for (int j = 0; j < Mo::N; ++j) gu[j] = s;
+        for (int j = 0; j < Mo::NP; ++j) gp[j] = 0.0;
+        if (CC == 2) gp[0] = 1.0;
+    }
 }
 
 // One reverse RK4 step of NC columns z_c = (lam_c, mu_c) through the interval [t_k, t_{k+1}] (h = -dt):
@@ -162,8 +180,8 @@ HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double
     double ymid[N], gu1[N], gum[N], gu4[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]);
-    if (CC) { cost_grad_u<Mo, CC>(hi.u, gu1); cost_grad_u<Mo, CC>(ymid, gum); cost_grad_u<Mo, CC>(lo.u, gu4); }
     const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
+    if (CC) { cost_grad_u<Mo, CC>(hi.u, pv, t_hi, gu1); cost_grad_u<Mo, CC>(ymid, pv, t_mid, gum); cost_grad_u<Mo, CC>(lo.u, pv, t_lo, gu4); }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         double V1[N], V2[N], V3[N], V4[N], l2[N], l3[N], l4[N];
@@ -198,6 +216,12 @@ HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double
             Mo::vjp_p(W1, lam[c], hi.u, pv, t_hi);
             Mo::vjp_p(W23, l23, ymid, pv, t_mid);
             Mo::vjp_p(W4, l4, lo.u, pv, t_lo);
+            if (cost_has_gp<CC>::value && c == 0) {   // dgrad -= g_p: like g_u it only drives the affine column; stages 2 and 3 share ymid
+                double gp1[NP], gpm[NP], gp4[NP];
+                cost_grad_p<Mo, CC>(hi.u, pv, t_hi, gp1); cost_grad_p<Mo, CC>(ymid, pv, t_mid, gpm); cost_grad_p<Mo, CC>(lo.u, pv, t_lo, gp4);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { W1[j] += gp1[j]; W23[j] += 2.0 * gpm[j]; W4[j] += gp4[j]; }
+            }
 #pragma unroll
             for (int j = 0; j < NP; ++j) mu[c][j] = mu[c][j] + (dt / 6.0) * (W1[j] + 2.0 * W23[j] + W4[j]);
         }
@@ -473,7 +497,7 @@ HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const d
         for (int j = 0; j < N; ++j) Y4[j] = y[j] - dt * F3[j];
         Mo::f(F4, Y4, pv, t_lo);
         double gu1[N], gu2[N], gu3[N], gu4[N];
-        if (CC) { cost_grad_u<Mo, CC>(y, gu1); cost_grad_u<Mo, CC>(Y2, gu2); cost_grad_u<Mo, CC>(Y3, gu3); cost_grad_u<Mo, CC>(Y4, gu4); }
+        if (CC) { cost_grad_u<Mo, CC>(y, pv, t_hi, gu1); cost_grad_u<Mo, CC>(Y2, pv, t_mid, gu2); cost_grad_u<Mo, CC>(Y3, pv, t_mid, gu3); cost_grad_u<Mo, CC>(Y4, pv, t_lo, gu4); }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             double ls[N], V1[N], V2[N], V3[N], V4[N], W[NP], Wacc[NP];
@@ -505,6 +529,12 @@ HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const d
                 for (int j = 0; j < N; ++j) V4[j] += gu4[j]; }
 #pragma unroll
             for (int j = 0; j < NP; ++j) Wacc[j] += W[j];
+            if (cost_has_gp<CC>::value && c == 0) {   // dgrad -= g_p at the four stage states (src/backsolve_adjoint.jl:59)
+                double gp1[NP], gp2[NP], gp3[NP], gp4[NP];
+                cost_grad_p<Mo, CC>(y, pv, t_hi, gp1); cost_grad_p<Mo, CC>(Y2, pv, t_mid, gp2); cost_grad_p<Mo, CC>(Y3, pv, t_mid, gp3); cost_grad_p<Mo, CC>(Y4, pv, t_lo, gp4);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) Wacc[j] += gp1[j] + 2.0 * (gp2[j] + gp3[j]) + gp4[j];
+            }
 #pragma unroll
             for (int j = 0; j < N; ++j) lam[c][j] = lam[c][j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
 #pragma unroll
@@ -562,7 +592,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
         const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
         double lam_hi[NC][N], d_hi[NC][N], V[N], guh[N], gul[N];
-        cost_grad_u<Mo, CC>(hi.u, guh); cost_grad_u<Mo, CC>(lo.u, gul);      // zero when CC == 0
+        cost_grad_u<Mo, CC>(hi.u, pv, t_hi, guh); cost_grad_u<Mo, CC>(lo.u, pv, t_lo, gul);      // zero when CC == 0
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             Mo::vjp_u(V, lam[c], hi.u, pv, t_hi);
@@ -623,7 +653,7 @@ HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p
         [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
             const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
             double rec[4 * N], V[N], guh[N], gul[N];
-            cost_grad_u<Mo, CC>(hi.u, guh); cost_grad_u<Mo, CC>(lo.u, gul);      // zero when CC == 0
+            cost_grad_u<Mo, CC>(hi.u, pv, t_hi, guh); cost_grad_u<Mo, CC>(lo.u, pv, t_lo, gul);      // zero when CC == 0
             Mo::vjp_u(V, lam[0], hi.u, pv, t_hi);
 #pragma unroll
             for (int j = 0; j < N; ++j) { rec[j] = lam[0][j]; rec[N + j] = -(V[j] + guh[j]); }
@@ -654,8 +684,8 @@ struct GK15 {
                                      0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
 };
 
-// AdjointSensitivityIntegrand (src/quadrature_adjoint.jl:486-502): y = sol(t), lam = adj_sol(t), out = f_p^T lam
-template <class Mo>
+// AdjointSensitivityIntegrand (src/quadrature_adjoint.jl:486-502): y = sol(t), lam = adj_sol(t), out = f_p^T lam (+ g_p)
+template <class Mo, int CC = 0>
 HIPADJ_HD void quad_integrand(const Geom& g, long i, const double (&pv)[Mo::NP], const dbl2* __restrict__ knots,
                               const dbl2* __restrict__ adj, double t, double (&out)[Mo::NP]) {
     constexpr int N = Mo::N;
@@ -678,9 +708,14 @@ HIPADJ_HD void quad_integrand(const Geom& g, long i, const double (&pv)[Mo::NP],
     for (int j = 0; j < N; ++j) { l0[j] = rec[j]; d0[j] = rec[N + j]; l1[j] = rec[2 * N + j]; d1[j] = rec[3 * N + j]; }
     hermite<N>(1.0 - thf, -g.dt, l0, d0, l1, d1, lam);   // adjoint step runs t_hi -> t_lo
     Mo::vjp_p(out, lam, y, pv, t);
+    if (cost_has_gp<CC>::value) {   // out .+= dgdp  (src/quadrature_adjoint.jl:497-500)
+        double gp[Mo::NP]; cost_grad_p<Mo, CC>(y, pv, t, gp);
+#pragma unroll
+        for (int j = 0; j < Mo::NP; ++j) out[j] += gp[j];
+    }
 }
 
-template <class Mo>
+template <class Mo, int CC = 0>
 HIPADJ_HD double gk15_eval(const Geom& g, long i, const double (&pv)[Mo::NP], const dbl2* __restrict__ knots,
                            const dbl2* __restrict__ adj, double a, double b, double (&I)[Mo::NP]) {
     constexpr int NP = Mo::NP;
@@ -690,12 +725,12 @@ HIPADJ_HD double gk15_eval(const Geom& g, long i, const double (&pv)[Mo::NP], co
     for (int j = 0; j < NP; ++j) { I[j] = 0.0; Ig[j] = 0.0; }
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
-        quad_integrand<Mo>(g, i, pv, knots, adj, c - h * GK15::X[q], f1);
-        quad_integrand<Mo>(g, i, pv, knots, adj, c + h * GK15::X[q], f2);
+        quad_integrand<Mo, CC>(g, i, pv, knots, adj, c - h * GK15::X[q], f1);
+        quad_integrand<Mo, CC>(g, i, pv, knots, adj, c + h * GK15::X[q], f2);
 #pragma unroll
         for (int j = 0; j < NP; ++j) { const double s = f1[j] + f2[j]; I[j] += GK15::WK[q] * s; if (q & 1) Ig[j] += GK15::WG[q / 2] * s; }
     }
-    quad_integrand<Mo>(g, i, pv, knots, adj, c, f1);
+    quad_integrand<Mo, CC>(g, i, pv, knots, adj, c, f1);
     double e = 0.0;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -709,7 +744,7 @@ HIPADJ_HD double gk15_eval(const Geom& g, long i, const double (&pv)[Mo::NP], co
 // QuadratureAdjoint pass 2: one lane = one (trajectory, loss interval): quadgk(integrand, t[i], t[i+1]; atol, rtol)
 // — adaptive bisection of the worst segment until E <= max(atol, rtol*|I|)  (src/quadrature_adjoint.jl:580-591).
 // MAXSEG bounds the per-lane segment list (QuadGK itself is bounded by maxevals).
-template <class Mo, int MAXSEG>
+template <class Mo, int MAXSEG, int CC = 0>
 HIPADJ_HD void quad_gk_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
                             const dbl2* __restrict__ adj, double a, double b, double atol, double rtol,
                             double (&res)[Mo::NP]) {
@@ -719,7 +754,7 @@ HIPADJ_HD void quad_gk_lane(const Geom& g, long i, const double* __restrict__ p,
     double I[NP];
     int ns = 1;
     sa[0] = a; sb[0] = b;
-    { double I0[NP]; sE[0] = gk15_eval<Mo>(g, i, pv, knots, adj, a, b, I0);
+    { double I0[NP]; sE[0] = gk15_eval<Mo, CC>(g, i, pv, knots, adj, a, b, I0);
       for (int j = 0; j < NP; ++j) { sI[0][j] = I0[j]; I[j] = I0[j]; } }
     double E = sE[0];
     for (;;) {
@@ -733,8 +768,8 @@ HIPADJ_HD void quad_gk_lane(const Geom& g, long i, const double* __restrict__ p,
         const double wa = sa[w], wb = sb[w], mid = 0.5 * (wa + wb);
         if (!(mid > (wa < wb ? wa : wb) && mid < (wa < wb ? wb : wa))) break;
         double I1[NP], I2[NP];
-        const double E1 = gk15_eval<Mo>(g, i, pv, knots, adj, wa, mid, I1);
-        const double E2 = gk15_eval<Mo>(g, i, pv, knots, adj, mid, wb, I2);
+        const double E1 = gk15_eval<Mo, CC>(g, i, pv, knots, adj, wa, mid, I1);
+        const double E2 = gk15_eval<Mo, CC>(g, i, pv, knots, adj, mid, wb, I2);
         for (int j = 0; j < NP; ++j) { I[j] += I1[j] + I2[j] - sI[w][j]; sI[w][j] = I1[j]; sI[ns][j] = I2[j]; }
         E += E1 + E2 - sE[w];
         sa[w] = wa; sb[w] = mid; sE[w] = E1;

@@ -76,6 +76,15 @@ inline int plan_auto_segments(long N, int S, int n, int np = 0) {
     return (int)target;
 }
 
+inline int plan_check_cost(const hipadj_config* cfg, std::string& err) {
+    if (cfg->cont_cost < HIPADJ_CCOST_NONE || cfg->cont_cost > HIPADJ_CCOST_MODEL) { err = "unknown cont_cost"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !plan_user_model(cfg->model)) { err = "HIPADJ_CCOST_MODEL needs a runtime-registered model with hipadj_model_set_cost"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->cont_cost >= HIPADJ_CCOST_U1SQ_PLUS_P1 && cfg->alg == HIPADJ_ALG_GAUSS) {
+        err = "GaussAdjoint with a parameter-dependent continuous cost (dgdp_continuous) is not offered: the reference adds +dgdp to its negated integrand (src/gauss_adjoint.jl:755-758) and no reference test pins that sign";
+        return HIPADJ_ERR_UNSUPPORTED; }
+    return HIPADJ_OK;
+}
+
 inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (!cfg) { err = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->struct_size != sizeof(hipadj_config)) { err = "hipadj_config.struct_size mismatch (ABI)"; return HIPADJ_ERR_INVALID_ARG; }
@@ -108,7 +117,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (!(cfg->abstol > 0) || !(cfg->reltol > 0)) { err = "adaptive Tsit5 needs abstol > 0 and reltol > 0"; return HIPADJ_ERR_INVALID_ARG; }
         if (cfg->nsave < 0 || (cfg->nsave > 0 && !cfg->save_times)) { err = "save_times missing"; return HIPADJ_ERR_INVALID_ARG; }
         if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
-        if (cfg->cont_cost != HIPADJ_CCOST_NONE && cfg->cont_cost != HIPADJ_CCOST_HALF_SQ_SUM) { err = "unknown cont_cost"; return HIPADJ_ERR_INVALID_ARG; }
+        { const int crc = plan_check_cost(cfg, err); if (crc != HIPADJ_OK) return crc; }
         if (cfg->max_steps < 0) { err = "max_steps must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
         {   // the 8 x NZ stage rows of a wave live in LDS (hipadj_adaptive.hpp): 8 * NZ * 64 lanes * 8 B <= 160 KB
             const int NZ = cfg->alg == HIPADJ_ALG_INTERPOLATING ? n + np : (cfg->alg == HIPADJ_ALG_BACKSOLVE ? 2 * n + np : n);
@@ -145,7 +154,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->time_segments < 0) { err = "time_segments must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->ckpt_stride < 0) { err = "ckpt_stride must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
-    if (cfg->cont_cost != HIPADJ_CCOST_NONE && cfg->cont_cost != HIPADJ_CCOST_HALF_SQ_SUM) { err = "unknown cont_cost"; return HIPADJ_ERR_INVALID_ARG; }
+    { const int crc = plan_check_cost(cfg, err); if (crc != HIPADJ_OK) return crc; }
     if (cfg->cont_cost != HIPADJ_CCOST_NONE && (P.field || P.mlp)) { err = "continuous costs are available for the lane-per-trajectory family only"; return HIPADJ_ERR_UNSUPPORTED; }
     P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = (int)S; P.M = cfg->nsave;
     P.save_of_knot.assign(S + 1, -1); P.ckpt_of_knot.assign(S + 1, -1);

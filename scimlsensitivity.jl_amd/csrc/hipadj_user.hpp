@@ -31,7 +31,9 @@ namespace hipadj {
 
 struct UserModelSrc {
     std::string name, f, vjp_u, vjp_p;
-    int n = 0, np = 0;
+    std::string dgdu, dgdp;   // optional continuous cost (hipadj_model_set_cost)
+    bool has_cost = false;
+    int n = 0, np = 0, rev = 0;   // rev: bumped when the sources change, part of the code-cache key
 };
 
 struct UserRegistry {
@@ -115,7 +117,12 @@ inline std::string user_model_struct(const UserModelSrc& m) {
       << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
       << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_u << "\n    }\n"
       << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
-      << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_p << "\n    }\n};\n}  // namespace hipadj\n";
+      << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_p << "\n    }\n"
+      << "    // continuous cost attached with hipadj_model_set_cost (dgdu_continuous / dgdp_continuous); zero when absent\n"
+      << "    HIPADJ_HD static void dgdu(double (&out)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+      << "        (void)u; (void)p; (void)t;\n" << (m.has_cost ? m.dgdu : std::string("for (int i = 0; i < N; ++i) out[i] = 0.0;")) << "\n    }\n"
+      << "    HIPADJ_HD static void dgdp(double (&out)[NP], const double (&u)[N], const double (&p)[NP], double t) {\n"
+      << "        (void)u; (void)p; (void)t;\n" << (m.has_cost ? m.dgdp : std::string("for (int i = 0; i < NP; ++i) out[i] = 0.0;")) << "\n    }\n};\n}  // namespace hipadj\n";
     return o.str();
 }
 
@@ -125,13 +132,14 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
                         std::map<std::string, std::string>& lowered, std::string& err) {
     UserRegistry& R = user_registry();
     UserModelSrc src;
-    std::string key = std::to_string(model);
-    for (const auto& e : exprs) key += "|" + e;
+    std::string key;
     {
         std::lock_guard<std::mutex> lk(R.mu);
         const int idx = model - HIPADJ_MODEL_USER_BASE;
         if (idx < 0 || idx >= (int)R.models.size()) { err = "unknown user model id"; return HIPADJ_ERR_INVALID_ARG; }
         src = R.models[idx];
+        key = std::to_string(model) + "#" + std::to_string(src.rev);
+        for (const auto& e : exprs) key += "|" + e;
         auto it = R.code_cache.find(key);
         if (it != R.code_cache.end()) { code = it->second; lowered = R.lowered_cache[key]; return HIPADJ_OK; }
     }
@@ -173,6 +181,22 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         R.code_cache[key] = code; R.lowered_cache[key] = lowered;
     }
     return HIPADJ_OK;
+}
+
+inline int user_set_cost(int32_t model, const char* dgdu, const char* dgdp, std::string& err) {
+    if (!dgdu || !dgdp) { err = "hipadj_model_set_cost: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
+    R.models[idx].dgdu = dgdu; R.models[idx].dgdp = dgdp; R.models[idx].has_cost = true; R.models[idx].rev++;
+    return HIPADJ_OK;
+}
+inline bool user_has_cost(int32_t model) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    return idx >= 0 && idx < (int)R.models.size() && R.models[idx].has_cost;
 }
 
 inline int user_register(const char* name, int32_t n, int32_t np, const char* f, const char* vu, const char* vp, int32_t* id, std::string& err) {

@@ -13,9 +13,13 @@ import numpy as np
 
 from . import _lib
 from .engine import Engine
-from .problems import RK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum
+from .problems import (RK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum,
+                       FirstStateSquaredPlusFirstParam, ModelCost)
 from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
                                      QuadratureAdjoint, GaussAdjoint, ischeckpointing)
+
+
+_COSTS = {HalfSquaredSum: _lib.CCOST_HALF_SQ_SUM, FirstStateSquaredPlusFirstParam: _lib.CCOST_U1SQ_PLUS_P1, ModelCost: _lib.CCOST_MODEL}
 
 
 def _save_times(tspan, saveat, dt):
@@ -70,12 +74,12 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
         ensprob = EnsembleProblem(ensprob, ensprob.u0[None, :])
     prob = ensprob.prob
     ts = _save_times(prob.tspan, saveat, dt)
-    if g is not None and not isinstance(g, HalfSquaredSum):
-        raise ValueError("g must be a registered continuous cost (HalfSquaredSum()) or None")
+    if g is not None and not isinstance(g, tuple(_COSTS)):
+        raise ValueError("g must be a registered continuous cost (HalfSquaredSum(), FirstStateSquaredPlusFirstParam(), ModelCost()) or None")
     loss_kind, shift = (_lib.LOSS_LSQ_SHIFT, dgdu_discrete.shift) if isinstance(dgdu_discrete, LsqShift) else (_lib.LOSS_COTANGENT, 0.0)
     eng = Engine(prob.f, sensealg.name, ensprob.u0.shape[0], prob.tspan[0], prob.tspan[1], dt, save_times=ts,
                  loss_kind=loss_kind, loss_shift=shift, p_shared=(ensprob.p.ndim == 1), device=device,
-                 time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_lib.CCOST_HALF_SQ_SUM if g is not None else 0),
+                 time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_COSTS[type(g)] if g is not None else 0),
                  stepper=(1 if adaptive else 0), abstol=abstol, reltol=reltol, max_steps=max_steps,
                  **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive))
     out = eng.forward(ensprob.u0, ensprob.p, want_out=want_out)

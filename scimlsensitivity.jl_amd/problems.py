@@ -25,6 +25,13 @@ class DeviceFunction:
         self.name, self.n, self.np = name, int(n), int(np)
         self.id = _lib.register_model(name, n, np, f, vjp, vjp_p, check=check)
 
+    def set_cost(self, dgdu, dgdp):
+        """Attach a continuous cost through its gradients — the `dgdu_continuous` / `dgdp_continuous` keywords of
+        adjoint_sensitivities (src/sensitivity_interface.jl:373-526) as HIP C++ bodies writing `out` from `u`, `p`, `t`.
+        Select it with solve(..., g=ModelCost())."""
+        _lib.set_model_cost(self.id, dgdu, dgdp)
+        return self
+
     def __repr__(self):
         return f"DeviceFunction({self.name!r}, n={self.n}, np={self.np}, id={self.id})"
 
@@ -75,6 +82,17 @@ class HalfSquaredSum:
     """Continuous cost g(u, p, t) = (sum(u))^2 / 2 with dgdu_continuous = sum(u) in every component
     (the `g`/`dg` pair of test/Core3/adjoint.jl:913-919); evaluated inside the reverse kernels
     (accumulate_cost!, src/derivative_wrappers.jl:1411-1442)."""
+
+
+@dataclass(frozen=True)
+class FirstStateSquaredPlusFirstParam:
+    """Continuous cost g(u, p, t) = u[1]^2 + p[1] with dgdu_continuous = [2 u1, 0, ...] and dgdp_continuous = [1, 0, ...]
+    (test/Core7/mixed_costs.jl:46-57): the registered cost with a parameter term."""
+
+
+@dataclass(frozen=True)
+class ModelCost:
+    """The continuous cost attached to a DeviceFunction with set_cost(dgdu, dgdp)."""
 
 
 @dataclass

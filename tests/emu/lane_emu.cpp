@@ -131,7 +131,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             double acc[NP]; for (int j = 0; j < NP; ++j) acc[j] = 0.0;
             for (int q = 0; q < P.nq; ++q) {
                 double res[NP];
-                quad_gk_lane<Mo, 128>(g, i, p, knots.data(), adj.data(), P.qa[q], P.qb[q], atol, rtol, res);
+                quad_gk_lane<Mo, 128, (LOSS >> 1)>(g, i, p, knots.data(), adj.data(), P.qa[q], P.qb[q], atol, rtol, res);
                 for (int j = 0; j < NP; ++j) acc[j] += res[j];
             }
             for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = acc[j];
@@ -180,11 +180,15 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
 
 template <class Mo>
 static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* ns) {
-    const bool cc = cfg->cont_cost == HIPADJ_CCOST_HALF_SQ_SUM;
-    switch (cfg->alg) {
-    case HIPADJ_ALG_INTERPOLATING: return cc ? run_adaptive<Mo, 0, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns) : run_adaptive<Mo, 0, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-    case HIPADJ_ALG_BACKSOLVE: return cc ? run_adaptive<Mo, 1, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns) : run_adaptive<Mo, 1, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-    case HIPADJ_ALG_GAUSS: return cc ? run_adaptive<Mo, 2, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns) : run_adaptive<Mo, 2, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    switch (cfg->alg * 4 + cfg->cont_cost) {
+    case HIPADJ_ALG_INTERPOLATING * 4 + 0: return run_adaptive<Mo, 0, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_INTERPOLATING * 4 + 1: return run_adaptive<Mo, 0, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_INTERPOLATING * 4 + 2: return run_adaptive<Mo, 0, 2>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 0: return run_adaptive<Mo, 1, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 1: return run_adaptive<Mo, 1, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 2: return run_adaptive<Mo, 1, 2>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_GAUSS * 4 + 0: return run_adaptive<Mo, 2, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_GAUSS * 4 + 1: return run_adaptive<Mo, 2, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     default: return HIPADJ_ERR_UNSUPPORTED;
     }
 }
@@ -192,12 +196,15 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 template <class Mo>
 static int dispatch_mode(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out) {
     if (P.adaptive) return dispatch_adaptive<Mo>(cfg, P, u0, p, dLdu, du0, dp, out, nullptr);
-    const int mode = ((cfg->loss_kind == HIPADJ_LOSS_COTANGENT && P.M > 0) ? 0 : 1) | (cfg->cont_cost == HIPADJ_CCOST_HALF_SQ_SUM ? 2 : 0);
+    const int mode = ((cfg->loss_kind == HIPADJ_LOSS_COTANGENT && P.M > 0) ? 0 : 1) | (cfg->cont_cost << 1);
     switch (mode) {
     case 0: return run<Mo, 0>(cfg, P, u0, p, dLdu, du0, dp, out);
     case 1: return run<Mo, 1>(cfg, P, u0, p, dLdu, du0, dp, out);
     case 2: return run<Mo, 2>(cfg, P, u0, p, dLdu, du0, dp, out);
-    default: return run<Mo, 3>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case 3: return run<Mo, 3>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case 4: return run<Mo, 4>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case 5: return run<Mo, 5>(cfg, P, u0, p, dLdu, du0, dp, out);
+    default: return HIPADJ_ERR_UNSUPPORTED;
     }
 }
 

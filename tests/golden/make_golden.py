@@ -128,6 +128,18 @@ def main():
     gc = solc.y[14:, -1]
     out["lvt_continuous"] = dict(u0=[1.0, 1.0], p=p4.tolist(), tspan=[0, 4.0], cost="g = (u1+u2)^2/2", du0=gc[:2].tolist(), dp=gc[2:].tolist())
 
+    # mixed continuous cost with a parameter term, G = int_0^10 u1^2 + p1 dt on LV (test/Core7/mixed_costs.jl:13-57:
+    # `g(u, p, t) = u[1]^2 + p[1]`, dgdu = [2 u1, 0], dgdp = [1, 0, 0, 0]; the reference compares with ForwardDiff of quadgk)
+    def rhs_m(t, z):
+        u = z[:2]; S = z[2:14].reshape(2, 6)
+        f_, J, P = lv(u, p4, t)
+        dS = J @ S; dS[:, 2:] += P
+        dG = 2.0 * u[0] * S[0]; dG[2] += 1.0
+        return np.concatenate([f_, dS.ravel(), dG])
+    solm = solve_ivp(rhs_m, (0, 10.0), np.concatenate([[1.0, 1.0], S0.ravel(), np.zeros(6)]), method="DOP853", rtol=1e-13, atol=1e-13)
+    gm = solm.y[14:, -1]
+    out["lv_mixed_cost"] = dict(u0=[1.0, 1.0], p=p4.tolist(), tspan=[0, 10.0], cost="g = u1^2 + p1", du0=gm[:2].tolist(), dp=gm[2:].tolist())
+
     with open(os.path.join(HERE, "gradients.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k, v in out.items():

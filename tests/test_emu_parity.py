@@ -240,3 +240,39 @@ def test_tsit5_max_steps_overflow_is_an_error_and_plan_rejections():
         cfg = E.make_config("lorenz", alg, 1, 0.0, 10.0, 0.0, ts, stepper=1, **kw)
         with pytest.raises(RuntimeError):
             E.forward_adjoint(cfg, 3, 3, u0, p, np.zeros((1, len(ts), 3)))
+
+
+# ---- dgdp_continuous: g = u1^2 + p1 (test/Core7/mixed_costs.jl:13-57) ---------------------------------------------
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve", "quadrature"])
+@pytest.mark.parametrize("segments", [1, 4])
+def test_mixed_cost_with_parameter_term_rk4(alg, segments):
+    rng = np.random.default_rng(21)
+    N, T, dt = 3, 2.0, 0.01
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    ts = np.linspace(0, T, 5)
+    ck = alg == "backsolve"
+    cfg = E.make_config("lv", alg, N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, cont_cost=2, checkpointing=ck, time_segments=segments,
+                        quad_abstol=1e-10, quad_reltol=1e-10)
+    du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
+    ref = O.Problem("LV", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, cont_cost=2,
+                    checkpointing=ck, quad_abstol=1e-10, quad_reltol=1e-10)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < 1e-11 and rel(dp, rdp) < 1e-11
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve"])
+def test_mixed_cost_tsit5_against_golden(alg):
+    """The reference's own setup: LV, G = int_0^10 u1^2 + p1 dt, Tsit5 with tight tolerances, against the DOP853
+    forward-sensitivity gradient (tests/golden/gradients.json: lv_mixed_cost)."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gradients.json")))["lv_mixed_cost"]
+    cfg = E.make_config("lv", alg, 1, 0.0, 10.0, 0.0, [], loss_kind=1, cont_cost=2, stepper=1, abstol=1e-12, reltol=1e-12, max_steps=20000)
+    du0, dp, _ = E.forward_adjoint(cfg, 2, 4, np.asarray([gold["u0"]]), np.asarray(gold["p"]))
+    assert rel(du0[0], np.asarray(gold["du0"])) < 1e-8 and rel(dp, np.asarray(gold["dp"])) < 1e-8
+
+
+def test_gauss_with_parameter_dependent_cost_is_rejected():
+    for stepper in (0, 1):
+        cfg = E.make_config("lv", "gauss", 1, 0.0, 1.0, 0.1, [1.0], loss_kind=1, cont_cost=2, stepper=stepper)
+        with pytest.raises(RuntimeError, match="rc=-6"):
+            E.forward_adjoint(cfg, 2, 4, np.ones((1, 2)), np.array([1.5, 1.0, 3.0, 1.0]))

@@ -589,3 +589,71 @@ def test_runtime_model_compile_error_surfaces_at_solve(sa):
     bad = sa.DeviceFunction("broken_at_solve", 2, 2, "du[0] = undefined_symbol; du[1] = 0.0;", "out[0] = 0.0; out[1] = 0.0;", "out[0] = 0.0; out[1] = 0.0;")
     with pytest.raises(sa.HipadjError, match="failed to compile"):
         sa.solve(sa.EnsembleProblem(sa.ODEProblem(bad, np.ones(2), (0, 1.0), np.ones(2)), np.ones((4, 2))), sa.RK4(), dt=0.1, saveat=[1.0])
+
+
+# ---- dgdp_continuous (accumulate_cost! with a parameter block; test/Core7/mixed_costs.jl, adjoint_param.jl) ------------
+@pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("quadrature", "QUADRATURE")])
+def test_mixed_cost_with_parameter_term(sa, alg, oalg, stepper):
+    """g = u1^2 + p1 on LV (test/Core7/mixed_costs.jl:13-57) plus a discrete LSQ loss, ensemble of 100."""
+    if stepper == "tsit5" and alg == "quadrature":
+        pytest.skip("QuadratureAdjoint is not wired for the adaptive path")
+    rng = np.random.default_rng(51)
+    N, T = 100, 2.0
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    ts = np.linspace(0, T, 5)
+    ck = alg == "backsolve"
+    if stepper == "rk4":
+        salg, kw, okw = sa.RK4(), dict(dt=0.01), dict(stepper="RK4", dt=0.01)
+    else:
+        salg, kw, okw = sa.Tsit5(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
+    sens = sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10) if alg == "quadrature" else sensealg_of(sa, alg)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, T), p), u0), salg, saveat=ts, sensealg=sens,
+                   dgdu_discrete=sa.LsqShift(2.0), g=sa.FirstStateSquaredPlusFirstParam(), **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=sa.LsqShift(2.0), g=sa.FirstStateSquaredPlusFirstParam())
+    ref = O.Problem("LV", alg=oalg, t0=0, t1=T, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, cont_cost=2, checkpointing=ck,
+                    quad_abstol=1e-10, quad_reltol=1e-10, **okw)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
+def test_mixed_cost_reference_setup_against_golden(sa):
+    """LV, G = int_0^10 u1^2 + p1 dt, Tsit5 abstol = reltol = 1e-12 (1e-14 in the reference), vs the DOP853 gradient."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gradients.json")))["lv_mixed_cost"]
+    u0 = np.asarray([gold["u0"]]); p = np.asarray(gold["p"])
+    for alg in (sa.InterpolatingAdjoint(), sa.BacksolveAdjoint(checkpointing=False)):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, 10.0), p), u0), sa.Tsit5(), saveat=None, sensealg=alg,
+                       g=sa.FirstStateSquaredPlusFirstParam(), abstol=1e-12, reltol=1e-12, max_steps=20000)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), g=sa.FirstStateSquaredPlusFirstParam())
+        assert rel(du0[0], gold["du0"]) < 1e-8 and rel(dp, gold["dp"]) < 1e-8
+        sol.engine.close()
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve", "quadrature"])
+def test_runtime_model_with_attached_cost_equals_registered_cost(sa, alg):
+    """dgdu_continuous / dgdp_continuous supplied as text for a runtime model (HIPADJ_CCOST_MODEL) must reproduce the
+    compiled-in cost #2 on the compiled-in model."""
+    m = UM.LV
+    f = sa.DeviceFunction("lv_runtime_cost", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"]).set_cost(
+        "out[0] = 2.0*u[0]; out[1] = 0.0;", "out[0] = 1.0; out[1] = 0.0; out[2] = 0.0; out[3] = 0.0;")
+    rng = np.random.default_rng(53)
+    N, T, dt = 70, 2.0, 0.01
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    ts = np.linspace(0, T, 5)
+    res = []
+    for ff, g in (("lv", sa.FirstStateSquaredPlusFirstParam()), (f, sa.ModelCost())):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(ff, u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sensealg_of(sa, alg),
+                       dgdu_discrete=sa.LsqShift(2.0), g=g)
+        res.append(sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0), g=g))
+        sol.engine.close()
+    assert rel(res[1][0], res[0][0]) < 1e-12 and rel(res[1][1], res[0][1]) < 1e-12
+
+
+def test_gauss_with_parameter_dependent_cost_is_rejected(sa):
+    u0 = np.ones((4, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    with pytest.raises(sa.HipadjError) as e:
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, 1.0), p), u0), sa.RK4(), dt=0.1, saveat=[1.0], sensealg=sa.GaussAdjoint(),
+                 g=sa.FirstStateSquaredPlusFirstParam())
+    assert e.value.status == -6
