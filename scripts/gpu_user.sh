@@ -1,10 +1,4 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-mkdir -p gpurun_out/ts5
-echo "== pytest tsit5 + runtime" ; timeout 1500 python -m pytest tests -m gpu -x -q -k "tsit5 or runtime or native" 2>&1 | grep -v "^  File" | tail -4
-echo "== bench tsit5" ; timeout 600 python scripts/bench_tsit5.py 10000 2>&1 | tee gpurun_out/ts5/tsit5.jsonl | python -c "
-import sys, json
-for l in sys.stdin:
-    try: d=json.loads(l)
-    except Exception: continue
-    print(d['model'], d['alg'], d['abstol'], 'fwd %.3f adj %.3f ms'%(d['forward_ms'], d['adjoint_ms']))"
+echo "== new tests" ; timeout 1500 python -m pytest tests -m gpu -x -q -k "mixed or attached or rejected or native" 2>&1 | grep -v "^  File" | tail -12
+echo "== full gpu suite" ; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
