@@ -350,6 +350,12 @@ template <class Mo> struct FwdCursor {
         rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; lc = -1;
         ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i];
     }
+    // position the cursor on the step containing t by bisection (quadrature lanes start anywhere in [t0, T])
+    HIPADJ_HD void seek(double t) {
+        int lo = 0, hi = ns - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[((long)mid * RW + 1) * Npad + i] < t) lo = mid + 1; else hi = mid; }
+        sc = lo; ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i];
+    }
     // y = sol(t): the reverse sweep moves mostly downward, so a linear cursor walk replaces the binary search
     HIPADJ_HD void eval(double t, double (&y)[Mo::N]) {
         while (t < ta && sc > 0) { --sc; tb = ta; ta = rec[((long)sc * RW + 0) * Npad + i]; }
@@ -367,14 +373,42 @@ template <class Mo> struct FwdCursor {
 };
 
 // reverse sweeps.  ALG: 0 Interpolating (z = [lam; mu]), 1 Backsolve (z = [lam; mu; y]), 2 Gauss (z = lam, mu by quadrature)
+// ALG 3 = Quadrature pass 1: z = lam, every accepted step is recorded (dense adjoint solution, src/quadrature_adjoint.jl:527-530)
 template <class Mo, int ALG> struct AdjNZ { static constexpr int value = ALG == 0 ? Mo::N + Mo::NP : (ALG == 1 ? 2 * Mo::N + Mo::NP : Mo::N); };
+
+// cursor into the dense ADJOINT solution of one trajectory: records in order of decreasing time, record s covers
+// [t_end, t_start] with t_end < t_start, monomial coefficients in theta = (t - t_start) / (t_end - t_start)
+template <class Mo> struct AdjCursor {
+    static constexpr int N = Mo::N, RW = 2 + 5 * Mo::N;
+    const double* rec; long Npad, i; int ns, sc, lc;
+    double ts, te, c[5][Mo::N];   // ts = start (upper), te = end (lower)
+    HIPADJ_HD void init(const double* r, long np, long ii, int nsteps, double t) {
+        rec = r; Npad = np; i = ii; ns = nsteps; lc = -1;
+        int lo = 0, hi = ns - 1;   // first record whose lower end is <= t
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[((long)mid * RW + 1) * Npad + i] > t) lo = mid + 1; else hi = mid; }
+        sc = lo; ts = rec[((long)sc * RW + 0) * Npad + i]; te = rec[((long)sc * RW + 1) * Npad + i];
+    }
+    HIPADJ_HD void eval(double t, double (&lam)[Mo::N]) {
+        while (t < te && sc < ns - 1) { ++sc; ts = te; te = rec[((long)sc * RW + 1) * Npad + i]; }
+        while (t > ts && sc > 0) { --sc; te = ts; ts = rec[((long)sc * RW + 0) * Npad + i]; }
+        if (sc != lc) {
+            lc = sc;
+            const long base = ((long)sc * RW + 2) * Npad + i;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int j = 0; j < N; ++j) c[m][j] = rec[base + (long)(m * N + j) * Npad];
+        }
+        poly_eval<N>((t - ts) / (te - ts), c, lam);
+    }
+};
 
 template <class Mo, int ALG, int CC>
 HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __restrict__ p, const double* __restrict__ rec,
                                   const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
                                   const double* __restrict__ ck_t, const double* __restrict__ save_t, const double* __restrict__ tstops_desc,
                                   int ntstops, const double* __restrict__ cotT, double (&lam_out)[Mo::N], double (&mu_out)[Mo::NP], int* __restrict__ flag,
-                                  double* kbase, int kstride) {
+                                  double* kbase, int kstride, double* __restrict__ arec = nullptr, int* __restrict__ nsteps_adj = nullptr, int SmaxA = 0) {
     constexpr int N = Mo::N, NP = Mo::NP, NZ = AdjNZ<Mo, ALG>::value;
     const KStore<NZ> K{kbase, kstride};
     double pv[NP];
@@ -406,7 +440,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         double gu[N]; cost_grad_u<Mo, CC>(y, pv, t, gu);
 #pragma unroll
         for (int j = 0; j < N; ++j) dz[j] = -dl[j] - gu[j];
-        if (ALG != 2) {
+        if (ALG == 0 || ALG == 1) {
             Mo::vjp_p(dg, lam, y, pv, t);
             if (cost_has_gp<CC>::value) {   // dgrad -= g_p
                 double gp[NP]; cost_grad_p<Mo, CC>(y, pv, t, gp);
@@ -422,8 +456,22 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             for (int j = 0; j < N; ++j) dz[N + NP + j] = f[j];
         }
     };
+    int sa = 0;
+    bool aoverflow = false;
     auto cb = [&](double t, double tprev, double (&zz)[NZ], const KStore<NZ>& KK) -> bool {
         bool mod = false;
+        if (ALG == 3 && t != tprev) {   // dense adjoint solution for the quadrature pass
+            if (sa < SmaxA) {
+                constexpr int RW = 2 + 5 * N;
+                double c[5][NZ]; tsit5_poly<NZ>(KK, t - tprev, c);
+                arec[((long)sa * RW + 0) * g.Npad + i] = tprev; arec[((long)sa * RW + 1) * g.Npad + i] = t;
+#pragma unroll
+                for (int m = 0; m < 5; ++m)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) arec[((long)sa * RW + 2 + m * N + j) * g.Npad + i] = c[m][j];
+            } else aoverflow = true;
+            ++sa;
+        }
         if (ALG == 2 && t != tprev) {   // IntegratingSumCallback: 3-point Gauss-Legendre of -(df/dp)^T lam on [tprev, t]
             const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;
 #pragma unroll 1
@@ -465,14 +513,95 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
     for (int j = 0; j < N; ++j) lam_out[j] = z[j];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) mu_out[j] = ALG == 2 ? gacc[j] : z[N + j];
-    if (na < 0) {
+    for (int j = 0; j < NP; ++j) {
+        if constexpr (ALG == 2) mu_out[j] = gacc[j];
+        else if constexpr (ALG == 3) mu_out[j] = 0.0;      // dp comes from the quadrature pass
+        else mu_out[j] = z[N + j];
+    }
+    if (ALG == 3) nsteps_adj[i] = sa < SmaxA ? sa : SmaxA;
+    if (na < 0 || aoverflow) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(flag, 4);
 #else
         *flag |= 4;
 #endif
     }
+}
+
+// ---- QuadratureAdjoint pass 2 on the adaptive solutions: quadgk(t -> f_p(y(t))^T lam(t) + g_p, a, b; atol, rtol) -----------
+// (src/quadrature_adjoint.jl:486-502, 537-616).  Same Gauss-Kronrod (7,15) rule and worst-segment bisection as
+// quad_gk_lane (hipadj_lane.hpp); the integrand reads both dense solutions through cursors.
+template <int NP, class F>
+HIPADJ_HD double gk15_eval_f(F&& integrand, double a, double b, double (&I)[NP]) {
+    const double c = 0.5 * (a + b), h = 0.5 * (b - a);
+    double Ig[NP], f1[NP], f2[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { I[j] = 0.0; Ig[j] = 0.0; }
+#pragma unroll 1
+    for (int q = 0; q < 7; ++q) {
+        integrand(c - h * GK15::X[q], f1);
+        integrand(c + h * GK15::X[q], f2);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { const double s = f1[j] + f2[j]; I[j] += GK15::WK[q] * s; if (q & 1) Ig[j] += GK15::WG[q / 2] * s; }
+    }
+    integrand(c, f1);
+    double e = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        I[j] += GK15::WK[7] * f1[j]; Ig[j] += GK15::WG[3] * f1[j];
+        I[j] *= h; Ig[j] *= h;
+        const double d = I[j] - Ig[j]; e += d * d;
+    }
+    return sqrt(e);
+}
+
+template <class Mo, int MAXSEG, int CC>
+HIPADJ_HD void quad_gk_tsit5_lane(const AdaptGeom& g, long i, const double* __restrict__ p, const double* __restrict__ rec,
+                                  const int* __restrict__ nsteps, const double* __restrict__ arec, const int* __restrict__ nsteps_adj,
+                                  double a, double b, double atol, double rtol, double (&res)[Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    double pv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
+    FwdCursor<Mo> cf; cf.init(rec, g.Npad, i, nsteps[i]); cf.seek(0.5 * (a + b));
+    AdjCursor<Mo> ca; ca.init(arec, g.Npad, i, nsteps_adj[i], 0.5 * (a + b));
+    auto integrand = [&](double t, double (&out)[NP]) {
+        double y[N], lam[N];
+        cf.eval(t, y); ca.eval(t, lam);
+        Mo::vjp_p(out, lam, y, pv, t);
+        if (cost_has_gp<CC>::value) {
+            double gp[NP]; cost_grad_p<Mo, CC>(y, pv, t, gp);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) out[j] += gp[j];
+        }
+    };
+    double sa[MAXSEG], sb[MAXSEG], sE[MAXSEG], sI[MAXSEG][NP];
+    double I[NP];
+    int ns = 1;
+    sa[0] = a; sb[0] = b;
+    { double I0[NP]; sE[0] = gk15_eval_f<NP>(integrand, a, b, I0);
+      for (int j = 0; j < NP; ++j) { sI[0][j] = I0[j]; I[j] = I0[j]; } }
+    double E = sE[0];
+    for (;;) {
+        double nrm = 0.0;
+        for (int j = 0; j < NP; ++j) nrm += I[j] * I[j];
+        nrm = sqrt(nrm);
+        const double tol = atol > rtol * nrm ? atol : rtol * nrm;
+        if (E <= tol || ns + 1 > MAXSEG) break;
+        int w = 0;
+        for (int s = 1; s < ns; ++s) if (sE[s] > sE[w]) w = s;
+        const double wa = sa[w], wb = sb[w], mid = 0.5 * (wa + wb);
+        if (!(mid > (wa < wb ? wa : wb) && mid < (wa < wb ? wb : wa))) break;
+        double I1[NP], I2[NP];
+        const double E1 = gk15_eval_f<NP>(integrand, wa, mid, I1);
+        const double E2 = gk15_eval_f<NP>(integrand, mid, wb, I2);
+        for (int j = 0; j < NP; ++j) { I[j] += I1[j] + I2[j] - sI[w][j]; sI[w][j] = I1[j]; sI[ns][j] = I2[j]; }
+        E += E1 + E2 - sE[w];
+        sa[w] = wa; sb[w] = mid; sE[w] = E1;
+        sa[ns] = mid; sb[ns] = wb; sE[ns] = E2;
+        ++ns;
+    }
+    for (int j = 0; j < NP; ++j) { double s = 0.0; for (int q = 0; q < ns; ++q) s += sI[q][j]; res[j] = s; }
 }
 
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
@@ -495,16 +624,33 @@ __global__ void __launch_bounds__(64) k_adjoint_tsit5(AdaptGeom g, const double*
                                                       const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
                                                       const double* __restrict__ ck_t, const double* __restrict__ save_t,
                                                       const double* __restrict__ tstops_desc, int ntstops, const double* __restrict__ cotT,
-                                                      double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+                                                      double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
+                                                      double* __restrict__ arec, int* __restrict__ nsteps_adj, int SmaxA) {
     __shared__ double ks[KS_ROWS * AdjNZ<Mo, ALG>::value * 64];
     const long i = (long)blockIdx.x * 64 + threadIdx.x;
     if (i >= g.N) return;
     double lam[Mo::N], mu[Mo::NP];
-    adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec, nsteps, yT, ckpt, ck_t, save_t, tstops_desc, ntstops, cotT, lam, mu, flag, ks + threadIdx.x, 64);
+    adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec, nsteps, yT, ckpt, ck_t, save_t, tstops_desc, ntstops, cotT, lam, mu, flag, ks + threadIdx.x, 64, arec, nsteps_adj, SmaxA);
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) du0[i * Mo::N + j] = lam[j];
+    if (ALG != 3) {
 #pragma unroll
-    for (int j = 0; j < Mo::NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j];
+        for (int j = 0; j < Mo::NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j]; }
+}
+
+// one lane per (trajectory, quadrature interval); qres [interval][NP][Npad]
+template <class Mo, int CC>
+__global__ void __launch_bounds__(64) k_quad_gk_tsit5(AdaptGeom g, const double* __restrict__ p, const double* __restrict__ rec,
+                                                      const int* __restrict__ nsteps, const double* __restrict__ arec,
+                                                      const int* __restrict__ nsteps_adj, const double* __restrict__ qa,
+                                                      const double* __restrict__ qb, double atol, double rtol, double* __restrict__ qres) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    const int q = blockIdx.y;
+    if (i >= g.N) return;
+    double res[Mo::NP];
+    quad_gk_tsit5_lane<Mo, 128, CC>(g, i, p, rec, nsteps, arec, nsteps_adj, qa[q], qb[q], atol, rtol, res);
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) qres[((long)q * Mo::NP + j) * g.Npad + i] = res[j];
 }
 #endif
 

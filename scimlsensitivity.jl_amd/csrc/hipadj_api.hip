@@ -53,8 +53,8 @@ struct hipadj_handle {
     hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish
     bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
     AdaptGeom ag{};
-    double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr;
-    int *d_nsteps = nullptr, ntstops = 0;
+    double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr, *d_arec = nullptr;
+    int *d_nsteps = nullptr, *d_nsteps_adj = nullptr, ntstops = 0, SmaxA = 0;
     unsigned* d_ticket = nullptr;
     int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
@@ -122,7 +122,7 @@ extern "C" int hipadj_model_check(int32_t model_id) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->umod) (void)hipModuleUnload(h->umod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -167,6 +167,11 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
         if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)P.Smax * RW * Np));
         A(dev_alloc(h, &h->d_nsteps, (size_t)Np));
+        if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // dense adjoint solution: the reverse solve also stops at every loss time
+            h->SmaxA = 2 * P.Smax + h->M + 16;
+            A(dev_alloc(h, &h->d_arec, (size_t)h->SmaxA * RW * Np));
+            A(dev_alloc(h, &h->d_nsteps_adj, (size_t)Np));
+        }
         if (P.nck > 0) { A(dev_alloc(h, &h->d_ckpt, (size_t)P.nck * n * Np)); A(dev_alloc(h, &h->d_ck_t, (size_t)P.nck)); }
         if (h->M > 0) A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
         h->ntstops = (int)P.tstops_desc.size();
@@ -603,6 +608,7 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     if (h->adaptive) {
         k.forward = "hipadj::k_forward_tsit5<" + U + ">";
         k.main_k = "hipadj::k_adjoint_tsit5<" + U + ", " + I(h->cfg.alg) + ", " + I(cc) + ">";
+        if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) k.gk = "hipadj::k_quad_gk_tsit5<" + U + ", " + I(cc) + ">";
         k.tail = finish;
         return k;
     }
@@ -667,7 +673,14 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     if (h->adaptive) {
         TRY(ulaunch(h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
                     (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, h->ntstops,
-                    (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag));
+                    (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag, h->d_arec, h->d_nsteps_adj, h->SmaxA));
+        if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
+            const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+            TRY(ulaunch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
+                        (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres));
+            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+            HIP_TRY(h, hipGetLastError());
+        }
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         const dim3 sgrid(waves, (unsigned)h->nseg);
@@ -724,9 +737,18 @@ template <class Mo, int ALG, int CC> static int adaptive_adjoint_l(hipadj_handle
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
                        (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
-                       (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag);
+                       (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag,
+                       h->d_arec, h->d_nsteps_adj, h->SmaxA);
     HIP_TRY(h, hipGetLastError());
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+    if constexpr (ALG == 3) {
+        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        hipLaunchKernelGGL((k_quad_gk_tsit5<Mo, CC>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
+                           (const int*)h->d_nsteps, (const double*)h->d_arec, (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+    }
     hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
                        (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, (double*)nullptr);
     HIP_TRY(h, hipGetLastError());
@@ -748,6 +770,9 @@ template <class Mo> static int adaptive_adjoint(hipadj_handle* h, const double* 
     case HIPADJ_ALG_BACKSOLVE * 4 + 2: return adaptive_adjoint_l<Mo, 1, 2>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_QUADRATURE * 4 + 0: return adaptive_adjoint_l<Mo, 3, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_QUADRATURE * 4 + 1: return adaptive_adjoint_l<Mo, 3, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_QUADRATURE * 4 + 2: return adaptive_adjoint_l<Mo, 3, 2>(h, d_cot, d_du0, d_dp);
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
     }
 }

@@ -110,7 +110,6 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {
         // adaptive path: no step grid; arbitrary ascending loss times inside [t0, t1]
         if (!plan_small_model(cfg->model)) { err = "adaptive Tsit5 is available for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->alg == HIPADJ_ALG_QUADRATURE) { err = "QuadratureAdjoint with adaptive Tsit5 is not available on the device yet"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg != HIPADJ_ALG_BACKSOLVE && cfg->checkpointing) { err = "checkpointing=true with adaptive Tsit5: Backsolve only (Interpolating/Gauss keep the dense solution)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->ntraj <= 0) { err = "ntraj must be positive"; return HIPADJ_ERR_INVALID_ARG; }
         if (!(cfg->t1 > cfg->t0)) { err = "need t1 > t0"; return HIPADJ_ERR_INVALID_ARG; }
@@ -120,7 +119,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         { const int crc = plan_check_cost(cfg, err); if (crc != HIPADJ_OK) return crc; }
         if (cfg->max_steps < 0) { err = "max_steps must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
         {   // the 8 x NZ stage rows of a wave live in LDS (hipadj_adaptive.hpp): 8 * NZ * 64 lanes * 8 B <= 160 KB
-            const int NZ = cfg->alg == HIPADJ_ALG_INTERPOLATING ? n + np : (cfg->alg == HIPADJ_ALG_BACKSOLVE ? 2 * n + np : n);
+            const int NZ = cfg->alg == HIPADJ_ALG_INTERPOLATING ? n + np : (cfg->alg == HIPADJ_ALG_BACKSOLVE ? 2 * n + np : n);   // Gauss, Quadrature: lam only
             if (8L * NZ * 64 * 8 > 160L * 1024) { err = "adaptive Tsit5: augmented state too large for the LDS stage storage (need 8 * NZ * 512 B <= 160 KB)"; return HIPADJ_ERR_UNSUPPORTED; }
         }
         P.adaptive = true; P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = 0; P.M = cfg->nsave;
@@ -142,8 +141,19 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         std::vector<double> ts(P.save_times); ts.insert(ts.end(), P.ck_times.begin(), P.ck_times.end());
         for (size_t a = 1; a < ts.size(); ++a) { const double v = ts[a]; size_t b = a; while (b > 0 && ts[b - 1] < v) { ts[b] = ts[b - 1]; --b; } ts[b] = v; }
         P.tstops_desc = ts;
-        P.nseg = 1; P.seg_bounds.assign(2, 0); P.nq = 0;
+        P.nseg = 1; P.seg_bounds.assign(2, 0);
         P.save_of_knot.assign(1, -1); P.ckpt_of_knot.assign(1, -1); P.prev_ck.assign(1, 0);
+        P.qa.clear(); P.qb.clear();
+        if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // interval order of src/quadrature_adjoint.jl:563-616 (end correction, pairs descending, start correction)
+            const auto& t = P.save_times;
+            if (t.empty()) { P.qa.push_back(cfg->t0); P.qb.push_back(cfg->t1); }
+            else {
+                if (t.back() != cfg->t1) { P.qa.push_back(t.back()); P.qb.push_back(cfg->t1); }
+                for (int i = (int)t.size() - 2; i >= 0; --i) { P.qa.push_back(t[i]); P.qb.push_back(t[i + 1]); }
+                if (t.front() != cfg->t0) { P.qa.push_back(cfg->t0); P.qb.push_back(t.front()); }
+            }
+        }
+        P.nq = (int)P.qa.size();
         return HIPADJ_OK;
     }
     if (cfg->ntraj <= 0) { err = "ntraj must be positive"; return HIPADJ_ERR_INVALID_ARG; }

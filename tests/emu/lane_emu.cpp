@@ -165,11 +165,25 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     if (flag & 4) return HIPADJ_ERR_MAXITERS;
     if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
     if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
+    const int SmaxA = 2 * P.Smax + P.M + 16;
+    std::vector<double> arec(ALG == 3 ? (size_t)SmaxA * RW * Np : 0);
+    std::vector<int> nsteps_adj((size_t)Np, 0);
+    const double qatol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, qrtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
     for (long i = 0; i < P.N; ++i) {
         double lam[N], mu[NP];
         adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec.data(), nsteps.data(), yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ck_times.data(),
-                                        P.save_times.data(), P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), lam, mu, &flag, kbuf.data(), 1);
+                                        P.save_times.data(), P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), lam, mu, &flag, kbuf.data(), 1,
+                                        arec.empty() ? nullptr : arec.data(), nsteps_adj.data(), SmaxA);
         for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+        if (ALG == 3) {   // k_quad_gk_tsit5 + k_quad_sum
+            if (flag & 4) return HIPADJ_ERR_MAXITERS;
+            for (int j = 0; j < NP; ++j) mu[j] = 0.0;
+            for (int q = 0; q < P.nq; ++q) {
+                double res[NP];
+                quad_gk_tsit5_lane<Mo, 128, CC>(g, i, p, rec.data(), nsteps.data(), arec.data(), nsteps_adj.data(), P.qa[q], P.qb[q], qatol, qrtol, res);
+                for (int j = 0; j < NP; ++j) mu[j] += res[j];
+            }
+        }
         for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[j];
     }
     if (flag & 4) return HIPADJ_ERR_MAXITERS;
@@ -189,6 +203,9 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
     case HIPADJ_ALG_BACKSOLVE * 4 + 2: return run_adaptive<Mo, 1, 2>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_GAUSS * 4 + 0: return run_adaptive<Mo, 2, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_GAUSS * 4 + 1: return run_adaptive<Mo, 2, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_QUADRATURE * 4 + 0: return run_adaptive<Mo, 3, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_QUADRATURE * 4 + 1: return run_adaptive<Mo, 3, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_QUADRATURE * 4 + 2: return run_adaptive<Mo, 3, 2>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     default: return HIPADJ_ERR_UNSUPPORTED;
     }
 }

@@ -178,7 +178,7 @@ def test_no_loss_times_with_cotangent_loss_kind_is_safe():
 
 
 # ---- adaptive Tsit5 (hipadj_adaptive.hpp): the stepper of the reference's own tests ---------------------------------
-TS_ALGS = ["interpolating", "backsolve", "gauss"]
+TS_ALGS = ["interpolating", "backsolve", "gauss", "quadrature"]
 
 
 @pytest.mark.parametrize("alg", TS_ALGS)
@@ -193,10 +193,11 @@ def test_tsit5_lane_bodies_match_oracle(alg, model, omodel, u0c, p):
     ts = np.array([0.0, 0.13, 0.5, 0.77, 1.0, 1.9, 2.0])          # off any grid
     delta = rng.standard_normal((N, len(ts), n))
     ck = alg == "backsolve"
-    cfg = E.make_config(model, alg, N, 0.0, T, 0.0, ts, loss_kind=0, checkpointing=ck, p_shared=False, stepper=1, abstol=1e-8, reltol=1e-7)
+    cfg = E.make_config(model, alg, N, 0.0, T, 0.0, ts, loss_kind=0, checkpointing=ck, p_shared=False, stepper=1, abstol=1e-8, reltol=1e-7,
+                        quad_abstol=1e-9, quad_reltol=1e-9)
     du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
     ref = O.Problem(omodel, alg=alg.upper(), stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-7, save_times=ts,
-                    loss="COTANGENT", checkpointing=ck)
+                    loss="COTANGENT", checkpointing=ck, quad_abstol=1e-9, quad_reltol=1e-9)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
 
@@ -209,7 +210,7 @@ def test_tsit5_reference_test_setup_lvt_matches_golden(alg):
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gradients.json")))["lvt"]
     ts = np.asarray(gold["ts"])
     cfg = E.make_config("lvt", alg, 1, gold["tspan"][0], gold["tspan"][1], 0.0, ts, loss_kind=1, loss_shift=2.0,
-                        checkpointing=(alg == "backsolve"), stepper=1, abstol=1e-12, reltol=1e-12, max_steps=20000)
+                        checkpointing=(alg == "backsolve"), stepper=1, abstol=1e-12, reltol=1e-12, max_steps=20000, quad_abstol=1e-12, quad_reltol=1e-12)
     du0, dp, _ = E.forward_adjoint(cfg, 2, 4, np.asarray([gold["u0"]]), np.asarray(gold["p"]))
     tol = 1e-6 if alg != "backsolve" else 1e-5
     assert rel(du0[0], np.asarray(gold["du0"])) < tol and rel(dp, np.asarray(gold["dp"])) < tol
@@ -221,10 +222,11 @@ def test_tsit5_no_start_initial_dt_hint_and_continuous_cost():
         for alg in TS_ALGS:
             if alg == "backsolve" and "no_start" in kw:
                 continue
-            cfg = E.make_config("lv", alg, 1, 0.0, 1.0, 0.05, ts, loss_kind=1, loss_shift=2.0, stepper=1, abstol=1e-9, reltol=1e-9, **kw)
+            cfg = E.make_config("lv", alg, 1, 0.0, 1.0, 0.05, ts, loss_kind=1, loss_shift=2.0, stepper=1, abstol=1e-9, reltol=1e-9,
+                                quad_abstol=1e-10, quad_reltol=1e-10, **kw)
             du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
             ref = O.Problem("LV", alg=alg.upper(), stepper="TSIT5", t0=0, t1=1.0, dt=0.05, abstol=1e-9, reltol=1e-9, save_times=ts,
-                            loss="LSQ_SHIFT", loss_shift=2.0, **okw)
+                            loss="LSQ_SHIFT", loss_shift=2.0, quad_abstol=1e-10, quad_reltol=1e-10, **okw)
             rdu0, rdp, _ = ref.adjoint(u0[0], p)
             assert rel(du0[0], rdu0) < 1e-11 and rel(dp, rdp) < 1e-11, (kw, alg)
 
@@ -234,7 +236,7 @@ def test_tsit5_max_steps_overflow_is_an_error_and_plan_rejections():
     cfg = E.make_config("lorenz", "interpolating", 1, 0.0, 10.0, 0.0, [10.0], loss_kind=1, stepper=1, abstol=1e-10, reltol=1e-10, max_steps=50)
     with pytest.raises(RuntimeError, match="rc=-7"):
         E.forward_adjoint(cfg, 3, 3, u0, p)
-    for bad in (dict(alg="quadrature"), dict(alg="interpolating", checkpointing=True), dict(alg="gauss", abstol=0.0),
+    for bad in (dict(alg="interpolating", checkpointing=True), dict(alg="gauss", abstol=0.0),
                 dict(alg="interpolating", ts=[0.5, 0.5]), dict(alg="interpolating", ts=[11.0])):
         kw = dict(bad); alg = kw.pop("alg"); ts = kw.pop("ts", [1.0])
         cfg = E.make_config("lorenz", alg, 1, 0.0, 10.0, 0.0, ts, stepper=1, **kw)
@@ -260,13 +262,14 @@ def test_mixed_cost_with_parameter_term_rk4(alg, segments):
     assert rel(du0, rdu0) < 1e-11 and rel(dp, rdp) < 1e-11
 
 
-@pytest.mark.parametrize("alg", ["interpolating", "backsolve"])
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve", "quadrature"])
 def test_mixed_cost_tsit5_against_golden(alg):
     """The reference's own setup: LV, G = int_0^10 u1^2 + p1 dt, Tsit5 with tight tolerances, against the DOP853
     forward-sensitivity gradient (tests/golden/gradients.json: lv_mixed_cost)."""
     import json, os
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gradients.json")))["lv_mixed_cost"]
-    cfg = E.make_config("lv", alg, 1, 0.0, 10.0, 0.0, [], loss_kind=1, cont_cost=2, stepper=1, abstol=1e-12, reltol=1e-12, max_steps=20000)
+    cfg = E.make_config("lv", alg, 1, 0.0, 10.0, 0.0, [], loss_kind=1, cont_cost=2, stepper=1, abstol=1e-12, reltol=1e-12, max_steps=20000,
+                        quad_abstol=1e-12, quad_reltol=1e-12)
     du0, dp, _ = E.forward_adjoint(cfg, 2, 4, np.asarray([gold["u0"]]), np.asarray(gold["p"]))
     assert rel(du0[0], np.asarray(gold["du0"])) < 1e-8 and rel(dp, np.asarray(gold["dp"])) < 1e-8
 

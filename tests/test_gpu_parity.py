@@ -449,7 +449,11 @@ def test_continuous_cost_on_device(sa, alg, oalg):
 
 
 # ---- adaptive Tsit5 on the device (csrc/hipadj_adaptive.hpp) ---------------------------------------------------------
-TS_ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS")]
+TS_ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE")]
+
+
+def ts_sensealg(sa, alg, tol=1e-10):
+    return sa.QuadratureAdjoint(abstol=tol, reltol=tol) if alg == "quadrature" else sensealg_of(sa, alg)
 
 
 @pytest.mark.parametrize("alg,oalg", TS_ALGS)
@@ -473,10 +477,10 @@ def test_tsit5_cotangent_all_models(sa, alg, oalg, model, omodel, u0c, p):
     delta = rng.standard_normal((N, len(ts), n))
     ck = alg == "backsolve"
     sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model, u0[0], (0, T), pp[0]), u0, pp), sa.Tsit5(), saveat=ts,
-                   sensealg=sensealg_of(sa, alg), abstol=1e-9, reltol=1e-9)
+                   sensealg=ts_sensealg(sa, alg), abstol=1e-9, reltol=1e-9)
     du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=delta)
     ref = O.Problem(omodel, alg=oalg, stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts,
-                    loss="COTANGENT", checkpointing=ck)
+                    loss="COTANGENT", checkpointing=ck, quad_abstol=1e-10, quad_reltol=1e-10)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     sol.engine.close()
@@ -491,7 +495,7 @@ def test_tsit5_reference_lvt_setup_against_golden(sa, alg, oalg):
     ts = np.asarray(gold["ts"])
     u0 = np.asarray([gold["u0"]]); p = np.asarray(gold["p"])
     sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lvt", u0[0], tuple(gold["tspan"]), p), u0), sa.Tsit5(), saveat=ts,
-                   sensealg=sensealg_of(sa, alg), dgdu_discrete=sa.LsqShift(2.0), abstol=1e-12, reltol=1e-12, max_steps=20000)
+                   sensealg=ts_sensealg(sa, alg, 1e-12), dgdu_discrete=sa.LsqShift(2.0), abstol=1e-12, reltol=1e-12, max_steps=20000)
     du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
     tol = 1e-6 if alg != "backsolve" else 1e-5       # Backsolve re-integrates y backwards: the reference tests loosen it too (adjoint.jl:371)
     assert rel(sol.u[0], np.asarray(gold["u"])) < 1e-8
@@ -562,8 +566,6 @@ def test_runtime_lv_equals_builtin_lv(sa, alg, oalg):
 def test_runtime_models_match_oracle(sa, name, omodel, dims, alg, oalg, stepper):
     """Models the library has never seen: Robertson kinetics (test/Core3/adjoint.jl:1434-1441, mild rates) and the synthetic
     ring with n = 4 (time-segmented, prefetch depth 4) and n = 6 (too many columns to segment, depth 2)."""
-    if stepper == "tsit5" and alg == "quadrature":
-        pytest.skip("QuadratureAdjoint is not wired for the adaptive path")
     m = UM.ROBER if name == "rober" else UM.ring(dims[0])
     f = _device_function(sa, name + "_runtime", m)
     rng = np.random.default_rng(43)
@@ -577,9 +579,9 @@ def test_runtime_models_match_oracle(sa, name, omodel, dims, alg, oalg, stepper)
         salg, kw, okw = sa.RK4(), dict(dt=dt), dict(stepper="RK4", dt=dt)
     else:
         salg, kw, okw = sa.Tsit5(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
-    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), salg, saveat=ts, sensealg=sensealg_of(sa, alg), **kw)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), salg, saveat=ts, sensealg=ts_sensealg(sa, alg), **kw)
     du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=delta)
-    ref = O.Problem(omodel, alg=oalg, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=ck, dims=dims, **okw)
+    ref = O.Problem(omodel, alg=oalg, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=ck, dims=dims, quad_abstol=1e-10, quad_reltol=1e-10, **okw)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     sol.engine.close()
@@ -596,8 +598,6 @@ def test_runtime_model_compile_error_surfaces_at_solve(sa):
 @pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("quadrature", "QUADRATURE")])
 def test_mixed_cost_with_parameter_term(sa, alg, oalg, stepper):
     """g = u1^2 + p1 on LV (test/Core7/mixed_costs.jl:13-57) plus a discrete LSQ loss, ensemble of 100."""
-    if stepper == "tsit5" and alg == "quadrature":
-        pytest.skip("QuadratureAdjoint is not wired for the adaptive path")
     rng = np.random.default_rng(51)
     N, T = 100, 2.0
     u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
