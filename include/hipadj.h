@@ -59,8 +59,8 @@ typedef enum {
 typedef enum {
     HIPADJ_STEPPER_RK4_FIXED = 0,      /* fixed-step classic RK4, cubic-Hermite dense output; loss times on the step grid */
     HIPADJ_STEPPER_TSIT5_ADAPTIVE = 1  /* adaptive Tsit5 with per-trajectory step control and its own interpolant (the stepper of
-                                          the reference's tests); arbitrary loss times; lane-per-trajectory models;
-                                          Interpolating / Backsolve / Gauss */
+                                          the reference's tests); arbitrary loss times; lane-per-trajectory models; all four
+                                          sensealgs (checkpointing=true: Backsolve only) */
 } hipadj_stepper;
 
 /* how dgdu_discrete(out, u, p, t, i) is evaluated at loss time t_i (src/adjoint_common.jl:771-773) */
