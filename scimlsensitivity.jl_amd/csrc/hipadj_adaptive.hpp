@@ -37,7 +37,7 @@ namespace hipadj {
 
 struct AdaptGeom {
     long N, Npad;
-    int M, Smax, nck;
+    int M, Smax, nck, SmaxI;   // SmaxI: record capacity of ONE checkpoint interval (checkpointing=true for Interpolating/Gauss)
     double t0, t1, dt0, abstol, reltol;
     double loss_shift;
     int loss_kind, no_start, p_shared, cont_cost;
@@ -135,10 +135,15 @@ HIPADJ_HD void poly_eval(double th, const double (&c)[5][NZ], double (&y)[NZ]) {
 //   the start when cb_at_init) and returns true when it modified u (=> the FSAL derivative is recomputed,
 //   derivative_discontinuity!).  tstops: ntstops times sorted along the integration direction.
 // Returns the number of accepted steps, or -1 when max_steps was exceeded.
-template <int NZ, class Rhs, class Cb>
+struct NoPre { HIPADJ_HD void operator()(double) const {} };
+
+// pre(t) runs at the top of every step attempt, AFTER a pending k_1 = f(u, t) was evaluated: the checkpointed sweeps
+// switch their interval solution there, so that every evaluation AT a checkpoint time still reads the interval above
+// (as the reference's `t in interval` test does) and every stage below it reads the re-solved interval.
+template <int NZ, class Rhs, class Cb, class Pre = NoPre>
 HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, double dt_hint, double abstol, double reltol,
                               const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps,
-                              const KStore<NZ>& K, Rhs&& rhs, Cb&& cb) {
+                              const KStore<NZ>& K, Rhs&& rhs, Cb&& cb, Pre&& pre = NoPre()) {
     const double EPS = 2.220446049250313e-16;
     const double tdir = tend >= tstart ? 1.0 : -1.0;
     double t = tstart, tprev = tstart;
@@ -186,6 +191,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
                 dt = tdir * hmin2(hmin2(100.0 * h0, h1), habs(tend - t));
             }
         }
+        pre(t);
         // next stop: the first tstop strictly ahead of t (beyond the 100-eps snap), else tend
         while (its < ntstops && tdir * tstops[its] <= tdir * t + 100.0 * EPS * hmax2(habs(t), habs(tstops[its]))) ++its;
         double tstop = tend;
@@ -403,19 +409,53 @@ template <class Mo> struct AdjCursor {
     }
 };
 
-template <class Mo, int ALG, int CC>
+// CK = true (Interpolating / Gauss with checkpointing=true, src/interpolating_adjoint.jl:54-109, 207-277): no dense forward
+// solution exists; `lrec` is this lane's buffer for ONE checkpoint interval [c_j, c_{j+1}] (capacity g.SmaxI steps), re-solved
+// from the stored sol(c_j) with the forward tolerances and dt = |last step of the previous interval solution| (:245-251)
+// whenever the sweep steps below the current interval; the last interval is solved eagerly (:88-92).
+template <class Mo, int ALG, int CC, bool CK = false>
 HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __restrict__ p, const double* __restrict__ rec,
                                   const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
                                   const double* __restrict__ ck_t, const double* __restrict__ save_t, const double* __restrict__ tstops_desc,
                                   int ntstops, const double* __restrict__ cotT, double (&lam_out)[Mo::N], double (&mu_out)[Mo::NP], int* __restrict__ flag,
-                                  double* kbase, int kstride, double* __restrict__ arec = nullptr, int* __restrict__ nsteps_adj = nullptr, int SmaxA = 0) {
+                                  double* kbase, int kstride, double* __restrict__ arec = nullptr, int* __restrict__ nsteps_adj = nullptr, int SmaxA = 0,
+                                  double* kfbase = nullptr, double* lrec = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP, NZ = AdjNZ<Mo, ALG>::value;
     const KStore<NZ> K{kbase, kstride};
     double pv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
     FwdCursor<Mo> cur;
-    if (ALG != 1) cur.init(rec, g.Npad, i, nsteps[i]);
+    int icur = g.nck - 2;            // CK: checkpoint interval the cursor's records belong to
+    bool ck_overflow = false;
+    auto resolve = [&](int j, double dt_hint) {
+        constexpr int RW = 2 + 5 * N;
+        const KStore<N> KF{kfbase, kstride};
+        double uu[N];
+#pragma unroll
+        for (int jj = 0; jj < N; ++jj) uu[jj] = ckpt[((long)j * N + jj) * g.Npad + i];
+        int sl = 0;
+        const int nr = tsit5_integrate<N>(uu, ck_t[j], ck_t[j + 1], dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF,
+            [&](double (&du)[N], const double (&u_)[N], double t) { Mo::f(du, u_, pv, t); },
+            [&](double t, double tprev, double (&un)[N], const KStore<N>& KK) -> bool {
+                (void)un;
+                if (sl < g.SmaxI) {
+                    double c[5][N]; tsit5_poly<N>(KK, t - tprev, c);
+                    lrec[((long)sl * RW + 0) * g.Npad + i] = tprev; lrec[((long)sl * RW + 1) * g.Npad + i] = t;
+#pragma unroll
+                    for (int m = 0; m < 5; ++m)
+#pragma unroll
+                        for (int jj = 0; jj < N; ++jj) lrec[((long)sl * RW + 2 + m * N + jj) * g.Npad + i] = c[m][jj];
+                } else ck_overflow = true;
+                ++sl;
+                return false;
+            });
+        if (nr < 0) ck_overflow = true;
+        cur.init(lrec, g.Npad, i, sl < g.SmaxI ? sl : g.SmaxI);
+        icur = j;
+    };
+    if (CK) resolve(g.nck - 2, 0.0);
+    else if (ALG != 1) cur.init(rec, g.Npad, i, nsteps[i]);
     double z[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) z[j] = 0.0;
@@ -509,7 +549,15 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         return mod;
     };
     const bool cb_at_init = g.M > 0 && time_hits(g.t1, save_t[g.M - 1]);
-    const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.Smax, K, rhs, cb);
+    auto pre = [&](double t) {
+        if (CK) {
+            if (icur > 0 && !(t > ck_t[icur])) {   // the sweep stands on (or below) the lower end of its interval: the next stages need the one below
+                const double dtl = cur.ns > 0 ? habs(lrec[((long)(cur.ns - 1) * (2 + 5 * N) + 1) * g.Npad + i] - lrec[((long)(cur.ns - 1) * (2 + 5 * N) + 0) * g.Npad + i]) : 0.0;
+                resolve(icur - 1, dtl);
+            }
+        }
+    };
+    const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.Smax, K, rhs, cb, pre);
 #pragma unroll
     for (int j = 0; j < N; ++j) lam_out[j] = z[j];
 #pragma unroll
@@ -519,7 +567,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         else mu_out[j] = z[N + j];
     }
     if (ALG == 3) nsteps_adj[i] = sa < SmaxA ? sa : SmaxA;
-    if (na < 0 || aoverflow) {
+    if (na < 0 || aoverflow || ck_overflow) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(flag, 4);
 #else
@@ -619,18 +667,19 @@ __global__ void __launch_bounds__(64) k_forward_tsit5(AdaptGeom g, const double*
     forward_tsit5_lane<Mo>(g, i, u0, p, rec, nsteps, save_t, outT, ck_t, ckpt, yT, flag, ks + threadIdx.x, 64);
 }
 
-template <class Mo, int ALG, int CC>
+template <class Mo, int ALG, int CC, bool CK = false>
 __global__ void __launch_bounds__(64) k_adjoint_tsit5(AdaptGeom g, const double* __restrict__ p, const double* __restrict__ rec,
                                                       const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
                                                       const double* __restrict__ ck_t, const double* __restrict__ save_t,
                                                       const double* __restrict__ tstops_desc, int ntstops, const double* __restrict__ cotT,
                                                       double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
                                                       double* __restrict__ arec, int* __restrict__ nsteps_adj, int SmaxA) {
-    __shared__ double ks[KS_ROWS * AdjNZ<Mo, ALG>::value * 64];
+    __shared__ double ks[KS_ROWS * (AdjNZ<Mo, ALG>::value + (CK ? Mo::N : 0)) * 64];   // CK: + the stage rows of the interval re-solve
     const long i = (long)blockIdx.x * 64 + threadIdx.x;
     if (i >= g.N) return;
     double lam[Mo::N], mu[Mo::NP];
-    adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec, nsteps, yT, ckpt, ck_t, save_t, tstops_desc, ntstops, cotT, lam, mu, flag, ks + threadIdx.x, 64, arec, nsteps_adj, SmaxA);
+    adjoint_tsit5_lane<Mo, ALG, CC, CK>(g, i, p, rec, nsteps, yT, ckpt, ck_t, save_t, tstops_desc, ntstops, cotT, lam, mu, flag, ks + threadIdx.x, 64, arec, nsteps_adj, SmaxA,
+                                        ks + KS_ROWS * AdjNZ<Mo, ALG>::value * 64 + threadIdx.x, CK ? const_cast<double*>(rec) : nullptr);
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) du0[i * Mo::N + j] = lam[j];
     if (ALG != 3) {

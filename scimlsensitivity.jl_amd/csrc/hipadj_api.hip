@@ -165,7 +165,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         const int RW = 2 + 5 * n;   // record width, hipadj_adaptive.hpp
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
-        if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)P.Smax * RW * Np));
+        if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)(P.ip_ckpt ? P.SmaxI : P.Smax) * RW * Np));   // checkpointing=true: one interval per lane
         A(dev_alloc(h, &h->d_nsteps, (size_t)Np));
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // dense adjoint solution: the reverse solve also stops at every loss time
             h->SmaxA = 2 * P.Smax + h->M + 16;
@@ -185,7 +185,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             if (!ok2) rc = HIPADJ_ERR_HIP;
         }
         AdaptGeom& ag = h->ag;
-        ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = P.Smax; ag.nck = P.nck; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
+        ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = P.Smax; ag.nck = P.nck; ag.SmaxI = P.SmaxI; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
         ag.abstol = cfg->abstol; ag.reltol = cfg->reltol; ag.loss_shift = cfg->loss_shift; ag.loss_kind = cfg->loss_kind;
         ag.no_start = cfg->no_start; ag.p_shared = cfg->p_shared; ag.cont_cost = cfg->cont_cost;
     } else if (!P.field && !P.mlp) {
@@ -607,7 +607,7 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     const std::string finish = "hipadj::k_finish<" + I(n) + ", " + I(np) + ">", compose = "hipadj::k_compose_finish<" + U + ">";
     if (h->adaptive) {
         k.forward = "hipadj::k_forward_tsit5<" + U + ">";
-        k.main_k = "hipadj::k_adjoint_tsit5<" + U + ", " + I(h->cfg.alg) + ", " + I(cc) + ">";
+        k.main_k = "hipadj::k_adjoint_tsit5<" + U + ", " + I(h->cfg.alg) + ", " + I(cc) + (h->ip_ckpt ? ", true>" : ", false>");
         if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) k.gk = "hipadj::k_quad_gk_tsit5<" + U + ", " + I(cc) + ">";
         k.tail = finish;
         return k;
@@ -648,7 +648,7 @@ static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     double* outT = (d_out && h->M > 0) ? h->d_outT : (double*)nullptr;
     if (h->adaptive)
-        TRY(ulaunch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->d_rec, h->d_nsteps, (const double*)h->d_save_t, outT,
+        TRY(ulaunch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps, (const double*)h->d_save_t, outT,
                     (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag));
     else
         TRY(ulaunch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
@@ -719,13 +719,13 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
 // ---- adaptive Tsit5 (hipadj_adaptive.hpp) ------------------------------------------------------------------
 template <class Mo> static int adaptive_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
-    hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->d_rec, h->d_nsteps,
+    hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
                        (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
     HIP_TRY(h, hipGetLastError());
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
     return HIPADJ_OK;
 }
-template <class Mo, int ALG, int CC> static int adaptive_adjoint_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+template <class Mo, int ALG, int CC, bool CK = false> static int adaptive_adjoint_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
@@ -735,7 +735,7 @@ template <class Mo, int ALG, int CC> static int adaptive_adjoint_l(hipadj_handle
     harvest_set(h, es, true);
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
-    hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
+    hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
                        (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
                        (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag,
                        h->d_arec, h->d_nsteps_adj, h->SmaxA);
@@ -761,6 +761,16 @@ template <class Mo, int ALG, int CC> static int adaptive_adjoint_l(hipadj_handle
     return HIPADJ_OK;
 }
 template <class Mo> static int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    if (h->ip_ckpt) {   // checkpointing=true for Interpolating / Gauss: per-interval re-solve inside the sweep
+        switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
+        case HIPADJ_ALG_INTERPOLATING * 4 + 0: return adaptive_adjoint_l<Mo, 0, 0, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_INTERPOLATING * 4 + 1: return adaptive_adjoint_l<Mo, 0, 1, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_INTERPOLATING * 4 + 2: return adaptive_adjoint_l<Mo, 0, 2, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1, true>(h, d_cot, d_du0, d_dp);
+        default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no checkpointed adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
+        }
+    }
     switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
     case HIPADJ_ALG_INTERPOLATING * 4 + 0: return adaptive_adjoint_l<Mo, 0, 0>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_INTERPOLATING * 4 + 1: return adaptive_adjoint_l<Mo, 0, 1>(h, d_cot, d_du0, d_dp);

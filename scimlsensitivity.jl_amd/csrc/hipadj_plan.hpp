@@ -32,6 +32,7 @@ struct Plan {
     bool adaptive = false;   // adaptive Tsit5 (hipadj_adaptive.hpp)
     bool user = false;       // runtime-compiled right-hand side (hipadj_user.hpp)
     int Smax = 0;            // capacity of the per-trajectory dense solution (adaptive)
+    int SmaxI = 0;           // adaptive + checkpointing=true (Interpolating/Gauss): record capacity of ONE checkpoint interval
     std::vector<double> ck_times, tstops_desc;   // adaptive: checkpoint times (ascending), reverse tstops (descending)
     int NQ = 0;              // activation records per step (MLP)
 };
@@ -110,7 +111,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {
         // adaptive path: no step grid; arbitrary ascending loss times inside [t0, t1]
         if (!plan_small_model(cfg->model)) { err = "adaptive Tsit5 is available for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->alg != HIPADJ_ALG_BACKSOLVE && cfg->checkpointing) { err = "checkpointing=true with adaptive Tsit5: Backsolve only (Interpolating/Gauss keep the dense solution)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg == HIPADJ_ALG_QUADRATURE && cfg->checkpointing) { err = "QuadratureAdjoint has no checkpointing (src/sensitivity_algorithms.jl:1665-1677)"; return HIPADJ_ERR_INVALID_ARG; }
         if (cfg->ntraj <= 0) { err = "ntraj must be positive"; return HIPADJ_ERR_INVALID_ARG; }
         if (!(cfg->t1 > cfg->t0)) { err = "need t1 > t0"; return HIPADJ_ERR_INVALID_ARG; }
         if (!(cfg->abstol > 0) || !(cfg->reltol > 0)) { err = "adaptive Tsit5 needs abstol > 0 and reltol > 0"; return HIPADJ_ERR_INVALID_ARG; }
@@ -120,7 +121,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (cfg->max_steps < 0) { err = "max_steps must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
         {   // the 8 x NZ stage rows of a wave live in LDS (hipadj_adaptive.hpp): 8 * NZ * 64 lanes * 8 B <= 160 KB
             const int NZ = cfg->alg == HIPADJ_ALG_INTERPOLATING ? n + np : (cfg->alg == HIPADJ_ALG_BACKSOLVE ? 2 * n + np : n);   // Gauss, Quadrature: lam only
-            if (8L * NZ * 64 * 8 > 160L * 1024) { err = "adaptive Tsit5: augmented state too large for the LDS stage storage (need 8 * NZ * 512 B <= 160 KB)"; return HIPADJ_ERR_UNSUPPORTED; }
+            const bool ipck = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing;   // + the rows of the interval re-solve
+            if (8L * (NZ + (ipck ? n : 0)) * 64 * 8 > 160L * 1024) { err = "adaptive Tsit5: augmented state too large for the LDS stage storage (need 8 * NZ * 512 B <= 160 KB)"; return HIPADJ_ERR_UNSUPPORTED; }
         }
         P.adaptive = true; P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = 0; P.M = cfg->nsave;
         P.Smax = cfg->max_steps > 0 ? cfg->max_steps : 2048;
@@ -130,13 +132,15 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
             if (i > 0 && !(cfg->save_times[i] > cfg->save_times[i - 1])) { err = "save_times must be strictly ascending (duplicate event times are out of scope)"; return HIPADJ_ERR_INVALID_ARG; }
         }
         P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
+        P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing;
         P.ck_times.clear();
-        if (P.bs_ckpt) {   // default checkpoints = sol.t of the saveat solve: t0, save times, t1 (src/backsolve_adjoint.jl:132)
+        if (P.bs_ckpt || P.ip_ckpt) {   // default checkpoints = sol.t of the saveat solve: t0, save times, t1 (src/backsolve_adjoint.jl:132)
             if (P.save_times.empty() || P.save_times.front() > cfg->t0) P.ck_times.push_back(cfg->t0);
             for (double t : P.save_times) P.ck_times.push_back(t);
             if (P.ck_times.back() < cfg->t1) P.ck_times.push_back(cfg->t1);
         }
         P.nck = (int)P.ck_times.size();
+        if (P.ip_ckpt) { const int per = 4 * P.Smax / (P.nck > 1 ? P.nck - 1 : 1); P.SmaxI = per < 64 ? 64 : per; }
         // reverse tstops: loss times (PresetTimeCallback) + checkpoint times, descending
         std::vector<double> ts(P.save_times); ts.insert(ts.end(), P.ck_times.begin(), P.ck_times.end());
         for (size_t a = 1; a < ts.size(); ++a) { const double v = ts[a]; size_t b = a; while (b > 0 && ts[b - 1] < v) { ts[b] = ts[b - 1]; --b; } ts[b] = v; }

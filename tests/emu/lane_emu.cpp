@@ -145,21 +145,21 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
 }
 
 // adaptive Tsit5: loops the lane bodies of hipadj_adaptive.hpp exactly as k_forward_tsit5 / k_adjoint_tsit5 + k_finish do
-template <class Mo, int ALG, int CC>
+template <class Mo, int ALG, int CC, bool CK = false>
 static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
                         double* du0, double* dp, double* out, int* nsteps_out) {
     constexpr int N = Mo::N, NP = Mo::NP, RW = 2 + 5 * N;
     AdaptGeom g; g.N = P.N; g.Npad = P.Npad; g.M = P.M; g.Smax = P.Smax; g.nck = P.nck; g.t0 = cfg->t0; g.t1 = cfg->t1; g.dt0 = cfg->dt;
     g.abstol = cfg->abstol; g.reltol = cfg->reltol; g.loss_shift = cfg->loss_shift; g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start;
-    g.p_shared = cfg->p_shared; g.cont_cost = cfg->cont_cost;
+    g.p_shared = cfg->p_shared; g.cont_cost = cfg->cont_cost; g.SmaxI = P.SmaxI;
     const long Np = P.Npad;
-    std::vector<double> rec(ALG != 1 ? (size_t)P.Smax * RW * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np), ckpt((size_t)P.nck * N * Np);
+    std::vector<double> rec(ALG != 1 ? (size_t)(CK ? P.SmaxI : P.Smax) * RW * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np), ckpt((size_t)P.nck * N * Np);
     std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
     std::vector<int> nsteps((size_t)Np, 0);
     int flag = 0;
-    std::vector<double> kbuf((size_t)KS_ROWS * (2 * N + NP));   // stage storage of one lane (LDS columns on the device), stride 1 here
+    std::vector<double> kbuf((size_t)KS_ROWS * (2 * N + NP)), kfbuf((size_t)KS_ROWS * N);   // stage storage of one lane (LDS columns on the device), stride 1 here
     for (long i = 0; i < P.N; ++i)
-        forward_tsit5_lane<Mo>(g, i, u0, p, rec.empty() ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(),
+        forward_tsit5_lane<Mo>(g, i, u0, p, (rec.empty() || CK) ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(),
                                P.ck_times.data(), ckpt.empty() ? nullptr : ckpt.data(), yT.data(), &flag, kbuf.data(), 1);
     if (nsteps_out) for (long i = 0; i < P.N; ++i) nsteps_out[i] = nsteps[i];
     if (flag & 4) return HIPADJ_ERR_MAXITERS;
@@ -171,9 +171,9 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     const double qatol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, qrtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
     for (long i = 0; i < P.N; ++i) {
         double lam[N], mu[NP];
-        adjoint_tsit5_lane<Mo, ALG, CC>(g, i, p, rec.data(), nsteps.data(), yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ck_times.data(),
-                                        P.save_times.data(), P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), lam, mu, &flag, kbuf.data(), 1,
-                                        arec.empty() ? nullptr : arec.data(), nsteps_adj.data(), SmaxA);
+        adjoint_tsit5_lane<Mo, ALG, CC, CK>(g, i, p, rec.data(), nsteps.data(), yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ck_times.data(),
+                                            P.save_times.data(), P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), lam, mu, &flag, kbuf.data(), 1,
+                                            arec.empty() ? nullptr : arec.data(), nsteps_adj.data(), SmaxA, kfbuf.data(), CK ? rec.data() : nullptr);
         for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
         if (ALG == 3) {   // k_quad_gk_tsit5 + k_quad_sum
             if (flag & 4) return HIPADJ_ERR_MAXITERS;
@@ -194,6 +194,16 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
 
 template <class Mo>
 static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* ns) {
+    if (P.ip_ckpt) {
+        switch (cfg->alg * 4 + cfg->cont_cost) {
+        case HIPADJ_ALG_INTERPOLATING * 4 + 0: return run_adaptive<Mo, 0, 0, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_INTERPOLATING * 4 + 1: return run_adaptive<Mo, 0, 1, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_INTERPOLATING * 4 + 2: return run_adaptive<Mo, 0, 2, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_GAUSS * 4 + 0: return run_adaptive<Mo, 2, 0, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_GAUSS * 4 + 1: return run_adaptive<Mo, 2, 1, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        default: return HIPADJ_ERR_UNSUPPORTED;
+        }
+    }
     switch (cfg->alg * 4 + cfg->cont_cost) {
     case HIPADJ_ALG_INTERPOLATING * 4 + 0: return run_adaptive<Mo, 0, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_INTERPOLATING * 4 + 1: return run_adaptive<Mo, 0, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);

@@ -236,7 +236,7 @@ def test_tsit5_max_steps_overflow_is_an_error_and_plan_rejections():
     cfg = E.make_config("lorenz", "interpolating", 1, 0.0, 10.0, 0.0, [10.0], loss_kind=1, stepper=1, abstol=1e-10, reltol=1e-10, max_steps=50)
     with pytest.raises(RuntimeError, match="rc=-7"):
         E.forward_adjoint(cfg, 3, 3, u0, p)
-    for bad in (dict(alg="interpolating", checkpointing=True), dict(alg="gauss", abstol=0.0),
+    for bad in (dict(alg="quadrature", checkpointing=True), dict(alg="gauss", abstol=0.0),
                 dict(alg="interpolating", ts=[0.5, 0.5]), dict(alg="interpolating", ts=[11.0])):
         kw = dict(bad); alg = kw.pop("alg"); ts = kw.pop("ts", [1.0])
         cfg = E.make_config("lorenz", alg, 1, 0.0, 10.0, 0.0, ts, stepper=1, **kw)
@@ -279,3 +279,28 @@ def test_gauss_with_parameter_dependent_cost_is_rejected():
         cfg = E.make_config("lv", "gauss", 1, 0.0, 1.0, 0.1, [1.0], loss_kind=1, cont_cost=2, stepper=stepper)
         with pytest.raises(RuntimeError, match="rc=-6"):
             E.forward_adjoint(cfg, 2, 4, np.ones((1, 2)), np.array([1.5, 1.0, 3.0, 1.0]))
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "gauss"])
+@pytest.mark.parametrize("tol", [1e-9, 1e-5])
+def test_tsit5_checkpointed_interpolating_gauss_resolve_intervals(alg, tol):
+    """checkpointing=true with Tsit5 (src/interpolating_adjoint.jl:54-109, 207-277): per-interval adaptive re-solve from the
+    stored checkpoint with dt = |last step of the previous interval solution|; interval switch semantics identical to the
+    oracle's, so even loose tolerances agree to roundoff."""
+    rng = np.random.default_rng(61)
+    N, T = 3, 3.0
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.array([0.4, 1.0, 1.7, 2.2, 3.0])
+    cfg = E.make_config("lorenz", alg, N, 0.0, T, 0.0, ts, loss_kind=1, loss_shift=2.0, stepper=1, abstol=tol, reltol=tol, checkpointing=True)
+    du0, dp, out = E.forward_adjoint(cfg, 3, 3, u0, p)
+    ref = O.Problem("LORENZ", alg=alg.upper(), stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=tol, reltol=tol, save_times=ts, loss="LSQ_SHIFT",
+                    loss_shift=2.0, checkpointing=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+def test_tsit5_checkpoint_interval_overflow_is_an_error():
+    u0 = np.array([[1.0, 0.0, 0.0]]); p = np.array([10.0, 28.0, 8 / 3])
+    cfg = E.make_config("lorenz", "interpolating", 1, 0.0, 10.0, 0.0, [10.0], loss_kind=1, stepper=1, abstol=1e-11, reltol=1e-11, checkpointing=True, max_steps=10)
+    with pytest.raises(RuntimeError, match="rc=-7"):
+        E.forward_adjoint(cfg, 3, 3, u0, p)

@@ -657,3 +657,22 @@ def test_gauss_with_parameter_dependent_cost_is_rejected(sa):
         sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, 1.0), p), u0), sa.RK4(), dt=0.1, saveat=[1.0], sensealg=sa.GaussAdjoint(),
                  g=sa.FirstStateSquaredPlusFirstParam())
     assert e.value.status == -6
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+@pytest.mark.parametrize("tol", [1e-9, 1e-5])
+def test_tsit5_checkpointed_interpolating_gauss(sa, alg, oalg, tol):
+    """checkpointing=true with Tsit5: no dense forward solution in HBM, per-lane adaptive re-solve of one checkpoint interval."""
+    N, T = 200, 3.0
+    u0, p = lorenz_inputs(N, seed=5)
+    ts = np.array([0.4, 1.0, 1.7, 2.2, 3.0])
+    sens = sa.InterpolatingAdjoint(checkpointing=True) if alg == "interpolating" else sa.GaussAdjoint(checkpointing=True)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=sens,
+                   dgdu_discrete=sa.LsqShift(2.0), abstol=tol, reltol=tol)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+    ref = O.Problem("LORENZ", alg=oalg, stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=tol, reltol=tol, save_times=ts, loss="LSQ_SHIFT",
+                    loss_shift=2.0, checkpointing=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    assert sol.engine.stats()["workspace_bytes"] < 50e6        # no 2048-step dense record buffer
+    sol.engine.close()
