@@ -140,7 +140,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
             if (P.ck_times.back() < cfg->t1) P.ck_times.push_back(cfg->t1);
         }
         P.nck = (int)P.ck_times.size();
-        if (P.ip_ckpt) { const int per = 4 * P.Smax / (P.nck > 1 ? P.nck - 1 : 1); P.SmaxI = per < 64 ? 64 : per; }
+        if (P.ip_ckpt) { const int per = 2 * P.Smax / (P.nck > 1 ? P.nck - 1 : 1); P.SmaxI = per < 64 ? 64 : per; }   // twice the average share of an interval
         // reverse tstops: loss times (PresetTimeCallback) + checkpoint times, descending
         std::vector<double> ts(P.save_times); ts.insert(ts.end(), P.ck_times.begin(), P.ck_times.end());
         for (size_t a = 1; a < ts.size(); ++a) { const double v = ts[a]; size_t b = a; while (b > 0 && ts[b - 1] < v) { ts[b] = ts[b - 1]; --b; } ts[b] = v; }
