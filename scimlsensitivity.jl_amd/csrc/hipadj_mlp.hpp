@@ -65,7 +65,10 @@ template <int H> __device__ __forceinline__ MlpW<H> mlp_weights(const double* __
 }
 
 // LDS of one workgroup: the exchanged activation tile and the cross-wave reduction scratch
+// wfrag (adjoint kernel only): W2^T in MFMA A-fragment order — fragment (row tile t, K-step st) is 64 consecutive doubles
+// (lane l holds W2^T[16 t + (l&15)][4 st + (l>>4)]), so a wave's A operand is one conflict-free ds_read_b64.
 template <int H> struct MlpLds { double act[H * 16]; double red[Mlp<H>::NW][16][2]; };
+template <int H> struct MlpLdsW { double wfrag[H * H]; };
 
 // acc[t] (+)= rows (16 (t0 + t) .. +15) of  Wm (H x H, column-major) . act   with act read from the LDS tile.
 // The TW A operands of a K-step (16 x 4 blocks of Wm, L2-resident) are fetched ONE K-step ahead; a scheduling fence per
@@ -96,6 +99,33 @@ __device__ __forceinline__ void mlp_gemm(const double* __restrict__ Wm, const do
     }
 }
 
+// A operands from the LDS fragment copy of the matrix (see MlpLdsW): no L2 traffic in the time loop.  With 16 batch
+// columns per workgroup a weight fetched from L2 is used by only 16 columns: 512 B per MFMA per wave = 32 B/clk per CU,
+// 19.7 TB/s chip-wide at the FP64-MFMA peak — beyond what the L2 delivers; LDS serves the same 32 B/clk at a quarter of
+// its bandwidth.
+template <int H>
+__device__ __forceinline__ void mlp_gemm_lds(const double* __restrict__ wfrag, const double* __restrict__ act, int t0, mlp_d4 (&acc)[Mlp<H>::TW]) {
+    constexpr int TW = Mlp<H>::TW, NK = H / 4;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned act_off = (lane >> 4) * 16u + (lane & 15u);
+#pragma unroll
+    for (int st = 0; st < NK; ++st) {
+        const double b = act[act_off + (unsigned)(64 * st)];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfrag[((unsigned)(t0 + t) * NK + st) * 64u + lane], b, acc[t], 0, 0, 0);
+    }
+}
+
+// tanh for the activations: (1 - t) / (1 + t) with t = exp(-2|x|) in (0, 1].  The cancellation in 1 - t for small |x| is
+// an ABSOLUTE error of one ulp of 1 (1e-16) in a quantity that only enters sums W h — harmless against the 1e-6 gate — and
+// the formula costs one exp and one division instead of the general-purpose library tanh (the forward passes of this
+// kernel are bound by these VALU instructions, not by the MFMAs).
+__device__ __forceinline__ double mlp_tanh(double x) {
+    const double t = exp(-2.0 * fabs(x));
+    const double r = (1.0 - t) / (1.0 + t);
+    return x < 0.0 ? -r : r;
+}
+
 __device__ __forceinline__ double group_sum4(double v) {   // sum over the four 16-lane groups (same column j)
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -119,7 +149,7 @@ __device__ __forceinline__ void mlp_reduce2(MlpLds<H>& L, double o0, double o1, 
 // forward pass for the workgroup's 16 columns: x[D] per lane (column l&15, replicated over lane groups and waves);
 // h1/h2 hold THIS WAVE's rows (tiles t0 .. t0+TW-1) in the MFMA accumulator layout
 template <int H>
-__device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, const double (&x)[2], double (&h1)[Mlp<H>::TW][4], double (&h2)[Mlp<H>::TW][4], double (&out)[2]) {
+__device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, const double* __restrict__ w2frag, const double (&x)[2], double (&h1)[Mlp<H>::TW][4], double (&h2)[Mlp<H>::TW][4], double (&out)[2]) {
     constexpr int TW = Mlp<H>::TW;
     const unsigned lq = (threadIdx.x & 63u) >> 4, li = threadIdx.x & 15u;
     const int t0 = (threadIdx.x >> 6) * TW;
@@ -129,20 +159,20 @@ __device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const unsigned row = (unsigned)(16 * (t0 + t) + 4 * r) + lq;
-            h1[t][r] = tanh(w.b1[row] + w.W1[row] * x[0] + w.W1[row + (unsigned)H] * x[1]);
+            h1[t][r] = mlp_tanh(w.b1[row] + w.W1[row] * x[0] + w.W1[row + (unsigned)H] * x[1]);
             acc[t][r] = w.b2[row];
             L.act[row * 16u + li] = h1[t][r];
         }
     }
     __syncthreads();
-    mlp_gemm<H>(w.W2, L.act, t0, acc);
+    if (w2frag) mlp_gemm_lds<H>(w2frag, L.act, t0, acc); else mlp_gemm<H>(w.W2, L.act, t0, acc);
     double o0 = 0.0, o1 = 0.0;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const unsigned row = (unsigned)(16 * (t0 + t) + 4 * r) + lq;
-            h2[t][r] = tanh(acc[t][r]);
+            h2[t][r] = mlp_tanh(acc[t][r]);
             o0 += w.W3[row * 2u] * h2[t][r];
             o1 += w.W3[row * 2u + 1u] * h2[t][r];
         }
@@ -154,7 +184,7 @@ __device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, cons
 // (df/du)^T lam for the workgroup's columns, given the activations of the forward pass; g1/g2 are this wave's rows of
 // the layer cotangents
 template <int H>
-__device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, const double (&lam)[2], const double (&h1)[Mlp<H>::TW][4], const double (&h2)[Mlp<H>::TW][4],
+__device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, const double* __restrict__ wfrag, const double (&lam)[2], const double (&h1)[Mlp<H>::TW][4], const double (&h2)[Mlp<H>::TW][4],
                                              double (&g1)[Mlp<H>::TW][4], double (&g2)[Mlp<H>::TW][4], double (&dlam)[2]) {
     constexpr int TW = Mlp<H>::TW;
     const unsigned lq = (threadIdx.x & 63u) >> 4, li = threadIdx.x & 15u;
@@ -171,7 +201,7 @@ __device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, con
         }
     }
     __syncthreads();
-    mlp_gemm<H>(w.W2T, L.act, t0, acc);
+    mlp_gemm_lds<H>(wfrag, L.act, t0, acc);
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
@@ -203,16 +233,22 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_forward(MlpGeom g, const dou
                                                             double* __restrict__ knots, double* __restrict__ out, const int* __restrict__ save_of_knot) {
     constexpr int TW = Mlp<H>::TW, D = 2;
     __shared__ MlpLds<H> L;
+    __shared__ MlpLdsW<H> LW;        // W2 in A-fragment order (the forward solve only needs W2)
     const long traj = blockIdx.y;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     const bool writer = (threadIdx.x >> 4) == 0;          // wave 0, lane group 0
     const MlpW<H> w = mlp_weights<H>(p, w2t, g.p_shared, traj);
     const long nB = (long)D * g.B;
+    for (int e = threadIdx.x; e < H * H; e += Mlp<H>::NT) {
+        const int l = e & 63, f = e >> 6, st = f % (H / 4), t = f / (H / 4);
+        LW.wfrag[e] = w.W2[(16 * t + (l & 15)) + (4 * st + (l >> 4)) * H];
+    }
+    __syncthreads();
     double x[D], k1[D], k2[D], k3[D], k4[D], xs[D], h1[TW][4], h2[TW][4];
     x[0] = u0[traj * nB + (long)col * D]; x[1] = u0[traj * nB + (long)col * D + 1];
     const double dt = g.dt;
     for (int k = 0; k <= g.S; ++k) {
-        mlp_forward<H>(w, L, x, h1, h2, k1);
+        mlp_forward<H>(w, L, LW.wfrag, x, h1, h2, k1);
         if (writer) {
             double* kn = knots + ((traj * (g.S + 1) + k) * 2) * nB;
             kn[col] = x[0]; kn[g.B + col] = x[1]; kn[nB + col] = k1[0]; kn[nB + g.B + col] = k1[1];
@@ -221,11 +257,11 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_forward(MlpGeom g, const dou
         }
         if (k == g.S) break;
         xs[0] = x[0] + 0.5 * dt * k1[0]; xs[1] = x[1] + 0.5 * dt * k1[1];
-        mlp_forward<H>(w, L, xs, h1, h2, k2);
+        mlp_forward<H>(w, L, LW.wfrag, xs, h1, h2, k2);
         xs[0] = x[0] + 0.5 * dt * k2[0]; xs[1] = x[1] + 0.5 * dt * k2[1];
-        mlp_forward<H>(w, L, xs, h1, h2, k3);
+        mlp_forward<H>(w, L, LW.wfrag, xs, h1, h2, k3);
         xs[0] = x[0] + dt * k3[0]; xs[1] = x[1] + dt * k3[1];
-        mlp_forward<H>(w, L, xs, h1, h2, k4);
+        mlp_forward<H>(w, L, LW.wfrag, xs, h1, h2, k4);
         x[0] = x[0] + (dt / 6.0) * (k1[0] + 2.0 * (k2[0] + k3[0]) + k4[0]);
         x[1] = x[1] + (dt / 6.0) * (k1[1] + 2.0 * (k2[1] + k3[1]) + k4[1]);
     }
@@ -267,12 +303,18 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const dou
                                                     double* __restrict__ du0, int* __restrict__ flag) {
     constexpr int TW = Mlp<H>::TW, D = 2;
     __shared__ MlpLds<H> L;
+    __shared__ MlpLdsW<H> LW;
     const long traj = blockIdx.y;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     const bool writer = (threadIdx.x >> 4) == 0;          // wave 0, lane group 0
     const MlpW<H> w = mlp_weights<H>(p, w2t, g.p_shared, traj);
     const long nB = (long)D * g.B;
     const double dt = g.dt;
+    for (int e = threadIdx.x; e < H * H; e += Mlp<H>::NT) {   // W2^T -> A-fragment order, once per workgroup
+        const int l = e & 63, f = e >> 6, st = f % (H / 4), t = f / (H / 4);
+        LW.wfrag[e] = w.W2T[(16 * t + (l & 15)) + (4 * st + (l >> 4)) * H];
+    }
+    __syncthreads();
     auto knot = [&](int k, double (&xx)[2], double (&ff)[2]) {
         const double* kn = knots + ((traj * (g.S + 1) + k) * 2) * nB;
         xx[0] = kn[col]; xx[1] = kn[g.B + col]; ff[0] = kn[nB + col]; ff[1] = kn[nB + g.B + col];
@@ -293,27 +335,27 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const dou
         xm[0] = 0.5 * (xl[0] + xh[0]) + (0.125 * dt) * (fl[0] - fh[0]);
         xm[1] = 0.5 * (xl[1] + xh[1]) + (0.125 * dt) * (fl[1] - fh[1]);
         // stage 1 at x_hi
-        mlp_forward<H>(w, L, xh, h1, h2, out);
-        mlp_backward<H>(w, L, lam, h1, h2, g1, g2, V1);
+        mlp_forward<H>(w, L, (const double*)nullptr, xh, h1, h2, out);
+        mlp_backward<H>(w, L, LW.wfrag, lam, h1, h2, g1, g2, V1);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 0, col, dt / 6.0, xh, lam, h1, h2, g1, g2);
         // stages 2, 3 at the Hermite midpoint (same activations)
         ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
-        mlp_forward<H>(w, L, xm, h1, h2, out);
-        mlp_backward<H>(w, L, ls, h1, h2, g1, g2, V2);
+        mlp_forward<H>(w, L, (const double*)nullptr, xm, h1, h2, out);
+        mlp_backward<H>(w, L, LW.wfrag, ls, h1, h2, g1, g2, V2);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 1, col, dt / 3.0, xm, ls, h1, h2, g1, g2);
         ls[0] = lam[0] + 0.5 * dt * V2[0]; ls[1] = lam[1] + 0.5 * dt * V2[1];
-        mlp_backward<H>(w, L, ls, h1, h2, g1, g2, V3);
+        mlp_backward<H>(w, L, LW.wfrag, ls, h1, h2, g1, g2, V3);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 2, col, dt / 3.0, xm, ls, h1, h2, g1, g2);
         // stage 4 at x_lo
         ls[0] = lam[0] + dt * V3[0]; ls[1] = lam[1] + dt * V3[1];
-        mlp_forward<H>(w, L, xl, h1, h2, out);
-        mlp_backward<H>(w, L, ls, h1, h2, g1, g2, V4);
+        mlp_forward<H>(w, L, (const double*)nullptr, xl, h1, h2, out);
+        mlp_backward<H>(w, L, LW.wfrag, ls, h1, h2, g1, g2, V4);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 3, col, dt / 6.0, xl, ls, h1, h2, g1, g2);
         lam[0] = lam[0] + (dt / 6.0) * (V1[0] + 2.0 * (V2[0] + V3[0]) + V4[0]);
         lam[1] = lam[1] + (dt / 6.0) * (V1[1] + 2.0 * (V2[1] + V3[1]) + V4[1]);
         if (ALG == 2) {
             double V5[D];
-            mlp_backward<H>(w, L, lam, h1, h2, g1, g2, V5);                   // fsallast at x_lo (activations of stage 4)
+            mlp_backward<H>(w, L, LW.wfrag, lam, h1, h2, g1, g2, V5);                   // fsallast at x_lo (activations of stage 4)
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
@@ -324,8 +366,8 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const dou
                     yg[j] = (1.0 - tf) * xl[j] + tf * xh[j] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (xh[j] - xl[j]) + (tf - 1.0) * dt * fl[j] + tf * dt * fh[j]);
                 }
                 double dl[D];
-                mlp_forward<H>(w, L, yg, h1, h2, out);
-                mlp_backward<H>(w, L, lg, h1, h2, g1, g2, dl);
+                mlp_forward<H>(w, L, (const double*)nullptr, yg, h1, h2, out);
+                mlp_backward<H>(w, L, LW.wfrag, lg, h1, h2, g1, g2, dl);
                 mlp_record<H>(R, g, qbase + nq, col, 0.5 * dt, yg, lg, h1, h2, g1, g2);
             }
         }
