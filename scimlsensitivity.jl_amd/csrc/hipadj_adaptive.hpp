@@ -160,6 +160,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
     bool need_k0 = true, first = true;
     double dt = 0.0, qold = 1e-4;
     int its = 0, naccept = 0, guard = 0;
+    double ts_cur = ntstops > 0 ? tstops[0] : tend;
 #pragma unroll 1
     while (tdir * t < tdir * tend) {
         if (++guard > 16 * max_steps + 64) return -1;
@@ -192,10 +193,12 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             }
         }
         pre(t);
-        // next stop: the first tstop strictly ahead of t (beyond the 100-eps snap), else tend
-        while (its < ntstops && tdir * tstops[its] <= tdir * t + 100.0 * EPS * hmax2(habs(t), habs(tstops[its]))) ++its;
+        // next stop: the first tstop strictly ahead of t (beyond the 100-eps snap), else tend.  The candidate lives in a
+        // register and is re-read only when the cursor moves: a dependent L2 round trip per attempt is a visible fraction
+        // of a step when one wave owns the CU.
+        while (its < ntstops && tdir * ts_cur <= tdir * t + 100.0 * EPS * hmax2(habs(t), habs(ts_cur))) { ++its; ts_cur = its < ntstops ? tstops[its] : tend; }
         double tstop = tend;
-        if (its < ntstops && tdir * tstops[its] < tdir * tend) tstop = tstops[its];
+        if (its < ntstops && tdir * ts_cur < tdir * tend) tstop = ts_cur;
         double h = dt;
         if (habs(h) > habs(tstop - t)) h = tstop - t;
         if (habs((t + h) - tstop) < 100.0 * EPS * hmax2(habs(t + h), habs(tstop))) h = tstop - t;
@@ -247,8 +250,10 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             }
         }
         const double EEst = sqrt(e2 / NZ);
-        const double q11 = pow(hmax2(EEst, 1e-300), 7.0 / 50.0);
-        double q = q11 / pow(qold, 2.0 / 25.0);
+        // x^c as exp(c log x): within a few ulp of pow() (the step-size factor is not an accuracy-critical quantity) at about a
+        // third of its instruction count
+        const double q11 = exp((7.0 / 50.0) * log(hmax2(EEst, 1e-300)));
+        double q = q11 / exp((2.0 / 25.0) * log(qold));
         q = hmax2(1.0 / 10.0, hmin2(5.0, q / 0.9));
         if (EEst <= 1.0 || habs(h) < 1e-14 * hmax2(1.0, habs(t))) {
             double tnew = t + h;
@@ -304,6 +309,9 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
         for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = u[j];
         ++mc; }
+    // next output / checkpoint time, cached in registers (one dependent L2 load per accepted step otherwise)
+    const double TINF = 1.7976931348623157e308;
+    double ts_next = (outT && ms < g.M) ? save_t[ms] : TINF, tc_next = (ckpt && mc < g.nck) ? ck_t[mc] : TINF;
     const int na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.Smax, K,
         [&](double (&du)[N], const double (&uu)[N], double t) { Mo::f(du, uu, pv, t); },
         [&](double t, double tprev, double (&un)[N], const KStore<N>& KK) -> bool {
@@ -319,16 +327,16 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 }
             } else overflow = true;
             ++s;
-            while (outT && ms < g.M && (save_t[ms] <= t || time_hits(save_t[ms], t))) {
-                double y[N]; poly_eval<N>((save_t[ms] - tprev) / h, c, y);
+            while (ts_next <= t || time_hits(ts_next, t)) {
+                double y[N]; poly_eval<N>((ts_next - tprev) / h, c, y);
 #pragma unroll
                 for (int j = 0; j < N; ++j) outT[((long)ms * N + j) * g.Npad + i] = y[j];
-                ++ms; }
-            while (ckpt && mc < g.nck && (ck_t[mc] <= t || time_hits(ck_t[mc], t))) {
-                double y[N]; poly_eval<N>((ck_t[mc] - tprev) / h, c, y);
+                ++ms; ts_next = ms < g.M ? save_t[ms] : TINF; }
+            while (tc_next <= t || time_hits(tc_next, t)) {
+                double y[N]; poly_eval<N>((tc_next - tprev) / h, c, y);
 #pragma unroll
                 for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = y[j];
-                ++mc; }
+                ++mc; tc_next = mc < g.nck ? ck_t[mc] : TINF; }
             (void)un;
             return false;
         });
@@ -362,7 +370,9 @@ template <class Mo> struct FwdCursor {
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[((long)mid * RW + 1) * Npad + i] < t) lo = mid + 1; else hi = mid; }
         sc = lo; ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i];
     }
-    // y = sol(t): the reverse sweep moves mostly downward, so a linear cursor walk replaces the binary search
+    // y = sol(t): the reverse sweep moves mostly downward, so a linear cursor walk replaces the binary search.
+    // (Measured: fetching the record below one step ahead into a second register set changes the sweep by -2 % .. +7 %:
+    // the sweep is bound by the instruction count of a step, not by this round trip.)
     HIPADJ_HD void eval(double t, double (&y)[Mo::N]) {
         while (t < ta && sc > 0) { --sc; tb = ta; ta = rec[((long)sc * RW + 0) * Npad + i]; }
         while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[((long)sc * RW + 1) * Npad + i]; }
@@ -466,7 +476,9 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
     for (int j = 0; j < NP; ++j) gacc[j] = 0.0;
     int cur_time = g.M, bs_cur = g.nck;
+    double t_loss = g.M > 0 ? save_t[g.M - 1] : 0.0;
     if (ALG == 1 && bs_cur >= 1 && time_hits(g.t1, ck_t[bs_cur - 1])) --bs_cur;
+    double t_ck = (ALG == 1 && ckpt && bs_cur >= 1) ? ck_t[bs_cur - 1] : 0.0;
 
     auto rhs = [&](double (&dz)[NZ], const double (&zz)[NZ], double t) {
         double y[N], lam[N], dl[N], dg[NP];
@@ -527,12 +539,13 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 for (int j = 0; j < NP; ++j) gacc[j] += half * wq * (-W[j]);
             }
         }
-        if (ALG == 1 && ckpt && bs_cur >= 1 && time_hits(t, ck_t[bs_cur - 1])) {   // backsolve_checkpoint_callbacks
+        if (ALG == 1 && ckpt && bs_cur >= 1 && time_hits(t, t_ck)) {               // backsolve_checkpoint_callbacks (t_ck = ck_t[bs_cur - 1], cached)
 #pragma unroll
             for (int j = 0; j < N; ++j) zz[N + NP + j] = ckpt[((long)(bs_cur - 1) * N + j) * g.Npad + i];
             --bs_cur; mod = true;
+            t_ck = bs_cur >= 1 ? ck_t[bs_cur - 1] : 0.0;
         }
-        if (cur_time >= 1 && time_hits(t, save_t[cur_time - 1])) {                   // ReverseLossCallback
+        if (cur_time >= 1 && time_hits(t, t_loss)) {                                  // ReverseLossCallback (t_loss = save_t[cur_time - 1], cached)
             if (!(g.no_start && ALG != 1 && cur_time == 1)) {
                 double y[N];
                 if (ALG == 1) {
@@ -545,6 +558,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 mod = true;
             }
             --cur_time;
+            t_loss = cur_time >= 1 ? save_t[cur_time - 1] : 0.0;
         }
         return mod;
     };
