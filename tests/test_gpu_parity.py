@@ -676,3 +676,74 @@ def test_tsit5_checkpointed_interpolating_gauss(sa, alg, oalg, tol):
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     assert sol.engine.stats()["workspace_bytes"] < 0.6 * 2048 * 17 * 8 * 256        # less than the 2048-step dense record buffer alone
     sol.engine.close()
+
+
+# ---- randomized differential test: device vs oracle over the whole configuration space ----------------------------------
+def _random_case(rng, sa):
+    models = [("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0], (0, 0, 0, 0)), ("lvt", "LVT", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0], (0, 0, 0, 0)),
+              ("lorenz", "LORENZ", [1.0, 0.0, 0.0], [10.0, 28.0, 8 / 3], (0, 0, 0, 0)), ("lindiag", "LINDIAG", [1.0, 1.0], [0.5, -0.7], (0, 0, 0, 0)),
+              ("rober", "ROBER", [0.8, 0.3, 0.2], [0.4, 1.0, 0.7], (0, 0, 0, 0))]
+    n_ring = int(rng.integers(2, 8))
+    models.append((f"ring{n_ring}", "RING", list(rng.uniform(0.3, 1.0, n_ring)), list(rng.uniform(0.4, 1.2, n_ring + 1)), (n_ring, 0, 0, 0)))
+    model, omodel, u0c, p, dims = models[int(rng.integers(len(models)))]
+    alg, oalg = ALGS[int(rng.integers(4))]
+    stepper = "rk4" if rng.random() < 0.5 else "tsit5"
+    ckpt = bool(rng.random() < 0.5) and alg != "quadrature"
+    if alg == "backsolve" and not ckpt and model == "lorenz":
+        ckpt = True                               # Backsolve without checkpoints is unstable on Lorenz (src/sensitivity_algorithms.jl:168-198)
+    user = model == "rober" or model.startswith("ring")
+    if user and ckpt and alg in ("interpolating", "gauss") and stepper == "rk4":
+        ckpt = False                              # not offered for runtime models on the fixed-step path
+    cost = int(rng.integers(0, 3)) if not user else 0
+    if cost == 2 and (alg == "gauss" or len(p) < 1):
+        cost = 1
+    N = int(rng.integers(1, 200))
+    T = float(rng.choice([0.5, 1.0, 2.0]))
+    if stepper == "rk4":
+        dt = float(rng.choice([0.01, 0.02, 0.05]))
+        S = int(round(T / dt))
+        ks = np.unique(rng.integers(0, S + 1, int(rng.integers(0, 7))))
+        if ckpt and alg in ("interpolating", "gauss"):
+            ks = np.unique(np.concatenate([ks, np.arange(0, S + 1, 10)]))      # checkpoint intervals <= 16 steps
+        ts = ks * dt
+    else:
+        dt = 0.0
+        ts = np.unique(np.round(rng.uniform(0, T, int(rng.integers(0, 6))), 3))
+        if rng.random() < 0.5:
+            ts = np.unique(np.concatenate([ts, [T]]))
+    loss_lsq = bool(rng.random() < 0.5) or len(ts) == 0
+    segs = int(rng.choice([0, 1, 3]))
+    return dict(model=model, omodel=omodel, u0c=u0c, p=p, dims=dims, alg=alg, oalg=oalg, stepper=stepper, ckpt=ckpt, cost=cost, N=N, T=T, dt=dt,
+                ts=ts, loss_lsq=loss_lsq, segs=segs, user=user, p_shared=bool(rng.random() < 0.5))
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_randomized_configurations_match_oracle(sa, seed):
+    rng = np.random.default_rng(1000 + seed)
+    c = _random_case(rng, sa)
+    n, npar = len(c["u0c"]), len(c["p"])
+    f = c["model"]
+    if c["user"]:
+        m = UM.ROBER if c["model"] == "rober" else UM.ring(c["dims"][0])
+        f = _device_function(sa, c["model"] + "_fuzz", m)
+    u0 = np.asarray(c["u0c"]) + 0.05 * rng.standard_normal((c["N"], n))
+    p = np.asarray(c["p"]) if c["p_shared"] else np.asarray(c["p"]) * (1 + 0.03 * rng.standard_normal((c["N"], npar)))
+    sens = {"interpolating": sa.InterpolatingAdjoint(checkpointing=c["ckpt"]), "backsolve": sa.BacksolveAdjoint(checkpointing=c["ckpt"]),
+            "gauss": sa.GaussAdjoint(checkpointing=c["ckpt"]), "quadrature": sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10)}[c["alg"]]
+    g = [None, sa.HalfSquaredSum(), sa.FirstStateSquaredPlusFirstParam()][c["cost"]]
+    delta = None if c["loss_lsq"] else rng.standard_normal((c["N"], len(c["ts"]), n))
+    if c["stepper"] == "rk4":
+        salg, kw, okw = sa.RK4(), dict(dt=c["dt"], time_segments=c["segs"]), dict(stepper="RK4", dt=c["dt"])
+    else:
+        salg, kw, okw = sa.Tsit5(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
+    prob = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, c["T"]), p if c["p_shared"] else p[0], c["dims"]), u0, p)
+    sol = sa.solve(prob, salg, saveat=c["ts"], sensealg=sens, dgdu_discrete=(sa.LsqShift(1.5) if c["loss_lsq"] else None), g=g, **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=c["ts"], dgdu_discrete=(sa.LsqShift(1.5) if c["loss_lsq"] else delta), g=g)
+    ref = O.Problem(c["omodel"], alg=c["oalg"], t0=0.0, t1=c["T"], save_times=c["ts"], loss=("LSQ_SHIFT" if c["loss_lsq"] else "COTANGENT"),
+                    loss_shift=1.5, checkpointing=c["ckpt"], dims=c["dims"], cont_cost=c["cost"], quad_abstol=1e-10, quad_reltol=1e-10, **okw)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    msg = {k: (v if not isinstance(v, (list, np.ndarray)) else np.asarray(v).round(3).tolist()) for k, v in c.items() if k not in ("u0c", "p")}
+    if len(c["ts"]):
+        assert rel(sol.u, rout) < RTOL, msg
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL, msg
+    sol.engine.close()
