@@ -747,3 +747,28 @@ def test_randomized_configurations_match_oracle(sa, seed):
         assert rel(sol.u, rout) < RTOL, msg
     assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL, msg
     sol.engine.close()
+
+
+def test_independent_handles_on_concurrent_host_threads(sa):
+    """The reference's concurrency model is EnsembleThreads: many independent solves on host threads
+    (test/Core4/ensembles.jl:16-20).  Handles are independent (own stream, workspaces); ctypes drops the GIL during calls."""
+    import threading
+    T, dt = 2.0, 0.01
+    ts = np.linspace(0, T, 21)
+    cases = [("interpolating", 3), ("backsolve", 4), ("gauss", 5), ("quadrature", 6)]
+    serial, threaded = {}, {}
+
+    def work(alg, seed, dst):
+        u0, p = lorenz_inputs(300, seed=seed)
+        for rep in range(3):
+            sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts,
+                           sensealg=sensealg_of(sa, alg), dgdu_discrete=sa.LsqShift(2.0))
+            dst[alg] = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+            sol.engine.close()
+
+    for alg, seed in cases:
+        work(alg, seed, serial)
+    th = [threading.Thread(target=work, args=(alg, seed, threaded)) for alg, seed in cases]
+    [t.start() for t in th]; [t.join() for t in th]
+    for alg, _ in cases:
+        assert np.array_equal(serial[alg][0], threaded[alg][0]) and np.array_equal(serial[alg][1], threaded[alg][1])
