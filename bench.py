@@ -36,27 +36,45 @@ def inputs(n_total):
     return u0, p
 
 
-def cpu_baseline(u0, p, ts, budget_s=15.0):
+def cpu_baseline(u0, p, ts, budget_s=20.0):
     """The oracle (CPU restatement of the reference algorithm — NOT Julia) timed on a bounded sample of the same
     workload with all host cores (OpenMP over trajectories)."""
+    os.environ.setdefault("OMP_PROC_BIND", "spread")   # read by libgomp when the oracle library is first loaded
+    os.environ.setdefault("OMP_PLACES", "threads")
     import oracle as O
     cores = os.cpu_count() or 1
     pr = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=T_FINAL, dt=DT, save_times=ts,
                    loss="LSQ_SHIFT", loss_shift=LOSS_SHIFT)
-    n = min(len(u0), 4 * cores)
-    t0 = time.perf_counter()
-    pr.adjoint_ensemble(u0[:n], p, nthreads=cores, want_out=False)
-    probe = time.perf_counter() - t0
-    n = int(min(len(u0), max(n, n * budget_s / max(probe, 1e-3))))
-    n = max(cores, (n // cores) * cores)
-    t0 = time.perf_counter()
-    du0, dp, _, tm = pr.adjoint_ensemble(u0[:n], p, nthreads=cores, want_out=False)
-    wall = time.perf_counter() - t0
-    rev = tm["reverse_s"]  # max over threads of the time spent in reverse passes
-    return dict(value=n / rev, unit="trajectories/s", cores=cores, kind="port",
-                sample=f"{n} of the workload's trajectories, reverse pass only ({rev:.2f} s; forward+reverse wall {wall:.2f} s), "
-                       f"C oracle, OpenMP over trajectories, gcc -O2 -ffp-contract=off",
-                ns_per_vjp_step=rev / (n * 1000 * 4) * 1e9), du0, dp, n
+    # thread count: the oracle allocates per trajectory and its OpenMP scaling collapses beyond ~32 threads on the 2-socket
+    # host (kernel VM contention), so the baseline uses the thread count that maximises ITS throughput
+    best, probe_log = None, []
+    for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}, reverse=True):
+        m = min(len(u0), 64 * nt)
+        pr.adjoint_ensemble(u0[:m], p, nthreads=nt, want_out=False)                    # warm the per-thread arenas
+        _, _, _, tmp = pr.adjoint_ensemble(u0[:m], p, nthreads=nt, want_out=False)
+        rate = m / tmp["reverse_s"]
+        probe_log.append(f"{nt}:{rate:.3g}")
+        if best is None or rate > best[1]:
+            best = (nt, rate)
+    cores_used = best[0]
+    n = max(cores_used, (len(u0) // cores_used) * cores_used)
+    # timed sample: the workload's trajectories, repeated until about `budget_s` core-seconds of reverse-pass work were measured
+    rev, wall, reps = 0.0, 0.0, 0
+    while reps < 500 and rev * cores_used < budget_s:
+        t0 = time.perf_counter()
+        du0, dp, _, tm = pr.adjoint_ensemble(u0[:n], p, nthreads=cores_used, want_out=False)
+        wall += time.perf_counter() - t0
+        rev += tm["reverse_s"]  # max over threads of the time spent in reverse passes
+        reps += 1
+    # the same path on ONE host thread (SURVEY.md §8d asks for both): a smaller sample, same inputs
+    n1 = min(len(u0), 2048)
+    _, _, _, tm1 = pr.adjoint_ensemble(u0[:n1], p, nthreads=1, want_out=False)
+    return dict(value=n * reps / rev, unit="trajectories/s", cores=cores_used, host_threads=cores, thread_probe_traj_per_s=" ".join(probe_log), kind="port",
+                single_thread_value=n1 / tm1["reverse_s"], single_thread_ns_per_vjp_step=tm1["reverse_s"] / (n1 * 1000 * 4) * 1e9,
+                sample=f"{n} of the workload's trajectories x {reps} repeats, reverse passes only ({rev:.2f} s on {cores_used} threads = "
+                       f"{rev * cores_used:.0f} core-seconds; forward+reverse wall {wall:.2f} s), C oracle, OpenMP over trajectories, "
+                       f"gcc -O2 -ffp-contract=off",
+                ns_per_vjp_step=rev / (n * reps * 1000 * 4) * 1e9), du0, dp, n
 
 
 def main():

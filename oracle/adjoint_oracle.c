@@ -11,6 +11,7 @@
  */
 #include "adjoint_oracle.h"
 #include <math.h>
+#include <malloc.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -969,6 +970,9 @@ int orc_adjoint_ensemble(const orc_config *cfg, long N, const double *u0, const 
     double tf = 0, tr = 0;
     if (p_shared) memset(dp, 0, sizeof(double) * np);
     (void)nthreads;
+    /* per-trajectory dense solutions are allocated and freed on every thread: keep them in the per-thread malloc arenas
+     * (no mmap/munmap per trajectory, which serialises all threads on the process-wide mapping lock) */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30);
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel
