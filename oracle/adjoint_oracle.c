@@ -334,10 +334,27 @@ typedef struct {
     double *k;             /* [nsteps][nk][n]; RK4: k[0]=f(u0,t0), k[1]=f(u1,t1) (FSAL pair) ; Tsit5: 7 stages */
 } orc_dense;
 
+/* Dense solutions are recycled per thread: an ensemble run would otherwise grow and free ~100 KB of arrays per trajectory on
+ * every thread, and the page faults / heap trimming behind that serialise the threads in the kernel (the OpenMP baseline of
+ * bench.py collapsed beyond 32 threads).  A released buffer set keeps its capacity and is handed to the next dense_init of the
+ * same shape on this thread. */
+#define ORC_DENSE_POOL 4
+static __thread orc_dense tls_pool[ORC_DENSE_POOL];
+static __thread int tls_pool_used[ORC_DENSE_POOL];
 static void dense_init(orc_dense *d, int n, int kind) {
-    memset(d, 0, sizeof(*d)); d->n = n; d->kind = kind; d->nk = (kind == ORC_STEPPER_TSIT5) ? 7 : 2;
+    int nk = (kind == ORC_STEPPER_TSIT5) ? 7 : 2;
+    for (int i = 0; i < ORC_DENSE_POOL; ++i)
+        if (tls_pool_used[i] == 1 && tls_pool[i].n == n && tls_pool[i].nk == nk) {
+            *d = tls_pool[i]; tls_pool_used[i] = 0; d->kind = kind; d->nsteps = 0; return;
+        }
+    memset(d, 0, sizeof(*d)); d->n = n; d->kind = kind; d->nk = nk;
 }
-static void dense_free(orc_dense *d) { free(d->t0); free(d->t1); free(d->u0); free(d->u1); free(d->k); memset(d, 0, sizeof(*d)); }
+static void dense_free(orc_dense *d) {
+    if (d->cap > 0)
+        for (int i = 0; i < ORC_DENSE_POOL; ++i)
+            if (tls_pool_used[i] == 0) { tls_pool[i] = *d; tls_pool_used[i] = 1; memset(d, 0, sizeof(*d)); return; }
+    free(d->t0); free(d->t1); free(d->u0); free(d->u1); free(d->k); memset(d, 0, sizeof(*d));
+}
 static void dense_push(orc_dense *d, double t0, double t1, const double *u0, const double *u1, const double *k) {
     if (d->nsteps == d->cap) {
         d->cap = d->cap ? 2 * d->cap : 256;
