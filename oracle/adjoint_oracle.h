@@ -14,8 +14,12 @@
  *   (2) the cross-method relations the reference tests assert (test/Core3/adjoint.jl:366-404,
  *       691-705, 1201-1241; test/Core3/user_vjp.jl:79-113), with scipy DOP853 forward
  *       sensitivities standing in for ForwardDiff (tests/golden/ + tests/golden/make_golden.py).
+ *   (3) the mixed continuous cost g = u1^2 + p1 of test/Core7/mixed_costs.jl:13-57 (dgdp_continuous) against the same
+ *       kind of DOP853 forward-sensitivity gradient.
+ * The adaptive Tsit5 path (the stepper of every reference test) is what (1)-(3) exercise; it also runs on the device.
  * Fixed-step RK4 ensembles (BASELINE configs 2/3) are covered by NO reference test:
  * for those sizes parity is "unpinned" beyond the relations above.
+ * ORC_MODEL_ROBER / ORC_MODEL_RING exist only as checkers for runtime-registered device models (hipadj_model_register).
  */
 #ifndef ADJOINT_ORACLE_H
 #define ADJOINT_ORACLE_H
