@@ -135,6 +135,10 @@ int hipadj_model_sizes(int32_t model, const int32_t dims[4], int32_t *n, int32_t
  *   vjp_u_body  writes out[0..n)  = (df/du)^T lam  from lam, u, p, t    (vjp(dlam, lam, u, p, t), UN-negated)
  *   vjp_p_body  writes out[0..np) = (df/dp)^T lam  from lam, u, p, t    (vjp_p(dgrad, lam, u, p, t), UN-negated)
  * All are `double`; local variables and device math functions are allowed; no global memory access.
+ * vjp_u_body == vjp_p_body == NULL selects AUTOMATIC VJPs — the reference's `autojacvec = true` (ForwardDiff Jacobian,
+ * src/sensitivity_algorithms.jl:629-660): f_body is then compiled a second time with forward-mode dual numbers, so it must
+ * declare its locals as `real` (or `auto`) instead of `double`; + - * / comparisons and sin cos tan exp log sqrt tanh sinh
+ * cosh atan fabs pow are available on `real`.
  * Limits: 1 <= n <= 8, 1 <= np <= 32.  On success *model_id (>= HIPADJ_MODEL_USER_BASE) is valid for hipadj_config.model
  * for the lifetime of the process; registering the same name again replaces the sources (new id). */
 int hipadj_model_register(const char *name, int32_t n, int32_t np, const char *f_body, const char *vjp_u_body,

@@ -106,12 +106,13 @@ def model_sizes(model, dims=(0, 0, 0, 0)):
     return n.value, npar.value
 
 
-def register_model(name, n, npar, f, vjp, vjp_p, check=False):
+def register_model(name, n, npar, f, vjp=None, vjp_p=None, check=False):
     """hipadj_model_register: runtime ingestion of a right-hand side and its two VJPs (HIP C++ bodies, see include/hipadj.h).
     Adds `name` to MODEL and returns the model id; check=True compiles for gfx950 immediately (no device needed)."""
     L = load()
     mid = C.c_int32()
-    rc = L.hipadj_model_register(name.encode(), int(n), int(npar), f.encode(), vjp.encode(), vjp_p.encode(), C.byref(mid))
+    enc = lambda b: None if b is None else b.encode()
+    rc = L.hipadj_model_register(name.encode(), int(n), int(npar), f.encode(), enc(vjp), enc(vjp_p), C.byref(mid))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
     if check:

@@ -33,6 +33,7 @@ struct UserModelSrc {
     std::string name, f, vjp_u, vjp_p;
     std::string dgdu, dgdp;   // optional continuous cost (hipadj_model_set_cost)
     bool has_cost = false;
+    bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
     int n = 0, np = 0, rev = 0;   // rev: bumped when the sources change, part of the code-cache key
 };
 
@@ -109,16 +110,35 @@ inline bool user_read_file(const std::string& path, std::string& out) {
 
 inline std::string user_model_struct(const UserModelSrc& m) {
     std::ostringstream o;
-    o << "#include \"hipadj_kernels.hpp\"\n#include \"hipadj_adaptive.hpp\"\n"
+    o << "#include \"hipadj_kernels.hpp\"\n#include \"hipadj_adaptive.hpp\"\n#include \"hipadj_dual.hpp\"\n"
       << "namespace hipadj {\n// runtime-registered model '" << m.name << "'\nstruct UserModel {\n"
-      << "    static constexpr int N = " << m.n << ", NP = " << m.np << ";\n    static constexpr bool TIME_DEP = true;\n"
-      << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
-      << "        (void)u; (void)p; (void)t;\n" << m.f << "\n    }\n"
-      << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
-      << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_u << "\n    }\n"
-      << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
-      << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_p << "\n    }\n"
-      << "    // continuous cost attached with hipadj_model_set_cost (dgdu_continuous / dgdp_continuous); zero when absent\n"
+      << "    static constexpr int N = " << m.n << ", NP = " << m.np << ";\n    static constexpr bool TIME_DEP = true;\n";
+    if (m.auto_vjp) {
+        // f is compiled for real = double and real = Dual<K>; the VJPs are lam-weighted column sums of the dual partials
+        o << "    template <class real> HIPADJ_HD static void f_t(real (&du)[N], const real (&u)[N], const real (&p)[NP], real t) {\n"
+          << "        (void)u; (void)p; (void)t;\n" << m.f << "\n    }\n"
+          << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) { f_t<double>(du, u, p, t); }\n"
+          << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        Dual<N> uu[N], pp[NP], dd[N];\n"
+          << "        for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n"
+          << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
+          << "        f_t<Dual<N>>(dd, uu, pp, Dual<N>(t));\n"
+          << "        for (int j = 0; j < N; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n"
+          << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        Dual<NP> uu[N], pp[NP], dd[N];\n"
+          << "        for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n"
+          << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
+          << "        f_t<Dual<NP>>(dd, uu, pp, Dual<NP>(t));\n"
+          << "        for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n";
+    } else {
+        o << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        (void)u; (void)p; (void)t;\n" << m.f << "\n    }\n"
+          << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_u << "\n    }\n"
+          << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_p << "\n    }\n";
+    }
+    o << "    // continuous cost attached with hipadj_model_set_cost (dgdu_continuous / dgdp_continuous); zero when absent\n"
       << "    HIPADJ_HD static void dgdu(double (&out)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
       << "        (void)u; (void)p; (void)t;\n" << (m.has_cost ? m.dgdu : std::string("for (int i = 0; i < N; ++i) out[i] = 0.0;")) << "\n    }\n"
       << "    HIPADJ_HD static void dgdp(double (&out)[NP], const double (&u)[N], const double (&p)[NP], double t) {\n"
@@ -145,15 +165,16 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
     }
     RtcApi& A = rtc_api();
     if (!A.lib || !A.err.empty()) { err = A.err.empty() ? "hiprtc unavailable" : A.err; return HIPADJ_ERR_UNSUPPORTED; }
-    const char* hnames[] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp"};
-    std::string htext[4];
+    constexpr int NH = 5;
+    const char* hnames[NH] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp", "hipadj_dual.hpp"};
+    std::string htext[NH];
     const std::string dir = user_csrc_dir();
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NH; ++i)
         if (!user_read_file(dir + "/" + hnames[i], htext[i])) { err = "cannot read kernel header " + dir + "/" + hnames[i] + " (set HIPADJ_CSRC_DIR)"; return HIPADJ_ERR_UNSUPPORTED; }
-    const char* hptr[] = {htext[0].c_str(), htext[1].c_str(), htext[2].c_str(), htext[3].c_str()};
+    const char* hptr[NH] = {htext[0].c_str(), htext[1].c_str(), htext[2].c_str(), htext[3].c_str(), htext[4].c_str()};
     const std::string tu = user_model_struct(src);
     hiprtcProgram prog = nullptr;
-    if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", 4, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
+    if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", NH, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
     for (const auto& e : exprs) A.AddNameExpression(prog, e.c_str());
     std::vector<std::string> optv = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     if (const char* e = std::getenv("HIPADJ_RTC_FLAGS")) { std::istringstream is(e); std::string w; while (is >> w) optv.push_back(w); }   // tuning / debugging hook
@@ -200,11 +221,13 @@ inline bool user_has_cost(int32_t model) {
 }
 
 inline int user_register(const char* name, int32_t n, int32_t np, const char* f, const char* vu, const char* vp, int32_t* id, std::string& err) {
-    if (!name || !f || !vu || !vp || !id) { err = "hipadj_model_register: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+    if (!name || !f || !id) { err = "hipadj_model_register: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+    if ((vu == nullptr) != (vp == nullptr)) { err = "hipadj_model_register: give both vjp_u_body and vjp_p_body, or neither (automatic forward-mode VJPs)"; return HIPADJ_ERR_INVALID_ARG; }
     if (n < 1 || n > 8 || np < 1 || np > 32) { err = "hipadj_model_register: need 1 <= n <= 8 and 1 <= np <= 32 (state and parameters live in VGPRs)"; return HIPADJ_ERR_INVALID_ARG; }
     UserRegistry& R = user_registry();
     std::lock_guard<std::mutex> lk(R.mu);
-    UserModelSrc m; m.name = name; m.n = n; m.np = np; m.f = f; m.vjp_u = vu; m.vjp_p = vp;
+    UserModelSrc m; m.name = name; m.n = n; m.np = np; m.f = f; m.auto_vjp = vu == nullptr;
+    if (!m.auto_vjp) { m.vjp_u = vu; m.vjp_p = vp; }
     R.models.push_back(m);
     *id = HIPADJ_MODEL_USER_BASE + (int32_t)R.models.size() - 1;
     plan_user_sizes_hook() = &user_model_sizes;

@@ -151,6 +151,10 @@ def test_runtime_model_registration_compiles_for_gfx950_and_reports_errors():
     for n, npar in ((0, 1), (9, 1), (2, 0), (2, 33)):
         with pytest.raises(_lib.HipadjError):
             _lib.register_model("bad_dims", n, npar, "", "", "")
+    # automatic VJPs (autojacvec = true): only f is given, compiled for double and for forward-mode dual numbers
+    _lib.register_model("mm_auto_cpu_check", 2, 3, "real s = u[0] / (p[2] + u[0]); du[0] = -p[0]*s + p[1]*u[1]; du[1] = p[0]*s - p[1]*u[1]*exp(-0.1*t);", check=True)
+    with pytest.raises(_lib.HipadjError):                      # one VJP without the other
+        _lib.register_model("half_vjp", 2, 2, "du[0] = u[0]; du[1] = u[1];", "out[0] = lam[0]; out[1] = lam[1];", None)
 
 
 def test_runtime_model_plans_like_a_lane_model():

@@ -772,3 +772,34 @@ def test_independent_handles_on_concurrent_host_threads(sa):
     [t.start() for t in th]; [t.join() for t in th]
     for alg, _ in cases:
         assert np.array_equal(serial[alg][0], threaded[alg][0]) and np.array_equal(serial[alg][1], threaded[alg][1])
+
+
+# ---- automatic VJPs for runtime models: forward-mode dual numbers (the reference's autojacvec = true) -------------------
+@pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring5", "RING", (5, 0, 0, 0))])
+def test_runtime_models_with_automatic_vjps_match_oracle(sa, name, omodel, dims, alg, oalg, stepper):
+    """Only `f` is registered; (df/du)^T lam and (df/dp)^T lam come from dual numbers on the device and must reproduce the
+    oracle's hand-derived VJPs (test/Core3/user_vjp.jl:79-113 compares the user-VJP route with AD in the same way)."""
+    m = UM.ROBER if name == "rober" else UM.ring(dims[0])
+    key = name + "_autovjp"
+    if key not in _registered:
+        _registered[key] = sa.DeviceFunction(key, m["n"], m["np"], m["f"])
+    f = _registered[key]
+    rng = np.random.default_rng(47)
+    N, T, dt = 70, 1.5, 0.01
+    n, npar = m["n"], m["np"]
+    u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar))
+    ts = np.arange(0, T + 1e-9, 0.25)
+    delta = rng.standard_normal((N, len(ts), n))
+    ck = alg == "backsolve"
+    if stepper == "rk4":
+        salg, kw, okw = sa.RK4(), dict(dt=dt), dict(stepper="RK4", dt=dt)
+    else:
+        salg, kw, okw = sa.Tsit5(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), salg, saveat=ts, sensealg=ts_sensealg(sa, alg), **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=delta)
+    ref = O.Problem(omodel, alg=oalg, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=ck, dims=dims, quad_abstol=1e-10, quad_reltol=1e-10, **okw)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
