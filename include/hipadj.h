@@ -147,6 +147,9 @@ int hipadj_model_register(const char *name, int32_t n, int32_t np, const char *f
  * (src/sensitivity_interface.jl:373-526): dgdu_body writes out[0..n) = dg/du, dgdp_body writes out[0..np) = dg/dp from u, p, t.
  * Selected per handle with cont_cost = HIPADJ_CCOST_MODEL. */
 int hipadj_model_set_cost(int32_t model_id, const char *dgdu_body, const char *dgdp_body);
+/* Same, from the cost itself: g_body assigns `g` (declared `real g`) from u, p, t with `real` locals; dg/du and dg/dp are
+ * generated by forward-mode dual numbers — the reference's gradient!(g) fallback (src/derivative_wrappers.jl:1428-1441). */
+int hipadj_model_set_cost_function(int32_t model_id, const char *g_body);
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
  * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
 int hipadj_model_check(int32_t model_id);

@@ -18,7 +18,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_model_check", "hipadj_model_set_cost",
+    "hipadj_model_register", "hipadj_model_check", "hipadj_model_set_cost", "hipadj_model_set_cost_function",
 )
 
 
@@ -94,6 +94,7 @@ def load():
     L.hipadj_model_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
     L.hipadj_model_check.argtypes = [C.c_int32]
     L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
+    L.hipadj_model_set_cost_function.argtypes = [C.c_int32, C.c_char_p]
     _lib = L
     return L
 
@@ -123,9 +124,13 @@ def register_model(name, n, npar, f, vjp=None, vjp_p=None, check=False):
     return mid.value
 
 
-def set_model_cost(model_id, dgdu, dgdp):
-    """hipadj_model_set_cost: attach dgdu_continuous / dgdp_continuous bodies to a runtime-registered model."""
+def set_model_cost(model_id, dgdu=None, dgdp=None, g=None):
+    """hipadj_model_set_cost / hipadj_model_set_cost_function: attach a continuous cost to a runtime-registered model, either
+    through its gradient bodies or through the cost itself (gradients by dual numbers)."""
     L = load()
-    rc = L.hipadj_model_set_cost(int(model_id), dgdu.encode(), dgdp.encode())
+    if g is not None:
+        rc = L.hipadj_model_set_cost_function(int(model_id), g.encode())
+    else:
+        rc = L.hipadj_model_set_cost(int(model_id), dgdu.encode(), dgdp.encode())
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())

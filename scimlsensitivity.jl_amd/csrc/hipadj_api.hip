@@ -111,6 +111,10 @@ extern "C" int hipadj_model_set_cost(int32_t model_id, const char* dgdu_body, co
     return user_set_cost(model_id, dgdu_body, dgdp_body, g_create_error);
 }
 
+extern "C" int hipadj_model_set_cost_function(int32_t model_id, const char* g_body) {
+    return user_set_cost_function(model_id, g_body, g_create_error);
+}
+
 extern "C" int hipadj_model_check(int32_t model_id) {
     std::vector<char> code; std::map<std::string, std::string> low;
     return user_compile(model_id, {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 2, 7>" : "hipadj::k_interp<hipadj::UserModel, 2, 1>"},

@@ -32,6 +32,7 @@ namespace hipadj {
 struct UserModelSrc {
     std::string name, f, vjp_u, vjp_p;
     std::string dgdu, dgdp;   // optional continuous cost (hipadj_model_set_cost)
+    std::string gfun;         // ... or the cost itself (hipadj_model_set_cost_function): gradients by dual numbers
     bool has_cost = false;
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
     int n = 0, np = 0, rev = 0;   // rev: bumped when the sources change, part of the code-cache key
@@ -138,11 +139,26 @@ inline std::string user_model_struct(const UserModelSrc& m) {
           << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_p << "\n    }\n";
     }
-    o << "    // continuous cost attached with hipadj_model_set_cost (dgdu_continuous / dgdp_continuous); zero when absent\n"
-      << "    HIPADJ_HD static void dgdu(double (&out)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
-      << "        (void)u; (void)p; (void)t;\n" << (m.has_cost ? m.dgdu : std::string("for (int i = 0; i < N; ++i) out[i] = 0.0;")) << "\n    }\n"
-      << "    HIPADJ_HD static void dgdp(double (&out)[NP], const double (&u)[N], const double (&p)[NP], double t) {\n"
-      << "        (void)u; (void)p; (void)t;\n" << (m.has_cost ? m.dgdp : std::string("for (int i = 0; i < NP; ++i) out[i] = 0.0;")) << "\n    }\n};\n}  // namespace hipadj\n";
+    o << "    // continuous cost attached with hipadj_model_set_cost[_function] (dgdu_continuous / dgdp_continuous); zero when absent\n";
+    if (m.has_cost && !m.gfun.empty()) {
+        // only g was given: its gradients by forward-mode dual numbers (the reference differentiates `g` with ForwardDiff when
+        // no dgdu/dgdp are supplied, src/derivative_wrappers.jl:1428-1441)
+        o << "    template <class real> HIPADJ_HD static real g_t(const real (&u)[N], const real (&p)[NP], real t) {\n"
+          << "        (void)u; (void)p; (void)t; real g = 0.0;\n" << m.gfun << "\n        return g;\n    }\n"
+          << "    HIPADJ_HD static void dgdu(double (&out)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        Dual<N> uu[N], pp[NP];\n        for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n"
+          << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n        const Dual<N> gv = g_t<Dual<N>>(uu, pp, Dual<N>(t));\n"
+          << "        for (int j = 0; j < N; ++j) out[j] = gv.d[j];\n    }\n"
+          << "    HIPADJ_HD static void dgdp(double (&out)[NP], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        Dual<NP> uu[N], pp[NP];\n        for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n"
+          << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n        const Dual<NP> gv = g_t<Dual<NP>>(uu, pp, Dual<NP>(t));\n"
+          << "        for (int j = 0; j < NP; ++j) out[j] = gv.d[j];\n    }\n};\n}  // namespace hipadj\n";
+    } else {
+        o << "    HIPADJ_HD static void dgdu(double (&out)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        (void)u; (void)p; (void)t;\n" << (m.has_cost ? m.dgdu : std::string("for (int i = 0; i < N; ++i) out[i] = 0.0;")) << "\n    }\n"
+          << "    HIPADJ_HD static void dgdp(double (&out)[NP], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        (void)u; (void)p; (void)t;\n" << (m.has_cost ? m.dgdp : std::string("for (int i = 0; i < NP; ++i) out[i] = 0.0;")) << "\n    }\n};\n}  // namespace hipadj\n";
+    }
     return o.str();
 }
 
@@ -204,13 +220,22 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
     return HIPADJ_OK;
 }
 
+inline int user_set_cost_function(int32_t model, const char* g, std::string& err) {
+    if (!g) { err = "hipadj_model_set_cost_function: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost_function: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
+    R.models[idx].gfun = g; R.models[idx].has_cost = true; R.models[idx].rev++;
+    return HIPADJ_OK;
+}
 inline int user_set_cost(int32_t model, const char* dgdu, const char* dgdp, std::string& err) {
     if (!dgdu || !dgdp) { err = "hipadj_model_set_cost: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
     UserRegistry& R = user_registry();
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
-    R.models[idx].dgdu = dgdu; R.models[idx].dgdp = dgdp; R.models[idx].has_cost = true; R.models[idx].rev++;
+    R.models[idx].dgdu = dgdu; R.models[idx].dgdp = dgdp; R.models[idx].gfun.clear(); R.models[idx].has_cost = true; R.models[idx].rev++;
     return HIPADJ_OK;
 }
 inline bool user_has_cost(int32_t model) {

@@ -803,3 +803,21 @@ def test_runtime_models_with_automatic_vjps_match_oracle(sa, name, omodel, dims,
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     sol.engine.close()
+
+
+def test_runtime_model_cost_function_with_automatic_gradients(sa):
+    """g(u, p, t) given as text, dgdu / dgdp by dual numbers (the reference's gradient!(g) fallback): must equal the registered
+    cost #2 with its hand-written gradients."""
+    m = UM.LV
+    f = sa.DeviceFunction("lv_runtime_gfun", m["n"], m["np"], m["f"]).set_cost(g="g = u[0]*u[0] + p[0];")
+    rng = np.random.default_rng(57)
+    N, T = 70, 2.0
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    ts = np.linspace(0, T, 5)
+    res = []
+    for ff, g in (("lv", sa.FirstStateSquaredPlusFirstParam()), (f, sa.ModelCost())):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(ff, u0[0], (0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.InterpolatingAdjoint(),
+                       dgdu_discrete=sa.LsqShift(2.0), g=g, abstol=1e-10, reltol=1e-10)
+        res.append(sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=sa.LsqShift(2.0), g=g))
+        sol.engine.close()
+    assert rel(res[1][0], res[0][0]) < 1e-9 and rel(res[1][1], res[0][1]) < 1e-9
