@@ -53,14 +53,16 @@ def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
 
 
 def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
-          device=0, time_segments=0, no_start=False, want_out=True, g=None, abstol=1e-6, reltol=1e-3, max_steps=0):
+          device=0, time_segments=0, no_start=False, want_out=True, g=None, abstol=1e-6, reltol=1e-3, max_steps=0, save_idxs=None):
     """Forward solve of an EnsembleProblem on the device.  The returned solution owns the device-resident
     interpolant tiles (Interpolating/Gauss/Quadrature) or checkpoints (Backsolve) the reverse pass consumes.
     `dgdu_discrete` may be given here already (LsqShift or None = cotangents) because the fused reverse kernel
     is specialised on it at handle creation; likewise the continuous cost `g` (HalfSquaredSum() or None).
     alg = RK4(): fixed step `dt` (required).  alg = Tsit5(): adaptive, `abstol`/`reltol` are used for the forward AND
     the reverse solve (src/sensitivity_interface.jl:432), `dt` is the optional initial-step hint, `saveat` may hold
-    arbitrary ascending times, `max_steps` bounds the accepted steps per trajectory (default 2048)."""
+    arbitrary ascending times, `max_steps` bounds the accepted steps per trajectory (default 2048).
+    `save_idxs` (src/concrete_solve.jl:733-736, 774-824): only those state components appear in `sol.u`; cotangents handed to
+    adjoint_sensitivities then have that shape and the other components receive zero (`_out[_save_idxs] .= ...`)."""
     adaptive = isinstance(alg, Tsit5)
     if not adaptive and not isinstance(alg, RK4):
         raise ValueError("alg must be RK4() (fixed step) or Tsit5() (adaptive)")
@@ -83,8 +85,17 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
                  stepper=(1 if adaptive else 0), abstol=abstol, reltol=reltol, max_steps=max_steps,
                  **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive))
     out = eng.forward(ensprob.u0, ensprob.p, want_out=want_out)
+    idxs = None
+    if save_idxs is not None:
+        idxs = np.atleast_1d(np.asarray(save_idxs, dtype=np.int64))
+        if idxs.min() < 0 or idxs.max() >= eng.n:
+            raise ValueError(f"save_idxs out of range for a {eng.n}-state model")
+        if isinstance(dgdu_discrete, LsqShift):
+            raise ValueError("save_idxs with the fused LsqShift loss is ambiguous: hand the cotangents instead")
+        if out is not None:
+            out = np.ascontiguousarray(out[:, :, idxs])
     return EnsembleSolution(engine=eng, u=out, t=ts, prob=ensprob, alg=alg, dt=dt,
-                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g))
+                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g, save_idxs=idxs))
 
 
 def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, sensealg=None, checkpoints=None, g=None, **kwargs):
@@ -112,7 +123,13 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, senseal
         raise ValueError("dgdu_discrete required")
     if eng.cfg.loss_kind != _lib.LOSS_COTANGENT:
         raise ValueError("solution was prepared with a fused LsqShift loss; cotangents need dgdu_discrete=None at solve time")
-    return eng.adjoint(np.asarray(dgdu_discrete, dtype=np.float64))
+    delta = np.asarray(dgdu_discrete, dtype=np.float64)
+    idxs = sol.extra.get("save_idxs")
+    if idxs is not None:                      # cotangent of the saved components only: zero elsewhere (src/concrete_solve.jl:790-824)
+        full = np.zeros((eng.N, eng.M, eng.n))
+        full[:, :, idxs] = delta.reshape(eng.N, eng.M, len(idxs))
+        delta = full
+    return eng.adjoint(delta)
 
 
 def concrete_solve_adjoint(prob, alg, sensealg, u0, p, *, dt=None, saveat, **kw):
@@ -123,7 +140,7 @@ def concrete_solve_adjoint(prob, alg, sensealg, u0, p, *, dt=None, saveat, **kw)
     sol = solve(ens, alg, dt=dt, saveat=saveat, sensealg=sensealg, **kw)
 
     def pullback(delta):
-        return adjoint_sensitivities(sol, alg, dgdu_discrete=np.asarray(delta, dtype=np.float64).reshape(sol.u.shape))
+        return adjoint_sensitivities(sol, alg, dgdu_discrete=np.asarray(delta, dtype=np.float64).reshape(sol.u.shape))   # sol.u already has the save_idxs shape
     return sol.u, pullback
 
 

@@ -821,3 +821,21 @@ def test_runtime_model_cost_function_with_automatic_gradients(sa):
         res.append(sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=sa.LsqShift(2.0), g=g))
         sol.engine.close()
     assert rel(res[1][0], res[0][0]) < 1e-9 and rel(res[1][1], res[0][1]) < 1e-9
+
+
+def test_save_idxs_cotangents_are_padded_with_zeros(sa):
+    """save_idxs (src/concrete_solve.jl:733-736, 774-824): the saved solution holds a subset of the state; its cotangent is
+    scattered into a zero cotangent of the full state."""
+    rng = np.random.default_rng(71)
+    N, T, dt = 50, 1.0, 0.01
+    u0, p = lorenz_inputs(N, seed=9)
+    ts = np.linspace(0, T, 6)
+    prob = sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0)
+    out, pullback = sa.concrete_solve_adjoint(prob.prob, sa.RK4(), sa.InterpolatingAdjoint(), u0, p, dt=dt, saveat=ts, save_idxs=[0, 2])
+    assert out.shape == (N, len(ts), 2)
+    delta = rng.standard_normal(out.shape)
+    du0, dp = pullback(delta)
+    full = np.zeros((N, len(ts), 3)); full[:, :, [0, 2]] = delta
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT")
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, full)
+    assert rel(out, rout[:, :, [0, 2]]) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
