@@ -839,3 +839,34 @@ def test_save_idxs_cotangents_are_padded_with_zeros(sa):
     ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT")
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, full)
     assert rel(out, rout[:, :, [0, 2]]) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+
+
+def test_million_trajectory_ensemble_64bit_indexing(sa):
+    """Sized for 288 GB of HBM: 10^6 trajectories x 700 RK4 steps = 2.1e9 knot pairs (33.6 GB, element indices beyond 2^31),
+    then 10^6 adaptive trajectories with a 256-step record capacity (35 GB).  A sample is checked against the oracle."""
+    N = 1_000_000
+    rng = np.random.default_rng(81)
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8.0 / 3.0])
+    idx = np.concatenate([np.arange(0, 8), rng.integers(0, N, 40), np.arange(N - 8, N)])
+    # fixed-step
+    T, dt = 7.0, 0.01
+    ts = np.linspace(0, T, 8)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint(),
+                   dgdu_discrete=sa.LsqShift(2.0), want_out=False)
+    assert sol.engine.stats()["workspace_bytes"] > 33e9
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+    sol.engine.close()
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, _, _, _ = ref.adjoint_ensemble(u0[idx], p)
+    assert rel(du0[idx], rdu0) < RTOL and np.all(np.isfinite(dp))
+    # adaptive
+    T = 2.0
+    ts = np.linspace(0, T, 5)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.InterpolatingAdjoint(),
+                   dgdu_discrete=sa.LsqShift(2.0), abstol=1e-6, reltol=1e-6, max_steps=256, want_out=False)
+    assert sol.engine.stats()["workspace_bytes"] > 34e9
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+    sol.engine.close()
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-6, reltol=1e-6, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, _, _, _ = ref.adjoint_ensemble(u0[idx], p)
+    assert rel(du0[idx], rdu0) < RTOL and np.all(np.isfinite(dp))
