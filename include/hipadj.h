@@ -53,7 +53,10 @@ typedef enum {
     HIPADJ_ALG_INTERPOLATING = 0,
     HIPADJ_ALG_BACKSOLVE = 1,
     HIPADJ_ALG_GAUSS = 2,
-    HIPADJ_ALG_QUADRATURE = 3
+    HIPADJ_ALG_QUADRATURE = 3,
+    HIPADJ_ALG_GAUSS_KRONROD = 4  /* GaussKronrodAdjoint (src/sensitivity_algorithms.jl:612-711): GaussAdjoint with a per-step adaptive
+                                     (7,15) Gauss-Kronrod rule.  Its callback lives in DiffEqCallbacks (not vendored): restated from
+                                     recall, pinned only by GaussKronrod == Gauss == Interpolating.  Adaptive Tsit5 only. */
 } hipadj_alg;
 
 typedef enum {

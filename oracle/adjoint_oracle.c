@@ -755,11 +755,14 @@ static void gauss_step(adj_ctx *A, orc_integ *I) {
     }
 }
 
+static void gausskronrod_step(adj_ctx *A, orc_integ *I);   /* defined next to the GK tables below */
+
 /* CallbackSet ordering: Gauss: CallbackSet(cb_integrate, cb2_loss) (src/gauss_adjoint.jl:850);
  * Backsolve: CallbackSet(cb_checkpoint, cb_loss) (src/backsolve_adjoint.jl:545). */
 static int adjoint_step_cb(orc_integ *I, void *c) {
     adj_ctx *A = (adj_ctx *)c; int mod = 0;
     if (A->alg == ORC_ALG_GAUSS && I->t != I->tprev) gauss_step(A, I);
+    if (A->alg == ORC_ALG_GAUSS_KRONROD && I->t != I->tprev) gausskronrod_step(A, I);
     if (A->alg == ORC_ALG_BACKSOLVE) mod |= backsolve_ckpt(A, I);
     mod |= loss_jump(A, I);
     return mod;
@@ -768,6 +771,7 @@ static int adjoint_step_cb(orc_integ *I, void *c) {
 /* =====================================================================================
  * 5. QuadGK [upstream-recall]: adaptive Gauss-Kronrod (7,15), global error heap, Euclidean norm
  * ===================================================================================== */
+#define ORC_MAXNP_COST 64
 static const double GK_X[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
                                0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
                                0.586087235467691130294144838258730, 0.405845151377397166906606412076961,
@@ -778,6 +782,33 @@ static const double GK_WK[8] = {0.022935322010529224963732008058970, 0.063092092
                                 0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
 static const double GK_WG[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
                                 0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
+
+/* IntegratingGKSumCallback [upstream-recall: DiffEqCallbacks, NOT vendored; src/gauss_adjoint.jl:820-825 only constructs it]:
+ * GaussKronrodAdjoint "uses Gauss-Kronrod quadrature instead of Gauss quadrature, to achieve error control"
+ * (src/sensitivity_algorithms.jl:617-618).  Restated here as: per accepted step a (7,15) Gauss-Kronrod rule of the same
+ * integrand on [tprev, t] with the integrator's own interpolant; if the Euclidean norm of (Kronrod - Gauss) exceeds 1e-7 the
+ * panel is halved recursively.  Node count, norm and tolerance are recalled, not read: parity for this sensealg is UNPINNED
+ * beyond the relation GaussKronrod == Gauss == Interpolating that the reference tests assert (test/Core3/adjoint.jl:223-305). */
+#define ORC_GK_TOL 1e-7
+#define ORC_GK_MAXDEPTH 12
+static void gk_panel(adj_ctx *A, orc_integ *I, double a, double b, int depth) {
+    int np = A->np; double c = 0.5 * (a + b), h = 0.5 * (b - a);
+    double *lam = A->scratch, *out = A->scratch + A->n;
+    double IK[ORC_MAXNP_COST], IG[ORC_MAXNP_COST];
+    for (int i = 0; i < np; ++i) { IK[i] = 0; IG[i] = 0; }
+    for (int j = 0; j < 15; ++j) {
+        int q = j < 7 ? j : 14 - j; double x = j < 7 ? -GK_X[q] : GK_X[q];      /* ascending nodes; q == 7 is the centre */
+        if (j == 7) { q = 7; x = 0.0; }
+        double tt = c + h * x;
+        integ_interp(I, tt, lam);
+        gauss_integrand(A, out, tt, lam);
+        for (int i = 0; i < np; ++i) { IK[i] += GK_WK[q] * out[i]; if (q & 1) IG[i] += GK_WG[q / 2] * out[i]; }
+    }
+    double e = 0; for (int i = 0; i < np; ++i) { IK[i] *= h; IG[i] *= h; double d = IK[i] - IG[i]; e += d * d; }
+    if (sqrt(e) <= ORC_GK_TOL || depth >= ORC_GK_MAXDEPTH) { for (int i = 0; i < np; ++i) A->gauss_acc[i] += IK[i]; return; }
+    gk_panel(A, I, a, c, depth + 1); gk_panel(A, I, c, b, depth + 1);
+}
+static void gausskronrod_step(adj_ctx *A, orc_integ *I) { gk_panel(A, I, I->tprev, I->t, 0); }
 
 typedef void (*orc_integrand)(double *out, double t, void *ctx);
 typedef struct { double a, b, E; double *I; } gk_seg;
@@ -838,7 +869,6 @@ double orc_test_quadgk_poly(int degree, double a, double b, double atol, double 
 }
 
 /* AdjointSensitivityIntegrand (src/quadrature_adjoint.jl:486-502): y = sol(t), lam = adj_sol(t), out = f_p^T lam */
-#define ORC_MAXNP_COST 64
 typedef struct { adj_ctx *A; const orc_dense *adj; long hint; double *lam; } quad_ctx;
 static void quad_integrand(double *out, double t, void *c) {
     quad_ctx *Q = (quad_ctx *)c; adj_ctx *A = Q->A;
@@ -863,7 +893,8 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     /* GaussIntegrand adds +dgdp to the NEGATED f_p^T lam (src/gauss_adjoint.jl:755-758) while the sum runs backward in time;
      * no reference test covers Gauss with dgdp_continuous (test/Core7/mixed_costs.jl, adjoint_param.jl use Backsolve /
      * Interpolating / Quadrature), so the sign is not restated here */
-    if (cfg->cont_cost == 2 && cfg->alg == ORC_ALG_GAUSS) return -6;
+    if (cfg->cont_cost == 2 && (cfg->alg == ORC_ALG_GAUSS || cfg->alg == ORC_ALG_GAUSS_KRONROD)) return -6;
+    if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cfg->cont_cost == 2 && np > ORC_MAXNP_COST) return -6;
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
@@ -917,7 +948,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     }
     z = (double *)calloc(nz, sizeof(double));
     if (cfg->alg == ORC_ALG_BACKSOLVE) { memcpy(z + n + np, uend, sizeof(double) * n); if (A.bs_cur >= 1 && time_hits(cfg->t1, ck_t[A.bs_cur - 1])) A.bs_cur -= 1; }
-    if (cfg->alg == ORC_ALG_GAUSS) A.gauss_acc = (double *)calloc(np, sizeof(double));
+    if (cfg->alg == ORC_ALG_GAUSS || cfg->alg == ORC_ALG_GAUSS_KRONROD) A.gauss_acc = (double *)calloc(np, sizeof(double));
     orc_dense adjrec; int have_rec = 0;
     if (cfg->alg == ORC_ALG_QUADRATURE) { dense_init(&adjrec, n, cfg->stepper); have_rec = 1; }
     int cb_at_init = (M > 0 && time_hits(cfg->t1, cfg->save_times[M - 1]));
@@ -926,7 +957,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     /* unpack (src/sensitivity_interface.jl:500-508) */
     memcpy(du0, z, sizeof(double) * n);
     if (cfg->alg == ORC_ALG_INTERPOLATING || cfg->alg == ORC_ALG_BACKSOLVE) memcpy(dp, z + n, sizeof(double) * np);
-    else if (cfg->alg == ORC_ALG_GAUSS) memcpy(dp, A.gauss_acc, sizeof(double) * np);
+    else if (cfg->alg == ORC_ALG_GAUSS || cfg->alg == ORC_ALG_GAUSS_KRONROD) memcpy(dp, A.gauss_acc, sizeof(double) * np);
     else {
         /* res = sum over loss intervals of quadgk(integrand, t[i], t[i+1]) + end/start corrections
          * (src/quadrature_adjoint.jl:563-616) */

@@ -40,7 +40,8 @@ enum {
     ORC_MODEL_ROBER = 7,     /* Robertson kinetics `rober` (test/Core3/adjoint.jl:1434-1441); checker for runtime-registered models */
     ORC_MODEL_RING = 8       /* synthetic ring, dims = {n <= 8}, np = n + 1; checker for runtime-registered models with n > 3 */
 };
-enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3 };
+enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3,
+       ORC_ALG_GAUSS_KRONROD = 4 /* [upstream-recall] per-step adaptive GK(7,15): parity UNPINNED beyond GaussKronrod == Gauss */ };
 enum { ORC_STEPPER_RK4 = 0, ORC_STEPPER_TSIT5 = 1 };
 enum { ORC_LOSS_COTANGENT = 0, ORC_LOSS_LSQ_SHIFT = 1 };
 

@@ -5,7 +5,7 @@ Import as `scimlsensitivity_jl_amd` (shim at the repo root).  The numerical path
 behind the C ABI in include/hipadj.h; importing this package does not require a GPU, creating an Engine does."""
 from ._lib import HipadjError, model_sizes, load as load_library, LIB_PATH
 from .sensitivity_algorithms import (AbstractSensitivityAlgorithm, AbstractAdjointSensitivityAlgorithm, DeviceVJP,
-                                     InterpolatingAdjoint, BacksolveAdjoint, QuadratureAdjoint, GaussAdjoint,
+                                     InterpolatingAdjoint, BacksolveAdjoint, QuadratureAdjoint, GaussAdjoint, GaussKronrodAdjoint,
                                      ischeckpointing)
 from .problems import (RK4, Tsit5, DeviceFunction, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum,
                        FirstStateSquaredPlusFirstParam, ModelCost)
@@ -19,7 +19,7 @@ build_extension = _build.build
 __all__ = [
     "HipadjError", "model_sizes", "load_library", "LIB_PATH", "AbstractSensitivityAlgorithm",
     "AbstractAdjointSensitivityAlgorithm", "DeviceVJP", "InterpolatingAdjoint", "BacksolveAdjoint",
-    "QuadratureAdjoint", "GaussAdjoint", "ischeckpointing", "RK4", "Tsit5", "DeviceFunction", "ODEProblem", "EnsembleProblem",
+    "QuadratureAdjoint", "GaussAdjoint", "GaussKronrodAdjoint", "ischeckpointing", "RK4", "Tsit5", "DeviceFunction", "ODEProblem", "EnsembleProblem",
     "EnsembleSolution", "LsqShift", "HalfSquaredSum", "FirstStateSquaredPlusFirstParam", "ModelCost", "Engine", "solve", "adjoint_sensitivities", "concrete_solve_adjoint",
     "make_autograd_function", "shard_range", "allreduce_dp", "gather_du0", "build_extension",
 ]

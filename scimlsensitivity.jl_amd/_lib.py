@@ -10,7 +10,7 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NONFINITE, ERR_STATE, ERR_UNSUP
 MODEL_USER_BASE = 1000
 
 MODEL = dict(lv=0, lvt=1, lorenz=2, lindiag=3, fallmass=4, mlp=5, bruss=6)
-ALG = dict(interpolating=0, backsolve=1, gauss=2, quadrature=3)
+ALG = dict(interpolating=0, backsolve=1, gauss=2, quadrature=3, gausskronrod=4)
 LOSS_COTANGENT, LOSS_LSQ_SHIFT = 0, 1
 CCOST_NONE, CCOST_HALF_SQ_SUM, CCOST_U1SQ_PLUS_P1, CCOST_MODEL = 0, 1, 2, 3
 

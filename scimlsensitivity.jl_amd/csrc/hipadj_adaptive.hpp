@@ -388,7 +388,8 @@ template <class Mo> struct FwdCursor {
     }
 };
 
-// reverse sweeps.  ALG: 0 Interpolating (z = [lam; mu]), 1 Backsolve (z = [lam; mu; y]), 2 Gauss (z = lam, mu by quadrature)
+// reverse sweeps.  ALG: 0 Interpolating (z = [lam; mu]), 1 Backsolve (z = [lam; mu; y]), 2 Gauss (z = lam, mu by quadrature),
+// 3 Quadrature pass 1 (z = lam, recorded densely), 4 GaussKronrod (as Gauss with a per-step adaptive (7,15) rule)
 // ALG 3 = Quadrature pass 1: z = lam, every accepted step is recorded (dense adjoint solution, src/quadrature_adjoint.jl:527-530)
 template <class Mo, int ALG> struct AdjNZ { static constexpr int value = ALG == 0 ? Mo::N + Mo::NP : (ALG == 1 ? 2 * Mo::N + Mo::NP : Mo::N); };
 
@@ -539,6 +540,46 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 for (int j = 0; j < NP; ++j) gacc[j] += half * wq * (-W[j]);
             }
         }
+        if (ALG == 4 && t != tprev) {
+            // IntegratingGKSumCallback [upstream-recall, DiffEqCallbacks is not vendored; src/gauss_adjoint.jl:820-825 only
+            // constructs it]: (7,15) Gauss-Kronrod rule of the same integrand on the step, halved recursively (left half first)
+            // while the Euclidean norm of Kronrod - Gauss exceeds 1e-7; same restatement as oracle `gk_panel`.
+            constexpr int GKD = 12;
+            const double hstep = t - tprev;
+            double pa[GKD + 2], pb[GKD + 2]; int pd[GKD + 2]; int sp = 1;
+            pa[0] = tprev; pb[0] = t; pd[0] = 0;
+#pragma unroll 1
+            while (sp > 0) {
+                --sp;
+                const double a = pa[sp], b = pb[sp]; const int d = pd[sp];
+                const double c = 0.5 * (a + b), h = 0.5 * (b - a);
+                double IK[NP], IG[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { IK[j] = 0.0; IG[j] = 0.0; }
+#pragma unroll 1
+                for (int jn = 0; jn < 15; ++jn) {
+                    const int q = jn < 7 ? jn : (jn == 7 ? 7 : 14 - jn);
+                    const double x = jn < 7 ? -GK15::X[q] : (jn == 7 ? 0.0 : GK15::X[q]);
+                    const double tt = c + h * x;
+                    double y[N], W[NP], lamq[N];
+                    kstore_interp<NZ, N>(KK, (tt - tprev) / hstep, hstep, lamq);
+                    cur.eval(tt, y);
+                    Mo::vjp_p(W, lamq, y, pv, tt);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) { IK[j] += GK15::WK[q] * (-W[j]); if (q & 1) IG[j] += GK15::WG[q / 2] * (-W[j]); }
+                }
+                double e = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { IK[j] *= h; IG[j] *= h; const double dd = IK[j] - IG[j]; e += dd * dd; }
+                if (sqrt(e) <= 1e-7 || d >= GKD) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) gacc[j] += IK[j];
+                } else {
+                    pa[sp] = c; pb[sp] = b; pd[sp] = d + 1; ++sp;      // right half: after the left one
+                    pa[sp] = a; pb[sp] = c; pd[sp] = d + 1; ++sp;
+                }
+            }
+        }
         if (ALG == 1 && ckpt && bs_cur >= 1 && time_hits(t, t_ck)) {               // backsolve_checkpoint_callbacks (t_ck = ck_t[bs_cur - 1], cached)
 #pragma unroll
             for (int j = 0; j < N; ++j) zz[N + NP + j] = ckpt[((long)(bs_cur - 1) * N + j) * g.Npad + i];
@@ -576,7 +617,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     for (int j = 0; j < N; ++j) lam_out[j] = z[j];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        if constexpr (ALG == 2) mu_out[j] = gacc[j];
+        if constexpr (ALG == 2 || ALG == 4) mu_out[j] = gacc[j];
         else if constexpr (ALG == 3) mu_out[j] = 0.0;      // dp comes from the quadrature pass
         else mu_out[j] = z[N + j];
     }

@@ -772,6 +772,8 @@ template <class Mo> static int adaptive_adjoint(hipadj_handle* h, const double* 
         case HIPADJ_ALG_INTERPOLATING * 4 + 2: return adaptive_adjoint_l<Mo, 0, 2, true>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0, true>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return adaptive_adjoint_l<Mo, 4, 0, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return adaptive_adjoint_l<Mo, 4, 1, true>(h, d_cot, d_du0, d_dp);
         default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no checkpointed adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
         }
     }
@@ -787,6 +789,8 @@ template <class Mo> static int adaptive_adjoint(hipadj_handle* h, const double* 
     case HIPADJ_ALG_QUADRATURE * 4 + 0: return adaptive_adjoint_l<Mo, 3, 0>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_QUADRATURE * 4 + 1: return adaptive_adjoint_l<Mo, 3, 1>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_QUADRATURE * 4 + 2: return adaptive_adjoint_l<Mo, 3, 2>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return adaptive_adjoint_l<Mo, 4, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return adaptive_adjoint_l<Mo, 4, 1>(h, d_cot, d_du0, d_dp);
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
     }
 }

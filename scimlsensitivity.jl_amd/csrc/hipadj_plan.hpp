@@ -80,7 +80,7 @@ inline int plan_auto_segments(long N, int S, int n, int np = 0) {
 inline int plan_check_cost(const hipadj_config* cfg, std::string& err) {
     if (cfg->cont_cost < HIPADJ_CCOST_NONE || cfg->cont_cost > HIPADJ_CCOST_MODEL) { err = "unknown cont_cost"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !plan_user_model(cfg->model)) { err = "HIPADJ_CCOST_MODEL needs a runtime-registered model with hipadj_model_set_cost"; return HIPADJ_ERR_INVALID_ARG; }
-    if (cfg->cont_cost >= HIPADJ_CCOST_U1SQ_PLUS_P1 && cfg->alg == HIPADJ_ALG_GAUSS) {
+    if (cfg->cont_cost >= HIPADJ_CCOST_U1SQ_PLUS_P1 && (cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD)) {
         err = "GaussAdjoint with a parameter-dependent continuous cost (dgdp_continuous) is not offered: the reference adds +dgdp to its negated integrand (src/gauss_adjoint.jl:755-758) and no reference test pins that sign";
         return HIPADJ_ERR_UNSUPPORTED; }
     return HIPADJ_OK;
@@ -106,7 +106,9 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (cfg->dims[0] != 8 && cfg->dims[0] != 16 && cfg->dims[0] != 32) { err = "Brusselator grid must be 8, 16 or 32 (one workgroup per trajectory)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "BacksolveAdjoint is not offered for the PDE family: backward diffusion is ill-posed (src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }
     }
-    if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_QUADRATURE) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_GAUSS_KRONROD) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE || P.field || P.mlp)) {
+        err = "GaussKronrodAdjoint is offered with adaptive Tsit5 on the lane-per-trajectory models (use GaussAdjoint with fixed-step RK4)"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {
         // adaptive path: no step grid; arbitrary ascending loss times inside [t0, t1]
@@ -121,7 +123,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (cfg->max_steps < 0) { err = "max_steps must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
         {   // the 8 x NZ stage rows of a wave live in LDS (hipadj_adaptive.hpp): 8 * NZ * 64 lanes * 8 B <= 160 KB
             const int NZ = cfg->alg == HIPADJ_ALG_INTERPOLATING ? n + np : (cfg->alg == HIPADJ_ALG_BACKSOLVE ? 2 * n + np : n);   // Gauss, Quadrature: lam only
-            const bool ipck = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing;   // + the rows of the interval re-solve
+            const bool ipck = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) && cfg->checkpointing;   // + the rows of the interval re-solve
             if (8L * (NZ + (ipck ? n : 0)) * 64 * 8 > 160L * 1024) { err = "adaptive Tsit5: augmented state too large for the LDS stage storage (need 8 * NZ * 512 B <= 160 KB)"; return HIPADJ_ERR_UNSUPPORTED; }
         }
         P.adaptive = true; P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = 0; P.M = cfg->nsave;
@@ -132,7 +134,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
             if (i > 0 && !(cfg->save_times[i] > cfg->save_times[i - 1])) { err = "save_times must be strictly ascending (duplicate event times are out of scope)"; return HIPADJ_ERR_INVALID_ARG; }
         }
         P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
-        P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing;
+        P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) && cfg->checkpointing;
         P.ck_times.clear();
         if (P.bs_ckpt || P.ip_ckpt) {   // default checkpoints = sol.t of the saveat solve: t0, save times, t1 (src/backsolve_adjoint.jl:132)
             if (P.save_times.empty() || P.save_times.front() > cfg->t0) P.ck_times.push_back(cfg->t0);

@@ -16,7 +16,7 @@ from .engine import Engine
 from .problems import (RK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum,
                        FirstStateSquaredPlusFirstParam, ModelCost)
 from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
-                                     QuadratureAdjoint, GaussAdjoint, ischeckpointing)
+                                     QuadratureAdjoint, GaussAdjoint, GaussKronrodAdjoint, ischeckpointing)
 
 
 _COSTS = {HalfSquaredSum: _lib.CCOST_HALF_SQ_SUM, FirstStateSquaredPlusFirstParam: _lib.CCOST_U1SQ_PLUS_P1, ModelCost: _lib.CCOST_MODEL}
@@ -33,7 +33,7 @@ def _save_times(tspan, saveat, dt):
 
 def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
     kw = {}
-    if isinstance(sensealg, (BacksolveAdjoint, InterpolatingAdjoint, GaussAdjoint)):
+    if isinstance(sensealg, (BacksolveAdjoint, InterpolatingAdjoint, GaussAdjoint, GaussKronrodAdjoint)):
         kw["checkpointing"] = sensealg.checkpointing
         if adaptive:
             if checkpoints is not None:

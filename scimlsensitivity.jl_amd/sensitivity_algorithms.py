@@ -71,11 +71,23 @@ class GaussAdjoint(AbstractAdjointSensitivityAlgorithm):
         _check_vjp(self.autojacvec)
 
 
+@dataclass(frozen=True)
+class GaussKronrodAdjoint(AbstractAdjointSensitivityAlgorithm):
+    """GaussKronrodAdjoint(; autojacvec, checkpointing = false) (src/sensitivity_algorithms.jl:612-711): GaussAdjoint with
+    Gauss-Kronrod quadrature per step "to achieve error control".  Adaptive Tsit5 only on the device."""
+    autojacvec: object = None
+    checkpointing: bool = False
+    name = "gausskronrod"
+
+    def __post_init__(self):
+        _check_vjp(self.autojacvec)
+
+
 def ischeckpointing(sensealg, sol=None):
     """src/sensitivity_algorithms.jl:1665-1677: Backsolve uses its flag; Interpolating/Gauss checkpoint when
     asked or when the forward solution is not dense."""
     if isinstance(sensealg, BacksolveAdjoint):
         return sensealg.checkpointing
-    if isinstance(sensealg, (InterpolatingAdjoint, GaussAdjoint)):
+    if isinstance(sensealg, (InterpolatingAdjoint, GaussAdjoint, GaussKronrodAdjoint)):
         return sensealg.checkpointing or (sol is not None and not getattr(sol, "dense", True))
     return False

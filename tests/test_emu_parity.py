@@ -304,3 +304,31 @@ def test_tsit5_checkpoint_interval_overflow_is_an_error():
     cfg = E.make_config("lorenz", "interpolating", 1, 0.0, 10.0, 0.0, [10.0], loss_kind=1, stepper=1, abstol=1e-11, reltol=1e-11, checkpointing=True, max_steps=10)
     with pytest.raises(RuntimeError, match="rc=-7"):
         E.forward_adjoint(cfg, 3, 3, u0, p)
+
+
+# ---- GaussKronrodAdjoint (adaptive Tsit5): per-step adaptive (7,15) rule, [upstream-recall] restatement ------------------
+@pytest.mark.parametrize("ckpt", [False, True])
+@pytest.mark.parametrize("model,omodel,u0c,p", MODELS[:3])
+def test_gausskronrod_matches_oracle_and_gauss(model, omodel, u0c, p, ckpt):
+    """The device lane vs the oracle's gk_panel on identical inputs, plus the relation the reference tests pin:
+    GaussKronrod == Gauss == Interpolating (test/Core3/adjoint.jl:223-305)."""
+    rng = np.random.default_rng(91)
+    N, T = 3, 2.0
+    n, npar = len(u0c), len(p)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n)); pp = np.asarray(p)
+    ts = np.array([0.0, 0.4, 1.1, 2.0])
+    res = {}
+    for alg in ("gausskronrod", "gauss"):
+        cfg = E.make_config(model, alg, N, 0.0, T, 0.0, ts, loss_kind=1, loss_shift=2.0, stepper=1, abstol=1e-9, reltol=1e-9, checkpointing=ckpt)
+        res[alg] = E.forward_adjoint(cfg, n, npar, u0, pp)
+    ref = O.Problem(omodel, alg="GAUSS_KRONROD", stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="LSQ_SHIFT",
+                    loss_shift=2.0, checkpointing=ckpt)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, pp)
+    assert rel(res["gausskronrod"][0], rdu0) < 1e-10 and rel(res["gausskronrod"][1], rdp) < 1e-10
+    assert rel(res["gausskronrod"][1], res["gauss"][1]) < 1e-7 and rel(res["gausskronrod"][0], res["gauss"][0]) < 1e-12
+
+
+def test_gausskronrod_needs_the_adaptive_stepper():
+    cfg = E.make_config("lv", "gausskronrod", 1, 0.0, 1.0, 0.1, [1.0], loss_kind=1)
+    with pytest.raises(RuntimeError, match="rc=-6"):
+        E.forward_adjoint(cfg, 2, 4, np.ones((1, 2)), np.array([1.5, 1.0, 3.0, 1.0]))

@@ -870,3 +870,25 @@ def test_million_trajectory_ensemble_64bit_indexing(sa):
     ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-6, reltol=1e-6, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
     rdu0, _, _, _ = ref.adjoint_ensemble(u0[idx], p)
     assert rel(du0[idx], rdu0) < RTOL and np.all(np.isfinite(dp))
+
+
+@pytest.mark.parametrize("ckpt", [False, True])
+def test_gausskronrod_adjoint(sa, ckpt):
+    """GaussKronrodAdjoint with Tsit5 (test/Core3/adjoint.jl:223-305 runs it next to the other sensealgs): device vs the oracle's
+    restatement, and GaussKronrod == Gauss == Interpolating."""
+    N, T = 300, 2.0
+    u0, p = lorenz_inputs(N, seed=17)
+    ts = np.array([0.0, 0.4, 1.1, 2.0])
+    res = {}
+    for name, alg in (("gk", sa.GaussKronrodAdjoint(checkpointing=ckpt)), ("gauss", sa.GaussAdjoint(checkpointing=ckpt)), ("interp", sa.InterpolatingAdjoint())):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=alg,
+                       dgdu_discrete=sa.LsqShift(2.0), abstol=1e-10, reltol=1e-10, max_steps=4096)
+        res[name] = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+        sol.engine.close()
+    ref = O.Problem("LORENZ", alg="GAUSS_KRONROD", stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, loss="LSQ_SHIFT",
+                    loss_shift=2.0, checkpointing=ckpt)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(res["gk"][0], rdu0) < RTOL and rel(res["gk"][1], rdp) < RTOL
+    assert rel(res["gk"][1], res["gauss"][1]) < 1e-6 and rel(res["gk"][1], res["interp"][1]) < 1e-6
+    with pytest.raises(sa.HipadjError):
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=0.01, saveat=ts, sensealg=sa.GaussKronrodAdjoint())
