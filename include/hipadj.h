@@ -56,7 +56,8 @@ typedef enum {
     HIPADJ_ALG_QUADRATURE = 3,
     HIPADJ_ALG_GAUSS_KRONROD = 4  /* GaussKronrodAdjoint (src/sensitivity_algorithms.jl:612-711): GaussAdjoint with a per-step adaptive
                                      (7,15) Gauss-Kronrod rule.  Its callback lives in DiffEqCallbacks (not vendored): restated from
-                                     recall, pinned only by GaussKronrod == Gauss == Interpolating.  Adaptive Tsit5 only. */
+                                     recall, pinned only by GaussKronrod == Gauss == Interpolating.  Lane-per-trajectory models; RK4
+                                     (time-segmented like Gauss) and Tsit5; checkpointing=true with Tsit5 only. */
 } hipadj_alg;
 
 typedef enum {

@@ -423,6 +423,16 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                            d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         HIP_TRY(h, hipGetLastError());
         break; }
+    case HIPADJ_ALG_GAUSS_KRONROD: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussKronrodAdjoint with dgdp_continuous is not offered"); } else {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
+                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        HIP_TRY(h, hipGetLastError());
+        break; }
     case HIPADJ_ALG_QUADRATURE: {
         hipLaunchKernelGGL((k_quad_adj<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
                            (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0);
@@ -620,7 +630,8 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: k.main_k = "hipadj::k_interp<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.tail = compose; break;
     case HIPADJ_ALG_BACKSOLVE: k.main_k = "hipadj::k_backsolve<" + U + ", " + I(cc) + ">"; k.tail = compose; break;
-    case HIPADJ_ALG_GAUSS: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ">"; k.tail = compose; break;
+    case HIPADJ_ALG_GAUSS: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ", false>"; k.tail = compose; break;
+    case HIPADJ_ALG_GAUSS_KRONROD: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ", true>"; k.tail = compose; break;
     default: k.main_k = "hipadj::k_quad_adj<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.gk = "hipadj::k_quad_gk<" + U + ", " + I(cc) + ">"; k.tail = finish; break;
     }
     return k;
@@ -689,7 +700,7 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         SegPlan sp{h->nseg, h->d_seg_bounds};
         const dim3 sgrid(waves, (unsigned)h->nseg);
         switch (h->cfg.alg) {
-        case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS:
+        case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:
             TRY(ulaunch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
             composed = true; break;
         case HIPADJ_ALG_BACKSOLVE:

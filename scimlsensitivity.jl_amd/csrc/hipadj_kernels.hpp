@@ -366,7 +366,7 @@ __device__ __forceinline__ void store_segment_map(double* __restrict__ dst, long
 }
 
 // GaussAdjoint, time-segmented like k_interp (segment maps -> k_compose_finish)
-template <class Mo, int PF, int LOSS>
+template <class Mo, int PF, int LOSS, bool GKR = false>
 __global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                                 const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                                                 double* __restrict__ segbuf) {
@@ -378,11 +378,11 @@ __global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double
     double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
     if (seg == sp.nseg - 1) {
         double lam[1][N], mu[1][NP];
-        gauss_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        gauss_lane<Mo, 1, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
         store_segment_map<Mo, 1>(dst, g.Npad, lam, mu);
     } else {
         double lam[NC][N], mu[NC][NP];
-        gauss_lane<Mo, NC, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        gauss_lane<Mo, NC, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
         store_segment_map<Mo, NC>(dst, g.Npad, lam, mu);
     }
 }

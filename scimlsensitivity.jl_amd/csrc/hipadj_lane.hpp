@@ -563,6 +563,20 @@ HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gauss-Kronrod (7,15) constants (QUADPACK qk15 / QuadGK order 7)
+struct GK15 {
+    static constexpr double X[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
+                                    0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
+                                    0.586087235467691130294144838258730, 0.405845151377397166906606412076961,
+                                    0.207784955007898467600689403773245, 0.0};
+    static constexpr double WK[8] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
+                                     0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
+                                     0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
+                                     0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
+    static constexpr double WG[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
+                                     0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
+};
+
 // GaussAdjoint: lambda-only reverse RK4; after every step a 2-point Gauss-Legendre rule (div(order+1, 2) nodes
 // for RK4) of  -(df/dp)^T lam  over the step, with lambda from the ADJOINT step's Hermite interpolant (FSAL
 // derivatives at both ends) and y from the forward interpolant  (src/gauss_adjoint.jl:745-759, 809-851).
@@ -570,7 +584,11 @@ HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double 
 // ------------------------------------------------------------------------------------------------
 // Like interp_lane the sweep is linear in (lam, mu) given y(t), so it takes NC columns (affine + basis) and a segment
 // [k_lo, k_hi): the same time segmentation and composition apply.
-template <class Mo, int NC, int PF, int MODE, int KMAX = 0>
+// GKR = true: GaussKronrodAdjoint — the step's quadrature is an adaptive (7,15) Gauss-Kronrod rule instead of the 2-point
+// Gauss-Legendre rule (IntegratingGKSumCallback [upstream-recall], same restatement as hipadj_adaptive.hpp / oracle gk_panel:
+// halve the panel, left half first, while ||Kronrod - Gauss||_2 > 1e-7).  On a fixed RK4 step both interpolants are cubic,
+// so the first panel is accepted to roundoff and the result differs from GaussAdjoint by the 2-point rule's error only.
+template <class Mo, int NC, int PF, int MODE, int KMAX = 0, bool GKR = false>
 HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p, const dbl2* __restrict__ knots,
                           const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                           double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP], const CkptSrc* ck = nullptr) {
@@ -611,14 +629,51 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
             Mo::vjp_u(V, lam[c], lo.u, pv, t_lo);
 #pragma unroll
             for (int j = 0; j < N; ++j) d_lo[j] = -(V[j] + ((CC && c == 0) ? gul[j] : 0.0));          // fsallast
+            if constexpr (!GKR) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const double th = 0.5 * (1.0 + (q == 0 ? -xg : xg));
-                double lg[N], W[NP];
-                hermite<N>(th, -dt, lam_hi[c], d_hi[c], lam[c], d_lo, lg);
-                Mo::vjp_p(W, lg, yg[q], pv, t_hi - th * dt);
+                for (int q = 0; q < 2; ++q) {
+                    const double th = 0.5 * (1.0 + (q == 0 ? -xg : xg));
+                    double lg[N], W[NP];
+                    hermite<N>(th, -dt, lam_hi[c], d_hi[c], lam[c], d_lo, lg);
+                    Mo::vjp_p(W, lg, yg[q], pv, t_hi - th * dt);
 #pragma unroll
-                for (int j = 0; j < NP; ++j) mu[c][j] += (0.5 * dt) * W[j];
+                    for (int j = 0; j < NP; ++j) mu[c][j] += (0.5 * dt) * W[j];
+                }
+            } else {
+                // panels in theta (0 at t_hi, 1 at t_lo); time runs backward: int over the panel of -W dt = dt * h_theta * sum w W
+                constexpr int GKD = 12;
+                double pa[GKD + 2], pb[GKD + 2]; int pd[GKD + 2]; int sp = 1;
+                pa[0] = 0.0; pb[0] = 1.0; pd[0] = 0;
+#pragma unroll 1
+                while (sp > 0) {
+                    --sp;
+                    const double a = pa[sp], b = pb[sp]; const int d = pd[sp];
+                    const double cc = 0.5 * (a + b), hh = 0.5 * (b - a);
+                    double IK[NP], IG[NP];
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) { IK[j] = 0.0; IG[j] = 0.0; }
+#pragma unroll 1
+                    for (int jn = 0; jn < 15; ++jn) {
+                        const int q = jn < 7 ? jn : (jn == 7 ? 7 : 14 - jn);
+                        const double th = cc + hh * (jn < 7 ? -GK15::X[q] : (jn == 7 ? 0.0 : GK15::X[q]));
+                        double lg[N], yq[N], W[NP];
+                        hermite<N>(th, -dt, lam_hi[c], d_hi[c], lam[c], d_lo, lg);
+                        hermite<N>(1.0 - th, dt, lo.u, lo.f, hi.u, hi.f, yq);
+                        Mo::vjp_p(W, lg, yq, pv, t_hi - th * dt);
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) { IK[j] += GK15::WK[q] * W[j]; if (q & 1) IG[j] += GK15::WG[q / 2] * W[j]; }
+                    }
+                    double e = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) { IK[j] *= dt * hh; IG[j] *= dt * hh; const double dd = IK[j] - IG[j]; e += dd * dd; }
+                    if (sqrt(e) <= 1e-7 || d >= GKD) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) mu[c][j] += IK[j];
+                    } else {
+                        pa[sp] = cc; pb[sp] = b; pd[sp] = d + 1; ++sp;
+                        pa[sp] = a; pb[sp] = cc; pd[sp] = d + 1; ++sp;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -670,19 +725,6 @@ HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p
     for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
 }
 
-// Gauss-Kronrod (7,15) constants (QUADPACK qk15 / QuadGK order 7)
-struct GK15 {
-    static constexpr double X[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
-                                    0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
-                                    0.586087235467691130294144838258730, 0.405845151377397166906606412076961,
-                                    0.207784955007898467600689403773245, 0.0};
-    static constexpr double WK[8] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
-                                     0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
-                                     0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
-                                     0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
-    static constexpr double WG[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
-                                     0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
-};
 
 // AdjointSensitivityIntegrand (src/quadrature_adjoint.jl:486-502): y = sol(t), lam = adj_sol(t), out = f_p^T lam (+ g_p)
 template <class Mo, int CC = 0>

@@ -107,8 +107,9 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "BacksolveAdjoint is not offered for the PDE family: backward diffusion is ill-posed (src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_GAUSS_KRONROD) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
-    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE || P.field || P.mlp)) {
-        err = "GaussKronrodAdjoint is offered with adaptive Tsit5 on the lane-per-trajectory models (use GaussAdjoint with fixed-step RK4)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (P.field || P.mlp)) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && cfg->stepper == HIPADJ_STEPPER_RK4_FIXED && cfg->checkpointing) {
+        err = "GaussKronrodAdjoint(checkpointing=true) is offered with adaptive Tsit5 only"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {
         // adaptive path: no step grid; arbitrary ascending loss times inside [t0, t1]
@@ -200,7 +201,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (longest > HIPADJ_CKPT_KMAX) { err = "checkpoint interval longer than 16 steps: the re-solve tile would not fit the LDS budget"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     P.nseg = 1;
-    const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
+    const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
     if (seg_alg) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n, np) : cfg->time_segments;
         if ((1 + n) * (n + np) > 64) P.nseg = 1;   // segment lanes would not fit the register file

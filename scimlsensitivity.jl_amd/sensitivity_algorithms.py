@@ -74,7 +74,7 @@ class GaussAdjoint(AbstractAdjointSensitivityAlgorithm):
 @dataclass(frozen=True)
 class GaussKronrodAdjoint(AbstractAdjointSensitivityAlgorithm):
     """GaussKronrodAdjoint(; autojacvec, checkpointing = false) (src/sensitivity_algorithms.jl:612-711): GaussAdjoint with
-    Gauss-Kronrod quadrature per step "to achieve error control".  Adaptive Tsit5 only on the device."""
+    Gauss-Kronrod quadrature per step "to achieve error control"."""
     autojacvec: object = None
     checkpointing: bool = False
     name = "gausskronrod"

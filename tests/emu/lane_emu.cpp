@@ -121,6 +121,27 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         }
         compose<Mo>(P, segbuf, du0, dp_traj);
         break; }
+    case HIPADJ_ALG_GAUSS_KRONROD: {
+        std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
+        for (int seg = 0; seg < P.nseg; ++seg) for (long i = 0; i < P.N; ++i) {
+            double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
+            const int kl = P.seg_bounds[seg], kh = P.seg_bounds[seg + 1];
+            if (seg == P.nseg - 1) {
+                double lam[1][N], mu[1][NP];
+                if (P.ip_ckpt) gauss_lane<Mo, 1, PF, LOSS, KM, true>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
+                else gauss_lane<Mo, 1, PF, LOSS, 0, true>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
+                for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
+            } else {
+                double lam[NC][N], mu[NC][NP];
+                if (P.ip_ckpt) gauss_lane<Mo, NC, PF, LOSS, KM, true>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
+                else gauss_lane<Mo, NC, PF, LOSS, 0, true>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
+                                               for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
+            }
+        }
+        compose<Mo>(P, segbuf, du0, dp_traj);
+        break; }
     case HIPADJ_ALG_QUADRATURE: {
         std::vector<dbl2> adj((size_t)P.S * 2 * N * Np);
         const double atol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, rtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;

@@ -328,7 +328,18 @@ def test_gausskronrod_matches_oracle_and_gauss(model, omodel, u0c, p, ckpt):
     assert rel(res["gausskronrod"][1], res["gauss"][1]) < 1e-7 and rel(res["gausskronrod"][0], res["gauss"][0]) < 1e-12
 
 
-def test_gausskronrod_needs_the_adaptive_stepper():
-    cfg = E.make_config("lv", "gausskronrod", 1, 0.0, 1.0, 0.1, [1.0], loss_kind=1)
+@pytest.mark.parametrize("segments", [1, 4])
+def test_gausskronrod_fixed_step_matches_oracle(segments):
+    """Fixed-step RK4: both interpolants are cubic on a step, the first (7,15) panel is accepted; time segmentation applies."""
+    rng = np.random.default_rng(93)
+    N, T, dt = 3, 2.0, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.linspace(0, T, 5)
+    cfg = E.make_config("lorenz", "gausskronrod", N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, time_segments=segments)
+    du0, dp, _ = E.forward_adjoint(cfg, 3, 3, u0, p)
+    ref = O.Problem("LORENZ", alg="GAUSS_KRONROD", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < 1e-11 and rel(dp, rdp) < 1e-11
+    cfg = E.make_config("lorenz", "gausskronrod", N, 0.0, T, dt, ts, loss_kind=1, checkpointing=True)
     with pytest.raises(RuntimeError, match="rc=-6"):
-        E.forward_adjoint(cfg, 2, 4, np.ones((1, 2)), np.array([1.5, 1.0, 3.0, 1.0]))
+        E.forward_adjoint(cfg, 3, 3, u0, p)
