@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/hipadj.h"
@@ -652,21 +653,27 @@ static int user_prepare(hipadj_handle* h) {
     return HIPADJ_OK;
 }
 
-// launch of a module kernel; every argument is passed with exactly the parameter type of the kernel
-template <class... Args> static int ulaunch(hipadj_handle* h, hipFunction_t fn, dim3 g, dim3 b, Args... args) {
+// launch of a module kernel.  `sig` is the SAME kernel template instantiated for a compiled-in model: it is never called,
+// it only lets the compiler check that the argument list handed to hipModuleLaunchKernel has exactly the kernel's
+// parameter types (a mismatch would otherwise be silent memory corruption on the device).
+template <class... P, class... A> static int ulaunch(void (*sig)(P...), hipadj_handle* h, hipFunction_t fn, dim3 g, dim3 b, A... args) {
+    (void)sig;
+    static_assert(sizeof...(P) == sizeof...(A), "argument count differs from the kernel's parameter list");
+    static_assert((std::is_same<P, A>::value && ...), "argument types differ from the kernel's parameter list");
     void* ptrs[] = {(void*)&args...};
     HIP_TRY(h, hipModuleLaunchKernel(fn, g.x, g.y, g.z, b.x, b.y, b.z, 0, h->stream, ptrs, nullptr));
     return HIPADJ_OK;
 }
+static_assert(std::is_same<decltype(&k_interp<ModelLV, 8, 1>), decltype(&k_gauss<ModelLV, 4, 1, false>)>::value, "k_interp / k_gauss share one launch site");
 
 static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     double* outT = (d_out && h->M > 0) ? h->d_outT : (double*)nullptr;
     if (h->adaptive)
-        TRY(ulaunch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps, (const double*)h->d_save_t, outT,
+        TRY(ulaunch(&k_forward_tsit5<ModelLV>, h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps, (const double*)h->d_save_t, outT,
                     (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag));
     else
-        TRY(ulaunch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
+        TRY(ulaunch(&k_forward<ModelLV>, h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
                     (const int*)h->d_save_of_knot, h->d_yT));
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
     return HIPADJ_OK;
@@ -686,12 +693,12 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     bool composed = false;
     if (h->adaptive) {
-        TRY(ulaunch(h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
+        TRY(ulaunch(&k_adjoint_tsit5<ModelLV, 0, 0, false>, h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
                     (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, h->ntstops,
                     (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag, h->d_arec, h->d_nsteps_adj, h->SmaxA));
         if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-            TRY(ulaunch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
+            TRY(ulaunch(&k_quad_gk_tsit5<ModelLV, 0>, h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
                         (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres));
             hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
             HIP_TRY(h, hipGetLastError());
@@ -701,16 +708,16 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         const dim3 sgrid(waves, (unsigned)h->nseg);
         switch (h->cfg.alg) {
         case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:
-            TRY(ulaunch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
+            TRY(ulaunch(&k_interp<ModelLV, 8, 1>, h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
             composed = true; break;
         case HIPADJ_ALG_BACKSOLVE:
-            TRY(ulaunch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+            TRY(ulaunch(&k_backsolve<ModelLV, 0>, h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
                         (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
             composed = true; break;
         default: {
-            TRY(ulaunch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0));
+            TRY(ulaunch(&k_quad_adj<ModelLV, 8, 1>, h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0));
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-            TRY(ulaunch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const dbl2*)h->d_adj, (const double*)h->d_qa,
+            TRY(ulaunch(&k_quad_gk<ModelLV, 0>, h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const dbl2*)h->d_adj, (const double*)h->d_qa,
                         (const double*)h->d_qb, atol, rtol, h->d_qres));
             hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
             HIP_TRY(h, hipGetLastError());
@@ -719,9 +726,9 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     }
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
     if (composed)
-        TRY(ulaunch(h, h->uf_tail, dim3(cblocks), dim3(FIN), h->g, h->nseg, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
+        TRY(ulaunch(&k_compose_finish<ModelLV>, h, h->uf_tail, dim3(cblocks), dim3(FIN), h->g, h->nseg, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     else
-        TRY(ulaunch(h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)d_du0, (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
+        TRY(ulaunch(&k_finish<2, 4>, h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)d_du0, (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     if (h->cfg.p_shared) {
         hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)(composed ? cblocks : fblocks), h->np, (const double*)h->d_partial, d_dp);
         HIP_TRY(h, hipGetLastError());
