@@ -60,7 +60,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     is specialised on it at handle creation; likewise the continuous cost `g` (HalfSquaredSum() or None).
     alg = RK4(): fixed step `dt` (required).  alg = Tsit5(): adaptive, `abstol`/`reltol` are used for the forward AND
     the reverse solve (src/sensitivity_interface.jl:432), `dt` is the optional initial-step hint, `saveat` may hold
-    arbitrary ascending times, `max_steps` bounds the accepted steps per trajectory (default 2048).
+    arbitrary ascending times, `max_steps` bounds the accepted steps per trajectory (0 = sized automatically by a counting pass of the forward solve).
     `save_idxs` (src/concrete_solve.jl:733-736, 774-824): only those state components appear in `sol.u`; cotangents handed to
     adjoint_sensitivities then have that shape and the other components receive zero (`_out[_save_idxs] .= ...`)."""
     adaptive = isinstance(alg, Tsit5)

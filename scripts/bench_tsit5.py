@@ -15,7 +15,7 @@ for model, u0c, p, T, ts, sig in cases:
         for alg in (sa.InterpolatingAdjoint(), sa.BacksolveAdjoint(), sa.GaussAdjoint()):
             try:
                 sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model, u0[0], (0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=alg,
-                               dgdu_discrete=sa.LsqShift(2.0), abstol=tol[0], reltol=tol[1], max_steps=8192 if tol[0] < 1e-7 else 2048)
+                               dgdu_discrete=sa.LsqShift(2.0), abstol=tol[0], reltol=tol[1], max_steps=0)
                 eng = sol.engine
                 best = 1e9
                 for _ in range(3):
