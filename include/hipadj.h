@@ -105,10 +105,10 @@ typedef struct {
     int32_t time_segments;     /* 0 = automatic; 1 = strictly sequential in time; C > 1 = C time segments per trajectory */
     int32_t cont_cost;         /* hipadj_cont_cost: continuous cost g(u,p,t) added to the loss as int g dt (accumulate_cost!,
                                   src/derivative_wrappers.jl:1411-1442; adjoint_sensitivities(...; g, dgdu_continuous)) */
-    int32_t max_steps;         /* Tsit5: capacity of the per-trajectory dense solution in accepted steps.  0 => automatic: hipadj_forward
-                                  first counts the accepted steps (no records written), sizes the record buffers to the maximum and
-                                  then runs the real pass (one extra forward pass + one host sync; bound 100 000 steps = the
-                                  reference's maxiters) */
+    int32_t max_steps;         /* Tsit5: capacity of the per-trajectory dense solution in accepted steps.  0 => automatic: the buffers
+                                  start at 128 steps; hipadj_forward reads the true step counts back after the pass and, when they
+                                  do not fit, regrows the buffers and repeats the pass (one host sync per forward; bound 100 000
+                                  steps = the reference's maxiters) */
     double abstol, reltol;     /* Tsit5: tolerances of the forward AND reverse solves (src/sensitivity_interface.jl:432 defaults 1e-6 / 1e-3) */
 } hipadj_config;
 

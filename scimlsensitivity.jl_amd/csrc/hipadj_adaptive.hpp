@@ -28,7 +28,8 @@
 //   c_0 = u_start, c_1 = h k_1, c_m = h sum_j r_{j,m-1} k_j.  The 7 stage derivatives are folded into 4 coefficient
 //   vectors when the step is accepted: 35 % fewer bytes per record than (u, k_1..k_7) and a Horner evaluation (4 n FMAs)
 //   per reverse-pass stage instead of the 7-term b_j(theta) sum.
-//   nsteps[i] accepted steps (<= Smax; overflow is reported through flag bit 4 => HIPADJ_ERR_MAXITERS)
+//   nsteps[i] accepted steps (the true count; beyond Smax the records are not written and flag bit 4 => HIPADJ_ERR_MAXITERS,
+//   or, with an auto-sized capacity, the host regrows the buffers and repeats the pass)
 #pragma once
 
 #include "hipadj_lane.hpp"
@@ -37,7 +38,8 @@ namespace hipadj {
 
 struct AdaptGeom {
     long N, Npad;
-    int M, Smax, nck, SmaxI;   // SmaxI: record capacity of ONE checkpoint interval (checkpointing=true for Interpolating/Gauss)
+    int M, Smax, nck, SmaxI;   // Smax: record capacity; SmaxI: capacity of ONE checkpoint interval (checkpointing=true for Interpolating/Gauss)
+    int maxit;                 // bound on the accepted steps of the forward solve (>= Smax; = Smax unless the capacity is auto-sized)
     double t0, t1, dt0, abstol, reltol;
     double loss_shift;
     int loss_kind, no_start, p_shared, cont_cost;
@@ -312,7 +314,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     // next output / checkpoint time, cached in registers (one dependent L2 load per accepted step otherwise)
     const double TINF = 1.7976931348623157e308;
     double ts_next = (outT && ms < g.M) ? save_t[ms] : TINF, tc_next = (ckpt && mc < g.nck) ? ck_t[mc] : TINF;
-    const int na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.Smax, K,
+    const int na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.maxit, K,
         [&](double (&du)[N], const double (&uu)[N], double t) { Mo::f(du, uu, pv, t); },
         [&](double t, double tprev, double (&un)[N], const KStore<N>& KK) -> bool {
             const double h = t - tprev;
@@ -340,7 +342,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             (void)un;
             return false;
         });
-    nsteps[i] = s < g.Smax ? s : g.Smax;
+    nsteps[i] = s;   // the TRUE count, also beyond the capacity: the host sizes the buffers from it (flag bit 4 marks the overflow)
     if (yT) {
 #pragma unroll
         for (int j = 0; j < N; ++j) yT[(long)j * g.Npad + i] = u[j]; }
@@ -466,7 +468,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         icur = j;
     };
     if (CK) resolve(g.nck - 2, 0.0);
-    else if (ALG != 1) cur.init(rec, g.Npad, i, nsteps[i]);
+    else if (ALG != 1) cur.init(rec, g.Npad, i, nsteps[i] < g.Smax ? nsteps[i] : g.Smax);   // clamped: an overflowed forward pass is an error, not a fault
     double z[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) z[j] = 0.0;
@@ -612,7 +614,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             }
         }
     };
-    const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.Smax, K, rhs, cb, pre);
+    const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.maxit, K, rhs, cb, pre);
 #pragma unroll
     for (int j = 0; j < N; ++j) lam_out[j] = z[j];
 #pragma unroll
@@ -666,7 +668,7 @@ HIPADJ_HD void quad_gk_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     double pv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
-    FwdCursor<Mo> cf; cf.init(rec, g.Npad, i, nsteps[i]); cf.seek(0.5 * (a + b));
+    FwdCursor<Mo> cf; cf.init(rec, g.Npad, i, nsteps[i] < g.Smax ? nsteps[i] : g.Smax); cf.seek(0.5 * (a + b));
     AdjCursor<Mo> ca; ca.init(arec, g.Npad, i, nsteps_adj[i], 0.5 * (a + b));
     auto integrand = [&](double t, double (&out)[NP]) {
         double y[N], lam[N];

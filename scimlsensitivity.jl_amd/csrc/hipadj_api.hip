@@ -175,15 +175,16 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         const int RW = 2 + 5 * n;   // record width, hipadj_adaptive.hpp
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
-        h->auto_steps = cfg->max_steps == 0;   // capacity from a counting pass at hipadj_forward (adaptive_autosize); else the caller's bound
-        if (!h->auto_steps && cfg->alg != HIPADJ_ALG_BACKSOLVE) {
-            A(dev_alloc(h, &h->d_rec, (size_t)(P.ip_ckpt ? P.SmaxI : P.Smax) * RW * Np));   // checkpointing=true: one interval per lane
-            h->rec_cap = P.ip_ckpt ? P.SmaxI : P.Smax;
+        h->auto_steps = cfg->max_steps == 0;   // capacity follows the measured step counts (adaptive_autosize); else the caller's bound
+        if (cfg->alg != HIPADJ_ALG_BACKSOLVE) {
+            h->rec_cap = h->auto_steps ? 128 : (P.ip_ckpt ? P.SmaxI : P.Smax);   // checkpointing=true: one interval per lane
+            A(dev_alloc(h, &h->d_rec, (size_t)h->rec_cap * RW * Np));
         }
         A(dev_alloc(h, &h->d_nsteps, (size_t)Np));
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // dense adjoint solution: the reverse solve also stops at every loss time
             A(dev_alloc(h, &h->d_nsteps_adj, (size_t)Np));
-            if (!h->auto_steps) { h->SmaxA = 2 * P.Smax + h->M + 16; A(dev_alloc(h, &h->d_arec, (size_t)h->SmaxA * RW * Np)); }
+            h->SmaxA = 2 * (h->auto_steps ? (int)h->rec_cap : P.Smax) + h->M + 16;
+            A(dev_alloc(h, &h->d_arec, (size_t)h->SmaxA * RW * Np));
         }
         if (P.nck > 0) { A(dev_alloc(h, &h->d_ckpt, (size_t)P.nck * n * Np)); A(dev_alloc(h, &h->d_ck_t, (size_t)P.nck)); }
         if (h->M > 0) A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
@@ -198,7 +199,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             if (!ok2) rc = HIPADJ_ERR_HIP;
         }
         AdaptGeom& ag = h->ag;
-        ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = h->auto_steps ? HIPADJ_AUTO_MAXITERS : P.Smax; ag.nck = P.nck; ag.SmaxI = P.SmaxI; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
+        ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = (h->auto_steps && cfg->alg != HIPADJ_ALG_BACKSOLVE) ? (int)h->rec_cap : P.Smax; ag.maxit = h->auto_steps ? HIPADJ_AUTO_MAXITERS : P.Smax; ag.nck = P.nck; ag.SmaxI = P.SmaxI; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
         ag.abstol = cfg->abstol; ag.reltol = cfg->reltol; ag.loss_shift = cfg->loss_shift; ag.loss_kind = cfg->loss_kind;
         ag.no_start = cfg->no_start; ag.p_shared = cfg->p_shared; ag.cont_cost = cfg->cont_cost;
     } else if (!P.field && !P.mlp) {
@@ -677,15 +678,18 @@ static_assert(std::is_same<decltype(&k_interp<ModelLV, 8, 1>), decltype(&k_gauss
 static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     double* outT = (d_out && h->M > 0) ? h->d_outT : (double*)nullptr;
-    if (h->adaptive && h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE) {
-        h->ag.Smax = HIPADJ_AUTO_MAXITERS;
-        TRY(ulaunch(&k_forward_tsit5<ModelLV>, h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, (double*)nullptr, h->d_nsteps, (const double*)h->d_save_t,
-                    (double*)nullptr, (const double*)h->d_ck_t, (double*)nullptr, (double*)nullptr, h->d_flag));
-        TRY(adaptive_autosize(h));
+    if (h->adaptive) {
+        const bool sized = h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE;
+        if (sized && h->ip_ckpt) h->ag.SmaxI = (int)h->rec_cap;
+        for (int pass = 0; pass < 2; ++pass) {
+            TRY(ulaunch(&k_forward_tsit5<ModelLV>, h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
+                        (const double*)h->d_save_t, outT, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag));
+            if (!sized) break;
+            const int again = adaptive_autosize(h);
+            if (again < 0) return again;
+            if (again == 0) break;
+        }
     }
-    if (h->adaptive)
-        TRY(ulaunch(&k_forward_tsit5<ModelLV>, h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps, (const double*)h->d_save_t, outT,
-                    (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag));
     else
         TRY(ulaunch(&k_forward<ModelLV>, h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
                     (const int*)h->d_save_of_knot, h->d_yT));
@@ -753,49 +757,52 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
 }
 
 // ---- adaptive Tsit5 (hipadj_adaptive.hpp) ------------------------------------------------------------------
-// max_steps == 0 ("auto", the reference's maxiters = 1e5 behaviour): a first forward pass only COUNTS the accepted steps per
-// trajectory (no records written), the host takes the maximum, and the record buffers are (re)allocated to exactly that
-// capacity before the real pass — the step sequences of the two passes are identical, so nothing can overflow.  Lorenz at the
-// default tolerances takes ~100 steps: 140 MB of records for 10^4 trajectories instead of the 2.8 GB a fixed 2048-step bound
-// reserves.  Costs one extra forward pass (no stores) and one host synchronisation per hipadj_forward.
+// max_steps == 0 ("auto", the reference's maxiters = 1e5 behaviour): the record buffers start small and follow the measured
+// step counts.  Every forward pass stores the TRUE number of accepted steps per trajectory (also beyond the capacity, where the
+// records are simply not written); after the pass the host takes the maximum: if it fits, the pass stands (steady state: ONE
+// pass + one host synchronisation); if not, the buffers are regrown to that maximum (+12 %) and the pass is repeated — the step
+// sequence is the same, so the second pass cannot overflow.  Lorenz at the default tolerances takes ~100 steps: 0.2 GB of
+// records for 10^4 trajectories instead of the 2.85 GB a fixed 2048-step bound reserves.
+// Returns 1 when the forward pass has to be repeated, 0 when it stands, a negative status on error.
 static int adaptive_autosize(hipadj_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::vector<int> ns((size_t)h->Npad);
     HIP_TRY(h, hipMemcpy(ns.data(), h->d_nsteps, sizeof(int) * (size_t)h->Npad, hipMemcpyDeviceToHost));
     long mx = 1;
     for (long i = 0; i < h->N; ++i) if (ns[i] > mx) mx = ns[i];
+    if (mx <= h->rec_cap || mx >= HIPADJ_AUTO_MAXITERS) return 0;     // fits (or ran into maxiters: the flag reports it)
     const int RW = 2 + 5 * h->n;
-    if (mx > h->rec_cap) {
-        const long cap = mx + mx / 8 + 8;      // a little head room: a later forward with other u0 / p need not reallocate
-        auto regrow = [&](double** buf, size_t old_count, size_t new_count) -> int {
-            if (*buf) { (void)hipFree(*buf); *buf = nullptr; h->ws_bytes -= (double)(old_count * sizeof(double)); }
-            return dev_alloc(h, buf, new_count);
-        };
-        if (h->cfg.alg != HIPADJ_ALG_BACKSOLVE) TRY(regrow(&h->d_rec, (size_t)h->rec_cap * RW * h->Npad, (size_t)cap * RW * h->Npad));
-        if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
-            const long capA = 2 * cap + h->M + 16;
-            TRY(regrow(&h->d_arec, (size_t)h->SmaxA * RW * h->Npad, (size_t)capA * RW * h->Npad));
-            h->SmaxA = (int)capA;
-        }
-        h->rec_cap = cap;
-        h->st.workspace_bytes = h->ws_bytes;
+    const long cap = mx + mx / 8 + 8;
+    auto regrow = [&](double** buf, size_t old_count, size_t new_count) -> int {
+        if (*buf) { (void)hipFree(*buf); *buf = nullptr; h->ws_bytes -= (double)(old_count * sizeof(double)); }
+        return dev_alloc(h, buf, new_count);
+    };
+    TRY(regrow(&h->d_rec, (size_t)h->rec_cap * RW * h->Npad, (size_t)cap * RW * h->Npad));
+    if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
+        const long capA = 2 * cap + h->M + 16;
+        TRY(regrow(&h->d_arec, (size_t)h->SmaxA * RW * h->Npad, (size_t)capA * RW * h->Npad));
+        h->SmaxA = (int)capA;
     }
-    h->ag.Smax = (int)h->rec_cap; h->ag.SmaxI = (int)h->rec_cap;
-    return HIPADJ_OK;
+    h->rec_cap = cap;
+    h->st.workspace_bytes = h->ws_bytes;
+    h->ag.Smax = (int)cap; h->ag.SmaxI = (int)cap;
+    HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));                  // the overflow mark of the pass that is being repeated
+    return 1;
 }
 
 template <class Mo> static int adaptive_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
-    if (h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE) {
-        h->ag.Smax = HIPADJ_AUTO_MAXITERS;
-        hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, (double*)nullptr, h->d_nsteps,
-                           (const double*)h->d_save_t, (double*)nullptr, (const double*)h->d_ck_t, (double*)nullptr, (double*)nullptr, h->d_flag);
+    const bool sized = h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE;
+    if (sized && h->ip_ckpt) h->ag.SmaxI = (int)h->rec_cap;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
+                           (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
         HIP_TRY(h, hipGetLastError());
-        TRY(adaptive_autosize(h));
+        if (!sized) break;
+        const int again = adaptive_autosize(h);
+        if (again < 0) return again;
+        if (again == 0) break;
     }
-    hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
-                       (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
-    HIP_TRY(h, hipGetLastError());
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
     return HIPADJ_OK;
 }

@@ -170,7 +170,7 @@ template <class Mo, int ALG, int CC, bool CK = false>
 static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
                         double* du0, double* dp, double* out, int* nsteps_out) {
     constexpr int N = Mo::N, NP = Mo::NP, RW = 2 + 5 * N;
-    AdaptGeom g; g.N = P.N; g.Npad = P.Npad; g.M = P.M; g.Smax = P.Smax; g.nck = P.nck; g.t0 = cfg->t0; g.t1 = cfg->t1; g.dt0 = cfg->dt;
+    AdaptGeom g; g.N = P.N; g.Npad = P.Npad; g.M = P.M; g.Smax = P.Smax; g.maxit = P.Smax; g.nck = P.nck; g.t0 = cfg->t0; g.t1 = cfg->t1; g.dt0 = cfg->dt;
     g.abstol = cfg->abstol; g.reltol = cfg->reltol; g.loss_shift = cfg->loss_shift; g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start;
     g.p_shared = cfg->p_shared; g.cont_cost = cfg->cont_cost; g.SmaxI = P.SmaxI;
     const long Np = P.Npad;
