@@ -409,12 +409,19 @@ __global__ void __launch_bounds__(512) k_mlp_wgrad(const double* __restrict__ A,
             const dbl2 v = *reinterpret_cast<const dbl2*>(Bm + (q * RB + row) * (long)B + s_base + 2 * pr);
             *reinterpret_cast<dbl2*>(bt + row * WG_PITCH + 2 * pr) = v;
         }
+        // this wave's A fragments of the slab (4 chunks x 4 samples per lane) are requested BEFORE the barrier, so their global
+        // latency overlaps the LDS staging of the B slab instead of sitting in front of every chunk's MFMAs
+        dbl2 afr[WG_SAMPLES / 16][2];
+#pragma unroll
+        for (int c4 = 0; c4 < WG_SAMPLES / 16; ++c4) {
+            const double* ap = A + (q * RA + 16 * ti + li) * (long)B + s_base + 16 * c4 + 4 * lq;
+            afr[c4][0] = *reinterpret_cast<const dbl2*>(ap); afr[c4][1] = *reinterpret_cast<const dbl2*>(ap + 2);
+        }
         __syncthreads();
 #pragma unroll
         for (int c4 = 0; c4 < WG_SAMPLES / 16; ++c4) {
             const int s0 = 16 * c4 + 4 * lq;
-            const double* ap = A + (q * RA + 16 * ti + li) * (long)B + s_base + s0;
-            const dbl2 a01 = *reinterpret_cast<const dbl2*>(ap), a23 = *reinterpret_cast<const dbl2*>(ap + 2);
+            const dbl2 a01 = afr[c4][0], a23 = afr[c4][1];
 #pragma unroll
             for (int t = 0; t < NTB; ++t) {
                 const double* bp = bt + (16 * t + li) * WG_PITCH + s0;
