@@ -899,3 +899,37 @@ def test_gausskronrod_adjoint(sa, ckpt):
         ref = O.Problem("LORENZ", alg="GAUSS_KRONROD", stepper="RK4", t0=0, t1=T, dt=0.01, save_times=tg, loss="LSQ_SHIFT", loss_shift=2.0)
         rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
         assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomized_configurations_gausskronrod(sa, seed):
+    """The randomized configurations again with GaussKronrodAdjoint (RK4 and Tsit5, compiled-in and runtime models)."""
+    rng = np.random.default_rng(5000 + seed)
+    c = _random_case(rng, sa)
+    c["alg"], c["oalg"] = "gausskronrod", "GAUSS_KRONROD"
+    if c["stepper"] == "rk4" or c["model"] == "lorenz":
+        c["ckpt"] = c["ckpt"] and c["stepper"] == "tsit5"
+    if c["cost"] == 2:
+        c["cost"] = 1
+    n, npar = len(c["u0c"]), len(c["p"])
+    f = c["model"]
+    if c["user"]:
+        m = UM.ROBER if c["model"] == "rober" else UM.ring(c["dims"][0])
+        f = _device_function(sa, c["model"] + "_fuzz", m)
+    u0 = np.asarray(c["u0c"]) + 0.05 * rng.standard_normal((c["N"], n))
+    p = np.asarray(c["p"]) if c["p_shared"] else np.asarray(c["p"]) * (1 + 0.03 * rng.standard_normal((c["N"], npar)))
+    g = [None, sa.HalfSquaredSum()][c["cost"]]
+    delta = None if c["loss_lsq"] else rng.standard_normal((c["N"], len(c["ts"]), n))
+    if c["stepper"] == "rk4":
+        salg, kw, okw = sa.RK4(), dict(dt=c["dt"], time_segments=c["segs"]), dict(stepper="RK4", dt=c["dt"])
+    else:
+        salg, kw, okw = sa.Tsit5(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
+    prob = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, c["T"]), p if c["p_shared"] else p[0], c["dims"]), u0, p)
+    sol = sa.solve(prob, salg, saveat=c["ts"], sensealg=sa.GaussKronrodAdjoint(checkpointing=c["ckpt"]),
+                   dgdu_discrete=(sa.LsqShift(1.5) if c["loss_lsq"] else None), g=g, **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=c["ts"], dgdu_discrete=(sa.LsqShift(1.5) if c["loss_lsq"] else delta), g=g)
+    ref = O.Problem(c["omodel"], alg="GAUSS_KRONROD", t0=0.0, t1=c["T"], save_times=c["ts"], loss=("LSQ_SHIFT" if c["loss_lsq"] else "COTANGENT"),
+                    loss_shift=1.5, checkpointing=c["ckpt"], dims=c["dims"], cont_cost=c["cost"], **okw)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL, {k: v for k, v in c.items() if k not in ("u0c", "p", "ts")}
+    sol.engine.close()
