@@ -639,21 +639,21 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 template <int NP, class F>
 HIPADJ_HD double gk15_eval_f(F&& integrand, double a, double b, double (&I)[NP]) {
     const double c = 0.5 * (a + b), h = 0.5 * (b - a);
-    double Ig[NP], f1[NP], f2[NP];
+    double Ig[NP], f1[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) { I[j] = 0.0; Ig[j] = 0.0; }
+    // the 15 nodes in ascending time: the two cursors behind `integrand` then only walk forward through their records
+    // (the symmetric-pair order of QUADPACK would make them jump across the panel 14 times)
 #pragma unroll 1
-    for (int q = 0; q < 7; ++q) {
-        integrand(c - h * GK15::X[q], f1);
-        integrand(c + h * GK15::X[q], f2);
+    for (int jn = 0; jn < 15; ++jn) {
+        const int q = jn < 7 ? jn : (jn == 7 ? 7 : 14 - jn);
+        integrand(c + h * (jn < 7 ? -GK15::X[q] : (jn == 7 ? 0.0 : GK15::X[q])), f1);
 #pragma unroll
-        for (int j = 0; j < NP; ++j) { const double s = f1[j] + f2[j]; I[j] += GK15::WK[q] * s; if (q & 1) Ig[j] += GK15::WG[q / 2] * s; }
+        for (int j = 0; j < NP; ++j) { I[j] += GK15::WK[q] * f1[j]; if (q & 1) Ig[j] += GK15::WG[q / 2] * f1[j]; }
     }
-    integrand(c, f1);
     double e = 0.0;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        I[j] += GK15::WK[7] * f1[j]; Ig[j] += GK15::WG[3] * f1[j];
         I[j] *= h; Ig[j] *= h;
         const double d = I[j] - Ig[j]; e += d * d;
     }
