@@ -123,7 +123,7 @@ extern "C" int hipadj_model_set_cost_function(int32_t model_id, const char* g_bo
 
 extern "C" int hipadj_model_check(int32_t model_id) {
     std::vector<char> code; std::map<std::string, std::string> low;
-    return user_compile(model_id, {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 2, 7>" : "hipadj::k_interp<hipadj::UserModel, 2, 1>"},
+    return user_compile(model_id, {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 1, 7>" : "hipadj::k_interp<hipadj::UserModel, 1, 1>"},
                         code, low, g_create_error);
 }
 
@@ -625,10 +625,13 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     const int n = h->n, np = h->np;
     const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);
     const int cc = mode >> 1;
-    const int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : (n <= 5 ? 4 : 2), PFG = n <= 3 ? 4 : 2;
+    const int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : 1, PFG = n <= 3 ? 4 : 1;   // more than three states: the plain rolled sweep (reverse_sweep, PF == 1)
     auto I = [](int v) { return std::to_string(v); };
     UserKernels k;
-    const std::string finish = "hipadj::k_finish<" + I(n) + ", " + I(np) + ">", compose = "hipadj::k_compose_finish<" + U + ">";
+    const bool seg = (1 + n) * (n + np) <= 64;          // same rule as the planner: wider models stay sequential in time ...
+    const std::string SG = seg ? ", true>" : ", false>";  // ... and compile only the one-column path (k_interp SEG)
+    const std::string finish = "hipadj::k_finish<" + I(n) + ", " + I(np) + ">";
+    const std::string compose = seg ? "hipadj::k_compose_finish<" + U + ">" : "hipadj::k_finish_map<" + I(n) + ", " + I(np) + ">";
     if (h->adaptive) {
         k.forward = "hipadj::k_forward_tsit5<" + U + ">";
         k.main_k = "hipadj::k_adjoint_tsit5<" + U + ", " + I(h->cfg.alg) + ", " + I(cc) + (h->ip_ckpt ? ", true>" : ", false>");
@@ -638,10 +641,10 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     }
     k.forward = "hipadj::k_forward<" + U + ">";
     switch (h->cfg.alg) {
-    case HIPADJ_ALG_INTERPOLATING: k.main_k = "hipadj::k_interp<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.tail = compose; break;
-    case HIPADJ_ALG_BACKSOLVE: k.main_k = "hipadj::k_backsolve<" + U + ", " + I(cc) + ">"; k.tail = compose; break;
-    case HIPADJ_ALG_GAUSS: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ", false>"; k.tail = compose; break;
-    case HIPADJ_ALG_GAUSS_KRONROD: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ", true>"; k.tail = compose; break;
+    case HIPADJ_ALG_INTERPOLATING: k.main_k = "hipadj::k_interp<" + U + ", " + I(PF) + ", " + I(mode) + SG; k.tail = compose; break;
+    case HIPADJ_ALG_BACKSOLVE: k.main_k = "hipadj::k_backsolve<" + U + ", " + I(cc) + SG; k.tail = compose; break;
+    case HIPADJ_ALG_GAUSS: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ", false" + SG; k.tail = compose; break;
+    case HIPADJ_ALG_GAUSS_KRONROD: k.main_k = "hipadj::k_gauss<" + U + ", " + I(PFG) + ", " + I(mode) + ", true" + SG; k.tail = compose; break;
     default: k.main_k = "hipadj::k_quad_adj<" + U + ", " + I(PF) + ", " + I(mode) + ">"; k.gk = "hipadj::k_quad_gk<" + U + ", " + I(cc) + ">"; k.tail = finish; break;
     }
     return k;
@@ -743,12 +746,15 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         }
     }
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-    if (composed)
+    const bool seg_kernels = (1 + h->n) * (h->n + h->np) <= 64;
+    if (composed && seg_kernels)
         TRY(ulaunch(&k_compose_finish<ModelLV>, h, h->uf_tail, dim3(cblocks), dim3(FIN), h->g, h->nseg, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
+    else if (composed)
+        TRY(ulaunch(&k_finish_map<2, 4>, h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     else
         TRY(ulaunch(&k_finish<2, 4>, h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)d_du0, (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     if (h->cfg.p_shared) {
-        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)(composed ? cblocks : fblocks), h->np, (const double*)h->d_partial, d_dp);
+        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)((composed && seg_kernels) ? cblocks : fblocks), h->np, (const double*)h->d_partial, d_dp);
         HIP_TRY(h, hipGetLastError());
     }
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));

@@ -35,7 +35,10 @@ __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restri
 }
 
 // segbuf layout: [segment][column][N+NP][Npad]; the top segment only fills column 0.
-template <class Mo, int PF, int LOSS>
+// SEG = false (runtime models whose (1 + n)(n + np) segment columns do not fit the register file: the planner keeps them
+// sequential in time) compiles ONLY the one-column path: the unused (1 + n)-column code would otherwise set the kernel's
+// register allocation (n = 7: 256 VGPRs + 256 AGPRs + 2.7 KB scratch, and a wrong result on the device).
+template <class Mo, int PF, int LOSS, bool SEG = true>
 __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const double* __restrict__ p,
                                                  const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                                                  const int* __restrict__ save_of_knot, double* __restrict__ segbuf) {
@@ -45,14 +48,14 @@ __global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const doubl
     if (i >= g.N) return;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
     double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
-    if (seg == sp.nseg - 1) {
+    if (!SEG || seg == sp.nseg - 1) {
         double lam[1][N], mu[1][NP];
         interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
 #pragma unroll
         for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
 #pragma unroll
         for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
-    } else {
+    } else if constexpr (SEG) {
         double lam[NC][N], mu[NC][NP];
         interp_lane<Mo, NC, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
 #pragma unroll
@@ -309,6 +312,28 @@ __global__ void __launch_bounds__(FIN) k_finish(long Ntraj, long Npad, const dou
     if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
 }
 
+// finishing stage for the one-segment (SEG = false) sweeps: the top map's column 0 of segbuf IS (lam(t0), mu(t0))
+template <int N, int NP>
+__global__ void __launch_bounds__(FIN) k_finish_map(long Ntraj, long Npad, const double* __restrict__ segbuf, double* __restrict__ du0,
+                                                    double* __restrict__ dp_rows, double* __restrict__ partial, int* __restrict__ flag,
+                                                    unsigned* __restrict__ ticket_ctr, double* __restrict__ dp_sum) {
+    const long i = (long)blockIdx.x * FIN + threadIdx.x;
+    const bool valid = i < Ntraj;
+    double mu[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[j] = 0.0;
+    if (valid) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { const double v = segbuf[(long)j * Npad + i]; du0[i * N + j] = v; bad |= !finite_d(v); }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { mu[j] = segbuf[(long)(N + j) * Npad + i]; bad |= !finite_d(mu[j]); if (dp_rows) dp_rows[i * NP + j] = mu[j]; }
+        if (bad) atomicOr(flag, 1);
+    }
+    block_partial<NP>(mu, valid, partial);
+    if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
+}
+
 // dp[j] = sum over workgroup partials in block order (one workgroup per parameter)
 __global__ void __launch_bounds__(FIN) k_reduce_final(int nblocks, int np, const double* __restrict__ partial, double* __restrict__ dp) {
     __shared__ double sh[FIN];
@@ -322,7 +347,7 @@ __global__ void __launch_bounds__(FIN) k_reduce_final(int nblocks, int np, const
 }
 
 // BacksolveAdjoint, segmented at checkpoint knots; writes the segment maps like k_interp
-template <class Mo, int CC>
+template <class Mo, int CC, bool SEG = true>
 __global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ yT,
                                                     const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
                                                     const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
@@ -333,14 +358,14 @@ __global__ void __launch_bounds__(WAVE) k_backsolve(Geom g, SegPlan sp, const do
     if (i >= g.N) return;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
     double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
-    if (seg == sp.nseg - 1) {
+    if (!SEG || seg == sp.nseg - 1) {
         double lam[1][N], mu[1][NP];
         backsolve_lane<Mo, 1, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
 #pragma unroll
         for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
 #pragma unroll
         for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
-    } else {
+    } else if constexpr (SEG) {
         double lam[NC][N], mu[NC][NP];
         backsolve_lane<Mo, NC, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
 #pragma unroll
@@ -366,7 +391,7 @@ __device__ __forceinline__ void store_segment_map(double* __restrict__ dst, long
 }
 
 // GaussAdjoint, time-segmented like k_interp (segment maps -> k_compose_finish)
-template <class Mo, int PF, int LOSS, bool GKR = false>
+template <class Mo, int PF, int LOSS, bool GKR = false, bool SEG = true>
 __global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                                 const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
                                                 double* __restrict__ segbuf) {
@@ -376,11 +401,11 @@ __global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double
     if (i >= g.N) return;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
     double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
-    if (seg == sp.nseg - 1) {
+    if (!SEG || seg == sp.nseg - 1) {
         double lam[1][N], mu[1][NP];
         gauss_lane<Mo, 1, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
         store_segment_map<Mo, 1>(dst, g.Npad, lam, mu);
-    } else {
+    } else if constexpr (SEG) {
         double lam[NC][N], mu[NC][NP];
         gauss_lane<Mo, NC, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
         store_segment_map<Mo, NC>(dst, g.Npad, lam, mu);

@@ -277,6 +277,27 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
         }
         init(s >= 0, gl);
     }
+    if constexpr (PF == 1) {
+        // PF = 1: plain rolled loop, one knot in flight.  Used for runtime-compiled models with more than three states: there
+        // the unrolled prefetch blocks below multiply an already large step body (transcendentals per component per stage)
+        // into kernels of 256 VGPRs + 256 AGPRs + KBs of scratch, which hipcc's spilling does not survive (wrong results on
+        // the device for n = 5 and 7 although the same source is exact on the host).  Latency-bound, small, correct.
+#pragma unroll 1
+        for (int k = k_hi - 1; k >= k_lo; --k) {
+            Knot<Mo> lo; load_knot<Mo>(knots, g.Npad, k, i, lo, g.kmask);
+            const int s = save_of_knot[k];
+            const bool jump = s >= 0 && !(g.no_start && s == 0);
+            double gl[N];
+            if (LOSS == 0) load_cot<Mo, LOSS>(g, i, s, cotT, gl);
+            else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) gl[j] = lo.u[j] - g.loss_shift;
+            }
+            step(carry, lo, k, jump, gl);
+            carry = lo;
+        }
+        return;
+    }
     Knot<Mo> ring[PF];
     double cot[PF][N];
 #pragma unroll

@@ -43,7 +43,11 @@ static void compose(const Plan& P, const std::vector<double>& segbuf, double* du
 template <class Mo, int LOSS>   // LOSS = MODE = discrete-loss kind | (continuous cost << 1)
 static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
                double* du0, double* dp, double* out) {
-    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, PF = 8;
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+#ifndef EMU_PF
+#define EMU_PF 8
+#endif
+    constexpr int PF = EMU_PF;   // -DEMU_PF=2|4 exercises the shallow prefetch rings the runtime-compiled models use
     Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1;
     const long Np = P.Npad;

@@ -343,3 +343,31 @@ def test_gausskronrod_fixed_step_matches_oracle(segments):
     cfg = E.make_config("lorenz", "gausskronrod", N, 0.0, T, dt, ts, loss_kind=1, checkpointing=True)
     with pytest.raises(RuntimeError, match="rc=-6"):
         E.forward_adjoint(cfg, 3, 3, u0, p)
+
+
+def test_rolled_sweep_variant_pf1(tmp_path):
+    """reverse_sweep with PF == 1 (the plain rolled loop that runtime-compiled models with more than three states use)
+    against the oracle, via a -DEMU_PF=1 build of the emulator."""
+    import ctypes as C, subprocess
+    lib = str(tmp_path / "liblane_emu_pf1.so")
+    subprocess.check_call(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DEMU_PF=1", "-o", lib, E._SRC])
+    L = C.CDLL(lib); L.emu_last_error.restype = C.c_char_p
+    saved, E._lib = E._lib, L
+    try:
+        rng = np.random.default_rng(1)
+        N = 4
+        u0 = np.array([1.0, 0.0, 0.0]) + 0.05 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+        for alg in ("gauss", "interpolating", "quadrature", "gausskronrod"):
+            for lk in (0, 1):
+                for ts in ([1.4], [0.0, 0.7, 2.0], []):
+                    for segs in (1, 3):
+                        ts_ = np.array(ts); delta = rng.standard_normal((N, len(ts_), 3))
+                        cot = delta if (len(ts_) and lk == 0) else None
+                        cfg = E.make_config("lorenz", alg, N, 0.0, 2.0, 0.05, ts_, loss_kind=lk, loss_shift=1.0, time_segments=segs, no_start=True)
+                        du0, dp, _ = E.forward_adjoint(cfg, 3, 3, u0, p, cot)
+                        ref = O.Problem("LORENZ", alg.upper().replace("GAUSSKRONROD", "GAUSS_KRONROD"), "RK4", 0.0, 2.0, 0.05, save_times=ts_,
+                                        loss="COTANGENT" if lk == 0 else "LSQ_SHIFT", loss_shift=1.0, no_start=True)
+                        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, cot)
+                        assert rel(du0, rdu0) < 1e-11 and rel(dp, rdp) < 1e-11, (alg, lk, ts, segs)
+    finally:
+        E._lib = saved

@@ -691,6 +691,7 @@ def _random_case(rng, sa):
     ckpt = bool(rng.random() < 0.5) and alg != "quadrature"
     if alg == "backsolve" and not ckpt and model == "lorenz":
         ckpt = True                               # Backsolve without checkpoints is unstable on Lorenz (src/sensitivity_algorithms.jl:168-198)
+    lorenz_backsolve = alg == "backsolve" and model == "lorenz"
     user = model == "rober" or model.startswith("ring")
     if user and ckpt and alg in ("interpolating", "gauss") and stepper == "rk4":
         ckpt = False                              # not offered for runtime models on the fixed-step path
@@ -701,6 +702,8 @@ def _random_case(rng, sa):
     T = float(rng.choice([0.5, 1.0, 2.0]))
     if stepper == "rk4":
         dt = float(rng.choice([0.01, 0.02, 0.05]))
+        if model == "lorenz" and dt > 0.02:
+            dt = 0.02                             # RK4 at dt = 0.05 is not a usable discretisation of Lorenz (Backsolve diverges)
         S = int(round(T / dt))
         ks = np.unique(rng.integers(0, S + 1, int(rng.integers(0, 7))))
         if ckpt and alg in ("interpolating", "gauss"):
@@ -711,10 +714,13 @@ def _random_case(rng, sa):
         ts = np.unique(np.round(rng.uniform(0, T, int(rng.integers(0, 6))), 3))
         if rng.random() < 0.5:
             ts = np.unique(np.concatenate([ts, [T]]))
+    if lorenz_backsolve and len(ts) < 3:          # too few checkpoints to keep the backward y of Lorenz bounded
+        alg, oalg, ckpt = "interpolating", "INTERPOLATING", False
     loss_lsq = bool(rng.random() < 0.5) or len(ts) == 0
     segs = int(rng.choice([0, 1, 3]))
     return dict(model=model, omodel=omodel, u0c=u0c, p=p, dims=dims, alg=alg, oalg=oalg, stepper=stepper, ckpt=ckpt, cost=cost, N=N, T=T, dt=dt,
-                ts=ts, loss_lsq=loss_lsq, segs=segs, user=user, p_shared=bool(rng.random() < 0.5))
+                ts=ts, loss_lsq=loss_lsq, segs=segs, user=user, p_shared=bool(rng.random() < 0.5), no_start=bool(rng.random() < 0.3),
+                auto_vjp=bool(rng.random() < 0.5))
 
 
 @pytest.mark.parametrize("seed", range(120))
@@ -726,7 +732,13 @@ def test_randomized_configurations_match_oracle(sa, seed):
     f = c["model"]
     if c["user"]:
         m = UM.ROBER if c["model"] == "rober" else UM.ring(c["dims"][0])
-        f = _device_function(sa, c["model"] + "_fuzz", m)
+        if c["auto_vjp"]:                        # only f registered: VJPs by dual numbers
+            key = c["model"] + "_fuzz_auto"
+            if key not in _registered:
+                _registered[key] = sa.DeviceFunction(key, m["n"], m["np"], m["f"])
+            f = _registered[key]
+        else:
+            f = _device_function(sa, c["model"] + "_fuzz", m)
     u0 = np.asarray(c["u0c"]) + 0.05 * rng.standard_normal((c["N"], n))
     p = np.asarray(c["p"]) if c["p_shared"] else np.asarray(c["p"]) * (1 + 0.03 * rng.standard_normal((c["N"], npar)))
     sens = {"interpolating": sa.InterpolatingAdjoint(checkpointing=c["ckpt"]), "backsolve": sa.BacksolveAdjoint(checkpointing=c["ckpt"]),
@@ -738,10 +750,11 @@ def test_randomized_configurations_match_oracle(sa, seed):
     else:
         salg, kw, okw = sa.Tsit5(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
     prob = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, c["T"]), p if c["p_shared"] else p[0], c["dims"]), u0, p)
-    sol = sa.solve(prob, salg, saveat=c["ts"], sensealg=sens, dgdu_discrete=(sa.LsqShift(1.5) if c["loss_lsq"] else None), g=g, **kw)
+    sol = sa.solve(prob, salg, saveat=c["ts"], sensealg=sens, dgdu_discrete=(sa.LsqShift(1.5) if c["loss_lsq"] else None), g=g, no_start=c["no_start"], **kw)
     du0, dp = sa.adjoint_sensitivities(sol, salg, t=c["ts"], dgdu_discrete=(sa.LsqShift(1.5) if c["loss_lsq"] else delta), g=g)
     ref = O.Problem(c["omodel"], alg=c["oalg"], t0=0.0, t1=c["T"], save_times=c["ts"], loss=("LSQ_SHIFT" if c["loss_lsq"] else "COTANGENT"),
-                    loss_shift=1.5, checkpointing=c["ckpt"], dims=c["dims"], cont_cost=c["cost"], quad_abstol=1e-10, quad_reltol=1e-10, **okw)
+                    loss_shift=1.5, checkpointing=c["ckpt"], dims=c["dims"], cont_cost=c["cost"], quad_abstol=1e-10, quad_reltol=1e-10,
+                    no_start=c["no_start"], **okw)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
     msg = {k: (v if not isinstance(v, (list, np.ndarray)) else np.asarray(v).round(3).tolist()) for k, v in c.items() if k not in ("u0c", "p")}
     if len(c["ts"]):
