@@ -160,6 +160,10 @@ int hipadj_model_set_cost_function(int32_t model_id, const char *g_body);
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
  * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
 int hipadj_model_check(int32_t model_id);
+/* Compiles every kernel a handle of configuration *cfg would launch (forward, reverse, quadrature, tail) — what hipadj_create
+ * does lazily for a runtime-registered model — without a device; HIPADJ_OK at once for built-in models.  Lets a caller warm the
+ * process-wide code cache and surface compile errors of a particular sensealg / stepper combination ahead of time. */
+int hipadj_model_check_config(const hipadj_config *cfg);
 
 /* Replaces the per-call setup of ODEAdjointProblem + adjointdiffcache (src/interpolating_adjoint.jl:307-451,
  * src/backsolve_adjoint.jl:123-272, src/adjoint_common.jl:42-469): validates the configuration, allocates the

@@ -18,7 +18,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_model_check", "hipadj_model_set_cost", "hipadj_model_set_cost_function",
+    "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_model_set_cost", "hipadj_model_set_cost_function",
 )
 
 
@@ -93,6 +93,7 @@ def load():
     L.hipadj_get_stats.argtypes = [vp, C.POINTER(HipadjStats)]
     L.hipadj_model_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
     L.hipadj_model_check.argtypes = [C.c_int32]
+    L.hipadj_model_check_config.argtypes = [C.POINTER(HipadjConfig)]
     L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_model_set_cost_function.argtypes = [C.c_int32, C.c_char_p]
     _lib = L

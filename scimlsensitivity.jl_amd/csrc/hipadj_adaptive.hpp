@@ -90,6 +90,7 @@ HIPADJ_HD bool time_hits(double t, double target) { return habs(t - target) <= 1
 // Stage storage of one lane: rows 0..6 = k_1..k_7 of the current step, row 7 = the step's start value.
 // Device: base = LDS array + lane, stride = 64.  Host emulation: a local array, stride 1.
 constexpr int KS_ROWS = 8, KS_UPREV = 7;
+constexpr int TS5_WIDE = 9;    // widest state vector whose six stage rows are summed in one batch (tsit5_integrate)
 template <int NZ> struct KStore {
     double* base; int stride;
     HIPADJ_HD double get(int row, int i) const { return base[(row * NZ + i) * stride]; }
@@ -216,7 +217,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
         for (int s = 1; s < 7; ++s) {
 #pragma unroll
             for (int i = 0; i < NZ; ++i) w[i] = 0.0;
-            {
+            if constexpr (NZ <= TS5_WIDE) {
                 double as[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) as[j] = TS5::a(s, j);
@@ -224,6 +225,16 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
                 for (int j = 0; j < 6; ++j)
 #pragma unroll
                     for (int i = 0; i < NZ; ++i) w[i] += as[j] * K.get(j, i);
+            } else {
+                // wide state vectors (runtime models with n + np + n > TS5_WIDE): one stage row at a time.  Six rows in flight
+                // are 12 NZ VGPRs on top of u, w and the rhs temporaries; past 256 the allocator spills inside this divergent
+                // loop nest, and spilled kernels have produced wrong lanes on gfx950.
+#pragma unroll 1
+                for (int j = 0; j < 6; ++j) {
+                    const double asj = TS5::a(s, j);
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) w[i] += asj * K.get(j, i);
+                }
             }
 #pragma unroll
             for (int i = 0; i < NZ; ++i) w[i] = K.get(KS_UPREV, i) + h * w[i];
@@ -238,11 +249,20 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             double err[NZ];
 #pragma unroll
             for (int i = 0; i < NZ; ++i) err[i] = 0.0;
+            if constexpr (NZ <= TS5_WIDE) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const double btj = TS5::bt(j);
+                for (int j = 0; j < 7; ++j) {
+                    const double btj = TS5::bt(j);
 #pragma unroll
-                for (int i = 0; i < NZ; ++i) err[i] += btj * K.get(j, i);
+                    for (int i = 0; i < NZ; ++i) err[i] += btj * K.get(j, i);
+                }
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < 7; ++j) {
+                    const double btj = TS5::bt(j);
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) err[i] += btj * K.get(j, i);
+                }
             }
 #pragma unroll
             for (int i = 0; i < NZ; ++i) {
@@ -273,7 +293,11 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             }
             if (naccept > max_steps) return -1;
         } else {
-            dt = h / hmin2(5.0, q11 / 0.9);   // u still holds the step's start value
+            dt = h / hmin2(5.0, q11 / 0.9);
+            // the step's start value comes back from its LDS row: with both outcomes of the step test overwriting u, the register
+            // copy of u is dead across the stage loop (2 NZ VGPRs less at the point of highest pressure; same values, bit for bit)
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) u[i] = K.get(KS_UPREV, i);
             if (!(EEst < 1e300)) {            // overflowed stage derivatives must not meet the zero padding of the tableau rows
 #pragma unroll 1
                 for (int j = 1; j < 7; ++j)

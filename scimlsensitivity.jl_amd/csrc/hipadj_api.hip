@@ -127,6 +127,16 @@ extern "C" int hipadj_model_check(int32_t model_id) {
                         code, low, g_create_error);
 }
 
+// Every kernel a handle of this configuration would launch, compiled now (no device needed): the ahead-of-time form of what
+// hipadj_create does lazily.  Built-in models have nothing to compile.
+struct UserKernels;
+static int user_compile_config(const hipadj_config* cfg, std::string& err);
+extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
+    if (!cfg) { g_create_error = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->model < HIPADJ_MODEL_USER_BASE) return HIPADJ_OK;
+    return user_compile_config(cfg, g_create_error);
+}
+
 #define TRY(expr) do { int _rc = (expr); if (_rc != HIPADJ_OK) return _rc; } while (0)
 
 static void free_all(hipadj_handle* h) {
@@ -663,6 +673,19 @@ static int user_prepare(hipadj_handle* h) {
     HIP_TRY(h, hipModuleGetFunction(&h->uf_tail, h->umod, low[k.tail].c_str()));
     if (!k.gk.empty()) HIP_TRY(h, hipModuleGetFunction(&h->uf_gk, h->umod, low[k.gk].c_str()));
     return HIPADJ_OK;
+}
+
+static int user_compile_config(const hipadj_config* cfg, std::string& err) {
+    hipadj_handle h;
+    h.cfg = *cfg; h.cfg.save_times = nullptr;
+    Plan P;
+    { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
+    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt;
+    const UserKernels k = user_kernel_names(&h);
+    std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
+    if (!k.gk.empty()) exprs.push_back(k.gk);
+    std::vector<char> code; std::map<std::string, std::string> low;
+    return user_compile(cfg->model, exprs, code, low, err);
 }
 
 // launch of a module kernel.  `sig` is the SAME kernel template instantiated for a compiled-in model: it is never called,

@@ -204,6 +204,11 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         A.DestroyProgram(&prog);
         return HIPADJ_ERR_INVALID_ARG;
     }
+    if (std::getenv("HIPADJ_RTC_SHOWLOG")) {   // debugging hook: the compiler's log of a successful build (remarks)
+        size_t ls = 0; A.GetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0'); if (ls) A.GetProgramLog(prog, &log[0]);
+        std::fprintf(stderr, "%s\n", log.c_str());
+    }
     lowered.clear();
     for (const auto& e : exprs) {
         const char* low = nullptr;
@@ -213,6 +218,11 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
     size_t cs = 0; A.GetCodeSize(prog, &cs);
     code.assign(cs, 0); A.GetCode(prog, code.data());
     A.DestroyProgram(&prog);
+    if (const char* d = std::getenv("HIPADJ_RTC_DUMP")) {   // debugging hook: keep the code object (llvm-objdump -d, llvm-readelf --notes)
+        static int serial = 0;
+        const std::string fn = std::string(d) + "/" + src.name + "_" + std::to_string(serial++) + ".hsaco";
+        if (FILE* fp = std::fopen(fn.c_str(), "wb")) { std::fwrite(code.data(), 1, code.size(), fp); std::fclose(fp); }
+    }
     {
         std::lock_guard<std::mutex> lk(R.mu);
         R.code_cache[key] = code; R.lowered_cache[key] = lowered;

@@ -651,6 +651,42 @@ def test_runtime_model_with_attached_cost_equals_registered_cost(sa, alg):
     assert rel(res[1][0], res[0][0]) < 1e-12 and rel(res[1][1], res[0][1]) < 1e-12
 
 
+@pytest.mark.parametrize("n", [3, 4, 6])
+@pytest.mark.parametrize("alg,oalg", [("backsolve", "BACKSOLVE"), ("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+def test_runtime_model_tsit5_without_loss_times(sa, n, alg, oalg):
+    """No loss times, no checkpoints => no tstops at all on the reverse solve.  (Regression: the ROCm 7.2 compiler placed the
+    register-spill copies of k_adjoint_tsit5 inside the tstop-advance region, ahead of its exec restore — with an empty tstop
+    list the copies never ran and the loss-callback index was garbage: a GPU memory fault found by the randomized test,
+    seed 10064.  tests/tools/isa_lint.py checks the code objects for that placement.)  Without a cost the gradient is
+    exactly zero; with g = (sum u)^2/2 attached to the runtime model it must match the oracle's cont_cost = 1."""
+    m = UM.ring(n)
+    N, T = 53, 0.5
+    for k, pvec in enumerate((np.linspace(0.5, 1.1, n + 1), np.array([0.7, 0.9, 0.5, 1.1, 0.6, 0.8, 1.0])[: n + 1])):
+        rng = np.random.default_rng(100 + k)
+        u0 = 1.0 + 0.05 * rng.standard_normal((N, n))
+        sens = {"backsolve": sa.BacksolveAdjoint, "interpolating": sa.InterpolatingAdjoint, "gauss": sa.GaussAdjoint}[alg](checkpointing=False)
+        f0 = _device_function(sa, f"ring{n}_nolost", m)
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f0, u0[0], (0.0, T), pvec), u0), sa.Tsit5(), saveat=[], sensealg=sens,
+                       dgdu_discrete=sa.LsqShift(1.5), abstol=1e-9, reltol=1e-9)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=[], dgdu_discrete=sa.LsqShift(1.5))
+        assert np.all(du0 == 0.0) and np.all(dp == 0.0)
+        sol.engine.close()
+        if alg == "gauss":
+            continue                                # Gauss takes no cost with a parameter gradient (a model cost may have one)
+        key = f"ring{n}_nolost_cost"
+        if key not in _registered:
+            _registered[key] = sa.DeviceFunction(key, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"]).set_cost(
+                g="real s = 0.0; for (int i = 0; i < N; ++i) s += u[i]; g = 0.5*s*s;")
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(_registered[key], u0[0], (0.0, T), pvec), u0), sa.Tsit5(), saveat=[], sensealg=sens,
+                       g=sa.ModelCost(), abstol=1e-9, reltol=1e-9)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), g=sa.ModelCost())
+        ref = O.Problem("RING", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=[], loss="LSQ_SHIFT",
+                        loss_shift=1.5, checkpointing=False, dims=(n, 0, 0, 0), cont_cost=1)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, pvec)
+        assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+        sol.engine.close()
+
+
 def test_gauss_with_parameter_dependent_cost_is_rejected(sa):
     u0 = np.ones((4, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
     with pytest.raises(sa.HipadjError) as e:

@@ -1,0 +1,38 @@
+"""CPU check of the shipped gfx950 code for the spill-placement miscompile described in tests/tools/isa_lint.py: the
+built-in library, and the runtime-compiled kernels of the configuration that exposed it (hiprtc needs no device)."""
+import ctypes as C
+import glob
+import os
+import sys
+
+import pytest
+
+import emu as E
+import user_models as UM
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+import isa_lint  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(isa_lint.OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
+
+
+def test_builtin_library_has_no_spill_copies_ahead_of_exec_restores(sa):
+    sa.load_library()
+    assert isa_lint.lint(os.path.join(ROOT, "scimlsensitivity.jl_amd", "libhipadj.so")) == []
+
+
+@pytest.mark.parametrize("n,alg", [(3, "backsolve"), (4, "backsolve"), (4, "interpolating")])
+def test_runtime_tsit5_kernels_have_no_spill_copies_ahead_of_exec_restores(tmp_path, monkeypatch, n, alg):
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.ring(n)
+    name = f"ring{n}_lint_{alg}"
+    _lib.register_model(name, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+    cfg = E.make_config(name, alg, 53, 0.0, 0.5, 0.0, [], loss_kind=1, stepper=1, abstol=1e-9, reltol=1e-9, checkpointing=False)
+    L = _lib.load()
+    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+    objs = glob.glob(str(tmp_path / "*.hsaco"))
+    assert objs
+    for o in objs:
+        assert isa_lint.lint(o) == []
