@@ -98,13 +98,34 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
                             extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g, save_idxs=idxs))
 
 
-def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, sensealg=None, checkpoints=None, g=None, **kwargs):
+def _dgdp_sum(sol, dgdp, shared):
+    """sum_i dl_i/dp over the save times (and over the ensemble when p is shared)"""
+    eng = sol.engine
+    if callable(dgdp):
+        if sol.u is None or sol.extra.get("save_idxs") is not None:
+            raise ValueError("a callable dgdp_discrete needs the full saved states (solve(..., want_out=True) without save_idxs)")
+        p = sol.prob.p
+        rows = [np.asarray(dgdp(sol.u[:, i, :], p, sol.t[i], i), dtype=np.float64).reshape(eng.N, eng.np) for i in range(eng.M)]
+        tot = np.sum(rows, axis=0) if rows else np.zeros((eng.N, eng.np))
+    else:
+        tot = np.asarray(dgdp, dtype=np.float64).reshape(eng.N, eng.M, eng.np).sum(axis=1)
+    return tot.sum(axis=0) if shared else tot
+
+
+def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_discrete=None, sensealg=None, checkpoints=None, g=None, **kwargs):
     """(du0, dp) for the loss  sum_i l_i(u(t_i))  with dl_i/du = dgdu_discrete at the times `t`
     (src/sensitivity_interface.jl:373-526).  `dgdu_discrete`: LsqShift(c) or an array [N][M][n] of cotangents
     (the AD path hands `Delta[:, i]`, src/concrete_solve.jl:842-851).  Returns du0 [N][n] and dp: [np] row
-    (sum over the ensemble when p is shared) or [N][np]."""
+    (sum over the ensemble when p is shared) or [N][np].
+    `dgdp_discrete`: the direct parameter derivative of a loss that also depends on p at the save times — an array
+    [N][M][np] of dl_i/dp, or a callable (u_i [N][n], p, t_i, i) -> [N][np].  The reference adds it to the parameter part
+    of the augmented state inside ReverseLossCallback (src/adjoint_common.jl:775-779); that part obeys mu' = -f_p^T lam,
+    which does not contain mu, so the jumps commute with the integration and their sum is added to dp once, exactly."""
     if kwargs:
-        raise TypeError(f"unsupported keyword(s) {sorted(kwargs)} (dgdp, callbacks: SURVEY.md §8f)")
+        raise TypeError(f"unsupported keyword(s) {sorted(kwargs)} (callbacks: SURVEY.md §8f)")
+    if dgdp_discrete is not None:
+        du0, dp = adjoint_sensitivities(sol, alg, t=t, dgdu_discrete=dgdu_discrete, sensealg=sensealg, checkpoints=checkpoints, g=g)
+        return du0, dp + _dgdp_sum(sol, dgdp_discrete, dp.ndim == 1)
     if g is not None and sol.extra.get("g") != g:
         raise ValueError("pass the continuous cost g to solve(...) as well: the reverse kernel is specialised on it")
     eng = sol.engine

@@ -687,6 +687,45 @@ def test_runtime_model_tsit5_without_loss_times(sa, n, alg, oalg):
         sol.engine.close()
 
 
+@pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
+@pytest.mark.parametrize("shared", [True, False])
+def test_dgdp_discrete_against_finite_differences(sa, stepper, shared):
+    """A discrete loss that depends on p directly, l_i = |u(t_i) - p_1 e|^2 / 2 (dgdp_discrete, src/adjoint_common.jl:775-779):
+    dL/dp = adjoint part + sum_i dl_i/dp, checked against central differences of the oracle's forward solves."""
+    rng = np.random.default_rng(77)
+    N, T = 6, 1.0
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2))
+    pc = np.array([1.5, 1.0, 3.0, 1.0])
+    p = pc if shared else pc * (1 + 0.02 * rng.standard_normal((N, 4)))
+    ts = np.array([0.25, 0.5, 1.0])
+    if stepper == "rk4":
+        salg, kw, okw = sa.RK4(), dict(dt=0.01), dict(stepper="RK4", dt=0.01)
+    else:
+        salg, kw, okw = sa.Tsit5(), dict(abstol=1e-11, reltol=1e-11), dict(stepper="TSIT5", dt=0.0, abstol=1e-11, reltol=1e-11)
+    ref = O.Problem("LV", alg="INTERPOLATING", t0=0.0, t1=T, save_times=ts, loss="COTANGENT", **okw)
+
+    def loss_rows(pp):                                   # per-trajectory loss from the oracle's forward solve
+        _, _, out, _ = ref.adjoint_ensemble(u0, pp, np.zeros((N, len(ts), 2)))
+        p1 = pp[0] if pp.ndim == 1 else pp[:, 0][:, None, None]
+        return 0.5 * ((out - p1) ** 2).sum(axis=(1, 2))
+
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0.0, T), pc), u0, p), salg, saveat=ts, sensealg=sa.InterpolatingAdjoint(), **kw)
+    p1 = p[0] if shared else p[:, 0][:, None, None]
+    dgdu = sol.u - p1
+    dgdp = lambda ui, pp, t, i: np.concatenate([-(ui - (pp[0] if pp.ndim == 1 else pp[:, :1])).sum(axis=1, keepdims=True), np.zeros((N, 3))], axis=1)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=dgdu, dgdp_discrete=dgdp)
+    dgdp_arr = np.stack([dgdp(sol.u[:, i, :], p, ts[i], i) for i in range(len(ts))], axis=1)
+    du0b, dpb = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=dgdu, dgdp_discrete=dgdp_arr)
+    assert np.array_equal(dp, dpb) and np.array_equal(du0, du0b)
+    fd = np.zeros((N, 4))
+    for j in range(4):
+        e = np.zeros(4); e[j] = 1e-6
+        fd[:, j] = (loss_rows(p + e) - loss_rows(p - e)) / 2e-6
+    want = fd.sum(axis=0) if shared else fd
+    assert rel(dp, want) < 2e-6, (dp, want)
+    sol.engine.close()
+
+
 def test_gauss_with_parameter_dependent_cost_is_rejected(sa):
     u0 = np.ones((4, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
     with pytest.raises(sa.HipadjError) as e:
