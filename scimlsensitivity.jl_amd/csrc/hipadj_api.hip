@@ -123,8 +123,12 @@ extern "C" int hipadj_model_set_cost_function(int32_t model_id, const char* g_bo
 
 extern "C" int hipadj_model_check(int32_t model_id) {
     std::vector<char> code; std::map<std::string, std::string> low;
-    return user_compile(model_id, {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 1, 7>" : "hipadj::k_interp<hipadj::UserModel, 1, 1>"},
-                        code, low, g_create_error);
+    std::vector<std::string> exprs = {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 1, 7>" : "hipadj::k_interp<hipadj::UserModel, 1, 1>"};
+    if (const char* e = std::getenv("HIPADJ_CHECK_EXPRS")) {   // debugging hook: further ';'-separated kernel instantiations (ISA studies with HIPADJ_RTC_DUMP)
+        std::string t(e); size_t a = 0;
+        while (a <= t.size()) { const size_t b = t.find(';', a); const std::string x = t.substr(a, b == std::string::npos ? std::string::npos : b - a); if (!x.empty()) exprs.push_back(x); if (b == std::string::npos) break; a = b + 1; }
+    }
+    return user_compile(model_id, exprs, code, low, g_create_error);
 }
 
 // Every kernel a handle of this configuration would launch, compiled now (no device needed): the ahead-of-time form of what
