@@ -639,7 +639,8 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     const int n = h->n, np = h->np;
     const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);
     const int cc = mode >> 1;
-    const int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : 1, PFG = n <= 3 ? 4 : 1;   // more than three states: the plain rolled sweep (reverse_sweep, PF == 1)
+    int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : 1; const int PFG = n <= 3 ? 4 : 1;   // more than three states: the plain rolled sweep (reverse_sweep, PF == 1)
+    if (const char* e = std::getenv("HIPADJ_USER_PF")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) PF = v; }   // tuning hook: prefetch depth of k_interp for runtime models
     auto I = [](int v) { return std::to_string(v); };
     UserKernels k;
     const bool seg = (1 + n) * (n + np) <= 64;          // same rule as the planner: wider models stay sequential in time ...
