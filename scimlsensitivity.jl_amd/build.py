@@ -6,9 +6,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "hipadj_api.hip")
 LIB = os.path.join(HERE, "libhipadj.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("hipadj_api.hip", "hipadj_kernels.hpp", "hipadj_lane.hpp", "hipadj_models.hpp", "hipadj_plan.hpp")] + \
-       [os.path.join(os.path.dirname(HERE), "include", "hipadj.h")]
+import glob
+
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h*"))) + [os.path.join(os.path.dirname(HERE), "include", "hipadj.h")]   # every header and the .hip
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 

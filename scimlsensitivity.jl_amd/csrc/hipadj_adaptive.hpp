@@ -90,7 +90,10 @@ HIPADJ_HD bool time_hits(double t, double target) { return habs(t - target) <= 1
 // Stage storage of one lane: rows 0..6 = k_1..k_7 of the current step, row 7 = the step's start value.
 // Device: base = LDS array + lane, stride = 64.  Host emulation: a local array, stride 1.
 constexpr int KS_ROWS = 8, KS_UPREV = 7;
-constexpr int TS5_WIDE = 9;    // widest state vector whose six stage rows are summed in one batch (tsit5_integrate)
+#ifndef HIPADJ_TS5_WIDE
+#define HIPADJ_TS5_WIDE 9
+#endif
+constexpr int TS5_WIDE = HIPADJ_TS5_WIDE;   // widest state vector whose six stage rows are summed in one batch (tsit5_integrate)
 template <int NZ> struct KStore {
     double* base; int stride;
     HIPADJ_HD double get(int row, int i) const { return base[(row * NZ + i) * stride]; }

@@ -17,7 +17,10 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <unistd.h>
+
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <mutex>
@@ -162,6 +165,95 @@ inline std::string user_model_struct(const UserModelSrc& m) {
     return o.str();
 }
 
+// ---- check of freshly compiled code objects for a known miscompile -------------------------------
+// The ROCm 7.2 compiler can place register-spill copies (v_accvgpr_write/read, scratch_store/load) at the top of a
+// control-flow join block AHEAD of the `s_or_b64 exec, exec, s[..]` that re-enables the lanes which skipped the region; when
+// the join is reached through the region's s_cbranch_execz the copies run with an empty exec mask and a loop-carried value
+// is lost (found as a GPU fault of k_adjoint_tsit5 with an empty tstop list).  Every runtime model gets its own register
+// allocation, so the pattern is looked for in each new code object: llvm-objdump of the ROCm installation disassembles it
+// ($HIPADJ_OBJDUMP, $ROCM_PATH/lib/llvm/bin, /opt/rocm/lib/llvm/bin); without that tool the check is skipped.
+// HIPADJ_RTC_VERIFY=0 turns it off.  Same walk as tests/tools/isa_lint.py.
+inline std::string user_objdump_path() {
+    std::vector<std::string> cand;
+    if (const char* e = std::getenv("HIPADJ_OBJDUMP")) cand.push_back(e);
+    if (const char* e = std::getenv("ROCM_PATH")) cand.push_back(std::string(e) + "/lib/llvm/bin/llvm-objdump");
+    cand.push_back("/opt/rocm/lib/llvm/bin/llvm-objdump");
+    for (const auto& c : cand) if (access(c.c_str(), X_OK) == 0) return c;
+    return std::string();
+}
+
+// returns the number of flagged sites (0 = clean), -1 when the check could not run; `what` names the first site
+inline int user_isa_check(const std::vector<char>& code, std::string& what) {
+    if (const char* e = std::getenv("HIPADJ_RTC_VERIFY")) if (e[0] == '0') return -1;
+    const std::string objdump = user_objdump_path();
+    if (objdump.empty()) return -1;
+    char tmpl[] = "/tmp/hipadj_isa_XXXXXX";
+    const int fd = mkstemp(tmpl);
+    if (fd < 0) return -1;
+    const bool wrote = write(fd, code.data(), code.size()) == (ssize_t)code.size();
+    close(fd);
+    if (!wrote) { unlink(tmpl); return -1; }
+    const std::string cmd = "'" + objdump + "' -d --no-show-raw-insn '" + tmpl + "' 2>/dev/null";
+    FILE* pp = popen(cmd.c_str(), "r");
+    if (!pp) { unlink(tmpl); return -1; }
+    struct Insn { unsigned long addr; std::string op; long target; };   // target: offset from the kernel symbol, -1 = none
+    std::vector<std::pair<std::string, std::vector<Insn>>> kernels;
+    char line[1024];
+    while (fgets(line, sizeof(line), pp)) {
+        std::string l(line);
+        while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+        if (!l.empty() && l.back() == ':' && l.find(" <") != std::string::npos && l[0] != ' ' && l[0] != '\t') {
+            const size_t a = l.find('<'), b = l.rfind('>');
+            if (a != std::string::npos && b != std::string::npos && b > a) kernels.push_back({l.substr(a + 1, b - a - 1), {}});
+            continue;
+        }
+        if (kernels.empty() || l.empty() || (l[0] != ' ' && l[0] != '\t')) continue;
+        const size_t c = l.find("//");
+        if (c == std::string::npos) continue;
+        size_t b0 = l.find_first_not_of(" \t");
+        std::string op = l.substr(b0, c - b0);
+        while (!op.empty() && (op.back() == ' ' || op.back() == '\t')) op.pop_back();
+        const unsigned long addr = std::strtoul(l.c_str() + c + 2, nullptr, 16);
+        long target = -1;
+        if (op.compare(0, 9, "s_cbranch") == 0 || op.compare(0, 8, "s_branch") == 0) {
+            const size_t px = l.rfind("+0x");
+            if (px != std::string::npos && px > c) target = (long)std::strtoul(l.c_str() + px + 3, nullptr, 16);
+        }
+        kernels.back().second.push_back({addr, op, target});
+    }
+    const int prc = pclose(pp);
+    unlink(tmpl);
+    if (prc != 0 || kernels.empty()) return -1;
+    auto starts = [](const std::string& s, const char* pre) { return s.compare(0, std::strlen(pre), pre) == 0; };
+    static const char* STOP[] = {"s_cbranch", "s_branch", "s_endpgm", "s_or_b64 exec", "s_and_saveexec", "s_andn2_saveexec", "s_or_saveexec",
+                                 "s_mov_b64 exec", "s_andn2_b64 exec", "s_xor_b64 exec"};
+    static const char* SPILL[] = {"v_accvgpr_write", "v_accvgpr_read", "scratch_store", "scratch_load", "buffer_store", "buffer_load"};
+    int found = 0;
+    for (const auto& kn : kernels) {
+        const auto& ins = kn.second;
+        if (ins.empty()) continue;
+        const unsigned long base = ins[0].addr;
+        std::map<unsigned long, int> tgt;   // address -> 1 = branch target, 2 = target of an s_cbranch_execz
+        for (const auto& i : ins) if (i.target >= 0) { int& t = tgt[base + (unsigned long)i.target]; t = std::max(t, starts(i.op, "s_cbranch_execz") ? 2 : 1); }
+        for (size_t k = 0; k < ins.size(); ++k) {
+            if (!starts(ins[k].op, "s_or_b64 exec, exec")) continue;
+            int spills = 0;
+            for (long j = (long)k - 1; j >= 0; --j) {
+                bool stop = false;
+                for (const char* sname : STOP) if (starts(ins[j].op, sname)) { stop = true; break; }
+                if (stop) break;
+                for (const char* sp : SPILL) if (starts(ins[j].op, sp)) { ++spills; break; }
+                const auto it = tgt.find(ins[j].addr);
+                if (it != tgt.end()) {
+                    if (spills > 0 && it->second == 2) { if (!found) { char b[64]; snprintf(b, sizeof(b), " @ 0x%lx", ins[k].addr); what = kn.first + b; } ++found; }
+                    break;
+                }
+            }
+        }
+    }
+    return found;
+}
+
 // Compiles (or fetches from the process-wide cache) the code object holding `exprs` for user model `model`.
 // Returns HIPADJ_OK and fills code + lowered names; on failure err carries the hiprtc log.
 inline int user_compile(int32_t model, const std::vector<std::string>& exprs, std::vector<char>& code,
@@ -189,39 +281,53 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         if (!user_read_file(dir + "/" + hnames[i], htext[i])) { err = "cannot read kernel header " + dir + "/" + hnames[i] + " (set HIPADJ_CSRC_DIR)"; return HIPADJ_ERR_UNSUPPORTED; }
     const char* hptr[NH] = {htext[0].c_str(), htext[1].c_str(), htext[2].c_str(), htext[3].c_str(), htext[4].c_str()};
     const std::string tu = user_model_struct(src);
-    hiprtcProgram prog = nullptr;
-    if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", NH, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
-    for (const auto& e : exprs) A.AddNameExpression(prog, e.c_str());
-    std::vector<std::string> optv = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    if (const char* e = std::getenv("HIPADJ_RTC_FLAGS")) { std::istringstream is(e); std::string w; while (is >> w) optv.push_back(w); }   // tuning / debugging hook
-    std::vector<const char*> opts; for (const auto& o : optv) opts.push_back(o.c_str());
-    const hiprtcResult cr = A.CompileProgram(prog, (int)opts.size(), opts.data());
-    if (cr != HIPRTC_SUCCESS) {
-        size_t ls = 0; A.GetProgramLogSize(prog, &ls);
-        std::string log(ls, '\0'); if (ls) A.GetProgramLog(prog, &log[0]);
-        if (log.size() > 4000) log.resize(4000);
-        err = "model '" + src.name + "' failed to compile:\n" + log;
+    // attempt 0: -O3.  If the ISA check (user_isa_check) flags the code object: attempt 1 at -O1 — a different schedule and
+    // register allocation (the one known case is clean there); still flagged => refuse rather than run lanes on garbage.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        hiprtcProgram prog = nullptr;
+        if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", NH, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
+        for (const auto& e : exprs) A.AddNameExpression(prog, e.c_str());
+        std::vector<std::string> optv = {"--offload-arch=gfx950", attempt == 0 ? "-O3" : "-O1", "-std=c++17"};
+        if (const char* e = std::getenv("HIPADJ_RTC_FLAGS")) { std::istringstream is(e); std::string w; while (is >> w) optv.push_back(w); }   // tuning / debugging hook
+        std::vector<const char*> opts; for (const auto& o : optv) opts.push_back(o.c_str());
+        const hiprtcResult cr = A.CompileProgram(prog, (int)opts.size(), opts.data());
+        if (cr != HIPRTC_SUCCESS) {
+            size_t ls = 0; A.GetProgramLogSize(prog, &ls);
+            std::string log(ls, '\0'); if (ls) A.GetProgramLog(prog, &log[0]);
+            if (log.size() > 4000) log.resize(4000);
+            err = "model '" + src.name + "' failed to compile:\n" + log;
+            A.DestroyProgram(&prog);
+            return HIPADJ_ERR_INVALID_ARG;
+        }
+        if (std::getenv("HIPADJ_RTC_SHOWLOG")) {   // debugging hook: the compiler's log of a successful build (remarks)
+            size_t ls = 0; A.GetProgramLogSize(prog, &ls);
+            std::string log(ls, '\0'); if (ls) A.GetProgramLog(prog, &log[0]);
+            std::fprintf(stderr, "%s\n", log.c_str());
+        }
+        lowered.clear();
+        for (const auto& e : exprs) {
+            const char* low = nullptr;
+            if (A.GetLoweredName(prog, e.c_str(), &low) != HIPRTC_SUCCESS || !low) { err = "no lowered name for " + e; A.DestroyProgram(&prog); return HIPADJ_ERR_HIP; }
+            lowered[e] = low;
+        }
+        size_t cs = 0; A.GetCodeSize(prog, &cs);
+        code.assign(cs, 0); A.GetCode(prog, code.data());
         A.DestroyProgram(&prog);
-        return HIPADJ_ERR_INVALID_ARG;
-    }
-    if (std::getenv("HIPADJ_RTC_SHOWLOG")) {   // debugging hook: the compiler's log of a successful build (remarks)
-        size_t ls = 0; A.GetProgramLogSize(prog, &ls);
-        std::string log(ls, '\0'); if (ls) A.GetProgramLog(prog, &log[0]);
-        std::fprintf(stderr, "%s\n", log.c_str());
-    }
-    lowered.clear();
-    for (const auto& e : exprs) {
-        const char* low = nullptr;
-        if (A.GetLoweredName(prog, e.c_str(), &low) != HIPRTC_SUCCESS || !low) { err = "no lowered name for " + e; A.DestroyProgram(&prog); return HIPADJ_ERR_HIP; }
-        lowered[e] = low;
-    }
-    size_t cs = 0; A.GetCodeSize(prog, &cs);
-    code.assign(cs, 0); A.GetCode(prog, code.data());
-    A.DestroyProgram(&prog);
-    if (const char* d = std::getenv("HIPADJ_RTC_DUMP")) {   // debugging hook: keep the code object (llvm-objdump -d, llvm-readelf --notes)
-        static int serial = 0;
-        const std::string fn = std::string(d) + "/" + src.name + "_" + std::to_string(serial++) + ".hsaco";
-        if (FILE* fp = std::fopen(fn.c_str(), "wb")) { std::fwrite(code.data(), 1, code.size(), fp); std::fclose(fp); }
+        if (const char* d = std::getenv("HIPADJ_RTC_DUMP")) {   // debugging hook: keep the code object (llvm-objdump -d, llvm-readelf --notes)
+            static int serial = 0;
+            const std::string fn = std::string(d) + "/" + src.name + "_" + std::to_string(serial++) + ".hsaco";
+            if (FILE* fp = std::fopen(fn.c_str(), "wb")) { std::fwrite(code.data(), 1, code.size(), fp); std::fclose(fp); }
+        }
+        std::string where;
+        const int flagged = user_isa_check(code, where);
+        if (std::getenv("HIPADJ_RTC_SHOWLOG")) std::fprintf(stderr, "hipadj: ISA check of '%s' (attempt %d): %d %s\n", src.name.c_str(), attempt, flagged, where.c_str());
+        if (flagged <= 0) break;                           // clean, or the check could not run (no llvm-objdump: documented)
+        if (attempt == 1) {
+            err = "model '" + src.name + "': the compiler placed register-spill copies ahead of an exec restore (" + where +
+                  ") at -O3 and at -O1; lanes could read stale values, so this configuration is refused (fewer states/parameters, "
+                  "another stepper, or HIPADJ_RTC_FLAGS may help; HIPADJ_RTC_VERIFY=0 overrides)";
+            return HIPADJ_ERR_UNSUPPORTED;
+        }
     }
     {
         std::lock_guard<std::mutex> lk(R.mu);

@@ -36,3 +36,21 @@ def test_runtime_tsit5_kernels_have_no_spill_copies_ahead_of_exec_restores(tmp_p
     assert objs
     for o in objs:
         assert isa_lint.lint(o) == []
+
+
+def test_runtime_compile_retries_at_O1_when_the_check_flags_the_code_object(tmp_path, monkeypatch):
+    """Product-side guard (user_isa_check in csrc/hipadj_user.hpp): the batched stage sum forced onto a 13-wide state
+    (-DHIPADJ_TS5_WIDE=64) reproduces the flagged placement at -O3; the library must notice, rebuild at -O1 and hand out a
+    clean code object."""
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.ring(4)
+    _lib.register_model("ring4_lint_retry", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+    monkeypatch.setenv("HIPADJ_RTC_FLAGS", "-DHIPADJ_TS5_WIDE=64")
+    cfg = E.make_config("ring4_lint_retry", "backsolve", 53, 0.0, 0.5, 0.0, [], loss_kind=1, stepper=1, abstol=1e-9, reltol=1e-9, checkpointing=False)
+    L = _lib.load()
+    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+    objs = sorted(glob.glob(str(tmp_path / "*.hsaco")))
+    if len(objs) == 1:
+        pytest.skip("this compiler build does not produce the flagged placement for the probe configuration")
+    assert len(objs) == 2 and isa_lint.lint(objs[0]) != [] and isa_lint.lint(objs[1]) == []
