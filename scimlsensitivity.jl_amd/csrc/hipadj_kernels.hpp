@@ -38,13 +38,26 @@ __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restri
 // SEG = false (runtime models whose (1 + n)(n + np) segment columns do not fit the register file: the planner keeps them
 // sequential in time) compiles ONLY the one-column path: the unused (1 + n)-column code would otherwise set the kernel's
 // register allocation (n = 7: 256 VGPRs + 256 AGPRs + 2.7 KB scratch, and a wrong result on the device).
-template <class Mo, int PF, int LOSS, bool SEG = true>
-__global__ void __launch_bounds__(WAVE) k_interp(Geom g, SegPlan sp, const double* __restrict__ p,
-                                                 const dbl2* __restrict__ knots, const double* __restrict__ cotT,
-                                                 const int* __restrict__ save_of_knot, double* __restrict__ segbuf) {
+// WPB = waves per workgroup.  1: grid (wave blocks, segments), one wave per workgroup.  4: a 1-D grid of 256-thread
+// workgroups whose four waves take four consecutive (wave block, segment) items — the hardware spreads the waves of ONE
+// workgroup over the four SIMDs of its CU, which single-wave workgroups do not guarantee (a SIMD that happens to receive
+// three of a CU's eight waves finishes 1.5x later than the kernel needs).
+template <class Mo, int PF, int LOSS, bool SEG = true, int WPB = 1>
+__global__ void __launch_bounds__(WAVE * WPB) k_interp(Geom g, SegPlan sp, const double* __restrict__ p,
+                                                       const dbl2* __restrict__ knots, const double* __restrict__ cotT,
+                                                       const int* __restrict__ save_of_knot, double* __restrict__ segbuf) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
-    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
-    const int seg = sp.nseg - 1 - (int)blockIdx.y;   // longest (top, 1-column) segment is dispatched first
+    long i; int seg;
+    if constexpr (WPB == 1) {
+        i = (long)blockIdx.x * WAVE + threadIdx.x;
+        seg = sp.nseg - 1 - (int)blockIdx.y;         // longest (top, 1-column) segment is dispatched first
+    } else {
+        const int nwb = (int)(g.Npad / WAVE);
+        const int item = (int)blockIdx.x * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform (SGPR): loop bounds stay scalar
+        if (item >= nwb * sp.nseg) return;
+        seg = sp.nseg - 1 - item / nwb;
+        i = (long)(item % nwb) * WAVE + (threadIdx.x & (WAVE - 1));
+    }
     if (i >= g.N) return;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
     double* __restrict__ dst = segbuf + (long)seg * NC * R * g.Npad + i;
