@@ -47,7 +47,7 @@ struct Geom {
     int loss_kind;     // 0 cotangent, 1 lsq_shift
     int no_start;
     int p_shared;
-    int kmask;         // experiment hook (normally -1): knot index & kmask is what gets loaded — isolates HBM from issue limits
+    int kmask;         // always -1 in the library (knot index & kmask is what gets loaded: a masked index served a one-off study that separated HBM from issue limits)
 };
 
 template <class Mo> struct Knot { double u[Mo::N]; double f[Mo::N]; };
