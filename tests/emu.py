@@ -41,7 +41,7 @@ def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shi
     save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
     c = PL.HipadjConfig()
     c.struct_size = C.sizeof(PL.HipadjConfig)
-    c.model, c.alg, c.stepper = PL.MODEL[model], PL.ALG[alg], stepper
+    c.model, c.alg, c.stepper = (PL.MODEL_USER_BASE + 4 if model == "emu_ring4" else PL.MODEL[model]), PL.ALG[alg], stepper   # emu_ring4: test-only model of lane_emu.cpp
     c.ntraj = ntraj
     c.t0, c.t1, c.dt = t0, t1, dt
     c.nsave = len(save)

@@ -16,6 +16,32 @@
 
 using namespace hipadj;
 
+// TEST-ONLY model: the n-state ring of tests/user_models.py (the device receives it as text through hipadj_model_register;
+// the oracle has it as ORC_MODEL_RING).  Its Backsolve state [lam; mu; y] is 3n + 1 wide: n = 4 puts the host emulation on the
+// wide-state branch of tsit5_integrate (NZ > TS5_WIDE), which no compiled-in model reaches.  Model id = HIPADJ_MODEL_USER_BASE + n.
+template <int NN> struct EmuRing {
+    static constexpr int N = NN, NP = NN + 1;
+    static constexpr bool TIME_DEP = false;
+    static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) {
+        for (int i = 0; i < N; ++i) du[i] = p[i] * (u[(i + 1) % N] - u[i]) + p[N] * std::sin(u[(i + N - 1) % N]);
+    }
+    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double) {
+        for (int j = 0; j < N; ++j) dl[j] = -p[j] * l[j] + p[(j + N - 1) % N] * l[(j + N - 1) % N] + p[N] * std::cos(u[j]) * l[(j + 1) % N];
+    }
+    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&)[NP], double) {
+        double s = 0.0;
+        for (int k = 0; k < N; ++k) { dg[k] = l[k] * (u[(k + 1) % N] - u[k]); s += l[k] * std::sin(u[(k + N - 1) % N]); }
+        dg[N] = s;
+    }
+};
+static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
+    const int nn = model - HIPADJ_MODEL_USER_BASE;
+    if (nn != 4) return HIPADJ_ERR_INVALID_ARG;
+    *n = nn; *np = nn + 1;
+    return HIPADJ_OK;
+}
+static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, true);
+
 template <class Mo>
 static void compose(const Plan& P, const std::vector<double>& segbuf, double* du0, std::vector<double>& dp_traj) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
@@ -283,6 +309,7 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     case HIPADJ_MODEL_LORENZ: return dispatch_mode<ModelLorenz>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_LINDIAG: return dispatch_mode<ModelLinDiag>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_FALLMASS: return dispatch_mode<ModelFallMass>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 4: return dispatch_mode<EmuRing<4>>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

@@ -371,3 +371,47 @@ def test_rolled_sweep_variant_pf1(tmp_path):
                         assert rel(du0, rdu0) < 1e-11 and rel(dp, rdp) < 1e-11, (alg, lk, ts, segs)
     finally:
         E._lib = saved
+
+
+# ---- a 13-wide Backsolve state: the wide-state branch of tsit5_integrate (NZ > TS5_WIDE), which only runtime models reach ----
+@pytest.mark.parametrize("ckpt", [False, True])
+@pytest.mark.parametrize("alg", TS_ALGS + ["gausskronrod"])
+def test_tsit5_wide_state_ring4_matches_oracle(alg, ckpt):
+    """emu_ring4 = the 4-state ring of tests/user_models.py compiled into the emulator (test-only); the oracle's ORC_MODEL_RING."""
+    if alg == "quadrature" and ckpt:
+        pytest.skip("QuadratureAdjoint has no checkpointing")
+    rng = np.random.default_rng(41)
+    N, T, n, npar = 3, 1.5, 4, 5
+    u0 = np.array([0.6, 0.9, 0.4, 0.8]) + 0.05 * rng.standard_normal((N, n))
+    pp = np.array([0.7, 0.9, 0.5, 1.1, 0.6]) * (1 + 0.03 * rng.standard_normal((N, npar)))
+    for ts in (np.array([0.0, 0.31, 0.75, 1.5]), np.array([])):          # with loss times / with no tstops at all
+        delta = rng.standard_normal((N, len(ts), n))
+        cfg = E.make_config("emu_ring4", alg, N, 0.0, T, 0.0, ts, loss_kind=0, checkpointing=ckpt, p_shared=False, stepper=1, abstol=1e-9, reltol=1e-8,
+                            quad_abstol=1e-10, quad_reltol=1e-10, cont_cost=(1 if alg != "gausskronrod" else 0))
+        du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+        ref = O.Problem("RING", alg=("GAUSS_KRONROD" if alg == "gausskronrod" else alg.upper()), stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-8, save_times=ts, loss="COTANGENT",
+                        checkpointing=ckpt, quad_abstol=1e-10, quad_reltol=1e-10, dims=(4, 0, 0, 0), cont_cost=(1 if alg != "gausskronrod" else 0))
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+        if len(ts):
+            assert rel(out, rout) < 1e-12
+        assert rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_rk4_ring4_matches_oracle(alg):
+    rng = np.random.default_rng(43)
+    N, T, dt, n, npar = 3, 1.0, 0.01, 4, 5
+    u0 = np.array([0.6, 0.9, 0.4, 0.8]) + 0.05 * rng.standard_normal((N, n))
+    pp = np.array([0.7, 0.9, 0.5, 1.1, 0.6])
+    ts = np.array([0.0, 0.3, 0.7, 1.0])
+    ck = alg == "backsolve"
+    for segs in (1, 3):
+        if alg == "quadrature" and segs > 1:
+            continue
+        cfg = E.make_config("emu_ring4", alg, N, 0.0, T, dt, ts, loss_kind=1, loss_shift=1.5, checkpointing=ck, ckpt_stride=10, time_segments=segs,
+                            quad_abstol=1e-10, quad_reltol=1e-10)
+        du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, None)
+        ref = O.Problem("RING", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=1.5, checkpointing=ck,
+                        checkpoints=np.arange(0, 101, 10) * dt, quad_abstol=1e-10, quad_reltol=1e-10, dims=(4, 0, 0, 0))
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp)
+        assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
