@@ -268,6 +268,7 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         src = R.models[idx];
         key = std::to_string(model) + "#" + std::to_string(src.rev);
         for (const auto& e : exprs) key += "|" + e;
+        if (const char* fl = std::getenv("HIPADJ_RTC_FLAGS")) key += std::string("|flags:") + fl;   // a debugging run with other flags must not be served from the cache
         auto it = R.code_cache.find(key);
         if (it != R.code_cache.end()) { code = it->second; lowered = R.lowered_cache[key]; return HIPADJ_OK; }
     }
