@@ -57,6 +57,7 @@ struct hipadj_handle {
     hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish
     bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
     AdaptGeom ag{};
+    int cbs = 0;         // k_compose_finish workgroup size: 0 = by ensemble size, 64 / 256 forced (HIPADJ_CBS; tuning study)
     bool wpb4 = false;   // k_interp in 256-thread workgroups (HIPADJ_WPB=4; tuning study)
     double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr, *d_arec = nullptr;
     int *d_nsteps = nullptr, *d_nsteps_adj = nullptr, ntstops = 0, SmaxA = 0;
@@ -248,7 +249,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) A(dev_alloc(h, &h->d_fadj, (size_t)h->N * S * 4 * n));
     }
     A(dev_alloc(h, &h->d_dp_traj, (size_t)np * Np));
-    A(dev_alloc(h, &h->d_partial, (size_t)((h->N + FIN / 4 - 1) / (FIN / 4)) * np));
+    A(dev_alloc(h, &h->d_partial, (size_t)((h->N + 15) / 16) * np));   // one row per finishing workgroup (at most N / 16 of them)
     A(dev_alloc(h, &h->d_io_a, (size_t)h->N * (h->M > 0 ? h->M : 1) * n));
     A(dev_alloc(h, &h->d_du0, (size_t)h->N * n));
     A(dev_alloc(h, &h->d_dp, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
@@ -281,6 +282,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_FUSED_FINAL")) h->fused_final = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_WPB")) h->wpb4 = std::atoi(e) == 4;
+    if (const char* e = std::getenv("HIPADJ_CBS")) h->cbs = std::atoi(e);
     h->fg.N = h->N; h->fg.S = (int)S; h->fg.M = h->M; h->fg.t0 = cfg->t0; h->fg.dt = cfg->dt; h->fg.loss_shift = cfg->loss_shift;
     h->fg.loss_kind = cfg->loss_kind; h->fg.no_start = cfg->no_start; h->fg.p_shared = cfg->p_shared;
     h->mg.N = h->N; h->mg.B = cfg->dims[2]; h->mg.S = (int)S; h->mg.M = h->M; h->mg.t0 = cfg->t0; h->mg.dt = cfg->dt; h->mg.loss_shift = cfg->loss_shift;
@@ -402,6 +404,18 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
     const unsigned cblocks = (unsigned)((h->N + FIN / 4 - 1) / (FIN / 4));   // composition: 4 lanes per trajectory
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;   // per-trajectory dp rows [N][np]
     double* dp_sum = (h->cfg.p_shared && h->fused_final) ? d_dp : (double*)nullptr;   // in-launch last-arriver reduction (optional)
+    // composition workgroups: 64 trajectories each, or 16 each while that still leaves the chip short of workgroups
+    // (10^4 trajectories: 625 instead of 157 workgroups, -1.7 us per reverse pass; profiles/README.md)
+    const bool small_blocks = h->cbs == 64 || (h->cbs == 0 && cblocks < 1024);
+    const unsigned compose_blocks = small_blocks ? (unsigned)((h->N + 15) / 16) : cblocks;
+    auto launch_compose = [&]() {
+        if (small_blocks)
+            hipLaunchKernelGGL((k_compose_finish<Mo, 64>), dim3(compose_blocks), dim3(64), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        else
+            hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(compose_blocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+    };
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
@@ -434,8 +448,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                            (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1 && !dispatch_events) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        launch_compose();
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_BACKSOLVE: {
@@ -445,8 +458,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                            (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        launch_compose();
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_GAUSS: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); } else {
@@ -459,8 +471,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                                (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        launch_compose();
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_GAUSS_KRONROD: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussKronrodAdjoint with dgdp_continuous is not offered"); } else {
@@ -469,8 +480,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
                            (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(cblocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                           d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        launch_compose();
         HIP_TRY(h, hipGetLastError());
         break; }
     case HIPADJ_ALG_QUADRATURE: {
@@ -493,7 +503,7 @@ template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const 
         HIP_TRY(h, hipGetLastError());
     }
     if (h->cfg.p_shared && !h->fused_final) {   // dp = sum over workgroup partials, fixed order
-        const unsigned nb = h->cfg.alg == HIPADJ_ALG_QUADRATURE ? fblocks : cblocks;
+        const unsigned nb = h->cfg.alg == HIPADJ_ALG_QUADRATURE ? fblocks : compose_blocks;
         hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)nb, h->np, (const double*)h->d_partial, d_dp);
         HIP_TRY(h, hipGetLastError());
     }

@@ -122,9 +122,9 @@ __global__ void __launch_bounds__(WAVE) k_interp_ckpt(Geom g, SegPlan sp, const 
 // partials in block order => dp is bit-reproducible for a given N.
 constexpr int FIN = 256;
 
-template <int NP>
+template <int NP, int BS = FIN>
 __device__ __forceinline__ void block_partial(const double (&mu)[NP], bool valid, double* __restrict__ partial) {
-    __shared__ double sh[FIN / WAVE][NP];
+    __shared__ double sh[BS / WAVE][NP];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -137,7 +137,7 @@ __device__ __forceinline__ void block_partial(const double (&mu)[NP], bool valid
     if (threadIdx.x < NP) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < FIN / WAVE; ++w) t += sh[w][threadIdx.x];
+        for (int w = 0; w < BS / WAVE; ++w) t += sh[w][threadIdx.x];
         partial[(long)blockIdx.x * NP + threadIdx.x] = t;
     }
 }
@@ -180,13 +180,13 @@ __device__ __forceinline__ void final_reduce_last_arriver(const double* __restri
 // trajectory: each takes a contiguous quarter of the lower maps, fetches them in ONE round of independent loads and
 // folds them into a single affine map (map o map), the first quarter applying its maps to the top segment's vector;
 // three shuffle hops then push the vector through the other quarters' composed maps.
-template <class Mo>
-__global__ void __launch_bounds__(FIN) k_compose_finish(Geom g, int nseg, const double* __restrict__ segbuf,
+template <class Mo, int BS = FIN>   // BS = workgroup size: BS / 4 trajectories per workgroup (BS = 64: 4x the workgroups for small ensembles)
+__global__ void __launch_bounds__(BS) k_compose_finish(Geom g, int nseg, const double* __restrict__ segbuf,
                                                         double* __restrict__ du0, double* __restrict__ dp_rows,
                                                         double* __restrict__ partial, int* __restrict__ flag,
                                                         unsigned* __restrict__ ticket_ctr, double* __restrict__ dp_sum) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, CHT = 3;
-    const long i_raw = (long)blockIdx.x * (FIN / 4) + (threadIdx.x >> 2);
+    const long i_raw = (long)blockIdx.x * (BS / 4) + (threadIdx.x >> 2);
     const int part = threadIdx.x & 3;
     const bool tvalid = i_raw < g.N;
     const long i = tvalid ? i_raw : g.N - 1;
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(FIN) k_compose_finish(Geom g, int nseg, const 
         for (int j = 0; j < NP; ++j) { bad |= !finite_d(mu[j]); if (dp_rows) dp_rows[i * NP + j] = mu[j]; }
         if (bad) atomicOr(flag, 1);
     }
-    block_partial<NP>(mu, owner, partial);
+    block_partial<NP, BS>(mu, owner, partial);
     if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
 }
 
