@@ -1,15 +1,42 @@
-"""Build libhipadj.so (gfx950) in-tree with hipcc.  `python -m scimlsensitivity_jl_amd.build` or build.build()."""
+"""Build libhipadj.so (gfx950) in-tree with hipcc.  `python -m scimlsensitivity_jl_amd.build` or build.build().
+
+The library consists of one translation unit for the C ABI (csrc/hipadj_api.hip) and one per kernel family / compiled-in
+model / stepper (csrc/hipadj_tu_lane.hip and csrc/hipadj_tu_family.hip, selected with -D): the device code of the ~400
+kernel instantiations dominates the build, so the units are compiled in parallel and linked once.
+"""
+import glob
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "hipadj_api.hip")
+CSRC = os.path.join(HERE, "csrc")
+SRC = os.path.join(CSRC, "hipadj_api.hip")
 LIB = os.path.join(HERE, "libhipadj.so")
-import glob
+OBJ = os.path.join(HERE, "build")
 
-DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h*"))) + [os.path.join(os.path.dirname(HERE), "include", "hipadj.h")]   # every header and the .hip
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+DEPS = sorted(glob.glob(os.path.join(CSRC, "*.h*"))) + [os.path.join(os.path.dirname(HERE), "include", "hipadj.h"), os.path.abspath(__file__)]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+LANE_MODELS = ["ModelLV", "ModelLVT", "ModelLorenz", "ModelLinDiag", "ModelFallMass"]   # csrc/hipadj_models.hpp
+FIELD_GRIDS = [8, 16, 32]
+MLP_HIDDEN = [32, 128]
+
+
+def units():
+    """(object name, source, extra flags), most expensive first so that the pool drains evenly."""
+    u = []
+    for m in LANE_MODELS:
+        u.append((f"lane_{m}_rk4.o", "hipadj_tu_lane.hip", [f"-DHIPADJ_TU_MODEL={m}", "-DHIPADJ_TU_PART=0"]))
+    for m in LANE_MODELS:
+        u.append((f"lane_{m}_tsit5.o", "hipadj_tu_lane.hip", [f"-DHIPADJ_TU_MODEL={m}", "-DHIPADJ_TU_PART=1"]))
+    for h in sorted(MLP_HIDDEN, reverse=True):
+        u.append((f"mlp_{h}.o", "hipadj_tu_family.hip", [f"-DHIPADJ_TU_MLP={h}"]))
+    for g in sorted(FIELD_GRIDS, reverse=True):
+        u.append((f"field_{g}.o", "hipadj_tu_family.hip", [f"-DHIPADJ_TU_FIELD={g}"]))
+    u.append(("api.o", "hipadj_api.hip", []))
+    return u
 
 
 def needs_build():
@@ -19,15 +46,30 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     """Compile every HIP source of the package for gfx950 (cross-compiles without a GPU)."""
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB, SRC]
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = jobs or int(os.environ.get("HIPADJ_BUILD_JOBS", "0")) or max(1, min(os.cpu_count() or 1, 16))
+
+    def compile_unit(u):
+        obj, src, extra = u
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(OBJ, obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return os.path.join(OBJ, obj)
+
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(compile_unit, units()))
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     return LIB
 
 

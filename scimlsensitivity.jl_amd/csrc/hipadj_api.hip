@@ -2,81 +2,12 @@
 // Host side only does validation, workspace ownership, launch sequencing and timing; all arithmetic is in
 // hipadj_lane.hpp / hipadj_kernels.hpp.  No CPU fallback exists: without a usable HIP device
 // hipadj_create returns HIPADJ_ERR_NO_DEVICE.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/hipadj.h"
-#include "hipadj_kernels.hpp"
-#include "hipadj_field.hpp"
-#include "hipadj_mlp.hpp"
-#include "hipadj_adaptive.hpp"
+#include "hipadj_host.hpp"
 #include "hipadj_plan.hpp"
 #include "hipadj_user.hpp"
 
-using namespace hipadj;
-
-static constexpr int HIPADJ_AUTO_MAXITERS = 100000;   // max_steps == 0: the reference's default maxiters
-
-struct hipadj_handle {
-    hipadj_config cfg{};
-    int n = 0, np = 0;
-    long N = 0, Npad = 0;
-    int S = 0, M = 0, nck = 0, nseg = 1, nq = 0;
-    Geom g{};
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};            // forward begin/end
-    // adjoint timing: a ring of event sets harvested with hipEventQuery, so that back-to-back asynchronous
-    // calls never block the host on the previous call (a blocking harvest serialises launch and execution)
-    static constexpr int NSET = 16;
-    struct EvSet { hipEvent_t a0 = nullptr, a1 = nullptr, k0 = nullptr, k1 = nullptr; bool pending = false, full = true; } evs[NSET];
-    int ev_next = 0;
-    std::vector<double> save_times;
-    std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
-    // device workspaces (owned)
-    double *d_u0 = nullptr, *d_p = nullptr, *d_outT = nullptr, *d_yT = nullptr, *d_ckpt = nullptr, *d_cotT = nullptr;
-    double *d_segbuf = nullptr, *d_dp_traj = nullptr, *d_qres = nullptr, *d_qa = nullptr, *d_qb = nullptr, *d_partial = nullptr;
-    double *d_io_a = nullptr, *d_du0 = nullptr, *d_dp = nullptr;   // staging for the host-pointer API
-    dbl2 *d_knots = nullptr, *d_adj = nullptr;
-    bool field = false;                   // workgroup-per-trajectory family (BRUSS)
-    bool ip_ckpt = false;                 // Interpolating/Gauss checkpointing=true
-    double *d_fknots = nullptr, *d_fadj = nullptr;
-    bool mlp = false; int NQ = 0, ksplit = 1;
-    double *d_w2t = nullptr, *d_ax = nullptr, *d_al = nullptr, *d_ah1 = nullptr, *d_ah2 = nullptr, *d_ag1 = nullptr, *d_ag2 = nullptr;
-    double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
-    MlpGeom mg{};
-    FieldGeom fg{};
-    bool user = false;                    // runtime-compiled right-hand side (hipadj_user.hpp)
-    hipModule_t umod = nullptr;
-    hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish
-    bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
-    AdaptGeom ag{};
-    int cbs = 0;         // k_compose_finish workgroup size: 0 = by ensemble size, 64 / 256 forced (HIPADJ_CBS; tuning study)
-    bool wpb4 = false;   // k_interp in 256-thread workgroups (HIPADJ_WPB=4; tuning study)
-    double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr, *d_arec = nullptr;
-    int *d_nsteps = nullptr, *d_nsteps_adj = nullptr, ntstops = 0, SmaxA = 0;
-    bool auto_steps = false;              // max_steps == 0: record capacity sized from a counting pass of the forward solve
-    long rec_cap = 0;                     // accepted steps the record buffer(s) currently hold per trajectory
-    unsigned* d_ticket = nullptr;
-    int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
-    const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
-    bool have_forward = false, timing_pending_fwd = false;
-    int fused_final = 0;                  // 1: dp reduced in-launch by the last-arriving workgroup (HIPADJ_FUSED_FINAL)
-    int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)
-    double ws_bytes = 0;
-    hipadj_stats st{};
-    std::string err;
-};
-
 static thread_local std::string g_create_error;
 static int user_prepare(hipadj_handle* h);   // hiprtc compilation of the kernels of a runtime-registered model
-static int adaptive_autosize(hipadj_handle* h);   // record capacity from the counting pass (max_steps == 0)
 
 extern "C" int hipadj_version(void) { return HIPADJ_VERSION; }
 
@@ -101,16 +32,6 @@ extern "C" int hipadj_model_sizes(int32_t model, const int32_t dims[4], int32_t*
     return plan_model_sizes(model, dims, n, np);
 }
 
-#define HIPADJ_FAIL(h, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (h)->err = _b; return (code); } while (0)
-#define HIP_TRY(h, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
-    HIPADJ_FAIL(h, HIPADJ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
-
-template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
-    if (count == 0) { *p = nullptr; return HIPADJ_OK; }
-    HIP_TRY(h, hipMalloc((void**)p, count * sizeof(T)));
-    h->ws_bytes += (double)(count * sizeof(T));
-    return HIPADJ_OK;
-}
 extern "C" int hipadj_model_register(const char* name, int32_t n, int32_t np, const char* f_body, const char* vjp_u_body,
                                      const char* vjp_p_body, int32_t* model_id) {
     return user_register(name, n, np, f_body, vjp_u_body, vjp_p_body, model_id, g_create_error);
@@ -144,7 +65,6 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
     return user_compile_config(cfg, g_create_error);
 }
 
-#define TRY(expr) do { int _rc = (expr); if (_rc != HIPADJ_OK) return _rc; } while (0)
 
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
@@ -328,16 +248,6 @@ extern "C" int hipadj_set_stream(hipadj_handle* h, void* s) {
     return HIPADJ_OK;
 }
 
-static void harvest_set(hipadj_handle* h, hipadj_handle::EvSet& q, bool block) {
-    if (!q.pending) return;
-    hipEvent_t last = q.full ? q.a1 : q.k1;
-    if (block) { if (hipEventSynchronize(last) != hipSuccess) { q.pending = false; return; } }
-    else if (hipEventQuery(last) != hipSuccess) return;           // still running: look again later
-    float ms = 0.f;
-    if (q.full && hipEventElapsedTime(&ms, q.a0, q.a1) == hipSuccess) { h->st.adjoint_ms_last = ms; h->st.adjoint_ms_total += ms; }
-    if (hipEventElapsedTime(&ms, q.k0, q.k1) == hipSuccess) { h->st.adjoint_main_kernel_ms_last = ms; h->st.adjoint_main_kernel_ms_total += ms; }
-    q.pending = false;
-}
 static void harvest_timing(hipadj_handle* h, bool block) {
     float ms = 0.f;
     if (h->timing_pending_fwd && (block ? hipEventSynchronize(h->ev[1]) : hipEventQuery(h->ev[1])) == hipSuccess) {
@@ -369,215 +279,6 @@ extern "C" int hipadj_get_stats(hipadj_handle* h, hipadj_stats* st) {
     return HIPADJ_OK;
 }
 
-// ---- launch helpers --------------------------------------------------------------------------------------
-static int launch_transpose_to_soa(hipadj_handle* h, const double* src, double* dst, int C) {
-    dim3 blk(32, 8), grd((unsigned)((h->Npad + 31) / 32), (unsigned)((C + 31) / 32));
-    hipLaunchKernelGGL(k_aos_to_soa, grd, blk, 0, h->stream, src, dst, h->N, h->Npad, C);
-    HIP_TRY(h, hipGetLastError());
-    return HIPADJ_OK;
-}
-static int launch_transpose_to_aos(hipadj_handle* h, const double* src, double* dst, int C) {
-    dim3 blk(32, 8), grd((unsigned)((h->N + 31) / 32), (unsigned)((C + 31) / 32));
-    hipLaunchKernelGGL(k_soa_to_aos, grd, blk, 0, h->stream, src, dst, h->N, h->Npad, C);
-    HIP_TRY(h, hipGetLastError());
-    return HIPADJ_OK;
-}
-
-template <class Mo> static int forward_impl(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
-    const unsigned waves = (unsigned)(h->Npad / WAVE);
-    dbl2* knots = h->d_knots;
-    double* ck = h->d_ckpt;
-    hipLaunchKernelGGL((k_forward<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, d_u0, d_p, knots, ck,
-                       h->d_ckpt_of_knot, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, h->d_save_of_knot, h->d_yT);
-    HIP_TRY(h, hipGetLastError());
-    if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
-    return HIPADJ_OK;
-}
-
-template <class Mo, int LOSS> static int adjoint_impl_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    // software-prefetch depth, chosen so that each kernel keeps 2 waves per SIMD (<= 256 VGPRs): the cotangent ring
-    // and the Gauss-node state cost registers
-    constexpr int PF = (LOSS & 1) == 1 ? 8 : 6, PFG = 4;   // LOSS here = MODE = discrete-loss kind | (continuous cost << 1)
-    const unsigned waves = (unsigned)(h->Npad / WAVE);
-    const double* p = h->p_dev_last;
-    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
-    const unsigned cblocks = (unsigned)((h->N + FIN / 4 - 1) / (FIN / 4));   // composition: 4 lanes per trajectory
-    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;   // per-trajectory dp rows [N][np]
-    double* dp_sum = (h->cfg.p_shared && h->fused_final) ? d_dp : (double*)nullptr;   // in-launch last-arriver reduction (optional)
-    // composition workgroups: 64 trajectories each, or 16 each while that still leaves the chip short of workgroups
-    // (10^4 trajectories: 625 instead of 157 workgroups, -1.7 us per reverse pass; profiles/README.md)
-    const bool small_blocks = h->cbs == 64 || (h->cbs == 0 && cblocks < 1024);
-    const unsigned compose_blocks = small_blocks ? (unsigned)((h->N + 15) / 16) : cblocks;
-    auto launch_compose = [&]() {
-        if (small_blocks)
-            hipLaunchKernelGGL((k_compose_finish<Mo, 64>), dim3(compose_blocks), dim3(64), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
-        else
-            hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(compose_blocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
-                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
-    };
-    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
-    hipadj_handle::EvSet& es = h->evs[h->ev_next];
-    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
-    harvest_set(h, es, true);                   // ring full: only now wait for the oldest call
-    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
-    hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
-    bool dispatch_events = false;               // k0/k1 ride on the kernel's dispatch packet instead (k_interp, below)
-    if (h->timing >= 1 && !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt)) HIP_TRY(h, hipEventRecord(k0, h->stream));
-    switch (h->cfg.alg) {
-    case HIPADJ_ALG_INTERPOLATING: {
-        SegPlan sp{h->nseg, h->d_seg_bounds};
-        if (h->ip_ckpt)
-            hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
-        else if (h->wpb4) {
-            // 256-thread workgroups, four (wave block, segment) items each: one wave per SIMD by construction (hipadj_kernels.hpp)
-            const unsigned items = waves * (unsigned)h->nseg;
-            hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS, true, 4>), dim3((items + 3) / 4), dim3(4 * WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
-                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
-            dispatch_events = true;
-        } else if (h->timing >= 1) {
-            // the dominant kernel's own begin/end timestamps (events attached to the dispatch packet): what rocprofv3 reports
-            // as the kernel's duration.  A hipEventRecord pair around the launch also counts the two marker packets and the
-            // dispatch latency (+8-10 us on a 0.12 ms kernel).
-            hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, k0, k1, 0, h->g, sp, p,
-                                  (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
-            dispatch_events = true;
-        } else
-        hipLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p,
-                           (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
-        HIP_TRY(h, hipGetLastError());
-        if (h->timing >= 1 && !dispatch_events) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        launch_compose();
-        HIP_TRY(h, hipGetLastError());
-        break; }
-    case HIPADJ_ALG_BACKSOLVE: {
-        SegPlan sp{h->nseg, h->d_seg_bounds};
-        hipLaunchKernelGGL((k_backsolve<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
-                           (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
-                           (const int*)h->d_save_of_knot, h->d_segbuf);
-        HIP_TRY(h, hipGetLastError());
-        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        launch_compose();
-        HIP_TRY(h, hipGetLastError());
-        break; }
-    case HIPADJ_ALG_GAUSS: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); } else {
-        SegPlan sp{h->nseg, h->d_seg_bounds};
-        if (h->ip_ckpt)
-            hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
-        else
-            hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
-                               (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
-        HIP_TRY(h, hipGetLastError());
-        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        launch_compose();
-        HIP_TRY(h, hipGetLastError());
-        break; }
-    case HIPADJ_ALG_GAUSS_KRONROD: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussKronrodAdjoint with dgdp_continuous is not offered"); } else {
-        SegPlan sp{h->nseg, h->d_seg_bounds};
-        hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
-                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
-        HIP_TRY(h, hipGetLastError());
-        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        launch_compose();
-        HIP_TRY(h, hipGetLastError());
-        break; }
-    case HIPADJ_ALG_QUADRATURE: {
-        hipLaunchKernelGGL((k_quad_adj<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
-                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0);
-        HIP_TRY(h, hipGetLastError());
-        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
-        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-        hipLaunchKernelGGL((k_quad_gk<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
-                           (const dbl2*)h->d_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
-        HIP_TRY(h, hipGetLastError());
-        break; }
-    }
-    // finishing stage: NaN/Inf scan + per-workgroup partial sums of mu (Interpolating fused it with the composition)
-    if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
-        hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
-                           (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
-        HIP_TRY(h, hipGetLastError());
-    }
-    if (h->cfg.p_shared && !h->fused_final) {   // dp = sum over workgroup partials, fixed order
-        const unsigned nb = h->cfg.alg == HIPADJ_ALG_QUADRATURE ? fblocks : compose_blocks;
-        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)nb, h->np, (const double*)h->d_partial, d_dp);
-        HIP_TRY(h, hipGetLastError());
-    }
-    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
-    es.pending = h->timing >= 1; es.full = h->timing >= 2;
-    return HIPADJ_OK;   // timings are harvested lazily at the next synchronize / call
-}
-
-template <class Mo> static int adjoint_impl(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    // no loss times => no cotangent buffer exists: run the LSQ specialisation (its jump select is never taken)
-    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);   // MODE = loss | cost << 1
-    switch (mode) {
-    case 0: return adjoint_impl_l<Mo, 0>(h, d_cot, d_du0, d_dp);
-    case 1: return adjoint_impl_l<Mo, 1>(h, d_cot, d_du0, d_dp);
-    case 2: return adjoint_impl_l<Mo, 2>(h, d_cot, d_du0, d_dp);
-    case 3: return adjoint_impl_l<Mo, 3>(h, d_cot, d_du0, d_dp);
-    case 4: return adjoint_impl_l<Mo, 4>(h, d_cot, d_du0, d_dp);
-    case 5: return adjoint_impl_l<Mo, 5>(h, d_cot, d_du0, d_dp);
-    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "cont_cost %d is not available for compiled-in models", h->cfg.cont_cost);
-    }
-}
-
-// ---- workgroup-per-trajectory family (Brusselator) -----------------------------------------------------
-template <int G> static int field_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
-    hipLaunchKernelGGL((k_bruss_forward<G>), dim3((unsigned)h->N), dim3(Bruss<G>::T), 0, h->stream, h->fg, d_u0, d_p, h->d_fknots,
-                       (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
-    HIP_TRY(h, hipGetLastError());
-    return HIPADJ_OK;
-}
-template <int G> static int field_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    const double* p = h->p_dev_last;
-    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
-    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
-    hipadj_handle::EvSet& es = h->evs[h->ev_next];
-    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
-    harvest_set(h, es, true);
-    HIP_TRY(h, hipEventRecord(es.a0, h->stream));
-    HIP_TRY(h, hipEventRecord(es.k0, h->stream));
-    const dim3 grid((unsigned)h->N), blk(Bruss<G>::T);
-    switch (h->cfg.alg) {
-    case HIPADJ_ALG_INTERPOLATING:
-        hipLaunchKernelGGL((k_bruss_adjoint<G, 0>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj, h->d_flag);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-        break;
-    case HIPADJ_ALG_GAUSS:
-        hipLaunchKernelGGL((k_bruss_adjoint<G, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj, h->d_flag);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-        break;
-    case HIPADJ_ALG_QUADRATURE: {
-        hipLaunchKernelGGL((k_bruss_quad_adj<G>), grid, blk, 0, h->stream, h->fg, p, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, h->d_fadj, d_du0, h->d_flag);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-        hipLaunchKernelGGL((k_bruss_quad_gk<G, 128>), dim3((unsigned)h->N, (unsigned)h->nq), blk, 0, h->stream, h->fg, h->Npad, p,
-                           (const double*)h->d_fknots, (const double*)h->d_fadj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
-        HIP_TRY(h, hipGetLastError());
-        const unsigned waves = (unsigned)(h->Npad / WAVE);
-        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
-        HIP_TRY(h, hipGetLastError());
-        break; }
-    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg not available for the PDE family");
-    }
-    hipLaunchKernelGGL((k_finish<0, 3>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
-                       (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, h->cfg.p_shared ? d_dp : (double*)nullptr);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(es.a1, h->stream));
-    es.pending = true;
-    return HIPADJ_OK;
-}
 #define DISPATCH_GRID(h, fn, ...)                                                          \
     switch ((h)->cfg.dims[0]) {                                                            \
     case 8: return fn<8>(__VA_ARGS__);                                                     \
@@ -585,62 +286,6 @@ template <int G> static int field_adjoint(hipadj_handle* h, const double* d_cot,
     case 32: return fn<32>(__VA_ARGS__);                                                   \
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "unsupported Brusselator grid %d", (h)->cfg.dims[0]); }
 
-
-// ---- FP64-MFMA family (MLP neural ODE) -----------------------------------------------------------------
-template <int H> static int mlp_forward_launch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
-    const int groups = h->cfg.p_shared ? 1 : (int)h->N;
-    hipLaunchKernelGGL(k_mlp_transpose_w2, dim3(64, (unsigned)groups), dim3(256), 0, h->stream, H, Mlp<H>::NPAR, H * 2 + H, d_p, h->d_w2t);
-    HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL((k_mlp_forward<H>), dim3((unsigned)(h->mg.B / 16), (unsigned)h->N), dim3(Mlp<H>::NT), 0, h->stream, h->mg, d_u0, d_p, (const double*)h->d_w2t,
-                       h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
-    HIP_TRY(h, hipGetLastError());
-    return HIPADJ_OK;
-}
-template <int H> static int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    constexpr int HP = Mlp<H>::HP;
-    const double* p = h->p_dev_last;
-    hipadj_handle::EvSet& es = h->evs[h->ev_next];
-    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
-    harvest_set(h, es, true);
-    HIP_TRY(h, hipEventRecord(es.a0, h->stream));
-    HIP_TRY(h, hipEventRecord(es.k0, h->stream));
-    MlpRec<H> R{h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2};
-    const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), blk(64), sweep_blk(Mlp<H>::NT);
-    if (h->cfg.alg == HIPADJ_ALG_GAUSS)
-        hipLaunchKernelGGL((k_mlp_adjoint<H, 2>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
-    else
-        hipLaunchKernelGGL((k_mlp_adjoint<H, 0>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-    const long groups = h->cfg.p_shared ? 1 : h->N;
-    const long Qper = (h->N * (long)h->S * h->NQ) / groups;
-    const int B = h->mg.B, ks = h->ksplit;
-    if (B % 64 == 0) {
-        const size_t lds1 = (size_t)HP * WG_PITCH * sizeof(double), lds2 = (size_t)16 * WG_PITCH * sizeof(double);
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_wgrad<H / 16 + 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64 * (H / 16)), lds1, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((k_mlp_wgrad<1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64 * (H / 16)), lds2, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64), lds1, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
-        HIP_TRY(h, hipGetLastError());
-    } else {   // batches that are not a multiple of 64 columns: 16-sample chunks straight from global memory
-        hipLaunchKernelGGL((k_mlp_wgrad_small<H / 16 + 1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((k_mlp_wgrad_small<1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((k_mlp_wgrad_small<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
-        HIP_TRY(h, hipGetLastError());
-    }
-    hipLaunchKernelGGL((k_mlp_wreduce<H>), dim3((Mlp<H>::NPAR + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, ks, (const double*)h->d_c1, (const double*)h->d_c2,
-                       (const double*)h->d_c3, d_dp);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(es.a1, h->stream));
-    es.pending = true;
-    return HIPADJ_OK;
-}
 #define DISPATCH_HIDDEN(h, fn, ...)                                                        \
     switch ((h)->cfg.dims[1]) {                                                            \
     case 32: return fn<32>(__VA_ARGS__);                                                   \
@@ -719,17 +364,20 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     return user_compile(cfg->model, exprs, code, low, err);
 }
 
-// launch of a module kernel.  `sig` is the SAME kernel template instantiated for a compiled-in model: it is never called,
-// it only lets the compiler check that the argument list handed to hipModuleLaunchKernel has exactly the kernel's
-// parameter types (a mismatch would otherwise be silent memory corruption on the device).
-template <class... P, class... A> static int ulaunch(void (*sig)(P...), hipadj_handle* h, hipFunction_t fn, dim3 g, dim3 b, A... args) {
-    (void)sig;
-    static_assert(sizeof...(P) == sizeof...(A), "argument count differs from the kernel's parameter list");
-    static_assert((std::is_same<P, A>::value && ...), "argument types differ from the kernel's parameter list");
-    void* ptrs[] = {(void*)&args...};
-    HIP_TRY(h, hipModuleLaunchKernel(fn, g.x, g.y, g.z, b.x, b.y, b.z, 0, h->stream, ptrs, nullptr));
-    return HIPADJ_OK;
-}
+// launch of a module kernel.  `Sig` is the type of the SAME kernel template instantiated for a compiled-in model
+// (`decltype(&k_interp<ModelLV, 8, 1>)`: unevaluated, so nothing is instantiated in this translation unit): it only lets the
+// compiler check that the argument list handed to hipModuleLaunchKernel has exactly the kernel's parameter types (a mismatch
+// would otherwise be silent memory corruption on the device).
+template <class Sig> struct usig;
+template <class... P> struct usig<void (*)(P...)> {
+    template <class... A> static int launch(hipadj_handle* h, hipFunction_t fn, dim3 g, dim3 b, A... args) {
+        static_assert(sizeof...(P) == sizeof...(A), "argument count differs from the kernel's parameter list");
+        static_assert((std::is_same<P, A>::value && ...), "argument types differ from the kernel's parameter list");
+        void* ptrs[] = {(void*)&args...};
+        HIP_TRY(h, hipModuleLaunchKernel(fn, g.x, g.y, g.z, b.x, b.y, b.z, 0, h->stream, ptrs, nullptr));
+        return HIPADJ_OK;
+    }
+};
 static_assert(std::is_same<decltype(&k_interp<ModelLV, 8, 1>), decltype(&k_gauss<ModelLV, 4, 1, false>)>::value, "k_interp / k_gauss share one launch site");
 
 static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
@@ -739,7 +387,7 @@ static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
         const bool sized = h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE;
         if (sized && h->ip_ckpt) h->ag.SmaxI = (int)h->rec_cap;
         for (int pass = 0; pass < 2; ++pass) {
-            TRY(ulaunch(&k_forward_tsit5<ModelLV>, h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
+            TRY(usig<decltype(&k_forward_tsit5<ModelLV>)>::launch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
                         (const double*)h->d_save_t, outT, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag));
             if (!sized) break;
             const int again = adaptive_autosize(h);
@@ -748,7 +396,7 @@ static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
         }
     }
     else
-        TRY(ulaunch(&k_forward<ModelLV>, h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
+        TRY(usig<decltype(&k_forward<ModelLV>)>::launch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
                     (const int*)h->d_save_of_knot, h->d_yT));
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
     return HIPADJ_OK;
@@ -768,12 +416,12 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     bool composed = false;
     if (h->adaptive) {
-        TRY(ulaunch(&k_adjoint_tsit5<ModelLV, 0, 0, false>, h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
+        TRY(usig<decltype(&k_adjoint_tsit5<ModelLV, 0, 0, false>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
                     (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, h->ntstops,
                     (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag, h->d_arec, h->d_nsteps_adj, h->SmaxA));
         if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-            TRY(ulaunch(&k_quad_gk_tsit5<ModelLV, 0>, h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
+            TRY(usig<decltype(&k_quad_gk_tsit5<ModelLV, 0>)>::launch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
                         (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres));
             hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
             HIP_TRY(h, hipGetLastError());
@@ -783,16 +431,16 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         const dim3 sgrid(waves, (unsigned)h->nseg);
         switch (h->cfg.alg) {
         case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:
-            TRY(ulaunch(&k_interp<ModelLV, 8, 1>, h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
+            TRY(usig<decltype(&k_interp<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
             composed = true; break;
         case HIPADJ_ALG_BACKSOLVE:
-            TRY(ulaunch(&k_backsolve<ModelLV, 0>, h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+            TRY(usig<decltype(&k_backsolve<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
                         (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
             composed = true; break;
         default: {
-            TRY(ulaunch(&k_quad_adj<ModelLV, 8, 1>, h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0));
+            TRY(usig<decltype(&k_quad_adj<ModelLV, 8, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0));
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-            TRY(ulaunch(&k_quad_gk<ModelLV, 0>, h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const dbl2*)h->d_adj, (const double*)h->d_qa,
+            TRY(usig<decltype(&k_quad_gk<ModelLV, 0>)>::launch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const dbl2*)h->d_adj, (const double*)h->d_qa,
                         (const double*)h->d_qb, atol, rtol, h->d_qres));
             hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
             HIP_TRY(h, hipGetLastError());
@@ -802,11 +450,11 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
     const bool seg_kernels = (1 + h->n) * (h->n + h->np) <= 64;
     if (composed && seg_kernels)
-        TRY(ulaunch(&k_compose_finish<ModelLV>, h, h->uf_tail, dim3(cblocks), dim3(FIN), h->g, h->nseg, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
+        TRY(usig<decltype(&k_compose_finish<ModelLV>)>::launch(h, h->uf_tail, dim3(cblocks), dim3(FIN), h->g, h->nseg, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     else if (composed)
-        TRY(ulaunch(&k_finish_map<2, 4>, h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
+        TRY(usig<decltype(&k_finish_map<2, 4>)>::launch(h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     else
-        TRY(ulaunch(&k_finish<2, 4>, h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)d_du0, (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
+        TRY(usig<decltype(&k_finish<2, 4>)>::launch(h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)d_du0, (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     if (h->cfg.p_shared) {
         hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)((composed && seg_kernels) ? cblocks : fblocks), h->np, (const double*)h->d_partial, d_dp);
         HIP_TRY(h, hipGetLastError());
@@ -824,7 +472,7 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
 // sequence is the same, so the second pass cannot overflow.  Lorenz at the default tolerances takes ~100 steps: 0.2 GB of
 // records for 10^4 trajectories instead of the 2.85 GB a fixed 2048-step bound reserves.
 // Returns 1 when the forward pass has to be repeated, 0 when it stands, a negative status on error.
-static int adaptive_autosize(hipadj_handle* h) {
+int adaptive_autosize(hipadj_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::vector<int> ns((size_t)h->Npad);
     HIP_TRY(h, hipMemcpy(ns.data(), h->d_nsteps, sizeof(int) * (size_t)h->Npad, hipMemcpyDeviceToHost));
@@ -850,87 +498,6 @@ static int adaptive_autosize(hipadj_handle* h) {
     return 1;
 }
 
-template <class Mo> static int adaptive_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
-    const unsigned waves = (unsigned)(h->Npad / WAVE);
-    const bool sized = h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE;
-    if (sized && h->ip_ckpt) h->ag.SmaxI = (int)h->rec_cap;
-    for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
-                           (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
-        HIP_TRY(h, hipGetLastError());
-        if (!sized) break;
-        const int again = adaptive_autosize(h);
-        if (again < 0) return again;
-        if (again == 0) break;
-    }
-    if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
-    return HIPADJ_OK;
-}
-template <class Mo, int ALG, int CC, bool CK = false> static int adaptive_adjoint_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    const unsigned waves = (unsigned)(h->Npad / WAVE);
-    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
-    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
-    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
-    hipadj_handle::EvSet& es = h->evs[h->ev_next];
-    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
-    harvest_set(h, es, true);
-    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
-    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
-    hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
-                       (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
-                       (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag,
-                       h->d_arec, h->d_nsteps_adj, h->SmaxA);
-    HIP_TRY(h, hipGetLastError());
-    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-    if constexpr (ALG == 3) {
-        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-        hipLaunchKernelGGL((k_quad_gk_tsit5<Mo, CC>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
-                           (const int*)h->d_nsteps, (const double*)h->d_arec, (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
-        HIP_TRY(h, hipGetLastError());
-    }
-    hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
-                       (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, (double*)nullptr);
-    HIP_TRY(h, hipGetLastError());
-    if (h->cfg.p_shared) {
-        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
-        HIP_TRY(h, hipGetLastError());
-    }
-    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
-    es.pending = h->timing >= 1; es.full = h->timing >= 2;
-    return HIPADJ_OK;
-}
-template <class Mo> static int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    if (h->ip_ckpt) {   // checkpointing=true for Interpolating / Gauss: per-interval re-solve inside the sweep
-        switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
-        case HIPADJ_ALG_INTERPOLATING * 4 + 0: return adaptive_adjoint_l<Mo, 0, 0, true>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_INTERPOLATING * 4 + 1: return adaptive_adjoint_l<Mo, 0, 1, true>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_INTERPOLATING * 4 + 2: return adaptive_adjoint_l<Mo, 0, 2, true>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0, true>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1, true>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return adaptive_adjoint_l<Mo, 4, 0, true>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return adaptive_adjoint_l<Mo, 4, 1, true>(h, d_cot, d_du0, d_dp);
-        default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no checkpointed adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
-        }
-    }
-    switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
-    case HIPADJ_ALG_INTERPOLATING * 4 + 0: return adaptive_adjoint_l<Mo, 0, 0>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_INTERPOLATING * 4 + 1: return adaptive_adjoint_l<Mo, 0, 1>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_INTERPOLATING * 4 + 2: return adaptive_adjoint_l<Mo, 0, 2>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_BACKSOLVE * 4 + 0: return adaptive_adjoint_l<Mo, 1, 0>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_BACKSOLVE * 4 + 1: return adaptive_adjoint_l<Mo, 1, 1>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_BACKSOLVE * 4 + 2: return adaptive_adjoint_l<Mo, 1, 2>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_QUADRATURE * 4 + 0: return adaptive_adjoint_l<Mo, 3, 0>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_QUADRATURE * 4 + 1: return adaptive_adjoint_l<Mo, 3, 1>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_QUADRATURE * 4 + 2: return adaptive_adjoint_l<Mo, 3, 2>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return adaptive_adjoint_l<Mo, 4, 0>(h, d_cot, d_du0, d_dp);
-    case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return adaptive_adjoint_l<Mo, 4, 1>(h, d_cot, d_du0, d_dp);
-    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
-    }
-}
 
 static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (h->user) return user_forward(h, d_u0, d_p, d_out);

@@ -1,0 +1,122 @@
+// hipadj_host.hpp — host-side state shared by the translation units of libhipadj.so: the handle, the error macros and the
+// small launch helpers.  The library is built from several translation units compiled in parallel (build.py): hipadj_api.hip
+// (C ABI, planning, runtime-compiled models) and one unit per kernel family / compiled-in model (hipadj_tu_*.hip), which
+// instantiate the launch sequences of hipadj_host_impl.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/hipadj.h"
+#include "hipadj_kernels.hpp"
+#include "hipadj_field.hpp"
+#include "hipadj_mlp.hpp"
+#include "hipadj_adaptive.hpp"
+
+using namespace hipadj;
+
+static constexpr int HIPADJ_AUTO_MAXITERS = 100000;   // max_steps == 0: the reference's default maxiters
+
+struct hipadj_handle {
+    hipadj_config cfg{};
+    int n = 0, np = 0;
+    long N = 0, Npad = 0;
+    int S = 0, M = 0, nck = 0, nseg = 1, nq = 0;
+    Geom g{};
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};            // forward begin/end
+    // adjoint timing: a ring of event sets harvested with hipEventQuery, so that back-to-back asynchronous
+    // calls never block the host on the previous call (a blocking harvest serialises launch and execution)
+    static constexpr int NSET = 16;
+    struct EvSet { hipEvent_t a0 = nullptr, a1 = nullptr, k0 = nullptr, k1 = nullptr; bool pending = false, full = true; } evs[NSET];
+    int ev_next = 0;
+    std::vector<double> save_times;
+    std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
+    // device workspaces (owned)
+    double *d_u0 = nullptr, *d_p = nullptr, *d_outT = nullptr, *d_yT = nullptr, *d_ckpt = nullptr, *d_cotT = nullptr;
+    double *d_segbuf = nullptr, *d_dp_traj = nullptr, *d_qres = nullptr, *d_qa = nullptr, *d_qb = nullptr, *d_partial = nullptr;
+    double *d_io_a = nullptr, *d_du0 = nullptr, *d_dp = nullptr;   // staging for the host-pointer API
+    dbl2 *d_knots = nullptr, *d_adj = nullptr;
+    bool field = false;                   // workgroup-per-trajectory family (BRUSS)
+    bool ip_ckpt = false;                 // Interpolating/Gauss checkpointing=true
+    double *d_fknots = nullptr, *d_fadj = nullptr;
+    bool mlp = false; int NQ = 0, ksplit = 1;
+    double *d_w2t = nullptr, *d_ax = nullptr, *d_al = nullptr, *d_ah1 = nullptr, *d_ah2 = nullptr, *d_ag1 = nullptr, *d_ag2 = nullptr;
+    double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
+    MlpGeom mg{};
+    FieldGeom fg{};
+    bool user = false;                    // runtime-compiled right-hand side (hipadj_user.hpp)
+    hipModule_t umod = nullptr;
+    hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish
+    bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
+    AdaptGeom ag{};
+    int cbs = 0;         // k_compose_finish workgroup size: 0 = by ensemble size, 64 / 256 forced (HIPADJ_CBS; tuning study)
+    bool wpb4 = false;   // k_interp in 256-thread workgroups (HIPADJ_WPB=4; tuning study)
+    double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr, *d_arec = nullptr;
+    int *d_nsteps = nullptr, *d_nsteps_adj = nullptr, ntstops = 0, SmaxA = 0;
+    bool auto_steps = false;              // max_steps == 0: record capacity sized from a counting pass of the forward solve
+    long rec_cap = 0;                     // accepted steps the record buffer(s) currently hold per trajectory
+    unsigned* d_ticket = nullptr;
+    int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
+    const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
+    bool have_forward = false, timing_pending_fwd = false;
+    int fused_final = 0;                  // 1: dp reduced in-launch by the last-arriving workgroup (HIPADJ_FUSED_FINAL)
+    int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)
+    double ws_bytes = 0;
+    hipadj_stats st{};
+    std::string err;
+};
+
+#define HIPADJ_FAIL(h, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (h)->err = _b; return (code); } while (0)
+#define HIP_TRY(h, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    HIPADJ_FAIL(h, HIPADJ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+
+template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
+    if (count == 0) { *p = nullptr; return HIPADJ_OK; }
+    HIP_TRY(h, hipMalloc((void**)p, count * sizeof(T)));
+    h->ws_bytes += (double)(count * sizeof(T));
+    return HIPADJ_OK;
+}
+#define TRY(expr) do { int _rc = (expr); if (_rc != HIPADJ_OK) return _rc; } while (0)
+
+static inline void harvest_set(hipadj_handle* h, hipadj_handle::EvSet& q, bool block) {
+    if (!q.pending) return;
+    hipEvent_t last = q.full ? q.a1 : q.k1;
+    if (block) { if (hipEventSynchronize(last) != hipSuccess) { q.pending = false; return; } }
+    else if (hipEventQuery(last) != hipSuccess) return;           // still running: look again later
+    float ms = 0.f;
+    if (q.full && hipEventElapsedTime(&ms, q.a0, q.a1) == hipSuccess) { h->st.adjoint_ms_last = ms; h->st.adjoint_ms_total += ms; }
+    if (hipEventElapsedTime(&ms, q.k0, q.k1) == hipSuccess) { h->st.adjoint_main_kernel_ms_last = ms; h->st.adjoint_main_kernel_ms_total += ms; }
+    q.pending = false;
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------------
+static inline int launch_transpose_to_soa(hipadj_handle* h, const double* src, double* dst, int C) {
+    dim3 blk(32, 8), grd((unsigned)((h->Npad + 31) / 32), (unsigned)((C + 31) / 32));
+    hipLaunchKernelGGL(k_aos_to_soa, grd, blk, 0, h->stream, src, dst, h->N, h->Npad, C);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+static inline int launch_transpose_to_aos(hipadj_handle* h, const double* src, double* dst, int C) {
+    dim3 blk(32, 8), grd((unsigned)((h->N + 31) / 32), (unsigned)((C + 31) / 32));
+    hipLaunchKernelGGL(k_soa_to_aos, grd, blk, 0, h->stream, src, dst, h->N, h->Npad, C);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+
+// ---- launch sequences per kernel family: defined in hipadj_host_impl.hpp, instantiated explicitly by the hipadj_tu_*.hip units
+template <class Mo> int forward_impl(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out);
+template <class Mo> int adjoint_impl(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp);
+template <class Mo> int adaptive_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out);
+template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp);
+template <int G> int field_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out);
+template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp);
+template <int H> int mlp_forward_launch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out);
+template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp);
+int adaptive_autosize(hipadj_handle* h);   // record capacity from the counting pass (max_steps == 0); defined in hipadj_api.hip

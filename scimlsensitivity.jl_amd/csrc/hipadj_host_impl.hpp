@@ -1,0 +1,339 @@
+// hipadj_host_impl.hpp — the launch sequences (host code) of every kernel family.  Included by the hipadj_tu_*.hip units only:
+// each unit explicitly instantiates the sequences of one compiled-in model / family, so that the device code of the families
+// compiles in parallel.
+#pragma once
+#include "hipadj_host.hpp"
+
+template <class Mo> int forward_impl(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    dbl2* knots = h->d_knots;
+    double* ck = h->d_ckpt;
+    hipLaunchKernelGGL((k_forward<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, d_u0, d_p, knots, ck,
+                       h->d_ckpt_of_knot, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, h->d_save_of_knot, h->d_yT);
+    HIP_TRY(h, hipGetLastError());
+    if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
+    return HIPADJ_OK;
+}
+
+template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    // software-prefetch depth, chosen so that each kernel keeps 2 waves per SIMD (<= 256 VGPRs): the cotangent ring
+    // and the Gauss-node state cost registers
+    constexpr int PF = (LOSS & 1) == 1 ? 8 : 6, PFG = 4;   // LOSS here = MODE = discrete-loss kind | (continuous cost << 1)
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    const double* p = h->p_dev_last;
+    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
+    const unsigned cblocks = (unsigned)((h->N + FIN / 4 - 1) / (FIN / 4));   // composition: 4 lanes per trajectory
+    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;   // per-trajectory dp rows [N][np]
+    double* dp_sum = (h->cfg.p_shared && h->fused_final) ? d_dp : (double*)nullptr;   // in-launch last-arriver reduction (optional)
+    // composition workgroups: 64 trajectories each, or 16 each while that still leaves the chip short of workgroups
+    // (10^4 trajectories: 625 instead of 157 workgroups, -1.7 us per reverse pass; profiles/README.md)
+    const bool small_blocks = h->cbs == 64 || (h->cbs == 0 && cblocks < 1024);
+    const unsigned compose_blocks = small_blocks ? (unsigned)((h->N + 15) / 16) : cblocks;
+    auto launch_compose = [&]() {
+        if (small_blocks)
+            hipLaunchKernelGGL((k_compose_finish<Mo, 64>), dim3(compose_blocks), dim3(64), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        else
+            hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(compose_blocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+    };
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);                   // ring full: only now wait for the oldest call
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
+    bool dispatch_events = false;               // k0/k1 ride on the kernel's dispatch packet instead (k_interp, below)
+    if (h->timing >= 1 && !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt)) HIP_TRY(h, hipEventRecord(k0, h->stream));
+    switch (h->cfg.alg) {
+    case HIPADJ_ALG_INTERPOLATING: {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        if (h->ip_ckpt)
+            hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+        else if (h->wpb4) {
+            // 256-thread workgroups, four (wave block, segment) items each: one wave per SIMD by construction (hipadj_kernels.hpp)
+            const unsigned items = waves * (unsigned)h->nseg;
+            hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS, true, 4>), dim3((items + 3) / 4), dim3(4 * WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+            dispatch_events = true;
+        } else if (h->timing >= 1) {
+            // the dominant kernel's own begin/end timestamps (events attached to the dispatch packet): what rocprofv3 reports
+            // as the kernel's duration.  A hipEventRecord pair around the launch also counts the two marker packets and the
+            // dispatch latency (+8-10 us on a 0.12 ms kernel).
+            hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, k0, k1, 0, h->g, sp, p,
+                                  (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+            dispatch_events = true;
+        } else
+        hipLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p,
+                           (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1 && !dispatch_events) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        launch_compose();
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    case HIPADJ_ALG_BACKSOLVE: {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        hipLaunchKernelGGL((k_backsolve<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
+                           (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
+                           (const int*)h->d_save_of_knot, h->d_segbuf);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        launch_compose();
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    case HIPADJ_ALG_GAUSS: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); } else {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        if (h->ip_ckpt)
+            hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+        else
+            hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
+                               (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        launch_compose();
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    case HIPADJ_ALG_GAUSS_KRONROD: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussKronrodAdjoint with dgdp_continuous is not offered"); } else {
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
+                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        launch_compose();
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    case HIPADJ_ALG_QUADRATURE: {
+        hipLaunchKernelGGL((k_quad_adj<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
+                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        hipLaunchKernelGGL((k_quad_gk<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
+                           (const dbl2*)h->d_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    }
+    // finishing stage: NaN/Inf scan + per-workgroup partial sums of mu (Interpolating fused it with the composition)
+    if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
+        hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
+                           (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->cfg.p_shared && !h->fused_final) {   // dp = sum over workgroup partials, fixed order
+        const unsigned nb = h->cfg.alg == HIPADJ_ALG_QUADRATURE ? fblocks : compose_blocks;
+        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)nb, h->np, (const double*)h->d_partial, d_dp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = h->timing >= 1; es.full = h->timing >= 2;
+    return HIPADJ_OK;   // timings are harvested lazily at the next synchronize / call
+}
+
+template <class Mo> int adjoint_impl(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    // no loss times => no cotangent buffer exists: run the LSQ specialisation (its jump select is never taken)
+    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);   // MODE = loss | cost << 1
+    switch (mode) {
+    case 0: return adjoint_impl_l<Mo, 0>(h, d_cot, d_du0, d_dp);
+    case 1: return adjoint_impl_l<Mo, 1>(h, d_cot, d_du0, d_dp);
+    case 2: return adjoint_impl_l<Mo, 2>(h, d_cot, d_du0, d_dp);
+    case 3: return adjoint_impl_l<Mo, 3>(h, d_cot, d_du0, d_dp);
+    case 4: return adjoint_impl_l<Mo, 4>(h, d_cot, d_du0, d_dp);
+    case 5: return adjoint_impl_l<Mo, 5>(h, d_cot, d_du0, d_dp);
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "cont_cost %d is not available for compiled-in models", h->cfg.cont_cost);
+    }
+}
+
+// ---- workgroup-per-trajectory family (Brusselator) -----------------------------------------------------
+template <int G> int field_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    hipLaunchKernelGGL((k_bruss_forward<G>), dim3((unsigned)h->N), dim3(Bruss<G>::T), 0, h->stream, h->fg, d_u0, d_p, h->d_fknots,
+                       (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    const double* p = h->p_dev_last;
+    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
+    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);
+    HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    const dim3 grid((unsigned)h->N), blk(Bruss<G>::T);
+    switch (h->cfg.alg) {
+    case HIPADJ_ALG_INTERPOLATING:
+        hipLaunchKernelGGL((k_bruss_adjoint<G, 0>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        break;
+    case HIPADJ_ALG_GAUSS:
+        hipLaunchKernelGGL((k_bruss_adjoint<G, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        break;
+    case HIPADJ_ALG_QUADRATURE: {
+        hipLaunchKernelGGL((k_bruss_quad_adj<G>), grid, blk, 0, h->stream, h->fg, p, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, h->d_fadj, d_du0, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        hipLaunchKernelGGL((k_bruss_quad_gk<G, 128>), dim3((unsigned)h->N, (unsigned)h->nq), blk, 0, h->stream, h->fg, h->Npad, p,
+                           (const double*)h->d_fknots, (const double*)h->d_fadj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
+        HIP_TRY(h, hipGetLastError());
+        const unsigned waves = (unsigned)(h->Npad / WAVE);
+        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg not available for the PDE family");
+    }
+    hipLaunchKernelGGL((k_finish<0, 3>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
+                       (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, h->cfg.p_shared ? d_dp : (double*)nullptr);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = true;
+    return HIPADJ_OK;
+}
+
+// ---- FP64-MFMA family (MLP neural ODE) -----------------------------------------------------------------
+template <int H> int mlp_forward_launch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    const int groups = h->cfg.p_shared ? 1 : (int)h->N;
+    hipLaunchKernelGGL(k_mlp_transpose_w2, dim3(64, (unsigned)groups), dim3(256), 0, h->stream, H, Mlp<H>::NPAR, H * 2 + H, d_p, h->d_w2t);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL((k_mlp_forward<H>), dim3((unsigned)(h->mg.B / 16), (unsigned)h->N), dim3(Mlp<H>::NT), 0, h->stream, h->mg, d_u0, d_p, (const double*)h->d_w2t,
+                       h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    constexpr int HP = Mlp<H>::HP;
+    const double* p = h->p_dev_last;
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);
+    HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    MlpRec<H> R{h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2};
+    const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), blk(64), sweep_blk(Mlp<H>::NT);
+    if (h->cfg.alg == HIPADJ_ALG_GAUSS)
+        hipLaunchKernelGGL((k_mlp_adjoint<H, 2>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
+    else
+        hipLaunchKernelGGL((k_mlp_adjoint<H, 0>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
+                           (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+    const long groups = h->cfg.p_shared ? 1 : h->N;
+    const long Qper = (h->N * (long)h->S * h->NQ) / groups;
+    const int B = h->mg.B, ks = h->ksplit;
+    if (B % 64 == 0) {
+        const size_t lds1 = (size_t)HP * WG_PITCH * sizeof(double), lds2 = (size_t)16 * WG_PITCH * sizeof(double);
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_wgrad<H / 16 + 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64 * (H / 16)), lds1, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_mlp_wgrad<1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64 * (H / 16)), lds2, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64), lds1, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
+        HIP_TRY(h, hipGetLastError());
+    } else {   // batches that are not a multiple of 64 columns: 16-sample chunks straight from global memory
+        hipLaunchKernelGGL((k_mlp_wgrad_small<H / 16 + 1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_mlp_wgrad_small<1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_mlp_wgrad_small<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL((k_mlp_wreduce<H>), dim3((Mlp<H>::NPAR + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, ks, (const double*)h->d_c1, (const double*)h->d_c2,
+                       (const double*)h->d_c3, d_dp);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = true;
+    return HIPADJ_OK;
+}
+
+template <class Mo> int adaptive_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    const bool sized = h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE;
+    if (sized && h->ip_ckpt) h->ag.SmaxI = (int)h->rec_cap;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
+                           (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        if (!sized) break;
+        const int again = adaptive_autosize(h);
+        if (again < 0) return again;
+        if (again == 0) break;
+    }
+    if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
+    return HIPADJ_OK;
+}
+template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    const unsigned waves = (unsigned)(h->Npad / WAVE);
+    const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
+    double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
+                       (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
+                       (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag,
+                       h->d_arec, h->d_nsteps_adj, h->SmaxA);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+    if constexpr (ALG == 3) {
+        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        hipLaunchKernelGGL((k_quad_gk_tsit5<Mo, CC>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
+                           (const int*)h->d_nsteps, (const double*)h->d_arec, (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
+                       (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, (double*)nullptr);
+    HIP_TRY(h, hipGetLastError());
+    if (h->cfg.p_shared) {
+        hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = h->timing >= 1; es.full = h->timing >= 2;
+    return HIPADJ_OK;
+}
+template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    if (h->ip_ckpt) {   // checkpointing=true for Interpolating / Gauss: per-interval re-solve inside the sweep
+        switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
+        case HIPADJ_ALG_INTERPOLATING * 4 + 0: return adaptive_adjoint_l<Mo, 0, 0, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_INTERPOLATING * 4 + 1: return adaptive_adjoint_l<Mo, 0, 1, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_INTERPOLATING * 4 + 2: return adaptive_adjoint_l<Mo, 0, 2, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return adaptive_adjoint_l<Mo, 4, 0, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return adaptive_adjoint_l<Mo, 4, 1, true>(h, d_cot, d_du0, d_dp);
+        default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no checkpointed adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
+        }
+    }
+    switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
+    case HIPADJ_ALG_INTERPOLATING * 4 + 0: return adaptive_adjoint_l<Mo, 0, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_INTERPOLATING * 4 + 1: return adaptive_adjoint_l<Mo, 0, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_INTERPOLATING * 4 + 2: return adaptive_adjoint_l<Mo, 0, 2>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 0: return adaptive_adjoint_l<Mo, 1, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 1: return adaptive_adjoint_l<Mo, 1, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_BACKSOLVE * 4 + 2: return adaptive_adjoint_l<Mo, 1, 2>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_QUADRATURE * 4 + 0: return adaptive_adjoint_l<Mo, 3, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_QUADRATURE * 4 + 1: return adaptive_adjoint_l<Mo, 3, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_QUADRATURE * 4 + 2: return adaptive_adjoint_l<Mo, 3, 2>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return adaptive_adjoint_l<Mo, 4, 0>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return adaptive_adjoint_l<Mo, 4, 1>(h, d_cot, d_du0, d_dp);
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
+    }
+}

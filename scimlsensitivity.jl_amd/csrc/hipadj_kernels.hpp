@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(FIN) k_finish_map(long Ntraj, long Npad, const
 }
 
 // dp[j] = sum over workgroup partials in block order (one workgroup per parameter)
-__global__ void __launch_bounds__(FIN) k_reduce_final(int nblocks, int np, const double* __restrict__ partial, double* __restrict__ dp) {
+static __global__ void __launch_bounds__(FIN) k_reduce_final(int nblocks, int np, const double* __restrict__ partial, double* __restrict__ dp) {
     __shared__ double sh[FIN];
     const int j = blockIdx.x;
     double s = 0.0;
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(WAVE) k_quad_gk(Geom g, const double* __restri
     for (int j = 0; j < NP; ++j) qres[((long)q * NP + j) * g.Npad + i] = res[j];
 }
 // res .+= quadgk(...) in the reference's order (src/quadrature_adjoint.jl:563-616)
-__global__ void __launch_bounds__(WAVE) k_quad_sum(long N, long Npad, int np, int nq, const double* __restrict__ qres,
+static __global__ void __launch_bounds__(WAVE) k_quad_sum(long N, long Npad, int np, int nq, const double* __restrict__ qres,
                                                    double* __restrict__ dp_traj) {
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= N) return;
@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(WAVE) k_quad_sum(long N, long Npad, int np, in
 
 // ---- utilities -------------------------------------------------------------------------------------------
 // AoS [N][C] (caller layout) -> SoA [C][Npad]; 32x32 LDS tile, +1 padding against bank conflicts
-__global__ void k_aos_to_soa(const double* __restrict__ src, double* __restrict__ dst, long N, long Npad, int C) {
+static __global__ void k_aos_to_soa(const double* __restrict__ src, double* __restrict__ dst, long N, long Npad, int C) {
     __shared__ double tile[32][33];
     const long i0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {
@@ -504,7 +504,7 @@ __global__ void k_aos_to_soa(const double* __restrict__ src, double* __restrict_
         if (c < C && i < Npad) dst[(long)c * Npad + i] = tile[threadIdx.x][r];
     }
 }
-__global__ void k_soa_to_aos(const double* __restrict__ src, double* __restrict__ dst, long N, long Npad, int C) {
+static __global__ void k_soa_to_aos(const double* __restrict__ src, double* __restrict__ dst, long N, long Npad, int C) {
     __shared__ double tile[32][33];
     const long i0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {

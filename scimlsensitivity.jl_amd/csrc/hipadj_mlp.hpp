@@ -217,7 +217,7 @@ __device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, con
 }
 
 // W2T[i + k*H] = W2[k + i*H]
-__global__ void k_mlp_transpose_w2(int H, int npar, int hd, const double* __restrict__ p, double* __restrict__ w2t) {
+static __global__ void k_mlp_transpose_w2(int H, int npar, int hd, const double* __restrict__ p, double* __restrict__ w2t) {
     const long traj = blockIdx.y;
     const double* W2 = p + traj * npar + hd;   // hd = H*D + H
     double* o = w2t + traj * (long)H * H;

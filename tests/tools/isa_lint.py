@@ -18,27 +18,41 @@ SPILL = ("v_accvgpr_write", "v_accvgpr_read", "scratch_store", "scratch_load", "
 
 
 def extract_gfx950(path):
+    """Every gfx950 code object of `path`: the file itself when it is a plain code object, else one temporary file per
+    clang offload bundle (a library linked from several translation units carries one bundle per unit)."""
     d = open(path, "rb").read()
-    i = d.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    if i < 0:
-        return path
-    n = struct.unpack_from("<Q", d, i + 24)[0]
-    off = i + 32
-    for _ in range(n):
-        o, sz, tl = struct.unpack_from("<QQQ", d, off)
-        off += 24
-        triple = d[off:off + tl]
-        off += tl
-        if b"gfx950" in triple:
-            f = tempfile.NamedTemporaryFile(suffix=".hsaco", delete=False)
-            f.write(d[i + o:i + o + sz])
-            f.close()
-            return f.name
-    raise RuntimeError("no gfx950 code object in " + path)
+    out, pos = [], 0
+    while True:
+        i = d.find(b"__CLANG_OFFLOAD_BUNDLE__", pos)
+        if i < 0:
+            break
+        n = struct.unpack_from("<Q", d, i + 24)[0]
+        off = i + 32
+        pos = i + 24
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", d, off)
+            off += 24
+            triple = d[off:off + tl]
+            off += tl
+            if b"gfx950" in triple and sz > 0:
+                f = tempfile.NamedTemporaryFile(suffix=".hsaco", delete=False)
+                f.write(d[i + o:i + o + sz])
+                f.close()
+                out.append(f.name)
+            pos = max(pos, i + o + sz)
+    if not out:
+        if d[:4] == b"\x7fELF" and b"__CLANG_OFFLOAD_BUNDLE__" not in d:
+            return [path]
+        raise RuntimeError("no gfx950 code object in " + path)
+    return out
+
+
+def disassemble(path):
+    return "\n".join(subprocess.check_output([OBJDUMP, "-d", "--no-show-raw-insn", co]).decode() for co in extract_gfx950(path))
 
 
 def lint(path):
-    txt = subprocess.check_output([OBJDUMP, "-d", "--no-show-raw-insn", extract_gfx950(path)]).decode()
+    txt = disassemble(path)
     kernels, cur = [], None
     for line in txt.split("\n"):
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
