@@ -22,13 +22,34 @@ from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, Interp
 _COSTS = {HalfSquaredSum: _lib.CCOST_HALF_SQ_SUM, FirstStateSquaredPlusFirstParam: _lib.CCOST_U1SQ_PLUS_P1, ModelCost: _lib.CCOST_MODEL}
 
 
-def _save_times(tspan, saveat, dt):
+def _save_times(tspan, saveat, dt, save_everystep=False, save_start=True, save_end=True):
+    """The times `ts` of the primal output / loss jumps, as the forward pass of _concrete_solve_adjoint forms them
+    (src/concrete_solve.jl:713-770):
+      saveat a number   ts = t0:saveat:T, and T appended when the span is not a multiple of saveat (fix_endpoints, :725, 2827-2831);
+                        save_start / save_end do not trim this list (the solve is dense and `out = sol(ts)`)
+      saveat a list     sorted(saveat) (:752)
+      saveat empty      every step of the forward solve (save_everystep), minus the first / last point for save_start = false /
+                        save_end = false (:740-750); fixed-step only here (an adaptive solve's step times are not known up front)
+    `saveat=None` without `save_everystep` means "no discrete loss" (a continuous cost only)."""
+    t0, t1 = float(tspan[0]), float(tspan[1])
     if saveat is None:
-        return np.zeros(0)
+        if not save_everystep:
+            return np.zeros(0)
+        if not dt:
+            raise ValueError("save_everystep without saveat needs the fixed step dt (RK4())")
+        ts = t0 + dt * np.arange(int(round((t1 - t0) / dt)) + 1)
+        ts[-1] = t1
+        return np.ascontiguousarray(ts[(0 if save_start else 1):(len(ts) if save_end else len(ts) - 1)])
     if np.isscalar(saveat):
-        m = int(round((tspan[1] - tspan[0]) / saveat))
-        return tspan[0] + saveat * np.arange(m + 1)
-    return np.ascontiguousarray(np.asarray(saveat, dtype=np.float64))
+        step = abs(float(saveat))
+        m = int(np.floor((t1 - t0) / step * (1.0 + 4e-16) + 1e-12))        # length of the range t0:step:T
+        ts = t0 + step * np.arange(m + 1)
+        if abs(ts[-1] - t1) <= 1e-12 * max(1.0, abs(t1)):
+            ts[-1] = t1
+        else:
+            ts = np.append(ts, t1)
+        return ts
+    return np.ascontiguousarray(np.sort(np.asarray(saveat, dtype=np.float64)))
 
 
 def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
@@ -53,7 +74,8 @@ def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
 
 
 def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
-          device=0, time_segments=0, no_start=False, want_out=True, g=None, abstol=1e-6, reltol=1e-3, max_steps=0, save_idxs=None):
+          device=0, time_segments=0, no_start=None, want_out=True, g=None, abstol=1e-6, reltol=1e-3, max_steps=0, save_idxs=None,
+          save_start=True, save_end=True, save_everystep=False):
     """Forward solve of an EnsembleProblem on the device.  The returned solution owns the device-resident
     interpolant tiles (Interpolating/Gauss/Quadrature) or checkpoints (Backsolve) the reverse pass consumes.
     `dgdu_discrete` may be given here already (LsqShift or None = cotangents) because the fused reverse kernel
@@ -62,7 +84,10 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     the reverse solve (src/sensitivity_interface.jl:432), `dt` is the optional initial-step hint, `saveat` may hold
     arbitrary ascending times, `max_steps` bounds the accepted steps per trajectory (0 = sized automatically by a counting pass of the forward solve).
     `save_idxs` (src/concrete_solve.jl:733-736, 774-824): only those state components appear in `sol.u`; cotangents handed to
-    adjoint_sensitivities then have that shape and the other components receive zero (`_out[_save_idxs] .= ...`)."""
+    adjoint_sensitivities then have that shape and the other components receive zero (`_out[_save_idxs] .= ...`).
+    `save_start` / `save_end` / `save_everystep`: the forward solve's saving flags as _concrete_solve_adjoint reads them
+    (`_save_times`); `no_start` defaults to the reference's `!save_start && t0 in ts` (src/concrete_solve.jl:962), which
+    suppresses the loss jump at t0."""
     adaptive = isinstance(alg, Tsit5)
     if not adaptive and not isinstance(alg, RK4):
         raise ValueError("alg must be RK4() (fixed step) or Tsit5() (adaptive)")
@@ -75,7 +100,9 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     if isinstance(ensprob, ODEProblem):
         ensprob = EnsembleProblem(ensprob, ensprob.u0[None, :])
     prob = ensprob.prob
-    ts = _save_times(prob.tspan, saveat, dt)
+    ts = _save_times(prob.tspan, saveat, dt, save_everystep, save_start, save_end)
+    if no_start is None:
+        no_start = (not save_start) and len(ts) > 0 and bool(np.any(np.abs(ts - prob.tspan[0]) <= 1e-12 * max(1.0, abs(prob.tspan[0]))))
     if g is not None and not isinstance(g, tuple(_COSTS)):
         raise ValueError("g must be a registered continuous cost (HalfSquaredSum(), FirstStateSquaredPlusFirstParam(), ModelCost()) or None")
     loss_kind, shift = (_lib.LOSS_LSQ_SHIFT, dgdu_discrete.shift) if isinstance(dgdu_discrete, LsqShift) else (_lib.LOSS_COTANGENT, 0.0)

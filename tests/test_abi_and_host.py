@@ -174,3 +174,24 @@ def test_runtime_model_plans_like_a_lane_model():
         assert rc in (_lib.OK, _lib.ERR_NO_DEVICE), L.hipadj_last_error(None)
         if rc == _lib.OK:
             L.hipadj_destroy(h)
+
+
+def test_save_times_follow_the_reference_saving_rules(sa):
+    """src/concrete_solve.jl:713-770: scalar saveat = the range t0:saveat:T with T appended when the span is not a multiple
+    (fix_endpoints); a list is sorted; an empty saveat = every step, trimmed by save_start / save_end."""
+    from scimlsensitivity_jl_amd.interface import _save_times
+    ts = _save_times((0.0, 10.0), 0.1, 0.01)
+    assert len(ts) == 101 and ts[0] == 0.0 and ts[-1] == 10.0 and np.allclose(np.diff(ts), 0.1)
+    ts = _save_times((0.0, 0.3), 0.1, 0.01)                      # 0.3 / 0.1 = 2.9999999999999996 in floating point
+    assert len(ts) == 4 and ts[-1] == 0.3
+    ts = _save_times((0.0, 1.0), 0.35, 0.01)                     # not a multiple: 0, .35, .7 and the end point
+    assert np.allclose(ts, [0.0, 0.35, 0.7, 1.0])
+    ts = _save_times((1.0, 2.0), [1.75, 1.25, 2.0], 0.01)
+    assert np.array_equal(ts, [1.25, 1.75, 2.0])
+    assert len(_save_times((0.0, 1.0), None, 0.01)) == 0         # no discrete loss
+    ts = _save_times((0.0, 1.0), None, 0.25, save_everystep=True)
+    assert np.array_equal(ts, [0.0, 0.25, 0.5, 0.75, 1.0])
+    assert np.array_equal(_save_times((0.0, 1.0), None, 0.25, True, False, True), [0.25, 0.5, 0.75, 1.0])
+    assert np.array_equal(_save_times((0.0, 1.0), None, 0.25, True, False, False), [0.25, 0.5, 0.75])
+    with pytest.raises(ValueError):
+        _save_times((0.0, 1.0), None, 0.0, save_everystep=True)
