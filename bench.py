@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--strong", action="store_true")
     ap.add_argument("--segments", type=int, default=0, help="time segments per trajectory (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--native-allreduce", action="store_true",
+                    help="N > 1: all-reduce dL/dp inside the C ABI (hipadj_comm_*: RCCL in-stream on the handle's stream) instead of torch.distributed")
     args = ap.parse_args()
 
     import torch
@@ -115,6 +117,9 @@ def main():
     eng = sa.Engine("lorenz", "interpolating", n_local, 0.0, T_FINAL, DT, save_times=ts, loss_kind=1, loss_shift=LOSS_SHIFT,
                     p_shared=True, device=local_rank, time_segments=args.segments)
     eng.use_torch_stream()
+    native = world > 1 and args.native_allreduce
+    if native:
+        sa.init_native_allreduce(eng)     # torch.distributed only ships the 128-byte RCCL id
     eng.set_timing(1)       # HIP events around the dominant kernel only (2 per step; the whole-call bracket costs ~8 us per step)
     u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
     p = torch.tensor(p_np, device=dev, dtype=torch.float64)
@@ -132,7 +137,7 @@ def main():
         # dp is double-buffered and the previous step's reduction is only waited for here
         dp = dps[state["it"] & 1]
         eng.adjoint_dev(None, du0, dp)
-        if world > 1:
+        if world > 1 and not native:
             if state["pending"] is not None:
                 state["pending"].wait()
             state["pending"] = dist.all_reduce(dp, op=dist.ReduceOp.SUM, async_op=True)
@@ -194,7 +199,8 @@ def main():
                                    f"InterpolatingAdjoint, fixed-step RK4 dt={DT}, tspan=(0,{T_FINAL}), loss times 0:{SAVE_DT}:{T_FINAL}, "
                                    f"dgdu = u - {LOSS_SHIFT} (BASELINE configs[1])",
                        "ntraj_total": n_total, "rk4_steps": S, "loss_times": len(ts),
-                       "time_segments": st1["time_segments"], "parallelism": f"ensemble-shard x{world}"},
+                       "time_segments": st1["time_segments"], "parallelism": f"ensemble-shard x{world}",
+                       "dp_allreduce": ("none" if world == 1 else "rccl in-stream (hipadj_comm)" if native else "torch.distributed nccl, async")},
             "ns_per_vjp_step": elapsed / args.steps / (n_total * S * 4.0) * 1e9,
             "forward_solve_ms": fwd_ms,
             "forward_plus_reverse_ms": (fwd_ms + ms_per_step) if fwd_ms is not None else None,

@@ -31,7 +31,8 @@ typedef enum {
     HIPADJ_ERR_NONFINITE = -4,    /* a trajectory produced NaN/Inf — the reference's retcode checks */
     HIPADJ_ERR_STATE = -5,        /* adjoint requested before forward */
     HIPADJ_ERR_UNSUPPORTED = -6,
-    HIPADJ_ERR_MAXITERS = -7      /* adaptive solve ran out of steps (max_steps) — the reference's ReturnCode.MaxIters */
+    HIPADJ_ERR_MAXITERS = -7,     /* adaptive solve ran out of steps (max_steps) — the reference's ReturnCode.MaxIters */
+    HIPADJ_ERR_RCCL = -8          /* RCCL missing or a collective failed (hipadj_comm_*) */
 } hipadj_status;
 
 /* compile-time model registry: device-inlined f, (df/du)^T lam, (df/dp)^T lam — the reference's user-VJP seam
@@ -193,6 +194,24 @@ int hipadj_synchronize(hipadj_handle *h);
 int hipadj_set_timing(hipadj_handle *h, int level);
 
 int hipadj_get_stats(hipadj_handle *h, hipadj_stats *stats);
+
+/* Sharded ensembles — replaces the reference's EnsembleDistributed pattern (test/Core4/distributed.jl, docs/src/tutorials/
+ * data_parallel.md:77-136: every worker solves its own trajectories, the outer loss sums them).  One process per GPU, one
+ * handle per process holding a contiguous trajectory range; trajectories never interact, so the ONLY exchange is the sum of
+ * dL/dp over the shards when p is shared.  A handle that carries a communicator all-reduces dp[np] over RCCL (xGMI inside a
+ * node) in-stream at the end of every hipadj_adjoint / hipadj_adjoint_dev call; du0 stays sharded.  RCCL is bound with dlopen
+ * at the first of these calls (a library already loaded by the process — torch's — is reused).
+ *   hipadj_comm_unique_id  rank 0: a fresh 128-byte id (ncclGetUniqueId) that the host ships to the other ranks by its own
+ *                          means (Julia Distributed, MPI, torch.distributed, a file)
+ *   hipadj_comm_init_rank  collective over the nranks processes: ncclCommInitRank on the handle's device; owned by the handle
+ *   hipadj_comm_attach     use an existing ncclComm_t of the host instead (not owned; NULL detaches)
+ *   hipadj_comm_destroy    drops the communicator (hipadj_destroy does it as well)
+ * Summation order depends on the shard count: compare results across shard counts at rtol 1e-12, not bitwise. */
+#define HIPADJ_COMM_ID_BYTES 128
+int hipadj_comm_unique_id(char *id /* [HIPADJ_COMM_ID_BYTES] */);
+int hipadj_comm_init_rank(hipadj_handle *h, const char *id /* [HIPADJ_COMM_ID_BYTES] */, int nranks, int rank);
+int hipadj_comm_attach(hipadj_handle *h, void *nccl_comm);
+int hipadj_comm_destroy(hipadj_handle *h);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ from .problems import (RK4, Tsit5, DeviceFunction, ODEProblem, EnsembleProblem, 
                        FirstStateSquaredPlusFirstParam, ModelCost)
 from .engine import Engine
 from .interface import solve, adjoint_sensitivities, concrete_solve_adjoint, make_autograd_function
-from .distributed import shard_range, allreduce_dp, gather_du0
+from .distributed import shard_range, allreduce_dp, gather_du0, comm_unique_id, init_native_allreduce
 from . import build as _build
 
 build_extension = _build.build
@@ -21,5 +21,5 @@ __all__ = [
     "AbstractAdjointSensitivityAlgorithm", "DeviceVJP", "InterpolatingAdjoint", "BacksolveAdjoint",
     "QuadratureAdjoint", "GaussAdjoint", "GaussKronrodAdjoint", "ischeckpointing", "RK4", "Tsit5", "DeviceFunction", "ODEProblem", "EnsembleProblem",
     "EnsembleSolution", "LsqShift", "HalfSquaredSum", "FirstStateSquaredPlusFirstParam", "ModelCost", "Engine", "solve", "adjoint_sensitivities", "concrete_solve_adjoint",
-    "make_autograd_function", "shard_range", "allreduce_dp", "gather_du0", "build_extension",
+    "make_autograd_function", "shard_range", "allreduce_dp", "gather_du0", "comm_unique_id", "init_native_allreduce", "build_extension",
 ]

@@ -6,7 +6,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libhipadj.so")
 
-OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NONFINITE, ERR_STATE, ERR_UNSUPPORTED, ERR_MAXITERS = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NONFINITE, ERR_STATE, ERR_UNSUPPORTED, ERR_MAXITERS, ERR_RCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8
+COMM_ID_BYTES = 128
 MODEL_USER_BASE = 1000
 
 MODEL = dict(lv=0, lvt=1, lorenz=2, lindiag=3, fallmass=4, mlp=5, bruss=6)
@@ -19,6 +20,7 @@ DECLARED_SYMBOLS = (
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
     "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_model_set_cost", "hipadj_model_set_cost_function",
+    "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
 )
 
 
@@ -96,6 +98,10 @@ def load():
     L.hipadj_model_check_config.argtypes = [C.POINTER(HipadjConfig)]
     L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_model_set_cost_function.argtypes = [C.c_int32, C.c_char_p]
+    L.hipadj_comm_unique_id.argtypes = [C.c_char_p]
+    L.hipadj_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.hipadj_comm_attach.argtypes = [vp, vp]
+    L.hipadj_comm_destroy.argtypes = [vp]
     _lib = L
     return L
 

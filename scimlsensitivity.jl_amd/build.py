@@ -39,6 +39,26 @@ def units():
     return u
 
 
+API_ONLY = {"hipadj_user.hpp", "hipadj_dual.hpp", "hipadj_comm.hpp", "hipadj_api.hip"}   # included by hipadj_api.hip alone
+
+
+def _stale(obj, src):
+    """An object is rebuilt when its source, a header it can see, hipadj.h or this script is newer."""
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    api = os.path.basename(src) == "hipadj_api.hip"
+    for d in DEPS:
+        b = os.path.basename(d)
+        if b.endswith(".hip") and d != src:
+            continue
+        if not api and b in API_ONLY:
+            continue
+        if os.path.exists(d) and os.path.getmtime(d) > t:
+            return True
+    return False
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -56,6 +76,8 @@ def build(force=False, verbose=False, jobs=None):
 
     def compile_unit(u):
         obj, src, extra = u
+        if not force and not _stale(os.path.join(OBJ, obj), os.path.join(CSRC, src)):
+            return os.path.join(OBJ, obj)
         cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(OBJ, obj)]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -5,6 +5,7 @@
 #include "hipadj_host.hpp"
 #include "hipadj_plan.hpp"
 #include "hipadj_user.hpp"
+#include "hipadj_comm.hpp"
 
 static thread_local std::string g_create_error;
 static int user_prepare(hipadj_handle* h);   // hiprtc compilation of the kernels of a runtime-registered model
@@ -21,6 +22,7 @@ extern "C" const char* hipadj_status_string(int s) {
     case HIPADJ_ERR_STATE: return "invalid call order (forward solve required first)";
     case HIPADJ_ERR_MAXITERS: return "adaptive solve exceeded max_steps";
     case HIPADJ_ERR_UNSUPPORTED: return "unsupported configuration";
+    case HIPADJ_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
     }
 }
@@ -227,10 +229,63 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     return HIPADJ_OK;
 }
 
+
+// ---- dL/dp all-reduce over RCCL (hipadj_comm.hpp) ---------------------------------------------------------------
+extern "C" int hipadj_comm_unique_id(char* id) {
+    if (!id) { g_create_error = "id == NULL"; return HIPADJ_ERR_INVALID_ARG; }
+    RcclApi& A = rccl_api();
+    if (!A.err.empty()) { g_create_error = A.err; return HIPADJ_ERR_RCCL; }
+    RcclUniqueId u;
+    const int rc = A.GetUniqueId(&u);
+    if (rc != 0) { g_create_error = rccl_error("ncclGetUniqueId", rc); return HIPADJ_ERR_RCCL; }
+    std::memcpy(id, u.internal, sizeof(u.internal));
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_comm_destroy(hipadj_handle* h) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->comm && h->comm_owned) {
+        (void)hipSetDevice(h->cfg.device);
+        (void)hipStreamSynchronize(h->stream);
+        const int rc = rccl_api().CommDestroy(h->comm);
+        h->comm = nullptr; h->comm_owned = false;
+        if (rc != 0) { h->err = rccl_error("ncclCommDestroy", rc); return HIPADJ_ERR_RCCL; }
+    }
+    h->comm = nullptr; h->comm_owned = false;
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_comm_init_rank(hipadj_handle* h, const char* id, int nranks, int rank) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_comm_init_rank: id != NULL and 0 <= rank < nranks required");
+    if (!h->cfg.p_shared) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "per-trajectory parameters (p_shared = 0) have no cross-shard reduction: dp stays sharded like du0");
+    RcclApi& A = rccl_api();
+    if (!A.err.empty()) { h->err = A.err; return HIPADJ_ERR_RCCL; }
+    TRY(hipadj_comm_destroy(h));
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    RcclUniqueId u;
+    std::memcpy(u.internal, id, sizeof(u.internal));
+    RcclComm c = nullptr;
+    const int rc = A.CommInitRank(&c, nranks, u, rank);   // collective over the nranks processes
+    if (rc != 0 || !c) { h->err = rccl_error("ncclCommInitRank", rc); return HIPADJ_ERR_RCCL; }
+    h->comm = c; h->comm_owned = true;
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_comm_attach(hipadj_handle* h, void* nccl_comm) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (nccl_comm && !h->cfg.p_shared) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "per-trajectory parameters (p_shared = 0) have no cross-shard reduction: dp stays sharded like du0");
+    if (nccl_comm) { RcclApi& A = rccl_api(); if (!A.err.empty()) { h->err = A.err; return HIPADJ_ERR_RCCL; } }
+    TRY(hipadj_comm_destroy(h));
+    h->comm = nccl_comm; h->comm_owned = false;
+    return HIPADJ_OK;
+}
+
 extern "C" int hipadj_destroy(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
+    (void)hipadj_comm_destroy(h);
     free_all(h);
     delete h;
     return HIPADJ_OK;
@@ -538,6 +593,10 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     harvest_timing(h, false);
     TRY(adjoint_dispatch(h, d_dLdu, d_du0, d_dp));
+    if (h->comm) {   // the one exchange of the sharded ensemble: dp = sum over the ranks' shards, in-stream
+        const int rc = rccl_api().AllReduce(d_dp, d_dp, (size_t)h->np, RCCL_DOUBLE, RCCL_SUM, h->comm, h->stream);
+        if (rc != 0) { h->err = rccl_error("ncclAllReduce", rc); return HIPADJ_ERR_RCCL; }
+    }
     h->st.adjoint_calls++;
     return HIPADJ_OK;
 }

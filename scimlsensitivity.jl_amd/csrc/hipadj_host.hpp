@@ -69,6 +69,8 @@ struct hipadj_handle {
     int fused_final = 0;                  // 1: dp reduced in-launch by the last-arriving workgroup (HIPADJ_FUSED_FINAL)
     int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)
     double ws_bytes = 0;
+    void* comm = nullptr;                 // ncclComm_t of the ensemble shards (hipadj_comm.hpp); dp is all-reduced over it
+    bool comm_owned = false;
     hipadj_stats st{};
     std::string err;
 };

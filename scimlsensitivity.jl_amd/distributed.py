@@ -42,3 +42,30 @@ def gather_du0(du0_local, n_total, group=None):
     bufs = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(bufs, pad, group=group)
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def comm_unique_id():
+    """A fresh RCCL unique id (128 bytes) from the library (hipadj_comm_unique_id): rank 0 calls this and ships the bytes."""
+    import ctypes as C
+    from . import _lib
+    buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    rc = _lib.load().hipadj_comm_unique_id(buf)
+    if rc != _lib.OK:
+        raise _lib.HipadjError(rc, _lib.load().hipadj_last_error(None).decode())
+    return buf.raw
+
+
+def init_native_allreduce(engine, group=None):
+    """Gives `engine` (this rank's shard) the library's own RCCL communicator over the ranks of the torch.distributed group:
+    torch.distributed only carries the 128-byte unique id from rank 0 to the others (any backend: gloo or nccl); afterwards
+    every engine.adjoint / adjoint_dev all-reduces dL/dp in-stream inside the C ABI and torch is not involved in the exchange
+    — the way a non-Python host (the Julia glue of INTEGRATION.md) runs the sharded path."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("torch.distributed is not initialised (it ships the unique id to the other ranks)")
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init_rank(box[0], ws, rank)
+    return engine

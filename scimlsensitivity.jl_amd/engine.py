@@ -104,6 +104,21 @@ class Engine:
         self._check(self._L.hipadj_adjoint_dev(self._h, C.c_void_p(dLdu.data_ptr()) if dLdu is not None else None,
                                                C.c_void_p(du0.data_ptr()), C.c_void_p(dp.data_ptr())))
 
+    # ---- sharded ensembles: dL/dp all-reduce over RCCL inside the library (include/hipadj.h, hipadj_comm_*) ----
+    def comm_init_rank(self, unique_id, nranks, rank):
+        """Collective: joins the RCCL communicator named by the 128-byte `unique_id` (comm_unique_id() of rank 0, shipped by the
+        host); from then on every adjoint call all-reduces dp over the ranks in-stream."""
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {_lib.COMM_ID_BYTES} bytes")
+        self._check(self._L.hipadj_comm_init_rank(self._h, C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES), int(nranks), int(rank)))
+
+    def comm_attach(self, nccl_comm):
+        """Use an existing ncclComm_t (integer address) of the host; None detaches."""
+        self._check(self._L.hipadj_comm_attach(self._h, C.c_void_p(nccl_comm)))
+
+    def comm_destroy(self):
+        self._check(self._L.hipadj_comm_destroy(self._h))
+
     def set_timing(self, level):
         """0: no device events, 1: dominant-kernel bracket only, 2: + whole-call bracket (default)."""
         self._check(self._L.hipadj_set_timing(self._h, int(level)))

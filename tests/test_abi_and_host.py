@@ -195,3 +195,17 @@ def test_save_times_follow_the_reference_saving_rules(sa):
     assert np.array_equal(_save_times((0.0, 1.0), None, 0.25, True, False, False), [0.25, 0.5, 0.75])
     with pytest.raises(ValueError):
         _save_times((0.0, 1.0), None, 0.0, save_everystep=True)
+
+
+def test_comm_entry_points_validate_and_bind_rccl_lazily(sa):
+    """hipadj_comm_* (include/hipadj.h): NULL handles / ids are rejected; the unique id comes from RCCL bound with dlopen
+    (no link-time dependency: `ldd libhipadj.so` does not list librccl)."""
+    import subprocess
+    L = sa.load_library()
+    assert L.hipadj_comm_unique_id(None) == -1 and L.hipadj_comm_init_rank(None, None, 1, 0) == -1
+    assert L.hipadj_comm_attach(None, None) == -1 and L.hipadj_comm_destroy(None) == -1
+    a, b = sa.comm_unique_id(), sa.comm_unique_id()
+    assert len(a) == 128 and a != b
+    assert L.hipadj_status_string(-8) == b"RCCL error"
+    needed = subprocess.check_output(["readelf", "-d", sa.LIB_PATH]).decode()
+    assert "rccl" not in needed and "hiprtc" not in needed

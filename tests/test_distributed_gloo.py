@@ -51,3 +51,38 @@ def test_two_rank_shard_and_allreduce_matches_single_process():
         pr.join(60)
         assert pr.exitcode == 0
     assert err_dp < 1e-13 and err_du0 == 0.0
+
+
+class _RecordingEngine:
+    """stands in for the device engine (which needs a GPU): records what init_native_allreduce hands to comm_init_rank"""
+    def comm_init_rank(self, unique_id, nranks, rank):
+        self.args = (bytes(unique_id), nranks, rank)
+
+
+def _worker_native_id(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import scimlsensitivity_jl_amd as sa
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = sa.init_native_allreduce(_RecordingEngine())
+    q.put(eng.args)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_allreduce_setup_ships_one_unique_id_to_every_rank():
+    """hipadj_comm_*: rank 0 draws the 128-byte RCCL id from the library, torch.distributed (gloo here) only carries it; every
+    rank then joins with (id, world, rank).  The communicator itself needs GPUs (GPU suite: single-rank communicator)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_native_id, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = sorted((q.get(timeout=180) for _ in range(2)), key=lambda a: a[2])
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert got[0][0] == got[1][0] and len(got[0][0]) == 128 and any(got[0][0])
+    assert [g[1:] for g in got] == [(2, 0), (2, 1)]
