@@ -71,10 +71,13 @@ def load():
             "This package has no CPU fallback.")
     # torch ships its own HIP runtime: when torch is going to be used for device memory / streams it must
     # initialise first, otherwise the process ends up with a second runtime that sees no GPU.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # HIPADJ_NO_TORCH=1: a host without torch in the process (what the Julia glue would be): libhipadj.so then runs on the HIP
+    # runtime / hiprtc / RCCL of the ROCm installation alone.
+    if os.environ.get("HIPADJ_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     dp, vp = C.POINTER(C.c_double), C.c_void_p
     L.hipadj_version.restype = C.c_int
