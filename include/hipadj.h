@@ -94,7 +94,11 @@ typedef struct {
     double t0, t1, dt;         /* tspan; RK4: fixed step, (t1 - t0)/dt must be an integer number of steps S;
                                   Tsit5: initial step (<= 0: automatic) */
     int32_t nsave;             /* M loss/save times */
-    const double *save_times;  /* [M] ascending, each on the step grid t0 + k*dt (copied at create) */
+    const double *save_times;  /* [M] strictly ascending inside [t0, t1] (copied at create).  RK4: on the step grid t0 + k*dt; off-grid
+                                  times are accepted for HIPADJ_ALG_INTERPOLATING without checkpointing on the compiled-in
+                                  lane models (the reverse solve stops at them like the reference's PresetTimeCallback tstops,
+                                  src/adjoint_common.jl:848-855; out = sol(ts) is interpolated, src/concrete_solve.jl:718-727).
+                                  Tsit5: arbitrary times */
     int32_t loss_kind;         /* hipadj_loss */
     double loss_shift;
     int32_t checkpointing;     /* sensealg.checkpointing (Backsolve default true: sensitivity_algorithms.jl:260-265) */

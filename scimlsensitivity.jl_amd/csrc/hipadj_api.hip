@@ -71,7 +71,7 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->umod) (void)hipModuleUnload(h->umod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -181,6 +181,17 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_seg_bounds, (size_t)h->nseg + 1));
     A(dev_alloc(h, &h->d_flag, 1));
     A(dev_alloc(h, &h->d_ticket, 1));
+    h->offgrid = P.offgrid;
+    if (P.offgrid) {   // reverse step list of the off-grid sweep + the save times for out = sol(ts)
+        h->nrs = (int)P.rs_t.size(); h->rs_save_at_start = P.rs_save_at_start;
+        A(dev_alloc(h, &h->d_rs_t, (size_t)h->nrs)); A(dev_alloc(h, &h->d_rs_h, (size_t)h->nrs)); A(dev_alloc(h, &h->d_rs_te, (size_t)h->nrs));
+        A(dev_alloc(h, &h->d_rs_save, (size_t)h->nrs)); A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
+        if (rc == HIPADJ_OK && !(HT(hipMemcpy(h->d_rs_t, P.rs_t.data(), sizeof(double) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
+                                 HT(hipMemcpy(h->d_rs_h, P.rs_h.data(), sizeof(double) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
+                                 HT(hipMemcpy(h->d_rs_te, P.rs_te.data(), sizeof(double) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
+                                 HT(hipMemcpy(h->d_rs_save, P.rs_save.data(), sizeof(int) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
+                                 HT(hipMemcpy(h->d_save_t, P.save_times.data(), sizeof(double) * h->M, hipMemcpyHostToDevice), "memcpy"))) rc = HIPADJ_ERR_HIP;
+    }
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
         if (!h->field) A(dev_alloc(h, &h->d_adj, (size_t)S * 2 * n * Np));

@@ -69,6 +69,8 @@ struct hipadj_handle {
     int fused_final = 0;                  // 1: dp reduced in-launch by the last-arriving workgroup (HIPADJ_FUSED_FINAL)
     int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)
     double ws_bytes = 0;
+    bool offgrid = false;                 // fixed-step RK4 with loss times off the step grid: reverse step list on the device
+    double *d_rs_t = nullptr, *d_rs_h = nullptr, *d_rs_te = nullptr; int* d_rs_save = nullptr; int nrs = 0, rs_save_at_start = -1;
     void* comm = nullptr;                 // ncclComm_t of the ensemble shards (hipadj_comm.hpp); dp is all-reduced over it
     bool comm_owned = false;
     hipadj_stats st{};

@@ -11,6 +11,10 @@ template <class Mo> int forward_impl(hipadj_handle* h, const double* d_u0, const
     hipLaunchKernelGGL((k_forward<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, d_u0, d_p, knots, ck,
                        h->d_ckpt_of_knot, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, h->d_save_of_knot, h->d_yT);
     HIP_TRY(h, hipGetLastError());
+    if (h->offgrid && d_out && h->M > 0) {   // out = sol(ts) by interpolation: the save times are not knots
+        hipLaunchKernelGGL((k_out_offgrid<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, (const dbl2*)knots, (const double*)h->d_save_t, h->d_outT);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
     return HIPADJ_OK;
 }
@@ -44,7 +48,23 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
     bool dispatch_events = false;               // k0/k1 ride on the kernel's dispatch packet instead (k_interp, below)
-    if (h->timing >= 1 && !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt)) HIP_TRY(h, hipEventRecord(k0, h->stream));
+    if (h->timing >= 1 && (h->offgrid || !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt))) HIP_TRY(h, hipEventRecord(k0, h->stream));
+    if (h->offgrid) {   // loss times off the step grid (planner: InterpolatingAdjoint only): sequential sweep over the reverse step list
+        RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        hipLaunchKernelGGL((k_interp_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
+                           (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        HIP_TRY(h, hipGetLastError());
+        if (h->cfg.p_shared && !h->fused_final) {
+            hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
+            HIP_TRY(h, hipGetLastError());
+        }
+        if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+        es.pending = h->timing >= 1; es.full = h->timing >= 2;
+        return HIPADJ_OK;
+    }
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         SegPlan sp{h->nseg, h->d_seg_bounds};

@@ -173,6 +173,67 @@ HIPADJ_HD void cost_grad_p(const double (&y)[Mo::N], const double (&p)[Mo::NP], 
 //   lam' = -(df/du)^T lam - g_u , mu' = -(df/dp)^T lam  with y from the forward Hermite interpolant.
 // The cost term g_u does not depend on lam: it only drives the affine column (c = 0).
 // WITH_MU = false skips the parameter block (Quadrature integrates lambda only).
+// The step itself works on the forward state at its three stage times (y_hi at the start t_hi, y_mid, y_lo at the end t_lo
+// = t_hi - dt): adj_rk4_step below supplies them from two knots of the common grid, the off-grid sweep from general-theta
+// Hermite evaluations.
+template <class Mo, int NC, bool WITH_MU, int CC = 0>
+HIPADJ_HD void adj_rk4_stages(const double (&y_hi)[Mo::N], const double (&ymid)[Mo::N], const double (&y_lo)[Mo::N], const double (&pv)[Mo::NP],
+                              double t_hi, double t_mid, double t_lo, double dt, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    double gu1[N], gum[N], gu4[N];
+    if (CC) { cost_grad_u<Mo, CC>(y_hi, pv, t_hi, gu1); cost_grad_u<Mo, CC>(ymid, pv, t_mid, gum); cost_grad_u<Mo, CC>(y_lo, pv, t_lo, gu4); }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double V1[N], V2[N], V3[N], V4[N], l2[N], l3[N], l4[N];
+        Mo::vjp_u(V1, lam[c], y_hi, pv, t_hi);
+        if (CC && c == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) V1[j] += gu1[j]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) l2[j] = lam[c][j] + (0.5 * dt) * V1[j];
+        Mo::vjp_u(V2, l2, ymid, pv, t_mid);
+        if (CC && c == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) V2[j] += gum[j]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) l3[j] = lam[c][j] + (0.5 * dt) * V2[j];
+        Mo::vjp_u(V3, l3, ymid, pv, t_mid);
+        if (CC && c == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) V3[j] += gum[j]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) l4[j] = lam[c][j] + dt * V3[j];
+        Mo::vjp_u(V4, l4, y_lo, pv, t_lo);
+        if (CC && c == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) V4[j] += gu4[j]; }
+        if (WITH_MU) {
+            // mu' = -(df/dp)^T lam, RK4 weights 1:2:2:1.  (df/dp)^T lam is linear in lam and stages 2 and 3 share the
+            // same y (the Hermite midpoint) and t, so their two VJPs collapse into one on lam_2 + lam_3.
+            double W1[NP], W23[NP], W4[NP], l23[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) l23[j] = l2[j] + l3[j];
+            Mo::vjp_p(W1, lam[c], y_hi, pv, t_hi);
+            Mo::vjp_p(W23, l23, ymid, pv, t_mid);
+            Mo::vjp_p(W4, l4, y_lo, pv, t_lo);
+            if (cost_has_gp<CC>::value && c == 0) {   // dgrad -= g_p: like g_u it only drives the affine column; stages 2 and 3 share ymid
+                double gp1[NP], gpm[NP], gp4[NP];
+                cost_grad_p<Mo, CC>(y_hi, pv, t_hi, gp1); cost_grad_p<Mo, CC>(ymid, pv, t_mid, gpm); cost_grad_p<Mo, CC>(y_lo, pv, t_lo, gp4);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { W1[j] += gp1[j]; W23[j] += 2.0 * gpm[j]; W4[j] += gp4[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[c][j] = mu[c][j] + (dt / 6.0) * (W1[j] + 2.0 * W23[j] + W4[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[c][j] = lam[c][j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+    }
+}
+
+
+// The same step on the common grid: stage states from two knots (theta = 0, 1/2, 1).  Kept as its own copy of the stage
+// arithmetic — this is the body of the tuned streaming kernels, whose instruction schedule is not to move when the general
+// form above changes.
 template <class Mo, int NC, bool WITH_MU, int CC = 0>
 HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&pv)[Mo::NP], double t_lo, double dt,
                             double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
@@ -465,6 +526,104 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
     };
     if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, LOSS>(g, i, k_lo, k_hi, pv, *ck, cotT, save_of_knot, init, step);
     else reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot, init, step);
+}
+
+template <int N>
+HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double (&f0)[N], const double (&u1)[N], const double (&f1)[N], double (&y)[N]);
+
+// ------------------------------------------------------------------------------------------------
+// InterpolatingAdjoint with loss times OFF the step grid (fixed-step RK4, saveat not a multiple of dt — including the end
+// point that fix_endpoints appends, src/concrete_solve.jl:725, 2827-2831).  The reverse solve stops at every loss time
+// (PresetTimeCallback -> tstops, src/adjoint_common.jl:848-855): a step is cut short to land on the tstop and the solver
+// continues from there with the full dt, so below the first off-grid loss time the reverse steps no longer coincide with the
+// forward knots and every stage needs the general-theta Hermite value of the forward solution — possibly from two different
+// forward steps within one reverse step.
+//
+// The reverse step sequence depends on (t0, t1, dt, loss times) only, not on the trajectory: the planner (hipadj_plan.hpp)
+// builds it once on the host with the arithmetic of the oracle's `integrate` (dt = min(|dtcache|, |tstop - t|), snap within
+// 100 eps) and the lanes walk it in lockstep: uniform control flow, the knot cursor moves for all lanes of a wave at once.
+// Sequential in time (one column); the tuned streaming sweep with time segmentation serves the on-grid case.
+// ------------------------------------------------------------------------------------------------
+struct RevSteps {
+    const double* t;      // [n] start time of reverse step q
+    const double* h;      // [n] its length > 0 (the step runs from t[q] down to te[q])
+    const double* te;     // [n] end time (snapped onto the tstop it lands on)
+    const int* save;      // [n] loss time that fires at te[q] (jump after the step) or -1
+    int n;
+    int save_at_start;    // loss time equal to t1 (fires before the first step) or -1
+    double t_start;       // t1
+};
+
+// forward knots cur + 1 (hi), cur (lo) and the prefetched cur - 1 (nx) of one trajectory; times only ever decrease
+template <class Mo> struct KnotCursor { Knot<Mo> hi, lo, nx; int cur; };
+
+template <class Mo>
+HIPADJ_HD void cursor_init(const Geom& g, long i, const dbl2* __restrict__ knots, KnotCursor<Mo>& c) {
+    c.cur = g.S - 1;
+    load_knot<Mo>(knots, g.Npad, g.S, i, c.hi);
+    load_knot<Mo>(knots, g.Npad, g.S - 1, i, c.lo);
+    load_knot<Mo>(knots, g.Npad, g.S > 1 ? g.S - 2 : 0, i, c.nx);
+}
+// y = sol(tau) from the forward cubic-Hermite dense output; tau is the same for every lane of the wave
+template <class Mo>
+HIPADJ_HD void cursor_eval(const Geom& g, long i, const dbl2* __restrict__ knots, KnotCursor<Mo>& c, double tau, double (&y)[Mo::N]) {
+    int kk = (int)((tau - g.t0) / g.dt);
+    kk = kk < 0 ? 0 : (kk > g.S - 1 ? g.S - 1 : kk);
+    if (tau < g.t0 + kk * g.dt && kk > 0) --kk;   // roundoff of (tau - t0)/dt at a knot
+    while (c.cur > kk) {
+        c.hi = c.lo; c.lo = c.nx; --c.cur;
+        load_knot<Mo>(knots, g.Npad, c.cur > 0 ? c.cur - 1 : 0, i, c.nx);
+    }
+    const double th = (tau - (g.t0 + c.cur * g.dt)) / g.dt;
+    hermite<Mo::N>(th, g.dt, c.lo.u, c.lo.f, c.hi.u, c.hi.f, y);
+}
+
+template <class Mo, int MODE>   // MODE = discrete-loss kind | (continuous cost << 1)
+HIPADJ_HD void interp_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                   const double* __restrict__ cotT, const RevSteps& R, double (&lam)[1][Mo::N], double (&mu)[1][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+    KnotCursor<Mo> c; cursor_init<Mo>(g, i, knots, c);
+    double y_hi[N], y_mid[N], y_lo[N];
+    cursor_eval<Mo>(g, i, knots, c, R.t_start, y_hi);
+    auto jump = [&](int s, const double (&y)[N]) {   // lam += dgdu_discrete(y, p, t_s, s): cotangent column or u - shift
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[0][j] += (LOSS == 0) ? cotT[((long)s * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+    };
+    if (R.save_at_start >= 0) jump(R.save_at_start, y_hi);   // PresetTimeCallback fires at initialisation when T is a loss time
+#pragma unroll 1
+    for (int q = 0; q < R.n; ++q) {
+        const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
+        cursor_eval<Mo>(g, i, knots, c, tm, y_mid);
+        cursor_eval<Mo>(g, i, knots, c, te, y_lo);
+        adj_rk4_stages<Mo, 1, true, CC>(y_hi, y_mid, y_lo, pv, t, tm, te, hs, lam, mu);
+        const int s = R.save[q];
+        if (s >= 0) jump(s, y_lo);
+#pragma unroll
+        for (int j = 0; j < N; ++j) y_hi[j] = y_lo[j];
+    }
+}
+
+// out = sol(ts) at save times off the step grid (src/concrete_solve.jl:718-727): one Hermite evaluation per save time
+template <class Mo>
+HIPADJ_HD void out_offgrid_lane(const Geom& g, long i, const dbl2* __restrict__ knots, const double* __restrict__ save_t, double* __restrict__ outT) {
+    constexpr int N = Mo::N;
+    for (int s = 0; s < g.M; ++s) {
+        const double tau = save_t[s];
+        int kk = (int)((tau - g.t0) / g.dt);
+        kk = kk < 0 ? 0 : (kk > g.S - 1 ? g.S - 1 : kk);
+        if (tau < g.t0 + kk * g.dt && kk > 0) --kk;
+        Knot<Mo> lo, hi;
+        load_knot<Mo>(knots, g.Npad, kk, i, lo); load_knot<Mo>(knots, g.Npad, kk + 1, i, hi);
+        double y[N];
+        hermite<N>((tau - (g.t0 + kk * g.dt)) / g.dt, g.dt, lo.u, lo.f, hi.u, hi.f, y);
+#pragma unroll
+        for (int j = 0; j < N; ++j) outT[((long)s * N + j) * g.Npad + i] = y[j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

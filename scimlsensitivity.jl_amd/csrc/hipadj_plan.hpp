@@ -35,7 +35,41 @@ struct Plan {
     int SmaxI = 0;           // adaptive + checkpointing=true (Interpolating/Gauss): record capacity of ONE checkpoint interval
     std::vector<double> ck_times, tstops_desc;   // adaptive: checkpoint times (ascending), reverse tstops (descending)
     int NQ = 0;              // activation records per step (MLP)
+    // fixed-step RK4 with loss times off the step grid (InterpolatingAdjoint): the reverse step sequence, the same for every
+    // trajectory (hipadj_lane.hpp, interp_offgrid_lane)
+    bool offgrid = false;
+    std::vector<double> rs_t, rs_h, rs_te;
+    std::vector<int> rs_save;
+    int rs_save_at_start = -1;
 };
+
+// The reverse solve of the reference on a fixed step with tstops at the loss times [upstream-recall, restated from the oracle's
+// `integrate`]: dt = min(|dt|, |tstop - t|), a step whose remainder would be a roundoff sliver lands on the tstop, t snaps onto
+// the tstop within 100 eps, and after a stop the solver continues with the full dt.  save[q] = the loss time that fires at the
+// end of step q (PresetTimeCallback), honouring no_start (src/adjoint_common.jl:761).
+inline void plan_reverse_steps(const hipadj_config* cfg, Plan& P) {
+    const double EPS = 2.220446049250313e-16;
+    const std::vector<double>& st = P.save_times;
+    std::vector<double> ts(st.rbegin(), st.rend());     // descending = along the integration direction
+    ts.push_back(cfg->t0);
+    auto loss_at = [&](double t) { for (int i = 0; i < (int)st.size(); ++i) if (st[i] == t) return (cfg->no_start && i == 0) ? -1 : i; return -1; };
+    P.rs_t.clear(); P.rs_h.clear(); P.rs_te.clear(); P.rs_save.clear();
+    P.rs_save_at_start = loss_at(cfg->t1);
+    double t = cfg->t1;
+    size_t its = 0;
+    while (t > cfg->t0) {
+        while (its < ts.size() && -ts[its] <= -t + 100 * EPS * std::fmax(std::fabs(t), std::fabs(ts[its]))) ++its;
+        if (its >= ts.size()) break;
+        const double tstop = ts[its];
+        double d = -cfg->dt;
+        if (std::fabs(d) > std::fabs(tstop - t)) d = tstop - t;
+        if (std::fabs((t + d) - tstop) < 100 * EPS * std::fmax(std::fabs(t + d), std::fabs(tstop))) d = tstop - t;
+        double tnew = t + d;
+        if (std::fabs(tnew - tstop) < 100 * EPS * std::fmax(std::fabs(tnew), std::fabs(tstop))) tnew = tstop;
+        P.rs_t.push_back(t); P.rs_h.push_back(-d); P.rs_te.push_back(tnew); P.rs_save.push_back(loss_at(tnew));
+        t = tnew;
+    }
+}
 
 // runtime-registered models (ids >= HIPADJ_MODEL_USER_BASE, hipadj_user.hpp): sizes come from the registry
 typedef int (*plan_user_sizes_fn)(int32_t model, int32_t* n, int32_t* np);
@@ -178,9 +212,23 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     P.save_times.assign(cfg->save_times, cfg->save_times + cfg->nsave);
     for (int i = 0; i < cfg->nsave; ++i) {
         const double kr = (cfg->save_times[i] - cfg->t0) / cfg->dt; const long k = std::lround(kr);
-        if (k < 0 || k > S || std::fabs(kr - (double)k) > 1e-6) { err = "save_times must lie on the step grid t0 + k*dt within [t0, t1]"; return HIPADJ_ERR_INVALID_ARG; }
+        if (!(cfg->save_times[i] >= cfg->t0 - 1e-6 * cfg->dt && cfg->save_times[i] <= cfg->t1 + 1e-6 * cfg->dt)) { err = "save_times must lie inside [t0, t1]"; return HIPADJ_ERR_INVALID_ARG; }
         if (i > 0 && !(cfg->save_times[i] > cfg->save_times[i - 1])) { err = "save_times must be strictly ascending (duplicate event times are out of scope)"; return HIPADJ_ERR_INVALID_ARG; }
-        P.save_of_knot[k] = i;
+        if (k < 0 || k > S || std::fabs(kr - (double)k) > 1e-6) P.offgrid = true;
+        else P.save_of_knot[k] = i;
+    }
+    if (P.offgrid) {
+        // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
+        if (cfg->alg != HIPADJ_ALG_INTERPOLATING || cfg->checkpointing || P.field || P.mlp || P.user) {
+            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint (checkpointing = false) on the compiled-in lane-per-trajectory models; "
+                  "other sensealgs need times on the grid, or the adaptive stepper (arbitrary times)";
+            return HIPADJ_ERR_UNSUPPORTED; }
+        for (int i = 0; i < cfg->nsave; ++i) {   // the sweep takes the times literally; they must not leave the span
+            if (P.save_times[i] < cfg->t0) P.save_times[i] = cfg->t0;
+            if (P.save_times[i] > cfg->t1) P.save_times[i] = cfg->t1;
+        }
+        P.save_of_knot.assign(S + 1, -1);   // no fused select on the knots: jumps are driven by the reverse step list
+        plan_reverse_steps(cfg, P);
     }
     // checkpoints: BacksolveAdjoint only.  Interpolating/Gauss checkpointing re-solves, on this fixed grid,
     // bit-identical knots from the stored values; the dense tiles are kept instead.
@@ -202,7 +250,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     P.nseg = 1;
     const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
-    if (seg_alg) {
+    if (seg_alg && !P.offgrid) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n, np) : cfg->time_segments;
         if ((1 + n) * (n + np) > 64) P.nseg = 1;   // segment lanes would not fit the register file
         if (P.nseg > P.S) P.nseg = P.S;

@@ -85,6 +85,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     for (long i = 0; i < P.N; ++i)
         forward_lane<Mo>(g, i, u0, p, knots.empty() ? nullptr : knots.data(), ckpt.empty() ? nullptr : ckpt.data(),
                          P.ckpt_of_knot.data(), outT.data(), P.save_of_knot.data(), yT.data());
+    if (P.offgrid) for (long i = 0; i < P.N; ++i) out_offgrid_lane<Mo>(g, i, knots.data(), P.save_times.data(), outT.data());   // k_out_offgrid
     if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
     if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
     const double* cot = cotT.empty() ? nullptr : cotT.data();
@@ -92,6 +93,16 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     constexpr int KM = HIPADJ_CKPT_KMAX;
     switch (cfg->alg) {
     case HIPADJ_ALG_INTERPOLATING: {
+        if (P.offgrid) {   // k_interp_offgrid: loss times off the step grid, the planner's reverse step list
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            for (long i = 0; i < P.N; ++i) {
+                double lam[1][N], mu[1][NP];
+                interp_offgrid_lane<Mo, LOSS>(g, i, p, knots.data(), cot, RS, lam, mu);
+                for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
+                for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[0][j];
+            }
+            break;
+        }
         std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
         for (int seg = 0; seg < P.nseg; ++seg) for (long i = 0; i < P.N; ++i) {
             double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;

@@ -77,9 +77,8 @@ def test_no_cpu_fallback_without_device(sa):
 
 @pytest.mark.parametrize("kw,msg", [
     (dict(dt=0.03), "integer number of steps"),
-    (dict(save=[0.505]), "step grid"),
     (dict(save=[0.5, 0.5]), "strictly ascending"),
-    (dict(save=[1.5]), "step grid"),
+    (dict(save=[1.5]), "inside [t0, t1]"),
     (dict(ntraj=0), "ntraj"),
     (dict(dt=-0.1), "dt > 0"),
 ])
@@ -89,6 +88,17 @@ def test_planner_rejects_misuse(kw, msg):
     b = (C.c_int * 64)()
     rc = E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq))
     assert rc == -1 and msg in E.lib().emu_last_error().decode()
+
+
+def test_planner_offgrid_loss_times_build_the_reverse_step_list():
+    """Loss times off the step grid: accepted for InterpolatingAdjoint (one segment, reverse step list), unsupported elsewhere."""
+    nseg, nck, nq = C.c_int(), C.c_int(), C.c_int()
+    b = (C.c_int * 64)()
+    cfg = E.make_config("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, [0.505, 1.0], time_segments=4)
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 1
+    cfg = E.make_config("lorenz", "gauss", 4, 0.0, 1.0, 0.01, [0.505, 1.0])
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == -6
+    assert "off the step grid" in E.lib().emu_last_error().decode()
 
 
 def test_planner_segments_checkpoints_and_quadrature_intervals():

@@ -1072,3 +1072,32 @@ def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
     with pytest.raises(sa.HipadjError):
         sol.engine.comm_init_rank(sa.comm_unique_id(), 1, 0)
     sol.engine.close()
+
+
+@pytest.mark.parametrize("saveat", [0.35, [0.137, 0.4, 0.40499, 1.2345], [1.4999]])
+def test_offgrid_loss_times_interpolating(sa, saveat):
+    """Fixed-step RK4 with loss times off the step grid (saveat not a multiple of dt; scalar saveat = the range plus the end
+    point of fix_endpoints, src/concrete_solve.jl:725): k_interp_offgrid + k_out_offgrid against the oracle's generic
+    integrator with tstops.  Cotangent loss with per-trajectory parameters, then the fused LSQ loss with shared ones."""
+    rng = np.random.default_rng(21)
+    N, T, dt = 130, 1.5, 0.01
+    u0, p = lorenz_inputs(N)
+    prob = sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0)
+    sol = sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    ts = sol.t
+    assert ts[-1] <= T and (np.isscalar(saveat) is False or ts[-1] == T)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+    pN = p * (1 + 0.02 * rng.standard_normal((N, 3)))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0, pN), sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.InterpolatingAdjoint())
+    delta = rng.standard_normal(sol.u.shape)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=delta)
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT")
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pN, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+    with pytest.raises(sa.HipadjError, match="off the step grid"):
+        sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
