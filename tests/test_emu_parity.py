@@ -420,7 +420,7 @@ def test_rk4_ring4_matches_oracle(alg):
 OFFGRID_TS = [
     [0.0, 0.333, 0.71, 1.5],                 # off the grid in the middle, both end points
     [0.137, 0.4, 0.40499, 1.2345],           # neither end point; one on-grid time; two stops less than one step apart
-    np.append(np.arange(0.0, 1.5, 0.35), 1.5),   # saveat = 0.35: the range t0:saveat:T plus the end point of fix_endpoints
+    np.append(np.arange(0.0, 1.5, 0.333), 1.5),  # saveat = 0.333: the range t0:saveat:T plus the end point of fix_endpoints
     [1.4999],                                # a single stop one sliver below T
 ]
 

@@ -206,7 +206,9 @@ def test_errors_mirror_reference_misuse(sa):
     with pytest.raises(sa.HipadjError):
         sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.03, save_times=[0.5])      # non-integer step count
     with pytest.raises(sa.HipadjError):
-        sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, save_times=[0.505])    # off-grid loss time
+        sa.Engine("lorenz", "gauss", 4, 0.0, 1.0, 0.01, save_times=[0.505])            # off-grid loss time (Interpolating takes them)
+    with pytest.raises(sa.HipadjError):
+        sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, save_times=[0.5, 1.2])  # outside [t0, t1]
     e = sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, save_times=[0.5, 1.0])
     with pytest.raises(sa.HipadjError):
         e.adjoint(np.zeros((4, 2, 3)))                                                  # reverse before forward
@@ -1074,9 +1076,9 @@ def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
     sol.engine.close()
 
 
-@pytest.mark.parametrize("saveat", [0.35, [0.137, 0.4, 0.40499, 1.2345], [1.4999]])
+@pytest.mark.parametrize("saveat", [0.333, [0.137, 0.4, 0.40499, 1.2345], [1.4999]])
 def test_offgrid_loss_times_interpolating(sa, saveat):
-    """Fixed-step RK4 with loss times off the step grid (saveat not a multiple of dt; scalar saveat = the range plus the end
+    """Fixed-step RK4 with loss times off the step grid (saveat = 0.333 is not a multiple of dt; scalar saveat = the range plus the end
     point of fix_endpoints, src/concrete_solve.jl:725): k_interp_offgrid + k_out_offgrid against the oracle's generic
     integrator with tstops.  Cotangent loss with per-trajectory parameters, then the fused LSQ loss with shared ones."""
     rng = np.random.default_rng(21)
