@@ -392,6 +392,10 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
         return k;
     }
     k.forward = "hipadj::k_forward<" + U + ">";
+    if (h->offgrid) {   // loss times off the step grid (planner: InterpolatingAdjoint only); the `gk` slot carries the out = sol(ts) kernel
+        k.main_k = "hipadj::k_interp_offgrid<" + U + ", " + I(mode) + ">"; k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = finish;
+        return k;
+    }
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: k.main_k = "hipadj::k_interp<" + U + ", " + I(PF) + ", " + I(mode) + SG; k.tail = compose; break;
     case HIPADJ_ALG_BACKSOLVE: k.main_k = "hipadj::k_backsolve<" + U + ", " + I(cc) + SG; k.tail = compose; break;
@@ -422,7 +426,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     h.cfg = *cfg; h.cfg.save_times = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
-    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt;
+    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid;
     const UserKernels k = user_kernel_names(&h);
     std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
     if (!k.gk.empty()) exprs.push_back(k.gk);
@@ -464,6 +468,8 @@ static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
     else
         TRY(usig<decltype(&k_forward<ModelLV>)>::launch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
                     (const int*)h->d_save_of_knot, h->d_yT));
+    if (h->offgrid && outT)
+        TRY(usig<decltype(&k_out_offgrid<ModelLV>)>::launch(h, h->uf_gk, dim3(waves), dim3(WAVE), h->g, (const dbl2*)h->d_knots, (const double*)h->d_save_t, h->d_outT));
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
     return HIPADJ_OK;
 }
@@ -492,6 +498,9 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
             hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
             HIP_TRY(h, hipGetLastError());
         }
+    } else if (h->offgrid) {
+        RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        TRY(usig<decltype(&k_interp_offgrid<ModelLV, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj));
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         const dim3 sgrid(waves, (unsigned)h->nseg);

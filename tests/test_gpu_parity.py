@@ -1103,3 +1103,22 @@ def test_offgrid_loss_times_interpolating(sa, saveat):
     sol.engine.close()
     with pytest.raises(sa.HipadjError, match="off the step grid"):
         sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+
+
+@pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring6", "RING", (6, 0, 0, 0))])
+def test_offgrid_loss_times_runtime_models(sa, name, omodel, dims):
+    """The off-grid sweep compiled with hiprtc for models the library has never seen (3 and 6 states)."""
+    m = UM.ROBER if name == "rober" else UM.ring(dims[0])
+    f = _device_function(sa, name + "_runtime", m)
+    rng = np.random.default_rng(44)
+    N, T, dt = 70, 1.0, 0.01
+    n, npar = m["n"], m["np"]
+    u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar))
+    ts = np.array([0.0, 0.123, 0.5, 0.7777, 1.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint())
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem(omodel, alg="INTERPOLATING", stepper="RK4", dt=dt, t0=0, t1=T, save_times=ts, loss="COTANGENT", dims=dims)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
