@@ -396,6 +396,10 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
         k.main_k = "hipadj::k_interp_offgrid<" + U + ", " + I(mode) + ">"; k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = finish;
         return k;
     }
+    if (h->ip_ckpt) {   // checkpointing=true (Interpolating / Gauss): checkpoint tiles + in-kernel interval re-solve; the planner admits models whose segment columns fit the VGPRs
+        k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_INTERPOLATING ? "hipadj::k_interp_ckpt<" : "hipadj::k_gauss_ckpt<") + U + ", " + I(mode) + ">"; k.tail = compose;
+        return k;
+    }
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: k.main_k = "hipadj::k_interp<" + U + ", " + I(PF) + ", " + I(mode) + SG; k.tail = compose; break;
     case HIPADJ_ALG_BACKSOLVE: k.main_k = "hipadj::k_backsolve<" + U + ", " + I(cc) + SG; k.tail = compose; break;
@@ -449,6 +453,7 @@ template <class... P> struct usig<void (*)(P...)> {
     }
 };
 static_assert(std::is_same<decltype(&k_interp<ModelLV, 8, 1>), decltype(&k_gauss<ModelLV, 4, 1, false>)>::value, "k_interp / k_gauss share one launch site");
+static_assert(std::is_same<decltype(&k_interp_ckpt<ModelLV, 1>), decltype(&k_gauss_ckpt<ModelLV, 1>)>::value, "k_interp_ckpt / k_gauss_ckpt share one launch site");
 
 static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
@@ -504,6 +509,11 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         const dim3 sgrid(waves, (unsigned)h->nseg);
+        if (h->ip_ckpt) {
+            TRY(usig<decltype(&k_interp_ckpt<ModelLV, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck,
+                                                                   (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
+            composed = true;
+        } else
         switch (h->cfg.alg) {
         case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:
             TRY(usig<decltype(&k_interp<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));

@@ -241,7 +241,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }
         P.nck = c;
     }
-    if (P.ip_ckpt && P.user) { err = "checkpointing=true for Interpolating/Gauss is not offered for runtime-compiled models yet"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (P.ip_ckpt && P.user && (1 + n) * (n + np) > 64) {   // the checkpointed sweeps carry the 1 + n segment columns in VGPRs
+        err = "checkpointing=true for Interpolating/Gauss on the fixed step needs (1 + n)(n + np) <= 64 for a runtime-compiled model (wider models: the adaptive stepper)"; return HIPADJ_ERR_UNSUPPORTED; }
     P.prev_ck.assign(S + 1, 0);
     if (P.ip_ckpt) {
         int last = 0, longest = 0;

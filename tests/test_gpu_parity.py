@@ -1122,3 +1122,30 @@ def test_offgrid_loss_times_runtime_models(sa, name, omodel, dims):
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     sol.engine.close()
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+@pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring4", "RING", (4, 0, 0, 0))])
+def test_runtime_models_checkpointed_fixed_step(sa, name, omodel, dims, alg, oalg):
+    """InterpolatingAdjoint / GaussAdjoint(checkpointing=true) on the fixed step for runtime-registered models: checkpoint tiles +
+    in-kernel interval re-solve (k_interp_ckpt / k_gauss_ckpt through hiprtc), time-segmented; a model whose segment columns do not
+    fit the registers is refused."""
+    m = UM.ROBER if name == "rober" else UM.ring(dims[0])
+    f = _device_function(sa, name + "_runtime", m)
+    rng = np.random.default_rng(45)
+    N, T, dt = 70, 1.0, 0.01
+    n, npar = m["n"], m["np"]
+    u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar))
+    ts = np.arange(0, T + 1e-9, 0.1)
+    delta = rng.standard_normal((N, len(ts), n))
+    salg = sa.InterpolatingAdjoint(checkpointing=True) if alg == "interpolating" else sa.GaussAdjoint(checkpointing=True)
+    for segs in (1, 3):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=salg, time_segments=segs)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+        ref = O.Problem(omodel, alg=oalg, stepper="RK4", dt=dt, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=True, dims=dims)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+        assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+        sol.engine.close()
+    wide = _device_function(sa, "ring6_runtime", UM.ring(6))
+    with pytest.raises(sa.HipadjError, match="checkpointing=true"):
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem(wide, np.full(6, 0.5), (0, T), np.full(7, 0.5)), np.full((4, 6), 0.5)), sa.RK4(), dt=dt, saveat=ts, sensealg=salg)

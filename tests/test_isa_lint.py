@@ -74,3 +74,20 @@ def test_runtime_offgrid_kernels_compile_without_a_device(tmp_path, monkeypatch,
     assert "k_interp_offgrid" in txt and "k_out_offgrid" in txt
     for o in objs:
         assert isa_lint.lint(o) == []
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "gauss"])
+def test_runtime_checkpointed_fixed_step_kernels_compile_without_a_device(tmp_path, monkeypatch, alg):
+    """checkpointing=true on the fixed step for a runtime-registered model (k_interp_ckpt / k_gauss_ckpt through hiprtc)."""
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.ring(4)
+    name = f"ring4_ckpt_{alg}"
+    _lib.register_model(name, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+    cfg = E.make_config(name, alg, 53, 0.0, 0.5, 0.01, [0.0, 0.1, 0.2, 0.3, 0.4, 0.5], loss_kind=0, checkpointing=True)
+    L = _lib.load()
+    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+    objs = glob.glob(str(tmp_path / "*.hsaco"))
+    assert objs and ("k_interp_ckpt" if alg == "interpolating" else "k_gauss_ckpt") in "".join(isa_lint.disassemble(o) for o in objs)
+    for o in objs:
+        assert isa_lint.lint(o) == []
