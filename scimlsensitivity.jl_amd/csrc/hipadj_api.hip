@@ -71,7 +71,7 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->umod) (void)hipModuleUnload(h->umod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -148,6 +148,10 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
         if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
+        if (P.ip_ckpt && P.ck_longest > HIPADJ_CKPT_KMAX) {   // one re-solve tile [longest + 1][n][64] per (wave, segment) in HBM
+            h->gtile_stride = (long)(P.ck_longest + 1) * n * 64;
+            A(dev_alloc(h, &h->d_gtile, (size_t)h->gtile_stride * (size_t)(Np / 64) * (size_t)h->nseg));
+        }
     } else if (P.mlp) {
         h->mlp = true; h->field = false; h->NQ = P.NQ;
         const size_t Hh = cfg->dims[1], Bb = cfg->dims[2], Q = (size_t)h->N * S * P.NQ, HP = Hh + 16;
@@ -181,7 +185,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_seg_bounds, (size_t)h->nseg + 1));
     A(dev_alloc(h, &h->d_flag, 1));
     A(dev_alloc(h, &h->d_ticket, 1));
-    h->offgrid = P.offgrid;
+    h->offgrid = P.offgrid; h->ck_long = P.ck_longest > HIPADJ_CKPT_KMAX;
     if (P.offgrid) {   // reverse step list of the off-grid sweep + the save times for out = sol(ts)
         h->nrs = (int)P.rs_t.size(); h->rs_save_at_start = P.rs_save_at_start;
         A(dev_alloc(h, &h->d_rs_t, (size_t)h->nrs)); A(dev_alloc(h, &h->d_rs_h, (size_t)h->nrs)); A(dev_alloc(h, &h->d_rs_te, (size_t)h->nrs));
@@ -397,7 +401,7 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
         return k;
     }
     if (h->ip_ckpt) {   // checkpointing=true (Interpolating / Gauss): checkpoint tiles + in-kernel interval re-solve; the planner admits models whose segment columns fit the VGPRs
-        k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_INTERPOLATING ? "hipadj::k_interp_ckpt<" : "hipadj::k_gauss_ckpt<") + U + ", " + I(mode) + ">"; k.tail = compose;
+        k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_INTERPOLATING ? "hipadj::k_interp_ckpt<" : "hipadj::k_gauss_ckpt<") + U + ", " + I(mode) + (h->ck_long ? ", true>" : ", false>"); k.tail = compose;
         return k;
     }
     switch (h->cfg.alg) {
@@ -430,7 +434,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     h.cfg = *cfg; h.cfg.save_times = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
-    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid;
+    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX;
     const UserKernels k = user_kernel_names(&h);
     std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
     if (!k.gk.empty()) exprs.push_back(k.gk);
@@ -511,7 +515,7 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         const dim3 sgrid(waves, (unsigned)h->nseg);
         if (h->ip_ckpt) {
             TRY(usig<decltype(&k_interp_ckpt<ModelLV, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck,
-                                                                   (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
+                                                                   (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride));
             composed = true;
         } else
         switch (h->cfg.alg) {

@@ -69,6 +69,7 @@ struct hipadj_handle {
     int fused_final = 0;                  // 1: dp reduced in-launch by the last-arriving workgroup (HIPADJ_FUSED_FINAL)
     int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)
     double ws_bytes = 0;
+    double* d_gtile = nullptr; long gtile_stride = 0; bool ck_long = false;   // checkpoint intervals longer than HIPADJ_CKPT_KMAX: re-solve tiles in HBM
     bool offgrid = false;                 // fixed-step RK4 with loss times off the step grid: reverse step list on the device
     double *d_rs_t = nullptr, *d_rs_h = nullptr, *d_rs_te = nullptr; int* d_rs_save = nullptr; int nrs = 0, rs_save_at_start = -1;
     void* comm = nullptr;                 // ncclComm_t of the ensemble shards (hipadj_comm.hpp); dp is all-reduced over it

@@ -68,9 +68,12 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
-        if (h->ip_ckpt)
+        if (h->ip_ckpt && h->ck_long)
+            hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride);
+        else if (h->ip_ckpt)
             hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else if (h->wpb4) {
             // 256-thread workgroups, four (wave block, segment) items each: one wave per SIMD by construction (hipadj_kernels.hpp)
             const unsigned items = waves * (unsigned)h->nseg;
@@ -104,9 +107,12 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         break; }
     case HIPADJ_ALG_GAUSS: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
-        if (h->ip_ckpt)
+        if (h->ip_ckpt && h->ck_long)
+            hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride);
+        else if (h->ip_ckpt)
             hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else
             hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
                                (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);

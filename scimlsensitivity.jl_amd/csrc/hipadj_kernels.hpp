@@ -82,13 +82,16 @@ __global__ void __launch_bounds__(WAVE * WPB) k_interp(Geom g, SegPlan sp, const
 }
 
 // checkpointing=true variants: checkpoint tiles in HBM, interval re-solve tile in LDS ([step][component][lane])
-template <class Mo, int LOSS>
+// GT = true: checkpoint intervals longer than HIPADJ_CKPT_KMAX steps — the re-solve tile of a wave is a slice of an HBM scratch
+// buffer (gtile + wave * gtile_stride, same [step][component][lane] layout: 512 B rows, coalesced) instead of LDS.
+template <class Mo, int LOSS, bool GT = false>
 __global__ void __launch_bounds__(WAVE) k_interp_ckpt(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ ckpt,
                                                       const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
                                                       const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                                                      double* __restrict__ segbuf) {
+                                                      double* __restrict__ segbuf, double* __restrict__ gtile, long gtile_stride) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, KM = HIPADJ_CKPT_KMAX;
-    __shared__ double tile[(KM + 1) * N * WAVE];
+    __shared__ double tile_lds[GT ? 1 : (KM + 1) * N * WAVE];
+    double* tile = GT ? gtile + ((long)blockIdx.y * gridDim.x + blockIdx.x) * gtile_stride : tile_lds;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     const int seg = sp.nseg - 1 - (int)blockIdx.y;
     if (i >= g.N) return;
@@ -425,13 +428,14 @@ __global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double
     }
 }
 
-template <class Mo, int LOSS>
+template <class Mo, int LOSS, bool GT = false>
 __global__ void __launch_bounds__(WAVE) k_gauss_ckpt(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ ckpt,
                                                      const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,
                                                      const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                                                     double* __restrict__ segbuf) {
+                                                     double* __restrict__ segbuf, double* __restrict__ gtile, long gtile_stride) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP, KM = HIPADJ_CKPT_KMAX;
-    __shared__ double tile[(KM + 1) * N * WAVE];
+    __shared__ double tile_lds[GT ? 1 : (KM + 1) * N * WAVE];
+    double* tile = GT ? gtile + ((long)blockIdx.y * gridDim.x + blockIdx.x) * gtile_stride : tile_lds;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     const int seg = sp.nseg - 1 - (int)blockIdx.y;
     if (i >= g.N) return;

@@ -27,6 +27,7 @@ struct Plan {
     bool bs_ckpt = false;
     bool ip_ckpt = false;    // Interpolating/Gauss with checkpointing=true: checkpoint tiles + in-kernel interval re-solve
     std::vector<int> prev_ck; // largest checkpoint knot < k
+    int ck_longest = 0;      // longest checkpoint interval in steps (fixed-step checkpointed Interpolating/Gauss)
     bool field = false;      // workgroup-per-trajectory family (hipadj_field.hpp)
     bool mlp = false;        // FP64-MFMA family (hipadj_mlp.hpp)
     bool adaptive = false;   // adaptive Tsit5 (hipadj_adaptive.hpp)
@@ -247,7 +248,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (P.ip_ckpt) {
         int last = 0, longest = 0;
         for (long k = 1; k <= S; ++k) { P.prev_ck[k] = last; if (P.ckpt_of_knot[k] >= 0) { if ((int)k - last > longest) longest = (int)k - last; last = (int)k; } }
-        if (longest > HIPADJ_CKPT_KMAX) { err = "checkpoint interval longer than 16 steps: the re-solve tile would not fit the LDS budget"; return HIPADJ_ERR_UNSUPPORTED; }
+        P.ck_longest = longest;   // <= HIPADJ_CKPT_KMAX: the re-solve tile lives in LDS; longer intervals: a per-wave slice of an HBM scratch buffer
     }
     P.nseg = 1;
     const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));

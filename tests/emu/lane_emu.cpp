@@ -78,7 +78,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1;
     const long Np = P.Npad;
     std::vector<dbl2> knots((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) ? (size_t)(P.S + 1) * N * Np : 0);
-    std::vector<double> tile((size_t)(HIPADJ_CKPT_KMAX + 1) * N);
+    std::vector<double> tile((size_t)((P.ck_longest > HIPADJ_CKPT_KMAX ? P.ck_longest : HIPADJ_CKPT_KMAX) + 1) * N);   // LDS tile, or the HBM slice of k_*_ckpt<..., GT = true>
     std::vector<double> ckpt((P.bs_ckpt || P.ip_ckpt) ? (size_t)P.nck * N * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np);
     std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0);
     std::vector<double> dp_traj((size_t)NP * Np, 0.0);

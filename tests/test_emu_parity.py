@@ -126,12 +126,22 @@ def test_checkpointed_interpolating_gauss_resolve_tiles(alg, segments, stride):
         assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
 
 
-def test_checkpoint_interval_too_long_is_rejected():
-    import ctypes as C
-    cfg = E.make_config("lorenz", "interpolating", 2, 0.0, 1.0, 0.01, [0.5, 1.0], checkpointing=True)   # 50-step intervals
-    nseg, nck, nq = C.c_int(), C.c_int(), C.c_int(); b = (C.c_int * 8)()
-    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 8, C.byref(nck), C.byref(nq)) == -6
-    assert "checkpoint interval" in E.lib().emu_last_error().decode()
+@pytest.mark.parametrize("alg", ["interpolating", "gauss"])
+@pytest.mark.parametrize("segments", [1, 3])
+def test_long_checkpoint_intervals_resolve_through_the_hbm_tile(alg, segments):
+    """Checkpoints = the save times (the reference default, sol.t of the saveat solve): saveat = 0.5 on dt = 0.01 gives 50-step
+    intervals, longer than the LDS re-solve tile (HIPADJ_CKPT_KMAX = 16): the planner switches the tile to an HBM slice per wave
+    (k_interp_ckpt / k_gauss_ckpt <..., GT = true>); the emulation runs the same lane body with a tile of that size."""
+    rng = np.random.default_rng(19)
+    N, T, dt = 3, 2.0, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.array([0.0, 0.5, 1.0, 1.37, 2.0])                     # intervals of 50, 50, 37 and 63 steps
+    delta = rng.standard_normal((N, len(ts), 3))
+    cfg = E.make_config("lorenz", alg, N, 0.0, T, dt, ts, loss_kind=0, checkpointing=True, time_segments=segments)
+    du0, dp, out = E.forward_adjoint(cfg, 3, 3, u0, p, delta)
+    ref = O.Problem("LORENZ", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", checkpointing=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
 
 
 @pytest.mark.parametrize("segments", [2, 5, 0])

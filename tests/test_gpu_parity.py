@@ -1149,3 +1149,31 @@ def test_runtime_models_checkpointed_fixed_step(sa, name, omodel, dims, alg, oal
     wide = _device_function(sa, "ring6_runtime", UM.ring(6))
     with pytest.raises(sa.HipadjError, match="checkpointing=true"):
         sa.solve(sa.EnsembleProblem(sa.ODEProblem(wide, np.full(6, 0.5), (0, T), np.full(7, 0.5)), np.full((4, 6), 0.5)), sa.RK4(), dt=dt, saveat=ts, sensealg=salg)
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+def test_long_checkpoint_intervals_on_device(sa, alg, oalg):
+    """checkpointing=true with the reference's default checkpoints (= the save times) when those are sparse: 50-step intervals exceed
+    the LDS re-solve tile, the tiles move to an HBM slice per wave (k_*_ckpt<..., GT = true>).  Compiled-in and runtime models."""
+    rng = np.random.default_rng(46)
+    N, T, dt = 130, 2.0, 0.01
+    u0, p = lorenz_inputs(N)
+    ts = np.array([0.0, 0.5, 1.0, 1.37, 2.0])
+    delta = rng.standard_normal((N, len(ts), 3))
+    salg = sa.InterpolatingAdjoint(checkpointing=True) if alg == "interpolating" else sa.GaussAdjoint(checkpointing=True)
+    ref = O.Problem("LORENZ", alg=oalg, stepper="RK4", dt=dt, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    for segs in (1, 0):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=salg, time_segments=segs)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+        assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+        sol.engine.close()
+    m = UM.ROBER
+    f = _device_function(sa, "rober_runtime", m)
+    u0r = rng.uniform(0.3, 1.0, (N, 3)); pr = rng.uniform(0.4, 1.2, (N, 3))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0r[0], (0, T), pr[0]), u0r, pr), sa.RK4(), dt=dt, saveat=ts, sensealg=salg)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem("ROBER", alg=oalg, stepper="RK4", dt=dt, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0r, pr, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
