@@ -397,7 +397,7 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     }
     k.forward = "hipadj::k_forward<" + U + ">";
     if (h->offgrid) {   // loss times off the step grid (planner: InterpolatingAdjoint only); the `gk` slot carries the out = sol(ts) kernel
-        k.main_k = "hipadj::k_interp_offgrid<" + U + ", " + I(mode) + ">"; k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = finish;
+        k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_GAUSS ? "hipadj::k_gauss_offgrid<" : "hipadj::k_interp_offgrid<") + U + ", " + I(mode) + ">"; k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = finish;
         return k;
     }
     if (h->ip_ckpt) {   // checkpointing=true (Interpolating / Gauss): checkpoint tiles + in-kernel interval re-solve; the planner admits models whose segment columns fit the VGPRs
@@ -458,6 +458,7 @@ template <class... P> struct usig<void (*)(P...)> {
 };
 static_assert(std::is_same<decltype(&k_interp<ModelLV, 8, 1>), decltype(&k_gauss<ModelLV, 4, 1, false>)>::value, "k_interp / k_gauss share one launch site");
 static_assert(std::is_same<decltype(&k_interp_ckpt<ModelLV, 1>), decltype(&k_gauss_ckpt<ModelLV, 1>)>::value, "k_interp_ckpt / k_gauss_ckpt share one launch site");
+static_assert(std::is_same<decltype(&k_interp_offgrid<ModelLV, 1>), decltype(&k_gauss_offgrid<ModelLV, 1>)>::value, "k_interp_offgrid / k_gauss_offgrid share one launch site");
 
 static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);

@@ -49,8 +49,12 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
     bool dispatch_events = false;               // k0/k1 ride on the kernel's dispatch packet instead (k_interp, below)
     if (h->timing >= 1 && (h->offgrid || !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt))) HIP_TRY(h, hipEventRecord(k0, h->stream));
-    if (h->offgrid) {   // loss times off the step grid (planner: InterpolatingAdjoint only): sequential sweep over the reverse step list
+    if (h->offgrid) {   // loss times off the step grid (planner: Interpolating / Gauss): sequential sweep over the reverse step list
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        if (h->cfg.alg == HIPADJ_ALG_GAUSS) {
+            if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); }
+            else hipLaunchKernelGGL((k_gauss_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
+        } else
         hipLaunchKernelGGL((k_interp_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));

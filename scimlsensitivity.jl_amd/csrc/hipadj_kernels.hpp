@@ -467,6 +467,19 @@ __global__ void __launch_bounds__(WAVE) k_interp_offgrid(Geom g, RevSteps R, con
 #pragma unroll
     for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[0][j];
 }
+template <class Mo, int MODE>
+__global__ void __launch_bounds__(WAVE) k_gauss_offgrid(Geom g, RevSteps R, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                                        const double* __restrict__ cotT, double* __restrict__ du0, double* __restrict__ dp_traj) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    if (i >= g.N) return;
+    double lam[1][N], mu[1][NP];
+    gauss_offgrid_lane<Mo, MODE>(g, i, p, knots, cotT, R, lam, mu);
+#pragma unroll
+    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[0][j];
+}
 template <class Mo>
 __global__ void __launch_bounds__(WAVE) k_out_offgrid(Geom g, const dbl2* __restrict__ knots, const double* __restrict__ save_t, double* __restrict__ outT) {
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;

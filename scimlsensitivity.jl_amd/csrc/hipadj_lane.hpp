@@ -863,6 +863,61 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
     else reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot, init, step);
 }
 
+// GaussAdjoint with loss times off the step grid: the lambda-only sweep over the planner's reverse step list (see
+// interp_offgrid_lane) with the 2-point Gauss-Legendre rule of gauss_lane on every reverse step — lambda from the adjoint step's
+// Hermite interpolant, y from the forward dense output at the node times.  The five forward states of a step (start, node,
+// middle, node, end) are evaluated in descending time, which is the only order the knot cursor supports.
+template <class Mo, int MODE>
+HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                  const double* __restrict__ cotT, const RevSteps& R, double (&lam)[1][Mo::N], double (&mu)[1][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
+    const double xg = 0.5773502691896257645;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+    KnotCursor<Mo> c; cursor_init<Mo>(g, i, knots, c);
+    double y_hi[N], y_mid[N], y_lo[N], yg[2][N];
+    cursor_eval<Mo>(g, i, knots, c, R.t_start, y_hi);
+    auto jump = [&](int s, const double (&y)[N]) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[0][j] += (LOSS == 0) ? cotT[((long)s * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+    };
+    if (R.save_at_start >= 0) jump(R.save_at_start, y_hi);
+#pragma unroll 1
+    for (int q = 0; q < R.n; ++q) {
+        const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
+        const double th0 = 0.5 * (1.0 - xg), th1 = 0.5 * (1.0 + xg);       // theta along the adjoint step: 0 at t, 1 at te
+        cursor_eval<Mo>(g, i, knots, c, t - th0 * hs, yg[0]);
+        cursor_eval<Mo>(g, i, knots, c, tm, y_mid);
+        cursor_eval<Mo>(g, i, knots, c, t - th1 * hs, yg[1]);
+        cursor_eval<Mo>(g, i, knots, c, te, y_lo);
+        double lam_hi[N], d_hi[N], d_lo[N], V[N], guh[N], gul[N];
+        cost_grad_u<Mo, CC>(y_hi, pv, t, guh); cost_grad_u<Mo, CC>(y_lo, pv, te, gul);      // zero when CC == 0
+        Mo::vjp_u(V, lam[0], y_hi, pv, t);
+#pragma unroll
+        for (int j = 0; j < N; ++j) { lam_hi[j] = lam[0][j]; d_hi[j] = -(V[j] + (CC ? guh[j] : 0.0)); }       // fsalfirst of the adjoint step
+        adj_rk4_stages<Mo, 1, false, CC>(y_hi, y_mid, y_lo, pv, t, tm, te, hs, lam, mu);
+        Mo::vjp_u(V, lam[0], y_lo, pv, te);
+#pragma unroll
+        for (int j = 0; j < N; ++j) d_lo[j] = -(V[j] + (CC ? gul[j] : 0.0));                                   // fsallast
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+            const double th = qn == 0 ? th0 : th1;
+            double lg[N], W[NP];
+            hermite<N>(th, -hs, lam_hi, d_hi, lam[0], d_lo, lg);
+            Mo::vjp_p(W, lg, yg[qn], pv, t - th * hs);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[0][j] += (0.5 * hs) * W[j];
+        }
+        const int s = R.save[q];
+        if (s >= 0) jump(s, y_lo);
+#pragma unroll
+        for (int j = 0; j < N; ++j) y_hi[j] = y_lo[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // QuadratureAdjoint pass 1: lambda-only reverse RK4 "saved densely": per step k (from knot k+1 to k) the record
 //   adj[k] = ( lam_start (post-jump at k+1), dlam_start, lam_end (pre-jump at k), dlam_end )   4N doubles

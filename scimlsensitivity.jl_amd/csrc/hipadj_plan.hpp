@@ -220,8 +220,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (P.offgrid) {
         // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
-        if (cfg->alg != HIPADJ_ALG_INTERPOLATING || cfg->checkpointing || P.field || P.mlp) {
-            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint (checkpointing = false) on the lane-per-trajectory models; "
+        if ((cfg->alg != HIPADJ_ALG_INTERPOLATING && cfg->alg != HIPADJ_ALG_GAUSS) || cfg->checkpointing || P.field || P.mlp) {
+            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint and GaussAdjoint (checkpointing = false) on the lane-per-trajectory models; "
                   "other sensealgs need times on the grid, or the adaptive stepper (arbitrary times)";
             return HIPADJ_ERR_UNSUPPORTED; }
         for (int i = 0; i < cfg->nsave; ++i) {   // the sweep takes the times literally; they must not leave the span

@@ -142,6 +142,16 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         compose<Mo>(P, segbuf, du0, dp_traj);
         break; }
     case HIPADJ_ALG_GAUSS: {
+        if (P.offgrid) {   // k_gauss_offgrid
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            for (long i = 0; i < P.N; ++i) {
+                double lam[1][N], mu[1][NP];
+                gauss_offgrid_lane<Mo, LOSS>(g, i, p, knots.data(), cot, RS, lam, mu);
+                for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
+                for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[0][j];
+            }
+            break;
+        }
         std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
         for (int seg = 0; seg < P.nseg; ++seg) for (long i = 0; i < P.N; ++i) {
             double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;

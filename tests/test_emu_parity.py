@@ -435,9 +435,10 @@ OFFGRID_TS = [
 ]
 
 
+@pytest.mark.parametrize("alg", ["interpolating", "gauss"])
 @pytest.mark.parametrize("ts", OFFGRID_TS)
 @pytest.mark.parametrize("model,omodel,u0c,p", MODELS)
-def test_offgrid_loss_times_interpolating_matches_oracle(model, omodel, u0c, p, ts):
+def test_offgrid_loss_times_interpolating_matches_oracle(model, omodel, u0c, p, ts, alg):
     """Loss times off the step grid (fixed-step RK4): the reverse solve stops at each of them and continues with the full dt,
     so its steps leave the forward knots (interp_offgrid_lane + the planner's reverse step list) — against the oracle's generic
     integrator with tstops.  Cotangent and LSQ losses, per-trajectory parameters, no_start."""
@@ -448,15 +449,15 @@ def test_offgrid_loss_times_interpolating_matches_oracle(model, omodel, u0c, p, 
     u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
     pp = np.asarray(p) * (1 + 0.03 * rng.standard_normal((N, npar)))
     delta = rng.standard_normal((N, len(ts), n))
-    cfg = E.make_config(model, "interpolating", N, 0.0, T, dt, ts, loss_kind=0, p_shared=False)
+    cfg = E.make_config(model, alg, N, 0.0, T, dt, ts, loss_kind=0, p_shared=False)
     du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
-    ref = O.Problem(omodel, alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT")
+    ref = O.Problem(omodel, alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT")
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
     for ns in (False, True):
-        cfg = E.make_config(model, "interpolating", N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, no_start=ns)
+        cfg = E.make_config(model, alg, N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, no_start=ns)
         du0, dp, _ = E.forward_adjoint(cfg, n, npar, u0, np.asarray(p))
-        ref = O.Problem(omodel, alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, no_start=ns)
+        ref = O.Problem(omodel, alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, no_start=ns)
         rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, np.asarray(p))
         assert rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
 
@@ -470,7 +471,12 @@ def test_offgrid_loss_times_with_continuous_cost_and_rejections():
     ref = O.Problem("LV", alg="INTERPOLATING", stepper="RK4", t0=0, t1=1.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, cont_cost=1)
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
     assert rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
-    for alg, kw in (("gauss", {}), ("backsolve", dict(checkpointing=True)), ("quadrature", {}), ("interpolating", dict(checkpointing=True))):
+    cfg = E.make_config("lv", "gauss", 3, 0.0, 1.0, 0.01, ts, loss_kind=1, loss_shift=2.0, cont_cost=1)
+    du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
+    ref = O.Problem("LV", alg="GAUSS", stepper="RK4", t0=0, t1=1.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, cont_cost=1)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
+    for alg, kw in (("gausskronrod", {}), ("backsolve", dict(checkpointing=True)), ("quadrature", {}), ("interpolating", dict(checkpointing=True)), ("gauss", dict(checkpointing=True))):
         with pytest.raises(RuntimeError, match="off the step grid"):
             E.forward_adjoint(E.make_config("lv", alg, 3, 0.0, 1.0, 0.01, ts, loss_kind=1, loss_shift=2.0, **kw), 2, 4, u0, p)
     with pytest.raises(RuntimeError, match="inside"):

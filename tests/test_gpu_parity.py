@@ -206,7 +206,7 @@ def test_errors_mirror_reference_misuse(sa):
     with pytest.raises(sa.HipadjError):
         sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.03, save_times=[0.5])      # non-integer step count
     with pytest.raises(sa.HipadjError):
-        sa.Engine("lorenz", "gauss", 4, 0.0, 1.0, 0.01, save_times=[0.505])            # off-grid loss time (Interpolating takes them)
+        sa.Engine("lorenz", "quadrature", 4, 0.0, 1.0, 0.01, save_times=[0.505])       # off-grid loss time (Interpolating / Gauss take them)
     with pytest.raises(sa.HipadjError):
         sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, save_times=[0.5, 1.2])  # outside [t0, t1]
     e = sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, save_times=[0.5, 1.0])
@@ -1102,7 +1102,14 @@ def test_offgrid_loss_times_interpolating(sa, saveat):
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     sol.engine.close()
     with pytest.raises(sa.HipadjError, match="off the step grid"):
-        sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+        sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.QuadratureAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    # GaussAdjoint on the same off-grid times: lambda-only sweep + 2-point Gauss-Legendre rule per reverse step
+    sol = sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+    ref = O.Problem("LORENZ", alg="GAUSS", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
 
 
 @pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring6", "RING", (6, 0, 0, 0))])
