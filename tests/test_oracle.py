@@ -7,6 +7,7 @@ The reference (pure Julia) cannot run here, so the pins are:
   * self-checks of the restated upstream pieces (Tsit5 tableau, GK15 rule, RK4 order).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -214,3 +215,24 @@ def test_continuous_cost_matches_forward_sensitivity_gradient(alg, golden):
                    cont_cost=1, quad_abstol=1e-12, quad_reltol=1e-12)
     du0, dp, _ = pr.adjoint(g["u0"], g["p"])
     assert rel(du0, g["du0"]) < 1e-8 and rel(dp, g["dp"]) < 1e-8
+
+
+@pytest.mark.parametrize("alg", ["INTERPOLATING", "GAUSS"])
+def test_offgrid_fixed_step_gradient_converges_to_the_forward_sensitivity_gradient(alg):
+    """Loss times off the step grid on a fixed step: the reverse solve stops at them (tstops) and reads the forward solution
+    through its cubic-Hermite dense output.  Pinned against an independent scipy DOP853 forward-sensitivity gradient
+    (tests/golden/make_golden.py: the role ForwardDiff plays in the reference's tests, test/Core3/adjoint.jl:691-705, 741-747):
+    the error must fall at fourth order in dt — neither the shortened steps nor the interpolation may cost an order."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    u0, p, T = [1.0, 1.0], [1.5, 1.0, 3.0, 1.0], 2.0
+    ts = np.array([0.137, 0.4, 0.40499, 1.2345, 2.0])
+    rdu0, rdp, _ = mg.gradient(mg.lv, u0, np.array(p), (0.0, T), ts, lambda u, i: u - 2.0)
+    errs = []
+    for dt in (0.04, 0.02, 0.01):
+        pr = O.Problem("LV", alg=alg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+        du0, dp, _ = pr.adjoint(u0, p)
+        errs.append(max(rel(du0, rdu0), rel(dp, rdp)))
+    orders = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert errs[-1] < 1e-6 and np.all(orders > 3.3), (errs, orders)
