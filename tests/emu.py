@@ -15,9 +15,21 @@ _CSRC = os.path.join(_ROOT, "scimlsensitivity.jl_amd", "csrc")
 
 
 def build(force=False):
+    """Seven translation units (-DEMU_UNIT=0..6: entry points + one unit per model) compiled in parallel, then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("hipadj_lane.hpp", "hipadj_models.hpp", "hipadj_plan.hpp", "hipadj_adaptive.hpp")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _LIB, _SRC])
+        objdir = os.path.join(_HERE, "emu", "build")
+        os.makedirs(objdir, exist_ok=True)
+
+        def unit(k):
+            obj = os.path.join(objdir, f"unit{k}.o")
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-DEMU_UNIT={k}", "-c", _SRC, "-o", obj])
+            return obj
+        with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(unit, range(7)))
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-o", _LIB + ".tmp"] + objs)
+        os.replace(_LIB + ".tmp", _LIB)
     return _LIB
 
 

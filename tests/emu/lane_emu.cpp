@@ -296,8 +296,14 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
     }
 }
 
+// Build units (tests/emu.py compiles them in parallel): EMU_UNIT undefined = everything in one translation unit (the variant builds
+// of test_emu_parity.py); EMU_UNIT = 0 = the C entry points, the per-model dispatchers declared `extern template`;
+// EMU_UNIT = 1..6 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
+#ifndef EMU_UNIT
+#define EMU_UNIT -1
+#endif
 template <class Mo>
-static int dispatch_mode(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out) {
+int dispatch_mode(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out) {
     if (P.adaptive) return dispatch_adaptive<Mo>(cfg, P, u0, p, dLdu, du0, dp, out, nullptr);
     const int mode = ((cfg->loss_kind == HIPADJ_LOSS_COTANGENT && P.M > 0) ? 0 : 1) | (cfg->cont_cost << 1);
     switch (mode) {
@@ -311,6 +317,28 @@ static int dispatch_mode(const hipadj_config* cfg, const Plan& P, const double* 
     }
 }
 
+#if EMU_UNIT == 0
+extern template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<ModelLVT>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<ModelLorenz>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<ModelLinDiag>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<ModelFallMass>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuRing<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 1
+template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 2
+template int dispatch_mode<ModelLVT>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 3
+template int dispatch_mode<ModelLorenz>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 4
+template int dispatch_mode<ModelLinDiag>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 5
+template int dispatch_mode<ModelFallMass>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 6
+template int dispatch_mode<EmuRing<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#endif
+
+#if EMU_UNIT <= 0
 static std::string g_err;
 extern "C" const char* emu_last_error() { return g_err.c_str(); }
 
@@ -334,3 +362,4 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }
+#endif   // EMU_UNIT <= 0
