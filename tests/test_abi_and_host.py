@@ -219,3 +219,22 @@ def test_comm_entry_points_validate_and_bind_rccl_lazily(sa):
     assert L.hipadj_status_string(-8) == b"RCCL error"
     needed = subprocess.check_output(["readelf", "-d", sa.LIB_PATH]).decode()
     assert "rccl" not in needed and "hiprtc" not in needed
+
+
+def _build_host_demo(sa, tmp_path):
+    import subprocess
+    exe = str(tmp_path / "host_demo")
+    libdir = os.path.dirname(sa.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host_demo.c"),
+                           "-o", exe, "-L" + libdir, "-lhipadj", "-Wl,-rpath," + libdir, "-lm"])
+    return exe
+
+
+def test_c_host_compiles_against_the_header_and_fails_loudly_without_a_device(sa, tmp_path):
+    """include/hipadj.h is valid strict C99, every entry point the example uses links from libhipadj.so, and a plain C host gets
+    HIPADJ_ERR_NO_DEVICE with a message on a machine without a GPU (no CPU fallback)."""
+    import subprocess
+    sa.load_library()
+    exe = _build_host_demo(sa, tmp_path)
+    r = subprocess.run([exe, "8"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 100" in r.stdout

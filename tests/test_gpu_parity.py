@@ -1184,3 +1184,33 @@ def test_long_checkpoint_intervals_on_device(sa, alg, oalg):
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0r, pr, delta)
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     sol.engine.close()
+
+
+def test_c_host_demo_matches_oracle(sa, tmp_path):
+    """examples/host_demo.c: the C ABI driven from plain C (no Python in the loop): forward + InterpolatingAdjoint on a Lorenz
+    ensemble, and the same ensemble as two shards summed by hand; numbers against the oracle on the same LCG inputs."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, libdir = str(tmp_path / "host_demo"), os.path.dirname(sa.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "host_demo.c"),
+                           "-o", exe, "-L" + libdir, "-lhipadj", "-Wl,-rpath," + libdir, "-lm"])
+    N = 200
+    r = subprocess.run([exe, str(N)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    val = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.strip().split("\n")}
+    s, u0 = 20240601, np.empty((N, 3))
+
+    def lcg():
+        nonlocal s
+        s = (s * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return ((s >> 11) & ((1 << 53) - 1)) / float(1 << 53) - 0.5
+    for i in range(N):
+        u0[i] = [1.0 + 0.1 * lcg(), 0.1 * lcg(), 0.1 * lcg()]
+    p = np.array([10.0, 28.0, 8.0 / 3.0])
+    ts = np.array([0.1 * i for i in range(11)]); ts[10] = 1.0
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=1.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(val["dp"], rdp) < RTOL and rel(val["dp_shards"], rdp) < RTOL and rel(val["dp_shards"], val["dp"]) < 1e-12
+    assert rel(val["du0_first"], rdu0[0]) < RTOL and rel(val["du0_last"], rdu0[-1]) < RTOL and rel(val["out_last"], rout[-1, -1]) < RTOL
+    assert val["du0_shards_equal"][0] == 1
