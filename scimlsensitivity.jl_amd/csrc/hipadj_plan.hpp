@@ -53,7 +53,10 @@ inline void plan_reverse_steps(const hipadj_config* cfg, Plan& P) {
     const std::vector<double>& st = P.save_times;
     std::vector<double> ts(st.rbegin(), st.rend());     // descending = along the integration direction
     ts.push_back(cfg->t0);
-    auto loss_at = [&](double t) { for (int i = 0; i < (int)st.size(); ++i) if (st[i] == t) return (cfg->no_start && i == 0) ? -1 : i; return -1; };
+    auto loss_at = [&](double t) {   // the callback's time test (within 100 eps), honouring no_start for the first loss time
+        for (int i = 0; i < (int)st.size(); ++i)
+            if (std::fabs(st[i] - t) <= 100 * EPS * std::fmax(std::fabs(st[i]), std::fabs(t))) return (cfg->no_start && i == 0) ? -1 : i;
+        return -1; };
     P.rs_t.clear(); P.rs_h.clear(); P.rs_te.clear(); P.rs_save.clear();
     P.rs_save_at_start = loss_at(cfg->t1);
     double t = cfg->t1;

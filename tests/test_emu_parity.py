@@ -432,6 +432,7 @@ OFFGRID_TS = [
     [0.137, 0.4, 0.40499, 1.2345],           # neither end point; one on-grid time; two stops less than one step apart
     np.append(np.arange(0.0, 1.5, 0.333), 1.5),  # saveat = 0.333: the range t0:saveat:T plus the end point of fix_endpoints
     [1.4999],                                # a single stop one sliver below T
+    [0.2, 1.5 - 2e-16],                      # a loss time within roundoff of T: fires at initialisation, like the callback's time test
 ]
 
 
