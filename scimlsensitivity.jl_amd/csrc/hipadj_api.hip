@@ -71,7 +71,7 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->umod) (void)hipModuleUnload(h->umod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -144,7 +144,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     } else if (!P.field && !P.mlp) {
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
-        if (cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));
+        if ((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) || P.offgrid) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));   // off-grid Backsolve: the checkpoint states are interpolated from the knots
         if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
         if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
@@ -190,6 +190,11 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         h->nrs = (int)P.rs_t.size(); h->rs_save_at_start = P.rs_save_at_start;
         A(dev_alloc(h, &h->d_rs_t, (size_t)h->nrs)); A(dev_alloc(h, &h->d_rs_h, (size_t)h->nrs)); A(dev_alloc(h, &h->d_rs_te, (size_t)h->nrs));
         A(dev_alloc(h, &h->d_rs_save, (size_t)h->nrs)); A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
+        if (P.nck > 0) {   // Backsolve: checkpoint times + the slot that replaces y at the end of each reverse step
+            A(dev_alloc(h, &h->d_ck_t, (size_t)P.nck)); A(dev_alloc(h, &h->d_rs_ck, (size_t)h->nrs));
+            if (rc == HIPADJ_OK && !(HT(hipMemcpy(h->d_ck_t, P.ck_times.data(), sizeof(double) * P.nck, hipMemcpyHostToDevice), "memcpy") &&
+                                     HT(hipMemcpy(h->d_rs_ck, P.rs_ck.data(), sizeof(int) * h->nrs, hipMemcpyHostToDevice), "memcpy"))) rc = HIPADJ_ERR_HIP;
+        }
         if (rc == HIPADJ_OK && !(HT(hipMemcpy(h->d_rs_t, P.rs_t.data(), sizeof(double) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
                                  HT(hipMemcpy(h->d_rs_h, P.rs_h.data(), sizeof(double) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
                                  HT(hipMemcpy(h->d_rs_te, P.rs_te.data(), sizeof(double) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
@@ -397,7 +402,9 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     }
     k.forward = "hipadj::k_forward<" + U + ">";
     if (h->offgrid) {   // loss times off the step grid (planner: InterpolatingAdjoint only); the `gk` slot carries the out = sol(ts) kernel
-        k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_GAUSS ? "hipadj::k_gauss_offgrid<" : "hipadj::k_interp_offgrid<") + U + ", " + I(mode) + ">"; k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = finish;
+        if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE) k.main_k = "hipadj::k_backsolve_offgrid<" + U + ", " + I(cc) + ">";
+        else k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_GAUSS ? "hipadj::k_gauss_offgrid<" : "hipadj::k_interp_offgrid<") + U + ", " + I(mode) + ">";
+        k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = finish;
         return k;
     }
     if (h->ip_ckpt) {   // checkpointing=true (Interpolating / Gauss): checkpoint tiles + in-kernel interval re-solve; the planner admits models whose segment columns fit the VGPRs
@@ -479,7 +486,9 @@ static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
         TRY(usig<decltype(&k_forward<ModelLV>)>::launch(h, h->uf_forward, dim3(waves), dim3(WAVE), h->g, d_u0, d_p, h->d_knots, h->d_ckpt, (const int*)h->d_ckpt_of_knot, outT,
                     (const int*)h->d_save_of_knot, h->d_yT));
     if (h->offgrid && outT)
-        TRY(usig<decltype(&k_out_offgrid<ModelLV>)>::launch(h, h->uf_gk, dim3(waves), dim3(WAVE), h->g, (const dbl2*)h->d_knots, (const double*)h->d_save_t, h->d_outT));
+        TRY(usig<decltype(&k_out_offgrid<ModelLV>)>::launch(h, h->uf_gk, dim3(waves), dim3(WAVE), h->g, (const dbl2*)h->d_knots, (const double*)h->d_save_t, h->M, h->d_outT));
+    if (h->offgrid && h->d_ckpt)   // Backsolve: the checkpoint states at the (off-grid) checkpoint times
+        TRY(usig<decltype(&k_out_offgrid<ModelLV>)>::launch(h, h->uf_gk, dim3(waves), dim3(WAVE), h->g, (const dbl2*)h->d_knots, (const double*)h->d_ck_t, h->nck, h->d_ckpt));
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
     return HIPADJ_OK;
 }
@@ -509,7 +518,10 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
             HIP_TRY(h, hipGetLastError());
         }
     } else if (h->offgrid) {
-        RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
+            TRY(usig<decltype(&k_backsolve_offgrid<ModelLV, 0>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_cotT, d_du0, h->d_dp_traj));
+        else
         TRY(usig<decltype(&k_interp_offgrid<ModelLV, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj));
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};

@@ -71,7 +71,7 @@ struct hipadj_handle {
     double ws_bytes = 0;
     double* d_gtile = nullptr; long gtile_stride = 0; bool ck_long = false;   // checkpoint intervals longer than HIPADJ_CKPT_KMAX: re-solve tiles in HBM
     bool offgrid = false;                 // fixed-step RK4 with loss times off the step grid: reverse step list on the device
-    double *d_rs_t = nullptr, *d_rs_h = nullptr, *d_rs_te = nullptr; int* d_rs_save = nullptr; int nrs = 0, rs_save_at_start = -1;
+    double *d_rs_t = nullptr, *d_rs_h = nullptr, *d_rs_te = nullptr; int *d_rs_save = nullptr, *d_rs_ck = nullptr; int nrs = 0, rs_save_at_start = -1;
     void* comm = nullptr;                 // ncclComm_t of the ensemble shards (hipadj_comm.hpp); dp is all-reduced over it
     bool comm_owned = false;
     hipadj_stats st{};

@@ -12,7 +12,11 @@ template <class Mo> int forward_impl(hipadj_handle* h, const double* d_u0, const
                        h->d_ckpt_of_knot, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, h->d_save_of_knot, h->d_yT);
     HIP_TRY(h, hipGetLastError());
     if (h->offgrid && d_out && h->M > 0) {   // out = sol(ts) by interpolation: the save times are not knots
-        hipLaunchKernelGGL((k_out_offgrid<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, (const dbl2*)knots, (const double*)h->d_save_t, h->d_outT);
+        hipLaunchKernelGGL((k_out_offgrid<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, (const dbl2*)knots, (const double*)h->d_save_t, h->M, h->d_outT);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->offgrid && h->d_ckpt) {           // Backsolve: the checkpoint states at the (off-grid) checkpoint times
+        hipLaunchKernelGGL((k_out_offgrid<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, (const dbl2*)knots, (const double*)h->d_ck_t, h->nck, h->d_ckpt);
         HIP_TRY(h, hipGetLastError());
     }
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
@@ -50,8 +54,10 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     bool dispatch_events = false;               // k0/k1 ride on the kernel's dispatch packet instead (k_interp, below)
     if (h->timing >= 1 && (h->offgrid || !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt))) HIP_TRY(h, hipEventRecord(k0, h->stream));
     if (h->offgrid) {   // loss times off the step grid (planner: Interpolating / Gauss): sequential sweep over the reverse step list
-        RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->nrs, h->rs_save_at_start, h->cfg.t1};
-        if (h->cfg.alg == HIPADJ_ALG_GAUSS) {
+        RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
+            hipLaunchKernelGGL((k_backsolve_offgrid<Mo, (LOSS >> 1)>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
+        else if (h->cfg.alg == HIPADJ_ALG_GAUSS) {
             if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); }
             else hipLaunchKernelGGL((k_gauss_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
         } else

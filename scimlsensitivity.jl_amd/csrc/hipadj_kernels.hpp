@@ -480,11 +480,25 @@ __global__ void __launch_bounds__(WAVE) k_gauss_offgrid(Geom g, RevSteps R, cons
 #pragma unroll
     for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[0][j];
 }
-template <class Mo>
-__global__ void __launch_bounds__(WAVE) k_out_offgrid(Geom g, const dbl2* __restrict__ knots, const double* __restrict__ save_t, double* __restrict__ outT) {
+template <class Mo, int CC>
+__global__ void __launch_bounds__(WAVE) k_backsolve_offgrid(Geom g, RevSteps R, const double* __restrict__ p, const double* __restrict__ yT, const double* __restrict__ ckpt,
+                                                            const double* __restrict__ cotT, double* __restrict__ du0, double* __restrict__ dp_traj) {
+    constexpr int N = Mo::N, NP = Mo::NP;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= g.N) return;
-    out_offgrid_lane<Mo>(g, i, knots, save_t, outT);
+    double lam[1][N], mu[1][NP];
+    backsolve_offgrid_lane<Mo, CC>(g, i, p, yT, ckpt, cotT, R, lam, mu);
+#pragma unroll
+    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[0][j];
+}
+// sol(times[0..nt)) -> dst [nt][n][Npad]: the primal output at off-grid save times, or Backsolve's checkpoint states
+template <class Mo>
+__global__ void __launch_bounds__(WAVE) k_out_offgrid(Geom g, const dbl2* __restrict__ knots, const double* __restrict__ times, int nt, double* __restrict__ dst) {
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    if (i >= g.N) return;
+    out_offgrid_lane<Mo>(g, i, knots, times, nt, dst);
 }
 
 template <class Mo, int PF, int LOSS>

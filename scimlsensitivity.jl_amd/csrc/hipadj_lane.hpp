@@ -549,6 +549,7 @@ struct RevSteps {
     const double* h;      // [n] its length > 0 (the step runs from t[q] down to te[q])
     const double* te;     // [n] end time (snapped onto the tstop it lands on)
     const int* save;      // [n] loss time that fires at te[q] (jump after the step) or -1
+    const int* ck;        // [n] Backsolve: checkpoint slot whose stored forward state replaces y at te[q], or -1 (nullptr otherwise)
     int n;
     int save_at_start;    // loss time equal to t1 (fires before the first step) or -1
     double t_start;       // t1
@@ -608,11 +609,102 @@ HIPADJ_HD void interp_offgrid_lane(const Geom& g, long i, const double* __restri
     }
 }
 
+// BacksolveAdjoint with loss times off the step grid: z = [lam; mu; y] integrated backward over the planner's reverse step list
+// (no forward interpolant in the sweep: y is part of the state), y overwritten by the stored forward value at every checkpoint
+// time — the default checkpoints, sol.t of the saveat solve = t0, the save times, T (src/backsolve_adjoint.jl:132, 523-546), whose
+// values k_out_offgrid interpolated from the forward dense output — and the loss gradient evaluated at the (just overwritten)
+// backsolved y (src/adjoint_common.jl:765-767).  The stage arithmetic is backsolve_lane's, on a step of length hs.
+template <class Mo, int CC>
+HIPADJ_HD void backsolve_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const double* __restrict__ yT,
+                                      const double* __restrict__ ckpt, const double* __restrict__ cotT, const RevSteps& R,
+                                      double (&lam)[1][Mo::N], double (&mu)[1][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+    double y[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { lam[0][j] = 0.0; y[j] = yT[(long)j * g.Npad + i]; }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+    if (R.save_at_start >= 0) { double gl[N]; loss_grad<Mo>(g, i, R.save_at_start, cotT, y, gl);
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; }
+#pragma unroll 1
+    for (int q = 0; q < R.n; ++q) {
+        const double t_hi = R.t[q], dt = R.h[q], t_lo = R.te[q], t_mid = t_hi - 0.5 * dt;
+        double F1[N], F2[N], F3[N], F4[N], Y2[N], Y3[N], Y4[N];
+        Mo::f(F1, y, pv, t_hi);
+#pragma unroll
+        for (int j = 0; j < N; ++j) Y2[j] = y[j] - (0.5 * dt) * F1[j];
+        Mo::f(F2, Y2, pv, t_mid);
+#pragma unroll
+        for (int j = 0; j < N; ++j) Y3[j] = y[j] - (0.5 * dt) * F2[j];
+        Mo::f(F3, Y3, pv, t_mid);
+#pragma unroll
+        for (int j = 0; j < N; ++j) Y4[j] = y[j] - dt * F3[j];
+        Mo::f(F4, Y4, pv, t_lo);
+        double ls[N], V1[N], V2[N], V3[N], V4[N], W[NP], Wacc[NP], gu[N], gp[NP];
+        Mo::vjp_u(V1, lam[0], y, pv, t_hi); Mo::vjp_p(Wacc, lam[0], y, pv, t_hi);
+        if (CC) { cost_grad_u<Mo, CC>(y, pv, t_hi, gu);
+#pragma unroll
+            for (int j = 0; j < N; ++j) V1[j] += gu[j]; }
+        if (cost_has_gp<CC>::value) { cost_grad_p<Mo, CC>(y, pv, t_hi, gp);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) Wacc[j] += gp[j]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) ls[j] = lam[0][j] + (0.5 * dt) * V1[j];
+        Mo::vjp_u(V2, ls, Y2, pv, t_mid); Mo::vjp_p(W, ls, Y2, pv, t_mid);
+        if (CC) { cost_grad_u<Mo, CC>(Y2, pv, t_mid, gu);
+#pragma unroll
+            for (int j = 0; j < N; ++j) V2[j] += gu[j]; }
+        if (cost_has_gp<CC>::value) { cost_grad_p<Mo, CC>(Y2, pv, t_mid, gp);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) W[j] += gp[j]; }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+#pragma unroll
+        for (int j = 0; j < N; ++j) ls[j] = lam[0][j] + (0.5 * dt) * V2[j];
+        Mo::vjp_u(V3, ls, Y3, pv, t_mid); Mo::vjp_p(W, ls, Y3, pv, t_mid);
+        if (CC) { cost_grad_u<Mo, CC>(Y3, pv, t_mid, gu);
+#pragma unroll
+            for (int j = 0; j < N; ++j) V3[j] += gu[j]; }
+        if (cost_has_gp<CC>::value) { cost_grad_p<Mo, CC>(Y3, pv, t_mid, gp);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) W[j] += gp[j]; }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+#pragma unroll
+        for (int j = 0; j < N; ++j) ls[j] = lam[0][j] + dt * V3[j];
+        Mo::vjp_u(V4, ls, Y4, pv, t_lo); Mo::vjp_p(W, ls, Y4, pv, t_lo);
+        if (CC) { cost_grad_u<Mo, CC>(Y4, pv, t_lo, gu);
+#pragma unroll
+            for (int j = 0; j < N; ++j) V4[j] += gu[j]; }
+        if (cost_has_gp<CC>::value) { cost_grad_p<Mo, CC>(Y4, pv, t_lo, gp);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) W[j] += gp[j]; }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) Wacc[j] += W[j];
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[0][j] = lam[0][j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[0][j] = mu[0][j] + (dt / 6.0) * Wacc[j];
+#pragma unroll
+        for (int j = 0; j < N; ++j) y[j] = y[j] - (dt / 6.0) * (F1[j] + 2.0 * (F2[j] + F3[j]) + F4[j]);
+        const int c = R.ck ? R.ck[q] : -1;
+        if (c >= 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = ckpt[((long)c * N + j) * g.Npad + i]; }
+        const int sv = R.save[q];
+        if (sv >= 0) { double gl[N]; loss_grad<Mo>(g, i, sv, cotT, y, gl);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; }
+    }
+}
+
 // out = sol(ts) at save times off the step grid (src/concrete_solve.jl:718-727): one Hermite evaluation per save time
 template <class Mo>
-HIPADJ_HD void out_offgrid_lane(const Geom& g, long i, const dbl2* __restrict__ knots, const double* __restrict__ save_t, double* __restrict__ outT) {
+HIPADJ_HD void out_offgrid_lane(const Geom& g, long i, const dbl2* __restrict__ knots, const double* __restrict__ save_t, int nt, double* __restrict__ outT) {
     constexpr int N = Mo::N;
-    for (int s = 0; s < g.M; ++s) {
+    for (int s = 0; s < nt; ++s) {
         const double tau = save_t[s];
         int kk = (int)((tau - g.t0) / g.dt);
         kk = kk < 0 ? 0 : (kk > g.S - 1 ? g.S - 1 : kk);

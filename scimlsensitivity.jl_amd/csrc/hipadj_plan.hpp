@@ -40,7 +40,7 @@ struct Plan {
     // trajectory (hipadj_lane.hpp, interp_offgrid_lane)
     bool offgrid = false;
     std::vector<double> rs_t, rs_h, rs_te;
-    std::vector<int> rs_save;
+    std::vector<int> rs_save, rs_ck;
     int rs_save_at_start = -1;
 };
 
@@ -51,13 +51,18 @@ struct Plan {
 inline void plan_reverse_steps(const hipadj_config* cfg, Plan& P) {
     const double EPS = 2.220446049250313e-16;
     const std::vector<double>& st = P.save_times;
-    std::vector<double> ts(st.rbegin(), st.rend());     // descending = along the integration direction
+    const bool bs = cfg->alg == HIPADJ_ALG_BACKSOLVE;      // Backsolve: no_start is not consulted (src/adjoint_common.jl:761 reads it for the others), checkpoint stops
+    auto hits = [&](double a, double b) { return std::fabs(a - b) <= 100 * EPS * std::fmax(std::fabs(a), std::fabs(b)); };
+    // tstops along the integration direction (descending): loss times and, for Backsolve, the checkpoint times
+    std::vector<double> ts(st.rbegin(), st.rend());
+    if (bs) { ts.insert(ts.end(), P.ck_times.begin(), P.ck_times.end());
+              for (size_t a = 1; a < ts.size(); ++a) { const double v = ts[a]; size_t b = a; while (b > 0 && ts[b - 1] < v) { ts[b] = ts[b - 1]; --b; } ts[b] = v; } }
     ts.push_back(cfg->t0);
     auto loss_at = [&](double t) {   // the callback's time test (within 100 eps), honouring no_start for the first loss time
-        for (int i = 0; i < (int)st.size(); ++i)
-            if (std::fabs(st[i] - t) <= 100 * EPS * std::fmax(std::fabs(st[i]), std::fabs(t))) return (cfg->no_start && i == 0) ? -1 : i;
+        for (int i = 0; i < (int)st.size(); ++i) if (hits(st[i], t)) return (cfg->no_start && !bs && i == 0) ? -1 : i;
         return -1; };
-    P.rs_t.clear(); P.rs_h.clear(); P.rs_te.clear(); P.rs_save.clear();
+    auto ck_at = [&](double t) { for (int i = 0; i < (int)P.ck_times.size(); ++i) if (hits(P.ck_times[i], t)) return i; return -1; };
+    P.rs_t.clear(); P.rs_h.clear(); P.rs_te.clear(); P.rs_save.clear(); P.rs_ck.clear();
     P.rs_save_at_start = loss_at(cfg->t1);
     double t = cfg->t1;
     size_t its = 0;
@@ -70,7 +75,7 @@ inline void plan_reverse_steps(const hipadj_config* cfg, Plan& P) {
         if (std::fabs((t + d) - tstop) < 100 * EPS * std::fmax(std::fabs(t + d), std::fabs(tstop))) d = tstop - t;
         double tnew = t + d;
         if (std::fabs(tnew - tstop) < 100 * EPS * std::fmax(std::fabs(tnew), std::fabs(tstop))) tnew = tstop;
-        P.rs_t.push_back(t); P.rs_h.push_back(-d); P.rs_te.push_back(tnew); P.rs_save.push_back(loss_at(tnew));
+        P.rs_t.push_back(t); P.rs_h.push_back(-d); P.rs_te.push_back(tnew); P.rs_save.push_back(loss_at(tnew)); P.rs_ck.push_back(bs ? ck_at(tnew) : -1);
         t = tnew;
     }
 }
@@ -223,23 +228,31 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (P.offgrid) {
         // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
-        if ((cfg->alg != HIPADJ_ALG_INTERPOLATING && cfg->alg != HIPADJ_ALG_GAUSS) || cfg->checkpointing || P.field || P.mlp) {
-            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint and GaussAdjoint (checkpointing = false) on the lane-per-trajectory models; "
-                  "other sensealgs need times on the grid, or the adaptive stepper (arbitrary times)";
+        const bool og_ig = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && !cfg->checkpointing;
+        const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->ckpt_stride == 0;
+        if (!(og_ig || og_bs) || P.field || P.mlp) {
+            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false) and BacksolveAdjoint (checkpoints = the save "
+                  "times, ckpt_stride = 0) on the lane-per-trajectory models; other configurations need times on the grid, or the adaptive stepper (arbitrary times)";
             return HIPADJ_ERR_UNSUPPORTED; }
         for (int i = 0; i < cfg->nsave; ++i) {   // the sweep takes the times literally; they must not leave the span
             if (P.save_times[i] < cfg->t0) P.save_times[i] = cfg->t0;
             if (P.save_times[i] > cfg->t1) P.save_times[i] = cfg->t1;
         }
         P.save_of_knot.assign(S + 1, -1);   // no fused select on the knots: jumps are driven by the reverse step list
+        P.ck_times.clear();
+        if (og_bs && cfg->checkpointing) {  // default checkpoints = sol.t of the saveat solve: t0, the save times, t1 (src/backsolve_adjoint.jl:132)
+            if (P.save_times.empty() || P.save_times.front() > cfg->t0) P.ck_times.push_back(cfg->t0);
+            for (double t : P.save_times) P.ck_times.push_back(t);
+            if (P.ck_times.back() < cfg->t1) P.ck_times.push_back(cfg->t1);
+        }
         plan_reverse_steps(cfg, P);
     }
     // checkpoints: BacksolveAdjoint only.  Interpolating/Gauss checkpointing re-solves, on this fixed grid,
     // bit-identical knots from the stored values; the dense tiles are kept instead.
     P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
     P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing && !P.field && !P.mlp;
-    P.nck = 0;
-    if (P.bs_ckpt || P.ip_ckpt) {
+    P.nck = P.offgrid ? (int)P.ck_times.size() : 0;   // off-grid Backsolve: checkpoint TIMES (interpolated states), not knots
+    if ((P.bs_ckpt || P.ip_ckpt) && !P.offgrid) {
         int c = 0;
         if (cfg->ckpt_stride > 0) { for (long k = 0; k <= S; k += cfg->ckpt_stride) P.ckpt_of_knot[k] = c++; if (P.ckpt_of_knot[S] < 0) P.ckpt_of_knot[S] = c++; }
         else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }

@@ -77,15 +77,18 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1;
     const long Np = P.Npad;
-    std::vector<dbl2> knots((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) ? (size_t)(P.S + 1) * N * Np : 0);
+    std::vector<dbl2> knots(((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) || P.offgrid) ? (size_t)(P.S + 1) * N * Np : 0);
     std::vector<double> tile((size_t)((P.ck_longest > HIPADJ_CKPT_KMAX ? P.ck_longest : HIPADJ_CKPT_KMAX) + 1) * N);   // LDS tile, or the HBM slice of k_*_ckpt<..., GT = true>
-    std::vector<double> ckpt((P.bs_ckpt || P.ip_ckpt) ? (size_t)P.nck * N * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np);
+    std::vector<double> ckpt((P.bs_ckpt || P.ip_ckpt || (P.offgrid && P.nck > 0)) ? (size_t)P.nck * N * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np);
     std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0);
     std::vector<double> dp_traj((size_t)NP * Np, 0.0);
     for (long i = 0; i < P.N; ++i)
         forward_lane<Mo>(g, i, u0, p, knots.empty() ? nullptr : knots.data(), ckpt.empty() ? nullptr : ckpt.data(),
                          P.ckpt_of_knot.data(), outT.data(), P.save_of_knot.data(), yT.data());
-    if (P.offgrid) for (long i = 0; i < P.N; ++i) out_offgrid_lane<Mo>(g, i, knots.data(), P.save_times.data(), outT.data());   // k_out_offgrid
+    if (P.offgrid) for (long i = 0; i < P.N; ++i) {   // k_out_offgrid: primal output and (Backsolve) checkpoint states by interpolation
+        out_offgrid_lane<Mo>(g, i, knots.data(), P.save_times.data(), P.M, outT.data());
+        if (P.nck > 0) out_offgrid_lane<Mo>(g, i, knots.data(), P.ck_times.data(), P.nck, ckpt.data());
+    }
     if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
     if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
     const double* cot = cotT.empty() ? nullptr : cotT.data();
@@ -94,7 +97,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     switch (cfg->alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         if (P.offgrid) {   // k_interp_offgrid: loss times off the step grid, the planner's reverse step list
-            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), P.nck > 0 ? P.rs_ck.data() : nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
             for (long i = 0; i < P.N; ++i) {
                 double lam[1][N], mu[1][NP];
                 interp_offgrid_lane<Mo, LOSS>(g, i, p, knots.data(), cot, RS, lam, mu);
@@ -123,6 +126,16 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         compose<Mo>(P, segbuf, du0, dp_traj);
         break; }
     case HIPADJ_ALG_BACKSOLVE: {
+        if (P.offgrid) {   // k_backsolve_offgrid
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), P.nck > 0 ? P.rs_ck.data() : nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            for (long i = 0; i < P.N; ++i) {
+                double lam[1][N], mu[1][NP];
+                backsolve_offgrid_lane<Mo, (LOSS >> 1)>(g, i, p, yT.data(), ckpt.empty() ? nullptr : ckpt.data(), cot, RS, lam, mu);
+                for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
+                for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[0][j];
+            }
+            break;
+        }
         std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
         const double* ck = ckpt.empty() ? nullptr : ckpt.data();
         for (int seg = 0; seg < P.nseg; ++seg) for (long i = 0; i < P.N; ++i) {
@@ -143,7 +156,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         break; }
     case HIPADJ_ALG_GAUSS: {
         if (P.offgrid) {   // k_gauss_offgrid
-            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), P.nck > 0 ? P.rs_ck.data() : nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
             for (long i = 0; i < P.N; ++i) {
                 double lam[1][N], mu[1][NP];
                 gauss_offgrid_lane<Mo, LOSS>(g, i, p, knots.data(), cot, RS, lam, mu);

@@ -436,13 +436,17 @@ OFFGRID_TS = [
 ]
 
 
-@pytest.mark.parametrize("alg", ["interpolating", "gauss"])
+@pytest.mark.parametrize("alg", ["interpolating", "gauss", "backsolve", "backsolve_nockpt"])
 @pytest.mark.parametrize("ts", OFFGRID_TS)
 @pytest.mark.parametrize("model,omodel,u0c,p", MODELS)
 def test_offgrid_loss_times_interpolating_matches_oracle(model, omodel, u0c, p, ts, alg):
     """Loss times off the step grid (fixed-step RK4): the reverse solve stops at each of them and continues with the full dt,
     so its steps leave the forward knots (interp_offgrid_lane + the planner's reverse step list) — against the oracle's generic
     integrator with tstops.  Cotangent and LSQ losses, per-trajectory parameters, no_start."""
+    # Backsolve with no or sparse checkpoints amplifies roundoff on Lorenz (the instability of src/sensitivity_algorithms.jl:168-198): 1e-6 there
+    tol = 1e-6 if (alg.startswith("backsolve") and model == "lorenz") else 1e-9
+    ck = alg == "backsolve"                  # Backsolve: checkpoints = t0, the save times, T (interpolated forward states); or none
+    alg = alg.split("_")[0]
     rng = np.random.default_rng(11)
     N, T, dt = 4, 1.5, 0.01
     n, npar = len(u0c), len(p)
@@ -450,17 +454,17 @@ def test_offgrid_loss_times_interpolating_matches_oracle(model, omodel, u0c, p, 
     u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
     pp = np.asarray(p) * (1 + 0.03 * rng.standard_normal((N, npar)))
     delta = rng.standard_normal((N, len(ts), n))
-    cfg = E.make_config(model, alg, N, 0.0, T, dt, ts, loss_kind=0, p_shared=False)
+    cfg = E.make_config(model, alg, N, 0.0, T, dt, ts, loss_kind=0, p_shared=False, checkpointing=ck)
     du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
-    ref = O.Problem(omodel, alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT")
+    ref = O.Problem(omodel, alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", checkpointing=ck)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
-    assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
+    assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < tol and rel(dp, rdp) < tol
     for ns in (False, True):
-        cfg = E.make_config(model, alg, N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, no_start=ns)
+        cfg = E.make_config(model, alg, N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, no_start=ns, checkpointing=ck)
         du0, dp, _ = E.forward_adjoint(cfg, n, npar, u0, np.asarray(p))
-        ref = O.Problem(omodel, alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, no_start=ns)
+        ref = O.Problem(omodel, alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, no_start=ns, checkpointing=ck)
         rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, np.asarray(p))
-        assert rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
+        assert rel(du0, rdu0) < tol and rel(dp, rdp) < tol
 
 
 def test_offgrid_loss_times_with_continuous_cost_and_rejections():
@@ -477,7 +481,13 @@ def test_offgrid_loss_times_with_continuous_cost_and_rejections():
     ref = O.Problem("LV", alg="GAUSS", stepper="RK4", t0=0, t1=1.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, cont_cost=1)
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
     assert rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
-    for alg, kw in (("gausskronrod", {}), ("backsolve", dict(checkpointing=True)), ("quadrature", {}), ("interpolating", dict(checkpointing=True)), ("gauss", dict(checkpointing=True))):
+    for ck in (True, False):
+        cfg = E.make_config("lv", "backsolve", 3, 0.0, 1.0, 0.01, ts, loss_kind=1, loss_shift=2.0, cont_cost=2, checkpointing=ck)
+        du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
+        ref = O.Problem("LV", alg="BACKSOLVE", stepper="RK4", t0=0, t1=1.0, dt=0.01, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, cont_cost=2, checkpointing=ck)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+        assert rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
+    for alg, kw in (("gausskronrod", {}), ("backsolve", dict(checkpointing=True, ckpt_stride=10)), ("quadrature", {}), ("interpolating", dict(checkpointing=True)), ("gauss", dict(checkpointing=True))):
         with pytest.raises(RuntimeError, match="off the step grid"):
             E.forward_adjoint(E.make_config("lv", alg, 3, 0.0, 1.0, 0.01, ts, loss_kind=1, loss_shift=2.0, **kw), 2, 4, u0, p)
     with pytest.raises(RuntimeError, match="inside"):

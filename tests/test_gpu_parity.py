@@ -1214,3 +1214,40 @@ def test_c_host_demo_matches_oracle(sa, tmp_path):
     assert rel(val["dp"], rdp) < RTOL and rel(val["dp_shards"], rdp) < RTOL and rel(val["dp_shards"], val["dp"]) < 1e-12
     assert rel(val["du0_first"], rdu0[0]) < RTOL and rel(val["du0_last"], rdu0[-1]) < RTOL and rel(val["out_last"], rout[-1, -1]) < RTOL
     assert val["du0_shards_equal"][0] == 1
+
+
+@pytest.mark.parametrize("ckpt", [True, False])
+def test_offgrid_loss_times_backsolve(sa, ckpt):
+    """BacksolveAdjoint with loss times off the step grid: joint backward RK4 on [lam; mu; y] over the reverse step list, y
+    overwritten at the checkpoint times (= t0, the save times, T: states interpolated from the forward dense output) — compiled-in
+    LV and a runtime model; Lorenz only with checkpoints every 0.1 (without them Backsolve is unstable there)."""
+    rng = np.random.default_rng(47)
+    N, T, dt = 130, 1.5, 0.01
+    ts = np.array([0.137, 0.4, 0.40499, 1.2345])
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    delta = rng.standard_normal((N, len(ts), 2))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sa.BacksolveAdjoint(checkpointing=ckpt))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem("LV", alg="BACKSOLVE", stepper="RK4", dt=dt, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=ckpt)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+    m = UM.ROBER
+    f = _device_function(sa, "rober_runtime", m)
+    u0r = rng.uniform(0.3, 1.0, (N, 3)); pr = rng.uniform(0.4, 1.2, (N, 3))
+    delta = rng.standard_normal((N, len(ts), 3))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0r[0], (0, T), pr[0]), u0r, pr), sa.RK4(), dt=dt, saveat=ts, sensealg=sa.BacksolveAdjoint(checkpointing=ckpt))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem("ROBER", alg="BACKSOLVE", stepper="RK4", dt=dt, t0=0, t1=T, save_times=ts, loss="COTANGENT", checkpointing=ckpt)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0r, pr, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+    if ckpt:
+        u0l, pl = lorenz_inputs(N)
+        tsl = np.append(np.arange(0.0, T, 0.1003), T)
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0l[0], (0, T), pl), u0l), sa.RK4(), dt=dt, saveat=tsl, sensealg=sa.BacksolveAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=tsl, dgdu_discrete=sa.LsqShift(2.0))
+        ref = O.Problem("LORENZ", alg="BACKSOLVE", stepper="RK4", dt=dt, t0=0, t1=T, save_times=tsl, loss="LSQ_SHIFT", loss_shift=2.0, checkpointing=True)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0l, pl)
+        assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+        sol.engine.close()

@@ -56,22 +56,23 @@ def test_runtime_compile_retries_at_O1_when_the_check_flags_the_code_object(tmp_
     assert len(objs) == 2 and isa_lint.lint(objs[0]) != [] and isa_lint.lint(objs[1]) == []
 
 
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve"])
 @pytest.mark.parametrize("n", [3, 6])
-def test_runtime_offgrid_kernels_compile_without_a_device(tmp_path, monkeypatch, n):
+def test_runtime_offgrid_kernels_compile_without_a_device(tmp_path, monkeypatch, n, alg):
     """Loss times off the step grid for a runtime-registered model: hipadj_model_check_config compiles k_forward, k_interp_offgrid,
     k_out_offgrid and k_finish with hiprtc (no device needed); the code objects pass the spill-placement lint."""
     from scimlsensitivity_jl_amd import _lib
     m = UM.ring(n)
-    name = f"ring{n}_offgrid"
+    name = f"ring{n}_offgrid_{alg}"
     _lib.register_model(name, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
     monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
-    cfg = E.make_config(name, "interpolating", 53, 0.0, 0.5, 0.01, [0.1234, 0.3, 0.5], loss_kind=0)
+    cfg = E.make_config(name, alg, 53, 0.0, 0.5, 0.01, [0.1234, 0.3, 0.5], loss_kind=0, checkpointing=(alg == "backsolve"))
     L = _lib.load()
     assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
     objs = glob.glob(str(tmp_path / "*.hsaco"))
     assert objs
     txt = "".join(isa_lint.disassemble(o) for o in objs)
-    assert "k_interp_offgrid" in txt and "k_out_offgrid" in txt
+    assert ("k_interp_offgrid" if alg == "interpolating" else "k_backsolve_offgrid") in txt and "k_out_offgrid" in txt
     for o in objs:
         assert isa_lint.lint(o) == []
 
