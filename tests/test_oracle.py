@@ -217,7 +217,7 @@ def test_continuous_cost_matches_forward_sensitivity_gradient(alg, golden):
     assert rel(du0, g["du0"]) < 1e-8 and rel(dp, g["dp"]) < 1e-8
 
 
-@pytest.mark.parametrize("alg", ["INTERPOLATING", "GAUSS"])
+@pytest.mark.parametrize("alg", ["INTERPOLATING", "GAUSS", "BACKSOLVE"])
 def test_offgrid_fixed_step_gradient_converges_to_the_forward_sensitivity_gradient(alg):
     """Loss times off the step grid on a fixed step: the reverse solve stops at them (tstops) and reads the forward solution
     through its cubic-Hermite dense output.  Pinned against an independent scipy DOP853 forward-sensitivity gradient
@@ -231,7 +231,7 @@ def test_offgrid_fixed_step_gradient_converges_to_the_forward_sensitivity_gradie
     rdu0, rdp, _ = mg.gradient(mg.lv, u0, np.array(p), (0.0, T), ts, lambda u, i: u - 2.0)
     errs = []
     for dt in (0.04, 0.02, 0.01):
-        pr = O.Problem("LV", alg=alg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+        pr = O.Problem("LV", alg=alg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, checkpointing=(alg == "BACKSOLVE"))
         du0, dp, _ = pr.adjoint(u0, p)
         errs.append(max(rel(du0, rdu0), rel(dp, rdp)))
     orders = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
