@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 100 /* 0.1.0 */
+#define HIPADJ_VERSION 101 /* 0.1.1: + hipadj_comm_* (RCCL all-reduce of dp), save_times off the step grid, HIPADJ_ERR_RCCL */
 
 typedef enum {
     HIPADJ_OK = 0,
