@@ -492,3 +492,22 @@ def test_offgrid_loss_times_with_continuous_cost_and_rejections():
             E.forward_adjoint(E.make_config("lv", alg, 3, 0.0, 1.0, 0.01, ts, loss_kind=1, loss_shift=2.0, **kw), 2, 4, u0, p)
     with pytest.raises(RuntimeError, match="inside"):
         E.forward_adjoint(E.make_config("lv", "interpolating", 3, 0.0, 1.0, 0.01, [0.5, 1.2], loss_kind=1, loss_shift=2.0), 2, 4, u0, p)
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_loss_at_every_step_save_everystep(alg):
+    """saveat empty = every step of the forward solve is a loss time (src/concrete_solve.jl:740-750; `solve(..., save_everystep=True)`
+    in the host mirror), with and without the first / last point (save_start / save_end = false): M = S + 1 jumps, S quadrature
+    intervals for QuadratureAdjoint, every knot a Backsolve checkpoint."""
+    rng = np.random.default_rng(23)
+    N, T, dt = 3, 0.5, 0.01
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    S = int(round(T / dt))
+    for sl in (slice(0, S + 1), slice(1, S), slice(1, S + 1)):
+        ts = (dt * np.arange(S + 1))[sl]
+        delta = rng.standard_normal((N, len(ts), 2))
+        cfg = E.make_config("lv", alg, N, 0.0, T, dt, ts, loss_kind=0, checkpointing=(alg == "backsolve"), time_segments=0)
+        du0, dp, out = E.forward_adjoint(cfg, 2, 4, u0, p, delta)
+        ref = O.Problem("LV", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", checkpointing=(alg == "backsolve"))
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+        assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
