@@ -96,8 +96,8 @@ typedef struct {
     int32_t nsave;             /* M loss/save times */
     const double *save_times;  /* [M] strictly ascending inside [t0, t1] (copied at create).  RK4: on the step grid t0 + k*dt; off-grid
                                   times are accepted for HIPADJ_ALG_INTERPOLATING / HIPADJ_ALG_GAUSS without checkpointing and for
-                                  HIPADJ_ALG_BACKSOLVE with ckpt_stride = 0 on the lane-per-trajectory models (the reverse solve stops at them like the reference's PresetTimeCallback tstops,
-                                  src/adjoint_common.jl:848-855; out = sol(ts) is interpolated, src/concrete_solve.jl:718-727).
+                                  HIPADJ_ALG_BACKSOLVE with ckpt_stride = 0 on the lane-per-trajectory models (the reverse solve stops at
+                                  them like the reference's PresetTimeCallback tstops, src/adjoint_common.jl:848-855; out = sol(ts) is interpolated, src/concrete_solve.jl:718-727).
                                   Tsit5: arbitrary times */
     int32_t loss_kind;         /* hipadj_loss */
     double loss_shift;
