@@ -238,3 +238,90 @@ def test_c_host_compiles_against_the_header_and_fails_loudly_without_a_device(sa
     exe = _build_host_demo(sa, tmp_path)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
     assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 101" in r.stdout
+
+
+class _StubEngine:
+    """Stands in for the device handle (which needs a GPU) so that the HOST logic of interface.py — argument mapping, saving rules,
+    cotangent packing, dgdp_discrete, error paths — runs in the CPU suite.  It records the configuration it was created with and
+    returns recognisable arrays; no arithmetic of the path happens here (the parity tests proper are the `-m gpu` suite)."""
+    created = []
+
+    def __init__(self, model, alg, ntraj, t0, t1, dt, save_times=(), **kw):
+        from types import SimpleNamespace
+        self.model, self.alg, self.N, self.kw = model, alg, int(ntraj), dict(kw)
+        self.t0, self.t1, self.dt = t0, t1, dt
+        self.save = np.asarray(save_times, dtype=np.float64)
+        self.M, self.n, self.np = len(self.save), 3, 3
+        self.p_shared = bool(kw.get("p_shared", True))
+        self.cfg = SimpleNamespace(loss_kind=kw.get("loss_kind", 0), loss_shift=kw.get("loss_shift", 0.0))
+        self.adjoint_args = []
+        _StubEngine.created.append(self)
+
+    def forward(self, u0, p, want_out=True):
+        return np.arange(self.N * self.M * self.n, dtype=np.float64).reshape(self.N, self.M, self.n) if (want_out and self.M) else None
+
+    def adjoint(self, dLdu=None):
+        self.adjoint_args.append(None if dLdu is None else np.array(dLdu))
+        return np.ones((self.N, self.n)), (np.full(self.np, 2.0) if self.p_shared else np.full((self.N, self.np), 2.0))
+
+    def close(self):
+        pass
+
+
+def test_host_mirror_logic_with_a_stub_engine(sa, monkeypatch):
+    from scimlsensitivity_jl_amd import interface, _lib
+    monkeypatch.setattr(interface, "Engine", _StubEngine)
+    _StubEngine.created.clear()
+    u0 = np.zeros((4, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    prob = sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0.0, 1.0), p), u0)
+    # saving rules -> engine configuration (src/concrete_solve.jl:713-770, 962)
+    sol = sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), save_start=False)
+    e = _StubEngine.created[-1]
+    assert e.alg == "backsolve" and np.allclose(e.save, [0, 0.25, 0.5, 0.75, 1.0]) and e.kw["no_start"] is True and e.kw["checkpointing"] is True
+    assert e.kw["stepper"] == 0 and e.kw["loss_kind"] == _lib.LOSS_COTANGENT and sol.u.shape == (4, 5, 3)
+    sol = sa.solve(prob, sa.Tsit5(), saveat=[0.9, 0.3], sensealg=sa.QuadratureAdjoint(abstol=1e-9, reltol=1e-8), abstol=1e-7, reltol=1e-5, dgdu_discrete=sa.LsqShift(2.0))
+    e = _StubEngine.created[-1]
+    assert e.kw["stepper"] == 1 and np.allclose(e.save, [0.3, 0.9]) and e.kw["no_start"] is False and e.dt == 0.0
+    assert (e.kw["quad_abstol"], e.kw["quad_reltol"], e.kw["abstol"], e.kw["reltol"]) == (1e-9, 1e-8, 1e-7, 1e-5)
+    assert e.kw["loss_kind"] == _lib.LOSS_LSQ_SHIFT and e.kw["loss_shift"] == 2.0
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=sol.t, dgdu_discrete=sa.LsqShift(2.0))
+    assert e.adjoint_args == [None] and du0.shape == (4, 3) and dp.shape == (3,)
+    with pytest.raises(ValueError, match="specialised"):
+        sa.adjoint_sensitivities(sol, sa.Tsit5(), dgdu_discrete=sa.LsqShift(3.0))
+    with pytest.raises(ValueError, match="save times"):
+        sa.adjoint_sensitivities(sol, sa.Tsit5(), t=[0.3, 0.8], dgdu_discrete=sa.LsqShift(2.0))
+    with pytest.raises(ValueError, match="re-run solve"):
+        sa.adjoint_sensitivities(sol, sa.Tsit5(), sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    # equally spaced custom checkpoints -> ckpt_stride; anything else is refused
+    sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.2, 0.4, 0.6, 0.8, 1.0])
+    assert _StubEngine.created[-1].kw["ckpt_stride"] == 20
+    with pytest.raises(ValueError, match="equally spaced"):
+        sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.2, 0.5, 1.0])
+    # save_idxs: cotangents of the saved components are scattered into the full state, zeros elsewhere (:790-824)
+    sol = sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.5, sensealg=sa.InterpolatingAdjoint(), save_idxs=[2, 0])
+    e = _StubEngine.created[-1]
+    assert sol.u.shape == (4, 3, 2) and np.array_equal(sol.u[..., 0], np.arange(36.0).reshape(4, 3, 3)[..., 2])
+    delta = np.arange(24.0).reshape(4, 3, 2)
+    sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=delta)
+    full = e.adjoint_args[-1]
+    assert full.shape == (4, 3, 3) and np.array_equal(full[..., 2], delta[..., 0]) and np.array_equal(full[..., 0], delta[..., 1]) and np.all(full[..., 1] == 0)
+    with pytest.raises(ValueError, match="out of range"):
+        sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.5, save_idxs=[3])
+    # dgdp_discrete: sum over the save times (and the ensemble for shared p) added to dp once (src/adjoint_common.jl:775-779)
+    sol = sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.5, sensealg=sa.InterpolatingAdjoint())
+    dl = np.ones((4, 3, 3))
+    _, dp = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=np.zeros((4, 3, 3)), dgdp_discrete=dl)
+    assert np.array_equal(dp, np.full(3, 2.0 + 12.0))
+    _, dp = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=np.zeros((4, 3, 3)), dgdp_discrete=lambda u, p_, t, i: np.full((4, 3), float(i)))
+    assert np.array_equal(dp, np.full(3, 2.0 + 4 * (0 + 1 + 2)))
+    # the (out, pullback) contract of _concrete_solve_adjoint
+    out, pullback = sa.concrete_solve_adjoint(prob.prob, sa.RK4(), sa.GaussAdjoint(), u0, p, dt=0.01, saveat=0.5)
+    du0, dp = pullback(np.ones(out.size))
+    assert out.shape == (4, 3, 3) and du0.shape == (4, 3) and _StubEngine.created[-1].adjoint_args[-1].shape == (4, 3, 3)
+    # misuse
+    with pytest.raises(ValueError, match="needs dt"):
+        sa.solve(prob, sa.RK4(), saveat=0.5)
+    with pytest.raises(TypeError):
+        sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.5, sensealg="interpolating")
+    with pytest.raises(TypeError, match="unsupported keyword"):
+        sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=np.zeros((4, 3, 3)), callback=object())
