@@ -325,3 +325,18 @@ def test_host_mirror_logic_with_a_stub_engine(sa, monkeypatch):
         sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.5, sensealg="interpolating")
     with pytest.raises(TypeError, match="unsupported keyword"):
         sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=np.zeros((4, 3, 3)), callback=object())
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
+    """bench.py's cpu_baseline leg (the oracle = CPU restatement, timed beside the GPU path on rank 0 at N = 1) on a tiny sample: keys,
+    units and the parity inputs it hands back; bench.py's synthetic inputs are deterministic."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    u0, p = bench.inputs(300)
+    u0b, _ = bench.inputs(300)
+    assert np.array_equal(u0, u0b) and u0.shape == (300, 3) and np.allclose(p, [10.0, 28.0, 8 / 3])
+    ts = np.linspace(0.0, bench.T_FINAL, 101)
+    cb, du0, dp, n = bench.cpu_baseline(u0, p, ts, budget_s=0.05)
+    assert cb["kind"] == "port" and cb["unit"] == "trajectories/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread_value"] > 0
+    assert "sample" in cb and du0.shape == (n, 3) and dp.shape == (3,) and 1 <= n <= 300
