@@ -73,6 +73,7 @@ static void free_all(hipadj_handle* h) {
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
@@ -216,6 +217,12 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (ok && h->nq > 0) ok = HT(hipMemcpy(h->d_qa, qa.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy") &&
                               HT(hipMemcpy(h->d_qb, qb.data(), sizeof(double) * h->nq, hipMemcpyHostToDevice), "memcpy");
     if (!ok) return fail(HIPADJ_ERR_HIP);
+    h->d_save_rev = h->d_save_of_knot;
+    if (P.save_of_knot_rev != P.save_of_knot) {   // no_start suppresses the jump at T: the reverse kernels get their own map
+        h->d_save_rev = nullptr;
+        if (dev_alloc(h, &h->d_save_rev, (size_t)S + 1) != HIPADJ_OK) return fail(HIPADJ_ERR_HIP);
+        if (!HT(hipMemcpy(h->d_save_rev, P.save_of_knot_rev.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice), "memcpy")) return fail(HIPADJ_ERR_HIP);
+    }
 
     Geom& g = h->g;
     g.N = h->N; g.Npad = Np; g.S = (int)S; g.M = h->M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
@@ -528,19 +535,19 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         const dim3 sgrid(waves, (unsigned)h->nseg);
         if (h->ip_ckpt) {
             TRY(usig<decltype(&k_interp_ckpt<ModelLV, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck,
-                                                                   (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride));
+                                                                   (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride));
             composed = true;
         } else
         switch (h->cfg.alg) {
         case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:
-            TRY(usig<decltype(&k_interp<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
+            TRY(usig<decltype(&k_interp<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf));
             composed = true; break;
         case HIPADJ_ALG_BACKSOLVE:
             TRY(usig<decltype(&k_backsolve<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
-                        (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf));
+                        (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf));
             composed = true; break;
         default: {
-            TRY(usig<decltype(&k_quad_adj<ModelLV, 8, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0));
+            TRY(usig<decltype(&k_quad_adj<ModelLV, 8, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_adj, d_du0));
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
             TRY(usig<decltype(&k_quad_gk<ModelLV, 0>)>::launch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const dbl2*)h->d_adj, (const double*)h->d_qa,
                         (const double*)h->d_qb, atol, rtol, h->d_qres));

@@ -63,6 +63,7 @@ struct hipadj_handle {
     bool auto_steps = false;              // max_steps == 0: record capacity sized from a counting pass of the forward solve
     long rec_cap = 0;                     // accepted steps the record buffer(s) currently hold per trajectory
     unsigned* d_ticket = nullptr;
+    int* d_save_rev = nullptr;            // the reverse kernels' loss-time map: d_save_of_knot itself, or an own copy when no_start clears the jump at T (hipadj_plan.hpp)
     int *d_prev_ck = nullptr, *d_save_of_knot = nullptr, *d_ckpt_of_knot = nullptr, *d_seg_bounds = nullptr, *d_flag = nullptr;
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
     bool have_forward = false, timing_pending_fwd = false;

@@ -80,26 +80,26 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt && h->ck_long)
             hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else if (h->ip_ckpt)
             hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else if (h->wpb4) {
             // 256-thread workgroups, four (wave block, segment) items each: one wave per SIMD by construction (hipadj_kernels.hpp)
             const unsigned items = waves * (unsigned)h->nseg;
             hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS, true, 4>), dim3((items + 3) / 4), dim3(4 * WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
-                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
             dispatch_events = true;
         } else if (h->timing >= 1) {
             // the dominant kernel's own begin/end timestamps (events attached to the dispatch packet): what rocprofv3 reports
             // as the kernel's duration.  A hipEventRecord pair around the launch also counts the two marker packets and the
             // dispatch latency (+8-10 us on a 0.12 ms kernel).
             hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, k0, k1, 0, h->g, sp, p,
-                                  (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+                                  (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
             dispatch_events = true;
         } else
         hipLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p,
-                           (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+                           (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1 && !dispatch_events) HIP_TRY(h, hipEventRecord(k1, h->stream));
         launch_compose();
@@ -109,7 +109,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         SegPlan sp{h->nseg, h->d_seg_bounds};
         hipLaunchKernelGGL((k_backsolve<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
                            (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
-                           (const int*)h->d_save_of_knot, h->d_segbuf);
+                           (const int*)h->d_save_rev, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         launch_compose();
@@ -119,13 +119,13 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt && h->ck_long)
             hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else if (h->ip_ckpt)
             hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf, h->d_gtile, h->gtile_stride);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else
             hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
-                               (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+                               (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         launch_compose();
@@ -134,7 +134,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     case HIPADJ_ALG_GAUSS_KRONROD: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussKronrodAdjoint with dgdp_continuous is not offered"); } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
-                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_segbuf);
+                           (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         launch_compose();
@@ -142,7 +142,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         break; }
     case HIPADJ_ALG_QUADRATURE: {
         hipLaunchKernelGGL((k_quad_adj<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
-                           (const double*)h->d_cotT, (const int*)h->d_save_of_knot, h->d_adj, d_du0);
+                           (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_adj, d_du0);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
@@ -203,19 +203,19 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING:
         hipLaunchKernelGGL((k_bruss_adjoint<G, 0>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj, h->d_flag);
+                           (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         break;
     case HIPADJ_ALG_GAUSS:
         hipLaunchKernelGGL((k_bruss_adjoint<G, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, d_du0, h->d_dp_traj, h->d_flag);
+                           (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         break;
     case HIPADJ_ALG_QUADRATURE: {
         hipLaunchKernelGGL((k_bruss_quad_adj<G>), grid, blk, 0, h->stream, h->fg, p, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, h->d_fadj, d_du0, h->d_flag);
+                           (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
@@ -258,10 +258,10 @@ template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, d
     const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), blk(64), sweep_blk(Mlp<H>::NT);
     if (h->cfg.alg == HIPADJ_ALG_GAUSS)
         hipLaunchKernelGGL((k_mlp_adjoint<H, 2>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
+                           (const int*)h->d_save_rev, R, d_du0, h->d_flag);
     else
         hipLaunchKernelGGL((k_mlp_adjoint<H, 0>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_of_knot, R, d_du0, h->d_flag);
+                           (const int*)h->d_save_rev, R, d_du0, h->d_flag);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(es.k1, h->stream));
     const long groups = h->cfg.p_shared ? 1 : h->N;

@@ -23,6 +23,7 @@ struct Plan {
     int S = 0, M = 0, nck = 0, nseg = 1, nq = 0;
     std::vector<double> save_times;
     std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
+    std::vector<int> save_of_knot_rev;   // the map the REVERSE kernels read: save_of_knot, minus the jump no_start suppresses when it sits at T (see make_plan)
     std::vector<double> qa, qb;
     bool bs_ckpt = false;
     bool ip_ckpt = false;    // Interpolating/Gauss with checkpointing=true: checkpoint tiles + in-kernel interval re-solve
@@ -192,7 +193,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         for (size_t a = 1; a < ts.size(); ++a) { const double v = ts[a]; size_t b = a; while (b > 0 && ts[b - 1] < v) { ts[b] = ts[b - 1]; --b; } ts[b] = v; }
         P.tstops_desc = ts;
         P.nseg = 1; P.seg_bounds.assign(2, 0);
-        P.save_of_knot.assign(1, -1); P.ckpt_of_knot.assign(1, -1); P.prev_ck.assign(1, 0);
+        P.save_of_knot.assign(1, -1); P.save_of_knot_rev = P.save_of_knot; P.ckpt_of_knot.assign(1, -1); P.prev_ck.assign(1, 0);
         P.qa.clear(); P.qb.clear();
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // interval order of src/quadrature_adjoint.jl:563-616 (end correction, pairs descending, start correction)
             const auto& t = P.save_times;
@@ -302,6 +303,12 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         b.push_back((int)S);
         P.seg_bounds = b; P.nseg = (int)b.size() - 1;
     }
+    // no_start drops the jump of the FIRST loss time wherever it lies (`cur_time == 1 && no_start`, src/adjoint_common.jl:761; not
+    // for Backsolve).  The sweeps test it on every step (`s == 0`), but the jump that fires at initialisation (first loss time
+    // == T, i.e. the only one) is applied unconditionally by the kernels: the reverse pass therefore reads a copy of the map with
+    // that entry cleared.  The forward pass keeps the full map (out = sol(ts) still has the column).
+    P.save_of_knot_rev = P.save_of_knot;
+    if (cfg->no_start && cfg->alg != HIPADJ_ALG_BACKSOLVE && P.save_of_knot[S] == 0) P.save_of_knot_rev[S] = -1;
     P.qa.clear(); P.qb.clear();
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
         const auto& t = P.save_times;

@@ -111,14 +111,14 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
             if (seg == P.nseg - 1) {
                 double lam[1][N], mu[1][NP];
-                if (P.ip_ckpt) interp_lane<Mo, 1, PF, LOSS, KM>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
-                else interp_lane<Mo, 1, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                if (P.ip_ckpt) interp_lane<Mo, 1, PF, LOSS, KM>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, nullptr, cot, P.save_of_knot_rev.data(), lam, mu, &CK);
+                else interp_lane<Mo, 1, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
                 for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
             } else {
                 double lam[NC][N], mu[NC][NP];
-                if (P.ip_ckpt) interp_lane<Mo, NC, PF, LOSS, KM>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
-                else interp_lane<Mo, NC, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                if (P.ip_ckpt) interp_lane<Mo, NC, PF, LOSS, KM>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, nullptr, cot, P.save_of_knot_rev.data(), lam, mu, &CK);
+                else interp_lane<Mo, NC, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
             }
@@ -142,12 +142,12 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
             if (seg == P.nseg - 1) {
                 double lam[1][N], mu[1][NP];
-                backsolve_lane<Mo, 1, (LOSS >> 1)>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
+                backsolve_lane<Mo, 1, (LOSS >> 1)>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
                 for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
             } else {
                 double lam[NC][N], mu[NC][NP];
-                backsolve_lane<Mo, NC, (LOSS >> 1)>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot.data(), lam, mu);
+                backsolve_lane<Mo, NC, (LOSS >> 1)>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, yT.data(), ck, P.ckpt_of_knot.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
             }
@@ -171,14 +171,14 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             const int kl = P.seg_bounds[seg], kh = P.seg_bounds[seg + 1];
             if (seg == P.nseg - 1) {
                 double lam[1][N], mu[1][NP];
-                if (P.ip_ckpt) gauss_lane<Mo, 1, PF, LOSS, KM>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
-                else gauss_lane<Mo, 1, PF, LOSS>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                if (P.ip_ckpt) gauss_lane<Mo, 1, PF, LOSS, KM>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot_rev.data(), lam, mu, &CK);
+                else gauss_lane<Mo, 1, PF, LOSS>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
                 for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
             } else {
                 double lam[NC][N], mu[NC][NP];
-                if (P.ip_ckpt) gauss_lane<Mo, NC, PF, LOSS, KM>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
-                else gauss_lane<Mo, NC, PF, LOSS>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                if (P.ip_ckpt) gauss_lane<Mo, NC, PF, LOSS, KM>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot_rev.data(), lam, mu, &CK);
+                else gauss_lane<Mo, NC, PF, LOSS>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
             }
@@ -192,14 +192,14 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             const int kl = P.seg_bounds[seg], kh = P.seg_bounds[seg + 1];
             if (seg == P.nseg - 1) {
                 double lam[1][N], mu[1][NP];
-                if (P.ip_ckpt) gauss_lane<Mo, 1, PF, LOSS, KM, true>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
-                else gauss_lane<Mo, 1, PF, LOSS, 0, true>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                if (P.ip_ckpt) gauss_lane<Mo, 1, PF, LOSS, KM, true>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot_rev.data(), lam, mu, &CK);
+                else gauss_lane<Mo, 1, PF, LOSS, 0, true>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
                 for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
             } else {
                 double lam[NC][N], mu[NC][NP];
-                if (P.ip_ckpt) gauss_lane<Mo, NC, PF, LOSS, KM, true>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot.data(), lam, mu, &CK);
-                else gauss_lane<Mo, NC, PF, LOSS, 0, true>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot.data(), lam, mu);
+                if (P.ip_ckpt) gauss_lane<Mo, NC, PF, LOSS, KM, true>(g, i, kl, kh, p, nullptr, cot, P.save_of_knot_rev.data(), lam, mu, &CK);
+                else gauss_lane<Mo, NC, PF, LOSS, 0, true>(g, i, kl, kh, p, knots.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }
             }
@@ -211,7 +211,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         const double atol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, rtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
         for (long i = 0; i < P.N; ++i) {
             double lam[N];
-            quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot.data(), adj.data(), lam);
+            quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot_rev.data(), adj.data(), lam);
             for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
             double acc[NP]; for (int j = 0; j < NP; ++j) acc[j] = 0.0;
             for (int q = 0; q < P.nq; ++q) {

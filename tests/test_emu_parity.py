@@ -511,3 +511,64 @@ def test_loss_at_every_step_save_everystep(alg):
         ref = O.Problem("LV", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", checkpointing=(alg == "backsolve"))
         rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
         assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
+def _fuzz_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    model, omodel, u0c, p = MODELS[int(rng.integers(len(MODELS)))]
+    alg = ["interpolating", "backsolve", "gauss", "quadrature", "gausskronrod"][int(rng.integers(5))]
+    T = float(rng.choice([0.5, 1.0, 1.5]))
+    dt = float(rng.choice([0.01, 0.02, 0.05]))
+    if model == "lorenz":
+        dt = min(dt, 0.02)
+    S = int(round(T / dt))
+    offgrid = bool(rng.random() < 0.4) and alg in ("interpolating", "gauss", "backsolve")
+    ckpt = bool(rng.random() < 0.5) and alg != "quadrature" and not (alg == "gausskronrod")
+    if offgrid and alg != "backsolve":
+        ckpt = False
+    if alg == "backsolve" and model == "lorenz":
+        ckpt = True
+    m = int(rng.integers(0, 7))
+    if offgrid:
+        ts = np.unique(np.round(rng.uniform(0, T, max(m, 1)), 4))
+        if rng.random() < 0.5:
+            ts = np.unique(np.concatenate([ts, [T]]))
+        if rng.random() < 0.3:
+            ts = np.unique(np.concatenate([[0.0], ts]))
+    else:
+        ks = np.unique(rng.integers(0, S + 1, m))
+        if ckpt and alg in ("interpolating", "gauss") and rng.random() < 0.5:
+            ks = np.unique(np.concatenate([ks, np.arange(0, S + 1, 10)]))          # short intervals (LDS tile) half of the time, long ones else
+        ts = ks * dt
+    if alg == "backsolve" and model == "lorenz" and len(ts) < 4:
+        alg, ckpt, offgrid_ok = "interpolating", False, True
+    cost = int(rng.integers(0, 3))
+    if cost == 2 and alg in ("gauss", "gausskronrod"):
+        cost = 1
+    lsq = bool(rng.random() < 0.5) or len(ts) == 0
+    return dict(model=model, omodel=omodel, u0c=u0c, p=p, alg=alg, T=T, dt=dt, ts=ts, ckpt=ckpt, cost=cost, lsq=lsq,
+                N=int(rng.integers(1, 6)), segs=int(rng.choice([0, 1, 3])), no_start=bool(rng.random() < 0.3), p_shared=bool(rng.random() < 0.5), rng=rng)
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_randomized_configurations_emulator_vs_oracle(seed):
+    """Randomized differential test of the device lane bodies (host emulation) against the oracle: model x sensealg x on-grid /
+    off-grid loss times x checkpointing (short and long intervals) x continuous cost x loss kind x segments x no_start x parameter
+    sharing.  The CPU-side sibling of test_randomized_configurations_match_oracle (GPU suite), covering the fixed-step paths that
+    landed after it was written (off-grid sweeps, HBM re-solve tiles)."""
+    c = _fuzz_case(seed)
+    rng, n, npar, N = c["rng"], len(c["u0c"]), len(c["p"]), c["N"]
+    u0 = np.asarray(c["u0c"]) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(c["p"]) if c["p_shared"] else np.asarray(c["p"]) * (1 + 0.03 * rng.standard_normal((N, npar)))
+    ts = c["ts"]
+    delta = None if c["lsq"] else rng.standard_normal((N, len(ts), n))
+    cfg = E.make_config(c["model"], c["alg"], N, 0.0, c["T"], c["dt"], ts, loss_kind=(1 if c["lsq"] else 0), loss_shift=2.0, checkpointing=c["ckpt"],
+                        no_start=c["no_start"], p_shared=c["p_shared"], time_segments=c["segs"], cont_cost=c["cost"], quad_abstol=1e-10, quad_reltol=1e-10)
+    du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+    oalg = {"gausskronrod": "GAUSS_KRONROD"}.get(c["alg"], c["alg"].upper())
+    ref = O.Problem(c["omodel"], alg=oalg, stepper="RK4", t0=0, t1=c["T"], dt=c["dt"], save_times=ts, loss=("LSQ_SHIFT" if c["lsq"] else "COTANGENT"),
+                    loss_shift=2.0, checkpointing=c["ckpt"], no_start=c["no_start"], cont_cost=c["cost"], quad_abstol=1e-10, quad_reltol=1e-10)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    tol = 1e-6 if (c["alg"] == "backsolve" and c["model"] == "lorenz") else 1e-8
+    scale = max(np.max(np.abs(rdu0)), np.max(np.abs(rdp)), 1e-300)
+    assert (len(ts) == 0 or rel(out, rout) < 1e-10) and np.max(np.abs(du0 - rdu0)) < tol * scale and np.max(np.abs(dp - rdp)) < tol * scale, c
