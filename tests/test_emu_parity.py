@@ -572,3 +572,49 @@ def test_randomized_configurations_emulator_vs_oracle(seed):
     tol = 1e-6 if (c["alg"] == "backsolve" and c["model"] == "lorenz") else 1e-8
     scale = max(np.max(np.abs(rdu0)), np.max(np.abs(rdp)), 1e-300)
     assert (len(ts) == 0 or rel(out, rout) < 1e-10) and np.max(np.abs(du0 - rdu0)) < tol * scale and np.max(np.abs(dp - rdp)) < tol * scale, c
+
+
+def _fuzz_case_tsit5(seed):
+    rng = np.random.default_rng(5000 + seed)
+    model, omodel, u0c, p = MODELS[int(rng.integers(len(MODELS)))]
+    alg = ["interpolating", "backsolve", "gauss", "quadrature", "gausskronrod"][int(rng.integers(5))]
+    T = float(rng.choice([0.5, 1.0, 1.5]))
+    tol = float(rng.choice([1e-6, 1e-8, 1e-10]))
+    ckpt = bool(rng.random() < 0.5) and alg != "quadrature"
+    if alg == "backsolve" and model == "lorenz":
+        ckpt = True
+    ts = np.unique(np.round(rng.uniform(0, T, int(rng.integers(0, 6))), 3))
+    if rng.random() < 0.5:
+        ts = np.unique(np.concatenate([ts, [T]]))
+    if rng.random() < 0.3:
+        ts = np.unique(np.concatenate([[0.0], ts]))
+    if alg == "backsolve" and model == "lorenz" and len(ts) < 4:
+        alg, ckpt = "interpolating", False
+    cost = int(rng.integers(0, 3))
+    if cost == 2 and alg in ("gauss", "gausskronrod"):
+        cost = 1
+    return dict(model=model, omodel=omodel, u0c=u0c, p=p, alg=alg, T=T, tol=tol, ts=ts, ckpt=ckpt, cost=cost, lsq=bool(rng.random() < 0.5) or len(ts) == 0,
+                N=int(rng.integers(1, 5)), no_start=bool(rng.random() < 0.3), p_shared=bool(rng.random() < 0.5), rng=rng)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_configurations_emulator_vs_oracle_tsit5(seed):
+    """The adaptive Tsit5 lane bodies (per-lane step control, cursor interpolation, checkpoint re-solves, Gauss / GK quadrature) under the
+    same randomized treatment: the host emulation takes the oracle's step sequences, so the agreement is at roundoff level."""
+    c = _fuzz_case_tsit5(seed)
+    rng, n, npar, N = c["rng"], len(c["u0c"]), len(c["p"]), c["N"]
+    u0 = np.asarray(c["u0c"]) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(c["p"]) if c["p_shared"] else np.asarray(c["p"]) * (1 + 0.03 * rng.standard_normal((N, npar)))
+    ts = c["ts"]
+    delta = None if c["lsq"] else rng.standard_normal((N, len(ts), n))
+    cfg = E.make_config(c["model"], c["alg"], N, 0.0, c["T"], 0.0, ts, loss_kind=(1 if c["lsq"] else 0), loss_shift=2.0, checkpointing=c["ckpt"], no_start=c["no_start"],
+                        p_shared=c["p_shared"], cont_cost=c["cost"], quad_abstol=1e-10, quad_reltol=1e-10, stepper=1, abstol=c["tol"], reltol=c["tol"])
+    du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+    oalg = {"gausskronrod": "GAUSS_KRONROD"}.get(c["alg"], c["alg"].upper())
+    ref = O.Problem(c["omodel"], alg=oalg, stepper="TSIT5", t0=0, t1=c["T"], dt=0.0, abstol=c["tol"], reltol=c["tol"], save_times=ts,
+                    loss=("LSQ_SHIFT" if c["lsq"] else "COTANGENT"), loss_shift=2.0, checkpointing=c["ckpt"], no_start=c["no_start"], cont_cost=c["cost"],
+                    quad_abstol=1e-10, quad_reltol=1e-10)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    tol = 1e-6 if (c["alg"] == "backsolve" and c["model"] == "lorenz") else 1e-8
+    scale = max(np.max(np.abs(rdu0)), np.max(np.abs(rdp)), 1e-300)
+    assert (len(ts) == 0 or rel(out, rout) < 1e-10) and np.max(np.abs(du0 - rdu0)) < tol * scale and np.max(np.abs(dp - rdp)) < tol * scale, c
