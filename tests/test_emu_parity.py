@@ -513,9 +513,13 @@ def test_loss_at_every_step_save_everystep(alg):
         assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
 
 
+RING4 = ("emu_ring4", "RING", [0.6, 0.4, 0.8, 0.5], [0.7, 0.9, 0.5, 1.1, 0.8])   # the 4-state ring compiled into the emulator (a runtime model on the device)
+
+
 def _fuzz_case(seed):
     rng = np.random.default_rng(1000 + seed)
-    model, omodel, u0c, p = MODELS[int(rng.integers(len(MODELS)))]
+    models = MODELS + [RING4]
+    model, omodel, u0c, p = models[int(rng.integers(len(models)))]
     alg = ["interpolating", "backsolve", "gauss", "quadrature", "gausskronrod"][int(rng.integers(5))]
     T = float(rng.choice([0.5, 1.0, 1.5]))
     dt = float(rng.choice([0.01, 0.02, 0.05]))
@@ -545,6 +549,8 @@ def _fuzz_case(seed):
     cost = int(rng.integers(0, 3))
     if cost == 2 and alg in ("gauss", "gausskronrod"):
         cost = 1
+    if model == "emu_ring4":
+        cost = 0                              # the registered costs belong to the compiled-in models
     lsq = bool(rng.random() < 0.5) or len(ts) == 0
     return dict(model=model, omodel=omodel, u0c=u0c, p=p, alg=alg, T=T, dt=dt, ts=ts, ckpt=ckpt, cost=cost, lsq=lsq,
                 N=int(rng.integers(1, 6)), segs=int(rng.choice([0, 1, 3])), no_start=bool(rng.random() < 0.3), p_shared=bool(rng.random() < 0.5), rng=rng)
@@ -567,7 +573,8 @@ def test_randomized_configurations_emulator_vs_oracle(seed):
     du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
     oalg = {"gausskronrod": "GAUSS_KRONROD"}.get(c["alg"], c["alg"].upper())
     ref = O.Problem(c["omodel"], alg=oalg, stepper="RK4", t0=0, t1=c["T"], dt=c["dt"], save_times=ts, loss=("LSQ_SHIFT" if c["lsq"] else "COTANGENT"),
-                    loss_shift=2.0, checkpointing=c["ckpt"], no_start=c["no_start"], cont_cost=c["cost"], quad_abstol=1e-10, quad_reltol=1e-10)
+                    loss_shift=2.0, checkpointing=c["ckpt"], no_start=c["no_start"], cont_cost=c["cost"], quad_abstol=1e-10, quad_reltol=1e-10,
+                    dims=((4, 0, 0, 0) if c["model"] == "emu_ring4" else (0, 0, 0, 0)))
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     tol = 1e-6 if (c["alg"] == "backsolve" and c["model"] == "lorenz") else 1e-8
     scale = max(np.max(np.abs(rdu0)), np.max(np.abs(rdp)), 1e-300)
