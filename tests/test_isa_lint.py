@@ -56,7 +56,7 @@ def test_runtime_compile_retries_at_O1_when_the_check_flags_the_code_object(tmp_
     assert len(objs) == 2 and isa_lint.lint(objs[0]) != [] and isa_lint.lint(objs[1]) == []
 
 
-@pytest.mark.parametrize("alg", ["interpolating", "backsolve"])
+@pytest.mark.parametrize("alg", ["interpolating", "gauss", "backsolve"])
 @pytest.mark.parametrize("n", [3, 6])
 def test_runtime_offgrid_kernels_compile_without_a_device(tmp_path, monkeypatch, n, alg):
     """Loss times off the step grid for a runtime-registered model: hipadj_model_check_config compiles k_forward, k_interp_offgrid,
@@ -72,7 +72,7 @@ def test_runtime_offgrid_kernels_compile_without_a_device(tmp_path, monkeypatch,
     objs = glob.glob(str(tmp_path / "*.hsaco"))
     assert objs
     txt = "".join(isa_lint.disassemble(o) for o in objs)
-    assert ("k_interp_offgrid" if alg == "interpolating" else "k_backsolve_offgrid") in txt and "k_out_offgrid" in txt
+    assert {"interpolating": "k_interp_offgrid", "gauss": "k_gauss_offgrid", "backsolve": "k_backsolve_offgrid"}[alg] in txt and "k_out_offgrid" in txt
     for o in objs:
         assert isa_lint.lint(o) == []
 
