@@ -1037,44 +1037,6 @@ def test_randomized_configurations_gausskronrod(sa, seed):
     sol.engine.close()
 
 
-def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
-    """hipadj_comm_*: with a communicator attached every adjoint call all-reduces dp in-stream over RCCL.  One GPU here, so
-    the communicator has one rank and the sum over ranks is the identity — this exercises the dlopen binding, the
-    communicator life cycle and the in-stream collective on the handle's stream; two shards summed by hand stand in for
-    two ranks (their communicator needs two GPUs: the driver's multi-GPU bench with --native-allreduce)."""
-    T, dt, N = 1.0, 0.01, 130
-    u0, p = lorenz_inputs(N)
-    ts = np.linspace(0, T, 11)
-
-    def grads(u0s, with_comm):
-        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0s[0], (0, T), p), u0s), sa.RK4(), dt=dt, saveat=ts,
-                       sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
-        if with_comm:
-            sol.engine.comm_init_rank(sa.comm_unique_id(), 1, 0)
-        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
-        du0b, dpb = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))     # the collective is repeatable
-        assert np.array_equal(dp, dpb) and np.array_equal(du0, du0b)
-        if with_comm:
-            sol.engine.comm_destroy()
-            assert np.array_equal(sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))[1], dp)
-        sol.engine.close()
-        return du0, dp
-
-    du0, dp = grads(u0, False)
-    du0c, dpc = grads(u0, True)
-    assert np.array_equal(du0, du0c) and np.array_equal(dp, dpc)
-    lo, hi = sa.shard_range(N, 0, 2)
-    parts = [grads(u0[a:b], True) for a, b in ((lo, hi), sa.shard_range(N, 1, 2))]
-    assert rel(parts[0][1] + parts[1][1], dp) < 1e-12
-    assert np.array_equal(np.concatenate([parts[0][0], parts[1][0]]), du0)
-    # per-trajectory parameters have no cross-shard reduction
-    pN = np.tile(p, (8, 1))
-    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0[:8], pN), sa.RK4(), dt=dt, saveat=ts,
-                   sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
-    with pytest.raises(sa.HipadjError):
-        sol.engine.comm_init_rank(sa.comm_unique_id(), 1, 0)
-    sol.engine.close()
-
 
 @pytest.mark.parametrize("saveat", [0.333, [0.137, 0.4, 0.40499, 1.2345], [1.4999]])
 def test_offgrid_loss_times_interpolating(sa, saveat):
@@ -1251,3 +1213,43 @@ def test_offgrid_loss_times_backsolve(sa, ckpt):
         rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0l, pl)
         assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
         sol.engine.close()
+
+
+# last in the file: the only test that needs RCCL in the process
+def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
+    """hipadj_comm_*: with a communicator attached every adjoint call all-reduces dp in-stream over RCCL.  One GPU here, so
+    the communicator has one rank and the sum over ranks is the identity — this exercises the dlopen binding, the
+    communicator life cycle and the in-stream collective on the handle's stream; two shards summed by hand stand in for
+    two ranks (their communicator needs two GPUs: the driver's multi-GPU bench with --native-allreduce)."""
+    T, dt, N = 1.0, 0.01, 130
+    u0, p = lorenz_inputs(N)
+    ts = np.linspace(0, T, 11)
+
+    def grads(u0s, with_comm):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0s[0], (0, T), p), u0s), sa.RK4(), dt=dt, saveat=ts,
+                       sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+        if with_comm:
+            sol.engine.comm_init_rank(sa.comm_unique_id(), 1, 0)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+        du0b, dpb = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))     # the collective is repeatable
+        assert np.array_equal(dp, dpb) and np.array_equal(du0, du0b)
+        if with_comm:
+            sol.engine.comm_destroy()
+            assert np.array_equal(sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))[1], dp)
+        sol.engine.close()
+        return du0, dp
+
+    du0, dp = grads(u0, False)
+    du0c, dpc = grads(u0, True)
+    assert np.array_equal(du0, du0c) and np.array_equal(dp, dpc)
+    lo, hi = sa.shard_range(N, 0, 2)
+    parts = [grads(u0[a:b], True) for a, b in ((lo, hi), sa.shard_range(N, 1, 2))]
+    assert rel(parts[0][1] + parts[1][1], dp) < 1e-12
+    assert np.array_equal(np.concatenate([parts[0][0], parts[1][0]]), du0)
+    # per-trajectory parameters have no cross-shard reduction
+    pN = np.tile(p, (8, 1))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0[:8], pN), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    with pytest.raises(sa.HipadjError):
+        sol.engine.comm_init_rank(sa.comm_unique_id(), 1, 0)
+    sol.engine.close()
