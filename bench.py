@@ -8,11 +8,18 @@
 
 A "step" = one reverse pass (the hot path) over one rank's ensemble shard with the forward solution already
 resident in HBM (the forward solve runs once, untimed, like the reference's forward `solve` precedes its
-pullback).  Every rank owns `--ntraj` trajectories (weak scaling: the ensemble grows with the GPU count, no
-data-path collective); the only exchange is the all-reduce of dL/dp (3 doubles) over RCCL, which IS inside the
-timed step.  `--strong` shards a fixed 10^4-trajectory ensemble instead.
+pullback).
 
-Rank 0 prints ONE JSON line.  The oracle (oracle/) appears only in the cpu_baseline leg and the parity check.
+N = 1: the 10^4-trajectory ensemble of BASELINE configs[1] on one GPU.
+N > 1: STRONG scaling by default — the same 10^4-trajectory ensemble sharded into contiguous ranges (north_star: ">= 6x at
+8 GPUs for a 10^4-trajectory ensemble"; 1250 trajectories per GPU at N = 8), no data-path collective; the only exchange is the
+all-reduce of dL/dp (3 doubles) over RCCL, INSIDE the timed step, issued in-stream by the library (hipadj_comm_*;
+`--torch-allreduce` uses torch.distributed's asynchronous all-reduce instead).  The line also carries a second figure,
+`weak_scaling` (10^4 trajectories PER GPU, measured in the same run); `--weak` makes that the headline instead.
+
+Rank 0 prints ONE JSON line.  The oracle (oracle/) appears only in the cpu_baseline leg and the parity checks.
+At N = 1 the line also carries `shard_sizes` (the reverse pass at the 1250 / 2500 / 5000-trajectory shards of the 8 / 4 / 2-GPU
+layouts, on this one GPU) and `other_configs` (BASELINE configs[2..4] at their stated sizes, each with its own roofline).
 """
 import argparse
 import json
@@ -27,6 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 T_FINAL, DT, SAVE_DT, LOSS_SHIFT, SEED = 10.0, 0.01, 0.1, 2.0, 20240601
+HBM_PEAK_GBS, FP64_MFMA_PEAK_TF, FP64_VALU_PEAK_TF = 8000.0, 78.6, 78.6     # /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def inputs(n_total):
@@ -36,17 +44,24 @@ def inputs(n_total):
     return u0, p
 
 
+def save_times():
+    return np.linspace(0.0, T_FINAL, int(round(T_FINAL / SAVE_DT)) + 1)
+
+
+def oracle_problem(alg="INTERPOLATING", **kw):
+    import oracle as O
+    return O.Problem("LORENZ", alg=alg, stepper="RK4", t0=0.0, t1=T_FINAL, dt=DT, save_times=save_times(), loss="LSQ_SHIFT", loss_shift=LOSS_SHIFT, **kw)
+
+
 def cpu_baseline(u0, p, ts, budget_s=20.0):
     """The oracle (CPU restatement of the reference algorithm — NOT Julia) timed on a bounded sample of the same
-    workload with all host cores (OpenMP over trajectories)."""
+    workload with the host thread count that maximises ITS throughput (OpenMP over trajectories)."""
     os.environ.setdefault("OMP_PROC_BIND", "spread")   # read by libgomp when the oracle library is first loaded
     os.environ.setdefault("OMP_PLACES", "threads")
-    import oracle as O
     cores = os.cpu_count() or 1
-    pr = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=T_FINAL, dt=DT, save_times=ts,
-                   loss="LSQ_SHIFT", loss_shift=LOSS_SHIFT)
-    # thread count: the oracle allocates per trajectory and its OpenMP scaling collapses beyond ~32 threads on the 2-socket
-    # host (kernel VM contention), so the baseline uses the thread count that maximises ITS throughput
+    pr = oracle_problem()
+    # thread count: the oracle allocates per trajectory and its OpenMP scaling collapses beyond ~32-64 threads on the 2-socket
+    # host (kernel VM contention), so the baseline uses the thread count that maximises ITS throughput and says which
     best, probe_log = None, []
     for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}, reverse=True):
         m = min(len(u0), 64 * nt)
@@ -62,19 +77,152 @@ def cpu_baseline(u0, p, ts, budget_s=20.0):
     rev, wall, reps = 0.0, 0.0, 0
     while reps < 500 and rev * cores_used < budget_s:
         t0 = time.perf_counter()
-        du0, dp, _, tm = pr.adjoint_ensemble(u0[:n], p, nthreads=cores_used, want_out=False)
+        _, _, _, tm = pr.adjoint_ensemble(u0[:n], p, nthreads=cores_used, want_out=False)
         wall += time.perf_counter() - t0
         rev += tm["reverse_s"]  # max over threads of the time spent in reverse passes
         reps += 1
     # the same path on ONE host thread (SURVEY.md §8d asks for both): a smaller sample, same inputs
     n1 = min(len(u0), 2048)
     _, _, _, tm1 = pr.adjoint_ensemble(u0[:n1], p, nthreads=1, want_out=False)
-    return dict(value=n * reps / rev, unit="trajectories/s", cores=cores_used, host_threads=cores, thread_probe_traj_per_s=" ".join(probe_log), kind="port",
+    return dict(value=n * reps / rev, unit="trajectories/s", cores=cores_used, host_threads=cores,
+                cores_note=f"{cores_used} of {cores} host threads (the thread count at which the oracle is fastest)",
+                thread_probe_traj_per_s=" ".join(probe_log), kind="port",
                 single_thread_value=n1 / tm1["reverse_s"], single_thread_ns_per_vjp_step=tm1["reverse_s"] / (n1 * 1000 * 4) * 1e9,
                 sample=f"{n} of the workload's trajectories x {reps} repeats, reverse passes only ({rev:.2f} s on {cores_used} threads = "
                        f"{rev * cores_used:.0f} core-seconds; forward+reverse wall {wall:.2f} s), C oracle, OpenMP over trajectories, "
                        f"gcc -O2 -ffp-contract=off",
-                ns_per_vjp_step=rev / (n * reps * 1000 * 4) * 1e9), du0, dp, n
+                ns_per_vjp_step=rev / (n * reps * 1000 * 4) * 1e9)
+
+
+class Runner:
+    """One engine on this rank's shard + the timed loop of the driver contract."""
+
+    def __init__(self, sa, torch, dist, args, n_local, u0_np, p_np, local_rank, world, native):
+        self.torch, self.dist, self.world, self.native = torch, dist, world, native
+        dev = torch.device("cuda", local_rank)
+        self.eng = sa.Engine("lorenz", "interpolating", n_local, 0.0, T_FINAL, DT, save_times=save_times(), loss_kind=1, loss_shift=LOSS_SHIFT,
+                             p_shared=True, device=local_rank, time_segments=args.segments)
+        self.eng.use_torch_stream()
+        if native:
+            sa.init_native_allreduce(self.eng)     # torch.distributed only ships the 128-byte RCCL id
+        self.eng.set_timing(1)   # HIP events around the dominant kernel only (on its dispatch packet); the whole-call bracket costs ~8 us per step
+        self.u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
+        self.p = torch.tensor(p_np, device=dev, dtype=torch.float64)
+        self.du0 = torch.empty((n_local, 3), device=dev, dtype=torch.float64)
+        self.dps = [torch.empty(3, device=dev, dtype=torch.float64) for _ in range(2)]
+        self.eng.forward_dev(self.u0, self.p, None)          # forward solve: interpolant tiles now resident in HBM
+        torch.cuda.synchronize()
+        self.eng.forward_dev(self.u0, self.p, None)          # once more: forward_solve_ms is the steady-state call, not the first launch (code load)
+        torch.cuda.synchronize()
+        self.it, self.pending = 0, None
+
+    def step(self):
+        # reverse pass of this step.  torch carrier: the all-reduce of dL/dp (RCCL, its own stream) overlaps the NEXT step's kernels —
+        # dp is double-buffered and the previous step's reduction is only waited for here.  Native carrier: in-stream inside the call.
+        dp = self.dps[self.it & 1]
+        self.eng.adjoint_dev(None, self.du0, dp)
+        if self.world > 1 and not self.native:
+            if self.pending is not None:
+                self.pending.wait()
+            self.pending = self.dist.all_reduce(dp, op=self.dist.ReduceOp.SUM, async_op=True)
+        self.it += 1
+
+    def drain(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+
+    def timed(self, steps, warmup):
+        torch, dist = self.torch, self.dist
+        for _ in range(warmup):
+            self.step()
+        self.drain()
+        torch.cuda.synchronize()
+        self.eng.synchronize()
+        st0 = self.eng.stats()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.drain()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        self.eng.synchronize()
+        st1 = self.eng.stats()
+        if self.world > 1:
+            tt = torch.tensor([elapsed], device=self.u0.device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, st0, st1
+
+    def last_dp(self):
+        return self.dps[(self.it - 1) & 1]
+
+    def close(self):
+        self.eng.close()
+
+
+def other_configs(sa, torch):
+    """BASELINE configs[2..4] at their stated sizes on this GPU, each with the roofline that bounds it (reverse pass only, forward
+    solution resident; library events on the launch stream).  Short: a few repeats each."""
+    from test_gpu_parity import mlp_params, bruss_u0
+    out = []
+    rng = np.random.default_rng(0)
+
+    def run(eng, u0, p, delta, reps):
+        eng.forward(u0, p, want_out=False)
+        eng.adjoint(delta)
+        s0 = eng.stats()
+        for _ in range(reps):
+            eng.adjoint(delta)
+        s1 = eng.stats()
+        return ((s1["adjoint_ms_total"] - s0["adjoint_ms_total"]) / reps, (s1["adjoint_main_kernel_ms_total"] - s0["adjoint_main_kernel_ms_total"]) / reps, s1)
+
+    # configs[2]: the C2 ensemble, BacksolveAdjoint(checkpointing=true), a checkpoint every 10 steps — compute-bound (reads only the checkpoints)
+    u0, p = inputs(10000)
+    eng = sa.Engine("lorenz", "backsolve", 10000, 0.0, T_FINAL, DT, save_times=save_times(), loss_kind=1, loss_shift=LOSS_SHIFT, checkpointing=True)
+    ms, kms, st = run(eng, u0, p, None, 10)
+    # FP64 work of the sequential formulation: per trajectory and step 4 f + 4 vjp_u + 4 vjp_p + stage algebra ~ 226 flop (SURVEY.md §8d)
+    out.append(dict(config="configs[2]: Lorenz 10^4 x 1000 steps, BacksolveAdjoint(checkpointing=true), checkpoints every 10 steps (1 GPU)",
+                    reverse_ms=ms, main_kernel_ms=kms, trajectories_per_s=10000 / (ms * 1e-3), time_segments=st["time_segments"],
+                    roofline=dict(bound="fp64_valu", achieved=226.0 * 1e4 * 1000 / (kms * 1e-3) / 1e12, peak=FP64_VALU_PEAK_TF, unit="TFLOP/s",
+                                  frac=226.0 * 1e4 * 1000 / (kms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                                  note="flops of the SEQUENTIAL formulation (226 per trajectory-step); the time-segmented kernel executes ~3.3x that",
+                                  hbm_bytes=st["adjoint_algorithmic_bytes"])))
+    eng.close()
+    # configs[3]: MLP 2 -> 128 -> 128 -> 2, 4096 columns, 150 RK4 steps, 30 loss times, GaussAdjoint (FP64 MFMA)
+    d, H, B, S = 2, 128, 4096, 150
+    ts = 0.01 * np.arange(5, S + 1, 5)
+    eng = sa.Engine("mlp", "gauss", 1, 0.0, S * 0.01, 0.01, save_times=ts, dims=(d, H, B, 0))
+    ms, kms, st = run(eng, rng.standard_normal((1, d * B)), mlp_params(d, H), rng.standard_normal((1, len(ts), d * B)), 3)
+    gemms = (3 + 4 + 1 + 4) * S           # H x H x B contractions per step in the sweep (3 forward + 4 backward + Gauss nodes)
+    sweep_flops = gemms * 2.0 * H * H * B
+    wgrad_flops = 2 * S * 2.0 * B * (H * (H + 16) + H * 16 + 16 * (H + 16))
+    out.append(dict(config="configs[3]: MLP 2-128-128-2, batch 4096, 150 RK4 steps, GaussAdjoint (1 GPU)", reverse_ms=ms, sweep_kernel_ms=kms,
+                    weight_gradient_ms=ms - kms,
+                    roofline=dict(bound="mfma", achieved=sweep_flops / (kms * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                                  frac=sweep_flops / (kms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, kernel="k_mlp_adjoint",
+                                  weight_gradient_TFLOPs=wgrad_flops / max((ms - kms) * 1e-3, 1e-9) / 1e12)))
+    eng.close()
+    # configs[4]: Brusselator 32 x 32 (n = 2048), QuadratureAdjoint, 400 explicit RK4 steps; N = 1 (the config) and N = 256 (fills the chip)
+    G, dtb, Sb = 32, 2.5e-5, 400
+    tsb = dtb * np.arange(0, Sb + 1, 100)
+    for N in (1, 256):
+        eng = sa.Engine("bruss", "quadrature", N, 0.0, Sb * dtb, dtb, save_times=tsb, dims=(G, 0, 0, 0))
+        ms, kms, st = run(eng, bruss_u0(G, N), np.array([3.4, 1.0, 10.0]), rng.standard_normal((N, len(tsb), 2 * G * G)), 3)
+        n = 2 * G * G
+        by = N * (Sb + 1) * 16.0 * n + N * Sb * 32.0 * n      # knots read + dense-lambda record written (SURVEY.md §8d)
+        out.append(dict(config=f"configs[4]: Brusselator 32x32, QuadratureAdjoint, 400 RK4 steps, N = {N} (1 GPU)", reverse_ms=ms, lambda_pass_ms=kms,
+                        us_per_step=kms * 1e3 / Sb,
+                        roofline=dict(bound="hbm", achieved=by / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      kernel="k_bruss_quad_adj", algorithmic_bytes_per_launch=by)))
+        eng.close()
+    return out
 
 
 def main():
@@ -82,12 +230,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--ntraj", type=int, default=10000, help="trajectories per rank (weak) or in total (--strong)")
-    ap.add_argument("--strong", action="store_true")
+    ap.add_argument("--ntraj", type=int, default=10000, help="trajectories of the ensemble (strong scaling: in total; weak: per rank)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: headline = weak scaling (--ntraj per rank); default = strong (the fixed ensemble sharded)")
+    ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--segments", type=int, default=0, help="time segments per trajectory (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--native-allreduce", action="store_true",
-                    help="N > 1: all-reduce dL/dp inside the C ABI (hipadj_comm_*: RCCL in-stream on the handle's stream) instead of torch.distributed")
+    ap.add_argument("--no-extras", action="store_true", help="skip shard_sizes / other_configs (N = 1) and the second scaling figure (N > 1)")
+    ap.add_argument("--torch-allreduce", action="store_true",
+                    help="N > 1: all-reduce dL/dp with torch.distributed (async, own stream) instead of in-stream RCCL inside the C ABI (hipadj_comm_*)")
+    ap.add_argument("--native-allreduce", action="store_true", help="(default for N > 1; kept for compatibility)")
     args = ap.parse_args()
 
     import torch
@@ -105,128 +256,106 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+    native = world > 1 and not args.torch_allreduce
+    ts = save_times()
+    S = int(round(T_FINAL / DT))
 
-    n_total = args.ntraj if args.strong else args.ntraj * world
-    u0_all, p_np = inputs(n_total)
-    lo, hi = sa.shard_range(n_total, rank, world)
-    u0_np = u0_all[lo:hi]
-    n_local = hi - lo
-    ts = np.linspace(0.0, T_FINAL, int(round(T_FINAL / SAVE_DT)) + 1)
+    def measure(strong, steps, warmup):
+        n_total = args.ntraj if (strong or world == 1) else args.ntraj * world
+        u0_all, p_np = inputs(n_total)
+        lo, hi = sa.shard_range(n_total, rank, world)
+        r = Runner(sa, torch, dist, args, hi - lo, u0_all[lo:hi], p_np, local_rank, world, native)
+        elapsed, st0, st1 = r.timed(steps, warmup)
+        return r, n_total, u0_all, p_np, (lo, hi), elapsed, st0, st1
 
-    eng = sa.Engine("lorenz", "interpolating", n_local, 0.0, T_FINAL, DT, save_times=ts, loss_kind=1, loss_shift=LOSS_SHIFT,
-                    p_shared=True, device=local_rank, time_segments=args.segments)
-    eng.use_torch_stream()
-    native = world > 1 and args.native_allreduce
-    if native:
-        sa.init_native_allreduce(eng)     # torch.distributed only ships the 128-byte RCCL id
-    eng.set_timing(1)       # HIP events around the dominant kernel only (2 per step; the whole-call bracket costs ~8 us per step)
-    u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
-    p = torch.tensor(p_np, device=dev, dtype=torch.float64)
-    du0 = torch.empty((n_local, 3), device=dev, dtype=torch.float64)
-    dps = [torch.empty(3, device=dev, dtype=torch.float64) for _ in range(2)]
-    eng.forward_dev(u0, p, None)          # forward solve: interpolant tiles now resident in HBM
-    torch.cuda.synchronize()
-    eng.forward_dev(u0, p, None)          # once more: forward_solve_ms below is the steady-state call, not the first launch (code load)
-    torch.cuda.synchronize()
-    fwd_ms = None
-    state = {"it": 0, "pending": None}
-
-    def step():
-        # reverse pass of this step; the all-reduce of dL/dp (RCCL, its own stream) overlaps the NEXT step's kernels:
-        # dp is double-buffered and the previous step's reduction is only waited for here
-        dp = dps[state["it"] & 1]
-        eng.adjoint_dev(None, du0, dp)
-        if world > 1 and not native:
-            if state["pending"] is not None:
-                state["pending"].wait()
-            state["pending"] = dist.all_reduce(dp, op=dist.ReduceOp.SUM, async_op=True)
-        state["it"] += 1
-
-    def drain():
-        if state["pending"] is not None:
-            state["pending"].wait()
-            state["pending"] = None
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    eng.synchronize()
-    st0 = eng.stats()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    eng.synchronize()
-    st1 = eng.stats()
-    fwd_ms = st1["forward_ms_last"]
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
+    strong = world > 1 and not args.weak
+    r, n_total, u0_all, p_np, (lo, hi), elapsed, st0, st1 = measure(strong, args.steps, args.warmup)
+    res = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total / (elapsed / args.steps)
-        S = int(round(T_FINAL / DT))
-        # dominant kernel (k_interp): HIP events recorded by the library on the launch stream around every launch
+        fwd_ms = st1["forward_ms_last"]
+        # dominant kernel (k_interp): HIP events attached by the library to the kernel's dispatch packet on the launch stream, every launch
         k_calls = st1["adjoint_calls"] - st0["adjoint_calls"]
         k_ms = (st1["adjoint_main_kernel_ms_total"] - st0["adjoint_main_kernel_ms_total"]) / max(k_calls, 1)
         alg_bytes = st1["adjoint_algorithmic_bytes"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1 and n_total == 10000:
             try:
-                traffic = json.load(open(tpath)).get("k_interp_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic, traffic_src = tj.get("k_interp_hbm_bytes_per_launch"), "NOT live: committed PMC pass, " + tj.get("source", tpath)
             except Exception:
                 traffic = None
         res = {
             "metric": "adjoint_trajectories_per_sec", "value": value, "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Lorenz-63 ensemble, {args.ntraj} trajectories{'' if args.strong else ' per GPU'}, "
+            "config": {"workload": f"Lorenz-63 ensemble, {args.ntraj} trajectories{' in total (sharded)' if strong else ' per GPU' if world > 1 else ''}, "
                                    f"InterpolatingAdjoint, fixed-step RK4 dt={DT}, tspan=(0,{T_FINAL}), loss times 0:{SAVE_DT}:{T_FINAL}, "
                                    f"dgdu = u - {LOSS_SHIFT} (BASELINE configs[1])",
-                       "ntraj_total": n_total, "rk4_steps": S, "loss_times": len(ts),
+                       "ntraj_total": n_total, "ntraj_per_gpu": hi - lo, "rk4_steps": S, "loss_times": len(ts),
                        "time_segments": st1["time_segments"], "parallelism": f"ensemble-shard x{world}",
                        "dp_allreduce": ("none" if world == 1 else "rccl in-stream (hipadj_comm)" if native else "torch.distributed nccl, async")},
             "ns_per_vjp_step": elapsed / args.steps / (n_total * S * 4.0) * 1e9,
             "forward_solve_ms": fwd_ms,
             "forward_plus_reverse_ms": (fwd_ms + ms_per_step) if fwd_ms is not None else None,
-            "roofline": {"bound": "hbm", "kernel": "k_interp", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": "k_interp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
-                         # not measured live: SQ counters of the committed PMC pass.  The 13 time segments buy 13x the waves for
-                         # 3.8x the column work, and the kernel's limiter at N = 10^4 is FP64 issue, not HBM
-                         "secondary": {"bound": "fp64_valu_issue", "frac": 0.70, "source": "profiles/r1_rocprofv3_pmc_sq.txt"}},
+                         "whole_pass_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only: at N > 1 the other ranks would sit in the teardown
-            cb, rdu0, rdp, n_s = cpu_baseline(u0_np, p_np, ts)
-            res["cpu_baseline"] = cb
-            g = du0[:n_s].cpu().numpy()
-            res["parity_max_rel_du0_vs_oracle_sample"] = float(np.max(np.abs(g - rdu0)) / np.max(np.abs(rdu0)))
-        elif world > 1:
-            # N > 1: no CPU timing leg, only the checker on rank 0's first 256 trajectories (~25 ms of oracle work)
-            import oracle as O
-            pr = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=T_FINAL, dt=DT, save_times=ts,
-                           loss="LSQ_SHIFT", loss_shift=LOSS_SHIFT)
-            n_s = min(256, n_local)
-            rdu0 = pr.adjoint_ensemble(u0_np[:n_s], p_np, nthreads=1, want_out=False)[0]
-            g = du0[:n_s].cpu().numpy()
-            res["parity_max_rel_du0_vs_oracle_sample"] = float(np.max(np.abs(g - rdu0)) / np.max(np.abs(rdu0)))
+        # ---- parity: du0 of every trajectory of this rank's shard and (N = 1) the REDUCED dp against the oracle on the same set
+        du0 = r.du0.cpu().numpy()
+        dp = r.last_dp().cpu().numpy()
+        pr = oracle_problem()
+        if world == 1:
+            rdu0, rdp, _, _ = pr.adjoint_ensemble(u0_all, p_np, want_out=False)          # all trajectories: ~1 s on the host cores
+            res["parity_max_rel_du0_vs_oracle"] = float(np.max(np.abs(du0 - rdu0)) / np.max(np.abs(rdu0)))
+            res["parity_max_rel_dp_vs_oracle"] = float(np.max(np.abs(dp - rdp) / np.abs(rdp)))
+            res["parity_trajectories"] = int(n_total)
+        else:
+            rdu0, rdp, _, _ = pr.adjoint_ensemble(u0_all, p_np, want_out=False)          # the WHOLE ensemble: dp is the all-reduced sum
+            res["parity_max_rel_du0_vs_oracle"] = float(np.max(np.abs(du0 - rdu0[lo:hi])) / np.max(np.abs(rdu0[lo:hi])))
+            res["parity_max_rel_dp_vs_oracle"] = float(np.max(np.abs(dp - rdp) / np.abs(rdp)))
+            res["parity_trajectories"] = int(n_total)
+    r.close()
+
+    if world > 1 and not args.no_extras:
+        # the other scaling figure, same run, fewer steps
+        r2, n2, _, _, _, el2, s0, s1 = measure(not strong, max(5, args.steps // 2), args.warmup)
+        if rank == 0:
+            k2 = max(5, args.steps // 2)
+            res["weak_scaling" if strong else "strong_scaling"] = {
+                "value": n2 / (el2 / k2), "unit": "trajectories/s", "ms_per_step": el2 / k2 * 1e3, "ntraj_total": n2,
+                "time_segments": s1["time_segments"], "steps": k2}
+        r2.close()
+
+    if rank == 0 and world == 1:
+        if not args.no_extras:
+            # the shard sizes of the 8 / 4 / 2-GPU strong-scaling layouts on THIS GPU: the per-rank step time the multi-GPU figure rests on
+            sh = []
+            for n_s in (1250, 2500, 5000):
+                u0s, _ = inputs(10000)
+                rs = Runner(sa, torch, dist, args, n_s, u0s[:n_s], p_np, local_rank, 1, False)
+                el, s0, s1 = rs.timed(args.steps, args.warmup)
+                kc = s1["adjoint_calls"] - s0["adjoint_calls"]
+                sh.append({"ntraj": n_s, "gpus_of_layout": 10000 // n_s, "ms_per_step": el / args.steps * 1e3, "trajectories_per_s": n_s / (el / args.steps),
+                           "k_interp_ms": (s1["adjoint_main_kernel_ms_total"] - s0["adjoint_main_kernel_ms_total"]) / max(kc, 1),
+                           "time_segments": s1["time_segments"],
+                           "implied_speedup_if_allreduce_hidden": res["ms_per_step"] / (el / args.steps * 1e3)})
+                rs.close()
+            res["shard_sizes"] = sh
+            try:
+                res["other_configs"] = other_configs(sa, torch)
+            except Exception as e:      # the headline must not die on a secondary figure
+                res["other_configs_error"] = repr(e)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(u0_all, p_np, ts)
+    if rank == 0:
         print(json.dumps(res))
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
 

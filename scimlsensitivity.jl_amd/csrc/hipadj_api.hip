@@ -231,6 +231,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_FUSED_FINAL")) h->fused_final = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_WPB")) h->wpb4 = std::atoi(e) == 4;
+    if (const char* e = std::getenv("HIPADJ_NO_OPS")) h->no_ops = std::atoi(e) != 0;
     if (const char* e = std::getenv("HIPADJ_CBS")) h->cbs = std::atoi(e);
     h->fg.N = h->N; h->fg.S = (int)S; h->fg.M = h->M; h->fg.t0 = cfg->t0; h->fg.dt = cfg->dt; h->fg.loss_shift = cfg->loss_shift;
     h->fg.loss_kind = cfg->loss_kind; h->fg.no_start = cfg->no_start; h->fg.p_shared = cfg->p_shared;

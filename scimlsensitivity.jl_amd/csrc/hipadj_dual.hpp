@@ -101,7 +101,9 @@ template <int K> HIPADJ_HD Dual<K> sinh(const Dual<K>& x) { return dual_chain(x,
 template <int K> HIPADJ_HD Dual<K> cosh(const Dual<K>& x) { return dual_chain(x, ::cosh(x.v), ::sinh(x.v)); }
 template <int K> HIPADJ_HD Dual<K> atan(const Dual<K>& x) { return dual_chain(x, ::atan(x.v), 1.0 / (1.0 + x.v * x.v)); }
 template <int K> HIPADJ_HD Dual<K> fabs(const Dual<K>& x) { return dual_chain(x, ::fabs(x.v), x.v < 0.0 ? -1.0 : 1.0); }
-template <int K> HIPADJ_HD Dual<K> pow(const Dual<K>& x, double e) { const double pw = ::pow(x.v, e - 1.0); return dual_chain(x, pw * x.v, e * pw); }
+// value and derivative are formed separately: pow(x, e-1) * x is inf * 0 = NaN at x == 0 for e < 1 where pow(0, e) is finite;
+// e == 0 has derivative 0 everywhere (also at x == 0, where e * pow(0, -1) would be 0 * inf)
+template <int K> HIPADJ_HD Dual<K> pow(const Dual<K>& x, double e) { return dual_chain(x, ::pow(x.v, e), e == 0.0 ? 0.0 : e * ::pow(x.v, e - 1.0)); }
 template <int K> HIPADJ_HD Dual<K> pow(const Dual<K>& x, int e) { return pow(x, (double)e); }
 template <int K> HIPADJ_HD Dual<K> pow(const Dual<K>& x, const Dual<K>& e) { return exp(e * log(x)); }
 

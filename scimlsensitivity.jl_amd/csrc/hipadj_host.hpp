@@ -58,6 +58,7 @@ struct hipadj_handle {
     AdaptGeom ag{};
     int cbs = 0;         // k_compose_finish workgroup size: 0 = by ensemble size, 64 / 256 forced (HIPADJ_CBS; tuning study)
     bool wpb4 = false;   // k_interp in 256-thread workgroups (HIPADJ_WPB=4; tuning study)
+    bool no_ops = false; // HIPADJ_NO_OPS=1: the generic vjp_u / vjp_p form of the multi-column step also for models with stage operators (A/B study)
     double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr, *d_arec = nullptr;
     int *d_nsteps = nullptr, *d_nsteps_adj = nullptr, ntstops = 0, SmaxA = 0;
     bool auto_steps = false;              // max_steps == 0: record capacity sized from a counting pass of the forward solve

@@ -90,16 +90,25 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS, true, 4>), dim3((items + 3) / 4), dim3(4 * WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
                                   h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
             dispatch_events = true;
-        } else if (h->timing >= 1) {
+        } else {
             // the dominant kernel's own begin/end timestamps (events attached to the dispatch packet): what rocprofv3 reports
             // as the kernel's duration.  A hipEventRecord pair around the launch also counts the two marker packets and the
             // dispatch latency (+8-10 us on a 0.12 ms kernel).
-            hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, k0, k1, 0, h->g, sp, p,
-                                  (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
-            dispatch_events = true;
-        } else
-        hipLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p,
-                           (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
+            const hipEvent_t e0 = h->timing >= 1 ? k0 : (hipEvent_t) nullptr, e1 = h->timing >= 1 ? k1 : (hipEvent_t) nullptr;
+            bool launched = false;
+            if constexpr (model_has_ops<Mo>::value && (LOSS >> 1) == 0) {
+                // shared parameters + several time segments: the stage-operator form of the multi-column step (adj_rk4_step_ops)
+                if (h->cfg.p_shared && h->nseg > 1 && !h->no_ops) {
+                    hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS, true, 1, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, p,
+                                          (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
+                    launched = true;
+                }
+            }
+            if (!launched)
+                hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, p,
+                                      (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
+            dispatch_events = h->timing >= 1;
+        }
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1 && !dispatch_events) HIP_TRY(h, hipEventRecord(k1, h->stream));
         launch_compose();

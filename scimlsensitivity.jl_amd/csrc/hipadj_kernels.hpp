@@ -42,7 +42,9 @@ __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restri
 // workgroups whose four waves take four consecutive (wave block, segment) items — the hardware spreads the waves of ONE
 // workgroup over the four SIMDs of its CU, which single-wave workgroups do not guarantee (a SIMD that happens to receive
 // three of a CU's eight waves finishes 1.5x later than the kernel needs).
-template <class Mo, int PF, int LOSS, bool SEG = true, int WPB = 1>
+// PSH = true: launched only when the parameters are shared (g.p_shared): lets models with stage operators keep their (p, dt)
+// constants in SGPRs (interp_lane).
+template <class Mo, int PF, int LOSS, bool SEG = true, int WPB = 1, bool PSH = false>
 __global__ void __launch_bounds__(WAVE * WPB) k_interp(Geom g, SegPlan sp, const double* __restrict__ p,
                                                        const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                                                        const int* __restrict__ save_of_knot, double* __restrict__ segbuf) {
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(WAVE * WPB) k_interp(Geom g, SegPlan sp, const
         for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
     } else if constexpr (SEG) {
         double lam[NC][N], mu[NC][NP];
-        interp_lane<Mo, NC, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        interp_lane<Mo, NC, PF, LOSS, 0, PSH>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll

@@ -234,6 +234,50 @@ HIPADJ_HD void adj_rk4_stages(const double (&y_hi)[Mo::N], const double (&ymid)[
 // The same step on the common grid: stage states from two knots (theta = 0, 1/2, 1).  Kept as its own copy of the stage
 // arithmetic — this is the body of the tuned streaming kernels, whose instruction schedule is not to move when the general
 // form above changes.
+// The multi-column form of the step for models that carry stage operators (model_has_ops; hipadj_models.hpp).  A lane of a
+// lower time segment advances 1 + n columns through the same y(t), and at 10^4 trajectories the sweep is bound by FP64 issue, not
+// by HBM, so the per-column instruction count is what sets the kernel time.  With h = dt and the stage matrices
+//   M1 = I + h/2 J(y_hi)^T ,  Lm = h/2 J(y_mid)^T ,  Lm2 = h J(y_mid)^T ,  M4 = 1/3 I + h/6 J(y_lo)^T
+// the classic stages read   l2 = M1 lam ,  l3 = lam + Lm l2 ,  l4 = lam + Lm2 l3   and, with V1 = 2 (l2 - lam)/h, V2 = 2 (l3 - lam)/h,
+// V3 = (l4 - lam)/h,  the update  lam + h/6 (V1 + 2 V2 + 2 V3 + V4)  becomes
+//   lam' = -1/3 lam + 1/3 l2 + 2/3 l3 + M4 l4
+// — the same RK4 step in a different association (differences at roundoff level; the coefficients sum to 1, no cancellation
+// beyond an ulp of lam), 41 FP64 instructions per column for Lorenz instead of 49, all FMAs but the three leading multiplies.
+// mu' = -(df/dp)^T lam with weights 1:2:2:1 and stages 2, 3 sharing y_mid:  mu += P1 lam + Pm (l2 + l3) + P4 l4  with
+// P1 = h/6 f_p(y_hi)^T, Pm = h/3 f_p(y_mid)^T, P4 = h/6 f_p(y_lo)^T: 12 instead of 21.  Costs without a continuous term only.
+template <class Mo, int NC, bool WITH_MU>
+HIPADJ_HD void adj_rk4_step_ops(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&oc)[model_ops_count<Mo>::value], double t_lo, double dt,
+                                double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
+    constexpr int N = Mo::N;
+    double ymid[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]);
+    const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
+    typename Mo::JT M1, Lm, Lm2, M4;
+    Mo::template jt_prep<0>(M1, oc, hi.u, t_hi);
+    Mo::template jt_prep<1>(Lm, oc, ymid, t_mid);
+    Mo::template jt_prep<2>(Lm2, oc, ymid, t_mid);
+    Mo::template jt_prep<3>(M4, oc, lo.u, t_lo);
+    typename Mo::PT P1, Pm, P4;
+    if (WITH_MU) { Mo::template pt_prep<0>(P1, oc, hi.u, t_hi); Mo::template pt_prep<1>(Pm, oc, ymid, t_mid); Mo::template pt_prep<0>(P4, oc, lo.u, t_lo); }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double l2[N], l3[N], l4[N], acc[N];
+        Mo::jt_mul(l2, M1, lam[c]);
+        Mo::jt_mul_add(l3, Lm, lam[c], l2);
+        Mo::jt_mul_add(l4, Lm2, lam[c], l3);
+        if (WITH_MU) {
+            double l23[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) l23[j] = l2[j] + l3[j];
+            Mo::pt_acc(mu[c], P1, lam[c]); Mo::pt_acc(mu[c], Pm, l23); Mo::pt_acc(mu[c], P4, l4);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = (2.0 / 3.0) * l3[j] + (1.0 / 3.0) * (l2[j] - lam[c][j]);
+        Mo::jt_mul_add(lam[c], M4, acc, l4);
+    }
+}
+
 template <class Mo, int NC, bool WITH_MU, int CC = 0>
 HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&pv)[Mo::NP], double t_lo, double dt,
                             double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
@@ -501,13 +545,22 @@ HIPADJ_HD void reverse_sweep_ckpt(const Geom& g, long i, int k_lo, int k_hi, con
 //   top segment (k_hi == S): NC = 1, the jump at T is applied before the first step.
 // The jump at knot k_lo is applied at the end (so segment results chain without double counting).
 // ------------------------------------------------------------------------------------------------
-template <class Mo, int NC, int PF, int MODE, int KMAX = 0>   // MODE = discrete-loss kind | (continuous cost << 1)
+// PSH = true: the caller guarantees shared parameters (g.p_shared); multi-column lanes of models with stage operators then run
+// adj_rk4_step_ops with the (p, dt)-only constants in SGPRs.
+template <class Mo, int NC, int PF, int MODE, int KMAX = 0, bool PSH = false>   // MODE = discrete-loss kind | (continuous cost << 1)
 HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const double* __restrict__ p,
                            const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                            const int* __restrict__ save_of_knot, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP],
                            const CkptSrc* ck = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
+    constexpr bool OPS = model_has_ops<Mo>::value && NC > 1 && CC == 0 && PSH;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
+    double oc[model_ops_count<Mo>::value];
+    if constexpr (OPS) {
+        Mo::ops_const(oc, pv, g.dt);
+#pragma unroll
+        for (int q = 0; q < model_ops_count<Mo>::value; ++q) oc[q] = hipadj_uniform(oc[q]);
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -520,7 +573,8 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
         for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
     };
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
-        adj_rk4_step<Mo, NC, true, CC>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
+        if constexpr (OPS) adj_rk4_step_ops<Mo, NC, true>(hi, lo, oc, g.t0 + k * g.dt, g.dt, lam, mu);
+        else adj_rk4_step<Mo, NC, true, CC>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
 #pragma unroll
         for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
     };

@@ -23,6 +23,23 @@
 
 namespace hipadj {
 
+// does a model carry the stage operators (JT / PT) of the multi-column sweep?  (runtime-compiled user models and the small
+// registry models do not: they run the generic vjp_u / vjp_p form)
+template <class Mo, class = void> struct model_has_ops { static constexpr bool value = false; };
+template <class Mo, class = void> struct model_ops_count { static constexpr int value = 1; };
+#if !defined(HIPADJ_DISABLE_OPS)     // development A/B switch (scripts/kbench.hip): the generic form for every model
+template <class Mo> struct model_has_ops<Mo, decltype((void)Mo::HAS_OPS)> { static constexpr bool value = Mo::HAS_OPS; };
+template <class Mo> struct model_ops_count<Mo, decltype((void)Mo::NOC)> { static constexpr int value = Mo::NOC; };
+#endif
+// A wave-uniform double as the compiler should see it: both halves through v_readfirstlane, i.e. an SGPR pair (device code only).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double hipadj_uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+#else
+inline double hipadj_uniform(double v) { return v; }
+#endif
+
 constexpr int HIPADJ_CKPT_KMAX = 16;   // longest checkpoint interval (steps) the in-kernel re-solve tile holds
 
 // Lotka-Volterra (test/Core3/user_vjp.jl:6-10): du1 = p1 u1 - p2 u1 u2 ; du2 = -p3 u2 + p4 u1 u2
@@ -77,6 +94,49 @@ struct ModelLorenz {
     }
     HIPADJ_HD static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&)[NP], double) {
         dg[0] = (u[1] - u[0]) * l[0]; dg[1] = u[0] * l[1]; dg[2] = -u[2] * l[2];
+    }
+    // Stage operators for the multi-column (time-segmented) reverse sweep — adj_rk4_step_ops, hipadj_lane.hpp.  The same two
+    // products as vjp_u / vjp_p, split three ways:
+    //   ops_const   what depends on (p, dt) only: formed ONCE per lane; with shared parameters the sweep moves these values to
+    //               SGPRs (wave-uniform), so they cost neither VGPRs nor instructions inside the time loop
+    //   jt_prep / pt_prep   the y-dependent entries of  JT = shift I + c (df/du)^T  and  PT = c (df/dp)^T : once per stage, shared
+    //               by the 1 + n columns of the lane
+    //   jt_mul / jt_mul_add / pt_acc   per column: out = JT l , out = base + JT l , mu += PT l — pure FMA chains
+    // (df/du)^T = [-s  r-z  y ;  s  -1  x ;  0  -x  -b]  at u = (x, y, z), p = (s, r, b); (df/dp)^T = diag(y - x, x, -z).
+    // The four JT of a step (which = 0..3): M1 = I + h/2 J(y_hi)^T, Lm = h/2 J(y_mid)^T, Lm2 = h J(y_mid)^T, M4 = I/3 + h/6 J(y_lo)^T;
+    // the two PT scales (which = 0, 1): h/6, h/3.
+    static constexpr bool HAS_OPS = true;
+    static constexpr int NOC = 26;       // 4 x {c, d0, d1, d2, a10, c r} + {h/6, h/3}
+    struct JT { double d0, d1, d2, a10, a01, a02, a12; };
+    struct PT { double q0, q1, q2; };
+    HIPADJ_HD static void ops_const(double (&oc)[NOC], const double (&p)[NP], double h) {
+        const double cs[4] = {0.5 * h, 0.5 * h, h, h / 6.0}, sh[4] = {1.0, 0.0, 0.0, 1.0 / 3.0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            oc[6 * w + 0] = cs[w]; oc[6 * w + 1] = sh[w] - cs[w] * p[0]; oc[6 * w + 2] = sh[w] - cs[w]; oc[6 * w + 3] = sh[w] - cs[w] * p[2];
+            oc[6 * w + 4] = cs[w] * p[0]; oc[6 * w + 5] = cs[w] * p[1];
+        }
+        oc[24] = h / 6.0; oc[25] = h / 3.0;
+    }
+    template <int W> HIPADJ_HD static void jt_prep(JT& J, const double (&oc)[NOC], const double (&u)[N], double) {
+        J.d0 = oc[6 * W + 1]; J.d1 = oc[6 * W + 2]; J.d2 = oc[6 * W + 3]; J.a10 = oc[6 * W + 4];
+        J.a01 = oc[6 * W + 5] - oc[6 * W] * u[2]; J.a02 = oc[6 * W] * u[1]; J.a12 = oc[6 * W] * u[0];
+    }
+    HIPADJ_HD static void jt_mul(double (&o)[N], const JT& J, const double (&l)[N]) {
+        o[0] = J.d0 * l[0] + J.a01 * l[1] + J.a02 * l[2];
+        o[1] = J.a10 * l[0] + J.d1 * l[1] + J.a12 * l[2];
+        o[2] = J.d2 * l[2] - J.a12 * l[1];
+    }
+    HIPADJ_HD static void jt_mul_add(double (&o)[N], const JT& J, const double (&b)[N], const double (&l)[N]) {
+        o[0] = b[0] + J.d0 * l[0] + J.a01 * l[1] + J.a02 * l[2];
+        o[1] = b[1] + J.a10 * l[0] + J.d1 * l[1] + J.a12 * l[2];
+        o[2] = b[2] + J.d2 * l[2] - J.a12 * l[1];
+    }
+    template <int W> HIPADJ_HD static void pt_prep(PT& Q, const double (&oc)[NOC], const double (&u)[N], double) {
+        Q.q0 = oc[24 + W] * (u[1] - u[0]); Q.q1 = oc[24 + W] * u[0]; Q.q2 = -oc[24 + W] * u[2];
+    }
+    HIPADJ_HD static void pt_acc(double (&mu)[NP], const PT& Q, const double (&l)[N]) {
+        mu[0] += Q.q0 * l[0]; mu[1] += Q.q1 * l[1]; mu[2] += Q.q2 * l[2];
     }
 };
 

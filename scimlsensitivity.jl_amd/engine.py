@@ -44,6 +44,7 @@ class Engine:
         if rc != _lib.OK:
             raise HipadjError(rc, L.hipadj_last_error(None).decode())
         self._h = h
+        self.forward_generation = 0     # bumped by every forward solve: the handle holds ONE forward solution (interface.EnsembleAdjoint checks it)
         st = self.stats()
         self.n, self.np = st["n"], st["np"]
 
@@ -78,6 +79,7 @@ class Engine:
         if p.shape != ((self.np,) if self.p_shared else (self.N, self.np)):
             raise ValueError(f"p has shape {p.shape}")
         out = np.empty((self.N, self.M, self.n)) if (want_out and self.M) else None
+        self.forward_generation += 1
         self._check(self._L.hipadj_forward(self._h, _dptr(u0), _dptr(p), _dptr(out) if out is not None else None))
         return out
 
@@ -97,6 +99,9 @@ class Engine:
         self._check(self._L.hipadj_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def forward_dev(self, u0, p, out=None):
+        """Asynchronous on the handle's stream; errors raised ON the device (non-finite values, Tsit5 step capacity) surface at the
+        next synchronize() — call it before consuming du0 / dp."""
+        self.forward_generation += 1
         self._check(self._L.hipadj_forward_dev(self._h, C.c_void_p(u0.data_ptr()), C.c_void_p(p.data_ptr()),
                                                C.c_void_p(out.data_ptr()) if out is not None else None))
 

@@ -122,7 +122,8 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
         if out is not None:
             out = np.ascontiguousarray(out[:, :, idxs])
     return EnsembleSolution(engine=eng, u=out, t=ts, prob=ensprob, alg=alg, dt=dt,
-                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g, save_idxs=idxs))
+                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g, save_idxs=idxs,
+                                       checkpoints=(None if checkpoints is None else np.asarray(checkpoints, dtype=np.float64))))
 
 
 def _dgdp_sum(sol, dgdp, shared):
@@ -159,6 +160,16 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_di
     want_alg = (sensealg or sol.extra["sensealg"])
     if want_alg.name != eng.alg:
         raise ValueError(f"solution was prepared for sensealg={eng.alg!r}; re-run solve(...; sensealg={want_alg!r})")
+    # the handle was configured at solve time (checkpointing flag, Quadrature tolerances, checkpoint list): anything different
+    # handed here would be silently dropped, so it is an error like a different g / LsqShift (the reference builds the adjoint
+    # problem from THESE arguments, src/sensitivity_interface.jl:426-526)
+    if sensealg is not None and sensealg != sol.extra["sensealg"]:
+        raise ValueError(f"sensealg={sensealg!r} differs from the one the forward solve was prepared with ({sol.extra['sensealg']!r}); "
+                         "pass it to solve(...)")
+    if checkpoints is not None:
+        ck0 = sol.extra.get("checkpoints")
+        if ck0 is None or not (len(ck0) == len(checkpoints) and np.allclose(np.asarray(checkpoints, dtype=np.float64), ck0, rtol=0, atol=1e-12)):
+            raise ValueError("checkpoints differ from the list the forward solve was prepared with; pass checkpoints=... to solve(...)")
     if t is not None and not (len(t) == len(sol.t) and np.allclose(np.asarray(t, dtype=np.float64), sol.t, rtol=0, atol=1e-12)):
         raise ValueError("t must equal the save times the forward solve was run with")
     if isinstance(dgdu_discrete, LsqShift):
@@ -198,23 +209,44 @@ def make_autograd_function():
     import torch
 
     class EnsembleAdjoint(torch.autograd.Function):
+        """out = EnsembleAdjoint.apply(u0 [N][n], p [np] or [N][np], engine).  The forward solution lives in the engine's single
+        handle: a second forward on the same engine before the backward of the first invalidates it, which backward detects
+        (forward-generation counter) instead of differentiating the wrong solution.  Both directions end with
+        engine.synchronize(): the device-pointer calls of the C ABI are asynchronous and only hipadj_synchronize reads the device
+        status word (non-finite sensitivities, Tsit5 step-capacity overflow = the reference's unstable / MaxIters retcodes)."""
+
         @staticmethod
         def forward(ctx, u0, p, engine):
             if not (u0.is_cuda and p.is_cuda and u0.dtype == torch.float64 and p.dtype == torch.float64):
                 raise ValueError("u0 and p must be float64 tensors on the engine's GPU")
+            if u0.device.index != engine.device or p.device.index != engine.device:
+                raise ValueError(f"u0 / p live on cuda:{u0.device.index} / cuda:{p.device.index}, the engine on cuda:{engine.device}")
+            if tuple(u0.shape) != (engine.N, engine.n):
+                raise ValueError(f"u0 must be [{engine.N}][{engine.n}], got {tuple(u0.shape)}")
+            want_p = (engine.np,) if engine.p_shared else (engine.N, engine.np)
+            if tuple(p.shape) != want_p:
+                raise ValueError(f"p must have shape {want_p}, got {tuple(p.shape)}")
             engine.use_torch_stream()
             out = torch.empty((engine.N, engine.M, engine.n), dtype=torch.float64, device=u0.device)
             engine.forward_dev(u0.contiguous(), p.contiguous(), out)
+            engine.synchronize()
             ctx.engine = engine
+            ctx.generation = engine.forward_generation
             return out
 
         @staticmethod
         def backward(ctx, grad_out):
             eng = ctx.engine
+            if eng.forward_generation != ctx.generation:
+                raise RuntimeError("the engine ran another forward solve since this output was produced: its handle holds ONE forward "
+                                   "solution (use one Engine per live forward, or call backward before the next forward)")
+            if tuple(grad_out.shape) != (eng.N, eng.M, eng.n):
+                raise ValueError(f"cotangent must be [{eng.N}][{eng.M}][{eng.n}], got {tuple(grad_out.shape)}")
             eng.use_torch_stream()
             du0 = torch.empty((eng.N, eng.n), dtype=torch.float64, device=grad_out.device)
             dp = torch.empty((eng.np,) if eng.p_shared else (eng.N, eng.np), dtype=torch.float64, device=grad_out.device)
             eng.adjoint_dev(grad_out.contiguous(), du0, dp)
+            eng.synchronize()
             return du0, dp, None
 
     return EnsembleAdjoint

@@ -13,6 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def _hip_device_count():
+    """Is a ROCm GPU visible?  Read from the kernel driver's device node — not through a HIP runtime: loading /opt/rocm's
+    libamdhip64 into the test process next to the one torch bundles would give the process two HIP runtimes."""
+    return 1 if os.path.exists("/dev/kfd") else 0
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a machine without a GPU: the `gpu`-marked tests are skipped at collection time (the product has no CPU
+    fallback, they could only fail with HIPADJ_ERR_NO_DEVICE).  `-m gpu` on a box that HAS a device is unaffected."""
+    if not any("gpu" in it.keywords for it in items) or _hip_device_count() > 0:
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible (there is no CPU fallback)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import json

@@ -118,6 +118,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             } else {
                 double lam[NC][N], mu[NC][NP];
                 if (P.ip_ckpt) interp_lane<Mo, NC, PF, LOSS, KM>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, nullptr, cot, P.save_of_knot_rev.data(), lam, mu, &CK);
+                else if (g.p_shared) interp_lane<Mo, NC, PF, LOSS, 0, true>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot_rev.data(), lam, mu);   // as the library: stage-operator step for models that carry one
                 else interp_lane<Mo, NC, PF, LOSS>(g, i, P.seg_bounds[seg], P.seg_bounds[seg + 1], p, knots.data(), cot, P.save_of_knot_rev.data(), lam, mu);
                 for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
                                                for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; }

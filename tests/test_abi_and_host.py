@@ -292,6 +292,16 @@ def test_host_mirror_logic_with_a_stub_engine(sa, monkeypatch):
         sa.adjoint_sensitivities(sol, sa.Tsit5(), t=[0.3, 0.8], dgdu_discrete=sa.LsqShift(2.0))
     with pytest.raises(ValueError, match="re-run solve"):
         sa.adjoint_sensitivities(sol, sa.Tsit5(), sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+    # a sensealg with other options, or another checkpoint list, at adjoint time is an error, not silently the solve-time value
+    with pytest.raises(ValueError, match="differs from the one the forward solve"):
+        sa.adjoint_sensitivities(sol, sa.Tsit5(), sensealg=sa.QuadratureAdjoint(abstol=1e-12, reltol=1e-12), dgdu_discrete=sa.LsqShift(2.0))
+    sa.adjoint_sensitivities(sol, sa.Tsit5(), sensealg=sa.QuadratureAdjoint(abstol=1e-9, reltol=1e-8), dgdu_discrete=sa.LsqShift(2.0))
+    solc = sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.5, 1.0])
+    sa.adjoint_sensitivities(solc, sa.RK4(), checkpoints=[0.0, 0.5, 1.0], dgdu_discrete=np.zeros((4, 5, 3)))
+    with pytest.raises(ValueError, match="checkpoints differ"):
+        sa.adjoint_sensitivities(solc, sa.RK4(), checkpoints=[0.0, 0.25, 0.5, 0.75, 1.0], dgdu_discrete=np.zeros((4, 5, 3)))
+    with pytest.raises(ValueError, match="checkpoints differ"):
+        sa.adjoint_sensitivities(sol, sa.Tsit5(), checkpoints=[0.3, 0.9], dgdu_discrete=sa.LsqShift(2.0))
     # equally spaced custom checkpoints -> ckpt_stride; anything else is refused
     sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.2, 0.4, 0.6, 0.8, 1.0])
     assert _StubEngine.created[-1].kw["ckpt_stride"] == 20
@@ -337,6 +347,7 @@ def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
     u0b, _ = bench.inputs(300)
     assert np.array_equal(u0, u0b) and u0.shape == (300, 3) and np.allclose(p, [10.0, 28.0, 8 / 3])
     ts = np.linspace(0.0, bench.T_FINAL, 101)
-    cb, du0, dp, n = bench.cpu_baseline(u0, p, ts, budget_s=0.05)
+    cb = bench.cpu_baseline(u0, p, ts, budget_s=0.05)
     assert cb["kind"] == "port" and cb["unit"] == "trajectories/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread_value"] > 0
-    assert "sample" in cb and du0.shape == (n, 3) and dp.shape == (3,) and 1 <= n <= 300
+    assert "sample" in cb and f"{cb['cores']} of {cb['host_threads']} host threads" in cb["cores_note"]
+    assert np.allclose(bench.save_times(), ts) and bench.oracle_problem().M == 101

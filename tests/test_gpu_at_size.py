@@ -1,0 +1,129 @@
+"""Parity at the sizes BASELINE.json's configs state (`-m gpu`): the HIP path through the C ABI vs the CPU oracle on the
+same seeded inputs, including the reduced dL/dp — the one quantity that crosses GPUs.  Tolerance rtol = 1e-6 (Float64).
+
+  C2  Lorenz-63, 10^4 trajectories x 1000 RK4 steps, InterpolatingAdjoint              du0 and dp over ALL trajectories
+  C3  the same ensemble, BacksolveAdjoint(checkpointing=true), checkpoints every 10 steps  (test/Core3/adjoint.jl:1201-1241:
+      Backsolve with checkpoints ~ Interpolating on Lorenz)                              du0 and dp over ALL trajectories
+  C4  MLP 2 -> 128 -> 128 -> 2, 4096 columns, 150 RK4 steps, GaussAdjoint                du0 on a column sample, dp on a column chunk
+  C5  Brusselator 32 x 32 (n = 2048), 400 RK4 steps, QuadratureAdjoint                  du0, dp, out
+
+The oracle runs multi-threaded over trajectories (tests/oracle.py); the whole file takes well under a minute of host time."""
+import numpy as np
+import pytest
+
+import oracle as O
+from test_gpu_parity import RTOL, rel, lorenz_inputs, mlp_params, bruss_u0
+
+pytestmark = pytest.mark.gpu
+
+
+def _c2_setup():
+    N, T, dt = 10000, 10.0, 0.01
+    u0, p = lorenz_inputs(N)            # seed 20240601: bench.py's ensemble
+    return N, T, dt, u0, p, np.linspace(0.0, T, 101)
+
+
+def test_config2_full_ensemble_du0_and_dp_vs_oracle(sa):
+    """BASELINE configs[1] at size: every trajectory's du0 and the REDUCED dp against the oracle run on all 10^4 trajectories,
+    for the fused LSQ loss (bench.py's workload) and for random cotangents (the AD path)."""
+    N, T, dt, u0, p, ts = _c2_setup()
+    prob = sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0)
+    sol = sa.solve(prob, sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0), want_out=False)
+    assert sol.engine.stats()["time_segments"] > 1          # the time-segmented kernel is the one under test
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+    sol.engine.close()
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, want_out=False)
+    assert rel(du0, rdu0) < RTOL
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < RTOL     # component-wise: no component hides behind a larger one
+    # cotangent path
+    delta = np.random.default_rng(3).standard_normal((N, len(ts), 3))
+    sol = sa.solve(prob, sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint(), want_out=False)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    sol.engine.close()
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT")
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, delta, want_out=False)
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+
+
+@pytest.mark.parametrize("shards", [1, 8])
+def test_config3_backsolve_checkpointed_at_size(sa, shards):
+    """BASELINE configs[2]: 10^4 x 1000 steps, BacksolveAdjoint(checkpointing=true), a checkpoint every 10 steps (= every loss time).
+    shards = 8 runs the eight 1250-trajectory shards of the 8-GPU layout one after the other on this GPU and sums their dp on the
+    host (the all-reduce): per-trajectory du0 and the reduced dp against the oracle over the whole ensemble; and, as the reference
+    asserts on Lorenz (test/Core3/adjoint.jl:1201-1203, 1236-1241), Backsolve with checkpoints ~ Interpolating at rtol 1e-5... here
+    on the reduced dp at 1e-4 (observed 6e-6; the backsolved states between checkpoints differ by the RK4 truncation error of a 10-step interval)."""
+    N, T, dt, u0, p, ts = _c2_setup()
+    du0 = np.empty((N, 3)); dp = np.zeros(3)
+    for r in range(shards):
+        lo, hi = sa.shard_range(N, r, shards)
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0[lo:hi]), sa.RK4(), dt=dt, saveat=ts,
+                       sensealg=sa.BacksolveAdjoint(checkpointing=True), dgdu_discrete=sa.LsqShift(2.0), want_out=False)
+        a, b = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+        du0[lo:hi] = a; dp += b
+        sol.engine.close()
+    ref = O.Problem("LORENZ", alg="BACKSOLVE", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, checkpointing=True)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, want_out=False)
+    assert rel(du0, rdu0) < RTOL
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < RTOL
+    refi = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    _, idp, _, _ = refi.adjoint_ensemble(u0, p, want_out=False)
+    assert rel(dp, idp) < 1e-4
+
+
+def test_config4_mlp_gauss_150_steps(sa):
+    """BASELINE configs[3] at its benchmarked length (150 RK4 steps, 30 loss times, 4096 columns).  The batch columns are independent
+    2-state ODEs that share the weights, so the oracle restricted to a column subset gives those columns' du0 exactly and the
+    subset's share of dp: du0 of the full-width run is checked on 256 sampled columns, dp of a device run on the first 256 columns
+    against the oracle on the same columns, and the full-width dp against the sum of the sixteen 256-column device runs."""
+    d, H, B, T, dt = 2, 128, 4096, 1.5, 0.01
+    rng = np.random.default_rng(8)
+    u0 = rng.standard_normal((1, d * B)); p = mlp_params(d, H)
+    ts = np.linspace(0.05, T, 30)
+    delta = rng.standard_normal((1, len(ts), d * B))
+
+    def device(cols):
+        nb = len(cols)
+        sel = (cols[:, None] * d + np.arange(d)[None, :]).ravel()
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("mlp", u0[0, sel], (0, T), p, (d, H, nb, 0)), u0[:, sel]), sa.RK4(), dt=dt, saveat=ts,
+                       sensealg=sa.GaussAdjoint(), want_out=False)
+        out = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta[:, :, sel])
+        sol.engine.close()
+        return out, sel
+
+    (a_full, b_full), _ = device(np.arange(B))
+    # 16 chunks of 16 sampled columns: one oracle "trajectory" per chunk, OpenMP over the chunks
+    cols = np.sort(rng.choice(B, 256, replace=False))
+    sel = (cols[:, None] * d + np.arange(d)[None, :]).ravel()
+    ref = O.Problem("MLP", alg="GAUSS", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", dims=(d, H, 16, 0))
+    rdu0, _, _, _ = ref.adjoint_ensemble(u0[0, sel].reshape(16, 16 * d), p,
+                                         np.ascontiguousarray(delta[0][:, sel].reshape(len(ts), 16, 16 * d).transpose(1, 0, 2)), want_out=False)
+    assert rel(a_full[0, sel], rdu0.ravel()) < RTOL
+    # dp: device run on the first 256 columns vs the oracle on the same columns (16 chunks, shared p => summed)
+    first = np.arange(256)
+    (a_c, b_c), selc = device(first)
+    _, rdp, _, _ = ref.adjoint_ensemble(u0[0, selc].reshape(16, 16 * d), p,
+                                        np.ascontiguousarray(delta[0][:, selc].reshape(len(ts), 16, 16 * d).transpose(1, 0, 2)), want_out=False)
+    assert rel(b_c, rdp) < RTOL
+    assert rel(a_full[0, selc], a_c[0]) < 1e-10
+    b_sum = b_c.copy()
+    for k in range(1, B // 256):
+        b_sum += device(np.arange(256 * k, 256 * (k + 1)))[0][1]
+    assert rel(b_full, b_sum) < 1e-9
+
+
+def test_config5_brusselator_quadrature_400_steps(sa):
+    """BASELINE configs[4]: 32 x 32 grid (n = 2048), QuadratureAdjoint, 400 explicit RK4 steps at the stability limit dt = 2.5e-5."""
+    G, dt, t0, t1 = 32, 2.5e-5, 0.0, 0.01
+    u0 = bruss_u0(G, 1); p = np.array([3.4, 1.0, 10.0])
+    ts = np.array([0.0, 0.0025, 0.005, 0.0075, 0.01])
+    dims = (G, 0, 0, 0)
+    d1 = np.random.default_rng(1).standard_normal((1, len(ts), 2048))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("bruss", u0[0], (t0, t1), p, dims), u0), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10))
+    a1, b1 = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=d1)
+    ref = O.Problem("BRUSS", alg="QUADRATURE", stepper="RK4", t0=t0, t1=t1, dt=dt, save_times=ts, loss="COTANGENT", dims=dims,
+                    quad_abstol=1e-10, quad_reltol=1e-10)
+    rdu0, rdp, rout = ref.adjoint(u0[0], p, d1[0])
+    assert rel(sol.u[0], rout) < RTOL and rel(a1[0], rdu0) < RTOL and rel(b1, rdp) < RTOL
+    sol.engine.close()
