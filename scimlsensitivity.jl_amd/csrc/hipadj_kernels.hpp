@@ -44,8 +44,11 @@ __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restri
 // three of a CU's eight waves finishes 1.5x later than the kernel needs).
 // PSH = true: launched only when the parameters are shared (g.p_shared): lets models with stage operators keep their (p, dt)
 // constants in SGPRs (interp_lane).
+#ifndef HIPADJ_KINTERP_ATTR      // development hook (scripts/kbench.hip): e.g. __attribute__((amdgpu_waves_per_eu(3, 3)))
+#define HIPADJ_KINTERP_ATTR
+#endif
 template <class Mo, int PF, int LOSS, bool SEG = true, int WPB = 1, bool PSH = false>
-__global__ void __launch_bounds__(WAVE * WPB) k_interp(Geom g, SegPlan sp, const double* __restrict__ p,
+__global__ void HIPADJ_KINTERP_ATTR __launch_bounds__(WAVE * WPB) k_interp(Geom g, SegPlan sp, const double* __restrict__ p,
                                                        const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                                                        const int* __restrict__ save_of_knot, double* __restrict__ segbuf) {
     constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;

@@ -280,7 +280,10 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         const int C = P.nseg; P.seg_bounds.assign(C + 1, 0);
         if (C == 1) { P.seg_bounds[1] = (int)S; }
         else {
-            double w_top = 1.0 + 0.8 * n;             // a 1-column lane advances ~w_top steps per (1+n)-column step
+            // a 1-column lane advances ~w_top steps per (1+n)-column step: the ratio of the two step bodies' VALU instruction counts
+            // (Lorenz, stage-operator form of the multi-column step with shared parameters: 263 : 101, profiles/README.md round 2)
+            double w_top = 1.0 + 0.8 * n;
+            if (cfg->model == HIPADJ_MODEL_LORENZ && cfg->p_shared && cfg->alg == HIPADJ_ALG_INTERPOLATING && cfg->cont_cost == HIPADJ_CCOST_NONE && !cfg->checkpointing) w_top = 2.6;
             if (const char* e = std::getenv("HIPADJ_WTOP")) { const double v = std::atof(e); if (v > 0) w_top = v; }   // tuning hook
             const double unit = (double)S / ((C - 1) + w_top);
             double acc = 0.0;

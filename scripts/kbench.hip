@@ -119,9 +119,31 @@ int main(int argc, char** argv) {
         } else {
             hipExtLaunchKernelGGL((k_interp<Mo, KB_PF, 1, true, 1, true>), dim3(waves, 1u), dim3(WAVE), 0, st, k0, k1, 0, g, sp, (const double*)d_p, (const dbl2*)d_knots, (const double*)nullptr, (const int*)d_save, d_segbuf);
         }
-        hipLaunchKernelGGL((k_compose_finish<Mo, 64>), dim3(compose_blocks), dim3(64), 0, st, g, C, (const double*)d_segbuf, d_du0, (double*)nullptr, d_partial, d_flag, d_ticket, (double*)nullptr);
-        hipLaunchKernelGGL(k_reduce_final, dim3(3u), dim3(FIN), 0, st, (int)compose_blocks, 3, (const double*)d_partial, d_dp);
+        if (getenv("KB_FUSED_FINAL")) {
+            hipLaunchKernelGGL((k_compose_finish<Mo, 64>), dim3(compose_blocks), dim3(64), 0, st, g, C, (const double*)d_segbuf, d_du0, (double*)nullptr, d_partial, d_flag, d_ticket, d_dp);
+        } else {
+            hipLaunchKernelGGL((k_compose_finish<Mo, 64>), dim3(compose_blocks), dim3(64), 0, st, g, C, (const double*)d_segbuf, d_du0, (double*)nullptr, d_partial, d_flag, d_ticket, (double*)nullptr);
+            hipLaunchKernelGGL(k_reduce_final, dim3(3u), dim3(FIN), 0, st, (int)compose_blocks, 3, (const double*)d_partial, d_dp);
+        }
     };
+    if (mode == "graph") {     // the three launches of a pass captured once and replayed
+        hipGraph_t gr; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        pass(nullptr, nullptr);
+        CK(hipStreamEndCapture(st, &gr));
+        CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+        CK(hipEventRecord(a0, st));
+        for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(a1, st));
+        CK(hipStreamSynchronize(st));
+        float tot; CK(hipEventElapsedTime(&tot, a0, a1));
+        double dp[3]; CK(hipMemcpy(dp, d_dp, 24, hipMemcpyDeviceToHost));
+        printf("{\"mode\": \"graph\", \"fused_final\": %d, \"ntraj\": %ld, \"segments\": %d, \"pass_ms\": %.5f, \"dp\": [%.17g, %.17g, %.17g]}\n", getenv("KB_FUSED_FINAL") ? 1 : 0, N, C, tot / reps, dp[0], dp[1], dp[2]);
+        return 0;
+    }
     if (mode == "bench") {
         std::vector<hipEvent_t> e0(reps), e1(reps);
         for (int r = 0; r < reps; ++r) { CK(hipEventCreate(&e0[r])); CK(hipEventCreate(&e1[r])); }
@@ -135,6 +157,8 @@ int main(int argc, char** argv) {
         float tot; CK(hipEventElapsedTime(&tot, a0, a1));
         std::vector<float> km(reps);
         for (int r = 0; r < reps; ++r) CK(hipEventElapsedTime(&km[r], e0[r], e1[r]));
+        { double f5 = 0, l5 = 0; for (int r = 0; r < 5 && r < reps; ++r) { f5 += km[r]; l5 += km[reps - 1 - r]; }
+          printf("k_interp ms in launch order: first5 mean %.5f last5 mean %.5f |", f5 / 5, l5 / 5); for (int r = 0; r < reps && r < 12; ++r) printf(" %.4f", km[r]); printf("\n"); }
         std::sort(km.begin(), km.end());
         double mean = 0; for (float v : km) mean += v; mean /= reps;
         double dp[3]; CK(hipMemcpy(dp, d_dp, 24, hipMemcpyDeviceToHost));
@@ -176,6 +200,14 @@ int main(int argc, char** argv) {
     auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
     printf("wave lifetime us: min %.1f p10 %.1f med %.1f p90 %.1f max %.1f | start skew us: med %.1f p90 %.1f max %.1f | last wave ends at %.1f us\n",
            pct(life, 0) / 1e3, pct(life, .1) / 1e3, pct(life, .5) / 1e3, pct(life, .9) / 1e3, pct(life, 1) / 1e3, pct(start, .5) / 1e3, pct(start, .9) / 1e3, pct(start, 1) / 1e3, busy_max / 1e3);
+    if (const char* dump = getenv("KB_TRACE_DUMP")) {   // raw per-wave records for offline analysis: seg wave_block start_ns life_ns xcc se sh cu simd
+        FILE* f = fopen(dump, "w");
+        for (size_t w = 0; w < nw; ++w) {
+            const unsigned hw = (unsigned)(tr[6 * w + 4] & 0xffffffffu), xcc = (unsigned)(tr[6 * w + 4] >> 32) & 0xf;
+            fprintf(f, "%d %zu %.0f %.0f %u %u %u %u %u\n", (int)tr[6 * w + 5], w % waves, start[w], life[w], xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf, (hw >> 4) & 3);
+        }
+        fclose(f);
+    }
     // lifetime by segment kind and by co-residency
     std::vector<double> ltop, llow;
     for (size_t w = 0; w < nw; ++w) ((int)tr[6 * w + 5] == C - 1 ? ltop : llow).push_back(life[w]);
