@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 101 /* 0.1.1: + hipadj_comm_* (RCCL all-reduce of dp), save_times off the step grid, HIPADJ_ERR_RCCL */
+#define HIPADJ_VERSION 102 /* 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -115,6 +115,12 @@ typedef struct {
                                   do not fit, regrows the buffers and repeats the pass (one host sync per forward; bound 100 000
                                   steps = the reference's maxiters) */
     double abstol, reltol;     /* Tsit5: tolerances of the forward AND reverse solves (src/sensitivity_interface.jl:432 defaults 1e-6 / 1e-3) */
+    int32_t ncheckpoints;      /* > 0: the `checkpoints` keyword of adjoint_sensitivities (src/sensitivity_interface.jl:484-486,
+                                  src/backsolve_adjoint.jl:132, src/interpolating_adjoint.jl:54-58): an explicit, strictly ascending list of
+                                  checkpoint times inside [t0, t1] (copied at create); t0 and t1 are added when missing, as the reference's
+                                  interval construction does.  RK4: every time on the step grid t0 + k*dt, any spacing (ckpt_stride must be
+                                  0).  Tsit5: arbitrary times.  0: ckpt_stride, or the save times (the reference default) */
+    const double *checkpoints; /* [ncheckpoints] */
 } hipadj_config;
 
 typedef struct {

@@ -1,0 +1,291 @@
+"""
+    HIPAdj
+
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 102) — the MI355X-native batched continuous-adjoint
+engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
+
+  * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
+    `InterpolatingAdjoint` / `BacksolveAdjoint` / `GaussAdjoint` / `GaussKronrodAdjoint` / `QuadratureAdjoint` and names the
+    device model of the right-hand side.  Loading this package next to SciMLSensitivity activates
+    `ext/SciMLSensitivityHIPAdjExt.jl`, which adds the `_concrete_solve_adjoint` / `_adjoint_sensitivities` methods for it
+    (the same mechanism as `ext/SciMLSensitivityMooncakeExt.jl:123`).
+  * `Handle`, `forward!`, `adjoint!` — the three calls behind it.
+  * `register_model` — the `ODEFunction(f!; vjp, vjp_p)` seam (src/derivative_wrappers.jl:284-359) with C text instead of closures;
+    with Symbolics loaded, `register_model(f!, n, np)` emits the text from a Julia function (ext/HIPAdjSymbolicsExt.jl).
+
+Layouts: Julia is column-major, the ABI row-major — a Julia `Matrix{Float64}` of size `(n, N)` IS the ABI's `u0[N][n]`, an
+`Array{Float64,3}` of size `(n, M, N)` IS `out[N][M][n]`.  No copies, no transposes.
+
+This file was written in an image without Julia and has not been executed; `tests/c/julia_seam.c` performs the same call sequence
+with the same struct layout from C (CPU: loads, exports, loud NO_DEVICE; GPU: numbers against the oracle), so the ABI side of every
+`ccall` below is checked.
+"""
+module HIPAdj
+
+import Libdl
+using SciMLBase: SciMLBase
+
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version
+
+# ---------------------------------------------------------------------------------------------------------------------
+# library
+# ---------------------------------------------------------------------------------------------------------------------
+const LIB = Ref{Ptr{Cvoid}}(C_NULL)
+
+"Path of libhipadj.so: `ENV[\"HIPADJ_LIBRARY\"]`, else the loader's search path."
+libpath() = get(ENV, "HIPADJ_LIBRARY", "libhipadj.so")
+
+function lib()
+    if LIB[] == C_NULL
+        LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
+        v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
+        v == 102 || error("libhipadj ABI version $v, this binding was written for 102")
+    end
+    return LIB[]
+end
+sym(name::Symbol) = Libdl.dlsym(lib(), name)
+
+hipadj_version() = Int(ccall(sym(:hipadj_version), Cint, ()))
+
+# mirrors `hipadj_config` (include/hipadj.h) field by field; Julia lays an isbits struct out like C does
+struct HipadjConfig
+    struct_size::UInt32
+    model::Int32
+    alg::Int32
+    stepper::Int32
+    dims::NTuple{4, Int32}
+    ntraj::Int64
+    t0::Float64
+    t1::Float64
+    dt::Float64
+    nsave::Int32
+    save_times::Ptr{Float64}
+    loss_kind::Int32
+    loss_shift::Float64
+    checkpointing::Int32
+    ckpt_stride::Int32
+    quad_abstol::Float64
+    quad_reltol::Float64
+    no_start::Int32
+    p_shared::Int32
+    device::Int32
+    time_segments::Int32
+    cont_cost::Int32
+    max_steps::Int32
+    abstol::Float64
+    reltol::Float64
+    ncheckpoints::Int32
+    checkpoints::Ptr{Float64}
+end
+
+# byte offsets of include/hipadj.h as the C compiler sees them (tests/c/julia_seam.c asserts the same table with offsetof)
+const CONFIG_OFFSETS = (0, 4, 8, 12, 16, 32, 40, 48, 56, 64, 72, 80, 88, 96, 100, 104, 112, 120, 124, 128, 132, 136, 140, 144,
+                        152, 160, 168)
+const CONFIG_SIZE = 176
+
+function check_layout()
+    sizeof(HipadjConfig) == CONFIG_SIZE || error("HipadjConfig is $(sizeof(HipadjConfig)) bytes, the header says $CONFIG_SIZE")
+    for (i, off) in enumerate(CONFIG_OFFSETS)
+        fieldoffset(HipadjConfig, i) == off ||
+            error("HipadjConfig.$(fieldname(HipadjConfig, i)) at $(fieldoffset(HipadjConfig, i)), the header says $off")
+    end
+    return true
+end
+
+# enums of the header
+const ALG_INTERPOLATING, ALG_BACKSOLVE, ALG_GAUSS, ALG_QUADRATURE, ALG_GAUSS_KRONROD = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
+const STEPPER_RK4_FIXED, STEPPER_TSIT5_ADAPTIVE = Int32(0), Int32(1)
+const LOSS_COTANGENT, LOSS_LSQ_SHIFT = Int32(0), Int32(1)
+const MODEL_USER_BASE = Int32(1000)
+
+struct HipadjError <: Exception
+    status::Int
+    msg::String
+end
+Base.showerror(io::IO, e::HipadjError) = print(io, "hipadj status ", e.status, ": ", e.msg)
+
+last_error(h::Ptr{Cvoid}) = unsafe_string(ccall(sym(:hipadj_last_error), Cstring, (Ptr{Cvoid},), h))
+
+"Non-zero status -> exception carrying `hipadj_last_error` (the reference `error(...)`s on misuse, src/interpolating_adjoint.jl:321-326)."
+function check(rc::Integer, h::Ptr{Cvoid} = C_NULL)
+    rc == 0 && return nothing
+    throw(HipadjError(Int(rc), last_error(h)))
+end
+
+# ---------------------------------------------------------------------------------------------------------------------
+# models
+# ---------------------------------------------------------------------------------------------------------------------
+"A right-hand side that lives on the device: a compiled-in registry entry or a runtime-registered one."
+struct DeviceModel
+    id::Int32
+    dims::NTuple{4, Int32}
+    n::Int
+    np::Int
+end
+
+function model_sizes(id::Integer, dims::NTuple{4, Int32})
+    n = Ref{Int32}(0); np = Ref{Int32}(0)
+    d = Ref(dims)
+    check(ccall(sym(:hipadj_model_sizes), Cint, (Int32, Ptr{Int32}, Ref{Int32}, Ref{Int32}), Int32(id), d, n, np))
+    return Int(n[]), Int(np[])
+end
+
+const BUILTIN = Dict(:lv => 0, :lvt => 1, :lorenz => 2, :lindiag => 3, :fallmass => 4, :mlp => 5, :bruss => 6)
+
+"`builtin_model(:lorenz)`, `builtin_model(:mlp; dims = (2, 128, 4096))`, `builtin_model(:bruss; dims = (32,))`"
+function builtin_model(name::Symbol; dims = ())
+    d = ntuple(i -> i <= length(dims) ? Int32(dims[i]) : Int32(0), 4)
+    id = Int32(BUILTIN[name])
+    n, np = model_sizes(id, d)
+    return DeviceModel(id, d, n, np)
+end
+
+"""
+    register_model(name, n, np; f, vjp_u = nothing, vjp_p = nothing, dgdu = nothing, dgdp = nothing) -> DeviceModel
+
+`f`, `vjp_u`, `vjp_p`: BODIES of the three device functions as C text over `du`/`out`, `u`, `p`, `lam`, `t` — exactly the argument
+meaning of `ODEFunction(f!; vjp, vjp_p)` (both VJPs un-negated).  `vjp_u === vjp_p === nothing` selects forward-mode dual numbers on
+the device (`autojacvec = true`): declare locals of `f` as `real`.  Compiled with hiprtc at `Handle` creation; `check = true` compiles
+once now (no device needed) so that source errors surface here.
+"""
+function register_model(name::AbstractString, n::Integer, np::Integer; f::AbstractString, vjp_u = nothing, vjp_p = nothing,
+        dgdu = nothing, dgdp = nothing, check_now::Bool = true)
+    id = Ref{Int32}(0)
+    # Julia Strings are NUL-terminated in memory: pointer(s) is a valid `const char *` while s is preserved
+    cs(x) = x === nothing ? Ptr{UInt8}(C_NULL) : pointer(x)
+    sname, sf = String(name), String(f)
+    sv = vjp_u === nothing ? nothing : String(vjp_u); sw = vjp_p === nothing ? nothing : String(vjp_p)
+    GC.@preserve sname sf sv sw begin
+        check(ccall(sym(:hipadj_model_register), Cint, (Ptr{UInt8}, Int32, Int32, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ref{Int32}),
+                    pointer(sname), Int32(n), Int32(np), pointer(sf), cs(sv), cs(sw), id))
+    end
+    if dgdu !== nothing
+        su = String(dgdu); sp = dgdp === nothing ? nothing : String(dgdp)
+        GC.@preserve su sp check(ccall(sym(:hipadj_model_set_cost), Cint, (Int32, Ptr{UInt8}, Ptr{UInt8}), id[], pointer(su), cs(sp)))
+    end
+    check_now && check(ccall(sym(:hipadj_model_check), Cint, (Int32,), id[]))
+    return DeviceModel(id[], (Int32(0), Int32(0), Int32(0), Int32(0)), Int(n), Int(np))
+end
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the sensealg the extension dispatches on (seam B1 of SURVEY.md §8b)
+# ---------------------------------------------------------------------------------------------------------------------
+"""
+    HIPBatchedAdjoint(inner = nothing; model, device = 0, time_segments = 0, max_steps = 0)
+
+`inner`: the reference algorithm whose semantics are wanted (`InterpolatingAdjoint()`, `BacksolveAdjoint(checkpointing = true)`,
+`GaussAdjoint()`, `GaussKronrodAdjoint()`, `QuadratureAdjoint(abstol, reltol)`; read by the extension).  The state of the problem is a
+MATRIX whose columns are independent trajectories of `model` — the documented batching pattern of the reference
+(docs/src/tutorials/data_parallel.md:11-75, test/Core5/size_handling_adjoint.jl:37-70); `p` is a vector shared by all columns or an
+`np x N` matrix.
+"""
+struct HIPBatchedAdjoint{A} <: SciMLBase.AbstractAdjointSensitivityAlgorithm{0, false, Val{:central}}
+    inner::A
+    model::DeviceModel
+    device::Int32
+    time_segments::Int32
+    max_steps::Int32
+end
+HIPBatchedAdjoint(inner; model::DeviceModel, device::Integer = 0, time_segments::Integer = 0, max_steps::Integer = 0) =
+    HIPBatchedAdjoint{typeof(inner)}(inner, model, Int32(device), Int32(time_segments), Int32(max_steps))
+
+# ---------------------------------------------------------------------------------------------------------------------
+# handle + the three calls
+# ---------------------------------------------------------------------------------------------------------------------
+mutable struct Handle
+    ptr::Ptr{Cvoid}
+    n::Int
+    np::Int
+    N::Int
+    M::Int
+    p_shared::Bool
+    function Handle(cfg::HipadjConfig, n, np, keep...)
+        check_layout()
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = GC.@preserve keep ccall(sym(:hipadj_create), Cint, (Ref{HipadjConfig}, Ref{Ptr{Cvoid}}), Ref(cfg), out)
+        check(rc)                                   # message of a failed create: hipadj_last_error(NULL)
+        h = new(out[], n, np, Int(cfg.ntraj), Int(cfg.nsave), cfg.p_shared != 0)
+        finalizer(destroy!, h)
+        return h
+    end
+end
+
+function destroy!(h::Handle)
+    if h.ptr != C_NULL
+        ccall(sym(:hipadj_destroy), Cint, (Ptr{Cvoid},), h.ptr)
+        h.ptr = C_NULL
+    end
+    return nothing
+end
+
+"""
+    Handle(model; alg, stepper, N, tspan, dt, ts, loss_kind = LOSS_COTANGENT, loss_shift = 0.0, checkpointing = false,
+           checkpoints = nothing, quad_abstol = 1e-6, quad_reltol = 1e-3, no_start = false, p_shared = true, device = 0,
+           time_segments = 0, cont_cost = 0, max_steps = 0, abstol = 1e-6, reltol = 1e-3)
+"""
+function Handle(model::DeviceModel; alg::Int32, stepper::Int32, N::Integer, tspan, dt::Real, ts::Vector{Float64},
+        loss_kind::Int32 = LOSS_COTANGENT, loss_shift::Real = 0.0, checkpointing::Bool = false, checkpoints = nothing,
+        quad_abstol::Real = 1e-6, quad_reltol::Real = 1e-3, no_start::Bool = false, p_shared::Bool = true, device::Integer = 0,
+        time_segments::Integer = 0, cont_cost::Integer = 0, max_steps::Integer = 0, abstol::Real = 1e-6, reltol::Real = 1e-3)
+    cks = checkpoints === nothing ? Float64[] : sort(collect(Float64, checkpoints))
+    cfg = HipadjConfig(UInt32(sizeof(HipadjConfig)), model.id, alg, stepper, model.dims, Int64(N),
+        Float64(tspan[1]), Float64(tspan[2]), Float64(dt), Int32(length(ts)), isempty(ts) ? Ptr{Float64}(C_NULL) : pointer(ts),
+        loss_kind, Float64(loss_shift), Int32(checkpointing), Int32(0), Float64(quad_abstol), Float64(quad_reltol),
+        Int32(no_start), Int32(p_shared), Int32(device), Int32(time_segments), Int32(cont_cost), Int32(max_steps),
+        Float64(abstol), Float64(reltol), Int32(length(cks)), isempty(cks) ? Ptr{Float64}(C_NULL) : pointer(cks))
+    return Handle(cfg, model.n, model.np, ts, cks)   # ts / cks are copied by hipadj_create; kept alive across the call
+end
+
+"`out = forward!(h, u0, p)`: u0 `(n, N)`, p `(np,)` or `(np, N)`; returns `out` `(n, M, N)` = sol(ts) of every trajectory."
+function forward!(h::Handle, u0::Matrix{Float64}, p::VecOrMat{Float64}; want_out::Bool = true)
+    size(u0) == (h.n, h.N) || throw(DimensionMismatch("u0 must be ($(h.n), $(h.N)), got $(size(u0))"))
+    (h.p_shared ? size(p) == (h.np,) : size(p) == (h.np, h.N)) || throw(DimensionMismatch("p has size $(size(p))"))
+    out = want_out && h.M > 0 ? Array{Float64}(undef, h.n, h.M, h.N) : nothing
+    check(ccall(sym(:hipadj_forward), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                h.ptr, u0, p, out === nothing ? Ptr{Float64}(C_NULL) : pointer(out)), h.ptr)
+    return out
+end
+
+"`(du0, dp) = adjoint!(h, Δ)`: Δ `(n, M, N)` cotangents of `out` (or `nothing` for the fused LSQ loss); du0 `(n, N)`, dp `(np,)` summed over the ensemble or `(np, N)`."
+function adjoint!(h::Handle, Δ::Union{Nothing, Array{Float64, 3}})
+    Δ === nothing || size(Δ) == (h.n, h.M, h.N) || throw(DimensionMismatch("Δ must be ($(h.n), $(h.M), $(h.N)), got $(size(Δ))"))
+    du0 = Matrix{Float64}(undef, h.n, h.N)
+    dp = h.p_shared ? Vector{Float64}(undef, h.np) : Matrix{Float64}(undef, h.np, h.N)
+    check(ccall(sym(:hipadj_adjoint), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                h.ptr, Δ === nothing ? Ptr{Float64}(C_NULL) : pointer(Δ), du0, dp), h.ptr)
+    return du0, dp
+end
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the direct API (seam B2): forward solution object + the generic the SciMLSensitivity extension adds its method to
+# ---------------------------------------------------------------------------------------------------------------------
+"Forward solution of the device engine: what `adjoint_sensitivities` consumes in place of an ODESolution."
+struct HIPAdjSolution
+    handle::Handle
+    u::Array{Float64, 3}      # (n, M, N) = sol(ts) of every trajectory
+    t::Vector{Float64}
+    p
+end
+
+"`hip_solve(prob, alg, sensealg::HIPBatchedAdjoint; u0, p, saveat, dt, ...) -> HIPAdjSolution` (method: ext/SciMLSensitivityHIPAdjExt.jl)"
+function hip_solve end
+
+"Stack an `EnsembleProblem`'s trajectories into the matrix state: `(u0 (n, N), p (np,) or (np, N))` from `prob_func(prob, i, 1)`."
+function ensemble_u0_p(ens::SciMLBase.EnsembleProblem, trajectories::Integer)
+    probs = [ens.prob_func(ens.prob, i, 1) for i in 1:trajectories]
+    u0 = reduce(hcat, (vec(pr.u0) for pr in probs))
+    ps = [pr.p for pr in probs]
+    p = all(q -> q == ps[1], ps) ? collect(Float64, ps[1]) : reduce(hcat, (vec(q) for q in ps))
+    return u0, p
+end
+
+# sharded ensembles: one process (Distributed worker) per GPU; the library all-reduces dp over RCCL in-stream (include/hipadj.h, hipadj_comm_*)
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall(sym(:hipadj_comm_unique_id), Cint, (Ptr{UInt8},), id))
+    return id
+end
+comm_init_rank!(h::Handle, id::Vector{UInt8}, nranks::Integer, rank::Integer) =
+    check(ccall(sym(:hipadj_comm_init_rank), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), h.ptr, id, nranks, rank), h.ptr)
+
+end # module

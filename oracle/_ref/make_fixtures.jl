@@ -1,0 +1,92 @@
+# oracle/_ref/make_fixtures.jl — run THE REFERENCE (SciMLSensitivity.jl's CPU path) on the configurations the CPU oracle restates and
+# write tests/golden/reference_fixtures.json.  The build image has no Julia, so this file has never been executed there: it is the
+# exact script that turns "parity unpinned" into a pinned oracle on the first machine that has Julia:
+#
+#     julia --project=oracle/_ref -e 'using Pkg; Pkg.instantiate()'
+#     julia --project=oracle/_ref oracle/_ref/make_fixtures.jl          # writes tests/golden/reference_fixtures.json
+#     python -m pytest tests/test_reference_fixtures.py                # oracle vs the reference's numbers (skipped while the file is absent)
+#
+# Every case targets one [upstream-recall] assumption of the oracle (DESIGN.md §5 table): the behaviour lives in OrdinaryDiffEq /
+# DiffEqCallbacks / QuadGK, which are not vendored in the reference tree, so the oracle restates it from the published algorithms
+# and only a run of the real packages can confirm it.
+using SciMLSensitivity, OrdinaryDiffEq, JSON
+
+lorenz!(du, u, p, t) = (du[1] = p[1] * (u[2] - u[1]); du[2] = u[1] * (p[2] - u[3]) - u[2]; du[3] = u[1] * u[2] - p[3] * u[3]; nothing)   # test/Core3/adjoint.jl:1160-1166
+lv!(du, u, p, t) = (du[1] = p[1] * u[1] - p[2] * u[1] * u[2]; du[2] = -p[3] * u[2] + p[4] * u[1] * u[2]; nothing)                     # test/Core3/user_vjp.jl:6-10
+lvt!(du, u, p, t) = (du[1] = p[1] * u[1] - p[2] * u[1] * u[2] * t; du[2] = -p[3] * u[2] + t * p[4] * u[1] * u[2]; nothing)            # test/Core3/adjoint.jl:8-12
+dg(out, u, p, t, i) = (out .= u .- 2.0)                                                                                            # test/Core3/adjoint.jl:49-51
+
+models = Dict("LORENZ" => (lorenz!, [1.0, 0.0, 0.0], [10.0, 28.0, 8 / 3]), "LV" => (lv!, [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]),
+              "LVT" => (lvt!, [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]))
+
+sensealgs = Dict(
+    "INTERPOLATING" => InterpolatingAdjoint(autojacvec = ReverseDiffVJP()),
+    "INTERPOLATING_CKPT" => InterpolatingAdjoint(autojacvec = ReverseDiffVJP(), checkpointing = true),
+    "BACKSOLVE" => BacksolveAdjoint(autojacvec = ReverseDiffVJP(), checkpointing = true),
+    "BACKSOLVE_NOCKPT" => BacksolveAdjoint(autojacvec = ReverseDiffVJP(), checkpointing = false),
+    "GAUSS" => GaussAdjoint(autojacvec = ReverseDiffVJP()),
+    "GAUSS_CKPT" => GaussAdjoint(autojacvec = ReverseDiffVJP(), checkpointing = true),
+    "GAUSS_KRONROD" => GaussKronrodAdjoint(autojacvec = ReverseDiffVJP()),
+    "QUADRATURE" => QuadratureAdjoint(autojacvec = ReverseDiffVJP()),                                  # default abstol 1e-6, reltol 1e-3
+    "QUADRATURE_TIGHT" => QuadratureAdjoint(autojacvec = ReverseDiffVJP(), abstol = 1e-12, reltol = 1e-12),
+)
+
+# one fixture = one call of adjoint_sensitivities on a forward solution, exactly as tests/oracle.py's Problem.adjoint does
+function run_case(; name, model, alg, stepper, tspan, dt = nothing, abstol = 1e-6, reltol = 1e-3, saveat, checkpoints = nothing, targets)
+    f!, u0, p = models[model]
+    prob = ODEProblem(f!, u0, tspan, p)
+    solver = stepper == "RK4" ? RK4() : Tsit5()
+    skw = stepper == "RK4" ? (dt = dt, adaptive = false) : (abstol = abstol, reltol = reltol)
+    sa = sensealgs[alg]
+    ts = saveat isa Number ? collect(tspan[1]:saveat:tspan[2]) : collect(saveat)
+    # the forward solve the pullback of _concrete_solve_adjoint closes over (src/concrete_solve.jl:689-707): dense unless checkpointing
+    sol = if alg == "BACKSOLVE" || endswith(alg, "_CKPT")
+        solve(prob, solver; saveat = ts, skw...)
+    else
+        solve(prob, solver; skw...)
+    end
+    kw = checkpoints === nothing ? (;) : (checkpoints = checkpoints,)
+    du0, dp = adjoint_sensitivities(sol, solver; t = ts, dgdu_discrete = dg, sensealg = sa, skw..., kw...)
+    out = sol(ts)
+    return Dict("name" => name, "model" => model, "alg" => replace(alg, "_CKPT" => "", "_NOCKPT" => "", "_TIGHT" => ""),
+                "checkpointing" => (alg == "BACKSOLVE" || endswith(alg, "_CKPT")), "stepper" => stepper, "tspan" => collect(tspan),
+                "dt" => something(dt, 0.0), "abstol" => abstol, "reltol" => reltol, "ts" => ts,
+                "quad_abstol" => (sa isa QuadratureAdjoint ? sa.abstol : 1e-6), "quad_reltol" => (sa isa QuadratureAdjoint ? sa.reltol : 1e-3),
+                "checkpoints" => checkpoints === nothing ? nothing : collect(checkpoints),
+                "u0" => u0, "p" => p, "du0" => collect(du0), "dp" => vec(collect(dp)), "out" => [collect(out[:, i]) for i in 1:length(ts)],
+                "forward_steps" => length(sol.t) - 1, "targets" => targets)
+end
+
+cases = Any[]
+# (1) fixed-step RK4 + cubic-Hermite dense output + PresetTimeCallback at the loss times (incl. the one at T firing at initialisation)
+for alg in ("INTERPOLATING", "BACKSOLVE", "GAUSS", "GAUSS_KRONROD", "QUADRATURE", "QUADRATURE_TIGHT", "INTERPOLATING_CKPT", "GAUSS_CKPT", "BACKSOLVE_NOCKPT")
+    push!(cases, run_case(name = "rk4_lorenz_T2_$alg", model = "LORENZ", alg = alg, stepper = "RK4", tspan = (0.0, 2.0), dt = 0.01, saveat = 0.1,
+        targets = "RK4 tableau + FSAL, Hermite dense output at theta = 1/2, PresetTimeCallback (initialisation firing at T, jump after the step), " *
+                  "Gauss node count div(order+1,2) = 2 for RK4, GK15 rule and tolerance semantics of quadgk, IntegratingGKSumCallback tolerance, " *
+                  "fixed-step interval re-solve (DESIGN §6.1: the oracle keeps the user dt)"))
+end
+# (2) loss times OFF the step grid: tstops cut the step short, the solver continues with the full dt
+for alg in ("INTERPOLATING", "GAUSS", "BACKSOLVE")
+    push!(cases, run_case(name = "rk4_lv_offgrid_$alg", model = "LV", alg = alg, stepper = "RK4", tspan = (0.0, 2.0), dt = 0.01, saveat = [0.137, 0.4, 0.40499, 1.2345, 2.0],
+        targets = "tstops handling of a non-adaptive solver (dt = min(dt, tstop - t), sliver rule, snap within 100 eps), general-theta Hermite"))
+end
+# (3) adaptive Tsit5 at the reference's default tolerances: the step SEQUENCE depends on the PI controller constants, the initial-step
+#     heuristic and the error norm; `forward_steps` pins them, the gradients then follow
+for alg in ("INTERPOLATING", "BACKSOLVE", "GAUSS", "GAUSS_KRONROD", "QUADRATURE", "INTERPOLATING_CKPT", "GAUSS_CKPT")
+    for (tol, tag) in ((1e-6, "default"), (1e-10, "tight"))
+        push!(cases, run_case(name = "tsit5_lvt_$(tag)_$alg", model = "LVT", alg = alg, stepper = "TSIT5", tspan = (0.0, 10.0), abstol = tol, reltol = tol == 1e-6 ? 1e-3 : tol,
+            saveat = 0.5, targets = "Tsit5 tableau and its 4th-order interpolant, PI controller (beta1 = 7/50, beta2 = 2/25, gamma = 9/10, qmin = 1/5, qmax = 10), " *
+                                    "Hairer initial step, error norm, Gauss node count 3 for Tsit5, adaptive interval re-solve with dt = last step of the previous interval"))
+    end
+end
+# (4) custom checkpoint lists (`checkpoints = sol.t[1:500:end]`-style, test/Core3/adjoint.jl:119-121)
+for alg in ("INTERPOLATING_CKPT", "GAUSS_CKPT", "BACKSOLVE")
+    push!(cases, run_case(name = "rk4_lorenz_customckpt_$alg", model = "LORENZ", alg = alg, stepper = "RK4", tspan = (0.0, 2.0), dt = 0.01, saveat = [0.0, 0.4, 0.9, 1.3, 2.0],
+        checkpoints = [0.07, 0.3, 0.45, 1.25, 1.8], targets = "interval construction from an arbitrary checkpoint list (src/interpolating_adjoint.jl:54-58), Backsolve checkpoint callbacks (:523-546)"))
+end
+
+open(joinpath(@__DIR__, "..", "..", "tests", "golden", "reference_fixtures.json"), "w") do io
+    JSON.print(io, Dict("generator" => "oracle/_ref/make_fixtures.jl", "SciMLSensitivity" => string(pkgversion(SciMLSensitivity)),
+                        "OrdinaryDiffEq" => string(pkgversion(OrdinaryDiffEq)), "julia" => string(VERSION), "cases" => cases), 1)
+end
+println("wrote ", length(cases), " cases")

@@ -36,6 +36,7 @@ class HipadjConfig(C.Structure):
         ("no_start", C.c_int32), ("p_shared", C.c_int32), ("device", C.c_int32), ("time_segments", C.c_int32),
         ("cont_cost", C.c_int32), ("max_steps", C.c_int32),
         ("abstol", C.c_double), ("reltol", C.c_double),
+        ("ncheckpoints", C.c_int32), ("checkpoints", C.POINTER(C.c_double)),
     ]
 
 

@@ -86,7 +86,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (!cfg) { g_create_error = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
         auto* h = new hipadj_handle();
     auto fail = [&](int code) { g_create_error = h->err; free_all(h); delete h; return code; };
-    h->cfg = *cfg; h->cfg.save_times = nullptr;
+    h->cfg = *cfg; h->cfg.save_times = nullptr; h->cfg.checkpoints = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, h->err); if (prc != HIPADJ_OK) return fail(prc); }
     const int n = P.n, np = P.np; const long S = P.S;
@@ -446,7 +446,7 @@ static int user_prepare(hipadj_handle* h) {
 
 static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     hipadj_handle h;
-    h.cfg = *cfg; h.cfg.save_times = nullptr;
+    h.cfg = *cfg; h.cfg.save_times = nullptr; h.cfg.checkpoints = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
     h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX;

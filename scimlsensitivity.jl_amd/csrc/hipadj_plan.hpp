@@ -130,6 +130,19 @@ inline int plan_check_cost(const hipadj_config* cfg, std::string& err) {
     return HIPADJ_OK;
 }
 
+// the `checkpoints` list of the configuration (ncheckpoints > 0): strictly ascending inside [t0, t1], not combined with ckpt_stride
+inline int plan_check_checkpoint_list(const hipadj_config* cfg, std::string& err) {
+    if (cfg->ncheckpoints < 0 || (cfg->ncheckpoints > 0 && !cfg->checkpoints)) { err = "checkpoints missing"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->ncheckpoints > 0 && cfg->ckpt_stride > 0) { err = "give either ckpt_stride or an explicit checkpoint list, not both"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->ncheckpoints > 0 && cfg->alg == HIPADJ_ALG_QUADRATURE) { err = "QuadratureAdjoint has no checkpointing (src/sensitivity_algorithms.jl:1665-1677)"; return HIPADJ_ERR_INVALID_ARG; }
+    const double slack = 1e-9 * std::fmax(1.0, std::fabs(cfg->t1 - cfg->t0));
+    for (int i = 0; i < cfg->ncheckpoints; ++i) {
+        if (!(cfg->checkpoints[i] >= cfg->t0 - slack && cfg->checkpoints[i] <= cfg->t1 + slack)) { err = "checkpoints must lie inside [t0, t1]"; return HIPADJ_ERR_INVALID_ARG; }
+        if (i > 0 && !(cfg->checkpoints[i] > cfg->checkpoints[i - 1])) { err = "checkpoints must be strictly ascending"; return HIPADJ_ERR_INVALID_ARG; }
+    }
+    return HIPADJ_OK;
+}
+
 inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (!cfg) { err = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->struct_size != sizeof(hipadj_config)) { err = "hipadj_config.struct_size mismatch (ABI)"; return HIPADJ_ERR_INVALID_ARG; }
@@ -181,9 +194,11 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
         P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) && cfg->checkpointing;
         P.ck_times.clear();
-        if (P.bs_ckpt || P.ip_ckpt) {   // default checkpoints = sol.t of the saveat solve: t0, save times, t1 (src/backsolve_adjoint.jl:132)
-            if (P.save_times.empty() || P.save_times.front() > cfg->t0) P.ck_times.push_back(cfg->t0);
-            for (double t : P.save_times) P.ck_times.push_back(t);
+        { const int crc = plan_check_checkpoint_list(cfg, err); if (crc != HIPADJ_OK) return crc; }
+        if (P.bs_ckpt || P.ip_ckpt) {   // default checkpoints = sol.t of the saveat solve: t0, save times, t1 (src/backsolve_adjoint.jl:132); or the caller's list
+            std::vector<double> src = cfg->ncheckpoints > 0 ? std::vector<double>(cfg->checkpoints, cfg->checkpoints + cfg->ncheckpoints) : P.save_times;
+            if (src.empty() || src.front() > cfg->t0) P.ck_times.push_back(cfg->t0);
+            for (double t : src) P.ck_times.push_back(t);
             if (P.ck_times.back() < cfg->t1) P.ck_times.push_back(cfg->t1);
         }
         P.nck = (int)P.ck_times.size();
@@ -215,6 +230,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->time_segments < 0) { err = "time_segments must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->ckpt_stride < 0) { err = "ckpt_stride must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
+    { const int crc = plan_check_checkpoint_list(cfg, err); if (crc != HIPADJ_OK) return crc; }
     { const int crc = plan_check_cost(cfg, err); if (crc != HIPADJ_OK) return crc; }
     if (cfg->cont_cost != HIPADJ_CCOST_NONE && (P.field || P.mlp)) { err = "continuous costs are available for the lane-per-trajectory family only"; return HIPADJ_ERR_UNSUPPORTED; }
     P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = (int)S; P.M = cfg->nsave;
@@ -230,7 +246,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (P.offgrid) {
         // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
         const bool og_ig = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && !cfg->checkpointing;
-        const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->ckpt_stride == 0;
+        const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->ckpt_stride == 0 && cfg->ncheckpoints == 0;
         if (!(og_ig || og_bs) || P.field || P.mlp) {
             err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false) and BacksolveAdjoint (checkpoints = the save "
                   "times, ckpt_stride = 0) on the lane-per-trajectory models; other configurations need times on the grid, or the adaptive stepper (arbitrary times)";
@@ -255,7 +271,20 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     P.nck = P.offgrid ? (int)P.ck_times.size() : 0;   // off-grid Backsolve: checkpoint TIMES (interpolated states), not knots
     if ((P.bs_ckpt || P.ip_ckpt) && !P.offgrid) {
         int c = 0;
-        if (cfg->ckpt_stride > 0) { for (long k = 0; k <= S; k += cfg->ckpt_stride) P.ckpt_of_knot[k] = c++; if (P.ckpt_of_knot[S] < 0) P.ckpt_of_knot[S] = c++; }
+        if (cfg->ncheckpoints > 0) {
+            // explicit list (adjoint_sensitivities(...; checkpoints), src/sensitivity_interface.jl:484-486): any spacing, every time a knot;
+            // t0 and T are checkpoints as well (the interval construction of src/interpolating_adjoint.jl:54-58 adds the tail up to T,
+            // the forward solution starts at t0)
+            std::vector<char> is_ck((size_t)S + 1, 0);
+            is_ck[0] = is_ck[S] = 1;
+            for (int i = 0; i < cfg->ncheckpoints; ++i) {
+                const double kr = (cfg->checkpoints[i] - cfg->t0) / cfg->dt; const long k = std::lround(kr);
+                if (k < 0 || k > S || std::fabs(kr - (double)k) > 1e-6) { err = "fixed-step RK4: checkpoints must lie on the step grid t0 + k*dt (arbitrary times: the adaptive stepper)"; return HIPADJ_ERR_UNSUPPORTED; }
+                is_ck[k] = 1;
+            }
+            for (long k = 0; k <= S; ++k) if (is_ck[k]) P.ckpt_of_knot[k] = c++;
+        }
+        else if (cfg->ckpt_stride > 0) { for (long k = 0; k <= S; k += cfg->ckpt_stride) P.ckpt_of_knot[k] = c++; if (P.ckpt_of_knot[S] < 0) P.ckpt_of_knot[S] = c++; }
         else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }
         P.nck = c;
     }

@@ -15,7 +15,7 @@ class Engine:
     def __init__(self, model, alg, ntraj, t0, t1, dt, save_times=(), loss_kind=_lib.LOSS_COTANGENT, loss_shift=0.0,
                  checkpointing=False, ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False,
                  p_shared=True, device=0, time_segments=0, dims=(0, 0, 0, 0), cont_cost=0,
-                 stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0):
+                 stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0, checkpoints=None):
         L = _lib.load()
         self._L = L
         self._save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
@@ -34,6 +34,9 @@ class Engine:
         c.no_start, c.p_shared, c.device, c.time_segments = int(bool(no_start)), int(bool(p_shared)), int(device), int(time_segments)
         c.cont_cost = int(cont_cost)
         c.max_steps, c.abstol, c.reltol = int(max_steps), float(abstol), float(reltol)
+        self._ck = None if checkpoints is None else np.ascontiguousarray(np.asarray(checkpoints, dtype=np.float64))
+        c.ncheckpoints = 0 if self._ck is None else len(self._ck)
+        c.checkpoints = _dptr(self._ck) if c.ncheckpoints else None
         self.cfg = c
         self.model, self.alg = model, alg
         self.N, self.M = int(ntraj), len(self._save)

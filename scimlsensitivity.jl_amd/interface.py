@@ -53,21 +53,23 @@ def _save_times(tspan, saveat, dt, save_everystep=False, save_start=True, save_e
 
 
 def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
+    """sensealg options -> handle configuration.  `checkpoints` (adjoint_sensitivities' keyword, default sol.t; src/sensitivity_interface.jl:
+    484-486, src/backsolve_adjoint.jl:132): any strictly ascending list — on the step grid for RK4(), arbitrary for Tsit5(); an equally
+    spaced grid list is handed over as a stride (the planner's cheaper form), anything else as the explicit list (ABI 102)."""
     kw = {}
     if isinstance(sensealg, (BacksolveAdjoint, InterpolatingAdjoint, GaussAdjoint, GaussKronrodAdjoint)):
         kw["checkpointing"] = sensealg.checkpointing
-        if adaptive:
-            if checkpoints is not None:
-                raise ValueError("Tsit5(): checkpoints default to the save times (sol.t of the saveat solve); custom lists are not wired")
-            return kw
         if checkpoints is not None and sensealg.checkpointing:
-            # `checkpoints` of adjoint_sensitivities (default sol.t): must be equally spaced on the step grid here
-            ck = np.asarray(checkpoints, dtype=np.float64)
-            ks = np.rint((ck - t0) / dt).astype(np.int64)
-            stride = int(ks[1] - ks[0]) if len(ks) > 1 else 0
-            if len(ks) > 2 and not np.all(np.diff(ks)[:-1] == stride):
-                raise ValueError("checkpoints must be equally spaced on the step grid (ckpt_stride)")
-            kw["ckpt_stride"] = stride
+            ck = np.sort(np.asarray(checkpoints, dtype=np.float64))
+            if len(ck) > 1 and np.any(np.diff(ck) <= 0):
+                raise ValueError("checkpoints must be distinct")
+            if not adaptive and len(ck) > 1:
+                ks = np.rint((ck - t0) / dt).astype(np.int64)
+                d = np.diff(ks)
+                if np.all(np.abs((ck - t0) / dt - ks) < 1e-6) and ks[0] == 0 and np.all(d[:-1] == d[0]) and d[-1] <= d[0]:
+                    kw["ckpt_stride"] = int(d[0])          # 0, s, 2s, ... (+ the end point): the stride form
+                    return kw
+            kw["checkpoints"] = ck
     elif isinstance(sensealg, QuadratureAdjoint):
         kw["quad_abstol"], kw["quad_reltol"] = sensealg.abstol, sensealg.reltol
     return kw

@@ -48,7 +48,7 @@ def lib():
 
 def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shift=0.0, checkpointing=False,
                 ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, p_shared=True, time_segments=1, cont_cost=0,
-                stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0):
+                stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0, checkpoints=None):
     from scimlsensitivity_jl_amd import _lib as PL
     save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
     c = PL.HipadjConfig()
@@ -64,7 +64,10 @@ def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shi
     c.no_start, c.p_shared, c.device, c.time_segments = int(no_start), int(p_shared), 0, time_segments
     c.cont_cost = cont_cost
     c.max_steps, c.abstol, c.reltol = max_steps, abstol, reltol
-    c._keep = save
+    ck = None if checkpoints is None else np.ascontiguousarray(np.asarray(checkpoints, dtype=np.float64))
+    c.ncheckpoints = 0 if ck is None else len(ck)
+    c.checkpoints = ck.ctypes.data_as(C.POINTER(C.c_double)) if c.ncheckpoints else None
+    c._keep = (save, ck)
     return c
 
 

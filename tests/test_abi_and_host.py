@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(sa):
     assert set(names) == set(_lib.DECLARED_SYMBOLS)
     for nm in names:
         assert hasattr(L, nm), nm
-    assert L.hipadj_version() == 101
+    assert L.hipadj_version() == 102
     assert L.hipadj_status_string(-2).decode().startswith("no usable HIP device")
 
 
@@ -237,7 +237,7 @@ def test_c_host_compiles_against_the_header_and_fails_loudly_without_a_device(sa
     sa.load_library()
     exe = _build_host_demo(sa, tmp_path)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
-    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 101" in r.stdout
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 102" in r.stdout
 
 
 class _StubEngine:
@@ -305,8 +305,13 @@ def test_host_mirror_logic_with_a_stub_engine(sa, monkeypatch):
     # equally spaced custom checkpoints -> ckpt_stride; anything else is refused
     sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.2, 0.4, 0.6, 0.8, 1.0])
     assert _StubEngine.created[-1].kw["ckpt_stride"] == 20
-    with pytest.raises(ValueError, match="equally spaced"):
-        sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.2, 0.5, 1.0])
+    # any other ascending list goes through as the explicit checkpoint list of ABI 102
+    sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.2, 0.5, 1.0])
+    assert "ckpt_stride" not in _StubEngine.created[-1].kw and np.allclose(_StubEngine.created[-1].kw["checkpoints"], [0.0, 0.2, 0.5, 1.0])
+    sa.solve(prob, sa.Tsit5(), saveat=[0.9, 0.3], sensealg=sa.InterpolatingAdjoint(checkpointing=True), checkpoints=[0.77, 0.1234])
+    assert np.allclose(_StubEngine.created[-1].kw["checkpoints"], [0.1234, 0.77])
+    with pytest.raises(ValueError, match="distinct"):
+        sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.5, 0.5, 1.0])
     # save_idxs: cotangents of the saved components are scattered into the full state, zeros elsewhere (:790-824)
     sol = sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.5, sensealg=sa.InterpolatingAdjoint(), save_idxs=[2, 0])
     e = _StubEngine.created[-1]

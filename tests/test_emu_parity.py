@@ -625,3 +625,43 @@ def test_randomized_configurations_emulator_vs_oracle_tsit5(seed):
     tol = 1e-6 if (c["alg"] == "backsolve" and c["model"] == "lorenz") else 1e-8
     scale = max(np.max(np.abs(rdu0)), np.max(np.abs(rdp)), 1e-300)
     assert (len(ts) == 0 or rel(out, rout) < 1e-10) and np.max(np.abs(du0 - rdu0)) < tol * scale and np.max(np.abs(dp - rdp)) < tol * scale, c
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "gauss", "backsolve"])
+@pytest.mark.parametrize("stepper", ["RK4", "TSIT5"])
+@pytest.mark.parametrize("segments", [1, 3])
+def test_general_checkpoint_lists(alg, stepper, segments):
+    """`checkpoints` of adjoint_sensitivities (src/sensitivity_interface.jl:484-486; intervals src/interpolating_adjoint.jl:54-58, Backsolve
+    callbacks src/backsolve_adjoint.jl:523-546) as an arbitrary ascending list — unequal spacing, not the save times, first entry > t0
+    and last entry < T (both ends are added like the reference's interval construction does).  RK4: on the step grid (intervals of
+    7 ... 80 steps: LDS and HBM re-solve tiles); Tsit5: arbitrary times."""
+    if stepper == "TSIT5" and segments > 1:
+        pytest.skip("time segmentation is a fixed-step feature")
+    rng = np.random.default_rng(23)
+    N, T, dt = 3, 2.0, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.array([0.0, 0.4, 0.9, 1.3, 2.0])
+    cks = np.array([0.07, 0.3, 0.45, 1.25, 1.8]) if stepper == "RK4" else np.array([0.0712, 0.3, 0.4567, 1.25, 1.8111])
+    delta = rng.standard_normal((N, len(ts), 3))
+    tol = 1e-9
+    cfg = E.make_config("lorenz", alg, N, 0.0, T, dt if stepper == "RK4" else 0.0, ts, loss_kind=0, checkpointing=True, time_segments=segments,
+                        checkpoints=cks, stepper=(0 if stepper == "RK4" else 1), abstol=tol, reltol=tol, max_steps=4000)
+    du0, dp, out = E.forward_adjoint(cfg, 3, 3, u0, p, delta)
+    ref = O.Problem("LORENZ", alg=alg.upper(), stepper=stepper, t0=0, t1=T, dt=dt if stepper == "RK4" else 0.0, abstol=tol, reltol=tol, save_times=ts,
+                    loss="COTANGENT", checkpointing=True, checkpoints=cks)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(out, rout) < 1e-10 and rel(du0, rdu0) < 1e-8 and rel(dp, rdp) < 1e-8
+    # and the list matters: the default checkpoints (= save times) give a different Backsolve answer
+    if alg == "backsolve" and stepper == "RK4":
+        cfg0 = E.make_config("lorenz", alg, N, 0.0, T, dt, ts, loss_kind=0, checkpointing=True, time_segments=segments)
+        d0, _, _ = E.forward_adjoint(cfg0, 3, 3, u0, p, delta)
+        assert rel(d0, du0) > 1e-9
+
+
+def test_checkpoint_list_misuse():
+    ts = np.array([0.0, 1.0])
+    for kw, msg in ((dict(checkpoints=[0.5, 0.5]), "ascending"), (dict(checkpoints=[0.5, 2.5]), "inside"), (dict(checkpoints=[0.5], ckpt_stride=10), "either"),
+                    (dict(checkpoints=[0.333]), "step grid")):
+        cfg = E.make_config("lorenz", "backsolve", 1, 0.0, 1.0, 0.01, ts, checkpointing=True, **kw)
+        with pytest.raises(RuntimeError, match=msg):
+            E.forward_adjoint(cfg, 3, 3, np.ones((1, 3)), np.array([10.0, 28.0, 8 / 3]), np.zeros((1, 2, 3)))
