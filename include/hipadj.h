@@ -76,7 +76,8 @@ typedef enum {
 
 /* continuous costs g(u, p, t) with device-inlined dgdu_continuous / dgdp_continuous
  * (accumulate_cost!, src/derivative_wrappers.jl:1411-1442; AdjointSensitivityIntegrand `out .+= dgdp`, src/quadrature_adjoint.jl:497-500).
- * GaussAdjoint is offered for costs without a parameter term only: no reference test covers its `+dgdp` (src/gauss_adjoint.jl:755-758). */
+ * GaussAdjoint / GaussKronrodAdjoint take the parameter term with the sign of the other algorithms (Gauss == Interpolating == Quadrature); the
+ * reference's own line (src/gauss_adjoint.jl:755-758, `out .+= dgdp` after the negation, no test) reads the other way — DESIGN.md 6.5. */
 typedef enum {
     HIPADJ_CCOST_NONE = 0,
     HIPADJ_CCOST_HALF_SQ_SUM = 1, /* g = (sum(u))^2 / 2, dgdu = sum(u) in every component, dgdp = 0 (test/Core3/adjoint.jl:913-919) */

@@ -565,6 +565,11 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 kstore_interp<NZ, N>(KK, (tt - tprev) / h, h, lamq);
                 cur.eval(tt, y);
                 Mo::vjp_p(W, lamq, y, pv, tt);
+                if (cost_has_gp<CC>::value) {   // + g_p at the node; sign: DESIGN.md 6.5 (Gauss == Interpolating == Quadrature)
+                    double gp[NP]; cost_grad_p<Mo, CC>(y, pv, tt, gp);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                }
 #pragma unroll
                 for (int j = 0; j < NP; ++j) gacc[j] += half * wq * (-W[j]);
             }
@@ -594,6 +599,11 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     kstore_interp<NZ, N>(KK, (tt - tprev) / hstep, hstep, lamq);
                     cur.eval(tt, y);
                     Mo::vjp_p(W, lamq, y, pv, tt);
+                    if (cost_has_gp<CC>::value) {
+                        double gp[NP]; cost_grad_p<Mo, CC>(y, pv, tt, gp);
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                    }
 #pragma unroll
                     for (int j = 0; j < NP; ++j) { IK[j] += GK15::WK[q] * (-W[j]); if (q & 1) IG[j] += GK15::WG[q / 2] * (-W[j]); }
                 }

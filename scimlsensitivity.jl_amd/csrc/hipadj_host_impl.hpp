@@ -58,8 +58,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
             hipLaunchKernelGGL((k_backsolve_offgrid<Mo, (LOSS >> 1)>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
         else if (h->cfg.alg == HIPADJ_ALG_GAUSS) {
-            if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); }
-            else hipLaunchKernelGGL((k_gauss_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
+            hipLaunchKernelGGL((k_gauss_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
         } else
         hipLaunchKernelGGL((k_interp_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
         HIP_TRY(h, hipGetLastError());
@@ -124,7 +123,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         launch_compose();
         HIP_TRY(h, hipGetLastError());
         break; }
-    case HIPADJ_ALG_GAUSS: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussAdjoint with dgdp_continuous is not offered"); } else {
+    case HIPADJ_ALG_GAUSS: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt && h->ck_long)
             hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
@@ -140,7 +139,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         launch_compose();
         HIP_TRY(h, hipGetLastError());
         break; }
-    case HIPADJ_ALG_GAUSS_KRONROD: if constexpr ((LOSS >> 1) >= 2) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "GaussKronrodAdjoint with dgdp_continuous is not offered"); } else {
+    case HIPADJ_ALG_GAUSS_KRONROD: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
                            (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
@@ -360,8 +359,10 @@ template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, 
         case HIPADJ_ALG_INTERPOLATING * 4 + 2: return adaptive_adjoint_l<Mo, 0, 2, true>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0, true>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS * 4 + 2: return adaptive_adjoint_l<Mo, 2, 2, true>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return adaptive_adjoint_l<Mo, 4, 0, true>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return adaptive_adjoint_l<Mo, 4, 1, true>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS_KRONROD * 4 + 2: return adaptive_adjoint_l<Mo, 4, 2, true>(h, d_cot, d_du0, d_dp);
         default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no checkpointed adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
         }
     }
@@ -374,11 +375,13 @@ template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, 
     case HIPADJ_ALG_BACKSOLVE * 4 + 2: return adaptive_adjoint_l<Mo, 1, 2>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_GAUSS * 4 + 0: return adaptive_adjoint_l<Mo, 2, 0>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_GAUSS * 4 + 1: return adaptive_adjoint_l<Mo, 2, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS * 4 + 2: return adaptive_adjoint_l<Mo, 2, 2>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_QUADRATURE * 4 + 0: return adaptive_adjoint_l<Mo, 3, 0>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_QUADRATURE * 4 + 1: return adaptive_adjoint_l<Mo, 3, 1>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_QUADRATURE * 4 + 2: return adaptive_adjoint_l<Mo, 3, 2>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return adaptive_adjoint_l<Mo, 4, 0>(h, d_cot, d_du0, d_dp);
     case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return adaptive_adjoint_l<Mo, 4, 1>(h, d_cot, d_du0, d_dp);
+    case HIPADJ_ALG_GAUSS_KRONROD * 4 + 2: return adaptive_adjoint_l<Mo, 4, 2>(h, d_cot, d_du0, d_dp);
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg %d / cont_cost %d has no adaptive device kernel", h->cfg.alg, h->cfg.cont_cost);
     }
 }

@@ -962,6 +962,11 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
                     double lg[N], W[NP];
                     hermite<N>(th, -dt, lam_hi[c], d_hi[c], lam[c], d_lo, lg);
                     Mo::vjp_p(W, lg, yg[q], pv, t_hi - th * dt);
+                    if (cost_has_gp<CC>::value && c == 0) {   // + g_p at the node (affine column only); sign: DESIGN.md 6.5 — Gauss == Interpolating == Quadrature
+                        double gp[NP]; cost_grad_p<Mo, CC>(yg[q], pv, t_hi - th * dt, gp);
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                    }
 #pragma unroll
                     for (int j = 0; j < NP; ++j) mu[c][j] += (0.5 * dt) * W[j];
                 }
@@ -986,6 +991,11 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
                         hermite<N>(th, -dt, lam_hi[c], d_hi[c], lam[c], d_lo, lg);
                         hermite<N>(1.0 - th, dt, lo.u, lo.f, hi.u, hi.f, yq);
                         Mo::vjp_p(W, lg, yq, pv, t_hi - th * dt);
+                        if (cost_has_gp<CC>::value && c == 0) {
+                            double gp[NP]; cost_grad_p<Mo, CC>(yq, pv, t_hi - th * dt, gp);
+#pragma unroll
+                            for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                        }
 #pragma unroll
                         for (int j = 0; j < NP; ++j) { IK[j] += GK15::WK[q] * W[j]; if (q & 1) IG[j] += GK15::WG[q / 2] * W[j]; }
                     }
@@ -1054,6 +1064,11 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
             double lg[N], W[NP];
             hermite<N>(th, -hs, lam_hi, d_hi, lam[0], d_lo, lg);
             Mo::vjp_p(W, lg, yg[qn], pv, t - th * hs);
+            if (cost_has_gp<CC>::value) {
+                double gp[NP]; cost_grad_p<Mo, CC>(yg[qn], pv, t - th * hs, gp);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) W[j] += gp[j];
+            }
 #pragma unroll
             for (int j = 0; j < NP; ++j) mu[0][j] += (0.5 * hs) * W[j];
         }

@@ -124,9 +124,6 @@ inline int plan_auto_segments(long N, int S, int n, int np = 0) {
 inline int plan_check_cost(const hipadj_config* cfg, std::string& err) {
     if (cfg->cont_cost < HIPADJ_CCOST_NONE || cfg->cont_cost > HIPADJ_CCOST_MODEL) { err = "unknown cont_cost"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !plan_user_model(cfg->model)) { err = "HIPADJ_CCOST_MODEL needs a runtime-registered model with hipadj_model_set_cost"; return HIPADJ_ERR_INVALID_ARG; }
-    if (cfg->cont_cost >= HIPADJ_CCOST_U1SQ_PLUS_P1 && (cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD)) {
-        err = "GaussAdjoint with a parameter-dependent continuous cost (dgdp_continuous) is not offered: the reference adds +dgdp to its negated integrand (src/gauss_adjoint.jl:755-758) and no reference test pins that sign";
-        return HIPADJ_ERR_UNSUPPORTED; }
     return HIPADJ_OK;
 }
 

@@ -14,6 +14,7 @@
 #pragma once
 
 #include <dlfcn.h>
+#include <elf.h>
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
@@ -170,71 +171,71 @@ inline std::string user_model_struct(const UserModelSrc& m) {
 // control-flow join block AHEAD of the `s_or_b64 exec, exec, s[..]` that re-enables the lanes which skipped the region; when
 // the join is reached through the region's s_cbranch_execz the copies run with an empty exec mask and a loop-carried value
 // is lost (found as a GPU fault of k_adjoint_tsit5 with an empty tstop list).  Every runtime model gets its own register
-// allocation, so the pattern is looked for in each new code object: llvm-objdump of the ROCm installation disassembles it
-// ($HIPADJ_OBJDUMP, $ROCM_PATH/lib/llvm/bin, /opt/rocm/lib/llvm/bin); without that tool the check is skipped.
-// HIPADJ_RTC_VERIFY=0 turns it off.  Same walk as tests/tools/isa_lint.py.
-inline std::string user_objdump_path() {
-    std::vector<std::string> cand;
-    if (const char* e = std::getenv("HIPADJ_OBJDUMP")) cand.push_back(e);
-    if (const char* e = std::getenv("ROCM_PATH")) cand.push_back(std::string(e) + "/lib/llvm/bin/llvm-objdump");
-    cand.push_back("/opt/rocm/lib/llvm/bin/llvm-objdump");
-    for (const auto& c : cand) if (access(c.c_str(), X_OK) == 0) return c;
-    return std::string();
-}
+// allocation, so the pattern is looked for in each new code object — IN PROCESS: the .text section of the ELF is walked with the
+// disassembler of libamd_comgr (the code-object manager hiprtc itself sits on, so it is already mapped; bound with dlopen like
+// hiprtc), no child process, no temporary file.  Without comgr the check is skipped; HIPADJ_RTC_VERIFY=0 turns it off.
+// Same walk as tests/tools/isa_lint.py (which uses llvm-objdump and is the cross-check of this scan in the CPU suite).
+struct ComgrDis {
+    typedef struct { uint64_t handle; } info_t;
+    void* lib = nullptr;
+    int (*create)(const char*, uint64_t (*)(uint64_t, char*, uint64_t, void*), void (*)(const char*, void*), void (*)(uint64_t, void*), info_t*) = nullptr;
+    int (*disasm)(info_t, uint64_t, void*, uint64_t*) = nullptr;
+    int (*destroy)(info_t) = nullptr;
+    bool ok = false;
+    ComgrDis() {
+        for (const char* nm : {"libamd_comgr.so.3", "libamd_comgr.so", "/opt/rocm/lib/libamd_comgr.so"}) if ((lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) return;
+        create = (decltype(create))dlsym(lib, "amd_comgr_create_disassembly_info");
+        disasm = (decltype(disasm))dlsym(lib, "amd_comgr_disassemble_instruction");
+        destroy = (decltype(destroy))dlsym(lib, "amd_comgr_destroy_disassembly_info");
+        ok = create && disasm && destroy;
+    }
+};
+inline ComgrDis& comgr_dis() { static ComgrDis D; return D; }
 
-// returns the number of flagged sites (0 = clean), -1 when the check could not run; `what` names the first site
+struct IsaScanCtx { const char* base; uint64_t size; std::string text; long target; };
+inline uint64_t isa_scan_read(uint64_t from, char* to, uint64_t size, void* u) {
+    const IsaScanCtx* c = (const IsaScanCtx*)u;
+    if (from >= c->size) return 0;
+    const uint64_t n = size < c->size - from ? size : c->size - from;
+    std::memcpy(to, c->base + from, n);
+    return n;
+}
+inline void isa_scan_print(const char* s, void* u) { IsaScanCtx* c = (IsaScanCtx*)u; while (*s == ' ' || *s == '\t') ++s; c->text = s; }
+inline void isa_scan_addr(uint64_t a, void* u) { ((IsaScanCtx*)u)->target = (long)a; }
+
+// returns the number of flagged sites (0 = clean), -1 when the check could not run; `what` names the first site (.text offset)
 inline int user_isa_check(const std::vector<char>& code, std::string& what) {
     if (const char* e = std::getenv("HIPADJ_RTC_VERIFY")) if (e[0] == '0') return -1;
-    const std::string objdump = user_objdump_path();
-    if (objdump.empty()) return -1;
-    char tmpl[] = "/tmp/hipadj_isa_XXXXXX";
-    const int fd = mkstemp(tmpl);
-    if (fd < 0) return -1;
-    const bool wrote = write(fd, code.data(), code.size()) == (ssize_t)code.size();
-    close(fd);
-    if (!wrote) { unlink(tmpl); return -1; }
-    const std::string cmd = "'" + objdump + "' -d --no-show-raw-insn '" + tmpl + "' 2>/dev/null";
-    FILE* pp = popen(cmd.c_str(), "r");
-    if (!pp) { unlink(tmpl); return -1; }
-    struct Insn { unsigned long addr; std::string op; long target; };   // target: offset from the kernel symbol, -1 = none
-    std::vector<std::pair<std::string, std::vector<Insn>>> kernels;
-    char line[1024];
-    while (fgets(line, sizeof(line), pp)) {
-        std::string l(line);
-        while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
-        if (!l.empty() && l.back() == ':' && l.find(" <") != std::string::npos && l[0] != ' ' && l[0] != '\t') {
-            const size_t a = l.find('<'), b = l.rfind('>');
-            if (a != std::string::npos && b != std::string::npos && b > a) kernels.push_back({l.substr(a + 1, b - a - 1), {}});
-            continue;
-        }
-        if (kernels.empty() || l.empty() || (l[0] != ' ' && l[0] != '\t')) continue;
-        const size_t c = l.find("//");
-        if (c == std::string::npos) continue;
-        size_t b0 = l.find_first_not_of(" \t");
-        std::string op = l.substr(b0, c - b0);
-        while (!op.empty() && (op.back() == ' ' || op.back() == '\t')) op.pop_back();
-        const unsigned long addr = std::strtoul(l.c_str() + c + 2, nullptr, 16);
-        long target = -1;
-        if (op.compare(0, 9, "s_cbranch") == 0 || op.compare(0, 8, "s_branch") == 0) {
-            const size_t px = l.rfind("+0x");
-            if (px != std::string::npos && px > c) target = (long)std::strtoul(l.c_str() + px + 3, nullptr, 16);
-        }
-        kernels.back().second.push_back({addr, op, target});
-    }
-    const int prc = pclose(pp);
-    unlink(tmpl);
-    if (prc != 0 || kernels.empty()) return -1;
+    ComgrDis& D = comgr_dis();
+    if (!D.ok || code.size() < sizeof(Elf64_Ehdr) || std::memcmp(code.data(), ELFMAG, SELFMAG) != 0) return -1;
+    const Elf64_Ehdr* eh = (const Elf64_Ehdr*)code.data();
+    if (eh->e_shoff == 0 || eh->e_shoff + (uint64_t)eh->e_shnum * sizeof(Elf64_Shdr) > code.size() || eh->e_shstrndx >= eh->e_shnum) return -1;
+    const Elf64_Shdr* sh = (const Elf64_Shdr*)(code.data() + eh->e_shoff);
+    const char* names = code.data() + sh[eh->e_shstrndx].sh_offset;
+    struct Insn { unsigned long addr; std::string op; long target; };   // target: .text offset of a branch target, -1 = none
     auto starts = [](const std::string& s, const char* pre) { return s.compare(0, std::strlen(pre), pre) == 0; };
     static const char* STOP[] = {"s_cbranch", "s_branch", "s_endpgm", "s_or_b64 exec", "s_and_saveexec", "s_andn2_saveexec", "s_or_saveexec",
                                  "s_mov_b64 exec", "s_andn2_b64 exec", "s_xor_b64 exec"};
     static const char* SPILL[] = {"v_accvgpr_write", "v_accvgpr_read", "scratch_store", "scratch_load", "buffer_store", "buffer_load"};
-    int found = 0;
-    for (const auto& kn : kernels) {
-        const auto& ins = kn.second;
-        if (ins.empty()) continue;
-        const unsigned long base = ins[0].addr;
+    int found = 0; bool scanned = false;
+    for (int si = 0; si < eh->e_shnum; ++si) {
+        if (std::strcmp(names + sh[si].sh_name, ".text") != 0 || sh[si].sh_offset + sh[si].sh_size > code.size()) continue;
+        IsaScanCtx c{code.data() + sh[si].sh_offset, sh[si].sh_size, std::string(), -1};
+        ComgrDis::info_t info;
+        if (D.create("amdgcn-amd-amdhsa--gfx950", isa_scan_read, isa_scan_print, isa_scan_addr, &info) != 0) return -1;
+        std::vector<Insn> ins;
+        for (uint64_t a = 0; a < c.size;) {
+            uint64_t sz = 0; c.target = -1; c.text.clear();
+            if (D.disasm(info, a, &c, &sz) != 0 || sz == 0) { a += 4; continue; }     // padding / data words between kernels
+            const bool br = starts(c.text, "s_cbranch") || starts(c.text, "s_branch");
+            ins.push_back({(unsigned long)a, c.text, br ? c.target : -1});
+            a += sz;
+        }
+        D.destroy(info);
+        scanned = true;
         std::map<unsigned long, int> tgt;   // address -> 1 = branch target, 2 = target of an s_cbranch_execz
-        for (const auto& i : ins) if (i.target >= 0) { int& t = tgt[base + (unsigned long)i.target]; t = std::max(t, starts(i.op, "s_cbranch_execz") ? 2 : 1); }
+        for (const auto& i : ins) if (i.target >= 0) { int& t = tgt[(unsigned long)i.target]; t = std::max(t, starts(i.op, "s_cbranch_execz") ? 2 : 1); }
         for (size_t k = 0; k < ins.size(); ++k) {
             if (!starts(ins[k].op, "s_or_b64 exec, exec")) continue;
             int spills = 0;
@@ -245,13 +246,13 @@ inline int user_isa_check(const std::vector<char>& code, std::string& what) {
                 for (const char* sp : SPILL) if (starts(ins[j].op, sp)) { ++spills; break; }
                 const auto it = tgt.find(ins[j].addr);
                 if (it != tgt.end()) {
-                    if (spills > 0 && it->second == 2) { if (!found) { char b[64]; snprintf(b, sizeof(b), " @ 0x%lx", ins[k].addr); what = kn.first + b; } ++found; }
+                    if (spills > 0 && it->second == 2) { if (!found) { char b[64]; snprintf(b, sizeof(b), ".text + 0x%lx", ins[k].addr); what = b; } ++found; }
                     break;
                 }
             }
         }
     }
-    return found;
+    return scanned ? found : -1;
 }
 
 // Compiles (or fetches from the process-wide cache) the code object holding `exprs` for user model `model`.
@@ -322,7 +323,7 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         std::string where;
         const int flagged = user_isa_check(code, where);
         if (std::getenv("HIPADJ_RTC_SHOWLOG")) std::fprintf(stderr, "hipadj: ISA check of '%s' (attempt %d): %d %s\n", src.name.c_str(), attempt, flagged, where.c_str());
-        if (flagged <= 0) break;                           // clean, or the check could not run (no llvm-objdump: documented)
+        if (flagged <= 0) break;                           // clean, or the check could not run (no libamd_comgr: documented)
         if (attempt == 1) {
             err = "model '" + src.name + "': the compiler placed register-spill copies ahead of an exec restore (" + where +
                   ") at -O3 and at -O1; lanes could read stale values, so this configuration is refused (fewer states/parameters, "

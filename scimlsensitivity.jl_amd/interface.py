@@ -184,13 +184,38 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_di
         raise ValueError("dgdu_discrete required")
     if eng.cfg.loss_kind != _lib.LOSS_COTANGENT:
         raise ValueError("solution was prepared with a fused LsqShift loss; cotangents need dgdu_discrete=None at solve time")
-    delta = np.asarray(dgdu_discrete, dtype=np.float64)
     idxs = sol.extra.get("save_idxs")
+    delta = pack_cotangent(dgdu_discrete, eng.N, eng.M, eng.n if idxs is None else len(idxs))
     if idxs is not None:                      # cotangent of the saved components only: zero elsewhere (src/concrete_solve.jl:790-824)
         full = np.zeros((eng.N, eng.M, eng.n))
         full[:, :, idxs] = delta.reshape(eng.N, eng.M, len(idxs))
         delta = full
     return eng.adjoint(delta)
+
+
+def pack_cotangent(delta, N, M, nsave, only_end=False):
+    """The cotangent of the saved solution in any form the reference's pullback accepts (src/concrete_solve.jl:776-869) as the dense block
+    [N][M][nsave] the C ABI takes:
+      * a dense array with N * M * nsave elements (the `Array(sol)` form; any shape that reshapes to [N][M][nsave]);
+      * a sequence of M per-time cotangents, each [N][nsave] — the vector-of-arrays / VectorOfArray forms (:818-867); an entry that is
+        None stands for NoTangent / ZeroTangent and contributes zeros;
+      * only_end (a single save time == T, :716, 783-814): additionally the bare state cotangent [N][nsave] ("user did sol[end]")."""
+    if delta is None:
+        return np.zeros((N, M, nsave))
+    if isinstance(delta, (list, tuple)):
+        if len(delta) != M:
+            raise ValueError(f"a vector-of-arrays cotangent needs one entry per save time ({M}), got {len(delta)}")
+        out = np.zeros((N, M, nsave))
+        for i, x in enumerate(delta):
+            if x is not None:
+                out[:, i, :] = np.asarray(x, dtype=np.float64).reshape(N, nsave)
+        return out
+    d = np.asarray(delta, dtype=np.float64)
+    if only_end and d.size == N * nsave:
+        return d.reshape(N, 1, nsave)
+    if d.size != N * M * nsave:
+        raise ValueError(f"cotangent has {d.size} elements, expected {N} x {M} x {nsave}")
+    return d.reshape(N, M, nsave)
 
 
 def concrete_solve_adjoint(prob, alg, sensealg, u0, p, *, dt=None, saveat, **kw):
@@ -200,8 +225,12 @@ def concrete_solve_adjoint(prob, alg, sensealg, u0, p, *, dt=None, saveat, **kw)
                           np.atleast_2d(u0), np.asarray(p))
     sol = solve(ens, alg, dt=dt, saveat=saveat, sensealg=sensealg, **kw)
 
+    N, M, nsave = sol.u.shape                  # sol.u already has the save_idxs shape
+    only_end = bool(M == 1 and abs(sol.t[0] - sol.prob.prob.tspan[1]) <= 1e-12 * max(1.0, abs(sol.prob.prob.tspan[1])))   # src/concrete_solve.jl:716
+
     def pullback(delta):
-        return adjoint_sensitivities(sol, alg, dgdu_discrete=np.asarray(delta, dtype=np.float64).reshape(sol.u.shape))   # sol.u already has the save_idxs shape
+        return adjoint_sensitivities(sol, alg, dgdu_discrete=pack_cotangent(delta, N, M, nsave, only_end))
+    pullback.only_end = only_end
     return sol.u, pullback
 
 

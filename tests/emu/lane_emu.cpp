@@ -287,8 +287,10 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
         case HIPADJ_ALG_INTERPOLATING * 4 + 2: return run_adaptive<Mo, 0, 2, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
         case HIPADJ_ALG_GAUSS * 4 + 0: return run_adaptive<Mo, 2, 0, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
         case HIPADJ_ALG_GAUSS * 4 + 1: return run_adaptive<Mo, 2, 1, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_GAUSS * 4 + 2: return run_adaptive<Mo, 2, 2, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
         case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return run_adaptive<Mo, 4, 0, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
         case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return run_adaptive<Mo, 4, 1, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_GAUSS_KRONROD * 4 + 2: return run_adaptive<Mo, 4, 2, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
         default: return HIPADJ_ERR_UNSUPPORTED;
         }
     }
@@ -301,11 +303,13 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
     case HIPADJ_ALG_BACKSOLVE * 4 + 2: return run_adaptive<Mo, 1, 2>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_GAUSS * 4 + 0: return run_adaptive<Mo, 2, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_GAUSS * 4 + 1: return run_adaptive<Mo, 2, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_GAUSS * 4 + 2: return run_adaptive<Mo, 2, 2>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_QUADRATURE * 4 + 0: return run_adaptive<Mo, 3, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_QUADRATURE * 4 + 1: return run_adaptive<Mo, 3, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_QUADRATURE * 4 + 2: return run_adaptive<Mo, 3, 2>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_GAUSS_KRONROD * 4 + 0: return run_adaptive<Mo, 4, 0>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     case HIPADJ_ALG_GAUSS_KRONROD * 4 + 1: return run_adaptive<Mo, 4, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+    case HIPADJ_ALG_GAUSS_KRONROD * 4 + 2: return run_adaptive<Mo, 4, 2>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
     default: return HIPADJ_ERR_UNSUPPORTED;
     }
 }

@@ -312,6 +312,21 @@ def test_host_mirror_logic_with_a_stub_engine(sa, monkeypatch):
     assert np.allclose(_StubEngine.created[-1].kw["checkpoints"], [0.1234, 0.77])
     with pytest.raises(ValueError, match="distinct"):
         sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.25, sensealg=sa.BacksolveAdjoint(), checkpoints=[0.0, 0.5, 0.5, 1.0])
+    # cotangent forms of the pullback (src/concrete_solve.jl:776-869): dense array, vector of per-time arrays with NoTangent entries, only_end
+    out, pull = sa.concrete_solve_adjoint(prob.prob, sa.RK4(), sa.InterpolatingAdjoint(), u0, p, dt=0.01, saveat=0.5)
+    e = _StubEngine.created[-1]
+    assert out.shape == (4, 3, 3) and pull.only_end is False
+    dense = np.arange(36.0).reshape(4, 3, 3)
+    pull(dense); pull([dense[:, 0], None, dense[:, 2]]); pull(dense.ravel())
+    assert np.array_equal(e.adjoint_args[0], dense) and np.array_equal(e.adjoint_args[2], dense)
+    assert np.array_equal(e.adjoint_args[1][:, 0], dense[:, 0]) and not e.adjoint_args[1][:, 1].any() and np.array_equal(e.adjoint_args[1][:, 2], dense[:, 2])
+    with pytest.raises(ValueError, match="one entry per save time"):
+        pull([dense[:, 0]])
+    out, pull = sa.concrete_solve_adjoint(prob.prob, sa.RK4(), sa.InterpolatingAdjoint(), u0, p, dt=0.01, saveat=[1.0])     # a single save time == T
+    e = _StubEngine.created[-1]
+    assert pull.only_end is True and out.shape == (4, 1, 3)
+    pull(np.ones((4, 3))); pull([2 * np.ones((4, 3))]); pull(np.ones((4, 1, 3)))                                               # sol[end], [sol[end]], Array(sol)
+    assert [a.shape for a in e.adjoint_args] == [(4, 1, 3)] * 3 and e.adjoint_args[1][0, 0, 0] == 2.0
     # save_idxs: cotangents of the saved components are scattered into the full state, zeros elsewhere (:790-824)
     sol = sa.solve(prob, sa.RK4(), dt=0.01, saveat=0.5, sensealg=sa.InterpolatingAdjoint(), save_idxs=[2, 0])
     e = _StubEngine.created[-1]

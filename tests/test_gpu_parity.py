@@ -597,7 +597,7 @@ def test_runtime_model_compile_error_surfaces_at_solve(sa):
 
 # ---- dgdp_continuous (accumulate_cost! with a parameter block; test/Core7/mixed_costs.jl, adjoint_param.jl) ------------
 @pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
-@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("quadrature", "QUADRATURE")])
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("quadrature", "QUADRATURE"), ("gauss", "GAUSS")])
 def test_mixed_cost_with_parameter_term(sa, alg, oalg, stepper):
     """g = u1^2 + p1 on LV (test/Core7/mixed_costs.jl:13-57) plus a discrete LSQ loss, ensemble of 100."""
     rng = np.random.default_rng(51)
@@ -728,12 +728,23 @@ def test_dgdp_discrete_against_finite_differences(sa, stepper, shared):
     sol.engine.close()
 
 
-def test_gauss_with_parameter_dependent_cost_is_rejected(sa):
-    u0 = np.ones((4, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
-    with pytest.raises(sa.HipadjError) as e:
-        sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, 1.0), p), u0), sa.RK4(), dt=0.1, saveat=[1.0], sensealg=sa.GaussAdjoint(),
-                 g=sa.FirstStateSquaredPlusFirstParam())
-    assert e.value.status == -6
+def test_gauss_with_parameter_dependent_cost_on_device(sa):
+    """GaussAdjoint / GaussKronrodAdjoint with dgdp_continuous (the sign that keeps Gauss == Interpolating; the reference's
+    own line src/gauss_adjoint.jl:755-758 has no test): device vs oracle, compiled-in and runtime-attached cost, off-grid loss times."""
+    rng = np.random.default_rng(52)
+    N, T = 64, 2.0
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    for sens, oalg in ((sa.GaussAdjoint(), "GAUSS"), (sa.GaussKronrodAdjoint(), "GAUSS_KRONROD"), (sa.GaussAdjoint(checkpointing=True), "GAUSS")):
+        for ts in (np.linspace(0, T, 5), np.array([0.333, 1.0, 1.777])):
+            if len(ts) == 3 and (oalg != "GAUSS" or sens.checkpointing):
+                continue
+            sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, T), p), u0), sa.RK4(), dt=0.01, saveat=ts, sensealg=sens,
+                           dgdu_discrete=sa.LsqShift(2.0), g=sa.FirstStateSquaredPlusFirstParam())
+            du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=sol.t, dgdu_discrete=sa.LsqShift(2.0), g=sa.FirstStateSquaredPlusFirstParam())
+            ref = O.Problem("LV", alg=oalg, stepper="RK4", t0=0, t1=T, dt=0.01, save_times=sol.t, loss="LSQ_SHIFT", loss_shift=2.0, cont_cost=2, checkpointing=sens.checkpointing)
+            rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+            assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+            sol.engine.close()
 
 
 @pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
