@@ -222,6 +222,18 @@ def other_configs(sa, torch):
                         roofline=dict(bound="hbm", achieved=by / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       kernel="k_bruss_quad_adj", algorithmic_bytes_per_launch=by)))
         eng.close()
+    # configs[4] over the horizon the reference documents, tspan = (0, 11.5), loss times 0:0.5:11.5: 460 000 explicit RK4 steps at the diffusion
+    # stability limit (the docs use the implicit FBDF); 15 GB of knots + 30 GB of dense lambda record in HBM
+    try:
+        Sh = 460000
+        tsh = 0.5 * np.arange(0, 24)
+        eng = sa.Engine("bruss", "quadrature", 1, 0.0, Sh * dtb, dtb, save_times=tsh, dims=(G, 0, 0, 0))
+        ms, kms, st = run(eng, bruss_u0(G, 1), np.array([3.4, 1.0, 10.0]), rng.standard_normal((1, len(tsh), 2 * G * G)), 1)
+        out.append(dict(config="configs[4] at the documented horizon: Brusselator 32x32, tspan (0, 11.5), QuadratureAdjoint, 460 000 RK4 steps of dt = 2.5e-5, N = 1 (1 GPU)",
+                        forward_ms=st["forward_ms_last"], reverse_ms=ms, lambda_pass_ms=kms, us_per_step=kms * 1e3 / Sh, workspace_GB=st["workspace_bytes"] / 1e9))
+        eng.close()
+    except Exception as e:
+        out.append(dict(config="configs[4] at the documented horizon", error=repr(e)))
     return out
 
 
