@@ -53,7 +53,26 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
     bool dispatch_events = false;               // k0/k1 ride on the kernel's dispatch packet instead (k_interp, below)
     if (h->timing >= 1 && (h->offgrid || !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt))) HIP_TRY(h, hipEventRecord(k0, h->stream));
-    if (h->offgrid) {   // loss times off the step grid (planner: Interpolating / Gauss): sequential sweep over the reverse step list
+    if (h->offgrid && h->nseg > 1) {   // off-grid Interpolating / Gauss, time-segmented over the reverse step list (k_offgrid_seg + composition)
+        RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        SegPlan sp{h->nseg, h->d_seg_bounds};
+        if (h->cfg.alg == HIPADJ_ALG_GAUSS)
+            hipLaunchKernelGGL((k_offgrid_seg<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, R, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, h->d_segbuf);
+        else
+            hipLaunchKernelGGL((k_offgrid_seg<Mo, LOSS, false>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, R, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, h->d_segbuf);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        launch_compose();
+        HIP_TRY(h, hipGetLastError());
+        if (h->cfg.p_shared && !h->fused_final) {
+            hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)compose_blocks, h->np, (const double*)h->d_partial, d_dp);
+            HIP_TRY(h, hipGetLastError());
+        }
+        if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+        es.pending = h->timing >= 1; es.full = h->timing >= 2;
+        return HIPADJ_OK;
+    }
+    if (h->offgrid) {   // loss times off the step grid, one column, sequential in time (Backsolve; runtime models; forced time_segments = 1)
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
             hipLaunchKernelGGL((k_backsolve_offgrid<Mo, (LOSS >> 1)>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_cotT, d_du0, h->d_dp_traj);

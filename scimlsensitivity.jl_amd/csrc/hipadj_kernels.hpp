@@ -485,6 +485,39 @@ __global__ void __launch_bounds__(WAVE) k_gauss_offgrid(Geom g, RevSteps R, cons
 #pragma unroll
     for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[0][j];
 }
+// Time-segmented off-grid sweeps: the reverse step list (host-planned, the same for every trajectory) is cut into sp.nseg pieces;
+// bounds are in "position" r = R.n - q (increasing with time like knot indices): segment s covers steps q in [R.n - bounds[s + 1],
+// R.n - bounds[s]).  Segment maps in the k_interp layout, composed by k_compose_finish.  GAUSS = true: gauss_offgrid_lane.
+template <class Mo, int MODE, bool GAUSS>
+__global__ void __launch_bounds__(WAVE) k_offgrid_seg(Geom g, RevSteps R, SegPlan sp, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                                      const double* __restrict__ cotT, double* __restrict__ segbuf) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, RR = N + NP;
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int seg = sp.nseg - 1 - (int)blockIdx.y;         // the (longer, 1-column) top segment is dispatched first
+    if (i >= g.N) return;
+    const int q_lo = R.n - sp.bounds[seg + 1], q_hi = R.n - sp.bounds[seg];
+    double* __restrict__ dst = segbuf + (long)seg * NC * RR * g.Npad + i;
+    if (seg == sp.nseg - 1) {
+        double lam[1][N], mu[1][NP];
+        if constexpr (GAUSS) gauss_offgrid_lane<Mo, MODE, 1>(g, i, p, knots, cotT, R, lam, mu, q_lo, q_hi);
+        else interp_offgrid_lane<Mo, MODE, 1>(g, i, p, knots, cotT, R, lam, mu, q_lo, q_hi);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dst[(long)j * g.Npad] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dst[(long)(N + j) * g.Npad] = mu[0][j];
+    } else {
+        double lam[NC][N], mu[NC][NP];
+        if constexpr (GAUSS) gauss_offgrid_lane<Mo, MODE, NC>(g, i, p, knots, cotT, R, lam, mu, q_lo, q_hi);
+        else interp_offgrid_lane<Mo, MODE, NC>(g, i, p, knots, cotT, R, lam, mu, q_lo, q_hi);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) dst[((long)c * RR + j) * g.Npad] = lam[c][j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dst[((long)c * RR + N + j) * g.Npad] = mu[c][j];
+        }
+    }
+}
 template <class Mo, int CC>
 __global__ void __launch_bounds__(WAVE) k_backsolve_offgrid(Geom g, RevSteps R, const double* __restrict__ p, const double* __restrict__ yT, const double* __restrict__ ckpt,
                                                             const double* __restrict__ cotT, double* __restrict__ du0, double* __restrict__ dp_traj) {

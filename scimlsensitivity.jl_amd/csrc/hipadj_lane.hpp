@@ -612,6 +612,21 @@ struct RevSteps {
 // forward knots cur + 1 (hi), cur (lo) and the prefetched cur - 1 (nx) of one trajectory; times only ever decrease
 template <class Mo> struct KnotCursor { Knot<Mo> hi, lo, nx; int cur; };
 
+// the forward step that holds tau: [kk, kk + 1] with the roundoff guard of the original walk
+HIPADJ_HD int cursor_interval(const Geom& g, double tau) {
+    int kk = (int)((tau - g.t0) / g.dt);
+    kk = kk < 0 ? 0 : (kk > g.S - 1 ? g.S - 1 : kk);
+    if (tau < g.t0 + kk * g.dt && kk > 0) --kk;   // roundoff of (tau - t0)/dt at a knot
+    return kk;
+}
+// start the cursor on the step that holds tau (a time segment of the reverse step list starts anywhere in [t0, T])
+template <class Mo>
+HIPADJ_HD void cursor_init_at(const Geom& g, long i, const dbl2* __restrict__ knots, KnotCursor<Mo>& c, double tau) {
+    c.cur = cursor_interval(g, tau);
+    load_knot<Mo>(knots, g.Npad, c.cur + 1, i, c.hi);
+    load_knot<Mo>(knots, g.Npad, c.cur, i, c.lo);
+    load_knot<Mo>(knots, g.Npad, c.cur > 0 ? c.cur - 1 : 0, i, c.nx);
+}
 template <class Mo>
 HIPADJ_HD void cursor_init(const Geom& g, long i, const dbl2* __restrict__ knots, KnotCursor<Mo>& c) {
     c.cur = g.S - 1;
@@ -622,9 +637,7 @@ HIPADJ_HD void cursor_init(const Geom& g, long i, const dbl2* __restrict__ knots
 // y = sol(tau) from the forward cubic-Hermite dense output; tau is the same for every lane of the wave
 template <class Mo>
 HIPADJ_HD void cursor_eval(const Geom& g, long i, const dbl2* __restrict__ knots, KnotCursor<Mo>& c, double tau, double (&y)[Mo::N]) {
-    int kk = (int)((tau - g.t0) / g.dt);
-    kk = kk < 0 ? 0 : (kk > g.S - 1 ? g.S - 1 : kk);
-    if (tau < g.t0 + kk * g.dt && kk > 0) --kk;   // roundoff of (tau - t0)/dt at a knot
+    const int kk = cursor_interval(g, tau);
     while (c.cur > kk) {
         c.hi = c.lo; c.lo = c.nx; --c.cur;
         load_knot<Mo>(knots, g.Npad, c.cur > 0 ? c.cur - 1 : 0, i, c.nx);
@@ -633,29 +646,39 @@ HIPADJ_HD void cursor_eval(const Geom& g, long i, const dbl2* __restrict__ knots
     hermite<Mo::N>(th, g.dt, c.lo.u, c.lo.f, c.hi.u, c.hi.f, y);
 }
 
-template <class Mo, int MODE>   // MODE = discrete-loss kind | (continuous cost << 1)
+// NC = 1: the whole sweep (q_lo = 0, q_hi = R.n) or the top segment of a time-segmented one; NC = 1 + n: a lower segment [q_lo, q_hi) of the
+// reverse step list carrying the affine column and n basis columns exactly like interp_lane — the step list does not depend on the
+// trajectory, so cutting it into segments and composing their affine maps (k_compose_finish) applies unchanged.
+template <class Mo, int MODE, int NC = 1>   // MODE = discrete-loss kind | (continuous cost << 1)
 HIPADJ_HD void interp_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
-                                   const double* __restrict__ cotT, const RevSteps& R, double (&lam)[1][Mo::N], double (&mu)[1][Mo::NP]) {
+                                   const double* __restrict__ cotT, const RevSteps& R, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP],
+                                   int q_lo = 0, int q_hi = -1) {
     constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
+    if (q_hi < 0) q_hi = R.n;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
 #pragma unroll
-    for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
-    KnotCursor<Mo> c; cursor_init<Mo>(g, i, knots, c);
+        for (int j = 0; j < N; ++j) lam[c][j] = (c > 0 && c - 1 == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
+    }
+    const double t_first = q_lo == 0 ? R.t_start : R.t[q_lo];
+    KnotCursor<Mo> c;
+    if (q_lo == 0) cursor_init<Mo>(g, i, knots, c); else cursor_init_at<Mo>(g, i, knots, c, t_first);
     double y_hi[N], y_mid[N], y_lo[N];
-    cursor_eval<Mo>(g, i, knots, c, R.t_start, y_hi);
-    auto jump = [&](int s, const double (&y)[N]) {   // lam += dgdu_discrete(y, p, t_s, s): cotangent column or u - shift
+    cursor_eval<Mo>(g, i, knots, c, t_first, y_hi);
+    auto jump = [&](int s, const double (&y)[N]) {   // lam += dgdu_discrete(y, p, t_s, s): cotangent column or u - shift (affine column)
 #pragma unroll
         for (int j = 0; j < N; ++j) lam[0][j] += (LOSS == 0) ? cotT[((long)s * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
     };
-    if (R.save_at_start >= 0) jump(R.save_at_start, y_hi);   // PresetTimeCallback fires at initialisation when T is a loss time
+    if (q_lo == 0 && R.save_at_start >= 0) jump(R.save_at_start, y_hi);   // PresetTimeCallback fires at initialisation when T is a loss time
 #pragma unroll 1
-    for (int q = 0; q < R.n; ++q) {
+    for (int q = q_lo; q < q_hi; ++q) {
         const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
         cursor_eval<Mo>(g, i, knots, c, tm, y_mid);
         cursor_eval<Mo>(g, i, knots, c, te, y_lo);
-        adj_rk4_stages<Mo, 1, true, CC>(y_hi, y_mid, y_lo, pv, t, tm, te, hs, lam, mu);
+        adj_rk4_stages<Mo, NC, true, CC>(y_hi, y_mid, y_lo, pv, t, tm, te, hs, lam, mu);
         const int s = R.save[q];
         if (s >= 0) jump(s, y_lo);
 #pragma unroll
@@ -1023,54 +1046,68 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
 // interp_offgrid_lane) with the 2-point Gauss-Legendre rule of gauss_lane on every reverse step — lambda from the adjoint step's
 // Hermite interpolant, y from the forward dense output at the node times.  The five forward states of a step (start, node,
 // middle, node, end) are evaluated in descending time, which is the only order the knot cursor supports.
-template <class Mo, int MODE>
+template <class Mo, int MODE, int NC = 1>
 HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
-                                  const double* __restrict__ cotT, const RevSteps& R, double (&lam)[1][Mo::N], double (&mu)[1][Mo::NP]) {
+                                  const double* __restrict__ cotT, const RevSteps& R, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP],
+                                  int q_lo = 0, int q_hi = -1) {
     constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
     const double xg = 0.5773502691896257645;
+    if (q_hi < 0) q_hi = R.n;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
 #pragma unroll
-    for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
-    KnotCursor<Mo> c; cursor_init<Mo>(g, i, knots, c);
+        for (int j = 0; j < N; ++j) lam[c][j] = (c > 0 && c - 1 == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
+    }
+    const double t_first = q_lo == 0 ? R.t_start : R.t[q_lo];
+    KnotCursor<Mo> cu;
+    if (q_lo == 0) cursor_init<Mo>(g, i, knots, cu); else cursor_init_at<Mo>(g, i, knots, cu, t_first);
     double y_hi[N], y_mid[N], y_lo[N], yg[2][N];
-    cursor_eval<Mo>(g, i, knots, c, R.t_start, y_hi);
+    cursor_eval<Mo>(g, i, knots, cu, t_first, y_hi);
     auto jump = [&](int s, const double (&y)[N]) {
 #pragma unroll
         for (int j = 0; j < N; ++j) lam[0][j] += (LOSS == 0) ? cotT[((long)s * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
     };
-    if (R.save_at_start >= 0) jump(R.save_at_start, y_hi);
+    if (q_lo == 0 && R.save_at_start >= 0) jump(R.save_at_start, y_hi);
 #pragma unroll 1
-    for (int q = 0; q < R.n; ++q) {
+    for (int q = q_lo; q < q_hi; ++q) {
         const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
         const double th0 = 0.5 * (1.0 - xg), th1 = 0.5 * (1.0 + xg);       // theta along the adjoint step: 0 at t, 1 at te
-        cursor_eval<Mo>(g, i, knots, c, t - th0 * hs, yg[0]);
-        cursor_eval<Mo>(g, i, knots, c, tm, y_mid);
-        cursor_eval<Mo>(g, i, knots, c, t - th1 * hs, yg[1]);
-        cursor_eval<Mo>(g, i, knots, c, te, y_lo);
-        double lam_hi[N], d_hi[N], d_lo[N], V[N], guh[N], gul[N];
+        cursor_eval<Mo>(g, i, knots, cu, t - th0 * hs, yg[0]);
+        cursor_eval<Mo>(g, i, knots, cu, tm, y_mid);
+        cursor_eval<Mo>(g, i, knots, cu, t - th1 * hs, yg[1]);
+        cursor_eval<Mo>(g, i, knots, cu, te, y_lo);
+        double lam_hi[NC][N], d_hi[NC][N], V[N], guh[N], gul[N];
         cost_grad_u<Mo, CC>(y_hi, pv, t, guh); cost_grad_u<Mo, CC>(y_lo, pv, te, gul);      // zero when CC == 0
-        Mo::vjp_u(V, lam[0], y_hi, pv, t);
 #pragma unroll
-        for (int j = 0; j < N; ++j) { lam_hi[j] = lam[0][j]; d_hi[j] = -(V[j] + (CC ? guh[j] : 0.0)); }       // fsalfirst of the adjoint step
-        adj_rk4_stages<Mo, 1, false, CC>(y_hi, y_mid, y_lo, pv, t, tm, te, hs, lam, mu);
-        Mo::vjp_u(V, lam[0], y_lo, pv, te);
+        for (int c = 0; c < NC; ++c) {
+            Mo::vjp_u(V, lam[c], y_hi, pv, t);
 #pragma unroll
-        for (int j = 0; j < N; ++j) d_lo[j] = -(V[j] + (CC ? gul[j] : 0.0));                                   // fsallast
+            for (int j = 0; j < N; ++j) { lam_hi[c][j] = lam[c][j]; d_hi[c][j] = -(V[j] + ((CC && c == 0) ? guh[j] : 0.0)); }       // fsalfirst of the adjoint step
+        }
+        adj_rk4_stages<Mo, NC, false, CC>(y_hi, y_mid, y_lo, pv, t, tm, te, hs, lam, mu);
 #pragma unroll
-        for (int qn = 0; qn < 2; ++qn) {
-            const double th = qn == 0 ? th0 : th1;
-            double lg[N], W[NP];
-            hermite<N>(th, -hs, lam_hi, d_hi, lam[0], d_lo, lg);
-            Mo::vjp_p(W, lg, yg[qn], pv, t - th * hs);
-            if (cost_has_gp<CC>::value) {
-                double gp[NP]; cost_grad_p<Mo, CC>(yg[qn], pv, t - th * hs, gp);
+        for (int c = 0; c < NC; ++c) {
+            double d_lo[N];
+            Mo::vjp_u(V, lam[c], y_lo, pv, te);
 #pragma unroll
-                for (int j = 0; j < NP; ++j) W[j] += gp[j];
+            for (int j = 0; j < N; ++j) d_lo[j] = -(V[j] + ((CC && c == 0) ? gul[j] : 0.0));                                   // fsallast
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+                const double th = qn == 0 ? th0 : th1;
+                double lg[N], W[NP];
+                hermite<N>(th, -hs, lam_hi[c], d_hi[c], lam[c], d_lo, lg);
+                Mo::vjp_p(W, lg, yg[qn], pv, t - th * hs);
+                if (cost_has_gp<CC>::value && c == 0) {
+                    double gp[NP]; cost_grad_p<Mo, CC>(yg[qn], pv, t - th * hs, gp);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) mu[c][j] += (0.5 * hs) * W[j];
             }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) mu[0][j] += (0.5 * hs) * W[j];
         }
         const int s = R.save[q];
         if (s >= 0) jump(s, y_lo);

@@ -295,26 +295,31 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     P.nseg = 1;
     const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
-    if (seg_alg && !P.offgrid) {
-        P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, P.S, n, np) : cfg->time_segments;
+    // off-grid Interpolating / Gauss on compiled-in models: the reverse STEP LIST is what gets segmented (it does not depend on the
+    // trajectory); bounds are then positions r = nrs - q in that list instead of knot indices (k_offgrid_seg)
+    const bool seg_offgrid = P.offgrid && !P.user && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS);
+    const long L = seg_offgrid ? (long)P.rs_t.size() : S;      // length of the axis the segments cut
+    if (seg_alg && (!P.offgrid || seg_offgrid)) {
+        P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, (int)L, n, np) : cfg->time_segments;
         if ((1 + n) * (n + np) > 64) P.nseg = 1;   // segment lanes would not fit the register file
-        if (P.nseg > P.S) P.nseg = P.S;
+        if (P.nseg > L) P.nseg = (int)L;
         if (P.nseg < 1) P.nseg = 1;
     }
     // the top segment carries 1 column, the others 1 + n: give the top segment a proportionally longer span
     {
         const int C = P.nseg; P.seg_bounds.assign(C + 1, 0);
-        if (C == 1) { P.seg_bounds[1] = (int)S; }
+        if (C == 1) { P.seg_bounds[1] = (int)L; }
         else {
             // a 1-column lane advances ~w_top steps per (1+n)-column step: the ratio of the two step bodies' VALU instruction counts
             // (Lorenz, stage-operator form of the multi-column step with shared parameters: 263 : 101, profiles/README.md round 2)
             double w_top = 1.0 + 0.8 * n;
             if (cfg->model == HIPADJ_MODEL_LORENZ && cfg->p_shared && cfg->alg == HIPADJ_ALG_INTERPOLATING && cfg->cont_cost == HIPADJ_CCOST_NONE && !cfg->checkpointing) w_top = 2.6;
+            if (seg_offgrid) w_top = 1.0 + 0.27 * n;   // the general-theta Hermite evaluations and the cursor walk of a step are shared by its columns, so a 1-column step is relatively dearer (Lorenz, measured: 1.8 best of 1.8 / 2.1 / 2.35 / 2.7 / 3.4)
             if (const char* e = std::getenv("HIPADJ_WTOP")) { const double v = std::atof(e); if (v > 0) w_top = v; }   // tuning hook
-            const double unit = (double)S / ((C - 1) + w_top);
+            const double unit = (double)L / ((C - 1) + w_top);
             double acc = 0.0;
             for (int s = 1; s < C; ++s) { acc += unit; int b = (int)std::lround(acc); if (b <= P.seg_bounds[s - 1]) b = P.seg_bounds[s - 1] + 1; P.seg_bounds[s] = b; }
-            P.seg_bounds[C] = (int)S;
+            P.seg_bounds[C] = (int)L;
             for (int s = C - 1; s >= 1; --s) if (P.seg_bounds[s] >= P.seg_bounds[s + 1]) P.seg_bounds[s] = P.seg_bounds[s + 1] - 1;
         }
     }

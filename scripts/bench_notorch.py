@@ -22,10 +22,13 @@ prob = sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0.0, T), p), u0)
 
 CASES = [
     ("on-grid saveat=0.1 (BASELINE configs[1]), time-segmented k_interp", dict(saveat=0.1)),
-    ("off-grid saveat=0.1003 (100 stops off the step grid), k_interp_offgrid", dict(saveat=0.1003)),
+    ("off-grid saveat=0.1003 (100 stops off the step grid), time-segmented k_offgrid_seg", dict(saveat=0.1003)),
+    ("off-grid saveat=0.1003, sequential in time (time_segments = 1), k_interp_offgrid", dict(saveat=0.1003, time_segments=1)),
+    ("off-grid saveat=0.1003, GaussAdjoint, time-segmented", dict(saveat=0.1003, sensealg=sa.GaussAdjoint())),
 ]
 for label, kw in CASES:
-    sol = sa.solve(prob, sa.RK4(), dt=DT, sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0), want_out=False, **kw)
+    kw.setdefault("sensealg", sa.InterpolatingAdjoint())
+    sol = sa.solve(prob, sa.RK4(), dt=DT, dgdu_discrete=sa.LsqShift(2.0), want_out=False, **kw)
     eng = sol.engine
     eng.adjoint(None)                                    # warm-up (code load)
     st0 = eng.stats()

@@ -96,6 +96,24 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     constexpr int KM = HIPADJ_CKPT_KMAX;
     switch (cfg->alg) {
     case HIPADJ_ALG_INTERPOLATING: {
+        if (P.offgrid && P.nseg > 1) {   // k_offgrid_seg<..., false> + k_compose_finish
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
+            for (long i = 0; i < P.N; ++i) for (int seg = 0; seg < P.nseg; ++seg) {
+                const int q_lo = RS.n - P.seg_bounds[seg + 1], q_hi = RS.n - P.seg_bounds[seg];
+                double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
+                if (seg == P.nseg - 1) { double lam[1][N], mu[1][NP];
+                    interp_offgrid_lane<Mo, LOSS, 1>(g, i, p, knots.data(), cot, RS, lam, mu, q_lo, q_hi);
+                    for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
+                    for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
+                } else { double lam[NC][N], mu[NC][NP];
+                    interp_offgrid_lane<Mo, LOSS, NC>(g, i, p, knots.data(), cot, RS, lam, mu, q_lo, q_hi);
+                    for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
+                                                   for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; } }
+            }
+            compose<Mo>(P, segbuf, du0, dp_traj);
+            break;
+        }
         if (P.offgrid) {   // k_interp_offgrid: loss times off the step grid, the planner's reverse step list
             const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), P.nck > 0 ? P.rs_ck.data() : nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
             for (long i = 0; i < P.N; ++i) {
@@ -156,6 +174,24 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         compose<Mo>(P, segbuf, du0, dp_traj);
         break; }
     case HIPADJ_ALG_GAUSS: {
+        if (P.offgrid && P.nseg > 1) {   // k_offgrid_seg<..., true> + k_compose_finish
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
+            for (long i = 0; i < P.N; ++i) for (int seg = 0; seg < P.nseg; ++seg) {
+                const int q_lo = RS.n - P.seg_bounds[seg + 1], q_hi = RS.n - P.seg_bounds[seg];
+                double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;
+                if (seg == P.nseg - 1) { double lam[1][N], mu[1][NP];
+                    gauss_offgrid_lane<Mo, LOSS, 1>(g, i, p, knots.data(), cot, RS, lam, mu, q_lo, q_hi);
+                    for (int j = 0; j < N; ++j) dst[(size_t)j * Np] = lam[0][j];
+                    for (int j = 0; j < NP; ++j) dst[(size_t)(N + j) * Np] = mu[0][j];
+                } else { double lam[NC][N], mu[NC][NP];
+                    gauss_offgrid_lane<Mo, LOSS, NC>(g, i, p, knots.data(), cot, RS, lam, mu, q_lo, q_hi);
+                    for (int c = 0; c < NC; ++c) { for (int j = 0; j < N; ++j) dst[((size_t)c * R + j) * Np] = lam[c][j];
+                                                   for (int j = 0; j < NP; ++j) dst[((size_t)c * R + N + j) * Np] = mu[c][j]; } }
+            }
+            compose<Mo>(P, segbuf, du0, dp_traj);
+            break;
+        }
         if (P.offgrid) {   // k_gauss_offgrid
             const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), P.nck > 0 ? P.rs_ck.data() : nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
             for (long i = 0; i < P.N; ++i) {

@@ -444,6 +444,25 @@ OFFGRID_TS = [
 ]
 
 
+@pytest.mark.parametrize("segments", [1, 3, 8])
+@pytest.mark.parametrize("alg", ["interpolating", "gauss"])
+@pytest.mark.parametrize("ts", OFFGRID_TS)
+def test_offgrid_time_segmentation_is_invisible(ts, alg, segments):
+    """The reverse step list of the off-grid sweep does not depend on the trajectory, so it is cut into time segments whose affine maps are
+    composed exactly like the on-grid ones (k_offgrid_seg + k_compose_finish): any segment count must reproduce the oracle."""
+    rng = np.random.default_rng(12)
+    N, T, dt = 3, 1.5, 0.01
+    ts = np.asarray(ts, dtype=np.float64)
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.05 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    delta = rng.standard_normal((N, len(ts), 3))
+    for loss_kind, d, cost in ((0, delta, 0), (1, None, 0), (1, None, 1), (0, delta, 2)):
+        cfg = E.make_config("lorenz", alg, N, 0.0, T, dt, ts, loss_kind=loss_kind, loss_shift=2.0, time_segments=segments, cont_cost=cost)
+        du0, dp, out = E.forward_adjoint(cfg, 3, 3, u0, p, d)
+        ref = O.Problem("LORENZ", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT" if loss_kind == 0 else "LSQ_SHIFT", loss_shift=2.0, cont_cost=cost)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, d)
+        assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
+
+
 @pytest.mark.parametrize("alg", ["interpolating", "gauss", "backsolve", "backsolve_nockpt"])
 @pytest.mark.parametrize("ts", OFFGRID_TS)
 @pytest.mark.parametrize("model,omodel,u0c,p", MODELS)
@@ -555,8 +574,6 @@ def _fuzz_case(seed):
     if alg == "backsolve" and model == "lorenz" and len(ts) < 4:
         alg, ckpt, offgrid_ok = "interpolating", False, True
     cost = int(rng.integers(0, 3))
-    if cost == 2 and alg in ("gauss", "gausskronrod"):
-        cost = 1
     if model == "emu_ring4":
         cost = 0                              # the registered costs belong to the compiled-in models
     lsq = bool(rng.random() < 0.5) or len(ts) == 0
@@ -606,8 +623,6 @@ def _fuzz_case_tsit5(seed):
     if alg == "backsolve" and model == "lorenz" and len(ts) < 4:
         alg, ckpt = "interpolating", False
     cost = int(rng.integers(0, 3))
-    if cost == 2 and alg in ("gauss", "gausskronrod"):
-        cost = 1
     return dict(model=model, omodel=omodel, u0c=u0c, p=p, alg=alg, T=T, tol=tol, ts=ts, ckpt=ckpt, cost=cost, lsq=bool(rng.random() < 0.5) or len(ts) == 0,
                 N=int(rng.integers(1, 5)), no_start=bool(rng.random() < 0.3), p_shared=bool(rng.random() < 0.5), rng=rng)
 
