@@ -104,7 +104,7 @@ class Runner:
                              p_shared=True, device=local_rank, time_segments=args.segments)
         self.eng.use_torch_stream()
         if native:
-            sa.init_native_allreduce(self.eng)     # torch.distributed only ships the 128-byte RCCL id
+            native = self.native = self._try_native(sa, torch, dist, dev, world)
         self.eng.set_timing(1)   # HIP events around the dominant kernel only (on its dispatch packet); the whole-call bracket costs ~8 us per step
         self.u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
         self.p = torch.tensor(p_np, device=dev, dtype=torch.float64)
@@ -115,6 +115,33 @@ class Runner:
         self.eng.forward_dev(self.u0, self.p, None)          # once more: forward_solve_ms is the steady-state call, not the first launch (code load)
         torch.cuda.synchronize()
         self.it, self.pending = 0, None
+
+    def _try_native(self, sa, torch, dist, dev, world):
+        """The library's own RCCL communicator (torch.distributed only ships the 128-byte id).  Every failure that can be SEEN — the id
+        cannot be drawn, ncclCommInitRank returns an error on some rank — makes all ranks agree on the torch.distributed carrier
+        instead of losing the run."""
+        rank = dist.get_rank()
+        try:
+            box = [sa.comm_unique_id() if rank == 0 else None]
+        except Exception as e:
+            box = [None]
+            sys.stderr.write(f"bench: native RCCL id failed on rank 0 ({e!r}); falling back to torch.distributed\n")
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            return False
+        ok = True
+        try:
+            self.eng.comm_init_rank(box[0], world, rank)
+        except Exception as e:
+            ok = False
+            sys.stderr.write(f"bench: hipadj_comm_init_rank failed on rank {rank} ({e!r}); falling back to torch.distributed\n")
+        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                self.eng.comm_destroy()
+            return False
+        return True
 
     def step(self):
         # reverse pass of this step.  torch carrier: the all-reduce of dL/dp (RCCL, its own stream) overlaps the NEXT step's kernels —
@@ -310,7 +337,7 @@ def main():
                                    f"dgdu = u - {LOSS_SHIFT} (BASELINE configs[1])",
                        "ntraj_total": n_total, "ntraj_per_gpu": hi - lo, "rk4_steps": S, "loss_times": len(ts),
                        "time_segments": st1["time_segments"], "parallelism": f"ensemble-shard x{world}",
-                       "dp_allreduce": ("none" if world == 1 else "rccl in-stream (hipadj_comm)" if native else "torch.distributed nccl, async")},
+                       "dp_allreduce": ("none" if world == 1 else "rccl in-stream (hipadj_comm)" if r.native else "torch.distributed nccl, async")},
             "ns_per_vjp_step": elapsed / args.steps / (n_total * S * 4.0) * 1e9,
             "forward_solve_ms": fwd_ms,
             "forward_plus_reverse_ms": (fwd_ms + ms_per_step) if fwd_ms is not None else None,

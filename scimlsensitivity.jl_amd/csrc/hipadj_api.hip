@@ -604,6 +604,10 @@ int adaptive_autosize(hipadj_handle* h) {
     h->rec_cap = cap;
     h->st.workspace_bytes = h->ws_bytes;
     h->ag.Smax = (int)cap; h->ag.SmaxI = (int)cap;
+    if (h->ip_ckpt) { HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int))); return 0; }   // (the pass marked "more steps than the old capacity": not an error here)
+                                // checkpointing=true: the forward pass writes no records (only the checkpoint states), so nothing has to be
+                                // repeated; the buffer just regrown is the ONE-interval record buffer of the reverse sweep, sized by the
+                                // whole-trajectory step count — a safe bound for any single interval
     HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));                  // the overflow mark of the pass that is being repeated
     return 1;
 }

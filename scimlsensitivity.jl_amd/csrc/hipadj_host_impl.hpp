@@ -117,7 +117,9 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             if constexpr (model_has_ops<Mo>::value && (LOSS >> 1) == 0) {
                 // shared parameters + several time segments: the stage-operator form of the multi-column step (adj_rk4_step_ops)
                 if (h->cfg.p_shared && h->nseg > 1 && !h->no_ops) {
-                    hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS, true, 1, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, p,
+                    // prefetch depth 4: the multi-segment launch is bound by FP64 issue, not by HBM latency (PF 8 / 6 / 4 / 3 measure within 2 % of
+                    // each other, 4 marginally best and half the code of 8: profiles/r2_kbench_visit9_prefetch_depth.log)
+                    hipExtLaunchKernelGGL((k_interp<Mo, 4, LOSS, true, 1, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, p,
                                           (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
                     launched = true;
                 }

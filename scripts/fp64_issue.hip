@@ -30,6 +30,41 @@ __global__ void __launch_bounds__(64) k_fma(double* out, int iters, double a, do
     if (s == 12345.678) out[0] = s;
 }
 
+// the matrix pipe: CH independent accumulators of v_mfma_f64_16x16x4_f64 (2 * 16 * 16 * 4 = 2048 flop per wave-instruction)
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int CH>
+__global__ void __launch_bounds__(64) k_mfma(double* out, int iters, double a, double b) {
+    d4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = d4{(double)c, 0.0, 0.0, 0.0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    if (s == 12345.678) out[0] = s;
+}
+template <int CH>
+void run_mfma(int waves_per_simd, double* d) {
+    const int iters = 2000, blocks = 1024 * waves_per_simd;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_mfma<CH>), dim3(blocks), dim3(64), 0, 0, d, 10, 1.0000001, 1e-9);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_mfma<CH>), dim3(blocks), dim3(64), 0, 0, d, iters, 1.0000001, 1e-9);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double inst_per_simd = (double)iters * 8 * CH * waves_per_simd;
+    printf("v_mfma_f64_16x16x4_f64           chains %2d  waves/SIMD %d  %.3f ms  ns per wave-instruction per SIMD %.3f;  TFLOP/s %.1f\n", CH, waves_per_simd, ms,
+           ms * 1e6 / inst_per_simd, inst_per_simd * 1024 * 2048.0 / (ms * 1e-3) / 1e12);
+}
+
 template <int CH, int VG>
 void run(int waves_per_simd, double* d, const char* tag) {
     const int iters = 2000, blocks = 1024 * waves_per_simd;
@@ -62,5 +97,7 @@ int main() {
     run<3, 0>(4, d, "3 chains");
     run<12, 0>(4, d, "12 chains");
     run<12, 0>(8, d, "12 chains");
+    run_mfma<1>(1, d); run_mfma<2>(1, d); run_mfma<4>(1, d); run_mfma<8>(1, d);
+    run_mfma<4>(2, d); run_mfma<8>(2, d); run_mfma<4>(4, d);
     return 0;
 }

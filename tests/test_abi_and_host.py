@@ -91,10 +91,15 @@ def test_planner_rejects_misuse(kw, msg):
 
 
 def test_planner_offgrid_loss_times_build_the_reverse_step_list():
-    """Loss times off the step grid: accepted for InterpolatingAdjoint (one segment, reverse step list), unsupported elsewhere."""
+    """Loss times off the step grid: accepted for InterpolatingAdjoint / GaussAdjoint (the reverse step list, itself cut into time segments:
+    the bounds are positions in that list — 101 steps here: 49 + 1 + 50 + the stop at 0.505 — not knot indices), one segment for
+    Backsolve, unsupported for Quadrature."""
     nseg, nck, nq = C.c_int(), C.c_int(), C.c_int()
     b = (C.c_int * 64)()
     cfg = E.make_config("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, [0.505, 1.0], time_segments=4)
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 4
+    assert b[0] == 0 and b[4] == 101 and all(b[i] < b[i + 1] for i in range(4)) and (b[4] - b[3]) > (b[1] - b[0])     # the 1-column top segment is the longest
+    cfg = E.make_config("lorenz", "backsolve", 4, 0.0, 1.0, 0.01, [0.505, 1.0], time_segments=4, checkpointing=True)
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 1
     cfg = E.make_config("lorenz", "quadrature", 4, 0.0, 1.0, 0.01, [0.505, 1.0])
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == -6
