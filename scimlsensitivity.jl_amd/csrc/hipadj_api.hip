@@ -204,7 +204,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     }
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
-        if (!h->field) A(dev_alloc(h, &h->d_adj, (size_t)S * 2 * n * Np));
+        if (!h->field) A(dev_alloc(h, &h->d_adj, (size_t)(P.offgrid ? P.rs_t.size() : (size_t)S) * 2 * n * Np));   // one record per reverse step
         A(dev_alloc(h, &h->d_qres, (size_t)h->nq * np * Np));
         A(dev_alloc(h, &h->d_qa, (size_t)h->nq)); A(dev_alloc(h, &h->d_qb, (size_t)h->nq));
     }

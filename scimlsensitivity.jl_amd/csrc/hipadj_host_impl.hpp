@@ -72,6 +72,28 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         es.pending = h->timing >= 1; es.full = h->timing >= 2;
         return HIPADJ_OK;
     }
+    if (h->offgrid && h->cfg.alg == HIPADJ_ALG_QUADRATURE) {   // dense lambda over the reverse step list, then adaptive GK15 per (trajectory, loss interval)
+        RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        hipLaunchKernelGGL((k_quad_adj_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, h->d_adj, d_du0);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
+        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        hipLaunchKernelGGL((k_quad_gk_offgrid<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nq), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots,
+                           (const dbl2*)h->d_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
+                           (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        HIP_TRY(h, hipGetLastError());
+        if (h->cfg.p_shared && !h->fused_final) {
+            hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)fblocks, h->np, (const double*)h->d_partial, d_dp);
+            HIP_TRY(h, hipGetLastError());
+        }
+        if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+        es.pending = h->timing >= 1; es.full = h->timing >= 2;
+        return HIPADJ_OK;
+    }
     if (h->offgrid) {   // loss times off the step grid, one column, sequential in time (Backsolve; runtime models; forced time_segments = 1)
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)

@@ -567,6 +567,32 @@ __global__ void __launch_bounds__(WAVE) k_quad_gk(Geom g, const double* __restri
 #pragma unroll
     for (int j = 0; j < NP; ++j) qres[((long)q * NP + j) * g.Npad + i] = res[j];
 }
+// QuadratureAdjoint with loss times off the step grid (hipadj_lane.hpp): pass 1 sequential over the reverse step list, pass 2 one lane per
+// (trajectory, loss interval)
+template <class Mo, int MODE>
+__global__ void __launch_bounds__(WAVE) k_quad_adj_offgrid(Geom g, RevSteps R, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                                           const double* __restrict__ cotT, dbl2* __restrict__ adj, double* __restrict__ du0) {
+    constexpr int N = Mo::N;
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    if (i >= g.N) return;
+    double lam[N];
+    quad_adj_offgrid_lane<Mo, MODE>(g, i, p, knots, cotT, R, adj, lam);
+#pragma unroll
+    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+}
+template <class Mo, int CC = 0>
+__global__ void __launch_bounds__(WAVE) k_quad_gk_offgrid(Geom g, RevSteps R, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                                          const dbl2* __restrict__ adj, const double* __restrict__ qa, const double* __restrict__ qb,
+                                                          double atol, double rtol, double* __restrict__ qres) {
+    constexpr int NP = Mo::NP;
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const int q = blockIdx.y;
+    if (i >= g.N) return;
+    double res[NP];
+    quad_gk_offgrid_lane<Mo, 128, CC>(g, i, p, knots, adj, R, qa[q], qb[q], atol, rtol, res);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) qres[((long)q * NP + j) * g.Npad + i] = res[j];
+}
 // res .+= quadgk(...) in the reference's order (src/quadrature_adjoint.jl:563-616)
 static __global__ void __launch_bounds__(WAVE) k_quad_sum(long N, long Npad, int np, int nq, const double* __restrict__ qres,
                                                    double* __restrict__ dp_traj) {

@@ -1254,4 +1254,143 @@ HIPADJ_HD void quad_gk_lane(const Geom& g, long i, const double* __restrict__ p,
     for (int j = 0; j < NP; ++j) { double s = 0.0; for (int q = 0; q < ns; ++q) s += sI[q][j]; res[j] = s; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// QuadratureAdjoint with loss times OFF the step grid.  Pass 1: the lambda-only sweep over the planner's reverse step list
+// (interp_offgrid_lane without the parameter block) records every reverse step q — start value / derivative (after the jump
+// that fired at its start), end value / derivative (before the jump at its end) — in adj[q][2N pairs][Npad]: the dense adjoint
+// solution (`save_everystep`, src/quadrature_adjoint.jl:527-530) with the Hermite data of a fixed-step solver.  Pass 2: the
+// same adaptive GK15 as quad_gk_lane; the integrand finds the reverse step that holds t by bisection over the (trajectory-
+// independent) step list and the forward step by cursor_interval.
+// ------------------------------------------------------------------------------------------------
+template <class Mo, int MODE>
+HIPADJ_HD void quad_adj_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                     const double* __restrict__ cotT, const RevSteps& R, dbl2* __restrict__ adj, double (&lamo)[Mo::N]) {
+    constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+    double lam[1][N], mu[1][NP];
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+    KnotCursor<Mo> c; cursor_init<Mo>(g, i, knots, c);
+    double y_hi[N], y_mid[N], y_lo[N];
+    cursor_eval<Mo>(g, i, knots, c, R.t_start, y_hi);
+    auto jump = [&](int s, const double (&y)[N]) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[0][j] += (LOSS == 0) ? cotT[((long)s * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+    };
+    if (R.save_at_start >= 0) jump(R.save_at_start, y_hi);
+#pragma unroll 1
+    for (int q = 0; q < R.n; ++q) {
+        const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
+        cursor_eval<Mo>(g, i, knots, c, tm, y_mid);
+        cursor_eval<Mo>(g, i, knots, c, te, y_lo);
+        double rec[4 * N], V[N], guh[N], gul[N];
+        cost_grad_u<Mo, CC>(y_hi, pv, t, guh); cost_grad_u<Mo, CC>(y_lo, pv, te, gul);      // zero when CC == 0
+        Mo::vjp_u(V, lam[0], y_hi, pv, t);
+#pragma unroll
+        for (int j = 0; j < N; ++j) { rec[j] = lam[0][j]; rec[N + j] = -(V[j] + guh[j]); }
+        adj_rk4_stages<Mo, 1, false, CC>(y_hi, y_mid, y_lo, pv, t, tm, te, hs, lam, mu);
+        Mo::vjp_u(V, lam[0], y_lo, pv, te);
+#pragma unroll
+        for (int j = 0; j < N; ++j) { rec[2 * N + j] = lam[0][j]; rec[3 * N + j] = -(V[j] + gul[j]); }
+#pragma unroll
+        for (int j = 0; j < 2 * N; ++j) { dbl2 d; d.x = rec[2 * j]; d.y = rec[2 * j + 1]; adj[((long)q * 2 * N + j) * g.Npad + i] = d; }
+        const int s = R.save[q];
+        if (s >= 0) jump(s, y_lo);
+#pragma unroll
+        for (int j = 0; j < N; ++j) y_hi[j] = y_lo[j];
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
+}
+
+template <class Mo, int CC = 0>
+HIPADJ_HD void quad_integrand_offgrid(const Geom& g, long i, const double (&pv)[Mo::NP], const dbl2* __restrict__ knots,
+                                      const dbl2* __restrict__ adj, const RevSteps& R, double t, double (&out)[Mo::NP]) {
+    constexpr int N = Mo::N;
+    // reverse step q with te[q] <= t <= t[q]: the step list runs downward in time, te[] is descending
+    int lo = 0, hi = R.n - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.te[mid] > t) lo = mid + 1; else hi = mid; }
+    const int q = lo;
+    double rec[4 * N];
+#pragma unroll
+    for (int j = 0; j < 2 * N; ++j) { const dbl2 d = adj[((long)q * 2 * N + j) * g.Npad + i]; rec[2 * j] = d.x; rec[2 * j + 1] = d.y; }
+    const double hs = R.h[q];
+    double tha = (R.t[q] - t) / hs;                  // theta along the adjoint step: 0 at its start (upper end), 1 at its end
+    tha = tha < 0.0 ? 0.0 : (tha > 1.0 ? 1.0 : tha);
+    const int k = cursor_interval(g, t);
+    Knot<Mo> klo, khi;
+    load_knot<Mo>(knots, g.Npad, k, i, klo); load_knot<Mo>(knots, g.Npad, k + 1, i, khi);
+    double y[N], lam[N], l0[N], d0[N], l1[N], d1[N];
+    hermite<N>((t - (g.t0 + k * g.dt)) / g.dt, g.dt, klo.u, klo.f, khi.u, khi.f, y);
+#pragma unroll
+    for (int j = 0; j < N; ++j) { l0[j] = rec[j]; d0[j] = rec[N + j]; l1[j] = rec[2 * N + j]; d1[j] = rec[3 * N + j]; }
+    hermite<N>(tha, -hs, l0, d0, l1, d1, lam);
+    Mo::vjp_p(out, lam, y, pv, t);
+    if (cost_has_gp<CC>::value) {
+        double gp[Mo::NP]; cost_grad_p<Mo, CC>(y, pv, t, gp);
+#pragma unroll
+        for (int j = 0; j < Mo::NP; ++j) out[j] += gp[j];
+    }
+}
+
+// quadgk over one loss interval with the off-grid integrand: the bisection logic of quad_gk_lane, the panel rule of gk15_eval
+template <class Mo, int MAXSEG, int CC = 0>
+HIPADJ_HD void quad_gk_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                    const dbl2* __restrict__ adj, const RevSteps& R, double a, double b, double atol, double rtol,
+                                    double (&res)[Mo::NP]) {
+    constexpr int NP = Mo::NP;
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+    auto panel = [&](double pa, double pb, double (&I)[NP]) -> double {
+        const double c = 0.5 * (pa + pb), h = 0.5 * (pb - pa);
+        double Ig[NP], f1[NP], f2[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { I[j] = 0.0; Ig[j] = 0.0; }
+#pragma unroll 1
+        for (int q = 0; q < 7; ++q) {
+            quad_integrand_offgrid<Mo, CC>(g, i, pv, knots, adj, R, c - h * GK15::X[q], f1);
+            quad_integrand_offgrid<Mo, CC>(g, i, pv, knots, adj, R, c + h * GK15::X[q], f2);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { const double s = f1[j] + f2[j]; I[j] += GK15::WK[q] * s; if (q & 1) Ig[j] += GK15::WG[q / 2] * s; }
+        }
+        quad_integrand_offgrid<Mo, CC>(g, i, pv, knots, adj, R, c, f1);
+        double e = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            I[j] += GK15::WK[7] * f1[j]; Ig[j] += GK15::WG[3] * f1[j];
+            I[j] *= h; Ig[j] *= h;
+            const double d = I[j] - Ig[j]; e += d * d;
+        }
+        return sqrt(e);
+    };
+    double sa[MAXSEG], sb[MAXSEG], sE[MAXSEG], sI[MAXSEG][NP];
+    double I[NP];
+    int ns = 1;
+    sa[0] = a; sb[0] = b;
+    { double I0[NP]; sE[0] = panel(a, b, I0);
+      for (int j = 0; j < NP; ++j) { sI[0][j] = I0[j]; I[j] = I0[j]; } }
+    double E = sE[0];
+    for (;;) {
+        double nrm = 0.0;
+        for (int j = 0; j < NP; ++j) nrm += I[j] * I[j];
+        nrm = sqrt(nrm);
+        const double tol = atol > rtol * nrm ? atol : rtol * nrm;
+        if (E <= tol || ns + 1 > MAXSEG) break;
+        int w = 0;
+        for (int s = 1; s < ns; ++s) if (sE[s] > sE[w]) w = s;
+        const double wa = sa[w], wb = sb[w], mid = 0.5 * (wa + wb);
+        if (!(mid > (wa < wb ? wa : wb) && mid < (wa < wb ? wb : wa))) break;
+        double I1[NP], I2[NP];
+        const double E1 = panel(wa, mid, I1);
+        const double E2 = panel(mid, wb, I2);
+        for (int j = 0; j < NP; ++j) { I[j] += I1[j] + I2[j] - sI[w][j]; sI[w][j] = I1[j]; sI[ns][j] = I2[j]; }
+        E += E1 + E2 - sE[w];
+        sa[w] = wa; sb[w] = mid; sE[w] = E1;
+        sa[ns] = mid; sb[ns] = wb; sE[ns] = E2;
+        ++ns;
+    }
+    for (int j = 0; j < NP; ++j) { double s = 0.0; for (int q = 0; q < ns; ++q) s += sI[q][j]; res[j] = s; }
+}
+
 }  // namespace hipadj

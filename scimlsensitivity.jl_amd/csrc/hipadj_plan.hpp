@@ -244,9 +244,10 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
         const bool og_ig = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && !cfg->checkpointing;
         const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->ckpt_stride == 0 && cfg->ncheckpoints == 0;
-        if (!(og_ig || og_bs) || P.field || P.mlp) {
-            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false) and BacksolveAdjoint (checkpoints = the save "
-                  "times, ckpt_stride = 0) on the lane-per-trajectory models; other configurations need times on the grid, or the adaptive stepper (arbitrary times)";
+        const bool og_q = cfg->alg == HIPADJ_ALG_QUADRATURE && !P.user;       // compiled-in lane models (round 2)
+        if (!(og_ig || og_bs || og_q) || P.field || P.mlp) {
+            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false), QuadratureAdjoint (compiled-in models) and "
+                  "BacksolveAdjoint (checkpoints = the save times, ckpt_stride = 0) on the lane-per-trajectory models; other configurations need times on the grid, or the adaptive stepper (arbitrary times)";
             return HIPADJ_ERR_UNSUPPORTED; }
         for (int i = 0; i < cfg->nsave; ++i) {   // the sweep takes the times literally; they must not leave the span
             if (P.save_times[i] < cfg->t0) P.save_times[i] = cfg->t0;
@@ -348,9 +349,12 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         const auto& t = P.save_times;
         if (t.empty()) { P.qa.push_back(cfg->t0); P.qb.push_back(cfg->t1); }
         else {
-            if (P.save_of_knot[S] < 0) { P.qa.push_back(t.back()); P.qb.push_back(cfg->t1); }
+            // end / start corrections when T / t0 is not a loss time (:563-616); off the grid the knot map is empty, so the times decide
+            const bool last_is_T = P.offgrid ? !(t.back() < cfg->t1) : P.save_of_knot[S] >= 0;
+            const bool first_is_t0 = P.offgrid ? !(t.front() > cfg->t0) : P.save_of_knot[0] >= 0;
+            if (!last_is_T) { P.qa.push_back(t.back()); P.qb.push_back(cfg->t1); }
             for (int i = (int)t.size() - 2; i >= 0; --i) { P.qa.push_back(t[i]); P.qb.push_back(t[i + 1]); }
-            if (P.save_of_knot[0] < 0) { P.qa.push_back(cfg->t0); P.qb.push_back(t.front()); }
+            if (!first_is_t0) { P.qa.push_back(cfg->t0); P.qb.push_back(t.front()); }
         }
     }
     P.nq = (int)P.qa.size();

@@ -244,8 +244,24 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         compose<Mo>(P, segbuf, du0, dp_traj);
         break; }
     case HIPADJ_ALG_QUADRATURE: {
-        std::vector<dbl2> adj((size_t)P.S * 2 * N * Np);
+        std::vector<dbl2> adj((size_t)(P.offgrid ? P.rs_t.size() : (size_t)P.S) * 2 * N * Np);
         const double atol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, rtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
+        if (P.offgrid) {   // k_quad_adj_offgrid + k_quad_gk_offgrid + k_quad_sum
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            for (long i = 0; i < P.N; ++i) {
+                double lam[N];
+                quad_adj_offgrid_lane<Mo, LOSS>(g, i, p, knots.data(), cot, RS, adj.data(), lam);
+                for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+                double acc[NP]; for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+                for (int q = 0; q < P.nq; ++q) {
+                    double res[NP];
+                    quad_gk_offgrid_lane<Mo, 128, (LOSS >> 1)>(g, i, p, knots.data(), adj.data(), RS, P.qa[q], P.qb[q], atol, rtol, res);
+                    for (int j = 0; j < NP; ++j) acc[j] += res[j];
+                }
+                for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = acc[j];
+            }
+            break;
+        }
         for (long i = 0; i < P.N; ++i) {
             double lam[N];
             quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot_rev.data(), adj.data(), lam);

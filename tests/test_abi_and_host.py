@@ -102,6 +102,8 @@ def test_planner_offgrid_loss_times_build_the_reverse_step_list():
     cfg = E.make_config("lorenz", "backsolve", 4, 0.0, 1.0, 0.01, [0.505, 1.0], time_segments=4, checkpointing=True)
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 1
     cfg = E.make_config("lorenz", "quadrature", 4, 0.0, 1.0, 0.01, [0.505, 1.0])
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nq.value == 2     # [0.505, 1.0] and the start correction [0, 0.505]
+    cfg = E.make_config("lorenz", "gausskronrod", 4, 0.0, 1.0, 0.01, [0.505, 1.0])
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == -6
     assert "off the step grid" in E.lib().emu_last_error().decode()
 

@@ -1075,7 +1075,7 @@ def test_offgrid_loss_times_interpolating(sa, saveat):
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     sol.engine.close()
     with pytest.raises(sa.HipadjError, match="off the step grid"):
-        sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.QuadratureAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
+        sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.GaussKronrodAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
     # GaussAdjoint on the same off-grid times: lambda-only sweep + 2-point Gauss-Legendre rule per reverse step
     sol = sa.solve(prob, sa.RK4(), dt=dt, saveat=saveat, sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
     du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
@@ -1083,6 +1083,22 @@ def test_offgrid_loss_times_interpolating(sa, saveat):
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
     sol.engine.close()
+
+
+@pytest.mark.parametrize("saveat", [0.333, [0.137, 0.4, 0.40499, 1.2345]])
+def test_offgrid_loss_times_quadrature(sa, saveat):
+    """QuadratureAdjoint with loss times off the step grid (k_quad_adj_offgrid + k_quad_gk_offgrid), default and tight quadgk tolerances."""
+    rng = np.random.default_rng(41)
+    N, T, dt = 150, 1.5, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    for sens in (sa.QuadratureAdjoint(), sa.QuadratureAdjoint(abstol=1e-12, reltol=1e-12)):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=saveat, sensealg=sens)
+        delta = rng.standard_normal(sol.u.shape)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=sol.t, dgdu_discrete=delta)
+        ref = O.Problem("LORENZ", alg="QUADRATURE", stepper="RK4", t0=0, t1=T, dt=dt, save_times=sol.t, loss="COTANGENT", quad_abstol=sens.abstol, quad_reltol=sens.reltol)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+        assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+        sol.engine.close()
 
 
 @pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring6", "RING", (6, 0, 0, 0))])
