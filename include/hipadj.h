@@ -92,7 +92,8 @@ typedef struct {
     int32_t stepper;           /* hipadj_stepper */
     int32_t dims[4];           /* model shape parameters (MLP, BRUSS), else 0 */
     int64_t ntraj;             /* N trajectories in this handle's shard */
-    double t0, t1, dt;         /* tspan; RK4: fixed step, (t1 - t0)/dt must be an integer number of steps S;
+    double t0, t1, dt;         /* tspan; RK4: fixed step; a span that is not a multiple of dt ends with a shortened step (lane-per-trajectory
+                                  models: such spans run the off-grid sweeps; PDE / MLP families: (t1 - t0)/dt must be an integer);
                                   Tsit5: initial step (<= 0: automatic) */
     int32_t nsave;             /* M loss/save times */
     const double *save_times;  /* [M] strictly ascending inside [t0, t1] (copied at create).  RK4: on the step grid t0 + k*dt; off-grid

@@ -227,7 +227,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     Geom& g = h->g;
     g.N = h->N; g.Npad = Np; g.S = (int)S; g.M = h->M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
-    g.kmask = -1;
+    g.kmask = -1; g.h_last = P.h_last;
     if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_FUSED_FINAL")) h->fused_final = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_WPB")) h->wpb4 = std::atoi(e) == 4;

@@ -48,7 +48,10 @@ struct Geom {
     int no_start;
     int p_shared;
     int kmask;         // always -1 in the library (knot index & kmask is what gets loaded: a masked index served a one-off study that separated HBM from issue limits)
+    double h_last;     // length of the LAST forward step [t_{S-1}, T]: = dt, or the remainder when the span is not a multiple of dt (the reference's
+                       // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
 };
+HIPADJ_HD double knot_step(const Geom& g, int k) { return k == g.S - 1 ? g.h_last : g.dt; }   // length of the forward step [t_k, t_{k+1}]
 
 template <class Mo> struct Knot { double u[Mo::N]; double f[Mo::N]; };
 
@@ -99,9 +102,8 @@ HIPADJ_HD void forward_lane(const Geom& g, long i, const double* __restrict__ u0
     double u[N], k1[N], k2[N], k3[N], k4[N], us[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) u[j] = u0[i * N + j];
-    const double dt = g.dt;
     for (int k = 0; k <= g.S; ++k) {
-        const double t = g.t0 + k * dt;
+        const double t = g.t0 + k * g.dt, dt = knot_step(g, k);
         Mo::f(k1, u, pv, t);
         if (knots) store_knot<Mo>(knots, g.Npad, k, i, u, k1);
         if (ckpt) { const int c = ckpt_of_knot[k]; if (c >= 0) {
@@ -642,8 +644,8 @@ HIPADJ_HD void cursor_eval(const Geom& g, long i, const dbl2* __restrict__ knots
         c.hi = c.lo; c.lo = c.nx; --c.cur;
         load_knot<Mo>(knots, g.Npad, c.cur > 0 ? c.cur - 1 : 0, i, c.nx);
     }
-    const double th = (tau - (g.t0 + c.cur * g.dt)) / g.dt;
-    hermite<Mo::N>(th, g.dt, c.lo.u, c.lo.f, c.hi.u, c.hi.f, y);
+    const double hk = knot_step(g, c.cur), th = (tau - (g.t0 + c.cur * g.dt)) / hk;
+    hermite<Mo::N>(th, hk, c.lo.u, c.lo.f, c.hi.u, c.hi.f, y);
 }
 
 // NC = 1: the whole sweep (q_lo = 0, q_hi = R.n) or the top segment of a time-segmented one; NC = 1 + n: a lower segment [q_lo, q_hi) of the
@@ -789,7 +791,7 @@ HIPADJ_HD void out_offgrid_lane(const Geom& g, long i, const dbl2* __restrict__ 
         Knot<Mo> lo, hi;
         load_knot<Mo>(knots, g.Npad, kk, i, lo); load_knot<Mo>(knots, g.Npad, kk + 1, i, hi);
         double y[N];
-        hermite<N>((tau - (g.t0 + kk * g.dt)) / g.dt, g.dt, lo.u, lo.f, hi.u, hi.f, y);
+        hermite<N>((tau - (g.t0 + kk * g.dt)) / knot_step(g, kk), knot_step(g, kk), lo.u, lo.f, hi.u, hi.f, y);
 #pragma unroll
         for (int j = 0; j < N; ++j) outT[((long)s * N + j) * g.Npad + i] = y[j];
     }
@@ -1323,7 +1325,7 @@ HIPADJ_HD void quad_integrand_offgrid(const Geom& g, long i, const double (&pv)[
     Knot<Mo> klo, khi;
     load_knot<Mo>(knots, g.Npad, k, i, klo); load_knot<Mo>(knots, g.Npad, k + 1, i, khi);
     double y[N], lam[N], l0[N], d0[N], l1[N], d1[N];
-    hermite<N>((t - (g.t0 + k * g.dt)) / g.dt, g.dt, klo.u, klo.f, khi.u, khi.f, y);
+    hermite<N>((t - (g.t0 + k * g.dt)) / knot_step(g, k), knot_step(g, k), klo.u, klo.f, khi.u, khi.f, y);
 #pragma unroll
     for (int j = 0; j < N; ++j) { l0[j] = rec[j]; d0[j] = rec[N + j]; l1[j] = rec[2 * N + j]; d1[j] = rec[3 * N + j]; }
     hermite<N>(tha, -hs, l0, d0, l1, d1, lam);

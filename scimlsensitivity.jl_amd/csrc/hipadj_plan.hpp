@@ -40,6 +40,7 @@ struct Plan {
     // fixed-step RK4 with loss times off the step grid (InterpolatingAdjoint): the reverse step sequence, the same for every
     // trajectory (hipadj_lane.hpp, interp_offgrid_lane)
     bool offgrid = false;
+    double h_last = 0.0;     // length of the last forward step (= dt unless the span is not a multiple of dt)
     std::vector<double> rs_t, rs_h, rs_te;
     std::vector<int> rs_save, rs_ck;
     int rs_save_at_start = -1;
@@ -221,8 +222,18 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (cfg->ntraj <= 0) { err = "ntraj must be positive"; return HIPADJ_ERR_INVALID_ARG; }
     if (!(cfg->dt > 0) || !(cfg->t1 > cfg->t0)) { err = "need dt > 0 and t1 > t0"; return HIPADJ_ERR_INVALID_ARG; }
-    const double sreal = (cfg->t1 - cfg->t0) / cfg->dt; const long S = std::lround(sreal);
-    if (S < 1 || std::fabs(sreal - (double)S) > 1e-6 * (double)S || S > 100000000L) { err = "(t1 - t0)/dt must be a positive integer number of steps"; return HIPADJ_ERR_INVALID_ARG; }
+    // Number of forward steps.  A span that is not a multiple of dt ends with a shortened step, as the reference's fixed-step solve does
+    // (dt = min(dt, tend - t)): S = ceil, h_last = the remainder; the reverse solve then starts from T with the full dt, so its steps never
+    // coincide with the forward knots and the configuration runs the off-grid sweeps (lane-per-trajectory models; forced below).
+    const double sreal = (cfg->t1 - cfg->t0) / cfg->dt; long S = std::lround(sreal);
+    bool ragged = false;
+    if (S < 1 || std::fabs(sreal - (double)S) > 1e-6 * (double)(S < 1 ? 1 : S)) {
+        S = (long)std::floor(sreal * (1.0 + 1e-12)) + 1;
+        ragged = sreal > 0.0;
+    }
+    if (S < 1 || S > 100000000L) { err = "(t1 - t0)/dt must give between 1 and 1e8 steps"; return HIPADJ_ERR_INVALID_ARG; }
+    P.h_last = ragged ? (cfg->t1 - cfg->t0) - (double)(S - 1) * cfg->dt : cfg->dt;
+    if (ragged && (P.field || P.mlp)) { err = "a span that is not a multiple of dt (shortened last step) is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->nsave < 0 || (cfg->nsave > 0 && !cfg->save_times)) { err = "save_times missing"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->time_segments < 0) { err = "time_segments must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
@@ -240,6 +251,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (k < 0 || k > S || std::fabs(kr - (double)k) > 1e-6) P.offgrid = true;
         else P.save_of_knot[k] = i;
     }
+    if (ragged) P.offgrid = true;   // the reverse steps leave the knots right from T
     if (P.offgrid) {
         // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
         const bool og_ig = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && !cfg->checkpointing;

@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
     Plan P; std::string err;
     if (make_plan(&cfg, P, err) != HIPADJ_OK) { fprintf(stderr, "plan: %s\n", err.c_str()); return 1; }
     const int n = 3, np = 3, S = P.S, C = P.nseg; const long Np = P.Npad;
-    Geom g{N, Np, S, P.M, 0.0, dt, 2.0, 1, 0, 1, -1};
+    Geom g{N, Np, S, P.M, 0.0, dt, 2.0, 1, 0, 1, -1, dt};
     // inputs: a fixed seed (not numpy's stream: dp differs from bench.py's unless N matches and u0 is loaded from a file)
     std::vector<double> u0((size_t)N * 3);
     { FILE* f = fopen("/tmp/kbench_u0.bin", "rb");

@@ -75,7 +75,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
 #endif
     constexpr int PF = EMU_PF;   // -DEMU_PF=2|4 exercises the shallow prefetch rings the runtime-compiled models use
     Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
-    g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1;
+    g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1; g.h_last = P.h_last;
     const long Np = P.Npad;
     std::vector<dbl2> knots(((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) || P.offgrid) ? (size_t)(P.S + 1) * N * Np : 0);
     std::vector<double> tile((size_t)((P.ck_longest > HIPADJ_CKPT_KMAX ? P.ck_longest : HIPADJ_CKPT_KMAX) + 1) * N);   // LDS tile, or the HBM slice of k_*_ckpt<..., GT = true>

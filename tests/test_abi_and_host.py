@@ -76,7 +76,7 @@ def test_no_cpu_fallback_without_device(sa):
 
 
 @pytest.mark.parametrize("kw,msg", [
-    (dict(dt=0.03), "integer number of steps"),
+    (dict(dt=3e-9), "between 1 and 1e8 steps"),
     (dict(save=[0.5, 0.5]), "strictly ascending"),
     (dict(save=[1.5]), "inside [t0, t1]"),
     (dict(ntraj=0), "ntraj"),
@@ -88,6 +88,17 @@ def test_planner_rejects_misuse(kw, msg):
     b = (C.c_int * 64)()
     rc = E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq))
     assert rc == -1 and msg in E.lib().emu_last_error().decode()
+
+
+def test_planner_span_not_a_multiple_of_dt_takes_a_short_last_step():
+    """dt = 0.03 on (0, 1): 34 forward steps, the last one 0.01 long; such spans always run the off-grid sweeps (the reverse steps start from T
+    with the full dt); the PDE / MLP families refuse them."""
+    nseg, nck, nq = C.c_int(), C.c_int(), C.c_int()
+    b = (C.c_int * 64)()
+    cfg = E.make_config("lorenz", "interpolating", 4, 0.0, 1.0, 0.03, [0.51, 0.99], time_segments=3)     # 0.51 = 17 * 0.03: on the knots, still off-grid
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 3 and b[3] >= 34
+    cfg = E.make_config("lorenz", "gausskronrod", 4, 0.0, 1.0, 0.03, [0.51])
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == -6
 
 
 def test_planner_offgrid_loss_times_build_the_reverse_step_list():

@@ -708,3 +708,32 @@ def test_checkpoint_list_misuse():
         cfg = E.make_config("lorenz", "backsolve", 1, 0.0, 1.0, 0.01, ts, checkpointing=True, **kw)
         with pytest.raises(RuntimeError, match=msg):
             E.forward_adjoint(cfg, 3, 3, np.ones((1, 3)), np.array([10.0, 28.0, 8 / 3]), np.zeros((1, 2, 3)))
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "gauss", "backsolve", "quadrature"])
+@pytest.mark.parametrize("T,ts", [(1.005, [0.0, 0.5, 1.005]), (1.0049, [0.3, 0.77]), (0.7333, [0.7333]), (1.005, [])])
+@pytest.mark.parametrize("segments", [1, 3])
+def test_span_that_is_not_a_multiple_of_dt(alg, T, ts, segments):
+    """solve(prob, RK4(), dt = 0.01) on tspan = (0, 1.005): the reference's fixed-step solve shortens its LAST step (dt = min(dt, tend - t)), the
+    reverse solve starts from T with the full dt again — its steps never coincide with the forward knots.  The planner marks such spans
+    off-grid (S = ceil, h_last = the remainder), the forward kernel takes the short last step, the Hermite cursor uses the interval's own
+    length.  Against the oracle's generic integrator, all sensealgs that have an off-grid sweep."""
+    if segments > 1 and alg in ("backsolve", "quadrature"):
+        pytest.skip("one-column sweeps")
+    rng = np.random.default_rng(17)
+    N, dt = 3, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.05 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    ts = np.asarray(ts, dtype=np.float64)
+    ck = alg == "backsolve"
+    delta = rng.standard_normal((N, len(ts), 3))
+    for loss_kind, d in ((0, delta), (1, None)):
+        if len(ts) == 0 and loss_kind == 0:
+            continue
+        cfg = E.make_config("lorenz", alg, N, 0.0, T, dt, ts, loss_kind=loss_kind, loss_shift=2.0, time_segments=segments, checkpointing=ck, quad_abstol=1e-11, quad_reltol=1e-11,
+                            cont_cost=(1 if len(ts) == 0 else 0))
+        du0, dp, out = E.forward_adjoint(cfg, 3, 3, u0, p, d)
+        ref = O.Problem("LORENZ", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT" if loss_kind == 0 else "LSQ_SHIFT", loss_shift=2.0,
+                        checkpointing=ck, quad_abstol=1e-11, quad_reltol=1e-11, cont_cost=(1 if len(ts) == 0 else 0))
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, d)
+        tol = 1e-6 if alg == "backsolve" else 1e-9
+        assert (len(ts) == 0 or rel(out, rout) < 1e-11) and rel(du0, rdu0) < tol and rel(dp, rdp) < tol

@@ -1085,6 +1085,22 @@ def test_offgrid_loss_times_interpolating(sa, saveat):
     sol.engine.close()
 
 
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_span_that_is_not_a_multiple_of_dt(sa, alg, oalg):
+    """tspan = (0, 1.005) with dt = 0.01: shortened last forward step, reverse steps off the knots from T on (planner: S = ceil, h_last)."""
+    rng = np.random.default_rng(43)
+    N, T, dt = 130, 1.005, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8 / 3])
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=0.25, sensealg=sensealg_of(sa, alg))
+    assert np.allclose(sol.t, [0, 0.25, 0.5, 0.75, 1.0, 1.005]) and sol.engine.stats()["nsteps"] == 101
+    delta = rng.standard_normal(sol.u.shape)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=sol.t, dgdu_discrete=delta)
+    ref = O.Problem("LORENZ", alg=oalg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=sol.t, loss="COTANGENT", checkpointing=(alg == "backsolve"))
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    sol.engine.close()
+
+
 @pytest.mark.parametrize("saveat", [0.333, [0.137, 0.4, 0.40499, 1.2345]])
 def test_offgrid_loss_times_quadrature(sa, saveat):
     """QuadratureAdjoint with loss times off the step grid (k_quad_adj_offgrid + k_quad_gk_offgrid), default and tight quadgk tolerances."""
