@@ -43,6 +43,7 @@ struct AdaptGeom {
     double t0, t1, dt0, abstol, reltol;
     double loss_shift;
     int loss_kind, no_start, p_shared, cont_cost;
+    int SmaxA;                 // QuadratureAdjoint: capacity (steps) of the dense ADJOINT record; its readers clamp the stored TRUE step count with it
 };
 
 // Tsit5 coefficients (Tsitouras 2011); same values as oracle/adjoint_oracle.c (order conditions checked there).
@@ -660,7 +661,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         else if constexpr (ALG == 3) mu_out[j] = 0.0;      // dp comes from the quadrature pass
         else mu_out[j] = z[N + j];
     }
-    if (ALG == 3) nsteps_adj[i] = sa < SmaxA ? sa : SmaxA;
+    if (ALG == 3) nsteps_adj[i] = sa;   // the TRUE count, also beyond the capacity: the host sizes the buffer from it (readers clamp with g.SmaxA)
     if (na < 0 || aoverflow || ck_overflow) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(flag, 4);
@@ -706,7 +707,7 @@ HIPADJ_HD void quad_gk_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
     for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
     FwdCursor<Mo> cf; cf.init(rec, g.Npad, i, nsteps[i] < g.Smax ? nsteps[i] : g.Smax); cf.seek(0.5 * (a + b));
-    AdjCursor<Mo> ca; ca.init(arec, g.Npad, i, nsteps_adj[i], 0.5 * (a + b));
+    AdjCursor<Mo> ca; ca.init(arec, g.Npad, i, nsteps_adj[i] < g.SmaxA ? nsteps_adj[i] : g.SmaxA, 0.5 * (a + b));
     auto integrand = [&](double t, double (&out)[NP]) {
         double y[N], lam[N];
         cf.eval(t, y); ca.eval(t, lam);

@@ -124,6 +124,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // dense adjoint solution: the reverse solve also stops at every loss time
             A(dev_alloc(h, &h->d_nsteps_adj, (size_t)Np));
             h->SmaxA = 2 * (h->auto_steps ? (int)h->rec_cap : P.Smax) + h->M + 16;
+            if (const char* e = std::getenv("HIPADJ_SMAXA")) { const int v = std::atoi(e); if (v > 0) h->SmaxA = v; }   // test hook: start the dense adjoint record too small
+            h->ag.SmaxA = h->SmaxA;
             A(dev_alloc(h, &h->d_arec, (size_t)h->SmaxA * RW * Np));
         }
         if (P.nck > 0) { A(dev_alloc(h, &h->d_ckpt, (size_t)P.nck * n * Np)); A(dev_alloc(h, &h->d_ck_t, (size_t)P.nck)); }
@@ -515,9 +517,15 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     bool composed = false;
     if (h->adaptive) {
-        TRY(usig<decltype(&k_adjoint_tsit5<ModelLV, 0, 0, false>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
-                    (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, h->ntstops,
-                    (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag, h->d_arec, h->d_nsteps_adj, h->SmaxA));
+        for (int pass = 0; pass < 2; ++pass) {
+            TRY(usig<decltype(&k_adjoint_tsit5<ModelLV, 0, 0, false>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
+                        (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, h->ntstops,
+                        (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag, h->d_arec, h->d_nsteps_adj, h->SmaxA));
+            if (!(h->cfg.alg == HIPADJ_ALG_QUADRATURE && h->auto_steps)) break;
+            const int again = adaptive_adjoint_autosize(h);
+            if (again < 0) return again;
+            if (again == 0) break;
+        }
         if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
             TRY(usig<decltype(&k_quad_gk_tsit5<ModelLV, 0>)>::launch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
@@ -599,7 +607,7 @@ int adaptive_autosize(hipadj_handle* h) {
     if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
         const long capA = 2 * cap + h->M + 16;
         TRY(regrow(&h->d_arec, (size_t)h->SmaxA * RW * h->Npad, (size_t)capA * RW * h->Npad));
-        h->SmaxA = (int)capA;
+        h->SmaxA = (int)capA; h->ag.SmaxA = h->SmaxA;
     }
     h->rec_cap = cap;
     h->st.workspace_bytes = h->ws_bytes;
@@ -612,6 +620,28 @@ int adaptive_autosize(hipadj_handle* h) {
     return 1;
 }
 
+
+// The dense ADJOINT record of QuadratureAdjoint on the adaptive path with max_steps == 0: its capacity starts as a guess (twice the
+// forward capacity + the loss times); the sweep stores the TRUE step count per trajectory, the host reads the maximum after the sweep and,
+// when the record did not fit, regrows it and asks for the sweep to be repeated (same step sequence: it cannot overflow again) — what
+// adaptive_autosize does for the forward records.  One stream synchronisation per adjoint call, in this mode only.
+// Returns 1 = repeat the sweep, 0 = it stands, negative = error.
+int adaptive_adjoint_autosize(hipadj_handle* h) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<int> ns((size_t)h->Npad);
+    HIP_TRY(h, hipMemcpy(ns.data(), h->d_nsteps_adj, sizeof(int) * (size_t)h->Npad, hipMemcpyDeviceToHost));
+    long mx = 1;
+    for (long i = 0; i < h->N; ++i) if (ns[i] > mx) mx = ns[i];
+    if (mx <= h->SmaxA || mx >= 8L * HIPADJ_AUTO_MAXITERS) return 0;
+    const int RW = 2 + 5 * h->n;
+    const long capA = mx + mx / 8 + 8;
+    if (h->d_arec) { (void)hipFree(h->d_arec); h->d_arec = nullptr; h->ws_bytes -= (double)((size_t)h->SmaxA * RW * h->Npad * sizeof(double)); }
+    TRY(dev_alloc(h, &h->d_arec, (size_t)capA * RW * h->Npad));
+    h->SmaxA = (int)capA; h->ag.SmaxA = h->SmaxA;
+    h->st.workspace_bytes = h->ws_bytes;
+    HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
+    return 1;
+}
 
 static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (h->user) return user_forward(h, d_u0, d_p, d_out);

@@ -127,3 +127,4 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
 template <int H> int mlp_forward_launch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out);
 template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp);
 int adaptive_autosize(hipadj_handle* h);   // record capacity from the counting pass (max_steps == 0); defined in hipadj_api.hip
+int adaptive_adjoint_autosize(hipadj_handle* h);   // the same for QuadratureAdjoint's dense adjoint record

@@ -369,11 +369,17 @@ template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hip
     harvest_set(h, es, true);
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
-    hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
-                       (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
-                       (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag,
-                       h->d_arec, h->d_nsteps_adj, h->SmaxA);
-    HIP_TRY(h, hipGetLastError());
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
+                           (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
+                           (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag,
+                           h->d_arec, h->d_nsteps_adj, h->SmaxA);
+        HIP_TRY(h, hipGetLastError());
+        if (!(ALG == 3 && h->auto_steps)) break;
+        const int again = adaptive_adjoint_autosize(h);   // dense adjoint record too small for some trajectory: regrown, sweep repeated once
+        if (again < 0) return again;
+        if (again == 0) break;
+    }
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
     if constexpr (ALG == 3) {
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;

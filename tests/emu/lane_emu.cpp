@@ -304,6 +304,7 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
     if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
     const int SmaxA = 2 * P.Smax + P.M + 16;
+    g.SmaxA = SmaxA;
     std::vector<double> arec(ALG == 3 ? (size_t)SmaxA * RW * Np : 0);
     std::vector<int> nsteps_adj((size_t)Np, 0);
     const double qatol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, qrtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;

@@ -525,6 +525,28 @@ def test_tsit5_large_ensemble_sampled_against_oracle_and_cross_method(sa):
     assert rel(res["gauss"][0], res["interpolating"][0]) < 1e-5 and rel(res["gauss"][1], res["interpolating"][1]) < 1e-5
 
 
+def test_tsit5_quadrature_dense_adjoint_record_regrows(sa, monkeypatch):
+    """QuadratureAdjoint on the adaptive path with max_steps = 0: the dense adjoint record starts from a guess; when a trajectory's reverse
+    solve takes more steps the sweep reports the true count, the buffer is regrown and the sweep repeated (HIPADJ_SMAXA forces a small start)."""
+    rng = np.random.default_rng(44)
+    N, T = 100, 4.0
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    ts = np.linspace(0, T, 9)
+    ref = O.Problem("LV", alg="QUADRATURE", stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-6, reltol=1e-6, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, quad_abstol=1e-10, quad_reltol=1e-10)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    for smaxa in (None, "12"):
+        if smaxa:
+            monkeypatch.setenv("HIPADJ_SMAXA", smaxa)
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10),
+                       dgdu_discrete=sa.LsqShift(2.0), abstol=1e-6, reltol=1e-6, max_steps=0)      # < 128 forward steps: the forward pass does not resize anything
+        ws0 = sol.engine.stats()["workspace_bytes"]
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts)
+        assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+        if smaxa:
+            assert sol.engine.stats()["workspace_bytes"] > ws0          # the record was regrown
+        sol.engine.close()
+
+
 def test_tsit5_max_steps_is_reported(sa):
     u0, p = lorenz_inputs(64)
     with pytest.raises(sa.HipadjError) as e:
