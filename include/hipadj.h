@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 102 /* 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
+#define HIPADJ_VERSION 103 /* 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -170,6 +170,16 @@ int hipadj_model_set_cost(int32_t model_id, const char *dgdu_body, const char *d
 /* Same, from the cost itself: g_body assigns `g` (declared `real g`) from u, p, t with `real` locals; dg/du and dg/dp are
  * generated by forward-mode dual numbers — the reference's gradient!(g) fallback (src/derivative_wrappers.jl:1428-1441). */
 int hipadj_model_set_cost_function(int32_t model_id, const char *g_body);
+/* ODEFunction(f; mass_matrix = M) for a runtime-registered model: M u' = f(u, p, t) with a CONSTANT NON-SINGULAR n x n matrix M
+ * (row-major; NULL removes it) — test/Core3/adjoint.jl:1315-1376.  The reference hands M to the forward solver and M' (resp.
+ * [M' 0; 0 I], [M' 0 0; 0 I 0; 0 0 M]) to the adjoint problems (src/interpolating_adjoint.jl:413-426, src/backsolve_adjoint.jl:232-247,
+ * src/quadrature_adjoint.jl:194-206, src/gauss_adjoint.jl:403-415) and divides the loss jumps by lu(M') (src/adjoint_common.jl:110-135,
+ * 805-807).  The device steppers are explicit, so the generated model is F = M^{-1} f with F_u' nu = f_u' (M^{-T} nu): the sweep
+ * integrates nu = M' lam, the parameter integrand f_p' lam is unchanged, and du0 is mapped back to lam(t0) = M^{-T} nu(t0) — what the
+ * reference returns (src/sensitivity_interface.jl:500; note that dG/du0 itself is M' du0).  All sensealgs, RK4 and Tsit5.
+ * A singular M (semi-explicit DAE, src/adjoint_common.jl:117-135, 790-803) needs an implicit stepper: HIPADJ_ERR_UNSUPPORTED.
+ * Handles created earlier keep the matrix they were created with. */
+int hipadj_model_set_mass_matrix(int32_t model_id, const double *M);
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
  * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
 int hipadj_model_check(int32_t model_id);

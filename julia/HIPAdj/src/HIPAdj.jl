@@ -1,7 +1,7 @@
 """
     HIPAdj
 
-Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 102) — the MI355X-native batched continuous-adjoint
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 103) — the MI355X-native batched continuous-adjoint
 engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
 
   * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, set_mass_matrix!, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -39,7 +39,7 @@ function lib()
     if LIB[] == C_NULL
         LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
         v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
-        v == 102 || error("libhipadj ABI version $v, this binding was written for 102")
+        v == 103 || error("libhipadj ABI version $v, this binding was written for 103")
     end
     return LIB[]
 end
@@ -141,7 +141,7 @@ function builtin_model(name::Symbol; dims = ())
 end
 
 """
-    register_model(name, n, np; f, vjp_u = nothing, vjp_p = nothing, dgdu = nothing, dgdp = nothing) -> DeviceModel
+    register_model(name, n, np; f, vjp_u = nothing, vjp_p = nothing, dgdu = nothing, dgdp = nothing, mass_matrix = nothing) -> DeviceModel
 
 `f`, `vjp_u`, `vjp_p`: BODIES of the three device functions as C text over `du`/`out`, `u`, `p`, `lam`, `t` — exactly the argument
 meaning of `ODEFunction(f!; vjp, vjp_p)` (both VJPs un-negated).  `vjp_u === vjp_p === nothing` selects forward-mode dual numbers on
@@ -149,7 +149,7 @@ the device (`autojacvec = true`): declare locals of `f` as `real`.  Compiled wit
 once now (no device needed) so that source errors surface here.
 """
 function register_model(name::AbstractString, n::Integer, np::Integer; f::AbstractString, vjp_u = nothing, vjp_p = nothing,
-        dgdu = nothing, dgdp = nothing, check_now::Bool = true)
+        dgdu = nothing, dgdp = nothing, mass_matrix = nothing, check_now::Bool = true)
     id = Ref{Int32}(0)
     # Julia Strings are NUL-terminated in memory: pointer(s) is a valid `const char *` while s is preserved
     cs(x) = x === nothing ? Ptr{UInt8}(C_NULL) : pointer(x)
@@ -163,9 +163,30 @@ function register_model(name::AbstractString, n::Integer, np::Integer; f::Abstra
         su = String(dgdu); sp = dgdp === nothing ? nothing : String(dgdp)
         GC.@preserve su sp check(ccall(sym(:hipadj_model_set_cost), Cint, (Int32, Ptr{UInt8}, Ptr{UInt8}), id[], pointer(su), cs(sp)))
     end
+    mass_matrix === nothing || set_mass_matrix!(id[], n, mass_matrix)
     check_now && check(ccall(sym(:hipadj_model_check), Cint, (Int32,), id[]))
     return DeviceModel(id[], (Int32(0), Int32(0), Int32(0), Int32(0)), Int(n), Int(np))
 end
+
+"""
+    set_mass_matrix!(model, M)          # M === nothing (or I) removes it
+
+`ODEFunction(f!; mass_matrix = M)` for a registered model: `M u' = f` with a constant NON-SINGULAR matrix (test/Core3/adjoint.jl:1315-1376).
+The ABI takes M row-major, Julia stores column-major, so the transpose is materialised once here.  `du0` keeps the reference's meaning
+(lam(t0) of `M' lam' = -J' lam`, src/sensitivity_interface.jl:500).  A singular `M` (semi-explicit DAE) is refused by the library: the
+device steppers are explicit.
+"""
+function set_mass_matrix!(id::Integer, n::Integer, M)
+    if M === nothing
+        check(ccall(sym(:hipadj_model_set_mass_matrix), Cint, (Int32, Ptr{Float64}), Int32(id), Ptr{Float64}(C_NULL)))
+        return nothing
+    end
+    size(M) == (n, n) || error("mass_matrix must be $n x $n")
+    Mt = Matrix{Float64}(permutedims(M))           # column-major M' == row-major M
+    GC.@preserve Mt check(ccall(sym(:hipadj_model_set_mass_matrix), Cint, (Int32, Ptr{Float64}), Int32(id), pointer(Mt)))
+    return nothing
+end
+set_mass_matrix!(m::DeviceModel, M) = set_mass_matrix!(m.id, m.n, M)
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the sensealg the extension dispatches on (seam B1 of SURVEY.md §8b)

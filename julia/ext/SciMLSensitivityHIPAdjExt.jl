@@ -34,6 +34,7 @@ using SciMLSensitivity: InterpolatingAdjoint, BacksolveAdjoint, GaussAdjoint, Ga
 using SciMLBase: SciMLBase, ReturnCode
 using ChainRulesCore: ChainRulesCore, NoTangent, ZeroTangent, AbstractThunk, AbstractZero, Tangent, unthunk
 using RecursiveArrayTools: AbstractVectorOfArray
+import LinearAlgebra
 import HIPAdj
 using HIPAdj: HIPBatchedAdjoint, HIPAdjSolution, Handle, forward!, adjoint!
 
@@ -110,6 +111,19 @@ function pack_cotangent(Δ, n::Int, N::Int, M::Int, only_end::Bool, idxs)
     return buf
 end
 
+"""
+The mass matrix of the matrix-state problem would be `(n N) x (n N)`; the device wants the per-trajectory `n x n` block, attached to the
+device model (`HIPAdj.register_model(...; mass_matrix = M)` / `HIPAdj.set_mass_matrix!`).  A problem that carries its own is refused
+instead of being silently integrated with M = I (src/adjoint_common.jl:110-135).
+"""
+function check_mass_matrix(prob)
+    mm = prob.f.mass_matrix
+    (mm === LinearAlgebra.I || mm isa LinearAlgebra.UniformScaling && isone(mm.λ)) ||
+        error("HIPBatchedAdjoint: attach the n x n mass matrix to the device model (HIPAdj.register_model(...; mass_matrix = M)); " *
+              "prob.f.mass_matrix of the matrix-state problem is not read")
+    return nothing
+end
+
 function SciMLBase._concrete_solve_adjoint(
         prob::SciMLBase.AbstractODEProblem, alg, sensealg::HIPBatchedAdjoint,
         u0::AbstractMatrix, p, originator::SciMLBase.ADOriginator, args...;
@@ -118,6 +132,7 @@ function SciMLBase._concrete_solve_adjoint(
     )
     inner = sensealg.inner
     model = sensealg.model
+    check_mass_matrix(prob)
     n, N = size(u0)
     n == model.n || error("HIPBatchedAdjoint: the device model has $(model.n) states, u0 has $n rows (columns are trajectories)")
     p_shared = p isa AbstractVector
@@ -171,6 +186,7 @@ called once per trajectory and loss time on the host to fill the cotangent block
 """
 function HIPAdj.hip_solve(prob::SciMLBase.AbstractODEProblem, alg, sensealg::HIPBatchedAdjoint; u0 = prob.u0, p = prob.p, saveat,
         dt = nothing, abstol = 1.0e-6, reltol = 1.0e-3, checkpoints = nothing)
+    check_mass_matrix(prob)
     n, N = size(u0)
     stepper = stepper_of(alg)
     ts, _ = save_times(prob.tspan, saveat, dt, true, true, stepper)

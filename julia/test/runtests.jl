@@ -6,7 +6,7 @@ using Test, HIPAdj, SciMLSensitivity, OrdinaryDiffEq, Zygote, Random
 
 @testset "layout" begin
     @test HIPAdj.check_layout()
-    @test hipadj_version() == 102
+    @test hipadj_version() == 103
 end
 
 lorenz!(du, u, p, t) = (du[1] = p[1] * (u[2] - u[1]); du[2] = u[1] * (p[2] - u[3]) - u[2]; du[3] = u[1] * u[2] - p[3] * u[3]; nothing)
@@ -45,4 +45,25 @@ end
                                           sensealg = HIPBatchedAdjoint(InterpolatingAdjoint(); model = builtin_model(:lorenz)))), p)
     g_s = Zygote.gradient(p -> loss(solve(prob, RK4(); p, dt = 0.01, adaptive = false, saveat = 0.1, sensealg = dev)), p)
     @test isapprox(g_s[1], g_b[1]; rtol = 1e-10)
+end
+
+@testset "mass matrix (test/Core3/adjoint.jl:1315-1376)" begin
+    # M u' = A u + p + e2 sum(p): the reference's own mass-matrix problem, on a matrix state of N identical columns
+    A = [1.0 2 3; 4 5 6; 7 8 9]; mm = -[1.0 2 4; 2 3 7; 1 3 41]
+    m = HIPAdj.register_model("affine3_mm", 3, 3;
+        f = "du[0] = 1.0*u[0] + 2.0*u[1] + 3.0*u[2] + p[0]; du[1] = 4.0*u[0] + 5.0*u[1] + 6.0*u[2] + p[1] + (p[0] + p[1] + p[2]); du[2] = 7.0*u[0] + 8.0*u[1] + 9.0*u[2] + p[2];",
+        vjp_u = "out[0] = 1.0*lam[0] + 4.0*lam[1] + 7.0*lam[2]; out[1] = 2.0*lam[0] + 5.0*lam[1] + 8.0*lam[2]; out[2] = 3.0*lam[0] + 6.0*lam[1] + 9.0*lam[2];",
+        vjp_p = "out[0] = lam[0] + lam[1]; out[1] = 2.0*lam[1]; out[2] = lam[2] + lam[1];", mass_matrix = mm)
+    foo(du, u, p, t) = (du .= A * u .+ p; du[2] += sum(p); nothing)
+    pm = [1.0, 2.0, 3.0]; ts = 0:0.01:1
+    prob_mm = ODEProblem(ODEFunction(foo, mass_matrix = mm), [1.0, 2.0, 3.0], (0.0, 1.0), pm)
+    sol_mm = solve(prob_mm, Rodas4(), reltol = 1.0e-14, abstol = 1.0e-14)
+    dg(out, u, p, t, i) = out .= 1
+    du0_ref, dp_ref = adjoint_sensitivities(sol_mm, Rodas4(); t = ts, dgdu_discrete = dg, abstol = 1.0e-14, reltol = 1.0e-14, sensealg = InterpolatingAdjoint())
+    dev = HIPBatchedAdjoint(InterpolatingAdjoint(); model = m)
+    cols = ODEProblem((dU, U, p, t) -> nothing, repeat([1.0, 2.0, 3.0], 1, 4), (0.0, 1.0), pm)      # the right-hand side lives in the device model
+    sol = HIPAdj.hip_solve(cols, Tsit5(), dev; saveat = collect(ts), abstol = 1.0e-12, reltol = 1.0e-12)
+    du0, dp = adjoint_sensitivities(sol, Tsit5(); sensealg = dev, dgdu_discrete = dg)
+    @test isapprox(dp ./ 4, dp_ref; rtol = 1e-8)            # shared p: the device sums over the 4 identical columns
+    @test isapprox(du0[:, 1], du0_ref; rtol = 1e-8)         # lam(t0), the reference's convention
 end

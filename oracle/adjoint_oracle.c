@@ -51,6 +51,7 @@ static int model_init(orc_model *m, int id, const int dims[4]) {
         int G = m->dims[0]; if (G <= 1) return -1;
         m->n = 2 * G * G; m->np = 3; break; }
     case ORC_MODEL_ROBER: m->n = 3; m->np = 3; break;
+    case ORC_MODEL_AFFINE3: m->n = 3; m->np = 3; break;
     case ORC_MODEL_RING: { int r = m->dims[0]; if (r < 2 || r > 8) return -1; m->n = r; m->np = r + 1; break; }
     default: return -1;
     }
@@ -92,6 +93,11 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
         du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
         du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
         du[2] = p[1] * u[1] * u[1];
+        break;
+    case ORC_MODEL_AFFINE3: /* `foo` of the mass-matrix test, test/Core3/adjoint.jl:1315-1321: du = A u + p; du[2] += sum(p), A = [1 2 3; 4 5 6; 7 8 9] */
+        du[0] = 1.0 * u[0] + 2.0 * u[1] + 3.0 * u[2] + p[0];
+        du[1] = 4.0 * u[0] + 5.0 * u[1] + 6.0 * u[2] + p[1] + (p[0] + p[1] + p[2]);
+        du[2] = 7.0 * u[0] + 8.0 * u[1] + 9.0 * u[2] + p[2];
         break;
     case ORC_MODEL_RING: {  /* synthetic test subject for runtime-registered models (NOT from the reference):
                                du_i = p_i (u_{i+1} - u_i) + p_n sin(u_{i-1}), indices mod n */
@@ -182,6 +188,14 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
             dgrad[2] = u[1] * u[2] * lam[0] - u[1] * u[2] * lam[1];
         }
         break;
+    case ORC_MODEL_AFFINE3:
+        if (dlam) {
+            dlam[0] = 1.0 * lam[0] + 4.0 * lam[1] + 7.0 * lam[2];
+            dlam[1] = 2.0 * lam[0] + 5.0 * lam[1] + 8.0 * lam[2];
+            dlam[2] = 3.0 * lam[0] + 6.0 * lam[1] + 9.0 * lam[2];
+        }
+        if (dgrad) { dgrad[0] = lam[0] + lam[1]; dgrad[1] = 2.0 * lam[1]; dgrad[2] = lam[2] + lam[1]; }
+        break;
     case ORC_MODEL_RING: {
         int r = m->n;
         if (dlam) for (int j = 0; j < r; ++j)
@@ -247,6 +261,45 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
         (void)t;
         break; }
     }
+}
+
+/* -------------------------------------------------------------------------------------
+ * Constant non-singular mass matrix  M u' = f(u, p, t)   (ODEFunction(f; mass_matrix = M), test/Core3/adjoint.jl:1315-1325).
+ * The reference hands the solver the mass matrix itself: the forward problem keeps M, the adjoint problems get
+ *   [M' 0; 0 I]            Interpolating   (src/interpolating_adjoint.jl:413-426)
+ *   [M' 0 0; 0 I 0; 0 0 M] Backsolve       (src/backsolve_adjoint.jl:232-247)
+ *   M'                     Quadrature / Gauss (src/quadrature_adjoint.jl:194-206, src/gauss_adjoint.jl:403-415)
+ * and the loss jumps are divided by lu(M') (adjointdiffcache, src/adjoint_common.jl:110-135; ReverseLossCallback :805-807).
+ * An explicit stepper needs the blocks solved: every right-hand side block b of a row block with mass matrix B becomes B^{-1} b.
+ * du0 is lam(t0) exactly as the reference returns it (src/sensitivity_interface.jl:500) - no M' factor.
+ * Singular M (semi-explicit DAE, :117-135, 790-803) needs an implicit solver and is outside this restatement.
+ * Process-wide and read-only while a solve runs (set before, cleared after). */
+#define ORC_MM_MAXN 8
+static int g_mm_n = 0;
+static double g_mm_inv[ORC_MM_MAXN * ORC_MM_MAXN], g_mm_invT[ORC_MM_MAXN * ORC_MM_MAXN];
+int orc_set_mass_matrix(int n, const double *M) {
+    if (!M || n <= 0) { g_mm_n = 0; return 0; }
+    if (n > ORC_MM_MAXN) return -1;
+    double a[ORC_MM_MAXN][2 * ORC_MM_MAXN];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { a[i][j] = M[i * n + j]; a[i][n + j] = (i == j); }
+    double scale = 0; for (int i = 0; i < n * n; ++i) scale = fmax(scale, fabs(M[i]));
+    for (int c = 0; c < n; ++c) {               /* Gauss-Jordan with partial pivoting */
+        int piv = c; for (int r = c + 1; r < n; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (!(fabs(a[piv][c]) > 1e-13 * scale)) { g_mm_n = 0; return -2; }   /* "must be nonsingular" :132-133 */
+        if (piv != c) for (int j = 0; j < 2 * n; ++j) { double tmp = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = tmp; }
+        double d = a[c][c]; for (int j = 0; j < 2 * n; ++j) a[c][j] /= d;
+        for (int r = 0; r < n; ++r) if (r != c) { double f = a[r][c]; if (f != 0) for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { g_mm_inv[i * n + j] = a[i][n + j]; g_mm_invT[j * n + i] = a[i][n + j]; }
+    g_mm_n = n;
+    return 0;
+}
+/* v <- A v for the n x n block A, when a mass matrix of that size is set */
+static void mm_solve(const double *A, int n, double *v) {
+    if (g_mm_n != n) return;
+    double r[ORC_MM_MAXN];
+    for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += A[i * n + j] * v[j]; r[i] = s; }
+    for (int i = 0; i < n; ++i) v[i] = r[i];
 }
 
 int orc_model_f(int model, const int dims[4], const double *u, const double *p, double t, double *du) {
@@ -565,7 +618,7 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
  * 3. Forward solve (src/concrete_solve.jl:689-770)
  * ===================================================================================== */
 typedef struct { const orc_model *m; const double *p; } fwd_ctx;
-static void fwd_rhs(double *du, const double *u, double t, void *c) { fwd_ctx *f = (fwd_ctx *)c; model_f(f->m, du, u, f->p, t); }
+static void fwd_rhs(double *du, const double *u, double t, void *c) { fwd_ctx *f = (fwd_ctx *)c; model_f(f->m, du, u, f->p, t); mm_solve(g_mm_inv, f->m->n, du); }
 
 static orc_alg make_alg(const orc_config *cfg) {
     orc_alg a; a.kind = cfg->stepper; a.dt = cfg->dt; a.abstol = cfg->abstol > 0 ? cfg->abstol : 1e-6; a.reltol = cfg->reltol > 0 ? cfg->reltol : 1e-3;
@@ -679,6 +732,7 @@ static void rhs_interpolating(double *dz, const double *z, double t, void *c) {
     for (int i = 0; i < n; ++i) dz[i] *= -1.0;               /* :169 */
     for (int i = 0; i < np; ++i) dz[n + i] *= -1.0;          /* :170 */
     accumulate_cost(A, dz, dz + n);                          /* :172 */
+    mm_solve(g_mm_invT, n, dz);                              /* mass matrix [M' 0; 0 I]  :413-426 */
 }
 /* (S::ODEBacksolveSensitivityFunction)(du,u,p,t)  src/backsolve_adjoint.jl:32-61 ; z = [lam; grad; y] (:78-120) */
 static void rhs_backsolve(double *dz, const double *z, double t, void *c) {
@@ -688,6 +742,7 @@ static void rhs_backsolve(double *dz, const double *z, double t, void *c) {
     model_f(A->m, dz + n + np, A->y, A->p, t);                /* dy = f(y,p,t), not negated :54 */
     for (int i = 0; i < n + np; ++i) dz[i] *= -1.0;
     accumulate_cost(A, dz, dz + n);                           /* :59 */
+    mm_solve(g_mm_invT, n, dz); mm_solve(g_mm_inv, n, dz + n + np);   /* mass matrix [M' 0 0; 0 I 0; 0 0 M]  :232-247 */
 }
 /* Quadrature / Gauss: u = lam only (src/quadrature_adjoint.jl:35-46, src/gauss_adjoint.jl:118-128) */
 static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
@@ -696,6 +751,7 @@ static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
     model_vjp(A->m, dz, NULL, z, A->y, A->p, t);
     for (int i = 0; i < n; ++i) dz[i] *= -1.0;
     accumulate_cost(A, dz, NULL);                             /* quadrature_adjoint.jl:44, gauss_adjoint.jl:126 */
+    mm_solve(g_mm_invT, n, dz);                               /* mass matrix M'  quadrature_adjoint.jl:194-206, gauss_adjoint.jl:403-415 */
 }
 
 static int time_hits(double t, double target) { return fabs(t - target) <= 100 * DBL_EPSILON * fmax(fabs(t), fabs(target)); }
@@ -713,10 +769,11 @@ static int loss_jump(adj_ctx *A, orc_integ *I) {
         fetch_y(A, I->t);
     }
     int idx = A->cur_time - 1;
-    for (int i = 0; i < n; ++i) {
-        double g = (A->cfg->loss_kind == ORC_LOSS_COTANGENT) ? A->dLdu[(size_t)idx * n + i] : (A->y[i] - A->cfg->loss_shift);
-        I->u[i] += g;                                                                        /* :812-813 */
-    }
+    double *gu = A->scratch;
+    for (int i = 0; i < n; ++i)
+        gu[i] = (A->cfg->loss_kind == ORC_LOSS_COTANGENT) ? A->dLdu[(size_t)idx * n + i] : (A->y[i] - A->cfg->loss_shift);
+    mm_solve(g_mm_invT, n, gu);                                                              /* ldiv!(F, dlam_d), F = lu(M')  :805-807 */
+    for (int i = 0; i < n; ++i) I->u[i] += gu[i];                                            /* :812-813 */
     A->cur_time -= 1;
     return 1;
 }

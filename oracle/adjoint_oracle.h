@@ -38,7 +38,9 @@ enum {
     ORC_MODEL_MLP = 5,       /* tanh MLP d->H->H->d applied column-wise to a d x B state */
     ORC_MODEL_BRUSS = 6,     /* 2-D Brusselator, periodic 5-point Laplacian */
     ORC_MODEL_ROBER = 7,     /* Robertson kinetics `rober` (test/Core3/adjoint.jl:1434-1441); checker for runtime-registered models */
-    ORC_MODEL_RING = 8       /* synthetic ring, dims = {n <= 8}, np = n + 1; checker for runtime-registered models with n > 3 */
+    ORC_MODEL_RING = 8,      /* synthetic ring, dims = {n <= 8}, np = n + 1; checker for runtime-registered models with n > 3 */
+    ORC_MODEL_AFFINE3 = 9    /* du = A u + p, du[2] += sum(p): `foo` of the mass-matrix test (test/Core3/adjoint.jl:1315-1321); checker for
+                                runtime-registered models with a mass matrix */
 };
 enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3,
        ORC_ALG_GAUSS_KRONROD = 4 /* [upstream-recall] per-step adaptive GK(7,15): parity UNPINNED beyond GaussKronrod == Gauss */ };
@@ -65,6 +67,11 @@ typedef struct {
 } orc_config;
 
 int orc_model_sizes(int model, const int dims[4], int *n, int *np);
+
+/* Constant non-singular mass matrix M (n x n, row-major) for every following solve of a model with n states: M u' = f
+   (ODEFunction(f; mass_matrix = M), src/adjoint_common.jl:110-135, 805-807; the adjoint problems carry M' / [M' 0; 0 I]).
+   NULL clears it.  Returns -2 when M is singular (semi-explicit DAEs are outside the restatement).  Process-wide. */
+int orc_set_mass_matrix(int n, const double *M);
 
 /* forward solve of ONE trajectory; out[M][n] = sol(save_times) (src/concrete_solve.jl:718-727) */
 int orc_forward(const orc_config *cfg, const double *u0, const double *p, double *out, long *nsteps);

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_model_set_cost", "hipadj_model_set_cost_function",
+    "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_model_set_mass_matrix",
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
 )
 
@@ -102,6 +102,7 @@ def load():
     L.hipadj_model_check_config.argtypes = [C.POINTER(HipadjConfig)]
     L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_model_set_cost_function.argtypes = [C.c_int32, C.c_char_p]
+    L.hipadj_model_set_mass_matrix.argtypes = [C.c_int32, C.POINTER(C.c_double)]
     L.hipadj_comm_unique_id.argtypes = [C.c_char_p]
     L.hipadj_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.hipadj_comm_attach.argtypes = [vp, vp]
@@ -127,12 +128,33 @@ def register_model(name, n, npar, f, vjp=None, vjp_p=None, check=False):
     rc = L.hipadj_model_register(name.encode(), int(n), int(npar), f.encode(), enc(vjp), enc(vjp_p), C.byref(mid))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
-    if check:
-        rc = L.hipadj_model_check(mid.value)
-        if rc != OK:
-            raise HipadjError(rc, L.hipadj_last_error(None).decode())
     MODEL[name] = mid.value
+    if check:
+        check_model(mid.value)
     return mid.value
+
+
+def check_model(model_id):
+    """hipadj_model_check: compile the forward and InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed)."""
+    L = load()
+    rc = L.hipadj_model_check(int(model_id))
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+
+
+def set_model_mass_matrix(model_id, n, M):
+    """hipadj_model_set_mass_matrix: ODEFunction(f; mass_matrix = M) for a runtime-registered model (constant, non-singular; None removes)."""
+    L = load()
+    if M is None:
+        rc = L.hipadj_model_set_mass_matrix(int(model_id), None)
+    else:
+        import numpy as np
+        A = np.ascontiguousarray(M, dtype=np.float64)
+        if A.shape != (n, n):
+            raise ValueError(f"mass_matrix must be {n} x {n}, got {A.shape}")
+        rc = L.hipadj_model_set_mass_matrix(int(model_id), A.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
 
 
 def set_model_cost(model_id, dgdu=None, dgdp=None, g=None):

@@ -47,6 +47,10 @@ extern "C" int hipadj_model_set_cost_function(int32_t model_id, const char* g_bo
     return user_set_cost_function(model_id, g_body, g_create_error);
 }
 
+extern "C" int hipadj_model_set_mass_matrix(int32_t model_id, const double* M) {
+    return user_set_mass_matrix(model_id, M, g_create_error);
+}
+
 extern "C" int hipadj_model_check(int32_t model_id) {
     std::vector<char> code; std::map<std::string, std::string> low;
     std::vector<std::string> exprs = {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 1, 7>" : "hipadj::k_interp<hipadj::UserModel, 1, 1>"};
@@ -254,7 +258,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->st.vjp_steps = (double)h->N * (double)S * 4.0;
     h->user = P.user;
     if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { h->err = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost)"; return fail(HIPADJ_ERR_INVALID_ARG); }
-    if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
+    if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); }
     *out = h;
     return HIPADJ_OK;
 }
@@ -503,6 +507,18 @@ static int user_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
     return HIPADJ_OK;
 }
 
+// Mass matrix: the sweep leaves nu(t0) = M^T lam(t0) in du0 [N][n]; the reference returns lam(t0) (src/sensitivity_interface.jl:500),
+// so every row is multiplied by M^{-T} in place.  One thread per trajectory; n <= 8.
+struct MassInv { double a[64]; };
+__global__ void k_mass_du0(long N, int n, MassInv mi, double* __restrict__ du0) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double v[8], r[8];
+    for (int j = 0; j < n; ++j) v[j] = du0[i * n + j];
+    for (int j = 0; j < n; ++j) { double s = 0.0; for (int k = 0; k < n; ++k) s += mi.a[k * n + j] * v[k]; r[j] = s; }
+    for (int j = 0; j < n; ++j) du0[i * n + j] = r[j];
+}
+
 static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     const double* p = h->p_dev_last;
@@ -575,6 +591,11 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         TRY(usig<decltype(&k_finish<2, 4>)>::launch(h, h->uf_tail, dim3(fblocks), dim3(FIN), h->N, h->Npad, (const double*)d_du0, (const double*)h->d_dp_traj, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     if (h->cfg.p_shared) {
         hipLaunchKernelGGL(k_reduce_final, dim3((unsigned)h->np), dim3(FIN), 0, h->stream, (int)((composed && seg_kernels) ? cblocks : fblocks), h->np, (const double*)h->d_partial, d_dp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->has_mm) {
+        MassInv mi; std::memcpy(mi.a, h->minv, sizeof(mi.a));
+        hipLaunchKernelGGL(k_mass_du0, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N, h->n, mi, d_du0);
         HIP_TRY(h, hipGetLastError());
     }
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));

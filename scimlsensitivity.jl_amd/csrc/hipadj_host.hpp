@@ -52,6 +52,7 @@ struct hipadj_handle {
     MlpGeom mg{};
     FieldGeom fg{};
     bool user = false;                    // runtime-compiled right-hand side (hipadj_user.hpp)
+    bool has_mm = false; double minv[64] = {0};   // the model's mass matrix at create time (M^{-1}, row-major): du0 = M^{-T} nu(t0) after the sweep
     hipModule_t umod = nullptr;
     hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish
     bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)

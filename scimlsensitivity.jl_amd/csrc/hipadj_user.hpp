@@ -20,6 +20,7 @@
 
 #include <unistd.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -39,6 +40,8 @@ struct UserModelSrc {
     std::string gfun;         // ... or the cost itself (hipadj_model_set_cost_function): gradients by dual numbers
     bool has_cost = false;
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
+    bool has_mm = false;      // constant non-singular mass matrix (hipadj_model_set_mass_matrix): minv = M^{-1}, row-major n x n
+    double minv[64] = {0};
     int n = 0, np = 0, rev = 0;   // rev: bumped when the sources change, part of the code-cache key
 };
 
@@ -118,10 +121,34 @@ inline std::string user_model_struct(const UserModelSrc& m) {
     o << "#include \"hipadj_kernels.hpp\"\n#include \"hipadj_adaptive.hpp\"\n#include \"hipadj_dual.hpp\"\n"
       << "namespace hipadj {\n// runtime-registered model '" << m.name << "'\nstruct UserModel {\n"
       << "    static constexpr int N = " << m.n << ", NP = " << m.np << ";\n    static constexpr bool TIME_DEP = true;\n";
+    if (m.has_mm) {
+        // constant mass matrix M u' = f (ODEFunction(f; mass_matrix = M), src/adjoint_common.jl:110-135): the kernels integrate
+        // u' = F(u) = M^{-1} f(u) and the adjoint of THAT system, nu' = -F_u^T nu with the plain jumps nu += g_u.  nu = M^T lam, where lam is
+        // the reference's adjoint (M^T lam' = -f_u^T lam, jumps M^{-T} g_u :805-807), mu' = -F_p^T nu = -f_p^T lam is the same
+        // parameter integrand; the host maps du0 = lam(t0) = M^{-T} nu(t0) after the sweep (k_mass_du0).  Zero entries of M^{-1} are dropped.
+        char num[40];
+        o << "    template <class real> HIPADJ_HD static void mm_inv(real (&v)[N]) {\n        real r[N];\n";
+        for (int i = 0; i < m.n; ++i) {
+            o << "        r[" << i << "] = real(0.0)";
+            for (int j = 0; j < m.n; ++j) if (m.minv[i * m.n + j] != 0.0) { snprintf(num, sizeof(num), "%.17g", m.minv[i * m.n + j]); o << " + real(" << num << ") * v[" << j << "]"; }
+            o << ";\n";
+        }
+        o << "        for (int i = 0; i < N; ++i) v[i] = r[i];\n    }\n"
+          << "    HIPADJ_HD static void mm_invT(double (&w)[N], const double (&lam)[N]) {\n";
+        for (int i = 0; i < m.n; ++i) {
+            o << "        w[" << i << "] = 0.0";
+            for (int j = 0; j < m.n; ++j) if (m.minv[j * m.n + i] != 0.0) { snprintf(num, sizeof(num), "%.17g", m.minv[j * m.n + i]); o << " + (" << num << ") * lam[" << j << "]"; }
+            o << ";\n";
+        }
+        o << "    }\n";
+    }
     if (m.auto_vjp) {
         // f is compiled for real = double and real = Dual<K>; the VJPs are lam-weighted column sums of the dual partials
-        o << "    template <class real> HIPADJ_HD static void f_t(real (&du)[N], const real (&u)[N], const real (&p)[NP], real t) {\n"
-          << "        (void)u; (void)p; (void)t;\n" << m.f << "\n    }\n"
+        o << "    template <class real> HIPADJ_HD static void " << (m.has_mm ? "f_raw_t" : "f_t") << "(real (&du)[N], const real (&u)[N], const real (&p)[NP], real t) {\n"
+          << "        (void)u; (void)p; (void)t;\n" << m.f << "\n    }\n";
+        if (m.has_mm)
+            o << "    template <class real> HIPADJ_HD static void f_t(real (&du)[N], const real (&u)[N], const real (&p)[NP], real t) { f_raw_t<real>(du, u, p, t); mm_inv<real>(du); }\n";
+        o << ""
           << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) { f_t<double>(du, u, p, t); }\n"
           << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        Dual<N> uu[N], pp[NP], dd[N];\n"
@@ -136,12 +163,17 @@ inline std::string user_model_struct(const UserModelSrc& m) {
           << "        f_t<Dual<NP>>(dd, uu, pp, Dual<NP>(t));\n"
           << "        for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n";
     } else {
-        o << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+        const char* sfx = m.has_mm ? "_raw" : "";
+        o << "    HIPADJ_HD static void f" << sfx << "(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        (void)u; (void)p; (void)t;\n" << m.f << "\n    }\n"
-          << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "    HIPADJ_HD static void vjp_u" << sfx << "(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_u << "\n    }\n"
-          << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "    HIPADJ_HD static void vjp_p" << sfx << "(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_p << "\n    }\n";
+        if (m.has_mm)   // F = M^{-1} f:  F_u^T lam = f_u^T (M^{-T} lam),  F_p^T lam = f_p^T (M^{-T} lam)
+            o << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) { f_raw(du, u, p, t); mm_inv<double>(du); }\n"
+              << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { double w[N]; mm_invT(w, lam); vjp_u_raw(out, w, u, p, t); }\n"
+              << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { double w[N]; mm_invT(w, lam); vjp_p_raw(out, w, u, p, t); }\n";
     }
     o << "    // continuous cost attached with hipadj_model_set_cost[_function] (dgdu_continuous / dgdp_continuous); zero when absent\n";
     if (m.has_cost && !m.gfun.empty()) {
@@ -355,6 +387,45 @@ inline int user_set_cost(int32_t model, const char* dgdu, const char* dgdp, std:
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
     R.models[idx].dgdu = dgdu; R.models[idx].dgdp = dgdp; R.models[idx].gfun.clear(); R.models[idx].has_cost = true; R.models[idx].rev++;
     return HIPADJ_OK;
+}
+// ODEFunction(f; mass_matrix = M) for a runtime model: M row-major n x n, constant and non-singular; NULL removes it.
+// Singular M (semi-explicit DAE, src/adjoint_common.jl:117-135, 790-803) needs an implicit stepper: refused.
+inline int user_set_mass_matrix(int32_t model, const double* M, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_mass_matrix: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
+    UserModelSrc& m = R.models[idx];
+    if (!M) { if (m.has_mm) { m.has_mm = false; m.rev++; } return HIPADJ_OK; }
+    const int n = m.n;
+    double a[8][16]; double scale = 0.0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+        if (!std::isfinite(M[i * n + j])) { err = "hipadj_model_set_mass_matrix: non-finite entry"; return HIPADJ_ERR_INVALID_ARG; }
+        a[i][j] = M[i * n + j]; a[i][n + j] = i == j ? 1.0 : 0.0; scale = std::fmax(scale, std::fabs(M[i * n + j]));
+    }
+    for (int c = 0; c < n; ++c) {   // Gauss-Jordan, partial pivoting
+        int piv = c; for (int r = c + 1; r < n; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (!(std::fabs(a[piv][c]) > 1e-13 * scale)) {
+            err = "hipadj_model_set_mass_matrix: the mass matrix is singular; a semi-explicit DAE needs an implicit stepper (the device steppers are RK4 / Tsit5) "
+                  "- only constant non-singular mass matrices are supported";
+            return HIPADJ_ERR_UNSUPPORTED;
+        }
+        if (piv != c) for (int j = 0; j < 2 * n; ++j) std::swap(a[c][j], a[piv][j]);
+        const double d = a[c][c]; for (int j = 0; j < 2 * n; ++j) a[c][j] /= d;
+        for (int r = 0; r < n; ++r) if (r != c && a[r][c] != 0.0) { const double f = a[r][c]; for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) m.minv[i * n + j] = a[i][n + j];
+    m.has_mm = true; m.rev++;
+    return HIPADJ_OK;
+}
+// M^{-1} of the model's mass matrix (row-major into out[n*n]); false when it has none
+inline bool user_mass_matrix_inverse(int32_t model, double* out) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size() || !R.models[idx].has_mm) return false;
+    std::memcpy(out, R.models[idx].minv, sizeof(double) * 64);
+    return true;
 }
 inline bool user_has_cost(int32_t model) {
     UserRegistry& R = user_registry();

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB_PATH = os.path.join(_ORACLE_DIR, "liboracle_adjoint.so")
 
-MODEL = dict(LV=0, LVT=1, LORENZ=2, LINDIAG=3, FALLMASS=4, MLP=5, BRUSS=6, ROBER=7, RING=8)
+MODEL = dict(LV=0, LVT=1, LORENZ=2, LINDIAG=3, FALLMASS=4, MLP=5, BRUSS=6, ROBER=7, RING=8, AFFINE3=9)
 ALG = dict(INTERPOLATING=0, BACKSOLVE=1, GAUSS=2, QUADRATURE=3, GAUSS_KRONROD=4)
 STEPPER = dict(RK4=0, TSIT5=1)
 LOSS = dict(COTANGENT=0, LSQ_SHIFT=1)
@@ -56,6 +56,7 @@ def lib():
                                            C.c_int, dp, dp]
         L.orc_model_f.argtypes = [C.c_int, C.POINTER(C.c_int), dp, dp, C.c_double, dp]
         L.orc_model_vjp.argtypes = [C.c_int, C.POINTER(C.c_int), dp, dp, dp, C.c_double, dp, dp]
+        L.orc_set_mass_matrix.argtypes = [C.c_int, dp]
         L.orc_test_quadgk_poly.restype = C.c_double
         L.orc_test_quadgk_poly.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                            C.POINTER(C.c_long)]
@@ -70,6 +71,23 @@ def _p(a):
 
 def _arr(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class mass_matrix:
+    """with oracle.mass_matrix(M): ...  — every oracle solve inside runs M u' = f (orc_set_mass_matrix; process-wide)."""
+
+    def __init__(self, M):
+        self.M = _arr(M)
+
+    def __enter__(self):
+        n = self.M.shape[0]
+        rc = lib().orc_set_mass_matrix(n, _p(self.M))
+        if rc:
+            raise ValueError("singular (or oversized) mass matrix")
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_mass_matrix(0, None)
 
 
 def model_sizes(model, dims=(0, 0, 0, 0)):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(sa):
     assert set(names) == set(_lib.DECLARED_SYMBOLS)
     for nm in names:
         assert hasattr(L, nm), nm
-    assert L.hipadj_version() == 102
+    assert L.hipadj_version() == 103
     assert L.hipadj_status_string(-2).decode().startswith("no usable HIP device")
 
 
@@ -185,6 +185,30 @@ def test_runtime_model_registration_compiles_for_gfx950_and_reports_errors():
         _lib.register_model("half_vjp", 2, 2, "du[0] = u[0]; du[1] = u[1];", "out[0] = lam[0]; out[1] = lam[1];", None)
 
 
+def test_runtime_model_mass_matrix_registration():
+    """ODEFunction(f; mass_matrix = M) (test/Core3/adjoint.jl:1315-1325): a constant non-singular M is folded into the generated model (hand VJPs
+    and dual-number VJPs both compile for gfx950); a singular one (semi-explicit DAE, src/adjoint_common.jl:117-135) is refused with the reason."""
+    import user_models as UM
+    import scimlsensitivity_jl_amd as sa
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.AFFINE3
+    f = sa.DeviceFunction("affine3_mm_cpu", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"], mass_matrix=UM.AFFINE3_MM, check=True)
+    assert np.array_equal(f.mass_matrix, np.array(UM.AFFINE3_MM))
+    sa.DeviceFunction("affine3_mm_auto_cpu", m["n"], m["np"], m["f"], mass_matrix=UM.AFFINE3_MM, check=True)
+    with pytest.raises(_lib.HipadjError, match="singular") as e:
+        f.set_mass_matrix(np.diag([1.0, 1.0, 0.0]))
+    assert e.value.status == -6
+    with pytest.raises(ValueError):
+        f.set_mass_matrix(np.eye(2))
+    with pytest.raises(_lib.HipadjError):
+        f.set_mass_matrix(np.full((3, 3), np.nan))
+    with pytest.raises(_lib.HipadjError):
+        _lib.set_model_mass_matrix(_lib.MODEL["lorenz"], 3, np.eye(3))      # compiled-in models carry none
+    f.set_mass_matrix(None)
+    assert f.mass_matrix is None
+    _lib.check_model(f.id)
+
+
 def test_runtime_model_plans_like_a_lane_model():
     """A registered model goes through the same planner: segmentation only while (1+n)(n+np) columns fit the registers."""
     import emu as E
@@ -255,7 +279,7 @@ def test_c_host_compiles_against_the_header_and_fails_loudly_without_a_device(sa
     sa.load_library()
     exe = _build_host_demo(sa, tmp_path)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
-    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 102" in r.stdout
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 103" in r.stdout
 
 
 class _StubEngine:

@@ -267,3 +267,34 @@ def test_every_algorithm_equals_the_explicit_adjoint_integral(explicit, case, mo
     du0, dp, _ = O.Problem(model, alg=alg, checkpointing=ckpt, **kw).adjoint(g["u0"], g["p"], delta)
     tol = 2e-9 if alg != "BACKSOLVE" else 1e-7        # Backsolve re-integrates y backward: the reference allows it 1e-5 ... 1e-7 on these problems
     assert rel(dp, g["dp"]) < tol and rel(du0, g["du0"]) < tol, (rel(dp, g["dp"]), rel(du0, g["du0"]))
+
+
+# ---- constant mass matrix (test/Core3/adjoint.jl:1315-1376) --------------------------------------------------------------
+@pytest.mark.parametrize("alg", ["INTERPOLATING", "BACKSOLVE", "GAUSS", "QUADRATURE", "GAUSS_KRONROD"])
+def test_mass_matrix_reference_problem_closed_form(alg):
+    """The reference's own assertion for its mass-matrix problem — adjoint ≈ ForwardDiff.gradient(G), rtol 1e-11 (:1336-1376) — with the
+    closed form of the linear problem (tests/golden/make_mass_matrix.py) in the place of ForwardDiff; Tsit5 at 1e-13 tolerances."""
+    import json, os
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mass_matrix.json")))
+    ts = np.array(G["ts"])
+    with O.mass_matrix(np.array(G["M"])):
+        P = O.Problem("AFFINE3", alg=alg, stepper="TSIT5", t0=0.0, t1=1.0, dt=0.0, abstol=1e-13, reltol=1e-13, save_times=ts, loss="COTANGENT",
+                      quad_abstol=1e-13, quad_reltol=1e-13, checkpointing=(alg == "BACKSOLVE"))
+        du0, dp, out = P.adjoint(G["u0"], G["p"], np.ones((len(ts), 3)))
+    assert np.max(np.abs(dp - G["dGdp"])) / np.max(np.abs(G["dGdp"])) < 1e-11
+    assert np.max(np.abs(du0 - G["lam0"])) / np.max(np.abs(G["lam0"])) < 1e-10          # du0 = lam(t0) (src/sensitivity_interface.jl:500)
+    assert np.max(np.abs(out[-1] - G["u_end"])) < 1e-11
+
+
+def test_mass_matrix_identity_is_a_no_op_and_singular_is_refused():
+    ts = np.array([0.5, 1.0]); u0 = [0.7, 0.5, 0.9]; p = [0.5, 0.9, 0.7]; d = np.ones((2, 3))
+    P = O.Problem("ROBER", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=1.0, dt=0.01, save_times=ts, loss="COTANGENT")
+    a = P.adjoint(u0, p, d)
+    with O.mass_matrix(np.eye(3)):
+        b = P.adjoint(u0, p, d)
+    c = P.adjoint(u0, p, d)                                      # cleared on exit
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    with pytest.raises(ValueError):
+        with O.mass_matrix(np.diag([1.0, 1.0, 0.0])):
+            pass

@@ -25,3 +25,14 @@ LV = dict(  # the built-in `lv` re-entered through the runtime path (test/Core3/
     f="du[0] = p[0]*u[0] - p[1]*u[0]*u[1]; du[1] = -p[2]*u[1] + p[3]*u[0]*u[1];",
     vjp="out[0] = (p[0] - p[1]*u[1])*lam[0] + p[3]*u[1]*lam[1]; out[1] = -p[1]*u[0]*lam[0] + (-p[2] + p[3]*u[0])*lam[1];",
     vjp_p="const double xy = u[0]*u[1]; out[0] = u[0]*lam[0]; out[1] = -xy*lam[0]; out[2] = -u[1]*lam[1]; out[3] = xy*lam[1];")
+
+
+AFFINE3 = dict(  # `foo` of the mass-matrix test, test/Core3/adjoint.jl:1315-1321: du = A u + p; du[2] += sum(p)   (oracle: ORC_MODEL_AFFINE3)
+    n=3, np=3,
+    f=("du[0] = 1.0*u[0] + 2.0*u[1] + 3.0*u[2] + p[0];"
+       "du[1] = 4.0*u[0] + 5.0*u[1] + 6.0*u[2] + p[1] + (p[0] + p[1] + p[2]);"
+       "du[2] = 7.0*u[0] + 8.0*u[1] + 9.0*u[2] + p[2];"),
+    vjp=("out[0] = 1.0*lam[0] + 4.0*lam[1] + 7.0*lam[2]; out[1] = 2.0*lam[0] + 5.0*lam[1] + 8.0*lam[2];"
+         "out[2] = 3.0*lam[0] + 6.0*lam[1] + 9.0*lam[2];"),
+    vjp_p="out[0] = lam[0] + lam[1]; out[1] = 2.0*lam[1]; out[2] = lam[2] + lam[1];")
+AFFINE3_MM = [[-1.0, -2.0, -4.0], [-2.0, -3.0, -7.0], [-1.0, -3.0, -41.0]]   # mm = -[1 2 4; 2 3 7; 1 3 41], test/Core3/adjoint.jl:1322
