@@ -33,6 +33,12 @@
 namespace hipadj {
 
 typedef double mlp_d4 __attribute__((ext_vector_type(4)));
+#ifndef HIPADJ_MLP_KUNROLL
+#define HIPADJ_MLP_KUNROLL 8    // K-steps unrolled per loop trip of the LDS-fed contractions: a full unroll (32) lets the scheduler hoist every ds_read, the sweep then
+                                // needs more than its 256 registers and spills (68-276 B of scratch per lane, 6.45 ms); 8 at a time: 237-245 registers, no scratch, 5.3 ms
+#endif
+#define HIPADJ_MLP_PRAGMA_(x) _Pragma(#x)
+#define HIPADJ_MLP_UNROLL_K HIPADJ_MLP_PRAGMA_(unroll HIPADJ_MLP_KUNROLL)
 
 struct MlpGeom {
     long N;            // trajectories (each with its own d x B state)
@@ -108,7 +114,7 @@ __device__ __forceinline__ void mlp_gemm_lds(const double* __restrict__ wfrag, c
     constexpr int TW = Mlp<H>::TW, NK = H / 4;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned act_off = (lane >> 4) * 16u + (lane & 15u);
-#pragma unroll
+    HIPADJ_MLP_UNROLL_K
     for (int st = 0; st < NK; ++st) {
         const double b = act[act_off + (unsigned)(64 * st)];
 #pragma unroll
@@ -116,11 +122,113 @@ __device__ __forceinline__ void mlp_gemm_lds(const double* __restrict__ wfrag, c
     }
 }
 
+// A operands held in REGISTERS for the whole sweep (HIPADJ_MLP_REGW): a wave only ever needs the A fragments of its own TW row tiles,
+// H/4 doubles per lane and tile (H = 128, eight waves: 32 doubles = 64 VGPRs for W2, as many for W2^T).  With two waves per SIMD each
+// wave owns 256 registers, so both fit next to the activations; the MFMAs then read A from the register file, B (the activation tile) from
+// LDS — half the LDS traffic of the fragment copy (which ran the LDS port at its limit, 128 B/clk, at full matrix rate) and no L2 traffic
+// at all in the forward passes of the adjoint kernel (where LDS had no room for a second 128 KB copy).
+#ifndef HIPADJ_MLP_REGW
+#define HIPADJ_MLP_REGW 0      // 0: W2 from L2 / W2^T from LDS (round 1); 1: W2 in registers; 2: both in registers (measured slower: the sweep already needs its 256 registers, the fragments spill)
+#endif
+#ifndef HIPADJ_MLP_FSAL
+#define HIPADJ_MLP_FSAL 1      // reuse the activations at x_lo as those at x_hi of the next step, and V5 as V1 when no loss jump intervenes
+#endif
+template <int H> struct MlpWReg { double a[Mlp<H>::TW][H / 4]; };
+template <int H>
+__device__ __forceinline__ void mlp_load_frag(const double* __restrict__ Wm, MlpWReg<H>& r) {
+    constexpr int TW = Mlp<H>::TW, NK = H / 4;
+    const unsigned li = threadIdx.x & 15u, lq = (threadIdx.x & 63u) >> 4;
+    const unsigned t0 = (threadIdx.x >> 6) * (unsigned)TW;
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int st = 0; st < NK; ++st) r.a[t][st] = Wm[(16u * (t0 + (unsigned)t) + li) + (4u * (unsigned)st + lq) * (unsigned)H];
+}
+template <int H>
+__device__ __forceinline__ void mlp_gemm_reg(const MlpWReg<H>& r, const double* __restrict__ act, mlp_d4 (&acc)[Mlp<H>::TW]) {
+    constexpr int TW = Mlp<H>::TW, NK = H / 4;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned act_off = (lane >> 4) * 16u + (lane & 15u);
+#pragma unroll
+    for (int st = 0; st < NK; ++st) {
+        const double b = act[act_off + (unsigned)(64 * st)];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a[t][st], b, acc[t], 0, 0, 0);
+    }
+}
+// ONE LDS copy of W2 for BOTH contractions of the adjoint kernel (HIPADJ_MLP_SWZ).  The forward pass needs A fragments of W2
+// (lane (i = l&15, q = l>>4), tile t, K-step s: element (16t + i, 4s + q)), the backward pass A fragments of W2^T (element (4s + q, 16t + i) of
+// W2): a 16 x 2 and a 2 x 16 footprint per half wave.  No row pitch serves both without bank conflicts, an XOR swizzle does: element (r, c) lives at
+//     r * H + (c ^ sw(r)),   sw(r) = 2 (r & 15) ^ 16 (r & 1)
+// forward: the 16 rows of a fragment land on 16 distinct even bank pairs, q picks the odd one; backward: the two rows of a half wave differ in
+// bit 4, the 16 columns fill the low four bits.  128 KB for H = 128: the forward passes of the sweep no longer fetch their A operands from L2
+// (19.7 TB/s chip-wide at the matrix peak - more than the L2 delivers), and no register is spent on weights.
+#ifndef HIPADJ_MLP_SWZ
+#define HIPADJ_MLP_SWZ 1
+#endif
+__device__ __forceinline__ unsigned mlp_swz(unsigned r) { return (2u * (r & 15u)) ^ (16u * (r & 1u)); }
+template <int H>
+__device__ __forceinline__ void mlp_fill_swz(const double* __restrict__ W2, double* __restrict__ w2s) {
+    for (int e = threadIdx.x; e < H * H; e += Mlp<H>::NT) {
+        const unsigned r = (unsigned)e % (unsigned)H, c = (unsigned)e / (unsigned)H;      // W2 is column-major: coalesced reads
+        w2s[r * (unsigned)H + (c ^ mlp_swz(r))] = W2[e];
+    }
+}
+// acc[t] += rows of W2 . act   (A fragment (16 (t0+t) + i, 4 st + q))
+template <int H>
+__device__ __forceinline__ void mlp_gemm_swz_n(const double* __restrict__ w2s, const double* __restrict__ act, int t0, mlp_d4 (&acc)[Mlp<H>::TW]) {
+    constexpr int TW = Mlp<H>::TW, NK = H / 4;
+    const unsigned lane = threadIdx.x & 63u, i = lane & 15u, q = lane >> 4;
+    const unsigned act_off = q * 16u + i;
+    const unsigned sw = mlp_swz(i), swh = sw & ~3u;
+    unsigned base[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) base[t] = (16u * (unsigned)(t0 + t) + i) * (unsigned)H + (q ^ (sw & 3u));
+    HIPADJ_MLP_UNROLL_K
+    for (int st = 0; st < NK; ++st) {
+        const double b = act[act_off + (unsigned)(64 * st)];
+        const unsigned cx = (unsigned)(4 * st) ^ swh;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w2s[base[t] + cx], b, acc[t], 0, 0, 0);
+    }
+}
+// acc[t] += rows of W2^T . act   (A fragment = element (4 st + q, 16 (t0+t) + i) of W2)
+template <int H>
+__device__ __forceinline__ void mlp_gemm_swz_t(const double* __restrict__ w2s, const double* __restrict__ act, int t0, mlp_d4 (&acc)[Mlp<H>::TW]) {
+    constexpr int TW = Mlp<H>::TW, NK = H / 4;
+    const unsigned lane = threadIdx.x & 63u, i = lane & 15u, q = lane >> 4;
+    const unsigned act_off = q * 16u + i;
+    unsigned col[TW][4];                                     // (16 t + i) ^ sw(4 st + q) for the four values of st & 3
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) col[t][m] = q * (unsigned)H + ((16u * (unsigned)(t0 + t) + i) ^ (2u * q) ^ (16u * (q & 1u)) ^ (8u * (unsigned)m));
+    HIPADJ_MLP_UNROLL_K
+    for (int st = 0; st < NK; ++st) {
+        const double b = act[act_off + (unsigned)(64 * st)];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w2s[(unsigned)(4 * st * H) + col[t][st & 3]], b, acc[t], 0, 0, 0);
+    }
+}
+// SRC: 0 = A operands from global memory / L2 (mem), 1 = from the LDS fragment copy (mem), 2 = from registers (reg),
+// 3 / 4 = from the swizzled LDS copy of W2, plain / transposed (mem)
+template <int H, int SRC>
+__device__ __forceinline__ void mlp_gemm_any(const double* __restrict__ mem, const MlpWReg<H>& reg, const double* __restrict__ act, int t0, mlp_d4 (&acc)[Mlp<H>::TW]) {
+    if constexpr (SRC == 2) mlp_gemm_reg<H>(reg, act, acc);
+    else if constexpr (SRC == 3) mlp_gemm_swz_n<H>(mem, act, t0, acc);
+    else if constexpr (SRC == 4) mlp_gemm_swz_t<H>(mem, act, t0, acc);
+    else if constexpr (SRC == 1) mlp_gemm_lds<H>(mem, act, t0, acc);
+    else mlp_gemm<H>(mem, act, t0, acc);
+}
+
 // tanh for the activations: (1 - t) / (1 + t) with t = exp(-2|x|) in (0, 1].  The cancellation in 1 - t for small |x| is
 // an ABSOLUTE error of one ulp of 1 (1e-16) in a quantity that only enters sums W h — harmless against the 1e-6 gate — and
 // the formula costs one exp and one division instead of the general-purpose library tanh (the forward passes of this
 // kernel are bound by these VALU instructions, not by the MFMAs).
 __device__ __forceinline__ double mlp_tanh(double x) {
+#ifdef HIPADJ_MLP_DBG_NOTANH      // scripts/mlpbench.hip: what the sweep costs without the transcendental work (wrong numbers, timing only)
+    return x * 0.5;
+#endif
     const double t = exp(-2.0 * fabs(x));
     const double r = (1.0 - t) / (1.0 + t);
     return x < 0.0 ? -r : r;
@@ -146,11 +254,28 @@ __device__ __forceinline__ void mlp_reduce2(MlpLds<H>& L, double o0, double o1, 
     out[0] = s0; out[1] = s1;
 }
 
+// activation records for the weight-gradient GEMMs; q indexes (traj, step, point); all arrays [q][rows][B]
+template <int H> struct MlpRec { double *AX, *AL, *AH1, *AH2, *AG1, *AG2; };
+// Where a pass writes its record rows AS SOON AS they exist (HIPADJ_MLP_EARLY_REC): h1 before the contraction, h2 after it, g2 before the
+// transposed contraction, g1 after it - four 16 KB bursts per workgroup spread over the pass instead of one 64 KB burst at its end.  All 256
+// workgroups run in lockstep, so the end-of-pass form hit HBM with 16.7 MB at once and every CU waited for its share of the write bandwidth
+// (about 8 us per record, a third of the GaussAdjoint step); the spread stores drain under the MFMAs of the same pass.
+template <int H> struct MlpSink { MlpRec<H> R; long q; long B; int col; double wq; };
+#ifndef HIPADJ_MLP_EARLY_REC
+#define HIPADJ_MLP_EARLY_REC 1
+#endif
+
 // forward pass for the workgroup's 16 columns: x[D] per lane (column l&15, replicated over lane groups and waves);
 // h1/h2 hold THIS WAVE's rows (tiles t0 .. t0+TW-1) in the MFMA accumulator layout
-template <int H>
-__device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, const double* __restrict__ w2frag, const double (&x)[2], double (&h1)[Mlp<H>::TW][4], double (&h2)[Mlp<H>::TW][4], double (&out)[2]) {
-    constexpr int TW = Mlp<H>::TW;
+template <int H, int SRC, bool REC = false>
+__device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, const double* __restrict__ w2mem, const MlpWReg<H>& w2reg, const double (&x)[2], double (&h1)[Mlp<H>::TW][4], double (&h2)[Mlp<H>::TW][4], double (&out)[2],
+                                            const MlpSink<H>* sk = nullptr) {
+    constexpr int TW = Mlp<H>::TW, HP = Mlp<H>::HP;
+    if (REC && (threadIdx.x >> 4) == 0) {                 // wave 0, lane group 0: the d-sized rows and the ones rows
+        double* ax = sk->R.AX + sk->q * 16 * sk->B;
+        ax[sk->col] = x[0]; ax[sk->B + sk->col] = x[1]; ax[2 * sk->B + sk->col] = 1.0;
+        sk->R.AH1[(sk->q * HP + H) * sk->B + sk->col] = 1.0; sk->R.AH2[(sk->q * HP + H) * sk->B + sk->col] = 1.0;
+    }
     const unsigned lq = (threadIdx.x & 63u) >> 4, li = threadIdx.x & 15u;
     const int t0 = (threadIdx.x >> 6) * TW;
     mlp_d4 acc[TW];
@@ -162,10 +287,11 @@ __device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, cons
             h1[t][r] = mlp_tanh(w.b1[row] + w.W1[row] * x[0] + w.W1[row + (unsigned)H] * x[1]);
             acc[t][r] = w.b2[row];
             L.act[row * 16u + li] = h1[t][r];
+            if (REC) sk->R.AH1[(sk->q * HP + (long)row) * sk->B + sk->col] = h1[t][r];
         }
     }
     __syncthreads();
-    if (w2frag) mlp_gemm_lds<H>(w2frag, L.act, t0, acc); else mlp_gemm<H>(w.W2, L.act, t0, acc);
+    mlp_gemm_any<H, SRC>(w2mem, w2reg, L.act, t0, acc);
     double o0 = 0.0, o1 = 0.0;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
@@ -173,6 +299,7 @@ __device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, cons
         for (int r = 0; r < 4; ++r) {
             const unsigned row = (unsigned)(16 * (t0 + t) + 4 * r) + lq;
             h2[t][r] = mlp_tanh(acc[t][r]);
+            if (REC) sk->R.AH2[(sk->q * HP + (long)row) * sk->B + sk->col] = h2[t][r];
             o0 += w.W3[row * 2u] * h2[t][r];
             o1 += w.W3[row * 2u + 1u] * h2[t][r];
         }
@@ -183,10 +310,14 @@ __device__ __forceinline__ void mlp_forward(const MlpW<H>& w, MlpLds<H>& L, cons
 
 // (df/du)^T lam for the workgroup's columns, given the activations of the forward pass; g1/g2 are this wave's rows of
 // the layer cotangents
-template <int H>
-__device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, const double* __restrict__ wfrag, const double (&lam)[2], const double (&h1)[Mlp<H>::TW][4], const double (&h2)[Mlp<H>::TW][4],
-                                             double (&g1)[Mlp<H>::TW][4], double (&g2)[Mlp<H>::TW][4], double (&dlam)[2]) {
+template <int H, int SRC, bool REC = false>
+__device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, const double* __restrict__ wfrag, const MlpWReg<H>& wtreg, const double (&lam)[2], const double (&h1)[Mlp<H>::TW][4], const double (&h2)[Mlp<H>::TW][4],
+                                             double (&g1)[Mlp<H>::TW][4], double (&g2)[Mlp<H>::TW][4], double (&dlam)[2], const MlpSink<H>* sk = nullptr) {
     constexpr int TW = Mlp<H>::TW;
+    if (REC && (threadIdx.x >> 4) == 0) {
+        double* al = sk->R.AL + sk->q * 16 * sk->B;
+        al[sk->col] = sk->wq * lam[0]; al[sk->B + sk->col] = sk->wq * lam[1];
+    }
     const unsigned lq = (threadIdx.x & 63u) >> 4, li = threadIdx.x & 15u;
     const int t0 = (threadIdx.x >> 6) * TW;
     mlp_d4 acc[TW];
@@ -198,10 +329,11 @@ __device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, con
             g2[t][r] = (w.W3[row * 2u] * lam[0] + w.W3[row * 2u + 1u] * lam[1]) * (1.0 - h2[t][r] * h2[t][r]);
             acc[t][r] = 0.0;
             L.act[row * 16u + li] = g2[t][r];
+            if (REC) sk->R.AG2[(sk->q * H + (long)row) * sk->B + sk->col] = sk->wq * g2[t][r];
         }
     }
     __syncthreads();
-    mlp_gemm_lds<H>(wfrag, L.act, t0, acc);
+    mlp_gemm_any<H, SRC>(wfrag, wtreg, L.act, t0, acc);
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
@@ -209,6 +341,7 @@ __device__ __forceinline__ void mlp_backward(const MlpW<H>& w, MlpLds<H>& L, con
         for (int r = 0; r < 4; ++r) {
             const unsigned row = (unsigned)(16 * (t0 + t) + 4 * r) + lq;
             g1[t][r] = acc[t][r] * (1.0 - h1[t][r] * h1[t][r]);
+            if (REC) sk->R.AG1[(sk->q * H + (long)row) * sk->B + sk->col] = sk->wq * g1[t][r];
             d0 += w.W1[row] * g1[t][r];
             d1 += w.W1[row + (unsigned)H] * g1[t][r];
         }
@@ -233,22 +366,34 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_forward(MlpGeom g, const dou
                                                             double* __restrict__ knots, double* __restrict__ out, const int* __restrict__ save_of_knot) {
     constexpr int TW = Mlp<H>::TW, D = 2;
     __shared__ MlpLds<H> L;
-    __shared__ MlpLdsW<H> LW;        // W2 in A-fragment order (the forward solve only needs W2)
     const long traj = blockIdx.y;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     const bool writer = (threadIdx.x >> 4) == 0;          // wave 0, lane group 0
     const MlpW<H> w = mlp_weights<H>(p, w2t, g.p_shared, traj);
     const long nB = (long)D * g.B;
+    MlpWReg<H> WR;
+#ifndef HIPADJ_MLP_FWD_REGW
+#define HIPADJ_MLP_FWD_REGW 1   // the forward solve keeps its W2 fragments in registers (226 VGPRs, no spill): 3 % faster than the LDS fragment copy, 128 KB of LDS free
+#endif
+#if HIPADJ_MLP_FWD_REGW >= 1
+    constexpr int FS = 2;
+    const double* wmem = nullptr;
+    mlp_load_frag<H>(w.W2, WR);                           // this wave's A fragments of W2, in registers for the whole solve
+#else
+    constexpr int FS = 1;
+    __shared__ MlpLdsW<H> LW;        // W2 in A-fragment order (the forward solve only needs W2)
     for (int e = threadIdx.x; e < H * H; e += Mlp<H>::NT) {
         const int l = e & 63, f = e >> 6, st = f % (H / 4), t = f / (H / 4);
         LW.wfrag[e] = w.W2[(16 * t + (l & 15)) + (4 * st + (l >> 4)) * H];
     }
     __syncthreads();
+    const double* wmem = LW.wfrag;
+#endif
     double x[D], k1[D], k2[D], k3[D], k4[D], xs[D], h1[TW][4], h2[TW][4];
     x[0] = u0[traj * nB + (long)col * D]; x[1] = u0[traj * nB + (long)col * D + 1];
     const double dt = g.dt;
     for (int k = 0; k <= g.S; ++k) {
-        mlp_forward<H>(w, L, LW.wfrag, x, h1, h2, k1);
+        mlp_forward<H, FS>(w, L, wmem, WR, x, h1, h2, k1);
         if (writer) {
             double* kn = knots + ((traj * (g.S + 1) + k) * 2) * nB;
             kn[col] = x[0]; kn[g.B + col] = x[1]; kn[nB + col] = k1[0]; kn[nB + g.B + col] = k1[1];
@@ -257,23 +402,24 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_forward(MlpGeom g, const dou
         }
         if (k == g.S) break;
         xs[0] = x[0] + 0.5 * dt * k1[0]; xs[1] = x[1] + 0.5 * dt * k1[1];
-        mlp_forward<H>(w, L, LW.wfrag, xs, h1, h2, k2);
+        mlp_forward<H, FS>(w, L, wmem, WR, xs, h1, h2, k2);
         xs[0] = x[0] + 0.5 * dt * k2[0]; xs[1] = x[1] + 0.5 * dt * k2[1];
-        mlp_forward<H>(w, L, LW.wfrag, xs, h1, h2, k3);
+        mlp_forward<H, FS>(w, L, wmem, WR, xs, h1, h2, k3);
         xs[0] = x[0] + dt * k3[0]; xs[1] = x[1] + dt * k3[1];
-        mlp_forward<H>(w, L, LW.wfrag, xs, h1, h2, k4);
+        mlp_forward<H, FS>(w, L, wmem, WR, xs, h1, h2, k4);
         x[0] = x[0] + (dt / 6.0) * (k1[0] + 2.0 * (k2[0] + k3[0]) + k4[0]);
         x[1] = x[1] + (dt / 6.0) * (k1[1] + 2.0 * (k2[1] + k3[1]) + k4[1]);
     }
 }
 
-// activation records for the weight-gradient GEMMs; q indexes (traj, step, point); all arrays [q][rows][B]
-template <int H> struct MlpRec { double *AX, *AL, *AH1, *AH2, *AG1, *AG2; };
 
 template <int H>
 __device__ __forceinline__ void mlp_record(const MlpRec<H>& R, const MlpGeom& g, long q, int col, double wq, const double (&x)[2], const double (&lam)[2],
                                            const double (&h1)[Mlp<H>::TW][4], const double (&h2)[Mlp<H>::TW][4], const double (&g1)[Mlp<H>::TW][4], const double (&g2)[Mlp<H>::TW][4]) {
     constexpr int TW = Mlp<H>::TW, HP = Mlp<H>::HP;
+#ifdef HIPADJ_MLP_DBG_NOREC       // scripts/mlpbench.hip: what the sweep costs without the record stores (timing only)
+    return;
+#endif
     const int lq = (threadIdx.x & 63) >> 4, t0 = (threadIdx.x >> 6) * TW;
     const long B = g.B;
     if ((threadIdx.x >> 4) == 0) {       // wave 0, lane group 0: the d-sized rows and the ones rows
@@ -303,18 +449,43 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const dou
                                                     double* __restrict__ du0, int* __restrict__ flag) {
     constexpr int TW = Mlp<H>::TW, D = 2;
     __shared__ MlpLds<H> L;
-    __shared__ MlpLdsW<H> LW;
     const long traj = blockIdx.y;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     const bool writer = (threadIdx.x >> 4) == 0;          // wave 0, lane group 0
     const MlpW<H> w = mlp_weights<H>(p, w2t, g.p_shared, traj);
     const long nB = (long)D * g.B;
     const double dt = g.dt;
+    MlpWReg<H> WF, WB;                                    // A fragments of W2 (forward passes) and W2^T (backward passes) when held in registers
+#if HIPADJ_MLP_SWZ
+    constexpr int FS = 3, BS = 4;
+    __shared__ MlpLdsW<H> LW;
+    mlp_fill_swz<H>(w.W2, LW.wfrag);                      // one swizzled copy of W2 serves both contractions
+    __syncthreads();
+    const double* fmem = LW.wfrag; const double* bmem = LW.wfrag;
+#else
+#if HIPADJ_MLP_REGW >= 1
+    constexpr int FS = 2;
+    const double* fmem = nullptr;
+    mlp_load_frag<H>(w.W2, WF);
+#else
+    constexpr int FS = 0;
+    const double* fmem = w.W2;
+#endif
+#if HIPADJ_MLP_REGW >= 2
+    constexpr int BS = 2;
+    const double* bmem = nullptr;
+    mlp_load_frag<H>(w.W2T, WB);
+#else
+    constexpr int BS = 1;
+    __shared__ MlpLdsW<H> LW;
     for (int e = threadIdx.x; e < H * H; e += Mlp<H>::NT) {   // W2^T -> A-fragment order, once per workgroup
         const int l = e & 63, f = e >> 6, st = f % (H / 4), t = f / (H / 4);
         LW.wfrag[e] = w.W2T[(16 * t + (l & 15)) + (4 * st + (l >> 4)) * H];
     }
     __syncthreads();
+    const double* bmem = LW.wfrag;
+#endif
+#endif
     auto knot = [&](int k, double (&xx)[2], double (&ff)[2]) {
         const double* kn = knots + ((traj * (g.S + 1) + k) * 2) * nB;
         xx[0] = kn[col]; xx[1] = kn[g.B + col]; ff[0] = kn[nB + col]; ff[1] = kn[nB + g.B + col];
@@ -328,6 +499,13 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const dou
     knot(g.S, xh, fh);
     { const int s = save_of_knot[g.S]; if (s >= 0) jump(s, xh, lam); }
     const double xg = 0.5773502691896257645;
+#if HIPADJ_MLP_FSAL
+    // first-same-as-last over the steps: the activations at x_lo of a step are those at x_hi of the next one (same inputs, same code:
+    // bit-identical), and GaussAdjoint's closing evaluation V5 = J(x_lo)^T lam is the next step's V1 unless a loss jump changed lam.
+    double h1e[TW][4], h2e[TW][4], Vn[D] = {0.0, 0.0};
+    bool have_v = false;                                   // uniform over the workgroup (save_of_knot is)
+    mlp_forward<H, FS>(w, L, fmem, WF, xh, h1e, h2e, out);
+#endif
     for (int k = g.S - 1; k >= 0; --k) {
         knot(k, xl, fl);
         const long qbase = (traj * g.S + k) * g.NQ;
@@ -335,27 +513,46 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const dou
         xm[0] = 0.5 * (xl[0] + xh[0]) + (0.125 * dt) * (fl[0] - fh[0]);
         xm[1] = 0.5 * (xl[1] + xh[1]) + (0.125 * dt) * (fl[1] - fh[1]);
         // stage 1 at x_hi
-        mlp_forward<H>(w, L, (const double*)nullptr, xh, h1, h2, out);
-        mlp_backward<H>(w, L, LW.wfrag, lam, h1, h2, g1, g2, V1);
+#if HIPADJ_MLP_FSAL
+        if (ALG == 2 && have_v) { V1[0] = Vn[0]; V1[1] = Vn[1]; }
+        else {
+            mlp_backward<H, BS>(w, L, bmem, WB, lam, h1e, h2e, g1, g2, V1);
+            if (ALG == 0) mlp_record<H>(R, g, qbase + 0, col, dt / 6.0, xh, lam, h1e, h2e, g1, g2);
+        }
+#else
+        mlp_forward<H, FS>(w, L, fmem, WF, xh, h1, h2, out);
+        mlp_backward<H, BS>(w, L, bmem, WB, lam, h1, h2, g1, g2, V1);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 0, col, dt / 6.0, xh, lam, h1, h2, g1, g2);
+#endif
         // stages 2, 3 at the Hermite midpoint (same activations)
         ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
-        mlp_forward<H>(w, L, (const double*)nullptr, xm, h1, h2, out);
-        mlp_backward<H>(w, L, LW.wfrag, ls, h1, h2, g1, g2, V2);
+        mlp_forward<H, FS>(w, L, fmem, WF, xm, h1, h2, out);
+        mlp_backward<H, BS>(w, L, bmem, WB, ls, h1, h2, g1, g2, V2);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 1, col, dt / 3.0, xm, ls, h1, h2, g1, g2);
         ls[0] = lam[0] + 0.5 * dt * V2[0]; ls[1] = lam[1] + 0.5 * dt * V2[1];
-        mlp_backward<H>(w, L, LW.wfrag, ls, h1, h2, g1, g2, V3);
+        mlp_backward<H, BS>(w, L, bmem, WB, ls, h1, h2, g1, g2, V3);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 2, col, dt / 3.0, xm, ls, h1, h2, g1, g2);
         // stage 4 at x_lo
         ls[0] = lam[0] + dt * V3[0]; ls[1] = lam[1] + dt * V3[1];
-        mlp_forward<H>(w, L, (const double*)nullptr, xl, h1, h2, out);
-        mlp_backward<H>(w, L, LW.wfrag, ls, h1, h2, g1, g2, V4);
+#if HIPADJ_MLP_FSAL
+        mlp_forward<H, FS>(w, L, fmem, WF, xl, h1e, h2e, out);
+        mlp_backward<H, BS>(w, L, bmem, WB, ls, h1e, h2e, g1, g2, V4);
+        if (ALG == 0) mlp_record<H>(R, g, qbase + 3, col, dt / 6.0, xl, ls, h1e, h2e, g1, g2);
+#else
+        mlp_forward<H, FS>(w, L, fmem, WF, xl, h1, h2, out);
+        mlp_backward<H, BS>(w, L, bmem, WB, ls, h1, h2, g1, g2, V4);
         if (ALG == 0) mlp_record<H>(R, g, qbase + 3, col, dt / 6.0, xl, ls, h1, h2, g1, g2);
+#endif
         lam[0] = lam[0] + (dt / 6.0) * (V1[0] + 2.0 * (V2[0] + V3[0]) + V4[0]);
         lam[1] = lam[1] + (dt / 6.0) * (V1[1] + 2.0 * (V2[1] + V3[1]) + V4[1]);
         if (ALG == 2) {
             double V5[D];
-            mlp_backward<H>(w, L, LW.wfrag, lam, h1, h2, g1, g2, V5);                   // fsallast at x_lo (activations of stage 4)
+#if HIPADJ_MLP_FSAL
+            mlp_backward<H, BS>(w, L, bmem, WB, lam, h1e, h2e, g1, g2, V5);             // fsallast at x_lo (activations of stage 4)
+            Vn[0] = V5[0]; Vn[1] = V5[1];
+#else
+            mlp_backward<H, BS>(w, L, bmem, WB, lam, h1, h2, g1, g2, V5);               // fsallast at x_lo (activations of stage 4)
+#endif
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
@@ -366,12 +563,25 @@ __global__ void __launch_bounds__(Mlp<H>::NT) k_mlp_adjoint(MlpGeom g, const dou
                     yg[j] = (1.0 - tf) * xl[j] + tf * xh[j] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (xh[j] - xl[j]) + (tf - 1.0) * dt * fl[j] + tf * dt * fh[j]);
                 }
                 double dl[D];
-                mlp_forward<H>(w, L, (const double*)nullptr, yg, h1, h2, out);
-                mlp_backward<H>(w, L, LW.wfrag, lg, h1, h2, g1, g2, dl);
+#if HIPADJ_MLP_EARLY_REC
+                const MlpSink<H> sk{R, qbase + nq, (long)g.B, col, 0.5 * dt};
+                mlp_forward<H, FS, true>(w, L, fmem, WF, yg, h1, h2, out, &sk);
+                mlp_backward<H, BS, true>(w, L, bmem, WB, lg, h1, h2, g1, g2, dl, &sk);
+#else
+                mlp_forward<H, FS>(w, L, fmem, WF, yg, h1, h2, out);
+                mlp_backward<H, BS>(w, L, bmem, WB, lg, h1, h2, g1, g2, dl);
                 mlp_record<H>(R, g, qbase + nq, col, 0.5 * dt, yg, lg, h1, h2, g1, g2);
+#endif
             }
         }
-        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) jump(s, xl, lam); }
+        {
+            const int s = save_of_knot[k];
+            const bool jumped = s >= 0 && !(g.no_start && s == 0);
+            if (jumped) jump(s, xl, lam);
+#if HIPADJ_MLP_FSAL
+            have_v = !jumped;
+#endif
+        }
         xh[0] = xl[0]; xh[1] = xl[1]; fh[0] = fl[0]; fh[1] = fl[1];
     }
     if (writer) {
