@@ -167,6 +167,11 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         h->ksplit = (int)(nslabs < 512 ? nslabs : 512);
         A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
         A(dev_alloc(h, &h->d_w2t, (size_t)groups * Hh * Hh));
+        if (const char* e = std::getenv("HIPADJ_MLP_RECORDS")) h->mlp_records = e[0] == '1';
+        if (!h->mlp_records) {
+            // in-register parameter gradient (hipadj_mlp_grad.hpp): one partial gradient per workgroup of 16 columns, no activation records
+            A(dev_alloc(h, &h->d_c1, (size_t)h->N * (Bb / 16) * (size_t)np));
+        } else {
         A(dev_alloc(h, &h->d_ax, Q * 16 * Bb)); A(dev_alloc(h, &h->d_al, Q * 16 * Bb));
         A(dev_alloc(h, &h->d_ah1, Q * HP * Bb)); A(dev_alloc(h, &h->d_ah2, Q * HP * Bb));
         A(dev_alloc(h, &h->d_ag1, Q * Hh * Bb)); A(dev_alloc(h, &h->d_ag2, Q * Hh * Bb));
@@ -176,6 +181,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         if (rc == HIPADJ_OK) {   // padding rows (zeros) and the ones rows are written once / by the sweep; zero everything first
             if (hipMemset(h->d_ax, 0, Q * 16 * Bb * 8) != hipSuccess || hipMemset(h->d_al, 0, Q * 16 * Bb * 8) != hipSuccess ||
                 hipMemset(h->d_ah1, 0, Q * HP * Bb * 8) != hipSuccess || hipMemset(h->d_ah2, 0, Q * HP * Bb * 8) != hipSuccess) { h->err = "hipMemset failed"; rc = HIPADJ_ERR_HIP; }
+        }
         }
     } else {
         A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));

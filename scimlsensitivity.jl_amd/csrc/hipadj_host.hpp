@@ -17,6 +17,7 @@
 #include "hipadj_kernels.hpp"
 #include "hipadj_field.hpp"
 #include "hipadj_mlp.hpp"
+#include "hipadj_mlp_grad.hpp"
 #include "hipadj_adaptive.hpp"
 
 using namespace hipadj;
@@ -47,6 +48,7 @@ struct hipadj_handle {
     bool ip_ckpt = false;                 // Interpolating/Gauss checkpointing=true
     double *d_fknots = nullptr, *d_fadj = nullptr;
     bool mlp = false; int NQ = 0, ksplit = 1;
+    bool mlp_records = false;             // HIPADJ_MLP_RECORDS=1: round-1 path (activation records + weight-gradient GEMM kernels) instead of the in-register gradient
     double *d_w2t = nullptr, *d_ax = nullptr, *d_al = nullptr, *d_ah1 = nullptr, *d_ah2 = nullptr, *d_ag1 = nullptr, *d_ag2 = nullptr;
     double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
     MlpGeom mg{};

@@ -305,6 +305,23 @@ template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, d
     harvest_set(h, es, true);
     HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    if (!h->mlp_records) {
+        // in-register parameter gradient: the sweep leaves one partial gradient per workgroup, a fixed-order sum finishes dp
+        const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), gblk(MlpG<H>::NT);
+        if (h->cfg.alg == HIPADJ_ALG_GAUSS)
+            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_c1, d_du0, h->d_flag);
+        else
+            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_c1, d_du0, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        const long groups = h->cfg.p_shared ? 1 : h->N;
+        const long per_group = (h->N * (long)(h->mg.B / 16)) / groups;
+        hipLaunchKernelGGL(k_mlp_grad_reduce, dim3((Mlp<H>::NPAR + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, (int)Mlp<H>::NPAR, per_group, (const double*)h->d_c1, d_dp);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+        es.pending = true;
+        return HIPADJ_OK;
+    }
     MlpRec<H> R{h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2};
     const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), blk(64), sweep_blk(Mlp<H>::NT);
     if (h->cfg.alg == HIPADJ_ALG_GAUSS)

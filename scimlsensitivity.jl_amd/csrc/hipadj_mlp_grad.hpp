@@ -1,0 +1,391 @@
+// hipadj_mlp_grad.hpp — reverse sweep of the FP64-MFMA family with the PARAMETER GRADIENT ACCUMULATED IN REGISTERS (round 2).
+//
+// The round-1 sweep (k_mlp_adjoint, hipadj_mlp.hpp) writes weighted activation records (5.6 GB for BASELINE configs[3]) and three split-K
+// GEMM kernels contract them afterwards: 10 GB of HBM traffic and a third of the reverse pass for a result of 17 282 numbers.  Here the
+// contraction happens where the operands are born:
+//
+//   * the batch columns sit on the M side of every contraction:  Out^T (16 x H) = Act^T (16 x H) . W (H x H), i.e. the activations are the
+//     A operand (from the LDS exchange tile) and the weights the B operand (from the swizzled LDS copy of W2, same two access patterns as
+//     mlp_gemm_swz_n / _t).  The accumulator then holds  D[column c = (l>>4) + 4 reg][hidden n = l & 15]:  for a FIXED register index the
+//     four lane groups hold columns c = kq + 4 ks — exactly the A / B operand layout of a K-step whose contraction index is the COLUMN.
+//     So the outer products of the weight gradient,
+//         dW2[i][j] += sum_c (w G2)[i][c] H1[j][c],
+//     take their A operand (this wave's rows of G2) straight from the registers the backward pass just produced and their B operand (all
+//     rows of H1) from the exchange tile the forward pass left in LDS: 64 MFMAs per quadrature point and wave, no transpose, no record.
+//   * a wave owns TW = 2 row tiles (four waves per workgroup, one per SIMD, 512 registers each): 2 x 8 accumulator tiles of dW2 = 128
+//     registers; the d-sized pieces (dW1, db1, db2, dW3, db3) are per-lane FMA accumulators reduced across lanes once at the end.
+//   * every workgroup (16 columns) writes ONE partial gradient (NPAR doubles) at the end of the sweep; k_mlp_grad_reduce sums the
+//     partials in a fixed order (bit-reproducible).  No activation record, no weight-gradient GEMM kernel, 35 MB of partials instead of
+//     5.6 GB of records.
+//
+// LDS: the swizzled copy of W2 (H*H doubles), ONE exchange tile tile[h][c] at h*16 + (c ^ (h & 14)) (the XOR keeps the column-major writes
+// of a D fragment, the A-operand reads of the contractions and the B-operand reads of the outer product free of bank conflicts at pitch
+// 16) and the cross-wave reduction scratch.  The tile holds H1 from the forward pass until the outer product of the same point has
+// read it, then G2 for the transposed contraction.
+// Same numerics as k_mlp_adjoint (same stages, same first-same-as-last reuse); the sums of the gradient are associated differently
+// (per workgroup, then over workgroups) — agreement with the record path and with the oracle is at round-off (tests/test_gpu_parity.py).
+#pragma once
+
+#include "hipadj_mlp.hpp"
+
+namespace hipadj {
+
+template <int H> struct MlpG {
+    static constexpr int D = 2, TT = H / 16;
+#ifndef HIPADJ_MLPG_MAXW
+#define HIPADJ_MLPG_MAXW 4
+#endif
+    static constexpr int NW = TT >= HIPADJ_MLPG_MAXW ? HIPADJ_MLPG_MAXW : TT;      // 4: one wave per SIMD
+    static constexpr int TW = TT / NW;                // row tiles per wave
+    static constexpr int NT = 64 * NW, NK = H / 4;
+    static constexpr int NPAR = Mlp<H>::NPAR;
+    static_assert(TT % NW == 0 && (H / 4) % 8 == 0, "hidden width must be a multiple of 32 (and of 64 beyond 48)");
+};
+template <int H> struct MlpGLds { double w2s[H * H]; double tile[H * 16]; double red[MlpG<H>::NW][16][2]; };
+
+template <int H>
+__device__ __forceinline__ void mlpg_fill_swz(const double* __restrict__ W2, double* __restrict__ w2s) {
+    for (int e = threadIdx.x; e < H * H; e += MlpG<H>::NT) {
+        const unsigned r = (unsigned)e % (unsigned)H, c = (unsigned)e / (unsigned)H;
+        w2s[r * (unsigned)H + (c ^ mlp_swz(r))] = W2[e];
+    }
+}
+
+// per-lane state of a pass in the transposed layout: hidden row 16 (t0 + t) + (l & 15), columns c_r = (l >> 4) + 4 r
+template <int H> struct MlpGCtx {
+    unsigned i, lq, t0;                 // l & 15, l >> 4, first row tile of the wave
+    unsigned a_off[4];                  // A-operand offsets into the tile for ks & 3 = 0..3 (without the 64 ks part)
+};
+template <int H> __device__ __forceinline__ MlpGCtx<H> mlpg_ctx() {
+    MlpGCtx<H> c; const unsigned lane = threadIdx.x & 63u;
+    c.i = lane & 15u; c.lq = lane >> 4; c.t0 = (threadIdx.x >> 6) * (unsigned)MlpG<H>::TW;
+    const unsigned iq = c.i ^ (c.lq & 2u);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) c.a_off[m] = 16u * c.lq + (iq ^ (unsigned)(4 * m));      // tile[(4ks + lq)][i]: (4ks + lq)*16 + (i ^ ((4ks + lq) & 14))
+    return c;
+}
+// tile[h][c] <- v for this lane's rows and columns
+template <int H>
+__device__ __forceinline__ void mlpg_put(double* __restrict__ tile, const MlpGCtx<H>& cx, const double (&v)[MlpG<H>::TW][4]) {
+#pragma unroll
+    for (int t = 0; t < MlpG<H>::TW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(16u * (cx.t0 + (unsigned)t) + cx.i) * 16u + ((cx.lq + 4u * (unsigned)r) ^ (cx.i & 14u))] = v[t][r];
+}
+// acc[t] += Act^T . W   with Act in the tile; TR = false: W[h][n] = W2[n][h] (forward), TR = true: W[h][n] = W2[h][n] (backward)
+template <int H, bool TR>
+__device__ __forceinline__ void mlpg_gemm(const double* __restrict__ w2s, const double* __restrict__ tile, const MlpGCtx<H>& cx, mlp_d4 (&acc)[MlpG<H>::TW]) {
+    constexpr int TW = MlpG<H>::TW, NK = MlpG<H>::NK;
+    unsigned bcol[TW][4], brow[TW];
+    if (TR) {
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bcol[t][m] = cx.lq * (unsigned)H + ((16u * (cx.t0 + (unsigned)t) + cx.i) ^ (2u * cx.lq) ^ (16u * (cx.lq & 1u)) ^ (8u * (unsigned)m));
+    } else {
+        const unsigned sw = mlp_swz(cx.i);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) { brow[t] = (16u * (cx.t0 + (unsigned)t) + cx.i) * (unsigned)H + (cx.lq ^ (sw & 3u)); bcol[t][0] = sw & ~3u; }
+    }
+    // Four K-steps per trip (the (ks & 3)-dependent offsets are compile-time choices), operands of the NEXT trip fetched before the MFMAs of
+    // this one: with one wave per SIMD nothing else hides the LDS latency.
+    auto fetch = [&](int kb, double (&a)[4], double (&b)[TW][4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const unsigned ks = (unsigned)(kb + m);
+            a[m] = tile[64u * ks + cx.a_off[m]];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) b[t][m] = TR ? w2s[4u * ks * (unsigned)H + bcol[t][m]] : w2s[brow[t] + ((4u * ks) ^ bcol[t][0])];
+        }
+    };
+    double a0[4], b0[TW][4], a1[4], b1[TW][4];
+    fetch(0, a0, b0);
+#ifndef HIPADJ_MLPG_KTRIPS
+#define HIPADJ_MLPG_KTRIPS 4     // trips unrolled (H = 128: all four).  A rolled loop makes hipcc carry the accumulators in architectural VGPRs and copy all sixteen to
+                                 // AGPRs and back around every trip, with the wait states for the matrix pipe to drain: 6.6 ms instead of 5.8 ms for BASELINE configs[3]
+#endif
+#pragma unroll HIPADJ_MLPG_KTRIPS
+    for (int kb = 0; kb < NK; kb += 8) {
+        fetch(kb + 4, a1, b1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[m], b0[t][m], acc[t], 0, 0, 0);
+        if (kb + 8 < NK) fetch(kb + 8, a0, b0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[m], b1[t][m], acc[t], 0, 0, 0);
+#if HIPADJ_MLPG_KTRIPS > 1
+        __builtin_amdgcn_sched_barrier(0);                 // unrolled trips: keep the scheduler from hoisting every trip's fetches to the top (spills)
+#endif
+    }
+}
+// the value of a column-layout quantity (one column per lane l & 15, replicated) at this lane's four columns
+__device__ __forceinline__ void mlpg_cols(double v, unsigned lq, double (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = __shfl(v, (int)(lq + 4u * (unsigned)r), 64);
+}
+// v + (v of the lane n places to the left in its row of 16, zero beyond the row): two 32-bit DPP moves and one FP64 add — VALU only; the
+// LDS crossbar (ds_bpermute, what __shfl_xor compiles to) cost 64 instructions and four dependent LDS round trips per reduction.
+template <int CTRL>
+__device__ __forceinline__ double mlpg_add_shr(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi2, lo2);
+}
+// sum over the hidden rows of per-lane partials p[d][r] (column c_r): over the 16 lanes of a lane group (row_shr 1, 2, 4, 8: lane 15 of the
+// row ends with the total), then over the waves through LDS; every lane gets the totals of ITS OWN column l & 15
+template <int H>
+__device__ __forceinline__ void mlpg_reduce(MlpGLds<H>& L, const MlpGCtx<H>& cx, double (&p)[2][4], double (&out)[2]) {
+    constexpr int NW = MlpG<H>::NW;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = p[d][r];
+            v = mlpg_add_shr<0x111>(v); v = mlpg_add_shr<0x112>(v); v = mlpg_add_shr<0x114>(v); v = mlpg_add_shr<0x118>(v);
+            p[d][r] = v;
+        }
+    const int wv = threadIdx.x >> 6;
+    if (cx.i == 15) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { L.red[wv][cx.lq + 4u * (unsigned)r][0] = p[0][r]; L.red[wv][cx.lq + 4u * (unsigned)r][1] = p[1][r]; }
+    }
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { s0 += L.red[w][cx.i][0]; s1 += L.red[w][cx.i][1]; }
+    out[0] = s0; out[1] = s1;
+}
+
+// gradient accumulators of one wave
+template <int H> struct MlpGAcc {
+    mlp_d4 w2[MlpG<H>::TW][MlpG<H>::TT];          // dW2 rows of the wave's tiles x all column tiles (D layout: row = (l>>4) + 4 reg, col = l & 15)
+    double w1[MlpG<H>::TW][2], b1[MlpG<H>::TW], b2[MlpG<H>::TW], w3[MlpG<H>::TW][2];   // per-lane partial sums over this lane's four columns
+    double b3[2];                                   // column layout: this lane's column
+};
+
+// forward pass up to the second hidden layer — the sweep never needs f itself (the knots carry it), so the output layer and its cross-lane
+// reduction are skipped; leaves H1 in the tile.  x: column layout.  NO barrier after the contraction: the next writer of the tile syncs first.
+template <int H>
+__device__ __forceinline__ void mlpg_forward(const MlpW<H>& w, MlpGLds<H>& L, const MlpGCtx<H>& cx, const double (&x)[2], double (&h1)[MlpG<H>::TW][4], double (&h2)[MlpG<H>::TW][4]) {
+    constexpr int TW = MlpG<H>::TW;
+    double x0[4], x1[4];
+    mlpg_cols(x[0], cx.lq, x0); mlpg_cols(x[1], cx.lq, x1);
+    mlp_d4 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const unsigned row = 16u * (cx.t0 + (unsigned)t) + cx.i;
+        const double wa = w.W1[row], wb = w.W1[row + (unsigned)H], bb = w.b1[row], b2 = w.b2[row];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h1[t][r] = mlp_tanh(bb + wa * x0[r] + wb * x1[r]); acc[t][r] = b2; }
+    }
+    mlpg_put<H>(L.tile, cx, h1);
+    __syncthreads();
+    mlpg_gemm<H, false>(L.w2s, L.tile, cx, acc);
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[t][r] = mlp_tanh(acc[t][r]);
+}
+
+// (df/du)^T lam for the workgroup's columns; REC: also accumulate wq * (df/dp)^T lam.  tile_h1: the tile still holds H1 of these activations.
+// x is only read when REC.  A holds the accumulators.  after_fwd: the previous pass was a forward pass (which ends without a barrier): sync
+// before the tile is overwritten.  Both flags are compile-time literals at the call sites (uniform).
+template <int H, bool REC>
+__device__ __forceinline__ void mlpg_backward(const MlpW<H>& w, MlpGLds<H>& L, const MlpGCtx<H>& cx, const double (&lam)[2], const double (&x)[2], const double (&h1)[MlpG<H>::TW][4],
+                                              const double (&h2)[MlpG<H>::TW][4], double (&dlam)[2], double wq, bool tile_h1, bool after_fwd, MlpGAcc<H>& A) {
+    constexpr int TW = MlpG<H>::TW, TT = MlpG<H>::TT;
+    double l0[4], l1[4], g2[TW][4];
+    mlpg_cols(lam[0], cx.lq, l0); mlpg_cols(lam[1], cx.lq, l1);
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const unsigned row = 16u * (cx.t0 + (unsigned)t) + cx.i;
+        const double wa = w.W3[row * 2u], wb = w.W3[row * 2u + 1u];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g2[t][r] = (wa * l0[r] + wb * l1[r]) * (1.0 - h2[t][r] * h2[t][r]);
+    }
+    if (REC) {
+        if (!tile_h1) { if (after_fwd) __syncthreads(); mlpg_put<H>(L.tile, cx, h1); __syncthreads(); }      // uniform
+        // dW2[rows of tile t][cols of tile tj] += sum_c (wq G2)[i][c] H1[j][c]:  A = this wave's G2 (registers), B = H1 rows of tile tj (LDS)
+        double ga[TW][4];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            double s2 = 0.0, s30 = 0.0, s31 = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ga[t][r] = wq * g2[t][r]; s2 += ga[t][r]; s30 += l0[r] * h2[t][r]; s31 += l1[r] * h2[t][r]; }
+            A.b2[t] += s2; A.w3[t][0] += wq * s30; A.w3[t][1] += wq * s31;
+        }
+#ifndef HIPADJ_MLPG_DBG_NOOUTER      // scripts/mlpbench.hip: timing without the outer products (wrong dW2)
+#pragma unroll
+        for (int tj = 0; tj < TT; ++tj) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double b = L.tile[(16u * (unsigned)tj + cx.i) * 16u + ((cx.lq + 4u * (unsigned)ks) ^ (cx.i & 14u))];
+#pragma unroll
+                for (int t = 0; t < TW; ++t) A.w2[t][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[t][ks], b, A.w2[t][tj], 0, 0, 0);
+            }
+        }
+#endif
+        if (cx.lq == 0 && (threadIdx.x >> 6) == 0) { A.b3[0] += wq * lam[0]; A.b3[1] += wq * lam[1]; }   // lanes 0..15 of wave 0: one per column
+        __syncthreads();                                   // every wave has read H1 (contraction and outer product) before G2 replaces it
+    } else if (after_fwd) __syncthreads();
+    mlpg_put<H>(L.tile, cx, g2);
+    __syncthreads();
+    mlp_d4 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
+    mlpg_gemm<H, true>(L.w2s, L.tile, cx, acc);
+    double p[2][4], x0[4], x1[4];
+    if (REC) { mlpg_cols(x[0], cx.lq, x0); mlpg_cols(x[1], cx.lq, x1); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[0][r] = 0.0; p[1][r] = 0.0; }
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const unsigned row = 16u * (cx.t0 + (unsigned)t) + cx.i;
+        const double wa = w.W1[row], wb = w.W1[row + (unsigned)H];
+        double s1 = 0.0, s10 = 0.0, s11 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double g1 = acc[t][r] * (1.0 - h1[t][r] * h1[t][r]);
+            p[0][r] += wa * g1; p[1][r] += wb * g1;
+            if (REC) { s1 += g1; s10 += g1 * x0[r]; s11 += g1 * x1[r]; }
+        }
+        if (REC) { A.b1[t] += wq * s1; A.w1[t][0] += wq * s10; A.w1[t][1] += wq * s11; }
+    }
+    mlpg_reduce<H>(L, cx, p, dlam);
+}
+
+// reverse sweep with in-register parameter gradient.  part: [traj][gridDim.x][NPAR] partial gradients (one per workgroup).
+template <int H, int ALG>
+__global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
+                                                                  const int* __restrict__ save_of_knot, double* __restrict__ part, double* __restrict__ du0, int* __restrict__ flag) {
+    constexpr int TW = MlpG<H>::TW, TT = MlpG<H>::TT, D = 2, NPAR = MlpG<H>::NPAR;
+    __shared__ MlpGLds<H> L;
+    const long traj = blockIdx.y;
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool writer = (threadIdx.x >> 4) == 0;          // wave 0, lane group 0
+    const MlpW<H> w = mlp_weights<H>(p, nullptr, g.p_shared, traj);
+    const MlpGCtx<H> cx = mlpg_ctx<H>();
+    const long nB = (long)D * g.B;
+    const double dt = g.dt;
+    mlpg_fill_swz<H>(w.W2, L.w2s);
+    __syncthreads();
+    MlpGAcc<H> A;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+#pragma unroll
+        for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.w2[t][tj][r] = 0.0;
+        A.w1[t][0] = A.w1[t][1] = A.b1[t] = A.b2[t] = A.w3[t][0] = A.w3[t][1] = 0.0;
+    }
+    A.b3[0] = A.b3[1] = 0.0;
+    auto knot = [&](int k, double (&xx)[2], double (&ff)[2]) {
+        const double* kn = knots + ((traj * (g.S + 1) + k) * 2) * nB;
+        xx[0] = kn[col]; xx[1] = kn[g.B + col]; ff[0] = kn[nB + col]; ff[1] = kn[nB + g.B + col];
+    };
+    auto jump = [&](int s, const double (&xx)[2], double (&lam)[2]) {
+        if (g.loss_kind == 0) { const double* c = cot + (traj * g.M + s) * nB; lam[0] += c[(long)col * D]; lam[1] += c[(long)col * D + 1]; }
+        else { lam[0] += xx[0] - g.loss_shift; lam[1] += xx[1] - g.loss_shift; }
+    };
+    double lam[D] = {0.0, 0.0}, xh[D], fh[D], xl[D], fl[D];
+    double h1[TW][4], h2[TW][4], h1e[TW][4], h2e[TW][4], Vn[D] = {0.0, 0.0};
+    bool have_v = false;                                   // uniform over the workgroup
+    knot(g.S, xh, fh);
+    { const int s = save_of_knot[g.S]; if (s >= 0) jump(s, xh, lam); }
+    const double xg = 0.5773502691896257645;
+    mlpg_forward<H>(w, L, cx, xh, h1e, h2e);                // first-same-as-last: activations at x_hi of the first step
+    for (int k = g.S - 1; k >= 0; --k) {
+        knot(k, xl, fl);
+        double xm[D], ls[D], V1[D], V2[D], V3[D], V4[D], lam_hi[D] = {lam[0], lam[1]};
+        xm[0] = 0.5 * (xl[0] + xh[0]) + (0.125 * dt) * (fl[0] - fh[0]);
+        xm[1] = 0.5 * (xl[1] + xh[1]) + (0.125 * dt) * (fl[1] - fh[1]);
+        // stage 1 at x_hi (activations carried over from the previous step's x_lo)
+        if (ALG == 2 && have_v) { V1[0] = Vn[0]; V1[1] = Vn[1]; }
+        else mlpg_backward<H, ALG == 0>(w, L, cx, lam, xh, h1e, h2e, V1, dt / 6.0, false, true, A);   // after_fwd: the prologue's (or a node's backward-free) forward pass may precede
+        // stages 2, 3 at the Hermite midpoint (same activations)
+        ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
+        mlpg_forward<H>(w, L, cx, xm, h1, h2);
+        mlpg_backward<H, ALG == 0>(w, L, cx, ls, xm, h1, h2, V2, dt / 3.0, true, true, A);
+        ls[0] = lam[0] + 0.5 * dt * V2[0]; ls[1] = lam[1] + 0.5 * dt * V2[1];
+        mlpg_backward<H, ALG == 0>(w, L, cx, ls, xm, h1, h2, V3, dt / 3.0, false, false, A);
+        // stage 4 at x_lo
+        ls[0] = lam[0] + dt * V3[0]; ls[1] = lam[1] + dt * V3[1];
+        mlpg_forward<H>(w, L, cx, xl, h1e, h2e);
+        mlpg_backward<H, ALG == 0>(w, L, cx, ls, xl, h1e, h2e, V4, dt / 6.0, true, true, A);
+        lam[0] = lam[0] + (dt / 6.0) * (V1[0] + 2.0 * (V2[0] + V3[0]) + V4[0]);
+        lam[1] = lam[1] + (dt / 6.0) * (V1[1] + 2.0 * (V2[1] + V3[1]) + V4[1]);
+        if (ALG == 2) {
+            double V5[D];
+            mlpg_backward<H, false>(w, L, cx, lam, xl, h1e, h2e, V5, 0.0, false, false, A);      // fsallast at x_lo (activations of stage 4)
+            Vn[0] = V5[0]; Vn[1] = V5[1];
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq) {
+                const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
+                double lg[D], yg[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    lg[j] = (1.0 - th) * lam_hi[j] + th * lam[j] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lam[j] - lam_hi[j]) + (th - 1.0) * (-dt) * (-V1[j]) + th * (-dt) * (-V5[j]));
+                    yg[j] = (1.0 - tf) * xl[j] + tf * xh[j] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (xh[j] - xl[j]) + (tf - 1.0) * dt * fl[j] + tf * dt * fh[j]);
+                }
+                double dl[D];
+                mlpg_forward<H>(w, L, cx, yg, h1, h2);
+                mlpg_backward<H, true>(w, L, cx, lg, yg, h1, h2, dl, 0.5 * dt, true, true, A);
+            }
+        }
+        {
+            const int s = save_of_knot[k];
+            const bool jumped = s >= 0 && !(g.no_start && s == 0);
+            if (jumped) jump(s, xl, lam);
+            have_v = !jumped;
+        }
+        xh[0] = xl[0]; xh[1] = xl[1]; fh[0] = fl[0]; fh[1] = fl[1];
+    }
+    if (writer) {
+        du0[traj * nB + (long)col * D] = lam[0]; du0[traj * nB + (long)col * D + 1] = lam[1];
+        if (!(fabs(lam[0]) <= 1.79769313486231570e308) || !(fabs(lam[1]) <= 1.79769313486231570e308)) atomicOr(flag, 1);
+    }
+    // ---- this workgroup's partial gradient, in the parameter layout [W1 (H x d), b1, W2 (H x H), b2, W3 (d x H), b3], all column-major
+    double* __restrict__ o = part + (traj * (long)gridDim.x + blockIdx.x) * NPAR;
+    double* oW1 = o; double* ob1 = oW1 + H * D; double* oW2 = ob1 + H; double* ob2 = oW2 + H * H; double* oW3 = ob2 + H; double* ob3 = oW3 + D * H;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+#pragma unroll
+        for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oW2[(16u * (cx.t0 + (unsigned)t) + cx.lq + 4u * (unsigned)r) + (16u * (unsigned)tj + cx.i) * (unsigned)H] = A.w2[t][tj][r];
+        double v[6] = {A.w1[t][0], A.w1[t][1], A.b1[t], A.b2[t], A.w3[t][0], A.w3[t][1]};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { v[q] += __shfl_xor(v[q], 16, 64); v[q] += __shfl_xor(v[q], 32, 64); }     // the four lane groups hold the other columns of the same row
+        if (cx.lq == 0) {
+            const unsigned row = 16u * (cx.t0 + (unsigned)t) + cx.i;
+            oW1[row] = v[0]; oW1[row + (unsigned)H] = v[1]; ob1[row] = v[2]; ob2[row] = v[3]; oW3[row * 2u] = v[4]; oW3[row * 2u + 1u] = v[5];
+        }
+    }
+    {
+        double b0 = A.b3[0], b1 = A.b3[1];                 // lanes 0..15 of wave 0 hold one column each
+        b0 += __shfl_xor(b0, 1, 64); b0 += __shfl_xor(b0, 2, 64); b0 += __shfl_xor(b0, 4, 64); b0 += __shfl_xor(b0, 8, 64);
+        b1 += __shfl_xor(b1, 1, 64); b1 += __shfl_xor(b1, 2, 64); b1 += __shfl_xor(b1, 4, 64); b1 += __shfl_xor(b1, 8, 64);
+        if (threadIdx.x == 0) { ob3[0] = b0; ob3[1] = b1; }
+    }
+}
+
+// dp[grp][e] = sum over the partials of the group (fixed order); groups: 1 (shared parameters: all trajectories and workgroups) or one per trajectory
+static __global__ void k_mlp_grad_reduce(int npar, long per_group, const double* __restrict__ part, double* __restrict__ dp) {
+    const long grp = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npar) return;
+    const double* src = part + grp * per_group * npar + e;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    long k = 0;
+    for (; k + 4 <= per_group; k += 4) { s0 += src[k * npar]; s1 += src[(k + 1) * npar]; s2 += src[(k + 2) * npar]; s3 += src[(k + 3) * npar]; }
+    for (; k < per_group; ++k) s0 += src[k * npar];
+    dp[grp * npar + e] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace hipadj

@@ -10,7 +10,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
-#include "hipadj_mlp.hpp"
+#include "hipadj_mlp_grad.hpp"
 
 using namespace hipadj;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -75,6 +75,20 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (r > 0) { tot += ms; if (ms < best) best = ms; }
     }
+    // in-register gradient variant (hipadj_mlp_grad.hpp)
+    double* d_part; CK(hipMalloc(&d_part, sizeof(double) * (size_t)(B / 16) * NPAR));
+    double* d_dp; CK(hipMalloc(&d_dp, sizeof(double) * NPAR));
+    float gms = 0, gbest = 1e30f; double gtot = 0;
+    for (int r = 0; r < reps + 1; ++r) {
+        CK(hipEventRecord(e0));
+        if (alg == 2) hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, dim3(MlpG<H>::NT), 0, 0, g, (const double*)d_p, (const double*)d_knots, (const double*)d_cot, (const int*)d_save, d_part, d_du0, d_flag);
+        else hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, dim3(MlpG<H>::NT), 0, 0, g, (const double*)d_p, (const double*)d_knots, (const double*)d_cot, (const int*)d_save, d_part, d_du0, d_flag);
+        hipLaunchKernelGGL(k_mlp_grad_reduce, dim3((NPAR + 255) / 256, 1), dim3(256), 0, 0, (int)NPAR, (long)(B / 16), (const double*)d_part, d_dp);
+        CK(hipGetLastError());
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&gms, e0, e1));
+        if (r > 0) { gtot += gms; if (gms < gbest) gbest = gms; }
+    }
+    hipLaunchKernelGGL(k_checksum, dim3(64), dim3(256), 0, 0, (const double*)d_dp, (long)NPAR, d_sum + 7);
     hipLaunchKernelGGL(k_checksum, dim3(256), dim3(256), 0, 0, (const double*)d_du0, (long)D * B, d_sum);
     hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, 0, (const double*)R.AG2, Q * H * B, d_sum + 1);
     hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, 0, (const double*)R.AG1, Q * H * B, d_sum + 2);
@@ -84,7 +98,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_checksum, dim3(256), dim3(256), 0, 0, (const double*)d_knots, (long)(S + 1) * 2 * D * B, d_sum + 6);
     double cs[8]; CK(hipMemcpy(cs, d_sum, sizeof(cs), hipMemcpyDeviceToHost));
     const double gemms = (alg == 2 ? 12.0 : 7.0) * S, flops = gemms * 2.0 * H * H * B;
-    printf("{\"H\": %d, \"B\": %d, \"S\": %d, \"alg\": %d, \"forward_ms\": %.4f, \"sweep_ms_mean\": %.4f, \"sweep_ms_min\": %.4f, \"sweep_TFLOPs\": %.2f, \"cs_du0\": %.15g, \"cs_ag2\": %.15g, \"cs_ag1\": %.15g, \"cs_ah1\": %.15g, \"cs_ah2\": %.15g, \"cs_al\": %.15g, \"cs_knots\": %.15g}\n",
-           H, B, S, alg, fwd_ms, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6]);
+    printf("{\"H\": %d, \"B\": %d, \"S\": %d, \"alg\": %d, \"forward_ms\": %.4f, \"sweep_ms_mean\": %.4f, \"sweep_ms_min\": %.4f, \"sweep_TFLOPs\": %.2f, \"cs_du0\": %.15g, \"cs_ag2\": %.15g, \"cs_ag1\": %.15g, \"cs_ah1\": %.15g, \"cs_ah2\": %.15g, \"cs_al\": %.15g, \"cs_knots\": %.15g, \"grad_sweep_ms_mean\": %.4f, \"grad_sweep_ms_min\": %.4f, \"cs_dp\": %.15g}\n",
+           H, B, S, alg, fwd_ms, tot / reps, best, flops / (tot / reps * 1e-3) / 1e12, cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], gtot / reps, gbest, cs[7]);
     return 0;
 }
