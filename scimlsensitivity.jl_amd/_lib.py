@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhipadj.so")
+LIB_PATH = os.environ.get("HIPADJ_LIBRARY") or os.path.join(HERE, "libhipadj.so")   # HIPADJ_LIBRARY: another build of the same ABI (A/B runs; the Julia binding reads the same variable)
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NONFINITE, ERR_STATE, ERR_UNSUPPORTED, ERR_MAXITERS, ERR_RCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8
 COMM_ID_BYTES = 128

@@ -49,7 +49,10 @@ struct FieldGeom {
 
 template <int G> struct Bruss {
     static constexpr int CELLS = G * G;
-    static constexpr int T = CELLS < 256 ? CELLS : 256;   // threads per workgroup
+#ifndef HIPADJ_BRUSS_T
+#define HIPADJ_BRUSS_T 1024   // 32 x 32: one cell per thread, 16 waves on the CU.  Measured against 256 threads x 4 cells (round 1): forward solve 0.88 -> 0.69 ms,
+#endif                        // Interpolating 2.71 -> 1.95 us per step, Gauss 4.45 -> 3.26, Quadrature 3.47 -> 3.20 (N = 1) and 4.99 -> 4.66 (N = 256, HBM-bound)
+    static constexpr int T = CELLS < HIPADJ_BRUSS_T ? CELLS : HIPADJ_BRUSS_T;   // threads per workgroup
     static constexpr int Q = CELLS / T;                   // cells per thread
     static constexpr int NS = 2 * CELLS;                  // state size n
     static_assert(CELLS % T == 0 && T % 64 == 0, "grid must tile the workgroup");
