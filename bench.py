@@ -337,7 +337,7 @@ def main():
         res = {
             "metric": "adjoint_trajectories_per_sec", "value": value, "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Lorenz-63 ensemble, {args.ntraj} trajectories{' in total (sharded)' if strong else ' per GPU' if world > 1 else ''}, "
                                    f"InterpolatingAdjoint, fixed-step RK4 dt={DT}, tspan=(0,{T_FINAL}), loss times 0:{SAVE_DT}:{T_FINAL}, "

@@ -168,6 +168,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
         A(dev_alloc(h, &h->d_w2t, (size_t)groups * Hh * Hh));
         if (const char* e = std::getenv("HIPADJ_MLP_RECORDS")) h->mlp_records = e[0] == '1';
+        if (h->mlp_records && cfg->alg == HIPADJ_ALG_BACKSOLVE) { h->err = "HIPADJ_MLP_RECORDS=1 (the round-1 record path) has no BacksolveAdjoint"; return fail(HIPADJ_ERR_UNSUPPORTED); }
         if (!h->mlp_records) {
             // in-register parameter gradient (hipadj_mlp_grad.hpp): one partial gradient per workgroup of 16 columns, no activation records
             A(dev_alloc(h, &h->d_c1, (size_t)h->N * (Bb / 16) * (size_t)np));

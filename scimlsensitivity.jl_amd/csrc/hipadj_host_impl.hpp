@@ -308,10 +308,14 @@ template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, d
     if (!h->mlp_records) {
         // in-register parameter gradient: the sweep leaves one partial gradient per workgroup, a fixed-order sum finishes dp
         const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), gblk(MlpG<H>::NT);
+        const int* ck = nullptr;
         if (h->cfg.alg == HIPADJ_ALG_GAUSS)
-            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_c1, d_du0, h->d_flag);
+            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, d_du0, h->d_flag);
+        else if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
+            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 1>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev,
+                               h->cfg.checkpointing ? (const int*)h->d_ckpt_of_knot : ck, h->d_c1, d_du0, h->d_flag);
         else
-            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_c1, d_du0, h->d_flag);
+            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, d_du0, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         const long groups = h->cfg.p_shared ? 1 : h->N;

@@ -167,10 +167,12 @@ template <int H> struct MlpGAcc {
     double b3[2];                                   // column layout: this lane's column
 };
 
-// forward pass up to the second hidden layer — the sweep never needs f itself (the knots carry it), so the output layer and its cross-lane
-// reduction are skipped; leaves H1 in the tile.  x: column layout.  NO barrier after the contraction: the next writer of the tile syncs first.
-template <int H>
-__device__ __forceinline__ void mlpg_forward(const MlpW<H>& w, MlpGLds<H>& L, const MlpGCtx<H>& cx, const double (&x)[2], double (&h1)[MlpG<H>::TW][4], double (&h2)[MlpG<H>::TW][4]) {
+// forward pass.  OUT = false (Interpolating / Gauss sweeps): up to the second hidden layer — the sweep never needs f itself (the knots carry
+// it), so the output layer and its cross-lane reduction are skipped, and there is NO barrier after the contraction: the next writer of the
+// tile syncs first.  OUT = true (Backsolve: y' = f(y) is integrated along): out = f(x) for this lane's column, closing barrier inside the
+// reduction.  Leaves H1 in the tile.  x: column layout.
+template <int H, bool OUT = false>
+__device__ __forceinline__ void mlpg_forward(const MlpW<H>& w, MlpGLds<H>& L, const MlpGCtx<H>& cx, const double (&x)[2], double (&h1)[MlpG<H>::TW][4], double (&h2)[MlpG<H>::TW][4], double (&out)[2]) {
     constexpr int TW = MlpG<H>::TW;
     double x0[4], x1[4];
     mlpg_cols(x[0], cx.lq, x0); mlpg_cols(x[1], cx.lq, x1);
@@ -185,10 +187,22 @@ __device__ __forceinline__ void mlpg_forward(const MlpW<H>& w, MlpGLds<H>& L, co
     mlpg_put<H>(L.tile, cx, h1);
     __syncthreads();
     mlpg_gemm<H, false>(L.w2s, L.tile, cx, acc);
+    double p[2][4];
 #pragma unroll
-    for (int t = 0; t < TW; ++t)
+    for (int r = 0; r < 4; ++r) { p[0][r] = 0.0; p[1][r] = 0.0; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h2[t][r] = mlp_tanh(acc[t][r]);
+    for (int t = 0; t < TW; ++t) {
+        const unsigned row = 16u * (cx.t0 + (unsigned)t) + cx.i;
+        const double wa = OUT ? w.W3[row * 2u] : 0.0, wb = OUT ? w.W3[row * 2u + 1u] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h2[t][r] = mlp_tanh(acc[t][r]); if (OUT) { p[0][r] += wa * h2[t][r]; p[1][r] += wb * h2[t][r]; } }
+    }
+    if (OUT) { mlpg_reduce<H>(L, cx, p, out); out[0] += w.b3[0]; out[1] += w.b3[1]; }
+}
+template <int H>
+__device__ __forceinline__ void mlpg_forward(const MlpW<H>& w, MlpGLds<H>& L, const MlpGCtx<H>& cx, const double (&x)[2], double (&h1)[MlpG<H>::TW][4], double (&h2)[MlpG<H>::TW][4]) {
+    double unused[2];
+    mlpg_forward<H, false>(w, L, cx, x, h1, h2, unused);
 }
 
 // (df/du)^T lam for the workgroup's columns; REC: also accumulate wq * (df/dp)^T lam.  tile_h1: the tile still holds H1 of these activations.
@@ -263,7 +277,8 @@ __device__ __forceinline__ void mlpg_backward(const MlpW<H>& w, MlpGLds<H>& L, c
 // reverse sweep with in-register parameter gradient.  part: [traj][gridDim.x][NPAR] partial gradients (one per workgroup).
 template <int H, int ALG>
 __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
-                                                                  const int* __restrict__ save_of_knot, double* __restrict__ part, double* __restrict__ du0, int* __restrict__ flag) {
+                                                                  const int* __restrict__ save_of_knot, const int* __restrict__ ckpt_of_knot, double* __restrict__ part,
+                                                                  double* __restrict__ du0, int* __restrict__ flag) {
     constexpr int TW = MlpG<H>::TW, TT = MlpG<H>::TT, D = 2, NPAR = MlpG<H>::NPAR;
     __shared__ MlpGLds<H> L;
     const long traj = blockIdx.y;
@@ -299,6 +314,34 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
     knot(g.S, xh, fh);
     { const int s = save_of_knot[g.S]; if (s >= 0) jump(s, xh, lam); }
     const double xg = 0.5773502691896257645;
+    if constexpr (ALG == 1) {
+        // BacksolveAdjoint (src/backsolve_adjoint.jl:32-61): z = [lam; mu; y], y' = f(y) integrated backward with the same RK4 stages, the parameter
+        // gradient accumulated at the four stage states with the RK4 weights; y overwritten by the stored forward value at every checkpoint knot
+        // BEFORE the loss gradient is taken there (CallbackSet(checkpoint, loss), :523-546; src/adjoint_common.jl:765-767).  Four forward passes
+        // (with the output layer) and four backward passes with outer products per step.
+        double y[D] = {xh[0], xh[1]};
+        for (int k = g.S - 1; k >= 0; --k) {
+            double F1[D], F2[D], F3[D], F4[D], ys[D], ls[D], V1[D], V2[D], V3[D], V4[D];
+            mlpg_forward<H, true>(w, L, cx, y, h1, h2, F1);
+            mlpg_backward<H, true>(w, L, cx, lam, y, h1, h2, V1, dt / 6.0, true, false, A);
+            ys[0] = y[0] - 0.5 * dt * F1[0]; ys[1] = y[1] - 0.5 * dt * F1[1]; ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
+            mlpg_forward<H, true>(w, L, cx, ys, h1, h2, F2);
+            mlpg_backward<H, true>(w, L, cx, ls, ys, h1, h2, V2, dt / 3.0, true, false, A);
+            ys[0] = y[0] - 0.5 * dt * F2[0]; ys[1] = y[1] - 0.5 * dt * F2[1]; ls[0] = lam[0] + 0.5 * dt * V2[0]; ls[1] = lam[1] + 0.5 * dt * V2[1];
+            mlpg_forward<H, true>(w, L, cx, ys, h1, h2, F3);
+            mlpg_backward<H, true>(w, L, cx, ls, ys, h1, h2, V3, dt / 3.0, true, false, A);
+            ys[0] = y[0] - dt * F3[0]; ys[1] = y[1] - dt * F3[1]; ls[0] = lam[0] + dt * V3[0]; ls[1] = lam[1] + dt * V3[1];
+            mlpg_forward<H, true>(w, L, cx, ys, h1, h2, F4);
+            mlpg_backward<H, true>(w, L, cx, ls, ys, h1, h2, V4, dt / 6.0, true, false, A);
+            y[0] = y[0] - (dt / 6.0) * (F1[0] + 2.0 * (F2[0] + F3[0]) + F4[0]);
+            y[1] = y[1] - (dt / 6.0) * (F1[1] + 2.0 * (F2[1] + F3[1]) + F4[1]);
+            lam[0] = lam[0] + (dt / 6.0) * (V1[0] + 2.0 * (V2[0] + V3[0]) + V4[0]);
+            lam[1] = lam[1] + (dt / 6.0) * (V1[1] + 2.0 * (V2[1] + V3[1]) + V4[1]);
+            if (ckpt_of_knot && ckpt_of_knot[k] >= 0) { knot(k, xl, fl); y[0] = xl[0]; y[1] = xl[1]; }
+            const int s = save_of_knot[k];
+            if (s >= 0 && !(g.no_start && s == 0)) jump(s, y, lam);
+        }
+    } else {
     mlpg_forward<H>(w, L, cx, xh, h1e, h2e);                // first-same-as-last: activations at x_hi of the first step
     for (int k = g.S - 1; k >= 0; --k) {
         knot(k, xl, fl);
@@ -345,6 +388,7 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
             have_v = !jumped;
         }
         xh[0] = xl[0]; xh[1] = xl[1]; fh[0] = fl[0]; fh[1] = fl[1];
+    }
     }
     if (writer) {
         du0[traj * nB + (long)col * D] = lam[0]; du0[traj * nB + (long)col * D + 1] = lam[1];

@@ -360,6 +360,35 @@ def test_mlp_matches_oracle(sa, alg, oalg, H, B, N, shared):
     sol.engine.close()
 
 
+@pytest.mark.parametrize("ckpt", [True, False])
+@pytest.mark.parametrize("H,B,N,shared,loss", [(32, 32, 1, True, "cot"), (128, 16, 1, True, "lsq"), (32, 48, 2, False, "cot"), (128, 64, 2, True, "cot")])
+def test_mlp_backsolve_matches_oracle(sa, H, B, N, shared, loss, ckpt):
+    """BacksolveAdjoint on the FP64-MFMA family (round 2): y' = f(y) integrated backward along with lam, the parameter gradient accumulated at
+    the four RK4 stage states, y overwritten by the stored forward value at the checkpoints (= the save times, src/backsolve_adjoint.jl:132)
+    before the loss gradient is taken (LSQ loss: at the overwritten y); checkpointing = false: one backward integration from y(T)."""
+    d, T, dt = 2, 0.3, 0.05
+    dims = (d, H, B, 0)
+    rng = np.random.default_rng(14)
+    u0 = rng.standard_normal((N, d * B))
+    p = mlp_params(d, H) if shared else np.stack([mlp_params(d, H, seed=20 + i) for i in range(N)])
+    ts = np.array([0.0, 0.1, 0.2, 0.3])
+    delta = rng.standard_normal((N, len(ts), d * B)) if loss == "cot" else None
+    dg = delta if loss == "cot" else sa.LsqShift(0.3)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("mlp", u0[0], (0, T), p if shared else p[0], dims), u0, p), sa.RK4(), dt=dt, saveat=ts,
+                   sensealg=sa.BacksolveAdjoint(checkpointing=ckpt), dgdu_discrete=None if loss == "cot" else dg)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=dg)
+    ref = O.Problem("MLP", alg="BACKSOLVE", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT" if loss == "cot" else "LSQ_SHIFT", loss_shift=0.3,
+                    dims=dims, checkpointing=ckpt)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    # and the relation the reference asserts between the algorithms (test/Core3/adjoint.jl:1201-1241: Backsolve ≈ Interpolating, rtol 1e-5 there)
+    sol2 = sa.solve(sa.EnsembleProblem(sa.ODEProblem("mlp", u0[0], (0, T), p if shared else p[0], dims), u0, p), sa.RK4(), dt=dt, saveat=ts,
+                    sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=None if loss == "cot" else dg)
+    du0i, dpi = sa.adjoint_sensitivities(sol2, sa.RK4(), t=ts, dgdu_discrete=dg)
+    assert rel(dp, dpi) < 1e-4 and rel(du0, du0i) < 1e-4
+    sol.engine.close(); sol2.engine.close()
+
+
 def test_mlp_lsq_loss_gauss(sa):
     d, H, B, T, dt = 2, 32, 64, 0.2, 0.05
     dims = (d, H, B, 0)
