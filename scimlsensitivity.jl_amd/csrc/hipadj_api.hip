@@ -75,7 +75,7 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
@@ -169,7 +169,21 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_w2t, (size_t)groups * Hh * Hh));
         if (const char* e = std::getenv("HIPADJ_MLP_RECORDS")) h->mlp_records = e[0] == '1';
         if (h->mlp_records && cfg->alg == HIPADJ_ALG_BACKSOLVE) { h->err = "HIPADJ_MLP_RECORDS=1 (the round-1 record path) has no BacksolveAdjoint"; return fail(HIPADJ_ERR_UNSUPPORTED); }
-        if (!h->mlp_records) {
+        if (h->mlp_records && cfg->alg == HIPADJ_ALG_QUADRATURE) { h->err = "HIPADJ_MLP_RECORDS=1 (the round-1 record path) has no QuadratureAdjoint"; return fail(HIPADJ_ERR_UNSUPPORTED); }
+        if (!h->mlp_records && cfg->alg == HIPADJ_ALG_QUADRATURE) {
+            // dense adjoint record of pass 1 + the buffers of the host-driven adaptive Gauss-Kronrod pass (mlp_quadrature, hipadj_host_impl.hpp)
+            const size_t wg = Bb / 16, per_entry = wg * (size_t)np;
+            size_t chunk = ((size_t)768 << 20) / (per_entry * sizeof(double)); chunk = chunk < 2 ? 2 : (chunk > 64 ? 64 : chunk); chunk &= ~(size_t)1;
+            h->mq_chunk = (int)chunk;
+            h->mq_pool_cap = 2 * (long)h->N * P.nq + 64;
+            A(dev_alloc(h, &h->d_fadj, (size_t)h->N * S * 4 * n));
+            A(dev_alloc(h, &h->d_c1, chunk * per_entry));
+            A(dev_alloc(h, &h->d_mq_pool, (size_t)h->mq_pool_cap * np));
+            A(dev_alloc(h, &h->d_mq_norm, (size_t)4 * 4096));
+            A(dev_alloc(h, &h->d_mq_ids, (size_t)1 << 16));
+            { double* tmp = nullptr; A(dev_alloc(h, &tmp, (size_t)4096 * 3)); h->d_mq_panels = tmp; }      // 4096 panels of 24 bytes
+            h->qa_host = P.qa; h->qb_host = P.qb;
+        } else if (!h->mlp_records) {
             // in-register parameter gradient (hipadj_mlp_grad.hpp): one partial gradient per workgroup of 16 columns, no activation records
             A(dev_alloc(h, &h->d_c1, (size_t)h->N * (Bb / 16) * (size_t)np));
         } else {
@@ -217,8 +231,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     }
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
-        if (!h->field) A(dev_alloc(h, &h->d_adj, (size_t)(P.offgrid ? P.rs_t.size() : (size_t)S) * 2 * n * Np));   // one record per reverse step
-        A(dev_alloc(h, &h->d_qres, (size_t)h->nq * np * Np));
+        if (!h->field && !h->mlp) A(dev_alloc(h, &h->d_adj, (size_t)(P.offgrid ? P.rs_t.size() : (size_t)S) * 2 * n * Np));   // one record per reverse step
+        if (!h->mlp) A(dev_alloc(h, &h->d_qres, (size_t)h->nq * np * Np));
         A(dev_alloc(h, &h->d_qa, (size_t)h->nq)); A(dev_alloc(h, &h->d_qb, (size_t)h->nq));
     }
     if (rc != HIPADJ_OK) return fail(rc);

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,10 @@ struct hipadj_handle {
     bool mlp_records = false;             // HIPADJ_MLP_RECORDS=1: round-1 path (activation records + weight-gradient GEMM kernels) instead of the in-register gradient
     double *d_w2t = nullptr, *d_ax = nullptr, *d_al = nullptr, *d_ah1 = nullptr, *d_ah2 = nullptr, *d_ag1 = nullptr, *d_ag2 = nullptr;
     double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
+    // MLP family, QuadratureAdjoint: host-driven adaptive Gauss-Kronrod (mlp_quadrature): pool of panel vectors, panel list, id lists, norms
+    double *d_mq_pool = nullptr, *d_mq_norm = nullptr; void* d_mq_panels = nullptr; int *d_mq_ids = nullptr;
+    long mq_pool_cap = 0; int mq_chunk = 0;
+    std::vector<double> qa_host, qb_host;
     MlpGeom mg{};
     FieldGeom fg{};
     bool user = false;                    // runtime-compiled right-hand side (hipadj_user.hpp)

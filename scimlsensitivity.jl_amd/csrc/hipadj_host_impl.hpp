@@ -297,6 +297,138 @@ template <int H> int mlp_forward_launch(hipadj_handle* h, const double* d_u0, co
     HIP_TRY(h, hipGetLastError());
     return HIPADJ_OK;
 }
+// QuadratureAdjoint pass 2 for the FP64-MFMA family: quadgk(integrand, t_{i-1}, t_i; atol, rtol) for every trajectory and loss interval
+// (src/quadrature_adjoint.jl:573-616), integrand = f_p^T lam summed over the whole batch.  The error norm of a panel is a norm over all
+// parameters AND all columns, so the adaptive decisions cannot be taken inside a workgroup: the panels are evaluated on the device
+// (k_mlp_quad_panel: 15-point Kronrod and 7-point Gauss sums as two entries, per-workgroup partials, fixed-order reduction into a pool of
+// panel vectors), the norms come back to the host, and the host runs QuadGK's loop — global error heap per interval, bisect the worst
+// segment, stop at E <= max(atol, rtol |I|), final re-sum — exactly as the oracle's quadgk_vec does, one bisection per unfinished interval
+// and round (the intervals are independent, so batching them changes nothing).  Smooth problems finish in round 0.
+template <int H> int mlp_quadrature(hipadj_handle* h, const double* p, double* d_dp) {
+    constexpr int NPAR = Mlp<H>::NPAR;
+    const int nWG = h->mg.B / 16, nq = h->nq; const long N = h->N;
+    const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+    struct Seg { double a, b, E; int idK; };
+    struct Item { std::vector<Seg> segs; double E = 0.0, Inorm = 0.0; long nev = 0; bool done = false; };
+    std::vector<Item> items((size_t)N * nq);
+    int next_id = 0;
+    auto grow_pool = [&](long need) -> int {
+        if (need <= h->mq_pool_cap) return HIPADJ_OK;
+        long cap = h->mq_pool_cap; while (cap < need) cap *= 2;
+        double* np_ = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&np_, sizeof(double) * (size_t)cap * NPAR));
+        HIP_TRY(h, hipMemcpyAsync(np_, h->d_mq_pool, sizeof(double) * (size_t)next_id * NPAR, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_mq_pool);
+        h->ws_bytes += (double)((cap - h->mq_pool_cap) * (long)NPAR * 8);
+        h->d_mq_pool = np_; h->mq_pool_cap = cap;
+        return HIPADJ_OK;
+    };
+    // evaluate panels [a, b] of trajectory tr: returns per request (||K||^2, ||K - G||^2) and the pool id of K
+    struct Req { int tr; double a, b; int idK; double nK2, nE2; };
+    auto eval = [&](std::vector<Req>& R) -> int {
+        TRY(grow_pool((long)next_id + 2 * (long)R.size()));
+        for (auto& r : R) { r.idK = next_id; next_id += 2; }
+        const size_t per = (size_t)h->mq_chunk / 2;          // requests per launch (two entries each)
+        std::vector<MlpPanel> pan; std::vector<int> ids; std::vector<double> nrm;
+        for (size_t b0 = 0; b0 < R.size(); b0 += per) {
+            const size_t cnt = std::min(per, R.size() - b0);
+            pan.clear(); ids.clear();
+            for (size_t q = 0; q < cnt; ++q) { const Req& r = R[b0 + q]; pan.push_back(MlpPanel{r.tr, 0, r.a, r.b}); pan.push_back(MlpPanel{r.tr, 1, r.a, r.b}); }
+            for (size_t q = 0; q < cnt; ++q) ids.push_back(R[b0 + q].idK);
+            for (size_t q = 0; q < cnt; ++q) ids.push_back(R[b0 + q].idK + 1);
+            HIP_TRY(h, hipMemcpyAsync(h->d_mq_panels, pan.data(), sizeof(MlpPanel) * pan.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_mq_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL((k_mlp_quad_panel<H>), dim3((unsigned)nWG, (unsigned)pan.size()), dim3(MlpG<H>::NT), 0, h->stream, h->mg, p, (const double*)h->d_fknots,
+                               (const double*)h->d_fadj, (const MlpPanel*)h->d_mq_panels, h->d_c1);
+            HIP_TRY(h, hipGetLastError());
+            // the entries of this launch occupy consecutive pool slots idK(first request) ..: (K, G) pairs
+            hipLaunchKernelGGL(k_mlp_grad_reduce, dim3((NPAR + 255) / 256, (unsigned)pan.size()), dim3(256), 0, h->stream, (int)NPAR, (long)nWG, (const double*)h->d_c1,
+                               h->d_mq_pool + (size_t)R[b0].idK * NPAR);
+            HIP_TRY(h, hipGetLastError());
+            hipLaunchKernelGGL(k_mlp_quad_norm, dim3((unsigned)cnt), dim3(256), 0, h->stream, (int)NPAR, (const double*)h->d_mq_pool, (const int*)h->d_mq_ids, (const int*)h->d_mq_ids + cnt, h->d_mq_norm);
+            HIP_TRY(h, hipGetLastError());
+            nrm.resize(2 * cnt);
+            HIP_TRY(h, hipMemcpyAsync(nrm.data(), h->d_mq_norm, sizeof(double) * 2 * cnt, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));    // also orders the reuse of d_mq_panels / d_mq_ids / d_c1 by the next launch
+            for (size_t q = 0; q < cnt; ++q) { R[b0 + q].nK2 = nrm[2 * q]; R[b0 + q].nE2 = nrm[2 * q + 1]; }
+        }
+        return HIPADJ_OK;
+    };
+    // || sum of the K vectors of the listed items ||
+    auto total_norms = [&](const std::vector<size_t>& which) -> int {
+        const size_t per = 1024;
+        for (size_t b0 = 0; b0 < which.size(); b0 += per) {
+            const size_t cnt = std::min(per, which.size() - b0);
+            std::vector<int> ids, start(1, 0);
+            for (size_t q = 0; q < cnt; ++q) { for (const Seg& sg : items[which[b0 + q]].segs) ids.push_back(sg.idK); start.push_back((int)ids.size()); }
+            if (ids.size() + start.size() > ((size_t)1 << 16)) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "QuadratureAdjoint (MLP family): the segment lists outgrew the id buffer; loosen the quadrature tolerances"); }
+            std::vector<int> both(ids); both.insert(both.end(), start.begin(), start.end());
+            HIP_TRY(h, hipMemcpyAsync(h->d_mq_ids, both.data(), sizeof(int) * both.size(), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_mlp_quad_sum, dim3((unsigned)cnt), dim3(256), 0, h->stream, (int)NPAR, (const double*)h->d_mq_pool, (const int*)h->d_mq_ids, (const int*)h->d_mq_ids + ids.size(),
+                               (double*)nullptr, h->d_mq_norm);
+            HIP_TRY(h, hipGetLastError());
+            std::vector<double> n2(cnt);
+            HIP_TRY(h, hipMemcpyAsync(n2.data(), h->d_mq_norm, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            for (size_t q = 0; q < cnt; ++q) items[which[b0 + q]].Inorm = std::sqrt(n2[q]);
+        }
+        return HIPADJ_OK;
+    };
+    // round 0: the whole interval
+    {
+        std::vector<Req> R;
+        for (long tr = 0; tr < N; ++tr) for (int qi = 0; qi < nq; ++qi) R.push_back(Req{(int)tr, h->qa_host[qi], h->qb_host[qi], 0, 0.0, 0.0});
+        TRY(eval(R));
+        for (size_t q = 0; q < R.size(); ++q) { Item& it = items[q]; it.segs.push_back(Seg{R[q].a, R[q].b, std::sqrt(R[q].nE2), R[q].idK}); it.E = it.segs[0].E; it.Inorm = std::sqrt(R[q].nK2); it.nev = 15; }
+    }
+    const long maxevals = 10000000L;
+    for (int round = 0; round < 4096; ++round) {
+        std::vector<size_t> act; std::vector<int> worst; std::vector<Req> R;
+        for (size_t q = 0; q < items.size(); ++q) {
+            Item& it = items[q];
+            if (it.done) continue;
+            if (it.E <= std::fmax(atol, rtol * it.Inorm) || it.nev >= maxevals) { it.done = true; continue; }
+            int wi = 0; for (int sidx = 1; sidx < (int)it.segs.size(); ++sidx) if (it.segs[sidx].E > it.segs[wi].E) wi = sidx;
+            const Seg sw = it.segs[wi]; const double mid = 0.5 * (sw.a + sw.b);
+            if (!(mid > std::fmin(sw.a, sw.b) && mid < std::fmax(sw.a, sw.b))) { it.done = true; continue; }      // cannot be split further
+            act.push_back(q); worst.push_back(wi);
+            const int tr = (int)(q / (size_t)nq);
+            R.push_back(Req{tr, sw.a, mid, 0, 0.0, 0.0}); R.push_back(Req{tr, mid, sw.b, 0, 0.0, 0.0});
+        }
+        if (act.empty()) break;
+        TRY(eval(R));
+        for (size_t q = 0; q < act.size(); ++q) {
+            Item& it = items[act[q]]; const Seg sw = it.segs[worst[q]];
+            const Seg s1{R[2 * q].a, R[2 * q].b, std::sqrt(R[2 * q].nE2), R[2 * q].idK}, s2{R[2 * q + 1].a, R[2 * q + 1].b, std::sqrt(R[2 * q + 1].nE2), R[2 * q + 1].idK};
+            it.E += s1.E + s2.E - sw.E; it.nev += 30;
+            it.segs[worst[q]] = s1; it.segs.push_back(s2);
+        }
+        TRY(total_norms(act));
+    }
+    // dp = sum of the K vectors of all accepted segments (QuadGK's final re-sum), per parameter group
+    {
+        const long groups = h->cfg.p_shared ? 1 : N;
+        std::vector<int> ids, start(1, 0);
+        for (long gidx = 0; gidx < groups; ++gidx) {
+            const long t0 = h->cfg.p_shared ? 0 : gidx, t1 = h->cfg.p_shared ? N : gidx + 1;
+            for (long tr = t0; tr < t1; ++tr) for (int qi = 0; qi < nq; ++qi) for (const Seg& sg : items[(size_t)tr * nq + qi].segs) ids.push_back(sg.idK);
+            start.push_back((int)ids.size());
+        }
+        if (ids.size() + start.size() > ((size_t)1 << 16)) { HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "QuadratureAdjoint (MLP family): the segment lists outgrew the id buffer; loosen the quadrature tolerances"); }
+        std::vector<int> both(ids); both.insert(both.end(), start.begin(), start.end());
+        HIP_TRY(h, hipMemcpyAsync(h->d_mq_ids, both.data(), sizeof(int) * both.size(), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_mlp_quad_sum, dim3((unsigned)groups, (unsigned)((NPAR + 255) / 256)), dim3(256), 0, h->stream, (int)NPAR, (const double*)h->d_mq_pool, (const int*)h->d_mq_ids, (const int*)h->d_mq_ids + ids.size(), d_dp, (double*)nullptr);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(h->stream));        // `both` must outlive the copy
+    }
+    if (std::getenv("HIPADJ_MQ_DEBUG")) {                   // debugging hook: how much adaptivity a run needed
+        long segs = 0; for (const Item& it : items) segs += (long)it.segs.size();
+        std::fprintf(stderr, "hipadj: MLP quadrature: %zu intervals, %ld accepted segments, %d panel vectors evaluated\n", items.size(), segs, next_id);
+    }
+    return HIPADJ_OK;
+}
+
 template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     constexpr int HP = Mlp<H>::HP;
     const double* p = h->p_dev_last;
@@ -308,14 +440,23 @@ template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, d
     if (!h->mlp_records) {
         // in-register parameter gradient: the sweep leaves one partial gradient per workgroup, a fixed-order sum finishes dp
         const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), gblk(MlpG<H>::NT);
-        const int* ck = nullptr;
+        const int* ck = nullptr; double* noadj = nullptr;
         if (h->cfg.alg == HIPADJ_ALG_GAUSS)
-            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, d_du0, h->d_flag);
+            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, noadj, d_du0, h->d_flag);
         else if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
             hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 1>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev,
-                               h->cfg.checkpointing ? (const int*)h->d_ckpt_of_knot : ck, h->d_c1, d_du0, h->d_flag);
+                               h->cfg.checkpointing ? (const int*)h->d_ckpt_of_knot : ck, h->d_c1, noadj, d_du0, h->d_flag);
+        else if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
+            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 3>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, (double*)nullptr, h->d_fadj, d_du0, h->d_flag);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+            TRY(mlp_quadrature<H>(h, p, d_dp));
+            HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+            es.pending = true;
+            return HIPADJ_OK;
+        }
         else
-            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, d_du0, h->d_flag);
+            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, noadj, d_du0, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         const long groups = h->cfg.p_shared ? 1 : h->N;

@@ -26,6 +26,7 @@
 // (per workgroup, then over workgroups) — agreement with the record path and with the oracle is at round-off (tests/test_gpu_parity.py).
 #pragma once
 
+#include "hipadj_field.hpp"   // the Gauss-Kronrod tables c_gk_*
 #include "hipadj_mlp.hpp"
 
 namespace hipadj {
@@ -274,11 +275,36 @@ __device__ __forceinline__ void mlpg_backward(const MlpW<H>& w, MlpGLds<H>& L, c
     mlpg_reduce<H>(L, cx, p, dlam);
 }
 
+// a workgroup's partial gradient in the parameter layout [W1 (H x d), b1, W2 (H x H), b2, W3 (d x H), b3], all column-major
+template <int H>
+__device__ __forceinline__ void mlpg_write_partial(const MlpGCtx<H>& cx, MlpGAcc<H>& A, double* __restrict__ o) {
+    constexpr int TW = MlpG<H>::TW, TT = MlpG<H>::TT, D = 2;
+    double* oW1 = o; double* ob1 = oW1 + H * D; double* oW2 = ob1 + H; double* ob2 = oW2 + H * H; double* oW3 = ob2 + H; double* ob3 = oW3 + D * H;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+#pragma unroll
+        for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oW2[(16u * (cx.t0 + (unsigned)t) + cx.lq + 4u * (unsigned)r) + (16u * (unsigned)tj + cx.i) * (unsigned)H] = A.w2[t][tj][r];
+        double v[6] = {A.w1[t][0], A.w1[t][1], A.b1[t], A.b2[t], A.w3[t][0], A.w3[t][1]};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { v[q] += __shfl_xor(v[q], 16, 64); v[q] += __shfl_xor(v[q], 32, 64); }     // the four lane groups hold the other columns of the same row
+        if (cx.lq == 0) {
+            const unsigned row = 16u * (cx.t0 + (unsigned)t) + cx.i;
+            oW1[row] = v[0]; oW1[row + (unsigned)H] = v[1]; ob1[row] = v[2]; ob2[row] = v[3]; oW3[row * 2u] = v[4]; oW3[row * 2u + 1u] = v[5];
+        }
+    }
+    double b0 = A.b3[0], b1 = A.b3[1];                     // lanes 0..15 of wave 0 hold one column each
+    b0 += __shfl_xor(b0, 1, 64); b0 += __shfl_xor(b0, 2, 64); b0 += __shfl_xor(b0, 4, 64); b0 += __shfl_xor(b0, 8, 64);
+    b1 += __shfl_xor(b1, 1, 64); b1 += __shfl_xor(b1, 2, 64); b1 += __shfl_xor(b1, 4, 64); b1 += __shfl_xor(b1, 8, 64);
+    if (threadIdx.x == 0) { ob3[0] = b0; ob3[1] = b1; }
+}
+
 // reverse sweep with in-register parameter gradient.  part: [traj][gridDim.x][NPAR] partial gradients (one per workgroup).
 template <int H, int ALG>
 __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
                                                                   const int* __restrict__ save_of_knot, const int* __restrict__ ckpt_of_knot, double* __restrict__ part,
-                                                                  double* __restrict__ du0, int* __restrict__ flag) {
+                                                                  double* __restrict__ adj, double* __restrict__ du0, int* __restrict__ flag) {
     constexpr int TW = MlpG<H>::TW, TT = MlpG<H>::TT, D = 2, NPAR = MlpG<H>::NPAR;
     __shared__ MlpGLds<H> L;
     const long traj = blockIdx.y;
@@ -349,7 +375,7 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
         xm[0] = 0.5 * (xl[0] + xh[0]) + (0.125 * dt) * (fl[0] - fh[0]);
         xm[1] = 0.5 * (xl[1] + xh[1]) + (0.125 * dt) * (fl[1] - fh[1]);
         // stage 1 at x_hi (activations carried over from the previous step's x_lo)
-        if (ALG == 2 && have_v) { V1[0] = Vn[0]; V1[1] = Vn[1]; }
+        if ((ALG == 2 || ALG == 3) && have_v) { V1[0] = Vn[0]; V1[1] = Vn[1]; }
         else mlpg_backward<H, ALG == 0>(w, L, cx, lam, xh, h1e, h2e, V1, dt / 6.0, false, true, A);   // after_fwd: the prologue's (or a node's backward-free) forward pass may precede
         // stages 2, 3 at the Hermite midpoint (same activations)
         ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
@@ -363,12 +389,22 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
         mlpg_backward<H, ALG == 0>(w, L, cx, ls, xl, h1e, h2e, V4, dt / 6.0, true, true, A);
         lam[0] = lam[0] + (dt / 6.0) * (V1[0] + 2.0 * (V2[0] + V3[0]) + V4[0]);
         lam[1] = lam[1] + (dt / 6.0) * (V1[1] + 2.0 * (V2[1] + V3[1]) + V4[1]);
-        if (ALG == 2) {
+        if (ALG == 2 || ALG == 3) {
             double V5[D];
             mlpg_backward<H, false>(w, L, cx, lam, xl, h1e, h2e, V5, 0.0, false, false, A);      // fsallast at x_lo (activations of stage 4)
             Vn[0] = V5[0]; Vn[1] = V5[1];
+            if (ALG == 3 && writer) {
+                // QuadratureAdjoint pass 1 (src/quadrature_adjoint.jl:527-530): the dense adjoint solution, one Hermite record per step
+                // adj[traj][k][4][d][B] = (lam at t_hi after the jump, lam' there, lam at t_lo before the jump, lam' there), lam' = -J^T lam
+                double* rec = adj + ((traj * g.S + k) * 4) * nB;
 #pragma unroll
-            for (int nq = 0; nq < 2; ++nq) {
+                for (int j = 0; j < D; ++j) {
+                    rec[(long)j * g.B + col] = lam_hi[j]; rec[nB + (long)j * g.B + col] = -V1[j];
+                    rec[2 * nB + (long)j * g.B + col] = lam[j]; rec[3 * nB + (long)j * g.B + col] = -V5[j];
+                }
+            }
+#pragma unroll
+            for (int nq = 0; nq < (ALG == 2 ? 2 : 0); ++nq) {
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
                 double lg[D], yg[D];
 #pragma unroll
@@ -394,29 +430,104 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
         du0[traj * nB + (long)col * D] = lam[0]; du0[traj * nB + (long)col * D + 1] = lam[1];
         if (!(fabs(lam[0]) <= 1.79769313486231570e308) || !(fabs(lam[1]) <= 1.79769313486231570e308)) atomicOr(flag, 1);
     }
-    // ---- this workgroup's partial gradient, in the parameter layout [W1 (H x d), b1, W2 (H x H), b2, W3 (d x H), b3], all column-major
-    double* __restrict__ o = part + (traj * (long)gridDim.x + blockIdx.x) * NPAR;
-    double* oW1 = o; double* ob1 = oW1 + H * D; double* oW2 = ob1 + H; double* ob2 = oW2 + H * H; double* oW3 = ob2 + H; double* ob3 = oW3 + D * H;
+    if (ALG == 3) return;                                  // the quadrature over f_p^T lam is k_mlp_quad_panel's
+    // ---- this workgroup's partial gradient
+    mlpg_write_partial<H>(cx, A, part + (traj * (long)gridDim.x + blockIdx.x) * NPAR);
+}
+
+// QuadratureAdjoint pass 2 for the FP64-MFMA family: one Gauss-Kronrod (7,15) panel per blockIdx.y, evaluated for the workgroup's 16 columns.
+// entry e = (trajectory, a, b, rule): rule 0 = the 15-point Kronrod sum, rule 1 = the embedded 7-point Gauss sum (the seven odd Kronrod
+// nodes) — the two sums of a panel are two entries (two accumulator sets do not fit the registers next to the sweep state).  Every node:
+// y(t) from the forward Hermite knots, lam(t) from the dense adjoint record of pass 1, one forward and one backward pass with the outer
+// products weighted by h w_j (AdjointSensitivityIntegrand, src/quadrature_adjoint.jl:486-502).  The adaptive part of quadgk — the error
+// norm over ALL columns and parameters, the segment heap — runs on the host between launches (mlp_quadrature in hipadj_host_impl.hpp).
+struct MlpPanel { int traj, rule; double a, b; };
+template <int H>
+__global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_quad_panel(MlpGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ adj,
+                                                                const MlpPanel* __restrict__ panels, double* __restrict__ part) {
+    constexpr int TW = MlpG<H>::TW, TT = MlpG<H>::TT, D = 2, NPAR = MlpG<H>::NPAR;
+    __shared__ MlpGLds<H> L;
+    const MlpPanel pe = panels[blockIdx.y];
+    const long traj = pe.traj;
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+    const MlpW<H> w = mlp_weights<H>(p, nullptr, g.p_shared, traj);
+    const MlpGCtx<H> cx = mlpg_ctx<H>();
+    const long nB = (long)D * g.B;
+    const double dt = g.dt;
+    mlpg_fill_swz<H>(w.W2, L.w2s);
+    __syncthreads();
+    MlpGAcc<H> A;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
 #pragma unroll
         for (int tj = 0; tj < TT; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) oW2[(16u * (cx.t0 + (unsigned)t) + cx.lq + 4u * (unsigned)r) + (16u * (unsigned)tj + cx.i) * (unsigned)H] = A.w2[t][tj][r];
-        double v[6] = {A.w1[t][0], A.w1[t][1], A.b1[t], A.b2[t], A.w3[t][0], A.w3[t][1]};
+            for (int r = 0; r < 4; ++r) A.w2[t][tj][r] = 0.0;
+        A.w1[t][0] = A.w1[t][1] = A.b1[t] = A.b2[t] = A.w3[t][0] = A.w3[t][1] = 0.0;
+    }
+    A.b3[0] = A.b3[1] = 0.0;
+    const double c = 0.5 * (pe.a + pe.b), hw = 0.5 * (pe.b - pe.a);
+    double h1[TW][4], h2[TW][4];
+    for (int node = 0; node < 15; ++node) {                 // nodes c - h x_0 .. c - h x_6, c, c + h x_6 .. c + h x_0 (ascending time)
+        const int j = node < 8 ? node : 14 - node;
+        double wgt;
+        if (pe.rule == 0) wgt = c_gk_wk[j];
+        else { if (!(j & 1)) continue; wgt = c_gk_wg[j >> 1]; }          // uniform over the workgroup
+        const double t = node < 7 ? c - hw * c_gk_x[j] : (node == 7 ? c : c + hw * c_gk_x[j]);
+        int k = (int)((t - g.t0) / dt);
+        if (k < 0) k = 0;
+        if (k > g.S - 1) k = g.S - 1;
+        if (t < g.t0 + k * dt && k > 0) --k;
+        if (t > g.t0 + (k + 1) * dt && k < g.S - 1) ++k;
+        const double tf = (t - (g.t0 + k * dt)) / dt, th = 1.0 - tf;      // forward fraction in [t_k, t_k+1]; adjoint fraction from t_hi downward
+        const double* k0 = knots + ((traj * (g.S + 1) + k) * 2) * nB;
+        const double* k1 = k0 + 2 * nB;
+        const double* rec = adj + ((traj * g.S + k) * 4) * nB;
+        double yg[D], lg[D];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { v[q] += __shfl_xor(v[q], 16, 64); v[q] += __shfl_xor(v[q], 32, 64); }     // the four lane groups hold the other columns of the same row
-        if (cx.lq == 0) {
-            const unsigned row = 16u * (cx.t0 + (unsigned)t) + cx.i;
-            oW1[row] = v[0]; oW1[row + (unsigned)H] = v[1]; ob1[row] = v[2]; ob2[row] = v[3]; oW3[row * 2u] = v[4]; oW3[row * 2u + 1u] = v[5];
+        for (int jd = 0; jd < D; ++jd) {
+            const double xl = k0[(long)jd * g.B + col], fl = k0[nB + (long)jd * g.B + col], xh = k1[(long)jd * g.B + col], fh = k1[nB + (long)jd * g.B + col];
+            yg[jd] = (1.0 - tf) * xl + tf * xh + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (xh - xl) + (tf - 1.0) * dt * fl + tf * dt * fh);
+            const double l0 = rec[(long)jd * g.B + col], d0 = rec[nB + (long)jd * g.B + col], l1 = rec[2 * nB + (long)jd * g.B + col], d1 = rec[3 * nB + (long)jd * g.B + col];
+            // Hermite on the adjoint step (from t_hi to t_lo, step -dt): lam(th) with end derivatives d0 (at t_hi), d1 (at t_lo)
+            lg[jd] = (1.0 - th) * l0 + th * l1 + th * (th - 1.0) * ((1.0 - 2.0 * th) * (l1 - l0) + (th - 1.0) * (-dt) * d0 + th * (-dt) * d1);
         }
+        double dl[D];
+        mlpg_forward<H>(w, L, cx, yg, h1, h2);
+        mlpg_backward<H, true>(w, L, cx, lg, yg, h1, h2, dl, hw * wgt, true, true, A);
     }
-    {
-        double b0 = A.b3[0], b1 = A.b3[1];                 // lanes 0..15 of wave 0 hold one column each
-        b0 += __shfl_xor(b0, 1, 64); b0 += __shfl_xor(b0, 2, 64); b0 += __shfl_xor(b0, 4, 64); b0 += __shfl_xor(b0, 8, 64);
-        b1 += __shfl_xor(b1, 1, 64); b1 += __shfl_xor(b1, 2, 64); b1 += __shfl_xor(b1, 4, 64); b1 += __shfl_xor(b1, 8, 64);
-        if (threadIdx.x == 0) { ob3[0] = b0; ob3[1] = b1; }
+    double* __restrict__ o = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * NPAR;
+    mlpg_write_partial<H>(cx, A, o);
+}
+
+// ||K||^2 and ||K - G||^2 of panel vectors (one workgroup per pair); out[2 pair], out[2 pair + 1]
+static __global__ void k_mlp_quad_norm(int npar, const double* __restrict__ pool, const int* __restrict__ idK, const int* __restrict__ idG, double* __restrict__ out) {
+    __shared__ double red[2][256];
+    const double* K = pool + (long)idK[blockIdx.x] * npar; const double* G = pool + (long)idG[blockIdx.x] * npar;
+    double s0 = 0.0, s1 = 0.0;
+    for (int e = threadIdx.x; e < npar; e += 256) { const double k = K[e], d = k - G[e]; s0 += k * k; s1 += d * d; }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; } __syncthreads(); }
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = red[0][0]; out[2 * blockIdx.x + 1] = red[1][0]; }
+}
+// out[list][e] = sum of the pool vectors ids[start[list] .. start[list + 1]) (fixed order), elements split over blockIdx.y;
+// norm2[list] = || that sum ||^2 when norm2 != nullptr (then launched with gridDim.y == 1: one fixed-order tree per list)
+static __global__ void k_mlp_quad_sum(int npar, const double* __restrict__ pool, const int* __restrict__ ids, const int* __restrict__ start, double* __restrict__ out, double* __restrict__ norm2) {
+    __shared__ double red[256];
+    const int l = blockIdx.x, b = start[l], e1 = start[l + 1];
+    double s2 = 0.0;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < npar; e += 256 * gridDim.y) {
+        double s = 0.0;
+        for (int q = b; q < e1; ++q) s += pool[(long)ids[q] * npar + e];
+        if (out) out[(long)l * npar + e] = s;
+        s2 += s * s;
     }
+    if (!norm2) return;
+    red[threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) norm2[l] = red[0];
 }
 
 // dp[grp][e] = sum over the partials of the group (fixed order); groups: 1 (shared parameters: all trajectories and workgroups) or one per trajectory

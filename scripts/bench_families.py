@@ -38,12 +38,12 @@ def main():
     ts = dt * np.arange(5, S + 1, 5)
     u0 = rng.standard_normal((1, d * B)); p = mlp_params(d, H)
     delta = rng.standard_normal((1, len(ts), d * B))
-    for alg in ("gauss", "interpolating"):
+    for alg in ("gauss", "interpolating", "backsolve", "quadrature"):
         eng = sa.Engine("mlp", alg, 1, 0.0, S * dt, dt, save_times=ts, dims=(d, H, B, 0))
         r, du0, dp = run(eng, u0, p, delta, 3)
         nq = 2 if alg == "gauss" else 4
         # flops of the sweep: per step (3 fwd + 4 bwd [+1 fsal + 2x(fwd+bwd) for Gauss]) H x H x B contractions, 2 flop/MAC
-        gemms = (3 + 4 + (1 + 4 if alg == "gauss" else 0)) * S
+        gemms = (3 + 4 + (1 + 4 if alg == "gauss" else 0)) * S          # nominal count of the Gauss / Interpolating stage algebra (Backsolve: 8, Quadrature: sweep 8 + 2 x 22 nodes per interval)
         sweep_flops = gemms * 2.0 * H * H * B
         wgrad_flops = nq * S * 2.0 * B * (H * (H + 16) + H * 16 + 16 * (H + 16))
         r.update(case=f"mlp H={H} B={B} S={S} {alg}", sweep_TFLOPs=sweep_flops / (r["main_kernel_ms"] * 1e-3) / 1e12,

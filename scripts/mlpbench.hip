@@ -81,8 +81,8 @@ int main(int argc, char** argv) {
     float gms = 0, gbest = 1e30f; double gtot = 0;
     for (int r = 0; r < reps + 1; ++r) {
         CK(hipEventRecord(e0));
-        if (alg == 2) hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, dim3(MlpG<H>::NT), 0, 0, g, (const double*)d_p, (const double*)d_knots, (const double*)d_cot, (const int*)d_save, (const int*)nullptr, d_part, d_du0, d_flag);
-        else hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, dim3(MlpG<H>::NT), 0, 0, g, (const double*)d_p, (const double*)d_knots, (const double*)d_cot, (const int*)d_save, (const int*)nullptr, d_part, d_du0, d_flag);
+        if (alg == 2) hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, dim3(MlpG<H>::NT), 0, 0, g, (const double*)d_p, (const double*)d_knots, (const double*)d_cot, (const int*)d_save, (const int*)nullptr, d_part, (double*)nullptr, d_du0, d_flag);
+        else hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, dim3(MlpG<H>::NT), 0, 0, g, (const double*)d_p, (const double*)d_knots, (const double*)d_cot, (const int*)d_save, (const int*)nullptr, d_part, (double*)nullptr, d_du0, d_flag);
         hipLaunchKernelGGL(k_mlp_grad_reduce, dim3((NPAR + 255) / 256, 1), dim3(256), 0, 0, (int)NPAR, (long)(B / 16), (const double*)d_part, d_dp);
         CK(hipGetLastError());
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&gms, e0, e1));
