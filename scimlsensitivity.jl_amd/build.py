@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 LANE_MODELS = ["ModelLV", "ModelLVT", "ModelLorenz", "ModelLinDiag", "ModelFallMass"]   # csrc/hipadj_models.hpp
 FIELD_GRIDS = [8, 16, 32]
-MLP_HIDDEN = [32, 128]
+MLP_HIDDEN = [32, 64, 128]
 
 
 def units():

@@ -399,6 +399,7 @@ extern "C" int hipadj_get_stats(hipadj_handle* h, hipadj_stats* st) {
 #define DISPATCH_HIDDEN(h, fn, ...)                                                        \
     switch ((h)->cfg.dims[1]) {                                                            \
     case 32: return fn<32>(__VA_ARGS__);                                                   \
+    case 64: return fn<64>(__VA_ARGS__);                                                   \
     case 128: return fn<128>(__VA_ARGS__);                                                 \
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "unsupported hidden width %d", (h)->cfg.dims[1]); }
 

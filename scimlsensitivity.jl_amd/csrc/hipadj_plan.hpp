@@ -152,7 +152,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (!plan_small_model(cfg->model) && !P.field && !P.mlp) { err = "unknown model"; return HIPADJ_ERR_UNSUPPORTED; }
     if (P.mlp) {
         if (cfg->dims[0] != 2) { err = "MLP family: state width d must be 2 (docs/src/Benchmark.md:62 shape)"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->dims[1] != 32 && cfg->dims[1] != 128) { err = "MLP family: hidden width must be 32 or 128"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->dims[1] != 32 && cfg->dims[1] != 64 && cfg->dims[1] != 128) { err = "MLP family: hidden width must be 32, 64 or 128 (the weight matrix lives in LDS)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->dims[2] % 16 != 0) { err = "MLP family: batch must be a multiple of 16 (one workgroup per 16 columns)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg != HIPADJ_ALG_GAUSS && cfg->alg != HIPADJ_ALG_INTERPOLATING && cfg->alg != HIPADJ_ALG_BACKSOLVE && cfg->alg != HIPADJ_ALG_QUADRATURE) { err = "MLP family offers Gauss-, Interpolating-, Backsolve- and QuadratureAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->checkpointing && cfg->alg != HIPADJ_ALG_BACKSOLVE) { err = "MLP family: checkpointing = true is available for BacksolveAdjoint (the sweeps read the forward knots, 64 B per column and step)"; return HIPADJ_ERR_UNSUPPORTED; }

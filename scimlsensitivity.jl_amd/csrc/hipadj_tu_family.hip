@@ -1,6 +1,6 @@
 // hipadj_tu_family.hip — translation units of the workgroup-per-trajectory (Brusselator) and FP64-MFMA (MLP) families:
 //   hipcc -DHIPADJ_TU_FIELD=32     Brusselator grid 8 / 16 / 32
-//   hipcc -DHIPADJ_TU_MLP=128      hidden width 32 / 128
+//   hipcc -DHIPADJ_TU_MLP=128      hidden width 32 / 64 / 128
 #include "hipadj_host_impl.hpp"
 
 #if defined(HIPADJ_TU_FIELD)
