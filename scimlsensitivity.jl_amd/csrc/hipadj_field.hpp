@@ -359,23 +359,39 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_quad_adj(FieldGeom g, con
     load_fknot<G>(knots, g, traj, g.S, nb, hi);
     { const int s = save_of_knot[g.S]; if (s >= 0) field_jump<G>(g, traj, s, cot, nb, hi.U, hi.V, lU, lV); }
     load_fknot<G>(knots, g, traj, g.S - 1, nb, lo);
+    // First-same-as-last over the steps: lam' at the END of step k+1 (record slot 3) is -J(u_{k+1})^T lam there, which is exactly the V1 that
+    // step k computes at its start - unless a loss jump changed lam at knot k+1.  So the closing exchange + VJP of a step is only done when a
+    // jump follows (uniform: save_of_knot) or at the last step; otherwise the slot is filled one iteration later (4 instead of 5 LDS exchanges).
+    bool pending = false;                                   // slot 3 of step k+1 still to be written (uniform)
     for (int k = g.S - 1; k >= 0; --k) {
         load_fknot<G>(knots, g, traj, k > 0 ? k - 1 : 0, nb, nx);
         double* rec = adj + ((traj * g.S + k) * 4) * NS;
-        double v1U[Q], v1V[Q], v5U[Q], v5V[Q];
+        double v1U[Q], v1V[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) { rec[nb.c[q]] = lU[q]; rec[CELLS + nb.c[q]] = lV[q]; }
         field_rk4_step<G, false>(sh, nb, P, g.dt, hi, lo, lU, lV, wd, v1U, v1V);
-        publish<G>(sh[0], nb, lU, lV);
-        bruss_vjp<G, false>(sh[0], nb, P, lo.U, lo.V, lU, lV, v5U, v5V, 0.0, wd);
-        __syncthreads();       // the next step republishes sh[0]
+        if (pending) {
+            double* up = rec + 4 * NS;                      // record of step k+1
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { up[3 * NS + nb.c[q]] = -v1U[q]; up[3 * NS + CELLS + nb.c[q]] = -v1V[q]; }
+        }
+        const int s = save_of_knot[k];
+        const bool jumps = s >= 0 && !(g.no_start && s == 0);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             rec[NS + nb.c[q]] = -v1U[q]; rec[NS + CELLS + nb.c[q]] = -v1V[q];
             rec[2 * NS + nb.c[q]] = lU[q]; rec[2 * NS + CELLS + nb.c[q]] = lV[q];
-            rec[3 * NS + nb.c[q]] = -v5U[q]; rec[3 * NS + CELLS + nb.c[q]] = -v5V[q];
         }
-        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) field_jump<G>(g, traj, s, cot, nb, lo.U, lo.V, lU, lV); }
+        if (jumps || k == 0) {
+            double v5U[Q], v5V[Q];
+            publish<G>(sh[0], nb, lU, lV);
+            bruss_vjp<G, false>(sh[0], nb, P, lo.U, lo.V, lU, lV, v5U, v5V, 0.0, wd);
+            __syncthreads();       // the next step republishes sh[0]
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { rec[3 * NS + nb.c[q]] = -v5U[q]; rec[3 * NS + CELLS + nb.c[q]] = -v5V[q]; }
+            pending = false;
+        } else pending = true;
+        if (jumps) field_jump<G>(g, traj, s, cot, nb, lo.U, lo.V, lU, lV);
         hi = lo; lo = nx;
     }
     bool bad = false;
