@@ -1,7 +1,7 @@
 """
     HIPAdj
 
-Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 103) — the MI355X-native batched continuous-adjoint
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 104) — the MI355X-native batched continuous-adjoint
 engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
 
   * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, set_mass_matrix!, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -39,7 +39,7 @@ function lib()
     if LIB[] == C_NULL
         LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
         v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
-        v == 103 || error("libhipadj ABI version $v, this binding was written for 103")
+        v == 104 || error("libhipadj ABI version $v, this binding was written for 104")
     end
     return LIB[]
 end
@@ -187,6 +187,34 @@ function set_mass_matrix!(id::Integer, n::Integer, M)
     return nothing
 end
 set_mass_matrix!(m::DeviceModel, M) = set_mass_matrix!(m.id, m.n, M)
+
+"""
+    set_affect!(model, body)            # body === nothing removes it
+
+The `affect!` of a `DiscreteCallback` at preset times as device text (test/Callbacks1/discrete_callbacks.jl:260-330): `body` edits `un` — which starts
+as a copy of `u` — from `u`, `p`, `t` (locals `real`; the reverse callback's two VJPs are generated by dual numbers).  An event problem is a chain
+of ordinary handles, one per span between consecutive event times: `affect_apply` maps the end state of a piece to the start state of the next,
+`affect_vjp` maps `du0` of the upper piece to the extra cotangent at the end of the lower one and returns the parameter term
+(src/callback_tracking.jl:330-452 for a DiscreteCallback).  The Python host mirror (`scimlsensitivity.jl_amd/events.py`) is the executed reference of
+that composition; ContinuousCallbacks stay with the reference's CPU path.
+"""
+function set_affect!(m::DeviceModel, body)
+    s = body === nothing ? nothing : String(body)
+    GC.@preserve s check(ccall(sym(:hipadj_model_set_affect), Cint, (Int32, Ptr{UInt8}), m.id, s === nothing ? Ptr{UInt8}(C_NULL) : pointer(s)))
+    return m
+end
+function affect_apply(m::DeviceModel, u::Matrix{Float64}, p::Union{Vector{Float64}, Matrix{Float64}}, t::Real; device::Integer = 0)
+    out = similar(u)                                       # (n, N) column-major == the ABI's [N][n]
+    check(ccall(sym(:hipadj_affect_apply), Cint, (Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}),
+                m.id, Int32(device), size(u, 2), u, p, Int32(p isa Vector), Float64(t), out))
+    return out
+end
+function affect_vjp(m::DeviceModel, u::Matrix{Float64}, p::Union{Vector{Float64}, Matrix{Float64}}, t::Real, lam::Matrix{Float64}; device::Integer = 0)
+    lam_out = similar(lam); gp = Matrix{Float64}(undef, m.np, size(u, 2))
+    check(ccall(sym(:hipadj_affect_vjp), Cint, (Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                m.id, Int32(device), size(u, 2), u, p, Int32(p isa Vector), Float64(t), lam, lam_out, gp))
+    return lam_out, gp
+end
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the sensealg the extension dispatches on (seam B1 of SURVEY.md §8b)

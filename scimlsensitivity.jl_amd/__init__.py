@@ -7,10 +7,11 @@ from ._lib import HipadjError, model_sizes, load as load_library, LIB_PATH
 from .sensitivity_algorithms import (AbstractSensitivityAlgorithm, AbstractAdjointSensitivityAlgorithm, DeviceVJP,
                                      InterpolatingAdjoint, BacksolveAdjoint, QuadratureAdjoint, GaussAdjoint, GaussKronrodAdjoint,
                                      ischeckpointing)
-from .problems import (RK4, Tsit5, DeviceFunction, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum,
+from .problems import (RK4, Tsit5, DeviceFunction, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum, PresetTimeCallback,
                        FirstStateSquaredPlusFirstParam, ModelCost)
 from .engine import Engine
 from .interface import solve, adjoint_sensitivities, concrete_solve_adjoint, make_autograd_function
+from .events import EventSolution
 from .distributed import shard_range, allreduce_dp, gather_du0, comm_unique_id, init_native_allreduce
 from . import build as _build
 

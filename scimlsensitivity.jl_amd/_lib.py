@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_model_set_mass_matrix",
+    "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
 )
 
@@ -103,6 +103,10 @@ def load():
     L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_model_set_cost_function.argtypes = [C.c_int32, C.c_char_p]
     L.hipadj_model_set_mass_matrix.argtypes = [C.c_int32, C.POINTER(C.c_double)]
+    L.hipadj_model_set_affect.argtypes = [C.c_int32, C.c_char_p]
+    L.hipadj_affect_apply.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double)]
+    L.hipadj_affect_vjp.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.hipadj_comm_unique_id.argtypes = [C.c_char_p]
     L.hipadj_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.hipadj_comm_attach.argtypes = [vp, vp]
@@ -140,6 +144,41 @@ def check_model(model_id):
     rc = L.hipadj_model_check(int(model_id))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
+
+
+def set_model_affect(model_id, body):
+    """hipadj_model_set_affect: the DiscreteCallback affect of a runtime-registered model (None removes it)."""
+    L = load()
+    rc = L.hipadj_model_set_affect(int(model_id), None if body is None else body.encode())
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+
+
+def affect_apply(model_id, u, p, t, device=0):
+    """hipadj_affect_apply: u_out[i] = a(u[i], p, t) on the device; u [N][n], p [np] or [N][np] (host arrays in and out)."""
+    import numpy as np
+    L = load()
+    u = np.ascontiguousarray(u, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.empty_like(u)
+    dp_ = C.POINTER(C.c_double)
+    rc = L.hipadj_affect_apply(int(model_id), int(device), u.shape[0], u.ctypes.data_as(dp_), p.ctypes.data_as(dp_), int(p.ndim == 1), float(t), out.ctypes.data_as(dp_))
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+    return out
+
+
+def affect_vjp(model_id, u, p, t, lam, npar, device=0):
+    """hipadj_affect_vjp: ((da/du)^T lam, (da/dp)^T lam per trajectory) at the left state u."""
+    import numpy as np
+    L = load()
+    u = np.ascontiguousarray(u, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64); lam = np.ascontiguousarray(lam, dtype=np.float64)
+    lo = np.empty_like(u); g = np.empty((u.shape[0], int(npar)))
+    dp_ = C.POINTER(C.c_double)
+    rc = L.hipadj_affect_vjp(int(model_id), int(device), u.shape[0], u.ctypes.data_as(dp_), p.ctypes.data_as(dp_), int(p.ndim == 1), float(t), lam.ctypes.data_as(dp_),
+                             lo.ctypes.data_as(dp_), g.ctypes.data_as(dp_))
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+    return lo, g
 
 
 def set_model_mass_matrix(model_id, n, M):

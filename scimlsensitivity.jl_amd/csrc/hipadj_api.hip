@@ -51,9 +51,86 @@ extern "C" int hipadj_model_set_mass_matrix(int32_t model_id, const double* M) {
     return user_set_mass_matrix(model_id, M, g_create_error);
 }
 
+extern "C" int hipadj_model_set_affect(int32_t model_id, const char* affect_body) {
+    return user_set_affect(model_id, affect_body, g_create_error);
+}
+
+// ---- DiscreteCallback affects applied between solves (host-level composition of event problems, interface.py) --------------------------------
+// Both calls are synchronous and take HOST pointers: the data of an event is N x (n + np) doubles.  The kernels are compiled for the model with
+// hiprtc on first use (same cache as the solve kernels).
+namespace {
+struct AffectFns { hipModule_t mod = nullptr; hipFunction_t apply = nullptr, vjp = nullptr; };
+int affect_functions(int32_t model, AffectFns& F, std::string& err) {
+    std::vector<char> code; std::map<std::string, std::string> low;
+    const std::vector<std::string> exprs = {"hipadj::k_user_affect<hipadj::UserModel>", "hipadj::k_user_affect_vjp<hipadj::UserModel>"};
+    const int rc = user_compile(model, exprs, code, low, err);
+    if (rc != HIPADJ_OK) return rc;
+    if (hipModuleLoadData(&F.mod, code.data()) != hipSuccess || hipModuleGetFunction(&F.apply, F.mod, low[exprs[0]].c_str()) != hipSuccess ||
+        hipModuleGetFunction(&F.vjp, F.mod, low[exprs[1]].c_str()) != hipSuccess) { err = "hipadj affect: loading the compiled kernels failed"; if (F.mod) (void)hipModuleUnload(F.mod); return HIPADJ_ERR_HIP; }
+    return HIPADJ_OK;
+}
+struct DevBufs {
+    std::vector<void*> v;
+    ~DevBufs() { for (void* q : v) if (q) (void)hipFree(q); }
+    double* get(size_t count, const double* src, bool& ok) {
+        void* q = nullptr;
+        if (hipMalloc(&q, sizeof(double) * (count ? count : 1)) != hipSuccess) { ok = false; return nullptr; }
+        v.push_back(q);
+        if (src && hipMemcpy(q, src, sizeof(double) * count, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        return (double*)q;
+    }
+};
+int affect_prologue(int32_t model, int32_t device, int64_t N, int32_t& n, int32_t& np, std::string& err) {
+    if (N <= 0) { err = "hipadj affect: N must be positive"; return HIPADJ_ERR_INVALID_ARG; }
+    if (user_model_sizes(model, &n, &np) != HIPADJ_OK) { err = "hipadj affect: unknown model id (affects are attached to runtime-registered models)"; return HIPADJ_ERR_INVALID_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { err = "no usable HIP device (this library has no CPU fallback)"; return HIPADJ_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return HIPADJ_ERR_HIP; }
+    return HIPADJ_OK;
+}
+}  // namespace
+
+extern "C" int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double* u, const double* p, int32_t p_shared, double t, double* out) {
+    if (!u || !p || !out) { g_create_error = "hipadj_affect_apply: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+    int32_t n = 0, np = 0;
+    { const int rc = affect_prologue(model_id, device, N, n, np, g_create_error); if (rc != HIPADJ_OK) return rc; }
+    AffectFns F;
+    { const int rc = affect_functions(model_id, F, g_create_error); if (rc != HIPADJ_OK) return rc; }
+    bool ok = true; DevBufs B;
+    double* d_u = B.get((size_t)N * n, u, ok); double* d_p = B.get(p_shared ? (size_t)np : (size_t)N * np, p, ok); double* d_o = B.get((size_t)N * n, nullptr, ok);
+    long Nl = (long)N, ldp = p_shared ? 0 : np;
+    void* args[] = {&Nl, &ldp, &d_u, &d_p, &t, &d_o};
+    ok = ok && hipModuleLaunchKernel(F.apply, (unsigned)((N + 255) / 256), 1, 1, 256, 1, 1, 0, nullptr, args, nullptr) == hipSuccess;
+    ok = ok && hipMemcpy(out, d_o, sizeof(double) * (size_t)N * n, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipModuleUnload(F.mod);
+    if (!ok) { g_create_error = "hipadj_affect_apply: a HIP call failed"; return HIPADJ_ERR_HIP; }
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double* u, const double* p, int32_t p_shared, double t, const double* lam,
+                                 double* lam_out, double* dp_rows) {
+    if (!u || !p || !lam || !lam_out || !dp_rows) { g_create_error = "hipadj_affect_vjp: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+    int32_t n = 0, np = 0;
+    { const int rc = affect_prologue(model_id, device, N, n, np, g_create_error); if (rc != HIPADJ_OK) return rc; }
+    AffectFns F;
+    { const int rc = affect_functions(model_id, F, g_create_error); if (rc != HIPADJ_OK) return rc; }
+    bool ok = true; DevBufs B;
+    double* d_u = B.get((size_t)N * n, u, ok); double* d_p = B.get(p_shared ? (size_t)np : (size_t)N * np, p, ok); double* d_l = B.get((size_t)N * n, lam, ok);
+    double* d_lo = B.get((size_t)N * n, nullptr, ok); double* d_g = B.get((size_t)N * np, nullptr, ok);
+    long Nl = (long)N, ldp = p_shared ? 0 : np;
+    void* args[] = {&Nl, &ldp, &d_u, &d_p, &t, &d_l, &d_lo, &d_g};
+    ok = ok && hipModuleLaunchKernel(F.vjp, (unsigned)((N + 255) / 256), 1, 1, 256, 1, 1, 0, nullptr, args, nullptr) == hipSuccess;
+    ok = ok && hipMemcpy(lam_out, d_lo, sizeof(double) * (size_t)N * n, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(dp_rows, d_g, sizeof(double) * (size_t)N * np, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipModuleUnload(F.mod);
+    if (!ok) { g_create_error = "hipadj_affect_vjp: a HIP call failed"; return HIPADJ_ERR_HIP; }
+    return HIPADJ_OK;
+}
+
 extern "C" int hipadj_model_check(int32_t model_id) {
     std::vector<char> code; std::map<std::string, std::string> low;
     std::vector<std::string> exprs = {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 1, 7>" : "hipadj::k_interp<hipadj::UserModel, 1, 1>"};
+    if (user_has_affect(model_id)) { exprs.push_back("hipadj::k_user_affect<hipadj::UserModel>"); exprs.push_back("hipadj::k_user_affect_vjp<hipadj::UserModel>"); }
     if (const char* e = std::getenv("HIPADJ_CHECK_EXPRS")) {   // debugging hook: further ';'-separated kernel instantiations (ISA studies with HIPADJ_RTC_DUMP)
         std::string t(e); size_t a = 0;
         while (a <= t.size()) { const size_t b = t.find(';', a); const std::string x = t.substr(a, b == std::string::npos ? std::string::npos : b - a); if (!x.empty()) exprs.push_back(x); if (b == std::string::npos) break; a = b + 1; }

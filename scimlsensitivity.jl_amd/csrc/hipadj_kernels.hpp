@@ -634,4 +634,38 @@ static __global__ void k_soa_to_aos(const double* __restrict__ src, double* __re
     }
 }
 
+// ---- DiscreteCallback affects of runtime models (hipadj_model_set_affect; src/callback_tracking.jl:232-470) --------------------------------
+// u_out[i] = a(u[i], p, t): the affect applied to every trajectory's state at an event time.  ldp = 0: shared parameters, NP: per trajectory.
+template <class Mo>
+__global__ void __launch_bounds__(256) k_user_affect(long N, long ldp, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double uu[Mo::N], pp[Mo::NP], un[Mo::N];
+#pragma unroll
+    for (int j = 0; j < Mo::N; ++j) uu[j] = u[i * Mo::N + j];
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) pp[j] = p[i * ldp + j];
+    Mo::affect(un, uu, pp, t);
+#pragma unroll
+    for (int j = 0; j < Mo::N; ++j) out[i * Mo::N + j] = un[j];
+}
+// the reverse callback at an event (:330-452): lam_out = (da/du)^T lam evaluated at the LEFT state u, dp_rows[i] = (da/dp)^T lam
+template <class Mo>
+__global__ void __launch_bounds__(256) k_user_affect_vjp(long N, long ldp, const double* __restrict__ u, const double* __restrict__ p, double t, const double* __restrict__ lam,
+                                                         double* __restrict__ lam_out, double* __restrict__ dp_rows) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double uu[Mo::N], pp[Mo::NP], ll[Mo::N], lo[Mo::N], gp[Mo::NP];
+#pragma unroll
+    for (int j = 0; j < Mo::N; ++j) { uu[j] = u[i * Mo::N + j]; ll[j] = lam[i * Mo::N + j]; }
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) pp[j] = p[i * ldp + j];
+    Mo::affect_vjp_u(lo, ll, uu, pp, t);
+    Mo::affect_vjp_p(gp, ll, uu, pp, t);
+#pragma unroll
+    for (int j = 0; j < Mo::N; ++j) lam_out[i * Mo::N + j] = lo[j];
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) dp_rows[i * Mo::NP + j] = gp[j];
+}
+
 }  // namespace hipadj

@@ -40,6 +40,7 @@ struct UserModelSrc {
     std::string gfun;         // ... or the cost itself (hipadj_model_set_cost_function): gradients by dual numbers
     bool has_cost = false;
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
+    std::string affect;       // DiscreteCallback affect body (hipadj_model_set_affect): modifies un (pre-set to u) from u, p, t; empty = identity
     bool has_mm = false;      // constant non-singular mass matrix (hipadj_model_set_mass_matrix): minv = M^{-1}, row-major n x n
     double minv[64] = {0};
     int n = 0, np = 0, rev = 0;   // rev: bumped when the sources change, part of the code-cache key
@@ -175,6 +176,22 @@ inline std::string user_model_struct(const UserModelSrc& m) {
               << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { double w[N]; mm_invT(w, lam); vjp_u_raw(out, w, u, p, t); }\n"
               << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { double w[N]; mm_invT(w, lam); vjp_p_raw(out, w, u, p, t); }\n";
     }
+    // DiscreteCallback affect u <- a(u, p, t) (hipadj_model_set_affect): the body edits `un`, which starts as a copy of u; its VJPs by dual numbers
+    o << "    template <class real> HIPADJ_HD static void affect_t(real (&un)[N], const real (&u)[N], const real (&p)[NP], real t) {\n"
+      << "        (void)u; (void)p; (void)t;\n        for (int i = 0; i < N; ++i) un[i] = u[i];\n" << m.affect << "\n    }\n"
+      << "    HIPADJ_HD static void affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t) { affect_t<double>(un, u, p, t); }\n"
+      << "    HIPADJ_HD static void affect_vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+      << "        Dual<N> uu[N], pp[NP], dd[N];\n"
+      << "        for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n"
+      << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
+      << "        affect_t<Dual<N>>(dd, uu, pp, Dual<N>(t));\n"
+      << "        for (int j = 0; j < N; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n"
+      << "    HIPADJ_HD static void affect_vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+      << "        Dual<NP> uu[N], pp[NP], dd[N];\n"
+      << "        for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n"
+      << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
+      << "        affect_t<Dual<NP>>(dd, uu, pp, Dual<NP>(t));\n"
+      << "        for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n";
     o << "    // continuous cost attached with hipadj_model_set_cost[_function] (dgdu_continuous / dgdp_continuous); zero when absent\n";
     if (m.has_cost && !m.gfun.empty()) {
         // only g was given: its gradients by forward-mode dual numbers (the reference differentiates `g` with ForwardDiff when
@@ -387,6 +404,21 @@ inline int user_set_cost(int32_t model, const char* dgdu, const char* dgdp, std:
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
     R.models[idx].dgdu = dgdu; R.models[idx].dgdp = dgdp; R.models[idx].gfun.clear(); R.models[idx].has_cost = true; R.models[idx].rev++;
     return HIPADJ_OK;
+}
+// DiscreteCallback affect of a runtime model: `body` edits un[0..n) (a copy of u) from u, p, t with `real` locals; NULL / empty removes it
+inline int user_set_affect(int32_t model, const char* body, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_affect: unknown model id (affects are attached to runtime-registered models)"; return HIPADJ_ERR_INVALID_ARG; }
+    R.models[idx].affect = body ? body : ""; R.models[idx].rev++;
+    return HIPADJ_OK;
+}
+inline bool user_has_affect(int32_t model) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    return idx >= 0 && idx < (int)R.models.size() && !R.models[idx].affect.empty();
 }
 // ODEFunction(f; mass_matrix = M) for a runtime model: M row-major n x n, constant and non-singular; NULL removes it.
 // Singular M (semi-explicit DAE, src/adjoint_common.jl:117-135, 790-803) needs an implicit stepper: refused.

@@ -1,0 +1,123 @@
+"""DiscreteCallback at preset times with a state affect, composed on the host from per-piece device solves.
+
+The reference differentiates hybrid systems by tracking the callbacks of the forward solve and replaying them as reverse callbacks
+(src/callback_tracking.jl:232-470): at an event time the adjoint becomes  lam <- (da/du)' lam  (Jacobian of the affect at the LEFT state) and the
+parameter gradient receives  (da/dp)' lam.  Between two events nothing differs from an ordinary problem — so an event problem is a chain of ordinary
+handles: piece j integrates [e_j, e_{j+1}], the affect kernel (hipadj_affect_apply) maps its end state to the start state of piece j + 1; in reverse,
+du0 of piece j + 1 goes through hipadj_affect_vjp and enters piece j as one more cotangent at its end time.  Every sensealg, stepper and model
+family of the pieces is available unchanged; the hot kernels know nothing about events.
+
+    f = sa.DeviceFunction("lv_dose", 2, 4, body).set_affect("un[0] += 2.0;")
+    sol = sa.solve(ensprob, sa.Tsit5(), saveat=0.5, sensealg=sa.BacksolveAdjoint(), callback=sa.PresetTimeCallback([5.0]))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), dgdu_discrete=delta)
+
+Semantics (save_positions = (false, false), the form of test/Callbacks1/discrete_callbacks.jl:263-268): a save time that coincides with an event time
+holds the RIGHT limit — OrdinaryDiffEq applies the discrete callbacks of a step before its regular saveat save [upstream-recall]; event times outside
+(t0, t1) are ignored.  Not covered: ContinuousCallback (root finding and the implicit event-time corrections, :367-431), affects that change p,
+save_positions with a `true`."""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .problems import ODEProblem, EnsembleProblem, LsqShift
+
+
+@dataclass
+class EventSolution:
+    """What solve(..., callback=PresetTimeCallback(...)) returns: the pieces (each owning its device-resident forward solution), the saved states
+    assembled over all save times, and the left states at the events (needed by the reverse callbacks)."""
+    pieces: list                 # EnsembleSolution per piece, in time order
+    piece_cols: list             # per piece: indices into `t` of its own save times
+    edges: list                  # [t0, e_1, ..., e_k, t_end]
+    u_left: list                 # state at the end of piece j (before the affect), j < last
+    u: np.ndarray                # [N][M][n] = sol(ts), right limits at event times
+    t: np.ndarray
+    prob: object
+    alg: object
+    model_id: int
+    device: int
+    extra: dict = field(default_factory=dict)
+
+    def close(self):
+        for s in self.pieces:
+            s.engine.close()
+
+
+def _model_id(prob):
+    mid = _lib.MODEL[prob.f]
+    if mid < _lib.MODEL_USER_BASE:
+        raise ValueError("callback: affects are attached to runtime-registered models (DeviceFunction(...).set_affect(body))")
+    return mid
+
+
+def solve_with_events(solve, ts_of, ensprob, alg, callback, *, saveat=None, dt=None, device=0, dgdu_discrete=None, checkpoints=None, save_idxs=None,
+                      save_start=True, save_end=True, save_everystep=False, **kw):
+    if isinstance(ensprob, ODEProblem):
+        ensprob = EnsembleProblem(ensprob, ensprob.u0[None, :])
+    prob = ensprob.prob
+    if checkpoints is not None or save_idxs is not None or save_everystep:
+        raise ValueError("callback: `checkpoints`, `save_idxs` and `save_everystep` are not combined with event problems (the pieces use their defaults)")
+    mid = _model_id(prob)
+    t0, t1 = prob.tspan
+    ts = ts_of(prob.tspan, saveat, 0.0 if dt is None else dt, False, save_start, save_end)
+    if len(ts) == 0:
+        raise ValueError("callback: the event problem needs at least one save time (the loss lives there)")
+    ev = sorted({float(e) for e in callback.times if t0 < e < t1 and e <= ts[-1]})    # events after the last loss time cannot influence it
+    edges = [t0] + ev + [t1]
+    N = ensprob.u0.shape[0]
+    pieces, cols, u_left = [], [], []
+    u0 = ensprob.u0
+    out = None
+    for j in range(len(edges) - 1):
+        a, b = edges[j], edges[j + 1]
+        last = j == len(edges) - 2
+        own = [i for i, s in enumerate(ts) if (a <= s < b) or (last and s == b)]
+        sv = [ts[i] for i in own] + ([] if last else [b])          # the piece's end state feeds the affect
+        pj = EnsembleProblem(ODEProblem(prob.f, u0[0], (a, b), prob.p, prob.dims), u0, ensprob.p)
+        sol = solve(pj, alg, dt=dt, saveat=sv, device=device, dgdu_discrete=None, **kw)
+        pieces.append(sol); cols.append(own)
+        if out is None:
+            out = np.zeros((N, len(ts), sol.u.shape[2]))
+        for q, i in enumerate(own):
+            out[:, i, :] = sol.u[:, q, :]
+        if not last:
+            ul = np.ascontiguousarray(sol.u[:, -1, :])
+            u_left.append(ul)
+            u0 = _lib.affect_apply(mid, ul, ensprob.p, b, device=device)
+    return EventSolution(pieces=pieces, piece_cols=cols, edges=edges, u_left=u_left, u=out, t=np.asarray(ts), prob=ensprob, alg=alg, model_id=mid, device=device,
+                         extra=dict(dgdu_discrete=dgdu_discrete, callback=callback))
+
+
+def adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, *, t=None, dgdu_discrete=None, dgdp_discrete=None, **kw):
+    """(du0, dp) of an event problem: the pieces' reverse passes from the last to the first, chained by the reverse callbacks."""
+    if dgdp_discrete is not None:
+        raise ValueError("callback: dgdp_discrete is not supported for hybrid systems (the reference errors likewise, src/callback_tracking.jl:283-284)")
+    if t is not None and not np.array_equal(np.asarray(t, dtype=np.float64), sol.t):
+        raise ValueError("t must equal the save times of the forward solve")
+    dg = dgdu_discrete if dgdu_discrete is not None else sol.extra.get("dgdu_discrete")
+    N, M, n = sol.u.shape
+    if isinstance(dg, LsqShift):
+        delta = sol.u - dg.shift                                    # dgdu_discrete(out, u, p, t, i) = u - shift, at the saved (right-limit) states
+    elif dg is None:
+        raise ValueError("dgdu_discrete required (cotangents [N][M][n] or LsqShift)")
+    else:
+        delta = np.asarray(dg, dtype=np.float64).reshape(N, M, n)
+    p = sol.prob.p
+    shared = p.ndim == 1
+    npar = p.shape[-1]
+    dp = np.zeros(npar) if shared else np.zeros((N, npar))
+    lam_in = None
+    du0 = None
+    for j in range(len(sol.pieces) - 1, -1, -1):
+        own = sol.piece_cols[j]
+        cot = [delta[:, i, :] for i in own]
+        if j < len(sol.pieces) - 1:
+            cot.append(lam_in)                                       # the reverse callback's output enters at the piece's end time
+        dj = np.ascontiguousarray(np.stack(cot, axis=1))
+        du0, dpj = adjoint_sensitivities(sol.pieces[j], alg, t=sol.pieces[j].t, dgdu_discrete=dj, **kw)
+        dp = dp + np.asarray(dpj).reshape(dp.shape)
+        if j > 0:
+            lam_in, gp = _lib.affect_vjp(sol.model_id, sol.u_left[j - 1], p, sol.edges[j], du0, npar, device=sol.device)
+            dp = dp + (gp.sum(axis=0) if shared else gp)
+    return du0, dp

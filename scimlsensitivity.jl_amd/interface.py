@@ -77,7 +77,7 @@ def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
 
 def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
           device=0, time_segments=0, no_start=None, want_out=True, g=None, abstol=1e-6, reltol=1e-3, max_steps=0, save_idxs=None,
-          save_start=True, save_end=True, save_everystep=False):
+          save_start=True, save_end=True, save_everystep=False, callback=None):
     """Forward solve of an EnsembleProblem on the device.  The returned solution owns the device-resident
     interpolant tiles (Interpolating/Gauss/Quadrature) or checkpoints (Backsolve) the reverse pass consumes.
     `dgdu_discrete` may be given here already (LsqShift or None = cotangents) because the fused reverse kernel
@@ -90,6 +90,11 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     `save_start` / `save_end` / `save_everystep`: the forward solve's saving flags as _concrete_solve_adjoint reads them
     (`_save_times`); `no_start` defaults to the reference's `!save_start && t0 in ts` (src/concrete_solve.jl:962), which
     suppresses the loss jump at t0."""
+    if callback is not None:       # DiscreteCallback at preset times: a chain of ordinary pieces (events.py)
+        from . import events
+        return events.solve_with_events(solve, _save_times, ensprob, alg, callback, dt=dt, saveat=saveat, sensealg=sensealg, dgdu_discrete=dgdu_discrete, checkpoints=checkpoints,
+                                        device=device, time_segments=time_segments, g=g, abstol=abstol, reltol=reltol, max_steps=max_steps, save_idxs=save_idxs,
+                                        save_start=save_start, save_end=save_end, save_everystep=save_everystep)
     adaptive = isinstance(alg, Tsit5)
     if not adaptive and not isinstance(alg, RK4):
         raise ValueError("alg must be RK4() (fixed step) or Tsit5() (adaptive)")
@@ -151,6 +156,9 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_di
     [N][M][np] of dl_i/dp, or a callable (u_i [N][n], p, t_i, i) -> [N][np].  The reference adds it to the parameter part
     of the augmented state inside ReverseLossCallback (src/adjoint_common.jl:775-779); that part obeys mu' = -f_p^T lam,
     which does not contain mu, so the jumps commute with the integration and their sum is added to dp once, exactly."""
+    from . import events
+    if isinstance(sol, events.EventSolution):     # DiscreteCallback problem: the pieces' reverse passes chained by the reverse callbacks
+        return events.adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, t=t, dgdu_discrete=dgdu_discrete, dgdp_discrete=dgdp_discrete, g=g, **kwargs)
     if kwargs:
         raise TypeError(f"unsupported keyword(s) {sorted(kwargs)} (callbacks: SURVEY.md §8f)")
     if dgdp_discrete is not None:

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(sa):
     assert set(names) == set(_lib.DECLARED_SYMBOLS)
     for nm in names:
         assert hasattr(L, nm), nm
-    assert L.hipadj_version() == 103
+    assert L.hipadj_version() == 104
     assert L.hipadj_status_string(-2).decode().startswith("no usable HIP device")
 
 
@@ -209,6 +209,31 @@ def test_runtime_model_mass_matrix_registration():
     _lib.check_model(f.id)
 
 
+def test_runtime_model_affect_registration_and_loud_failure_without_a_device():
+    """DiscreteCallback affects (hipadj_model_set_affect): the affect and its dual-number VJPs compile for gfx950 with the model; the host-level
+    composition (events.py) calls hipadj_affect_apply / _vjp, which fail loudly without a device — no CPU fallback."""
+    import os
+    import user_models as UM
+    import scimlsensitivity_jl_amd as sa
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.LV
+    f = sa.DeviceFunction("lv_affect_cpu", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"]).set_affect("for (int i = 0; i < N; ++i) un[i] += p[1] / 8.0 * sin(u[i]);")
+    _lib.check_model(f.id)
+    bad = sa.DeviceFunction("lv_affect_bad_cpu", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"]).set_affect("un[0] += nope;")
+    with pytest.raises(_lib.HipadjError, match="undeclared identifier"):
+        _lib.check_model(bad.id)
+    with pytest.raises(_lib.HipadjError):
+        _lib.set_model_affect(_lib.MODEL["lorenz"], "un[0] += 1.0;")          # compiled-in models carry none
+    assert sa.PresetTimeCallback([3, 1.5]).times == (3.0, 1.5)
+    if not os.path.exists("/dev/kfd"):
+        with pytest.raises(_lib.HipadjError) as e:
+            _lib.affect_apply(f.id, np.ones((4, 2)), np.ones(4), 1.0)
+        assert e.value.status == -2
+        with pytest.raises(_lib.HipadjError) as e:
+            _lib.affect_vjp(f.id, np.ones((4, 2)), np.ones(4), 1.0, np.ones((4, 2)), 4)
+        assert e.value.status == -2
+
+
 def test_runtime_model_plans_like_a_lane_model():
     """A registered model goes through the same planner: segmentation only while (1+n)(n+np) columns fit the registers."""
     import emu as E
@@ -279,7 +304,7 @@ def test_c_host_compiles_against_the_header_and_fails_loudly_without_a_device(sa
     sa.load_library()
     exe = _build_host_demo(sa, tmp_path)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
-    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 103" in r.stdout
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 104" in r.stdout
 
 
 class _StubEngine:
