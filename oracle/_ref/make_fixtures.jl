@@ -85,6 +85,42 @@ for alg in ("INTERPOLATING_CKPT", "GAUSS_CKPT", "BACKSOLVE")
         checkpoints = [0.07, 0.3, 0.45, 1.25, 1.8], targets = "interval construction from an arbitrary checkpoint list (src/interpolating_adjoint.jl:54-58), Backsolve checkpoint callbacks (:523-546)"))
 end
 
+# (5) constant non-singular mass matrix (test/Core3/adjoint.jl:1315-1376): the reference's own test problem, mass-matrix solver Rodas4;
+#     pins the du0 convention (lam(t0), no M' factor) and the M' handling of every sensealg.  Checked by tests/test_reference_fixtures.py against
+#     the oracle with orc_set_mass_matrix (explicit stepper on M^-1 f: the fixture's tolerances are 1e-12, agreement is asserted at 1e-8).
+let
+    A = [1.0 2 3; 4 5 6; 7 8 9]; mm = -[1.0 2 4; 2 3 7; 1 3 41]
+    foo!(du, u, p, t) = (du .= A * u .+ p; du[2] += sum(p); nothing)
+    u0 = [1.0, 2.0, 3.0]; p = [1.0, 2.0, 3.0]; ts = collect(0:0.01:1)
+    prob = ODEProblem(ODEFunction(foo!, mass_matrix = mm), u0, (0.0, 1.0), p)
+    sol = solve(prob, Rodas4(), reltol = 1.0e-12, abstol = 1.0e-12)
+    dgone(out, u, p, t, i) = (out .= 1)
+    for (nm, sa) in (("INTERPOLATING", InterpolatingAdjoint()), ("BACKSOLVE_NOCKPT", BacksolveAdjoint(checkpointing = false)), ("GAUSS", GaussAdjoint()), ("QUADRATURE", QuadratureAdjoint(abstol = 1e-12, reltol = 1e-12)))
+        du0, dp = adjoint_sensitivities(sol, Rodas4(); t = ts, dgdu_discrete = dgone, abstol = 1.0e-12, reltol = 1.0e-12, sensealg = sa)
+        push!(cases, Dict("name" => "massmatrix_affine3_$nm", "kind" => "mass_matrix", "model" => "AFFINE3", "alg" => replace(nm, "_NOCKPT" => ""), "M" => [collect(mm[i, :]) for i in 1:3],
+                          "u0" => u0, "p" => p, "ts" => ts, "tspan" => [0.0, 1.0], "du0" => collect(du0), "dp" => vec(collect(dp)),
+                          "targets" => "du0 = lam(t0) of M' lam' = -J' lam (src/sensitivity_interface.jl:500), loss jumps divided by lu(M') (src/adjoint_common.jl:805-807)"))
+    end
+end
+# (6) DiscreteCallback at a preset time with a state affect (test/Callbacks1/discrete_callbacks.jl:263-268, save_positions = (false, false)): pins which
+#     value `saveat` stores AT the event time (events.py assumes the right limit) and the reverse callback lam <- (da/du)' lam, grad += (da/dp)' lam
+let
+    u0 = [1.0, 1.0]; p = [1.5, 1.0, 3.0, 1.0]; ts = collect(0.0:0.5:10.0)
+    prob = ODEProblem(lv!, u0, (0.0, 10.0), p)
+    for (nm, aff!) in (("dose", integ -> (integ.u[1] += 2.0)), ("sin", integ -> (integ.u .+= integ.p[2] / 8 * sin.(integ.u))), ("reset", integ -> (integ.u[1] = 2.0)))
+        cb = DiscreteCallback((u, t, integ) -> t == 5.0, aff!, save_positions = (false, false))
+        sol = solve(prob, Tsit5(); callback = cb, tstops = [5.0], abstol = 1e-10, reltol = 1e-10, saveat = ts)
+        for (an, sa) in (("INTERPOLATING", InterpolatingAdjoint(autojacvec = ReverseDiffVJP())), ("BACKSOLVE", BacksolveAdjoint(autojacvec = ReverseDiffVJP())), ("GAUSS", GaussAdjoint(autojacvec = ReverseDiffVJP())))
+            du0, dp = adjoint_sensitivities(sol, Tsit5(); t = ts, dgdu_discrete = dg, sensealg = sa, callback = cb, tstops = [5.0], abstol = 1e-10, reltol = 1e-10)
+            push!(cases, Dict("name" => "event_lv_$(nm)_$an", "kind" => "event", "affect" => nm, "alg" => an, "u0" => u0, "p" => p, "ts" => ts, "tspan" => [0.0, 10.0],
+                              "event_times" => [5.0], "abstol" => 1e-10, "reltol" => 1e-10, "saved_at_event" => collect(sol(5.0)), "out" => [collect(sol.u[i]) for i in 1:length(sol.t)],
+                              "du0" => collect(du0), "dp" => vec(collect(dp)),
+                              "targets" => "value saved AT an event time with save_positions = (false, false) (right limit assumed, scimlsensitivity.jl_amd/events.py), " *
+                                           "reverse callback of a DiscreteCallback (src/callback_tracking.jl:330-452)"))
+        end
+    end
+end
+
 open(joinpath(@__DIR__, "..", "..", "tests", "golden", "reference_fixtures.json"), "w") do io
     JSON.print(io, Dict("generator" => "oracle/_ref/make_fixtures.jl", "SciMLSensitivity" => string(pkgversion(SciMLSensitivity)),
                         "OrdinaryDiffEq" => string(pkgversion(OrdinaryDiffEq)), "julia" => string(VERSION), "cases" => cases), 1)
