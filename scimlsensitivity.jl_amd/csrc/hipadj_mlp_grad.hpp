@@ -347,22 +347,18 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
         // (with the output layer) and four backward passes with outer products per step.
         double y[D] = {xh[0], xh[1]};
         for (int k = g.S - 1; k >= 0; --k) {
-            double F1[D], F2[D], F3[D], F4[D], ys[D], ls[D], V1[D], V2[D], V3[D], V4[D];
-            mlpg_forward<H, true>(w, L, cx, y, h1, h2, F1);
-            mlpg_backward<H, true>(w, L, cx, lam, y, h1, h2, V1, dt / 6.0, true, false, A);
-            ys[0] = y[0] - 0.5 * dt * F1[0]; ys[1] = y[1] - 0.5 * dt * F1[1]; ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
-            mlpg_forward<H, true>(w, L, cx, ys, h1, h2, F2);
-            mlpg_backward<H, true>(w, L, cx, ls, ys, h1, h2, V2, dt / 3.0, true, false, A);
-            ys[0] = y[0] - 0.5 * dt * F2[0]; ys[1] = y[1] - 0.5 * dt * F2[1]; ls[0] = lam[0] + 0.5 * dt * V2[0]; ls[1] = lam[1] + 0.5 * dt * V2[1];
-            mlpg_forward<H, true>(w, L, cx, ys, h1, h2, F3);
-            mlpg_backward<H, true>(w, L, cx, ls, ys, h1, h2, V3, dt / 3.0, true, false, A);
-            ys[0] = y[0] - dt * F3[0]; ys[1] = y[1] - dt * F3[1]; ls[0] = lam[0] + dt * V3[0]; ls[1] = lam[1] + dt * V3[1];
-            mlpg_forward<H, true>(w, L, cx, ys, h1, h2, F4);
-            mlpg_backward<H, true>(w, L, cx, ls, ys, h1, h2, V4, dt / 6.0, true, false, A);
-            y[0] = y[0] - (dt / 6.0) * (F1[0] + 2.0 * (F2[0] + F3[0]) + F4[0]);
-            y[1] = y[1] - (dt / 6.0) * (F1[1] + 2.0 * (F2[1] + F3[1]) + F4[1]);
-            lam[0] = lam[0] + (dt / 6.0) * (V1[0] + 2.0 * (V2[0] + V3[0]) + V4[0]);
-            lam[1] = lam[1] + (dt / 6.0) * (V1[1] + 2.0 * (V2[1] + V3[1]) + V4[1]);
+            // the four stages as ONE rolled loop body (a = 0, 1/2, 1/2, 1; weights dt/6, dt/3, dt/3, dt/6): a quarter of the code and of the live
+            // ranges of the unrolled form, which spilled 868 bytes per lane to scratch
+            double Fp[D] = {0.0, 0.0}, Vp[D] = {0.0, 0.0}, Fs[D] = {0.0, 0.0}, Vs[D] = {0.0, 0.0};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double a = st == 0 ? 0.0 : (st == 3 ? dt : 0.5 * dt), wst = (st == 0 || st == 3) ? dt / 6.0 : dt / 3.0;
+                double ys[D] = {y[0] - a * Fp[0], y[1] - a * Fp[1]}, ls[D] = {lam[0] + a * Vp[0], lam[1] + a * Vp[1]};
+                mlpg_forward<H, true>(w, L, cx, ys, h1, h2, Fp);
+                mlpg_backward<H, true>(w, L, cx, ls, ys, h1, h2, Vp, wst, true, false, A);
+                Fs[0] += wst * Fp[0]; Fs[1] += wst * Fp[1]; Vs[0] += wst * Vp[0]; Vs[1] += wst * Vp[1];
+            }
+            y[0] -= Fs[0]; y[1] -= Fs[1]; lam[0] += Vs[0]; lam[1] += Vs[1];
             if (ckpt_of_knot && ckpt_of_knot[k] >= 0) { knot(k, xl, fl); y[0] = xl[0]; y[1] = xl[1]; }
             const int s = save_of_knot[k];
             if (s >= 0 && !(g.no_start && s == 0)) jump(s, y, lam);
@@ -378,11 +374,14 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
         if ((ALG == 2 || ALG == 3) && have_v) { V1[0] = Vn[0]; V1[1] = Vn[1]; }
         else mlpg_backward<H, ALG == 0>(w, L, cx, lam, xh, h1e, h2e, V1, dt / 6.0, false, true, A);   // after_fwd: the prologue's (or a node's backward-free) forward pass may precede
         // stages 2, 3 at the Hermite midpoint (same activations)
-        ls[0] = lam[0] + 0.5 * dt * V1[0]; ls[1] = lam[1] + 0.5 * dt * V1[1];
         mlpg_forward<H>(w, L, cx, xm, h1, h2);
-        mlpg_backward<H, ALG == 0>(w, L, cx, ls, xm, h1, h2, V2, dt / 3.0, true, true, A);
-        ls[0] = lam[0] + 0.5 * dt * V2[0]; ls[1] = lam[1] + 0.5 * dt * V2[1];
-        mlpg_backward<H, ALG == 0>(w, L, cx, ls, xm, h1, h2, V3, dt / 3.0, false, false, A);
+        V3[0] = V1[0]; V3[1] = V1[1];
+#pragma unroll 1
+        for (int s23 = 0; s23 < 2; ++s23) {                   // one rolled body for both (less code, fewer live ranges): ls = lam + dt/2 * (the previous stage's V);
+            ls[0] = lam[0] + 0.5 * dt * V3[0]; ls[1] = lam[1] + 0.5 * dt * V3[1];     // the tile holds H1 (and a forward pass precedes) only the first time
+            V2[0] = V3[0]; V2[1] = V3[1];                     // after the loop: V2 = stage 2's, V3 = stage 3's
+            mlpg_backward<H, ALG == 0>(w, L, cx, ls, xm, h1, h2, V3, dt / 3.0, s23 == 0, s23 == 0, A);
+        }
         // stage 4 at x_lo
         ls[0] = lam[0] + dt * V3[0]; ls[1] = lam[1] + dt * V3[1];
         mlpg_forward<H>(w, L, cx, xl, h1e, h2e);
@@ -403,8 +402,8 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
                     rec[2 * nB + (long)j * g.B + col] = lam[j]; rec[3 * nB + (long)j * g.B + col] = -V5[j];
                 }
             }
-#pragma unroll
-            for (int nq = 0; nq < (ALG == 2 ? 2 : 0); ++nq) {
+#pragma unroll 1
+            for (int nq = 0; nq < (ALG == 2 ? 2 : 0); ++nq) {           // rolled: one copy of the node's two passes (fewer live ranges, less scratch)
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
                 double lg[D], yg[D];
 #pragma unroll
