@@ -180,18 +180,21 @@ int hipadj_model_set_cost_function(int32_t model_id, const char *g_body);
  * A singular M (semi-explicit DAE, src/adjoint_common.jl:117-135, 790-803) needs an implicit stepper: HIPADJ_ERR_UNSUPPORTED.
  * Handles created earlier keep the matrix they were created with. */
 int hipadj_model_set_mass_matrix(int32_t model_id, const double *M);
-/* DiscreteCallback at preset times with a state affect  u <- a(u, p, t)  (test/Callbacks1/discrete_callbacks.jl:260-330; the reverse pass of
- * src/callback_tracking.jl:232-470 for a DiscreteCallback: lam <- (da/du)' lam at the LEFT state, grad += (da/dp)' lam).
- * affect_body edits un[0..n) — which starts as a copy of u — from u, p, t (declare locals `real`: the two VJPs are generated by forward-mode dual
- * numbers).  An event problem is composed on the host from per-piece solves (the spans between consecutive event times are ordinary handles):
- * hipadj_affect_apply maps the end state of a piece to the start state of the next, hipadj_affect_vjp maps du0 of the upper piece to the extra
- * cotangent at the end of the lower one and returns the parameter term (per trajectory).  Host pointers, synchronous; u, lam, out: [N][n];
- * p: [np] (p_shared) or [N][np]; dp_rows: [N][np].  Not covered: ContinuousCallback (root finding + the implicit event-time corrections),
- * affects that change p, save_positions other than (false, false) — the host mirror defines the value saved AT an event time as the right limit. */
+/* DiscreteCallback at preset times with an affect  (u, p) <- a(u, p, t)  (test/Callbacks1/discrete_callbacks.jl:260-330, incl. the parameter-changing
+ * case :303-312; the reverse pass of src/callback_tracking.jl:232-470 for a DiscreteCallback: lam <- (da/du)' lam at the LEFT state, grad += (da/dp)' lam).
+ * affect_body edits un[0..n) and / or pn[0..np) — which start as copies of u and p — from u, p, t (declare locals `real`: the Jacobian products are
+ * generated by forward-mode dual numbers).  An event problem is composed on the host from per-piece solves (the spans between consecutive event times
+ * are ordinary handles): hipadj_affect_apply maps the end state (and parameters) of a piece to the start state (and parameters) of the next;
+ * hipadj_affect_vjp is the reverse callback for the map (u, p) -> (un, pn):
+ *     lam_out = (dun/du)' lam + (dpn/du)' gp,      gp_out = (dun/dp)' lam + (dpn/dp)' gp
+ * with lam = du0 of the upper piece and gp [N][np] = the gradient with respect to the parameters after the event of everything later in time
+ * (an affect that leaves p alone: gp_out = (dun/dp)' lam + gp).  Host pointers, synchronous; u, lam, out: [N][n]; p: [np] (p_shared) or [N][np];
+ * p_out (may be NULL), gp, gp_out: [N][np].  Not covered: ContinuousCallback (root finding + the implicit event-time corrections), save_positions
+ * other than (false, false) — the host mirror defines the value saved AT an event time as the right limit. */
 int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
-int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, double *out);
+int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, double *out, double *p_out);
 int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, const double *lam,
-                      double *lam_out, double *dp_rows);
+                      const double *gp, double *lam_out, double *gp_out);
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
  * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
 int hipadj_model_check(int32_t model_id);

@@ -192,7 +192,7 @@ set_mass_matrix!(m::DeviceModel, M) = set_mass_matrix!(m.id, m.n, M)
     set_affect!(model, body)            # body === nothing removes it
 
 The `affect!` of a `DiscreteCallback` at preset times as device text (test/Callbacks1/discrete_callbacks.jl:260-330): `body` edits `un` — which starts
-as a copy of `u` — from `u`, `p`, `t` (locals `real`; the reverse callback's two VJPs are generated by dual numbers).  An event problem is a chain
+as a copy of `u` — and / or `pn` (a copy of `p`) from `u`, `p`, `t` (locals `real`; the reverse callback's Jacobian products are generated by dual numbers).  An event problem is a chain
 of ordinary handles, one per span between consecutive event times: `affect_apply` maps the end state of a piece to the start state of the next,
 `affect_vjp` maps `du0` of the upper piece to the extra cotangent at the end of the lower one and returns the parameter term
 (src/callback_tracking.jl:330-452 for a DiscreteCallback).  The Python host mirror (`scimlsensitivity.jl_amd/events.py`) is the executed reference of
@@ -204,16 +204,17 @@ function set_affect!(m::DeviceModel, body)
     return m
 end
 function affect_apply(m::DeviceModel, u::Matrix{Float64}, p::Union{Vector{Float64}, Matrix{Float64}}, t::Real; device::Integer = 0)
-    out = similar(u)                                       # (n, N) column-major == the ABI's [N][n]
-    check(ccall(sym(:hipadj_affect_apply), Cint, (Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}),
-                m.id, Int32(device), size(u, 2), u, p, Int32(p isa Vector), Float64(t), out))
-    return out
+    out = similar(u); pout = Matrix{Float64}(undef, m.np, size(u, 2))     # (n, N) / (np, N) column-major == the ABI's [N][n] / [N][np]
+    check(ccall(sym(:hipadj_affect_apply), Cint, (Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ptr{Float64}),
+                m.id, Int32(device), size(u, 2), u, p, Int32(p isa Vector), Float64(t), out, pout))
+    return out, pout
 end
-function affect_vjp(m::DeviceModel, u::Matrix{Float64}, p::Union{Vector{Float64}, Matrix{Float64}}, t::Real, lam::Matrix{Float64}; device::Integer = 0)
-    lam_out = similar(lam); gp = Matrix{Float64}(undef, m.np, size(u, 2))
-    check(ccall(sym(:hipadj_affect_vjp), Cint, (Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                m.id, Int32(device), size(u, 2), u, p, Int32(p isa Vector), Float64(t), lam, lam_out, gp))
-    return lam_out, gp
+"`(lam_out, gp_out)` of the reverse callback for the map `(u, p) -> (un, pn)`; `gp` `(np, N)`: gradient w.r.t. the parameters after the event of everything later in time"
+function affect_vjp(m::DeviceModel, u::Matrix{Float64}, p::Union{Vector{Float64}, Matrix{Float64}}, t::Real, lam::Matrix{Float64}, gp::Matrix{Float64}; device::Integer = 0)
+    lam_out = similar(lam); gp_out = similar(gp)
+    check(ccall(sym(:hipadj_affect_vjp), Cint, (Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                m.id, Int32(device), size(u, 2), u, p, Int32(p isa Vector), Float64(t), lam, gp, lam_out, gp_out))
+    return lam_out, gp_out
 end
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -104,9 +104,9 @@ def load():
     L.hipadj_model_set_cost_function.argtypes = [C.c_int32, C.c_char_p]
     L.hipadj_model_set_mass_matrix.argtypes = [C.c_int32, C.POINTER(C.c_double)]
     L.hipadj_model_set_affect.argtypes = [C.c_int32, C.c_char_p]
-    L.hipadj_affect_apply.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double)]
+    L.hipadj_affect_apply.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.hipadj_affect_vjp.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double),
-                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.hipadj_comm_unique_id.argtypes = [C.c_char_p]
     L.hipadj_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.hipadj_comm_attach.argtypes = [vp, vp]
@@ -154,28 +154,30 @@ def set_model_affect(model_id, body):
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
 
 
-def affect_apply(model_id, u, p, t, device=0):
-    """hipadj_affect_apply: u_out[i] = a(u[i], p, t) on the device; u [N][n], p [np] or [N][np] (host arrays in and out)."""
+def affect_apply(model_id, u, p, t, npar, device=0):
+    """hipadj_affect_apply: (u_out[i], p_out[i]) = a(u[i], p, t) on the device; u [N][n], p [np] or [N][np] (host arrays in and out; p_out [N][np])."""
     import numpy as np
     L = load()
     u = np.ascontiguousarray(u, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
-    out = np.empty_like(u)
+    out = np.empty_like(u); pout = np.empty((u.shape[0], int(npar)))
     dp_ = C.POINTER(C.c_double)
-    rc = L.hipadj_affect_apply(int(model_id), int(device), u.shape[0], u.ctypes.data_as(dp_), p.ctypes.data_as(dp_), int(p.ndim == 1), float(t), out.ctypes.data_as(dp_))
+    rc = L.hipadj_affect_apply(int(model_id), int(device), u.shape[0], u.ctypes.data_as(dp_), p.ctypes.data_as(dp_), int(p.ndim == 1), float(t), out.ctypes.data_as(dp_),
+                               pout.ctypes.data_as(dp_))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
-    return out
+    return out, pout
 
 
-def affect_vjp(model_id, u, p, t, lam, npar, device=0):
-    """hipadj_affect_vjp: ((da/du)^T lam, (da/dp)^T lam per trajectory) at the left state u."""
+def affect_vjp(model_id, u, p, t, lam, gp, device=0):
+    """hipadj_affect_vjp: the reverse callback of the map (u, p) -> (un, pn) at the left state: (lam_out, gp_out) from (lam, gp [N][np])."""
     import numpy as np
     L = load()
     u = np.ascontiguousarray(u, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64); lam = np.ascontiguousarray(lam, dtype=np.float64)
-    lo = np.empty_like(u); g = np.empty((u.shape[0], int(npar)))
+    gp = np.ascontiguousarray(gp, dtype=np.float64)
+    lo = np.empty_like(u); g = np.empty_like(gp)
     dp_ = C.POINTER(C.c_double)
     rc = L.hipadj_affect_vjp(int(model_id), int(device), u.shape[0], u.ctypes.data_as(dp_), p.ctypes.data_as(dp_), int(p.ndim == 1), float(t), lam.ctypes.data_as(dp_),
-                             lo.ctypes.data_as(dp_), g.ctypes.data_as(dp_))
+                             gp.ctypes.data_as(dp_), lo.ctypes.data_as(dp_), g.ctypes.data_as(dp_))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
     return lo, g

@@ -90,7 +90,7 @@ int affect_prologue(int32_t model, int32_t device, int64_t N, int32_t& n, int32_
 }
 }  // namespace
 
-extern "C" int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double* u, const double* p, int32_t p_shared, double t, double* out) {
+extern "C" int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double* u, const double* p, int32_t p_shared, double t, double* out, double* p_out) {
     if (!u || !p || !out) { g_create_error = "hipadj_affect_apply: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
     int32_t n = 0, np = 0;
     { const int rc = affect_prologue(model_id, device, N, n, np, g_create_error); if (rc != HIPADJ_OK) return rc; }
@@ -98,30 +98,32 @@ extern "C" int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, 
     { const int rc = affect_functions(model_id, F, g_create_error); if (rc != HIPADJ_OK) return rc; }
     bool ok = true; DevBufs B;
     double* d_u = B.get((size_t)N * n, u, ok); double* d_p = B.get(p_shared ? (size_t)np : (size_t)N * np, p, ok); double* d_o = B.get((size_t)N * n, nullptr, ok);
+    double* d_po = B.get((size_t)N * np, nullptr, ok);
     long Nl = (long)N, ldp = p_shared ? 0 : np;
-    void* args[] = {&Nl, &ldp, &d_u, &d_p, &t, &d_o};
+    void* args[] = {&Nl, &ldp, &d_u, &d_p, &t, &d_o, &d_po};
     ok = ok && hipModuleLaunchKernel(F.apply, (unsigned)((N + 255) / 256), 1, 1, 256, 1, 1, 0, nullptr, args, nullptr) == hipSuccess;
     ok = ok && hipMemcpy(out, d_o, sizeof(double) * (size_t)N * n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (p_out) ok = ok && hipMemcpy(p_out, d_po, sizeof(double) * (size_t)N * np, hipMemcpyDeviceToHost) == hipSuccess;
     (void)hipModuleUnload(F.mod);
     if (!ok) { g_create_error = "hipadj_affect_apply: a HIP call failed"; return HIPADJ_ERR_HIP; }
     return HIPADJ_OK;
 }
 
 extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double* u, const double* p, int32_t p_shared, double t, const double* lam,
-                                 double* lam_out, double* dp_rows) {
-    if (!u || !p || !lam || !lam_out || !dp_rows) { g_create_error = "hipadj_affect_vjp: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+                                 const double* gp, double* lam_out, double* gp_out) {
+    if (!u || !p || !lam || !gp || !lam_out || !gp_out) { g_create_error = "hipadj_affect_vjp: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
     int32_t n = 0, np = 0;
     { const int rc = affect_prologue(model_id, device, N, n, np, g_create_error); if (rc != HIPADJ_OK) return rc; }
     AffectFns F;
     { const int rc = affect_functions(model_id, F, g_create_error); if (rc != HIPADJ_OK) return rc; }
     bool ok = true; DevBufs B;
     double* d_u = B.get((size_t)N * n, u, ok); double* d_p = B.get(p_shared ? (size_t)np : (size_t)N * np, p, ok); double* d_l = B.get((size_t)N * n, lam, ok);
-    double* d_lo = B.get((size_t)N * n, nullptr, ok); double* d_g = B.get((size_t)N * np, nullptr, ok);
+    double* d_gi = B.get((size_t)N * np, gp, ok); double* d_lo = B.get((size_t)N * n, nullptr, ok); double* d_g = B.get((size_t)N * np, nullptr, ok);
     long Nl = (long)N, ldp = p_shared ? 0 : np;
-    void* args[] = {&Nl, &ldp, &d_u, &d_p, &t, &d_l, &d_lo, &d_g};
+    void* args[] = {&Nl, &ldp, &d_u, &d_p, &t, &d_l, &d_gi, &d_lo, &d_g};
     ok = ok && hipModuleLaunchKernel(F.vjp, (unsigned)((N + 255) / 256), 1, 1, 256, 1, 1, 0, nullptr, args, nullptr) == hipSuccess;
     ok = ok && hipMemcpy(lam_out, d_lo, sizeof(double) * (size_t)N * n, hipMemcpyDeviceToHost) == hipSuccess;
-    ok = ok && hipMemcpy(dp_rows, d_g, sizeof(double) * (size_t)N * np, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(gp_out, d_g, sizeof(double) * (size_t)N * np, hipMemcpyDeviceToHost) == hipSuccess;
     (void)hipModuleUnload(F.mod);
     if (!ok) { g_create_error = "hipadj_affect_vjp: a HIP call failed"; return HIPADJ_ERR_HIP; }
     return HIPADJ_OK;

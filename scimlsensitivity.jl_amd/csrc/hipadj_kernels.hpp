@@ -635,37 +635,43 @@ static __global__ void k_soa_to_aos(const double* __restrict__ src, double* __re
 }
 
 // ---- DiscreteCallback affects of runtime models (hipadj_model_set_affect; src/callback_tracking.jl:232-470) --------------------------------
-// u_out[i] = a(u[i], p, t): the affect applied to every trajectory's state at an event time.  ldp = 0: shared parameters, NP: per trajectory.
+// (u_out[i], p_out[i]) = a(u[i], p, t): the affect applied to every trajectory's state (and, for affects that edit `pn`, its parameters) at an
+// event time.  ldp = 0: shared parameters, NP: per trajectory; p_out is always per trajectory [N][NP].
 template <class Mo>
-__global__ void __launch_bounds__(256) k_user_affect(long N, long ldp, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_user_affect(long N, long ldp, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ out,
+                                                     double* __restrict__ p_out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    double uu[Mo::N], pp[Mo::NP], un[Mo::N];
+    double uu[Mo::N], pp[Mo::NP], un[Mo::N], pn[Mo::NP];
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) uu[j] = u[i * Mo::N + j];
 #pragma unroll
     for (int j = 0; j < Mo::NP; ++j) pp[j] = p[i * ldp + j];
-    Mo::affect(un, uu, pp, t);
+    Mo::affect(un, pn, uu, pp, t);
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) out[i * Mo::N + j] = un[j];
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) p_out[i * Mo::NP + j] = pn[j];
 }
-// the reverse callback at an event (:330-452): lam_out = (da/du)^T lam evaluated at the LEFT state u, dp_rows[i] = (da/dp)^T lam
+// the reverse callback at an event (:330-452), for the map (u, p) -> (un, pn) at the LEFT state:
+//   lam_out = (dun/du)^T lam + (dpn/du)^T gp,   gp_out = (dun/dp)^T lam + (dpn/dp)^T gp
+// gp [N][NP]: the gradient with respect to the parameters AFTER the event (of everything later in time); an affect that leaves p alone has
+// dpn/dp = I, dpn/du = 0, i.e. gp_out = (dun/dp)^T lam + gp.
 template <class Mo>
 __global__ void __launch_bounds__(256) k_user_affect_vjp(long N, long ldp, const double* __restrict__ u, const double* __restrict__ p, double t, const double* __restrict__ lam,
-                                                         double* __restrict__ lam_out, double* __restrict__ dp_rows) {
+                                                         const double* __restrict__ gp, double* __restrict__ lam_out, double* __restrict__ gp_out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    double uu[Mo::N], pp[Mo::NP], ll[Mo::N], lo[Mo::N], gp[Mo::NP];
+    double uu[Mo::N], pp[Mo::NP], ll[Mo::N], gg[Mo::NP], lo[Mo::N], go[Mo::NP];
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) { uu[j] = u[i * Mo::N + j]; ll[j] = lam[i * Mo::N + j]; }
 #pragma unroll
-    for (int j = 0; j < Mo::NP; ++j) pp[j] = p[i * ldp + j];
-    Mo::affect_vjp_u(lo, ll, uu, pp, t);
-    Mo::affect_vjp_p(gp, ll, uu, pp, t);
+    for (int j = 0; j < Mo::NP; ++j) { pp[j] = p[i * ldp + j]; gg[j] = gp[i * Mo::NP + j]; }
+    Mo::affect_vjp(lo, go, ll, gg, uu, pp, t);
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) lam_out[i * Mo::N + j] = lo[j];
 #pragma unroll
-    for (int j = 0; j < Mo::NP; ++j) dp_rows[i * Mo::NP + j] = gp[j];
+    for (int j = 0; j < Mo::NP; ++j) gp_out[i * Mo::NP + j] = go[j];
 }
 
 }  // namespace hipadj

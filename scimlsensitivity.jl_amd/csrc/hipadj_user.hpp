@@ -176,22 +176,22 @@ inline std::string user_model_struct(const UserModelSrc& m) {
               << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { double w[N]; mm_invT(w, lam); vjp_u_raw(out, w, u, p, t); }\n"
               << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { double w[N]; mm_invT(w, lam); vjp_p_raw(out, w, u, p, t); }\n";
     }
-    // DiscreteCallback affect u <- a(u, p, t) (hipadj_model_set_affect): the body edits `un`, which starts as a copy of u; its VJPs by dual numbers
-    o << "    template <class real> HIPADJ_HD static void affect_t(real (&un)[N], const real (&u)[N], const real (&p)[NP], real t) {\n"
-      << "        (void)u; (void)p; (void)t;\n        for (int i = 0; i < N; ++i) un[i] = u[i];\n" << m.affect << "\n    }\n"
-      << "    HIPADJ_HD static void affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t) { affect_t<double>(un, u, p, t); }\n"
-      << "    HIPADJ_HD static void affect_vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
-      << "        Dual<N> uu[N], pp[NP], dd[N];\n"
-      << "        for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n"
-      << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
-      << "        affect_t<Dual<N>>(dd, uu, pp, Dual<N>(t));\n"
-      << "        for (int j = 0; j < N; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n"
-      << "    HIPADJ_HD static void affect_vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
-      << "        Dual<NP> uu[N], pp[NP], dd[N];\n"
-      << "        for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n"
-      << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
-      << "        affect_t<Dual<NP>>(dd, uu, pp, Dual<NP>(t));\n"
-      << "        for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n";
+    // DiscreteCallback affect (u, p) <- a(u, p, t) (hipadj_model_set_affect): the body edits `un` and / or `pn`, which start as copies of u and p;
+    // the reverse callback's products with both Jacobians by forward-mode dual numbers (one pass seeded on u, one on p)
+    o << "    template <class real> HIPADJ_HD static void affect_t(real (&un)[N], real (&pn)[NP], const real (&u)[N], const real (&p)[NP], real t) {\n"
+      << "        (void)u; (void)p; (void)t;\n        for (int i = 0; i < N; ++i) un[i] = u[i];\n        for (int i = 0; i < NP; ++i) pn[i] = p[i];\n" << m.affect << "\n    }\n"
+      << "    HIPADJ_HD static void affect(double (&un)[N], double (&pn)[NP], const double (&u)[N], const double (&p)[NP], double t) { affect_t<double>(un, pn, u, p, t); }\n"
+      << "    HIPADJ_HD static void affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&gp)[NP], const double (&u)[N], const double (&p)[NP], double t) {\n"
+      << "        {   Dual<N> uu[N], pp[NP], du_[N], dp_[NP];\n"
+      << "            for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n"
+      << "            for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
+      << "            affect_t<Dual<N>>(du_, dp_, uu, pp, Dual<N>(t));\n"
+      << "            for (int j = 0; j < N; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * du_[i].d[j]; for (int k = 0; k < NP; ++k) s += gp[k] * dp_[k].d[j]; lo[j] = s; } }\n"
+      << "        {   Dual<NP> uu[N], pp[NP], du_[N], dp_[NP];\n"
+      << "            for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n"
+      << "            for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
+      << "            affect_t<Dual<NP>>(du_, dp_, uu, pp, Dual<NP>(t));\n"
+      << "            for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * du_[i].d[j]; for (int k = 0; k < NP; ++k) s += gp[k] * dp_[k].d[j]; go[j] = s; } }\n    }\n";
     o << "    // continuous cost attached with hipadj_model_set_cost[_function] (dgdu_continuous / dgdp_continuous); zero when absent\n";
     if (m.has_cost && !m.gfun.empty()) {
         // only g was given: its gradients by forward-mode dual numbers (the reference differentiates `g` with ForwardDiff when

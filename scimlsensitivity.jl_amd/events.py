@@ -13,8 +13,9 @@ family of the pieces is available unchanged; the hot kernels know nothing about 
 
 Semantics (save_positions = (false, false), the form of test/Callbacks1/discrete_callbacks.jl:263-268): a save time that coincides with an event time
 holds the RIGHT limit — OrdinaryDiffEq applies the discrete callbacks of a step before its regular saveat save [upstream-recall]; event times outside
-(t0, t1) are ignored.  Not covered: ContinuousCallback (root finding and the implicit event-time corrections, :367-431), affects that change p,
-save_positions with a `true`."""
+(t0, t1) are ignored.  An affect may also edit the parameters (`pn`, test/Callbacks1/discrete_callbacks.jl:303-312): the pieces after such an event
+run with per-trajectory parameters and the reverse callbacks carry the gradient with respect to the later parameters back through d(pn)/d(u, p).
+Not covered: ContinuousCallback (root finding and the implicit event-time corrections, :367-431), save_positions with a `true`."""
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -31,6 +32,7 @@ class EventSolution:
     piece_cols: list             # per piece: indices into `t` of its own save times
     edges: list                  # [t0, e_1, ..., e_k, t_end]
     u_left: list                 # state at the end of piece j (before the affect), j < last
+    p_piece: list                # parameters of piece j, [N][np] (they change where an affect edits pn)
     u: np.ndarray                # [N][M][n] = sol(ts), right limits at event times
     t: np.ndarray
     prob: object
@@ -66,15 +68,18 @@ def solve_with_events(solve, ts_of, ensprob, alg, callback, *, saveat=None, dt=N
     ev = sorted({float(e) for e in callback.times if t0 < e < t1 and e <= ts[-1]})    # events after the last loss time cannot influence it
     edges = [t0] + ev + [t1]
     N = ensprob.u0.shape[0]
-    pieces, cols, u_left = [], [], []
-    u0 = ensprob.u0
+    pieces, cols, u_left, p_piece = [], [], [], []
+    npar = ensprob.p.shape[-1]
+    # every piece runs with per-trajectory parameters: the reverse callbacks need the parameter gradient per trajectory, and an affect may edit pn
+    u0, pcur = ensprob.u0, np.ascontiguousarray(np.broadcast_to(ensprob.p, (N, npar)))
     out = None
     for j in range(len(edges) - 1):
         a, b = edges[j], edges[j + 1]
         last = j == len(edges) - 2
         own = [i for i, s in enumerate(ts) if (a <= s < b) or (last and s == b)]
         sv = [ts[i] for i in own] + ([] if last else [b])          # the piece's end state feeds the affect
-        pj = EnsembleProblem(ODEProblem(prob.f, u0[0], (a, b), prob.p, prob.dims), u0, ensprob.p)
+        pj = EnsembleProblem(ODEProblem(prob.f, u0[0], (a, b), pcur[0], prob.dims), u0, pcur)
+        p_piece.append(pcur)
         sol = solve(pj, alg, dt=dt, saveat=sv, device=device, dgdu_discrete=None, **kw)
         pieces.append(sol); cols.append(own)
         if out is None:
@@ -84,8 +89,8 @@ def solve_with_events(solve, ts_of, ensprob, alg, callback, *, saveat=None, dt=N
         if not last:
             ul = np.ascontiguousarray(sol.u[:, -1, :])
             u_left.append(ul)
-            u0 = _lib.affect_apply(mid, ul, ensprob.p, b, device=device)
-    return EventSolution(pieces=pieces, piece_cols=cols, edges=edges, u_left=u_left, u=out, t=np.asarray(ts), prob=ensprob, alg=alg, model_id=mid, device=device,
+            u0, pcur = _lib.affect_apply(mid, ul, pcur, b, npar, device=device)
+    return EventSolution(pieces=pieces, piece_cols=cols, edges=edges, u_left=u_left, p_piece=p_piece, u=out, t=np.asarray(ts), prob=ensprob, alg=alg, model_id=mid, device=device,
                          extra=dict(dgdu_discrete=dgdu_discrete, callback=callback))
 
 
@@ -103,10 +108,9 @@ def adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, *, t=None, dgd
         raise ValueError("dgdu_discrete required (cotangents [N][M][n] or LsqShift)")
     else:
         delta = np.asarray(dg, dtype=np.float64).reshape(N, M, n)
-    p = sol.prob.p
-    shared = p.ndim == 1
-    npar = p.shape[-1]
-    dp = np.zeros(npar) if shared else np.zeros((N, npar))
+    shared = sol.prob.p.ndim == 1
+    npar = sol.prob.p.shape[-1]
+    gp = np.zeros((N, npar))          # gradient with respect to the CURRENT piece's parameters, per trajectory, of everything later in time
     lam_in = None
     du0 = None
     for j in range(len(sol.pieces) - 1, -1, -1):
@@ -116,8 +120,7 @@ def adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, *, t=None, dgd
             cot.append(lam_in)                                       # the reverse callback's output enters at the piece's end time
         dj = np.ascontiguousarray(np.stack(cot, axis=1))
         du0, dpj = adjoint_sensitivities(sol.pieces[j], alg, t=sol.pieces[j].t, dgdu_discrete=dj, **kw)
-        dp = dp + np.asarray(dpj).reshape(dp.shape)
-        if j > 0:
-            lam_in, gp = _lib.affect_vjp(sol.model_id, sol.u_left[j - 1], p, sol.edges[j], du0, npar, device=sol.device)
-            dp = dp + (gp.sum(axis=0) if shared else gp)
-    return du0, dp
+        gp = gp + np.asarray(dpj).reshape(N, npar)
+        if j > 0:                                                    # reverse callback of the event between piece j - 1 and piece j
+            lam_in, gp = _lib.affect_vjp(sol.model_id, sol.u_left[j - 1], sol.p_piece[j - 1], sol.edges[j], du0, gp, device=sol.device)
+    return du0, (gp.sum(axis=0) if shared else gp)

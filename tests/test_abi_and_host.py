@@ -227,10 +227,10 @@ def test_runtime_model_affect_registration_and_loud_failure_without_a_device():
     assert sa.PresetTimeCallback([3, 1.5]).times == (3.0, 1.5)
     if not os.path.exists("/dev/kfd"):
         with pytest.raises(_lib.HipadjError) as e:
-            _lib.affect_apply(f.id, np.ones((4, 2)), np.ones(4), 1.0)
+            _lib.affect_apply(f.id, np.ones((4, 2)), np.ones(4), 1.0, 4)
         assert e.value.status == -2
         with pytest.raises(_lib.HipadjError) as e:
-            _lib.affect_vjp(f.id, np.ones((4, 2)), np.ones(4), 1.0, np.ones((4, 2)), 4)
+            _lib.affect_vjp(f.id, np.ones((4, 2)), np.ones(4), 1.0, np.ones((4, 2)), np.zeros((4, 4)))
         assert e.value.status == -2
 
 

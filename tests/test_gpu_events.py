@@ -12,12 +12,17 @@ pytestmark = pytest.mark.gpu
 _reg = {}
 
 AFFECTS = {
-    # name: (device text, numpy affect (u [N][n], p [N][np] -> u), numpy VJP (u, p, lam) -> (lam_out, gp [N][np]))
-    "dose": ("un[0] += 2.0;", lambda u, p: u + np.array([2.0, 0.0]), lambda u, p, l: (l.copy(), np.zeros_like(p))),
+    # name: (device text, numpy affect (u [N][n], p [N][np]) -> (un, pn), numpy reverse callback (u, p, lam, gp) -> (lam_out, gp_out))
+    "dose": ("un[0] += 2.0;", lambda u, p: (u + np.array([2.0, 0.0]), p), lambda u, p, l, g: (l.copy(), g.copy())),
     "sin": ("for (int i = 0; i < N; ++i) un[i] += p[1] / 8.0 * sin(u[i]);",
-            lambda u, p: u + p[:, 1:2] / 8.0 * np.sin(u),
-            lambda u, p, l: (l * (1.0 + p[:, 1:2] / 8.0 * np.cos(u)), np.stack([np.zeros(len(u)), (l * np.sin(u)).sum(axis=1) / 8.0, np.zeros(len(u)), np.zeros(len(u))], axis=1))),
-    "reset": ("un[0] = 2.0;", lambda u, p: np.stack([np.full(len(u), 2.0), u[:, 1]], axis=1), lambda u, p, l: (np.stack([np.zeros(len(u)), l[:, 1]], axis=1), np.zeros_like(p))),
+            lambda u, p: (u + p[:, 1:2] / 8.0 * np.sin(u), p),
+            lambda u, p, l, g: (l * (1.0 + p[:, 1:2] / 8.0 * np.cos(u)), g + np.stack([np.zeros(len(u)), (l * np.sin(u)).sum(axis=1) / 8.0, np.zeros(len(u)), np.zeros(len(u))], axis=1))),
+    "reset": ("un[0] = 2.0;", lambda u, p: (np.stack([np.full(len(u), 2.0), u[:, 1]], axis=1), p), lambda u, p, l, g: (np.stack([np.zeros(len(u)), l[:, 1]], axis=1), g.copy())),
+    # test/Callbacks1/discrete_callbacks.jl:303-312: integrator.p .= 2 p .- 0.5 (here milder, so that the dynamics stay tame), plus a state term that reads p
+    "pchange": ("for (int k = 0; k < NP; ++k) pn[k] = 1.1 * p[k] - 0.05; un[1] += 0.1 * p[3] * u[0];",
+                lambda u, p: (np.stack([u[:, 0], u[:, 1] + 0.1 * p[:, 3] * u[:, 0]], axis=1), 1.1 * p - 0.05),
+                lambda u, p, l, g: (np.stack([l[:, 0] + 0.1 * p[:, 3] * l[:, 1], l[:, 1]], axis=1),
+                                    1.1 * g + np.stack([np.zeros(len(u)), np.zeros(len(u)), np.zeros(len(u)), 0.1 * u[:, 0] * l[:, 1]], axis=1))),
 }
 
 
@@ -33,10 +38,10 @@ def fun(sa, name):
 
 
 def oracle_chain(name, events, ts, T, u0, pp, delta, alg, okw, shared):
-    """the same composition from the oracle's pieces: returns (u at ts, du0, dp)"""
+    """the same composition from the oracle's pieces (per-trajectory parameters throughout): returns (u at ts, du0, dp)"""
     aff, vjp = AFFECTS[name][1], AFFECTS[name][2]
     N = len(u0)
-    P = np.broadcast_to(pp, (N, 4)) if shared else pp
+    P = np.ascontiguousarray(np.broadcast_to(pp, (N, 4)))
     ev = sorted(e for e in events if 0.0 < e < T and e <= ts[-1])
     edges = [0.0] + ev + [T]
     pieces, u, out, ul = [], u0, np.zeros((N, len(ts), 2)), []
@@ -45,22 +50,21 @@ def oracle_chain(name, events, ts, T, u0, pp, delta, alg, okw, shared):
         own = [i for i, s in enumerate(ts) if (a <= s < b) or (last and s == b)]
         sv = np.array([ts[i] for i in own] + ([] if last else [b]))
         pr = O.Problem("LV", alg=alg, t0=a, t1=b, save_times=sv, loss="COTANGENT", checkpointing=(alg == "BACKSOLVE"), quad_abstol=1e-12, quad_reltol=1e-12, **okw)
-        _, _, o, _ = pr.adjoint_ensemble(u, pp, np.zeros((N, len(sv), 2)))
-        pieces.append((pr, own, u.copy()))
+        _, _, o, _ = pr.adjoint_ensemble(u, P, np.zeros((N, len(sv), 2)))
+        pieces.append((pr, own, u.copy(), P.copy()))
         for q, i in enumerate(own):
             out[:, i] = o[:, q]
         if not last:
-            ul.append(o[:, -1].copy()); u = aff(o[:, -1], P)
-    dp = np.zeros(4) if shared else np.zeros((N, 4)); lam_in = None; du0 = None
+            ul.append(o[:, -1].copy()); u, P = aff(o[:, -1], P); P = np.ascontiguousarray(P)
+    gp = np.zeros((N, 4)); lam_in = None; du0 = None
     for j in range(len(pieces) - 1, -1, -1):
-        pr, own, ustart = pieces[j]
+        pr, own, ustart, Pj = pieces[j]
         cot = [delta[:, i] for i in own] + ([lam_in] if j < len(pieces) - 1 else [])
-        du0, dpj, _, _ = pr.adjoint_ensemble(ustart, pp, np.ascontiguousarray(np.stack(cot, axis=1)))
-        dp = dp + dpj
+        du0, dpj, _, _ = pr.adjoint_ensemble(ustart, Pj, np.ascontiguousarray(np.stack(cot, axis=1)))
+        gp = gp + dpj
         if j > 0:
-            lam_in, gp = vjp(ul[j - 1], P, du0)
-            dp = dp + (gp.sum(axis=0) if shared else gp)
-    return out, du0, dp
+            lam_in, gp = vjp(ul[j - 1], pieces[j - 1][3], du0, gp)
+    return out, du0, (gp.sum(axis=0) if shared else gp)
 
 
 ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE")]
@@ -71,14 +75,14 @@ def sensealg_of(sa, alg):
 
 
 @pytest.mark.parametrize("alg,oalg", ALGS)
-@pytest.mark.parametrize("name,events", [("dose", [5.0]), ("dose", [2.0, 4.0, 8.0]), ("sin", [5.0]), ("reset", [5.0])])
+@pytest.mark.parametrize("name,events", [("dose", [5.0]), ("dose", [2.0, 4.0, 8.0]), ("sin", [5.0]), ("reset", [5.0]), ("pchange", [5.0]), ("pchange", [3.0, 6.5])])
 @pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
 def test_discrete_callback_matches_oracle_chain(sa, alg, oalg, name, events, stepper):
     """test/Callbacks1/discrete_callbacks.jl:260-330: saveat 0.5 on (0, 10), Lotka-Volterra, g = sum(sol) replaced by random cotangents; the
     event time 5.0 (and 2.0, 4.0, 8.0) is a save time as well: the saved state there is the right limit."""
     rng = np.random.default_rng(61)
     N, T = 70, 10.0
-    shared = name != "sin"
+    shared = name not in ("sin",)
     u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2))
     pp = np.array([1.5, 1.0, 3.0, 1.0]) if shared else np.array([1.5, 1.0, 3.0, 1.0]) + 0.05 * rng.standard_normal((N, 4))
     ts = np.arange(0.0, T + 1e-9, 0.5)
@@ -96,7 +100,8 @@ def test_discrete_callback_matches_oracle_chain(sa, alg, oalg, name, events, ste
     sol.close()
 
 
-def test_discrete_callback_gradient_is_the_derivative_of_the_loss(sa):
+@pytest.mark.parametrize("name", ["sin", "pchange"])
+def test_discrete_callback_gradient_is_the_derivative_of_the_loss(sa, name):
     """The reference's assertion (discrete_callbacks.jl:200-216): adjoint ≈ ForwardDiff through the solve with the callback — here central
     differences of the loss through the device's own forward solves with the callback (state- and parameter-dependent affect, two events)."""
     rng = np.random.default_rng(62)
@@ -104,7 +109,7 @@ def test_discrete_callback_gradient_is_the_derivative_of_the_loss(sa):
     u0 = np.array([[1.0, 1.0]]); pp = np.array([1.5, 1.0, 3.0, 1.0])
     ts = np.arange(0.5, T + 1e-9, 0.5)
     w = rng.standard_normal((1, len(ts), 2))
-    f = fun(sa, "sin")
+    f = fun(sa, name)
 
     def loss_and_grad(u0_, p_, grad):
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0_[0], (0.0, T), p_), u0_, p_), sa.RK4(), dt=0.005, saveat=ts, sensealg=sa.InterpolatingAdjoint(),
