@@ -142,3 +142,17 @@ def test_discrete_callback_misuse(sa):
     du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=sa.LsqShift(0.5))
     assert np.all(np.isfinite(du0)) and np.all(np.isfinite(dp))
     sol.close()
+
+
+def test_concrete_solve_adjoint_with_a_callback(sa):
+    """The (out, pullback) contract (src/concrete_solve.jl:523-1042) with `callback` among the solve keywords (:563-575 track_callbacks)."""
+    rng = np.random.default_rng(63)
+    N, T = 8, 4.0
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); pp = np.array([1.5, 1.0, 3.0, 1.0])
+    ts = np.arange(0.5, T + 1e-9, 0.5)
+    f = fun(sa, "sin")
+    out, pullback = sa.concrete_solve_adjoint(sa.ODEProblem(f, u0[0], (0.0, T), pp), sa.RK4(), sa.GaussAdjoint(), u0, pp, dt=0.01, saveat=ts, callback=sa.PresetTimeCallback([2.0]))
+    delta = rng.standard_normal(out.shape)
+    du0, dp = pullback(delta)
+    rout, rdu0, rdp = oracle_chain("sin", [2.0], ts, T, u0, pp, delta, "GAUSS", dict(stepper="RK4", dt=0.01), True)
+    assert rel(out, rout) < 1e-9 and rel(du0, rdu0) < 1e-8 and rel(dp, rdp) < 1e-8
