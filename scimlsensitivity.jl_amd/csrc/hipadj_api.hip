@@ -153,7 +153,7 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
-                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_w2t, h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2, h->d_c1, h->d_c2, h->d_c3, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
+                    h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
@@ -240,16 +240,9 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         }
     } else if (P.mlp) {
         h->mlp = true; h->field = false; h->NQ = P.NQ;
-        const size_t Hh = cfg->dims[1], Bb = cfg->dims[2], Q = (size_t)h->N * S * P.NQ, HP = Hh + 16;
-        const long groups = cfg->p_shared ? 1 : h->N;
-        const long nslabs = (long)(Q / groups) * ((Bb + 63) / 64);   // weight-gradient GEMMs: 64-sample slabs, 2 workgroups per CU
-        h->ksplit = (int)(nslabs < 512 ? nslabs : 512);
+        const size_t Bb = cfg->dims[2];
         A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
-        A(dev_alloc(h, &h->d_w2t, (size_t)groups * Hh * Hh));
-        if (const char* e = std::getenv("HIPADJ_MLP_RECORDS")) h->mlp_records = e[0] == '1';
-        if (h->mlp_records && cfg->alg == HIPADJ_ALG_BACKSOLVE) { h->err = "HIPADJ_MLP_RECORDS=1 (the round-1 record path) has no BacksolveAdjoint"; return fail(HIPADJ_ERR_UNSUPPORTED); }
-        if (h->mlp_records && cfg->alg == HIPADJ_ALG_QUADRATURE) { h->err = "HIPADJ_MLP_RECORDS=1 (the round-1 record path) has no QuadratureAdjoint"; return fail(HIPADJ_ERR_UNSUPPORTED); }
-        if (!h->mlp_records && cfg->alg == HIPADJ_ALG_QUADRATURE) {
+        if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
             // dense adjoint record of pass 1 + the buffers of the host-driven adaptive Gauss-Kronrod pass (mlp_quadrature, hipadj_host_impl.hpp)
             const size_t wg = Bb / 16, per_entry = wg * (size_t)np;
             size_t chunk = ((size_t)768 << 20) / (per_entry * sizeof(double)); chunk = chunk < 2 ? 2 : (chunk > 64 ? 64 : chunk); chunk &= ~(size_t)1;
@@ -262,20 +255,9 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             A(dev_alloc(h, &h->d_mq_ids, (size_t)1 << 16));
             { double* tmp = nullptr; A(dev_alloc(h, &tmp, (size_t)4096 * 3)); h->d_mq_panels = tmp; }      // 4096 panels of 24 bytes
             h->qa_host = P.qa; h->qb_host = P.qb;
-        } else if (!h->mlp_records) {
+        } else {
             // in-register parameter gradient (hipadj_mlp_grad.hpp): one partial gradient per workgroup of 16 columns, no activation records
             A(dev_alloc(h, &h->d_c1, (size_t)h->N * (Bb / 16) * (size_t)np));
-        } else {
-        A(dev_alloc(h, &h->d_ax, Q * 16 * Bb)); A(dev_alloc(h, &h->d_al, Q * 16 * Bb));
-        A(dev_alloc(h, &h->d_ah1, Q * HP * Bb)); A(dev_alloc(h, &h->d_ah2, Q * HP * Bb));
-        A(dev_alloc(h, &h->d_ag1, Q * Hh * Bb)); A(dev_alloc(h, &h->d_ag2, Q * Hh * Bb));
-        A(dev_alloc(h, &h->d_c1, (size_t)groups * h->ksplit * Hh * HP));
-        A(dev_alloc(h, &h->d_c2, (size_t)groups * h->ksplit * Hh * 16));
-        A(dev_alloc(h, &h->d_c3, (size_t)groups * h->ksplit * 16 * HP));
-        if (rc == HIPADJ_OK) {   // padding rows (zeros) and the ones rows are written once / by the sweep; zero everything first
-            if (hipMemset(h->d_ax, 0, Q * 16 * Bb * 8) != hipSuccess || hipMemset(h->d_al, 0, Q * 16 * Bb * 8) != hipSuccess ||
-                hipMemset(h->d_ah1, 0, Q * HP * Bb * 8) != hipSuccess || hipMemset(h->d_ah2, 0, Q * HP * Bb * 8) != hipSuccess) { h->err = "hipMemset failed"; rc = HIPADJ_ERR_HIP; }
-        }
         }
     } else {
         A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));

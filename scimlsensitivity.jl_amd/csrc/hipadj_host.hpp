@@ -48,10 +48,8 @@ struct hipadj_handle {
     bool field = false;                   // workgroup-per-trajectory family (BRUSS)
     bool ip_ckpt = false;                 // Interpolating/Gauss checkpointing=true
     double *d_fknots = nullptr, *d_fadj = nullptr;
-    bool mlp = false; int NQ = 0, ksplit = 1;
-    bool mlp_records = false;             // HIPADJ_MLP_RECORDS=1: round-1 path (activation records + weight-gradient GEMM kernels) instead of the in-register gradient
-    double *d_w2t = nullptr, *d_ax = nullptr, *d_al = nullptr, *d_ah1 = nullptr, *d_ah2 = nullptr, *d_ag1 = nullptr, *d_ag2 = nullptr;
-    double *d_c1 = nullptr, *d_c2 = nullptr, *d_c3 = nullptr;
+    bool mlp = false; int NQ = 0;
+    double *d_c1 = nullptr;               // MLP family: the workgroups' partial gradients (Quadrature: of one launch of panels)
     // MLP family, QuadratureAdjoint: host-driven adaptive Gauss-Kronrod (mlp_quadrature): pool of panel vectors, panel list, id lists, norms
     double *d_mq_pool = nullptr, *d_mq_norm = nullptr; void* d_mq_panels = nullptr; int *d_mq_ids = nullptr;
     long mq_pool_cap = 0; int mq_chunk = 0;

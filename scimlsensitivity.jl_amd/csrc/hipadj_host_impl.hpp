@@ -289,10 +289,7 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
 
 // ---- FP64-MFMA family (MLP neural ODE) -----------------------------------------------------------------
 template <int H> int mlp_forward_launch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
-    const int groups = h->cfg.p_shared ? 1 : (int)h->N;
-    hipLaunchKernelGGL(k_mlp_transpose_w2, dim3(64, (unsigned)groups), dim3(256), 0, h->stream, H, Mlp<H>::NPAR, H * 2 + H, d_p, h->d_w2t);
-    HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL((k_mlp_forward<H>), dim3((unsigned)(h->mg.B / 16), (unsigned)h->N), dim3(Mlp<H>::NT), 0, h->stream, h->mg, d_u0, d_p, (const double*)h->d_w2t,
+    hipLaunchKernelGGL((k_mlp_forward<H>), dim3((unsigned)(h->mg.B / 16), (unsigned)h->N), dim3(Mlp<H>::NT), 0, h->stream, h->mg, d_u0, d_p,
                        h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
     HIP_TRY(h, hipGetLastError());
     return HIPADJ_OK;
@@ -430,75 +427,36 @@ template <int H> int mlp_quadrature(hipadj_handle* h, const double* p, double* d
 }
 
 template <int H> int mlp_adjoint_launch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    constexpr int HP = Mlp<H>::HP;
     const double* p = h->p_dev_last;
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
     harvest_set(h, es, true);
     HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     HIP_TRY(h, hipEventRecord(es.k0, h->stream));
-    if (!h->mlp_records) {
-        // in-register parameter gradient: the sweep leaves one partial gradient per workgroup, a fixed-order sum finishes dp
-        const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), gblk(MlpG<H>::NT);
-        const int* ck = nullptr; double* noadj = nullptr;
-        if (h->cfg.alg == HIPADJ_ALG_GAUSS)
-            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, noadj, d_du0, h->d_flag);
-        else if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
-            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 1>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev,
-                               h->cfg.checkpointing ? (const int*)h->d_ckpt_of_knot : ck, h->d_c1, noadj, d_du0, h->d_flag);
-        else if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
-            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 3>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, (double*)nullptr, h->d_fadj, d_du0, h->d_flag);
-            HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-            TRY(mlp_quadrature<H>(h, p, d_dp));
-            HIP_TRY(h, hipEventRecord(es.a1, h->stream));
-            es.pending = true;
-            return HIPADJ_OK;
-        }
-        else
-            hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, noadj, d_du0, h->d_flag);
+    // in-register parameter gradient: the sweep leaves one partial gradient per workgroup, a fixed-order sum finishes dp
+    const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), gblk(MlpG<H>::NT);
+    const int* ck = nullptr; double* noadj = nullptr;
+    if (h->cfg.alg == HIPADJ_ALG_GAUSS)
+        hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 2>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, noadj, d_du0, h->d_flag);
+    else if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
+        hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 1>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev,
+                           h->cfg.checkpointing ? (const int*)h->d_ckpt_of_knot : ck, h->d_c1, noadj, d_du0, h->d_flag);
+    else if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
+        hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 3>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, (double*)nullptr, h->d_fadj, d_du0, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-        const long groups = h->cfg.p_shared ? 1 : h->N;
-        const long per_group = (h->N * (long)(h->mg.B / 16)) / groups;
-        hipLaunchKernelGGL(k_mlp_grad_reduce, dim3((Mlp<H>::NPAR + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, (int)Mlp<H>::NPAR, per_group, (const double*)h->d_c1, d_dp);
-        HIP_TRY(h, hipGetLastError());
+        TRY(mlp_quadrature<H>(h, p, d_dp));
         HIP_TRY(h, hipEventRecord(es.a1, h->stream));
         es.pending = true;
         return HIPADJ_OK;
     }
-    MlpRec<H> R{h->d_ax, h->d_al, h->d_ah1, h->d_ah2, h->d_ag1, h->d_ag2};
-    const dim3 grid((unsigned)(h->mg.B / 16), (unsigned)h->N), blk(64), sweep_blk(Mlp<H>::NT);
-    if (h->cfg.alg == HIPADJ_ALG_GAUSS)
-        hipLaunchKernelGGL((k_mlp_adjoint<H, 2>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_rev, R, d_du0, h->d_flag);
     else
-        hipLaunchKernelGGL((k_mlp_adjoint<H, 0>), grid, sweep_blk, 0, h->stream, h->mg, p, (const double*)h->d_w2t, (const double*)h->d_fknots, d_cot,
-                           (const int*)h->d_save_rev, R, d_du0, h->d_flag);
+        hipLaunchKernelGGL((k_mlp_adjoint_grad<H, 0>), grid, gblk, 0, h->stream, h->mg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, ck, h->d_c1, noadj, d_du0, h->d_flag);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(es.k1, h->stream));
     const long groups = h->cfg.p_shared ? 1 : h->N;
-    const long Qper = (h->N * (long)h->S * h->NQ) / groups;
-    const int B = h->mg.B, ks = h->ksplit;
-    if (B % 64 == 0) {
-        const size_t lds1 = (size_t)HP * WG_PITCH * sizeof(double), lds2 = (size_t)16 * WG_PITCH * sizeof(double);
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_wgrad<H / 16 + 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64 * (H / 16)), lds1, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((k_mlp_wgrad<1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64 * (H / 16)), lds2, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((k_mlp_wgrad<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), dim3(64), lds1, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
-        HIP_TRY(h, hipGetLastError());
-    } else {   // batches that are not a multiple of 64 columns: 16-sample chunks straight from global memory
-        hipLaunchKernelGGL((k_mlp_wgrad_small<H / 16 + 1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag2, (const double*)h->d_ah1, H, HP, Qper, B, ks, h->d_c1);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((k_mlp_wgrad_small<1>), dim3(H / 16, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_ag1, (const double*)h->d_ax, H, 16, Qper, B, ks, h->d_c2);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((k_mlp_wgrad_small<H / 16 + 1>), dim3(1, (unsigned)ks, (unsigned)groups), blk, 0, h->stream, (const double*)h->d_al, (const double*)h->d_ah2, 16, HP, Qper, B, ks, h->d_c3);
-        HIP_TRY(h, hipGetLastError());
-    }
-    hipLaunchKernelGGL((k_mlp_wreduce<H>), dim3((Mlp<H>::NPAR + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, ks, (const double*)h->d_c1, (const double*)h->d_c2,
-                       (const double*)h->d_c3, d_dp);
+    const long per_group = (h->N * (long)(h->mg.B / 16)) / groups;
+    hipLaunchKernelGGL(k_mlp_grad_reduce, dim3((Mlp<H>::NPAR + 255) / 256, (unsigned)groups), dim3(256), 0, h->stream, (int)Mlp<H>::NPAR, per_group, (const double*)h->d_c1, d_dp);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(es.a1, h->stream));
     es.pending = true;

@@ -1,12 +1,12 @@
 // hipadj_mlp_grad.hpp — reverse sweep of the FP64-MFMA family with the PARAMETER GRADIENT ACCUMULATED IN REGISTERS (round 2).
 //
-// The round-1 sweep (k_mlp_adjoint, hipadj_mlp.hpp) writes weighted activation records (5.6 GB for BASELINE configs[3]) and three split-K
-// GEMM kernels contract them afterwards: 10 GB of HBM traffic and a third of the reverse pass for a result of 17 282 numbers.  Here the
-// contraction happens where the operands are born:
+// The round-1 sweep wrote weighted activation records (5.6 GB for BASELINE configs[3]) and three split-K GEMM kernels contracted them
+// afterwards: 10 GB of HBM traffic and a third of the reverse pass for a result of 17 282 numbers (retired; profiles/r2_mlpbench_variants.log).
+// Here the contraction happens where the operands are born:
 //
 //   * the batch columns sit on the M side of every contraction:  Out^T (16 x H) = Act^T (16 x H) . W (H x H), i.e. the activations are the
-//     A operand (from the LDS exchange tile) and the weights the B operand (from the swizzled LDS copy of W2, same two access patterns as
-//     mlp_gemm_swz_n / _t).  The accumulator then holds  D[column c = (l>>4) + 4 reg][hidden n = l & 15]:  for a FIXED register index the
+//     A operand (from the LDS exchange tile) and the weights the B operand (from the XOR-swizzled LDS copy of W2, mlp_swz: the plain and the
+//     transposed access pattern are both free of bank conflicts).  The accumulator then holds  D[column c = (l>>4) + 4 reg][hidden n = l & 15]:  for a FIXED register index the
 //     four lane groups hold columns c = kq + 4 ks — exactly the A / B operand layout of a K-step whose contraction index is the COLUMN.
 //     So the outer products of the weight gradient,
 //         dW2[i][j] += sum_c (w G2)[i][c] H1[j][c],
@@ -22,8 +22,8 @@
 // of a D fragment, the A-operand reads of the contractions and the B-operand reads of the outer product free of bank conflicts at pitch
 // 16) and the cross-wave reduction scratch.  The tile holds H1 from the forward pass until the outer product of the same point has
 // read it, then G2 for the transposed contraction.
-// Same numerics as k_mlp_adjoint (same stages, same first-same-as-last reuse); the sums of the gradient are associated differently
-// (per workgroup, then over workgroups) — agreement with the record path and with the oracle is at round-off (tests/test_gpu_parity.py).
+// The sums of the gradient are associated per workgroup, then over workgroups in a fixed order — agreement with the oracle is at round-off
+// (tests/test_gpu_parity.py).
 #pragma once
 
 #include "hipadj_field.hpp"   // the Gauss-Kronrod tables c_gk_*
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
     const long traj = blockIdx.y;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     const bool writer = (threadIdx.x >> 4) == 0;          // wave 0, lane group 0
-    const MlpW<H> w = mlp_weights<H>(p, nullptr, g.p_shared, traj);
+    const MlpW<H> w = mlp_weights<H>(p, g.p_shared, traj);
     const MlpGCtx<H> cx = mlpg_ctx<H>();
     const long nB = (long)D * g.B;
     const double dt = g.dt;
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_quad_panel(MlpGeom g, const
     const MlpPanel pe = panels[blockIdx.y];
     const long traj = pe.traj;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
-    const MlpW<H> w = mlp_weights<H>(p, nullptr, g.p_shared, traj);
+    const MlpW<H> w = mlp_weights<H>(p, g.p_shared, traj);
     const MlpGCtx<H> cx = mlpg_ctx<H>();
     const long nB = (long)D * g.B;
     const double dt = g.dt;
