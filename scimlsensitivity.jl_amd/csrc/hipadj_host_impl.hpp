@@ -37,8 +37,12 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     // (10^4 trajectories: 625 instead of 157 workgroups, -1.7 us per reverse pass; profiles/README.md)
     const bool small_blocks = h->cbs == 64 || (h->cbs == 0 && cblocks < 1024);
     const unsigned compose_blocks = small_blocks ? (unsigned)((h->N + 15) / 16) : cblocks;
+    static const bool compose16 = []() { const char* e = std::getenv("HIPADJ_COMPOSE16"); return !(e && e[0] == '0'); }();   // A/B switch of the 16-lane composition
     auto launch_compose = [&]() {
-        if (small_blocks)
+        if (small_blocks && compose16)      // 16 lanes per trajectory, FIN / 16 = 16 trajectories per workgroup: the same number of workgroups (and partials)
+            hipLaunchKernelGGL((k_compose_finish16<Mo>), dim3(compose_blocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        else if (small_blocks)
             hipLaunchKernelGGL((k_compose_finish<Mo, 64>), dim3(compose_blocks), dim3(64), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
                                d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         else

@@ -310,6 +310,127 @@ __global__ void __launch_bounds__(BS) k_compose_finish(Geom g, int nseg, const d
     if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
 }
 
+// The same composition with SIXTEEN lanes per trajectory (one DPP row), for ensembles that leave the chip idle during this kernel (< 65 536
+// trajectories: the 4-lane form runs 625 single-wave workgroups at 10^4 and spends its time in ONE round of 72 loads per lane).  Lane q folds
+// its contiguous chunk of the lower maps (one map at 13 segments, four at 62) into an affine map; the vector then walks down the row:
+// step s moves it one lane to the right with two DPP row_shr:1 moves per double — VALU only, no LDS crossbar — and lane s applies its map.
+// 3x the loads in flight and a chain of 15 cheap steps instead of three shuffle hops after a long load round.
+__device__ __forceinline__ double dpp_row_shr1(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true));
+}
+template <class Mo>
+__global__ void __launch_bounds__(FIN) k_compose_finish16(Geom g, int nseg, const double* __restrict__ segbuf,
+                                                          double* __restrict__ du0, double* __restrict__ dp_rows,
+                                                          double* __restrict__ partial, int* __restrict__ flag,
+                                                          unsigned* __restrict__ ticket_ctr, double* __restrict__ dp_sum) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    const long i_raw = (long)blockIdx.x * (FIN / 16) + (threadIdx.x >> 4);
+    const int part = threadIdx.x & 15;
+    const bool tvalid = i_raw < g.N;
+    const long i = tvalid ? i_raw : g.N - 1;
+    const int L = nseg - 1;                                  // lower maps, rank 0 = segment nseg-2 ... rank L-1 = segment 0
+    const int r0 = (L * part) / 16, r1 = (L * (part + 1)) / 16;
+    double A[N][N], Bm[NP][N], cl[N], cm[NP];                // this lane's composed map: lam <- A lam + cl ; mu <- mu + Bm lam + cm
+#pragma unroll
+    for (int a = 0; a < N; ++a) { cl[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) A[a][b] = (a == b) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int a = 0; a < NP; ++a) { cm[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) Bm[a][b] = 0.0; }
+    for (int rk = r0; rk < r1; ++rk) {
+        double m[NC * R];
+        const double* __restrict__ src = segbuf + (long)(nseg - 2 - rk) * NC * R * g.Npad + i;
+#pragma unroll
+        for (int e = 0; e < NC * R; ++e) m[e] = src[(long)e * g.Npad];
+        // G <- m o G   (m: c_l = m[j], c_m = m[N+j], A[:,c] = m[(c+1)R + j], B[:,c] = m[(c+1)R + N + j])
+        double nA[N][N], nB[NP][N], ncl[N], ncm[NP];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { ncl[j] = m[j];
+#pragma unroll
+            for (int c = 0; c < N; ++c) ncl[j] += m[(c + 1) * R + j] * cl[c]; }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { ncm[j] = cm[j] + m[N + j];
+#pragma unroll
+            for (int c = 0; c < N; ++c) ncm[j] += m[(c + 1) * R + N + j] * cl[c]; }
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = 0; b < N; ++b) { double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += m[(c + 1) * R + a] * A[c][b];
+                nA[a][b] = v; }
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+            for (int b = 0; b < N; ++b) { double v = Bm[a][b];
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += m[(c + 1) * R + N + a] * A[c][b];
+                nB[a][b] = v; }
+#pragma unroll
+        for (int a = 0; a < N; ++a) { cl[a] = ncl[a];
+#pragma unroll
+            for (int b = 0; b < N; ++b) A[a][b] = nA[a][b]; }
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { cm[a] = ncm[a];
+#pragma unroll
+            for (int b = 0; b < N; ++b) Bm[a][b] = nB[a][b]; }
+    }
+    // the vector: lane 0 starts from the top segment's (c_l, c_m) and applies its own map; then one lane to the right per step
+    double lam[N], mu[NP];
+    {
+        const double* __restrict__ src = segbuf + (long)(nseg - 1) * NC * R * g.Npad + i;
+        double tl[N], tm[NP];
+#pragma unroll
+        for (int j = 0; j < N; ++j) tl[j] = part == 0 ? src[(long)j * g.Npad] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) tm[j] = part == 0 ? src[(long)(N + j) * g.Npad] : 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { double v = cl[j];
+#pragma unroll
+            for (int c = 0; c < N; ++c) v += A[j][c] * tl[c];
+            lam[j] = v; }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { double v = tm[j] + cm[j];
+#pragma unroll
+            for (int c = 0; c < N; ++c) v += Bm[j][c] * tl[c];
+            mu[j] = v; }
+    }
+#pragma unroll
+    for (int s = 1; s < 16; ++s) {
+        double li[N], mi[NP];
+#pragma unroll
+        for (int j = 0; j < N; ++j) li[j] = dpp_row_shr1(lam[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mi[j] = dpp_row_shr1(mu[j]);
+        if (part == s) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { double v = cl[j];
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += A[j][c] * li[c];
+                lam[j] = v; }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { double v = mi[j] + cm[j];
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += Bm[j][c] * li[c];
+                mu[j] = v; }
+        }
+    }
+    const bool owner = tvalid && part == 15;
+    if (owner) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { du0[i * N + j] = lam[j]; bad |= !finite_d(lam[j]); }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { bad |= !finite_d(mu[j]); if (dp_rows) dp_rows[i * NP + j] = mu[j]; }
+        if (bad) atomicOr(flag, 1);
+    }
+    block_partial<NP, FIN>(mu, owner, partial);
+    if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
+}
+
 // finishing stage for kernels that already wrote du0 [N][n] and dp_traj [NP][Npad]
 template <int N, int NP>
 __global__ void __launch_bounds__(FIN) k_finish(long Ntraj, long Npad, const double* __restrict__ du0,
