@@ -88,3 +88,30 @@ def test_julia_call_sequence_from_c_matches_oracle(tmp_path, alg, oalg):
     rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
     assert rel(vals["dp"], rdp) < 1e-6 and rel(vals["du0_first"], rdu0[0]) < 1e-6 and rel(vals["du0_last"], rdu0[-1]) < 1e-6
     assert rel(vals["out_last"], rout[-1, -1]) < 1e-6
+
+
+def _build_model_calls(sa, tmp_path):
+    exe = str(tmp_path / "julia_model_calls")
+    libdir = os.path.dirname(sa.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "julia_model_calls.c"),
+                           "-o", exe, "-L" + libdir, "-lhipadj", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_julia_model_calls_from_c(tmp_path):
+    """register_model / set_mass_matrix! / set_affect! / affect_apply / affect_vjp as HIPAdj.jl calls them.  Without a device: registration, the
+    singular-matrix refusal and the gfx950 compile work, the first device call fails loudly (status -2); with one: the affect numbers."""
+    import scimlsensitivity_jl_amd as sa
+    sa.build_extension()
+    exe = _build_model_calls(sa, tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert "singular -6" in r.stdout and "version 104" in r.stdout
+    if not os.path.exists("/dev/kfd"):
+        assert r.returncode == 1 and "hipadj status -2" in r.stderr and "no usable HIP device" in r.stderr
+        return
+    assert r.returncode == 0, r.stderr
+    vals = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.strip().split("\n") if l.split()[0] in ("out", "pout", "lam_out", "gp_out")}
+    # un[0] += 2 p[3]; pn[1] = 1.1 p[1]   with p = [1.5, 1.0, 3.0, 0.5]
+    assert np.allclose(vals["out"], [2.0, 2.0, 6.0, 6.0]) and np.allclose(vals["pout"], [1.5, 1.1, 3.0, 0.5])
+    # lam_out = lam (dun/du = I, dpn/du = 0); gp_out = (dun/dp)' lam + (dpn/dp)' gp: row 0: gp = [0.1, 0.2, 0.3, 0.4], lam = [1, -1]
+    assert np.allclose(vals["lam_out"], [1.0, 3.0]) and np.allclose(vals["gp_out"], [0.1, 1.1 * 0.2, 0.3, 0.4 + 2.0 * 1.0])
