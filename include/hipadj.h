@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 104 /* 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
+#define HIPADJ_VERSION 105 /* 0.1.3: + hipadj_runtime_compiler; 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -202,6 +202,11 @@ int hipadj_model_check(int32_t model_id);
  * does lazily for a runtime-registered model — without a device; HIPADJ_OK at once for built-in models.  Lets a caller warm the
  * process-wide code cache and surface compile errors of a particular sensealg / stepper combination ahead of time. */
 int hipadj_model_check_config(const hipadj_config *cfg);
+/* Which compiler builds the runtime-registered models: "<path of the bound libhiprtc> [own link-map namespace]; HIP x.y.z" written to buf
+ * (NUL-terminated, truncated to cap).  The library binds the hiprtc of the ROCm toolkit it was built with ($HIPADJ_HIPRTC, $ROCM_PATH/lib, the
+ * build-time ROCm root) — not whatever hiprtc the host process happens to carry: a torch wheel bundles an older ROCm whose compiler
+ * miscompiles wide models.  Returns HIPADJ_OK, or HIPADJ_ERR_UNSUPPORTED (with the reason in buf) when no hiprtc is found. */
+int hipadj_runtime_compiler(char *buf, int32_t cap);
 
 /* Replaces the per-call setup of ODEAdjointProblem + adjointdiffcache (src/interpolating_adjoint.jl:307-451,
  * src/backsolve_adjoint.jl:123-272, src/adjoint_common.jl:42-469): validates the configuration, allocates the

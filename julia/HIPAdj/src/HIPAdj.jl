@@ -1,7 +1,7 @@
 """
     HIPAdj
 
-Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 104) — the MI355X-native batched continuous-adjoint
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 105) — the MI355X-native batched continuous-adjoint
 engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
 
   * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -39,13 +39,19 @@ function lib()
     if LIB[] == C_NULL
         LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
         v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
-        v == 104 || error("libhipadj ABI version $v, this binding was written for 104")
+        v == 105 || error("libhipadj ABI version $v, this binding was written for 105")
     end
     return LIB[]
 end
 sym(name::Symbol) = Libdl.dlsym(lib(), name)
 
 hipadj_version() = Int(ccall(sym(:hipadj_version), Cint, ()))
+"Which hiprtc compiles the runtime-registered models (`hipadj_runtime_compiler`): the build toolkit's — a Julia process has no other."
+function runtime_compiler()
+    buf = Vector{UInt8}(undef, 1024)
+    check(ccall(sym(:hipadj_runtime_compiler), Cint, (Ptr{UInt8}, Int32), buf, Int32(length(buf))))
+    return unsafe_string(pointer(buf))
+end
 
 # mirrors `hipadj_config` (include/hipadj.h) field by field; Julia lays an isbits struct out like C does
 struct HipadjConfig

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
+    "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
 )
 
@@ -100,6 +100,7 @@ def load():
     L.hipadj_model_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
     L.hipadj_model_check.argtypes = [C.c_int32]
     L.hipadj_model_check_config.argtypes = [C.POINTER(HipadjConfig)]
+    L.hipadj_runtime_compiler.argtypes = [C.c_char_p, C.c_int32]
     L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_model_set_cost_function.argtypes = [C.c_int32, C.c_char_p]
     L.hipadj_model_set_mass_matrix.argtypes = [C.c_int32, C.POINTER(C.c_double)]
@@ -136,6 +137,17 @@ def register_model(name, n, npar, f, vjp=None, vjp_p=None, check=False):
     if check:
         check_model(mid.value)
     return mid.value
+
+
+def runtime_compiler():
+    """hipadj_runtime_compiler: '<libhiprtc path> [own link-map namespace]; HIP x.y.z' — the compiler of the runtime-registered models
+    (the build toolkit's, also inside a torch process whose wheel bundles an older ROCm)."""
+    L = load()
+    buf = C.create_string_buffer(1024)
+    rc = L.hipadj_runtime_compiler(buf, 1024)
+    if rc != OK:
+        raise HipadjError(rc, buf.value.decode())
+    return buf.value.decode()
 
 
 def check_model(model_id):
@@ -183,17 +195,24 @@ def affect_vjp(model_id, u, p, t, lam, gp, device=0):
     return lo, g
 
 
+MASS = {}     # model id -> mass matrix (numpy [n][n]) or absent: the host mirror needs it where it chains pieces (events.py)
+
+
 def set_model_mass_matrix(model_id, n, M):
     """hipadj_model_set_mass_matrix: ODEFunction(f; mass_matrix = M) for a runtime-registered model (constant, non-singular; None removes)."""
     L = load()
     if M is None:
         rc = L.hipadj_model_set_mass_matrix(int(model_id), None)
+        if rc == OK:
+            MASS.pop(int(model_id), None)
     else:
         import numpy as np
         A = np.ascontiguousarray(M, dtype=np.float64)
         if A.shape != (n, n):
             raise ValueError(f"mass_matrix must be {n} x {n}, got {A.shape}")
         rc = L.hipadj_model_set_mass_matrix(int(model_id), A.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc == OK:
+            MASS[int(model_id)] = A.copy()
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
 

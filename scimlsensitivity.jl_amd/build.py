@@ -71,6 +71,9 @@ def build(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    # the ROCm root this build's compiler lives in: runtime-registered models are compiled by the SAME toolkit's hiprtc (csrc/hipadj_user.hpp rtc_api)
+    rocm_root = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+    rocm_def = [f'-DHIPADJ_ROCM_PATH="{rocm_root}"']
     os.makedirs(OBJ, exist_ok=True)
     jobs = jobs or int(os.environ.get("HIPADJ_BUILD_JOBS", "0")) or max(1, min(os.cpu_count() or 1, 16))
 
@@ -78,7 +81,7 @@ def build(force=False, verbose=False, jobs=None):
         obj, src, extra = u
         if not force and not _stale(os.path.join(OBJ, obj), os.path.join(CSRC, src)):
             return os.path.join(OBJ, obj)
-        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(OBJ, obj)]
+        cmd = [hipcc] + FLAGS + rocm_def + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(OBJ, obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -140,6 +140,14 @@ extern "C" int hipadj_model_check(int32_t model_id) {
     return user_compile(model_id, exprs, code, low, g_create_error);
 }
 
+extern "C" int hipadj_runtime_compiler(char* buf, int32_t cap) {
+    if (!buf || cap <= 0) return HIPADJ_ERR_INVALID_ARG;
+    const std::string d = rtc_describe();
+    std::snprintf(buf, (size_t)cap, "%s", d.c_str());
+    RtcApi& A = rtc_api();
+    return (A.lib && A.err.empty()) ? HIPADJ_OK : HIPADJ_ERR_UNSUPPORTED;
+}
+
 // Every kernel a handle of this configuration would launch, compiled now (no device needed): the ahead-of-time form of what
 // hipadj_create does lazily.  Built-in models have nothing to compile.
 struct UserKernels;

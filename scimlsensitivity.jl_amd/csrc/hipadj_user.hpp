@@ -9,12 +9,16 @@
 // (read from csrc/ next to libhipadj.so), loaded with hipModuleLoadData and launched with hipModuleLaunchKernel.
 // Nothing here is a CPU path: a model that fails to compile fails hipadj_create with the compiler log.
 //
-// hiprtc is bound with dlopen at first use, not at link time: a process that has torch loaded already carries a
-// HIP runtime + hiprtc pair, and binding by soname picks that pair instead of mixing two runtimes.
+// hiprtc is bound with dlopen / dlmopen at first use, not at link time (rtc_api below: the toolkit's compiler, also inside a torch process).
 #pragma once
 
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <dlfcn.h>
 #include <elf.h>
+#include <limits.h>
+#include <link.h>
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
@@ -74,15 +78,59 @@ struct RtcApi {
     hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
     hiprtcResult (*GetCode)(hiprtcProgram, char*) = nullptr;
     hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
-    std::string err;
+    std::string err, path;     // path: the bound libhiprtc
+    bool isolated = false;     // loaded with dlmopen next to another hiprtc / comgr copy
 };
+
+// Which hiprtc compiles the runtime models.  A process that has torch loaded carries torch's own HIP runtime, hiprtc and comgr (the wheel
+// bundles the ROCm it was built against), and binding hiprtc by soname picks THAT compiler — an older LLVM than the toolkit that built
+// libhipadj.so.  The bundled ROCm 7.0 compiler miscompiles wide runtime models (5-state ring with a dense mass matrix, GaussAdjoint: parameter
+// gradient wrong in the 6th digit and worse, the same translation unit is exact with the 7.2 toolkit) — so all device code of
+// this library, static and runtime-compiled, comes from ONE compiler: the toolkit's libhiprtc ($HIPADJ_HIPRTC, else $ROCM_PATH/lib, else the
+// build-time ROCm root).  When another hiprtc / comgr copy is already mapped, the toolkit's pair is loaded into its own link-map namespace
+// (dlmopen): libhiprtc resolves libamd_comgr by soname, and in the global namespace that would be the older copy again.  The code object is
+// loaded by whatever HIP runtime the process uses (code-object ABI v6 on both sides).  Without a toolkit installation: the soname binding.
+#ifndef HIPADJ_ROCM_PATH
+#define HIPADJ_ROCM_PATH "/opt/rocm"
+#endif
+inline std::string rtc_realpath(const std::string& p) { char b[PATH_MAX]; return realpath(p.c_str(), b) ? std::string(b) : std::string(); }
+inline std::string rtc_dirname(const std::string& p) { const size_t k = p.rfind('/'); return k == std::string::npos ? std::string() : p.substr(0, k); }
+struct RtcForeign { std::string dir; bool found; };
+inline int rtc_phdr_cb(struct dl_phdr_info* info, size_t, void* u) {
+    RtcForeign* f = (RtcForeign*)u;
+    if (!info->dlpi_name || !info->dlpi_name[0]) return 0;
+    const std::string rp = rtc_realpath(info->dlpi_name);
+    const size_t k = rp.rfind('/');
+    const std::string base = k == std::string::npos ? rp : rp.substr(k + 1);
+    if ((base.compare(0, 9, "libhiprtc") == 0 || base.compare(0, 12, "libamd_comgr") == 0) && rtc_dirname(rp) != f->dir) f->found = true;
+    return 0;
+}
 
 inline RtcApi& rtc_api() {
     static RtcApi A;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
-        for (const char* nm : names) { A.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (A.lib) break; }
+        std::string want;
+        if (const char* e = std::getenv("HIPADJ_HIPRTC")) want = e;                       // a path, or a bare soname = "whatever the process has"
+        else {
+            std::vector<std::string> roots;
+            if (const char* r = std::getenv("ROCM_PATH")) roots.push_back(r);
+            roots.push_back(HIPADJ_ROCM_PATH);
+            for (const auto& r : roots) { const std::string c = rtc_realpath(r + "/lib/libhiprtc.so"); if (!c.empty()) { want = c; break; } }
+        }
+        if (!want.empty() && want.find('/') != std::string::npos) {
+            const std::string rp = rtc_realpath(want);
+            if (!rp.empty()) {
+                RtcForeign f{rtc_dirname(rp), false};
+                dl_iterate_phdr(rtc_phdr_cb, &f);
+                A.lib = f.found ? dlmopen(LM_ID_NEWLM, rp.c_str(), RTLD_NOW | RTLD_LOCAL) : dlopen(rp.c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (A.lib) { A.path = rp; A.isolated = f.found; }
+            }
+        } else if (!want.empty()) { A.lib = dlopen(want.c_str(), RTLD_NOW | RTLD_LOCAL); if (A.lib) A.path = want; }
+        if (!A.lib) {
+            const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
+            for (const char* nm : names) { A.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (A.lib) { A.path = nm; break; } }
+        }
         if (!A.lib) { A.err = "hiprtc not found (libhiprtc.so): runtime-compiled models are unavailable"; return; }
         auto S = [&](const char* s) { void* p = dlsym(A.lib, s); if (!p && A.err.empty()) A.err = std::string("hiprtc symbol missing: ") + s; return p; };
         A.CreateProgram = (decltype(A.CreateProgram))S("hiprtcCreateProgram");
@@ -96,6 +144,29 @@ inline RtcApi& rtc_api() {
         A.DestroyProgram = (decltype(A.DestroyProgram))S("hiprtcDestroyProgram");
     });
     return A;
+}
+
+// "path [own link-map namespace]; HIP x.y.z" of the bound hiprtc: the HIP version is the one the compiler itself reports (hiprtc defines
+// HIP_VERSION_* for every program; a one-line probe prints them through #pragma message).
+inline std::string rtc_describe() {
+    RtcApi& A = rtc_api();
+    if (!A.lib || !A.err.empty()) return A.err.empty() ? "hiprtc unavailable" : A.err;
+    static std::string ver;
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        const char* src = "#define HIPADJ_S2(x) #x\n#define HIPADJ_S(x) HIPADJ_S2(x)\n"
+                          "#pragma message(\"hipadj-probe \" HIPADJ_S(HIP_VERSION_MAJOR) \".\" HIPADJ_S(HIP_VERSION_MINOR) \".\" HIPADJ_S(HIP_VERSION_PATCH) \" end\")\n";
+        hiprtcProgram prog = nullptr;
+        if (A.CreateProgram(&prog, src, "hipadj_probe.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return;
+        const char* opts[] = {"--offload-arch=gfx950"};
+        (void)A.CompileProgram(prog, 1, opts);
+        size_t ls = 0; A.GetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0'); if (ls) A.GetProgramLog(prog, &log[0]);
+        A.DestroyProgram(&prog);
+        const size_t a = log.find("hipadj-probe "), b = log.find(" end", a == std::string::npos ? 0 : a);
+        if (a != std::string::npos && b != std::string::npos) ver = log.substr(a + 13, b - a - 13);
+    });
+    return A.path + (A.isolated ? " [own link-map namespace]" : "") + "; HIP " + (ver.empty() ? "?" : ver);
 }
 
 // directory holding the library's kernel headers: $HIPADJ_CSRC_DIR, else csrc/ next to libhipadj.so
@@ -364,10 +435,20 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         size_t cs = 0; A.GetCodeSize(prog, &cs);
         code.assign(cs, 0); A.GetCode(prog, code.data());
         A.DestroyProgram(&prog);
+        if (const char* ov = std::getenv("HIPADJ_RTC_OVERRIDE")) {   // debugging hook: run a code object built offline (hipcc) from the translation unit HIPADJ_RTC_DUMP wrote
+            if (FILE* fp = std::fopen(ov, "rb")) { std::fseek(fp, 0, SEEK_END); const long sz = std::ftell(fp); std::fseek(fp, 0, SEEK_SET); code.assign((size_t)sz, 0); if (std::fread(code.data(), 1, (size_t)sz, fp) != (size_t)sz) code.clear(); std::fclose(fp); }
+        }
         if (const char* d = std::getenv("HIPADJ_RTC_DUMP")) {   // debugging hook: keep the code object (llvm-objdump -d, llvm-readelf --notes)
             static int serial = 0;
             const std::string fn = std::string(d) + "/" + src.name + "_" + std::to_string(serial++) + ".hsaco";
             if (FILE* fp = std::fopen(fn.c_str(), "wb")) { std::fwrite(code.data(), 1, code.size(), fp); std::fclose(fp); }
+            if (FILE* fp = std::fopen((fn + ".hip").c_str(), "wb")) {   // ... and the translation unit, with the instantiations spelled out (hipcc -S / -emit-llvm studies)
+                std::fwrite(tu.data(), 1, tu.size(), fp);
+                std::fprintf(fp, "void* hipadj_name_expressions[] = {");
+                for (const auto& e : exprs) std::fprintf(fp, "(void*)&%s, ", e.c_str());
+                std::fprintf(fp, "nullptr};\n");
+                std::fclose(fp);
+            }
         }
         std::string where;
         const int flagged = user_isa_check(code, where);

@@ -122,5 +122,9 @@ def adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, *, t=None, dgd
         du0, dpj = adjoint_sensitivities(sol.pieces[j], alg, t=sol.pieces[j].t, dgdu_discrete=dj, **kw)
         gp = gp + np.asarray(dpj).reshape(N, npar)
         if j > 0:                                                    # reverse callback of the event between piece j - 1 and piece j
-            lam_in, gp = _lib.affect_vjp(sol.model_id, sol.u_left[j - 1], sol.p_piece[j - 1], sol.edges[j], du0, gp, device=sol.device)
+            # with a mass matrix a piece returns the reference's lam(t0) = M^{-T} dL/du (src/sensitivity_interface.jl:500); the callback acts on
+            # dL/du itself, and the cotangent handed to the lower piece is a dL/du as well: convert (rows: lam' M)
+            M = _lib.MASS.get(sol.model_id)
+            lam_true = du0 if M is None else du0 @ M
+            lam_in, gp = _lib.affect_vjp(sol.model_id, sol.u_left[j - 1], sol.p_piece[j - 1], sol.edges[j], lam_true, gp, device=sol.device)
     return du0, (gp.sum(axis=0) if shared else gp)

@@ -15,7 +15,7 @@ _CSRC = os.path.join(_ROOT, "scimlsensitivity.jl_amd", "csrc")
 
 
 def build(force=False):
-    """Seven translation units (-DEMU_UNIT=0..6: entry points + one unit per model) compiled in parallel, then linked."""
+    """Eight translation units (-DEMU_UNIT=0..7: entry points + one unit per model) compiled in parallel, then linked."""
     from concurrent.futures import ThreadPoolExecutor
     deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("hipadj_lane.hpp", "hipadj_models.hpp", "hipadj_plan.hpp", "hipadj_adaptive.hpp")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
@@ -26,14 +26,21 @@ def build(force=False):
             obj = os.path.join(objdir, f"unit{k}.o")
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-DEMU_UNIT={k}", "-c", _SRC, "-o", obj])
             return obj
-        with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as pool:
-            objs = list(pool.map(unit, range(7)))
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(unit, range(8)))
         subprocess.check_call(["g++", "-shared", "-fPIC", "-o", _LIB + ".tmp"] + objs)
         os.replace(_LIB + ".tmp", _LIB)
     return _LIB
 
 
 _lib = None
+_EMU_ONLY = {"emu_ring4": 4, "emu_ring5mm": 105}      # test-only models of lane_emu.cpp (offset from MODEL_USER_BASE)
+
+
+def ring_mm_inverse(n):
+    """M^{-1} of lane_emu.cpp's EmuRingMM<n>."""
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    return 0.8 * (i == j) + 0.15 * np.sin(1.0 + 3.0 * i + 7.0 * j)
 
 
 def lib():
@@ -53,7 +60,7 @@ def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shi
     save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
     c = PL.HipadjConfig()
     c.struct_size = C.sizeof(PL.HipadjConfig)
-    c.model, c.alg, c.stepper = (PL.MODEL_USER_BASE + 4 if model == "emu_ring4" else PL.MODEL[model]), PL.ALG[alg], stepper   # emu_ring4: test-only model of lane_emu.cpp
+    c.model, c.alg, c.stepper = _EMU_ONLY[model] + PL.MODEL_USER_BASE if model in _EMU_ONLY else PL.MODEL[model], PL.ALG[alg], stepper   # emu_ring4: test-only model of lane_emu.cpp
     c.ntraj = ntraj
     c.t0, c.t1, c.dt = t0, t1, dt
     c.nsave = len(save)

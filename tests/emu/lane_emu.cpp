@@ -34,10 +34,32 @@ template <int NN> struct EmuRing {
         dg[N] = s;
     }
 };
+// TEST-ONLY: the ring behind a constant mass matrix, wrapped the way the generator of hipadj_user.hpp wraps a runtime model that has one
+// (F = M^{-1} f, F_u^T lam = f_u^T (M^{-T} lam), likewise F_p).  M^{-1}[i][j] = 0.8 [i == j] + 0.15 sin(1 + 3 i + 7 j) (tests/emu.py holds the
+// same formula); n = 5 is the first ring whose Gauss pass is NOT time-segmented ((1 + n)(n + np) > 64).  Model id = HIPADJ_MODEL_USER_BASE + 100 + n.
+template <int NN> struct EmuRingMM {
+    static constexpr int N = NN, NP = NN + 1;
+    static constexpr bool TIME_DEP = true;
+    static double minv(int i, int j) { return (i == j ? 0.8 : 0.0) + 0.15 * std::sin(1.0 + 3.0 * i + 7.0 * j); }
+    static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) {
+        double r[N]; EmuRing<NN>::f(r, u, p, t);
+        for (int i = 0; i < N; ++i) { double s = 0.0; for (int j = 0; j < N; ++j) s += minv(i, j) * r[j]; du[i] = s; }
+    }
+    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) {
+        double w[N];
+        for (int i = 0; i < N; ++i) { double s = 0.0; for (int j = 0; j < N; ++j) s += minv(j, i) * l[j]; w[i] = s; }
+        EmuRing<NN>::vjp_u(dl, w, u, p, t);
+    }
+    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) {
+        double w[N];
+        for (int i = 0; i < N; ++i) { double s = 0.0; for (int j = 0; j < N; ++j) s += minv(j, i) * l[j]; w[i] = s; }
+        EmuRing<NN>::vjp_p(dg, w, u, p, t);
+    }
+};
 static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
     const int nn = model - HIPADJ_MODEL_USER_BASE;
-    if (nn != 4) return HIPADJ_ERR_INVALID_ARG;
-    *n = nn; *np = nn + 1;
+    if (nn != 4 && nn != 105) return HIPADJ_ERR_INVALID_ARG;
+    *n = nn % 100; *np = nn % 100 + 1;
     return HIPADJ_OK;
 }
 static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, true);
@@ -369,7 +391,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 
 // Build units (tests/emu.py compiles them in parallel): EMU_UNIT undefined = everything in one translation unit (the variant builds
 // of test_emu_parity.py); EMU_UNIT = 0 = the C entry points, the per-model dispatchers declared `extern template`;
-// EMU_UNIT = 1..6 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
+// EMU_UNIT = 1..7 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
 #ifndef EMU_UNIT
 #define EMU_UNIT -1
 #endif
@@ -395,6 +417,7 @@ extern template int dispatch_mode<ModelLorenz>(const hipadj_config*, const Plan&
 extern template int dispatch_mode<ModelLinDiag>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<ModelFallMass>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRing<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuRingMM<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 1
 template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 2
@@ -407,6 +430,8 @@ template int dispatch_mode<ModelLinDiag>(const hipadj_config*, const Plan&, cons
 template int dispatch_mode<ModelFallMass>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 6
 template int dispatch_mode<EmuRing<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 7
+template int dispatch_mode<EmuRingMM<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #endif
 
 #if EMU_UNIT <= 0
@@ -430,6 +455,7 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     case HIPADJ_MODEL_LINDIAG: return dispatch_mode<ModelLinDiag>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_FALLMASS: return dispatch_mode<ModelFallMass>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 4: return dispatch_mode<EmuRing<4>>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 105: return dispatch_mode<EmuRingMM<5>>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

@@ -25,8 +25,33 @@ def test_library_exports_every_declared_symbol(sa):
     assert set(names) == set(_lib.DECLARED_SYMBOLS)
     for nm in names:
         assert hasattr(L, nm), nm
-    assert L.hipadj_version() == 104
+    assert L.hipadj_version() == 105
     assert L.hipadj_status_string(-2).decode().startswith("no usable HIP device")
+
+
+def test_runtime_models_are_compiled_by_the_build_toolkits_hiprtc(sa):
+    """One compiler for all device code: libhipadj.so binds the hiprtc of the ROCm toolkit it was built with, also in a process whose torch wheel
+    carries an older hiprtc / comgr pair (then in its own link-map namespace).  The older bundled compiler miscompiled a wide runtime model
+    (tests/test_gpu_mass_matrix.py::test_wide_ring_dense_mass_matrix_gauss_regression, DESIGN.md 6.8); HIPADJ_HIPRTC overrides the choice."""
+    import os, subprocess, sys
+    from scimlsensitivity_jl_amd import _lib
+    desc = _lib.runtime_compiler()
+    root = os.path.realpath(os.environ.get("ROCM_PATH", "/opt/rocm"))
+    assert desc.startswith(root + "/lib/libhiprtc.so"), desc
+    with open(os.path.join(root, ".info", "version")) as fh:
+        major_minor = ".".join(fh.read().strip().split(".")[:2])
+    assert f"; HIP {major_minor}." in desc, desc
+    import torch
+    bundled = os.path.exists(os.path.join(os.path.dirname(torch.__file__), "lib", "libhiprtc.so"))
+    if bundled and "HIPADJ_NO_TORCH" not in os.environ:
+        assert "[own link-map namespace]" in desc, desc
+    # a torch-free host process (what the Julia glue is) takes the same library by a plain dlopen; the explicit override is honoured
+    code = "import sys; sys.path.insert(0, %r); from scimlsensitivity_jl_amd import _lib; print(_lib.runtime_compiler())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPADJ_NO_TORCH="1"), capture_output=True, text=True, timeout=300).stdout
+    assert out.startswith(root + "/lib/libhiprtc.so") and "namespace" not in out, out
+    if bundled:
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPADJ_HIPRTC="libhiprtc.so"), capture_output=True, text=True, timeout=300).stdout
+        assert out.startswith("libhiprtc.so; HIP "), out
 
 
 def test_struct_layouts_match_header(sa, tmp_path):
@@ -304,7 +329,7 @@ def test_c_host_compiles_against_the_header_and_fails_loudly_without_a_device(sa
     sa.load_library()
     exe = _build_host_demo(sa, tmp_path)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
-    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 104" in r.stdout
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 105" in r.stdout
 
 
 class _StubEngine:

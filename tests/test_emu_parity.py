@@ -435,6 +435,30 @@ def test_rk4_ring4_matches_oracle(alg):
         assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
 
 
+@pytest.mark.parametrize("alg", ["interpolating", "gauss", "gausskronrod", "backsolve", "quadrature"])
+def test_wide_ring5_with_mass_matrix_one_column_path(alg):
+    """emu_ring5mm: the 5-state ring behind a dense constant mass matrix, wrapped as the generator of hipadj_user.hpp wraps a runtime model
+    (F = M^-1 f, VJPs through M^-T).  (1 + n)(n + np) = 66 > 64: the sweeps are NOT time-segmented (NC = 1 lanes + k_finish_map on the device) —
+    the configuration in which a runtime model was once miscompiled by an older hiprtc; here the lane logic itself against
+    the oracle in its mass-matrix formulation.  The emulated lanes return nu(t0) = M' lam(t0) (the device's k_mass_du0 maps back)."""
+    rng = np.random.default_rng(5)
+    n, npar, N, T = 5, 6, 6, 2.0
+    u0 = rng.uniform(0.3, 1.0, (N, n)); ts = np.array([0.4, 1.1, 2.0]); delta = rng.standard_normal((N, 3, n))
+    pp = rng.uniform(0.4, 1.2, (N, npar))
+    M = np.linalg.inv(E.ring_mm_inverse(n))
+    for segs in (1, 3):
+        if alg in ("quadrature", "gausskronrod") and segs > 1:
+            continue
+        cfg = E.make_config("emu_ring5mm", alg, N, 0.0, T, 0.01, ts, loss_kind=0, p_shared=False, time_segments=segs, checkpointing=(alg == "backsolve"), ckpt_stride=10,
+                            quad_abstol=1e-12, quad_reltol=1e-12)
+        du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+        with O.mass_matrix(M):
+            ref = O.Problem("RING", alg=("GAUSS_KRONROD" if alg == "gausskronrod" else alg.upper()), t0=0.0, t1=T, save_times=ts, loss="COTANGENT", dims=(n, 0, 0, 0), stepper="RK4", dt=0.01,
+                            checkpointing=(alg == "backsolve"), checkpoints=np.arange(0, 201, 10) * 0.01, quad_abstol=1e-12, quad_reltol=1e-12)
+            rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+        assert rel(out, rout) < 1e-12 and rel(du0, rdu0 @ M) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
 OFFGRID_TS = [
     [0.0, 0.333, 0.71, 1.5],                 # off the grid in the middle, both end points
     [0.137, 0.4, 0.40499, 1.2345],           # neither end point; one on-grid time; two stops less than one step apart

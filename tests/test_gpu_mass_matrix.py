@@ -118,3 +118,32 @@ def test_mass_matrix_can_be_removed_and_identity_is_a_no_op(sa):
     plain.set_mass_matrix(None); d = run()
     assert rel(b[0], a[0]) < 1e-14 and rel(b[1], a[1]) < 1e-14 and rel(d[0], a[0]) == 0 and rel(d[1], a[1]) == 0
     assert rel(c[1], a[1]) > 1e-3                                  # a different system
+
+
+@pytest.mark.parametrize("auto", [False, True])
+@pytest.mark.parametrize("nring", [5, 6])
+def test_wide_ring_dense_mass_matrix_gauss_regression(sa, nring, auto):
+    """Regression: 5- / 6-state ring (one-column, non-segmented sweeps) behind a dense mass matrix, GaussAdjoint + RK4.  Compiled by the hiprtc a
+    torch wheel bundles (ROCm 7.0) this kernel returned parameter gradients wrong from the 6th digit up to non-finite; the library now binds
+    the build toolkit's compiler (hipadj_runtime_compiler)."""
+    import user_models as UM
+    from scimlsensitivity_jl_amd import _lib
+    assert "HIP 7.0" not in _lib.runtime_compiler()
+    rng = np.random.default_rng(5)
+    m = UM.ring(nring); n, npar = m["n"], m["np"]
+    f = sa.DeviceFunction(f"ring{nring}_mmreg{int(auto)}", n, npar, m["f"], *(() if auto else (m["vjp"], m["vjp_p"])))
+    for N in (3, 54):
+        u0 = rng.uniform(0.3, 1.0, (N, n)); ts = np.array([0.4, 1.1, 2.0]); delta = rng.standard_normal((N, 3, n))
+        M = np.eye(n) * 1.5 + 0.3 * rng.standard_normal((n, n))
+        f.set_mass_matrix(M)
+        pp = rng.uniform(0.4, 1.2, (N, npar))
+        for alg, oalg in (("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD"), ("interpolating", "INTERPOLATING")):
+            sens = dict(gauss=sa.GaussAdjoint, gausskronrod=sa.GaussKronrodAdjoint, interpolating=sa.InterpolatingAdjoint)[alg]()
+            sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 2.0), pp[0], (nring, 0, 0, 0)), u0, pp), sa.RK4(), dt=0.01, saveat=ts, sensealg=sens)
+            du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), dgdu_discrete=delta)
+            with O.mass_matrix(M):
+                ref = O.Problem("RING", alg=oalg, t0=0.0, t1=2.0, save_times=ts, loss="COTANGENT", dims=(nring, 0, 0, 0), stepper="RK4", dt=0.01)
+                rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+            assert rel(sol.u, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-9, (nring, auto, N, alg)
+            sol.engine.close()
+    f.set_mass_matrix(None)
