@@ -490,11 +490,12 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     const int n = h->n, np = h->np;
     const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);
     const int cc = mode >> 1;
-    int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : 1; const int PFG = n <= 3 ? 4 : 1;   // more than three states: the plain rolled sweep (reverse_sweep, PF == 1)
+    int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : 1, PFG = n <= 3 ? 4 : 1;   // more than three states: the plain rolled sweep (reverse_sweep, PF == 1)
     if (const char* e = std::getenv("HIPADJ_USER_PF")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) PF = v; }   // tuning hook: prefetch depth of k_interp for runtime models
+    if (const char* e = std::getenv("HIPADJ_USER_PFG")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) PFG = v; }   // ... and of k_gauss / k_quad_adj
     auto I = [](int v) { return std::to_string(v); };
     UserKernels k;
-    const bool seg = (1 + n) * (n + np) <= 64;          // same rule as the planner: wider models stay sequential in time ...
+    const bool seg = plan_seg_fits(n, np);              // same rule as the planner: wider models stay sequential in time ...
     const std::string SG = seg ? ", true>" : ", false>";  // ... and compile only the one-column path (k_interp SEG)
     const std::string finish = "hipadj::k_finish<" + I(n) + ", " + I(np) + ">";
     const std::string compose = seg ? "hipadj::k_compose_finish<" + U + ">" : "hipadj::k_finish_map<" + I(n) + ", " + I(np) + ">";
@@ -673,7 +674,7 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         }
     }
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
-    const bool seg_kernels = (1 + h->n) * (h->n + h->np) <= 64;
+    const bool seg_kernels = plan_seg_fits(h->n, h->np);
     if (composed && seg_kernels)
         TRY(usig<decltype(&k_compose_finish<ModelLV>)>::launch(h, h->uf_tail, dim3(cblocks), dim3(FIN), h->g, h->nseg, (const double*)h->d_segbuf, d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, no_sum));
     else if (composed)

@@ -280,60 +280,108 @@ HIPADJ_HD void adj_rk4_step_ops(const Knot<Mo>& hi, const Knot<Mo>& lo, const do
     }
 }
 
+// One RK4 step of the adjoint for the column(s) held in `lam` / `mu`: LT = double is one column, LT = Cols<G> a bundle of G columns that go through
+// the model's VJP bodies as one scalar (hipadj_models.hpp).  `aff`: the (first) column is the affine one and takes the cost terms.
+// V1_out (optional): (df/du)^T lam at the step's start, which GaussAdjoint reuses as the Hermite slope of lam there.
+template <class Mo, class LT, bool WITH_MU, int CC>
+HIPADJ_HD void adj_rk4_core(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&ymid)[Mo::N], const double (&pv)[Mo::NP], double t_lo, double dt,
+                            LT (&lam)[Mo::N], LT (&mu)[Mo::NP], bool aff, const double (&gu1)[Mo::N], const double (&gum)[Mo::N], const double (&gu4)[Mo::N],
+                            LT (*V1_out)[Mo::N] = nullptr) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    using MV = model_vjp<Mo, LT>;
+    const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
+    LT V1[N], V2[N], V3[N], V4[N], l2[N], l3[N], l4[N];
+    MV::u(V1, lam, hi.u, pv, t_hi);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V1[j], gu1[j]); }
+    if (V1_out) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) (*V1_out)[j] = V1[j]; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) l2[j] = lam[j] + (0.5 * dt) * V1[j];
+    MV::u(V2, l2, ymid, pv, t_mid);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V2[j], gum[j]); }
+#pragma unroll
+    for (int j = 0; j < N; ++j) l3[j] = lam[j] + (0.5 * dt) * V2[j];
+    MV::u(V3, l3, ymid, pv, t_mid);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V3[j], gum[j]); }
+#pragma unroll
+    for (int j = 0; j < N; ++j) l4[j] = lam[j] + dt * V3[j];
+    MV::u(V4, l4, lo.u, pv, t_lo);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V4[j], gu4[j]); }
+    if (WITH_MU) {
+        // mu' = -(df/dp)^T lam, RK4 weights 1:2:2:1.  (df/dp)^T lam is linear in lam and stages 2 and 3 share the
+        // same y (the Hermite midpoint) and t, so their two VJPs collapse into one on lam_2 + lam_3.
+        LT W1[NP], W23[NP], W4[NP], l23[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) l23[j] = l2[j] + l3[j];
+        MV::p_(W1, lam, hi.u, pv, t_hi);
+        MV::p_(W23, l23, ymid, pv, t_mid);
+        MV::p_(W4, l4, lo.u, pv, t_lo);
+        if (cost_has_gp<CC>::value && aff) {   // dgrad -= g_p: like g_u it only drives the affine column; stages 2 and 3 share ymid
+            double gp1[NP], gpm[NP], gp4[NP];
+            cost_grad_p<Mo, CC>(hi.u, pv, t_hi, gp1); cost_grad_p<Mo, CC>(ymid, pv, t_mid, gpm); cost_grad_p<Mo, CC>(lo.u, pv, t_lo, gp4);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { cols_add_first(W1[j], gp1[j]); cols_add_first(W23[j], 2.0 * gpm[j]); cols_add_first(W4[j], gp4[j]); }
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[j] = mu[j] + (dt / 6.0) * (W1[j] + 2.0 * W23[j] + W4[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[j] = lam[j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+}
+
+// columns C0, C0 + G, ... of a segment lane, bundle by bundle (the last bundle may be narrower; a bundle of one column runs as plain doubles)
+template <class Mo, int NC, int C0, int G, bool WITH_MU, int CC>
+HIPADJ_HD void adj_rk4_bundles(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&ymid)[Mo::N], const double (&pv)[Mo::NP], double t_lo, double dt,
+                               double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP], const double (&gu1)[Mo::N], const double (&gum)[Mo::N], const double (&gu4)[Mo::N]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    if constexpr (C0 < NC) {
+        constexpr int W = (NC - C0 < G) ? NC - C0 : G;
+        if constexpr (W == 1) adj_rk4_core<Mo, double, WITH_MU, CC>(hi, lo, ymid, pv, t_lo, dt, lam[C0], mu[C0], C0 == 0, gu1, gum, gu4);
+        else {
+            Cols<W> L[N], M_[NP];
+#pragma unroll
+            for (int g = 0; g < W; ++g) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) L[j].v[g] = lam[C0 + g][j];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) M_[j].v[g] = mu[C0 + g][j];
+            }
+            adj_rk4_core<Mo, Cols<W>, WITH_MU, CC>(hi, lo, ymid, pv, t_lo, dt, L, M_, C0 == 0, gu1, gum, gu4);
+#pragma unroll
+            for (int g = 0; g < W; ++g) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) lam[C0 + g][j] = L[j].v[g];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) mu[C0 + g][j] = M_[j].v[g];
+            }
+        }
+        adj_rk4_bundles<Mo, NC, C0 + W, G, WITH_MU, CC>(hi, lo, ymid, pv, t_lo, dt, lam, mu, gu1, gum, gu4);
+    }
+}
+
 template <class Mo, int NC, bool WITH_MU, int CC = 0>
 HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&pv)[Mo::NP], double t_lo, double dt,
                             double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP]) {
-    constexpr int N = Mo::N, NP = Mo::NP;
+    constexpr int N = Mo::N;
     double ymid[N], gu1[N], gum[N], gu4[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]);
+    for (int j = 0; j < N; ++j) { ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]); gu1[j] = 0.0; gum[j] = 0.0; gu4[j] = 0.0; }
     const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
     if (CC) { cost_grad_u<Mo, CC>(hi.u, pv, t_hi, gu1); cost_grad_u<Mo, CC>(ymid, pv, t_mid, gum); cost_grad_u<Mo, CC>(lo.u, pv, t_lo, gu4); }
+    if constexpr (NC > 1 && model_has_cols<Mo>::value && cols_bundle<N, NC>::NB == 1)
+        adj_rk4_bundles<Mo, NC, 0, cols_bundle<N, NC>::G, WITH_MU, CC>(hi, lo, ymid, pv, t_lo, dt, lam, mu, gu1, gum, gu4);
+    else {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        double V1[N], V2[N], V3[N], V4[N], l2[N], l3[N], l4[N];
-        Mo::vjp_u(V1, lam[c], hi.u, pv, t_hi);
-        if (CC && c == 0) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) V1[j] += gu1[j]; }
-#pragma unroll
-        for (int j = 0; j < N; ++j) l2[j] = lam[c][j] + (0.5 * dt) * V1[j];
-        Mo::vjp_u(V2, l2, ymid, pv, t_mid);
-        if (CC && c == 0) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) V2[j] += gum[j]; }
-#pragma unroll
-        for (int j = 0; j < N; ++j) l3[j] = lam[c][j] + (0.5 * dt) * V2[j];
-        Mo::vjp_u(V3, l3, ymid, pv, t_mid);
-        if (CC && c == 0) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) V3[j] += gum[j]; }
-#pragma unroll
-        for (int j = 0; j < N; ++j) l4[j] = lam[c][j] + dt * V3[j];
-        Mo::vjp_u(V4, l4, lo.u, pv, t_lo);
-        if (CC && c == 0) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) V4[j] += gu4[j]; }
-        if (WITH_MU) {
-            // mu' = -(df/dp)^T lam, RK4 weights 1:2:2:1.  (df/dp)^T lam is linear in lam and stages 2 and 3 share the
-            // same y (the Hermite midpoint) and t, so their two VJPs collapse into one on lam_2 + lam_3.
-            double W1[NP], W23[NP], W4[NP], l23[N];
-#pragma unroll
-            for (int j = 0; j < N; ++j) l23[j] = l2[j] + l3[j];
-            Mo::vjp_p(W1, lam[c], hi.u, pv, t_hi);
-            Mo::vjp_p(W23, l23, ymid, pv, t_mid);
-            Mo::vjp_p(W4, l4, lo.u, pv, t_lo);
-            if (cost_has_gp<CC>::value && c == 0) {   // dgrad -= g_p: like g_u it only drives the affine column; stages 2 and 3 share ymid
-                double gp1[NP], gpm[NP], gp4[NP];
-                cost_grad_p<Mo, CC>(hi.u, pv, t_hi, gp1); cost_grad_p<Mo, CC>(ymid, pv, t_mid, gpm); cost_grad_p<Mo, CC>(lo.u, pv, t_lo, gp4);
-#pragma unroll
-                for (int j = 0; j < NP; ++j) { W1[j] += gp1[j]; W23[j] += 2.0 * gpm[j]; W4[j] += gp4[j]; }
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) mu[c][j] = mu[c][j] + (dt / 6.0) * (W1[j] + 2.0 * W23[j] + W4[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < N; ++j) lam[c][j] = lam[c][j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+        for (int c = 0; c < NC; ++c) adj_rk4_core<Mo, double, WITH_MU, CC>(hi, lo, ymid, pv, t_lo, dt, lam[c], mu[c], c == 0, gu1, gum, gu4);
     }
 }
 
@@ -584,8 +632,8 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
     else reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot, init, step);
 }
 
-template <int N>
-HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double (&f0)[N], const double (&u1)[N], const double (&f1)[N], double (&y)[N]);
+template <int N, class LT = double>
+HIPADJ_HD void hermite(double th, double h, const LT (&u0)[N], const LT (&f0)[N], const LT (&u1)[N], const LT (&f1)[N], LT (&y)[N]);
 
 // ------------------------------------------------------------------------------------------------
 // InterpolatingAdjoint with loss times OFF the step grid (fixed-step RK4, saveat not a multiple of dt — including the end
@@ -906,8 +954,8 @@ HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const d
 }
 
 // cubic Hermite at general theta on a step (u0,f0) -> (u1,f1) of signed length h
-template <int N>
-HIPADJ_HD void hermite(double th, double h, const double (&u0)[N], const double (&f0)[N], const double (&u1)[N], const double (&f1)[N], double (&y)[N]) {
+template <int N, class LT>
+HIPADJ_HD void hermite(double th, double h, const LT (&u0)[N], const LT (&f0)[N], const LT (&u1)[N], const LT (&f1)[N], LT (&y)[N]) {
 #pragma unroll
     for (int j = 0; j < N; ++j)
         y[j] = (1.0 - th) * u0[j] + th * u1[j] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (u1[j] - u0[j]) + (th - 1.0) * h * f0[j] + th * h * f1[j]);
@@ -932,6 +980,70 @@ struct GK15 {
 // for RK4) of  -(df/dp)^T lam  over the step, with lambda from the ADJOINT step's Hermite interpolant (FSAL
 // derivatives at both ends) and y from the forward interpolant  (src/gauss_adjoint.jl:745-759, 809-851).
 // Time runs backward, so the accumulated sum equals int_{t0}^{T} lam^T f_p dt.
+// One GaussAdjoint step (2-point rule) for the column(s) in lam / mu; LT as in adj_rk4_core.  yg: the forward state at the two Gauss nodes.
+template <class Mo, class LT, int CC>
+HIPADJ_HD void gauss_core(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&ymid)[Mo::N], const double (&yg)[2][Mo::N], const double (&pv)[Mo::NP],
+                          double t_lo, double dt, LT (&lam)[Mo::N], LT (&mu)[Mo::NP], bool aff,
+                          const double (&guh)[Mo::N], const double (&gum)[Mo::N], const double (&gul)[Mo::N]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    using MV = model_vjp<Mo, LT>;
+    const double xg = 0.5773502691896257645, t_hi = t_lo + dt;
+    LT lam_hi[N], d_hi[N], d_lo[N], V[N], dummy_mu[NP];
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam_hi[j] = lam[j];
+    adj_rk4_core<Mo, LT, false, CC>(hi, lo, ymid, pv, t_lo, dt, lam, dummy_mu, aff, guh, gum, gul, &V);   // V = (df/du)^T lam (+ g_u) at t_hi: fsalfirst of the adjoint step
+#pragma unroll
+    for (int j = 0; j < N; ++j) d_hi[j] = -V[j];
+    MV::u(V, lam, lo.u, pv, t_lo);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V[j], gul[j]); }
+#pragma unroll
+    for (int j = 0; j < N; ++j) d_lo[j] = -V[j];                                                          // fsallast
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double th = 0.5 * (1.0 + (q == 0 ? -xg : xg));
+        LT lg[N], W[NP];
+        hermite<N, LT>(th, -dt, lam_hi, d_hi, lam, d_lo, lg);
+        MV::p_(W, lg, yg[q], pv, t_hi - th * dt);
+        if (cost_has_gp<CC>::value && aff) {   // + g_p at the node (affine column only); sign: DESIGN.md 6.5 — Gauss == Interpolating == Quadrature
+            double gp[NP]; cost_grad_p<Mo, CC>(yg[q], pv, t_hi - th * dt, gp);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) cols_add_first(W[j], gp[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mu[j] = mu[j] + (0.5 * dt) * W[j];
+    }
+}
+template <class Mo, int NC, int C0, int G, int CC>
+HIPADJ_HD void gauss_bundles(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&ymid)[Mo::N], const double (&yg)[2][Mo::N], const double (&pv)[Mo::NP], double t_lo, double dt,
+                             double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP], const double (&guh)[Mo::N], const double (&gum)[Mo::N], const double (&gul)[Mo::N]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    if constexpr (C0 < NC) {
+        constexpr int W = (NC - C0 < G) ? NC - C0 : G;
+        if constexpr (W == 1) gauss_core<Mo, double, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam[C0], mu[C0], C0 == 0, guh, gum, gul);
+        else {
+            Cols<W> L[N], M_[NP];
+#pragma unroll
+            for (int g = 0; g < W; ++g) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) L[j].v[g] = lam[C0 + g][j];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) M_[j].v[g] = mu[C0 + g][j];
+            }
+            gauss_core<Mo, Cols<W>, CC>(hi, lo, ymid, yg, pv, t_lo, dt, L, M_, C0 == 0, guh, gum, gul);
+#pragma unroll
+            for (int g = 0; g < W; ++g) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) lam[C0 + g][j] = L[j].v[g];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) mu[C0 + g][j] = M_[j].v[g];
+            }
+        }
+        gauss_bundles<Mo, NC, C0 + W, G, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam, mu, guh, gum, gul);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Like interp_lane the sweep is linear in (lam, mu) given y(t), so it takes NC columns (affine + basis) and a segment
 // [k_lo, k_hi): the same time segmentation and composition apply.
@@ -960,6 +1072,19 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
     };
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
         const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
+        if constexpr (!GKR && NC > 1 && model_has_cols<Mo>::value && cols_bundle<N, NC, HIPADJ_COLS_ELEMS_GAUSS>::NB == 1) {   // column bundles (hipadj_models.hpp): the same step, G columns per pass through the model's VJPs
+            double ymid[N], guh[N], gum[N], gul[N], yg[2][N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) { ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]); gum[j] = 0.0; }
+            cost_grad_u<Mo, CC>(hi.u, pv, t_hi, guh); cost_grad_u<Mo, CC>(lo.u, pv, t_lo, gul);
+            if (CC) cost_grad_u<Mo, CC>(ymid, pv, t_lo + 0.5 * dt, gum);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) hermite<N>(1.0 - 0.5 * (1.0 + (q == 0 ? -xg : xg)), dt, lo.u, lo.f, hi.u, hi.f, yg[q]);
+            gauss_bundles<Mo, NC, 0, cols_bundle<N, NC, HIPADJ_COLS_ELEMS_GAUSS>::G, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam, mu, guh, gum, gul);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+            return;
+        }
         double lam_hi[NC][N], d_hi[NC][N], V[N], guh[N], gul[N];
         cost_grad_u<Mo, CC>(hi.u, pv, t_hi, guh); cost_grad_u<Mo, CC>(lo.u, pv, t_lo, gul);      // zero when CC == 0
 #pragma unroll

@@ -40,6 +40,77 @@ __device__ __forceinline__ double hipadj_uniform(double v) {
 inline double hipadj_uniform(double v) { return v; }
 #endif
 
+// ---- column bundles -------------------------------------------------------------------------------------------------------------------
+// A time-segment lane carries 1 + n adjoint columns (hipadj_lane.hpp) and the model's VJPs are LINEAR in lam, so G columns can go through a
+// VJP body as ONE scalar of type Cols<G>: everything that depends on (u, p, t) only — transcendentals, products of states — is then evaluated once
+// per bundle by construction instead of once per column if the optimiser happens to merge the copies (it did not for runtime models with
+// n <= 4 states: sin/cos inlined per column, 2.2x the instructions of the n = 5 kernel).  A model opts in with HAS_COLS and
+// templated bodies vjp_u_t<LT> / vjp_p_t<LT>; only linear operations exist on the type, so a body that is not linear in lam does not compile
+// with it (the runtime-model compiler then falls back to the per-column form).
+template <int G> struct Cols {
+    double v[G];
+    HIPADJ_HD Cols() {}
+    HIPADJ_HD Cols(double x) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) v[g] = x; }
+    HIPADJ_HD Cols(int x) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) v[g] = (double)x; }
+};
+#define HIPADJ_COLS_BIN(OP)                                                                                                      \
+    template <int G> HIPADJ_HD Cols<G> operator OP(const Cols<G>& a, const Cols<G>& b) { Cols<G> r;                              \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) r.v[g] = a.v[g] OP b.v[g];                                                 \
+        return r; }
+HIPADJ_COLS_BIN(+)
+HIPADJ_COLS_BIN(-)
+#undef HIPADJ_COLS_BIN
+template <int G> HIPADJ_HD Cols<G> operator-(const Cols<G>& a) { Cols<G> r;
+#pragma unroll
+    for (int g = 0; g < G; ++g) r.v[g] = -a.v[g];
+    return r; }
+template <int G> HIPADJ_HD Cols<G> operator+(const Cols<G>& a) { return a; }
+template <int G> HIPADJ_HD Cols<G> operator*(double s, const Cols<G>& a) { Cols<G> r;
+#pragma unroll
+    for (int g = 0; g < G; ++g) r.v[g] = s * a.v[g];
+    return r; }
+template <int G> HIPADJ_HD Cols<G> operator*(const Cols<G>& a, double s) { return s * a; }
+template <int G> HIPADJ_HD Cols<G> operator/(const Cols<G>& a, double s) { Cols<G> r;
+#pragma unroll
+    for (int g = 0; g < G; ++g) r.v[g] = a.v[g] / s;
+    return r; }
+template <int G> HIPADJ_HD Cols<G>& operator+=(Cols<G>& a, const Cols<G>& b) { a = a + b; return a; }
+template <int G> HIPADJ_HD Cols<G>& operator-=(Cols<G>& a, const Cols<G>& b) { a = a - b; return a; }
+template <int G> HIPADJ_HD Cols<G>& operator*=(Cols<G>& a, double s) { a = s * a; return a; }
+template <int G> HIPADJ_HD Cols<G>& operator/=(Cols<G>& a, double s) { a = a / s; return a; }
+// the affine column (index 0 of the first bundle) alone receives the cost terms g_u / g_p
+template <int G> HIPADJ_HD void cols_add_first(Cols<G>& a, double x) { a.v[0] += x; }
+HIPADJ_HD void cols_add_first(double& a, double x) { a += x; }
+template <class Mo, class = void> struct model_has_cols { static constexpr bool value = false; };
+template <class Mo> struct model_has_cols<Mo, decltype((void)Mo::HAS_COLS)> { static constexpr bool value = Mo::HAS_COLS; };
+// Bundle width for n states and NC columns: at most ELEMS doubles per bundle vector (seven such vectors are live in an RK4 step), the columns spread
+// evenly over the fewest bundles.  The sweeps bundle only when ONE bundle holds all columns (NB == 1: n <= 4 for InterpolatingAdjoint at 24 elements,
+// n <= 5 for the lambda-only GaussAdjoint step at 32): with two or more bundles the (u, p, t)-dependent work is repeated per bundle and the measured
+// kernels are slower than the per-column form (ring n = 5 / 6 / 8: 4.5 / 7.7 / 19.9 ms against 1.4 / 1.9 / 4.6 ms, profiles/r2_user_cols_ab.log).
+#ifndef HIPADJ_COLS_ELEMS
+#define HIPADJ_COLS_ELEMS 24
+#endif
+#ifndef HIPADJ_COLS_ELEMS_GAUSS
+#define HIPADJ_COLS_ELEMS_GAUSS 32
+#endif
+template <int N, int NC, int ELEMS = HIPADJ_COLS_ELEMS> struct cols_bundle {
+    static constexpr int GMAX = (ELEMS / N) < 2 ? 2 : (ELEMS / N);
+    static constexpr int NB = (NC + GMAX - 1) / GMAX;
+    static constexpr int G = (NC + NB - 1) / NB;
+};
+template <class Mo, class LT> struct model_vjp {   // LT = double: the model's plain entry points; LT = Cols<G>: its templated bodies
+    HIPADJ_HD static void u(LT (&out)[Mo::N], const LT (&lam)[Mo::N], const double (&y)[Mo::N], const double (&p)[Mo::NP], double t) { Mo::template vjp_u_t<LT>(out, lam, y, p, t); }
+    HIPADJ_HD static void p_(LT (&out)[Mo::NP], const LT (&lam)[Mo::N], const double (&y)[Mo::N], const double (&p)[Mo::NP], double t) { Mo::template vjp_p_t<LT>(out, lam, y, p, t); }
+};
+template <class Mo> struct model_vjp<Mo, double> {
+    HIPADJ_HD static void u(double (&out)[Mo::N], const double (&lam)[Mo::N], const double (&y)[Mo::N], const double (&p)[Mo::NP], double t) { Mo::vjp_u(out, lam, y, p, t); }
+    HIPADJ_HD static void p_(double (&out)[Mo::NP], const double (&lam)[Mo::N], const double (&y)[Mo::N], const double (&p)[Mo::NP], double t) { Mo::vjp_p(out, lam, y, p, t); }
+};
+
 constexpr int HIPADJ_CKPT_KMAX = 16;   // longest checkpoint interval (steps) the in-kernel re-solve tile holds
 
 // Lotka-Volterra (test/Core3/user_vjp.jl:6-10): du1 = p1 u1 - p2 u1 u2 ; du2 = -p3 u2 + p4 u1 u2

@@ -106,13 +106,23 @@ inline int plan_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, in
     }
 }
 
+// Widest segment state a lane carries in registers: (1 + n) columns of n + np doubles.  160 admits every runtime model up to n = 8 states with
+// np = n + 1 parameters (9 x 17 = 153 doubles of 512 registers per lane); measured with the ring models, 10^4 trajectories x 1000 steps, 13
+// segments against one: InterpolatingAdjoint 3.2x / 2.8x / 1.6x faster at n = 5 / 6 / 8 (profiles/r2_user_segments_ab.log).  The cap used to be 64
+// because wider kernels came back wrong from the compiler then bound for runtime models.  HIPADJ_SEG_CAP is a tuning hook.
+inline int plan_seg_cap() {
+    static const int cap = [] { const char* e = std::getenv("HIPADJ_SEG_CAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 160; }();
+    return cap;
+}
+inline bool plan_seg_fits(int n, int np) { return (1 + n) * (n + np) <= plan_seg_cap(); }
+
 // Number of time segments per trajectory for the linear (Interpolating) reverse pass: enough
 // (trajectory-wave x segment) workgroups to put ~2 waves on each of the 1024 SIMDs of an MI355X, each segment
 // keeping >= 16 steps.  A non-top segment carries 1 + n columns, so segmentation only pays once the added
 // parallelism exceeds that factor.
 inline int plan_auto_segments(long N, int S, int n, int np = 0) {
     const long waves = (N + 63) / 64;
-    if ((1 + n) * (n + np) > 64) return 1;   // a segment lane holds (1 + n) columns of n + np doubles in VGPRs
+    if (!plan_seg_fits(n, np)) return 1;   // a segment lane holds (1 + n) columns of n + np doubles in VGPRs
     // the segmented kernel needs ~250 VGPRs => 2 resident waves per SIMD => 2048 wave slots on 256 CUs x 4 SIMDs;
     // floor() keeps the grid within ONE residency round (a partial second round would double the makespan)
     long target = 2048 / waves;
@@ -299,7 +309,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }
         P.nck = c;
     }
-    if (P.ip_ckpt && P.user && (1 + n) * (n + np) > 64) {   // the checkpointed sweeps carry the 1 + n segment columns in VGPRs
+    if (P.ip_ckpt && P.user && (1 + n) * (n + np) > 64) {   // the checkpointed sweeps carry the 1 + n segment columns in VGPRs next to the re-solve state (not re-measured beyond 64)
         err = "checkpointing=true for Interpolating/Gauss on the fixed step needs (1 + n)(n + np) <= 64 for a runtime-compiled model (wider models: the adaptive stepper)"; return HIPADJ_ERR_UNSUPPORTED; }
     P.prev_ck.assign(S + 1, 0);
     if (P.ip_ckpt) {
@@ -315,7 +325,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     const long L = seg_offgrid ? (long)P.rs_t.size() : S;      // length of the axis the segments cut
     if (seg_alg && (!P.offgrid || seg_offgrid)) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, (int)L, n, np) : cfg->time_segments;
-        if ((1 + n) * (n + np) > 64) P.nseg = 1;   // segment lanes would not fit the register file
+        if (!plan_seg_fits(n, np)) P.nseg = 1;   // segment lanes would not fit the register file
         if (P.nseg > L) P.nseg = (int)L;
         if (P.nseg < 1) P.nseg = 1;
     }

@@ -45,6 +45,7 @@ struct UserModelSrc {
     bool has_cost = false;
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
     std::string affect;       // DiscreteCallback affect body (hipadj_model_set_affect): modifies un (pre-set to u) from u, p, t; empty = identity
+    bool cols = true;         // the VJP bodies compile for Cols<G> (column bundles); cleared by user_compile when they do not
     bool has_mm = false;      // constant non-singular mass matrix (hipadj_model_set_mass_matrix): minv = M^{-1}, row-major n x n
     double minv[64] = {0};
     int n = 0, np = 0, rev = 0;   // rev: bumped when the sources change, part of the code-cache key
@@ -80,6 +81,11 @@ struct RtcApi {
     hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
     std::string err, path;     // path: the bound libhiprtc
     bool isolated = false;     // loaded with dlmopen next to another hiprtc / comgr copy
+    char*** ns_environ = nullptr;   // `environ` of the C library copy inside that namespace
+    // A link-map namespace holds its own libc, whose `environ` was copied when it was loaded.  setenv in the process (python: os.environ[...] = ...)
+    // may move the array; the copy then dangles and the next getenv inside hiprtc / comgr walks freed memory.  Every entry into the namespace
+    // first points its `environ` at the live array.
+    void enter() const { if (ns_environ) *ns_environ = ::environ; }
 };
 
 // Which hiprtc compiles the runtime models.  A process that has torch loaded carries torch's own HIP runtime, hiprtc and comgr (the wheel
@@ -124,7 +130,7 @@ inline RtcApi& rtc_api() {
                 RtcForeign f{rtc_dirname(rp), false};
                 dl_iterate_phdr(rtc_phdr_cb, &f);
                 A.lib = f.found ? dlmopen(LM_ID_NEWLM, rp.c_str(), RTLD_NOW | RTLD_LOCAL) : dlopen(rp.c_str(), RTLD_NOW | RTLD_LOCAL);
-                if (A.lib) { A.path = rp; A.isolated = f.found; }
+                if (A.lib) { A.path = rp; A.isolated = f.found; if (f.found) A.ns_environ = (char***)dlsym(A.lib, "environ"); }
             }
         } else if (!want.empty()) { A.lib = dlopen(want.c_str(), RTLD_NOW | RTLD_LOCAL); if (A.lib) A.path = want; }
         if (!A.lib) {
@@ -157,6 +163,7 @@ inline std::string rtc_describe() {
         const char* src = "#define HIPADJ_S2(x) #x\n#define HIPADJ_S(x) HIPADJ_S2(x)\n"
                           "#pragma message(\"hipadj-probe \" HIPADJ_S(HIP_VERSION_MAJOR) \".\" HIPADJ_S(HIP_VERSION_MINOR) \".\" HIPADJ_S(HIP_VERSION_PATCH) \" end\")\n";
         hiprtcProgram prog = nullptr;
+        A.enter();
         if (A.CreateProgram(&prog, src, "hipadj_probe.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return;
         const char* opts[] = {"--offload-arch=gfx950"};
         (void)A.CompileProgram(prog, 1, opts);
@@ -192,7 +199,8 @@ inline std::string user_model_struct(const UserModelSrc& m) {
     std::ostringstream o;
     o << "#include \"hipadj_kernels.hpp\"\n#include \"hipadj_adaptive.hpp\"\n#include \"hipadj_dual.hpp\"\n"
       << "namespace hipadj {\n// runtime-registered model '" << m.name << "'\nstruct UserModel {\n"
-      << "    static constexpr int N = " << m.n << ", NP = " << m.np << ";\n    static constexpr bool TIME_DEP = true;\n";
+      << "    static constexpr int N = " << m.n << ", NP = " << m.np << ";\n    static constexpr bool TIME_DEP = true;\n"
+      << "    static constexpr bool HAS_COLS = " << (m.cols ? "true" : "false") << ";   // column bundles through the VJP bodies (hipadj_models.hpp)\n";
     if (m.has_mm) {
         // constant mass matrix M u' = f (ODEFunction(f; mass_matrix = M), src/adjoint_common.jl:110-135): the kernels integrate
         // u' = F(u) = M^{-1} f(u) and the adjoint of THAT system, nu' = -F_u^T nu with the plain jumps nu += g_u.  nu = M^T lam, where lam is
@@ -206,9 +214,9 @@ inline std::string user_model_struct(const UserModelSrc& m) {
             o << ";\n";
         }
         o << "        for (int i = 0; i < N; ++i) v[i] = r[i];\n    }\n"
-          << "    HIPADJ_HD static void mm_invT(double (&w)[N], const double (&lam)[N]) {\n";
+          << "    template <class LT> HIPADJ_HD static void mm_invT(LT (&w)[N], const LT (&lam)[N]) {\n";
         for (int i = 0; i < m.n; ++i) {
-            o << "        w[" << i << "] = 0.0";
+            o << "        w[" << i << "] = LT(0.0)";
             for (int j = 0; j < m.n; ++j) if (m.minv[j * m.n + i] != 0.0) { snprintf(num, sizeof(num), "%.17g", m.minv[j * m.n + i]); o << " + (" << num << ") * lam[" << j << "]"; }
             o << ";\n";
         }
@@ -222,30 +230,40 @@ inline std::string user_model_struct(const UserModelSrc& m) {
             o << "    template <class real> HIPADJ_HD static void f_t(real (&du)[N], const real (&u)[N], const real (&p)[NP], real t) { f_raw_t<real>(du, u, p, t); mm_inv<real>(du); }\n";
         o << ""
           << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) { f_t<double>(du, u, p, t); }\n"
-          << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          // LT = double: one adjoint column; LT = Cols<G>: a bundle of G columns behind ONE dual-number evaluation of f (hipadj_models.hpp)
+          << "    template <class LT> HIPADJ_HD static void vjp_u_t(LT (&out)[N], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        Dual<N> uu[N], pp[NP], dd[N];\n"
           << "        for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n"
           << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
           << "        f_t<Dual<N>>(dd, uu, pp, Dual<N>(t));\n"
-          << "        for (int j = 0; j < N; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n"
-          << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        for (int j = 0; j < N; ++j) { LT s = LT(0.0); for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n"
+          << "    template <class LT> HIPADJ_HD static void vjp_p_t(LT (&out)[NP], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        Dual<NP> uu[N], pp[NP], dd[N];\n"
           << "        for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n"
           << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
           << "        f_t<Dual<NP>>(dd, uu, pp, Dual<NP>(t));\n"
-          << "        for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n";
+          << "        for (int j = 0; j < NP; ++j) { LT s = LT(0.0); for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n"
+          << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_u_t<double>(out, lam, u, p, t); }\n"
+          << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_p_t<double>(out, lam, u, p, t); }\n";
     } else {
+        // the VJP bodies are templates on the type LT of `lam` / `out`: double = one adjoint column, Cols<G> = a bundle of G columns that shares
+        // everything depending on (u, p, t) only (hipadj_models.hpp).  A body that is not linear in lam does not compile for Cols: HAS_COLS = false then.
         const char* sfx = m.has_mm ? "_raw" : "";
         o << "    HIPADJ_HD static void f" << sfx << "(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        (void)u; (void)p; (void)t;\n" << m.f << "\n    }\n"
-          << "    HIPADJ_HD static void vjp_u" << sfx << "(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "    template <class LT> HIPADJ_HD static void vjp_u_raw_t(LT (&out)[N], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_u << "\n    }\n"
-          << "    HIPADJ_HD static void vjp_p" << sfx << "(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "    template <class LT> HIPADJ_HD static void vjp_p_raw_t(LT (&out)[NP], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
           << "        (void)lam; (void)u; (void)p; (void)t;\n" << m.vjp_p << "\n    }\n";
         if (m.has_mm)   // F = M^{-1} f:  F_u^T lam = f_u^T (M^{-T} lam),  F_p^T lam = f_p^T (M^{-T} lam)
             o << "    HIPADJ_HD static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double t) { f_raw(du, u, p, t); mm_inv<double>(du); }\n"
-              << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { double w[N]; mm_invT(w, lam); vjp_u_raw(out, w, u, p, t); }\n"
-              << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { double w[N]; mm_invT(w, lam); vjp_p_raw(out, w, u, p, t); }\n";
+              << "    template <class LT> HIPADJ_HD static void vjp_u_t(LT (&out)[N], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { LT w[N]; mm_invT<LT>(w, lam); vjp_u_raw_t<LT>(out, w, u, p, t); }\n"
+              << "    template <class LT> HIPADJ_HD static void vjp_p_t(LT (&out)[NP], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { LT w[N]; mm_invT<LT>(w, lam); vjp_p_raw_t<LT>(out, w, u, p, t); }\n";
+        else
+            o << "    template <class LT> HIPADJ_HD static void vjp_u_t(LT (&out)[N], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_u_raw_t<LT>(out, lam, u, p, t); }\n"
+              << "    template <class LT> HIPADJ_HD static void vjp_p_t(LT (&out)[NP], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_p_raw_t<LT>(out, lam, u, p, t); }\n";
+        o << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_u_t<double>(out, lam, u, p, t); }\n"
+          << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_p_t<double>(out, lam, u, p, t); }\n";
     }
     // DiscreteCallback affect (u, p) <- a(u, p, t) (hipadj_model_set_affect): the body edits `un` and / or `pn`, which start as copies of u and p;
     // the reverse callback's products with both Jacobians by forward-mode dual numbers (one pass seeded on u, one on p)
@@ -390,6 +408,7 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         key = std::to_string(model) + "#" + std::to_string(src.rev);
         for (const auto& e : exprs) key += "|" + e;
         if (const char* fl = std::getenv("HIPADJ_RTC_FLAGS")) key += std::string("|flags:") + fl;   // a debugging run with other flags must not be served from the cache
+        if (const char* e = std::getenv("HIPADJ_USER_COLS")) key += std::string("|cols:") + e;
         auto it = R.code_cache.find(key);
         if (it != R.code_cache.end()) { code = it->second; lowered = R.lowered_cache[key]; return HIPADJ_OK; }
     }
@@ -402,16 +421,19 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
     for (int i = 0; i < NH; ++i)
         if (!user_read_file(dir + "/" + hnames[i], htext[i])) { err = "cannot read kernel header " + dir + "/" + hnames[i] + " (set HIPADJ_CSRC_DIR)"; return HIPADJ_ERR_UNSUPPORTED; }
     const char* hptr[NH] = {htext[0].c_str(), htext[1].c_str(), htext[2].c_str(), htext[3].c_str(), htext[4].c_str()};
-    const std::string tu = user_model_struct(src);
+    if (const char* e = std::getenv("HIPADJ_USER_COLS")) if (e[0] == '0') src.cols = false;   // A/B hook: the per-column form of the segment lanes
+    std::string tu = user_model_struct(src);
     // attempt 0: -O3.  If the ISA check (user_isa_check) flags the code object: attempt 1 at -O1 — a different schedule and
     // register allocation (the one known case is clean there); still flagged => refuse rather than run lanes on garbage.
     for (int attempt = 0; attempt < 2; ++attempt) {
         hiprtcProgram prog = nullptr;
+        A.enter();
         if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", NH, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
         for (const auto& e : exprs) A.AddNameExpression(prog, e.c_str());
         std::vector<std::string> optv = {"--offload-arch=gfx950", attempt == 0 ? "-O3" : "-O1", "-std=c++17"};
         if (const char* e = std::getenv("HIPADJ_RTC_FLAGS")) { std::istringstream is(e); std::string w; while (is >> w) optv.push_back(w); }   // tuning / debugging hook
         std::vector<const char*> opts; for (const auto& o : optv) opts.push_back(o.c_str());
+        A.enter();
         const hiprtcResult cr = A.CompileProgram(prog, (int)opts.size(), opts.data());
         if (cr != HIPRTC_SUCCESS) {
             size_t ls = 0; A.GetProgramLogSize(prog, &ls);
@@ -419,6 +441,13 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
             if (log.size() > 4000) log.resize(4000);
             err = "model '" + src.name + "' failed to compile:\n" + log;
             A.DestroyProgram(&prog);
+            if (src.cols) {   // a VJP body that is not written linearly in `lam` (a double temporary holding a lam term, ...) does not compile for column bundles:
+                src.cols = false;   // once more in the per-column form; a genuine error fails again and is reported from that (plainer) build
+                { std::lock_guard<std::mutex> lk(R.mu); const int idx = model - HIPADJ_MODEL_USER_BASE; if (R.models[idx].rev == src.rev) R.models[idx].cols = false; }
+                tu = user_model_struct(src);
+                attempt = -1;
+                continue;
+            }
             return HIPADJ_ERR_INVALID_ARG;
         }
         if (std::getenv("HIPADJ_RTC_SHOWLOG")) {   // debugging hook: the compiler's log of a successful build (remarks)

@@ -25,14 +25,19 @@ template <int NN> struct EmuRing {
     static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) {
         for (int i = 0; i < N; ++i) du[i] = p[i] * (u[(i + 1) % N] - u[i]) + p[N] * std::sin(u[(i + N - 1) % N]);
     }
-    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double) {
+    // the VJP bodies as templates on the type of lam / out, like the generated runtime models: LT = Cols<G> runs a bundle of G segment columns
+    // through them at once (hipadj_models.hpp), which the segmented emulator cases (time_segments > 1) exercise on the host
+    static constexpr bool HAS_COLS = true;
+    template <class LT> static void vjp_u_t(LT (&dl)[N], const LT (&l)[N], const double (&u)[N], const double (&p)[NP], double) {
         for (int j = 0; j < N; ++j) dl[j] = -p[j] * l[j] + p[(j + N - 1) % N] * l[(j + N - 1) % N] + p[N] * std::cos(u[j]) * l[(j + 1) % N];
     }
-    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&)[NP], double) {
-        double s = 0.0;
+    template <class LT> static void vjp_p_t(LT (&dg)[NP], const LT (&l)[N], const double (&u)[N], const double (&)[NP], double) {
+        LT s = LT(0.0);
         for (int k = 0; k < N; ++k) { dg[k] = l[k] * (u[(k + 1) % N] - u[k]); s += l[k] * std::sin(u[(k + N - 1) % N]); }
         dg[N] = s;
     }
+    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_u_t<double>(dl, l, u, p, t); }
+    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_p_t<double>(dg, l, u, p, t); }
 };
 // TEST-ONLY: the ring behind a constant mass matrix, wrapped the way the generator of hipadj_user.hpp wraps a runtime model that has one
 // (F = M^{-1} f, F_u^T lam = f_u^T (M^{-T} lam), likewise F_p).  M^{-1}[i][j] = 0.8 [i == j] + 0.15 sin(1 + 3 i + 7 j) (tests/emu.py holds the
@@ -45,16 +50,19 @@ template <int NN> struct EmuRingMM {
         double r[N]; EmuRing<NN>::f(r, u, p, t);
         for (int i = 0; i < N; ++i) { double s = 0.0; for (int j = 0; j < N; ++j) s += minv(i, j) * r[j]; du[i] = s; }
     }
-    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) {
-        double w[N];
-        for (int i = 0; i < N; ++i) { double s = 0.0; for (int j = 0; j < N; ++j) s += minv(j, i) * l[j]; w[i] = s; }
-        EmuRing<NN>::vjp_u(dl, w, u, p, t);
+    static constexpr bool HAS_COLS = true;
+    template <class LT> static void vjp_u_t(LT (&dl)[N], const LT (&l)[N], const double (&u)[N], const double (&p)[NP], double t) {
+        LT w[N];
+        for (int i = 0; i < N; ++i) { LT s = LT(0.0); for (int j = 0; j < N; ++j) s += minv(j, i) * l[j]; w[i] = s; }
+        EmuRing<NN>::template vjp_u_t<LT>(dl, w, u, p, t);
     }
-    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) {
-        double w[N];
-        for (int i = 0; i < N; ++i) { double s = 0.0; for (int j = 0; j < N; ++j) s += minv(j, i) * l[j]; w[i] = s; }
-        EmuRing<NN>::vjp_p(dg, w, u, p, t);
+    template <class LT> static void vjp_p_t(LT (&dg)[NP], const LT (&l)[N], const double (&u)[N], const double (&p)[NP], double t) {
+        LT w[N];
+        for (int i = 0; i < N; ++i) { LT s = LT(0.0); for (int j = 0; j < N; ++j) s += minv(j, i) * l[j]; w[i] = s; }
+        EmuRing<NN>::template vjp_p_t<LT>(dg, w, u, p, t);
     }
+    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_u_t<double>(dl, l, u, p, t); }
+    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_p_t<double>(dg, l, u, p, t); }
 };
 static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
     const int nn = model - HIPADJ_MODEL_USER_BASE;

@@ -54,6 +54,28 @@ def test_runtime_models_are_compiled_by_the_build_toolkits_hiprtc(sa):
         assert out.startswith("libhiprtc.so; HIP "), out
 
 
+def test_runtime_compiler_survives_setenv_in_the_host_process():
+    """The toolkit's hiprtc lives in its own link-map namespace next to torch's — with its own libc, whose `environ` is a copy.  Setting variables in
+    the host process after the first compile (os.environ[...] = ... reallocates the array) left that copy dangling: the next getenv inside hiprtc
+    crashed (seen on the GPU box as a segfault in hiprtcCreateProgram).  rtc_api().enter() re-points it before every call."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import scimlsensitivity_jl_amd as sa, user_models as UM\n"
+        "from scimlsensitivity_jl_amd import _lib\n"
+        "print(_lib.runtime_compiler(), flush=True)\n"
+        "for i in range(3000): os.environ['HIPADJ_DUMMY_%%d' %% i] = 'y' * 200\n"
+        "m = UM.ring(4); f = sa.DeviceFunction('ring4_env', 4, 5, m['f'], m['vjp'], m['vjp_p'])\n"
+        "_lib.check_model(f.id)\n"
+        "for i in range(3000, 6000): os.environ['HIPADJ_DUMMY_%%d' %% i] = 'z' * 100\n"
+        "f.set_mass_matrix([[2.0, 0.1, 0, 0], [0, 1.5, 0, 0.2], [0, 0, 1.0, 0], [0.3, 0, 0, 1.2]]); _lib.check_model(f.id)\n"
+        "print('compiled twice', flush=True)\n") % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "compiled twice" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
+
+
 def test_struct_layouts_match_header(sa, tmp_path):
     """ctypes mirrors vs the C compiler's view of include/hipadj.h (sizeof / offsetof)."""
     import subprocess

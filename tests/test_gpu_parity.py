@@ -1393,3 +1393,65 @@ def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
     with pytest.raises(sa.HipadjError):
         sol.engine.comm_init_rank(sa.comm_unique_id(), 1, 0)
     sol.engine.close()
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")])
+@pytest.mark.parametrize("nring", [5, 6, 8])
+def test_wide_runtime_models_are_time_segmented(sa, nring, alg, oalg):
+    """Runtime models with 5..8 states: the linear sweeps are time-segmented like the narrow ones ((1 + n)(n + np) <= 160 doubles of segment
+    state per lane; 64 before the runtime models were bound to the build toolkit's compiler).  Automatic and explicit segment counts against the
+    oracle, which knows nothing about segments."""
+    m = UM.ring(nring)
+    f = _device_function(sa, f"ring{nring}_runtime", m)
+    rng = np.random.default_rng(50 + nring)
+    N, T, dt, n, npar = 150, 3.0, 0.01, m["n"], m["np"]
+    u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar))
+    ts = np.arange(0.25, T + 1e-9, 0.25)
+    delta = rng.standard_normal((N, len(ts), n))
+    sens = dict(interpolating=sa.InterpolatingAdjoint, gauss=sa.GaussAdjoint, gausskronrod=sa.GaussKronrodAdjoint)[alg]()
+    ref = O.Problem("RING", alg=oalg, t0=0, t1=T, save_times=ts, loss="COTANGENT", dims=(nring, 0, 0, 0), stepper="RK4", dt=dt)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    for segs in (0, 5, 1):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, time_segments=segs)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+        used = sol.engine.stats()["time_segments"]
+        assert (used > 1) if segs == 0 else (used == segs), (segs, used)
+        assert rel(sol.u, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10, (nring, alg, segs)
+        sol.engine.close()
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+def test_column_bundles_and_their_fallback(sa, alg, oalg, monkeypatch):
+    """Segment lanes of runtime models with n <= 4 (Gauss: n <= 5) push all 1 + n adjoint columns through the VJP bodies as ONE Cols<G> scalar
+    (csrc/hipadj_models.hpp): same numbers as the per-column form (HIPADJ_USER_COLS=0) to roundoff, both equal to the oracle; a body that keeps a
+    lam term in a `double` temporary does not compile for bundles and silently takes the per-column form; continuous costs ride on the affine
+    column of the bundle."""
+    rng = np.random.default_rng(61)
+    T, dt, N = 2.0, 0.01, 90
+    ts = np.arange(0.2, T + 1e-9, 0.2)
+    sens = dict(interpolating=sa.InterpolatingAdjoint, gauss=sa.GaussAdjoint)[alg]
+    for nring in (3, 4, 5):
+        m = UM.ring(nring); n, npar = m["n"], m["np"]
+        u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar)); delta = rng.standard_normal((N, len(ts), n))
+        ref = O.Problem("RING", alg=oalg, t0=0, t1=T, save_times=ts, loss="COTANGENT", dims=(nring, 0, 0, 0), stepper="RK4", dt=dt)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, pp, delta)
+        got = {}
+        for cols in ("1", "0"):
+            monkeypatch.setenv("HIPADJ_USER_COLS", cols)
+            f = _device_function(sa, f"ring{nring}_runtime", m)
+            sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=sens(), time_segments=4)
+            got[cols] = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+            sol.engine.close()
+            assert rel(got[cols][0], rdu0) < 1e-11 and rel(got[cols][1], rdp) < 1e-11, (nring, cols)
+        assert rel(got["1"][0], got["0"][0]) < 1e-13 and rel(got["1"][1], got["0"][1]) < 1e-13
+    monkeypatch.delenv("HIPADJ_USER_COLS")
+    # Lotka-Volterra with a VJP body that parks lam terms in doubles: not a bundle body -> per-column form, same result as the built-in model
+    lv_tmp = sa.DeviceFunction("lv_double_temporaries", 2, 4, UM.LV["f"],
+                               "double a = lam[0], b = lam[1]; out[0] = (p[0] - p[1]*u[1])*a + p[3]*u[1]*b; out[1] = -p[1]*u[0]*a + (-p[2] + p[3]*u[0])*b;",
+                               "const double xy = u[0]*u[1]; double a = lam[0]; out[0] = u[0]*a; out[1] = -xy*a; out[2] = -u[1]*lam[1]; out[3] = xy*lam[1];")
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0]); delta = rng.standard_normal((N, len(ts), 2))
+    res = []
+    for fn in ("lv", lv_tmp):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fn, u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sens(), time_segments=4)
+        res.append(sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)); sol.engine.close()
+    assert rel(res[1][0], res[0][0]) < 1e-12 and rel(res[1][1], res[0][1]) < 1e-12
