@@ -845,6 +845,55 @@ HIPADJ_HD void out_offgrid_lane(const Geom& g, long i, const dbl2* __restrict__ 
     }
 }
 
+// One reverse RK4 step of (lam, mu) along the re-integrated forward stage states y, Y2, Y3, Y4 for the column(s) in lam / mu (LT as in adj_rk4_core)
+template <class Mo, class LT, int CC>
+HIPADJ_HD void backsolve_core(const double (&y)[Mo::N], const double (&Y2)[Mo::N], const double (&Y3)[Mo::N], const double (&Y4)[Mo::N], const double (&pv)[Mo::NP],
+                              double t_lo, double dt, LT (&lam)[Mo::N], LT (&mu)[Mo::NP], bool aff,
+                              const double (&gu1)[Mo::N], const double (&gu2)[Mo::N], const double (&gu3)[Mo::N], const double (&gu4)[Mo::N]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    using MV = model_vjp<Mo, LT>;
+    const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
+    LT ls[N], V1[N], V2[N], V3[N], V4[N], W[NP], Wacc[NP];
+    MV::u(V1, lam, y, pv, t_hi); MV::p_(Wacc, lam, y, pv, t_hi);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V1[j], gu1[j]); }
+#pragma unroll
+    for (int j = 0; j < N; ++j) ls[j] = lam[j] + (0.5 * dt) * V1[j];
+    MV::u(V2, ls, Y2, pv, t_mid); MV::p_(W, ls, Y2, pv, t_mid);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V2[j], gu2[j]); }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ls[j] = lam[j] + (0.5 * dt) * V2[j];
+    MV::u(V3, ls, Y3, pv, t_mid); MV::p_(W, ls, Y3, pv, t_mid);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V3[j], gu3[j]); }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ls[j] = lam[j] + dt * V3[j];
+    MV::u(V4, ls, Y4, pv, t_lo); MV::p_(W, ls, Y4, pv, t_lo);
+    if (CC && aff) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) cols_add_first(V4[j], gu4[j]); }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) Wacc[j] += W[j];
+    if (cost_has_gp<CC>::value && aff) {   // dgrad -= g_p at the four stage states (src/backsolve_adjoint.jl:59)
+        double gp1[NP], gp2[NP], gp3[NP], gp4[NP];
+        cost_grad_p<Mo, CC>(y, pv, t_hi, gp1); cost_grad_p<Mo, CC>(Y2, pv, t_mid, gp2); cost_grad_p<Mo, CC>(Y3, pv, t_mid, gp3); cost_grad_p<Mo, CC>(Y4, pv, t_lo, gp4);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) cols_add_first(Wacc[j], gp1[j] + 2.0 * (gp2[j] + gp3[j]) + gp4[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[j] = lam[j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[j] = mu[j] + (dt / 6.0) * Wacc[j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // BacksolveAdjoint, sequential in time per trajectory: z = [lam; mu; y], dy = f(y) integrated backward,
 // y overwritten by the stored forward value at every checkpoint knot, loss gradient evaluated at the
@@ -896,48 +945,29 @@ HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const d
         for (int j = 0; j < N; ++j) Y4[j] = y[j] - dt * F3[j];
         Mo::f(F4, Y4, pv, t_lo);
         double gu1[N], gu2[N], gu3[N], gu4[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { gu1[j] = 0.0; gu2[j] = 0.0; gu3[j] = 0.0; gu4[j] = 0.0; }
         if (CC) { cost_grad_u<Mo, CC>(y, pv, t_hi, gu1); cost_grad_u<Mo, CC>(Y2, pv, t_mid, gu2); cost_grad_u<Mo, CC>(Y3, pv, t_mid, gu3); cost_grad_u<Mo, CC>(Y4, pv, t_lo, gu4); }
+        if constexpr (NC > 1 && model_has_cols<Mo>::value && cols_bundle<N, NC>::NB == 1) {   // all columns as one Cols<NC> scalar (hipadj_models.hpp)
+            Cols<NC> L[N], M_[NP];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            double ls[N], V1[N], V2[N], V3[N], V4[N], W[NP], Wacc[NP];
-            Mo::vjp_u(V1, lam[c], y, pv, t_hi); Mo::vjp_p(Wacc, lam[c], y, pv, t_hi);
-            if (CC && c == 0) {
+            for (int c = 0; c < NC; ++c) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) V1[j] += gu1[j]; }
+                for (int j = 0; j < N; ++j) L[j].v[c] = lam[c][j];
 #pragma unroll
-            for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V1[j];
-            Mo::vjp_u(V2, ls, Y2, pv, t_mid); Mo::vjp_p(W, ls, Y2, pv, t_mid);
-            if (CC && c == 0) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) V2[j] += gu2[j]; }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
-#pragma unroll
-            for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + (0.5 * dt) * V2[j];
-            Mo::vjp_u(V3, ls, Y3, pv, t_mid); Mo::vjp_p(W, ls, Y3, pv, t_mid);
-            if (CC && c == 0) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) V3[j] += gu3[j]; }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) Wacc[j] += 2.0 * W[j];
-#pragma unroll
-            for (int j = 0; j < N; ++j) ls[j] = lam[c][j] + dt * V3[j];
-            Mo::vjp_u(V4, ls, Y4, pv, t_lo); Mo::vjp_p(W, ls, Y4, pv, t_lo);
-            if (CC && c == 0) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) V4[j] += gu4[j]; }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) Wacc[j] += W[j];
-            if (cost_has_gp<CC>::value && c == 0) {   // dgrad -= g_p at the four stage states (src/backsolve_adjoint.jl:59)
-                double gp1[NP], gp2[NP], gp3[NP], gp4[NP];
-                cost_grad_p<Mo, CC>(y, pv, t_hi, gp1); cost_grad_p<Mo, CC>(Y2, pv, t_mid, gp2); cost_grad_p<Mo, CC>(Y3, pv, t_mid, gp3); cost_grad_p<Mo, CC>(Y4, pv, t_lo, gp4);
-#pragma unroll
-                for (int j = 0; j < NP; ++j) Wacc[j] += gp1[j] + 2.0 * (gp2[j] + gp3[j]) + gp4[j];
+                for (int j = 0; j < NP; ++j) M_[j].v[c] = mu[c][j];
             }
+            backsolve_core<Mo, Cols<NC>, CC>(y, Y2, Y3, Y4, pv, t_lo, dt, L, M_, true, gu1, gu2, gu3, gu4);
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[c][j] = lam[c][j] + (dt / 6.0) * (V1[j] + 2.0 * (V2[j] + V3[j]) + V4[j]);
+            for (int c = 0; c < NC; ++c) {
 #pragma unroll
-            for (int j = 0; j < NP; ++j) mu[c][j] = mu[c][j] + (dt / 6.0) * Wacc[j];
+                for (int j = 0; j < N; ++j) lam[c][j] = L[j].v[c];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) mu[c][j] = M_[j].v[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) backsolve_core<Mo, double, CC>(y, Y2, Y3, Y4, pv, t_lo, dt, lam[c], mu[c], c == 0, gu1, gu2, gu3, gu4);
         }
 #pragma unroll
         for (int j = 0; j < N; ++j) y[j] = y[j] - (dt / 6.0) * (F1[j] + 2.0 * (F2[j] + F3[j]) + F4[j]);

@@ -38,10 +38,23 @@ def test_runtime_tsit5_kernels_have_no_spill_copies_ahead_of_exec_restores(tmp_p
         assert isa_lint.lint(o) == []
 
 
-def test_runtime_compile_retries_at_O1_when_the_check_flags_the_code_object(tmp_path, monkeypatch):
-    """Product-side guard (user_isa_check in csrc/hipadj_user.hpp): the batched stage sum forced onto a 13-wide state
-    (-DHIPADJ_TS5_WIDE=64) reproduces the flagged placement at -O3; the library must notice, rebuild at -O1 and hand out a
-    clean code object."""
+def test_runtime_compile_retries_at_O1_when_the_check_flags_the_code_object():
+    """Product-side guard (user_isa_check in csrc/hipadj_user.hpp).  The flagged placement comes from the hiprtc a torch wheel bundles (ROCm 7.0),
+    which compiled the runtime models before the library bound the build toolkit's compiler; the 7.2 toolkit does not produce it
+    for the probe.  So the probe runs in a child process that asks for the in-process hiprtc (HIPADJ_HIPRTC=libhiprtc.so)."""
+    import subprocess, sys
+    import torch
+    if not os.path.exists(os.path.join(os.path.dirname(torch.__file__), "lib", "libhiprtc.so")):
+        pytest.skip("no bundled hiprtc to bind")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-p", "no:cacheprovider", "-k", "inner_retry_probe", "-rs"],
+                       env=dict(os.environ, HIPADJ_HIPRTC="libhiprtc.so", HIPADJ_LINT_INNER="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
+@pytest.mark.skipif(os.environ.get("HIPADJ_LINT_INNER") != "1", reason="runs inside test_runtime_compile_retries_at_O1_when_the_check_flags_the_code_object")
+def test_inner_retry_probe(tmp_path, monkeypatch):
+    """The batched stage sum forced onto a 13-wide state (-DHIPADJ_TS5_WIDE=64) reproduces the flagged placement at -O3; the library must notice,
+    rebuild at -O1 and hand out a clean code object."""
     from scimlsensitivity_jl_amd import _lib
     m = UM.ring(4)
     _lib.register_model("ring4_lint_retry", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
