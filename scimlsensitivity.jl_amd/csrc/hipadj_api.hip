@@ -490,7 +490,10 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     const int n = h->n, np = h->np;
     const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);
     const int cc = mode >> 1;
-    int PF = n <= 3 ? ((mode & 1) ? 8 : 6) : 1, PFG = n <= 3 ? 4 : 1;   // more than three states: the plain rolled sweep (reverse_sweep, PF == 1)
+    // knot prefetch depth of the reverse sweeps: the unrolled PF-deep blocks pay for small step bodies only (n <= 3 and a right-hand side without
+    // library math, user_calls_math); everything else runs the rolled sweep with one knot in flight, which measured fastest at every n = 2 ... 8
+    const bool deep = n <= 3 && !user_calls_math(h->cfg.model);
+    int PF = deep ? ((mode & 1) ? 8 : 6) : 1, PFG = deep ? 4 : 1;
     if (const char* e = std::getenv("HIPADJ_USER_PF")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) PF = v; }   // tuning hook: prefetch depth of k_interp for runtime models
     if (const char* e = std::getenv("HIPADJ_USER_PFG")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) PFG = v; }   // ... and of k_gauss / k_quad_adj
     auto I = [](int v) { return std::to_string(v); };

@@ -24,6 +24,7 @@
 
 #include <unistd.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -529,6 +530,26 @@ inline bool user_has_affect(int32_t model) {
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     return idx >= 0 && idx < (int)R.models.size() && !R.models[idx].affect.empty();
+}
+// Does the model text call library math (sin, exp, pow, ...)?  Such step bodies are large once inlined; the PF-deep unrolled prefetch blocks then
+// multiply them past the instruction cache and the sweep gets SLOWER with depth (ring n = 2 / 3: 0.44 / 0.78 ms at depth 1, 0.92 / 1.25 ms at 6),
+// while a polynomial right-hand side gains from it (Lotka-Volterra 0.133 -> 0.076 ms at depth 4): profiles/r2_user_prefetch_depth.log.
+inline bool user_calls_math(int32_t model) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) return false;
+    const UserModelSrc& m = R.models[idx];
+    const std::string text = m.f + " " + m.vjp_u + " " + m.vjp_p;
+    for (const char* fn : {"sin", "cos", "tan", "exp", "log", "pow", "sqrt", "cbrt", "erf", "gamma", "atan", "hypot"}) {
+        for (size_t at = text.find(fn); at != std::string::npos; at = text.find(fn, at + 1)) {
+            size_t e = at + std::strlen(fn);
+            while (e < text.size() && (std::isalnum((unsigned char)text[e]) || text[e] == '_')) ++e;    // sinh, expm1, log1p, sqrtf, ...
+            while (e < text.size() && text[e] == ' ') ++e;
+            if (e < text.size() && text[e] == '(') return true;
+        }
+    }
+    return false;
 }
 // ODEFunction(f; mass_matrix = M) for a runtime model: M row-major n x n, constant and non-singular; NULL removes it.
 // Singular M (semi-explicit DAE, src/adjoint_common.jl:117-135, 790-803) needs an implicit stepper: refused.

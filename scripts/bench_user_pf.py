@@ -25,25 +25,32 @@ def main():
     import user_models as UM
     from scimlsensitivity_jl_amd import _lib
     print(json.dumps(dict(compiler=_lib.runtime_compiler())), flush=True)
-    sizes = [int(x) for x in os.environ.get("PF_SIZES", "4,5,6,8").split(",")]
     depths = [int(x) for x in os.environ.get("PF_DEPTHS", "1,2,4").split(",")]
     N, S, dt = int(os.environ.get("PF_NTRAJ", "10000")), 1000, 0.01
     ts = dt * np.arange(10, S + 1, 10)
     rng = np.random.default_rng(0)
-    for n in sizes:
-        m = UM.ring(n); npar = m["np"]
-        f = sa.DeviceFunction(f"ring{n}_pf", n, npar, m["f"], m["vjp"], m["vjp_p"])
+    named = dict(lv=(UM.LV, "LV"), rober=(UM.ROBER, "ROBER"))      # PF_SIZES accepts these names next to ring sizes (polynomial right-hand sides)
+    for key in os.environ.get("PF_SIZES", "4,5,6,8").split(","):
+        if key in named:
+            m, omodel = named[key]; n = m["n"]; odims = (0, 0, 0, 0)
+        else:
+            n = int(key); m = UM.ring(n); omodel = "RING"; odims = (n, 0, 0, 0)
+        npar = m["np"]
+        f = sa.DeviceFunction(f"{key}_pf", n, npar, m["f"], m["vjp"], m["vjp_p"])
         u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar)); delta = rng.standard_normal((N, len(ts), n))
         nref = 16
         for alg in os.environ.get("PF_ALGS", "interpolating,gauss").split(","):
-            ref = O.Problem("RING", alg=alg.upper(), t0=0.0, t1=S * dt, save_times=ts, loss="COTANGENT", dims=(n, 0, 0, 0), stepper="RK4", dt=dt)
+            ref = O.Problem(omodel, alg=alg.upper(), t0=0.0, t1=S * dt, save_times=ts, loss="COTANGENT", dims=odims, stepper="RK4", dt=dt)
             rdu0, rdp, _, _ = ref.adjoint_ensemble(u0[:nref], pp[:nref], delta[:nref])
             for d in depths:
-                os.environ["HIPADJ_USER_PF"] = str(d); os.environ["HIPADJ_USER_PFG"] = str(d)
+                if d > 0:
+                    os.environ["HIPADJ_USER_PF"] = str(d); os.environ["HIPADJ_USER_PFG"] = str(d)
+                else:                                       # depth 0: the library's own choice (user_kernel_names)
+                    os.environ.pop("HIPADJ_USER_PF", None); os.environ.pop("HIPADJ_USER_PFG", None)
                 sens = dict(interpolating=sa.InterpolatingAdjoint, gauss=sa.GaussAdjoint, quadrature=sa.QuadratureAdjoint, backsolve=sa.BacksolveAdjoint)[alg]()
                 t0 = time.perf_counter()
                 try:
-                    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, S * dt), pp[0], (n, 0, 0, 0)), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=sens)
+                    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, S * dt), pp[0], odims), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=sens)
                 except Exception as e:
                     print(json.dumps(dict(n=n, alg=alg, depth=d, error=str(e)[:300])), flush=True); continue
                 build_s = time.perf_counter() - t0
@@ -54,7 +61,7 @@ def main():
                 for _ in range(reps):
                     du0, dp = eng.adjoint(delta)
                 s1 = eng.stats()
-                print(json.dumps(dict(n=n, np=npar, alg=alg, depth=d, N=N, steps=S, time_segments=s1.get("time_segments"), forward_ms=s1.get("forward_ms_last"),
+                print(json.dumps(dict(model=key, n=n, np=npar, alg=alg, depth=d, N=N, steps=S, time_segments=s1.get("time_segments"), forward_ms=s1.get("forward_ms_last"),
                                       adjoint_ms=(s1["adjoint_ms_total"] - s0["adjoint_ms_total"]) / reps,
                                       main_kernel_ms=(s1["adjoint_main_kernel_ms_total"] - s0["adjoint_main_kernel_ms_total"]) / reps,
                                       err_du0=rel(du0[:nref], rdu0), err_dp=rel(dp[:nref], rdp), build_s=round(build_s, 1))), flush=True)

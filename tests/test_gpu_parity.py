@@ -663,8 +663,8 @@ def test_runtime_lv_equals_builtin_lv(sa, alg, oalg):
 @pytest.mark.parametrize("alg,oalg", ALGS)
 @pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring4", "RING", (4, 0, 0, 0)), ("ring6", "RING", (6, 0, 0, 0))])
 def test_runtime_models_match_oracle(sa, name, omodel, dims, alg, oalg, stepper):
-    """Models the library has never seen: Robertson kinetics (test/Core3/adjoint.jl:1434-1441, mild rates) and the synthetic
-    ring with n = 4 (time-segmented, prefetch depth 4) and n = 6 (too many columns to segment, depth 2)."""
+    """Models the library has never seen: Robertson kinetics (test/Core3/adjoint.jl:1434-1441, mild rates; polynomial: deep knot prefetch) and the
+    synthetic ring with n = 4 (column bundles) and n = 6 (per-column segment lanes); both rings call sin / cos: rolled sweep, one knot in flight."""
     m = UM.ROBER if name == "rober" else UM.ring(dims[0])
     f = _device_function(sa, name + "_runtime", m)
     rng = np.random.default_rng(43)
