@@ -36,10 +36,25 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     // composition workgroups: 64 trajectories each, or 16 each while that still leaves the chip short of workgroups
     // (10^4 trajectories: 625 instead of 157 workgroups, -1.7 us per reverse pass; profiles/README.md)
     const bool small_blocks = h->cbs == 64 || (h->cbs == 0 && cblocks < 1024);
-    const unsigned compose_blocks = small_blocks ? (unsigned)((h->N + 15) / 16) : cblocks;
+    unsigned compose_blocks = small_blocks ? (unsigned)((h->N + 15) / 16) : cblocks;
     static const bool compose16 = []() { const char* e = std::getenv("HIPADJ_COMPOSE16"); return !(e && e[0] == '0'); }();   // A/B switch of the 16-lane composition
+    // lane-per-trajectory form (coalesced rows, maps spread over the waves of a workgroup) while a wave folds at most three maps: up to 24 lower
+    // maps, i.e. >= ~5000 trajectories at 1000 steps (10^4: tail 20.8 -> 16.0 us, 5000: 21 -> 18 us); with more maps per trajectory (small shards,
+    // 50-62 segments) the 16-lane form's shorter chains win (profiles/r2_compose_w_segments.log).  HIPADJ_COMPOSE_W = 0 / 4 / 8 forces a form.
+    static const int compose_w = []() { const char* e = std::getenv("HIPADJ_COMPOSE_W"); return e ? std::atoi(e) : -1; }();
+    const unsigned wblocks = (unsigned)((h->N + WAVE - 1) / WAVE);
+    const int lower_maps = h->nseg - 1;
+    const bool wave_form = h->nseg > 1 && (compose_w > 0 || (compose_w < 0 && lower_maps <= 24));
+    const int wave_w = compose_w > 0 ? compose_w : (lower_maps <= 12 ? 4 : 8);
+    if (wave_form) compose_blocks = wblocks;
     auto launch_compose = [&]() {
-        if (small_blocks && compose16)      // 16 lanes per trajectory, FIN / 16 = 16 trajectories per workgroup: the same number of workgroups (and partials)
+        if (wave_form && wave_w >= 8)
+            hipLaunchKernelGGL((k_compose_finish_w<Mo, 8>), dim3(wblocks), dim3(WAVE * 8), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        else if (wave_form)
+            hipLaunchKernelGGL((k_compose_finish_w<Mo, 4>), dim3(wblocks), dim3(WAVE * 4), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
+                               d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
+        else if (small_blocks && compose16)      // 16 lanes per trajectory, FIN / 16 = 16 trajectories per workgroup: the same number of workgroups (and partials)
             hipLaunchKernelGGL((k_compose_finish16<Mo>), dim3(compose_blocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
                                d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
         else if (small_blocks)

@@ -431,6 +431,133 @@ __global__ void __launch_bounds__(FIN) k_compose_finish16(Geom g, int nseg, cons
     if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
 }
 
+// The composition with ONE LANE per trajectory and the lower maps spread over the W waves of the workgroup.  Every load is a wave-wide 512-byte row
+// of the segment buffer (the 4- and 16-lane forms above put lanes of one trajectory on different maps: 64 cache lines per load instruction, and the
+// kernel was latency-bound at 11-14 us whatever the ensemble size); wave w folds its contiguous chunk of the maps into one affine map with the next
+// map's loads in flight, then the running vector (lam, mu) goes down the waves through a 3 KB LDS tile, one barrier per hand-over.
+template <class Mo, int W>
+__global__ void __launch_bounds__(WAVE * W) k_compose_finish_w(Geom g, int nseg, const double* __restrict__ segbuf,
+                                                               double* __restrict__ du0, double* __restrict__ dp_rows,
+                                                               double* __restrict__ partial, int* __restrict__ flag,
+                                                               unsigned* __restrict__ ticket_ctr, double* __restrict__ dp_sum) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    __shared__ double vec[R][WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const long i_raw = (long)blockIdx.x * WAVE + lane;
+    const bool tvalid = i_raw < g.N;
+    const long i = tvalid ? i_raw : g.N - 1;
+    const int L = nseg - 1;                                  // lower maps, rank 0 = segment nseg-2 ... rank L-1 = segment 0
+    const int r0 = (L * wv) / W, r1 = (L * (wv + 1)) / W;
+    double A[N][N], Bm[NP][N], cl[N], cm[NP];                // this wave's composed map: lam <- A lam + cl ; mu <- mu + Bm lam + cm
+#pragma unroll
+    for (int a = 0; a < N; ++a) { cl[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) A[a][b] = (a == b) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int a = 0; a < NP; ++a) { cm[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) Bm[a][b] = 0.0; }
+    double m[NC * R], mn[NC * R];
+    if (r0 < r1) {
+        const double* __restrict__ src = segbuf + (long)(nseg - 2 - r0) * NC * R * g.Npad + i;
+#pragma unroll
+        for (int e = 0; e < NC * R; ++e) mn[e] = src[(long)e * g.Npad];
+    }
+    for (int rk = r0; rk < r1; ++rk) {
+#pragma unroll
+        for (int e = 0; e < NC * R; ++e) m[e] = mn[e];
+        if (rk + 1 < r1) {                                   // the next map's loads are in flight while this one is folded in
+            const double* __restrict__ src = segbuf + (long)(nseg - 3 - rk) * NC * R * g.Npad + i;
+#pragma unroll
+            for (int e = 0; e < NC * R; ++e) mn[e] = src[(long)e * g.Npad];
+        }
+        // G <- m o G   (m: c_l = m[j], c_m = m[N+j], A[:,c] = m[(c+1)R + j], B[:,c] = m[(c+1)R + N + j])
+        double nA[N][N], nB[NP][N], ncl[N], ncm[NP];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { ncl[j] = m[j];
+#pragma unroll
+            for (int c = 0; c < N; ++c) ncl[j] += m[(c + 1) * R + j] * cl[c]; }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { ncm[j] = cm[j] + m[N + j];
+#pragma unroll
+            for (int c = 0; c < N; ++c) ncm[j] += m[(c + 1) * R + N + j] * cl[c]; }
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = 0; b < N; ++b) { double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += m[(c + 1) * R + a] * A[c][b];
+                nA[a][b] = v; }
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+            for (int b = 0; b < N; ++b) { double v = Bm[a][b];
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += m[(c + 1) * R + N + a] * A[c][b];
+                nB[a][b] = v; }
+#pragma unroll
+        for (int a = 0; a < N; ++a) { cl[a] = ncl[a];
+#pragma unroll
+            for (int b = 0; b < N; ++b) A[a][b] = nA[a][b]; }
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { cm[a] = ncm[a];
+#pragma unroll
+            for (int b = 0; b < N; ++b) Bm[a][b] = nB[a][b]; }
+    }
+    // the vector: wave 0 starts from the top segment's (c_l, c_m), every wave applies its own map and hands over through LDS
+    double lam[N], mu[NP];
+#pragma unroll
+    for (int j = 0; j < N; ++j) lam[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mu[j] = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < W; ++s) {
+        if (wv == s) {
+            double tl[N], tm[NP];
+            if (s == 0) {
+                const double* __restrict__ src = segbuf + (long)(nseg - 1) * NC * R * g.Npad + i;
+#pragma unroll
+                for (int j = 0; j < N; ++j) tl[j] = src[(long)j * g.Npad];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) tm[j] = src[(long)(N + j) * g.Npad];
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) tl[j] = vec[j][lane];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) tm[j] = vec[N + j][lane];
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) { double v = cl[j];
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += A[j][c] * tl[c];
+                lam[j] = v; }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { double v = tm[j] + cm[j];
+#pragma unroll
+                for (int c = 0; c < N; ++c) v += Bm[j][c] * tl[c];
+                mu[j] = v; }
+            if (s < W - 1) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) vec[j][lane] = lam[j];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) vec[N + j][lane] = mu[j];
+            }
+        }
+        if (s < W - 1) __syncthreads();
+    }
+    const bool owner = tvalid && wv == W - 1;
+    if (owner) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { du0[i * N + j] = lam[j]; bad |= !finite_d(lam[j]); }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { bad |= !finite_d(mu[j]); if (dp_rows) dp_rows[i * NP + j] = mu[j]; }
+        if (bad) atomicOr(flag, 1);
+    }
+    block_partial<NP, WAVE * W>(mu, owner, partial);
+    if (dp_sum) final_reduce_last_arriver<NP>(partial, (int)gridDim.x, ticket_ctr, dp_sum);
+}
+
 // finishing stage for kernels that already wrote du0 [N][n] and dp_traj [NP][Npad]
 template <int N, int NP>
 __global__ void __launch_bounds__(FIN) k_finish(long Ntraj, long Npad, const double* __restrict__ du0,

@@ -127,7 +127,12 @@ inline int plan_auto_segments(long N, int S, int n, int np = 0) {
     // floor() keeps the grid within ONE residency round (a partial second round would double the makespan)
     long target = 2048 / waves;
     long maxseg = S / 16; if (maxseg < 1) maxseg = 1;
-    if (target > maxseg) target = maxseg;
+    if (target > maxseg) {
+        // clipped by the 16-step minimum: between one and two residency rounds the SIMDs that hold two waves set the makespan, so prefer exactly
+        // ONE wave per SIMD (1250 Lorenz trajectories x 1000 steps: 51 segments 40.0 us per reverse pass, 62 segments 44.0 us; profiles/r2_compose_w_segments.log)
+        target = maxseg;
+        if (waves * maxseg > 1024 && 1024 / waves >= 1) target = 1024 / waves < maxseg ? 1024 / waves : maxseg;
+    }
     if ((double)target < 1.0 + n) return 1;
     return (int)target;
 }
