@@ -1,6 +1,6 @@
 """Randomized combinations (`-m gpu`) of the round's host-facing additions on runtime models: a constant mass matrix, DiscreteCallback events (state- and
 parameter-dependent, parameter-changing), both steppers, all four sensealgs, shared / per-trajectory parameters — device vs the same chain built
-from the oracle's pieces (the oracle in its mass-matrix formulation), 40 seeds."""
+from the oracle's pieces (the oracle in its mass-matrix formulation), 56 seeds (the last 16 on 6- and 8-state models)."""
 import numpy as np
 import pytest
 
@@ -59,10 +59,10 @@ def oracle_chain(omodel, dims, n, npar, events, ts, T, u0, pp, delta, alg, okw, 
     return out, du0, (gp.sum(axis=0) if shared else gp)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(56))
 def test_random_mass_matrix_and_event_combinations(sa, seed):
     rng = np.random.default_rng(7000 + seed)
-    name = ["rober", "ring4", "ring5"][int(rng.integers(3))]
+    name = ["rober", "ring4", "ring5"][int(rng.integers(3))] if seed < 40 else ["ring6", "ring8"][int(rng.integers(2))]   # 40+: the wide models (per-column segment lanes)
     m, omodel, dims = (UM.ROBER, "ROBER", (0, 0, 0, 0)) if name == "rober" else (UM.ring(int(name[4:])), "RING", (int(name[4:]), 0, 0, 0))
     n, npar = m["n"], m["np"]
     alg, oalg = ALGS[int(rng.integers(4))]
