@@ -512,8 +512,9 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     k.forward = "hipadj::k_forward<" + U + ">";
     if (h->offgrid) {   // loss times off the step grid (planner: InterpolatingAdjoint only); the `gk` slot carries the out = sol(ts) kernel
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE) k.main_k = "hipadj::k_backsolve_offgrid<" + U + ", " + I(cc) + ">";
+        else if (h->nseg > 1) k.main_k = "hipadj::k_offgrid_seg<" + U + ", " + I(mode) + (h->cfg.alg == HIPADJ_ALG_GAUSS ? ", true>" : ", false>");   // time-segmented over the reverse step list
         else k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_GAUSS ? "hipadj::k_gauss_offgrid<" : "hipadj::k_interp_offgrid<") + U + ", " + I(mode) + ">";
-        k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = finish;
+        k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = (h->nseg > 1 && h->cfg.alg != HIPADJ_ALG_BACKSOLVE) ? compose : finish;
         return k;
     }
     if (h->ip_ckpt) {   // checkpointing=true (Interpolating / Gauss): checkpoint tiles + in-kernel interval re-solve; the planner admits models whose segment columns fit the VGPRs
@@ -550,7 +551,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     h.cfg = *cfg; h.cfg.save_times = nullptr; h.cfg.checkpoints = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
-    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX;
+    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
     const UserKernels k = user_kernel_names(&h);
     std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
     if (!k.gk.empty()) exprs.push_back(k.gk);
@@ -648,7 +649,11 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
             TRY(usig<decltype(&k_backsolve_offgrid<ModelLV, 0>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_cotT, d_du0, h->d_dp_traj));
-        else
+        else if (h->nseg > 1) {
+            SegPlan sp{h->nseg, h->d_seg_bounds};
+            TRY(usig<decltype(&k_offgrid_seg<ModelLV, 1, false>)>::launch(h, h->uf_main, dim3(waves, (unsigned)h->nseg), dim3(WAVE), h->g, R, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, h->d_segbuf));
+            composed = true;
+        } else
         TRY(usig<decltype(&k_interp_offgrid<ModelLV, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj));
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};

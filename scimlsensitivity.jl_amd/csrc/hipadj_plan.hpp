@@ -324,9 +324,9 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     P.nseg = 1;
     const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
-    // off-grid Interpolating / Gauss on compiled-in models: the reverse STEP LIST is what gets segmented (it does not depend on the
+    // off-grid Interpolating / Gauss: the reverse STEP LIST is what gets segmented (it does not depend on the
     // trajectory); bounds are then positions r = nrs - q in that list instead of knot indices (k_offgrid_seg)
-    const bool seg_offgrid = P.offgrid && !P.user && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS);
+    const bool seg_offgrid = P.offgrid && (!P.user || plan_seg_fits(n, np)) && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS);
     const long L = seg_offgrid ? (long)P.rs_t.size() : S;      // length of the axis the segments cut
     if (seg_alg && (!P.offgrid || seg_offgrid)) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, (int)L, n, np) : cfg->time_segments;

@@ -1214,6 +1214,31 @@ def test_offgrid_loss_times_quadrature(sa, saveat):
         sol.engine.close()
 
 
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+@pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring4", "RING", (4, 0, 0, 0)), ("ring6", "RING", (6, 0, 0, 0))])
+def test_offgrid_runtime_models_time_segmented(sa, name, omodel, dims, alg, oalg):
+    """Loss times off the step grid for runtime models, time-segmented over the reverse step list like the compiled-in models (k_offgrid_seg through
+    hiprtc + composition): automatic, explicit and no segmentation against the oracle."""
+    m = UM.ROBER if name == "rober" else UM.ring(dims[0])
+    f = _device_function(sa, name + "_runtime", m)
+    rng = np.random.default_rng(46)
+    N, T, dt = 70, 2.0, 0.01
+    n, npar = m["n"], m["np"]
+    u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar))
+    ts = np.array([0.0, 0.123, 0.5, 0.7777, 1.3003, 2.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    sens = sa.InterpolatingAdjoint() if alg == "interpolating" else sa.GaussAdjoint()
+    ref = O.Problem(omodel, alg=oalg, stepper="RK4", dt=dt, t0=0, t1=T, save_times=ts, loss="COTANGENT", dims=dims)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    for segs in (0, 4, 1):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, time_segments=segs)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+        used = sol.engine.stats()["time_segments"]
+        assert (used > 1) if segs == 0 else (used == segs), (segs, used)
+        assert rel(sol.u, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10, (name, alg, segs)
+        sol.engine.close()
+
+
 @pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring6", "RING", (6, 0, 0, 0))])
 def test_offgrid_loss_times_runtime_models(sa, name, omodel, dims):
     """The off-grid sweep compiled with hiprtc for models the library has never seen (3 and 6 states)."""
