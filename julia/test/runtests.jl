@@ -7,6 +7,7 @@ using Test, HIPAdj, SciMLSensitivity, OrdinaryDiffEq, Zygote, Random
 @testset "layout" begin
     @test HIPAdj.check_layout()
     @test hipadj_version() == 105
+    @test occursin("libhiprtc", runtime_compiler())          # the build toolkit's hiprtc (a Julia process carries no other)
 end
 
 lorenz!(du, u, p, t) = (du[1] = p[1] * (u[2] - u[1]); du[2] = u[1] * (p[2] - u[3]) - u[2]; du[3] = u[1] * u[2] - p[3] * u[3]; nothing)
