@@ -166,6 +166,7 @@ static void free_all(hipadj_handle* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
+    if (h->umod_alt) (void)hipModuleUnload(h->umod_alt);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -543,6 +544,22 @@ static int user_prepare(hipadj_handle* h) {
     HIP_TRY(h, hipModuleGetFunction(&h->uf_main, h->umod, low[k.main_k].c_str()));
     HIP_TRY(h, hipModuleGetFunction(&h->uf_tail, h->umod, low[k.tail].c_str()));
     if (!k.gk.empty()) HIP_TRY(h, hipModuleGetFunction(&h->uf_gk, h->umod, low[k.gk].c_str()));
+    // Reverse kernels of wide models can spill thousands of registers (512 registers + KBs of scratch per lane).  One such kernel came back WRONG from
+    // the toolkit's compiler at -O3 and right at -O1 / -O0 (8-state ring, dual-number VJPs, GaussAdjoint: 1232 spilled registers, 2860 B of scratch;
+    // DESIGN.md 6.8) — no pattern a static check could flag.  So a reverse kernel with >= 1 KB of scratch per lane gets a second build at -O1, and the
+    // first adjoint call runs both and compares (user_adjoint): agreement keeps the -O3 build, disagreement the -O1 one.  HIPADJ_RTC_SELFTEST=0 skips it.
+    int scratch = 0;
+    if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, h->uf_main) != hipSuccess) scratch = 0;
+    const char* st = std::getenv("HIPADJ_RTC_SELFTEST");
+    const int st_min = st ? std::atoi(st) : 1024;          // 0 = off, otherwise the scratch size (bytes per lane) from which the self-test runs
+    if (st_min > 0 && scratch >= st_min && !std::getenv("HIPADJ_RTC_OVERRIDE")) {
+        std::vector<char> code2; std::map<std::string, std::string> low2;
+        const int rc2 = user_compile(h->cfg.model, exprs, code2, low2, h->err, true);
+        if (rc2 != HIPADJ_OK) return rc2;
+        HIP_TRY(h, hipModuleLoadData(&h->umod_alt, code2.data()));
+        HIP_TRY(h, hipModuleGetFunction(&h->uf_main_alt, h->umod_alt, low2[k.main_k].c_str()));
+        h->rtc_selftest = 1;
+    }
     return HIPADJ_OK;
 }
 
@@ -615,7 +632,7 @@ __global__ void k_mass_du0(long N, int n, MassInv mi, double* __restrict__ du0) 
     for (int j = 0; j < n; ++j) du0[i * n + j] = r[j];
 }
 
-static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     const double* p = h->p_dev_last;
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN), cblocks = (unsigned)((h->N + FIN / 4 - 1) / (FIN / 4));
@@ -771,6 +788,43 @@ static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* 
     if (h->adaptive) { DISPATCH_MODEL(h, adaptive_forward, h, d_u0, d_p, d_out); }
     DISPATCH_MODEL(h, forward_impl, h, d_u0, d_p, d_out);
 }
+// The first reverse pass of a runtime model whose reverse kernel spills heavily (user_prepare): run the -O3 build, then the -O1 build, compare
+// du0 and dp on the host.  Agreement (1e-9 relative, and no non-finite flag from the -O3 run): the -O3 build stays.  Otherwise the -O1 build is
+// used from here on and a note goes to stderr.  The outputs handed back are those of the build that stays.
+static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    if (h->rtc_selftest != 1) return user_adjoint_run(h, d_cot, d_du0, d_dp);
+    h->rtc_selftest = 2;
+    const size_t n0 = (size_t)h->N * h->n, n1 = h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np;
+    std::vector<double> a0(n0), a1(n1), b0(n0), b1(n1);
+    auto fetch = [&](std::vector<double>& x0, std::vector<double>& x1, int& flag) -> int {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpy(x0.data(), d_du0, sizeof(double) * n0, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(x1.data(), d_dp, sizeof(double) * n1, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+        return HIPADJ_OK;
+    };
+    int flag_a = 0, flag_b = 0;
+    TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));
+    TRY(fetch(a0, a1, flag_a));
+    HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
+    std::swap(h->uf_main, h->uf_main_alt);                 // the -O1 build
+    TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));
+    TRY(fetch(b0, b1, flag_b));
+    auto differ = [](const std::vector<double>& x, const std::vector<double>& y) {
+        double scale = 0.0, d = 0.0;
+        for (size_t i = 0; i < x.size(); ++i) { if (!(std::fabs(x[i]) <= 1.79e308)) return true; scale = std::max(scale, std::fabs(y[i])); d = std::max(d, std::fabs(x[i] - y[i])); }
+        return d > 1e-9 * (scale > 0.0 ? scale : 1.0);
+    };
+    const bool bad = (flag_a & 1) || differ(a0, b0) || differ(a1, b1);
+    if (bad && !(flag_b & 1)) {
+        h->rtc_selftest = 3;
+        std::fprintf(stderr, "hipadj: the -O3 build of the reverse kernel of runtime model %d disagrees with its -O1 build on the first reverse pass; using the -O1 build (DESIGN.md 6.8)\n", h->cfg.model);
+    } else {
+        std::swap(h->uf_main, h->uf_main_alt);             // agreement (or both non-finite: a diverged trajectory — the flag of the second run stands for the caller's check)
+    }
+    return HIPADJ_OK;
+}
+
 static int adjoint_dispatch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     if (h->user) return user_adjoint(h, d_cot, d_du0, d_dp);
     if (h->field) { DISPATCH_GRID(h, field_adjoint, h, d_cot, d_du0, d_dp); }

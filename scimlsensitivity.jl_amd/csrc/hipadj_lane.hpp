@@ -377,7 +377,7 @@ HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double
     for (int j = 0; j < N; ++j) { ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]); gu1[j] = 0.0; gum[j] = 0.0; gu4[j] = 0.0; }
     const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
     if (CC) { cost_grad_u<Mo, CC>(hi.u, pv, t_hi, gu1); cost_grad_u<Mo, CC>(ymid, pv, t_mid, gum); cost_grad_u<Mo, CC>(lo.u, pv, t_lo, gu4); }
-    if constexpr (NC > 1 && model_has_cols<Mo>::value && cols_bundle<N, NC>::NB == 1)
+    if constexpr (NC > 1 && model_has_cols<Mo>::value && (cols_bundle<N, NC>::NB == 1 || model_cols_multi<Mo>::value))
         adj_rk4_bundles<Mo, NC, 0, cols_bundle<N, NC>::G, WITH_MU, CC>(hi, lo, ymid, pv, t_lo, dt, lam, mu, gu1, gum, gu4);
     else {
 #pragma unroll
@@ -1102,7 +1102,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
     };
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
         const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
-        if constexpr (!GKR && NC > 1 && model_has_cols<Mo>::value && cols_bundle<N, NC, HIPADJ_COLS_ELEMS_GAUSS>::NB == 1) {   // column bundles (hipadj_models.hpp): the same step, G columns per pass through the model's VJPs
+        if constexpr (!GKR && NC > 1 && model_has_cols<Mo>::value && (cols_bundle<N, NC, HIPADJ_COLS_ELEMS_GAUSS>::NB == 1 || model_cols_multi<Mo>::value)) {   // column bundles (hipadj_models.hpp): the same step, G columns per pass through the model's VJPs
             double ymid[N], guh[N], gum[N], gul[N], yg[2][N];
 #pragma unroll
             for (int j = 0; j < N; ++j) { ymid[j] = 0.5 * (lo.u[j] + hi.u[j]) + (0.125 * dt) * (lo.f[j] - hi.f[j]); gum[j] = 0.0; }

@@ -102,6 +102,10 @@ template <int N, int NC, int ELEMS = HIPADJ_COLS_ELEMS> struct cols_bundle {
     static constexpr int NB = (NC + GMAX - 1) / GMAX;
     static constexpr int G = (NC + NB - 1) / NB;
 };
+// models whose VJPs cost one evaluation per CALL whatever the number of columns (dual-number models: the whole Jacobian per evaluation of f) bundle
+// in several groups as well; set by the generator (COLS_MULTI)
+template <class Mo, class = void> struct model_cols_multi { static constexpr bool value = false; };
+template <class Mo> struct model_cols_multi<Mo, decltype((void)Mo::COLS_MULTI)> { static constexpr bool value = Mo::COLS_MULTI; };
 template <class Mo, class LT> struct model_vjp {   // LT = double: the model's plain entry points; LT = Cols<G>: its templated bodies
     HIPADJ_HD static void u(LT (&out)[Mo::N], const LT (&lam)[Mo::N], const double (&y)[Mo::N], const double (&p)[Mo::NP], double t) { Mo::template vjp_u_t<LT>(out, lam, y, p, t); }
     HIPADJ_HD static void p_(LT (&out)[Mo::NP], const LT (&lam)[Mo::N], const double (&y)[Mo::N], const double (&p)[Mo::NP], double t) { Mo::template vjp_p_t<LT>(out, lam, y, p, t); }

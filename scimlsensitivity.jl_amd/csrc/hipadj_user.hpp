@@ -201,7 +201,9 @@ inline std::string user_model_struct(const UserModelSrc& m) {
     o << "#include \"hipadj_kernels.hpp\"\n#include \"hipadj_adaptive.hpp\"\n#include \"hipadj_dual.hpp\"\n"
       << "namespace hipadj {\n// runtime-registered model '" << m.name << "'\nstruct UserModel {\n"
       << "    static constexpr int N = " << m.n << ", NP = " << m.np << ";\n    static constexpr bool TIME_DEP = true;\n"
-      << "    static constexpr bool HAS_COLS = " << (m.cols ? "true" : "false") << ";   // column bundles through the VJP bodies (hipadj_models.hpp)\n";
+      // column bundles through the VJP bodies (hipadj_models.hpp).  Dual-number VJPs: only up to three states — the bundle keeps the whole dual Jacobian live next
+      // to all columns, and measured slower than the per-column form from n = 4 on (ring n = 3: 5.0 -> 1.45 ms, n = 4: 1.6 -> 3.3 ms; profiles/r2_user_auto_cols_ab.log)
+      << "    static constexpr bool HAS_COLS = " << ((m.cols && (!m.auto_vjp || m.n <= 3)) ? "true" : "false") << ";\n";
     if (m.has_mm) {
         // constant mass matrix M u' = f (ODEFunction(f; mass_matrix = M), src/adjoint_common.jl:110-135): the kernels integrate
         // u' = F(u) = M^{-1} f(u) and the adjoint of THAT system, nu' = -F_u^T nu with the plain jumps nu += g_u.  nu = M^T lam, where lam is
@@ -397,7 +399,7 @@ inline int user_isa_check(const std::vector<char>& code, std::string& what) {
 // Compiles (or fetches from the process-wide cache) the code object holding `exprs` for user model `model`.
 // Returns HIPADJ_OK and fills code + lowered names; on failure err carries the hiprtc log.
 inline int user_compile(int32_t model, const std::vector<std::string>& exprs, std::vector<char>& code,
-                        std::map<std::string, std::string>& lowered, std::string& err) {
+                        std::map<std::string, std::string>& lowered, std::string& err, bool low_opt = false) {
     UserRegistry& R = user_registry();
     UserModelSrc src;
     std::string key;
@@ -410,6 +412,7 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         for (const auto& e : exprs) key += "|" + e;
         if (const char* fl = std::getenv("HIPADJ_RTC_FLAGS")) key += std::string("|flags:") + fl;   // a debugging run with other flags must not be served from the cache
         if (const char* e = std::getenv("HIPADJ_USER_COLS")) key += std::string("|cols:") + e;
+        if (low_opt) key += "|O1";                          // the second opinion of the heavy-kernel self-test (user_prepare)
         auto it = R.code_cache.find(key);
         if (it != R.code_cache.end()) { code = it->second; lowered = R.lowered_cache[key]; return HIPADJ_OK; }
     }
@@ -431,7 +434,7 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         A.enter();
         if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", NH, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
         for (const auto& e : exprs) A.AddNameExpression(prog, e.c_str());
-        std::vector<std::string> optv = {"--offload-arch=gfx950", attempt == 0 ? "-O3" : "-O1", "-std=c++17"};
+        std::vector<std::string> optv = {"--offload-arch=gfx950", (attempt == 0 && !low_opt) ? "-O3" : "-O1", "-std=c++17"};
         if (const char* e = std::getenv("HIPADJ_RTC_FLAGS")) { std::istringstream is(e); std::string w; while (is >> w) optv.push_back(w); }   // tuning / debugging hook
         std::vector<const char*> opts; for (const auto& o : optv) opts.push_back(o.c_str());
         A.enter();

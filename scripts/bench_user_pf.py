@@ -36,7 +36,8 @@ def main():
         else:
             n = int(key); m = UM.ring(n); omodel = "RING"; odims = (n, 0, 0, 0)
         npar = m["np"]
-        f = sa.DeviceFunction(f"{key}_pf", n, npar, m["f"], m["vjp"], m["vjp_p"])
+        auto = os.environ.get("PF_AUTO") == "1"                       # dual-number VJPs (only f is registered)
+        f = sa.DeviceFunction(f"{key}_pf{int(auto)}", n, npar, m["f"]) if auto else sa.DeviceFunction(f"{key}_pf", n, npar, m["f"], m["vjp"], m["vjp_p"])
         u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar)); delta = rng.standard_normal((N, len(ts), n))
         nref = 16
         for alg in os.environ.get("PF_ALGS", "interpolating,gauss").split(","):

@@ -1480,3 +1480,29 @@ def test_column_bundles_and_their_fallback(sa, alg, oalg, monkeypatch):
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fn, u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sens(), time_segments=4)
         res.append(sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)); sol.engine.close()
     assert rel(res[1][0], res[0][0]) < 1e-12 and rel(res[1][1], res[0][1]) < 1e-12
+
+
+def test_heavy_runtime_kernel_is_cross_checked_against_its_O1_build(sa, capfd):
+    """A reverse kernel that spills heavily (>= 1 KB of scratch per lane) gets a second build at -O1, and the first reverse pass runs both and compares
+    (user_prepare / user_adjoint in csrc/hipadj_api.hip).  The 8-state ring with dual-number VJPs under GaussAdjoint is the case that motivated it: the
+    toolkit's compiler returns non-finite gradients for it at -O3 (1232 spilled registers) and exact ones at -O1 — the library must notice, say so, and
+    hand back the right numbers; the explicit-VJP ring of the same size passes the comparison silently."""
+    nring = 8
+    m = UM.ring(nring); n, npar = m["n"], m["np"]
+    rng = np.random.default_rng(71)
+    N, T, dt = 130, 2.0, 0.01
+    u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar))
+    ts = np.arange(0.25, T + 1e-9, 0.25); delta = rng.standard_normal((N, len(ts), n))
+    ref = O.Problem("RING", alg="GAUSS", t0=0, t1=T, save_times=ts, loss="COTANGENT", dims=(nring, 0, 0, 0), stepper="RK4", dt=dt)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    for auto in (True, False):
+        f = sa.DeviceFunction(f"ring8_selftest_{int(auto)}", n, npar, m["f"], *(() if auto else (m["vjp"], m["vjp_p"])))
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=sa.GaussAdjoint())
+        capfd.readouterr()
+        for rep in range(2):                       # the second call runs the build that stayed, without the comparison
+            du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+            assert rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10, (auto, rep)
+        err = capfd.readouterr().err
+        if not auto:
+            assert "disagrees with its -O1 build" not in err
+        sol.engine.close()
