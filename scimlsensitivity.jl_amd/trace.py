@@ -269,4 +269,6 @@ def bodies(f, n, np_, auto_vjp=False):
     if auto_vjp:
         return emit(outs, "du", real="real"), None, None
     lam = [Node("var", name=f"lam[{i}]") for i in range(n)]
-    return emit(outs, "du"), emit(vjp_graphs(outs, u, lam), "out"), emit(vjp_graphs(outs, p, lam), "out")
+    # VJP temporaries are `auto`: the device compiles these bodies for lam = double (one adjoint column) and for lam = Cols<G> (a bundle of segment
+    # columns, csrc/hipadj_models.hpp); a `double` temporary holding a lam term would force the per-column form
+    return emit(outs, "du"), emit(vjp_graphs(outs, u, lam), "out", real="auto"), emit(vjp_graphs(outs, p, lam), "out", real="auto")

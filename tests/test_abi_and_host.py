@@ -76,6 +76,35 @@ def test_runtime_compiler_survives_setenv_in_the_host_process():
     assert r.returncode == 0 and "compiled twice" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
 
 
+def test_runtime_model_kernel_choices(sa, tmp_path, monkeypatch):
+    """What user_kernel_names / the planner pick for runtime models, read off the name expressions of the dumped translation units (no device needed):
+    a polynomial right-hand side with n <= 3 takes the deep unrolled prefetch (k_interp<U, 8 | 6, ...>), model text that calls library math the rolled
+    sweep with one knot in flight (k_interp<U, 1, ...>); a 5- to 8-state model gets the segmented kernels (SEG = true: segment state <= 160 doubles);
+    dual-number models bundle their columns only up to three states."""
+    import glob
+    import user_models as UM
+    from scimlsensitivity_jl_amd import _lib
+    import emu as E
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+
+    def names(tag, m, alg="interpolating", auto=False):
+        mid = _lib.register_model(tag, m["n"], m["np"], m["f"], None if auto else m["vjp"], None if auto else m["vjp_p"])
+        cfg = E.make_config(tag, alg, 10000, 0.0, 10.0, 0.01, 0.1 * np.arange(1, 101), loss_kind=0, p_shared=False)
+        cfg.model = mid
+        L = _lib.load()
+        assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+        tu = open(sorted(glob.glob(str(tmp_path / (tag + "_*.hip"))))[-1]).read()
+        return tu
+    tu = names("choice_lv", UM.LV)
+    assert "k_interp<hipadj::UserModel, 6, 0, true>" in tu
+    tu = names("choice_ring3", UM.ring(3))
+    assert "k_interp<hipadj::UserModel, 1, 0, true>" in tu and "HAS_COLS = true" in tu
+    tu = names("choice_ring8", UM.ring(8), alg="gauss")
+    assert "k_gauss<hipadj::UserModel, 1, 0, false, true>" in tu and "k_compose_finish<hipadj::UserModel>" in tu
+    assert "HAS_COLS = true" in names("choice_auto3", UM.ring(3), auto=True)
+    assert "HAS_COLS = false" in names("choice_auto4", UM.ring(4), auto=True)
+
+
 def test_struct_layouts_match_header(sa, tmp_path):
     """ctypes mirrors vs the C compiler's view of include/hipadj.h (sizeof / offsetof)."""
     import subprocess

@@ -101,3 +101,28 @@ def test_traced_lorenz_on_device(alg, oalg, auto):
     rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
     assert rel(sol.u, rout) < 1e-6 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
     sol.engine.close()
+
+
+def test_traced_vjp_bodies_compile_for_column_bundles(tmp_path, monkeypatch):
+    """The tracer writes lam-dependent temporaries as `auto`, so the emitted VJP bodies compile for lam = Cols<G> (a bundle of segment columns through
+    one pass of the body, csrc/hipadj_models.hpp): the generated model keeps HAS_COLS = true and its segmented kernels build without a device.  A
+    hand-written body with a `double` temporary holding a lam term builds too — in the per-column form (HAS_COLS = false in its final translation unit)."""
+    import glob
+    from scimlsensitivity_jl_amd import _lib, trace
+
+    def f(du, u, p, t):
+        du[0] = p[0] * u[0] - p[1] * u[0] * u[1] + trace.sin(u[2])
+        du[1] = -p[2] * u[1] + p[3] * u[0] * u[1] / (1.0 + u[2] * u[2])
+        du[2] = -u[2] * p[0] + trace.exp(-u[0])
+    import scimlsensitivity_jl_amd as sa
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+    F = sa.DeviceFunction.from_callable("traced_cols_probe", f, 3, 4)
+    _lib.check_model(F.id)
+    tus = sorted(glob.glob(str(tmp_path / "traced_cols_probe_*.hip")))
+    assert tus and "HAS_COLS = true" in open(tus[-1]).read() and "const auto w" in open(tus[-1]).read()
+    G = sa.DeviceFunction("double_temporaries_probe", 2, 4, "du[0] = p[0]*u[0] - p[1]*u[0]*u[1]; du[1] = -p[2]*u[1] + p[3]*u[0]*u[1];",
+                          "double a = lam[0], b = lam[1]; out[0] = (p[0] - p[1]*u[1])*a + p[3]*u[1]*b; out[1] = -p[1]*u[0]*a + (-p[2] + p[3]*u[0])*b;",
+                          "const double xy = u[0]*u[1]; double a = lam[0]; out[0] = u[0]*a; out[1] = -xy*a; out[2] = -u[1]*lam[1]; out[3] = xy*lam[1];")
+    _lib.check_model(G.id)
+    tus = sorted(glob.glob(str(tmp_path / "double_temporaries_probe_*.hip")))
+    assert tus and "HAS_COLS = false" in open(tus[-1]).read()
