@@ -2,6 +2,8 @@
 hipadj_model_register (the ODEFunction(f!; vjp, vjp_p) seam, src/derivative_wrappers.jl:284-359).
 CPU: the traced VJP graphs against the oracle's hand-derived model VJPs and against finite differences; the emitted text compiles for
 gfx950 (hipadj_model_check, no device).  GPU: a traced Lorenz gives the gradients of the compiled-in Lorenz and of the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -126,3 +128,49 @@ def test_traced_vjp_bodies_compile_for_column_bundles(tmp_path, monkeypatch):
     _lib.check_model(G.id)
     tus = sorted(glob.glob(str(tmp_path / "double_temporaries_probe_*.hip")))
     assert tus and "HAS_COLS = false" in open(tus[-1]).read()
+
+
+def test_traced_vjp_bodies_give_the_same_numbers_through_a_bundle(tmp_path):
+    """Host check of the bundle semantics on tracer output: the emitted vjp_u / vjp_p text, compiled by g++ against csrc/hipadj_models.hpp, evaluated once with
+    lam = Cols<3> (three columns in one pass) and three times with lam = double — identical to the last bit (same operations per column)."""
+    import subprocess
+    from scimlsensitivity_jl_amd import trace
+
+    def f(du, u, p, t):
+        du[0] = p[0] * u[0] - p[1] * u[0] * u[1] + trace.sin(u[2])
+        du[1] = -p[2] * u[1] + p[3] * u[0] * u[1] / (1.0 + u[2] * u[2])
+        du[2] = -u[2] * p[0] + trace.exp(-u[0]) * t
+    fb, vu, vp = trace.bodies(f, 3, 4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "bundle_host.cpp"
+    src.write_text('''
+#include <cmath>
+#include <cstdio>
+using std::sin; using std::cos; using std::exp; using std::pow; using std::log; using std::sqrt; using std::tanh;
+#include "hipadj_models.hpp"
+using namespace hipadj;
+constexpr int N = 3, NP = 4;
+template <class LT> void vjp_u_t(LT (&out)[N], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { (void)t; %s }
+template <class LT> void vjp_p_t(LT (&out)[NP], const LT (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { (void)t; %s }
+int main() {
+    const double u[N] = {0.7, 1.3, -0.4}, p[NP] = {1.5, 1.0, 3.0, 0.8}, t = 0.37;
+    const double L[3][N] = {{0.3, -1.1, 0.6}, {1.0, 0.0, 0.0}, {-0.2, 0.9, 2.5}};
+    Cols<3> lam[N], ou[N], op[NP];
+    for (int j = 0; j < N; ++j) for (int g = 0; g < 3; ++g) lam[j].v[g] = L[g][j];
+    vjp_u_t<Cols<3>>(ou, lam, u, p, t); vjp_p_t<Cols<3>>(op, lam, u, p, t);
+    int bad = 0;
+    for (int g = 0; g < 3; ++g) {
+        double l[N], a[N], b[NP];
+        for (int j = 0; j < N; ++j) l[j] = L[g][j];
+        vjp_u_t<double>(a, l, u, p, t); vjp_p_t<double>(b, l, u, p, t);
+        for (int j = 0; j < N; ++j) bad += a[j] != ou[j].v[g];
+        for (int j = 0; j < NP; ++j) bad += b[j] != op[j].v[g];
+    }
+    std::printf("bad %%d\\n", bad);
+    return bad;
+}
+''' % (vu, vp))
+    exe = tmp_path / "bundle_host"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "scimlsensitivity.jl_amd", "csrc"), str(src), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
