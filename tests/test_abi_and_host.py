@@ -208,6 +208,13 @@ def test_planner_segments_checkpoints_and_quadrature_intervals():
     assert bounds[-1] - bounds[-2] > bounds[1] - bounds[0]          # the 1-column top segment is the longest
     assert 157 * nseg <= 2048                                       # one residency round on 1024 SIMDs x 2 waves
     assert plan("interpolating", 10 ** 6, 0.01, ts, time_segments=0)[0] == 1    # big ensembles stay sequential in time
+    # strong-scaling shards: two waves per SIMD where the 16-step minimum allows it (2500 trajectories: 40 waves x 51 = 2040), otherwise exactly ONE
+    # residency round (1250: 20 waves x 51 = 1020 <= 1024 — not the 62 segments of the step limit, which would leave 216 SIMDs with two waves), and
+    # the step limit itself when even that does not fill the chip (640: 10 waves x 62)
+    assert plan("interpolating", 5000, 0.01, ts, time_segments=0)[0] == 25
+    assert plan("interpolating", 2500, 0.01, ts, time_segments=0)[0] == 51
+    assert plan("interpolating", 1250, 0.01, ts, time_segments=0)[0] == 51
+    assert plan("interpolating", 640, 0.01, ts, time_segments=0)[0] == 62
     assert plan("interpolating", 100, 0.01, ts, time_segments=5)[0] == 5
     assert plan("backsolve", 64, 0.01, ts, checkpointing=True)[2] == 101        # default checkpoints = saved points
     assert plan("backsolve", 64, 0.01, ts[1:-1], checkpointing=True)[2] == 101  # endpoints are always stored
