@@ -50,7 +50,7 @@ hipadj_version() = Int(ccall(sym(:hipadj_version), Cint, ()))
 function runtime_compiler()
     buf = Vector{UInt8}(undef, 1024)
     check(ccall(sym(:hipadj_runtime_compiler), Cint, (Ptr{UInt8}, Int32), buf, Int32(length(buf))))
-    return unsafe_string(pointer(buf))
+    return GC.@preserve buf unsafe_string(pointer(buf))
 end
 
 # mirrors `hipadj_config` (include/hipadj.h) field by field; Julia lays an isbits struct out like C does
