@@ -98,3 +98,37 @@ def test_event_chain_misuse(lv_with_affect):
         events.adjoint_sensitivities_events(_fake_adjoint, sol, None, dgdu_discrete=np.ones((1, 2, 2)), dgdp_discrete=np.ones((1, 2, 4)))
     with pytest.raises(ValueError):
         events.adjoint_sensitivities_events(_fake_adjoint, sol, None)
+
+
+def test_event_chain_with_a_mass_matrix_converts_lambda_to_the_state_gradient(lv_with_affect, monkeypatch):
+    """With a mass matrix a piece returns the reference's lam(t0) = M^-T dG/du0 (src/sensitivity_interface.jl:500), while the reverse callback acts on
+    dG/du and the lower piece expects a dG/du cotangent: events.py converts with lam' M at every event (_lib.MASS).  Oracle-backed stand-ins in the
+    mass-matrix formulation; the parameter gradient of the chain against central differences of the chained forward solves, du0 against M^-T times
+    the finite-difference state gradient."""
+    rng = np.random.default_rng(11)
+    N, T, dt = 2, 2.0, 0.01
+    M = np.array([[1.4, 0.3], [-0.2, 0.9]])
+    mid = _lib.MODEL["lv_fake_user"]
+    monkeypatch.setitem(_lib.MASS, mid, M)
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0]) + 0.05 * rng.standard_normal((N, 4))
+    ts = np.array([0.5, 1.0, 1.5, 2.0]); w = rng.standard_normal((N, len(ts), 2))
+    cb = PresetTimeCallback([0.7, 1.0])
+
+    def run(u0_, p_, grad):
+        with O.mass_matrix(M):
+            ens = EnsembleProblem(ODEProblem("lv_fake_user", u0_[0], (0.0, T), p_[0]), u0_, p_)
+            sol = events.solve_with_events(_fake_solve, lv_with_affect, ens, None, cb, saveat=ts, dt=dt, sensealg="INTERPOLATING")
+            L = float((sol.u * w).sum())
+            return (L, events.adjoint_sensitivities_events(_fake_adjoint, sol, None, dgdu_discrete=w)) if grad else (L, None)
+
+    L, (du0, dp) = run(u0, p, True)
+    h = 1e-6
+    for k in range(4):
+        e = np.zeros_like(p); e[:, k] = h
+        fd = (run(u0, p + e, False)[0] - run(u0, p - e, False)[0]) / (2 * h)
+        assert abs(fd - dp[:, k].sum()) < 3e-6 * max(1.0, abs(fd))
+    g = np.zeros(2)
+    for j in range(2):
+        e = np.zeros_like(u0); e[1, j] = h
+        g[j] = (run(u0 + e, p, False)[0] - run(u0 - e, p, False)[0]) / (2 * h)
+    assert np.allclose(du0[1], np.linalg.solve(M.T, g), rtol=0, atol=3e-6 * max(1.0, np.abs(g).max()))     # lam(t0) = M^-T dG/du0
