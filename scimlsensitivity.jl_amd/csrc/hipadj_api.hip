@@ -806,7 +806,7 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     int flag_a = 0, flag_b = 0;
     TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));
     TRY(fetch(a0, a1, flag_a));
-    HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
+    HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));   // in stream order with the second run
     std::swap(h->uf_main, h->uf_main_alt);                 // the -O1 build
     TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));
     TRY(fetch(b0, b1, flag_b));
