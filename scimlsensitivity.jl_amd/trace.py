@@ -262,13 +262,15 @@ def evaluate(outs, env):
     return [vals[id(o)] for o in outs]
 
 
-def bodies(f, n, np_, auto_vjp=False):
+def bodies(f, n, np_, auto_vjp=False, bundle=False):
     """(f_body, vjp_u_body, vjp_p_body) for hipadj_model_register; auto_vjp = True: only f (locals `real`), the device differentiates
     it with forward-mode dual numbers (the reference's autojacvec = true)."""
     outs, u, p, t = trace(f, n, np_)
     if auto_vjp:
         return emit(outs, "du", real="real"), None, None
     lam = [Node("var", name=f"lam[{i}]") for i in range(n)]
-    # VJP temporaries are `auto`: the device compiles these bodies for lam = double (one adjoint column) and for lam = Cols<G> (a bundle of segment
-    # columns, csrc/hipadj_models.hpp); a `double` temporary holding a lam term would force the per-column form
-    return emit(outs, "du"), emit(vjp_graphs(outs, u, lam), "out", real="auto"), emit(vjp_graphs(outs, p, lam), "out", real="auto")
+    # bundle = True: VJP temporaries are `auto`, so that the device can compile these bodies for lam = Cols<G> (a bundle of segment columns through one
+    # pass of the body, csrc/hipadj_models.hpp) as well as for lam = double; with `double` temporaries (the default until the bundled kernels of traced
+    # models have had their GPU parity run) a lam term held in a temporary forces the per-column form, which is what every GPU test of round 2 exercised
+    real = "auto" if bundle else "double"
+    return emit(outs, "du"), emit(vjp_graphs(outs, u, lam), "out", real=real), emit(vjp_graphs(outs, p, lam), "out", real=real)

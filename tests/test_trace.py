@@ -106,7 +106,7 @@ def test_traced_lorenz_on_device(alg, oalg, auto):
 
 
 def test_traced_vjp_bodies_compile_for_column_bundles(tmp_path, monkeypatch):
-    """The tracer writes lam-dependent temporaries as `auto`, so the emitted VJP bodies compile for lam = Cols<G> (a bundle of segment columns through
+    """With bundle = True the tracer writes lam-dependent temporaries as `auto`, so the emitted VJP bodies compile for lam = Cols<G> (a bundle of segment columns through
     one pass of the body, csrc/hipadj_models.hpp): the generated model keeps HAS_COLS = true and its segmented kernels build without a device.  A
     hand-written body with a `double` temporary holding a lam term builds too — in the per-column form (HAS_COLS = false in its final translation unit)."""
     import glob
@@ -118,7 +118,7 @@ def test_traced_vjp_bodies_compile_for_column_bundles(tmp_path, monkeypatch):
         du[2] = -u[2] * p[0] + trace.exp(-u[0])
     import scimlsensitivity_jl_amd as sa
     monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
-    F = sa.DeviceFunction.from_callable("traced_cols_probe", f, 3, 4)
+    F = sa.DeviceFunction.from_callable("traced_cols_probe", f, 3, 4, bundle=True)
     _lib.check_model(F.id)
     tus = sorted(glob.glob(str(tmp_path / "traced_cols_probe_*.hip")))
     assert tus and "HAS_COLS = true" in open(tus[-1]).read() and "const auto w" in open(tus[-1]).read()
@@ -140,7 +140,7 @@ def test_traced_vjp_bodies_give_the_same_numbers_through_a_bundle(tmp_path):
         du[0] = p[0] * u[0] - p[1] * u[0] * u[1] + trace.sin(u[2])
         du[1] = -p[2] * u[1] + p[3] * u[0] * u[1] / (1.0 + u[2] * u[2])
         du[2] = -u[2] * p[0] + trace.exp(-u[0]) * t
-    fb, vu, vp = trace.bodies(f, 3, 4)
+    fb, vu, vp = trace.bodies(f, 3, 4, bundle=True)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "bundle_host.cpp"
     src.write_text('''
