@@ -54,44 +54,71 @@ def oracle_problem(alg="INTERPOLATING", **kw):
 
 
 def cpu_baseline(u0, p, ts, budget_s=20.0):
-    """The oracle (CPU restatement of the reference algorithm — NOT Julia) timed on a bounded sample of the same
-    workload with the host thread count that maximises ITS throughput (OpenMP over trajectories)."""
-    os.environ.setdefault("OMP_PROC_BIND", "spread")   # read by libgomp when the oracle library is first loaded
-    os.environ.setdefault("OMP_PLACES", "threads")
+    """The oracle (CPU restatement of the reference algorithm — NOT Julia) timed on the workload's own trajectories (reverse passes
+    only, like `value`), OpenMP over trajectories.  Every figure is the median of >= 5 repeats of the SAME call (all trajectories,
+    rounded down to a multiple of the thread count) and carries its spread; the thread count is the one at which that median is
+    highest, and the probe that chose it is the same measurement, so probe and reported value agree by construction."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")    # read by libgomp when the oracle library is first loaded: neighbouring cores, no migration
+    os.environ.setdefault("OMP_PLACES", "cores")
     cores = os.cpu_count() or 1
     pr = oracle_problem()
-    # thread count: the oracle allocates per trajectory and its OpenMP scaling collapses beyond ~32-64 threads on the 2-socket
-    # host (kernel VM contention), so the baseline uses the thread count that maximises ITS throughput and says which
-    best, probe_log = None, []
+
+    def sample(nt, min_reps, max_s):
+        n = max(nt, (len(u0) // nt) * nt)
+        pr.adjoint_ensemble(u0[:n], p, nthreads=nt, want_out=False)                    # warm-up: per-thread solution pools, page faults
+        rates, rev, t_start = [], 0.0, time.perf_counter()
+        while len(rates) < min_reps or (rev * nt < max_s and len(rates) < 200 and time.perf_counter() - t_start < 60.0):
+            _, _, _, tm = pr.adjoint_ensemble(u0[:n], p, nthreads=nt, want_out=False)
+            rates.append(n / tm["reverse_s"])          # reverse_s = max over threads of the time spent in reverse passes
+            rev += tm["reverse_s"]
+        return n, np.array(rates), rev
+
+    probe = {}
     for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}, reverse=True):
-        m = min(len(u0), 64 * nt)
-        pr.adjoint_ensemble(u0[:m], p, nthreads=nt, want_out=False)                    # warm the per-thread arenas
-        _, _, _, tmp = pr.adjoint_ensemble(u0[:m], p, nthreads=nt, want_out=False)
-        rate = m / tmp["reverse_s"]
-        probe_log.append(f"{nt}:{rate:.3g}")
-        if best is None or rate > best[1]:
-            best = (nt, rate)
-    cores_used = best[0]
-    n = max(cores_used, (len(u0) // cores_used) * cores_used)
-    # timed sample: the workload's trajectories, repeated until about `budget_s` core-seconds of reverse-pass work were measured
-    rev, wall, reps = 0.0, 0.0, 0
-    while reps < 500 and rev * cores_used < budget_s:
-        t0 = time.perf_counter()
-        _, _, _, tm = pr.adjoint_ensemble(u0[:n], p, nthreads=cores_used, want_out=False)
-        wall += time.perf_counter() - t0
-        rev += tm["reverse_s"]  # max over threads of the time spent in reverse passes
-        reps += 1
-    # the same path on ONE host thread (SURVEY.md §8d asks for both): a smaller sample, same inputs
-    n1 = min(len(u0), 2048)
-    _, _, _, tm1 = pr.adjoint_ensemble(u0[:n1], p, nthreads=1, want_out=False)
-    return dict(value=n * reps / rev, unit="trajectories/s", cores=cores_used, host_threads=cores,
-                cores_note=f"{cores_used} of {cores} host threads (the thread count at which the oracle is fastest)",
-                thread_probe_traj_per_s=" ".join(probe_log), kind="port",
-                single_thread_value=n1 / tm1["reverse_s"], single_thread_ns_per_vjp_step=tm1["reverse_s"] / (n1 * 1000 * 4) * 1e9,
-                sample=f"{n} of the workload's trajectories x {reps} repeats, reverse passes only ({rev:.2f} s on {cores_used} threads = "
-                       f"{rev * cores_used:.0f} core-seconds; forward+reverse wall {wall:.2f} s), C oracle, OpenMP over trajectories, "
-                       f"gcc -O2 -ffp-contract=off",
-                ns_per_vjp_step=rev / (n * reps * 1000 * 4) * 1e9)
+        _, rates, _ = sample(nt, 5, 0.0)
+        probe[nt] = float(np.median(rates))
+    cores_used = max(probe, key=probe.get)
+    n, rates, rev = sample(cores_used, 5, budget_s)
+    med = float(np.median(rates))
+    # the same path on ONE host thread (SURVEY.md §8d asks for both): a smaller sample, same inputs, median of 5
+    n1 = min(len(u0), 1024)
+    pr.adjoint_ensemble(u0[:n1], p, nthreads=1, want_out=False)
+    r1 = np.array([n1 / pr.adjoint_ensemble(u0[:n1], p, nthreads=1, want_out=False)[3]["reverse_s"] for _ in range(5)])
+    return dict(value=med, unit="trajectories/s", cores=cores_used, host_threads=cores,
+                cores_note=f"{cores_used} of {cores} host threads (the thread count at which the oracle's median rate is highest)",
+                repeats=int(len(rates)), spread_min_max=[float(rates.min()), float(rates.max())],
+                spread_rel=float((rates.max() - rates.min()) / med),
+                thread_probe_traj_per_s=" ".join(f"{k}:{v:.3g}" for k, v in sorted(probe.items(), reverse=True)),
+                probe_vs_value_rel_diff=abs(probe[cores_used] - med) / med, kind="port",
+                single_thread_value=float(np.median(r1)), single_thread_spread_min_max=[float(r1.min()), float(r1.max())],
+                single_thread_ns_per_vjp_step=1e9 / (float(np.median(r1)) * 1000 * 4),
+                parallel_efficiency=med / (cores_used * float(np.median(r1))),
+                sample=f"{n} of the workload's trajectories x {len(rates)} repeats, reverse passes only, median ({rev:.2f} s on {cores_used} threads = "
+                       f"{rev * cores_used:.0f} core-seconds), C oracle, OpenMP over trajectories (static schedule, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, "
+                       f"OMP_PLACES={os.environ.get('OMP_PLACES')}), gcc -O2 -ffp-contract=off",
+                ns_per_vjp_step=1e9 / (med * 1000 * 4))
+
+
+STUB = os.environ.get("HIPADJ_BENCH_STUB") == "1"     # launcher / carrier self-test on CPU (tests/bench_stub.py, gloo): no kernel runs, the line says so
+_ABANDONED = []                                        # engines whose communicator bootstrap hung: never destroyed (hipadj_destroy would wait for the hung stream)
+
+
+def _call_with_timeout(fn, seconds):
+    """Runs fn() on a daemon thread.  Returns (finished, exception or None): a collective that never returns (one rank missing from the
+    RCCL bootstrap) costs `seconds`, not the run."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            fn()
+        except BaseException as e:      # noqa: BLE001 — reported to the caller
+            box["e"] = e
+        box["done"] = True
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    return bool(box.get("done")), box.get("e")
 
 
 class Runner:
@@ -99,28 +126,41 @@ class Runner:
 
     def __init__(self, sa, torch, dist, args, n_local, u0_np, p_np, local_rank, world, native):
         self.torch, self.dist, self.world, self.native = torch, dist, world, native
-        dev = torch.device("cuda", local_rank)
-        self.eng = sa.Engine("lorenz", "interpolating", n_local, 0.0, T_FINAL, DT, save_times=save_times(), loss_kind=1, loss_shift=LOSS_SHIFT,
+        dev = self.dev = torch.device("cpu") if STUB else torch.device("cuda", local_rank)
+        self.sync = (lambda: None) if STUB else torch.cuda.synchronize
+
+        def make_engine():
+            return sa.Engine("lorenz", "interpolating", n_local, 0.0, T_FINAL, DT, save_times=save_times(), loss_kind=1, loss_shift=LOSS_SHIFT,
                              p_shared=True, device=local_rank, time_segments=args.segments)
-        self.eng.use_torch_stream()
+        self.eng = make_engine()
+        self.native_note = None
         if native:
-            native = self.native = self._try_native(sa, torch, dist, dev, world)
+            # on the handle's OWN stream, before it is moved to torch's: a collective that hangs then blocks a stream nobody else uses
+            native = self.native = self._try_native(sa, torch, dist, dev, world, make_engine)
+        self.eng.use_torch_stream()
         self.eng.set_timing(1)   # HIP events around the dominant kernel only (on its dispatch packet); the whole-call bracket costs ~8 us per step
         self.u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
         self.p = torch.tensor(p_np, device=dev, dtype=torch.float64)
         self.du0 = torch.empty((n_local, 3), device=dev, dtype=torch.float64)
         self.dps = [torch.empty(3, device=dev, dtype=torch.float64) for _ in range(2)]
         self.eng.forward_dev(self.u0, self.p, None)          # forward solve: interpolant tiles now resident in HBM
-        torch.cuda.synchronize()
+        self.sync()
         self.eng.forward_dev(self.u0, self.p, None)          # once more: forward_solve_ms is the steady-state call, not the first launch (code load)
-        torch.cuda.synchronize()
+        self.sync()
         self.it, self.pending = 0, None
 
-    def _try_native(self, sa, torch, dist, dev, world):
-        """The library's own RCCL communicator (torch.distributed only ships the 128-byte id).  Every failure that can be SEEN — the id
-        cannot be drawn, ncclCommInitRank returns an error on some rank — makes all ranks agree on the torch.distributed carrier
-        instead of losing the run."""
+    def _agree(self, ok):
+        """All ranks learn whether EVERY rank succeeded (torch.distributed carries the flag)."""
+        flag = self.torch.tensor([1 if ok else 0], device=self.dev, dtype=self.torch.int32)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def _try_native(self, sa, torch, dist, dev, world, make_engine):
+        """The library's own RCCL communicator (torch.distributed only ships the 128-byte id).  Every failure — the id cannot be drawn,
+        ncclCommInitRank returns an error or does not return within HIPADJ_COMM_TIMEOUT seconds on some rank, the probe all-reduce of
+        hipadj_comm_selfcheck comes back wrong or hangs — makes ALL ranks agree on the torch.distributed carrier instead of losing the run."""
         rank = dist.get_rank()
+        tmo = float(os.environ.get("HIPADJ_COMM_TIMEOUT", "90"))
         try:
             box = [sa.comm_unique_id() if rank == 0 else None]
         except Exception as e:
@@ -128,19 +168,28 @@ class Runner:
             sys.stderr.write(f"bench: native RCCL id failed on rank 0 ({e!r}); falling back to torch.distributed\n")
         dist.broadcast_object_list(box, src=0)
         if box[0] is None:
+            self.native_note = "ncclGetUniqueId failed"
             return False
-        ok = True
-        try:
-            self.eng.comm_init_rank(box[0], world, rank)
-        except Exception as e:
-            ok = False
-            sys.stderr.write(f"bench: hipadj_comm_init_rank failed on rank {rank} ({e!r}); falling back to torch.distributed\n")
-        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if ok:
-                self.eng.comm_destroy()
-            return False
+        hung = False
+        for what, fn in (("hipadj_comm_init_rank", lambda: self.eng.comm_init_rank(box[0], world, rank)),
+                         ("hipadj_comm_selfcheck", lambda: self.eng.comm_selfcheck())):
+            done, err = _call_with_timeout(fn, tmo)
+            ok = done and err is None
+            if not ok:
+                hung = hung or not done
+                sys.stderr.write(f"bench: {what} {'did not return within %g s' % tmo if not done else 'failed'} on rank {rank} ({err!r}); "
+                                 f"falling back to torch.distributed\n")
+            if not self._agree(ok):
+                self.native_note = f"{what} failed or timed out on some rank"
+                if hung:                       # the handle may still be inside the collective: leave it alone for good, start over on a fresh one
+                    _ABANDONED.append(self.eng)
+                    self.eng = make_engine()
+                else:
+                    try:
+                        self.eng.comm_destroy()
+                    except Exception:
+                        pass
+                return False
         return True
 
     def step(self):
@@ -164,20 +213,20 @@ class Runner:
         for _ in range(warmup):
             self.step()
         self.drain()
-        torch.cuda.synchronize()
+        self.sync()
         self.eng.synchronize()
         st0 = self.eng.stats()
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        self.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
         self.drain()
-        torch.cuda.synchronize()
+        self.sync()
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        self.sync()
         elapsed = time.perf_counter() - t0
         self.eng.synchronize()
         st1 = self.eng.stats()
@@ -271,6 +320,27 @@ def other_configs(sa, torch):
     return out
 
 
+def self_launch(n):
+    """Re-executes this script as n ranks under torch.distributed.run on 127.0.0.1 (a free port), one rank per GPU; returns the exit
+    code.  Refuses before spawning when fewer than n devices are visible."""
+    import socket
+    import subprocess
+    if not STUB:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write(f"bench.py --gpus {n}: only {have} HIP device(s) visible; refusing to run a smaller job under that label\n")
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,21 +357,35 @@ def main():
     ap.add_argument("--native-allreduce", action="store_true", help="(default for N > 1; kept for compatibility)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import scimlsensitivity_jl_amd as sa
-
+    # ---- launch: `python bench.py --gpus N` with no torchrun environment starts its own N ranks (one per GPU); the driver's torchrun line
+    # lands in the else branch with WORLD_SIZE = N.  `--gpus N` never measures fewer than N GPUs.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torchrun: bench.py starts its own ranks)")
+
+    import torch
+    import torch.distributed as dist
+    if STUB:
+        import bench_stub as sa           # tests/bench_stub.py: the launcher / carrier self-test, no kernel runs
+    else:
+        import scimlsensitivity_jl_amd as sa
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) visible")
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if STUB:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     native = world > 1 and not args.torch_allreduce
     ts = save_times()
     S = int(round(T_FINAL / DT))
@@ -344,7 +428,10 @@ def main():
                                    f"dgdu = u - {LOSS_SHIFT} (BASELINE configs[1])",
                        "ntraj_total": n_total, "ntraj_per_gpu": hi - lo, "rk4_steps": S, "loss_times": len(ts),
                        "time_segments": st1["time_segments"], "parallelism": f"ensemble-shard x{world}",
-                       "dp_allreduce": ("none" if world == 1 else "rccl in-stream (hipadj_comm)" if r.native else "torch.distributed nccl, async")},
+                       "dp_allreduce": ("none" if world == 1 else "rccl in-stream (hipadj_comm)" if r.native else "torch.distributed nccl, async"),
+                       # ranks the dp all-reduce really spans: ncclCommCount of the handle's communicator (native carrier), or the process group's size
+                       "rccl_ranks": (0 if world == 1 else r.eng.comm_count() if r.native else dist.get_world_size()),
+                       "native_allreduce_fallback": r.native_note},
             "ns_per_vjp_step": elapsed / args.steps / (n_total * S * 4.0) * 1e9,
             "forward_solve_ms": fwd_ms,
             "forward_plus_reverse_ms": (fwd_ms + ms_per_step) if fwd_ms is not None else None,
@@ -356,8 +443,10 @@ def main():
         # ---- parity: du0 of every trajectory of this rank's shard and (N = 1) the REDUCED dp against the oracle on the same set
         du0 = r.du0.cpu().numpy()
         dp = r.last_dp().cpu().numpy()
-        pr = oracle_problem()
-        if world == 1:
+        pr = None if STUB else oracle_problem()
+        if STUB:      # launcher / carrier self-test: nothing was computed, nothing is compared; the reduced stand-in dp lets the test see the all-reduce
+            res.update(metric="STUB_no_kernel_ran", data="STUB (tests/bench_stub.py): launcher and all-reduce carrier self-test on CPU", stub_dp=[float(x) for x in dp])
+        elif world == 1:
             rdu0, rdp, _, _ = pr.adjoint_ensemble(u0_all, p_np, want_out=False)          # all trajectories: ~1 s on the host cores
             res["parity_max_rel_du0_vs_oracle"] = float(np.max(np.abs(du0 - rdu0)) / np.max(np.abs(rdu0)))
             res["parity_max_rel_dp_vs_oracle"] = float(np.max(np.abs(dp - rdp) / np.abs(rdp)))
@@ -379,7 +468,7 @@ def main():
                 "time_segments": s1["time_segments"], "steps": k2}
         r2.close()
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not STUB:
         if not args.no_extras:
             # the shard sizes of the 8 / 4 / 2-GPU strong-scaling layouts on THIS GPU: the per-rank step time the multi-GPU figure rests on
             sh = []

@@ -248,12 +248,17 @@ int hipadj_get_stats(hipadj_handle *h, hipadj_stats *stats);
  *   hipadj_comm_init_rank  collective over the nranks processes: ncclCommInitRank on the handle's device; owned by the handle
  *   hipadj_comm_attach     use an existing ncclComm_t of the host instead (not owned; NULL detaches)
  *   hipadj_comm_destroy    drops the communicator (hipadj_destroy does it as well)
+ *   hipadj_comm_count      ranks of the handle's communicator (ncclCommCount); 0 = no communicator, dp is the shard's own sum
+ *   hipadj_comm_selfcheck  collective: all-reduces a known probe exactly as dp is all-reduced and checks the sum — call once
+ *                          after hipadj_comm_init_rank / _attach on every rank (synchronises the handle's stream)
  * Summation order depends on the shard count: compare results across shard counts at rtol 1e-12, not bitwise. */
 #define HIPADJ_COMM_ID_BYTES 128
 int hipadj_comm_unique_id(char *id /* [HIPADJ_COMM_ID_BYTES] */);
 int hipadj_comm_init_rank(hipadj_handle *h, const char *id /* [HIPADJ_COMM_ID_BYTES] */, int nranks, int rank);
 int hipadj_comm_attach(hipadj_handle *h, void *nccl_comm);
 int hipadj_comm_destroy(hipadj_handle *h);
+int hipadj_comm_count(hipadj_handle *h, int *nranks);
+int hipadj_comm_selfcheck(hipadj_handle *h);
 
 #ifdef __cplusplus
 }

@@ -397,6 +397,58 @@ extern "C" int hipadj_comm_init_rank(hipadj_handle* h, const char* id, int nrank
     return HIPADJ_OK;
 }
 
+extern "C" int hipadj_comm_count(hipadj_handle* h, int* nranks) {
+    if (!h || !nranks) return HIPADJ_ERR_INVALID_ARG;
+    *nranks = 0;                                   // no communicator: the handle's dp is its shard's own sum
+    if (!h->comm) return HIPADJ_OK;
+    RcclApi& A = rccl_api();
+    if (!A.err.empty()) { h->err = A.err; return HIPADJ_ERR_RCCL; }
+    const int rc = A.CommCount(h->comm, nranks);
+    if (rc != 0) { h->err = rccl_error("ncclCommCount", rc); return HIPADJ_ERR_RCCL; }
+    return HIPADJ_OK;
+}
+
+// Collective: every rank all-reduces the probe (1, rank + 1, 2^-rank) exactly as hipadj_adjoint(_dev) all-reduces dp (same
+// communicator, stream, datatype and operator) and compares with what nranks ranks must produce.  A wrong binding of the RCCL
+// ABI (datatype / operator enumerators, the by-value unique id) or a communicator that spans other ranks than the host believes
+// shows up here, before a gradient is wrong.  Synchronises the handle's stream.
+extern "C" int hipadj_comm_selfcheck(hipadj_handle* h) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!h->comm) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_comm_selfcheck: the handle has no communicator");
+    RcclApi& A = rccl_api();
+    if (!A.err.empty()) { h->err = A.err; return HIPADJ_ERR_RCCL; }
+    int nranks = 0, rank = -1;
+    int rc = A.CommCount(h->comm, &nranks);
+    if (rc == 0 && A.CommUserRank) rc = A.CommUserRank(h->comm, &rank);
+    if (rc != 0 || nranks < 1) { h->err = rccl_error("ncclCommCount / ncclCommUserRank", rc); return HIPADJ_ERR_RCCL; }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    double probe[3] = {1.0, (double)(rank + 1), std::ldexp(1.0, -(rank < 0 ? 0 : rank % 50))}, got[3] = {0, 0, 0};
+    double* d = nullptr;
+    HIP_TRY(h, hipMalloc(&d, sizeof(probe)));
+    hipError_t e = hipMemcpyAsync(d, probe, sizeof(probe), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        rc = A.AllReduce(d, d, 3, RCCL_DOUBLE, RCCL_SUM, h->comm, h->stream);
+        e = hipMemcpyAsync(got, d, sizeof(got), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(d);
+    if (rc != 0) { h->err = rccl_error("ncclAllReduce (self-check)", rc); return HIPADJ_ERR_RCCL; }
+    HIP_TRY(h, e);
+    double want2 = 0.0;
+    for (int r = 0; r < nranks; ++r) want2 += std::ldexp(1.0, -(r % 50));
+    const double want[3] = {(double)nranks, 0.5 * nranks * (nranks + 1.0), want2};
+    if (rank < 0) { probe[1] = 0; }   // rank unknown (an attached communicator of an RCCL without ncclCommUserRank): only the count and the powers are checked
+    const bool ok = got[0] == want[0] && (rank < 0 || got[1] == want[1]) && (rank < 0 || std::fabs(got[2] - want[2]) <= 1e-15 * want[2]);
+    if (!ok) {
+        char msg[256];
+        std::snprintf(msg, sizeof msg, "hipadj_comm_selfcheck: all-reduce over %d ranks returned (%.17g, %.17g, %.17g), expected (%.17g, %.17g, %.17g)",
+                      nranks, got[0], got[1], got[2], want[0], want[1], want[2]);
+        h->err = msg;
+        return HIPADJ_ERR_RCCL;
+    }
+    return HIPADJ_OK;
+}
+
 extern "C" int hipadj_comm_attach(hipadj_handle* h, void* nccl_comm) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (nccl_comm && !h->cfg.p_shared) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "per-trajectory parameters (p_shared = 0) have no cross-shard reduction: dp stays sharded like du0");

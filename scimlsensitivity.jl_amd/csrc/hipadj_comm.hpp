@@ -32,6 +32,7 @@ struct RcclApi {
     int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
     int (*CommDestroy)(RcclComm) = nullptr;
     int (*CommCount)(RcclComm, int*) = nullptr;
+    int (*CommUserRank)(RcclComm, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -50,6 +51,7 @@ inline RcclApi& rccl_api() {
         A.CommInitRank = (decltype(A.CommInitRank))S("ncclCommInitRank");
         A.CommDestroy = (decltype(A.CommDestroy))S("ncclCommDestroy");
         A.CommCount = (decltype(A.CommCount))S("ncclCommCount");
+        A.CommUserRank = (decltype(A.CommUserRank))S("ncclCommUserRank");
         A.AllReduce = (decltype(A.AllReduce))S("ncclAllReduce");
         A.GetErrorString = (decltype(A.GetErrorString))S("ncclGetErrorString");
     });

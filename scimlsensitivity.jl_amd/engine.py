@@ -127,6 +127,16 @@ class Engine:
     def comm_destroy(self):
         self._check(self._L.hipadj_comm_destroy(self._h))
 
+    def comm_count(self):
+        """Ranks of the handle's RCCL communicator (ncclCommCount); 0 = none (dp is this shard's own sum)."""
+        n = C.c_int(0)
+        self._check(self._L.hipadj_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def comm_selfcheck(self):
+        """Collective: all-reduces a known probe the way dp is all-reduced and verifies the sum (raises HipadjError otherwise)."""
+        self._check(self._L.hipadj_comm_selfcheck(self._h))
+
     def set_timing(self, level):
         """0: no device events, 1: dominant-kernel bracket only, 2: + whole-call bracket (default)."""
         self._check(self._L.hipadj_set_timing(self._h, int(level)))

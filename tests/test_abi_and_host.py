@@ -364,11 +364,24 @@ def test_comm_entry_points_validate_and_bind_rccl_lazily(sa):
     L = sa.load_library()
     assert L.hipadj_comm_unique_id(None) == -1 and L.hipadj_comm_init_rank(None, None, 1, 0) == -1
     assert L.hipadj_comm_attach(None, None) == -1 and L.hipadj_comm_destroy(None) == -1
+    assert L.hipadj_comm_count(None, None) == -1 and L.hipadj_comm_selfcheck(None) == -1
     a, b = sa.comm_unique_id(), sa.comm_unique_id()
     assert len(a) == 128 and a != b
     assert L.hipadj_status_string(-8) == b"RCCL error"
     needed = subprocess.check_output(["readelf", "-d", sa.LIB_PATH]).decode()
     assert "rccl" not in needed and "hiprtc" not in needed
+
+
+def test_hand_declared_rccl_abi_matches_the_toolkits_header():
+    """csrc/hipadj_comm.hpp binds RCCL with dlopen and declares the few enumerators / signatures it uses by hand; tests/c/rccl_abi_check.cpp
+    static_asserts every one of them against <rccl/rccl.h> (compile only).  The N > 1 all-reduce has never run on this pool's 1-GPU boxes:
+    this is what keeps a silently different datatype / operator number or id size from reaching the driver's 8-GPU run."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc, "-fsyntax-only", "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "scimlsensitivity.jl_amd", "csrc"),
+                        os.path.join(ROOT, "tests", "c", "rccl_abi_check.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
 
 
 def _build_host_demo(sa, tmp_path):
@@ -520,4 +533,5 @@ def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
     cb = bench.cpu_baseline(u0, p, ts, budget_s=0.05)
     assert cb["kind"] == "port" and cb["unit"] == "trajectories/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread_value"] > 0
     assert "sample" in cb and f"{cb['cores']} of {cb['host_threads']} host threads" in cb["cores_note"]
+    assert cb["repeats"] >= 5 and cb["spread_min_max"][0] <= cb["value"] <= cb["spread_min_max"][1] and str(cb["cores"]) + ":" in cb["thread_probe_traj_per_s"]
     assert np.allclose(bench.save_times(), ts) and bench.oracle_problem().M == 101

@@ -1,0 +1,63 @@
+"""bench.py's launch logic on CPU: `python bench.py --gpus 2` with no torchrun environment must start two ranks
+itself and print ONE line with n_gpus = 2; it must refuse — not shrink — when the devices are not there; a native-communicator
+bootstrap that fails, hangs or fails its probe on one rank must end in the torch.distributed carrier on every rank.
+The engine is tests/bench_stub.py (HIPADJ_BENCH_STUB=1, gloo): no kernel runs and the line says so."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra, timeout=300):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _lines(stdout):
+    return [json.loads(ln) for ln in stdout.splitlines() if ln.startswith("{")]
+
+
+def _expected_dp(ntraj):
+    sys.path.insert(0, ROOT)
+    import bench
+    u0, _ = bench.inputs(ntraj)
+    return u0.sum(axis=0)
+
+
+@pytest.mark.parametrize("comm,carrier,ranks", [("ok", "rccl in-stream (hipadj_comm)", 2), ("fail", "torch.distributed nccl, async", 2),
+                                                ("hang", "torch.distributed nccl, async", 2), ("badcheck", "torch.distributed nccl, async", 2)])
+def test_gpus_2_without_torchrun_starts_two_ranks_and_prints_one_line(comm, carrier, ranks):
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--ntraj", "101", "--no-cpu-baseline"],
+             {"HIPADJ_BENCH_STUB": "1", "HIPADJ_BENCH_STUB_COMM": comm, "HIPADJ_COMM_TIMEOUT": "5"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["metric"] == "STUB_no_kernel_ran" and "STUB" in ln["data"]
+    assert ln["config"]["dp_allreduce"] == carrier and ln["config"]["rccl_ranks"] == ranks
+    assert (ln["config"]["native_allreduce_fallback"] is None) == (comm == "ok")
+    assert ln["config"]["ntraj_per_gpu"] == 51 and ln["config"]["ntraj_total"] == 101          # strong scaling: the ensemble is sharded
+    np.testing.assert_allclose(ln["stub_dp"], _expected_dp(101), rtol=1e-13)                   # the all-reduce spanned both shards
+    assert ln["weak_scaling"]["ntraj_total"] == 202
+
+
+def test_gpus_n_refuses_instead_of_running_fewer():
+    # no stub: the real path on a machine without (enough) HIP devices — must exit non-zero before any line is printed
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], {})
+    assert r.returncode != 0 and not _lines(r.stdout)
+    assert "HIP device" in r.stderr
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"HIPADJ_BENCH_STUB": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not _lines(r.stdout)
+    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "1"], {"HIPADJ_BENCH_STUB": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not _lines(r.stdout)
