@@ -162,7 +162,7 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
@@ -243,6 +243,32 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
         if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
+        if (!P.user) {   // event knots of the forward solve (k_forward_ev): save times, checkpoints, the knot in front of a shortened last step
+            if (const char* e = std::getenv("HIPADJ_FWD_EV")) h->fwd_ev = std::atoi(e);
+            std::vector<int> ek, es, ec;
+            forward_events(P, cfg->dt, ek, es, ec);
+            h->nfev = (int)ek.size();
+            const size_t ne = ek.size() + 1;   // never a zero-sized allocation
+            ek.push_back(0); es.push_back(-1); ec.push_back(-1);
+            A(dev_alloc(h, &h->d_fev_knot, ne)); A(dev_alloc(h, &h->d_fev_save, ne)); A(dev_alloc(h, &h->d_fev_ckpt, ne));
+            if (rc == HIPADJ_OK && !(HT(hipMemcpy(h->d_fev_knot, ek.data(), sizeof(int) * ne, hipMemcpyHostToDevice), "memcpy") &&
+                                     HT(hipMemcpy(h->d_fev_save, es.data(), sizeof(int) * ne, hipMemcpyHostToDevice), "memcpy") &&
+                                     HT(hipMemcpy(h->d_fev_ckpt, ec.data(), sizeof(int) * ne, hipMemcpyHostToDevice), "memcpy"))) rc = HIPADJ_ERR_HIP;
+        }
+        {   // the composition tree of the one-launch reverse pass (hipadj_fused.hpp): map slots per (block, node) and arrival counters
+            if (const char* e = std::getenv("HIPADJ_FUSED")) h->fused = std::atoi(e);
+            if (!(cfg->alg == HIPADJ_ALG_INTERPOLATING && !P.ip_ckpt && !P.offgrid && !P.user)) h->fused = 0;   // kernels with a fused tail so far
+            int radix = 4;
+            if (const char* e = std::getenv("HIPADJ_TREE_RADIX")) radix = std::atoi(e) == 8 ? 8 : 4;
+            long slots = 0, ctrs = 0;
+            tree_plan_shape(h->nseg, radix, (long)(Np / 64), h->tp, &slots, &ctrs);
+            h->tcnt_n = ctrs;
+            if (h->fused) {
+                A(dev_alloc(h, &h->d_tbuf, (size_t)slots * (size_t)((1 + n) * (n + np)) * 64));
+                A(dev_alloc(h, &h->d_tcnt, (size_t)ctrs));
+                if (rc == HIPADJ_OK && !HT(hipMemset(h->d_tcnt, 0, sizeof(unsigned) * (size_t)ctrs), "memset")) rc = HIPADJ_ERR_HIP;
+            }
+        }
         if (P.ip_ckpt && P.ck_longest > HIPADJ_CKPT_KMAX) {   // one re-solve tile [longest + 1][n][64] per (wave, segment) in HBM
             h->gtile_stride = (long)(P.ck_longest + 1) * n * 64;
             A(dev_alloc(h, &h->d_gtile, (size_t)h->gtile_stride * (size_t)(Np / 64) * (size_t)h->nseg));
@@ -894,6 +920,11 @@ extern "C" int hipadj_forward_dev(hipadj_handle* h, const double* d_u0, const do
     const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
     if (d_p != h->d_p) HIP_TRY(h, hipMemcpyAsync(h->d_p, d_p, pb, hipMemcpyDeviceToDevice, h->stream));
     h->p_dev_last = h->d_p;
+    if (h->d_tcnt) {   // arrival counters of the one-launch reverse pass: each is reset by its last arriver; a pass that died half-way (a faulting
+                       // user model) must not poison the next solve, so every forward solve starts from zeros (in stream order, off the reverse path)
+        HIP_TRY(h, hipMemsetAsync(h->d_tcnt, 0, sizeof(unsigned) * (size_t)h->tcnt_n, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_ticket, 0, sizeof(unsigned), h->stream));
+    }
     HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
     TRY(forward_dispatch(h, d_u0, h->d_p, d_out));
     HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));

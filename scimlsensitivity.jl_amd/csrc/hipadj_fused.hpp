@@ -1,0 +1,192 @@
+// hipadj_fused.hpp — the reverse pass as ONE launch: the time-segmented sweep kernels finish the pass themselves.
+//
+// A segment wave leaves an affine map  (lam, mu) -> (A lam + c_l, mu + B lam + c_m)  of its time segment in registers
+// (hipadj_lane.hpp, "TIME SEGMENTATION").  Until round 3 the maps went to HBM and two more kernels composed them per trajectory
+// (k_compose_finish*) and summed dp (k_reduce_final): three dependent launches, whose fixed cost — 8.5 + 4.4 us of kernels and
+// ~5 us of dispatch gaps — was 13 % of the 10^4-trajectory pass and half of a 1250-trajectory shard's.
+//
+// Here the waves of one trajectory block (64 trajectories x C segments = C waves, on C different CUs) compose their maps as a
+// TREE through HBM — composition of affine maps is associative, so any bracketing gives the sequential result up to roundoff:
+//   level 0: every wave publishes its map (write-through stores), then takes a ticket on its parent node (RADIX children);
+//   the LAST arriver of a node loads the node's children, folds them in rank order (upper segment first) and carries the node's
+//   map one level up; the wave that completes the root holds (lam(t0), mu(t0)) of its 64 trajectories: it writes du0, scans for
+//   NaN/Inf, reduces mu over its lanes and takes a ticket on the ensemble; the last block sums the per-block partials in block order.
+// The bracketing depends on (C, RADIX) only and every sum runs in a fixed order, never on arrival order: dp is bit-reproducible
+// for a given N, as before.  A pass costs ceil(log_RADIX C) + 1 hand-offs (~2.5-3 us each on a draining chip) instead of two
+// kernel boundaries + two kernels.
+//
+// Visibility across CUs / XCDs (cdna_hip_programming.md §6 Guideline 16, MI355X_MICROARCH.md "inter-workgroup visibility"):
+// payload by agent-scope relaxed atomic stores (= sc1, write-through: no release fence needed) -> every storing wave drains
+// vmcnt -> ONE lane's relaxed agent-scope fetch_add on the node's counter; the last arriver reads the children with agent-scope
+// relaxed atomic loads (sc1: served below the CU's L1, which is never refreshed by other CUs' stores).  Every hand-off here is
+// wave -> wave (64-thread workgroups), so no workgroup barrier is involved.  Counters are zeroed when the handle is created and
+// before every forward solve, and each is reset by its own last arriver.
+#pragma once
+
+#include "hipadj_lane.hpp"
+
+namespace hipadj {
+
+constexpr int HIPADJ_TREE_MAXLEV = 8;
+
+struct TreePlan {
+    int radix;                              // children per node (4: one batch of loads per level; 8: two batches, one level less from 17 segments on)
+    int nlev;                               // levels above the leaves; count[0] = C (segments), count[nlev] = 1
+    int count[HIPADJ_TREE_MAXLEV + 1];      // nodes per trajectory block on level l
+    long map_off[HIPADJ_TREE_MAXLEV + 1];   // first map slot of level l in tbuf (slots of one level: [block][node])
+    int cnt_off[HIPADJ_TREE_MAXLEV + 1];    // first arrival counter of level l (l >= 1) in cnt ([block][node])
+    double* tbuf;                           // map slots: MAPSZ * 64 doubles each, [entry][lane]
+    unsigned* cnt;
+    double* partial;                        // [blocks][NP] per-block sums of mu
+    unsigned* ticket;                       // ensemble ticket (one word)
+};
+
+// Host side: the shape of the tree for C leaves (hipadj_plan.hpp / hipadj_api.hip allocate by it).
+inline void tree_plan_shape(int C, int radix, long blocks, TreePlan& T, long* map_slots, long* counters) {
+    T.radix = radix; T.nlev = 0; T.count[0] = C; T.map_off[0] = 0; T.cnt_off[0] = 0;
+    long slots = (long)C * blocks, ctr = 0;
+    while (T.count[T.nlev] > 1) {
+        const int l = T.nlev + 1;
+        T.count[l] = (T.count[l - 1] + radix - 1) / radix;
+        T.map_off[l] = slots; T.cnt_off[l] = (int)ctr;
+        slots += (long)T.count[l] * blocks; ctr += (long)T.count[l] * blocks;
+        T.nlev = l;
+    }
+    if (map_slots) *map_slots = slots;
+    if (counters) *counters = ctr > 0 ? ctr : 1;
+}
+
+// O = L o U for segment maps stored as m[c * R + j]: column c = 0 the affine column (c_l, c_m), columns 1..N the images of the
+// basis vectors (A, B); rows j < N lambda, j >= N mu.  U acts first (the upper time segment), L second.
+//   lam: A_O = A_L A_U, c_O = A_L c_U + c_L;   mu: B_O = B_U + B_L A_U, cm_O = cm_U + B_L c_U + cm_L.
+template <int N, int NP>
+HIPADJ_HD void map_compose(const double (&U)[(1 + N) * (N + NP)], const double (&L)[(1 + N) * (N + NP)], double (&O)[(1 + N) * (N + NP)]) {
+    constexpr int R = N + NP;
+#pragma unroll
+    for (int c = 0; c <= N; ++c) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double v = c == 0 ? L[j] : 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) v += L[(k + 1) * R + j] * U[c * R + k];
+            O[c * R + j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            double v = U[c * R + N + j] + (c == 0 ? L[N + j] : 0.0);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v += L[(k + 1) * R + N + j] * U[c * R + k];
+            O[c * R + N + j] = v;
+        }
+    }
+}
+
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+
+__device__ __forceinline__ void map_store_agent(double* __restrict__ dst, double v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double map_load_agent(const double* __restrict__ src) { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one wave: ticket on `ctr`; true on every lane iff this wave is the last of `expected` arrivers (then the counter is reset).
+// The caller has issued its payload stores; they are drained here before the ticket is drawn.
+__device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, unsigned expected) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through payload stores have left the CU
+    unsigned old = 0;
+    if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if (old != expected - 1u) return false;
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next pass
+    return true;
+}
+
+// The tail of a segment wave.  m: this wave's map (NCOL = 1 + N columns; a top-segment / single-segment wave passes its vector in
+// column 0 and zeros elsewhere).  block: trajectory block (64 trajectories), rank: 0 = top segment ... C-1 = the segment at t0.
+// du0 [N_traj][N] (caller layout), dp_rows [N_traj][NP] or null, dp_sum [NP] or null (shared parameters), flag: non-finite marker.
+template <int N, int NP>
+__device__ __forceinline__ void fused_tail(double (&m)[(1 + N) * (N + NP)], const TreePlan& T, long ntraj, long blocks, long block, int rank,
+                                           double* __restrict__ du0, double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {
+    constexpr int R = N + NP, MAPSZ = (1 + N) * R;
+    const int lane = threadIdx.x & 63, RADIX = T.radix;
+    int idx = rank;
+    for (int l = 0; l < T.nlev; ++l) {
+        const int count = T.count[l], parent = idx / RADIX;
+        const int first = parent * RADIX, nchild = (count - first) < RADIX ? (count - first) : RADIX;
+        if (nchild > 1) {
+            double* __restrict__ slot = T.tbuf + (T.map_off[l] + block * count + idx) * (long)(MAPSZ * 64) + lane;
+#pragma unroll
+            for (int e = 0; e < MAPSZ; ++e) map_store_agent(slot + e * 64, m[e]);
+            if (!tree_arrive_last(T.cnt + T.cnt_off[l + 1] + block * T.count[l + 1] + parent, (unsigned)nchild)) return;
+            // last arriver of the node: fold its children, upper segment (lower rank) first
+            const double* __restrict__ src = T.tbuf + (T.map_off[l] + block * count + first) * (long)(MAPSZ * 64) + lane;
+            // children in batches of four (4 x MAPSZ doubles in flight fit the register file next to m; RADIX = 8 takes two batches)
+            for (int c0 = 0; c0 < nchild; c0 += 4) {
+                {
+                    double ch[4][MAPSZ];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int cc = c0 + c < nchild ? c0 + c : nchild - 1;    // clamped: uniform addresses, all loads issued before the first use
+#pragma unroll
+                        for (int e = 0; e < MAPSZ; ++e) ch[c][e] = map_load_agent(src + ((long)cc * MAPSZ + e) * 64);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c0 + c == 0) {
+#pragma unroll
+                            for (int e = 0; e < MAPSZ; ++e) m[e] = ch[0][e];
+                        } else if (c0 + c < nchild) {
+                            double o[MAPSZ];
+                            map_compose<N, NP>(m, ch[c], o);
+#pragma unroll
+                            for (int e = 0; e < MAPSZ; ++e) m[e] = o[e];
+                        }
+                    }
+                }
+            }
+        }
+        idx = parent;
+    }
+    // root: column 0 holds (lam(t0), mu(t0)) of the block's trajectories
+    const long i = block * 64 + lane;
+    const bool valid = i < ntraj;
+    bool bad = false;
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) { du0[i * N + j] = m[j]; bad |= !(fabs(m[j]) <= 1.79769313486231570e308); }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { bad |= !(fabs(m[N + j]) <= 1.79769313486231570e308); if (dp_rows) dp_rows[i * NP + j] = m[N + j]; }
+        if (bad) atomicOr(flag, 1);
+    }
+    if (!dp_sum) return;
+    double s[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        double v = valid ? m[N + j] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);   // fixed tree over the lanes
+        s[j] = v;
+    }
+    if (blocks == 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dp_sum[j] = s[j];
+        }
+        return;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) map_store_agent(T.partial + block * NP + j, s[j]);
+    }
+    if (!tree_arrive_last(T.ticket, (unsigned)blocks)) return;
+    // last block: lane l sums blocks l, l + 64, ... in increasing order, then the same fixed tree over the lanes
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        double v = 0.0;
+        for (long b = lane; b < blocks; b += 64) v += map_load_agent(T.partial + b * NP + j);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) dp_sum[j] = v;
+    }
+}
+
+#endif  // device code
+
+}  // namespace hipadj

@@ -78,6 +78,13 @@ struct hipadj_handle {
     const double* p_dev_last = nullptr;  // device p used by the last forward (the adjoint reuses it)
     bool have_forward = false, timing_pending_fwd = false;
     int fused_final = 0;                  // 1: dp reduced in-launch by the last-arriving workgroup (HIPADJ_FUSED_FINAL)
+    // one launch per reverse pass (hipadj_fused.hpp): composition tree + dp reduction inside the sweep kernel.  fused: 1 = on (default where a
+    // fused kernel exists), 0 = the three-launch sequence (HIPADJ_FUSED=0: A/B and fallback)
+    int fused = 1;
+    TreePlan tp{};
+    double* d_tbuf = nullptr; unsigned* d_tcnt = nullptr; long tcnt_n = 0;
+    int *d_fev_knot = nullptr, *d_fev_save = nullptr, *d_fev_ckpt = nullptr, nfev = 0;   // event knots of the forward solve (k_forward_ev)
+    int fwd_ev = 1;                       // HIPADJ_FWD_EV=0: the per-knot form k_forward (A/B)
     int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)
     double ws_bytes = 0;
     double* d_gtile = nullptr; long gtile_stride = 0; bool ck_long = false;   // checkpoint intervals longer than HIPADJ_CKPT_KMAX: re-solve tiles in HBM

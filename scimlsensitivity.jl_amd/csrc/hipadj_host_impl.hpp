@@ -8,6 +8,11 @@ template <class Mo> int forward_impl(hipadj_handle* h, const double* d_u0, const
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     dbl2* knots = h->d_knots;
     double* ck = h->d_ckpt;
+    if (h->fwd_ev && h->d_fev_knot)
+        hipLaunchKernelGGL((k_forward_ev<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, d_u0, d_p,
+                           FwdEvents{h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->nfev}, knots, ck,
+                           (d_out && h->M > 0 && !h->offgrid) ? h->d_outT : (double*)nullptr, h->d_yT);
+    else
     hipLaunchKernelGGL((k_forward<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, d_u0, d_p, knots, ck,
                        h->d_ckpt_of_knot, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, h->d_save_of_knot, h->d_yT);
     HIP_TRY(h, hipGetLastError());
@@ -143,6 +148,28 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         else if (h->ip_ckpt)
             hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
                                (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
+        else if (h->fused && h->d_tbuf && !h->wpb4) {
+            // ONE launch per reverse pass (hipadj_fused.hpp): the sweep's waves compose their segment maps as a tree through HBM, the root wave of
+            // each block writes du0 and its partial of dp, the last block sums the partials.  No k_compose_finish*, no k_reduce_final.
+            TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
+            const hipEvent_t e0 = h->timing >= 1 ? k0 : (hipEvent_t) nullptr, e1 = h->timing >= 1 ? k1 : (hipEvent_t) nullptr;
+            double* dps = h->cfg.p_shared ? d_dp : (double*)nullptr;
+            bool launched = false;
+            if constexpr (model_has_ops<Mo>::value && (LOSS >> 1) == 0) {
+                if (h->cfg.p_shared && h->nseg > 1 && !h->no_ops) {
+                    hipExtLaunchKernelGGL((k_interp_fused<Mo, 4, LOSS, true, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
+                                          (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                    launched = true;
+                }
+            }
+            if (!launched)
+                hipExtLaunchKernelGGL((k_interp_fused<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
+                                      (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+            HIP_TRY(h, hipGetLastError());
+            if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+            es.pending = h->timing >= 1; es.full = h->timing >= 2;
+            return HIPADJ_OK;
+        }
         else if (h->wpb4) {
             // 256-thread workgroups, four (wave block, segment) items each: one wave per SIMD by construction (hipadj_kernels.hpp)
             const unsigned items = waves * (unsigned)h->nseg;

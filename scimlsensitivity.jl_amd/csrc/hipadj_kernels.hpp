@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include "hipadj_lane.hpp"
+#include "hipadj_fused.hpp"
 #if !defined(__HIPCC_RTC__)
 #include "hipadj_plan.hpp"
 #endif
@@ -32,6 +33,16 @@ __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restri
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= g.N) return;
     forward_lane<Mo>(g, i, u0, p, knots, ckpt, ckpt_of_knot, outT, save_of_knot, yT);
+}
+
+// the forward solve as a tight loop between event knots (forward_lane_ev); padding lanes of the last wave repeat its last trajectory
+// (their stores hit their own padded columns), so the wave runs without an exec mask
+template <class Mo>
+__global__ void __launch_bounds__(WAVE) k_forward_ev(Geom g, const double* __restrict__ u0, const double* __restrict__ p, FwdEvents ev,
+                                                     dbl2* __restrict__ knots, double* __restrict__ ckpt, double* __restrict__ outT, double* __restrict__ yT) {
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    if (i >= g.N) return;
+    forward_lane_ev<Mo>(g, i, u0, p, ev, knots, ckpt, outT, yT);
 }
 
 // segbuf layout: [segment][column][N+NP][Npad]; the top segment only fills column 0.
@@ -84,6 +95,43 @@ __global__ void HIPADJ_KINTERP_ATTR __launch_bounds__(WAVE * WPB) k_interp(Geom 
             for (int j = 0; j < NP; ++j) dst[((long)c * R + N + j) * g.Npad] = mu[c][j];
         }
     }
+}
+
+// The same sweep as ONE launch per reverse pass: every wave hands its segment map to the composition tree of hipadj_fused.hpp
+// instead of a segment buffer for k_compose_finish* / k_reduce_final.  Grid (wave blocks, segments), 64-thread workgroups; lanes
+// beyond the ensemble (the padding of the last block) run on the padded tiles and are masked where results leave the wave.
+template <class Mo, int PF, int LOSS, bool SEG = true, bool PSH = false>
+__global__ void HIPADJ_KINTERP_ATTR __launch_bounds__(WAVE) k_interp_fused(Geom g, SegPlan sp, TreePlan tp, const double* __restrict__ p,
+                                                       const dbl2* __restrict__ knots, const double* __restrict__ cotT,
+                                                       const int* __restrict__ save_of_knot, double* __restrict__ du0,
+                                                       double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    const long i_raw = (long)blockIdx.x * WAVE + threadIdx.x;
+    const long i = i_raw < g.N ? i_raw : g.N - 1;                    // padding lanes of the last block repeat its last trajectory
+    const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;      // rank 0 = the top (longest, 1-column) segment: dispatched first
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    double m[NC * R];
+    if (!SEG || rank == 0) {
+        double lam[1][N], mu[1][NP];
+        interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+#pragma unroll
+        for (int e = 0; e < NC * R; ++e) m[e] = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) m[j] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) m[N + j] = mu[0][j];
+    } else if constexpr (SEG) {
+        double lam[NC][N], mu[NC][NP];
+        interp_lane<Mo, NC, PF, LOSS, 0, PSH>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) m[c * R + j] = lam[c][j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) m[c * R + N + j] = mu[c][j];
+        }
+    }
+    fused_tail<N, NP>(m, tp, g.N, (long)gridDim.x, (long)blockIdx.x, rank, du0, dp_rows, dp_sum, flag);
 }
 
 // checkpointing=true variants: checkpoint tiles in HBM, interval re-solve tile in LDS ([step][component][lane])

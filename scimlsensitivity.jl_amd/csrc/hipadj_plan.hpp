@@ -46,6 +46,17 @@ struct Plan {
     int rs_save_at_start = -1;
 };
 
+// Event knots of the fixed-step forward solve (forward_lane_ev, hipadj_lane.hpp): every knot where something besides the plain step
+// happens — a save time (out = sol(ts) on the grid), a checkpoint, and knot S - 1 when the last step is shortened (span not a multiple of dt).
+inline void forward_events(const Plan& P, double dt, std::vector<int>& knot, std::vector<int>& save, std::vector<int>& ckpt) {
+    knot.clear(); save.clear(); ckpt.clear();
+    const bool ragged = P.h_last != dt;
+    for (int k = 0; k <= P.S; ++k) {
+        const int sv = k < (int)P.save_of_knot.size() ? P.save_of_knot[k] : -1, ck = k < (int)P.ckpt_of_knot.size() ? P.ckpt_of_knot[k] : -1;
+        if (sv >= 0 || ck >= 0 || (ragged && k == P.S - 1)) { knot.push_back(k); save.push_back(sv); ckpt.push_back(ck); }
+    }
+}
+
 // The reverse solve of the reference on a fixed step with tstops at the loss times [upstream-recall, restated from the oracle's
 // `integrate`]: dt = min(|dt|, |tstop - t|), a step whose remainder would be a roundoff sliver lands on the tstop, t snaps onto
 // the tstop within 100 eps, and after a stop the solver continues with the full dt.  save[q] = the loss time that fires at the

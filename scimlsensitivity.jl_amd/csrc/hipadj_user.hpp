@@ -418,13 +418,14 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
     }
     RtcApi& A = rtc_api();
     if (!A.lib || !A.err.empty()) { err = A.err.empty() ? "hiprtc unavailable" : A.err; return HIPADJ_ERR_UNSUPPORTED; }
-    constexpr int NH = 5;
-    const char* hnames[NH] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp", "hipadj_dual.hpp"};
+    constexpr int NH = 6;
+    const char* hnames[NH] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp", "hipadj_dual.hpp", "hipadj_fused.hpp"};
     std::string htext[NH];
     const std::string dir = user_csrc_dir();
     for (int i = 0; i < NH; ++i)
         if (!user_read_file(dir + "/" + hnames[i], htext[i])) { err = "cannot read kernel header " + dir + "/" + hnames[i] + " (set HIPADJ_CSRC_DIR)"; return HIPADJ_ERR_UNSUPPORTED; }
-    const char* hptr[NH] = {htext[0].c_str(), htext[1].c_str(), htext[2].c_str(), htext[3].c_str(), htext[4].c_str()};
+    const char* hptr[NH];
+    for (int i = 0; i < NH; ++i) hptr[i] = htext[i].c_str();
     if (const char* e = std::getenv("HIPADJ_USER_COLS")) if (e[0] == '0') src.cols = false;   // A/B hook: the per-column form of the segment lanes
     std::string tu = user_model_struct(src);
     // attempt 0: -O3.  If the ISA check (user_isa_check) flags the code object: attempt 1 at -O1 — a different schedule and
