@@ -53,14 +53,36 @@ def oracle_problem(alg="INTERPOLATING", **kw):
     return O.Problem("LORENZ", alg=alg, stepper="RK4", t0=0.0, t1=T_FINAL, dt=DT, save_times=save_times(), loss="LSQ_SHIFT", loss_shift=LOSS_SHIFT, **kw)
 
 
+def host_cpu_budget():
+    """CPUs this process can really use: the smallest of the hardware threads, the scheduler affinity mask and the cgroup CPU quota
+    (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1).  os.cpu_count() alone reports the whole host inside a container."""
+    n, src = os.cpu_count() or 1, "os.cpu_count"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, src = a, "sched_getaffinity"
+    except Exception:
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            q, per = parse(open(path).read())
+            if q not in ("max", "-1") and float(per) > 0:
+                c = max(1, int(float(q) / float(per) + 0.5))
+                if c < n:
+                    n, src = c, path
+        except Exception:
+            pass
+    return n, src
+
+
 def cpu_baseline(u0, p, ts, budget_s=20.0):
     """The oracle (CPU restatement of the reference algorithm — NOT Julia) timed on the workload's own trajectories (reverse passes
     only, like `value`), OpenMP over trajectories.  Every figure is the median of >= 5 repeats of the SAME call (all trajectories,
     rounded down to a multiple of the thread count) and carries its spread; the thread count is the one at which that median is
     highest, and the probe that chose it is the same measurement, so probe and reported value agree by construction."""
-    os.environ.setdefault("OMP_PROC_BIND", "close")    # read by libgomp when the oracle library is first loaded: neighbouring cores, no migration
-    os.environ.setdefault("OMP_PLACES", "cores")
     cores = os.cpu_count() or 1
+    budget, budget_src = host_cpu_budget()
     pr = oracle_problem()
 
     def sample(nt, min_reps, max_s):
@@ -74,7 +96,13 @@ def cpu_baseline(u0, p, ts, budget_s=20.0):
         return n, np.array(rates), rev
 
     probe = {}
-    for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}, reverse=True):
+    # thread counts around what this process may really use (the box reports 256 hardware threads; the container's CPU quota was 16 of them in
+    # round 3's scaling study — beyond the quota the threads are throttled and the rate collapses: profiles/r3_cpu_scaling_study.log)
+    ladder = {budget, max(1, budget // 2)}
+    c = cores
+    while c >= 4:                       # the quota is not always visible from inside (no cpu.max): the ladder finds the knee anyway
+        ladder.add(c); c //= 2
+    for nt in sorted(ladder, reverse=True):
         _, rates, _ = sample(nt, 5, 0.0)
         probe[nt] = float(np.median(rates))
     cores_used = max(probe, key=probe.get)
@@ -85,7 +113,8 @@ def cpu_baseline(u0, p, ts, budget_s=20.0):
     pr.adjoint_ensemble(u0[:n1], p, nthreads=1, want_out=False)
     r1 = np.array([n1 / pr.adjoint_ensemble(u0[:n1], p, nthreads=1, want_out=False)[3]["reverse_s"] for _ in range(5)])
     return dict(value=med, unit="trajectories/s", cores=cores_used, host_threads=cores,
-                cores_note=f"{cores_used} of {cores} host threads (the thread count at which the oracle's median rate is highest)",
+                cores_note=f"{cores_used} of {cores} host threads (the thread count at which the oracle's median rate is highest); usable CPUs of this process: {budget} ({budget_src})",
+                host_cpu_budget=budget,
                 repeats=int(len(rates)), spread_min_max=[float(rates.min()), float(rates.max())],
                 spread_rel=float((rates.max() - rates.min()) / med),
                 thread_probe_traj_per_s=" ".join(f"{k}:{v:.3g}" for k, v in sorted(probe.items(), reverse=True)),
@@ -94,8 +123,7 @@ def cpu_baseline(u0, p, ts, budget_s=20.0):
                 single_thread_ns_per_vjp_step=1e9 / (float(np.median(r1)) * 1000 * 4),
                 parallel_efficiency=med / (cores_used * float(np.median(r1))),
                 sample=f"{n} of the workload's trajectories x {len(rates)} repeats, reverse passes only, median ({rev:.2f} s on {cores_used} threads = "
-                       f"{rev * cores_used:.0f} core-seconds), C oracle, OpenMP over trajectories (static schedule, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, "
-                       f"OMP_PLACES={os.environ.get('OMP_PLACES')}), gcc -O2 -ffp-contract=off",
+                       f"{rev * cores_used:.0f} core-seconds), C oracle, OpenMP over trajectories (static schedule, unbound threads), gcc -O2 -ffp-contract=off",
                 ns_per_vjp_step=1e9 / (med * 1000 * 4))
 
 
@@ -138,7 +166,7 @@ class Runner:
             # on the handle's OWN stream, before it is moved to torch's: a collective that hangs then blocks a stream nobody else uses
             native = self.native = self._try_native(sa, torch, dist, dev, world, make_engine)
         self.eng.use_torch_stream()
-        self.eng.set_timing(1)   # HIP events around the dominant kernel only (on its dispatch packet); the whole-call bracket costs ~8 us per step
+        self.eng.set_timing(args.timing)   # 1: HIP events around the dominant kernel only (on its dispatch packet); the whole-call bracket (2) costs ~8 us per step
         self.u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
         self.p = torch.tensor(p_np, device=dev, dtype=torch.float64)
         self.du0 = torch.empty((n_local, 3), device=dev, dtype=torch.float64)
@@ -351,6 +379,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--segments", type=int, default=0, help="time segments per trajectory (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing", type=int, default=1, help="library event level inside the timed loop: 1 = events on the dominant kernel's dispatch packet (default), 0 = none (A/B of their cost)")
     ap.add_argument("--no-extras", action="store_true", help="skip shard_sizes / other_configs (N = 1) and the second scaling figure (N > 1)")
     ap.add_argument("--torch-allreduce", action="store_true",
                     help="N > 1: all-reduce dL/dp with torch.distributed (async, own stream) instead of in-stream RCCL inside the C ABI (hipadj_comm_*)")

@@ -263,8 +263,12 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             long slots = 0, ctrs = 0;
             tree_plan_shape(h->nseg, radix, (long)(Np / 64), h->tp, &slots, &ctrs);
             h->tcnt_n = ctrs;
+            if (h->tp.nlev == 0) slots = 1;    // a single segment: the root wave finishes alone, no slot is ever written
+            const size_t slot_doubles = (size_t)(((1 + n) * (n + np) + 1) / 2) * 128;   // rows of 64 x 16 bytes
+            if ((double)slots * (double)slot_doubles * 8.0 >= 2147483648.0) h->fused = 0;        // beyond the buffer descriptor's range
+            h->tp.tbuf_bytes = (long)(slots * slot_doubles * 8);
             if (h->fused) {
-                A(dev_alloc(h, &h->d_tbuf, (size_t)slots * (size_t)((1 + n) * (n + np)) * 64));
+                A(dev_alloc(h, &h->d_tbuf, (size_t)slots * slot_doubles));
                 A(dev_alloc(h, &h->d_tcnt, (size_t)ctrs));
                 if (rc == HIPADJ_OK && !HT(hipMemset(h->d_tcnt, 0, sizeof(unsigned) * (size_t)ctrs), "memset")) rc = HIPADJ_ERR_HIP;
             }

@@ -16,9 +16,10 @@
 // kernel boundaries + two kernels.
 //
 // Visibility across CUs / XCDs (cdna_hip_programming.md §6 Guideline 16, MI355X_MICROARCH.md "inter-workgroup visibility"):
-// payload by agent-scope relaxed atomic stores (= sc1, write-through: no release fence needed) -> every storing wave drains
-// vmcnt -> ONE lane's relaxed agent-scope fetch_add on the node's counter; the last arriver reads the children with agent-scope
-// relaxed atomic loads (sc1: served below the CU's L1, which is never refreshed by other CUs' stores).  Every hand-off here is
+// payload by 16-byte sc1 (write-through) buffer stores — no release fence needed — -> the storing wave drains vmcnt -> ONE lane's
+// relaxed agent-scope fetch_add on the node's counter; the last arriver reads the children with 16-byte sc1 buffer loads (served
+// below the CU's L1, which is never refreshed by other CUs' stores).  8-byte agent-scope atomics did the same at 2.7x the fabric
+// writes per byte (first form of this file: +6.5 us of kernel time at 10^4 trajectories, +10-20 us on the shards).  Every hand-off here is
 // wave -> wave (64-thread workgroups), so no workgroup barrier is involved.  Counters are zeroed when the handle is created and
 // before every forward solve, and each is reset by its own last arriver.
 #pragma once
@@ -35,7 +36,8 @@ struct TreePlan {
     int count[HIPADJ_TREE_MAXLEV + 1];      // nodes per trajectory block on level l
     long map_off[HIPADJ_TREE_MAXLEV + 1];   // first map slot of level l in tbuf (slots of one level: [block][node])
     int cnt_off[HIPADJ_TREE_MAXLEV + 1];    // first arrival counter of level l (l >= 1) in cnt ([block][node])
-    double* tbuf;                           // map slots: MAPSZ * 64 doubles each, [entry][lane]
+    double* tbuf;                           // map slots: ceil(MAPSZ / 2) rows of 64 x 16 bytes each (entries 2r, 2r + 1 of lane l in row r)
+    long tbuf_bytes;                        // < 2^31 (buffer descriptor range; larger trees fall back to the three-launch sequence)
     unsigned* cnt;
     double* partial;                        // [blocks][NP] per-block sums of mu
     unsigned* ticket;                       // ensemble ticket (one word)
@@ -86,6 +88,20 @@ HIPADJ_HD void map_compose(const double (&U)[(1 + N) * (N + NP)], const double (
 __device__ __forceinline__ void map_store_agent(double* __restrict__ dst, double v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double map_load_agent(const double* __restrict__ src) { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// 16-byte sc1 accesses through a buffer descriptor over the whole slot array (compiler-tracked vmcnt, unlike inline asm): voffset = the
+// lane's 16 bytes inside a 1 KB row, soffset = the row (wave-uniform).  aux 16 = sc1.
+typedef unsigned int hipadj_u4 __attribute__((ext_vector_type(4)));
+template <class RS>
+__device__ __forceinline__ void pair_store_sc1(RS rs, int voff, int soff, double a, double b) {
+    hipadj_u4 v; v.x = __double2loint(a); v.y = __double2hiint(a); v.z = __double2loint(b); v.w = __double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 16);
+}
+template <class RS>
+__device__ __forceinline__ void pair_load_sc1(RS rs, int voff, int soff, double& a, double& b) {
+    const hipadj_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16);
+    a = __hiloint2double((int)v.y, (int)v.x); b = __hiloint2double((int)v.w, (int)v.z);
+}
+
 // one wave: ticket on `ctr`; true on every lane iff this wave is the last of `expected` arrivers (then the counter is reset).
 // The caller has issued its payload stores; they are drained here before the ticket is drawn.
 __device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, unsigned expected) {
@@ -104,40 +120,42 @@ __device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, uns
 template <int N, int NP>
 __device__ __forceinline__ void fused_tail(double (&m)[(1 + N) * (N + NP)], const TreePlan& T, long ntraj, long blocks, long block, int rank,
                                            double* __restrict__ du0, double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {
-    constexpr int R = N + NP, MAPSZ = (1 + N) * R;
-    const int lane = threadIdx.x & 63, RADIX = T.radix;
+    constexpr int R = N + NP, MAPSZ = (1 + N) * R, MAPP = (MAPSZ + 1) / 2;      // a slot: MAPP rows of 64 x 16 bytes (entries 2r, 2r + 1 of the lane)
+    constexpr int SLOTB = MAPP * 1024;
+    const int lane = threadIdx.x & 63, RADIX = T.radix, voff = lane * 16;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(T.tbuf, 0, (int)T.tbuf_bytes, 0x00020000);
     int idx = rank;
     for (int l = 0; l < T.nlev; ++l) {
         const int count = T.count[l], parent = idx / RADIX;
         const int first = parent * RADIX, nchild = (count - first) < RADIX ? (count - first) : RADIX;
         if (nchild > 1) {
-            double* __restrict__ slot = T.tbuf + (T.map_off[l] + block * count + idx) * (long)(MAPSZ * 64) + lane;
+            const int slot0 = (int)(T.map_off[l] + block * count) + first;       // the node's first child
+            const int so = (slot0 + (idx - first)) * SLOTB;
 #pragma unroll
-            for (int e = 0; e < MAPSZ; ++e) map_store_agent(slot + e * 64, m[e]);
+            for (int r = 0; r < MAPP; ++r) pair_store_sc1(rs, voff, so + r * 1024, m[2 * r], 2 * r + 1 < MAPSZ ? m[2 * r + 1] : 0.0);
             if (!tree_arrive_last(T.cnt + T.cnt_off[l + 1] + block * T.count[l + 1] + parent, (unsigned)nchild)) return;
-            // last arriver of the node: fold its children, upper segment (lower rank) first
-            const double* __restrict__ src = T.tbuf + (T.map_off[l] + block * count + first) * (long)(MAPSZ * 64) + lane;
-            // children in batches of four (4 x MAPSZ doubles in flight fit the register file next to m; RADIX = 8 takes two batches)
+            // last arriver of the node: fold its children, upper segment (lower rank) first; children in batches of four
+            // (4 x MAPSZ doubles in flight fit the register file next to m; RADIX = 8 takes two batches)
             for (int c0 = 0; c0 < nchild; c0 += 4) {
-                {
-                    double ch[4][MAPSZ];
+                double ch[4][2 * MAPP];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int cc = c0 + c < nchild ? c0 + c : nchild - 1;    // clamped: uniform addresses, all loads issued before the first use
+                for (int c = 0; c < 4; ++c) {
+                    const int cc = c0 + c < nchild ? c0 + c : nchild - 1;        // clamped: uniform addresses, all loads issued before the first use
 #pragma unroll
-                        for (int e = 0; e < MAPSZ; ++e) ch[c][e] = map_load_agent(src + ((long)cc * MAPSZ + e) * 64);
-                    }
+                    for (int r = 0; r < MAPP; ++r) pair_load_sc1(rs, voff, (slot0 + cc) * SLOTB + r * 1024, ch[c][2 * r], ch[c][2 * r + 1]);
+                }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (c0 + c == 0) {
+                for (int c = 0; c < 4; ++c) {
+                    if (c0 + c == 0) {
 #pragma unroll
-                            for (int e = 0; e < MAPSZ; ++e) m[e] = ch[0][e];
-                        } else if (c0 + c < nchild) {
-                            double o[MAPSZ];
-                            map_compose<N, NP>(m, ch[c], o);
+                        for (int e = 0; e < MAPSZ; ++e) m[e] = ch[0][e];
+                    } else if (c0 + c < nchild) {
+                        double lo_[MAPSZ], o[MAPSZ];
 #pragma unroll
-                            for (int e = 0; e < MAPSZ; ++e) m[e] = o[e];
-                        }
+                        for (int e = 0; e < MAPSZ; ++e) lo_[e] = ch[c][e];
+                        map_compose<N, NP>(m, lo_, o);
+#pragma unroll
+                        for (int e = 0; e < MAPSZ; ++e) m[e] = o[e];
                     }
                 }
             }

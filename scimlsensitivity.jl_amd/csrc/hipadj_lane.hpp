@@ -155,6 +155,7 @@ HIPADJ_HD void forward_lane_ev(const Geom& g, long i, const double* __restrict__
     for (int e = 0; e <= ev.nev; ++e) {
         const int kn = e < ev.nev ? ev.knot[e] : g.S;            // run of plain steps up to the next event (or to the end)
         const double dt = (k == g.S - 1) ? g.h_last : g.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+#pragma unroll 2
         for (; k < kn; ++k) {
             const double t = g.t0 + k * g.dt;
             double k2[N], k3[N], k4[N], us[N];

@@ -1,0 +1,76 @@
+"""The one-launch reverse pass (csrc/hipadj_fused.hpp) against the three-launch sequence it replaces (`-m gpu`).
+
+The composition tree hands segment maps from wave to wave through HBM inside one launch (write-through stores, arrival counters,
+sc1 loads) and reuses the same slots and counters every pass.  A stale cache line or a counter left over from the previous pass
+would not show in a test that repeats one computation — the stale data would be the right data — so every round here changes
+the inputs (initial states, parameters, cotangents) and the same handle runs many rounds back to back.  The reference engine is
+the same library with HIPADJ_FUSED=0 (k_interp + k_compose_finish* + k_reduce_final: round 2's path, oracle-checked at size)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from test_gpu_parity import RTOL, rel, lorenz_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(sa, monkeypatch, N, ts, T, dt, loss_kind, p_shared=True, segments=0, radix=None):
+    kw = dict(save_times=ts, loss_kind=loss_kind, loss_shift=2.0, p_shared=p_shared, time_segments=segments)
+    monkeypatch.setenv("HIPADJ_FUSED", "0")
+    ref = sa.Engine("lorenz", "interpolating", N, 0.0, T, dt, **kw)
+    monkeypatch.setenv("HIPADJ_FUSED", "1")
+    if radix:
+        monkeypatch.setenv("HIPADJ_TREE_RADIX", str(radix))
+    fus = sa.Engine("lorenz", "interpolating", N, 0.0, T, dt, **kw)
+    monkeypatch.delenv("HIPADJ_FUSED")
+    monkeypatch.delenv("HIPADJ_TREE_RADIX", raising=False)
+    return ref, fus
+
+
+@pytest.mark.parametrize("N,radix", [(1250, 4), (1250, 8), (10000, 4), (777, 4), (64, 4), (65, 4)])
+def test_fused_pass_equals_three_launch_sequence_on_changing_data(sa, monkeypatch, N, radix):
+    T, dt = 10.0, 0.01
+    ts = np.linspace(0.0, T, 101)
+    ref, fus = _engines(sa, monkeypatch, N, ts, T, dt, loss_kind=0, radix=radix)
+    assert fus.stats()["time_segments"] == ref.stats()["time_segments"] > 1
+    rng = np.random.default_rng(N)
+    u0, p = lorenz_inputs(N)
+    for rnd in range(6):
+        u0r = u0 + 0.01 * rng.standard_normal(u0.shape)
+        pr = p * (1.0 + 0.01 * rng.standard_normal(3))
+        ref.forward(u0r, pr, want_out=False); fus.forward(u0r, pr, want_out=False)
+        for rep in range(4):          # several reverse passes per forward solution, new cotangents each time: slots and counters are reused immediately
+            delta = rng.standard_normal((N, len(ts), 3)) * (1.0 + rep)
+            a, b = ref.adjoint(delta), fus.adjoint(delta)
+            assert rel(b[0], a[0]) < 1e-11, (rnd, rep)
+            assert np.max(np.abs(b[1] - a[1]) / np.abs(a[1])) < 1e-10, (rnd, rep)
+    # the same inputs twice: bit-for-bit (fixed bracketing, fixed summation order)
+    delta = rng.standard_normal((N, len(ts), 3))
+    a, b = fus.adjoint(delta), fus.adjoint(delta)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    ref.close(); fus.close()
+
+
+def test_fused_pass_with_per_trajectory_parameters_and_nonfinite_flag(sa, monkeypatch):
+    """p_shared = 0: dp rows per trajectory leave the root wave directly (no ensemble ticket); a NaN in one trajectory is reported
+    (HIPADJ_ERR_NONFINITE, the reference's retcode check) by the fused tail like by k_compose_finish."""
+    N, T, dt = 300, 4.0, 0.01
+    ts = np.linspace(0.0, T, 41)
+    ref, fus = _engines(sa, monkeypatch, N, ts, T, dt, loss_kind=1, p_shared=False, segments=7)
+    u0, p = lorenz_inputs(N)
+    P = np.tile(p, (N, 1)) * (1.0 + 0.02 * np.random.default_rng(1).standard_normal((N, 3)))
+    ref.forward(u0, P, want_out=False); fus.forward(u0, P, want_out=False)
+    a, b = ref.adjoint(None), fus.adjoint(None)
+    assert rel(b[0], a[0]) < 1e-11 and rel(b[1], a[1]) < 1e-11 and b[1].shape == (N, 3)
+    orc = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = orc.adjoint_ensemble(u0, P, want_out=False)
+    assert rel(b[0], rdu0) < RTOL and rel(b[1], rdp) < RTOL
+    bad = u0.copy(); bad[17, 0] = np.nan
+    fus.forward(bad, P, want_out=False)
+    with pytest.raises(sa.HipadjError) as e:
+        fus.adjoint(None)
+    assert e.value.status == -4
+    fus.forward(u0, P, want_out=False)        # the handle recovers: counters are zeroed by the next forward solve
+    c = fus.adjoint(None)
+    assert np.array_equal(c[0], b[0]) and np.array_equal(c[1], b[1])
+    ref.close(); fus.close()
