@@ -166,7 +166,6 @@ class Runner:
             # on the handle's OWN stream, before it is moved to torch's: a collective that hangs then blocks a stream nobody else uses
             native = self.native = self._try_native(sa, torch, dist, dev, world, make_engine)
         self.eng.use_torch_stream()
-        self.eng.set_timing(args.timing)   # 1: HIP events around the dominant kernel only (on its dispatch packet); the whole-call bracket (2) costs ~8 us per step
         self.u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
         self.p = torch.tensor(p_np, device=dev, dtype=torch.float64)
         self.du0 = torch.empty((n_local, 3), device=dev, dtype=torch.float64)
@@ -237,19 +236,27 @@ class Runner:
             self.pending = None
 
     def timed(self, steps, warmup):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides (the driver's contract).  The library records NO per-kernel events
+        in here (a dispatch-packet event pair costs 5-6 us per launch on the one-launch pass: profiles/r3_visit2_fused_16B_timing_ab.log); one HIP
+        event pair on the launch stream brackets the whole region instead -> self.region_ms."""
         torch, dist = self.torch, self.dist
+        self.eng.set_timing(0)
         for _ in range(warmup):
             self.step()
         self.drain()
         self.sync()
         self.eng.synchronize()
-        st0 = self.eng.stats()
+        ev = None if STUB else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         if self.world > 1:
             dist.barrier()
         self.sync()
         t0 = time.perf_counter()
+        if ev:
+            ev[0].record()
         for _ in range(steps):
             self.step()
+        if ev:
+            ev[1].record()
         self.drain()
         self.sync()
         if self.world > 1:
@@ -257,12 +264,28 @@ class Runner:
         self.sync()
         elapsed = time.perf_counter() - t0
         self.eng.synchronize()
-        st1 = self.eng.stats()
+        self.region_ms = ev[0].elapsed_time(ev[1]) if ev else elapsed * 1e3
         if self.world > 1:
             tt = torch.tensor([elapsed], device=self.u0.device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return elapsed, st0, st1
+        return elapsed
+
+    def profiled(self, steps):
+        """The same step with the library's event pair on the dominant kernel's dispatch packet (what rocprofv3 reports as the kernel's
+        duration), back to back like the timed region: (average kernel ms, stats)."""
+        self.eng.set_timing(1)
+        for _ in range(3):
+            self.step()
+        self.drain(); self.sync(); self.eng.synchronize()
+        st0 = self.eng.stats()
+        for _ in range(steps):
+            self.step()
+        self.drain(); self.sync(); self.eng.synchronize()
+        st1 = self.eng.stats()
+        self.eng.set_timing(0)
+        calls = max(st1["adjoint_calls"] - st0["adjoint_calls"], 1)
+        return (st1["adjoint_main_kernel_ms_total"] - st0["adjoint_main_kernel_ms_total"]) / calls, st1
 
     def last_dp(self):
         return self.dps[(self.it - 1) & 1]
@@ -379,7 +402,6 @@ def main():
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--segments", type=int, default=0, help="time segments per trajectory (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--timing", type=int, default=1, help="library event level inside the timed loop: 1 = events on the dominant kernel's dispatch packet (default), 0 = none (A/B of their cost)")
     ap.add_argument("--no-extras", action="store_true", help="skip shard_sizes / other_configs (N = 1) and the second scaling figure (N > 1)")
     ap.add_argument("--torch-allreduce", action="store_true",
                     help="N > 1: all-reduce dL/dp with torch.distributed (async, own stream) instead of in-stream RCCL inside the C ABI (hipadj_comm_*)")
@@ -424,19 +446,19 @@ def main():
         u0_all, p_np = inputs(n_total)
         lo, hi = sa.shard_range(n_total, rank, world)
         r = Runner(sa, torch, dist, args, hi - lo, u0_all[lo:hi], p_np, local_rank, world, native)
-        elapsed, st0, st1 = r.timed(steps, warmup)
-        return r, n_total, u0_all, p_np, (lo, hi), elapsed, st0, st1
+        elapsed = r.timed(steps, warmup)
+        k_ms, st1 = r.profiled(max(10, min(steps, 50)))
+        return r, n_total, u0_all, p_np, (lo, hi), elapsed, k_ms, st1
 
     strong = world > 1 and not args.weak
-    r, n_total, u0_all, p_np, (lo, hi), elapsed, st0, st1 = measure(strong, args.steps, args.warmup)
+    r, n_total, u0_all, p_np, (lo, hi), elapsed, k_ms, st1 = measure(strong, args.steps, args.warmup)
     res = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total / (elapsed / args.steps)
         fwd_ms = st1["forward_ms_last"]
-        # dominant kernel (k_interp): HIP events attached by the library to the kernel's dispatch packet on the launch stream, every launch
-        k_calls = st1["adjoint_calls"] - st0["adjoint_calls"]
-        k_ms = (st1["adjoint_main_kernel_ms_total"] - st0["adjoint_main_kernel_ms_total"]) / max(k_calls, 1)
+        # dominant kernel: HIP events attached by the library to the kernel's dispatch packet on the launch stream (r.profiled: the same step,
+        # back to back, right after the timed region); the timed region itself is bracketed by ONE event pair on that stream (region_ms)
         alg_bytes = st1["adjoint_algorithmic_bytes"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = None, None
@@ -464,10 +486,15 @@ def main():
             "ns_per_vjp_step": elapsed / args.steps / (n_total * S * 4.0) * 1e9,
             "forward_solve_ms": fwd_ms,
             "forward_plus_reverse_ms": (fwd_ms + ms_per_step) if fwd_ms is not None else None,
-            "roofline": {"bound": "hbm", "kernel": "k_interp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_interp_fused" if st1.get("launches_per_pass", 3) == 1 else "k_interp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
-                         "whole_pass_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "kernel_ms_note": "average launch duration from HIP events on the kernel's dispatch packet (= rocprofv3's duration), same step back to back right after the timed region; "
+                                           "the one-launch kernel contains the composition tree and the dp reduction",
+                         "launches_per_pass": st1.get("launches_per_pass"),
+                         "region_event_ms_per_step": r.region_ms / args.steps,
+                         "whole_pass_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step_note": "stage operators (the 263-instruction 4-column step) exist for the compiled-in Lorenz model only; other models run the generic multi-column step"},
         }
         # ---- parity: du0 of every trajectory of this rank's shard and (N = 1) the REDUCED dp against the oracle on the same set
         du0 = r.du0.cpu().numpy()
@@ -489,7 +516,7 @@ def main():
 
     if world > 1 and not args.no_extras:
         # the other scaling figure, same run, fewer steps
-        r2, n2, _, _, _, el2, s0, s1 = measure(not strong, max(5, args.steps // 2), args.warmup)
+        r2, n2, _, _, _, el2, _, s1 = measure(not strong, max(5, args.steps // 2), args.warmup)
         if rank == 0:
             k2 = max(5, args.steps // 2)
             res["weak_scaling" if strong else "strong_scaling"] = {
@@ -504,11 +531,10 @@ def main():
             for n_s in (1250, 2500, 5000):
                 u0s, _ = inputs(10000)
                 rs = Runner(sa, torch, dist, args, n_s, u0s[:n_s], p_np, local_rank, 1, False)
-                el, s0, s1 = min((rs.timed(args.steps, args.warmup) for _ in range(2)), key=lambda r: r[0])   # best of two: a one-off driver stall (seen: 47 ms) must not stand for the shard's rate
-                kc = s1["adjoint_calls"] - s0["adjoint_calls"]
+                el = min(rs.timed(args.steps, args.warmup) for _ in range(2))   # best of two: a one-off driver stall (seen: 47 ms) must not stand for the shard's rate
+                km, s1 = rs.profiled(20)
                 sh.append({"ntraj": n_s, "gpus_of_layout": 10000 // n_s, "ms_per_step": el / args.steps * 1e3, "trajectories_per_s": n_s / (el / args.steps),
-                           "k_interp_ms": (s1["adjoint_main_kernel_ms_total"] - s0["adjoint_main_kernel_ms_total"]) / max(kc, 1),
-                           "time_segments": s1["time_segments"],
+                           "kernel_ms": km, "time_segments": s1["time_segments"], "launches_per_pass": s1.get("launches_per_pass"),
                            "implied_speedup_if_allreduce_hidden": res["ms_per_step"] / (el / args.steps * 1e3)})
                 rs.close()
             res["shard_sizes"] = sh

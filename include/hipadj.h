@@ -137,6 +137,9 @@ typedef struct {
     double adjoint_algorithmic_bytes; /* per adjoint call, SURVEY.md §8d definition */
     double vjp_steps;                 /* N * S * 4 per adjoint call (src/derivative_wrappers.jl:256 equivalents) */
     double workspace_bytes;
+    int32_t launches_per_pass;        /* kernel launches of one reverse pass as configured: 1 = the sweep kernel finishes the pass itself (composition tree
+                                         and dp reduction in-launch, csrc/hipadj_fused.hpp), 3 = sweep + composition + reduction, 0 = other sequences */
+    int32_t reserved0;
 } hipadj_stats;
 
 typedef struct hipadj_handle hipadj_handle;

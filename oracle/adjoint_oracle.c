@@ -53,6 +53,9 @@ static int model_init(orc_model *m, int id, const int dims[4]) {
     case ORC_MODEL_ROBER: m->n = 3; m->np = 3; break;
     case ORC_MODEL_AFFINE3: m->n = 3; m->np = 3; break;
     case ORC_MODEL_RING: { int r = m->dims[0]; if (r < 2 || r > 8) return -1; m->n = r; m->np = r + 1; break; }
+    case ORC_MODEL_IDXAFF: { int R = m->dims[0], Cc = m->dims[1]; if (R < 1 || Cc < 1) return -1; m->n = R * Cc; m->np = 2; break; }
+    case ORC_MODEL_MLP1: { int d = m->dims[0], H = m->dims[1]; if (d < 1 || H < 1) return -1; m->n = d; m->np = H * d + H + d * H + d; break; }
+    case ORC_MODEL_DENSELIN: { int r = m->dims[0]; if (r < 1) return -1; m->n = r; m->np = r * r; break; }
     default: return -1;
     }
     return 0;
@@ -103,6 +106,23 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
                                du_i = p_i (u_{i+1} - u_i) + p_n sin(u_{i-1}), indices mod n */
         int r = m->n;
         for (int i = 0; i < r; ++i) du[i] = p[i] * (u[(i + 1) % r] - u[i]) + p[r] * sin(u[(i + r - 1) % r]);
+        break; }
+    case ORC_MODEL_IDXAFF: { /* `rhs!` of test/Core5/size_handling_adjoint.jl:41-48: a R x Cc matrix state, df[i, j] = p[1] i + p[2] j (1-based, column-major) */
+        int R = m->dims[0], Cc = m->dims[1];
+        for (int j = 0; j < Cc; ++j) for (int i = 0; i < R; ++i) du[i + (size_t)j * R] = p[0] * (i + 1) + p[1] * (j + 1);
+        break; }
+    case ORC_MODEL_MLP1: {   /* docs/src/Benchmark.md:62: Chain(x -> x.^3, Dense(d, H, tanh), Dense(H, d)); parameters in Lux's flattening order
+                                (layer_2.weight [H x d] column-major, layer_2.bias, layer_3.weight [d x H], layer_3.bias) */
+        int d = m->dims[0], H = m->dims[1];
+        const double *W1 = p, *b1 = W1 + H * d, *W2 = b1 + H, *b2 = W2 + d * H;
+        double *h = m->work;
+        for (int i = 0; i < H; ++i) { double s = b1[i]; for (int j = 0; j < d; ++j) s += W1[i + j * H] * (u[j] * u[j] * u[j]); h[i] = tanh(s); }
+        for (int i = 0; i < d; ++i) { double s = b2[i]; for (int j = 0; j < H; ++j) s += W2[i + j * d] * h[j]; du[i] = s; }
+        break; }
+    case ORC_MODEL_DENSELIN: { /* u' = A u, A = reshape(p, n, n) column-major: every parameter its own entry of a dense linear map (checker for the
+                                  wide runtime models with np = n^2; NOT from the reference) */
+        int r = m->n;
+        for (int i = 0; i < r; ++i) { double s = 0; for (int j = 0; j < r; ++j) s += p[i + (size_t)j * r] * u[j]; du[i] = s; }
         break; }
     case ORC_MODEL_MLP: {
         /* U is d x B column-major; f(U) = W3 tanh(W2 tanh(W1 U + b1) + b2) + b3 (docs/src/Benchmark.md:62 shape) */
@@ -206,6 +226,33 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
             dgrad[r] = s;
         }
         break; }
+    case ORC_MODEL_IDXAFF: {
+        int R = m->dims[0], Cc = m->dims[1];
+        if (dlam) memset(dlam, 0, sizeof(double) * (size_t)m->n);          /* f does not depend on the state */
+        if (dgrad) { double g0 = 0, g1 = 0;
+            for (int j = 0; j < Cc; ++j) for (int i = 0; i < R; ++i) { g0 += (i + 1) * lam[i + (size_t)j * R]; g1 += (j + 1) * lam[i + (size_t)j * R]; }
+            dgrad[0] = g0; dgrad[1] = g1; }
+        break; }
+    case ORC_MODEL_MLP1: {
+        int d = m->dims[0], H = m->dims[1];
+        const double *W1 = p, *b1 = W1 + H * d, *W2 = b1 + H;
+        double *h = m->work, *gz = h + H;
+        for (int i = 0; i < H; ++i) { double s = b1[i]; for (int j = 0; j < d; ++j) s += W1[i + j * H] * (u[j] * u[j] * u[j]); h[i] = tanh(s); }
+        for (int j = 0; j < H; ++j) { double s = 0; for (int i = 0; i < d; ++i) s += W2[i + j * d] * lam[i]; gz[j] = s * (1.0 - h[j] * h[j]); }
+        if (dlam) for (int j = 0; j < d; ++j) { double s = 0; for (int i = 0; i < H; ++i) s += W1[i + j * H] * gz[i]; dlam[j] = s * 3.0 * u[j] * u[j]; }
+        if (dgrad) {
+            double *gW1 = dgrad, *gb1 = gW1 + H * d, *gW2 = gb1 + H, *gb2 = gW2 + d * H;
+            for (int j = 0; j < d; ++j) for (int i = 0; i < H; ++i) gW1[i + j * H] = gz[i] * (u[j] * u[j] * u[j]);
+            for (int i = 0; i < H; ++i) gb1[i] = gz[i];
+            for (int j = 0; j < H; ++j) for (int i = 0; i < d; ++i) gW2[i + j * d] = lam[i] * h[j];
+            for (int i = 0; i < d; ++i) gb2[i] = lam[i];
+        }
+        break; }
+    case ORC_MODEL_DENSELIN: {
+        int r = m->n;
+        if (dlam) for (int j = 0; j < r; ++j) { double s = 0; for (int i = 0; i < r; ++i) s += p[i + (size_t)j * r] * lam[i]; dlam[j] = s; }
+        if (dgrad) for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) dgrad[i + (size_t)j * r] = lam[i] * u[j];
+        break; }
     case ORC_MODEL_MLP: {
         int d = m->dims[0], H = m->dims[1], B = m->dims[2];
         const double *W1 = p, *b1 = W1 + H * d, *W2 = b1 + H, *b2 = W2 + H * H, *W3 = b2 + H;
@@ -304,7 +351,7 @@ static void mm_solve(const double *A, int n, double *v) {
 
 int orc_model_f(int model, const int dims[4], const double *u, const double *p, double t, double *du) {
     orc_model m; if (model_init(&m, model, dims)) return -1;
-    if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+    if (m.id == ORC_MODEL_MLP || m.id == ORC_MODEL_MLP1) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
     model_f(&m, du, u, p, t);
     free(m.work);
     return 0;
@@ -312,7 +359,7 @@ int orc_model_f(int model, const int dims[4], const double *u, const double *p, 
 int orc_model_vjp(int model, const int dims[4], const double *lam, const double *u, const double *p, double t,
                   double *dlam, double *dgrad) {
     orc_model m; if (model_init(&m, model, dims)) return -1;
-    if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+    if (m.id == ORC_MODEL_MLP || m.id == ORC_MODEL_MLP1) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
     model_vjp(&m, dlam, dgrad, lam, u, p, t);
     free(m.work);
     return 0;
@@ -1055,7 +1102,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
 
 int orc_forward(const orc_config *cfg, const double *u0, const double *p, double *out, long *nsteps) {
     orc_model m; if (model_init(&m, cfg->model, cfg->dims)) return -1;
-    if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+    if (m.id == ORC_MODEL_MLP || m.id == ORC_MODEL_MLP1) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
     orc_dense sol; double *u = (double *)malloc(sizeof(double) * m.n); memcpy(u, u0, sizeof(double) * m.n);
     long nrhs = 0;
     int st = forward_dense(&m, cfg, p, cfg->t0, cfg->t1, u, 0.0, &sol, &nrhs);
@@ -1070,7 +1117,7 @@ int orc_adjoint(const orc_config *cfg, const double *u0, const double *p, const 
                 double *du0, double *dp, double *out, long *nrhs) {
     orc_model m; if (model_init(&m, cfg->model, cfg->dims)) return -1;
     if (cfg->loss_kind == ORC_LOSS_COTANGENT && !dLdu && cfg->nsave > 0) return -1;
-    if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+    if (m.id == ORC_MODEL_MLP || m.id == ORC_MODEL_MLP1) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
     long nr = 0;
     int st = adjoint_one(&m, cfg, u0, p, dLdu, du0, dp, out, &nr, NULL, NULL);
     if (nrhs) *nrhs = nr;
@@ -1095,7 +1142,7 @@ int orc_adjoint_ensemble(const orc_config *cfg, long N, const double *u0, const 
 #endif
     {
         orc_model m = m0; m.work = NULL;
-        if (m.id == ORC_MODEL_MLP) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
+        if (m.id == ORC_MODEL_MLP || m.id == ORC_MODEL_MLP1) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
         double *dpl = (double *)calloc(np, sizeof(double)), *dpi = (double *)calloc(np, sizeof(double));
         double ltf = 0, ltr = 0;
 #ifdef _OPENMP

@@ -39,8 +39,12 @@ enum {
     ORC_MODEL_BRUSS = 6,     /* 2-D Brusselator, periodic 5-point Laplacian */
     ORC_MODEL_ROBER = 7,     /* Robertson kinetics `rober` (test/Core3/adjoint.jl:1434-1441); checker for runtime-registered models */
     ORC_MODEL_RING = 8,      /* synthetic ring, dims = {n <= 8}, np = n + 1; checker for runtime-registered models with n > 3 */
-    ORC_MODEL_AFFINE3 = 9    /* du = A u + p, du[2] += sum(p): `foo` of the mass-matrix test (test/Core3/adjoint.jl:1315-1321); checker for
+    ORC_MODEL_AFFINE3 = 9,   /* du = A u + p, du[2] += sum(p): `foo` of the mass-matrix test (test/Core3/adjoint.jl:1315-1321); checker for
                                 runtime-registered models with a mass matrix */
+    /* checkers for the wide (workgroup-per-trajectory) runtime models, csrc/hipadj_wide.hpp */
+    ORC_MODEL_IDXAFF = 10,   /* R x Cc matrix state, df[i,j] = p1 i + p2 j: `rhs!` of test/Core5/size_handling_adjoint.jl:37-48; dims = {R, Cc} */
+    ORC_MODEL_MLP1 = 11,     /* Chain(x -> x.^3, Dense(d, H, tanh), Dense(H, d)): the neural ODE of docs/src/Benchmark.md:62; dims = {d, H} */
+    ORC_MODEL_DENSELIN = 12  /* u' = A u with A = reshape(p, n, n): np = n^2 (NOT from the reference); dims = {n} */
 };
 enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3,
        ORC_ALG_GAUSS_KRONROD = 4 /* [upstream-recall] per-step adaptive GK(7,15): parity UNPINNED beyond GaussKronrod == Gauss */ };

@@ -50,6 +50,7 @@ class HipadjStats(C.Structure):
         ("forward_calls", C.c_int64), ("adjoint_calls", C.c_int64),
         ("adjoint_main_kernel_ms_last", C.c_double), ("adjoint_main_kernel_ms_total", C.c_double),
         ("adjoint_algorithmic_bytes", C.c_double), ("vjp_steps", C.c_double), ("workspace_bytes", C.c_double),
+        ("launches_per_pass", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -367,6 +367,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
 
     h->st.struct_size = sizeof(hipadj_stats); h->st.n = n; h->st.np = np; h->st.ntraj = h->N; h->st.nsteps = S;
     h->st.time_segments = h->nseg; h->st.workspace_bytes = h->ws_bytes;
+    h->st.launches_per_pass = (h->fused && h->d_tbuf) ? 1 : ((!P.field && !P.mlp && !P.adaptive && cfg->alg != HIPADJ_ALG_QUADRATURE) ? 3 : 0);
     // ALGORITHMIC bytes of one reverse pass: knots (u,f) once, cotangents (if read), du0 + dp out
     double bytes = 0.0;
     if (P.adaptive) bytes = 0.0;   // data-dependent (accepted steps per trajectory): not modelled
