@@ -198,6 +198,23 @@ int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
 int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, double *out, double *p_out);
 int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, const double *lam,
                       const double *gp, double *lam_out, double *gp_out);
+/* Wide runtime models — more than 8 states or more than 32 parameters (up to n = 4096 states): the workgroup-per-trajectory family
+ * (csrc/hipadj_wide.hpp).  ONE workgroup of `threads` threads integrates one trajectory; the stage state, the stage adjoint and the VJP
+ * output are tiles in LDS, threads own the components tid, tid + threads, ...  The model is TWO bodies of HIP C++, run by every thread
+ * of the workgroup with the same arguments (SPMD) — f and the joint VJP, i.e. the reference's internal contract
+ * vecjacobian!(dlam, y, lam, p, t, S; dgrad) (src/derivative_wrappers.jl:256-267) rather than the separate vjp / vjp_p of the small models:
+ *   f_body    writes du[0..n)                         from u[0..n), p[0..np), t
+ *   vjp_body  writes dlam[0..n) = (df/du)' lam        from lam[0..n), u, p, t;  and, inside `if (WP) { ... }`, adds w * (df/dp)' lam to the
+ *             gradient: `gp[j] += w * ...` for entries owned by exactly one thread (one thread per weight of an MLP / entry of a matrix), or
+ *             `acc[q] += w * ...` = this thread's partial of parameter acc_first + q (a coefficient every component feeds; nacc <= 16
+ *             such parameters; the partials are summed over the workgroup once per sweep)
+ * Available inside the bodies: `tid`, `T` (= threads), `N`, `NP`, `HIPADJ_W_FOR(i, count) { ... }` (i = tid, tid + T, ... < count),
+ * `wg_sync()` (workgroup barrier between dependent phases, e.g. hidden layers), `ws[0..lds_doubles)` LDS scratch.  u, lam, du, dlam, ws are
+ * LDS, p is global memory.  threads: a multiple of 64 in [64, 1024], 0 = automatic.  Offered: fixed-step RK4, loss times on the step grid,
+ * Interpolating / Backsolve (checkpoints) / Gauss / QuadratureAdjoint, discrete losses; parity-tested against the oracle on the reference's
+ * 30 x 50 matrix-state problem (test/Core5/size_handling_adjoint.jl:37-70) and the 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62. */
+int hipadj_wmodel_register(const char *name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
+                           const char *f_body, const char *vjp_body, int32_t *model_id);
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
  * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
 int hipadj_model_check(int32_t model_id);

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
+    "hipadj_model_register", "hipadj_wmodel_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
     "hipadj_comm_count", "hipadj_comm_selfcheck",
 )
@@ -100,6 +100,7 @@ def load():
     L.hipadj_set_timing.argtypes = [vp, C.c_int]
     L.hipadj_get_stats.argtypes = [vp, C.POINTER(HipadjStats)]
     L.hipadj_model_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
+    L.hipadj_wmodel_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
     L.hipadj_model_check.argtypes = [C.c_int32]
     L.hipadj_model_check_config.argtypes = [C.POINTER(HipadjConfig)]
     L.hipadj_runtime_compiler.argtypes = [C.c_char_p, C.c_int32]
@@ -135,6 +136,20 @@ def register_model(name, n, npar, f, vjp=None, vjp_p=None, check=False):
     mid = C.c_int32()
     enc = lambda b: None if b is None else b.encode()
     rc = L.hipadj_model_register(name.encode(), int(n), int(npar), f.encode(), enc(vjp), enc(vjp_p), C.byref(mid))
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+    MODEL[name] = mid.value
+    if check:
+        check_model(mid.value)
+    return mid.value
+
+
+def register_wide_model(name, n, npar, f, vjp, threads=0, lds_doubles=0, nacc=0, acc_first=0, check=False):
+    """hipadj_wmodel_register: a model of the workgroup-per-trajectory family (more than 8 states or 32 parameters; include/hipadj.h):
+    the SPMD bodies of f and of the joint VJP.  Adds `name` to MODEL and returns the model id."""
+    L = load()
+    mid = C.c_int32()
+    rc = L.hipadj_wmodel_register(name.encode(), int(n), int(npar), int(threads), int(lds_doubles), int(nacc), int(acc_first), f.encode(), vjp.encode(), C.byref(mid))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
     MODEL[name] = mid.value

@@ -9,6 +9,9 @@
 
 static thread_local std::string g_create_error;
 static int user_prepare(hipadj_handle* h);   // hiprtc compilation of the kernels of a runtime-registered model
+static int wide_prepare(hipadj_handle* h);   // ... of a wide model (workgroup-per-trajectory family, hipadj_wide.hpp)
+static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out);
+static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp);
 
 extern "C" int hipadj_version(void) { return HIPADJ_VERSION; }
 
@@ -37,6 +40,11 @@ extern "C" int hipadj_model_sizes(int32_t model, const int32_t dims[4], int32_t*
 extern "C" int hipadj_model_register(const char* name, int32_t n, int32_t np, const char* f_body, const char* vjp_u_body,
                                      const char* vjp_p_body, int32_t* model_id) {
     return user_register(name, n, np, f_body, vjp_u_body, vjp_p_body, model_id, g_create_error);
+}
+
+extern "C" int hipadj_wmodel_register(const char* name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
+                                      const char* f_body, const char* vjp_body, int32_t* model_id) {
+    return user_register_wide(name, n, np, threads, lds_doubles, nacc, acc_first, f_body, vjp_body, model_id, g_create_error);
 }
 
 extern "C" int hipadj_model_set_cost(int32_t model_id, const char* dgdu_body, const char* dgdp_body) {
@@ -129,8 +137,26 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
     return HIPADJ_OK;
 }
 
+static std::vector<std::string> wide_kernel_names(int alg) {
+    const std::string U = "hipadj::UserW";
+    std::vector<std::string> e = {"hipadj::k_wide_forward<" + U + ">"};
+    switch (alg) {
+    case HIPADJ_ALG_INTERPOLATING: e.push_back("hipadj::k_wide_adjoint<" + U + ", 0>"); break;
+    case HIPADJ_ALG_GAUSS: e.push_back("hipadj::k_wide_adjoint<" + U + ", 2>"); break;
+    case HIPADJ_ALG_BACKSOLVE: e.push_back("hipadj::k_wide_backsolve<" + U + ">"); break;
+    case HIPADJ_ALG_QUADRATURE: e.push_back("hipadj::k_wide_quad_adj<" + U + ">"); e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ">"); break;
+    default: break;
+    }
+    return e;
+}
+
 extern "C" int hipadj_model_check(int32_t model_id) {
     std::vector<char> code; std::map<std::string, std::string> low;
+    if (user_model_is_wide(model_id)) {   // a wide model: the forward solve and every sweep of the family
+        std::vector<std::string> all = wide_kernel_names(HIPADJ_ALG_INTERPOLATING);
+        for (int a : {HIPADJ_ALG_GAUSS, HIPADJ_ALG_BACKSOLVE, HIPADJ_ALG_QUADRATURE}) { const auto e = wide_kernel_names(a); all.insert(all.end(), e.begin() + 1, e.end()); }
+        return user_compile(model_id, all, code, low, g_create_error);
+    }
     std::vector<std::string> exprs = {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 1, 7>" : "hipadj::k_interp<hipadj::UserModel, 1, 1>"};
     if (user_has_affect(model_id)) { exprs.push_back("hipadj::k_user_affect<hipadj::UserModel>"); exprs.push_back("hipadj::k_user_affect_vjp<hipadj::UserModel>"); }
     if (const char* e = std::getenv("HIPADJ_CHECK_EXPRS")) {   // debugging hook: further ';'-separated kernel instantiations (ISA studies with HIPADJ_RTC_DUMP)
@@ -162,7 +188,7 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->d_wscr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
@@ -236,6 +262,21 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = (h->auto_steps && cfg->alg != HIPADJ_ALG_BACKSOLVE) ? (int)h->rec_cap : P.Smax; ag.maxit = h->auto_steps ? HIPADJ_AUTO_MAXITERS : P.Smax; ag.nck = P.nck; ag.SmaxI = P.SmaxI; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
         ag.abstol = cfg->abstol; ag.reltol = cfg->reltol; ag.loss_shift = cfg->loss_shift; ag.loss_kind = cfg->loss_kind;
         ag.no_start = cfg->no_start; ag.p_shared = cfg->p_shared; ag.cont_cost = cfg->cont_cost;
+    } else if (P.wide) {
+        // workgroup-per-trajectory family of runtime models (hipadj_wide.hpp): trajectory-major knots, Backsolve checkpoints, Quadrature records
+        h->wide = true;
+        h->wg.N = h->N; h->wg.S = (int)S; h->wg.M = h->M; h->wg.nck = h->nck; h->wg.t0 = cfg->t0; h->wg.dt = cfg->dt; h->wg.loss_shift = cfg->loss_shift;
+        h->wg.loss_kind = cfg->loss_kind; h->wg.no_start = cfg->no_start; h->wg.p_shared = cfg->p_shared;
+        if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
+        else {
+            A(dev_alloc(h, &h->d_yT, (size_t)h->N * n));
+            if (h->nck > 0) A(dev_alloc(h, &h->d_ckpt, (size_t)h->N * h->nck * n));
+        }
+        if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
+            A(dev_alloc(h, &h->d_fadj, (size_t)h->N * S * 4 * n));
+            A(dev_alloc(h, &h->d_qres, (size_t)h->N * (h->nq > 0 ? h->nq : 1) * np));
+            A(dev_alloc(h, &h->d_wscr, (size_t)h->N * (h->nq > 0 ? h->nq : 1) * (3 + HIPADJ_WIDE_MAXSEG) * np));
+        }
     } else if (!P.field && !P.mlp) {
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
@@ -331,8 +372,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     }
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
-        if (!h->field && !h->mlp) A(dev_alloc(h, &h->d_adj, (size_t)(P.offgrid ? P.rs_t.size() : (size_t)S) * 2 * n * Np));   // one record per reverse step
-        if (!h->mlp) A(dev_alloc(h, &h->d_qres, (size_t)h->nq * np * Np));
+        if (!h->field && !h->mlp && !h->wide) A(dev_alloc(h, &h->d_adj, (size_t)(P.offgrid ? P.rs_t.size() : (size_t)S) * 2 * n * Np));   // one record per reverse step
+        if (!h->mlp && !h->wide) A(dev_alloc(h, &h->d_qres, (size_t)h->nq * np * Np));
         A(dev_alloc(h, &h->d_qa, (size_t)h->nq)); A(dev_alloc(h, &h->d_qb, (size_t)h->nq));
     }
     if (rc != HIPADJ_OK) return fail(rc);
@@ -380,7 +421,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->st.vjp_steps = (double)h->N * (double)S * 4.0;
     h->user = P.user;
     if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { h->err = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost)"; return fail(HIPADJ_ERR_INVALID_ARG); }
-    if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); }
+    if (P.wide) { const int urc = wide_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
+    else if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); }
     *out = h;
     return HIPADJ_OK;
 }
@@ -651,6 +693,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     h.cfg = *cfg; h.cfg.save_times = nullptr; h.cfg.checkpoints = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
+    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg), code, low, err); }
     h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
     const UserKernels k = user_kernel_names(&h);
     std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
@@ -864,7 +907,70 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
     return 1;
 }
 
+// ---- wide runtime models: workgroup-per-trajectory family (hipadj_wide.hpp) ----------------------------------------------------------------
+static int wide_prepare(hipadj_handle* h) {
+    if (user_has_cost(h->cfg.model) || user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no continuous cost / affect");
+    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg);
+    std::vector<char> code; std::map<std::string, std::string> low;
+    const int rc = user_compile(h->cfg.model, exprs, code, low, h->err);
+    if (rc != HIPADJ_OK) return rc;
+    HIP_TRY(h, hipModuleLoadData(&h->umod, code.data()));
+    HIP_TRY(h, hipModuleGetFunction(&h->uf_forward, h->umod, low[exprs[0]].c_str()));
+    HIP_TRY(h, hipModuleGetFunction(&h->uf_main, h->umod, low[exprs[1]].c_str()));
+    if (exprs.size() > 2) HIP_TRY(h, hipModuleGetFunction(&h->uf_gk, h->umod, low[exprs[2]].c_str()));
+    h->wide_T = user_wide_threads(h->cfg.model);
+    return HIPADJ_OK;
+}
+
+static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE;
+    TRY(usig<decltype(&k_wide_forward<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, d_u0, d_p,
+                bs ? (double*)nullptr : h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot,
+                (bs && h->nck > 0) ? h->d_ckpt : (double*)nullptr, (const int*)h->d_ckpt_of_knot, bs ? h->d_yT : (double*)nullptr));
+    return HIPADJ_OK;
+}
+
+static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    const double* p = h->p_dev_last;
+    hipadj_handle::EvSet& es = h->evs[h->ev_next];
+    h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
+    harvest_set(h, es, true);
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
+    if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
+    const dim3 grid((unsigned)h->N), blk((unsigned)h->wide_T);
+    // per-trajectory gradient rows: straight into the caller's dp when the parameters are per trajectory, else a workspace that k_wide_reduce_dp sums
+    double* rows = h->cfg.p_shared ? h->d_dp_traj : d_dp;
+    switch (h->cfg.alg) {
+    case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS:
+        TRY(usig<decltype(&k_wide_adjoint<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, rows, h->d_flag));
+        break;
+    case HIPADJ_ALG_BACKSOLVE:
+        TRY(usig<decltype(&k_wide_backsolve<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_yT, (const double*)(h->nck > 0 ? h->d_ckpt : nullptr),
+                    (const int*)h->d_ckpt_of_knot, d_cot, (const int*)h->d_save_rev, d_du0, rows, h->d_flag));
+        break;
+    case HIPADJ_ALG_QUADRATURE: {
+        TRY(usig<decltype(&k_wide_quad_adj<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag));
+        if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG>)>::launch(h, h->uf_gk, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, (const double*)h->d_fknots,
+                    (const double*)h->d_fadj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
+        hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows);
+        HIP_TRY(h, hipGetLastError());
+        break; }
+    default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg not available for wide models");
+    }
+    if (h->timing >= 1 && h->cfg.alg != HIPADJ_ALG_QUADRATURE) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+    if (h->cfg.p_shared) {
+        hipLaunchKernelGGL(k_wide_reduce_dp, dim3((unsigned)((h->np + 255) / 256)), dim3(256), 0, h->stream, h->N, h->np, (const double*)h->d_dp_traj, d_dp, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+    es.pending = h->timing >= 1; es.full = h->timing >= 2;
+    return HIPADJ_OK;
+}
+
 static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    if (h->wide) return wide_forward(h, d_u0, d_p, d_out);
     if (h->user) return user_forward(h, d_u0, d_p, d_out);
     if (h->field) { DISPATCH_GRID(h, field_forward, h, d_u0, d_p, d_out); }
     if (h->mlp) { DISPATCH_HIDDEN(h, mlp_forward_launch, h, d_u0, d_p, d_out); }
@@ -909,6 +1015,7 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
 }
 
 static int adjoint_dispatch(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    if (h->wide) return wide_adjoint(h, d_cot, d_du0, d_dp);
     if (h->user) return user_adjoint(h, d_cot, d_du0, d_dp);
     if (h->field) { DISPATCH_GRID(h, field_adjoint, h, d_cot, d_du0, d_dp); }
     if (h->mlp) { DISPATCH_HIDDEN(h, mlp_adjoint_launch, h, d_cot, d_du0, d_dp); }

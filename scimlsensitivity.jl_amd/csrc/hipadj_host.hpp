@@ -20,8 +20,11 @@
 #include "hipadj_mlp.hpp"
 #include "hipadj_mlp_grad.hpp"
 #include "hipadj_adaptive.hpp"
+#include "hipadj_wide.hpp"
 
 using namespace hipadj;
+
+#define HIPADJ_WIDE_MAXSEG 32   // segments of one adaptive Gauss-Kronrod quadrature in the wide family (segment integrals are np-vectors in HBM scratch)
 
 static constexpr int HIPADJ_AUTO_MAXITERS = 100000;   // max_steps == 0: the reference's default maxiters
 
@@ -57,6 +60,8 @@ struct hipadj_handle {
     MlpGeom mg{};
     FieldGeom fg{};
     bool user = false;                    // runtime-compiled right-hand side (hipadj_user.hpp)
+    bool wide = false;                    // ... of the workgroup-per-trajectory family (hipadj_wide.hpp)
+    WideGeom wg{}; int wide_T = 0; double* d_wscr = nullptr;
     bool has_mm = false; double minv[64] = {0};   // the model's mass matrix at create time (M^{-1}, row-major): du0 = M^{-T} nu(t0) after the sweep
     hipModule_t umod = nullptr;
     hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish

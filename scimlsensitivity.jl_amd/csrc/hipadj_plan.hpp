@@ -33,6 +33,7 @@ struct Plan {
     bool mlp = false;        // FP64-MFMA family (hipadj_mlp.hpp)
     bool adaptive = false;   // adaptive Tsit5 (hipadj_adaptive.hpp)
     bool user = false;       // runtime-compiled right-hand side (hipadj_user.hpp)
+    bool wide = false;       // ... of the workgroup-per-trajectory family (hipadj_wide.hpp): planned like the PDE family, BacksolveAdjoint included
     int Smax = 0;            // capacity of the per-trajectory dense solution (adaptive)
     int SmaxI = 0;           // adaptive + checkpointing=true (Interpolating/Gauss): record capacity of ONE checkpoint interval
     std::vector<double> ck_times, tstops_desc;   // adaptive: checkpoint times (ascending), reverse tstops (descending)
@@ -96,6 +97,8 @@ inline void plan_reverse_steps(const hipadj_config* cfg, Plan& P) {
 // runtime-registered models (ids >= HIPADJ_MODEL_USER_BASE, hipadj_user.hpp): sizes come from the registry
 typedef int (*plan_user_sizes_fn)(int32_t model, int32_t* n, int32_t* np);
 inline plan_user_sizes_fn& plan_user_sizes_hook() { static plan_user_sizes_fn f = nullptr; return f; }
+typedef bool (*plan_user_wide_fn)(int32_t);   // is this runtime model one of the workgroup-per-trajectory family (hipadj_wmodel_register)?
+inline plan_user_wide_fn& plan_user_wide_hook() { static plan_user_wide_fn f = nullptr; return f; }
 inline bool plan_user_model(int m) { return m >= HIPADJ_MODEL_USER_BASE; }
 inline bool plan_small_model(int m) { return (m >= HIPADJ_MODEL_LV && m <= HIPADJ_MODEL_FALLMASS) || plan_user_model(m); }
 
@@ -175,7 +178,14 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     P.field = cfg->model == HIPADJ_MODEL_BRUSS;
     P.mlp = cfg->model == HIPADJ_MODEL_MLP;
     P.user = plan_user_model(cfg->model);
+    P.wide = P.user && plan_user_wide_hook() && plan_user_wide_hook()(cfg->model);
     if (!plan_small_model(cfg->model) && !P.field && !P.mlp) { err = "unknown model"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (P.wide) {   // what the wide family offers so far: fixed-step RK4, loss times on the step grid, the four sensealgs, discrete losses
+        if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED) { err = "wide models (hipadj_wmodel_register) run the fixed-step RK4 stepper"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "continuous costs are available for the lane-per-trajectory family only"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->checkpointing && cfg->alg != HIPADJ_ALG_BACKSOLVE) { err = "wide models: checkpointing = true is available for BacksolveAdjoint (Interpolating / Gauss keep the dense knots)"; return HIPADJ_ERR_UNSUPPORTED; }
+    }
     if (P.mlp) {
         if (cfg->dims[0] != 2) { err = "MLP family: state width d must be 2 (docs/src/Benchmark.md:62 shape)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->dims[1] != 32 && cfg->dims[1] != 64 && cfg->dims[1] != 128) { err = "MLP family: hidden width must be 32, 64 or 128 (the weight matrix lives in LDS)"; return HIPADJ_ERR_UNSUPPORTED; }
@@ -260,7 +270,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (S < 1 || S > 100000000L) { err = "(t1 - t0)/dt must give between 1 and 1e8 steps"; return HIPADJ_ERR_INVALID_ARG; }
     P.h_last = ragged ? (cfg->t1 - cfg->t0) - (double)(S - 1) * cfg->dt : cfg->dt;
-    if (ragged && (P.field || P.mlp)) { err = "a span that is not a multiple of dt (shortened last step) is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (ragged && (P.field || P.mlp || P.wide)) { err = "a span that is not a multiple of dt (shortened last step) is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->nsave < 0 || (cfg->nsave > 0 && !cfg->save_times)) { err = "save_times missing"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->time_segments < 0) { err = "time_segments must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
@@ -284,7 +294,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         const bool og_ig = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && !cfg->checkpointing;
         const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->ckpt_stride == 0 && cfg->ncheckpoints == 0;
         const bool og_q = cfg->alg == HIPADJ_ALG_QUADRATURE && !P.user;       // compiled-in lane models (round 2)
-        if (!(og_ig || og_bs || og_q) || P.field || P.mlp) {
+        if (!(og_ig || og_bs || og_q) || P.field || P.mlp || P.wide) {
             err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false), QuadratureAdjoint (compiled-in models) and "
                   "BacksolveAdjoint (checkpoints = the save times, ckpt_stride = 0) on the lane-per-trajectory models; other configurations need times on the grid, or the adaptive stepper (arbitrary times)";
             return HIPADJ_ERR_UNSUPPORTED; }
@@ -304,7 +314,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     // checkpoints: BacksolveAdjoint only.  Interpolating/Gauss checkpointing re-solves, on this fixed grid,
     // bit-identical knots from the stored values; the dense tiles are kept instead.
     P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
-    P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing && !P.field && !P.mlp;
+    P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing && !P.field && !P.mlp && !P.wide;
     P.nck = P.offgrid ? (int)P.ck_times.size() : 0;   // off-grid Backsolve: checkpoint TIMES (interpolated states), not knots
     if ((P.bs_ckpt || P.ip_ckpt) && !P.offgrid) {
         int c = 0;
@@ -334,7 +344,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         P.ck_longest = longest;   // <= HIPADJ_CKPT_KMAX: the re-solve tile lives in LDS; longer intervals: a per-wave slice of an HBM scratch buffer
     }
     P.nseg = 1;
-    const bool seg_alg = !P.field && !P.mlp && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
+    const bool seg_alg = !P.field && !P.mlp && !P.wide && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
     // off-grid Interpolating / Gauss: the reverse STEP LIST is what gets segmented (it does not depend on the
     // trajectory); bounds are then positions r = nrs - q in that list instead of knot indices (k_offgrid_seg)
     const bool seg_offgrid = P.offgrid && (!P.user || plan_seg_fits(n, np)) && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS);

@@ -50,6 +50,10 @@ struct UserModelSrc {
     bool has_mm = false;      // constant non-singular mass matrix (hipadj_model_set_mass_matrix): minv = M^{-1}, row-major n x n
     double minv[64] = {0};
     int n = 0, np = 0, rev = 0;   // rev: bumped when the sources change, part of the code-cache key
+    // wide model (hipadj_wmodel_register; hipadj_wide.hpp): SPMD bodies f / vjp for a workgroup of `threads` per trajectory
+    bool wide = false;
+    std::string wvjp;             // the joint VJP body (the reference's vecjacobian! contract)
+    int threads = 0, nw = 0, nacc = 0, acc0 = 0;
 };
 
 struct UserRegistry {
@@ -196,7 +200,24 @@ inline bool user_read_file(const std::string& path, std::string& out) {
     return true;
 }
 
+inline std::string user_wide_struct(const UserModelSrc& m) {
+    std::ostringstream o;
+    const int na = m.nacc > 0 ? m.nacc : 1;
+    o << "#include \"hipadj_wide.hpp\"\n"
+      << "namespace hipadj {\n// runtime-registered wide model '" << m.name << "' (workgroup-per-trajectory family, hipadj_wide.hpp)\n"
+      << "#define HIPADJ_W_FOR(i, n) for (int i = tid; i < (n); i += T)\n#define wg_sync() hipadj::wide_sync<T>()\n"
+      << "struct UserW {\n    static constexpr int N = " << m.n << ", NP = " << m.np << ", T = " << m.threads << ", NW = " << m.nw << ", NACC = " << m.nacc
+      << ", ACC0 = " << m.acc0 << ";\n"
+      << "    static __device__ __forceinline__ void f(double* __restrict__ du, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {\n"
+      << "        (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.f << "\n    }\n"
+      << "    template <bool WP> static __device__ __forceinline__ void vjp(double* __restrict__ dlam, double* __restrict__ gp, double (&acc)[" << na << "], double w,\n"
+      << "            const double* __restrict__ lam, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {\n"
+      << "        (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wvjp << "\n    }\n};\n}  // namespace hipadj\n";
+    return o.str();
+}
+
 inline std::string user_model_struct(const UserModelSrc& m) {
+    if (m.wide) return user_wide_struct(m);
     std::ostringstream o;
     o << "#include \"hipadj_kernels.hpp\"\n#include \"hipadj_adaptive.hpp\"\n#include \"hipadj_dual.hpp\"\n"
       << "namespace hipadj {\n// runtime-registered model '" << m.name << "'\nstruct UserModel {\n"
@@ -418,8 +439,8 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
     }
     RtcApi& A = rtc_api();
     if (!A.lib || !A.err.empty()) { err = A.err.empty() ? "hiprtc unavailable" : A.err; return HIPADJ_ERR_UNSUPPORTED; }
-    constexpr int NH = 6;
-    const char* hnames[NH] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp", "hipadj_dual.hpp", "hipadj_fused.hpp"};
+    constexpr int NH = 7;
+    const char* hnames[NH] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp", "hipadj_dual.hpp", "hipadj_fused.hpp", "hipadj_wide.hpp"};
     std::string htext[NH];
     const std::string dir = user_csrc_dir();
     for (int i = 0; i < NH; ++i)
@@ -446,7 +467,7 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
             if (log.size() > 4000) log.resize(4000);
             err = "model '" + src.name + "' failed to compile:\n" + log;
             A.DestroyProgram(&prog);
-            if (src.cols) {   // a VJP body that is not written linearly in `lam` (a double temporary holding a lam term, ...) does not compile for column bundles:
+            if (src.cols && !src.wide) {   // a VJP body that is not written linearly in `lam` (a double temporary holding a lam term, ...) does not compile for column bundles:
                 src.cols = false;   // once more in the per-column form; a genuine error fails again and is reported from that (plainer) build
                 { std::lock_guard<std::mutex> lk(R.mu); const int idx = model - HIPADJ_MODEL_USER_BASE; if (R.models[idx].rev == src.rev) R.models[idx].cols = false; }
                 tu = user_model_struct(src);
@@ -604,7 +625,7 @@ inline bool user_has_cost(int32_t model) {
 inline int user_register(const char* name, int32_t n, int32_t np, const char* f, const char* vu, const char* vp, int32_t* id, std::string& err) {
     if (!name || !f || !id) { err = "hipadj_model_register: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
     if ((vu == nullptr) != (vp == nullptr)) { err = "hipadj_model_register: give both vjp_u_body and vjp_p_body, or neither (automatic forward-mode VJPs)"; return HIPADJ_ERR_INVALID_ARG; }
-    if (n < 1 || n > 8 || np < 1 || np > 32) { err = "hipadj_model_register: need 1 <= n <= 8 and 1 <= np <= 32 (state and parameters live in VGPRs)"; return HIPADJ_ERR_INVALID_ARG; }
+    if (n < 1 || n > 8 || np < 1 || np > 32) { err = "hipadj_model_register: need 1 <= n <= 8 and 1 <= np <= 32 (state and parameters live in VGPRs); larger models: hipadj_wmodel_register (workgroup per trajectory)"; return HIPADJ_ERR_INVALID_ARG; }
     UserRegistry& R = user_registry();
     std::lock_guard<std::mutex> lk(R.mu);
     UserModelSrc m; m.name = name; m.n = n; m.np = np; m.f = f; m.auto_vjp = vu == nullptr;
@@ -612,6 +633,50 @@ inline int user_register(const char* name, int32_t n, int32_t np, const char* f,
     R.models.push_back(m);
     *id = HIPADJ_MODEL_USER_BASE + (int32_t)R.models.size() - 1;
     plan_user_sizes_hook() = &user_model_sizes;
+    return HIPADJ_OK;
+}
+
+
+inline bool user_model_is_wide(int32_t model) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    return idx >= 0 && idx < (int)R.models.size() && R.models[idx].wide;
+}
+inline int user_wide_threads(int32_t model) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    return (idx >= 0 && idx < (int)R.models.size()) ? R.models[idx].threads : 0;
+}
+
+// hipadj_wmodel_register: a model for the workgroup-per-trajectory family.  threads = 0 picks the workgroup size: a quarter of max(n, min(np, 4096))
+// rounded up to whole wavefronts, between 64 (one wavefront per trajectory) and 1024.
+inline int user_register_wide(const char* name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
+                              const char* f, const char* vjp, int32_t* id, std::string& err) {
+    if (!name || !f || !vjp || !id) { err = "hipadj_wmodel_register: NULL argument (f_body and vjp_body are both required)"; return HIPADJ_ERR_INVALID_ARG; }
+    if (n < 1 || n > 4096 || np < 1 || np > (1 << 20)) { err = "hipadj_wmodel_register: need 1 <= n <= 4096 and 1 <= np <= 2^20"; return HIPADJ_ERR_INVALID_ARG; }
+    if (lds_doubles < 0 || nacc < 0 || nacc > 16 || acc_first < 0 || (nacc > 0 && acc_first + nacc > np)) {
+        err = "hipadj_wmodel_register: need lds_doubles >= 0, 0 <= nacc <= 16 and the reduced parameters [acc_first, acc_first + nacc) inside [0, np)"; return HIPADJ_ERR_INVALID_ARG; }
+    if (threads == 0) {
+        const int work = n > (np < 4096 ? np : 4096) ? n : (np < 4096 ? np : 4096);
+        threads = ((work + 3) / 4 + 63) / 64 * 64;
+        if (threads < 64) threads = 64;
+        if (threads > 1024) threads = 1024;
+    }
+    if (threads % 64 != 0 || threads < 64 || threads > 1024) { err = "hipadj_wmodel_register: threads must be a multiple of 64 between 64 and 1024 (0 = automatic)"; return HIPADJ_ERR_INVALID_ARG; }
+    if ((n + threads - 1) / threads > 16) { err = "hipadj_wmodel_register: more than 16 state components per thread (raise threads)"; return HIPADJ_ERR_INVALID_ARG; }
+    // LDS of the heaviest kernel (Backsolve: four state-sized tiles) + the model's scratch + the gradient accumulator (np <= 8192) + reduction rows: 160 KB per workgroup
+    const long lds = 4L * n + lds_doubles + (np <= 8192 ? np : 1) + (threads / 64) * 34 + 64;
+    if (lds * 8 > 160L * 1024) { err = "hipadj_wmodel_register: 4 n + lds_doubles + min(np, 8192) doubles exceed the 160 KB of LDS of a workgroup"; return HIPADJ_ERR_INVALID_ARG; }
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    UserModelSrc m; m.name = name; m.n = n; m.np = np; m.f = f; m.wvjp = vjp; m.wide = true; m.cols = false;
+    m.threads = threads; m.nw = lds_doubles; m.nacc = nacc; m.acc0 = acc_first;
+    R.models.push_back(m);
+    *id = HIPADJ_MODEL_USER_BASE + (int32_t)R.models.size() - 1;
+    plan_user_sizes_hook() = &user_model_sizes;
+    plan_user_wide_hook() = &user_model_is_wide;
     return HIPADJ_OK;
 }
 

@@ -1,0 +1,543 @@
+// hipadj_wide.hpp — the generic workgroup-per-trajectory kernel family: runtime-registered models with more than 8 states or more
+// than 32 parameters (hipadj_wmodel_register; VERDICT r2 "missing 1": the mapping north_star names — one wavefront / workgroup per
+// trajectory, state / adjoint tiles in LDS, lanes over the state components, shuffle reductions for the per-trajectory VJP sums).
+//
+// The lane-per-trajectory family keeps a trajectory's whole augmented state in one lane's VGPRs, which ends at 8 states; the
+// Brusselator (hipadj_field.hpp) and the 3-layer MLP (hipadj_mlp*.hpp) are bespoke.  Here ONE workgroup of T threads (T = 64: one
+// wavefront; up to 1024) integrates one trajectory of ANY model that provides two SPMD functions — the reference's own internal
+// contract, `vecjacobian!(dlam, y, lam, p, t, S; dgrad)` (src/derivative_wrappers.jl:256-267: (df/du)^T lam and (df/dp)^T lam
+// from ONE reverse sweep over f), plus f itself:
+//
+//   f   (du, u, p, t, ws, tid)                           du[0..N) = f(u, p, t)                   u, du in LDS
+//   vjp<WP>(dlam, gp, acc, w, lam, u, p, t, ws, tid)     dlam[0..N) = (df/du)^T lam              lam, u, dlam in LDS
+//                                                        if WP:  gp[j] += w * ((df/dp)^T lam)_j  for entries the calling thread OWNS
+//                                                                (one thread per entry: MLP weights, a dense matrix), or
+//                                                                acc[q] += w * (partial of parameter ACC0 + q over this thread's
+//                                                                components) for parameters that every component feeds (PDE
+//                                                                coefficients): reduced over the workgroup ONCE, at the end of the sweep
+// Every thread of the workgroup calls them with the same arguments; inside, work is split by `tid` (HIPADJ_W_FOR) and `wg_sync()`
+// separates dependent phases (hidden layers); `ws` is NW doubles of LDS scratch.  Inputs are complete on entry; the framework
+// synchronises after the call.  The bodies are HIP C++ text compiled by hiprtc into the kernels below (hipadj_user.hpp).
+//
+// Threads own components c = tid + q T (q < Q): lambda, the Runge-Kutta accumulators and the knot slices live in registers per
+// owned component; only what other threads must see goes through LDS (the stage state y, the stage adjoint ls, the VJP output).
+// Layouts are trajectory-major (a workgroup streams its own contiguous knots): knots [N][S+1][2][n] (u_k, f(u_k));
+// out / cotangents [N][M][n] in the caller's layout, used in place; Backsolve checkpoints [N][nck][n]; Quadrature's dense adjoint
+// record [N][S][4][n]; per-trajectory gradient rows dp_traj [N][np].
+//
+// What is restated (reference = SciMLSensitivity.jl), same arithmetic as the other families (oracle-checked):
+//   Interpolating RHS   src/interpolating_adjoint.jl:150-174      Backsolve  src/backsolve_adjoint.jl:32-61, 523-546
+//   Gauss               src/gauss_adjoint.jl:118-128, 745-759, 809-851   Quadrature  src/quadrature_adjoint.jl:35-46, 486-502, 510-616
+//   loss jumps          src/adjoint_common.jl:754-821              RK4 + cubic Hermite dense output [upstream-recall], SURVEY.md A.8
+#pragma once
+
+#if !defined(__HIPCC_RTC__)
+#include <hip/hip_runtime.h>
+#endif
+#include "hipadj_lane.hpp"
+
+namespace hipadj {
+
+struct WideGeom {
+    long N;
+    int S, M, nck;
+    double t0, dt, loss_shift;
+    int loss_kind, no_start, p_shared;
+};
+
+// Gauss-Kronrod (7,15) tables (QuadGK order 7), runtime-indexed by the rolled node loop
+__constant__ double cw_gk_x[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
+                                  0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
+                                  0.586087235467691130294144838258730, 0.405845151377397166906606412076961,
+                                  0.207784955007898467600689403773245, 0.0};
+__constant__ double cw_gk_wk[8] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
+                                   0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
+                                   0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
+                                   0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
+__constant__ double cw_gk_wg[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
+                                   0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
+
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+
+// workgroup barrier of the SPMD bodies: a single wavefront only needs its LDS traffic ordered
+template <int T> __device__ __forceinline__ void wide_sync() {
+    if constexpr (T == 64) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+    else __syncthreads();
+}
+
+// workgroup sum of K per-thread values into out[0..K) (LDS), fixed order: shuffle tree per wave, then the waves in order
+template <int T, int K>
+__device__ __forceinline__ void wide_block_sum(const double (&v)[K], double* __restrict__ red /* LDS [T/64][K] */, double* __restrict__ out /* LDS [K] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        double x = v[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) red[wv * K + j] = x;
+    }
+    wide_sync<T>();
+    if ((int)threadIdx.x < K) { double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) s += red[w * K + threadIdx.x];
+        out[threadIdx.x] = s; }
+    wide_sync<T>();
+}
+
+template <class Mo> struct WideShape {
+    static constexpr int N = Mo::N, NP = Mo::NP, T = Mo::T, NW = Mo::NW > 0 ? Mo::NW : 1, NACC = Mo::NACC, NA = Mo::NACC > 0 ? Mo::NACC : 1;
+    static constexpr int Q = (N + T - 1) / T;                 // owned components per thread
+    static constexpr int QP = (NP + T - 1) / T;               // owned parameter entries per thread (zeroing / writing gp)
+    static constexpr bool GP_LDS = NP <= 8192;                // the gradient accumulator of a sweep: LDS up to 64 KB, else the trajectory's dp row in HBM
+    static_assert(T % 64 == 0 && T >= 64 && T <= 1024, "threads per trajectory: a multiple of 64 up to 1024");
+};
+
+// ---- forward solve: fixed-step RK4, knots (u_k, f(u_k)), out = sol(ts) on the grid, Backsolve's checkpoints and y(T) --------------------------
+template <class Mo>
+__global__ void __launch_bounds__(Mo::T) k_wide_forward(WideGeom g, const double* __restrict__ u0, const double* __restrict__ p, double* __restrict__ knots,
+                                                        double* __restrict__ out, const int* __restrict__ save_of_knot, double* __restrict__ ckpt,
+                                                        const int* __restrict__ ckpt_of_knot, double* __restrict__ yT) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, T = W::T, Q = W::Q;
+    __shared__ double us[N], du[N], ws[W::NW];
+    const long traj = blockIdx.x; const int tid = threadIdx.x;
+    const double* pp = g.p_shared ? p : p + traj * W::NP;
+    double u[Q], k1[Q], k2[Q], k3[Q], k4[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; u[q] = c < N ? u0[traj * N + c] : 0.0; }
+    auto rhs = [&](const double (&x)[Q], double t, double (&k)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) us[c] = x[q]; }
+        wide_sync<T>();
+        Mo::f(du, us, pp, t, ws, tid);
+        wide_sync<T>();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; k[q] = c < N ? du[c] : 0.0; }
+    };
+    const double dt = g.dt;
+    for (int k = 0; k <= g.S; ++k) {
+        const double t = g.t0 + k * dt;
+        rhs(u, t, k1);
+        if (knots) { double* kn = knots + ((traj * (g.S + 1) + k) * 2) * N;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { kn[c] = u[q]; kn[N + c] = k1[q]; } } }
+        if (out) { const int s = save_of_knot[k]; if (s >= 0) { double* o = out + (traj * g.M + s) * N;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) o[c] = u[q]; } } }
+        if (ckpt) { const int s = ckpt_of_knot[k]; if (s >= 0) { double* o = ckpt + (traj * g.nck + s) * N;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) o[c] = u[q]; } } }
+        if (k == g.S) break;
+        double s_[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) s_[q] = u[q] + 0.5 * dt * k1[q];
+        rhs(s_, t + 0.5 * dt, k2);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) s_[q] = u[q] + 0.5 * dt * k2[q];
+        rhs(s_, t + 0.5 * dt, k3);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) s_[q] = u[q] + dt * k3[q];
+        rhs(s_, t + dt, k4);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) u[q] = u[q] + (dt / 6.0) * (k1[q] + 2.0 * (k2[q] + k3[q]) + k4[q]);
+    }
+    if (yT) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) yT[traj * N + c] = u[q]; } }
+}
+
+// ---- shared pieces of the reverse sweeps -----------------------------------------------------------------------------------------
+template <class Mo> struct WKnot { double u[WideShape<Mo>::Q], f[WideShape<Mo>::Q]; };
+
+template <class Mo>
+__device__ __forceinline__ void wide_load_knot(const double* __restrict__ knots, const WideGeom& g, long traj, int k, WKnot<Mo>& kn) {
+    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q;
+    const double* b = knots + ((traj * (g.S + 1) + k) * 2) * N;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; kn.u[q] = c < N ? b[c] : 0.0; kn.f[q] = c < N ? b[N + c] : 0.0; }
+}
+
+// lam += dgdu_discrete at loss time s (src/adjoint_common.jl:771-773, 812-813): the cotangent column, or y - shift
+template <class Mo>
+__device__ __forceinline__ void wide_jump(const WideGeom& g, long traj, int s, const double* __restrict__ cot, const double (&y)[WideShape<Mo>::Q],
+                                          double (&lam)[WideShape<Mo>::Q]) {
+    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q;
+    if (g.loss_kind == 0) {
+        const double* c_ = cot + (traj * g.M + s) * N;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) lam[q] += c_[c]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) lam[q] += y[q] - g.loss_shift;
+    }
+}
+
+// the LDS tiles of one sweeping workgroup
+template <class Mo> struct WideTiles { double *y, *ls, *dl, *gp, *ws, *red; };
+
+// one evaluation of the model's joint VJP at stage state yv with stage adjoint lv: publishes both, returns (df/du)^T lv at the owned components
+template <class Mo, bool WP, bool PUBY = true>
+__device__ __forceinline__ void wide_vjp(const WideTiles<Mo>& L, const double* __restrict__ pp, double t, double w, const double (&yv)[WideShape<Mo>::Q],
+                                         const double (&lv)[WideShape<Mo>::Q], double (&acc)[WideShape<Mo>::NA], double (&v)[WideShape<Mo>::Q]) {
+    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { if (PUBY) L.y[c] = yv[q]; L.ls[c] = lv[q]; } }
+    wide_sync<T>();
+    Mo::template vjp<WP>(L.dl, L.gp, acc, w, L.ls, L.y, pp, t, L.ws, tid);
+    wide_sync<T>();
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; v[q] = c < N ? L.dl[c] : 0.0; }
+}
+
+// One reverse RK4 step of lam (and, WP, the parameter sums) through [t_k, t_{k+1}] on the common grid: stage states from two knots
+// (theta = 0, 1/2, 1).  Returns V1 = (df/du)^T lam at the step's start (Gauss / Quadrature reuse it as the Hermite slope).
+template <class Mo, bool WP>
+__device__ __forceinline__ void wide_rk4_step(const WideTiles<Mo>& L, const double* __restrict__ pp, double t_lo, double dt, const WKnot<Mo>& hi, const WKnot<Mo>& lo,
+                                              double (&lam)[WideShape<Mo>::Q], double (&acc)[WideShape<Mo>::NA], double (&v1)[WideShape<Mo>::Q]) {
+    constexpr int Q = WideShape<Mo>::Q;
+    const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
+    double m[Q], s[Q], a[Q], v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) m[q] = 0.5 * (lo.u[q] + hi.u[q]) + (0.125 * dt) * (lo.f[q] - hi.f[q]);
+    wide_vjp<Mo, WP>(L, pp, t_hi, dt / 6.0, hi.u, lam, acc, v1);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { a[q] = v1[q]; s[q] = lam[q] + (0.5 * dt) * v1[q]; }
+    wide_vjp<Mo, WP>(L, pp, t_mid, dt / 3.0, m, s, acc, v);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { a[q] += 2.0 * v[q]; s[q] = lam[q] + (0.5 * dt) * v[q]; }
+    wide_vjp<Mo, WP, false>(L, pp, t_mid, dt / 3.0, m, s, acc, v);          // stages 2 and 3 share the Hermite midpoint: y stays published
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { a[q] += 2.0 * v[q]; s[q] = lam[q] + dt * v[q]; }
+    wide_vjp<Mo, WP>(L, pp, t_lo, dt / 6.0, lo.u, s, acc, v);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = lam[q] + (dt / 6.0) * (a[q] + v[q]);
+}
+
+template <class Mo>
+__device__ __forceinline__ void wide_zero_gp(const WideTiles<Mo>& L) {
+    constexpr int NP = Mo::NP, T = Mo::T;
+    for (int j = threadIdx.x; j < NP; j += T) L.gp[j] = 0.0;
+    wide_sync<T>();
+}
+
+// du0 = lam(t0); dp row = gp (+ the workgroup sums of the per-thread partials); non-finite scan (the reference's retcode check)
+template <class Mo>
+__device__ __forceinline__ void wide_finish(const WideGeom& g, long traj, const WideTiles<Mo>& L, const double (&lam)[WideShape<Mo>::Q], const double (&acc)[WideShape<Mo>::NA],
+                                            double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) { du0[traj * N + c] = lam[q]; bad |= !(fabs(lam[q]) <= 1.79769313486231570e308); } }
+    if (dp_traj) {
+        wide_sync<T>();
+        if constexpr (W::NACC > 0) {
+            __shared__ double accsum[W::NA];
+            wide_block_sum<T, W::NA>(acc, L.red, accsum);
+            if ((int)threadIdx.x < W::NACC) L.gp[Mo::ACC0 + threadIdx.x] += accsum[threadIdx.x];
+            wide_sync<T>();
+        }
+        double* row = dp_traj + traj * NP;
+        for (int j = threadIdx.x; j < NP; j += T) { const double v = L.gp[j]; bad |= !(fabs(v) <= 1.79769313486231570e308); if (W::GP_LDS) row[j] = v; }
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+// ---- InterpolatingAdjoint (ALG = 0) and GaussAdjoint (ALG = 2): one sweep; Gauss integrates lam only and adds the 2-node Gauss-Legendre sum of
+// f_p^T lam per step with lam from the adjoint step's own Hermite interpolant (IntegratingSumCallback [upstream-recall], src/gauss_adjoint.jl:809-851)
+template <class Mo, int ALG>
+__global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
+                                                        const int* __restrict__ save_of_knot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1];
+    const long traj = blockIdx.x;
+    const double* pp = g.p_shared ? p : p + traj * NP;
+    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
+    wide_zero_gp<Mo>(L);
+    double lam[Q], acc[W::NA];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
+    WKnot<Mo> hi, lo, nx;
+    wide_load_knot<Mo>(knots, g, traj, g.S, hi);
+    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam); }   // PresetTimeCallback fires at initialisation when T is a loss time
+    wide_load_knot<Mo>(knots, g, traj, g.S - 1, lo);
+    const double dt = g.dt, xg = 0.5773502691896257645;
+    for (int k = g.S - 1; k >= 0; --k) {
+        wide_load_knot<Mo>(knots, g, traj, k > 0 ? k - 1 : 0, nx);        // one knot ahead of the step
+        const double t_lo = g.t0 + k * dt;
+        double v1[Q];
+        if (ALG == 0) {
+            wide_rk4_step<Mo, true>(L, pp, t_lo, dt, hi, lo, lam, acc, v1);
+        } else {
+            double h0[Q], v5[Q], dacc[W::NA] = {};
+#pragma unroll
+            for (int q = 0; q < Q; ++q) h0[q] = lam[q];
+            wide_rk4_step<Mo, false>(L, pp, t_lo, dt, hi, lo, lam, dacc, v1);
+            wide_vjp<Mo, false>(L, pp, t_lo, 0.0, lo.u, lam, dacc, v5);     // fsallast: (df/du)^T lam_new at u_k
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq) {
+                const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
+                double gl[Q], yv[Q], dd[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    // adjoint-step Hermite (h = -dt; derivatives -v1 at the start, -v5 at the end); forward Hermite at theta_f = 1 - th on [t_k, t_{k+1}]
+                    gl[q] = (1.0 - th) * h0[q] + th * lam[q] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lam[q] - h0[q]) + (th - 1.0) * (-dt) * (-v1[q]) + th * (-dt) * (-v5[q]));
+                    yv[q] = (1.0 - tf) * lo.u[q] + tf * hi.u[q] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (hi.u[q] - lo.u[q]) + (tf - 1.0) * dt * lo.f[q] + tf * dt * hi.f[q]);
+                }
+                wide_vjp<Mo, true>(L, pp, t_lo + tf * dt, 0.5 * dt, yv, gl, acc, dd);
+            }
+        }
+        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) wide_jump<Mo>(g, traj, s, cot, lo.u, lam); }
+        hi = lo; lo = nx;
+    }
+    wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
+}
+
+// ---- BacksolveAdjoint: z = [lam; mu; y] integrated backward jointly, y overwritten by the stored forward value at every checkpoint knot, loss gradient at
+// the (possibly just overwritten) backsolved y (src/backsolve_adjoint.jl:32-61, 523-546; src/adjoint_common.jl:765-767; no_start is not consulted) ----
+template <class Mo>
+__global__ void __launch_bounds__(Mo::T) k_wide_backsolve(WideGeom g, const double* __restrict__ p, const double* __restrict__ yT, const double* __restrict__ ckpt,
+                                                          const int* __restrict__ ckpt_of_knot, const double* __restrict__ cot, const int* __restrict__ save_of_knot,
+                                                          double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    __shared__ double sy[N], sls[N], sdl[N], sdu[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1];
+    const long traj = blockIdx.x; const int tid = threadIdx.x;
+    const double* pp = g.p_shared ? p : p + traj * NP;
+    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
+    wide_zero_gp<Mo>(L);
+    double lam[Q], y[Q], acc[W::NA];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; lam[q] = 0.0; y[q] = c < N ? yT[traj * N + c] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
+    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y, lam); }
+    // one stage: f AND the joint VJP at the same published stage state
+    auto stage = [&](const double (&yv)[Q], const double (&lv)[Q], double t, double w, double (&F)[Q], double (&V)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { sy[c] = yv[q]; sls[c] = lv[q]; } }
+        wide_sync<T>();
+        Mo::f(sdu, sy, pp, t, sws, tid);
+        wide_sync<T>();                                               // f and vjp share the model's scratch
+        Mo::template vjp<true>(sdl, L.gp, acc, w, sls, sy, pp, t, sws, tid);
+        wide_sync<T>();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; F[q] = c < N ? sdu[c] : 0.0; V[q] = c < N ? sdl[c] : 0.0; }
+    };
+    const double dt = g.dt;
+    for (int k = g.S - 1; k >= 0; --k) {
+        const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
+        double F1[Q], F[Q], V[Q], Ys[Q], ls[Q], Fa[Q], Va[Q];
+        stage(y, lam, t_hi, dt / 6.0, F1, V);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { Fa[q] = F1[q]; Va[q] = V[q]; Ys[q] = y[q] - (0.5 * dt) * F1[q]; ls[q] = lam[q] + (0.5 * dt) * V[q]; }
+        stage(Ys, ls, t_mid, dt / 3.0, F, V);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { Fa[q] += 2.0 * F[q]; Va[q] += 2.0 * V[q]; Ys[q] = y[q] - (0.5 * dt) * F[q]; ls[q] = lam[q] + (0.5 * dt) * V[q]; }
+        stage(Ys, ls, t_mid, dt / 3.0, F, V);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { Fa[q] += 2.0 * F[q]; Va[q] += 2.0 * V[q]; Ys[q] = y[q] - dt * F[q]; ls[q] = lam[q] + dt * V[q]; }
+        stage(Ys, ls, t_lo, dt / 6.0, F, V);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { lam[q] = lam[q] + (dt / 6.0) * (Va[q] + V[q]); y[q] = y[q] - (dt / 6.0) * (Fa[q] + F[q]); }
+        if (ckpt) { const int c0 = ckpt_of_knot[k]; if (c0 >= 0) { const double* src = ckpt + (traj * g.nck + c0) * N;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) y[q] = src[c]; } } }
+        { const int s = save_of_knot[k]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y, lam); }
+    }
+    wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
+}
+
+// ---- QuadratureAdjoint pass 1: lambda-only sweep recording (lam_start, lam'_start, lam_end, lam'_end) per step = the dense adjoint solution
+// (src/quadrature_adjoint.jl:527-530) with the Hermite data of a fixed-step solver -------------------------------------------------------------
+template <class Mo>
+__global__ void __launch_bounds__(Mo::T) k_wide_quad_adj(WideGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
+                                                         const int* __restrict__ save_of_knot, double* __restrict__ adj, double* __restrict__ du0, int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW];
+    const long traj = blockIdx.x; const int tid = threadIdx.x;
+    const double* pp = g.p_shared ? p : p + traj * NP;
+    WideTiles<Mo> L{sy, sls, sdl, nullptr, sws, nullptr};
+    double lam[Q], dacc[W::NA] = {};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = 0.0;
+    WKnot<Mo> hi, lo, nx;
+    wide_load_knot<Mo>(knots, g, traj, g.S, hi);
+    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam); }
+    wide_load_knot<Mo>(knots, g, traj, g.S - 1, lo);
+    const double dt = g.dt;
+    for (int k = g.S - 1; k >= 0; --k) {
+        wide_load_knot<Mo>(knots, g, traj, k > 0 ? k - 1 : 0, nx);
+        double* rec = adj + ((traj * g.S + k) * 4) * N;
+        double v1[Q], v5[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) rec[c] = lam[q]; }
+        wide_rk4_step<Mo, false>(L, pp, g.t0 + k * dt, dt, hi, lo, lam, dacc, v1);
+        wide_vjp<Mo, false>(L, pp, g.t0 + k * dt, 0.0, lo.u, lam, dacc, v5);            // slope at the end of the step, before the jump
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { rec[N + c] = -v1[q]; rec[2 * N + c] = lam[q]; rec[3 * N + c] = -v5[q]; } }
+        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) wide_jump<Mo>(g, traj, s, cot, lo.u, lam); }
+        hi = lo; lo = nx;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { du0[traj * N + c] = lam[q]; bad |= !(fabs(lam[q]) <= 1.79769313486231570e308); } }
+    if (bad) atomicOr(flag, 1);
+}
+
+// ---- QuadratureAdjoint pass 2: workgroup (trajectory, loss interval) runs quadgk(t -> f_p(y(t))^T lam(t), a, b; atol, rtol) with workgroup-uniform
+// decisions (src/quadrature_adjoint.jl:486-502, 537-616; QuadGK [upstream-recall]: (7,15) rule, Euclidean norm over the np entries, bisect the
+// segment with the largest error until E <= max(atol, rtol |I|)).  Vectors of np entries (Kronrod / Gauss sums of a panel, the integrand, the
+// segments' integrals) live in a per-workgroup HBM scratch [3 + MAXSEG][np]; at most MAXSEG segments (documented cap).
+template <class Mo, int MAXSEG>
+__global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ adj,
+                                                        const double* __restrict__ qa, const double* __restrict__ qb, double atol, double rtol,
+                                                        double* __restrict__ scratch, double* __restrict__ qres) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * (2 * W::NA > 2 ? 2 * W::NA : 2)], sacc[2 * W::NA], sfi[W::GP_LDS ? NP : 1];
+    __shared__ double seg_a[MAXSEG], seg_b[MAXSEG], seg_E[MAXSEG], sn[2];
+    const long traj = blockIdx.x; const int qi = blockIdx.y, tid = threadIdx.x, nq = gridDim.y;
+    const double* pp = g.p_shared ? p : p + traj * NP;
+    double* base = scratch + ((traj * nq + qi) * (long)(3 + MAXSEG)) * NP;
+    double *IK = base, *IG = base + NP, *fig = base + 2 * NP, *segI = base + 3 * NP;   // Kronrod sum, Gauss sum, integrand (HBM form), segment integrals
+    double* fi = W::GP_LDS ? sfi : fig;
+    WideTiles<Mo> L{sy, sls, sdl, fi, sws, sred};
+
+    // integrand at time t: y = sol(t) (forward Hermite), lam = adj_sol(t) (the record's Hermite), f_p^T lam into fi[] and the per-thread partials
+    auto integrand = [&](double t, double (&part)[W::NA]) {
+        int k = (int)((t - g.t0) / g.dt);
+        if (k < 0) k = 0;
+        if (k > g.S - 1) k = g.S - 1;
+        if (t < g.t0 + k * g.dt && k > 0) --k;
+        if (t > g.t0 + (k + 1) * g.dt && k < g.S - 1) ++k;
+        const double thf = (t - (g.t0 + k * g.dt)) / g.dt, tha = 1.0 - thf;
+        const double* b0 = knots + ((traj * (g.S + 1) + k) * 2) * N;
+        const double* b1 = b0 + 2 * N;
+        const double* r = adj + ((traj * g.S + k) * 4) * N;
+        double yv[Q], lv[Q], dd[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int c = tid + q * T;
+            if (c < N) {
+                { const double u0_ = b0[c], f0 = b0[N + c], u1 = b1[c], f1 = b1[N + c];
+                  yv[q] = (1.0 - thf) * u0_ + thf * u1 + thf * (thf - 1.0) * ((1.0 - 2.0 * thf) * (u1 - u0_) + (thf - 1.0) * g.dt * f0 + thf * g.dt * f1); }
+                { const double l0 = r[c], d0 = r[N + c], l1 = r[2 * N + c], d1 = r[3 * N + c];
+                  lv[q] = (1.0 - tha) * l0 + tha * l1 + tha * (tha - 1.0) * ((1.0 - 2.0 * tha) * (l1 - l0) + (tha - 1.0) * (-g.dt) * d0 + tha * (-g.dt) * d1); }
+            } else { yv[q] = 0.0; lv[q] = 0.0; }
+        }
+        for (int j = tid; j < NP; j += T) fi[j] = 0.0;
+#pragma unroll
+        for (int q = 0; q < W::NA; ++q) part[q] = 0.0;
+        wide_vjp<Mo, true>(L, pp, t, 1.0, yv, lv, part, dd);             // its leading barrier also orders the zeroing of fi
+    };
+    // one GK15 panel: IK / IG <- h * (Kronrod / Gauss sums); returns E = |IK - IG|_2, identical in every thread
+    auto panel = [&](double a, double b) -> double {
+        const double c = 0.5 * (a + b), h = 0.5 * (b - a);
+        double ak[W::NA], ag[W::NA], part[W::NA];
+#pragma unroll
+        for (int q = 0; q < W::NA; ++q) { ak[q] = 0.0; ag[q] = 0.0; }
+        for (int j = tid; j < NP; j += T) { IK[j] = 0.0; IG[j] = 0.0; }
+#pragma unroll 1
+        for (int e = 0; e < 15; ++e) {
+            const int jj = e < 7 ? e : (e < 14 ? e - 7 : 7);
+            const double xj = cw_gk_x[jj], wk = cw_gk_wk[jj], wg = (jj & 1) ? cw_gk_wg[jj >> 1] : 0.0;
+            integrand(e < 7 ? c - h * xj : (e < 14 ? c + h * xj : c), part);
+            const double wgc = e == 14 ? cw_gk_wg[3] : wg;
+            for (int j = tid; j < NP; j += T) { const double f = fi[j]; IK[j] += wk * f; IG[j] += wgc * f; }   // each entry by its own thread, every node
+#pragma unroll
+            for (int q = 0; q < W::NA; ++q) { ak[q] += wk * part[q]; ag[q] += wgc * part[q]; }
+            wide_sync<T>();                                              // fi is zeroed again by the next node
+        }
+        if constexpr (W::NACC > 0) {                                     // parameters fed by every component: one workgroup sum per panel
+            double both[2 * W::NA];
+#pragma unroll
+            for (int q = 0; q < W::NA; ++q) { both[q] = ak[q]; both[W::NA + q] = ag[q]; }
+            wide_block_sum<T, 2 * W::NA>(both, sred, sacc);
+            if (tid < W::NACC) { IK[Mo::ACC0 + tid] += sacc[tid]; IG[Mo::ACC0 + tid] += sacc[W::NA + tid]; }
+            wide_sync<T>();
+        }
+        double e2[1] = {0.0};
+        for (int j = tid; j < NP; j += T) { const double ik = IK[j] * h, ig = IG[j] * h; IK[j] = ik; e2[0] += (ik - ig) * (ik - ig); }
+        wide_block_sum<T, 1>(e2, sred, sn);
+        return sqrt(sn[0]);
+    };
+    auto norm_of = [&](const double* v) -> double {                      // |v|_2 over np entries, workgroup-uniform
+        double s2[1] = {0.0};
+        for (int j = tid; j < NP; j += T) s2[0] += v[j] * v[j];
+        wide_block_sum<T, 1>(s2, sred, sn + 1);
+        return sqrt(sn[1]);
+    };
+    // quadgk: bisect the worst segment until E <= max(atol, rtol |I|).  Itot lives in the qres row of this (trajectory, interval).
+    double* Itot = qres + ((traj * nq + qi) * (long)NP);
+    double E = 0.0;
+    int ns = 0;
+    {
+        const double En = panel(qa[qi], qb[qi]);
+        for (int j = tid; j < NP; j += T) { segI[j] = IK[j]; Itot[j] = IK[j]; }
+        if (tid == 0) { seg_a[0] = qa[qi]; seg_b[0] = qb[qi]; seg_E[0] = En; }
+        E = En; ns = 1;
+        wide_sync<T>();
+    }
+    for (;;) {
+        const double nrm = norm_of(Itot);
+        const double tol = atol > rtol * nrm ? atol : rtol * nrm;
+        if (E <= tol || ns + 1 > MAXSEG) break;
+        int wi = 0;
+        for (int s2 = 1; s2 < ns; ++s2) if (seg_E[s2] > seg_E[wi]) wi = s2;
+        const double wa = seg_a[wi], wb = seg_b[wi], mid = 0.5 * (wa + wb);
+        if (!(mid > (wa < wb ? wa : wb) && mid < (wa < wb ? wb : wa))) break;
+        const double oE = seg_E[wi];
+        wide_sync<T>();
+        const double E1 = panel(wa, mid);                                 // first half replaces segment wi
+        for (int j = tid; j < NP; j += T) { Itot[j] += IK[j] - segI[(long)wi * NP + j]; segI[(long)wi * NP + j] = IK[j]; }
+        wide_sync<T>();
+        const double E2 = panel(mid, wb);                                 // second half becomes segment ns
+        for (int j = tid; j < NP; j += T) { Itot[j] += IK[j]; segI[(long)ns * NP + j] = IK[j]; }
+        if (tid == 0) { seg_b[wi] = mid; seg_E[wi] = E1; seg_a[ns] = mid; seg_b[ns] = wb; seg_E[ns] = E2; }
+        E += E1 + E2 - oE;
+        ++ns;
+        wide_sync<T>();
+    }
+    // QuadGK re-sums the accepted segments at the end (heap order; here in list order): Itot = sum of the segment integrals
+    wide_sync<T>();
+    for (int j = tid; j < NP; j += T) { double s = 0.0; for (int q = 0; q < ns; ++q) s += segI[(long)q * NP + j]; Itot[j] = s; }
+}
+
+// dp_traj[traj][j] = sum over the loss intervals of qres[traj][qi][j], in interval order (src/quadrature_adjoint.jl:563-616)
+static __global__ void k_wide_quad_sum(long N, int NP, int nq, const double* __restrict__ qres, double* __restrict__ dp_traj) {
+    const long traj = blockIdx.x;
+    for (int j = threadIdx.x; j < NP; j += blockDim.x) {
+        double s = 0.0;
+        for (int q = 0; q < nq; ++q) s += qres[(traj * nq + q) * (long)NP + j];
+        dp_traj[traj * NP + j] = s;
+    }
+}
+
+// dp[j] = sum over trajectories of dp_traj[traj][j], fixed order (shared parameters); rows: the per-trajectory gradient is the result
+static __global__ void k_wide_reduce_dp(long N, int NP, const double* __restrict__ dp_traj, double* __restrict__ dp, int* __restrict__ flag) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= NP) return;
+    double s = 0.0;
+    for (long i = 0; i < N; ++i) s += dp_traj[i * NP + j];
+    if (!(fabs(s) <= 1.79769313486231570e308)) atomicOr(flag, 1);
+    dp[j] = s;
+}
+
+#endif  // device code
+
+// a stand-in model with the shape of a generated one: lets the host translation unit name the kernels' parameter lists (usig) without instantiating them
+struct WideProbe {
+    static constexpr int N = 64, NP = 4, T = 64, NW = 1, NACC = 0, ACC0 = 0;
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+    static __device__ void f(double*, const double*, const double*, double, double*, int) {}
+    template <bool WP> static __device__ void vjp(double*, double*, double (&)[1], double, const double*, const double*, const double*, double, double*, int) {}
+#endif
+};
+
+}  // namespace hipadj

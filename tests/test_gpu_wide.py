@@ -1,0 +1,106 @@
+"""The workgroup-per-trajectory family of runtime models (csrc/hipadj_wide.hpp; `-m gpu`): parity against the CPU oracle on the same
+seeded inputs, rtol 1e-6 (Float64), for all four sensealgs.
+
+  (i)   the reference's matrix-state problem, a 30 x 50 state with df[i, j] = p1 i + p2 j (test/Core5/size_handling_adjoint.jl:37-70; the
+        reference asserts that every VJP backend gives the same dp) — also against the closed form: u(t) = u0 + t (p1 i + p2 j)
+  (ii)  the 2 -> 50 -> 2 neural ODE of the reference's published benchmark (docs/src/Benchmark.md:62: Chain(x -> x.^3, Dense(2, 50, tanh), Dense(50, 2)),
+        u0 = [2, 0], tspan = (0, 1.5), 30 loss times, loss = sum(abs2, data - pred)) as a runtime model (252 parameters)
+  (iii) dense linear maps u' = A u with every entry of A a parameter: np = n^2 = 576 (gradient accumulator in LDS) and 10 000 (in HBM)
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from test_gpu_parity import RTOL, rel, ALGS
+
+pytestmark = pytest.mark.gpu
+
+
+def _alg(sa, name):
+    return dict(interpolating=sa.InterpolatingAdjoint(), backsolve=sa.BacksolveAdjoint(), gauss=sa.GaussAdjoint(), quadrature=sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10))[name]
+
+
+def _run(sa, fun, oname, dims, u0, p, T, dt, ts, alg, oalg, delta_of_out, p_shared=True):
+    """device gradient and oracle gradient for the loss whose cotangents are delta_of_out(out)"""
+    N = len(u0)
+    ens = sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p if p_shared else p[0]), u0, None if p_shared else p)
+    sol = sa.solve(ens, sa.RK4(), dt=dt, saveat=ts, sensealg=_alg(sa, alg))
+    ref = O.Problem(oname, alg=oalg, stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", dims=dims, checkpointing=(oalg == "BACKSOLVE"),
+                    quad_abstol=1e-10, quad_reltol=1e-10)
+    out_ref = np.stack([ref.forward(u0[i], p if p_shared else p[i])[0] for i in range(N)])
+    assert rel(sol.u, out_ref) < 1e-12
+    delta = delta_of_out(sol.u)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    sol.engine.close()
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, delta)
+    return du0, dp, rdu0, rdp, sol.u
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_reference_matrix_state_30x50(sa, alg, oalg):
+    R, Cc, T, dt = 30, 50, 1.0, 0.01
+    ts = np.linspace(0.0, T, 11)
+    rng = np.random.default_rng(7)
+    N = 3
+    u0 = rng.standard_normal((N, R * Cc)); p = rng.random(2)
+    fun = sa.WideDeviceFunction.index_affine(f"idxaff_{alg}", R, Cc)
+    du0, dp, rdu0, rdp, out = _run(sa, fun, "IDXAFF", (R, Cc, 0, 0), u0, p, T, dt, ts, alg, oalg, lambda o: 2.0 * o)     # l = sum(abs2, sol)
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    # closed form: u_c(t) = u0_c + t (p1 i + p2 j)  =>  dl/dp1 = sum_s sum_c 2 u_c(t_s) t_s i_c, dl/du0 = sum_s 2 u(t_s)
+    ii = np.tile(np.arange(1, R + 1), Cc).astype(float); jj = np.repeat(np.arange(1, Cc + 1), R).astype(float)
+    ex = np.zeros(2); exu = np.zeros_like(u0)
+    for t in ts:
+        u = u0 + t * (p[0] * ii + p[1] * jj)
+        ex += [np.sum(2 * u * t * ii), np.sum(2 * u * t * jj)]; exu += 2 * u
+    assert rel(dp, ex) < 1e-9 and rel(du0, exu) < 1e-9
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("N", [1, 5])
+def test_benchmark_neural_ode_2_50_2(sa, alg, oalg, N):
+    d, H, T = 2, 50, 1.5
+    ts = np.linspace(0.0, T, 30)                       # range(tspan..., length = 30)
+    dt = T / (29 * 8)                                  # every loss time on the step grid
+    rng = np.random.default_rng(100)
+    p = np.concatenate([rng.standard_normal(H * d) * np.sqrt(1.0 / d), np.zeros(H), rng.standard_normal(d * H) * np.sqrt(1.0 / H), np.zeros(d)]) * 0.5
+    u0 = np.array([2.0, 0.0]) + 0.05 * rng.standard_normal((N, d)); u0[0] = [2.0, 0.0]
+    data = rng.standard_normal((N, len(ts), d))
+    fun = sa.WideDeviceFunction.dense_chain(f"node_{alg}_{N}", (d, H, d), input_power=3)
+    du0, dp, rdu0, rdp, _ = _run(sa, fun, "MLP1", (d, H, 0, 0), u0, p, T, dt, ts, alg, oalg, lambda o: 2.0 * (o - data))
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL and dp.shape == (252,)
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("n", [24, 100])
+def test_dense_linear_map_every_entry_a_parameter(sa, alg, oalg, n):
+    T, dt = 1.0, 0.02
+    ts = np.linspace(0.0, T, 6)
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)
+    p = A.flatten(order="F")
+    N = 2
+    u0 = rng.standard_normal((N, n))
+    w = rng.standard_normal((N, len(ts), n))
+    fun = sa.WideDeviceFunction.dense_linear(f"lin{n}_{alg}", n)
+    du0, dp, rdu0, rdp, _ = _run(sa, fun, "DENSELIN", (n, 0, 0, 0), u0, p, T, dt, ts, alg, oalg, lambda o: w)
+    assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL and dp.shape == (n * n,)
+
+
+def test_per_trajectory_parameters_and_lsq_loss(sa):
+    """p_shared = 0 (dp rows per trajectory) and the in-kernel loss dgdu = u - shift on a wide model"""
+    n, T, dt = 24, 1.0, 0.02
+    ts = np.linspace(0.0, T, 6)
+    rng = np.random.default_rng(3)
+    N = 4
+    P = np.stack([(rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)).flatten(order="F") for _ in range(N)])
+    u0 = rng.standard_normal((N, n))
+    fun = sa.WideDeviceFunction.dense_linear("lin24_rows", n)
+    ens = sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), P[0]), u0, P)
+    for alg, oalg in ALGS:
+        sol = sa.solve(ens, sa.RK4(), dt=dt, saveat=ts, sensealg=_alg(sa, alg), dgdu_discrete=sa.LsqShift(0.3), want_out=False)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts)
+        sol.engine.close()
+        ref = O.Problem("DENSELIN", alg=oalg, stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=0.3, dims=(n, 0, 0, 0),
+                        checkpointing=(oalg == "BACKSOLVE"), quad_abstol=1e-10, quad_reltol=1e-10)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, P)
+        assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL and dp.shape == (N, n * n), alg

@@ -1,0 +1,65 @@
+"""Wide runtime models (hipadj_wmodel_register, csrc/hipadj_wide.hpp) without a GPU: argument validation, the emitters of the host mirror,
+compilation of every kernel of the family for gfx950 with hiprtc (no device needed), and the planner's answers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_registration_validates_its_arguments(sa):
+    L = sa.load_library()
+    mid = C.c_int32()
+    f, v = b"HIPADJ_W_FOR(i, N) du[i] = -u[i];", b"HIPADJ_W_FOR(i, N) dlam[i] = -lam[i];"
+    bad = [(0, 4, 0, 0, 0, 0), (5000, 4, 0, 0, 0, 0), (16, 0, 0, 0, 0, 0), (16, 4, 100, 0, 0, 0), (16, 4, 2048, 0, 0, 0), (16, 4, 0, -1, 0, 0),
+           (16, 4, 0, 0, 17, 0), (16, 4, 0, 0, 3, 2), (4096, 4, 64, 0, 0, 0), (4096, 4, 0, 8000, 0, 0)]
+    for n, npar, T, nw, nacc, a0 in bad:
+        assert L.hipadj_wmodel_register(b"bad", n, npar, T, nw, nacc, a0, f, v, C.byref(mid)) == -1, (n, npar, T, nw, nacc, a0)
+    assert L.hipadj_wmodel_register(b"bad", 16, 4, 0, 0, 0, 0, None, v, C.byref(mid)) == -1
+    assert L.hipadj_wmodel_register(b"decay16", 16, 4, 0, 0, 0, 0, f, v, C.byref(mid)) == 0 and mid.value >= 1000
+    n, npar = C.c_int32(), C.c_int32()
+    assert L.hipadj_model_sizes(mid.value, (C.c_int32 * 4)(0, 0, 0, 0), C.byref(n), C.byref(npar)) == 0 and (n.value, npar.value) == (16, 4)
+    # the small-model entry point points at the wide one
+    assert L.hipadj_model_register(b"big", 9, 3, f, None, None, C.byref(mid)) == -1 and b"hipadj_wmodel_register" in L.hipadj_last_error(None)
+
+
+@pytest.mark.parametrize("make", ["chain", "chain3", "linear", "index"])
+def test_emitted_models_compile_for_gfx950(sa, make):
+    fun = dict(chain=lambda: sa.WideDeviceFunction.dense_chain("t_chain", (2, 50, 2), input_power=3),
+               chain3=lambda: sa.WideDeviceFunction.dense_chain("t_chain3", (3, 16, 24, 3)),
+               linear=lambda: sa.WideDeviceFunction.dense_linear("t_lin", 100),          # np = 10 000: the gradient accumulator moves to HBM
+               index=lambda: sa.WideDeviceFunction.index_affine("t_idx", 30, 50))[make]()
+    from scimlsensitivity_jl_amd import _lib
+    _lib.check_model(fun.id)      # forward + Interpolating / Gauss / Backsolve / Quadrature kernels; raises with the compiler log on an error
+
+
+def test_a_body_that_does_not_compile_is_reported_with_the_log(sa):
+    from scimlsensitivity_jl_amd import _lib
+    fun = sa.WideDeviceFunction("t_broken", 16, 2, "HIPADJ_W_FOR(i, N) du[i] = undefined_symbol;", "HIPADJ_W_FOR(i, N) dlam[i] = 0.0;")
+    with pytest.raises(sa.HipadjError, match="undefined_symbol"):
+        _lib.check_model(fun.id)
+
+
+def test_planner_answers_for_wide_models(sa):
+    from scimlsensitivity_jl_amd import _lib
+    L = sa.load_library()
+    fun = sa.WideDeviceFunction.dense_linear("t_plan", 12)
+    ts = np.linspace(0.0, 1.0, 6)
+
+    def check(**kw):
+        c = _lib.HipadjConfig()
+        c.struct_size = C.sizeof(_lib.HipadjConfig)
+        c.model, c.alg, c.stepper, c.ntraj, c.t0, c.t1, c.dt = fun.id, 0, 0, 3, 0.0, 1.0, 0.02
+        c.nsave, c.save_times = len(ts), ts.ctypes.data_as(C.POINTER(C.c_double))
+        c.p_shared, c.abstol, c.reltol = 1, 1e-6, 1e-3
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return L.hipadj_model_check_config(C.byref(c)), L.hipadj_last_error(None).decode()
+
+    for alg in (0, 1, 2, 3):
+        assert check(alg=alg, checkpointing=int(alg == 1))[0] == 0
+    rc, msg = check(stepper=1); assert rc == -6 and "fixed-step RK4" in msg
+    rc, msg = check(alg=4); assert rc == -6 and "GaussKronrod" in msg
+    rc, msg = check(cont_cost=1); assert rc == -6
+    rc, msg = check(alg=0, checkpointing=1); assert rc == -6 and "checkpointing" in msg
+    off = np.array([0.0, 0.333, 1.0])
+    rc, msg = check(nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double))); assert rc == -6 and "step grid" in msg
