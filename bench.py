@@ -165,11 +165,19 @@ class Runner:
         if native:
             # on the handle's OWN stream, before it is moved to torch's: a collective that hangs then blocks a stream nobody else uses
             native = self.native = self._try_native(sa, torch, dist, dev, world, make_engine)
-        self.eng.use_torch_stream()
+        # a real torch stream for the handle (torch's default "current stream" is the null stream, for which hipadj_set_stream keeps the handle's own
+        # stream): the region events, the caller's tensors and the torch.distributed all-reduce are all ordered on it
+        self.stream = None if STUB else torch.cuda.Stream(device=dev)
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self.eng.use_torch_stream()
+        else:
+            self.eng.use_torch_stream()
         self.u0 = torch.tensor(u0_np, device=dev, dtype=torch.float64)
         self.p = torch.tensor(p_np, device=dev, dtype=torch.float64)
         self.du0 = torch.empty((n_local, 3), device=dev, dtype=torch.float64)
         self.dps = [torch.empty(3, device=dev, dtype=torch.float64) for _ in range(2)]
+        self.sync()                                          # the tensors above were filled on torch's default stream
         self.eng.forward_dev(self.u0, self.p, None)          # forward solve: interpolant tiles now resident in HBM
         self.sync()
         self.eng.forward_dev(self.u0, self.p, None)          # once more: forward_solve_ms is the steady-state call, not the first launch (code load)
@@ -220,6 +228,12 @@ class Runner:
         return True
 
     def step(self):
+        if self.stream is None:
+            return self._step()
+        with self.torch.cuda.stream(self.stream):
+            return self._step()
+
+    def _step(self):
         # reverse pass of this step.  torch carrier: the all-reduce of dL/dp (RCCL, its own stream) overlaps the NEXT step's kernels —
         # dp is double-buffered and the previous step's reduction is only waited for here.  Native carrier: in-stream inside the call.
         dp = self.dps[self.it & 1]
@@ -252,11 +266,11 @@ class Runner:
         self.sync()
         t0 = time.perf_counter()
         if ev:
-            ev[0].record()
+            ev[0].record(self.stream)
         for _ in range(steps):
             self.step()
         if ev:
-            ev[1].record()
+            ev[1].record(self.stream)
         self.drain()
         self.sync()
         if self.world > 1:
@@ -356,6 +370,11 @@ def other_configs(sa, torch):
                         roofline=dict(bound="hbm", achieved=by / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       kernel="k_bruss_quad_adj", algorithmic_bytes_per_launch=by)))
         eng.close()
+    # ---- wide runtime models (csrc/hipadj_wide.hpp): the two problems the reference itself holds beyond 8 states / 32 parameters
+    try:
+        out += wide_rows(sa, run)
+    except Exception as e:
+        out.append(dict(config="wide runtime models", error=repr(e)))
     # configs[4] over the horizon the reference documents, tspan = (0, 11.5), loss times 0:0.5:11.5: 460 000 explicit RK4 steps at the diffusion
     # stability limit (the docs use the implicit FBDF); 15 GB of knots + 30 GB of dense lambda record in HBM
     try:
@@ -390,6 +409,49 @@ def self_launch(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def wide_rows(sa, run):
+    """The workgroup-per-trajectory family of runtime models on the reference's own two larger problems, each with the roofline that bounds it."""
+    rows = []
+    rng = np.random.default_rng(11)
+    # (i) the 30 x 50 matrix state of test/Core5/size_handling_adjoint.jl:37-70 (df[i,j] = p1 i + p2 j, saveat 0:0.1:1, l = sum(abs2, sol)): no arithmetic to
+    #     speak of, so an ensemble of them streams its knots: HBM-bound, 16 n bytes per trajectory and step (SURVEY.md 8d)
+    R, Cc, S, dt = 30, 50, 100, 0.01
+    n = R * Cc
+    ts = np.linspace(0.0, S * dt, 11)
+    fun = sa.WideDeviceFunction.index_affine("bench_idxaff", R, Cc)
+    for N in (1, 512):
+        eng = sa.Engine(fun.name, "interpolating", N, 0.0, S * dt, dt, save_times=ts)
+        ms, kms, st = run(eng, rng.standard_normal((N, n)), rng.random(2), rng.standard_normal((N, len(ts), n)), 5)
+        by = N * (S + 1) * 16.0 * n + N * len(ts) * 8.0 * n
+        rows.append(dict(config=f"wide model: the reference's 30 x 50 matrix state (test/Core5/size_handling_adjoint.jl), InterpolatingAdjoint, {S} RK4 steps, N = {N}, "
+                                f"{st['workspace_bytes'] / 1e6:.0f} MB workspace", reverse_ms=ms, sweep_kernel_ms=kms, us_per_step=kms * 1e3 / S,
+                         roofline=(dict(bound="hbm", achieved=by / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, kernel="k_wide_adjoint",
+                                        algorithmic_bytes_per_launch=by) if N > 1 else
+                                   dict(bound="latency", note="one workgroup on one CU: 4 joint-VJP calls per step, two workgroup barriers each", us_per_step=kms * 1e3 / S))))
+        eng.close()
+    # (ii) the neural ODE of docs/src/Benchmark.md:62 (Chain(x -> x.^3, Dense(2, 50, tanh), Dense(50, 2)), u0 = [2, 0], tspan (0, 1.5), 30 loss times) as a runtime model:
+    #      N = 1 is the reference's benchmark shape (its published gradient times on a CPU: 1.66 ms InterpolatingAdjoint / 2.48 ms BacksolveAdjoint with compiled
+    #      ReverseDiffVJP, adaptive Tsit5 — another stepper on other hardware, quoted for scale only); an ensemble of 4096 of them is FP64-VALU work
+    d, H, T = 2, 50, 1.5
+    ts = np.linspace(0.0, T, 30); dtn = T / (29 * 8); Sn = 29 * 8
+    fun = sa.WideDeviceFunction.dense_chain("bench_node", (d, H, d), input_power=3)
+    p = np.concatenate([rng.standard_normal(H * d) * 0.35, np.zeros(H), rng.standard_normal(d * H) * 0.07, np.zeros(d)])
+    flop_vjp = 10.0 * H * d + 2.0 * H + 2.0 * d            # forward recomputation + two transposed products + the outer products, 2 flop per multiply-add
+    for alg in ("interpolating", "backsolve"):
+        for N in (1, 4096):
+            eng = sa.Engine(fun.name, alg, N, 0.0, T, dtn, save_times=ts, checkpointing=(alg == "backsolve"))
+            u0 = np.array([2.0, 0.0]) + 0.05 * rng.standard_normal((N, d))
+            ms, kms, st = run(eng, u0, p, rng.standard_normal((N, len(ts), d)), 5)
+            fl = N * Sn * 4.0 * (flop_vjp + (6.0 * H * d if alg == "backsolve" else 0.0))
+            rows.append(dict(config=f"wide model: 2-50-2 neural ODE of docs/src/Benchmark.md as a runtime model (252 parameters), {alg}, {Sn} RK4 steps, N = {N}",
+                             forward_ms=st["forward_ms_last"], reverse_ms=ms, sweep_kernel_ms=kms, us_per_step=kms * 1e3 / Sn,
+                             roofline=dict(bound="fp64_valu" if N > 1 else "latency", achieved=fl / (kms * 1e-3) / 1e12, peak=FP64_VALU_PEAK_TF, unit="TFLOP/s",
+                                           frac=fl / (kms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, kernel="k_wide_adjoint" if alg == "interpolating" else "k_wide_backsolve",
+                                           note="one wavefront per trajectory, 50 of 64 lanes on the hidden layer; algorithmic flops (10 H d + 2 H + 2 d per joint VJP)")))
+            eng.close()
+    return rows
 
 
 def main():

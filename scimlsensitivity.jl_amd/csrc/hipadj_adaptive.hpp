@@ -144,6 +144,17 @@ HIPADJ_HD void poly_eval(double th, const double (&c)[5][NZ], double (&y)[NZ]) {
 // Returns the number of accepted steps, or -1 when max_steps was exceeded.
 struct NoPre { HIPADJ_HD void operator()(double) const {} };
 
+// w += sum_{j < S_} a(S_, j) K_j : the stage sum of stage S_ with exactly its S_ terms, in the oracle's order j = 0, 1, ...
+template <int NZ, int S_>
+HIPADJ_HD void tsit5_stage_sum(const KStore<NZ>& K, double (&w)[NZ]) {
+#pragma unroll
+    for (int j = 0; j < S_; ++j) {
+        const double a = TS5::a(S_, j);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) w[i] += a * K.get(j, i);
+    }
+}
+
 // pre(t) runs at the top of every step attempt, AFTER a pending k_1 = f(u, t) was evaluated: the checkpointed sweeps
 // switch their interval solution there, so that every evaluation AT a checkpoint time still reads the interval above
 // (as the reference's `t in interval` test does) and every stage below it reads the re-solved interval.
@@ -222,13 +233,16 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
 #pragma unroll
             for (int i = 0; i < NZ; ++i) w[i] = 0.0;
             if constexpr (NZ <= TS5_WIDE) {
-                double as[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) as[j] = TS5::a(s, j);
-#pragma unroll
-                for (int j = 0; j < 6; ++j)
-#pragma unroll
-                    for (int i = 0; i < NZ; ++i) w[i] += as[j] * K.get(j, i);
+                // only the s rows the tableau really has, coefficients as literals (round 3): the zero-padded 6-term form issued 36 NZ multiply-adds and
+                // LDS reads per step where 21 NZ are needed — the stage sums, not the right-hand side, were the larger half of a step's instructions
+                switch (s) {
+                case 1: tsit5_stage_sum<NZ, 1>(K, w); break;
+                case 2: tsit5_stage_sum<NZ, 2>(K, w); break;
+                case 3: tsit5_stage_sum<NZ, 3>(K, w); break;
+                case 4: tsit5_stage_sum<NZ, 4>(K, w); break;
+                case 5: tsit5_stage_sum<NZ, 5>(K, w); break;
+                default: tsit5_stage_sum<NZ, 6>(K, w); break;
+                }
             } else {
                 // wide state vectors (runtime models with n + np + n > TS5_WIDE): one stage row at a time.  Six rows in flight
                 // are 12 NZ VGPRs on top of u, w and the rhs temporaries; past 256 the allocator spills inside this divergent

@@ -235,7 +235,14 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
         h->auto_steps = cfg->max_steps == 0;   // capacity follows the measured step counts (adaptive_autosize); else the caller's bound
         if (cfg->alg != HIPADJ_ALG_BACKSOLVE) {
-            h->rec_cap = h->auto_steps ? 128 : (P.ip_ckpt ? P.SmaxI : P.Smax);   // checkpointing=true: one interval per lane
+            // automatic sizing starts from what 1 GiB of records holds (between 128 and 1024 accepted steps per trajectory; 10^4 Lorenz trajectories:
+            // 785): the first forward solve of a handle then stands without the regrow-and-repeat round — a stream synchronisation, hipFree + hipMalloc
+            // and a second pass, 23 ms against 0.5 ms of steady state for the 10^4-trajectory Lorenz ensemble at the default tolerances
+            long cap0 = (1L << 30) / ((long)RW * 8 * Np);
+            cap0 = cap0 < 128 ? 128 : (cap0 > 1024 ? 1024 : cap0);
+            if (P.ip_ckpt) cap0 = 128;                                            // checkpointing=true: one interval per lane
+            if (const char* e = std::getenv("HIPADJ_REC_CAP0")) { const long v = std::atol(e); if (v > 0) cap0 = v; }   // test hook: start the forward record too small
+            h->rec_cap = h->auto_steps ? cap0 : (P.ip_ckpt ? P.SmaxI : P.Smax);
             A(dev_alloc(h, &h->d_rec, (size_t)h->rec_cap * RW * Np));
         }
         A(dev_alloc(h, &h->d_nsteps, (size_t)Np));
@@ -298,7 +305,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         }
         {   // the composition tree of the one-launch reverse pass (hipadj_fused.hpp): map slots per (block, node) and arrival counters
             if (const char* e = std::getenv("HIPADJ_FUSED")) h->fused = std::atoi(e);
-            if (!(cfg->alg == HIPADJ_ALG_INTERPOLATING && !P.ip_ckpt && !P.offgrid && !P.user)) h->fused = 0;   // kernels with a fused tail so far
+            // kernels with a fused tail so far: the on-grid Interpolating / Gauss / Backsolve sweeps of the compiled-in models
+            if (!((cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_BACKSOLVE) && !P.ip_ckpt && !P.offgrid && !P.user)) h->fused = 0;
             int radix = 4;
             if (const char* e = std::getenv("HIPADJ_TREE_RADIX")) radix = std::atoi(e) == 8 ? 8 : 4;
             long slots = 0, ctrs = 0;

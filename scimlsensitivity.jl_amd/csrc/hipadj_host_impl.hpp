@@ -76,7 +76,8 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     hipEvent_t k0 = es.k0, k1 = es.k1;          // dominant-kernel bracket
     bool dispatch_events = false;               // k0/k1 ride on the kernel's dispatch packet instead (k_interp, below)
-    if (h->timing >= 1 && (h->offgrid || !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt))) HIP_TRY(h, hipEventRecord(k0, h->stream));
+    const bool fused_main = h->fused && h->d_tbuf && !h->offgrid && !h->ip_ckpt;   // the sweep kernel carries k0 / k1 on its own dispatch packet
+    if (h->timing >= 1 && !fused_main && (h->offgrid || !(h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->ip_ckpt))) HIP_TRY(h, hipEventRecord(k0, h->stream));
     if (h->offgrid && h->nseg > 1) {   // off-grid Interpolating / Gauss, time-segmented over the reverse step list (k_offgrid_seg + composition)
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
         SegPlan sp{h->nseg, h->d_seg_bounds};
@@ -204,6 +205,16 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         break; }
     case HIPADJ_ALG_BACKSOLVE: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
+        if (h->fused && h->d_tbuf) {   // one launch per reverse pass (hipadj_fused.hpp)
+            TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
+            hipExtLaunchKernelGGL((k_backsolve_fused<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+                                  (const double*)h->d_cotT, (const int*)h->d_save_rev, d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
+            HIP_TRY(h, hipGetLastError());
+            if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+            es.pending = h->timing >= 1; es.full = h->timing >= 2;
+            return HIPADJ_OK;
+        }
         hipLaunchKernelGGL((k_backsolve<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
                            (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
                            (const int*)h->d_save_rev, h->d_segbuf);
@@ -220,6 +231,16 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         else if (h->ip_ckpt)
             hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
                                (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
+        else if (h->fused && h->d_tbuf) {   // one launch per reverse pass (hipadj_fused.hpp)
+            TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
+            hipExtLaunchKernelGGL((k_gauss_fused<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev,
+                                  d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
+            HIP_TRY(h, hipGetLastError());
+            if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+            es.pending = h->timing >= 1; es.full = h->timing >= 2;
+            return HIPADJ_OK;
+        }
         else
             hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
                                (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);

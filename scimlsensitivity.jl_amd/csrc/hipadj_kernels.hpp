@@ -729,6 +729,67 @@ __global__ void __launch_bounds__(WAVE) k_gauss(Geom g, SegPlan sp, const double
     }
 }
 
+// a wave's segment result as a map for the composition tree of hipadj_fused.hpp: NCV = 1 (top / only segment) leaves the basis columns zero
+template <class Mo, int NCV>
+__device__ __forceinline__ void segment_map_regs(double (&m)[(1 + Mo::N) * (Mo::N + Mo::NP)], const double (&lam)[NCV][Mo::N], const double (&mu)[NCV][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP, R = N + NP;
+#pragma unroll
+    for (int e = 0; e < (1 + N) * R; ++e) m[e] = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCV; ++c) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) m[c * R + j] = lam[c][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) m[c * R + N + j] = mu[c][j];
+    }
+}
+
+// GaussAdjoint and BacksolveAdjoint (segmented at checkpoint knots) as ONE launch per reverse pass, like k_interp_fused
+template <class Mo, int PF, int LOSS, bool GKR = false, bool SEG = true>
+__global__ void __launch_bounds__(WAVE) k_gauss_fused(Geom g, SegPlan sp, TreePlan tp, const double* __restrict__ p, const dbl2* __restrict__ knots,
+                                                      const double* __restrict__ cotT, const int* __restrict__ save_of_knot, double* __restrict__ du0,
+                                                      double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    const long i_raw = (long)blockIdx.x * WAVE + threadIdx.x;
+    const long i = i_raw < g.N ? i_raw : g.N - 1;
+    const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    double m[NC * R];
+    if (!SEG || rank == 0) {
+        double lam[1][N], mu[1][NP];
+        gauss_lane<Mo, 1, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        segment_map_regs<Mo, 1>(m, lam, mu);
+    } else if constexpr (SEG) {
+        double lam[NC][N], mu[NC][NP];
+        gauss_lane<Mo, NC, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+        segment_map_regs<Mo, NC>(m, lam, mu);
+    }
+    fused_tail<N, NP>(m, tp, g.N, (long)gridDim.x, (long)blockIdx.x, rank, du0, dp_rows, dp_sum, flag);
+}
+
+template <class Mo, int CC, bool SEG = true>
+__global__ void __launch_bounds__(WAVE) k_backsolve_fused(Geom g, SegPlan sp, TreePlan tp, const double* __restrict__ p, const double* __restrict__ yT,
+                                                          const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
+                                                          const double* __restrict__ cotT, const int* __restrict__ save_of_knot, double* __restrict__ du0,
+                                                          double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    const long i_raw = (long)blockIdx.x * WAVE + threadIdx.x;
+    const long i = i_raw < g.N ? i_raw : g.N - 1;
+    const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    double m[NC * R];
+    if (!SEG || rank == 0) {
+        double lam[1][N], mu[1][NP];
+        backsolve_lane<Mo, 1, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+        segment_map_regs<Mo, 1>(m, lam, mu);
+    } else if constexpr (SEG) {
+        double lam[NC][N], mu[NC][NP];
+        backsolve_lane<Mo, NC, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+        segment_map_regs<Mo, NC>(m, lam, mu);
+    }
+    fused_tail<N, NP>(m, tp, g.N, (long)gridDim.x, (long)blockIdx.x, rank, du0, dp_rows, dp_sum, flag);
+}
+
 template <class Mo, int LOSS, bool GT = false>
 __global__ void __launch_bounds__(WAVE) k_gauss_ckpt(Geom g, SegPlan sp, const double* __restrict__ p, const double* __restrict__ ckpt,
                                                      const int* __restrict__ ckpt_of_knot, const int* __restrict__ prev_ck,

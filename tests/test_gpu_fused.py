@@ -14,14 +14,15 @@ from test_gpu_parity import RTOL, rel, lorenz_inputs
 pytestmark = pytest.mark.gpu
 
 
-def _engines(sa, monkeypatch, N, ts, T, dt, loss_kind, p_shared=True, segments=0, radix=None):
-    kw = dict(save_times=ts, loss_kind=loss_kind, loss_shift=2.0, p_shared=p_shared, time_segments=segments)
+def _engines(sa, monkeypatch, N, ts, T, dt, loss_kind, p_shared=True, segments=0, radix=None, alg="interpolating", model="lorenz", **more):
+    kw = dict(save_times=ts, loss_kind=loss_kind, loss_shift=2.0, p_shared=p_shared, time_segments=segments, **more)
     monkeypatch.setenv("HIPADJ_FUSED", "0")
-    ref = sa.Engine("lorenz", "interpolating", N, 0.0, T, dt, **kw)
+    ref = sa.Engine(model, alg, N, 0.0, T, dt, **kw)
     monkeypatch.setenv("HIPADJ_FUSED", "1")
     if radix:
         monkeypatch.setenv("HIPADJ_TREE_RADIX", str(radix))
-    fus = sa.Engine("lorenz", "interpolating", N, 0.0, T, dt, **kw)
+    fus = sa.Engine(model, alg, N, 0.0, T, dt, **kw)
+    assert fus.stats()["launches_per_pass"] == 1 and ref.stats()["launches_per_pass"] == 3
     monkeypatch.delenv("HIPADJ_FUSED")
     monkeypatch.delenv("HIPADJ_TREE_RADIX", raising=False)
     return ref, fus
@@ -73,4 +74,28 @@ def test_fused_pass_with_per_trajectory_parameters_and_nonfinite_flag(sa, monkey
     fus.forward(u0, P, want_out=False)        # the handle recovers: counters are zeroed by the next forward solve
     c = fus.adjoint(None)
     assert np.array_equal(c[0], b[0]) and np.array_equal(c[1], b[1])
+    ref.close(); fus.close()
+
+
+@pytest.mark.parametrize("alg,kw", [("gauss", {}), ("backsolve", dict(checkpointing=True)), ("backsolve", dict(checkpointing=True, ckpt_stride=10))])
+@pytest.mark.parametrize("model,N", [("lorenz", 1250), ("lv", 333)])
+def test_fused_gauss_and_backsolve_equal_their_three_launch_sequences(sa, monkeypatch, alg, kw, model, N):
+    """k_gauss_fused / k_backsolve_fused (segments cut at checkpoint knots) against k_gauss / k_backsolve + composition + reduction, on changing data"""
+    T, dt = (10.0, 0.01) if model == "lorenz" else (5.0, 0.01)
+    ts = np.linspace(0.0, T, 51)
+    ref, fus = _engines(sa, monkeypatch, N, ts, T, dt, loss_kind=0, alg=alg, model=model, **kw)
+    assert fus.stats()["time_segments"] == ref.stats()["time_segments"] > 1
+    rng = np.random.default_rng(N)
+    n, npar = fus.n, fus.np
+    if model == "lorenz":
+        u0, p = lorenz_inputs(N)
+    else:
+        u0, p = 1.0 + 0.1 * rng.standard_normal((N, 2)), np.array([1.5, 1.0, 3.0, 1.0])
+    for rnd in range(3):
+        u0r, pr = u0 + 0.01 * rng.standard_normal(u0.shape), p * (1.0 + 0.01 * rng.standard_normal(npar))
+        ref.forward(u0r, pr, want_out=False); fus.forward(u0r, pr, want_out=False)
+        for rep in range(3):
+            delta = rng.standard_normal((N, len(ts), n))
+            a, b = ref.adjoint(delta), fus.adjoint(delta)
+            assert rel(b[0], a[0]) < 1e-10 and rel(b[1], a[1]) < 1e-10, (rnd, rep)
     ref.close(); fus.close()

@@ -622,6 +622,28 @@ def test_tsit5_quadrature_dense_adjoint_record_regrows(sa, monkeypatch):
         sol.engine.close()
 
 
+def test_tsit5_forward_record_regrows_from_a_small_start(sa, monkeypatch):
+    """max_steps = 0: the forward record starts from a capacity guess (1 GiB worth, round 3); when a trajectory takes more accepted steps the pass reports
+    the true count, the buffer is regrown and the pass repeated — same results as a start that fits (HIPADJ_REC_CAP0 forces a small start)."""
+    N, T = 200, 6.0
+    u0, p = lorenz_inputs(N, seed=9)
+    ts = np.linspace(0, T, 13)
+    res = {}
+    for cap in (None, "16"):
+        if cap:
+            monkeypatch.setenv("HIPADJ_REC_CAP0", cap)
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.InterpolatingAdjoint(),
+                       dgdu_discrete=sa.LsqShift(2.0), abstol=1e-7, reltol=1e-7, max_steps=0)
+        res[cap] = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts) + (sol.u, sol.engine.stats()["workspace_bytes"])
+        sol.engine.close()
+    a, b = res[None], res["16"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert b[3] < a[3]                  # the regrown buffer follows the measured step count (+12 %), the default start is the generous one
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-7, reltol=1e-7, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(a[0], rdu0) < RTOL and rel(a[1], rdp) < RTOL
+
+
 def test_tsit5_max_steps_is_reported(sa):
     u0, p = lorenz_inputs(64)
     with pytest.raises(sa.HipadjError) as e:
