@@ -209,7 +209,8 @@ int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double 
  *             `acc[q] += w * ...` = this thread's partial of parameter acc_first + q (a coefficient every component feeds; nacc <= 16
  *             such parameters; the partials are summed over the workgroup once per sweep)
  * Available inside the bodies: `tid`, `T` (= threads), `N`, `NP`, `HIPADJ_W_FOR(i, count) { ... }` (i = tid, tid + T, ... < count),
- * `wg_sync()` (workgroup barrier between dependent phases, e.g. hidden layers), `ws[0..lds_doubles)` LDS scratch.  u, lam, du, dlam, ws are
+ * `wg_sync()` (workgroup barrier between dependent phases, e.g. hidden layers), `wg_sum(x)` (sum of one value per thread over the workgroup,
+ * returned to every thread: wavefront shuffles; every thread must call it), `ws[0..lds_doubles)` LDS scratch.  u, lam, du, dlam, ws are
  * LDS, p is global memory.  threads: a multiple of 64 in [64, 1024], 0 = automatic.  Offered: fixed-step RK4, loss times on the step grid,
  * Interpolating / Backsolve (checkpoints) / Gauss / QuadratureAdjoint, discrete losses; parity-tested against the oracle on the reference's
  * 30 x 50 matrix-state problem (test/Core5/size_handling_adjoint.jl:37-70) and the 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62. */

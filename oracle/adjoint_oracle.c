@@ -23,6 +23,16 @@
 
 #define ORC_MAXK 7
 
+/* [upstream-recall] constants as data (orc_test_set_recall, adjoint_oracle.h): what the restatement assumes about the un-vendored packages.  The
+ * defaults are the restatement; tests/test_recall_sensitivity.py perturbs one at a time and records which reference-held relation would notice. */
+static double g_recall[ORC_RECALL_COUNT] = {2, 3, 1e-7, 10.0, 0.2, 0.9, 7.0 / 50.0, 2.0 / 25.0, 1, 7};
+int orc_test_set_recall(int which, double value) {
+    static const double dflt[ORC_RECALL_COUNT] = {2, 3, 1e-7, 10.0, 0.2, 0.9, 7.0 / 50.0, 2.0 / 25.0, 1, 7};
+    if (which < 0) { memcpy(g_recall, dflt, sizeof dflt); return 0; }        /* reset all */
+    if (which >= ORC_RECALL_COUNT) return -1;
+    g_recall[which] = value; return 0;
+}
+
 /* =====================================================================================
  * 1. Models: f, (df/du)^T lam, (df/dp)^T lam — the user-VJP seam
  *    vjp(dlam, lam, u, p, t) / vjp_p(dgrad, lam, u, p, t), un-negated
@@ -632,9 +642,9 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
             }
             for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < 7; ++j) acc += TS_BT[j] * k[j * n + i]; I.utilde[i] = dt * acc; }
             double EEst = scaled_norm(I.utilde, I.uprev, I.u, n, alg->abstol, alg->reltol);
-            double q11 = pow(fmax(EEst, 1e-300), 7.0 / 50.0);
-            double q = q11 / pow(qold, 2.0 / 25.0);
-            q = fmax(1.0 / 10.0, fmin(5.0, q / 0.9));
+            double q11 = pow(fmax(EEst, 1e-300), g_recall[ORC_RECALL_BETA1]);
+            double q = q11 / pow(qold, g_recall[ORC_RECALL_BETA2]);
+            q = fmax(1.0 / g_recall[ORC_RECALL_QMAX], fmin(1.0 / g_recall[ORC_RECALL_QMIN], q / g_recall[ORC_RECALL_GAMMA]));
             if (EEst <= 1.0 || fabs(dt) < 1e-14 * fmax(1.0, fabs(t))) {
                 double tnew = t + dt;
                 if (fabs(tnew - tstop) < 100 * DBL_EPSILON * fmax(fabs(tnew), fabs(tstop))) tnew = tstop;
@@ -645,7 +655,7 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
                 if (fabs(I.dt) < 1e-14 * fmax(1.0, fabs(tnew))) I.dt = I.tdir * 1e-14 * fmax(1.0, fabs(tnew));
             } else {
                 memcpy(I.u, I.uprev, sizeof(double) * n);
-                I.dt = dt / fmin(5.0, q11 / 0.9);
+                I.dt = dt / fmin(1.0 / g_recall[ORC_RECALL_QMIN], q11 / g_recall[ORC_RECALL_GAMMA]);
                 I.nreject++;
                 continue;
             }
@@ -861,7 +871,8 @@ static void gauss_integrand(adj_ctx *A, double *out, double t, const double *lam
 static void gauss_step(adj_ctx *A, orc_integ *I) {
     static const double x2[2] = {-0.5773502691896257645, 0.5773502691896257645}, w2[2] = {1.0, 1.0};
     static const double x3[3] = {-0.7745966692414833770, 0.0, 0.7745966692414833770}, w3[3] = {5.0 / 9, 8.0 / 9, 5.0 / 9};
-    int ng = (I->kind == ORC_STEPPER_TSIT5) ? 3 : 2; const double *x = ng == 3 ? x3 : x2, *w = ng == 3 ? w3 : w2;
+    int ng = (int)g_recall[(I->kind == ORC_STEPPER_TSIT5) ? ORC_RECALL_GAUSS_NODES_TSIT5 : ORC_RECALL_GAUSS_NODES_RK4];
+    const double *x = ng == 3 ? x3 : x2, *w = ng == 3 ? w3 : w2;
     double half = 0.5 * (I->t - I->tprev), mid = 0.5 * (I->t + I->tprev);
     double *lam = A->scratch, *out = A->scratch + A->n;
     for (int g = 0; g < ng; ++g) {
@@ -921,7 +932,7 @@ static void gk_panel(adj_ctx *A, orc_integ *I, double a, double b, int depth) {
         for (int i = 0; i < np; ++i) { IK[i] += GK_WK[q] * out[i]; if (q & 1) IG[i] += GK_WG[q / 2] * out[i]; }
     }
     double e = 0; for (int i = 0; i < np; ++i) { IK[i] *= h; IG[i] *= h; double d = IK[i] - IG[i]; e += d * d; }
-    if (sqrt(e) <= ORC_GK_TOL || depth >= ORC_GK_MAXDEPTH) { for (int i = 0; i < np; ++i) A->gauss_acc[i] += IK[i]; return; }
+    if (sqrt(e) <= g_recall[ORC_RECALL_GK_TOL] || depth >= ORC_GK_MAXDEPTH) { for (int i = 0; i < np; ++i) A->gauss_acc[i] += IK[i]; return; }
     gk_panel(A, I, a, c, depth + 1); gk_panel(A, I, c, b, depth + 1);
 }
 static void gausskronrod_step(adj_ctx *A, orc_integ *I) { gk_panel(A, I, I->tprev, I->t, 0); }
@@ -1066,7 +1077,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     if (cfg->alg == ORC_ALG_GAUSS || cfg->alg == ORC_ALG_GAUSS_KRONROD) A.gauss_acc = (double *)calloc(np, sizeof(double));
     orc_dense adjrec; int have_rec = 0;
     if (cfg->alg == ORC_ALG_QUADRATURE) { dense_init(&adjrec, n, cfg->stepper); have_rec = 1; }
-    int cb_at_init = (M > 0 && time_hits(cfg->t1, cfg->save_times[M - 1]));
+    int cb_at_init = (M > 0 && time_hits(cfg->t1, cfg->save_times[M - 1])) && g_recall[ORC_RECALL_PRESET_AT_INIT] != 0.0;
     st = integrate(rhs, &A, nz, z, cfg->t1, cfg->t0, &alg, tst, nts, adjoint_step_cb, &A, cb_at_init, have_rec ? &adjrec : NULL, nrhs);
 
     /* unpack (src/sensitivity_interface.jl:500-508) */

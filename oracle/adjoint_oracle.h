@@ -97,6 +97,17 @@ int orc_model_f(int model, const int dims[4], const double *u, const double *p, 
 int orc_model_vjp(int model, const int dims[4], const double *lam, const double *u, const double *p, double t,
                   double *dlam, double *dgrad);
 
+/* [upstream-recall] constants of the restatement as data, for SENSITIVITY tests only (tests/test_recall_sensitivity.py): perturb one, run the relations
+   the reference's tests hold, see whether any of them would notice.  which < 0 resets all to the restated values.  Process-wide, not thread-safe. */
+enum { ORC_RECALL_GAUSS_NODES_RK4 = 0,   /* IntegratingSumCallback nodes per step with RK4: div(4 + 1, 2) = 2 */
+       ORC_RECALL_GAUSS_NODES_TSIT5 = 1, /* ... with Tsit5: div(5 + 1, 2) = 3 */
+       ORC_RECALL_GK_TOL = 2,            /* IntegratingGKSumCallback panel tolerance 1e-7 */
+       ORC_RECALL_QMAX = 3, ORC_RECALL_QMIN = 4, ORC_RECALL_GAMMA = 5, ORC_RECALL_BETA1 = 6, ORC_RECALL_BETA2 = 7,   /* PI controller 10, 1/5, 9/10, 7/50, 2/25 */
+       ORC_RECALL_PRESET_AT_INIT = 8,    /* PresetTimeCallback fires during initialisation when T is a preset time (1) */
+       ORC_RECALL_QUADGK_ORDER = 9,      /* QuadGK order 7 (the (7,15) pair); reserved: the tables hold that pair only */
+       ORC_RECALL_COUNT = 10 };
+int orc_test_set_recall(int which, double value);
+
 /* adaptive Gauss-Kronrod (7,15) on a polynomial test integrand, for pinning the quadrature rule */
 double orc_test_quadgk_poly(int degree, double a, double b, double atol, double rtol, long *nevals);
 /* Tsit5 tableau self-check: returns max order-condition residual up to order 5 */

@@ -205,7 +205,7 @@ inline std::string user_wide_struct(const UserModelSrc& m) {
     const int na = m.nacc > 0 ? m.nacc : 1;
     o << "#include \"hipadj_wide.hpp\"\n"
       << "namespace hipadj {\n// runtime-registered wide model '" << m.name << "' (workgroup-per-trajectory family, hipadj_wide.hpp)\n"
-      << "#define HIPADJ_W_FOR(i, n) for (int i = tid; i < (n); i += T)\n#define wg_sync() hipadj::wide_sync<T>()\n"
+      << "#define HIPADJ_W_FOR(i, n) for (int i = tid; i < (n); i += T)\n#define wg_sync() hipadj::wide_sync<T>()\n#define wg_sum(x) hipadj::wide_sum_all<T>(x)\n"
       << "struct UserW {\n    static constexpr int N = " << m.n << ", NP = " << m.np << ", T = " << m.threads << ", NW = " << m.nw << ", NACC = " << m.nacc
       << ", ACC0 = " << m.acc0 << ";\n"
       << "    static __device__ __forceinline__ void f(double* __restrict__ du, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {\n"

@@ -16,7 +16,8 @@
 //                                                                components) for parameters that every component feeds (PDE
 //                                                                coefficients): reduced over the workgroup ONCE, at the end of the sweep
 // Every thread of the workgroup calls them with the same arguments; inside, work is split by `tid` (HIPADJ_W_FOR) and `wg_sync()`
-// separates dependent phases (hidden layers); `ws` is NW doubles of LDS scratch.  Inputs are complete on entry; the framework
+// separates dependent phases (hidden layers); `wg_sum(x)` sums one value per thread over the workgroup (shuffle butterfly) for contractions with
+// few outputs; `ws` is NW doubles of LDS scratch.  Inputs are complete on entry; the framework
 // synchronises after the call.  The bodies are HIP C++ text compiled by hiprtc into the kernels below (hipadj_user.hpp).
 //
 // Threads own components c = tid + q T (q < Q): lambda, the Runge-Kutta accumulators and the knot slices live in registers per
@@ -63,6 +64,26 @@ __constant__ double cw_gk_wg[4] = {0.129484966168869693270611432679082, 0.279705
 template <int T> __device__ __forceinline__ void wide_sync() {
     if constexpr (T == 64) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
     else __syncthreads();
+}
+
+// wg_sum(x) of the SPMD bodies: the sum of one value per thread over the workgroup, returned to EVERY thread — the "wavefront shuffles for the
+// per-trajectory VJP reductions" of north_star: a contraction whose output is narrower than the workgroup (the 2 outputs of a 50 -> 2 layer, a scalar
+// coefficient) runs with the lanes over its INPUT index and one butterfly per output instead of a serial loop on one or two lanes.  Fixed order
+// (xor butterfly inside a wavefront: both partners add the same two numbers; then the wavefronts in order).  All threads must call it.
+template <int T> __device__ __forceinline__ double wide_sum_all(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if constexpr (T == 64) return v;
+    else {
+        __shared__ double part[T / 64];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) s += part[w];
+        __syncthreads();
+        return s;
+    }
 }
 
 // workgroup sum of K per-thread values into out[0..K) (LDS), fixed order: shuffle tree per wave, then the waves in order
