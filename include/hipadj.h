@@ -246,7 +246,11 @@ int hipadj_forward(hipadj_handle *h, const double *u0, const double *p, double *
  * dLdu [N][M][n] cotangents (COTANGENT loss) or NULL (LSQ_SHIFT); du0 [N][n]; dp [np] or [N][np]. */
 int hipadj_adjoint(hipadj_handle *h, const double *dLdu, double *du0, double *dp);
 
-/* Device-pointer variants (same layouts, memory of cfg.device); asynchronous on the handle's stream. */
+/* Device-pointer variants (same layouts, memory of cfg.device); asynchronous on the handle's stream.
+ * Exceptions, all synchronising the stream inside the call: (i) the FIRST hipadj_adjoint_dev of a handle whose runtime-compiled reverse kernel is
+ * cross-checked against its -O1 build (kernels with >= 1 KB of scratch per lane; every reverse kernel when the toolkit's compiler could not be bound:
+ * hipadj_runtime_compiler) runs the pass twice and compares du0 / dp on the host — do not put that call inside a stream capture; (ii) adaptive Tsit5 with
+ * max_steps = 0 reads the measured step counts back after the forward solve (and after QuadratureAdjoint's sweep). */
 int hipadj_forward_dev(hipadj_handle *h, const double *d_u0, const double *d_p, double *d_out);
 int hipadj_adjoint_dev(hipadj_handle *h, const double *d_dLdu, double *d_du0, double *d_dp);
 /* run on the caller's hipStream_t (e.g. torch's current stream); NULL restores the handle's own stream */

@@ -94,6 +94,9 @@ constexpr int KS_ROWS = 8, KS_UPREV = 7;
 #ifndef HIPADJ_TS5_WIDE
 #define HIPADJ_TS5_WIDE 9
 #endif
+#ifndef HIPADJ_TS5_PADDED
+#define HIPADJ_TS5_PADDED 0
+#endif
 constexpr int TS5_WIDE = HIPADJ_TS5_WIDE;   // widest state vector whose six stage rows are summed in one batch (tsit5_integrate)
 template <int NZ> struct KStore {
     double* base; int stride;
@@ -232,9 +235,19 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
         for (int s = 1; s < 7; ++s) {
 #pragma unroll
             for (int i = 0; i < NZ; ++i) w[i] = 0.0;
-            if constexpr (NZ <= TS5_WIDE) {
+            if constexpr (NZ <= TS5_WIDE && HIPADJ_TS5_PADDED) {
+                // the zero-padded 6-term form of rounds 1-2 (-DHIPADJ_TS5_PADDED=1): kept as the subject of the spill-placement probe of tests/test_isa_lint.py
+                // and for A/B builds; rows j >= s of K hold finite leftovers that the zero coefficients annihilate
+                double as[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) as[j] = TS5::a(s, j);
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) w[i] += as[j] * K.get(j, i);
+            } else if constexpr (NZ <= TS5_WIDE) {
                 // only the s rows the tableau really has, coefficients as literals (round 3): the zero-padded 6-term form issued 36 NZ multiply-adds and
-                // LDS reads per step where 21 NZ are needed — the stage sums, not the right-hand side, were the larger half of a step's instructions
+                // LDS reads per step where 21 NZ are needed
                 switch (s) {
                 case 1: tsit5_stage_sum<NZ, 1>(K, w); break;
                 case 2: tsit5_stage_sum<NZ, 2>(K, w); break;

@@ -68,7 +68,24 @@ extern "C" int hipadj_model_set_affect(int32_t model_id, const char* affect_body
 // hiprtc on first use (same cache as the solve kernels).
 namespace {
 struct AffectFns { hipModule_t mod = nullptr; hipFunction_t apply = nullptr, vjp = nullptr; };
-int affect_functions(int32_t model, AffectFns& F, std::string& err) {
+// loaded modules are kept per (model, source revision, device): an event chain calls these entry points once per event and reverse callback
+// (they reloaded the code object on every call).  Never unloaded: a model's affect lives as long as the process.
+struct AffectCache { std::mutex mu; std::map<std::string, AffectFns> m; };
+AffectCache& affect_cache() { static AffectCache c; return c; }
+int affect_functions_uncached(int32_t model, AffectFns& F, std::string& err);
+int affect_functions(int32_t model, int32_t device, AffectFns& F, std::string& err) {
+    int rev = 0;
+    { UserRegistry& R = user_registry(); std::lock_guard<std::mutex> lk(R.mu); const int idx = model - HIPADJ_MODEL_USER_BASE; if (idx >= 0 && idx < (int)R.models.size()) rev = R.models[idx].rev; }
+    const std::string key = std::to_string(model) + "#" + std::to_string(rev) + "@" + std::to_string(device);
+    AffectCache& Cc = affect_cache();
+    std::lock_guard<std::mutex> lk(Cc.mu);
+    auto it = Cc.m.find(key);
+    if (it != Cc.m.end()) { F = it->second; return HIPADJ_OK; }
+    const int rc = affect_functions_uncached(model, F, err);
+    if (rc == HIPADJ_OK) Cc.m[key] = F;
+    return rc;
+}
+int affect_functions_uncached(int32_t model, AffectFns& F, std::string& err) {
     std::vector<char> code; std::map<std::string, std::string> low;
     const std::vector<std::string> exprs = {"hipadj::k_user_affect<hipadj::UserModel>", "hipadj::k_user_affect_vjp<hipadj::UserModel>"};
     const int rc = user_compile(model, exprs, code, low, err);
@@ -103,7 +120,7 @@ extern "C" int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, 
     int32_t n = 0, np = 0;
     { const int rc = affect_prologue(model_id, device, N, n, np, g_create_error); if (rc != HIPADJ_OK) return rc; }
     AffectFns F;
-    { const int rc = affect_functions(model_id, F, g_create_error); if (rc != HIPADJ_OK) return rc; }
+    { const int rc = affect_functions(model_id, device, F, g_create_error); if (rc != HIPADJ_OK) return rc; }
     bool ok = true; DevBufs B;
     double* d_u = B.get((size_t)N * n, u, ok); double* d_p = B.get(p_shared ? (size_t)np : (size_t)N * np, p, ok); double* d_o = B.get((size_t)N * n, nullptr, ok);
     double* d_po = B.get((size_t)N * np, nullptr, ok);
@@ -112,7 +129,6 @@ extern "C" int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, 
     ok = ok && hipModuleLaunchKernel(F.apply, (unsigned)((N + 255) / 256), 1, 1, 256, 1, 1, 0, nullptr, args, nullptr) == hipSuccess;
     ok = ok && hipMemcpy(out, d_o, sizeof(double) * (size_t)N * n, hipMemcpyDeviceToHost) == hipSuccess;
     if (p_out) ok = ok && hipMemcpy(p_out, d_po, sizeof(double) * (size_t)N * np, hipMemcpyDeviceToHost) == hipSuccess;
-    (void)hipModuleUnload(F.mod);
     if (!ok) { g_create_error = "hipadj_affect_apply: a HIP call failed"; return HIPADJ_ERR_HIP; }
     return HIPADJ_OK;
 }
@@ -123,7 +139,7 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
     int32_t n = 0, np = 0;
     { const int rc = affect_prologue(model_id, device, N, n, np, g_create_error); if (rc != HIPADJ_OK) return rc; }
     AffectFns F;
-    { const int rc = affect_functions(model_id, F, g_create_error); if (rc != HIPADJ_OK) return rc; }
+    { const int rc = affect_functions(model_id, device, F, g_create_error); if (rc != HIPADJ_OK) return rc; }
     bool ok = true; DevBufs B;
     double* d_u = B.get((size_t)N * n, u, ok); double* d_p = B.get(p_shared ? (size_t)np : (size_t)N * np, p, ok); double* d_l = B.get((size_t)N * n, lam, ok);
     double* d_gi = B.get((size_t)N * np, gp, ok); double* d_lo = B.get((size_t)N * n, nullptr, ok); double* d_g = B.get((size_t)N * np, nullptr, ok);
@@ -132,7 +148,6 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
     ok = ok && hipModuleLaunchKernel(F.vjp, (unsigned)((N + 255) / 256), 1, 1, 256, 1, 1, 0, nullptr, args, nullptr) == hipSuccess;
     ok = ok && hipMemcpy(lam_out, d_lo, sizeof(double) * (size_t)N * n, hipMemcpyDeviceToHost) == hipSuccess;
     ok = ok && hipMemcpy(gp_out, d_g, sizeof(double) * (size_t)N * np, hipMemcpyDeviceToHost) == hipSuccess;
-    (void)hipModuleUnload(F.mod);
     if (!ok) { g_create_error = "hipadj_affect_vjp: a HIP call failed"; return HIPADJ_ERR_HIP; }
     return HIPADJ_OK;
 }
@@ -202,7 +217,9 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (!out) { g_create_error = "out == NULL"; return HIPADJ_ERR_INVALID_ARG; }
     *out = nullptr;
     if (!cfg) { g_create_error = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
-        auto* h = new hipadj_handle();
+    // before ANY other field is read: a caller built against another ABI hands over a struct of another size (reading sizeof(hipadj_config) bytes from it would run past its end)
+    if (cfg->struct_size != sizeof(hipadj_config)) { g_create_error = "hipadj_config.struct_size mismatch (ABI)"; return HIPADJ_ERR_INVALID_ARG; }
+    auto* h = new hipadj_handle();
     auto fail = [&](int code) { g_create_error = h->err; free_all(h); delete h; return code; };
     h->cfg = *cfg; h->cfg.save_times = nullptr; h->cfg.checkpoints = nullptr;
     Plan P;
@@ -684,8 +701,8 @@ static int user_prepare(hipadj_handle* h) {
     int scratch = 0;
     if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, h->uf_main) != hipSuccess) scratch = 0;
     const char* st = std::getenv("HIPADJ_RTC_SELFTEST");
-    const int st_min = st ? std::atoi(st) : 1024;          // 0 = off, otherwise the scratch size (bytes per lane) from which the self-test runs
-    if (st_min > 0 && scratch >= st_min && !std::getenv("HIPADJ_RTC_OVERRIDE")) {
+    const int st_min = st ? std::atoi(st) : (rtc_trusted() ? 1024 : 1);   // 0 = off, otherwise the scratch size (bytes per lane) from which the self-test runs; an untrusted compiler: every kernel
+    if (st_min > 0 && (scratch >= st_min || (!st && !rtc_trusted())) && !std::getenv("HIPADJ_RTC_OVERRIDE")) {
         std::vector<char> code2; std::map<std::string, std::string> low2;
         const int rc2 = user_compile(h->cfg.model, exprs, code2, low2, h->err, true);
         if (rc2 != HIPADJ_OK) return rc2;
@@ -987,7 +1004,8 @@ static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* 
 }
 // The first reverse pass of a runtime model whose reverse kernel spills heavily (user_prepare): run the -O3 build, then the -O1 build, compare
 // du0 and dp on the host.  Agreement (1e-9 relative, and no non-finite flag from the -O3 run): the -O3 build stays.  Otherwise the -O1 build is
-// used from here on and a note goes to stderr.  The outputs handed back are those of the build that stays.
+// used from here on and a note goes to stderr.  The outputs handed back are those of the build that stays.  This FIRST reverse pass of such a handle
+// synchronises the stream and copies du0 / dp to the host (include/hipadj.h says so at hipadj_adjoint_dev): it cannot be part of a stream capture.
 static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     if (h->rtc_selftest != 1) return user_adjoint_run(h, d_cot, d_du0, d_dp);
     h->rtc_selftest = 2;
@@ -1000,25 +1018,32 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
         return HIPADJ_OK;
     };
+    // -O1 first, -O3 second: on agreement the outputs left in du0 / dp are those of the build that stays
     int flag_a = 0, flag_b = 0;
+    std::swap(h->uf_main, h->uf_main_alt);                 // the -O1 build
     TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));
     TRY(fetch(a0, a1, flag_a));
     HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));   // in stream order with the second run
-    std::swap(h->uf_main, h->uf_main_alt);                 // the -O1 build
+    std::swap(h->uf_main, h->uf_main_alt);                 // the -O3 build
     TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));
     TRY(fetch(b0, b1, flag_b));
-    auto differ = [](const std::vector<double>& x, const std::vector<double>& y) {
+    // fixed step: the two builds do the same arithmetic up to contraction / reassociation (1e-9).  Adaptive Tsit5: they may legitimately accept different step
+    // sequences, so they only have to agree at the level of the solver's own tolerances
+    const double tol = h->adaptive ? std::max(1e-9, 100.0 * std::max(h->cfg.abstol, h->cfg.reltol)) : 1e-9;
+    auto differ = [tol](const std::vector<double>& x, const std::vector<double>& y) {   // x: the build under test, y: the reference build
         double scale = 0.0, d = 0.0;
         for (size_t i = 0; i < x.size(); ++i) { if (!(std::fabs(x[i]) <= 1.79e308)) return true; scale = std::max(scale, std::fabs(y[i])); d = std::max(d, std::fabs(x[i] - y[i])); }
-        return d > 1e-9 * (scale > 0.0 ? scale : 1.0);
+        return d > tol * (scale > 0.0 ? scale : 1.0);
     };
-    const bool bad = (flag_a & 1) || differ(a0, b0) || differ(a1, b1);
-    if (bad && !(flag_b & 1)) {
+    const bool bad = (flag_b & 1) || differ(b0, a0) || differ(b1, a1);
+    if (bad && !(flag_a & 1)) {
         h->rtc_selftest = 3;
         std::fprintf(stderr, "hipadj: the -O3 build of the reverse kernel of runtime model %d disagrees with its -O1 build on the first reverse pass; using the -O1 build (DESIGN.md 6.8)\n", h->cfg.model);
-    } else {
-        std::swap(h->uf_main, h->uf_main_alt);             // agreement (or both non-finite: a diverged trajectory — the flag of the second run stands for the caller's check)
+        std::swap(h->uf_main, h->uf_main_alt);             // the -O1 build from here on ...
+        HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+        TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));      // ... and its outputs for this call
     }
+    // agreement (or both non-finite: a diverged trajectory — the flag of the last run stands for the caller's check): the -O3 build stays, its outputs are in place
     return HIPADJ_OK;
 }
 

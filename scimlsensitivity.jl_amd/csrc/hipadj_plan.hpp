@@ -124,8 +124,11 @@ inline int plan_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, in
 // np = n + 1 parameters (9 x 17 = 153 doubles of 512 registers per lane); measured with the ring models, 10^4 trajectories x 1000 steps, 13
 // segments against one: InterpolatingAdjoint 3.2x / 2.8x / 1.6x faster at n = 5 / 6 / 8 (profiles/r2_user_segments_ab.log).  The cap used to be 64
 // because wider kernels came back wrong from the compiler then bound for runtime models.  HIPADJ_SEG_CAP is a tuning hook.
+typedef int (*plan_segcap_fn)();   // runtime models: the cap the bound compiler is trusted with (hipadj_user.hpp: 64 when the toolkit's hiprtc could not be bound)
+inline plan_segcap_fn& plan_user_segcap_hook() { static plan_segcap_fn f = nullptr; return f; }
 inline int plan_seg_cap() {
     static const int cap = [] { const char* e = std::getenv("HIPADJ_SEG_CAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 160; }();
+    if (plan_user_segcap_hook()) { const int c = plan_user_segcap_hook()(); if (c > 0 && c < cap && !std::getenv("HIPADJ_SEG_CAP")) return c; }
     return cap;
 }
 inline bool plan_seg_fits(int n, int np) { return (1 + n) * (n + np) <= plan_seg_cap(); }

@@ -86,6 +86,7 @@ struct RtcApi {
     hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
     std::string err, path;     // path: the bound libhiprtc
     bool isolated = false;     // loaded with dlmopen next to another hiprtc / comgr copy
+    bool by_path = false;      // bound from the toolkit installation by path ($HIPADJ_HIPRTC with a path, $ROCM_PATH/lib, the build-time ROCm root) — not by soname
     char*** ns_environ = nullptr;   // `environ` of the C library copy inside that namespace
     // A link-map namespace holds its own libc, whose `environ` was copied when it was loaded.  setenv in the process (python: os.environ[...] = ...)
     // may move the array; the copy then dangles and the next getenv inside hiprtc / comgr walks freed memory.  Every entry into the namespace
@@ -135,7 +136,7 @@ inline RtcApi& rtc_api() {
                 RtcForeign f{rtc_dirname(rp), false};
                 dl_iterate_phdr(rtc_phdr_cb, &f);
                 A.lib = f.found ? dlmopen(LM_ID_NEWLM, rp.c_str(), RTLD_NOW | RTLD_LOCAL) : dlopen(rp.c_str(), RTLD_NOW | RTLD_LOCAL);
-                if (A.lib) { A.path = rp; A.isolated = f.found; if (f.found) A.ns_environ = (char***)dlsym(A.lib, "environ"); }
+                if (A.lib) { A.path = rp; A.isolated = f.found; A.by_path = true; if (f.found) A.ns_environ = (char***)dlsym(A.lib, "environ"); }
             }
         } else if (!want.empty()) { A.lib = dlopen(want.c_str(), RTLD_NOW | RTLD_LOCAL); if (A.lib) A.path = want; }
         if (!A.lib) {
@@ -180,6 +181,33 @@ inline std::string rtc_describe() {
     });
     return A.path + (A.isolated ? " [own link-map namespace]" : "") + "; HIP " + (ver.empty() ? "?" : ver);
 }
+
+// Is the bound compiler the one this library was built and tested with?  No when the toolkit's libhiprtc could not be bound by path (a torch wheel alone,
+// no ROCm installation: the soname then resolves to the wheel's bundled pair) or when the compiler reports an older HIP than the build toolkit.  The
+// bundled ROCm 7.0 pair miscompiled WIDE runtime models, so an untrusted compiler gets the round-1 limits back: segment lanes up to 64
+// doubles of state (plan_seg_cap), and EVERY reverse kernel is cross-checked against its -O1 build on the first reverse pass (user_prepare), not only the
+// heavily spilling ones.  HIPADJ_RTC_TRUST=1 / 0 overrides.  One note on stderr.  
+inline bool rtc_trusted() {
+    static const bool ok = [] {
+        if (const char* e = std::getenv("HIPADJ_RTC_TRUST")) return e[0] != '0';
+        RtcApi& A = rtc_api();
+        if (!A.lib || !A.err.empty()) return true;                 // nothing will be compiled at all
+        bool good = A.by_path;
+        const std::string d = rtc_describe();
+        const size_t k = d.rfind("HIP ");
+        int maj = 0, min = 0;
+        if (k != std::string::npos && std::sscanf(d.c_str() + k + 4, "%d.%d", &maj, &min) == 2) {
+#if defined(HIP_VERSION_MAJOR) && defined(HIP_VERSION_MINOR)
+            if (maj < HIP_VERSION_MAJOR || (maj == HIP_VERSION_MAJOR && min < HIP_VERSION_MINOR)) good = false;
+#endif
+        } else good = false;
+        if (!good) std::fprintf(stderr, "hipadj: runtime models are compiled by %s, not by the toolkit this library was built with: segment lanes limited to 64 doubles, "
+                                        "every reverse kernel cross-checked against its -O1 build (set HIPADJ_HIPRTC or ROCM_PATH; HIPADJ_RTC_TRUST=1 overrides)\n", d.c_str());
+        return good;
+    }();
+    return ok;
+}
+inline int user_seg_cap() { return rtc_trusted() ? 0 : 64; }
 
 // directory holding the library's kernel headers: $HIPADJ_CSRC_DIR, else csrc/ next to libhipadj.so
 inline std::string user_csrc_dir() {
@@ -633,6 +661,7 @@ inline int user_register(const char* name, int32_t n, int32_t np, const char* f,
     R.models.push_back(m);
     *id = HIPADJ_MODEL_USER_BASE + (int32_t)R.models.size() - 1;
     plan_user_sizes_hook() = &user_model_sizes;
+    plan_user_segcap_hook() = &user_seg_cap;
     return HIPADJ_OK;
 }
 
@@ -676,6 +705,7 @@ inline int user_register_wide(const char* name, int32_t n, int32_t np, int32_t t
     R.models.push_back(m);
     *id = HIPADJ_MODEL_USER_BASE + (int32_t)R.models.size() - 1;
     plan_user_sizes_hook() = &user_model_sizes;
+    plan_user_segcap_hook() = &user_seg_cap;
     plan_user_wide_hook() = &user_model_is_wide;
     return HIPADJ_OK;
 }

@@ -33,6 +33,7 @@ class EventSolution:
     edges: list                  # [t0, e_1, ..., e_k, t_end]
     u_left: list                 # state at the end of piece j (before the affect), j < last
     p_piece: list                # parameters of piece j, [N][np] (they change where an affect edits pn)
+    mass_matrix: object          # the model's mass matrix AT SOLVE TIME (or None): the reverse chain converts with it, whatever the registry holds later
     u: np.ndarray                # [N][M][n] = sol(ts), right limits at event times
     t: np.ndarray
     prob: object
@@ -80,7 +81,10 @@ def solve_with_events(solve, ts_of, ensprob, alg, callback, *, saveat=None, dt=N
         sv = [ts[i] for i in own] + ([] if last else [b])          # the piece's end state feeds the affect
         pj = EnsembleProblem(ODEProblem(prob.f, u0[0], (a, b), pcur[0], prob.dims), u0, pcur)
         p_piece.append(pcur)
-        sol = solve(pj, alg, dt=dt, saveat=sv, device=device, dgdu_discrete=None, **kw)
+        # the first piece inherits the start-point rule of the ordinary path: no_start = !save_start && t0 in ts suppresses the loss jump at t0
+        # (src/concrete_solve.jl:962, src/adjoint_common.jl:761); later pieces start at an event time, where nothing is suppressed
+        ns = bool(j == 0 and not save_start and len(ts) and ts[0] == t0)
+        sol = solve(pj, alg, dt=dt, saveat=sv, device=device, dgdu_discrete=None, no_start=ns, **kw)
         pieces.append(sol); cols.append(own)
         if out is None:
             out = np.zeros((N, len(ts), sol.u.shape[2]))
@@ -90,12 +94,18 @@ def solve_with_events(solve, ts_of, ensprob, alg, callback, *, saveat=None, dt=N
             ul = np.ascontiguousarray(sol.u[:, -1, :])
             u_left.append(ul)
             u0, pcur = _lib.affect_apply(mid, ul, pcur, b, npar, device=device)
-    return EventSolution(pieces=pieces, piece_cols=cols, edges=edges, u_left=u_left, p_piece=p_piece, u=out, t=np.asarray(ts), prob=ensprob, alg=alg, model_id=mid, device=device,
+    mm = _lib.MASS.get(mid)
+    return EventSolution(pieces=pieces, piece_cols=cols, edges=edges, u_left=u_left, p_piece=p_piece, mass_matrix=None if mm is None else np.array(mm), u=out, t=np.asarray(ts), prob=ensprob, alg=alg, model_id=mid, device=device,
                          extra=dict(dgdu_discrete=dgdu_discrete, callback=callback))
 
 
-def adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, *, t=None, dgdu_discrete=None, dgdp_discrete=None, **kw):
-    """(du0, dp) of an event problem: the pieces' reverse passes from the last to the first, chained by the reverse callbacks."""
+def adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, *, t=None, dgdu_discrete=None, dgdp_discrete=None, sensealg=None, checkpoints=None, **kw):
+    """(du0, dp) of an event problem: the pieces' reverse passes from the last to the first, chained by the reverse callbacks.  `sensealg` must be the one
+    of the forward solve (each piece checks it, like the ordinary path); `checkpoints` is refused: the pieces use their own defaults."""
+    if checkpoints is not None:
+        raise ValueError("callback: `checkpoints` is not combined with event problems (the pieces use their defaults)")
+    if sensealg is not None:
+        kw = dict(kw, sensealg=sensealg)
     if dgdp_discrete is not None:
         raise ValueError("callback: dgdp_discrete is not supported for hybrid systems (the reference errors likewise, src/callback_tracking.jl:283-284)")
     if t is not None and not np.array_equal(np.asarray(t, dtype=np.float64), sol.t):
@@ -124,7 +134,7 @@ def adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, *, t=None, dgd
         if j > 0:                                                    # reverse callback of the event between piece j - 1 and piece j
             # with a mass matrix a piece returns the reference's lam(t0) = M^{-T} dL/du (src/sensitivity_interface.jl:500); the callback acts on
             # dL/du itself, and the cotangent handed to the lower piece is a dL/du as well: convert (rows: lam' M)
-            M = _lib.MASS.get(sol.model_id)
+            M = sol.mass_matrix                                      # snapshot taken at solve time
             lam_true = du0 if M is None else du0 @ M
             lam_in, gp = _lib.affect_vjp(sol.model_id, sol.u_left[j - 1], sol.p_piece[j - 1], sol.edges[j], lam_true, gp, device=sol.device)
     return du0, (gp.sum(axis=0) if shared else gp)

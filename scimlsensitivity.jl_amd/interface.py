@@ -52,7 +52,7 @@ def _save_times(tspan, saveat, dt, save_everystep=False, save_start=True, save_e
     return np.ascontiguousarray(np.sort(np.asarray(saveat, dtype=np.float64)))
 
 
-def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
+def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False, t1=None):
     """sensealg options -> handle configuration.  `checkpoints` (adjoint_sensitivities' keyword, default sol.t; src/sensitivity_interface.jl:
     484-486, src/backsolve_adjoint.jl:132): any strictly ascending list — on the step grid for RK4(), arbitrary for Tsit5(); an equally
     spaced grid list is handed over as a stride (the planner's cheaper form), anything else as the explicit list (ABI 102)."""
@@ -66,9 +66,15 @@ def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False):
             if not adaptive and len(ck) > 1:
                 ks = np.rint((ck - t0) / dt).astype(np.int64)
                 d = np.diff(ks)
-                if np.all(np.abs((ck - t0) / dt - ks) < 1e-6) and ks[0] == 0 and np.all(d[:-1] == d[0]) and d[-1] <= d[0]:
-                    kw["ckpt_stride"] = int(d[0])          # 0, s, 2s, ... (+ the end point): the stride form
-                    return kw
+                # the stride form means {0, s, 2s, ...} + the end point T: only a list that IS that set may take it ([0, 2, 4, 5] on [0, 10]
+                # is not stride 2 — its checkpoints are {0, 2, 4, 5, 10}, not {0, 2, ..., 10})
+                S = None if t1 is None else int(np.rint((t1 - t0) / dt))
+                on_grid = np.all(np.abs((ck - t0) / dt - ks) < 1e-6)
+                if on_grid and S is not None and ks[0] == 0 and np.all(d[:-1] == d[0]) and d[-1] <= d[0]:
+                    s_ = int(d[0])
+                    if set(ks.tolist()) | {S} == set(range(0, S + 1, s_)) | {S}:
+                        kw["ckpt_stride"] = s_
+                        return kw
             kw["checkpoints"] = ck
     elif isinstance(sensealg, QuadratureAdjoint):
         kw["quad_abstol"], kw["quad_reltol"] = sensealg.abstol, sensealg.reltol
@@ -117,7 +123,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
                  loss_kind=loss_kind, loss_shift=shift, p_shared=(ensprob.p.ndim == 1), device=device,
                  time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_COSTS[type(g)] if g is not None else 0),
                  stepper=(1 if adaptive else 0), abstol=abstol, reltol=reltol, max_steps=max_steps,
-                 **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive))
+                 **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive, t1=prob.tspan[1]))
     out = eng.forward(ensprob.u0, ensprob.p, want_out=want_out)
     idxs = None
     if save_idxs is not None:
@@ -158,7 +164,8 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_di
     which does not contain mu, so the jumps commute with the integration and their sum is added to dp once, exactly."""
     from . import events
     if isinstance(sol, events.EventSolution):     # DiscreteCallback problem: the pieces' reverse passes chained by the reverse callbacks
-        return events.adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, t=t, dgdu_discrete=dgdu_discrete, dgdp_discrete=dgdp_discrete, g=g, **kwargs)
+        return events.adjoint_sensitivities_events(adjoint_sensitivities, sol, alg, t=t, dgdu_discrete=dgdu_discrete, dgdp_discrete=dgdp_discrete, g=g,
+                                                   sensealg=sensealg, checkpoints=checkpoints, **kwargs)
     if kwargs:
         raise TypeError(f"unsupported keyword(s) {sorted(kwargs)} (callbacks: SURVEY.md §8f)")
     if dgdp_discrete is not None:

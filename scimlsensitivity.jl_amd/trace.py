@@ -46,7 +46,10 @@ class Node:
     def _no_compare(self, o):
         raise TypeError("comparisons of traced values are not traceable (the device code is straight-line)")
 
-    __lt__ = __le__ = __gt__ = __ge__ = _no_compare
+    __lt__ = __le__ = __gt__ = __ge__ = __eq__ = __ne__ = _no_compare     # == / != too: an identity comparison would silently bake one branch into the device code
+    __hash__ = object.__hash__                                              # the graph maps key nodes by identity
+
+    def __abs__(self): return fabs(self)
 
 
 def _n(x):

@@ -2,7 +2,7 @@
 """Torch-free timing of the headline workload and of the off-grid sweep through the host-pointer C ABI (HIPADJ_NO_TORCH=1:
 no torch import, the process runs on the HIP runtime of the ROCm installation alone — what a Julia host sees).  Prints one JSON
 line per case: the library's own HIP events around the dominant kernel (hipadj_stats) and the wall time of the synchronous
-host call (PCIe-inclusive: u0 in, du0 / dp out).  scripts/gpu_quick2.sh runs it plain and under rocprofv3 --kernel-trace --stats."""
+host call (PCIe-inclusive: u0 in, du0 / dp out).  scripts/archive/gpu_quick2.sh runs it plain and under rocprofv3 --kernel-trace --stats."""
 import json
 import os
 import sys

@@ -535,3 +535,32 @@ def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
     assert "sample" in cb and f"{cb['cores']} of {cb['host_threads']} host threads" in cb["cores_note"]
     assert cb["repeats"] >= 5 and cb["spread_min_max"][0] <= cb["value"] <= cb["spread_min_max"][1] and str(cb["cores"]) + ":" in cb["thread_probe_traj_per_s"]
     assert np.allclose(bench.save_times(), ts) and bench.oracle_problem().M == 101
+
+
+def test_an_untrusted_runtime_compiler_gets_the_conservative_limits(tmp_path):
+    """when the toolkit's hiprtc cannot be bound by path (a torch wheel without a ROCm installation) the soname resolves to whatever the process
+    carries — the bundled ROCm 7.0 pair miscompiled wide runtime models.  rtc_trusted() then limits segment lanes to 64 doubles of state
+    again (an 8-state ring runs the one-column kernels: SEG = false, k_finish_map) and says so once on stderr.  HIPADJ_RTC_TRUST=0 stands in for that situation."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, glob, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import scimlsensitivity_jl_amd as sa, user_models as UM, emu as E
+from scimlsensitivity_jl_amd import _lib
+m = UM.ring(8)
+mid = _lib.register_model("trust_ring8", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+cfg = E.make_config("trust_ring8", "interpolating", 10000, 0.0, 10.0, 0.01, 0.1 * np.arange(1, 101), loss_kind=0, p_shared=False); cfg.model = mid
+L = _lib.load()
+assert L.hipadj_model_check_config(C.byref(cfg)) == 0, L.hipadj_last_error(None)
+tu = open(sorted(glob.glob(sys.argv[1] + "/trust_ring8_*.hip"))[-1]).read()
+print("SEG_TRUE" if "k_interp<hipadj::UserModel, 1, 0, true>" in tu else "SEG_FALSE" if "k_interp<hipadj::UserModel, 1, 0, false>" in tu else "UNKNOWN")
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    out = {}
+    for trust in ("1", "0"):
+        d = tmp_path / trust; d.mkdir()
+        env = dict(os.environ, HIPADJ_RTC_TRUST=trust, HIPADJ_RTC_DUMP=str(d))
+        r = subprocess.run([sys.executable, "-c", code, str(d)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[trust] = (r.stdout.strip().splitlines()[-1], r.stderr)
+    assert out["1"][0] == "SEG_TRUE" and out["0"][0] == "SEG_FALSE"

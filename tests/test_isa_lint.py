@@ -59,7 +59,7 @@ def test_inner_retry_probe(tmp_path, monkeypatch):
     m = UM.ring(4)
     _lib.register_model("ring4_lint_retry", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
     monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
-    monkeypatch.setenv("HIPADJ_RTC_FLAGS", "-DHIPADJ_TS5_WIDE=64")
+    monkeypatch.setenv("HIPADJ_RTC_FLAGS", "-DHIPADJ_TS5_WIDE=64 -DHIPADJ_TS5_PADDED=1")   # the batched zero-padded stage sum of rounds 1-2: the code the old compiler mis-places
     cfg = E.make_config("ring4_lint_retry", "backsolve", 53, 0.0, 0.5, 0.0, [], loss_kind=1, stepper=1, abstol=1e-9, reltol=1e-9, checkpointing=False)
     L = _lib.load()
     assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
