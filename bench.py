@@ -35,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 T_FINAL, DT, SAVE_DT, LOSS_SHIFT, SEED = 10.0, 0.01, 0.1, 2.0, 20240601
 HBM_PEAK_GBS, FP64_MFMA_PEAK_TF, FP64_VALU_PEAK_TF = 8000.0, 78.6, 78.6     # /opt/skills/guides/MI355X_MICROARCH.md
+LDS_EXCHANGE_US_1024 = 0.38    # one LDS stage exchange of a 1024-thread workgroup (publish, barrier, stencil reads): scripts/r3/lds_exchange_floor.hip, profiles/r3_lds_exchange_floor.log
 
 
 def inputs(n_total):
@@ -351,11 +352,11 @@ def other_configs(sa, torch):
     executed = ((4 + 6 + 2) * S + jumps) * 2.0 * H * H * B
     out.append(dict(config="configs[3]: MLP 2-128-128-2, batch 4096, 150 RK4 steps, GaussAdjoint (1 GPU)", reverse_ms=ms, sweep_kernel_ms=kms,
                     gradient_reduction_ms=ms - kms, workspace_GB=st["workspace_bytes"] / 1e9,
-                    roofline=dict(bound="mfma", achieved=nominal / (ms * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
-                                  frac=nominal / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, kernel="k_mlp_adjoint_grad",
-                                  executed_TFLOPs=executed / (kms * 1e-3) / 1e12, executed_frac=executed / (kms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
-                                  note="nominal = the reference algorithm's 12 contractions + 2 weight-gradient outer products per step over the WHOLE reverse pass "
-                                       "(round 1: 241.6 + 54.5 GFLOP in 10.2 ms = 29 TFLOP/s); executed = what the kernel issues after first-same-as-last reuse")))
+                    roofline=dict(bound="mfma", achieved=executed / (kms * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                                  frac=executed / (kms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, kernel="k_mlp_adjoint_grad",
+                                  nominal_TFLOPs=nominal / (ms * 1e-3) / 1e12, nominal_frac=nominal / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
+                                  note="achieved / frac count the contractions the kernel EXECUTES (after first-same-as-last reuse) over the sweep kernel's time; nominal = the reference "
+                                       "algorithm's 12 contractions + 2 weight-gradient outer products per step over the whole reverse pass, i.e. work the kernel skips included")))
     eng.close()
     # configs[4]: Brusselator 32 x 32 (n = 2048), QuadratureAdjoint, 400 explicit RK4 steps; N = 1 (the config) and N = 256 (fills the chip)
     G, dtb, Sb = 32, 2.5e-5, 400
@@ -365,10 +366,19 @@ def other_configs(sa, torch):
         ms, kms, st = run(eng, bruss_u0(G, N), np.array([3.4, 1.0, 10.0]), rng.standard_normal((N, len(tsb), 2 * G * G)), 3)
         n = 2 * G * G
         by = N * (Sb + 1) * 16.0 * n + N * Sb * 32.0 * n      # knots read + dense-lambda record written
+        if N == 1:
+            # ONE workgroup on ONE CU: nothing streams, the step is a chain of LDS exchanges.  Floor model from scripts/r3/lds_exchange_floor.hip on this chip
+            # (profiles/r3_lds_exchange_floor.log): publishing a stage vector, the barrier and the five-point stencil reads of one stage cost 0.38 us for 1024
+            # threads (a bare barrier: 0.039 us); the lambda pass has 4 such exchanges per step (5 where a loss jump follows)
+            floor_us = 4 * LDS_EXCHANGE_US_1024
+            roof = dict(bound="latency", kernel="k_bruss_quad_adj", achieved_us_per_step=kms * 1e3 / Sb, floor_us_per_step=floor_us, frac=floor_us / (kms * 1e3 / Sb),
+                        note="frac = floor / achieved; floor = 4 LDS stage exchanges x 0.38 us (measured, 1024 threads: profiles/r3_lds_exchange_floor.log); HBM is idle at N = 1 "
+                             f"({by / (kms * 1e-3) / 1e9:.0f} GB/s)")
+        else:
+            roof = dict(bound="hbm", achieved=by / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        kernel="k_bruss_quad_adj", algorithmic_bytes_per_launch=by)
         out.append(dict(config=f"configs[4]: Brusselator 32x32, QuadratureAdjoint, 400 RK4 steps, N = {N} (1 GPU)", reverse_ms=ms, lambda_pass_ms=kms,
-                        us_per_step=kms * 1e3 / Sb,
-                        roofline=dict(bound="hbm", achieved=by / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      kernel="k_bruss_quad_adj", algorithmic_bytes_per_launch=by)))
+                        us_per_step=kms * 1e3 / Sb, roofline=roof))
         eng.close()
     # ---- wide runtime models (csrc/hipadj_wide.hpp): the two problems the reference itself holds beyond 8 states / 32 parameters
     try:

@@ -1,7 +1,7 @@
 """
     HIPAdj
 
-Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 105) — the MI355X-native batched continuous-adjoint
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 106) — the MI355X-native batched continuous-adjoint
 engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
 
   * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, dense_chain_bodies, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -39,7 +39,7 @@ function lib()
     if LIB[] == C_NULL
         LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
         v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
-        v == 105 || error("libhipadj ABI version $v, this binding was written for 105")
+        v == 106 || error("libhipadj ABI version $v, this binding was written for 106")
     end
     return LIB[]
 end
@@ -172,6 +172,73 @@ function register_model(name::AbstractString, n::Integer, np::Integer; f::Abstra
     mass_matrix === nothing || set_mass_matrix!(id[], n, mass_matrix)
     check_now && check(ccall(sym(:hipadj_model_check), Cint, (Int32,), id[]))
     return DeviceModel(id[], (Int32(0), Int32(0), Int32(0), Int32(0)), Int(n), Int(np))
+end
+
+"""
+    register_wide_model(name, n, np; f, vjp, threads = 0, lds_doubles = 0, nacc = 0, acc_first = 0) -> DeviceModel
+
+A model for the workgroup-per-trajectory family (`hipadj_wmodel_register`, ABI 106): more than 8 states or more than 32 parameters, up to
+`n = 4096`.  `f` and `vjp` are SPMD bodies run by every thread of the workgroup that owns a trajectory (`HIPADJ_W_FOR(i, count)`, `wg_sync()`,
+`wg_sum(x)`, `ws[...]`; include/hipadj.h); `vjp` is the joint product of `vecjacobian!` (src/derivative_wrappers.jl:256-267): `dlam` and, under
+`if (WP)`, the parameter gradient (`gp[j] += w * ...` for entries owned by one thread, `acc[q] += w * ...` for the `nacc` parameters
+`acc_first + q` fed by every component).  Fixed-step RK4, loss times on the step grid, the four sensealgs.
+`dense_chain_bodies(widths; input_power)` below writes the two bodies for `Lux.Chain(x -> x.^k, Dense(..., tanh), ..., Dense(...))`.
+"""
+function register_wide_model(name::AbstractString, n::Integer, np::Integer; f::AbstractString, vjp::AbstractString, threads::Integer = 0,
+        lds_doubles::Integer = 0, nacc::Integer = 0, acc_first::Integer = 0, check_now::Bool = true)
+    id = Ref{Int32}(0)
+    sname, sf, sv = String(name), String(f), String(vjp)
+    GC.@preserve sname sf sv begin
+        check(ccall(sym(:hipadj_wmodel_register), Cint, (Ptr{UInt8}, Int32, Int32, Int32, Int32, Int32, Int32, Ptr{UInt8}, Ptr{UInt8}, Ref{Int32}),
+                    pointer(sname), Int32(n), Int32(np), Int32(threads), Int32(lds_doubles), Int32(nacc), Int32(acc_first), pointer(sf), pointer(sv), id))
+    end
+    check_now && check(ccall(sym(:hipadj_model_check), Cint, (Int32,), id[]))
+    return DeviceModel(id[], (Int32(0), Int32(0), Int32(0), Int32(0)), Int(n), Int(np))
+end
+
+"""
+    dense_chain_bodies(widths; input_power = 1) -> (f, vjp, np, lds_doubles)
+
+The SPMD bodies of `u' = Chain(x -> x.^input_power, Dense(w1, w2, tanh), ..., Dense(w_{L}, w_{L+1}))(u)` with the parameters in Lux's flattening
+order (per layer: weight `[out x in]` column-major, then bias).  Lanes run over the outputs of a layer; a contraction with at most 8 outputs over at
+least 16 inputs runs lanes-over-inputs with one `wg_sum` (wavefront shuffles) per output.  Mirrors `WideDeviceFunction.dense_chain` of the Python host.
+"""
+function dense_chain_bodies(widths; input_power::Integer = 1)
+    w = collect(Int, widths); L = length(w) - 1
+    (L >= 1 && w[1] == w[end]) || error("widths = (n, ..., n) with at least one layer")
+    Woff = zeros(Int, L); Boff = zeros(Int, L); off = 0
+    for l in 1:L
+        Woff[l] = off; off += w[l + 1] * w[l]; Boff[l] = off; off += w[l + 1]
+    end
+    A = zeros(Int, L); for l in 2:L; A[l] = A[l - 1] + w[l - 1]; end          # activations a_0 .. a_{L-1} in ws (a_{l-1} at A[l])
+    G = zeros(Int, L); o = A[L] + w[L]
+    for l in L:-1:1; G[l] = o; o += w[l]; end                                   # backward vectors g_{l-1} at G[l]
+    inp = join(fill("u[i]", input_power), " * ")
+    dinp(j) = input_power == 1 ? "1.0" : string(Float64(input_power), " * ", join(fill("u[$j]", input_power - 1), " * "))
+    function matvec(out, nout, nin, coef, vec; bias = nothing, post = s -> s)
+        if nout <= 8 && nin >= 16
+            return [string("{ double part = 0.0; HIPADJ_W_FOR(j, $nin) part += ", coef(string(i), "j"), " * ", vec("j"), "; const double s = ",
+                           bias === nothing ? "" : string(bias(string(i)), " + "), "wg_sum(part); if (tid == 0) ", out(string(i)), " = ", post("s", string(i)), "; }") for i in 0:(nout - 1)]
+        end
+        return [string("HIPADJ_W_FOR(i, $nout) { double s = ", bias === nothing ? "0.0" : bias("i"), "; for (int j = 0; j < $nin; ++j) s += ", coef("i", "j"), " * ", vec("j"),
+                       "; ", out("i"), " = ", post("s", "i"), "; }")]
+    end
+    fwd = String["HIPADJ_W_FOR(i, $(w[1])) ws[$(A[1]) + i] = $inp;", "wg_sync();"]
+    for l in 1:(L - 1)
+        append!(fwd, matvec(i -> "ws[$(A[l + 1]) + $i]", w[l + 1], w[l], (i, j) -> "p[$(Woff[l]) + $i + $j * $(w[l + 1])]", j -> "ws[$(A[l]) + $j]";
+                            bias = i -> "p[$(Boff[l]) + $i]", post = (s, i) -> "tanh($s)"))
+        push!(fwd, "wg_sync();")
+    end
+    fb = vcat(fwd, matvec(i -> "du[$i]", w[L + 1], w[L], (i, j) -> "p[$(Woff[L]) + $i + $j * $(w[L + 1])]", j -> "ws[$(A[L]) + $j]"; bias = i -> "p[$(Boff[L]) + $i]", post = (s, i) -> s))
+    vb = copy(fwd)
+    for l in L:-1:1
+        gl = l == L ? "lam" : "(ws + $(G[l + 1]))"
+        push!(vb, "if (WP) { HIPADJ_W_FOR(e, $(w[l + 1] * w[l])) gp[$(Woff[l]) + e] += w * $gl[e % $(w[l + 1])] * ws[$(A[l]) + e / $(w[l + 1])]; HIPADJ_W_FOR(i, $(w[l + 1])) gp[$(Boff[l]) + i] += w * $gl[i]; }")
+        append!(vb, matvec(l == 1 ? (j -> "dlam[$j]") : (j -> "ws[$(G[l]) + $j]"), w[l], w[l + 1], (j, i) -> "p[$(Woff[l]) + $i + $j * $(w[l + 1])]", i -> "$gl[$i]";
+                           post = (s, j) -> l == 1 ? "$s * $(dinp(j))" : "$s * (1.0 - ws[$(A[l]) + $j] * ws[$(A[l]) + $j])"))
+        l > 1 && push!(vb, "wg_sync();")
+    end
+    return join(fb, "\n"), join(vb, "\n"), off, o
 end
 
 """

@@ -6,7 +6,7 @@ using Test, HIPAdj, SciMLSensitivity, OrdinaryDiffEq, Zygote, Random
 
 @testset "layout" begin
     @test HIPAdj.check_layout()
-    @test hipadj_version() == 105
+    @test hipadj_version() == 106
     @test occursin("libhiprtc", runtime_compiler())          # the build toolkit's hiprtc (a Julia process carries no other)
 end
 
@@ -67,4 +67,22 @@ end
     du0, dp = adjoint_sensitivities(sol, Tsit5(); sensealg = dev, dgdu_discrete = dg)
     @test isapprox(dp ./ 4, dp_ref; rtol = 1e-8)            # shared p: the device sums over the 4 identical columns
     @test isapprox(du0[:, 1], du0_ref; rtol = 1e-8)         # lam(t0), the reference's convention
+end
+
+# ---- wide runtime models (ABI 106): the Julia emitter writes the same SPMD text as the Python host's (tests/golden/dense_chain_bodies.json), and the
+# 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62 registers and compiles for gfx950
+@testset "wide models" begin
+    gold_path = joinpath(@__DIR__, "..", "..", "tests", "golden", "dense_chain_bodies.json")
+    if isfile(gold_path)
+        txt = read(gold_path, String)
+        # no JSON package in the test environment: compare through the escaped form the file holds
+        esc(s) = replace(replace(s, "\\" => "\\\\"), "\n" => "\\n", "\"" => "\\\"")
+        f, vjp, np, nw = dense_chain_bodies((2, 50, 2); input_power = 3)
+        @test np == 252
+        @test occursin(esc(f), txt) && occursin(esc(vjp), txt)
+        f3, vjp3, np3, _ = dense_chain_bodies((3, 16, 24, 3))
+        @test np3 == 547 && occursin(esc(f3), txt) && occursin(esc(vjp3), txt)
+        m = register_wide_model("node_2_50_2", 2, np; f = f, vjp = vjp, lds_doubles = nw)      # compiles forward + the four sweeps (no device needed)
+        @test m.n == 2 && m.np == 252
+    end
 end

@@ -95,7 +95,9 @@ constexpr int KS_ROWS = 8, KS_UPREV = 7;
 #define HIPADJ_TS5_WIDE 9
 #endif
 #ifndef HIPADJ_TS5_PADDED
-#define HIPADJ_TS5_PADDED 0
+#define HIPADJ_TS5_PADDED 1
+// A/B on one box, round 3 (profiles/r3_tsit5_stage_sum_ab.log): the zero-padded 6-term stage sum is 10-12 % FASTER than the sum with exactly its
+// terms behind a switch (Lorenz reverse 2.21 vs 2.48 ms, LV 0.52 vs 0.58): the sweep is bound by one wave's dependent chain, not by its FMA count
 #endif
 constexpr int TS5_WIDE = HIPADJ_TS5_WIDE;   // widest state vector whose six stage rows are summed in one batch (tsit5_integrate)
 template <int NZ> struct KStore {
@@ -236,8 +238,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
 #pragma unroll
             for (int i = 0; i < NZ; ++i) w[i] = 0.0;
             if constexpr (NZ <= TS5_WIDE && HIPADJ_TS5_PADDED) {
-                // the zero-padded 6-term form of rounds 1-2 (-DHIPADJ_TS5_PADDED=1): kept as the subject of the spill-placement probe of tests/test_isa_lint.py
-                // and for A/B builds; rows j >= s of K hold finite leftovers that the zero coefficients annihilate
+                // the zero-padded 6-term form (default): rows j >= s of K hold finite leftovers that the zero coefficients annihilate
                 double as[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) as[j] = TS5::a(s, j);
@@ -246,8 +247,8 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
 #pragma unroll
                     for (int i = 0; i < NZ; ++i) w[i] += as[j] * K.get(j, i);
             } else if constexpr (NZ <= TS5_WIDE) {
-                // only the s rows the tableau really has, coefficients as literals (round 3): the zero-padded 6-term form issued 36 NZ multiply-adds and
-                // LDS reads per step where 21 NZ are needed
+                // -DHIPADJ_TS5_PADDED=0: only the s rows the tableau really has, coefficients as literals (21 NZ instead of 36 NZ multiply-adds and LDS reads
+                // per step) — measured SLOWER (see the macro), kept for A/B builds
                 switch (s) {
                 case 1: tsit5_stage_sum<NZ, 1>(K, w); break;
                 case 2: tsit5_stage_sum<NZ, 2>(K, w); break;

@@ -696,8 +696,8 @@ inline int user_register_wide(const char* name, int32_t n, int32_t np, int32_t t
     if (threads % 64 != 0 || threads < 64 || threads > 1024) { err = "hipadj_wmodel_register: threads must be a multiple of 64 between 64 and 1024 (0 = automatic)"; return HIPADJ_ERR_INVALID_ARG; }
     if ((n + threads - 1) / threads > 16) { err = "hipadj_wmodel_register: more than 16 state components per thread (raise threads)"; return HIPADJ_ERR_INVALID_ARG; }
     // LDS of the heaviest kernel (Backsolve: four state-sized tiles) + the model's scratch + the gradient accumulator (np <= 8192) + reduction rows: 160 KB per workgroup
-    const long lds = 4L * n + lds_doubles + (np <= 8192 ? np : 1) + (threads / 64) * 34 + 64;
-    if (lds * 8 > 160L * 1024) { err = "hipadj_wmodel_register: 4 n + lds_doubles + min(np, 8192) doubles exceed the 160 KB of LDS of a workgroup"; return HIPADJ_ERR_INVALID_ARG; }
+    const long lds = 4L * n + lds_doubles + (np <= 8192 ? np : 1) + (np <= 4096 ? np : 1) + (threads / 64) * 34 + 64;   // tiles + scratch + gradient accumulator + parameter copy
+    if (lds * 8 > 160L * 1024) { err = "hipadj_wmodel_register: 4 n + lds_doubles + the gradient accumulator (np <= 8192) + the parameter copy (np <= 4096) exceed the 160 KB of LDS of a workgroup"; return HIPADJ_ERR_INVALID_ARG; }
     UserRegistry& R = user_registry();
     std::lock_guard<std::mutex> lk(R.mu);
     UserModelSrc m; m.name = name; m.n = n; m.np = np; m.f = f; m.wvjp = vjp; m.wide = true; m.cols = false;

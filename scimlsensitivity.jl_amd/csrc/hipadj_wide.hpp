@@ -110,8 +110,23 @@ template <class Mo> struct WideShape {
     static constexpr int Q = (N + T - 1) / T;                 // owned components per thread
     static constexpr int QP = (NP + T - 1) / T;               // owned parameter entries per thread (zeroing / writing gp)
     static constexpr bool GP_LDS = NP <= 8192;                // the gradient accumulator of a sweep: LDS up to 64 KB, else the trajectory's dp row in HBM
+    static constexpr bool P_LDS = NP <= 4096;                 // the parameters themselves: copied into LDS once per kernel (up to 32 KB).  Every phase of a model
+                                                              // body starts by reading weights; from HBM / L2 that is a ~0.3 us round trip per phase on a lone
+                                                              // workgroup (the 2-50-2 neural ODE: 1.5 us per joint VJP, four phases), from LDS it is ~50 ns
     static_assert(T % 64 == 0 && T >= 64 && T <= 1024, "threads per trajectory: a multiple of 64 up to 1024");
 };
+
+// the trajectory's parameter vector as the model bodies see it: an LDS copy (filled here; the caller's next barrier publishes it) or the global row
+template <class Mo>
+__device__ __forceinline__ const double* wide_params(double* __restrict__ sp, const double* __restrict__ p, int p_shared, long traj) {
+    using W = WideShape<Mo>;
+    const double* src = p_shared ? p : p + traj * W::NP;
+    if constexpr (W::P_LDS) {
+        for (int j = threadIdx.x; j < W::NP; j += W::T) sp[j] = src[j];
+        wide_sync<W::T>();
+        return sp;
+    } else return src;
+}
 
 // ---- forward solve: fixed-step RK4, knots (u_k, f(u_k)), out = sol(ts) on the grid, Backsolve's checkpoints and y(T) --------------------------
 template <class Mo>
@@ -120,9 +135,9 @@ __global__ void __launch_bounds__(Mo::T) k_wide_forward(WideGeom g, const double
                                                         const int* __restrict__ ckpt_of_knot, double* __restrict__ yT) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, T = W::T, Q = W::Q;
-    __shared__ double us[N], du[N], ws[W::NW];
+    __shared__ double us[N], du[N], ws[W::NW], sp[W::P_LDS ? W::NP : 1];
     const long traj = blockIdx.x; const int tid = threadIdx.x;
-    const double* pp = g.p_shared ? p : p + traj * W::NP;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     double u[Q], k1[Q], k2[Q], k3[Q], k4[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) { const int c = tid + q * T; u[q] = c < N ? u0[traj * N + c] : 0.0; }
@@ -272,9 +287,9 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double
                                                         const int* __restrict__ save_of_knot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
-    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1];
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
     const long traj = blockIdx.x;
-    const double* pp = g.p_shared ? p : p + traj * NP;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
     wide_zero_gp<Mo>(L);
     double lam[Q], acc[W::NA];
@@ -326,9 +341,9 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve(WideGeom g, const doub
                                                           double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
-    __shared__ double sy[N], sls[N], sdl[N], sdu[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1];
+    __shared__ double sy[N], sls[N], sdl[N], sdu[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
     const long traj = blockIdx.x; const int tid = threadIdx.x;
-    const double* pp = g.p_shared ? p : p + traj * NP;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
     wide_zero_gp<Mo>(L);
     double lam[Q], y[Q], acc[W::NA];
@@ -380,9 +395,9 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_adj(WideGeom g, const doubl
                                                          const int* __restrict__ save_of_knot, double* __restrict__ adj, double* __restrict__ du0, int* __restrict__ flag) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
-    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW];
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sp[W::P_LDS ? NP : 1];
     const long traj = blockIdx.x; const int tid = threadIdx.x;
-    const double* pp = g.p_shared ? p : p + traj * NP;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     WideTiles<Mo> L{sy, sls, sdl, nullptr, sws, nullptr};
     double lam[Q], dacc[W::NA] = {};
 #pragma unroll
@@ -422,9 +437,9 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
     __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * (2 * W::NA > 2 ? 2 * W::NA : 2)], sacc[2 * W::NA], sfi[W::GP_LDS ? NP : 1];
-    __shared__ double seg_a[MAXSEG], seg_b[MAXSEG], seg_E[MAXSEG], sn[2];
+    __shared__ double seg_a[MAXSEG], seg_b[MAXSEG], seg_E[MAXSEG], sn[2], sp[W::P_LDS ? NP : 1];
     const long traj = blockIdx.x; const int qi = blockIdx.y, tid = threadIdx.x, nq = gridDim.y;
-    const double* pp = g.p_shared ? p : p + traj * NP;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     double* base = scratch + ((traj * nq + qi) * (long)(3 + MAXSEG)) * NP;
     double *IK = base, *IG = base + NP, *fig = base + 2 * NP, *segI = base + 3 * NP;   // Kronrod sum, Gauss sum, integrand (HBM form), segment integrals
     double* fi = W::GP_LDS ? sfi : fig;

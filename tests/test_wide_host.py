@@ -63,3 +63,14 @@ def test_planner_answers_for_wide_models(sa):
     rc, msg = check(alg=0, checkpointing=1); assert rc == -6 and "checkpointing" in msg
     off = np.array([0.0, 0.333, 1.0])
     rc, msg = check(nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double))); assert rc == -6 and "step grid" in msg
+
+
+def test_dense_chain_emitter_matches_its_golden_text(sa):
+    """tests/golden/dense_chain_bodies.json holds the SPMD bodies the Python emitter writes for two chains; julia/test/runtests.jl compares
+    `HIPAdj.dense_chain_bodies` (the Julia emitter, never executed in this image) with the same file — one text, two host languages."""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dense_chain_bodies.json")) as f:
+        gold = json.load(f)
+    for key, g in gold.items():
+        m = sa.WideDeviceFunction.dense_chain("regold_" + key, g["widths"], input_power=g["input_power"])
+        assert m.np == g["np"] and m.source["f"] == g["f"] and m.source["vjp"] == g["vjp"], key
