@@ -9,6 +9,7 @@
 
 static thread_local std::string g_create_error;
 static int user_prepare(hipadj_handle* h);   // hiprtc compilation of the kernels of a runtime-registered model
+static bool fused_eligible(const hipadj_config* cfg, const Plan& P);   // which sweeps finish their reverse pass in one launch
 static int wide_prepare(hipadj_handle* h);   // ... of a wide model (workgroup-per-trajectory family, hipadj_wide.hpp)
 static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out);
 static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp);
@@ -322,8 +323,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         }
         {   // the composition tree of the one-launch reverse pass (hipadj_fused.hpp): map slots per (block, node) and arrival counters
             if (const char* e = std::getenv("HIPADJ_FUSED")) h->fused = std::atoi(e);
-            // kernels with a fused tail so far: the on-grid Interpolating / Gauss / Backsolve sweeps of the compiled-in models
-            if (!((cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_BACKSOLVE) && !P.ip_ckpt && !P.offgrid && !P.user)) h->fused = 0;
+            if (!fused_eligible(cfg, P)) h->fused = 0;
             int radix = 4;
             if (const char* e = std::getenv("HIPADJ_TREE_RADIX")) radix = std::atoi(e) == 8 ? 8 : 4;
             long slots = 0, ctrs = 0;
@@ -635,6 +635,12 @@ extern "C" int hipadj_get_stats(hipadj_handle* h, hipadj_stats* st) {
 // ---- runtime-compiled models (hipadj_user.hpp) --------------------------------------------------------------
 // Kernel instantiations a handle needs, by configuration.  Prefetch depths shrink with n: the knot ring holds
 // PF x 2n doubles in VGPRs.
+// kernels with a fused tail: the on-grid Interpolating / Gauss / GaussKronrod / Backsolve sweeps of the lane family (compiled-in and runtime models)
+static bool fused_eligible(const hipadj_config* cfg, const Plan& P) {
+    if (const char* e = std::getenv("HIPADJ_FUSED")) if (std::atoi(e) == 0) return false;
+    const bool alg_ok = cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || cfg->alg == HIPADJ_ALG_BACKSOLVE;
+    return alg_ok && !P.ip_ckpt && !P.offgrid && !P.adaptive && !P.wide && !P.field && !P.mlp;
+}
 struct UserKernels { std::string forward, main_k, tail, gk; };
 static UserKernels user_kernel_names(const hipadj_handle* h) {
     const std::string U = "hipadj::UserModel";
@@ -670,6 +676,17 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     }
     if (h->ip_ckpt) {   // checkpointing=true (Interpolating / Gauss): checkpoint tiles + in-kernel interval re-solve; the planner admits models whose segment columns fit the VGPRs
         k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_INTERPOLATING ? "hipadj::k_interp_ckpt<" : "hipadj::k_gauss_ckpt<") + U + ", " + I(mode) + (h->ck_long ? ", true>" : ", false>"); k.tail = compose;
+        return k;
+    }
+    if (h->fused && h->cfg.alg != HIPADJ_ALG_QUADRATURE) {   // one launch per reverse pass (hipadj_fused.hpp): the sweep kernel finishes the pass; `tail` stays a valid (unused) name
+        const std::string SB = seg ? "true" : "false";
+        switch (h->cfg.alg) {
+        case HIPADJ_ALG_INTERPOLATING: k.main_k = "hipadj::k_interp_fused<" + U + ", " + I(PF) + ", " + I(mode) + ", " + SB + ", false>"; break;
+        case HIPADJ_ALG_BACKSOLVE: k.main_k = "hipadj::k_backsolve_fused<" + U + ", " + I(cc) + ", " + SB + ">"; break;
+        case HIPADJ_ALG_GAUSS: k.main_k = "hipadj::k_gauss_fused<" + U + ", " + I(PFG) + ", " + I(mode) + ", false, " + SB + ">"; break;
+        default: k.main_k = "hipadj::k_gauss_fused<" + U + ", " + I(PFG) + ", " + I(mode) + ", true, " + SB + ">"; break;
+        }
+        k.tail = finish;
         return k;
     }
     switch (h->cfg.alg) {
@@ -720,6 +737,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
     if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg), code, low, err); }
     h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
+    h.fused = fused_eligible(cfg, P) ? 1 : 0;
     const UserKernels k = user_kernel_names(&h);
     std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
     if (!k.gk.empty()) exprs.push_back(k.gk);
@@ -742,6 +760,7 @@ template <class... P> struct usig<void (*)(P...)> {
     }
 };
 static_assert(std::is_same<decltype(&k_interp<ModelLV, 8, 1>), decltype(&k_gauss<ModelLV, 4, 1, false>)>::value, "k_interp / k_gauss share one launch site");
+static_assert(std::is_same<decltype(&k_interp_fused<ModelLV, 8, 1>), decltype(&k_gauss_fused<ModelLV, 4, 1, false>)>::value, "k_interp_fused / k_gauss_fused share one launch site");
 static_assert(std::is_same<decltype(&k_interp_ckpt<ModelLV, 1>), decltype(&k_gauss_ckpt<ModelLV, 1>)>::value, "k_interp_ckpt / k_gauss_ckpt share one launch site");
 static_assert(std::is_same<decltype(&k_interp_offgrid<ModelLV, 1>), decltype(&k_gauss_offgrid<ModelLV, 1>)>::value, "k_interp_offgrid / k_gauss_offgrid share one launch site");
 
@@ -826,6 +845,26 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         const dim3 sgrid(waves, (unsigned)h->nseg);
+        if (h->fused && h->d_tbuf && h->cfg.alg != HIPADJ_ALG_QUADRATURE) {
+            // one launch per reverse pass: the sweep kernel composes the segment maps, writes du0 / the dp rows and reduces dp (hipadj_fused.hpp)
+            TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
+            double* dps = h->cfg.p_shared ? d_dp : (double*)nullptr;
+            if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
+                TRY(usig<decltype(&k_backsolve_fused<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+                            (const double*)h->d_cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag));
+            else
+                TRY(usig<decltype(&k_interp_fused<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev,
+                            d_du0, dp_rows, dps, h->d_flag));
+            if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+            if (h->has_mm) {
+                MassInv mi; std::memcpy(mi.a, h->minv, sizeof(mi.a));
+                hipLaunchKernelGGL(k_mass_du0, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N, h->n, mi, d_du0);
+                HIP_TRY(h, hipGetLastError());
+            }
+            if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+            es.pending = h->timing >= 1; es.full = h->timing >= 2;
+            return HIPADJ_OK;
+        }
         if (h->ip_ckpt) {
             TRY(usig<decltype(&k_interp_ckpt<ModelLV, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck,
                                                                    (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride));

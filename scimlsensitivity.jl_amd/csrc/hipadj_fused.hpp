@@ -114,6 +114,56 @@ __device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, uns
     return true;
 }
 
+// The root of a trajectory block: v = (lam(t0)[N], mu(t0)[NP]) of the wave's 64 trajectories.  Writes du0 (caller layout) and the dp rows, scans for
+// NaN / Inf, and — shared parameters — sums mu over the lanes and, as the last block of the ensemble, over the blocks (fixed orders).
+// One-segment kernels (SEG = false, or C = 1) call this directly; segmented ones reach it through fused_tail.
+template <int N, int NP>
+__device__ __forceinline__ void fused_root(const double (&m)[N + NP], const TreePlan& T, long ntraj, long blocks, long block,
+                                           double* __restrict__ du0, double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const long i = block * 64 + lane;
+    const bool valid = i < ntraj;
+    bool bad = false;
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) { du0[i * N + j] = m[j]; bad |= !(fabs(m[j]) <= 1.79769313486231570e308); }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { bad |= !(fabs(m[N + j]) <= 1.79769313486231570e308); if (dp_rows) dp_rows[i * NP + j] = m[N + j]; }
+        if (bad) atomicOr(flag, 1);
+    }
+    if (!dp_sum) return;
+    double s[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        double v = valid ? m[N + j] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);   // fixed tree over the lanes
+        s[j] = v;
+    }
+    if (blocks == 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dp_sum[j] = s[j];
+        }
+        return;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) map_store_agent(T.partial + block * NP + j, s[j]);
+    }
+    if (!tree_arrive_last(T.ticket, (unsigned)blocks)) return;
+    // last block: lane l sums blocks l, l + 64, ... in increasing order, then the same fixed tree over the lanes
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        double v = 0.0;
+        for (long b = lane; b < blocks; b += 64) v += map_load_agent(T.partial + b * NP + j);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) dp_sum[j] = v;
+    }
+}
+
+
 // The tail of a segment wave.  m: this wave's map (NCOL = 1 + N columns; a top-segment / single-segment wave passes its vector in
 // column 0 and zeros elsewhere).  block: trajectory block (64 trajectories), rank: 0 = top segment ... C-1 = the segment at t0.
 // du0 [N_traj][N] (caller layout), dp_rows [N_traj][NP] or null, dp_sum [NP] or null (shared parameters), flag: non-finite marker.
@@ -163,46 +213,10 @@ __device__ __forceinline__ void fused_tail(double (&m)[(1 + N) * (N + NP)], cons
         idx = parent;
     }
     // root: column 0 holds (lam(t0), mu(t0)) of the block's trajectories
-    const long i = block * 64 + lane;
-    const bool valid = i < ntraj;
-    bool bad = false;
-    if (valid) {
+    double v[N + NP];
 #pragma unroll
-        for (int j = 0; j < N; ++j) { du0[i * N + j] = m[j]; bad |= !(fabs(m[j]) <= 1.79769313486231570e308); }
-#pragma unroll
-        for (int j = 0; j < NP; ++j) { bad |= !(fabs(m[N + j]) <= 1.79769313486231570e308); if (dp_rows) dp_rows[i * NP + j] = m[N + j]; }
-        if (bad) atomicOr(flag, 1);
-    }
-    if (!dp_sum) return;
-    double s[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        double v = valid ? m[N + j] : 0.0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);   // fixed tree over the lanes
-        s[j] = v;
-    }
-    if (blocks == 1) {
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) dp_sum[j] = s[j];
-        }
-        return;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) map_store_agent(T.partial + block * NP + j, s[j]);
-    }
-    if (!tree_arrive_last(T.ticket, (unsigned)blocks)) return;
-    // last block: lane l sums blocks l, l + 64, ... in increasing order, then the same fixed tree over the lanes
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        double v = 0.0;
-        for (long b = lane; b < blocks; b += 64) v += map_load_agent(T.partial + b * NP + j);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) dp_sum[j] = v;
-    }
+    for (int j = 0; j < N + NP; ++j) v[j] = m[j];
+    fused_root<N, NP>(v, T, ntraj, blocks, block, du0, dp_rows, dp_sum, flag);
 }
 
 #endif  // device code

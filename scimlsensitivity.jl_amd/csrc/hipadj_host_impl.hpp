@@ -251,6 +251,16 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         break; }
     case HIPADJ_ALG_GAUSS_KRONROD: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
+        if (h->fused && h->d_tbuf) {   // one launch per reverse pass (hipadj_fused.hpp)
+            TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
+            hipExtLaunchKernelGGL((k_gauss_fused<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev,
+                                  d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
+            HIP_TRY(h, hipGetLastError());
+            if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
+            es.pending = h->timing >= 1; es.full = h->timing >= 2;
+            return HIPADJ_OK;
+        }
         hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
                            (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());

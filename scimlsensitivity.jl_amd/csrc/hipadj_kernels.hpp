@@ -110,8 +110,18 @@ __global__ void HIPADJ_KINTERP_ATTR __launch_bounds__(WAVE) k_interp_fused(Geom 
     const long i = i_raw < g.N ? i_raw : g.N - 1;                    // padding lanes of the last block repeat its last trajectory
     const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;      // rank 0 = the top (longest, 1-column) segment: dispatched first
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    if constexpr (!SEG) {   // one segment (models whose segment columns do not fit the registers): the wave is its block's root, no map is ever built
+        double lam[1][N], mu[1][NP], v[R];
+        interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) v[N + j] = mu[0][j];
+        fused_root<N, NP>(v, tp, g.N, (long)gridDim.x, (long)blockIdx.x, du0, dp_rows, dp_sum, flag);
+        return;
+    }
     double m[NC * R];
-    if (!SEG || rank == 0) {
+    if (rank == 0) {
         double lam[1][N], mu[1][NP];
         interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
 #pragma unroll
@@ -754,8 +764,18 @@ __global__ void __launch_bounds__(WAVE) k_gauss_fused(Geom g, SegPlan sp, TreePl
     const long i = i_raw < g.N ? i_raw : g.N - 1;
     const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    if constexpr (!SEG) {
+        double lam[1][N], mu[1][NP], v[R];
+        gauss_lane<Mo, 1, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) v[N + j] = mu[0][j];
+        fused_root<N, NP>(v, tp, g.N, (long)gridDim.x, (long)blockIdx.x, du0, dp_rows, dp_sum, flag);
+        return;
+    }
     double m[NC * R];
-    if (!SEG || rank == 0) {
+    if (rank == 0) {
         double lam[1][N], mu[1][NP];
         gauss_lane<Mo, 1, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
         segment_map_regs<Mo, 1>(m, lam, mu);
@@ -777,8 +797,18 @@ __global__ void __launch_bounds__(WAVE) k_backsolve_fused(Geom g, SegPlan sp, Tr
     const long i = i_raw < g.N ? i_raw : g.N - 1;
     const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    if constexpr (!SEG) {
+        double lam[1][N], mu[1][NP], v[R];
+        backsolve_lane<Mo, 1, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = lam[0][j];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) v[N + j] = mu[0][j];
+        fused_root<N, NP>(v, tp, g.N, (long)gridDim.x, (long)blockIdx.x, du0, dp_rows, dp_sum, flag);
+        return;
+    }
     double m[NC * R];
-    if (!SEG || rank == 0) {
+    if (rank == 0) {
         double lam[1][N], mu[1][NP];
         backsolve_lane<Mo, 1, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);
         segment_map_regs<Mo, 1>(m, lam, mu);

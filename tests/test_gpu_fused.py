@@ -99,3 +99,28 @@ def test_fused_gauss_and_backsolve_equal_their_three_launch_sequences(sa, monkey
             a, b = ref.adjoint(delta), fus.adjoint(delta)
             assert rel(b[0], a[0]) < 1e-10 and rel(b[1], a[1]) < 1e-10, (rnd, rep)
     ref.close(); fus.close()
+
+
+@pytest.mark.parametrize("n,alg", [(2, "interpolating"), (4, "interpolating"), (4, "gauss"), (4, "backsolve"), (8, "interpolating")])
+def test_fused_pass_of_runtime_lane_models(sa, monkeypatch, n, alg):
+    """Runtime-registered lane models (hiprtc) take the same one-launch pass: k_*_fused<UserModel, ...>, segmented (n <= 4 ... 8 by the register budget) or as
+    one segment per trajectory (fused_root only).  Against the same model through the three-launch sequence, on changing data."""
+    import user_models as UM
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.LV if n == 2 else UM.ring(n)
+    name = f"fusedrt_{n}_{alg}"
+    _lib.register_model(name, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    N, T, dt = 700, 4.0, 0.01
+    ts = np.linspace(0.0, T, 41)
+    kw = dict(checkpointing=True) if alg == "backsolve" else {}
+    ref, fus = _engines(sa, monkeypatch, N, ts, T, dt, loss_kind=0, alg=alg, model=name, **kw)
+    rng = np.random.default_rng(n)
+    u0 = 1.0 + 0.1 * rng.standard_normal((N, m["n"])); p = 1.0 + 0.2 * rng.random(m["np"])
+    for rnd in range(2):
+        u0r = u0 + 0.01 * rng.standard_normal(u0.shape)
+        ref.forward(u0r, p, want_out=False); fus.forward(u0r, p, want_out=False)
+        for rep in range(3):
+            delta = rng.standard_normal((N, len(ts), m["n"]))
+            a, b = ref.adjoint(delta), fus.adjoint(delta)
+            assert rel(b[0], a[0]) < 1e-10 and rel(b[1], a[1]) < 1e-10, (rnd, rep)
+    ref.close(); fus.close()
