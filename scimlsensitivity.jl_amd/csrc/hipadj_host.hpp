@@ -67,7 +67,7 @@ struct hipadj_handle {
     hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish
     hipModule_t umod_alt = nullptr;            // the same kernels at -O1: second opinion for reverse kernels that spill heavily (user_prepare)
     hipFunction_t uf_main_alt = nullptr;
-    int rtc_selftest = 0;                      // 1: pending (first adjoint call runs both builds and compares), 2: agreed, 3: disagreed -> the -O1 build is used
+    int rtc_selftest = 0;                      // 1: pending (first adjoint call runs both builds and compares), 2: agreed, 3: disagreed -> the -O1 build is used, 4: disagreed, the -O1 build irreproducible -> the -O3 build stays
     bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
     AdaptGeom ag{};
     int cbs = 0;         // k_compose_finish workgroup size: 0 = by ensemble size, 64 / 256 forced (HIPADJ_CBS; tuning study)

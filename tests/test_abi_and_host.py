@@ -100,6 +100,9 @@ def test_runtime_model_kernel_choices(sa, tmp_path, monkeypatch):
     tu = names("choice_ring3", UM.ring(3))
     assert "k_interp_fused<hipadj::UserModel, 1, 0, true, false>" in tu and "HAS_COLS = true" in tu
     tu = names("choice_ring8", UM.ring(8), alg="gauss")
+    # a segment map of more than 64 entries (8-state ring: 153): the three-launch sequence stays (fused_eligible; the tail would spill heavily)
+    assert "k_gauss<hipadj::UserModel, 1, 0, false, true>" in tu and "k_compose_finish<hipadj::UserModel>" in tu and "k_gauss_fused" not in tu
+    tu = names("choice_ring4", UM.ring(4), alg="gauss")
     assert "k_gauss_fused<hipadj::UserModel, 1, 0, false, true>" in tu and "k_compose_finish<hipadj::UserModel>" not in tu
     assert "HAS_COLS = true" in names("choice_auto3", UM.ring(3), auto=True)
     assert "HAS_COLS = false" in names("choice_auto4", UM.ring(4), auto=True)
@@ -554,7 +557,7 @@ cfg = E.make_config("trust_ring8", "interpolating", 10000, 0.0, 10.0, 0.01, 0.1 
 L = _lib.load()
 assert L.hipadj_model_check_config(C.byref(cfg)) == 0, L.hipadj_last_error(None)
 tu = open(sorted(glob.glob(sys.argv[1] + "/trust_ring8_*.hip"))[-1]).read()
-print("SEG_TRUE" if "k_interp_fused<hipadj::UserModel, 1, 0, true, false>" in tu else "SEG_FALSE" if "k_interp_fused<hipadj::UserModel, 1, 0, false, false>" in tu else "UNKNOWN")
+print("SEG_TRUE" if "k_interp<hipadj::UserModel, 1, 0, true>" in tu else "SEG_FALSE" if "k_interp_fused<hipadj::UserModel, 1, 0, false, false>" in tu else "UNKNOWN")
 ''' % (ROOT, os.path.join(ROOT, "tests"))
     out = {}
     for trust in ("1", "0"):

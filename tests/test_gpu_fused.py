@@ -14,17 +14,20 @@ from test_gpu_parity import RTOL, rel, lorenz_inputs
 pytestmark = pytest.mark.gpu
 
 
-def _engines(sa, monkeypatch, N, ts, T, dt, loss_kind, p_shared=True, segments=0, radix=None, alg="interpolating", model="lorenz", **more):
+def _engines(sa, monkeypatch, N, ts, T, dt, loss_kind, p_shared=True, segments=0, radix=None, alg="interpolating", model="lorenz", user_cap=None, fused_launches=1, **more):
     kw = dict(save_times=ts, loss_kind=loss_kind, loss_shift=2.0, p_shared=p_shared, time_segments=segments, **more)
     monkeypatch.setenv("HIPADJ_FUSED", "0")
     ref = sa.Engine(model, alg, N, 0.0, T, dt, **kw)
     monkeypatch.setenv("HIPADJ_FUSED", "1")
     if radix:
         monkeypatch.setenv("HIPADJ_TREE_RADIX", str(radix))
+    if user_cap:
+        monkeypatch.setenv("HIPADJ_FUSED_USER_CAP", str(user_cap))
     fus = sa.Engine(model, alg, N, 0.0, T, dt, **kw)
-    assert fus.stats()["launches_per_pass"] == 1 and ref.stats()["launches_per_pass"] == 3
+    assert fus.stats()["launches_per_pass"] == fused_launches and ref.stats()["launches_per_pass"] == 3
     monkeypatch.delenv("HIPADJ_FUSED")
     monkeypatch.delenv("HIPADJ_TREE_RADIX", raising=False)
+    monkeypatch.delenv("HIPADJ_FUSED_USER_CAP", raising=False)
     return ref, fus
 
 
@@ -101,19 +104,23 @@ def test_fused_gauss_and_backsolve_equal_their_three_launch_sequences(sa, monkey
     ref.close(); fus.close()
 
 
-@pytest.mark.parametrize("n,alg", [(2, "interpolating"), (4, "interpolating"), (4, "gauss"), (4, "backsolve"), (8, "interpolating")])
-def test_fused_pass_of_runtime_lane_models(sa, monkeypatch, n, alg):
-    """Runtime-registered lane models (hiprtc) take the same one-launch pass: k_*_fused<UserModel, ...>, segmented (n <= 4 ... 8 by the register budget) or as
-    one segment per trajectory (fused_root only).  Against the same model through the three-launch sequence, on changing data."""
+@pytest.mark.parametrize("n,alg,cap", [(2, "interpolating", None), (4, "interpolating", None), (4, "gauss", None), (4, "backsolve", None),
+                                       (8, "interpolating", None), (8, "backsolve", None), (8, "interpolating", 160), (8, "backsolve", 160)])
+def test_fused_pass_of_runtime_lane_models(sa, monkeypatch, n, alg, cap):
+    """Runtime-registered lane models (hiprtc) take the same one-launch pass, k_*_fused<UserModel, ...>, while their segment map has at most 64 entries
+    ((1 + n)(n + np): n <= 4 here); wider maps make the tail one of the heavily spilling kernels and keep the three-launch sequence (cap None, n = 8).
+    With the cap lifted (HIPADJ_FUSED_USER_CAP, test hook) the 8-state kernels are compiled anyway: their -O3 builds are right, and the Backsolve one is the
+    case whose -O1 build came back wrong and irreproducible (GPU visit 8, profiles/r3_fused_wide_lane_probe.log) — the self-test's tie-break
+    (user_adjoint: a build has to reproduce itself) must then keep the -O3 build.  Against the same model through the three-launch sequence, on changing data."""
     import user_models as UM
     from scimlsensitivity_jl_amd import _lib
     m = UM.LV if n == 2 else UM.ring(n)
-    name = f"fusedrt_{n}_{alg}"
+    name = f"fusedrt_{n}_{alg}_{cap}"
     _lib.register_model(name, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
     N, T, dt = 700, 4.0, 0.01
     ts = np.linspace(0.0, T, 41)
     kw = dict(checkpointing=True) if alg == "backsolve" else {}
-    ref, fus = _engines(sa, monkeypatch, N, ts, T, dt, loss_kind=0, alg=alg, model=name, **kw)
+    ref, fus = _engines(sa, monkeypatch, N, ts, T, dt, loss_kind=0, alg=alg, model=name, user_cap=cap, fused_launches=(3 if (n == 8 and not cap) else 1), **kw)
     rng = np.random.default_rng(n)
     u0 = 1.0 + 0.1 * rng.standard_normal((N, m["n"])); p = 1.0 + 0.2 * rng.random(m["np"])
     for rnd in range(2):
