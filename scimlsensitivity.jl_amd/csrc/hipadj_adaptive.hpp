@@ -101,15 +101,40 @@ constexpr int KS_ROWS = 8, KS_UPREV = 7;
 #endif
 constexpr int TS5_WIDE = HIPADJ_TS5_WIDE;   // widest state vector whose six stage rows are summed in one batch (tsit5_integrate)
 template <int NZ> struct KStore {
+    static constexpr bool IN_REGS = false;
     double* base; int stride;
     HIPADJ_HD double get(int row, int i) const { return base[(row * NZ + i) * stride]; }
     HIPADJ_HD void set(int row, int i, double v) const { base[(row * NZ + i) * stride] = v; }
 };
+// The same rows in registers (round 3): 8 NZ doubles per lane, every index a compile-time constant, so tsit5_integrate runs its stage loop
+// unrolled — six instances of the right-hand side, each stage sum with exactly its terms and literal coefficients, no LDS round trip between a
+// stage and the next.  With 157 lone waves at 10^4 trajectories the adaptive kernels are bound by one wave's instruction stream (2.96 ns per
+// FP64 instruction), so the shorter stream is the whole point; 16 NZ VGPRs are affordable because a lone wave owns its SIMD's 512 registers.
+// Compiled-in models with NZ <= TS5_WIDE only (ts5_in_regs): runtime models keep the LDS rows — their kernels come out of hiprtc per model and
+// the rolled loop is the form that has been through the compiler-defect history of DESIGN.md 6.8.  Same arithmetic, expression for expression
+// (the padded sums of the LDS form add exact zeros), so step sequences are bit-identical; the host emulator runs this form for the same models.
+template <int NZ> struct KRegs {
+    static constexpr bool IN_REGS = true;
+    double v[8][NZ];
+    HIPADJ_HD double get(int row, int i) const { return v[row][i]; }
+    HIPADJ_HD void set(int row, int i, double x) { v[row][i] = x; }
+};
+#ifndef HIPADJ_TS5_REGS
+#define HIPADJ_TS5_REGS 1
+#endif
+template <class Mo, class = void> struct ts5_model_is_runtime { static constexpr bool value = false; };
+template <class Mo> struct ts5_model_is_runtime<Mo, decltype((void)Mo::HAS_COLS)> { static constexpr bool value = true; };   // the struct hipadj_user.hpp generates
+template <bool B, class A, class C> struct ts5_select { using type = A; };
+template <class A, class C> struct ts5_select<false, A, C> { using type = C; };
+template <class KS> HIPADJ_HD KS ts5_make_rows(double* base, int stride) {
+    if constexpr (KS::IN_REGS) { (void)base; (void)stride; return KS(); } else return KS{base, stride};
+}
+template <class Mo, int NZ> struct ts5_in_regs { static constexpr bool value = HIPADJ_TS5_REGS && !ts5_model_is_runtime<Mo>::value && NZ <= HIPADJ_TS5_WIDE; };
 
 // y = u_start + h sum_j b_j(theta) k_j : the continuous extension of the step held in K (used for the lambda values at the
 // Gauss nodes; the forward solution is stored in monomial form instead, see tsit5_poly)
-template <int NZ, int NOUT>
-HIPADJ_HD void kstore_interp(const KStore<NZ>& K, double th, double h, double (&y)[NOUT]) {
+template <int NZ, int NOUT, class KS>
+HIPADJ_HD void kstore_interp(const KS& K, double th, double h, double (&y)[NOUT]) {
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) y[i] = 0.0;
 #pragma unroll
@@ -123,8 +148,8 @@ HIPADJ_HD void kstore_interp(const KStore<NZ>& K, double th, double h, double (&
 }
 
 // monomial coefficients of the continuous extension of the accepted step held in K (see the layout note above)
-template <int NZ>
-HIPADJ_HD void tsit5_poly(const KStore<NZ>& K, double h, double (&c)[5][NZ]) {
+template <int NZ, class KS>
+HIPADJ_HD void tsit5_poly(const KS& K, double h, double (&c)[5][NZ]) {
 #pragma unroll
     for (int i = 0; i < NZ; ++i) { c[0][i] = K.get(KS_UPREV, i); c[1][i] = h * K.get(0, i); c[2][i] = 0.0; c[3][i] = 0.0; c[4][i] = 0.0; }
 #pragma unroll
@@ -150,8 +175,8 @@ HIPADJ_HD void poly_eval(double th, const double (&c)[5][NZ], double (&y)[NZ]) {
 struct NoPre { HIPADJ_HD void operator()(double) const {} };
 
 // w += sum_{j < S_} a(S_, j) K_j : the stage sum of stage S_ with exactly its S_ terms, in the oracle's order j = 0, 1, ...
-template <int NZ, int S_>
-HIPADJ_HD void tsit5_stage_sum(const KStore<NZ>& K, double (&w)[NZ]) {
+template <int NZ, int S_, class KS>
+HIPADJ_HD void tsit5_stage_sum(const KS& K, double (&w)[NZ]) {
 #pragma unroll
     for (int j = 0; j < S_; ++j) {
         const double a = TS5::a(S_, j);
@@ -163,10 +188,24 @@ HIPADJ_HD void tsit5_stage_sum(const KStore<NZ>& K, double (&w)[NZ]) {
 // pre(t) runs at the top of every step attempt, AFTER a pending k_1 = f(u, t) was evaluated: the checkpointed sweeps
 // switch their interval solution there, so that every evaluation AT a checkpoint time still reads the interval above
 // (as the reference's `t in interval` test does) and every stage below it reads the re-solved interval.
-template <int NZ, class Rhs, class Cb, class Pre = NoPre>
+// one stage with the rows in registers: w = u_n + h sum_{j < S_} a(S_, j) k_j (the oracle's order), k_{S_+1} = rhs(w, t + c(S_) h)
+template <int S_, int NZ, class KS, class Rhs>
+HIPADJ_HD void tsit5_stage_regs(KS& K, double (&w)[NZ], double h, double t, Rhs& rhs) {
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) w[i] = 0.0;
+    tsit5_stage_sum<NZ, S_>(K, w);
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) w[i] = K.get(KS_UPREV, i) + h * w[i];
+    double ks[NZ];
+    rhs(ks, w, t + TS5::c(S_) * h);
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) K.set(S_, i, ks[i]);
+}
+
+template <int NZ, class KS, class Rhs, class Cb, class Pre = NoPre>
 HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, double dt_hint, double abstol, double reltol,
                               const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps,
-                              const KStore<NZ>& K, Rhs&& rhs, Cb&& cb, Pre&& pre = NoPre()) {
+                              KS& K, Rhs&& rhs, Cb&& cb, Pre&& pre = NoPre()) {
     const double EPS = 2.220446049250313e-16;
     const double tdir = tend >= tstart ? 1.0 : -1.0;
     double t = tstart, tprev = tstart;
@@ -176,10 +215,17 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
         for (int i = 0; i < NZ; ++i) K.set(KS_UPREV, i, u[i]);
         cb(t, tprev, u, K);
     }
-#pragma unroll 1
-    for (int j = 1; j < 7; ++j)
+    if constexpr (KS::IN_REGS) {
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) K.set(j, i, 0.0);
+        for (int j = 1; j < 7; ++j)
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) K.set(j, i, 0.0);
+    } else {
+#pragma unroll 1
+        for (int j = 1; j < 7; ++j)
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) K.set(j, i, 0.0);
+    }
     bool need_k0 = true, first = true;
     double dt = 0.0, qold = 1e-4;
     int its = 0, naccept = 0, guard = 0;
@@ -233,6 +279,11 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
         // below).  Summation order j = 0, 1, ... is the oracle's.  (Measured alternative: forming the next stage's partial
         // sum next to rhs to hide the LDS round trip costs 9 x NZ extra FMAs per step and is 8 % slower — with one wave
         // per CU at N = 10^4 this loop is bound by instruction count, not by latency.)
+        if constexpr (KS::IN_REGS) {
+            // rows in registers: the stage loop unrolled, every sum with exactly its terms (see KRegs)
+            tsit5_stage_regs<1>(K, w, h, t, rhs); tsit5_stage_regs<2>(K, w, h, t, rhs); tsit5_stage_regs<3>(K, w, h, t, rhs);
+            tsit5_stage_regs<4>(K, w, h, t, rhs); tsit5_stage_regs<5>(K, w, h, t, rhs); tsit5_stage_regs<6>(K, w, h, t, rhs);
+        } else {
 #pragma unroll 1
         for (int s = 1; s < 7; ++s) {
 #pragma unroll
@@ -275,13 +326,14 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
 #pragma unroll
             for (int i = 0; i < NZ; ++i) K.set(s, i, ks[i]);
         }
+        }
         // w = u_{n+1} (the seventh stage state is the 5th-order solution), K row 6 = f(u_{n+1}) (FSAL)
         double e2 = 0.0;
         {
             double err[NZ];
 #pragma unroll
             for (int i = 0; i < NZ; ++i) err[i] = 0.0;
-            if constexpr (NZ <= TS5_WIDE) {
+            if constexpr (NZ <= TS5_WIDE || KS::IN_REGS) {
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
                     const double btj = TS5::bt(j);
@@ -330,11 +382,13 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             // copy of u is dead across the stage loop (2 NZ VGPRs less at the point of highest pressure; same values, bit for bit)
 #pragma unroll
             for (int i = 0; i < NZ; ++i) u[i] = K.get(KS_UPREV, i);
+            if constexpr (!KS::IN_REGS) {       // (the register form sums exactly its terms: no padding to protect)
             if (!(EEst < 1e300)) {            // overflowed stage derivatives must not meet the zero padding of the tableau rows
 #pragma unroll 1
                 for (int j = 1; j < 7; ++j)
 #pragma unroll
                     for (int i = 0; i < NZ; ++i) K.set(j, i, 0.0);
+            }
             }
         }
     }
@@ -349,7 +403,8 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                                   double* __restrict__ outT, const double* __restrict__ ck_t, double* __restrict__ ckpt,
                                   double* __restrict__ yT, int* __restrict__ flag, double* kbase, int kstride) {
     constexpr int N = Mo::N, RW = 2 + 5 * N;
-    const KStore<N> K{kbase, kstride};
+    using KS = typename ts5_select<ts5_in_regs<Mo, N>::value, KRegs<N>, const KStore<N>>::type;
+    KS K = ts5_make_rows<KS>(kbase, kstride);
     double pv[Mo::NP];
 #pragma unroll
     for (int j = 0; j < Mo::NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * Mo::NP + j];
@@ -372,7 +427,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     double ts_next = (outT && ms < g.M) ? save_t[ms] : TINF, tc_next = (ckpt && mc < g.nck) ? ck_t[mc] : TINF;
     const int na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.maxit, K,
         [&](double (&du)[N], const double (&uu)[N], double t) { Mo::f(du, uu, pv, t); },
-        [&](double t, double tprev, double (&un)[N], const KStore<N>& KK) -> bool {
+        [&](double t, double tprev, double (&un)[N], const auto& KK) -> bool {
             const double h = t - tprev;
             double c[5][N]; tsit5_poly<N>(KK, h, c);
             if (s < g.Smax) {
@@ -490,7 +545,8 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                                   double* kbase, int kstride, double* __restrict__ arec = nullptr, int* __restrict__ nsteps_adj = nullptr, int SmaxA = 0,
                                   double* kfbase = nullptr, double* lrec = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP, NZ = AdjNZ<Mo, ALG>::value;
-    const KStore<NZ> K{kbase, kstride};
+    using KS = typename ts5_select<ts5_in_regs<Mo, NZ>::value && !CK, KRegs<NZ>, const KStore<NZ>>::type;   // CK: the interval re-solve shares the sweep's live range — LDS rows
+    KS K = ts5_make_rows<KS>(kbase, kstride);
     double pv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
@@ -506,7 +562,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         int sl = 0;
         const int nr = tsit5_integrate<N>(uu, ck_t[j], ck_t[j + 1], dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF,
             [&](double (&du)[N], const double (&u_)[N], double t) { Mo::f(du, u_, pv, t); },
-            [&](double t, double tprev, double (&un)[N], const KStore<N>& KK) -> bool {
+            [&](double t, double tprev, double (&un)[N], const auto& KK) -> bool {
                 (void)un;
                 if (sl < g.SmaxI) {
                     double c[5][N]; tsit5_poly<N>(KK, t - tprev, c);
@@ -569,7 +625,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     };
     int sa = 0;
     bool aoverflow = false;
-    auto cb = [&](double t, double tprev, double (&zz)[NZ], const KStore<NZ>& KK) -> bool {
+    auto cb = [&](double t, double tprev, double (&zz)[NZ], const auto& KK) -> bool {
         bool mod = false;
         if (ALG == 3 && t != tprev) {   // dense adjoint solution for the quadrature pass
             if (sa < SmaxA) {
