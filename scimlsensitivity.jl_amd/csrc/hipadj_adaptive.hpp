@@ -101,7 +101,7 @@ constexpr int KS_ROWS = 8, KS_UPREV = 7;
 #endif
 constexpr int TS5_WIDE = HIPADJ_TS5_WIDE;   // widest state vector whose six stage rows are summed in one batch (tsit5_integrate)
 template <int NZ> struct KStore {
-    static constexpr bool IN_REGS = false;
+    static constexpr bool IN_REGS = false, ROLLED = true;
     double* base; int stride;
     HIPADJ_HD double get(int row, int i) const { return base[(row * NZ + i) * stride]; }
     HIPADJ_HD void set(int row, int i, double v) const { base[(row * NZ + i) * stride] = v; }
@@ -114,10 +114,21 @@ template <int NZ> struct KStore {
 // the rolled loop is the form that has been through the compiler-defect history of DESIGN.md 6.8.  Same arithmetic, expression for expression
 // (the padded sums of the LDS form add exact zeros), so step sequences are bit-identical; the host emulator runs this form for the same models.
 template <int NZ> struct KRegs {
-    static constexpr bool IN_REGS = true;
+    static constexpr bool IN_REGS = true, ROLLED = false;
     double v[8][NZ];
     HIPADJ_HD double get(int row, int i) const { return v[row][i]; }
     HIPADJ_HD void set(int row, int i, double x) { v[row][i] = x; }
+};
+// Registers, but ONE instance of the right-hand side: the stage loop stays rolled and only the (cheap) stage sum and the row store sit behind a
+// wave-uniform switch on the stage number.  For the workgroup-per-trajectory family (hipadj_wide.hpp), whose right-hand side is a whole model body
+// between two barriers: six inlined copies of it would multiply the code of every runtime model.
+template <int NZ> struct KRegsRolled : KRegs<NZ> { static constexpr bool ROLLED = true; };
+
+// How the step controller's norms are summed.  Lane family: the lane holds the whole state — plain sums over NZ components.  Workgroup family: a thread
+// holds its owned components, the sums run over the workgroup (hipadj_wide.hpp: WideNorm) and the divisor is the true number of components.
+struct TS5LaneNorm {
+    HIPADJ_HD double sum(double x) const { return x; }
+    HIPADJ_HD double count(int nz) const { return (double)nz; }
 };
 #ifndef HIPADJ_TS5_REGS
 #define HIPADJ_TS5_REGS 1
@@ -202,10 +213,11 @@ HIPADJ_HD void tsit5_stage_regs(KS& K, double (&w)[NZ], double h, double t, Rhs&
     for (int i = 0; i < NZ; ++i) K.set(S_, i, ks[i]);
 }
 
-template <int NZ, class KS, class Rhs, class Cb, class Pre = NoPre>
+template <int NZ, class KS, class Rhs, class Cb, class Pre = NoPre, class Red = TS5LaneNorm>
 HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, double dt_hint, double abstol, double reltol,
                               const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps,
-                              KS& K, Rhs&& rhs, Cb&& cb, Pre&& pre = NoPre()) {
+                              KS& K, Rhs&& rhs, Cb&& cb, Pre&& pre = NoPre(), Red red = Red()) {
+    const double ncomp = red.count(NZ);
     const double EPS = 2.220446049250313e-16;
     const double tdir = tend >= tstart ? 1.0 : -1.0;
     double t = tstart, tprev = tstart;
@@ -246,7 +258,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
                 double d0 = 0, d1 = 0;
 #pragma unroll
                 for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; d0 += (u[i] / sc) * (u[i] / sc); d1 += (w[i] / sc) * (w[i] / sc); }
-                d0 = sqrt(d0 / NZ); d1 = sqrt(d1 / NZ);
+                d0 = sqrt(red.sum(d0) / ncomp); d1 = sqrt(red.sum(d1) / ncomp);
                 double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
                 h0 = hmin2(h0, habs(tend - t));
                 double u1[NZ], f1[NZ];
@@ -256,7 +268,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
                 double d2 = 0;
 #pragma unroll
                 for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; const double q = (f1[i] - K.get(0, i)) / sc; d2 += q * q; }
-                d2 = sqrt(d2 / NZ) / h0;
+                d2 = sqrt(red.sum(d2) / ncomp) / h0;
                 const double h1 = (hmax2(d1, d2) <= 1e-15) ? hmax2(1e-6, h0 * 1e-3) : pow(0.01 / hmax2(d1, d2), 1.0 / 5.0);
                 dt = tdir * hmin2(hmin2(100.0 * h0, h1), habs(tend - t));
             }
@@ -279,10 +291,35 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
         // below).  Summation order j = 0, 1, ... is the oracle's.  (Measured alternative: forming the next stage's partial
         // sum next to rhs to hide the LDS round trip costs 9 x NZ extra FMAs per step and is 8 % slower — with one wave
         // per CU at N = 10^4 this loop is bound by instruction count, not by latency.)
-        if constexpr (KS::IN_REGS) {
+        if constexpr (KS::IN_REGS && !KS::ROLLED) {
             // rows in registers: the stage loop unrolled, every sum with exactly its terms (see KRegs)
             tsit5_stage_regs<1>(K, w, h, t, rhs); tsit5_stage_regs<2>(K, w, h, t, rhs); tsit5_stage_regs<3>(K, w, h, t, rhs);
             tsit5_stage_regs<4>(K, w, h, t, rhs); tsit5_stage_regs<5>(K, w, h, t, rhs); tsit5_stage_regs<6>(K, w, h, t, rhs);
+        } else if constexpr (KS::IN_REGS) {
+            // rows in registers, one instance of rhs (KRegsRolled): the stage number is uniform, so the switches are scalar branches
+#pragma unroll 1
+            for (int s = 1; s < 7; ++s) {
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) w[i] = 0.0;
+                switch (s) {
+                case 1: tsit5_stage_sum<NZ, 1>(K, w); break;
+                case 2: tsit5_stage_sum<NZ, 2>(K, w); break;
+                case 3: tsit5_stage_sum<NZ, 3>(K, w); break;
+                case 4: tsit5_stage_sum<NZ, 4>(K, w); break;
+                case 5: tsit5_stage_sum<NZ, 5>(K, w); break;
+                default: tsit5_stage_sum<NZ, 6>(K, w); break;
+                }
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) w[i] = K.get(KS_UPREV, i) + h * w[i];
+                double ks[NZ];
+                rhs(ks, w, t + TS5::c(s) * h);
+                switch (s) {
+#define HIPADJ_TS5_SETROW(R) case R: { _Pragma("unroll") for (int i = 0; i < NZ; ++i) K.set(R, i, ks[i]); } break;
+                HIPADJ_TS5_SETROW(1) HIPADJ_TS5_SETROW(2) HIPADJ_TS5_SETROW(3) HIPADJ_TS5_SETROW(4) HIPADJ_TS5_SETROW(5)
+                default: { _Pragma("unroll") for (int i = 0; i < NZ; ++i) K.set(6, i, ks[i]); } break;
+#undef HIPADJ_TS5_SETROW
+                }
+            }
         } else {
 #pragma unroll 1
         for (int s = 1; s < 7; ++s) {
@@ -355,7 +392,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
                 e2 += q * q;
             }
         }
-        const double EEst = sqrt(e2 / NZ);
+        const double EEst = sqrt(red.sum(e2) / ncomp);
         // x^c as exp(c log x): within a few ulp of pow() (the step-size factor is not an accuracy-critical quantity) at about a
         // third of its instruction count
         const double q11 = exp((7.0 / 50.0) * log(hmax2(EEst, 1e-300)));

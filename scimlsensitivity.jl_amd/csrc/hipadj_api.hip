@@ -153,7 +153,8 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
     return HIPADJ_OK;
 }
 
-static std::vector<std::string> wide_kernel_names(int alg) {
+static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false) {
+    if (ts5) return {"hipadj::k_wide_forward_ts5<hipadj::UserW>", "hipadj::k_wide_adjoint_ts5<hipadj::UserW, 2>"};
     const std::string U = "hipadj::UserW";
     std::vector<std::string> e = {"hipadj::k_wide_forward<" + U + ">"};
     switch (alg) {
@@ -246,8 +247,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     A(dev_alloc(h, &h->d_u0, (size_t)h->N * n));
     A(dev_alloc(h, &h->d_p, cfg->p_shared ? (size_t)np : (size_t)h->N * np));
     h->field = P.field;
-    h->adaptive = P.adaptive;
-    if (P.adaptive) {
+    h->adaptive = P.adaptive && !P.wide;
+    if (P.adaptive && !P.wide) {
         const int RW = 2 + 5 * n;   // record width, hipadj_adaptive.hpp
         A(dev_alloc(h, &h->d_outT, (size_t)h->M * n * Np));
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
@@ -292,7 +293,28 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         h->wide = true;
         h->wg.N = h->N; h->wg.S = (int)S; h->wg.M = h->M; h->wg.nck = h->nck; h->wg.t0 = cfg->t0; h->wg.dt = cfg->dt; h->wg.loss_shift = cfg->loss_shift;
         h->wg.loss_kind = cfg->loss_kind; h->wg.no_start = cfg->no_start; h->wg.p_shared = cfg->p_shared;
-        if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
+        if (P.adaptive) {
+            // adaptive Tsit5 (GaussAdjoint): trajectory-major dense records.  max_steps = 0: the capacity is what 2 GiB of records hold, between 64 and 4096
+            // accepted steps per trajectory (no regrow round in this family: a trajectory that needs more reports HIPADJ_ERR_MAXITERS and names max_steps)
+            h->wide_ts5 = true;
+            const long RW = 2 + 5L * n;
+            long cap = cfg->max_steps > 0 ? cfg->max_steps : (2L << 30) / (RW * 8 * h->N);
+            if (cfg->max_steps == 0) cap = cap < 64 ? 64 : (cap > 4096 ? 4096 : cap);
+            h->rec_cap = cap;
+            h->wa.t1 = cfg->t1; h->wa.abstol = cfg->abstol; h->wa.reltol = cfg->reltol; h->wa.dt0 = cfg->dt; h->wa.Smax = (int)cap; h->wa.maxit = (int)cap;
+            h->ag.Smax = (int)cap;   // (the overflow message names it)
+            A(dev_alloc(h, &h->d_rec, (size_t)h->N * cap * RW));
+            A(dev_alloc(h, &h->d_nsteps, (size_t)h->N));
+            if (h->M > 0) A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
+            h->ntstops = (int)P.tstops_desc.size(); h->wa.ntstops = h->ntstops;
+            if (h->ntstops > 0) A(dev_alloc(h, &h->d_tstops, (size_t)h->ntstops));
+            if (rc == HIPADJ_OK) {
+                bool ok2 = true;
+                if (h->M > 0) ok2 = ok2 && HT(hipMemcpy(h->d_save_t, P.save_times.data(), sizeof(double) * h->M, hipMemcpyHostToDevice), "memcpy");
+                if (h->ntstops > 0) ok2 = ok2 && HT(hipMemcpy(h->d_tstops, P.tstops_desc.data(), sizeof(double) * h->ntstops, hipMemcpyHostToDevice), "memcpy");
+                if (!ok2) rc = HIPADJ_ERR_HIP;
+            }
+        } else if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
         else {
             A(dev_alloc(h, &h->d_yT, (size_t)h->N * n));
             if (h->nck > 0) A(dev_alloc(h, &h->d_ckpt, (size_t)h->N * h->nck * n));
@@ -745,7 +767,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     h.cfg = *cfg; h.cfg.save_times = nullptr; h.cfg.checkpoints = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
-    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg), code, low, err); }
+    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg, P.adaptive), code, low, err); }
     h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
     h.fused = fused_eligible(cfg, P) ? 1 : 0;
     const UserKernels k = user_kernel_names(&h);
@@ -984,7 +1006,7 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
 // ---- wide runtime models: workgroup-per-trajectory family (hipadj_wide.hpp) ----------------------------------------------------------------
 static int wide_prepare(hipadj_handle* h) {
     if (user_has_cost(h->cfg.model) || user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no continuous cost / affect");
-    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg);
+    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5);
     std::vector<char> code; std::map<std::string, std::string> low;
     const int rc = user_compile(h->cfg.model, exprs, code, low, h->err);
     if (rc != HIPADJ_OK) return rc;
@@ -997,6 +1019,11 @@ static int wide_prepare(hipadj_handle* h) {
 }
 
 static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    if (h->wide_ts5) {
+        TRY(usig<decltype(&k_wide_forward_ts5<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, h->wa, d_u0, d_p, h->d_rec, h->d_nsteps,
+                    (const double*)h->d_save_t, (d_out && h->M > 0) ? d_out : (double*)nullptr, (double*)nullptr, h->d_flag));
+        return HIPADJ_OK;
+    }
     const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE;
     TRY(usig<decltype(&k_wide_forward<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, d_u0, d_p,
                 bs ? (double*)nullptr : h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot,
@@ -1014,6 +1041,10 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     const dim3 grid((unsigned)h->N), blk((unsigned)h->wide_T);
     // per-trajectory gradient rows: straight into the caller's dp when the parameters are per trajectory, else a workspace that k_wide_reduce_dp sums
     double* rows = h->cfg.p_shared ? h->d_dp_traj : d_dp;
+    if (h->wide_ts5) {
+        TRY(usig<decltype(&k_wide_adjoint_ts5<WideProbe, 2>)>::launch(h, h->uf_main, grid, blk, h->wg, h->wa, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_save_t,
+                    (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag));
+    } else
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS:
         TRY(usig<decltype(&k_wide_adjoint<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, rows, h->d_flag));

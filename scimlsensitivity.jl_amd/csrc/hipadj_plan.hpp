@@ -184,7 +184,10 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     P.wide = P.user && plan_user_wide_hook() && plan_user_wide_hook()(cfg->model);
     if (!plan_small_model(cfg->model) && !P.field && !P.mlp) { err = "unknown model"; return HIPADJ_ERR_UNSUPPORTED; }
     if (P.wide) {   // what the wide family offers so far: fixed-step RK4, loss times on the step grid, the four sensealgs, discrete losses
-        if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED) { err = "wide models (hipadj_wmodel_register) run the fixed-step RK4 stepper"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->alg != HIPADJ_ALG_GAUSS) {
+            err = "wide models (hipadj_wmodel_register): adaptive Tsit5 is offered with GaussAdjoint (the sweep integrates lam only); the other sensealgs run the fixed-step RK4 stepper"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->checkpointing) { err = "wide models: adaptive Tsit5 keeps the dense forward solution (checkpointing = false)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->ncheckpoints > 0) { err = "wide models: adaptive Tsit5 takes no checkpoint list"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "continuous costs are available for the lane-per-trajectory family only"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->checkpointing && cfg->alg != HIPADJ_ALG_BACKSOLVE) { err = "wide models: checkpointing = true is available for BacksolveAdjoint (Interpolating / Gauss keep the dense knots)"; return HIPADJ_ERR_UNSUPPORTED; }
@@ -217,7 +220,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
         { const int crc = plan_check_cost(cfg, err); if (crc != HIPADJ_OK) return crc; }
         if (cfg->max_steps < 0) { err = "max_steps must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
-        {   // the 8 x NZ stage rows of a wave live in LDS (hipadj_adaptive.hpp): 8 * NZ * 64 lanes * 8 B <= 160 KB
+        if (!P.wide) {   // the 8 x NZ stage rows of a wave live in LDS (hipadj_adaptive.hpp): 8 * NZ * 64 lanes * 8 B <= 160 KB
             const int NZ = cfg->alg == HIPADJ_ALG_INTERPOLATING ? n + np : (cfg->alg == HIPADJ_ALG_BACKSOLVE ? 2 * n + np : n);   // Gauss, Quadrature: lam only
             const bool ipck = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) && cfg->checkpointing;   // + the rows of the interval re-solve
             if (8L * (NZ + (ipck ? n : 0)) * 64 * 8 > 160L * 1024) { err = "adaptive Tsit5: augmented state too large for the LDS stage storage (need 8 * NZ * 512 B <= 160 KB)"; return HIPADJ_ERR_UNSUPPORTED; }

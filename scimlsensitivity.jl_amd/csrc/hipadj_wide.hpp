@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include "hipadj_lane.hpp"
+#include "hipadj_adaptive.hpp"
 
 namespace hipadj {
 
@@ -204,7 +205,7 @@ __device__ __forceinline__ void wide_jump(const WideGeom& g, long traj, int s, c
         for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) lam[q] += c_[c]; }
     } else {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) lam[q] += y[q] - g.loss_shift;
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) lam[q] += y[q] - g.loss_shift; }   // padding components stay zero (the adaptive controller's norms run over them)
     }
 }
 
@@ -566,6 +567,180 @@ static __global__ void k_wide_reduce_dp(long N, int NP, const double* __restrict
 }
 
 #endif  // device code
+
+
+// ==== adaptive Tsit5 for the workgroup-per-trajectory family (round 3) ===========================================================================
+// The stepper is hipadj_adaptive.hpp's tsit5_integrate itself — same controller, tstop clipping, FSAL and callback protocol as the lane family —
+// instantiated per THREAD over its owned components (NZ = Q), with the stage rows in registers (KRegsRolled: one instance of the model body in
+// the stage loop) and the controller's norms summed over the workgroup (WideNorm).  Every thread carries the same t, dt and error estimate, so
+// the control flow is uniform across the workgroup: no divergence inside a trajectory, and each trajectory takes its own step sequence.
+// Dense forward solution: trajectory-major records [N][Smax][2 + 5 n] = (t_start, t_end, c0..c4) in monomial form, as in the lane family.
+// Offered: the forward solve, GaussAdjoint (lam only; f_p^T lam by the 3-node Gauss-Legendre sum of IntegratingSumCallback on every accepted step)
+// and InterpolatingAdjoint (z = [lam; mu]; the mu part needs only two weighted sums of the stage values, see k_wide_adjoint_ts5).
+struct WideAdapt {
+    double t1, abstol, reltol, dt0;
+    int Smax, maxit, ntstops, pad;
+};
+
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+
+template <int T> struct WideNorm {
+    int n;
+    __device__ __forceinline__ double sum(double x) const { return wide_sum_all<T>(x); }
+    __device__ __forceinline__ double count(int) const { return (double)n; }
+};
+
+// cursor into the trajectory's dense forward solution; uniform over the workgroup (every thread walks the same records, holds its owned coefficients)
+template <class Mo> struct WideFwdCursor {
+    static constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q, RW = 2 + 5 * Mo::N;
+    const double* rec; int ns, sc, lc;
+    double ta, tb, c[5][Q];
+    __device__ __forceinline__ void init(const double* r, int nsteps) {
+        rec = r; ns = nsteps; sc = nsteps - 1; lc = -1;
+        ta = rec[(long)sc * RW + 0]; tb = rec[(long)sc * RW + 1];
+    }
+    __device__ __forceinline__ void eval(double t, double (&y)[Q]) {
+        while (t < ta && sc > 0) { --sc; tb = ta; ta = rec[(long)sc * RW + 0]; }
+        while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[(long)sc * RW + 1]; }
+        if (sc != lc) {
+            lc = sc;
+            const double* base = rec + (long)sc * RW + 2;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { const int comp = threadIdx.x + q * T; c[m][q] = comp < N ? base[m * N + comp] : 0.0; }
+        }
+        poly_eval<Q>((t - ta) / (tb - ta), c, y);
+    }
+};
+
+template <class Mo>
+__global__ void __launch_bounds__(Mo::T) k_wide_forward_ts5(WideGeom g, WideAdapt a, const double* __restrict__ u0, const double* __restrict__ p, double* __restrict__ rec,
+                                                            int* __restrict__ nsteps, const double* __restrict__ save_t, double* __restrict__ out, double* __restrict__ yT,
+                                                            int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, T = W::T, Q = W::Q, RW = 2 + 5 * N;
+    __shared__ double us[N], du[N], ws[W::NW], sp[W::P_LDS ? W::NP : 1];
+    const long traj = blockIdx.x; const int tid = threadIdx.x;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
+    double u[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; u[q] = c < N ? u0[traj * N + c] : 0.0; }
+    KRegsRolled<Q> K;
+    auto rhs = [&](double (&k)[Q], const double (&x)[Q], double t) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) us[c] = x[q]; }
+        wide_sync<T>();
+        Mo::f(du, us, pp, t, ws, tid);
+        wide_sync<T>();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; k[q] = c < N ? du[c] : 0.0; }
+    };
+    int s = 0, ms = 0;
+    bool overflow = false;
+    auto put = [&](double* dst, const double (&y)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) dst[c] = y[q]; }
+    };
+    while (out && ms < g.M && save_t[ms] <= g.t0) { put(out + (traj * g.M + ms) * N, u); ++ms; }      // loss times that coincide with t0
+    const double TINF = 1.7976931348623157e308;
+    double ts_next = (out && ms < g.M) ? save_t[ms] : TINF;
+    double* myrec = rec ? rec + traj * (long)a.Smax * RW : nullptr;
+    auto cb = [&](double t, double tprev, double (&un)[Q], const auto& KK) -> bool {
+        (void)un;
+        const double h = t - tprev;
+        double c[5][Q]; tsit5_poly<Q>(KK, h, c);
+        if (s < a.Smax) {
+            if (myrec) {
+                double* r = myrec + (long)s * RW;
+                if (tid == 0) { r[0] = tprev; r[1] = t; }
+#pragma unroll
+                for (int m = 0; m < 5; ++m)
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) { const int comp = tid + q * T; if (comp < N) r[2 + m * N + comp] = c[m][q]; }
+            }
+        } else overflow = true;
+        ++s;
+        while (ts_next <= t || time_hits(ts_next, t)) {
+            double y[Q]; poly_eval<Q>((ts_next - tprev) / h, c, y);
+            put(out + (traj * g.M + ms) * N, y);
+            ++ms; ts_next = ms < g.M ? save_t[ms] : TINF; }
+        return false;
+    };
+    const int na = tsit5_integrate<Q>(u, g.t0, a.t1, a.dt0, a.abstol, a.reltol, nullptr, 0, false, a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
+    if (tid == 0) nsteps[traj] = s;     // the TRUE count, also beyond the capacity (flag bit 4 marks the overflow)
+    if (yT) put(yT + traj * N, u);
+    if ((na < 0 || overflow) && tid == 0) atomicOr(flag, 4);
+}
+
+// Reverse sweeps on the adaptive solution.  ALG = 2 GaussAdjoint: z = lam; after every accepted step the 3-node Gauss-Legendre sum of -(df/dp)^T lam over the
+// step, lam from the step's own continuous extension (same restatement as adjoint_tsit5_lane: IntegratingSumCallback [upstream-recall], src/gauss_adjoint.jl:809-851).
+// ALG = 0 InterpolatingAdjoint: z = [lam; mu] with mu' = -(df/dp)^T lam.  mu never feeds a stage state, so its seven stage values W_j are not kept: the
+// step needs only  inc = sum_j b_j W_j  (the new mu) and  est = sum_j btilde_j W_j  (mu's share of the error estimate), accumulated stage by stage in the
+// tableau's order — the same sums, term for term, that tsit5_integrate forms for a lane's mu components.  Rows in LDS: mu, inc, est, the stage value W
+// (written by the model's vjp with weight 1 into a zeroed row; reduced parameters are summed over the workgroup per stage) and W of the FSAL stage.
+template <class Mo, int ALG>
+__global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdapt a, const double* __restrict__ p, const double* __restrict__ rec, const int* __restrict__ nsteps,
+                                                            const double* __restrict__ save_t, const double* __restrict__ tstops_desc, const double* __restrict__ cot,
+                                                            double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q, RW = 2 + 5 * N;
+    static_assert(ALG == 2, "the adaptive sweep of the workgroup family: GaussAdjoint");
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    const long traj = blockIdx.x;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
+    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
+    wide_zero_gp<Mo>(L);
+    WideFwdCursor<Mo> cur;
+    { const int ns = nsteps[traj]; cur.init(rec + traj * (long)a.Smax * RW, ns < a.Smax ? ns : a.Smax); }   // clamped: an overflowed forward pass is an error, not a fault
+    double z[Q], acc[W::NA], dacc[W::NA];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) z[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < W::NA; ++q) { acc[q] = 0.0; dacc[q] = 0.0; }
+    KRegsRolled<Q> K;
+    int cur_time = g.M;
+    double t_loss = g.M > 0 ? save_t[g.M - 1] : 0.0;
+    auto rhs = [&](double (&dz)[Q], const double (&zz)[Q], double t) {
+        double y[Q], dl[Q];
+        cur.eval(t, y);
+        wide_vjp<Mo, false>(L, pp, t, 0.0, y, zz, dacc, dl);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) dz[q] = -dl[q];
+    };
+    auto cb = [&](double t, double tprev, double (&zz)[Q], const auto& KK) -> bool {
+        bool mod = false;
+        if (t != tprev) {
+            const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;
+#pragma unroll 1
+            for (int nq = 0; nq < 3; ++nq) {
+                const double xq = nq == 0 ? -0.7745966692414833770 : (nq == 1 ? 0.0 : 0.7745966692414833770);
+                const double wq = nq == 1 ? 8.0 / 9.0 : 5.0 / 9.0;
+                const double tt = half * xq + mid;
+                double y[Q], lamq[Q], dd[Q];
+                kstore_interp<Q, Q>(KK, (tt - tprev) / h, h, lamq);
+                cur.eval(tt, y);
+                wide_vjp<Mo, true>(L, pp, tt, -(half * wq), y, lamq, acc, dd);
+            }
+        }
+        if (cur_time >= 1 && time_hits(t, t_loss)) {                                  // ReverseLossCallback
+            if (!(g.no_start && cur_time == 1)) {
+                double y[Q]; cur.eval(t, y);
+                wide_jump<Mo>(g, traj, cur_time - 1, cot, y, zz);
+                mod = true;
+            }
+            --cur_time;
+            t_loss = cur_time >= 1 ? save_t[cur_time - 1] : 0.0;
+        }
+        return mod;
+    };
+    const bool cb_at_init = g.M > 0 && time_hits(a.t1, save_t[g.M - 1]);
+    const int na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
+    wide_finish<Mo>(g, traj, L, z, acc, du0, dp_traj, flag);
+    if (na < 0 && threadIdx.x == 0) atomicOr(flag, 4);
+}
+
+#endif  // device code (adaptive)
 
 // a stand-in model with the shape of a generated one: lets the host translation unit name the kernels' parameter lists (usig) without instantiating them
 struct WideProbe {

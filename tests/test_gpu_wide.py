@@ -104,3 +104,80 @@ def test_per_trajectory_parameters_and_lsq_loss(sa):
                         checkpointing=(oalg == "BACKSOLVE"), quad_abstol=1e-10, quad_reltol=1e-10)
         rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, P)
         assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL and dp.shape == (N, n * n), alg
+
+
+# ---- adaptive Tsit5 in the workgroup family (GaussAdjoint) ----------------------------------------------------------------------------------
+def _run_ts5(sa, fun, oname, dims, u0, p, T, ts, tol, delta_of_out, p_shared=True, loss=None, max_steps=0):
+    N = len(u0)
+    ens = sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p if p_shared else p[0]), u0, None if p_shared else p)
+    kw = dict(dgdu_discrete=loss) if loss is not None else {}
+    sol = sa.solve(ens, sa.Tsit5(), saveat=ts, sensealg=sa.GaussAdjoint(), abstol=tol[0], reltol=tol[1], max_steps=max_steps, **kw)
+    ref = O.Problem(oname, alg="GAUSS", stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=tol[0], reltol=tol[1], save_times=ts, dims=dims,
+                    **(dict(loss="COTANGENT") if loss is None else dict(loss="LSQ_SHIFT", loss_shift=loss.shift)))
+    if loss is None:
+        delta = delta_of_out(sol.u)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=delta)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    else:
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p)
+    out = sol.u
+    sol.engine.close()
+    return du0, dp, rdu0, rdp, out, rout
+
+
+# the controller's norms are summed over the workgroup (per-thread partials, then a butterfly) instead of component by component: the error estimate differs
+# from the oracle's in the last bits, the accepted step sizes with it — far below the tolerance asserted here
+TS5_RTOL = 1e-8
+
+
+@pytest.mark.parametrize("tol", [(1e-6, 1e-3), (1e-9, 1e-9)])
+@pytest.mark.parametrize("N", [1, 5])
+def test_adaptive_tsit5_benchmark_neural_ode(sa, tol, N):
+    """docs/src/Benchmark.md:62 as published: Tsit5 with tolerances, 30 loss times — GaussAdjoint on the adaptive solution of a wide runtime model"""
+    d, H, T = 2, 50, 1.5
+    ts = np.linspace(0.0, T, 30)
+    rng = np.random.default_rng(100)
+    p = np.concatenate([rng.standard_normal(H * d) * np.sqrt(1.0 / d), np.zeros(H), rng.standard_normal(d * H) * np.sqrt(1.0 / H), np.zeros(d)]) * 0.5
+    u0 = np.array([2.0, 0.0]) + 0.05 * rng.standard_normal((N, d)); u0[0] = [2.0, 0.0]
+    data = rng.standard_normal((N, len(ts), d))
+    fun = sa.WideDeviceFunction.dense_chain(f"node_ts5_{N}_{tol[1]:.0e}", (d, H, d), input_power=3)
+    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "MLP1", (d, H, 0, 0), u0, p, T, ts, tol, lambda o: 2.0 * (o - data))
+    assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL and dp.shape == (252,)
+
+
+def test_adaptive_tsit5_matrix_state_30x50(sa):
+    R, Cc, T = 30, 50, 1.0
+    ts = np.linspace(0.0, T, 11)
+    rng = np.random.default_rng(7)
+    N = 3
+    u0 = rng.standard_normal((N, R * Cc)); p = rng.random(2)
+    fun = sa.WideDeviceFunction.index_affine("idxaff_ts5", R, Cc)
+    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "IDXAFF", (R, Cc, 0, 0), u0, p, T, ts, (1e-6, 1e-3), lambda o: 2.0 * o)
+    assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL
+
+
+@pytest.mark.parametrize("n", [24, 100])
+def test_adaptive_tsit5_dense_linear_rows_and_lsq(sa, n):
+    """per-trajectory parameters (np = n^2: 576 in LDS, 10 000 in HBM), the in-kernel loss dgdu = u - shift, loss times that are not step boundaries"""
+    T = 1.0
+    ts = np.array([0.0, 0.13, 0.37, 0.5, 0.81, 1.0])
+    rng = np.random.default_rng(n)
+    N = 3
+    P = np.stack([(rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)).flatten(order="F") for _ in range(N)])
+    u0 = rng.standard_normal((N, n))
+    fun = sa.WideDeviceFunction.dense_linear(f"lin{n}_ts5", n)
+    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "DENSELIN", (n, 0, 0, 0), u0, P, T, ts, (1e-8, 1e-6), None, p_shared=False, loss=sa.LsqShift(0.3))
+    assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL and dp.shape == (N, n * n)
+
+
+def test_adaptive_tsit5_wide_reports_a_record_that_is_too_small(sa):
+    d, H, T = 2, 50, 1.5
+    ts = np.linspace(0.0, T, 30)
+    rng = np.random.default_rng(1)
+    p = np.concatenate([rng.standard_normal(H * d) * 0.35, np.zeros(H), rng.standard_normal(d * H) * 0.07, np.zeros(d)])
+    u0 = np.array([[2.0, 0.0]])
+    fun = sa.WideDeviceFunction.dense_chain("node_ts5_small", (d, H, d), input_power=3)
+    with pytest.raises(Exception, match="max_steps"):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.GaussAdjoint(), abstol=1e-10, reltol=1e-10, max_steps=3)
+        sol.engine.synchronize()
