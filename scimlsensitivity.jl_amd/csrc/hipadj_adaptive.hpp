@@ -126,9 +126,17 @@ template <int NZ> struct KRegsRolled : KRegs<NZ> { static constexpr bool ROLLED 
 
 // How the step controller's norms are summed.  Lane family: the lane holds the whole state — plain sums over NZ components.  Workgroup family: a thread
 // holds its owned components, the sums run over the workgroup (hipadj_wide.hpp: WideNorm) and the divisor is the true number of components.
+// `which` names the norm: 0, 1, 2 = the three sums of the Hairer-Norsett-Wanner initial step (u, f(u0), f(u1) - f(u0); h = the trial step h0), 3 = the error
+// estimate of a step attempt (h = the step).  The hooks mark the points at which a policy that carries further state components OUTSIDE the integrated
+// vector (the workgroup family's parameter gradient, hipadj_wide.hpp: WideAugNorm) has to act; they are empty for everything else.
 struct TS5LaneNorm {
-    HIPADJ_HD double sum(double x) const { return x; }
+    HIPADJ_HD double sum(double x, int which, double h) const { (void)which; (void)h; return x; }
     HIPADJ_HD double count(int nz) const { return (double)nz; }
+    HIPADJ_HD void begin_attempt() const {}      // top of a step attempt (k_1 is valid)
+    HIPADJ_HD void after_k0() const {}           // k_1 = f(u, t) was just evaluated (first step, or after a callback changed u)
+    HIPADJ_HD void after_stage(int s) const { (void)s; }   // stage s = 1..6 was just evaluated (row s holds k_{s+1})
+    HIPADJ_HD void accept(double h) const { (void)h; }     // the attempt with step h is accepted: u <- u_{n+1}
+    HIPADJ_HD void fsal() const {}               // k_1 <- k_7 (no callback intervened)
 };
 #ifndef HIPADJ_TS5_REGS
 #define HIPADJ_TS5_REGS 1
@@ -249,16 +257,17 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             rhs(w, u, t);
 #pragma unroll
             for (int i = 0; i < NZ; ++i) K.set(0, i, w[i]);
+            red.after_k0();
             need_k0 = false;
         }
         if (first) {
             first = false;
             if (dt_hint > 0) dt = tdir * dt_hint;
             else {   // Hairer-Norsett-Wanner initial step; w still holds f(u0)
-                double d0 = 0, d1 = 0;
+                double d0 = 0, d1 = 0; const double h0_unused = 0.0;
 #pragma unroll
                 for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; d0 += (u[i] / sc) * (u[i] / sc); d1 += (w[i] / sc) * (w[i] / sc); }
-                d0 = sqrt(red.sum(d0) / ncomp); d1 = sqrt(red.sum(d1) / ncomp);
+                d0 = sqrt(red.sum(d0, 0, h0_unused) / ncomp); d1 = sqrt(red.sum(d1, 1, h0_unused) / ncomp);
                 double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
                 h0 = hmin2(h0, habs(tend - t));
                 double u1[NZ], f1[NZ];
@@ -268,7 +277,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
                 double d2 = 0;
 #pragma unroll
                 for (int i = 0; i < NZ; ++i) { const double sc = abstol + habs(u[i]) * reltol; const double q = (f1[i] - K.get(0, i)) / sc; d2 += q * q; }
-                d2 = sqrt(red.sum(d2) / ncomp) / h0;
+                d2 = sqrt(red.sum(d2, 2, h0) / ncomp) / h0;
                 const double h1 = (hmax2(d1, d2) <= 1e-15) ? hmax2(1e-6, h0 * 1e-3) : pow(0.01 / hmax2(d1, d2), 1.0 / 5.0);
                 dt = tdir * hmin2(hmin2(100.0 * h0, h1), habs(tend - t));
             }
@@ -285,6 +294,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
         if (habs((t + h) - tstop) < 100.0 * EPS * hmax2(habs(t + h), habs(tstop))) h = tstop - t;
 #pragma unroll
         for (int i = 0; i < NZ; ++i) K.set(KS_UPREV, i, u[i]);
+        red.begin_attempt();
         // Stage loop, rolled: ONE instance of rhs (and of the forward-solution cursor inside it).  The whole zero-padded
         // tableau row arrives in one batch of scalar loads, then a straight-line 6-term sum: rows j >= s of K hold finite
         // leftovers that the zero coefficients annihilate (non-finite leftovers are cleared when a step is rejected,
@@ -319,6 +329,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
                 default: { _Pragma("unroll") for (int i = 0; i < NZ; ++i) K.set(6, i, ks[i]); } break;
 #undef HIPADJ_TS5_SETROW
                 }
+                red.after_stage(s);
             }
         } else {
 #pragma unroll 1
@@ -362,6 +373,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             rhs(ks, w, t + TS5::c(s) * h);
 #pragma unroll
             for (int i = 0; i < NZ; ++i) K.set(s, i, ks[i]);
+            red.after_stage(s);
         }
         }
         // w = u_{n+1} (the seventh stage state is the 5th-order solution), K row 6 = f(u_{n+1}) (FSAL)
@@ -392,7 +404,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
                 e2 += q * q;
             }
         }
-        const double EEst = sqrt(red.sum(e2) / ncomp);
+        const double EEst = sqrt(red.sum(e2, 3, h) / ncomp);
         // x^c as exp(c log x): within a few ulp of pow() (the step-size factor is not an accuracy-critical quantity) at about a
         // third of its instruction count
         const double q11 = exp((7.0 / 50.0) * log(hmax2(EEst, 1e-300)));
@@ -404,6 +416,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             qold = hmax2(EEst, 1e-4);
 #pragma unroll
             for (int i = 0; i < NZ; ++i) u[i] = w[i];
+            red.accept(h);
             tprev = t; t = tnew; ++naccept;
             dt = h / q;
             if (habs(dt) < 1e-14 * hmax2(1.0, habs(tnew))) dt = tdir * 1e-14 * hmax2(1.0, habs(tnew));
@@ -411,6 +424,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             else {
 #pragma unroll
                 for (int i = 0; i < NZ; ++i) K.set(0, i, K.get(6, i));   // FSAL
+                red.fsal();
             }
             if (naccept > max_steps) return -1;
         } else {

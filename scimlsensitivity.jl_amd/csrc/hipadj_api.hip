@@ -154,7 +154,7 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
 }
 
 static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false) {
-    if (ts5) return {"hipadj::k_wide_forward_ts5<hipadj::UserW>", "hipadj::k_wide_adjoint_ts5<hipadj::UserW, 2>"};
+    if (ts5) return {"hipadj::k_wide_forward_ts5<hipadj::UserW>", std::string("hipadj::k_wide_adjoint_ts5<hipadj::UserW, ") + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : "2>")};
     const std::string U = "hipadj::UserW";
     std::vector<std::string> e = {"hipadj::k_wide_forward<" + U + ">"};
     switch (alg) {
@@ -1006,6 +1006,9 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
 // ---- wide runtime models: workgroup-per-trajectory family (hipadj_wide.hpp) ----------------------------------------------------------------
 static int wide_prepare(hipadj_handle* h) {
     if (user_has_cost(h->cfg.model) || user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no continuous cost / affect");
+    if (h->wide_ts5 && h->cfg.alg == HIPADJ_ALG_INTERPOLATING && user_wide_ts5_interp_lds(h->cfg.model) * 8 > 160L * 1024)
+        HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide model %d: InterpolatingAdjoint on the adaptive solution needs %ld KB of LDS (3 n + scratch + 5 np + the parameter copy), a workgroup has 160 KB — use GaussAdjoint, whose sweep integrates lam only",
+                    h->cfg.model, user_wide_ts5_interp_lds(h->cfg.model) * 8 / 1024);
     const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5);
     std::vector<char> code; std::map<std::string, std::string> low;
     const int rc = user_compile(h->cfg.model, exprs, code, low, h->err);

@@ -184,8 +184,10 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     P.wide = P.user && plan_user_wide_hook() && plan_user_wide_hook()(cfg->model);
     if (!plan_small_model(cfg->model) && !P.field && !P.mlp) { err = "unknown model"; return HIPADJ_ERR_UNSUPPORTED; }
     if (P.wide) {   // what the wide family offers so far: fixed-step RK4, loss times on the step grid, the four sensealgs, discrete losses
-        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->alg != HIPADJ_ALG_GAUSS) {
-            err = "wide models (hipadj_wmodel_register): adaptive Tsit5 is offered with GaussAdjoint (the sweep integrates lam only); the other sensealgs run the fixed-step RK4 stepper"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->alg != HIPADJ_ALG_GAUSS && cfg->alg != HIPADJ_ALG_INTERPOLATING) {
+            err = "wide models (hipadj_wmodel_register): adaptive Tsit5 is offered with GaussAdjoint and InterpolatingAdjoint; Backsolve- and QuadratureAdjoint run the fixed-step RK4 stepper"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->alg == HIPADJ_ALG_INTERPOLATING && np > 8192) {
+            err = "wide models: InterpolatingAdjoint on the adaptive solution keeps five parameter-sized rows in LDS (np <= 8192 at most; the exact budget is checked when the handle is created) — GaussAdjoint has no such limit"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->checkpointing) { err = "wide models: adaptive Tsit5 keeps the dense forward solution (checkpointing = false)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->ncheckpoints > 0) { err = "wide models: adaptive Tsit5 takes no checkpoint list"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }

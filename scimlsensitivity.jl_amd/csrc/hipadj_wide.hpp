@@ -586,8 +586,48 @@ struct WideAdapt {
 
 template <int T> struct WideNorm {
     int n;
-    __device__ __forceinline__ double sum(double x) const { return wide_sum_all<T>(x); }
+    __device__ __forceinline__ double sum(double x, int, double) const { return wide_sum_all<T>(x); }
     __device__ __forceinline__ double count(int) const { return (double)n; }
+    __device__ __forceinline__ void begin_attempt() const {}
+    __device__ __forceinline__ void after_k0() const {}
+    __device__ __forceinline__ void after_stage(int) const {}
+    __device__ __forceinline__ void accept(double) const {}
+    __device__ __forceinline__ void fsal() const {}
+};
+
+// InterpolatingAdjoint on the adaptive solution: z = [lam; mu], mu' = -(df/dp)^T lam.  lam lives in the integrated per-thread vector; mu (NP entries,
+// owned by whichever thread the model's vjp body assigns) lives in LDS rows managed here.  mu never feeds a stage state, so its seven stage
+// values K_j are not kept: a step needs  inc = sum_{j<6} a(6, j) K_j  (mu_{n+1} = mu_n + h inc)  and  est = sum_{j<7} btilde_j K_j  (mu's share of the
+// error estimate), accumulated stage by stage in the tableau's order — term for term the sums tsit5_integrate forms for a lane's mu components.
+// Rows: mu, inc, est, kc = the stage value the right-hand side just wrote (K = -(df/dp)^T lam: the vjp body runs with weight -1 into a zeroed row), k0 = k_1.
+template <class Mo> struct WideAugNorm {
+    static constexpr int N = Mo::N, NP = Mo::NP, T = Mo::T;
+    double *mu, *inc, *est, *k0, *kc;
+    double abstol, reltol;
+    __device__ __forceinline__ double count(int) const { return (double)(N + NP); }
+    __device__ __forceinline__ void begin_attempt() const {
+        for (int j = threadIdx.x; j < NP; j += T) { inc[j] = TS5::a(6, 0) * k0[j]; est[j] = TS5::bt(0) * k0[j]; }
+        wide_sync<T>();
+    }
+    __device__ __forceinline__ void after_k0() const { for (int j = threadIdx.x; j < NP; j += T) k0[j] = kc[j]; wide_sync<T>(); }
+    __device__ __forceinline__ void fsal() const { after_k0(); }
+    __device__ __forceinline__ void after_stage(int s) const {
+        const double as = s < 6 ? TS5::a(6, s) : 0.0, bs = TS5::bt(s);
+        for (int j = threadIdx.x; j < NP; j += T) { const double k = kc[j]; if (s < 6) inc[j] += as * k; est[j] += bs * k; }
+        wide_sync<T>();
+    }
+    __device__ __forceinline__ void accept(double h) const { for (int j = threadIdx.x; j < NP; j += T) mu[j] = mu[j] + h * inc[j]; wide_sync<T>(); }
+    __device__ __forceinline__ double sum(double x, int which, double h) const {
+        double part = 0.0;
+        for (int j = threadIdx.x; j < NP; j += T) {
+            const double m = mu[j];
+            double q;
+            if (which == 3) { const double mn = m + h * inc[j]; const double sc = abstol + hmax2(habs(m), habs(mn)) * reltol; q = h * est[j] / sc; }
+            else { const double sc = abstol + habs(m) * reltol; q = (which == 0 ? m : (which == 1 ? k0[j] : kc[j] - k0[j])) / sc; }
+            part += q * q;
+        }
+        return wide_sum_all<T>(x + part);
+    }
 };
 
 // cursor into the trajectory's dense forward solution; uniform over the workgroup (every thread walks the same records, holds its owned coefficients)
@@ -685,12 +725,17 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
                                                             double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q, RW = 2 + 5 * N;
-    static_assert(ALG == 2, "the adaptive sweep of the workgroup family: GaussAdjoint");
+    static_assert(ALG == 0 || ALG == 2, "the adaptive sweeps of the workgroup family: Interpolating- and GaussAdjoint");
+    static_assert(ALG == 2 || W::GP_LDS, "InterpolatingAdjoint on the adaptive solution keeps five parameter-sized rows in LDS (the planner checks the budget)");
     __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    __shared__ double srows[ALG == 0 ? 4 * NP : 1], saccs[W::NA];
     const long traj = blockIdx.x;
     const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
-    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
+    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};   // gp: Gauss' accumulator; Interpolating's mu
     wide_zero_gp<Mo>(L);
+    const WideAugNorm<Mo> aug{L.gp, srows, srows + (ALG == 0 ? NP : 0), srows + (ALG == 0 ? 2 * NP : 0), srows + (ALG == 0 ? 3 * NP : 0), a.abstol, a.reltol};
+    if (ALG == 0) { for (int j = threadIdx.x; j < 4 * NP; j += T) srows[j] = 0.0; wide_sync<T>(); }
+    WideTiles<Mo> LK = L; LK.gp = aug.kc;                                              // Interpolating: the vjp body writes the stage value of mu here
     WideFwdCursor<Mo> cur;
     { const int ns = nsteps[traj]; cur.init(rec + traj * (long)a.Smax * RW, ns < a.Smax ? ns : a.Smax); }   // clamped: an overflowed forward pass is an error, not a fault
     double z[Q], acc[W::NA], dacc[W::NA];
@@ -704,13 +749,23 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
     auto rhs = [&](double (&dz)[Q], const double (&zz)[Q], double t) {
         double y[Q], dl[Q];
         cur.eval(t, y);
-        wide_vjp<Mo, false>(L, pp, t, 0.0, y, zz, dacc, dl);
+        if constexpr (ALG == 0) {
+            for (int j = threadIdx.x; j < NP; j += T) aug.kc[j] = 0.0;              // (the barrier inside wide_vjp orders this against the body's accumulation)
+            wide_vjp<Mo, true>(LK, pp, t, -1.0, y, zz, dacc, dl);
+            if constexpr (W::NACC > 0) {                                           // parameters every component feeds: their stage value is a workgroup sum
+                wide_block_sum<T, W::NA>(dacc, L.red, saccs);
+                if ((int)threadIdx.x < W::NACC) aug.kc[Mo::ACC0 + threadIdx.x] += saccs[threadIdx.x];
+#pragma unroll
+                for (int q = 0; q < W::NA; ++q) dacc[q] = 0.0;
+                wide_sync<T>();
+            }
+        } else wide_vjp<Mo, false>(L, pp, t, 0.0, y, zz, dacc, dl);
 #pragma unroll
         for (int q = 0; q < Q; ++q) dz[q] = -dl[q];
     };
     auto cb = [&](double t, double tprev, double (&zz)[Q], const auto& KK) -> bool {
         bool mod = false;
-        if (t != tprev) {
+        if (ALG == 2 && t != tprev) {
             const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;
 #pragma unroll 1
             for (int nq = 0; nq < 3; ++nq) {
@@ -735,7 +790,9 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
         return mod;
     };
     const bool cb_at_init = g.M > 0 && time_hits(a.t1, save_t[g.M - 1]);
-    const int na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
+    int na;
+    if constexpr (ALG == 0) na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), aug);
+    else na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
     wide_finish<Mo>(g, traj, L, z, acc, du0, dp_traj, flag);
     if (na < 0 && threadIdx.x == 0) atomicOr(flag, 4);
 }

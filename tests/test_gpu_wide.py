@@ -106,13 +106,13 @@ def test_per_trajectory_parameters_and_lsq_loss(sa):
         assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL and dp.shape == (N, n * n), alg
 
 
-# ---- adaptive Tsit5 in the workgroup family (GaussAdjoint) ----------------------------------------------------------------------------------
-def _run_ts5(sa, fun, oname, dims, u0, p, T, ts, tol, delta_of_out, p_shared=True, loss=None, max_steps=0):
+# ---- adaptive Tsit5 in the workgroup family (GaussAdjoint, InterpolatingAdjoint) ----------------------------------------------------------------
+def _run_ts5(sa, fun, oname, dims, u0, p, T, ts, tol, delta_of_out, p_shared=True, loss=None, max_steps=0, alg="gauss"):
     N = len(u0)
     ens = sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p if p_shared else p[0]), u0, None if p_shared else p)
     kw = dict(dgdu_discrete=loss) if loss is not None else {}
-    sol = sa.solve(ens, sa.Tsit5(), saveat=ts, sensealg=sa.GaussAdjoint(), abstol=tol[0], reltol=tol[1], max_steps=max_steps, **kw)
-    ref = O.Problem(oname, alg="GAUSS", stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=tol[0], reltol=tol[1], save_times=ts, dims=dims,
+    sol = sa.solve(ens, sa.Tsit5(), saveat=ts, sensealg=(sa.GaussAdjoint() if alg == "gauss" else sa.InterpolatingAdjoint()), abstol=tol[0], reltol=tol[1], max_steps=max_steps, **kw)
+    ref = O.Problem(oname, alg=alg.upper(), stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=tol[0], reltol=tol[1], save_times=ts, dims=dims,
                     **(dict(loss="COTANGENT") if loss is None else dict(loss="LSQ_SHIFT", loss_shift=loss.shift)))
     if loss is None:
         delta = delta_of_out(sol.u)
@@ -131,34 +131,37 @@ def _run_ts5(sa, fun, oname, dims, u0, p, T, ts, tol, delta_of_out, p_shared=Tru
 TS5_RTOL = 1e-8
 
 
+@pytest.mark.parametrize("alg", ["gauss", "interpolating"])
 @pytest.mark.parametrize("tol", [(1e-6, 1e-3), (1e-9, 1e-9)])
 @pytest.mark.parametrize("N", [1, 5])
-def test_adaptive_tsit5_benchmark_neural_ode(sa, tol, N):
-    """docs/src/Benchmark.md:62 as published: Tsit5 with tolerances, 30 loss times — GaussAdjoint on the adaptive solution of a wide runtime model"""
+def test_adaptive_tsit5_benchmark_neural_ode(sa, tol, N, alg):
+    """docs/src/Benchmark.md:62 as published: Tsit5 with tolerances, 30 loss times — Gauss- and InterpolatingAdjoint on the adaptive solution of a wide runtime model"""
     d, H, T = 2, 50, 1.5
     ts = np.linspace(0.0, T, 30)
     rng = np.random.default_rng(100)
     p = np.concatenate([rng.standard_normal(H * d) * np.sqrt(1.0 / d), np.zeros(H), rng.standard_normal(d * H) * np.sqrt(1.0 / H), np.zeros(d)]) * 0.5
     u0 = np.array([2.0, 0.0]) + 0.05 * rng.standard_normal((N, d)); u0[0] = [2.0, 0.0]
     data = rng.standard_normal((N, len(ts), d))
-    fun = sa.WideDeviceFunction.dense_chain(f"node_ts5_{N}_{tol[1]:.0e}", (d, H, d), input_power=3)
-    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "MLP1", (d, H, 0, 0), u0, p, T, ts, tol, lambda o: 2.0 * (o - data))
+    fun = sa.WideDeviceFunction.dense_chain(f"node_ts5_{N}_{tol[1]:.0e}_{alg}", (d, H, d), input_power=3)
+    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "MLP1", (d, H, 0, 0), u0, p, T, ts, tol, lambda o: 2.0 * (o - data), alg=alg)
     assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL and dp.shape == (252,)
 
 
-def test_adaptive_tsit5_matrix_state_30x50(sa):
+@pytest.mark.parametrize("alg", ["gauss", "interpolating"])
+def test_adaptive_tsit5_matrix_state_30x50(sa, alg):
+    """(the two parameters of this model are the reduced kind: every component feeds them — Interpolating sums their stage values over the workgroup per stage)"""
     R, Cc, T = 30, 50, 1.0
     ts = np.linspace(0.0, T, 11)
     rng = np.random.default_rng(7)
     N = 3
     u0 = rng.standard_normal((N, R * Cc)); p = rng.random(2)
-    fun = sa.WideDeviceFunction.index_affine("idxaff_ts5", R, Cc)
-    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "IDXAFF", (R, Cc, 0, 0), u0, p, T, ts, (1e-6, 1e-3), lambda o: 2.0 * o)
+    fun = sa.WideDeviceFunction.index_affine(f"idxaff_ts5_{alg}", R, Cc)
+    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "IDXAFF", (R, Cc, 0, 0), u0, p, T, ts, (1e-6, 1e-3), lambda o: 2.0 * o, alg=alg)
     assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL
 
 
-@pytest.mark.parametrize("n", [24, 100])
-def test_adaptive_tsit5_dense_linear_rows_and_lsq(sa, n):
+@pytest.mark.parametrize("n,alg", [(24, "gauss"), (100, "gauss"), (24, "interpolating")])
+def test_adaptive_tsit5_dense_linear_rows_and_lsq(sa, n, alg):
     """per-trajectory parameters (np = n^2: 576 in LDS, 10 000 in HBM), the in-kernel loss dgdu = u - shift, loss times that are not step boundaries"""
     T = 1.0
     ts = np.array([0.0, 0.13, 0.37, 0.5, 0.81, 1.0])
@@ -166,8 +169,8 @@ def test_adaptive_tsit5_dense_linear_rows_and_lsq(sa, n):
     N = 3
     P = np.stack([(rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)).flatten(order="F") for _ in range(N)])
     u0 = rng.standard_normal((N, n))
-    fun = sa.WideDeviceFunction.dense_linear(f"lin{n}_ts5", n)
-    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "DENSELIN", (n, 0, 0, 0), u0, P, T, ts, (1e-8, 1e-6), None, p_shared=False, loss=sa.LsqShift(0.3))
+    fun = sa.WideDeviceFunction.dense_linear(f"lin{n}_ts5_{alg}", n)
+    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "DENSELIN", (n, 0, 0, 0), u0, P, T, ts, (1e-8, 1e-6), None, p_shared=False, loss=sa.LsqShift(0.3), alg=alg)
     assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL and dp.shape == (N, n * n)
 
 
@@ -181,3 +184,14 @@ def test_adaptive_tsit5_wide_reports_a_record_that_is_too_small(sa):
     with pytest.raises(Exception, match="max_steps"):
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.GaussAdjoint(), abstol=1e-10, reltol=1e-10, max_steps=3)
         sol.engine.synchronize()
+
+
+@pytest.mark.parametrize("n,where", [(100, "five parameter-sized rows"), (60, "KB of LDS")])
+def test_adaptive_interpolating_wide_refuses_what_does_not_fit_the_lds(sa, n, where):
+    """np = n^2 = 10 000: refused by the planner; 3 600: by the LDS budget of the handle (5 np + the parameter copy > 160 KB) — both name GaussAdjoint"""
+    rng = np.random.default_rng(n)
+    u0 = rng.standard_normal((2, n)); p = (rng.standard_normal((n, n)) / np.sqrt(n)).flatten()
+    fun = sa.WideDeviceFunction.dense_linear(f"lin{n}_ts5_refused", n)
+    with pytest.raises(Exception, match=where) as ei:
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, 1.0), p), u0), sa.Tsit5(), saveat=np.linspace(0, 1, 5), sensealg=sa.InterpolatingAdjoint(), abstol=1e-6, reltol=1e-3)
+    assert "GaussAdjoint" in str(ei.value)
