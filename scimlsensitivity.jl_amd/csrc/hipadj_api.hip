@@ -154,7 +154,8 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
 }
 
 static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false) {
-    if (ts5) return {"hipadj::k_wide_forward_ts5<hipadj::UserW>", std::string("hipadj::k_wide_adjoint_ts5<hipadj::UserW, ") + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : "2>")};
+    if (ts5) return {"hipadj::k_wide_forward_ts5<hipadj::UserW>", alg == HIPADJ_ALG_BACKSOLVE ? std::string("hipadj::k_wide_backsolve_ts5<hipadj::UserW>")
+                                                                    : std::string("hipadj::k_wide_adjoint_ts5<hipadj::UserW, ") + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : "2>")};
     const std::string U = "hipadj::UserW";
     std::vector<std::string> e = {"hipadj::k_wide_forward<" + U + ">"};
     switch (alg) {
@@ -303,7 +304,15 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             h->rec_cap = cap;
             h->wa.t1 = cfg->t1; h->wa.abstol = cfg->abstol; h->wa.reltol = cfg->reltol; h->wa.dt0 = cfg->dt; h->wa.Smax = (int)cap; h->wa.maxit = (int)cap;
             h->ag.Smax = (int)cap;   // (the overflow message names it)
-            A(dev_alloc(h, &h->d_rec, (size_t)h->N * cap * RW));
+            if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)h->N * cap * RW));
+            else {   // Backsolve keeps no records: y(T) and, checkpointing = true, the forward states at the checkpoint times [N][nck][n]
+                A(dev_alloc(h, &h->d_yT, (size_t)h->N * n));
+                h->wg.nck = P.nck;
+                if (P.nck > 0) {
+                    A(dev_alloc(h, &h->d_ckpt, (size_t)h->N * P.nck * n)); A(dev_alloc(h, &h->d_ck_t, (size_t)P.nck));
+                    if (rc == HIPADJ_OK && !HT(hipMemcpy(h->d_ck_t, P.ck_times.data(), sizeof(double) * P.nck, hipMemcpyHostToDevice), "memcpy")) rc = HIPADJ_ERR_HIP;
+                }
+            }
             A(dev_alloc(h, &h->d_nsteps, (size_t)h->N));
             if (h->M > 0) A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
             h->ntstops = (int)P.tstops_desc.size(); h->wa.ntstops = h->ntstops;
@@ -1006,9 +1015,12 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
 // ---- wide runtime models: workgroup-per-trajectory family (hipadj_wide.hpp) ----------------------------------------------------------------
 static int wide_prepare(hipadj_handle* h) {
     if (user_has_cost(h->cfg.model) || user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no continuous cost / affect");
-    if (h->wide_ts5 && h->cfg.alg == HIPADJ_ALG_INTERPOLATING && user_wide_ts5_interp_lds(h->cfg.model) * 8 > 160L * 1024)
-        HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide model %d: InterpolatingAdjoint on the adaptive solution needs %ld KB of LDS (3 n + scratch + 5 np + the parameter copy), a workgroup has 160 KB — use GaussAdjoint, whose sweep integrates lam only",
-                    h->cfg.model, user_wide_ts5_interp_lds(h->cfg.model) * 8 / 1024);
+    if (h->wide_ts5 && (h->cfg.alg == HIPADJ_ALG_INTERPOLATING || h->cfg.alg == HIPADJ_ALG_BACKSOLVE)) {
+        const long lds = user_wide_ts5_interp_lds(h->cfg.model, h->cfg.alg == HIPADJ_ALG_BACKSOLVE) * 8;
+        if (lds > 160L * 1024)
+            HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide model %d: Interpolating- / BacksolveAdjoint on the adaptive solution need %ld KB of LDS (state tiles + scratch + 5 np + the parameter copy), a workgroup has 160 KB — use GaussAdjoint, whose sweep integrates lam only",
+                        h->cfg.model, lds / 1024);
+    }
     const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5);
     std::vector<char> code; std::map<std::string, std::string> low;
     const int rc = user_compile(h->cfg.model, exprs, code, low, h->err);
@@ -1023,8 +1035,10 @@ static int wide_prepare(hipadj_handle* h) {
 
 static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (h->wide_ts5) {
-        TRY(usig<decltype(&k_wide_forward_ts5<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, h->wa, d_u0, d_p, h->d_rec, h->d_nsteps,
-                    (const double*)h->d_save_t, (d_out && h->M > 0) ? d_out : (double*)nullptr, (double*)nullptr, h->d_flag));
+        const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE;
+        TRY(usig<decltype(&k_wide_forward_ts5<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, h->wa, d_u0, d_p, bs ? (double*)nullptr : h->d_rec, h->d_nsteps,
+                    (const double*)h->d_save_t, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const double*)h->d_ck_t, (bs && h->wg.nck > 0) ? h->d_ckpt : (double*)nullptr,
+                    bs ? h->d_yT : (double*)nullptr, h->d_flag));
         return HIPADJ_OK;
     }
     const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE;
@@ -1044,7 +1058,10 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     const dim3 grid((unsigned)h->N), blk((unsigned)h->wide_T);
     // per-trajectory gradient rows: straight into the caller's dp when the parameters are per trajectory, else a workspace that k_wide_reduce_dp sums
     double* rows = h->cfg.p_shared ? h->d_dp_traj : d_dp;
-    if (h->wide_ts5) {
+    if (h->wide_ts5 && h->cfg.alg == HIPADJ_ALG_BACKSOLVE) {
+        TRY(usig<decltype(&k_wide_backsolve_ts5<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, h->wa, p, (const double*)h->d_yT, (const double*)(h->wg.nck > 0 ? h->d_ckpt : nullptr),
+                    (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag));
+    } else if (h->wide_ts5) {
         TRY(usig<decltype(&k_wide_adjoint_ts5<WideProbe, 2>)>::launch(h, h->uf_main, grid, blk, h->wg, h->wa, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_save_t,
                     (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag));
     } else

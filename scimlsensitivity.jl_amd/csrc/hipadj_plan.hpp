@@ -184,15 +184,15 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     P.wide = P.user && plan_user_wide_hook() && plan_user_wide_hook()(cfg->model);
     if (!plan_small_model(cfg->model) && !P.field && !P.mlp) { err = "unknown model"; return HIPADJ_ERR_UNSUPPORTED; }
     if (P.wide) {   // what the wide family offers so far: fixed-step RK4, loss times on the step grid, the four sensealgs, discrete losses
-        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->alg != HIPADJ_ALG_GAUSS && cfg->alg != HIPADJ_ALG_INTERPOLATING) {
-            err = "wide models (hipadj_wmodel_register): adaptive Tsit5 is offered with GaussAdjoint and InterpolatingAdjoint; Backsolve- and QuadratureAdjoint run the fixed-step RK4 stepper"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->alg == HIPADJ_ALG_INTERPOLATING && np > 8192) {
-            err = "wide models: InterpolatingAdjoint on the adaptive solution keeps five parameter-sized rows in LDS (np <= 8192 at most; the exact budget is checked when the handle is created) — GaussAdjoint has no such limit"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->checkpointing) { err = "wide models: adaptive Tsit5 keeps the dense forward solution (checkpointing = false)"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->ncheckpoints > 0) { err = "wide models: adaptive Tsit5 takes no checkpoint list"; return HIPADJ_ERR_UNSUPPORTED; }
+        const bool ts5 = cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE;
+        if (ts5 && cfg->alg == HIPADJ_ALG_QUADRATURE) {
+            err = "wide models (hipadj_wmodel_register): adaptive Tsit5 is offered with Gauss-, Interpolating- and BacksolveAdjoint; QuadratureAdjoint runs the fixed-step RK4 stepper"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (ts5 && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_BACKSOLVE) && np > 8192) {
+            err = "wide models: Interpolating- / BacksolveAdjoint on the adaptive solution keep five parameter-sized rows in LDS (np <= 8192 at most; the exact budget is checked when the handle is created) — GaussAdjoint has no such limit"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (ts5 && cfg->alg != HIPADJ_ALG_BACKSOLVE && (cfg->checkpointing || cfg->ncheckpoints > 0)) { err = "wide models: Gauss- / InterpolatingAdjoint on adaptive Tsit5 keep the dense forward solution (checkpointing = false, no checkpoint list)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "continuous costs are available for the lane-per-trajectory family only"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->checkpointing && cfg->alg != HIPADJ_ALG_BACKSOLVE) { err = "wide models: checkpointing = true is available for BacksolveAdjoint (Interpolating / Gauss keep the dense knots)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (!ts5 && cfg->checkpointing && cfg->alg != HIPADJ_ALG_BACKSOLVE) { err = "wide models: checkpointing = true is available for BacksolveAdjoint (Interpolating / Gauss keep the dense knots)"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (P.mlp) {
         if (cfg->dims[0] != 2) { err = "MLP family: state width d must be 2 (docs/src/Benchmark.md:62 shape)"; return HIPADJ_ERR_UNSUPPORTED; }

@@ -674,13 +674,13 @@ inline bool user_model_is_wide(int32_t model) {
 }
 // LDS doubles of the adaptive InterpolatingAdjoint sweep of a wide model (k_wide_adjoint_ts5<., 0>): three state tiles, the model's scratch, five
 // parameter-sized rows (mu, inc, est, k0, kc), the parameter copy, reduction rows
-inline long user_wide_ts5_interp_lds(int32_t model) {
+inline long user_wide_ts5_interp_lds(int32_t model, bool backsolve = false) {
     UserRegistry& R = user_registry();
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) return 0;
     const UserModelSrc& m = R.models[idx];
-    return 3L * m.n + m.nw + 5L * m.np + (m.np <= 4096 ? m.np : 1) + (m.threads / 64) * 34 + 96;
+    return (backsolve ? 4L : 3L) * m.n + m.nw + 5L * m.np + (m.np <= 4096 ? m.np : 1) + (m.threads / 64) * 34 + 96;
 }
 inline int user_wide_threads(int32_t model) {
     UserRegistry& R = user_registry();

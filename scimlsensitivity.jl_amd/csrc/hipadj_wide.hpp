@@ -604,7 +604,8 @@ template <class Mo> struct WideAugNorm {
     static constexpr int N = Mo::N, NP = Mo::NP, T = Mo::T;
     double *mu, *inc, *est, *k0, *kc;
     double abstol, reltol;
-    __device__ __forceinline__ double count(int) const { return (double)(N + NP); }
+    int nint;                                    // components of the integrated vector: n (Interpolating: lam) or 2 n (Backsolve: lam and y)
+    __device__ __forceinline__ double count(int) const { return (double)(nint + NP); }
     __device__ __forceinline__ void begin_attempt() const {
         for (int j = threadIdx.x; j < NP; j += T) { inc[j] = TS5::a(6, 0) * k0[j]; est[j] = TS5::bt(0) * k0[j]; }
         wide_sync<T>();
@@ -656,8 +657,8 @@ template <class Mo> struct WideFwdCursor {
 
 template <class Mo>
 __global__ void __launch_bounds__(Mo::T) k_wide_forward_ts5(WideGeom g, WideAdapt a, const double* __restrict__ u0, const double* __restrict__ p, double* __restrict__ rec,
-                                                            int* __restrict__ nsteps, const double* __restrict__ save_t, double* __restrict__ out, double* __restrict__ yT,
-                                                            int* __restrict__ flag) {
+                                                            int* __restrict__ nsteps, const double* __restrict__ save_t, double* __restrict__ out, const double* __restrict__ ck_t,
+                                                            double* __restrict__ ckpt, double* __restrict__ yT, int* __restrict__ flag) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, T = W::T, Q = W::Q, RW = 2 + 5 * N;
     __shared__ double us[N], du[N], ws[W::NW], sp[W::P_LDS ? W::NP : 1];
@@ -676,21 +677,23 @@ __global__ void __launch_bounds__(Mo::T) k_wide_forward_ts5(WideGeom g, WideAdap
 #pragma unroll
         for (int q = 0; q < Q; ++q) { const int c = tid + q * T; k[q] = c < N ? du[c] : 0.0; }
     };
-    int s = 0, ms = 0;
+    int s = 0, ms = 0, mc = 0;
     bool overflow = false;
     auto put = [&](double* dst, const double (&y)[Q]) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) dst[c] = y[q]; }
     };
     while (out && ms < g.M && save_t[ms] <= g.t0) { put(out + (traj * g.M + ms) * N, u); ++ms; }      // loss times that coincide with t0
+    while (ckpt && mc < g.nck && ck_t[mc] <= g.t0) { put(ckpt + (traj * g.nck + mc) * N, u); ++mc; }   // Backsolve's checkpoints sol(c_j) [N][nck][n]
     const double TINF = 1.7976931348623157e308;
-    double ts_next = (out && ms < g.M) ? save_t[ms] : TINF;
+    double ts_next = (out && ms < g.M) ? save_t[ms] : TINF, tc_next = (ckpt && mc < g.nck) ? ck_t[mc] : TINF;
     double* myrec = rec ? rec + traj * (long)a.Smax * RW : nullptr;
     auto cb = [&](double t, double tprev, double (&un)[Q], const auto& KK) -> bool {
         (void)un;
         const double h = t - tprev;
         double c[5][Q]; tsit5_poly<Q>(KK, h, c);
-        if (s < a.Smax) {
+        if (!myrec) { /* Backsolve keeps no records */ }
+        else if (s < a.Smax) {
             if (myrec) {
                 double* r = myrec + (long)s * RW;
                 if (tid == 0) { r[0] = tprev; r[1] = t; }
@@ -705,6 +708,10 @@ __global__ void __launch_bounds__(Mo::T) k_wide_forward_ts5(WideGeom g, WideAdap
             double y[Q]; poly_eval<Q>((ts_next - tprev) / h, c, y);
             put(out + (traj * g.M + ms) * N, y);
             ++ms; ts_next = ms < g.M ? save_t[ms] : TINF; }
+        while (tc_next <= t || time_hits(tc_next, t)) {
+            double y[Q]; poly_eval<Q>((tc_next - tprev) / h, c, y);
+            put(ckpt + (traj * g.nck + mc) * N, y);
+            ++mc; tc_next = mc < g.nck ? ck_t[mc] : TINF; }
         return false;
     };
     const int na = tsit5_integrate<Q>(u, g.t0, a.t1, a.dt0, a.abstol, a.reltol, nullptr, 0, false, a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
@@ -733,7 +740,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
     const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};   // gp: Gauss' accumulator; Interpolating's mu
     wide_zero_gp<Mo>(L);
-    const WideAugNorm<Mo> aug{L.gp, srows, srows + (ALG == 0 ? NP : 0), srows + (ALG == 0 ? 2 * NP : 0), srows + (ALG == 0 ? 3 * NP : 0), a.abstol, a.reltol};
+    const WideAugNorm<Mo> aug{L.gp, srows, srows + (ALG == 0 ? NP : 0), srows + (ALG == 0 ? 2 * NP : 0), srows + (ALG == 0 ? 3 * NP : 0), a.abstol, a.reltol, N};
     if (ALG == 0) { for (int j = threadIdx.x; j < 4 * NP; j += T) srows[j] = 0.0; wide_sync<T>(); }
     WideTiles<Mo> LK = L; LK.gp = aug.kc;                                              // Interpolating: the vjp body writes the stage value of mu here
     WideFwdCursor<Mo> cur;
@@ -795,6 +802,86 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
     else na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
     wide_finish<Mo>(g, traj, L, z, acc, du0, dp_traj, flag);
     if (na < 0 && threadIdx.x == 0) atomicOr(flag, 4);
+}
+
+
+// BacksolveAdjoint on the adaptive solution: z = [lam; mu; y] integrated backward jointly from y(T) (src/backsolve_adjoint.jl:32-61); lam and y are the
+// per-thread integrated vector (2 Q), mu goes through WideAugNorm as for Interpolating.  checkpointing = true: y is overwritten with the stored forward
+// value at every checkpoint time the sweep stops at (:523-546), before the loss gradient of that time is taken at the backsolved state.
+template <class Mo>
+__global__ void __launch_bounds__(Mo::T) k_wide_backsolve_ts5(WideGeom g, WideAdapt a, const double* __restrict__ p, const double* __restrict__ yT, const double* __restrict__ ckpt,
+                                                              const double* __restrict__ ck_t, const double* __restrict__ save_t, const double* __restrict__ tstops_desc,
+                                                              const double* __restrict__ cot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    static_assert(W::GP_LDS, "BacksolveAdjoint on the adaptive solution keeps five parameter-sized rows in LDS (the planner checks the budget)");
+    __shared__ double sy[N], sls[N], sdl[N], sdu[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[NP], sp[W::P_LDS ? NP : 1], srows[4 * NP], saccs[W::NA];
+    const long traj = blockIdx.x; const int tid = threadIdx.x;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
+    WideTiles<Mo> L{sy, sls, sdl, sgp, sws, sred};
+    wide_zero_gp<Mo>(L);
+    const WideAugNorm<Mo> aug{sgp, srows, srows + NP, srows + 2 * NP, srows + 3 * NP, a.abstol, a.reltol, 2 * N};
+    for (int j = tid; j < 4 * NP; j += T) srows[j] = 0.0;
+    wide_sync<T>();
+    double z[2 * Q], acc[W::NA], dacc[W::NA];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; z[q] = 0.0; z[Q + q] = c < N ? yT[traj * N + c] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < W::NA; ++q) { acc[q] = 0.0; dacc[q] = 0.0; }
+    KRegsRolled<2 * Q> K;
+    int cur_time = g.M, bs_cur = ckpt ? g.nck : 0;
+    double t_loss = g.M > 0 ? save_t[g.M - 1] : 0.0;
+    if (bs_cur >= 1 && time_hits(a.t1, ck_t[bs_cur - 1])) --bs_cur;
+    double t_ck = bs_cur >= 1 ? ck_t[bs_cur - 1] : 0.0;
+    auto rhs = [&](double (&dz)[2 * Q], const double (&zz)[2 * Q], double t) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { sls[c] = zz[q]; sy[c] = zz[Q + q]; } }
+        for (int j = tid; j < NP; j += T) aug.kc[j] = 0.0;
+        wide_sync<T>();
+        Mo::f(sdu, sy, pp, t, sws, tid);
+        wide_sync<T>();                                               // f and vjp share the model's scratch
+        Mo::template vjp<true>(sdl, aug.kc, dacc, -1.0, sls, sy, pp, t, sws, tid);
+        wide_sync<T>();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; dz[q] = c < N ? -sdl[c] : 0.0; dz[Q + q] = c < N ? sdu[c] : 0.0; }
+        if constexpr (W::NACC > 0) {
+            wide_block_sum<T, W::NA>(dacc, sred, saccs);
+            if (tid < W::NACC) aug.kc[Mo::ACC0 + tid] += saccs[tid];
+#pragma unroll
+            for (int q = 0; q < W::NA; ++q) dacc[q] = 0.0;
+            wide_sync<T>();
+        }
+    };
+    auto cb = [&](double t, double tprev, double (&zz)[2 * Q], const auto& KK) -> bool {
+        (void)tprev; (void)KK;
+        bool mod = false;
+        if (bs_cur >= 1 && time_hits(t, t_ck)) {                                      // backsolve_checkpoint_callbacks
+            const double* src = ckpt + (traj * g.nck + (bs_cur - 1)) * N;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) zz[Q + q] = src[c]; }
+            --bs_cur; mod = true;
+            t_ck = bs_cur >= 1 ? ck_t[bs_cur - 1] : 0.0;
+        }
+        if (cur_time >= 1 && time_hits(t, t_loss)) {                                  // ReverseLossCallback at the (possibly just overwritten) backsolved state; no_start is not consulted
+            double yv[Q], lv[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { lv[q] = zz[q]; yv[q] = zz[Q + q]; }
+            wide_jump<Mo>(g, traj, cur_time - 1, cot, yv, lv);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) zz[q] = lv[q];
+            mod = true;
+            --cur_time;
+            t_loss = cur_time >= 1 ? save_t[cur_time - 1] : 0.0;
+        }
+        return mod;
+    };
+    const bool cb_at_init = g.M > 0 && time_hits(a.t1, save_t[g.M - 1]);
+    const int na = tsit5_integrate<2 * Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), aug);
+    double lam[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = z[q];
+    wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
+    if (na < 0 && tid == 0) atomicOr(flag, 4);
 }
 
 #endif  // device code (adaptive)
