@@ -461,6 +461,22 @@ def wide_rows(sa, run):
                                            frac=fl / (kms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, kernel="k_wide_adjoint" if alg == "interpolating" else "k_wide_backsolve",
                                            note="one wavefront per trajectory, 50 of 64 lanes on the hidden layer; algorithmic flops (10 H d + 2 H + 2 d per joint VJP)")))
             eng.close()
+    # (iii) the same benchmark AS PUBLISHED: adaptive Tsit5 at the default tolerances (abstol 1e-6, reltol 1e-3) on the runtime model — the workgroup family's adaptive
+    #       stepper (per-trajectory step control, dense record; hipadj_wide.hpp).  No roofline: ~20 accepted steps of 7 model evaluations each, a latency chain.
+    #       Reference figures of docs/src/Benchmark.md (a CPU, Float32 state, other hardware): InterpolatingAdjoint 1.657 ms, BacksolveAdjoint 2.477 ms per gradient
+    #       (forward + reverse, compiled ReverseDiffVJP) — quoted for scale, not a vs_baseline.
+    pub = dict(interpolating=1.657, backsolve=2.477, gauss=None)
+    for alg in ("interpolating", "backsolve", "gauss"):
+        for N in (1, 4096):
+            eng = sa.Engine(fun.name, alg, N, 0.0, T, 0.0, save_times=ts, checkpointing=(alg == "backsolve"), stepper=1, abstol=1e-6, reltol=1e-3)
+            u0 = np.array([2.0, 0.0]) + 0.05 * rng.standard_normal((N, d))
+            ms, kms, st = run(eng, u0, p, rng.standard_normal((N, len(ts), d)), 5)
+            rows.append(dict(config=f"wide model: 2-50-2 neural ODE of docs/src/Benchmark.md AS PUBLISHED (adaptive Tsit5, abstol 1e-6, reltol 1e-3, 30 loss times), {alg}, N = {N}",
+                             forward_ms=st["forward_ms_last"], reverse_ms=ms, sweep_kernel_ms=kms, gradient_ms=st["forward_ms_last"] + ms,
+                             trajectories_per_s=N / ((st["forward_ms_last"] + ms) * 1e-3),
+                             reference_published_cpu_ms=pub[alg], roofline=dict(bound="latency", note="adaptive steps of one workgroup per trajectory; no bandwidth or flop roofline applies at these sizes",
+                                                                                kernel="k_wide_backsolve_ts5" if alg == "backsolve" else "k_wide_adjoint_ts5")))
+            eng.close()
     return rows
 
 

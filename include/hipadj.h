@@ -211,9 +211,12 @@ int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double 
  * Available inside the bodies: `tid`, `T` (= threads), `N`, `NP`, `HIPADJ_W_FOR(i, count) { ... }` (i = tid, tid + T, ... < count),
  * `wg_sync()` (workgroup barrier between dependent phases, e.g. hidden layers), `wg_sum(x)` (sum of one value per thread over the workgroup,
  * returned to every thread: wavefront shuffles; every thread must call it), `ws[0..lds_doubles)` LDS scratch.  u, lam, du, dlam, ws are
- * LDS, p is global memory.  threads: a multiple of 64 in [64, 1024], 0 = automatic.  Offered: fixed-step RK4, loss times on the step grid,
- * Interpolating / Backsolve (checkpoints) / Gauss / QuadratureAdjoint, discrete losses; parity-tested against the oracle on the reference's
- * 30 x 50 matrix-state problem (test/Core5/size_handling_adjoint.jl:37-70) and the 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62. */
+ * LDS, p is global memory.  threads: a multiple of 64 in [64, 1024], 0 = automatic.  Offered: fixed-step RK4 (loss times on the step grid;
+ * Interpolating / Backsolve (checkpoints) / Gauss / QuadratureAdjoint) and adaptive Tsit5 with per-trajectory step control (stepper =
+ * HIPADJ_STEPPER_TSIT5_ADAPTIVE, arbitrary loss times; Gauss-, Interpolating- and BacksolveAdjoint — the latter two keep five np-sized rows in LDS,
+ * HIPADJ_ERR_UNSUPPORTED naming GaussAdjoint when they do not fit; max_steps = 0 sizes the dense record from a 2 GiB budget, 64 ... 4096 steps);
+ * discrete losses; parity-tested against the oracle on the reference's 30 x 50 matrix-state problem (test/Core5/size_handling_adjoint.jl:37-70)
+ * and the 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62, with both steppers. */
 int hipadj_wmodel_register(const char *name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
                            const char *f_body, const char *vjp_body, int32_t *model_id);
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
