@@ -154,15 +154,19 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
 }
 
 static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false) {
-    if (ts5) return {"hipadj::k_wide_forward_ts5<hipadj::UserW>", alg == HIPADJ_ALG_BACKSOLVE ? std::string("hipadj::k_wide_backsolve_ts5<hipadj::UserW>")
-                                                                    : std::string("hipadj::k_wide_adjoint_ts5<hipadj::UserW, ") + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : "2>")};
+    if (ts5) {
+        std::vector<std::string> e = {"hipadj::k_wide_forward_ts5<hipadj::UserW>", alg == HIPADJ_ALG_BACKSOLVE ? std::string("hipadj::k_wide_backsolve_ts5<hipadj::UserW>")
+                                      : std::string("hipadj::k_wide_adjoint_ts5<hipadj::UserW, ") + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : (alg == HIPADJ_ALG_QUADRATURE ? "3>" : "2>"))};
+        if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_gk<hipadj::UserW, " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", true>");
+        return e;
+    }
     const std::string U = "hipadj::UserW";
     std::vector<std::string> e = {"hipadj::k_wide_forward<" + U + ">"};
     switch (alg) {
     case HIPADJ_ALG_INTERPOLATING: e.push_back("hipadj::k_wide_adjoint<" + U + ", 0>"); break;
     case HIPADJ_ALG_GAUSS: e.push_back("hipadj::k_wide_adjoint<" + U + ", 2>"); break;
     case HIPADJ_ALG_BACKSOLVE: e.push_back("hipadj::k_wide_backsolve<" + U + ">"); break;
-    case HIPADJ_ALG_QUADRATURE: e.push_back("hipadj::k_wide_quad_adj<" + U + ">"); e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ">"); break;
+    case HIPADJ_ALG_QUADRATURE: e.push_back("hipadj::k_wide_quad_adj<" + U + ">"); e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", false>"); break;
     default: break;
     }
     return e;
@@ -314,6 +318,13 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
                 }
             }
             A(dev_alloc(h, &h->d_nsteps, (size_t)h->N));
+            if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // dense adjoint solution (the reverse solve also stops at every loss time) + the quadrature workspaces
+                h->SmaxA = 2 * (int)cap + h->M + 16;
+                A(dev_alloc(h, &h->d_arec, (size_t)h->N * h->SmaxA * RW));
+                A(dev_alloc(h, &h->d_nsteps_adj, (size_t)h->N));
+                A(dev_alloc(h, &h->d_qres, (size_t)h->N * (h->nq > 0 ? h->nq : 1) * np));
+                A(dev_alloc(h, &h->d_wscr, (size_t)h->N * (h->nq > 0 ? h->nq : 1) * (3 + HIPADJ_WIDE_MAXSEG) * np));
+            }
             if (h->M > 0) A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
             h->ntstops = (int)P.tstops_desc.size(); h->wa.ntstops = h->ntstops;
             if (h->ntstops > 0) A(dev_alloc(h, &h->d_tstops, (size_t)h->ntstops));
@@ -1062,8 +1073,18 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         TRY(usig<decltype(&k_wide_backsolve_ts5<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, h->wa, p, (const double*)h->d_yT, (const double*)(h->wg.nck > 0 ? h->d_ckpt : nullptr),
                     (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag));
     } else if (h->wide_ts5) {
+        const bool quad = h->cfg.alg == HIPADJ_ALG_QUADRATURE;
         TRY(usig<decltype(&k_wide_adjoint_ts5<WideProbe, 2>)>::launch(h, h->uf_main, grid, blk, h->wg, h->wa, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_save_t,
-                    (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag));
+                    (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag, quad ? h->d_arec : (double*)nullptr, quad ? h->d_nsteps_adj : (int*)nullptr, quad ? h->SmaxA : 0));
+        if (quad) {
+            if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+            const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+            const WideQuadSrc src{nullptr, nullptr, h->d_rec, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->wa.Smax, h->SmaxA};
+            TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG, true>)>::launch(h, h->uf_gk, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, src,
+                        (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
+            hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows);
+            HIP_TRY(h, hipGetLastError());
+        }
     } else
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS:
@@ -1077,8 +1098,9 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         TRY(usig<decltype(&k_wide_quad_adj<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag));
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-        TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG>)>::launch(h, h->uf_gk, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, (const double*)h->d_fknots,
-                    (const double*)h->d_fadj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
+        const WideQuadSrc src{h->d_fknots, h->d_fadj, nullptr, nullptr, nullptr, nullptr, 0, 0};
+        TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG, false>)>::launch(h, h->uf_gk, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, src,
+                    (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
         hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows);
         HIP_TRY(h, hipGetLastError());
         break; }

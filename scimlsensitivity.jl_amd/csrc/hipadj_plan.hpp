@@ -185,8 +185,6 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (!plan_small_model(cfg->model) && !P.field && !P.mlp) { err = "unknown model"; return HIPADJ_ERR_UNSUPPORTED; }
     if (P.wide) {   // what the wide family offers so far: fixed-step RK4, loss times on the step grid, the four sensealgs, discrete losses
         const bool ts5 = cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE;
-        if (ts5 && cfg->alg == HIPADJ_ALG_QUADRATURE) {
-            err = "wide models (hipadj_wmodel_register): adaptive Tsit5 is offered with Gauss-, Interpolating- and BacksolveAdjoint; QuadratureAdjoint runs the fixed-step RK4 stepper"; return HIPADJ_ERR_UNSUPPORTED; }
         if (ts5 && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_BACKSOLVE) && np > 8192) {
             err = "wide models: Interpolating- / BacksolveAdjoint on the adaptive solution keep five parameter-sized rows in LDS (np <= 8192 at most; the exact budget is checked when the handle is created) — GaussAdjoint has no such limit"; return HIPADJ_ERR_UNSUPPORTED; }
         if (ts5 && cfg->alg != HIPADJ_ALG_BACKSOLVE && (cfg->checkpointing || cfg->ncheckpoints > 0)) { err = "wide models: Gauss- / InterpolatingAdjoint on adaptive Tsit5 keep the dense forward solution (checkpointing = false, no checkpoint list)"; return HIPADJ_ERR_UNSUPPORTED; }

@@ -47,6 +47,12 @@ struct WideGeom {
     int loss_kind, no_start, p_shared;
 };
 
+// where QuadratureAdjoint's second pass reads y(t) and lam(t) from: fixed step (knots + the Hermite records of pass 1) or the adaptive solutions' dense records
+struct WideQuadSrc {
+    const double* knots; const double* adj;                                   // fixed-step RK4
+    const double* rec; const int* nsteps; const double* arec; const int* nsteps_adj; int Smax, SmaxA;   // adaptive Tsit5 (null / 0 on the fixed step)
+};
+
 // Gauss-Kronrod (7,15) tables (QuadGK order 7), runtime-indexed by the rolled node loop
 __constant__ double cw_gk_x[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
                                   0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
@@ -431,10 +437,13 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_adj(WideGeom g, const doubl
 // decisions (src/quadrature_adjoint.jl:486-502, 537-616; QuadGK [upstream-recall]: (7,15) rule, Euclidean norm over the np entries, bisect the
 // segment with the largest error until E <= max(atol, rtol |I|)).  Vectors of np entries (Kronrod / Gauss sums of a panel, the integrand, the
 // segments' integrals) live in a per-workgroup HBM scratch [3 + MAXSEG][np]; at most MAXSEG segments (documented cap).
-template <class Mo, int MAXSEG>
-__global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ adj,
+template <class Mo> struct WideFwdCursor;
+template <class Mo> struct WideAdjCursor;
+template <class Mo, int MAXSEG, bool TS5 = false>
+__global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double* __restrict__ p, WideQuadSrc src,
                                                         const double* __restrict__ qa, const double* __restrict__ qb, double atol, double rtol,
                                                         double* __restrict__ scratch, double* __restrict__ qres) {
+    const double* __restrict__ knots = src.knots; const double* __restrict__ adj = src.adj;
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
     __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * (2 * W::NA > 2 ? 2 * W::NA : 2)], sacc[2 * W::NA], sfi[W::GP_LDS ? NP : 1];
@@ -446,8 +455,23 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
     double* fi = W::GP_LDS ? sfi : fig;
     WideTiles<Mo> L{sy, sls, sdl, fi, sws, sred};
 
+    // adaptive solutions: cursors into the trajectory's dense forward and adjoint records (uniform over the workgroup)
+    WideFwdCursor<Mo> curF; WideAdjCursor<Mo> curA;
+    if constexpr (TS5) {
+        constexpr long RW = 2 + 5L * N;
+        { const int ns = src.nsteps[traj]; curF.init(src.rec + traj * (long)src.Smax * RW, ns < src.Smax ? ns : src.Smax); }
+        { const int ns = src.nsteps_adj[traj]; curA.init(src.arec + traj * (long)src.SmaxA * RW, ns < src.SmaxA ? ns : src.SmaxA); }
+    }
     // integrand at time t: y = sol(t) (forward Hermite), lam = adj_sol(t) (the record's Hermite), f_p^T lam into fi[] and the per-thread partials
     auto integrand = [&](double t, double (&part)[W::NA]) {
+        if constexpr (TS5) {
+            double yv[Q], lv[Q], dd[Q];
+            curF.eval(t, yv); curA.eval(t, lv);
+            for (int j = tid; j < NP; j += T) fi[j] = 0.0;
+#pragma unroll
+            for (int q = 0; q < W::NA; ++q) part[q] = 0.0;
+            wide_vjp<Mo, true>(L, pp, t, 1.0, yv, lv, part, dd);
+        } else {
         int k = (int)((t - g.t0) / g.dt);
         if (k < 0) k = 0;
         if (k > g.S - 1) k = g.S - 1;
@@ -472,6 +496,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
 #pragma unroll
         for (int q = 0; q < W::NA; ++q) part[q] = 0.0;
         wide_vjp<Mo, true>(L, pp, t, 1.0, yv, lv, part, dd);             // its leading barrier also orders the zeroing of fi
+        }
     };
     // one GK15 panel: IK / IG <- h * (Kronrod / Gauss sums); returns E = |IK - IG|_2, identical in every thread
     auto panel = [&](double a, double b) -> double {
@@ -655,6 +680,31 @@ template <class Mo> struct WideFwdCursor {
     }
 };
 
+// cursor into the dense ADJOINT solution (QuadratureAdjoint pass 1 -> pass 2): records in order of decreasing time, record s covers [te, ts] with te < ts,
+// monomial coefficients in theta = (t - ts) / (te - ts)
+template <class Mo> struct WideAdjCursor {
+    static constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q, RW = 2 + 5 * Mo::N;
+    const double* rec; int ns, sc, lc;
+    double ts, te, c[5][Q];
+    __device__ __forceinline__ void init(const double* r, int nsteps) {
+        rec = r; ns = nsteps; sc = 0; lc = -1;
+        ts = rec[0]; te = rec[1];
+    }
+    __device__ __forceinline__ void eval(double t, double (&lam)[Q]) {
+        while (t < te && sc < ns - 1) { ++sc; ts = te; te = rec[(long)sc * RW + 1]; }
+        while (t > ts && sc > 0) { --sc; te = ts; ts = rec[(long)sc * RW + 0]; }
+        if (sc != lc) {
+            lc = sc;
+            const double* base = rec + (long)sc * RW + 2;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { const int comp = threadIdx.x + q * T; c[m][q] = comp < N ? base[m * N + comp] : 0.0; }
+        }
+        poly_eval<Q>((t - ts) / (te - ts), c, lam);
+    }
+};
+
 template <class Mo>
 __global__ void __launch_bounds__(Mo::T) k_wide_forward_ts5(WideGeom g, WideAdapt a, const double* __restrict__ u0, const double* __restrict__ p, double* __restrict__ rec,
                                                             int* __restrict__ nsteps, const double* __restrict__ save_t, double* __restrict__ out, const double* __restrict__ ck_t,
@@ -729,11 +779,12 @@ __global__ void __launch_bounds__(Mo::T) k_wide_forward_ts5(WideGeom g, WideAdap
 template <class Mo, int ALG>
 __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdapt a, const double* __restrict__ p, const double* __restrict__ rec, const int* __restrict__ nsteps,
                                                             const double* __restrict__ save_t, const double* __restrict__ tstops_desc, const double* __restrict__ cot,
-                                                            double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+                                                            double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
+                                                            double* __restrict__ arec, int* __restrict__ nsteps_adj, int SmaxA) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q, RW = 2 + 5 * N;
-    static_assert(ALG == 0 || ALG == 2, "the adaptive sweeps of the workgroup family: Interpolating- and GaussAdjoint");
-    static_assert(ALG == 2 || W::GP_LDS, "InterpolatingAdjoint on the adaptive solution keeps five parameter-sized rows in LDS (the planner checks the budget)");
+    static_assert(ALG == 0 || ALG == 2 || ALG == 3, "the adaptive sweeps of the workgroup family: Interpolating-, Gauss- and QuadratureAdjoint (pass 1: lam only, recorded densely)");
+    static_assert(ALG != 0 || W::GP_LDS, "InterpolatingAdjoint on the adaptive solution keeps five parameter-sized rows in LDS (the planner checks the budget)");
     __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
     __shared__ double srows[ALG == 0 ? 4 * NP : 1], saccs[W::NA];
     const long traj = blockIdx.x;
@@ -770,8 +821,22 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
 #pragma unroll
         for (int q = 0; q < Q; ++q) dz[q] = -dl[q];
     };
+    int sa = 0;
+    bool aoverflow = false;
     auto cb = [&](double t, double tprev, double (&zz)[Q], const auto& KK) -> bool {
         bool mod = false;
+        if (ALG == 3 && t != tprev) {   // the dense adjoint solution for the quadrature pass (src/quadrature_adjoint.jl:527-530)
+            if (sa < SmaxA) {
+                double c[5][Q]; tsit5_poly<Q>(KK, t - tprev, c);
+                double* r = arec + (traj * (long)SmaxA + sa) * RW;
+                if (threadIdx.x == 0) { r[0] = tprev; r[1] = t; }
+#pragma unroll
+                for (int m = 0; m < 5; ++m)
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) { const int comp = threadIdx.x + q * T; if (comp < N) r[2 + m * N + comp] = c[m][q]; }
+            } else aoverflow = true;
+            ++sa;
+        }
         if (ALG == 2 && t != tprev) {
             const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;
 #pragma unroll 1
@@ -800,8 +865,9 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
     int na;
     if constexpr (ALG == 0) na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), aug);
     else na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
-    wide_finish<Mo>(g, traj, L, z, acc, du0, dp_traj, flag);
-    if (na < 0 && threadIdx.x == 0) atomicOr(flag, 4);
+    wide_finish<Mo>(g, traj, L, z, acc, du0, ALG == 3 ? (double*)nullptr : dp_traj, flag);      // Quadrature: dp comes from the second pass
+    if (ALG == 3 && threadIdx.x == 0) nsteps_adj[traj] = sa;                                   // the TRUE count; readers clamp with SmaxA
+    if ((na < 0 || aoverflow) && threadIdx.x == 0) atomicOr(flag, 4);
 }
 
 

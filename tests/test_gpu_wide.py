@@ -112,9 +112,10 @@ def _run_ts5(sa, fun, oname, dims, u0, p, T, ts, tol, delta_of_out, p_shared=Tru
     ens = sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p if p_shared else p[0]), u0, None if p_shared else p)
     kw = dict(dgdu_discrete=loss) if loss is not None else {}
     base = alg.split("_")[0]
-    sens = dict(gauss=sa.GaussAdjoint(), interpolating=sa.InterpolatingAdjoint(), backsolve=sa.BacksolveAdjoint(), backsolve_nockpt=sa.BacksolveAdjoint(checkpointing=False))[alg]
+    sens = dict(gauss=sa.GaussAdjoint(), interpolating=sa.InterpolatingAdjoint(), backsolve=sa.BacksolveAdjoint(), backsolve_nockpt=sa.BacksolveAdjoint(checkpointing=False),
+                quadrature=sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10))[alg]
     sol = sa.solve(ens, sa.Tsit5(), saveat=ts, sensealg=sens, abstol=tol[0], reltol=tol[1], max_steps=max_steps, **kw)
-    ref = O.Problem(oname, alg=base.upper(), stepper="TSIT5", checkpointing=(alg == "backsolve"), t0=0.0, t1=T, dt=0.0, abstol=tol[0], reltol=tol[1], save_times=ts, dims=dims,
+    ref = O.Problem(oname, alg=base.upper(), stepper="TSIT5", checkpointing=(alg == "backsolve"), quad_abstol=1e-10, quad_reltol=1e-10, t0=0.0, t1=T, dt=0.0, abstol=tol[0], reltol=tol[1], save_times=ts, dims=dims,
                     **(dict(loss="COTANGENT") if loss is None else dict(loss="LSQ_SHIFT", loss_shift=loss.shift)))
     if loss is None:
         delta = delta_of_out(sol.u)
@@ -133,7 +134,7 @@ def _run_ts5(sa, fun, oname, dims, u0, p, T, ts, tol, delta_of_out, p_shared=Tru
 TS5_RTOL = 1e-8
 
 
-@pytest.mark.parametrize("alg", ["gauss", "interpolating", "backsolve", "backsolve_nockpt"])
+@pytest.mark.parametrize("alg", ["gauss", "interpolating", "backsolve", "backsolve_nockpt", "quadrature"])
 @pytest.mark.parametrize("tol", [(1e-6, 1e-3), (1e-9, 1e-9)])
 @pytest.mark.parametrize("N", [1, 5])
 def test_adaptive_tsit5_benchmark_neural_ode(sa, tol, N, alg):
@@ -149,7 +150,7 @@ def test_adaptive_tsit5_benchmark_neural_ode(sa, tol, N, alg):
     assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL and dp.shape == (252,)
 
 
-@pytest.mark.parametrize("alg", ["gauss", "interpolating", "backsolve"])
+@pytest.mark.parametrize("alg", ["gauss", "interpolating", "backsolve", "quadrature"])
 def test_adaptive_tsit5_matrix_state_30x50(sa, alg):
     """(the two parameters of this model are the reduced kind: every component feeds them — Interpolating sums their stage values over the workgroup per stage)"""
     R, Cc, T = 30, 50, 1.0
@@ -162,7 +163,7 @@ def test_adaptive_tsit5_matrix_state_30x50(sa, alg):
     assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL
 
 
-@pytest.mark.parametrize("n,alg", [(24, "gauss"), (100, "gauss"), (24, "interpolating"), (24, "backsolve")])
+@pytest.mark.parametrize("n,alg", [(24, "gauss"), (100, "gauss"), (24, "interpolating"), (24, "backsolve"), (24, "quadrature"), (100, "quadrature")])
 def test_adaptive_tsit5_dense_linear_rows_and_lsq(sa, n, alg):
     """per-trajectory parameters (np = n^2: 576 in LDS, 10 000 in HBM), the in-kernel loss dgdu = u - shift, loss times that are not step boundaries"""
     T = 1.0

@@ -57,11 +57,11 @@ def test_planner_answers_for_wide_models(sa):
 
     for alg in (0, 1, 2, 3):
         assert check(alg=alg, checkpointing=int(alg == 1))[0] == 0
-    # adaptive Tsit5: Gauss- and InterpolatingAdjoint (their kernels compile here, no device needed); Backsolve / Quadrature stay on the fixed step
+    # adaptive Tsit5: all four sensealgs (their kernels compile here, no device needed)
     off_grid = np.array([0.0, 0.137, 0.61, 1.0])
-    for alg in (0, 1, 2):
+    for alg in (0, 1, 2, 3):
         assert check(stepper=1, alg=alg, dt=0.0, nsave=4, save_times=off_grid.ctypes.data_as(C.POINTER(C.c_double)), checkpointing=int(alg == 1))[0] == 0
-    rc, msg = check(stepper=1, alg=3); assert rc == -6 and "fixed-step RK4" in msg
+    rc, msg = check(stepper=1, alg=4); assert rc == -6 and "GaussKronrod" in msg
     rc, msg = check(stepper=1, alg=2, checkpointing=1); assert rc == -6 and "checkpointing" in msg
     rc, msg = check(stepper=1, alg=2, abstol=0.0); assert rc == -1 and "abstol" in msg
     rc, msg = check(alg=4); assert rc == -6 and "GaussKronrod" in msg
