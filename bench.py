@@ -464,9 +464,9 @@ def wide_rows(sa, run):
     # (iii) the same benchmark AS PUBLISHED: adaptive Tsit5 at the default tolerances (abstol 1e-6, reltol 1e-3) on the runtime model — the workgroup family's adaptive
     #       stepper (per-trajectory step control, dense record; hipadj_wide.hpp).  No roofline: ~20 accepted steps of 7 model evaluations each, a latency chain.
     #       Reference figures of docs/src/Benchmark.md (a CPU, Float32 state, other hardware): InterpolatingAdjoint 1.657 ms, BacksolveAdjoint 2.477 ms per gradient
-    #       (forward + reverse, compiled ReverseDiffVJP) — quoted for scale, not a vs_baseline.
-    pub = dict(interpolating=1.657, backsolve=2.477, gauss=None)
-    for alg in ("interpolating", "backsolve", "gauss"):
+    #       QuadratureAdjoint 2.490 ms (forward + reverse, compiled ReverseDiffVJP) — quoted for scale, not a vs_baseline.
+    pub = dict(interpolating=1.657, backsolve=2.477, quadrature=2.490, gauss=None)
+    for alg in ("interpolating", "backsolve", "quadrature", "gauss"):
         for N in (1, 4096):
             eng = sa.Engine(fun.name, alg, N, 0.0, T, 0.0, save_times=ts, checkpointing=(alg == "backsolve"), stepper=1, abstol=1e-6, reltol=1e-3)
             u0 = np.array([2.0, 0.0]) + 0.05 * rng.standard_normal((N, d))
@@ -475,7 +475,7 @@ def wide_rows(sa, run):
                              forward_ms=st["forward_ms_last"], reverse_ms=ms, sweep_kernel_ms=kms, gradient_ms=st["forward_ms_last"] + ms,
                              trajectories_per_s=N / ((st["forward_ms_last"] + ms) * 1e-3),
                              reference_published_cpu_ms=pub[alg], roofline=dict(bound="latency", note="adaptive steps of one workgroup per trajectory; no bandwidth or flop roofline applies at these sizes",
-                                                                                kernel="k_wide_backsolve_ts5" if alg == "backsolve" else "k_wide_adjoint_ts5")))
+                                                                                kernel="k_wide_backsolve_ts5" if alg == "backsolve" else ("k_wide_adjoint_ts5 + k_wide_quad_gk" if alg == "quadrature" else "k_wide_adjoint_ts5"))))
             eng.close()
     return rows
 
