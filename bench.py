@@ -431,7 +431,7 @@ def wide_rows(sa, run):
     n = R * Cc
     ts = np.linspace(0.0, S * dt, 11)
     fun = sa.WideDeviceFunction.index_affine("bench_idxaff", R, Cc)
-    for N in (1, 512):
+    for N in (1, 512, 2048):
         eng = sa.Engine(fun.name, "interpolating", N, 0.0, S * dt, dt, save_times=ts)
         ms, kms, st = run(eng, rng.standard_normal((N, n)), rng.random(2), rng.standard_normal((N, len(ts), n)), 5)
         by = N * (S + 1) * 16.0 * n + N * len(ts) * 8.0 * n

@@ -299,14 +299,16 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         h->wg.N = h->N; h->wg.S = (int)S; h->wg.M = h->M; h->wg.nck = h->nck; h->wg.t0 = cfg->t0; h->wg.dt = cfg->dt; h->wg.loss_shift = cfg->loss_shift;
         h->wg.loss_kind = cfg->loss_kind; h->wg.no_start = cfg->no_start; h->wg.p_shared = cfg->p_shared;
         if (P.adaptive) {
-            // adaptive Tsit5 (GaussAdjoint): trajectory-major dense records.  max_steps = 0: the capacity is what 2 GiB of records hold, between 64 and 4096
-            // accepted steps per trajectory (no regrow round in this family: a trajectory that needs more reports HIPADJ_ERR_MAXITERS and names max_steps)
+            // adaptive Tsit5: trajectory-major dense records.  max_steps = 0: the capacity is what 8 GiB of records hold (of 288 GB), between 64 and 8192
+            // accepted steps per trajectory (no regrow round in this family — it would cost a stream synchronisation per forward solve: a trajectory that
+            // needs more reports HIPADJ_ERR_MAXITERS and names max_steps)
             h->wide_ts5 = true;
             const long RW = 2 + 5L * n;
-            long cap = cfg->max_steps > 0 ? cfg->max_steps : (2L << 30) / (RW * 8 * h->N);
-            if (cfg->max_steps == 0) cap = cap < 64 ? 64 : (cap > 4096 ? 4096 : cap);
+            long cap = cfg->max_steps > 0 ? cfg->max_steps : (8L << 30) / (RW * 8 * h->N);
+            if (cfg->max_steps == 0) cap = cap < 64 ? 64 : (cap > 8192 ? 8192 : cap);
             h->rec_cap = cap;
             h->wa.t1 = cfg->t1; h->wa.abstol = cfg->abstol; h->wa.reltol = cfg->reltol; h->wa.dt0 = cfg->dt; h->wa.Smax = (int)cap; h->wa.maxit = (int)cap;
+            if (cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->max_steps == 0) h->wa.maxit = HIPADJ_AUTO_MAXITERS;   // no records to hold: only the reference's maxiters bounds the solve
             h->ag.Smax = (int)cap;   // (the overflow message names it)
             if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)h->N * cap * RW));
             else {   // Backsolve keeps no records: y(T) and, checkpointing = true, the forward states at the checkpoint times [N][nck][n]
