@@ -160,3 +160,26 @@ def test_config5_documented_horizon(sa):
     sp = forward(u0 + h * d, p); lp = loss(sp); sp.engine.close()
     sm = forward(u0 - h * d, p); lm = loss(sm); sm.engine.close()
     assert abs(float(np.sum(du0 * d)) - (lp - lm) / (2 * h)) < 2e-5 * abs((lp - lm) / (2 * h)), (float(np.sum(du0 * d)), (lp - lm) / (2 * h))
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE")])
+def test_published_neural_ode_benchmark_4096_trajectories_adaptive(sa, alg, oalg):
+    """bench.py's "AS PUBLISHED" rows at size: the 2-50-2 neural ODE of docs/src/Benchmark.md:62 as a wide runtime model, adaptive Tsit5 at the default
+    tolerances, 4096 trajectories with their own step sequences — every du0 and the reduced dp against the oracle's Tsit5 on all of them."""
+    d, H, T, N = 2, 50, 1.5, 4096
+    ts = np.linspace(0.0, T, 30)
+    rng = np.random.default_rng(11)
+    p = np.concatenate([rng.standard_normal(H * d) * 0.35, np.zeros(H), rng.standard_normal(d * H) * 0.07, np.zeros(d)])
+    u0 = np.array([2.0, 0.0]) + 0.05 * rng.standard_normal((N, d))
+    data = rng.standard_normal((N, len(ts), d))
+    fun = sa.WideDeviceFunction.dense_chain(f"node_at_size_{alg}", (d, H, d), input_power=3)
+    sens = dict(interpolating=sa.InterpolatingAdjoint(), backsolve=sa.BacksolveAdjoint(), gauss=sa.GaussAdjoint(), quadrature=sa.QuadratureAdjoint())[alg]
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), sa.Tsit5(), saveat=ts, sensealg=sens, abstol=1e-6, reltol=1e-3)
+    delta = 2.0 * (sol.u - data)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=delta)
+    out = sol.u
+    sol.engine.close()
+    ref = O.Problem("MLP1", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-6, reltol=1e-3, save_times=ts, loss="COTANGENT", dims=(d, H, 0, 0),
+                    checkpointing=(oalg == "BACKSOLVE"))
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(out, rout) < 1e-8 and rel(du0, rdu0) < 1e-7 and rel(dp, rdp) < 1e-7
