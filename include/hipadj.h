@@ -215,7 +215,7 @@ int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double 
  * Interpolating / Backsolve (checkpoints) / Gauss / QuadratureAdjoint) and adaptive Tsit5 with per-trajectory step control (stepper =
  * HIPADJ_STEPPER_TSIT5_ADAPTIVE, arbitrary loss times; all four sensealgs — Interpolating and Backsolve keep five np-sized rows in LDS,
  * HIPADJ_ERR_UNSUPPORTED naming GaussAdjoint when they do not fit; max_steps = 0 sizes the dense record from an 8 GiB budget, 64 ... 8192 steps);
- * discrete losses; parity-tested against the oracle on the reference's 30 x 50 matrix-state problem (test/Core5/size_handling_adjoint.jl:37-70)
+ * discrete losses and the built-in continuous costs (cont_cost = HIPADJ_CCOST_HALF_SQ_SUM / HIPADJ_CCOST_U1SQ_PLUS_P1); parity-tested against the oracle on the reference's 30 x 50 matrix-state problem (test/Core5/size_handling_adjoint.jl:37-70)
  * and the 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62, with both steppers. */
 int hipadj_wmodel_register(const char *name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
                            const char *f_body, const char *vjp_body, int32_t *model_id);

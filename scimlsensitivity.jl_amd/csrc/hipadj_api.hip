@@ -153,15 +153,16 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
     return HIPADJ_OK;
 }
 
-static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false) {
+static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int cost = 0) {
+    // the reverse kernels of a handle with a built-in continuous cost are instantiated for WideWithCost<UserW, kind> (hipadj_wide.hpp); the forward solve never sees the cost
+    const std::string U = cost ? "hipadj::WideWithCost<hipadj::UserW, " + std::to_string(cost) + ">" : std::string("hipadj::UserW");
     if (ts5) {
-        std::vector<std::string> e = {"hipadj::k_wide_forward_ts5<hipadj::UserW>", alg == HIPADJ_ALG_BACKSOLVE ? std::string("hipadj::k_wide_backsolve_ts5<hipadj::UserW>")
-                                      : std::string("hipadj::k_wide_adjoint_ts5<hipadj::UserW, ") + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : (alg == HIPADJ_ALG_QUADRATURE ? "3>" : "2>"))};
-        if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_gk<hipadj::UserW, " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", true>");
+        std::vector<std::string> e = {"hipadj::k_wide_forward_ts5<hipadj::UserW>", alg == HIPADJ_ALG_BACKSOLVE ? "hipadj::k_wide_backsolve_ts5<" + U + ">"
+                                      : "hipadj::k_wide_adjoint_ts5<" + U + ", " + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : (alg == HIPADJ_ALG_QUADRATURE ? "3>" : "2>"))};
+        if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", true>");
         return e;
     }
-    const std::string U = "hipadj::UserW";
-    std::vector<std::string> e = {"hipadj::k_wide_forward<" + U + ">"};
+    std::vector<std::string> e = {"hipadj::k_wide_forward<hipadj::UserW>"};
     switch (alg) {
     case HIPADJ_ALG_INTERPOLATING: e.push_back("hipadj::k_wide_adjoint<" + U + ", 0>"); break;
     case HIPADJ_ALG_GAUSS: e.push_back("hipadj::k_wide_adjoint<" + U + ", 2>"); break;
@@ -789,7 +790,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     h.cfg = *cfg; h.cfg.save_times = nullptr; h.cfg.checkpoints = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
-    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg, P.adaptive), code, low, err); }
+    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg, P.adaptive, cfg->cont_cost), code, low, err); }
     h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
     h.fused = fused_eligible(cfg, P) ? 1 : 0;
     const UserKernels k = user_kernel_names(&h);
@@ -1027,14 +1028,14 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
 
 // ---- wide runtime models: workgroup-per-trajectory family (hipadj_wide.hpp) ----------------------------------------------------------------
 static int wide_prepare(hipadj_handle* h) {
-    if (user_has_cost(h->cfg.model) || user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no continuous cost / affect");
+    if (user_has_cost(h->cfg.model) || user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no cost / affect text (the built-in continuous costs are selected with cont_cost)");
     if (h->wide_ts5 && (h->cfg.alg == HIPADJ_ALG_INTERPOLATING || h->cfg.alg == HIPADJ_ALG_BACKSOLVE)) {
         const long lds = user_wide_ts5_interp_lds(h->cfg.model, h->cfg.alg == HIPADJ_ALG_BACKSOLVE) * 8;
         if (lds > 160L * 1024)
             HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide model %d: Interpolating- / BacksolveAdjoint on the adaptive solution need %ld KB of LDS (state tiles + scratch + 5 np + the parameter copy), a workgroup has 160 KB — use GaussAdjoint, whose sweep integrates lam only",
                         h->cfg.model, lds / 1024);
     }
-    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5);
+    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5, h->cfg.cont_cost);
     std::vector<char> code; std::map<std::string, std::string> low;
     const int rc = user_compile(h->cfg.model, exprs, code, low, h->err);
     if (rc != HIPADJ_OK) return rc;

@@ -218,6 +218,30 @@ __device__ __forceinline__ void wide_jump(const WideGeom& g, long traj, int s, c
 // the LDS tiles of one sweeping workgroup
 template <class Mo> struct WideTiles { double *y, *ls, *dl, *gp, *ws, *red; };
 
+// Continuous costs g(u, p, t) (src/adjoint_common.jl `accumulate_cost!`, src/derivative_wrappers.jl:1411-1442) of the built-in kinds on a wide model: the kernels are
+// instantiated for WideWithCost<UserW, CC> and every joint-VJP evaluation adds g_u to (df/du)^T lam and, where the parameter part is taken (WP), w g_p to the
+// gradient row — the same two places the lane family's adj_rk4_core / rhs add them.  CC = 1: g = (sum u)^2 / 2 (g_u = sum u in every component, one workgroup
+// sum per evaluation); CC = 2: g = u_1^2 + p_1 (g_u = 2 u_1 e_1, g_p = e_1).  A cost attached to a model as text (HIPADJ_CCOST_MODEL) is a lane-family feature.
+template <class Mo, int CC_> struct WideWithCost : Mo { static constexpr int CC = CC_; };
+template <class Mo, class = void> struct wide_cc { static constexpr int value = 0; };
+template <class Mo> struct wide_cc<Mo, decltype((void)Mo::CC)> { static constexpr int value = Mo::CC; };
+template <class Mo, bool WP>
+__device__ __forceinline__ void wide_cost_add(double* __restrict__ gp, double w, const double (&yv)[WideShape<Mo>::Q], double (&v)[WideShape<Mo>::Q]) {
+    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q, CC = wide_cc<Mo>::value;
+    if constexpr (CC == 1) {
+        (void)gp; (void)w;
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) s += yv[q]; }
+        s = wide_sum_all<T>(s);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) v[q] += s; }
+    } else if constexpr (CC == 2) {
+        if (threadIdx.x == 0) { v[0] += 2.0 * yv[0]; if (WP) gp[0] += w; }    // (after the body's closing barrier; the next evaluation opens with one)
+        if (WP) wide_sync<T>();
+    } else { (void)gp; (void)w; (void)yv; (void)v; }
+}
+
 // one evaluation of the model's joint VJP at stage state yv with stage adjoint lv: publishes both, returns (df/du)^T lv at the owned components
 template <class Mo, bool WP, bool PUBY = true>
 __device__ __forceinline__ void wide_vjp(const WideTiles<Mo>& L, const double* __restrict__ pp, double t, double w, const double (&yv)[WideShape<Mo>::Q],
@@ -231,6 +255,7 @@ __device__ __forceinline__ void wide_vjp(const WideTiles<Mo>& L, const double* _
     wide_sync<T>();
 #pragma unroll
     for (int q = 0; q < Q; ++q) { const int c = tid + q * T; v[q] = c < N ? L.dl[c] : 0.0; }
+    wide_cost_add<Mo, WP>(L.gp, w, yv, v);
 }
 
 // One reverse RK4 step of lam (and, WP, the parameter sums) through [t_k, t_{k+1}] on the common grid: stage states from two knots
@@ -370,6 +395,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve(WideGeom g, const doub
         wide_sync<T>();
 #pragma unroll
         for (int q = 0; q < Q; ++q) { const int c = tid + q * T; F[q] = c < N ? sdu[c] : 0.0; V[q] = c < N ? sdl[c] : 0.0; }
+        wide_cost_add<Mo, true>(L.gp, w, yv, V);
     };
     const double dt = g.dt;
     for (int k = g.S - 1; k >= 0; --k) {
@@ -908,8 +934,14 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve_ts5(WideGeom g, WideAd
         wide_sync<T>();                                               // f and vjp share the model's scratch
         Mo::template vjp<true>(sdl, aug.kc, dacc, -1.0, sls, sy, pp, t, sws, tid);
         wide_sync<T>();
+        {
+            double yv[Q], V[Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; dz[q] = c < N ? -sdl[c] : 0.0; dz[Q + q] = c < N ? sdu[c] : 0.0; }
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; yv[q] = zz[Q + q]; V[q] = c < N ? sdl[c] : 0.0; }
+            wide_cost_add<Mo, true>(aug.kc, -1.0, yv, V);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; dz[q] = -V[q]; dz[Q + q] = c < N ? sdu[c] : 0.0; }
+        }
         if constexpr (W::NACC > 0) {
             wide_block_sum<T, W::NA>(dacc, sred, saccs);
             if (tid < W::NACC) aug.kc[Mo::ACC0 + tid] += saccs[tid];

@@ -198,3 +198,46 @@ def test_adaptive_interpolating_wide_refuses_what_does_not_fit_the_lds(sa, n, wh
     with pytest.raises(Exception, match=where) as ei:
         sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, 1.0), p), u0), sa.Tsit5(), saveat=np.linspace(0, 1, 5), sensealg=sa.InterpolatingAdjoint(), abstol=1e-6, reltol=1e-3)
     assert "GaussAdjoint" in str(ei.value)
+
+
+# ---- continuous costs g(u, p, t) on wide models (the built-in kinds), both steppers, all four sensealgs -----------------------------------------
+@pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("model,kind", [("linear", 2), ("index", 1), ("chain", 1), ("chain", 2)])
+def test_continuous_costs_on_wide_models(sa, stepper, alg, oalg, model, kind):
+    """g = u_1^2 + p_1 (test/Core7/mixed_costs.jl:46-57) and g = (sum u)^2 / 2 (test/Core3/adjoint.jl:913-919) accumulated inside the wide reverse kernels
+    (WideWithCost), mixed with a discrete loss; dense linear map (owned parameters), 12 x 9 matrix state (reduced parameters), a 3-8-3 dense chain (59 parameters)."""
+    rng = np.random.default_rng(31 + kind)
+    T = 1.0
+    if model == "linear":
+        n = 8; fun = sa.WideDeviceFunction.dense_linear(f"cost_lin_{alg}_{stepper}", n); oname, dims = "DENSELIN", (n, 0, 0, 0)     # np = 64: the oracle's cost buffers hold 64 parameters
+        p = (rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)).flatten(order="F")
+    elif model == "index":
+        R, Cc = 12, 9; n = R * Cc; fun = sa.WideDeviceFunction.index_affine(f"cost_idx_{alg}_{stepper}", R, Cc); oname, dims = "IDXAFF", (R, Cc, 0, 0)
+        p = 0.2 * rng.random(2)
+    else:
+        n, H = 3, 8; fun = sa.WideDeviceFunction.dense_chain(f"cost_chain_{kind}_{alg}_{stepper}", (n, H, n), input_power=3); oname, dims = "MLP1", (n, H, 0, 0)   # the oracle's MLP1 cubes its input; np = 59
+        p = np.concatenate([rng.standard_normal(H * n) * 0.4, 0.1 * rng.standard_normal(H), rng.standard_normal(n * H) * 0.3, 0.1 * rng.standard_normal(n)])
+    N = 3
+    u0 = 0.5 * rng.standard_normal((N, n))
+    g = sa.FirstStateSquaredPlusFirstParam() if kind == 2 else sa.HalfSquaredSum()
+    if stepper == "rk4":
+        dt = 0.02; ts = np.linspace(0.0, T, 6); salg = sa.RK4(); kw = dict(dt=dt); okw = dict(stepper="RK4", dt=dt)
+    else:
+        ts = np.array([0.0, 0.21, 0.5, 0.77, 1.0]); salg = sa.Tsit5(); kw = dict(abstol=1e-9, reltol=1e-9); okw = dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
+    sens = sa.QuadratureAdjoint(abstol=1e-11, reltol=1e-11) if alg == "quadrature" else _alg(sa, alg)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), salg, saveat=ts, sensealg=sens, dgdu_discrete=sa.LsqShift(0.3), g=g, **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=sa.LsqShift(0.3), g=g)
+    sol.engine.close()
+    ref = O.Problem(oname, alg=oalg, t0=0.0, t1=T, save_times=ts, loss="LSQ_SHIFT", loss_shift=0.3, dims=dims, checkpointing=(oalg == "BACKSOLVE"),
+                    quad_abstol=1e-11, quad_reltol=1e-11, cont_cost=kind, **okw)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    tol = RTOL if stepper == "rk4" else 1e-7
+    assert rel(du0, rdu0) < tol and rel(dp, rdp) < tol
+
+
+def test_cost_text_on_a_wide_model_is_refused(sa):
+    fun = sa.WideDeviceFunction.dense_linear("cost_text_refused", 12)
+    u0 = np.ones((2, 12)); p = np.zeros(144)
+    with pytest.raises(Exception, match="built-in continuous costs"):
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, 1.0), p), u0), sa.RK4(), dt=0.1, saveat=np.linspace(0, 1, 3), sensealg=sa.InterpolatingAdjoint(), g=sa.ModelCost())
