@@ -65,9 +65,9 @@ def test_planner_answers_for_wide_models(sa):
     rc, msg = check(stepper=1, alg=2, checkpointing=1); assert rc == -6 and "checkpointing" in msg
     rc, msg = check(stepper=1, alg=2, abstol=0.0); assert rc == -1 and "abstol" in msg
     rc, msg = check(alg=4); assert rc == -6 and "GaussKronrod" in msg
-    for alg in (0, 1, 2, 3):     # the built-in continuous costs: WideWithCost<UserW, kind> kernels compile for every sensealg, both steppers
-        assert check(alg=alg, cont_cost=1 + alg % 2, checkpointing=int(alg == 1))[0] == 0
-        assert check(alg=alg, cont_cost=2 - alg % 2, stepper=1, dt=0.0, checkpointing=int(alg == 1))[0] == 0
+    # the built-in continuous costs: WideWithCost<UserW, kind> kernels compile (a sample here; every sensealg x stepper x kind runs on the GPU, test_gpu_wide.py)
+    assert check(alg=0, cont_cost=1)[0] == 0 and check(alg=3, cont_cost=2)[0] == 0
+    assert check(alg=1, cont_cost=2, stepper=1, dt=0.0, checkpointing=1)[0] == 0 and check(alg=2, cont_cost=1, stepper=1, dt=0.0)[0] == 0
     rc, msg = check(cont_cost=3); assert rc == -6 and "built-in continuous costs" in msg
     rc, msg = check(alg=0, checkpointing=1); assert rc == -6 and "checkpointing" in msg
     off = np.array([0.0, 0.333, 1.0])
