@@ -596,7 +596,11 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                                   double* kbase, int kstride, double* __restrict__ arec = nullptr, int* __restrict__ nsteps_adj = nullptr, int SmaxA = 0,
                                   double* kfbase = nullptr, double* lrec = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP, NZ = AdjNZ<Mo, ALG>::value;
-    using KS = typename ts5_select<ts5_in_regs<Mo, NZ>::value && !CK, KRegs<NZ>, const KStore<NZ>>::type;   // CK: the interval re-solve shares the sweep's live range — LDS rows
+#ifndef HIPADJ_TS5_REGS_CK
+#define HIPADJ_TS5_REGS_CK 1   // checkpointing = true: the rows of the sweep AND of the interval re-solve in registers (A/B hook)
+#endif
+    using KS = typename ts5_select<ts5_in_regs<Mo, NZ>::value && (!CK || HIPADJ_TS5_REGS_CK), KRegs<NZ>, const KStore<NZ>>::type;
+    using KSF = typename ts5_select<ts5_in_regs<Mo, NZ>::value && CK && HIPADJ_TS5_REGS_CK, KRegs<N>, const KStore<N>>::type;   // ... of the interval re-solve
     KS K = ts5_make_rows<KS>(kbase, kstride);
     double pv[NP];
 #pragma unroll
@@ -606,7 +610,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     bool ck_overflow = false;
     auto resolve = [&](int j, double dt_hint) {
         constexpr int RW = 2 + 5 * N;
-        const KStore<N> KF{kfbase, kstride};
+        KSF KF = ts5_make_rows<KSF>(kfbase, kstride);
         double uu[N];
 #pragma unroll
         for (int jj = 0; jj < N; ++jj) uu[jj] = ckpt[((long)j * N + jj) * g.Npad + i];
