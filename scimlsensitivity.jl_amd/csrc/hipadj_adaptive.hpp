@@ -520,12 +520,22 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 // cursor into one trajectory's forward dense solution: the step containing t, its coefficients cached in registers.
 // The walk touches only the step end points (one load per visited step: consecutive steps share an end point);
 // the 5 n coefficients are loaded once per step actually used.
-template <class Mo> struct FwdCursor {
+#ifndef HIPADJ_TS5_PREFETCH
+#define HIPADJ_TS5_PREFETCH 0   // A/B hook: 1 = fetch the record below one step ahead into a second register set.  Measured SLOWER twice: round 1 (-2 % .. +7 %)
+                                // and round 3 on the register-resident sweep (Lorenz 10^4: Interpolating 1.83 -> 1.94 ms, Gauss 2.43 -> 2.79; profiles/r3_tsit5_prefetch_ab.log)
+#endif
+template <class Mo, bool PF = (HIPADJ_TS5_PREFETCH != 0)> struct FwdCursor {
     static constexpr int N = Mo::N, RW = 2 + 5 * Mo::N;
     const double* rec; long Npad, i; int ns, sc, lc;
     double ta, tb, c[5][Mo::N];
+    // PF (off by default, see the macro): the reverse sweeps walk downward and the 64 lanes of a wave change records at different step attempts, so most
+    // attempts of the wave wait for SOME lane's 5 n coefficient loads (SQ_WAIT_ANY is a third of the wave cycles, profiles/r3_tsit5_counters.txt).  With PF
+    // the cursor also issues the loads of record s - 1 into a second register set when it arrives on record s.  It did not pay: the extra registers and
+    // the copies cost more than the round trips they hide.
+    // (PF = false: the quadrature lanes, which jump between nodes.)
+    double pc[PF ? 5 : 1][PF ? Mo::N : 1]; int pn;
     HIPADJ_HD void init(const double* r, long np, long ii, int nsteps) {
-        rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; lc = -1;
+        rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; lc = -1; pn = -2;
         ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i];
     }
     // position the cursor on the step containing t by bisection (quadrature lanes start anywhere in [t0, T])
@@ -542,11 +552,33 @@ template <class Mo> struct FwdCursor {
         while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[((long)sc * RW + 1) * Npad + i]; }
         if (sc != lc) {
             lc = sc;
-            const long base = ((long)sc * RW + 2) * Npad + i;
+            bool have = false;
+            if constexpr (PF) {
+                if (sc == pn) {
+                    have = true;
 #pragma unroll
-            for (int m = 0; m < 5; ++m)
+                    for (int m = 0; m < 5; ++m)
 #pragma unroll
-                for (int j = 0; j < N; ++j) c[m][j] = rec[base + (long)(m * N + j) * Npad];
+                        for (int j = 0; j < N; ++j) c[m][j] = pc[m][j];
+                }
+            }
+            if (!have) {
+                const long base = ((long)sc * RW + 2) * Npad + i;
+#pragma unroll
+                for (int m = 0; m < 5; ++m)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) c[m][j] = rec[base + (long)(m * N + j) * Npad];
+            }
+            if constexpr (PF) {
+                if (sc > 0) {          // the record below: issued now, consumed when the cursor gets there
+                    pn = sc - 1;
+                    const long base = ((long)pn * RW + 2) * Npad + i;
+#pragma unroll
+                    for (int m = 0; m < 5; ++m)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) pc[m][j] = rec[base + (long)(m * N + j) * Npad];
+                }
+            }
         }
         poly_eval<N>((t - ta) / (tb - ta), c, y);
     }
@@ -605,7 +637,8 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     double pv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
-    FwdCursor<Mo> cur;
+    FwdCursor<Mo, (HIPADJ_TS5_PREFETCH != 0) && !CK> cur;   // (CK: the sweep's and the re-solve's rows already fill the registers; with the second coefficient set on top one
+                                                          //  kernel — LinDiag, GaussKronrod — came back with the spill placement tests/tools/isa_lint.py flags)
     int icur = g.nck - 2;            // CK: checkpoint interval the cursor's records belong to
     bool ck_overflow = false;
     auto resolve = [&](int j, double dt_hint) {
@@ -845,7 +878,7 @@ HIPADJ_HD void quad_gk_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     double pv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) pv[j] = g.p_shared ? p[j] : p[i * NP + j];
-    FwdCursor<Mo> cf; cf.init(rec, g.Npad, i, nsteps[i] < g.Smax ? nsteps[i] : g.Smax); cf.seek(0.5 * (a + b));
+    FwdCursor<Mo, false> cf; cf.init(rec, g.Npad, i, nsteps[i] < g.Smax ? nsteps[i] : g.Smax); cf.seek(0.5 * (a + b));
     AdjCursor<Mo> ca; ca.init(arec, g.Npad, i, nsteps_adj[i] < g.SmaxA ? nsteps_adj[i] : g.SmaxA, 0.5 * (a + b));
     auto integrand = [&](double t, double (&out)[NP]) {
         double y[N], lam[N];
