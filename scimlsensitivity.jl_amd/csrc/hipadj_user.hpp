@@ -689,7 +689,7 @@ inline int user_wide_threads(int32_t model) {
     return (idx >= 0 && idx < (int)R.models.size()) ? R.models[idx].threads : 0;
 }
 
-// hipadj_wmodel_register: a model for the workgroup-per-trajectory family.  threads = 0 picks the workgroup size: a quarter of max(n, min(np, 4096))
+// hipadj_wmodel_register: a model for the workgroup-per-trajectory family.  threads = 0 picks the workgroup size: max(n / 2, min(np, 4096) / 4)
 // rounded up to whole wavefronts, between 64 (one wavefront per trajectory) and 1024.
 inline int user_register_wide(const char* name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
                               const char* f, const char* vjp, int32_t* id, std::string& err) {
@@ -698,8 +698,10 @@ inline int user_register_wide(const char* name, int32_t n, int32_t np, int32_t t
     if (lds_doubles < 0 || nacc < 0 || nacc > 16 || acc_first < 0 || (nacc > 0 && acc_first + nacc > np)) {
         err = "hipadj_wmodel_register: need lds_doubles >= 0, 0 <= nacc <= 16 and the reduced parameters [acc_first, acc_first + nacc) inside [0, np)"; return HIPADJ_ERR_INVALID_ARG; }
     if (threads == 0) {
-        const int work = n > (np < 4096 ? np : 4096) ? n : (np < 4096 ? np : 4096);
-        threads = ((work + 3) / 4 + 63) / 64 * 64;
+        // two state components per thread (measured on the HBM-bound 30 x 50 matrix state, 512 / 2048 trajectories: 384 threads = 4 components each 0.38 / 0.35 of
+        // the HBM peak, 768 threads 0.45 / 0.49; profiles/r3_wide_threads_sweep.log), or four parameter entries per thread where the parameters dominate
+        const int by_n = ((n + 1) / 2 + 63) / 64 * 64, by_p = (((np < 4096 ? np : 4096) + 3) / 4 + 63) / 64 * 64;
+        threads = by_n > by_p ? by_n : by_p;
         if (threads < 64) threads = 64;
         if (threads > 1024) threads = 1024;
     }
