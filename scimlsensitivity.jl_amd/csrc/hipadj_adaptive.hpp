@@ -110,8 +110,9 @@ template <int NZ> struct KStore {
 // unrolled — six instances of the right-hand side, each stage sum with exactly its terms and literal coefficients, no LDS round trip between a
 // stage and the next.  With 157 lone waves at 10^4 trajectories the adaptive kernels are bound by one wave's instruction stream (2.96 ns per
 // FP64 instruction), so the shorter stream is the whole point; 16 NZ VGPRs are affordable because a lone wave owns its SIMD's 512 registers.
-// Compiled-in models with NZ <= TS5_WIDE only (ts5_in_regs): runtime models keep the LDS rows — their kernels come out of hiprtc per model and
-// the rolled loop is the form that has been through the compiler-defect history of DESIGN.md 6.8.  Same arithmetic, expression for expression
+// Compiled-in models with NZ <= TS5_WIDE only (ts5_in_regs): runtime models keep the LDS rows — their kernels come out of hiprtc per model, the rolled loop is
+// the form that went through the compiler-defect history of DESIGN.md 6.8, and the one attempt to give them the register form (HIPADJ_TS5_REGS_USER, opt-in
+// through the environment variable of the same name) produced a wrong kernel in the GPU suite (hipadj_user.hpp).  Same arithmetic, expression for expression
 // (the padded sums of the LDS form add exact zeros), so step sequences are bit-identical; the host emulator runs this form for the same models.
 template <int NZ> struct KRegs {
     static constexpr bool IN_REGS = true, ROLLED = false;
@@ -148,7 +149,13 @@ template <class A, class C> struct ts5_select<false, A, C> { using type = C; };
 template <class KS> HIPADJ_HD KS ts5_make_rows(double* base, int stride) {
     if constexpr (KS::IN_REGS) { (void)base; (void)stride; return KS(); } else return KS{base, stride};
 }
-template <class Mo, int NZ> struct ts5_in_regs { static constexpr bool value = HIPADJ_TS5_REGS && !ts5_model_is_runtime<Mo>::value && NZ <= HIPADJ_TS5_WIDE; };
+#ifndef HIPADJ_TS5_REGS_USER
+#define HIPADJ_TS5_REGS_USER 0   // runtime models: opt-in experiment (environment variable HIPADJ_TS5_REGS_USER=1, hipadj_user.hpp); off under every compiler
+#endif
+// (runtime models: up to 8 augmented components — at 9 the 4-state ring's kernels fill all 512 registers and start to use scratch)
+template <class Mo, int NZ> struct ts5_in_regs {
+    static constexpr bool value = HIPADJ_TS5_REGS && (ts5_model_is_runtime<Mo>::value ? (HIPADJ_TS5_REGS_USER && NZ <= 8) : NZ <= HIPADJ_TS5_WIDE);
+};
 
 // y = u_start + h sum_j b_j(theta) k_j : the continuous extension of the step held in K (used for the lambda values at the
 // Gauss nodes; the forward solution is stored in monomial form instead, see tsit5_poly)

@@ -460,6 +460,7 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         key = std::to_string(model) + "#" + std::to_string(src.rev);
         for (const auto& e : exprs) key += "|" + e;
         if (const char* fl = std::getenv("HIPADJ_RTC_FLAGS")) key += std::string("|flags:") + fl;   // a debugging run with other flags must not be served from the cache
+        if (const char* e = std::getenv("HIPADJ_TS5_REGS_USER")) key += std::string("|ts5regs:") + e;
         if (const char* e = std::getenv("HIPADJ_USER_COLS")) key += std::string("|cols:") + e;
         if (low_opt) key += "|O1";                          // the second opinion of the heavy-kernel self-test (user_prepare)
         auto it = R.code_cache.find(key);
@@ -485,6 +486,13 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
         if (A.CreateProgram(&prog, tu.c_str(), "hipadj_user_model.hip", NH, hptr, hnames) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return HIPADJ_ERR_HIP; }
         for (const auto& e : exprs) A.AddNameExpression(prog, e.c_str());
         std::vector<std::string> optv = {"--offload-arch=gfx950", (attempt == 0 && !low_opt) ? "-O3" : "-O1", "-std=c++17"};
+        {   // adaptive Tsit5 of runtime models: the stage rows stay lane-private LDS columns.  The register form (hipadj_adaptive.hpp: KRegs) is 20-35 % faster here too
+            // (runtime LV, 10^4 trajectories: Interpolating 0.51 -> 0.40 ms, Backsolve 0.47 -> 0.31; profiles/r3_tsit5_user_regs_ab.log), and every code object passed the
+            // ISA check — but ONE of the suite's kernels came back with wrong parameter gradients (3-state ring, Interpolating, model cost, no tstops: GPU visit 22), the
+            // kind of wrong code DESIGN.md 6.8 is about.  HIPADJ_TS5_REGS_USER=1 opts in for experiments; it is not the default under any compiler.
+            const char* e = std::getenv("HIPADJ_TS5_REGS_USER");
+            optv.push_back((e && e[0] == '1') ? "-DHIPADJ_TS5_REGS_USER=1" : "-DHIPADJ_TS5_REGS_USER=0");
+        }
         if (const char* e = std::getenv("HIPADJ_RTC_FLAGS")) { std::istringstream is(e); std::string w; while (is >> w) optv.push_back(w); }   // tuning / debugging hook
         std::vector<const char*> opts; for (const auto& o : optv) opts.push_back(o.c_str());
         A.enter();

@@ -105,3 +105,34 @@ def test_runtime_checkpointed_fixed_step_kernels_compile_without_a_device(tmp_pa
     assert objs and ("k_interp_ckpt" if alg == "interpolating" else "k_gauss_ckpt") in "".join(isa_lint.disassemble(o) for o in objs)
     for o in objs:
         assert isa_lint.lint(o) == []
+
+
+@pytest.mark.parametrize("regs", ["1", "0", None])
+def test_runtime_tsit5_stage_rows_are_lds_columns_unless_opted_in(tmp_path, monkeypatch, regs):
+    """Adaptive Tsit5 of a runtime-registered lane model: by default (and with HIPADJ_TS5_REGS_USER=0) the stage rows are the lane-private LDS columns of
+    rounds 1-3 (8 x NZ x 64 doubles); HIPADJ_TS5_REGS_USER=1 opts into the register form the compiled-in models use (no LDS) — an experiment: it passes the
+    spill-placement lint and is 20-35 % faster, but one such kernel returned wrong gradients on the GPU (hipadj_user.hpp), so it is never the default."""
+    import re
+    import subprocess
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.LV
+    name = f"lv_ts5_rows_{regs}"
+    _lib.register_model(name, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+    if regs is None:
+        monkeypatch.delenv("HIPADJ_TS5_REGS_USER", raising=False)
+    else:
+        monkeypatch.setenv("HIPADJ_TS5_REGS_USER", regs)
+    cfg = E.make_config(name, "interpolating", 64, 0.0, 2.0, 0.0, [0.5, 1.0, 2.0], loss_kind=0, stepper=1, abstol=1e-8, reltol=1e-8, checkpointing=False)
+    L = _lib.load()
+    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+    objs = glob.glob(str(tmp_path / "*.hsaco"))
+    assert objs
+    lds = None
+    for o in objs:
+        assert isa_lint.lint(o) == []
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", o], capture_output=True, text=True).stdout
+        for mm in re.finditer(r"\.group_segment_fixed_size:\s+(\d+)[\s\S]*?\.name:\s+(\S+)", notes):
+            if "k_adjoint_tsit5" in mm.group(2):
+                lds = int(mm.group(1))
+    assert lds is not None and (lds == 0 if regs == "1" else lds == 8 * 6 * 64 * 8)
