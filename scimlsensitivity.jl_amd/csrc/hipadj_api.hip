@@ -1168,11 +1168,15 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         // -O1 build gave different wrong answers on every run); if neither does, the handle refuses to hand out gradients.
         auto same = [](const std::vector<double>& x, const std::vector<double>& y) { return std::memcmp(x.data(), y.data(), sizeof(double) * x.size()) == 0; };
         std::vector<double> c0(n0), c1(n1); int flag_c = 0;
-        std::swap(h->uf_main, h->uf_main_alt);             // the -O1 build
-        HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
-        TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));
-        TRY(fetch(c0, c1, flag_c));
-        if (same(c0, a0) && same(c1, a1)) {
+        std::swap(h->uf_main, h->uf_main_alt);             // the -O1 build, twice more: three identical results before it is trusted over the -O3 build
+        bool o1_repro = true;
+        for (int rep = 0; rep < 2 && o1_repro; ++rep) {
+            HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+            TRY(user_adjoint_run(h, d_cot, d_du0, d_dp));
+            TRY(fetch(c0, c1, flag_c));
+            o1_repro = same(c0, a0) && same(c1, a1);
+        }
+        if (o1_repro) {
             h->rtc_selftest = 3;                            // ... from here on, and its outputs for this call
             std::fprintf(stderr, "hipadj: the -O3 build of the reverse kernel of runtime model %d disagrees with its -O1 build on the first reverse pass; using the -O1 build (DESIGN.md 6.8)\n", h->cfg.model);
             return HIPADJ_OK;
