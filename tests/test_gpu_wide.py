@@ -241,3 +241,28 @@ def test_cost_text_on_a_wide_model_is_refused(sa):
     u0 = np.ones((2, 12)); p = np.zeros(144)
     with pytest.raises(Exception, match="built-in continuous costs"):
         sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, 1.0), p), u0), sa.RK4(), dt=0.1, saveat=np.linspace(0, 1, 3), sensealg=sa.InterpolatingAdjoint(), g=sa.ModelCost())
+
+
+@pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
+def test_device_gradients_against_independent_scipy_sensitivities(sa, stepper):
+    """Not through the oracle: the HIP path vs tests/golden/wide_models.json (DOP853 forward sensitivities of numpy restatements written from the reference's
+    definitions, make_wide_models.py) — the published neural ODE with Lux's parameter order and the matrix-state problem; rtol 1e-6 (north_star)."""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wide_models.json")) as f:
+        G = json.load(f)
+    g = G["node"]; d, H = g["dims"]; ts = np.asarray(g["ts"]); u0 = np.asarray(g["u0"])[None, :]; p = np.asarray(g["p"])
+    fun = sa.WideDeviceFunction.dense_chain(f"golden_node_{stepper}", (d, H, d), input_power=3)
+    salg, kw = (sa.RK4(), dict(dt=g["T"] / (29 * 32))) if stepper == "rk4" else (sa.Tsit5(), dict(abstol=1e-11, reltol=1e-11))
+    for sens in (sa.InterpolatingAdjoint(), sa.GaussAdjoint(), sa.BacksolveAdjoint(), sa.QuadratureAdjoint(abstol=1e-11, reltol=1e-11)):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, g["T"]), p), u0), salg, saveat=ts, sensealg=sens, **kw)
+        assert rel(sol.u[0], np.asarray(g["out"])) < 1e-8
+        du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=2.0 * (sol.u - np.asarray(g["data"])[None]))
+        sol.engine.close()
+        assert rel(du0[0], g["du0"]) < 1e-6 and rel(dp, g["dp"]) < 1e-6, type(sens).__name__
+    g = G["matrix"]; R, Cc = g["dims"]; ts = np.asarray(g["ts"]); u0 = np.asarray(g["u0"])[None, :]; p = np.asarray(g["p"])
+    fun = sa.WideDeviceFunction.index_affine(f"golden_matrix_{stepper}", R, Cc)
+    salg, kw = (sa.RK4(), dict(dt=0.01)) if stepper == "rk4" else (sa.Tsit5(), dict(abstol=1e-11, reltol=1e-11))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, g["T"]), p), u0), salg, saveat=ts, sensealg=sa.InterpolatingAdjoint(), **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=2.0 * sol.u)
+    sol.engine.close()
+    assert rel(du0[0], g["du0"]) < 1e-6 and rel(dp, g["dp"]) < 1e-6
