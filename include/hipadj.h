@@ -212,8 +212,8 @@ int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double 
  * `wg_sync()` (workgroup barrier between dependent phases, e.g. hidden layers), `wg_sum(x)` (sum of one value per thread over the workgroup,
  * returned to every thread: wavefront shuffles; every thread must call it), `ws[0..lds_doubles)` LDS scratch.  u, lam, du, dlam, ws are
  * LDS, p is global memory.  threads: a multiple of 64 in [64, 1024], 0 = automatic.  Offered: fixed-step RK4 (loss times on the step grid;
- * Interpolating / Backsolve (checkpoints) / Gauss / QuadratureAdjoint) and adaptive Tsit5 with per-trajectory step control (stepper =
- * HIPADJ_STEPPER_TSIT5_ADAPTIVE, arbitrary loss times; all four sensealgs — Interpolating and Backsolve keep five np-sized rows in LDS,
+ * Interpolating / Backsolve (checkpoints) / Gauss / GaussKronrod / QuadratureAdjoint) and adaptive Tsit5 with per-trajectory step control (stepper =
+ * HIPADJ_STEPPER_TSIT5_ADAPTIVE, arbitrary loss times; all four sensealgs and GaussKronrod on both — adaptive Interpolating and Backsolve keep five np-sized rows in LDS,
  * HIPADJ_ERR_UNSUPPORTED naming GaussAdjoint when they do not fit; max_steps = 0 sizes the dense record from an 8 GiB budget, 64 ... 8192 steps);
  * discrete losses and the built-in continuous costs (cont_cost = HIPADJ_CCOST_HALF_SQ_SUM / HIPADJ_CCOST_U1SQ_PLUS_P1); parity-tested against the oracle on the reference's 30 x 50 matrix-state problem (test/Core5/size_handling_adjoint.jl:37-70)
  * and the 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62, with both steppers. */

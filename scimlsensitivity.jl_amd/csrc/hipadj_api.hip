@@ -158,7 +158,7 @@ static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int
     const std::string U = cost ? "hipadj::WideWithCost<hipadj::UserW, " + std::to_string(cost) + ">" : std::string("hipadj::UserW");
     if (ts5) {
         std::vector<std::string> e = {"hipadj::k_wide_forward_ts5<hipadj::UserW>", alg == HIPADJ_ALG_BACKSOLVE ? "hipadj::k_wide_backsolve_ts5<" + U + ">"
-                                      : "hipadj::k_wide_adjoint_ts5<" + U + ", " + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : (alg == HIPADJ_ALG_QUADRATURE ? "3>" : "2>"))};
+                                      : "hipadj::k_wide_adjoint_ts5<" + U + ", " + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : (alg == HIPADJ_ALG_QUADRATURE ? "3>" : (alg == HIPADJ_ALG_GAUSS_KRONROD ? "4>" : "2>")))};
         if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", true>");
         return e;
     }
@@ -166,6 +166,7 @@ static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int
     switch (alg) {
     case HIPADJ_ALG_INTERPOLATING: e.push_back("hipadj::k_wide_adjoint<" + U + ", 0>"); break;
     case HIPADJ_ALG_GAUSS: e.push_back("hipadj::k_wide_adjoint<" + U + ", 2>"); break;
+    case HIPADJ_ALG_GAUSS_KRONROD: e.push_back("hipadj::k_wide_adjoint<" + U + ", 4>"); break;
     case HIPADJ_ALG_BACKSOLVE: e.push_back("hipadj::k_wide_backsolve<" + U + ">"); break;
     case HIPADJ_ALG_QUADRATURE: e.push_back("hipadj::k_wide_quad_adj<" + U + ">"); e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", false>"); break;
     default: break;
@@ -342,7 +343,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             A(dev_alloc(h, &h->d_yT, (size_t)h->N * n));
             if (h->nck > 0) A(dev_alloc(h, &h->d_ckpt, (size_t)h->N * h->nck * n));
         }
-        if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
+        if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) A(dev_alloc(h, &h->d_wscr, (size_t)h->N * 3 * np));   // per trajectory: integrand, Kronrod and Gauss rows of one panel
+        if (cfg->alg == HIPADJ_ALG_QUADRATURE && !P.adaptive) {
             A(dev_alloc(h, &h->d_fadj, (size_t)h->N * S * 4 * n));
             A(dev_alloc(h, &h->d_qres, (size_t)h->N * (h->nq > 0 ? h->nq : 1) * np));
             A(dev_alloc(h, &h->d_wscr, (size_t)h->N * (h->nq > 0 ? h->nq : 1) * (3 + HIPADJ_WIDE_MAXSEG) * np));
@@ -1078,7 +1080,8 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     } else if (h->wide_ts5) {
         const bool quad = h->cfg.alg == HIPADJ_ALG_QUADRATURE;
         TRY(usig<decltype(&k_wide_adjoint_ts5<WideProbe, 2>)>::launch(h, h->uf_main, grid, blk, h->wg, h->wa, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_save_t,
-                    (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag, quad ? h->d_arec : (double*)nullptr, quad ? h->d_nsteps_adj : (int*)nullptr, quad ? h->SmaxA : 0));
+                    (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag, quad ? h->d_arec : (double*)nullptr, quad ? h->d_nsteps_adj : (int*)nullptr, quad ? h->SmaxA : 0,
+                    h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD ? h->d_wscr : (double*)nullptr));
         if (quad) {
             if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
@@ -1090,8 +1093,9 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         }
     } else
     switch (h->cfg.alg) {
-    case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS:
-        TRY(usig<decltype(&k_wide_adjoint<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, rows, h->d_flag));
+    case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:
+        TRY(usig<decltype(&k_wide_adjoint<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, rows, h->d_flag,
+                    h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD ? h->d_wscr : (double*)nullptr));
         break;
     case HIPADJ_ALG_BACKSOLVE:
         TRY(usig<decltype(&k_wide_backsolve<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_yT, (const double*)(h->nck > 0 ? h->d_ckpt : nullptr),

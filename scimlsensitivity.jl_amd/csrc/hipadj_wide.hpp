@@ -312,14 +312,74 @@ __device__ __forceinline__ void wide_finish(const WideGeom& g, long traj, const 
     if (bad) atomicOr(flag, 1);
 }
 
+// GaussKronrodAdjoint's quadrature of one step (IntegratingGKSumCallback [upstream-recall], the lane family's restatement, hipadj_lane.hpp / hipadj_adaptive.hpp):
+// an adaptive (7,15) Gauss-Kronrod rule on [a0, b0] (in the caller's coordinate: theta on the fixed step, time on the adaptive one), halved — left half
+// first — while ||Kronrod - Gauss||_2 over the np entries exceeds 1e-7 (depth <= 12), with workgroup-uniform decisions.  node(s, part) evaluates the
+// integrand (df/dp)^T lam (+ g_p) at coordinate s into fi[0..np) and the per-thread partials of the reduced parameters; an accepted panel adds
+// sgn * fac(h) * Kronrod sum to the gradient row.  rows: three np-vectors of scratch (fi may be LDS).
+template <class Mo, class Node, class Fac>
+__device__ __forceinline__ void wide_gk_panels(const WideTiles<Mo>& L, double* __restrict__ fi, double* __restrict__ IK, double* __restrict__ IG, double* __restrict__ sn /* LDS [1] */,
+                                               double* __restrict__ sacc /* LDS [2 NA] */, double a0, double b0, double sgn, Fac&& fac, Node&& node) {
+    using W = WideShape<Mo>;
+    constexpr int NP = W::NP, T = W::T, GKD = 12;
+    const int tid = threadIdx.x;
+    double pa[GKD + 2], pb[GKD + 2]; int pd[GKD + 2]; int sp = 1;
+    pa[0] = a0; pb[0] = b0; pd[0] = 0;
+#pragma unroll 1
+    while (sp > 0) {
+        --sp;
+        const double a = pa[sp], b = pb[sp]; const int d = pd[sp];
+        const double c = 0.5 * (a + b), h = 0.5 * (b - a);
+        double ak[W::NA], ag[W::NA], part[W::NA];
+#pragma unroll
+        for (int q = 0; q < W::NA; ++q) { ak[q] = 0.0; ag[q] = 0.0; }
+        for (int j = tid; j < NP; j += T) { IK[j] = 0.0; IG[j] = 0.0; }
+#pragma unroll 1
+        for (int jn = 0; jn < 15; ++jn) {
+            const int q = jn < 7 ? jn : (jn == 7 ? 7 : 14 - jn);
+            const double x = jn < 7 ? -cw_gk_x[q] : (jn == 7 ? 0.0 : cw_gk_x[q]);
+            const double wk = cw_gk_wk[q], wg = (q & 1) ? cw_gk_wg[q >> 1] : 0.0;
+            node(c + h * x, part);
+            for (int j = tid; j < NP; j += T) { const double f = fi[j]; IK[j] += wk * f; IG[j] += wg * f; }
+#pragma unroll
+            for (int qq = 0; qq < W::NA; ++qq) { ak[qq] += wk * part[qq]; ag[qq] += wg * part[qq]; }
+            wide_sync<T>();                                              // fi is zeroed again by the next node
+        }
+        if constexpr (W::NACC > 0) {
+            double both[2 * W::NA];
+#pragma unroll
+            for (int q = 0; q < W::NA; ++q) { both[q] = ak[q]; both[W::NA + q] = ag[q]; }
+            wide_block_sum<T, 2 * W::NA>(both, L.red, sacc);
+            if (tid < W::NACC) { IK[Mo::ACC0 + tid] += sacc[tid]; IG[Mo::ACC0 + tid] += sacc[W::NA + tid]; }
+            wide_sync<T>();
+        }
+        const double f = fac(h);
+        double e2[1] = {0.0};
+        for (int j = tid; j < NP; j += T) { const double dd = (IK[j] - IG[j]) * f; e2[0] += dd * dd; }
+        wide_block_sum<T, 1>(e2, L.red, sn);
+        const double E = sqrt(sn[0]);
+        if (E <= 1e-7 || d >= GKD) {
+            for (int j = tid; j < NP; j += T) L.gp[j] += sgn * f * IK[j];
+            wide_sync<T>();
+        } else {
+            pa[sp] = c; pb[sp] = b; pd[sp] = d + 1; ++sp;      // right half: after the left one
+            pa[sp] = a; pb[sp] = c; pd[sp] = d + 1; ++sp;
+            wide_sync<T>();
+        }
+    }
+}
+
 // ---- InterpolatingAdjoint (ALG = 0) and GaussAdjoint (ALG = 2): one sweep; Gauss integrates lam only and adds the 2-node Gauss-Legendre sum of
 // f_p^T lam per step with lam from the adjoint step's own Hermite interpolant (IntegratingSumCallback [upstream-recall], src/gauss_adjoint.jl:809-851)
 template <class Mo, int ALG>
 __global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
-                                                        const int* __restrict__ save_of_knot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+                                                        const int* __restrict__ save_of_knot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
+                                                        double* __restrict__ gk_scratch) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
-    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    static_assert(ALG == 0 || ALG == 2 || ALG == 4, "Interpolating, Gauss (2-node rule per step), GaussKronrod (adaptive (7,15) rule per step)");
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * (ALG == 4 ? 2 * W::NA : W::NA) + 2], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    __shared__ double sgk[ALG == 4 ? 2 * W::NA + 1 : 1];
     const long traj = blockIdx.x;
     const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
@@ -346,6 +406,25 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double
             for (int q = 0; q < Q; ++q) h0[q] = lam[q];
             wide_rk4_step<Mo, false>(L, pp, t_lo, dt, hi, lo, lam, dacc, v1);
             wide_vjp<Mo, false>(L, pp, t_lo, 0.0, lo.u, lam, dacc, v5);     // fsallast: (df/du)^T lam_new at u_k
+            if constexpr (ALG == 4) {
+                // panels in theta (0 at t_{k+1}, 1 at t_k); time runs backward: the integral over a panel of half-width hh is dt * hh * sum w W
+                double* rows = gk_scratch + traj * 3L * NP;
+                WideTiles<Mo> LF = L; LF.gp = rows;                         // the integrand row
+                auto node = [&](double th, double (&part)[W::NA]) {
+                    const double tf = 1.0 - th;
+                    double gl[Q], yv[Q], dd[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        gl[q] = (1.0 - th) * h0[q] + th * lam[q] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lam[q] - h0[q]) + (th - 1.0) * (-dt) * (-v1[q]) + th * (-dt) * (-v5[q]));
+                        yv[q] = (1.0 - tf) * lo.u[q] + tf * hi.u[q] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (hi.u[q] - lo.u[q]) + (tf - 1.0) * dt * lo.f[q] + tf * dt * hi.f[q]);
+                    }
+                    for (int j = threadIdx.x; j < NP; j += T) rows[j] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < W::NA; ++q) part[q] = 0.0;
+                    wide_vjp<Mo, true>(LF, pp, t_lo + tf * dt, 1.0, yv, gl, part, dd);
+                };
+                wide_gk_panels<Mo>(L, rows, rows + NP, rows + 2 * NP, sgk + 2 * W::NA, sgk, 0.0, 1.0, 1.0, [dt](double hh) { return dt * hh; }, node);
+            } else {
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
@@ -357,6 +436,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double
                     yv[q] = (1.0 - tf) * lo.u[q] + tf * hi.u[q] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (hi.u[q] - lo.u[q]) + (tf - 1.0) * dt * lo.f[q] + tf * dt * hi.f[q]);
                 }
                 wide_vjp<Mo, true>(L, pp, t_lo + tf * dt, 0.5 * dt, yv, gl, acc, dd);
+            }
             }
         }
         { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) wide_jump<Mo>(g, traj, s, cot, lo.u, lam); }
@@ -806,13 +886,13 @@ template <class Mo, int ALG>
 __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdapt a, const double* __restrict__ p, const double* __restrict__ rec, const int* __restrict__ nsteps,
                                                             const double* __restrict__ save_t, const double* __restrict__ tstops_desc, const double* __restrict__ cot,
                                                             double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
-                                                            double* __restrict__ arec, int* __restrict__ nsteps_adj, int SmaxA) {
+                                                            double* __restrict__ arec, int* __restrict__ nsteps_adj, int SmaxA, double* __restrict__ gk_scratch) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q, RW = 2 + 5 * N;
-    static_assert(ALG == 0 || ALG == 2 || ALG == 3, "the adaptive sweeps of the workgroup family: Interpolating-, Gauss- and QuadratureAdjoint (pass 1: lam only, recorded densely)");
+    static_assert(ALG == 0 || ALG == 2 || ALG == 3 || ALG == 4, "the adaptive sweeps of the workgroup family: Interpolating-, Gauss-, GaussKronrod- and QuadratureAdjoint (pass 1: lam only, recorded densely)");
     static_assert(ALG != 0 || W::GP_LDS, "InterpolatingAdjoint on the adaptive solution keeps five parameter-sized rows in LDS (the planner checks the budget)");
     __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
-    __shared__ double srows[ALG == 0 ? 4 * NP : 1], saccs[W::NA];
+    __shared__ double srows[ALG == 0 ? 4 * NP : 1], saccs[W::NA], sgk[ALG == 4 ? 2 * W::NA + 1 : 1], sred4[ALG == 4 ? (T / 64) * 2 * W::NA + 2 : 1];
     const long traj = blockIdx.x;
     const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};   // gp: Gauss' accumulator; Interpolating's mu
@@ -862,6 +942,22 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
                     for (int q = 0; q < Q; ++q) { const int comp = threadIdx.x + q * T; if (comp < N) r[2 + m * N + comp] = c[m][q]; }
             } else aoverflow = true;
             ++sa;
+        }
+        if (ALG == 4 && t != tprev) {   // GaussKronrodAdjoint: panels in time over [tprev, t] (t < tprev: the half-width is negative, as in adjoint_tsit5_lane)
+            const double hstep = t - tprev;
+            double* rows = gk_scratch + traj * 3L * NP;
+            WideTiles<Mo> LF = L; LF.gp = rows; LF.red = sred4;
+            WideTiles<Mo> LR = L; LR.red = sred4;
+            auto node = [&](double tt, double (&part)[W::NA]) {
+                double y[Q], lamq[Q], dd[Q];
+                kstore_interp<Q, Q>(KK, (tt - tprev) / hstep, hstep, lamq);
+                cur.eval(tt, y);
+                for (int j = threadIdx.x; j < NP; j += T) rows[j] = 0.0;
+#pragma unroll
+                for (int q = 0; q < W::NA; ++q) part[q] = 0.0;
+                wide_vjp<Mo, true>(LF, pp, tt, 1.0, y, lamq, part, dd);
+            };
+            wide_gk_panels<Mo>(LR, rows, rows + NP, rows + 2 * NP, sgk + 2 * W::NA, sgk, tprev, t, -1.0, [](double hh) { return hh; }, node);
         }
         if (ALG == 2 && t != tprev) {
             const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;

@@ -266,3 +266,40 @@ def test_device_gradients_against_independent_scipy_sensitivities(sa, stepper):
     du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=2.0 * sol.u)
     sol.engine.close()
     assert rel(du0[0], g["du0"]) < 1e-6 and rel(dp, g["dp"]) < 1e-6
+
+
+# ---- GaussKronrodAdjoint on wide models: the step's quadrature is an adaptive (7,15) rule (wide_gk_panels), both steppers ----------------------------
+@pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
+@pytest.mark.parametrize("model,cost", [("linear", 0), ("index", 0), ("chain", 0), ("chain", 1), ("linear", 2)])
+def test_gauss_kronrod_on_wide_models(sa, stepper, model, cost):
+    """vs the oracle's GAUSS_KRONROD (its buffers hold np <= 64: an 8-state dense linear map, the 12 x 9 matrix state, a 3-8-3 chain); also close to GaussAdjoint,
+    from which it differs by the quadrature rule's error only."""
+    rng = np.random.default_rng(77 + cost)
+    T = 1.0
+    if model == "linear":
+        n = 8; fun = sa.WideDeviceFunction.dense_linear(f"gk_lin_{stepper}_{cost}", n); oname, dims = "DENSELIN", (n, 0, 0, 0)
+        p = (rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)).flatten(order="F")
+    elif model == "index":
+        R, Cc = 12, 9; n = R * Cc; fun = sa.WideDeviceFunction.index_affine(f"gk_idx_{stepper}_{cost}", R, Cc); oname, dims = "IDXAFF", (R, Cc, 0, 0)
+        p = 0.2 * rng.random(2)
+    else:
+        n, H = 3, 8; fun = sa.WideDeviceFunction.dense_chain(f"gk_chain_{stepper}_{cost}", (n, H, n), input_power=3); oname, dims = "MLP1", (n, H, 0, 0)
+        p = np.concatenate([rng.standard_normal(H * n) * 0.4, 0.1 * rng.standard_normal(H), rng.standard_normal(n * H) * 0.3, 0.1 * rng.standard_normal(n)])
+    N = 3
+    u0 = 0.5 * rng.standard_normal((N, n))
+    g = {0: None, 1: sa.HalfSquaredSum(), 2: sa.FirstStateSquaredPlusFirstParam()}[cost]
+    skw = dict(g=g) if g is not None else {}
+    if stepper == "rk4":
+        dt = 0.02; ts = np.linspace(0.0, T, 6); salg = sa.RK4(); kw = dict(dt=dt); okw = dict(stepper="RK4", dt=dt)
+    else:
+        ts = np.array([0.0, 0.21, 0.5, 0.77, 1.0]); salg = sa.Tsit5(); kw = dict(abstol=1e-9, reltol=1e-9); okw = dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
+    res = {}
+    for name, sens in (("gk", sa.GaussKronrodAdjoint()), ("gauss", sa.GaussAdjoint())):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), salg, saveat=ts, sensealg=sens, dgdu_discrete=sa.LsqShift(0.3), **skw, **kw)
+        res[name] = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=sa.LsqShift(0.3), **skw)
+        sol.engine.close()
+    ref = O.Problem(oname, alg="GAUSS_KRONROD", t0=0.0, t1=T, save_times=ts, loss="LSQ_SHIFT", loss_shift=0.3, dims=dims, cont_cost=cost, **okw)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+    tol = RTOL if stepper == "rk4" else 1e-7
+    assert rel(res["gk"][0], rdu0) < tol and rel(res["gk"][1], rdp) < tol
+    assert rel(res["gk"][1], res["gauss"][1]) < 1e-5
