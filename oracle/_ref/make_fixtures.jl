@@ -121,6 +121,36 @@ let
     end
 end
 
+# (7) the reference's published benchmark problem (docs/src/Benchmark.md:62-80) in Float64: Chain(x -> x.^3, Dense(2, 50, tanh), Dense(50, 2)) written with plain
+#     matrices in Lux's flat parameter order (layer_2.weight 50 x 2 column-major, layer_2.bias, layer_3.weight 2 x 50, layer_3.bias) — what the wide runtime
+#     model `dense_chain((2, 50, 2); input_power = 3)` and the oracle's MLP1 restate; Tsit5 at the default tolerances, 30 loss times, every sensealg.
+let
+    d, H = 2, 50
+    rng_p = [0.35 * sin(0.37 * i + 0.11 * i^2) for i in 1:(H * d)]; b1 = [0.05 * cos(1.3 * i) for i in 1:H]
+    w2 = [0.07 * sin(0.53 * i + 0.07 * i^2) for i in 1:(d * H)]; b2 = [0.05 * cos(2.1 * i) for i in 1:d]
+    p = vcat(rng_p, b1, w2, b2)
+    function node!(du, u, p, t)
+        W1 = reshape(view(p, 1:(H * d)), H, d); bb1 = view(p, (H * d + 1):(H * d + H))
+        W2 = reshape(view(p, (H * d + H + 1):(H * d + H + d * H)), d, H); bb2 = view(p, (H * d + H + d * H + 1):(H * d + H + d * H + d))
+        du .= W2 * tanh.(W1 * (u .^ 3) .+ bb1) .+ bb2
+        nothing
+    end
+    u0 = [2.0, 0.0]; tspan = (0.0, 1.5); ts = collect(range(tspan[1], tspan[2], length = 30))
+    data = [[cos(0.9 * i + j) for j in 1:d] for i in 1:length(ts)]
+    dgnode(out, u, p, t, i) = (out .= 2.0 .* (u .- data[i]))          # loss = sum(abs2, pred - data)
+    prob = ODEProblem(node!, u0, tspan, p)
+    for (nm, sa, ck) in (("INTERPOLATING", InterpolatingAdjoint(autojacvec = ReverseDiffVJP()), false), ("BACKSOLVE", BacksolveAdjoint(autojacvec = ReverseDiffVJP()), true),
+                         ("GAUSS", GaussAdjoint(autojacvec = ReverseDiffVJP()), false), ("QUADRATURE", QuadratureAdjoint(autojacvec = ReverseDiffVJP()), false))
+        sol = ck ? solve(prob, Tsit5(); saveat = ts, abstol = 1e-6, reltol = 1e-3) : solve(prob, Tsit5(); abstol = 1e-6, reltol = 1e-3)
+        du0, dp = adjoint_sensitivities(sol, Tsit5(); t = ts, dgdu_discrete = dgnode, sensealg = sa, abstol = 1e-6, reltol = 1e-3)
+        out = sol(ts)
+        push!(cases, Dict("name" => "node_2_50_2_tsit5_$nm", "kind" => "wide_node", "model" => "MLP1", "dims" => [d, H, 0, 0], "alg" => nm, "checkpointing" => ck,
+                          "stepper" => "TSIT5", "tspan" => collect(tspan), "abstol" => 1e-6, "reltol" => 1e-3, "ts" => ts, "u0" => u0, "p" => p, "data" => data,
+                          "du0" => collect(du0), "dp" => vec(collect(dp)), "out" => [collect(out[:, i]) for i in 1:length(ts)], "forward_steps" => length(sol.t) - 1,
+                          "targets" => "the published benchmark problem end to end: Lux's flat parameter order, Tsit5 step sequence at the default tolerances, every sensealg's gradient"))
+    end
+end
+
 open(joinpath(@__DIR__, "..", "..", "tests", "golden", "reference_fixtures.json"), "w") do io
     JSON.print(io, Dict("generator" => "oracle/_ref/make_fixtures.jl", "SciMLSensitivity" => string(pkgversion(SciMLSensitivity)),
                         "OrdinaryDiffEq" => string(pkgversion(OrdinaryDiffEq)), "julia" => string(VERSION), "cases" => cases), 1)

@@ -14,6 +14,7 @@ ALL = json.load(open(PATH))["cases"] if os.path.exists(PATH) else []
 CASES = [c for c in ALL if c.get("kind", "plain") == "plain"]
 MM_CASES = [c for c in ALL if c.get("kind") == "mass_matrix"]
 EVENT_CASES = [c for c in ALL if c.get("kind") == "event"]
+NODE_CASES = [c for c in ALL if c.get("kind") == "wide_node"]
 
 
 def rel(a, b):
@@ -66,3 +67,19 @@ def test_oracle_event_chain_matches_the_reference(case):
     out, du0, dp = oracle_chain(case["affect"], case["event_times"], ts, case["tspan"][1], u0, p, delta, case["alg"], okw, True)
     assert rel(out[0], np.asarray(case["out"])) < 1e-7, "value saved at the event time: " + case["targets"]
     assert rel(du0[0], case["du0"]) < 1e-6 and rel(dp, case["dp"]) < 1e-6, case["targets"]
+
+
+@pytest.mark.skipif(not NODE_CASES, reason="tests/golden/reference_fixtures.json absent: run oracle/_ref/make_fixtures.jl with Julia (parity unpinned)")
+@pytest.mark.parametrize("case", NODE_CASES, ids=[c["name"] for c in NODE_CASES])
+def test_oracle_published_neural_ode_matches_the_reference(case):
+    """make_fixtures.jl (7): the reference's benchmark problem — the oracle's MLP1 (and with it the wide runtime model, tests/test_gpu_wide.py) against the
+    reference's own Tsit5 step count, sol(ts) and gradients."""
+    ts = np.asarray(case["ts"]); data = np.asarray(case["data"])
+    pr = O.Problem("MLP1", alg=case["alg"], stepper="TSIT5", t0=case["tspan"][0], t1=case["tspan"][1], dt=0.0, abstol=case["abstol"], reltol=case["reltol"],
+                   save_times=ts, loss="COTANGENT", dims=tuple(case["dims"]), checkpointing=case["checkpointing"])
+    u0 = np.asarray(case["u0"])[None, :]; p = np.asarray(case["p"])
+    out, nsteps = pr.forward(u0[0], p)
+    assert nsteps == case["forward_steps"], f"step sequence differs: {case['targets']}"
+    assert rel(out, case["out"]) < 1e-9
+    du0, dp, _, _ = pr.adjoint_ensemble(u0, p, (2.0 * (np.asarray(case["out"]) - data))[None])
+    assert rel(du0[0], case["du0"]) < 1e-6 and rel(dp, case["dp"]) < 1e-6
