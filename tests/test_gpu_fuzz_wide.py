@@ -1,4 +1,4 @@
-"""Randomised differential test of the workgroup-per-trajectory family (`-m gpu`): model x stepper x sensealg x loss form x loss-time pattern x
+"""Randomised differential test of the workgroup-per-trajectory family (`-m gpu`): model x stepper x sensealg (the four + GaussKronrod) x loss form x loss-time pattern x
 parameter sharing x continuous cost x no_start, device through the C ABI vs the CPU oracle on the same seeded inputs.
 
 The patterns aim at the edges of the callback / tstop logic the two steppers restate: no loss time at all (only a continuous cost drives the
@@ -11,7 +11,7 @@ import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE")]
+ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE"), ("gausskronrod", "GAUSS_KRONROD")]
 _reg = {}
 
 
@@ -26,12 +26,12 @@ def _model(sa, which):
     return _reg[which]
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(60))
 def test_random_wide_configurations(sa, seed):
     rng = np.random.default_rng(9100 + seed)
     which = ["linear", "index", "chain"][int(rng.integers(3))]
     fun, oname, dims, n, npar = _model(sa, which)
-    alg, oalg = ALGS[int(rng.integers(4))]
+    alg, oalg = ALGS[int(rng.integers(5))]
     adaptive = bool(rng.random() < 0.5)
     T = 1.0
     N = int(rng.choice([1, 2, 5]))
@@ -58,7 +58,7 @@ def test_random_wide_configurations(sa, seed):
     u0 = 0.6 * rng.standard_normal((N, n))
     g = {0: None, 1: sa.HalfSquaredSum(), 2: sa.FirstStateSquaredPlusFirstParam()}[cost]
     sens = {"interpolating": sa.InterpolatingAdjoint(), "backsolve": sa.BacksolveAdjoint(checkpointing=bool(rng.random() < 0.5)), "gauss": sa.GaussAdjoint(),
-            "quadrature": sa.QuadratureAdjoint(abstol=1e-11, reltol=1e-11)}[alg]
+            "quadrature": sa.QuadratureAdjoint(abstol=1e-11, reltol=1e-11), "gausskronrod": sa.GaussKronrodAdjoint()}[alg]
     if adaptive:
         salg, kw, okw = sa.Tsit5(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="TSIT5", dt=0.0, abstol=1e-9, reltol=1e-9)
     else:
