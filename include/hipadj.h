@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 106 /* 0.1.4: + hipadj_wmodel_register (wide runtime models), hipadj_comm_count / _selfcheck, hipadj_stats.launches_per_pass; 0.1.3: + hipadj_runtime_compiler; 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
+#define HIPADJ_VERSION 106 /* 0.1.4: + hipadj_wmodel_register (wide runtime models: fixed-step RK4 and adaptive Tsit5, the four sensealgs + GaussKronrod, built-in continuous costs), hipadj_comm_count / _selfcheck, hipadj_stats.launches_per_pass; 0.1.3: + hipadj_runtime_compiler; 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
 
 typedef enum {
     HIPADJ_OK = 0,
