@@ -706,8 +706,10 @@ static __global__ void k_wide_reduce_dp(long N, int NP, const double* __restrict
 // the stage loop) and the controller's norms summed over the workgroup (WideNorm).  Every thread carries the same t, dt and error estimate, so
 // the control flow is uniform across the workgroup: no divergence inside a trajectory, and each trajectory takes its own step sequence.
 // Dense forward solution: trajectory-major records [N][Smax][2 + 5 n] = (t_start, t_end, c0..c4) in monomial form, as in the lane family.
-// Offered: the forward solve, GaussAdjoint (lam only; f_p^T lam by the 3-node Gauss-Legendre sum of IntegratingSumCallback on every accepted step)
-// and InterpolatingAdjoint (z = [lam; mu]; the mu part needs only two weighted sums of the stage values, see k_wide_adjoint_ts5).
+// Offered: the forward solve (k_wide_forward_ts5) and every sensealg — GaussAdjoint (lam only; f_p^T lam by the 3-node Gauss-Legendre sum of
+// IntegratingSumCallback on every accepted step), GaussKronrodAdjoint (the adaptive (7,15) rule instead, wide_gk_panels), InterpolatingAdjoint and
+// BacksolveAdjoint (z = [lam; mu(; y)]; the mu part needs only two weighted sums of the stage values, WideAugNorm), QuadratureAdjoint (dense adjoint
+// record + k_wide_quad_gk over record cursors).
 struct WideAdapt {
     double t1, abstol, reltol, dt0;
     int Smax, maxit, ntstops, pad;
@@ -881,7 +883,9 @@ __global__ void __launch_bounds__(Mo::T) k_wide_forward_ts5(WideGeom g, WideAdap
 // ALG = 0 InterpolatingAdjoint: z = [lam; mu] with mu' = -(df/dp)^T lam.  mu never feeds a stage state, so its seven stage values W_j are not kept: the
 // step needs only  inc = sum_j b_j W_j  (the new mu) and  est = sum_j btilde_j W_j  (mu's share of the error estimate), accumulated stage by stage in the
 // tableau's order — the same sums, term for term, that tsit5_integrate forms for a lane's mu components.  Rows in LDS: mu, inc, est, the stage value W
-// (written by the model's vjp with weight 1 into a zeroed row; reduced parameters are summed over the workgroup per stage) and W of the FSAL stage.
+// (written by the model's vjp with weight -1 into a zeroed row; reduced parameters are summed over the workgroup per stage) and the stage value of k_1 (WideAugNorm).
+// ALG = 3 QuadratureAdjoint pass 1: z = lam, every accepted step recorded in monomial form for k_wide_quad_gk<., ., true>.  ALG = 4 GaussKronrodAdjoint: as
+// Gauss with the adaptive (7,15) rule of wide_gk_panels on every accepted step.
 template <class Mo, int ALG>
 __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdapt a, const double* __restrict__ p, const double* __restrict__ rec, const int* __restrict__ nsteps,
                                                             const double* __restrict__ save_t, const double* __restrict__ tstops_desc, const double* __restrict__ cot,
