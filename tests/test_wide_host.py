@@ -84,3 +84,39 @@ def test_dense_chain_emitter_matches_its_golden_text(sa):
     for key, g in gold.items():
         m = sa.WideDeviceFunction.dense_chain("regold_" + key, g["widths"], input_power=g["input_power"])
         assert m.np == g["np"] and m.source["f"] == g["f"] and m.source["vjp"] == g["vjp"], key
+
+
+def test_kernel_choice_of_the_wide_family(sa, tmp_path, monkeypatch):
+    """Which kernels a wide handle instantiates, read off the name expressions of the dumped translation units (no device needed): the forward solve never
+    sees a cost; the reverse kernels of a handle with a built-in cost are instantiated for WideWithCost<UserW, kind>; stepper and sensealg pick the sweep."""
+    import glob
+    from scimlsensitivity_jl_amd import _lib
+    L = sa.load_library()
+    fun = sa.WideDeviceFunction.dense_linear("t_choice", 8)
+    ts = np.linspace(0.0, 1.0, 6)
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+
+    def names(**kw):
+        c = _lib.HipadjConfig()
+        c.struct_size = C.sizeof(_lib.HipadjConfig)
+        c.model, c.alg, c.stepper, c.ntraj, c.t0, c.t1, c.dt = fun.id, 0, 0, 3, 0.0, 1.0, 0.02
+        c.nsave, c.save_times = len(ts), ts.ctypes.data_as(C.POINTER(C.c_double))
+        c.p_shared, c.abstol, c.reltol = 1, 1e-6, 1e-3
+        for k, v in kw.items():
+            setattr(c, k, v)
+        before = set(glob.glob(str(tmp_path / "*.hip")))
+        assert L.hipadj_model_check_config(C.byref(c)) == 0, L.hipadj_last_error(None)
+        new = sorted(set(glob.glob(str(tmp_path / "*.hip"))) - before)
+        assert new, "served from the code cache: every configuration here must be a new one"
+        return open(new[-1]).read().split("hipadj_name_expressions")[-1]
+
+    e = names(alg=0)
+    assert "k_wide_forward<hipadj::UserW>" in e and "k_wide_adjoint<hipadj::UserW, 0>" in e
+    e = names(alg=4, cont_cost=1)
+    assert "k_wide_forward<hipadj::UserW>" in e and "k_wide_adjoint<hipadj::WideWithCost<hipadj::UserW, 1>, 4>" in e
+    e = names(alg=3, stepper=1, dt=0.0)
+    assert "k_wide_forward_ts5<hipadj::UserW>" in e and "k_wide_adjoint_ts5<hipadj::UserW, 3>" in e and "k_wide_quad_gk<hipadj::UserW, 32, true>" in e
+    e = names(alg=1, stepper=1, dt=0.0, checkpointing=1, cont_cost=2)
+    assert "k_wide_forward_ts5<hipadj::UserW>" in e and "k_wide_backsolve_ts5<hipadj::WideWithCost<hipadj::UserW, 2>>" in e
+    e = names(alg=3, cont_cost=2)
+    assert "k_wide_quad_adj<hipadj::WideWithCost<hipadj::UserW, 2>>" in e and "k_wide_quad_gk<hipadj::WideWithCost<hipadj::UserW, 2>, 32, false>" in e
