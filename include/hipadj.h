@@ -138,7 +138,8 @@ typedef struct {
     double vjp_steps;                 /* N * S * 4 per adjoint call (src/derivative_wrappers.jl:256 equivalents) */
     double workspace_bytes;
     int32_t launches_per_pass;        /* kernel launches of one reverse pass as configured: 1 = the sweep kernel finishes the pass itself (composition tree
-                                         and dp reduction in-launch, csrc/hipadj_fused.hpp), 3 = sweep + composition + reduction, 0 = other sequences */
+                                         and dp reduction in-launch, csrc/hipadj_fused.hpp), 3 = sweep + composition + reduction (lane family), wide models: the real count (sweep
+                                         [+ GK15 pass] [+ k_wide_reduce_dp for shared parameters]), 0 = other sequences */
     int32_t reserved0;
 } hipadj_stats;
 
@@ -219,7 +220,8 @@ int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double 
  * and the 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62, with both steppers. */
 int hipadj_wmodel_register(const char *name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
                            const char *f_body, const char *vjp_body, int32_t *model_id);
-/* Compiles the forward and the InterpolatingAdjoint kernels of a registered model for gfx950 (no device needed) so that
+/* Compiles the forward and the InterpolatingAdjoint kernels of a registered lane model — for a wide model both forward solves and every reverse sweep of
+ * the family (Interpolating, Gauss, GaussKronrod, Backsolve, Quadrature on RK4 and on adaptive Tsit5, without a cost) — for gfx950 (no device needed) so that
  * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
 int hipadj_model_check(int32_t model_id);
 /* Compiles every kernel a handle of configuration *cfg would launch (forward, reverse, quadrature, tail) — what hipadj_create

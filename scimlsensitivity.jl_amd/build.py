@@ -18,7 +18,7 @@ SRC = os.path.join(CSRC, "hipadj_api.hip")
 LIB = os.environ.get("HIPADJ_BUILD_LIB") or os.path.join(HERE, "libhipadj.so")
 OBJ = os.path.join(HERE, "build" if "HIPADJ_BUILD_LIB" not in os.environ else "build_" + os.path.splitext(os.path.basename(LIB))[0])
 
-DEPS = sorted(glob.glob(os.path.join(CSRC, "*.h*"))) + [os.path.join(os.path.dirname(HERE), "include", "hipadj.h"), os.path.abspath(__file__)]
+DEPS = sorted(glob.glob(os.path.join(CSRC, "*.h*"))) + [os.path.join(CSRC, "hipadj.map")] + [os.path.join(os.path.dirname(HERE), "include", "hipadj.h"), os.path.abspath(__file__)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("HIPADJ_BUILD_EXTRA", "").split()
 
 LANE_MODELS = ["ModelLV", "ModelLVT", "ModelLorenz", "ModelLinDiag", "ModelFallMass"]   # csrc/hipadj_models.hpp
@@ -92,7 +92,7 @@ def build(force=False, verbose=False, jobs=None):
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         objs = list(pool.map(compile_unit, units()))
     tmp = LIB + ".tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={os.path.join(CSRC, 'hipadj.map')}", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -176,9 +176,14 @@ static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int
 
 extern "C" int hipadj_model_check(int32_t model_id) {
     std::vector<char> code; std::map<std::string, std::string> low;
-    if (user_model_is_wide(model_id)) {   // a wide model: the forward solve and every sweep of the family
-        std::vector<std::string> all = wide_kernel_names(HIPADJ_ALG_INTERPOLATING);
-        for (int a : {HIPADJ_ALG_GAUSS, HIPADJ_ALG_BACKSOLVE, HIPADJ_ALG_QUADRATURE}) { const auto e = wide_kernel_names(a); all.insert(all.end(), e.begin() + 1, e.end()); }
+    if (user_model_is_wide(model_id)) {   // a wide model: both forward solves and every sweep of the family on both steppers, without a cost (cost variants and the
+                                          // 160 KB LDS limit of the adaptive Interpolating / Backsolve sweeps are per configuration: hipadj_model_check_config)
+        std::vector<std::string> all;
+        for (bool ts5 : {false, true})
+            for (int a : {HIPADJ_ALG_INTERPOLATING, HIPADJ_ALG_GAUSS, HIPADJ_ALG_GAUSS_KRONROD, HIPADJ_ALG_BACKSOLVE, HIPADJ_ALG_QUADRATURE}) {
+                if (ts5 && (a == HIPADJ_ALG_INTERPOLATING || a == HIPADJ_ALG_BACKSOLVE) && user_wide_ts5_interp_lds(model_id, a == HIPADJ_ALG_BACKSOLVE) * 8 > 160L * 1024) continue;
+                for (const auto& x : wide_kernel_names(a, ts5)) if (std::find(all.begin(), all.end(), x) == all.end()) all.push_back(x);
+            }
         return user_compile(model_id, all, code, low, g_create_error);
     }
     std::vector<std::string> exprs = {"hipadj::k_forward<hipadj::UserModel>", user_has_cost(model_id) ? "hipadj::k_interp<hipadj::UserModel, 1, 7>" : "hipadj::k_interp<hipadj::UserModel, 1, 1>"};
@@ -480,7 +485,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
 
     h->st.struct_size = sizeof(hipadj_stats); h->st.n = n; h->st.np = np; h->st.ntraj = h->N; h->st.nsteps = S;
     h->st.time_segments = h->nseg; h->st.workspace_bytes = h->ws_bytes;
-    h->st.launches_per_pass = (h->fused && h->d_tbuf) ? 1 : ((!P.field && !P.mlp && !P.adaptive && cfg->alg != HIPADJ_ALG_QUADRATURE) ? 3 : 0);
+    h->st.launches_per_pass = (h->fused && h->d_tbuf) ? 1 : ((!P.field && !P.mlp && !P.adaptive && !P.wide && cfg->alg != HIPADJ_ALG_QUADRATURE) ? 3 : 0);
+    if (P.wide) h->st.launches_per_pass = (cfg->alg == HIPADJ_ALG_QUADRATURE ? 2 : 1) + (cfg->p_shared ? 1 : 0);   // the sweep (+ the GK15 pass) + k_wide_reduce_dp for shared parameters
     // ALGORITHMIC bytes of one reverse pass: knots (u,f) once, cotangents (if read), du0 + dp out
     double bytes = 0.0;
     if (P.adaptive) bytes = 0.0;   // data-dependent (accepted steps per trajectory): not modelled

@@ -565,6 +565,7 @@ inline int user_set_cost_function(int32_t model, const char* g, std::string& err
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost_function: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
+    if (R.models[idx].wide) { err = "hipadj_model_set_cost_function: a wide model (hipadj_wmodel_register) takes the built-in continuous costs only (hipadj_config.cont_cost 1 / 2)"; return HIPADJ_ERR_UNSUPPORTED; }
     R.models[idx].gfun = g; R.models[idx].has_cost = true; R.models[idx].rev++;
     return HIPADJ_OK;
 }
@@ -574,6 +575,7 @@ inline int user_set_cost(int32_t model, const char* dgdu, const char* dgdp, std:
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
+    if (R.models[idx].wide) { err = "hipadj_model_set_cost: a wide model (hipadj_wmodel_register) takes the built-in continuous costs only (hipadj_config.cont_cost 1 / 2)"; return HIPADJ_ERR_UNSUPPORTED; }
     R.models[idx].dgdu = dgdu; R.models[idx].dgdp = dgdp; R.models[idx].gfun.clear(); R.models[idx].has_cost = true; R.models[idx].rev++;
     return HIPADJ_OK;
 }
@@ -583,6 +585,7 @@ inline int user_set_affect(int32_t model, const char* body, std::string& err) {
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_affect: unknown model id (affects are attached to runtime-registered models)"; return HIPADJ_ERR_INVALID_ARG; }
+    if (R.models[idx].wide && body && *body) { err = "hipadj_model_set_affect: DiscreteCallback affects are not implemented for wide models (hipadj_wmodel_register)"; return HIPADJ_ERR_UNSUPPORTED; }
     R.models[idx].affect = body ? body : ""; R.models[idx].rev++;
     return HIPADJ_OK;
 }
@@ -621,6 +624,10 @@ inline int user_set_mass_matrix(int32_t model, const double* M, std::string& err
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_mass_matrix: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
     UserModelSrc& m = R.models[idx];
     if (!M) { if (m.has_mm) { m.has_mm = false; m.rev++; } return HIPADJ_OK; }
+    if (m.wide || m.n > 8) {   // minv[64] / a[8][16] below are sized for the lane family (n <= 8); the wide kernels never consult has_mm
+        err = "hipadj_model_set_mass_matrix: mass matrices are implemented for lane-family runtime models (n <= 8) only, not for wide models (hipadj_wmodel_register)";
+        return HIPADJ_ERR_UNSUPPORTED;
+    }
     const int n = m.n;
     double a[8][16]; double scale = 0.0;
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {

@@ -120,3 +120,22 @@ def test_kernel_choice_of_the_wide_family(sa, tmp_path, monkeypatch):
     assert "k_wide_forward_ts5<hipadj::UserW>" in e and "k_wide_backsolve_ts5<hipadj::WideWithCost<hipadj::UserW, 2>>" in e
     e = names(alg=3, cont_cost=2)
     assert "k_wide_quad_adj<hipadj::WideWithCost<hipadj::UserW, 2>>" in e and "k_wide_quad_gk<hipadj::WideWithCost<hipadj::UserW, 2>, 32, false>" in e
+
+
+def test_wide_models_refuse_mass_matrix_cost_text_and_affect(sa):
+    """set_mass_matrix on a wide model used to overflow the n <= 8 stack arrays of the lane family; the wide kernels
+    consult neither a mass matrix nor cost / affect text, so all three are refused at the C ABI with HIPADJ_ERR_UNSUPPORTED."""
+    fun = sa.WideDeviceFunction.dense_linear("t_refuse40", 40)
+    with pytest.raises(sa.HipadjError) as e:
+        fun.set_mass_matrix(np.eye(40) * 2.0)
+    assert e.value.status == -6 and "wide" in str(e.value)
+    with pytest.raises(sa.HipadjError) as e:
+        fun.set_cost(g="g = u[0] * u[0];")
+    assert e.value.status == -6
+    with pytest.raises(sa.HipadjError) as e:
+        fun.set_cost(dgdu="out[0] = u[0];", dgdp="out[0] = 0.0;")
+    assert e.value.status == -6
+    with pytest.raises(sa.HipadjError) as e:
+        fun.set_affect("un[0] += 1.0;")
+    assert e.value.status == -6
+    fun.set_mass_matrix(None)       # removing what was never there stays a no-op
