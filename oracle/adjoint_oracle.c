@@ -66,6 +66,8 @@ static int model_init(orc_model *m, int id, const int dims[4]) {
     case ORC_MODEL_IDXAFF: { int R = m->dims[0], Cc = m->dims[1]; if (R < 1 || Cc < 1) return -1; m->n = R * Cc; m->np = 2; break; }
     case ORC_MODEL_MLP1: { int d = m->dims[0], H = m->dims[1]; if (d < 1 || H < 1) return -1; m->n = d; m->np = H * d + H + d * H + d; break; }
     case ORC_MODEL_DENSELIN: { int r = m->dims[0]; if (r < 1) return -1; m->n = r; m->np = r * r; break; }
+    case ORC_MODEL_PENDULUM: m->n = 2; m->np = 3; break;
+    case ORC_MODEL_LIN1P: m->n = 1; m->np = 2; break;
     default: return -1;
     }
     return 0;
@@ -106,6 +108,13 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
         du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
         du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
         du[2] = p[1] * u[1] * u[1];
+        break;
+    case ORC_MODEL_PENDULUM: /* test/Core7/adjoint_param.jl:6-10; the second term is the test's "simple controller that stabilizes pi" */
+        du[0] = p[0] * u[1];
+        du[1] = -sin(u[0]) + (-p[0] * sin(u[0]) + p[1] * u[1]);
+        break;
+    case ORC_MODEL_LIN1P:    /* test/Core7/adjoint_param.jl:56-59 */
+        du[0] = -u[0] * p[0] - p[1];
         break;
     case ORC_MODEL_AFFINE3: /* `foo` of the mass-matrix test, test/Core3/adjoint.jl:1315-1321: du = A u + p; du[2] += sum(p), A = [1 2 3; 4 5 6; 7 8 9] */
         du[0] = 1.0 * u[0] + 2.0 * u[1] + 3.0 * u[2] + p[0];
@@ -217,6 +226,15 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
             dgrad[1] = -u[1] * u[1] * lam[1] + u[1] * u[1] * lam[2];
             dgrad[2] = u[1] * u[2] * lam[0] - u[1] * u[2] * lam[1];
         }
+        break;
+    case ORC_MODEL_PENDULUM: { /* J = [0, p1; -(1 + p1) cos x1, p2];  f_p = [x2, 0, 0; -sin x1, x2, 0] */
+        const double c = cos(u[0]), sn = sin(u[0]);
+        if (dlam) { dlam[0] = -(1.0 + p[0]) * c * lam[1]; dlam[1] = p[0] * lam[0] + p[1] * lam[1]; }
+        if (dgrad) { dgrad[0] = u[1] * lam[0] - sn * lam[1]; dgrad[1] = u[1] * lam[1]; dgrad[2] = 0.0; }
+        break; }
+    case ORC_MODEL_LIN1P:
+        if (dlam) dlam[0] = -p[0] * lam[0];
+        if (dgrad) { dgrad[0] = -u[0] * lam[0]; dgrad[1] = -lam[0]; }
         break;
     case ORC_MODEL_AFFINE3:
         if (dlam) {
@@ -766,9 +784,17 @@ static void fetch_y(adj_ctx *A, double t) {
  *   cont_cost 1:  g = (sum u)^2 / 2           dgdu_j = sum(u), dgdp = 0        (test/Core3/adjoint.jl:913-919)
  *   cont_cost 2:  g = u_1^2 + p_1             dgdu = [2 u_1, 0, ...], dgdp = [1, 0, ...]   (test/Core7/mixed_costs.jl:46-57) */
 #define ORC_MAXNP_COST 64
+#define ORC_PI 3.14159265358979323846
+/* does the cost depend on the parameters (dgdp_continuous given)? */
+static int cost_has_gp(int cont_cost) { return cont_cost >= 2; }
+/* g_p(y, p, t) at the context's current y (fetch_y / the backsolved block come first) */
 static void cost_grad_p(const adj_ctx *A, double *gp) {
     for (int i = 0; i < A->np; ++i) gp[i] = 0.0;
     if (A->cfg->cont_cost == 2) gp[0] = 1.0;
+    else if (A->cfg->cont_cost == 3) {       /* r = -p1 sin x1 + p2 x2;  g_p = 10 r [-sin x1, x2, 0, ...]   (test/Core7/adjoint_param.jl:18-20) */
+        const double r = -A->p[0] * sin(A->y[0]) + A->p[1] * A->y[1];
+        gp[0] = -10.0 * r * sin(A->y[0]); gp[1] = 10.0 * r * A->y[1];
+    } else if (A->cfg->cont_cost == 4) { gp[0] = -A->y[0]; gp[1] = -1.0; }   /* test/Core7/adjoint_param.jl:64-67 */
 }
 static void accumulate_cost(const adj_ctx *A, double *dlam, double *dgrad) {
     if (A->cfg->cont_cost == 1) {
@@ -777,6 +803,14 @@ static void accumulate_cost(const adj_ctx *A, double *dlam, double *dgrad) {
     } else if (A->cfg->cont_cost == 2) {
         dlam[0] -= 2.0 * A->y[0];
         if (dgrad) dgrad[0] -= 1.0;
+    } else if (A->cfg->cont_cost == 3) {     /* g_u = [2 (x1 - pi) - 10 r p1 cos x1,  2 x2 + 10 r p2] */
+        const double r = -A->p[0] * sin(A->y[0]) + A->p[1] * A->y[1];
+        dlam[0] -= 2.0 * (A->y[0] - ORC_PI) - 10.0 * r * A->p[0] * cos(A->y[0]);
+        dlam[1] -= 2.0 * A->y[1] + 10.0 * r * A->p[1];
+        if (dgrad) { double gp[ORC_MAXNP_COST]; cost_grad_p(A, gp); for (int i = 0; i < A->np; ++i) dgrad[i] -= gp[i]; }
+    } else if (A->cfg->cont_cost == 4) {
+        dlam[0] -= -A->p[0];
+        if (dgrad) { dgrad[0] -= -A->y[0]; dgrad[1] -= -1.0; }
     }
 }
 
@@ -857,7 +891,7 @@ static void gauss_integrand(adj_ctx *A, double *out, double t, const double *lam
     fetch_y(A, t);
     model_vjp(A->m, NULL, out, lam, A->y, A->p, t);
     for (int i = 0; i < A->np; ++i) out[i] = -out[i];
-    if (A->cfg->cont_cost == 2) {
+    if (cost_has_gp(A->cfg->cont_cost)) {
         double gp[ORC_MAXNP_COST]; cost_grad_p(A, gp);
         for (int i = 0; i < A->np; ++i) out[i] -= gp[i];
     }
@@ -1002,7 +1036,7 @@ static void quad_integrand(double *out, double t, void *c) {
     fetch_y(A, t);
     dense_eval(Q->adj, t, Q->lam, &Q->hint);
     model_vjp(A->m, NULL, out, Q->lam, A->y, A->p, t);
-    if (A->cfg->cont_cost == 2) {                                /* out .+= dgdp_cache  (:497-500) */
+    if (cost_has_gp(A->cfg->cont_cost)) {                        /* out .+= dgdp_cache  (:497-500) */
         double gp[ORC_MAXNP_COST]; cost_grad_p(A, gp);
         for (int i = 0; i < A->np; ++i) out[i] += gp[i];
     }
@@ -1016,12 +1050,13 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
                        double *du0, double *dp, double *out, long *nrhs, double *t_fwd, double *t_rev) {
     int n = m->n, np = m->np, M = cfg->nsave;
     struct timespec c0, c1, c2;
-    if (cfg->cont_cost < 0 || cfg->cont_cost > 2) return -6;
+    if (cfg->cont_cost < 0 || cfg->cont_cost > 4) return -6;
+    if ((cfg->cont_cost == 3 && (n != 2 || np < 2)) || (cfg->cont_cost == 4 && (n < 1 || np < 2))) return -6;
     /* GaussIntegrand adds +dgdp to the NEGATED f_p^T lam (src/gauss_adjoint.jl:755-758) while the sum runs backward in time;
      * no reference test covers Gauss with dgdp_continuous (test/Core7/mixed_costs.jl, adjoint_param.jl use Backsolve /
      * Interpolating / Quadrature), so the sign is not restated here */
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
-    if (cfg->cont_cost == 2 && np > ORC_MAXNP_COST) return -6;
+    if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
     orc_dense sol; double *uend = (double *)malloc(sizeof(double) * n); memcpy(uend, u0, sizeof(double) * n);

@@ -44,7 +44,9 @@ enum {
     /* checkers for the wide (workgroup-per-trajectory) runtime models, csrc/hipadj_wide.hpp */
     ORC_MODEL_IDXAFF = 10,   /* R x Cc matrix state, df[i,j] = p1 i + p2 j: `rhs!` of test/Core5/size_handling_adjoint.jl:37-48; dims = {R, Cc} */
     ORC_MODEL_MLP1 = 11,     /* Chain(x -> x.^3, Dense(d, H, tanh), Dense(H, d)): the neural ODE of docs/src/Benchmark.md:62; dims = {d, H} */
-    ORC_MODEL_DENSELIN = 12  /* u' = A u with A = reshape(p, n, n): np = n^2 (NOT from the reference); dims = {n} */
+    ORC_MODEL_DENSELIN = 12, /* u' = A u with A = reshape(p, n, n): np = n^2 (NOT from the reference); dims = {n} */
+    ORC_MODEL_PENDULUM = 13, /* `pendulum_eom` of test/Core7/adjoint_param.jl:6-10: dx1 = p1 x2; dx2 = -sin x1 + (-p1 sin x1 + p2 x2); np = 3 (p3 unused, as in the test) */
+    ORC_MODEL_LIN1P = 14     /* `f` of test/Core7/adjoint_param.jl:56-59: du = -u p1 - p2; n = 1, np = 2 */
 };
 enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3,
        ORC_ALG_GAUSS_KRONROD = 4 /* [upstream-recall] per-step adaptive GK(7,15): parity UNPINNED beyond GaussKronrod == Gauss */ };
@@ -67,7 +69,10 @@ typedef struct {
     double quad_abstol, quad_reltol; /* QuadratureAdjoint(abstol, reltol) */
     int no_start;         /* suppress the jump at t0 (src/adjoint_common.jl:761) */
     int cont_cost;        /* continuous cost g(u,p,t) added to the loss as int g dt (accumulate_cost!, src/derivative_wrappers.jl:1411-1442):
-                             0 none; 1: g = (sum(u))^2 / 2, dgdu = sum(u) in every component (test/Core3/adjoint.jl:913-919), dgdp = 0 */
+                             0 none; 1: g = (sum(u))^2 / 2, dgdu = sum(u) in every component (test/Core3/adjoint.jl:913-919), dgdp = 0;
+                             2: g = u_1^2 + p_1 (test/Core7/mixed_costs.jl:46-57);
+                             3: g = (x1 - pi)^2 + x2^2 + 5 (-p1 sin x1 + p2 x2)^2, the pendulum cost of test/Core7/adjoint_param.jl:18 (parameter-dependent, np >= 2);
+                             4: g = -u_1 p_1 - p_2 (test/Core7/adjoint_param.jl:64) */
 } orc_config;
 
 int orc_model_sizes(int model, const int dims[4], int *n, int *np);
