@@ -363,6 +363,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
         if (!P.user) {   // event knots of the forward solve (k_forward_ev): save times, checkpoints, the knot in front of a shortened last step
             if (const char* e = std::getenv("HIPADJ_FWD_EV")) h->fwd_ev = std::atoi(e);
+            if (const char* e = std::getenv("HIPADJ_QUAD")) h->quad_fwd = std::atoi(e);
             std::vector<int> ek, es, ec;
             forward_events(P, cfg->dt, ek, es, ec);
             h->nfev = (int)ek.size();

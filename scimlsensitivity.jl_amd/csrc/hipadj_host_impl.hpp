@@ -8,7 +8,11 @@ template <class Mo> int forward_impl(hipadj_handle* h, const double* d_u0, const
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     dbl2* knots = h->d_knots;
     double* ck = h->d_ckpt;
-    if (h->fwd_ev && h->d_fev_knot)
+    if (h->fwd_ev && h->d_fev_knot && h->quad_fwd && QuadForm<Mo>::value)     // four lanes per trajectory (hipadj_quad.hpp)
+        hipLaunchKernelGGL((k_forward_quad<Mo>), dim3((unsigned)((h->N + WAVE / 4 - 1) / (WAVE / 4))), dim3(WAVE), 0, h->stream, h->g, d_u0, d_p,
+                           FwdEvents{h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->nfev}, knots, ck,
+                           (d_out && h->M > 0 && !h->offgrid) ? h->d_outT : (double*)nullptr, h->d_yT);
+    else if (h->fwd_ev && h->d_fev_knot)
         hipLaunchKernelGGL((k_forward_ev<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, d_u0, d_p,
                            FwdEvents{h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->nfev}, knots, ck,
                            (d_out && h->M > 0 && !h->offgrid) ? h->d_outT : (double*)nullptr, h->d_yT);

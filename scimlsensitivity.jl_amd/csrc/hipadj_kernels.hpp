@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include "hipadj_lane.hpp"
+#include "hipadj_quad.hpp"
 #include "hipadj_fused.hpp"
 #if !defined(__HIPCC_RTC__)
 #include "hipadj_plan.hpp"
@@ -43,6 +44,17 @@ __global__ void __launch_bounds__(WAVE) k_forward_ev(Geom g, const double* __res
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= g.N) return;
     forward_lane_ev<Mo>(g, i, u0, p, ev, knots, ckpt, outT, yT);
+}
+
+// the same forward solve with four lanes per trajectory (hipadj_quad.hpp): a wavefront = 16 trajectories, lane c of a quad = state component c; lanes
+// beyond the model's n components and beyond the ensemble leave at once (the DPP permutations of a component form never read them)
+template <class Mo>
+__global__ void __launch_bounds__(WAVE) k_forward_quad(Geom g, const double* __restrict__ u0, const double* __restrict__ p, FwdEvents ev,
+                                                       dbl2* __restrict__ knots, double* __restrict__ ckpt, double* __restrict__ outT, double* __restrict__ yT) {
+    const long i = (long)blockIdx.x * (WAVE / 4) + (threadIdx.x >> 2);
+    const int c = threadIdx.x & 3;
+    if (i >= g.N || c >= Mo::N) return;
+    if constexpr (QuadForm<Mo>::value) forward_quad_ev<Mo>(g, i, c, u0, p, ev, knots, ckpt, outT, yT);
 }
 
 // segbuf layout: [segment][column][N+NP][Npad]; the top segment only fills column 0.

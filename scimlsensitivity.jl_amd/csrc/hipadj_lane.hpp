@@ -55,28 +55,23 @@ HIPADJ_HD double knot_step(const Geom& g, int k) { return k == g.S - 1 ? g.h_las
 
 template <class Mo> struct Knot { double u[Mo::N]; double f[Mo::N]; };
 
-// knot k of trajectory i: 2N doubles packed as N pairs
+// knot k of trajectory i: N 16-byte pairs, pair j = (u_j, f_j(u)) — one component's value and slope, so that the four-lanes-per-trajectory forward
+// solve (hipadj_quad.hpp: lane c owns component c) stores its own pair and the lane family reads all N of them
 template <class Mo>
 HIPADJ_HD void load_knot(const dbl2* __restrict__ K, long Npad, int k, long i, Knot<Mo>& kn, int kmask = -1) {
     constexpr int N = Mo::N;
     k &= kmask;
-    double v[2 * N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const dbl2 d = K[((long)k * N + j) * Npad + i];
-        v[2 * j] = d.x; v[2 * j + 1] = d.y;
+        kn.u[j] = d.x; kn.f[j] = d.y;
     }
-#pragma unroll
-    for (int j = 0; j < N; ++j) { kn.u[j] = v[j]; kn.f[j] = v[N + j]; }
 }
 template <class Mo>
 HIPADJ_HD void store_knot(dbl2* __restrict__ K, long Npad, int k, long i, const double (&u)[Mo::N], const double (&f)[Mo::N]) {
     constexpr int N = Mo::N;
-    double v[2 * N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) { v[j] = u[j]; v[N + j] = f[j]; }
-#pragma unroll
-    for (int j = 0; j < N; ++j) { dbl2 d; d.x = v[2 * j]; d.y = v[2 * j + 1]; K[((long)k * N + j) * Npad + i] = d; }
+    for (int j = 0; j < N; ++j) { dbl2 d; d.x = u[j]; d.y = f[j]; K[((long)k * N + j) * Npad + i] = d; }
 }
 
 template <class Mo>
@@ -152,8 +147,11 @@ HIPADJ_HD void forward_lane_ev(const Geom& g, long i, const double* __restrict__
     for (int j = 0; j < N; ++j) u[j] = u0[i * N + j];
     Mo::f(k1, u, pv, g.t0);
     int k = 0;
+    // the NEXT event is fetched before the run of steps in front of the current one: its scalar loads complete under the step loop (hipadj_quad.hpp)
+    int kn_next = ev.nev > 0 ? ev.knot[0] : g.S, ck_next = ev.nev > 0 ? ev.ckpt[0] : -1, sv_next = ev.nev > 0 ? ev.save[0] : -1;
     for (int e = 0; e <= ev.nev; ++e) {
-        const int kn = e < ev.nev ? ev.knot[e] : g.S;            // run of plain steps up to the next event (or to the end)
+        const int kn = kn_next, c = ck_next, sv = sv_next;       // run of plain steps up to the next event (or to the end)
+        if (e + 1 < ev.nev) { kn_next = ev.knot[e + 1]; ck_next = ev.ckpt[e + 1]; sv_next = ev.save[e + 1]; } else kn_next = g.S;
         const double dt = (k == g.S - 1) ? g.h_last : g.dt, hh = 0.5 * dt, h6 = dt / 6.0;
 #pragma unroll 2
         for (; k < kn; ++k) {
@@ -174,7 +172,6 @@ HIPADJ_HD void forward_lane_ev(const Geom& g, long i, const double* __restrict__
             Mo::f(k1, u, pv, g.t0 + (k + 1) * g.dt);            // first-same-as-last: the slope stored with knot k + 1
         }
         if (e < ev.nev) {                                        // the event AT knot kn (k == kn now)
-            const int c = ev.ckpt[e], sv = ev.save[e];
             if (ckpt && c >= 0) {
 #pragma unroll
                 for (int j = 0; j < N; ++j) ckpt[((long)c * N + j) * g.Npad + i] = u[j]; }

@@ -468,8 +468,8 @@ inline int user_compile(int32_t model, const std::vector<std::string>& exprs, st
     }
     RtcApi& A = rtc_api();
     if (!A.lib || !A.err.empty()) { err = A.err.empty() ? "hiprtc unavailable" : A.err; return HIPADJ_ERR_UNSUPPORTED; }
-    constexpr int NH = 7;
-    const char* hnames[NH] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp", "hipadj_dual.hpp", "hipadj_fused.hpp", "hipadj_wide.hpp"};
+    constexpr int NH = 8;
+    const char* hnames[NH] = {"hipadj_models.hpp", "hipadj_lane.hpp", "hipadj_kernels.hpp", "hipadj_adaptive.hpp", "hipadj_dual.hpp", "hipadj_fused.hpp", "hipadj_wide.hpp", "hipadj_quad.hpp"};
     std::string htext[NH];
     const std::string dir = user_csrc_dir();
     for (int i = 0; i < NH; ++i)
