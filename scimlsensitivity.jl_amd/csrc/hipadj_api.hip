@@ -487,7 +487,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->st.struct_size = sizeof(hipadj_stats); h->st.n = n; h->st.np = np; h->st.ntraj = h->N; h->st.nsteps = S;
     h->st.time_segments = h->nseg; h->st.workspace_bytes = h->ws_bytes;
     h->st.launches_per_pass = (h->fused && h->d_tbuf) ? 1 : ((!P.field && !P.mlp && !P.adaptive && !P.wide && cfg->alg != HIPADJ_ALG_QUADRATURE) ? 3 : 0);
-    if (P.wide) h->st.launches_per_pass = (cfg->alg == HIPADJ_ALG_QUADRATURE ? 2 : 1) + (cfg->p_shared ? 1 : 0);   // the sweep (+ the GK15 pass) + k_wide_reduce_dp for shared parameters
+    if (P.wide) h->st.launches_per_pass = (cfg->alg == HIPADJ_ALG_QUADRATURE ? 2 : 1) + (cfg->p_shared ? (h->N > 64 ? 2 : 1) : 0);   // the sweep (+ the GK15 pass) + the one- or two-level k_wide_reduce_dp for shared parameters
     // ALGORITHMIC bytes of one reverse pass: knots (u,f) once, cotangents (if read), du0 + dp out
     double bytes = 0.0;
     if (P.adaptive) bytes = 0.0;   // data-dependent (accepted steps per trajectory): not modelled
@@ -1122,7 +1122,14 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     }
     if (h->timing >= 1 && h->cfg.alg != HIPADJ_ALG_QUADRATURE) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
     if (h->cfg.p_shared) {
-        hipLaunchKernelGGL(k_wide_reduce_dp, dim3((unsigned)((h->np + 255) / 256)), dim3(256), 0, h->stream, h->N, h->np, (const double*)h->d_dp_traj, d_dp, h->d_flag);
+        const unsigned jb = (unsigned)((h->np + 255) / 256);
+        if (h->N > 64) {   // two levels: chunk partials into d_partial (ceil(N / 16) rows are allocated, ceil(N / C) <= that are used), then the partials in chunk order
+            int C = (int)std::ceil(std::sqrt((double)h->N)); if (C < 16) C = 16;
+            const long nchunk = (h->N + C - 1) / C;
+            hipLaunchKernelGGL(k_wide_reduce_dp_chunks, dim3(jb, (unsigned)nchunk), dim3(256), 0, h->stream, h->N, h->np, C, (const double*)h->d_dp_traj, h->d_partial);
+            hipLaunchKernelGGL(k_wide_reduce_dp, dim3(jb), dim3(256), 0, h->stream, nchunk, h->np, (const double*)h->d_partial, d_dp, h->d_flag);
+        } else
+            hipLaunchKernelGGL(k_wide_reduce_dp, dim3(jb), dim3(256), 0, h->stream, h->N, h->np, (const double*)h->d_dp_traj, d_dp, h->d_flag);
         HIP_TRY(h, hipGetLastError());
     }
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));

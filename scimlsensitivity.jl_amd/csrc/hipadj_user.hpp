@@ -234,13 +234,16 @@ inline std::string user_wide_struct(const UserModelSrc& m) {
     o << "#include \"hipadj_wide.hpp\"\n"
       << "namespace hipadj {\n// runtime-registered wide model '" << m.name << "' (workgroup-per-trajectory family, hipadj_wide.hpp)\n"
       << "#define HIPADJ_W_FOR(i, n) for (int i = tid; i < (n); i += T)\n#define wg_sync() hipadj::wide_sync<T>()\n#define wg_sum(x) hipadj::wide_sum_all<T>(x)\n"
+      // tanh of a model body = the 31-instruction form of the MFMA family (|difference| to libm 2.2e-16: hipadj_wide.hpp wide_tanh); the library tanh is ~150
+      // instructions and dominated a joint VJP of the 2-50-2 neural ODE
+      << "#define tanh(x) hipadj::wide_tanh(x)\n"
       << "struct UserW {\n    static constexpr int N = " << m.n << ", NP = " << m.np << ", T = " << m.threads << ", NW = " << m.nw << ", NACC = " << m.nacc
       << ", ACC0 = " << m.acc0 << ";\n"
       << "    static __device__ __forceinline__ void f(double* __restrict__ du, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {\n"
       << "        (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.f << "\n    }\n"
       << "    template <bool WP> static __device__ __forceinline__ void vjp(double* __restrict__ dlam, double* __restrict__ gp, double (&acc)[" << na << "], double w,\n"
       << "            const double* __restrict__ lam, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {\n"
-      << "        (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wvjp << "\n    }\n};\n}  // namespace hipadj\n";
+      << "        (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wvjp << "\n    }\n};\n#undef tanh\n}  // namespace hipadj\n";
     return o.str();
 }
 

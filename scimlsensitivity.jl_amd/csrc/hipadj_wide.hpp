@@ -77,9 +77,36 @@ template <int T> __device__ __forceinline__ void wide_sync() {
 // per-trajectory VJP reductions" of north_star: a contraction whose output is narrower than the workgroup (the 2 outputs of a 50 -> 2 layer, a scalar
 // coefficient) runs with the lanes over its INPUT index and one butterfly per output instead of a serial loop on one or two lanes.  Fixed order
 // (xor butterfly inside a wavefront: both partners add the same two numbers; then the wavefronts in order).  All threads must call it.
-template <int T> __device__ __forceinline__ double wide_sum_all(double v) {
+#ifndef HIPADJ_WIDE_DPP_SUM
+#define HIPADJ_WIDE_DPP_SUM 1      // 0: the round-3 form (six ds_bpermute butterflies: an LDS-crossbar round trip per step)
+#endif
+template <int CTRL> __device__ __forceinline__ double wide_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wide_readlane(double x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+// sum over one wavefront, every lane gets it: four DPP steps inside a 16-lane row (xor 1, xor 2 as quad_perm, then row_half_mirror and row_mirror — after
+// the quad steps every lane of a quad holds the same value, so any partner in the other quad / half row does), then the four row sums through SGPRs.
+// Fixed order; no LDS traffic, no lgkmcnt wait.
+__device__ __forceinline__ double wide_wave_sum(double v) {
+#if HIPADJ_WIDE_DPP_SUM
+    v += wide_dpp<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+    v += wide_dpp<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+    v += wide_dpp<0x141>(v);      // row_half_mirror
+    v += wide_dpp<0x140>(v);      // row_mirror
+    return (wide_readlane(v, 0) + wide_readlane(v, 16)) + (wide_readlane(v, 32) + wide_readlane(v, 48));
+#else
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+#endif
+}
+template <int T> __device__ __forceinline__ double wide_sum_all(double v) {
+    v = wide_wave_sum(v);
     if constexpr (T == 64) return v;
     else {
         __shared__ double part[T / 64];
@@ -91,6 +118,29 @@ template <int T> __device__ __forceinline__ double wide_sum_all(double v) {
         __syncthreads();
         return s;
     }
+}
+
+// tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2|x|): the MFMA family's form (hipadj_mlp.hpp mlp_tanh; max |difference| to libm tanh 2.2e-16), 31 instructions.
+// t = 2^k e^r with k = rint(a log2 e), r = a - k ln 2 (two-part constant), e^r by the degree-12 Taylor polynomial (|r| <= 0.347), the quotient by v_rcp_f64 +
+// two Newton steps + one residual correction.  Model bodies of wide runtime models get it under the name tanh (hipadj_user.hpp user_wide_struct).
+__device__ __forceinline__ double wide_tanh(double x) {
+    const double a = fmax(-2.0 * fabs(x), -80.0);
+    const double kf = __builtin_rint(a * 1.4426950408889634074);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, a);
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+    double q = 1.0 / 479001600.0;
+    q = __builtin_fma(q, r, 1.0 / 39916800.0); q = __builtin_fma(q, r, 1.0 / 3628800.0); q = __builtin_fma(q, r, 1.0 / 362880.0);
+    q = __builtin_fma(q, r, 1.0 / 40320.0); q = __builtin_fma(q, r, 1.0 / 5040.0); q = __builtin_fma(q, r, 1.0 / 720.0);
+    q = __builtin_fma(q, r, 1.0 / 120.0); q = __builtin_fma(q, r, 1.0 / 24.0); q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5); q = __builtin_fma(q, r, 1.0); q = __builtin_fma(q, r, 1.0);
+    const double t = __builtin_amdgcn_ldexp(q, (int)kf);
+    const double d = 1.0 + t, n = 1.0 - t;
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    double z = n * y;
+    z = __builtin_fma(__builtin_fma(-d, z, n), y, z);
+    return __builtin_copysign(z, x);
 }
 
 // workgroup sum of K per-thread values into out[0..K) (LDS), fixed order: shuffle tree per wave, then the waves in order
@@ -687,7 +737,17 @@ static __global__ void k_wide_quad_sum(long N, int NP, int nq, const double* __r
     }
 }
 
-// dp[j] = sum over trajectories of dp_traj[traj][j], fixed order (shared parameters); rows: the per-trajectory gradient is the result
+// dp[j] = sum over trajectories of dp_traj[traj][j] (shared parameters), fixed order, in two levels (one thread per parameter used to chain all N
+// trajectories — 0.95 ms of every reverse pass of the 252-parameter neural ODE at N = 4096): blocks over chunks of C trajectories write partial rows, then
+// one thread per parameter adds the ceil(N / C) partials in chunk order.  C = max(16, ceil(sqrt(N))): both levels are ~sqrt(N) long.
+static __global__ void k_wide_reduce_dp_chunks(long N, int NP, int C, const double* __restrict__ dp_traj, double* __restrict__ part) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= NP) return;
+    const long i0 = (long)blockIdx.y * C, i1 = i0 + C < N ? i0 + C : N;
+    double s = 0.0;
+    for (long i = i0; i < i1; ++i) s += dp_traj[i * NP + j];
+    part[(long)blockIdx.y * NP + j] = s;
+}
 static __global__ void k_wide_reduce_dp(long N, int NP, const double* __restrict__ dp_traj, double* __restrict__ dp, int* __restrict__ flag) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= NP) return;
