@@ -62,7 +62,7 @@ static int model_init(orc_model *m, int id, const int dims[4]) {
         m->n = 2 * G * G; m->np = 3; break; }
     case ORC_MODEL_ROBER: m->n = 3; m->np = 3; break;
     case ORC_MODEL_AFFINE3: m->n = 3; m->np = 3; break;
-    case ORC_MODEL_RING: { int r = m->dims[0]; if (r < 2 || r > 8) return -1; m->n = r; m->np = r + 1; break; }
+    case ORC_MODEL_RING: { int r = m->dims[0]; if (r < 2 || r > 4096) return -1; m->n = r; m->np = r + 1; break; }
     case ORC_MODEL_IDXAFF: { int R = m->dims[0], Cc = m->dims[1]; if (R < 1 || Cc < 1) return -1; m->n = R * Cc; m->np = 2; break; }
     case ORC_MODEL_MLP1: { int d = m->dims[0], H = m->dims[1]; if (d < 1 || H < 1) return -1; m->n = d; m->np = H * d + H + d * H + d; break; }
     case ORC_MODEL_DENSELIN: { int r = m->dims[0]; if (r < 1) return -1; m->n = r; m->np = r * r; break; }
