@@ -363,7 +363,6 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
         if (!P.user) {   // event knots of the forward solve (k_forward_ev): save times, checkpoints, the knot in front of a shortened last step
             if (const char* e = std::getenv("HIPADJ_FWD_EV")) h->fwd_ev = std::atoi(e);
-            if (const char* e = std::getenv("HIPADJ_QUAD")) h->quad_fwd = std::atoi(e);
             std::vector<int> ek, es, ec;
             forward_events(P, cfg->dt, ek, es, ec);
             h->nfev = (int)ek.size();
@@ -475,6 +474,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
     g.kmask = -1; g.h_last = P.h_last;
     if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
+    if (const char* e = std::getenv("HIPADJ_QUAD")) h->quad_fwd = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_FUSED_FINAL")) h->fused_final = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_WPB")) h->wpb4 = std::atoi(e) == 4;
     if (const char* e = std::getenv("HIPADJ_NO_OPS")) h->no_ops = std::atoi(e) != 0;

@@ -3,6 +3,7 @@
 // compiles in parallel.
 #pragma once
 #include "hipadj_host.hpp"
+#include "hipadj_quad_ts5.hpp"
 
 template <class Mo> int forward_impl(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
@@ -549,6 +550,10 @@ template <class Mo> int adaptive_forward(hipadj_handle* h, const double* d_u0, c
     const bool sized = h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE;
     if (sized && h->ip_ckpt) h->ag.SmaxI = (int)h->rec_cap;
     for (int pass = 0; pass < 2; ++pass) {
+        if (h->quad_fwd && QuadForm<Mo>::value)      // four lanes per trajectory (hipadj_quad_ts5.hpp): same records, a third of the instructions per wave
+            hipLaunchKernelGGL((k_forward_tsit5_quad<Mo>), dim3((unsigned)((h->N + 15) / 16)), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
+                               (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
+        else
         hipLaunchKernelGGL((k_forward_tsit5<Mo>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
                            (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
         HIP_TRY(h, hipGetLastError());
@@ -571,6 +576,16 @@ template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hip
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     for (int pass = 0; pass < 2; ++pass) {
+        // (Gauss: the quad sweep exists — adjoint_tsit5_quad<Mo, 2> — but is NOT dispatched: it measured slower than the lane kernel (2.96 vs 2.39 ms, the three quadrature nodes per
+        //  step add exchanges) and returned lam with an error that grows with the step count on problems with interior loss times (1.8e-5 at tol 1e-11 where the lane kernel and
+        //  the Interpolating / Backsolve quad sweeps sit at 1e-13; scripts/r4/ts5_dbg2.py) — unexplained, so it stays off)
+        constexpr bool QUAD_OK = QuadAdj<Mo>::value && CC == 0 && !CK && (ALG == 0 || ALG == 1);
+        if (QUAD_OK && h->quad_fwd) {
+            if constexpr (QUAD_OK)
+                hipLaunchKernelGGL((k_adjoint_tsit5_quad<Mo, ALG>), dim3((unsigned)((h->N + 15) / 16)), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
+                                   (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
+                                   (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag);
+        } else
         hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
                            (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
                            (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag,

@@ -1,0 +1,262 @@
+// hipadj_quad_ts5.hpp — adaptive Tsit5 with four lanes per trajectory (round 4; the fixed-step forward solve of this mapping is hipadj_quad.hpp).
+//
+// The lane-per-trajectory adaptive kernels are bound by ONE wave's instruction stream (157 lone wavefronts at 10^4 trajectories, ~1200 VALU instructions per
+// step attempt of the Interpolating sweep, profiles/r3_tsit5_counters.txt): the stage sums, the interpolation of the forward solution, the error estimate
+// and the record / gradient stores all cost n (or n + np) instructions per lane.  Here lane c of a quad owns component c of every vector — state y_c,
+// adjoint lam_c, parameter sum mu_c — and runs hipadj_adaptive.hpp's tsit5_integrate ITSELF on its one to three components: same controller, tstop clipping,
+// FSAL and callback protocol, with the controller's norms summed over the quad by two DPP moves (QuadNorm).  The right-hand sides are the models' COMPONENT
+// FORMS (QuadForm / QuadAdj: uniform FMA chains on operands rotated through the quad with quad_perm).  Every lane of a quad carries the same t, dt and
+// error estimate bit for bit (the butterfly adds the same numbers in every lane), so a quad never diverges; quads of one wavefront take their own step
+// sequences under the exec mask like the lanes of the lane family do.  Lanes beyond the model's components stay alive with zero state and zero constants
+// (they contribute exact zeros to the norms) and skip the stores.
+//
+// Data layout = the lane family's (records [Smax][2 + 5 n][Npad], outT / ckpt / yT / cotT component-major, dp_traj [np][Npad]): every kernel of either
+// mapping reads what the other wrote.  Dispatched for models with QuadAdj (compiled-in Lorenz): the forward solve and the Interpolating and Backsolve sweeps
+// without a continuous cost and without checkpointing=true; everything else keeps the lane kernels (the Gauss sweep below is written but switched off: see
+// adaptive_adjoint_l, hipadj_host_impl.hpp).
+#pragma once
+#include "hipadj_quad.hpp"
+#include "hipadj_adaptive.hpp"
+
+namespace hipadj {
+
+// the controller's norms over a quad: this lane's partial sum + the three others', identical bits in all four lanes
+struct QuadNorm {
+    int ncomp;
+    HIPADJ_HD double sum(double x, int, double) const {
+        x += quad_perm<HIPADJ_QP(1, 0, 3, 2)>(x);
+        x += quad_perm<HIPADJ_QP(2, 3, 0, 1)>(x);
+        return x;
+    }
+    HIPADJ_HD double count(int) const { return (double)ncomp; }
+    HIPADJ_HD void begin_attempt() const {}
+    HIPADJ_HD void after_k0() const {}
+    HIPADJ_HD void after_stage(int) const {}
+    HIPADJ_HD void accept(double) const {}
+    HIPADJ_HD void fsal() const {}
+};
+
+// Component form of the joint VJP and of f on operands rotated through the quad: y1 = y_{c+1}, y2 = y_{c+2}, l1 = lam_{c+1}, l2 = lam_{c+2} (indices mod 3).
+template <class Mo> struct QuadAdj { static constexpr bool value = false; };
+// Lorenz-63, (df/du)^T = [-s  r-z  y ;  s  -1  x ;  0  -x  -b],  (df/dp)^T lam = ((y - x) lam_0, x lam_1, -z lam_2):
+//   (J^T lam)_c = A lam_c + (B0 + B2 y2) l1 + (C0 + C1 y1) l2        c = 0: -s, r - z, y     c = 1: -1, x, s      c = 2: -b, 0, -x
+//   (f_p^T lam)_c = (M0 y_c + M1 y1 + M2 y2) lam_c                   c = 0: y - x            c = 1: x             c = 2: -z
+//   f_c = (S1 y1 + S2 y2) (Q0 + Q1 y1 + Q2 y2) + D y_c               c = 0: s y1 - s y_c     c = 1: y2 (r - y1) - y_c    c = 2: y1 y2 - b y_c
+template <> struct QuadAdj<ModelLorenz> {
+    static constexpr bool value = true;
+    struct K { double A, B0, B2, C0, C1, M0, M1, M2, S1, S2, Q0, Q1, Q2, D; };
+    HIPADJ_HD static K consts(int c, const double (&p)[3]) {
+        K k = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (c == 0) { k.A = -p[0]; k.B0 = p[1]; k.B2 = -1.0; k.C1 = 1.0; k.M0 = -1.0; k.M1 = 1.0; k.S1 = 1.0; k.Q0 = p[0]; k.D = -p[0]; }
+        else if (c == 1) { k.A = -1.0; k.B2 = 1.0; k.C0 = p[0]; k.M2 = 1.0; k.S2 = 1.0; k.Q0 = p[1]; k.Q1 = -1.0; k.D = -1.0; }
+        else if (c == 2) { k.A = -p[2]; k.C1 = -1.0; k.M0 = -1.0; k.S1 = 1.0; k.Q2 = 1.0; k.D = -p[2]; }
+        return k;
+    }
+    static constexpr int R1 = HIPADJ_QP(1, 2, 0, 3), R2 = HIPADJ_QP(2, 0, 1, 3);
+    // un-negated products at (y_c, lam_c); WP: also the parameter part
+    template <bool WP> HIPADJ_HD static void vjp(const K& k, double yc, double lc, double, double& dl, double& dm) {
+        const double y1 = quad_perm<R1>(yc), y2 = quad_perm<R2>(yc), l1 = quad_perm<R1>(lc), l2 = quad_perm<R2>(lc);
+        const double b = fma(k.B2, y2, k.B0), cc = fma(k.C1, y1, k.C0);
+        dl = fma(cc, l2, fma(b, l1, k.A * lc));
+        if (WP) dm = fma(k.M2, y2, fma(k.M1, y1, k.M0 * yc)) * lc; else dm = 0.0;
+    }
+    // ... and f_c next to them (Backsolve integrates y backwards): one more pair of rotations is not needed, y1 / y2 are shared
+    HIPADJ_HD static void vjp_f(const K& k, double yc, double lc, double, double& dl, double& dm, double& fc) {
+        const double y1 = quad_perm<R1>(yc), y2 = quad_perm<R2>(yc), l1 = quad_perm<R1>(lc), l2 = quad_perm<R2>(lc);
+        const double b = fma(k.B2, y2, k.B0), cc = fma(k.C1, y1, k.C0);
+        dl = fma(cc, l2, fma(b, l1, k.A * lc));
+        dm = fma(k.M2, y2, fma(k.M1, y1, k.M0 * yc)) * lc;
+        fc = fma(fma(k.S2, y2, k.S1 * y1), fma(k.Q2, y2, fma(k.Q1, y1, k.Q0)), k.D * yc);
+    }
+};
+
+// ---- forward dense solve (the quad counterpart of forward_tsit5_lane): lane (i, c) integrates component c ------------------------------------------------
+template <class Mo>
+HIPADJ_HD void forward_tsit5_quad(const AdaptGeom& g, long i, int c, const double* __restrict__ u0, const double* __restrict__ p,
+                                  double* __restrict__ rec, int* __restrict__ nsteps, const double* __restrict__ save_t,
+                                  double* __restrict__ outT, const double* __restrict__ ck_t, double* __restrict__ ckpt,
+                                  double* __restrict__ yT, int* __restrict__ flag) {
+    constexpr int N = Mo::N, RW = 2 + 5 * N;
+    using Q = QuadForm<Mo>;
+    const bool own = c < N;
+    const int cc = own ? c : 0;
+    double pv[Mo::NP];
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) pv[j] = own ? (g.p_shared ? p[j] : p[i * Mo::NP + j]) : 0.0;     // a spare lane: zero constants, zero state
+    const typename Q::K kc = Q::consts(cc, pv);
+    KRegs<1> K;
+    double u[1] = {own ? u0[i * N + c] : 0.0};
+    int s = 0, ms = 0, mc = 0;
+    bool overflow = false;
+    while (outT && ms < g.M && save_t[ms] <= g.t0) { if (own) outT[((long)ms * N + c) * g.Npad + i] = u[0]; ++ms; }
+    while (ckpt && mc < g.nck && ck_t[mc] <= g.t0) { if (own) ckpt[((long)mc * N + c) * g.Npad + i] = u[0]; ++mc; }
+    const double TINF = 1.7976931348623157e308;
+    double ts_next = (outT && ms < g.M) ? save_t[ms] : TINF, tc_next = (ckpt && mc < g.nck) ? ck_t[mc] : TINF;
+    const int na = tsit5_integrate<1>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.maxit, K,
+        [&](double (&du)[1], const double (&uu)[1], double t) { du[0] = Q::f(kc, uu[0], t); },
+        [&](double t, double tprev, double (&un)[1], const auto& KK) -> bool {
+            const double h = t - tprev;
+            double cf[5][1]; tsit5_poly<1>(KK, h, cf);
+            if (s < g.Smax) {
+                if (rec && own) {
+                    if (c == 0) { rec[((long)s * RW + 0) * g.Npad + i] = tprev; rec[((long)s * RW + 1) * g.Npad + i] = t; }
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) rec[((long)s * RW + 2 + m * N + c) * g.Npad + i] = cf[m][0];
+                }
+            } else overflow = true;
+            ++s;
+            while (ts_next <= t || time_hits(ts_next, t)) {
+                double y[1]; poly_eval<1>((ts_next - tprev) / h, cf, y);
+                if (own) outT[((long)ms * N + c) * g.Npad + i] = y[0];
+                ++ms; ts_next = ms < g.M ? save_t[ms] : TINF; }
+            while (tc_next <= t || time_hits(tc_next, t)) {
+                double y[1]; poly_eval<1>((tc_next - tprev) / h, cf, y);
+                if (own) ckpt[((long)mc * N + c) * g.Npad + i] = y[0];
+                ++mc; tc_next = mc < g.nck ? ck_t[mc] : TINF; }
+            (void)un;
+            return false;
+        }, NoPre(), QuadNorm{N});
+    if (c == 0) nsteps[i] = s;
+    if (yT && own) yT[(long)c * g.Npad + i] = u[0];
+    if ((na < 0 || overflow) && c == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(flag, 4);
+#endif
+    }
+}
+
+// one component of the forward dense solution: the step containing t, this lane's five coefficients cached in registers (FwdCursor with one component)
+template <class Mo> struct QuadCursor {
+    static constexpr int N = Mo::N, RW = 2 + 5 * Mo::N;
+    const double* rec; long Npad, i; int ns, sc, lc, c; bool own;
+    double ta, tb, cf[5];
+    HIPADJ_HD void init(const double* r, long np, long ii, int nsteps, int comp, bool o) {
+        rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; lc = -1; c = comp; own = o;
+        ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i];
+    }
+    HIPADJ_HD double eval(double t) {
+        while (t < ta && sc > 0) { --sc; tb = ta; ta = rec[((long)sc * RW + 0) * Npad + i]; }
+        while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[((long)sc * RW + 1) * Npad + i]; }
+        if (sc != lc) {
+            lc = sc;
+            const long base = ((long)sc * RW + 2 + c) * Npad + i;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) cf[m] = own ? rec[base + (long)(m * N) * Npad] : 0.0;
+        }
+        const double th = (t - ta) / (tb - ta);
+        return cf[0] + th * (cf[1] + th * (cf[2] + th * (cf[3] + th * cf[4])));
+    }
+};
+
+// ---- reverse sweeps.  ALG: 0 Interpolating (lane: lam_c, mu_c), 1 Backsolve (lam_c, mu_c, y_c), 2 Gauss (lam_c; mu_c by 3-node Gauss-Legendre per step) ----
+template <int ALG> struct QuadNZ { static constexpr int value = ALG == 0 ? 2 : (ALG == 1 ? 3 : 1); };
+
+template <class Mo, int ALG>
+HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const double* __restrict__ p, const double* __restrict__ rec,
+                                  const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
+                                  const double* __restrict__ ck_t, const double* __restrict__ save_t, const double* __restrict__ tstops_desc,
+                                  int ntstops, const double* __restrict__ cotT, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    constexpr int N = Mo::N, NP = Mo::NP, NZ = QuadNZ<ALG>::value;
+    static_assert(N <= 4 && NP <= 4, "one component of each vector per lane of a quad");
+    using QA = QuadAdj<Mo>;
+    const bool ownl = c < N, ownm = c < NP;
+    double pv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) pv[j] = (ownl || ownm) ? (g.p_shared ? p[j] : p[i * NP + j]) : 0.0;
+    const typename QA::K kc = QA::consts((ownl || ownm) ? c : 3, pv);
+    KRegs<NZ> K;
+    QuadCursor<Mo> cur;
+    if (ALG != 1) cur.init(rec, g.Npad, i, nsteps[i] < g.Smax ? nsteps[i] : g.Smax, ownl ? c : 0, ownl);
+    QuadCursor<Mo>& cur2 = cur;
+    double z[NZ];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) z[j] = 0.0;
+    if (ALG == 1) z[2] = ownl ? yT[(long)c * g.Npad + i] : 0.0;
+    double gacc = 0.0;
+    int cur_time = g.M, bs_cur = g.nck;
+    double t_loss = g.M > 0 ? save_t[g.M - 1] : 0.0;
+    if (ALG == 1 && bs_cur >= 1 && time_hits(g.t1, ck_t[bs_cur - 1])) --bs_cur;
+    double t_ck = (ALG == 1 && ckpt && bs_cur >= 1) ? ck_t[bs_cur - 1] : 0.0;
+
+    auto rhs = [&](double (&dz)[NZ], const double (&zz)[NZ], double t) {
+        double dl, dm;
+        if constexpr (ALG == 1) {
+            double fc;
+            QA::vjp_f(kc, zz[2], zz[0], t, dl, dm, fc);
+            dz[0] = -dl; dz[1] = -dm; dz[2] = fc;
+        } else {
+            const double yc = cur.eval(t);
+            QA::template vjp<ALG == 0>(kc, yc, zz[0], t, dl, dm);
+            dz[0] = -dl;
+            if constexpr (ALG == 0) dz[1] = -dm;
+        }
+    };
+    auto cb = [&](double t, double tprev, double (&zz)[NZ], const auto& KK) -> bool {
+        bool mod = false;
+        if (ALG == 2 && t != tprev) {   // IntegratingSumCallback: 3-point Gauss-Legendre of -(df/dp)^T lam on [tprev, t], this lane's parameter
+            const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;
+#pragma unroll 1
+            for (int q = 0; q < 3; ++q) {
+                const double xq = q == 0 ? -0.7745966692414833770 : (q == 1 ? 0.0 : 0.7745966692414833770);
+                const double wq = q == 1 ? 8.0 / 9.0 : 5.0 / 9.0;
+                const double tt = half * xq + mid;
+                double lamq[1];
+                kstore_interp<NZ, 1>(KK, (tt - tprev) / h, h, lamq);
+                const double yc = cur2.eval(tt);
+                double dl, dm;
+                QA::template vjp<true>(kc, yc, lamq[0], tt, dl, dm);
+                gacc += half * wq * (-dm);
+            }
+        }
+        if (ALG == 1 && ckpt && bs_cur >= 1 && time_hits(t, t_ck)) {               // backsolve_checkpoint_callbacks
+            zz[NZ - 1] = ownl ? ckpt[((long)(bs_cur - 1) * N + c) * g.Npad + i] : 0.0;
+            --bs_cur; mod = true;
+            t_ck = bs_cur >= 1 ? ck_t[bs_cur - 1] : 0.0;
+        }
+        if (cur_time >= 1 && time_hits(t, t_loss)) {                                  // ReverseLossCallback
+            if (!(g.no_start && ALG != 1 && cur_time == 1)) {
+                double yc;
+                if (ALG == 1) yc = zz[NZ - 1]; else yc = cur.eval(t);
+                if (ownl) zz[0] += (g.loss_kind == 0) ? cotT[((long)(cur_time - 1) * N + c) * g.Npad + i] : (yc - g.loss_shift);
+                mod = true;
+            }
+            --cur_time;
+            t_loss = cur_time >= 1 ? save_t[cur_time - 1] : 0.0;
+        }
+        return mod;
+    };
+    const bool cb_at_init = g.M > 0 && time_hits(g.t1, save_t[g.M - 1]);
+    const int ncomp = ALG == 0 ? N + NP : (ALG == 1 ? 2 * N + NP : N);
+    const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.maxit, K, rhs, cb, NoPre(), QuadNorm{ncomp});
+    if (ownl) du0[i * N + c] = z[0];
+    if (ownm) dp_traj[(long)c * g.Npad + i] = (ALG == 2) ? gacc : z[1 < NZ ? 1 : 0];
+    if (na < 0 && c == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(flag, 4);
+#endif
+    }
+}
+
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+template <class Mo>
+__global__ void __launch_bounds__(64) k_forward_tsit5_quad(AdaptGeom g, const double* __restrict__ u0, const double* __restrict__ p,
+                                                           double* __restrict__ rec, int* __restrict__ nsteps, const double* __restrict__ save_t,
+                                                           double* __restrict__ outT, const double* __restrict__ ck_t, double* __restrict__ ckpt,
+                                                           double* __restrict__ yT, int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (i >= g.N) return;                      // whole quads leave together
+    if constexpr (QuadForm<Mo>::value) forward_tsit5_quad<Mo>(g, i, threadIdx.x & 3, u0, p, rec, nsteps, save_t, outT, ck_t, ckpt, yT, flag);
+}
+template <class Mo, int ALG>
+__global__ void __launch_bounds__(64) k_adjoint_tsit5_quad(AdaptGeom g, const double* __restrict__ p, const double* __restrict__ rec,
+                                                           const int* __restrict__ nsteps, const double* __restrict__ yT, const double* __restrict__ ckpt,
+                                                           const double* __restrict__ ck_t, const double* __restrict__ save_t,
+                                                           const double* __restrict__ tstops_desc, int ntstops, const double* __restrict__ cotT,
+                                                           double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (i >= g.N) return;
+    if constexpr (QuadAdj<Mo>::value) adjoint_tsit5_quad<Mo, ALG>(g, i, threadIdx.x & 3, p, rec, nsteps, yT, ckpt, ck_t, save_t, tstops_desc, ntstops, cotT, du0, dp_traj, flag);
+}
+#endif
+
+}  // namespace hipadj
