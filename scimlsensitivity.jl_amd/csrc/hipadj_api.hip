@@ -1145,6 +1145,80 @@ static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* 
     if (h->adaptive) { DISPATCH_MODEL(h, adaptive_forward, h, d_u0, d_p, d_out); }
     DISPATCH_MODEL(h, forward_impl, h, d_u0, d_p, d_out);
 }
+
+// Ground truth for a disagreement between the -O3 and the -O1 build of a reverse kernel ("which build reproduces itself" cannot tell when a
+// build is wrong in a reproducible way).  Neither build is asked: the directional derivative of the loss along random directions (d in u0, e in p) is taken by
+// central differences THROUGH THE FORWARD KERNEL (small, never one of the heavily spilling kernels) on the handle's own inputs,
+//     D = [L(u0 + eps d, p + eps e) - L(u0 - eps d, p - eps e)] / (2 eps),   L = sum_i <Delta_i, u(t_i)>  or  sum_i |u(t_i) - shift|^2 / 2,
+// and compared with  A = <du0, d> + <dp, e>  of each candidate.  Returns in `err[c]` the worst relative error |A - D| / |D| over the directions.
+// Available on the fixed step without a continuous cost (differences through an adaptive solve carry its step-size noise; the cost integral is not formed by the
+// forward kernel); `avail` says so.  The forward solution of the handle is restored before returning (one more forward solve on the original inputs).
+static int user_ground_truth(hipadj_handle* h, const double* d_cot, const std::vector<double>* cand_du0[2], const std::vector<double>* cand_dp[2], double (&err)[2], bool& avail) {
+    avail = false; err[0] = err[1] = 1e300;
+    if (h->adaptive || h->cfg.cont_cost != 0 || h->M <= 0 || std::getenv("HIPADJ_RTC_NO_GROUND_TRUTH")) return HIPADJ_OK;
+    const size_t N = (size_t)h->N, n = (size_t)h->n, np = (size_t)h->np, M = (size_t)h->M;
+    const size_t n0 = N * n, n1 = h->cfg.p_shared ? np : N * np, no = N * M * n;
+    std::vector<double> u0(n0), p(n1), cot, outp(no), outm(no), up(n0), pp(n1), d(n0), e(n1);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(u0.data(), h->d_u0, sizeof(double) * n0, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(p.data(), h->d_p, sizeof(double) * n1, hipMemcpyDeviceToHost));
+    const bool cotl = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT;
+    if (cotl) { cot.resize(no); HIP_TRY(h, hipMemcpy(cot.data(), d_cot, sizeof(double) * no, hipMemcpyDeviceToHost)); }
+    double *d_u = nullptr, *d_pp = nullptr, *d_o = nullptr;
+    auto release = [&]() { if (d_u) (void)hipFree(d_u); if (d_pp) (void)hipFree(d_pp); if (d_o) (void)hipFree(d_o); };
+    if (hipMalloc(&d_u, sizeof(double) * n0) != hipSuccess || hipMalloc(&d_pp, sizeof(double) * n1) != hipSuccess || hipMalloc(&d_o, sizeof(double) * no) != hipSuccess) { release(); return HIPADJ_OK; }
+    double us = 1.0, ps = 1.0;
+    for (double v : u0) us = std::max(us, std::fabs(v));
+    for (double v : p) ps = std::max(ps, std::fabs(v));
+    const double eps = 1e-6;
+    unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return ((double)(lcg >> 11) / 9007199254740992.0) * 2.0 - 1.0; };
+    // the jump at t0 is suppressed under no_start (src/adjoint_common.jl:761): that save time does not enter the loss
+    const bool skip0 = h->cfg.no_start && h->save_times.size() > 0 && std::fabs(h->save_times[0] - h->cfg.t0) <= 1e-12 * std::max(1.0, std::fabs(h->cfg.t0));
+    auto loss_diff = [&]() {      // L(+) - L(-)
+        double s = 0.0;
+        for (size_t i = 0; i < N; ++i) for (size_t m = skip0 ? 1 : 0; m < M; ++m) for (size_t j = 0; j < n; ++j) {
+            const size_t o = (i * M + m) * n + j;
+            if (cotl) s += cot[o] * (outp[o] - outm[o]);
+            else { const double a = outp[o] - h->cfg.loss_shift, b = outm[o] - h->cfg.loss_shift; s += 0.5 * (a * a - b * b); }
+        }
+        return s;
+    };
+    int rc = HIPADJ_OK;
+    double worst[2] = {0.0, 0.0};
+    for (int dir = 0; dir < 2 && rc == HIPADJ_OK; ++dir) {
+        for (auto& v : d) v = rnd() * us;
+        for (auto& v : e) v = rnd() * ps;
+        for (int sgn = 0; sgn < 2 && rc == HIPADJ_OK; ++sgn) {
+            const double sg = sgn == 0 ? eps : -eps;
+            for (size_t k = 0; k < n0; ++k) up[k] = u0[k] + sg * d[k];
+            for (size_t k = 0; k < n1; ++k) pp[k] = p[k] + sg * e[k];
+            if (hipMemcpy(d_u, up.data(), sizeof(double) * n0, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_pp, pp.data(), sizeof(double) * n1, hipMemcpyHostToDevice) != hipSuccess) { rc = HIPADJ_ERR_HIP; break; }
+            rc = forward_dispatch(h, d_u, d_pp, d_o);
+            if (rc == HIPADJ_OK && (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy((sgn == 0 ? outp : outm).data(), d_o, sizeof(double) * no, hipMemcpyDeviceToHost) != hipSuccess)) rc = HIPADJ_ERR_HIP;
+        }
+        if (rc != HIPADJ_OK) break;
+        const double D = loss_diff() / (2.0 * eps);
+        for (int c = 0; c < 2; ++c) {
+            double A = 0.0;
+            for (size_t k = 0; k < n0; ++k) A += (*cand_du0[c])[k] * d[k];
+            for (size_t k = 0; k < n1; ++k) A += (*cand_dp[c])[k] * e[k];
+            const double r = std::isfinite(A) ? std::fabs(A - D) / std::max(std::fabs(D), 1e-300) : 1e300;
+            worst[c] = std::max(worst[c], r);
+        }
+    }
+    // the handle's forward solution back on the original inputs (the reverse pass that follows reads it)
+    if (hipMemcpy(d_u, u0.data(), sizeof(double) * n0, hipMemcpyHostToDevice) == hipSuccess) {
+        const int rr = forward_dispatch(h, d_u, h->d_p, nullptr);
+        if (rr != HIPADJ_OK) rc = rr;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = HIPADJ_ERR_HIP;
+    } else rc = HIPADJ_ERR_HIP;
+    (void)hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream);
+    release();
+    if (rc != HIPADJ_OK) return rc;
+    err[0] = worst[0]; err[1] = worst[1]; avail = true;
+    return HIPADJ_OK;
+}
 // The first reverse pass of a runtime model whose reverse kernel spills heavily (user_prepare): run the -O3 build, then the -O1 build, compare
 // du0 and dp on the host.  Agreement (1e-9 relative, and no non-finite flag from the -O3 run): the -O3 build stays.  Otherwise the -O1 build is
 // used from here on and a note goes to stderr.  The outputs handed back are those of the build that stays.  This FIRST reverse pass of such a handle
@@ -1180,7 +1254,32 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     };
     const bool bad = (flag_b & 1) || differ(b0, a0) || differ(b1, a1);
     if (bad && !(flag_a & 1)) {
-        // A disagreement says that ONE of the builds is wrong.  Every reverse kernel is bit-reproducible on fixed inputs (fixed summation orders, no
+        // A disagreement says that ONE of the builds is wrong.  Ask neither: central differences of the loss through the forward kernel (user_ground_truth).
+        {
+            const std::vector<double>* c0[2] = {&a0, &b0}; const std::vector<double>* c1[2] = {&a1, &b1};     // 0: the -O1 build, 1: the -O3 build
+            double gerr[2]; bool avail = false;
+            TRY(user_ground_truth(h, d_cot, c0, c1, gerr, avail));
+            if (avail) {
+                const double GT_TOL = 1e-4;      // central differences at eps = 1e-6 are good to ~1e-8 on smooth problems; a miscompiled kernel is off by O(1)
+                const bool ok1 = gerr[0] < GT_TOL, ok3 = gerr[1] < GT_TOL && !(flag_b & 1);
+                if (ok3 && (!ok1 || gerr[1] <= gerr[0])) {          // the -O3 build is right (its outputs are in place: it ran last... before the ground truth's forward solves; re-run for the outputs)
+                    h->rtc_selftest = 4;
+                    std::fprintf(stderr, "hipadj: the -O1 build of the reverse kernel of runtime model %d disagrees with its -O3 build; finite differences of the forward solve side with the -O3 build (relative error %.1e vs %.1e): keeping it (DESIGN.md 6.8)\n", h->cfg.model, gerr[1], gerr[0]);
+                    HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+                    return user_adjoint_run(h, d_cot, d_du0, d_dp);
+                }
+                if (ok1) {
+                    h->rtc_selftest = 3;
+                    std::swap(h->uf_main, h->uf_main_alt);          // the -O1 build from here on
+                    std::fprintf(stderr, "hipadj: the -O3 build of the reverse kernel of runtime model %d disagrees with its -O1 build on the first reverse pass; finite differences of the forward solve side with the -O1 build (relative error %.1e vs %.1e): using the -O1 build (DESIGN.md 6.8)\n", h->cfg.model, gerr[0], gerr[1]);
+                    HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+                    return user_adjoint_run(h, d_cot, d_du0, d_dp);
+                }
+                h->rtc_selftest = 1;
+                HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "the -O3 and -O1 builds of the reverse kernel of runtime model %d disagree and NEITHER matches finite differences of the forward solve (relative errors %.1e / %.1e): no trustworthy build (DESIGN.md 6.8)", h->cfg.model, gerr[1], gerr[0]);
+            }
+        }
+        // No ground truth for this configuration (adaptive stepper, continuous cost): the older tie-break.  Every reverse kernel is bit-reproducible on fixed inputs (fixed summation orders, no
         // arrival-order dependence), so the tie-break is a second run of each: the -O1 build is used if it reproduces itself (the case this test was
         // written for); if it does not, but the -O3 build does, the -O3 build stays (seen once: a one-launch Backsolve kernel of an 8-state model whose
         // -O1 build gave different wrong answers on every run); if neither does, the handle refuses to hand out gradients.
@@ -1233,6 +1332,8 @@ extern "C" int hipadj_forward_dev(hipadj_handle* h, const double* d_u0, const do
     const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
     if (d_p != h->d_p) HIP_TRY(h, hipMemcpyAsync(h->d_p, d_p, pb, hipMemcpyDeviceToDevice, h->stream));
     h->p_dev_last = h->d_p;
+    // a runtime model whose two builds still have to be compared: the arbiter of a disagreement (user_ground_truth) differentiates the forward solve around THESE inputs
+    if (h->rtc_selftest == 1 && d_u0 != h->d_u0) HIP_TRY(h, hipMemcpyAsync(h->d_u0, d_u0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyDeviceToDevice, h->stream));
     if (h->d_tcnt) {   // arrival counters of the one-launch reverse pass: each is reset by its last arriver; a pass that died half-way (a faulting
                        // user model) must not poison the next solve, so every forward solve starts from zeros (in stream order, off the reverse path)
         HIP_TRY(h, hipMemsetAsync(h->d_tcnt, 0, sizeof(unsigned) * (size_t)h->tcnt_n, h->stream));
