@@ -153,7 +153,7 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
     return HIPADJ_OK;
 }
 
-static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int cost = 0) {
+static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int cost = 0, bool ip_ckpt = false) {
     // the reverse kernels of a handle with a built-in continuous cost are instantiated for WideWithCost<UserW, kind> (hipadj_wide.hpp); the forward solve never sees the cost
     const std::string U = cost ? "hipadj::WideWithCost<hipadj::UserW, " + std::to_string(cost) + ">" : std::string("hipadj::UserW");
     if (ts5) {
@@ -164,9 +164,9 @@ static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int
     }
     std::vector<std::string> e = {"hipadj::k_wide_forward<hipadj::UserW>"};
     switch (alg) {
-    case HIPADJ_ALG_INTERPOLATING: e.push_back("hipadj::k_wide_adjoint<" + U + ", 0>"); break;
-    case HIPADJ_ALG_GAUSS: e.push_back("hipadj::k_wide_adjoint<" + U + ", 2>"); break;
-    case HIPADJ_ALG_GAUSS_KRONROD: e.push_back("hipadj::k_wide_adjoint<" + U + ", 4>"); break;
+    case HIPADJ_ALG_INTERPOLATING: e.push_back(std::string("hipadj::k_wide_adjoint") + (ip_ckpt ? "_ck<" : "<") + U + ", 0>"); break;
+    case HIPADJ_ALG_GAUSS: e.push_back(std::string("hipadj::k_wide_adjoint") + (ip_ckpt ? "_ck<" : "<") + U + ", 2>"); break;
+    case HIPADJ_ALG_GAUSS_KRONROD: e.push_back(std::string("hipadj::k_wide_adjoint") + (ip_ckpt ? "_ck<" : "<") + U + ", 4>"); break;
     case HIPADJ_ALG_BACKSOLVE: e.push_back("hipadj::k_wide_backsolve<" + U + ">"); break;
     case HIPADJ_ALG_QUADRATURE: e.push_back("hipadj::k_wide_quad_adj<" + U + ">"); e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", false>"); break;
     default: break;
@@ -343,6 +343,10 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
                 if (h->ntstops > 0) ok2 = ok2 && HT(hipMemcpy(h->d_tstops, P.tstops_desc.data(), sizeof(double) * h->ntstops, hipMemcpyHostToDevice), "memcpy");
                 if (!ok2) rc = HIPADJ_ERR_HIP;
             }
+        } else if (P.ip_ckpt) {   // checkpointing = true for Interpolating / Gauss / GaussKronrod (k_wide_adjoint_ck): the states at the checkpoint knots + one re-solve tile per trajectory
+            h->wide_KT = P.ck_longest + 1;
+            A(dev_alloc(h, &h->d_fknots, (size_t)h->N * h->wide_KT * 2 * n));
+            A(dev_alloc(h, &h->d_ckpt, (size_t)h->N * h->nck * n));
         } else if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));
         else {
             A(dev_alloc(h, &h->d_yT, (size_t)h->N * n));
@@ -799,7 +803,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     h.cfg = *cfg; h.cfg.save_times = nullptr; h.cfg.checkpoints = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
-    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg, P.adaptive, cfg->cont_cost), code, low, err); }
+    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg, P.adaptive, cfg->cont_cost, P.ip_ckpt), code, low, err); }
     h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
     h.fused = fused_eligible(cfg, P) ? 1 : 0;
     const UserKernels k = user_kernel_names(&h);
@@ -1044,7 +1048,7 @@ static int wide_prepare(hipadj_handle* h) {
             HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide model %d: Interpolating- / BacksolveAdjoint on the adaptive solution need %ld KB of LDS (state tiles + scratch + 5 np + the parameter copy), a workgroup has 160 KB — use GaussAdjoint, whose sweep integrates lam only",
                         h->cfg.model, lds / 1024);
     }
-    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5, h->cfg.cont_cost);
+    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5, h->cfg.cont_cost, h->ip_ckpt);
     std::vector<char> code; std::map<std::string, std::string> low;
     const int rc = user_compile(h->cfg.model, exprs, code, low, h->err);
     if (rc != HIPADJ_OK) return rc;
@@ -1064,10 +1068,10 @@ static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
                     bs ? h->d_yT : (double*)nullptr, h->d_flag));
         return HIPADJ_OK;
     }
-    const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE;
+    const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE, ck = h->ip_ckpt;
     TRY(usig<decltype(&k_wide_forward<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, d_u0, d_p,
-                bs ? (double*)nullptr : h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot,
-                (bs && h->nck > 0) ? h->d_ckpt : (double*)nullptr, (const int*)h->d_ckpt_of_knot, bs ? h->d_yT : (double*)nullptr));
+                (bs || ck) ? (double*)nullptr : h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot,
+                ((bs || ck) && h->nck > 0) ? h->d_ckpt : (double*)nullptr, (const int*)h->d_ckpt_of_knot, bs ? h->d_yT : (double*)nullptr));
     return HIPADJ_OK;
 }
 
@@ -1101,6 +1105,10 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
     } else
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:
+        if (h->ip_ckpt)
+            TRY(usig<decltype(&k_wide_adjoint_ck<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck,
+                        h->d_fknots, h->wide_KT, d_cot, (const int*)h->d_save_rev, d_du0, rows, h->d_flag, h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD ? h->d_wscr : (double*)nullptr));
+        else
         TRY(usig<decltype(&k_wide_adjoint<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, rows, h->d_flag,
                     h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD ? h->d_wscr : (double*)nullptr));
         break;

@@ -189,7 +189,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
             err = "wide models: Interpolating- / BacksolveAdjoint on the adaptive solution keep five parameter-sized rows in LDS (np <= 8192 at most; the exact budget is checked when the handle is created) — GaussAdjoint has no such limit"; return HIPADJ_ERR_UNSUPPORTED; }
         if (ts5 && cfg->alg != HIPADJ_ALG_BACKSOLVE && (cfg->checkpointing || cfg->ncheckpoints > 0)) { err = "wide models: Gauss- / InterpolatingAdjoint on adaptive Tsit5 keep the dense forward solution (checkpointing = false, no checkpoint list)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->cont_cost == HIPADJ_CCOST_MODEL) { err = "wide models: the built-in continuous costs (HIPADJ_CCOST_HALF_SQ_SUM, HIPADJ_CCOST_U1SQ_PLUS_P1) are offered; a cost attached as text is a feature of the lane-per-trajectory family"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (!ts5 && cfg->checkpointing && cfg->alg != HIPADJ_ALG_BACKSOLVE) { err = "wide models: checkpointing = true is available for BacksolveAdjoint (Interpolating / Gauss keep the dense knots)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (!ts5 && cfg->checkpointing && cfg->alg == HIPADJ_ALG_QUADRATURE) { err = "wide models: QuadratureAdjoint keeps the dense forward solution (its second pass integrates over it); checkpointing = true is offered for Interpolating / Gauss / GaussKronrod / BacksolveAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (P.mlp) {
         if (cfg->dims[0] != 2) { err = "MLP family: state width d must be 2 (docs/src/Benchmark.md:62 shape)"; return HIPADJ_ERR_UNSUPPORTED; }
@@ -205,8 +205,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_GAUSS_KRONROD) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (P.field || P.mlp)) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
-    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && cfg->stepper == HIPADJ_STEPPER_RK4_FIXED && cfg->checkpointing) {
-        err = "GaussKronrodAdjoint(checkpointing=true) is offered with adaptive Tsit5 only"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && cfg->stepper == HIPADJ_STEPPER_RK4_FIXED && cfg->checkpointing && !P.wide) {
+        err = "GaussKronrodAdjoint(checkpointing=true) on the fixed step is offered for wide models; the lane family has it with adaptive Tsit5"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {
         // adaptive path: no step grid; arbitrary ascending loss times inside [t0, t1]
@@ -319,7 +319,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     // checkpoints: BacksolveAdjoint only.  Interpolating/Gauss checkpointing re-solves, on this fixed grid,
     // bit-identical knots from the stored values; the dense tiles are kept instead.
     P.bs_ckpt = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->checkpointing;
-    P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && cfg->checkpointing && !P.field && !P.mlp && !P.wide;
+    P.ip_ckpt = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || (P.wide && cfg->alg == HIPADJ_ALG_GAUSS_KRONROD)) && cfg->checkpointing && !P.field && !P.mlp;   // wide models: k_wide_adjoint_ck
     P.nck = P.offgrid ? (int)P.ck_times.size() : 0;   // off-grid Backsolve: checkpoint TIMES (interpolated states), not knots
     if ((P.bs_ckpt || P.ip_ckpt) && !P.offgrid) {
         int c = 0;
@@ -340,7 +340,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }
         P.nck = c;
     }
-    if (P.ip_ckpt && P.user && (1 + n) * (n + np) > 64) {   // the checkpointed sweeps carry the 1 + n segment columns in VGPRs next to the re-solve state (not re-measured beyond 64)
+    if (P.ip_ckpt && P.user && !P.wide && (1 + n) * (n + np) > 64) {   // the checkpointed sweeps carry the 1 + n segment columns in VGPRs next to the re-solve state (not re-measured beyond 64)
         err = "checkpointing=true for Interpolating/Gauss on the fixed step needs (1 + n)(n + np) <= 64 for a runtime-compiled model (wider models: the adaptive stepper)"; return HIPADJ_ERR_UNSUPPORTED; }
     P.prev_ck.assign(S + 1, 0);
     if (P.ip_ckpt) {

@@ -421,31 +421,14 @@ __device__ __forceinline__ void wide_gk_panels(const WideTiles<Mo>& L, double* _
 
 // ---- InterpolatingAdjoint (ALG = 0) and GaussAdjoint (ALG = 2): one sweep; Gauss integrates lam only and adds the 2-node Gauss-Legendre sum of
 // f_p^T lam per step with lam from the adjoint step's own Hermite interpolant (IntegratingSumCallback [upstream-recall], src/gauss_adjoint.jl:809-851)
+// one reverse step [t_k, t_{k+1}] of the Interpolating / Gauss / GaussKronrod sweep on the knots (hi = k + 1, lo = k), followed by the loss jump at t_k
 template <class Mo, int ALG>
-__global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
-                                                        const int* __restrict__ save_of_knot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
-                                                        double* __restrict__ gk_scratch) {
+__device__ __forceinline__ void wide_adjoint_step(const WideGeom& g, const WideTiles<Mo>& L, const double* __restrict__ pp, long traj, int k, const WKnot<Mo>& hi, const WKnot<Mo>& lo,
+                                                  double (&lam)[WideShape<Mo>::Q], double (&acc)[WideShape<Mo>::NA], const double* __restrict__ cot, const int* __restrict__ save_of_knot,
+                                                  double* __restrict__ gk_scratch, double* __restrict__ sgk) {
     using W = WideShape<Mo>;
-    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
-    static_assert(ALG == 0 || ALG == 2 || ALG == 4, "Interpolating, Gauss (2-node rule per step), GaussKronrod (adaptive (7,15) rule per step)");
-    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * (ALG == 4 ? 2 * W::NA : W::NA) + 2], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
-    __shared__ double sgk[ALG == 4 ? 2 * W::NA + 1 : 1];
-    const long traj = blockIdx.x;
-    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
-    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
-    wide_zero_gp<Mo>(L);
-    double lam[Q], acc[W::NA];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) lam[q] = 0.0;
-#pragma unroll
-    for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
-    WKnot<Mo> hi, lo, nx;
-    wide_load_knot<Mo>(knots, g, traj, g.S, hi);
-    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam); }   // PresetTimeCallback fires at initialisation when T is a loss time
-    wide_load_knot<Mo>(knots, g, traj, g.S - 1, lo);
+    constexpr int NP = W::NP, T = W::T, Q = W::Q;
     const double dt = g.dt, xg = 0.5773502691896257645;
-    for (int k = g.S - 1; k >= 0; --k) {
-        wide_load_knot<Mo>(knots, g, traj, k > 0 ? k - 1 : 0, nx);        // one knot ahead of the step
         const double t_lo = g.t0 + k * dt;
         double v1[Q];
         if (ALG == 0) {
@@ -490,7 +473,116 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double
             }
         }
         { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) wide_jump<Mo>(g, traj, s, cot, lo.u, lam); }
+}
+
+template <class Mo, int ALG>
+__global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
+                                                        const int* __restrict__ save_of_knot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
+                                                        double* __restrict__ gk_scratch) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    static_assert(ALG == 0 || ALG == 2 || ALG == 4, "Interpolating, Gauss (2-node rule per step), GaussKronrod (adaptive (7,15) rule per step)");
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * (ALG == 4 ? 2 * W::NA : W::NA) + 2], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    __shared__ double sgk[ALG == 4 ? 2 * W::NA + 1 : 1];
+    const long traj = blockIdx.x;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
+    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
+    wide_zero_gp<Mo>(L);
+    double lam[Q], acc[W::NA];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
+    WKnot<Mo> hi, lo, nx;
+    wide_load_knot<Mo>(knots, g, traj, g.S, hi);
+    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam); }   // PresetTimeCallback fires at initialisation when T is a loss time
+    wide_load_knot<Mo>(knots, g, traj, g.S - 1, lo);
+    for (int k = g.S - 1; k >= 0; --k) {
+        wide_load_knot<Mo>(knots, g, traj, k > 0 ? k - 1 : 0, nx);        // one knot ahead of the step
+        wide_adjoint_step<Mo, ALG>(g, L, pp, traj, k, hi, lo, lam, acc, cot, save_of_knot, gk_scratch, sgk);
         hi = lo; lo = nx;
+    }
+    wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
+}
+
+
+// ---- the same sweeps with checkpointing = true (src/interpolating_adjoint.jl:54-109, 207-277; round 4): no dense knots — the forward solve stores the state at the
+// checkpoint knots only ([N][nck][n], as for Backsolve), and the sweep re-solves one checkpoint interval at a time, top interval first, from its lower checkpoint
+// into a per-trajectory tile of (longest interval + 1) knots in HBM (written and read back by the same thread: no barrier), then walks the tile downward.  On the
+// fixed step the re-solve repeats the forward solve's arithmetic on the stored values, so the knots — and du0, dp — are those of the dense sweep bit for bit
+// (the user's dt is kept: DESIGN.md 6.1).  Memory: nck n + (K + 1) 2 n doubles per trajectory instead of (S + 1) 2 n.
+template <class Mo>
+__device__ __forceinline__ void wide_load_knot_at(const double* __restrict__ b, WKnot<Mo>& kn) {
+    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; kn.u[q] = c < N ? b[c] : 0.0; kn.f[q] = c < N ? b[N + c] : 0.0; }
+}
+template <class Mo, int ALG>
+__global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ck(WideGeom g, const double* __restrict__ p, const double* __restrict__ ckpt, const int* __restrict__ ckpt_of_knot,
+                                                           const int* __restrict__ prev_ck, double* __restrict__ tiles, int KT, const double* __restrict__ cot,
+                                                           const int* __restrict__ save_of_knot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
+                                                           double* __restrict__ gk_scratch) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    static_assert(ALG == 0 || ALG == 2 || ALG == 4, "Interpolating, Gauss, GaussKronrod");
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * (ALG == 4 ? 2 * W::NA : W::NA) + 2], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    __shared__ double sgk[ALG == 4 ? 2 * W::NA + 1 : 1];
+    const long traj = blockIdx.x; const int tid = threadIdx.x;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
+    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
+    wide_zero_gp<Mo>(L);
+    double lam[Q], acc[W::NA];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
+    double* __restrict__ tile = tiles + traj * (long)KT * 2 * N;
+    auto rhs = [&](const double (&x)[Q], double t, double (&kk)[Q]) {      // f at a stage state: the forward solve's own form (k_wide_forward), on the sweep's tiles
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) sy[c] = x[q]; }
+        wide_sync<T>();
+        Mo::f(sdl, sy, pp, t, sws, tid);
+        wide_sync<T>();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; kk[q] = c < N ? sdl[c] : 0.0; }
+    };
+    const double dt = g.dt;
+    bool top = true;
+    for (int khi = g.S; khi > 0;) {
+        const int klo = prev_ck[khi], slot = ckpt_of_knot[klo], len = khi - klo;
+        {   // re-solve [t_klo, t_khi] from the stored state
+            double u[Q], k1[Q], k2[Q], k3[Q], k4[Q], s_[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; u[q] = c < N ? ckpt[(traj * g.nck + slot) * N + c] : 0.0; }
+            for (int j = 0; j <= len; ++j) {
+                const double t = g.t0 + (klo + j) * dt;
+                rhs(u, t, k1);
+                double* kn = tile + (long)j * 2 * N;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { kn[c] = u[q]; kn[N + c] = k1[q]; } }
+                if (j == len) break;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) s_[q] = u[q] + 0.5 * dt * k1[q];
+                rhs(s_, t + 0.5 * dt, k2);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) s_[q] = u[q] + 0.5 * dt * k2[q];
+                rhs(s_, t + 0.5 * dt, k3);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) s_[q] = u[q] + dt * k3[q];
+                rhs(s_, t + dt, k4);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) u[q] = u[q] + (dt / 6.0) * (k1[q] + 2.0 * (k2[q] + k3[q]) + k4[q]);
+            }
+        }
+        WKnot<Mo> hi, lo;
+        wide_load_knot_at<Mo>(tile + (long)len * 2 * N, hi);
+        if (top) { top = false; const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam); }   // PresetTimeCallback fires at initialisation when T is a loss time
+        for (int k = khi - 1; k >= klo; --k) {
+            wide_load_knot_at<Mo>(tile + (long)(k - klo) * 2 * N, lo);
+            wide_adjoint_step<Mo, ALG>(g, L, pp, traj, k, hi, lo, lam, acc, cot, save_of_knot, gk_scratch, sgk);
+            hi = lo;
+        }
+        khi = klo;
     }
     wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
 }

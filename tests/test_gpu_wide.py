@@ -303,3 +303,41 @@ def test_gauss_kronrod_on_wide_models(sa, stepper, model, cost):
     tol = RTOL if stepper == "rk4" else 1e-7
     assert rel(res["gk"][0], rdu0) < tol and rel(res["gk"][1], rdp) < tol
     assert rel(res["gk"][1], res["gauss"][1]) < 1e-5
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")])
+@pytest.mark.parametrize("model", ["idxaff", "chain", "linear"])
+@pytest.mark.parametrize("ckpts", ["default", "stride7", "list"])
+def test_checkpointing_on_wide_models_fixed_step(sa, alg, oalg, model, ckpts):
+    """checkpointing = true for Interpolating / Gauss / GaussKronrod on a wide model (src/interpolating_adjoint.jl:54-109, 207-277): the forward solve keeps
+    the checkpoint states only, the sweep re-solves interval by interval (k_wide_adjoint_ck).  On the fixed step the re-solved knots are the forward solve's own, so
+    du0 / dp equal the dense sweep's BIT FOR BIT, and the oracle's checkpointed run at rtol 1e-6; the workspace shrinks."""
+    rng = np.random.default_rng(29)
+    if model == "idxaff":
+        fun, omodel, dims, n, npar = sa.WideDeviceFunction.index_affine("ck_idx", 30, 50), "IDXAFF", (30, 50, 0, 0), 1500, 2
+    elif model == "chain":
+        fun, omodel, dims, n, npar = sa.WideDeviceFunction.dense_chain("ck_chain", (2, 50, 2), input_power=3), "MLP1", (2, 50, 0, 0), 2, 252
+    else:
+        fun, omodel, dims, n, npar = sa.WideDeviceFunction.dense_linear("ck_lin", 12), "DENSELIN", (12, 0, 0, 0), 12, 144
+    N, T, dt = 4, 0.6, 0.01
+    ts = np.array([0.0, 0.1, 0.25, 0.4, 0.6]) if ckpts != "default" else np.linspace(0.0, T, 7)
+    u0 = rng.uniform(0.3, 1.0, (N, n)); p = rng.uniform(-0.4, 0.4, npar)
+    delta = rng.standard_normal((N, len(ts), n))
+    kw = dict(default={}, stride7=dict(ckpt_stride=7), list=dict(checkpoints=[0.07, 0.3, 0.31, 0.55]))[ckpts]
+    res, wsb = [], []
+    for ck in (False, True):
+        eng = sa.Engine(fun.name, alg, N, 0.0, T, dt, save_times=ts, checkpointing=ck, **(kw if ck else {}))
+        eng.forward(u0, p)
+        res.append(eng.adjoint(delta))
+        wsb.append(eng.stats()["workspace_bytes"])
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert wsb[1] < wsb[0]
+    if alg == "gausskronrod" and npar > 64:
+        return                      # the oracle's GK restatement holds its np-vectors on the stack (ORC_MAXNP_COST = 64); bit-equality with the dense sweep is the statement here
+    okw = dict(checkpoints=kw["checkpoints"]) if ckpts == "list" else {}
+    if ckpts == "stride7":
+        okw = dict(checkpoints=[k * 7 * dt for k in range(0, 9)] + [T])
+    ref = O.Problem(omodel, alg=oalg, stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, checkpointing=True, dims=dims, **okw)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(res[1][0], rdu0) < 1e-6 and rel(res[1][1], rdp) < 1e-6

@@ -70,7 +70,10 @@ def test_planner_answers_for_wide_models(sa):
     assert check(alg=0, cont_cost=1)[0] == 0 and check(alg=3, cont_cost=2)[0] == 0
     assert check(alg=1, cont_cost=2, stepper=1, dt=0.0, checkpointing=1)[0] == 0 and check(alg=2, cont_cost=1, stepper=1, dt=0.0)[0] == 0
     rc, msg = check(cont_cost=3); assert rc == -6 and "built-in continuous costs" in msg
-    rc, msg = check(alg=0, checkpointing=1); assert rc == -6 and "checkpointing" in msg
+    # checkpointing = true on the fixed step (round 4, k_wide_adjoint_ck): Interpolating / Gauss / GaussKronrod re-solve checkpoint intervals; Quadrature keeps the dense solution
+    for alg in (0, 2, 4):
+        assert check(alg=alg, checkpointing=1)[0] == 0 and check(alg=alg, checkpointing=1, ckpt_stride=7)[0] == 0
+    rc, msg = check(alg=3, checkpointing=1); assert rc == -6 and "QuadratureAdjoint keeps the dense" in msg
     off = np.array([0.0, 0.333, 1.0])
     rc, msg = check(nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double))); assert rc == -6 and "step grid" in msg
 
