@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 106 /* 0.1.4: + hipadj_wmodel_register (wide runtime models: fixed-step RK4 and adaptive Tsit5, the four sensealgs + GaussKronrod, built-in continuous costs), hipadj_comm_count / _selfcheck, hipadj_stats.launches_per_pass; 0.1.3: + hipadj_runtime_compiler; 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
+#define HIPADJ_VERSION 107 /* 0.1.5: + hipadj_wmodel_set_cost (continuous cost of a wide model as an SPMD body), checkpointing = true for Interpolating / Gauss / GaussKronrod on wide models (fixed step); 0.1.4: + hipadj_wmodel_register (wide runtime models: fixed-step RK4 and adaptive Tsit5, the four sensealgs + GaussKronrod, built-in continuous costs), hipadj_comm_count / _selfcheck, hipadj_stats.launches_per_pass; 0.1.3: + hipadj_runtime_compiler; 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -174,6 +174,11 @@ int hipadj_model_set_cost(int32_t model_id, const char *dgdu_body, const char *d
 /* Same, from the cost itself: g_body assigns `g` (declared `real g`) from u, p, t with `real` locals; dg/du and dg/dp are
  * generated by forward-mode dual numbers — the reference's gradient!(g) fallback (src/derivative_wrappers.jl:1428-1441). */
 int hipadj_model_set_cost_function(int32_t model_id, const char *g_body);
+/* The continuous cost of a WIDE model (hipadj_wmodel_register) — dgdu_continuous / dgdp_continuous of adjoint_sensitivities for a model beyond the lane family — as ONE
+ * SPMD body with the conventions of its vjp body:  cost<WP>(dlam, gp, acc, w, u, p, t, ws, tid)  ADDS dg/du into dlam[0..n) (entry i from the thread that owns it:
+ * HIPADJ_W_FOR loops do) and, under `if (WP)`, w * dg/dp into gp[...] (entries owned by one thread) or acc[...] (the model's reduced parameters).  It is evaluated
+ * with every joint VJP (accumulate_cost!, src/derivative_wrappers.jl:1411-1442).  NULL / "" removes it.  Selected per handle with cont_cost = HIPADJ_CCOST_MODEL. */
+int hipadj_wmodel_set_cost(int32_t model_id, const char *cost_body);
 /* ODEFunction(f; mass_matrix = M) for a runtime-registered model: M u' = f(u, p, t) with a CONSTANT NON-SINGULAR n x n matrix M
  * (row-major; NULL removes it) — test/Core3/adjoint.jl:1315-1376.  The reference hands M to the forward solver and M' (resp.
  * [M' 0; 0 I], [M' 0 0; 0 I 0; 0 0 M]) to the adjoint problems (src/interpolating_adjoint.jl:413-426, src/backsolve_adjoint.jl:232-247,

@@ -1,7 +1,7 @@
 """
     HIPAdj
 
-Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 106) — the MI355X-native batched continuous-adjoint
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 107) — the MI355X-native batched continuous-adjoint
 engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
 
   * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, dense_chain_bodies, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -39,7 +39,7 @@ function lib()
     if LIB[] == C_NULL
         LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
         v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
-        v == 106 || error("libhipadj ABI version $v, this binding was written for 106")
+        v == 107 || error("libhipadj ABI version $v, this binding was written for 107")
     end
     return LIB[]
 end
@@ -195,6 +195,22 @@ function register_wide_model(name::AbstractString, n::Integer, np::Integer; f::A
     end
     check_now && check(ccall(sym(:hipadj_model_check), Cint, (Int32,), id[]))
     return DeviceModel(id[], (Int32(0), Int32(0), Int32(0), Int32(0)), Int(n), Int(np))
+end
+
+"""
+    set_wide_cost!(m::DeviceModel, body)
+
+The continuous cost of a wide model (`hipadj_wmodel_set_cost`, ABI 107): one SPMD body that adds `dg/du` into `dlam` and, under `if (WP)`, `w * dg/dp` into `gp` / `acc`
+— `dgdu_continuous` / `dgdp_continuous` of `adjoint_sensitivities` for a model of the workgroup-per-trajectory family.  `nothing` removes it.
+"""
+function set_wide_cost!(m::DeviceModel, body::Union{AbstractString, Nothing})
+    if body === nothing
+        check(ccall(sym(:hipadj_wmodel_set_cost), Cint, (Int32, Ptr{UInt8}), m.id, C_NULL))
+    else
+        sb = String(body)
+        GC.@preserve sb check(ccall(sym(:hipadj_wmodel_set_cost), Cint, (Int32, Ptr{UInt8}), m.id, pointer(sb)))
+    end
+    return m
 end
 
 """

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_wmodel_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
+    "hipadj_model_register", "hipadj_wmodel_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_wmodel_set_cost", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
     "hipadj_comm_count", "hipadj_comm_selfcheck",
 )
@@ -106,6 +106,7 @@ def load():
     L.hipadj_runtime_compiler.argtypes = [C.c_char_p, C.c_int32]
     L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_model_set_cost_function.argtypes = [C.c_int32, C.c_char_p]
+    L.hipadj_wmodel_set_cost.argtypes = [C.c_int32, C.c_char_p]
     L.hipadj_model_set_mass_matrix.argtypes = [C.c_int32, C.POINTER(C.c_double)]
     L.hipadj_model_set_affect.argtypes = [C.c_int32, C.c_char_p]
     L.hipadj_affect_apply.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -56,6 +56,10 @@ extern "C" int hipadj_model_set_cost_function(int32_t model_id, const char* g_bo
     return user_set_cost_function(model_id, g_body, g_create_error);
 }
 
+extern "C" int hipadj_wmodel_set_cost(int32_t model_id, const char* cost_body) {
+    return user_set_wide_cost(model_id, cost_body, g_create_error);
+}
+
 extern "C" int hipadj_model_set_mass_matrix(int32_t model_id, const double* M) {
     return user_set_mass_matrix(model_id, M, g_create_error);
 }
@@ -210,6 +214,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err);
 extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
     if (!cfg) { g_create_error = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->model < HIPADJ_MODEL_USER_BASE) return HIPADJ_OK;
+    if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { g_create_error = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost / hipadj_wmodel_set_cost)"; return HIPADJ_ERR_INVALID_ARG; }
     return user_compile_config(cfg, g_create_error);
 }
 
@@ -503,7 +508,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->st.adjoint_algorithmic_bytes = bytes;
     h->st.vjp_steps = (double)h->N * (double)S * 4.0;
     h->user = P.user;
-    if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { h->err = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost)"; return fail(HIPADJ_ERR_INVALID_ARG); }
+    if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { h->err = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost / hipadj_wmodel_set_cost)"; return fail(HIPADJ_ERR_INVALID_ARG); }
     if (P.wide) { const int urc = wide_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
     else if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); }
     *out = h;
@@ -1041,7 +1046,7 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
 
 // ---- wide runtime models: workgroup-per-trajectory family (hipadj_wide.hpp) ----------------------------------------------------------------
 static int wide_prepare(hipadj_handle* h) {
-    if (user_has_cost(h->cfg.model) || user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no cost / affect text (the built-in continuous costs are selected with cont_cost)");
+    if (user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no affect text");
     if (h->wide_ts5 && (h->cfg.alg == HIPADJ_ALG_INTERPOLATING || h->cfg.alg == HIPADJ_ALG_BACKSOLVE)) {
         const long lds = user_wide_ts5_interp_lds(h->cfg.model, h->cfg.alg == HIPADJ_ALG_BACKSOLVE) * 8;
         if (lds > 160L * 1024)

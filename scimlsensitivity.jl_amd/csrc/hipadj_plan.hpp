@@ -188,7 +188,6 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (ts5 && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_BACKSOLVE) && np > 8192) {
             err = "wide models: Interpolating- / BacksolveAdjoint on the adaptive solution keep five parameter-sized rows in LDS (np <= 8192 at most; the exact budget is checked when the handle is created) — GaussAdjoint has no such limit"; return HIPADJ_ERR_UNSUPPORTED; }
         if (ts5 && cfg->alg != HIPADJ_ALG_BACKSOLVE && (cfg->checkpointing || cfg->ncheckpoints > 0)) { err = "wide models: Gauss- / InterpolatingAdjoint on adaptive Tsit5 keep the dense forward solution (checkpointing = false, no checkpoint list)"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->cont_cost == HIPADJ_CCOST_MODEL) { err = "wide models: the built-in continuous costs (HIPADJ_CCOST_HALF_SQ_SUM, HIPADJ_CCOST_U1SQ_PLUS_P1) are offered; a cost attached as text is a feature of the lane-per-trajectory family"; return HIPADJ_ERR_UNSUPPORTED; }
         if (!ts5 && cfg->checkpointing && cfg->alg == HIPADJ_ALG_QUADRATURE) { err = "wide models: QuadratureAdjoint keeps the dense forward solution (its second pass integrates over it); checkpointing = true is offered for Interpolating / Gauss / GaussKronrod / BacksolveAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (P.mlp) {

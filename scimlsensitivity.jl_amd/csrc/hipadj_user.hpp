@@ -53,6 +53,7 @@ struct UserModelSrc {
     // wide model (hipadj_wmodel_register; hipadj_wide.hpp): SPMD bodies f / vjp for a workgroup of `threads` per trajectory
     bool wide = false;
     std::string wvjp;             // the joint VJP body (the reference's vecjacobian! contract)
+    std::string wcost;            // continuous cost of a wide model (hipadj_wmodel_set_cost): SPMD body adding g_u into dlam and, WP, w g_p into gp / acc
     int threads = 0, nw = 0, nacc = 0, acc0 = 0;
 };
 
@@ -243,7 +244,10 @@ inline std::string user_wide_struct(const UserModelSrc& m) {
       << "        (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.f << "\n    }\n"
       << "    template <bool WP> static __device__ __forceinline__ void vjp(double* __restrict__ dlam, double* __restrict__ gp, double (&acc)[" << na << "], double w,\n"
       << "            const double* __restrict__ lam, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {\n"
-      << "        (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wvjp << "\n    }\n};\n#undef tanh\n}  // namespace hipadj\n";
+      << "        (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wvjp << "\n    }\n"
+      << "    template <bool WP> static __device__ __forceinline__ void cost(double* __restrict__ dlam, double* __restrict__ gp, double (&acc)[" << na << "], double w,\n"
+      << "            const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {\n"
+      << "        (void)dlam; (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wcost << "\n    }\n};\n#undef tanh\n}  // namespace hipadj\n";
     return o.str();
 }
 
@@ -568,7 +572,7 @@ inline int user_set_cost_function(int32_t model, const char* g, std::string& err
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost_function: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
-    if (R.models[idx].wide) { err = "hipadj_model_set_cost_function: a wide model (hipadj_wmodel_register) takes the built-in continuous costs only (hipadj_config.cont_cost 1 / 2)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (R.models[idx].wide) { err = "hipadj_model_set_cost_function: the cost of a wide model (hipadj_wmodel_register) is one SPMD body: hipadj_wmodel_set_cost"; return HIPADJ_ERR_UNSUPPORTED; }
     R.models[idx].gfun = g; R.models[idx].has_cost = true; R.models[idx].rev++;
     return HIPADJ_OK;
 }
@@ -578,8 +582,17 @@ inline int user_set_cost(int32_t model, const char* dgdu, const char* dgdp, std:
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_cost: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
-    if (R.models[idx].wide) { err = "hipadj_model_set_cost: a wide model (hipadj_wmodel_register) takes the built-in continuous costs only (hipadj_config.cont_cost 1 / 2)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (R.models[idx].wide) { err = "hipadj_model_set_cost: the cost of a wide model (hipadj_wmodel_register) is one SPMD body: hipadj_wmodel_set_cost"; return HIPADJ_ERR_UNSUPPORTED; }
     R.models[idx].dgdu = dgdu; R.models[idx].dgdp = dgdp; R.models[idx].gfun.clear(); R.models[idx].has_cost = true; R.models[idx].rev++;
+    return HIPADJ_OK;
+}
+// continuous cost of a WIDE model as one SPMD body (hipadj_wmodel_set_cost); NULL / empty removes it
+inline int user_set_wide_cost(int32_t model, const char* body, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size() || !R.models[idx].wide) { err = "hipadj_wmodel_set_cost: not a wide model id (hipadj_wmodel_register)"; return HIPADJ_ERR_INVALID_ARG; }
+    R.models[idx].wcost = body ? body : ""; R.models[idx].has_cost = !R.models[idx].wcost.empty(); R.models[idx].rev++;
     return HIPADJ_OK;
 }
 // DiscreteCallback affect of a runtime model: `body` edits un[0..n) (a copy of u) from u, p, t with `real` locals; NULL / empty removes it

@@ -271,13 +271,28 @@ template <class Mo> struct WideTiles { double *y, *ls, *dl, *gp, *ws, *red; };
 // Continuous costs g(u, p, t) (src/adjoint_common.jl `accumulate_cost!`, src/derivative_wrappers.jl:1411-1442) of the built-in kinds on a wide model: the kernels are
 // instantiated for WideWithCost<UserW, CC> and every joint-VJP evaluation adds g_u to (df/du)^T lam and, where the parameter part is taken (WP), w g_p to the
 // gradient row — the same two places the lane family's adj_rk4_core / rhs add them.  CC = 1: g = (sum u)^2 / 2 (g_u = sum u in every component, one workgroup
-// sum per evaluation); CC = 2: g = u_1^2 + p_1 (g_u = 2 u_1 e_1, g_p = e_1).  A cost attached to a model as text (HIPADJ_CCOST_MODEL) is a lane-family feature.
+// sum per evaluation); CC = 2: g = u_1^2 + p_1 (g_u = 2 u_1 e_1, g_p = e_1); CC = 3 (HIPADJ_CCOST_MODEL, round 4): the cost attached to the model as an SPMD body
+// (hipadj_wmodel_set_cost; wtrace.py writes it from a traced g): Mo::cost<WP>(dlam, gp, acc, w, u, p, t, ws, tid) ADDS g_u into dlam — entry i from the thread that owns i,
+// which HIPADJ_W_FOR loops do — and, WP, w g_p into gp / acc exactly like a vjp body; it runs on the vjp tile after the joint VJP has been read back.
 template <class Mo, int CC_> struct WideWithCost : Mo { static constexpr int CC = CC_; };
 template <class Mo, class = void> struct wide_cc { static constexpr int value = 0; };
 template <class Mo> struct wide_cc<Mo, decltype((void)Mo::CC)> { static constexpr int value = Mo::CC; };
 template <class Mo, bool WP>
-__device__ __forceinline__ void wide_cost_add(double* __restrict__ gp, double w, const double (&yv)[WideShape<Mo>::Q], double (&v)[WideShape<Mo>::Q]) {
+__device__ __forceinline__ void wide_cost_add(double* __restrict__ gp, double w, const double (&yv)[WideShape<Mo>::Q], double (&v)[WideShape<Mo>::Q],
+                                              double* __restrict__ dl_tile, const double* __restrict__ y_tile, double* __restrict__ ws, const double* __restrict__ pp, double t,
+                                              double (&acc)[WideShape<Mo>::NA]) {
     constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q, CC = wide_cc<Mo>::value;
+    (void)dl_tile; (void)y_tile; (void)ws; (void)pp; (void)t; (void)acc;
+    if constexpr (CC == 3) {
+        (void)yv;
+        // the vjp tile's owned entries were just read into v by this thread: zero them (owner-only writes, no barrier), let the cost body add g_u, read them back
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) dl_tile[c] = 0.0; }
+        Mo::template cost<WP>(dl_tile, gp, acc, w, y_tile, pp, t, ws, (int)threadIdx.x);
+        wide_sync<T>();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) v[q] += dl_tile[c]; }
+    } else
     if constexpr (CC == 1) {
         (void)gp; (void)w;
         double s = 0.0;
@@ -305,7 +320,7 @@ __device__ __forceinline__ void wide_vjp(const WideTiles<Mo>& L, const double* _
     wide_sync<T>();
 #pragma unroll
     for (int q = 0; q < Q; ++q) { const int c = tid + q * T; v[q] = c < N ? L.dl[c] : 0.0; }
-    wide_cost_add<Mo, WP>(L.gp, w, yv, v);
+    wide_cost_add<Mo, WP>(L.gp, w, yv, v, L.dl, L.y, L.ws, pp, t, acc);
 }
 
 // One reverse RK4 step of lam (and, WP, the parameter sums) through [t_k, t_{k+1}] on the common grid: stage states from two knots
@@ -617,7 +632,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve(WideGeom g, const doub
         wide_sync<T>();
 #pragma unroll
         for (int q = 0; q < Q; ++q) { const int c = tid + q * T; F[q] = c < N ? sdu[c] : 0.0; V[q] = c < N ? sdl[c] : 0.0; }
-        wide_cost_add<Mo, true>(L.gp, w, yv, V);
+        wide_cost_add<Mo, true>(L.gp, w, yv, V, sdl, sy, sws, pp, t, acc);
     };
     const double dt = g.dt;
     for (int k = g.S - 1; k >= 0; --k) {
@@ -1190,7 +1205,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve_ts5(WideGeom g, WideAd
             double yv[Q], V[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) { const int c = tid + q * T; yv[q] = zz[Q + q]; V[q] = c < N ? sdl[c] : 0.0; }
-            wide_cost_add<Mo, true>(aug.kc, -1.0, yv, V);
+            wide_cost_add<Mo, true>(aug.kc, -1.0, yv, V, sdl, sy, sws, pp, t, dacc);
 #pragma unroll
             for (int q = 0; q < Q; ++q) { const int c = tid + q * T; dz[q] = -V[q]; dz[Q + q] = c < N ? sdu[c] : 0.0; }
         }

@@ -153,10 +153,13 @@ def _topo(root):
 
 
 class _Gen:
-    def __init__(self, root, n, npar):
-        if root.length != n:
+    def __init__(self, root, n, npar, scalar_root=False):
+        """scalar_root: `root` is a continuous cost g(u, p, t) (a scalar); vjp_body() then emits the cost body of hipadj_wmodel_set_cost — g_u ADDED into dlam, w g_p into gp / acc"""
+        if not scalar_root and root.length != n:
             raise ValueError(f"the traced right-hand side has {root.length} components, the model {n}")
-        self.root, self.n, self.np = root, n, npar
+        if scalar_root and root.length != 0:
+            raise ValueError("a traced cost must be a scalar (ops.sum(...), or arithmetic on scalars)")
+        self.root, self.n, self.np, self.scalar_root = root, n, npar, scalar_root
         self.order = _topo(root)
         self.users = {x.id: [] for x in self.order}
         for x in self.order:
@@ -174,14 +177,15 @@ class _Gen:
         for x in self.order:
             if x.kind == "matvec" and x is not root:
                 self.mat[x.id] = self._alloc(x.length)
-        self.mat[root.id] = None
+        if not scalar_root:
+            self.mat[root.id] = None
         # scalar-valued nodes: sums and elementwise operations on scalars only
         self.scalars = [x for x in self.order if x.length == 0 and x.kind in ("sum", "ew")]
         # reverse pass: adjoint buffers of the materialised arrays (not of du: that is lam), scatter temporaries of the gathers
-        self.adj = {i: self._alloc(self._node(i).length) for i in self.mat if i != root.id}
+        self.adj = {i: self._alloc(self._node(i).length) for i in self.mat if i != root.id or scalar_root}
         self.tmp = {x.id: self._alloc(x.length) for x in self.order if x.kind == "gather" and x.args[0].kind != "const"}
         sc = sorted({x.data["k"] for x in self.order if x.kind == "pscalar"})
-        self.acc_first, self.nacc = (sc[0], len(sc)) if sc and sc[-1] - sc[0] + 1 == len(sc) and len(sc) <= 16 else (0, 0)
+        self.acc_first, self.nacc = (sc[0], len(sc)) if sc and sc[-1] - sc[0] + 1 == len(sc) and len(sc) <= 16 and not scalar_root else (0, 0)   # (a cost body never uses `acc`: the range belongs to the model)
         self.pscalars = sc
 
     def _node(self, i):
@@ -374,7 +378,8 @@ class _Gen:
             self._forward_unit(x, fw)
         out += fw
         zero = []
-        zero.append(f"HIPADJ_W_FOR(i, {self.n}) dlam[i] = 0.0;")
+        if not self.scalar_root:
+            zero.append(f"HIPADJ_W_FOR(i, {self.n}) dlam[i] = 0.0;")
         for i, off in self.adj.items():
             zero.append(f"HIPADJ_W_FOR(i, {self._node(i).length}) ws[{off} + i] = 0.0;")
         out += zero
@@ -383,6 +388,8 @@ class _Gen:
             out.append(f"double gs{k} = 0.0, gu{k} = 0.0;")      # gs: per-thread partial (summed over the workgroup), gu: uniform contribution (every thread holds the same)
         for x in self.scalars:
             out.append(f"double b{x.id} = 0.0, bu{x.id} = 0.0;")
+        if self.scalar_root:
+            out.append(f"bu{root.id} = 1.0;")        # d g / d g
         for x in reversed(units):
             if x.length == 0 and x.kind == "ew":       # scalar arithmetic: adjoint = workgroup sum of the partials + the uniform part, handed on as uniform
                 out.append(f"const double bt{x.id} = wg_sum(b{x.id}) + bu{x.id};")
@@ -448,6 +455,20 @@ class _Gen:
         while out and out[-1] == "wg_sync();":
             out.pop()
         return self._tables_text() + ("\n" if self.tables else "") + "\n".join(out)
+
+
+def cost_body(fn, n, npar):
+    """Trace a continuous cost g = fn(u, p, t, ops) (a scalar expression) and return (body, lds_doubles, nacc, acc_first) for hipadj_wmodel_set_cost."""
+    Arr._count[0] = 0
+    u, p, t = Arr("u", n), Arr("p", npar), Arr("t", 0)
+    g = fn(u, p, t, Ops())
+    if not isinstance(g, Arr) or g.length != 0:
+        raise TypeError("the traced cost must return a scalar expression (ops.sum(...))")
+    if g.kind not in ("sum", "ew"):
+        g = g * 1.0
+    G = _Gen(g, n, npar, scalar_root=True)
+    body = G.vjp_body()
+    return body, G.ws, G.nacc, G.acc_first
 
 
 def bodies(fn, n, npar):

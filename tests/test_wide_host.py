@@ -69,7 +69,12 @@ def test_planner_answers_for_wide_models(sa):
     # the built-in continuous costs: WideWithCost<UserW, kind> kernels compile (a sample here; every sensealg x stepper x kind runs on the GPU, test_gpu_wide.py)
     assert check(alg=0, cont_cost=1)[0] == 0 and check(alg=3, cont_cost=2)[0] == 0
     assert check(alg=1, cont_cost=2, stepper=1, dt=0.0, checkpointing=1)[0] == 0 and check(alg=2, cont_cost=1, stepper=1, dt=0.0)[0] == 0
-    rc, msg = check(cont_cost=3); assert rc == -6 and "built-in continuous costs" in msg
+    rc, msg = check(cont_cost=3); assert rc == -1 and "has no cost" in msg       # HIPADJ_CCOST_MODEL without hipadj_wmodel_set_cost
+    fun.set_cost(body="HIPADJ_W_FOR(i, N) dlam[i] += u[i]; if (WP) { HIPADJ_W_FOR(j, NP) gp[j] += 0.0; }")
+    for alg in (0, 1, 2, 3, 4):
+        assert check(alg=alg, cont_cost=3, checkpointing=int(alg == 1))[0] == 0, alg          # WideWithCost<UserW, 3> kernels compile for gfx950
+    assert check(alg=0, cont_cost=3, stepper=1, dt=0.0)[0] == 0 and check(alg=1, cont_cost=3, stepper=1, dt=0.0, checkpointing=1)[0] == 0
+    fun.set_cost(body=None)
     # checkpointing = true on the fixed step (round 4, k_wide_adjoint_ck): Interpolating / Gauss / GaussKronrod re-solve checkpoint intervals; Quadrature keeps the dense solution
     for alg in (0, 2, 4):
         assert check(alg=alg, checkpointing=1)[0] == 0 and check(alg=alg, checkpointing=1, ckpt_stride=7)[0] == 0
@@ -132,12 +137,16 @@ def test_wide_models_refuse_mass_matrix_cost_text_and_affect(sa):
     with pytest.raises(sa.HipadjError) as e:
         fun.set_mass_matrix(np.eye(40) * 2.0)
     assert e.value.status == -6 and "wide" in str(e.value)
-    with pytest.raises(sa.HipadjError) as e:
+    with pytest.raises(ValueError):                 # the lane family's cost forms do not apply: a wide model takes ONE SPMD body (hipadj_wmodel_set_cost)
         fun.set_cost(g="g = u[0] * u[0];")
-    assert e.value.status == -6
-    with pytest.raises(sa.HipadjError) as e:
+    with pytest.raises(ValueError):
         fun.set_cost(dgdu="out[0] = u[0];", dgdp="out[0] = 0.0;")
-    assert e.value.status == -6
+    from scimlsensitivity_jl_amd import _lib
+    L = sa.load_library()
+    assert L.hipadj_model_set_cost(fun.id, b"out[0] = u[0];", b"out[0] = 0.0;") == -6 and L.hipadj_model_set_cost_function(fun.id, b"g = u[0];") == -6
+    assert L.hipadj_wmodel_set_cost(0, b"") == -1                      # not a wide model id
+    fun.set_cost(body="HIPADJ_W_FOR(i, N) dlam[i] += u[i];")        # g = |u|^2 / 2: accepted, compiled with the sweeps of a handle that selects it
+    fun.set_cost(body=None)
     with pytest.raises(sa.HipadjError) as e:
         fun.set_affect("un[0] += 1.0;")
     assert e.value.status == -6
