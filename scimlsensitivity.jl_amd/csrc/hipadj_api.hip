@@ -157,7 +157,7 @@ extern "C" int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, co
     return HIPADJ_OK;
 }
 
-static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int cost = 0, bool ip_ckpt = false) {
+static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int cost = 0, bool ip_ckpt = false, bool offgrid = false) {
     // the reverse kernels of a handle with a built-in continuous cost are instantiated for WideWithCost<UserW, kind> (hipadj_wide.hpp); the forward solve never sees the cost
     const std::string U = cost ? "hipadj::WideWithCost<hipadj::UserW, " + std::to_string(cost) + ">" : std::string("hipadj::UserW");
     if (ts5) {
@@ -167,6 +167,11 @@ static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int
         return e;
     }
     std::vector<std::string> e = {"hipadj::k_wide_forward<hipadj::UserW>"};
+    if (offgrid) {   // loss times off the step grid: the sweep over the reverse step list, and out = sol(ts) by interpolation in the `gk` slot
+        e.push_back("hipadj::k_wide_adjoint_og<" + U + (alg == HIPADJ_ALG_GAUSS ? ", 2>" : ", 0>"));
+        e.push_back("hipadj::k_wide_out_offgrid<hipadj::UserW>");
+        return e;
+    }
     switch (alg) {
     case HIPADJ_ALG_INTERPOLATING: e.push_back(std::string("hipadj::k_wide_adjoint") + (ip_ckpt ? "_ck<" : "<") + U + ", 0>"); break;
     case HIPADJ_ALG_GAUSS: e.push_back(std::string("hipadj::k_wide_adjoint") + (ip_ckpt ? "_ck<" : "<") + U + ", 2>"); break;
@@ -808,7 +813,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     h.cfg = *cfg; h.cfg.save_times = nullptr; h.cfg.checkpoints = nullptr;
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
-    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg, P.adaptive, cfg->cont_cost, P.ip_ckpt), code, low, err); }
+    if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg, P.adaptive, cfg->cont_cost, P.ip_ckpt, P.offgrid), code, low, err); }
     h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
     h.fused = fused_eligible(cfg, P) ? 1 : 0;
     const UserKernels k = user_kernel_names(&h);
@@ -1053,7 +1058,7 @@ static int wide_prepare(hipadj_handle* h) {
             HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide model %d: Interpolating- / BacksolveAdjoint on the adaptive solution need %ld KB of LDS (state tiles + scratch + 5 np + the parameter copy), a workgroup has 160 KB — use GaussAdjoint, whose sweep integrates lam only",
                         h->cfg.model, lds / 1024);
     }
-    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5, h->cfg.cont_cost, h->ip_ckpt);
+    const std::vector<std::string> exprs = wide_kernel_names(h->cfg.alg, h->wide_ts5, h->cfg.cont_cost, h->ip_ckpt, h->offgrid);
     std::vector<char> code; std::map<std::string, std::string> low;
     const int rc = user_compile(h->cfg.model, exprs, code, low, h->err);
     if (rc != HIPADJ_OK) return rc;
@@ -1077,6 +1082,8 @@ static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
     TRY(usig<decltype(&k_wide_forward<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, d_u0, d_p,
                 (bs || ck) ? (double*)nullptr : h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot,
                 ((bs || ck) && h->nck > 0) ? h->d_ckpt : (double*)nullptr, (const int*)h->d_ckpt_of_knot, bs ? h->d_yT : (double*)nullptr));
+    if (h->offgrid && d_out && h->M > 0)     // the save times are not knots: out = sol(ts) from the forward Hermite interpolant
+        TRY(usig<decltype(&k_wide_out_offgrid<WideProbe>)>::launch(h, h->uf_gk, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, (const double*)h->d_fknots, (const double*)h->d_save_t, h->M, d_out));
     return HIPADJ_OK;
 }
 
@@ -1107,6 +1114,9 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
             hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows);
             HIP_TRY(h, hipGetLastError());
         }
+    } else if (h->offgrid) {
+        const RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        TRY(usig<decltype(&k_wide_adjoint_og<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, R, p, (const double*)h->d_fknots, d_cot, d_du0, rows, h->d_flag));
     } else
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:

@@ -298,9 +298,10 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         const bool og_ig = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && !cfg->checkpointing;
         const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->ckpt_stride == 0 && cfg->ncheckpoints == 0;
         const bool og_q = cfg->alg == HIPADJ_ALG_QUADRATURE && !P.user;       // compiled-in lane models (round 2)
-        if (!(og_ig || og_bs || og_q) || P.field || P.mlp || P.wide) {
+        const bool og_wide = P.wide && og_ig;      // wide models: Interpolating / Gauss over the reverse step list (k_wide_adjoint_og)
+        if (!(og_ig || og_bs || og_q) || P.field || P.mlp || (P.wide && !og_wide)) {
             err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false), QuadratureAdjoint (compiled-in models) and "
-                  "BacksolveAdjoint (checkpoints = the save times, ckpt_stride = 0) on the lane-per-trajectory models; other configurations need times on the grid, or the adaptive stepper (arbitrary times)";
+                  "BacksolveAdjoint (checkpoints = the save times, ckpt_stride = 0) on the lane-per-trajectory models, and for InterpolatingAdjoint / GaussAdjoint (checkpointing = false) on wide models; other configurations need times on the step grid, or the adaptive stepper (arbitrary times)";
             return HIPADJ_ERR_UNSUPPORTED; }
         for (int i = 0; i < cfg->nsave; ++i) {   // the sweep takes the times literally; they must not leave the span
             if (P.save_times[i] < cfg->t0) P.save_times[i] = cfg->t0;

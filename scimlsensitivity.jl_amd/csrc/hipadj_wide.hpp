@@ -602,6 +602,109 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ck(WideGeom g, const dou
     wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
 }
 
+// ---- loss times OFF the step grid on the fixed step (round 4; src/adjoint_common.jl:848-855: the reverse solve stops at every loss time): the sweep runs the host
+// planner's reverse step list (hipadj_plan.hpp plan_reverse_steps: dt-steps clipped at the loss times, the same for every trajectory) and takes y(t) of every stage
+// from the forward cubic-Hermite interpolant between the two knots around t.  Interpolating (ALG 0) and Gauss (ALG 2: 2-node rule per reverse step, lam from the
+// adjoint step's own Hermite interpolant).  out = sol(ts) comes from the same interpolant (k_wide_out_offgrid).
+template <class Mo>
+__device__ __forceinline__ void wide_hermite(const double* __restrict__ knots, const WideGeom& g, long traj, double t, double (&y)[WideShape<Mo>::Q]) {
+    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q;
+    int k = (int)floor((t - g.t0) / g.dt);
+    k = k < 0 ? 0 : (k > g.S - 1 ? g.S - 1 : k);
+    const double th = (t - (g.t0 + k * g.dt)) / g.dt;
+    const double* b0 = knots + ((traj * (g.S + 1) + k) * 2) * N;
+    const double* b1 = b0 + 2 * N;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int c = threadIdx.x + q * T;
+        if (c < N) {
+            const double y0 = b0[c], f0 = b0[N + c], y1 = b1[c], f1 = b1[N + c];
+            y[q] = (1.0 - th) * y0 + th * y1 + th * (th - 1.0) * ((1.0 - 2.0 * th) * (y1 - y0) + (th - 1.0) * g.dt * f0 + th * g.dt * f1);
+        } else y[q] = 0.0;
+    }
+}
+template <class Mo>
+__global__ void __launch_bounds__(Mo::T) k_wide_out_offgrid(WideGeom g, const double* __restrict__ knots, const double* __restrict__ save_t, int M, double* __restrict__ out) {
+    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q;
+    const long traj = blockIdx.x;
+    for (int m = 0; m < M; ++m) {
+        double y[Q];
+        wide_hermite<Mo>(knots, g, traj, save_t[m], y);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) out[(traj * M + m) * N + c] = y[q]; }
+    }
+}
+// one reverse RK4 step of length hs from t_hi on given stage states; returns V1 = (df/du)^T lam at the step's start
+template <class Mo, bool WP>
+__device__ __forceinline__ void wide_rk4_step_y(const WideTiles<Mo>& L, const double* __restrict__ pp, double t_hi, double hs, const double (&y_hi)[WideShape<Mo>::Q],
+                                                const double (&y_mid)[WideShape<Mo>::Q], const double (&y_lo)[WideShape<Mo>::Q], double (&lam)[WideShape<Mo>::Q],
+                                                double (&acc)[WideShape<Mo>::NA], double (&v1)[WideShape<Mo>::Q]) {
+    constexpr int Q = WideShape<Mo>::Q;
+    const double t_mid = t_hi - 0.5 * hs, t_lo = t_hi - hs;
+    double s[Q], a[Q], v[Q];
+    wide_vjp<Mo, WP>(L, pp, t_hi, hs / 6.0, y_hi, lam, acc, v1);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { a[q] = v1[q]; s[q] = lam[q] + (0.5 * hs) * v1[q]; }
+    wide_vjp<Mo, WP>(L, pp, t_mid, hs / 3.0, y_mid, s, acc, v);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { a[q] += 2.0 * v[q]; s[q] = lam[q] + (0.5 * hs) * v[q]; }
+    wide_vjp<Mo, WP, false>(L, pp, t_mid, hs / 3.0, y_mid, s, acc, v);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { a[q] += 2.0 * v[q]; s[q] = lam[q] + hs * v[q]; }
+    wide_vjp<Mo, WP>(L, pp, t_lo, hs / 6.0, y_lo, s, acc, v);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = lam[q] + (hs / 6.0) * (a[q] + v[q]);
+}
+template <class Mo, int ALG>
+__global__ void __launch_bounds__(Mo::T) k_wide_adjoint_og(WideGeom g, RevSteps R, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
+                                                           double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    static_assert(ALG == 0 || ALG == 2, "Interpolating, Gauss (2-node rule per reverse step)");
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA + 2], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    const long traj = blockIdx.x;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
+    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
+    wide_zero_gp<Mo>(L);
+    double lam[Q], acc[W::NA], y_hi[Q], y_mid[Q], y_lo[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
+    wide_hermite<Mo>(knots, g, traj, R.t_start, y_hi);
+    if (R.save_at_start >= 0) wide_jump<Mo>(g, traj, R.save_at_start, cot, y_hi, lam);       // PresetTimeCallback fires at initialisation when T is a loss time
+    const double xg = 0.5773502691896257645;
+    for (int qs = 0; qs < R.n; ++qs) {
+        const double t = R.t[qs], hs = R.h[qs], te = R.te[qs], tm = t - 0.5 * hs;
+        wide_hermite<Mo>(knots, g, traj, tm, y_mid);
+        wide_hermite<Mo>(knots, g, traj, te, y_lo);
+        double v1[Q];
+        if (ALG == 0) {
+            wide_rk4_step_y<Mo, true>(L, pp, t, hs, y_hi, y_mid, y_lo, lam, acc, v1);
+        } else {
+            double h0[Q], v5[Q], dacc[W::NA] = {};
+#pragma unroll
+            for (int q = 0; q < Q; ++q) h0[q] = lam[q];
+            wide_rk4_step_y<Mo, false>(L, pp, t, hs, y_hi, y_mid, y_lo, lam, dacc, v1);
+            wide_vjp<Mo, false>(L, pp, te, 0.0, y_lo, lam, dacc, v5);                        // fsallast: (df/du)^T lam_new at the step's end
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq) {
+                const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x);                    // theta along the adjoint step: 0 at t, 1 at te
+                double gl[Q], yv[Q], dd[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    gl[q] = (1.0 - th) * h0[q] + th * lam[q] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lam[q] - h0[q]) + (th - 1.0) * (-hs) * (-v1[q]) + th * (-hs) * (-v5[q]));
+                wide_hermite<Mo>(knots, g, traj, t - th * hs, yv);
+                wide_vjp<Mo, true>(L, pp, t - th * hs, 0.5 * hs, yv, gl, acc, dd);
+            }
+        }
+        { const int s = R.save[qs]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y_lo, lam); }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) y_hi[q] = y_lo[q];
+    }
+    wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
+}
+
 // ---- BacksolveAdjoint: z = [lam; mu; y] integrated backward jointly, y overwritten by the stored forward value at every checkpoint knot, loss gradient at
 // the (possibly just overwritten) backsolved y (src/backsolve_adjoint.jl:32-61, 523-546; src/adjoint_common.jl:765-767; no_start is not consulted) ----
 template <class Mo>

@@ -390,3 +390,33 @@ def test_checkpointing_on_wide_models_fixed_step(sa, alg, oalg, model, ckpts):
     ref = O.Problem(omodel, alg=oalg, stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, checkpointing=True, dims=dims, **okw)
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(res[1][0], rdu0) < 1e-6 and rel(res[1][1], rdp) < 1e-6
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+@pytest.mark.parametrize("model", ["idxaff", "chain", "ring"])
+@pytest.mark.parametrize("no_start", [False, True])
+def test_loss_times_off_the_step_grid_on_wide_models(sa, alg, oalg, model, no_start):
+    """Loss times that are not multiples of dt on the fixed step (src/adjoint_common.jl:848-855: PresetTimeCallback makes the reverse solve stop on them):
+    the sweep runs the planner's reverse step list with y(t) from the forward Hermite interpolant (k_wide_adjoint_og), out = sol(ts) by interpolation.  Against the oracle,
+    whose generic integrator takes the same clipped steps."""
+    from test_wtrace import ring
+    rng = np.random.default_rng(37)
+    if model == "idxaff":
+        fun, omodel, dims, n, npar = sa.WideDeviceFunction.index_affine("og_idx", 30, 50), "IDXAFF", (30, 50, 0, 0), 1500, 2
+    elif model == "chain":
+        fun, omodel, dims, n, npar = sa.WideDeviceFunction.dense_chain("og_chain", (2, 50, 2), input_power=3), "MLP1", (2, 50, 0, 0), 2, 252
+    else:
+        if "og_ring" not in _COSTFUN:
+            _COSTFUN["og_ring"] = sa.WideDeviceFunction.from_callable("og_ring", ring, 40, 41)
+        fun, omodel, dims, n, npar = _COSTFUN["og_ring"], "RING", (40, 0, 0, 0), 40, 41
+    N, T, dt = 4, 0.5, 0.01
+    ts = np.array([0.0, 0.0333, 0.1, 0.2171, 0.455, 0.5]) if not no_start else np.array([0.0, 0.123, 0.3707])
+    u0 = rng.uniform(0.3, 1.0, (N, n)); p = rng.uniform(0.2, 0.6, npar)
+    delta = rng.standard_normal((N, len(ts), n))
+    eng = sa.Engine(fun.name, alg, N, 0.0, T, dt, save_times=ts, no_start=no_start)
+    out = eng.forward(u0, p)
+    du0, dp = eng.adjoint(delta)
+    eng.close()
+    ref = O.Problem(omodel, alg=oalg, stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, dims=dims, no_start=no_start)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(out, rout) < 1e-10 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6

@@ -79,8 +79,12 @@ def test_planner_answers_for_wide_models(sa):
     for alg in (0, 2, 4):
         assert check(alg=alg, checkpointing=1)[0] == 0 and check(alg=alg, checkpointing=1, ckpt_stride=7)[0] == 0
     rc, msg = check(alg=3, checkpointing=1); assert rc == -6 and "QuadratureAdjoint keeps the dense" in msg
+    # loss times off the step grid (round 4, k_wide_adjoint_og): Interpolating / Gauss without checkpointing; the others name what is offered
     off = np.array([0.0, 0.333, 1.0])
-    rc, msg = check(nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double))); assert rc == -6 and "step grid" in msg
+    for alg in (0, 2):
+        assert check(alg=alg, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)))[0] == 0
+    for alg, kw in ((1, dict(checkpointing=1)), (3, {}), (4, {}), (0, dict(checkpointing=1))):
+        rc, msg = check(alg=alg, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)), **kw); assert rc == -6 and "step grid" in msg, (alg, msg)
 
 
 def test_dense_chain_emitter_matches_its_golden_text(sa):
