@@ -321,11 +321,15 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             // needs more reports HIPADJ_ERR_MAXITERS and names max_steps)
             h->wide_ts5 = true;
             const long RW = 2 + 5L * n;
-            long cap = cfg->max_steps > 0 ? cfg->max_steps : (8L << 30) / (RW * 8 * h->N);
+            long budget = 8L << 30;
+            if (const char* e = std::getenv("HIPADJ_WIDE_REC_BUDGET")) { const long v = std::atol(e); if (v > 0) budget = v; }   // test hook: start the record too small (regrow path)
+            long cap = cfg->max_steps > 0 ? cfg->max_steps : budget / (RW * 8 * h->N);
             if (cfg->max_steps == 0) cap = cap < 64 ? 64 : (cap > 8192 ? 8192 : cap);
             h->rec_cap = cap;
             h->wa.t1 = cfg->t1; h->wa.abstol = cfg->abstol; h->wa.reltol = cfg->reltol; h->wa.dt0 = cfg->dt; h->wa.Smax = (int)cap; h->wa.maxit = (int)cap;
-            if (cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->max_steps == 0) h->wa.maxit = HIPADJ_AUTO_MAXITERS;   // no records to hold: only the reference's maxiters bounds the solve
+            if (cfg->max_steps == 0) h->wa.maxit = HIPADJ_AUTO_MAXITERS;   // auto-sized: only the reference's maxiters bounds the solve (Backsolve holds no records; the others report
+                                                                           // the TRUE step count beyond the capacity, from which wide_autosize regrows the record)
+            h->wide_auto = cfg->max_steps == 0 && cfg->alg != HIPADJ_ALG_BACKSOLVE && cap < 8192;   // the 8 GiB budget cut the capacity short: overflow is plausible, check after every forward solve
             h->ag.Smax = (int)cap;   // (the overflow message names it)
             if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)h->N * cap * RW));
             else {   // Backsolve keeps no records: y(T) and, checkpointing = true, the forward states at the checkpoint times [N][nck][n]
@@ -1070,12 +1074,45 @@ static int wide_prepare(hipadj_handle* h) {
     return HIPADJ_OK;
 }
 
+// The dense record of a wide model's adaptive forward solve with max_steps = 0 when the 8 GiB budget cut its capacity below 8192 steps (large states): the kernel stores the
+// TRUE step count per trajectory; the host reads the maximum and, when some trajectory did not fit, regrows the record (and QuadratureAdjoint's adjoint record) and asks for the
+// solve to be repeated — what adaptive_autosize does for the lane family.  One stream synchronisation per forward solve, in this mode only.  1 = repeat, 0 = it stands.
+static int wide_autosize(hipadj_handle* h) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<int> ns((size_t)h->N);
+    HIP_TRY(h, hipMemcpy(ns.data(), h->d_nsteps, sizeof(int) * (size_t)h->N, hipMemcpyDeviceToHost));
+    long mx = 1;
+    for (long i = 0; i < h->N; ++i) if (ns[i] > mx) mx = ns[i];
+    if (mx <= h->rec_cap || mx >= HIPADJ_AUTO_MAXITERS) return 0;     // fits (or ran into maxiters: the flag reports it)
+    const long RW = 2 + 5L * h->n, cap = mx + mx / 8 + 8;
+    auto regrow = [&](double** buf, size_t old_count, size_t new_count) -> int {
+        if (*buf) { (void)hipFree(*buf); *buf = nullptr; h->ws_bytes -= (double)(old_count * sizeof(double)); }
+        return dev_alloc(h, buf, new_count);
+    };
+    TRY(regrow(&h->d_rec, (size_t)h->N * h->rec_cap * RW, (size_t)h->N * cap * RW));
+    if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
+        const long capA = 2 * cap + h->M + 16;
+        TRY(regrow(&h->d_arec, (size_t)h->N * h->SmaxA * RW, (size_t)h->N * capA * RW));
+        h->SmaxA = (int)capA;
+    }
+    h->rec_cap = cap; h->wa.Smax = (int)cap; h->ag.Smax = (int)cap;
+    h->st.workspace_bytes = h->ws_bytes;
+    HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));                  // the overflow mark of the pass that is being repeated
+    return 1;
+}
+
 static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (h->wide_ts5) {
         const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE;
-        TRY(usig<decltype(&k_wide_forward_ts5<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, h->wa, d_u0, d_p, bs ? (double*)nullptr : h->d_rec, h->d_nsteps,
-                    (const double*)h->d_save_t, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const double*)h->d_ck_t, (bs && h->wg.nck > 0) ? h->d_ckpt : (double*)nullptr,
-                    bs ? h->d_yT : (double*)nullptr, h->d_flag));
+        for (int pass = 0; pass < 2; ++pass) {
+            TRY(usig<decltype(&k_wide_forward_ts5<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, h->wa, d_u0, d_p, bs ? (double*)nullptr : h->d_rec, h->d_nsteps,
+                        (const double*)h->d_save_t, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const double*)h->d_ck_t, (bs && h->wg.nck > 0) ? h->d_ckpt : (double*)nullptr,
+                        bs ? h->d_yT : (double*)nullptr, h->d_flag));
+            if (!h->wide_auto) break;
+            const int again = wide_autosize(h);
+            if (again < 0) return again;
+            if (again == 0) break;
+        }
         return HIPADJ_OK;
     }
     const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE, ck = h->ip_ckpt;

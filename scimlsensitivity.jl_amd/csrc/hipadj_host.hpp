@@ -91,6 +91,7 @@ struct hipadj_handle {
     double* d_tbuf = nullptr; unsigned* d_tcnt = nullptr; long tcnt_n = 0;
     int *d_fev_knot = nullptr, *d_fev_save = nullptr, *d_fev_ckpt = nullptr, nfev = 0;   // event knots of the forward solve (k_forward_ev)
     int fwd_ev = 1;                       // HIPADJ_FWD_EV=0: the per-knot form k_forward (A/B)
+    bool wide_auto = false;               // wide models, adaptive, max_steps = 0 and a budget-limited record: step counts are read back after every forward solve (wide_autosize)
     int wide_KT = 0;                      // wide models, checkpointing = true: knots of one re-solve tile (longest checkpoint interval + 1)
     int quad_fwd = 1;                     // HIPADJ_QUAD=0: one lane per trajectory for the forward solves of models with a component form (hipadj_quad.hpp; A/B)
     int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)

@@ -420,3 +420,31 @@ def test_loss_times_off_the_step_grid_on_wide_models(sa, alg, oalg, model, no_st
     ref = O.Problem(omodel, alg=oalg, stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, dims=dims, no_start=no_start)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(out, rout) < 1e-10 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE")])
+def test_adaptive_record_regrows_when_the_budget_cut_it_short(sa, monkeypatch, alg, oalg):
+    """max_steps = 0 on a wide model: the dense record's capacity comes from a memory budget; when that leaves fewer steps than a trajectory takes the forward solve stores
+    the true step counts, the host regrows the record (and Quadrature's adjoint record) and repeats the solve (wide_autosize) — HIPADJ_WIDE_REC_BUDGET makes the budget tiny here."""
+    monkeypatch.setenv("HIPADJ_WIDE_REC_BUDGET", "4096")
+    n = 12
+    fun = sa.WideDeviceFunction.dense_linear("regrow_lin", n) if "regrow" not in _COSTFUN else _COSTFUN["regrow"]
+    _COSTFUN["regrow"] = fun
+    rng = np.random.default_rng(41)
+    N, T = 5, 2.0
+    ts = np.linspace(0.0, T, 7)
+    A = np.zeros((n, n))
+    for k in range(n // 2):                                  # six rotations, 5 (k + 1) rad per unit time: hundreds of accepted steps at 1e-10
+        A[2 * k, 2 * k + 1], A[2 * k + 1, 2 * k] = 5.0 * (k + 1), -5.0 * (k + 1)
+    p = A.flatten(order="F")
+    u0 = rng.standard_normal((N, n))
+    delta = rng.standard_normal((N, len(ts), n))
+    eng = sa.Engine(fun.name, alg, N, 0.0, T, 0.0, save_times=ts, stepper=1, abstol=1e-10, reltol=1e-10, quad_abstol=1e-12, quad_reltol=1e-12)
+    ws0 = eng.stats()["workspace_bytes"]
+    eng.forward(u0, p)
+    assert eng.stats()["workspace_bytes"] > ws0            # 64 steps did not hold the solution at 1e-10
+    du0, dp = eng.adjoint(delta)
+    eng.close()
+    ref = O.Problem("DENSELIN", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, dims=(n, 0, 0, 0), quad_abstol=1e-12, quad_reltol=1e-12)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
