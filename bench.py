@@ -297,6 +297,14 @@ class Runner:
                     except Exception:
                         pass
                 return False
+        # the all-reduce off the next pass's critical path (hipadj_comm_overlap, ABI 107): this loop already alternates two dp buffers
+        self.native_overlap = False
+        if hasattr(self.eng, "comm_overlap") and os.environ.get("HIPADJ_COMM_OVERLAP", "1") != "0":
+            try:
+                self.eng.comm_overlap(True)
+                self.native_overlap = True
+            except Exception as e:      # noqa: BLE001 — an older library: the in-stream collective stands
+                sys.stderr.write(f"bench: hipadj_comm_overlap unavailable ({e!r}); the all-reduce stays in-stream\n")
         return True
 
     def step(self):
@@ -320,6 +328,8 @@ class Runner:
         if self.pending is not None:
             self.pending.wait()
             self.pending = None
+        if self.native and getattr(self, "native_overlap", False):
+            self.eng.synchronize()            # waits for the handle's collective stream as well
 
     def timed(self, steps, warmup):
         """EXACTLY `steps` steps between barrier + synchronize on both sides (the driver's contract).  The library records NO per-kernel events
@@ -653,7 +663,8 @@ def main():
                                    f"dgdu = u - {LOSS_SHIFT} (BASELINE configs[1])",
                        "ntraj_total": n_total, "ntraj_per_gpu": hi - lo, "rk4_steps": S, "loss_times": len(ts),
                        "time_segments": st1["time_segments"], "parallelism": f"ensemble-shard x{world}",
-                       "dp_allreduce": ("none" if world == 1 else "rccl in-stream (hipadj_comm)" if r.native else "torch.distributed nccl, async"),
+                       "dp_allreduce": ("none" if world == 1 else ("rccl on the handle's second stream, overlapped with the next pass (hipadj_comm_overlap)" if getattr(r, "native_overlap", False)
+                                                                            else "rccl in-stream (hipadj_comm)") if r.native else "torch.distributed nccl, async"),
                        # ranks the dp all-reduce really spans: ncclCommCount of the handle's communicator (native carrier), or the process group's size
                        "rccl_ranks": (0 if world == 1 else r.eng.comm_count() if r.native else dist.get_world_size()),
                        "native_allreduce_fallback": r.native_note},
@@ -704,6 +715,17 @@ def main():
                 "value": n2 / (el2 / k2), "unit": "trajectories/s", "ms_per_step": el2 / k2 * 1e3, "ntraj_total": n2,
                 "time_segments": s1["time_segments"], "steps": k2}
         r2.close()
+        # weak scaling at a SATURATING size (10^5 trajectories per GPU): where the per-GPU pass is long enough (~0.9 ms) for the all-reduce and the launch to vanish
+        if not STUB:
+            keep = args.ntraj
+            args.ntraj = 100000
+            r3, n3, _, _, _, el3, _, s3 = measure(False, max(5, args.steps // 2), args.warmup)
+            args.ntraj = keep
+            if rank == 0:
+                k3 = max(5, args.steps // 2)
+                res["weak_scaling_saturating"] = {"value": n3 / (el3 / k3), "unit": "trajectories/s", "ms_per_step": el3 / k3 * 1e3, "ntraj_total": n3, "ntraj_per_gpu": 100000,
+                                                  "time_segments": s3["time_segments"], "steps": k3}
+            r3.close()
 
     if rank == 0 and world == 1 and not STUB:
         if not args.no_pmc:
@@ -726,6 +748,19 @@ def main():
                            "implied_speedup_if_allreduce_hidden": res["ms_per_step"] / (el / args.steps * 1e3)})
                 rs.close()
             res["shard_sizes"] = sh
+            # the same pass at a SATURATING ensemble (SURVEY.md 8e asks for both sizes): 10^5 trajectories fill the chip with plain one-segment sweeps
+            try:
+                n_sat = 100000
+                u0s, _ = inputs(n_sat)
+                rs = Runner(sa, torch, dist, args, n_sat, u0s, p_np, local_rank, 1, False)
+                rs.power_preamble()
+                el = rs.timed(args.steps, args.warmup)
+                s1 = rs.eng.stats()
+                res["saturating_ensemble"] = {"ntraj": n_sat, "ms_per_step": el / args.steps * 1e3, "trajectories_per_s": n_sat / (el / args.steps), "time_segments": s1["time_segments"],
+                                              "whole_pass_frac_of_hbm_peak": s1["adjoint_algorithmic_bytes"] / (el / args.steps) / 1e9 / HBM_PEAK_GBS}
+                rs.close()
+            except Exception as e:      # noqa: BLE001
+                res["saturating_ensemble"] = {"error": repr(e)}
             try:
                 res["other_configs"] = other_configs(sa, torch)
             except Exception as e:      # the headline must not die on a secondary figure

@@ -294,6 +294,11 @@ int hipadj_comm_attach(hipadj_handle *h, void *nccl_comm);
 int hipadj_comm_destroy(hipadj_handle *h);
 int hipadj_comm_count(hipadj_handle *h, int *nranks);
 int hipadj_comm_selfcheck(hipadj_handle *h);
+/* on = 1: the all-reduce of dp moves to a second stream of the handle: hipadj_adjoint_dev enqueues the reverse pass on the handle's stream and the all-reduce behind it on
+ * that second stream, so that the NEXT reverse pass does not wait for the collective's latency (strong scaling: a 24-byte all-reduce costs 10-20 us next to a 30 us shard
+ * pass).  Contract: the caller alternates between TWO dp buffers from call to call; dp of call k is complete after hipadj_synchronize (which waits for both streams) — or
+ * once call k + 2 has been enqueued and the handle's stream has reached it.  on = 0 (default): in-stream, dp complete in stream order.  ABI 107. */
+int hipadj_comm_overlap(hipadj_handle *h, int on);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ DECLARED_SYMBOLS = (
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
     "hipadj_model_register", "hipadj_wmodel_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_wmodel_set_cost", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
-    "hipadj_comm_count", "hipadj_comm_selfcheck",
+    "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
 )
 
 
@@ -118,6 +118,7 @@ def load():
     L.hipadj_comm_destroy.argtypes = [vp]
     L.hipadj_comm_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.hipadj_comm_selfcheck.argtypes = [vp]
+    L.hipadj_comm_overlap.argtypes = [vp, C.c_int]
     _lib = L
     return L
 

@@ -234,6 +234,7 @@ static void free_all(hipadj_handle* h) {
     if (h->umod_alt) (void)hipModuleUnload(h->umod_alt);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
+    if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); if (h->comm_ready) (void)hipEventDestroy(h->comm_ready); for (auto e : h->comm_done) if (e) (void)hipEventDestroy(e); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -537,8 +538,22 @@ extern "C" int hipadj_comm_unique_id(char* id) {
     return HIPADJ_OK;
 }
 
+extern "C" int hipadj_comm_overlap(hipadj_handle* h, int on) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (on && !h->comm_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming));
+        for (auto& e : h->comm_done) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (!on && h->comm_stream) HIP_TRY(h, hipStreamSynchronize(h->comm_stream));
+    h->comm_overlap = on ? 1 : 0; h->comm_seq = 0;
+    return HIPADJ_OK;
+}
+
 extern "C" int hipadj_comm_destroy(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->comm_stream) { (void)hipSetDevice(h->cfg.device); (void)hipStreamSynchronize(h->comm_stream); }
     if (h->comm && h->comm_owned) {
         (void)hipSetDevice(h->cfg.device);
         (void)hipStreamSynchronize(h->stream);
@@ -663,6 +678,7 @@ extern "C" int hipadj_synchronize(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIP_TRY(h, hipStreamSynchronize(h->comm_stream));       // an overlapped all-reduce of dp (hipadj_comm_overlap)
     harvest_timing(h, true);
     int flag = 0;
     HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
@@ -1413,8 +1429,20 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !d_dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     harvest_timing(h, false);
+    const bool overlap = h->comm && h->comm_overlap && h->comm_stream;
+    // overlap (hipadj_comm_overlap): the caller alternates between TWO dp buffers; this pass may only overwrite its buffer once the all-reduce of the pass before last,
+    // which used the same one, is done
+    if (overlap && h->comm_seq >= 2) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->comm_done[h->comm_seq & 1], 0));
     TRY(adjoint_dispatch(h, d_dLdu, d_du0, d_dp));
-    if (h->comm) {   // the one exchange of the sharded ensemble: dp = sum over the ranks' shards, in-stream
+    if (overlap) {   // the all-reduce on its own stream, after this pass; the NEXT pass on h->stream does not wait for it (a 24-byte all-reduce is ~10-20 us of latency
+                     // against a 30 us shard pass: in-stream it is a third of the step)
+        HIP_TRY(h, hipEventRecord(h->comm_ready, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
+        const int rc = rccl_api().AllReduce(d_dp, d_dp, (size_t)h->np, RCCL_DOUBLE, RCCL_SUM, h->comm, h->comm_stream);
+        if (rc != 0) { h->err = rccl_error("ncclAllReduce", rc); return HIPADJ_ERR_RCCL; }
+        HIP_TRY(h, hipEventRecord(h->comm_done[h->comm_seq & 1], h->comm_stream));
+        ++h->comm_seq;
+    } else if (h->comm) {   // the one exchange of the sharded ensemble: dp = sum over the ranks' shards, in-stream
         const int rc = rccl_api().AllReduce(d_dp, d_dp, (size_t)h->np, RCCL_DOUBLE, RCCL_SUM, h->comm, h->stream);
         if (rc != 0) { h->err = rccl_error("ncclAllReduce", rc); return HIPADJ_ERR_RCCL; }
     }

@@ -101,6 +101,8 @@ struct hipadj_handle {
     double *d_rs_t = nullptr, *d_rs_h = nullptr, *d_rs_te = nullptr; int *d_rs_save = nullptr, *d_rs_ck = nullptr; int nrs = 0, rs_save_at_start = -1;
     void* comm = nullptr;                 // ncclComm_t of the ensemble shards (hipadj_comm.hpp); dp is all-reduced over it
     bool comm_owned = false;
+    // hipadj_comm_overlap: the all-reduce of dp on its own stream, off the critical path of the next reverse pass
+    int comm_overlap = 0; hipStream_t comm_stream = nullptr; hipEvent_t comm_ready = nullptr, comm_done[2] = {nullptr, nullptr}; unsigned comm_seq = 0;
     hipadj_stats st{};
     std::string err;
 };

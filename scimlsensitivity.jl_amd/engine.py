@@ -137,6 +137,10 @@ class Engine:
         """Collective: all-reduces a known probe the way dp is all-reduced and verifies the sum (raises HipadjError otherwise)."""
         self._check(self._L.hipadj_comm_selfcheck(self._h))
 
+    def comm_overlap(self, on=True):
+        """The all-reduce of dp on the handle's second stream, off the next pass's critical path (include/hipadj.h hipadj_comm_overlap): alternate two dp buffers."""
+        self._check(self._L.hipadj_comm_overlap(self._h, 1 if on else 0))
+
     def set_timing(self, level):
         """0: no device events, 1: dominant-kernel bracket only, 2: + whole-call bracket (default)."""
         self._check(self._L.hipadj_set_timing(self._h, int(level)))

@@ -32,7 +32,20 @@ def _expected_dp(ntraj):
     return u0.sum(axis=0)
 
 
-@pytest.mark.parametrize("comm,carrier,ranks", [("ok", "rccl in-stream (hipadj_comm)", 2), ("fail", "torch.distributed nccl, async", 2),
+OVERLAPPED = "rccl on the handle's second stream, overlapped with the next pass (hipadj_comm_overlap)"
+
+
+def test_native_carrier_can_stay_in_stream():
+    """HIPADJ_COMM_OVERLAP=0: the collective stays on the handle's stream (the round-3 behaviour); the default moves it to the second stream (next test)."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--ntraj", "101", "--no-cpu-baseline", "--no-extras"],
+             {"HIPADJ_BENCH_STUB": "1", "HIPADJ_BENCH_STUB_COMM": "ok", "HIPADJ_COMM_TIMEOUT": "5", "HIPADJ_COMM_OVERLAP": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    ln = _lines(r.stdout)[0]
+    assert ln["config"]["dp_allreduce"] == "rccl in-stream (hipadj_comm)"
+    np.testing.assert_allclose(ln["stub_dp"], _expected_dp(101), rtol=1e-13)
+
+
+@pytest.mark.parametrize("comm,carrier,ranks", [("ok", OVERLAPPED, 2), ("fail", "torch.distributed nccl, async", 2),
                                                 ("hang", "torch.distributed nccl, async", 2), ("badcheck", "torch.distributed nccl, async", 2)])
 def test_gpus_2_without_torchrun_starts_two_ranks_and_prints_one_line(comm, carrier, ranks):
     r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--ntraj", "101", "--no-cpu-baseline"],

@@ -1412,11 +1412,13 @@ def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
     u0, p = lorenz_inputs(N)
     ts = np.linspace(0, T, 11)
 
-    def grads(u0s, with_comm):
+    def grads(u0s, with_comm, overlap=False):
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0s[0], (0, T), p), u0s), sa.RK4(), dt=dt, saveat=ts,
                        sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
         if with_comm:
             sol.engine.comm_init_rank(sa.comm_unique_id(), 1, 0)
+            if overlap:
+                sol.engine.comm_overlap(True)      # the collective on the handle's second stream (hipadj_comm_overlap); the host API synchronises both
         du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
         du0b, dpb = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))     # the collective is repeatable
         assert np.array_equal(dp, dpb) and np.array_equal(du0, du0b)
@@ -1429,6 +1431,8 @@ def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
     du0, dp = grads(u0, False)
     du0c, dpc = grads(u0, True)
     assert np.array_equal(du0, du0c) and np.array_equal(dp, dpc)
+    du0o, dpo = grads(u0, True, overlap=True)
+    assert np.array_equal(du0, du0o) and np.array_equal(dp, dpo)
     lo, hi = sa.shard_range(N, 0, 2)
     parts = [grads(u0[a:b], True) for a, b in ((lo, hi), sa.shard_range(N, 1, 2))]
     assert rel(parts[0][1] + parts[1][1], dp) < 1e-12
