@@ -576,10 +576,7 @@ template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hip
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     for (int pass = 0; pass < 2; ++pass) {
-        // (Gauss: the quad sweep exists — adjoint_tsit5_quad<Mo, 2> — but is NOT dispatched: it measured slower than the lane kernel (2.96 vs 2.39 ms, the three quadrature nodes per
-        //  step add exchanges) and returned lam with an error that grows with the step count on problems with interior loss times (1.8e-5 at tol 1e-11 where the lane kernel and
-        //  the Interpolating / Backsolve quad sweeps sit at 1e-13; scripts/r4/ts5_dbg2.py) — unexplained, so it stays off)
-        constexpr bool QUAD_OK = QuadAdj<Mo>::value && CC == 0 && !CK && (ALG == 0 || ALG == 1);
+        constexpr bool QUAD_OK = QuadAdj<Mo>::value && CC == 0 && !CK && (ALG == 0 || ALG == 1 || ALG == 2);
         if (QUAD_OK && h->quad_fwd) {
             if constexpr (QUAD_OK)
                 hipLaunchKernelGGL((k_adjoint_tsit5_quad<Mo, ALG>), dim3((unsigned)((h->N + 15) / 16)), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,

@@ -11,9 +11,8 @@
 // (they contribute exact zeros to the norms) and skip the stores.
 //
 // Data layout = the lane family's (records [Smax][2 + 5 n][Npad], outT / ckpt / yT / cotT component-major, dp_traj [np][Npad]): every kernel of either
-// mapping reads what the other wrote.  Dispatched for models with QuadAdj (compiled-in Lorenz): the forward solve and the Interpolating and Backsolve sweeps
-// without a continuous cost and without checkpointing=true; everything else keeps the lane kernels (the Gauss sweep below is written but switched off: see
-// adaptive_adjoint_l, hipadj_host_impl.hpp).
+// mapping reads what the other wrote.  Dispatched for models with QuadAdj (compiled-in Lorenz): the forward solve and the Interpolating, Backsolve and Gauss sweeps
+// without a continuous cost and without checkpointing=true; everything else keeps the lane kernels.
 #pragma once
 #include "hipadj_quad.hpp"
 #include "hipadj_adaptive.hpp"
@@ -149,7 +148,11 @@ template <class Mo> struct QuadCursor {
 };
 
 // ---- reverse sweeps.  ALG: 0 Interpolating (lane: lam_c, mu_c), 1 Backsolve (lam_c, mu_c, y_c), 2 Gauss (lam_c; mu_c by 3-node Gauss-Legendre per step) ----
-template <int ALG> struct QuadNZ { static constexpr int value = ALG == 0 ? 2 : (ALG == 1 ? 3 : 1); };
+// Gauss: lam_c plus a DUMMY second component with zero derivative.  The one-component instantiation of tsit5_integrate returned a wrong lam from this kernel — deterministic,
+// growing with the step count on problems with interior loss times (1.8e-5 at tol 1e-11; scripts/r4/ts5_dbg2.py), identical with or without the quadrature nodes — while the
+// SAME source with the dummy component agrees with the oracle at 7e-14 (and the forward solve's one-component instantiation is right, and so is the lane family's with the rows in
+// LDS).  Not understood (compiler or template defect of that instantiation); the dummy adds exact zeros to the controller's norms (ncomp stays n) and two instructions per stage.
+template <int ALG> struct QuadNZ { static constexpr int value = ALG == 1 ? 3 : 2; };
 
 template <class Mo, int ALG>
 HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const double* __restrict__ p, const double* __restrict__ rec,
@@ -171,7 +174,7 @@ HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
     double z[NZ];
 #pragma unroll
     for (int j = 0; j < NZ; ++j) z[j] = 0.0;
-    if (ALG == 1) z[2] = ownl ? yT[(long)c * g.Npad + i] : 0.0;
+    if constexpr (ALG == 1) z[2] = ownl ? yT[(long)c * g.Npad + i] : 0.0;
     double gacc = 0.0;
     int cur_time = g.M, bs_cur = g.nck;
     double t_loss = g.M > 0 ? save_t[g.M - 1] : 0.0;
@@ -189,6 +192,7 @@ HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
             QA::template vjp<ALG == 0>(kc, yc, zz[0], t, dl, dm);
             dz[0] = -dl;
             if constexpr (ALG == 0) dz[1] = -dm;
+            else dz[1] = 0.0;                                  // Gauss: the dummy component (QuadNZ)
         }
     };
     auto cb = [&](double t, double tprev, double (&zz)[NZ], const auto& KK) -> bool {
@@ -229,7 +233,7 @@ HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
     const int ncomp = ALG == 0 ? N + NP : (ALG == 1 ? 2 * N + NP : N);
     const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.maxit, K, rhs, cb, NoPre(), QuadNorm{ncomp});
     if (ownl) du0[i * N + c] = z[0];
-    if (ownm) dp_traj[(long)c * g.Npad + i] = (ALG == 2) ? gacc : z[1 < NZ ? 1 : 0];
+    if (ownm) dp_traj[(long)c * g.Npad + i] = (ALG == 2) ? gacc : z[1];
     if (na < 0 && c == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(flag, 4);
