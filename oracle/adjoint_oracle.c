@@ -349,7 +349,7 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
  * du0 is lam(t0) exactly as the reference returns it (src/sensitivity_interface.jl:500) - no M' factor.
  * Singular M (semi-explicit DAE, :117-135, 790-803) needs an implicit solver and is outside this restatement.
  * Process-wide and read-only while a solve runs (set before, cleared after). */
-#define ORC_MM_MAXN 8
+#define ORC_MM_MAXN 64      /* (8 until round 4: traced wide models carry mass matrices beyond the lane family) */
 static int g_mm_n = 0;
 static double g_mm_inv[ORC_MM_MAXN * ORC_MM_MAXN], g_mm_invT[ORC_MM_MAXN * ORC_MM_MAXN];
 int orc_set_mass_matrix(int n, const double *M) {

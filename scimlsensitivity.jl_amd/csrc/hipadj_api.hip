@@ -395,6 +395,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         {   // the composition tree of the one-launch reverse pass (hipadj_fused.hpp): map slots per (block, node) and arrival counters
             if (const char* e = std::getenv("HIPADJ_FUSED")) h->fused = std::atoi(e);
             if (!fused_eligible(cfg, P)) h->fused = 0;
+            if (P.user && !rtc_trusted() && !std::getenv("HIPADJ_FUSED")) h->fused = 0;   // a runtime model compiled by a toolkit other than the build's: the in-launch hand-offs rest on
+                                                                                          // this compiler's code generation (hipadj_fused.hpp tree_arrive_last): three launches instead
             int radix = 4;
             if (const char* e = std::getenv("HIPADJ_TREE_RADIX")) radix = std::atoi(e) == 8 ? 8 : 4;
             long slots = 0, ctrs = 0;

@@ -109,6 +109,10 @@ __device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, uns
     unsigned old = 0;
     if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    // compiler-level ordering: the last arriver's sc1 loads of the children's payloads sit behind the control dependency on `old` AND behind this
+    // barrier, so no compiler version may hoist them above the ticket; the hardware side is the guide's recipe (16-byte sc1 stores drained before the ticket,
+    // sc1 loads after it: cdna_hip_programming.md section 6 G16).  Runtime models under an UNTRUSTED hiprtc keep the three-launch pass (hipadj_api.hip).
+    asm volatile("" ::: "memory");
     if (old != expected - 1u) return false;
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next pass
     return true;

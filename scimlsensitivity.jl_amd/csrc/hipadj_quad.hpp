@@ -88,6 +88,7 @@ HIPADJ_HD void forward_quad_ev(const Geom& g, long i, int c, const double* __res
         if (e + 1 < ev.nev) { kn_next = ev.knot[e + 1]; ck_next = ev.ckpt[e + 1]; sv_next = ev.save[e + 1]; } else kn_next = g.S;
         const double dt = (k == g.S - 1) ? g.h_last : g.dt, hh = 0.5 * dt, h6 = dt / 6.0;
         if (knots) {
+#pragma unroll 2
             for (; k < kn_end; ++k) {
                 const double t = g.t0 + k * g.dt;
                 { dbl2 d; d.x = u; d.y = k1; *kn = d; kn += kstep; }

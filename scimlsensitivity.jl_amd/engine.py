@@ -94,6 +94,10 @@ class Engine:
         du0 = np.empty((self.N, self.n))
         dp = np.empty(self.np if self.p_shared else (self.N, self.np))
         self._check(self._L.hipadj_adjoint(self._h, _dptr(dLdu) if dLdu is not None else None, _dptr(du0), _dptr(dp)))
+        from . import problems
+        M = problems.WIDE_MASS_MATRICES.get(self.model)
+        if M is not None:      # a traced wide model with a mass matrix: the device integrated nu = M' lam (problems.py from_callable); the reference returns lam(t0)
+            du0 = np.linalg.solve(M.T, du0.T).T.copy()
         return du0, dp
 
     # ---- device-pointer API (torch tensors on cuda:<device>) -------------------------------------------

@@ -15,6 +15,7 @@ ARRAYS and every operation knows how its adjoint is distributed:
     gather(x, idx), roll(x, s)                                              static index maps; the adjoint is the gather through the inverse map (no atomics, fixed order)
     sum(x)                                                                  workgroup sum (wg_sum); adjoint = broadcast
     matvec(p[a:b] as m x k column-major, x)                                 dense parameter matrix: adjoints W' g and the outer product into the gradient
+    matvec_const(A, x)                                                      constant matrix (e.g. the inverse of a mass matrix): adjoint A' g
 
     def ring(u, p, t, ops):                     # du_i = p_i (u_{i+1} - u_i) + p_n sin(u_{i-1})
         n = u.length
@@ -125,6 +126,14 @@ class Ops:
         return Arr("sum", 0, (x,))
 
     @staticmethod
+    def matvec_const(A, x):
+        """A @ x with a CONSTANT matrix A (m x k, numpy): e.g. the inverse of a mass matrix."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        if A.ndim != 2 or x.length != A.shape[1]:
+            raise ValueError("matvec_const: a constant m x k matrix and an array of k entries")
+        return Arr("cmatvec", A.shape[0], (x,), A=A)
+
+    @staticmethod
     def matvec(pslice, m, x):
         """reshape(p[a:b], (m, k)) @ x with the matrix in column-major order (Lux / Julia `reshape`): W[i, j] = p[a + i + j m]."""
         if pslice.kind != "pslice" or x.length == 0 or pslice.length != int(m) * x.length:
@@ -170,12 +179,12 @@ class _Gen:
         self.tables, self.table_of = [], {}
         self.ws = 0
         for x in self.order:          # sources of gathers / matvecs must be addressable
-            if x.kind in ("gather", "matvec"):
+            if x.kind in ("gather", "matvec", "cmatvec"):
                 s = x.args[0]
                 if s.kind not in _LEAF and s.id not in self.mat:
                     self.mat[s.id] = self._alloc(s.length)
         for x in self.order:
-            if x.kind == "matvec" and x is not root:
+            if x.kind in ("matvec", "cmatvec") and x is not root:
                 self.mat[x.id] = self._alloc(x.length)
         if not scalar_root:
             self.mat[root.id] = None
@@ -296,7 +305,12 @@ class _Gen:
             out.append(f"double s{x.id}; {{ double part = 0.0; HIPADJ_W_FOR(i, {x.args[0].length}) {{ {' '.join(lines)} part += {v}; }} s{x.id} = wg_sum(part); }}")
             return
         dst = self._base(x)
-        if x.kind == "matvec":
+        if x.kind == "cmatvec":
+            A = x.data["A"]; m, k = A.shape
+            tab = self._table("double", A.ravel(), "mtab")
+            src = self._base(x.args[0])
+            out.append(f"HIPADJ_W_FOR(i, {m}) {{ double s = 0.0; for (int j = 0; j < {k}; ++j) s += {tab}[i * {k} + j] * {src}[j]; {dst}[i] = s; }}")
+        elif x.kind == "matvec":
             m, k, off = x.data["m"], x.data["k"], x.data["off"]
             src = self._base(x.args[0])
             out.append(f"HIPADJ_W_FOR(i, {m}) {{ double s = 0.0; for (int j = 0; j < {k}; ++j) s += p[{off} + i + j * {m}] * {src}[j]; {dst}[i] = s; }}")
@@ -405,6 +419,14 @@ class _Gen:
                 src = x.args[0]
                 body = self._reverse_loop(src, f"bt{x.id}", gathers)
                 out.append(f"HIPADJ_W_FOR(i, {src.length}) {{ {' '.join(body)} }}")
+            elif x.kind == "cmatvec":
+                A = x.data["A"]; m, k = A.shape
+                tab = self._table("double", A.ravel(), "mtab")
+                zb = "lam" if x is root else f"(ws + {self.adj[x.id]})"
+                base, wp = self._target(x.args[0])
+                if base:
+                    line = f"HIPADJ_W_FOR(j, {k}) {{ double s = 0.0; for (int i = 0; i < {m}; ++i) s += {tab}[i * {k} + j] * {zb}[i]; "
+                    out.append(line + (f"if (WP) {base}[j] += w * s; }}" if wp else f"{base}[j] += s; }}"))
             elif x.kind == "matvec":
                 m, k, off = x.data["m"], x.data["k"], x.data["off"]
                 zb = "lam" if x is root else f"(ws + {self.adj[x.id]})"
@@ -478,7 +500,7 @@ def bodies(fn, n, npar):
     du = fn(u, p, t, Ops())
     if not isinstance(du, Arr):
         raise TypeError("the traced function must return the array expression of du")
-    if du.kind != "ew" and du.kind != "matvec":
+    if du.kind not in ("ew", "matvec", "cmatvec"):
         du = du * 1.0                                # a bare leaf / gather as the right-hand side: give it an elementwise root
     g = _Gen(du, n, npar)
     fb = g.forward_body()

@@ -7,7 +7,9 @@ timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -4 $OUT/
 ( timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ); tail -c 300 $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $REPO/bench.py --no-cpu-baseline --no-extras --no-pmc --steps 20 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; rm -rf $OUT/trace
+find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+find $OUT/trace -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_trace.csv; rm -rf $OUT/trace
+python $REPO/scripts/r4/phases.py $OUT/kernel_trace.csv 20 5 | tee $OUT/kernel_phases.txt
 cd $REPO
 scripts/r4/quad_fwd > $OUT/quad_fwd.log 2>&1
 ( HIPADJ_QUAD=1 python scripts/r4/ts5_bench.py; HIPADJ_QUAD=0 python scripts/r4/ts5_bench.py ) 2>&1 | grep -v amdgpu.ids > $OUT/ts5_quad_ab.log

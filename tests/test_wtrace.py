@@ -217,3 +217,44 @@ def test_emitted_text_is_pinned_by_a_golden_file():
         fn, n, npar, _, _ = CASES[case]
         fb, vb, nw, nacc, a0 = wtrace.bodies(fn, n, npar)
         assert (fb, vb, nw, nacc, a0) == (g["f"], g["vjp"], g["lds_doubles"], g["nacc"], g["acc_first"]), case
+
+
+def test_constant_matrix_products_on_the_host():
+    """ops.matvec_const (the inverse of a mass matrix at trace level): f and the joint VJP of F = A f(u) against numpy"""
+    n = 7
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((n, n)) + 3.0 * np.eye(n)
+    f, vjp = host_model(lambda u, p, t, ops: ops.matvec_const(A, ring(u, p, t, ops)), n, n + 1)
+    u, p, lam = rng.uniform(0.2, 1.2, n), rng.uniform(-0.8, 0.9, n + 1), rng.standard_normal(n)
+    base = O.model_f("RING", u, p, 0.0, (n, 0, 0, 0))
+    assert np.max(np.abs(f(u, p, 0.0) - A @ base)) < 1e-13
+    dl, gp = vjp(lam, u, p, 0.0)
+    rdl, rgp = O.model_vjp("RING", A.T @ lam, u, p, 0.0, (n, 0, 0, 0))
+    assert np.max(np.abs(dl - rdl)) < 1e-12 and np.max(np.abs(gp - rgp)) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE")])
+@pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
+def test_traced_wide_model_with_a_mass_matrix(sa, alg, oalg, stepper):
+    """ODEFunction(f; mass_matrix = M) for a model beyond the lane family (test/Core3/adjoint.jl:1315-1376 restated on a 12-state ring): M^{-1} is folded into the traced
+    right-hand side, the device integrates nu = M' lam, the host maps du0 = M^{-T} nu(t0); against the oracle, which carries M the reference's way."""
+    n = 12
+    rng = np.random.default_rng(13)
+    M = np.eye(n) * 2.0 + 0.3 * rng.standard_normal((n, n))
+    name = "wt_ring_mm"
+    fun = _FUN.get(name) or sa.WideDeviceFunction.from_callable(name, ring, n, n + 1, mass_matrix=M)
+    _FUN[name] = fun
+    N, T, dt = 5, 0.6, 0.01
+    ts = np.linspace(0.0, T, 5)
+    u0 = rng.uniform(0.3, 1.0, (N, n)); p = rng.uniform(0.2, 0.7, n + 1)
+    delta = rng.standard_normal((N, len(ts), n))
+    sens = dict(interpolating=sa.InterpolatingAdjoint(), backsolve=sa.BacksolveAdjoint(checkpointing=True), gauss=sa.GaussAdjoint(), quadrature=sa.QuadratureAdjoint(abstol=1e-12, reltol=1e-12))[alg]
+    salg, kw, okw = (sa.RK4(), dict(dt=dt), dict(stepper="RK4", dt=dt)) if stepper == "rk4" else (sa.Tsit5(), dict(abstol=1e-10, reltol=1e-10), dict(stepper="TSIT5", dt=0.0, abstol=1e-10, reltol=1e-10))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), salg, saveat=ts, sensealg=sens, **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, t=ts, dgdu_discrete=delta)
+    sol.engine.close()
+    with O.mass_matrix(M):
+        ref = O.Problem("RING", alg=oalg, t0=0.0, t1=T, save_times=ts, checkpointing=(alg == "backsolve"), dims=(n, 0, 0, 0), quad_abstol=1e-12, quad_reltol=1e-12, **okw)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(sol.u, rout) < 1e-6 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
