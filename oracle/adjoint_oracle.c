@@ -685,6 +685,7 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
         }
     }
     if (nrhs_out) *nrhs_out += I.nrhs;
+    if (getenv("ORC_TRACE_STEPS")) fprintf(stderr, "orc integrate: %s accepted %ld rejected %ld rhs %ld\n", I.tdir < 0 ? "reverse" : "forward", I.naccept, I.nreject, I.nrhs);   /* debugging aid: step statistics */
     free(ts); free(buf);
     return status;
 }

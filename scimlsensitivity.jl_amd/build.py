@@ -16,7 +16,7 @@ SRC = os.path.join(CSRC, "hipadj_api.hip")
 # A/B builds: HIPADJ_BUILD_LIB=<path of another .so> HIPADJ_BUILD_EXTRA="-D..." (objects go to build_<stem>/, the shipped library is untouched; load the
 # variant with HIPADJ_LIBRARY=<path>)
 LIB = os.environ.get("HIPADJ_BUILD_LIB") or os.path.join(HERE, "libhipadj.so")
-OBJ = os.path.join(HERE, "build" if "HIPADJ_BUILD_LIB" not in os.environ else "build_" + os.path.splitext(os.path.basename(LIB))[0])
+OBJ = os.path.join(HERE, "build") if "HIPADJ_BUILD_LIB" not in os.environ else os.path.join(HERE, "build_ab", os.path.splitext(os.path.basename(LIB))[0])   # build_ab/: git- and gpurun-ignored
 
 DEPS = sorted(glob.glob(os.path.join(CSRC, "*.h*"))) + [os.path.join(CSRC, "hipadj.map")] + [os.path.join(os.path.dirname(HERE), "include", "hipadj.h"), os.path.abspath(__file__)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("HIPADJ_BUILD_EXTRA", "").split()

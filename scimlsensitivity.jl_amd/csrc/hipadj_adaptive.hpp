@@ -88,6 +88,50 @@ HIPADJ_HD double hmin2(double a, double b) { return a < b ? a : b; }
 HIPADJ_HD double habs(double a) { return a < 0 ? -a : a; }
 HIPADJ_HD bool time_hits(double t, double target) { return habs(t - target) <= 100.0 * 2.220446049250313e-16 * hmax2(habs(t), habs(target)); }
 
+// log and exp of the step-size controller.  The factor EEst^(7/50) / qold^(2/25) costs two logarithms, two exponentials and a division per attempt when written with the math
+// library (~400 instructions: a third of a Lorenz attempt of the quad sweep, profiles/r4_tsit5_quad_counters.txt); here it is ONE logarithm (log qold is the previous accepted
+// attempt's, kept) and ONE exponential of the difference, both inlined at double accuracy (a few ulp: the accept / reject decision itself never sees them, only the NEXT step's
+// length does, exactly as with the round-2 exp(c log x) form of pow).  log: x = 2^e m, m in [sqrt(1/2), sqrt 2), log m = 2 atanh s, s = (m - 1) / (m + 1), |s| <= 0.172, odd
+// series to s^19; exp: r = y - k ln 2 (two-part), Taylor to r^12, ldexp.  The host pass (emulator) calls the library.
+HIPADJ_HD double ts5_log(double x) {      // x finite, > 0, normal
+#if defined(__HIP_DEVICE_COMPILE__)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m; e = low ? e - 1 : e;
+    const double a = m - 1.0, b = m + 1.0;
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    double sq = a * r;
+    sq = __builtin_fma(__builtin_fma(-b, sq, a), r, sq);
+    const double z = sq * sq;
+    double P = 1.0 / 19.0;
+    P = __builtin_fma(P, z, 1.0 / 17.0); P = __builtin_fma(P, z, 1.0 / 15.0); P = __builtin_fma(P, z, 1.0 / 13.0); P = __builtin_fma(P, z, 1.0 / 11.0);
+    P = __builtin_fma(P, z, 1.0 / 9.0); P = __builtin_fma(P, z, 1.0 / 7.0); P = __builtin_fma(P, z, 1.0 / 5.0); P = __builtin_fma(P, z, 1.0 / 3.0);
+    const double s2 = sq + sq;
+    const double lm = __builtin_fma(s2 * z, P, s2);
+    return __builtin_fma((double)e, 6.93147180559945286e-01, lm);
+#else
+    return log(x);
+#endif
+}
+HIPADJ_HD double ts5_exp(double y) {      // |y| < 700
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double kf = __builtin_rint(y * 1.44269504088896339);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, y);
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+    double q = 1.0 / 479001600.0;
+    q = __builtin_fma(q, r, 1.0 / 39916800.0); q = __builtin_fma(q, r, 1.0 / 3628800.0); q = __builtin_fma(q, r, 1.0 / 362880.0);
+    q = __builtin_fma(q, r, 1.0 / 40320.0); q = __builtin_fma(q, r, 1.0 / 5040.0); q = __builtin_fma(q, r, 1.0 / 720.0);
+    q = __builtin_fma(q, r, 1.0 / 120.0); q = __builtin_fma(q, r, 1.0 / 24.0); q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5); q = __builtin_fma(q, r, 1.0); q = __builtin_fma(q, r, 1.0);
+    return __builtin_amdgcn_ldexp(q, (int)kf);
+#else
+    return exp(y);
+#endif
+}
+
 // Stage storage of one lane: rows 0..6 = k_1..k_7 of the current step, row 7 = the step's start value.
 // Device: base = LDS array + lane, stride = 64.  Host emulation: a local array, stride 1.
 constexpr int KS_ROWS = 8, KS_UPREV = 7;
@@ -254,7 +298,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             for (int i = 0; i < NZ; ++i) K.set(j, i, 0.0);
     }
     bool need_k0 = true, first = true;
-    double dt = 0.0, qold = 1e-4;
+    double dt = 0.0, lqold = -9.21034037197618272;   // log qold, qold = 1e-4
     int its = 0, naccept = 0, guard = 0;
     double ts_cur = ntstops > 0 ? tstops[0] : tend;
 #pragma unroll 1
@@ -412,15 +456,15 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             }
         }
         const double EEst = sqrt(red.sum(e2, 3, h) / ncomp);
-        // x^c as exp(c log x): within a few ulp of pow() (the step-size factor is not an accuracy-critical quantity) at about a
-        // third of its instruction count
-        const double q11 = exp((7.0 / 50.0) * log(hmax2(EEst, 1e-300)));
-        double q = q11 / exp((2.0 / 25.0) * log(qold));
+        // q = EEst^(7/50) / qold^(2/25) as ONE exponential of (7/50) log EEst - (2/25) log qold, log qold kept from the attempt that set qold (ts5_log / ts5_exp above);
+        // EEst^(7/50) alone is needed by a rejected attempt only
+        const double lE = ts5_log(hmin2(hmax2(EEst, 1e-300), 1e300));
+        double q = ts5_exp((7.0 / 50.0) * lE - (2.0 / 25.0) * lqold);
         q = hmax2(1.0 / 10.0, hmin2(5.0, q / 0.9));
         if (EEst <= 1.0 || habs(h) < 1e-14 * hmax2(1.0, habs(t))) {
             double tnew = t + h;
             if (habs(tnew - tstop) < 100.0 * EPS * hmax2(habs(tnew), habs(tstop))) tnew = tstop;
-            qold = hmax2(EEst, 1e-4);
+            lqold = hmax2(lE, -9.21034037197618272);     // qold = max(EEst, 1e-4)
 #pragma unroll
             for (int i = 0; i < NZ; ++i) u[i] = w[i];
             red.accept(h);
@@ -435,7 +479,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             }
             if (naccept > max_steps) return -1;
         } else {
-            dt = h / hmin2(5.0, q11 / 0.9);
+            dt = h / hmin2(5.0, ts5_exp((7.0 / 50.0) * lE) / 0.9);
             // the step's start value comes back from its LDS row: with both outcomes of the step test overwriting u, the register
             // copy of u is dead across the stage loop (2 NZ VGPRs less at the point of highest pressure; same values, bit for bit)
 #pragma unroll

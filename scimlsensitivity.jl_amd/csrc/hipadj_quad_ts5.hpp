@@ -124,23 +124,46 @@ HIPADJ_HD void forward_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
     }
 }
 
-// one component of the forward dense solution: the step containing t, this lane's five coefficients cached in registers (FwdCursor with one component)
+// one component of the forward dense solution: the step containing t, this lane's five coefficients cached in registers (FwdCursor with one component).
+// The record BELOW the current one is requested when the cursor arrives on a record and consumed when it walks down: the sweep changes record ~3 times per attempt
+// of a wavefront (16 trajectories, each at its own abscissa), and a change used to cost two dependent round trips (the end point, then the coefficients) — 37 % of the
+// wavefront's cycles were s_waitcnt (profiles/r4_tsit5_quad_counters.txt).  Seven extra registers per lane here; the lane family's 5 n + 2 did not pay (hipadj_adaptive.hpp).
 template <class Mo> struct QuadCursor {
     static constexpr int N = Mo::N, RW = 2 + 5 * Mo::N;
-    const double* rec; long Npad, i; int ns, sc, lc, c; bool own;
+    const double* rec; long Npad, i; int ns, sc, c; bool own;
     double ta, tb, cf[5];
+    double pta, pcf[5];            // record sc - 1 (requested; valid when sc > 0)
+    HIPADJ_HD void fetch_coef(double (&d)[5], int s) const {
+        const long base = ((long)s * RW + 2 + c) * Npad + i;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) d[m] = own ? rec[base + (long)(m * N) * Npad] : 0.0;
+    }
+    HIPADJ_HD void fetch_below() {
+        if (sc > 0) { pta = rec[((long)(sc - 1) * RW + 0) * Npad + i]; fetch_coef(pcf, sc - 1); }
+    }
     HIPADJ_HD void init(const double* r, long np, long ii, int nsteps, int comp, bool o) {
-        rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; lc = -1; c = comp; own = o;
+        rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; c = comp; own = o;
         ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i];
+        fetch_coef(cf, sc);
+        pta = ta;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) pcf[m] = 0.0;
+        fetch_below();
     }
     HIPADJ_HD double eval(double t) {
-        while (t < ta && sc > 0) { --sc; tb = ta; ta = rec[((long)sc * RW + 0) * Npad + i]; }
-        while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[((long)sc * RW + 1) * Npad + i]; }
-        if (sc != lc) {
-            lc = sc;
-            const long base = ((long)sc * RW + 2 + c) * Npad + i;
+        if (t < ta && sc > 0) {
+            --sc; tb = ta; ta = pta;                       // one record down: requested when the cursor arrived on the record above
 #pragma unroll
-            for (int m = 0; m < 5; ++m) cf[m] = own ? rec[base + (long)(m * N) * Npad] : 0.0;
+            for (int m = 0; m < 5; ++m) cf[m] = pcf[m];
+            if (t < ta && sc > 0) {                         // further down (a step longer than a forward step): walk, then the coefficients
+                while (t < ta && sc > 0) { --sc; tb = ta; ta = rec[((long)sc * RW + 0) * Npad + i]; }
+                fetch_coef(cf, sc);
+            }
+            fetch_below();
+        } else if (t > tb && sc < ns - 1) {                 // up: after a rejected attempt
+            while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[((long)sc * RW + 1) * Npad + i]; }
+            fetch_coef(cf, sc);
+            fetch_below();
         }
         const double th = (t - ta) / (tb - ta);
         return cf[0] + th * (cf[1] + th * (cf[2] + th * (cf[3] + th * cf[4])));

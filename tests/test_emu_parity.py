@@ -194,7 +194,8 @@ TS_ALGS = ["interpolating", "backsolve", "gauss", "quadrature"]
 @pytest.mark.parametrize("alg", TS_ALGS)
 @pytest.mark.parametrize("model,omodel,u0c,p", MODELS)
 def test_tsit5_lane_bodies_match_oracle(alg, model, omodel, u0c, p):
-    """Same controller arithmetic as the oracle => identical step sequences on the host build (no FMA contraction)."""
+    """The oracle's controller up to the rounding of the step-size factor (pow there, ONE exp of a difference of logs here: hipadj_adaptive.hpp ts5_log / ts5_exp) => the same
+    accept / reject sequence with step lengths equal to a few ulp on the host build (no FMA contraction); Lorenz amplifies those ulps to a few 1e-10 over T = 2."""
     rng = np.random.default_rng(14)
     N, T = 4, 2.0
     n, npar = len(u0c), len(p)
@@ -209,7 +210,7 @@ def test_tsit5_lane_bodies_match_oracle(alg, model, omodel, u0c, p):
     ref = O.Problem(omodel, alg=alg.upper(), stepper="TSIT5", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-7, save_times=ts,
                     loss="COTANGENT", checkpointing=ck, quad_abstol=1e-9, quad_reltol=1e-9)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
-    assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+    assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
 
 
 @pytest.mark.parametrize("alg", TS_ALGS)
