@@ -218,7 +218,8 @@ end
 
 The SPMD bodies of `u' = Chain(x -> x.^input_power, Dense(w1, w2, tanh), ..., Dense(w_{L}, w_{L+1}))(u)` with the parameters in Lux's flattening
 order (per layer: weight `[out x in]` column-major, then bias).  Lanes run over the outputs of a layer; a contraction with at most 8 outputs over at
-least 16 inputs runs lanes-over-inputs with one `wg_sum` (wavefront shuffles) per output.  Mirrors `WideDeviceFunction.dense_chain` of the Python host.
+least 16 inputs runs lanes-over-inputs with one `wg_sum` (wavefront shuffles) per output; a chain with ONE hidden layer and at most 8 inputs keeps every hidden unit
+in its thread's registers (no LDS scratch, no barrier).  Mirrors `WideDeviceFunction.dense_chain` of the Python host.
 """
 function dense_chain_bodies(widths; input_power::Integer = 1)
     w = collect(Int, widths); L = length(w) - 1
@@ -239,6 +240,27 @@ function dense_chain_bodies(widths; input_power::Integer = 1)
         end
         return [string("HIPADJ_W_FOR(i, $nout) { double s = ", bias === nothing ? "0.0" : bias("i"), "; for (int j = 0; j < $nin; ++j) s += ", coef("i", "j"), " * ", vec("j"),
                        "; ", out("i"), " = ", post("s", "i"), "; }")]
+    end
+    if L == 2 && w[1] <= 8
+        # ONE hidden layer between few inputs / outputs (the published 2-50-2 net): a hidden unit's activation, back-propagated value and gradient entries stay in the
+        # registers of the thread that owns it; only the d outputs / the d entries of dlam cross lanes (one wavefront sum each).  No LDS scratch, no barrier.
+        d, H = w[1], w[2]
+        W1, B1, W2, B2 = Woff[1], Boff[1], Woff[2], Boff[2]
+        xs = [string("const double x$k = ", join(fill("u[$k]", input_power), " * "), ";") for k in 0:(d - 1)]
+        hid = string("double s = p[$B1 + i]; ", join(["s += p[$W1 + i + $(k * H)] * x$k;" for k in 0:(d - 1)], " "), " const double h = tanh(s);")
+        fb = vcat(xs, [join(["double part$m = 0.0;" for m in 0:(d - 1)], " "),
+                       string("HIPADJ_W_FOR(i, $H) { $hid ", join(["part$m += p[$W2 + $m + i * $d] * h;" for m in 0:(d - 1)], " "), " }")],
+                  ["{ const double s = p[$B2 + $m] + wg_sum(part$m); if (tid == $m) du[$m] = s; }" for m in 0:(d - 1)])
+        vb = vcat(xs, [join(["const double l$m = lam[$m];" for m in 0:(d - 1)], " "), join(["double part$k = 0.0;" for k in 0:(d - 1)], " "),
+                       "HIPADJ_W_FOR(i, $H) { $hid",
+                       string("  double gh = ", join(["p[$W2 + $m + i * $d] * l$m" for m in 0:(d - 1)], " + "), ";"),
+                       string("  if (WP) { const double wh = w * h; ", join(["gp[$W2 + $m + i * $d] += l$m * wh;" for m in 0:(d - 1)], " "), " }"),
+                       "  gh *= 1.0 - h * h;",
+                       string("  if (WP) { const double wg = w * gh; ", join(["gp[$W1 + i + $(k * H)] += wg * x$k;" for k in 0:(d - 1)], " "), " gp[$B1 + i] += wg; }"),
+                       string("  ", join(["part$k += p[$W1 + i + $(k * H)] * gh;" for k in 0:(d - 1)], " "), " }"),
+                       "if (WP) { HIPADJ_W_FOR(m, $d) gp[$B2 + m] += w * lam[m]; }"],
+                  ["{ const double s = wg_sum(part$k); if (tid == $k) dlam[$k] = s * $(dinp(k)); }" for k in 0:(d - 1)])
+        return join(fb, "\n"), join(vb, "\n"), off, 1
     end
     fwd = String["HIPADJ_W_FOR(i, $(w[1])) ws[$(A[1]) + i] = $inp;", "wg_sync();"]
     for l in 1:(L - 1)
