@@ -216,7 +216,8 @@ int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double 
  *             such parameters; the partials are summed over the workgroup once per sweep)
  * Available inside the bodies: `tid`, `T` (= threads), `N`, `NP`, `HIPADJ_W_FOR(i, count) { ... }` (i = tid, tid + T, ... < count),
  * `wg_sync()` (workgroup barrier between dependent phases, e.g. hidden layers), `wg_sum(x)` (sum of one value per thread over the workgroup,
- * returned to every thread: wavefront shuffles; every thread must call it), `ws[0..lds_doubles)` LDS scratch.  u, lam, du, dlam, ws are
+ * returned to every thread: wavefront shuffles; every thread must call it), `wg_sum2(a, b, sa, sb)` (two such sums at once: one v_permlane32_swap level serves both),
+ * `ws[0..lds_doubles)` LDS scratch.  u, lam, du, dlam, ws are
  * LDS, p is global memory.  threads: a multiple of 64 in [64, 1024], 0 = automatic.  Offered: fixed-step RK4 (loss times on the step grid;
  * Interpolating / Backsolve (checkpoints) / Gauss / GaussKronrod / QuadratureAdjoint) and adaptive Tsit5 with per-trajectory step control (stepper =
  * HIPADJ_STEPPER_TSIT5_ADAPTIVE, arbitrary loss times; all four sensealgs and GaussKronrod on both — adaptive Interpolating and Backsolve keep five np-sized rows in LDS,

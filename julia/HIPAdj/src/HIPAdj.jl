@@ -243,23 +243,26 @@ function dense_chain_bodies(widths; input_power::Integer = 1)
     end
     if L == 2 && w[1] <= 8
         # ONE hidden layer between few inputs / outputs (the published 2-50-2 net): a hidden unit's activation, back-propagated value and gradient entries stay in the
-        # registers of the thread that owns it; only the d outputs / the d entries of dlam cross lanes (one wavefront sum each).  No LDS scratch, no barrier.
+        # registers of the thread that owns it; only the d outputs / the d entries of dlam cross lanes (in pairs: wg_sum2).  No LDS scratch, no barrier.  Every multiply-add
+        # is an explicit fma(): the dense and the checkpointed sweep are compared bit for bit and must not depend on how each kernel's compile contracted a sum of products.
         d, H = w[1], w[2]
         W1, B1, W2, B2 = Woff[1], Boff[1], Woff[2], Boff[2]
         xs = [string("const double x$k = ", join(fill("u[$k]", input_power), " * "), ";") for k in 0:(d - 1)]
-        hid = string("double s = p[$B1 + i]; ", join(["s += p[$W1 + i + $(k * H)] * x$k;" for k in 0:(d - 1)], " "), " const double h = tanh(s);")
+        hid = string("double s = p[$B1 + i]; ", join(["s = fma(p[$W1 + i + $(k * H)], x$k, s);" for k in 0:(d - 1)], " "), " const double h = tanh(s);")
         fb = vcat(xs, [join(["double part$m = 0.0;" for m in 0:(d - 1)], " "),
-                       string("HIPADJ_W_FOR(i, $H) { $hid ", join(["part$m += p[$W2 + $m + i * $d] * h;" for m in 0:(d - 1)], " "), " }")],
-                  ["{ const double s = p[$B2 + $m] + wg_sum(part$m); if (tid == $m) du[$m] = s; }" for m in 0:(d - 1)])
+                       string("HIPADJ_W_FOR(i, $H) { $hid ", join(["part$m = fma(p[$W2 + $m + i * $d], h, part$m);" for m in 0:(d - 1)], " "), " }")],
+                  [m + 1 < d ? "{ double s$m, s$(m + 1); wg_sum2(part$m, part$(m + 1), s$m, s$(m + 1)); if (tid == $m) du[$m] = p[$B2 + $m] + s$m; if (tid == $(m + 1)) du[$(m + 1)] = p[$B2 + $(m + 1)] + s$(m + 1); }" :
+                                "{ const double s = p[$B2 + $m] + wg_sum(part$m); if (tid == $m) du[$m] = s; }" for m in 0:2:(d - 1)])
         vb = vcat(xs, [join(["const double l$m = lam[$m];" for m in 0:(d - 1)], " "), join(["double part$k = 0.0;" for k in 0:(d - 1)], " "),
                        "HIPADJ_W_FOR(i, $H) { $hid",
-                       string("  double gh = ", join(["p[$W2 + $m + i * $d] * l$m" for m in 0:(d - 1)], " + "), ";"),
-                       string("  if (WP) { const double wh = w * h; ", join(["gp[$W2 + $m + i * $d] += l$m * wh;" for m in 0:(d - 1)], " "), " }"),
+                       string("  double gh = p[$W2 + 0 + i * $d] * l0; ", join(["gh = fma(p[$W2 + $m + i * $d], l$m, gh);" for m in 1:(d - 1)], " ")),
+                       string("  if (WP) { const double wh = w * h; ", join(["gp[$W2 + $m + i * $d] = fma(l$m, wh, gp[$W2 + $m + i * $d]);" for m in 0:(d - 1)], " "), " }"),
                        "  gh *= 1.0 - h * h;",
-                       string("  if (WP) { const double wg = w * gh; ", join(["gp[$W1 + i + $(k * H)] += wg * x$k;" for k in 0:(d - 1)], " "), " gp[$B1 + i] += wg; }"),
-                       string("  ", join(["part$k += p[$W1 + i + $(k * H)] * gh;" for k in 0:(d - 1)], " "), " }"),
-                       "if (WP) { HIPADJ_W_FOR(m, $d) gp[$B2 + m] += w * lam[m]; }"],
-                  ["{ const double s = wg_sum(part$k); if (tid == $k) dlam[$k] = s * $(dinp(k)); }" for k in 0:(d - 1)])
+                       string("  if (WP) { const double wg = w * gh; ", join(["gp[$W1 + i + $(k * H)] = fma(wg, x$k, gp[$W1 + i + $(k * H)]);" for k in 0:(d - 1)], " "), " gp[$B1 + i] += wg; }"),
+                       string("  ", join(["part$k = fma(p[$W1 + i + $(k * H)], gh, part$k);" for k in 0:(d - 1)], " "), " }"),
+                       "if (WP) { HIPADJ_W_FOR(m, $d) gp[$B2 + m] = fma(w, lam[m], gp[$B2 + m]); }"],
+                  [k + 1 < d ? "{ double s$k, s$(k + 1); wg_sum2(part$k, part$(k + 1), s$k, s$(k + 1)); if (tid == $k) dlam[$k] = s$k * $(dinp(k)); if (tid == $(k + 1)) dlam[$(k + 1)] = s$(k + 1) * $(dinp(k + 1)); }" :
+                                "{ const double s = wg_sum(part$k); if (tid == $k) dlam[$k] = s * $(dinp(k)); }" for k in 0:2:(d - 1)])
         return join(fb, "\n"), join(vb, "\n"), off, 1
     end
     fwd = String["HIPADJ_W_FOR(i, $(w[1])) ws[$(A[1]) + i] = $inp;", "wg_sync();"]

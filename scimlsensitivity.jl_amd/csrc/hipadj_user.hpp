@@ -234,7 +234,7 @@ inline std::string user_wide_struct(const UserModelSrc& m) {
     const int na = m.nacc > 0 ? m.nacc : 1;
     o << "#include \"hipadj_wide.hpp\"\n"
       << "namespace hipadj {\n// runtime-registered wide model '" << m.name << "' (workgroup-per-trajectory family, hipadj_wide.hpp)\n"
-      << "#define HIPADJ_W_FOR(i, n) for (int i = tid; i < (n); i += T)\n#define wg_sync() hipadj::wide_sync<T>()\n#define wg_sum(x) hipadj::wide_sum_all<T>(x)\n"
+      << "#define HIPADJ_W_FOR(i, n) for (int i = tid; i < (n); i += T)\n#define wg_sync() hipadj::wide_sync<T>()\n#define wg_sum(x) hipadj::wide_sum_all<T>(x)\n#define wg_sum2(a, b, sa, sb) hipadj::wide_sum2_all<T>(a, b, sa, sb)\n"
       // tanh of a model body = the 31-instruction form of the MFMA family (|difference| to libm 2.2e-16: hipadj_wide.hpp wide_tanh); the library tanh is ~150
       // instructions and dominated a joint VJP of the 2-50-2 neural ODE
       << "#define tanh(x) hipadj::wide_tanh(x)\n"

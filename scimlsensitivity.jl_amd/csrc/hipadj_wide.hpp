@@ -120,6 +120,23 @@ template <int T> __device__ __forceinline__ double wide_sum_all(double v) {
     }
 }
 
+// TWO sums over the workgroup at once (wg_sum2 of the SPMD bodies): sa = sum of a, sb = sum of b, to every thread.  On a single wavefront the first butterfly level
+// serves both — v_permlane32_swap (gfx950) leaves [a(0..31) | b(0..31)] and [a(32..63) | b(32..63)] in two registers, their sum holds 32 partials of a in the lower and 32
+// of b in the upper half — then the four DPP steps inside the rows once and four row sums through SGPRs: 27 instructions for the pair instead of 2 x 26.  Fixed order.
+template <int T> __device__ __forceinline__ void wide_sum2_all(double a, double b, double& sa, double& sb) {
+    if constexpr (T == 64 && HIPADJ_WIDE_DPP_SUM) {
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+        double v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+        v += wide_dpp<0xB1>(v);
+        v += wide_dpp<0x4E>(v);
+        v += wide_dpp<0x141>(v);
+        v += wide_dpp<0x140>(v);
+        sa = wide_readlane(v, 0) + wide_readlane(v, 16);
+        sb = wide_readlane(v, 32) + wide_readlane(v, 48);
+    } else { sa = wide_sum_all<T>(a); sb = wide_sum_all<T>(b); }
+}
+
 // tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2|x|): the MFMA family's form (hipadj_mlp.hpp mlp_tanh; max |difference| to libm tanh 2.2e-16), 31 instructions.
 // t = 2^k e^r with k = rint(a log2 e), r = a - k ln 2 (two-part constant), e^r by the degree-12 Taylor polynomial (|r| <= 0.347), the quotient by v_rcp_f64 +
 // two Newton steps + one residual correction.  Model bodies of wide runtime models get it under the name tanh (hipadj_user.hpp user_wide_struct).
@@ -332,7 +349,8 @@ __device__ __forceinline__ void wide_rk4_step(const WideTiles<Mo>& L, const doub
     const double t_hi = t_lo + dt, t_mid = t_lo + 0.5 * dt;
     double m[Q], s[Q], a[Q], v[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) m[q] = 0.5 * (lo.u[q] + hi.u[q]) + (0.125 * dt) * (lo.f[q] - hi.f[q]);
+    for (int q = 0; q < Q; ++q) m[q] = __builtin_fma(0.125 * dt, lo.f[q] - hi.f[q], 0.5 * (lo.u[q] + hi.u[q]));   // explicit: a sum of two products contracts either way round, and the
+                                                                                                                   // dense and the checkpointed sweep (two kernels) must agree bit for bit
     wide_vjp<Mo, WP>(L, pp, t_hi, dt / 6.0, hi.u, lam, acc, v1);
 #pragma unroll
     for (int q = 0; q < Q; ++q) { a[q] = v1[q]; s[q] = lam[q] + (0.5 * dt) * v1[q]; }
