@@ -46,6 +46,24 @@ def test_config2_full_ensemble_du0_and_dp_vs_oracle(sa):
     assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
 
 
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS")])
+def test_config2_ensemble_on_adaptive_tsit5_at_size(sa, alg, oalg):
+    """The C2 ensemble on the stepper of the reference's own tests (test/Core3/adjoint.jl:1157-1241 solves Lorenz with Tsit5): adaptive Tsit5 at 1e-9 / 1e-9, per-trajectory
+    step control, the four-lanes-per-trajectory kernels (k_forward_tsit5_quad, k_adjoint_tsit5_quad: inlined one-log-one-exp controller, look-ahead cursor) — every
+    trajectory's du0 and the reduced dp against the oracle's Tsit5 run on all 10^4 trajectories.  Device and oracle take the same step sequences up to the rounding of the
+    step-size factor, so they agree far below their common discretisation error; Lorenz over T = 10 amplifies that rounding to a few 1e-9."""
+    N, T, dt, u0, p, ts = _c2_setup()
+    ck = alg == "backsolve"
+    eng = sa.Engine("lorenz", alg, N, 0.0, T, 0.0, save_times=ts, loss_kind=1, loss_shift=2.0, p_shared=True, stepper=1, abstol=1e-9, reltol=1e-9, checkpointing=ck)
+    eng.forward(u0, p, want_out=False)
+    du0, dp = eng.adjoint(None)
+    eng.close()
+    ref = O.Problem("LORENZ", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, checkpointing=ck)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, want_out=False)
+    assert rel(du0, rdu0) < RTOL
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < RTOL
+
+
 @pytest.mark.parametrize("shards", [1, 8])
 def test_config3_backsolve_checkpointed_at_size(sa, shards):
     """BASELINE configs[2]: 10^4 x 1000 steps, BacksolveAdjoint(checkpointing=true), a checkpoint every 10 steps (= every loss time).
