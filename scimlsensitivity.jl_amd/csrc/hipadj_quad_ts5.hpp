@@ -128,6 +128,8 @@ HIPADJ_HD void forward_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
 // The record BELOW the current one is requested when the cursor arrives on a record and consumed when it walks down: the sweep changes record ~3 times per attempt
 // of a wavefront (16 trajectories, each at its own abscissa), and a change used to cost two dependent round trips (the end point, then the coefficients) — 37 % of the
 // wavefront's cycles were s_waitcnt (profiles/r4_tsit5_quad_counters.txt).  Seven extra registers per lane here; the lane family's 5 n + 2 did not pay (hipadj_adaptive.hpp).
+// A SECOND look-ahead level (record sc - 2 as well) measured slower: Interpolating 1.19 -> 1.32 ms, Gauss 1.76 -> 2.02 (the copies and the wider live range cost more than the
+// remaining wait).
 template <class Mo> struct QuadCursor {
     static constexpr int N = Mo::N, RW = 2 + 5 * Mo::N;
     const double* rec; long Npad, i; int ns, sc, c; bool own;
