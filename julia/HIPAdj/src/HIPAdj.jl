@@ -251,7 +251,7 @@ function dense_chain_bodies(widths; input_power::Integer = 1)
         hid = string("double s = p[$B1 + i]; ", join(["s = fma(p[$W1 + i + $(k * H)], x$k, s);" for k in 0:(d - 1)], " "), " const double h = tanh(s);")
         fb = vcat(xs, [join(["double part$m = 0.0;" for m in 0:(d - 1)], " "),
                        string("HIPADJ_W_FOR(i, $H) { $hid ", join(["part$m = fma(p[$W2 + $m + i * $d], h, part$m);" for m in 0:(d - 1)], " "), " }")],
-                  [m + 1 < d ? "{ double s$m, s$(m + 1); wg_sum2(part$m, part$(m + 1), s$m, s$(m + 1)); if (tid == $m) du[$m] = p[$B2 + $m] + s$m; if (tid == $(m + 1)) du[$(m + 1)] = p[$B2 + $(m + 1)] + s$(m + 1); }" :
+                  [m + 1 < d ? "{ double s$m, s$(m + 1); wg_sum2(part$m, part$(m + 1), s$m, s$(m + 1)); if (tid >= $m && tid < $(m + 2)) du[tid] = p[$B2 + tid] + (tid == $m ? s$m : s$(m + 1)); }" :
                                 "{ const double s = p[$B2 + $m] + wg_sum(part$m); if (tid == $m) du[$m] = s; }" for m in 0:2:(d - 1)])
         vb = vcat(xs, [join(["const double l$m = lam[$m];" for m in 0:(d - 1)], " "), join(["double part$k = 0.0;" for k in 0:(d - 1)], " "),
                        "HIPADJ_W_FOR(i, $H) { $hid",
@@ -261,7 +261,7 @@ function dense_chain_bodies(widths; input_power::Integer = 1)
                        string("  if (WP) { const double wg = w * gh; ", join(["gp[$W1 + i + $(k * H)] = fma(wg, x$k, gp[$W1 + i + $(k * H)]);" for k in 0:(d - 1)], " "), " gp[$B1 + i] += wg; }"),
                        string("  ", join(["part$k = fma(p[$W1 + i + $(k * H)], gh, part$k);" for k in 0:(d - 1)], " "), " }"),
                        "if (WP) { HIPADJ_W_FOR(m, $d) gp[$B2 + m] = fma(w, lam[m], gp[$B2 + m]); }"],
-                  [k + 1 < d ? "{ double s$k, s$(k + 1); wg_sum2(part$k, part$(k + 1), s$k, s$(k + 1)); if (tid == $k) dlam[$k] = s$k * $(dinp(k)); if (tid == $(k + 1)) dlam[$(k + 1)] = s$(k + 1) * $(dinp(k + 1)); }" :
+                  [k + 1 < d ? "{ double s$k, s$(k + 1); wg_sum2(part$k, part$(k + 1), s$k, s$(k + 1)); if (tid >= $k && tid < $(k + 2)) dlam[tid] = (tid == $k ? s$k : s$(k + 1)) * $(dinp("tid")); }" :
                                 "{ const double s = wg_sum(part$k); if (tid == $k) dlam[$k] = s * $(dinp(k)); }" for k in 0:2:(d - 1)])
         return join(fb, "\n"), join(vb, "\n"), off, 1
     end
