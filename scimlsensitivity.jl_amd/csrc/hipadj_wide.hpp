@@ -140,15 +140,17 @@ template <int T> __device__ __forceinline__ void wide_sum2_all(double a, double 
 // tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2|x|): the MFMA family's form (hipadj_mlp.hpp mlp_tanh; max |difference| to libm tanh 2.2e-16), 31 instructions.
 // t = 2^k e^r with k = rint(a log2 e), r = a - k ln 2 (two-part constant), e^r by the degree-12 Taylor polynomial (|r| <= 0.347), the quotient by v_rcp_f64 +
 // two Newton steps + one residual correction.  Model bodies of wide runtime models get it under the name tanh (hipadj_user.hpp user_wide_struct).
+// The Taylor coefficients come from constant memory: scalar loads (hoisted out of the step loop) leave them in SGPRs, which a VOP3 v_fma_f64 takes as its addend directly;
+// as literals they were materialised in VGPRs and every v_fmac (addend = destination) was preceded by a copy of its constant: nine v_mov_b64 per tanh.
+static __constant__ double wide_tanh_c[10] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0};
 __device__ __forceinline__ double wide_tanh(double x) {
     const double a = fmax(-2.0 * fabs(x), -80.0);
     const double kf = __builtin_rint(a * 1.4426950408889634074);
     double r = __builtin_fma(kf, -6.93147180369123816490e-01, a);
     r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
-    double q = 1.0 / 479001600.0;
-    q = __builtin_fma(q, r, 1.0 / 39916800.0); q = __builtin_fma(q, r, 1.0 / 3628800.0); q = __builtin_fma(q, r, 1.0 / 362880.0);
-    q = __builtin_fma(q, r, 1.0 / 40320.0); q = __builtin_fma(q, r, 1.0 / 5040.0); q = __builtin_fma(q, r, 1.0 / 720.0);
-    q = __builtin_fma(q, r, 1.0 / 120.0); q = __builtin_fma(q, r, 1.0 / 24.0); q = __builtin_fma(q, r, 1.0 / 6.0);
+    double q = wide_tanh_c[0];
+#pragma unroll
+    for (int k = 1; k < 10; ++k) q = __builtin_fma(q, r, wide_tanh_c[k]);
     q = __builtin_fma(q, r, 0.5); q = __builtin_fma(q, r, 1.0); q = __builtin_fma(q, r, 1.0);
     const double t = __builtin_amdgcn_ldexp(q, (int)kf);
     const double d = 1.0 + t, n = 1.0 - t;
