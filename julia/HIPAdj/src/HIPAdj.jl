@@ -179,7 +179,7 @@ end
 
 A model for the workgroup-per-trajectory family (`hipadj_wmodel_register`, ABI 106): more than 8 states or more than 32 parameters, up to
 `n = 4096`.  `f` and `vjp` are SPMD bodies run by every thread of the workgroup that owns a trajectory (`HIPADJ_W_FOR(i, count)`, `wg_sync()`,
-`wg_sum(x)`, `ws[...]`; include/hipadj.h); `vjp` is the joint product of `vecjacobian!` (src/derivative_wrappers.jl:256-267): `dlam` and, under
+`wg_sum(x)`, `wg_sum2(a, b, sa, sb)`, `ws[...]`; include/hipadj.h); `vjp` is the joint product of `vecjacobian!` (src/derivative_wrappers.jl:256-267): `dlam` and, under
 `if (WP)`, the parameter gradient (`gp[j] += w * ...` for entries owned by one thread, `acc[q] += w * ...` for the `nacc` parameters
 `acc_first + q` fed by every component).  Fixed-step RK4 (loss times on the step grid) and adaptive Tsit5 (arbitrary loss times, per-trajectory step control):
 the four sensealgs and GaussKronrodAdjoint on both, the built-in continuous costs.
