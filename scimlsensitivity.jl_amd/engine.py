@@ -115,6 +115,13 @@ class Engine:
     def adjoint_dev(self, dLdu, du0, dp):
         self._check(self._L.hipadj_adjoint_dev(self._h, C.c_void_p(dLdu.data_ptr()) if dLdu is not None else None,
                                                C.c_void_p(du0.data_ptr()), C.c_void_p(dp.data_ptr())))
+        from . import problems
+        M = problems.WIDE_MASS_MATRICES.get(self.model)
+        if M is not None:      # a traced wide model with a mass matrix: the same map as the host-pointer entry point (adjoint above), on the device
+            import torch
+            self.synchronize()                                   # the handle's stream need not be torch's current one
+            MT = torch.as_tensor(np.ascontiguousarray(M.T), dtype=torch.float64, device=du0.device)
+            du0.copy_(torch.linalg.solve(MT, du0.T).T)
 
     # ---- sharded ensembles: dL/dp all-reduce over RCCL inside the library (include/hipadj.h, hipadj_comm_*) ----
     def comm_init_rank(self, unique_id, nranks, rank):

@@ -258,3 +258,31 @@ def test_traced_wide_model_with_a_mass_matrix(sa, alg, oalg, stepper):
         ref = O.Problem("RING", alg=oalg, t0=0.0, t1=T, save_times=ts, checkpointing=(alg == "backsolve"), dims=(n, 0, 0, 0), quad_abstol=1e-12, quad_reltol=1e-12, **okw)
         rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(sol.u, rout) < 1e-6 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
+
+
+@pytest.mark.gpu
+def test_traced_mass_matrix_model_through_the_device_pointer_entry_points(sa):
+    """The du0 = M^{-T} nu(t0) map of a traced mass-matrix model also on the device-pointer path (Engine.adjoint_dev, the torch autograd bridge's entry point): the same numbers
+    as the host-pointer call."""
+    import torch
+    n = 12
+    rng = np.random.default_rng(13)
+    M = np.eye(n) * 2.0 + 0.3 * rng.standard_normal((n, n))
+    name = "wt_ring_mm"
+    fun = _FUN.get(name) or sa.WideDeviceFunction.from_callable(name, ring, n, n + 1, mass_matrix=M)
+    _FUN[name] = fun
+    N, T, dt = 5, 0.6, 0.01
+    ts = np.linspace(0.0, T, 5)
+    u0 = rng.uniform(0.3, 1.0, (N, n)); p = rng.uniform(0.2, 0.7, n + 1)
+    delta = rng.standard_normal((N, len(ts), n))
+    eng = sa.Engine(fun.name, "interpolating", N, 0.0, T, dt, save_times=ts)
+    eng.forward(u0, p)
+    du0_h, dp_h = eng.adjoint(delta)
+    dev = torch.device("cuda", eng.device)
+    d_u0, d_p, d_delta = (torch.as_tensor(a, device=dev) for a in (u0, p, delta))
+    d_du0 = torch.empty((N, n), dtype=torch.float64, device=dev); d_dp = torch.empty(n + 1, dtype=torch.float64, device=dev)
+    eng.forward_dev(d_u0, d_p, None)
+    eng.adjoint_dev(d_delta, d_du0, d_dp)
+    eng.synchronize(); torch.cuda.synchronize()
+    assert rel(d_du0.cpu().numpy(), du0_h) < 1e-13 and rel(d_dp.cpu().numpy(), dp_h) < 1e-13
+    eng.close()
