@@ -24,6 +24,10 @@ template <int CTRL> __device__ __forceinline__ double quad_perm(double x) {
     hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+#elif defined(HIPADJ_QUAD_EMU)
+// TEST-ONLY host emulation (tests/emu/quad_emu.cpp): four host threads run the four lanes of a quad in lockstep and meet here
+double hipadj_quad_emu_exchange(int ctrl, double x);
+template <int CTRL> inline double quad_perm(double x) { return hipadj_quad_emu_exchange(CTRL, x); }
 #else
 template <int CTRL> inline double quad_perm(double x) { return x; }   // host pass of hipcc: never executed
 #endif

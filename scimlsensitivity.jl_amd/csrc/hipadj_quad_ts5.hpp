@@ -176,8 +176,13 @@ template <class Mo> struct QuadCursor {
 // Gauss: lam_c plus a DUMMY second component with zero derivative.  The one-component instantiation of tsit5_integrate returned a wrong lam from this kernel — deterministic,
 // growing with the step count on problems with interior loss times (1.8e-5 at tol 1e-11; scripts/r4/ts5_dbg2.py), identical with or without the quadrature nodes — while the
 // SAME source with the dummy component agrees with the oracle at 7e-14 (and the forward solve's one-component instantiation is right, and so is the lane family's with the rows in
-// LDS).  Not understood (compiler or template defect of that instantiation); the dummy adds exact zeros to the controller's norms (ncomp stays n) and two instructions per stage.
-template <int ALG> struct QuadNZ { static constexpr int value = ALG == 1 ? 3 : 2; };
+// LDS).  The SOURCE is right: compiled for the host with one component (tests/emu/quad_emu.cpp: four threads per quad in lockstep, -DHIPADJ_QUAD_GAUSS_NZ=1) it agrees with
+// the oracle at 1e-14 and with the two-component build bit for bit (tests/test_quad_emu.py) — the defect is in the device code generation of that instantiation.  The
+// dummy adds exact zeros to the controller's norms (ncomp stays n) and two instructions per stage.
+#ifndef HIPADJ_QUAD_GAUSS_NZ
+#define HIPADJ_QUAD_GAUSS_NZ 2      // 1 = the one-component instantiation (tests/emu/quad_emu.cpp builds it on the host to tell a source defect from a code-generation one)
+#endif
+template <int ALG> struct QuadNZ { static constexpr int value = ALG == 1 ? 3 : (ALG == 2 ? HIPADJ_QUAD_GAUSS_NZ : 2); };
 
 template <class Mo, int ALG>
 HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const double* __restrict__ p, const double* __restrict__ rec,
@@ -217,7 +222,7 @@ HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
             QA::template vjp<ALG == 0>(kc, yc, zz[0], t, dl, dm);
             dz[0] = -dl;
             if constexpr (ALG == 0) dz[1] = -dm;
-            else dz[1] = 0.0;                                  // Gauss: the dummy component (QuadNZ)
+            else if constexpr (NZ > 1) dz[1] = 0.0;            // Gauss: the dummy component (QuadNZ)
         }
     };
     auto cb = [&](double t, double tprev, double (&zz)[NZ], const auto& KK) -> bool {
@@ -258,7 +263,7 @@ HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
     const int ncomp = ALG == 0 ? N + NP : (ALG == 1 ? 2 * N + NP : N);
     const int na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.maxit, K, rhs, cb, NoPre(), QuadNorm{ncomp});
     if (ownl) du0[i * N + c] = z[0];
-    if (ownm) dp_traj[(long)c * g.Npad + i] = (ALG == 2) ? gacc : z[1];
+    if (ownm) dp_traj[(long)c * g.Npad + i] = (ALG == 2) ? gacc : z[NZ > 1 ? 1 : 0];
     if (na < 0 && c == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(flag, 4);

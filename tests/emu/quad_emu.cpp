@@ -1,0 +1,114 @@
+// tests/emu/quad_emu.cpp — TEST-ONLY host emulation of the four-lanes-per-trajectory bodies (csrc/hipadj_quad_ts5.hpp).
+//
+// NOT a product path and NOT a CPU fallback: libhipadj never contains it, the package never loads it.  The quad bodies are SPMD code whose lanes exchange
+// operands through DPP quad_perm moves; here FOUR HOST THREADS run the four lanes of one quad in lockstep and meet in hipadj_quad_emu_exchange (every
+// lane publishes its value, a barrier, every lane reads the lane the control word selects, a barrier).  A quad whose lanes stop calling quad_perm the same
+// number of times — the device's lanes cannot: they share a program counter — deadlocks here and is reported after a time-out.
+// Compiled with g++ -ffp-contract=off (fma() calls stay fused, as written); -DHIPADJ_QUAD_GAUSS_NZ=1 builds the one-component Gauss instantiation that
+// returned wrong numbers on the device (hipadj_quad_ts5.hpp QuadNZ).
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#define HIPADJ_QUAD_EMU 1
+#include "../../scimlsensitivity.jl_amd/csrc/hipadj_plan.hpp"
+#include "../../scimlsensitivity.jl_amd/csrc/hipadj_quad_ts5.hpp"
+
+using namespace hipadj;
+
+namespace {
+struct QuadCtx {
+    double slot[4];
+    std::atomic<int> arrived{0};
+    std::atomic<int> generation{0};
+    std::atomic<bool> failed{false};
+    int lanes = 4;
+    void barrier() {
+        const int gen = generation.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == lanes) { arrived.store(0, std::memory_order_relaxed); generation.fetch_add(1, std::memory_order_release); return; }
+        const auto t0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        while (generation.load(std::memory_order_acquire) == gen) {
+            if (failed.load(std::memory_order_relaxed)) return;
+            if ((++spins & 0xFFF) == 0) {
+                std::this_thread::yield();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { failed.store(true); return; }   // the lanes of the quad diverged
+            }
+        }
+    }
+};
+thread_local QuadCtx* t_ctx = nullptr;
+thread_local int t_lane = 0;
+std::string g_err;
+}  // namespace
+
+namespace hipadj {
+double hipadj_quad_emu_exchange(int ctrl, double x) {
+    QuadCtx* q = t_ctx;
+    q->slot[t_lane] = x;
+    q->barrier();
+    const double r = q->slot[(ctrl >> (2 * t_lane)) & 3];
+    q->barrier();
+    return r;
+}
+}  // namespace hipadj
+
+template <class F> static bool run_quad(F&& body) {     // body(c) on four threads in lockstep; false when the lanes diverged
+    QuadCtx ctx;
+    std::thread th[4];
+    for (int c = 0; c < 4; ++c) th[c] = std::thread([&, c] { t_ctx = &ctx; t_lane = c; body(c); });
+    for (int c = 0; c < 4; ++c) th[c].join();
+    return !ctx.failed.load();
+}
+
+extern "C" const char* quad_emu_last_error() { return g_err.c_str(); }
+extern "C" int quad_emu_gauss_nz() { return QuadNZ<2>::value; }
+
+// Lorenz, adaptive Tsit5: forward_tsit5_quad + adjoint_tsit5_quad<ALG> exactly as k_forward_tsit5_quad / k_adjoint_tsit5_quad run them, one quad at a time
+template <int ALG>
+static int run_lorenz(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* nsteps_out) {
+    using Mo = ModelLorenz;
+    constexpr int N = Mo::N, NP = Mo::NP, RW = 2 + 5 * N;
+    AdaptGeom g; g.N = P.N; g.Npad = P.Npad; g.M = P.M; g.Smax = P.Smax; g.maxit = P.Smax; g.nck = P.nck; g.t0 = cfg->t0; g.t1 = cfg->t1; g.dt0 = cfg->dt;
+    g.abstol = cfg->abstol; g.reltol = cfg->reltol; g.loss_shift = cfg->loss_shift; g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start;
+    g.p_shared = cfg->p_shared; g.cont_cost = cfg->cont_cost; g.SmaxI = P.SmaxI; g.SmaxA = 0;
+    const long Np = P.Npad;
+    std::vector<double> rec(ALG != 1 ? (size_t)P.Smax * RW * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np), ckpt((size_t)P.nck * N * Np);
+    std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
+    std::vector<int> nsteps((size_t)Np, 0);
+    int flag = 0;
+    for (long i = 0; i < P.N; ++i) {
+        const bool ok = run_quad([&](int c) {
+            forward_tsit5_quad<Mo>(g, i, c, u0, p, rec.empty() ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(), P.ck_times.data(),
+                                   ckpt.empty() ? nullptr : ckpt.data(), yT.data(), &flag); });
+        if (!ok) { g_err = "forward_tsit5_quad: the lanes of a quad diverged"; return HIPADJ_ERR_HIP; }
+        if (nsteps[i] > P.Smax) { g_err = "forward solve exceeded max_steps"; return HIPADJ_ERR_MAXITERS; }
+    }
+    if (nsteps_out) for (long i = 0; i < P.N; ++i) nsteps_out[i] = nsteps[i];
+    if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
+    if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
+    for (long i = 0; i < P.N; ++i) {
+        const bool ok = run_quad([&](int c) {
+            adjoint_tsit5_quad<Mo, ALG>(g, i, c, p, rec.data(), nsteps.data(), yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ck_times.data(), P.save_times.data(),
+                                        P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), du0, dp_traj.data(), &flag); });
+        if (!ok) { g_err = "adjoint_tsit5_quad: the lanes of a quad diverged"; return HIPADJ_ERR_HIP; }
+    }
+    if (cfg->p_shared) { for (int j = 0; j < NP; ++j) { double s = 0; for (long i = 0; i < P.N; ++i) s += dp_traj[(size_t)j * Np + i]; dp[j] = s; } }
+    else for (long i = 0; i < P.N; ++i) for (int j = 0; j < NP; ++j) dp[i * NP + j] = dp_traj[(size_t)j * Np + i];
+    return HIPADJ_OK;
+}
+
+extern "C" int quad_emu_forward_adjoint(const hipadj_config* cfg, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* nsteps) {
+    if (cfg->model != HIPADJ_MODEL_LORENZ || cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE || cfg->cont_cost != 0) { g_err = "quad emulator: Lorenz on adaptive Tsit5 without a cost"; return HIPADJ_ERR_UNSUPPORTED; }
+    Plan P; const int rc = make_plan(cfg, P, g_err); if (rc) return rc;
+    if (P.ip_ckpt) { g_err = "quad emulator: no checkpointing = true"; return HIPADJ_ERR_UNSUPPORTED; }
+    switch (cfg->alg) {
+    case HIPADJ_ALG_INTERPOLATING: return run_lorenz<0>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    case HIPADJ_ALG_BACKSOLVE: return run_lorenz<1>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    case HIPADJ_ALG_GAUSS: return run_lorenz<2>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    default: g_err = "quad emulator: Interpolating, Backsolve, Gauss"; return HIPADJ_ERR_UNSUPPORTED;
+    }
+}
