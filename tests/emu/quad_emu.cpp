@@ -56,11 +56,11 @@ double hipadj_quad_emu_exchange(int ctrl, double x) {
 }
 }  // namespace hipadj
 
-template <class F> static bool run_quad(F&& body) {     // body(c) on four threads in lockstep; false when the lanes diverged
-    QuadCtx ctx;
+template <class F> static bool run_quad(F&& body, int lanes = 4) {     // body(c) on `lanes` threads in lockstep; false when the lanes diverged
+    QuadCtx ctx; ctx.lanes = lanes;
     std::thread th[4];
-    for (int c = 0; c < 4; ++c) th[c] = std::thread([&, c] { t_ctx = &ctx; t_lane = c; body(c); });
-    for (int c = 0; c < 4; ++c) th[c].join();
+    for (int c = 0; c < lanes; ++c) th[c] = std::thread([&, c] { t_ctx = &ctx; t_lane = c; body(c); });
+    for (int c = 0; c < lanes; ++c) th[c].join();
     return !ctx.failed.load();
 }
 
@@ -111,4 +111,36 @@ extern "C" int quad_emu_forward_adjoint(const hipadj_config* cfg, const double* 
     case HIPADJ_ALG_GAUSS: return run_lorenz<2>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
     default: g_err = "quad emulator: Interpolating, Backsolve, Gauss"; return HIPADJ_ERR_UNSUPPORTED;
     }
+}
+
+// Lorenz, fixed-step RK4 forward solve: forward_quad_ev as k_forward_quad runs it (the lanes c >= n of a quad leave at once: three threads).  knots_out [N][S + 1][2][3]
+// = (u_k, f(u_k)) per knot, out [N][M][3] = sol(ts) on the grid, yT [N][3].
+extern "C" int quad_emu_forward_rk4(const hipadj_config* cfg, const double* u0, const double* p, double* knots_out, double* out, double* yT_out) {
+    using Mo = ModelLorenz;
+    constexpr int N = Mo::N;
+    if (cfg->model != HIPADJ_MODEL_LORENZ || cfg->stepper != HIPADJ_STEPPER_RK4_FIXED) { g_err = "quad emulator: Lorenz on fixed-step RK4"; return HIPADJ_ERR_UNSUPPORTED; }
+    Plan P; const int rc = make_plan(cfg, P, g_err); if (rc) return rc;
+    if (P.offgrid) { g_err = "quad emulator: loss times on the step grid"; return HIPADJ_ERR_UNSUPPORTED; }
+    Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
+    g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1; g.h_last = P.h_last;
+    const long Np = P.Npad;
+    std::vector<int> ek, es, ec;
+    forward_events(P, cfg->dt, ek, es, ec);
+    const int nev = (int)ek.size();
+    ek.push_back(0); es.push_back(-1); ec.push_back(-1);
+    std::vector<dbl2> knots((size_t)(P.S + 1) * N * Np);
+    std::vector<double> outT((size_t)(P.M > 0 ? P.M : 1) * N * Np), yT((size_t)N * Np);
+    const FwdEvents ev{ek.data(), es.data(), ec.data(), nev};
+    for (long i = 0; i < P.N; ++i) {
+        const bool ok = run_quad([&](int c) { forward_quad_ev<Mo>(g, i, c, u0, p, ev, knots.data(), nullptr, outT.data(), yT.data()); }, N);
+        if (!ok) { g_err = "forward_quad_ev: the lanes of a quad diverged"; return HIPADJ_ERR_HIP; }
+    }
+    for (long i = 0; i < P.N; ++i) {
+        for (int k = 0; k <= P.S; ++k) for (int j = 0; j < N; ++j) {
+            const dbl2 d = knots[((size_t)k * N + j) * Np + i];
+            knots_out[((i * (P.S + 1) + k) * 2 + 0) * N + j] = d.x; knots_out[((i * (P.S + 1) + k) * 2 + 1) * N + j] = d.y; }
+        for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
+        for (int j = 0; j < N; ++j) yT_out[i * N + j] = yT[(size_t)j * Np + i];
+    }
+    return HIPADJ_OK;
 }

@@ -42,3 +42,17 @@ def forward_adjoint(cfg, u0, p, dLdu=None, gauss_nz=2):
     if rc:
         raise RuntimeError(f"quad emulator rc={rc}: {L.quad_emu_last_error().decode()}")
     return du0, dp, out, ns
+
+
+def forward_rk4(cfg, u0, p):
+    """(knots [N][S + 1][2][3] = (u_k, f(u_k)), out [N][M][3], y(T) [N][3]) of the fixed-step forward solve through forward_quad_ev."""
+    L = lib(2)
+    u0 = np.ascontiguousarray(u0, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
+    N, M = u0.shape[0], cfg.nsave
+    S = int(round((cfg.t1 - cfg.t0) / cfg.dt))
+    knots = np.zeros((N, S + 1, 2, 3)); out = np.zeros((N, M, 3)); yT = np.zeros((N, 3))
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = L.quad_emu_forward_rk4(C.byref(cfg), P(u0), P(p), P(knots), P(out), P(yT))
+    if rc:
+        raise RuntimeError(f"quad emulator rc={rc}: {L.quad_emu_last_error().decode()}")
+    return knots, out, yT

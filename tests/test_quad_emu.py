@@ -51,3 +51,22 @@ def test_one_component_gauss_instantiation_on_the_host():
     print("nz2 vs oracle", rel(a[0], rdu0), rel(a[1], rdp), " nz1 vs oracle", rel(b[0], rdu0), rel(b[1], rdp), " nz1 vs nz2", rel(b[0], a[0]), rel(b[1], a[1]))
     assert rel(a[0], rdu0) < 1e-9 and rel(a[1], rdp) < 1e-9
     assert rel(b[0], rdu0) < 1e-9 and rel(b[1], rdp) < 1e-9
+
+
+def test_fixed_step_forward_quad_on_the_host():
+    """forward_quad_ev (hipadj_quad.hpp: the forward solve of the headline workload, one state component per lane of a quad, event knots for the save times): knots (u_k, f(u_k)),
+    sol(ts) and y(T) against the oracle's RK4 solve and its right-hand side.  The component form is not expression-for-expression the plain form (du_0 = y sigma - sigma x,
+    fused as written), so agreement is at roundoff amplified by Lorenz over T = 2, not bit for bit."""
+    rng = np.random.default_rng(8)
+    N, T, dt = 3, 2.0, 0.01
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.3 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8.0 / 3.0])
+    ts = np.linspace(0.0, T, 21)
+    cfg = E.make_config("lorenz", "interpolating", N, 0.0, T, dt, ts, loss_kind=1, loss_shift=2.0, p_shared=True)
+    knots, out, yT = Q.forward_rk4(cfg, u0, p)
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    _, _, rout, _ = ref.adjoint_ensemble(u0, p)
+    assert rel(out, rout) < 1e-11 and rel(yT, rout[:, -1, :]) < 1e-11
+    assert np.array_equal(knots[:, 0, 0, :], u0) and rel(knots[:, ::10, 0, :], rout) < 1e-11          # the knots on the save grid are sol(ts)
+    for i in range(N):
+        for k in (0, 57, 200):
+            assert rel(knots[i, k, 1], O.model_f("LORENZ", knots[i, k, 0], p)) < 1e-14                  # the slope stored with a knot is f at that knot
