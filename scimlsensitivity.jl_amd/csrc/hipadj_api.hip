@@ -495,7 +495,14 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
     g.kmask = -1; g.h_last = P.h_last;
     if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
-    if (const char* e = std::getenv("HIPADJ_QUAD")) h->quad_fwd = std::atoi(e);
+    {
+        int cus = 256, mode = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus <= 0) cus = 256;
+        if (const char* e = std::getenv("HIPADJ_QUAD")) mode = std::atoi(e);
+        const long simds = 4L * cus;
+        h->quad_fwd = mode == 2 || (mode == 1 && h->N <= 16 * simds);
+        h->quad_adj = mode == 2 || (mode == 1 && h->N <= 32 * simds);
+    }
     if (const char* e = std::getenv("HIPADJ_FUSED_FINAL")) h->fused_final = std::atoi(e);
     if (const char* e = std::getenv("HIPADJ_WPB")) h->wpb4 = std::atoi(e) == 4;
     if (const char* e = std::getenv("HIPADJ_NO_OPS")) h->no_ops = std::atoi(e) != 0;

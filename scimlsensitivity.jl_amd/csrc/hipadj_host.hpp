@@ -93,7 +93,12 @@ struct hipadj_handle {
     int fwd_ev = 1;                       // HIPADJ_FWD_EV=0: the per-knot form k_forward (A/B)
     bool wide_auto = false;               // wide models, adaptive, max_steps = 0 and a budget-limited record: step counts are read back after every forward solve (wide_autosize)
     int wide_KT = 0;                      // wide models, checkpointing = true: knots of one re-solve tile (longest checkpoint interval + 1)
-    int quad_fwd = 1;                     // HIPADJ_QUAD=0: one lane per trajectory for the forward solves of models with a component form (hipadj_quad.hpp; A/B)
+    // four lanes per trajectory (hipadj_quad.hpp, hipadj_quad_ts5.hpp) for models with a component form — while the quads do not outnumber the SIMDs' wavefront slots: a quad
+    // kernel launches 4 x the wavefronts of the lane kernel with ~0.7 x the instructions each, which pays only as long as those wavefronts find idle SIMDs.  Measured, Lorenz
+    // (profiles/r4_quad_vs_lane_by_N.log): forward RK4 0.117 vs 0.164 ms at 10^4 trajectories, 0.223 vs 0.167 at 2 x 10^4; Tsit5 Interpolating sweep 1.52 vs 1.80 at 2 x 10^4,
+    // 2.57 vs 2.09 at 4 x 10^4.  Forward solves: N <= 16 SIMDs (one wavefront per SIMD); reverse sweeps (two 209-register wavefronts fit a SIMD): N <= 32 SIMDs.
+    // HIPADJ_QUAD=0: never, 2: always (A/B).
+    int quad_fwd = 1, quad_adj = 1;
     int timing = 2;                       // 0: no events, 1: dominant-kernel bracket only, 2: + whole-call bracket (HIPADJ_TIMING)
     double ws_bytes = 0;
     double* d_gtile = nullptr; long gtile_stride = 0; bool ck_long = false;   // checkpoint intervals longer than HIPADJ_CKPT_KMAX: re-solve tiles in HBM

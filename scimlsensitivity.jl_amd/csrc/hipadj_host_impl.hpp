@@ -577,7 +577,7 @@ template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hip
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     for (int pass = 0; pass < 2; ++pass) {
         constexpr bool QUAD_OK = QuadAdj<Mo>::value && CC == 0 && !CK && (ALG == 0 || ALG == 1 || ALG == 2);
-        if (QUAD_OK && h->quad_fwd) {
+        if (QUAD_OK && h->quad_adj) {
             if constexpr (QUAD_OK)
                 hipLaunchKernelGGL((k_adjoint_tsit5_quad<Mo, ALG>), dim3((unsigned)((h->N + 15) / 16)), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
                                    (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
