@@ -33,9 +33,9 @@ struct QuadCtx {
         long spins = 0;
         while (generation.load(std::memory_order_acquire) == gen) {
             if (failed.load(std::memory_order_relaxed)) return;
-            if ((++spins & 0xFFF) == 0) {
+            if (++spins > 64) {                                 // a short spin, then give the core away: four threads must make progress on ANY number of cores
                 std::this_thread::yield();
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { failed.store(true); return; }   // the lanes of the quad diverged
+                if ((spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { failed.store(true); return; }   // the lanes of the quad diverged
             }
         }
     }
