@@ -11,7 +11,7 @@
 // (they contribute exact zeros to the norms) and skip the stores.
 //
 // Data layout = the lane family's (records [Smax][2 + 5 n][Npad], outT / ckpt / yT / cotT component-major, dp_traj [np][Npad]): every kernel of either
-// mapping reads what the other wrote.  Dispatched for models with QuadAdj (compiled-in Lorenz): the forward solve and the Interpolating, Backsolve and Gauss sweeps
+// mapping reads what the other wrote.  Dispatched for models with QuadAdj (compiled-in Lorenz, Lotka-Volterra and its time-dependent form): the forward solve and the Interpolating, Backsolve and Gauss sweeps
 // without a continuous cost and without checkpointing=true; everything else keeps the lane kernels.
 #pragma once
 #include "hipadj_quad.hpp"
@@ -68,6 +68,43 @@ template <> struct QuadAdj<ModelLorenz> {
         fc = fma(fma(k.S2, y2, k.S1 * y1), fma(k.Q2, y2, fma(k.Q1, y1, k.Q0)), k.D * yc);
     }
 };
+
+// Lotka-Volterra (n = 2, np = 4: lanes 0, 1 own y_c, lam_c; all four lanes own mu_c), plain and time-dependent (`fb`, test/Core3/adjoint.jl:8-12: the product terms carry t).
+// The four operands every lane needs are BROADCASTS of lanes 0 and 1 (X = y_0, Y = y_1, LX = lam_0, LY = lam_1); "the other component" is picked by constants:
+//   (J^T lam)_c = (A + t B yo) lam_c + (t C yo) lo,   yo = G0 X + G1 Y, lo = G0 LX + G1 LY       c = 0: p1, -p2, p4, other = 1      c = 1: -p3, p4, -p2, other = 0
+//   (f_p^T lam)_c = (E1 X + E2 Y + t E3 X Y)(F1 LX + F2 LY)                                       x lam_0,  -x y t lam_0,  -y lam_1,  x y t lam_1
+//   f_c = y_c (A + t B yo)
+template <bool TD> struct QuadAdjLV {
+    static constexpr bool value = true;
+    struct K { double A, B, C, G0, G1, E1, E2, E3, F1, F2; };
+    HIPADJ_HD static K consts(int c, const double (&p)[4]) {
+        K k = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (c == 0) { k.A = p[0]; k.B = -p[1]; k.C = p[3]; k.G1 = 1.0; k.E1 = 1.0; k.F1 = 1.0; }
+        else if (c == 1) { k.A = -p[2]; k.B = p[3]; k.C = -p[1]; k.G0 = 1.0; k.E3 = -1.0; k.F1 = 1.0; }
+        else if (c == 2) { k.E2 = -1.0; k.F2 = 1.0; }
+        else { k.E3 = 1.0; k.F2 = 1.0; }
+        return k;
+    }
+    static constexpr int B0 = HIPADJ_QP(0, 0, 0, 0), B1 = HIPADJ_QP(1, 1, 1, 1);
+    template <bool WP> HIPADJ_HD static void vjp(const K& k, double yc, double lc, double t, double& dl, double& dm) {
+        const double X = quad_perm<B0>(yc), Y = quad_perm<B1>(yc), LX = quad_perm<B0>(lc), LY = quad_perm<B1>(lc);
+        const double tt = TD ? t : 1.0;
+        const double yo = fma(k.G1, Y, k.G0 * X), lo = fma(k.G1, LY, k.G0 * LX);
+        dl = fma(k.C * tt * yo, lo, fma(k.B * tt, yo, k.A) * lc);
+        if (WP) dm = fma(k.E3 * tt, X * Y, fma(k.E2, Y, k.E1 * X)) * fma(k.F2, LY, k.F1 * LX); else dm = 0.0;
+    }
+    HIPADJ_HD static void vjp_f(const K& k, double yc, double lc, double t, double& dl, double& dm, double& fc) {
+        const double X = quad_perm<B0>(yc), Y = quad_perm<B1>(yc), LX = quad_perm<B0>(lc), LY = quad_perm<B1>(lc);
+        const double tt = TD ? t : 1.0;
+        const double yo = fma(k.G1, Y, k.G0 * X), lo = fma(k.G1, LY, k.G0 * LX);
+        const double g = fma(k.B * tt, yo, k.A);
+        dl = fma(k.C * tt * yo, lo, g * lc);
+        dm = fma(k.E3 * tt, X * Y, fma(k.E2, Y, k.E1 * X)) * fma(k.F2, LY, k.F1 * LX);
+        fc = yc * g;
+    }
+};
+template <> struct QuadAdj<ModelLV> : QuadAdjLV<false> {};
+template <> struct QuadAdj<ModelLVT> : QuadAdjLV<true> {};
 
 // ---- forward dense solve (the quad counterpart of forward_tsit5_lane): lane (i, c) integrates component c ------------------------------------------------
 template <class Mo>

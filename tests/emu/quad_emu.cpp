@@ -67,10 +67,9 @@ template <class F> static bool run_quad(F&& body, int lanes = 4) {     // body(c
 extern "C" const char* quad_emu_last_error() { return g_err.c_str(); }
 extern "C" int quad_emu_gauss_nz() { return QuadNZ<2>::value; }
 
-// Lorenz, adaptive Tsit5: forward_tsit5_quad + adjoint_tsit5_quad<ALG> exactly as k_forward_tsit5_quad / k_adjoint_tsit5_quad run them, one quad at a time
-template <int ALG>
-static int run_lorenz(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* nsteps_out) {
-    using Mo = ModelLorenz;
+// adaptive Tsit5 of a model with a component form: forward_tsit5_quad + adjoint_tsit5_quad<ALG> exactly as k_forward_tsit5_quad / k_adjoint_tsit5_quad run them, one quad at a time
+template <class Mo, int ALG>
+static int run_ts5(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* nsteps_out) {
     constexpr int N = Mo::N, NP = Mo::NP, RW = 2 + 5 * N;
     AdaptGeom g; g.N = P.N; g.Npad = P.Npad; g.M = P.M; g.Smax = P.Smax; g.maxit = P.Smax; g.nck = P.nck; g.t0 = cfg->t0; g.t1 = cfg->t1; g.dt0 = cfg->dt;
     g.abstol = cfg->abstol; g.reltol = cfg->reltol; g.loss_shift = cfg->loss_shift; g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start;
@@ -101,15 +100,24 @@ static int run_lorenz(const hipadj_config* cfg, const Plan& P, const double* u0,
     return HIPADJ_OK;
 }
 
+template <class Mo>
+static int dispatch_ts5(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* nsteps) {
+    switch (cfg->alg) {
+    case HIPADJ_ALG_INTERPOLATING: return run_ts5<Mo, 0>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    case HIPADJ_ALG_BACKSOLVE: return run_ts5<Mo, 1>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    case HIPADJ_ALG_GAUSS: return run_ts5<Mo, 2>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    default: g_err = "quad emulator: Interpolating, Backsolve, Gauss"; return HIPADJ_ERR_UNSUPPORTED;
+    }
+}
 extern "C" int quad_emu_forward_adjoint(const hipadj_config* cfg, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* nsteps) {
-    if (cfg->model != HIPADJ_MODEL_LORENZ || cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE || cfg->cont_cost != 0) { g_err = "quad emulator: Lorenz on adaptive Tsit5 without a cost"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE || cfg->cont_cost != 0) { g_err = "quad emulator: adaptive Tsit5 without a cost"; return HIPADJ_ERR_UNSUPPORTED; }
     Plan P; const int rc = make_plan(cfg, P, g_err); if (rc) return rc;
     if (P.ip_ckpt) { g_err = "quad emulator: no checkpointing = true"; return HIPADJ_ERR_UNSUPPORTED; }
-    switch (cfg->alg) {
-    case HIPADJ_ALG_INTERPOLATING: return run_lorenz<0>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
-    case HIPADJ_ALG_BACKSOLVE: return run_lorenz<1>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
-    case HIPADJ_ALG_GAUSS: return run_lorenz<2>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
-    default: g_err = "quad emulator: Interpolating, Backsolve, Gauss"; return HIPADJ_ERR_UNSUPPORTED;
+    switch (cfg->model) {
+    case HIPADJ_MODEL_LORENZ: return dispatch_ts5<ModelLorenz>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    case HIPADJ_MODEL_LV: return dispatch_ts5<ModelLV>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    case HIPADJ_MODEL_LVT: return dispatch_ts5<ModelLVT>(cfg, P, u0, p, dLdu, du0, dp, out, nsteps);
+    default: g_err = "quad emulator: lorenz, lv, lvt"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }
 

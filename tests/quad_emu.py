@@ -31,11 +31,12 @@ def lib(gauss_nz=2):
 
 
 def forward_adjoint(cfg, u0, p, dLdu=None, gauss_nz=2):
-    """(du0 [N][3], dp, out [N][M][3], forward step counts) of the Lorenz ensemble through the quad bodies."""
+    """(du0 [N][n], dp, out [N][M][n], forward step counts) of a lorenz / lv / lvt ensemble through the quad bodies."""
     L = lib(gauss_nz)
     u0 = np.ascontiguousarray(u0, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
-    N, M = u0.shape[0], cfg.nsave
-    du0 = np.zeros((N, 3)); dp = np.zeros(3 if cfg.p_shared else (N, 3)); out = np.zeros((N, M, 3)); ns = np.zeros(N, dtype=np.int32)
+    N, n, M = u0.shape[0], u0.shape[1], cfg.nsave
+    npar = p.shape[-1]
+    du0 = np.zeros((N, n)); dp = np.zeros(npar if cfg.p_shared else (N, npar)); out = np.zeros((N, M, n)); ns = np.zeros(N, dtype=np.int32)
     d = None if dLdu is None else np.ascontiguousarray(dLdu, dtype=np.float64)
     P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     rc = L.quad_emu_forward_adjoint(C.byref(cfg), P(u0), P(p), P(d) if d is not None else None, P(du0), P(dp), P(out), ns.ctypes.data_as(C.POINTER(C.c_int)))

@@ -89,3 +89,32 @@ def test_adaptive_forward_quad_out_and_records(sa, monkeypatch):
     ref = O.Problem("LORENZ", alg="QUADRATURE", stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, quad_abstol=1e-12, quad_reltol=1e-12)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(res["1"][0], rout) < 1e-8 and rel(res["1"][1], rdu0) < 1e-6 and rel(res["1"][2], rdp) < 1e-6
+
+
+@pytest.mark.parametrize("p_shared", [True, False])
+@pytest.mark.parametrize("model,omodel", [("lv", "LV"), ("lvt", "LVT")])
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS")])
+def test_lotka_volterra_adaptive_sweeps_quad_against_lane_and_oracle(sa, monkeypatch, alg, oalg, model, omodel, p_shared):
+    """QuadAdjLV (hipadj_quad_ts5.hpp): two lanes carry y and lam, all four a parameter sum; plain and time-dependent LV, shared and per-trajectory parameters, 67 trajectories
+    (a partial last wavefront), off-grid loss times — against the one-lane-per-trajectory kernels and the oracle."""
+    rng = np.random.default_rng(23)
+    N, T = 67, 3.0
+    u0 = np.array([1.0, 1.0]) + 0.2 * rng.standard_normal((N, 2))
+    p = np.array([1.5, 1.0, 3.0, 1.0]) * (1 + 0.05 * rng.standard_normal((N, 4)))
+    if p_shared:
+        p = p[0]
+    ts = np.array([0.0, 0.4, 1.0, 1.7, 2.5, T])
+    delta = rng.standard_normal((N, len(ts), 2))
+    ck = alg == "backsolve"
+    res = {}
+    for quad in ("2", "0"):
+        monkeypatch.setenv("HIPADJ_QUAD", quad)
+        eng = sa.Engine(model, alg, N, 0.0, T, 0.0, save_times=ts, stepper=1, abstol=1e-10, reltol=1e-10, checkpointing=ck, p_shared=p_shared)
+        out = eng.forward(u0, p)
+        res[quad] = (out,) + eng.adjoint(delta)
+        eng.close()
+    for a, b in zip(res["2"], res["0"]):
+        assert rel(a, b) < 1e-9
+    ref = O.Problem(omodel, alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, checkpointing=ck, loss="COTANGENT")
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(res["2"][0], rout) < 1e-10 and rel(res["2"][1], rdu0) < 1e-8 and rel(res["2"][2], rdp) < 1e-8

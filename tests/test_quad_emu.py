@@ -70,3 +70,25 @@ def test_fixed_step_forward_quad_on_the_host():
     for i in range(N):
         for k in (0, 57, 200):
             assert rel(knots[i, k, 1], O.model_f("LORENZ", knots[i, k, 0], p)) < 1e-14                  # the slope stored with a knot is f at that knot
+
+
+@pytest.mark.parametrize("p_shared", [True, False])
+@pytest.mark.parametrize("model,omodel", [("lv", "LV"), ("lvt", "LVT")])
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve", "gauss"])
+def test_lotka_volterra_quad_bodies_match_the_oracle_on_the_host(alg, model, omodel, p_shared):
+    """QuadAdjLV (n = 2, np = 4: two lanes carry y and lam, all four a parameter sum; operands are broadcasts of lanes 0 and 1), plain and time-dependent (`fb`,
+    test/Core3/adjoint.jl:8-12), with shared and with per-trajectory parameters."""
+    rng = np.random.default_rng(17)
+    N, T = 3, 3.0
+    u0 = np.array([1.0, 1.0]) + 0.2 * rng.standard_normal((N, 2))
+    p = np.array([1.5, 1.0, 3.0, 1.0]) * (1 + 0.05 * rng.standard_normal((N, 4)))
+    if p_shared:
+        p = p[0]
+    ts = np.array([0.0, 0.4, 1.0, 1.7, 2.5, T])
+    delta = rng.standard_normal((N, len(ts), 2))
+    ck = alg == "backsolve"
+    cfg = E.make_config(model, alg, N, 0.0, T, 0.0, ts, loss_kind=0, checkpointing=ck, p_shared=p_shared, stepper=1, abstol=1e-10, reltol=1e-10, max_steps=4000)
+    du0, dp, out, ns = Q.forward_adjoint(cfg, u0, p, delta)
+    ref = O.Problem(omodel, alg=alg.upper(), stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, checkpointing=ck, loss="COTANGENT")
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
