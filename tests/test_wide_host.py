@@ -155,3 +155,14 @@ def test_wide_models_refuse_mass_matrix_cost_text_and_affect(sa):
         fun.set_affect("un[0] += 1.0;")
     assert e.value.status == -6
     fun.set_mass_matrix(None)       # removing what was never there stays a no-op
+
+
+def test_a_reregistered_name_drops_the_traced_mass_matrix_of_its_predecessor(sa):
+    """engine.py maps du0 = M^{-T} nu(t0) for traced models registered with a mass matrix, looked up by model NAME: the entry must not outlive a re-registration
+    of that name without a matrix (the next handle would map du0 with a matrix the device no longer integrates with)."""
+    from scimlsensitivity_jl_amd import problems
+    ring = lambda u, p, t, ops: p[0:6] * (ops.roll(u, -1) - u)
+    sa.WideDeviceFunction.from_callable("mm_stale", ring, 6, 6, mass_matrix=np.eye(6) * 2.0)
+    assert "mm_stale" in problems.WIDE_MASS_MATRICES
+    sa.WideDeviceFunction.from_callable("mm_stale", ring, 6, 6)
+    assert "mm_stale" not in problems.WIDE_MASS_MATRICES
