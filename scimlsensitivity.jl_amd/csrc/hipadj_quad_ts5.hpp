@@ -266,16 +266,22 @@ HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
         bool mod = false;
         if (ALG == 2 && t != tprev) {   // IntegratingSumCallback: 3-point Gauss-Legendre of -(df/dp)^T lam on [tprev, t], this lane's parameter
             const double half = 0.5 * (t - tprev), mid = 0.5 * (t + tprev), h = t - tprev;
+            // lam at the three nodes from the MONOMIAL form of the step's continuous extension (tsit5_poly, the form the forward records use), built once per step for this
+            // lane's component: 25 instructions + 4 per node instead of the seven b_j(theta) polynomials (~40) and a division per node; theta_q = (1 + x_q) / 2 is a constant
+            double c1 = h * KK.get(0, 0), c2 = 0.0, c3 = 0.0, c4 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { const double kj = KK.get(j, 0); c2 = fma(TS5::r(j, 1), kj, c2); c3 = fma(TS5::r(j, 2), kj, c3); c4 = fma(TS5::r(j, 3), kj, c4); }
+            c2 *= h; c3 *= h; c4 *= h;
+            const double c0 = KK.get(KS_UPREV, 0);
 #pragma unroll 1
             for (int q = 0; q < 3; ++q) {
                 const double xq = q == 0 ? -0.7745966692414833770 : (q == 1 ? 0.0 : 0.7745966692414833770);
                 const double wq = q == 1 ? 8.0 / 9.0 : 5.0 / 9.0;
-                const double tt = half * xq + mid;
-                double lamq[1];
-                kstore_interp<NZ, 1>(KK, (tt - tprev) / h, h, lamq);
+                const double tt = half * xq + mid, th = fma(0.5, xq, 0.5);
+                const double lamq = fma(th, fma(th, fma(th, fma(th, c4, c3), c2), c1), c0);
                 const double yc = cur2.eval(tt);
                 double dl, dm;
-                QA::template vjp<true>(kc, yc, lamq[0], tt, dl, dm);
+                QA::template vjp<true>(kc, yc, lamq, tt, dl, dm);
                 gacc += half * wq * (-dm);
             }
         }
