@@ -92,3 +92,17 @@ def test_lotka_volterra_quad_bodies_match_the_oracle_on_the_host(alg, model, omo
     ref = O.Problem(omodel, alg=alg.upper(), stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, checkpointing=ck, loss="COTANGENT")
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-9 and rel(dp, rdp) < 1e-9
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve", "gauss"])
+def test_quad_bodies_no_start_and_per_trajectory_parameters_on_the_host(alg):
+    """`no_start` (the loss has no term at t0: src/concrete_solve.jl:600-640 drops the first save time) and per-trajectory parameters through the quad bodies."""
+    u0, p, ts, delta = _case(seed=11, N=3)
+    rng = np.random.default_rng(2)
+    pp = p * (1 + 0.02 * rng.standard_normal((len(u0), 3)))
+    ck = alg == "backsolve"
+    cfg = E.make_config("lorenz", alg, len(u0), 0.0, 2.0, 0.0, ts, loss_kind=0, checkpointing=ck, p_shared=False, stepper=1, abstol=1e-9, reltol=1e-9, max_steps=4000, no_start=True)
+    du0, dp, out, _ = Q.forward_adjoint(cfg, u0, pp, delta)
+    ref = O.Problem("LORENZ", alg=alg.upper(), stepper="TSIT5", t0=0.0, t1=2.0, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, checkpointing=ck, loss="COTANGENT", no_start=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(out, rout) < 1e-10 and rel(du0, rdu0) < 1e-8 and rel(dp, rdp) < 1e-8
