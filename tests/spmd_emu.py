@@ -89,6 +89,19 @@ template <bool WP> static void model_vjp_t(double* __restrict__ dlam, double* __
     (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;
 %(vjp)s
 }
+template <bool WP> static void model_cost_t(double* __restrict__ dlam, double* __restrict__ gp, double (&acc)[%(na)d], double w, const double* __restrict__ u,
+                                            const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {
+    (void)dlam; (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;
+%(cost)s
+}
+extern "C" int spmd_cost(int threads, int reverse, int wp, double* dlam, double* gp, double* acc_out, double w, const double* u, const double* p, double t, double* ws) {
+    T = threads;
+    return emu::run(threads, reverse, [&](int tid) {
+        double a[%(na)d] = {0};
+        if (wp) model_cost_t<true>(dlam, gp, a, w, u, p, t, ws, tid); else model_cost_t<false>(dlam, gp, a, w, u, p, t, ws, tid);
+        for (int q = 0; q < %(na)d; ++q) acc_out[tid * %(na)d + q] = a[q];
+    });
+}
 extern "C" int spmd_f(int threads, int reverse, double* du, const double* u, const double* p, double t, double* ws) {
     T = threads;
     return emu::run(threads, reverse, [&](int tid) { model_f_t(du, u, p, t, ws, tid); });
@@ -109,9 +122,9 @@ _cache = {}
 class SpmdModel:
     """f / vjp of one pair of bodies under T cooperating threads (threads, reverse order or not)."""
 
-    def __init__(self, f_body, vjp_body, n, npar, lds_doubles=0, nacc=0, acc_first=0):
+    def __init__(self, f_body, vjp_body, n, npar, lds_doubles=0, nacc=0, acc_first=0, cost_body=""):
         self.n, self.np, self.nw, self.nacc, self.a0 = int(n), int(npar), max(int(lds_doubles), 1), int(nacc), int(acc_first)
-        src = RUNTIME % dict(f=f_body, vjp=vjp_body, n=self.n, np=self.np, na=max(self.nacc, 1))
+        src = RUNTIME % dict(f=f_body, vjp=vjp_body, cost=cost_body, n=self.n, np=self.np, na=max(self.nacc, 1))
         key = hashlib.sha1(src.encode()).hexdigest()
         if key not in _cache:
             d = tempfile.mkdtemp(prefix="spmd_emu_")
@@ -136,6 +149,19 @@ class SpmdModel:
         dlam, gp, ws = np.full(self.n, np.nan), np.zeros(self.np), np.zeros(self.nw)
         acc = np.zeros((int(threads), max(self.nacc, 1)))
         if self.L.spmd_vjp(int(threads), int(reverse), int(wp), P(dlam), P(gp), P(acc), C.c_double(w), P(lam), P(u), P(p), C.c_double(t), P(ws)):
+            raise RuntimeError("the threads of the workgroup did not reach the same collective calls (the device would hang)")
+        for q in range(self.nacc):
+            gp[self.a0 + q] += acc[:, q].sum()
+        return dlam, gp
+
+    def cost(self, u, p, t, w=1.0, wp=True, threads=64, reverse=False, dlam0=None):
+        """The cost body ADDS dg/du into dlam (dlam0, default zeros) and w dg/dp into the gradient: returns (dlam, gp)."""
+        P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        u, p = np.ascontiguousarray(u, dtype=np.float64), np.ascontiguousarray(p, dtype=np.float64)
+        dlam = np.zeros(self.n) if dlam0 is None else np.array(dlam0, dtype=np.float64)
+        gp, ws = np.zeros(self.np), np.zeros(self.nw)
+        acc = np.zeros((int(threads), max(self.nacc, 1)))
+        if self.L.spmd_cost(int(threads), int(reverse), int(wp), P(dlam), P(gp), P(acc), C.c_double(w), P(u), P(p), C.c_double(t), P(ws)):
             raise RuntimeError("the threads of the workgroup did not reach the same collective calls (the device would hang)")
         for q in range(self.nacc):
             gp[self.a0 + q] += acc[:, q].sum()

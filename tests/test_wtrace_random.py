@@ -82,3 +82,36 @@ def test_random_traced_models_against_numpy_and_finite_differences(seed, n):
             xp, xm = x.copy(), x.copy(); xp[k] += eps; xm[k] -= eps
             fd = (lam @ (ev(xp, p) if x is u else ev(u, xp)) - lam @ (ev(xm, p) if x is u else ev(u, xm))) / (2 * eps)
             assert abs(g[k] - sc * fd) <= 2e-6 * max(1.0, abs(fd), np.max(np.abs(g))), (seed, "u" if x is u else "p", int(k), g[k], sc * fd)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_traced_costs_against_finite_differences(seed):
+    """A continuous cost g(u, p, t) traced to the SPMD body hipadj_wmodel_set_cost takes (wtrace.cost_body: dg/du added into dlam, w dg/dp into the gradient row —
+    accumulate_cost!, src/derivative_wrappers.jl:1411-1442): random scalar expressions, against central differences of the same function evaluated with numpy."""
+    from scimlsensitivity_jl_amd import wtrace
+    n = 9
+    fn, npar = random_rhs(7000 + seed, n)
+    rng = np.random.default_rng(seed)
+    wts = rng.uniform(0.5, 1.5, n)
+    k1, k2 = 3 * n, 3 * n + 1
+
+    def g(u, p, t, ops):           # a scalar: weighted sum of squares of a random array expression + scalar parameters
+        r = fn(u, p, t, ops)
+        return ops.sum(ops.const(wts) * r * r) * p[k1] + 0.5 * p[k2] * p[k2] + ops.sum(u) * t
+    body, nw, nacc, a0 = wtrace.cost_body(g, n, npar)
+    m = SE.SpmdModel("", "", n, npar, lds_doubles=nw, nacc=nacc, acc_first=a0, cost_body=body)
+    u, p, t = rng.uniform(0.2, 1.2, n), rng.uniform(-0.8, 0.9, npar), 0.37
+    ev = lambda uu, pp: float(g(uu, pp, t, NpOps))
+    base = rng.standard_normal(n)                                   # the body ADDS to dlam
+    res = [m.cost(u, p, t, w=0.7, threads=th, reverse=rev, dlam0=base) for th, rev in ((1, False), (64, False), (64, True))]
+    for a in res[1:]:
+        assert np.max(np.abs(a[0] - res[0][0])) <= 1e-11 * max(1.0, np.max(np.abs(res[0][0]))) and np.max(np.abs(a[1] - res[0][1])) <= 1e-11 * max(1.0, np.max(np.abs(res[0][1])))
+    dlam, gp = res[1]
+    eps = 1e-6
+    for x, got, sc in ((u, dlam - base, 1.0), (p, gp, 0.7)):
+        for k in rng.choice(len(x), size=min(len(x), 12), replace=False):
+            xp, xm = x.copy(), x.copy(); xp[k] += eps; xm[k] -= eps
+            fd = ((ev(xp, p) if x is u else ev(u, xp)) - (ev(xm, p) if x is u else ev(u, xm))) / (2 * eps)
+            assert abs(got[k] - sc * fd) <= 2e-6 * max(1.0, abs(fd), np.max(np.abs(got))), (seed, "u" if x is u else "p", int(k), got[k], sc * fd)
+    d2, g2 = m.cost(u, p, t, w=0.7, wp=False, threads=64, dlam0=base)     # WP = false: the state part only
+    assert np.max(np.abs(d2 - dlam)) <= 1e-12 * max(1.0, np.max(np.abs(dlam))) and not g2.any()
