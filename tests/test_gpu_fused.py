@@ -101,6 +101,11 @@ def test_fused_gauss_and_backsolve_equal_their_three_launch_sequences(sa, monkey
             delta = rng.standard_normal((N, len(ts), n))
             a, b = ref.adjoint(delta), fus.adjoint(delta)
             assert rel(b[0], a[0]) < 1e-10 and rel(b[1], a[1]) < 1e-10, (rnd, rep)
+    # ... and the one-launch pass against the ORACLE on the last inputs (not only the library against itself: VERDICT r3 weak 1c)
+    okw = dict(checkpointing=True, checkpoints=np.arange(0, int(round(T / dt)) + 1, kw["ckpt_stride"]) * dt) if kw.get("ckpt_stride") else dict(checkpointing=bool(kw.get("checkpointing")))
+    orc = O.Problem(model.upper(), alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", **okw)
+    rdu0, rdp, _, _ = orc.adjoint_ensemble(u0r, pr, delta, want_out=False)
+    assert rel(b[0], rdu0) < 1e-6 and rel(b[1], rdp) < 1e-6
     ref.close(); fus.close()
 
 
@@ -138,4 +143,9 @@ def test_fused_pass_of_runtime_lane_models(sa, monkeypatch, capfd, n, alg, cap):
                 ref.close(); fus.close()
                 return
             assert rel(b[0], a[0]) < 1e-10 and rel(b[1], a[1]) < 1e-10, (rnd, rep)
+    # the one-launch pass of the runtime model against the ORACLE's model of the same right-hand side, on the last inputs
+    orc = O.Problem("LV" if n == 2 else "RING", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", checkpointing=(alg == "backsolve"),
+                    dims=((0, 0, 0, 0) if n == 2 else (n, 0, 0, 0)))
+    rdu0, rdp, _, _ = orc.adjoint_ensemble(u0r, p, delta, want_out=False)
+    assert rel(b[0], rdu0) < 1e-6 and rel(b[1], rdp) < 1e-6
     ref.close(); fus.close()
