@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 107 /* 0.1.5: + hipadj_wmodel_set_cost (continuous cost of a wide model as an SPMD body), checkpointing = true for Interpolating / Gauss / GaussKronrod on wide models (fixed step); 0.1.4: + hipadj_wmodel_register (wide runtime models: fixed-step RK4 and adaptive Tsit5, the four sensealgs + GaussKronrod, built-in continuous costs), hipadj_comm_count / _selfcheck, hipadj_stats.launches_per_pass; 0.1.3: + hipadj_runtime_compiler; 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
+#define HIPADJ_VERSION 108 /* 0.1.6: + device-resident discrete losses (HIPADJ_LOSS_LSQ_DATA / HIPADJ_LOSS_MODEL, hipadj_set_loss_data[_dev], hipadj_model_set_discrete_loss[_function], hipadj_wmodel_set_discrete_loss, hipadj_loss_value[_dev]), hipadj_adjoint_dev_soa / hipadj_soa_stride, hipadj_config.loss_scale / ndevices / device_ids (one handle over several devices), hipadj_config.reference_literal; 0.1.5: + hipadj_wmodel_set_cost (continuous cost of a wide model as an SPMD body), checkpointing = true for Interpolating / Gauss / GaussKronrod on wide models (fixed step); 0.1.4: + hipadj_wmodel_register (wide runtime models: fixed-step RK4 and adaptive Tsit5, the four sensealgs + GaussKronrod, built-in continuous costs), hipadj_comm_count / _selfcheck, hipadj_stats.launches_per_pass; 0.1.3: + hipadj_runtime_compiler; 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -68,10 +68,18 @@ typedef enum {
                                           sensealgs (checkpointing=true: Backsolve only) */
 } hipadj_stepper;
 
-/* how dgdu_discrete(out, u, p, t, i) is evaluated at loss time t_i (src/adjoint_common.jl:771-773) */
+/* how dgdu_discrete(out, u, p, t, i) — and dgdp_discrete — is evaluated at loss time t_i (src/adjoint_common.jl:771-779).  Kinds 1-3 keep the loss ON THE DEVICE:
+ * nothing crosses the host link between the forward solve and the reverse pass (a cotangent block of BASELINE configs[1] is 24 MB each way). */
 typedef enum {
     HIPADJ_LOSS_COTANGENT = 0, /* out = dLdu[:, i]   — the AD path, src/concrete_solve.jl:842-851 */
-    HIPADJ_LOSS_LSQ_SHIFT = 1  /* out = u - loss_shift — test/Core3/adjoint.jl:49-51, 1169-1172; fused in-kernel */
+    HIPADJ_LOSS_LSQ_SHIFT = 1, /* out = u - loss_shift — test/Core3/adjoint.jl:49-51, 1169-1172; fused in-kernel */
+    HIPADJ_LOSS_LSQ_DATA = 2,  /* out = loss_scale * (u - data[:, i]) with a per-(trajectory, time) data block handed over ONCE (hipadj_set_loss_data[_dev]);
+                                  loss_scale = 2 is the gradient of sum(abs2, sol .- data), the loss of the reference's tutorials and benchmark (docs/src/Benchmark.md:80,
+                                  docs/src/tutorials/parameter_estimation_ode.md:43, docs/src/tutorials/data_parallel.md:115-116, docs/src/examples/pde/brusselator.md:221).  Every kernel family, both steppers, all sensealgs. */
+    HIPADJ_LOSS_MODEL = 3      /* out = the dgdu_discrete body attached to a runtime-registered model (hipadj_model_set_discrete_loss / hipadj_wmodel_set_discrete_loss),
+                                  evaluated in the sweep at every loss time, together with its dgdp_discrete body (src/adjoint_common.jl:775-779,
+                                  src/quadrature_adjoint.jl:545-552, 601-605; test/Core7/mixed_costs.jl:199-390).  The bodies see the data block of
+                                  hipadj_set_loss_data when one was set. */
 } hipadj_loss;
 
 /* continuous costs g(u, p, t) with device-inlined dgdu_continuous / dgdp_continuous
@@ -123,6 +131,17 @@ typedef struct {
                                   interval construction does.  RK4: every time on the step grid t0 + k*dt, any spacing (ckpt_stride must be
                                   0).  Tsit5: arbitrary times.  0: ckpt_stride, or the save times (the reference default) */
     const double *checkpoints; /* [ncheckpoints] */
+    double loss_scale;         /* HIPADJ_LOSS_LSQ_DATA: the factor w of dgdu = w (u - data); 0 means 1 */
+    int32_t ndevices;          /* > 1: ONE handle over several devices — the ensemble is cut into ndevices contiguous trajectory ranges (the partitioning of the reference's
+                                  EnsembleDistributed pattern, docs/src/tutorials/data_parallel.md:77-136, inside one process and one `solve` call): every range gets its own
+                                  stream, workspaces and kernels on its device; host-pointer calls scatter u0 / gather out, du0 and sum dp over the ranges in range order;
+                                  device-pointer calls take buffers of device_ids[0] and move the slices by peer copies.  0 / 1: the single device `device`. */
+    const int32_t *device_ids; /* [ndevices] HIP ordinals (copied at create); the same ordinal may repeat ("virtual shards": how a 1-GPU box tests the path); NULL: 0 .. ndevices-1 */
+    int32_t reference_literal; /* 1: reproduce the reference's lines where this library deliberately deviates from them: GaussAdjoint / GaussKronrodAdjoint take
+                                  dgdp_continuous with the sign src/gauss_adjoint.jl:753-758 has as written (-f_p' lam + g_p under the reversed-time sum), and drop dgdp_discrete
+                                  (ReverseLossCallback skips it for `isq` algorithms, src/adjoint_common.jl:776, and src/gauss_adjoint.jl adds it nowhere).  0 (default): the
+                                  mathematically consistent forms (Gauss == Interpolating == Quadrature).  Exists so that a reference-generated fixture can decide each with one number. */
+    int32_t reserved1;
 } hipadj_config;
 
 typedef struct {
@@ -226,6 +245,22 @@ int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double 
  * and the 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62, with both steppers. */
 int hipadj_wmodel_register(const char *name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
                            const char *f_body, const char *vjp_body, int32_t *model_id);
+/* Discrete loss ON THE DEVICE for a runtime-registered lane model (n <= 8) — dgdu_discrete / dgdp_discrete of adjoint_sensitivities (src/sensitivity_interface.jl:373-526,
+ * evaluated by ReverseLossCallback at every loss time, src/adjoint_common.jl:771-779), selected per handle with loss_kind = HIPADJ_LOSS_MODEL:
+ *   dgdu_body  writes out[0..n)  = dl_i/du   from u[0..n), p[0..np), t (= t_i), i (the 0-based index of the loss time; the reference's `i` is i + 1) and d[0..n)
+ *   dgdp_body  writes out[0..np) = dl_i/dp   from the same arguments; NULL: the loss does not depend on p
+ * d is the column data[trajectory][i][0..n) of the block set with hipadj_set_loss_data[_dev] (zeros when none was set).  All `double`, no global memory access.
+ * The sweep adds dgdu to lam and dgdp to the parameter gradient at t_i — every sensealg (QuadratureAdjoint and GaussAdjoint add the parameter part next to their
+ * quadrature; the reference's GaussAdjoint drops it: hipadj_config.reference_literal), both steppers, checkpointing, off-grid loss times. */
+int hipadj_model_set_discrete_loss(int32_t model_id, const char *dgdu_body, const char *dgdp_body);
+/* The same from the loss itself: l_body assigns `l` (declared `real l`) = l_i(u, p, t, i, d) with `real` locals; dl/du and dl/dp by forward-mode dual numbers, and
+ * hipadj_loss_value[_dev] can then return the loss as well. */
+int hipadj_model_set_discrete_loss_function(int32_t model_id, const char *l_body);
+/* ... of a WIDE model (hipadj_wmodel_register), as ONE SPMD body with the conventions of its vjp body:  dloss<WP>(dlam, gp, acc, u, p, t, i, d, ws, tid)  ADDS dl_i/du into
+ * dlam[0..n) (entry k from the thread that owns it: HIPADJ_W_FOR loops do) and, under `if (WP)`, dl_i/dp into gp[...] (entries owned by one thread) or acc[...] (the model's
+ * reduced parameters).  u, dlam: LDS tiles; d: the trajectory's data column [n] in global memory (NULL when no block was set).  NULL / "" removes it. */
+int hipadj_wmodel_set_discrete_loss(int32_t model_id, const char *dloss_body);
+
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered lane model — for a wide model both forward solves and every reverse sweep of
  * the family (Interpolating, Gauss, GaussKronrod, Backsolve, Quadrature on RK4 and on adaptive Tsit5, without a cost) — for gfx950 (no device needed) so that
  * source errors surface before hipadj_create; the compiler log is available through hipadj_last_error(NULL). */
@@ -264,6 +299,21 @@ int hipadj_adjoint(hipadj_handle *h, const double *dLdu, double *du0, double *dp
  * max_steps = 0 reads the measured step counts back after the forward solve (and after QuadratureAdjoint's sweep). */
 int hipadj_forward_dev(hipadj_handle *h, const double *d_u0, const double *d_p, double *d_out);
 int hipadj_adjoint_dev(hipadj_handle *h, const double *d_dLdu, double *d_du0, double *d_dp);
+/* The data block of a device-resident loss (HIPADJ_LOSS_LSQ_DATA; HIPADJ_LOSS_MODEL bodies see it as `d`): data [N][M][n] in the layout of `out`, copied into the handle
+ * (the lane family keeps it transposed like its cotangents, so the reverse pass streams it coalesced and needs no per-pass transposition).  Call again to change it;
+ * the _dev form is asynchronous on the handle's stream.  A handle of kind HIPADJ_LOSS_LSQ_DATA without a block refuses hipadj_adjoint with HIPADJ_ERR_STATE. */
+int hipadj_set_loss_data(hipadj_handle *h, const double *data);
+int hipadj_set_loss_data_dev(hipadj_handle *h, const double *d_data);
+/* The loss itself, summed over the ensemble, from the primal output `out` [N][M][n] of the last forward solve: LSQ_SHIFT: sum |u - shift|^2 / 2; LSQ_DATA: loss_scale / 2 *
+ * sum |u - data|^2; HIPADJ_LOSS_MODEL: sum l_i for models registered with hipadj_model_set_discrete_loss_function.  The loss time at t0 is left out under no_start.
+ * Fixed summation order (bit-reproducible).  _dev: out and loss [1] in device memory, asynchronous. */
+int hipadj_loss_value(hipadj_handle *h, const double *out, double *loss);
+int hipadj_loss_value_dev(hipadj_handle *h, const double *d_out, double *d_loss);
+/* Cotangents handed over ALREADY in the lane family's streaming layout: Delta_soa[(i_time * n + j) * ld + trajectory] with ld = hipadj_soa_stride (N rounded up to 64) —
+ * the reverse pass then reads the block in place (hipadj_adjoint_dev transposes [N][M][n] into this layout first: one more launch, 2 x 8 n M N bytes of traffic).
+ * Lane-per-trajectory models (both steppers); other families: HIPADJ_ERR_UNSUPPORTED. */
+int hipadj_adjoint_dev_soa(hipadj_handle *h, const double *d_dLdu_soa, double *d_du0, double *d_dp);
+int hipadj_soa_stride(hipadj_handle *h, int64_t *ld);
 /* run on the caller's hipStream_t (e.g. torch's current stream); NULL restores the handle's own stream */
 int hipadj_set_stream(hipadj_handle *h, void *hip_stream);
 int hipadj_synchronize(hipadj_handle *h);

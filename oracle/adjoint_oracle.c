@@ -733,6 +733,7 @@ typedef struct {
     const double *save_t; int M; const double *dLdu; int cur_time; /* 1-based countdown (adjoint_common.jl:819) */
     /* Gauss accumulation (src/gauss_adjoint.jl:809) */
     double *gauss_acc;
+    double *dgp_acc;      /* QuadratureAdjoint: sum of dgdp_discrete over the loss times (src/quadrature_adjoint.jl:545-552, 601-605) */
     /* backsolve checkpoint cursor */
     int bs_cur;
     long *nrhs;
@@ -846,6 +847,25 @@ static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
     mm_solve(g_mm_invT, n, dz);                               /* mass matrix M'  quadrature_adjoint.jl:194-206, gauss_adjoint.jl:403-415 */
 }
 
+/* the oracle's test losses l_i(u, p, t_i, i, d) for ORC_LOSS_TEST (adjoint_oracle.h): gradient with respect to u and p */
+static void test_loss_grad(int id, int n, int np, const double *y, const double *p, double t, int i, const double *d, double *gu, double *gp) {
+    for (int j = 0; j < n; ++j) gu[j] = 0.0;
+    for (int j = 0; j < np && j < ORC_MAXNP_COST; ++j) gp[j] = 0.0;
+    const double d0 = d ? d[0] : 0.0;
+    switch (id) {
+    case 1: for (int j = 0; j < n; ++j) gu[j] = 2.0 * (y[j] - (d ? d[j] : 0.0)); break;
+    case 2: gu[0] = 2.0 * y[0]; gp[0] = 1.0; break;
+    case 3: gu[0] = 2.0 * y[0]; if (np > 1) gp[1] = 1.0; break;
+    case 4: {
+        const double un = y[n - 1], u1 = y[0], k = (double)(i + 1);
+        gu[0] += k * p[0] * un + sin(t);
+        gu[n - 1] += k * p[0] * u1 + p[1] * p[1] * d0;
+        gp[0] = k * u1 * un; gp[1] = 2.0 * p[1] * d0 * un;
+        break; }
+    default: break;
+    }
+}
+
 static int time_hits(double t, double target) { return fabs(t - target) <= 100 * DBL_EPSILON * fmax(fabs(t), fabs(target)); }
 
 /* ReverseLossCallback (src/adjoint_common.jl:754-821): lam += dgdu(y, p, t_i, i); counter counts down (:819) */
@@ -862,8 +882,21 @@ static int loss_jump(adj_ctx *A, orc_integ *I) {
     }
     int idx = A->cur_time - 1;
     double *gu = A->scratch;
-    for (int i = 0; i < n; ++i)
-        gu[i] = (A->cfg->loss_kind == ORC_LOSS_COTANGENT) ? A->dLdu[(size_t)idx * n + i] : (A->y[i] - A->cfg->loss_shift);
+    const int lk = A->cfg->loss_kind;
+    if (lk == ORC_LOSS_TEST) {
+        /* dgdu(gu, y, p, t[cur_time], cur_time); dgdp(gp, ...) added to the parameter block of the state (:771-779).  For the `isq` algorithms (Quadrature, Gauss) the callback
+         * skips dgdp: QuadratureAdjoint adds it next to its quadrature (src/quadrature_adjoint.jl:545-552, 601-605) — collected in dgp_acc here; GaussAdjoint adds it NOWHERE in the
+         * reference, which drops the term: the restatement puts it into the quadrature accumulator (Gauss == Interpolating == Quadrature) unless reference_literal asks for the drop. */
+        double gp[ORC_MAXNP_COST]; const double *d = A->dLdu ? A->dLdu + (size_t)idx * n : NULL;
+        test_loss_grad(A->cfg->dloss_id, n, np, A->y, A->p, I->t, idx, d, gu, gp);
+        if (A->alg == ORC_ALG_INTERPOLATING || A->alg == ORC_ALG_BACKSOLVE) for (int i = 0; i < np; ++i) I->u[n + i] += gp[i];
+        else if (A->alg == ORC_ALG_QUADRATURE) for (int i = 0; i < np; ++i) A->dgp_acc[i] += gp[i];
+        else if (!A->cfg->reference_literal) for (int i = 0; i < np; ++i) A->gauss_acc[i] += gp[i];
+    } else {
+        const double w = A->cfg->loss_scale != 0.0 ? A->cfg->loss_scale : 1.0;
+        for (int i = 0; i < n; ++i)
+            gu[i] = (lk == ORC_LOSS_COTANGENT) ? A->dLdu[(size_t)idx * n + i] : (lk == ORC_LOSS_LSQ_DATA ? w * (A->y[i] - A->dLdu[(size_t)idx * n + i]) : (A->y[i] - A->cfg->loss_shift));
+    }
     mm_solve(g_mm_invT, n, gu);                                                              /* ldiv!(F, dlam_d), F = lu(M')  :805-807 */
     for (int i = 0; i < n; ++i) I->u[i] += gu[i];                                            /* :812-813 */
     A->cur_time -= 1;
@@ -894,7 +927,9 @@ static void gauss_integrand(adj_ctx *A, double *out, double t, const double *lam
     for (int i = 0; i < A->np; ++i) out[i] = -out[i];
     if (cost_has_gp(A->cfg->cont_cost)) {
         double gp[ORC_MAXNP_COST]; cost_grad_p(A, gp);
-        for (int i = 0; i < A->np; ++i) out[i] -= gp[i];
+        /* reference_literal: `out .+= dgdp_cache` after the negation, as src/gauss_adjoint.jl:753-758 is written — the form a reference-generated fixture would decide */
+        if (A->cfg->reference_literal) for (int i = 0; i < A->np; ++i) out[i] += gp[i];
+        else for (int i = 0; i < A->np; ++i) out[i] -= gp[i];
     }
 }
 
@@ -1111,6 +1146,8 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     z = (double *)calloc(nz, sizeof(double));
     if (cfg->alg == ORC_ALG_BACKSOLVE) { memcpy(z + n + np, uend, sizeof(double) * n); if (A.bs_cur >= 1 && time_hits(cfg->t1, ck_t[A.bs_cur - 1])) A.bs_cur -= 1; }
     if (cfg->alg == ORC_ALG_GAUSS || cfg->alg == ORC_ALG_GAUSS_KRONROD) A.gauss_acc = (double *)calloc(np, sizeof(double));
+    A.dgp_acc = (double *)calloc(np > 0 ? np : 1, sizeof(double));
+    if (cfg->loss_kind == ORC_LOSS_TEST && (np > ORC_MAXNP_COST || (cfg->dloss_id == 4 && np < 2))) { free(A.dgp_acc); free(A.gauss_acc); free(A.y); free(A.scratch); free(z); free(tst); free(ck_t); free(ck_u); free(uend); dense_free(&sol); return -6; }
     orc_dense adjrec; int have_rec = 0;
     if (cfg->alg == ORC_ALG_QUADRATURE) { dense_init(&adjrec, n, cfg->stepper); have_rec = 1; }
     int cb_at_init = (M > 0 && time_hits(cfg->t1, cfg->save_times[M - 1])) && g_recall[ORC_RECALL_PRESET_AT_INIT] != 0.0;
@@ -1134,6 +1171,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             if (cfg->save_times[0] != cfg->t0) { quadgk_vec(quad_integrand, &Q, np, cfg->t0, cfg->save_times[0], atol, rtol, seg, &nev); for (int i = 0; i < np; ++i) dp[i] += seg[i]; }
         }
         if (nrhs) *nrhs += nev;
+        for (int i = 0; i < np; ++i) dp[i] += A.dgp_acc[i];                                  /* res .+= dgdp_cache at every loss time */
         free(seg); free(Q.lam);
     }
     clock_gettime(CLOCK_MONOTONIC, &c2);
@@ -1142,7 +1180,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
 
     if (have_rec) dense_free(&adjrec);
     if (A.cpsol_valid) dense_free(&A.cpsol);
-    free(A.int_a); free(A.int_b); free(A.gauss_acc); free(A.y); free(A.scratch);
+    free(A.int_a); free(A.int_b); free(A.gauss_acc); free(A.dgp_acc); free(A.y); free(A.scratch);
     free(z); free(tst); free(ck_t); free(ck_u); free(uend); dense_free(&sol);
     return st;
 }
@@ -1163,7 +1201,7 @@ int orc_forward(const orc_config *cfg, const double *u0, const double *p, double
 int orc_adjoint(const orc_config *cfg, const double *u0, const double *p, const double *dLdu,
                 double *du0, double *dp, double *out, long *nrhs) {
     orc_model m; if (model_init(&m, cfg->model, cfg->dims)) return -1;
-    if (cfg->loss_kind == ORC_LOSS_COTANGENT && !dLdu && cfg->nsave > 0) return -1;
+    if ((cfg->loss_kind == ORC_LOSS_COTANGENT || cfg->loss_kind == ORC_LOSS_LSQ_DATA) && !dLdu && cfg->nsave > 0) return -1;
     if (m.id == ORC_MODEL_MLP || m.id == ORC_MODEL_MLP1) m.work = (double *)calloc((size_t)4 * m.dims[1], sizeof(double));
     long nr = 0;
     int st = adjoint_one(&m, cfg, u0, p, dLdu, du0, dp, out, &nr, NULL, NULL);

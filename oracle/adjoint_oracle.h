@@ -51,7 +51,11 @@ enum {
 enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3,
        ORC_ALG_GAUSS_KRONROD = 4 /* [upstream-recall] per-step adaptive GK(7,15): parity UNPINNED beyond GaussKronrod == Gauss */ };
 enum { ORC_STEPPER_RK4 = 0, ORC_STEPPER_TSIT5 = 1 };
-enum { ORC_LOSS_COTANGENT = 0, ORC_LOSS_LSQ_SHIFT = 1 };
+enum { ORC_LOSS_COTANGENT = 0, ORC_LOSS_LSQ_SHIFT = 1,
+       ORC_LOSS_LSQ_DATA = 2,  /* dgdu_discrete = loss_scale (u - data[i]) with the data block handed in the cotangents' place: sum(abs2, sol .- data) for scale 2
+                                  (docs/src/Benchmark.md:80, docs/src/tutorials/parameter_estimation_ode.md:43) */
+       ORC_LOSS_TEST = 3       /* one of the oracle's test losses, chosen by dloss_id, with dgdu_discrete AND dgdp_discrete (src/adjoint_common.jl:771-779): the checker
+                                  for discrete-loss bodies attached to runtime-registered device models */ };
 
 typedef struct {
     int model, alg, stepper;
@@ -73,6 +77,14 @@ typedef struct {
                              2: g = u_1^2 + p_1 (test/Core7/mixed_costs.jl:46-57);
                              3: g = (x1 - pi)^2 + x2^2 + 5 (-p1 sin x1 + p2 x2)^2, the pendulum cost of test/Core7/adjoint_param.jl:18 (parameter-dependent, np >= 2);
                              4: g = -u_1 p_1 - p_2 (test/Core7/adjoint_param.jl:64) */
+    double loss_scale;    /* ORC_LOSS_LSQ_DATA: w of dgdu = w (u - data); 0 means 1 */
+    int dloss_id;         /* ORC_LOSS_TEST, with i the 0-based loss-time index, d the data column (zeros when no block is given), u_n the last state:
+                             1: l_i = sum_j (u_j - d_j)^2;
+                             2: l_i = u_1^2 + p_1   (test/Core7/mixed_costs.jl:199-227: dgdu = [2 u1, 0], dgdp = [1, 0, 0, 0]);
+                             3: l_i = u_1^2 + p_2   (test/Core7/mixed_costs.jl:404-424, the discrete part of the mixed cost);
+                             4: l_i = (i + 1) p_1 u_1 u_n + sin(t_i) u_1 + p_2^2 d_1 u_n   (every argument of the callback in use; np >= 2) */
+    int reference_literal;/* 1: the reference's lines where the restatement deliberately deviates: GaussAdjoint / GaussKronrodAdjoint take g_p of a
+                             continuous cost with the sign src/gauss_adjoint.jl:753-758 has as written, and drop dgdp_discrete (src/adjoint_common.jl:776 `!isq`) */
 } orc_config;
 
 int orc_model_sizes(int model, const int dims[4], int *n, int *np);
@@ -85,7 +97,7 @@ int orc_set_mass_matrix(int n, const double *M);
 /* forward solve of ONE trajectory; out[M][n] = sol(save_times) (src/concrete_solve.jl:718-727) */
 int orc_forward(const orc_config *cfg, const double *u0, const double *p, double *out, long *nsteps);
 
-/* forward + adjoint of ONE trajectory. dLdu: [M][n] cotangents or NULL (LSQ_SHIFT).
+/* forward + adjoint of ONE trajectory. dLdu: [M][n] cotangents, or the data block of ORC_LOSS_LSQ_DATA / ORC_LOSS_TEST, or NULL (LSQ_SHIFT; TEST without data).
    du0[n], dp[np] (row vector of src/sensitivity_interface.jl:500-508), out[M][n] (may be NULL). */
 int orc_adjoint(const orc_config *cfg, const double *u0, const double *p, const double *dLdu,
                 double *du0, double *dp, double *out, long *nrhs);

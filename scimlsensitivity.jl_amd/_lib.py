@@ -12,7 +12,7 @@ MODEL_USER_BASE = 1000
 
 MODEL = dict(lv=0, lvt=1, lorenz=2, lindiag=3, fallmass=4, mlp=5, bruss=6)
 ALG = dict(interpolating=0, backsolve=1, gauss=2, quadrature=3, gausskronrod=4)
-LOSS_COTANGENT, LOSS_LSQ_SHIFT = 0, 1
+LOSS_COTANGENT, LOSS_LSQ_SHIFT, LOSS_LSQ_DATA, LOSS_MODEL = 0, 1, 2, 3
 CCOST_NONE, CCOST_HALF_SQ_SUM, CCOST_U1SQ_PLUS_P1, CCOST_MODEL = 0, 1, 2, 3
 
 DECLARED_SYMBOLS = (
@@ -22,6 +22,8 @@ DECLARED_SYMBOLS = (
     "hipadj_model_register", "hipadj_wmodel_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_wmodel_set_cost", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
     "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
+    "hipadj_model_set_discrete_loss", "hipadj_model_set_discrete_loss_function", "hipadj_wmodel_set_discrete_loss", "hipadj_set_loss_data", "hipadj_set_loss_data_dev",
+    "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride",
 )
 
 
@@ -38,6 +40,8 @@ class HipadjConfig(C.Structure):
         ("cont_cost", C.c_int32), ("max_steps", C.c_int32),
         ("abstol", C.c_double), ("reltol", C.c_double),
         ("ncheckpoints", C.c_int32), ("checkpoints", C.POINTER(C.c_double)),
+        ("loss_scale", C.c_double), ("ndevices", C.c_int32), ("device_ids", C.POINTER(C.c_int32)),
+        ("reference_literal", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -119,6 +123,15 @@ def load():
     L.hipadj_comm_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.hipadj_comm_selfcheck.argtypes = [vp]
     L.hipadj_comm_overlap.argtypes = [vp, C.c_int]
+    L.hipadj_model_set_discrete_loss.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
+    L.hipadj_model_set_discrete_loss_function.argtypes = [C.c_int32, C.c_char_p]
+    L.hipadj_wmodel_set_discrete_loss.argtypes = [C.c_int32, C.c_char_p]
+    L.hipadj_set_loss_data.argtypes = [vp, dp]
+    L.hipadj_set_loss_data_dev.argtypes = [vp, vp]
+    L.hipadj_loss_value.argtypes = [vp, dp, dp]
+    L.hipadj_loss_value_dev.argtypes = [vp, vp, vp]
+    L.hipadj_adjoint_dev_soa.argtypes = [vp, vp, vp, vp]
+    L.hipadj_soa_stride.argtypes = [vp, C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -234,6 +247,21 @@ def set_model_mass_matrix(model_id, n, M):
         rc = L.hipadj_model_set_mass_matrix(int(model_id), A.ctypes.data_as(C.POINTER(C.c_double)))
         if rc == OK:
             MASS[int(model_id)] = A.copy()
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+
+
+def set_model_discrete_loss(model_id, dgdu=None, dgdp=None, l=None, wide=None):
+    """hipadj_model_set_discrete_loss[_function] / hipadj_wmodel_set_discrete_loss: the discrete loss of a runtime-registered model as device text —
+    its gradient bodies (dgdu, optional dgdp), the loss itself (l: gradients by dual numbers, and hipadj_loss_value can return the loss), or, for a
+    wide model, one SPMD body."""
+    L = load()
+    if wide is not None:
+        rc = L.hipadj_wmodel_set_discrete_loss(int(model_id), wide.encode() if wide else None)
+    elif l is not None:
+        rc = L.hipadj_model_set_discrete_loss_function(int(model_id), l.encode())
+    else:
+        rc = L.hipadj_model_set_discrete_loss(int(model_id), None if dgdu is None else dgdu.encode(), None if dgdp is None else dgdp.encode())
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
 

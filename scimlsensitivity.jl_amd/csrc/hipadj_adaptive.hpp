@@ -42,7 +42,8 @@ struct AdaptGeom {
     int maxit;                 // bound on the accepted steps of the forward solve (>= Smax; = Smax unless the capacity is auto-sized)
     double t0, t1, dt0, abstol, reltol;
     double loss_shift;
-    int loss_kind, no_start, p_shared, cont_cost;
+    int loss_kind, no_start, p_shared, cont_cost;   // loss_kind: hipadj_loss (0 cotangent, 1 lsq_shift, 2 lsq_data, 3 the model's discrete-loss bodies)
+    double la, lb; int lflags;                      // as Geom: dgdu = la u + lb c for the kinds that stream a column; bit 0 of lflags drops dgdp_discrete
     int SmaxA;                 // QuadratureAdjoint: capacity (steps) of the dense ADJOINT record; its readers clamp the stored TRUE step count with it
 };
 
@@ -856,9 +857,27 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
                     for (int j = 0; j < N; ++j) y[j] = zz[N + NP + j];
                 } else cur.eval(t, y);
+                double gl[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j)
-                    zz[j] += (g.loss_kind == 0) ? cotT[((long)(cur_time - 1) * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+                    gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift) : __builtin_fma(g.la, y[j], g.lb * cotT[((long)(cur_time - 1) * N + j) * g.Npad + i]);
+                if constexpr (model_has_dloss<Mo>::value) {   // dgdu_discrete / dgdp_discrete bodies of the model (hipadj_model_set_discrete_loss); gl holds the data column on entry
+                    if (g.loss_kind == 3) {
+                        double d[N], o[N], gpd[NP];
+#pragma unroll
+                        for (int j = 0; j < N; ++j) d[j] = gl[j];
+                        Mo::dgdu_disc(o, y, pv, t, cur_time - 1, d);
+#pragma unroll
+                        for (int j = 0; j < N; ++j) gl[j] = o[j];
+                        if (!(g.lflags & 1)) {
+                            Mo::dgdp_disc(gpd, y, pv, t, cur_time - 1, d);
+#pragma unroll
+                            for (int j = 0; j < NP; ++j) { if constexpr (ALG == 0 || ALG == 1) zz[N + j] += gpd[j]; else gacc[j] += gpd[j]; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) zz[j] += gl[j];
                 mod = true;
             }
             --cur_time;
@@ -881,7 +900,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         if constexpr (ALG == 2 || ALG == 4) mu_out[j] = gacc[j];
-        else if constexpr (ALG == 3) mu_out[j] = 0.0;      // dp comes from the quadrature pass
+        else if constexpr (ALG == 3) mu_out[j] = gacc[j];  // dp comes from the quadrature pass; gacc: the sum of dgdp_discrete of a model's discrete loss (else zero)
         else mu_out[j] = z[N + j];
     }
     if (ALG == 3) nsteps_adj[i] = sa;   // the TRUE count, also beyond the capacity: the host sizes the buffer from it (readers clamp with g.SmaxA)
@@ -1000,7 +1019,7 @@ __global__ void __launch_bounds__(64) k_adjoint_tsit5(AdaptGeom g, const double*
                                         ks + KS_ROWS * AdjNZ<Mo, ALG>::value * 64 + threadIdx.x, CK ? const_cast<double*>(rec) : nullptr);
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) du0[i * Mo::N + j] = lam[j];
-    if (ALG != 3) {
+    if (ALG != 3 || model_has_dloss<Mo>::value) {   // QuadratureAdjoint: k_quad_sum writes dp_traj from the quadrature (and adds to it for a model with discrete-loss bodies)
 #pragma unroll
         for (int j = 0; j < Mo::NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j]; }
 }

@@ -60,6 +60,17 @@ extern "C" int hipadj_wmodel_set_cost(int32_t model_id, const char* cost_body) {
     return user_set_wide_cost(model_id, cost_body, g_create_error);
 }
 
+extern "C" int hipadj_model_set_discrete_loss(int32_t model_id, const char* dgdu_body, const char* dgdp_body) {
+    return user_set_discrete_loss(model_id, dgdu_body, dgdp_body, nullptr, g_create_error);
+}
+extern "C" int hipadj_model_set_discrete_loss_function(int32_t model_id, const char* l_body) {
+    if (!l_body) { g_create_error = "hipadj_model_set_discrete_loss_function: NULL argument"; return HIPADJ_ERR_INVALID_ARG; }
+    return user_set_discrete_loss(model_id, nullptr, nullptr, l_body, g_create_error);
+}
+extern "C" int hipadj_wmodel_set_discrete_loss(int32_t model_id, const char* dloss_body) {
+    return user_set_wide_discrete_loss(model_id, dloss_body, g_create_error);
+}
+
 extern "C" int hipadj_model_set_mass_matrix(int32_t model_id, const double* M) {
     return user_set_mass_matrix(model_id, M, g_create_error);
 }
@@ -227,11 +238,12 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->d_wscr};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->d_wscr, h->d_ldata, h->d_lpart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
     if (h->umod_alt) (void)hipModuleUnload(h->umod_alt);
+    if (h->lmod) (void)hipModuleUnload(h->lmod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
     if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); if (h->comm_ready) (void)hipEventDestroy(h->comm_ready); for (auto e : h->comm_done) if (e) (void)hipEventDestroy(e); }
@@ -299,7 +311,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         if (h->M > 0) A(dev_alloc(h, &h->d_save_t, (size_t)h->M));
         h->ntstops = (int)P.tstops_desc.size();
         if (h->ntstops > 0) A(dev_alloc(h, &h->d_tstops, (size_t)h->ntstops));
-        if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
+        if (cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT && h->M > 0) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));   // cotangents per pass, or the data block of a device-resident loss (hipadj_set_loss_data)
         if (rc == HIPADJ_OK) {
             bool ok2 = true;
             if (h->M > 0) ok2 = ok2 && HT(hipMemcpy(h->d_save_t, P.save_times.data(), sizeof(double) * h->M, hipMemcpyHostToDevice), "memcpy");
@@ -318,8 +330,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         h->wg.loss_kind = cfg->loss_kind; h->wg.no_start = cfg->no_start; h->wg.p_shared = cfg->p_shared;
         if (P.adaptive) {
             // adaptive Tsit5: trajectory-major dense records.  max_steps = 0: the capacity is what 8 GiB of records hold (of 288 GB), between 64 and 8192
-            // accepted steps per trajectory (no regrow round in this family — it would cost a stream synchronisation per forward solve: a trajectory that
-            // needs more reports HIPADJ_ERR_MAXITERS and names max_steps)
+            // accepted steps per trajectory; when the budget cut the capacity below 8192 steps the step counts are read back after every forward solve and the record
+            // is regrown on overflow (wide_autosize: one stream synchronisation per forward solve, in that mode only)
             h->wide_ts5 = true;
             const long RW = 2 + 5L * n;
             long budget = 8L << 30;
@@ -378,7 +390,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_yT, (size_t)n * Np));
         if ((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) || P.offgrid) A(dev_alloc(h, &h->d_knots, (size_t)(S + 1) * n * Np));   // off-grid Backsolve: the checkpoint states are interpolated from the knots
         if (bs_ckpt) A(dev_alloc(h, &h->d_ckpt, (size_t)h->nck * n * Np));
-        if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));
+        if (cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT && h->M > 0) A(dev_alloc(h, &h->d_cotT, (size_t)h->M * n * Np));   // cotangents per pass, or the data block of a device-resident loss (hipadj_set_loss_data)
         A(dev_alloc(h, &h->d_segbuf, (size_t)h->nseg * (1 + n) * (n + np) * Np));
         if (!P.user) {   // event knots of the forward solve (k_forward_ev): save times, checkpoints, the knot in front of a shortened last step
             if (const char* e = std::getenv("HIPADJ_FWD_EV")) h->fwd_ev = std::atoi(e);
@@ -494,6 +506,15 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     g.N = h->N; g.Npad = Np; g.S = (int)S; g.M = h->M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
     g.kmask = -1; g.h_last = P.h_last;
+    // dgdu = la u + lb c for the kinds that stream a column c: cotangents and model bodies take c itself, HIPADJ_LOSS_LSQ_DATA w (u - c)
+    const double lw = cfg->loss_scale != 0.0 ? cfg->loss_scale : 1.0;
+    g.la = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? lw : 0.0; g.lb = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? -lw : 1.0;
+    const bool gauss_like = cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD;
+    g.lflags = (cfg->reference_literal && gauss_like) ? 1 : 0;   // the reference's GaussAdjoint drops dgdp_discrete (src/adjoint_common.jl:776 `!isq`; nothing in src/gauss_adjoint.jl adds it)
+    h->ag.la = g.la; h->ag.lb = g.lb; h->ag.lflags = g.lflags;
+    h->wg.la = g.la; h->wg.lb = g.lb; h->wg.lflags = g.lflags;
+    h->fg.lsq_w = lw; h->mg.lsq_w = lw;
+    if (h->d_cotT && cfg->loss_kind != HIPADJ_LOSS_COTANGENT && hipMemset(h->d_cotT, 0, sizeof(double) * (size_t)h->M * n * Np) != hipSuccess) { h->err = "hipMemset failed"; return fail(HIPADJ_ERR_HIP); }
     if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
     {
         int cus = 256, mode = 1;
@@ -522,12 +543,14 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     else if (cfg->alg == HIPADJ_ALG_BACKSOLVE || P.ip_ckpt) bytes = (double)h->N * ((double)h->nck * 8.0 * n + 8.0 * n);
     else bytes = (double)h->N * (double)(S + 1) * 16.0 * n;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) bytes += (double)h->N * (double)S * 2.0 * 32.0 * n;   // dense lambda write + read
-    if (cfg->loss_kind == HIPADJ_LOSS_COTANGENT) bytes += (double)h->N * h->M * 8.0 * n;
+    if (cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) bytes += (double)h->N * h->M * 8.0 * n;   // the cotangent / data block is read once
     bytes += (double)h->N * 8.0 * (n + np);
     h->st.adjoint_algorithmic_bytes = bytes;
     h->st.vjp_steps = (double)h->N * (double)S * 4.0;
     h->user = P.user;
     if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { h->err = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost / hipadj_wmodel_set_cost)"; return fail(HIPADJ_ERR_INVALID_ARG); }
+    if (cfg->loss_kind == HIPADJ_LOSS_MODEL && !user_has_dloss(cfg->model)) { h->err = "loss_kind = HIPADJ_LOSS_MODEL but the model has no discrete-loss bodies (hipadj_model_set_discrete_loss / hipadj_wmodel_set_discrete_loss)"; return fail(HIPADJ_ERR_INVALID_ARG); }
+    if (cfg->ndevices > 1) { h->err = "a handle over several devices is created through hipadj_create's multi-device path (internal error: reached the single-device constructor)"; return fail(HIPADJ_ERR_INVALID_ARG); }
     if (P.wide) { const int urc = wide_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
     else if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); }
     *out = h;
@@ -556,7 +579,11 @@ extern "C" int hipadj_comm_overlap(hipadj_handle* h, int on) {
         for (auto& e : h->comm_done) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     if (!on && h->comm_stream) HIP_TRY(h, hipStreamSynchronize(h->comm_stream));
-    h->comm_overlap = on ? 1 : 0; h->comm_seq = 0;
+    // switching it on AGAIN while collectives are in flight must not forget them: the sequence number — whose parity picks the comm_done event a pass
+    // waits for — restarts only on a real off -> on transition, where the second stream has been drained by the `off` above
+    if ((on ? 1 : 0) != h->comm_overlap) h->comm_seq = 0;
+    h->comm_overlap = on ? 1 : 0;
+    { const char* e = std::getenv("HIPADJ_TEST_COMM_DELAY"); h->comm_test_delay = (on && e) ? std::atol(e) : 0L; }   // test hook, see hipadj_adjoint_dev
     return HIPADJ_OK;
 }
 
@@ -751,7 +778,7 @@ struct UserKernels { std::string forward, main_k, tail, gk; };
 static UserKernels user_kernel_names(const hipadj_handle* h) {
     const std::string U = "hipadj::UserModel";
     const int n = h->n, np = h->np;
-    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);
+    const int mode = (loss_streams(h) ? 0 : 1) | (h->cfg.cont_cost << 1);
     const int cc = mode >> 1;
     // knot prefetch depth of the reverse sweeps: the unrolled PF-deep blocks pay for small step bodies only (n <= 3 and a right-hand side without
     // library math, user_calls_math); everything else runs the rolled sweep with one knot in flight, which measured fastest at every n = 2 ... 8
@@ -915,7 +942,8 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN), cblocks = (unsigned)((h->N + FIN / 4 - 1) / (FIN / 4));
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
     double* no_sum = nullptr;
-    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    const double* cotT = h->cot_soa ? h->cot_soa : h->d_cotT;   // hipadj_adjoint_dev_soa: the caller's block, already in the streaming layout
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
     harvest_set(h, es, true);
@@ -926,7 +954,7 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
         for (int pass = 0; pass < 2; ++pass) {
             TRY(usig<decltype(&k_adjoint_tsit5<ModelLV, 0, 0, false>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_yT,
                         (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, h->ntstops,
-                        (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag, h->d_arec, h->d_nsteps_adj, h->SmaxA));
+                        cotT, d_du0, h->d_dp_traj, h->d_flag, h->d_arec, h->d_nsteps_adj, h->SmaxA));
             if (!(h->cfg.alg == HIPADJ_ALG_QUADRATURE && h->auto_steps)) break;
             const int again = adaptive_adjoint_autosize(h);
             if (again < 0) return again;
@@ -936,19 +964,19 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
             TRY(usig<decltype(&k_quad_gk_tsit5<ModelLV, 0>)>::launch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
                         (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres));
-            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj, h->cfg.loss_kind == HIPADJ_LOSS_MODEL ? 1 : 0);
             HIP_TRY(h, hipGetLastError());
         }
     } else if (h->offgrid) {
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
-            TRY(usig<decltype(&k_backsolve_offgrid<ModelLV, 0>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_cotT, d_du0, h->d_dp_traj));
+            TRY(usig<decltype(&k_backsolve_offgrid<ModelLV, 0>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, cotT, d_du0, h->d_dp_traj));
         else if (h->nseg > 1) {
             SegPlan sp{h->nseg, h->d_seg_bounds};
-            TRY(usig<decltype(&k_offgrid_seg<ModelLV, 1, false>)>::launch(h, h->uf_main, dim3(waves, (unsigned)h->nseg), dim3(WAVE), h->g, R, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, h->d_segbuf));
+            TRY(usig<decltype(&k_offgrid_seg<ModelLV, 1, false>)>::launch(h, h->uf_main, dim3(waves, (unsigned)h->nseg), dim3(WAVE), h->g, R, sp, p, (const dbl2*)h->d_knots, cotT, h->d_segbuf));
             composed = true;
         } else
-        TRY(usig<decltype(&k_interp_offgrid<ModelLV, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj));
+        TRY(usig<decltype(&k_interp_offgrid<ModelLV, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, cotT, d_du0, h->d_dp_traj));
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
         const dim3 sgrid(waves, (unsigned)h->nseg);
@@ -958,9 +986,9 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
             double* dps = h->cfg.p_shared ? d_dp : (double*)nullptr;
             if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
                 TRY(usig<decltype(&k_backsolve_fused<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
-                            (const double*)h->d_cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag));
+                            cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag));
             else
-                TRY(usig<decltype(&k_interp_fused<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev,
+                TRY(usig<decltype(&k_interp_fused<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
                             d_du0, dp_rows, dps, h->d_flag));
             if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
             if (h->has_mm) {
@@ -974,23 +1002,26 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
         }
         if (h->ip_ckpt) {
             TRY(usig<decltype(&k_interp_ckpt<ModelLV, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck,
-                                                                   (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride));
+                                                                   cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride));
             composed = true;
         } else
         switch (h->cfg.alg) {
         case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:
-            TRY(usig<decltype(&k_interp<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf));
+            TRY(usig<decltype(&k_interp<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, h->d_segbuf));
             composed = true; break;
         case HIPADJ_ALG_BACKSOLVE:
             TRY(usig<decltype(&k_backsolve<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
-                        (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf));
+                        cotT, (const int*)h->d_save_rev, h->d_segbuf));
             composed = true; break;
         default: {
-            TRY(usig<decltype(&k_quad_adj<ModelLV, 8, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_adj, d_du0));
+            // a model with discrete-loss bodies (HIPADJ_LOSS_MODEL): the sweep leaves the sum of dgdp_discrete over the loss times in dp_traj, to which k_quad_sum adds the quadrature
+            const bool dl = h->cfg.loss_kind == HIPADJ_LOSS_MODEL;
+            TRY(usig<decltype(&k_quad_adj<ModelLV, 8, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, h->d_adj, d_du0,
+                        dl ? h->d_dp_traj : (double*)nullptr));
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
             TRY(usig<decltype(&k_quad_gk<ModelLV, 0>)>::launch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->g, p, (const dbl2*)h->d_knots, (const dbl2*)h->d_adj, (const double*)h->d_qa,
                         (const double*)h->d_qb, atol, rtol, h->d_qres));
-            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj);
+            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj, dl ? 1 : 0);
             HIP_TRY(h, hipGetLastError());
             break; }
         }
@@ -1034,9 +1065,15 @@ int adaptive_autosize(hipadj_handle* h) {
     if (mx <= h->rec_cap || mx >= HIPADJ_AUTO_MAXITERS) return 0;     // fits (or ran into maxiters: the flag reports it)
     const int RW = 2 + 5 * h->n;
     const long cap = mx + mx / 8 + 8;
+    // the larger buffer first, the old one released only once it exists: a failed allocation leaves the handle with its old (consistent) record and capacities, and without
+    // a forward solution — a later hipadj_adjoint_dev then reports HIPADJ_ERR_STATE instead of sweeping a null record
     auto regrow = [&](double** buf, size_t old_count, size_t new_count) -> int {
-        if (*buf) { (void)hipFree(*buf); *buf = nullptr; h->ws_bytes -= (double)(old_count * sizeof(double)); }
-        return dev_alloc(h, buf, new_count);
+        double* nb = nullptr;
+        const int rc = dev_alloc(h, &nb, new_count);
+        if (rc != HIPADJ_OK) { h->have_forward = false; return rc; }
+        if (*buf) { (void)hipFree(*buf); h->ws_bytes -= (double)(old_count * sizeof(double)); }
+        *buf = nb;
+        return HIPADJ_OK;
     };
     TRY(regrow(&h->d_rec, (size_t)h->rec_cap * RW * h->Npad, (size_t)cap * RW * h->Npad));
     if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
@@ -1070,8 +1107,10 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
     if (mx <= h->SmaxA || mx >= 8L * HIPADJ_AUTO_MAXITERS) return 0;
     const int RW = 2 + 5 * h->n;
     const long capA = mx + mx / 8 + 8;
-    if (h->d_arec) { (void)hipFree(h->d_arec); h->d_arec = nullptr; h->ws_bytes -= (double)((size_t)h->SmaxA * RW * h->Npad * sizeof(double)); }
-    TRY(dev_alloc(h, &h->d_arec, (size_t)capA * RW * h->Npad));
+    { double* nb = nullptr;     // the larger record first (a failed allocation keeps the old one and its capacity)
+      TRY(dev_alloc(h, &nb, (size_t)capA * RW * h->Npad));
+      if (h->d_arec) { (void)hipFree(h->d_arec); h->ws_bytes -= (double)((size_t)h->SmaxA * RW * h->Npad * sizeof(double)); }
+      h->d_arec = nb; }
     h->SmaxA = (int)capA; h->ag.SmaxA = h->SmaxA;
     h->st.workspace_bytes = h->ws_bytes;
     HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
@@ -1110,9 +1149,15 @@ static int wide_autosize(hipadj_handle* h) {
     for (long i = 0; i < h->N; ++i) if (ns[i] > mx) mx = ns[i];
     if (mx <= h->rec_cap || mx >= HIPADJ_AUTO_MAXITERS) return 0;     // fits (or ran into maxiters: the flag reports it)
     const long RW = 2 + 5L * h->n, cap = mx + mx / 8 + 8;
+    // the larger buffer first, the old one released only once it exists: a failed allocation leaves the handle with its old (consistent) record and capacities, and without
+    // a forward solution — a later hipadj_adjoint_dev then reports HIPADJ_ERR_STATE instead of sweeping a null record
     auto regrow = [&](double** buf, size_t old_count, size_t new_count) -> int {
-        if (*buf) { (void)hipFree(*buf); *buf = nullptr; h->ws_bytes -= (double)(old_count * sizeof(double)); }
-        return dev_alloc(h, buf, new_count);
+        double* nb = nullptr;
+        const int rc = dev_alloc(h, &nb, new_count);
+        if (rc != HIPADJ_OK) { h->have_forward = false; return rc; }
+        if (*buf) { (void)hipFree(*buf); h->ws_bytes -= (double)(old_count * sizeof(double)); }
+        *buf = nb;
+        return HIPADJ_OK;
     };
     TRY(regrow(&h->d_rec, (size_t)h->N * h->rec_cap * RW, (size_t)h->N * cap * RW));
     if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
@@ -1173,7 +1218,7 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
             const WideQuadSrc src{nullptr, nullptr, h->d_rec, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->wa.Smax, h->SmaxA};
             TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG, true>)>::launch(h, h->uf_gk, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, src,
                         (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
-            hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows);
+            hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows, h->cfg.loss_kind == HIPADJ_LOSS_MODEL ? 1 : 0);
             HIP_TRY(h, hipGetLastError());
         }
     } else if (h->offgrid) {
@@ -1194,13 +1239,13 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
                     (const int*)h->d_ckpt_of_knot, d_cot, (const int*)h->d_save_rev, d_du0, rows, h->d_flag));
         break;
     case HIPADJ_ALG_QUADRATURE: {
-        TRY(usig<decltype(&k_wide_quad_adj<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag));
+        TRY(usig<decltype(&k_wide_quad_adj<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag, rows));
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
         const WideQuadSrc src{h->d_fknots, h->d_fadj, nullptr, nullptr, nullptr, nullptr, 0, 0};
         TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG, false>)>::launch(h, h->uf_gk, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, src,
                     (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
-        hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows);
+        hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows, h->cfg.loss_kind == HIPADJ_LOSS_MODEL ? 1 : 0);
         HIP_TRY(h, hipGetLastError());
         break; }
     default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "sensealg not available for wide models");
@@ -1240,7 +1285,9 @@ static int forward_dispatch(hipadj_handle* h, const double* d_u0, const double* 
 // forward kernel); `avail` says so.  The forward solution of the handle is restored before returning (one more forward solve on the original inputs).
 static int user_ground_truth(hipadj_handle* h, const double* d_cot, const std::vector<double>* cand_du0[2], const std::vector<double>* cand_dp[2], double (&err)[2], bool& avail) {
     avail = false; err[0] = err[1] = 1e300;
-    if (h->adaptive || h->cfg.cont_cost != 0 || h->M <= 0 || std::getenv("HIPADJ_RTC_NO_GROUND_TRUTH")) return HIPADJ_OK;
+    // mass-matrix models: du0 handed back is lam(t0) = M^{-T} nu(t0) (the reference's convention), NOT dL/du0 = M' du0 — the differences would contradict both builds;
+    // device-resident losses other than the shifted least squares: the arbiter below knows only the cotangent and the shift form of the loss
+    if (h->adaptive || h->cfg.cont_cost != 0 || h->M <= 0 || h->has_mm || h->cfg.loss_kind > HIPADJ_LOSS_LSQ_SHIFT || std::getenv("HIPADJ_RTC_NO_GROUND_TRUTH")) return HIPADJ_OK;
     const size_t N = (size_t)h->N, n = (size_t)h->n, np = (size_t)h->np, M = (size_t)h->M;
     const size_t n0 = N * n, n1 = h->cfg.p_shared ? np : N * np, no = N * M * n;
     std::vector<double> u0(n0), p(n1), cot, outp(no), outm(no), up(n0), pp(n1), d(n0), e(n1);
@@ -1360,8 +1407,9 @@ static int user_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
                     HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
                     return user_adjoint_run(h, d_cot, d_du0, d_dp);
                 }
-                h->rtc_selftest = 1;
-                HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "the -O3 and -O1 builds of the reverse kernel of runtime model %d disagree and NEITHER matches finite differences of the forward solve (relative errors %.1e / %.1e): no trustworthy build (DESIGN.md 6.8)", h->cfg.model, gerr[1], gerr[0]);
+                // neither candidate is within GT_TOL of the differences: on a stiff or chaotic long-horizon problem the differences themselves (eps = 1e-6) can be off by more than
+                // that, so this is no verdict — fall through to the reproducibility tie-break below instead of refusing
+                std::fprintf(stderr, "hipadj: runtime model %d: the -O3 and -O1 builds of the reverse kernel disagree and finite differences of the forward solve match neither (relative errors %.1e / %.1e): deciding by reproducibility (DESIGN.md 6.8)\n", h->cfg.model, gerr[1], gerr[0]);
             }
         }
         // No ground truth for this configuration (adaptive stepper, continuous cost): the older tie-break.  Every reverse kernel is bit-reproducible on fixed inputs (fixed summation orders, no
@@ -1408,6 +1456,13 @@ static int adjoint_dispatch(hipadj_handle* h, const double* d_cot, double* d_du0
     DISPATCH_MODEL(h, adjoint_impl, h, d_cot, d_du0, d_dp);
 }
 
+// test hook of the overlapped all-reduce (HIPADJ_TEST_COMM_DELAY, hipadj_adjoint_dev): spin `ticks` of the 100 MHz wall clock, then dp *= 2
+__global__ void k_test_delay_scale(double* __restrict__ dp, int np, long ticks) {
+    const long t0 = (long)wall_clock64();
+    while ((long)wall_clock64() - t0 < ticks) {}
+    for (int j = threadIdx.x; j < np; j += blockDim.x) dp[j] *= 2.0;
+}
+
 extern "C" int hipadj_forward_dev(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!d_u0 || !d_p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
@@ -1436,6 +1491,9 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
     if (!h->have_forward) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_adjoint called before hipadj_forward (the reverse pass consumes the forward solution)");
     if (!d_du0 || !d_dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !d_dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
+    if (h->cfg.loss_kind == HIPADJ_LOSS_LSQ_DATA && h->M > 0 && !h->have_ldata) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "loss_kind = HIPADJ_LOSS_LSQ_DATA: hand the data block over first (hipadj_set_loss_data / hipadj_set_loss_data_dev)");
+    // device-resident losses: the workgroup families read the handle's data block in the cotangents' place (the lane family streams its transposed copy in d_cotT)
+    if (h->cfg.loss_kind == HIPADJ_LOSS_LSQ_DATA || h->cfg.loss_kind == HIPADJ_LOSS_MODEL) d_dLdu = h->have_ldata ? h->d_ldata : nullptr;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     harvest_timing(h, false);
     const bool overlap = h->comm && h->comm_overlap && h->comm_stream;
@@ -1449,6 +1507,9 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
         HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
         const int rc = rccl_api().AllReduce(d_dp, d_dp, (size_t)h->np, RCCL_DOUBLE, RCCL_SUM, h->comm, h->comm_stream);
         if (rc != 0) { h->err = rccl_error("ncclAllReduce", rc); return HIPADJ_ERR_RCCL; }
+        // test hook (tests/test_gpu_parity.py): a one-rank all-reduce is the identity, so nothing on a 1-GPU box could tell whether a consumer of dp waited for the second
+        // stream.  HIPADJ_TEST_COMM_DELAY=<microseconds> makes the collective SLOW and VISIBLE: a spin of that length, then dp *= 2, both on the second stream in front of comm_done.
+        if (h->comm_test_delay > 0) { hipLaunchKernelGGL(k_test_delay_scale, dim3(1), dim3(64), 0, h->comm_stream, d_dp, h->np, h->comm_test_delay * 100L); HIP_TRY(h, hipGetLastError()); }
         HIP_TRY(h, hipEventRecord(h->comm_done[h->comm_seq & 1], h->comm_stream));
         ++h->comm_seq;
     } else if (h->comm) {   // the one exchange of the sharded ensemble: dp = sum over the ranks' shards, in-stream
@@ -1457,6 +1518,111 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
     }
     h->st.adjoint_calls++;
     return HIPADJ_OK;
+}
+
+// ---- device-resident discrete losses: the data block, the loss value, cotangents in the streaming layout -----------------------------------------------
+static int loss_data_install(hipadj_handle* h) {   // h->d_ldata [N][M][n] is in place (stream order): the lane family's transposed copy
+    const bool lane = !h->wide && !h->field && !h->mlp;
+    if (lane && h->d_cotT && h->M > 0) TRY(launch_transpose_to_soa(h, h->d_ldata, h->d_cotT, h->M * h->n));
+    h->have_ldata = true;
+    return HIPADJ_OK;
+}
+static int loss_data_buffer(hipadj_handle* h) {
+    if (h->cfg.loss_kind != HIPADJ_LOSS_LSQ_DATA && h->cfg.loss_kind != HIPADJ_LOSS_MODEL) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_set_loss_data: the handle's loss_kind is neither HIPADJ_LOSS_LSQ_DATA nor HIPADJ_LOSS_MODEL");
+    if (h->M <= 0) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_set_loss_data: the handle has no loss times");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->d_ldata) { TRY(dev_alloc(h, &h->d_ldata, (size_t)h->N * h->M * h->n)); h->st.workspace_bytes = h->ws_bytes; }
+    return HIPADJ_OK;
+}
+extern "C" int hipadj_set_loss_data_dev(hipadj_handle* h, const double* d_data) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!d_data) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "data must be non-NULL");
+    TRY(loss_data_buffer(h));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ldata, d_data, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyDeviceToDevice, h->stream));
+    return loss_data_install(h);
+}
+extern "C" int hipadj_set_loss_data(hipadj_handle* h, const double* data) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!data) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "data must be non-NULL");
+    TRY(loss_data_buffer(h));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ldata, data, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
+    TRY(loss_data_install(h));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // the caller's buffer may go away
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_loss_value_dev(hipadj_handle* h, const double* d_out, double* d_loss) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!d_out || !d_loss) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "out and loss must be non-NULL");
+    const int kind = h->cfg.loss_kind;
+    if (kind == HIPADJ_LOSS_COTANGENT) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_loss_value: a cotangent handle does not know the loss (its gradient comes from the caller's AD)");
+    if (kind == HIPADJ_LOSS_LSQ_DATA && !h->have_ldata) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_loss_value: hand the data block over first (hipadj_set_loss_data)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const long total = (long)h->N * h->M * h->n;
+    // the loss time at t0 does not enter the loss under no_start (src/adjoint_common.jl:761)
+    const int m0 = (h->cfg.no_start && !h->save_times.empty() && std::fabs(h->save_times[0] - h->cfg.t0) <= 1e-12 * std::max(1.0, std::fabs(h->cfg.t0))) ? 1 : 0;
+    if (total == 0) { HIP_TRY(h, hipMemsetAsync(d_loss, 0, sizeof(double), h->stream)); return HIPADJ_OK; }
+    if (kind == HIPADJ_LOSS_MODEL) {
+        bool has_value = false;
+        if (h->wide || !user_has_dloss(h->cfg.model, &has_value) || !has_value)
+            HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_loss_value: the model's discrete loss was given as gradient bodies; register the loss itself with hipadj_model_set_discrete_loss_function (lane models)");
+        if (!h->lf_value) {
+            const std::vector<std::string> ex = {"hipadj::k_user_loss_value<hipadj::UserModel>"};
+            std::vector<char> code; std::map<std::string, std::string> low;
+            TRY(user_compile(h->cfg.model, ex, code, low, h->err));
+            HIP_TRY(h, hipModuleLoadData(&h->lmod, code.data()));
+            HIP_TRY(h, hipModuleGetFunction(&h->lf_value, h->lmod, low[ex[0]].c_str()));
+        }
+        if (!h->d_save_t) {   // (fixed-step handles on the grid keep no device copy of the save times)
+            TRY(dev_alloc(h, &h->d_save_t, (size_t)h->M));
+            HIP_TRY(h, hipMemcpyAsync(h->d_save_t, h->save_times.data(), sizeof(double) * h->M, hipMemcpyHostToDevice, h->stream));
+        }
+        if (!h->d_lpart) TRY(dev_alloc(h, &h->d_lpart, (size_t)std::max<long>(h->N, (total + LV_CHUNK - 1) / LV_CHUNK)));
+        long Nl = h->N, ldp = h->cfg.p_shared ? 0 : h->np; int M = h->M, m0_ = m0;
+        const double* dd = h->have_ldata ? h->d_ldata : nullptr; const double* pp = h->p_dev_last ? h->p_dev_last : h->d_p; const double* st = h->d_save_t;
+        void* args[] = {&Nl, &M, &m0_, &ldp, &d_out, &dd, &pp, &st, &h->d_lpart};
+        HIP_TRY(h, hipModuleLaunchKernel(h->lf_value, (unsigned)((h->N + 255) / 256), 1, 1, 256, 1, 1, 0, h->stream, args, nullptr));
+        hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(256), 0, h->stream, h->N, (const double*)h->d_lpart, d_loss);
+        HIP_TRY(h, hipGetLastError());
+        return HIPADJ_OK;
+    }
+    const long nb = (total + LV_CHUNK - 1) / LV_CHUNK;
+    if (!h->d_lpart) TRY(dev_alloc(h, &h->d_lpart, (size_t)std::max<long>(h->N, nb)));
+    hipLaunchKernelGGL(k_loss_value, dim3((unsigned)nb), dim3(256), 0, h->stream, total, h->M, h->n, m0, kind, h->cfg.loss_shift, h->cfg.loss_scale != 0.0 ? h->cfg.loss_scale : 1.0,
+                       d_out, (const double*)h->d_ldata, h->d_lpart);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(256), 0, h->stream, nb, (const double*)h->d_lpart, d_loss);
+    HIP_TRY(h, hipGetLastError());
+    return HIPADJ_OK;
+}
+extern "C" int hipadj_loss_value(hipadj_handle* h, const double* out, double* loss) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!out || !loss) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "out and loss must be non-NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    // d_io_a is the host API's staging block of [N][M][n]; one more double behind d_du0 carries the result
+    HIP_TRY(h, hipMemcpyAsync(h->d_io_a, out, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
+    TRY(hipadj_loss_value_dev(h, h->d_io_a, h->d_du0));
+    HIP_TRY(h, hipMemcpyAsync(loss, h->d_du0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return HIPADJ_OK;
+}
+
+extern "C" int hipadj_soa_stride(hipadj_handle* h, int64_t* ld) {
+    if (!h || !ld) return HIPADJ_ERR_INVALID_ARG;
+    if (h->wide || h->field || h->mlp) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "the streaming cotangent layout belongs to the lane-per-trajectory family; this handle's family reads [N][M][n] in place");
+    *ld = h->Npad;
+    return HIPADJ_OK;
+}
+extern "C" int hipadj_adjoint_dev_soa(hipadj_handle* h, const double* d_dLdu_soa, double* d_du0, double* d_dp) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->wide || h->field || h->mlp) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_adjoint_dev_soa: the streaming cotangent layout belongs to the lane-per-trajectory family; this handle's family reads [N][M][n] in place");
+    if (h->cfg.loss_kind != HIPADJ_LOSS_COTANGENT || h->M <= 0) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_adjoint_dev_soa: the handle takes no cotangents (loss_kind / no loss times)");
+    if (!d_dLdu_soa) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
+    if (h->rtc_selftest == 1) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_adjoint_dev_soa: the first reverse pass of this handle cross-checks two builds of a runtime-compiled kernel; run hipadj_adjoint_dev once first");
+    h->cot_soa = d_dLdu_soa;
+    const int rc = hipadj_adjoint_dev(h, d_dLdu_soa, d_du0, d_dp);
+    h->cot_soa = nullptr;
+    return rc;
 }
 
 extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* p, double* out) {
@@ -1480,6 +1646,9 @@ extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0,
     if (cot) HIP_TRY(h, hipMemcpyAsync(h->d_io_a, dLdu, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
     TRY(hipadj_adjoint_dev(h, cot ? h->d_io_a : nullptr, h->d_du0, h->d_dp));
     const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
+    // an overlapped all-reduce (hipadj_comm_overlap) runs on the handle's SECOND stream: the copy of dp below is enqueued on the first one and has to wait for the collective
+    // that was just recorded, not only for the reverse pass (with more than one rank the host could otherwise receive the un-reduced shard sum)
+    if (h->comm && h->comm_overlap && h->comm_stream && h->comm_seq > 0) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->comm_done[(h->comm_seq - 1) & 1], 0));
     HIP_TRY(h, hipMemcpyAsync(du0, h->d_du0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(dp, h->d_dp, pb, hipMemcpyDeviceToHost, h->stream));
     return hipadj_synchronize(h);

@@ -44,7 +44,8 @@ struct FieldGeom {
     long N;
     int S, M;
     double t0, dt, loss_shift;
-    int loss_kind, no_start, p_shared;
+    int loss_kind, no_start, p_shared;   // loss_kind: hipadj_loss 0 cotangent, 1 lsq_shift, 2 lsq_data (dgdu = lsq_w (u - data), the block in the cotangents' place)
+    double lsq_w;
 };
 
 template <int G> struct Bruss {
@@ -229,6 +230,10 @@ __device__ __forceinline__ void field_jump(const FieldGeom& g, long traj, int s,
         const double* c = cot + (traj * g.M + s) * NS;
 #pragma unroll
         for (int q = 0; q < Q; ++q) { lU[q] += c[nb.c[q]]; lV[q] += c[CELLS + nb.c[q]]; }
+    } else if (g.loss_kind == 2) {
+        const double* c = cot + (traj * g.M + s) * NS;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { lU[q] += g.lsq_w * (U[q] - c[nb.c[q]]); lV[q] += g.lsq_w * (V[q] - c[CELLS + nb.c[q]]); }
     } else {
 #pragma unroll
         for (int q = 0; q < Q; ++q) { lU[q] += U[q] - g.loss_shift; lV[q] += V[q] - g.loss_shift; }

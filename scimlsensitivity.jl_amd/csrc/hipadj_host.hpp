@@ -104,10 +104,16 @@ struct hipadj_handle {
     double* d_gtile = nullptr; long gtile_stride = 0; bool ck_long = false;   // checkpoint intervals longer than HIPADJ_CKPT_KMAX: re-solve tiles in HBM
     bool offgrid = false;                 // fixed-step RK4 with loss times off the step grid: reverse step list on the device
     double *d_rs_t = nullptr, *d_rs_h = nullptr, *d_rs_te = nullptr; int *d_rs_save = nullptr, *d_rs_ck = nullptr; int nrs = 0, rs_save_at_start = -1;
+    // device-resident discrete losses (HIPADJ_LOSS_LSQ_DATA / HIPADJ_LOSS_MODEL): the data block of hipadj_set_loss_data.  Lane family: transposed into d_cotT (the reverse
+    // kernels stream it like a cotangent block); workgroup families: d_ldata [N][M][n] in the caller's layout, handed to the kernels in the cotangents' place
+    double* d_ldata = nullptr; bool have_ldata = false;
+    const double* cot_soa = nullptr;      // set for the duration of a hipadj_adjoint_dev_soa call
+    hipModule_t lmod = nullptr; hipFunction_t lf_value = nullptr;   // runtime model with a discrete-loss FUNCTION: its loss-value kernel (hipadj_loss_value)
+    double* d_lpart = nullptr;            // per-workgroup partials of hipadj_loss_value
     void* comm = nullptr;                 // ncclComm_t of the ensemble shards (hipadj_comm.hpp); dp is all-reduced over it
     bool comm_owned = false;
     // hipadj_comm_overlap: the all-reduce of dp on its own stream, off the critical path of the next reverse pass
-    int comm_overlap = 0; hipStream_t comm_stream = nullptr; hipEvent_t comm_ready = nullptr, comm_done[2] = {nullptr, nullptr}; unsigned comm_seq = 0;
+    int comm_overlap = 0; hipStream_t comm_stream = nullptr; hipEvent_t comm_ready = nullptr, comm_done[2] = {nullptr, nullptr}; unsigned comm_seq = 0; long comm_test_delay = 0;
     hipadj_stats st{};
     std::string err;
 };
@@ -123,6 +129,9 @@ template <class T> static int dev_alloc(hipadj_handle* h, T** p, size_t count) {
     return HIPADJ_OK;
 }
 #define TRY(expr) do { int _rc = (expr); if (_rc != HIPADJ_OK) return _rc; } while (0)
+
+// does the reverse pass stream a column next to the state at the loss times — cotangents, or the data block of a device-resident loss?  (template bit 0 of the lane kernels' MODE)
+static inline bool loss_streams(const hipadj_handle* h) { return h->M > 0 && h->cfg.loss_kind != HIPADJ_LOSS_LSQ_SHIFT; }
 
 static inline void harvest_set(hipadj_handle* h, hipadj_handle::EvSet& q, bool block) {
     if (!q.pending) return;

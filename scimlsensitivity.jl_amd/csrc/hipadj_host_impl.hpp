@@ -74,7 +74,10 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             hipLaunchKernelGGL((k_compose_finish<Mo>), dim3(compose_blocks), dim3(FIN), 0, h->stream, h->g, h->nseg, (const double*)h->d_segbuf,
                                d_du0, dp_rows, h->d_partial, h->d_flag, h->d_ticket, dp_sum);
     };
-    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    // the column the sweep streams at the loss times: the caller's block already in the streaming layout (hipadj_adjoint_dev_soa), or the handle's own buffer — cotangents
+    // transposed here per pass, or the data block of a device-resident loss transposed ONCE by hipadj_set_loss_data
+    const double* cotT = h->cot_soa ? h->cot_soa : h->d_cotT;
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
     harvest_set(h, es, true);                   // ring full: only now wait for the oldest call
@@ -87,9 +90,9 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
         SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->cfg.alg == HIPADJ_ALG_GAUSS)
-            hipLaunchKernelGGL((k_offgrid_seg<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, R, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, h->d_segbuf);
+            hipLaunchKernelGGL((k_offgrid_seg<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, R, sp, p, (const dbl2*)h->d_knots, cotT, h->d_segbuf);
         else
-            hipLaunchKernelGGL((k_offgrid_seg<Mo, LOSS, false>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, R, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, h->d_segbuf);
+            hipLaunchKernelGGL((k_offgrid_seg<Mo, LOSS, false>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, R, sp, p, (const dbl2*)h->d_knots, cotT, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         launch_compose();
@@ -104,7 +107,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     }
     if (h->offgrid && h->cfg.alg == HIPADJ_ALG_QUADRATURE) {   // dense lambda over the reverse step list, then adaptive GK15 per (trajectory, loss interval)
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
-        hipLaunchKernelGGL((k_quad_adj_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, h->d_adj, d_du0);
+        hipLaunchKernelGGL((k_quad_adj_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, cotT, h->d_adj, d_du0, (double*)nullptr);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
@@ -127,11 +130,11 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     if (h->offgrid) {   // loss times off the step grid, one column, sequential in time (Backsolve; runtime models; forced time_segments = 1)
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
-            hipLaunchKernelGGL((k_backsolve_offgrid<Mo, (LOSS >> 1)>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
+            hipLaunchKernelGGL((k_backsolve_offgrid<Mo, (LOSS >> 1)>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, cotT, d_du0, h->d_dp_traj);
         else if (h->cfg.alg == HIPADJ_ALG_GAUSS) {
-            hipLaunchKernelGGL((k_gauss_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
+            hipLaunchKernelGGL((k_gauss_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, cotT, d_du0, h->d_dp_traj);
         } else
-        hipLaunchKernelGGL((k_interp_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, d_du0, h->d_dp_traj);
+        hipLaunchKernelGGL((k_interp_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, cotT, d_du0, h->d_dp_traj);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         hipLaunchKernelGGL((k_finish<Mo::N, Mo::NP>), dim3(fblocks), dim3(FIN), 0, h->stream, h->N, h->Npad, (const double*)d_du0,
@@ -150,10 +153,10 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt && h->ck_long)
             hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else if (h->ip_ckpt)
             hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else if (h->fused && h->d_tbuf && !h->wpb4) {
             // ONE launch per reverse pass (hipadj_fused.hpp): the sweep's waves compose their segment maps as a tree through HBM, the root wave of
             // each block writes du0 and its partial of dp, the last block sums the partials.  No k_compose_finish*, no k_reduce_final.
@@ -164,13 +167,13 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             if constexpr (model_has_ops<Mo>::value && (LOSS >> 1) == 0) {
                 if (h->cfg.p_shared && h->nseg > 1 && !h->no_ops) {
                     hipExtLaunchKernelGGL((k_interp_fused<Mo, 4, LOSS, true, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
-                                          (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                                          (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
                     launched = true;
                 }
             }
             if (!launched)
                 hipExtLaunchKernelGGL((k_interp_fused<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
-                                      (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                                      (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
             HIP_TRY(h, hipGetLastError());
             if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
             es.pending = h->timing >= 1; es.full = h->timing >= 2;
@@ -180,7 +183,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             // 256-thread workgroups, four (wave block, segment) items each: one wave per SIMD by construction (hipadj_kernels.hpp)
             const unsigned items = waves * (unsigned)h->nseg;
             hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS, true, 4>), dim3((items + 3) / 4), dim3(4 * WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
-                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, h->d_segbuf);
             dispatch_events = true;
         } else {
             // the dominant kernel's own begin/end timestamps (events attached to the dispatch packet): what rocprofv3 reports
@@ -194,13 +197,13 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
                     // prefetch depth 4: the multi-segment launch is bound by FP64 issue, not by HBM latency (PF 8 / 6 / 4 / 3 measure within 2 % of
                     // each other, 4 marginally best and half the code of 8: profiles/r2_kbench_visit9_prefetch_depth.log)
                     hipExtLaunchKernelGGL((k_interp<Mo, 4, LOSS, true, 1, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, p,
-                                          (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
+                                          (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, h->d_segbuf);
                     launched = true;
                 }
             }
             if (!launched)
                 hipExtLaunchKernelGGL((k_interp<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, p,
-                                      (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
+                                      (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, h->d_segbuf);
             dispatch_events = h->timing >= 1;
         }
         HIP_TRY(h, hipGetLastError());
@@ -214,14 +217,14 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
             hipExtLaunchKernelGGL((k_backsolve_fused<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
                                   h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
-                                  (const double*)h->d_cotT, (const int*)h->d_save_rev, d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
+                                  cotT, (const int*)h->d_save_rev, d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
             HIP_TRY(h, hipGetLastError());
             if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
             es.pending = h->timing >= 1; es.full = h->timing >= 2;
             return HIPADJ_OK;
         }
         hipLaunchKernelGGL((k_backsolve<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_yT,
-                           (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, (const double*)h->d_cotT,
+                           (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot, cotT,
                            (const int*)h->d_save_rev, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
@@ -232,14 +235,14 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         SegPlan sp{h->nseg, h->d_seg_bounds};
         if (h->ip_ckpt && h->ck_long)
             hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else if (h->ip_ckpt)
             hipLaunchKernelGGL((k_gauss_ckpt<Mo, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
-                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
+                               (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
         else if (h->fused && h->d_tbuf) {   // one launch per reverse pass (hipadj_fused.hpp)
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
             hipExtLaunchKernelGGL((k_gauss_fused<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
-                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
                                   d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
             HIP_TRY(h, hipGetLastError());
             if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
@@ -248,7 +251,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         }
         else
             hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
-                               (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
+                               cotT, (const int*)h->d_save_rev, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         launch_compose();
@@ -259,7 +262,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         if (h->fused && h->d_tbuf) {   // one launch per reverse pass (hipadj_fused.hpp)
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
             hipExtLaunchKernelGGL((k_gauss_fused<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
-                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const dbl2*)h->d_knots, (const double*)h->d_cotT, (const int*)h->d_save_rev,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
                                   d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
             HIP_TRY(h, hipGetLastError());
             if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
@@ -267,7 +270,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             return HIPADJ_OK;
         }
         hipLaunchKernelGGL((k_gauss<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const dbl2*)h->d_knots,
-                           (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_segbuf);
+                           cotT, (const int*)h->d_save_rev, h->d_segbuf);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         launch_compose();
@@ -275,7 +278,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         break; }
     case HIPADJ_ALG_QUADRATURE: {
         hipLaunchKernelGGL((k_quad_adj<Mo, PF, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, p, (const dbl2*)h->d_knots,
-                           (const double*)h->d_cotT, (const int*)h->d_save_rev, h->d_adj, d_du0);
+                           cotT, (const int*)h->d_save_rev, h->d_adj, d_du0, (double*)nullptr);
         HIP_TRY(h, hipGetLastError());
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
@@ -304,7 +307,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
 
 template <class Mo> int adjoint_impl(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     // no loss times => no cotangent buffer exists: run the LSQ specialisation (its jump select is never taken)
-    const int mode = ((h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) ? 0 : 1) | (h->cfg.cont_cost << 1);   // MODE = loss | cost << 1
+    const int mode = (loss_streams(h) ? 0 : 1) | (h->cfg.cont_cost << 1);   // MODE = loss | cost << 1; loss bit 0: a column is streamed (cotangents, or the data of HIPADJ_LOSS_LSQ_DATA)
     switch (mode) {
     case 0: return adjoint_impl_l<Mo, 0>(h, d_cot, d_du0, d_dp);
     case 1: return adjoint_impl_l<Mo, 1>(h, d_cot, d_du0, d_dp);
@@ -569,7 +572,10 @@ template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hip
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
-    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    // the column the sweep streams at the loss times: the caller's block already in the streaming layout (hipadj_adjoint_dev_soa), or the handle's own buffer — cotangents
+    // transposed here per pass, or the data block of a device-resident loss transposed ONCE by hipadj_set_loss_data
+    const double* cotT = h->cot_soa ? h->cot_soa : h->d_cotT;
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
     harvest_set(h, es, true);
@@ -581,11 +587,11 @@ template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hip
             if constexpr (QUAD_OK)
                 hipLaunchKernelGGL((k_adjoint_tsit5_quad<Mo, ALG>), dim3((unsigned)((h->N + 15) / 16)), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
                                    (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
-                                   (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag);
+                                   (const double*)h->d_tstops, h->ntstops, cotT, d_du0, h->d_dp_traj, h->d_flag);
         } else
         hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
                            (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
-                           (const double*)h->d_tstops, h->ntstops, (const double*)h->d_cotT, d_du0, h->d_dp_traj, h->d_flag,
+                           (const double*)h->d_tstops, h->ntstops, cotT, d_du0, h->d_dp_traj, h->d_flag,
                            h->d_arec, h->d_nsteps_adj, h->SmaxA);
         HIP_TRY(h, hipGetLastError());
         if (!(ALG == 3 && h->auto_steps)) break;

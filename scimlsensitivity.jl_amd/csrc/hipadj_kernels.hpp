@@ -941,14 +941,18 @@ __global__ void __launch_bounds__(WAVE) k_out_offgrid(Geom g, const dbl2* __rest
 template <class Mo, int PF, int LOSS>
 __global__ void __launch_bounds__(WAVE) k_quad_adj(Geom g, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                                    const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                                                   dbl2* __restrict__ adj, double* __restrict__ du0) {
-    constexpr int N = Mo::N;
+                                                   dbl2* __restrict__ adj, double* __restrict__ du0, double* __restrict__ gpd_out) {
+    constexpr int N = Mo::N, NP = Mo::NP;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= g.N) return;
-    double lam[N];
-    quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots, cotT, save_of_knot, adj, lam);
+    double lam[N], gpo[NP];
+    quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots, cotT, save_of_knot, adj, lam, gpo);
 #pragma unroll
     for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+    if (gpd_out) {   // [NP][Npad]: sum of dgdp_discrete over the loss times, one more term of k_quad_sum (models with discrete-loss bodies)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) gpd_out[(long)j * g.Npad + i] = gpo[j];
+    }
 }
 
 // one lane per (trajectory, quadrature interval); qres [interval][NP][Npad]
@@ -970,14 +974,18 @@ __global__ void __launch_bounds__(WAVE) k_quad_gk(Geom g, const double* __restri
 // (trajectory, loss interval)
 template <class Mo, int MODE>
 __global__ void __launch_bounds__(WAVE) k_quad_adj_offgrid(Geom g, RevSteps R, const double* __restrict__ p, const dbl2* __restrict__ knots,
-                                                           const double* __restrict__ cotT, dbl2* __restrict__ adj, double* __restrict__ du0) {
-    constexpr int N = Mo::N;
+                                                           const double* __restrict__ cotT, dbl2* __restrict__ adj, double* __restrict__ du0, double* __restrict__ gpd_out) {
+    constexpr int N = Mo::N, NP = Mo::NP;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= g.N) return;
-    double lam[N];
-    quad_adj_offgrid_lane<Mo, MODE>(g, i, p, knots, cotT, R, adj, lam);
+    double lam[N], gpo[NP];
+    quad_adj_offgrid_lane<Mo, MODE>(g, i, p, knots, cotT, R, adj, lam, gpo);
 #pragma unroll
     for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
+    if (gpd_out) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) gpd_out[(long)j * g.Npad + i] = gpo[j];
+    }
 }
 template <class Mo, int CC = 0>
 __global__ void __launch_bounds__(WAVE) k_quad_gk_offgrid(Geom g, RevSteps R, const double* __restrict__ p, const dbl2* __restrict__ knots,
@@ -993,12 +1001,13 @@ __global__ void __launch_bounds__(WAVE) k_quad_gk_offgrid(Geom g, RevSteps R, co
     for (int j = 0; j < NP; ++j) qres[((long)q * NP + j) * g.Npad + i] = res[j];
 }
 // res .+= quadgk(...) in the reference's order (src/quadrature_adjoint.jl:563-616)
+// add = 1: dp_traj already holds the sum of dgdp_discrete over the loss times (src/quadrature_adjoint.jl:545-552, 601-605), left there by pass 1 for a model with discrete-loss bodies
 static __global__ void __launch_bounds__(WAVE) k_quad_sum(long N, long Npad, int np, int nq, const double* __restrict__ qres,
-                                                   double* __restrict__ dp_traj) {
+                                                   double* __restrict__ dp_traj, int add = 0) {
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= N) return;
     for (int j = 0; j < np; ++j) {
-        double s = 0.0;
+        double s = add ? dp_traj[(long)j * Npad + i] : 0.0;
         for (int q = 0; q < nq; ++q) s += qres[((long)q * np + j) * Npad + i];
         dp_traj[(long)j * Npad + i] = s;
     }
@@ -1031,6 +1040,57 @@ static __global__ void k_soa_to_aos(const double* __restrict__ src, double* __re
         const long i = i0 + r; const int c = c0 + threadIdx.x;
         if (i < N && c < C) dst[i * C + c] = tile[threadIdx.x][r];
     }
+}
+
+// ---- the loss itself (hipadj_loss_value): built-in kinds from the primal output out [N][M][n] (caller layout) and the data block [N][M][n] --------------------------
+//   kind 1: sum |u - shift|^2 / 2;  kind 2: scale / 2 * sum |u - data|^2.  m0 = 1 leaves the loss time at t0 out (no_start).
+// Two levels in a fixed order: block b sums elements [b * LV_CHUNK, (b + 1) * LV_CHUNK) (thread-strided partials, then a fixed tree), k_sum_fixed adds the block partials.
+constexpr int LV_CHUNK = 16384;
+static __global__ void __launch_bounds__(256) k_loss_value(long total, int M, int n, int m0, int kind, double shift, double scale, const double* __restrict__ out,
+                                                           const double* __restrict__ data, double* __restrict__ part) {
+    __shared__ double sh[256];
+    const long b0 = (long)blockIdx.x * LV_CHUNK, b1 = b0 + LV_CHUNK < total ? b0 + LV_CHUNK : total;
+    double s = 0.0;
+    for (long e = b0 + threadIdx.x; e < b1; e += 256) {
+        const int m = (int)((e / n) % M);
+        if (m < m0) continue;
+        const double r = out[e] - (kind == 2 ? data[e] : shift);
+        s += r * r;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = 0.5 * (kind == 2 ? scale : 1.0) * sh[0];
+}
+static __global__ void __launch_bounds__(256) k_sum_fixed(long count, const double* __restrict__ part, double* __restrict__ res) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (long e = threadIdx.x; e < count; e += 256) s += part[e];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) res[0] = sh[0];
+}
+// ... of a runtime model registered with hipadj_model_set_discrete_loss_function: part[i] = sum over the loss times of l_i(u(t_i), p, t_i, i, d_i) for trajectory i
+template <class Mo, class = void> struct model_has_lvalue { static constexpr bool value = false; };
+template <class Mo> struct model_has_lvalue<Mo, decltype((void)Mo::HAS_LVALUE)> { static constexpr bool value = Mo::HAS_LVALUE; };
+template <class Mo>
+__global__ void __launch_bounds__(256) k_user_loss_value(long N, int M, int m0, long ldp, const double* __restrict__ out, const double* __restrict__ data, const double* __restrict__ p,
+                                                         const double* __restrict__ save_t, double* __restrict__ part) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double s = 0.0;
+    if constexpr (model_has_lvalue<Mo>::value) {
+        double pv[Mo::NP], u[Mo::N], d[Mo::N];
+#pragma unroll
+        for (int j = 0; j < Mo::NP; ++j) pv[j] = p[i * ldp + j];
+        for (int m = m0; m < M; ++m) {
+#pragma unroll
+            for (int j = 0; j < Mo::N; ++j) { u[j] = out[(i * M + m) * Mo::N + j]; d[j] = data ? data[(i * M + m) * Mo::N + j] : 0.0; }
+            s += Mo::l_disc(u, pv, save_t[m], m, d);
+        }
+    }
+    part[i] = s;
 }
 
 // ---- DiscreteCallback affects of runtime models (hipadj_model_set_affect; src/callback_tracking.jl:232-470) --------------------------------

@@ -44,10 +44,13 @@ struct Geom {
     int M;         // loss times
     double t0, dt;
     double loss_shift;
-    int loss_kind;     // 0 cotangent, 1 lsq_shift
+    int loss_kind;     // hipadj_loss: 0 cotangent, 1 lsq_shift, 2 lsq_data, 3 the model's dgdu_discrete / dgdp_discrete bodies
     int no_start;
     int p_shared;
     int kmask;         // always -1 in the library (knot index & kmask is what gets loaded: a masked index served a one-off study that separated HBM from issue limits)
+    double la, lb;     // the loss gradient of the kinds that stream a column c (cotangent or data) next to the state u:  dgdu = la u + lb c  — (0, 1) cotangent and model bodies
+                       // (which get the raw data column), (w, -w) HIPADJ_LOSS_LSQ_DATA with scale w.  la = 0, lb = 1 returns c bit for bit (0 u + 1 c, u finite)
+    int lflags;        // bit 0: drop dgdp_discrete (hipadj_config.reference_literal on GaussAdjoint)
     double h_last;     // length of the LAST forward step [t_{S-1}, T]: = dt, or the remainder when the span is not a multiple of dt (the reference's
                        // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
 };
@@ -186,12 +189,43 @@ HIPADJ_HD void forward_lane_ev(const Geom& g, long i, const double* __restrict__
         for (int j = 0; j < N; ++j) yT[(long)j * g.Npad + i] = u[j]; }
 }
 
-// loss gradient dgdu_discrete(out, u, p, t_i, i): cotangent column or u - shift
+// loss gradient dgdu_discrete(out, u, p, t_i, i): u - shift, or la u + lb c with the streamed column c (cotangent column; data column of a device-resident loss)
+HIPADJ_HD double loss_affine(const Geom& g, double u, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(g.la, u, g.lb * c);
+#else
+    return g.la * u + g.lb * c;
+#endif
+}
 template <class Mo>
 HIPADJ_HD void loss_grad(const Geom& g, long i, int s, const double* __restrict__ cotT, const double (&y)[Mo::N], double (&gl)[Mo::N]) {
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j)
-        gl[j] = (g.loss_kind == 0) ? cotT[((long)s * Mo::N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+        gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift) : loss_affine(g, y[j], cotT[((long)s * Mo::N + j) * g.Npad + i]);
+}
+
+// Discrete loss bodies attached to a runtime-registered model (hipadj_model_set_discrete_loss; HIPADJ_LOSS_MODEL): dgdu_discrete(out, u, p, t_i, i) and
+// dgdp_discrete(out, u, p, t_i, i) of ReverseLossCallback (src/adjoint_common.jl:771-779).  On entry gl holds the data column of this (trajectory, loss time) — what the
+// bodies see as `d`; on exit dl_i/du; gpd = dl_i/dp (zero for every other loss kind and for models without bodies).  Evaluated at EVERY step of the straight-line sweeps
+// and selected by the loss flag like the built-in kinds (a branch per step costs the counted waits of the software prefetch, reverse_sweep below).
+template <class Mo, class = void> struct model_has_dloss { static constexpr bool value = false; };
+template <class Mo> struct model_has_dloss<Mo, decltype((void)Mo::HAS_DLOSS)> { static constexpr bool value = Mo::HAS_DLOSS; };
+template <class Mo>
+HIPADJ_HD void loss_model(const Geom& g, const double (&y)[Mo::N], const double (&pv)[Mo::NP], double t, int s, double (&gl)[Mo::N], double (&gpd)[Mo::NP]) {
+#pragma unroll
+    for (int j = 0; j < Mo::NP; ++j) gpd[j] = 0.0;
+    if constexpr (model_has_dloss<Mo>::value) {
+        if (g.loss_kind == 3) {
+            double d[Mo::N], o[Mo::N];
+#pragma unroll
+            for (int j = 0; j < Mo::N; ++j) d[j] = gl[j];
+            const int si = s > 0 ? s : 0;
+            Mo::dgdu_disc(o, y, pv, t, si, d);
+#pragma unroll
+            for (int j = 0; j < Mo::N; ++j) gl[j] = o[j];
+            if (!(g.lflags & 1)) Mo::dgdp_disc(gpd, y, pv, t, si, d);
+        }
+    } else { (void)g; (void)y; (void)pv; (void)t; (void)s; (void)gl; }
 }
 
 // continuous cost g(u,p,t) (accumulate_cost!, src/derivative_wrappers.jl:1411-1442: dlam -= g_u, dgrad -= g_p):
@@ -475,7 +509,9 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
         const int s = save_of_knot[k_hi];
         double gl[N];
         if (LOSS == 0) {
-            if (s >= 0) load_cot<Mo, LOSS>(g, i, s, cotT, gl);
+            if (s >= 0) { load_cot<Mo, LOSS>(g, i, s, cotT, gl);
+#pragma unroll
+                for (int j = 0; j < N; ++j) gl[j] = loss_affine(g, carry.u[j], gl[j]); }
             else {
 #pragma unroll
                 for (int j = 0; j < N; ++j) gl[j] = 0.0;
@@ -484,7 +520,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
 #pragma unroll
             for (int j = 0; j < N; ++j) gl[j] = carry.u[j] - g.loss_shift;
         }
-        init(s >= 0, gl);
+        init(s >= 0, gl, carry.u, s);
     }
     if constexpr (PF == 1) {
         // PF = 1: plain rolled loop, one knot in flight.  Used for runtime-compiled models with more than three states: there
@@ -497,7 +533,9 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
             const int s = save_of_knot[k];
             const bool jump = s >= 0 && !(g.no_start && s == 0);
             double gl[N];
-            if (LOSS == 0) load_cot<Mo, LOSS>(g, i, s, cotT, gl);
+            if (LOSS == 0) { load_cot<Mo, LOSS>(g, i, s, cotT, gl);
+#pragma unroll
+                for (int j = 0; j < N; ++j) gl[j] = loss_affine(g, lo.u[j], gl[j]); }
             else {
 #pragma unroll
                 for (int j = 0; j < N; ++j) gl[j] = lo.u[j] - g.loss_shift;
@@ -531,7 +569,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
             const bool jump = s >= 0 && !(g.no_start && s == 0);
             double gl[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) gl[j] = LOSS == 0 ? cot[r][j] : (ring[r].u[j] - g.loss_shift);
+            for (int j = 0; j < N; ++j) gl[j] = LOSS == 0 ? loss_affine(g, ring[r].u[j], cot[r][j]) : (ring[r].u[j] - g.loss_shift);
             HIPADJ_STEP_FENCE();
             step(r == 0 ? carry : ring[r > 0 ? r - 1 : 0], ring[r], k, jump, gl);
             HIPADJ_STEP_FENCE();
@@ -555,7 +593,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
             const bool jump = s >= 0 && !(g.no_start && s == 0);
             double gl[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) gl[j] = LOSS == 0 ? cot[r][j] : (ring[r].u[j] - g.loss_shift);
+            for (int j = 0; j < N; ++j) gl[j] = LOSS == 0 ? loss_affine(g, ring[r].u[j], cot[r][j]) : (ring[r].u[j] - g.loss_shift);
             step(r == 0 ? carry : ring[r > 0 ? r - 1 : 0], ring[r], k, jump, gl);
         }
     }
@@ -621,8 +659,8 @@ HIPADJ_HD void reverse_sweep_ckpt(const Geom& g, long i, int k_lo, int k_hi, con
                 const int s = save_of_knot[k_hi];
                 double gl[N];
 #pragma unroll
-                for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? ((s >= 0) ? cotT[((long)s * N + j) * g.Npad + i] : 0.0) : (hi.u[j] - g.loss_shift);
-                init(s >= 0, gl);
+                for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? ((s >= 0) ? loss_affine(g, hi.u[j], cotT[((long)s * N + j) * g.Npad + i]) : 0.0) : (hi.u[j] - g.loss_shift);
+                init(s >= 0, gl, hi.u, s);
             }
         }
         // ---- walk the interval backward
@@ -635,7 +673,7 @@ HIPADJ_HD void reverse_sweep_ckpt(const Geom& g, long i, int k_lo, int k_hi, con
             const bool jump = s >= 0 && !(g.no_start && s == 0);
             double gl[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? (jump ? cotT[((long)s * N + j) * g.Npad + i] : 0.0) : (lo.u[j] - g.loss_shift);
+            for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? (jump ? loss_affine(g, lo.u[j], cotT[((long)s * N + j) * g.Npad + i]) : 0.0) : (lo.u[j] - g.loss_shift);
             step(hi, lo, k, jump, gl);
             hi = lo;
         }
@@ -672,15 +710,30 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
 #pragma unroll
         for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
     }
-    auto init = [&](bool jump, const double (&gl)[N]) {
+    // the loss jump of the affine column: lam += dgdu_discrete and, for a model with discrete-loss bodies, mu += dgdp_discrete (src/adjoint_common.jl:771-779)
+    auto jump_add = [&](bool jump, const double (&gl_in)[N], const double (&y)[N], double t, int s) {
+        if constexpr (model_has_dloss<Mo>::value) {
+            double gl[N], gpd[NP];
 #pragma unroll
-        for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+            for (int j = 0; j < N; ++j) gl[j] = gl_in[j];
+            loss_model<Mo>(g, y, pv, t, s, gl, gpd);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[0][j] += jump ? gpd[j] : 0.0;
+        } else {
+            (void)y; (void)t; (void)s;
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl_in[j] : 0.0;
+        }
     };
+    auto init = [&](bool jump, const double (&gl)[N], const double (&y)[N], int s) { jump_add(jump, gl, y, g.t0 + g.S * g.dt, s); };
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
         if constexpr (OPS) adj_rk4_step_ops<Mo, NC, true>(hi, lo, oc, g.t0 + k * g.dt, g.dt, lam, mu);
         else adj_rk4_step<Mo, NC, true, CC>(hi, lo, pv, g.t0 + k * g.dt, g.dt, lam, mu);
-#pragma unroll
-        for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        int s = 0;
+        if constexpr (model_has_dloss<Mo>::value) s = save_of_knot[k];
+        jump_add(jump, gl, lo.u, g.t0 + k * g.dt, s);
     };
     if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, LOSS>(g, i, k_lo, k_hi, pv, *ck, cotT, save_of_knot, init, step);
     else reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot, init, step);
@@ -772,11 +825,19 @@ HIPADJ_HD void interp_offgrid_lane(const Geom& g, long i, const double* __restri
     if (q_lo == 0) cursor_init<Mo>(g, i, knots, c); else cursor_init_at<Mo>(g, i, knots, c, t_first);
     double y_hi[N], y_mid[N], y_lo[N];
     cursor_eval<Mo>(g, i, knots, c, t_first, y_hi);
-    auto jump = [&](int s, const double (&y)[N]) {   // lam += dgdu_discrete(y, p, t_s, s): cotangent column or u - shift (affine column)
+    auto jump = [&](int s, const double (&y)[N], double ts) {   // lam += dgdu_discrete(y, p, t_s, s): cotangent / data column or u - shift (affine column); mu += dgdp_discrete
+        double gl[N], gpd[NP];
 #pragma unroll
-        for (int j = 0; j < N; ++j) lam[0][j] += (LOSS == 0) ? cotT[((long)s * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+        for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? loss_affine(g, y[j], cotT[((long)s * N + j) * g.Npad + i]) : (y[j] - g.loss_shift);
+        loss_model<Mo>(g, y, pv, ts, s, gl, gpd);
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+        if constexpr (model_has_dloss<Mo>::value) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[0][j] += gpd[j];
+        }
     };
-    if (q_lo == 0 && R.save_at_start >= 0) jump(R.save_at_start, y_hi);   // PresetTimeCallback fires at initialisation when T is a loss time
+    if (q_lo == 0 && R.save_at_start >= 0) jump(R.save_at_start, y_hi, R.t_start);   // PresetTimeCallback fires at initialisation when T is a loss time
 #pragma unroll 1
     for (int q = q_lo; q < q_hi; ++q) {
         const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
@@ -784,7 +845,7 @@ HIPADJ_HD void interp_offgrid_lane(const Geom& g, long i, const double* __restri
         cursor_eval<Mo>(g, i, knots, c, te, y_lo);
         adj_rk4_stages<Mo, NC, true, CC>(y_hi, y_mid, y_lo, pv, t, tm, te, hs, lam, mu);
         const int s = R.save[q];
-        if (s >= 0) jump(s, y_lo);
+        if (s >= 0) jump(s, y_lo, te);
 #pragma unroll
         for (int j = 0; j < N; ++j) y_hi[j] = y_lo[j];
     }
@@ -806,9 +867,18 @@ HIPADJ_HD void backsolve_offgrid_lane(const Geom& g, long i, const double* __res
     for (int j = 0; j < N; ++j) { lam[0][j] = 0.0; y[j] = yT[(long)j * g.Npad + i]; }
 #pragma unroll
     for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
-    if (R.save_at_start >= 0) { double gl[N]; loss_grad<Mo>(g, i, R.save_at_start, cotT, y, gl);
+    auto jump = [&](int s, double ts) {   // lam += dgdu_discrete at the backsolved y (src/adjoint_common.jl:765-767); mu += dgdp_discrete
+        double gl[N], gpd[NP];
+        loss_grad<Mo>(g, i, s, cotT, y, gl);
+        loss_model<Mo>(g, y, pv, ts, s, gl, gpd);
 #pragma unroll
-        for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; }
+        for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+        if constexpr (model_has_dloss<Mo>::value) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[0][j] += gpd[j];
+        }
+    };
+    if (R.save_at_start >= 0) jump(R.save_at_start, R.t_start);
 #pragma unroll 1
     for (int q = 0; q < R.n; ++q) {
         const double t_hi = R.t[q], dt = R.h[q], t_lo = R.te[q], t_mid = t_hi - 0.5 * dt;
@@ -875,9 +945,7 @@ HIPADJ_HD void backsolve_offgrid_lane(const Geom& g, long i, const double* __res
 #pragma unroll
             for (int j = 0; j < N; ++j) y[j] = ckpt[((long)c * N + j) * g.Npad + i]; }
         const int sv = R.save[q];
-        if (sv >= 0) { double gl[N]; loss_grad<Mo>(g, i, sv, cotT, y, gl);
-#pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; }
+        if (sv >= 0) jump(sv, t_lo);
     }
 }
 
@@ -976,9 +1044,14 @@ HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const d
 #pragma unroll
         for (int j = 0; j < N; ++j) y[j] = yT[(long)j * g.Npad + i];
         const int s = save_of_knot[g.S];
-        if (s >= 0) { double gl[N]; loss_grad<Mo>(g, i, s, cotT, y, gl);
+        if (s >= 0) { double gl[N], gpd[NP]; loss_grad<Mo>(g, i, s, cotT, y, gl);
+            loss_model<Mo>(g, y, pv, g.t0 + g.S * g.dt, s, gl, gpd);
 #pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += gl[j]; }
+            for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+            if constexpr (model_has_dloss<Mo>::value) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) mu[0][j] += gpd[j];
+            } }
     } else {
         const int c0 = ckpt_of_knot[k_hi];      // the planner only cuts segments at checkpoint knots
 #pragma unroll
@@ -1030,9 +1103,14 @@ HIPADJ_HD void backsolve_lane(const Geom& g, long i, int k_lo, int k_hi, const d
             for (int j = 0; j < N; ++j) y[j] = ckpt[((long)c * N + j) * g.Npad + i]; } }
         const int s = save_of_knot[k];
         if (s >= 0) {
-            double gl[N]; loss_grad<Mo>(g, i, s, cotT, y, gl);
+            double gl[N], gpd[NP]; loss_grad<Mo>(g, i, s, cotT, y, gl);
+            loss_model<Mo>(g, y, pv, t_lo, s, gl, gpd);
 #pragma unroll
             for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+            if constexpr (model_has_dloss<Mo>::value) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) mu[0][j] += gpd[j];
+            }
         }
     }
 }
@@ -1150,12 +1228,28 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
     }
     const double dt = g.dt;
     const double xg = 0.5773502691896257645;
-    auto init = [&](bool jump, const double (&gl)[N]) {
+    // the loss jump of the affine column (interp_lane): lam += dgdu_discrete; the parameter part of a model's discrete loss goes to the quadrature accumulator
+    auto jump_add = [&](bool jump, const double (&gl_in)[N], const double (&y)[N], double t, int s) {
+        if constexpr (model_has_dloss<Mo>::value) {
+            double gl[N], gpd[NP];
 #pragma unroll
-        for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+            for (int j = 0; j < N; ++j) gl[j] = gl_in[j];
+            loss_model<Mo>(g, y, pv, t, s, gl, gpd);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[0][j] += jump ? gpd[j] : 0.0;
+        } else {
+            (void)y; (void)t; (void)s;
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl_in[j] : 0.0;
+        }
     };
+    auto init = [&](bool jump, const double (&gl)[N], const double (&y)[N], int s) { jump_add(jump, gl, y, g.t0 + g.S * dt, s); };
     auto step = [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
         const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
+        int s_loss = 0;
+        if constexpr (model_has_dloss<Mo>::value) s_loss = save_of_knot[k];
         if constexpr (!GKR && NC > 1 && model_has_cols<Mo>::value && (cols_bundle<N, NC, HIPADJ_COLS_ELEMS_GAUSS>::NB == 1 || model_cols_multi<Mo>::value)) {   // column bundles (hipadj_models.hpp): the same step, G columns per pass through the model's VJPs
             double ymid[N], guh[N], gum[N], gul[N], yg[2][N];
 #pragma unroll
@@ -1165,8 +1259,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
 #pragma unroll
             for (int q = 0; q < 2; ++q) hermite<N>(1.0 - 0.5 * (1.0 + (q == 0 ? -xg : xg)), dt, lo.u, lo.f, hi.u, hi.f, yg[q]);
             gauss_bundles<Mo, NC, 0, cols_bundle<N, NC, HIPADJ_COLS_ELEMS_GAUSS>::G, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam, mu, guh, gum, gul);
-#pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+            jump_add(jump, gl, lo.u, t_lo, s_loss);
             return;
         }
         double lam_hi[NC][N], d_hi[NC][N], V[N], guh[N], gul[N];
@@ -1246,8 +1339,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+        jump_add(jump, gl, lo.u, t_lo, s_loss);
     };
     if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, LOSS>(g, i, k_lo, k_hi, pv, *ck, cotT, save_of_knot, init, step);
     else reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot, init, step);
@@ -1277,11 +1369,19 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
     if (q_lo == 0) cursor_init<Mo>(g, i, knots, cu); else cursor_init_at<Mo>(g, i, knots, cu, t_first);
     double y_hi[N], y_mid[N], y_lo[N], yg[2][N];
     cursor_eval<Mo>(g, i, knots, cu, t_first, y_hi);
-    auto jump = [&](int s, const double (&y)[N]) {
+    auto jump = [&](int s, const double (&y)[N], double ts) {
+        double gl[N], gpd[NP];
 #pragma unroll
-        for (int j = 0; j < N; ++j) lam[0][j] += (LOSS == 0) ? cotT[((long)s * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+        for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? loss_affine(g, y[j], cotT[((long)s * N + j) * g.Npad + i]) : (y[j] - g.loss_shift);
+        loss_model<Mo>(g, y, pv, ts, s, gl, gpd);
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+        if constexpr (model_has_dloss<Mo>::value) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mu[0][j] += gpd[j];
+        }
     };
-    if (q_lo == 0 && R.save_at_start >= 0) jump(R.save_at_start, y_hi);
+    if (q_lo == 0 && R.save_at_start >= 0) jump(R.save_at_start, y_hi, R.t_start);
 #pragma unroll 1
     for (int q = q_lo; q < q_hi; ++q) {
         const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
@@ -1321,7 +1421,7 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
             }
         }
         const int s = R.save[q];
-        if (s >= 0) jump(s, y_lo);
+        if (s >= 0) jump(s, y_lo, te);
 #pragma unroll
         for (int j = 0; j < N; ++j) y_hi[j] = y_lo[j];
     }
@@ -1335,20 +1435,34 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
 template <class Mo, int PF, int MODE>
 HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
                              const double* __restrict__ cotT, const int* __restrict__ save_of_knot,
-                             dbl2* __restrict__ adj, double (&lamo)[Mo::N]) {
+                             dbl2* __restrict__ adj, double (&lamo)[Mo::N], double (&gpo)[Mo::NP]) {
     constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
     double lam[1][N], mu[1][NP];
 #pragma unroll
     for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+    for (int j = 0; j < NP; ++j) { mu[0][j] = 0.0; gpo[j] = 0.0; }
     const double dt = g.dt;
-    reverse_sweep<Mo, PF, LOSS>(g, i, 0, g.S, knots, cotT, save_of_knot,
-        [&](bool jump, const double (&gl)[N]) {
+    // gpo: the sum of dgdp_discrete over the loss times — the reference adds it next to the quadrature (src/quadrature_adjoint.jl:545-552, 601-605)
+    auto jump_add = [&](bool jump, const double (&gl_in)[N], const double (&y)[N], double t, int s) {
+        if constexpr (model_has_dloss<Mo>::value) {
+            double gl[N], gpd[NP];
+#pragma unroll
+            for (int j = 0; j < N; ++j) gl[j] = gl_in[j];
+            loss_model<Mo>(g, y, pv, t, s, gl, gpd);
 #pragma unroll
             for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
-        },
+#pragma unroll
+            for (int j = 0; j < NP; ++j) gpo[j] += jump ? gpd[j] : 0.0;
+        } else {
+            (void)y; (void)t; (void)s;
+#pragma unroll
+            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl_in[j] : 0.0;
+        }
+    };
+    reverse_sweep<Mo, PF, LOSS>(g, i, 0, g.S, knots, cotT, save_of_knot,
+        [&](bool jump, const double (&gl)[N], const double (&y)[N], int s) { jump_add(jump, gl, y, g.t0 + g.S * dt, s); },
         [&](const Knot<Mo>& hi, const Knot<Mo>& lo, int k, bool jump, const double (&gl)[N]) {
             const double t_lo = g.t0 + k * dt, t_hi = t_lo + dt;
             double rec[4 * N], V[N], guh[N], gul[N];
@@ -1362,8 +1476,9 @@ HIPADJ_HD void quad_adj_lane(const Geom& g, long i, const double* __restrict__ p
             for (int j = 0; j < N; ++j) { rec[2 * N + j] = lam[0][j]; rec[3 * N + j] = -(V[j] + gul[j]); }
 #pragma unroll
             for (int j = 0; j < 2 * N; ++j) { dbl2 d; d.x = rec[2 * j]; d.y = rec[2 * j + 1]; adj[((long)k * 2 * N + j) * g.Npad + i] = d; }
-#pragma unroll
-            for (int j = 0; j < N; ++j) lam[0][j] += jump ? gl[j] : 0.0;
+            int s = 0;
+            if constexpr (model_has_dloss<Mo>::value) s = save_of_knot[k];
+            jump_add(jump, gl, lo.u, t_lo, s);
         });
 #pragma unroll
     for (int j = 0; j < N; ++j) lamo[j] = lam[0][j];
@@ -1475,22 +1590,30 @@ HIPADJ_HD void quad_gk_lane(const Geom& g, long i, const double* __restrict__ p,
 // ------------------------------------------------------------------------------------------------
 template <class Mo, int MODE>
 HIPADJ_HD void quad_adj_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
-                                     const double* __restrict__ cotT, const RevSteps& R, dbl2* __restrict__ adj, double (&lamo)[Mo::N]) {
+                                     const double* __restrict__ cotT, const RevSteps& R, dbl2* __restrict__ adj, double (&lamo)[Mo::N], double (&gpo)[Mo::NP]) {
     constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
     double lam[1][N], mu[1][NP];
 #pragma unroll
     for (int j = 0; j < N; ++j) lam[0][j] = 0.0;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) mu[0][j] = 0.0;
+    for (int j = 0; j < NP; ++j) { mu[0][j] = 0.0; gpo[j] = 0.0; }
     KnotCursor<Mo> c; cursor_init<Mo>(g, i, knots, c);
     double y_hi[N], y_mid[N], y_lo[N];
     cursor_eval<Mo>(g, i, knots, c, R.t_start, y_hi);
-    auto jump = [&](int s, const double (&y)[N]) {
+    auto jump = [&](int s, const double (&y)[N], double ts) {
+        double gl[N], gpd[NP];
 #pragma unroll
-        for (int j = 0; j < N; ++j) lam[0][j] += (LOSS == 0) ? cotT[((long)s * N + j) * g.Npad + i] : (y[j] - g.loss_shift);
+        for (int j = 0; j < N; ++j) gl[j] = (LOSS == 0) ? loss_affine(g, y[j], cotT[((long)s * N + j) * g.Npad + i]) : (y[j] - g.loss_shift);
+        loss_model<Mo>(g, y, pv, ts, s, gl, gpd);
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[0][j] += gl[j];
+        if constexpr (model_has_dloss<Mo>::value) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) gpo[j] += gpd[j];
+        }
     };
-    if (R.save_at_start >= 0) jump(R.save_at_start, y_hi);
+    if (R.save_at_start >= 0) jump(R.save_at_start, y_hi, R.t_start);
 #pragma unroll 1
     for (int q = 0; q < R.n; ++q) {
         const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
@@ -1508,7 +1631,7 @@ HIPADJ_HD void quad_adj_offgrid_lane(const Geom& g, long i, const double* __rest
 #pragma unroll
         for (int j = 0; j < 2 * N; ++j) { dbl2 d; d.x = rec[2 * j]; d.y = rec[2 * j + 1]; adj[((long)q * 2 * N + j) * g.Npad + i] = d; }
         const int s = R.save[q];
-        if (s >= 0) jump(s, y_lo);
+        if (s >= 0) jump(s, y_lo, te);
 #pragma unroll
         for (int j = 0; j < N; ++j) y_hi[j] = y_lo[j];
     }

@@ -31,7 +31,8 @@ struct MlpGeom {
     long N;            // trajectories (each with its own d x B state)
     int B, S, M;
     double t0, dt, loss_shift;
-    int loss_kind, no_start, p_shared;
+    int loss_kind, no_start, p_shared;   // loss_kind: hipadj_loss 0 cotangent, 1 lsq_shift, 2 lsq_data (dgdu = lsq_w (u - data), the block in the cotangents' place)
+    double lsq_w;
     int NQ;            // unused (round-1 record count), kept for the launch sites' aggregate initialisation
 };
 

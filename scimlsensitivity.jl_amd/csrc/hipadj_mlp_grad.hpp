@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(MlpG<H>::NT) k_mlp_adjoint_grad(MlpGeom g, con
     };
     auto jump = [&](int s, const double (&xx)[2], double (&lam)[2]) {
         if (g.loss_kind == 0) { const double* c = cot + (traj * g.M + s) * nB; lam[0] += c[(long)col * D]; lam[1] += c[(long)col * D + 1]; }
+        else if (g.loss_kind == 2) { const double* c = cot + (traj * g.M + s) * nB; lam[0] += g.lsq_w * (xx[0] - c[(long)col * D]); lam[1] += g.lsq_w * (xx[1] - c[(long)col * D + 1]); }
         else { lam[0] += xx[0] - g.loss_shift; lam[1] += xx[1] - g.loss_shift; }
     };
     double lam[D] = {0.0, 0.0}, xh[D], fh[D], xl[D], fl[D];

@@ -215,7 +215,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (!(cfg->t1 > cfg->t0)) { err = "need t1 > t0"; return HIPADJ_ERR_INVALID_ARG; }
         if (!(cfg->abstol > 0) || !(cfg->reltol > 0)) { err = "adaptive Tsit5 needs abstol > 0 and reltol > 0"; return HIPADJ_ERR_INVALID_ARG; }
         if (cfg->nsave < 0 || (cfg->nsave > 0 && !cfg->save_times)) { err = "save_times missing"; return HIPADJ_ERR_INVALID_ARG; }
-        if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
+        if (cfg->loss_kind < HIPADJ_LOSS_COTANGENT || cfg->loss_kind > HIPADJ_LOSS_MODEL) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
+        if (cfg->loss_kind == HIPADJ_LOSS_MODEL && cfg->model < HIPADJ_MODEL_USER_BASE) { err = "loss_kind = HIPADJ_LOSS_MODEL needs a runtime-registered model with discrete-loss bodies (hipadj_model_set_discrete_loss); compiled-in models take HIPADJ_LOSS_LSQ_DATA"; return HIPADJ_ERR_INVALID_ARG; }
         { const int crc = plan_check_cost(cfg, err); if (crc != HIPADJ_OK) return crc; }
         if (cfg->max_steps < 0) { err = "max_steps must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
         if (!P.wide) {   // the 8 x NZ stage rows of a wave live in LDS (hipadj_adaptive.hpp): 8 * NZ * 64 lanes * 8 B <= 160 KB
@@ -276,7 +277,8 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     P.h_last = ragged ? (cfg->t1 - cfg->t0) - (double)(S - 1) * cfg->dt : cfg->dt;
     if (ragged && (P.field || P.mlp || P.wide)) { err = "a span that is not a multiple of dt (shortened last step) is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->nsave < 0 || (cfg->nsave > 0 && !cfg->save_times)) { err = "save_times missing"; return HIPADJ_ERR_INVALID_ARG; }
-    if (cfg->loss_kind != HIPADJ_LOSS_COTANGENT && cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->loss_kind < HIPADJ_LOSS_COTANGENT || cfg->loss_kind > HIPADJ_LOSS_MODEL) { err = "unknown loss_kind"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->loss_kind == HIPADJ_LOSS_MODEL && cfg->model < HIPADJ_MODEL_USER_BASE) { err = "loss_kind = HIPADJ_LOSS_MODEL needs a runtime-registered model with discrete-loss bodies (hipadj_model_set_discrete_loss); compiled-in models take HIPADJ_LOSS_LSQ_DATA"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->time_segments < 0) { err = "time_segments must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->ckpt_stride < 0) { err = "ckpt_stride must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
     { const int crc = plan_check_checkpoint_list(cfg, err); if (crc != HIPADJ_OK) return crc; }

@@ -294,7 +294,7 @@ HIPADJ_HD void adjoint_tsit5_quad(const AdaptGeom& g, long i, int c, const doubl
             if (!(g.no_start && ALG != 1 && cur_time == 1)) {
                 double yc;
                 if (ALG == 1) yc = zz[NZ - 1]; else yc = cur.eval(t);
-                if (ownl) zz[0] += (g.loss_kind == 0) ? cotT[((long)(cur_time - 1) * N + c) * g.Npad + i] : (yc - g.loss_shift);
+                if (ownl) zz[0] += (g.loss_kind == 1) ? (yc - g.loss_shift) : __builtin_fma(g.la, yc, g.lb * cotT[((long)(cur_time - 1) * N + c) * g.Npad + i]);
                 mod = true;
             }
             --cur_time;

@@ -44,6 +44,9 @@ struct UserModelSrc {
     std::string dgdu, dgdp;   // optional continuous cost (hipadj_model_set_cost)
     std::string gfun;         // ... or the cost itself (hipadj_model_set_cost_function): gradients by dual numbers
     bool has_cost = false;
+    // optional discrete loss ON THE DEVICE (hipadj_model_set_discrete_loss[_function], hipadj_wmodel_set_discrete_loss): dgdu_discrete / dgdp_discrete of ReverseLossCallback
+    std::string dl_du, dl_dp, dl_fun, wdloss;
+    bool has_dloss = false;
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
     std::string affect;       // DiscreteCallback affect body (hipadj_model_set_affect): modifies un (pre-set to u) from u, p, t; empty = identity
     bool cols = true;         // the VJP bodies compile for Cols<G> (column bundles); cleared by user_compile when they do not
@@ -247,7 +250,13 @@ inline std::string user_wide_struct(const UserModelSrc& m) {
       << "        (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wvjp << "\n    }\n"
       << "    template <bool WP> static __device__ __forceinline__ void cost(double* __restrict__ dlam, double* __restrict__ gp, double (&acc)[" << na << "], double w,\n"
       << "            const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ ws, int tid) {\n"
-      << "        (void)dlam; (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wcost << "\n    }\n};\n#undef tanh\n}  // namespace hipadj\n";
+      << "        (void)dlam; (void)gp; (void)acc; (void)w; (void)u; (void)p; (void)t; (void)ws; (void)tid;\n" << m.wcost << "\n    }\n";
+    if (m.has_dloss)   // the model's discrete loss (hipadj_wmodel_set_discrete_loss; HIPADJ_LOSS_MODEL): ADDS dl_i/du into dlam and, WP, dl_i/dp into gp / acc (hipadj_wide.hpp wide_jump)
+        o << "    static constexpr bool HAS_DLOSS = true;\n"
+          << "    template <bool WP> static __device__ __forceinline__ void dloss(double* __restrict__ dlam, double* __restrict__ gp, double (&acc)[" << na << "],\n"
+          << "            const double* __restrict__ u, const double* __restrict__ p, double t, int i, const double* __restrict__ d, double* __restrict__ ws, int tid) {\n"
+          << "        (void)dlam; (void)gp; (void)acc; (void)u; (void)p; (void)t; (void)i; (void)d; (void)ws; (void)tid;\n" << m.wdloss << "\n    }\n";
+    o << "};\n#undef tanh\n}  // namespace hipadj\n";
     return o.str();
 }
 
@@ -340,6 +349,30 @@ inline std::string user_model_struct(const UserModelSrc& m) {
       << "            for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
       << "            affect_t<Dual<NP>>(du_, dp_, uu, pp, Dual<NP>(t));\n"
       << "            for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * du_[i].d[j]; for (int k = 0; k < NP; ++k) s += gp[k] * dp_[k].d[j]; go[j] = s; } }\n    }\n";
+    if (m.has_dloss) {
+        // discrete loss on the device (hipadj_model_set_discrete_loss[_function]; HIPADJ_LOSS_MODEL): dgdu_discrete(out, u, p, t_i, i) / dgdp_discrete(out, u, p, t_i, i) of
+        // ReverseLossCallback (src/adjoint_common.jl:771-779) with d = the data column of this (trajectory, loss time)
+        o << "    static constexpr bool HAS_DLOSS = true;\n";
+        if (!m.dl_fun.empty()) {
+            o << "    template <class real> HIPADJ_HD static real l_disc_t(const real (&u)[N], const real (&p)[NP], real t, int i, const double (&d)[N]) {\n"
+              << "        (void)u; (void)p; (void)t; (void)i; (void)d; real l = 0.0;\n" << m.dl_fun << "\n        return l;\n    }\n"
+              << "    static constexpr bool HAS_LVALUE = true;\n"
+              << "    HIPADJ_HD static double l_disc(const double (&u)[N], const double (&p)[NP], double t, int i, const double (&d)[N]) { return l_disc_t<double>(u, p, t, i, d); }\n"
+              << "    HIPADJ_HD static void dgdu_disc(double (&out)[N], const double (&u)[N], const double (&p)[NP], double t, int i, const double (&d)[N]) {\n"
+              << "        Dual<N> uu[N], pp[NP];\n        for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n"
+              << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n        const Dual<N> lv = l_disc_t<Dual<N>>(uu, pp, Dual<N>(t), i, d);\n"
+              << "        for (int j = 0; j < N; ++j) out[j] = lv.d[j];\n    }\n"
+              << "    HIPADJ_HD static void dgdp_disc(double (&out)[NP], const double (&u)[N], const double (&p)[NP], double t, int i, const double (&d)[N]) {\n"
+              << "        Dual<NP> uu[N], pp[NP];\n        for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n"
+              << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n        const Dual<NP> lv = l_disc_t<Dual<NP>>(uu, pp, Dual<NP>(t), i, d);\n"
+              << "        for (int j = 0; j < NP; ++j) out[j] = lv.d[j];\n    }\n";
+        } else {
+            o << "    HIPADJ_HD static void dgdu_disc(double (&out)[N], const double (&u)[N], const double (&p)[NP], double t, int i, const double (&d)[N]) {\n"
+              << "        (void)u; (void)p; (void)t; (void)i; (void)d;\n" << m.dl_du << "\n    }\n"
+              << "    HIPADJ_HD static void dgdp_disc(double (&out)[NP], const double (&u)[N], const double (&p)[NP], double t, int i, const double (&d)[N]) {\n"
+              << "        (void)u; (void)p; (void)t; (void)i; (void)d;\n" << (m.dl_dp.empty() ? std::string("for (int j = 0; j < NP; ++j) out[j] = 0.0;") : m.dl_dp) << "\n    }\n";
+        }
+    }
     o << "    // continuous cost attached with hipadj_model_set_cost[_function] (dgdu_continuous / dgdp_continuous); zero when absent\n";
     if (m.has_cost && !m.gfun.empty()) {
         // only g was given: its gradients by forward-mode dual numbers (the reference differentiates `g` with ForwardDiff when
@@ -673,6 +706,35 @@ inline bool user_mass_matrix_inverse(int32_t model, double* out) {
     if (idx < 0 || idx >= (int)R.models.size() || !R.models[idx].has_mm) return false;
     std::memcpy(out, R.models[idx].minv, sizeof(double) * 64);
     return true;
+}
+// discrete loss bodies of a lane model (hipadj_model_set_discrete_loss): dgdu required, dgdp may be NULL; both NULL removes the loss
+inline int user_set_discrete_loss(int32_t model, const char* dgdu, const char* dgdp, const char* lfun, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_discrete_loss: unknown model id (discrete losses are attached to runtime-registered models)"; return HIPADJ_ERR_INVALID_ARG; }
+    UserModelSrc& m = R.models[idx];
+    if (m.wide) { err = "hipadj_model_set_discrete_loss: the discrete loss of a wide model (hipadj_wmodel_register) is one SPMD body: hipadj_wmodel_set_discrete_loss"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (!dgdu && dgdp) { err = "hipadj_model_set_discrete_loss: dgdp_body without dgdu_body"; return HIPADJ_ERR_INVALID_ARG; }
+    m.dl_du = dgdu ? dgdu : ""; m.dl_dp = dgdp ? dgdp : ""; m.dl_fun = lfun ? lfun : "";
+    m.has_dloss = !m.dl_du.empty() || !m.dl_fun.empty(); m.rev++;
+    return HIPADJ_OK;
+}
+inline int user_set_wide_discrete_loss(int32_t model, const char* body, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size() || !R.models[idx].wide) { err = "hipadj_wmodel_set_discrete_loss: not a wide model id (hipadj_wmodel_register)"; return HIPADJ_ERR_INVALID_ARG; }
+    R.models[idx].wdloss = body ? body : ""; R.models[idx].has_dloss = !R.models[idx].wdloss.empty(); R.models[idx].rev++;
+    return HIPADJ_OK;
+}
+inline bool user_has_dloss(int32_t model, bool* has_value = nullptr) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) return false;
+    if (has_value) *has_value = !R.models[idx].dl_fun.empty();
+    return R.models[idx].has_dloss;
 }
 inline bool user_has_cost(int32_t model) {
     UserRegistry& R = user_registry();

@@ -44,7 +44,8 @@ struct WideGeom {
     long N;
     int S, M, nck;
     double t0, dt, loss_shift;
-    int loss_kind, no_start, p_shared;
+    int loss_kind, no_start, p_shared;   // loss_kind: hipadj_loss (0 cotangent, 1 lsq_shift, 2 lsq_data, 3 the model's discrete-loss body)
+    double la, lb; int lflags;           // as Geom (hipadj_lane.hpp): dgdu = la u + lb c for the kinds that stream a column; bit 0 of lflags drops dgdp_discrete
 };
 
 // where QuadratureAdjoint's second pass reads y(t) and lam(t) from: fixed step (knots + the Hermite records of pass 1) or the adaptive solutions' dense records
@@ -144,16 +145,21 @@ template <int T> __device__ __forceinline__ void wide_sum2_all(double a, double 
 // as literals they were materialised in VGPRs and every v_fmac (addend = destination) was preceded by a copy of its constant: nine v_mov_b64 per tanh.
 static __constant__ double wide_tanh_c[10] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0};
 __device__ __forceinline__ double wide_tanh(double x) {
-    const double a = fmax(-2.0 * fabs(x), -80.0);
+    // tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2 |x|) = 2^k q(r).  Two things the plain form lost: (i) fmax(-2 |NaN|, -80) is -80, i.e. tanh(NaN) = +-1 and a
+    // non-finite pre-activation never reached the NaN / Inf flag — the clamp is a compare-and-select now, which keeps a NaN; (ii) 1 - t cancels for |x| << 1 (absolute accuracy
+    // 1e-16 only) — the numerator is formed as (1 - 2^k) - 2^k r q1(r) with q(r) = 1 + r q1(r): exact in the first term, relative accuracy in the second (k = 0: 1 - t = -r q1).
+    double a = -2.0 * fabs(x);
+    a = a < -80.0 ? -80.0 : a;
     const double kf = __builtin_rint(a * 1.4426950408889634074);
     double r = __builtin_fma(kf, -6.93147180369123816490e-01, a);
     r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
     double q = wide_tanh_c[0];
 #pragma unroll
     for (int k = 1; k < 10; ++k) q = __builtin_fma(q, r, wide_tanh_c[k]);
-    q = __builtin_fma(q, r, 0.5); q = __builtin_fma(q, r, 1.0); q = __builtin_fma(q, r, 1.0);
-    const double t = __builtin_amdgcn_ldexp(q, (int)kf);
-    const double d = 1.0 + t, n = 1.0 - t;
+    q = __builtin_fma(q, r, 0.5); q = __builtin_fma(q, r, 1.0);            // q1(r) = (exp(r) - 1) / r
+    const double s = __builtin_amdgcn_ldexp(1.0, (int)kf), sr = s * r;
+    const double t = __builtin_fma(sr, q, s);                              // 2^k exp(r)
+    const double d = 1.0 + t, n = __builtin_fma(-sr, q, 1.0 - s);
     double y = __builtin_amdgcn_rcp(d);
     y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
     y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
@@ -269,23 +275,43 @@ __device__ __forceinline__ void wide_load_knot(const double* __restrict__ knots,
     for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; kn.u[q] = c < N ? b[c] : 0.0; kn.f[q] = c < N ? b[N + c] : 0.0; }
 }
 
-// lam += dgdu_discrete at loss time s (src/adjoint_common.jl:771-773, 812-813): the cotangent column, or y - shift
-template <class Mo>
-__device__ __forceinline__ void wide_jump(const WideGeom& g, long traj, int s, const double* __restrict__ cot, const double (&y)[WideShape<Mo>::Q],
-                                          double (&lam)[WideShape<Mo>::Q]) {
-    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q;
-    if (g.loss_kind == 0) {
-        const double* c_ = cot + (traj * g.M + s) * N;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) lam[q] += c_[c]; }
-    } else {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) lam[q] += y[q] - g.loss_shift; }   // padding components stay zero (the adaptive controller's norms run over them)
-    }
-}
-
 // the LDS tiles of one sweeping workgroup
 template <class Mo> struct WideTiles { double *y, *ls, *dl, *gp, *ws, *red; };
+
+// a model with a discrete-loss body (hipadj_wmodel_set_discrete_loss): Mo::dloss<WP>(dlam, gp, acc, u, p, t, i, d, ws, tid)
+template <class Mo, class = void> struct wide_has_dloss { static constexpr bool value = false; };
+template <class Mo> struct wide_has_dloss<Mo, decltype((void)Mo::HAS_DLOSS)> { static constexpr bool value = Mo::HAS_DLOSS; };
+
+// lam += dgdu_discrete at loss time s (src/adjoint_common.jl:771-773, 812-813): y - shift, or la y + lb c with the column c of the cotangent / data block ([N][M][n], used in
+// place), or the model's discrete-loss body (HIPADJ_LOSS_MODEL) — an SPMD body like the continuous cost: it ADDS dl/du into the vjp tile and, WP, dl/dp into the gradient row
+// (src/adjoint_common.jl:775-779; WP = false where the sweep carries no gradient row, i.e. never for a model with a body: Quadrature's pass 1 gets a row for it).
+template <class Mo, bool WP = true>
+__device__ __forceinline__ void wide_jump(const WideGeom& g, long traj, int s, const double* __restrict__ cot, const double (&y)[WideShape<Mo>::Q],
+                                          double (&lam)[WideShape<Mo>::Q], const WideTiles<Mo>& L, const double* __restrict__ pp, double t, double (&acc)[WideShape<Mo>::NA]) {
+    constexpr int N = Mo::N, T = Mo::T, Q = WideShape<Mo>::Q;
+    if constexpr (wide_has_dloss<Mo>::value) {
+        if (g.loss_kind == 3) {
+            const int tid = threadIdx.x;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { L.y[c] = y[q]; L.dl[c] = 0.0; } }
+            wide_sync<T>();
+            if (g.lflags & 1) Mo::template dloss<false>(L.dl, L.gp, acc, L.y, pp, t, s, cot ? cot + (traj * g.M + s) * N : (const double*)nullptr, L.ws, tid);
+            else Mo::template dloss<WP>(L.dl, L.gp, acc, L.y, pp, t, s, cot ? cot + (traj * g.M + s) * N : (const double*)nullptr, L.ws, tid);
+            wide_sync<T>();
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) lam[q] += L.dl[c]; }
+            return;
+        }
+    } else { (void)L; (void)pp; (void)t; (void)acc; }
+    if (g.loss_kind == 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) lam[q] += y[q] - g.loss_shift; }   // padding components stay zero (the adaptive controller's norms run over them)
+    } else {
+        const double* c_ = cot + (traj * g.M + s) * N;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = threadIdx.x + q * T; if (c < N) lam[q] += __builtin_fma(g.la, y[q], g.lb * c_[c]); }
+    }
+}
 
 // Continuous costs g(u, p, t) (src/adjoint_common.jl `accumulate_cost!`, src/derivative_wrappers.jl:1411-1442) of the built-in kinds on a wide model: the kernels are
 // instantiated for WideWithCost<UserW, CC> and every joint-VJP evaluation adds g_u to (df/du)^T lam and, where the parameter part is taken (WP), w g_p to the
@@ -507,7 +533,7 @@ __device__ __forceinline__ void wide_adjoint_step(const WideGeom& g, const WideT
             }
             }
         }
-        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) wide_jump<Mo>(g, traj, s, cot, lo.u, lam); }
+        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) wide_jump<Mo>(g, traj, s, cot, lo.u, lam, L, pp, t_lo, acc); }
 }
 
 template <class Mo, int ALG>
@@ -530,7 +556,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint(WideGeom g, const double
     for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
     WKnot<Mo> hi, lo, nx;
     wide_load_knot<Mo>(knots, g, traj, g.S, hi);
-    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam); }   // PresetTimeCallback fires at initialisation when T is a loss time
+    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam, L, pp, g.t0 + g.S * g.dt, acc); }   // PresetTimeCallback fires at initialisation when T is a loss time
     wide_load_knot<Mo>(knots, g, traj, g.S - 1, lo);
     for (int k = g.S - 1; k >= 0; --k) {
         wide_load_knot<Mo>(knots, g, traj, k > 0 ? k - 1 : 0, nx);        // one knot ahead of the step
@@ -611,7 +637,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ck(WideGeom g, const dou
         }
         WKnot<Mo> hi, lo;
         wide_load_knot_at<Mo>(tile + (long)len * 2 * N, hi);
-        if (top) { top = false; const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam); }   // PresetTimeCallback fires at initialisation when T is a loss time
+        if (top) { top = false; const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam, L, pp, g.t0 + g.S * dt, acc); }   // PresetTimeCallback fires at initialisation when T is a loss time
         for (int k = khi - 1; k >= klo; --k) {
             wide_load_knot_at<Mo>(tile + (long)(k - klo) * 2 * N, lo);
             wide_adjoint_step<Mo, ALG>(g, L, pp, traj, k, hi, lo, lam, acc, cot, save_of_knot, gk_scratch, sgk);
@@ -692,7 +718,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_og(WideGeom g, RevSteps 
 #pragma unroll
     for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
     wide_hermite<Mo>(knots, g, traj, R.t_start, y_hi);
-    if (R.save_at_start >= 0) wide_jump<Mo>(g, traj, R.save_at_start, cot, y_hi, lam);       // PresetTimeCallback fires at initialisation when T is a loss time
+    if (R.save_at_start >= 0) wide_jump<Mo>(g, traj, R.save_at_start, cot, y_hi, lam, L, pp, R.t_start, acc);       // PresetTimeCallback fires at initialisation when T is a loss time
     const double xg = 0.5773502691896257645;
     for (int qs = 0; qs < R.n; ++qs) {
         const double t = R.t[qs], hs = R.h[qs], te = R.te[qs], tm = t - 0.5 * hs;
@@ -718,7 +744,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_og(WideGeom g, RevSteps 
                 wide_vjp<Mo, true>(L, pp, t - th * hs, 0.5 * hs, yv, gl, acc, dd);
             }
         }
-        { const int s = R.save[qs]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y_lo, lam); }
+        { const int s = R.save[qs]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y_lo, lam, L, pp, te, acc); }
 #pragma unroll
         for (int q = 0; q < Q; ++q) y_hi[q] = y_lo[q];
     }
@@ -743,7 +769,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve(WideGeom g, const doub
     for (int q = 0; q < Q; ++q) { const int c = tid + q * T; lam[q] = 0.0; y[q] = c < N ? yT[traj * N + c] : 0.0; }
 #pragma unroll
     for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
-    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y, lam); }
+    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y, lam, L, pp, g.t0 + g.S * g.dt, acc); }
     // one stage: f AND the joint VJP at the same published stage state
     auto stage = [&](const double (&yv)[Q], const double (&lv)[Q], double t, double w, double (&F)[Q], double (&V)[Q]) {
 #pragma unroll
@@ -776,7 +802,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve(WideGeom g, const doub
         if (ckpt) { const int c0 = ckpt_of_knot[k]; if (c0 >= 0) { const double* src = ckpt + (traj * g.nck + c0) * N;
 #pragma unroll
             for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) y[q] = src[c]; } } }
-        { const int s = save_of_knot[k]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y, lam); }
+        { const int s = save_of_knot[k]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y, lam, L, pp, t_lo, acc); }
     }
     wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
 }
@@ -785,19 +811,23 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve(WideGeom g, const doub
 // (src/quadrature_adjoint.jl:527-530) with the Hermite data of a fixed-step solver -------------------------------------------------------------
 template <class Mo>
 __global__ void __launch_bounds__(Mo::T) k_wide_quad_adj(WideGeom g, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
-                                                         const int* __restrict__ save_of_knot, double* __restrict__ adj, double* __restrict__ du0, int* __restrict__ flag) {
+                                                         const int* __restrict__ save_of_knot, double* __restrict__ adj, double* __restrict__ du0, int* __restrict__ flag,
+                                                         double* __restrict__ dp_traj) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
-    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sp[W::P_LDS ? NP : 1];
+    constexpr bool DL = wide_has_dloss<Mo>::value;   // a model with a discrete-loss body: this pass also sums dgdp_discrete over the loss times into the trajectory's gradient row
+                                                     // (src/quadrature_adjoint.jl:545-552, 601-605), to which k_wide_quad_sum then ADDS the quadrature
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sp[W::P_LDS ? NP : 1], sgp[(DL && W::GP_LDS) ? NP : 1], sred[DL ? (T / 64) * W::NA + 2 : 1];
     const long traj = blockIdx.x; const int tid = threadIdx.x;
     const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
-    WideTiles<Mo> L{sy, sls, sdl, nullptr, sws, nullptr};
-    double lam[Q], dacc[W::NA] = {};
+    WideTiles<Mo> L{sy, sls, sdl, DL ? (W::GP_LDS ? sgp : dp_traj + traj * NP) : (double*)nullptr, sws, DL ? sred : (double*)nullptr};
+    if constexpr (DL) wide_zero_gp<Mo>(L);
+    double lam[Q], dacc[W::NA] = {}, lacc[W::NA] = {};
 #pragma unroll
     for (int q = 0; q < Q; ++q) lam[q] = 0.0;
     WKnot<Mo> hi, lo, nx;
     wide_load_knot<Mo>(knots, g, traj, g.S, hi);
-    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, hi.u, lam); }
+    { const int s = save_of_knot[g.S]; if (s >= 0) wide_jump<Mo, DL>(g, traj, s, cot, hi.u, lam, L, pp, g.t0 + g.S * g.dt, lacc); }
     wide_load_knot<Mo>(knots, g, traj, g.S - 1, lo);
     const double dt = g.dt;
     for (int k = g.S - 1; k >= 0; --k) {
@@ -810,9 +840,10 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_adj(WideGeom g, const doubl
         wide_vjp<Mo, false>(L, pp, g.t0 + k * dt, 0.0, lo.u, lam, dacc, v5);            // slope at the end of the step, before the jump
 #pragma unroll
         for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { rec[N + c] = -v1[q]; rec[2 * N + c] = lam[q]; rec[3 * N + c] = -v5[q]; } }
-        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) wide_jump<Mo>(g, traj, s, cot, lo.u, lam); }
+        { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) wide_jump<Mo, DL>(g, traj, s, cot, lo.u, lam, L, pp, g.t0 + k * dt, lacc); }
         hi = lo; lo = nx;
     }
+    if constexpr (DL) { wide_finish<Mo>(g, traj, L, lam, lacc, du0, dp_traj, flag); return; }
     bool bad = false;
 #pragma unroll
     for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { du0[traj * N + c] = lam[q]; bad |= !(fabs(lam[q]) <= 1.79769313486231570e308); } }
@@ -958,10 +989,10 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
 }
 
 // dp_traj[traj][j] = sum over the loss intervals of qres[traj][qi][j], in interval order (src/quadrature_adjoint.jl:563-616)
-static __global__ void k_wide_quad_sum(long N, int NP, int nq, const double* __restrict__ qres, double* __restrict__ dp_traj) {
+static __global__ void k_wide_quad_sum(long N, int NP, int nq, const double* __restrict__ qres, double* __restrict__ dp_traj, int add = 0) {   // add: the row already holds pass 1's dgdp_discrete sum
     const long traj = blockIdx.x;
     for (int j = threadIdx.x; j < NP; j += blockDim.x) {
-        double s = 0.0;
+        double s = add ? dp_traj[traj * NP + j] : 0.0;
         for (int q = 0; q < nq; ++q) s += qres[(traj * nq + q) * (long)NP + j];
         dp_traj[traj * NP + j] = s;
     }
@@ -1269,7 +1300,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
         if (cur_time >= 1 && time_hits(t, t_loss)) {                                  // ReverseLossCallback
             if (!(g.no_start && cur_time == 1)) {
                 double y[Q]; cur.eval(t, y);
-                wide_jump<Mo>(g, traj, cur_time - 1, cot, y, zz);
+                wide_jump<Mo>(g, traj, cur_time - 1, cot, y, zz, L, pp, t, acc);
                 mod = true;
             }
             --cur_time;
@@ -1281,7 +1312,8 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
     int na;
     if constexpr (ALG == 0) na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), aug);
     else na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
-    wide_finish<Mo>(g, traj, L, z, acc, du0, ALG == 3 ? (double*)nullptr : dp_traj, flag);      // Quadrature: dp comes from the second pass
+    wide_finish<Mo>(g, traj, L, z, acc, du0, (ALG == 3 && !wide_has_dloss<Mo>::value) ? (double*)nullptr : dp_traj, flag);      // Quadrature: dp comes from the second pass (a model with a
+                                                                                                                                  // discrete-loss body leaves its dgdp_discrete sum in the row: k_wide_quad_sum adds)
     if (ALG == 3 && threadIdx.x == 0) nsteps_adj[traj] = sa;                                   // the TRUE count; readers clamp with SmaxA
     if ((na < 0 || aoverflow) && threadIdx.x == 0) atomicOr(flag, 4);
 }
@@ -1354,7 +1386,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve_ts5(WideGeom g, WideAd
             double yv[Q], lv[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) { lv[q] = zz[q]; yv[q] = zz[Q + q]; }
-            wide_jump<Mo>(g, traj, cur_time - 1, cot, yv, lv);
+            wide_jump<Mo>(g, traj, cur_time - 1, cot, yv, lv, L, pp, t, acc);
 #pragma unroll
             for (int q = 0; q < Q; ++q) zz[q] = lv[q];
             mod = true;
@@ -1380,6 +1412,7 @@ struct WideProbe {
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
     static __device__ void f(double*, const double*, const double*, double, double*, int) {}
     template <bool WP> static __device__ void vjp(double*, double*, double (&)[1], double, const double*, const double*, const double*, double, double*, int) {}
+    template <bool WP> static __device__ void dloss(double*, double*, double (&)[1], const double*, const double*, double, int, const double*, double*, int) {}
 #endif
 };
 

@@ -15,7 +15,7 @@ class Engine:
     def __init__(self, model, alg, ntraj, t0, t1, dt, save_times=(), loss_kind=_lib.LOSS_COTANGENT, loss_shift=0.0,
                  checkpointing=False, ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False,
                  p_shared=True, device=0, time_segments=0, dims=(0, 0, 0, 0), cont_cost=0,
-                 stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0, checkpoints=None):
+                 stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0, checkpoints=None, loss_scale=0.0, devices=None, reference_literal=False):
         L = _lib.load()
         self._L = L
         self._save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
@@ -37,6 +37,11 @@ class Engine:
         self._ck = None if checkpoints is None else np.ascontiguousarray(np.asarray(checkpoints, dtype=np.float64))
         c.ncheckpoints = 0 if self._ck is None else len(self._ck)
         c.checkpoints = _dptr(self._ck) if c.ncheckpoints else None
+        c.loss_scale = float(loss_scale)
+        self._devs = None if devices is None else np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+        c.ndevices = 0 if self._devs is None else len(self._devs)
+        c.device_ids = self._devs.ctypes.data_as(C.POINTER(C.c_int32)) if c.ndevices else None
+        c.reference_literal = int(bool(reference_literal))
         self.cfg = c
         self.model, self.alg = model, alg
         self.N, self.M = int(ntraj), len(self._save)
@@ -99,6 +104,38 @@ class Engine:
         if M is not None:      # a traced wide model with a mass matrix: the device integrated nu = M' lam (problems.py from_callable); the reference returns lam(t0)
             du0 = np.linalg.solve(M.T, du0.T).T.copy()
         return du0, dp
+
+    # ---- device-resident discrete losses (include/hipadj.h: hipadj_set_loss_data, hipadj_loss_value) ------
+    def set_loss_data(self, data):
+        """The data block [N][M][n] of HIPADJ_LOSS_LSQ_DATA / of a model's discrete-loss bodies (host array; copied into the handle)."""
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if data.shape != (self.N, self.M, self.n):
+            raise ValueError(f"data must be [{self.N}][{self.M}][{self.n}], got {data.shape}")
+        self._check(self._L.hipadj_set_loss_data(self._h, _dptr(data)))
+
+    def set_loss_data_dev(self, data):
+        self._check(self._L.hipadj_set_loss_data_dev(self._h, C.c_void_p(data.data_ptr())))
+
+    def loss_value(self, out):
+        """The loss summed over the ensemble from the primal output `out` [N][M][n] (hipadj_loss_value)."""
+        out = np.ascontiguousarray(out, dtype=np.float64)
+        if out.shape != (self.N, self.M, self.n):
+            raise ValueError(f"out must be [{self.N}][{self.M}][{self.n}], got {out.shape}")
+        v = np.zeros(1)
+        self._check(self._L.hipadj_loss_value(self._h, _dptr(out), _dptr(v)))
+        return float(v[0])
+
+    def loss_value_dev(self, out, loss):
+        self._check(self._L.hipadj_loss_value_dev(self._h, C.c_void_p(out.data_ptr()), C.c_void_p(loss.data_ptr())))
+
+    def soa_stride(self):
+        ld = C.c_int64(0)
+        self._check(self._L.hipadj_soa_stride(self._h, C.byref(ld)))
+        return int(ld.value)
+
+    def adjoint_dev_soa(self, dLdu_soa, du0, dp):
+        """Cotangents already in the lane family's streaming layout [M][n][soa_stride()] (hipadj_adjoint_dev_soa): no transposition launch."""
+        self._check(self._L.hipadj_adjoint_dev_soa(self._h, C.c_void_p(dLdu_soa.data_ptr()), C.c_void_p(du0.data_ptr()), C.c_void_p(dp.data_ptr())))
 
     # ---- device-pointer API (torch tensors on cuda:<device>) -------------------------------------------
     def use_torch_stream(self):

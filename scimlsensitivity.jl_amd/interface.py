@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Engine
-from .problems import (RK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, HalfSquaredSum,
+from .problems import (RK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, LsqData, ModelLoss, HalfSquaredSum,
                        FirstStateSquaredPlusFirstParam, ModelCost)
 from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
                                      QuadratureAdjoint, GaussAdjoint, GaussKronrodAdjoint, ischeckpointing)
@@ -83,7 +83,7 @@ def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False, t1=None):
 
 def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
           device=0, time_segments=0, no_start=None, want_out=True, g=None, abstol=1e-6, reltol=1e-3, max_steps=0, save_idxs=None,
-          save_start=True, save_end=True, save_everystep=False, callback=None):
+          save_start=True, save_end=True, save_everystep=False, callback=None, devices=None, reference_literal=False):
     """Forward solve of an EnsembleProblem on the device.  The returned solution owns the device-resident
     interpolant tiles (Interpolating/Gauss/Quadrature) or checkpoints (Backsolve) the reverse pass consumes.
     `dgdu_discrete` may be given here already (LsqShift or None = cotangents) because the fused reverse kernel
@@ -95,7 +95,11 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     adjoint_sensitivities then have that shape and the other components receive zero (`_out[_save_idxs] .= ...`).
     `save_start` / `save_end` / `save_everystep`: the forward solve's saving flags as _concrete_solve_adjoint reads them
     (`_save_times`); `no_start` defaults to the reference's `!save_start && t0 in ts` (src/concrete_solve.jl:962), which
-    suppresses the loss jump at t0."""
+    suppresses the loss jump at t0.
+    `dgdu_discrete` = LsqData(data, scale) or ModelLoss(data): the loss stays on the device (include/hipadj.h HIPADJ_LOSS_LSQ_DATA / HIPADJ_LOSS_MODEL) — the data
+    block is handed over once, the reverse pass takes no cotangents and `sol.loss_value()` returns the loss.
+    `devices` = a list of HIP ordinals: one handle over several devices (contiguous trajectory ranges; hipadj_config.device_ids).
+    `reference_literal`: reproduce the reference's lines where the library deliberately deviates (hipadj_config.reference_literal)."""
     if callback is not None:       # DiscreteCallback at preset times: a chain of ordinary pieces (events.py)
         from . import events
         return events.solve_with_events(solve, _save_times, ensprob, alg, callback, dt=dt, saveat=saveat, sensealg=sensealg, dgdu_discrete=dgdu_discrete, checkpoints=checkpoints,
@@ -118,12 +122,22 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
         no_start = (not save_start) and len(ts) > 0 and bool(np.any(np.abs(ts - prob.tspan[0]) <= 1e-12 * max(1.0, abs(prob.tspan[0]))))
     if g is not None and not isinstance(g, tuple(_COSTS)):
         raise ValueError("g must be a registered continuous cost (HalfSquaredSum(), FirstStateSquaredPlusFirstParam(), ModelCost()) or None")
-    loss_kind, shift = (_lib.LOSS_LSQ_SHIFT, dgdu_discrete.shift) if isinstance(dgdu_discrete, LsqShift) else (_lib.LOSS_COTANGENT, 0.0)
+    loss_kind, shift, scale = _lib.LOSS_COTANGENT, 0.0, 0.0
+    if isinstance(dgdu_discrete, LsqShift):
+        loss_kind, shift = _lib.LOSS_LSQ_SHIFT, dgdu_discrete.shift
+    elif isinstance(dgdu_discrete, LsqData):
+        loss_kind, scale = _lib.LOSS_LSQ_DATA, dgdu_discrete.scale
+    elif isinstance(dgdu_discrete, ModelLoss):
+        loss_kind = _lib.LOSS_MODEL
+    if isinstance(dgdu_discrete, (LsqData, ModelLoss)) and save_idxs is not None:
+        raise ValueError("save_idxs with a device-resident loss is ambiguous: hand the cotangents instead")
     eng = Engine(prob.f, sensealg.name, ensprob.u0.shape[0], prob.tspan[0], prob.tspan[1], dt, save_times=ts,
-                 loss_kind=loss_kind, loss_shift=shift, p_shared=(ensprob.p.ndim == 1), device=device,
+                 loss_kind=loss_kind, loss_shift=shift, loss_scale=scale, devices=devices, reference_literal=reference_literal, p_shared=(ensprob.p.ndim == 1), device=device,
                  time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_COSTS[type(g)] if g is not None else 0),
                  stepper=(1 if adaptive else 0), abstol=abstol, reltol=reltol, max_steps=max_steps,
                  **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive, t1=prob.tspan[1]))
+    if isinstance(dgdu_discrete, (LsqData, ModelLoss)) and dgdu_discrete.data is not None and eng.M > 0:
+        eng.set_loss_data(np.asarray(dgdu_discrete.data, dtype=np.float64).reshape(eng.N, eng.M, eng.n))
     out = eng.forward(ensprob.u0, ensprob.p, want_out=want_out)
     idxs = None
     if save_idxs is not None:
@@ -193,12 +207,16 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_di
         if eng.cfg.loss_kind != _lib.LOSS_LSQ_SHIFT or eng.cfg.loss_shift != dgdu_discrete.shift:
             raise ValueError("pass dgdu_discrete=LsqShift(...) to solve(...) as well: the reverse kernel is specialised on it")
         return eng.adjoint(None)
+    if isinstance(dgdu_discrete, (LsqData, ModelLoss)):
+        if sol.extra.get("dgdu_discrete") != dgdu_discrete:
+            raise ValueError("pass the same device-resident loss (LsqData / ModelLoss) to solve(...) as well: the handle is configured with it and owns its data block")
+        return eng.adjoint(None)
     if dgdu_discrete is None:
-        if eng.cfg.loss_kind == _lib.LOSS_LSQ_SHIFT or eng.M == 0:
+        if eng.cfg.loss_kind != _lib.LOSS_COTANGENT or eng.M == 0:
             return eng.adjoint(None)
         raise ValueError("dgdu_discrete required")
     if eng.cfg.loss_kind != _lib.LOSS_COTANGENT:
-        raise ValueError("solution was prepared with a fused LsqShift loss; cotangents need dgdu_discrete=None at solve time")
+        raise ValueError("solution was prepared with a loss that stays on the device (LsqShift / LsqData / ModelLoss); cotangents need dgdu_discrete=None at solve time")
     idxs = sol.extra.get("save_idxs")
     delta = pack_cotangent(dgdu_discrete, eng.N, eng.M, eng.n if idxs is None else len(idxs))
     if idxs is not None:                      # cotangent of the saved components only: zero elsewhere (src/concrete_solve.jl:790-824)

@@ -1,5 +1,7 @@
 """Parity tests proper (`-m gpu`): the HIP path through the C ABI vs the CPU oracle on identical seeded inputs.
 Tolerance: rtol = 1e-6 (Float64), the bar BASELINE.json's north_star states; observed errors are ~1e-13."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1412,7 +1414,7 @@ def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
     u0, p = lorenz_inputs(N)
     ts = np.linspace(0, T, 11)
 
-    def grads(u0s, with_comm, overlap=False):
+    def grads(u0s, with_comm, overlap=False, scaled=1.0):
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0s[0], (0, T), p), u0s), sa.RK4(), dt=dt, saveat=ts,
                        sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=sa.LsqShift(2.0))
         if with_comm:
@@ -1424,7 +1426,7 @@ def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
         assert np.array_equal(dp, dpb) and np.array_equal(du0, du0b)
         if with_comm:
             sol.engine.comm_destroy()
-            assert np.array_equal(sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))[1], dp)
+            assert np.array_equal(scaled * sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqShift(2.0))[1], dp)
         sol.engine.close()
         return du0, dp
 
@@ -1433,6 +1435,14 @@ def test_single_rank_rccl_communicator_leaves_dp_unchanged(sa):
     assert np.array_equal(du0, du0c) and np.array_equal(dp, dpc)
     du0o, dpo = grads(u0, True, overlap=True)
     assert np.array_equal(du0, du0o) and np.array_equal(dp, dpo)
+    # the HOST entry point copies dp back on the handle's first stream while the overlapped collective runs on the second.  A one-rank all-reduce is the identity,
+    # so the library's test hook makes it slow and visible (a 300 us spin, then dp *= 2, on the second stream): the host must see the doubled value, in every call
+    os.environ["HIPADJ_TEST_COMM_DELAY"] = "300"
+    try:
+        du0d, dpd = grads(u0, True, overlap=True, scaled=2.0)
+    finally:
+        del os.environ["HIPADJ_TEST_COMM_DELAY"]
+    assert np.array_equal(du0, du0d) and np.array_equal(2.0 * dp, dpd)
     lo, hi = sa.shard_range(N, 0, 2)
     parts = [grads(u0[a:b], True) for a, b in ((lo, hi), sa.shard_range(N, 1, 2))]
     assert rel(parts[0][1] + parts[1][1], dp) < 1e-12
