@@ -481,6 +481,133 @@ def other_configs(sa, torch):
     return out
 
 
+def loss_paths(sa, torch, args, u0_np, p_np, local_rank, headline_ms):
+    """The SAME 10^4-trajectory reverse pass through every route a caller's loss can take, each as a sustained loop like the headline:
+      lsq_data_device   sum(abs2, sol .- data) with the data block resident in the handle (HIPADJ_LOSS_LSQ_DATA): no cotangents, one launch
+      cotangent_soa     Delta on the device already in the streaming layout (hipadj_adjoint_dev_soa): one launch
+      cotangent_path    Delta on the device as [N][M][n] (the AD pullback's shape): the transposition launch + the sweep
+      host_api          hipadj_forward / hipadj_adjoint with HOST pointers — what the Julia binding calls (julia/HIPAdj/src/HIPAdj.jl): Delta upload, du0 / dp download included,
+                        with the PCIe bound of the bytes that cross the link."""
+    N = len(u0_np); ts = save_times(); M = len(ts); n = 3
+    dev = torch.device("cuda", local_rank)
+    rng = np.random.default_rng(7)
+    out = {}
+    stream = torch.cuda.Stream(device=dev)
+
+    def loop(fn, eng, steps, warmup, preamble):
+        eng.set_timing(0)
+        with torch.cuda.stream(stream):
+            for _ in range(preamble + warmup):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(steps):
+                fn()
+            e1.record(stream)
+        torch.cuda.synchronize()
+        eng.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    pre = 0 if args.no_preamble else 400
+    u0 = torch.tensor(u0_np, device=dev); p = torch.tensor(p_np, device=dev)
+    du0 = torch.empty((N, n), device=dev, dtype=torch.float64); dp = torch.empty(3, device=dev, dtype=torch.float64)
+    # --- the device-resident data loss
+    data = torch.tensor(2.0 + 0.5 * rng.standard_normal((N, M, n)), device=dev)
+    eng = sa.Engine("lorenz", "interpolating", N, 0.0, T_FINAL, DT, save_times=ts, loss_kind=2, loss_scale=2.0, p_shared=True, device=local_rank, time_segments=args.segments)
+    with torch.cuda.stream(stream):
+        eng.use_torch_stream()
+        eng.set_loss_data_dev(data)
+        eng.forward_dev(u0, p, None)
+    torch.cuda.synchronize()
+    ms = loop(lambda: eng.adjoint_dev(None, du0, dp), eng, args.steps, args.warmup, pre)
+    by = eng.stats()["adjoint_algorithmic_bytes"]
+    out["lsq_data_device"] = dict(ms_per_step=ms, over_headline=ms / headline_ms, algorithmic_bytes=by, frac_of_hbm_peak=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, launches_per_pass=eng.stats()["launches_per_pass"],
+                                  note="loss = sum(abs2, sol .- data), data [N][M][n] handed over once (hipadj_set_loss_data_dev); the sweep streams it next to the knots")
+    # parity of this route against the oracle on a sample
+    try:
+        import oracle as O
+        k = 256
+        pr = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=T_FINAL, dt=DT, save_times=ts, loss="LSQ_DATA", loss_scale=2.0)
+        rdu0, _, _, _ = pr.adjoint_ensemble(u0_np[:k], p_np, data[:k].cpu().numpy(), want_out=False)
+        out["lsq_data_device"]["parity_max_rel_du0_vs_oracle_first_256"] = float(np.max(np.abs(du0[:k].cpu().numpy() - rdu0)) / np.max(np.abs(rdu0)))
+    except Exception as e:      # noqa: BLE001
+        out["lsq_data_device"]["parity_error"] = repr(e)
+    eng.close()
+    # --- cotangents on the device: AD layout (+ transposition) and streaming layout
+    eng = sa.Engine("lorenz", "interpolating", N, 0.0, T_FINAL, DT, save_times=ts, loss_kind=0, p_shared=True, device=local_rank, time_segments=args.segments)
+    delta = torch.tensor(rng.standard_normal((N, M, n)), device=dev)
+    with torch.cuda.stream(stream):
+        eng.use_torch_stream()
+        eng.forward_dev(u0, p, None)
+    torch.cuda.synchronize()
+    ms_aos = loop(lambda: eng.adjoint_dev(delta, du0, dp), eng, args.steps, args.warmup, pre)
+    ld = eng.soa_stride()
+    soa = torch.zeros((M, n, ld), device=dev, dtype=torch.float64); soa[:, :, :N] = delta.permute(1, 2, 0)
+    ref_du0 = du0.clone()
+    ms_soa = loop(lambda: eng.adjoint_dev_soa(soa, du0, dp), eng, args.steps, args.warmup, pre)
+    by = eng.stats()["adjoint_algorithmic_bytes"]
+    out["cotangent_soa"] = dict(ms_per_step=ms_soa, over_headline=ms_soa / headline_ms, frac_of_hbm_peak=by / (ms_soa * 1e-3) / 1e9 / HBM_PEAK_GBS, bit_identical_to_cotangent_path=bool(torch.equal(ref_du0, du0)),
+                                note="Delta handed over as [M][n][ld] (hipadj_adjoint_dev_soa): the sweep reads it in place, one launch")
+    out["cotangent_path"] = dict(ms_per_step=ms_aos, over_headline=ms_aos / headline_ms, transposition_ms=ms_aos - ms_soa, extra_hbm_bytes=2.0 * N * M * n * 8,
+                                 note="Delta as [N][M][n] (the pullback's shape): k_aos_to_soa (reads and writes the block once more) + the sweep")
+    # --- the host-pointer API the Julia binding calls: pageable host arrays in, host arrays out
+    delta_h = delta.cpu().numpy()
+    eng.set_timing(0)
+    eng.forward(u0_np, p_np, want_out=True); eng.adjoint(delta_h)          # first calls: staging buffers, page faults
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.forward(u0_np, p_np, want_out=True)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        eng.adjoint(delta_h)
+    t2 = time.perf_counter()
+    link = 63.0e9     # PCIe 5.0 x16, one direction (MI355X_MICROARCH.md)
+    up, down = N * M * n * 8.0, N * n * 8.0 + 24.0
+    out["host_api"] = dict(forward_ms=(t1 - t0) / reps * 1e3, adjoint_ms=(t2 - t1) / reps * 1e3, gradient_ms=(t2 - t0) / reps * 1e3,
+                           adjoint_bytes_over_the_link=up + down, adjoint_pcie_bound_ms=(up + down) / link * 1e3,
+                           forward_bytes_over_the_link=N * n * 8.0 + 24.0 + N * M * n * 8.0, forward_pcie_bound_ms=(N * n * 8.0 + 24.0 + N * M * n * 8.0) / link * 1e3,
+                           note="hipadj_forward (u0 up, out = sol(ts) down) and hipadj_adjoint (Delta up, du0 / dp down) with pageable numpy arrays, synchronous, wall clock; the link, not the kernel, "
+                                "sets these: a loss that stays on the device (lsq_data_device) crosses it with N n + np doubles per gradient instead of 2 N M n")
+    eng.close()
+    return out
+
+
+def single_process_multi_device(sa, torch, args, world, local_rank):
+    """hipadj_config.device_ids: ONE handle over `world` devices in ONE process (what a Julia host that calls `solve` once can reach) — rank 0 runs it on all
+    visible devices after the per-process measurement, the other ranks wait.  Device-pointer calls on the primary device, strong scaling of the same 10^4-trajectory ensemble."""
+    n_total = args.ntraj
+    u0_np, p_np = inputs(n_total)
+    dev = torch.device("cuda", local_rank)
+    eng = sa.Engine("lorenz", "interpolating", n_total, 0.0, T_FINAL, DT, save_times=save_times(), loss_kind=1, loss_shift=LOSS_SHIFT, p_shared=True, devices=list(range(world)))
+    u0 = torch.tensor(u0_np, device=dev); p = torch.tensor(p_np, device=dev)
+    du0 = torch.empty((n_total, 3), device=dev, dtype=torch.float64); dp = torch.empty(3, device=dev, dtype=torch.float64)
+    stream = torch.cuda.Stream(device=dev)
+    eng.set_timing(0)
+    with torch.cuda.stream(stream):
+        eng.use_torch_stream()
+        eng.forward_dev(u0, p, None)
+        for _ in range(200 + args.warmup):
+            eng.adjoint_dev(None, du0, dp)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            eng.adjoint_dev(None, du0, dp)
+        e1.record(stream)
+    torch.cuda.synchronize()
+    eng.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    pr = oracle_problem()
+    k = 256
+    rdu0, _, _, _ = pr.adjoint_ensemble(u0_np[:k], p_np, want_out=False)
+    err = float(np.max(np.abs(du0[:k].cpu().numpy() - rdu0)) / np.max(np.abs(rdu0)))
+    eng.close()
+    return dict(devices=world, ntraj_total=n_total, ms_per_step=ms, value=n_total / (ms * 1e-3), unit="trajectories/s", parity_max_rel_du0_vs_oracle_first_256=err,
+                note="one process, one handle over all devices (hipadj_config.device_ids): slices of device 0's buffers go to the other devices by peer copies inside the call, dp partials are summed on device 0")
+
+
 def self_launch(n):
     """Re-executes this script as n ranks under torch.distributed.run on 127.0.0.1 (a free port), one rank per GPU; returns the exit
     code.  Refuses before spawning when fewer than n devices are visible."""
@@ -727,6 +854,16 @@ def main():
                                                   "time_segments": s3["time_segments"], "steps": k3}
             r3.close()
 
+    if world > 1 and not STUB and not args.no_extras:
+        # ONE handle over all devices in ONE process (hipadj_config.device_ids), measured by rank 0 while the other ranks wait at the barrier
+        dist.barrier()
+        if rank == 0:
+            try:
+                res["single_process_multi_device"] = single_process_multi_device(sa, torch, args, world, local_rank)
+            except Exception as e:      # noqa: BLE001
+                res["single_process_multi_device"] = {"error": repr(e)}
+        dist.barrier()
+
     if rank == 0 and world == 1 and not STUB:
         if not args.no_pmc:
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = live_traffic(n_total)
@@ -761,6 +898,10 @@ def main():
                 rs.close()
             except Exception as e:      # noqa: BLE001
                 res["saturating_ensemble"] = {"error": repr(e)}
+            try:
+                res["loss_paths"] = loss_paths(sa, torch, args, u0_all, p_np, local_rank, res["ms_per_step"])
+            except Exception as e:      # noqa: BLE001 — the headline must not die on a secondary figure
+                res["loss_paths_error"] = repr(e)
             try:
                 res["other_configs"] = other_configs(sa, torch)
             except Exception as e:      # the headline must not die on a secondary figure

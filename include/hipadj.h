@@ -168,6 +168,8 @@ int hipadj_version(void);
 const char *hipadj_status_string(int status);
 /* message of the last failing call on this handle; handle == NULL: last hipadj_create failure of this thread */
 const char *hipadj_last_error(const hipadj_handle *h);
+/* HIP devices the library sees (0 without a usable device): what a host expands `devices = :all` with for hipadj_config.device_ids */
+int hipadj_device_count(void);
 /* n and np of a registered model (the reference reads them off u0 / p) */
 int hipadj_model_sizes(int32_t model, const int32_t dims[4], int32_t *n, int32_t *np);
 

@@ -1,7 +1,7 @@
 """
     HIPAdj
 
-Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 107) — the MI355X-native batched continuous-adjoint
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 108) — the MI355X-native batched continuous-adjoint
 engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
 
   * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
@@ -39,7 +39,7 @@ function lib()
     if LIB[] == C_NULL
         LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
         v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
-        v == 107 || error("libhipadj ABI version $v, this binding was written for 107")
+        v == 108 || error("libhipadj ABI version $v, this binding was written for 108")
     end
     return LIB[]
 end
@@ -82,12 +82,17 @@ struct HipadjConfig
     reltol::Float64
     ncheckpoints::Int32
     checkpoints::Ptr{Float64}
+    loss_scale::Float64
+    ndevices::Int32
+    device_ids::Ptr{Int32}
+    reference_literal::Int32
+    reserved1::Int32
 end
 
 # byte offsets of include/hipadj.h as the C compiler sees them (tests/c/julia_seam.c asserts the same table with offsetof)
 const CONFIG_OFFSETS = (0, 4, 8, 12, 16, 32, 40, 48, 56, 64, 72, 80, 88, 96, 100, 104, 112, 120, 124, 128, 132, 136, 140, 144,
-                        152, 160, 168)
-const CONFIG_SIZE = 176
+                        152, 160, 168, 176, 184, 192, 200, 204)
+const CONFIG_SIZE = 208
 
 function check_layout()
     sizeof(HipadjConfig) == CONFIG_SIZE || error("HipadjConfig is $(sizeof(HipadjConfig)) bytes, the header says $CONFIG_SIZE")
@@ -101,7 +106,7 @@ end
 # enums of the header
 const ALG_INTERPOLATING, ALG_BACKSOLVE, ALG_GAUSS, ALG_QUADRATURE, ALG_GAUSS_KRONROD = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
 const STEPPER_RK4_FIXED, STEPPER_TSIT5_ADAPTIVE = Int32(0), Int32(1)
-const LOSS_COTANGENT, LOSS_LSQ_SHIFT = Int32(0), Int32(1)
+const LOSS_COTANGENT, LOSS_LSQ_SHIFT, LOSS_LSQ_DATA, LOSS_MODEL = Int32(0), Int32(1), Int32(2), Int32(3)
 const MODEL_USER_BASE = Int32(1000)
 
 struct HipadjError <: Exception
@@ -336,13 +341,16 @@ end
 # the sensealg the extension dispatches on (seam B1 of SURVEY.md §8b)
 # ---------------------------------------------------------------------------------------------------------------------
 """
-    HIPBatchedAdjoint(inner = nothing; model, device = 0, time_segments = 0, max_steps = 0)
+    HIPBatchedAdjoint(inner = nothing; model, device = 0, devices = nothing, time_segments = 0, max_steps = 0)
 
 `inner`: the reference algorithm whose semantics are wanted (`InterpolatingAdjoint()`, `BacksolveAdjoint(checkpointing = true)`,
 `GaussAdjoint()`, `GaussKronrodAdjoint()`, `QuadratureAdjoint(abstol, reltol)`; read by the extension).  The state of the problem is a
 MATRIX whose columns are independent trajectories of `model` — the documented batching pattern of the reference
 (docs/src/tutorials/data_parallel.md:11-75, test/Core5/size_handling_adjoint.jl:37-70); `p` is a vector shared by all columns or an
 `np x N` matrix.
+`devices = :all` (or a list of ordinals): ONE `solve` call uses every GPU of the node — the columns are cut into contiguous ranges, one per device, inside the library
+(`hipadj_config.device_ids`, ABI 108): the single-process counterpart of the reference's `EnsembleDistributed` pattern (docs/src/tutorials/data_parallel.md:77-136,
+test/Core4/distributed.jl:15-41), with no worker processes and no id exchange.
 """
 struct HIPBatchedAdjoint{A} <: SciMLBase.AbstractAdjointSensitivityAlgorithm{0, false, Val{:central}}
     inner::A
@@ -350,9 +358,11 @@ struct HIPBatchedAdjoint{A} <: SciMLBase.AbstractAdjointSensitivityAlgorithm{0, 
     device::Int32
     time_segments::Int32
     max_steps::Int32
+    devices::Union{Nothing, Symbol, Vector{Int32}}
 end
-HIPBatchedAdjoint(inner; model::DeviceModel, device::Integer = 0, time_segments::Integer = 0, max_steps::Integer = 0) =
-    HIPBatchedAdjoint{typeof(inner)}(inner, model, Int32(device), Int32(time_segments), Int32(max_steps))
+HIPBatchedAdjoint(inner; model::DeviceModel, device::Integer = 0, devices = nothing, time_segments::Integer = 0, max_steps::Integer = 0) =
+    HIPBatchedAdjoint{typeof(inner)}(inner, model, Int32(device), Int32(time_segments), Int32(max_steps),
+                                     devices === nothing || devices isa Symbol ? devices : collect(Int32, devices))
 
 # ---------------------------------------------------------------------------------------------------------------------
 # handle + the three calls
@@ -386,19 +396,66 @@ end
 """
     Handle(model; alg, stepper, N, tspan, dt, ts, loss_kind = LOSS_COTANGENT, loss_shift = 0.0, checkpointing = false,
            checkpoints = nothing, quad_abstol = 1e-6, quad_reltol = 1e-3, no_start = false, p_shared = true, device = 0,
-           time_segments = 0, cont_cost = 0, max_steps = 0, abstol = 1e-6, reltol = 1e-3)
+           time_segments = 0, cont_cost = 0, max_steps = 0, abstol = 1e-6, reltol = 1e-3, loss_scale = 0.0, devices = nothing, reference_literal = false)
+
+`devices = [0, 1, ..., 7]` (or `:all`): ONE handle over several devices — the ensemble is cut into contiguous trajectory ranges, one per device, and the host-pointer calls
+scatter / gather / sum over them (`hipadj_config.device_ids`, ABI 108): what a single `solve` call needs to use a whole node.
+`loss_kind = LOSS_LSQ_DATA` with `loss_scale` (and `set_loss_data!`) keeps `sum(abs2, sol .- data)` on the device; `LOSS_MODEL` runs the model's discrete-loss bodies.
 """
 function Handle(model::DeviceModel; alg::Int32, stepper::Int32, N::Integer, tspan, dt::Real, ts::Vector{Float64},
         loss_kind::Int32 = LOSS_COTANGENT, loss_shift::Real = 0.0, checkpointing::Bool = false, checkpoints = nothing,
         quad_abstol::Real = 1e-6, quad_reltol::Real = 1e-3, no_start::Bool = false, p_shared::Bool = true, device::Integer = 0,
-        time_segments::Integer = 0, cont_cost::Integer = 0, max_steps::Integer = 0, abstol::Real = 1e-6, reltol::Real = 1e-3)
+        time_segments::Integer = 0, cont_cost::Integer = 0, max_steps::Integer = 0, abstol::Real = 1e-6, reltol::Real = 1e-3,
+        loss_scale::Real = 0.0, devices = nothing, reference_literal::Bool = false)
     cks = checkpoints === nothing ? Float64[] : sort(collect(Float64, checkpoints))
+    devs = devices === nothing ? Int32[] : (devices === :all ? collect(Int32, 0:(device_count() - 1)) : collect(Int32, devices))
     cfg = HipadjConfig(UInt32(sizeof(HipadjConfig)), model.id, alg, stepper, model.dims, Int64(N),
         Float64(tspan[1]), Float64(tspan[2]), Float64(dt), Int32(length(ts)), isempty(ts) ? Ptr{Float64}(C_NULL) : pointer(ts),
         loss_kind, Float64(loss_shift), Int32(checkpointing), Int32(0), Float64(quad_abstol), Float64(quad_reltol),
         Int32(no_start), Int32(p_shared), Int32(device), Int32(time_segments), Int32(cont_cost), Int32(max_steps),
-        Float64(abstol), Float64(reltol), Int32(length(cks)), isempty(cks) ? Ptr{Float64}(C_NULL) : pointer(cks))
-    return Handle(cfg, model.n, model.np, ts, cks)   # ts / cks are copied by hipadj_create; kept alive across the call
+        Float64(abstol), Float64(reltol), Int32(length(cks)), isempty(cks) ? Ptr{Float64}(C_NULL) : pointer(cks),
+        Float64(loss_scale), Int32(length(devs)), isempty(devs) ? Ptr{Int32}(C_NULL) : pointer(devs), Int32(reference_literal), Int32(0))
+    return Handle(cfg, model.n, model.np, ts, cks, devs)   # ts / cks / devs are copied by hipadj_create; kept alive across the call
+end
+
+"Number of HIP devices the library sees (`hipadj_device_count`): what `devices = :all` expands to."
+device_count() = Int(ccall(sym(:hipadj_device_count), Cint, ()))
+
+"""
+    set_loss_data!(h, data)
+
+The data block `(n, M, N)` of a device-resident loss (`hipadj_set_loss_data`): `loss_kind = LOSS_LSQ_DATA` differentiates `loss_scale / 2 * sum(abs2, sol .- data)` inside
+the reverse kernels — `adjoint!(h, nothing)` then takes no cotangents, and nothing crosses the host link between the forward and the reverse pass — and the
+discrete-loss bodies of a model (`set_discrete_loss!`, `LOSS_MODEL`) see it as `d`.
+"""
+function set_loss_data!(h::Handle, data::Array{Float64, 3})
+    size(data) == (h.n, h.M, h.N) || throw(DimensionMismatch("data must be ($(h.n), $(h.M), $(h.N)), got $(size(data))"))
+    check(ccall(sym(:hipadj_set_loss_data), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, data), h.ptr)
+    return h
+end
+
+"`loss_value(h, out)`: the loss of a device-resident discrete loss summed over the ensemble, evaluated on the device from `out = forward!(...)` (`hipadj_loss_value`)."
+function loss_value(h::Handle, out::Array{Float64, 3})
+    size(out) == (h.n, h.M, h.N) || throw(DimensionMismatch("out must be ($(h.n), $(h.M), $(h.N)), got $(size(out))"))
+    l = Ref{Float64}(0.0)
+    check(ccall(sym(:hipadj_loss_value), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}), h.ptr, out, l), h.ptr)
+    return l[]
+end
+
+"""
+    set_discrete_loss!(model; dgdu = nothing, dgdp = nothing, l = nothing)
+
+`dgdu_discrete` / `dgdp_discrete` of `adjoint_sensitivities` as device text (`hipadj_model_set_discrete_loss[_function]`): bodies writing `out` from `u`, `p`, `t`,
+`i` (0-based index of the loss time: the reference's `i - 1`) and `d` (the data column of this trajectory and time), or the loss itself (`l = "l = u[0]*u[0] + p[0];"`,
+gradients by dual numbers).  Selected per handle with `loss_kind = LOSS_MODEL`.
+"""
+function set_discrete_loss!(model::DeviceModel; dgdu = nothing, dgdp = nothing, l = nothing)
+    if l !== nothing
+        check(ccall(sym(:hipadj_model_set_discrete_loss_function), Cint, (Int32, Cstring), model.id, l))
+    else
+        check(ccall(sym(:hipadj_model_set_discrete_loss), Cint, (Int32, Cstring, Cstring), model.id, dgdu === nothing ? C_NULL : dgdu, dgdp === nothing ? C_NULL : dgdp))
+    end
+    return model
 end
 
 "`out = forward!(h, u0, p)`: u0 `(n, N)`, p `(np,)` or `(np, N)`; returns `out` `(n, M, N)` = sol(ts) of every trajectory."

@@ -149,7 +149,7 @@ function SciMLBase._concrete_solve_adjoint(
         checkpointing = ischeckpointing(inner), checkpoints,
         quad_abstol = inner isa QuadratureAdjoint ? inner.abstol : 1.0e-6,
         quad_reltol = inner isa QuadratureAdjoint ? inner.reltol : 1.0e-3,
-        no_start, p_shared, device = sensealg.device, time_segments = sensealg.time_segments, max_steps = sensealg.max_steps,
+        no_start, p_shared, device = sensealg.device, devices = sensealg.devices, time_segments = sensealg.time_segments, max_steps = sensealg.max_steps,
         abstol, reltol)
     raw = forward!(h, u0d, pd)                                          # (n, M, N)
     idxs = save_idxs === nothing ? nothing : (save_idxs isa Number ? [save_idxs] : collect(save_idxs))
@@ -194,7 +194,7 @@ function HIPAdj.hip_solve(prob::SciMLBase.AbstractODEProblem, alg, sensealg::HIP
     h = Handle(sensealg.model; alg = algid(inner), stepper, N, tspan = prob.tspan, dt = something(dt, 0.0), ts,
         checkpointing = ischeckpointing(inner), checkpoints,
         quad_abstol = inner isa QuadratureAdjoint ? inner.abstol : 1.0e-6, quad_reltol = inner isa QuadratureAdjoint ? inner.reltol : 1.0e-3,
-        p_shared = p isa AbstractVector, device = sensealg.device, time_segments = sensealg.time_segments, max_steps = sensealg.max_steps, abstol, reltol)
+        p_shared = p isa AbstractVector, device = sensealg.device, devices = sensealg.devices, time_segments = sensealg.time_segments, max_steps = sensealg.max_steps, abstol, reltol)
     raw = forward!(h, convert(Matrix{Float64}, u0), p isa AbstractVector ? convert(Vector{Float64}, p) : convert(Matrix{Float64}, p))
     return HIPAdjSolution(h, raw, ts, p)
 end

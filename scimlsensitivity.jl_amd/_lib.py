@@ -23,7 +23,7 @@ DECLARED_SYMBOLS = (
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
     "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
     "hipadj_model_set_discrete_loss", "hipadj_model_set_discrete_loss_function", "hipadj_wmodel_set_discrete_loss", "hipadj_set_loss_data", "hipadj_set_loss_data_dev",
-    "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride",
+    "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride", "hipadj_device_count",
 )
 
 
@@ -132,6 +132,7 @@ def load():
     L.hipadj_loss_value_dev.argtypes = [vp, vp, vp]
     L.hipadj_adjoint_dev_soa.argtypes = [vp, vp, vp, vp]
     L.hipadj_soa_stride.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.hipadj_device_count.restype = C.c_int
     _lib = L
     return L
 

@@ -793,7 +793,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 if (cost_has_gp<CC>::value) {   // + g_p at the node; sign: DESIGN.md 6.5 (Gauss == Interpolating == Quadrature)
                     double gp[NP]; cost_grad_p<Mo, CC>(y, pv, tt, gp);
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                    for (int j = 0; j < NP; ++j) W[j] += ((g.lflags & 2) ? -1.0 : 1.0) * gp[j];     // lflags bit 1: the reference's line as written (hipadj_config.reference_literal)
                 }
 #pragma unroll
                 for (int j = 0; j < NP; ++j) gacc[j] += half * wq * (-W[j]);
@@ -827,7 +827,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     if (cost_has_gp<CC>::value) {
                         double gp[NP]; cost_grad_p<Mo, CC>(y, pv, tt, gp);
 #pragma unroll
-                        for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                        for (int j = 0; j < NP; ++j) W[j] += ((g.lflags & 2) ? -1.0 : 1.0) * gp[j];
                     }
 #pragma unroll
                     for (int j = 0; j < NP; ++j) { IK[j] += GK15::WK[q] * (-W[j]); if (q & 1) IG[j] += GK15::WG[q / 2] * (-W[j]); }
@@ -857,12 +857,12 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
                     for (int j = 0; j < N; ++j) y[j] = zz[N + NP + j];
                 } else cur.eval(t, y);
-                double gl[N];
+                if constexpr (model_has_dloss<Mo>::value) {   // a model with discrete-loss bodies (hipadj_model_set_discrete_loss): dgdu_discrete / dgdp_discrete evaluated here when the handle selects them
+                    double gl[N];
 #pragma unroll
-                for (int j = 0; j < N; ++j)
-                    gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift) : __builtin_fma(g.la, y[j], g.lb * cotT[((long)(cur_time - 1) * N + j) * g.Npad + i]);
-                if constexpr (model_has_dloss<Mo>::value) {   // dgdu_discrete / dgdp_discrete bodies of the model (hipadj_model_set_discrete_loss); gl holds the data column on entry
-                    if (g.loss_kind == 3) {
+                    for (int j = 0; j < N; ++j)
+                        gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift) : __builtin_fma(g.la, y[j], g.lb * cotT[((long)(cur_time - 1) * N + j) * g.Npad + i]);
+                    if (g.loss_kind == 3) {      // gl holds the data column
                         double d[N], o[N], gpd[NP];
 #pragma unroll
                         for (int j = 0; j < N; ++j) d[j] = gl[j];
@@ -875,9 +875,13 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                             for (int j = 0; j < NP; ++j) { if constexpr (ALG == 0 || ALG == 1) zz[N + j] += gpd[j]; else gacc[j] += gpd[j]; }
                         }
                     }
-                }
 #pragma unroll
-                for (int j = 0; j < N; ++j) zz[j] += gl[j];
+                    for (int j = 0; j < N; ++j) zz[j] += gl[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j)      // u - shift, or la u + lb c with the streamed column c: the cotangent (0, 1), or the data of HIPADJ_LOSS_LSQ_DATA (w, -w)
+                        zz[j] += (g.loss_kind == 1) ? (y[j] - g.loss_shift) : __builtin_fma(g.la, y[j], g.lb * cotT[((long)(cur_time - 1) * N + j) * g.Npad + i]);
+                }
                 mod = true;
             }
             --cur_time;

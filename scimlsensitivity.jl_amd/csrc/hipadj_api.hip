@@ -6,6 +6,7 @@
 #include "hipadj_plan.hpp"
 #include "hipadj_user.hpp"
 #include "hipadj_comm.hpp"
+#include "hipadj_multi.hpp"
 
 static thread_local std::string g_create_error;
 static int user_prepare(hipadj_handle* h);   // hiprtc compilation of the kernels of a runtime-registered model
@@ -30,6 +31,8 @@ extern "C" const char* hipadj_status_string(int s) {
     default: return "unknown status";
     }
 }
+
+extern "C" int hipadj_device_count(void) { int n = 0; return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? n : 0; }
 
 extern "C" const char* hipadj_last_error(const hipadj_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -256,6 +259,9 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (!cfg) { g_create_error = "cfg == NULL"; return HIPADJ_ERR_INVALID_ARG; }
     // before ANY other field is read: a caller built against another ABI hands over a struct of another size (reading sizeof(hipadj_config) bytes from it would run past its end)
     if (cfg->struct_size != sizeof(hipadj_config)) { g_create_error = "hipadj_config.struct_size mismatch (ABI)"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->ndevices < 0) { g_create_error = "hipadj_config.ndevices must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->ndevices > 1) return multi_create(cfg, out, g_create_error);      // one handle over several devices: G ordinary handles on contiguous trajectory ranges (hipadj_multi.hpp)
+    if (cfg->ndevices == 1 && cfg->device_ids) { hipadj_config c1 = *cfg; c1.device = cfg->device_ids[0]; c1.ndevices = 0; c1.device_ids = nullptr; return hipadj_create(&c1, out); }
     auto* h = new hipadj_handle();
     auto fail = [&](int code) { g_create_error = h->err; free_all(h); delete h; return code; };
     h->cfg = *cfg; h->cfg.save_times = nullptr; h->cfg.checkpoints = nullptr;
@@ -510,7 +516,9 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     const double lw = cfg->loss_scale != 0.0 ? cfg->loss_scale : 1.0;
     g.la = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? lw : 0.0; g.lb = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? -lw : 1.0;
     const bool gauss_like = cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD;
-    g.lflags = (cfg->reference_literal && gauss_like) ? 1 : 0;   // the reference's GaussAdjoint drops dgdp_discrete (src/adjoint_common.jl:776 `!isq`; nothing in src/gauss_adjoint.jl adds it)
+    g.lflags = (cfg->reference_literal && gauss_like) ? 3 : 0;   // bit 0: the reference's GaussAdjoint drops dgdp_discrete (src/adjoint_common.jl:776 `!isq`; nothing in src/gauss_adjoint.jl
+                                                                 // adds it); bit 1: its g_p term of a continuous cost as src/gauss_adjoint.jl:753-758 is written
+    if (cfg->reference_literal && gauss_like && (P.wide || P.field || P.mlp) && cfg->cont_cost != HIPADJ_CCOST_NONE) { h->err = "reference_literal (the g_p sign of src/gauss_adjoint.jl:753-758) is offered for the lane-per-trajectory models"; return fail(HIPADJ_ERR_UNSUPPORTED); }
     h->ag.la = g.la; h->ag.lb = g.lb; h->ag.lflags = g.lflags;
     h->wg.la = g.la; h->wg.lb = g.lb; h->wg.lflags = g.lflags;
     h->fg.lsq_w = lw; h->mg.lsq_w = lw;
@@ -550,7 +558,6 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->user = P.user;
     if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { h->err = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost / hipadj_wmodel_set_cost)"; return fail(HIPADJ_ERR_INVALID_ARG); }
     if (cfg->loss_kind == HIPADJ_LOSS_MODEL && !user_has_dloss(cfg->model)) { h->err = "loss_kind = HIPADJ_LOSS_MODEL but the model has no discrete-loss bodies (hipadj_model_set_discrete_loss / hipadj_wmodel_set_discrete_loss)"; return fail(HIPADJ_ERR_INVALID_ARG); }
-    if (cfg->ndevices > 1) { h->err = "a handle over several devices is created through hipadj_create's multi-device path (internal error: reached the single-device constructor)"; return fail(HIPADJ_ERR_INVALID_ARG); }
     if (P.wide) { const int urc = wide_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
     else if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); }
     *out = h;
@@ -570,8 +577,10 @@ extern "C" int hipadj_comm_unique_id(char* id) {
     return HIPADJ_OK;
 }
 
+#define HIPADJ_NO_MULTI(h, what) do { if ((h)->multi) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, what ": not offered on a handle over several devices (hipadj_config.ndevices > 1): it already spans the node; shard across processes with one single-device handle per process") ; } while (0)
 extern "C" int hipadj_comm_overlap(hipadj_handle* h, int on) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    HIPADJ_NO_MULTI(h, "hipadj_comm_overlap");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (on && !h->comm_stream) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
@@ -589,6 +598,7 @@ extern "C" int hipadj_comm_overlap(hipadj_handle* h, int on) {
 
 extern "C" int hipadj_comm_destroy(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->multi) return HIPADJ_OK;
     if (h->comm_stream) { (void)hipSetDevice(h->cfg.device); (void)hipStreamSynchronize(h->comm_stream); }
     if (h->comm && h->comm_owned) {
         (void)hipSetDevice(h->cfg.device);
@@ -603,6 +613,7 @@ extern "C" int hipadj_comm_destroy(hipadj_handle* h) {
 
 extern "C" int hipadj_comm_init_rank(hipadj_handle* h, const char* id, int nranks, int rank) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    HIPADJ_NO_MULTI(h, "hipadj_comm_init_rank");
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_comm_init_rank: id != NULL and 0 <= rank < nranks required");
     if (!h->cfg.p_shared) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "per-trajectory parameters (p_shared = 0) have no cross-shard reduction: dp stays sharded like du0");
     RcclApi& A = rccl_api();
@@ -621,7 +632,7 @@ extern "C" int hipadj_comm_init_rank(hipadj_handle* h, const char* id, int nrank
 extern "C" int hipadj_comm_count(hipadj_handle* h, int* nranks) {
     if (!h || !nranks) return HIPADJ_ERR_INVALID_ARG;
     *nranks = 0;                                   // no communicator: the handle's dp is its shard's own sum
-    if (!h->comm) return HIPADJ_OK;
+    if (h->multi || !h->comm) return HIPADJ_OK;
     RcclApi& A = rccl_api();
     if (!A.err.empty()) { h->err = A.err; return HIPADJ_ERR_RCCL; }
     const int rc = A.CommCount(h->comm, nranks);
@@ -635,6 +646,7 @@ extern "C" int hipadj_comm_count(hipadj_handle* h, int* nranks) {
 // shows up here, before a gradient is wrong.  Synchronises the handle's stream.
 extern "C" int hipadj_comm_selfcheck(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    HIPADJ_NO_MULTI(h, "hipadj_comm_selfcheck");
     if (!h->comm) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_comm_selfcheck: the handle has no communicator");
     RcclApi& A = rccl_api();
     if (!A.err.empty()) { h->err = A.err; return HIPADJ_ERR_RCCL; }
@@ -672,6 +684,7 @@ extern "C" int hipadj_comm_selfcheck(hipadj_handle* h) {
 
 extern "C" int hipadj_comm_attach(hipadj_handle* h, void* nccl_comm) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    HIPADJ_NO_MULTI(h, "hipadj_comm_attach");
     if (nccl_comm && !h->cfg.p_shared) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "per-trajectory parameters (p_shared = 0) have no cross-shard reduction: dp stays sharded like du0");
     if (nccl_comm) { RcclApi& A = rccl_api(); if (!A.err.empty()) { h->err = A.err; return HIPADJ_ERR_RCCL; } }
     TRY(hipadj_comm_destroy(h));
@@ -681,6 +694,7 @@ extern "C" int hipadj_comm_attach(hipadj_handle* h, void* nccl_comm) {
 
 extern "C" int hipadj_destroy(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->multi) { (void)multi_synchronize(h); multi_free(h); delete h; return HIPADJ_OK; }
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipadj_comm_destroy(h);
@@ -691,6 +705,7 @@ extern "C" int hipadj_destroy(hipadj_handle* h) {
 
 extern "C" int hipadj_set_timing(hipadj_handle* h, int level) {
     if (!h || level < 0 || level > 2) return HIPADJ_ERR_INVALID_ARG;
+    for (hipadj_handle* c : h->shards) c->timing = level;
     h->timing = level;
     return HIPADJ_OK;
 }
@@ -712,6 +727,7 @@ static void harvest_timing(hipadj_handle* h, bool block) {
 
 extern "C" int hipadj_synchronize(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->multi) return multi_synchronize(h);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIP_TRY(h, hipStreamSynchronize(h->comm_stream));       // an overlapped all-reduce of dp (hipadj_comm_overlap)
@@ -729,6 +745,7 @@ extern "C" int hipadj_synchronize(hipadj_handle* h) {
 extern "C" int hipadj_get_stats(hipadj_handle* h, hipadj_stats* st) {
     if (!h || !st) return HIPADJ_ERR_INVALID_ARG;
     if (st->struct_size != sizeof(hipadj_stats)) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_stats.struct_size mismatch");
+    if (h->multi) return multi_get_stats(h, st);
     *st = h->st;
     return HIPADJ_OK;
 }
@@ -1466,6 +1483,7 @@ __global__ void k_test_delay_scale(double* __restrict__ dp, int np, long ticks) 
 extern "C" int hipadj_forward_dev(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!d_u0 || !d_p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
+    if (h->multi) return multi_forward_dev(h, d_u0, d_p, d_out);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     harvest_timing(h, false);
     // keep private copies: the adjoint needs p, and u0 may be released by the caller
@@ -1491,6 +1509,7 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
     if (!h->have_forward) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_adjoint called before hipadj_forward (the reverse pass consumes the forward solution)");
     if (!d_du0 || !d_dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !d_dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
+    if (h->multi) return multi_adjoint_dev(h, d_dLdu, d_du0, d_dp);
     if (h->cfg.loss_kind == HIPADJ_LOSS_LSQ_DATA && h->M > 0 && !h->have_ldata) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "loss_kind = HIPADJ_LOSS_LSQ_DATA: hand the data block over first (hipadj_set_loss_data / hipadj_set_loss_data_dev)");
     // device-resident losses: the workgroup families read the handle's data block in the cotangents' place (the lane family streams its transposed copy in d_cotT)
     if (h->cfg.loss_kind == HIPADJ_LOSS_LSQ_DATA || h->cfg.loss_kind == HIPADJ_LOSS_MODEL) d_dLdu = h->have_ldata ? h->d_ldata : nullptr;
@@ -1537,6 +1556,7 @@ static int loss_data_buffer(hipadj_handle* h) {
 extern "C" int hipadj_set_loss_data_dev(hipadj_handle* h, const double* d_data) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!d_data) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "data must be non-NULL");
+    if (h->multi) return multi_set_loss_data(h, d_data, true);
     TRY(loss_data_buffer(h));
     HIP_TRY(h, hipMemcpyAsync(h->d_ldata, d_data, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyDeviceToDevice, h->stream));
     return loss_data_install(h);
@@ -1544,6 +1564,7 @@ extern "C" int hipadj_set_loss_data_dev(hipadj_handle* h, const double* d_data) 
 extern "C" int hipadj_set_loss_data(hipadj_handle* h, const double* data) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!data) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "data must be non-NULL");
+    if (h->multi) return multi_set_loss_data(h, data, false);
     TRY(loss_data_buffer(h));
     HIP_TRY(h, hipMemcpyAsync(h->d_ldata, data, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
     TRY(loss_data_install(h));
@@ -1554,6 +1575,7 @@ extern "C" int hipadj_set_loss_data(hipadj_handle* h, const double* data) {
 extern "C" int hipadj_loss_value_dev(hipadj_handle* h, const double* d_out, double* d_loss) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!d_out || !d_loss) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "out and loss must be non-NULL");
+    if (h->multi) return multi_loss_value(h, d_out, d_loss, true);
     const int kind = h->cfg.loss_kind;
     if (kind == HIPADJ_LOSS_COTANGENT) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_loss_value: a cotangent handle does not know the loss (its gradient comes from the caller's AD)");
     if (kind == HIPADJ_LOSS_LSQ_DATA && !h->have_ldata) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_loss_value: hand the data block over first (hipadj_set_loss_data)");
@@ -1598,6 +1620,7 @@ extern "C" int hipadj_loss_value_dev(hipadj_handle* h, const double* d_out, doub
 extern "C" int hipadj_loss_value(hipadj_handle* h, const double* out, double* loss) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!out || !loss) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "out and loss must be non-NULL");
+    if (h->multi) return multi_loss_value(h, out, loss, false);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // d_io_a is the host API's staging block of [N][M][n]; one more double behind d_du0 carries the result
     HIP_TRY(h, hipMemcpyAsync(h->d_io_a, out, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
@@ -1609,12 +1632,14 @@ extern "C" int hipadj_loss_value(hipadj_handle* h, const double* out, double* lo
 
 extern "C" int hipadj_soa_stride(hipadj_handle* h, int64_t* ld) {
     if (!h || !ld) return HIPADJ_ERR_INVALID_ARG;
+    HIPADJ_NO_MULTI(h, "hipadj_soa_stride (the streaming layout is padded per shard)");
     if (h->wide || h->field || h->mlp) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "the streaming cotangent layout belongs to the lane-per-trajectory family; this handle's family reads [N][M][n] in place");
     *ld = h->Npad;
     return HIPADJ_OK;
 }
 extern "C" int hipadj_adjoint_dev_soa(hipadj_handle* h, const double* d_dLdu_soa, double* d_du0, double* d_dp) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    HIPADJ_NO_MULTI(h, "hipadj_adjoint_dev_soa (the streaming layout is padded per shard)");
     if (h->wide || h->field || h->mlp) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_adjoint_dev_soa: the streaming cotangent layout belongs to the lane-per-trajectory family; this handle's family reads [N][M][n] in place");
     if (h->cfg.loss_kind != HIPADJ_LOSS_COTANGENT || h->M <= 0) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_adjoint_dev_soa: the handle takes no cotangents (loss_kind / no loss times)");
     if (!d_dLdu_soa) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
@@ -1625,21 +1650,26 @@ extern "C" int hipadj_adjoint_dev_soa(hipadj_handle* h, const double* d_dLdu_soa
     return rc;
 }
 
-extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* p, double* out) {
-    if (!h) return HIPADJ_ERR_INVALID_ARG;
-    if (!u0 || !p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
+// host-pointer calls = enqueue (copies in, the device call, copies out: nothing here waits for the device) + hipadj_synchronize; a handle over several devices enqueues
+// on every shard before it drains any (hipadj_multi.hpp)
+static int forward_host_enqueue(hipadj_handle* h, const double* u0, const double* p, double* out) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
     HIP_TRY(h, hipMemcpyAsync(h->d_u0, u0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_p, p, pb, hipMemcpyHostToDevice, h->stream));
     TRY(hipadj_forward_dev(h, h->d_u0, h->d_p, out ? h->d_io_a : nullptr));
     if (out && h->M > 0) HIP_TRY(h, hipMemcpyAsync(out, h->d_io_a, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyDeviceToHost, h->stream));
+    return HIPADJ_OK;
+}
+extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* p, double* out) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!u0 || !p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
+    if (h->multi) return multi_forward(h, u0, p, out);
+    TRY(forward_host_enqueue(h, u0, p, out));
     return hipadj_synchronize(h);
 }
 
-extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0, double* dp) {
-    if (!h) return HIPADJ_ERR_INVALID_ARG;
-    if (!du0 || !dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
+static int adjoint_host_enqueue(hipadj_handle* h, const double* dLdu, double* du0, double* dp) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const bool cot = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0;
     if (cot && !dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
@@ -1651,5 +1681,15 @@ extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0,
     if (h->comm && h->comm_overlap && h->comm_stream && h->comm_seq > 0) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->comm_done[(h->comm_seq - 1) & 1], 0));
     HIP_TRY(h, hipMemcpyAsync(du0, h->d_du0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(dp, h->d_dp, pb, hipMemcpyDeviceToHost, h->stream));
+    return HIPADJ_OK;
+}
+extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0, double* dp) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (!du0 || !dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
+    if (h->multi) {
+        if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
+        return multi_adjoint(h, dLdu, du0, dp);
+    }
+    TRY(adjoint_host_enqueue(h, dLdu, du0, dp));
     return hipadj_synchronize(h);
 }

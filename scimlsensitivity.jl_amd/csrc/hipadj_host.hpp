@@ -110,6 +110,13 @@ struct hipadj_handle {
     const double* cot_soa = nullptr;      // set for the duration of a hipadj_adjoint_dev_soa call
     hipModule_t lmod = nullptr; hipFunction_t lf_value = nullptr;   // runtime model with a discrete-loss FUNCTION: its loss-value kernel (hipadj_loss_value)
     double* d_lpart = nullptr;            // per-workgroup partials of hipadj_loss_value
+    // ONE handle over several devices (hipadj_multi.hpp): the shards are ordinary handles on contiguous trajectory ranges; everything above is unused in a multi handle
+    // except cfg, n, np, N, M, the (primary) stream and err
+    bool multi = false;
+    std::vector<hipadj_handle*> shards; std::vector<long> shard_off; std::vector<int> dev_ids;
+    std::vector<hipEvent_t> shard_ev; hipEvent_t multi_in = nullptr;
+    double* d_dp_parts = nullptr;         // primary device: the shards' dp partials [G][np] + G doubles (loss values)
+    std::vector<double> dp_host;          // host-pointer calls: the shards' dp partials
     void* comm = nullptr;                 // ncclComm_t of the ensemble shards (hipadj_comm.hpp); dp is all-reduced over it
     bool comm_owned = false;
     // hipadj_comm_overlap: the all-reduce of dp on its own stream, off the critical path of the next reverse pass

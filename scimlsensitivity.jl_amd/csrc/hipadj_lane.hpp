@@ -1146,7 +1146,7 @@ struct GK15 {
 template <class Mo, class LT, int CC>
 HIPADJ_HD void gauss_core(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&ymid)[Mo::N], const double (&yg)[2][Mo::N], const double (&pv)[Mo::NP],
                           double t_lo, double dt, LT (&lam)[Mo::N], LT (&mu)[Mo::NP], bool aff,
-                          const double (&guh)[Mo::N], const double (&gum)[Mo::N], const double (&gul)[Mo::N]) {
+                          const double (&guh)[Mo::N], const double (&gum)[Mo::N], const double (&gul)[Mo::N], double gsgn = 1.0) {
     constexpr int N = Mo::N, NP = Mo::NP;
     using MV = model_vjp<Mo, LT>;
     const double xg = 0.5773502691896257645, t_hi = t_lo + dt;
@@ -1171,7 +1171,7 @@ HIPADJ_HD void gauss_core(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (
         if (cost_has_gp<CC>::value && aff) {   // + g_p at the node (affine column only); sign: DESIGN.md 6.5 — Gauss == Interpolating == Quadrature
             double gp[NP]; cost_grad_p<Mo, CC>(yg[q], pv, t_hi - th * dt, gp);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) cols_add_first(W[j], gp[j]);
+            for (int j = 0; j < NP; ++j) cols_add_first(W[j], gsgn * gp[j]);     // gsgn = -1: the reference's line as written (hipadj_config.reference_literal, gauss_lane)
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) mu[j] = mu[j] + (0.5 * dt) * W[j];
@@ -1179,11 +1179,11 @@ HIPADJ_HD void gauss_core(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (
 }
 template <class Mo, int NC, int C0, int G, int CC>
 HIPADJ_HD void gauss_bundles(const Knot<Mo>& hi, const Knot<Mo>& lo, const double (&ymid)[Mo::N], const double (&yg)[2][Mo::N], const double (&pv)[Mo::NP], double t_lo, double dt,
-                             double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP], const double (&guh)[Mo::N], const double (&gum)[Mo::N], const double (&gul)[Mo::N]) {
+                             double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP], const double (&guh)[Mo::N], const double (&gum)[Mo::N], const double (&gul)[Mo::N], double gsgn = 1.0) {
     constexpr int N = Mo::N, NP = Mo::NP;
     if constexpr (C0 < NC) {
         constexpr int W = (NC - C0 < G) ? NC - C0 : G;
-        if constexpr (W == 1) gauss_core<Mo, double, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam[C0], mu[C0], C0 == 0, guh, gum, gul);
+        if constexpr (W == 1) gauss_core<Mo, double, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam[C0], mu[C0], C0 == 0, guh, gum, gul, gsgn);
         else {
             Cols<W> L[N], M_[NP];
 #pragma unroll
@@ -1193,7 +1193,7 @@ HIPADJ_HD void gauss_bundles(const Knot<Mo>& hi, const Knot<Mo>& lo, const doubl
 #pragma unroll
                 for (int j = 0; j < NP; ++j) M_[j].v[g] = mu[C0 + g][j];
             }
-            gauss_core<Mo, Cols<W>, CC>(hi, lo, ymid, yg, pv, t_lo, dt, L, M_, C0 == 0, guh, gum, gul);
+            gauss_core<Mo, Cols<W>, CC>(hi, lo, ymid, yg, pv, t_lo, dt, L, M_, C0 == 0, guh, gum, gul, gsgn);
 #pragma unroll
             for (int g = 0; g < W; ++g) {
 #pragma unroll
@@ -1202,7 +1202,7 @@ HIPADJ_HD void gauss_bundles(const Knot<Mo>& hi, const Knot<Mo>& lo, const doubl
                 for (int j = 0; j < NP; ++j) mu[C0 + g][j] = M_[j].v[g];
             }
         }
-        gauss_bundles<Mo, NC, C0 + W, G, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam, mu, guh, gum, gul);
+        gauss_bundles<Mo, NC, C0 + W, G, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam, mu, guh, gum, gul, gsgn);
     }
 }
 
@@ -1228,6 +1228,9 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
     }
     const double dt = g.dt;
     const double xg = 0.5773502691896257645;
+    // g_p of a parameter-dependent continuous cost enters the quadrature with the sign of the other algorithms; hipadj_config.reference_literal (lflags bit 1)
+    // takes src/gauss_adjoint.jl:753-758 as written instead: -f_p' lam + g_p under the reversed-time sum, i.e. the opposite sign of the g_p term
+    const double gsgn = (g.lflags & 2) ? -1.0 : 1.0;
     // the loss jump of the affine column (interp_lane): lam += dgdu_discrete; the parameter part of a model's discrete loss goes to the quadrature accumulator
     auto jump_add = [&](bool jump, const double (&gl_in)[N], const double (&y)[N], double t, int s) {
         if constexpr (model_has_dloss<Mo>::value) {
@@ -1258,7 +1261,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
             if (CC) cost_grad_u<Mo, CC>(ymid, pv, t_lo + 0.5 * dt, gum);
 #pragma unroll
             for (int q = 0; q < 2; ++q) hermite<N>(1.0 - 0.5 * (1.0 + (q == 0 ? -xg : xg)), dt, lo.u, lo.f, hi.u, hi.f, yg[q]);
-            gauss_bundles<Mo, NC, 0, cols_bundle<N, NC, HIPADJ_COLS_ELEMS_GAUSS>::G, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam, mu, guh, gum, gul);
+            gauss_bundles<Mo, NC, 0, cols_bundle<N, NC, HIPADJ_COLS_ELEMS_GAUSS>::G, CC>(hi, lo, ymid, yg, pv, t_lo, dt, lam, mu, guh, gum, gul, gsgn);
             jump_add(jump, gl, lo.u, t_lo, s_loss);
             return;
         }
@@ -1292,7 +1295,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
                     if (cost_has_gp<CC>::value && c == 0) {   // + g_p at the node (affine column only); sign: DESIGN.md 6.5 — Gauss == Interpolating == Quadrature
                         double gp[NP]; cost_grad_p<Mo, CC>(yg[q], pv, t_hi - th * dt, gp);
 #pragma unroll
-                        for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                        for (int j = 0; j < NP; ++j) W[j] += gsgn * gp[j];
                     }
 #pragma unroll
                     for (int j = 0; j < NP; ++j) mu[c][j] += (0.5 * dt) * W[j];
@@ -1321,7 +1324,7 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
                         if (cost_has_gp<CC>::value && c == 0) {
                             double gp[NP]; cost_grad_p<Mo, CC>(yq, pv, t_hi - th * dt, gp);
 #pragma unroll
-                            for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                            for (int j = 0; j < NP; ++j) W[j] += gsgn * gp[j];
                         }
 #pragma unroll
                         for (int j = 0; j < NP; ++j) { IK[j] += GK15::WK[q] * W[j]; if (q & 1) IG[j] += GK15::WG[q / 2] * W[j]; }
@@ -1414,7 +1417,7 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
                 if (cost_has_gp<CC>::value && c == 0) {
                     double gp[NP]; cost_grad_p<Mo, CC>(yg[qn], pv, t - th * hs, gp);
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) W[j] += gp[j];
+                    for (int j = 0; j < NP; ++j) W[j] += ((g.lflags & 2) ? -1.0 : 1.0) * gp[j];
                 }
 #pragma unroll
                 for (int j = 0; j < NP; ++j) mu[c][j] += (0.5 * hs) * W[j];

@@ -20,11 +20,13 @@
 enum { O_struct_size = 0, O_model = 4, O_alg = 8, O_stepper = 12, O_dims = 16, O_ntraj = 32, O_t0 = 40, O_t1 = 48, O_dt = 56, O_nsave = 64,
        O_save_times = 72, O_loss_kind = 80, O_loss_shift = 88, O_checkpointing = 96, O_ckpt_stride = 100, O_quad_abstol = 104,
        O_quad_reltol = 112, O_no_start = 120, O_p_shared = 124, O_device = 128, O_time_segments = 132, O_cont_cost = 136,
-       O_max_steps = 140, O_abstol = 144, O_reltol = 152, O_ncheckpoints = 160, O_checkpoints = 168, CONFIG_SIZE = 176 };
+       O_max_steps = 140, O_abstol = 144, O_reltol = 152, O_ncheckpoints = 160, O_checkpoints = 168, O_loss_scale = 176, O_ndevices = 184,
+       O_device_ids = 192, O_reference_literal = 200, O_reserved1 = 204, CONFIG_SIZE = 208 };
 #define TIE(f) _Static_assert(offsetof(hipadj_config, f) == O_##f, "HIPAdj.CONFIG_OFFSETS disagrees with include/hipadj.h at " #f)
 TIE(struct_size); TIE(model); TIE(alg); TIE(stepper); TIE(dims); TIE(ntraj); TIE(t0); TIE(t1); TIE(dt); TIE(nsave); TIE(save_times);
 TIE(loss_kind); TIE(loss_shift); TIE(checkpointing); TIE(ckpt_stride); TIE(quad_abstol); TIE(quad_reltol); TIE(no_start); TIE(p_shared);
 TIE(device); TIE(time_segments); TIE(cont_cost); TIE(max_steps); TIE(abstol); TIE(reltol); TIE(ncheckpoints); TIE(checkpoints);
+TIE(loss_scale); TIE(ndevices); TIE(device_ids); TIE(reference_literal); TIE(reserved1);
 _Static_assert(sizeof(hipadj_config) == CONFIG_SIZE, "HIPAdj.CONFIG_SIZE disagrees with include/hipadj.h");
 
 #define PUT(buf, off, type, val) do { type v_ = (type)(val); memcpy((buf) + (off), &v_, sizeof(type)); } while (0)
@@ -37,6 +39,8 @@ static double lcg(unsigned long long *s) {
 int main(int argc, char **argv) {
     const long N = argc > 1 ? atol(argv[1]) : 96;
     const int alg = argc > 2 ? atoi(argv[2]) : HIPADJ_ALG_INTERPOLATING;
+    const int G = argc > 3 ? atoi(argv[3]) : 0;           /* > 1: Handle(...; devices = fill(0, G)) — ONE handle over G (virtual) shards, hipadj_config.device_ids (ABI 108) */
+    int32_t devs[64] = {0};
     enum { n = 3, np = 3, M = 11 };
     const double p[np] = {10.0, 28.0, 8.0 / 3.0};
     double ts[M];
@@ -75,6 +79,7 @@ int main(int argc, char **argv) {
     PUT(cfg, O_p_shared, int32_t, 1);
     PUT(cfg, O_abstol, double, 1e-6); PUT(cfg, O_reltol, double, 1e-3);
     PUT(cfg, O_checkpoints, const double *, NULL);
+    if (G > 1 && G <= 64) { PUT(cfg, O_ndevices, int32_t, G); PUT(cfg, O_device_ids, const int32_t *, devs); }
 
     rc = hipadj_create((const hipadj_config *)(const void *)cfg, &h);       /* ccall(:hipadj_create, Cint, (Ref{HipadjConfig}, Ref{Ptr{Cvoid}}), ...) */
     if (rc != HIPADJ_OK) { fprintf(stderr, "hipadj status %d: %s\n", rc, hipadj_last_error(NULL)); return 1; }   /* HIPAdj.check */

@@ -55,7 +55,7 @@ def lib():
 
 def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shift=0.0, checkpointing=False,
                 ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, p_shared=True, time_segments=1, cont_cost=0,
-                stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0, checkpoints=None):
+                stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0, checkpoints=None, loss_scale=0.0, reference_literal=False):
     from scimlsensitivity_jl_amd import _lib as PL
     save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
     c = PL.HipadjConfig()
@@ -65,7 +65,8 @@ def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shi
     c.t0, c.t1, c.dt = t0, t1, dt
     c.nsave = len(save)
     c.save_times = save.ctypes.data_as(C.POINTER(C.c_double)) if len(save) else None
-    c.loss_kind, c.loss_shift = loss_kind, loss_shift
+    c.loss_kind, c.loss_shift, c.loss_scale = loss_kind, loss_shift, loss_scale
+    c.reference_literal = int(bool(reference_literal))
     c.checkpointing, c.ckpt_stride = int(checkpointing), ckpt_stride
     c.quad_abstol, c.quad_reltol = quad_abstol, quad_reltol
     c.no_start, c.p_shared, c.device, c.time_segments = int(no_start), int(p_shared), 0, time_segments

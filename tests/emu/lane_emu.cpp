@@ -106,11 +106,12 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     constexpr int PF = EMU_PF;   // -DEMU_PF=2|4 exercises the shallow prefetch rings the runtime-compiled models use
     Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1; g.h_last = P.h_last;
+    { const double lw = cfg->loss_scale != 0.0 ? cfg->loss_scale : 1.0; g.la = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? lw : 0.0; g.lb = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? -lw : 1.0; g.lflags = (cfg->reference_literal && (cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD)) ? 3 : 0; }   // hipadj_create's rule (csrc/hipadj_api.hip)
     const long Np = P.Npad;
     std::vector<dbl2> knots(((cfg->alg != HIPADJ_ALG_BACKSOLVE && !P.ip_ckpt) || P.offgrid) ? (size_t)(P.S + 1) * N * Np : 0);
     std::vector<double> tile((size_t)((P.ck_longest > HIPADJ_CKPT_KMAX ? P.ck_longest : HIPADJ_CKPT_KMAX) + 1) * N);   // LDS tile, or the HBM slice of k_*_ckpt<..., GT = true>
     std::vector<double> ckpt((P.bs_ckpt || P.ip_ckpt || (P.offgrid && P.nck > 0)) ? (size_t)P.nck * N * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np);
-    std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0);
+    std::vector<double> cotT(cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT ? (size_t)P.M * N * Np : 0);
     std::vector<double> dp_traj((size_t)NP * Np, 0.0);
     for (long i = 0; i < P.N; ++i)
         forward_lane<Mo>(g, i, u0, p, knots.empty() ? nullptr : knots.data(), ckpt.empty() ? nullptr : ckpt.data(),
@@ -280,7 +281,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
             const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
             for (long i = 0; i < P.N; ++i) {
                 double lam[N];
-                quad_adj_offgrid_lane<Mo, LOSS>(g, i, p, knots.data(), cot, RS, adj.data(), lam);
+                { double gpo[NP]; quad_adj_offgrid_lane<Mo, LOSS>(g, i, p, knots.data(), cot, RS, adj.data(), lam, gpo); }
                 for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
                 double acc[NP]; for (int j = 0; j < NP; ++j) acc[j] = 0.0;
                 for (int q = 0; q < P.nq; ++q) {
@@ -294,7 +295,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         }
         for (long i = 0; i < P.N; ++i) {
             double lam[N];
-            quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot_rev.data(), adj.data(), lam);
+            { double gpo[NP]; quad_adj_lane<Mo, PF, LOSS>(g, i, p, knots.data(), cot, P.save_of_knot_rev.data(), adj.data(), lam, gpo); }
             for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
             double acc[NP]; for (int j = 0; j < NP; ++j) acc[j] = 0.0;
             for (int q = 0; q < P.nq; ++q) {
@@ -319,10 +320,11 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     constexpr int N = Mo::N, NP = Mo::NP, RW = 2 + 5 * N;
     AdaptGeom g; g.N = P.N; g.Npad = P.Npad; g.M = P.M; g.Smax = P.Smax; g.maxit = P.Smax; g.nck = P.nck; g.t0 = cfg->t0; g.t1 = cfg->t1; g.dt0 = cfg->dt;
     g.abstol = cfg->abstol; g.reltol = cfg->reltol; g.loss_shift = cfg->loss_shift; g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start;
+    { const double lw = cfg->loss_scale != 0.0 ? cfg->loss_scale : 1.0; g.la = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? lw : 0.0; g.lb = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? -lw : 1.0; g.lflags = (cfg->reference_literal && (cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD)) ? 3 : 0; }
     g.p_shared = cfg->p_shared; g.cont_cost = cfg->cont_cost; g.SmaxI = P.SmaxI;
     const long Np = P.Npad;
     std::vector<double> rec(ALG != 1 ? (size_t)(CK ? P.SmaxI : P.Smax) * RW * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np), ckpt((size_t)P.nck * N * Np);
-    std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
+    std::vector<double> cotT(cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
     std::vector<int> nsteps((size_t)Np, 0);
     int flag = 0;
     std::vector<double> kbuf((size_t)KS_ROWS * (2 * N + NP)), kfbuf((size_t)KS_ROWS * N);   // stage storage of one lane (LDS columns on the device), stride 1 here
@@ -406,7 +408,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 template <class Mo>
 int dispatch_mode(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out) {
     if (P.adaptive) return dispatch_adaptive<Mo>(cfg, P, u0, p, dLdu, du0, dp, out, nullptr);
-    const int mode = ((cfg->loss_kind == HIPADJ_LOSS_COTANGENT && P.M > 0) ? 0 : 1) | (cfg->cont_cost << 1);
+    const int mode = ((cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT && P.M > 0) ? 0 : 1) | (cfg->cont_cost << 1);
     switch (mode) {
     case 0: return run<Mo, 0>(cfg, P, u0, p, dLdu, du0, dp, out);
     case 1: return run<Mo, 1>(cfg, P, u0, p, dLdu, du0, dp, out);

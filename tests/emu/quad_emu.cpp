@@ -73,10 +73,11 @@ static int run_ts5(const hipadj_config* cfg, const Plan& P, const double* u0, co
     constexpr int N = Mo::N, NP = Mo::NP, RW = 2 + 5 * N;
     AdaptGeom g; g.N = P.N; g.Npad = P.Npad; g.M = P.M; g.Smax = P.Smax; g.maxit = P.Smax; g.nck = P.nck; g.t0 = cfg->t0; g.t1 = cfg->t1; g.dt0 = cfg->dt;
     g.abstol = cfg->abstol; g.reltol = cfg->reltol; g.loss_shift = cfg->loss_shift; g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start;
+    { const double lw = cfg->loss_scale != 0.0 ? cfg->loss_scale : 1.0; g.la = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? lw : 0.0; g.lb = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? -lw : 1.0; g.lflags = (cfg->reference_literal && (cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD)) ? 3 : 0; }
     g.p_shared = cfg->p_shared; g.cont_cost = cfg->cont_cost; g.SmaxI = P.SmaxI; g.SmaxA = 0;
     const long Np = P.Npad;
     std::vector<double> rec(ALG != 1 ? (size_t)P.Smax * RW * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np), ckpt((size_t)P.nck * N * Np);
-    std::vector<double> cotT(cfg->loss_kind == HIPADJ_LOSS_COTANGENT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
+    std::vector<double> cotT(cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
     std::vector<int> nsteps((size_t)Np, 0);
     int flag = 0;
     for (long i = 0; i < P.N; ++i) {
@@ -131,6 +132,7 @@ extern "C" int quad_emu_forward_rk4(const hipadj_config* cfg, const double* u0, 
     if (P.offgrid) { g_err = "quad emulator: loss times on the step grid"; return HIPADJ_ERR_UNSUPPORTED; }
     Geom g; g.N = P.N; g.Npad = P.Npad; g.S = P.S; g.M = P.M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared; g.kmask = -1; g.h_last = P.h_last;
+    { const double lw = cfg->loss_scale != 0.0 ? cfg->loss_scale : 1.0; g.la = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? lw : 0.0; g.lb = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? -lw : 1.0; g.lflags = (cfg->reference_literal && (cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD)) ? 3 : 0; }   // hipadj_create's rule (csrc/hipadj_api.hip)
     const long Np = P.Npad;
     std::vector<int> ek, es, ec;
     forward_events(P, cfg->dt, ek, es, ec);

@@ -62,8 +62,14 @@ def test_inner_retry_probe(tmp_path, monkeypatch):
     monkeypatch.setenv("HIPADJ_RTC_FLAGS", "-DHIPADJ_TS5_WIDE=64 -DHIPADJ_TS5_PADDED=1")   # the batched zero-padded stage sum of rounds 1-2: the code the old compiler mis-places
     cfg = E.make_config("ring4_lint_retry", "backsolve", 53, 0.0, 0.5, 0.0, [], loss_kind=1, stepper=1, abstol=1e-9, reltol=1e-9, checkpointing=False)
     L = _lib.load()
-    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+    rc = L.hipadj_model_check_config(C.byref(cfg))
     objs = sorted(glob.glob(str(tmp_path / "*.hsaco")))
+    if rc != _lib.OK:
+        # round 5: with the discrete-loss plumbing in the callback the old compiler mis-places the copies at -O1 as well — the guard's OTHER designed outcome: both builds
+        # flagged, the configuration is refused by name instead of running lanes on stale values (user_compile, attempt 1)
+        assert rc == _lib.ERR_UNSUPPORTED and b"register-spill copies ahead of an exec restore" in L.hipadj_last_error(None) and b"at -O3 and at -O1" in L.hipadj_last_error(None)
+        assert len(objs) == 2 and isa_lint.lint(objs[0]) != [] and isa_lint.lint(objs[1]) != []
+        return
     if len(objs) == 1:
         pytest.skip("this compiler build does not produce the flagged placement for the probe configuration")
     assert len(objs) == 2 and isa_lint.lint(objs[0]) != [] and isa_lint.lint(objs[1]) == []

@@ -54,7 +54,7 @@ def test_julia_struct_text_matches_header():
     c_offs = {m.group(1): int(m.group(2)) for m in re.finditer(r"O_(\w+) = (\d+)", c_src)}
     assert [c_offs[f] for f in c_fields] == offs                       # the C replay asserts THESE against offsetof() at compile time
     assert int(re.search(r"const CONFIG_SIZE = (\d+)", jl).group(1)) == int(re.search(r"CONFIG_SIZE = (\d+) \}", c_src).group(1))
-    assert "v == 107" in jl and "#define HIPADJ_VERSION 107" in hdr
+    assert "v == 108" in jl and "#define HIPADJ_VERSION 108" in hdr
 
 
 def test_julia_call_sequence_from_c_fails_loudly_without_a_device(tmp_path):
@@ -64,7 +64,7 @@ def test_julia_call_sequence_from_c_fails_loudly_without_a_device(tmp_path):
         pytest.skip("a GPU is present: the GPU variant of this test runs the sequence for real")
     exe = _build(sa, tmp_path)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
-    assert r.returncode == 1 and "hipadj status -2" in r.stderr and "no usable HIP device" in r.stderr and "version 107" in r.stdout
+    assert r.returncode == 1 and "hipadj status -2" in r.stderr and "no usable HIP device" in r.stderr and "version 108" in r.stdout
 
 
 @pytest.mark.gpu
@@ -90,6 +90,29 @@ def test_julia_call_sequence_from_c_matches_oracle(tmp_path, alg, oalg):
     assert rel(vals["out_last"], rout[-1, -1]) < 1e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", [0, 1, 2, 3])
+def test_julia_call_sequence_over_eight_virtual_shards(tmp_path, alg):
+    """ONE handle over several devices through the HOST-pointer calls the Julia binding makes (`Handle(...; devices = ...)`, hipadj_config.device_ids).
+    A 1-GPU box runs the eight shards as virtual shards on device 0: out and du0 are sliced, so they must equal the single-device run; dp is the sum of the
+    shards' partials in shard order — compared at 1e-12 (the summation order differs from the single handle's block tree)."""
+    import scimlsensitivity_jl_amd as sa
+    sa.build_extension()
+    exe = _build(sa, tmp_path)
+    N = 203        # not a multiple of 8: ragged ranges
+    runs = []
+    for G in (0, 8):
+        r = subprocess.run([exe, str(N), str(alg), str(G)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        runs.append({l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.strip().split("\n")})
+    one, eight = runs
+    rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    assert np.array_equal(one["out_last"], eight["out_last"])
+    # du0 of a trajectory does not depend on its neighbours — up to the planner's choice of time segments, which follows the shard's size: roundoff, not bits
+    assert rel(eight["du0_first"], one["du0_first"]) < 1e-12 and rel(eight["du0_last"], one["du0_last"]) < 1e-12
+    assert rel(eight["dp"], one["dp"]) < 1e-12
+
+
 def _build_model_calls(sa, tmp_path):
     exe = str(tmp_path / "julia_model_calls")
     libdir = os.path.dirname(sa.LIB_PATH)
@@ -105,7 +128,7 @@ def test_julia_model_calls_from_c(tmp_path):
     sa.build_extension()
     exe = _build_model_calls(sa, tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True)
-    assert "singular -6" in r.stdout and "version 107" in r.stdout
+    assert "singular -6" in r.stdout and "version 108" in r.stdout
     if not os.path.exists("/dev/kfd"):
         assert r.returncode == 1 and "hipadj status -2" in r.stderr and "no usable HIP device" in r.stderr
         return
