@@ -2,6 +2,7 @@
 // Host side only does validation, workspace ownership, launch sequencing and timing; all arithmetic is in
 // hipadj_lane.hpp / hipadj_kernels.hpp.  No CPU fallback exists: without a usable HIP device
 // hipadj_create returns HIPADJ_ERR_NO_DEVICE.
+#include <thread>
 #include "hipadj_host.hpp"
 #include "hipadj_plan.hpp"
 #include "hipadj_user.hpp"
@@ -246,6 +247,7 @@ static void free_all(hipadj_handle* h) {
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
     if (h->umod_alt) (void)hipModuleUnload(h->umod_alt);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->lmod) (void)hipModuleUnload(h->lmod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
@@ -522,6 +524,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->ag.la = g.la; h->ag.lb = g.lb; h->ag.lflags = g.lflags;
     h->wg.la = g.la; h->wg.lb = g.lb; h->wg.lflags = g.lflags;
     h->fg.lsq_w = lw; h->mg.lsq_w = lw;
+    if (h->d_cotT && (double)n * (double)Np * 8.0 >= 2147483648.0) { h->err = "the streamed cotangent / data column of one loss time (n x Npad doubles) must stay below 2 GiB per handle (buffer-descriptor range): shard the ensemble"; return fail(HIPADJ_ERR_UNSUPPORTED); }
     if (h->d_cotT && cfg->loss_kind != HIPADJ_LOSS_COTANGENT && hipMemset(h->d_cotT, 0, sizeof(double) * (size_t)h->M * n * Np) != hipSuccess) { h->err = "hipMemset failed"; return fail(HIPADJ_ERR_HIP); }
     if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
     {
@@ -1539,6 +1542,7 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
     return HIPADJ_OK;
 }
 
+static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size_t count);
 // ---- device-resident discrete losses: the data block, the loss value, cotangents in the streaming layout -----------------------------------------------
 static int loss_data_install(hipadj_handle* h) {   // h->d_ldata [N][M][n] is in place (stream order): the lane family's transposed copy
     const bool lane = !h->wide && !h->field && !h->mlp;
@@ -1566,7 +1570,7 @@ extern "C" int hipadj_set_loss_data(hipadj_handle* h, const double* data) {
     if (!data) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "data must be non-NULL");
     if (h->multi) return multi_set_loss_data(h, data, false);
     TRY(loss_data_buffer(h));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ldata, data, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
+    TRY(upload_block(h, h->d_ldata, data, (size_t)h->N * h->M * h->n));
     TRY(loss_data_install(h));
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // the caller's buffer may go away
     return HIPADJ_OK;
@@ -1623,7 +1627,7 @@ extern "C" int hipadj_loss_value(hipadj_handle* h, const double* out, double* lo
     if (h->multi) return multi_loss_value(h, out, loss, false);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // d_io_a is the host API's staging block of [N][M][n]; one more double behind d_du0 carries the result
-    HIP_TRY(h, hipMemcpyAsync(h->d_io_a, out, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
+    TRY(upload_block(h, h->d_io_a, out, (size_t)h->N * h->M * h->n));
     TRY(hipadj_loss_value_dev(h, h->d_io_a, h->d_du0));
     HIP_TRY(h, hipMemcpyAsync(loss, h->d_du0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1650,6 +1654,38 @@ extern "C" int hipadj_adjoint_dev_soa(hipadj_handle* h, const double* d_dLdu_soa
     return rc;
 }
 
+// Pinned staging of the host-pointer calls.  host_copy_par: memcpy by a few host threads (one thread moves ~10 GB/s, the link 50-60).
+static void host_copy_par(double* dst, const double* src, size_t count) {
+    const size_t bytes = count * sizeof(double);
+    unsigned nt = std::thread::hardware_concurrency(); nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
+    if (const char* e = std::getenv("HIPADJ_HOST_COPY_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
+    if (bytes < ((size_t)4 << 20) || nt == 1) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = (count + nt - 1) / nt;
+    for (unsigned t = 1; t < nt; ++t) { const size_t a = per * t, b = std::min(count, a + per); if (a < b) th.emplace_back([=] { std::memcpy(dst + a, src + a, (b - a) * sizeof(double)); }); }
+    std::memcpy(dst, src, std::min(per, count) * sizeof(double));
+    for (auto& x : th) x.join();
+}
+static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's pinned block, grown on demand; nullptr: no pinned memory to be had (the pageable copy still works)
+    if (h->pin_count >= count) return h->h_pin;
+    if (std::getenv("HIPADJ_NO_PINNED")) return nullptr;
+    if (h->h_pin) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->h_pin); h->h_pin = nullptr; h->pin_count = 0; }
+    void* q = nullptr;
+    if (hipHostMalloc(&q, count * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    h->h_pin = (double*)q; h->pin_count = count;
+    return h->h_pin;
+}
+// host -> device through the pinned block (src pageable); falls back to the plain pageable copy
+static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size_t count) {
+    double* pin = count * sizeof(double) >= ((size_t)1 << 20) ? host_pin(h, count) : nullptr;
+    if (pin) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));      // an earlier download out of the pinned block must have left it
+        host_copy_par(pin, src, count);
+        HIP_TRY(h, hipMemcpyAsync(d_dst, pin, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else HIP_TRY(h, hipMemcpyAsync(d_dst, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return HIPADJ_OK;
+}
+
 // host-pointer calls = enqueue (copies in, the device call, copies out: nothing here waits for the device) + hipadj_synchronize; a handle over several devices enqueues
 // on every shard before it drains any (hipadj_multi.hpp)
 static int forward_host_enqueue(hipadj_handle* h, const double* u0, const double* p, double* out) {
@@ -1673,7 +1709,7 @@ static int adjoint_host_enqueue(hipadj_handle* h, const double* dLdu, double* du
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const bool cot = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0;
     if (cot && !dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
-    if (cot) HIP_TRY(h, hipMemcpyAsync(h->d_io_a, dLdu, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyHostToDevice, h->stream));
+    if (cot) TRY(upload_block(h, h->d_io_a, dLdu, (size_t)h->N * h->M * h->n));
     TRY(hipadj_adjoint_dev(h, cot ? h->d_io_a : nullptr, h->d_du0, h->d_dp));
     const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
     // an overlapped all-reduce (hipadj_comm_overlap) runs on the handle's SECOND stream: the copy of dp below is enqueued on the first one and has to wait for the collective

@@ -102,12 +102,20 @@ __device__ __forceinline__ void pair_load_sc1(RS rs, int voff, int soff, double&
     a = __hiloint2double((int)v.y, (int)v.x); b = __hiloint2double((int)v.w, (int)v.z);
 }
 
+#ifndef HIPADJ_TREE_ACQREL
+#define HIPADJ_TREE_ACQREL 0      // 1: the conforming acquire-release ticket (A/B builds: scripts/r5/ab_variants.sh measures its cost)
+#endif
 // one wave: ticket on `ctr`; true on every lane iff this wave is the last of `expected` arrivers (then the counter is reset).
 // The caller has issued its payload stores; they are drained here before the ticket is drawn.
 __device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, unsigned expected) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through payload stores have left the CU
     unsigned old = 0;
+#if HIPADJ_TREE_ACQREL
+    // the language-level form: an agent-scope acquire-release RMW — the compiler adds the L2 write-back in front and the L1 invalidate behind it
+    if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
     if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
     // compiler-level ordering: the last arriver's sc1 loads of the children's payloads sit behind the control dependency on `old` AND behind this
     // barrier, so no compiler version may hoist them above the ticket; the hardware side is the guide's recipe (16-byte sc1 stores drained before the ticket,

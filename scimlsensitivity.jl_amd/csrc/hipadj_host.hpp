@@ -108,6 +108,10 @@ struct hipadj_handle {
     // kernels stream it like a cotangent block); workgroup families: d_ldata [N][M][n] in the caller's layout, handed to the kernels in the cotangents' place
     double* d_ldata = nullptr; bool have_ldata = false;
     const double* cot_soa = nullptr;      // set for the duration of a hipadj_adjoint_dev_soa call
+    // host-pointer calls: the [N][M][n] block (cotangents up, out = sol(ts) down) goes through a PINNED staging buffer of the handle — the caller's arrays are pageable
+    // (a Julia / numpy array), and a pageable hipMemcpyAsync of 24 MB ran at 3 GB/s (profiles/r5_visit1_bench.json: 7.7 ms for the Delta of BASELINE configs[1] against 0.39 ms
+    // of link time); host threads copy into the pinned block, ONE DMA moves it
+    double* h_pin = nullptr; size_t pin_count = 0;
     hipModule_t lmod = nullptr; hipFunction_t lf_value = nullptr;   // runtime model with a discrete-loss FUNCTION: its loss-value kernel (hipadj_loss_value)
     double* d_lpart = nullptr;            // per-workgroup partials of hipadj_loss_value
     // ONE handle over several devices (hipadj_multi.hpp): the shards are ordinary handles on contiguous trajectory ranges; everything above is unused in a multi handle

@@ -112,8 +112,10 @@ __global__ void HIPADJ_KINTERP_ATTR __launch_bounds__(WAVE * WPB) k_interp(Geom 
 // The same sweep as ONE launch per reverse pass: every wave hands its segment map to the composition tree of hipadj_fused.hpp
 // instead of a segment buffer for k_compose_finish* / k_reduce_final.  Grid (wave blocks, segments), 64-thread workgroups; lanes
 // beyond the ensemble (the padding of the last block) run on the padded tiles and are masked where results leave the wave.
+// PSH (the stage-operator form of the compiled-in Lorenz model, the headline kernels): at least two wavefronts per SIMD, i.e. at most 256 VGPRs — the column-streaming
+// instantiation came out at 260 once the loss gradient became la u + lb c (round 5), which halves the residency for four registers
 template <class Mo, int PF, int LOSS, bool SEG = true, bool PSH = false>
-__global__ void HIPADJ_KINTERP_ATTR __launch_bounds__(WAVE) k_interp_fused(Geom g, SegPlan sp, TreePlan tp, const double* __restrict__ p,
+__global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(PSH ? 2 : 1))) __launch_bounds__(WAVE) k_interp_fused(Geom g, SegPlan sp, TreePlan tp, const double* __restrict__ p,
                                                        const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                                                        const int* __restrict__ save_of_knot, double* __restrict__ du0,
                                                        double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {

@@ -487,12 +487,32 @@ HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double
 //                            => L2 hits, no extra HBM traffic)
 // A final partial block (< PF steps) runs the same body under per-step guards.
 // ------------------------------------------------------------------------------------------------
+// The streamed column (cotangents, or the data of a device-resident loss) of loss time s for trajectory i; s < 0: the step is no loss time and the value is never used.
+// On the device the column comes through a BUFFER descriptor over the one row block [N][Npad] of that loss time, whose size is ZERO when s < 0: an out-of-range buffer
+// load returns 0 without touching memory.  Round 4 loaded column 0 on the nine of ten steps that are no loss time ("L2 hits, no extra HBM traffic") — three more
+// lane-strided loads per step through the L1 fill path next to the three of the knot: the cotangent sweep ran 21 % behind the fused-loss sweep for 5 % more HBM bytes
+// (profiles/r5_visit1_bench.json).  The descriptor also takes the 64-bit lane address arithmetic (two VALU instructions per load) off the vector pipe.
+#ifndef HIPADJ_COT_BUFFER
+#define HIPADJ_COT_BUFFER 1      // 0: the round-4 form (A/B builds)
+#endif
 template <class Mo, int LOSS>
 HIPADJ_HD void load_cot(const Geom& g, long i, int s, const double* __restrict__ cotT, double (&c)[Mo::N]) {
     if (LOSS == 0) {
         const int sc = s > 0 ? s : 0;
+#if defined(__HIP_DEVICE_COMPILE__) && HIPADJ_COT_BUFFER
+        typedef unsigned int cot_u2 __attribute__((ext_vector_type(2)));
+        const int row_bytes = (int)(g.Npad * 8);                                   // < 2^31 / N: hipadj_create checks
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(cotT + (long)sc * Mo::N * g.Npad), 0, s >= 0 ? Mo::N * row_bytes : 0, 0x00020000);
+        const int voff = (int)i * 8;
+#pragma unroll
+        for (int j = 0; j < Mo::N; ++j) {
+            const cot_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, j * row_bytes, 0);
+            c[j] = __hiloint2double((int)v.y, (int)v.x);
+        }
+#else
 #pragma unroll
         for (int j = 0; j < Mo::N; ++j) c[j] = cotT[((long)sc * Mo::N + j) * g.Npad + i];
+#endif
     } else {
 #pragma unroll
         for (int j = 0; j < Mo::N; ++j) c[j] = 0.0;
