@@ -485,7 +485,7 @@ def loss_paths(sa, torch, args, u0_np, p_np, local_rank, headline_ms):
     """The SAME 10^4-trajectory reverse pass through every route a caller's loss can take, each as a sustained loop like the headline:
       lsq_data_device   sum(abs2, sol .- data) with the data block resident in the handle (HIPADJ_LOSS_LSQ_DATA): no cotangents, one launch
       cotangent_soa     Delta on the device already in the streaming layout (hipadj_adjoint_dev_soa): one launch
-      cotangent_path    Delta on the device as [N][M][n] (the AD pullback's shape): the transposition launch + the sweep
+      cotangent_path    Delta on the device as [N][M][n] (the AD pullback's shape): transposed inside the sweep, one launch
       host_api          hipadj_forward / hipadj_adjoint with HOST pointers — what the Julia binding calls (julia/HIPAdj/src/HIPAdj.jl): Delta upload, du0 / dp download included,
                         with the PCIe bound of the bytes that cross the link."""
     N = len(u0_np); ts = save_times(); M = len(ts); n = 3
@@ -550,7 +550,7 @@ def loss_paths(sa, torch, args, u0_np, p_np, local_rank, headline_ms):
     out["cotangent_soa"] = dict(ms_per_step=ms_soa, over_headline=ms_soa / headline_ms, frac_of_hbm_peak=by / (ms_soa * 1e-3) / 1e9 / HBM_PEAK_GBS, bit_identical_to_cotangent_path=bool(torch.equal(ref_du0, du0)),
                                 note="Delta handed over as [M][n][ld] (hipadj_adjoint_dev_soa): the sweep reads it in place, one launch")
     out["cotangent_path"] = dict(ms_per_step=ms_aos, over_headline=ms_aos / headline_ms, transposition_ms=ms_aos - ms_soa, extra_hbm_bytes=2.0 * N * M * n * 8,
-                                 note="Delta as [N][M][n] (the pullback's shape): k_aos_to_soa (reads and writes the block once more) + the sweep")
+                                 note="Delta as [N][M][n] (the pullback's shape): every sweep wave transposes the slice of its own knots on the way in (cot_transpose_slice; HIPADJ_COT_INSWEEP=0: the k_aos_to_soa launch of round 4)")
     # --- the host-pointer API the Julia binding calls: pageable host arrays in, host arrays out
     delta_h = delta.cpu().numpy()
     eng.set_timing(0)

@@ -2,6 +2,7 @@
 // Host side only does validation, workspace ownership, launch sequencing and timing; all arithmetic is in
 // hipadj_lane.hpp / hipadj_kernels.hpp.  No CPU fallback exists: without a usable HIP device
 // hipadj_create returns HIPADJ_ERR_NO_DEVICE.
+#include <chrono>
 #include <thread>
 #include "hipadj_host.hpp"
 #include "hipadj_plan.hpp"
@@ -247,7 +248,7 @@ static void free_all(hipadj_handle* h) {
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
     if (h->umod_alt) (void)hipModuleUnload(h->umod_alt);
-    if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->h_pin) { (void)hipHostUnregister(h->h_pin); std::free(h->h_pin); }
     if (h->lmod) (void)hipModuleUnload(h->lmod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
@@ -525,7 +526,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     h->wg.la = g.la; h->wg.lb = g.lb; h->wg.lflags = g.lflags;
     h->fg.lsq_w = lw; h->mg.lsq_w = lw;
     if (h->d_cotT && (double)n * (double)Np * 8.0 >= 2147483648.0) { h->err = "the streamed cotangent / data column of one loss time (n x Npad doubles) must stay below 2 GiB per handle (buffer-descriptor range): shard the ensemble"; return fail(HIPADJ_ERR_UNSUPPORTED); }
-    if (h->d_cotT && cfg->loss_kind != HIPADJ_LOSS_COTANGENT && hipMemset(h->d_cotT, 0, sizeof(double) * (size_t)h->M * n * Np) != hipSuccess) { h->err = "hipMemset failed"; return fail(HIPADJ_ERR_HIP); }
+    if (h->d_cotT && hipMemset(h->d_cotT, 0, sizeof(double) * (size_t)h->M * n * Np) != hipSuccess) { h->err = "hipMemset failed"; return fail(HIPADJ_ERR_HIP); }
     if (const char* e = std::getenv("HIPADJ_TIMING")) h->timing = std::atoi(e);
     {
         int cus = 256, mode = 1;
@@ -963,7 +964,13 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
     double* no_sum = nullptr;
     const double* cotT = h->cot_soa ? h->cot_soa : h->d_cotT;   // hipadj_adjoint_dev_soa: the caller's block, already in the streaming layout
-    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    // cotangents as [N][M][n]: the one-launch sweeps transpose their own slices on the way in (cot_transpose_slice), the other sequences keep the transposition launch
+    static const bool insweep_on = []() { const char* e = std::getenv("HIPADJ_COT_INSWEEP"); return !(e && e[0] == '0'); }();
+    const bool cot_aos_in = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa;
+    const bool insweep = cot_aos_in && insweep_on && !h->adaptive && !h->offgrid && h->fused && h->d_tbuf && h->cfg.alg != HIPADJ_ALG_QUADRATURE;   // = the one-launch branch below
+    Geom gk = h->g;
+    if (insweep) { gk.cot_aos = d_cot; gk.cot_wr = h->d_cotT; }
+    if (cot_aos_in && !insweep) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
     harvest_set(h, es, true);
@@ -1005,10 +1012,10 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
             double* dps = h->cfg.p_shared ? d_dp : (double*)nullptr;
             if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
-                TRY(usig<decltype(&k_backsolve_fused<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+                TRY(usig<decltype(&k_backsolve_fused<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), gk, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
                             cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag));
             else
-                TRY(usig<decltype(&k_interp_fused<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
+                TRY(usig<decltype(&k_interp_fused<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), gk, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
                             d_du0, dp_rows, dps, h->d_flag));
             if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
             if (h->has_mm) {
@@ -1669,9 +1676,13 @@ static void host_copy_par(double* dst, const double* src, size_t count) {
 static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's pinned block, grown on demand; nullptr: no pinned memory to be had (the pageable copy still works)
     if (h->pin_count >= count) return h->h_pin;
     if (std::getenv("HIPADJ_NO_PINNED")) return nullptr;
-    if (h->h_pin) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->h_pin); h->h_pin = nullptr; h->pin_count = 0; }
+    if (h->h_pin) { (void)hipStreamSynchronize(h->stream); (void)hipHostUnregister(h->h_pin); std::free(h->h_pin); h->h_pin = nullptr; h->pin_count = 0; }
+    // ordinary (cached) pages, registered with the runtime: hipHostMalloc's default block is fine-grained coherent memory, which the host WRITES at a fraction of its memcpy rate
+    // (measured: the staged upload took 12.5 ms against 7.7 ms for the plain pageable copy, profiles/r5_visit2_bench.json)
     void* q = nullptr;
-    if (hipHostMalloc(&q, count * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (posix_memalign(&q, 4096, count * sizeof(double)) != 0 || !q) return nullptr;
+    std::memset(q, 0, count * sizeof(double));                                  // touch the pages before they are pinned
+    if (hipHostRegister(q, count * sizeof(double), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); std::free(q); return nullptr; }
     h->h_pin = (double*)q; h->pin_count = count;
     return h->h_pin;
 }
@@ -1679,9 +1690,18 @@ static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's p
 static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size_t count) {
     double* pin = count * sizeof(double) >= ((size_t)1 << 20) ? host_pin(h, count) : nullptr;
     if (pin) {
+        static const bool trace = std::getenv("HIPADJ_HOST_TIMING") != nullptr;      // diagnosis: where a host-pointer call spends its time (stderr)
         HIP_TRY(h, hipStreamSynchronize(h->stream));      // an earlier download out of the pinned block must have left it
+        const auto t0 = std::chrono::steady_clock::now();
         host_copy_par(pin, src, count);
+        const auto t1 = std::chrono::steady_clock::now();
         HIP_TRY(h, hipMemcpyAsync(d_dst, pin, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (trace) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            const auto t2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "hipadj upload_block: %.1f MB, host copy into the pinned block %.3f ms, DMA %.3f ms\n", count * 8.0 / 1e6,
+                         std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+        }
     } else HIP_TRY(h, hipMemcpyAsync(d_dst, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return HIPADJ_OK;
 }

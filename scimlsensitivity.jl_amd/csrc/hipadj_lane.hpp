@@ -51,6 +51,9 @@ struct Geom {
     double la, lb;     // the loss gradient of the kinds that stream a column c (cotangent or data) next to the state u:  dgdu = la u + lb c  — (0, 1) cotangent and model bodies
                        // (which get the raw data column), (w, -w) HIPADJ_LOSS_LSQ_DATA with scale w.  la = 0, lb = 1 returns c bit for bit (0 u + 1 c, u finite)
     int lflags;        // bit 0: drop dgdp_discrete (hipadj_config.reference_literal on GaussAdjoint)
+    // the cotangent block as the AD pullback hands it, [N][M][n], and the handle's streaming buffer [M][n][Npad]: set (per launch) when the one-launch sweeps transpose
+    // their own slices on the way in (hipadj_kernels.hpp cot_transpose_slice); null otherwise
+    const double* cot_aos = nullptr; double* cot_wr = nullptr;
     double h_last;     // length of the LAST forward step [t_{S-1}, T]: = dt, or the remainder when the span is not a multiple of dt (the reference's
                        // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
 };

@@ -277,3 +277,20 @@ def bodies(f, n, np_, auto_vjp=False, bundle=False):
     # models have had their GPU parity run) a lam term held in a temporary forces the per-column form, which is what every GPU test of round 2 exercised
     real = "auto" if bundle else "double"
     return emit(outs, "du"), emit(vjp_graphs(outs, u, lam), "out", real=real), emit(vjp_graphs(outs, p, lam), "out", real=real)
+
+
+def discrete_loss_bodies(l, n, np_):
+    """A discrete loss written in the host language, `l(u, p, t, i, d) -> scalar` (u, p, d indexable; t the loss time; i its 0-based index as a real number; d the data
+    column of this trajectory and time), traced once: returns (dgdu_body, dgdp_body, l_body) for hipadj_model_set_discrete_loss[_function] - the gradients by reverse-mode
+    differentiation of the recorded graph, the loss itself for the device-side value (hipadj_loss_value).  The reference evaluates the user's dgdu_discrete / dgdp_discrete
+    closures on the host per loss time (src/adjoint_common.jl:771-779); here they become device text once."""
+    u = [Node("var", name=f"u[{k}]") for k in range(n)]
+    p = [Node("var", name=f"p[{k}]") for k in range(np_)]
+    d = [Node("var", name=f"d[{k}]") for k in range(n)]
+    t = Node("var", name="t")
+    i = Node("var", name="(double)i")
+    out = _n(l(u, p, t, i, d))
+    gu = vjp_graphs([out], u, [_n(1.0)])
+    gp = vjp_graphs([out], p, [_n(1.0)])
+    lb = "real l_[1]; " + emit([out], "l_", real="real") + " l = l_[0];"      # emit assigns an array; the body's result variable is the scalar `l`
+    return emit(gu, "out"), emit(gp, "out"), lb

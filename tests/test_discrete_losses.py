@@ -116,3 +116,42 @@ def test_wide_model_with_a_discrete_loss_body_compiles_for_gfx950(sa):
         c = _cfg(sa, f.id, alg, stepper, ts)
         rc = L.hipadj_model_check_config(C.byref(c))
         assert rc == 0, L.hipadj_last_error(None).decode()[:2000]
+
+
+def test_traced_discrete_loss_bodies_are_the_gradients_of_the_callable():
+    """trace.discrete_loss_bodies: the emitted dgdu / dgdp text of a host-language loss l(u, p, t, i, d), evaluated as C, equals central differences of the callable, and the
+    emitted loss body returns its value (compiled with gcc: the same text the device compiles)."""
+    import ctypes, math, subprocess, tempfile
+    from scimlsensitivity_jl_amd import trace
+
+    def l(u, p, t, i, d, sin=trace.sin):
+        return (i + 1.0) * p[0] * u[0] * u[1] + sin(t) * u[0] + p[1] ** 2 * d[0] * u[1] + u[1] / (1.0 + d[1] * d[1])
+    gu, gp, lb = trace.discrete_loss_bodies(l, 2, 4)
+    src = f"""#include <math.h>
+typedef double real;
+void dgdu(double* out, const double* u, const double* p, double t, int i, const double* d) {{ {gu} }}
+void dgdp(double* out, const double* u, const double* p, double t, int i, const double* d) {{ {gp} }}
+double lval(const double* u, const double* p, double t, int i, const double* d) {{ real l = 0.0; {lb} return l; }}
+"""
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "dl.c"); so = os.path.join(td, "dl.so")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-O1", "-shared", "-fPIC", c, "-o", so, "-lm"], check=True)
+        L = ctypes.CDLL(so)
+        A = ctypes.POINTER(ctypes.c_double)
+        L.lval.restype = ctypes.c_double
+        for fn in (L.dgdu, L.dgdp, L.lval):
+            fn.argtypes = [A, A, A, ctypes.c_double, ctypes.c_int, A][(0 if fn is not L.lval else 1):]
+        u = np.array([1.3, 0.7]); p = np.array([1.5, 1.0, 3.0, 1.0]); d = np.array([0.9, 1.7]); t = 2.5; i = 3
+        ptr = lambda a: a.ctypes.data_as(A)
+        f = lambda uu, pp: l(uu, pp, t, float(i), d, sin=math.sin)
+        assert abs(L.lval(ptr(u), ptr(p), t, i, ptr(d)) - f(u, p)) < 1e-14
+        out_u = np.zeros(2); out_p = np.zeros(4)
+        L.dgdu(ptr(out_u), ptr(u), ptr(p), t, i, ptr(d)); L.dgdp(ptr(out_p), ptr(u), ptr(p), t, i, ptr(d))
+        h = 1e-6
+        for j in range(2):
+            e = np.zeros(2); e[j] = h
+            assert abs(out_u[j] - (f(u + e, p) - f(u - e, p)) / (2 * h)) < 1e-8
+        for j in range(4):
+            e = np.zeros(4); e[j] = h
+            assert abs(out_p[j] - (f(u, p + e) - f(u, p - e)) / (2 * h)) < 1e-8

@@ -36,6 +36,9 @@ def _lv_with_loss(sa, how):
             f.set_discrete_loss(dgdu=FULL_DGDU, dgdp=FULL_DGDP)
         elif how == "function":
             f.set_discrete_loss(l=FULL_L)
+        elif how in ("traced", "traced_value"):      # the same loss as a host-language callable, traced once (trace.discrete_loss_bodies)
+            from scimlsensitivity_jl_amd import trace
+            f.set_discrete_loss(l=lambda u, p, t, i, d: (i + 1.0) * p[0] * u[0] * u[1] + trace.sin(t) * u[0] + p[1] ** 2 * d[0] * u[1], value=(how == "traced_value"))
         elif how == "u1sq_p1":      # test/Core7/mixed_costs.jl:199-227
             f.set_discrete_loss(dgdu="out[0] = 2.0 * u[0]; out[1] = 0.0;", dgdp="out[0] = 1.0; out[1] = 0.0; out[2] = 0.0; out[3] = 0.0;")
         elif how == "lsq":          # sum(abs2, sol .- data) as a model body: must equal the built-in HIPADJ_LOSS_LSQ_DATA
@@ -122,7 +125,7 @@ def test_lsq_data_loss_on_the_workgroup_families(sa, alg, oalg):
 
 @pytest.mark.parametrize("stepper", ["rk4", "tsit5"])
 @pytest.mark.parametrize("alg,oalg", ALGS + [("gausskronrod", "GAUSS_KRONROD")])
-@pytest.mark.parametrize("how", ["bodies", "function"])
+@pytest.mark.parametrize("how", ["bodies", "function", "traced", "traced_value"])
 def test_model_discrete_loss_bodies_on_the_lane_family(sa, alg, oalg, stepper, how):
     """dgdu_discrete + dgdp_discrete as device bodies (or the loss itself, differentiated by dual numbers) inside the sweeps — every sensealg, both steppers — against the
     oracle's test loss 4 and, on the reference's own problem (test/Core7/mixed_costs.jl:10-16), against scipy forward sensitivities."""
@@ -140,7 +143,7 @@ def test_model_discrete_loss_bodies_on_the_lane_family(sa, alg, oalg, stepper, h
     loss = sa.ModelLoss(data)
     sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 10.0), p), u0), alg_obj, saveat=ts, sensealg=sens, dgdu_discrete=loss, save_start=False, save_end=False, **kw)
     du0, dp = sa.adjoint_sensitivities(sol, alg_obj, t=ts, dgdu_discrete=loss)
-    if how == "function":
+    if how in ("function", "traced_value"):
         k = np.arange(1, len(ts) + 1)[None, :]
         want = np.sum(k * p[0] * sol.u[:, :, 0] * sol.u[:, :, 1] + np.sin(ts)[None, :] * sol.u[:, :, 0] + p[1] ** 2 * data[:, :, 0] * sol.u[:, :, 1])
         assert abs(sol.loss_value() - want) <= 1e-12 * abs(want)
