@@ -964,12 +964,12 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
     double* no_sum = nullptr;
     const double* cotT = h->cot_soa ? h->cot_soa : h->d_cotT;   // hipadj_adjoint_dev_soa: the caller's block, already in the streaming layout
-    // cotangents as [N][M][n]: the one-launch sweeps transpose their own slices on the way in (cot_transpose_slice), the other sequences keep the transposition launch
-    static const bool insweep_on = []() { const char* e = std::getenv("HIPADJ_COT_INSWEEP"); return !(e && e[0] == '0'); }();
+    // cotangents as [N][M][n]: the one-launch sweeps read them in place (load_cot / loss_grad), the other sequences keep the transposition launch
+    static const bool insweep_on = []() { const char* e = std::getenv("HIPADJ_COT_INPLACE"); return !(e && e[0] == '0'); }();
     const bool cot_aos_in = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa;
-    const bool insweep = cot_aos_in && insweep_on && !h->adaptive && !h->offgrid && h->fused && h->d_tbuf && h->cfg.alg != HIPADJ_ALG_QUADRATURE;   // = the one-launch branch below
+    const bool insweep = cot_aos_in && (double)h->N * h->M * h->n * 8.0 < 2147483648.0 && insweep_on && !h->adaptive && !h->offgrid && h->fused && h->d_tbuf && h->cfg.alg != HIPADJ_ALG_QUADRATURE;   // = the one-launch branch below
     Geom gk = h->g;
-    if (insweep) { gk.cot_aos = d_cot; gk.cot_wr = h->d_cotT; }
+    if (insweep) gk.cot_aos = d_cot;
     if (cot_aos_in && !insweep) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;

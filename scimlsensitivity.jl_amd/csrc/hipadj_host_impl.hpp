@@ -77,16 +77,16 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     // the column the sweep streams at the loss times: the caller's block already in the streaming layout (hipadj_adjoint_dev_soa), or the handle's own buffer — cotangents
     // transposed here per pass, or the data block of a device-resident loss transposed ONCE by hipadj_set_loss_data
     const double* cotT = h->cot_soa ? h->cot_soa : h->d_cotT;
-    // cotangents in the pullback's layout [N][M][n]: the one-launch sweeps transpose their own slices on the way in (hipadj_kernels.hpp cot_transpose_slice), every other
-    // sequence keeps the transposition launch.  HIPADJ_COT_INSWEEP=0: always the launch (A/B)
-    static const bool insweep_on = []() { const char* e = std::getenv("HIPADJ_COT_INSWEEP"); return !(e && e[0] == '0'); }();
+    // cotangents in the pullback's layout [N][M][n]: the one-launch sweeps read them in place (hipadj_lane.hpp load_cot / loss_grad), every other sequence keeps the
+    // transposition launch.  HIPADJ_COT_INPLACE=0: always the launch (A/B)
+    static const bool insweep_on = []() { const char* e = std::getenv("HIPADJ_COT_INPLACE"); return !(e && e[0] == '0'); }();
     const bool one_launch = h->fused && h->d_tbuf && !h->offgrid && !h->ip_ckpt &&
                             ((h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->wpb4) || h->cfg.alg == HIPADJ_ALG_BACKSOLVE || h->cfg.alg == HIPADJ_ALG_GAUSS ||
                              h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD);
     const bool cot_aos_in = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa;
-    const bool insweep = cot_aos_in && one_launch && insweep_on;
+    const bool insweep = cot_aos_in && one_launch && insweep_on && (double)h->N * h->M * h->n * 8.0 < 2147483648.0;
     Geom gk = h->g;                             // the geometry of THIS launch
-    if (insweep) { gk.cot_aos = d_cot; gk.cot_wr = h->d_cotT; }
+    if (insweep) gk.cot_aos = d_cot;
     if (cot_aos_in && !insweep) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;

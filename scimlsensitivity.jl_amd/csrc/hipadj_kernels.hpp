@@ -109,34 +109,6 @@ __global__ void HIPADJ_KINTERP_ATTR __launch_bounds__(WAVE * WPB) k_interp(Geom 
     }
 }
 
-// The cotangents of the AD pullback arrive as [N][M][n] (src/concrete_solve.jl:842-851: Delta[:, i] per trajectory), the sweeps stream [M][n][Npad].  Until round 5 a
-// transposition kernel stood between the two: one more launch and the block read and written once more (15 us next to a 110 us sweep, profiles/r5_visit2_bench.json).  The
-// one-launch sweeps now transpose ON THE WAY IN: every (trajectory block, time segment) wave needs exactly the loss times of ITS knots, for its 64 trajectories — each lane
-// reads its own trajectory's contiguous run of (s_hi - s_lo + 1) n doubles (in flight together, up to 24 at a time) and writes them into the rows of the streaming buffer
-// that this wave — and only this wave — will read back: 512-byte coalesced rows, ordered behind a drained vmcnt.  Every loss time belongs to exactly one segment
-// (the jump at a segment's lower knot is taken by that segment, hipadj_lane.hpp), so the waves write disjoint rows.
-template <int N>
-__device__ __forceinline__ void cot_transpose_slice(const Geom& g, long i_raw, int k_lo, int k_last, const int* __restrict__ save_of_knot) {
-    int s_lo = -1, s_hi = -1;
-    for (int k = k_lo; k <= k_last; ++k) { const int s = save_of_knot[k]; if (s >= 0) { s_lo = s; break; } }
-    if (s_lo < 0) return;                                                  // no loss time among this segment's knots
-    for (int k = k_last; k >= k_lo; --k) { const int s = save_of_knot[k]; if (s >= 0) { s_hi = s; break; } }
-    if (i_raw < g.N) {
-        const double* __restrict__ src = g.cot_aos + ((long)i_raw * g.M + s_lo) * N;
-        double* __restrict__ dst = g.cot_wr + (long)s_lo * N * g.Npad + i_raw;     // row (s, j) = row s_lo * N + e of the [M * N][Npad] block, e = (s - s_lo) N + j
-        const int K = (s_hi - s_lo + 1) * N;
-        constexpr int CH = 24;
-        for (int e0 = 0; e0 < K; e0 += CH) {
-            double v[CH];
-#pragma unroll
-            for (int q = 0; q < CH; ++q) v[q] = src[e0 + q < K ? e0 + q : K - 1];
-#pragma unroll
-            for (int q = 0; q < CH; ++q) if (e0 + q < K) dst[(long)(e0 + q) * g.Npad] = v[q];
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the rows are in L2 before this wave's sweep asks for them
-}
-
 // The same sweep as ONE launch per reverse pass: every wave hands its segment map to the composition tree of hipadj_fused.hpp
 // instead of a segment buffer for k_compose_finish* / k_reduce_final.  Grid (wave blocks, segments), 64-thread workgroups; lanes
 // beyond the ensemble (the padding of the last block) run on the padded tiles and are masked where results leave the wave.
@@ -152,7 +124,6 @@ __global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(PSH ? 2 :
     const long i = i_raw < g.N ? i_raw : g.N - 1;                    // padding lanes of the last block repeat its last trajectory
     const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;      // rank 0 = the top (longest, 1-column) segment: dispatched first
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
-    if constexpr ((LOSS & 1) == 0) { if (g.cot_aos) cot_transpose_slice<N>(g, i_raw, k_lo, k_hi == g.S ? k_hi : k_hi - 1, save_of_knot); }
     if constexpr (!SEG) {   // one segment (models whose segment columns do not fit the registers): the wave is its block's root, no map is ever built
         double lam[1][N], mu[1][NP], v[R];
         interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
@@ -807,7 +778,6 @@ __global__ void __launch_bounds__(WAVE) k_gauss_fused(Geom g, SegPlan sp, TreePl
     const long i = i_raw < g.N ? i_raw : g.N - 1;
     const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
-    if constexpr ((LOSS & 1) == 0) { if (g.cot_aos) cot_transpose_slice<N>(g, i_raw, k_lo, k_hi == g.S ? k_hi : k_hi - 1, save_of_knot); }
     if constexpr (!SEG) {
         double lam[1][N], mu[1][NP], v[R];
         gauss_lane<Mo, 1, PF, LOSS, 0, GKR>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
@@ -841,7 +811,6 @@ __global__ void __launch_bounds__(WAVE) k_backsolve_fused(Geom g, SegPlan sp, Tr
     const long i = i_raw < g.N ? i_raw : g.N - 1;
     const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
-    if (g.cot_aos) cot_transpose_slice<N>(g, i_raw, k_lo, k_hi == g.S ? k_hi : k_hi - 1, save_of_knot);
     if constexpr (!SEG) {
         double lam[1][N], mu[1][NP], v[R];
         backsolve_lane<Mo, 1, CC>(g, i, k_lo, k_hi, p, yT, ckpt, ckpt_of_knot, cotT, save_of_knot, lam, mu);

@@ -51,9 +51,9 @@ struct Geom {
     double la, lb;     // the loss gradient of the kinds that stream a column c (cotangent or data) next to the state u:  dgdu = la u + lb c  — (0, 1) cotangent and model bodies
                        // (which get the raw data column), (w, -w) HIPADJ_LOSS_LSQ_DATA with scale w.  la = 0, lb = 1 returns c bit for bit (0 u + 1 c, u finite)
     int lflags;        // bit 0: drop dgdp_discrete (hipadj_config.reference_literal on GaussAdjoint)
-    // the cotangent block as the AD pullback hands it, [N][M][n], and the handle's streaming buffer [M][n][Npad]: set (per launch) when the one-launch sweeps transpose
-    // their own slices on the way in (hipadj_kernels.hpp cot_transpose_slice); null otherwise
-    const double* cot_aos = nullptr; double* cot_wr = nullptr;
+    // the cotangent block as the AD pullback hands it, [N][M][n] (src/concrete_solve.jl:842-851): set (per launch) when the one-launch sweeps read it IN PLACE (load_cot,
+    // loss_grad below) — every lane only ever needs its own trajectory's column; null: the streaming buffer cotT [M][n][Npad]
+    const double* cot_aos = nullptr;
     double h_last;     // length of the LAST forward step [t_{S-1}, T]: = dt, or the remainder when the span is not a multiple of dt (the reference's
                        // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
 };
@@ -204,7 +204,8 @@ template <class Mo>
 HIPADJ_HD void loss_grad(const Geom& g, long i, int s, const double* __restrict__ cotT, const double (&y)[Mo::N], double (&gl)[Mo::N]) {
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j)
-        gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift) : loss_affine(g, y[j], cotT[((long)s * Mo::N + j) * g.Npad + i]);
+        gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift)
+                                    : loss_affine(g, y[j], g.cot_aos ? (i < g.N ? g.cot_aos[((long)i * g.M + s) * Mo::N + j] : 0.0) : cotT[((long)s * Mo::N + j) * g.Npad + i]);
 }
 
 // Discrete loss bodies attached to a runtime-registered model (hipadj_model_set_discrete_loss; HIPADJ_LOSS_MODEL): dgdu_discrete(out, u, p, t_i, i) and
@@ -502,6 +503,27 @@ template <class Mo, int LOSS>
 HIPADJ_HD void load_cot(const Geom& g, long i, int s, const double* __restrict__ cotT, double (&c)[Mo::N]) {
     if (LOSS == 0) {
         const int sc = s > 0 ? s : 0;
+        if (g.cot_aos) {
+            // Delta in the pullback's layout [N][M][n], read in place: lane i takes the n contiguous doubles of (trajectory i, loss time s).  Lanes are M n doubles apart, so a
+            // load touches one 128-byte line per lane — of which the next loss times of the same lane use the rest out of L2 — instead of one per eight lanes; it is issued once
+            // per loss time, a prefetch block ahead (reverse_sweep), and replaces a transposition that read and wrote the whole block once more in front of every pass
+            // (12-14 us next to a 110 us sweep whether as its own launch or as a prologue of the sweep's waves: profiles/r5_visit3_bench.json).
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef unsigned int cot_u2 __attribute__((ext_vector_type(2)));
+            const int col_bytes = (int)(g.M * Mo::N * 8);                              // N M n 8 < 2^31: the host checks before it sets cot_aos
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.cot_aos + (long)sc * Mo::N), 0, s >= 0 ? (int)g.N * col_bytes - sc * Mo::N * 8 : 0, 0x00020000);
+            const int voff = (int)i * col_bytes;                                       // padding lanes (i >= N) fall beyond num_records: 0, no memory access
+#pragma unroll
+            for (int j = 0; j < Mo::N; ++j) {
+                const cot_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, j * 8, 0);
+                c[j] = __hiloint2double((int)v.y, (int)v.x);
+            }
+#else
+#pragma unroll
+            for (int j = 0; j < Mo::N; ++j) c[j] = (s >= 0 && i < g.N) ? g.cot_aos[((long)i * g.M + sc) * Mo::N + j] : 0.0;
+#endif
+            return;
+        }
 #if defined(__HIP_DEVICE_COMPILE__) && HIPADJ_COT_BUFFER
         typedef unsigned int cot_u2 __attribute__((ext_vector_type(2)));
         const int row_bytes = (int)(g.Npad * 8);                                   // < 2^31 / N: hipadj_create checks

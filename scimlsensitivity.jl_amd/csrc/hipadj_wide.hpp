@@ -921,14 +921,26 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
         double ak[W::NA], ag[W::NA], part[W::NA];
 #pragma unroll
         for (int q = 0; q < W::NA; ++q) { ak[q] = 0.0; ag[q] = 0.0; }
-        for (int j = tid; j < NP; j += T) { IK[j] = 0.0; IG[j] = 0.0; }
+        // The Kronrod / Gauss sums of the panel: entry j = tid + m T is owned by one thread for all fifteen nodes, so up to 16 entries per thread stay in REGISTERS (round 5; until
+        // then every node read, updated and wrote both np-vectors in the HBM scratch: 8 KB of read-modify-write per node of the published 2-50-2 net);
+        // wider gradients keep the scratch form.  The sums are the same additions in the same order: results unchanged bit for bit.
+        constexpr int PJ = (NP + T - 1) / T;
+        constexpr bool RG = PJ <= 16;
+        double rk[RG ? PJ : 1], rg[RG ? PJ : 1];
+        if constexpr (RG) {
+#pragma unroll
+            for (int m = 0; m < PJ; ++m) { rk[m] = 0.0; rg[m] = 0.0; }
+        } else { for (int j = tid; j < NP; j += T) { IK[j] = 0.0; IG[j] = 0.0; } }
 #pragma unroll 1
         for (int e = 0; e < 15; ++e) {
             const int jj = e < 7 ? e : (e < 14 ? e - 7 : 7);
             const double xj = cw_gk_x[jj], wk = cw_gk_wk[jj], wg = (jj & 1) ? cw_gk_wg[jj >> 1] : 0.0;
             integrand(e < 7 ? c - h * xj : (e < 14 ? c + h * xj : c), part);
             const double wgc = e == 14 ? cw_gk_wg[3] : wg;
-            for (int j = tid; j < NP; j += T) { const double f = fi[j]; IK[j] += wk * f; IG[j] += wgc * f; }   // each entry by its own thread, every node
+            if constexpr (RG) {
+#pragma unroll
+                for (int m = 0; m < PJ; ++m) { const int j = tid + m * T; if (j < NP) { const double f = fi[j]; rk[m] += wk * f; rg[m] += wgc * f; } }
+            } else { for (int j = tid; j < NP; j += T) { const double f = fi[j]; IK[j] += wk * f; IG[j] += wgc * f; } }   // each entry by its own thread, every node
 #pragma unroll
             for (int q = 0; q < W::NA; ++q) { ak[q] += wk * part[q]; ag[q] += wgc * part[q]; }
             wide_sync<T>();                                              // fi is zeroed again by the next node
@@ -938,11 +950,17 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
 #pragma unroll
             for (int q = 0; q < W::NA; ++q) { both[q] = ak[q]; both[W::NA + q] = ag[q]; }
             wide_block_sum<T, 2 * W::NA>(both, sred, sacc);
-            if (tid < W::NACC) { IK[Mo::ACC0 + tid] += sacc[tid]; IG[Mo::ACC0 + tid] += sacc[W::NA + tid]; }
+            if constexpr (RG) {
+#pragma unroll
+                for (int m = 0; m < PJ; ++m) { const int j = tid + m * T - (int)Mo::ACC0; if (j >= 0 && j < W::NACC) { rk[m] += sacc[j]; rg[m] += sacc[W::NA + j]; } }
+            } else if (tid < W::NACC) { IK[Mo::ACC0 + tid] += sacc[tid]; IG[Mo::ACC0 + tid] += sacc[W::NA + tid]; }
             wide_sync<T>();
         }
         double e2[1] = {0.0};
-        for (int j = tid; j < NP; j += T) { const double ik = IK[j] * h, ig = IG[j] * h; IK[j] = ik; e2[0] += (ik - ig) * (ik - ig); }
+        if constexpr (RG) {
+#pragma unroll
+            for (int m = 0; m < PJ; ++m) { const int j = tid + m * T; if (j < NP) { const double ik = rk[m] * h, ig = rg[m] * h; IK[j] = ik; e2[0] += (ik - ig) * (ik - ig); } }
+        } else { for (int j = tid; j < NP; j += T) { const double ik = IK[j] * h, ig = IG[j] * h; IK[j] = ik; e2[0] += (ik - ig) * (ik - ig); } }
         wide_block_sum<T, 1>(e2, sred, sn);
         return sqrt(sn[0]);
     };

@@ -12,6 +12,17 @@ ts = bench.save_times(); M = len(ts)
 eng = sa.Engine("lorenz", "interpolating", N, 0.0, bench.T_FINAL, bench.DT, save_times=ts, loss_kind=0, p_shared=True)
 delta = np.random.default_rng(3).standard_normal((N, M, 3))
 eng.set_timing(0)
+# what bench.py's process has that a bare host program has not: torch loaded (PROBE_TORCH=1), device work enqueued through a torch stream the handle adopted
+# (PROBE_TSTREAM=1), the cotangents coming out of a torch CPU tensor (PROBE_TDELTA=1)
+if os.environ.get("PROBE_TORCH") or os.environ.get("PROBE_TSTREAM") or os.environ.get("PROBE_TDELTA"):
+    import torch
+    x = torch.zeros(1 << 20, device="cuda"); x += 1; torch.cuda.synchronize()
+    if os.environ.get("PROBE_TSTREAM"):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            eng.use_torch_stream()
+    if os.environ.get("PROBE_TDELTA"):
+        delta = torch.tensor(delta, device="cuda").cpu().numpy()
 eng.forward(u0, p, want_out=True); eng.adjoint(delta)
 R = 8
 t0 = time.perf_counter()

@@ -18,9 +18,17 @@ def build(force=False):
     """Eight translation units (-DEMU_UNIT=0..7: entry points + one unit per model) compiled in parallel, then linked."""
     from concurrent.futures import ThreadPoolExecutor
     deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("hipadj_lane.hpp", "hipadj_models.hpp", "hipadj_plan.hpp", "hipadj_adaptive.hpp")]
-    if force or not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
-        objdir = os.path.join(_HERE, "emu", "build")
-        os.makedirs(objdir, exist_ok=True)
+    def stale():
+        return force or not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps)
+    if not stale():
+        return _LIB
+    import fcntl
+    objdir = os.path.join(_HERE, "emu", "build")
+    os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lk:      # pytest-xdist workers: one builds, the others wait and find the library fresh
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not stale():
+            return _LIB
 
         def unit(k):
             obj = os.path.join(objdir, f"unit{k}.o")
