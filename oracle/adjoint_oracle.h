@@ -50,7 +50,9 @@ enum {
 };
 enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3,
        ORC_ALG_GAUSS_KRONROD = 4 /* [upstream-recall] per-step adaptive GK(7,15): parity UNPINNED beyond GaussKronrod == Gauss */ };
-enum { ORC_STEPPER_RK4 = 0, ORC_STEPPER_TSIT5 = 1 };
+enum { ORC_STEPPER_RK4 = 0, ORC_STEPPER_TSIT5 = 1,
+       ORC_STEPPER_ETDRK4 = 2 };   /* fixed-step exponential RK4 (Cox & Matthews 2002) for the semilinear PDE model: u' = alpha/dx^2 L u + N(u, t), the periodic
+                                    * Laplacian L diagonalised by the 2-D DFT, phi-functions per mode; ORC_MODEL_BRUSS with a power-of-two grid only (adjoint_oracle.c 2b) */
 enum { ORC_LOSS_COTANGENT = 0, ORC_LOSS_LSQ_SHIFT = 1,
        ORC_LOSS_LSQ_DATA = 2,  /* dgdu_discrete = loss_scale (u - data[i]) with the data block handed in the cotangents' place: sum(abs2, sol .- data) for scale 2
                                   (docs/src/Benchmark.md:80, docs/src/tutorials/parameter_estimation_ode.md:43) */

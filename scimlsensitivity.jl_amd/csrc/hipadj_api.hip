@@ -964,13 +964,7 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
     double* no_sum = nullptr;
     const double* cotT = h->cot_soa ? h->cot_soa : h->d_cotT;   // hipadj_adjoint_dev_soa: the caller's block, already in the streaming layout
-    // cotangents as [N][M][n]: the one-launch sweeps read them in place (load_cot / loss_grad), the other sequences keep the transposition launch
-    static const bool insweep_on = []() { const char* e = std::getenv("HIPADJ_COT_INPLACE"); return !(e && e[0] == '0'); }();
-    const bool cot_aos_in = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa;
-    const bool insweep = cot_aos_in && (double)h->N * h->M * h->n * 8.0 < 2147483648.0 && insweep_on && !h->adaptive && !h->offgrid && h->fused && h->d_tbuf && h->cfg.alg != HIPADJ_ALG_QUADRATURE;   // = the one-launch branch below
-    Geom gk = h->g;
-    if (insweep) gk.cot_aos = d_cot;
-    if (cot_aos_in && !insweep) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
+    if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));   // runtime models keep the transposition launch
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
     harvest_set(h, es, true);
@@ -1012,10 +1006,10 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
             double* dps = h->cfg.p_shared ? d_dp : (double*)nullptr;
             if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
-                TRY(usig<decltype(&k_backsolve_fused<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), gk, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+                TRY(usig<decltype(&k_backsolve_fused<ModelLV, 0>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
                             cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag));
             else
-                TRY(usig<decltype(&k_interp_fused<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), gk, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
+                TRY(usig<decltype(&k_interp_fused<ModelLV, 8, 1>)>::launch(h, h->uf_main, sgrid, dim3(WAVE), h->g, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
                             d_du0, dp_rows, dps, h->d_flag));
             if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
             if (h->has_mm) {
@@ -1746,6 +1740,12 @@ extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0,
         if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
         return multi_adjoint(h, dLdu, du0, dp);
     }
+    static const bool trace = std::getenv("HIPADJ_HOST_TIMING") != nullptr;      // diagnosis (stderr): enqueue (upload + launches + download requests) and drain of one host-pointer call
+    const auto t0 = std::chrono::steady_clock::now();
     TRY(adjoint_host_enqueue(h, dLdu, du0, dp));
-    return hipadj_synchronize(h);
+    const auto t1 = std::chrono::steady_clock::now();
+    const int rc = hipadj_synchronize(h);
+    if (trace) std::fprintf(stderr, "hipadj_adjoint: enqueue %.3f ms, drain %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    return rc;
 }

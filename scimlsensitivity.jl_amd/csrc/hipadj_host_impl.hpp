@@ -77,16 +77,12 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     // the column the sweep streams at the loss times: the caller's block already in the streaming layout (hipadj_adjoint_dev_soa), or the handle's own buffer — cotangents
     // transposed here per pass, or the data block of a device-resident loss transposed ONCE by hipadj_set_loss_data
     const double* cotT = h->cot_soa ? h->cot_soa : h->d_cotT;
-    // cotangents in the pullback's layout [N][M][n]: the one-launch sweeps read them in place (hipadj_lane.hpp load_cot / loss_grad), every other sequence keeps the
-    // transposition launch.  HIPADJ_COT_INPLACE=0: always the launch (A/B)
+    // cotangents in the pullback's layout [N][M][n]: the one-launch Interpolating sweep reads them in place (template variant HIPADJ_MODE_COT_INPLACE, hipadj_lane.hpp
+    // load_cot), every other sequence keeps the transposition launch.  HIPADJ_COT_INPLACE=0: always the launch (A/B)
     static const bool insweep_on = []() { const char* e = std::getenv("HIPADJ_COT_INPLACE"); return !(e && e[0] == '0'); }();
-    const bool one_launch = h->fused && h->d_tbuf && !h->offgrid && !h->ip_ckpt &&
-                            ((h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->wpb4) || h->cfg.alg == HIPADJ_ALG_BACKSOLVE || h->cfg.alg == HIPADJ_ALG_GAUSS ||
-                             h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD);
+    const bool one_launch = LOSS == 0 && h->fused && h->d_tbuf && !h->offgrid && !h->ip_ckpt && h->cfg.alg == HIPADJ_ALG_INTERPOLATING && !h->wpb4;   // = the k_interp_fused branch below
     const bool cot_aos_in = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !h->cot_soa;
     const bool insweep = cot_aos_in && one_launch && insweep_on && (double)h->N * h->M * h->n * 8.0 < 2147483648.0;
-    Geom gk = h->g;                             // the geometry of THIS launch
-    if (insweep) gk.cot_aos = d_cot;
     if (cot_aos_in && !insweep) TRY(launch_transpose_to_soa(h, d_cot, h->d_cotT, h->M * h->n));
     hipadj_handle::EvSet& es = h->evs[h->ev_next];
     h->ev_next = (h->ev_next + 1) % hipadj_handle::NSET;
@@ -176,13 +172,28 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             bool launched = false;
             if constexpr (model_has_ops<Mo>::value && (LOSS >> 1) == 0) {
                 if (h->cfg.p_shared && h->nseg > 1 && !h->no_ops) {
-                    hipExtLaunchKernelGGL((k_interp_fused<Mo, 4, LOSS, true, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, gk, sp, tp, p,
+                    if constexpr (LOSS == 0) {
+                        if (insweep) {
+                            hipExtLaunchKernelGGL((k_interp_fused<Mo, 4, HIPADJ_MODE_COT_INPLACE, true, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
+                                                  (const dbl2*)h->d_knots, d_cot, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                            launched = true;
+                        }
+                    }
+                    if (!launched)
+                    hipExtLaunchKernelGGL((k_interp_fused<Mo, 4, LOSS, true, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
                                           (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
                     launched = true;
                 }
             }
+            if constexpr (LOSS == 0) {
+                if (!launched && insweep) {
+                    hipExtLaunchKernelGGL((k_interp_fused<Mo, PF, HIPADJ_MODE_COT_INPLACE>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
+                                          (const dbl2*)h->d_knots, d_cot, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                    launched = true;
+                }
+            }
             if (!launched)
-                hipExtLaunchKernelGGL((k_interp_fused<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, gk, sp, tp, p,
+                hipExtLaunchKernelGGL((k_interp_fused<Mo, PF, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
                                       (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
             HIP_TRY(h, hipGetLastError());
             if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
@@ -226,7 +237,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         if (h->fused && h->d_tbuf) {   // one launch per reverse pass (hipadj_fused.hpp)
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
             hipExtLaunchKernelGGL((k_backsolve_fused<Mo, (LOSS >> 1)>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
-                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, gk, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const double*)h->d_yT, (const double*)h->d_ckpt, (const int*)h->d_ckpt_of_knot,
                                   cotT, (const int*)h->d_save_rev, d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
             HIP_TRY(h, hipGetLastError());
             if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
@@ -252,7 +263,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         else if (h->fused && h->d_tbuf) {   // one launch per reverse pass (hipadj_fused.hpp)
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
             hipExtLaunchKernelGGL((k_gauss_fused<Mo, PFG, LOSS>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
-                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, gk, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
                                   d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
             HIP_TRY(h, hipGetLastError());
             if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));
@@ -272,7 +283,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
         if (h->fused && h->d_tbuf) {   // one launch per reverse pass (hipadj_fused.hpp)
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
             hipExtLaunchKernelGGL((k_gauss_fused<Mo, PFG, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->timing >= 1 ? k0 : (hipEvent_t) nullptr,
-                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, gk, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
+                                  h->timing >= 1 ? k1 : (hipEvent_t) nullptr, 0, h->g, sp, tp, p, (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev,
                                   d_du0, dp_rows, h->cfg.p_shared ? d_dp : (double*)nullptr, h->d_flag);
             HIP_TRY(h, hipGetLastError());
             if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a1, h->stream));

@@ -32,6 +32,7 @@
 
 #include "hipadj_models.hpp"
 
+#define HIPADJ_MODE_COT_INPLACE 64     // template MODE bit of the lane sweeps: cotangents read in place from [N][M][n] (load_cot)
 namespace hipadj {
 
 struct alignas(16) dbl2 { double x, y; };
@@ -51,9 +52,7 @@ struct Geom {
     double la, lb;     // the loss gradient of the kinds that stream a column c (cotangent or data) next to the state u:  dgdu = la u + lb c  — (0, 1) cotangent and model bodies
                        // (which get the raw data column), (w, -w) HIPADJ_LOSS_LSQ_DATA with scale w.  la = 0, lb = 1 returns c bit for bit (0 u + 1 c, u finite)
     int lflags;        // bit 0: drop dgdp_discrete (hipadj_config.reference_literal on GaussAdjoint)
-    // the cotangent block as the AD pullback hands it, [N][M][n] (src/concrete_solve.jl:842-851): set (per launch) when the one-launch sweeps read it IN PLACE (load_cot,
-    // loss_grad below) — every lane only ever needs its own trajectory's column; null: the streaming buffer cotT [M][n][Npad]
-    const double* cot_aos = nullptr;
+
     double h_last;     // length of the LAST forward step [t_{S-1}, T]: = dt, or the remainder when the span is not a multiple of dt (the reference's
                        // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
 };
@@ -204,8 +203,7 @@ template <class Mo>
 HIPADJ_HD void loss_grad(const Geom& g, long i, int s, const double* __restrict__ cotT, const double (&y)[Mo::N], double (&gl)[Mo::N]) {
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j)
-        gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift)
-                                    : loss_affine(g, y[j], g.cot_aos ? (i < g.N ? g.cot_aos[((long)i * g.M + s) * Mo::N + j] : 0.0) : cotT[((long)s * Mo::N + j) * g.Npad + i]);
+        gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift) : loss_affine(g, y[j], cotT[((long)s * Mo::N + j) * g.Npad + i]);
 }
 
 // Discrete loss bodies attached to a runtime-registered model (hipadj_model_set_discrete_loss; HIPADJ_LOSS_MODEL): dgdu_discrete(out, u, p, t_i, i) and
@@ -499,31 +497,31 @@ HIPADJ_HD void adj_rk4_step(const Knot<Mo>& hi, const Knot<Mo>& lo, const double
 #ifndef HIPADJ_COT_BUFFER
 #define HIPADJ_COT_BUFFER 1      // 0: the round-4 form (A/B builds)
 #endif
-template <class Mo, int LOSS>
+template <class Mo, int LOSS>      // LOSS: 0 streamed column in the streaming layout, 1 formed in the kernel (u - shift), 2 streamed column read IN PLACE from the pullback's layout
 HIPADJ_HD void load_cot(const Geom& g, long i, int s, const double* __restrict__ cotT, double (&c)[Mo::N]) {
-    if (LOSS == 0) {
+    if constexpr (LOSS == 2) {
+        // Delta as the AD pullback hands it, [N][M][n] (src/concrete_solve.jl:842-851), read in place: lane i takes the n contiguous doubles of (trajectory i, loss time s).
+        // Lanes are M n doubles apart, so a load touches one 128-byte line per lane — of which the lane's next loss times use the rest out of L2 — instead of one per eight
+        // lanes; it is issued once per loss time, a prefetch block ahead, and replaces a transposition that read and wrote the whole block once more in front of every pass
+        // (12-14 us next to a 110 us sweep, as its own launch or as a prologue of the sweep's waves: profiles/r5_visit3_bench.json).  A compile-time variant: selecting
+        // the layout at run time cost the stage-operator kernel its last registers (33-47 scratch operations, twice the time: profiles/r5_visit4_bench.json).
         const int sc = s > 0 ? s : 0;
-        if (g.cot_aos) {
-            // Delta in the pullback's layout [N][M][n], read in place: lane i takes the n contiguous doubles of (trajectory i, loss time s).  Lanes are M n doubles apart, so a
-            // load touches one 128-byte line per lane — of which the next loss times of the same lane use the rest out of L2 — instead of one per eight lanes; it is issued once
-            // per loss time, a prefetch block ahead (reverse_sweep), and replaces a transposition that read and wrote the whole block once more in front of every pass
-            // (12-14 us next to a 110 us sweep whether as its own launch or as a prologue of the sweep's waves: profiles/r5_visit3_bench.json).
 #if defined(__HIP_DEVICE_COMPILE__)
-            typedef unsigned int cot_u2 __attribute__((ext_vector_type(2)));
-            const int col_bytes = (int)(g.M * Mo::N * 8);                              // N M n 8 < 2^31: the host checks before it sets cot_aos
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.cot_aos + (long)sc * Mo::N), 0, s >= 0 ? (int)g.N * col_bytes - sc * Mo::N * 8 : 0, 0x00020000);
-            const int voff = (int)i * col_bytes;                                       // padding lanes (i >= N) fall beyond num_records: 0, no memory access
+        typedef unsigned int cot_u2 __attribute__((ext_vector_type(2)));
+        const int col_bytes = (int)(g.M * Mo::N * 8);                              // N M n 8 < 2^31: the host checks before it picks this variant
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(cotT + (long)sc * Mo::N), 0, s >= 0 ? (int)g.N * col_bytes - sc * Mo::N * 8 : 0, 0x00020000);
+        const int voff = (int)i * col_bytes;                                       // padding lanes (i >= N) fall beyond num_records: 0, no memory access
 #pragma unroll
-            for (int j = 0; j < Mo::N; ++j) {
-                const cot_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, j * 8, 0);
-                c[j] = __hiloint2double((int)v.y, (int)v.x);
-            }
+        for (int j = 0; j < Mo::N; ++j) {
+            const cot_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, j * 8, 0);
+            c[j] = __hiloint2double((int)v.y, (int)v.x);
+        }
 #else
 #pragma unroll
-            for (int j = 0; j < Mo::N; ++j) c[j] = (s >= 0 && i < g.N) ? g.cot_aos[((long)i * g.M + sc) * Mo::N + j] : 0.0;
+        for (int j = 0; j < Mo::N; ++j) c[j] = (s >= 0 && i < g.N) ? cotT[((long)i * g.M + sc) * Mo::N + j] : 0.0;
 #endif
-            return;
-        }
+    } else if (LOSS == 0) {
+        const int sc = s > 0 ? s : 0;
 #if defined(__HIP_DEVICE_COMPILE__) && HIPADJ_COT_BUFFER
         typedef unsigned int cot_u2 __attribute__((ext_vector_type(2)));
         const int row_bytes = (int)(g.Npad * 8);                                   // < 2^31 / N: hipadj_create checks
@@ -553,7 +551,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
     if (k_hi == g.S) {   // PresetTimeCallback fires at initialisation when T is a loss time
         const int s = save_of_knot[k_hi];
         double gl[N];
-        if (LOSS == 0) {
+        if (LOSS != 1) {
             if (s >= 0) { load_cot<Mo, LOSS>(g, i, s, cotT, gl);
 #pragma unroll
                 for (int j = 0; j < N; ++j) gl[j] = loss_affine(g, carry.u[j], gl[j]); }
@@ -578,7 +576,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
             const int s = save_of_knot[k];
             const bool jump = s >= 0 && !(g.no_start && s == 0);
             double gl[N];
-            if (LOSS == 0) { load_cot<Mo, LOSS>(g, i, s, cotT, gl);
+            if (LOSS != 1) { load_cot<Mo, LOSS>(g, i, s, cotT, gl);
 #pragma unroll
                 for (int j = 0; j < N; ++j) gl[j] = loss_affine(g, lo.u[j], gl[j]); }
             else {
@@ -596,7 +594,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
     for (int r = 0; r < PF; ++r) {
         const int kk = k_hi - 1 - r, kc = kk > k_lo ? kk : k_lo;
         load_knot<Mo>(knots, g.Npad, kc, i, ring[r], g.kmask);
-        load_cot<Mo, LOSS>(g, i, LOSS == 0 ? save_of_knot[kc] : 0, cotT, cot[r]);
+        load_cot<Mo, LOSS>(g, i, LOSS != 1 ? save_of_knot[kc] : 0, cotT, cot[r]);
     }
     int kb = k_hi - 1;
     for (; kb - (PF - 1) >= k_lo; kb -= PF) {
@@ -605,7 +603,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
         for (int r = 0; r < PF; ++r) {
             sfl[r] = save_of_knot[kb - r];
             const int kn = kb - PF - r;
-            sfn[r] = LOSS == 0 ? save_of_knot[kn > k_lo ? kn : k_lo] : 0;
+            sfn[r] = LOSS != 1 ? save_of_knot[kn > k_lo ? kn : k_lo] : 0;
         }
 #pragma unroll
         for (int r = 0; r < PF; ++r) {
@@ -614,7 +612,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
             const bool jump = s >= 0 && !(g.no_start && s == 0);
             double gl[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) gl[j] = LOSS == 0 ? loss_affine(g, ring[r].u[j], cot[r][j]) : (ring[r].u[j] - g.loss_shift);
+            for (int j = 0; j < N; ++j) gl[j] = LOSS != 1 ? loss_affine(g, ring[r].u[j], cot[r][j]) : (ring[r].u[j] - g.loss_shift);
             HIPADJ_STEP_FENCE();
             step(r == 0 ? carry : ring[r > 0 ? r - 1 : 0], ring[r], k, jump, gl);
             HIPADJ_STEP_FENCE();
@@ -638,7 +636,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
             const bool jump = s >= 0 && !(g.no_start && s == 0);
             double gl[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) gl[j] = LOSS == 0 ? loss_affine(g, ring[r].u[j], cot[r][j]) : (ring[r].u[j] - g.loss_shift);
+            for (int j = 0; j < N; ++j) gl[j] = LOSS != 1 ? loss_affine(g, ring[r].u[j], cot[r][j]) : (ring[r].u[j] - g.loss_shift);
             step(r == 0 ? carry : ring[r > 0 ? r - 1 : 0], ring[r], k, jump, gl);
         }
     }
@@ -739,7 +737,9 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
                            const dbl2* __restrict__ knots, const double* __restrict__ cotT,
                            const int* __restrict__ save_of_knot, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP],
                            const CkptSrc* ck = nullptr) {
-    constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
+    // MODE bit 6 (HIPADJ_MODE_COT_INPLACE): the streamed column is read in place from the pullback's layout (load_cot<., 2>); one-launch sweeps without checkpoints only
+    constexpr int N = Mo::N, NP = Mo::NP, LOSS = (MODE & 1) ? 1 : ((MODE & HIPADJ_MODE_COT_INPLACE) ? 2 : 0), CC = (MODE & (HIPADJ_MODE_COT_INPLACE - 1)) >> 1;
+    static_assert(!(MODE & HIPADJ_MODE_COT_INPLACE) || KMAX == 0, "the in-place cotangent layout is a variant of the straight sweep");
     constexpr bool OPS = model_has_ops<Mo>::value && NC > 1 && CC == 0 && PSH;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
     double oc[model_ops_count<Mo>::value];
@@ -780,7 +780,7 @@ HIPADJ_HD void interp_lane(const Geom& g, long i, int k_lo, int k_hi, const doub
         if constexpr (model_has_dloss<Mo>::value) s = save_of_knot[k];
         jump_add(jump, gl, lo.u, g.t0 + k * g.dt, s);
     };
-    if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, LOSS>(g, i, k_lo, k_hi, pv, *ck, cotT, save_of_knot, init, step);
+    if (KMAX > 0) reverse_sweep_ckpt<Mo, KMAX, (LOSS == 1 ? 1 : 0)>(g, i, k_lo, k_hi, pv, *ck, cotT, save_of_knot, init, step);
     else reverse_sweep<Mo, PF, LOSS>(g, i, k_lo, k_hi, knots, cotT, save_of_knot, init, step);
 }
 
