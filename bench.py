@@ -478,6 +478,21 @@ def other_configs(sa, torch):
         eng.close()
     except Exception as e:
         out.append(dict(config="configs[4] at the documented horizon", error=repr(e)))
+    # the same horizon with the stiff stepper of the family (HIPADJ_STEPPER_ETDRK4_FIXED, csrc/hipadj_field_etd.hpp): the diffusion term exact in the DFT basis, 7360 steps
+    # of dt = 1/640 (the step at which the gradient meets scipy's Radau to 1e-5..1e-6, tests/test_etd_stepper.py) instead of 460 000
+    try:
+        dte, Se = 0.0015625, 7360
+        tsh = 0.5 * np.arange(0, 24)
+        for alg, N in (("quadrature", 1), ("interpolating", 1), ("interpolating", 64)):
+            eng = sa.Engine("bruss", alg, N, 0.0, Se * dte, dte, save_times=tsh, dims=(G, 0, 0, 0), stepper=2)
+            ms, kms, st = run(eng, bruss_u0(G, N), np.array([3.4, 1.0, 10.0]), rng.standard_normal((N, len(tsh), 2 * G * G)), 1)
+            out.append(dict(config=f"configs[4] at the documented horizon with the exponential stepper: Brusselator 32x32, tspan (0, 11.5), {alg}, 7360 ETDRK4 steps of dt = 1/640, N = {N} (1 GPU)",
+                            forward_ms=st["forward_ms_last"], reverse_ms=ms, sweep_kernel_ms=kms, us_per_step=kms * 1e3 / Se, workspace_GB=st["workspace_bytes"] / 1e9,
+                            roofline=dict(bound="latency", kernel="k_bruss_adjoint_etd", note="one workgroup per trajectory: nine 32 x 32 complex FFTs per reverse step (ten lane-exchange "
+                                          "levels and one LDS transposition each) are a dependent chain; N = 64 runs 64 of them side by side")))
+            eng.close()
+    except Exception as e:
+        out.append(dict(config="configs[4] at the documented horizon with the exponential stepper", error=repr(e)))
     return out
 
 
@@ -699,6 +714,7 @@ def main():
     ap.add_argument("--segments", type=int, default=0, help="time segments per trajectory (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip shard_sizes / other_configs (N = 1) and the second scaling figure (N > 1)")
+    ap.add_argument("--loss-paths-only", action="store_true", help="with --no-extras: still print loss_paths (the loss routes of the headline pass)")
     ap.add_argument("--torch-allreduce", action="store_true",
                     help="N > 1: all-reduce dL/dp with torch.distributed (async, own stream) instead of in-stream RCCL inside the C ABI (hipadj_comm_*)")
     ap.add_argument("--native-allreduce", action="store_true", help="(default for N > 1; kept for compatibility)")
@@ -906,6 +922,8 @@ def main():
                 res["other_configs"] = other_configs(sa, torch)
             except Exception as e:      # the headline must not die on a secondary figure
                 res["other_configs_error"] = repr(e)
+        elif args.loss_paths_only:
+            res["loss_paths"] = loss_paths(sa, torch, args, u0_all, p_np, local_rank, res["ms_per_step"])
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(u0_all, p_np, ts)
     if rank == 0:

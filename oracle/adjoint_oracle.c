@@ -870,7 +870,6 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
         if (m->id != ORC_MODEL_BRUSS) return -6;
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
         a.split_G = G; a.split_coef = p[2] / (dx * dx);
-        if (getenv("ORC_ETD_FWD_SUB")) a.dt = cfg->dt / atoi(getenv("ORC_ETD_FWD_SUB"));   /* EXPERIMENT */
     }
     dense_init(sol, m->n, cfg->stepper);
     return integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, NULL, NULL, 0, sol, nrhs);

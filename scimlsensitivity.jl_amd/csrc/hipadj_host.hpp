@@ -17,6 +17,7 @@
 #include "../../include/hipadj.h"
 #include "hipadj_kernels.hpp"
 #include "hipadj_field.hpp"
+#include "hipadj_field_etd.hpp"
 #include "hipadj_mlp.hpp"
 #include "hipadj_mlp_grad.hpp"
 #include "hipadj_adaptive.hpp"

@@ -342,6 +342,12 @@ template <class Mo> int adjoint_impl(hipadj_handle* h, const double* d_cot, doub
 
 // ---- workgroup-per-trajectory family (Brusselator) -----------------------------------------------------
 template <int G> int field_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
+    if (h->cfg.stepper == HIPADJ_STEPPER_ETDRK4_FIXED) {   // the exponential stepper (hipadj_field_etd.hpp)
+        hipLaunchKernelGGL((k_bruss_forward_etd<G>), dim3((unsigned)h->N), dim3(Bruss<G>::T), 0, h->stream, h->fg, d_u0, d_p, h->d_fknots,
+                           (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
+        HIP_TRY(h, hipGetLastError());
+        return HIPADJ_OK;
+    }
     hipLaunchKernelGGL((k_bruss_forward<G>), dim3((unsigned)h->N), dim3(Bruss<G>::T), 0, h->stream, h->fg, d_u0, d_p, h->d_fknots,
                        (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot);
     HIP_TRY(h, hipGetLastError());
@@ -357,8 +363,13 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
     HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     const dim3 grid((unsigned)h->N), blk(Bruss<G>::T);
+    const bool etd = h->cfg.stepper == HIPADJ_STEPPER_ETDRK4_FIXED;
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING:
+        if (etd)
+            hipLaunchKernelGGL((k_bruss_adjoint_etd<G, 0>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
+                               (const int*)h->d_save_rev, (double*)nullptr, d_du0, h->d_dp_traj, h->d_flag);
+        else
         hipLaunchKernelGGL((k_bruss_adjoint<G, 0>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
                            (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
         HIP_TRY(h, hipGetLastError());
@@ -371,6 +382,10 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         break;
     case HIPADJ_ALG_QUADRATURE: {
+        if (etd)     // pass 1 with the exponential stepper; pass 2 (k_bruss_quad_gk) integrates over the same knots and the same dense record
+            hipLaunchKernelGGL((k_bruss_adjoint_etd<G, 3>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
+                               (const int*)h->d_save_rev, h->d_fadj, d_du0, (double*)nullptr, h->d_flag);
+        else
         hipLaunchKernelGGL((k_bruss_quad_adj<G>), grid, blk, 0, h->stream, h->fg, p, (const double*)h->d_fknots, d_cot,
                            (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag);
         HIP_TRY(h, hipGetLastError());

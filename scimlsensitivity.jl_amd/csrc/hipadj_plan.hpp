@@ -206,7 +206,12 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (P.field || P.mlp)) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && cfg->stepper == HIPADJ_STEPPER_RK4_FIXED && cfg->checkpointing && !P.wide) {
         err = "GaussKronrodAdjoint(checkpointing=true) on the fixed step is offered for wide models; the lane family has it with adaptive Tsit5"; return HIPADJ_ERR_UNSUPPORTED; }
-    if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ETDRK4_FIXED) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->stepper == HIPADJ_STEPPER_ETDRK4_FIXED) {   // the exponential stepper: everything below treats it as a fixed-step scheme with Hermite dense output
+        if (!P.field) { err = "HIPADJ_STEPPER_ETDRK4_FIXED integrates the semilinear PDE family (HIPADJ_MODEL_BRUSS): its linear part is diagonal in the DFT basis"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg != HIPADJ_ALG_INTERPOLATING && cfg->alg != HIPADJ_ALG_QUADRATURE) { err = "HIPADJ_STEPPER_ETDRK4_FIXED: Interpolating- and QuadratureAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->cont_cost != 0) { err = "HIPADJ_STEPPER_ETDRK4_FIXED: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
+    }
     if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {
         // adaptive path: no step grid; arbitrary ascending loss times inside [t0, t1]
         if (!plan_small_model(cfg->model)) { err = "adaptive Tsit5 is available for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Engine
-from .problems import (RK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, LsqData, ModelLoss, HalfSquaredSum,
+from .problems import (RK4, ETDRK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, LsqData, ModelLoss, HalfSquaredSum,
                        FirstStateSquaredPlusFirstParam, ModelCost)
 from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
                                      QuadratureAdjoint, GaussAdjoint, GaussKronrodAdjoint, ischeckpointing)
@@ -106,10 +106,10 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
                                         device=device, time_segments=time_segments, g=g, abstol=abstol, reltol=reltol, max_steps=max_steps, save_idxs=save_idxs,
                                         save_start=save_start, save_end=save_end, save_everystep=save_everystep)
     adaptive = isinstance(alg, Tsit5)
-    if not adaptive and not isinstance(alg, RK4):
-        raise ValueError("alg must be RK4() (fixed step) or Tsit5() (adaptive)")
+    if not adaptive and not isinstance(alg, (RK4, ETDRK4)):
+        raise ValueError("alg must be RK4() / ETDRK4() (fixed step) or Tsit5() (adaptive)")
     if not adaptive and dt is None:
-        raise ValueError("RK4() needs dt")
+        raise ValueError("RK4() / ETDRK4() need dt")
     if dt is None:
         dt = 0.0
     if not isinstance(sensealg, AbstractAdjointSensitivityAlgorithm):
@@ -134,7 +134,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     eng = Engine(prob.f, sensealg.name, ensprob.u0.shape[0], prob.tspan[0], prob.tspan[1], dt, save_times=ts,
                  loss_kind=loss_kind, loss_shift=shift, loss_scale=scale, devices=devices, reference_literal=reference_literal, p_shared=(ensprob.p.ndim == 1), device=device,
                  time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_COSTS[type(g)] if g is not None else 0),
-                 stepper=(1 if adaptive else 0), abstol=abstol, reltol=reltol, max_steps=max_steps,
+                 stepper=(1 if adaptive else (2 if isinstance(alg, ETDRK4) else 0)), abstol=abstol, reltol=reltol, max_steps=max_steps,
                  **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive, t1=prob.tspan[1]))
     if isinstance(dgdu_discrete, (LsqData, ModelLoss)) and dgdu_discrete.data is not None and eng.M > 0:
         eng.set_loss_data(np.asarray(dgdu_discrete.data, dtype=np.float64).reshape(eng.N, eng.M, eng.n))
