@@ -109,7 +109,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     if not adaptive and not isinstance(alg, (RK4, ETDRK4)):
         raise ValueError("alg must be RK4() / ETDRK4() (fixed step) or Tsit5() (adaptive)")
     if not adaptive and dt is None:
-        raise ValueError("RK4() / ETDRK4() need dt")
+        raise ValueError("a fixed-step alg (RK4(), ETDRK4()) needs dt")
     if dt is None:
         dt = 0.0
     if not isinstance(sensealg, AbstractAdjointSensitivityAlgorithm):
