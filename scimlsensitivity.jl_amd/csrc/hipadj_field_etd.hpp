@@ -58,7 +58,7 @@ __device__ __forceinline__ void etd_phi(double z, double& ez, double& p1, double
         p1 = a1; p2 = a2; p3 = a3;
     } else { p1 = (ez - 1.0) / z; p2 = (p1 - 1.0) / z; p3 = (p2 - 0.5) / z; }
 }
-struct EtdCoef { double E, E2, Q, f1, f2, f3; };
+struct EtdCoef { double E2, Q, f1, f2, f3; };      // e^{hM} is taken as (e^{hM/2})^2 where it is used (two registers less in a kernel that has 128; the oracle does the same)
 __device__ __forceinline__ int etd_rev(int x, int bits) { return (int)(__brev((unsigned)x) >> (32 - bits)); }
 // coefficients of this thread's mode for dz/dt = coef * L z + N, signed step h
 template <int G>
@@ -72,7 +72,7 @@ __device__ __forceinline__ EtdCoef etd_coefs(double coef, double h) {
     double ez, p1, p2, p3, ezh, q1, q2, q3;
     etd_phi(z, ez, p1, p2, p3); etd_phi(0.5 * z, ezh, q1, q2, q3);
     EtdCoef c;
-    c.E = ez; c.E2 = ezh; c.Q = 0.5 * h * q1;
+    (void)ez; c.E2 = ezh; c.Q = 0.5 * h * q1;
     c.f1 = h * (p1 - 3.0 * p2 + 4.0 * p3); c.f2 = h * (p2 - 2.0 * p3); c.f3 = h * (4.0 * p3 - p2);
     return c;
 }
@@ -95,7 +95,9 @@ template <int G> struct EtdFft {
     // one butterfly level of span M.  DIF (forward): exchange, then the upper lane multiplies by w^k; DIT (inverse): the upper lane multiplies by conj(w)^k, then exchange
     template <int M, bool INV> __device__ __forceinline__ void level(double& re, double& im) const {
         const bool up = (r & M) != 0;
-        const int k = (r & (M - 1)) * (G / (2 * M));
+        int k = (r & (M - 1)) * (G / (2 * M));
+        asm volatile("" : "+v"(k));      // keeps the twiddle reads where they are: hoisted out of the time loop, the ten pairs of a 2-D transform cost the kernel (128 registers per lane at
+                                         // 1024 threads) 58 spilled registers
         const double wr = up ? L->tw_re[k] : 1.0, wi = up ? (INV ? -L->tw_im[k] : L->tw_im[k]) : 0.0;
         const double sg = up ? -1.0 : 1.0;
         if (INV) { const double a = re * wr - im * wi, b = re * wi + im * wr; re = a; im = b; }
@@ -172,14 +174,24 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_forward_etd(FieldGeom g, 
         double n3r, n3i; etd_react<G>(nb, P, tmid, sr, si, n3r, n3i); F.fwd(n3r, n3i);
         sr = c.E2 * ar + c.Q * (2.0 * n3r - n1r); si = c.E2 * ai + c.Q * (2.0 * n3i - n1i); F.inv(sr, si);
         double n4r, n4i; etd_react<G>(nb, P, tmid, sr, si, n4r, n4i); F.fwd(n4r, n4i);
-        zr = c.E * zr + c.f1 * n1r + 2.0 * c.f2 * (n2r + n3r) + c.f3 * n4r;
-        zi = c.E * zi + c.f1 * n1i + 2.0 * c.f2 * (n2i + n3i) + c.f3 * n4i;
+        zr = (c.E2 * c.E2) * zr + c.f1 * n1r + 2.0 * c.f2 * (n2r + n3r) + c.f3 * n4r;
+        zi = (c.E2 * c.E2) * zi + c.f1 * n1i + 2.0 * c.f2 * (n2i + n3i) + c.f3 * n4i;
         sr = zr; si = zi; F.inv(sr, si);
         U[0] = sr; V[0] = si;
     }
 }
 
 // ---- reverse pass: InterpolatingAdjoint (ALG = 0: lam and the gradient partials) and QuadratureAdjoint pass 1 (ALG = 3: lam only, dense record for k_bruss_quad_gk) ----
+// publish (a, b) and take the 5-point stencil of both at this thread's cell.  NOT inlined: four inlined copies per reverse step (one per stage) cost the Interpolating kernel
+// 70 registers — 56 of them spilled at the 128 a lane has with 1024 threads (kernel-resource-usage remarks) — and twice the time (23.3 instead of 11.9 us per step)
+template <int G>
+__device__ __attribute__((noinline)) void etd_publish_laplace(double* __restrict__ buf, int c, int im, int ip, int jm, int jp, double a, double b, double& La, double& Lb) {
+    constexpr int CELLS = Bruss<G>::CELLS;
+    buf[c] = a; buf[CELLS + c] = b;
+    __syncthreads();
+    La = buf[im] + buf[ip] + buf[jp] + buf[jm] - 4.0 * a;
+    Lb = buf[CELLS + im] + buf[CELLS + ip] + buf[CELLS + jp] + buf[CELLS + jm] - 4.0 * b;
+}
 // N(lam; y) = -R(y)^T lam (the reaction block of the transposed Jacobian, negated: lam' = M lam + N with M = -(alpha/dx^2) L); WITH_P: the gradient partials
 // w += wgt * (df/dp)^T lam, whose alpha entry needs L lam of the stage (published for the stencil)
 template <int G, bool WITH_P>
@@ -189,9 +201,8 @@ __device__ __forceinline__ void etd_adj_react(EtdLds<G>& L, int /*unused*/, cons
     nU = -((uv2 - (P.A + 1.0)) * lU + (P.A - uv2) * lV);
     nV = -(uu * lU - uu * lV);
     if (WITH_P) {
-        double a[1] = {lU}, b[1] = {lV}, La[1], Lb[1];
-        publish<G>(L.sh[0], nb, a, b);
-        laplace<G>(L.sh[0], nb, a, b, La, Lb);
+        double La[1], Lb[1];
+        etd_publish_laplace<G>(L.sh[0], nb.c[0], nb.im[0], nb.ip[0], nb.jm[0], nb.jp[0], lU, lV, La[0], Lb[0]);
         w[0] += wgt * (-yU * lU + yU * lV);
         w[1] += wgt * lU;
         w[2] += wgt * ((yU * La[0] + yV * Lb[0]) * P.idx2);
@@ -221,14 +232,13 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
     const EtdCoef c = etd_coefs<G>(-P.adx, -dt);              // lam' = -(alpha/dx^2) L lam + N, stepped with h = -dt
     const int cell = nb.c[0];
     double lU[1] = {0.0}, lV[1] = {0.0}, w[3] = {0.0, 0.0, 0.0};
-    FKnot<G> hi, lo, nx;
+    FKnot<G> hi, lo;
     load_fknot<G>(knots, g, traj, g.S, nb, hi);
     { const int s = save_of_knot[g.S]; if (s >= 0) field_jump<G>(g, traj, s, cot, nb, hi.U, hi.V, lU, lV); }
-    load_fknot<G>(knots, g, traj, g.S - 1, nb, lo);
     double zr = lU[0], zi = lV[0];
     F.fwd(zr, zi);
     for (int k = g.S - 1; k >= 0; --k) {
-        load_fknot<G>(knots, g, traj, k > 0 ? k - 1 : 0, nb, nx);
+        load_fknot<G>(knots, g, traj, k, nb, lo);              // no knot prefetch: at 1024 threads a wave has 128 registers and the step's chain of transforms hides the load
         const double mU = 0.5 * (lo.U[0] + hi.U[0]) + (0.125 * dt) * (lo.fU[0] - hi.fU[0]);      // Hermite midpoint of the forward knots
         const double mV = 0.5 * (lo.V[0] + hi.V[0]) + (0.125 * dt) * (lo.fV[0] - hi.fV[0]);
         double* rec = ALG == 3 ? adj + ((traj * g.S + k) * 4) * NS : nullptr;
@@ -245,8 +255,8 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
         double n3r, n3i; etd_adj_react<G, WP>(L, 0, nb, P, mU, mV, sr, si, n3r, n3i, dt / 3.0, w); F.fwd(n3r, n3i);
         sr = c.E2 * ar + c.Q * (2.0 * n3r - n1r); si = c.E2 * ai + c.Q * (2.0 * n3i - n1i); F.inv(sr, si);
         double n4r, n4i; etd_adj_react<G, WP>(L, 1, nb, P, lo.U[0], lo.V[0], sr, si, n4r, n4i, dt / 6.0, w); F.fwd(n4r, n4i);
-        zr = c.E * zr + c.f1 * n1r + 2.0 * c.f2 * (n2r + n3r) + c.f3 * n4r;
-        zi = c.E * zi + c.f1 * n1i + 2.0 * c.f2 * (n2i + n3i) + c.f3 * n4i;
+        zr = (c.E2 * c.E2) * zr + c.f1 * n1r + 2.0 * c.f2 * (n2r + n3r) + c.f3 * n4r;
+        zi = (c.E2 * c.E2) * zi + c.f1 * n1i + 2.0 * c.f2 * (n2i + n3i) + c.f3 * n4i;
         sr = zr; si = zi; F.inv(sr, si);
         lU[0] = sr; lV[0] = si;
         if (ALG == 3) {
@@ -260,7 +270,7 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
               field_jump<G>(g, traj, s, cot, nb, lo.U, lo.V, lU, lV);
               zr = lU[0]; zi = lV[0]; F.fwd(zr, zi);            // the jump changed lam in real space: refresh its spectral image
           } }
-        hi = lo; lo = nx;
+        hi = lo;
     }
     if (ALG == 3) {
         du0[traj * NS + cell] = lU[0]; du0[traj * NS + CELLS + cell] = lV[0];

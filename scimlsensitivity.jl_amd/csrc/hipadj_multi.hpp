@@ -16,7 +16,7 @@
 #include "hipadj_host.hpp"
 
 static int forward_host_enqueue(hipadj_handle* h, const double* u0, const double* p, double* out);
-static int adjoint_host_enqueue(hipadj_handle* h, const double* dLdu, double* du0, double* dp);
+static int adjoint_host_enqueue(hipadj_handle* h, const double* dLdu, double* du0, double* dp, bool drain_first);
 
 static __global__ void k_sum_rows(int G, int np, const double* __restrict__ parts, double* __restrict__ dp) {   // dp[j] = sum_g parts[g][j], shard order
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,7 +110,7 @@ static int multi_adjoint(hipadj_handle* h, const double* dLdu, double* du0, doub
     const int G = (int)h->shards.size(); const size_t n = h->n, np = h->np, M = h->M;
     for (int g = 0; g < G; ++g) {
         const size_t lo = (size_t)h->shard_off[g];
-        const int rc = adjoint_host_enqueue(h->shards[g], dLdu ? dLdu + lo * M * n : nullptr, du0 + lo * n, h->cfg.p_shared ? h->dp_host.data() + (size_t)g * np : dp + lo * np);
+        const int rc = adjoint_host_enqueue(h->shards[g], dLdu ? dLdu + lo * M * n : nullptr, du0 + lo * n, h->cfg.p_shared ? h->dp_host.data() + (size_t)g * np : dp + lo * np, false);
         if (rc != HIPADJ_OK) return multi_fail(h, g, rc);
     }
     TRY(multi_synchronize(h));
