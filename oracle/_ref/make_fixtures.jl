@@ -151,6 +151,29 @@ let
     end
 end
 
+# (8) the two deliberate deviations under GaussAdjoint, each decided by ONE number (DESIGN.md 6.5 / 6.11; hipadj_config.reference_literal, orc_config.reference_literal):
+#     (a) dgdp_continuous: src/gauss_adjoint.jl:753-758 computes -f_p' lam + g_p, the library -f_p' lam - g_p (which keeps Gauss == Interpolating == Quadrature);
+#     (b) dgdp_discrete: GaussAdjoint's callback has no slot for it (src/gauss_adjoint.jl:820-851), Interpolating / Quadrature add it (src/adjoint_common.jl:775-779).
+#     The problem and costs of test/Core7/mixed_costs.jl:10-57 (g = u1^2 + p1); "dp_interpolating" is the same gradient from InterpolatingAdjoint: if the reference's Gauss
+#     differs from it by 2 * integral(g_p) = 2 * (t1 - t0) in dp[1], (a) is as the source reads; if its discrete case misses sum_i dgdp_i, (b) is.
+let
+    u0 = [1.0, 1.0]; p = [1.5, 1.0, 3.0, 1.0]; tspan = (0.0, 10.0); ts = collect(1.0:1.0:9.0)
+    prob = ODEProblem(lv!, u0, tspan, p)
+    sol = solve(prob, Tsit5(); abstol = 1e-12, reltol = 1e-12)
+    gcont(u, p, t) = u[1]^2 + p[1]
+    dgu(out, u, p, t) = (out .= 0.0; out[1] = 2.0 * u[1])
+    dgp(out, u, p, t) = (out .= 0.0; out[1] = 1.0)
+    dgud(out, u, p, t, i) = (out .= 0.0; out[1] = 2.0 * u[1])
+    dgpd(out, u, p, t, i) = (out .= 0.0; out[1] = 1.0)
+    for (nm, sa) in (("GAUSS", GaussAdjoint(autojacvec = ReverseDiffVJP())), ("INTERPOLATING", InterpolatingAdjoint(autojacvec = ReverseDiffVJP())))
+        _, dpc = adjoint_sensitivities(sol, Tsit5(); g = gcont, dgdu_continuous = dgu, dgdp_continuous = dgp, sensealg = sa, abstol = 1e-12, reltol = 1e-12)
+        _, dpd = adjoint_sensitivities(sol, Tsit5(); t = ts, dgdu_discrete = dgud, dgdp_discrete = dgpd, sensealg = sa, abstol = 1e-12, reltol = 1e-12)
+        push!(cases, Dict("name" => "gauss_literal_$nm", "kind" => "gauss_literal", "model" => "LV", "alg" => nm, "stepper" => "TSIT5", "tspan" => collect(tspan),
+                          "abstol" => 1e-12, "reltol" => 1e-12, "ts" => ts, "u0" => u0, "p" => p, "dp_continuous_cost" => vec(collect(dpc)), "dp_discrete_cost" => vec(collect(dpd)),
+                          "targets" => "the sign of g_p in the Gauss integrand and the fate of dgdp_discrete under GaussAdjoint: compare with orc_config.reference_literal = 0 / 1"))
+    end
+end
+
 open(joinpath(@__DIR__, "..", "..", "tests", "golden", "reference_fixtures.json"), "w") do io
     JSON.print(io, Dict("generator" => "oracle/_ref/make_fixtures.jl", "SciMLSensitivity" => string(pkgversion(SciMLSensitivity)),
                         "OrdinaryDiffEq" => string(pkgversion(OrdinaryDiffEq)), "julia" => string(VERSION), "cases" => cases), 1)
