@@ -65,7 +65,7 @@ typedef enum {
     HIPADJ_STEPPER_RK4_FIXED = 0,      /* fixed-step classic RK4, cubic-Hermite dense output; loss times on the step grid */
     HIPADJ_STEPPER_ETDRK4_FIXED = 2,   /* fixed-step exponential RK4 (Cox & Matthews 2002; OrdinaryDiffEq's ETDRK4) for the semilinear PDE family (HIPADJ_MODEL_BRUSS): the
                                         * diffusion term is integrated exactly in the 2-D DFT basis, dt is bound by the reaction terms only — the stiff stepper for the
-                                        * horizon the reference documents (docs/src/examples/pde/brusselator.md:115 uses FBDF).  Interpolating- and QuadratureAdjoint,
+                                        * horizon the reference documents (docs/src/examples/pde/brusselator.md:115 uses FBDF).  Interpolating-, Gauss- and QuadratureAdjoint,
                                         * loss times on the step grid, cubic-Hermite dense output like RK4_FIXED.  */
     HIPADJ_STEPPER_TSIT5_ADAPTIVE = 1  /* adaptive Tsit5 with per-trajectory step control and its own interpolant (the stepper of
                                           the reference's tests); arbitrary loss times; lane-per-trajectory models; all four

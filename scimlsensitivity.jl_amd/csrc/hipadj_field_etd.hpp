@@ -83,7 +83,7 @@ template <int M> __device__ __forceinline__ double etd_xor(double v) {      // t
     return __hiloint2double(hi, lo);
 }
 
-template <int G> struct EtdFft {
+template <int G, bool PIN_TWIDDLES = false> struct EtdFft {      // PIN_TWIDDLES: keep the twiddle reads inside the transforms (kernels at their register limit)
     EtdLds<G>* L; int par;
     int r, row;
     __device__ __forceinline__ void init(EtdLds<G>* lds) {
@@ -96,8 +96,9 @@ template <int G> struct EtdFft {
     template <int M, bool INV> __device__ __forceinline__ void level(double& re, double& im) const {
         const bool up = (r & M) != 0;
         int k = (r & (M - 1)) * (G / (2 * M));
-        asm volatile("" : "+v"(k));      // keeps the twiddle reads where they are: hoisted out of the time loop, the ten pairs of a 2-D transform cost the kernel (128 registers per lane at
-                                         // 1024 threads) 58 spilled registers
+        if constexpr (PIN_TWIDDLES) asm volatile("" : "+v"(k));      // keeps the twiddle reads where they are: hoisted out of the time loop, the ten pairs of a 2-D transform cost the
+                                                                     // Interpolating kernel (128 registers per lane at 1024 threads) 58 spilled registers; the forward and the lambda-only
+                                                                     // kernels have the room and let the compiler keep them in registers
         const double wr = up ? L->tw_re[k] : 1.0, wi = up ? (INV ? -L->tw_im[k] : L->tw_im[k]) : 0.0;
         const double sg = up ? -1.0 : 1.0;
         if (INV) { const double a = re * wr - im * wi, b = re * wi + im * wr; re = a; im = b; }
@@ -181,12 +182,15 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_forward_etd(FieldGeom g, 
     }
 }
 
-// ---- reverse pass: InterpolatingAdjoint (ALG = 0: lam and the gradient partials) and QuadratureAdjoint pass 1 (ALG = 3: lam only, dense record for k_bruss_quad_gk) ----
+// ---- reverse pass: InterpolatingAdjoint (ALG = 0: lam and the gradient partials), GaussAdjoint (ALG = 2: lam only + two Gauss nodes per step) and QuadratureAdjoint
+// pass 1 (ALG = 3: lam only, dense record for k_bruss_quad_gk) ----
 // publish (a, b) and take the 5-point stencil of both at this thread's cell.  NOT inlined: four inlined copies per reverse step (one per stage) cost the Interpolating kernel
 // 70 registers — 56 of them spilled at the 128 a lane has with 1024 threads (kernel-resource-usage remarks) — and twice the time (23.3 instead of 11.9 us per step)
 template <int G>
-__device__ __attribute__((noinline)) void etd_publish_laplace(double* __restrict__ buf, int c, int im, int ip, int jm, int jp, double a, double b, double& La, double& Lb) {
+__device__ __attribute__((noinline)) void etd_publish_laplace(double* __restrict__ buf, int c, int im, int ip, int jm, int jp, double a, double b, double& La, double& Lb,
+                                                              bool lead_sync = false) {
     constexpr int CELLS = Bruss<G>::CELLS;
+    if (lead_sync) __syncthreads();      // uniform: the previous reader of `buf` had no barrier after it (two publications with no transform in between)
     buf[c] = a; buf[CELLS + c] = b;
     __syncthreads();
     La = buf[im] + buf[ip] + buf[jp] + buf[jm] - 4.0 * a;
@@ -222,13 +226,13 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
                                                                    const double* __restrict__ cot, const int* __restrict__ save_of_knot, double* __restrict__ adj,
                                                                    double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
     constexpr int CELLS = Bruss<G>::CELLS, NS = Bruss<G>::NS;
-    constexpr bool WP = ALG == 0;
+    constexpr bool WP = ALG == 0, REC = ALG == 3, GAUSS = ALG == 2;
     __shared__ EtdLds<G> L;
     const long traj = blockIdx.x;
     Nbr<G> nb; nb.init();
     const BrussP P = load_bruss_p<G>(p, g.p_shared, traj);
     const double dt = g.dt;
-    EtdFft<G> F; F.init(&L);
+    EtdFft<G, ALG != 3> F; F.init(&L);
     const EtdCoef c = etd_coefs<G>(-P.adx, -dt);              // lam' = -(alpha/dx^2) L lam + N, stepped with h = -dt
     const int cell = nb.c[0];
     double lU[1] = {0.0}, lV[1] = {0.0}, w[3] = {0.0, 0.0, 0.0};
@@ -241,11 +245,12 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
         load_fknot<G>(knots, g, traj, k, nb, lo);              // no knot prefetch: at 1024 threads a wave has 128 registers and the step's chain of transforms hides the load
         const double mU = 0.5 * (lo.U[0] + hi.U[0]) + (0.125 * dt) * (lo.fU[0] - hi.fU[0]);      // Hermite midpoint of the forward knots
         const double mV = 0.5 * (lo.V[0] + hi.V[0]) + (0.125 * dt) * (lo.fV[0] - hi.fV[0]);
-        double* rec = ALG == 3 ? adj + ((traj * g.S + k) * 4) * NS : nullptr;
-        if (ALG == 3) {
-            double vU, vV;
-            etd_adj_full<G>(L, 0, nb, P, hi.U[0], hi.V[0], lU[0], lV[0], vU, vV);
-            rec[cell] = lU[0]; rec[CELLS + cell] = lV[0]; rec[NS + cell] = -vU; rec[NS + CELLS + cell] = -vV;
+        double* rec = REC ? adj + ((traj * g.S + k) * 4) * NS : nullptr;
+        double hU = 0.0, hV = 0.0, v1U = 0.0, v1V = 0.0;          // GaussAdjoint: lam and J^T lam at the start of the step (the Hermite data of lam over the step)
+        if (REC || GAUSS) {
+            etd_adj_full<G>(L, 0, nb, P, hi.U[0], hi.V[0], lU[0], lV[0], v1U, v1V);
+            if (REC) { rec[cell] = lU[0]; rec[CELLS + cell] = lV[0]; rec[NS + cell] = -v1U; rec[NS + CELLS + cell] = -v1V; }
+            hU = lU[0]; hV = lV[0];
         }
         double n1r, n1i; etd_adj_react<G, WP>(L, 0, nb, P, hi.U[0], hi.V[0], lU[0], lV[0], n1r, n1i, dt / 6.0, w); F.fwd(n1r, n1i);
         const double ar = c.E2 * zr + c.Q * n1r, ai = c.E2 * zi + c.Q * n1i;
@@ -259,11 +264,29 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
         zi = (c.E2 * c.E2) * zi + c.f1 * n1i + 2.0 * c.f2 * (n2i + n3i) + c.f3 * n4i;
         sr = zr; si = zi; F.inv(sr, si);
         lU[0] = sr; lV[0] = si;
-        if (ALG == 3) {
+        if (REC || GAUSS) {
             double vU, vV;
             etd_adj_full<G>(L, 1, nb, P, lo.U[0], lo.V[0], lU[0], lV[0], vU, vV);
-            rec[2 * NS + cell] = lU[0]; rec[2 * NS + CELLS + cell] = lV[0]; rec[3 * NS + cell] = -vU; rec[3 * NS + CELLS + cell] = -vV;
-            __syncthreads();                                     // the next step's opening record publishes into the same buffer with no transposition in between
+            if (REC) { rec[2 * NS + cell] = lU[0]; rec[2 * NS + CELLS + cell] = lV[0]; rec[3 * NS + cell] = -vU; rec[3 * NS + CELLS + cell] = -vV; }
+            if (GAUSS) {
+                // GaussAdjoint (src/gauss_adjoint.jl:745-759, 809-851): two Gauss-Legendre nodes per step, lam from the Hermite interpolant of the adjoint step
+                // (h = -dt, slopes -v1 at its start and -v at its end), y from the forward one — as k_bruss_adjoint<G, 2> does on the RK4 grid
+                const double xg = 0.5773502691896257645;
+#pragma unroll 1
+                for (int nq = 0; nq < 2; ++nq) {
+                    const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
+                    const double gU = (1.0 - th) * hU + th * lU[0] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lU[0] - hU) + (th - 1.0) * (-dt) * (-v1U) + th * (-dt) * (-vU));
+                    const double gV = (1.0 - th) * hV + th * lV[0] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lV[0] - hV) + (th - 1.0) * (-dt) * (-v1V) + th * (-dt) * (-vV));
+                    const double yU = (1.0 - tf) * lo.U[0] + tf * hi.U[0] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (hi.U[0] - lo.U[0]) + (tf - 1.0) * dt * lo.fU[0] + tf * dt * hi.fU[0]);
+                    const double yV = (1.0 - tf) * lo.V[0] + tf * hi.V[0] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (hi.V[0] - lo.V[0]) + (tf - 1.0) * dt * lo.fV[0] + tf * dt * hi.fV[0]);
+                    double La, Lb;
+                    etd_publish_laplace<G>(L.sh[0], nb.c[0], nb.im[0], nb.ip[0], nb.jm[0], nb.jp[0], gU, gV, La, Lb, true);
+                    w[0] += (0.5 * dt) * (-yU * gU + yU * gV);
+                    w[1] += (0.5 * dt) * gU;
+                    w[2] += (0.5 * dt) * ((yU * La + yV * Lb) * P.idx2);
+                }
+            }
+            __syncthreads();                                     // the next step's opening publication goes into the same buffer with no transposition in between
         }
         { const int s = save_of_knot[k];
           if (s >= 0 && !(g.no_start && s == 0)) {              // uniform over the workgroup
@@ -272,7 +295,7 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
           } }
         hi = lo;
     }
-    if (ALG == 3) {
+    if (REC) {
         du0[traj * NS + cell] = lU[0]; du0[traj * NS + CELLS + cell] = lV[0];
         if (!(fabs(lU[0]) <= 1.79769313486231570e308) || !(fabs(lV[0]) <= 1.79769313486231570e308)) atomicOr(flag, 1);
     } else field_finish<G>(g, traj, Npad, nb, lU, lV, w, L.red, du0, dp_traj, flag);

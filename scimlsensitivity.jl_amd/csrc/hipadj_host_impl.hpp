@@ -376,6 +376,10 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         break;
     case HIPADJ_ALG_GAUSS:
+        if (etd)
+            hipLaunchKernelGGL((k_bruss_adjoint_etd<G, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
+                               (const int*)h->d_save_rev, (double*)nullptr, d_du0, h->d_dp_traj, h->d_flag);
+        else
         hipLaunchKernelGGL((k_bruss_adjoint<G, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
                            (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
         HIP_TRY(h, hipGetLastError());

@@ -209,7 +209,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ETDRK4_FIXED) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->stepper == HIPADJ_STEPPER_ETDRK4_FIXED) {   // the exponential stepper: everything below treats it as a fixed-step scheme with Hermite dense output
         if (!P.field) { err = "HIPADJ_STEPPER_ETDRK4_FIXED integrates the semilinear PDE family (HIPADJ_MODEL_BRUSS): its linear part is diagonal in the DFT basis"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->alg != HIPADJ_ALG_INTERPOLATING && cfg->alg != HIPADJ_ALG_QUADRATURE) { err = "HIPADJ_STEPPER_ETDRK4_FIXED: Interpolating- and QuadratureAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg != HIPADJ_ALG_INTERPOLATING && cfg->alg != HIPADJ_ALG_QUADRATURE && cfg->alg != HIPADJ_ALG_GAUSS) { err = "HIPADJ_STEPPER_ETDRK4_FIXED: Interpolating-, Gauss- and QuadratureAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->cont_cost != 0) { err = "HIPADJ_STEPPER_ETDRK4_FIXED: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {

@@ -1,5 +1,5 @@
 """The exponential stepper of the PDE family on the device (HIPADJ_STEPPER_ETDRK4_FIXED, csrc/hipadj_field_etd.hpp: ETDRK4 with the diffusion term exact in the DFT
-basis, in-workgroup FFTs) against the oracle's restatement (ORC_STEPPER_ETDRK4) — forward solution, Interpolating- and QuadratureAdjoint, all grids, the loss kinds of
+basis, in-workgroup FFTs) against the oracle's restatement (ORC_STEPPER_ETDRK4) — forward solution, Interpolating-, Gauss- and QuadratureAdjoint, all grids, the loss kinds of
 the family, spans across the forcing switch — and against scipy's Radau directly (tests/golden/bruss_etd.json)."""
 import json
 import os
@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL = 1e-9
 
 
-@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("quadrature", "QUADRATURE")])
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("quadrature", "QUADRATURE"), ("gauss", "GAUSS")])
 @pytest.mark.parametrize("G,dt,t0,t1,N", [(8, 0.0125, 0.9, 1.4, 3), (16, 0.00625, 1.0, 1.2, 2), (32, 0.003125, 1.05, 1.15, 1)])
 def test_etdrk4_lsq_matches_oracle_across_the_forcing_switch(sa, alg, oalg, G, dt, t0, t1, N):
     u0 = bruss_u0(G, N); p = np.array([3.4, 1.0, 10.0])
     S = int(round((t1 - t0) / dt))
     ts = t0 + dt * np.arange(0, S + 1, S // 4)
     dims = (G, 0, 0, 0)
-    sens = sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10) if alg == "quadrature" else sa.InterpolatingAdjoint()
+    sens = sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10) if alg == "quadrature" else (sa.GaussAdjoint() if alg == "gauss" else sa.InterpolatingAdjoint())
     sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("bruss", u0[0], (t0, t1), p, dims), u0), sa.ETDRK4(), dt=dt, saveat=ts, sensealg=sens, dgdu_discrete=sa.LsqShift(2.0))
     du0, dp = sa.adjoint_sensitivities(sol, sa.ETDRK4(), t=ts)
     ref = O.Problem("BRUSS", alg=oalg, stepper="ETDRK4", t0=t0, t1=t1, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, dims=dims, quad_abstol=1e-10, quad_reltol=1e-10)
@@ -33,7 +33,7 @@ def test_etdrk4_lsq_matches_oracle_across_the_forcing_switch(sa, alg, oalg, G, d
     sol.engine.close()
 
 
-@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("quadrature", "QUADRATURE")])
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("quadrature", "QUADRATURE"), ("gauss", "GAUSS")])
 def test_etdrk4_cotangents_per_trajectory_parameters_and_data_loss(sa, alg, oalg):
     G, dt, t0, t1, N = 8, 0.0125, 0.0, 0.5, 4
     rng = np.random.default_rng(2)
@@ -41,7 +41,7 @@ def test_etdrk4_cotangents_per_trajectory_parameters_and_data_loss(sa, alg, oalg
     ts = np.array([0.0, 0.25, 0.5])
     delta = rng.standard_normal((N, len(ts), 2 * G * G))
     dims = (G, 0, 0, 0)
-    sens = sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10) if alg == "quadrature" else sa.InterpolatingAdjoint()
+    sens = sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10) if alg == "quadrature" else (sa.GaussAdjoint() if alg == "gauss" else sa.InterpolatingAdjoint())
     sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("bruss", u0[0], (t0, t1), p[0], dims), u0, p), sa.ETDRK4(), dt=dt, saveat=ts, sensealg=sens)
     du0, dp = sa.adjoint_sensitivities(sol, sa.ETDRK4(), t=ts, dgdu_discrete=delta)
     ref = O.Problem("BRUSS", alg=oalg, stepper="ETDRK4", t0=t0, t1=t1, dt=dt, save_times=ts, loss="COTANGENT", dims=dims, quad_abstol=1e-10, quad_reltol=1e-10)
@@ -97,4 +97,4 @@ def test_etdrk4_is_refused_outside_its_family(sa):
     with pytest.raises(sa.HipadjError):
         sa.Engine("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, save_times=[1.0], stepper=2)
     with pytest.raises(sa.HipadjError):
-        sa.Engine("bruss", "gauss", 1, 0.0, 1.0, 0.0125, save_times=[1.0], dims=(8, 0, 0, 0), stepper=2)
+        sa.Engine("bruss", "backsolve", 1, 0.0, 1.0, 0.0125, save_times=[1.0], dims=(8, 0, 0, 0), stepper=2)
