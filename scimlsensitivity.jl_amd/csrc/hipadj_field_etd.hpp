@@ -77,10 +77,18 @@ __device__ __forceinline__ EtdCoef etd_coefs(double coef, double h) {
     return c;
 }
 
-template <int M> __device__ __forceinline__ double etd_xor(double v) {      // the value of lane ^ M (rows of at most 32 lanes: the swizzle's bit mode)
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (M << 10) | 0x1F);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (M << 10) | 0x1F);
-    return __hiloint2double(hi, lo);
+// the value of lane ^ M.  M = 1, 2, 8 are single DPP moves on the vector pipe (quad_perm, row_ror:8), M = 4 is two (row_half_mirror = lane ^ 7, then quad_perm
+// [3, 2, 1, 0] = lane ^ 3); only M = 16 goes through the LDS crossbar (ds_swizzle, bit mode) — with sixteen wavefronts per CU the swizzles of a transform had the LDS pipe
+// as busy as the vector pipe
+template <int M> __device__ __forceinline__ int etd_xor32(int v) {
+    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+    else if constexpr (M == 4) return __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true), 0x1B, 0xf, 0xf, true);
+    else if constexpr (M == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);
+    else return __builtin_amdgcn_ds_swizzle(v, (M << 10) | 0x1F);
+}
+template <int M> __device__ __forceinline__ double etd_xor(double v) {
+    return __hiloint2double(etd_xor32<M>(__double2hiint(v)), etd_xor32<M>(__double2loint(v)));
 }
 
 template <int G, bool PIN_TWIDDLES = false> struct EtdFft {      // PIN_TWIDDLES: keep the twiddle reads inside the transforms (kernels at their register limit)
