@@ -226,6 +226,14 @@ int hipadj_model_set_mass_matrix(int32_t model_id, const double *M);
  * p_out (may be NULL), gp, gp_out: [N][np].  Not covered: ContinuousCallback (root finding + the implicit event-time corrections), save_positions
  * other than (false, false) — the host mirror defines the value saved AT an event time as the right limit. */
 int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
+/* The same for a wide model (hipadj_wmodel_register; ABI 108, round 5): dual numbers do not scale to 4096 states, so the reverse callback comes as text too.
+ * Both bodies are SERIAL code run by one thread per trajectory (an event happens a handful of times per solve), over plain arrays:
+ *   affect_body      edits un[0..N) / pn[0..NP) — copies of u / p on entry — from u, p, t
+ *   affect_vjp_body  edits lo[0..N) / go[0..NP) — copies of lam / gp on entry, i.e. the reverse callback of the identity — from lam, gp, u, p, t, so that
+ *                    lo = (dun/du)' lam + (dpn/du)' gp,  go = (dun/dp)' lam + (dpn/dp)' gp.  "" = the affect's Jacobian is the identity (a constant dose).
+ * e.g. affect "for (int i = 0; i < N; ++i) un[i] += p[1] / 8.0 * sin(u[i]);"  with  vjp "for (int i = 0; i < N; ++i) { lo[i] = lam[i] * (1.0 + p[1] / 8.0 * cos(u[i])); go[1] += lam[i] * sin(u[i]) / 8.0; }".
+ * Both NULL removes the affect.  hipadj_affect_apply / hipadj_affect_vjp below serve both families. */
+int hipadj_wmodel_set_affect(int32_t model_id, const char *affect_body, const char *affect_vjp_body);
 int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, double *out, double *p_out);
 int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, const double *lam,
                       const double *gp, double *lam_out, double *gp_out);

@@ -866,12 +866,12 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
      * snapped last step by (m-1) per interval and the step size degenerates after a few intervals (observed here:
      * 49^19 * 1e-15).  In exact arithmetic dt' == dt, so the oracle keeps the user's dt for fixed-step re-solves. */
     if (dt_hint > 0 && cfg->stepper == ORC_STEPPER_TSIT5) a.dt = dt_hint;
+    dense_init(sol, m->n, cfg->stepper);                        /* before any early return: the callers release `sol` on every path */
     if (cfg->stepper == ORC_STEPPER_ETDRK4) {                   /* u' = (alpha/dx^2) L u + N(u, t) */
         if (m->id != ORC_MODEL_BRUSS) return -6;
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
         a.split_G = G; a.split_coef = p[2] / (dx * dx);
     }
-    dense_init(sol, m->n, cfg->stepper);
     return integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, NULL, NULL, 0, sol, nrhs);
 }
 

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = (
     "hipadj_version", "hipadj_status_string", "hipadj_last_error", "hipadj_model_sizes", "hipadj_create",
     "hipadj_destroy", "hipadj_forward", "hipadj_adjoint", "hipadj_forward_dev", "hipadj_adjoint_dev",
     "hipadj_set_stream", "hipadj_synchronize", "hipadj_set_timing", "hipadj_get_stats",
-    "hipadj_model_register", "hipadj_wmodel_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_wmodel_set_cost", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
+    "hipadj_model_register", "hipadj_wmodel_register", "hipadj_model_check", "hipadj_model_check_config", "hipadj_runtime_compiler", "hipadj_model_set_cost", "hipadj_model_set_cost_function", "hipadj_wmodel_set_cost", "hipadj_model_set_mass_matrix", "hipadj_model_set_affect", "hipadj_wmodel_set_affect", "hipadj_affect_apply", "hipadj_affect_vjp",
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
     "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
     "hipadj_model_set_discrete_loss", "hipadj_model_set_discrete_loss_function", "hipadj_wmodel_set_discrete_loss", "hipadj_set_loss_data", "hipadj_set_loss_data_dev",
@@ -113,6 +113,7 @@ def load():
     L.hipadj_wmodel_set_cost.argtypes = [C.c_int32, C.c_char_p]
     L.hipadj_model_set_mass_matrix.argtypes = [C.c_int32, C.POINTER(C.c_double)]
     L.hipadj_model_set_affect.argtypes = [C.c_int32, C.c_char_p]
+    L.hipadj_wmodel_set_affect.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_affect_apply.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.hipadj_affect_vjp.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -197,6 +198,14 @@ def set_model_affect(model_id, body):
     """hipadj_model_set_affect: the DiscreteCallback affect of a runtime-registered model (None removes it)."""
     L = load()
     rc = L.hipadj_model_set_affect(int(model_id), None if body is None else body.encode())
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+
+
+def set_wide_model_affect(model_id, body, vjp_body):
+    """hipadj_wmodel_set_affect: the affect of a wide model and its reverse callback, both as serial text (None, None removes them)."""
+    L = load()
+    rc = L.hipadj_wmodel_set_affect(int(model_id), None if body is None else body.encode(), None if vjp_body is None else vjp_body.encode())
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
 

@@ -80,6 +80,9 @@ extern "C" int hipadj_model_set_mass_matrix(int32_t model_id, const double* M) {
     return user_set_mass_matrix(model_id, M, g_create_error);
 }
 
+extern "C" int hipadj_wmodel_set_affect(int32_t model_id, const char* affect_body, const char* affect_vjp_body) {
+    return user_set_wide_affect(model_id, affect_body, affect_vjp_body, g_create_error);
+}
 extern "C" int hipadj_model_set_affect(int32_t model_id, const char* affect_body) {
     return user_set_affect(model_id, affect_body, g_create_error);
 }
@@ -108,7 +111,8 @@ int affect_functions(int32_t model, int32_t device, AffectFns& F, std::string& e
 }
 int affect_functions_uncached(int32_t model, AffectFns& F, std::string& err) {
     std::vector<char> code; std::map<std::string, std::string> low;
-    const std::vector<std::string> exprs = {"hipadj::k_user_affect<hipadj::UserModel>", "hipadj::k_user_affect_vjp<hipadj::UserModel>"};
+    const std::vector<std::string> exprs = user_model_is_wide(model) ? std::vector<std::string>{"hipadj::k_wide_affect<hipadj::UserW>", "hipadj::k_wide_affect_vjp<hipadj::UserW>"}
+                                                                     : std::vector<std::string>{"hipadj::k_user_affect<hipadj::UserModel>", "hipadj::k_user_affect_vjp<hipadj::UserModel>"};
     const int rc = user_compile(model, exprs, code, low, err);
     if (rc != HIPADJ_OK) return rc;
     if (hipModuleLoadData(&F.mod, code.data()) != hipSuccess || hipModuleGetFunction(&F.apply, F.mod, low[exprs[0]].c_str()) != hipSuccess ||
@@ -1140,7 +1144,6 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
 
 // ---- wide runtime models: workgroup-per-trajectory family (hipadj_wide.hpp) ----------------------------------------------------------------
 static int wide_prepare(hipadj_handle* h) {
-    if (user_has_affect(h->cfg.model)) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "wide models carry no affect text");
     if (h->wide_ts5 && (h->cfg.alg == HIPADJ_ALG_INTERPOLATING || h->cfg.alg == HIPADJ_ALG_BACKSOLVE)) {
         const long lds = user_wide_ts5_interp_lds(h->cfg.model, h->cfg.alg == HIPADJ_ALG_BACKSOLVE) * 8;
         if (lds > 160L * 1024)

@@ -46,6 +46,7 @@ struct UserModelSrc {
     bool has_cost = false;
     // optional discrete loss ON THE DEVICE (hipadj_model_set_discrete_loss[_function], hipadj_wmodel_set_discrete_loss): dgdu_discrete / dgdp_discrete of ReverseLossCallback
     std::string dl_du, dl_dp, dl_fun, wdloss;
+    std::string waffect_vjp;           // wide models: the reverse callback of `affect` as text (hipadj_wmodel_set_affect)
     bool has_dloss = false;
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
     std::string affect;       // DiscreteCallback affect body (hipadj_model_set_affect): modifies un (pre-set to u) from u, p, t; empty = identity
@@ -256,6 +257,13 @@ inline std::string user_wide_struct(const UserModelSrc& m) {
           << "    template <bool WP> static __device__ __forceinline__ void dloss(double* __restrict__ dlam, double* __restrict__ gp, double (&acc)[" << na << "],\n"
           << "            const double* __restrict__ u, const double* __restrict__ p, double t, int i, const double* __restrict__ d, double* __restrict__ ws, int tid) {\n"
           << "        (void)dlam; (void)gp; (void)acc; (void)u; (void)p; (void)t; (void)i; (void)d; (void)ws; (void)tid;\n" << m.wdloss << "\n    }\n";
+    if (!m.affect.empty())   // DiscreteCallback affect of a wide model and its reverse callback (hipadj_wmodel_set_affect): serial bodies run by ONE thread per trajectory
+                             // between two pieces of an event chain (k_wide_affect / k_wide_affect_vjp, hipadj_wide.hpp) — an event happens a handful of times per solve
+        o << "    static __device__ void affect(double* __restrict__ un, double* __restrict__ pn, const double* __restrict__ u, const double* __restrict__ p, double t) {\n"
+          << "        (void)un; (void)pn; (void)u; (void)p; (void)t;\n" << m.affect << "\n    }\n"
+          << "    static __device__ void affect_vjp(double* __restrict__ lo, double* __restrict__ go, const double* __restrict__ lam, const double* __restrict__ gp,\n"
+          << "            const double* __restrict__ u, const double* __restrict__ p, double t) {\n"
+          << "        (void)lo; (void)go; (void)lam; (void)gp; (void)u; (void)p; (void)t;\n" << m.waffect_vjp << "\n    }\n";
     o << "};\n#undef tanh\n}  // namespace hipadj\n";
     return o.str();
 }
@@ -634,8 +642,18 @@ inline int user_set_affect(int32_t model, const char* body, std::string& err) {
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_affect: unknown model id (affects are attached to runtime-registered models)"; return HIPADJ_ERR_INVALID_ARG; }
-    if (R.models[idx].wide && body && *body) { err = "hipadj_model_set_affect: DiscreteCallback affects are not implemented for wide models (hipadj_wmodel_register)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (R.models[idx].wide && body && *body) { err = "hipadj_model_set_affect: a wide model (hipadj_wmodel_register) takes its affect together with the reverse callback: hipadj_wmodel_set_affect"; return HIPADJ_ERR_UNSUPPORTED; }
     R.models[idx].affect = body ? body : ""; R.models[idx].rev++;
+    return HIPADJ_OK;
+}
+// wide models: the affect and its reverse callback as text (no dual numbers at n up to 4096); both NULL removes them
+inline int user_set_wide_affect(int32_t model, const char* body, const char* vjp_body, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size() || !R.models[idx].wide) { err = "hipadj_wmodel_set_affect: not a wide model id (hipadj_wmodel_register)"; return HIPADJ_ERR_INVALID_ARG; }
+    if ((body && *body) != (vjp_body && *vjp_body) && !(body && *body && vjp_body)) { err = "hipadj_wmodel_set_affect: affect_body and affect_vjp_body come together (an empty vjp body = the identity reverse callback, e.g. a constant dose)"; return HIPADJ_ERR_INVALID_ARG; }
+    R.models[idx].affect = body ? body : ""; R.models[idx].waffect_vjp = vjp_body ? vjp_body : ""; R.models[idx].rev++;
     return HIPADJ_OK;
 }
 inline bool user_has_affect(int32_t model) {

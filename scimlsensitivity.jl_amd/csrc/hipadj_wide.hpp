@@ -1434,4 +1434,30 @@ struct WideProbe {
 #endif
 };
 
+// ---- DiscreteCallback affects of wide models (round 5; hipadj_wmodel_set_affect, the event chains of events.py / src/callback_tracking.jl:232-470) ----------------------
+// Same contract and argument lists as k_user_affect / k_user_affect_vjp of the lane family (hipadj_kernels.hpp), so hipadj_affect_apply / hipadj_affect_vjp launch either:
+// one thread per trajectory, the model's serial bodies on global rows.  un / pn start as copies of u / p; lo / go start as lam / gp (the reverse callback of the identity).
+template <class Mo>
+__global__ void __launch_bounds__(256) k_wide_affect(long N, long ldp, const double* __restrict__ u, const double* __restrict__ p, double t, double* __restrict__ out,
+                                                     double* __restrict__ p_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double* ui = u + i * Mo::N; const double* pi = p + i * ldp;
+    double* un = out + i * Mo::N; double* pn = p_out + i * Mo::NP;
+    for (int j = 0; j < Mo::N; ++j) un[j] = ui[j];
+    for (int j = 0; j < Mo::NP; ++j) pn[j] = pi[j];
+    Mo::affect(un, pn, ui, pi, t);
+}
+template <class Mo>
+__global__ void __launch_bounds__(256) k_wide_affect_vjp(long N, long ldp, const double* __restrict__ u, const double* __restrict__ p, double t, const double* __restrict__ lam,
+                                                         const double* __restrict__ gp, double* __restrict__ lam_out, double* __restrict__ gp_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double* ui = u + i * Mo::N; const double* pi = p + i * ldp; const double* li = lam + i * Mo::N; const double* gi = gp + i * Mo::NP;
+    double* lo = lam_out + i * Mo::N; double* go = gp_out + i * Mo::NP;
+    for (int j = 0; j < Mo::N; ++j) lo[j] = li[j];
+    for (int j = 0; j < Mo::NP; ++j) go[j] = gi[j];
+    Mo::affect_vjp(lo, go, li, gi, ui, pi, t);
+}
+
 }  // namespace hipadj

@@ -201,3 +201,45 @@ def test_published_neural_ode_benchmark_4096_trajectories_adaptive(sa, alg, oalg
                     checkpointing=(oalg == "BACKSOLVE"))
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(out, rout) < 1e-8 and rel(du0, rdu0) < 1e-7 and rel(dp, rdp) < 1e-7
+
+
+def test_config2_device_resident_data_loss_and_eight_shards_in_one_handle_at_size(sa):
+    """Round 5 at BASELINE configs[1]'s size: (i) the loss sum(abs2, sol .- data) evaluated inside the sweep (HIPADJ_LOSS_LSQ_DATA, the data block resident in the handle, no
+    cotangents) — every trajectory's du0 and the reduced dp against the oracle on all 10^4 trajectories, and the device-side loss value; (ii) the same ensemble through ONE
+    handle over eight (virtual) shards (hipadj_config.device_ids): du0 bit-identical to the single-device handle, dp at round-off (the partials are summed in shard order)."""
+    N, T, dt, u0, p, ts = _c2_setup()
+    data = 1.0 + 0.5 * np.random.default_rng(11).standard_normal((N, len(ts), 3))
+    loss = sa.LsqData(data, 2.0)
+    prob = sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0)
+    sol = sa.solve(prob, sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=loss)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=loss)
+    lv = sol.loss_value()
+    assert sol.engine.stats()["launches_per_pass"] == 1
+    sol.engine.close()
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_DATA", loss_scale=2.0)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, data)
+    assert rel(du0, rdu0) < RTOL
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < RTOL
+    want = float(np.sum((rout - data) ** 2))
+    assert abs(lv - want) <= 1e-9 * abs(want)
+    sol8 = sa.solve(prob, sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=loss, devices=[0] * 8)
+    du8, dp8 = sa.adjoint_sensitivities(sol8, sa.RK4(), t=ts, dgdu_discrete=loss)
+    sol8.engine.close()
+    assert np.array_equal(du8, du0)
+    assert np.max(np.abs(dp8 - dp) / np.abs(dp)) < 1e-11
+
+
+def test_config5_exponential_stepper_at_size_across_the_forcing_switch(sa):
+    """configs[4]'s grid (32 x 32, n = 2048) on the stiff stepper of round 5 (HIPADJ_STEPPER_ETDRK4_FIXED) over (0, 2.2) — 1408 steps of dt = 1/640 across the switch of
+    the forcing at t = 1.1 — QuadratureAdjoint (the config's sensealg) and InterpolatingAdjoint against the oracle's ETDRK4: out, du0, dp."""
+    G, dt, S = 32, 0.0015625, 1408
+    u0 = bruss_u0(G, 1); p = np.array([3.4, 1.0, 10.0])
+    ts = np.array([0.55, 1.1, 1.65, 2.2])
+    delta = np.random.default_rng(1).standard_normal((1, len(ts), 2 * G * G))
+    for sens, oalg in ((sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10), "QUADRATURE"), (sa.InterpolatingAdjoint(), "INTERPOLATING")):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("bruss", u0[0], (0.0, S * dt), p, (G, 0, 0, 0)), u0), sa.ETDRK4(), dt=dt, saveat=ts, sensealg=sens, save_start=False)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.ETDRK4(), t=ts, dgdu_discrete=delta)
+        ref = O.Problem("BRUSS", alg=oalg, stepper="ETDRK4", t0=0.0, t1=S * dt, dt=dt, save_times=ts, loss="COTANGENT", dims=(G, 0, 0, 0), quad_abstol=1e-10, quad_reltol=1e-10)
+        rdu0, rdp, rout = ref.adjoint(u0[0], p, delta[0])
+        assert rel(sol.u[0], rout) < RTOL and rel(du0[0], rdu0) < RTOL and rel(dp, rdp) < RTOL, oalg
+        sol.engine.close()

@@ -134,7 +134,7 @@ def test_kernel_choice_of_the_wide_family(sa, tmp_path, monkeypatch):
     assert "k_wide_quad_adj<hipadj::WideWithCost<hipadj::UserW, 2>>" in e and "k_wide_quad_gk<hipadj::WideWithCost<hipadj::UserW, 2>, 32, false>" in e
 
 
-def test_wide_models_refuse_mass_matrix_cost_text_and_affect(sa):
+def test_wide_models_refuse_mass_matrix_and_lane_style_cost_or_affect_text(sa):
     """set_mass_matrix on a wide model used to overflow the n <= 8 stack arrays of the lane family; the wide kernels
     consult neither a mass matrix nor cost / affect text, so all three are refused at the C ABI with HIPADJ_ERR_UNSUPPORTED."""
     fun = sa.WideDeviceFunction.dense_linear("t_refuse40", 40)
@@ -151,9 +151,12 @@ def test_wide_models_refuse_mass_matrix_cost_text_and_affect(sa):
     assert L.hipadj_wmodel_set_cost(0, b"") == -1                      # not a wide model id
     fun.set_cost(body="HIPADJ_W_FOR(i, N) dlam[i] += u[i];")        # g = |u|^2 / 2: accepted, compiled with the sweeps of a handle that selects it
     fun.set_cost(body=None)
-    with pytest.raises(sa.HipadjError) as e:
-        fun.set_affect("un[0] += 1.0;")
-    assert e.value.status == -6
+    with pytest.raises(sa.HipadjError) as e:        # the lane family's affect setter (dual-number reverse callback) refuses a wide model and names the right entry point
+        _lib.set_model_affect(fun.id, "un[0] += 1.0;")
+    assert e.value.status == -6 and "hipadj_wmodel_set_affect" in str(e.value)
+    fun.set_affect("un[0] += 1.0;", "")             # round 5: a wide model takes the affect together with its reverse callback as text (hipadj_wmodel_set_affect)
+    assert L.hipadj_wmodel_set_affect(0, b"un[0] += 1.0;", b"") == -1          # not a wide model id
+    fun.set_affect(None)
     fun.set_mass_matrix(None)       # removing what was never there stays a no-op
 
 
