@@ -206,7 +206,7 @@ def test_published_neural_ode_benchmark_4096_trajectories_adaptive(sa, alg, oalg
 def test_config2_device_resident_data_loss_and_eight_shards_in_one_handle_at_size(sa):
     """Round 5 at BASELINE configs[1]'s size: (i) the loss sum(abs2, sol .- data) evaluated inside the sweep (HIPADJ_LOSS_LSQ_DATA, the data block resident in the handle, no
     cotangents) — every trajectory's du0 and the reduced dp against the oracle on all 10^4 trajectories, and the device-side loss value; (ii) the same ensemble through ONE
-    handle over eight (virtual) shards (hipadj_config.device_ids): du0 bit-identical to the single-device handle, dp at round-off (the partials are summed in shard order)."""
+    handle over eight (virtual) shards (hipadj_config.device_ids): du0 and dp equal to the single-device handle's at round-off (the shards choose their own time segmentation; the dp partials are summed in shard order)."""
     N, T, dt, u0, p, ts = _c2_setup()
     data = 1.0 + 0.5 * np.random.default_rng(11).standard_normal((N, len(ts), 3))
     loss = sa.LsqData(data, 2.0)
@@ -225,7 +225,7 @@ def test_config2_device_resident_data_loss_and_eight_shards_in_one_handle_at_siz
     sol8 = sa.solve(prob, sa.RK4(), dt=dt, saveat=ts, sensealg=sa.InterpolatingAdjoint(), dgdu_discrete=loss, devices=[0] * 8)
     du8, dp8 = sa.adjoint_sensitivities(sol8, sa.RK4(), t=ts, dgdu_discrete=loss)
     sol8.engine.close()
-    assert np.array_equal(du8, du0)
+    assert rel(du8, du0) < 1e-11          # not bit-identical at this size: a 1250-trajectory shard runs 51 time segments, the 10^4 ensemble 13 (another association of the same maps)
     assert np.max(np.abs(dp8 - dp) / np.abs(dp)) < 1e-11
 
 
