@@ -1722,21 +1722,25 @@ extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* 
     return hipadj_synchronize(h);
 }
 
-// drain_first: wait for the reverse pass before the two small downloads into the caller's PAGEABLE arrays are requested.  A pageable device-to-host copy behind pending work
-// makes the runtime wait for the stream on a slow path (measured: 8 ms per call of the 10^4-trajectory pass against 1 ms when the stream is idle at that point,
-// profiles/r5_visit4_bench.json vs r5_visit7_bench.json); the single-handle call has nothing to overlap with, a handle over several devices keeps the asynchronous form
-// (it enqueues on every shard before it drains any).
-static int adjoint_host_enqueue(hipadj_handle* h, const double* dLdu, double* du0, double* dp, bool drain_first) {
+// The host-pointer reverse call in two phases: adjoint_host_run (upload of the cotangents + the reverse pass, nothing waits) and adjoint_host_download (the two small
+// downloads into the caller's PAGEABLE arrays, requested only once the stream is drained).  A pageable device-to-host copy behind pending work makes the runtime wait for the
+// stream on a slow path (measured: 8 ms per call of the 10^4-trajectory pass against 1 ms when the stream is idle at that point, profiles/r5_visit4_bench.json vs
+// r5_visit7_bench.json).  A handle over several devices runs phase 1 on every shard before phase 2 on any, so the devices still work concurrently (hipadj_multi.hpp).
+static int adjoint_host_run(hipadj_handle* h, const double* dLdu) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const bool cot = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0;
     if (cot && !dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
     if (cot) TRY(upload_block(h, h->d_io_a, dLdu, (size_t)h->N * h->M * h->n));
     TRY(hipadj_adjoint_dev(h, cot ? h->d_io_a : nullptr, h->d_du0, h->d_dp));
-    const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
-    // an overlapped all-reduce (hipadj_comm_overlap) runs on the handle's SECOND stream: the copy of dp below is enqueued on the first one and has to wait for the collective
+    // an overlapped all-reduce (hipadj_comm_overlap) runs on the handle's SECOND stream: the copy of dp is enqueued on the first one and has to wait for the collective
     // that was just recorded, not only for the reverse pass (with more than one rank the host could otherwise receive the un-reduced shard sum)
     if (h->comm && h->comm_overlap && h->comm_stream && h->comm_seq > 0) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->comm_done[(h->comm_seq - 1) & 1], 0));
-    if (drain_first) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return HIPADJ_OK;
+}
+static int adjoint_host_download(hipadj_handle* h, double* du0, double* dp) {
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpyAsync(du0, h->d_du0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(dp, h->d_dp, pb, hipMemcpyDeviceToHost, h->stream));
     return HIPADJ_OK;
@@ -1750,7 +1754,8 @@ extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0,
     }
     static const bool trace = std::getenv("HIPADJ_HOST_TIMING") != nullptr;      // diagnosis (stderr): enqueue (upload + launches + download requests) and drain of one host-pointer call
     const auto t0 = std::chrono::steady_clock::now();
-    TRY(adjoint_host_enqueue(h, dLdu, du0, dp, true));
+    TRY(adjoint_host_run(h, dLdu));
+    TRY(adjoint_host_download(h, du0, dp));
     const auto t1 = std::chrono::steady_clock::now();
     const int rc = hipadj_synchronize(h);
     if (trace) std::fprintf(stderr, "hipadj_adjoint: enqueue %.3f ms, drain %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),

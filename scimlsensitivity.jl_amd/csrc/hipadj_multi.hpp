@@ -8,7 +8,7 @@
 // stream, workspaces and kernels; nothing about a shard's kernels knows that it is a shard.  Trajectories never interact, so the only cross-shard arithmetic is the sum of
 // dL/dp over the shards when p is shared — taken in shard order (fixed), on the host for the host-pointer calls and by one small kernel on the first device for the
 // device-pointer calls.  du0 / out stay sliced.
-//   host-pointer calls   every shard's copies and kernels are enqueued on ITS stream (no synchronisation in between), then all streams are drained: the devices run concurrently
+//   host-pointer calls   every shard's uploads and kernels are enqueued on ITS stream before any stream is waited for: the devices run concurrently; the downloads follow per shard
 //   device-pointer calls buffers live on device_ids[0] ("the primary"): shards on that device read and write the caller's slices in place, shards elsewhere go through their
 //                        staging buffers with hipMemcpyPeerAsync; the primary stream (hipadj_set_stream) is ordered before and after the shard streams by events
 // The same ordinal may repeat in device_ids: "virtual shards" on one device — how a 1-GPU box tests this path and how tests/c/julia_seam.c drives it.
@@ -16,7 +16,8 @@
 #include "hipadj_host.hpp"
 
 static int forward_host_enqueue(hipadj_handle* h, const double* u0, const double* p, double* out);
-static int adjoint_host_enqueue(hipadj_handle* h, const double* dLdu, double* du0, double* dp, bool drain_first);
+static int adjoint_host_run(hipadj_handle* h, const double* dLdu);
+static int adjoint_host_download(hipadj_handle* h, double* du0, double* dp);
 
 static __global__ void k_sum_rows(int G, int np, const double* __restrict__ parts, double* __restrict__ dp) {   // dp[j] = sum_g parts[g][j], shard order
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,9 +109,14 @@ static int multi_forward(hipadj_handle* h, const double* u0, const double* p, do
 
 static int multi_adjoint(hipadj_handle* h, const double* dLdu, double* du0, double* dp) {
     const int G = (int)h->shards.size(); const size_t n = h->n, np = h->np, M = h->M;
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < G; ++g) {      // phase 1 on every shard: uploads and reverse passes enqueued, nothing waits — the devices run concurrently
         const size_t lo = (size_t)h->shard_off[g];
-        const int rc = adjoint_host_enqueue(h->shards[g], dLdu ? dLdu + lo * M * n : nullptr, du0 + lo * n, h->cfg.p_shared ? h->dp_host.data() + (size_t)g * np : dp + lo * np, false);
+        const int rc = adjoint_host_run(h->shards[g], dLdu ? dLdu + lo * M * n : nullptr);
+        if (rc != HIPADJ_OK) return multi_fail(h, g, rc);
+    }
+    for (int g = 0; g < G; ++g) {      // phase 2: each shard's downloads once ITS stream is drained
+        const size_t lo = (size_t)h->shard_off[g];
+        const int rc = adjoint_host_download(h->shards[g], du0 + lo * n, h->cfg.p_shared ? h->dp_host.data() + (size_t)g * np : dp + lo * np);
         if (rc != HIPADJ_OK) return multi_fail(h, g, rc);
     }
     TRY(multi_synchronize(h));
