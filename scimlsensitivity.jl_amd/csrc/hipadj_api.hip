@@ -545,7 +545,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (const char* e = std::getenv("HIPADJ_NO_OPS")) h->no_ops = std::atoi(e) != 0;
     if (const char* e = std::getenv("HIPADJ_CBS")) h->cbs = std::atoi(e);
     h->fg.N = h->N; h->fg.S = (int)S; h->fg.M = h->M; h->fg.t0 = cfg->t0; h->fg.dt = cfg->dt; h->fg.loss_shift = cfg->loss_shift;
-    h->fg.loss_kind = cfg->loss_kind; h->fg.no_start = cfg->no_start; h->fg.p_shared = cfg->p_shared;
+    h->fg.loss_kind = cfg->loss_kind; h->fg.no_start = cfg->no_start; h->fg.p_shared = cfg->p_shared; h->fg.cont_cost = cfg->cont_cost;
     h->mg.N = h->N; h->mg.B = cfg->dims[2]; h->mg.S = (int)S; h->mg.M = h->M; h->mg.t0 = cfg->t0; h->mg.dt = cfg->dt; h->mg.loss_shift = cfg->loss_shift;
     h->mg.loss_kind = cfg->loss_kind; h->mg.no_start = cfg->no_start; h->mg.p_shared = cfg->p_shared; h->mg.NQ = P.NQ;
 

@@ -46,6 +46,7 @@ struct FieldGeom {
     double t0, dt, loss_shift;
     int loss_kind, no_start, p_shared;   // loss_kind: hipadj_loss 0 cotangent, 1 lsq_shift, 2 lsq_data (dgdu = lsq_w (u - data), the block in the cotangents' place)
     double lsq_w;
+    int cont_cost;      // hipadj_cont_cost 0 none, 1 g = (sum u)^2 / 2, 2 g = u_1^2 + p_1 (round 5: accumulate_cost!, src/derivative_wrappers.jl:1411-1442, on the PDE family)
 };
 
 template <int G> struct Bruss {
@@ -240,12 +241,43 @@ __device__ __forceinline__ void field_jump(const FieldGeom& g, long traj, int s,
     }
 }
 
+// Continuous costs on the PDE family (round 5): the cost gradient g_u(y(t)) enters every stage next to J^T lam (dlam -= g_u in the reference's sign, V = J^T lam + g_u
+// here), g_p the gradient quadrature.  HIPADJ_CCOST_HALF_SQ_SUM needs sum(y) at the three stage points of a step: the sums of (u, f) over a knot's cells are taken once
+// per knot (field_knot_sums: one workgroup reduction), the Hermite midpoint of the sums is the sum of the midpoint.  HIPADJ_CCOST_U1SQ_PLUS_P1 touches cell 0 of the
+// first species and parameter 1 only.
+struct FieldCostSums { double S, SF; };      // sum over both species of u and of f(u) at a knot
+template <int G, int CC>
+__device__ __forceinline__ FieldCostSums field_knot_sums(const FKnot<G>& kn, double* __restrict__ red) {
+    FieldCostSums r{0.0, 0.0};
+    if constexpr (CC == 1) {
+        double v[2] = {0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < Bruss<G>::Q; ++q) { v[0] += kn.U[q] + kn.V[q]; v[1] += kn.fU[q] + kn.fV[q]; }
+        block_sum<Bruss<G>::T, 2>(v, red);
+        r.S = v[0]; r.SF = v[1];
+    }
+    return r;
+}
+// V += g_u(y) at the thread's cells for the stage state (yU, yV) whose cell sum is Sy; WITH_P: w += wgt * g_p
+template <int G, bool WITH_P, int CC>
+__device__ __forceinline__ void field_cost_add(const Nbr<G>& nb, double Sy, const double (&yU)[Bruss<G>::Q], double (&vU)[Bruss<G>::Q], double (&vV)[Bruss<G>::Q],
+                                               double wgt, double (&w)[3]) {
+    if constexpr (CC == 1) {
+#pragma unroll
+        for (int q = 0; q < Bruss<G>::Q; ++q) { vU[q] += Sy; vV[q] += Sy; }
+    } else if constexpr (CC == 2) {
+#pragma unroll
+        for (int q = 0; q < Bruss<G>::Q; ++q) if (nb.c[q] == 0) { vU[q] += 2.0 * yU[q]; if (WITH_P) w[0] += wgt; }
+    }
+}
+
 // One reverse RK4 step of lam (and the mu partials) through [t_k, t_{k+1}].  4 LDS exchanges.
 // Returns V1 = (df/du)^T lam_hi (i.e. -lam' at the start) in (v1U, v1V) for the Gauss / Quadrature records.
-template <int G, bool WITH_P>
+template <int G, bool WITH_P, int CC = 0>
 __device__ __forceinline__ void field_rk4_step(double (*sh)[Bruss<G>::NS], const Nbr<G>& nb, const BrussP& P, double dt,
                                                const FKnot<G>& hi, const FKnot<G>& lo, double (&lU)[Bruss<G>::Q], double (&lV)[Bruss<G>::Q],
-                                               double (&w)[3], double (&v1U)[Bruss<G>::Q], double (&v1V)[Bruss<G>::Q]) {
+                                               double (&w)[3], double (&v1U)[Bruss<G>::Q], double (&v1V)[Bruss<G>::Q],
+                                               const FieldCostSums& chi, const FieldCostSums& clo) {
     constexpr int Q = Bruss<G>::Q;
     double mU[Q], mV[Q], sU[Q], sV[Q], aU[Q], aV[Q], vU[Q], vV[Q];
 #pragma unroll
@@ -253,20 +285,25 @@ __device__ __forceinline__ void field_rk4_step(double (*sh)[Bruss<G>::NS], const
         mU[q] = 0.5 * (lo.U[q] + hi.U[q]) + (0.125 * dt) * (lo.fU[q] - hi.fU[q]);
         mV[q] = 0.5 * (lo.V[q] + hi.V[q]) + (0.125 * dt) * (lo.fV[q] - hi.fV[q]);
     }
+    const double Smid = 0.5 * (clo.S + chi.S) + (0.125 * dt) * (clo.SF - chi.SF);
     publish<G>(sh[0], nb, lU, lV);
     bruss_vjp<G, WITH_P>(sh[0], nb, P, hi.U, hi.V, lU, lV, v1U, v1V, dt / 6.0, w);
+    if constexpr (CC != 0) field_cost_add<G, WITH_P, CC>(nb, chi.S, hi.U, v1U, v1V, dt / 6.0, w);
 #pragma unroll
     for (int q = 0; q < Q; ++q) { aU[q] = v1U[q]; aV[q] = v1V[q]; sU[q] = lU[q] + (0.5 * dt) * v1U[q]; sV[q] = lV[q] + (0.5 * dt) * v1V[q]; }
     publish<G>(sh[1], nb, sU, sV);
     bruss_vjp<G, WITH_P>(sh[1], nb, P, mU, mV, sU, sV, vU, vV, dt / 3.0, w);
+    if constexpr (CC != 0) field_cost_add<G, WITH_P, CC>(nb, Smid, mU, vU, vV, dt / 3.0, w);
 #pragma unroll
     for (int q = 0; q < Q; ++q) { aU[q] += 2.0 * vU[q]; aV[q] += 2.0 * vV[q]; sU[q] = lU[q] + (0.5 * dt) * vU[q]; sV[q] = lV[q] + (0.5 * dt) * vV[q]; }
     publish<G>(sh[0], nb, sU, sV);
     bruss_vjp<G, WITH_P>(sh[0], nb, P, mU, mV, sU, sV, vU, vV, dt / 3.0, w);
+    if constexpr (CC != 0) field_cost_add<G, WITH_P, CC>(nb, Smid, mU, vU, vV, dt / 3.0, w);
 #pragma unroll
     for (int q = 0; q < Q; ++q) { aU[q] += 2.0 * vU[q]; aV[q] += 2.0 * vV[q]; sU[q] = lU[q] + dt * vU[q]; sV[q] = lV[q] + dt * vV[q]; }
     publish<G>(sh[1], nb, sU, sV);
     bruss_vjp<G, WITH_P>(sh[1], nb, P, lo.U, lo.V, sU, sV, vU, vV, dt / 6.0, w);
+    if constexpr (CC != 0) field_cost_add<G, WITH_P, CC>(nb, clo.S, lo.U, vU, vV, dt / 6.0, w);
 #pragma unroll
     for (int q = 0; q < Q; ++q) { lU[q] = lU[q] + (dt / 6.0) * (aU[q] + vU[q]); lV[q] = lV[q] + (dt / 6.0) * (aV[q] + vV[q]); }
 }
@@ -291,7 +328,7 @@ __device__ __forceinline__ void field_finish(const FieldGeom& g, long traj, long
 
 // InterpolatingAdjoint (ALG = 0) and GaussAdjoint (ALG = 2) share the sweep; Gauss adds the FSAL exchange and the
 // two Gauss-Legendre nodes per step (lam from the adjoint step's Hermite interpolant, y from the forward one).
-template <int G, int ALG>
+template <int G, int ALG, int CC = 0>
 __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint(FieldGeom g, long Npad, const double* __restrict__ p, const double* __restrict__ knots,
                                                                const double* __restrict__ cot, const int* __restrict__ save_of_knot,
                                                                double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
@@ -308,21 +345,24 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint(FieldGeom g, long
     load_fknot<G>(knots, g, traj, g.S, nb, hi);
     { const int s = save_of_knot[g.S]; if (s >= 0) field_jump<G>(g, traj, s, cot, nb, hi.U, hi.V, lU, lV); }
     load_fknot<G>(knots, g, traj, g.S - 1, nb, lo);
+    FieldCostSums chi = field_knot_sums<G, CC>(hi, red), clo = chi;
     const double dt = g.dt;
     const double xg = 0.5773502691896257645;
     for (int k = g.S - 1; k >= 0; --k) {
         load_fknot<G>(knots, g, traj, k > 0 ? k - 1 : 0, nb, nx);        // prefetch one knot ahead
+        clo = field_knot_sums<G, CC>(lo, red);
         double v1U[Q], v1V[Q];
         if (ALG == 0) {
-            field_rk4_step<G, true>(sh, nb, P, dt, hi, lo, lU, lV, w, v1U, v1V);
+            field_rk4_step<G, true, CC>(sh, nb, P, dt, hi, lo, lU, lV, w, v1U, v1V, chi, clo);
         } else {
             double hU[Q], hV[Q], wd[3];
 #pragma unroll
             for (int q = 0; q < Q; ++q) { hU[q] = lU[q]; hV[q] = lV[q]; }
-            field_rk4_step<G, false>(sh, nb, P, dt, hi, lo, lU, lV, wd, v1U, v1V);
+            field_rk4_step<G, false, CC>(sh, nb, P, dt, hi, lo, lU, lV, wd, v1U, v1V, chi, clo);
             double v5U[Q], v5V[Q];
             publish<G>(sh[0], nb, lU, lV);                                 // fsallast: (df/du)^T lam_new at u_k
             bruss_vjp<G, false>(sh[0], nb, P, lo.U, lo.V, lU, lV, v5U, v5V, 0.0, wd);
+            if constexpr (CC != 0) field_cost_add<G, false, CC>(nb, clo.S, lo.U, v5U, v5V, 0.0, wd);
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;
@@ -338,17 +378,21 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint(FieldGeom g, long
                 }
                 publish<G>(sh[1 - nq], nb, gU, gV);
                 bruss_vjp<G, true>(sh[1 - nq], nb, P, yU, yV, gU, gV, dU_, dV_, 0.5 * dt, w);
+                if constexpr (CC == 2) {      // + g_p in the Gauss integrand (the library's sign: Gauss == Interpolating)
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) if (nb.c[q] == 0) w[0] += 0.5 * dt;
+                }
             }
             __syncthreads();   // the next step republishes sh[0], which node 1 has just been reading
         }
         { const int s = save_of_knot[k]; if (s >= 0 && !(g.no_start && s == 0)) field_jump<G>(g, traj, s, cot, nb, lo.U, lo.V, lU, lV); }
-        hi = lo; lo = nx;
+        hi = lo; lo = nx; chi = clo;
     }
     field_finish<G>(g, traj, Npad, nb, lU, lV, w, red, du0, dp_traj, flag);
 }
 
 // QuadratureAdjoint pass 1: lambda-only sweep recording (lam_start, lam'_start, lam_end, lam'_end) per step
-template <int G>
+template <int G, int CC = 0>
 __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_quad_adj(FieldGeom g, const double* __restrict__ p, const double* __restrict__ knots,
                                                                 const double* __restrict__ cot, const int* __restrict__ save_of_knot,
                                                                 double* __restrict__ adj, double* __restrict__ du0, int* __restrict__ flag) {
@@ -360,10 +404,12 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_quad_adj(FieldGeom g, con
     double lU[Q], lV[Q], wd[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < Q; ++q) { lU[q] = 0.0; lV[q] = 0.0; }
+    __shared__ double redc[CC == 1 ? (Bruss<G>::T / 64) * 2 : 1];
     FKnot<G> hi, lo, nx;
     load_fknot<G>(knots, g, traj, g.S, nb, hi);
     { const int s = save_of_knot[g.S]; if (s >= 0) field_jump<G>(g, traj, s, cot, nb, hi.U, hi.V, lU, lV); }
     load_fknot<G>(knots, g, traj, g.S - 1, nb, lo);
+    FieldCostSums chi = field_knot_sums<G, CC>(hi, redc), clo = chi;
     // First-same-as-last over the steps: lam' at the END of step k+1 (record slot 3) is -J(u_{k+1})^T lam there, which is exactly the V1 that
     // step k computes at its start - unless a loss jump changed lam at knot k+1.  So the closing exchange + VJP of a step is only done when a
     // jump follows (uniform: save_of_knot) or at the last step; otherwise the slot is filled one iteration later (4 instead of 5 LDS exchanges).
@@ -374,7 +420,8 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_quad_adj(FieldGeom g, con
         double v1U[Q], v1V[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) { rec[nb.c[q]] = lU[q]; rec[CELLS + nb.c[q]] = lV[q]; }
-        field_rk4_step<G, false>(sh, nb, P, g.dt, hi, lo, lU, lV, wd, v1U, v1V);
+        clo = field_knot_sums<G, CC>(lo, redc);
+        field_rk4_step<G, false, CC>(sh, nb, P, g.dt, hi, lo, lU, lV, wd, v1U, v1V, chi, clo);
         if (pending) {
             double* up = rec + 4 * NS;                      // record of step k+1
 #pragma unroll
@@ -391,13 +438,14 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_quad_adj(FieldGeom g, con
             double v5U[Q], v5V[Q];
             publish<G>(sh[0], nb, lU, lV);
             bruss_vjp<G, false>(sh[0], nb, P, lo.U, lo.V, lU, lV, v5U, v5V, 0.0, wd);
+            if constexpr (CC != 0) field_cost_add<G, false, CC>(nb, clo.S, lo.U, v5U, v5V, 0.0, wd);
             __syncthreads();       // the next step republishes sh[0]
 #pragma unroll
             for (int q = 0; q < Q; ++q) { rec[3 * NS + nb.c[q]] = -v5U[q]; rec[3 * NS + CELLS + nb.c[q]] = -v5V[q]; }
             pending = false;
         } else pending = true;
         if (jumps) field_jump<G>(g, traj, s, cot, nb, lo.U, lo.V, lU, lV);
-        hi = lo; lo = nx;
+        hi = lo; lo = nx; chi = clo;
     }
     bool bad = false;
 #pragma unroll
@@ -411,7 +459,7 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_quad_adj(FieldGeom g, con
 // QuadratureAdjoint pass 2: workgroup (trajectory, loss interval) runs quadgk(integrand, a, b; atol, rtol) with
 // block-uniform decisions: every GK15 panel is evaluated cooperatively (per-thread partial integrands, ONE
 // workgroup reduction per panel), the segment list lives in LDS.
-template <int G, int MAXSEG>
+template <int G, int MAXSEG, int CC = 0>
 __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_quad_gk(FieldGeom g, long Npad, const double* __restrict__ p, const double* __restrict__ knots,
                                                                const double* __restrict__ adj, const double* __restrict__ qa,
                                                                const double* __restrict__ qb, double atol, double rtol,
@@ -452,6 +500,10 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_quad_gk(FieldGeom g, long
         publish<G>(sh[flip], nb, lU, lV);
         out[0] = out[1] = out[2] = 0.0;
         bruss_vjp<G, true>(sh[flip], nb, P, yU, yV, lU, lV, dU_, dV_, 1.0, out);
+        if constexpr (CC == 2) {       // + g_p of the continuous cost in the integrand (src/quadrature_adjoint.jl:486-502 with dgdp_continuous): one thread carries it into the block sum
+#pragma unroll
+            for (int q = 0; q < Q; ++q) if (nb.c[q] == 0) out[0] += 1.0;
+        }
         flip ^= 1;
     };
     // one GK15 panel: returns workgroup-summed I (Kronrod) and E = |I_K - I_G|_2, identical in every thread.

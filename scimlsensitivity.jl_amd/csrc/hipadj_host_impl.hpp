@@ -364,11 +364,16 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
     HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     const dim3 grid((unsigned)h->N), blk(Bruss<G>::T);
     const bool etd = h->cfg.stepper == HIPADJ_STEPPER_ETDRK4_FIXED;
+    const int cc = h->cfg.cont_cost;      // continuous cost: a compile-time variant of the RK4 kernels (a run-time branch cost the cost-free kernels 16-24 registers and spills)
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING:
         if (etd)
             hipLaunchKernelGGL((k_bruss_adjoint_etd<G, 0>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
                                (const int*)h->d_save_rev, (double*)nullptr, d_du0, h->d_dp_traj, h->d_flag);
+        else if (cc == 1)
+            hipLaunchKernelGGL((k_bruss_adjoint<G, 0, 1>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
+        else if (cc == 2)
+            hipLaunchKernelGGL((k_bruss_adjoint<G, 0, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
         else
         hipLaunchKernelGGL((k_bruss_adjoint<G, 0>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
                            (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
@@ -379,6 +384,10 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
         if (etd)
             hipLaunchKernelGGL((k_bruss_adjoint_etd<G, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
                                (const int*)h->d_save_rev, (double*)nullptr, d_du0, h->d_dp_traj, h->d_flag);
+        else if (cc == 1)
+            hipLaunchKernelGGL((k_bruss_adjoint<G, 2, 1>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
+        else if (cc == 2)
+            hipLaunchKernelGGL((k_bruss_adjoint<G, 2, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
         else
         hipLaunchKernelGGL((k_bruss_adjoint<G, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
                            (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
@@ -389,12 +398,20 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
         if (etd)     // pass 1 with the exponential stepper; pass 2 (k_bruss_quad_gk) integrates over the same knots and the same dense record
             hipLaunchKernelGGL((k_bruss_adjoint_etd<G, 3>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,
                                (const int*)h->d_save_rev, h->d_fadj, d_du0, (double*)nullptr, h->d_flag);
+        else if (cc == 1)
+            hipLaunchKernelGGL((k_bruss_quad_adj<G, 1>), grid, blk, 0, h->stream, h->fg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag);
+        else if (cc == 2)
+            hipLaunchKernelGGL((k_bruss_quad_adj<G, 2>), grid, blk, 0, h->stream, h->fg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag);
         else
         hipLaunchKernelGGL((k_bruss_quad_adj<G>), grid, blk, 0, h->stream, h->fg, p, (const double*)h->d_fknots, d_cot,
                            (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+        if (cc == 2)      // only this cost has a g_p for the integrand
+            hipLaunchKernelGGL((k_bruss_quad_gk<G, 128, 2>), dim3((unsigned)h->N, (unsigned)h->nq), blk, 0, h->stream, h->fg, h->Npad, p,
+                               (const double*)h->d_fknots, (const double*)h->d_fadj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
+        else
         hipLaunchKernelGGL((k_bruss_quad_gk<G, 128>), dim3((unsigned)h->N, (unsigned)h->nq), blk, 0, h->stream, h->fg, h->Npad, p,
                            (const double*)h->d_fknots, (const double*)h->d_fadj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres);
         HIP_TRY(h, hipGetLastError());

