@@ -29,6 +29,10 @@
 
 namespace hipadj {
 
+#ifndef HIPADJ_ETD_PIN
+#define HIPADJ_ETD_PIN(ALG) ((ALG) == 0)      // reverse kernels whose transforms read their twiddles from LDS per level instead of holding them in registers: only the
+                                              // Interpolating kernel (39 spilled registers otherwise; measured 113 vs 117 ms, Gauss 85 vs 113, profiles/r5_etd_twiddles_ab.jsonl)
+#endif
 template <int G> struct EtdShape {
     static_assert(G == 8 || G == 16 || G == 32, "the exponential stepper holds one grid cell per thread: G = 8, 16 or 32");
     static_assert(Bruss<G>::Q == 1, "one cell per thread");
@@ -94,20 +98,34 @@ template <int M> __device__ __forceinline__ double etd_xor(double v) {
 template <int G, bool PIN_TWIDDLES = false> struct EtdFft {      // PIN_TWIDDLES: keep the twiddle reads inside the transforms (kernels at their register limit)
     EtdLds<G>* L; int par;
     int r, row;
+    double twr[EtdShape<G>::LOGG], twi[EtdShape<G>::LOGG];      // !PIN_TWIDDLES: this lane's factor of every butterfly level — (1, 0) on the lower lane of a pair — in registers: the
+                                                                // same for the row and the column pass (the lane index is the position in both)
     __device__ __forceinline__ void init(EtdLds<G>* lds) {
         L = lds; par = 0; r = threadIdx.x & (G - 1); row = threadIdx.x / G;
         const double pi = 3.14159265358979323846;
         if ((int)threadIdx.x < G / 2) { L->tw_re[threadIdx.x] = cos(2.0 * pi * threadIdx.x / G); L->tw_im[threadIdx.x] = -sin(2.0 * pi * threadIdx.x / G); }
         __syncthreads();
+#pragma unroll
+        for (int l = 0; l < EtdShape<G>::LOGG; ++l) {
+            const int M = 1 << l;
+            const bool up = (r & M) != 0;
+            const int k = (r & (M - 1)) * (G / (2 * M));
+            twr[l] = up ? L->tw_re[k] : 1.0; twi[l] = up ? L->tw_im[k] : 0.0;
+        }
     }
     // one butterfly level of span M.  DIF (forward): exchange, then the upper lane multiplies by w^k; DIT (inverse): the upper lane multiplies by conj(w)^k, then exchange
     template <int M, bool INV> __device__ __forceinline__ void level(double& re, double& im) const {
         const bool up = (r & M) != 0;
+        constexpr int LV = M == 1 ? 0 : (M == 2 ? 1 : (M == 4 ? 2 : (M == 8 ? 3 : 4)));
+        double wr, wi;
+        if constexpr (!PIN_TWIDDLES) { wr = twr[LV]; wi = INV ? -twi[LV] : twi[LV]; }
+        else {
         int k = (r & (M - 1)) * (G / (2 * M));
-        if constexpr (PIN_TWIDDLES) asm volatile("" : "+v"(k));      // keeps the twiddle reads where they are: hoisted out of the time loop, the ten pairs of a 2-D transform cost the
+        asm volatile("" : "+v"(k));      // keeps the twiddle reads where they are: hoisted out of the time loop, the ten pairs of a 2-D transform cost the
                                                                      // Interpolating kernel (128 registers per lane at 1024 threads) 58 spilled registers; the forward and the lambda-only
                                                                      // kernels have the room and let the compiler keep them in registers
-        const double wr = up ? L->tw_re[k] : 1.0, wi = up ? (INV ? -L->tw_im[k] : L->tw_im[k]) : 0.0;
+        wr = up ? L->tw_re[k] : 1.0; wi = up ? (INV ? -L->tw_im[k] : L->tw_im[k]) : 0.0;
+        }
         const double sg = up ? -1.0 : 1.0;
         if (INV) { const double a = re * wr - im * wi, b = re * wi + im * wr; re = a; im = b; }
         const double sr = etd_xor<M>(re), si = etd_xor<M>(im);
@@ -240,7 +258,7 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
     Nbr<G> nb; nb.init();
     const BrussP P = load_bruss_p<G>(p, g.p_shared, traj);
     const double dt = g.dt;
-    EtdFft<G, ALG != 3> F; F.init(&L);
+    EtdFft<G, HIPADJ_ETD_PIN(ALG)> F; F.init(&L);
     const EtdCoef c = etd_coefs<G>(-P.adx, -dt);              // lam' = -(alpha/dx^2) L lam + N, stepped with h = -dt
     const int cell = nb.c[0];
     double lU[1] = {0.0}, lV[1] = {0.0}, w[3] = {0.0, 0.0, 0.0};
