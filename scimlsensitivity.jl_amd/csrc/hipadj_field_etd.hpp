@@ -30,8 +30,8 @@
 namespace hipadj {
 
 #ifndef HIPADJ_ETD_PIN
-#define HIPADJ_ETD_PIN(ALG) ((ALG) == 0)      // reverse kernels whose transforms read their twiddles from LDS per level instead of holding them in registers: only the
-                                              // Interpolating kernel (39 spilled registers otherwise; measured 113 vs 117 ms, Gauss 85 vs 113, profiles/r5_etd_twiddles_ab.jsonl)
+#define HIPADJ_ETD_PIN(ALG) false            // true: that reverse kernel's transforms read their twiddles from LDS per level instead of holding them in registers (A/B;
+                                              // registers win everywhere: Interpolating 116 -> 92 ms with 18 spilled registers, profiles/r5_etd_twiddles_ab.jsonl)
 #endif
 template <int G> struct EtdShape {
     static_assert(G == 8 || G == 16 || G == 32, "the exponential stepper holds one grid cell per thread: G = 8, 16 or 32");
@@ -223,19 +223,18 @@ __device__ __attribute__((noinline)) void etd_publish_laplace(double* __restrict
     Lb = buf[CELLS + im] + buf[CELLS + ip] + buf[CELLS + jp] + buf[CELLS + jm] - 4.0 * b;
 }
 // N(lam; y) = -R(y)^T lam (the reaction block of the transposed Jacobian, negated: lam' = M lam + N with M = -(alpha/dx^2) L); WITH_P: the gradient partials
-// w += wgt * (df/dp)^T lam, whose alpha entry needs L lam of the stage (published for the stencil)
+// w += wgt * (df/dp)^T lam
 template <int G, bool WITH_P>
-__device__ __forceinline__ void etd_adj_react(EtdLds<G>& L, int /*unused*/, const Nbr<G>& nb, const BrussP& P, double yU, double yV, double lU, double lV,
+__device__ __forceinline__ void etd_adj_react(const BrussP& P, double yU, double yV, double LyU, double LyV, double lU, double lV,
                                               double& nU, double& nV, double wgt, double (&w)[3]) {
     const double uv2 = 2.0 * yU * yV, uu = yU * yU;
     nU = -((uv2 - (P.A + 1.0)) * lU + (P.A - uv2) * lV);
     nV = -(uu * lU - uu * lV);
-    if (WITH_P) {
-        double La[1], Lb[1];
-        etd_publish_laplace<G>(L.sh[0], nb.c[0], nb.im[0], nb.ip[0], nb.jm[0], nb.jp[0], lU, lV, La[0], Lb[0]);
+    if (WITH_P) {      // sum_c lam_c (L y)_c == sum_c y_c (L lam)_c (L symmetric): the alpha entry takes the Laplacian of the STAGE STATE, which is a Hermite combination of the
+                       // knots' Laplacians (LyU, LyV) — one stencil pass per knot instead of one per stage on lam
         w[0] += wgt * (-yU * lU + yU * lV);
         w[1] += wgt * lU;
-        w[2] += wgt * ((yU * La[0] + yV * Lb[0]) * P.idx2);
+        w[2] += wgt * ((lU * LyU + lV * LyV) * P.idx2);
     }
 }
 // the full -lam' = J(y)^T lam at the thread's cell (Quadrature record), lam published in buffer `buf`
@@ -267,10 +266,22 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
     { const int s = save_of_knot[g.S]; if (s >= 0) field_jump<G>(g, traj, s, cot, nb, hi.U, hi.V, lU, lV); }
     double zr = lU[0], zi = lV[0];
     F.fwd(zr, zi);
+    // Interpolating: the Laplacians of the knot (u, f) of both species — of the upper knot carried from step to step, of the lower one taken at the top of the step
+    double LhU = 0.0, LhV = 0.0, LhfU = 0.0, LhfV = 0.0, LlU = 0.0, LlV = 0.0, LlfU = 0.0, LlfV = 0.0;
+    if (WP) {
+        etd_publish_laplace<G>(L.sh[0], nb.c[0], nb.im[0], nb.ip[0], nb.jm[0], nb.jp[0], hi.U[0], hi.V[0], LhU, LhV);
+        etd_publish_laplace<G>(L.sh[0], nb.c[0], nb.im[0], nb.ip[0], nb.jm[0], nb.jp[0], hi.fU[0], hi.fV[0], LhfU, LhfV, true);
+    }
     for (int k = g.S - 1; k >= 0; --k) {
         load_fknot<G>(knots, g, traj, k, nb, lo);              // no knot prefetch: at 1024 threads a wave has 128 registers and the step's chain of transforms hides the load
         const double mU = 0.5 * (lo.U[0] + hi.U[0]) + (0.125 * dt) * (lo.fU[0] - hi.fU[0]);      // Hermite midpoint of the forward knots
         const double mV = 0.5 * (lo.V[0] + hi.V[0]) + (0.125 * dt) * (lo.fV[0] - hi.fV[0]);
+        double LmU = 0.0, LmV = 0.0;
+        if (WP) {
+            etd_publish_laplace<G>(L.sh[0], nb.c[0], nb.im[0], nb.ip[0], nb.jm[0], nb.jp[0], lo.U[0], lo.V[0], LlU, LlV, true);
+            etd_publish_laplace<G>(L.sh[0], nb.c[0], nb.im[0], nb.ip[0], nb.jm[0], nb.jp[0], lo.fU[0], lo.fV[0], LlfU, LlfV, true);
+            LmU = 0.5 * (LlU + LhU) + (0.125 * dt) * (LlfU - LhfU); LmV = 0.5 * (LlV + LhV) + (0.125 * dt) * (LlfV - LhfV);
+        }
         double* rec = REC ? adj + ((traj * g.S + k) * 4) * NS : nullptr;
         double hU = 0.0, hV = 0.0, v1U = 0.0, v1V = 0.0;          // GaussAdjoint: lam and J^T lam at the start of the step (the Hermite data of lam over the step)
         if (REC || GAUSS) {
@@ -278,14 +289,14 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
             if (REC) { rec[cell] = lU[0]; rec[CELLS + cell] = lV[0]; rec[NS + cell] = -v1U; rec[NS + CELLS + cell] = -v1V; }
             hU = lU[0]; hV = lV[0];
         }
-        double n1r, n1i; etd_adj_react<G, WP>(L, 0, nb, P, hi.U[0], hi.V[0], lU[0], lV[0], n1r, n1i, dt / 6.0, w); F.fwd(n1r, n1i);
+        double n1r, n1i; etd_adj_react<G, WP>(P, hi.U[0], hi.V[0], LhU, LhV, lU[0], lV[0], n1r, n1i, dt / 6.0, w); F.fwd(n1r, n1i);
         const double ar = c.E2 * zr + c.Q * n1r, ai = c.E2 * zi + c.Q * n1i;
         double sr = ar, si = ai; F.inv(sr, si);
-        double n2r, n2i; etd_adj_react<G, WP>(L, 1, nb, P, mU, mV, sr, si, n2r, n2i, dt / 3.0, w); F.fwd(n2r, n2i);
+        double n2r, n2i; etd_adj_react<G, WP>(P, mU, mV, LmU, LmV, sr, si, n2r, n2i, dt / 3.0, w); F.fwd(n2r, n2i);
         sr = c.E2 * zr + c.Q * n2r; si = c.E2 * zi + c.Q * n2i; F.inv(sr, si);
-        double n3r, n3i; etd_adj_react<G, WP>(L, 0, nb, P, mU, mV, sr, si, n3r, n3i, dt / 3.0, w); F.fwd(n3r, n3i);
+        double n3r, n3i; etd_adj_react<G, WP>(P, mU, mV, LmU, LmV, sr, si, n3r, n3i, dt / 3.0, w); F.fwd(n3r, n3i);
         sr = c.E2 * ar + c.Q * (2.0 * n3r - n1r); si = c.E2 * ai + c.Q * (2.0 * n3i - n1i); F.inv(sr, si);
-        double n4r, n4i; etd_adj_react<G, WP>(L, 1, nb, P, lo.U[0], lo.V[0], sr, si, n4r, n4i, dt / 6.0, w); F.fwd(n4r, n4i);
+        double n4r, n4i; etd_adj_react<G, WP>(P, lo.U[0], lo.V[0], LlU, LlV, sr, si, n4r, n4i, dt / 6.0, w); F.fwd(n4r, n4i);
         zr = (c.E2 * c.E2) * zr + c.f1 * n1r + 2.0 * c.f2 * (n2r + n3r) + c.f3 * n4r;
         zi = (c.E2 * c.E2) * zi + c.f1 * n1i + 2.0 * c.f2 * (n2i + n3i) + c.f3 * n4i;
         sr = zr; si = zi; F.inv(sr, si);
@@ -319,7 +330,7 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint_etd(FieldGeom g, 
               field_jump<G>(g, traj, s, cot, nb, lo.U, lo.V, lU, lV);
               zr = lU[0]; zi = lV[0]; F.fwd(zr, zi);            // the jump changed lam in real space: refresh its spectral image
           } }
-        hi = lo;
+        hi = lo; LhU = LlU; LhV = LlV; LhfU = LlfU; LhfV = LlfV;
     }
     if (REC) {
         du0[traj * NS + cell] = lU[0]; du0[traj * NS + CELLS + cell] = lV[0];
