@@ -466,3 +466,36 @@ def test_adaptive_record_regrows_when_the_budget_cut_it_short(sa, monkeypatch, a
     ref = O.Problem("DENSELIN", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, dims=(n, 0, 0, 0), quad_abstol=1e-12, quad_reltol=1e-12)
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
+
+
+@pytest.mark.parametrize("alg", ["gauss", "interpolating", "quadrature"])
+@pytest.mark.parametrize("H", [32, 64])
+def test_dense_chain_2_H_H_2_is_routed_to_the_mfma_family(sa, alg, H):
+    """Round 5 (VERDICT r4 next 5b): a weight-shared tanh chain 2 -> H -> H -> 2 over an ensemble is the FP64-MFMA family's model with the trajectories as batch columns;
+    `solve` routes it there (interface._mfma_route) unless mfma=False.  Both routes — the workgroup-per-trajectory kernels of the runtime model and the MFMA kernels of
+    csrc/hipadj_mlp*.hpp — must give the same out, du0 and dp, for cotangents and for the device-resident data loss."""
+    from test_gpu_parity import mlp_params
+    rng = np.random.default_rng(5)
+    N, d, T, dt = 32, 2, 0.3, 0.05
+    fun = sa.WideDeviceFunction.dense_chain(f"route_chain_{H}", (d, H, H, d))
+    u0 = rng.standard_normal((N, d)); p = mlp_params(d, H)
+    ts = np.array([0.0, 0.1, 0.2, 0.3])
+    delta = rng.standard_normal((N, len(ts), d))
+    sens = {"gauss": sa.GaussAdjoint(), "interpolating": sa.InterpolatingAdjoint(), "quadrature": sa.QuadratureAdjoint(abstol=1e-11, reltol=1e-11)}[alg]
+    res = {}
+    for route in (False, None):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, mfma=route)
+        assert ("mfma_route" in sol.extra) == (route is None)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+        res[route] = (sol.u.copy(), du0, dp)
+        sol.engine.close()
+    for a, b in zip(res[False], res[None]):
+        assert rel(b, a) < 1e-9
+    data = 0.5 * rng.standard_normal((N, len(ts), d))
+    res = {}
+    for route in (False, None):
+        loss = sa.LsqData(data, 2.0)
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, dgdu_discrete=loss, mfma=route)
+        res[route] = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=loss)
+        sol.engine.close()
+    assert rel(res[None][0], res[False][0]) < 1e-9 and rel(res[None][1], res[False][1]) < 1e-9
