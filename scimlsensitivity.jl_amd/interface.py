@@ -88,8 +88,8 @@ def _mfma_route(ensprob, alg, sensealg, dgdu_discrete, checkpoints, callback, g,
     H = 32 on (measured: bench.py `dense_chain_crossover`).  Returns H when the problem can take the MFMA route, else None.  """
     if isinstance(ensprob, ODEProblem):
         return None
-    f = getattr(ensprob.prob, "f", None)
-    chain = getattr(f, "chain", None)
+    from .problems import DENSE_CHAINS
+    chain = DENSE_CHAINS.get(ensprob.prob.f)      # ODEProblem keeps the model's NAME
     if chain is None or callback is not None or g is not None or save_idxs is not None or devices is not None or checkpoints is not None:
         return None
     w, power = chain
