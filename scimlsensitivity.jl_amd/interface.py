@@ -105,9 +105,10 @@ def _mfma_route(ensprob, alg, sensealg, dgdu_discrete, checkpoints, callback, g,
 
 
 def _to_columns(x):
-    """[N][d] (or [N][M][d]) of an ensemble -> the batched state of the MFMA family: component-major, the trajectories as columns"""
+    """[N][d] (or [N][M][d]) of an ensemble -> the batched state of the MFMA family, a d x B matrix stored column-major with the trajectories as its columns: the SAME
+    memory order per time ([B][d]); only the time axis of a cotangent block moves in front of the trajectories"""
     x = np.asarray(x, dtype=np.float64)
-    return np.ascontiguousarray(x.T).reshape(1, -1) if x.ndim == 2 else np.ascontiguousarray(x.transpose(1, 2, 0)).reshape(1, x.shape[1], -1)
+    return np.ascontiguousarray(x).reshape(1, -1) if x.ndim == 2 else np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(1, x.shape[1], -1)
 
 
 def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
@@ -140,7 +141,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
         inner = solve(EnsembleProblem(ODEProblem("mlp", _to_columns(ensprob.u0)[0], ensprob.prob.tspan, ensprob.p, (d, H, N, 0)), _to_columns(ensprob.u0)), alg, dt=dt, saveat=saveat,
                       sensealg=sensealg, dgdu_discrete=loss, device=device, no_start=no_start, want_out=want_out, save_start=save_start, save_end=save_end,
                       save_everystep=save_everystep, mfma=False)
-        u = None if inner.u is None else np.ascontiguousarray(inner.u.reshape(inner.u.shape[1], d, N).transpose(2, 0, 1))
+        u = None if inner.u is None else np.ascontiguousarray(inner.u.reshape(inner.u.shape[1], N, d).transpose(1, 0, 2))
         return EnsembleSolution(engine=inner.engine, u=u, t=inner.t, prob=ensprob, alg=alg, dt=dt,
                                 extra=dict(inner.extra, mfma_route=dict(inner=inner, N=N, d=d, H=H, loss=loss), dgdu_discrete=dgdu_discrete))
     if callback is not None:       # DiscreteCallback at preset times: a chain of ordinary pieces (events.py)
@@ -241,7 +242,7 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_di
         elif dgdu_discrete is not None and not isinstance(dgdu_discrete, LsqShift):
             dg = _to_columns(pack_cotangent(dgdu_discrete, N, len(sol.t), d))
         du0, dp = adjoint_sensitivities(route["inner"], alg, t=t, dgdu_discrete=dg, sensealg=sensealg)
-        return np.ascontiguousarray(du0.reshape(d, N).T), dp
+        return np.ascontiguousarray(du0.reshape(N, d)), dp
     eng = sol.engine
     want_alg = (sensealg or sol.extra["sensealg"])
     if want_alg.name != eng.alg:
