@@ -326,8 +326,8 @@ __device__ __forceinline__ void field_finish(const FieldGeom& g, long traj, long
     if (bad) atomicOr(flag, 1);
 }
 
-// InterpolatingAdjoint (ALG = 0) and GaussAdjoint (ALG = 2) share the sweep; Gauss adds the FSAL exchange and the
-// two Gauss-Legendre nodes per step (lam from the adjoint step's Hermite interpolant, y from the forward one).
+// InterpolatingAdjoint (ALG = 0), GaussAdjoint (ALG = 2) and GaussKronrodAdjoint (ALG = 4, round 5) share the sweep; Gauss adds the FSAL exchange and the
+// two Gauss-Legendre nodes per step (lam from the adjoint step's Hermite interpolant, y from the forward one), GaussKronrod the adaptive (7,15) rule instead.
 template <int G, int ALG, int CC = 0>
 __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint(FieldGeom g, long Npad, const double* __restrict__ p, const double* __restrict__ knots,
                                                                const double* __restrict__ cot, const int* __restrict__ save_of_knot,
@@ -335,6 +335,7 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint(FieldGeom g, long
     constexpr int Q = Bruss<G>::Q, NS = Bruss<G>::NS, T = Bruss<G>::T;
     __shared__ double sh[2][NS];
     __shared__ double red[(T / 64) * 3];
+    __shared__ double redk[ALG == 4 ? (T / 64) * 6 : 1];
     const long traj = blockIdx.x;
     Nbr<G> nb; nb.init();
     const BrussP P = load_bruss_p<G>(p, g.p_shared, traj);
@@ -363,6 +364,62 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint(FieldGeom g, long
             publish<G>(sh[0], nb, lU, lV);                                 // fsallast: (df/du)^T lam_new at u_k
             bruss_vjp<G, false>(sh[0], nb, P, lo.U, lo.V, lU, lV, v5U, v5V, 0.0, wd);
             if constexpr (CC != 0) field_cost_add<G, false, CC>(nb, clo.S, lo.U, v5U, v5V, 0.0, wd);
+            // the integrand of the step's gradient quadrature at theta (0 at t_hi, 1 at t_lo): (df/dp)^T lam (+ g_p) with lam from the adjoint step's Hermite interpolant and y
+            // from the forward one, as per-thread partials added into out[3] with weight wq
+            auto node = [&](double th, double wq, double (&out)[3], int buf) {
+                const double tf = 1.0 - th;
+                double gU[Q], gV[Q], yU[Q], yV[Q], dU_[Q], dV_[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    gU[q] = (1.0 - th) * hU[q] + th * lU[q] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lU[q] - hU[q]) + (th - 1.0) * (-dt) * (-v1U[q]) + th * (-dt) * (-v5U[q]));
+                    gV[q] = (1.0 - th) * hV[q] + th * lV[q] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lV[q] - hV[q]) + (th - 1.0) * (-dt) * (-v1V[q]) + th * (-dt) * (-v5V[q]));
+                    yU[q] = (1.0 - tf) * lo.U[q] + tf * hi.U[q] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (hi.U[q] - lo.U[q]) + (tf - 1.0) * dt * lo.fU[q] + tf * dt * hi.fU[q]);
+                    yV[q] = (1.0 - tf) * lo.V[q] + tf * hi.V[q] + tf * (tf - 1.0) * ((1.0 - 2.0 * tf) * (hi.V[q] - lo.V[q]) + (tf - 1.0) * dt * lo.fV[q] + tf * dt * hi.fV[q]);
+                }
+                publish<G>(sh[buf], nb, gU, gV);
+                bruss_vjp<G, true>(sh[buf], nb, P, yU, yV, gU, gV, dU_, dV_, wq, out);
+                if constexpr (CC == 2) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) if (nb.c[q] == 0) out[0] += wq;
+                }
+            };
+            if constexpr (ALG == 4) {
+                // GaussKronrodAdjoint (src/gauss_adjoint.jl:820-825; IntegratingGKSumCallback [upstream-recall], the restatement of hipadj_wide.hpp wide_gk_panels / oracle
+                // gk_panel): the adaptive (7,15) rule on the step, halved — the half next to t_hi first — while ||Kronrod - Gauss||_2 over the three gradient entries exceeds
+                // 1e-7 (depth <= 12), decisions uniform over the workgroup; an accepted panel's Kronrod sum is added by thread 0 (w is summed over the workgroup at the end)
+                constexpr int GKD = 12;
+                double pa[GKD + 2], pb[GKD + 2]; int pd[GKD + 2]; int sp = 1;
+                pa[0] = 0.0; pb[0] = 1.0; pd[0] = 0;
+#pragma unroll 1
+                while (sp > 0) {
+                    --sp;
+                    const double a = pa[sp], b = pb[sp]; const int d = pd[sp];
+                    const double c = 0.5 * (a + b), h = 0.5 * (b - a);
+                    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+                    for (int jn = 0; jn < 15; ++jn) {
+                        const int qn = jn < 7 ? jn : (jn == 7 ? 7 : 14 - jn);
+                        const double x = jn < 7 ? -c_gk_x[qn] : (jn == 7 ? 0.0 : c_gk_x[qn]);
+                        double f[3] = {0.0, 0.0, 0.0};
+                        node(c + h * x, 1.0, f, jn & 1);
+                        const double wk = c_gk_wk[qn], wg = (qn & 1) ? c_gk_wg[qn >> 1] : 0.0;
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) { acc[e] += wk * f[e]; acc[3 + e] += wg * f[e]; }
+                    }
+                    __syncthreads();                                     // the last node's stencil reads precede the reduction scratch / the next publication
+                    block_sum<T, 6>(acc, redk);
+                    const double fq = dt * h;
+                    double e2 = 0.0;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { const double dd = (acc[e] - acc[3 + e]) * fq; e2 += dd * dd; }
+                    if (sqrt(e2) <= 1e-7 || d >= GKD) {
+                        if (threadIdx.x == 0) { w[0] += fq * acc[0]; w[1] += fq * acc[1]; w[2] += fq * acc[2]; }
+                    } else {
+                        pa[sp] = c; pb[sp] = b; pd[sp] = d + 1; ++sp;      // the half next to t_lo: after the other one
+                        pa[sp] = a; pb[sp] = c; pd[sp] = d + 1; ++sp;
+                    }
+                }
+            } else
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x), tf = 1.0 - th;

@@ -394,6 +394,16 @@ template <int G> int field_adjoint(hipadj_handle* h, const double* d_cot, double
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         break;
+    case HIPADJ_ALG_GAUSS_KRONROD:      // the adaptive (7,15) rule per step in the Gauss sweep (RK4 only: the planner refuses the exponential stepper)
+        if (cc == 1)
+            hipLaunchKernelGGL((k_bruss_adjoint<G, 4, 1>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
+        else if (cc == 2)
+            hipLaunchKernelGGL((k_bruss_adjoint<G, 4, 2>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
+        else
+            hipLaunchKernelGGL((k_bruss_adjoint<G, 4>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, d_du0, h->d_dp_traj, h->d_flag);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+        break;
     case HIPADJ_ALG_QUADRATURE: {
         if (etd)     // pass 1 with the exponential stepper; pass 2 (k_bruss_quad_gk) integrates over the same knots and the same dense record
             hipLaunchKernelGGL((k_bruss_adjoint_etd<G, 3>), grid, blk, 0, h->stream, h->fg, h->Npad, p, (const double*)h->d_fknots, d_cot,

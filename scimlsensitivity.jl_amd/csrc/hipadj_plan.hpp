@@ -203,7 +203,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "BacksolveAdjoint is not offered for the PDE family: backward diffusion is ill-posed (src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_GAUSS_KRONROD) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
-    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (P.field || P.mlp)) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (P.mlp || (P.field && cfg->stepper != HIPADJ_STEPPER_RK4_FIXED))) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory, wide and (RK4) PDE families"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && cfg->stepper == HIPADJ_STEPPER_RK4_FIXED && cfg->checkpointing && !P.wide) {
         err = "GaussKronrodAdjoint(checkpointing=true) on the fixed step is offered for wide models; the lane family has it with adaptive Tsit5"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ETDRK4_FIXED) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
