@@ -182,14 +182,17 @@ static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int
     const std::string U = cost ? "hipadj::WideWithCost<hipadj::UserW, " + std::to_string(cost) + ">" : std::string("hipadj::UserW");
     if (ts5) {
         std::vector<std::string> e = {"hipadj::k_wide_forward_ts5<hipadj::UserW>", alg == HIPADJ_ALG_BACKSOLVE ? "hipadj::k_wide_backsolve_ts5<" + U + ">"
-                                      : "hipadj::k_wide_adjoint_ts5<" + U + ", " + (alg == HIPADJ_ALG_INTERPOLATING ? "0>" : (alg == HIPADJ_ALG_QUADRATURE ? "3>" : (alg == HIPADJ_ALG_GAUSS_KRONROD ? "4>" : "2>")))};
+                                      : "hipadj::k_wide_adjoint_ts5<" + U + ", " + (alg == HIPADJ_ALG_INTERPOLATING ? "0" : (alg == HIPADJ_ALG_QUADRATURE ? "3" : (alg == HIPADJ_ALG_GAUSS_KRONROD ? "4" : "2"))) + (ip_ckpt ? ", true>" : ", false>")};
         if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", true>");
         return e;
     }
     std::vector<std::string> e = {"hipadj::k_wide_forward<hipadj::UserW>"};
     if (offgrid) {   // loss times off the step grid: the sweep over the reverse step list, and out = sol(ts) by interpolation in the `gk` slot
-        e.push_back("hipadj::k_wide_adjoint_og<" + U + (alg == HIPADJ_ALG_GAUSS ? ", 2>" : ", 0>"));
+        if (alg == HIPADJ_ALG_BACKSOLVE) e.push_back("hipadj::k_wide_backsolve_og<" + U + ">");
+        else if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_adj_og<" + U + ">");
+        else e.push_back("hipadj::k_wide_adjoint_og<" + U + (alg == HIPADJ_ALG_GAUSS ? ", 2>" : ", 0>"));
         e.push_back("hipadj::k_wide_out_offgrid<hipadj::UserW>");
+        if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", false, true>");   // fourth name: uf_aux
         return e;
     }
     switch (alg) {
@@ -357,7 +360,14 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
                                                                            // the TRUE step count beyond the capacity, from which wide_autosize regrows the record)
             h->wide_auto = cfg->max_steps == 0 && cfg->alg != HIPADJ_ALG_BACKSOLVE && cap < 8192;   // the 8 GiB budget cut the capacity short: overflow is plausible, check after every forward solve
             h->ag.Smax = (int)cap;   // (the overflow message names it)
-            if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)h->N * cap * RW));
+            if (P.ip_ckpt) {   // checkpointing = true for Interpolating / Gauss / GaussKronrod (k_wide_adjoint_ts5<., ., true>): the forward states at the checkpoint times and ONE
+                               // interval's records per trajectory, re-solved inside the sweep (capacity P.SmaxI steps; an interval that needs more is reported, flag bit 4)
+                h->wide_auto = false;
+                h->wg.nck = P.nck; h->wide_SmaxI = P.SmaxI;
+                A(dev_alloc(h, &h->d_rec, (size_t)h->N * P.SmaxI * RW));
+                A(dev_alloc(h, &h->d_ckpt, (size_t)h->N * P.nck * n)); A(dev_alloc(h, &h->d_ck_t, (size_t)P.nck));
+                if (rc == HIPADJ_OK && !HT(hipMemcpy(h->d_ck_t, P.ck_times.data(), sizeof(double) * P.nck, hipMemcpyHostToDevice), "memcpy")) rc = HIPADJ_ERR_HIP;
+            } else if (cfg->alg != HIPADJ_ALG_BACKSOLVE) A(dev_alloc(h, &h->d_rec, (size_t)h->N * cap * RW));
             else {   // Backsolve keeps no records: y(T) and, checkpointing = true, the forward states at the checkpoint times [N][nck][n]
                 A(dev_alloc(h, &h->d_yT, (size_t)h->N * n));
                 h->wg.nck = P.nck;
@@ -391,10 +401,11 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         else {
             A(dev_alloc(h, &h->d_yT, (size_t)h->N * n));
             if (h->nck > 0) A(dev_alloc(h, &h->d_ckpt, (size_t)h->N * h->nck * n));
+            if (P.offgrid) A(dev_alloc(h, &h->d_fknots, (size_t)h->N * (S + 1) * 2 * n));   // off-grid Backsolve: out = sol(ts) and the checkpoint states are interpolated from the forward knots
         }
         if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD) A(dev_alloc(h, &h->d_wscr, (size_t)h->N * 3 * np));   // per trajectory: integrand, Kronrod and Gauss rows of one panel
         if (cfg->alg == HIPADJ_ALG_QUADRATURE && !P.adaptive) {
-            A(dev_alloc(h, &h->d_fadj, (size_t)h->N * S * 4 * n));
+            A(dev_alloc(h, &h->d_fadj, (size_t)h->N * (P.offgrid ? P.rs_t.size() : (size_t)S) * 4 * n));   // one record per (reverse) step
             A(dev_alloc(h, &h->d_qres, (size_t)h->N * (h->nq > 0 ? h->nq : 1) * np));
             A(dev_alloc(h, &h->d_wscr, (size_t)h->N * (h->nq > 0 ? h->nq : 1) * (3 + HIPADJ_WIDE_MAXSEG) * np));
         }
@@ -799,7 +810,7 @@ static bool fused_eligible(const hipadj_config* cfg, const Plan& P) {
     }
     return true;
 }
-struct UserKernels { std::string forward, main_k, tail, gk; };
+struct UserKernels { std::string forward, main_k, tail, gk, aux; };
 static UserKernels user_kernel_names(const hipadj_handle* h) {
     const std::string U = "hipadj::UserModel";
     const int n = h->n, np = h->np;
@@ -827,6 +838,7 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     k.forward = "hipadj::k_forward<" + U + ">";
     if (h->offgrid) {   // loss times off the step grid (planner: InterpolatingAdjoint only); the `gk` slot carries the out = sol(ts) kernel
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE) k.main_k = "hipadj::k_backsolve_offgrid<" + U + ", " + I(cc) + ">";
+        else if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) { k.main_k = "hipadj::k_quad_adj_offgrid<" + U + ", " + I(mode) + ">"; k.aux = "hipadj::k_quad_gk_offgrid<" + U + ", " + I(cc) + ">"; }   // round 5
         else if (h->nseg > 1) k.main_k = "hipadj::k_offgrid_seg<" + U + ", " + I(mode) + (h->cfg.alg == HIPADJ_ALG_GAUSS ? ", true>" : ", false>");   // time-segmented over the reverse step list
         else k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_GAUSS ? "hipadj::k_gauss_offgrid<" : "hipadj::k_interp_offgrid<") + U + ", " + I(mode) + ">";
         k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = (h->nseg > 1 && h->cfg.alg != HIPADJ_ALG_BACKSOLVE) ? compose : finish;
@@ -861,6 +873,7 @@ static int user_prepare(hipadj_handle* h) {
     const UserKernels k = user_kernel_names(h);
     std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
     if (!k.gk.empty()) exprs.push_back(k.gk);
+    if (!k.aux.empty()) exprs.push_back(k.aux);
     std::vector<char> code; std::map<std::string, std::string> low;
     const bool force_o1 = std::getenv("HIPADJ_RTC_FORCE_O1") != nullptr;   // debugging hook: run the -O1 build only (no self-test)
     const int rc = user_compile(h->cfg.model, exprs, code, low, h->err, force_o1);
@@ -870,6 +883,7 @@ static int user_prepare(hipadj_handle* h) {
     HIP_TRY(h, hipModuleGetFunction(&h->uf_main, h->umod, low[k.main_k].c_str()));
     HIP_TRY(h, hipModuleGetFunction(&h->uf_tail, h->umod, low[k.tail].c_str()));
     if (!k.gk.empty()) HIP_TRY(h, hipModuleGetFunction(&h->uf_gk, h->umod, low[k.gk].c_str()));
+    if (!k.aux.empty()) HIP_TRY(h, hipModuleGetFunction(&h->uf_aux, h->umod, low[k.aux].c_str()));
     // Reverse kernels of wide models can spill thousands of registers (512 registers + KBs of scratch per lane).  One such kernel came back WRONG from
     // the toolkit's compiler at -O3 and right at -O1 / -O0 (8-state ring, dual-number VJPs, GaussAdjoint: 1232 spilled registers, 2860 B of scratch;
     // DESIGN.md 6.8) — no pattern a static check could flag.  So a reverse kernel with >= 1 KB of scratch per lane gets a second build at -O1, and the
@@ -900,6 +914,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     const UserKernels k = user_kernel_names(&h);
     std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
     if (!k.gk.empty()) exprs.push_back(k.gk);
+    if (!k.aux.empty()) exprs.push_back(k.aux);
     std::vector<char> code; std::map<std::string, std::string> low;
     return user_compile(cfg->model, exprs, code, low, err);
 }
@@ -996,7 +1011,15 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
             TRY(usig<decltype(&k_backsolve_offgrid<ModelLV, 0>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, cotT, d_du0, h->d_dp_traj));
-        else if (h->nseg > 1) {
+        else if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {   // dense lambda over the reverse step list, then adaptive GK15 per (trajectory, loss interval): adjoint_impl's sequence for the compiled-in models
+            const bool dl = h->cfg.loss_kind == HIPADJ_LOSS_MODEL;
+            TRY(usig<decltype(&k_quad_adj_offgrid<ModelLV, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, cotT, h->d_adj, d_du0, dl ? h->d_dp_traj : (double*)nullptr));
+            const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+            TRY(usig<decltype(&k_quad_gk_offgrid<ModelLV, 0>)>::launch(h, h->uf_aux, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, (const dbl2*)h->d_adj, (const double*)h->d_qa,
+                        (const double*)h->d_qb, atol, rtol, h->d_qres));
+            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj, dl ? 1 : 0);
+            HIP_TRY(h, hipGetLastError());
+        } else if (h->nseg > 1) {
             SegPlan sp{h->nseg, h->d_seg_bounds};
             TRY(usig<decltype(&k_offgrid_seg<ModelLV, 1, false>)>::launch(h, h->uf_main, dim3(waves, (unsigned)h->nseg), dim3(WAVE), h->g, R, sp, p, (const dbl2*)h->d_knots, cotT, h->d_segbuf));
             composed = true;
@@ -1158,6 +1181,7 @@ static int wide_prepare(hipadj_handle* h) {
     HIP_TRY(h, hipModuleGetFunction(&h->uf_forward, h->umod, low[exprs[0]].c_str()));
     HIP_TRY(h, hipModuleGetFunction(&h->uf_main, h->umod, low[exprs[1]].c_str()));
     if (exprs.size() > 2) HIP_TRY(h, hipModuleGetFunction(&h->uf_gk, h->umod, low[exprs[2]].c_str()));
+    if (exprs.size() > 3) HIP_TRY(h, hipModuleGetFunction(&h->uf_aux, h->umod, low[exprs[3]].c_str()));   // off-grid Quadrature: uf_gk is the out = sol(ts) kernel, the GK pass sits here
     h->wide_T = user_wide_threads(h->cfg.model);
     return HIPADJ_OK;
 }
@@ -1197,10 +1221,10 @@ static int wide_autosize(hipadj_handle* h) {
 
 static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (h->wide_ts5) {
-        const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE;
+        const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE, ck = h->ip_ckpt;      // ck: the checkpoint states only, no dense record
         for (int pass = 0; pass < 2; ++pass) {
-            TRY(usig<decltype(&k_wide_forward_ts5<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, h->wa, d_u0, d_p, bs ? (double*)nullptr : h->d_rec, h->d_nsteps,
-                        (const double*)h->d_save_t, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const double*)h->d_ck_t, (bs && h->wg.nck > 0) ? h->d_ckpt : (double*)nullptr,
+            TRY(usig<decltype(&k_wide_forward_ts5<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, h->wa, d_u0, d_p, (bs || ck) ? (double*)nullptr : h->d_rec, h->d_nsteps,
+                        (const double*)h->d_save_t, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const double*)h->d_ck_t, ((bs || ck) && h->wg.nck > 0) ? h->d_ckpt : (double*)nullptr,
                         bs ? h->d_yT : (double*)nullptr, h->d_flag));
             if (!h->wide_auto) break;
             const int again = wide_autosize(h);
@@ -1209,12 +1233,14 @@ static int wide_forward(hipadj_handle* h, const double* d_u0, const double* d_p,
         }
         return HIPADJ_OK;
     }
-    const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE, ck = h->ip_ckpt;
+    const bool bs = h->cfg.alg == HIPADJ_ALG_BACKSOLVE, ck = h->ip_ckpt, og = h->offgrid;
     TRY(usig<decltype(&k_wide_forward<WideProbe>)>::launch(h, h->uf_forward, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, d_u0, d_p,
-                (bs || ck) ? (double*)nullptr : h->d_fknots, (d_out && h->M > 0) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot,
-                ((bs || ck) && h->nck > 0) ? h->d_ckpt : (double*)nullptr, (const int*)h->d_ckpt_of_knot, bs ? h->d_yT : (double*)nullptr));
-    if (h->offgrid && d_out && h->M > 0)     // the save times are not knots: out = sol(ts) from the forward Hermite interpolant
+                ((bs && !og) || ck) ? (double*)nullptr : h->d_fknots, (d_out && h->M > 0 && !og) ? d_out : (double*)nullptr, (const int*)h->d_save_of_knot,
+                ((bs || ck) && !og && h->nck > 0) ? h->d_ckpt : (double*)nullptr, (const int*)h->d_ckpt_of_knot, bs ? h->d_yT : (double*)nullptr));
+    if (og && d_out && h->M > 0)     // the save times are not knots: out = sol(ts) from the forward Hermite interpolant
         TRY(usig<decltype(&k_wide_out_offgrid<WideProbe>)>::launch(h, h->uf_gk, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, (const double*)h->d_fknots, (const double*)h->d_save_t, h->M, d_out));
+    if (og && bs && h->nck > 0)      // Backsolve: the checkpoint states at the (off-grid) checkpoint times
+        TRY(usig<decltype(&k_wide_out_offgrid<WideProbe>)>::launch(h, h->uf_gk, dim3((unsigned)h->N), dim3((unsigned)h->wide_T), h->wg, (const double*)h->d_fknots, (const double*)h->d_ck_t, h->nck, h->d_ckpt));
     return HIPADJ_OK;
 }
 
@@ -1233,13 +1259,14 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
                     (const double*)h->d_ck_t, (const double*)h->d_save_t, (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag));
     } else if (h->wide_ts5) {
         const bool quad = h->cfg.alg == HIPADJ_ALG_QUADRATURE;
-        TRY(usig<decltype(&k_wide_adjoint_ts5<WideProbe, 2>)>::launch(h, h->uf_main, grid, blk, h->wg, h->wa, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_save_t,
+        const bool ck = h->ip_ckpt;   // checkpointing = true: d_rec holds one interval per trajectory, written by the sweep itself
+        TRY(usig<decltype(&k_wide_adjoint_ts5<WideProbe, 2>)>::launch(h, h->uf_main, grid, blk, h->wg, h->wa, p, ck ? (const double*)nullptr : (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_save_t,
                     (const double*)h->d_tstops, d_cot, d_du0, rows, h->d_flag, quad ? h->d_arec : (double*)nullptr, quad ? h->d_nsteps_adj : (int*)nullptr, quad ? h->SmaxA : 0,
-                    h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD ? h->d_wscr : (double*)nullptr));
+                    h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD ? h->d_wscr : (double*)nullptr, ck ? h->d_rec : (double*)nullptr, (const double*)(ck ? h->d_ckpt : nullptr), (const double*)(ck ? h->d_ck_t : nullptr), h->wide_SmaxI));
         if (quad) {
             if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-            const WideQuadSrc src{nullptr, nullptr, h->d_rec, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->wa.Smax, h->SmaxA};
+            const WideQuadSrc src{nullptr, nullptr, h->d_rec, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->wa.Smax, h->SmaxA, nullptr, nullptr, 0};
             TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG, true>)>::launch(h, h->uf_gk, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, src,
                         (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
             hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows, h->cfg.loss_kind == HIPADJ_LOSS_MODEL ? 1 : 0);
@@ -1247,6 +1274,18 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         }
     } else if (h->offgrid) {
         const RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
+            TRY(usig<decltype(&k_wide_backsolve_og<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, R, p, (const double*)h->d_yT, (const double*)(h->nck > 0 ? h->d_ckpt : nullptr), d_cot, d_du0, rows, h->d_flag));
+        else if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {
+            TRY(usig<decltype(&k_wide_quad_adj_og<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, R, p, (const double*)h->d_fknots, d_cot, h->d_fadj, d_du0, h->d_flag, rows));
+            if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
+            const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
+            const WideQuadSrc src{h->d_fknots, h->d_fadj, nullptr, nullptr, nullptr, nullptr, 0, 0, h->d_rs_t, h->d_rs_te, h->nrs};
+            TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG, false, true>)>::launch(h, h->uf_aux, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, src,
+                        (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
+            hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows, h->cfg.loss_kind == HIPADJ_LOSS_MODEL ? 1 : 0);
+            HIP_TRY(h, hipGetLastError());
+        } else
         TRY(usig<decltype(&k_wide_adjoint_og<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, R, p, (const double*)h->d_fknots, d_cot, d_du0, rows, h->d_flag));
     } else
     switch (h->cfg.alg) {
@@ -1266,7 +1305,7 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
         TRY(usig<decltype(&k_wide_quad_adj<WideProbe>)>::launch(h, h->uf_main, grid, blk, h->wg, p, (const double*)h->d_fknots, d_cot, (const int*)h->d_save_rev, h->d_fadj, d_du0, h->d_flag, rows));
         if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k1, h->stream));
         const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
-        const WideQuadSrc src{h->d_fknots, h->d_fadj, nullptr, nullptr, nullptr, nullptr, 0, 0};
+        const WideQuadSrc src{h->d_fknots, h->d_fadj, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
         TRY(usig<decltype(&k_wide_quad_gk<WideProbe, HIPADJ_WIDE_MAXSEG, false>)>::launch(h, h->uf_gk, dim3((unsigned)h->N, (unsigned)h->nq), blk, h->wg, p, src,
                     (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_wscr, h->d_qres));
         hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows, h->cfg.loss_kind == HIPADJ_LOSS_MODEL ? 1 : 0);

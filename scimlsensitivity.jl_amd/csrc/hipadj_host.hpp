@@ -69,6 +69,8 @@ struct hipadj_handle {
     hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish
     hipModule_t umod_alt = nullptr;            // the same kernels at -O1: second opinion for reverse kernels that spill heavily (user_prepare)
     hipFunction_t uf_main_alt = nullptr;
+    hipFunction_t uf_aux = nullptr;        // a fifth kernel of the model's module: QuadratureAdjoint with loss times off the step grid (uf_gk carries out = sol(ts), the GK pass sits here)
+    int wide_SmaxI = 0;                    // wide models, adaptive stepper, checkpointing = true: the step capacity of the one-interval record a trajectory re-solves into
     int rtc_selftest = 0;                      // 1: pending (first adjoint call runs both builds and compares), 2: agreed, 3: disagreed -> the -O1 build is used, 4: disagreed, the -O1 build irreproducible -> the -O3 build stays
     bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
     AdaptGeom ag{};

@@ -187,7 +187,6 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         const bool ts5 = cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE;
         if (ts5 && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_BACKSOLVE) && np > 8192) {
             err = "wide models: Interpolating- / BacksolveAdjoint on the adaptive solution keep five parameter-sized rows in LDS (np <= 8192 at most; the exact budget is checked when the handle is created) — GaussAdjoint has no such limit"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (ts5 && cfg->alg != HIPADJ_ALG_BACKSOLVE && (cfg->checkpointing || cfg->ncheckpoints > 0)) { err = "wide models: Gauss- / InterpolatingAdjoint on adaptive Tsit5 keep the dense forward solution (checkpointing = false, no checkpoint list)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (!ts5 && cfg->checkpointing && cfg->alg == HIPADJ_ALG_QUADRATURE) { err = "wide models: QuadratureAdjoint keeps the dense forward solution (its second pass integrates over it); checkpointing = true is offered for Interpolating / Gauss / GaussKronrod / BacksolveAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (P.mlp) {
@@ -306,11 +305,12 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
         const bool og_ig = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && !cfg->checkpointing;
         const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->ckpt_stride == 0 && cfg->ncheckpoints == 0;
-        const bool og_q = cfg->alg == HIPADJ_ALG_QUADRATURE && !P.user;       // compiled-in lane models (round 2)
-        const bool og_wide = P.wide && og_ig;      // wide models: Interpolating / Gauss over the reverse step list (k_wide_adjoint_og)
-        if (!(og_ig || og_bs || og_q) || P.field || P.mlp || (P.wide && !og_wide)) {
-            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false), QuadratureAdjoint (compiled-in models) and "
-                  "BacksolveAdjoint (checkpoints = the save times, ckpt_stride = 0) on the lane-per-trajectory models, and for InterpolatingAdjoint / GaussAdjoint (checkpointing = false) on wide models; other configurations need times on the step grid, or the adaptive stepper (arbitrary times)";
+        const bool og_q = cfg->alg == HIPADJ_ALG_QUADRATURE && !P.wide;       // lane models: compiled-in (round 2) and runtime-registered (round 5)
+        // wide models: Interpolating / Gauss (k_wide_adjoint_og), Backsolve (k_wide_backsolve_og) and Quadrature (k_wide_quad_adj_og + the GK pass over the reverse step list, round 5)
+        const bool og_wide = P.wide && (og_ig || og_bs || (cfg->alg == HIPADJ_ALG_QUADRATURE && !cfg->checkpointing));
+        if (!(og_ig || og_bs || og_q || og_wide) || P.field || P.mlp || (P.wide && !og_wide)) {
+            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false), QuadratureAdjoint and "
+                  "BacksolveAdjoint (checkpoints = the save times, ckpt_stride = 0) on the lane-per-trajectory and wide models; other configurations need times on the step grid, or the adaptive stepper (arbitrary times)";
             return HIPADJ_ERR_UNSUPPORTED; }
         for (int i = 0; i < cfg->nsave; ++i) {   // the sweep takes the times literally; they must not leave the span
             if (P.save_times[i] < cfg->t0) P.save_times[i] = cfg->t0;

@@ -52,6 +52,7 @@ struct WideGeom {
 struct WideQuadSrc {
     const double* knots; const double* adj;                                   // fixed-step RK4
     const double* rec; const int* nsteps; const double* arec; const int* nsteps_adj; int Smax, SmaxA;   // adaptive Tsit5 (null / 0 on the fixed step)
+    const double* rs_t; const double* rs_te; int nrs;                         // loss times off the step grid: `adj` holds one record per REVERSE step q, which runs rs_t[q] -> rs_te[q]
 };
 
 // Gauss-Kronrod (7,15) tables (QuadGK order 7), runtime-indexed by the rolled node loop
@@ -807,6 +808,103 @@ __global__ void __launch_bounds__(Mo::T) k_wide_backsolve(WideGeom g, const doub
     wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
 }
 
+// ---- BacksolveAdjoint with loss times OFF the step grid (round 5; backsolve_offgrid_lane of the lane family on a workgroup): z = [lam; mu; y] over the planner's reverse step
+// list — no forward interpolant in the sweep, y is part of the state —, y overwritten by the stored forward value at every checkpoint TIME (the default checkpoints: t0, the
+// save times, T, src/backsolve_adjoint.jl:132, 523-546; their states interpolated from the forward knots by k_wide_out_offgrid), the loss gradient at the just overwritten
+// backsolved y (src/adjoint_common.jl:765-767).  The stage arithmetic is k_wide_backsolve's on a step of length R.h[q].
+template <class Mo>
+__global__ void __launch_bounds__(Mo::T) k_wide_backsolve_og(WideGeom g, RevSteps R, const double* __restrict__ p, const double* __restrict__ yT, const double* __restrict__ ckpt,
+                                                             const double* __restrict__ cot, double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    __shared__ double sy[N], sls[N], sdl[N], sdu[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    const long traj = blockIdx.x; const int tid = threadIdx.x;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
+    WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
+    wide_zero_gp<Mo>(L);
+    double lam[Q], y[Q], acc[W::NA];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; lam[q] = 0.0; y[q] = c < N ? yT[traj * N + c] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < W::NA; ++q) acc[q] = 0.0;
+    if (R.save_at_start >= 0) wide_jump<Mo>(g, traj, R.save_at_start, cot, y, lam, L, pp, R.t_start, acc);
+    auto stage = [&](const double (&yv)[Q], const double (&lv)[Q], double t, double w, double (&F)[Q], double (&V)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { sy[c] = yv[q]; sls[c] = lv[q]; } }
+        wide_sync<T>();
+        Mo::f(sdu, sy, pp, t, sws, tid);
+        wide_sync<T>();
+        Mo::template vjp<true>(sdl, L.gp, acc, w, sls, sy, pp, t, sws, tid);
+        wide_sync<T>();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; F[q] = c < N ? sdu[c] : 0.0; V[q] = c < N ? sdl[c] : 0.0; }
+        wide_cost_add<Mo, true>(L.gp, w, yv, V, sdl, sy, sws, pp, t, acc);
+    };
+    for (int qs = 0; qs < R.n; ++qs) {
+        const double t_hi = R.t[qs], dt = R.h[qs], t_lo = R.te[qs], t_mid = t_hi - 0.5 * dt;
+        double F1[Q], F[Q], V[Q], Ys[Q], ls[Q], Fa[Q], Va[Q];
+        stage(y, lam, t_hi, dt / 6.0, F1, V);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { Fa[q] = F1[q]; Va[q] = V[q]; Ys[q] = y[q] - (0.5 * dt) * F1[q]; ls[q] = lam[q] + (0.5 * dt) * V[q]; }
+        stage(Ys, ls, t_mid, dt / 3.0, F, V);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { Fa[q] += 2.0 * F[q]; Va[q] += 2.0 * V[q]; Ys[q] = y[q] - (0.5 * dt) * F[q]; ls[q] = lam[q] + (0.5 * dt) * V[q]; }
+        stage(Ys, ls, t_mid, dt / 3.0, F, V);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { Fa[q] += 2.0 * F[q]; Va[q] += 2.0 * V[q]; Ys[q] = y[q] - dt * F[q]; ls[q] = lam[q] + dt * V[q]; }
+        stage(Ys, ls, t_lo, dt / 6.0, F, V);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { lam[q] = lam[q] + (dt / 6.0) * (Va[q] + V[q]); y[q] = y[q] - (dt / 6.0) * (Fa[q] + F[q]); }
+        { const int c0 = (ckpt && R.ck) ? R.ck[qs] : -1; if (c0 >= 0) { const double* src = ckpt + (traj * g.nck + c0) * N;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) y[q] = src[c]; } } }
+        { const int s = R.save[qs]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y, lam, L, pp, t_lo, acc); }
+    }
+    wide_finish<Mo>(g, traj, L, lam, acc, du0, dp_traj, flag);
+}
+
+// ---- QuadratureAdjoint pass 1 with loss times OFF the step grid (round 5): the lambda-only sweep over the planner's reverse step list, y(t) of every stage from the forward
+// Hermite interpolant, recording (lam_start, lam'_start, lam_end, lam'_end) per REVERSE step q: the dense adjoint solution on the non-uniform grid R.t[q] -> R.te[q], which
+// k_wide_quad_gk<..., 2> reads back through a cursor over the same list
+template <class Mo>
+__global__ void __launch_bounds__(Mo::T) k_wide_quad_adj_og(WideGeom g, RevSteps R, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
+                                                            double* __restrict__ adj, double* __restrict__ du0, int* __restrict__ flag, double* __restrict__ dp_traj) {
+    using W = WideShape<Mo>;
+    constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
+    constexpr bool DL = wide_has_dloss<Mo>::value;
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sp[W::P_LDS ? NP : 1], sgp[(DL && W::GP_LDS) ? NP : 1], sred[DL ? (T / 64) * W::NA + 2 : 1];
+    const long traj = blockIdx.x; const int tid = threadIdx.x;
+    const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
+    WideTiles<Mo> L{sy, sls, sdl, DL ? (W::GP_LDS ? sgp : dp_traj + traj * NP) : (double*)nullptr, sws, DL ? sred : (double*)nullptr};
+    if constexpr (DL) wide_zero_gp<Mo>(L);
+    double lam[Q], dacc[W::NA] = {}, lacc[W::NA] = {}, y_hi[Q], y_mid[Q], y_lo[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) lam[q] = 0.0;
+    wide_hermite<Mo>(knots, g, traj, R.t_start, y_hi);
+    if (R.save_at_start >= 0) wide_jump<Mo, DL>(g, traj, R.save_at_start, cot, y_hi, lam, L, pp, R.t_start, lacc);
+    for (int qs = 0; qs < R.n; ++qs) {
+        const double t = R.t[qs], hs = R.h[qs], te = R.te[qs];
+        wide_hermite<Mo>(knots, g, traj, t - 0.5 * hs, y_mid);
+        wide_hermite<Mo>(knots, g, traj, te, y_lo);
+        double* rec = adj + ((traj * R.n + qs) * 4) * N;
+        double v1[Q], v5[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) rec[c] = lam[q]; }
+        wide_rk4_step_y<Mo, false>(L, pp, t, hs, y_hi, y_mid, y_lo, lam, dacc, v1);
+        wide_vjp<Mo, false>(L, pp, te, 0.0, y_lo, lam, dacc, v5);                         // slope at the end of the step, before the jump
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { rec[N + c] = -v1[q]; rec[2 * N + c] = lam[q]; rec[3 * N + c] = -v5[q]; } }
+        { const int s = R.save[qs]; if (s >= 0) wide_jump<Mo, DL>(g, traj, s, cot, y_lo, lam, L, pp, te, lacc); }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) y_hi[q] = y_lo[q];
+    }
+    if constexpr (DL) { wide_finish<Mo>(g, traj, L, lam, lacc, du0, dp_traj, flag); return; }
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) { du0[traj * N + c] = lam[q]; bad |= !(fabs(lam[q]) <= 1.79769313486231570e308); } }
+    if (bad) atomicOr(flag, 1);
+}
+
 // ---- QuadratureAdjoint pass 1: lambda-only sweep recording (lam_start, lam'_start, lam_end, lam'_end) per step = the dense adjoint solution
 // (src/quadrature_adjoint.jl:527-530) with the Hermite data of a fixed-step solver -------------------------------------------------------------
 template <class Mo>
@@ -856,7 +954,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_adj(WideGeom g, const doubl
 // segments' integrals) live in a per-workgroup HBM scratch [3 + MAXSEG][np]; at most MAXSEG segments (documented cap).
 template <class Mo> struct WideFwdCursor;
 template <class Mo> struct WideAdjCursor;
-template <class Mo, int MAXSEG, bool TS5 = false>
+template <class Mo, int MAXSEG, bool TS5 = false, bool OG = false>
 __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double* __restrict__ p, WideQuadSrc src,
                                                         const double* __restrict__ qa, const double* __restrict__ qb, double atol, double rtol,
                                                         double* __restrict__ scratch, double* __restrict__ qres) {
@@ -879,6 +977,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
         { const int ns = src.nsteps[traj]; curF.init(src.rec + traj * (long)src.Smax * RW, ns < src.Smax ? ns : src.Smax); }
         { const int ns = src.nsteps_adj[traj]; curA.init(src.arec + traj * (long)src.SmaxA * RW, ns < src.SmaxA ? ns : src.SmaxA); }
     }
+    int og_q = 0;   // OG: cursor into the reverse step list
     // integrand at time t: y = sol(t) (forward Hermite), lam = adj_sol(t) (the record's Hermite), f_p^T lam into fi[] and the per-thread partials
     auto integrand = [&](double t, double (&part)[W::NA]) {
         if constexpr (TS5) {
@@ -894,10 +993,20 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
         if (k > g.S - 1) k = g.S - 1;
         if (t < g.t0 + k * g.dt && k > 0) --k;
         if (t > g.t0 + (k + 1) * g.dt && k < g.S - 1) ++k;
-        const double thf = (t - (g.t0 + k * g.dt)) / g.dt, tha = 1.0 - thf;
+        const double thf = (t - (g.t0 + k * g.dt)) / g.dt; double tha = 1.0 - thf;
         const double* b0 = knots + ((traj * (g.S + 1) + k) * 2) * N;
         const double* b1 = b0 + 2 * N;
-        const double* r = adj + ((traj * g.S + k) * 4) * N;
+        // the adjoint record that holds t: step k of the knot grid, or (OG) the reverse step q with rs_te[q] <= t <= rs_t[q] — the walk starts where the last node left it
+        double ha = g.dt;
+        const double* r;
+        if constexpr (OG) {
+            while (og_q < src.nrs - 1 && t < src.rs_te[og_q]) ++og_q;
+            while (og_q > 0 && t > src.rs_t[og_q]) --og_q;
+            const double ts_ = src.rs_t[og_q];
+            ha = ts_ - src.rs_te[og_q];
+            tha = (ts_ - t) / ha;
+            r = adj + ((traj * src.nrs + og_q) * 4) * N;
+        } else r = adj + ((traj * g.S + k) * 4) * N;
         double yv[Q], lv[Q], dd[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -906,7 +1015,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_quad_gk(WideGeom g, const double
                 { const double u0_ = b0[c], f0 = b0[N + c], u1 = b1[c], f1 = b1[N + c];
                   yv[q] = (1.0 - thf) * u0_ + thf * u1 + thf * (thf - 1.0) * ((1.0 - 2.0 * thf) * (u1 - u0_) + (thf - 1.0) * g.dt * f0 + thf * g.dt * f1); }
                 { const double l0 = r[c], d0 = r[N + c], l1 = r[2 * N + c], d1 = r[3 * N + c];
-                  lv[q] = (1.0 - tha) * l0 + tha * l1 + tha * (tha - 1.0) * ((1.0 - 2.0 * tha) * (l1 - l0) + (tha - 1.0) * (-g.dt) * d0 + tha * (-g.dt) * d1); }
+                  lv[q] = (1.0 - tha) * l0 + tha * l1 + tha * (tha - 1.0) * ((1.0 - 2.0 * tha) * (l1 - l0) + (tha - 1.0) * (-ha) * d0 + tha * (-ha) * d1); }
             } else { yv[q] = 0.0; lv[q] = 0.0; }
         }
         for (int j = tid; j < NP; j += T) fi[j] = 0.0;
@@ -1225,14 +1334,20 @@ __global__ void __launch_bounds__(Mo::T) k_wide_forward_ts5(WideGeom g, WideAdap
 // (written by the model's vjp with weight -1 into a zeroed row; reduced parameters are summed over the workgroup per stage) and the stage value of k_1 (WideAugNorm).
 // ALG = 3 QuadratureAdjoint pass 1: z = lam, every accepted step recorded in monomial form for k_wide_quad_gk<., ., true>.  ALG = 4 GaussKronrodAdjoint: as
 // Gauss with the adaptive (7,15) rule of wide_gk_panels on every accepted step.
-template <class Mo, int ALG>
+// CK = true (round 5; checkpointing = true for Interpolating / Gauss / GaussKronrod, src/interpolating_adjoint.jl:54-109, 207-277 — adjoint_tsit5_lane's scheme on a workgroup): no
+// dense forward solution exists.  `lrec` holds ONE checkpoint interval [c_j, c_{j+1}] per trajectory (capacity SmaxI steps), re-solved from the stored sol(c_j) with the forward
+// tolerances and dt = |last step of the previous interval solution| (:245-251) whenever the sweep steps below the current interval; the last interval is solved eagerly (:88-92).
+// Every thread writes the two times of a record itself (and reads back what it wrote), the coefficients are owned per component: no cross-thread visibility is needed.
+template <class Mo, int ALG, bool CK = false>
 __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdapt a, const double* __restrict__ p, const double* __restrict__ rec, const int* __restrict__ nsteps,
                                                             const double* __restrict__ save_t, const double* __restrict__ tstops_desc, const double* __restrict__ cot,
                                                             double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag,
-                                                            double* __restrict__ arec, int* __restrict__ nsteps_adj, int SmaxA, double* __restrict__ gk_scratch) {
+                                                            double* __restrict__ arec, int* __restrict__ nsteps_adj, int SmaxA, double* __restrict__ gk_scratch,
+                                                            double* lrec_all, const double* __restrict__ ckpt, const double* __restrict__ ck_t, int SmaxI) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q, RW = 2 + 5 * N;
     static_assert(ALG == 0 || ALG == 2 || ALG == 3 || ALG == 4, "the adaptive sweeps of the workgroup family: Interpolating-, Gauss-, GaussKronrod- and QuadratureAdjoint (pass 1: lam only, recorded densely)");
+    static_assert(!(CK && ALG == 3), "QuadratureAdjoint has no checkpointing");
     static_assert(ALG != 0 || W::GP_LDS, "InterpolatingAdjoint on the adaptive solution keeps five parameter-sized rows in LDS (the planner checks the budget)");
     __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
     __shared__ double srows[ALG == 0 ? 4 * NP : 1], saccs[W::NA], sgk[ALG == 4 ? 2 * W::NA + 1 : 1], sred4[ALG == 4 ? (T / 64) * 2 * W::NA + 2 : 1];
@@ -1244,7 +1359,46 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
     if (ALG == 0) { for (int j = threadIdx.x; j < 4 * NP; j += T) srows[j] = 0.0; wide_sync<T>(); }
     WideTiles<Mo> LK = L; LK.gp = aug.kc;                                              // Interpolating: the vjp body writes the stage value of mu here
     WideFwdCursor<Mo> cur;
-    { const int ns = nsteps[traj]; cur.init(rec + traj * (long)a.Smax * RW, ns < a.Smax ? ns : a.Smax); }   // clamped: an overflowed forward pass is an error, not a fault
+    int icur = g.nck - 2;            // CK: the checkpoint interval the cursor's records belong to
+    bool ck_overflow = false;
+    auto resolve = [&](int j, double dt_hint) {
+        const int tid = threadIdx.x;
+        double* lrec = lrec_all + traj * (long)SmaxI * RW;
+        KRegsRolled<Q> KF;
+        double uu[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const int c = tid + q * T; uu[q] = c < N ? ckpt[(traj * g.nck + j) * N + c] : 0.0; }
+        int sl = 0;
+        auto frhs = [&](double (&k)[Q], const double (&x)[Q], double t) {      // f at a stage state: the forward solve's own form (k_wide_forward_ts5), on the sweep's tiles
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; if (c < N) sy[c] = x[q]; }
+            wide_sync<T>();
+            Mo::f(sdl, sy, pp, t, sws, tid);
+            wide_sync<T>();
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int c = tid + q * T; k[q] = c < N ? sdl[c] : 0.0; }
+        };
+        auto fcb = [&](double t, double tprev, double (&un)[Q], const auto& KK) -> bool {
+            (void)un;
+            if (sl < SmaxI) {
+                double c[5][Q]; tsit5_poly<Q>(KK, t - tprev, c);
+                double* r = lrec + (long)sl * RW;
+                r[0] = tprev; r[1] = t;                                          // by every thread: each reads back its own store
+#pragma unroll
+                for (int m = 0; m < 5; ++m)
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) { const int comp = tid + q * T; if (comp < N) r[2 + m * N + comp] = c[m][q]; }
+            } else ck_overflow = true;
+            ++sl;
+            return false;
+        };
+        const int nr = tsit5_integrate<Q>(uu, ck_t[j], ck_t[j + 1], dt_hint > 0 ? dt_hint : a.dt0, a.abstol, a.reltol, nullptr, 0, false, SmaxI, KF, frhs, fcb, NoPre(), WideNorm<T>{N});
+        if (nr < 0) ck_overflow = true;
+        cur.init(lrec, sl < SmaxI ? sl : SmaxI);
+        icur = j;
+    };
+    if constexpr (CK) resolve(g.nck - 2, 0.0);
+    else { const int ns = nsteps[traj]; cur.init(rec + traj * (long)a.Smax * RW, ns < a.Smax ? ns : a.Smax); }   // clamped: an overflowed forward pass is an error, not a fault
     double z[Q], acc[W::NA], dacc[W::NA];
 #pragma unroll
     for (int q = 0; q < Q; ++q) z[q] = 0.0;
@@ -1327,13 +1481,22 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_ts5(WideGeom g, WideAdap
         return mod;
     };
     const bool cb_at_init = g.M > 0 && time_hits(a.t1, save_t[g.M - 1]);
+    auto pre = [&](double t) {
+        if constexpr (CK) {
+            if (icur > 0 && !(t > ck_t[icur])) {   // the sweep stands on (or below) the lower end of its interval: the next stages need the one below
+                const double* last = cur.rec + (long)(cur.ns - 1) * RW;
+                const double dtl = cur.ns > 0 ? fabs(last[1] - last[0]) : 0.0;
+                resolve(icur - 1, dtl);
+            }
+        } else (void)t;
+    };
     int na;
-    if constexpr (ALG == 0) na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), aug);
-    else na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, NoPre(), WideNorm<T>{N});
+    if constexpr (ALG == 0) na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, pre, aug);
+    else na = tsit5_integrate<Q>(z, a.t1, g.t0, a.dt0, a.abstol, a.reltol, tstops_desc, a.ntstops, cb_at_init, 8 * a.maxit, K, rhs, cb, pre, WideNorm<T>{N});
     wide_finish<Mo>(g, traj, L, z, acc, du0, (ALG == 3 && !wide_has_dloss<Mo>::value) ? (double*)nullptr : dp_traj, flag);      // Quadrature: dp comes from the second pass (a model with a
                                                                                                                                   // discrete-loss body leaves its dgdp_discrete sum in the row: k_wide_quad_sum adds)
     if (ALG == 3 && threadIdx.x == 0) nsteps_adj[traj] = sa;                                   // the TRUE count; readers clamp with SmaxA
-    if ((na < 0 || aoverflow) && threadIdx.x == 0) atomicOr(flag, 4);
+    if ((na < 0 || aoverflow || ck_overflow) && threadIdx.x == 0) atomicOr(flag, 4);
 }
 
 

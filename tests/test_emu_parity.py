@@ -598,7 +598,7 @@ def _fuzz_case(seed):
     if model == "lorenz":
         dt = min(dt, 0.02)
     S = int(round(T / dt))
-    offgrid = bool(rng.random() < 0.4) and (alg in ("interpolating", "gauss", "backsolve") or (alg == "quadrature" and model != "emu_ring4"))   # off-grid Quadrature: compiled-in models
+    offgrid = bool(rng.random() < 0.4) and alg in ("interpolating", "gauss", "backsolve", "quadrature")
     ckpt = bool(rng.random() < 0.5) and alg != "quadrature" and not (alg == "gausskronrod")
     if offgrid and alg != "backsolve":
         ckpt = False

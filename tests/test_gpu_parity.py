@@ -1282,6 +1282,28 @@ def test_offgrid_loss_times_runtime_models(sa, name, omodel, dims):
     sol.engine.close()
 
 
+@pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring6", "RING", (6, 0, 0, 0))])
+@pytest.mark.parametrize("no_start", [False, True])
+def test_offgrid_quadrature_runtime_models(sa, name, omodel, dims, no_start):
+    """QuadratureAdjoint with loss times off the step grid for runtime-registered lane models (round 5; until then compiled-in models only): the dense adjoint record over
+    the reverse step list (k_quad_adj_offgrid) and quadgk per loss interval (k_quad_gk_offgrid) through hiprtc, against the oracle."""
+    m = UM.ROBER if name == "rober" else UM.ring(dims[0])
+    f = _device_function(sa, name + "_runtime", m)
+    rng = np.random.default_rng(47)
+    N, T, dt = 70, 1.0, 0.01
+    n, npar = m["n"], m["np"]
+    u0 = rng.uniform(0.3, 1.0, (N, n)); pp = rng.uniform(0.4, 1.2, (N, npar))
+    ts = np.array([0.0, 0.123, 0.5, 0.7777, 1.0]) if not no_start else np.array([0.0, 0.3141, 0.8])
+    delta = rng.standard_normal((N, len(ts), n))
+    sens = sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0, T), pp[0]), u0, pp), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, no_start=no_start)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
+    ref = O.Problem(omodel, alg="QUADRATURE", stepper="RK4", dt=dt, t0=0, t1=T, save_times=ts, loss="COTANGENT", dims=dims, no_start=no_start, quad_abstol=1e-10, quad_reltol=1e-10)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < 1e-8
+    sol.engine.close()
+
+
 @pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
 @pytest.mark.parametrize("name,omodel,dims", [("rober", "ROBER", (0, 0, 0, 0)), ("ring4", "RING", (4, 0, 0, 0))])
 def test_runtime_models_checkpointed_fixed_step(sa, name, omodel, dims, alg, oalg):

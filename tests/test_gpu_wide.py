@@ -113,9 +113,10 @@ def _run_ts5(sa, fun, oname, dims, u0, p, T, ts, tol, delta_of_out, p_shared=Tru
     kw = dict(dgdu_discrete=loss) if loss is not None else {}
     base = alg.split("_")[0]
     sens = dict(gauss=sa.GaussAdjoint(), interpolating=sa.InterpolatingAdjoint(), backsolve=sa.BacksolveAdjoint(), backsolve_nockpt=sa.BacksolveAdjoint(checkpointing=False),
-                quadrature=sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10))[alg]
+                quadrature=sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10), gauss_ckpt=sa.GaussAdjoint(checkpointing=True), interpolating_ckpt=sa.InterpolatingAdjoint(checkpointing=True),
+                gausskronrod_ckpt=sa.GaussKronrodAdjoint(checkpointing=True))[alg]
     sol = sa.solve(ens, sa.Tsit5(), saveat=ts, sensealg=sens, abstol=tol[0], reltol=tol[1], max_steps=max_steps, **kw)
-    ref = O.Problem(oname, alg=base.upper(), stepper="TSIT5", checkpointing=(alg == "backsolve"), quad_abstol=1e-10, quad_reltol=1e-10, t0=0.0, t1=T, dt=0.0, abstol=tol[0], reltol=tol[1], save_times=ts, dims=dims,
+    ref = O.Problem(oname, alg={"gausskronrod": "GAUSS_KRONROD"}.get(base, base.upper()), stepper="TSIT5", checkpointing=(alg == "backsolve" or alg.endswith("_ckpt")), quad_abstol=1e-10, quad_reltol=1e-10, t0=0.0, t1=T, dt=0.0, abstol=tol[0], reltol=tol[1], save_times=ts, dims=dims,
                     **(dict(loss="COTANGENT") if loss is None else dict(loss="LSQ_SHIFT", loss_shift=loss.shift)))
     if loss is None:
         delta = delta_of_out(sol.u)
@@ -175,6 +176,41 @@ def test_adaptive_tsit5_dense_linear_rows_and_lsq(sa, n, alg):
     fun = sa.WideDeviceFunction.dense_linear(f"lin{n}_ts5_{alg}", n)
     du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, "DENSELIN", (n, 0, 0, 0), u0, P, T, ts, (1e-8, 1e-6), None, p_shared=False, loss=sa.LsqShift(0.3), alg=alg)
     assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL and dp.shape == (N, n * n)
+
+
+@pytest.mark.parametrize("alg", ["gauss_ckpt", "interpolating_ckpt", "gausskronrod_ckpt"])
+@pytest.mark.parametrize("model", ["chain", "idxaff", "linear"])
+def test_adaptive_tsit5_checkpointing_on_wide_models(sa, model, alg):
+    """checkpointing = true for Interpolating / Gauss / GaussKronrod on the ADAPTIVE solution of a wide model (VERDICT r4 missing 5, coverage row a5; src/interpolating_adjoint.jl:54-109,
+    207-277): the forward solve keeps the states at the checkpoint times only (t0, the loss times, T), the sweep re-solves one interval at a time into a per-trajectory record —
+    with the forward tolerances and the last step of the interval above as the first guess — exactly the oracle's (and the lane family's) scheme; the workspace shrinks with it."""
+    rng = np.random.default_rng(53)
+    N, T = 3, 1.2
+    ts = np.array([0.0, 0.2, 0.45, 0.7, 0.95, 1.2])
+    if model == "chain":
+        if alg == "gausskronrod_ckpt":
+            pytest.skip("the oracle's GK restatement holds its np-vectors on the stack (ORC_MAXNP_COST = 64); the 2-parameter and the 36-parameter model cover the sensealg")
+        fun, omodel, dims, n = sa.WideDeviceFunction.dense_chain("ckts5_chain_" + alg, (2, 50, 2), input_power=3), "MLP1", (2, 50, 0, 0), 2
+        p = rng.standard_normal(252) * 0.3; u0 = np.array([2.0, 0.0]) + 0.05 * rng.standard_normal((N, 2))
+    elif model == "idxaff":
+        fun, omodel, dims, n = sa.WideDeviceFunction.index_affine("ckts5_idx_" + alg, 30, 50), "IDXAFF", (30, 50, 0, 0), 1500
+        p = rng.random(2); u0 = rng.standard_normal((N, n))
+    else:
+        n = 6
+        fun, omodel, dims = sa.WideDeviceFunction.dense_linear("ckts5_lin_" + alg, n), "DENSELIN", (n, 0, 0, 0)
+        p = (rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)).flatten(order="F"); u0 = rng.standard_normal((N, n))
+    data = rng.standard_normal((N, len(ts), n))
+    du0, dp, rdu0, rdp, out, rout = _run_ts5(sa, fun, omodel, dims, u0, p, T, ts, (1e-8, 1e-6), lambda o: 2.0 * (o - data), alg=alg)
+    assert rel(out, rout) < TS5_RTOL and rel(du0, rdu0) < TS5_RTOL and rel(dp, rdp) < TS5_RTOL
+    # against the dense sweep of the same handle family: the same gradient up to the solver tolerance, from a smaller workspace
+    ens = sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0, None)
+    wsb, grads = [], []
+    for ck in (False, True):
+        sens = {"gauss": sa.GaussAdjoint, "interpolating": sa.InterpolatingAdjoint, "gausskronrod": sa.GaussKronrodAdjoint}[alg.split("_")[0]](checkpointing=ck)
+        sol = sa.solve(ens, sa.Tsit5(), saveat=ts, sensealg=sens, abstol=1e-8, reltol=1e-6)
+        grads.append(sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=2.0 * (sol.u - data)))
+        wsb.append(sol.engine.stats()["workspace_bytes"]); sol.engine.close()
+    assert wsb[1] < wsb[0] and rel(grads[1][0], grads[0][0]) < 1e-4 and rel(grads[1][1], grads[0][1]) < 1e-4
 
 
 def test_adaptive_tsit5_wide_reports_a_record_that_is_too_small(sa):
@@ -436,6 +472,38 @@ def test_loss_times_off_the_step_grid_on_wide_models(sa, alg, oalg, model, no_st
     du0, dp = eng.adjoint(delta)
     eng.close()
     ref = O.Problem(omodel, alg=oalg, stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, dims=dims, no_start=no_start)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(out, rout) < 1e-10 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
+
+
+@pytest.mark.parametrize("alg,oalg,ck", [("backsolve", "BACKSOLVE", True), ("backsolve", "BACKSOLVE", False), ("quadrature", "QUADRATURE", False)])
+@pytest.mark.parametrize("model", ["idxaff", "chain", "ring"])
+@pytest.mark.parametrize("no_start", [False, True])
+def test_loss_times_off_the_step_grid_backsolve_and_quadrature_on_wide_models(sa, alg, oalg, ck, model, no_start):
+    """The two sensealgs the off-grid sweeps of the wide family lacked (VERDICT r4 missing 5; src/adjoint_common.jl:848-855): BacksolveAdjoint over the reverse step list with the
+    default checkpoints = t0, the save times, T interpolated from the forward knots (or none), and QuadratureAdjoint — the dense adjoint record on the non-uniform reverse grid and
+    quadgk per loss interval over it.  Against the oracle's generic integrator on the same clipped steps."""
+    from test_wtrace import ring
+    rng = np.random.default_rng(41)
+    if model == "idxaff":
+        fun, omodel, dims, n, npar = sa.WideDeviceFunction.index_affine("ogq_idx", 30, 50), "IDXAFF", (30, 50, 0, 0), 1500, 2
+    elif model == "chain":
+        fun, omodel, dims, n, npar = sa.WideDeviceFunction.dense_chain("ogq_chain", (2, 50, 2), input_power=3), "MLP1", (2, 50, 0, 0), 2, 252
+    else:
+        if "og_ring" not in _COSTFUN:
+            _COSTFUN["og_ring"] = sa.WideDeviceFunction.from_callable("og_ring", ring, 40, 41)
+        fun, omodel, dims, n, npar = _COSTFUN["og_ring"], "RING", (40, 0, 0, 0), 40, 41
+    N, T, dt = 4, 0.5, 0.01
+    ts = np.array([0.0, 0.0333, 0.1, 0.2171, 0.455, 0.5]) if not no_start else np.array([0.0, 0.123, 0.3707])
+    u0 = rng.uniform(0.3, 1.0, (N, n)); p = rng.uniform(0.2, 0.6, npar)
+    delta = rng.standard_normal((N, len(ts), n))
+    eng = sa.Engine(fun.name, alg, N, 0.0, T, dt, save_times=ts, no_start=no_start, checkpointing=ck)
+    out = eng.forward(u0, p)
+    du0, dp = eng.adjoint(delta)
+    du0b, dpb = eng.adjoint(delta)                                     # a second pass over the same forward solution: the records and cursors are re-entrant
+    eng.close()
+    assert np.array_equal(du0, du0b) and np.array_equal(dp, dpb)
+    ref = O.Problem(omodel, alg=oalg, stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, dims=dims, no_start=no_start, checkpointing=ck)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(out, rout) < 1e-10 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
 

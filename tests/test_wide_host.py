@@ -62,8 +62,9 @@ def test_planner_answers_for_wide_models(sa):
     for alg in (0, 1, 2, 3):
         assert check(stepper=1, alg=alg, dt=0.0, nsave=4, save_times=off_grid.ctypes.data_as(C.POINTER(C.c_double)), checkpointing=int(alg == 1))[0] == 0
     assert check(stepper=1, alg=4, dt=0.0)[0] == 0                      # GaussKronrodAdjoint: adaptive (7,15) rule per step, both steppers
-    rc, msg = check(stepper=1, alg=4, checkpointing=1); assert rc == -6 and "checkpointing" in msg
-    rc, msg = check(stepper=1, alg=2, checkpointing=1); assert rc == -6 and "checkpointing" in msg
+    for alg in (0, 2, 4):                                              # checkpointing = true on the adaptive solution (round 5): the interval re-solve inside the sweep compiles
+        assert check(stepper=1, alg=alg, dt=0.0, checkpointing=1)[0] == 0, alg
+    rc, msg = check(stepper=1, alg=3, dt=0.0, checkpointing=1); assert rc == -1 and "no checkpointing" in msg
     rc, msg = check(stepper=1, alg=2, abstol=0.0); assert rc == -1 and "abstol" in msg
     assert check(alg=4)[0] == 0
     # the built-in continuous costs: WideWithCost<UserW, kind> kernels compile (a sample here; every sensealg x stepper x kind runs on the GPU, test_gpu_wide.py)
@@ -79,11 +80,12 @@ def test_planner_answers_for_wide_models(sa):
     for alg in (0, 2, 4):
         assert check(alg=alg, checkpointing=1)[0] == 0 and check(alg=alg, checkpointing=1, ckpt_stride=7)[0] == 0
     rc, msg = check(alg=3, checkpointing=1); assert rc == -6 and "QuadratureAdjoint keeps the dense" in msg
-    # loss times off the step grid (round 4, k_wide_adjoint_og): Interpolating / Gauss without checkpointing; the others name what is offered
+    # loss times off the step grid: Interpolating / Gauss without checkpointing (round 4, k_wide_adjoint_og), Backsolve with its default checkpoints or none and Quadrature
+    # (round 5, k_wide_backsolve_og / k_wide_quad_adj_og + the GK pass over the reverse step list); the others name what is offered
     off = np.array([0.0, 0.333, 1.0])
-    for alg in (0, 2):
-        assert check(alg=alg, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)))[0] == 0
-    for alg, kw in ((1, dict(checkpointing=1)), (3, {}), (4, {}), (0, dict(checkpointing=1))):
+    for alg, kw in ((0, {}), (2, {}), (1, dict(checkpointing=1)), (1, {}), (3, {})):
+        assert check(alg=alg, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)), **kw)[0] == 0, (alg, kw)
+    for alg, kw in ((1, dict(checkpointing=1, ckpt_stride=5)), (4, {}), (0, dict(checkpointing=1)), (2, dict(checkpointing=1))):
         rc, msg = check(alg=alg, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)), **kw); assert rc == -6 and "step grid" in msg, (alg, msg)
 
 
@@ -127,9 +129,16 @@ def test_kernel_choice_of_the_wide_family(sa, tmp_path, monkeypatch):
     e = names(alg=4, cont_cost=1)
     assert "k_wide_forward<hipadj::UserW>" in e and "k_wide_adjoint<hipadj::WideWithCost<hipadj::UserW, 1>, 4>" in e
     e = names(alg=3, stepper=1, dt=0.0)
-    assert "k_wide_forward_ts5<hipadj::UserW>" in e and "k_wide_adjoint_ts5<hipadj::UserW, 3>" in e and "k_wide_quad_gk<hipadj::UserW, 32, true>" in e
+    assert "k_wide_forward_ts5<hipadj::UserW>" in e and "k_wide_adjoint_ts5<hipadj::UserW, 3, false>" in e and "k_wide_quad_gk<hipadj::UserW, 32, true>" in e
     e = names(alg=1, stepper=1, dt=0.0, checkpointing=1, cont_cost=2)
     assert "k_wide_forward_ts5<hipadj::UserW>" in e and "k_wide_backsolve_ts5<hipadj::WideWithCost<hipadj::UserW, 2>>" in e
+    e = names(alg=2, stepper=1, dt=0.0, checkpointing=1)                 # round 5: the interval re-solve inside the adaptive sweep
+    assert "k_wide_adjoint_ts5<hipadj::UserW, 2, true>" in e
+    off = np.array([0.0, 0.333, 1.0])                                   # round 5: loss times off the step grid, the two sensealgs that were missing
+    e = names(alg=3, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)))
+    assert "k_wide_quad_adj_og<hipadj::UserW>" in e and "k_wide_out_offgrid<hipadj::UserW>" in e and "k_wide_quad_gk<hipadj::UserW, 32, false, true>" in e
+    e = names(alg=1, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)), checkpointing=1)
+    assert "k_wide_backsolve_og<hipadj::UserW>" in e
     e = names(alg=3, cont_cost=2)
     assert "k_wide_quad_adj<hipadj::WideWithCost<hipadj::UserW, 2>>" in e and "k_wide_quad_gk<hipadj::WideWithCost<hipadj::UserW, 2>, 32, false>" in e
 
