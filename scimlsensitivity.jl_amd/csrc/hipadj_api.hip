@@ -250,7 +250,7 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->d_wscr, h->d_ldata, h->d_lpart};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->d_wscr, h->d_ldata, h->d_lpart, h->d_og_i, h->d_og_h, h->d_og_tile};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
@@ -503,6 +503,13 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
                                  HT(hipMemcpy(h->d_rs_te, P.rs_te.data(), sizeof(double) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
                                  HT(hipMemcpy(h->d_rs_save, P.rs_save.data(), sizeof(int) * h->nrs, hipMemcpyHostToDevice), "memcpy") &&
                                  HT(hipMemcpy(h->d_save_t, P.save_times.data(), sizeof(double) * h->M, hipMemcpyHostToDevice), "memcpy"))) rc = HIPADJ_ERR_HIP;
+    }
+    if (P.og_ck) {   // checkpointing = true over the reverse step list: the interval table and one knot tile per lane
+        h->og_ck = true; h->og_nint = (int)P.og_S.size();
+        std::vector<int> tab; tab.insert(tab.end(), P.og_S.begin(), P.og_S.end()); tab.insert(tab.end(), P.og_qlo.begin(), P.og_qlo.end()); tab.insert(tab.end(), P.og_qhi.begin(), P.og_qhi.end());
+        A(dev_alloc(h, &h->d_og_i, tab.size())); A(dev_alloc(h, &h->d_og_h, (size_t)h->og_nint)); A(dev_alloc(h, &h->d_og_tile, (size_t)P.og_tile_knots * n * Np));
+        if (rc == HIPADJ_OK && !(HT(hipMemcpy(h->d_og_i, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice), "memcpy") &&
+                                 HT(hipMemcpy(h->d_og_h, P.og_hlast.data(), sizeof(double) * h->og_nint, hipMemcpyHostToDevice), "memcpy"))) rc = HIPADJ_ERR_HIP;
     }
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {
@@ -837,9 +844,11 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     }
     k.forward = "hipadj::k_forward<" + U + ">";
     if (h->offgrid) {   // loss times off the step grid (planner: InterpolatingAdjoint only); the `gk` slot carries the out = sol(ts) kernel
-        if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE) k.main_k = "hipadj::k_backsolve_offgrid<" + U + ", " + I(cc) + ">";
+        if (h->og_ck) k.main_k = "hipadj::k_offgrid_ckpt<" + U + ", " + I(mode) + ", " + I(h->cfg.alg == HIPADJ_ALG_INTERPOLATING ? 0 : (h->cfg.alg == HIPADJ_ALG_GAUSS ? 2 : 4)) + ">";
+        else if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE) k.main_k = "hipadj::k_backsolve_offgrid<" + U + ", " + I(cc) + ">";
         else if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) { k.main_k = "hipadj::k_quad_adj_offgrid<" + U + ", " + I(mode) + ">"; k.aux = "hipadj::k_quad_gk_offgrid<" + U + ", " + I(cc) + ">"; }   // round 5
         else if (h->nseg > 1) k.main_k = "hipadj::k_offgrid_seg<" + U + ", " + I(mode) + (h->cfg.alg == HIPADJ_ALG_GAUSS ? ", true>" : ", false>");   // time-segmented over the reverse step list
+        else if (h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD) k.main_k = "hipadj::k_gauss_offgrid<" + U + ", " + I(mode) + ", true>";
         else k.main_k = std::string(h->cfg.alg == HIPADJ_ALG_GAUSS ? "hipadj::k_gauss_offgrid<" : "hipadj::k_interp_offgrid<") + U + ", " + I(mode) + ">";
         k.gk = "hipadj::k_out_offgrid<" + U + ">"; k.tail = (h->nseg > 1 && h->cfg.alg != HIPADJ_ALG_BACKSOLVE) ? compose : finish;
         return k;
@@ -909,7 +918,7 @@ static int user_compile_config(const hipadj_config* cfg, std::string& err) {
     Plan P;
     { const int prc = make_plan(cfg, P, err); if (prc != HIPADJ_OK) return prc; }
     if (P.wide) { std::vector<char> code; std::map<std::string, std::string> low; return user_compile(cfg->model, wide_kernel_names(cfg->alg, P.adaptive, cfg->cont_cost, P.ip_ckpt, P.offgrid), code, low, err); }
-    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
+    h.n = P.n; h.np = P.np; h.M = P.M; h.adaptive = P.adaptive; h.ip_ckpt = P.ip_ckpt; h.offgrid = P.offgrid; h.og_ck = P.og_ck; h.ck_long = P.ck_longest > HIPADJ_CKPT_KMAX; h.nseg = P.nseg;
     h.fused = fused_eligible(cfg, P) ? 1 : 0;
     const UserKernels k = user_kernel_names(&h);
     std::vector<std::string> exprs = {k.forward, k.main_k, k.tail};
@@ -1009,6 +1018,10 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
         }
     } else if (h->offgrid) {
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        if (h->og_ck) {
+            const OgIntervals I{h->d_og_i, h->d_og_i + h->og_nint, h->d_og_i + 2 * h->og_nint, h->d_og_h, h->d_ck_t, h->og_nint};
+            TRY(usig<decltype(&k_offgrid_ckpt<ModelLV, 1, 0>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, I, p, (const double*)h->d_ckpt, h->d_og_tile, cotT, d_du0, h->d_dp_traj));
+        } else
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
             TRY(usig<decltype(&k_backsolve_offgrid<ModelLV, 0>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, cotT, d_du0, h->d_dp_traj));
         else if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) {   // dense lambda over the reverse step list, then adaptive GK15 per (trajectory, loss interval): adjoint_impl's sequence for the compiled-in models

@@ -71,6 +71,8 @@ struct hipadj_handle {
     hipFunction_t uf_main_alt = nullptr;
     hipFunction_t uf_aux = nullptr;        // a fifth kernel of the model's module: QuadratureAdjoint with loss times off the step grid (uf_gk carries out = sol(ts), the GK pass sits here)
     int wide_SmaxI = 0;                    // wide models, adaptive stepper, checkpointing = true: the step capacity of the one-interval record a trajectory re-solves into
+    // checkpointing = true over the reverse step list (k_offgrid_ckpt): per interval (S, q_lo, q_hi) [3][nint] ints, the last step lengths [nint], the per-lane knot tile
+    bool og_ck = false; int og_nint = 0; int* d_og_i = nullptr; double* d_og_h = nullptr; dbl2* d_og_tile = nullptr;
     int rtc_selftest = 0;                      // 1: pending (first adjoint call runs both builds and compares), 2: agreed, 3: disagreed -> the -O1 build is used, 4: disagreed, the -O1 build irreproducible -> the -O3 build stays
     bool adaptive = false;                // adaptive Tsit5 (hipadj_adaptive.hpp)
     AdaptGeom ag{};

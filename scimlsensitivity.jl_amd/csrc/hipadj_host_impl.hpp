@@ -135,10 +135,21 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     }
     if (h->offgrid) {   // loss times off the step grid, one column, sequential in time (Backsolve; runtime models; forced time_segments = 1)
         RevSteps R{h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->nrs, h->rs_save_at_start, h->cfg.t1};
+        if (h->og_ck) {   // checkpointing = true: per-interval re-solve into the lane's knot tile (offgrid_ckpt_lane)
+            const OgIntervals I{h->d_og_i, h->d_og_i + h->og_nint, h->d_og_i + 2 * h->og_nint, h->d_og_h, h->d_ck_t, h->og_nint};
+            if (h->cfg.alg == HIPADJ_ALG_INTERPOLATING)
+                hipLaunchKernelGGL((k_offgrid_ckpt<Mo, LOSS, 0>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, I, p, (const double*)h->d_ckpt, h->d_og_tile, cotT, d_du0, h->d_dp_traj);
+            else if (h->cfg.alg == HIPADJ_ALG_GAUSS)
+                hipLaunchKernelGGL((k_offgrid_ckpt<Mo, LOSS, 2>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, I, p, (const double*)h->d_ckpt, h->d_og_tile, cotT, d_du0, h->d_dp_traj);
+            else
+                hipLaunchKernelGGL((k_offgrid_ckpt<Mo, LOSS, 4>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, I, p, (const double*)h->d_ckpt, h->d_og_tile, cotT, d_du0, h->d_dp_traj);
+        } else
         if (h->cfg.alg == HIPADJ_ALG_BACKSOLVE)
             hipLaunchKernelGGL((k_backsolve_offgrid<Mo, (LOSS >> 1)>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const double*)h->d_yT, (const double*)h->d_ckpt, cotT, d_du0, h->d_dp_traj);
         else if (h->cfg.alg == HIPADJ_ALG_GAUSS) {
             hipLaunchKernelGGL((k_gauss_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, cotT, d_du0, h->d_dp_traj);
+        } else if (h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD) {
+            hipLaunchKernelGGL((k_gauss_offgrid<Mo, LOSS, true>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, cotT, d_du0, h->d_dp_traj);
         } else
         hipLaunchKernelGGL((k_interp_offgrid<Mo, LOSS>), dim3(waves), dim3(WAVE), 0, h->stream, h->g, R, p, (const dbl2*)h->d_knots, cotT, d_du0, h->d_dp_traj);
         HIP_TRY(h, hipGetLastError());

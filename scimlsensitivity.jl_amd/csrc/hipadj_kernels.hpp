@@ -873,14 +873,29 @@ __global__ void __launch_bounds__(WAVE) k_interp_offgrid(Geom g, RevSteps R, con
 #pragma unroll
     for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[0][j];
 }
-template <class Mo, int MODE>
+template <class Mo, int MODE, bool GKR = false>   // GKR: GaussKronrodAdjoint (the adaptive (7,15) rule per reverse step)
 __global__ void __launch_bounds__(WAVE) k_gauss_offgrid(Geom g, RevSteps R, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                                         const double* __restrict__ cotT, double* __restrict__ du0, double* __restrict__ dp_traj) {
     constexpr int N = Mo::N, NP = Mo::NP;
     const long i = (long)blockIdx.x * WAVE + threadIdx.x;
     if (i >= g.N) return;
     double lam[1][N], mu[1][NP];
-    gauss_offgrid_lane<Mo, MODE>(g, i, p, knots, cotT, R, lam, mu);
+    gauss_offgrid_lane<Mo, MODE, 1, GKR>(g, i, p, knots, cotT, R, lam, mu);
+#pragma unroll
+    for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[0][j];
+}
+// Interpolating / Gauss / GaussKronrod (ALG 0 / 2 / 4) with checkpointing = true over the reverse step list (offgrid_ckpt_lane): one lane per trajectory, sequential in time;
+// `tile` is the per-lane knot tile of one checkpoint interval [(longest interval) + 1][N pairs][Npad], written and read by the same lane
+template <class Mo, int MODE, int ALG>
+__global__ void __launch_bounds__(WAVE) k_offgrid_ckpt(Geom g, RevSteps R, OgIntervals I, const double* __restrict__ p, const double* __restrict__ ckpt, dbl2* tile,
+                                                       const double* __restrict__ cotT, double* __restrict__ du0, double* __restrict__ dp_traj) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    if (i >= g.N) return;
+    double lam[1][N], mu[1][NP];
+    offgrid_ckpt_lane<Mo, MODE, ALG>(g, i, p, ckpt, tile, cotT, R, I, lam, mu);
 #pragma unroll
     for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
 #pragma unroll

@@ -57,6 +57,9 @@ struct Geom {
                        // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
 };
 HIPADJ_HD double knot_step(const Geom& g, int k) { return k == g.S - 1 ? g.h_last : g.dt; }   // length of the forward step [t_k, t_{k+1}]
+// time of knot k: t0 + k dt, except the end of a span that is not a multiple of dt (T itself; round 5: the slope stored with that knot was taken at t0 + S dt — invisible for
+// autonomous models, 5e-9 in the gradients of a time-dependent one)
+HIPADJ_HD double knot_time(const Geom& g, int k) { return (k == g.S && g.h_last != g.dt) ? g.t0 + (g.S - 1) * g.dt + g.h_last : g.t0 + k * g.dt; }
 
 template <class Mo> struct Knot { double u[Mo::N]; double f[Mo::N]; };
 
@@ -103,7 +106,7 @@ HIPADJ_HD void forward_lane(const Geom& g, long i, const double* __restrict__ u0
 #pragma unroll
     for (int j = 0; j < N; ++j) u[j] = u0[i * N + j];
     for (int k = 0; k <= g.S; ++k) {
-        const double t = g.t0 + k * g.dt, dt = knot_step(g, k);
+        const double t = knot_time(g, k), dt = knot_step(g, k);
         Mo::f(k1, u, pv, t);
         if (knots) store_knot<Mo>(knots, g.Npad, k, i, u, k1);
         if (ckpt) { const int c = ckpt_of_knot[k]; if (c >= 0) {
@@ -158,6 +161,7 @@ HIPADJ_HD void forward_lane_ev(const Geom& g, long i, const double* __restrict__
         const int kn = kn_next, c = ck_next, sv = sv_next;       // run of plain steps up to the next event (or to the end)
         if (e + 1 < ev.nev) { kn_next = ev.knot[e + 1]; ck_next = ev.ckpt[e + 1]; sv_next = ev.save[e + 1]; } else kn_next = g.S;
         const double dt = (k == g.S - 1) ? g.h_last : g.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+        const bool rag = k == g.S - 1 && g.h_last != g.dt;          // the shortened last step (a run of its own): its end is T, not t0 + S dt
 #pragma unroll 2
         for (; k < kn; ++k) {
             const double t = g.t0 + k * g.dt;
@@ -174,7 +178,7 @@ HIPADJ_HD void forward_lane_ev(const Geom& g, long i, const double* __restrict__
             Mo::f(k4, us, pv, t + dt);
 #pragma unroll
             for (int j = 0; j < N; ++j) u[j] = u[j] + h6 * (k1[j] + 2.0 * (k2[j] + k3[j]) + k4[j]);
-            Mo::f(k1, u, pv, g.t0 + (k + 1) * g.dt);            // first-same-as-last: the slope stored with knot k + 1
+            Mo::f(k1, u, pv, rag ? t + dt : g.t0 + (k + 1) * g.dt);   // first-same-as-last: the slope stored with knot k + 1
         }
         if (e < ev.nev) {                                        // the event AT knot kn (k == kn now)
             if (ckpt && c >= 0) {
@@ -851,13 +855,19 @@ HIPADJ_HD void cursor_eval(const Geom& g, long i, const dbl2* __restrict__ knots
 // NC = 1: the whole sweep (q_lo = 0, q_hi = R.n) or the top segment of a time-segmented one; NC = 1 + n: a lower segment [q_lo, q_hi) of the
 // reverse step list carrying the affine column and n basis columns exactly like interp_lane — the step list does not depend on the
 // trajectory, so cutting it into segments and composing their affine maps (k_compose_finish) applies unchanged.
+// checkpointing = true over the reverse step list (offgrid_ckpt_lane below): the sweep is CONTINUED from one checkpoint interval into the next — the adjoint state stays in
+// the caller's (lam, mu), the forward state at the interval's upper end is the one the interval above ended on (its re-solved solution at that time IS the stored checkpoint)
+template <int N> struct OgCarry { bool cont; double y[N]; };
+
 template <class Mo, int MODE, int NC = 1>   // MODE = discrete-loss kind | (continuous cost << 1)
 HIPADJ_HD void interp_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                    const double* __restrict__ cotT, const RevSteps& R, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP],
-                                   int q_lo = 0, int q_hi = -1) {
+                                   int q_lo = 0, int q_hi = -1, OgCarry<Mo::N>* carry = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
     if (q_hi < 0) q_hi = R.n;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
+    const bool cont = carry && carry->cont;
+    if (!cont) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -865,11 +875,15 @@ HIPADJ_HD void interp_offgrid_lane(const Geom& g, long i, const double* __restri
 #pragma unroll
         for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
     }
+    }
     const double t_first = q_lo == 0 ? R.t_start : R.t[q_lo];
     KnotCursor<Mo> c;
-    if (q_lo == 0) cursor_init<Mo>(g, i, knots, c); else cursor_init_at<Mo>(g, i, knots, c, t_first);
+    if (q_lo == 0 && !carry) cursor_init<Mo>(g, i, knots, c); else cursor_init_at<Mo>(g, i, knots, c, t_first);
     double y_hi[N], y_mid[N], y_lo[N];
-    cursor_eval<Mo>(g, i, knots, c, t_first, y_hi);
+    if (cont) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) y_hi[j] = carry->y[j];
+    } else cursor_eval<Mo>(g, i, knots, c, t_first, y_hi);
     auto jump = [&](int s, const double (&y)[N], double ts) {   // lam += dgdu_discrete(y, p, t_s, s): cotangent / data column or u - shift (affine column); mu += dgdp_discrete
         double gl[N], gpd[NP];
 #pragma unroll
@@ -893,6 +907,11 @@ HIPADJ_HD void interp_offgrid_lane(const Geom& g, long i, const double* __restri
         if (s >= 0) jump(s, y_lo, te);
 #pragma unroll
         for (int j = 0; j < N; ++j) y_hi[j] = y_lo[j];
+    }
+    if (carry) {
+        carry->cont = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) carry->y[j] = y_hi[j];
     }
 }
 
@@ -1397,14 +1416,19 @@ HIPADJ_HD void gauss_lane(const Geom& g, long i, int k_lo, int k_hi, const doubl
 // interp_offgrid_lane) with the 2-point Gauss-Legendre rule of gauss_lane on every reverse step — lambda from the adjoint step's
 // Hermite interpolant, y from the forward dense output at the node times.  The five forward states of a step (start, node,
 // middle, node, end) are evaluated in descending time, which is the only order the knot cursor supports.
-template <class Mo, int MODE, int NC = 1>
+// GKR = true (round 5): GaussKronrodAdjoint — the adaptive (7,15) rule of gauss_lane's GKR branch on every REVERSE step, panels in theta along the step.  A reverse step
+// can straddle a forward knot (the integrand is then only C1 inside it: the first panel is no longer accepted to roundoff); every panel walks its fifteen nodes in
+// descending time on a knot cursor of its own, started at the panel's upper end (three knot loads per panel, next to fifteen VJP evaluations).
+template <class Mo, int MODE, int NC = 1, bool GKR = false>
 HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restrict__ p, const dbl2* __restrict__ knots,
                                   const double* __restrict__ cotT, const RevSteps& R, double (&lam)[NC][Mo::N], double (&mu)[NC][Mo::NP],
-                                  int q_lo = 0, int q_hi = -1) {
+                                  int q_lo = 0, int q_hi = -1, OgCarry<Mo::N>* carry = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP, LOSS = MODE & 1, CC = MODE >> 1;
     const double xg = 0.5773502691896257645;
     if (q_hi < 0) q_hi = R.n;
     double pv[NP]; load_p<Mo>(p, g, i, pv);
+    const bool cont = carry && carry->cont;
+    if (!cont) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -1412,11 +1436,15 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
 #pragma unroll
         for (int j = 0; j < NP; ++j) mu[c][j] = 0.0;
     }
+    }
     const double t_first = q_lo == 0 ? R.t_start : R.t[q_lo];
     KnotCursor<Mo> cu;
-    if (q_lo == 0) cursor_init<Mo>(g, i, knots, cu); else cursor_init_at<Mo>(g, i, knots, cu, t_first);
+    if (q_lo == 0 && !carry) cursor_init<Mo>(g, i, knots, cu); else cursor_init_at<Mo>(g, i, knots, cu, t_first);
     double y_hi[N], y_mid[N], y_lo[N], yg[2][N];
-    cursor_eval<Mo>(g, i, knots, cu, t_first, y_hi);
+    if (cont) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) y_hi[j] = carry->y[j];
+    } else cursor_eval<Mo>(g, i, knots, cu, t_first, y_hi);
     auto jump = [&](int s, const double (&y)[N], double ts) {
         double gl[N], gpd[NP];
 #pragma unroll
@@ -1434,9 +1462,9 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
     for (int q = q_lo; q < q_hi; ++q) {
         const double t = R.t[q], hs = R.h[q], te = R.te[q], tm = t - 0.5 * hs;
         const double th0 = 0.5 * (1.0 - xg), th1 = 0.5 * (1.0 + xg);       // theta along the adjoint step: 0 at t, 1 at te
-        cursor_eval<Mo>(g, i, knots, cu, t - th0 * hs, yg[0]);
+        if constexpr (!GKR) cursor_eval<Mo>(g, i, knots, cu, t - th0 * hs, yg[0]);
         cursor_eval<Mo>(g, i, knots, cu, tm, y_mid);
-        cursor_eval<Mo>(g, i, knots, cu, t - th1 * hs, yg[1]);
+        if constexpr (!GKR) cursor_eval<Mo>(g, i, knots, cu, t - th1 * hs, yg[1]);
         cursor_eval<Mo>(g, i, knots, cu, te, y_lo);
         double lam_hi[NC][N], d_hi[NC][N], V[N], guh[N], gul[N];
         cost_grad_u<Mo, CC>(y_hi, pv, t, guh); cost_grad_u<Mo, CC>(y_lo, pv, te, gul);      // zero when CC == 0
@@ -1453,6 +1481,7 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
             Mo::vjp_u(V, lam[c], y_lo, pv, te);
 #pragma unroll
             for (int j = 0; j < N; ++j) d_lo[j] = -(V[j] + ((CC && c == 0) ? gul[j] : 0.0));                                   // fsallast
+            if constexpr (!GKR) {
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn) {
                 const double th = qn == 0 ? th0 : th1;
@@ -1467,11 +1496,106 @@ HIPADJ_HD void gauss_offgrid_lane(const Geom& g, long i, const double* __restric
 #pragma unroll
                 for (int j = 0; j < NP; ++j) mu[c][j] += (0.5 * hs) * W[j];
             }
+            } else {
+                // panels in theta (0 at t, 1 at te), left half first, halved while ||Kronrod - Gauss||_2 > 1e-7 (depth <= 12): gauss_lane's GKR branch on a step of length hs
+                constexpr int GKD = 12;
+                double pa[GKD + 2], pb[GKD + 2]; int pd[GKD + 2]; int sp = 1;
+                pa[0] = 0.0; pb[0] = 1.0; pd[0] = 0;
+#pragma unroll 1
+                while (sp > 0) {
+                    --sp;
+                    const double a = pa[sp], b = pb[sp]; const int d = pd[sp];
+                    const double cc = 0.5 * (a + b), hh = 0.5 * (b - a);
+                    double IK[NP], IG[NP];
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) { IK[j] = 0.0; IG[j] = 0.0; }
+                    KnotCursor<Mo> cp;
+                    cursor_init_at<Mo>(g, i, knots, cp, t - a * hs);
+#pragma unroll 1
+                    for (int jn = 0; jn < 15; ++jn) {
+                        const int qq = jn < 7 ? jn : (jn == 7 ? 7 : 14 - jn);
+                        const double th = cc + hh * (jn < 7 ? -GK15::X[qq] : (jn == 7 ? 0.0 : GK15::X[qq]));
+                        double lg[N], yq[N], W[NP];
+                        hermite<N>(th, -hs, lam_hi[c], d_hi[c], lam[c], d_lo, lg);
+                        cursor_eval<Mo>(g, i, knots, cp, t - th * hs, yq);
+                        Mo::vjp_p(W, lg, yq, pv, t - th * hs);
+                        if (cost_has_gp<CC>::value && c == 0) {
+                            double gp[NP]; cost_grad_p<Mo, CC>(yq, pv, t - th * hs, gp);
+#pragma unroll
+                            for (int j = 0; j < NP; ++j) W[j] += ((g.lflags & 2) ? -1.0 : 1.0) * gp[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) { IK[j] += GK15::WK[qq] * W[j]; if (qq & 1) IG[j] += GK15::WG[qq / 2] * W[j]; }
+                    }
+                    double e = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) { IK[j] *= hs * hh; IG[j] *= hs * hh; const double dd = IK[j] - IG[j]; e += dd * dd; }
+                    if (sqrt(e) <= 1e-7 || d >= GKD) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) mu[c][j] += IK[j];
+                    } else {
+                        pa[sp] = cc; pb[sp] = b; pd[sp] = d + 1; ++sp;
+                        pa[sp] = a; pb[sp] = cc; pd[sp] = d + 1; ++sp;
+                    }
+                }
+            }
         }
         const int s = R.save[q];
         if (s >= 0) jump(s, y_lo, te);
 #pragma unroll
         for (int j = 0; j < N; ++j) y_hi[j] = y_lo[j];
+    }
+    if (carry) {
+        carry->cont = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) carry->y[j] = y_hi[j];
+    }
+}
+
+// Interpolating- / Gauss- / GaussKronrodAdjoint(checkpointing = true) with loss times OFF the step grid (round 5; src/interpolating_adjoint.jl:54-109, 207-277 on the fixed step
+// with arbitrary checkpoint times).  The checkpoints — t0, the loss times, T, or the caller's list — are stops of the reverse solve; for every interval [c_j, c_{j+1}], top down, the lane
+// re-solves the forward problem from the stored sol(c_j) with the user's dt (the last step shortened onto c_{j+1}) into a per-lane knot tile and runs the interval's share of the
+// reverse step list over THAT solution: the off-grid sweeps above on a geometry whose origin is c_j.  At c_j itself the first stage of the next step still reads the interval above
+// (its value there is the stored checkpoint), every later one the interval below — the reference's `t in interval` rule.
+//   I.S[j] / I.hlast[j]: steps of interval j and the length of its last one; I.q_lo[j], I.q_hi[j]: its reverse steps; ck_t[j] = c_j; ckpt [nck][N][Npad]; tile [(max S_j) + 1] knots
+struct OgIntervals { const int* S; const int* q_lo; const int* q_hi; const double* hlast; const double* ck_t; int n; };
+
+template <class Mo, int MODE, int ALG>
+HIPADJ_HD void offgrid_ckpt_lane(const Geom& g, long i, const double* __restrict__ p, const double* __restrict__ ckpt, dbl2* tile,
+                                 const double* __restrict__ cotT, const RevSteps& R, const OgIntervals& I, double (&lam)[1][Mo::N], double (&mu)[1][Mo::NP]) {
+    constexpr int N = Mo::N, NP = Mo::NP;
+    static_assert(ALG == 0 || ALG == 2 || ALG == 4, "Interpolating, Gauss, GaussKronrod");
+    double pv[NP]; load_p<Mo>(p, g, i, pv);
+    OgCarry<N> carry; carry.cont = false;
+#pragma unroll 1
+    for (int j = I.n - 1; j >= 0; --j) {
+        Geom gj = g;
+        gj.t0 = I.ck_t[j]; gj.S = I.S[j]; gj.h_last = I.hlast[j];
+        {   // re-solve [c_j, c_{j+1}] from the stored state: forward_lane's arithmetic
+            double u[N], k1[N], k2[N], k3[N], k4[N], us[N];
+#pragma unroll
+            for (int c = 0; c < N; ++c) u[c] = ckpt[((long)j * N + c) * g.Npad + i];
+#pragma unroll 1
+            for (int k = 0; k <= gj.S; ++k) {
+                const double t = knot_time(gj, k), dt = knot_step(gj, k);
+                Mo::f(k1, u, pv, t);
+                store_knot<Mo>(tile, g.Npad, k, i, u, k1);
+                if (k == gj.S) break;
+#pragma unroll
+                for (int c = 0; c < N; ++c) us[c] = u[c] + 0.5 * dt * k1[c];
+                Mo::f(k2, us, pv, t + 0.5 * dt);
+#pragma unroll
+                for (int c = 0; c < N; ++c) us[c] = u[c] + 0.5 * dt * k2[c];
+                Mo::f(k3, us, pv, t + 0.5 * dt);
+#pragma unroll
+                for (int c = 0; c < N; ++c) us[c] = u[c] + dt * k3[c];
+                Mo::f(k4, us, pv, t + dt);
+#pragma unroll
+                for (int c = 0; c < N; ++c) u[c] = u[c] + (dt / 6.0) * (k1[c] + 2.0 * (k2[c] + k3[c]) + k4[c]);
+            }
+        }
+        if constexpr (ALG == 0) interp_offgrid_lane<Mo, MODE, 1>(gj, i, p, tile, cotT, R, lam, mu, I.q_lo[j], I.q_hi[j], &carry);
+        else gauss_offgrid_lane<Mo, MODE, 1, ALG == 4>(gj, i, p, tile, cotT, R, lam, mu, I.q_lo[j], I.q_hi[j], &carry);
     }
 }
 

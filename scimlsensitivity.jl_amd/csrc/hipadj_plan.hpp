@@ -45,6 +45,12 @@ struct Plan {
     std::vector<double> rs_t, rs_h, rs_te;
     std::vector<int> rs_save, rs_ck;
     int rs_save_at_start = -1;
+    // ... and Interpolating / Gauss / GaussKronrod with checkpointing = true on top (offgrid_ckpt_lane, round 5): per checkpoint interval [c_j, c_{j+1}] the steps of its
+    // re-solve, the length of the last one (it lands on c_{j+1}) and its share [q_lo, q_hi) of the reverse step list
+    bool og_ck = false;
+    std::vector<int> og_S, og_qlo, og_qhi;
+    std::vector<double> og_hlast;
+    int og_tile_knots = 0;
 };
 
 // Event knots of the fixed-step forward solve (forward_lane_ev, hipadj_lane.hpp): every knot where something besides the plain step
@@ -67,9 +73,9 @@ inline void plan_reverse_steps(const hipadj_config* cfg, Plan& P) {
     const std::vector<double>& st = P.save_times;
     const bool bs = cfg->alg == HIPADJ_ALG_BACKSOLVE;      // Backsolve: no_start is not consulted (src/adjoint_common.jl:761 reads it for the others), checkpoint stops
     auto hits = [&](double a, double b) { return std::fabs(a - b) <= 100 * EPS * std::fmax(std::fabs(a), std::fabs(b)); };
-    // tstops along the integration direction (descending): loss times and, for Backsolve, the checkpoint times
+    // tstops along the integration direction (descending): loss times and, with checkpoints (Backsolve; the checkpointed sweeps, src/sensitivity_interface.jl:484-486), their times
     std::vector<double> ts(st.rbegin(), st.rend());
-    if (bs) { ts.insert(ts.end(), P.ck_times.begin(), P.ck_times.end());
+    if (bs || P.og_ck) { ts.insert(ts.end(), P.ck_times.begin(), P.ck_times.end());
               for (size_t a = 1; a < ts.size(); ++a) { const double v = ts[a]; size_t b = a; while (b > 0 && ts[b - 1] < v) { ts[b] = ts[b - 1]; --b; } ts[b] = v; } }
     ts.push_back(cfg->t0);
     auto loss_at = [&](double t) {   // the callback's time test (within 100 eps), honouring no_start for the first loss time
@@ -203,8 +209,6 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_GAUSS_KRONROD) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (P.mlp || (P.field && cfg->stepper != HIPADJ_STEPPER_RK4_FIXED))) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory, wide and (RK4) PDE families"; return HIPADJ_ERR_UNSUPPORTED; }
-    if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && cfg->stepper == HIPADJ_STEPPER_RK4_FIXED && cfg->checkpointing && !P.wide) {
-        err = "GaussKronrodAdjoint(checkpointing=true) on the fixed step is offered for wide models; the lane family has it with adaptive Tsit5"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ETDRK4_FIXED) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->stepper == HIPADJ_STEPPER_ETDRK4_FIXED) {   // the exponential stepper: everything below treats it as a fixed-step scheme with Hermite dense output
         if (!P.field) { err = "HIPADJ_STEPPER_ETDRK4_FIXED integrates the semilinear PDE family (HIPADJ_MODEL_BRUSS): its linear part is diagonal in the DFT basis"; return HIPADJ_ERR_UNSUPPORTED; }
@@ -301,16 +305,21 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         else P.save_of_knot[k] = i;
     }
     if (ragged) P.offgrid = true;   // the reverse steps leave the knots right from T
+    if (!P.offgrid && cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && cfg->checkpointing && !P.wide) {
+        err = "GaussKronrodAdjoint(checkpointing=true) with the loss times on the step grid is offered for wide models; the lane family has it with adaptive Tsit5 and over the reverse step list (loss times off the grid)"; return HIPADJ_ERR_UNSUPPORTED; }
     if (P.offgrid) {
         // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
-        const bool og_ig = (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS) && !cfg->checkpointing;
-        const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE && cfg->ckpt_stride == 0 && cfg->ncheckpoints == 0;
+        const bool og_gk = cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && !P.wide;   // lane models (round 5): gauss_offgrid_lane's GKR branch, sequential in time
+        const bool ig_alg = cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS;
+        P.og_ck = (ig_alg || og_gk) && cfg->checkpointing && !P.wide;         // lane models (round 5): offgrid_ckpt_lane, sequential in time
+        const bool og_ig = (ig_alg && !cfg->checkpointing) || og_gk || P.og_ck;
+        const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE;    // any checkpoint choice (round 5: ckpt_stride and explicit lists too — the reverse step list stops at whatever times they name)
         const bool og_q = cfg->alg == HIPADJ_ALG_QUADRATURE && !P.wide;       // lane models: compiled-in (round 2) and runtime-registered (round 5)
         // wide models: Interpolating / Gauss (k_wide_adjoint_og), Backsolve (k_wide_backsolve_og) and Quadrature (k_wide_quad_adj_og + the GK pass over the reverse step list, round 5)
-        const bool og_wide = P.wide && (og_ig || og_bs || (cfg->alg == HIPADJ_ALG_QUADRATURE && !cfg->checkpointing));
+        const bool og_wide = P.wide && ((og_ig && !og_gk) || og_bs || (cfg->alg == HIPADJ_ALG_QUADRATURE && !cfg->checkpointing));
         if (!(og_ig || og_bs || og_q || og_wide) || P.field || P.mlp || (P.wide && !og_wide)) {
-            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint (checkpointing = false), QuadratureAdjoint and "
-                  "BacksolveAdjoint (checkpoints = the save times, ckpt_stride = 0) on the lane-per-trajectory and wide models; other configurations need times on the step grid, or the adaptive stepper (arbitrary times)";
+            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint / GaussKronrodAdjoint (GaussKronrod and checkpointing = true: lane models), QuadratureAdjoint and "
+                  "BacksolveAdjoint on the lane-per-trajectory and wide models; other configurations need times on the step grid, or the adaptive stepper (arbitrary times)";
             return HIPADJ_ERR_UNSUPPORTED; }
         for (int i = 0; i < cfg->nsave; ++i) {   // the sweep takes the times literally; they must not leave the span
             if (P.save_times[i] < cfg->t0) P.save_times[i] = cfg->t0;
@@ -318,12 +327,40 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         }
         P.save_of_knot.assign(S + 1, -1);   // no fused select on the knots: jumps are driven by the reverse step list
         P.ck_times.clear();
-        if (og_bs && cfg->checkpointing) {  // default checkpoints = sol.t of the saveat solve: t0, the save times, t1 (src/backsolve_adjoint.jl:132)
-            if (P.save_times.empty() || P.save_times.front() > cfg->t0) P.ck_times.push_back(cfg->t0);
-            for (double t : P.save_times) P.ck_times.push_back(t);
+        if ((og_bs || P.og_ck) && cfg->checkpointing) {  // default checkpoints = sol.t of the saveat solve: t0, the save times, t1 (src/backsolve_adjoint.jl:132); or the caller's list
+                                            // (src/sensitivity_interface.jl:484-486: any times inside the span), or every ckpt_stride-th knot of the forward grid
+            std::vector<double> src;
+            if (cfg->ncheckpoints > 0) src.assign(cfg->checkpoints, cfg->checkpoints + cfg->ncheckpoints);
+            else if (cfg->ckpt_stride > 0) { for (long k = 0; k < S; k += cfg->ckpt_stride) src.push_back(cfg->t0 + (double)k * cfg->dt); }
+            else src = P.save_times;
+            for (double& t : src) { if (t < cfg->t0) t = cfg->t0; if (t > cfg->t1) t = cfg->t1; }
+            if (src.empty() || src.front() > cfg->t0) P.ck_times.push_back(cfg->t0);
+            for (double t : src) if (P.ck_times.empty() || t > P.ck_times.back()) P.ck_times.push_back(t);
             if (P.ck_times.back() < cfg->t1) P.ck_times.push_back(cfg->t1);
         }
         plan_reverse_steps(cfg, P);
+        if (P.og_ck) {
+            const double EPS = 2.220446049250313e-16;
+            const int nint = (int)P.ck_times.size() - 1;
+            P.og_S.assign(nint, 0); P.og_hlast.assign(nint, cfg->dt); P.og_qlo.assign(nint, 0); P.og_qhi.assign(nint, 0); P.og_tile_knots = 0;
+            for (int j = 0; j < nint; ++j) {   // the re-solve of [c_j, c_{j+1}]: full dt-steps, the last one shortened onto c_{j+1}; a remainder that is a roundoff sliver joins the step before it
+                const double a = P.ck_times[j], b = P.ck_times[j + 1], L = b - a;
+                long Sj = (long)std::floor(L / cfg->dt);
+                if (Sj < 1) Sj = 0;
+                const double rem = L - (double)Sj * cfg->dt;
+                if (Sj == 0 || rem > 100 * EPS * std::fmax(std::fabs(a), std::fabs(b))) Sj += 1;
+                P.og_S[j] = (int)Sj; P.og_hlast[j] = L - (double)(Sj - 1) * cfg->dt;
+                if ((int)Sj + 1 > P.og_tile_knots) P.og_tile_knots = (int)Sj + 1;
+            }
+            int q = 0;
+            const int nrs = (int)P.rs_t.size();
+            for (int j = nint - 1; j >= 0; --j) {   // every checkpoint is a stop: a reverse step lies inside one interval
+                P.og_qlo[j] = q;
+                while (q < nrs && P.rs_t[q] - 0.5 * P.rs_h[q] > P.ck_times[j]) ++q;
+                P.og_qhi[j] = q;
+                if (P.og_qhi[j] <= P.og_qlo[j]) { err = "two checkpoint times are closer than the time resolution of the reverse solve (100 eps): no step falls between them"; return HIPADJ_ERR_INVALID_ARG; }
+            }
+        }
     }
     // checkpoints: BacksolveAdjoint only.  Interpolating/Gauss checkpointing re-solves, on this fixed grid,
     // bit-identical knots from the stored values; the dense tiles are kept instead.
@@ -349,7 +386,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         else { for (long k = 0; k <= S; ++k) if (k == 0 || k == S || P.save_of_knot[k] >= 0) P.ckpt_of_knot[k] = c++; }
         P.nck = c;
     }
-    if (P.ip_ckpt && P.user && !P.wide && (1 + n) * (n + np) > 64) {   // the checkpointed sweeps carry the 1 + n segment columns in VGPRs next to the re-solve state (not re-measured beyond 64)
+    if (P.ip_ckpt && !P.og_ck && P.user && !P.wide && (1 + n) * (n + np) > 64) {   // the checkpointed sweeps carry the 1 + n segment columns in VGPRs next to the re-solve state (not re-measured beyond 64)
         err = "checkpointing=true for Interpolating/Gauss on the fixed step needs (1 + n)(n + np) <= 64 for a runtime-compiled model (wider models: the adaptive stepper)"; return HIPADJ_ERR_UNSUPPORTED; }
     P.prev_ck.assign(S + 1, 0);
     if (P.ip_ckpt) {
@@ -361,7 +398,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     const bool seg_alg = !P.field && !P.mlp && !P.wide && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS || cfg->alg == HIPADJ_ALG_GAUSS_KRONROD || (cfg->alg == HIPADJ_ALG_BACKSOLVE && P.bs_ckpt));
     // off-grid Interpolating / Gauss: the reverse STEP LIST is what gets segmented (it does not depend on the
     // trajectory); bounds are then positions r = nrs - q in that list instead of knot indices (k_offgrid_seg)
-    const bool seg_offgrid = P.offgrid && (!P.user || plan_seg_fits(n, np)) && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS);
+    const bool seg_offgrid = P.offgrid && !P.og_ck && (!P.user || plan_seg_fits(n, np)) && (cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS);
     const long L = seg_offgrid ? (long)P.rs_t.size() : S;      // length of the axis the segments cut
     if (seg_alg && (!P.offgrid || seg_offgrid)) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, (int)L, n, np) : cfg->time_segments;

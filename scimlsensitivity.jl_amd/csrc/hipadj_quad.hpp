@@ -91,6 +91,7 @@ HIPADJ_HD void forward_quad_ev(const Geom& g, long i, int c, const double* __res
         const int kn_end = kn_next, ck = ck_next, sv = sv_next;    // run of plain steps up to the next event (or to the end)
         if (e + 1 < ev.nev) { kn_next = ev.knot[e + 1]; ck_next = ev.ckpt[e + 1]; sv_next = ev.save[e + 1]; } else kn_next = g.S;
         const double dt = (k == g.S - 1) ? g.h_last : g.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+        const bool rag = k == g.S - 1 && g.h_last != g.dt;          // the shortened last step of a span that is not a multiple of dt (a run of its own): its end is T, not t0 + S dt
         if (knots) {
 #pragma unroll 2
             for (; k < kn_end; ++k) {
@@ -100,7 +101,7 @@ HIPADJ_HD void forward_quad_ev(const Geom& g, long i, int c, const double* __res
                 const double k3 = Q::f(kc, fma(hh, k2, u), t + hh);
                 const double k4 = Q::f(kc, fma(dt, k3, u), t + dt);
                 u = fma(h6, k1 + 2.0 * (k2 + k3) + k4, u);
-                k1 = Q::f(kc, u, g.t0 + (k + 1) * g.dt);           // first-same-as-last: the slope stored with knot k + 1
+                k1 = Q::f(kc, u, rag ? t + dt : g.t0 + (k + 1) * g.dt);   // first-same-as-last: the slope stored with knot k + 1
             }
         } else {
             for (; k < kn_end; ++k) {
@@ -109,7 +110,7 @@ HIPADJ_HD void forward_quad_ev(const Geom& g, long i, int c, const double* __res
                 const double k3 = Q::f(kc, fma(hh, k2, u), t + hh);
                 const double k4 = Q::f(kc, fma(dt, k3, u), t + dt);
                 u = fma(h6, k1 + 2.0 * (k2 + k3) + k4, u);
-                k1 = Q::f(kc, u, g.t0 + (k + 1) * g.dt);
+                k1 = Q::f(kc, u, rag ? t + dt : g.t0 + (k + 1) * g.dt);
             }
         }
         if (e < ev.nev) {                                          // the event AT knot kn_end (k == kn_end now)

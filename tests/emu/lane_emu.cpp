@@ -125,6 +125,19 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
     const double* cot = cotT.empty() ? nullptr : cotT.data();
     const CkptSrc CK{ckpt.empty() ? nullptr : ckpt.data(), P.ckpt_of_knot.data(), P.prev_ck.data(), tile.data(), 1, 0};
     constexpr int KM = HIPADJ_CKPT_KMAX;
+    if (P.og_ck) {   // k_offgrid_ckpt<Mo, LOSS, ALG>: checkpointing = true over the reverse step list
+        const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+        const OgIntervals I{P.og_S.data(), P.og_qlo.data(), P.og_qhi.data(), P.og_hlast.data(), P.ck_times.data(), (int)P.og_S.size()};
+        std::vector<dbl2> og_tile((size_t)P.og_tile_knots * N * Np);
+        for (long i = 0; i < P.N; ++i) {
+            double lam[1][N], mu[1][NP];
+            if (cfg->alg == HIPADJ_ALG_INTERPOLATING) offgrid_ckpt_lane<Mo, LOSS, 0>(g, i, p, ckpt.data(), og_tile.data(), cot, RS, I, lam, mu);
+            else if (cfg->alg == HIPADJ_ALG_GAUSS) offgrid_ckpt_lane<Mo, LOSS, 2>(g, i, p, ckpt.data(), og_tile.data(), cot, RS, I, lam, mu);
+            else offgrid_ckpt_lane<Mo, LOSS, 4>(g, i, p, ckpt.data(), og_tile.data(), cot, RS, I, lam, mu);
+            for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
+            for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[0][j];
+        }
+    } else
     switch (cfg->alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         if (P.offgrid && P.nseg > 1) {   // k_offgrid_seg<..., false> + k_compose_finish
@@ -254,6 +267,16 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
         compose<Mo>(P, segbuf, du0, dp_traj);
         break; }
     case HIPADJ_ALG_GAUSS_KRONROD: {
+        if (P.offgrid) {   // k_gauss_offgrid<..., true>: sequential in time
+            const RevSteps RS{P.rs_t.data(), P.rs_h.data(), P.rs_te.data(), P.rs_save.data(), nullptr, (int)P.rs_t.size(), P.rs_save_at_start, cfg->t1};
+            for (long i = 0; i < P.N; ++i) {
+                double lam[1][N], mu[1][NP];
+                gauss_offgrid_lane<Mo, LOSS, 1, true>(g, i, p, knots.data(), cot, RS, lam, mu);
+                for (int j = 0; j < N; ++j) du0[i * N + j] = lam[0][j];
+                for (int j = 0; j < NP; ++j) dp_traj[(size_t)j * Np + i] = mu[0][j];
+            }
+            break;
+        }
         std::vector<double> segbuf((size_t)P.nseg * NC * R * Np, 0.0);
         for (int seg = 0; seg < P.nseg; ++seg) for (long i = 0; i < P.N; ++i) {
             double* dst = segbuf.data() + (size_t)seg * NC * R * Np + i;

@@ -176,14 +176,16 @@ def test_planner_span_not_a_multiple_of_dt_takes_a_short_last_step():
     b = (C.c_int * 64)()
     cfg = E.make_config("lorenz", "interpolating", 4, 0.0, 1.0, 0.03, [0.51, 0.99], time_segments=3)     # 0.51 = 17 * 0.03: on the knots, still off-grid
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 3 and b[3] >= 34
-    cfg = E.make_config("lorenz", "gausskronrod", 4, 0.0, 1.0, 0.03, [0.51])
-    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == -6
+    cfg = E.make_config("lorenz", "gausskronrod", 4, 0.0, 1.0, 0.03, [0.51], time_segments=3)    # round 5: GaussKronrod runs the reverse step list too, sequential in time
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 1
+    cfg = E.make_config("lorenz", "interpolating", 4, 0.0, 1.0, 0.03, [0.51], checkpointing=True, time_segments=3)   # ... and so do the checkpointed sweeps: t0, 0.51, T
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 1 and nck.value == 3
 
 
 def test_planner_offgrid_loss_times_build_the_reverse_step_list():
     """Loss times off the step grid: accepted for InterpolatingAdjoint / GaussAdjoint (the reverse step list, itself cut into time segments:
     the bounds are positions in that list — 101 steps here: 49 + 1 + 50 + the stop at 0.505 — not knot indices), one segment for
-    Backsolve, unsupported for Quadrature."""
+    Backsolve, GaussKronrod and the checkpointed sweeps; Quadrature: one interval pair."""
     nseg, nck, nq = C.c_int(), C.c_int(), C.c_int()
     b = (C.c_int * 64)()
     cfg = E.make_config("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, [0.505, 1.0], time_segments=4)
@@ -193,9 +195,12 @@ def test_planner_offgrid_loss_times_build_the_reverse_step_list():
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 1
     cfg = E.make_config("lorenz", "quadrature", 4, 0.0, 1.0, 0.01, [0.505, 1.0])
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nq.value == 2     # [0.505, 1.0] and the start correction [0, 0.505]
-    cfg = E.make_config("lorenz", "gausskronrod", 4, 0.0, 1.0, 0.01, [0.505, 1.0])
-    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == -6
-    assert "off the step grid" in E.lib().emu_last_error().decode()
+    cfg = E.make_config("lorenz", "gausskronrod", 4, 0.0, 1.0, 0.01, [0.505, 1.0], time_segments=4)       # round 5: the (7,15) rule per reverse step, sequential in time
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 1
+    cfg = E.make_config("lorenz", "gauss", 4, 0.0, 1.0, 0.01, [0.505, 1.0], time_segments=4, checkpointing=True)   # round 5: checkpointed, the checkpoints t0, 0.505, T are stops
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == 0 and nseg.value == 1 and nck.value == 3
+    cfg = E.make_config("lorenz", "interpolating", 4, 0.0, 1.0, 0.01, [0.505, 1.0], checkpointing=True, checkpoints=[0.3, 0.3 + 1e-16 * 3])
+    assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == -1 and "closer than the time resolution" in E.lib().emu_last_error().decode()
 
 
 def test_planner_segments_checkpoints_and_quadrature_intervals():
