@@ -1296,8 +1296,10 @@ def test_shortened_last_step_of_a_time_dependent_model(sa, alg, oalg):
     du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
     ref = O.Problem("LVT", alg=oalg, stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", checkpointing=(alg == "backsolve"))
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
-    tol = 1e-6 if alg == "quadrature" else 1e-10          # (default quadgk tolerances for Quadrature; the others see the 5e-9 the wrong slope time used to cost)
-    assert rel(sol.u, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < tol
+    # sol(1.004) is where the wrong slope time showed most (5.6e-7 relative): decisive at 1e-10.  The gradients moved by 5e-9: visible to Interpolating / Gauss at 1e-9
+    # (Backsolve carries its own roundoff amplification, Quadrature its default quadgk tolerances)
+    tol = dict(interpolating=1e-9, gauss=1e-9, backsolve=1e-7, quadrature=1e-6)[alg]
+    assert rel(sol.u, rout) < 1e-10 and rel(du0, rdu0) < tol and rel(dp, rdp) < tol
     sol.engine.close()
 
 
