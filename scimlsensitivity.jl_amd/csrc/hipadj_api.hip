@@ -280,7 +280,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     const int n = P.n, np = P.np; const long S = P.S;
     h->n = n; h->np = np; h->N = P.N; h->Npad = P.Npad; h->S = P.S; h->M = P.M; h->nck = P.nck; h->nseg = P.nseg; h->nq = P.nq;
     h->save_times = P.save_times; h->save_of_knot = P.save_of_knot; h->ckpt_of_knot = P.ckpt_of_knot; h->seg_bounds = P.seg_bounds;
-    const bool bs_ckpt = P.bs_ckpt || P.ip_ckpt;
+    const bool bs_ckpt = P.bs_ckpt || P.ip_ckpt || P.og_ck;   // (og_ck: GaussKronrod over the reverse step list is not an ip_ckpt configuration of the lane family, its checkpoint states are needed all the same)
     h->ip_ckpt = P.ip_ckpt;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { h->err = hipadj_status_string(HIPADJ_ERR_NO_DEVICE); return fail(HIPADJ_ERR_NO_DEVICE); }
@@ -510,6 +510,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_og_i, tab.size())); A(dev_alloc(h, &h->d_og_h, (size_t)h->og_nint)); A(dev_alloc(h, &h->d_og_tile, (size_t)P.og_tile_knots * n * Np));
         if (rc == HIPADJ_OK && !(HT(hipMemcpy(h->d_og_i, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice), "memcpy") &&
                                  HT(hipMemcpy(h->d_og_h, P.og_hlast.data(), sizeof(double) * h->og_nint, hipMemcpyHostToDevice), "memcpy"))) rc = HIPADJ_ERR_HIP;
+        if (rc == HIPADJ_OK && (!h->d_ckpt || !h->d_ck_t || !h->d_knots)) { h->err = "internal: the checkpointed sweep over the reverse step list lacks its checkpoint states, times or forward knots"; rc = HIPADJ_ERR_STATE; }
     }
     const std::vector<double>&qa = P.qa, &qb = P.qb;
     if (cfg->alg == HIPADJ_ALG_QUADRATURE) {

@@ -74,3 +74,19 @@ def test_world_size_mismatch_is_refused():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not _lines(r.stdout)
     r = _run(["--gpus", "1", "--steps", "2", "--warmup", "1"], {"HIPADJ_BENCH_STUB": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not _lines(r.stdout)
+
+
+def test_a_worker_that_dies_after_the_headline_still_yields_the_line():
+    """bench.py runs the measurement in a child of a GPU-free supervisor (bench.supervise): the child checkpoints its result once the headline is complete; when it is killed
+    later — a GPU fault in a secondary figure makes ROCr abort the process, which no `except` sees — the supervisor prints the checkpoint and says which part is missing."""
+    common = ["--steps", "3", "--warmup", "1", "--ntraj", "101", "--no-cpu-baseline", "--no-extras"]
+    r = _run(common, {"HIPADJ_BENCH_STUB": "1", "HIPADJ_BENCH_TEST_DIE": "after_headline"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["steps"] == 3
+    assert lines[0]["secondary_figures_incomplete"]["worker_exit_code"] != 0
+    ok = _run(common, {"HIPADJ_BENCH_STUB": "1"})                                   # the undisturbed run: the same line without the note
+    assert ok.returncode == 0 and "secondary_figures_incomplete" not in _lines(ok.stdout)[0]
+    assert {k for k in _lines(ok.stdout)[0]} == {k for k in lines[0]} - {"secondary_figures_incomplete"}
+    direct = _run(common, {"HIPADJ_BENCH_STUB": "1", "HIPADJ_BENCH_SUPERVISE": "0", "HIPADJ_BENCH_TEST_DIE": "after_headline"})   # without the supervisor the death is what the caller sees
+    assert direct.returncode != 0 and not _lines(direct.stdout)
