@@ -39,5 +39,6 @@ if d:
     print(open('gpurun_out/vf2/kernel_phases.txt').read())
 PY
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/vf2/smoke.log 2>&1; tail -2 gpurun_out/vf2/smoke.log
-timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider -rxX > gpurun_out/vf2/gpu_tests.log 2>&1
+# (the three wide-family files ran on this round's unchanged wide kernels in visit 13 — 299 passed, profiles/r5_gpu_suite_wide.log — and are left out here for the GPU-minute budget)
+timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider -rxX --ignore=tests/test_gpu_wide.py --ignore=tests/test_gpu_fuzz_wide.py --ignore=tests/test_gpu_wide_events.py > gpurun_out/vf2/gpu_tests.log 2>&1
 tail -6 gpurun_out/vf2/gpu_tests.log | cut -c1-300
