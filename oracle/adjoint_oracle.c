@@ -872,7 +872,15 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
         a.split_G = G; a.split_coef = p[2] / (dx * dx);
     }
-    return integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, NULL, NULL, 0, sol, nrhs);
+    int st = integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, NULL, NULL, 0, sol, nrhs);
+    if (st == 0 && sol->nsteps == 0) {
+        /* a span shorter than the solver's time resolution (a checkpoint one ulp below T makes [c, T] such an interval): no step was taken and the solution is its
+         * initial value — recorded as ONE step of the span's length with zero slopes, so that dense_eval finds a record (it used to index step -1) */
+        double *k0 = (double *)calloc((size_t)sol->nk * m->n, sizeof(double));
+        dense_push(sol, ta, tb, u, u, k0);
+        free(k0);
+    }
+    return st;
 }
 
 /* =====================================================================================

@@ -590,6 +590,22 @@ def test_shortened_last_step_of_a_time_dependent_model(alg):
     assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
 
 
+@pytest.mark.parametrize("alg", ["interpolating", "gauss", "backsolve"])
+def test_checkpoint_one_ulp_below_the_end_of_the_span(alg):
+    """A loss time (hence a default checkpoint) 2e-16 below T: the checkpoint interval [c, T] is shorter than the solver's time resolution and its re-solve takes no step.  The oracle
+    used to index step -1 of that empty solution (a crash found in round 5); it records the initial value as one zero-slope step now.  The planner treats the time as the knot S."""
+    rng = np.random.default_rng(17)
+    N, T, dt = 3, 1.5, 0.01
+    ts = np.array([0.2, 1.5 - 2e-16])
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    delta = rng.standard_normal((N, len(ts), 2))
+    cfg = E.make_config("lv", alg, N, 0.0, T, dt, ts, loss_kind=0, checkpointing=True)
+    du0, dp, out = E.forward_adjoint(cfg, 2, 4, u0, p, delta)
+    ref = O.Problem("LV", alg=alg.upper(), stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="COTANGENT", checkpointing=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
+    assert rel(out, rout) < 1e-12 and rel(du0, rdu0) < 1e-10 and rel(dp, rdp) < 1e-10
+
+
 def test_offgrid_loss_times_with_continuous_cost_and_rejections():
     rng = np.random.default_rng(12)
     u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((3, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
