@@ -190,7 +190,7 @@ static std::vector<std::string> wide_kernel_names(int alg, bool ts5 = false, int
     if (offgrid) {   // loss times off the step grid: the sweep over the reverse step list, and out = sol(ts) by interpolation in the `gk` slot
         if (alg == HIPADJ_ALG_BACKSOLVE) e.push_back("hipadj::k_wide_backsolve_og<" + U + ">");
         else if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_adj_og<" + U + ">");
-        else e.push_back("hipadj::k_wide_adjoint_og<" + U + (alg == HIPADJ_ALG_GAUSS ? ", 2>" : ", 0>"));
+        else e.push_back("hipadj::k_wide_adjoint_og<" + U + (alg == HIPADJ_ALG_GAUSS ? ", 2>" : (alg == HIPADJ_ALG_GAUSS_KRONROD ? ", 4>" : ", 0>")));
         e.push_back("hipadj::k_wide_out_offgrid<hipadj::UserW>");
         if (alg == HIPADJ_ALG_QUADRATURE) e.push_back("hipadj::k_wide_quad_gk<" + U + ", " + std::to_string(HIPADJ_WIDE_MAXSEG) + ", false, true>");   // fourth name: uf_aux
         return e;
@@ -1300,7 +1300,8 @@ static int wide_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, do
             hipLaunchKernelGGL(k_wide_quad_sum, grid, dim3(256), 0, h->stream, h->N, h->np, h->nq, (const double*)h->d_qres, rows, h->cfg.loss_kind == HIPADJ_LOSS_MODEL ? 1 : 0);
             HIP_TRY(h, hipGetLastError());
         } else
-        TRY(usig<decltype(&k_wide_adjoint_og<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, R, p, (const double*)h->d_fknots, d_cot, d_du0, rows, h->d_flag));
+        TRY(usig<decltype(&k_wide_adjoint_og<WideProbe, 0>)>::launch(h, h->uf_main, grid, blk, h->wg, R, p, (const double*)h->d_fknots, d_cot, d_du0, rows, h->d_flag,
+                    h->cfg.alg == HIPADJ_ALG_GAUSS_KRONROD ? h->d_wscr : (double*)nullptr));
     } else
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: case HIPADJ_ALG_GAUSS: case HIPADJ_ALG_GAUSS_KRONROD:

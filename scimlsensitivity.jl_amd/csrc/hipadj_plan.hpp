@@ -309,16 +309,16 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         err = "GaussKronrodAdjoint(checkpointing=true) with the loss times on the step grid is offered for wide models; the lane family has it with adaptive Tsit5 and over the reverse step list (loss times off the grid)"; return HIPADJ_ERR_UNSUPPORTED; }
     if (P.offgrid) {
         // loss times off the step grid t0 + k*dt: the reverse steps leave the forward knots (hipadj_lane.hpp, interp_offgrid_lane)
-        const bool og_gk = cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && !P.wide;   // lane models (round 5): gauss_offgrid_lane's GKR branch, sequential in time
+        const bool og_gk = cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && !(P.wide && cfg->checkpointing);   // round 5: gauss_offgrid_lane's GKR branch (sequential in time) / k_wide_adjoint_og<., 4>
         const bool ig_alg = cfg->alg == HIPADJ_ALG_INTERPOLATING || cfg->alg == HIPADJ_ALG_GAUSS;
         P.og_ck = (ig_alg || og_gk) && cfg->checkpointing && !P.wide;         // lane models (round 5): offgrid_ckpt_lane, sequential in time
         const bool og_ig = (ig_alg && !cfg->checkpointing) || og_gk || P.og_ck;
         const bool og_bs = cfg->alg == HIPADJ_ALG_BACKSOLVE;    // any checkpoint choice (round 5: ckpt_stride and explicit lists too — the reverse step list stops at whatever times they name)
         const bool og_q = cfg->alg == HIPADJ_ALG_QUADRATURE && !P.wide;       // lane models: compiled-in (round 2) and runtime-registered (round 5)
         // wide models: Interpolating / Gauss (k_wide_adjoint_og), Backsolve (k_wide_backsolve_og) and Quadrature (k_wide_quad_adj_og + the GK pass over the reverse step list, round 5)
-        const bool og_wide = P.wide && ((og_ig && !og_gk) || og_bs || (cfg->alg == HIPADJ_ALG_QUADRATURE && !cfg->checkpointing));
+        const bool og_wide = P.wide && (og_ig || og_bs || (cfg->alg == HIPADJ_ALG_QUADRATURE && !cfg->checkpointing));
         if (!(og_ig || og_bs || og_q || og_wide) || P.field || P.mlp || (P.wide && !og_wide)) {
-            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint / GaussKronrodAdjoint (GaussKronrod and checkpointing = true: lane models), QuadratureAdjoint and "
+            err = "save_times off the step grid t0 + k*dt are offered for InterpolatingAdjoint / GaussAdjoint / GaussKronrodAdjoint (checkpointing = true over the reverse step list: lane models), QuadratureAdjoint and "
                   "BacksolveAdjoint on the lane-per-trajectory and wide models; other configurations need times on the step grid, or the adaptive stepper (arbitrary times)";
             return HIPADJ_ERR_UNSUPPORTED; }
         for (int i = 0; i < cfg->nsave; ++i) {   // the sweep takes the times literally; they must not leave the span

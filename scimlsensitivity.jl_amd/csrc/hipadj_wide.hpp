@@ -704,11 +704,12 @@ __device__ __forceinline__ void wide_rk4_step_y(const WideTiles<Mo>& L, const do
 }
 template <class Mo, int ALG>
 __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_og(WideGeom g, RevSteps R, const double* __restrict__ p, const double* __restrict__ knots, const double* __restrict__ cot,
-                                                           double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag) {
+                                                           double* __restrict__ du0, double* __restrict__ dp_traj, int* __restrict__ flag, double* __restrict__ gk_scratch) {
     using W = WideShape<Mo>;
     constexpr int N = W::N, NP = W::NP, T = W::T, Q = W::Q;
-    static_assert(ALG == 0 || ALG == 2, "Interpolating, Gauss (2-node rule per reverse step)");
-    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * W::NA + 2], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    static_assert(ALG == 0 || ALG == 2 || ALG == 4, "Interpolating, Gauss (2-node rule per reverse step), GaussKronrod (round 5: the adaptive (7,15) rule per reverse step)");
+    __shared__ double sy[N], sls[N], sdl[N], sws[W::NW], sred[(T / 64) * (ALG == 4 ? 2 * W::NA : W::NA) + 2], sgp[W::GP_LDS ? NP : 1], sp[W::P_LDS ? NP : 1];
+    __shared__ double sgk[ALG == 4 ? 2 * W::NA + 1 : 1];
     const long traj = blockIdx.x;
     const double* pp = wide_params<Mo>(sp, p, g.p_shared, traj);
     WideTiles<Mo> L{sy, sls, sdl, W::GP_LDS ? sgp : dp_traj + traj * NP, sws, sred};
@@ -734,6 +735,24 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_og(WideGeom g, RevSteps 
             for (int q = 0; q < Q; ++q) h0[q] = lam[q];
             wide_rk4_step_y<Mo, false>(L, pp, t, hs, y_hi, y_mid, y_lo, lam, dacc, v1);
             wide_vjp<Mo, false>(L, pp, te, 0.0, y_lo, lam, dacc, v5);                        // fsallast: (df/du)^T lam_new at the step's end
+            if constexpr (ALG == 4) {
+                // panels in theta (0 at t, 1 at te), wide_adjoint_step's GaussKronrod branch on a step of length hs; y(t) of a node from the forward interpolant at the node's time
+                // (a reverse step can straddle a forward knot: wide_hermite finds the interval per evaluation)
+                double* rows = gk_scratch + traj * 3L * NP;
+                WideTiles<Mo> LF = L; LF.gp = rows;
+                auto node = [&](double th, double (&part)[W::NA]) {
+                    double gl[Q], yv[Q], dd[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        gl[q] = (1.0 - th) * h0[q] + th * lam[q] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lam[q] - h0[q]) + (th - 1.0) * (-hs) * (-v1[q]) + th * (-hs) * (-v5[q]));
+                    wide_hermite<Mo>(knots, g, traj, t - th * hs, yv);
+                    for (int j = threadIdx.x; j < NP; j += T) rows[j] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < W::NA; ++q) part[q] = 0.0;
+                    wide_vjp<Mo, true>(LF, pp, t - th * hs, 1.0, yv, gl, part, dd);
+                };
+                wide_gk_panels<Mo>(L, rows, rows + NP, rows + 2 * NP, sgk + 2 * W::NA, sgk, 0.0, 1.0, 1.0, [hs](double hh) { return hs * hh; }, node);
+            } else {
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
                 const double x = nq == 0 ? -xg : xg, th = 0.5 * (1.0 + x);                    // theta along the adjoint step: 0 at t, 1 at te
@@ -743,6 +762,7 @@ __global__ void __launch_bounds__(Mo::T) k_wide_adjoint_og(WideGeom g, RevSteps 
                     gl[q] = (1.0 - th) * h0[q] + th * lam[q] + th * (th - 1.0) * ((1.0 - 2.0 * th) * (lam[q] - h0[q]) + (th - 1.0) * (-hs) * (-v1[q]) + th * (-hs) * (-v5[q]));
                 wide_hermite<Mo>(knots, g, traj, t - th * hs, yv);
                 wide_vjp<Mo, true>(L, pp, t - th * hs, 0.5 * hs, yv, gl, acc, dd);
+            }
             }
         }
         { const int s = R.save[qs]; if (s >= 0) wide_jump<Mo>(g, traj, s, cot, y_lo, lam, L, pp, te, acc); }

@@ -446,7 +446,7 @@ def test_checkpointing_on_wide_models_fixed_step(sa, alg, oalg, model, ckpts):
     assert rel(res[1][0], rdu0) < 1e-6 and rel(res[1][1], rdp) < 1e-6
 
 
-@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS")])
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")])
 @pytest.mark.parametrize("model", ["idxaff", "chain", "ring"])
 @pytest.mark.parametrize("no_start", [False, True])
 def test_loss_times_off_the_step_grid_on_wide_models(sa, alg, oalg, model, no_start):
@@ -463,6 +463,8 @@ def test_loss_times_off_the_step_grid_on_wide_models(sa, alg, oalg, model, no_st
         if "og_ring" not in _COSTFUN:
             _COSTFUN["og_ring"] = sa.WideDeviceFunction.from_callable("og_ring", ring, 40, 41)
         fun, omodel, dims, n, npar = _COSTFUN["og_ring"], "RING", (40, 0, 0, 0), 40, 41
+    if alg == "gausskronrod" and npar > 64:
+        pytest.skip("the oracle's GK restatement holds its np-vectors on the stack (ORC_MAXNP_COST = 64); the 2- and the 41-parameter model cover the sensealg (round 5: k_wide_adjoint_og<., 4>)")
     N, T, dt = 4, 0.5, 0.01
     ts = np.array([0.0, 0.0333, 0.1, 0.2171, 0.455, 0.5]) if not no_start else np.array([0.0, 0.123, 0.3707])
     u0 = rng.uniform(0.3, 1.0, (N, n)); p = rng.uniform(0.2, 0.6, npar)

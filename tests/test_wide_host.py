@@ -83,9 +83,9 @@ def test_planner_answers_for_wide_models(sa):
     # loss times off the step grid: Interpolating / Gauss without checkpointing (round 4, k_wide_adjoint_og), Backsolve with its default checkpoints or none and Quadrature
     # (round 5, k_wide_backsolve_og / k_wide_quad_adj_og + the GK pass over the reverse step list); the others name what is offered
     off = np.array([0.0, 0.333, 1.0])
-    for alg, kw in ((0, {}), (2, {}), (1, dict(checkpointing=1)), (1, {}), (3, {}), (1, dict(checkpointing=1, ckpt_stride=5))):
+    for alg, kw in ((0, {}), (2, {}), (4, {}), (1, dict(checkpointing=1)), (1, {}), (3, {}), (1, dict(checkpointing=1, ckpt_stride=5))):
         assert check(alg=alg, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)), **kw)[0] == 0, (alg, kw)
-    for alg, kw in ((4, {}), (0, dict(checkpointing=1)), (2, dict(checkpointing=1))):     # GaussKronrod and the checkpointed sweeps over the reverse step list: lane models
+    for alg, kw in ((4, dict(checkpointing=1)), (0, dict(checkpointing=1)), (2, dict(checkpointing=1))):     # the checkpointed sweeps over the reverse step list: lane models
         rc, msg = check(alg=alg, nsave=3, save_times=off.ctypes.data_as(C.POINTER(C.c_double)), **kw); assert rc == -6 and "step grid" in msg, (alg, msg)
 
 
