@@ -108,10 +108,12 @@ typedef struct {
                                   models: such spans run the off-grid sweeps; PDE / MLP families: (t1 - t0)/dt must be an integer);
                                   Tsit5: initial step (<= 0: automatic) */
     int32_t nsave;             /* M loss/save times */
-    const double *save_times;  /* [M] strictly ascending inside [t0, t1] (copied at create).  RK4: on the step grid t0 + k*dt; off-grid
-                                  times are accepted for HIPADJ_ALG_INTERPOLATING / HIPADJ_ALG_GAUSS without checkpointing and for
-                                  HIPADJ_ALG_BACKSOLVE with ckpt_stride = 0 on the lane-per-trajectory models (the reverse solve stops at
-                                  them like the reference's PresetTimeCallback tstops, src/adjoint_common.jl:848-855; out = sol(ts) is interpolated, src/concrete_solve.jl:718-727).
+    const double *save_times;  /* [M] strictly ascending inside [t0, t1] (copied at create).  RK4: on the step grid t0 + k*dt, or anywhere: the reverse
+                                  solve then stops at them like the reference's PresetTimeCallback tstops (src/adjoint_common.jl:848-855) and out = sol(ts)
+                                  is interpolated (src/concrete_solve.jl:718-727).  Off-grid times are taken by every sensealg on the lane-per-trajectory and
+                                  the wide models — lane models also with checkpointing = true / ckpt_stride / a checkpoint list (the checkpoints are stops
+                                  too and may lie anywhere; BacksolveAdjoint's likewise on wide models); the PDE / MLP families and the checkpointed
+                                  Interpolating / Gauss / GaussKronrod sweeps of wide models need times on the grid (HIPADJ_ERR_UNSUPPORTED otherwise).
                                   Tsit5: arbitrary times */
     int32_t loss_kind;         /* hipadj_loss */
     double loss_shift;
