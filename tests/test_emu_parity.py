@@ -676,10 +676,8 @@ def _fuzz_case(seed):
     if model == "lorenz":
         dt = min(dt, 0.02)
     S = int(round(T / dt))
-    offgrid = bool(rng.random() < 0.4) and alg in ("interpolating", "gauss", "backsolve", "quadrature")
-    ckpt = bool(rng.random() < 0.5) and alg != "quadrature" and not (alg == "gausskronrod")
-    if offgrid and alg != "backsolve":
-        ckpt = False
+    offgrid = bool(rng.random() < 0.4)                       # round 5: every sensealg runs the reverse step list
+    ckpt = bool(rng.random() < 0.5) and alg != "quadrature" and not (alg == "gausskronrod" and not offgrid)    # ... also checkpointed (GaussKronrod + checkpointing on the grid stays refused for lanes)
     if alg == "backsolve" and model == "lorenz":
         ckpt = True
     m = int(rng.integers(0, 7))
@@ -689,6 +687,8 @@ def _fuzz_case(seed):
             ts = np.unique(np.concatenate([ts, [T]]))
         if rng.random() < 0.3:
             ts = np.unique(np.concatenate([[0.0], ts]))
+        if alg == "gausskronrod" and ckpt:
+            ts = np.unique(np.concatenate([ts, [0.123457 * T]]))       # (rounded times can all fall on the grid, where this pair is refused: one that cannot)
     else:
         ks = np.unique(rng.integers(0, S + 1, m))
         if ckpt and alg in ("interpolating", "gauss") and rng.random() < 0.5:
