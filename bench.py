@@ -69,8 +69,27 @@ def supervise():
     os.close(fd)
     os.unlink(path)
     env = dict(os.environ, HIPADJ_BENCH_WORKER="1", HIPADJ_BENCH_CHECKPOINT=path)
+
+    def _die_with_parent():      # the worker must not outlive its supervisor (a launcher that kills the rank kills this process; the GPU would stay held by an orphan)
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, 9)      # PR_SET_PDEATHSIG, SIGKILL
+        except Exception:      # noqa: BLE001
+            pass
     try:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)      # stderr is inherited
+        import signal
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, preexec_fn=_die_with_parent)      # stderr is inherited
+        for sig in (signal.SIGTERM, signal.SIGINT):      # a launcher's termination request goes on to the worker
+            try:
+                signal.signal(sig, lambda s, f: proc.send_signal(s))
+            except Exception:      # noqa: BLE001 — not the main thread
+                pass
+        raw, _ = proc.communicate()
+
+        class _R:
+            returncode = proc.returncode
+            stdout = raw
+        p = _R
         out = p.stdout.decode(errors="replace")
         if p.returncode == 0:
             sys.stdout.write(out); sys.stdout.flush()
@@ -946,6 +965,8 @@ def main():
         _checkpoint(res)
         if os.environ.get("HIPADJ_BENCH_TEST_DIE") == "after_headline":      # tests/test_bench_launch.py: the supervisor's path
             os.abort()
+        if os.environ.get("HIPADJ_BENCH_TEST_DIE") == "sleep":               # ... and a worker that is still busy when the launcher ends the rank
+            time.sleep(120)
 
     if world > 1 and not args.no_extras:
         # the other scaling figure, same run, fewer steps

@@ -90,3 +90,30 @@ def test_a_worker_that_dies_after_the_headline_still_yields_the_line():
     assert {k for k in _lines(ok.stdout)[0]} == {k for k in lines[0]} - {"secondary_figures_incomplete"}
     direct = _run(common, {"HIPADJ_BENCH_STUB": "1", "HIPADJ_BENCH_SUPERVISE": "0", "HIPADJ_BENCH_TEST_DIE": "after_headline"})   # without the supervisor the death is what the caller sees
     assert direct.returncode != 0 and not _lines(direct.stdout)
+
+
+def test_ending_the_supervisor_ends_the_worker():
+    """A launcher that terminates a rank (torchrun on another rank's failure, the driver's timeout) signals the SUPERVISOR: the request is passed on, and a worker whose supervisor
+    is killed outright is killed with it (PR_SET_PDEATHSIG) — no orphan keeps a GPU."""
+    import signal
+    import time
+    import psutil
+    env = dict(os.environ, HIPADJ_BENCH_STUB="1", HIPADJ_BENCH_TEST_DIE="sleep")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for how in (signal.SIGTERM, signal.SIGKILL):
+        sup = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--ntraj", "101", "--no-cpu-baseline", "--no-extras"],
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        worker = None
+        for _ in range(300):                       # the worker appears, then reaches its sleep (the stub's headline takes a second or two)
+            kids = psutil.Process(sup.pid).children()
+            if kids:
+                worker = kids[0]
+                break
+            time.sleep(0.1)
+        assert worker is not None
+        time.sleep(3.0)
+        sup.send_signal(how)
+        sup.wait(timeout=20)
+        gone, alive = psutil.wait_procs([worker], timeout=20)
+        assert not alive, f"the worker outlived its supervisor ({how!r})"
