@@ -85,6 +85,21 @@ for alg in ("INTERPOLATING_CKPT", "GAUSS_CKPT", "BACKSOLVE")
         checkpoints = [0.07, 0.3, 0.45, 1.25, 1.8], targets = "interval construction from an arbitrary checkpoint list (src/interpolating_adjoint.jl:54-58), Backsolve checkpoint callbacks (:523-546)"))
 end
 
+# (9) (round 5) loss times off the step grid COMBINED with checkpointing / GaussKronrod / Quadrature on the fixed step — the configurations the device's reverse-step-list sweeps
+#     gained last (k_offgrid_ckpt, gauss_offgrid_lane<GKR>, the wide family's off-grid Backsolve / Quadrature).  What they pin: whether the checkpoints are stops of the reverse
+#     solve, that an interval is re-solved from the INTERPOLATED sol(c_j) of the saveat solve with the user's dt and a shortened last step, and which interval a stage exactly
+#     at a checkpoint reads (`t in interval`, src/interpolating_adjoint.jl:207-277) — the re-solved solutions differ from the forward one at the level of the scheme's error here,
+#     so unlike case (1) a wrong choice is visible.  The span (0, 1.505) is not a multiple of dt either: the last forward step is shortened (dt = min(dt, tend - t)).
+for alg in ("INTERPOLATING_CKPT", "GAUSS_CKPT", "GAUSS_KRONROD", "QUADRATURE_TIGHT", "BACKSOLVE")
+    push!(cases, run_case(name = "rk4_lvt_offgrid_ragged_$alg", model = "LVT", alg = alg, stepper = "RK4", tspan = (0.0, 1.505), dt = 0.01, saveat = [0.137, 0.4, 0.40499, 1.2345, 1.502],
+        targets = "checkpoints as tstops of the reverse solve, interval re-solve from interpolated checkpoint states (fixed step: the user dt, shortened last step), " *
+                  "`t in interval` at a checkpoint, the slope of the last forward knot at t = T (time-dependent model, a loss time inside the shortened step)"))
+end
+for alg in ("INTERPOLATING_CKPT", "GAUSS_CKPT", "BACKSOLVE")
+    push!(cases, run_case(name = "rk4_lorenz_offgrid_customckpt_$alg", model = "LORENZ", alg = alg, stepper = "RK4", tspan = (0.0, 1.5), dt = 0.01, saveat = [0.137, 0.4, 0.40499, 1.2345],
+        checkpoints = [0.2, 0.6543, 1.1], targets = "an explicit checkpoint list OFF the step grid next to loss times off the grid: both are stops, only the checkpoints delimit re-solve intervals"))
+end
+
 # (5) constant non-singular mass matrix (test/Core3/adjoint.jl:1315-1376): the reference's own test problem, mass-matrix solver Rodas4;
 #     pins the du0 convention (lam(t0), no M' factor) and the M' handling of every sensealg.  Checked by tests/test_reference_fixtures.py against
 #     the oracle with orc_set_mass_matrix (explicit stepper on M^-1 f: the fixture's tolerances are 1e-12, agreement is asserted at 1e-8).
