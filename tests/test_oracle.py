@@ -330,3 +330,29 @@ def test_wide_models_match_independent_forward_sensitivities(alg, stepper):
         assert rel(out, np.asarray(g["out"])) < 1e-9, key
         du0, dp, _, _ = pr.adjoint_ensemble(u0, p, cot(g, np.asarray(g["out"]))[None])
         assert rel(du0[0], g["du0"]) < 2e-8 and rel(dp, g["dp"]) < 2e-8, (key, rel(du0[0], g["du0"]), rel(dp, g["dp"]))
+
+
+@pytest.mark.parametrize("alg,ck,cks", [("INTERPOLATING", False, None), ("INTERPOLATING", True, None), ("INTERPOLATING", True, [0.2, 0.6543, 1.1]), ("GAUSS", True, None),
+                                        ("GAUSS_KRONROD", False, None), ("GAUSS_KRONROD", True, None), ("QUADRATURE", False, None), ("BACKSOLVE", True, None),
+                                        ("BACKSOLVE", True, [0.2, 0.6543, 1.1]), ("BACKSOLVE", False, None)])
+def test_offgrid_ragged_configurations_converge_to_the_independent_gradient(alg, ck, cks):
+    """The fixed-step configurations of round 5 — loss times off the step grid on a span that is not a multiple of dt, with checkpointing (default checkpoints and an explicit list off
+    the grid), GaussKronrod, Quadrature, Backsolve — against tests/golden/offgrid_ragged.json (scipy DOP853 forward sensitivities, nothing shared with the oracle).  RK4's error at
+    dt = 0.005 and at dt = 0.0025: the distance to the independent gradient is small and falls by ~16 (fourth order), i.e. the reverse step list, the interval re-solves from
+    interpolated checkpoints, the shortened last steps and the jumps converge to the right thing; the adaptive stepper at tight tolerances hits it directly."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "offgrid_ragged.json")) as f:
+        gold = json.load(f)
+    ts = np.asarray(gold["ts"])
+    errs = []
+    for dt in (0.005, 0.0025):
+        pr = O.Problem("LVT", alg=alg, stepper="RK4", t0=gold["tspan"][0], t1=gold["tspan"][1], dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0,
+                       checkpointing=ck, checkpoints=cks, quad_abstol=1e-13, quad_reltol=1e-13)
+        du0, dp, out = pr.adjoint(gold["u0"], gold["p"])
+        errs.append(max(rel(du0, gold["du0"]), rel(dp, gold["dp"])))
+        assert rel(out, np.asarray(gold["out"])) < 1e-8
+    assert errs[0] < 2e-8 and errs[1] < 2e-9 and errs[0] / errs[1] > 8.0, errs
+    pr = O.Problem("LVT", alg=alg, stepper="TSIT5", t0=gold["tspan"][0], t1=gold["tspan"][1], dt=0.0, abstol=1e-12, reltol=1e-12, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0,
+                   checkpointing=ck, checkpoints=cks, quad_abstol=1e-13, quad_reltol=1e-13)      # (all of them exist on the adaptive stepper as well)
+    du0, dp, _ = pr.adjoint(gold["u0"], gold["p"])
+    assert rel(du0, gold["du0"]) < 1e-8 and rel(dp, gold["dp"]) < 1e-8
