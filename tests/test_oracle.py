@@ -307,13 +307,15 @@ def _wide_golden():
         return json.load(f)
 
 
-@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("alg", ALGS + ["INTERPOLATING_CKPT", "GAUSS_CKPT"])
 @pytest.mark.parametrize("stepper", ["RK4", "TSIT5"])
 def test_wide_models_match_independent_forward_sensitivities(alg, stepper):
     """The oracle's MLP1 (the 2-50-2 neural ODE of docs/src/Benchmark.md:62, Lux parameter order), DENSELIN and IDXAFF models: du0, dp and sol(ts) against
     DOP853 forward sensitivities of numpy restatements written from the reference's definitions (matrix form, no shared code).  RK4 at dt = 1e-3 (global error
     ~1e-12 here), Tsit5 at 1e-12 / 1e-12; Quadrature's GK tolerance 1e-12."""
     G = _wide_golden()
+    ckpt = alg.endswith("_CKPT") or alg == "BACKSOLVE"       # round 5: the checkpointed sweeps too (the wide family has them on both steppers) ...
+    alg = alg.replace("_CKPT", "")
     kw = dict(stepper="RK4", dt=1e-3) if stepper == "RK4" else dict(stepper="TSIT5", dt=0.0, abstol=1e-12, reltol=1e-12)
     cases = [("node", "MLP1", tuple(G["node"]["dims"]) + (0, 0), lambda g, out: 2.0 * (out - np.asarray(g["data"]))),
              ("linear", "DENSELIN", (G["linear"]["n"], 0, 0, 0), lambda g, out: np.asarray(g["w"])),
@@ -321,9 +323,8 @@ def test_wide_models_match_independent_forward_sensitivities(alg, stepper):
     for key, oname, dims, cot in cases:
         g = G[key]
         ts = np.asarray(g["ts"])
-        if stepper == "RK4" and key == "linear":
-            continue                                   # its loss times are not on a step grid
-        pr = O.Problem(oname, alg=alg, t0=0.0, t1=g["T"], save_times=ts, loss="COTANGENT", dims=dims, checkpointing=(alg == "BACKSOLVE"),
+        # (... and the linear model on RK4, whose loss times are not on a step grid: the reverse step list)
+        pr = O.Problem(oname, alg=alg, t0=0.0, t1=g["T"], save_times=ts, loss="COTANGENT", dims=dims, checkpointing=ckpt,
                        quad_abstol=1e-12, quad_reltol=1e-12, **kw)
         u0 = np.asarray(g["u0"])[None, :]; p = np.asarray(g["p"])
         out, _ = pr.forward(u0[0], p)
