@@ -85,13 +85,8 @@ def supervise():
             except Exception:      # noqa: BLE001 — not the main thread
                 pass
         raw, _ = proc.communicate()
-
-        class _R:
-            returncode = proc.returncode
-            stdout = raw
-        p = _R
-        out = p.stdout.decode(errors="replace")
-        if p.returncode == 0:
+        rc, out = proc.returncode, raw.decode(errors="replace")
+        if rc == 0:
             sys.stdout.write(out); sys.stdout.flush()
             return 0
         try:
@@ -99,8 +94,8 @@ def supervise():
                 res = json.load(f)
         except Exception:      # noqa: BLE001 — no checkpoint: the worker died before the headline (or is a rank that prints nothing)
             sys.stdout.write(out); sys.stdout.flush()
-            return p.returncode
-        res["secondary_figures_incomplete"] = {"worker_exit_code": p.returncode,
+            return rc
+        res["secondary_figures_incomplete"] = {"worker_exit_code": rc,
                                                "note": "the bench process ended abnormally AFTER the headline (timed region, roofline, parity) had been measured and checkpointed; "
                                                        "the figures present are complete, the ones missing were not reached (HIPADJ_BENCH_TRACE=1 names them on stderr)"}
         print(json.dumps(res)); sys.stdout.flush()
