@@ -57,6 +57,88 @@ def _checkpoint(res):
         pass
 
 
+EXTRAS_PATH = os.environ.get("HIPADJ_BENCH_EXTRAS", os.path.join(ROOT, "bench_extras.json"))
+LINE_LIMIT = 4096     # bytes of the ONE stdout line (round 5's 20 KB line was not parsed by the driver); everything else goes to EXTRAS_PATH
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _r(x, sig=6):
+    """Floats of the stdout line at `sig` significant digits (the extras file keeps full precision)."""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if np.isfinite(x) else None      # strict JSON: no NaN / Infinity literals on the line
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact(res):
+    """The ONE stdout line: the driver contract's keys + roofline + cpu_baseline + cold_burst + parity + shard_sizes, numbers and short tags only (< LINE_LIMIT bytes,
+    checked by tests/test_bench_launch.py).  Prose notes, loss_paths, other_configs and every table live in bench_extras.json (write_extras)."""
+    out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = res.get("config", {})
+    out["config"] = _pick(cfg, ("workload", "ntraj_total", "ntraj_per_gpu", "rk4_steps", "loss_times", "time_segments", "parallelism", "dp_allreduce", "rccl_ranks",
+                                "native_allreduce_fallback"))
+    out.update(_pick(res, ("ns_per_vjp_step", "power_preamble_passes", "forward_solve_ms")))
+    if res.get("cold_burst"):
+        out["cold_burst"] = _pick(res["cold_burst"], ("ms_per_step", "value", "whole_pass_frac"))
+    if res.get("roofline"):
+        out["roofline"] = _pick(res["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch",
+                                                   "kernel_ms", "launches_per_pass", "whole_pass_frac"))
+    if res.get("cpu_baseline"):
+        cb = res["cpu_baseline"]
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ns_per_vjp_step", "single_thread_value", "repeats", "spread_rel"))
+        out["cpu_baseline"]["sample"] = cb.get("sample_short") or str(cb.get("sample", ""))[:160]
+    out.update(_pick(res, ("parity_max_rel_du0_vs_oracle", "parity_max_rel_dp_vs_oracle", "parity_trajectories", "stub_dp")))
+    if res.get("shard_sizes"):
+        out["shard_sizes"] = [_pick(s, ("ntraj", "gpus_of_layout", "ms_per_step", "kernel_ms", "implied_speedup_if_allreduce_hidden")) for s in res["shard_sizes"]]
+    for k in ("weak_scaling", "strong_scaling", "weak_scaling_saturating"):
+        if res.get(k):
+            out[k] = _pick(res[k], ("value", "ms_per_step", "ntraj_total", "steps"))
+    if isinstance(res.get("saturating_ensemble"), dict):
+        out["saturating_ensemble"] = _pick(res["saturating_ensemble"], ("ntraj", "ms_per_step", "whole_pass_frac_of_hbm_peak"))
+    if isinstance(res.get("single_process_multi_device"), dict):
+        out["single_process_multi_device"] = _pick(res["single_process_multi_device"], ("value", "ms_per_step", "devices", "error"))
+    if res.get("secondary_figures_incomplete"):
+        out["secondary_figures_incomplete"] = _pick(res["secondary_figures_incomplete"], ("worker_exit_code",))
+    out["extras"] = res.get("extras_file")
+    out = _r(out)
+    if "stub_dp" in res:
+        out["stub_dp"] = res["stub_dp"]      # tests/test_bench_launch.py compares the stand-in's all-reduced sum at 1e-13
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:      # never expected; if a field grows, the optional tables go first, the contract keys never
+        for k in ("single_process_multi_device", "saturating_ensemble", "weak_scaling_saturating", "shard_sizes"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) < LINE_LIMIT:
+                break
+    return line
+
+
+def write_extras(res):
+    """Everything measured (the full dictionary, prose included) -> bench_extras.json next to bench.py (HIPADJ_BENCH_EXTRAS overrides); returns the path written or None."""
+    for path in (EXTRAS_PATH, os.path.join("/tmp", "bench_extras.json")):
+        try:
+            with open(path + ".tmp", "w") as f:
+                json.dump(res, f, indent=1)
+            os.replace(path + ".tmp", path)
+            return path
+        except Exception:      # noqa: BLE001 — a read-only tree must not cost the line
+            continue
+    return None
+
+
+def emit(res):
+    res["extras_file"] = write_extras(res)
+    line = compact(res)
+    sys.stdout.write(line + "\n"); sys.stdout.flush()
+    sys.stderr.write(f"[bench] the line above is {len(line)} bytes; everything else: {res['extras_file']}\n"); sys.stderr.flush()
+
+
 def supervise():
     """`python bench.py ...` is a two-process affair per rank: this supervisor (no GPU context, never imports torch) runs the real bench as a child (HIPADJ_BENCH_WORKER=1) and
     relays its ONE JSON line.  The child checkpoints its result after the headline — timed region, roofline, parity: everything the contract asks for — and again after every
@@ -98,7 +180,7 @@ def supervise():
         res["secondary_figures_incomplete"] = {"worker_exit_code": rc,
                                                "note": "the bench process ended abnormally AFTER the headline (timed region, roofline, parity) had been measured and checkpointed; "
                                                        "the figures present are complete, the ones missing were not reached (HIPADJ_BENCH_TRACE=1 names them on stderr)"}
-        print(json.dumps(res)); sys.stdout.flush()
+        emit(res)
         return 0
     finally:
         for q in (path, path + ".tmp"):
@@ -193,6 +275,7 @@ def cpu_baseline(u0, p, ts, budget_s=20.0):
                 single_thread_value=float(np.median(r1)), single_thread_spread_min_max=[float(r1.min()), float(r1.max())],
                 single_thread_ns_per_vjp_step=1e9 / (float(np.median(r1)) * 1000 * 4),
                 parallel_efficiency=med / (cores_used * float(np.median(r1))),
+                sample_short=f"{n} trajectories x {len(rates)} repeats, reverse passes only, median; {rev * cores_used:.0f} core-s; C oracle, OpenMP",
                 sample=f"{n} of the workload's trajectories x {len(rates)} repeats, reverse passes only, median ({rev:.2f} s on {cores_used} threads = "
                        f"{rev * cores_used:.0f} core-seconds), C oracle, OpenMP over trajectories (static schedule, unbound threads), gcc -O2 -ffp-contract=off",
                 ns_per_vjp_step=1e9 / (med * 1000 * 4))
@@ -911,7 +994,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Lorenz-63 ensemble, {args.ntraj} trajectories{' in total (sharded)' if strong else ' per GPU' if world > 1 else ''}, "
                                    f"InterpolatingAdjoint, fixed-step RK4 dt={DT}, tspan=(0,{T_FINAL}), loss times 0:{SAVE_DT}:{T_FINAL}, "
-                                   f"dgdu = u - {LOSS_SHIFT} (BASELINE configs[1])",
+                                   f"dgdu = u - {LOSS_SHIFT} (BASELINE configs[1])".replace("  ", " "),
                        "ntraj_total": n_total, "ntraj_per_gpu": hi - lo, "rk4_steps": S, "loss_times": len(ts),
                        "time_segments": st1["time_segments"], "parallelism": f"ensemble-shard x{world}",
                        "dp_allreduce": ("none" if world == 1 else ("rccl on the handle's second stream, overlapped with the next pass (hipadj_comm_overlap)" if getattr(r, "native_overlap", False)
@@ -1055,7 +1138,7 @@ def main():
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(u0_all, p_np, ts)
     if rank == 0:
-        print(json.dumps(res))
+        emit(res)
     if world > 1:
         dist.destroy_process_group()
 

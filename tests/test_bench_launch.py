@@ -62,6 +62,42 @@ def test_gpus_2_without_torchrun_starts_two_ranks_and_prints_one_line(comm, carr
     assert ln["weak_scaling"]["ntraj_total"] == 202
 
 
+def test_the_stdout_line_is_compact_strict_json_and_the_tables_go_to_the_extras_file(tmp_path):
+    """VERDICT r5 item 1: round 5's 20 KB line was not parsed by the driver.  The line is < 4096 bytes of strict JSON (no NaN / Infinity literals) with the contract's keys;
+    a full-sized result (the shape of a real N = 1 run, with loss_paths / other_configs / prose notes) still compacts below the limit, and the extras file holds everything."""
+    extras = str(tmp_path / "extras.json")
+    r = _run(["--steps", "3", "--warmup", "1", "--ntraj", "101", "--no-cpu-baseline", "--no-extras"], {"HIPADJ_BENCH_STUB": "1", "HIPADJ_BENCH_EXTRAS": extras})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1 and len(out[0]) < 4096
+
+    def strict(x):
+        raise ValueError(f"non-strict JSON constant {x}")
+    ln = json.loads(out[0], parse_constant=strict)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in ln, k
+    assert "workload" in ln["config"] and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(ln["roofline"])
+    full = json.load(open(extras))
+    assert full["roofline"]["kernel_ms_note"] and ln["extras"] == extras
+    sys.path.insert(0, ROOT)
+    import bench
+    big = dict(full)
+    big["cpu_baseline"] = dict(value=149066.1234567, unit="trajectories/s", cores=16, kind="port", sample="x" * 900, sample_short="10000 trajectories x 30 repeats", ns_per_vjp_step=1.68,
+                               single_thread_value=9360.0, repeats=30, spread_rel=0.05, cores_note="y" * 500)
+    big["cold_burst"] = dict(ms_per_step=0.13, value=7.6e7, unit="trajectories/s", whole_pass_frac=0.46)
+    big["shard_sizes"] = [dict(ntraj=n, gpus_of_layout=10000 // n, ms_per_step=0.03, trajectories_per_s=1e7, kernel_ms=0.03, time_segments=20, launches_per_pass=1,
+                               implied_speedup_if_allreduce_hidden=4.0) for n in (1250, 2500, 5000)]
+    big["other_configs"] = [{"config": "z" * 300, "note": "w" * 500} for _ in range(30)]
+    big["loss_paths"] = {"note": "v" * 5000}
+    big["roofline"]["traffic"] = 548.9e6
+    big["roofline"]["traffic_source"] = "t" * 600
+    line = bench.compact(big)
+    assert len(line) < 4096
+    back = json.loads(line, parse_constant=strict)
+    assert back["cpu_baseline"]["cores"] == 16 and back["cpu_baseline"]["kind"] == "port" and back["roofline"]["traffic"] == 548.9e6
+    assert "other_configs" not in back and "loss_paths" not in back and len(back["shard_sizes"]) == 3
+
+
 def test_gpus_n_refuses_instead_of_running_fewer():
     # no stub: the real path on a machine without (enough) HIP devices — must exit non-zero before any line is printed
     r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], {})
