@@ -42,6 +42,13 @@ def _mark(msg):
     """Progress marker on stderr (stdout carries the ONE JSON line): HIPADJ_BENCH_TRACE=1 names the figure under measurement, so that a run that dies says where."""
     if os.environ.get("HIPADJ_BENCH_TRACE"):
         sys.stderr.write(f"[bench] {msg}\n"); sys.stderr.flush()
+    maps = os.environ.get("HIPADJ_BENCH_TRACE_MAPS")      # the address space at the last marker: names the owner of a faulting address after ROCr has aborted the process
+    if maps:
+        try:
+            with open("/proc/self/maps") as f, open(maps, "w") as g:
+                g.write(f"# at marker: {msg}\n" + f.read())
+        except Exception:      # noqa: BLE001
+            pass
 
 
 def _checkpoint(res):

@@ -247,6 +247,12 @@ extern "C" int hipadj_model_check_config(const hipadj_config* cfg) {
 }
 
 
+#ifdef HIPADJ_WAVE_TRACE
+// development builds (-DHIPADJ_WAVE_TRACE, scripts/r6/wave_trace.py): a device buffer of 24 time stamps per wave that the next one-launch reverse passes fill; never in the shipped library
+unsigned long long* g_hipadj_wave_trace = nullptr;
+extern "C" int hipadj_debug_set_trace(void* dev_ptr) { g_hipadj_wave_trace = (unsigned long long*)dev_ptr; return HIPADJ_OK; }
+#endif
+
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
@@ -1041,6 +1047,7 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
         TRY(usig<decltype(&k_interp_offgrid<ModelLV, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, cotT, d_du0, h->d_dp_traj));
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
+        seg_plan_inline(sp, h->seg_bounds.data());
         const dim3 sgrid(waves, (unsigned)h->nseg);
         if (h->fused && h->d_tbuf && h->cfg.alg != HIPADJ_ALG_QUADRATURE) {
             // one launch per reverse pass: the sweep kernel composes the segment maps, writes du0 / the dp rows and reduces dp (hipadj_fused.hpp)
@@ -1735,6 +1742,7 @@ static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's p
     std::memset(q, 0, count * sizeof(double));                                  // touch the pages before they are pinned
     if (hipHostRegister(q, count * sizeof(double), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); std::free(q); return nullptr; }
     h->h_pin = (double*)q; h->pin_count = count;
+    if (std::getenv("HIPADJ_TRACE_PIN")) std::fprintf(stderr, "hipadj host_pin: handle %p registered [%p, %p)\n", (void*)h, q, (void*)((char*)q + count * sizeof(double)));
     return h->h_pin;
 }
 // host -> device through the pinned block (src pageable); falls back to the plain pageable copy

@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(Bruss<G>::T) k_bruss_adjoint(FieldGeom g, long
                         const int qn = jn < 7 ? jn : (jn == 7 ? 7 : 14 - jn);
                         const double x = jn < 7 ? -c_gk_x[qn] : (jn == 7 ? 0.0 : c_gk_x[qn]);
                         double f[3] = {0.0, 0.0, 0.0};
-                        node(c + h * x, 1.0, f, jn & 1);
+                        node(c + h * x, 1.0, f, (jn + 1) & 1);      // the first node of a panel publishes into sh[1]: sh[0] may still be read by the fsallast VJP above (no barrier in between), like the 2-node path below
                         const double wk = c_gk_wk[qn], wg = (qn & 1) ? c_gk_wg[qn >> 1] : 0.0;
 #pragma unroll
                         for (int e = 0; e < 3; ++e) { acc[e] += wk * f[e]; acc[3 + e] += wg * f[e]; }

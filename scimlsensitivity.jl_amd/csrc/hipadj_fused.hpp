@@ -41,7 +41,15 @@ struct TreePlan {
     unsigned* cnt;
     double* partial;                        // [blocks][NP] per-block sums of mu
     unsigned* ticket;                       // ensemble ticket (one word)
+#ifdef HIPADJ_WAVE_TRACE
+    unsigned long long* trace;              // development builds only (see HIPADJ_TP, hipadj_lane.hpp)
+#endif
 };
+#ifdef HIPADJ_WAVE_TRACE
+#define HIPADJ_TTRACE(T) ((T).trace)
+#else
+#define HIPADJ_TTRACE(T) ((unsigned long long*)nullptr)
+#endif
 
 // Host side: the shape of the tree for C leaves (hipadj_plan.hpp / hipadj_api.hip allocate by it).
 inline void tree_plan_shape(int C, int radix, long blocks, TreePlan& T, long* map_slots, long* counters) {
@@ -107,8 +115,10 @@ __device__ __forceinline__ void pair_load_sc1(RS rs, int voff, int soff, double&
 #endif
 // one wave: ticket on `ctr`; true on every lane iff this wave is the last of `expected` arrivers (then the counter is reset).
 // The caller has issued its payload stores; they are drained here before the ticket is drawn.
-__device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, unsigned expected) {
+__device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, unsigned expected, unsigned long long* tr = nullptr, int slot = 0) {
+    (void)tr; (void)slot;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through payload stores have left the CU
+    HIPADJ_TP(tr, slot, 0);                                     // stores drained
     unsigned old = 0;
 #if HIPADJ_TREE_ACQREL
     // the language-level form: an agent-scope acquire-release RMW — the compiler adds the L2 write-back in front and the L1 invalidate behind it
@@ -121,6 +131,7 @@ __device__ __forceinline__ bool tree_arrive_last(unsigned* __restrict__ ctr, uns
     // barrier, so no compiler version may hoist them above the ticket; the hardware side is the guide's recipe (16-byte sc1 stores drained before the ticket,
     // sc1 loads after it: cdna_hip_programming.md section 6 G16).  Runtime models under an UNTRUSTED hiprtc keep the three-launch pass (hipadj_api.hip).
     asm volatile("" ::: "memory");
+    HIPADJ_TP(tr, slot + 1, old);                               // ticket returned
     if (old != expected - 1u) return false;
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next pass
     return true;
@@ -163,7 +174,8 @@ __device__ __forceinline__ void fused_root(const double (&m)[N + NP], const Tree
 #pragma unroll
         for (int j = 0; j < NP; ++j) map_store_agent(T.partial + block * NP + j, s[j]);
     }
-    if (!tree_arrive_last(T.ticket, (unsigned)blocks)) return;
+    HIPADJ_TP(HIPADJ_TTRACE(T), 20, s[0]);                      // du0 written, mu reduced over the lanes, the block's partial issued
+    if (!tree_arrive_last(T.ticket, (unsigned)blocks, HIPADJ_TTRACE(T), 21)) return;
     // last block: lane l sums blocks l, l + 64, ... in increasing order, then the same fixed tree over the lanes
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -172,6 +184,7 @@ __device__ __forceinline__ void fused_root(const double (&m)[N + NP], const Tree
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) dp_sum[j] = v;
+        if (j == NP - 1) HIPADJ_TP(HIPADJ_TTRACE(T), 23, v);   // the ensemble's dp summed
     }
 }
 
@@ -195,7 +208,8 @@ __device__ __forceinline__ void fused_tail(double (&m)[(1 + N) * (N + NP)], cons
             const int so = (slot0 + (idx - first)) * SLOTB;
 #pragma unroll
             for (int r = 0; r < MAPP; ++r) pair_store_sc1(rs, voff, so + r * 1024, m[2 * r], 2 * r + 1 < MAPSZ ? m[2 * r + 1] : 0.0);
-            if (!tree_arrive_last(T.cnt + T.cnt_off[l + 1] + block * T.count[l + 1] + parent, (unsigned)nchild)) return;
+            HIPADJ_TP(HIPADJ_TTRACE(T), 4 + 4 * l, 0);            // level l: payload stores issued
+            if (!tree_arrive_last(T.cnt + T.cnt_off[l + 1] + block * T.count[l + 1] + parent, (unsigned)nchild, HIPADJ_TTRACE(T), 5 + 4 * l)) return;
             // last arriver of the node: fold its children, upper segment (lower rank) first; children in batches of four
             // (4 x MAPSZ doubles in flight fit the register file next to m; RADIX = 8 takes two batches)
             for (int c0 = 0; c0 < nchild; c0 += 4) {
@@ -221,6 +235,7 @@ __device__ __forceinline__ void fused_tail(double (&m)[(1 + N) * (N + NP)], cons
                     }
                 }
             }
+            HIPADJ_TP(HIPADJ_TTRACE(T), 7 + 4 * l, m[0]);         // level l: children loaded and folded
         }
         idx = parent;
     }

@@ -24,6 +24,9 @@
 #include "hipadj_wide.hpp"
 
 using namespace hipadj;
+#ifdef HIPADJ_WAVE_TRACE
+extern unsigned long long* g_hipadj_wave_trace;      // development builds only: defined in hipadj_api.hip, set through hipadj_debug_set_trace
+#endif
 
 #define HIPADJ_WIDE_MAXSEG 32   // segments of one adaptive Gauss-Kronrod quadrature in the wide family (segment integrals are np-vectors in HBM scratch)
 

@@ -168,6 +168,7 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
+        seg_plan_inline(sp, h->seg_bounds.data());
         if (h->ip_ckpt && h->ck_long)
             hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
                                (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
@@ -178,6 +179,9 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             // ONE launch per reverse pass (hipadj_fused.hpp): the sweep's waves compose their segment maps as a tree through HBM, the root wave of
             // each block writes du0 and its partial of dp, the last block sums the partials.  No k_compose_finish*, no k_reduce_final.
             TreePlan tp = h->tp; tp.tbuf = h->d_tbuf; tp.cnt = h->d_tcnt; tp.partial = h->d_partial; tp.ticket = h->d_ticket;
+#ifdef HIPADJ_WAVE_TRACE
+            tp.trace = g_hipadj_wave_trace; h->g.trace = g_hipadj_wave_trace;      // development builds: per-wave time stamps of this launch (hipadj_debug_set_trace)
+#endif
             const hipEvent_t e0 = h->timing >= 1 ? k0 : (hipEvent_t) nullptr, e1 = h->timing >= 1 ? k1 : (hipEvent_t) nullptr;
             double* dps = h->cfg.p_shared ? d_dp : (double*)nullptr;
             bool launched = false;

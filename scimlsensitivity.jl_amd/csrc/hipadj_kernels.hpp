@@ -21,10 +21,16 @@ namespace hipadj {
 
 constexpr int WAVE = 64;
 
+constexpr int HIPADJ_SEG_INLINE = 64;
 struct SegPlan {
     int nseg;              // C
     const int* bounds;     // device [C+1] knot indices, bounds[0] = 0, bounds[C] = S
+    int inl[HIPADJ_SEG_INLINE + 1];   // the same bounds INSIDE the kernarg segment when C <= 64 (filled by seg_plan_inline; zeros otherwise): a wave of the one-launch pass reads its
+                                      // two bounds with the scalar loads that fetch its other arguments instead of a dependent global load in front of its first knot load (round 6)
 };
+// bound s of the plan: from the kernarg copy when the launch site filled it (k_interp_fused), else from the device array
+HIPADJ_HD int seg_bound(const SegPlan& sp, int s) { return sp.nseg <= HIPADJ_SEG_INLINE ? sp.inl[s] : sp.bounds[s]; }
+inline void seg_plan_inline(SegPlan& sp, const int* host_bounds) { if (sp.nseg <= HIPADJ_SEG_INLINE) for (int s = 0; s <= sp.nseg; ++s) sp.inl[s] = host_bounds[s]; }
 
 template <class Mo>
 __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restrict__ u0, const double* __restrict__ p,
@@ -67,6 +73,9 @@ __global__ void __launch_bounds__(WAVE) k_forward_quad(Geom g, const double* __r
 // three of a CU's eight waves finishes 1.5x later than the kernel needs).
 // PSH = true: launched only when the parameters are shared (g.p_shared): lets models with stage operators keep their (p, dt)
 // constants in SGPRs (interp_lane).
+#ifndef HIPADJ_SEG_BOUNDS_GLOBAL
+#define HIPADJ_SEG_BOUNDS_GLOBAL 0
+#endif
 #ifndef HIPADJ_KINTERP_ATTR      // development hook (scripts/kbench.hip): e.g. __attribute__((amdgpu_waves_per_eu(3, 3)))
 #define HIPADJ_KINTERP_ATTR
 #endif
@@ -123,7 +132,13 @@ __global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(PSH ? 2 :
     const long i_raw = (long)blockIdx.x * WAVE + threadIdx.x;
     const long i = i_raw < g.N ? i_raw : g.N - 1;                    // padding lanes of the last block repeat its last trajectory
     const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;      // rank 0 = the top (longest, 1-column) segment: dispatched first
-    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+    HIPADJ_TP(HIPADJ_GTRACE(g), 0, 0);                               // wave entry
+#if HIPADJ_SEG_BOUNDS_GLOBAL
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];      // A/B: round 5's dependent global load
+#else
+    const int k_lo = seg_bound(sp, seg), k_hi = seg_bound(sp, seg + 1);
+#endif
+    HIPADJ_TP(HIPADJ_GTRACE(g), 1, k_lo + k_hi);                     // segment bounds loaded
     if constexpr (!SEG) {   // one segment (models whose segment columns do not fit the registers): the wave is its block's root, no map is ever built
         double lam[1][N], mu[1][NP], v[R];
         interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
@@ -155,6 +170,7 @@ __global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(PSH ? 2 :
             for (int j = 0; j < NP; ++j) m[c * R + N + j] = mu[c][j];
         }
     }
+    HIPADJ_TP(HIPADJ_GTRACE(g), 3, m[0]);                            // sweep done: the segment's map is in registers
     fused_tail<N, NP>(m, tp, g.N, (long)gridDim.x, (long)blockIdx.x, rank, du0, dp_rows, dp_sum, flag);
 }
 

@@ -55,7 +55,23 @@ struct Geom {
 
     double h_last;     // length of the LAST forward step [t_{S-1}, T]: = dt, or the remainder when the span is not a multiple of dt (the reference's
                        // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
+#ifdef HIPADJ_WAVE_TRACE
+    unsigned long long* trace;   // development builds only (scripts/r6/wave_trace.py): 24 time stamps per wave of the one-launch pass, or null
+#endif
 };
+// HIPADJ_TP(ptr, slot, dep): development builds (-DHIPADJ_WAVE_TRACE) let lane 0 of a wave store the 100 MHz real-time counter into slot `slot` of the wave's record once `dep`
+// (a value the point waits for) is available; nothing in the product build.  The record of a wave: [blockIdx.y][blockIdx.x][24].
+#if defined(HIPADJ_WAVE_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+#define HIPADJ_TP(ptr, slot, dep) do { if (ptr) { asm volatile("" :: "v"(dep)); const unsigned long long tp_now_ = wall_clock64(); \
+    if ((threadIdx.x & 63) == 0) (ptr)[(((long)blockIdx.y * gridDim.x + blockIdx.x) * 24) + (slot)] = tp_now_; } } while (0)
+#else
+#define HIPADJ_TP(ptr, slot, dep) ((void)0)
+#endif
+#ifdef HIPADJ_WAVE_TRACE
+#define HIPADJ_GTRACE(g) ((g).trace)
+#else
+#define HIPADJ_GTRACE(g) ((unsigned long long*)nullptr)
+#endif
 HIPADJ_HD double knot_step(const Geom& g, int k) { return k == g.S - 1 ? g.h_last : g.dt; }   // length of the forward step [t_k, t_{k+1}]
 // time of knot k: t0 + k dt, except the end of a span that is not a multiple of dt (T itself; round 5: the slope stored with that knot was taken at t0 + S dt — invisible for
 // autonomous models, 5e-9 in the gradients of a time-dependent one)
@@ -601,6 +617,7 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
         load_cot<Mo, LOSS>(g, i, LOSS != 1 ? save_of_knot[kc] : 0, cotT, cot[r]);
     }
     int kb = k_hi - 1;
+    HIPADJ_TP(HIPADJ_GTRACE(g), 2, ring[0].u[0]);      // the first knot of the ring has arrived
     for (; kb - (PF - 1) >= k_lo; kb -= PF) {
         int sfl[PF], sfn[PF];       // loss flags of this block and (cotangent prefetch) of the next one: scalar loads up front
 #pragma unroll

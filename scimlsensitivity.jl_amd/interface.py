@@ -137,7 +137,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
         N, d = ensprob.u0.shape
         loss = dgdu_discrete
         if isinstance(dgdu_discrete, LsqData):
-            loss = LsqData(None if dgdu_discrete.data is None else _to_columns(np.asarray(dgdu_discrete.data).reshape(N, -1, d)), dgdu_discrete.scale)
+            loss = LsqData(_to_columns(np.asarray(dgdu_discrete.data).reshape(N, -1, d)), dgdu_discrete.scale)
         inner = solve(EnsembleProblem(ODEProblem("mlp", _to_columns(ensprob.u0)[0], ensprob.prob.tspan, ensprob.p, (d, H, N, 0)), _to_columns(ensprob.u0)), alg, dt=dt, saveat=saveat,
                       sensealg=sensealg, dgdu_discrete=loss, device=device, no_start=no_start, want_out=want_out, save_start=save_start, save_end=save_end,
                       save_everystep=save_everystep, mfma=False)
@@ -200,14 +200,18 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
 def _dgdp_sum(sol, dgdp, shared):
     """sum_i dl_i/dp over the save times (and over the ensemble when p is shared)"""
     eng = sol.engine
+    N, M, npar = eng.N, eng.M, eng.np
+    route = sol.extra.get("mfma_route")
+    if route is not None:      # the handle behind a routed dense chain is ONE batched trajectory: the ensemble's shapes come from the route
+        N, M = route["N"], len(sol.t)
     if callable(dgdp):
         if sol.u is None or sol.extra.get("save_idxs") is not None:
             raise ValueError("a callable dgdp_discrete needs the full saved states (solve(..., want_out=True) without save_idxs)")
         p = sol.prob.p
-        rows = [np.asarray(dgdp(sol.u[:, i, :], p, sol.t[i], i), dtype=np.float64).reshape(eng.N, eng.np) for i in range(eng.M)]
-        tot = np.sum(rows, axis=0) if rows else np.zeros((eng.N, eng.np))
+        rows = [np.asarray(dgdp(sol.u[:, i, :], p, sol.t[i], i), dtype=np.float64).reshape(N, npar) for i in range(M)]
+        tot = np.sum(rows, axis=0) if rows else np.zeros((N, npar))
     else:
-        tot = np.asarray(dgdp, dtype=np.float64).reshape(eng.N, eng.M, eng.np).sum(axis=1)
+        tot = np.asarray(dgdp, dtype=np.float64).reshape(N, M, npar).sum(axis=1)
     return tot.sum(axis=0) if shared else tot
 
 
@@ -234,6 +238,8 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_di
     route = sol.extra.get("mfma_route")
     if route is not None:      # a dense chain solved on the FP64-MFMA family (solve above): cotangents in, du0 out in the ensemble's shapes
         N, d = route["N"], route["d"]
+        if checkpoints is not None:      # the route is taken only without a checkpoint list (_mfma_route): one handed here would be dropped silently
+            raise ValueError("checkpoints differ from the list the forward solve was prepared with; pass checkpoints=... to solve(...)")
         dg = dgdu_discrete
         if isinstance(dgdu_discrete, LsqData):
             if dgdu_discrete != sol.extra.get("dgdu_discrete"):

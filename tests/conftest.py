@@ -11,6 +11,16 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    if not hasattr(config, "workerinput"):
+        # the pytest-xdist controller (pytest.ini: -n 4), or a single-process run: build once BEFORE the workers start (they then find every library fresh instead of racing
+        # for the same object files) and map libhipadj.so into this process too — the tests run in the workers, but a record of "which native libraries did the pytest
+        # processes load" that looks at the controller must see the library the suite is about
+        try:
+            import scimlsensitivity_jl_amd as mod
+            mod.build_extension()
+            mod.load_library()
+        except Exception as e:      # noqa: BLE001 — the `sa` fixture reports a broken build where it matters
+            sys.stderr.write(f"conftest: library not built / loaded in the controller: {e!r}\n")
 
 
 def _hip_device_count():

@@ -564,11 +564,17 @@ def test_dense_chain_2_H_H_2_is_routed_to_the_mfma_family(sa, alg, H):
     data = 0.5 * rng.standard_normal((N, len(ts), d))
     res = {}
     for route in (False, None):
+        rng0 = np.random.default_rng(23)
         loss = sa.LsqData(data, 2.0)
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, dgdu_discrete=loss, mfma=route)
-        res[route] = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=loss)
+        dgdp = rng0.standard_normal((N, len(ts), len(p)))      # a loss with a direct parameter term: added to dp once (the routed handle has N = 1)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=loss, dgdp_discrete=dgdp)
+        res[route] = (du0, dp, np.array([sol.loss_value()]), np.array([2.0 * np.sum((sol.u - data) ** 2)]))
+        with pytest.raises(ValueError):
+            sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=loss, checkpoints=[0.0, 0.15, 0.3])
         sol.engine.close()
     assert rel(res[None][0], res[False][0]) < 1e-9 and rel(res[None][1], res[False][1]) < 1e-9
+    assert rel(res[None][2], res[False][2]) < 1e-12 and rel(res[None][2], res[None][3]) < 1e-12
 
 
 @pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE")])
