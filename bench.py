@@ -866,15 +866,18 @@ def wide_rows(sa, run):
             funx = sa.WideDeviceFunction.dense_chain(f"bench_chain_{Hx}", (2, Hx, Hx, 2))
             px = mlp_params(2, Hx); u0x = rng.standard_normal((Nx, 2)); dx = rng.standard_normal((Nx, len(tsx), 2))
             row = dict(H=Hx)
-            for name, eng, u0e, de in (("workgroup_per_trajectory", sa.Engine(funx.name, "gauss", Nx, 0.0, Tx, Tx / Sx, save_times=tsx), u0x, dx),
-                                       ("fp64_mfma", sa.Engine("mlp", "gauss", 1, 0.0, Tx, Tx / Sx, save_times=tsx, dims=(2, Hx, Nx, 0)), _I._to_columns(u0x), _I._to_columns(dx))):
+            # the SAME registered chain twice: as registered (hipadj_config.family = 1) and as the library routes it (family = 0: hipadj_route.hpp puts it on the FP64-MFMA family,
+            # transposition kernels of the [N][M][d] blocks included)
+            for name, eng, u0e, de in (("workgroup_per_trajectory", sa.Engine(funx.name, "gauss", Nx, 0.0, Tx, Tx / Sx, save_times=tsx, family=1), u0x, dx),
+                                       ("fp64_mfma", sa.Engine(funx.name, "gauss", Nx, 0.0, Tx, Tx / Sx, save_times=tsx), u0x, dx)):
+                assert (eng.stats()["routed_family"] == 3) == (name == "fp64_mfma")
                 ms, kms, st = run(eng, u0e, px, de, 2)
                 row[name] = dict(forward_ms=st["forward_ms_last"], reverse_ms=ms)
                 eng.close()
             row["mfma_speedup_reverse"] = row["workgroup_per_trajectory"]["reverse_ms"] / row["fp64_mfma"]["reverse_ms"]
             cross.append(row)
         _mark("dense chains 2-H-H-2 (tanh), N = 4096, 150 RK4 steps, Gauss")
-        rows.append(dict(config="dense chains 2-H-H-2 (tanh), N = 4096, 150 RK4 steps, GaussAdjoint: the runtime wide model against the FP64-MFMA family solve() routes them to",
+        rows.append(dict(config="dense chains 2-H-H-2 (tanh), N = 4096, 150 RK4 steps, GaussAdjoint: the runtime wide model as registered against the FP64-MFMA family hipadj_create routes it to",
                          dense_chain_crossover=cross,
                          note="the MFMA family wins at every width it is built for (32, 64, 128): a chain with H x H contractions belongs on the matrix cores; the published 2-50-2 net has "
                               "none (one hidden layer) and stays on the workgroup family"))

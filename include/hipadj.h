@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 108 /* 0.1.6: + device-resident discrete losses (HIPADJ_LOSS_LSQ_DATA / HIPADJ_LOSS_MODEL, hipadj_set_loss_data[_dev], hipadj_model_set_discrete_loss[_function], hipadj_wmodel_set_discrete_loss, hipadj_loss_value[_dev]), hipadj_adjoint_dev_soa / hipadj_soa_stride, hipadj_config.loss_scale / ndevices / device_ids (one handle over several devices), hipadj_config.reference_literal; 0.1.5: + hipadj_wmodel_set_cost (continuous cost of a wide model as an SPMD body), checkpointing = true for Interpolating / Gauss / GaussKronrod on wide models (fixed step); 0.1.4: + hipadj_wmodel_register (wide runtime models: fixed-step RK4 and adaptive Tsit5, the four sensealgs + GaussKronrod, built-in continuous costs), hipadj_comm_count / _selfcheck, hipadj_stats.launches_per_pass; 0.1.3: + hipadj_runtime_compiler; 0.1.2: + hipadj_config.ncheckpoints / checkpoints (general checkpoint lists); 0.1.1: hipadj_comm_*, off-grid save_times, HIPADJ_ERR_RCCL */
+#define HIPADJ_VERSION 109 /* 0.1.7: + hipadj_wmodel_declare_dense_chain and hipadj_config.family: the LIBRARY selects the kernel family of a declared dense chain (FP64-MFMA family for 2 -> H -> H -> 2). History of 108 and earlier: docs/ABI_HISTORY.md */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -97,6 +97,14 @@ typedef enum {
     HIPADJ_CCOST_MODEL = 3        /* the cost attached to a runtime-registered model with hipadj_model_set_cost */
 } hipadj_cont_cost;
 
+/* kernel family selection (hipadj_config.family, hipadj_stats.routed_family; ABI 109) */
+typedef enum {
+    HIPADJ_FAMILY_AUTO = 0,
+    HIPADJ_FAMILY_AS_REGISTERED = 1,
+    HIPADJ_FAMILY_MFMA = 3          /* the FP64-MFMA family of HIPADJ_MODEL_MLP (csrc/hipadj_mlp*.hpp) */
+} hipadj_family;
+typedef enum { HIPADJ_ACT_TANH = 1 } hipadj_activation;
+
 typedef struct {
     uint32_t struct_size;      /* = sizeof(hipadj_config); ABI guard */
     int32_t model;             /* hipadj_model */
@@ -147,7 +155,10 @@ typedef struct {
                                   dgdp_continuous with the sign src/gauss_adjoint.jl:753-758 has as written (-f_p' lam + g_p under the reversed-time sum), and drop dgdp_discrete
                                   (ReverseLossCallback skips it for `isq` algorithms, src/adjoint_common.jl:776, and src/gauss_adjoint.jl adds it nowhere).  0 (default): the
                                   mathematically consistent forms (Gauss == Interpolating == Quadrature).  Exists so that a reference-generated fixture can decide each with one number. */
-    int32_t reserved1;
+    int32_t family;            /* a hipadj_family value; this field was reserved1 before ABI 109.  HIPADJ_FAMILY_AUTO = 0: hipadj_create picks the kernel family — a wide model declared as a dense chain
+                                  (hipadj_wmodel_declare_dense_chain) of shape 2 -> H -> H -> 2, H in {32, 64, 128}, tanh, on fixed-step RK4 with shared parameters and a multiple
+                                  of 16 trajectories runs on the FP64-MFMA family (the trajectories become the batch columns of HIPADJ_MODEL_MLP; same handle API and array shapes;
+                                  hipadj_stats.routed_family says so).  HIPADJ_FAMILY_AS_REGISTERED = 1: always the family the model was registered for. */
 } hipadj_config;
 
 typedef struct {
@@ -165,7 +176,7 @@ typedef struct {
     int32_t launches_per_pass;        /* kernel launches of one reverse pass as configured: 1 = the sweep kernel finishes the pass itself (composition tree
                                          and dp reduction in-launch, csrc/hipadj_fused.hpp), 3 = sweep + composition + reduction (lane family), wide models: the real count (sweep
                                          [+ GK15 pass] [+ k_wide_reduce_dp for shared parameters]), 0 = other sequences */
-    int32_t reserved0;
+    int32_t routed_family;            /* hipadj_family the library chose for this handle when it differs from the registered one (HIPADJ_FAMILY_MFMA), else 0 (was reserved0; ABI 109) */
 } hipadj_stats;
 
 typedef struct hipadj_handle hipadj_handle;
@@ -276,6 +287,12 @@ int hipadj_model_set_discrete_loss_function(int32_t model_id, const char *l_body
  * dlam[0..n) (entry k from the thread that owns it: HIPADJ_W_FOR loops do) and, under `if (WP)`, dl_i/dp into gp[...] (entries owned by one thread) or acc[...] (the model's
  * reduced parameters).  u, dlam: LDS tiles; d: the trajectory's data column [n] in global memory (NULL when no block was set).  NULL / "" removes it. */
 int hipadj_wmodel_set_discrete_loss(int32_t model_id, const char *dloss_body);
+/* Declares that wide model `model_id` IS the dense chain Lux.Chain(x -> x.^input_power, Dense(widths[0], widths[1], act), ..., Dense(widths[L-1], widths[L])) — `act` on every
+ * layer but the last, parameters in Lux's flattening order (per layer: weight [out x in] column-major, then bias) — the structure behind the neural ODEs of the reference's docs
+ * (docs/src/Benchmark.md:62-96).  The bodies given to hipadj_wmodel_register stay the model's definition for the workgroup-per-trajectory family; with the declaration
+ * hipadj_create selects the family ITSELF (hipadj_config.family): a chain with H x H contractions belongs on the matrix cores, the published 2-50-2 net does not.
+ * widths == NULL withdraws the declaration.  Errors: widths that do not reproduce the model's n / np, an activation other than HIPADJ_ACT_TANH -> HIPADJ_ERR_INVALID_ARG. */
+int hipadj_wmodel_declare_dense_chain(int32_t model_id, const int32_t *widths, int32_t nwidths, int32_t activation, int32_t input_power);
 
 /* Compiles the forward and the InterpolatingAdjoint kernels of a registered lane model — for a wide model both forward solves and every reverse sweep of
  * the family (Interpolating, Gauss, GaussKronrod, Backsolve, Quadrature on RK4 and on adaptive Tsit5, without a cost) — for gfx950 (no device needed) so that

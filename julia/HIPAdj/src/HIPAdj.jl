@@ -1,7 +1,7 @@
 """
     HIPAdj
 
-Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 108) — the MI355X-native batched continuous-adjoint
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 109) — the MI355X-native batched continuous-adjoint
 engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
 
   * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, dense_chain_model, declare_dense_chain!, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -39,7 +39,7 @@ function lib()
     if LIB[] == C_NULL
         LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
         v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
-        v == 108 || error("libhipadj ABI version $v, this binding was written for 108")
+        v == 109 || error("libhipadj ABI version $v, this binding was written for 109")
     end
     return LIB[]
 end
@@ -86,7 +86,7 @@ struct HipadjConfig
     ndevices::Int32
     device_ids::Ptr{Int32}
     reference_literal::Int32
-    reserved1::Int32
+    family::Int32              # hipadj_family (ABI 109): FAMILY_AUTO = the library selects the kernel family of a declared dense chain, FAMILY_AS_REGISTERED
 end
 
 # byte offsets of include/hipadj.h as the C compiler sees them (tests/c/julia_seam.c asserts the same table with offsetof)
@@ -109,6 +109,8 @@ const STEPPER_RK4_FIXED, STEPPER_TSIT5_ADAPTIVE = Int32(0), Int32(1)
 const STEPPER_ETDRK4_FIXED = Int32(2)      # exponential RK4 for the PDE family (include/hipadj.h HIPADJ_STEPPER_ETDRK4_FIXED; OrdinaryDiffEq's ETDRK4)
 const LOSS_COTANGENT, LOSS_LSQ_SHIFT, LOSS_LSQ_DATA, LOSS_MODEL = Int32(0), Int32(1), Int32(2), Int32(3)
 const MODEL_USER_BASE = Int32(1000)
+const FAMILY_AUTO, FAMILY_AS_REGISTERED, FAMILY_MFMA = Int32(0), Int32(1), Int32(3)      # hipadj_family
+const ACT_TANH = Int32(1)                                                                 # hipadj_activation
 
 struct HipadjError <: Exception
     status::Int
@@ -217,6 +219,35 @@ function set_wide_cost!(m::DeviceModel, body::Union{AbstractString, Nothing})
         GC.@preserve sb check(ccall(sym(:hipadj_wmodel_set_cost), Cint, (Int32, Ptr{UInt8}), m.id, pointer(sb)))
     end
     return m
+end
+
+"""
+    declare_dense_chain!(m::DeviceModel, widths; input_power = 1)
+
+Tells the library that wide model `m` IS the tanh chain `widths` (`hipadj_wmodel_declare_dense_chain`, ABI 109): `hipadj_create` then selects the kernel family itself — a
+chain `2 -> H -> H -> 2`, `H in (32, 64, 128)`, on fixed-step RK4 with shared weights and a multiple of 16 trajectories runs on the FP64-MFMA family (the H x H contractions on
+the matrix cores), everything else on the workgroup-per-trajectory family the bodies were written for.  `widths = nothing` withdraws the declaration.
+"""
+function declare_dense_chain!(m::DeviceModel, widths; input_power::Integer = 1)
+    if widths === nothing
+        check(ccall(sym(:hipadj_wmodel_declare_dense_chain), Cint, (Int32, Ptr{Int32}, Int32, Int32, Int32), m.id, C_NULL, Int32(0), ACT_TANH, Int32(1)))
+    else
+        w = collect(Int32, widths)
+        GC.@preserve w check(ccall(sym(:hipadj_wmodel_declare_dense_chain), Cint, (Int32, Ptr{Int32}, Int32, Int32, Int32), m.id, pointer(w), Int32(length(w)), ACT_TANH, Int32(input_power)))
+    end
+    return m
+end
+
+"""
+    dense_chain_model(name, widths; input_power = 1, threads = 0) -> DeviceModel
+
+`Lux.Chain(x -> x.^input_power, Dense(w1, w2, tanh), ..., Dense(wL, wL+1))` as a device model in one call: the bodies of `dense_chain_bodies`, registered with
+`register_wide_model` and declared with `declare_dense_chain!` — the library picks the kernel family (what `WideDeviceFunction.dense_chain` of the Python host does).
+"""
+function dense_chain_model(name::AbstractString, widths; input_power::Integer = 1, threads::Integer = 0, check_now::Bool = false)
+    f, vjp, np, nw = dense_chain_bodies(widths; input_power = input_power)
+    m = register_wide_model(name, first(widths), np; f = f, vjp = vjp, threads = threads, lds_doubles = nw, check_now = check_now)
+    return declare_dense_chain!(m, widths; input_power = input_power)
 end
 
 """
@@ -397,17 +428,18 @@ end
 """
     Handle(model; alg, stepper, N, tspan, dt, ts, loss_kind = LOSS_COTANGENT, loss_shift = 0.0, checkpointing = false,
            checkpoints = nothing, quad_abstol = 1e-6, quad_reltol = 1e-3, no_start = false, p_shared = true, device = 0,
-           time_segments = 0, cont_cost = 0, max_steps = 0, abstol = 1e-6, reltol = 1e-3, loss_scale = 0.0, devices = nothing, reference_literal = false)
+           time_segments = 0, cont_cost = 0, max_steps = 0, abstol = 1e-6, reltol = 1e-3, loss_scale = 0.0, devices = nothing, reference_literal = false, family = FAMILY_AUTO)
 
 `devices = [0, 1, ..., 7]` (or `:all`): ONE handle over several devices — the ensemble is cut into contiguous trajectory ranges, one per device, and the host-pointer calls
 scatter / gather / sum over them (`hipadj_config.device_ids`, ABI 108): what a single `solve` call needs to use a whole node.
+`family = FAMILY_AS_REGISTERED` keeps a declared dense chain (`declare_dense_chain!`) on the workgroup-per-trajectory family; the default lets the library choose (ABI 109).
 `loss_kind = LOSS_LSQ_DATA` with `loss_scale` (and `set_loss_data!`) keeps `sum(abs2, sol .- data)` on the device; `LOSS_MODEL` runs the model's discrete-loss bodies.
 """
 function Handle(model::DeviceModel; alg::Int32, stepper::Int32, N::Integer, tspan, dt::Real, ts::Vector{Float64},
         loss_kind::Int32 = LOSS_COTANGENT, loss_shift::Real = 0.0, checkpointing::Bool = false, checkpoints = nothing,
         quad_abstol::Real = 1e-6, quad_reltol::Real = 1e-3, no_start::Bool = false, p_shared::Bool = true, device::Integer = 0,
         time_segments::Integer = 0, cont_cost::Integer = 0, max_steps::Integer = 0, abstol::Real = 1e-6, reltol::Real = 1e-3,
-        loss_scale::Real = 0.0, devices = nothing, reference_literal::Bool = false)
+        loss_scale::Real = 0.0, devices = nothing, reference_literal::Bool = false, family::Integer = FAMILY_AUTO)
     cks = checkpoints === nothing ? Float64[] : sort(collect(Float64, checkpoints))
     devs = devices === nothing ? Int32[] : (devices === :all ? collect(Int32, 0:(device_count() - 1)) : collect(Int32, devices))
     cfg = HipadjConfig(UInt32(sizeof(HipadjConfig)), model.id, alg, stepper, model.dims, Int64(N),
@@ -415,7 +447,7 @@ function Handle(model::DeviceModel; alg::Int32, stepper::Int32, N::Integer, tspa
         loss_kind, Float64(loss_shift), Int32(checkpointing), Int32(0), Float64(quad_abstol), Float64(quad_reltol),
         Int32(no_start), Int32(p_shared), Int32(device), Int32(time_segments), Int32(cont_cost), Int32(max_steps),
         Float64(abstol), Float64(reltol), Int32(length(cks)), isempty(cks) ? Ptr{Float64}(C_NULL) : pointer(cks),
-        Float64(loss_scale), Int32(length(devs)), isempty(devs) ? Ptr{Int32}(C_NULL) : pointer(devs), Int32(reference_literal), Int32(0))
+        Float64(loss_scale), Int32(length(devs)), isempty(devs) ? Ptr{Int32}(C_NULL) : pointer(devs), Int32(reference_literal), Int32(family))
     return Handle(cfg, model.n, model.np, ts, cks, devs)   # ts / cks / devs are copied by hipadj_create; kept alive across the call
 end
 

@@ -6,7 +6,7 @@ using Test, HIPAdj, SciMLSensitivity, OrdinaryDiffEq, Zygote, Random
 
 @testset "layout" begin
     @test HIPAdj.check_layout()
-    @test hipadj_version() == 108
+    @test hipadj_version() == 109
     @test occursin("libhiprtc", runtime_compiler())          # the build toolkit's hiprtc (a Julia process carries no other)
 end
 
@@ -84,5 +84,10 @@ end
         @test np3 == 547 && occursin(esc(f3), txt) && occursin(esc(vjp3), txt)
         m = register_wide_model("node_2_50_2", 2, np; f = f, vjp = vjp, lds_doubles = nw)      # compiles forward + the four sweeps (no device needed)
         @test m.n == 2 && m.np == 252
+        # ABI 109: the structure is declared, the library selects the family; widths that do not reproduce the model are refused
+        @test declare_dense_chain!(m, (2, 50, 2); input_power = 3) === m
+        @test_throws HIPAdj.HipadjError declare_dense_chain!(m, (2, 40, 2); input_power = 3)
+        mc = dense_chain_model("chain_2_64_64_2", (2, 64, 64, 2))
+        @test mc.n == 2 && mc.np == 2 * 64 + 64 + 64 * 64 + 64 + 2 * 64 + 2
     end
 end

@@ -23,7 +23,7 @@ DECLARED_SYMBOLS = (
     "hipadj_comm_unique_id", "hipadj_comm_init_rank", "hipadj_comm_attach", "hipadj_comm_destroy",
     "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
     "hipadj_model_set_discrete_loss", "hipadj_model_set_discrete_loss_function", "hipadj_wmodel_set_discrete_loss", "hipadj_set_loss_data", "hipadj_set_loss_data_dev",
-    "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride", "hipadj_device_count",
+    "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride", "hipadj_device_count", "hipadj_wmodel_declare_dense_chain",
 )
 
 
@@ -41,7 +41,7 @@ class HipadjConfig(C.Structure):
         ("abstol", C.c_double), ("reltol", C.c_double),
         ("ncheckpoints", C.c_int32), ("checkpoints", C.POINTER(C.c_double)),
         ("loss_scale", C.c_double), ("ndevices", C.c_int32), ("device_ids", C.POINTER(C.c_int32)),
-        ("reference_literal", C.c_int32), ("reserved1", C.c_int32),
+        ("reference_literal", C.c_int32), ("family", C.c_int32),
     ]
 
 
@@ -54,7 +54,7 @@ class HipadjStats(C.Structure):
         ("forward_calls", C.c_int64), ("adjoint_calls", C.c_int64),
         ("adjoint_main_kernel_ms_last", C.c_double), ("adjoint_main_kernel_ms_total", C.c_double),
         ("adjoint_algorithmic_bytes", C.c_double), ("vjp_steps", C.c_double), ("workspace_bytes", C.c_double),
-        ("launches_per_pass", C.c_int32), ("reserved0", C.c_int32),
+        ("launches_per_pass", C.c_int32), ("routed_family", C.c_int32),
     ]
 
 
@@ -106,6 +106,7 @@ def load():
     L.hipadj_model_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
     L.hipadj_wmodel_register.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
     L.hipadj_model_check.argtypes = [C.c_int32]
+    L.hipadj_wmodel_declare_dense_chain.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]
     L.hipadj_model_check_config.argtypes = [C.POINTER(HipadjConfig)]
     L.hipadj_runtime_compiler.argtypes = [C.c_char_p, C.c_int32]
     L.hipadj_model_set_cost.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
@@ -173,6 +174,21 @@ def register_wide_model(name, n, npar, f, vjp, threads=0, lds_doubles=0, nacc=0,
     if check:
         check_model(mid.value)
     return mid.value
+
+
+FAMILY_AUTO, FAMILY_AS_REGISTERED, FAMILY_MFMA, ACT_TANH = 0, 1, 3, 1      # hipadj_family / hipadj_activation
+
+
+def declare_dense_chain(model_id, widths, input_power=1):
+    """hipadj_wmodel_declare_dense_chain: the wide model IS this tanh chain — hipadj_create then selects the kernel family itself (widths = None withdraws the declaration)."""
+    L = load()
+    if widths is None:
+        rc = L.hipadj_wmodel_declare_dense_chain(int(model_id), None, 0, ACT_TANH, 1)
+    else:
+        w = (C.c_int32 * len(widths))(*[int(x) for x in widths])
+        rc = L.hipadj_wmodel_declare_dense_chain(int(model_id), w, len(widths), ACT_TANH, int(input_power))
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
 
 
 def runtime_compiler():

@@ -9,6 +9,7 @@
 #include "hipadj_user.hpp"
 #include "hipadj_comm.hpp"
 #include "hipadj_multi.hpp"
+#include "hipadj_route.hpp"
 
 static thread_local std::string g_create_error;
 static int user_prepare(hipadj_handle* h);   // hiprtc compilation of the kernels of a runtime-registered model
@@ -74,6 +75,10 @@ extern "C" int hipadj_model_set_discrete_loss_function(int32_t model_id, const c
 }
 extern "C" int hipadj_wmodel_set_discrete_loss(int32_t model_id, const char* dloss_body) {
     return user_set_wide_discrete_loss(model_id, dloss_body, g_create_error);
+}
+
+extern "C" int hipadj_wmodel_declare_dense_chain(int32_t model_id, const int32_t* widths, int32_t nwidths, int32_t activation, int32_t input_power) {
+    return user_declare_dense_chain(model_id, widths, nwidths, activation, input_power, g_create_error);
 }
 
 extern "C" int hipadj_model_set_mass_matrix(int32_t model_id, const double* M) {
@@ -278,6 +283,9 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (cfg->ndevices < 0) { g_create_error = "hipadj_config.ndevices must be >= 0"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->ndevices > 1) return multi_create(cfg, out, g_create_error);      // one handle over several devices: G ordinary handles on contiguous trajectory ranges (hipadj_multi.hpp)
     if (cfg->ndevices == 1 && cfg->device_ids) { hipadj_config c1 = *cfg; c1.device = cfg->device_ids[0]; c1.ndevices = 0; c1.device_ids = nullptr; return hipadj_create(&c1, out); }
+    if (cfg->family != HIPADJ_FAMILY_AUTO && cfg->family != HIPADJ_FAMILY_AS_REGISTERED) { g_create_error = "hipadj_config.family must be HIPADJ_FAMILY_AUTO or HIPADJ_FAMILY_AS_REGISTERED"; return HIPADJ_ERR_INVALID_ARG; }
+    { int H = 0;      // a declared dense chain of the shape the FP64-MFMA family is built for runs there (hipadj_route.hpp); anything that family refuses continues below
+      if (route_eligible(cfg, H)) { const int rrc = route_create(cfg, H, out); if (rrc != HIPADJ_OK || *out) return rrc; } }
     auto* h = new hipadj_handle();
     auto fail = [&](int code) { g_create_error = h->err; free_all(h); delete h; return code; };
     h->cfg = *cfg; h->cfg.save_times = nullptr; h->cfg.checkpoints = nullptr;
@@ -613,6 +621,7 @@ extern "C" int hipadj_comm_unique_id(char* id) {
 #define HIPADJ_NO_MULTI(h, what) do { if ((h)->multi) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, what ": not offered on a handle over several devices (hipadj_config.ndevices > 1): it already spans the node; shard across processes with one single-device handle per process") ; } while (0)
 extern "C" int hipadj_comm_overlap(hipadj_handle* h, int on) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->route) { const int rc_ = hipadj_comm_overlap(h->inner, on); if (rc_ != HIPADJ_OK) h->err = hipadj_last_error(h->inner); return rc_; }
     HIPADJ_NO_MULTI(h, "hipadj_comm_overlap");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (on && !h->comm_stream) {
@@ -631,6 +640,7 @@ extern "C" int hipadj_comm_overlap(hipadj_handle* h, int on) {
 
 extern "C" int hipadj_comm_destroy(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->route) { const int rc_ = hipadj_comm_destroy(h->inner); if (rc_ != HIPADJ_OK) h->err = hipadj_last_error(h->inner); return rc_; }
     if (h->multi) return HIPADJ_OK;
     if (h->comm_stream) { (void)hipSetDevice(h->cfg.device); (void)hipStreamSynchronize(h->comm_stream); }
     if (h->comm && h->comm_owned) {
@@ -646,6 +656,7 @@ extern "C" int hipadj_comm_destroy(hipadj_handle* h) {
 
 extern "C" int hipadj_comm_init_rank(hipadj_handle* h, const char* id, int nranks, int rank) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->route) { const int rc_ = hipadj_comm_init_rank(h->inner, id, nranks, rank); if (rc_ != HIPADJ_OK) h->err = hipadj_last_error(h->inner); return rc_; }
     HIPADJ_NO_MULTI(h, "hipadj_comm_init_rank");
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_comm_init_rank: id != NULL and 0 <= rank < nranks required");
     if (!h->cfg.p_shared) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "per-trajectory parameters (p_shared = 0) have no cross-shard reduction: dp stays sharded like du0");
@@ -664,6 +675,7 @@ extern "C" int hipadj_comm_init_rank(hipadj_handle* h, const char* id, int nrank
 
 extern "C" int hipadj_comm_count(hipadj_handle* h, int* nranks) {
     if (!h || !nranks) return HIPADJ_ERR_INVALID_ARG;
+    if (h->route) { const int rc_ = hipadj_comm_count(h->inner, nranks); if (rc_ != HIPADJ_OK) h->err = hipadj_last_error(h->inner); return rc_; }
     *nranks = 0;                                   // no communicator: the handle's dp is its shard's own sum
     if (h->multi || !h->comm) return HIPADJ_OK;
     RcclApi& A = rccl_api();
@@ -679,6 +691,7 @@ extern "C" int hipadj_comm_count(hipadj_handle* h, int* nranks) {
 // shows up here, before a gradient is wrong.  Synchronises the handle's stream.
 extern "C" int hipadj_comm_selfcheck(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->route) { const int rc_ = hipadj_comm_selfcheck(h->inner); if (rc_ != HIPADJ_OK) h->err = hipadj_last_error(h->inner); return rc_; }
     HIPADJ_NO_MULTI(h, "hipadj_comm_selfcheck");
     if (!h->comm) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_comm_selfcheck: the handle has no communicator");
     RcclApi& A = rccl_api();
@@ -717,6 +730,7 @@ extern "C" int hipadj_comm_selfcheck(hipadj_handle* h) {
 
 extern "C" int hipadj_comm_attach(hipadj_handle* h, void* nccl_comm) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->route) { const int rc_ = hipadj_comm_attach(h->inner, nccl_comm); if (rc_ != HIPADJ_OK) h->err = hipadj_last_error(h->inner); return rc_; }
     HIPADJ_NO_MULTI(h, "hipadj_comm_attach");
     if (nccl_comm && !h->cfg.p_shared) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "per-trajectory parameters (p_shared = 0) have no cross-shard reduction: dp stays sharded like du0");
     if (nccl_comm) { RcclApi& A = rccl_api(); if (!A.err.empty()) { h->err = A.err; return HIPADJ_ERR_RCCL; } }
@@ -728,6 +742,7 @@ extern "C" int hipadj_comm_attach(hipadj_handle* h, void* nccl_comm) {
 extern "C" int hipadj_destroy(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (h->multi) { (void)multi_synchronize(h); multi_free(h); delete h; return HIPADJ_OK; }
+    if (h->route) { route_free(h); delete h; return HIPADJ_OK; }
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipadj_comm_destroy(h);
@@ -739,12 +754,14 @@ extern "C" int hipadj_destroy(hipadj_handle* h) {
 extern "C" int hipadj_set_timing(hipadj_handle* h, int level) {
     if (!h || level < 0 || level > 2) return HIPADJ_ERR_INVALID_ARG;
     for (hipadj_handle* c : h->shards) c->timing = level;
+    if (h->route) h->inner->timing = level;
     h->timing = level;
     return HIPADJ_OK;
 }
 
 extern "C" int hipadj_set_stream(hipadj_handle* h, void* s) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->route) { (void)hipadj_set_stream(h->inner, s); h->stream = h->inner->stream; return HIPADJ_OK; }
     h->stream = s ? (hipStream_t)s : h->own_stream;
     return HIPADJ_OK;
 }
@@ -760,6 +777,7 @@ static void harvest_timing(hipadj_handle* h, bool block) {
 
 extern "C" int hipadj_synchronize(hipadj_handle* h) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->route) { const int rc_ = hipadj_synchronize(h->inner); if (rc_ != HIPADJ_OK) h->err = hipadj_last_error(h->inner); return rc_; }
     if (h->multi) return multi_synchronize(h);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -779,6 +797,7 @@ extern "C" int hipadj_get_stats(hipadj_handle* h, hipadj_stats* st) {
     if (!h || !st) return HIPADJ_ERR_INVALID_ARG;
     if (st->struct_size != sizeof(hipadj_stats)) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_stats.struct_size mismatch");
     if (h->multi) return multi_get_stats(h, st);
+    if (h->route) return route_get_stats(h, st);
     *st = h->st;
     return HIPADJ_OK;
 }
@@ -1551,6 +1570,7 @@ __global__ void k_test_delay_scale(double* __restrict__ dp, int np, long ticks) 
 extern "C" int hipadj_forward_dev(hipadj_handle* h, const double* d_u0, const double* d_p, double* d_out) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!d_u0 || !d_p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
+    if (h->route) return route_forward_dev(h, d_u0, d_p, d_out);
     if (h->multi) return multi_forward_dev(h, d_u0, d_p, d_out);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     harvest_timing(h, false);
@@ -1577,6 +1597,7 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
     if (!h->have_forward) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_adjoint called before hipadj_forward (the reverse pass consumes the forward solution)");
     if (!d_du0 || !d_dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
     if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !d_dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
+    if (h->route) return route_adjoint_dev(h, d_dLdu, d_du0, d_dp);
     if (h->multi) return multi_adjoint_dev(h, d_dLdu, d_du0, d_dp);
     if (h->cfg.loss_kind == HIPADJ_LOSS_LSQ_DATA && h->M > 0 && !h->have_ldata) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "loss_kind = HIPADJ_LOSS_LSQ_DATA: hand the data block over first (hipadj_set_loss_data / hipadj_set_loss_data_dev)");
     // device-resident losses: the workgroup families read the handle's data block in the cotangents' place (the lane family streams its transposed copy in d_cotT)
@@ -1625,6 +1646,7 @@ static int loss_data_buffer(hipadj_handle* h) {
 extern "C" int hipadj_set_loss_data_dev(hipadj_handle* h, const double* d_data) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!d_data) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "data must be non-NULL");
+    if (h->route) return route_set_loss_data(h, d_data, true);
     if (h->multi) return multi_set_loss_data(h, d_data, true);
     TRY(loss_data_buffer(h));
     HIP_TRY(h, hipMemcpyAsync(h->d_ldata, d_data, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyDeviceToDevice, h->stream));
@@ -1633,6 +1655,7 @@ extern "C" int hipadj_set_loss_data_dev(hipadj_handle* h, const double* d_data) 
 extern "C" int hipadj_set_loss_data(hipadj_handle* h, const double* data) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!data) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "data must be non-NULL");
+    if (h->route) return route_set_loss_data(h, data, false);
     if (h->multi) return multi_set_loss_data(h, data, false);
     TRY(loss_data_buffer(h));
     TRY(upload_block(h, h->d_ldata, data, (size_t)h->N * h->M * h->n));
@@ -1644,6 +1667,7 @@ extern "C" int hipadj_set_loss_data(hipadj_handle* h, const double* data) {
 extern "C" int hipadj_loss_value_dev(hipadj_handle* h, const double* d_out, double* d_loss) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!d_out || !d_loss) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "out and loss must be non-NULL");
+    if (h->route) return route_loss_value(h, d_out, d_loss, true);
     if (h->multi) return multi_loss_value(h, d_out, d_loss, true);
     const int kind = h->cfg.loss_kind;
     if (kind == HIPADJ_LOSS_COTANGENT) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_loss_value: a cotangent handle does not know the loss (its gradient comes from the caller's AD)");
@@ -1689,6 +1713,7 @@ extern "C" int hipadj_loss_value_dev(hipadj_handle* h, const double* d_out, doub
 extern "C" int hipadj_loss_value(hipadj_handle* h, const double* out, double* loss) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!out || !loss) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "out and loss must be non-NULL");
+    if (h->route) return route_loss_value(h, out, loss, false);
     if (h->multi) return multi_loss_value(h, out, loss, false);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // d_io_a is the host API's staging block of [N][M][n]; one more double behind d_du0 carries the result
@@ -1702,14 +1727,14 @@ extern "C" int hipadj_loss_value(hipadj_handle* h, const double* out, double* lo
 extern "C" int hipadj_soa_stride(hipadj_handle* h, int64_t* ld) {
     if (!h || !ld) return HIPADJ_ERR_INVALID_ARG;
     HIPADJ_NO_MULTI(h, "hipadj_soa_stride (the streaming layout is padded per shard)");
-    if (h->wide || h->field || h->mlp) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "the streaming cotangent layout belongs to the lane-per-trajectory family; this handle's family reads [N][M][n] in place");
+    if (h->route || h->wide || h->field || h->mlp) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "the streaming cotangent layout belongs to the lane-per-trajectory family; this handle's family reads [N][M][n] in place");
     *ld = h->Npad;
     return HIPADJ_OK;
 }
 extern "C" int hipadj_adjoint_dev_soa(hipadj_handle* h, const double* d_dLdu_soa, double* d_du0, double* d_dp) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     HIPADJ_NO_MULTI(h, "hipadj_adjoint_dev_soa (the streaming layout is padded per shard)");
-    if (h->wide || h->field || h->mlp) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_adjoint_dev_soa: the streaming cotangent layout belongs to the lane-per-trajectory family; this handle's family reads [N][M][n] in place");
+    if (h->route || h->wide || h->field || h->mlp) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_adjoint_dev_soa: the streaming cotangent layout belongs to the lane-per-trajectory family; this handle's family reads [N][M][n] in place");
     if (h->cfg.loss_kind != HIPADJ_LOSS_COTANGENT || h->M <= 0) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "hipadj_adjoint_dev_soa: the handle takes no cotangents (loss_kind / no loss times)");
     if (!d_dLdu_soa) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
     if (h->rtc_selftest == 1) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_adjoint_dev_soa: the first reverse pass of this handle cross-checks two builds of a runtime-compiled kernel; run hipadj_adjoint_dev once first");
@@ -1779,6 +1804,7 @@ static int forward_host_enqueue(hipadj_handle* h, const double* u0, const double
 extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* p, double* out) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!u0 || !p) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "u0 and p must be non-NULL");
+    if (h->route) return route_forward(h, u0, p, out);
     if (h->multi) return multi_forward(h, u0, p, out);
     TRY(forward_host_enqueue(h, u0, p, out));
     return hipadj_synchronize(h);
@@ -1810,6 +1836,7 @@ static int adjoint_host_download(hipadj_handle* h, double* du0, double* dp) {
 extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0, double* dp) {
     if (!h) return HIPADJ_ERR_INVALID_ARG;
     if (!du0 || !dp) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "du0 and dp must be non-NULL");
+    if (h->route) return route_adjoint(h, dLdu, du0, dp);
     if (h->multi) {
         if (h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0 && !dLdu) HIPADJ_FAIL(h, HIPADJ_ERR_INVALID_ARG, "dLdu required for HIPADJ_LOSS_COTANGENT");
         return multi_adjoint(h, dLdu, du0, dp);

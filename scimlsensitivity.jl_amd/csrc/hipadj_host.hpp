@@ -129,6 +129,9 @@ struct hipadj_handle {
     std::vector<hipEvent_t> shard_ev; hipEvent_t multi_in = nullptr;
     double* d_dp_parts = nullptr;         // primary device: the shards' dp partials [G][np] + G doubles (loss values)
     std::vector<double> dp_host;          // host-pointer calls: the shards' dp partials
+    // a dense chain the library runs on the FP64-MFMA family (hipadj_route.hpp): `inner` is the MLP handle whose batch columns are this handle's trajectories; everything
+    // above is unused in a routed handle except cfg, n, np, N, M, S, err and the two transposition blocks
+    bool route = false; hipadj_handle* inner = nullptr; double *d_rt_a = nullptr, *d_rt_b = nullptr;
     void* comm = nullptr;                 // ncclComm_t of the ensemble shards (hipadj_comm.hpp); dp is all-reduced over it
     bool comm_owned = false;
     // hipadj_comm_overlap: the all-reduce of dp on its own stream, off the critical path of the next reverse pass

@@ -29,7 +29,21 @@ struct SegPlan {
                                       // two bounds with the scalar loads that fetch its other arguments instead of a dependent global load in front of its first knot load (round 6)
 };
 // bound s of the plan: from the kernarg copy when the launch site filled it (k_interp_fused), else from the device array
-HIPADJ_HD int seg_bound(const SegPlan& sp, int s) { return sp.nseg <= HIPADJ_SEG_INLINE ? sp.inl[s] : sp.bounds[s]; }
+// (two separate loads behind a uniform branch, each pinned by a (convergent, hence not speculated) readfirstlane: merged into ONE load through a selected pointer — kernarg or global — the compiler emits a flat
+// vector load + s_waitcnt vmcnt instead of the scalar load next to the other arguments)
+HIPADJ_HD void seg_bounds_of(const SegPlan& sp, int seg, int& k_lo, int& k_hi) {
+    if (sp.nseg <= HIPADJ_SEG_INLINE) {
+        k_lo = sp.inl[seg]; k_hi = sp.inl[seg + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+        k_lo = __builtin_amdgcn_readfirstlane(k_lo); k_hi = __builtin_amdgcn_readfirstlane(k_hi);
+#endif
+    } else {
+        k_lo = sp.bounds[seg]; k_hi = sp.bounds[seg + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+        k_lo = __builtin_amdgcn_readfirstlane(k_lo); k_hi = __builtin_amdgcn_readfirstlane(k_hi);
+#endif
+    }
+}
 inline void seg_plan_inline(SegPlan& sp, const int* host_bounds) { if (sp.nseg <= HIPADJ_SEG_INLINE) for (int s = 0; s <= sp.nseg; ++s) sp.inl[s] = host_bounds[s]; }
 
 template <class Mo>
@@ -136,7 +150,7 @@ __global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(PSH ? 2 :
 #if HIPADJ_SEG_BOUNDS_GLOBAL
     const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];      // A/B: round 5's dependent global load
 #else
-    const int k_lo = seg_bound(sp, seg), k_hi = seg_bound(sp, seg + 1);
+    int k_lo, k_hi; seg_bounds_of(sp, seg, k_lo, k_hi);
 #endif
     HIPADJ_TP(HIPADJ_GTRACE(g), 1, k_lo + k_hi);                     // segment bounds loaded
     if constexpr (!SEG) {   // one segment (models whose segment columns do not fit the registers): the wave is its block's root, no map is ever built

@@ -59,6 +59,9 @@ struct UserModelSrc {
     std::string wvjp;             // the joint VJP body (the reference's vecjacobian! contract)
     std::string wcost;            // continuous cost of a wide model (hipadj_wmodel_set_cost): SPMD body adding g_u into dlam and, WP, w g_p into gp / acc
     int threads = 0, nw = 0, nacc = 0, acc0 = 0;
+    // hipadj_wmodel_declare_dense_chain (ABI 109): the model IS the dense chain widths[0] -> ... -> widths[L] (Lux's parameter order) with `chain_act` on every layer but the
+    // last and the input map x -> x^chain_power: hipadj_create may then pick the kernel family itself (hipadj_route.hpp)
+    std::vector<int> chain; int chain_power = 1, chain_act = 0;
 };
 
 struct UserRegistry {
@@ -802,6 +805,35 @@ inline int user_wide_threads(int32_t model) {
 
 // hipadj_wmodel_register: a model for the workgroup-per-trajectory family.  threads = 0 picks the workgroup size: max(n / 2, min(np, 4096) / 4)
 // rounded up to whole wavefronts, between 64 (one wavefront per trajectory) and 1024.
+// declares (or, widths == NULL, withdraws) the dense-chain structure of a wide model; the widths must reproduce the model's n and np
+inline int user_declare_dense_chain(int32_t model, const int32_t* widths, int32_t nwidths, int32_t activation, int32_t input_power, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size() || !R.models[idx].wide) { err = "hipadj_wmodel_declare_dense_chain: not a model of hipadj_wmodel_register"; return HIPADJ_ERR_INVALID_ARG; }
+    UserModelSrc& m = R.models[idx];
+    if (!widths || nwidths == 0) { m.chain.clear(); return HIPADJ_OK; }
+    if (nwidths < 2 || nwidths > 16 || activation != HIPADJ_ACT_TANH || input_power < 1 || input_power > 8) {
+        err = "hipadj_wmodel_declare_dense_chain: need 2 <= nwidths <= 16, activation = HIPADJ_ACT_TANH and 1 <= input_power <= 8"; return HIPADJ_ERR_INVALID_ARG; }
+    long np = 0;
+    for (int l = 1; l < nwidths; ++l) { if (widths[l] < 1 || widths[l - 1] < 1) { err = "hipadj_wmodel_declare_dense_chain: widths must be positive"; return HIPADJ_ERR_INVALID_ARG; } np += (long)widths[l] * widths[l - 1] + widths[l]; }
+    if (widths[0] != m.n || widths[nwidths - 1] != m.n || np != m.np) {
+        err = "hipadj_wmodel_declare_dense_chain: the widths do not reproduce the registered model (n = widths[0] = widths[last], np = sum of out * in + out per layer)"; return HIPADJ_ERR_INVALID_ARG; }
+    m.chain.assign(widths, widths + nwidths); m.chain_power = input_power; m.chain_act = activation;
+    return HIPADJ_OK;
+}
+// the declared chain of a model (false: none, or not a wide model, or the model carries a cost / loss body / reverse callback the matrix-core family has no counterpart for)
+inline bool user_dense_chain(int32_t model, std::vector<int>& widths, int& power) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) return false;
+    const UserModelSrc& m = R.models[idx];
+    if (!m.wide || m.chain.empty()) return false;
+    widths = m.chain; power = m.chain_power;
+    return true;
+}
+
 inline int user_register_wide(const char* name, int32_t n, int32_t np, int32_t threads, int32_t lds_doubles, int32_t nacc, int32_t acc_first,
                               const char* f, const char* vjp, int32_t* id, std::string& err) {
     if (!name || !f || !vjp || !id) { err = "hipadj_wmodel_register: NULL argument (f_body and vjp_body are both required)"; return HIPADJ_ERR_INVALID_ARG; }

@@ -15,7 +15,7 @@ class Engine:
     def __init__(self, model, alg, ntraj, t0, t1, dt, save_times=(), loss_kind=_lib.LOSS_COTANGENT, loss_shift=0.0,
                  checkpointing=False, ckpt_stride=0, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False,
                  p_shared=True, device=0, time_segments=0, dims=(0, 0, 0, 0), cont_cost=0,
-                 stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0, checkpoints=None, loss_scale=0.0, devices=None, reference_literal=False):
+                 stepper=0, abstol=1e-6, reltol=1e-3, max_steps=0, checkpoints=None, loss_scale=0.0, devices=None, reference_literal=False, family=0):
         L = _lib.load()
         self._L = L
         self._save = np.ascontiguousarray(np.asarray(save_times, dtype=np.float64))
@@ -42,6 +42,7 @@ class Engine:
         c.ndevices = 0 if self._devs is None else len(self._devs)
         c.device_ids = self._devs.ctypes.data_as(C.POINTER(C.c_int32)) if c.ndevices else None
         c.reference_literal = int(bool(reference_literal))
+        c.family = int(family)      # hipadj_family: 0 = the library selects the kernel family (a declared dense chain 2-H-H-2 runs on the FP64-MFMA family), 1 = as registered
         self.cfg = c
         self.model, self.alg = model, alg
         self.N, self.M = int(ntraj), len(self._save)

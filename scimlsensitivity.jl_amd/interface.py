@@ -81,36 +81,6 @@ def _engine_kwargs(sensealg, checkpoints, dt, t0, adaptive=False, t1=None):
     return kw
 
 
-def _mfma_route(ensprob, alg, sensealg, dgdu_discrete, checkpoints, callback, g, save_idxs, devices):
-    """A weight-shared dense chain 2 -> H -> H -> 2 (tanh, H = 32 / 64 / 128) over an ensemble whose size is a multiple of 16 IS the FP64-MFMA family's model
-    (csrc/hipadj_mlp*.hpp: the trajectories are the columns of one batched state, the two H x H contractions run on the matrix cores) — `WideDeviceFunction.dense_chain`
-    registers it as a workgroup-per-trajectory model, which is the right family for the published 2-50-2 net (200 multiply-adds next to 50 tanh) and the wrong one from
-    H = 32 on (measured: bench.py `dense_chain_crossover`).  Returns H when the problem can take the MFMA route, else None.  """
-    if isinstance(ensprob, ODEProblem):
-        return None
-    from .problems import DENSE_CHAINS
-    chain = DENSE_CHAINS.get(ensprob.prob.f)      # ODEProblem keeps the model's NAME
-    if chain is None or callback is not None or g is not None or save_idxs is not None or devices is not None or checkpoints is not None:
-        return None
-    w, power = chain
-    if len(w) != 4 or w[0] != 2 or w[3] != 2 or w[1] != w[2] or w[1] not in (32, 64, 128) or power != 1:
-        return None
-    if not isinstance(alg, RK4) or ensprob.p.ndim != 1 or ensprob.u0.shape[0] % 16 != 0:
-        return None
-    if sensealg.name not in ("gauss", "interpolating", "backsolve", "quadrature") or isinstance(dgdu_discrete, ModelLoss):
-        return None
-    if getattr(sensealg, "checkpointing", False) and sensealg.name != "backsolve":
-        return None
-    return int(w[1])
-
-
-def _to_columns(x):
-    """[N][d] (or [N][M][d]) of an ensemble -> the batched state of the MFMA family, a d x B matrix stored column-major with the trajectories as its columns: the SAME
-    memory order per time ([B][d]); only the time axis of a cotangent block moves in front of the trajectories"""
-    x = np.asarray(x, dtype=np.float64)
-    return np.ascontiguousarray(x).reshape(1, -1) if x.ndim == 2 else np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(1, x.shape[1], -1)
-
-
 def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdjoint(), dgdu_discrete=None, checkpoints=None,
           device=0, time_segments=0, no_start=None, want_out=True, g=None, abstol=1e-6, reltol=1e-3, max_steps=0, save_idxs=None,
           save_start=True, save_end=True, save_everystep=False, callback=None, devices=None, reference_literal=False, mfma=None):
@@ -129,21 +99,11 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     `dgdu_discrete` = LsqData(data, scale) or ModelLoss(data): the loss stays on the device (include/hipadj.h HIPADJ_LOSS_LSQ_DATA / HIPADJ_LOSS_MODEL) — the data
     block is handed over once, the reverse pass takes no cotangents and `sol.loss_value()` returns the loss.
     `devices` = a list of HIP ordinals: one handle over several devices (contiguous trajectory ranges; hipadj_config.device_ids).
-    `reference_literal`: reproduce the reference's lines where the library deliberately deviates (hipadj_config.reference_literal)."""
-    H = None if mfma is False else _mfma_route(ensprob, alg, sensealg, dgdu_discrete, checkpoints, callback, g, save_idxs, devices)
-    if mfma is True and H is None:
-        raise ValueError("mfma=True: the problem is not a weight-shared dense_chain (2, H, H, 2), H in (32, 64, 128), on RK4 with an ensemble size that is a multiple of 16")
-    if H is not None:      # the same problem as ONE batched trajectory of the FP64-MFMA family; the solution object translates shapes back (adjoint_sensitivities below)
-        N, d = ensprob.u0.shape
-        loss = dgdu_discrete
-        if isinstance(dgdu_discrete, LsqData):
-            loss = LsqData(_to_columns(np.asarray(dgdu_discrete.data).reshape(N, -1, d)), dgdu_discrete.scale)
-        inner = solve(EnsembleProblem(ODEProblem("mlp", _to_columns(ensprob.u0)[0], ensprob.prob.tspan, ensprob.p, (d, H, N, 0)), _to_columns(ensprob.u0)), alg, dt=dt, saveat=saveat,
-                      sensealg=sensealg, dgdu_discrete=loss, device=device, no_start=no_start, want_out=want_out, save_start=save_start, save_end=save_end,
-                      save_everystep=save_everystep, mfma=False)
-        u = None if inner.u is None else np.ascontiguousarray(inner.u.reshape(inner.u.shape[1], N, d).transpose(1, 0, 2))
-        return EnsembleSolution(engine=inner.engine, u=u, t=inner.t, prob=ensprob, alg=alg, dt=dt,
-                                extra=dict(inner.extra, mfma_route=dict(inner=inner, N=N, d=d, H=H, loss=loss), dgdu_discrete=dgdu_discrete))
+    `reference_literal`: reproduce the reference's lines where the library deliberately deviates (hipadj_config.reference_literal).
+    `mfma`: None — the LIBRARY selects the kernel family (a WideDeviceFunction.dense_chain of shape (2, H, H, 2), H in (32, 64, 128), runs on the FP64-MFMA family:
+    hipadj_config.family, csrc/hipadj_route.hpp; `sol.extra["mfma_routed"]` says so); False — the family the model was registered for; True — raise unless routed."""
+    if mfma not in (None, True, False):
+        raise ValueError("mfma must be None (the library selects the kernel family), True (insist on the FP64-MFMA family) or False (the family the model was registered for)")
     if callback is not None:       # DiscreteCallback at preset times: a chain of ordinary pieces (events.py)
         from . import events
         return events.solve_with_events(solve, _save_times, ensprob, alg, callback, dt=dt, saveat=saveat, sensealg=sensealg, dgdu_discrete=dgdu_discrete, checkpoints=checkpoints,
@@ -179,7 +139,13 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
                  loss_kind=loss_kind, loss_shift=shift, loss_scale=scale, devices=devices, reference_literal=reference_literal, p_shared=(ensprob.p.ndim == 1), device=device,
                  time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_COSTS[type(g)] if g is not None else 0),
                  stepper=(1 if adaptive else (2 if isinstance(alg, ETDRK4) else 0)), abstol=abstol, reltol=reltol, max_steps=max_steps,
+                 family=(_lib.FAMILY_AS_REGISTERED if mfma is False else _lib.FAMILY_AUTO),
                  **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive, t1=prob.tspan[1]))
+    routed = hasattr(eng, "stats") and eng.stats().get("routed_family") == _lib.FAMILY_MFMA      # hipadj_create put a declared dense chain on the FP64-MFMA family (csrc/hipadj_route.hpp)
+    if mfma is True and not routed:
+        eng.close()
+        raise ValueError("mfma=True: the library did not take this problem to the FP64-MFMA family (a weight-shared dense_chain (2, H, H, 2), H in (32, 64, 128), on RK4 "
+                         "with an ensemble size that is a multiple of 16, loss times on the step grid)")
     if isinstance(dgdu_discrete, (LsqData, ModelLoss)) and dgdu_discrete.data is not None and eng.M > 0:
         eng.set_loss_data(np.asarray(dgdu_discrete.data, dtype=np.float64).reshape(eng.N, eng.M, eng.n))
     out = eng.forward(ensprob.u0, ensprob.p, want_out=want_out)
@@ -193,7 +159,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
         if out is not None:
             out = np.ascontiguousarray(out[:, :, idxs])
     return EnsembleSolution(engine=eng, u=out, t=ts, prob=ensprob, alg=alg, dt=dt,
-                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g, save_idxs=idxs,
+                            extra=dict(sensealg=sensealg, dgdu_discrete=dgdu_discrete, g=g, save_idxs=idxs, mfma_routed=routed,
                                        checkpoints=(None if checkpoints is None else np.asarray(checkpoints, dtype=np.float64))))
 
 
@@ -201,9 +167,6 @@ def _dgdp_sum(sol, dgdp, shared):
     """sum_i dl_i/dp over the save times (and over the ensemble when p is shared)"""
     eng = sol.engine
     N, M, npar = eng.N, eng.M, eng.np
-    route = sol.extra.get("mfma_route")
-    if route is not None:      # the handle behind a routed dense chain is ONE batched trajectory: the ensemble's shapes come from the route
-        N, M = route["N"], len(sol.t)
     if callable(dgdp):
         if sol.u is None or sol.extra.get("save_idxs") is not None:
             raise ValueError("a callable dgdp_discrete needs the full saved states (solve(..., want_out=True) without save_idxs)")
@@ -235,20 +198,6 @@ def adjoint_sensitivities(sol, alg=RK4(), *, t=None, dgdu_discrete=None, dgdp_di
         return du0, dp + _dgdp_sum(sol, dgdp_discrete, dp.ndim == 1)
     if g is not None and sol.extra.get("g") != g:
         raise ValueError("pass the continuous cost g to solve(...) as well: the reverse kernel is specialised on it")
-    route = sol.extra.get("mfma_route")
-    if route is not None:      # a dense chain solved on the FP64-MFMA family (solve above): cotangents in, du0 out in the ensemble's shapes
-        N, d = route["N"], route["d"]
-        if checkpoints is not None:      # the route is taken only without a checkpoint list (_mfma_route): one handed here would be dropped silently
-            raise ValueError("checkpoints differ from the list the forward solve was prepared with; pass checkpoints=... to solve(...)")
-        dg = dgdu_discrete
-        if isinstance(dgdu_discrete, LsqData):
-            if dgdu_discrete != sol.extra.get("dgdu_discrete"):
-                raise ValueError("pass the same device-resident loss (LsqData) to solve(...) as well: the handle is configured with it and owns its data block")
-            dg = route["loss"]
-        elif dgdu_discrete is not None and not isinstance(dgdu_discrete, LsqShift):
-            dg = _to_columns(pack_cotangent(dgdu_discrete, N, len(sol.t), d))
-        du0, dp = adjoint_sensitivities(route["inner"], alg, t=t, dgdu_discrete=dg, sensealg=sensealg)
-        return np.ascontiguousarray(du0.reshape(N, d)), dp
     eng = sol.engine
     want_alg = (sensealg or sol.extra["sensealg"])
     if want_alg.name != eng.alg:

@@ -21,12 +21,12 @@ enum { O_struct_size = 0, O_model = 4, O_alg = 8, O_stepper = 12, O_dims = 16, O
        O_save_times = 72, O_loss_kind = 80, O_loss_shift = 88, O_checkpointing = 96, O_ckpt_stride = 100, O_quad_abstol = 104,
        O_quad_reltol = 112, O_no_start = 120, O_p_shared = 124, O_device = 128, O_time_segments = 132, O_cont_cost = 136,
        O_max_steps = 140, O_abstol = 144, O_reltol = 152, O_ncheckpoints = 160, O_checkpoints = 168, O_loss_scale = 176, O_ndevices = 184,
-       O_device_ids = 192, O_reference_literal = 200, O_reserved1 = 204, CONFIG_SIZE = 208 };
+       O_device_ids = 192, O_reference_literal = 200, O_family = 204, CONFIG_SIZE = 208 };
 #define TIE(f) _Static_assert(offsetof(hipadj_config, f) == O_##f, "HIPAdj.CONFIG_OFFSETS disagrees with include/hipadj.h at " #f)
 TIE(struct_size); TIE(model); TIE(alg); TIE(stepper); TIE(dims); TIE(ntraj); TIE(t0); TIE(t1); TIE(dt); TIE(nsave); TIE(save_times);
 TIE(loss_kind); TIE(loss_shift); TIE(checkpointing); TIE(ckpt_stride); TIE(quad_abstol); TIE(quad_reltol); TIE(no_start); TIE(p_shared);
 TIE(device); TIE(time_segments); TIE(cont_cost); TIE(max_steps); TIE(abstol); TIE(reltol); TIE(ncheckpoints); TIE(checkpoints);
-TIE(loss_scale); TIE(ndevices); TIE(device_ids); TIE(reference_literal); TIE(reserved1);
+TIE(loss_scale); TIE(ndevices); TIE(device_ids); TIE(reference_literal); TIE(family);
 _Static_assert(sizeof(hipadj_config) == CONFIG_SIZE, "HIPAdj.CONFIG_SIZE disagrees with include/hipadj.h");
 
 #define PUT(buf, off, type, val) do { type v_ = (type)(val); memcpy((buf) + (off), &v_, sizeof(type)); } while (0)

@@ -542,7 +542,7 @@ def test_adaptive_record_regrows_when_the_budget_cut_it_short(sa, monkeypatch, a
 @pytest.mark.parametrize("H", [32, 64])
 def test_dense_chain_2_H_H_2_is_routed_to_the_mfma_family(sa, alg, H):
     """Round 5 (VERDICT r4 next 5b): a weight-shared tanh chain 2 -> H -> H -> 2 over an ensemble is the FP64-MFMA family's model with the trajectories as batch columns;
-    `solve` routes it there (interface._mfma_route) unless mfma=False.  Both routes — the workgroup-per-trajectory kernels of the runtime model and the MFMA kernels of
+    hipadj_create routes it there (csrc/hipadj_route.hpp, ABI 109: the chain is declared with hipadj_wmodel_declare_dense_chain) unless hipadj_config.family says "as registered" (mfma=False).  Both routes — the workgroup-per-trajectory kernels of the runtime model and the MFMA kernels of
     csrc/hipadj_mlp*.hpp — must give the same out, du0 and dp, for cotangents and for the device-resident data loss."""
     from test_gpu_parity import mlp_params
     rng = np.random.default_rng(5)
@@ -555,7 +555,7 @@ def test_dense_chain_2_H_H_2_is_routed_to_the_mfma_family(sa, alg, H):
     res = {}
     for route in (False, None):
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, mfma=route)
-        assert ("mfma_route" in sol.extra) == (route is None)
+        assert sol.extra["mfma_routed"] == (route is None) and (sol.engine.stats()["routed_family"] == 3) == (route is None)
         du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=delta)
         res[route] = (sol.u.copy(), du0, dp)
         sol.engine.close()
@@ -569,7 +569,7 @@ def test_dense_chain_2_H_H_2_is_routed_to_the_mfma_family(sa, alg, H):
         sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(fun, u0[0], (0.0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sens, dgdu_discrete=loss, mfma=route)
         dgdp = rng0.standard_normal((N, len(ts), len(p)))      # a loss with a direct parameter term: added to dp once (the routed handle has N = 1)
         du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=loss, dgdp_discrete=dgdp)
-        res[route] = (du0, dp, np.array([sol.loss_value()]), np.array([2.0 * np.sum((sol.u - data) ** 2)]))
+        res[route] = (du0, dp, np.array([sol.loss_value()]), np.array([np.sum((sol.u - data) ** 2)]))      # scale 2: the loss is (scale / 2) sum(abs2, sol .- data)
         with pytest.raises(ValueError):
             sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=loss, checkpoints=[0.0, 0.15, 0.3])
         sol.engine.close()
@@ -603,6 +603,48 @@ def test_hand_written_wide_bodies_with_a_mass_matrix(sa, alg, oalg, stepper):
         ref = O.Problem("DENSELIN", alg=oalg, t0=0.0, t1=T, save_times=ts, checkpointing=(alg == "backsolve"), dims=(n, 0, 0, 0), quad_abstol=1e-12, quad_reltol=1e-12, **okw)
         rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, delta)
     assert rel(sol.u, rout) < 1e-6 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
+
+
+@pytest.mark.gpu
+def test_routed_dense_chain_through_the_device_pointer_calls(sa):
+    """The C ABI's device-pointer entry points on a handle the library routed to the FP64-MFMA family (hipadj_route.hpp): forward_dev / adjoint_dev / set_loss_data_dev /
+    loss_value_dev take and return the ensemble's shapes ([N][M][d] blocks) — against the same model on the family it was registered for; the streaming-layout call is refused;
+    a configuration the MFMA family does not take (loss times off the step grid, adaptive Tsit5, N not a multiple of 16) silently stays on the registered family."""
+    import torch
+    from test_gpu_parity import mlp_params
+    rng = np.random.default_rng(9)
+    N, d, H, T, dt = 48, 2, 32, 0.3, 0.05
+    fun = sa.WideDeviceFunction.dense_chain("route_dev_chain", (d, H, H, d))
+    u0 = rng.standard_normal((N, d)); p = mlp_params(d, H)
+    ts = np.array([0.1, 0.2, 0.3]); delta = rng.standard_normal((N, len(ts), d)); data = rng.standard_normal((N, len(ts), d))
+    dev = torch.device("cuda:0")
+    res = {}
+    for fam in (1, 0):
+        eng = sa.Engine(fun.name, "interpolating", N, 0.0, T, dt, save_times=ts, family=fam)
+        assert (eng.stats()["routed_family"] == 3) == (fam == 0) and eng.n == d and eng.N == N
+        tu0, tp, td = torch.tensor(u0, device=dev), torch.tensor(p, device=dev), torch.tensor(delta, device=dev)
+        out = torch.empty((N, len(ts), d), dtype=torch.float64, device=dev); du0 = torch.empty((N, d), dtype=torch.float64, device=dev); dp = torch.empty(len(p), dtype=torch.float64, device=dev)
+        eng.use_torch_stream()
+        eng.forward_dev(tu0, tp, out); eng.adjoint_dev(td, du0, dp); eng.synchronize()
+        res[fam] = [out.cpu().numpy(), du0.cpu().numpy(), dp.cpu().numpy()]
+        if fam == 0:
+            with pytest.raises(sa.HipadjError):
+                eng.soa_stride()
+        eng.close()
+        eng = sa.Engine(fun.name, "gauss", N, 0.0, T, dt, save_times=ts, loss_kind=2, loss_scale=2.0, family=fam)
+        eng.use_torch_stream()
+        eng.set_loss_data_dev(torch.tensor(data, device=dev)); eng.forward_dev(tu0, tp, out); eng.adjoint_dev(None, du0, dp)
+        lv = torch.empty(1, dtype=torch.float64, device=dev); eng.loss_value_dev(out, lv); eng.synchronize()
+        res[fam] += [du0.cpu().numpy(), dp.cpu().numpy(), lv.cpu().numpy(), np.array([eng.loss_value(out.cpu().numpy())])]
+        eng.close()
+    for a, b in zip(res[1], res[0]):
+        assert rel(b, a) < 1e-9
+    assert rel(res[0][5], np.array([np.sum((res[0][0] - data) ** 2)])) < 1e-12
+    for kw in (dict(save_times=np.array([0.07, 0.3])), dict(save_times=ts, stepper=1), dict(save_times=ts, ntraj=N - 8)):
+        n_ = kw.pop("ntraj", N)
+        eng = sa.Engine(fun.name, "interpolating", n_, 0.0, T, 0.0 if kw.get("stepper") else dt, **kw)
+        assert eng.stats()["routed_family"] == 0
+        eng.close()
 
 
 _MM = {}

@@ -178,3 +178,24 @@ def test_a_reregistered_name_drops_the_traced_mass_matrix_of_its_predecessor(sa)
     assert "mm_stale" in problems.WIDE_MASS_MATRICES
     sa.WideDeviceFunction.from_callable("mm_stale", ring, 6, 6)
     assert "mm_stale" not in problems.WIDE_MASS_MATRICES
+
+
+def test_dense_chain_declaration_is_validated_by_the_library(sa):
+    """hipadj_wmodel_declare_dense_chain (ABI 109): the structure behind a wide model is declared to the LIBRARY, which selects the kernel family in hipadj_create
+    (csrc/hipadj_route.hpp) — here, without a device, the declaration's own checks: widths must reproduce the registered n / np, only wide models take one, NULL withdraws it."""
+    from scimlsensitivity_jl_amd import _lib
+    fun = sa.WideDeviceFunction.dense_chain("decl_chain_host", (2, 32, 32, 2))        # registers AND declares
+    assert fun.np == 2 * 32 + 32 + 32 * 32 + 32 + 2 * 32 + 2
+    _lib.declare_dense_chain(fun.id, (2, 32, 32, 2))
+    with pytest.raises(sa.HipadjError, match="do not reproduce"):
+        _lib.declare_dense_chain(fun.id, (2, 16, 32, 2))
+    with pytest.raises(sa.HipadjError, match="do not reproduce"):
+        _lib.declare_dense_chain(fun.id, (3, 32, 32, 3))
+    _lib.declare_dense_chain(fun.id, None)                                            # withdrawn
+    lane = sa.DeviceFunction("decl_lane_host", 2, 1, "du[0] = p[0] * u[1]; du[1] = -u[0];", "out[0] = -lam[1]; out[1] = p[0] * lam[0];", "out[0] = lam[0] * u[1];")
+    with pytest.raises(sa.HipadjError, match="hipadj_wmodel_register"):
+        _lib.declare_dense_chain(lane.id, (2, 4, 2))
+    L = _lib.load()
+    import ctypes as C
+    w = (C.c_int32 * 3)(2, 50, 2)
+    assert L.hipadj_wmodel_declare_dense_chain(fun.id, w, 3, 7, 1) == -1          # an activation other than HIPADJ_ACT_TANH
