@@ -261,7 +261,7 @@ extern "C" int hipadj_debug_set_trace(void* dev_ptr) { g_hipadj_wave_trace = (un
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
-                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->d_wscr, h->d_ldata, h->d_lpart, h->d_og_i, h->d_og_h, h->d_og_tile};
+                    h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->d_wscr, h->d_ldata, h->d_lpart, h->d_lval, h->d_og_i, h->d_og_h, h->d_og_tile};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
@@ -448,9 +448,14 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             if (P.user && !rtc_trusted() && !std::getenv("HIPADJ_FUSED")) h->fused = 0;   // a runtime model compiled by a toolkit other than the build's: the in-launch hand-offs rest on
                                                                                           // this compiler's code generation (hipadj_fused.hpp tree_arrive_last): three launches instead
             int radix = 4;
-            if (const char* e = std::getenv("HIPADJ_TREE_RADIX")) radix = std::atoi(e) == 8 ? 8 : 4;
+            if (const char* e = std::getenv("HIPADJ_TREE_RADIX")) { const int v = std::atoi(e); radix = (v == 8 || v == 16) ? v : 4; }
+            // grouped form (k_interp_fused_g): the stage-operator sweeps of a compiled-in model with shared parameters — the kernels of BASELINE configs[1] and its shards
+            h->fgroup = 0;
+            if (const char* e = std::getenv("HIPADJ_FUSED_GROUP")) { const int v = std::atoi(e); h->fgroup = (v == 4 || v == 8) ? v : 0; }
+            if (h->fgroup && !(h->fused && !P.user && cfg->alg == HIPADJ_ALG_INTERPOLATING && cfg->p_shared && h->nseg > 1 && cfg->cont_cost == HIPADJ_CCOST_NONE && !P.offgrid && !P.ip_ckpt &&
+                               cfg->loss_kind == HIPADJ_LOSS_LSQ_SHIFT && cfg->model == HIPADJ_MODEL_LORENZ && !std::getenv("HIPADJ_NO_OPS") && !std::getenv("HIPADJ_WPB"))) h->fgroup = 0;
             long slots = 0, ctrs = 0;
-            tree_plan_shape(h->nseg, radix, (long)(Np / 64), h->tp, &slots, &ctrs);
+            tree_plan_shape(h->fgroup ? (h->nseg + h->fgroup - 1) / h->fgroup : h->nseg, radix, (long)(Np / 64), h->tp, &slots, &ctrs);
             h->tcnt_n = ctrs;
             if (h->tp.nlev == 0) slots = 1;    // a single segment: the root wave finishes alone, no slot is ever written
             const size_t slot_doubles = (size_t)(((1 + n) * (n + np) + 1) / 2) * 128;   // rows of 64 x 16 bytes
@@ -745,6 +750,9 @@ extern "C" int hipadj_destroy(hipadj_handle* h) {
     if (h->route) { route_free(h); delete h; return HIPADJ_OK; }
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
+    // ... and every OTHER stream this handle may have enqueued work on (hipadj_set_stream moves it; a staged upload or a kernel of an earlier stream may still be in flight while
+    // its buffers — the registered staging block among them — are released below): destroy is not a hot path, the device-wide wait is the simple guarantee
+    (void)hipDeviceSynchronize();
     (void)hipadj_comm_destroy(h);
     free_all(h);
     delete h;
@@ -1066,7 +1074,6 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
         TRY(usig<decltype(&k_interp_offgrid<ModelLV, 1>)>::launch(h, h->uf_main, dim3(waves), dim3(WAVE), h->g, R, p, (const dbl2*)h->d_knots, cotT, d_du0, h->d_dp_traj));
     } else {
         SegPlan sp{h->nseg, h->d_seg_bounds};
-        seg_plan_inline(sp, h->seg_bounds.data());
         const dim3 sgrid(waves, (unsigned)h->nseg);
         if (h->fused && h->d_tbuf && h->cfg.alg != HIPADJ_ALG_QUADRATURE) {
             // one launch per reverse pass: the sweep kernel composes the segment maps, writes du0 / the dp rows and reduces dp (hipadj_fused.hpp)
@@ -1716,10 +1723,11 @@ extern "C" int hipadj_loss_value(hipadj_handle* h, const double* out, double* lo
     if (h->route) return route_loss_value(h, out, loss, false);
     if (h->multi) return multi_loss_value(h, out, loss, false);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    // d_io_a is the host API's staging block of [N][M][n]; one more double behind d_du0 carries the result
+    // d_io_a is the host API's staging block of [N][M][n]; the value lands in a word of its own (it used to overwrite du0's first entry in the staging buffer)
+    if (!h->d_lval) TRY(dev_alloc(h, &h->d_lval, 1));
     TRY(upload_block(h, h->d_io_a, out, (size_t)h->N * h->M * h->n));
-    TRY(hipadj_loss_value_dev(h, h->d_io_a, h->d_du0));
-    HIP_TRY(h, hipMemcpyAsync(loss, h->d_du0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    TRY(hipadj_loss_value_dev(h, h->d_io_a, h->d_lval));
+    HIP_TRY(h, hipMemcpyAsync(loss, h->d_lval, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return HIPADJ_OK;
 }
@@ -1759,7 +1767,7 @@ static void host_copy_par(double* dst, const double* src, size_t count) {
 static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's pinned block, grown on demand; nullptr: no pinned memory to be had (the pageable copy still works)
     if (h->pin_count >= count) return h->h_pin;
     if (std::getenv("HIPADJ_NO_PINNED")) return nullptr;
-    if (h->h_pin) { (void)hipStreamSynchronize(h->stream); (void)hipHostUnregister(h->h_pin); std::free(h->h_pin); h->h_pin = nullptr; h->pin_count = 0; }
+    if (h->h_pin) { (void)hipStreamSynchronize(h->stream); (void)hipDeviceSynchronize(); (void)hipHostUnregister(h->h_pin); std::free(h->h_pin); h->h_pin = nullptr; h->pin_count = 0; }   // (device-wide: the block may have been read on a stream the handle has since left)
     // ordinary (cached) pages, registered with the runtime: hipHostMalloc's default block is fine-grained coherent memory, which the host WRITES at a fraction of its memcpy rate
     // (measured: the staged upload took 12.5 ms against 7.7 ms for the plain pageable copy, profiles/r5_visit2_bench.json)
     void* q = nullptr;

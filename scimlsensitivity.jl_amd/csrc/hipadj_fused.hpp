@@ -31,7 +31,7 @@ namespace hipadj {
 constexpr int HIPADJ_TREE_MAXLEV = 8;
 
 struct TreePlan {
-    int radix;                              // children per node (4: one batch of loads per level; 8: two batches, one level less from 17 segments on)
+    int radix;                              // children per node (4: one batch of loads per level; 8 / 16: two / four batches, fewer levels)
     int nlev;                               // levels above the leaves; count[0] = C (segments), count[nlev] = 1
     int count[HIPADJ_TREE_MAXLEV + 1];      // nodes per trajectory block on level l
     long map_off[HIPADJ_TREE_MAXLEV + 1];   // first map slot of level l in tbuf (slots of one level: [block][node])
@@ -244,6 +244,33 @@ __device__ __forceinline__ void fused_tail(double (&m)[(1 + N) * (N + NP)], cons
 #pragma unroll
     for (int j = 0; j < N + NP; ++j) v[j] = m[j];
     fused_root<N, NP>(v, T, ntraj, blocks, block, du0, dp_rows, dp_sum, flag);
+}
+
+// GROUPED form (round 6): G consecutive segments of one trajectory block share a WORKGROUP of G waves, and the first level of the composition happens in LDS instead of HBM —
+// every wave but the first publishes its map into the workgroup's LDS block ([wave][entry][lane]: 512-byte rows, conflict-free), one barrier, the first wave folds them in rank
+// order and carries the group's map into the tree of hipadj_fused.hpp as leaf `group` of ceil(C / G) leaves.  The wave timeline of a 1250-trajectory shard
+// (profiles/r6_wave_trace_1250_*.jsonl) prices a level of the HBM tree at 3.7-4.9 us (payload stores 0.6, drain 0.45, ticket 0.45, sibling loads + fold 2-3.2) against
+// ~12.7 us of sweep: three levels + the root are as long as the sweep itself.  `nvalid`: waves of this group that carry a segment (the last group of a block may be short).
+template <int N, int NP, int G>
+__device__ __forceinline__ void fused_tail_group(double (&m)[(1 + N) * (N + NP)], double* __restrict__ lds, const TreePlan& T, long ntraj, long blocks, long block, int group,
+                                                 int wv, int nvalid, double* __restrict__ du0, double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {
+    constexpr int MAPSZ = (1 + N) * (N + NP);
+    const int lane = threadIdx.x & 63;
+    if (wv > 0 && wv < nvalid) {
+#pragma unroll
+        for (int e = 0; e < MAPSZ; ++e) lds[((wv - 1) * MAPSZ + e) * 64 + lane] = m[e];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    for (int c = 1; c < nvalid; ++c) {      // upper segment (lower rank) first, like the tree's fold
+        double lo_[MAPSZ], o[MAPSZ];
+#pragma unroll
+        for (int e = 0; e < MAPSZ; ++e) lo_[e] = lds[((c - 1) * MAPSZ + e) * 64 + lane];
+        map_compose<N, NP>(m, lo_, o);
+#pragma unroll
+        for (int e = 0; e < MAPSZ; ++e) m[e] = o[e];
+    }
+    fused_tail<N, NP>(m, T, ntraj, blocks, block, group, du0, dp_rows, dp_sum, flag);
 }
 
 #endif  // device code

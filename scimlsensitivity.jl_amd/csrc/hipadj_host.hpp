@@ -95,6 +95,7 @@ struct hipadj_handle {
     // one launch per reverse pass (hipadj_fused.hpp): composition tree + dp reduction inside the sweep kernel.  fused: 1 = on (default where a
     // fused kernel exists), 0 = the three-launch sequence (HIPADJ_FUSED=0: A/B and fallback)
     int fused = 1;
+    int fgroup = 0;                       // G > 0: G waves (consecutive segments of a trajectory block) per workgroup, first composition level in LDS (k_interp_fused_g; 4 or 8)
     TreePlan tp{};
     double* d_tbuf = nullptr; unsigned* d_tcnt = nullptr; long tcnt_n = 0;
     int *d_fev_knot = nullptr, *d_fev_save = nullptr, *d_fev_ckpt = nullptr, nfev = 0;   // event knots of the forward solve (k_forward_ev)
@@ -122,6 +123,7 @@ struct hipadj_handle {
     double* h_pin = nullptr; size_t pin_count = 0;
     hipModule_t lmod = nullptr; hipFunction_t lf_value = nullptr;   // runtime model with a discrete-loss FUNCTION: its loss-value kernel (hipadj_loss_value)
     double* d_lpart = nullptr;            // per-workgroup partials of hipadj_loss_value
+    double* d_lval = nullptr;             // ... and the one double its host-pointer form (and a non-local shard of a multi handle) receives the value in
     // ONE handle over several devices (hipadj_multi.hpp): the shards are ordinary handles on contiguous trajectory ranges; everything above is unused in a multi handle
     // except cfg, n, np, N, M, the (primary) stream and err
     bool multi = false;

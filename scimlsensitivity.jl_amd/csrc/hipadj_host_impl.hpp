@@ -168,7 +168,6 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
     switch (h->cfg.alg) {
     case HIPADJ_ALG_INTERPOLATING: {
         SegPlan sp{h->nseg, h->d_seg_bounds};
-        seg_plan_inline(sp, h->seg_bounds.data());
         if (h->ip_ckpt && h->ck_long)
             hipLaunchKernelGGL((k_interp_ckpt<Mo, LOSS, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, h->g, sp, p, (const double*)h->d_ckpt,
                                (const int*)h->d_ckpt_of_knot, (const int*)h->d_prev_ck, cotT, (const int*)h->d_save_rev, h->d_segbuf, h->d_gtile, h->gtile_stride);
@@ -186,7 +185,17 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             double* dps = h->cfg.p_shared ? d_dp : (double*)nullptr;
             bool launched = false;
             if constexpr (model_has_ops<Mo>::value && (LOSS >> 1) == 0) {
-                if (h->cfg.p_shared && h->nseg > 1 && !h->no_ops) {
+                if (h->fgroup) {      // (hipadj_create set it only for the configuration this branch serves: shared parameters, several segments, the fused LSQ_SHIFT loss)      // G waves per workgroup, first composition level in LDS
+                    const unsigned ng = (unsigned)((h->nseg + h->fgroup - 1) / h->fgroup);
+                    if (h->fgroup == 8)
+                        hipExtLaunchKernelGGL((k_interp_fused_g<Mo, 4, LOSS, 8>), dim3(waves, ng), dim3(WAVE * 8), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
+                                              (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                    else
+                        hipExtLaunchKernelGGL((k_interp_fused_g<Mo, 4, LOSS, 4>), dim3(waves, ng), dim3(WAVE * 4), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
+                                              (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                    launched = true;
+                }
+                if (!launched && h->cfg.p_shared && h->nseg > 1 && !h->no_ops) {
                     if constexpr (LOSS == 0) {
                         if (insweep) {
                             hipExtLaunchKernelGGL((k_interp_fused<Mo, 4, HIPADJ_MODE_COT_INPLACE, true, true>), dim3(waves, (unsigned)h->nseg), dim3(WAVE), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,

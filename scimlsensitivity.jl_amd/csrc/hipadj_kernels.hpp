@@ -21,30 +21,13 @@ namespace hipadj {
 
 constexpr int WAVE = 64;
 
-constexpr int HIPADJ_SEG_INLINE = 64;
 struct SegPlan {
     int nseg;              // C
     const int* bounds;     // device [C+1] knot indices, bounds[0] = 0, bounds[C] = S
-    int inl[HIPADJ_SEG_INLINE + 1];   // the same bounds INSIDE the kernarg segment when C <= 64 (filled by seg_plan_inline; zeros otherwise): a wave of the one-launch pass reads its
-                                      // two bounds with the scalar loads that fetch its other arguments instead of a dependent global load in front of its first knot load (round 6)
 };
-// bound s of the plan: from the kernarg copy when the launch site filled it (k_interp_fused), else from the device array
-// (two separate loads behind a uniform branch, each pinned by a (convergent, hence not speculated) readfirstlane: merged into ONE load through a selected pointer — kernarg or global — the compiler emits a flat
-// vector load + s_waitcnt vmcnt instead of the scalar load next to the other arguments)
-HIPADJ_HD void seg_bounds_of(const SegPlan& sp, int seg, int& k_lo, int& k_hi) {
-    if (sp.nseg <= HIPADJ_SEG_INLINE) {
-        k_lo = sp.inl[seg]; k_hi = sp.inl[seg + 1];
-#if defined(__HIP_DEVICE_COMPILE__)
-        k_lo = __builtin_amdgcn_readfirstlane(k_lo); k_hi = __builtin_amdgcn_readfirstlane(k_hi);
-#endif
-    } else {
-        k_lo = sp.bounds[seg]; k_hi = sp.bounds[seg + 1];
-#if defined(__HIP_DEVICE_COMPILE__)
-        k_lo = __builtin_amdgcn_readfirstlane(k_lo); k_hi = __builtin_amdgcn_readfirstlane(k_hi);
-#endif
-    }
-}
-inline void seg_plan_inline(SegPlan& sp, const int* host_bounds) { if (sp.nseg <= HIPADJ_SEG_INLINE) for (int s = 0; s <= sp.nseg; ++s) sp.inl[s] = host_bounds[s]; }
+// (round 6 measured the bounds INSIDE the kernarg segment — a 65-entry table read with the scalar loads of the other arguments instead of a dependent global load: 0.1 us
+// faster at 1250 trajectories, 1 us SLOWER at 2500 / 5000 / 10^4, profiles/r6_shard_time_bounds_ab.jsonl; the wave timeline shows why: the bounds are 0.5-0.9 us of a 28 us
+// pass either way, profiles/r6_wave_trace_1250_*.jsonl — not kept)
 
 template <class Mo>
 __global__ void __launch_bounds__(WAVE) k_forward(Geom g, const double* __restrict__ u0, const double* __restrict__ p,
@@ -87,9 +70,6 @@ __global__ void __launch_bounds__(WAVE) k_forward_quad(Geom g, const double* __r
 // three of a CU's eight waves finishes 1.5x later than the kernel needs).
 // PSH = true: launched only when the parameters are shared (g.p_shared): lets models with stage operators keep their (p, dt)
 // constants in SGPRs (interp_lane).
-#ifndef HIPADJ_SEG_BOUNDS_GLOBAL
-#define HIPADJ_SEG_BOUNDS_GLOBAL 0
-#endif
 #ifndef HIPADJ_KINTERP_ATTR      // development hook (scripts/kbench.hip): e.g. __attribute__((amdgpu_waves_per_eu(3, 3)))
 #define HIPADJ_KINTERP_ATTR
 #endif
@@ -147,11 +127,15 @@ __global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(PSH ? 2 :
     const long i = i_raw < g.N ? i_raw : g.N - 1;                    // padding lanes of the last block repeat its last trajectory
     const int rank = (int)blockIdx.y, seg = sp.nseg - 1 - rank;      // rank 0 = the top (longest, 1-column) segment: dispatched first
     HIPADJ_TP(HIPADJ_GTRACE(g), 0, 0);                               // wave entry
-#if HIPADJ_SEG_BOUNDS_GLOBAL
-    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];      // A/B: round 5's dependent global load
-#else
-    int k_lo, k_hi; seg_bounds_of(sp, seg, k_lo, k_hi);
+#if defined(HIPADJ_WAVE_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+    if (HIPADJ_GTRACE(g) && threadIdx.x == 0) {                      // where the wave runs: (XCC_ID << 32) | HW_ID (SIMD, CU, SH, SE)
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        HIPADJ_GTRACE(g)[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 24] = ((unsigned long long)xcc << 32) | hwid;
+    }
 #endif
+    const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
     HIPADJ_TP(HIPADJ_GTRACE(g), 1, k_lo + k_hi);                     // segment bounds loaded
     if constexpr (!SEG) {   // one segment (models whose segment columns do not fit the registers): the wave is its block's root, no map is ever built
         double lam[1][N], mu[1][NP], v[R];
@@ -186,6 +170,52 @@ __global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(PSH ? 2 :
     }
     HIPADJ_TP(HIPADJ_GTRACE(g), 3, m[0]);                            // sweep done: the segment's map is in registers
     fused_tail<N, NP>(m, tp, g.N, (long)gridDim.x, (long)blockIdx.x, rank, du0, dp_rows, dp_sum, flag);
+}
+
+// The one-launch pass with G waves per workgroup (hipadj_fused.hpp, "GROUPED form"): grid (wave blocks, ceil(C / G)), wave w of workgroup y sweeps the segment of rank
+// y G + w; the group's maps are composed through LDS, the group's first wave enters the HBM tree as leaf y.  Segmented sweeps of models with stage operators (the headline /
+// shard kernels) only; G = 4: one wave per SIMD of the workgroup's CU, G = 8: two.
+template <class Mo, int PF, int LOSS, int G>
+__global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(2))) __launch_bounds__(WAVE * G) k_interp_fused_g(Geom g, SegPlan sp, TreePlan tp, const double* __restrict__ p,
+                                                       const dbl2* __restrict__ knots, const double* __restrict__ cotT,
+                                                       const int* __restrict__ save_of_knot, double* __restrict__ du0,
+                                                       double* __restrict__ dp_rows, double* __restrict__ dp_sum, int* __restrict__ flag) {
+    constexpr int N = Mo::N, NP = Mo::NP, NC = 1 + N, R = N + NP;
+    __shared__ double lds[(G - 1) * NC * R * WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long i_raw = (long)blockIdx.x * WAVE + lane;
+    const long i = i_raw < g.N ? i_raw : g.N - 1;                    // padding lanes of the last block repeat its last trajectory
+    const int rank = (int)blockIdx.y * G + wv;
+    const int nvalid = sp.nseg - (int)blockIdx.y * G < G ? sp.nseg - (int)blockIdx.y * G : G;
+    double m[NC * R];
+#pragma unroll
+    for (int e = 0; e < NC * R; ++e) m[e] = 0.0;
+    if (rank < sp.nseg) {
+        const int seg = sp.nseg - 1 - rank;
+        HIPADJ_TP(HIPADJ_GTRACE(g), 0, 0);
+        const int k_lo = sp.bounds[seg], k_hi = sp.bounds[seg + 1];
+        HIPADJ_TP(HIPADJ_GTRACE(g), 1, k_lo + k_hi);
+        if (rank == 0) {
+            double lam[1][N], mu[1][NP];
+            interp_lane<Mo, 1, PF, LOSS>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+#pragma unroll
+            for (int j = 0; j < N; ++j) m[j] = lam[0][j];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) m[N + j] = mu[0][j];
+        } else {
+            double lam[NC][N], mu[NC][NP];
+            interp_lane<Mo, NC, PF, LOSS, 0, true>(g, i, k_lo, k_hi, p, knots, cotT, save_of_knot, lam, mu);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) m[c * R + j] = lam[c][j];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) m[c * R + N + j] = mu[c][j];
+            }
+        }
+        HIPADJ_TP(HIPADJ_GTRACE(g), 3, m[0]);
+    }
+    fused_tail_group<N, NP, G>(m, lds, tp, g.N, (long)gridDim.x, (long)blockIdx.x, (int)blockIdx.y, wv, nvalid, du0, dp_rows, dp_sum, flag);
 }
 
 // checkpointing=true variants: checkpoint tiles in HBM, interval re-solve tile in LDS ([step][component][lane])

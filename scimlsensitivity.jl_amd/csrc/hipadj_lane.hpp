@@ -56,14 +56,14 @@ struct Geom {
     double h_last;     // length of the LAST forward step [t_{S-1}, T]: = dt, or the remainder when the span is not a multiple of dt (the reference's
                        // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
 #ifdef HIPADJ_WAVE_TRACE
-    unsigned long long* trace;   // development builds only (scripts/r6/wave_trace.py): 24 time stamps per wave of the one-launch pass, or null
+    unsigned long long* trace;   // development builds only (scripts/r6/wave_trace.py): 32 words per wave of the one-launch pass (time stamps, hardware ids), or null
 #endif
 };
 // HIPADJ_TP(ptr, slot, dep): development builds (-DHIPADJ_WAVE_TRACE) let lane 0 of a wave store the 100 MHz real-time counter into slot `slot` of the wave's record once `dep`
-// (a value the point waits for) is available; nothing in the product build.  The record of a wave: [blockIdx.y][blockIdx.x][24].
+// (a value the point waits for) is available; nothing in the product build.  The record of a wave: [rank = blockIdx.y * waves per workgroup + wave][blockIdx.x][32]; slot 24 = (XCC_ID << 32) | HW_ID.
 #if defined(HIPADJ_WAVE_TRACE) && defined(__HIP_DEVICE_COMPILE__)
 #define HIPADJ_TP(ptr, slot, dep) do { if (ptr) { asm volatile("" :: "v"(dep)); const unsigned long long tp_now_ = wall_clock64(); \
-    if ((threadIdx.x & 63) == 0) (ptr)[(((long)blockIdx.y * gridDim.x + blockIdx.x) * 24) + (slot)] = tp_now_; } } while (0)
+    if ((threadIdx.x & 63) == 0) (ptr)[(((long)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)) * gridDim.x + blockIdx.x) * 32) + (slot)] = tp_now_; } } while (0)
 #else
 #define HIPADJ_TP(ptr, slot, dep) ((void)0)
 #endif

@@ -227,8 +227,9 @@ static int multi_loss_value(hipadj_handle* h, const double* out, double* loss, b
         else {
             HIP_TRY(h, hipSetDevice(c->cfg.device));
             HIP_TRY(h, hipMemcpyPeerAsync(c->d_io_a, c->cfg.device, po, d0, sizeof(double) * Ng * M * n, c->stream));
-            rc = hipadj_loss_value_dev(c, c->d_io_a, c->d_du0);
-            if (rc == HIPADJ_OK) HIP_TRY(h, hipMemcpyPeerAsync(parts + g, d0, c->d_du0, c->cfg.device, sizeof(double), c->stream));
+            if (!c->d_lval && hipMalloc((void**)&c->d_lval, sizeof(double)) != hipSuccess) { (void)hipGetLastError(); HIPADJ_FAIL(h, HIPADJ_ERR_HIP, "hipMalloc failed"); }
+            rc = hipadj_loss_value_dev(c, c->d_io_a, c->d_lval);
+            if (rc == HIPADJ_OK) HIP_TRY(h, hipMemcpyPeerAsync(parts + g, d0, c->d_lval, c->cfg.device, sizeof(double), c->stream));
         }
         if (rc != HIPADJ_OK) return multi_fail(h, g, rc);
     }

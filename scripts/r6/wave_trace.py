@@ -54,10 +54,13 @@ def main():
         ms_untraced = e0.elapsed_time(e1) / 200
         stt = eng.stats()
         Cseg = stt["time_segments"]
+        G = int(os.environ.get("HIPADJ_FUSED_GROUP", "0") or 0)      # grouped form: the records are [ceil(C / G) G][waves]; ranks beyond C stay empty
+        if G > 1:
+            Cseg = (Cseg + G - 1) // G * G
         waves = (n + 63) // 64
         recs = []
         for rep in range(5):      # five traced launches, each in the middle of a burst (the pass before and after are ordinary)
-            buf = torch.zeros((Cseg, waves, 24), dtype=torch.int64, device=dev)
+            buf = torch.zeros((Cseg, waves, 32), dtype=torch.int64, device=dev)
             torch.cuda.synchronize()
             for _ in range(20):
                 eng.adjoint_dev(None, du0, dp)
@@ -69,11 +72,13 @@ def main():
             torch.cuda.synchronize()
             recs.append(buf.cpu().numpy().astype(np.int64))
     eng.close()
-    print(json.dumps(dict(ntraj=n, steps=S, segments=Cseg, waves=waves * Cseg, ms_per_pass_untraced_loop=ms_untraced, launches=stt["launches_per_pass"])))
+    print(json.dumps(dict(ntraj=n, steps=S, segments=stt["time_segments"], group=G, wtop=os.environ.get("HIPADJ_WTOP"), radix=os.environ.get("HIPADJ_TREE_RADIX"), waves=waves * Cseg, ms_per_pass_untraced_loop=ms_untraced, launches=stt["launches_per_pass"])))
     names = {0: "entry", 1: "bounds", 2: "first_knot", 3: "sweep_done", 20: "root_issued", 21: "root_drained", 22: "ensemble_ticket", 23: "dp_written"}
     for l in range(4):
         names.update({4 + 4 * l: f"L{l}_stores_issued", 5 + 4 * l: f"L{l}_drained", 6 + 4 * l: f"L{l}_ticket", 7 + 4 * l: f"L{l}_folded"})
     for rep, r in enumerate(recs):
+        r = r[: stt["time_segments"]]
+        Cseg = stt["time_segments"]
         t0 = r[:, :, 0][r[:, :, 0] > 0].min()
         us = np.where(r > 0, (r - t0) * 0.01, np.nan)          # microseconds since the first wave's entry
         span = np.nanmax(us)
@@ -100,6 +105,24 @@ def main():
             y, x = w[0]
             row["dp_writer"] = dict(rank=int(y), block=int(x), timeline_us={names[k]: round(float(us[y, x, k]), 2) for k in sorted(names) if np.isfinite(us[y, x, k])})
         # when did the LAST sweep finish, and how long after it did the kernel end?
+        # sweep duration by rank (0 = the top, one-column segment) and by how many waves share the wave's SIMD
+        sw = us[:, :, 3] - us[:, :, 2]
+        row["sweep_us_by_rank"] = {str(k): round(float(np.nanmedian(sw[k])), 2) for k in sorted(set([0, 1, 2, Cseg // 2, Cseg - 2, Cseg - 1]))}
+        row["sweep_done_us_by_rank_max"] = {str(k): round(float(np.nanmax(us[k, :, 3])), 2) for k in sorted(set([0, 1, 2, Cseg // 2, Cseg - 2, Cseg - 1]))}
+        hw = r[:, :, 24]
+        h32 = hw & 0xffffffff      # HW_ID: SIMD_ID bits 5:4, CU_ID 11:8, SH_ID 12, SE_ID 15:13
+        simd_key = (((hw >> 32) & 0xf) << 16) | (((h32 >> 13) & 7) << 12) | (((h32 >> 12) & 1) << 8) | (((h32 >> 8) & 0xf) << 4) | ((h32 >> 4) & 3)
+        keys, counts = np.unique(simd_key, return_counts=True)
+        cnt_of = dict(zip(keys.tolist(), counts.tolist()))
+        share = np.vectorize(lambda k: cnt_of[k])(simd_key)
+        row["simds_used"] = int(len(keys)); row["waves_per_simd_histogram"] = {str(c): int((counts == c).sum()) for c in sorted(set(counts.tolist()))}
+        row["sweep_us_by_simd_sharing"] = {str(c): dict(n=int((share == c).sum()), med=round(float(np.nanmedian(sw[share == c])), 2), max=round(float(np.nanmax(sw[share == c])), 2),
+                                                         done_max=round(float(np.nanmax(us[:, :, 3][share == c])), 2)) for c in sorted(set(share.ravel().tolist()))}
+        xcc = (hw >> 32) & 0xf
+        row["waves_per_xcc"] = {str(x): int((xcc == x).sum()) for x in sorted(set(xcc.ravel().tolist()))}
+        slow = np.argsort(np.nan_to_num(us[:, :, 3], nan=-1.0).ravel())[-8:][::-1]
+        row["slowest_sweeps"] = [dict(rank=int(i // waves), block=int(i % waves), sweep_us=round(float(sw.ravel()[i]), 2), done_us=round(float(us[:, :, 3].ravel()[i]), 2),
+                                      shares_simd_with=int(share.ravel()[i]) - 1, xcc=int(xcc.ravel()[i])) for i in slow]
         row["last_sweep_done_us"] = float(np.nanmax(us[:, :, 3]))
         row["tail_after_last_sweep_us"] = float(span - np.nanmax(us[:, :, 3]))
         print(json.dumps(row))

@@ -149,3 +149,33 @@ def test_fused_pass_of_runtime_lane_models(sa, monkeypatch, capfd, n, alg, cap):
     rdu0, rdp, _, _ = orc.adjoint_ensemble(u0r, p, delta, want_out=False)
     assert rel(b[0], rdu0) < 1e-6 and rel(b[1], rdp) < 1e-6
     ref.close(); fus.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,segs,radix", [(4, 48, 4), (8, 96, 16), (4, 10, 4), (8, 13, 4)])
+def test_grouped_one_launch_pass_matches_the_plain_one(sa, G, segs, radix, monkeypatch):
+    """Round 6: HIPADJ_FUSED_GROUP = G puts G consecutive segments of a trajectory block into one workgroup and composes their maps through LDS before the HBM tree
+    (k_interp_fused_g, csrc/hipadj_fused.hpp "GROUPED form").  Another bracketing of the same associative composition: du0 / dp agree with the plain one-launch pass to
+    round-off and with the oracle at the parity tolerance; ragged last groups (13 segments in groups of 8, 10 in groups of 4) included."""
+    import oracle as O
+    rng = np.random.default_rng(3)
+    N, T, dt = 1250, 10.0, 0.01
+    ts = np.linspace(0.0, T, 101)
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8.0 / 3.0])
+    res = {}
+    for grouped in (False, True):
+        if grouped:
+            monkeypatch.setenv("HIPADJ_FUSED_GROUP", str(G)); monkeypatch.setenv("HIPADJ_TREE_RADIX", str(radix))
+        eng = sa.Engine("lorenz", "interpolating", N, 0.0, T, dt, save_times=ts, loss_kind=1, loss_shift=2.0, time_segments=segs)
+        eng.forward(u0, p, want_out=False)
+        res[grouped] = eng.adjoint(None)
+        assert eng.stats()["launches_per_pass"] == 1 and eng.stats()["time_segments"] == segs
+        again = eng.adjoint(None)
+        assert np.array_equal(again[0], res[grouped][0]) and np.array_equal(again[1], res[grouped][1])      # reproducible from pass to pass
+        eng.close()
+    monkeypatch.delenv("HIPADJ_FUSED_GROUP"); monkeypatch.delenv("HIPADJ_TREE_RADIX")
+    assert np.max(np.abs(res[True][0] - res[False][0])) / np.max(np.abs(res[False][0])) < 1e-10
+    assert np.max(np.abs(res[True][1] - res[False][1]) / np.abs(res[False][1])) < 1e-10
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, want_out=False)
+    assert np.max(np.abs(res[True][0] - rdu0)) / np.max(np.abs(rdu0)) < 1e-6 and np.max(np.abs(res[True][1] - rdp) / np.abs(rdp)) < 1e-6
