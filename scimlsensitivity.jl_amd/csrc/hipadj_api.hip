@@ -5,6 +5,7 @@
 #include <chrono>
 #include <thread>
 #include "hipadj_host.hpp"
+#include <sys/mman.h>
 #include "hipadj_plan.hpp"
 #include "hipadj_user.hpp"
 #include "hipadj_comm.hpp"
@@ -258,6 +259,7 @@ unsigned long long* g_hipadj_wave_trace = nullptr;
 extern "C" int hipadj_debug_set_trace(void* dev_ptr) { g_hipadj_wave_trace = (unsigned long long*)dev_ptr; return HIPADJ_OK; }
 #endif
 
+static void host_pin_release(hipadj_handle* h);
 static void free_all(hipadj_handle* h) {
     void* ptrs[] = {h->d_u0, h->d_p, h->d_outT, h->d_yT, h->d_ckpt, h->d_cotT, h->d_segbuf, h->d_dp_traj, h->d_qres, h->d_qa,
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
@@ -266,7 +268,7 @@ static void free_all(hipadj_handle* h) {
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
     if (h->umod_alt) (void)hipModuleUnload(h->umod_alt);
-    if (h->h_pin) { (void)hipHostUnregister(h->h_pin); std::free(h->h_pin); }
+    host_pin_release(h);
     if (h->lmod) (void)hipModuleUnload(h->lmod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
@@ -449,11 +451,9 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
                                                                                           // this compiler's code generation (hipadj_fused.hpp tree_arrive_last): three launches instead
             int radix = 4;
             if (const char* e = std::getenv("HIPADJ_TREE_RADIX")) { const int v = std::atoi(e); radix = (v == 8 || v == 16) ? v : 4; }
-            // grouped form (k_interp_fused_g): the stage-operator sweeps of a compiled-in model with shared parameters — the kernels of BASELINE configs[1] and its shards
-            h->fgroup = 0;
-            if (const char* e = std::getenv("HIPADJ_FUSED_GROUP")) { const int v = std::atoi(e); h->fgroup = (v == 4 || v == 8) ? v : 0; }
-            if (h->fgroup && !(h->fused && !P.user && cfg->alg == HIPADJ_ALG_INTERPOLATING && cfg->p_shared && h->nseg > 1 && cfg->cont_cost == HIPADJ_CCOST_NONE && !P.offgrid && !P.ip_ckpt &&
-                               cfg->loss_kind == HIPADJ_LOSS_LSQ_SHIFT && cfg->model == HIPADJ_MODEL_LORENZ && !std::getenv("HIPADJ_NO_OPS") && !std::getenv("HIPADJ_WPB"))) h->fgroup = 0;
+            // grouped form (k_interp_fused_g): chosen by the planner (plan_group_choice) for the stage-operator sweeps of BASELINE configs[1] and its shards
+            h->fgroup = (h->fused && h->nseg > 1) ? P.fgroup : 0;
+            if (h->fgroup && !std::getenv("HIPADJ_TREE_RADIX")) radix = P.tree_radix;
             long slots = 0, ctrs = 0;
             tree_plan_shape(h->fgroup ? (h->nseg + h->fgroup - 1) / h->fgroup : h->nseg, radix, (long)(Np / 64), h->tp, &slots, &ctrs);
             h->tcnt_n = ctrs;
@@ -1764,18 +1764,32 @@ static void host_copy_par(double* dst, const double* src, size_t count) {
     std::memcpy(dst, src, std::min(per, count) * sizeof(double));
     for (auto& x : th) x.join();
 }
+// The staging block lives in its OWN anonymous mapping with an inaccessible guard page on either side — never in the brk heap.  Round 5's block was posix_memalign memory: once
+// glibc's dynamic mmap threshold has risen (a larger block was freed earlier), such a block comes from the heap, page-adjacent to the caller's small arrays, and registering it
+// there made the next pageable device-to-host copy into a fresh heap array just below it die with "Memory access fault by GPU ... Write access to a read-only page" (the one-in-
+// a-dozen abort of round 5's bench; reproduced in seconds by scripts/r6/fault_stress.py, reduced in scripts/r6/repro_readonly_fault.hip; profiles/r6_fault_*).  The guard pages
+// keep the kernel from merging the mapping with a neighbour's and the registration from sharing a page with anything else.
+static void host_pin_release(hipadj_handle* h) {
+    if (!h->h_pin) return;
+    (void)hipHostUnregister(h->h_pin);
+    (void)munmap((char*)h->h_pin - 4096, h->pin_map_len);
+    h->h_pin = nullptr; h->pin_count = 0; h->pin_map_len = 0;
+}
 static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's pinned block, grown on demand; nullptr: no pinned memory to be had (the pageable copy still works)
     if (h->pin_count >= count) return h->h_pin;
     if (std::getenv("HIPADJ_NO_PINNED")) return nullptr;
-    if (h->h_pin) { (void)hipStreamSynchronize(h->stream); (void)hipDeviceSynchronize(); (void)hipHostUnregister(h->h_pin); std::free(h->h_pin); h->h_pin = nullptr; h->pin_count = 0; }   // (device-wide: the block may have been read on a stream the handle has since left)
+    if (h->h_pin) { (void)hipStreamSynchronize(h->stream); (void)hipDeviceSynchronize(); host_pin_release(h); }   // (device-wide: the block may have been read on a stream the handle has since left)
     // ordinary (cached) pages, registered with the runtime: hipHostMalloc's default block is fine-grained coherent memory, which the host WRITES at a fraction of its memcpy rate
     // (measured: the staged upload took 12.5 ms against 7.7 ms for the plain pageable copy, profiles/r5_visit2_bench.json)
-    void* q = nullptr;
-    if (posix_memalign(&q, 4096, count * sizeof(double)) != 0 || !q) return nullptr;
-    std::memset(q, 0, count * sizeof(double));                                  // touch the pages before they are pinned
-    if (hipHostRegister(q, count * sizeof(double), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); std::free(q); return nullptr; }
-    h->h_pin = (double*)q; h->pin_count = count;
-    if (std::getenv("HIPADJ_TRACE_PIN")) std::fprintf(stderr, "hipadj host_pin: handle %p registered [%p, %p)\n", (void*)h, q, (void*)((char*)q + count * sizeof(double)));
+    const size_t bytes = count * sizeof(double), len = (bytes + 4095) / 4096 * 4096 + 2 * 4096;
+    char* m = (char*)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == (char*)MAP_FAILED) return nullptr;
+    (void)mprotect(m, 4096, PROT_NONE); (void)mprotect(m + len - 4096, 4096, PROT_NONE);
+    void* q = m + 4096;
+    std::memset(q, 0, bytes);                                                    // touch the pages before they are pinned
+    if (hipHostRegister(q, len - 2 * 4096, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); (void)munmap(m, len); return nullptr; }
+    h->h_pin = (double*)q; h->pin_count = count; h->pin_map_len = len;
+    if (std::getenv("HIPADJ_TRACE_PIN")) std::fprintf(stderr, "hipadj host_pin: handle %p registered [%p, %p) (own mapping, guard pages)\n", (void*)h, q, (void*)((char*)q + len - 2 * 4096));
     return h->h_pin;
 }
 // host -> device through the pinned block (src pageable); falls back to the plain pageable copy

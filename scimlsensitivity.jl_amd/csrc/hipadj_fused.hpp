@@ -176,11 +176,29 @@ __device__ __forceinline__ void fused_root(const double (&m)[N + NP], const Tree
     }
     HIPADJ_TP(HIPADJ_TTRACE(T), 20, s[0]);                      // du0 written, mu reduced over the lanes, the block's partial issued
     if (!tree_arrive_last(T.ticket, (unsigned)blocks, HIPADJ_TTRACE(T), 21)) return;
-    // last block: lane l sums blocks l, l + 64, ... in increasing order, then the same fixed tree over the lanes
+    // last block: lane l sums blocks l, l + 64, ... in increasing order, then the same fixed tree over the lanes.  The loads of Q rounds (64 Q blocks) x NP entries are
+    // issued together: one memory round trip instead of a dependent chain of ceil(blocks / 64) x NP (round 6: 2.8-3.4 us of the 10^4-trajectory pass' tail, 157 blocks,
+    // profiles/r6_wave_trace_10000*.jsonl "root: ticket->dp written")
+    constexpr int Q = NP <= 4 ? 4 : (NP <= 8 ? 2 : 1);      // rounds in flight: Q x NP registers (runtime models carry up to 32 parameters: one round, the old order)
+    double acc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+    for (long b0 = lane; b0 < blocks; b0 += 64 * Q) {
+        double x[Q][NP];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const long b = b0 + 64 * q;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) x[q][j] = b < blocks ? map_load_agent(T.partial + b * NP + j) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) acc[j] += x[q][j];
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        double v = 0.0;
-        for (long b = lane; b < blocks; b += 64) v += map_load_agent(T.partial + b * NP + j);
+        double v = acc[j];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) dp_sum[j] = v;

@@ -21,6 +21,7 @@ struct Plan {
     int n = 0, np = 0;
     long N = 0, Npad = 0;
     int S = 0, M = 0, nck = 0, nseg = 1, nq = 0;
+    int fgroup = 0, tree_radix = 4;   // grouped one-launch pass (k_interp_fused_g): waves per workgroup (0 = the plain form) and the radix of the HBM tree above the groups
     std::vector<double> save_times;
     std::vector<int> save_of_knot, ckpt_of_knot, seg_bounds;
     std::vector<int> save_of_knot_rev;   // the map the REVERSE kernels read: save_of_knot, minus the jump no_start suppresses when it sits at T (see make_plan)
@@ -158,6 +159,26 @@ inline int plan_auto_segments(long N, int S, int n, int np = 0) {
     }
     if ((double)target < 1.0 + n) return 1;
     return (int)target;
+}
+
+// The GROUPED one-launch pass (hipadj_fused.hpp; the stage-operator sweep of the compiled-in Lorenz model with shared parameters and the fused LSQ_SHIFT loss — BASELINE
+// configs[1] and its shards): G consecutive segments per workgroup, first composition level in LDS.  Measured on MI355X, 1000 steps (profiles/r6_shard_group_ab.jsonl), best of
+// the forms tried — 1250 trajectories (20 blocks): G = 4 x 12 groups, radix 4: 23.8 us (plain, 51 segments: 27.2); 2500 (40): G = 8 x 6, radix 8: 33.5 (40.5); 5000 (79):
+// G = 8 x 3: 52.8 (61.4); 10^4 (157): G = 4 x 3: 107.4 (110.0).  The rule behind those: an 8-wave workgroup (84 KB of LDS, 2 waves per SIMD) owns a CU, so at most 256 of them;
+// 4-wave workgroups pair up on a CU (<= 512), and a shard too small to fill the chip twice keeps one wave per SIMD (G = 4, <= 256 workgroups).  Returns false where nothing
+// was measured to gain (fewer than 3 groups per block, segments shorter than 8 steps).
+inline bool plan_group_choice(long N, int S, int& G, int& segs, int& radix) {
+    const long blocks = (N + 63) / 64;
+    long groups;
+    if (blocks <= 25) { G = 4; groups = 256 / blocks; }
+    else if (blocks <= 128) { G = 8; groups = 256 / blocks; }
+    else { G = 4; groups = 512 / blocks; }
+    while (groups > 1 && groups * G > S / (G == 8 ? 10 : 16)) --groups;      // segments of at least 16 steps (10 in the two-waves-per-SIMD form)
+    if (groups > 16) groups = 16;                                            // one level of a radix-16 tree
+    if (groups < 3) return false;
+    segs = (int)(groups * G);
+    radix = groups <= 4 ? 4 : (groups <= 8 ? 8 : 4);                          // 12 groups: 4 + 4 + 4 under a root of 3 (measured ahead of one radix-16 level, 23.8 vs 24.1 us)
+    return true;
 }
 
 inline int plan_check_cost(const hipadj_config* cfg, std::string& err) {
@@ -402,6 +423,17 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     const long L = seg_offgrid ? (long)P.rs_t.size() : S;      // length of the axis the segments cut
     if (seg_alg && (!P.offgrid || seg_offgrid)) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, (int)L, n, np) : cfg->time_segments;
+        {   // the grouped one-launch pass where it was measured to win (plan_group_choice); HIPADJ_FUSED_GROUP = 0 keeps the plain form, 4 / 8 force a group size on the
+            // segment count given (A/B runs, tests)
+            const bool eligible = cfg->model == HIPADJ_MODEL_LORENZ && cfg->alg == HIPADJ_ALG_INTERPOLATING && cfg->p_shared && cfg->loss_kind == HIPADJ_LOSS_LSQ_SHIFT &&
+                                  cfg->cont_cost == HIPADJ_CCOST_NONE && !cfg->checkpointing && !P.offgrid && !std::getenv("HIPADJ_NO_OPS") && !std::getenv("HIPADJ_WPB");
+            const char* e = std::getenv("HIPADJ_FUSED_GROUP"); const int forced = e ? std::atoi(e) : -1;
+            if (eligible && forced != 0) {
+                int G = 0, segs = 0, radix = 4;
+                if (forced == 4 || forced == 8) { P.fgroup = forced; if (const char* r = std::getenv("HIPADJ_TREE_RADIX")) { const int v = std::atoi(r); P.tree_radix = (v == 8 || v == 16) ? v : 4; } }
+                else if (cfg->time_segments == 0 && plan_group_choice(P.N, (int)L, G, segs, radix)) { P.fgroup = G; P.nseg = segs; P.tree_radix = radix; }
+            }
+        }
         if (!plan_seg_fits(n, np)) P.nseg = 1;   // segment lanes would not fit the register file
         if (P.nseg > L) P.nseg = (int)L;
         if (P.nseg < 1) P.nseg = 1;
