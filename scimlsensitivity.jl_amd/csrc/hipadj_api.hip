@@ -1636,6 +1636,7 @@ extern "C" int hipadj_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double
 }
 
 static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size_t count);
+static int download_block(hipadj_handle* h, double* dst, const double* d_src, size_t count);
 // ---- device-resident discrete losses: the data block, the loss value, cotangents in the streaming layout -----------------------------------------------
 static int loss_data_install(hipadj_handle* h) {   // h->d_ldata [N][M][n] is in place (stream order): the lane family's transposed copy
     const bool lane = !h->wide && !h->field && !h->mlp;
@@ -1727,9 +1728,7 @@ extern "C" int hipadj_loss_value(hipadj_handle* h, const double* out, double* lo
     if (!h->d_lval) TRY(dev_alloc(h, &h->d_lval, 1));
     TRY(upload_block(h, h->d_io_a, out, (size_t)h->N * h->M * h->n));
     TRY(hipadj_loss_value_dev(h, h->d_io_a, h->d_lval));
-    HIP_TRY(h, hipMemcpyAsync(loss, h->d_lval, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return HIPADJ_OK;
+    return download_block(h, loss, h->d_lval, 1);
 }
 
 extern "C" int hipadj_soa_stride(hipadj_handle* h, int64_t* ld) {
@@ -1772,7 +1771,7 @@ static void host_copy_par(double* dst, const double* src, size_t count) {
 static void host_pin_release(hipadj_handle* h) {
     if (!h->h_pin) return;
     (void)hipHostUnregister(h->h_pin);
-    (void)munmap((char*)h->h_pin - 4096, h->pin_map_len);
+    if (h->pin_map_len) (void)munmap((char*)h->h_pin - 4096, h->pin_map_len); else std::free(h->h_pin);      // (else: the reproduction hook's heap block)
     h->h_pin = nullptr; h->pin_count = 0; h->pin_map_len = 0;
 }
 static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's pinned block, grown on demand; nullptr: no pinned memory to be had (the pageable copy still works)
@@ -1782,6 +1781,15 @@ static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's p
     // ordinary (cached) pages, registered with the runtime: hipHostMalloc's default block is fine-grained coherent memory, which the host WRITES at a fraction of its memcpy rate
     // (measured: the staged upload took 12.5 ms against 7.7 ms for the plain pageable copy, profiles/r5_visit2_bench.json)
     const size_t bytes = count * sizeof(double), len = (bytes + 4095) / 4096 * 4096 + 2 * 4096;
+    if (std::getenv("HIPADJ_PIN_HEAP")) {      // REPRODUCTION HOOK (scripts/r6/fault_ab.py): round 5's block, posix_memalign memory registered in place — never use otherwise
+        void* q = nullptr;
+        if (posix_memalign(&q, 4096, bytes) != 0 || !q) return nullptr;
+        std::memset(q, 0, bytes);
+        if (hipHostRegister(q, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); std::free(q); return nullptr; }
+        h->h_pin = (double*)q; h->pin_count = count; h->pin_map_len = 0;
+        if (std::getenv("HIPADJ_TRACE_PIN")) std::fprintf(stderr, "hipadj host_pin: handle %p registered [%p, %p) (HEAP block: reproduction hook)\n", (void*)h, q, (void*)((char*)q + bytes));
+        return h->h_pin;
+    }
     char* m = (char*)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == (char*)MAP_FAILED) return nullptr;
     (void)mprotect(m, 4096, PROT_NONE); (void)mprotect(m + len - 4096, 4096, PROT_NONE);
@@ -1792,12 +1800,26 @@ static double* host_pin(hipadj_handle* h, size_t count) {      // the handle's p
     if (std::getenv("HIPADJ_TRACE_PIN")) std::fprintf(stderr, "hipadj host_pin: handle %p registered [%p, %p) (own mapping, guard pages)\n", (void*)h, q, (void*)((char*)q + len - 2 * 4096));
     return h->h_pin;
 }
-// host -> device through the pinned block (src pageable); falls back to the plain pageable copy
+// ---- host-pointer transfers --------------------------------------------------------------------------------------------------------------------------------------------
+// EVERY transfer between a caller's host array and the device goes through the handle's staging block (round 6): the host side of each DMA is memory this library owns,
+// registered once, in its own mapping — the caller's arrays are only ever touched by the CPU.  Why: a pageable hipMemcpy makes the runtime pin the caller's pages on the fly and
+// keep those pins cached; with the arrays of a numpy / Julia host (allocated, freed and re-allocated at the same heap addresses from call to call) a device-to-host copy of du0
+// ended in "Memory access fault by GPU ... Write access to a read-only page" and took the host process with it (round 5: one bench run in a dozen; round 6: reproduced in the
+// first seconds of scripts/r6/fault_stress.py, profiles/r6_fault_stress_reproduced_visit3.log; A/B of the three transfer modes: scripts/r6/fault_ab.py).  Staging costs one
+// CPU copy per block (host_copy_par: a few threads at memcpy rate — 24 MB of out / Delta in ~0.5 ms) and removes the runtime's on-the-fly pinning from the path altogether.
+// HIPADJ_HOST_DIRECT=1 restores the direct pageable copies (A/B); HIPADJ_NO_PINNED=1 or a failed registration fall back to them as well.
+static bool host_direct() { static const bool v = [] { const char* e = std::getenv("HIPADJ_HOST_DIRECT"); return e && e[0] == '1'; }(); return v; }
+// the handle's staging block with room for `count` doubles (grown on demand: a growth drains the device first, so it may only be asked for while nothing staged is pending —
+// every call site asks ONCE, up front, for the most it will hold); nullptr: direct pageable copies
+static double* stage_block(hipadj_handle* h, size_t count) { return host_direct() ? nullptr : host_pin(h, count + 8); }
+
+// host -> device: count doubles of `src` into d_dst (asynchronous once the host copy is done; the stream is drained first: an earlier transfer may still be using the block)
 static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size_t count) {
-    double* pin = count * sizeof(double) >= ((size_t)1 << 20) ? host_pin(h, count) : nullptr;
+    // (HIPADJ_HOST_DIRECT=1 keeps round 5's rule for this one: blocks of 1 MB and more through the registered block, smaller ones pageable)
+    double* pin = (host_direct() && count * sizeof(double) >= ((size_t)1 << 20)) ? host_pin(h, count) : stage_block(h, count);
     if (pin) {
         static const bool trace = std::getenv("HIPADJ_HOST_TIMING") != nullptr;      // diagnosis: where a host-pointer call spends its time (stderr)
-        HIP_TRY(h, hipStreamSynchronize(h->stream));      // an earlier download out of the pinned block must have left it
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
         const auto t0 = std::chrono::steady_clock::now();
         host_copy_par(pin, src, count);
         const auto t1 = std::chrono::steady_clock::now();
@@ -1811,16 +1833,45 @@ static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size
     } else HIP_TRY(h, hipMemcpyAsync(d_dst, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return HIPADJ_OK;
 }
+// device -> host, synchronous: count doubles of d_src into `dst`
+static int download_block(hipadj_handle* h, double* dst, const double* d_src, size_t count) {
+    double* pin = stage_block(h, count);
+    if (pin) {
+        HIP_TRY(h, hipMemcpyAsync(pin, d_src, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        host_copy_par(dst, pin, count);
+    } else {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpyAsync(dst, d_src, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return HIPADJ_OK;
+}
 
-// host-pointer calls = enqueue (copies in, the device call, copies out: nothing here waits for the device) + hipadj_synchronize; a handle over several devices enqueues
-// on every shard before it drains any (hipadj_multi.hpp)
+// host-pointer calls = enqueue (copies in, the device call, the copy out into the staging block: nothing waits for the device beyond the block's hand-over) + finish (drain,
+// CPU copy into the caller's array); a handle over several devices enqueues on every shard before it finishes any (hipadj_multi.hpp)
 static int forward_host_enqueue(hipadj_handle* h, const double* u0, const double* p, double* out) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
-    HIP_TRY(h, hipMemcpyAsync(h->d_u0, u0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_p, p, pb, hipMemcpyHostToDevice, h->stream));
+    const size_t nu = (size_t)h->N * h->n, pc = h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np, no = (size_t)h->N * h->M * h->n;
+    double* pin = stage_block(h, std::max(nu + pc, (out && h->M > 0) ? no : (size_t)0));
+    if (pin) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(pin, u0, sizeof(double) * nu); std::memcpy(pin + nu, p, sizeof(double) * pc);
+        HIP_TRY(h, hipMemcpyAsync(h->d_u0, pin, sizeof(double) * nu, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_p, pin + nu, sizeof(double) * pc, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->d_u0, u0, sizeof(double) * nu, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_p, p, sizeof(double) * pc, hipMemcpyHostToDevice, h->stream));
+    }
     TRY(hipadj_forward_dev(h, h->d_u0, h->d_p, out ? h->d_io_a : nullptr));
-    if (out && h->M > 0) HIP_TRY(h, hipMemcpyAsync(out, h->d_io_a, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (out && h->M > 0) HIP_TRY(h, hipMemcpyAsync(pin ? pin : out, h->d_io_a, sizeof(double) * no, hipMemcpyDeviceToHost, h->stream));      // (in-stream behind the uploads that read the block)
+    return HIPADJ_OK;
+}
+static int forward_host_finish(hipadj_handle* h, double* out) {
+    if (!out || h->M <= 0 || !h->h_pin || host_direct()) return HIPADJ_OK;      // direct mode: the copy went into `out` itself
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    host_copy_par(out, h->h_pin, (size_t)h->N * h->M * h->n);
     return HIPADJ_OK;
 }
 extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* p, double* out) {
@@ -1829,13 +1880,13 @@ extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* 
     if (h->route) return route_forward(h, u0, p, out);
     if (h->multi) return multi_forward(h, u0, p, out);
     TRY(forward_host_enqueue(h, u0, p, out));
+    TRY(forward_host_finish(h, out));
     return hipadj_synchronize(h);
 }
 
-// The host-pointer reverse call in two phases: adjoint_host_run (upload of the cotangents + the reverse pass, nothing waits) and adjoint_host_download (the two small
-// downloads into the caller's PAGEABLE arrays, requested only once the stream is drained).  A pageable device-to-host copy behind pending work makes the runtime wait for the
-// stream on a slow path (measured: 8 ms per call of the 10^4-trajectory pass against 1 ms when the stream is idle at that point, profiles/r5_visit4_bench.json vs
-// r5_visit7_bench.json).  A handle over several devices runs phase 1 on every shard before phase 2 on any, so the devices still work concurrently (hipadj_multi.hpp).
+// The host-pointer reverse call in two phases: adjoint_host_run (upload of the cotangents + the reverse pass, nothing waits) and adjoint_host_download (du0 / dp through the
+// staging block once the stream is drained).  A handle over several devices runs phase 1 on every shard before phase 2 on any, so the devices still work concurrently
+// (hipadj_multi.hpp).
 static int adjoint_host_run(hipadj_handle* h, const double* dLdu) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const bool cot = h->cfg.loss_kind == HIPADJ_LOSS_COTANGENT && h->M > 0;
@@ -1849,10 +1900,15 @@ static int adjoint_host_run(hipadj_handle* h, const double* dLdu) {
 }
 static int adjoint_host_download(hipadj_handle* h, double* du0, double* dp) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const size_t pb = sizeof(double) * (h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np);
+    const size_t nu = (size_t)h->N * h->n, pc = h->cfg.p_shared ? (size_t)h->np : (size_t)h->N * h->np;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpyAsync(du0, h->d_du0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(dp, h->d_dp, pb, hipMemcpyDeviceToHost, h->stream));
+    double* pin = stage_block(h, nu + pc);
+    HIP_TRY(h, hipMemcpyAsync(pin ? pin : du0, h->d_du0, sizeof(double) * nu, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(pin ? pin + nu : dp, h->d_dp, sizeof(double) * pc, hipMemcpyDeviceToHost, h->stream));
+    if (pin) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(du0, pin, sizeof(double) * nu); std::memcpy(dp, pin + nu, sizeof(double) * pc);
+    }
     return HIPADJ_OK;
 }
 extern "C" int hipadj_adjoint(hipadj_handle* h, const double* dLdu, double* du0, double* dp) {

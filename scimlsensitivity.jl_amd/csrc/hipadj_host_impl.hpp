@@ -185,14 +185,20 @@ template <class Mo, int LOSS> int adjoint_impl_l(hipadj_handle* h, const double*
             double* dps = h->cfg.p_shared ? d_dp : (double*)nullptr;
             bool launched = false;
             if constexpr (model_has_ops<Mo>::value && (LOSS >> 1) == 0) {
-                if (h->fgroup) {      // (hipadj_create set it only for the configuration this branch serves: shared parameters, several segments, the fused LSQ_SHIFT loss)      // G waves per workgroup, first composition level in LDS
+                if (h->fgroup) {      // (the planner set it only for the configuration this branch serves: shared parameters, several segments, no cost — plan_group_choice)
+                    // G waves per workgroup, first composition level in LDS (k_interp_fused_g); the loss forms of the plain one-launch pass: fused LSQ_SHIFT, a streamed
+                    // column (cotangents in the streaming layout, the data block of LSQ_DATA), cotangents read in place from the pullback's layout
                     const unsigned ng = (unsigned)((h->nseg + h->fgroup - 1) / h->fgroup);
-                    if (h->fgroup == 8)
-                        hipExtLaunchKernelGGL((k_interp_fused_g<Mo, 4, LOSS, 8>), dim3(waves, ng), dim3(WAVE * 8), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
-                                              (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
-                    else
-                        hipExtLaunchKernelGGL((k_interp_fused_g<Mo, 4, LOSS, 4>), dim3(waves, ng), dim3(WAVE * 4), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
-                                              (const dbl2*)h->d_knots, cotT, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                    auto go = [&](auto mode, auto gsz, const double* col) {
+                        constexpr int MODE = decltype(mode)::value, GS = decltype(gsz)::value;
+                        hipExtLaunchKernelGGL((k_interp_fused_g<Mo, 4, MODE, GS>), dim3(waves, ng), dim3(WAVE * GS), 0, h->stream, e0, e1, 0, h->g, sp, tp, p,
+                                              (const dbl2*)h->d_knots, col, (const int*)h->d_save_rev, d_du0, dp_rows, dps, h->d_flag);
+                    };
+                    using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
+                    bool inplace = false;
+                    if constexpr (LOSS == 0) inplace = insweep;
+                    if (inplace) { if (h->fgroup == 8) go(std::integral_constant<int, HIPADJ_MODE_COT_INPLACE>{}, I8{}, d_cot); else go(std::integral_constant<int, HIPADJ_MODE_COT_INPLACE>{}, I4{}, d_cot); }
+                    else { if (h->fgroup == 8) go(std::integral_constant<int, LOSS>{}, I8{}, cotT); else go(std::integral_constant<int, LOSS>{}, I4{}, cotT); }
                     launched = true;
                 }
                 if (!launched && h->cfg.p_shared && h->nseg > 1 && !h->no_ops) {

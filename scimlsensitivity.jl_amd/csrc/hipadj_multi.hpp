@@ -16,6 +16,7 @@
 #include "hipadj_host.hpp"
 
 static int forward_host_enqueue(hipadj_handle* h, const double* u0, const double* p, double* out);
+static int forward_host_finish(hipadj_handle* h, double* out);
 static int adjoint_host_run(hipadj_handle* h, const double* dLdu);
 static int adjoint_host_download(hipadj_handle* h, double* du0, double* dp);
 
@@ -101,6 +102,10 @@ static int multi_forward(hipadj_handle* h, const double* u0, const double* p, do
     for (int g = 0; g < G; ++g) {
         const size_t lo = (size_t)h->shard_off[g];
         const int rc = forward_host_enqueue(h->shards[g], u0 + lo * n, h->cfg.p_shared ? p : p + lo * np, out ? out + lo * M * n : nullptr);
+        if (rc != HIPADJ_OK) return multi_fail(h, g, rc);
+    }
+    for (int g = 0; g < G; ++g) {      // every shard is running: now drain them one by one and hand the outputs over
+        const int rc = forward_host_finish(h->shards[g], out ? out + (size_t)h->shard_off[g] * M * n : nullptr);
         if (rc != HIPADJ_OK) return multi_fail(h, g, rc);
     }
     h->have_forward = true;

@@ -425,7 +425,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
         P.nseg = cfg->time_segments == 0 ? plan_auto_segments(P.N, (int)L, n, np) : cfg->time_segments;
         {   // the grouped one-launch pass where it was measured to win (plan_group_choice); HIPADJ_FUSED_GROUP = 0 keeps the plain form, 4 / 8 force a group size on the
             // segment count given (A/B runs, tests)
-            const bool eligible = cfg->model == HIPADJ_MODEL_LORENZ && cfg->alg == HIPADJ_ALG_INTERPOLATING && cfg->p_shared && cfg->loss_kind == HIPADJ_LOSS_LSQ_SHIFT &&
+            const bool eligible = cfg->model == HIPADJ_MODEL_LORENZ && cfg->alg == HIPADJ_ALG_INTERPOLATING && cfg->p_shared && cfg->loss_kind != HIPADJ_LOSS_MODEL &&
                                   cfg->cont_cost == HIPADJ_CCOST_NONE && !cfg->checkpointing && !P.offgrid && !std::getenv("HIPADJ_NO_OPS") && !std::getenv("HIPADJ_WPB");
             const char* e = std::getenv("HIPADJ_FUSED_GROUP"); const int forced = e ? std::atoi(e) : -1;
             if (eligible && forced != 0) {

@@ -15,6 +15,7 @@
 
 static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size_t count);
 static int adjoint_host_download(hipadj_handle* h, double* du0, double* dp);
+static int download_block(hipadj_handle* h, double* dst, const double* d_src, size_t count);
 
 // out[b][a][:] = in[a][b][:]   (A x B blocks of d doubles)
 static __global__ void k_swap_leading(long A, long B, long d, const double* __restrict__ in, double* __restrict__ out) {
@@ -96,13 +97,10 @@ static int route_adjoint_dev(hipadj_handle* h, const double* d_dLdu, double* d_d
 static int route_forward(hipadj_handle* h, const double* u0, const double* p, double* out) {
     hipadj_handle* in = h->inner;
     HIP_TRY(h, hipSetDevice(in->cfg.device));
-    HIP_TRY(h, hipMemcpyAsync(in->d_u0, u0, sizeof(double) * (size_t)h->N * h->n, hipMemcpyHostToDevice, in->stream));
-    HIP_TRY(h, hipMemcpyAsync(in->d_p, p, sizeof(double) * (size_t)h->np, hipMemcpyHostToDevice, in->stream));
+    ROUTE_TRY(h, upload_block(in, in->d_u0, u0, (size_t)h->N * h->n));      // (through the inner handle's staging block, like every host-pointer transfer: hipadj_api.hip)
+    ROUTE_TRY(h, upload_block(in, in->d_p, p, (size_t)h->np));
     TRY(route_forward_dev(h, in->d_u0, in->d_p, out ? h->d_rt_b : nullptr));
-    if (out && h->M > 0) {
-        HIP_TRY(h, hipStreamSynchronize(in->stream));
-        HIP_TRY(h, hipMemcpyAsync(out, h->d_rt_b, sizeof(double) * (size_t)h->N * h->M * h->n, hipMemcpyDeviceToHost, in->stream));
-    }
+    if (out && h->M > 0) ROUTE_TRY(h, download_block(in, out, h->d_rt_b, (size_t)h->N * h->M * h->n));
     ROUTE_TRY(h, hipadj_synchronize(in));
     return HIPADJ_OK;
 }
@@ -137,8 +135,7 @@ static int route_loss_value(hipadj_handle* h, const double* out, double* loss, b
     TRY(route_swap(h, h->N, h->M, src, h->d_rt_b));
     if (dev) { ROUTE_TRY(h, hipadj_loss_value_dev(in, h->d_rt_b, loss)); return HIPADJ_OK; }
     ROUTE_TRY(h, hipadj_loss_value_dev(in, h->d_rt_b, h->d_rt_a));      // (the uploaded block has been consumed by the transposition)
-    HIP_TRY(h, hipMemcpyAsync(loss, h->d_rt_a, sizeof(double), hipMemcpyDeviceToHost, in->stream));
-    HIP_TRY(h, hipStreamSynchronize(in->stream));
+    ROUTE_TRY(h, download_block(in, loss, h->d_rt_a, 1));
     return HIPADJ_OK;
 }
 static int route_get_stats(hipadj_handle* h, hipadj_stats* st) {

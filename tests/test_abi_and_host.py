@@ -203,7 +203,8 @@ def test_planner_offgrid_loss_times_build_the_reverse_step_list():
     assert E.lib().emu_plan(C.byref(cfg), C.byref(nseg), b, 64, C.byref(nck), C.byref(nq)) == -1 and "closer than the time resolution" in E.lib().emu_last_error().decode()
 
 
-def test_planner_segments_checkpoints_and_quadrature_intervals():
+def test_planner_segments_checkpoints_and_quadrature_intervals(monkeypatch):
+    monkeypatch.setenv("HIPADJ_FUSED_GROUP", "0")      # the plain one-launch pass first (the rule every model gets); the grouped form of the Lorenz stage-operator sweeps below
     def plan(alg, N, S_dt, save, **k):
         cfg = E.make_config("lorenz", alg, N, 0.0, 10.0, S_dt, save, **k)
         nseg, nck, nq = C.c_int(), C.c_int(), C.c_int()
@@ -224,6 +225,13 @@ def test_planner_segments_checkpoints_and_quadrature_intervals():
     assert plan("interpolating", 1250, 0.01, ts, time_segments=0)[0] == 51
     assert plan("interpolating", 640, 0.01, ts, time_segments=0)[0] == 62
     assert plan("interpolating", 100, 0.01, ts, time_segments=5)[0] == 5
+    # round 6: the grouped form (G segments per workgroup, first composition level in LDS; hipadj_plan.hpp plan_group_choice, measured: profiles/r6_shard_group_ab.jsonl) —
+    # 8-wave workgroups own a CU (<= 256 of them), 4-wave ones pair up (<= 512), the smallest shards keep one wave per SIMD; beyond 170 blocks the plain rule stands
+    monkeypatch.delenv("HIPADJ_FUSED_GROUP")
+    assert [plan("interpolating", N, 0.01, ts, time_segments=0)[0] for N in (640, 1250, 2500, 5000, 10000, 20000, 10 ** 6)] == [60, 48, 48, 24, 12, 6, 1]
+    assert plan("interpolating", 1250, 0.01, ts, time_segments=7)[0] == 7                 # an explicit segment count is kept
+    assert plan("gauss", 1250, 0.01, ts, time_segments=0)[0] == 51                        # other sweeps: the plain rule
+    monkeypatch.setenv("HIPADJ_FUSED_GROUP", "0")
     assert plan("backsolve", 64, 0.01, ts, checkpointing=True)[2] == 101        # default checkpoints = saved points
     assert plan("backsolve", 64, 0.01, ts[1:-1], checkpointing=True)[2] == 101  # endpoints are always stored
     assert plan("backsolve", 64, 0.01, ts, checkpointing=True, ckpt_stride=250)[2] == 5

@@ -152,30 +152,44 @@ def test_fused_pass_of_runtime_lane_models(sa, monkeypatch, capfd, n, alg, cap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("G,segs,radix", [(4, 48, 4), (8, 96, 16), (4, 10, 4), (8, 13, 4)])
-def test_grouped_one_launch_pass_matches_the_plain_one(sa, G, segs, radix, monkeypatch):
-    """Round 6: HIPADJ_FUSED_GROUP = G puts G consecutive segments of a trajectory block into one workgroup and composes their maps through LDS before the HBM tree
-    (k_interp_fused_g, csrc/hipadj_fused.hpp "GROUPED form").  Another bracketing of the same associative composition: du0 / dp agree with the plain one-launch pass to
-    round-off and with the oracle at the parity tolerance; ragged last groups (13 segments in groups of 8, 10 in groups of 4) included."""
+@pytest.mark.parametrize("loss", ["shift", "cotangent", "data"])
+@pytest.mark.parametrize("G,segs,radix", [(4, 48, 4), (8, 96, 16), (4, 10, 4), (8, 13, 4), (0, 0, 0)])
+def test_grouped_one_launch_pass_matches_the_plain_one(sa, G, segs, radix, loss, monkeypatch):
+    """Round 6: G consecutive segments of a trajectory block in one workgroup, their maps composed through LDS before the HBM tree (k_interp_fused_g, csrc/hipadj_fused.hpp
+    "GROUPED form"; chosen by the planner for the stage-operator sweeps of the compiled-in Lorenz model — plan_group_choice — or forced with HIPADJ_FUSED_GROUP).  Another
+    bracketing of the same associative composition: du0 / dp agree with the plain one-launch pass (HIPADJ_FUSED_GROUP = 0) to round-off and with the oracle at the parity
+    tolerance, for every loss route of the pass (fused LSQ_SHIFT, cotangents read in place, the device-resident data block); ragged last groups (13 segments in groups of 8,
+    10 in groups of 4) and the planner's own choice (G = 0 here: nothing forced) included."""
     import oracle as O
     rng = np.random.default_rng(3)
     N, T, dt = 1250, 10.0, 0.01
     ts = np.linspace(0.0, T, 101)
     u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); p = np.array([10.0, 28.0, 8.0 / 3.0])
+    block = rng.standard_normal((N, len(ts), 3))
+    kw = dict(shift=dict(loss_kind=1, loss_shift=2.0), cotangent=dict(loss_kind=0), data=dict(loss_kind=2, loss_scale=2.0))[loss]
     res = {}
     for grouped in (False, True):
+        monkeypatch.setenv("HIPADJ_FUSED_GROUP", "0")
         if grouped:
-            monkeypatch.setenv("HIPADJ_FUSED_GROUP", str(G)); monkeypatch.setenv("HIPADJ_TREE_RADIX", str(radix))
-        eng = sa.Engine("lorenz", "interpolating", N, 0.0, T, dt, save_times=ts, loss_kind=1, loss_shift=2.0, time_segments=segs)
+            if G:
+                monkeypatch.setenv("HIPADJ_FUSED_GROUP", str(G)); monkeypatch.setenv("HIPADJ_TREE_RADIX", str(radix))
+            else:
+                monkeypatch.delenv("HIPADJ_FUSED_GROUP")
+        eng = sa.Engine("lorenz", "interpolating", N, 0.0, T, dt, save_times=ts, time_segments=segs, **kw)
+        if loss == "data":
+            eng.set_loss_data(block)
         eng.forward(u0, p, want_out=False)
-        res[grouped] = eng.adjoint(None)
-        assert eng.stats()["launches_per_pass"] == 1 and eng.stats()["time_segments"] == segs
-        again = eng.adjoint(None)
+        res[grouped] = eng.adjoint(block if loss == "cotangent" else None)
+        assert eng.stats()["launches_per_pass"] == 1 and (segs == 0 or eng.stats()["time_segments"] == segs)
+        if grouped and not G:
+            assert eng.stats()["time_segments"] == 48          # plan_group_choice: 20 blocks -> 12 groups of 4
+        again = eng.adjoint(block if loss == "cotangent" else None)
         assert np.array_equal(again[0], res[grouped][0]) and np.array_equal(again[1], res[grouped][1])      # reproducible from pass to pass
         eng.close()
-    monkeypatch.delenv("HIPADJ_FUSED_GROUP"); monkeypatch.delenv("HIPADJ_TREE_RADIX")
+    monkeypatch.delenv("HIPADJ_FUSED_GROUP", raising=False); monkeypatch.delenv("HIPADJ_TREE_RADIX", raising=False)
     assert np.max(np.abs(res[True][0] - res[False][0])) / np.max(np.abs(res[False][0])) < 1e-10
-    assert np.max(np.abs(res[True][1] - res[False][1]) / np.abs(res[False][1])) < 1e-10
-    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
-    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, want_out=False)
+    assert np.max(np.abs(res[True][1] - res[False][1]) / np.abs(res[False][1])) < 1e-9
+    okw = dict(shift=dict(loss="LSQ_SHIFT", loss_shift=2.0), cotangent=dict(loss="COTANGENT"), data=dict(loss="LSQ_DATA", loss_scale=2.0))[loss]
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=T, dt=dt, save_times=ts, **okw)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, None if loss == "shift" else block, want_out=False)
     assert np.max(np.abs(res[True][0] - rdu0)) / np.max(np.abs(rdu0)) < 1e-6 and np.max(np.abs(res[True][1] - rdp) / np.abs(rdp)) < 1e-6
