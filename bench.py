@@ -88,7 +88,7 @@ def compact(res):
     checked by tests/test_bench_launch.py).  Prose notes, loss_paths, other_configs and every table live in bench_extras.json (write_extras)."""
     out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
     cfg = res.get("config", {})
-    out["config"] = _pick(cfg, ("workload", "ntraj_total", "ntraj_per_gpu", "rk4_steps", "loss_times", "time_segments", "parallelism", "dp_allreduce", "rccl_ranks",
+    out["config"] = _pick(cfg, ("workload", "ntraj_total", "ntraj_per_gpu", "rk4_steps", "loss_times", "time_segments", "waves_per_workgroup", "parallelism", "dp_allreduce", "rccl_ranks",
                                 "native_allreduce_fallback"))
     out.update(_pick(res, ("ns_per_vjp_step", "power_preamble_passes", "forward_solve_ms")))
     if res.get("cold_burst"):
@@ -195,6 +195,20 @@ def supervise():
                 os.unlink(q)
             except OSError:
                 pass
+
+
+def grouped_form(n_traj, segments):
+    """Waves per workgroup of the one-launch pass as the planner chose it (csrc/hipadj_plan.hpp plan_group_choice, mirrored here only to NAME the kernel in the line: the
+    grouped form k_interp_fused_g composes G consecutive segments of a trajectory block through LDS; 0 = the plain k_interp_fused)."""
+    if os.environ.get("HIPADJ_FUSED_GROUP") in ("0", "4", "8"):
+        return int(os.environ["HIPADJ_FUSED_GROUP"])
+    blocks = (n_traj + 63) // 64
+    G, groups = (4, 256 // blocks) if blocks <= 25 else ((8, 256 // blocks) if blocks <= 128 else (4, 512 // blocks))
+    S = int(round(T_FINAL / DT))
+    while groups > 1 and groups * G > S // (10 if G == 8 else 16):
+        groups -= 1
+    groups = min(groups, 16)
+    return G if groups >= 3 and groups * G == segments else 0
 
 
 def inputs(n_total):
@@ -1006,7 +1020,8 @@ def main():
                                    f"InterpolatingAdjoint, fixed-step RK4 dt={DT}, tspan=(0,{T_FINAL}), loss times 0:{SAVE_DT}:{T_FINAL}, "
                                    f"dgdu = u - {LOSS_SHIFT} (BASELINE configs[1])".replace("  ", " "),
                        "ntraj_total": n_total, "ntraj_per_gpu": hi - lo, "rk4_steps": S, "loss_times": len(ts),
-                       "time_segments": st1["time_segments"], "parallelism": f"ensemble-shard x{world}",
+                       "time_segments": st1["time_segments"], "waves_per_workgroup": (grouped_form(hi - lo, st1["time_segments"]) or 1) if one_launch else 1,
+                       "parallelism": f"ensemble-shard x{world}",
                        "dp_allreduce": ("none" if world == 1 else ("rccl on the handle's second stream, overlapped with the next pass (hipadj_comm_overlap)" if getattr(r, "native_overlap", False)
                                                                             else "rccl in-stream (hipadj_comm)") if r.native else "torch.distributed nccl, async"),
                        # ranks the dp all-reduce really spans: ncclCommCount of the handle's communicator (native carrier), or the process group's size
@@ -1020,7 +1035,7 @@ def main():
                                                                 "whole_pass_frac": st1["adjoint_algorithmic_bytes"] / (r.cold_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}),
             "forward_solve_ms": fwd_ms,
             "forward_plus_reverse_ms": (fwd_ms + ms_per_step) if fwd_ms is not None else None,
-            "roofline": {"bound": "hbm", "kernel": "k_interp_fused" if one_launch else "k_interp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("k_interp_fused_g" if grouped_form(hi - lo, st1["time_segments"]) else "k_interp_fused") if one_launch else "k_interp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": "not collected (filled after the timed region at N = 1)",
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
                          "kernel_ms_note": ("one launch per reverse pass: kernel_ms = the timed region's HIP event pair on the launch stream / steps (contains the launch gaps; the kernel "

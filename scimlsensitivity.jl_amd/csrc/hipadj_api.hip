@@ -557,6 +557,9 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     g.N = h->N; g.Npad = Np; g.S = (int)S; g.M = h->M; g.t0 = cfg->t0; g.dt = cfg->dt; g.loss_shift = cfg->loss_shift;
     g.loss_kind = cfg->loss_kind; g.no_start = cfg->no_start; g.p_shared = cfg->p_shared;
     g.kmask = -1; g.h_last = P.h_last;
+#ifdef HIPADJ_PRIO_TOGGLE
+    g.prio_phase = -1;      // only the grouped one-launch pass sets a phase (k_interp_fused_g)
+#endif
     // dgdu = la u + lb c for the kinds that stream a column c: cotangents and model bodies take c itself, HIPADJ_LOSS_LSQ_DATA w (u - c)
     const double lw = cfg->loss_scale != 0.0 ? cfg->loss_scale : 1.0;
     g.la = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? lw : 0.0; g.lb = cfg->loss_kind == HIPADJ_LOSS_LSQ_DATA ? -lw : 1.0;

@@ -190,6 +190,9 @@ __global__ void HIPADJ_KINTERP_ATTR __attribute__((amdgpu_waves_per_eu(2))) __la
     double m[NC * R];
 #pragma unroll
     for (int e = 0; e < NC * R; ++e) m[e] = 0.0;
+#ifdef HIPADJ_PRIO_TOGGLE
+    g.prio_phase = (2 * rank >= sp.nseg) ? 1 : 0;      // the second half of the ranks is dispatched behind the first: the younger wave of every SIMD
+#endif
     if (rank < sp.nseg) {
         const int seg = sp.nseg - 1 - rank;
         HIPADJ_TP(HIPADJ_GTRACE(g), 0, 0);

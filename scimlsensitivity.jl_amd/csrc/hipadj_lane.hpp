@@ -55,6 +55,9 @@ struct Geom {
 
     double h_last;     // length of the LAST forward step [t_{S-1}, T]: = dt, or the remainder when the span is not a multiple of dt (the reference's
                        // fixed-step solve shortens its final step, dt = min(dt, tend - t)); such spans always run the off-grid sweeps
+#ifdef HIPADJ_PRIO_TOGGLE
+    int prio_phase;              // A/B builds only (scripts/r6): 0 / 1 = which of the alternating priority phases this wave starts in, -1 = leave the priority alone
+#endif
 #ifdef HIPADJ_WAVE_TRACE
     unsigned long long* trace;   // development builds only (scripts/r6/wave_trace.py): 32 words per wave of the one-launch pass (time stamps, hardware ids), or null
 #endif
@@ -618,7 +621,15 @@ HIPADJ_HD void reverse_sweep(const Geom& g, long i, int k_lo, int k_hi, const db
     }
     int kb = k_hi - 1;
     HIPADJ_TP(HIPADJ_GTRACE(g), 2, ring[0].u[0]);      // the first knot of the ring has arrived
+#if defined(HIPADJ_PRIO_TOGGLE) && defined(__HIP_DEVICE_COMPILE__)
+    int prio_it = g.prio_phase;
+#endif
     for (; kb - (PF - 1) >= k_lo; kb -= PF) {
+#if defined(HIPADJ_PRIO_TOGGLE) && defined(__HIP_DEVICE_COMPILE__)
+        // A/B: the two waves of a SIMD take turns at the higher issue priority, one block of PF steps each (round 6: the older wave of a SIMD finishes its segment in 67 us,
+        // the younger in 112 us and runs ALONE — at the lone-wave issue rate — for the last 40 %: profiles/r6_wave_trace_10000_hwid.jsonl)
+        if (g.prio_phase >= 0) { if ((prio_it++ >> HIPADJ_PRIO_TOGGLE) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
         int sfl[PF], sfn[PF];       // loss flags of this block and (cotangent prefetch) of the next one: scalar loads up front
 #pragma unroll
         for (int r = 0; r < PF; ++r) {

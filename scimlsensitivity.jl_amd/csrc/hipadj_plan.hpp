@@ -447,6 +447,10 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
             // (Lorenz, stage-operator form of the multi-column step with shared parameters: 263 : 101, profiles/README.md round 2)
             double w_top = 1.0 + 0.8 * n;
             if (cfg->model == HIPADJ_MODEL_LORENZ && cfg->p_shared && cfg->alg == HIPADJ_ALG_INTERPOLATING && cfg->cont_cost == HIPADJ_CCOST_NONE && !cfg->checkpointing) w_top = 2.6;
+            // grouped form with ONE wave per SIMD (G = 4 on a small shard): a lone wave issues one instruction per ~5.5 cycles whatever its kind, so the one-column step is
+            // relatively dearer than its instruction count says — and the top segment's wave is the one that folds its group (1250 trajectories, 48 segments: w_top 1.8 / 2.1 /
+            // 2.4 / 2.6 / 3.0 -> 23.3 / 23.1 / 23.5 / 24.0 / 25.4 us; two waves per SIMD are flat between 1.8 and 2.6: profiles/r6_wtop_grouped.jsonl)
+            if (P.fgroup == 4 && (P.N + 63) / 64 <= 25 && cfg->time_segments == 0) w_top = 2.1;
             if (seg_offgrid) w_top = 1.0 + 0.27 * n;   // the general-theta Hermite evaluations and the cursor walk of a step are shared by its columns, so a 1-column step is relatively dearer (Lorenz, measured: 1.8 best of 1.8 / 2.1 / 2.35 / 2.7 / 3.4)
             if (const char* e = std::getenv("HIPADJ_WTOP")) { const double v = std::atof(e); if (v > 0) w_top = v; }   // tuning hook
             const double unit = (double)L / ((C - 1) + w_top);
