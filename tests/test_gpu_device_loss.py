@@ -346,3 +346,44 @@ def test_multi_handle_refusals_and_wide_models(sa):
         res.append(sa.adjoint_sensitivities(sol, sa.RK4(), t=tsn, dgdu_discrete=delta))
         sol.engine.close()
     assert np.array_equal(res[0][0], res[1][0]) and rel(res[1][1], res[0][1]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_host_pointer_calls_staged_and_direct_agree(sa):
+    """Round 6 (VERDICT r5 next 2): every transfer of the host-pointer calls goes through the handle's own registered staging block (an anonymous mapping with guard pages;
+    csrc/hipadj_api.hip "host-pointer transfers") — HIPADJ_HOST_DIRECT=1 restores round 5's direct pageable copies.  Both modes, in fresh processes (the switch is read once):
+    forward / adjoint / set_loss_data / loss_value on a plain handle, a handle over three virtual shards and a routed dense chain return the same bits; ragged sizes (a block of
+    odd length, N not a multiple of anything) included."""
+    import json, os, subprocess, sys
+    code = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+import scimlsensitivity_jl_amd as sa
+rng = np.random.default_rng(4)
+out = {}
+ts = np.linspace(0.0, 2.0, 21); p = np.array([10.0, 28.0, 8.0 / 3.0])
+for tag, N, kw in (("plain", 777, {}), ("multi", 1001, dict(devices=[0, 0, 0]))):
+    u0 = np.array([1.0, 0.0, 0.0]) + 0.1 * rng.standard_normal((N, 3)); delta = rng.standard_normal((N, len(ts), 3)); data = rng.standard_normal((N, len(ts), 3))
+    eng = sa.Engine("lorenz", "interpolating", N, 0.0, 2.0, 0.01, save_times=ts, loss_kind=0, **kw)
+    o = eng.forward(u0, p); du0, dp = eng.adjoint(delta); eng.close()
+    eng = sa.Engine("lorenz", "gauss", N, 0.0, 2.0, 0.01, save_times=ts, loss_kind=2, loss_scale=2.0, **kw)
+    eng.set_loss_data(data); o2 = eng.forward(u0, p); du1, dp1 = eng.adjoint(None); lv = eng.loss_value(o2); eng.close()
+    out[tag] = [float(np.sum(o * np.arange(o.size).reshape(o.shape) %% 7)), float(du0.sum()), [float(x) for x in dp], float(du1.sum()), [float(x) for x in dp1], lv]
+fun = sa.WideDeviceFunction.dense_chain("stage_chain", (2, 32, 32, 2))
+N = 48; u0 = rng.standard_normal((N, 2)); pc = 0.3 * rng.standard_normal(fun.np); tsc = np.array([0.1, 0.2, 0.3]); delta = rng.standard_normal((N, 3, 2))
+eng = sa.Engine(fun.name, "interpolating", N, 0.0, 0.3, 0.05, save_times=tsc)
+assert eng.stats()["routed_family"] == 3
+o = eng.forward(u0, pc); du0, dp = eng.adjoint(delta); eng.close()
+out["routed"] = [float(o.sum()), float(du0.sum()), float(dp.sum())]
+print(json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("staged", "direct"):
+        env = dict(os.environ)
+        env.pop("HIPADJ_HOST_DIRECT", None)
+        if mode == "direct":
+            env["HIPADJ_HOST_DIRECT"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["staged"] == res["direct"]
