@@ -9,8 +9,11 @@
  * reference itself cannot be executed here; its ODE stepping / dense output / quadrature arithmetic
  * lives in un-vendored packages (OrdinaryDiffEq >= 7, DiffEqCallbacks >= 4.18, QuadGK >= 2.11.3,
  * /root/reference/Project.toml:71,99-109, no Manifest).  This oracle is therefore pinned on
- *   (1) the two literal known answers the reference tests hold for this path
- *       (test/Core7/physical_ode_regression.jl:42-51, test/Core1/sparse_adjoint.jl:32-33),
+ *   (1) the literal known answers the reference tests hold for this path
+ *       (test/Core7/physical_ode_regression.jl:42-51, test/Core1/sparse_adjoint.jl:32-33) and, round 6, the one derivative its tests RECORD for configuration C1:
+ *       d sum(sol) / d p[1] of the Lotka-Volterra problem (Tsit5, saveat 0.1, tolerances 1e-12) written down three times in test/Core6/forward_prob_kwargs.jl:28-30
+ *       (FiniteDiff 8.305557728, ForwardDiff 8.305305252, Zygote 8.305266428) — the oracle's 8.3053626623 (all four sensealgs) lies inside that bracket, 6.9e-6 from
+ *       the ForwardDiff number; the bracket is 3.5e-5 wide, which is all the precision the record has (tests/golden/reference_literals.json, tests/test_oracle.py),
  *   (2) the cross-method relations the reference tests assert (test/Core3/adjoint.jl:366-404,
  *       691-705, 1201-1241; test/Core3/user_vjp.jl:79-113), with scipy DOP853 forward
  *       sensitivities standing in for ForwardDiff (tests/golden/ + tests/golden/make_golden.py).

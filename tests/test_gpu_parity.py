@@ -1691,3 +1691,23 @@ def test_brusselator_gauss_kronrod(sa, cost):
     assert rel(res["gk"][1], res["gauss"][1]) < 1e-5
     with pytest.raises(sa.HipadjError):      # not on the exponential stepper
         sa.Engine("bruss", "gausskronrod", 1, 0.0, 1.0, 0.0125, save_times=[1.0], dims=dims, stepper=2)
+
+
+@pytest.mark.gpu
+def test_device_gradient_of_c1_against_the_literal_the_reference_records(sa):
+    """BASELINE configs[0] through the C ABI — Lotka-Volterra, adaptive Tsit5 at 1e-12, saveat 0.1, loss = sum(sol) — against the derivative the reference's own test file
+    records for it (tests/golden/reference_literals.json, test/Core6/forward_prob_kwargs.jl:28-30): inside the bracket of the reference's three recorded numbers and 1e-5 from
+    its ForwardDiff value; and against the oracle's 8.3053626623 at the parity tolerance."""
+    import json
+    import os
+    case = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_literals.json")))["cases"][0]
+    rec, pb = case["recorded"], case["problem"]
+    ts = np.arange(0, 101) * pb["saveat"]
+    u0 = np.array([pb["u0"]]); p = np.array(pb["p"])
+    for sens in (sa.InterpolatingAdjoint(), sa.BacksolveAdjoint(), sa.GaussAdjoint(), sa.QuadratureAdjoint(abstol=1e-12, reltol=1e-12)):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], tuple(pb["tspan"]), p), u0), sa.Tsit5(), saveat=ts, sensealg=sens, abstol=pb["abstol"], reltol=pb["reltol"])
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=np.ones((1, len(ts), 2)))
+        sol.engine.close()
+        v = float(dp[0])
+        assert min(rec.values()) <= v <= max(rec.values()) and abs(v - rec["ForwardDiff.derivative"]) / rec["ForwardDiff.derivative"] < 1e-5
+        assert abs(v - 8.3053626623) / 8.3053626623 < RTOL
