@@ -67,9 +67,15 @@ typedef enum {
                                         * diffusion term is integrated exactly in the 2-D DFT basis, dt is bound by the reaction terms only — the stiff stepper for the
                                         * horizon the reference documents (docs/src/examples/pde/brusselator.md:115 uses FBDF).  Interpolating-, Gauss- and QuadratureAdjoint,
                                         * loss times on the step grid, cubic-Hermite dense output like RK4_FIXED.  */
-    HIPADJ_STEPPER_TSIT5_ADAPTIVE = 1  /* adaptive Tsit5 with per-trajectory step control and its own interpolant (the stepper of
+    HIPADJ_STEPPER_TSIT5_ADAPTIVE = 1, /* adaptive Tsit5 with per-trajectory step control and its own interpolant (the stepper of
                                           the reference's tests); arbitrary loss times; lane-per-trajectory models; all four
                                           sensealgs (checkpointing=true: Backsolve only) */
+    HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE = 3 /* adaptive Rosenbrock23 (ode23s as OrdinaryDiffEq ships it; test/Core2/stiff_adjoints.jl:53-75): the STIFF stepper of the
+                                          lane-per-trajectory models (compiled-in and runtime-registered, n <= 8) — W = I - d h J factored per lane in registers (J from the
+                                          model's VJP), forward solve AND reverse solve (the adjoint runs with the forward solve's alg, src/sensitivity_interface.jl:487-491;
+                                          the adjoint system's W is block triangular: an n x n solve plus a substitution).  Interpolating-, Gauss-, GaussKronrod- and
+                                          QuadratureAdjoint, arbitrary loss times, no continuous cost; not BacksolveAdjoint, not checkpointing = true; a mass matrix enters through the M^{-1} form
+                                          of the runtime models like everywhere in the lane family.  ABI 109 */
 } hipadj_stepper;
 
 /* how dgdu_discrete(out, u, p, t, i) — and dgdp_discrete — is evaluated at loss time t_i (src/adjoint_common.jl:771-779).  Kinds 1-3 keep the loss ON THE DEVICE:

@@ -35,7 +35,7 @@ sensealgs = Dict(
 function run_case(; name, model, alg, stepper, tspan, dt = nothing, abstol = 1e-6, reltol = 1e-3, saveat, checkpoints = nothing, targets)
     f!, u0, p = models[model]
     prob = ODEProblem(f!, u0, tspan, p)
-    solver = stepper == "RK4" ? RK4() : Tsit5()
+    solver = stepper == "RK4" ? RK4() : stepper == "ROS23" ? Rosenbrock23() : Tsit5()
     skw = stepper == "RK4" ? (dt = dt, adaptive = false) : (abstol = abstol, reltol = reltol)
     sa = sensealgs[alg]
     ts = saveat isa Number ? collect(tspan[1]:saveat:tspan[2]) : collect(saveat)
@@ -186,6 +186,18 @@ let
         push!(cases, Dict("name" => "gauss_literal_$nm", "kind" => "gauss_literal", "model" => "LV", "alg" => nm, "stepper" => "TSIT5", "tspan" => collect(tspan),
                           "abstol" => 1e-12, "reltol" => 1e-12, "ts" => ts, "u0" => u0, "p" => p, "dp_continuous_cost" => vec(collect(dpc)), "dp_discrete_cost" => vec(collect(dpd)),
                           "targets" => "the sign of g_p in the Gauss integrand and the fate of dgdp_discrete under GaussAdjoint: compare with orc_config.reference_literal = 0 / 1"))
+    end
+end
+
+# (10) (round 6) Rosenbrock23, the stiff stepper (test/Core2/stiff_adjoints.jl:66-80): the W-method's stages and its error estimate, the second-order dense output the
+#      reverse pass reads, the PI controller of the implicit algorithms (order 2 exponents, steady band 1 <= q <= 6/5), the initial step with exponent 1/3, dT by finite differences
+#      on the reverse pass (its right-hand side depends on t through the forward interpolant) and — the one the reference's own relation cannot see,
+#      tests/test_stiff_adjoints.py — the coefficient of dT in k3: `forward_steps` and the reverse statistics decide between `d h dT` (restated) and `h dT`.
+for alg in ("INTERPOLATING", "GAUSS", "GAUSS_KRONROD", "QUADRATURE")
+    for (tag, tol) in (("1e-6", 1e-6), ("1e-8", 1e-8))
+        push!(cases, run_case(name = "ros23_lvt_$(tag)_$alg", model = "LVT", alg = alg, stepper = "ROS23", tspan = (0.0, 10.0), abstol = tol, reltol = tol, saveat = 0.5,
+            targets = "Rosenbrock23 stages / error estimate / dense output, PI controller at order 2 with the steady band, initial step exponent 1/3, finite-difference dT, " *
+                      "Gauss node count div(2 + 1, 2) = 1 per step, the coefficient of dT in k3"))
     end
 end
 

@@ -26,9 +26,9 @@
 
 /* [upstream-recall] constants as data (orc_test_set_recall, adjoint_oracle.h): what the restatement assumes about the un-vendored packages.  The
  * defaults are the restatement; tests/test_recall_sensitivity.py perturbs one at a time and records which reference-held relation would notice. */
-static double g_recall[ORC_RECALL_COUNT] = {2, 3, 1e-7, 10.0, 0.2, 0.9, 7.0 / 50.0, 2.0 / 25.0, 1, 7};
+static double g_recall[ORC_RECALL_COUNT] = {2, 3, 1e-7, 10.0, 0.2, 0.9, 7.0 / 50.0, 2.0 / 25.0, 1, 7, 0.29289321881345247560};
 int orc_test_set_recall(int which, double value) {
-    static const double dflt[ORC_RECALL_COUNT] = {2, 3, 1e-7, 10.0, 0.2, 0.9, 7.0 / 50.0, 2.0 / 25.0, 1, 7};
+    static const double dflt[ORC_RECALL_COUNT] = {2, 3, 1e-7, 10.0, 0.2, 0.9, 7.0 / 50.0, 2.0 / 25.0, 1, 7, 0.29289321881345247560};
     if (which < 0) { memcpy(g_recall, dflt, sizeof dflt); return 0; }        /* reset all */
     if (which >= ORC_RECALL_COUNT) return -1;
     g_recall[which] = value; return 0;
@@ -462,6 +462,10 @@ double orc_test_tsit5_order_residual(void) {
 }
 
 typedef void (*orc_rhs)(double *du, const double *u, double t, void *ctx);
+/* Jacobian of a right-hand side with respect to its state at (u, t): J[r * n + c] = d rhs_r / d u_c (Rosenbrock23 only) */
+typedef void (*orc_jac)(double *J, const double *u, double t, void *ctx, int n);
+#define ROS_D 0.29289321881345247560      /* 1 / (2 + sqrt 2) */
+#define ROS_E32 7.41421356237309504880    /* 6 + sqrt 2 */
 
 /* one accepted step of a dense solution */
 typedef struct {
@@ -480,7 +484,7 @@ typedef struct {
 static __thread orc_dense tls_pool[ORC_DENSE_POOL];
 static __thread int tls_pool_used[ORC_DENSE_POOL];
 static void dense_init(orc_dense *d, int n, int kind) {
-    int nk = (kind == ORC_STEPPER_TSIT5) ? 7 : 2;
+    int nk = (kind == ORC_STEPPER_TSIT5) ? 7 : 2;      /* (Rosenbrock23: k1, k2) */
     for (int i = 0; i < ORC_DENSE_POOL; ++i)
         if (tls_pool_used[i] == 1 && tls_pool[i].n == n && tls_pool[i].nk == nk) {
             *d = tls_pool[i]; tls_pool_used[i] = 0; d->kind = kind; d->nsteps = 0; return;
@@ -516,6 +520,10 @@ static void dense_eval_step(const orc_dense *d, long s, double t, double *y) {
     if (d->kind == ORC_STEPPER_TSIT5) {
         double b[7]; tsit5_bweights(th, b);
         for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < 7; ++j) acc += b[j] * k[j * n + i]; y[i] = u0[i] + h * acc; }
+    } else if (d->kind == ORC_STEPPER_ROS23) {
+        /* Rosenbrock23's own dense output [upstream-recall]: u(th) = u0 + h (c1 k1 + c2 k2), c1 = th (1 - th) / (1 - 2 d), c2 = th (th - 2 d) / (1 - 2 d) */
+        const double c1 = th * (1 - th) / (1 - 2 * ROS_D), c2 = th * (th - 2 * ROS_D) / (1 - 2 * ROS_D);
+        for (int i = 0; i < n; ++i) y[i] = u0[i] + h * (c1 * k[i] + c2 * k[n + i]);
     } else {
         for (int i = 0; i < n; ++i)
             y[i] = (1 - th) * u0[i] + th * u1[i] + th * (th - 1) * ((1 - 2 * th) * (u1[i] - u0[i]) + (th - 1) * h * k[i] + th * h * k[n + i]);
@@ -560,6 +568,9 @@ typedef struct {
     /* ORC_STEPPER_ETDRK4: dz/dt = M z + N(z, t) with M = split_coef * (periodic 5-point Laplacian on a split_G x split_G grid, unscaled) on each of the two leading
      * species blocks of z (2 G^2 components) and M = 0 on the rest (the parameter-gradient block of the Interpolating adjoint) */
     int split_G; double split_coef;
+    /* ORC_STEPPER_ROS23: the Jacobian of the right-hand side; jac == NULL: the right-hand side is AFFINE in its state (every adjoint system is: lam' = -J(y(t))' lam - g_u,
+     * grad' = -f_p' lam - g_p), so column c of its Jacobian is rhs(e_c, t) - rhs(0, t) exactly.  autonomous != 0: no explicit time dependence (dT = 0). */
+    orc_jac jac; int autonomous;
 } orc_alg;
 
 /* -------------------------------------------------------------------------------------
@@ -653,6 +664,9 @@ static void integ_interp(const orc_integ *I, double t, double *y) {
     if (I->kind == ORC_STEPPER_TSIT5) {
         double b[7]; tsit5_bweights(th, b);
         for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < 7; ++j) acc += b[j] * I->k[j * n + i]; y[i] = I->uprev[i] + h * acc; }
+    } else if (I->kind == ORC_STEPPER_ROS23) {
+        const double c1 = th * (1 - th) / (1 - 2 * ROS_D), c2 = th * (th - 2 * ROS_D) / (1 - 2 * ROS_D);
+        for (int i = 0; i < n; ++i) y[i] = I->uprev[i] + h * (c1 * I->k[i] + c2 * I->k[n + i]);
     } else {
         for (int i = 0; i < n; ++i)
             y[i] = (1 - th) * I->uprev[i] + th * I->u[i] +
@@ -678,7 +692,7 @@ static double initial_dt(orc_integ *I, const orc_alg *alg, double tend) {
     double d2 = 0;
     for (int i = 0; i < n; ++i) { double sc = alg->abstol + fabs(I->u[i]) * alg->reltol; double q = (f1[i] - f0[i]) / sc; d2 += q * q; }
     d2 = sqrt(d2 / n) / h0;
-    double h1 = (fmax(d1, d2) <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+    double h1 = (fmax(d1, d2) <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / (alg->kind == ORC_STEPPER_ROS23 ? 3.0 : 5.0));   /* 1 / (order + 1) */
     return fmin(fmin(100 * h0, h1), fabs(tend - I->t));
 }
 
@@ -700,8 +714,11 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
     double *buf = (double *)calloc((size_t)n * (5 + ORC_MAXK + 1), sizeof(double));
     I.uprev = buf; I.tmp = buf + n; I.utilde = buf + 2 * n; I.fsal = buf + 3 * n; I.k = buf + 4 * n;
     double *us = buf + (size_t)n * (4 + ORC_MAXK + 1);
-    int adaptive = (alg->kind == ORC_STEPPER_TSIT5);
+    int ros = (alg->kind == ORC_STEPPER_ROS23);
+    int adaptive = (alg->kind == ORC_STEPPER_TSIT5) || ros;
     int etd = (alg->kind == ORC_STEPPER_ETDRK4);
+    double *rw = ros ? (double *)calloc((size_t)n * n * 2 + (size_t)n * 8, sizeof(double)) : NULL;   /* J, LU, then dT, f1, k3, b, z0, r0, r1, scratch */
+    int *rpiv = ros ? (int *)calloc((size_t)n * n, sizeof(int)) : NULL;      /* exchange flags (column, row) */
     int status = 0;
     etd_ws W; memset(&W, 0, sizeof(W));
     double *eb = NULL;
@@ -804,6 +821,82 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
             rhs(k + n, I.u, tnew, ctx); I.nrhs++;               /* fsallast */
             memcpy(I.fsal, k + n, sizeof(double) * n);
             I.tprev = t; I.t = tnew; I.naccept++;
+        } else if (ros) {
+            /* Rosenbrock23 (OrdinaryDiffEq's perform_step!, mass matrix I) [upstream-recall]:
+             *   W = I - d h J(u_n, t_n),  k1 = W \ (f0 + d h dT),  f1 = f(u_n + h/2 k1, t_n + h/2),  k2 = W \ (f1 - k1) + k1,  u_{n+1} = u_n + h k2,
+             *   f2 = f(u_{n+1}, t_n + h),  k3 = W \ (f2 - e32 (k2 - f1) - 2 (k1 - f0) + d h dT),  err = h/6 (k1 - 2 k2 + k3);
+             * (the coefficient of dT in k3 is ORC_RECALL_ROS_K3_T: d as in Shampine-Reichelt's ode23s, which makes err third order in h for non-autonomous systems — every reverse
+             *  pass is one; 1 is the other reading of the upstream source and costs 10-270 x the reverse steps for the same gradients, tests/test_stiff_adjoints.py)
+             * dT = d rhs / dt by a forward difference (FiniteDiff's default step sqrt(eps) max(1, |t|), taken along the direction of integration), 0 for autonomous systems;
+             * controller: PI with beta1 = 7 / (10 order), beta2 = 2 / (5 order), order 2, the implicit algorithms' steady band 1 <= q <= 6/5 -> q = 1. */
+            double *J = rw, *LU = rw + (size_t)n * n, *dT = LU + (size_t)n * n, *f1 = dT + n, *k3 = f1 + n, *b = k3 + n, *z0 = b + n, *r0 = z0 + n, *e1 = r0 + n;
+            double *k1 = k, *k2 = k + n;
+            const double gh = ROS_D * dt;
+            if (alg->jac) alg->jac(J, I.uprev, t, ctx, n);
+            else {
+                for (int i = 0; i < n; ++i) z0[i] = 0.0;
+                rhs(r0, z0, t, ctx); I.nrhs++;
+                for (int c = 0; c < n; ++c) {
+                    for (int i = 0; i < n; ++i) z0[i] = (i == c) ? 1.0 : 0.0;
+                    rhs(e1, z0, t, ctx); I.nrhs++;
+                    for (int r = 0; r < n; ++r) J[(size_t)r * n + c] = e1[r] - r0[r];
+                }
+            }
+            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) LU[(size_t)r * n + c] = (r == c ? 1.0 : 0.0) - gh * J[(size_t)r * n + c];
+            /* LU with partial pivoting by successive exchange (the device's unrolled form: row i > c is swapped up whenever its entry is larger) */
+            for (int c = 0; c < n; ++c) {
+                for (int i = c + 1; i < n; ++i) {
+                    int x = fabs(LU[(size_t)i * n + c]) > fabs(LU[(size_t)c * n + c]);
+                    rpiv[(size_t)c * n + i] = x;
+                    if (x) for (int j = 0; j < n; ++j) { double tmp = LU[(size_t)c * n + j]; LU[(size_t)c * n + j] = LU[(size_t)i * n + j]; LU[(size_t)i * n + j] = tmp; }
+                }
+                double inv = 1.0 / LU[(size_t)c * n + c];
+                for (int i = c + 1; i < n; ++i) {
+                    double l = LU[(size_t)i * n + c] * inv; LU[(size_t)i * n + c] = l;
+                    for (int j = c + 1; j < n; ++j) LU[(size_t)i * n + j] -= l * LU[(size_t)c * n + j];
+                }
+            }
+#define ROS_SOLVE(x) do { for (int c_ = 0; c_ < n; ++c_) for (int i_ = c_ + 1; i_ < n; ++i_) if (rpiv[(size_t)c_ * n + i_]) { double t_ = (x)[c_]; (x)[c_] = (x)[i_]; (x)[i_] = t_; } \
+                          for (int i_ = 1; i_ < n; ++i_) { double s_ = (x)[i_]; for (int j_ = 0; j_ < i_; ++j_) s_ -= LU[(size_t)i_ * n + j_] * (x)[j_]; (x)[i_] = s_; } \
+                          for (int i_ = n - 1; i_ >= 0; --i_) { double s_ = (x)[i_]; for (int j_ = i_ + 1; j_ < n; ++j_) s_ -= LU[(size_t)i_ * n + j_] * (x)[j_]; (x)[i_] = s_ / LU[(size_t)i_ * n + i_]; } } while (0)
+            if (alg->autonomous) for (int i = 0; i < n; ++i) dT[i] = 0.0;
+            else {
+                const double del = I.tdir * 1.4901161193847656e-08 * fmax(1.0, fabs(t));
+                rhs(dT, I.uprev, t + del, ctx); I.nrhs++;
+                for (int i = 0; i < n; ++i) dT[i] = (dT[i] - I.fsal[i]) / del;
+            }
+            for (int i = 0; i < n; ++i) b[i] = I.fsal[i] + gh * dT[i];
+            ROS_SOLVE(b);
+            for (int i = 0; i < n; ++i) { k1[i] = b[i]; us[i] = I.uprev[i] + 0.5 * dt * k1[i]; }
+            rhs(f1, us, t + 0.5 * dt, ctx); I.nrhs++;
+            for (int i = 0; i < n; ++i) b[i] = f1[i] - k1[i];
+            ROS_SOLVE(b);
+            for (int i = 0; i < n; ++i) { k2[i] = b[i] + k1[i]; I.u[i] = I.uprev[i] + dt * k2[i]; }
+            rhs(I.tmp, I.u, t + dt, ctx); I.nrhs++;                        /* f2 = fsallast */
+            for (int i = 0; i < n; ++i) b[i] = I.tmp[i] - ROS_E32 * (k2[i] - f1[i]) - 2.0 * (k1[i] - I.fsal[i]) + g_recall[ORC_RECALL_ROS_K3_T] * dt * dT[i];
+            ROS_SOLVE(b);
+#undef ROS_SOLVE
+            for (int i = 0; i < n; ++i) { k3[i] = b[i]; I.utilde[i] = dt / 6.0 * (k1[i] - 2.0 * k2[i] + k3[i]); }
+            double EEst = scaled_norm(I.utilde, I.uprev, I.u, n, alg->abstol, alg->reltol);
+            const double beta1 = 7.0 / 20.0, beta2 = 1.0 / 5.0;
+            double q11 = pow(fmax(EEst, 1e-300), beta1);
+            double q = q11 / pow(qold, beta2);
+            q = fmax(1.0 / g_recall[ORC_RECALL_QMAX], fmin(1.0 / g_recall[ORC_RECALL_QMIN], q / g_recall[ORC_RECALL_GAMMA]));
+            if (EEst <= 1.0 || fabs(dt) < 1e-14 * fmax(1.0, fabs(t))) {
+                double tnew = t + dt;
+                if (fabs(tnew - tstop) < 100 * DBL_EPSILON * fmax(fabs(tnew), fabs(tstop))) tnew = tstop;
+                if (q >= 1.0 && q <= 1.2) q = 1.0;                         /* qsteady_min = 1, qsteady_max = 6/5 for the adaptive implicit algorithms */
+                qold = fmax(EEst, 1e-4);
+                memcpy(I.fsal, I.tmp, sizeof(double) * n);
+                I.tprev = t; I.t = tnew; I.naccept++;
+                I.dt = dt / q;
+                if (fabs(I.dt) < 1e-14 * fmax(1.0, fabs(tnew))) I.dt = I.tdir * 1e-14 * fmax(1.0, fabs(tnew));
+            } else {
+                memcpy(I.u, I.uprev, sizeof(double) * n);
+                I.dt = dt / fmin(1.0 / g_recall[ORC_RECALL_QMIN], q11 / g_recall[ORC_RECALL_GAMMA]);
+                I.nreject++;
+                continue;
+            }
         } else {
             memcpy(k, I.fsal, sizeof(double) * n);
             for (int s = 1; s < 7; ++s) {
@@ -839,7 +932,7 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
     }
     if (nrhs_out) *nrhs_out += I.nrhs;
     if (getenv("ORC_TRACE_STEPS")) fprintf(stderr, "orc integrate: %s accepted %ld rejected %ld rhs %ld\n", I.tdir < 0 ? "reverse" : "forward", I.naccept, I.nreject, I.nrhs);   /* debugging aid: step statistics */
-    free(ts); free(buf); free(eb);
+    free(ts); free(buf); free(eb); free(rw); free(rpiv);
     return status;
 }
 
@@ -849,9 +942,27 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
 typedef struct { const orc_model *m; const double *p; } fwd_ctx;
 static void fwd_rhs(double *du, const double *u, double t, void *c) { fwd_ctx *f = (fwd_ctx *)c; model_f(f->m, du, u, f->p, t); mm_solve(g_mm_inv, f->m->n, du); }
 
+/* d f / d u of the forward problem from the model's VJP: (df/du)' e_r is row r of the Jacobian (mass matrix: rows of M^{-1} J by the same solve as fwd_rhs) */
+static void fwd_jac(double *J, const double *u, double t, void *c, int n) {
+    fwd_ctx *f = (fwd_ctx *)c;
+    double *e = (double *)calloc((size_t)2 * n, sizeof(double)), *row = e + n;
+    for (int r = 0; r < n; ++r) {
+        for (int i = 0; i < n; ++i) e[i] = (i == r) ? 1.0 : 0.0;
+        model_vjp(f->m, row, NULL, e, u, f->p, t);
+        for (int cidx = 0; cidx < n; ++cidx) J[(size_t)r * n + cidx] = row[cidx];
+    }
+    if (g_mm_n == n) for (int cidx = 0; cidx < n; ++cidx) {                 /* column by column: M^{-1} J */
+        for (int r = 0; r < n; ++r) e[r] = J[(size_t)r * n + cidx];
+        mm_solve(g_mm_inv, n, e);
+        for (int r = 0; r < n; ++r) J[(size_t)r * n + cidx] = e[r];
+    }
+    free(e);
+}
+static int model_autonomous(const orc_model *m) { return m->id != ORC_MODEL_LVT && m->id != ORC_MODEL_BRUSS; }
+
 static orc_alg make_alg(const orc_config *cfg) {
     orc_alg a; a.kind = cfg->stepper; a.dt = cfg->dt; a.abstol = cfg->abstol > 0 ? cfg->abstol : 1e-6; a.reltol = cfg->reltol > 0 ? cfg->reltol : 1e-3;
-    a.split_G = 0; a.split_coef = 0.0;
+    a.split_G = 0; a.split_coef = 0.0; a.jac = NULL; a.autonomous = 0;
     return a;
 }
 
@@ -865,7 +976,8 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
      * with L = interval length and m = L/dt steps the recursion dt' = L - (m-1) dt amplifies the roundoff of the
      * snapped last step by (m-1) per interval and the step size degenerates after a few intervals (observed here:
      * 49^19 * 1e-15).  In exact arithmetic dt' == dt, so the oracle keeps the user's dt for fixed-step re-solves. */
-    if (dt_hint > 0 && cfg->stepper == ORC_STEPPER_TSIT5) a.dt = dt_hint;
+    if (dt_hint > 0 && (cfg->stepper == ORC_STEPPER_TSIT5 || cfg->stepper == ORC_STEPPER_ROS23)) a.dt = dt_hint;
+    if (cfg->stepper == ORC_STEPPER_ROS23) { a.jac = fwd_jac; a.autonomous = model_autonomous(m); }
     dense_init(sol, m->n, cfg->stepper);                        /* before any early return: the callers release `sol` on every path */
     if (cfg->stepper == ORC_STEPPER_ETDRK4) {                   /* u' = (alpha/dx^2) L u + N(u, t) */
         if (m->id != ORC_MODEL_BRUSS) return -6;
@@ -1108,8 +1220,10 @@ static void gauss_integrand(adj_ctx *A, double *out, double t, const double *lam
 static void gauss_step(adj_ctx *A, orc_integ *I) {
     static const double x2[2] = {-0.5773502691896257645, 0.5773502691896257645}, w2[2] = {1.0, 1.0};
     static const double x3[3] = {-0.7745966692414833770, 0.0, 0.7745966692414833770}, w3[3] = {5.0 / 9, 8.0 / 9, 5.0 / 9};
+    static const double x1[1] = {0.0}, w1[1] = {2.0};
     int ng = (int)g_recall[(I->kind == ORC_STEPPER_TSIT5) ? ORC_RECALL_GAUSS_NODES_TSIT5 : ORC_RECALL_GAUSS_NODES_RK4];
-    const double *x = ng == 3 ? x3 : x2, *w = ng == 3 ? w3 : w2;
+    if (I->kind == ORC_STEPPER_ROS23) ng = 1;                 /* div(order + 1, 2) with order 2: the midpoint rule [upstream-recall] */
+    const double *x = ng == 3 ? x3 : (ng == 1 ? x1 : x2), *w = ng == 3 ? w3 : (ng == 1 ? w1 : w2);
     double half = 0.5 * (I->t - I->tprev), mid = 0.5 * (I->t + I->tprev);
     double *lam = A->scratch, *out = A->scratch + A->n;
     for (int g = 0; g < ng; ++g) {
@@ -1260,6 +1374,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
      * Interpolating / Quadrature), so the sign is not restated here */
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
+    if (cfg->stepper == ORC_STEPPER_ROS23 && (cfg->alg == ORC_ALG_BACKSOLVE || cfg->checkpointing)) return -6;   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
     orc_dense sol; double *uend = (double *)malloc(sizeof(double) * n); memcpy(uend, u0, sizeof(double) * n);

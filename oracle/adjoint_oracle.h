@@ -54,6 +54,9 @@ enum {
 enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3,
        ORC_ALG_GAUSS_KRONROD = 4 /* [upstream-recall] per-step adaptive GK(7,15): parity UNPINNED beyond GaussKronrod == Gauss */ };
 enum { ORC_STEPPER_RK4 = 0, ORC_STEPPER_TSIT5 = 1,
+       ORC_STEPPER_ROS23 = 3,      /* adaptive Rosenbrock23 (Shampine & Reichelt's ode23s as OrdinaryDiffEq ships it [upstream-recall]): the stiff stepper of
+                                      test/Core2/stiff_adjoints.jl:53-75; forward solve and the Interpolating / Gauss / GaussKronrod / Quadrature reverse solves (the adjoint runs
+                                      with the forward solve's alg, src/sensitivity_interface.jl:487-491); not BacksolveAdjoint, not checkpointing = true */
        ORC_STEPPER_ETDRK4 = 2 };   /* fixed-step exponential RK4 (Cox & Matthews 2002) for the semilinear PDE model: u' = alpha/dx^2 L u + N(u, t), the periodic
                                     * Laplacian L diagonalised by the 2-D DFT, phi-functions per mode; ORC_MODEL_BRUSS with a power-of-two grid only (adjoint_oracle.c 2b) */
 enum { ORC_LOSS_COTANGENT = 0, ORC_LOSS_LSQ_SHIFT = 1,
@@ -127,7 +130,8 @@ enum { ORC_RECALL_GAUSS_NODES_RK4 = 0,   /* IntegratingSumCallback nodes per ste
        ORC_RECALL_QMAX = 3, ORC_RECALL_QMIN = 4, ORC_RECALL_GAMMA = 5, ORC_RECALL_BETA1 = 6, ORC_RECALL_BETA2 = 7,   /* PI controller 10, 1/5, 9/10, 7/50, 2/25 */
        ORC_RECALL_PRESET_AT_INIT = 8,    /* PresetTimeCallback fires during initialisation when T is a preset time (1) */
        ORC_RECALL_QUADGK_ORDER = 9,      /* QuadGK order 7 (the (7,15) pair); reserved: the tables hold that pair only */
-       ORC_RECALL_COUNT = 10 };
+       ORC_RECALL_ROS_K3_T = 10,         /* Rosenbrock23: coefficient of h dT in k3 (error estimate only): d = 1 / (2 + sqrt 2) (Shampine-Reichelt); the alternative reading is 1 */
+       ORC_RECALL_COUNT = 11 };
 int orc_test_set_recall(int which, double value);
 
 /* adaptive Gauss-Kronrod (7,15) on a polynomial test integrand, for pinning the quadrature rule */

@@ -873,8 +873,9 @@ static UserKernels user_kernel_names(const hipadj_handle* h) {
     const std::string finish = "hipadj::k_finish<" + I(n) + ", " + I(np) + ">";
     const std::string compose = seg ? "hipadj::k_compose_finish<" + U + ">" : "hipadj::k_finish_map<" + I(n) + ", " + I(np) + ">";
     if (h->adaptive) {
-        k.forward = "hipadj::k_forward_tsit5<" + U + ">";
-        k.main_k = "hipadj::k_adjoint_tsit5<" + U + ", " + I(h->cfg.alg) + ", " + I(cc) + (h->ip_ckpt ? ", true>" : ", false>");
+        const bool ros = h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE;      // same kernels, STEP = 1 (ros23_integrate)
+        k.forward = "hipadj::k_forward_tsit5<" + U + (ros ? ", 1>" : ", 0>");
+        k.main_k = "hipadj::k_adjoint_tsit5<" + U + ", " + I(h->cfg.alg) + ", " + I(cc) + (h->ip_ckpt ? ", true" : ", false") + (ros ? ", 1>" : ", 0>");
         if (h->cfg.alg == HIPADJ_ALG_QUADRATURE) k.gk = "hipadj::k_quad_gk_tsit5<" + U + ", " + I(cc) + ">";
         k.tail = finish;
         return k;

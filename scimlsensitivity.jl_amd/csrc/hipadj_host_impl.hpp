@@ -650,7 +650,10 @@ template <class Mo> int adaptive_forward(hipadj_handle* h, const double* d_u0, c
     const bool sized = h->auto_steps && h->cfg.alg != HIPADJ_ALG_BACKSOLVE;
     if (sized && h->ip_ckpt) h->ag.SmaxI = (int)h->rec_cap;
     for (int pass = 0; pass < 2; ++pass) {
-        if (h->quad_fwd && QuadForm<Mo>::value)      // four lanes per trajectory (hipadj_quad_ts5.hpp): same records, a third of the instructions per wave
+        if (h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE)      // the stiff stepper: same records, ros23_integrate (hipadj_adaptive.hpp)
+            hipLaunchKernelGGL((k_forward_tsit5<Mo, 1>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->d_rec, h->d_nsteps,
+                               (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
+        else if (h->quad_fwd && QuadForm<Mo>::value)      // four lanes per trajectory (hipadj_quad_ts5.hpp): same records, a third of the instructions per wave
             hipLaunchKernelGGL((k_forward_tsit5_quad<Mo>), dim3((unsigned)((h->N + 15) / 16)), dim3(WAVE), 0, h->stream, h->ag, d_u0, d_p, h->ip_ckpt ? (double*)nullptr : h->d_rec, h->d_nsteps,
                                (const double*)h->d_save_t, (d_out && h->M > 0) ? h->d_outT : (double*)nullptr, (const double*)h->d_ck_t, h->d_ckpt, h->d_yT, h->d_flag);
         else
@@ -665,7 +668,7 @@ template <class Mo> int adaptive_forward(hipadj_handle* h, const double* d_u0, c
     if (d_out && h->M > 0) TRY(launch_transpose_to_aos(h, h->d_outT, d_out, h->M * h->n));
     return HIPADJ_OK;
 }
-template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+template <class Mo, int ALG, int CC, bool CK = false, int STEP = 0> int adaptive_adjoint_l(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
     const unsigned waves = (unsigned)(h->Npad / WAVE);
     const unsigned fblocks = (unsigned)((h->N + FIN - 1) / FIN);
     double* dp_rows = h->cfg.p_shared ? (double*)nullptr : d_dp;
@@ -679,14 +682,14 @@ template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hip
     if (h->timing >= 2) HIP_TRY(h, hipEventRecord(es.a0, h->stream));
     if (h->timing >= 1) HIP_TRY(h, hipEventRecord(es.k0, h->stream));
     for (int pass = 0; pass < 2; ++pass) {
-        constexpr bool QUAD_OK = QuadAdj<Mo>::value && CC == 0 && !CK && (ALG == 0 || ALG == 1 || ALG == 2);
+        constexpr bool QUAD_OK = QuadAdj<Mo>::value && CC == 0 && !CK && STEP == 0 && (ALG == 0 || ALG == 1 || ALG == 2);
         if (QUAD_OK && h->quad_adj) {
             if constexpr (QUAD_OK)
                 hipLaunchKernelGGL((k_adjoint_tsit5_quad<Mo, ALG>), dim3((unsigned)((h->N + 15) / 16)), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
                                    (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
                                    (const double*)h->d_tstops, h->ntstops, cotT, d_du0, h->d_dp_traj, h->d_flag);
         } else
-        hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
+        hipLaunchKernelGGL((k_adjoint_tsit5<Mo, ALG, CC, CK, STEP>), dim3(waves), dim3(WAVE), 0, h->stream, h->ag, h->p_dev_last, (const double*)h->d_rec,
                            (const int*)h->d_nsteps, (const double*)h->d_yT, (const double*)h->d_ckpt, (const double*)h->d_ck_t, (const double*)h->d_save_t,
                            (const double*)h->d_tstops, h->ntstops, cotT, d_du0, h->d_dp_traj, h->d_flag,
                            h->d_arec, h->d_nsteps_adj, h->SmaxA);
@@ -717,6 +720,15 @@ template <class Mo, int ALG, int CC, bool CK = false> int adaptive_adjoint_l(hip
     return HIPADJ_OK;
 }
 template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
+    if (h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the planner admitted: no Backsolve, no checkpointing, no cost
+        switch (h->cfg.alg) {
+        case HIPADJ_ALG_INTERPOLATING: return adaptive_adjoint_l<Mo, 0, 0, false, 1>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS: return adaptive_adjoint_l<Mo, 2, 0, false, 1>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_QUADRATURE: return adaptive_adjoint_l<Mo, 3, 0, false, 1>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS_KRONROD: return adaptive_adjoint_l<Mo, 4, 0, false, 1>(h, d_cot, d_du0, d_dp);
+        default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "Rosenbrock23: sensealg %d has no device kernel", h->cfg.alg);
+        }
+    }
     if (h->ip_ckpt) {   // checkpointing=true for Interpolating / Gauss: per-interval re-solve inside the sweep
         switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
         case HIPADJ_ALG_INTERPOLATING * 4 + 0: return adaptive_adjoint_l<Mo, 0, 0, true>(h, d_cot, d_du0, d_dp);

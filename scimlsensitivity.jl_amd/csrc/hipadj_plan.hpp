@@ -230,13 +230,20 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_GAUSS_KRONROD) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (P.mlp || (P.field && cfg->stepper != HIPADJ_STEPPER_RK4_FIXED))) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory, wide and (RK4) PDE families"; return HIPADJ_ERR_UNSUPPORTED; }
-    if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ETDRK4_FIXED) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ETDRK4_FIXED && cfg->stepper != HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
+    if (cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the stiff stepper of the lane family (hipadj_adaptive.hpp ros23_integrate): planned like adaptive Tsit5 below
+        if (!plan_small_model(cfg->model) || P.wide) { err = "Rosenbrock23 is available for the lane-per-trajectory models (n <= 8)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "Rosenbrock23: Interpolating-, Gauss-, GaussKronrod- and QuadratureAdjoint (the backsolved system is not affine in its state; BacksolveAdjoint of a stiff problem is unstable anyway, src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->checkpointing) { err = "Rosenbrock23: checkpointing = true is not offered (the dense forward solution is kept)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "Rosenbrock23: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->loss_kind == HIPADJ_LOSS_MODEL) { err = "Rosenbrock23: discrete losses by cotangents, HIPADJ_LOSS_LSQ_SHIFT or HIPADJ_LOSS_LSQ_DATA"; return HIPADJ_ERR_UNSUPPORTED; }
+    }
     if (cfg->stepper == HIPADJ_STEPPER_ETDRK4_FIXED) {   // the exponential stepper: everything below treats it as a fixed-step scheme with Hermite dense output
         if (!P.field) { err = "HIPADJ_STEPPER_ETDRK4_FIXED integrates the semilinear PDE family (HIPADJ_MODEL_BRUSS): its linear part is diagonal in the DFT basis"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg != HIPADJ_ALG_INTERPOLATING && cfg->alg != HIPADJ_ALG_QUADRATURE && cfg->alg != HIPADJ_ALG_GAUSS) { err = "HIPADJ_STEPPER_ETDRK4_FIXED: Interpolating-, Gauss- and QuadratureAdjoint"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->cont_cost != 0) { err = "HIPADJ_STEPPER_ETDRK4_FIXED: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
     }
-    if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE) {
+    if (cfg->stepper == HIPADJ_STEPPER_TSIT5_ADAPTIVE || cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {
         // adaptive path: no step grid; arbitrary ascending loss times inside [t0, t1]
         if (!plan_small_model(cfg->model)) { err = "adaptive Tsit5 is available for the lane-per-trajectory models"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg == HIPADJ_ALG_QUADRATURE && cfg->checkpointing) { err = "QuadratureAdjoint has no checkpointing (src/sensitivity_algorithms.jl:1665-1677)"; return HIPADJ_ERR_INVALID_ARG; }

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Engine
-from .problems import (RK4, ETDRK4, Tsit5, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, LsqData, ModelLoss, HalfSquaredSum,
+from .problems import (RK4, ETDRK4, Tsit5, Rosenbrock23, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, LsqData, ModelLoss, HalfSquaredSum,
                        FirstStateSquaredPlusFirstParam, ModelCost)
 from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
                                      QuadratureAdjoint, GaussAdjoint, GaussKronrodAdjoint, ischeckpointing)
@@ -88,7 +88,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     interpolant tiles (Interpolating/Gauss/Quadrature) or checkpoints (Backsolve) the reverse pass consumes.
     `dgdu_discrete` may be given here already (LsqShift or None = cotangents) because the fused reverse kernel
     is specialised on it at handle creation; likewise the continuous cost `g` (HalfSquaredSum() or None).
-    alg = RK4(): fixed step `dt` (required).  alg = Tsit5(): adaptive, `abstol`/`reltol` are used for the forward AND
+    alg = RK4(): fixed step `dt` (required).  alg = Tsit5() or Rosenbrock23() (the stiff stepper of the lane family): adaptive, `abstol`/`reltol` are used for the forward AND
     the reverse solve (src/sensitivity_interface.jl:432), `dt` is the optional initial-step hint, `saveat` may hold
     arbitrary ascending times, `max_steps` bounds the accepted steps per trajectory (0 = sized automatically by a counting pass of the forward solve).
     `save_idxs` (src/concrete_solve.jl:733-736, 774-824): only those state components appear in `sol.u`; cotangents handed to
@@ -109,9 +109,9 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
         return events.solve_with_events(solve, _save_times, ensprob, alg, callback, dt=dt, saveat=saveat, sensealg=sensealg, dgdu_discrete=dgdu_discrete, checkpoints=checkpoints,
                                         device=device, time_segments=time_segments, g=g, abstol=abstol, reltol=reltol, max_steps=max_steps, save_idxs=save_idxs,
                                         save_start=save_start, save_end=save_end, save_everystep=save_everystep)
-    adaptive = isinstance(alg, Tsit5)
+    adaptive = isinstance(alg, (Tsit5, Rosenbrock23))
     if not adaptive and not isinstance(alg, (RK4, ETDRK4)):
-        raise ValueError("alg must be RK4() / ETDRK4() (fixed step) or Tsit5() (adaptive)")
+        raise ValueError("alg must be RK4() / ETDRK4() (fixed step) or Tsit5() / Rosenbrock23() (adaptive)")
     if not adaptive and dt is None:
         raise ValueError("a fixed-step alg (RK4(), ETDRK4()) needs dt")
     if dt is None:
@@ -138,7 +138,7 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     eng = Engine(prob.f, sensealg.name, ensprob.u0.shape[0], prob.tspan[0], prob.tspan[1], dt, save_times=ts,
                  loss_kind=loss_kind, loss_shift=shift, loss_scale=scale, devices=devices, reference_literal=reference_literal, p_shared=(ensprob.p.ndim == 1), device=device,
                  time_segments=time_segments, no_start=no_start, dims=prob.dims, cont_cost=(_COSTS[type(g)] if g is not None else 0),
-                 stepper=(1 if adaptive else (2 if isinstance(alg, ETDRK4) else 0)), abstol=abstol, reltol=reltol, max_steps=max_steps,
+                 stepper=(3 if isinstance(alg, Rosenbrock23) else (1 if adaptive else (2 if isinstance(alg, ETDRK4) else 0))), abstol=abstol, reltol=reltol, max_steps=max_steps,
                  family=(_lib.FAMILY_AS_REGISTERED if mfma is False else _lib.FAMILY_AUTO),
                  **_engine_kwargs(sensealg, checkpoints, dt, prob.tspan[0], adaptive, t1=prob.tspan[1]))
     routed = hasattr(eng, "stats") and eng.stats().get("routed_family") == _lib.FAMILY_MFMA      # hipadj_create put a declared dense chain on the FP64-MFMA family (csrc/hipadj_route.hpp)

@@ -64,8 +64,31 @@ template <int NN> struct EmuRingMM {
     static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_u_t<double>(dl, l, u, p, t); }
     static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_p_t<double>(dg, l, u, p, t); }
 };
+// TEST-ONLY: Robertson kinetics in ODE form (tests/user_models.py ROBER, ORC_MODEL_ROBER): the stiff problem of the Rosenbrock23 cases — at p = (0.04, 3e7, 1e4) the W = I - d h J
+// solves of the lane bodies run at |h J| ~ 1e4 .. 1e9 with the pivoting LU doing real work.  Model id = HIPADJ_MODEL_USER_BASE + 203.
+struct EmuRober {
+    static constexpr int N = 3, NP = 3;
+    static constexpr bool TIME_DEP = false;
+    static constexpr bool HAS_COLS = false;
+    static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) {
+        du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
+        du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
+        du[2] = p[1] * u[1] * u[1];
+    }
+    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double) {
+        dl[0] = -p[0] * l[0] + p[0] * l[1];
+        dl[1] = p[2] * u[2] * l[0] + (-2.0 * p[1] * u[1] - p[2] * u[2]) * l[1] + 2.0 * p[1] * u[1] * l[2];
+        dl[2] = p[2] * u[1] * l[0] - p[2] * u[1] * l[1];
+    }
+    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&)[NP], double) {
+        dg[0] = -u[0] * l[0] + u[0] * l[1];
+        dg[1] = -u[1] * u[1] * l[1] + u[1] * u[1] * l[2];
+        dg[2] = u[1] * u[2] * l[0] - u[1] * u[2] * l[1];
+    }
+};
 static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
     const int nn = model - HIPADJ_MODEL_USER_BASE;
+    if (nn == 203) { *n = 3; *np = 3; return HIPADJ_OK; }
     if (nn != 4 && nn != 105) return HIPADJ_ERR_INVALID_ARG;
     *n = nn % 100; *np = nn % 100 + 1;
     return HIPADJ_OK;
@@ -337,7 +360,7 @@ static int run(const hipadj_config* cfg, const Plan& P, const double* u0, const 
 }
 
 // adaptive Tsit5: loops the lane bodies of hipadj_adaptive.hpp exactly as k_forward_tsit5 / k_adjoint_tsit5 + k_finish do
-template <class Mo, int ALG, int CC, bool CK = false>
+template <class Mo, int ALG, int CC, bool CK = false, int STEP = 0>      // STEP 1: Rosenbrock23 (hipadj_adaptive.hpp ros23_integrate)
 static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu,
                         double* du0, double* dp, double* out, int* nsteps_out) {
     constexpr int N = Mo::N, NP = Mo::NP, RW = 2 + 5 * N;
@@ -352,7 +375,7 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     int flag = 0;
     std::vector<double> kbuf((size_t)KS_ROWS * (2 * N + NP)), kfbuf((size_t)KS_ROWS * N);   // stage storage of one lane (LDS columns on the device), stride 1 here
     for (long i = 0; i < P.N; ++i)
-        forward_tsit5_lane<Mo>(g, i, u0, p, (rec.empty() || CK) ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(),
+        forward_tsit5_lane<Mo, STEP>(g, i, u0, p, (rec.empty() || CK) ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(),
                                P.ck_times.data(), ckpt.empty() ? nullptr : ckpt.data(), yT.data(), &flag, kbuf.data(), 1);
     if (nsteps_out) for (long i = 0; i < P.N; ++i) nsteps_out[i] = nsteps[i];
     if (flag & 4) return HIPADJ_ERR_MAXITERS;
@@ -365,7 +388,7 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     const double qatol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, qrtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
     for (long i = 0; i < P.N; ++i) {
         double lam[N], mu[NP];
-        adjoint_tsit5_lane<Mo, ALG, CC, CK>(g, i, p, rec.data(), nsteps.data(), yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ck_times.data(),
+        adjoint_tsit5_lane<Mo, ALG, CC, CK, STEP>(g, i, p, rec.data(), nsteps.data(), yT.data(), ckpt.empty() ? nullptr : ckpt.data(), P.ck_times.data(),
                                             P.save_times.data(), P.tstops_desc.data(), (int)P.tstops_desc.size(), cotT.empty() ? nullptr : cotT.data(), lam, mu, &flag, kbuf.data(), 1,
                                             arec.empty() ? nullptr : arec.data(), nsteps_adj.data(), SmaxA, kfbuf.data(), CK ? rec.data() : nullptr);
         for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
@@ -388,6 +411,15 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
 
 template <class Mo>
 static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* ns) {
+    if (cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {
+        switch (cfg->alg) {
+        case HIPADJ_ALG_INTERPOLATING: return run_adaptive<Mo, 0, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_GAUSS: return run_adaptive<Mo, 2, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_QUADRATURE: return run_adaptive<Mo, 3, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_GAUSS_KRONROD: return run_adaptive<Mo, 4, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        default: return HIPADJ_ERR_UNSUPPORTED;
+        }
+    }
     if (P.ip_ckpt) {
         switch (cfg->alg * 4 + cfg->cont_cost) {
         case HIPADJ_ALG_INTERPOLATING * 4 + 0: return run_adaptive<Mo, 0, 0, true>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
@@ -424,7 +456,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 
 // Build units (tests/emu.py compiles them in parallel): EMU_UNIT undefined = everything in one translation unit (the variant builds
 // of test_emu_parity.py); EMU_UNIT = 0 = the C entry points, the per-model dispatchers declared `extern template`;
-// EMU_UNIT = 1..7 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
+// EMU_UNIT = 1..8 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
 #ifndef EMU_UNIT
 #define EMU_UNIT -1
 #endif
@@ -451,6 +483,7 @@ extern template int dispatch_mode<ModelLinDiag>(const hipadj_config*, const Plan
 extern template int dispatch_mode<ModelFallMass>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRing<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRingMM<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuRober>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 1
 template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 2
@@ -465,6 +498,8 @@ template int dispatch_mode<ModelFallMass>(const hipadj_config*, const Plan&, con
 template int dispatch_mode<EmuRing<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 7
 template int dispatch_mode<EmuRingMM<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 8
+template int dispatch_mode<EmuRober>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #endif
 
 #if EMU_UNIT <= 0
@@ -489,6 +524,7 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     case HIPADJ_MODEL_FALLMASS: return dispatch_mode<ModelFallMass>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 4: return dispatch_mode<EmuRing<4>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 105: return dispatch_mode<EmuRingMM<5>>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 203: return dispatch_mode<EmuRober>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

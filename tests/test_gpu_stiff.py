@@ -1,0 +1,163 @@
+"""Rosenbrock23 on the device (`-m gpu`): HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE through the host mirror (`sa.Rosenbrock23()`), the stiff stepper of the lane-per-trajectory family
+— reference use: test/Core2/stiff_adjoints.jl:66-80, 142-157, 191.
+
+  * compiled-in models, every sensealg the stepper is built for, per-trajectory parameters, loss times off any grid: against the oracle;
+  * the reference's own stiff-adjoint fit (Lotka-Volterra, abstol = reltol = 1e-8, loss = sum(abs2, prediction - target)) against the gradient computed independently of the
+    oracle (tests/golden/stiff_adjoints.json) at the reference's bar, rtol 1e-4 (:157);
+  * Robertson kinetics at the classic stiff rates (0.04, 3e7, 1e4) over (0, 100) as a RUNTIME model (hiprtc): against the oracle and the independent Radau sensitivities;
+  * a 10^4-trajectory ensemble: every lane its own step sequence and its own LU; cross-method agreement and a sample against the oracle;
+  * what the library refuses for this stepper.
+Tolerances: two implementations of one adaptive controller agree to a fraction of the solver tolerance (a borderline accept / reject decided differently by an ulp), not to
+roundoff; the gates are rtol 1e-6 at tolerances 1e-8 .. 1e-9 (BASELINE.json north_star) and 1e-5 where ~3000 reverse steps each cross a kink of the forward interpolant."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import user_models as UM
+from test_gpu_parity import RTOL, rel, lorenz_inputs
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ALGS = [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE"), ("gausskronrod", "GAUSS_KRONROD")]
+_registered = {}
+
+
+def relc(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+def sens(sa, alg, tol):
+    return {"interpolating": sa.InterpolatingAdjoint(), "gauss": sa.GaussAdjoint(), "gausskronrod": sa.GaussKronrodAdjoint(),
+            "quadrature": sa.QuadratureAdjoint(abstol=tol, reltol=tol)}[alg]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(HERE, "golden", "stiff_adjoints.json")) as f:
+        return json.load(f)
+
+
+def rober(sa):
+    if "rober" not in _registered:
+        m = UM.ROBER
+        _registered["rober"] = sa.DeviceFunction("rober_ros23", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    return _registered["rober"]
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("model,omodel,u0c,p", [
+    ("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]),
+    ("lvt", "LVT", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]),
+    ("lorenz", "LORENZ", [1.0, 0.0, 0.0], [10.0, 28.0, 8 / 3]),
+    ("lindiag", "LINDIAG", [1.0, 1.0], [1.0, 2.0]),
+    ("fallmass", "FALLMASS", [1.0, 0.0], [9.81, 1.0]),
+])
+def test_rosenbrock23_cotangent_all_models(sa, alg, oalg, model, omodel, u0c, p):
+    rng = np.random.default_rng(31)
+    N, T = 70, 2.0
+    n, npar = sa.model_sizes(model)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.05 * rng.standard_normal((N, npar)))
+    ts = np.array([0.0, 0.13, 0.5, 0.77, 1.0, 1.9, 2.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model, u0[0], (0, T), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts, sensealg=sens(sa, alg, 1e-9), abstol=1e-9, reltol=1e-9)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=delta)
+    st = sol.engine.stats()
+    sol.engine.close()
+    ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="COTANGENT", quad_abstol=1e-9, quad_reltol=1e-9)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
+    assert st["launches_per_pass"] >= 1
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_reference_stiff_adjoint_fit_against_the_independent_gradient(sa, gold, alg, oalg):
+    """test/Core2/stiff_adjoints.jl:142-157 on the device: loss = sum(abs2, prediction - target) as the device-resident HIPADJ_LOSS_LSQ_DATA (scale 2)."""
+    c = gold["lv"]
+    ts = np.asarray(c["ts"]); u0 = np.asarray([c["u0"]]); p = np.asarray(c["p"]); tgt = np.asarray(c["target"])[None]
+    loss = sa.LsqData(tgt, 2.0)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0.0, 10.0), p), u0), sa.Rosenbrock23(), saveat=ts, sensealg=sens(sa, alg, 1e-8), dgdu_discrete=loss, abstol=1e-8, reltol=1e-8)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=loss)
+    lv = sol.loss_value()
+    sol.engine.close()
+    assert rel(dp, c["dp"]) < 1e-4 and rel(du0[0], c["du0"]) < 1e-4          # the reference's bar; measured on the oracle: 1.3e-5 / 6e-5
+    assert abs(lv - c["loss"]) < 1e-4 * c["loss"]
+    pr = O.Problem("LV", alg=oalg, stepper="ROS23", t0=0.0, t1=10.0, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="LSQ_DATA", loss_scale=2.0, quad_abstol=1e-8, quad_reltol=1e-8)
+    rdu0, rdp, _ = pr.adjoint(c["u0"], c["p"], tgt[0])
+    assert rel(du0[0], rdu0) < 1e-5 and rel(dp, rdp) < 1e-5
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_robertson_at_the_stiff_rates_runtime_model(sa, gold, alg, oalg):
+    """The problem class the stepper exists for: rates (0.04, 3e7, 1e4), tspan (0, 100), G = y3(50) + y3(100) — 100-600 forward steps where Tsit5 needs ~1e6; a small
+    ensemble around the classic rates, trajectory 0 at them exactly (the fixture's)."""
+    c = gold["rober"]
+    rng = np.random.default_rng(9)
+    N = 24
+    pp = np.asarray(c["p"]) * (1 + 0.1 * rng.uniform(-1, 1, (N, 3))); pp[0] = c["p"]
+    u0 = np.tile(np.asarray(c["u0"]), (N, 1)); u0[1:, 0] -= 0.05 * rng.uniform(0, 1, N - 1); u0[1:, 2] = 1.0 - u0[1:, 0]
+    ts = np.asarray(c["ts"])
+    d = np.zeros((N, 2, 3)); d[:, :, 2] = 1.0
+    f = rober(sa)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 100.0), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts,
+                   sensealg=(sa.QuadratureAdjoint(abstol=1e-12, reltol=1e-6) if alg == "quadrature" else sens(sa, alg, 1e-6)), abstol=1e-8, reltol=1e-6)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=d)
+    out = sol.u.copy()
+    sol.engine.close()
+    assert relc(dp[0], c["dp"]) < 1e-3 and relc(du0[0], c["du0"]) < 1e-3 and np.max(np.abs(out[0] - np.asarray(c["u_at_ts"]))) < 1e-5
+    pr = O.Problem("ROBER", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-8, reltol=1e-6, save_times=ts, loss="COTANGENT", quad_abstol=1e-12, quad_reltol=1e-6)
+    rdu0, rdp, rout, _ = pr.adjoint_ensemble(u0, pp, d)
+    assert np.max(np.abs(out - rout)) < 1e-9
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < 1e-4 and np.max(np.abs(du0 - rdu0) / np.abs(rdu0)) < 1e-4      # componentwise: dG/dp spans nine orders of magnitude
+
+
+def test_large_ensemble_every_lane_its_own_steps_and_factorisation(sa):
+    """10^4 Lorenz trajectories at 1e-6: cross-method agreement to solver tolerance and a sample against the oracle; shared parameters: dp is the ensemble sum."""
+    N, T = 10000, 1.0
+    u0, p = lorenz_inputs(N, seed=78)
+    ts = np.linspace(0, T, 11)
+    res = {}
+    for alg in ("interpolating", "gauss"):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, T), p), u0), sa.Rosenbrock23(), saveat=ts, sensealg=sens(sa, alg, 1e-8), dgdu_discrete=sa.LsqShift(2.0), abstol=1e-8, reltol=1e-8)
+        res[alg] = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=sa.LsqShift(2.0))
+        sol.engine.close()
+    idx = np.arange(0, N, 157)
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0 = np.array([ref.adjoint(u0[i], p)[0] for i in idx])
+    assert rel(res["interpolating"][0][idx], rdu0) < RTOL
+    assert rel(res["gauss"][0], res["interpolating"][0]) < 1e-5 and rel(res["gauss"][1], res["interpolating"][1]) < 1e-5
+
+
+def test_device_pointer_calls_and_replay(sa):
+    """forward_dev / adjoint_dev with this stepper on the caller's stream, twice: the second pass reproduces the first bit for bit (no state left behind by the first)."""
+    import torch
+    N, T = 256, 1.0
+    u0, p = lorenz_inputs(N, seed=3)
+    ts = np.linspace(0, T, 6)
+    eng = sa.Engine("lorenz", "interpolating", N, 0.0, T, 0.0, save_times=ts, loss_kind=1, loss_shift=2.0, stepper=3, abstol=1e-7, reltol=1e-7)
+    dev = torch.device("cuda:0")
+    tu0, tp = torch.tensor(u0, device=dev), torch.tensor(p, device=dev)
+    out = torch.empty((N, len(ts), 3), dtype=torch.float64, device=dev)
+    g = []
+    for _ in range(2):
+        du0, dp = torch.empty((N, 3), dtype=torch.float64, device=dev), torch.empty(3, dtype=torch.float64, device=dev)
+        eng.forward_dev(tu0, tp, out); eng.adjoint_dev(None, du0, dp); eng.synchronize()
+        g.append((du0.cpu().numpy(), dp.cpu().numpy()))
+    eng.close()
+    assert np.array_equal(g[0][0], g[1][0]) and np.array_equal(g[0][1], g[1][1])
+    ref = O.Problem("LORENZ", alg="INTERPOLATING", stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-7, reltol=1e-7, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, None)
+    assert rel(g[0][0], rdu0) < 1e-5 and rel(g[0][1], rdp) < 1e-5
+
+
+def test_what_the_library_refuses_for_this_stepper(sa):
+    u0, p = lorenz_inputs(8)
+    for kw in (dict(sensealg=sa.BacksolveAdjoint()), dict(sensealg=sa.InterpolatingAdjoint(checkpointing=True)), dict(sensealg=sa.GaussAdjoint(checkpointing=True))):
+        with pytest.raises(sa.HipadjError, match="Rosenbrock23"):
+            sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, 1.0), p), u0), sa.Rosenbrock23(), saveat=[1.0], **kw)
+    with pytest.raises(sa.HipadjError, match="Rosenbrock23"):      # the PDE family has its own stiff stepper (ETDRK4)
+        sa.Engine("bruss", "interpolating", 1, 0.0, 1.0, 0.0, save_times=[1.0], stepper=3, dims=(8, 0, 0, 0))

@@ -142,3 +142,21 @@ def test_runtime_tsit5_stage_rows_are_lds_columns_unless_opted_in(tmp_path, monk
             if "k_adjoint_tsit5" in mm.group(2):
                 lds = int(mm.group(1))
     assert lds is not None and (lds == 0 if regs == "1" else lds == 8 * 6 * 64 * 8)
+
+
+@pytest.mark.parametrize("name,alg", [("rober", "interpolating"), ("rober", "quadrature"), ("ring4", "gauss"), ("ring6", "gausskronrod")])
+def test_runtime_rosenbrock23_kernels_compile_without_a_device_and_are_clean(tmp_path, monkeypatch, name, alg):
+    """HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE for runtime-registered lane models: k_forward_tsit5<U, 1> and k_adjoint_tsit5<U, ALG, 0, false, 1> (the W solves unrolled over the
+    model's n) through hiprtc, and the spill-placement check on what it produced."""
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.ROBER if name == "rober" else UM.ring(int(name[4:]))
+    mname = f"{name}_ros23_lint_{alg}"
+    _lib.register_model(mname, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+    cfg = E.make_config(mname, alg, 53, 0.0, 0.5, 0.0, [0.25, 0.5], loss_kind=1, stepper=3, abstol=1e-8, reltol=1e-8)
+    L = _lib.load()
+    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+    objs = glob.glob(str(tmp_path / "*.hsaco"))
+    assert objs
+    for o in objs:
+        assert isa_lint.lint(o) == []

@@ -36,7 +36,7 @@ def test_oracle_matches_the_reference(case):
                    abstol=case["abstol"], reltol=case["reltol"], save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0,
                    checkpointing=case["checkpointing"], checkpoints=case.get("checkpoints"), quad_abstol=case["quad_abstol"], quad_reltol=case["quad_reltol"])
     du0, dp, out = pr.adjoint(case["u0"], case["p"])
-    if case["stepper"] == "TSIT5":
+    if case["stepper"] in ("TSIT5", "ROS23"):
         _, nsteps = pr.forward(case["u0"], case["p"])
         assert nsteps == case["forward_steps"], f"step sequence differs: {case['targets']}"
     assert rel(out, np.asarray(case["out"])) < 1e-9

@@ -1,0 +1,172 @@
+"""Rosenbrock23, the stiff stepper of the lane family (HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE; reference use: test/Core2/stiff_adjoints.jl:66-80, 142-157, 191) — CPU side:
+
+  * the oracle's restatement against gradients computed independently of it (tests/golden/stiff_adjoints.json, scipy forward sensitivities; generator committed beside it), at
+    the reference's own settings and bars: Lotka-Volterra fit, Rosenbrock23 abstol = reltol = 1e-8, rtol 1e-3 in place (:80) and 1e-4 out of place (:157) — the tighter one here;
+  * the same on Robertson kinetics at the classic stiff rates (0.04, 3e7, 1e4) over (0, 100): the problem class the stepper exists for;
+  * the device lane bodies (hipadj_adaptive.hpp ros23_integrate + the adjoint's block-triangular W solve), compiled for the host by tests/emu, against the oracle;
+  * what the planner refuses for this stepper;
+  * the one constant of the restatement that the reference's relations cannot pin (the coefficient of dT in k3): both readings pass the reference's bar, one takes 10 x the steps.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import emu as E
+import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ALGS = [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("quadrature", "QUADRATURE"), ("gausskronrod", "GAUSS_KRONROD")]
+ROS = 3      # HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+
+
+def relc(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(HERE, "golden", "stiff_adjoints.json")) as f:
+        return json.load(f)
+
+
+def test_golden_fixture_is_what_its_generator_writes(gold, tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_stiff_adjoints", os.path.join(HERE, "golden", "make_stiff_adjoints.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    lv = m.lv()
+    assert rel(lv["dp"], gold["lv"]["dp"]) < 1e-9 and rel(lv["target"], gold["lv"]["target"]) < 1e-10
+    # closed-form anchor of the Robertson fixture: mass conservation, y1 + y2 + y3 = 1 at both loss times, and d(sum)/dp = 0 => the three state gradients differ only through y3
+    u = np.asarray(gold["rober"]["u_at_ts"])
+    assert np.max(np.abs(u.sum(axis=1) - 1.0)) < 1e-10
+    assert gold["rober"]["spread_between_tolerances"] < 1e-9
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_oracle_lotka_volterra_fit_at_the_reference_bar(gold, alg, oalg):
+    """test/Core2/stiff_adjoints.jl:142-157: Rosenbrock23, abstol = reltol = 1e-8, saveat 0:0.5:10, loss = sum(abs2, prediction - target); `fdgrad ≈ rdgrad rtol = 1e-4`."""
+    c = gold["lv"]
+    pr = O.Problem("LV", alg=oalg, stepper="ROS23", t0=0.0, t1=10.0, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=c["ts"], loss="LSQ_DATA", loss_scale=2.0, quad_abstol=1e-8, quad_reltol=1e-8)
+    du0, dp, out = pr.adjoint(c["u0"], c["p"], np.asarray(c["target"]))
+    assert rel(dp, c["dp"]) < 1e-4 and rel(du0, c["du0"]) < 1e-4       # measured: 1.2e-5 / 4e-5
+    loss = float(((out - np.asarray(c["target"])) ** 2).sum())
+    assert abs(loss - c["loss"]) < 1e-4 * c["loss"]
+
+
+@pytest.mark.parametrize("tol,bar", [(1e-4, 1e-2), (1e-6, 5e-4), (1e-8, 1e-5)])
+def test_oracle_lotka_volterra_converges_with_the_tolerance(gold, tol, bar):
+    c = gold["lv"]
+    pr = O.Problem("LV", alg="INTERPOLATING", stepper="ROS23", t0=0.0, t1=10.0, dt=0.0, abstol=tol, reltol=tol, save_times=c["ts"], loss="LSQ_DATA", loss_scale=2.0)
+    du0, dp, _ = pr.adjoint(c["u0"], c["p"], np.asarray(c["target"]))
+    assert relc(dp, c["dp"]) < 5 * bar, relc(dp, c["dp"])      # measured 4.8e-3 / 2.7e-4 / 1.3e-5 (componentwise): second order in the step, as the method
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_oracle_robertson_at_the_stiff_rates(gold, alg, oalg):
+    """p = (0.04, 3e7, 1e4) (test/Core3/adjoint.jl:1458), G = y3(50) + y3(100) (:1465-1466): the gradient against Radau forward sensitivities, componentwise — dG/dp spans nine
+    orders of magnitude.  570 forward and ~5000 reverse steps at 1e-8; an explicit stepper needs ~1e6."""
+    c = gold["rober"]
+    d = np.zeros((2, 3)); d[:, 2] = 1.0
+    pr = O.Problem("ROBER", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-8, reltol=1e-6, save_times=c["ts"], loss="COTANGENT", quad_abstol=1e-12, quad_reltol=1e-6)
+    du0, dp, out = pr.adjoint(c["u0"], c["p"], d)
+    assert relc(dp, c["dp"]) < 1e-3 and relc(du0, c["du0"]) < 1e-3      # measured 8.5e-5 / 6.9e-5
+    assert np.max(np.abs(out - np.asarray(c["u_at_ts"]))) < 1e-5
+
+
+MODELS = [("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]), ("lvt", "LVT", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]), ("lorenz", "LORENZ", [1.0, 0.0, 0.0], [10.0, 28.0, 8 / 3])]
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("model,omodel,u0c,p", MODELS)
+def test_lane_bodies_match_oracle(alg, oalg, model, omodel, u0c, p):
+    """The device's stepper and its adjoint W solve (n x n LU of I + d h J', then the parameter rows by substitution) against the oracle's dense (n + np) LU of the same system:
+    the same controller, the same accept / reject sequence; `lvt` is the non-autonomous forward problem (dT by differences on the forward pass too).  Loss times off any grid."""
+    rng = np.random.default_rng(14)
+    N, T = 3, 2.0
+    n, npar = len(u0c), len(p)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.03 * rng.standard_normal((N, npar)))
+    ts = np.array([0.0, 0.13, 0.5, 0.77, 1.0, 1.9, 2.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    cfg = E.make_config(model, alg, N, 0.0, T, 0.0, ts, loss_kind=0, p_shared=False, stepper=ROS, abstol=1e-8, reltol=1e-8, quad_abstol=1e-8, quad_reltol=1e-8, max_steps=100000)
+    du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+    ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="COTANGENT", quad_abstol=1e-8, quad_reltol=1e-8)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-7 and rel(dp, rdp) < 1e-7      # measured <= 4e-14 / 5e-9 / 8e-10
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_lane_bodies_on_robertson_at_the_stiff_rates(gold, alg, oalg):
+    """|d h J| ~ 1e2 .. 1e7 in the W solves: the pivoting LU of the lanes doing real work.  Against the oracle AND against the independent gradient."""
+    c = gold["rober"]
+    d = np.zeros((1, 2, 3)); d[:, :, 2] = 1.0
+    cfg = E.make_config("emu_rober", alg, 1, 0.0, 100.0, 0.0, c["ts"], loss_kind=0, stepper=ROS, abstol=1e-8, reltol=1e-6, max_steps=20000, quad_abstol=1e-12, quad_reltol=1e-6)
+    du0, dp, out = E.forward_adjoint(cfg, 3, 3, [c["u0"]], c["p"], d)
+    pr = O.Problem("ROBER", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-8, reltol=1e-6, save_times=c["ts"], loss="COTANGENT", quad_abstol=1e-12, quad_reltol=1e-6)
+    rdu0, rdp, rout = pr.adjoint(c["u0"], c["p"], d[0])
+    assert np.max(np.abs(out[0] - rout)) < 1e-13
+    assert relc(dp, rdp) < 1e-6 and relc(du0[0], rdu0) < 1e-6
+    assert relc(dp, c["dp"]) < 1e-3 and relc(du0[0], c["du0"]) < 1e-3
+
+
+def test_lane_bodies_least_squares_loss_and_the_reference_fit(gold):
+    """The device-resident loss routes with this stepper: the fit of test/Core2/stiff_adjoints.jl as HIPADJ_LOSS_LSQ_DATA (scale 2 = sum(abs2, ...)), and dg = u - 2 (LSQ_SHIFT)."""
+    c = gold["lv"]
+    tgt = np.asarray(c["target"])[None]
+    cfg = E.make_config("lv", "interpolating", 1, 0.0, 10.0, 0.0, c["ts"], loss_kind=2, loss_scale=2.0, stepper=ROS, abstol=1e-8, reltol=1e-8, max_steps=20000)
+    du0, dp, out = E.forward_adjoint(cfg, 2, 4, [c["u0"]], c["p"], tgt)
+    assert rel(dp, c["dp"]) < 1e-4 and rel(du0[0], c["du0"]) < 1e-4
+    for alg, oalg in ALGS:
+        cfg = E.make_config("lv", alg, 1, 0.0, 10.0, 0.0, c["ts"], loss_kind=1, loss_shift=2.0, stepper=ROS, abstol=1e-8, reltol=1e-8, max_steps=20000, quad_abstol=1e-8, quad_reltol=1e-8)
+        du0, dp, _ = E.forward_adjoint(cfg, 2, 4, [c["u0"]], c["p"])
+        pr = O.Problem("LV", alg=oalg, stepper="ROS23", t0=0.0, t1=10.0, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=c["ts"], loss="LSQ_SHIFT", loss_shift=2.0, quad_abstol=1e-8, quad_reltol=1e-8)
+        rdu0, rdp, _ = pr.adjoint(c["u0"], c["p"])
+        # ~3000 reverse steps with a rejection at most forward knots (the interpolant's kinks): one borderline accept / reject decided differently by an ulp moves the answer
+        # by a fraction of the tolerance — measured 1e-7 on InterpolatingAdjoint, 1e-10 on the others
+        assert rel(du0[0], rdu0) < 2e-6 and rel(dp, rdp) < 2e-6, alg
+
+
+def test_step_capacity_overflow_is_an_error_and_what_the_planner_refuses():
+    u0 = np.array([[1.0, 1.0]]); p = np.array([1.5, 1.0, 3.0, 1.0])
+    cfg = E.make_config("lv", "interpolating", 1, 0.0, 10.0, 0.0, [10.0], loss_kind=1, stepper=ROS, abstol=1e-10, reltol=1e-10, max_steps=50)
+    with pytest.raises(RuntimeError, match="rc=-7"):
+        E.forward_adjoint(cfg, 2, 4, u0, p)
+    # BacksolveAdjoint re-integrates the state backwards: the system is not affine in its unknowns and its Jacobian needs second derivatives of the model — not built;
+    # checkpointing re-solves intervals inside the reverse pass — not built for this stepper; continuous costs neither
+    for bad in (dict(alg="backsolve", checkpointing=True), dict(alg="backsolve"), dict(alg="interpolating", checkpointing=True), dict(alg="gauss", checkpointing=True),
+                dict(alg="interpolating", cont_cost=1), dict(alg="quadrature", cont_cost=2)):
+        kw = dict(bad); alg = kw.pop("alg")
+        cfg = E.make_config("lv", alg, 1, 0.0, 10.0, 0.0, [10.0], stepper=ROS, **kw)
+        with pytest.raises(RuntimeError, match="rc=-6"):
+            E.forward_adjoint(cfg, 2, 4, u0, p, np.zeros((1, 1, 2)))
+    # the oracle refuses the same
+    with pytest.raises(RuntimeError):
+        O.Problem("LV", alg="BACKSOLVE", stepper="ROS23", t0=0, t1=1.0, dt=0.0, save_times=[1.0], loss="COTANGENT").adjoint(u0[0], p, np.zeros((1, 2)))
+
+
+def test_the_time_derivative_term_of_k3_is_not_pinned_by_the_reference_relation_but_by_the_step_count(gold):
+    """ORC_RECALL_ROS_K3_T: with `h dT` instead of `d h dT` the gradient still meets test/Core2/stiff_adjoints.jl's bar — the relation cannot tell the two readings apart — and the
+    reverse pass takes >= 8 x the right-hand sides (profiles/r6_rosenbrock23_steps.json: 10 - 270 x).  The restatement and the device hold `d h dT` (Shampine-Reichelt's form, third
+    order in h on u' = g(t)); oracle/_ref/README.md lists it among the constants a Julia run would settle."""
+    c = gold["lv"]
+    L = O.lib()
+    counts = {}
+    try:
+        for name, v in (("d", 0.29289321881345247560), ("one", 1.0)):
+            assert L.orc_test_set_recall(10, C.c_double(v)) == 0
+            pr = O.Problem("LV", alg="INTERPOLATING", stepper="ROS23", t0=0.0, t1=10.0, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=c["ts"], loss="LSQ_DATA", loss_scale=2.0)
+            u0, p, data = O._arr(c["u0"]), O._arr(c["p"]), O._arr(np.asarray(c["target"]))
+            du0, dp, out = np.zeros(2), np.zeros(4), np.zeros((len(c["ts"]), 2)); nr = C.c_long()
+            assert L.orc_adjoint(C.byref(pr.cfg), O._p(u0), O._p(p), O._p(data), O._p(du0), O._p(dp), O._p(out), C.byref(nr)) == 0
+            assert rel(dp, c["dp"]) < 1e-4, name
+            counts[name] = nr.value
+    finally:
+        L.orc_test_set_recall(10, C.c_double(0.29289321881345247560))
+    assert counts["one"] > 8 * counts["d"], counts
