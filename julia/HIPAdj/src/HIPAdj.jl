@@ -106,6 +106,7 @@ end
 # enums of the header
 const ALG_INTERPOLATING, ALG_BACKSOLVE, ALG_GAUSS, ALG_QUADRATURE, ALG_GAUSS_KRONROD = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
 const STEPPER_RK4_FIXED, STEPPER_TSIT5_ADAPTIVE = Int32(0), Int32(1)
+const STEPPER_ROSENBROCK23_ADAPTIVE = Int32(3)      # Rosenbrock23 for the lane-per-trajectory models (include/hipadj.h HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE; test/Core2/stiff_adjoints.jl:66-80)
 const STEPPER_ETDRK4_FIXED = Int32(2)      # exponential RK4 for the PDE family (include/hipadj.h HIPADJ_STEPPER_ETDRK4_FIXED; OrdinaryDiffEq's ETDRK4)
 const LOSS_COTANGENT, LOSS_LSQ_SHIFT, LOSS_LSQ_DATA, LOSS_MODEL = Int32(0), Int32(1), Int32(2), Int32(3)
 const MODEL_USER_BASE = Int32(1000)

@@ -66,12 +66,10 @@ def test_rosenbrock23_cotangent_all_models(sa, alg, oalg, model, omodel, u0c, p)
     delta = rng.standard_normal((N, len(ts), n))
     sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model, u0[0], (0, T), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts, sensealg=sens(sa, alg, 1e-9), abstol=1e-9, reltol=1e-9)
     du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=delta)
-    st = sol.engine.stats()
     sol.engine.close()
     ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="COTANGENT", quad_abstol=1e-9, quad_reltol=1e-9)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < RTOL and rel(dp, rdp) < RTOL
-    assert st["launches_per_pass"] >= 1
 
 
 @pytest.mark.parametrize("alg,oalg", ALGS)
