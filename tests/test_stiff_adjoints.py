@@ -170,3 +170,34 @@ def test_the_time_derivative_term_of_k3_is_not_pinned_by_the_reference_relation_
     finally:
         L.orc_test_set_recall(10, C.c_double(0.29289321881345247560))
     assert counts["one"] > 8 * counts["d"], counts
+
+
+# ---- constant non-singular mass matrix (the reference tests it WITH a Rosenbrock method: Rodas4, test/Core3/adjoint.jl:1308-1376) ------------------------------------------
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_oracle_mass_matrix_problem_against_its_closed_form(alg, oalg):
+    """`foo` with the dense M of test/Core3/adjoint.jl:1315-1321, G = sum of the states at ts: closed form in tests/golden/mass_matrix.json.  W = I - d h M^-1 J here is
+    M^-1 (M - d h J): the stages of the mass-matrix form of the method, computed through the M^-1 f rewrite the library uses for every stepper."""
+    with open(os.path.join(HERE, "golden", "mass_matrix.json")) as f:
+        G = json.load(f)
+    M = np.array(G["M"]); ts = np.array(G["ts"])
+    with O.mass_matrix(M):
+        pr = O.Problem("AFFINE3", alg=oalg, stepper="ROS23", t0=0, t1=1.0, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="COTANGENT", quad_abstol=1e-9, quad_reltol=1e-9)
+        du0, dp, out = pr.adjoint(G["u0"], G["p"], np.ones((len(ts), 3)))
+    assert rel(out[-1], G["u_end"]) < 2e-6 and rel(dp, G["dGdp"]) < 2e-6 and rel(du0, G["lam0"]) < 2e-6      # measured 2e-7 .. 5e-7
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_lane_bodies_behind_a_mass_matrix(alg, oalg):
+    """emu_ring5mm (F = M^-1 f, VJPs through M^-T: the wrapper hipadj_user.hpp generates; non-autonomous flag set, n = 5: the widest unrolled LU the emulator holds) against the
+    oracle's lam formulation.  The two formulations weigh the error norm differently (nu = M' lam here), so they agree to the solver tolerance, not to roundoff."""
+    rng = np.random.default_rng(5)
+    n, npar, N, T = 5, 6, 3, 2.0
+    u0 = rng.uniform(0.3, 1.0, (N, n)); ts = np.array([0.4, 1.1, 2.0]); delta = rng.standard_normal((N, 3, n))
+    pp = rng.uniform(0.4, 1.2, (N, npar))
+    M = np.linalg.inv(E.ring_mm_inverse(n))
+    cfg = E.make_config("emu_ring5mm", alg, N, 0.0, T, 0.0, ts, loss_kind=0, p_shared=False, stepper=ROS, abstol=1e-9, reltol=1e-9, quad_abstol=1e-9, quad_reltol=1e-9, max_steps=50000)
+    du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+    with O.mass_matrix(M):
+        ref = O.Problem("RING", alg=oalg, t0=0.0, t1=T, save_times=ts, loss="COTANGENT", dims=(n, 0, 0, 0), stepper="ROS23", dt=0.0, abstol=1e-9, reltol=1e-9, quad_abstol=1e-9, quad_reltol=1e-9)
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(out, rout) < 1e-10 and rel(du0, rdu0 @ M) < 1e-6 and rel(dp, rdp) < 1e-6      # measured 7e-15 / 2e-8 / 3e-8
