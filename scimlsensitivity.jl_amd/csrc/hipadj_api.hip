@@ -3,6 +3,10 @@
 // hipadj_lane.hpp / hipadj_kernels.hpp.  No CPU fallback exists: without a usable HIP device
 // hipadj_create returns HIPADJ_ERR_NO_DEVICE.
 #include <chrono>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include "hipadj_host.hpp"
 #include <sys/mman.h>
@@ -271,6 +275,8 @@ static void free_all(hipadj_handle* h) {
     host_pin_release(h);
     if (h->lmod) (void)hipModuleUnload(h->lmod);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < h->xfer_nev; ++i) if (h->xfer_ev[i]) (void)hipEventDestroy(h->xfer_ev[i]);
+    h->xfer_nev = 0;
     for (auto& q : h->evs) for (hipEvent_t e : {q.a0, q.a1, q.k0, q.k1}) if (e) (void)hipEventDestroy(e);
     if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); if (h->comm_ready) (void)hipEventDestroy(h->comm_ready); for (auto e : h->comm_done) if (e) (void)hipEventDestroy(e); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1755,17 +1761,132 @@ extern "C" int hipadj_adjoint_dev_soa(hipadj_handle* h, const double* d_dLdu_soa
     return rc;
 }
 
+// The copier threads of the host-pointer calls: a process-wide pool, started at the first block of 4 MB and more and parked on a condition variable in between (creating eight
+// threads per call cost 0.2-0.3 ms of a 0.9 ms call: profiles/r6_host_api_ab.jsonl).  run(nt, job) hands job(t), t = 0 .. nt-1, to the pool and returns at once; wait() blocks until
+// every job(t) has returned.  One block at a time (the mutex of the host-pointer transfer that owns it).
+struct XferPool {
+    std::mutex own;                      // held by the transfer using the pool
+    std::mutex m; std::condition_variable cv, cv_done;
+    std::vector<std::thread> th;
+    std::function<void(unsigned)> job; unsigned gen = 0, active = 0, njob = 0; bool stop = false;
+    void ensure(unsigned nt) {
+        while (th.size() < nt) { const unsigned t = (unsigned)th.size(); th.emplace_back([this, t] { loop(t); }); }
+    }
+    void loop(unsigned t) {
+        unsigned seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            if (t >= njob) continue;
+            auto f = job;
+            lk.unlock(); f(t); lk.lock();
+            if (--active == 0) cv_done.notify_all();
+        }
+    }
+    void run(unsigned nt, std::function<void(unsigned)> f) {
+        ensure(nt);
+        { std::lock_guard<std::mutex> lk(m); job = std::move(f); njob = nt; active = nt; ++gen; }
+        cv.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return active == 0; }); }
+    ~XferPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto& x : th) if (x.joinable()) x.join(); }
+};
+static XferPool& xfer_pool() { static XferPool P; return P; }
 // Pinned staging of the host-pointer calls.  host_copy_par: memcpy by a few host threads (one thread moves ~10 GB/s, the link 50-60).
 static void host_copy_par(double* dst, const double* src, size_t count) {
     const size_t bytes = count * sizeof(double);
     unsigned nt = std::thread::hardware_concurrency(); nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
     if (const char* e = std::getenv("HIPADJ_HOST_COPY_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
     if (bytes < ((size_t)4 << 20) || nt == 1) { std::memcpy(dst, src, bytes); return; }
-    std::vector<std::thread> th;
+    XferPool& P = xfer_pool();
+    std::lock_guard<std::mutex> own(P.own);
     const size_t per = (count + nt - 1) / nt;
-    for (unsigned t = 1; t < nt; ++t) { const size_t a = per * t, b = std::min(count, a + per); if (a < b) th.emplace_back([=] { std::memcpy(dst + a, src + a, (b - a) * sizeof(double)); }); }
+    P.run(nt - 1, [=](unsigned t) { const size_t a = per * (t + 1), b = std::min(count, a + per); if (a < b) std::memcpy(dst + a, src + a, (b - a) * sizeof(double)); });
     std::memcpy(dst, src, std::min(per, count) * sizeof(double));
-    for (auto& x : th) x.join();
+    P.wait();
+}
+// Pipelined staging (round 6): a block of 4 MB and more crosses in chunks, the CPU copy of one chunk running while the DMA of its neighbour is in flight —
+// the host-pointer forward / reverse calls pay max(CPU copy, DMA) + one chunk instead of their sum (24 MB: ~0.87 -> ~0.55 ms).  The copier threads (the pool above) each
+// copy their slice of every chunk in order and counts the chunk's arrivals; the calling thread alone talks to the runtime (issues the uploads / waits for the download events).
+static constexpr size_t HIPADJ_XFER_MIN_BYTES = (size_t)4 << 20;
+static unsigned xfer_threads() {
+    unsigned nt = std::thread::hardware_concurrency(); nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
+    if (const char* e = std::getenv("HIPADJ_HOST_COPY_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
+    return nt;
+}
+static int xfer_chunks(size_t count) {      // chunks of ~3 MB, at most 16 (the handle's events)
+    static const bool off = [] { const char* e = std::getenv("HIPADJ_HOST_PIPELINE"); return e && e[0] == '0'; }();      // A/B hook
+    if (off || count * sizeof(double) < HIPADJ_XFER_MIN_BYTES) return 1;
+    const size_t c = (count * sizeof(double) + ((size_t)3 << 20) - 1) / ((size_t)3 << 20);
+    return (int)(c > 16 ? 16 : c);
+}
+// host -> pinned block -> device
+static int stage_up_pipelined(hipadj_handle* h, double* d_dst, double* pin, const double* src, size_t count, int C) {
+    const unsigned nt = xfer_threads();
+    const size_t per = (count + C - 1) / C;
+    std::vector<std::atomic<unsigned>> done(C);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    auto work = [&](unsigned t) {
+        for (int c = 0; c < C; ++c) {
+            const size_t a = per * c, b = std::min(count, a + per), len = b - a, sl = (len + nt - 1) / nt, x = std::min(len, sl * t), y = std::min(len, x + sl);
+            if (x < y) std::memcpy(pin + a + x, src + a + x, (y - x) * sizeof(double));
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    XferPool& P = xfer_pool();
+    std::lock_guard<std::mutex> own(P.own);
+    P.run(nt, work);
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < C; ++c) {
+        while (done[c].load(std::memory_order_acquire) < nt) std::this_thread::yield();
+        const size_t a = per * c, b = std::min(count, a + per);
+        if (e == hipSuccess && a < b) e = hipMemcpyAsync(d_dst + a, pin + a, (b - a) * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    }
+    P.wait();
+    HIP_TRY(h, e);
+    return HIPADJ_OK;
+}
+// device -> pinned block, enqueue: one copy + one event per chunk (in-stream; nothing waits)
+static int stage_down_enqueue(hipadj_handle* h, double* pin, const double* d_src, size_t count) {
+    const int C = xfer_chunks(count);
+    h->xfer_chunks = C;
+    if (C == 1) { HIP_TRY(h, hipMemcpyAsync(pin, d_src, count * sizeof(double), hipMemcpyDeviceToHost, h->stream)); return HIPADJ_OK; }
+    while (h->xfer_nev < C) { HIP_TRY(h, hipEventCreateWithFlags(&h->xfer_ev[h->xfer_nev], hipEventDisableTiming)); ++h->xfer_nev; }
+    const size_t per = (count + C - 1) / C;
+    for (int c = 0; c < C; ++c) {
+        const size_t a = per * c, b = std::min(count, a + per);
+        if (a < b) HIP_TRY(h, hipMemcpyAsync(pin + a, d_src + a, (b - a) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipEventRecord(h->xfer_ev[c], h->stream));
+    }
+    return HIPADJ_OK;
+}
+// ... finish: pinned block -> the caller's array, chunk by chunk as the events complete
+static int stage_down_finish(hipadj_handle* h, double* dst, const double* pin, size_t count) {
+    const int C = h->xfer_chunks;
+    if (C <= 1) { HIP_TRY(h, hipStreamSynchronize(h->stream)); host_copy_par(dst, pin, count); return HIPADJ_OK; }
+    const unsigned nt = xfer_threads();
+    const size_t per = (count + C - 1) / C;
+    std::atomic<int> ready(0);      // chunks [0, ready) have arrived; -1: a runtime error, the copiers stop
+    auto work = [&](unsigned t) {
+        for (int c = 0; c < C; ++c) {
+            int r;
+            while ((r = ready.load(std::memory_order_acquire)) <= c) { if (r < 0) return; std::this_thread::yield(); }
+            const size_t a = per * c, b = std::min(count, a + per), len = b - a, sl = (len + nt - 1) / nt, x = std::min(len, sl * t), y = std::min(len, x + sl);
+            if (x < y) std::memcpy(dst + a + x, pin + a + x, (y - x) * sizeof(double));
+        }
+    };
+    XferPool& P = xfer_pool();
+    std::lock_guard<std::mutex> own(P.own);
+    P.run(nt, work);
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < C && e == hipSuccess; ++c) { e = hipEventSynchronize(h->xfer_ev[c]); if (e == hipSuccess) ready.store(c + 1, std::memory_order_release); }
+    if (e != hipSuccess) ready.store(-1, std::memory_order_release);
+    P.wait();
+    HIP_TRY(h, e);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return HIPADJ_OK;
 }
 // The staging block lives in its OWN anonymous mapping with an inaccessible guard page on either side — never in the brk heap.  Round 5's block was posix_memalign memory: once
 // glibc's dynamic mmap threshold has risen (a larger block was freed earlier), such a block comes from the heap, page-adjacent to the caller's small arrays, and registering it
@@ -1825,13 +1946,14 @@ static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size
         static const bool trace = std::getenv("HIPADJ_HOST_TIMING") != nullptr;      // diagnosis: where a host-pointer call spends its time (stderr)
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         const auto t0 = std::chrono::steady_clock::now();
-        host_copy_par(pin, src, count);
+        const int C = xfer_chunks(count);
+        if (C > 1) TRY(stage_up_pipelined(h, d_dst, pin, src, count, C)); else host_copy_par(pin, src, count);
         const auto t1 = std::chrono::steady_clock::now();
-        HIP_TRY(h, hipMemcpyAsync(d_dst, pin, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (C == 1) HIP_TRY(h, hipMemcpyAsync(d_dst, pin, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (trace) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             const auto t2 = std::chrono::steady_clock::now();
-            std::fprintf(stderr, "hipadj upload_block: %.1f MB, host copy into the pinned block %.3f ms, DMA %.3f ms\n", count * 8.0 / 1e6,
+            std::fprintf(stderr, C > 1 ? "hipadj upload_block: %.1f MB in chunks, host copies + issue of the DMAs %.3f ms, rest of the DMAs %.3f ms\n" : "hipadj upload_block: %.1f MB, host copy into the pinned block %.3f ms, DMA %.3f ms\n", count * 8.0 / 1e6,
                          std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
         }
     } else HIP_TRY(h, hipMemcpyAsync(d_dst, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1841,9 +1963,8 @@ static int upload_block(hipadj_handle* h, double* d_dst, const double* src, size
 static int download_block(hipadj_handle* h, double* dst, const double* d_src, size_t count) {
     double* pin = stage_block(h, count);
     if (pin) {
-        HIP_TRY(h, hipMemcpyAsync(pin, d_src, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        host_copy_par(dst, pin, count);
+        TRY(stage_down_enqueue(h, pin, d_src, count));
+        TRY(stage_down_finish(h, dst, pin, count));
     } else {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         HIP_TRY(h, hipMemcpyAsync(dst, d_src, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1868,14 +1989,15 @@ static int forward_host_enqueue(hipadj_handle* h, const double* u0, const double
         HIP_TRY(h, hipMemcpyAsync(h->d_p, p, sizeof(double) * pc, hipMemcpyHostToDevice, h->stream));
     }
     TRY(hipadj_forward_dev(h, h->d_u0, h->d_p, out ? h->d_io_a : nullptr));
-    if (out && h->M > 0) HIP_TRY(h, hipMemcpyAsync(pin ? pin : out, h->d_io_a, sizeof(double) * no, hipMemcpyDeviceToHost, h->stream));      // (in-stream behind the uploads that read the block)
+    if (out && h->M > 0) {      // (in-stream behind the uploads that read the block)
+        if (pin) TRY(stage_down_enqueue(h, pin, h->d_io_a, no)); else HIP_TRY(h, hipMemcpyAsync(out, h->d_io_a, sizeof(double) * no, hipMemcpyDeviceToHost, h->stream));
+    }
     return HIPADJ_OK;
 }
 static int forward_host_finish(hipadj_handle* h, double* out) {
     if (!out || h->M <= 0 || !h->h_pin || host_direct()) return HIPADJ_OK;      // direct mode: the copy went into `out` itself
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    host_copy_par(out, h->h_pin, (size_t)h->N * h->M * h->n);
+    TRY(stage_down_finish(h, out, h->h_pin, (size_t)h->N * h->M * h->n));
     return HIPADJ_OK;
 }
 extern "C" int hipadj_forward(hipadj_handle* h, const double* u0, const double* p, double* out) {

@@ -120,6 +120,7 @@ struct hipadj_handle {
     // host-pointer calls: the [N][M][n] block (cotangents up, out = sol(ts) down) goes through a PINNED staging buffer of the handle — the caller's arrays are pageable
     // (a Julia / numpy array), and a pageable hipMemcpyAsync of 24 MB ran at 3 GB/s (profiles/r5_visit1_bench.json: 7.7 ms for the Delta of BASELINE configs[1] against 0.39 ms
     // of link time); host threads copy into the pinned block, ONE DMA moves it
+    hipEvent_t xfer_ev[16] = {}; int xfer_nev = 0, xfer_chunks = 0;      // events behind the chunks of a pipelined device-to-host staging copy (hipadj_api.hip stage_down_*)
     double* h_pin = nullptr; size_t pin_count = 0, pin_map_len = 0;      // pin_map_len: bytes of the mmap region behind h_pin (guard pages included)
     hipModule_t lmod = nullptr; hipFunction_t lf_value = nullptr;   // runtime model with a discrete-loss FUNCTION: its loss-value kernel (hipadj_loss_value)
     double* d_lpart = nullptr;            // per-workgroup partials of hipadj_loss_value
