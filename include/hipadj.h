@@ -230,7 +230,11 @@ int hipadj_wmodel_set_cost(int32_t model_id, const char *cost_body);
  * 805-807).  The device steppers are explicit, so the generated model is F = M^{-1} f with F_u' nu = f_u' (M^{-T} nu): the sweep
  * integrates nu = M' lam, the parameter integrand f_p' lam is unchanged, and du0 is mapped back to lam(t0) = M^{-T} nu(t0) — what the
  * reference returns (src/sensitivity_interface.jl:500; note that dG/du0 itself is M' du0).  All sensealgs, RK4 and Tsit5.
- * A singular M (semi-explicit DAE, src/adjoint_common.jl:117-135, 790-803) needs an implicit stepper: HIPADJ_ERR_UNSUPPORTED.
+ * A SINGULAR M of the semi-explicit form [Md 0; 0 0] — zero rows that are also zero columns (the algebraic variables, src/adjoint_common.jl:116-122), Md non-singular (:131-133) —
+ * makes the model a DAE (round 6; test/Core3/adjoint.jl:1434-1530): HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE integrates M u' = f and M' lam' = -J' lam in mass-matrix form
+ * (W = M - d h J), from a consistent state (the algebraic entries of u0 are solved for, BrownFullBasicInit), with the loss jumps of src/adjoint_common.jl:790-813 (algebraic
+ * part of the cotangent eliminated through J_aa, its parameter term added to dp, the algebraic adjoints re-initialised); du0 = lam(t0).  Interpolating-, Gauss-, GaussKronrod-,
+ * QuadratureAdjoint; every other stepper refuses such a model at hipadj_create (HIPADJ_ERR_UNSUPPORTED).  Any other singular M: HIPADJ_ERR_UNSUPPORTED here.
  * Handles created earlier keep the matrix they were created with. */
 int hipadj_model_set_mass_matrix(int32_t model_id, const double *M);
 /* DiscreteCallback at preset times with an affect  (u, p) <- a(u, p, t)  (test/Callbacks1/discrete_callbacks.jl:260-330, incl. the parameter-changing

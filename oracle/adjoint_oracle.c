@@ -69,6 +69,7 @@ static int model_init(orc_model *m, int id, const int dims[4]) {
     case ORC_MODEL_DENSELIN: { int r = m->dims[0]; if (r < 1) return -1; m->n = r; m->np = r * r; break; }
     case ORC_MODEL_PENDULUM: m->n = 2; m->np = 3; break;
     case ORC_MODEL_LIN1P: m->n = 1; m->np = 2; break;
+    case ORC_MODEL_ROBERDAE: m->n = 3; m->np = 3; break;
     default: return -1;
     }
     return 0;
@@ -118,6 +119,11 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
         du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
         du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
         du[2] = p[1] * u[1] * u[1];
+        break;
+    case ORC_MODEL_ROBERDAE: /* `rober` exactly as test/Core3/adjoint.jl:1434-1441 writes it: the third row is the conservation constraint (mass matrix diag(1, 1, 0), :1450-1454) */
+        du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
+        du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
+        du[2] = u[0] + u[1] + u[2] - 1.0;
         break;
     case ORC_MODEL_PENDULUM: /* test/Core7/adjoint_param.jl:6-10; the second term is the test's "simple controller that stabilizes pi" */
         du[0] = p[0] * u[1];
@@ -234,6 +240,18 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
         if (dgrad) {
             dgrad[0] = -u[0] * lam[0] + u[0] * lam[1];
             dgrad[1] = -u[1] * u[1] * lam[1] + u[1] * u[1] * lam[2];
+            dgrad[2] = u[1] * u[2] * lam[0] - u[1] * u[2] * lam[1];
+        }
+        break;
+    case ORC_MODEL_ROBERDAE:
+        if (dlam) {
+            dlam[0] = -p[0] * lam[0] + p[0] * lam[1] + lam[2];
+            dlam[1] = p[2] * u[2] * lam[0] + (-2.0 * p[1] * u[1] - p[2] * u[2]) * lam[1] + lam[2];
+            dlam[2] = p[2] * u[1] * lam[0] - p[2] * u[1] * lam[1] + lam[2];
+        }
+        if (dgrad) {
+            dgrad[0] = -u[0] * lam[0] + u[0] * lam[1];
+            dgrad[1] = -u[1] * u[1] * lam[1];
             dgrad[2] = u[1] * u[2] * lam[0] - u[1] * u[2] * lam[1];
         }
         break;
@@ -362,9 +380,36 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
 #define ORC_MM_MAXN 64      /* (8 until round 4: traced wide models carry mass matrices beyond the lane family) */
 static int g_mm_n = 0;
 static double g_mm_inv[ORC_MM_MAXN * ORC_MM_MAXN], g_mm_invT[ORC_MM_MAXN * ORC_MM_MAXN];
+/* Semi-explicit DAE (round 6): a SINGULAR M whose zero rows are also zero columns — M = [Md 0; 0 0] up to the order of the variables, Md non-singular — is kept as it is
+ * (g_mm_dae): differential variables = rows of M with a non-zero (src/adjoint_common.jl:116-121 on M'), the rest algebraic (:122); Rosenbrock23 integrates M u' = f and
+ * M' lam' = -J' lam in mass-matrix form; the loss jumps follow :790-803.  g_mm_n stays 0 in that mode: none of the M^-1 rewrites above applies. */
+static int g_mm_dae = 0, g_dae_n = 0, g_dae_nalg = 0;
+static double g_dae_M[ORC_MM_MAXN * ORC_MM_MAXN];
+static int g_dae_isalg[ORC_MM_MAXN];
 int orc_set_mass_matrix(int n, const double *M) {
+    g_mm_dae = 0; g_dae_n = 0; g_dae_nalg = 0;
     if (!M || n <= 0) { g_mm_n = 0; return 0; }
     if (n > ORC_MM_MAXN) return -1;
+    {   /* semi-explicit DAE? */
+        int nalg = 0, ok = 1;
+        for (int i = 0; i < n; ++i) { int nz = 0; for (int j = 0; j < n; ++j) nz |= (M[i * n + j] != 0.0); g_dae_isalg[i] = !nz; nalg += !nz; }
+        if (nalg > 0 && nalg < n) {
+            for (int i = 0; i < n && ok; ++i) for (int j = 0; j < n; ++j) if (g_dae_isalg[j] && M[i * n + j] != 0.0) { ok = 0; break; }      /* zero columns too */
+            if (ok) {   /* Md = M[diff, diff] must be non-singular ("The submatrix corresponding to the differential variables of the mass matrix must be nonsingular!", :131-133) */
+                int nd = n - nalg, id[ORC_MM_MAXN], k = 0; double a[ORC_MM_MAXN][ORC_MM_MAXN];
+                for (int i = 0; i < n; ++i) if (!g_dae_isalg[i]) id[k++] = i;
+                for (int i = 0; i < nd; ++i) for (int j = 0; j < nd; ++j) a[i][j] = M[id[i] * n + id[j]];
+                double scale = 0; for (int i = 0; i < n * n; ++i) scale = fmax(scale, fabs(M[i]));
+                for (int c = 0; c < nd && ok; ++c) {
+                    int piv = c; for (int r = c + 1; r < nd; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+                    if (!(fabs(a[piv][c]) > 1e-13 * scale)) { ok = 0; break; }
+                    if (piv != c) for (int j = 0; j < nd; ++j) { double tmp = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = tmp; }
+                    for (int r = c + 1; r < nd; ++r) { double f = a[r][c] / a[c][c]; for (int j = c; j < nd; ++j) a[r][j] -= f * a[c][j]; }
+                }
+                if (ok) { memcpy(g_dae_M, M, sizeof(double) * (size_t)n * n); g_mm_dae = 1; g_dae_n = n; g_dae_nalg = nalg; g_mm_n = 0; return 0; }
+            }
+        }
+    }
     double a[ORC_MM_MAXN][2 * ORC_MM_MAXN];
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { a[i][j] = M[i * n + j]; a[i][n + j] = (i == j); }
     double scale = 0; for (int i = 0; i < n * n; ++i) scale = fmax(scale, fabs(M[i]));
@@ -571,6 +616,9 @@ typedef struct {
     /* ORC_STEPPER_ROS23: the Jacobian of the right-hand side; jac == NULL: the right-hand side is AFFINE in its state (every adjoint system is: lam' = -J(y(t))' lam - g_u,
      * grad' = -f_p' lam - g_p), so column c of its Jacobian is rhs(e_c, t) - rhs(0, t) exactly.  autonomous != 0: no explicit time dependence (dT = 0). */
     orc_jac jac; int autonomous;
+    /* ORC_STEPPER_ROS23: mass matrix of THIS system (row-major n x n; NULL = identity): W = mass - d h J and the stage right-hand sides carry mass * k (semi-explicit DAEs: a
+     * singular mass matrix is what the implicit stepper is for; a non-singular one is handled by the M^-1 rewrite above the integrator instead) */
+    const double *mass;
 } orc_alg;
 
 /* -------------------------------------------------------------------------------------
@@ -842,7 +890,8 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
                     for (int r = 0; r < n; ++r) J[(size_t)r * n + c] = e1[r] - r0[r];
                 }
             }
-            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) LU[(size_t)r * n + c] = (r == c ? 1.0 : 0.0) - gh * J[(size_t)r * n + c];
+            const double *Mm = alg->mass;
+            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) LU[(size_t)r * n + c] = (Mm ? Mm[(size_t)r * n + c] : (r == c ? 1.0 : 0.0)) - gh * J[(size_t)r * n + c];
             /* LU with partial pivoting by successive exchange (the device's unrolled form: row i > c is swapped up whenever its entry is larger) */
             for (int c = 0; c < n; ++c) {
                 for (int i = c + 1; i < n; ++i) {
@@ -869,13 +918,18 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
             ROS_SOLVE(b);
             for (int i = 0; i < n; ++i) { k1[i] = b[i]; us[i] = I.uprev[i] + 0.5 * dt * k1[i]; }
             rhs(f1, us, t + 0.5 * dt, ctx); I.nrhs++;
-            for (int i = 0; i < n; ++i) b[i] = f1[i] - k1[i];
+            /* mass-matrix form (the M^-1 f rewrite of the stages multiplied through by M; OrdinaryDiffEq's `mass_matrix === I` branches [upstream-recall]) */
+#define ROS_MASS(out, x) do { if (Mm) for (int i_ = 0; i_ < n; ++i_) { double s_ = 0.0; for (int j_ = 0; j_ < n; ++j_) s_ += Mm[(size_t)i_ * n + j_] * (x)[j_]; (out)[i_] = s_; } else for (int i_ = 0; i_ < n; ++i_) (out)[i_] = (x)[i_]; } while (0)
+            ROS_MASS(e1, k1);
+            for (int i = 0; i < n; ++i) b[i] = f1[i] - e1[i];
             ROS_SOLVE(b);
             for (int i = 0; i < n; ++i) { k2[i] = b[i] + k1[i]; I.u[i] = I.uprev[i] + dt * k2[i]; }
             rhs(I.tmp, I.u, t + dt, ctx); I.nrhs++;                        /* f2 = fsallast */
-            for (int i = 0; i < n; ++i) b[i] = I.tmp[i] - ROS_E32 * (k2[i] - f1[i]) - 2.0 * (k1[i] - I.fsal[i]) + g_recall[ORC_RECALL_ROS_K3_T] * dt * dT[i];
+            ROS_MASS(z0, k2);                                              /* (e1 still holds M k1) */
+            for (int i = 0; i < n; ++i) b[i] = I.tmp[i] - ROS_E32 * (z0[i] - f1[i]) - 2.0 * (e1[i] - I.fsal[i]) + g_recall[ORC_RECALL_ROS_K3_T] * dt * dT[i];
             ROS_SOLVE(b);
 #undef ROS_SOLVE
+#undef ROS_MASS
             for (int i = 0; i < n; ++i) { k3[i] = b[i]; I.utilde[i] = dt / 6.0 * (k1[i] - 2.0 * k2[i] + k3[i]); }
             double EEst = scaled_norm(I.utilde, I.uprev, I.u, n, alg->abstol, alg->reltol);
             const double beta1 = 7.0 / 20.0, beta2 = 1.0 / 5.0;
@@ -960,9 +1014,47 @@ static void fwd_jac(double *J, const double *u, double t, void *c, int n) {
 }
 static int model_autonomous(const orc_model *m) { return m->id != ORC_MODEL_LVT && m->id != ORC_MODEL_BRUSS; }
 
+/* ---- semi-explicit DAE helpers (g_mm_dae) -------------------------------------------------------------------------------------------------------------------------- */
+/* x <- A^-1 x, A row-major k x k (destroyed); Gaussian elimination with partial pivoting; 0 = ok */
+static int small_solve(double *A, int k, double *x) {
+    for (int c = 0; c < k; ++c) {
+        int piv = c; for (int r = c + 1; r < k; ++r) if (fabs(A[r * k + c]) > fabs(A[piv * k + c])) piv = r;
+        if (A[piv * k + c] == 0.0) return -1;
+        if (piv != c) { for (int j = 0; j < k; ++j) { double t = A[c * k + j]; A[c * k + j] = A[piv * k + j]; A[piv * k + j] = t; } double t = x[c]; x[c] = x[piv]; x[piv] = t; }
+        for (int r = c + 1; r < k; ++r) { double f = A[r * k + c] / A[c * k + c]; if (f != 0.0) { for (int j = c; j < k; ++j) A[r * k + j] -= f * A[c * k + j]; x[r] -= f * x[c]; } }
+    }
+    for (int i = k - 1; i >= 0; --i) { double v = x[i]; for (int j = i + 1; j < k; ++j) v -= A[i * k + j] * x[j]; x[i] = v / A[i * k + i]; }
+    return 0;
+}
+/* J = df/du (row-major) from the model's VJP: row r = (df/du)' e_r */
+static void model_jac_plain(const orc_model *m, double *J, const double *u, const double *p, double t) {
+    int n = m->n; double *e = (double *)calloc((size_t)2 * n, sizeof(double)), *row = e + n;
+    for (int r = 0; r < n; ++r) { for (int i = 0; i < n; ++i) e[i] = (i == r); model_vjp(m, row, NULL, e, u, p, t); for (int c = 0; c < n; ++c) J[(size_t)r * n + c] = row[c]; }
+    free(e);
+}
+/* BrownFullBasicInit [upstream-recall: OrdinaryDiffEq]: the differential variables keep their values, the algebraic ones are solved from 0 = f_alg(u_d, u_a) by Newton
+ * (the reference's DAE tests pass an inconsistent u0 and this initializealg: test/Core3/adjoint.jl:1460-1464) */
+static int dae_consistent_init(const orc_model *m, double *u, const double *p, double t) {
+    int n = m->n, na = g_dae_nalg, ia[ORC_MM_MAXN], k = 0;
+    for (int i = 0; i < n; ++i) if (g_dae_isalg[i]) ia[k++] = i;
+    double *f = (double *)calloc((size_t)n + (size_t)n * n + (size_t)na * na + na, sizeof(double)), *J = f + n, *B = J + (size_t)n * n, *r = B + (size_t)na * na;
+    int st = -7;
+    for (int it = 0; it < 50; ++it) {
+        model_f(m, f, u, p, t);
+        double nr = 0; for (int a = 0; a < na; ++a) { r[a] = -f[ia[a]]; nr = fmax(nr, fabs(r[a])); }
+        if (nr <= 1e-13) { st = 0; break; }
+        model_jac_plain(m, J, u, p, t);
+        for (int a = 0; a < na; ++a) for (int b = 0; b < na; ++b) B[a * na + b] = J[(size_t)ia[a] * n + ia[b]];
+        if (small_solve(B, na, r)) { st = -6; break; }
+        for (int a = 0; a < na; ++a) u[ia[a]] += r[a];
+    }
+    free(f);
+    return st;
+}
+
 static orc_alg make_alg(const orc_config *cfg) {
     orc_alg a; a.kind = cfg->stepper; a.dt = cfg->dt; a.abstol = cfg->abstol > 0 ? cfg->abstol : 1e-6; a.reltol = cfg->reltol > 0 ? cfg->reltol : 1e-3;
-    a.split_G = 0; a.split_coef = 0.0; a.jac = NULL; a.autonomous = 0;
+    a.split_G = 0; a.split_coef = 0.0; a.jac = NULL; a.autonomous = 0; a.mass = NULL;
     return a;
 }
 
@@ -979,6 +1071,11 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
     if (dt_hint > 0 && (cfg->stepper == ORC_STEPPER_TSIT5 || cfg->stepper == ORC_STEPPER_ROS23)) a.dt = dt_hint;
     if (cfg->stepper == ORC_STEPPER_ROS23) { a.jac = fwd_jac; a.autonomous = model_autonomous(m); }
     dense_init(sol, m->n, cfg->stepper);                        /* before any early return: the callers release `sol` on every path */
+    if (g_mm_dae) {                                            /* M u' = f with a singular M: the implicit stepper only, from a consistent state */
+        if (cfg->stepper != ORC_STEPPER_ROS23 || g_dae_n != m->n) return -6;
+        a.mass = g_dae_M;
+        int ist = dae_consistent_init(m, u, p, ta); if (ist) return ist;
+    }
     if (cfg->stepper == ORC_STEPPER_ETDRK4) {                   /* u' = (alpha/dx^2) L u + N(u, t) */
         if (m->id != ORC_MODEL_BRUSS) return -6;
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
@@ -1017,6 +1114,8 @@ typedef struct {
     int bs_cur;
     long *nrhs;
     int alg;
+    /* semi-explicit DAE: the algebraic parts of the loss jumps, push!(f.dlam_as, (dlam_a, t)) src/adjoint_common.jl:803 — [ndla][n] (zero on the differential entries) and their times */
+    double *dla, *dla_t; int ndla;
 } adj_ctx;
 
 /* stored forward value at checkpoint time c (non-dense `sol(c)` at a saved point) */
@@ -1175,6 +1274,30 @@ static int loss_jump(adj_ctx *A, orc_integ *I) {
         const double w = A->cfg->loss_scale != 0.0 ? A->cfg->loss_scale : 1.0;
         for (int i = 0; i < n; ++i)
             gu[i] = (lk == ORC_LOSS_COTANGENT) ? A->dLdu[(size_t)idx * n + i] : (lk == ORC_LOSS_LSQ_DATA ? w * (A->y[i] - A->dLdu[(size_t)idx * n + i]) : (A->y[i] - A->cfg->loss_shift));
+    }
+    if (g_mm_dae) {
+        /* src/adjoint_common.jl:790-813 for a semi-explicit DAE:  dhdd = J[alg, diff], dhda = J[alg, alg];  dlam_a = -(dhda' \ g_u[alg]);  dlam_d = dhdd' dlam_a + g_u[diff];
+         * push!(dlam_as, (dlam_a, t));  ldiv!(lu(M'[diff, diff]), dlam_d);  lam[diff] += dlam_d.  The algebraic entries of lam are then re-initialised from their constraint
+         * 0 = (J' lam)[alg] — the integrator's DAE initialisation after a callback that modified u [upstream-recall: BrownFullBasicInit via initializealg, test/Core3/adjoint.jl:1474]. */
+        int na = g_dae_nalg, nd = n - na, ia[ORC_MM_MAXN], id[ORC_MM_MAXN], ka = 0, kd = 0;
+        for (int i = 0; i < n; ++i) { if (g_dae_isalg[i]) ia[ka++] = i; else id[kd++] = i; }
+        double *J = (double *)calloc((size_t)n * n + (size_t)n * n + 2 * (size_t)n, sizeof(double)), *B = J + (size_t)n * n, *x = B + (size_t)n * n, *dld = x + n;
+        model_jac_plain(A->m, J, A->y, A->p, I->t);
+        for (int a = 0; a < na; ++a) { for (int b = 0; b < na; ++b) B[a * na + b] = J[(size_t)ia[b] * n + ia[a]]; x[a] = gu[ia[a]]; }     /* dhda' */
+        if (small_solve(B, na, x)) { free(J); return 0; }
+        double *rec = A->dla + (size_t)A->ndla * n;
+        for (int i = 0; i < n; ++i) rec[i] = 0.0;
+        for (int a = 0; a < na; ++a) rec[ia[a]] = -x[a];                                      /* dlam_a */
+        A->dla_t[A->ndla++] = I->t;
+        for (int d = 0; d < nd; ++d) { double v = gu[id[d]]; for (int a = 0; a < na; ++a) v += J[(size_t)ia[a] * n + id[d]] * rec[ia[a]]; dld[d] = v; }
+        for (int i = 0; i < nd; ++i) for (int j = 0; j < nd; ++j) B[i * nd + j] = g_dae_M[(size_t)id[j] * n + id[i]];                     /* M'[diff, diff] */
+        if (small_solve(B, nd, dld)) { free(J); return 0; }
+        for (int d = 0; d < nd; ++d) I->u[id[d]] += dld[d];
+        for (int a = 0; a < na; ++a) { for (int b = 0; b < na; ++b) B[a * na + b] = J[(size_t)ia[b] * n + ia[a]]; double v = 0.0; for (int d = 0; d < nd; ++d) v -= J[(size_t)id[d] * n + ia[a]] * I->u[id[d]]; x[a] = v; }
+        if (!small_solve(B, na, x)) for (int a = 0; a < na; ++a) I->u[ia[a]] = x[a];
+        free(J);
+        A->cur_time -= 1;
+        return 1;
     }
     mm_solve(g_mm_invT, n, gu);                                                              /* ldiv!(F, dlam_d), F = lu(M')  :805-807 */
     for (int i = 0; i < n; ++i) I->u[i] += gu[i];                                            /* :812-813 */
@@ -1374,7 +1497,8 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
      * Interpolating / Quadrature), so the sign is not restated here */
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
-    if (cfg->stepper == ORC_STEPPER_ROS23 && (cfg->alg == ORC_ALG_BACKSOLVE || cfg->checkpointing)) return -6;   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
+    if (cfg->stepper == ORC_STEPPER_ROS23 && (cfg->alg == ORC_ALG_BACKSOLVE || cfg->checkpointing)) return -6;
+    if (g_mm_dae && (cfg->stepper != ORC_STEPPER_ROS23 || g_dae_n != n || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* semi-explicit DAE: Rosenbrock23, discrete losses by cotangent / shift / data */   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
     orc_dense sol; double *uend = (double *)malloc(sizeof(double) * n); memcpy(uend, u0, sizeof(double) * n);
@@ -1419,6 +1543,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     for (int i = 0; i < nck; ++i) tst[nts++] = ck_t[i];
 
     orc_alg alg = make_alg(cfg);
+    double *adj_mass = NULL;
     if (cfg->stepper == ORC_STEPPER_ETDRK4) {                   /* lam' = -(alpha/dx^2) L lam - R(y(t))' lam (L symmetric), integrated with h < 0; the gradient block has M = 0 */
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
         alg.split_G = G; alg.split_coef = -p[2] / (dx * dx);
@@ -1428,6 +1553,13 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     case ORC_ALG_INTERPOLATING: nz = n + np; rhs = rhs_interpolating; break;           /* z0 = 0 (:412) */
     case ORC_ALG_BACKSOLVE: nz = 2 * n + np; rhs = rhs_backsolve; break;               /* z0 = [0; 0; y(T)] (:229-231) */
     default: nz = n; rhs = rhs_lambda_only; break;
+    }
+    if (g_mm_dae) {   /* mass matrix of the adjoint system: [M' 0; 0 I] (Interpolating, src/interpolating_adjoint.jl:413-426) or M' (Quadrature / Gauss) */
+        adj_mass = (double *)calloc((size_t)nz * nz, sizeof(double));
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) adj_mass[(size_t)i * nz + j] = g_dae_M[(size_t)j * n + i];
+        for (int i = n; i < nz; ++i) adj_mass[(size_t)i * nz + i] = 1.0;
+        alg.mass = adj_mass;
+        A.dla = (double *)calloc((size_t)(M + 1) * n, sizeof(double)); A.dla_t = (double *)calloc((size_t)M + 1, sizeof(double)); A.ndla = 0;
     }
     z = (double *)calloc(nz, sizeof(double));
     if (cfg->alg == ORC_ALG_BACKSOLVE) { memcpy(z + n + np, uend, sizeof(double) * n); if (A.bs_cur >= 1 && time_hits(cfg->t1, ck_t[A.bs_cur - 1])) A.bs_cur -= 1; }
@@ -1459,6 +1591,15 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
         if (nrhs) *nrhs += nev;
         for (int i = 0; i < np; ++i) dp[i] += A.dgp_acc[i];                                  /* res .+= dgdp_cache at every loss time */
         free(seg); free(Q.lam);
+    }
+    if (g_mm_dae) {   /* dp += sum over the loss jumps of f_p(y(t_i))' [0; dlam_a]  (src/sensitivity_interface.jl:510-521, quadrature_adjoint.jl:617-628, gauss_adjoint.jl:854-865) */
+        double *corr = (double *)calloc(np > 0 ? np : 1, sizeof(double));
+        for (int k = 0; k < A.ndla; ++k) {
+            fetch_y(&A, A.dla_t[k]);
+            model_vjp(m, NULL, corr, A.dla + (size_t)k * n, A.y, p, A.dla_t[k]);
+            for (int i = 0; i < np; ++i) dp[i] += corr[i];
+        }
+        free(corr); free(A.dla); free(A.dla_t); free(adj_mass);
     }
     clock_gettime(CLOCK_MONOTONIC, &c2);
     if (t_fwd) *t_fwd += (c1.tv_sec - c0.tv_sec) + 1e-9 * (c1.tv_nsec - c0.tv_nsec);

@@ -580,6 +580,9 @@ template <int M> struct SmallLU {
 
 // solve(prob, Rosenbrock23(); abstol, reltol, dt, tstops, callback) for a small system: the interface of tsit5_integrate plus `lin` — lin.factor(gh, u, t) forms and
 // factors W = I - gh J(u, t), lin.solve(b) overwrites b with W \ b — and `autonomous` (dT = 0).  cb sees the step's k1, k2 in rows 0, 1 of K (ros23_poly / ros23_interp).
+template <class T> struct ros_noref { using type = T; };
+template <class T> struct ros_noref<T&> { using type = T; };
+template <class T> struct ros_noref<T&&> { using type = T; };
 template <int NZ, class KS, class Rhs, class Lin, class Cb, class Pre = NoPre>
 HIPADJ_HD int ros23_integrate(double (&u)[NZ], double tstart, double tend, double dt_hint, double abstol, double reltol,
                               const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps,
@@ -655,14 +658,33 @@ HIPADJ_HD int ros23_integrate(double (&u)[NZ], double tstart, double tend, doubl
 #pragma unroll
         for (int i = 0; i < NZ; ++i) { K.set(0, i, b[i]); w[i] = u[i] + 0.5 * h * b[i]; }
         rhs(f1, w, t + 0.5 * h);
+        // mass-matrix form (Lin::MASS: a semi-explicit DAE, or its adjoint): the M^-1 f rewrite of the stages multiplied through by M — k2 = W \ (f1 - M k1) + k1,
+        // k3 = W \ (f2 - e32 (M k2 - f1) - 2 (M k1 - f0) + d h dT), W = M - d h J (lin.factor) — which stays meaningful for a singular M
+        constexpr bool MASS = ros_noref<Lin>::type::MASS != 0;
+        double mk1[MASS ? NZ : 1];
+        if constexpr (MASS) {
+            double k1v[NZ];
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) b[i] = f1[i] - K.get(0, i);
+            for (int i = 0; i < NZ; ++i) k1v[i] = K.get(0, i);
+            lin.mulM(mk1, k1v);
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) b[i] = f1[i] - (MASS ? mk1[MASS ? i : 0] : K.get(0, i));
         lin.solve(b);
 #pragma unroll
         for (int i = 0; i < NZ; ++i) { const double k2 = b[i] + K.get(0, i); K.set(1, i, k2); w[i] = u[i] + h * k2; }
         rhs(b, w, t + h);                                  // f2 (first-same-as-last of the next step)
+        if constexpr (MASS) {
+            double k2v[NZ], mk2[NZ];
 #pragma unroll
-        for (int i = 0; i < NZ; ++i) { K.set(3, i, b[i]); b[i] = b[i] - ROS23::E32 * (K.get(1, i) - f1[i]) - 2.0 * (K.get(0, i) - K.get(2, i)) + gh * dT[i]; }
+            for (int i = 0; i < NZ; ++i) k2v[i] = K.get(1, i);
+            lin.mulM(mk2, k2v);
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) { K.set(3, i, b[i]); b[i] = b[i] - ROS23::E32 * (mk2[i] - f1[i]) - 2.0 * (mk1[i] - K.get(2, i)) + gh * dT[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) { K.set(3, i, b[i]); b[i] = b[i] - ROS23::E32 * (K.get(1, i) - f1[i]) - 2.0 * (K.get(0, i) - K.get(2, i)) + gh * dT[i]; }
+        }
         lin.solve(b);
         double e2 = 0.0;
 #pragma unroll
@@ -699,10 +721,58 @@ HIPADJ_HD int ros23_integrate(double (&u)[NZ], double tstart, double tend, doubl
     return naccept;
 }
 
+// ---- semi-explicit DAEs (model_dae<Mo>) -------------------------------------------------------------------------------------------------------------------------------
+// the algebraic block of J' (TR) or of J, identity on the differential rows and columns — one factorisation serves every solve on the algebraic variables
+template <class Mo, bool TR> HIPADJ_HD void dae_alg_block(SmallLU<Mo::N>& B, const double (&y)[Mo::N], const double (&pv)[Mo::NP], double t) {
+#pragma unroll
+    for (int r = 0; r < Mo::N; ++r) {
+        double e[Mo::N], row[Mo::N];
+#pragma unroll
+        for (int j = 0; j < Mo::N; ++j) e[j] = j == r ? 1.0 : 0.0;
+        Mo::vjp_u(row, e, y, pv, t);                       // row r of J
+#pragma unroll
+        for (int c = 0; c < Mo::N; ++c) {
+            const bool aa = Mo::isalg(r) && Mo::isalg(c);
+            if (TR) B.a[c][r] = aa ? row[c] : (r == c ? 1.0 : 0.0); else B.a[r][c] = aa ? row[c] : (r == c ? 1.0 : 0.0);
+        }
+    }
+    B.factor();
+}
+// BrownFullBasicInit [upstream-recall]: the differential variables keep their values, the algebraic ones are solved from 0 = f_alg(u) by Newton (the oracle's dae_consistent_init)
+template <class Mo> HIPADJ_HD bool dae_consistent_init(double (&u)[Mo::N], const double (&pv)[Mo::NP], double t) {
+#pragma unroll 1
+    for (int it = 0; it < 50; ++it) {
+        double f[Mo::N], r[Mo::N];
+        Mo::f(f, u, pv, t);
+        double nr = 0.0;
+#pragma unroll
+        for (int j = 0; j < Mo::N; ++j) { r[j] = Mo::isalg(j) ? -f[j] : 0.0; nr = hmax2(nr, habs(r[j])); }
+        if (nr <= 1e-13) return true;
+        SmallLU<Mo::N> B; dae_alg_block<Mo, false>(B, u, pv, t);
+        B.solve(r);
+#pragma unroll
+        for (int j = 0; j < Mo::N; ++j) if (Mo::isalg(j)) u[j] += r[j];
+    }
+    return false;
+}
+
 // W = I - gh (df/du)(u, t) of the forward problem: (df/du)' e_r = row r of the Jacobian, from the model's VJP
 template <class Mo> struct RosLinFwd {
+    static constexpr bool MASS = model_dae<Mo>::value;
     const double (&pv)[Mo::NP];
     SmallLU<Mo::N> lu;
+    HIPADJ_HD void mulM(double (&out)[Mo::N], const double (&x)[Mo::N]) const {
+        if constexpr (MASS) {
+#pragma unroll
+            for (int i = 0; i < Mo::N; ++i) { double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < Mo::N; ++j) s += Mo::mass(i, j) * x[j];
+                out[i] = s; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < Mo::N; ++i) out[i] = x[i];
+        }
+    }
     HIPADJ_HD explicit RosLinFwd(const double (&p_)[Mo::NP]) : pv(p_) {}
     HIPADJ_HD void factor(double gh, const double (&u)[Mo::N], double t) {
 #pragma unroll
@@ -712,7 +782,7 @@ template <class Mo> struct RosLinFwd {
             for (int j = 0; j < Mo::N; ++j) e[j] = j == r ? 1.0 : 0.0;
             Mo::vjp_u(row, e, u, pv, t);
 #pragma unroll
-            for (int c = 0; c < Mo::N; ++c) lu.a[r][c] = (r == c ? 1.0 : 0.0) - gh * row[c];
+            for (int c = 0; c < Mo::N; ++c) { double mrc = (r == c ? 1.0 : 0.0); if constexpr (MASS) mrc = Mo::mass(r, c); lu.a[r][c] = mrc - gh * row[c]; }
         }
         lu.factor();
     }
@@ -738,6 +808,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     for (int j = 0; j < N; ++j) u[j] = u0[i * N + j];
     int s = 0, ms = 0, mc = 0;
     bool overflow = false;
+    if constexpr (model_dae<Mo>::value) { if (!dae_consistent_init<Mo>(u, pv, g.t0)) overflow = true; }      // (no consistent state found: reported like a step overflow)
     // points that coincide with t0
     while (outT && ms < g.M && save_t[ms] <= g.t0) {
 #pragma unroll
@@ -993,6 +1064,8 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     };
     int sa = 0;
     bool aoverflow = false;
+    double dcorr[model_dae<Mo>::value ? NP : 1];      // semi-explicit DAE: sum over the loss jumps of f_p' [0; dlam_a]
+    for (int j = 0; j < (model_dae<Mo>::value ? NP : 1); ++j) dcorr[j] = 0.0;
     auto cb = [&](double t, double tprev, double (&zz)[NZ], const auto& KK) -> bool {
         bool mod = false;
         if (ALG == 3 && t != tprev) {   // dense adjoint solution for the quadrature pass
@@ -1106,6 +1179,42 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     }
 #pragma unroll
                     for (int j = 0; j < N; ++j) zz[j] += gl[j];
+                } else if constexpr (model_dae<Mo>::value) {
+                    // src/adjoint_common.jl:790-813 for a semi-explicit DAE (the oracle's loss_jump, g_mm_dae):  dlam_a = -(J_aa' \ g_a);  dlam_d = g_d + (J' [0; dlam_a])_d;
+                    // dp += f_p' [0; dlam_a] (:803 with src/sensitivity_interface.jl:510-521 — kept apart from the integrated parameter block so that the controller's
+                    // error norm sees what the oracle's does);  M'[diff, diff] \ dlam_d;  lam_d += dlam_d;  lam_a re-initialised from 0 = (J' lam)_a
+                    double gl[N], x[N], v[N], dla[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        gl[j] = (g.loss_kind == 1) ? (y[j] - g.loss_shift) : __builtin_fma(g.la, y[j], g.lb * cotT[((long)(cur_time - 1) * N + j) * g.Npad + i]);
+                    SmallLU<N> B; dae_alg_block<Mo, true>(B, y, pv, t);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) x[j] = Mo::isalg(j) ? gl[j] : 0.0;
+                    B.solve(x);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) dla[j] = Mo::isalg(j) ? -x[j] : 0.0;
+                    { double W[NP]; Mo::vjp_p(W, dla, y, pv, t);
+#pragma unroll
+                      for (int j = 0; j < NP; ++j) dcorr[j] += W[j]; }
+                    Mo::vjp_u(v, dla, y, pv, t);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) x[j] = Mo::isalg(j) ? 0.0 : gl[j] + v[j];
+                    { SmallLU<N> Mt;
+#pragma unroll
+                      for (int r = 0; r < N; ++r)
+#pragma unroll
+                          for (int c = 0; c < N; ++c) Mt.a[r][c] = (!Mo::isalg(r) && !Mo::isalg(c)) ? Mo::mass(c, r) : (r == c ? 1.0 : 0.0);
+                      Mt.factor(); Mt.solve(x); }
+#pragma unroll
+                    for (int j = 0; j < N; ++j) if (!Mo::isalg(j)) zz[j] += x[j];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) dla[j] = Mo::isalg(j) ? 0.0 : zz[j];
+                    Mo::vjp_u(v, dla, y, pv, t);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) x[j] = Mo::isalg(j) ? -v[j] : 0.0;
+                    B.solve(x);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) if (Mo::isalg(j)) zz[j] = x[j];
                 } else {
 #pragma unroll
                     for (int j = 0; j < N; ++j)      // u - shift, or la u + lb c with the streamed column c: the cotangent (0, 1), or the data of HIPADJ_LOSS_LSQ_DATA (w, -w)
@@ -1132,7 +1241,18 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         // W = I - gh A(t_n) for the adjoint system z' = A(t) z + b(t):  A_ll = -J(y(t))', A_ml = -f_p(y(t))' (Interpolating), nothing else — so W is block triangular:
         // the lambda block by an n x n LU of I + gh J', the parameter block by substitution, x_mu = b_mu - gh f_p' x_lam
         struct Lin {
+            enum { MASS = model_dae<Mo>::value ? 1 : 0 };      // (a local class: no static data member) semi-explicit DAE: mass matrix [M' 0; 0 I] of the adjoint system (M' alone for the lambda-only sensealgs)
             const double (&pv)[NP]; decltype(cur)& cu; SmallLU<N> lu; double y[N], gh, t;
+            HIPADJ_HD void mulM(double (&out)[NZ], const double (&x)[NZ]) const {
+#pragma unroll
+                for (int r = 0; r < NZ; ++r) {
+                    double s_ = x[r];
+                    if constexpr (MASS) { if (r < N) { s_ = 0.0;
+#pragma unroll
+                        for (int c = 0; c < N; ++c) s_ += Mo::mass(c, r < N ? r : 0) * x[c]; } }
+                    out[r] = s_;
+                }
+            }
             HIPADJ_HD void factor(double gh_, const double (&)[NZ], double t_) {
                 gh = gh_; t = t_;
                 cu.eval(t, y);
@@ -1143,7 +1263,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     for (int j = 0; j < N; ++j) e[j] = j == c ? 1.0 : 0.0;
                     Mo::vjp_u(row, e, y, pv, t);                 // row c of J: column c of J'
 #pragma unroll
-                    for (int r = 0; r < N; ++r) lu.a[r][c] = (r == c ? 1.0 : 0.0) + gh * row[r];
+                    for (int r = 0; r < N; ++r) { double mrc = (r == c ? 1.0 : 0.0); if constexpr (MASS) mrc = Mo::mass(c, r); lu.a[r][c] = mrc + gh * row[r]; }
                 }
                 lu.factor();
             }
@@ -1170,6 +1290,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         if constexpr (ALG == 2 || ALG == 4) mu_out[j] = gacc[j];
         else if constexpr (ALG == 3) mu_out[j] = gacc[j];  // dp comes from the quadrature pass; gacc: the sum of dgdp_discrete of a model's discrete loss (else zero)
         else mu_out[j] = z[N + j];
+        if constexpr (model_dae<Mo>::value) mu_out[j] += dcorr[j];
     }
     if (ALG == 3) nsteps_adj[i] = sa;   // the TRUE count, also beyond the capacity: the host sizes the buffer from it (readers clamp with g.SmaxA)
     if (na < 0 || aoverflow || ck_overflow) {

@@ -87,6 +87,10 @@ template <int G> HIPADJ_HD void cols_add_first(Cols<G>& a, double x) { a.v[0] +=
 HIPADJ_HD void cols_add_first(double& a, double x) { a += x; }
 template <class Mo, class = void> struct model_has_cols { static constexpr bool value = false; };
 template <class Mo> struct model_has_cols<Mo, decltype((void)Mo::HAS_COLS)> { static constexpr bool value = Mo::HAS_COLS; };
+// Semi-explicit DAE (round 6): a model with `static constexpr bool DAE = true` carries its constant SINGULAR mass matrix — mass(i, j), row-major, and isalg(i) = row i of M
+// is zero (src/adjoint_common.jl:116-122) — and is integrated in mass-matrix form by the Rosenbrock23 lanes (hipadj_adaptive.hpp); every other stepper refuses it at plan time.
+template <class Mo, class = void> struct model_dae { static constexpr bool value = false; };
+template <class Mo> struct model_dae<Mo, decltype((void)Mo::DAE)> { static constexpr bool value = Mo::DAE; };
 // Bundle width for n states and NC columns: at most ELEMS doubles per bundle vector (seven such vectors are live in an RK4 step), the columns spread
 // evenly over the fewest bundles.  The sweeps bundle only when ONE bundle holds all columns (NB == 1: n <= 4 for InterpolatingAdjoint at 24 elements,
 // n <= 5 for the lambda-only GaussAdjoint step at 32): with two or more bundles the (u, p, t)-dependent work is repeated per bundle and the measured

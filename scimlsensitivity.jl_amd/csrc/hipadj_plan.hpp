@@ -106,6 +106,8 @@ typedef int (*plan_user_sizes_fn)(int32_t model, int32_t* n, int32_t* np);
 inline plan_user_sizes_fn& plan_user_sizes_hook() { static plan_user_sizes_fn f = nullptr; return f; }
 typedef bool (*plan_user_wide_fn)(int32_t);   // is this runtime model one of the workgroup-per-trajectory family (hipadj_wmodel_register)?
 inline plan_user_wide_fn& plan_user_wide_hook() { static plan_user_wide_fn f = nullptr; return f; }
+typedef bool (*plan_user_dae_fn)(int32_t);    // does this runtime model carry a SINGULAR mass matrix (semi-explicit DAE, hipadj_model_set_mass_matrix)?
+inline plan_user_dae_fn& plan_user_dae_hook() { static plan_user_dae_fn f = nullptr; return f; }
 inline bool plan_user_model(int m) { return m >= HIPADJ_MODEL_USER_BASE; }
 inline bool plan_small_model(int m) { return (m >= HIPADJ_MODEL_LV && m <= HIPADJ_MODEL_FALLMASS) || plan_user_model(m); }
 
@@ -231,6 +233,9 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->alg < HIPADJ_ALG_INTERPOLATING || cfg->alg > HIPADJ_ALG_GAUSS_KRONROD) { err = "unknown sensealg"; return HIPADJ_ERR_INVALID_ARG; }
     if (cfg->alg == HIPADJ_ALG_GAUSS_KRONROD && (P.mlp || (P.field && cfg->stepper != HIPADJ_STEPPER_RK4_FIXED))) { err = "GaussKronrodAdjoint is offered for the lane-per-trajectory, wide and (RK4) PDE families"; return HIPADJ_ERR_UNSUPPORTED; }
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ETDRK4_FIXED && cfg->stepper != HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
+    if (plan_user_model(cfg->model) && plan_user_dae_hook() && plan_user_dae_hook()(cfg->model)) {      // M u' = f with a singular M (src/adjoint_common.jl:117-135, 790-803)
+        if (cfg->stepper != HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) { err = "the model's mass matrix is singular (a semi-explicit DAE): HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE integrates it in mass-matrix form; the explicit steppers cannot"; return HIPADJ_ERR_UNSUPPORTED; }
+    }
     if (cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the stiff stepper of the lane family (hipadj_adaptive.hpp ros23_integrate): planned like adaptive Tsit5 below
         if (!plan_small_model(cfg->model) || P.wide) { err = "Rosenbrock23 is available for the lane-per-trajectory models (n <= 8)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "Rosenbrock23: Interpolating-, Gauss-, GaussKronrod- and QuadratureAdjoint (the backsolved system is not affine in its state; BacksolveAdjoint of a stiff problem is unstable anyway, src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }

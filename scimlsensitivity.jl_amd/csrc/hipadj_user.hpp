@@ -53,6 +53,8 @@ struct UserModelSrc {
     bool cols = true;         // the VJP bodies compile for Cols<G> (column bundles); cleared by user_compile when they do not
     bool has_mm = false;      // constant non-singular mass matrix (hipadj_model_set_mass_matrix): minv = M^{-1}, row-major n x n
     double minv[64] = {0};
+    bool dae = false;         // constant SINGULAR mass matrix of a semi-explicit DAE (round 6): mm = M itself (row-major), zero rows = algebraic variables; Rosenbrock23 only
+    double mm[64] = {0};
     int n = 0, np = 0, rev = 0;   // rev: bumped when the sources change, part of the code-cache key
     // wide model (hipadj_wmodel_register; hipadj_wide.hpp): SPMD bodies f / vjp for a workgroup of `threads` per trajectory
     bool wide = false;
@@ -280,6 +282,17 @@ inline std::string user_model_struct(const UserModelSrc& m) {
       // column bundles through the VJP bodies (hipadj_models.hpp).  Dual-number VJPs: only up to three states — the bundle keeps the whole dual Jacobian live next
       // to all columns, and measured slower than the per-column form from n = 4 on (ring n = 3: 5.0 -> 1.45 ms, n = 4: 1.6 -> 3.3 ms; profiles/r2_user_auto_cols_ab.log)
       << "    static constexpr bool HAS_COLS = " << ((m.cols && (!m.auto_vjp || m.n <= 3)) ? "true" : "false") << ";\n";
+    if (m.dae) {
+        // M u' = f with a singular M = [Md 0; 0 0] (src/adjoint_common.jl:117-135): the model stays f; the Rosenbrock23 lanes integrate it — and M' lam' = -J' lam — in
+        // mass-matrix form (hipadj_adaptive.hpp, model_dae): they ask for the entries of M and for which variables are algebraic (zero rows of M, :116-122)
+        char num[40];
+        o << "    static constexpr bool DAE = true;\n    HIPADJ_HD static double mass(int i, int j) { const int k = i * N + j; return";
+        for (int e = 0; e < m.n * m.n; ++e) if (m.mm[e] != 0.0) { snprintf(num, sizeof(num), "%.17g", m.mm[e]); o << " k == " << e << " ? " << num << " :"; }
+        o << " 0.0; }\n    HIPADJ_HD static bool isalg(int i) { return";
+        bool any = false;
+        for (int i = 0; i < m.n; ++i) { bool z = true; for (int j = 0; j < m.n; ++j) z = z && m.mm[i * m.n + j] == 0.0; if (z) { o << (any ? " || " : " ") << "i == " << i; any = true; } }
+        o << (any ? "" : " false") << "; }\n";
+    }
     if (m.has_mm) {
         // constant mass matrix M u' = f (ODEFunction(f; mass_matrix = M), src/adjoint_common.jl:110-135): the kernels integrate
         // u' = F(u) = M^{-1} f(u) and the adjoint of THAT system, nu' = -F_u^T nu with the plain jumps nu += g_u.  nu = M^T lam, where lam is
@@ -693,12 +706,33 @@ inline int user_set_mass_matrix(int32_t model, const double* M, std::string& err
     const int idx = model - HIPADJ_MODEL_USER_BASE;
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_mass_matrix: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
     UserModelSrc& m = R.models[idx];
-    if (!M) { if (m.has_mm) { m.has_mm = false; m.rev++; } return HIPADJ_OK; }
+    if (!M) { if (m.has_mm || m.dae) { m.has_mm = false; m.dae = false; m.rev++; } return HIPADJ_OK; }
     if (m.wide || m.n > 8) {   // minv[64] / a[8][16] below are sized for the lane family (n <= 8); the wide kernels never consult has_mm
         err = "hipadj_model_set_mass_matrix: mass matrices are implemented for lane-family runtime models (n <= 8) only, not for wide models (hipadj_wmodel_register)";
         return HIPADJ_ERR_UNSUPPORTED;
     }
     const int n = m.n;
+    {   // semi-explicit DAE?  zero rows of M that are also zero columns, the block of the other variables non-singular ("The submatrix corresponding to the differential
+        // variables of the mass matrix must be nonsingular!", src/adjoint_common.jl:131-133)
+        bool alg[8]; int nalg = 0; bool fin = true;
+        for (int i = 0; i < n; ++i) { bool z = true; for (int j = 0; j < n; ++j) { fin = fin && std::isfinite(M[i * n + j]); z = z && M[i * n + j] == 0.0; } alg[i] = z; nalg += z; }
+        if (fin && nalg > 0 && nalg < n) {
+            bool ok = true;
+            for (int i = 0; i < n && ok; ++i) for (int j = 0; j < n; ++j) if (alg[j] && M[i * n + j] != 0.0) { ok = false; break; }
+            if (ok) {
+                int id[8], nd = 0; double b[8][8], sc = 0.0;
+                for (int i = 0; i < n; ++i) if (!alg[i]) id[nd++] = i;
+                for (int i = 0; i < nd; ++i) for (int j = 0; j < nd; ++j) { b[i][j] = M[id[i] * n + id[j]]; sc = std::fmax(sc, std::fabs(b[i][j])); }
+                for (int c = 0; c < nd && ok; ++c) {
+                    int piv = c; for (int r = c + 1; r < nd; ++r) if (std::fabs(b[r][c]) > std::fabs(b[piv][c])) piv = r;
+                    if (!(std::fabs(b[piv][c]) > 1e-13 * sc)) { ok = false; break; }
+                    if (piv != c) for (int j = 0; j < nd; ++j) std::swap(b[c][j], b[piv][j]);
+                    for (int r = c + 1; r < nd; ++r) { const double f = b[r][c] / b[c][c]; for (int j = c; j < nd; ++j) b[r][j] -= f * b[c][j]; }
+                }
+                if (ok) { std::memcpy(m.mm, M, sizeof(double) * (size_t)n * n); m.dae = true; m.has_mm = false; m.rev++; return HIPADJ_OK; }
+            }
+        }
+    }
     double a[8][16]; double scale = 0.0;
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
         if (!std::isfinite(M[i * n + j])) { err = "hipadj_model_set_mass_matrix: non-finite entry"; return HIPADJ_ERR_INVALID_ARG; }
@@ -707,8 +741,8 @@ inline int user_set_mass_matrix(int32_t model, const double* M, std::string& err
     for (int c = 0; c < n; ++c) {   // Gauss-Jordan, partial pivoting
         int piv = c; for (int r = c + 1; r < n; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
         if (!(std::fabs(a[piv][c]) > 1e-13 * scale)) {
-            err = "hipadj_model_set_mass_matrix: the mass matrix is singular; a semi-explicit DAE needs an implicit stepper (the device steppers are RK4 / Tsit5) "
-                  "- only constant non-singular mass matrices are supported";
+            err = "hipadj_model_set_mass_matrix: the mass matrix is singular and not of the semi-explicit form [Md 0; 0 0] (zero rows that are also zero columns, Md non-singular: "
+                  "src/adjoint_common.jl:116-135) - that form is integrated by HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE, a non-singular M by every stepper";
             return HIPADJ_ERR_UNSUPPORTED;
         }
         if (piv != c) for (int j = 0; j < 2 * n; ++j) std::swap(a[c][j], a[piv][j]);
@@ -716,8 +750,14 @@ inline int user_set_mass_matrix(int32_t model, const double* M, std::string& err
         for (int r = 0; r < n; ++r) if (r != c && a[r][c] != 0.0) { const double f = a[r][c]; for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j]; }
     }
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) m.minv[i * n + j] = a[i][n + j];
-    m.has_mm = true; m.rev++;
+    m.has_mm = true; m.dae = false; m.rev++;
     return HIPADJ_OK;
+}
+inline bool user_model_is_dae(int32_t model) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    return idx >= 0 && idx < (int)R.models.size() && R.models[idx].dae;
 }
 // M^{-1} of the model's mass matrix (row-major into out[n*n]); false when it has none
 inline bool user_mass_matrix_inverse(int32_t model, double* out) {
@@ -776,6 +816,7 @@ inline int user_register(const char* name, int32_t n, int32_t np, const char* f,
     *id = HIPADJ_MODEL_USER_BASE + (int32_t)R.models.size() - 1;
     plan_user_sizes_hook() = &user_model_sizes;
     plan_user_segcap_hook() = &user_seg_cap;
+    plan_user_dae_hook() = &user_model_is_dae;
     return HIPADJ_OK;
 }
 

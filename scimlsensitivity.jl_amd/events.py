@@ -62,6 +62,9 @@ def solve_with_events(solve, ts_of, ensprob, alg, callback, *, saveat=None, dt=N
     if checkpoints is not None or save_idxs is not None or save_everystep:
         raise ValueError("callback: `checkpoints`, `save_idxs` and `save_everystep` are not combined with event problems (the pieces use their defaults)")
     mid = _model_id(prob)
+    mm0 = _lib.MASS.get(mid)
+    if mm0 is not None and abs(np.linalg.det(mm0)) < 1e-13 * max(1.0, float(np.abs(mm0).max())) ** mm0.shape[0]:
+        raise ValueError("callback: events are not combined with a singular mass matrix (semi-explicit DAE): the chaining of the pieces divides by M'")
     t0, t1 = prob.tspan
     ts = ts_of(prob.tspan, saveat, 0.0 if dt is None else dt, False, save_start, save_end)
     if len(ts) == 0:

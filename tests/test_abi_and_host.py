@@ -286,7 +286,7 @@ def test_runtime_model_registration_compiles_for_gfx950_and_reports_errors():
 
 def test_runtime_model_mass_matrix_registration():
     """ODEFunction(f; mass_matrix = M) (test/Core3/adjoint.jl:1315-1325): a constant non-singular M is folded into the generated model (hand VJPs
-    and dual-number VJPs both compile for gfx950); a singular one (semi-explicit DAE, src/adjoint_common.jl:117-135) is refused with the reason."""
+    and dual-number VJPs both compile for gfx950); a singular one is refused with the reason unless it has the semi-explicit form (next test)."""
     import user_models as UM
     import scimlsensitivity_jl_amd as sa
     from scimlsensitivity_jl_amd import _lib
@@ -294,9 +294,11 @@ def test_runtime_model_mass_matrix_registration():
     f = sa.DeviceFunction("affine3_mm_cpu", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"], mass_matrix=UM.AFFINE3_MM, check=True)
     assert np.array_equal(f.mass_matrix, np.array(UM.AFFINE3_MM))
     sa.DeviceFunction("affine3_mm_auto_cpu", m["n"], m["np"], m["f"], mass_matrix=UM.AFFINE3_MM, check=True)
-    with pytest.raises(_lib.HipadjError, match="singular") as e:
-        f.set_mass_matrix(np.diag([1.0, 1.0, 0.0]))
+    with pytest.raises(_lib.HipadjError, match="singular") as e:      # singular and NOT of the semi-explicit form [Md 0; 0 0]
+        f.set_mass_matrix(np.array([[1.0, 1.0, 0.0], [1.0, 1.0, 0.0], [0.0, 0.0, 1.0]]))
     assert e.value.status == -6
+    with pytest.raises(_lib.HipadjError, match="singular"):             # a zero row whose column is not zero
+        f.set_mass_matrix(np.array([[1.0, 0.0, 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]]))
     with pytest.raises(ValueError):
         f.set_mass_matrix(np.eye(2))
     with pytest.raises(_lib.HipadjError):
@@ -306,6 +308,30 @@ def test_runtime_model_mass_matrix_registration():
     f.set_mass_matrix(None)
     assert f.mass_matrix is None
     _lib.check_model(f.id)
+
+
+def test_runtime_model_singular_mass_matrix_is_a_dae_for_the_stiff_stepper_only(tmp_path, monkeypatch):
+    """mass_matrix = diag(1, 1, 0) on `rober` (test/Core3/adjoint.jl:1434-1454): accepted as a semi-explicit DAE; hipadj_model_check_config compiles the Rosenbrock23 kernels of
+    the generated model (DAE / mass / isalg members, hiprtc, no device) for every sensealg it is offered with and refuses the other steppers by name."""
+    import ctypes as C
+    import emu as E
+    import user_models as UM
+    import scimlsensitivity_jl_amd as sa
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.ROBERDAE
+    f = sa.DeviceFunction("roberdae_cpu", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"], mass_matrix=UM.ROBERDAE_MM)
+    L = _lib.load()
+    for alg in ("interpolating", "gauss", "gausskronrod", "quadrature"):
+        cfg = E.make_config("roberdae_cpu", alg, 8, 0.0, 100.0, 0.0, [50.0, 100.0], loss_kind=0, stepper=3, abstol=1e-8, reltol=1e-6)
+        assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+    for stepper, kw in ((0, dict(dt=0.01)), (1, dict(dt=0.0))):
+        cfg = E.make_config("roberdae_cpu", "interpolating", 8, 0.0, 1.0, kw["dt"], [1.0], loss_kind=0, stepper=stepper)
+        assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.ERR_UNSUPPORTED and b"singular" in L.hipadj_last_error(None)
+    cfg = E.make_config("roberdae_cpu", "backsolve", 8, 0.0, 1.0, 0.0, [1.0], loss_kind=0, stepper=3, checkpointing=True)
+    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.ERR_UNSUPPORTED
+    f.set_mass_matrix(None)            # back to an ODE model: every stepper again
+    cfg = E.make_config("roberdae_cpu", "interpolating", 8, 0.0, 1.0, 0.01, [1.0], loss_kind=0, stepper=0)
+    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
 
 
 def test_runtime_model_affect_registration_and_loud_failure_without_a_device():

@@ -205,3 +205,39 @@ def test_robertson_gradient_at_1e_6_against_the_oracle(sa, gold, alg, oalg):
     rdu0, rdp, rout, _ = pr.adjoint_ensemble(u0, pp, d)
     assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < 1e-6 and np.max(np.abs(du0 - rdu0) / np.abs(rdu0)) < 1e-6
     assert relc(dp[0], c["dp"]) < 1e-5 and relc(du0[0], c["du0"]) < 1e-5
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_semi_explicit_dae_singular_mass_matrix(sa, gold, alg, oalg):
+    """test/Core3/adjoint.jl:1434-1530 on the device: ODEFunction(rober, mass_matrix = diag(1, 1, 0)) — the third row of `rober` is the conservation constraint —, p = [0.04, 3e7,
+    1e4], tspan (0, 100), ts = [50, 100], dg = e_3, from the reference's inconsistent start u0 = [1, 0, 1] (trajectory 0) and from consistent perturbed starts.  Against the
+    oracle's restatement of the DAE adjoint (src/adjoint_common.jl:116-135, 790-813) and the independent Radau gradient of the equivalent ODE; the reference's bar between
+    sensealgs and against ForwardDiff is rtol 1e-5 (:1483-1514)."""
+    c = gold["rober"]
+    if "roberdae" not in _registered:
+        m = UM.ROBERDAE
+        _registered["roberdae"] = sa.DeviceFunction("roberdae_ros23", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"], mass_matrix=UM.ROBERDAE_MM)
+    f = _registered["roberdae"]
+    rng = np.random.default_rng(11)
+    N = 16
+    pp = np.asarray(c["p"]) * (1 + 0.1 * rng.uniform(-1, 1, (N, 3))); pp[0] = c["p"]
+    u0 = np.zeros((N, 3)); u0[:, 0] = 1.0 - 0.05 * rng.uniform(0, 1, N); u0[:, 2] = 1.0 - u0[:, 0]; u0[0] = [1.0, 0.0, 1.0]
+    ts = np.asarray(c["ts"])
+    d = np.zeros((N, 2, 3)); d[:, :, 2] = 1.0
+    quad = alg == "quadrature"
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 100.0), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts,
+                   sensealg=(sa.QuadratureAdjoint(abstol=1e-14, reltol=1e-8) if quad else sens(sa, alg, 1e-8)), abstol=1e-10, reltol=1e-8)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=d)
+    out = sol.u.copy()
+    sol.engine.close()
+    assert np.max(np.abs(out.sum(axis=2) - 1.0)) < 1e-9                 # the constraint along every solution (trajectory 0: after the consistent initialisation)
+    g = np.asarray(c["du0"])
+    assert relc(dp[0], c["dp"]) < 1e-5 and relc(du0[0, :2], [g[0] - g[2], g[1] - g[2]]) < 2e-4
+    with O.mass_matrix(np.asarray(UM.ROBERDAE_MM)):
+        pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=ts, loss="COTANGENT", quad_abstol=1e-14, quad_reltol=1e-8)
+        rdu0, rdp, rout, _ = pr.adjoint_ensemble(u0, pp, d)
+    bar = 1e-4 if quad else 1e-6          # quadgk's first panel on a stiff problem: see test_robertson_gradient_at_1e_6_against_the_oracle
+    assert np.max(np.abs(out - rout)) < 1e-9
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < bar and np.max(np.abs(du0 - rdu0)) < bar * np.max(np.abs(rdu0))
+    with pytest.raises(sa.HipadjError, match="singular"):              # the explicit steppers refuse the model
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[1], (0.0, 1.0), pp[1]), u0[1:3], pp[1:3]), sa.Tsit5(), saveat=[1.0])

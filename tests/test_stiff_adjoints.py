@@ -201,3 +201,63 @@ def test_lane_bodies_behind_a_mass_matrix(alg, oalg):
         ref = O.Problem("RING", alg=oalg, t0=0.0, t1=T, save_times=ts, loss="COTANGENT", dims=(n, 0, 0, 0), stepper="ROS23", dt=0.0, abstol=1e-9, reltol=1e-9, quad_abstol=1e-9, quad_reltol=1e-9)
         rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
     assert rel(out, rout) < 1e-10 and rel(du0, rdu0 @ M) < 1e-6 and rel(dp, rdp) < 1e-6      # measured 7e-15 / 2e-8 / 3e-8
+
+
+# ---- singular mass matrix: the semi-explicit DAE of test/Core3/adjoint.jl:1434-1530 -------------------------------------------------------------------------------------
+DAE_M = np.diag([1.0, 1.0, 0.0])
+
+
+def dae_golden(gold):
+    """`rober` with the conservation row as a constraint has the trajectory of the ODE form whenever sum(u0) = 1: the independent Radau gradient of the ODE fixture IS the DAE's
+    dG/dp; dG/d(differential u0) follows from it with y3(0) = 1 - y1(0) - y2(0)."""
+    c = gold["rober"]
+    g = np.asarray(c["du0"])
+    return c, np.asarray(c["dp"]), np.array([g[0] - g[2], g[1] - g[2]])
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("u0", [[1.0, 0.0, 0.0], [1.0, 0.0, 1.0]], ids=["consistent", "inconsistent"])
+def test_oracle_semi_explicit_dae_against_the_independent_gradient(gold, alg, oalg, u0):
+    """ODEFunction(rober, mass_matrix = diag(1, 1, 0)), p = [0.04, 3e7, 1e4], tspan (0, 100), ts = [50, 100], dg = e_3 (test/Core3/adjoint.jl:1434-1466): the reference asks
+    every sensealg to agree with ForwardDiff to rtol 1e-5 (:1483, 1493, 1503, 1514).  u0 = [1, 0, 1] is the reference's own, inconsistent, start (:1460): BrownFullBasicInit
+    moves y3 to 0.  du0 = lam(t0): its differential entries are dG/d(y1(0), y2(0)) along the constraint."""
+    c, gdp, gdu = dae_golden(gold)
+    d = np.zeros((2, 3)); d[:, 2] = 1.0
+    with O.mass_matrix(DAE_M):
+        pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=c["ts"], loss="COTANGENT", quad_abstol=1e-12, quad_reltol=1e-8)
+        du0, dp, out = pr.adjoint(u0, c["p"], d)
+    assert relc(dp, gdp) < 1e-5 and relc(du0[:2], gdu) < 2e-4           # measured 1.8e-6 (3.7e-6 Quadrature) / 3e-5 (the small second entry)
+    assert np.max(np.abs(out - np.asarray(c["u_at_ts"]))) < 1e-6 and np.max(np.abs(out.sum(axis=1) - 1.0)) < 1e-9      # the constraint holds along the solution
+
+
+def test_oracle_mass_matrix_forms_that_are_refused():
+    L = O.lib()
+    for M in (np.array([[1.0, 1.0], [1.0, 1.0]]), np.array([[1.0, 0.0, 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]]), np.zeros((2, 2))):     # singular, not [Md 0; 0 0]
+        Mc = np.ascontiguousarray(M)
+        assert L.orc_set_mass_matrix(M.shape[0], O._p(Mc)) == -2
+    L.orc_set_mass_matrix(0, None)
+    with O.mass_matrix(DAE_M):      # a DAE needs the implicit stepper
+        with pytest.raises(RuntimeError):
+            O.Problem("ROBERDAE", alg="INTERPOLATING", stepper="TSIT5", t0=0.0, t1=1.0, dt=0.0, save_times=[1.0], loss="COTANGENT").adjoint([1.0, 0.0, 0.0], [0.04, 3e7, 1e4], np.zeros((1, 3)))
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_lane_bodies_semi_explicit_dae(gold, alg, oalg):
+    """The DAE lanes (mass-matrix form of the stages, consistent initialisation, the loss jumps of src/adjoint_common.jl:790-813 with one factorisation of the algebraic block
+    serving the elimination and the re-initialisation) against the oracle, from the reference's inconsistent start, and against the independent gradient."""
+    c, gdp, gdu = dae_golden(gold)
+    d = np.zeros((1, 2, 3)); d[:, :, 2] = 1.0
+    cfg = E.make_config("emu_roberdae", alg, 1, 0.0, 100.0, 0.0, c["ts"], loss_kind=0, stepper=ROS, abstol=1e-10, reltol=1e-8, max_steps=100000, quad_abstol=1e-12, quad_reltol=1e-8)
+    du0, dp, out = E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 1.0]], c["p"], d)
+    with O.mass_matrix(DAE_M):
+        pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=c["ts"], loss="COTANGENT", quad_abstol=1e-12, quad_reltol=1e-8)
+        rdu0, rdp, rout = pr.adjoint([1.0, 0.0, 1.0], c["p"], d[0])
+    assert np.max(np.abs(out[0] - rout)) < 1e-9 and relc(dp, rdp) < 1e-6 and np.max(np.abs(du0[0] - rdu0)) < 1e-8      # measured 5e-11 / 2e-9 / 2e-11
+    assert relc(dp, gdp) < 1e-5
+
+
+def test_lane_bodies_dae_model_needs_the_stiff_stepper():
+    for st in (0, 1):
+        cfg = E.make_config("emu_roberdae", "interpolating", 1, 0.0, 1.0, 0.01, [1.0], loss_kind=1, stepper=st)
+        with pytest.raises(RuntimeError, match="singular"):
+            E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 0.0]], [0.04, 3e7, 1e4])

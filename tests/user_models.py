@@ -36,3 +36,14 @@ AFFINE3 = dict(  # `foo` of the mass-matrix test, test/Core3/adjoint.jl:1315-132
          "out[2] = 3.0*lam[0] + 6.0*lam[1] + 9.0*lam[2];"),
     vjp_p="out[0] = lam[0] + lam[1]; out[1] = 2.0*lam[1]; out[2] = lam[2] + lam[1];")
 AFFINE3_MM = [[-1.0, -2.0, -4.0], [-2.0, -3.0, -7.0], [-1.0, -3.0, -41.0]]   # mm = -[1 2 4; 2 3 7; 1 3 41], test/Core3/adjoint.jl:1322
+
+
+ROBERDAE = dict(  # `rober` exactly as test/Core3/adjoint.jl:1434-1441 writes it: the third row is the conservation constraint; mass matrix diag(1, 1, 0) (:1450-1454) — oracle: ORC_MODEL_ROBERDAE
+    n=3, np=3,
+    f="du[0] = -p[0]*u[0] + p[2]*u[1]*u[2]; du[1] = p[0]*u[0] - p[1]*u[1]*u[1] - p[2]*u[1]*u[2]; du[2] = u[0] + u[1] + u[2] - 1.0;",
+    vjp=("out[0] = -p[0]*lam[0] + p[0]*lam[1] + lam[2];"
+         "out[1] = p[2]*u[2]*lam[0] + (-2.0*p[1]*u[1] - p[2]*u[2])*lam[1] + lam[2];"
+         "out[2] = p[2]*u[1]*lam[0] - p[2]*u[1]*lam[1] + lam[2];"),
+    vjp_p=("out[0] = -u[0]*lam[0] + u[0]*lam[1]; out[1] = -u[1]*u[1]*lam[1];"
+           "out[2] = u[1]*u[2]*lam[0] - u[1]*u[2]*lam[1];"))
+ROBERDAE_MM = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]]
