@@ -326,8 +326,10 @@ end
 
 `ODEFunction(f!; mass_matrix = M)` for a registered model: `M u' = f` with a constant NON-SINGULAR matrix (test/Core3/adjoint.jl:1315-1376).
 The ABI takes M row-major, Julia stores column-major, so the transpose is materialised once here.  `du0` keeps the reference's meaning
-(lam(t0) of `M' lam' = -J' lam`, src/sensitivity_interface.jl:500).  A singular `M` (semi-explicit DAE) is refused by the library: the
-device steppers are explicit.
+(lam(t0) of `M' lam' = -J' lam`, src/sensitivity_interface.jl:500).  A singular `M` of the semi-explicit form `[Md 0; 0 0]` (zero rows that are
+also zero columns: the algebraic variables of src/adjoint_common.jl:116-135) makes the model a DAE: `STEPPER_ROSENBROCK23_ADAPTIVE` integrates it in
+mass-matrix form from a consistent state (test/Core3/adjoint.jl:1434-1530); the explicit steppers refuse such a model at `Handle` creation.
+Any other singular `M` is refused here.
 """
 function set_mass_matrix!(id::Integer, n::Integer, M)
     if M === nothing

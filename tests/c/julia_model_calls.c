@@ -16,9 +16,12 @@ int main(void) {
     const double M_rowmajor[n * n] = {2.0, 0.5, 0.0, 1.5};
     rc = hipadj_model_set_mass_matrix(id, M_rowmajor);
     if (rc != HIPADJ_OK) { fprintf(stderr, "mass matrix -> %d: %s\n", rc, hipadj_last_error(NULL)); return 2; }
-    const double singular[n * n] = {1.0, 0.0, 0.0, 0.0};
+    const double singular[n * n] = {1.0, 1.0, 1.0, 1.0};
     rc = hipadj_model_set_mass_matrix(id, singular);
     printf("singular %d\n", rc);                                            /* HIPADJ_ERR_UNSUPPORTED: refused, the previous matrix stays */
+    const double semi_explicit[n * n] = {1.0, 0.0, 0.0, 0.0};                /* [Md 0; 0 0]: a DAE for HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE (round 6) */
+    rc = hipadj_model_set_mass_matrix(id, semi_explicit);
+    printf("semi_explicit %d\n", rc);
     rc = hipadj_model_set_mass_matrix(id, NULL);                             /* set_mass_matrix!(m, nothing) */
     if (rc != HIPADJ_OK) return 2;
     /* set_affect!(m, "un[0] += 2.0; pn[1] = 1.1 * p[1];") */

@@ -128,7 +128,7 @@ def test_julia_model_calls_from_c(tmp_path):
     sa.build_extension()
     exe = _build_model_calls(sa, tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True)
-    assert "singular -6" in r.stdout and "version 109" in r.stdout
+    assert "singular -6" in r.stdout and "semi_explicit 0" in r.stdout and "version 109" in r.stdout
     if not os.path.exists("/dev/kfd"):
         assert r.returncode == 1 and "hipadj status -2" in r.stderr and "no usable HIP device" in r.stderr
         return
