@@ -201,6 +201,26 @@ for alg in ("INTERPOLATING", "GAUSS", "GAUSS_KRONROD", "QUADRATURE")
     end
 end
 
+# (11) (round 6) the semi-explicit DAE of test/Core3/adjoint.jl:1434-1530: `rober` with mass_matrix = diag(1, 1, 0), solved and differentiated with Rosenbrock23 from the
+#      test's inconsistent start [1, 0, 1] (BrownFullBasicInit): pins the mass-matrix form of the stages, the initialisation, the loss jump with its algebraic part
+#      (src/adjoint_common.jl:790-813), the re-initialisation of the algebraic adjoints and the jumps' parameter term (src/sensitivity_interface.jl:510-521).
+function rober_dae!(du, u, p, t)
+    du[1] = -p[1] * u[1] + p[3] * u[2] * u[3]; du[2] = p[1] * u[1] - p[2] * u[2]^2 - p[3] * u[2] * u[3]; du[3] = u[1] + u[2] + u[3] - 1
+    return nothing
+end
+let Mdae = [1.0 0 0; 0 1.0 0; 0 0 0], p = [0.04, 3.0e7, 1.0e4], ts = [50.0, 100.0]
+    dg3(out, u, p, t, i) = (fill!(out, 0); out[end] = 1)
+    prob = ODEProblem(ODEFunction(rober_dae!, mass_matrix = Mdae), [1.0, 0.0, 1.0], (0.0, 100.0), p)
+    sol = solve(prob, Rosenbrock23(); abstol = 1e-10, reltol = 1e-8, initializealg = BrownFullBasicInit())
+    for (nm, sa) in (("INTERPOLATING", InterpolatingAdjoint()), ("GAUSS", GaussAdjoint()), ("GAUSS_KRONROD", GaussKronrodAdjoint()), ("QUADRATURE", QuadratureAdjoint(abstol = 1e-14, reltol = 1e-8)))
+        du0, dp = adjoint_sensitivities(sol, Rosenbrock23(); t = ts, dgdu_discrete = dg3, sensealg = sa, abstol = 1e-10, reltol = 1e-8, initializealg = BrownFullBasicInit())
+        push!(cases, Dict("name" => "ros23_rober_dae_$nm", "kind" => "dae", "model" => "ROBERDAE", "alg" => nm, "stepper" => "ROS23", "tspan" => [0.0, 100.0], "abstol" => 1e-10, "reltol" => 1e-8,
+                          "ts" => ts, "u0" => [1.0, 0.0, 1.0], "p" => p, "mass_matrix" => [collect(Mdae[i, :]) for i in 1:3], "du0" => collect(du0), "dp" => vec(collect(dp)),
+                          "forward_steps" => length(sol.t) - 1, "out" => [collect(sol(t)) for t in ts],
+                          "targets" => "mass-matrix Rosenbrock23, BrownFullBasicInit, the DAE loss jump and its parameter term, re-initialised algebraic adjoints"))
+    end
+end
+
 open(joinpath(@__DIR__, "..", "..", "tests", "golden", "reference_fixtures.json"), "w") do io
     JSON.print(io, Dict("generator" => "oracle/_ref/make_fixtures.jl", "SciMLSensitivity" => string(pkgversion(SciMLSensitivity)),
                         "OrdinaryDiffEq" => string(pkgversion(OrdinaryDiffEq)), "julia" => string(VERSION), "cases" => cases), 1)

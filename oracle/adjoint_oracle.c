@@ -375,7 +375,7 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
  * and the loss jumps are divided by lu(M') (adjointdiffcache, src/adjoint_common.jl:110-135; ReverseLossCallback :805-807).
  * An explicit stepper needs the blocks solved: every right-hand side block b of a row block with mass matrix B becomes B^{-1} b.
  * du0 is lam(t0) exactly as the reference returns it (src/sensitivity_interface.jl:500) - no M' factor.
- * Singular M (semi-explicit DAE, :117-135, 790-803) needs an implicit solver and is outside this restatement.
+ * Singular M of the semi-explicit form (:117-135, 790-803): the DAE path below (round 6, Rosenbrock23 only); any other singular M is refused (-2).
  * Process-wide and read-only while a solve runs (set before, cleared after). */
 #define ORC_MM_MAXN 64      /* (8 until round 4: traced wide models carry mass matrices beyond the lane family) */
 static int g_mm_n = 0;

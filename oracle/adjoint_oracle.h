@@ -100,7 +100,9 @@ int orc_model_sizes(int model, const int dims[4], int *n, int *np);
 
 /* Constant non-singular mass matrix M (n x n, row-major) for every following solve of a model with n states: M u' = f
    (ODEFunction(f; mass_matrix = M), src/adjoint_common.jl:110-135, 805-807; the adjoint problems carry M' / [M' 0; 0 I]).
-   NULL clears it.  Returns -2 when M is singular (semi-explicit DAEs are outside the restatement).  Process-wide. */
+   NULL clears it.  A singular M of the semi-explicit form [Md 0; 0 0] (zero rows that are also zero columns, Md non-singular: src/adjoint_common.jl:116-135) is kept as a DAE:
+   ORC_STEPPER_ROS23 integrates M u' = f and M' lam' = -J' lam in mass-matrix form, with the loss jumps of :790-813 (every other stepper then returns -6).
+   Returns -2 for any other singular M.  Process-wide. */
 int orc_set_mass_matrix(int n, const double *M);
 
 /* forward solve of ONE trajectory; out[M][n] = sol(save_times) (src/concrete_solve.jl:718-727) */
