@@ -675,6 +675,27 @@ def other_configs(sa, torch):
     except Exception as e:
         _mark("configs[4] at the documented horizon with the exponential s")
         out.append(dict(config="configs[4] at the documented horizon with the exponential stepper", error=repr(e)))
+    # the stiff stepper of the lane family (round 6): Robertson kinetics at the classic stiff rates (0.04, 3e7, 1e4) +- 10 %, tspan (0, 100), G = y3(50) + y3(100), as a RUNTIME model
+    # (hiprtc), Rosenbrock23 at abstol 1e-8 / reltol 1e-6 — a problem adaptive Tsit5 needs ~1e6 steps per trajectory for (scripts/r6/bench_rosenbrock23.py has the full table)
+    try:
+        rob = sa.DeviceFunction("rober_bench_line", 3, 3,
+                                "du[0] = -p[0]*u[0] + p[2]*u[1]*u[2]; du[1] = p[0]*u[0] - p[1]*u[1]*u[1] - p[2]*u[1]*u[2]; du[2] = p[1]*u[1]*u[1];",
+                                "out[0] = -p[0]*lam[0] + p[0]*lam[1]; out[1] = p[2]*u[2]*lam[0] + (-2.0*p[1]*u[1] - p[2]*u[2])*lam[1] + 2.0*p[1]*u[1]*lam[2]; out[2] = p[2]*u[1]*lam[0] - p[2]*u[1]*lam[1];",
+                                "out[0] = -u[0]*lam[0] + u[0]*lam[1]; out[1] = -u[1]*u[1]*lam[1] + u[1]*u[1]*lam[2]; out[2] = u[1]*u[2]*lam[0] - u[1]*u[2]*lam[1];")
+        Nr = 8192
+        pr = np.array([0.04, 3.0e7, 1.0e4]) * (1 + 0.1 * rng.uniform(-1, 1, (Nr, 3)))
+        ur = np.tile([1.0, 0.0, 0.0], (Nr, 1)); tsr = np.array([50.0, 100.0]); dr = np.zeros((Nr, 2, 3)); dr[:, :, 2] = 1.0
+        for alg in ("interpolating", "gauss"):
+            eng = sa.Engine(rob.name, alg, Nr, 0.0, 100.0, 0.0, save_times=tsr, loss_kind=0, p_shared=False, stepper=3, abstol=1e-8, reltol=1e-6)
+            ms, kms, st = run(eng, ur, pr, dr, 3)
+            _mark("Rosenbrock23: Robertson at the stiff rates")
+            out.append(dict(config=f"Rosenbrock23 (stiff stepper, round 6): Robertson kinetics at rates (0.04, 3e7, 1e4) +- 10 %, tspan (0, 100), {Nr} trajectories, runtime model, {alg}, abstol 1e-8 / reltol 1e-6",
+                            forward_ms=st["forward_ms_last"], reverse_ms=ms, main_kernel_ms=kms, gradients_per_s=Nr / ((st["forward_ms_last"] + ms) * 1e-3),
+                            roofline=dict(bound="one wave's instruction stream (per-lane LU + three solves per step)", note="adaptive per-lane stepping: no fixed byte or flop count per launch")))
+            eng.close()
+    except Exception as e:
+        _mark("Rosenbrock23: Robertson at the stiff rates")
+        out.append(dict(config="Rosenbrock23: Robertson at the stiff rates", error=repr(e)))
     return out
 
 

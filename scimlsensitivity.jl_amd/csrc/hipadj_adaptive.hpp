@@ -978,7 +978,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                                   double* kbase, int kstride, double* __restrict__ arec = nullptr, int* __restrict__ nsteps_adj = nullptr, int SmaxA = 0,
                                   double* kfbase = nullptr, double* lrec = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP, NZ = AdjNZ<Mo, ALG>::value;
-    static_assert(STEP == 0 || (ALG != 1 && !CK), "Rosenbrock23: Interpolating / Gauss / GaussKronrod / Quadrature without checkpointing (the backsolved system is not affine in its state)");
+    static_assert(STEP == 0 || ALG != 1, "Rosenbrock23: Interpolating / Gauss / GaussKronrod / Quadrature (the backsolved system is not affine in its state)");
 #ifndef HIPADJ_TS5_REGS_CK
 #define HIPADJ_TS5_REGS_CK 1   // checkpointing = true: the rows of the sweep AND of the interval re-solve in registers (A/B hook)
 #endif
@@ -999,12 +999,12 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
         for (int jj = 0; jj < N; ++jj) uu[jj] = ckpt[((long)j * N + jj) * g.Npad + i];
         int sl = 0;
-        const int nr = tsit5_integrate<N>(uu, ck_t[j], ck_t[j + 1], dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF,
-            [&](double (&du)[N], const double (&u_)[N], double t) { Mo::f(du, u_, pv, t); },
-            [&](double t, double tprev, double (&un)[N], const auto& KK) -> bool {
+        auto frhs = [&](double (&du)[N], const double (&u_)[N], double t) { Mo::f(du, u_, pv, t); };
+        auto fcb = [&](double t, double tprev, double (&un)[N], const auto& KK) -> bool {
                 (void)un;
                 if (sl < g.SmaxI) {
-                    double c[5][N]; tsit5_poly<N>(KK, t - tprev, c);
+                    double c[5][N];
+                    if constexpr (STEP == 1) ros23_poly<N>(KK, t - tprev, c); else tsit5_poly<N>(KK, t - tprev, c);
                     lrec[((long)sl * RW + 0) * g.Npad + i] = tprev; lrec[((long)sl * RW + 1) * g.Npad + i] = t;
 #pragma unroll
                     for (int m = 0; m < 5; ++m)
@@ -1013,7 +1013,12 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 } else ck_overflow = true;
                 ++sl;
                 return false;
-            });
+            };
+        int nr;
+        if constexpr (STEP == 1) {      // the interval re-solved with the forward problem's own stepper (src/interpolating_adjoint.jl:245-251); a DAE's checkpoint is a consistent state already
+            RosLinFwd<Mo> flin(pv);
+            nr = ros23_integrate<N>(uu, ck_t[j], ck_t[j + 1], dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF, frhs, flin, !Mo::TIME_DEP, fcb);
+        } else nr = tsit5_integrate<N>(uu, ck_t[j], ck_t[j + 1], dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF, frhs, fcb);
         if (nr < 0) ck_overflow = true;
         cur.init(lrec, g.Npad, i, sl < g.SmaxI ? sl : g.SmaxI);
         icur = j;

@@ -720,7 +720,13 @@ template <class Mo, int ALG, int CC, bool CK = false, int STEP = 0> int adaptive
     return HIPADJ_OK;
 }
 template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    if (h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the planner admitted: no Backsolve, no checkpointing, no cost
+    if (h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the planner admitted: no Backsolve, no cost
+        if (h->ip_ckpt) switch (h->cfg.alg) {      // checkpointing = true: the intervals re-solved with Rosenbrock23 inside the sweep
+        case HIPADJ_ALG_INTERPOLATING: return adaptive_adjoint_l<Mo, 0, 0, true, 1>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS: return adaptive_adjoint_l<Mo, 2, 0, true, 1>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_GAUSS_KRONROD: return adaptive_adjoint_l<Mo, 4, 0, true, 1>(h, d_cot, d_du0, d_dp);
+        default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "Rosenbrock23: sensealg %d has no checkpointed device kernel", h->cfg.alg);
+        }
         switch (h->cfg.alg) {
         case HIPADJ_ALG_INTERPOLATING: return adaptive_adjoint_l<Mo, 0, 0, false, 1>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS: return adaptive_adjoint_l<Mo, 2, 0, false, 1>(h, d_cot, d_du0, d_dp);

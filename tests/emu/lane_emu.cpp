@@ -439,6 +439,12 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
 template <class Mo>
 static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* ns) {
     if (cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {
+        if (P.ip_ckpt) switch (cfg->alg) {
+        case HIPADJ_ALG_INTERPOLATING: return run_adaptive<Mo, 0, 0, true, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_GAUSS: return run_adaptive<Mo, 2, 0, true, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_GAUSS_KRONROD: return run_adaptive<Mo, 4, 0, true, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        default: return HIPADJ_ERR_UNSUPPORTED;
+        }
         switch (cfg->alg) {
         case HIPADJ_ALG_INTERPOLATING: return run_adaptive<Mo, 0, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
         case HIPADJ_ALG_GAUSS: return run_adaptive<Mo, 2, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);

@@ -154,7 +154,7 @@ def test_device_pointer_calls_and_replay(sa):
 
 def test_what_the_library_refuses_for_this_stepper(sa):
     u0, p = lorenz_inputs(8)
-    for kw in (dict(sensealg=sa.BacksolveAdjoint()), dict(sensealg=sa.InterpolatingAdjoint(checkpointing=True)), dict(sensealg=sa.GaussAdjoint(checkpointing=True))):
+    for kw in (dict(sensealg=sa.BacksolveAdjoint()), dict(sensealg=sa.BacksolveAdjoint(checkpointing=False))):
         with pytest.raises(sa.HipadjError, match="Rosenbrock23"):
             sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, 1.0), p), u0), sa.Rosenbrock23(), saveat=[1.0], **kw)
     with pytest.raises(sa.HipadjError, match="Rosenbrock23"):      # the PDE family has its own stiff stepper (ETDRK4)
@@ -241,3 +241,51 @@ def test_semi_explicit_dae_singular_mass_matrix(sa, gold, alg, oalg):
     assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < bar and np.max(np.abs(du0 - rdu0)) < 10 * bar * np.max(np.abs(rdu0))      # measured 6e-7 / 1.1e-6 (one trajectory: a step decided differently)
     with pytest.raises(sa.HipadjError, match="singular"):              # the explicit steppers refuse the model
         sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[1], (0.0, 1.0), pp[1]), u0[1:3], pp[1:3]), sa.Tsit5(), saveat=[1.0])
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")])
+@pytest.mark.parametrize("model,omodel,u0c,p", [("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]), ("lorenz", "LORENZ", [1.0, 0.0, 0.0], [10.0, 28.0, 8 / 3])])
+def test_rosenbrock23_checkpointed(sa, alg, oalg, model, omodel, u0c, p):
+    """checkpointing = true with the stiff stepper: the forward pass keeps sol(c_j) only, the reverse pass re-solves every interval with Rosenbrock23 (src/interpolating_adjoint.jl:
+    54-109, 207-277); against the oracle's checkpointed run and (solver tolerance) against the dense run."""
+    rng = np.random.default_rng(32)
+    N, T = 70, 2.0
+    n, npar = sa.model_sizes(model)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.05 * rng.standard_normal((N, npar)))
+    ts = np.array([0.0, 0.13, 0.5, 0.77, 1.0, 1.9, 2.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    salg = {"interpolating": sa.InterpolatingAdjoint, "gauss": sa.GaussAdjoint, "gausskronrod": sa.GaussKronrodAdjoint}[alg](checkpointing=True)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model, u0[0], (0, T), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts, sensealg=salg, abstol=1e-9, reltol=1e-9)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=delta)
+    sol.engine.close()
+    ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="COTANGENT", checkpointing=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < 1e-5 and rel(dp, rdp) < 1e-5
+    dense = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="COTANGENT")
+    ddu0, ddp, _, _ = dense.adjoint_ensemble(u0, pp, delta)
+    assert rel(du0, ddu0) < 1e-4 and rel(dp, ddp) < 1e-4
+
+
+def test_semi_explicit_dae_checkpointed_on_the_device(sa, gold):
+    """test/Core3/adjoint.jl:1505-1514: InterpolatingAdjoint(checkpointing = true) with an explicit checkpoint list on the singular-mass-matrix problem."""
+    c = gold["rober"]
+    if "roberdae" not in _registered:
+        m = UM.ROBERDAE
+        _registered["roberdae"] = sa.DeviceFunction("roberdae_ros23", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"], mass_matrix=UM.ROBERDAE_MM)
+    f = _registered["roberdae"]
+    N = 8
+    rng = np.random.default_rng(12)
+    pp = np.asarray(c["p"]) * (1 + 0.1 * rng.uniform(-1, 1, (N, 3))); pp[0] = c["p"]
+    u0 = np.tile([1.0, 0.0, 1.0], (N, 1))
+    ts = np.asarray(c["ts"]); d = np.zeros((N, 2, 3)); d[:, :, 2] = 1.0
+    ck = np.linspace(0.0, 100.0, 11)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 100.0), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts, sensealg=sa.InterpolatingAdjoint(checkpointing=True),
+                   checkpoints=ck, abstol=1e-10, reltol=1e-8)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=d)
+    sol.engine.close()
+    assert relc(dp[0], c["dp"]) < 1e-5
+    with O.mass_matrix(np.asarray(UM.ROBERDAE_MM)):
+        pr = O.Problem("ROBERDAE", alg="INTERPOLATING", stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=ts, loss="COTANGENT", checkpointing=True, checkpoints=ck)
+        rdu0, rdp, _, _ = pr.adjoint_ensemble(u0, pp, d)
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < 1e-5 and np.max(np.abs(du0 - rdu0)) < 1e-5 * np.max(np.abs(rdu0))

@@ -144,16 +144,17 @@ def test_runtime_tsit5_stage_rows_are_lds_columns_unless_opted_in(tmp_path, monk
     assert lds is not None and (lds == 0 if regs == "1" else lds == 8 * 6 * 64 * 8)
 
 
-@pytest.mark.parametrize("name,alg", [("rober", "interpolating"), ("rober", "quadrature"), ("ring4", "gauss"), ("ring6", "gausskronrod")])
-def test_runtime_rosenbrock23_kernels_compile_without_a_device_and_are_clean(tmp_path, monkeypatch, name, alg):
+@pytest.mark.parametrize("name,alg,ck", [("rober", "interpolating", False), ("rober", "quadrature", False), ("ring4", "gauss", False), ("ring6", "gausskronrod", False),
+                                         ("rober", "interpolating", True), ("ring4", "gausskronrod", True)])
+def test_runtime_rosenbrock23_kernels_compile_without_a_device_and_are_clean(tmp_path, monkeypatch, name, alg, ck):
     """HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE for runtime-registered lane models: k_forward_tsit5<U, 1> and k_adjoint_tsit5<U, ALG, 0, false, 1> (the W solves unrolled over the
     model's n) through hiprtc, and the spill-placement check on what it produced."""
     from scimlsensitivity_jl_amd import _lib
     m = UM.ROBER if name == "rober" else UM.ring(int(name[4:]))
-    mname = f"{name}_ros23_lint_{alg}"
+    mname = f"{name}_ros23_lint_{alg}{'_ck' if ck else ''}"
     _lib.register_model(mname, m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
     monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
-    cfg = E.make_config(mname, alg, 53, 0.0, 0.5, 0.0, [0.25, 0.5], loss_kind=1, stepper=3, abstol=1e-8, reltol=1e-8)
+    cfg = E.make_config(mname, alg, 53, 0.0, 0.5, 0.0, [0.25, 0.5], loss_kind=1, stepper=3, abstol=1e-8, reltol=1e-8, checkpointing=ck)
     L = _lib.load()
     assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
     objs = glob.glob(str(tmp_path / "*.hsaco"))

@@ -139,9 +139,8 @@ def test_step_capacity_overflow_is_an_error_and_what_the_planner_refuses():
     with pytest.raises(RuntimeError, match="rc=-7"):
         E.forward_adjoint(cfg, 2, 4, u0, p)
     # BacksolveAdjoint re-integrates the state backwards: the system is not affine in its unknowns and its Jacobian needs second derivatives of the model — not built;
-    # checkpointing re-solves intervals inside the reverse pass — not built for this stepper; continuous costs neither
-    for bad in (dict(alg="backsolve", checkpointing=True), dict(alg="backsolve"), dict(alg="interpolating", checkpointing=True), dict(alg="gauss", checkpointing=True),
-                dict(alg="interpolating", cont_cost=1), dict(alg="quadrature", cont_cost=2)):
+    # continuous costs neither
+    for bad in (dict(alg="backsolve", checkpointing=True), dict(alg="backsolve"), dict(alg="interpolating", cont_cost=1), dict(alg="quadrature", cont_cost=2)):
         kw = dict(bad); alg = kw.pop("alg")
         cfg = E.make_config("lv", alg, 1, 0.0, 10.0, 0.0, [10.0], stepper=ROS, **kw)
         with pytest.raises(RuntimeError, match="rc=-6"):
@@ -261,3 +260,43 @@ def test_lane_bodies_dae_model_needs_the_stiff_stepper():
         cfg = E.make_config("emu_roberdae", "interpolating", 1, 0.0, 1.0, 0.01, [1.0], loss_kind=1, stepper=st)
         with pytest.raises(RuntimeError, match="singular"):
             E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 0.0]], [0.04, 3e7, 1e4])
+
+
+# ---- checkpointing = true: the intervals re-solved with Rosenbrock23 inside the reverse pass (src/interpolating_adjoint.jl:54-109, 207-277) ---------------------------------
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")])
+@pytest.mark.parametrize("model,omodel,u0c,p", MODELS)
+def test_lane_bodies_checkpointed(alg, oalg, model, omodel, u0c, p):
+    """The forward pass keeps sol(c_j) only; every interval between checkpoints (default: the loss times and the span's ends) is re-solved by the forward stepper — Rosenbrock23 —
+    when the reverse solve enters it, from dt = the last step of the interval above.  The re-solved pieces are NOT the forward solution (other step sequences), so the gradient
+    moves at the solver tolerance against the dense run and agrees with the oracle's checkpointed run at the level two implementations of one controller do."""
+    rng = np.random.default_rng(15)
+    N, T = 3, 2.0
+    n, npar = len(u0c), len(p)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.03 * rng.standard_normal((N, npar)))
+    ts = np.array([0.0, 0.13, 0.5, 0.77, 1.0, 1.9, 2.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    cfg = E.make_config(model, alg, N, 0.0, T, 0.0, ts, loss_kind=0, p_shared=False, stepper=ROS, abstol=1e-8, reltol=1e-8, checkpointing=True, max_steps=100000)
+    du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+    ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="COTANGENT", checkpointing=True)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
+    dense = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="COTANGENT")
+    ddu0, ddp, _, _ = dense.adjoint_ensemble(u0, pp, delta)
+    assert rel(du0, ddu0) < 1e-4 and rel(dp, ddp) < 1e-4
+
+
+@pytest.mark.parametrize("ckpts", [None, "every_10"])
+def test_semi_explicit_dae_checkpointed(gold, ckpts):
+    """test/Core3/adjoint.jl:1505-1514: InterpolatingAdjoint(checkpointing = true), checkpoints = sol.t[1:10:end] on the singular-mass-matrix problem (here: the default list and a
+    list of ten points of the span): lanes = oracle, and the gradient still meets the reference's bar against the independent one."""
+    c, gdp, gdu = dae_golden(gold)
+    d = np.zeros((1, 2, 3)); d[:, :, 2] = 1.0
+    ck = None if ckpts is None else np.linspace(0.0, 100.0, 11)
+    cfg = E.make_config("emu_roberdae", "interpolating", 1, 0.0, 100.0, 0.0, c["ts"], loss_kind=0, stepper=ROS, abstol=1e-10, reltol=1e-8, max_steps=100000, checkpointing=True, checkpoints=ck)
+    du0, dp, out = E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 1.0]], c["p"], d)
+    with O.mass_matrix(DAE_M):
+        pr = O.Problem("ROBERDAE", alg="INTERPOLATING", stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=c["ts"], loss="COTANGENT", checkpointing=True, checkpoints=ck)
+        rdu0, rdp, rout = pr.adjoint([1.0, 0.0, 1.0], c["p"], d[0])
+    assert relc(dp, rdp) < 1e-6 and np.max(np.abs(du0[0] - rdu0)) < 1e-7
+    assert relc(dp, gdp) < 1e-5
