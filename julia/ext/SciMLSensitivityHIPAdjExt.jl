@@ -44,12 +44,14 @@ algid(::GaussAdjoint) = HIPAdj.ALG_GAUSS
 algid(::QuadratureAdjoint) = HIPAdj.ALG_QUADRATURE
 algid(::GaussKronrodAdjoint) = HIPAdj.ALG_GAUSS_KRONROD
 
-# the two steppers the device implements; anything else is an error, as unsupported combinations are in the reference
+# the steppers the device implements for lane and wide models; anything else is an error, as unsupported combinations are in the reference
 function stepper_of(alg)
     nm = nameof(typeof(alg))
     nm === :RK4 && return HIPAdj.STEPPER_RK4_FIXED
     nm === :Tsit5 && return HIPAdj.STEPPER_TSIT5_ADAPTIVE
-    error("HIPBatchedAdjoint: the device steppers are RK4() (fixed dt) and Tsit5() (adaptive); got $(nm)")
+    nm === :Rosenbrock23 && return HIPAdj.STEPPER_ROSENBROCK23_ADAPTIVE      # the stiff stepper of the lane-per-trajectory models (test/Core2/stiff_adjoints.jl:66-80); also the one
+                                                                             # stepper for a model with a singular mass matrix (set_mass_matrix!, test/Core3/adjoint.jl:1434-1530)
+    error("HIPBatchedAdjoint: the device steppers are RK4() (fixed dt), Tsit5() and Rosenbrock23() (adaptive); got $(nm)")
 end
 
 """

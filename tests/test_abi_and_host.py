@@ -445,6 +445,21 @@ def test_c_host_compiles_against_the_header_and_fails_loudly_without_a_device(sa
     assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 109" in r.stdout
 
 
+def test_c_stiff_dae_example_compiles_and_fails_loudly_without_a_device(sa, tmp_path):
+    """examples/stiff_dae_demo.c (the reference's singular-mass-matrix problem through the C ABI: model as text, singular semi-explicit mass matrix, Rosenbrock23): strict C99 against
+    include/hipadj.h; registration and the mass matrix succeed without a device, hipadj_create reports HIPADJ_ERR_NO_DEVICE."""
+    import subprocess
+    sa.load_library()
+    exe = str(tmp_path / "stiff_dae_demo")
+    libdir = os.path.dirname(sa.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "stiff_dae_demo.c"),
+                           "-o", exe, "-L" + libdir, "-lhipadj", "-Wl,-rpath," + libdir, "-lm"])
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a device is present: the GPU suite runs the example (tests/test_gpu_stiff.py)")
+    r = subprocess.run([exe, "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "hipadj_create" in r.stderr and "no usable HIP device" in r.stderr
+
+
 class _StubEngine:
     """Stands in for the device handle (which needs a GPU) so that the HOST logic of interface.py — argument mapping, saving rules,
     cotangent packing, dgdp_discrete, error paths — runs in the CPU suite.  It records the configuration it was created with and

@@ -289,3 +289,24 @@ def test_semi_explicit_dae_checkpointed_on_the_device(sa, gold):
         pr = O.Problem("ROBERDAE", alg="INTERPOLATING", stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=ts, loss="COTANGENT", checkpointing=True, checkpoints=ck)
         rdu0, rdp, _, _ = pr.adjoint_ensemble(u0, pp, d)
     assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < 1e-5 and np.max(np.abs(du0 - rdu0)) < 1e-5 * np.max(np.abs(rdu0))
+
+
+@pytest.mark.parametrize("alg", [0, 2, 3, 4])
+def test_c_example_of_the_stiff_dae_matches_the_independent_gradient(sa, gold, tmp_path, alg):
+    """examples/stiff_dae_demo.c: plain C against include/hipadj.h — hipadj_model_register, hipadj_model_set_mass_matrix(diag(1, 1, 0)), a handle on
+    HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE, host-pointer forward / adjoint — for every sensealg the stepper has; trajectory 0 is the reference's problem."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe, libdir = str(tmp_path / "stiff_dae_demo"), os.path.dirname(sa.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "stiff_dae_demo.c"),
+                           "-o", exe, "-L" + libdir, "-lhipadj", "-Wl,-rpath," + libdir, "-lm"])
+    r = subprocess.run([exe, "6", str(alg)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    val = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.strip().split("\n")}
+    c = gold["rober"]
+    g = np.asarray(c["du0"])
+    assert relc(val["dp"], c["dp"]) < 1e-5                                   # the reference's bar against ForwardDiff (test/Core3/adjoint.jl:1483)
+    assert relc(val["du0"][:2], [g[0] - g[2], g[1] - g[2]]) < 2e-4
+    assert np.max(np.abs(val["y_at_100"] - np.asarray(c["u_at_ts"])[1])) < 1e-6 and val["constraint_residual_max"][0] < 1e-9
+    assert val["tsit5_on_the_dae"][0] == -6
+    assert np.all(np.isfinite(val["dp_last"])) and relc(val["dp_last"], val["dp"]) > 1e-3       # the scaled rates give another gradient
