@@ -310,3 +310,71 @@ def test_c_example_of_the_stiff_dae_matches_the_independent_gradient(sa, gold, t
     assert np.max(np.abs(val["y_at_100"] - np.asarray(c["u_at_ts"])[1])) < 1e-6 and val["constraint_residual_max"][0] < 1e-9
     assert val["tsit5_on_the_dae"][0] == -6
     assert np.all(np.isfinite(val["dp_last"])) and relc(val["dp_last"], val["dp"]) > 1e-3       # the scaled rates give another gradient
+
+
+# ---- randomized differential test: the stiff stepper over its configuration space, device vs oracle ------------------------------------------------------------------------
+def _random_stiff_case(rng):
+    models = [("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0], (0, 0, 0, 0)), ("lvt", "LVT", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0], (0, 0, 0, 0)),
+              ("lorenz", "LORENZ", [1.0, 0.0, 0.0], [10.0, 28.0, 8 / 3], (0, 0, 0, 0)), ("lindiag", "LINDIAG", [1.0, 1.0], [0.5, -0.7], (0, 0, 0, 0)),
+              ("rober", "ROBER", [0.8, 0.3, 0.2], [0.4, 1.0, 0.7], (0, 0, 0, 0)), ("rober_stiff", "ROBER", [1.0, 0.0, 0.0], [0.04, 3.0e4, 1.0e2], (0, 0, 0, 0))]
+    n_ring = int(rng.integers(2, 8))
+    models.append((f"ring{n_ring}", "RING", list(rng.uniform(0.3, 1.0, n_ring)), list(rng.uniform(0.4, 1.2, n_ring + 1)), (n_ring, 0, 0, 0)))
+    model, omodel, u0c, p, dims = models[int(rng.integers(len(models)))]
+    alg, oalg = ALGS[int(rng.integers(4))]
+    user = model.startswith("rober") or model.startswith("ring")
+    c = dict(model=model, omodel=omodel, u0c=u0c, p=p, dims=dims, alg=alg, oalg=oalg, user=user, N=int(rng.integers(1, 150)), T=float(rng.choice([0.5, 1.0, 2.0])))
+    c["ckpt"] = bool(rng.random() < 0.4) and alg != "quadrature"
+    c["tol"] = float(rng.choice([1e-8, 1e-9]))
+    ts = np.unique(np.round(rng.uniform(0, c["T"], int(rng.integers(0, 6))), 3))
+    if rng.random() < 0.5:
+        ts = np.unique(np.concatenate([ts, [c["T"]]]))
+    c["ts"] = ts
+    c["loss"] = "shift" if (len(ts) == 0 or rng.random() < 0.35) else ("data" if rng.random() < 0.4 else "cot")
+    c["p_shared"] = bool(rng.random() < 0.5)
+    c["no_start"] = bool(rng.random() < 0.25)
+    c["auto_vjp"] = bool(rng.random() < 0.5)
+    c["mass"] = bool(user and model.startswith("ring") and n_ring <= 5 and rng.random() < 0.4)       # a dense well-conditioned mass matrix behind a runtime ring
+    return c
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_randomized_rosenbrock23_configurations_match_oracle(sa, seed):
+    rng = np.random.default_rng(int(os.environ.get("HIPADJ_FUZZ_BASE", "7000")) + seed)
+    c = _random_stiff_case(rng)
+    n, npar = len(c["u0c"]), len(c["p"])
+    f = c["model"]
+    Mm = None
+    if c["user"]:
+        m = UM.ROBER if c["model"].startswith("rober") else UM.ring(c["dims"][0])
+        if c["mass"]:
+            Mm = np.eye(n) * 1.5 + 0.3 * np.sin(1.0 + np.add.outer(3.0 * np.arange(n), 7.0 * np.arange(n)))
+        key = ("rober" if c["model"].startswith("rober") else c["model"]) + "_sfuzz" + ("_auto" if c["auto_vjp"] else "") + ("_mm" if c["mass"] else "")
+        if key not in _registered:
+            _registered[key] = sa.DeviceFunction(key, m["n"], m["np"], m["f"], *(() if c["auto_vjp"] else (m["vjp"], m["vjp_p"])), mass_matrix=Mm)
+        f = _registered[key]
+    u0 = np.asarray(c["u0c"]) + (0.0 if c["model"] == "rober_stiff" else 0.05) * rng.standard_normal((c["N"], n))
+    p = np.asarray(c["p"]) if c["p_shared"] else np.asarray(c["p"]) * (1 + 0.03 * rng.standard_normal((c["N"], npar)))
+    tol = c["tol"]
+    salg = {"interpolating": sa.InterpolatingAdjoint(checkpointing=c["ckpt"]), "gauss": sa.GaussAdjoint(checkpointing=c["ckpt"]),
+            "gausskronrod": sa.GaussKronrodAdjoint(checkpointing=c["ckpt"]), "quadrature": sa.QuadratureAdjoint(abstol=tol, reltol=tol)}[c["alg"]]
+    M = len(c["ts"])
+    blk = rng.standard_normal((c["N"], M, n))
+    loss = {"shift": sa.LsqShift(1.5), "data": sa.LsqData(blk, 2.0), "cot": None}[c["loss"]]
+    prob = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, c["T"]), p if c["p_shared"] else p[0], c["dims"]), u0, p)
+    sol = sa.solve(prob, sa.Rosenbrock23(), saveat=c["ts"], sensealg=salg, dgdu_discrete=loss, no_start=c["no_start"], abstol=tol, reltol=tol)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=c["ts"], dgdu_discrete=(blk if c["loss"] == "cot" else loss))
+    out = None if sol.u is None else np.array(sol.u)
+    sol.engine.close()
+    import contextlib
+    with (O.mass_matrix(Mm) if Mm is not None else contextlib.nullcontext()):
+        ref = O.Problem(c["omodel"], alg=c["oalg"], stepper="ROS23", t0=0.0, t1=c["T"], dt=0.0, abstol=tol, reltol=tol, save_times=c["ts"],
+                        loss={"shift": "LSQ_SHIFT", "data": "LSQ_DATA", "cot": "COTANGENT"}[c["loss"]], loss_shift=1.5, loss_scale=2.0, checkpointing=c["ckpt"], dims=c["dims"],
+                        quad_abstol=tol, quad_reltol=tol, no_start=c["no_start"])
+        rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, None if c["loss"] == "shift" else blk)
+    msg = {k: (v if not isinstance(v, (list, np.ndarray)) else np.asarray(v).round(3).tolist()) for k, v in c.items() if k not in ("u0c", "p")}
+    # two implementations of one adaptive controller: agreement to a fraction of the solver tolerance times the problem's amplification, not to roundoff; behind a mass matrix
+    # the two formulations (nu = M' lam here, lam there) weigh the error norm differently and agree to the tolerance itself
+    bar = 2e-5 if (c["mass"] or c["ckpt"]) else 2e-6
+    if M:
+        assert rel(out, rout) < (1e-6 if c["mass"] else RTOL), msg
+    assert rel(du0, rdu0) < bar and rel(dp, rdp) < bar, msg
