@@ -123,7 +123,7 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
     case ORC_MODEL_ROBERDAE: /* `rober` exactly as test/Core3/adjoint.jl:1434-1441 writes it: the third row is the conservation constraint (mass matrix diag(1, 1, 0), :1450-1454) */
         du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
         du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
-        du[2] = u[0] + u[1] + u[2] - 1.0;
+        du[2] = u[0] + u[1] + u[2] - 1.0 - (double)m->dims[0] * (p[0] - 0.04);      /* dims[0] = kappa: a constraint that DEPENDS ON A PARAMETER (0: the reference's rober) — the loss jumps' parameter term f_p' [0; dlam_a] is zero without it */
         break;
     case ORC_MODEL_PENDULUM: /* test/Core7/adjoint_param.jl:6-10; the second term is the test's "simple controller that stabilizes pi" */
         du[0] = p[0] * u[1];
@@ -250,7 +250,7 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
             dlam[2] = p[2] * u[1] * lam[0] - p[2] * u[1] * lam[1] + lam[2];
         }
         if (dgrad) {
-            dgrad[0] = -u[0] * lam[0] + u[0] * lam[1];
+            dgrad[0] = -u[0] * lam[0] + u[0] * lam[1] - (double)m->dims[0] * lam[2];
             dgrad[1] = -u[1] * u[1] * lam[1];
             dgrad[2] = u[1] * u[2] * lam[0] - u[1] * u[2] * lam[1];
         }

@@ -50,7 +50,8 @@ enum {
     ORC_MODEL_DENSELIN = 12, /* u' = A u with A = reshape(p, n, n): np = n^2 (NOT from the reference); dims = {n} */
     ORC_MODEL_PENDULUM = 13, /* `pendulum_eom` of test/Core7/adjoint_param.jl:6-10: dx1 = p1 x2; dx2 = -sin x1 + (-p1 sin x1 + p2 x2); np = 3 (p3 unused, as in the test) */
     ORC_MODEL_LIN1P = 14,    /* `f` of test/Core7/adjoint_param.jl:56-59: du = -u p1 - p2; n = 1, np = 2 */
-    ORC_MODEL_ROBERDAE = 15  /* `rober` as test/Core3/adjoint.jl:1434-1441 writes it (third row: y1 + y2 + y3 - 1): with orc_set_mass_matrix(diag(1, 1, 0)) the semi-explicit DAE of :1450-1700 */
+    ORC_MODEL_ROBERDAE = 15  /* `rober` as test/Core3/adjoint.jl:1434-1441 writes it (third row: y1 + y2 + y3 - 1): with orc_set_mass_matrix(diag(1, 1, 0)) the semi-explicit DAE of :1450-1700;
+                                dims[0] = kappa adds -kappa (p1 - 0.04) to the constraint (NOT from the reference: a parameter-dependent constraint, so that the jumps' parameter term is not zero) */
 };
 enum { ORC_ALG_INTERPOLATING = 0, ORC_ALG_BACKSOLVE = 1, ORC_ALG_GAUSS = 2, ORC_ALG_QUADRATURE = 3,
        ORC_ALG_GAUSS_KRONROD = 4 /* [upstream-recall] per-step adaptive GK(7,15): parity UNPINNED beyond GaussKronrod == Gauss */ };

@@ -1164,7 +1164,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
                     for (int j = 0; j < N; ++j) y[j] = zz[N + NP + j];
                 } else cur.eval(t, y);
-                if constexpr (model_has_dloss<Mo>::value) {   // a model with discrete-loss bodies (hipadj_model_set_discrete_loss): dgdu_discrete / dgdp_discrete evaluated here when the handle selects them
+                if constexpr (model_has_dloss<Mo>::value && !model_dae<Mo>::value) {   // a model with discrete-loss bodies (hipadj_model_set_discrete_loss): dgdu_discrete / dgdp_discrete evaluated here when the handle selects them (a DAE model takes the branch below whatever bodies it carries: HIPADJ_LOSS_MODEL is refused for its stepper)
                     double gl[N];
 #pragma unroll
                     for (int j = 0; j < N; ++j)
@@ -1413,7 +1413,7 @@ __global__ void __launch_bounds__(64) k_adjoint_tsit5(AdaptGeom g, const double*
                                         ks + KS_ROWS * AdjNZ<Mo, ALG>::value * 64 + threadIdx.x, CK ? const_cast<double*>(rec) : nullptr);
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) du0[i * Mo::N + j] = lam[j];
-    if (ALG != 3 || model_has_dloss<Mo>::value) {   // QuadratureAdjoint: k_quad_sum writes dp_traj from the quadrature (and adds to it for a model with discrete-loss bodies)
+    if (ALG != 3 || model_has_dloss<Mo>::value || model_dae<Mo>::value) {   // QuadratureAdjoint: k_quad_sum writes dp_traj from the quadrature (and ADDS to it for a model with discrete-loss bodies or a semi-explicit DAE, whose loss jumps leave their parameter term here)
 #pragma unroll
         for (int j = 0; j < Mo::NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j]; }
 }

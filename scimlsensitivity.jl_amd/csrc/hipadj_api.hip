@@ -614,7 +614,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (cfg->cont_cost == HIPADJ_CCOST_MODEL && !user_has_cost(cfg->model)) { h->err = "cont_cost = HIPADJ_CCOST_MODEL but the model has no cost (hipadj_model_set_cost / hipadj_wmodel_set_cost)"; return fail(HIPADJ_ERR_INVALID_ARG); }
     if (cfg->loss_kind == HIPADJ_LOSS_MODEL && !user_has_dloss(cfg->model)) { h->err = "loss_kind = HIPADJ_LOSS_MODEL but the model has no discrete-loss bodies (hipadj_model_set_discrete_loss / hipadj_wmodel_set_discrete_loss)"; return fail(HIPADJ_ERR_INVALID_ARG); }
     if (P.wide) { const int urc = wide_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
-    else if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); }
+    else if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); h->dae = user_model_is_dae(cfg->model); }
     *out = h;
     return HIPADJ_OK;
 }
@@ -1057,7 +1057,7 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
             TRY(usig<decltype(&k_quad_gk_tsit5<ModelLV, 0>)>::launch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
                         (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres));
-            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj, h->cfg.loss_kind == HIPADJ_LOSS_MODEL ? 1 : 0);
+            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj, (h->cfg.loss_kind == HIPADJ_LOSS_MODEL || h->dae) ? 1 : 0);
             HIP_TRY(h, hipGetLastError());
         }
     } else if (h->offgrid) {

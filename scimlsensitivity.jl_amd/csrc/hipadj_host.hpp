@@ -67,6 +67,7 @@ struct hipadj_handle {
     bool wide = false;                    // ... of the workgroup-per-trajectory family (hipadj_wide.hpp)
     WideGeom wg{}; int wide_T = 0; double* d_wscr = nullptr;
     bool wide_ts5 = false; WideAdapt wa{};       // adaptive Tsit5 of the wide family (hipadj_wide.hpp): records d_rec [N][Smax][2 + 5 n], d_nsteps [N]
+    bool dae = false;      // the model carries a singular semi-explicit mass matrix (hipadj_model_set_mass_matrix): the loss jumps of the reverse sweep leave a parameter term in dp_traj
     bool has_mm = false; double minv[64] = {0};   // the model's mass matrix at create time (M^{-1}, row-major): du0 = M^{-T} nu(t0) after the sweep
     hipModule_t umod = nullptr;
     hipFunction_t uf_forward = nullptr, uf_main = nullptr, uf_tail = nullptr, uf_gk = nullptr;   // tail = k_compose_finish or k_finish

@@ -88,8 +88,9 @@ struct EmuRober {
 };
 // TEST-ONLY: `rober` exactly as test/Core3/adjoint.jl:1434-1441 writes it (third row: the conservation constraint) with the mass matrix diag(1, 1, 0) of :1450-1454 — a
 // semi-explicit DAE, as hipadj_user.hpp generates a runtime model whose mass matrix is singular (DAE / mass / isalg).  Oracle: ORC_MODEL_ROBERDAE under orc_set_mass_matrix.
-// Model id = HIPADJ_MODEL_USER_BASE + 204.
-struct EmuRoberDAE {
+// Model id = HIPADJ_MODEL_USER_BASE + 204 (KAPPA = 0: the reference's constraint) and + 205 (KAPPA = 5: y1 + y2 + y3 = 1 + 5 (p1 - 0.04), a constraint that depends on a
+// parameter — without one the loss jumps' parameter term f_p' [0; dlam_a] is identically zero and nothing would notice it missing).
+template <int KAPPA> struct EmuRoberDAE {
     static constexpr int N = 3, NP = 3;
     static constexpr bool TIME_DEP = false;
     static constexpr bool HAS_COLS = false;
@@ -99,7 +100,7 @@ struct EmuRoberDAE {
     static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) {
         du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
         du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
-        du[2] = u[0] + u[1] + u[2] - 1.0;
+        du[2] = u[0] + u[1] + u[2] - 1.0 - KAPPA * (p[0] - 0.04);
     }
     static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double) {
         dl[0] = -p[0] * l[0] + p[0] * l[1] + l[2];
@@ -107,19 +108,19 @@ struct EmuRoberDAE {
         dl[2] = p[2] * u[1] * l[0] - p[2] * u[1] * l[1] + l[2];
     }
     static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&)[NP], double) {
-        dg[0] = -u[0] * l[0] + u[0] * l[1];
+        dg[0] = -u[0] * l[0] + u[0] * l[1] - KAPPA * l[2];
         dg[1] = -u[1] * u[1] * l[1];
         dg[2] = u[1] * u[2] * l[0] - u[1] * u[2] * l[1];
     }
 };
 static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
     const int nn = model - HIPADJ_MODEL_USER_BASE;
-    if (nn == 203 || nn == 204) { *n = 3; *np = 3; return HIPADJ_OK; }
+    if (nn == 203 || nn == 204 || nn == 205) { *n = 3; *np = 3; return HIPADJ_OK; }
     if (nn != 4 && nn != 105) return HIPADJ_ERR_INVALID_ARG;
     *n = nn % 100; *np = nn % 100 + 1;
     return HIPADJ_OK;
 }
-static bool emu_user_dae(int32_t model) { return model == HIPADJ_MODEL_USER_BASE + 204; }
+static bool emu_user_dae(int32_t model) { return model == HIPADJ_MODEL_USER_BASE + 204 || model == HIPADJ_MODEL_USER_BASE + 205; }
 static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, plan_user_dae_hook() = &emu_user_dae, true);
 
 template <class Mo>
@@ -421,7 +422,7 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
         for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
         if (ALG == 3) {   // k_quad_gk_tsit5 + k_quad_sum
             if (flag & 4) return HIPADJ_ERR_MAXITERS;
-            for (int j = 0; j < NP; ++j) mu[j] = 0.0;
+            if (!model_dae<Mo>::value) for (int j = 0; j < NP; ++j) mu[j] = 0.0;      // (k_quad_sum with add = 1 for a semi-explicit DAE: the loss jumps' parameter term is already there)
             for (int q = 0; q < P.nq; ++q) {
                 double res[NP];
                 quad_gk_tsit5_lane<Mo, 128, CC>(g, i, p, rec.data(), nsteps.data(), arec.data(), nsteps_adj.data(), P.qa[q], P.qb[q], qatol, qrtol, res);
@@ -489,7 +490,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 
 // Build units (tests/emu.py compiles them in parallel): EMU_UNIT undefined = everything in one translation unit (the variant builds
 // of test_emu_parity.py); EMU_UNIT = 0 = the C entry points, the per-model dispatchers declared `extern template`;
-// EMU_UNIT = 1..9 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
+// EMU_UNIT = 1..10 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
 #ifndef EMU_UNIT
 #define EMU_UNIT -1
 #endif
@@ -517,7 +518,8 @@ extern template int dispatch_mode<ModelFallMass>(const hipadj_config*, const Pla
 extern template int dispatch_mode<EmuRing<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRingMM<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRober>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
-extern template int dispatch_mode<EmuRoberDAE>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuRoberDAE<0>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuRoberDAE<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 1
 template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 2
@@ -535,7 +537,9 @@ template int dispatch_mode<EmuRingMM<5>>(const hipadj_config*, const Plan&, cons
 #elif EMU_UNIT == 8
 template int dispatch_mode<EmuRober>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 9
-template int dispatch_mode<EmuRoberDAE>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+template int dispatch_mode<EmuRoberDAE<0>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 10
+template int dispatch_mode<EmuRoberDAE<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #endif
 
 #if EMU_UNIT <= 0
@@ -561,7 +565,8 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     case HIPADJ_MODEL_USER_BASE + 4: return dispatch_mode<EmuRing<4>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 105: return dispatch_mode<EmuRingMM<5>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 203: return dispatch_mode<EmuRober>(cfg, P, u0, p, dLdu, du0, dp, out);
-    case HIPADJ_MODEL_USER_BASE + 204: return dispatch_mode<EmuRoberDAE>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 204: return dispatch_mode<EmuRoberDAE<0>>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 205: return dispatch_mode<EmuRoberDAE<5>>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

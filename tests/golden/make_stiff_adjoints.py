@@ -69,7 +69,36 @@ def rober():
                 spread_between_tolerances=spread)
 
 
+def rober_dae_kappa(kappa=5.0):
+    """The semi-explicit DAE of test/Core3/adjoint.jl:1434-1454 with a constraint that depends on a parameter — y1 + y2 + y3 = 1 + kappa (p1 - 0.04), NOT from the reference: with
+    the reference's own constraint the parameter term of the loss jumps, f_p' [0; dlam_a] (src/adjoint_common.jl:803, src/sensitivity_interface.jl:510-521), is identically zero
+    and no test could see it missing.  Reduced to the ODE in (y1, y2) with y3 = c(p) - y1 - y2; forward sensitivities with respect to p and (y1(0), y2(0)); G = y3(50) + y3(100)."""
+    p = np.array([0.04, 3.0e7, 1.0e4]); ts = [50.0, 100.0]
+    dc = np.array([kappa, 0.0, 0.0, 0.0, 0.0])                  # d c / d (p1, p2, p3, y1_0, y2_0)
+
+    def f(t, z):
+        y1, y2 = z[0], z[1]
+        S = z[2:].reshape(2, 5)
+        y3 = 1.0 + kappa * (p[0] - 0.04) - y1 - y2
+        dy3 = dc - S[0] - S[1]
+        fu = np.array([-p[0] * y1 + p[2] * y2 * y3, p[0] * y1 - p[1] * y2 * y2 - p[2] * y2 * y3])
+        J = np.array([[-p[0], p[2] * y3], [p[0], -2.0 * p[1] * y2 - p[2] * y3]])
+        d3 = np.array([p[2] * y2, -p[2] * y2])                   # d f / d y3
+        fp = np.zeros((2, 5)); fp[0, 0] = -y1; fp[1, 0] = y1; fp[1, 1] = -y2 * y2; fp[0, 2] = y2 * y3; fp[1, 2] = -y2 * y3
+        return np.concatenate([fu, (J @ S + np.outer(d3, dy3) + fp).ravel()])
+    z0 = np.zeros(2 + 10); z0[0] = 1.0; S0 = np.zeros((2, 5)); S0[0, 3] = 1.0; S0[1, 4] = 1.0; z0[2:] = S0.ravel()
+    res = {}
+    for tol in (1e-10, 1e-12):
+        sol = solve_ivp(f, (0.0, 100.0), z0, method="Radau", rtol=tol, atol=tol * 1e-4, t_eval=ts)
+        S = sol.y[2:].T.reshape(2, 2, 5)
+        y3 = 1.0 - sol.y[0] - sol.y[1]
+        res[tol] = (np.stack([sol.y[0], sol.y[1], y3], axis=1), (dc - S[0, 0] - S[0, 1]) + (dc - S[1, 0] - S[1, 1]))
+    u, g = res[1e-12]
+    return dict(kappa=kappa, u0=[1.0, 0.0, 0.0], p=p.tolist(), tspan=[0.0, 100.0], ts=ts, u_at_ts=u.tolist(), G=float(u[0, 2] + u[1, 2]), dp=g[:3].tolist(), du0_differential=g[3:].tolist(),
+                spread_between_tolerances=float(np.max(np.abs(res[1e-10][1] - g) / np.maximum(np.abs(g), 1e-300))))
+
+
 if __name__ == "__main__":
-    out = dict(lv=lv(), rober=rober(), source="tests/golden/make_stiff_adjoints.py: scipy forward sensitivities (DOP853 1e-13 on lv; Radau 1e-12 on rober)")
+    out = dict(lv=lv(), rober=rober(), rober_dae_kappa=rober_dae_kappa(), source="tests/golden/make_stiff_adjoints.py: scipy forward sensitivities (DOP853 1e-13 on lv; Radau 1e-12 on rober)")
     json.dump(out, open(os.path.join(HERE, "stiff_adjoints.json"), "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "target"} if isinstance(v, dict) else v for k, v in out.items()}, indent=1))

@@ -378,3 +378,30 @@ def test_randomized_rosenbrock23_configurations_match_oracle(sa, seed):
     if M:
         assert rel(out, rout) < (1e-6 if c["mass"] else RTOL), msg
     assert rel(du0, rdu0) < bar and rel(dp, rdp) < bar, msg
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_dae_with_a_parameter_dependent_constraint_on_the_device(sa, gold, alg, oalg):
+    """y1 + y2 + y3 = 1 + 5 (p1 - 0.04) (tests/user_models.py roberdae_kappa; NOT from the reference): the case in which the loss jumps' parameter term f_p' [0; dlam_a] is not
+    identically zero — 3.0 of dG/dp1 = 12.6.  QuadratureAdjoint carries it as the start value of k_quad_sum (add = 1 for a DAE handle)."""
+    c = gold["rober_dae_kappa"]
+    if "roberdae_kappa" not in _registered:
+        m = UM.roberdae_kappa(5.0)
+        _registered["roberdae_kappa"] = sa.DeviceFunction("roberdae_kappa_ros23", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"], mass_matrix=UM.ROBERDAE_MM)
+    f = _registered["roberdae_kappa"]
+    N = 8
+    rng = np.random.default_rng(13)
+    pp = np.asarray(c["p"]) * (1 + 0.05 * rng.uniform(-1, 1, (N, 3))); pp[0] = c["p"]
+    u0 = np.tile([1.0, 0.0, 1.0], (N, 1))
+    ts = np.asarray(c["ts"]); d = np.zeros((N, 2, 3)); d[:, :, 2] = 1.0
+    quad = alg == "quadrature"
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 100.0), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts,
+                   sensealg=(sa.QuadratureAdjoint(abstol=1e-14, reltol=1e-8) if quad else sens(sa, alg, 1e-8)), abstol=1e-10, reltol=1e-8)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=d)
+    sol.engine.close()
+    bar = 1e-4 if quad else 1e-6
+    assert relc(dp[0], c["dp"]) < 10 * bar and relc(du0[0, :2], c["du0_differential"]) < 2e-4
+    with O.mass_matrix(np.asarray(UM.ROBERDAE_MM)):
+        pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=ts, loss="COTANGENT", quad_abstol=1e-14, quad_reltol=1e-8, dims=(5, 0, 0, 0))
+        rdu0, rdp, _, _ = pr.adjoint_ensemble(u0, pp, d)
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < bar and np.max(np.abs(du0 - rdu0)) < 10 * bar * np.max(np.abs(rdu0))

@@ -300,3 +300,22 @@ def test_semi_explicit_dae_checkpointed(gold, ckpts):
         rdu0, rdp, rout = pr.adjoint([1.0, 0.0, 1.0], c["p"], d[0])
     assert relc(dp, rdp) < 1e-6 and np.max(np.abs(du0[0] - rdu0)) < 1e-7
     assert relc(dp, gdp) < 1e-5
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_dae_with_a_parameter_dependent_constraint(gold, alg, oalg):
+    """y1 + y2 + y3 = 1 + 5 (p1 - 0.04): the loss jumps' parameter term f_p' [0; dlam_a] (src/adjoint_common.jl:803; added to dp by src/sensitivity_interface.jl:510-521 and its
+    Quadrature / Gauss twins) is 3.0 of dG/dp1 = 12.6 here and identically zero on the reference's own constraint — this is the case that sees it.  Independent gradient: the
+    reduced ODE's Radau sensitivities (tests/golden/make_stiff_adjoints.py rober_dae_kappa).  Oracle and lanes, every sensealg (QuadratureAdjoint: the term rides in the
+    quadrature's start value, k_quad_sum with add = 1)."""
+    c = gold["rober_dae_kappa"]
+    d = np.zeros((1, 2, 3)); d[:, :, 2] = 1.0
+    with O.mass_matrix(DAE_M):
+        pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=c["ts"], loss="COTANGENT", quad_abstol=1e-12, quad_reltol=1e-8, dims=(5, 0, 0, 0))
+        rdu0, rdp, rout = pr.adjoint([1.0, 0.0, 1.0], c["p"], d[0])
+    assert relc(rdp, c["dp"]) < 1e-5 and relc(rdu0[:2], c["du0_differential"]) < 2e-4
+    assert abs(rdp[0] - gold["rober"]["dp"][0]) > 3.0          # (the term is there: the plain constraint's dG/dp1 is 9.59)
+    cfg = E.make_config("emu_roberdae_kappa", alg, 1, 0.0, 100.0, 0.0, c["ts"], loss_kind=0, stepper=ROS, abstol=1e-10, reltol=1e-8, max_steps=100000, quad_abstol=1e-12, quad_reltol=1e-8)
+    du0, dp, out = E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 1.0]], c["p"], d)
+    bar = 1e-4 if alg == "quadrature" else 1e-6      # quadgk's first panel on a stiff problem moves the answer by 3e-6 (DESIGN 4.10); the term under test is 24 % of dp[0]
+    assert relc(dp, rdp) < bar and np.max(np.abs(du0[0] - rdu0)) < 1e-8 and relc(dp, c["dp"]) < 10 * bar

@@ -47,3 +47,12 @@ ROBERDAE = dict(  # `rober` exactly as test/Core3/adjoint.jl:1434-1441 writes it
     vjp_p=("out[0] = -u[0]*lam[0] + u[0]*lam[1]; out[1] = -u[1]*u[1]*lam[1];"
            "out[2] = u[1]*u[2]*lam[0] - u[1]*u[2]*lam[1];"))
 ROBERDAE_MM = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]]
+
+
+def roberdae_kappa(kappa=5.0):
+    """ROBERDAE with the constraint y1 + y2 + y3 = 1 + kappa (p1 - 0.04) (NOT from the reference; oracle: ROBERDAE with dims[0] = kappa): a constraint that depends on a parameter"""
+    m = dict(ROBERDAE)
+    m["f"] = ROBERDAE["f"].replace("du[2] = u[0] + u[1] + u[2] - 1.0;", f"du[2] = u[0] + u[1] + u[2] - 1.0 - {kappa!r}*(p[0] - 0.04);")
+    m["vjp_p"] = ROBERDAE["vjp_p"].replace("out[0] = -u[0]*lam[0] + u[0]*lam[1];", f"out[0] = -u[0]*lam[0] + u[0]*lam[1] - {kappa!r}*lam[2];")
+    assert m["f"] != ROBERDAE["f"] and m["vjp_p"] != ROBERDAE["vjp_p"]
+    return m
