@@ -123,6 +123,7 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
     case ORC_MODEL_ROBERDAE: /* `rober` exactly as test/Core3/adjoint.jl:1434-1441 writes it: the third row is the conservation constraint (mass matrix diag(1, 1, 0), :1450-1454) */
         du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
         du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
+        if (m->dims[1]) { const double a = du[0], b = du[1]; du[0] = 2.0 * a + 0.3 * b; du[1] = 0.1 * a + 0.5 * b; }   /* dims[1] = 1: rows mixed by Md = [2 0.3; 0.1 0.5] (mass matrix [Md 0; 0 0]: the same trajectory) */
         du[2] = u[0] + u[1] + u[2] - 1.0 - (double)m->dims[0] * (p[0] - 0.04);      /* dims[0] = kappa: a constraint that DEPENDS ON A PARAMETER (0: the reference's rober) — the loss jumps' parameter term f_p' [0; dlam_a] is zero without it */
         break;
     case ORC_MODEL_PENDULUM: /* test/Core7/adjoint_param.jl:6-10; the second term is the test's "simple controller that stabilizes pi" */
@@ -243,18 +244,19 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
             dgrad[2] = u[1] * u[2] * lam[0] - u[1] * u[2] * lam[1];
         }
         break;
-    case ORC_MODEL_ROBERDAE:
+    case ORC_MODEL_ROBERDAE: {
+        const double l0 = m->dims[1] ? 2.0 * lam[0] + 0.1 * lam[1] : lam[0], l1 = m->dims[1] ? 0.3 * lam[0] + 0.5 * lam[1] : lam[1], l2 = lam[2];      /* Md' lam_d */
         if (dlam) {
-            dlam[0] = -p[0] * lam[0] + p[0] * lam[1] + lam[2];
-            dlam[1] = p[2] * u[2] * lam[0] + (-2.0 * p[1] * u[1] - p[2] * u[2]) * lam[1] + lam[2];
-            dlam[2] = p[2] * u[1] * lam[0] - p[2] * u[1] * lam[1] + lam[2];
+            dlam[0] = -p[0] * l0 + p[0] * l1 + l2;
+            dlam[1] = p[2] * u[2] * l0 + (-2.0 * p[1] * u[1] - p[2] * u[2]) * l1 + l2;
+            dlam[2] = p[2] * u[1] * l0 - p[2] * u[1] * l1 + l2;
         }
         if (dgrad) {
-            dgrad[0] = -u[0] * lam[0] + u[0] * lam[1] - (double)m->dims[0] * lam[2];
-            dgrad[1] = -u[1] * u[1] * lam[1];
-            dgrad[2] = u[1] * u[2] * lam[0] - u[1] * u[2] * lam[1];
+            dgrad[0] = -u[0] * l0 + u[0] * l1 - (double)m->dims[0] * l2;
+            dgrad[1] = -u[1] * u[1] * l1;
+            dgrad[2] = u[1] * u[2] * l0 - u[1] * u[2] * l1;
         }
-        break;
+        break; }
     case ORC_MODEL_PENDULUM: { /* J = [0, p1; -(1 + p1) cos x1, p2];  f_p = [x2, 0, 0; -sin x1, x2, 0] */
         const double c = cos(u[0]), sn = sin(u[0]);
         if (dlam) { dlam[0] = -(1.0 + p[0]) * c * lam[1]; dlam[1] = p[0] * lam[0] + p[1] * lam[1]; }

@@ -90,37 +90,40 @@ struct EmuRober {
 // semi-explicit DAE, as hipadj_user.hpp generates a runtime model whose mass matrix is singular (DAE / mass / isalg).  Oracle: ORC_MODEL_ROBERDAE under orc_set_mass_matrix.
 // Model id = HIPADJ_MODEL_USER_BASE + 204 (KAPPA = 0: the reference's constraint) and + 205 (KAPPA = 5: y1 + y2 + y3 = 1 + 5 (p1 - 0.04), a constraint that depends on a
 // parameter — without one the loss jumps' parameter term f_p' [0; dlam_a] is identically zero and nothing would notice it missing).
-template <int KAPPA> struct EmuRoberDAE {
+template <int KAPPA, int MIX = 0> struct EmuRoberDAE {      // MIX = 1 (id + 206): the differential rows mixed by Md = [2 0.3; 0.1 0.5], mass matrix [Md 0; 0 0] — the same trajectory, a non-trivial M'[diff, diff]
     static constexpr int N = 3, NP = 3;
     static constexpr bool TIME_DEP = false;
     static constexpr bool HAS_COLS = false;
     static constexpr bool DAE = true;
-    static double mass(int i, int j) { return (i == j && i < 2) ? 1.0 : 0.0; }
+    static double mass(int i, int j) { return (i == 2 || j == 2) ? 0.0 : (MIX ? (i == 0 ? (j == 0 ? 2.0 : 0.3) : (j == 0 ? 0.1 : 0.5)) : (i == j ? 1.0 : 0.0)); }
     static bool isalg(int i) { return i == 2; }
     static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) {
-        du[0] = -p[0] * u[0] + p[2] * u[1] * u[2];
-        du[1] = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
+        const double a = -p[0] * u[0] + p[2] * u[1] * u[2], b = p[0] * u[0] - p[1] * u[1] * u[1] - p[2] * u[1] * u[2];
+        du[0] = MIX ? 2.0 * a + 0.3 * b : a;
+        du[1] = MIX ? 0.1 * a + 0.5 * b : b;
         du[2] = u[0] + u[1] + u[2] - 1.0 - KAPPA * (p[0] - 0.04);
     }
     static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&u)[N], const double (&p)[NP], double) {
-        dl[0] = -p[0] * l[0] + p[0] * l[1] + l[2];
-        dl[1] = p[2] * u[2] * l[0] + (-2.0 * p[1] * u[1] - p[2] * u[2]) * l[1] + l[2];
-        dl[2] = p[2] * u[1] * l[0] - p[2] * u[1] * l[1] + l[2];
+        const double l0 = MIX ? 2.0 * l[0] + 0.1 * l[1] : l[0], l1 = MIX ? 0.3 * l[0] + 0.5 * l[1] : l[1];
+        dl[0] = -p[0] * l0 + p[0] * l1 + l[2];
+        dl[1] = p[2] * u[2] * l0 + (-2.0 * p[1] * u[1] - p[2] * u[2]) * l1 + l[2];
+        dl[2] = p[2] * u[1] * l0 - p[2] * u[1] * l1 + l[2];
     }
     static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&u)[N], const double (&)[NP], double) {
-        dg[0] = -u[0] * l[0] + u[0] * l[1] - KAPPA * l[2];
-        dg[1] = -u[1] * u[1] * l[1];
-        dg[2] = u[1] * u[2] * l[0] - u[1] * u[2] * l[1];
+        const double l0 = MIX ? 2.0 * l[0] + 0.1 * l[1] : l[0], l1 = MIX ? 0.3 * l[0] + 0.5 * l[1] : l[1];
+        dg[0] = -u[0] * l0 + u[0] * l1 - KAPPA * l[2];
+        dg[1] = -u[1] * u[1] * l1;
+        dg[2] = u[1] * u[2] * l0 - u[1] * u[2] * l1;
     }
 };
 static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
     const int nn = model - HIPADJ_MODEL_USER_BASE;
-    if (nn == 203 || nn == 204 || nn == 205) { *n = 3; *np = 3; return HIPADJ_OK; }
+    if (nn >= 203 && nn <= 206) { *n = 3; *np = 3; return HIPADJ_OK; }
     if (nn != 4 && nn != 105) return HIPADJ_ERR_INVALID_ARG;
     *n = nn % 100; *np = nn % 100 + 1;
     return HIPADJ_OK;
 }
-static bool emu_user_dae(int32_t model) { return model == HIPADJ_MODEL_USER_BASE + 204 || model == HIPADJ_MODEL_USER_BASE + 205; }
+static bool emu_user_dae(int32_t model) { return model >= HIPADJ_MODEL_USER_BASE + 204 && model <= HIPADJ_MODEL_USER_BASE + 206; }
 static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, plan_user_dae_hook() = &emu_user_dae, true);
 
 template <class Mo>
@@ -490,7 +493,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 
 // Build units (tests/emu.py compiles them in parallel): EMU_UNIT undefined = everything in one translation unit (the variant builds
 // of test_emu_parity.py); EMU_UNIT = 0 = the C entry points, the per-model dispatchers declared `extern template`;
-// EMU_UNIT = 1..10 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
+// EMU_UNIT = 1..11 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
 #ifndef EMU_UNIT
 #define EMU_UNIT -1
 #endif
@@ -520,6 +523,7 @@ extern template int dispatch_mode<EmuRingMM<5>>(const hipadj_config*, const Plan
 extern template int dispatch_mode<EmuRober>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRoberDAE<0>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRoberDAE<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuRoberDAE<5, 1>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 1
 template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 2
@@ -540,6 +544,8 @@ template int dispatch_mode<EmuRober>(const hipadj_config*, const Plan&, const do
 template int dispatch_mode<EmuRoberDAE<0>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 10
 template int dispatch_mode<EmuRoberDAE<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 11
+template int dispatch_mode<EmuRoberDAE<5, 1>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #endif
 
 #if EMU_UNIT <= 0
@@ -567,6 +573,7 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     case HIPADJ_MODEL_USER_BASE + 203: return dispatch_mode<EmuRober>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 204: return dispatch_mode<EmuRoberDAE<0>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 205: return dispatch_mode<EmuRoberDAE<5>>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 206: return dispatch_mode<EmuRoberDAE<5, 1>>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

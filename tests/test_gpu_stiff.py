@@ -405,3 +405,30 @@ def test_dae_with_a_parameter_dependent_constraint_on_the_device(sa, gold, alg, 
         pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=ts, loss="COTANGENT", quad_abstol=1e-14, quad_reltol=1e-8, dims=(5, 0, 0, 0))
         rdu0, rdp, _, _ = pr.adjoint_ensemble(u0, pp, d)
     assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < bar and np.max(np.abs(du0 - rdu0)) < 10 * bar * np.max(np.abs(rdu0))
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_dae_with_a_dense_differential_mass_block_on_the_device(sa, gold, alg, oalg):
+    """M = [Md 0; 0 0], Md = [2 0.3; 0.1 0.5], rows of the model mixed by the same Md (tests/user_models.py ROBERDAE_MIX_F; only f registered: VJPs by dual numbers): off-diagonal
+    mass entries in the generated model's mass(i, j), in W and M k, and lu(M'[diff, diff]) in the loss jumps.  dG/d(differential u0) = Md' lam_d(t0)."""
+    c = gold["rober_dae_kappa"]
+    if "roberdae_mix" not in _registered:
+        _registered["roberdae_mix"] = sa.DeviceFunction("roberdae_mix_ros23", 3, 3, UM.ROBERDAE_MIX_F, mass_matrix=UM.ROBERDAE_MIX_MM)
+    f = _registered["roberdae_mix"]
+    Md = np.asarray(UM.ROBERDAE_MIX_MD)
+    N = 6
+    rng = np.random.default_rng(14)
+    pp = np.asarray(c["p"]) * (1 + 0.05 * rng.uniform(-1, 1, (N, 3))); pp[0] = c["p"]
+    u0 = np.tile([1.0, 0.0, 1.0], (N, 1))
+    ts = np.asarray(c["ts"]); d = np.zeros((N, 2, 3)); d[:, :, 2] = 1.0
+    quad = alg == "quadrature"
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 100.0), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts,
+                   sensealg=(sa.QuadratureAdjoint(abstol=1e-14, reltol=1e-8) if quad else sens(sa, alg, 1e-8)), abstol=1e-10, reltol=1e-8)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=d)
+    sol.engine.close()
+    bar = 1e-4 if quad else 1e-6
+    assert relc(dp[0], c["dp"]) < 10 * bar and relc(Md.T @ du0[0, :2], c["du0_differential"]) < 2e-4
+    with O.mass_matrix(np.asarray(UM.ROBERDAE_MIX_MM)):
+        pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=ts, loss="COTANGENT", quad_abstol=1e-14, quad_reltol=1e-8, dims=(5, 1, 0, 0))
+        rdu0, rdp, _, _ = pr.adjoint_ensemble(u0, pp, d)
+    assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < bar and np.max(np.abs(du0 - rdu0)) < 10 * bar * np.max(np.abs(rdu0))

@@ -319,3 +319,19 @@ def test_dae_with_a_parameter_dependent_constraint(gold, alg, oalg):
     du0, dp, out = E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 1.0]], c["p"], d)
     bar = 1e-4 if alg == "quadrature" else 1e-6      # quadgk's first panel on a stiff problem moves the answer by 3e-6; the term under test is 24 % of dp[0]
     assert relc(dp, rdp) < bar and np.max(np.abs(du0[0] - rdu0)) < 1e-8 and relc(dp, c["dp"]) < 10 * bar
+
+
+@pytest.mark.parametrize("alg,oalg", [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")])
+def test_dae_with_a_dense_differential_mass_block(gold, alg, oalg):
+    """M = [Md 0; 0 0] with Md = [2 0.3; 0.1 0.5] and the differential rows of `rober` mixed by the same Md: the trajectory and dG/dp of the parameter-dependent case, with
+    off-diagonal mass entries in W = M - d h J, in M k, and a real lu(M'[diff, diff]) in the loss jumps; dG/d(differential u0) = Md' lam_d(t0) (du0 is the reference's lam(t0))."""
+    c = gold["rober_dae_kappa"]
+    Md = np.array([[2.0, 0.3], [0.1, 0.5]]); M = np.zeros((3, 3)); M[:2, :2] = Md
+    d = np.zeros((1, 2, 3)); d[:, :, 2] = 1.0
+    with O.mass_matrix(M):
+        pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=c["ts"], loss="COTANGENT", dims=(5, 1, 0, 0))
+        rdu0, rdp, rout = pr.adjoint([1.0, 0.0, 1.0], c["p"], d[0])
+    assert relc(rdp, c["dp"]) < 1e-5 and relc(Md.T @ rdu0[:2], c["du0_differential"]) < 2e-4
+    cfg = E.make_config("emu_roberdae_mix", alg, 1, 0.0, 100.0, 0.0, c["ts"], loss_kind=0, stepper=ROS, abstol=1e-10, reltol=1e-8, max_steps=100000)
+    du0, dp, out = E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 1.0]], c["p"], d)
+    assert relc(dp, rdp) < 1e-6 and np.max(np.abs(du0[0] - rdu0)) < 1e-7 and np.max(np.abs(out[0] - rout)) < 1e-9

@@ -56,3 +56,11 @@ def roberdae_kappa(kappa=5.0):
     m["vjp_p"] = ROBERDAE["vjp_p"].replace("out[0] = -u[0]*lam[0] + u[0]*lam[1];", f"out[0] = -u[0]*lam[0] + u[0]*lam[1] - {kappa!r}*lam[2];")
     assert m["f"] != ROBERDAE["f"] and m["vjp_p"] != ROBERDAE["vjp_p"]
     return m
+
+
+ROBERDAE_MIX_MD = [[2.0, 0.3], [0.1, 0.5]]
+ROBERDAE_MIX_MM = [[2.0, 0.3, 0.0], [0.1, 0.5, 0.0], [0.0, 0.0, 0.0]]
+ROBERDAE_MIX_F = ("const real a = -p[0]*u[0] + p[2]*u[1]*u[2]; const real b = p[0]*u[0] - p[1]*u[1]*u[1] - p[2]*u[1]*u[2];"
+                  "du[0] = 2.0*a + 0.3*b; du[1] = 0.1*a + 0.5*b; du[2] = u[0] + u[1] + u[2] - 1.0 - 5.0*(p[0] - 0.04);")
+"""roberdae_kappa(5) with its differential rows mixed by Md = [2 0.3; 0.1 0.5] and the mass matrix [Md 0; 0 0]: the same trajectory, a non-trivial M'[diff, diff] in the loss jumps
+and off-diagonal mass entries in W (oracle: ROBERDAE with dims = (5, 1)).  f only: VJPs by dual numbers."""
