@@ -1217,6 +1217,31 @@ static void rhs_backsolve(double *dz, const double *z, double t, void *c) {
     accumulate_cost(A, dz, dz + n);                           /* :59 */
     mm_solve(g_mm_invT, n, dz); mm_solve(g_mm_inv, n, dz + n + np);   /* mass matrix [M' 0 0; 0 I 0; 0 0 M]  :232-247 */
 }
+/* W of Rosenbrock23 for the backsolved system z = [lam; grad; y], which is NOT affine in y: the first-derivative blocks only — d(lam')/d lam = -J(y)', d(grad')/d lam = -f_p(y)',
+ * d(y')/dy = J(y) — the second-derivative blocks d(-J(y)' lam)/dy and d(-f_p(y)' lam)/dy dropped.  Rosenbrock23 is a W-method (Shampine & Reichelt: the order conditions hold for
+ * any W), so the order stands; the reference's W carries those blocks (AD / finite differences of the whole right-hand side), i.e. its step sequence differs from this one at the
+ * level of the tolerance: DELIBERATE DEVIATION, chosen because it keeps W block triangular — two n x n factorisations per lane and step on the device. */
+static void backsolve_jac(double *J, const double *z, double t, void *c, int nz) {
+    adj_ctx *A = (adj_ctx *)c; int n = A->n, np = A->np;
+    const double *y = z + n + np;
+    double *e = (double *)calloc((size_t)2 * n + np, sizeof(double)), *row = e + n, *grow = row + n;
+    for (size_t i = 0; i < (size_t)nz * nz; ++i) J[i] = 0.0;
+    for (int r = 0; r < n; ++r) {
+        for (int i = 0; i < n; ++i) e[i] = (i == r);
+        model_vjp(A->m, row, grow, e, y, A->p, t);                /* row r of df/du, row r of df/dp */
+        for (int cc = 0; cc < n; ++cc) { J[(size_t)cc * nz + r] = -row[cc]; J[(size_t)(n + np + r) * nz + (n + np + cc)] = row[cc]; }
+        for (int k = 0; k < np; ++k) J[(size_t)(n + k) * nz + r] = -grow[k];
+    }
+    if (g_mm_n == n) for (int col = 0; col < nz; ++col) {          /* the mass-matrix rewrite of rhs_backsolve, row block by row block */
+        for (int i = 0; i < n; ++i) e[i] = J[(size_t)i * nz + col];
+        mm_solve(g_mm_invT, n, e);
+        for (int i = 0; i < n; ++i) J[(size_t)i * nz + col] = e[i];
+        for (int i = 0; i < n; ++i) e[i] = J[(size_t)(n + np + i) * nz + col];
+        mm_solve(g_mm_inv, n, e);
+        for (int i = 0; i < n; ++i) J[(size_t)(n + np + i) * nz + col] = e[i];
+    }
+    free(e);
+}
 /* Quadrature / Gauss: u = lam only (src/quadrature_adjoint.jl:35-46, src/gauss_adjoint.jl:118-128) */
 static void rhs_lambda_only(double *dz, const double *z, double t, void *c) {
     adj_ctx *A = (adj_ctx *)c; int n = A->n;
@@ -1499,7 +1524,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
      * Interpolating / Quadrature), so the sign is not restated here */
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
-    if (cfg->stepper == ORC_STEPPER_ROS23 && cfg->alg == ORC_ALG_BACKSOLVE) return -6;
+    if (cfg->stepper == ORC_STEPPER_ROS23 && cfg->alg == ORC_ALG_BACKSOLVE && (g_mm_dae || cfg->cont_cost != 0)) return -6;   /* Backsolve on the stiff stepper: ODE models, discrete losses (see backsolve_jac) */
     if (g_mm_dae && (cfg->stepper != ORC_STEPPER_ROS23 || g_dae_n != n || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* semi-explicit DAE: Rosenbrock23, discrete losses by cotangent / shift / data */   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
@@ -1553,7 +1578,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     int nz; orc_rhs rhs; double *z;
     switch (cfg->alg) {
     case ORC_ALG_INTERPOLATING: nz = n + np; rhs = rhs_interpolating; break;           /* z0 = 0 (:412) */
-    case ORC_ALG_BACKSOLVE: nz = 2 * n + np; rhs = rhs_backsolve; break;               /* z0 = [0; 0; y(T)] (:229-231) */
+    case ORC_ALG_BACKSOLVE: nz = 2 * n + np; rhs = rhs_backsolve; if (cfg->stepper == ORC_STEPPER_ROS23) alg.jac = backsolve_jac; break;   /* z0 = [0; 0; y(T)] (:229-231) */
     default: nz = n; rhs = rhs_lambda_only; break;
     }
     if (g_mm_dae) {   /* mass matrix of the adjoint system: [M' 0; 0 I] (Interpolating, src/interpolating_adjoint.jl:413-426) or M' (Quadrature / Gauss) */

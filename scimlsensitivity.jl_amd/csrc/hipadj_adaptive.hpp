@@ -978,7 +978,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                                   double* kbase, int kstride, double* __restrict__ arec = nullptr, int* __restrict__ nsteps_adj = nullptr, int SmaxA = 0,
                                   double* kfbase = nullptr, double* lrec = nullptr) {
     constexpr int N = Mo::N, NP = Mo::NP, NZ = AdjNZ<Mo, ALG>::value;
-    static_assert(STEP == 0 || ALG != 1, "Rosenbrock23: Interpolating / Gauss / GaussKronrod / Quadrature (the backsolved system is not affine in its state)");
+    static_assert(STEP == 0 || ALG != 1 || !model_dae<Mo>::value, "Rosenbrock23: BacksolveAdjoint is not offered on a semi-explicit DAE (the reference documents it to fail there)");
 #ifndef HIPADJ_TS5_REGS_CK
 #define HIPADJ_TS5_REGS_CK 1   // checkpointing = true: the rows of the sweep AND of the interval re-solve in registers (A/B hook)
 #endif
@@ -1248,6 +1248,11 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         struct Lin {
             enum { MASS = model_dae<Mo>::value ? 1 : 0 };      // (a local class: no static data member) semi-explicit DAE: mass matrix [M' 0; 0 I] of the adjoint system (M' alone for the lambda-only sensealgs)
             const double (&pv)[NP]; decltype(cur)& cu; SmallLU<N> lu; double y[N], gh, t;
+            // BacksolveAdjoint (ALG == 1), z = [lam; mu; y]: the system is NOT affine in y.  Rosenbrock23 is a W-method (Shampine-Reichelt: its order does not depend on the
+            // Jacobian being exact), and W is formed from the first-derivative blocks only — d(lam')/d lam = -J', d(mu')/d lam = -f_p', d(y')/dy = J; the second-derivative
+            // blocks d(-J(y)' lam)/dy, d(-f_p(y)' lam)/dy are dropped (the reference's W carries them, by AD of the whole right-hand side: DESIGN 6, deliberate deviation) —
+            // so W stays block triangular: two n x n factorisations and one substitution per step.
+            SmallLU<ALG == 1 ? N : 1> luy;
             HIPADJ_HD void mulM(double (&out)[NZ], const double (&x)[NZ]) const {
 #pragma unroll
                 for (int r = 0; r < NZ; ++r) {
@@ -1258,9 +1263,12 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     out[r] = s_;
                 }
             }
-            HIPADJ_HD void factor(double gh_, const double (&)[NZ], double t_) {
+            HIPADJ_HD void factor(double gh_, const double (&zc)[NZ], double t_) {
                 gh = gh_; t = t_;
-                cu.eval(t, y);
+                if constexpr (ALG == 1) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) y[j] = zc[N + NP + j];      // the backsolved state
+                } else cu.eval(t, y);
 #pragma unroll
                 for (int c = 0; c < N; ++c) {
                     double e[N], row[N];
@@ -1269,8 +1277,13 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     Mo::vjp_u(row, e, y, pv, t);                 // row c of J: column c of J'
 #pragma unroll
                     for (int r = 0; r < N; ++r) { double mrc = (r == c ? 1.0 : 0.0); if constexpr (MASS) mrc = Mo::mass(c, r); lu.a[r][c] = mrc + gh * row[r]; }
+                    if constexpr (ALG == 1) {
+#pragma unroll
+                        for (int r = 0; r < N; ++r) luy.a[c][r] = (r == c ? 1.0 : 0.0) - gh * row[r];      // I - gh J, row c
+                    }
                 }
                 lu.factor();
+                if constexpr (ALG == 1) luy.factor();
             }
             HIPADJ_HD void solve(double (&b)[NZ]) const {
                 double x[N];
@@ -1279,13 +1292,21 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 lu.solve(x);
 #pragma unroll
                 for (int j = 0; j < N; ++j) b[j] = x[j];
-                if constexpr (ALG == 0) {
+                if constexpr (ALG == 0 || ALG == 1) {
                     double W[NP]; Mo::vjp_p(W, x, y, pv, t);
 #pragma unroll
                     for (int j = 0; j < NP; ++j) b[N + j] -= gh * W[j];
                 }
+                if constexpr (ALG == 1) {
+                    double xy[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) xy[j] = b[N + NP + j];
+                    luy.solve(xy);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) b[N + NP + j] = xy[j];
+                }
             }
-        } lin{pv, cur, {}, {}, 0.0, 0.0};
+        } lin{pv, cur, {}, {}, 0.0, 0.0, {}};
         na = ros23_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.maxit, K, rhs, lin, false, cb, pre);
     } else na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.maxit, K, rhs, cb, pre);
 #pragma unroll

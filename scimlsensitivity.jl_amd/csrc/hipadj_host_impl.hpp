@@ -720,7 +720,7 @@ template <class Mo, int ALG, int CC, bool CK = false, int STEP = 0> int adaptive
     return HIPADJ_OK;
 }
 template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    if (h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the planner admitted: no Backsolve, no cost
+    if (h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the planner admitted: no cost, no discrete-loss bodies
         if (h->ip_ckpt) switch (h->cfg.alg) {      // checkpointing = true: the intervals re-solved with Rosenbrock23 inside the sweep
         case HIPADJ_ALG_INTERPOLATING: return adaptive_adjoint_l<Mo, 0, 0, true, 1>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS: return adaptive_adjoint_l<Mo, 2, 0, true, 1>(h, d_cot, d_du0, d_dp);
@@ -729,6 +729,7 @@ template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, 
         }
         switch (h->cfg.alg) {
         case HIPADJ_ALG_INTERPOLATING: return adaptive_adjoint_l<Mo, 0, 0, false, 1>(h, d_cot, d_du0, d_dp);
+        case HIPADJ_ALG_BACKSOLVE: if constexpr (!model_dae<Mo>::value) return adaptive_adjoint_l<Mo, 1, 0, false, 1>(h, d_cot, d_du0, d_dp); else HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "Rosenbrock23: BacksolveAdjoint is not offered on a semi-explicit DAE");
         case HIPADJ_ALG_GAUSS: return adaptive_adjoint_l<Mo, 2, 0, false, 1>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_QUADRATURE: return adaptive_adjoint_l<Mo, 3, 0, false, 1>(h, d_cot, d_du0, d_dp);
         case HIPADJ_ALG_GAUSS_KRONROD: return adaptive_adjoint_l<Mo, 4, 0, false, 1>(h, d_cot, d_du0, d_dp);

@@ -238,7 +238,7 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the stiff stepper of the lane family (hipadj_adaptive.hpp ros23_integrate): planned like adaptive Tsit5 below
         if (!plan_small_model(cfg->model) || P.wide) { err = "Rosenbrock23 is available for the lane-per-trajectory models (n <= 8)"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->alg == HIPADJ_ALG_BACKSOLVE) { err = "Rosenbrock23: Interpolating-, Gauss-, GaussKronrod- and QuadratureAdjoint (the backsolved system is not affine in its state; BacksolveAdjoint of a stiff problem is unstable anyway, src/sensitivity_algorithms.jl:168-198)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg == HIPADJ_ALG_BACKSOLVE && plan_user_model(cfg->model) && plan_user_dae_hook() && plan_user_dae_hook()(cfg->model)) { err = "Rosenbrock23: BacksolveAdjoint is not offered on a semi-explicit DAE (the reference documents it to fail there, test/Core3/adjoint.jl:1516-1530)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "Rosenbrock23: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->loss_kind == HIPADJ_LOSS_MODEL) { err = "Rosenbrock23: discrete losses by cotangents, HIPADJ_LOSS_LSQ_SHIFT or HIPADJ_LOSS_LSQ_DATA"; return HIPADJ_ERR_UNSUPPORTED; }
     }

@@ -451,6 +451,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
         }
         switch (cfg->alg) {
         case HIPADJ_ALG_INTERPOLATING: return run_adaptive<Mo, 0, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
+        case HIPADJ_ALG_BACKSOLVE: if constexpr (!model_dae<Mo>::value) return run_adaptive<Mo, 1, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns); else return HIPADJ_ERR_UNSUPPORTED;
         case HIPADJ_ALG_GAUSS: return run_adaptive<Mo, 2, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
         case HIPADJ_ALG_QUADRATURE: return run_adaptive<Mo, 3, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
         case HIPADJ_ALG_GAUSS_KRONROD: return run_adaptive<Mo, 4, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);

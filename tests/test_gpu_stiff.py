@@ -154,11 +154,46 @@ def test_device_pointer_calls_and_replay(sa):
 
 def test_what_the_library_refuses_for_this_stepper(sa):
     u0, p = lorenz_inputs(8)
-    for kw in (dict(sensealg=sa.BacksolveAdjoint()), dict(sensealg=sa.BacksolveAdjoint(checkpointing=False))):
-        with pytest.raises(sa.HipadjError, match="Rosenbrock23"):
-            sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, 1.0), p), u0), sa.Rosenbrock23(), saveat=[1.0], **kw)
+    with pytest.raises(sa.HipadjError, match="Rosenbrock23"):      # continuous costs are not built for it
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, 1.0), p), u0), sa.Rosenbrock23(), saveat=[1.0], g=sa.HalfSquaredSum())
     with pytest.raises(sa.HipadjError, match="Rosenbrock23"):      # the PDE family has its own stiff stepper (ETDRK4)
         sa.Engine("bruss", "interpolating", 1, 0.0, 1.0, 0.0, save_times=[1.0], stepper=3, dims=(8, 0, 0, 0))
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve", "backsolve_nockpt", "gauss", "gausskronrod", "quadrature"])
+def test_reference_loop_over_the_implicit_solvers_linear_problem(sa, alg):
+    """test/Core2/stiff_adjoints.jl:197-222: dudt = u .* p, abstol = reltol = 1e-5, saveat 0.1, loss = sum(abs2, Array(sol)); every sensealg — BacksolveAdjoint included —
+    against the Zygote gradient at rtol 1e-2.  Here (the two-state `lindiag`): against the closed form dL/dp_i = sum_t 2 t u0_i^2 exp(2 p_i t) and dL/du0_i = sum_t 2 u0_i exp(2 p_i t)."""
+    u0 = np.array([[3.0, 2.0]]); p = np.array([0.6, 0.4]); ts = np.round(np.arange(0.0, 1.0 + 1e-9, 0.1), 10)
+    salg = {"interpolating": sa.InterpolatingAdjoint(), "backsolve": sa.BacksolveAdjoint(), "backsolve_nockpt": sa.BacksolveAdjoint(checkpointing=False), "gauss": sa.GaussAdjoint(),
+            "gausskronrod": sa.GaussKronrodAdjoint(), "quadrature": sa.QuadratureAdjoint()}[alg]
+    loss = sa.LsqData(np.zeros((1, len(ts), 2)), 2.0)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lindiag", u0[0], (0.0, 1.0), p), u0), sa.Rosenbrock23(), saveat=ts, sensealg=salg, dgdu_discrete=loss, abstol=1e-5, reltol=1e-5)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=loss)
+    sol.engine.close()
+    gdp = np.array([np.sum(2.0 * ts * u0[0, i] ** 2 * np.exp(2.0 * p[i] * ts)) for i in range(2)])
+    gdu = np.array([np.sum(2.0 * u0[0, i] * np.exp(2.0 * p[i] * ts)) for i in range(2)])
+    assert rel(dp, gdp) < 1e-2 and rel(du0[0], gdu) < 1e-2          # the reference's bar; measured ~1e-4
+
+
+@pytest.mark.parametrize("ckpt", [True, False])
+@pytest.mark.parametrize("model,omodel,u0c,p", [("lv", "LV", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]), ("lvt", "LVT", [1.0, 1.0], [1.5, 1.0, 3.0, 1.0]), ("lindiag", "LINDIAG", [3.0, 2.0], [0.6, 0.4])])
+def test_rosenbrock23_backsolve(sa, model, omodel, u0c, p, ckpt):
+    """BacksolveAdjoint on the stiff stepper: W from the first-derivative blocks (W-method), the same in the oracle — device against oracle, with and without the
+    checkpoint resets of the backsolved state."""
+    rng = np.random.default_rng(33)
+    N, T = 70, 1.0
+    n, npar = sa.model_sizes(model)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.05 * rng.standard_normal((N, npar)))
+    ts = np.array([0.0, 0.1, 0.33, 0.5, 0.77, 1.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model, u0[0], (0, T), pp[0]), u0, pp), sa.Rosenbrock23(), saveat=ts, sensealg=sa.BacksolveAdjoint(checkpointing=ckpt), abstol=1e-9, reltol=1e-9)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=delta)
+    sol.engine.close()
+    ref = O.Problem(omodel, alg="BACKSOLVE", stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="COTANGENT", checkpointing=ckpt)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(sol.u, rout) < RTOL and rel(du0, rdu0) < 1e-5 and rel(dp, rdp) < 1e-5
 
 
 @pytest.mark.parametrize("alg,oalg", ALGS)

@@ -138,16 +138,19 @@ def test_step_capacity_overflow_is_an_error_and_what_the_planner_refuses():
     cfg = E.make_config("lv", "interpolating", 1, 0.0, 10.0, 0.0, [10.0], loss_kind=1, stepper=ROS, abstol=1e-10, reltol=1e-10, max_steps=50)
     with pytest.raises(RuntimeError, match="rc=-7"):
         E.forward_adjoint(cfg, 2, 4, u0, p)
-    # BacksolveAdjoint re-integrates the state backwards: the system is not affine in its unknowns and its Jacobian needs second derivatives of the model — not built;
-    # continuous costs neither
-    for bad in (dict(alg="backsolve", checkpointing=True), dict(alg="backsolve"), dict(alg="interpolating", cont_cost=1), dict(alg="quadrature", cont_cost=2)):
+    # continuous costs are not built for this stepper
+    for bad in (dict(alg="interpolating", cont_cost=1), dict(alg="quadrature", cont_cost=2), dict(alg="backsolve", checkpointing=True, cont_cost=1)):
         kw = dict(bad); alg = kw.pop("alg")
         cfg = E.make_config("lv", alg, 1, 0.0, 10.0, 0.0, [10.0], stepper=ROS, **kw)
         with pytest.raises(RuntimeError, match="rc=-6"):
             E.forward_adjoint(cfg, 2, 4, u0, p, np.zeros((1, 1, 2)))
-    # the oracle refuses the same
-    with pytest.raises(RuntimeError):
-        O.Problem("LV", alg="BACKSOLVE", stepper="ROS23", t0=0, t1=1.0, dt=0.0, save_times=[1.0], loss="COTANGENT").adjoint(u0[0], p, np.zeros((1, 2)))
+    # BacksolveAdjoint on a semi-explicit DAE: refused by both (the reference documents it to fail there, test/Core3/adjoint.jl:1516-1530)
+    cfg = E.make_config("emu_roberdae", "backsolve", 1, 0.0, 1.0, 0.0, [1.0], stepper=ROS, checkpointing=True)
+    with pytest.raises(RuntimeError, match="rc=-6"):
+        E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 0.0]], [0.04, 3e7, 1e4], np.zeros((1, 1, 3)))
+    with O.mass_matrix(DAE_M):
+        with pytest.raises(RuntimeError):
+            O.Problem("ROBERDAE", alg="BACKSOLVE", stepper="ROS23", t0=0, t1=1.0, dt=0.0, save_times=[1.0], loss="COTANGENT", checkpointing=True).adjoint([1.0, 0.0, 0.0], [0.04, 3e7, 1e4], np.zeros((1, 3)))
 
 
 def test_the_time_derivative_term_of_k3_is_not_pinned_by_the_reference_relation_but_by_the_step_count(gold):
@@ -335,3 +338,27 @@ def test_dae_with_a_dense_differential_mass_block(gold, alg, oalg):
     cfg = E.make_config("emu_roberdae_mix", alg, 1, 0.0, 100.0, 0.0, c["ts"], loss_kind=0, stepper=ROS, abstol=1e-10, reltol=1e-8, max_steps=100000)
     du0, dp, out = E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 1.0]], c["p"], d)
     assert relc(dp, rdp) < 1e-6 and np.max(np.abs(du0[0] - rdu0)) < 1e-7 and np.max(np.abs(out[0] - rout)) < 1e-9
+
+
+# ---- BacksolveAdjoint on the stiff stepper (test/Core2/stiff_adjoints.jl:207-222 runs it with every implicit solver on u' = u .* p) ----------------------------------------
+@pytest.mark.parametrize("ckpt", [True, False])
+@pytest.mark.parametrize("model,omodel,u0c,p", [MODELS[0], MODELS[1], ("lindiag", "LINDIAG", [3.0, 2.0], [0.6, 0.4])])
+def test_lane_bodies_backsolve(model, omodel, u0c, p, ckpt):
+    """z = [lam; mu; y] is not affine in y; Rosenbrock23 is a W-method and W is formed from the first-derivative blocks only (two n x n factorisations and a substitution per
+    step; the reference's W carries the second-derivative blocks too: a deliberate deviation that moves the step sequence, not the order) — lanes against the oracle's same W, and
+    against InterpolatingAdjoint at the level BacksolveAdjoint reaches (the reference's own bar for this pair is rtol 1e-2, :221-222)."""
+    rng = np.random.default_rng(16)
+    N, T = 3, 1.0
+    n, npar = len(u0c), len(p)
+    u0 = np.asarray(u0c) + 0.05 * rng.standard_normal((N, n))
+    pp = np.asarray(p) * (1 + 0.03 * rng.standard_normal((N, npar)))
+    ts = np.array([0.0, 0.1, 0.33, 0.5, 0.77, 1.0])
+    delta = rng.standard_normal((N, len(ts), n))
+    cfg = E.make_config(model, "backsolve", N, 0.0, T, 0.0, ts, loss_kind=0, p_shared=False, stepper=ROS, abstol=1e-8, reltol=1e-8, checkpointing=ckpt, max_steps=100000)
+    du0, dp, out = E.forward_adjoint(cfg, n, npar, u0, pp, delta)
+    ref = O.Problem(omodel, alg="BACKSOLVE", stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="COTANGENT", checkpointing=ckpt)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, pp, delta)
+    assert rel(out, rout) < 1e-11 and rel(du0, rdu0) < 1e-6 and rel(dp, rdp) < 1e-6
+    ia = O.Problem(omodel, alg="INTERPOLATING", stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="COTANGENT")
+    idu0, idp, _, _ = ia.adjoint_ensemble(u0, pp, delta)
+    assert rel(du0, idu0) < 1e-3 and rel(dp, idp) < 1e-3
