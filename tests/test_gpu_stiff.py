@@ -355,7 +355,9 @@ def _random_stiff_case(rng):
     n_ring = int(rng.integers(2, 8))
     models.append((f"ring{n_ring}", "RING", list(rng.uniform(0.3, 1.0, n_ring)), list(rng.uniform(0.4, 1.2, n_ring + 1)), (n_ring, 0, 0, 0)))
     model, omodel, u0c, p, dims = models[int(rng.integers(len(models)))]
-    alg, oalg = ALGS[int(rng.integers(4))]
+    alg, oalg = (ALGS + [("backsolve", "BACKSOLVE")])[int(rng.integers(5))]
+    if alg == "backsolve" and model in ("lorenz", "rober_stiff"):      # backsolving a chaotic or a stiff trajectory is unstable (src/sensitivity_algorithms.jl:168-198)
+        alg, oalg = "interpolating", "INTERPOLATING"
     user = model.startswith("rober") or model.startswith("ring")
     c = dict(model=model, omodel=omodel, u0c=u0c, p=p, dims=dims, alg=alg, oalg=oalg, user=user, N=int(rng.integers(1, 150)), T=float(rng.choice([0.5, 1.0, 2.0])))
     c["ckpt"] = bool(rng.random() < 0.4) and alg != "quadrature"
@@ -372,7 +374,7 @@ def _random_stiff_case(rng):
     return c
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(80))
 def test_randomized_rosenbrock23_configurations_match_oracle(sa, seed):
     rng = np.random.default_rng(int(os.environ.get("HIPADJ_FUZZ_BASE", "7000")) + seed)
     c = _random_stiff_case(rng)
@@ -390,7 +392,7 @@ def test_randomized_rosenbrock23_configurations_match_oracle(sa, seed):
     u0 = np.asarray(c["u0c"]) + (0.0 if c["model"] == "rober_stiff" else 0.05) * rng.standard_normal((c["N"], n))
     p = np.asarray(c["p"]) if c["p_shared"] else np.asarray(c["p"]) * (1 + 0.03 * rng.standard_normal((c["N"], npar)))
     tol = c["tol"]
-    salg = {"interpolating": sa.InterpolatingAdjoint(checkpointing=c["ckpt"]), "gauss": sa.GaussAdjoint(checkpointing=c["ckpt"]),
+    salg = {"interpolating": sa.InterpolatingAdjoint(checkpointing=c["ckpt"]), "backsolve": sa.BacksolveAdjoint(checkpointing=c["ckpt"]), "gauss": sa.GaussAdjoint(checkpointing=c["ckpt"]),
             "gausskronrod": sa.GaussKronrodAdjoint(checkpointing=c["ckpt"]), "quadrature": sa.QuadratureAdjoint(abstol=tol, reltol=tol)}[c["alg"]]
     M = len(c["ts"])
     blk = rng.standard_normal((c["N"], M, n))
@@ -409,7 +411,7 @@ def test_randomized_rosenbrock23_configurations_match_oracle(sa, seed):
     msg = {k: (v if not isinstance(v, (list, np.ndarray)) else np.asarray(v).round(3).tolist()) for k, v in c.items() if k not in ("u0c", "p")}
     # two implementations of one adaptive controller: agreement to a fraction of the solver tolerance times the problem's amplification, not to roundoff; behind a mass matrix
     # the two formulations (nu = M' lam here, lam there) weigh the error norm differently and agree to the tolerance itself
-    bar = 2e-5 if (c["mass"] or c["ckpt"]) else 2e-6
+    bar = 2e-5 if (c["mass"] or c["ckpt"] or c["alg"] == "backsolve") else 2e-6
     if M:
         assert rel(out, rout) < (1e-6 if c["mass"] else RTOL), msg
     assert rel(du0, rdu0) < bar and rel(dp, rdp) < bar, msg
