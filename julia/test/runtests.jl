@@ -69,6 +69,33 @@ end
     @test isapprox(du0[:, 1], du0_ref; rtol = 1e-8)         # lam(t0), the reference's convention
 end
 
+# ---- round 6: Rosenbrock23 and the reference's singular-mass-matrix problem (test/Core3/adjoint.jl:1434-1530; test/Core2/stiff_adjoints.jl:66-80) ----------------------------
+@testset "stiff: Rosenbrock23, semi-explicit DAE (test/Core3/adjoint.jl:1434-1530)" begin
+    function rober(du, u, p, t)
+        du[1] = -p[1] * u[1] + p[3] * u[2] * u[3]; du[2] = p[1] * u[1] - p[2] * u[2]^2 - p[3] * u[2] * u[3]; du[3] = u[1] + u[2] + u[3] - 1
+        return nothing
+    end
+    Mdae = [1.0 0 0; 0 1.0 0; 0 0 0]
+    p = [0.04, 3.0e7, 1.0e4]; ts = [50.0, 100.0]
+    dg_singular(out, u, p, t, i) = (fill!(out, 0); out[end] = 1)
+    prob = ODEProblem(ODEFunction(rober, mass_matrix = Mdae), [1.0, 0.0, 1.0], (0.0, 100.0), p)
+    sol_ref = solve(prob, Rodas4(autodiff = AutoFiniteDiff()), reltol = 1.0e-12, abstol = 1.0e-12, initializealg = BrownFullBasicInit())
+    _, dp_ref = adjoint_sensitivities(sol_ref, Rodas4(autodiff = AutoFiniteDiff()); t = ts, dgdu_discrete = dg_singular, abstol = 1.0e-8, reltol = 1.0e-8,
+                                      sensealg = QuadratureAdjoint(), maxiters = Int(1.0e6), initializealg = BrownFullBasicInit())
+    m = register_model("rober_dae_jl", 3, 3;
+        f = "du[0] = -p[0]*u[0] + p[2]*u[1]*u[2]; du[1] = p[0]*u[0] - p[1]*u[1]*u[1] - p[2]*u[1]*u[2]; du[2] = u[0] + u[1] + u[2] - 1.0;", mass_matrix = Mdae)   # VJPs by dual numbers
+    for inner in (InterpolatingAdjoint(), GaussAdjoint(), GaussKronrodAdjoint(), QuadratureAdjoint(abstol = 1.0e-14, reltol = 1.0e-8), InterpolatingAdjoint(checkpointing = true))
+        dev = HIPBatchedAdjoint(inner; model = m)
+        cols = ODEProblem((dU, U, p, t) -> nothing, repeat([1.0, 0.0, 1.0], 1, 4), (0.0, 100.0), p)
+        sol = HIPAdj.hip_solve(cols, Rosenbrock23(), dev; saveat = ts, abstol = 1.0e-10, reltol = 1.0e-8)
+        @test maximum(abs.(sum(sol.u[:, :, 1], dims = 1) .- 1)) < 1e-8                    # the constraint, from the inconsistent start [1, 0, 1]
+        _, dp = adjoint_sensitivities(sol, Rosenbrock23(); sensealg = dev, dgdu_discrete = dg_singular)
+        @test isapprox(dp ./ 4, dp_ref; rtol = 1e-5)                                       # the reference's own bar (:1483)
+    end
+    @test_throws Exception HIPAdj.hip_solve(ODEProblem((dU, U, p, t) -> nothing, repeat([1.0, 0.0, 0.0], 1, 4), (0.0, 1.0), p), Tsit5(),
+                                            HIPBatchedAdjoint(InterpolatingAdjoint(); model = m); saveat = [1.0])      # a DAE model on an explicit stepper: refused by name
+end
+
 # ---- wide runtime models (ABI 106): the Julia emitter writes the same SPMD text as the Python host's (tests/golden/dense_chain_bodies.json), and the
 # 2 -> 50 -> 2 neural ODE of docs/src/Benchmark.md:62 registers and compiles for gfx950
 @testset "wide models" begin
