@@ -229,7 +229,7 @@ int hipadj_wmodel_set_cost(int32_t model_id, const char *cost_body);
  * (row-major; NULL removes it) — test/Core3/adjoint.jl:1315-1376.  The reference hands M to the forward solver and M' (resp.
  * [M' 0; 0 I], [M' 0 0; 0 I 0; 0 0 M]) to the adjoint problems (src/interpolating_adjoint.jl:413-426, src/backsolve_adjoint.jl:232-247,
  * src/quadrature_adjoint.jl:194-206, src/gauss_adjoint.jl:403-415) and divides the loss jumps by lu(M') (src/adjoint_common.jl:110-135,
- * 805-807).  The device steppers are explicit, so the generated model is F = M^{-1} f with F_u' nu = f_u' (M^{-T} nu): the sweep
+ * 805-807).  For a non-singular M the generated model is F = M^{-1} f (every stepper, Rosenbrock23 included) with F_u' nu = f_u' (M^{-T} nu): the sweep
  * integrates nu = M' lam, the parameter integrand f_p' lam is unchanged, and du0 is mapped back to lam(t0) = M^{-T} nu(t0) — what the
  * reference returns (src/sensitivity_interface.jl:500; note that dG/du0 itself is M' du0).  All sensealgs, RK4 and Tsit5.
  * A SINGULAR M of the semi-explicit form [Md 0; 0 0] — zero rows that are also zero columns (the algebraic variables, src/adjoint_common.jl:116-122), Md non-singular (:131-133) —
