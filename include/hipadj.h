@@ -225,13 +225,13 @@ int hipadj_model_set_cost_function(int32_t model_id, const char *g_body);
  * HIPADJ_W_FOR loops do) and, under `if (WP)`, w * dg/dp into gp[...] (entries owned by one thread) or acc[...] (the model's reduced parameters).  It is evaluated
  * with every joint VJP (accumulate_cost!, src/derivative_wrappers.jl:1411-1442).  NULL / "" removes it.  Selected per handle with cont_cost = HIPADJ_CCOST_MODEL. */
 int hipadj_wmodel_set_cost(int32_t model_id, const char *cost_body);
-/* ODEFunction(f; mass_matrix = M) for a runtime-registered model: M u' = f(u, p, t) with a CONSTANT NON-SINGULAR n x n matrix M
- * (row-major; NULL removes it) — test/Core3/adjoint.jl:1315-1376.  The reference hands M to the forward solver and M' (resp.
+/* ODEFunction(f; mass_matrix = M) for a runtime-registered model: M u' = f(u, p, t) with a CONSTANT n x n matrix M, non-singular or singular of the
+ * semi-explicit form described below (row-major; NULL removes it) — test/Core3/adjoint.jl:1315-1376.  The reference hands M to the forward solver and M' (resp.
  * [M' 0; 0 I], [M' 0 0; 0 I 0; 0 0 M]) to the adjoint problems (src/interpolating_adjoint.jl:413-426, src/backsolve_adjoint.jl:232-247,
  * src/quadrature_adjoint.jl:194-206, src/gauss_adjoint.jl:403-415) and divides the loss jumps by lu(M') (src/adjoint_common.jl:110-135,
  * 805-807).  For a non-singular M the generated model is F = M^{-1} f (every stepper, Rosenbrock23 included) with F_u' nu = f_u' (M^{-T} nu): the sweep
  * integrates nu = M' lam, the parameter integrand f_p' lam is unchanged, and du0 is mapped back to lam(t0) = M^{-T} nu(t0) — what the
- * reference returns (src/sensitivity_interface.jl:500; note that dG/du0 itself is M' du0).  All sensealgs, RK4 and Tsit5.
+ * reference returns (src/sensitivity_interface.jl:500; note that dG/du0 itself is M' du0).  All sensealgs, every stepper of the lane family.
  * A SINGULAR M of the semi-explicit form [Md 0; 0 0] — zero rows that are also zero columns (the algebraic variables, src/adjoint_common.jl:116-122), Md non-singular (:131-133) —
  * makes the model a DAE (round 6; test/Core3/adjoint.jl:1434-1530): HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE integrates M u' = f and M' lam' = -J' lam in mass-matrix form
  * (W = M - d h J), from a consistent state (the algebraic entries of u0 are solved for, BrownFullBasicInit), with the loss jumps of src/adjoint_common.jl:790-813 (algebraic
