@@ -1524,7 +1524,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
      * Interpolating / Quadrature), so the sign is not restated here */
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
-    if (cfg->stepper == ORC_STEPPER_ROS23 && cfg->alg == ORC_ALG_BACKSOLVE && (g_mm_dae || cfg->cont_cost != 0)) return -6;   /* Backsolve on the stiff stepper: ODE models, discrete losses (see backsolve_jac) */
+    if (cfg->stepper == ORC_STEPPER_ROS23 && cfg->alg == ORC_ALG_BACKSOLVE && g_mm_dae) return -6;   /* Backsolve on the stiff stepper: ODE models (see backsolve_jac; the cost's second-derivative blocks are dropped from W like the model's) */
     if (g_mm_dae && (cfg->stepper != ORC_STEPPER_ROS23 || g_dae_n != n || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* semi-explicit DAE: Rosenbrock23, discrete losses by cotangent / shift / data */   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */

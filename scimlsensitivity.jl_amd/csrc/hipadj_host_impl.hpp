@@ -720,21 +720,24 @@ template <class Mo, int ALG, int CC, bool CK = false, int STEP = 0> int adaptive
     return HIPADJ_OK;
 }
 template <class Mo> int adaptive_adjoint(hipadj_handle* h, const double* d_cot, double* d_du0, double* d_dp) {
-    if (h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the planner admitted: no cost, no discrete-loss bodies
-        if (h->ip_ckpt) switch (h->cfg.alg) {      // checkpointing = true: the intervals re-solved with Rosenbrock23 inside the sweep
-        case HIPADJ_ALG_INTERPOLATING: return adaptive_adjoint_l<Mo, 0, 0, true, 1>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_GAUSS: return adaptive_adjoint_l<Mo, 2, 0, true, 1>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_GAUSS_KRONROD: return adaptive_adjoint_l<Mo, 4, 0, true, 1>(h, d_cot, d_du0, d_dp);
-        default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "Rosenbrock23: sensealg %d has no checkpointed device kernel", h->cfg.alg);
+    if (h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the stiff stepper: the same table with STEP = 1 (a DAE model: the planner admitted no cost and no Backsolve)
+#define HIPADJ_ROS_CASE(A, C, K) case A * 4 + C: if constexpr (!model_dae<Mo>::value || (C == 0 && A != 1)) return adaptive_adjoint_l<Mo, A, C, K, 1>(h, d_cot, d_du0, d_dp); else break;
+        if (h->ip_ckpt) switch (h->cfg.alg * 4 + h->cfg.cont_cost) {      // checkpointing = true: the intervals re-solved with Rosenbrock23 inside the sweep
+        HIPADJ_ROS_CASE(0, 0, true) HIPADJ_ROS_CASE(0, 1, true) HIPADJ_ROS_CASE(0, 2, true)
+        HIPADJ_ROS_CASE(2, 0, true) HIPADJ_ROS_CASE(2, 1, true) HIPADJ_ROS_CASE(2, 2, true)
+        HIPADJ_ROS_CASE(4, 0, true) HIPADJ_ROS_CASE(4, 1, true) HIPADJ_ROS_CASE(4, 2, true)
+        default: break;
         }
-        switch (h->cfg.alg) {
-        case HIPADJ_ALG_INTERPOLATING: return adaptive_adjoint_l<Mo, 0, 0, false, 1>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_BACKSOLVE: if constexpr (!model_dae<Mo>::value) return adaptive_adjoint_l<Mo, 1, 0, false, 1>(h, d_cot, d_du0, d_dp); else HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "Rosenbrock23: BacksolveAdjoint is not offered on a semi-explicit DAE");
-        case HIPADJ_ALG_GAUSS: return adaptive_adjoint_l<Mo, 2, 0, false, 1>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_QUADRATURE: return adaptive_adjoint_l<Mo, 3, 0, false, 1>(h, d_cot, d_du0, d_dp);
-        case HIPADJ_ALG_GAUSS_KRONROD: return adaptive_adjoint_l<Mo, 4, 0, false, 1>(h, d_cot, d_du0, d_dp);
-        default: HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "Rosenbrock23: sensealg %d has no device kernel", h->cfg.alg);
+        else switch (h->cfg.alg * 4 + h->cfg.cont_cost) {
+        HIPADJ_ROS_CASE(0, 0, false) HIPADJ_ROS_CASE(0, 1, false) HIPADJ_ROS_CASE(0, 2, false)
+        HIPADJ_ROS_CASE(1, 0, false) HIPADJ_ROS_CASE(1, 1, false) HIPADJ_ROS_CASE(1, 2, false)
+        HIPADJ_ROS_CASE(2, 0, false) HIPADJ_ROS_CASE(2, 1, false) HIPADJ_ROS_CASE(2, 2, false)
+        HIPADJ_ROS_CASE(3, 0, false) HIPADJ_ROS_CASE(3, 1, false) HIPADJ_ROS_CASE(3, 2, false)
+        HIPADJ_ROS_CASE(4, 0, false) HIPADJ_ROS_CASE(4, 1, false) HIPADJ_ROS_CASE(4, 2, false)
+        default: break;
         }
+#undef HIPADJ_ROS_CASE
+        HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "Rosenbrock23: sensealg %d / cont_cost %d%s has no device kernel", h->cfg.alg, h->cfg.cont_cost, h->ip_ckpt ? " (checkpointed)" : "");
     }
     if (h->ip_ckpt) {   // checkpointing=true for Interpolating / Gauss: per-interval re-solve inside the sweep
         switch (h->cfg.alg * 4 + h->cfg.cont_cost) {

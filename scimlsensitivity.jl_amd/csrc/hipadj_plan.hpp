@@ -239,8 +239,10 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the stiff stepper of the lane family (hipadj_adaptive.hpp ros23_integrate): planned like adaptive Tsit5 below
         if (!plan_small_model(cfg->model) || P.wide) { err = "Rosenbrock23 is available for the lane-per-trajectory models (n <= 8)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->alg == HIPADJ_ALG_BACKSOLVE && plan_user_model(cfg->model) && plan_user_dae_hook() && plan_user_dae_hook()(cfg->model)) { err = "Rosenbrock23: BacksolveAdjoint is not offered on a semi-explicit DAE (the reference documents it to fail there, test/Core3/adjoint.jl:1516-1530)"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "Rosenbrock23: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->loss_kind == HIPADJ_LOSS_MODEL) { err = "Rosenbrock23: discrete losses by cotangents, HIPADJ_LOSS_LSQ_SHIFT or HIPADJ_LOSS_LSQ_DATA"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (plan_user_model(cfg->model) && plan_user_dae_hook() && plan_user_dae_hook()(cfg->model)) {      // a semi-explicit DAE: its loss jump (src/adjoint_common.jl:790-813) is built for the plain loss routes
+            if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "Rosenbrock23 on a semi-explicit DAE: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
+            if (cfg->loss_kind == HIPADJ_LOSS_MODEL) { err = "Rosenbrock23 on a semi-explicit DAE: discrete losses by cotangents, HIPADJ_LOSS_LSQ_SHIFT or HIPADJ_LOSS_LSQ_DATA"; return HIPADJ_ERR_UNSUPPORTED; }
+        }
     }
     if (cfg->stepper == HIPADJ_STEPPER_ETDRK4_FIXED) {   // the exponential stepper: everything below treats it as a fixed-step scheme with Hermite dense output
         if (!P.field) { err = "HIPADJ_STEPPER_ETDRK4_FIXED integrates the semilinear PDE family (HIPADJ_MODEL_BRUSS): its linear part is diagonal in the DFT basis"; return HIPADJ_ERR_UNSUPPORTED; }

@@ -443,20 +443,20 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
 template <class Mo>
 static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const double* u0, const double* p, const double* dLdu, double* du0, double* dp, double* out, int* ns) {
     if (cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {
-        if (P.ip_ckpt) switch (cfg->alg) {
-        case HIPADJ_ALG_INTERPOLATING: return run_adaptive<Mo, 0, 0, true, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-        case HIPADJ_ALG_GAUSS: return run_adaptive<Mo, 2, 0, true, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-        case HIPADJ_ALG_GAUSS_KRONROD: return run_adaptive<Mo, 4, 0, true, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-        default: return HIPADJ_ERR_UNSUPPORTED;
+#define EMU_ROS_CASE(A, C, K) case A * 4 + C: if constexpr (!model_dae<Mo>::value || (C == 0 && A != 1)) return run_adaptive<Mo, A, C, K, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns); else break;
+        if (P.ip_ckpt) switch (cfg->alg * 4 + cfg->cont_cost) {
+        EMU_ROS_CASE(0, 0, true) EMU_ROS_CASE(0, 1, true) EMU_ROS_CASE(0, 2, true) EMU_ROS_CASE(2, 0, true) EMU_ROS_CASE(2, 1, true) EMU_ROS_CASE(2, 2, true)
+        EMU_ROS_CASE(4, 0, true) EMU_ROS_CASE(4, 1, true) EMU_ROS_CASE(4, 2, true)
+        default: break;
         }
-        switch (cfg->alg) {
-        case HIPADJ_ALG_INTERPOLATING: return run_adaptive<Mo, 0, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-        case HIPADJ_ALG_BACKSOLVE: if constexpr (!model_dae<Mo>::value) return run_adaptive<Mo, 1, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns); else return HIPADJ_ERR_UNSUPPORTED;
-        case HIPADJ_ALG_GAUSS: return run_adaptive<Mo, 2, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-        case HIPADJ_ALG_QUADRATURE: return run_adaptive<Mo, 3, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-        case HIPADJ_ALG_GAUSS_KRONROD: return run_adaptive<Mo, 4, 0, false, 1>(cfg, P, u0, p, dLdu, du0, dp, out, ns);
-        default: return HIPADJ_ERR_UNSUPPORTED;
+        else switch (cfg->alg * 4 + cfg->cont_cost) {
+        EMU_ROS_CASE(0, 0, false) EMU_ROS_CASE(0, 1, false) EMU_ROS_CASE(0, 2, false) EMU_ROS_CASE(1, 0, false) EMU_ROS_CASE(1, 1, false) EMU_ROS_CASE(1, 2, false)
+        EMU_ROS_CASE(2, 0, false) EMU_ROS_CASE(2, 1, false) EMU_ROS_CASE(2, 2, false) EMU_ROS_CASE(3, 0, false) EMU_ROS_CASE(3, 1, false) EMU_ROS_CASE(3, 2, false)
+        EMU_ROS_CASE(4, 0, false) EMU_ROS_CASE(4, 1, false) EMU_ROS_CASE(4, 2, false)
+        default: break;
         }
+#undef EMU_ROS_CASE
+        return HIPADJ_ERR_UNSUPPORTED;
     }
     if (P.ip_ckpt) {
         switch (cfg->alg * 4 + cfg->cont_cost) {

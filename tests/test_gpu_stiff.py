@@ -154,8 +154,14 @@ def test_device_pointer_calls_and_replay(sa):
 
 def test_what_the_library_refuses_for_this_stepper(sa):
     u0, p = lorenz_inputs(8)
-    with pytest.raises(sa.HipadjError, match="Rosenbrock23"):      # continuous costs are not built for it
-        sa.solve(sa.EnsembleProblem(sa.ODEProblem("lorenz", u0[0], (0, 1.0), p), u0), sa.Rosenbrock23(), saveat=[1.0], g=sa.HalfSquaredSum())
+    if "roberdae" not in _registered:
+        m = UM.ROBERDAE
+        _registered["roberdae"] = sa.DeviceFunction("roberdae_ros23", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"], mass_matrix=UM.ROBERDAE_MM)
+    ud = np.tile([1.0, 0.0, 0.0], (4, 1)); pd = np.array([0.04, 3e7, 1e4])
+    with pytest.raises(sa.HipadjError, match="DAE"):               # a semi-explicit DAE takes no continuous cost ...
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem(_registered["roberdae"], ud[0], (0, 1.0), pd), ud), sa.Rosenbrock23(), saveat=[1.0], g=sa.HalfSquaredSum())
+    with pytest.raises(sa.HipadjError, match="DAE"):               # ... and no BacksolveAdjoint (the reference documents it to fail there)
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem(_registered["roberdae"], ud[0], (0, 1.0), pd), ud), sa.Rosenbrock23(), saveat=[1.0], sensealg=sa.BacksolveAdjoint())
     with pytest.raises(sa.HipadjError, match="Rosenbrock23"):      # the PDE family has its own stiff stepper (ETDRK4)
         sa.Engine("bruss", "interpolating", 1, 0.0, 1.0, 0.0, save_times=[1.0], stepper=3, dims=(8, 0, 0, 0))
 
@@ -371,6 +377,11 @@ def _random_stiff_case(rng):
     c["no_start"] = bool(rng.random() < 0.25)
     c["auto_vjp"] = bool(rng.random() < 0.5)
     c["mass"] = bool(user and model.startswith("ring") and n_ring <= 5 and rng.random() < 0.4)       # a dense well-conditioned mass matrix behind a runtime ring
+    # drawn last (earlier seeds keep their configurations): a continuous cost — the built-in ones on the compiled-in models, g = (sum u)^2 / 2 as text on the runtime rings
+    c["cost"] = int(rng.integers(0, 3)) if (not user and rng.random() < 0.5) else 0
+    if c["cost"] == 2 and alg == "gauss":
+        c["cost"] = 1
+    c["user_cost"] = bool(user and model.startswith("ring") and not c["mass"] and alg != "gauss" and rng.random() < 0.4)
     return c
 
 
@@ -389,6 +400,12 @@ def test_randomized_rosenbrock23_configurations_match_oracle(sa, seed):
         if key not in _registered:
             _registered[key] = sa.DeviceFunction(key, m["n"], m["np"], m["f"], *(() if c["auto_vjp"] else (m["vjp"], m["vjp_p"])), mass_matrix=Mm)
         f = _registered[key]
+        if c["user_cost"]:
+            key += "_cost"
+            if key not in _registered:
+                _registered[key] = sa.DeviceFunction(key, m["n"], m["np"], m["f"], *(() if c["auto_vjp"] else (m["vjp"], m["vjp_p"]))).set_cost(
+                    g="real s = 0.0; for (int i = 0; i < N; ++i) s += u[i]; g = 0.5*s*s;")
+            f = _registered[key]
     u0 = np.asarray(c["u0c"]) + (0.0 if c["model"] == "rober_stiff" else 0.05) * rng.standard_normal((c["N"], n))
     p = np.asarray(c["p"]) if c["p_shared"] else np.asarray(c["p"]) * (1 + 0.03 * rng.standard_normal((c["N"], npar)))
     tol = c["tol"]
@@ -398,15 +415,16 @@ def test_randomized_rosenbrock23_configurations_match_oracle(sa, seed):
     blk = rng.standard_normal((c["N"], M, n))
     loss = {"shift": sa.LsqShift(1.5), "data": sa.LsqData(blk, 2.0), "cot": None}[c["loss"]]
     prob = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, c["T"]), p if c["p_shared"] else p[0], c["dims"]), u0, p)
-    sol = sa.solve(prob, sa.Rosenbrock23(), saveat=c["ts"], sensealg=salg, dgdu_discrete=loss, no_start=c["no_start"], abstol=tol, reltol=tol)
-    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=c["ts"], dgdu_discrete=(blk if c["loss"] == "cot" else loss))
+    g = sa.ModelCost() if c["user_cost"] else [None, sa.HalfSquaredSum(), sa.FirstStateSquaredPlusFirstParam()][c["cost"]]
+    sol = sa.solve(prob, sa.Rosenbrock23(), saveat=c["ts"], sensealg=salg, dgdu_discrete=loss, no_start=c["no_start"], abstol=tol, reltol=tol, g=g)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=c["ts"], dgdu_discrete=(blk if c["loss"] == "cot" else loss), g=g)
     out = None if sol.u is None else np.array(sol.u)
     sol.engine.close()
     import contextlib
     with (O.mass_matrix(Mm) if Mm is not None else contextlib.nullcontext()):
         ref = O.Problem(c["omodel"], alg=c["oalg"], stepper="ROS23", t0=0.0, t1=c["T"], dt=0.0, abstol=tol, reltol=tol, save_times=c["ts"],
                         loss={"shift": "LSQ_SHIFT", "data": "LSQ_DATA", "cot": "COTANGENT"}[c["loss"]], loss_shift=1.5, loss_scale=2.0, checkpointing=c["ckpt"], dims=c["dims"],
-                        quad_abstol=tol, quad_reltol=tol, no_start=c["no_start"])
+                        quad_abstol=tol, quad_reltol=tol, no_start=c["no_start"], cont_cost=(1 if c["user_cost"] else c["cost"]))
         rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, None if c["loss"] == "shift" else blk)
     msg = {k: (v if not isinstance(v, (list, np.ndarray)) else np.asarray(v).round(3).tolist()) for k, v in c.items() if k not in ("u0c", "p")}
     # two implementations of one adaptive controller: agreement to a fraction of the solver tolerance times the problem's amplification, not to roundoff; behind a mass matrix
@@ -469,3 +487,27 @@ def test_dae_with_a_dense_differential_mass_block_on_the_device(sa, gold, alg, o
         pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=ts, loss="COTANGENT", quad_abstol=1e-14, quad_reltol=1e-8, dims=(5, 1, 0, 0))
         rdu0, rdp, _, _ = pr.adjoint_ensemble(u0, pp, d)
     assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < bar and np.max(np.abs(du0 - rdu0)) < 10 * bar * np.max(np.abs(rdu0))
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS + [("backsolve", "BACKSOLVE")])
+def test_model_discrete_loss_bodies_with_the_stiff_stepper(sa, alg, oalg):
+    """HIPADJ_LOSS_MODEL on Rosenbrock23: dgdu_discrete AND dgdp_discrete as device bodies of a runtime model (src/adjoint_common.jl:771-779; the loss of the oracle's test id 4 —
+    every argument of the reference's callback in use), every sensealg, against the oracle."""
+    from test_gpu_device_loss import _lv_with_loss
+    G = json.load(open(os.path.join(os.path.dirname(HERE), "tests", "golden", "discrete_losses.json")))
+    ts = np.array(G["ts"]); p = np.array(G["p"])
+    rng = np.random.default_rng(4)
+    N = 40
+    u0 = np.array(G["u0"]) + 0.05 * rng.standard_normal((N, 2))
+    data = rng.uniform(0.5, 2.0, (N, len(ts), 2))
+    salg = {"quadrature": sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10), "backsolve": sa.BacksolveAdjoint()}.get(alg) or sens(sa, alg, 1e-10)
+    f = _lv_with_loss(sa, "bodies")
+    loss = sa.ModelLoss(data)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 10.0), p), u0), sa.Rosenbrock23(), saveat=ts, sensealg=salg, dgdu_discrete=loss, save_start=False, save_end=False, abstol=1e-9, reltol=1e-9)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=loss)
+    sol.engine.close()
+    ref = O.Problem("LV", alg=oalg, stepper="ROS23", t0=0.0, t1=10.0, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="TEST", dloss_id=4, checkpointing=(alg == "backsolve"),
+                    quad_abstol=1e-10, quad_reltol=1e-10)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, data)
+    bar = 1e-4 if alg == "backsolve" else 1e-5      # T = 10 on Lotka-Volterra: thousands of reverse steps (and BacksolveAdjoint's own growth)
+    assert rel(du0, rdu0) < bar and rel(dp, rdp) < bar

@@ -138,12 +138,10 @@ def test_step_capacity_overflow_is_an_error_and_what_the_planner_refuses():
     cfg = E.make_config("lv", "interpolating", 1, 0.0, 10.0, 0.0, [10.0], loss_kind=1, stepper=ROS, abstol=1e-10, reltol=1e-10, max_steps=50)
     with pytest.raises(RuntimeError, match="rc=-7"):
         E.forward_adjoint(cfg, 2, 4, u0, p)
-    # continuous costs are not built for this stepper
-    for bad in (dict(alg="interpolating", cont_cost=1), dict(alg="quadrature", cont_cost=2), dict(alg="backsolve", checkpointing=True, cont_cost=1)):
-        kw = dict(bad); alg = kw.pop("alg")
-        cfg = E.make_config("lv", alg, 1, 0.0, 10.0, 0.0, [10.0], stepper=ROS, **kw)
-        with pytest.raises(RuntimeError, match="rc=-6"):
-            E.forward_adjoint(cfg, 2, 4, u0, p, np.zeros((1, 1, 2)))
+    # a semi-explicit DAE takes no continuous cost (its loss jump is built for the plain loss routes)
+    cfg = E.make_config("emu_roberdae", "interpolating", 1, 0.0, 1.0, 0.0, [1.0], stepper=ROS, cont_cost=1)
+    with pytest.raises(RuntimeError, match="rc=-6"):
+        E.forward_adjoint(cfg, 3, 3, [[1.0, 0.0, 0.0]], [0.04, 3e7, 1e4], np.zeros((1, 1, 3)))
     # BacksolveAdjoint on a semi-explicit DAE: refused by both (the reference documents it to fail there, test/Core3/adjoint.jl:1516-1530)
     cfg = E.make_config("emu_roberdae", "backsolve", 1, 0.0, 1.0, 0.0, [1.0], stepper=ROS, checkpointing=True)
     with pytest.raises(RuntimeError, match="rc=-6"):
@@ -362,3 +360,24 @@ def test_lane_bodies_backsolve(model, omodel, u0c, p, ckpt):
     ia = O.Problem(omodel, alg="INTERPOLATING", stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="COTANGENT")
     idu0, idp, _, _ = ia.adjoint_ensemble(u0, pp, delta)
     assert rel(du0, idu0) < 1e-3 and rel(dp, idp) < 1e-3
+
+
+# ---- continuous costs on the stiff stepper (accumulate_cost!, src/derivative_wrappers.jl:1411-1442; the costs of test/Core3/adjoint.jl:913-919 and test/Core7/mixed_costs.jl:46-57) ------
+@pytest.mark.parametrize("cost", [1, 2])
+@pytest.mark.parametrize("alg,oalg,ck", [("interpolating", "INTERPOLATING", False), ("interpolating", "INTERPOLATING", True), ("backsolve", "BACKSOLVE", True), ("gauss", "GAUSS", False),
+                                         ("gausskronrod", "GAUSS_KRONROD", True), ("quadrature", "QUADRATURE", False)])
+def test_lane_bodies_continuous_costs(alg, oalg, ck, cost):
+    """g = (sum u)^2 / 2 and g = u1^2 + p1 (with its dgdp_continuous) added to the discrete loss: the reverse right-hand side becomes affine (W unchanged, the cost's time
+    dependence enters through dT), Gauss / GaussKronrod / Quadrature add g_p to their integrands.  Lanes against the oracle on Lotka-Volterra."""
+    if alg == "gauss" and cost == 2:
+        pytest.skip("GaussAdjoint with dgdp_continuous: the sign convention case of DESIGN 6.5 — covered on Tsit5 with its own test")
+    rng = np.random.default_rng(17)
+    N, T = 2, 1.5
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0])
+    ts = np.array([0.0, 0.4, 1.0, 1.5])
+    cfg = E.make_config("lv", alg, N, 0.0, T, 0.0, ts, loss_kind=1, loss_shift=2.0, stepper=ROS, abstol=1e-8, reltol=1e-8, quad_abstol=1e-9, quad_reltol=1e-9, cont_cost=cost, checkpointing=ck, max_steps=100000)
+    du0, dp, out = E.forward_adjoint(cfg, 2, 4, u0, p)
+    ref = O.Problem("LV", alg=oalg, stepper="ROS23", t0=0, t1=T, dt=0.0, abstol=1e-8, reltol=1e-8, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, quad_abstol=1e-9, quad_reltol=1e-9,
+                    cont_cost=cost, checkpointing=ck)
+    rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, None)
+    assert rel(du0, rdu0) < 2e-6 and rel(dp, rdp) < 2e-6
