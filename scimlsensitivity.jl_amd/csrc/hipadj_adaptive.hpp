@@ -834,7 +834,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
                         for (int j = 0; j < N; ++j) rec[((long)s * RW + 2 + m * N + j) * g.Npad + i] = c[m][j];
                 }
-            } else overflow = true;
+            } else if (rec) overflow = true;      // (BacksolveAdjoint keeps no dense record: only the step bound g.maxit of the integrator limits it — with max_steps = 0 the reference's maxiters)
             ++s;
             while (ts_next <= t || time_hits(ts_next, t)) {
                 double y[N]; poly_eval<N>((ts_next - tprev) / h, c, y);

@@ -804,7 +804,7 @@ extern "C" int hipadj_synchronize(hipadj_handle* h) {
     HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
         HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
-        if (flag & 4) HIPADJ_FAIL(h, HIPADJ_ERR_MAXITERS, "adaptive Tsit5 exceeded max_steps = %d accepted steps on at least one trajectory (raise max_steps or loosen tolerances)", h->ag.Smax);
+        if (flag & 4) HIPADJ_FAIL(h, HIPADJ_ERR_MAXITERS, "the adaptive %s solve exceeded its step capacity (record capacity %d, step bound %d) on at least one trajectory, or a semi-explicit DAE found no consistent initial state (raise max_steps or loosen tolerances)", h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE ? "Rosenbrock23" : "Tsit5", h->ag.Smax, h->ag.maxit);
         HIPADJ_FAIL(h, HIPADJ_ERR_NONFINITE, "non-finite sensitivities (flag %d): a trajectory diverged", flag);
     }
     return HIPADJ_OK;
