@@ -75,7 +75,7 @@ typedef enum {
                                           model's VJP), forward solve AND reverse solve (the adjoint runs with the forward solve's alg, src/sensitivity_interface.jl:487-491;
                                           the adjoint system's W is block triangular: an n x n solve plus a substitution).  Interpolating-, Gauss-, GaussKronrod- and
                                           QuadratureAdjoint, arbitrary loss times, checkpointing = true (intervals re-solved with this stepper), and BacksolveAdjoint (its W formed from the first-derivative
-                                          blocks: the stepper is a W-method; not on a DAE); no continuous cost; a non-singular mass
+                                          blocks: the stepper is a W-method; not on a DAE); continuous costs and discrete-loss bodies like Tsit5 (not on a DAE); a non-singular mass
                                           matrix enters through the M^{-1} form of the runtime models like everywhere in the lane family, a singular semi-explicit one makes the
                                           model a DAE that ONLY this stepper integrates (hipadj_model_set_mass_matrix).  ABI 109 */
 } hipadj_stepper;
