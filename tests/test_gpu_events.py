@@ -156,3 +156,25 @@ def test_concrete_solve_adjoint_with_a_callback(sa):
     du0, dp = pullback(delta)
     rout, rdu0, rdp = oracle_chain("sin", [2.0], ts, T, u0, pp, delta, "GAUSS", dict(stepper="RK4", dt=0.01), True)
     assert rel(out, rout) < 1e-9 and rel(du0, rdu0) < 1e-8 and rel(dp, rdp) < 1e-8
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("name,events", [("dose", [2.0, 4.0, 8.0]), ("sin", [5.0]), ("pchange", [3.0, 6.5])])
+def test_discrete_callback_with_the_stiff_stepper(sa, alg, oalg, name, events):
+    """The same chains with Rosenbrock23 (round 6): every piece's forward and reverse solve on the stiff stepper, the pieces joined by the affect and its reverse callback."""
+    rng = np.random.default_rng(62)
+    N, T = 40, 10.0
+    shared = name not in ("sin",)
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2))
+    pp = np.array([1.5, 1.0, 3.0, 1.0]) if shared else np.array([1.5, 1.0, 3.0, 1.0]) + 0.05 * rng.standard_normal((N, 4))
+    ts = np.arange(0.0, T + 1e-9, 0.5)
+    delta = rng.standard_normal((N, len(ts), 2))
+    f = fun(sa, name)
+    salg, kw, okw = sa.Rosenbrock23(), dict(abstol=1e-9, reltol=1e-9), dict(stepper="ROS23", dt=0.0, abstol=1e-9, reltol=1e-9)
+    sens = sa.QuadratureAdjoint(abstol=1e-10, reltol=1e-10) if alg == "quadrature" else sensealg_of(sa, alg)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, T), pp if shared else pp[0]), u0, pp), salg, saveat=ts, sensealg=sens, callback=sa.PresetTimeCallback(events), **kw)
+    du0, dp = sa.adjoint_sensitivities(sol, salg, dgdu_discrete=delta)
+    rout, rdu0, rdp = oracle_chain(name, events, ts, T, u0, pp, delta, oalg, okw, shared)
+    bar = 1e-4 if alg == "backsolve" else 1e-5      # two implementations of one adaptive controller over ~3000 reverse steps per piece (and BacksolveAdjoint's growth)
+    assert rel(sol.u, rout) < 1e-7 and rel(du0, rdu0) < bar and rel(dp, rdp) < bar
+    sol.close()
