@@ -460,6 +460,12 @@ def test_dae_with_a_parameter_dependent_constraint_on_the_device(sa, gold, alg, 
         pr = O.Problem("ROBERDAE", alg=oalg, stepper="ROS23", t0=0.0, t1=100.0, dt=0.0, abstol=1e-10, reltol=1e-8, save_times=ts, loss="COTANGENT", quad_abstol=1e-14, quad_reltol=1e-8, dims=(5, 0, 0, 0))
         rdu0, rdp, _, _ = pr.adjoint_ensemble(u0, pp, d)
     assert np.max(np.abs(dp - rdp) / np.abs(rdp)) < bar and np.max(np.abs(du0 - rdu0)) < 10 * bar * np.max(np.abs(rdu0))
+    # shared parameters: dp is the sum over the ensemble (the jumps' parameter term included), here N copies of trajectory 0
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 100.0), pp[0]), u0), sa.Rosenbrock23(), saveat=ts,
+                   sensealg=(sa.QuadratureAdjoint(abstol=1e-14, reltol=1e-8) if quad else sens(sa, alg, 1e-8)), abstol=1e-10, reltol=1e-8)
+    _, dps = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=d)
+    sol.engine.close()
+    assert relc(dps, N * dp[0]) < 1e-12
 
 
 @pytest.mark.parametrize("alg,oalg", ALGS)
