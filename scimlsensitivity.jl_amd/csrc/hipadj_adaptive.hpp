@@ -724,18 +724,15 @@ HIPADJ_HD int ros23_integrate(double (&u)[NZ], double tstart, double tend, doubl
 // ---- semi-explicit DAEs (model_dae<Mo>) -------------------------------------------------------------------------------------------------------------------------------
 // the algebraic block of J' (TR) or of J, identity on the differential rows and columns — one factorisation serves every solve on the algebraic variables
 template <class Mo, bool TR> HIPADJ_HD void dae_alg_block(SmallLU<Mo::N>& B, const double (&y)[Mo::N], const double (&pv)[Mo::NP], double t) {
+    double J[Mo::N][Mo::N];
+    model_jacobian<Mo>(J, y, pv, t);
 #pragma unroll
-    for (int r = 0; r < Mo::N; ++r) {
-        double e[Mo::N], row[Mo::N];
-#pragma unroll
-        for (int j = 0; j < Mo::N; ++j) e[j] = j == r ? 1.0 : 0.0;
-        Mo::vjp_u(row, e, y, pv, t);                       // row r of J
+    for (int r = 0; r < Mo::N; ++r)
 #pragma unroll
         for (int c = 0; c < Mo::N; ++c) {
             const bool aa = Mo::isalg(r) && Mo::isalg(c);
-            if (TR) B.a[c][r] = aa ? row[c] : (r == c ? 1.0 : 0.0); else B.a[r][c] = aa ? row[c] : (r == c ? 1.0 : 0.0);
+            if (TR) B.a[c][r] = aa ? J[r][c] : (r == c ? 1.0 : 0.0); else B.a[r][c] = aa ? J[r][c] : (r == c ? 1.0 : 0.0);
         }
-    }
     B.factor();
 }
 // BrownFullBasicInit [upstream-recall]: the differential variables keep their values, the algebraic ones are solved from 0 = f_alg(u) by Newton (the oracle's dae_consistent_init)
@@ -775,15 +772,12 @@ template <class Mo> struct RosLinFwd {
     }
     HIPADJ_HD explicit RosLinFwd(const double (&p_)[Mo::NP]) : pv(p_) {}
     HIPADJ_HD void factor(double gh, const double (&u)[Mo::N], double t) {
+        double J[Mo::N][Mo::N];
+        model_jacobian<Mo>(J, u, pv, t);
 #pragma unroll
-        for (int r = 0; r < Mo::N; ++r) {
-            double e[Mo::N], row[Mo::N];
+        for (int r = 0; r < Mo::N; ++r)
 #pragma unroll
-            for (int j = 0; j < Mo::N; ++j) e[j] = j == r ? 1.0 : 0.0;
-            Mo::vjp_u(row, e, u, pv, t);
-#pragma unroll
-            for (int c = 0; c < Mo::N; ++c) { double mrc = (r == c ? 1.0 : 0.0); if constexpr (MASS) mrc = Mo::mass(r, c); lu.a[r][c] = mrc - gh * row[c]; }
-        }
+            for (int c = 0; c < Mo::N; ++c) { double mrc = (r == c ? 1.0 : 0.0); if constexpr (MASS) mrc = Mo::mass(r, c); lu.a[r][c] = mrc - gh * J[r][c]; }
         lu.factor();
     }
     HIPADJ_HD void solve(double (&b)[Mo::N]) const { lu.solve(b); }
@@ -1269,17 +1263,15 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
                     for (int j = 0; j < N; ++j) y[j] = zc[N + NP + j];      // the backsolved state
                 } else cu.eval(t, y);
+                double J[N][N];
+                model_jacobian<Mo>(J, y, pv, t);                 // row c of J = column c of J'
 #pragma unroll
                 for (int c = 0; c < N; ++c) {
-                    double e[N], row[N];
 #pragma unroll
-                    for (int j = 0; j < N; ++j) e[j] = j == c ? 1.0 : 0.0;
-                    Mo::vjp_u(row, e, y, pv, t);                 // row c of J: column c of J'
-#pragma unroll
-                    for (int r = 0; r < N; ++r) { double mrc = (r == c ? 1.0 : 0.0); if constexpr (MASS) mrc = Mo::mass(c, r); lu.a[r][c] = mrc + gh * row[r]; }
+                    for (int r = 0; r < N; ++r) { double mrc = (r == c ? 1.0 : 0.0); if constexpr (MASS) mrc = Mo::mass(c, r); lu.a[r][c] = mrc + gh * J[c][r]; }
                     if constexpr (ALG == 1) {
 #pragma unroll
-                        for (int r = 0; r < N; ++r) luy.a[c][r] = (r == c ? 1.0 : 0.0) - gh * row[r];      // I - gh J, row c
+                        for (int r = 0; r < N; ++r) luy.a[c][r] = (r == c ? 1.0 : 0.0) - gh * J[c][r];      // I - gh J, row c
                     }
                 }
                 lu.factor();

@@ -89,6 +89,25 @@ template <class Mo, class = void> struct model_has_cols { static constexpr bool 
 template <class Mo> struct model_has_cols<Mo, decltype((void)Mo::HAS_COLS)> { static constexpr bool value = Mo::HAS_COLS; };
 // Semi-explicit DAE (round 6): a model with `static constexpr bool DAE = true` carries its constant SINGULAR mass matrix — mass(i, j), row-major, and isalg(i) = row i of M
 // is zero (src/adjoint_common.jl:116-122) — and is integrated in mass-matrix form by the Rosenbrock23 lanes (hipadj_adaptive.hpp); every other stepper refuses it at plan time.
+// The Jacobian df/du for the W = M - d h J of Rosenbrock23 (hipadj_adaptive.hpp).  A model with dual-number VJPs hands it over from ONE dual evaluation of f (`HAS_JAC`, jac);
+// every other model gets it row by row from its VJP, (df/du)' e_r = row r — with hand-written bodies the unit vector folds into them.  (Measured, ring n = 6, 8192 trajectories:
+// n unit-vector calls of a dual-number vjp_u are n dual Jacobians — reverse 32 ms against 12 ms for hand-written bodies; profiles/r6_ros23_auto_vs_hand.jsonl.)
+template <class Mo, class = void> struct model_has_jac { static constexpr bool value = false; };
+template <class Mo> struct model_has_jac<Mo, decltype((void)Mo::HAS_JAC)> { static constexpr bool value = Mo::HAS_JAC; };
+template <class Mo> HIPADJ_HD void model_jacobian(double (&J)[Mo::N][Mo::N], const double (&u)[Mo::N], const double (&p)[Mo::NP], double t) {
+    if constexpr (model_has_jac<Mo>::value) Mo::jac(J, u, p, t);
+    else {
+#pragma unroll
+        for (int r = 0; r < Mo::N; ++r) {
+            double e[Mo::N], row[Mo::N];
+#pragma unroll
+            for (int j = 0; j < Mo::N; ++j) e[j] = j == r ? 1.0 : 0.0;
+            Mo::vjp_u(row, e, u, p, t);
+#pragma unroll
+            for (int c = 0; c < Mo::N; ++c) J[r][c] = row[c];
+        }
+    }
+}
 template <class Mo, class = void> struct model_dae { static constexpr bool value = false; };
 template <class Mo> struct model_dae<Mo, decltype((void)Mo::DAE)> { static constexpr bool value = Mo::DAE; };
 // Bundle width for n states and NC columns: at most ELEMS doubles per bundle vector (seven such vectors are live in an RK4 step), the columns spread

@@ -336,7 +336,15 @@ inline std::string user_model_struct(const UserModelSrc& m) {
           << "        f_t<Dual<NP>>(dd, uu, pp, Dual<NP>(t));\n"
           << "        for (int j = 0; j < NP; ++j) { LT s = LT(0.0); for (int i = 0; i < N; ++i) s += lam[i] * dd[i].d[j]; out[j] = s; }\n    }\n"
           << "    HIPADJ_HD static void vjp_u(double (&out)[N], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_u_t<double>(out, lam, u, p, t); }\n"
-          << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_p_t<double>(out, lam, u, p, t); }\n";
+          << "    HIPADJ_HD static void vjp_p(double (&out)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) { vjp_p_t<double>(out, lam, u, p, t); }\n"
+          // df/du from ONE dual evaluation (Rosenbrock23's W; hipadj_models.hpp model_jacobian): n unit-vector vjp_u calls would be n of them
+          << "    static constexpr bool HAS_JAC = true;\n"
+          << "    HIPADJ_HD static void jac(double (&J)[N][N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        Dual<N> uu[N], pp[NP], dd[N];\n"
+          << "        for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n"
+          << "        for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
+          << "        f_t<Dual<N>>(dd, uu, pp, Dual<N>(t));\n"
+          << "        for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) J[i][j] = dd[i].d[j];\n    }\n";
     } else {
         // the VJP bodies are templates on the type LT of `lam` / `out`: double = one adjoint column, Cols<G> = a bundle of G columns that shares
         // everything depending on (u, p, t) only (hipadj_models.hpp).  A body that is not linear in lam does not compile for Cols: HAS_COLS = false then.
