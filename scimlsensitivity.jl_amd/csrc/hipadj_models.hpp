@@ -91,7 +91,7 @@ template <class Mo> struct model_has_cols<Mo, decltype((void)Mo::HAS_COLS)> { st
 // is zero (src/adjoint_common.jl:116-122) — and is integrated in mass-matrix form by the Rosenbrock23 lanes (hipadj_adaptive.hpp); every other stepper refuses it at plan time.
 // The Jacobian df/du for the W = M - d h J of Rosenbrock23 (hipadj_adaptive.hpp).  A model with dual-number VJPs hands it over from ONE dual evaluation of f (`HAS_JAC`, jac);
 // every other model gets it row by row from its VJP, (df/du)' e_r = row r — with hand-written bodies the unit vector folds into them.  (Measured, ring n = 6, 8192 trajectories:
-// n unit-vector calls of a dual-number vjp_u are n dual Jacobians — reverse 32 ms against 12 ms for hand-written bodies; profiles/r6_ros23_auto_vs_hand.jsonl.)
+// n unit-vector calls of a dual-number vjp_u are n dual Jacobians — forward 4.5 ms, reverse 32 ms; with jac 2.1 / 15.9 ms; hand-written bodies 2.8 / 12.2 ms: profiles/r6_ros23_auto_vs_hand.jsonl.)
 template <class Mo, class = void> struct model_has_jac { static constexpr bool value = false; };
 template <class Mo> struct model_has_jac<Mo, decltype((void)Mo::HAS_JAC)> { static constexpr bool value = Mo::HAS_JAC; };
 template <class Mo> HIPADJ_HD void model_jacobian(double (&J)[Mo::N][Mo::N], const double (&u)[Mo::N], const double (&p)[Mo::NP], double t) {
