@@ -615,6 +615,12 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     if (cfg->loss_kind == HIPADJ_LOSS_MODEL && !user_has_dloss(cfg->model)) { h->err = "loss_kind = HIPADJ_LOSS_MODEL but the model has no discrete-loss bodies (hipadj_model_set_discrete_loss / hipadj_wmodel_set_discrete_loss)"; return fail(HIPADJ_ERR_INVALID_ARG); }
     if (P.wide) { const int urc = wide_prepare(h); if (urc != HIPADJ_OK) return fail(urc); }
     else if (P.user) { const int urc = user_prepare(h); if (urc != HIPADJ_OK) return fail(urc); h->has_mm = user_mass_matrix_inverse(cfg->model, h->minv); h->dae = user_model_is_dae(cfg->model); }
+    // Everything above — the zero fills of the workspaces (d_cotT, tickets, flags) and the uploads of the plan tables — was issued on the NULL stream, which does not order with
+    // the handle's non-blocking stream: a hipMemset of device memory may still be pending when the first call on the handle's stream writes the same buffer.  Seen (round 6): with
+    // other processes loading the GPU, the data block of a device-resident loss (hipadj_set_loss_data right after hipadj_create: transposed into d_cotT on the handle's stream) was
+    // wiped by the create-time hipMemset(d_cotT) that landed later — gradients of an all-zero data block, 323 times in 12 000 handles under load, never on a quiet device
+    // (scripts/r6/loop_lsq_diag.py, profiles/r6_lsq_zero_data_race.jsonl).  Drain the device once here.
+    if (hipDeviceSynchronize() != hipSuccess) { h->err = "hipDeviceSynchronize failed at the end of hipadj_create"; return fail(HIPADJ_ERR_HIP); }
     *out = h;
     return HIPADJ_OK;
 }
@@ -803,7 +809,7 @@ extern "C" int hipadj_synchronize(hipadj_handle* h) {
     int flag = 0;
     HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
-        HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
+        HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
         if (flag & 4) HIPADJ_FAIL(h, HIPADJ_ERR_MAXITERS, "the adaptive %s solve exceeded its step capacity (record capacity %d, step bound %d) on at least one trajectory, or a semi-explicit DAE found no consistent initial state (raise max_steps or loosen tolerances)", h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE ? "Rosenbrock23" : "Tsit5", h->ag.Smax, h->ag.maxit);
         HIPADJ_FAIL(h, HIPADJ_ERR_NONFINITE, "non-finite sensitivities (flag %d): a trajectory diverged", flag);
     }
@@ -1189,11 +1195,11 @@ int adaptive_autosize(hipadj_handle* h) {
     h->rec_cap = cap;
     h->st.workspace_bytes = h->ws_bytes;
     h->ag.Smax = (int)cap; h->ag.SmaxI = (int)cap;
-    if (h->ip_ckpt) { HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int))); return 0; }   // (the pass marked "more steps than the old capacity": not an error here)
+    if (h->ip_ckpt) { HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream)); return 0; }   // (the pass marked "more steps than the old capacity": not an error here)
                                 // checkpointing=true: the forward pass writes no records (only the checkpoint states), so nothing has to be
                                 // repeated; the buffer just regrown is the ONE-interval record buffer of the reverse sweep, sized by the
                                 // whole-trajectory step count — a safe bound for any single interval
-    HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));                  // the overflow mark of the pass that is being repeated
+    HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));                  // the overflow mark of the pass that is being repeated
     return 1;
 }
 
@@ -1218,7 +1224,7 @@ int adaptive_adjoint_autosize(hipadj_handle* h) {
       h->d_arec = nb; }
     h->SmaxA = (int)capA; h->ag.SmaxA = h->SmaxA;
     h->st.workspace_bytes = h->ws_bytes;
-    HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));
+    HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
     return 1;
 }
 
@@ -1272,7 +1278,7 @@ static int wide_autosize(hipadj_handle* h) {
     }
     h->rec_cap = cap; h->wa.Smax = (int)cap; h->ag.Smax = (int)cap;
     h->st.workspace_bytes = h->ws_bytes;
-    HIP_TRY(h, hipMemset(h->d_flag, 0, sizeof(int)));                  // the overflow mark of the pass that is being repeated
+    HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));                  // the overflow mark of the pass that is being repeated
     return 1;
 }
 
