@@ -1452,7 +1452,8 @@ static int user_ground_truth(hipadj_handle* h, const double* d_cot, const std::v
             const double sg = sgn == 0 ? eps : -eps;
             for (size_t k = 0; k < n0; ++k) up[k] = u0[k] + sg * d[k];
             for (size_t k = 0; k < n1; ++k) pp[k] = p[k] + sg * e[k];
-            if (hipMemcpy(d_u, up.data(), sizeof(double) * n0, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_pp, pp.data(), sizeof(double) * n1, hipMemcpyHostToDevice) != hipSuccess) { rc = HIPADJ_ERR_HIP; break; }
+            // (on the handle's stream: a null-stream copy does not order with the forward kernels that follow on a non-blocking stream; up / pp stay untouched until the synchronize below)
+            if (hipMemcpyAsync(d_u, up.data(), sizeof(double) * n0, hipMemcpyHostToDevice, h->stream) != hipSuccess || hipMemcpyAsync(d_pp, pp.data(), sizeof(double) * n1, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = HIPADJ_ERR_HIP; break; }
             rc = forward_dispatch(h, d_u, d_pp, d_o);
             if (rc == HIPADJ_OK && (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy((sgn == 0 ? outp : outm).data(), d_o, sizeof(double) * no, hipMemcpyDeviceToHost) != hipSuccess)) rc = HIPADJ_ERR_HIP;
         }
