@@ -620,7 +620,8 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
     // other processes loading the GPU, the data block of a device-resident loss (hipadj_set_loss_data right after hipadj_create: transposed into d_cotT on the handle's stream) was
     // wiped by the create-time hipMemset(d_cotT) that landed later — gradients of an all-zero data block, 323 times in 12 000 handles under load, never on a quiet device
     // (scripts/r6/loop_lsq_diag.py, profiles/r6_lsq_zero_data_race.jsonl).  Drain the device once here.
-    if (hipDeviceSynchronize() != hipSuccess) { h->err = "hipDeviceSynchronize failed at the end of hipadj_create"; return fail(HIPADJ_ERR_HIP); }
+    static const bool no_drain = [] { const char* e = std::getenv("HIPADJ_CREATE_NO_DRAIN"); return e && e[0] == '1'; }();      // REPRODUCTION HOOK of the race above (tests / scripts only)
+    if (!no_drain && hipDeviceSynchronize() != hipSuccess) { h->err = "hipDeviceSynchronize failed at the end of hipadj_create"; return fail(HIPADJ_ERR_HIP); }
     *out = h;
     return HIPADJ_OK;
 }

@@ -418,3 +418,40 @@ def test_pipelined_host_transfers_from_concurrent_host_threads(sa):
     for k in range(4):
         for a, b in zip(serial[k], threaded[k]):
             assert np.array_equal(a, b)
+
+
+def test_handles_created_on_a_loaded_device_see_their_data_block(sa):
+    """hipadj_create's zero fills run on the null stream; before round 6's fix the fill of d_cotT could land AFTER hipadj_set_loss_data had transposed the data block into
+    it on the handle's (non-blocking) stream — on a loaded device one handle in five computed the gradient of an all-zero data block (scripts/r6/create_race_inprocess.py with
+    HIPADJ_CREATE_NO_DRAIN=1: 300 of 1500).  Three host threads keep the device busy while 500 small LSQ_DATA handles are created, used and closed: every gradient bit-identical."""
+    import threading
+    stop = threading.Event()
+
+    def load(seed):
+        u0, p = lorenz_inputs(10000, seed=seed)
+        eng = sa.Engine("lorenz", "interpolating", 10000, 0.0, 10.0, 0.01, save_times=np.arange(0, 10.0 + 1e-9, 0.1), loss_kind=1, loss_shift=2.0)
+        eng.forward(u0, p, want_out=False)
+        while not stop.is_set():
+            eng.adjoint(None)
+        eng.close()
+    th = [threading.Thread(target=load, args=(40 + k,)) for k in range(3)]
+    [t.start() for t in th]
+    rng = np.random.default_rng(9)
+    N, T, dt = 66, 2.0, 0.01
+    u0 = np.array([1.0, 1.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.5, 1.0, 3.0, 1.0]); ts = np.array([0.503, 1.0, 1.777, 2.0])
+    data = rng.standard_normal((N, len(ts), 2))
+    ref, wrong = None, 0
+    try:
+        for _ in range(500):
+            sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lv", u0[0], (0, T), p), u0), sa.RK4(), dt=dt, saveat=ts, sensealg=sa.GaussAdjoint(), dgdu_discrete=sa.LsqData(data, 2.0))
+            du0, dp = sa.adjoint_sensitivities(sol, sa.RK4(), t=ts, dgdu_discrete=sa.LsqData(data, 2.0))
+            sol.engine.close()
+            if ref is None:
+                ref = (du0.copy(), dp.copy())
+            else:
+                wrong += not (np.array_equal(du0, ref[0]) and np.array_equal(dp, ref[1]))
+    finally:
+        stop.set(); [t.join() for t in th]
+    assert wrong == 0
+    rdu0, rdp, _, _ = O.Problem("LV", alg="GAUSS", stepper="RK4", t0=0, t1=T, dt=dt, save_times=ts, loss="LSQ_DATA", loss_scale=2.0).adjoint_ensemble(u0, p, data)
+    assert rel(ref[0], rdu0) < RTOL and rel(ref[1], rdp) < RTOL
