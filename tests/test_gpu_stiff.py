@@ -517,3 +517,17 @@ def test_model_discrete_loss_bodies_with_the_stiff_stepper(sa, alg, oalg):
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, data)
     bar = 1e-4 if alg == "backsolve" else 1e-5      # T = 10 on Lotka-Volterra: thousands of reverse steps (and BacksolveAdjoint's own growth)
     assert rel(du0, rdu0) < bar and rel(dp, rdp) < bar
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "backsolve", "gauss", "gausskronrod", "quadrature"])
+def test_falling_mass_literal_with_rosenbrock23(sa, alg):
+    """test/Core7/physical_ode_regression.jl:42-51 runs its falling mass with Rosenbrock23 too (:45) at the default tolerances: d/dp sum(position at 0:0.05:2) == [-27.675, 0.0],
+    atol 1e-2 — the one literal the reference holds for this stepper, on the device."""
+    ts = np.round(np.arange(0.0, 2.0 + 1e-9, 0.05), 10)
+    u0 = np.array([[1.0, 0.0]]); p = np.array([9.81, 1.0])
+    delta = np.zeros((1, len(ts), 2)); delta[:, :, 0] = 1.0
+    salg = {"interpolating": sa.InterpolatingAdjoint(), "backsolve": sa.BacksolveAdjoint(), "gauss": sa.GaussAdjoint(), "gausskronrod": sa.GaussKronrodAdjoint(), "quadrature": sa.QuadratureAdjoint()}[alg]
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("fallmass", u0[0], (0.0, 2.0), p), u0), sa.Rosenbrock23(), saveat=ts, sensealg=salg)      # abstol 1e-6, reltol 1e-3: the defaults
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=delta)
+    sol.engine.close()
+    assert np.allclose(dp, [-27.675, 0.0], atol=1e-2)
