@@ -174,7 +174,7 @@ def test_reference_loop_over_the_implicit_solvers_linear_problem(sa, alg):
     salg = {"interpolating": sa.InterpolatingAdjoint(), "backsolve": sa.BacksolveAdjoint(), "backsolve_nockpt": sa.BacksolveAdjoint(checkpointing=False), "gauss": sa.GaussAdjoint(),
             "gausskronrod": sa.GaussKronrodAdjoint(), "quadrature": sa.QuadratureAdjoint()}[alg]
     loss = sa.LsqData(np.zeros((1, len(ts), 2)), 2.0)
-    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lindiag", u0[0], (0.0, 1.0), p), u0), sa.Rosenbrock23(), saveat=ts, sensealg=salg, dgdu_discrete=loss, abstol=1e-5, reltol=1e-5)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem("lindiag", u0[0], (0.0, 1.0), p), u0), sa.Rosenbrock23(), saveat=ts, sensealg=salg, dgdu_discrete=loss, abstol=1e-5, reltol=1e-5, dt=0.01)      # dt = 0.01: the test's initial step (:203)
     du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=loss)
     sol.engine.close()
     gdp = np.array([np.sum(2.0 * ts * u0[0, i] ** 2 * np.exp(2.0 * p[i] * ts)) for i in range(2)])

@@ -381,3 +381,17 @@ def test_lane_bodies_continuous_costs(alg, oalg, ck, cost):
                     cont_cost=cost, checkpointing=ck)
     rdu0, rdp, _, _ = ref.adjoint_ensemble(u0, p, None)
     assert rel(du0, rdu0) < 2e-6 and rel(dp, rdp) < 2e-6
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "gauss", "quadrature", "backsolve"])
+def test_lane_bodies_initial_dt_hint(alg):
+    """`dt` with an adaptive stepper is the first step's length (test/Core2/stiff_adjoints.jl:203 passes dt = 0.01 to every implicit solver), for the forward AND the reverse solve."""
+    u0 = np.array([[1.0, 1.0]]); p = np.array([1.5, 1.0, 3.0, 1.0]); ts = [0.0, 0.4, 1.0]
+    ck = alg == "backsolve"
+    cfg = E.make_config("lv", alg, 1, 0.0, 1.0, 0.05, ts, loss_kind=1, loss_shift=2.0, stepper=ROS, abstol=1e-9, reltol=1e-9, quad_abstol=1e-10, quad_reltol=1e-10, checkpointing=ck, max_steps=100000)
+    du0, dp, _ = E.forward_adjoint(cfg, 2, 4, u0, p)
+    ref = O.Problem("LV", alg=alg.upper(), stepper="ROS23", t0=0, t1=1.0, dt=0.05, abstol=1e-9, reltol=1e-9, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, quad_abstol=1e-10, quad_reltol=1e-10, checkpointing=ck)
+    rdu0, rdp, _ = ref.adjoint(u0[0], p)
+    assert rel(du0[0], rdu0) < 1e-10 and rel(dp, rdp) < 1e-10      # measured 6e-14: the same step sequence
+    nohint = O.Problem("LV", alg=alg.upper(), stepper="ROS23", t0=0, t1=1.0, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, loss="LSQ_SHIFT", loss_shift=2.0, quad_abstol=1e-10, quad_reltol=1e-10, checkpointing=ck)
+    assert rel(nohint.adjoint(u0[0], p)[1], rdp) > 1e-13          # (the hint is used: another step sequence)
