@@ -531,3 +531,13 @@ def test_falling_mass_literal_with_rosenbrock23(sa, alg):
     du0, dp = sa.adjoint_sensitivities(sol, sa.Rosenbrock23(), t=ts, dgdu_discrete=delta)
     sol.engine.close()
     assert np.allclose(dp, [-27.675, 0.0], atol=1e-2)
+
+
+def test_python_example_of_the_stiff_ensemble_and_the_dae(sa):
+    """examples/stiff_robertson.py: the ODE and the DAE formulation of the same chemistry give the same dG/dp (the example prints the difference)."""
+    import subprocess, sys
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "stiff_robertson.py"), "64"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert float(last.split(":")[-1]) < 1e-5, r.stdout
