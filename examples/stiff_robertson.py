@@ -8,11 +8,13 @@
 
     python examples/stiff_robertson.py [ntraj = 1024]          (needs an MI355X; without one the first solve fails loudly: there is no CPU fallback)
 """
+import os
 import sys
 
 import numpy as np
 
-import scimlsensitivity_jl_amd as sa
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # the repository root (scimlsensitivity_jl_amd.py forwards to the package directory)
+import scimlsensitivity_jl_amd as sa  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rng = np.random.default_rng(0)
