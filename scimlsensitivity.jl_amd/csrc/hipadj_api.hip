@@ -1827,7 +1827,8 @@ static unsigned xfer_threads() {
 static int xfer_chunks(size_t count) {      // chunks of ~3 MB, at most 16 (the handle's events)
     static const bool off = [] { const char* e = std::getenv("HIPADJ_HOST_PIPELINE"); return e && e[0] == '0'; }();      // A/B hook
     if (off || count * sizeof(double) < HIPADJ_XFER_MIN_BYTES) return 1;
-    const size_t c = (count * sizeof(double) + ((size_t)3 << 20) - 1) / ((size_t)3 << 20);
+    static const size_t chunk = [] { const char* e = std::getenv("HIPADJ_HOST_CHUNK_MB"); const int v = e ? std::atoi(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 3) << 20; }();      // A/B hook: no size between 1 and 12 MB stands out of the run-to-run spread (profiles/r6_host_api_chunk_ab.jsonl)
+    const size_t c = (count * sizeof(double) + chunk - 1) / chunk;
     return (int)(c > 16 ? 16 : c);
 }
 // host -> pinned block -> device
