@@ -69,6 +69,7 @@ static int model_init(orc_model *m, int id, const int dims[4]) {
     case ORC_MODEL_DENSELIN: { int r = m->dims[0]; if (r < 1) return -1; m->n = r; m->np = r * r; break; }
     case ORC_MODEL_PENDULUM: m->n = 2; m->np = 3; break;
     case ORC_MODEL_LIN1P: m->n = 1; m->np = 2; break;
+    case ORC_MODEL_RELAX: m->n = 1; m->np = 2; break;
     case ORC_MODEL_ROBERDAE: m->n = 3; m->np = 3; break;
     default: return -1;
     }
@@ -132,6 +133,9 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
         break;
     case ORC_MODEL_LIN1P:    /* test/Core7/adjoint_param.jl:56-59 */
         du[0] = -u[0] * p[0] - p[1];
+        break;
+    case ORC_MODEL_RELAX:    /* test/Callbacks2/continuous_callbacks.jl:320 */
+        du[0] = p[0] - u[0];
         break;
     case ORC_MODEL_AFFINE3: /* `foo` of the mass-matrix test, test/Core3/adjoint.jl:1315-1321: du = A u + p; du[2] += sum(p), A = [1 2 3; 4 5 6; 7 8 9] */
         du[0] = 1.0 * u[0] + 2.0 * u[1] + 3.0 * u[2] + p[0];
@@ -265,6 +269,10 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
     case ORC_MODEL_LIN1P:
         if (dlam) dlam[0] = -p[0] * lam[0];
         if (dgrad) { dgrad[0] = -u[0] * lam[0]; dgrad[1] = -lam[0]; }
+        break;
+    case ORC_MODEL_RELAX:
+        if (dlam) dlam[0] = -lam[0];
+        if (dgrad) { dgrad[0] = lam[0]; dgrad[1] = 0.0; }
         break;
     case ORC_MODEL_AFFINE3:
         if (dlam) {
@@ -521,6 +529,8 @@ typedef struct {
     double *t0, *t1;       /* step start / end times */
     double *u0, *u1;       /* [nsteps][n] */
     double *k;             /* [nsteps][nk][n]; RK4: k[0]=f(u0,t0), k[1]=f(u1,t1) (FSAL pair) ; Tsit5: 7 stages */
+    double *hfull;         /* length of the step the stages belong to: t1 - t0, except on a step a ContinuousCallback cut short (t1 = the event time; section 3b) */
+    long *ev_s; int nev, ev_cap;   /* events of the solve, ascending in time: ev_s[k] = index of the first record AFTER event k (it starts at the event time, from the affected state) */
 } orc_dense;
 
 /* Dense solutions are recycled per thread: an ensemble run would otherwise grow and free ~100 KB of arrays per trajectory on
@@ -534,7 +544,7 @@ static void dense_init(orc_dense *d, int n, int kind) {
     int nk = (kind == ORC_STEPPER_TSIT5) ? 7 : 2;      /* (Rosenbrock23: k1, k2) */
     for (int i = 0; i < ORC_DENSE_POOL; ++i)
         if (tls_pool_used[i] == 1 && tls_pool[i].n == n && tls_pool[i].nk == nk) {
-            *d = tls_pool[i]; tls_pool_used[i] = 0; d->kind = kind; d->nsteps = 0; return;
+            *d = tls_pool[i]; tls_pool_used[i] = 0; d->kind = kind; d->nsteps = 0; d->nev = 0; return;
         }
     memset(d, 0, sizeof(*d)); d->n = n; d->kind = kind; d->nk = nk;
 }
@@ -542,7 +552,7 @@ static void dense_free(orc_dense *d) {
     if (d->cap > 0)
         for (int i = 0; i < ORC_DENSE_POOL; ++i)
             if (tls_pool_used[i] == 0) { tls_pool[i] = *d; tls_pool_used[i] = 1; memset(d, 0, sizeof(*d)); return; }
-    free(d->t0); free(d->t1); free(d->u0); free(d->u1); free(d->k); memset(d, 0, sizeof(*d));
+    free(d->t0); free(d->t1); free(d->u0); free(d->u1); free(d->k); free(d->hfull); free(d->ev_s); memset(d, 0, sizeof(*d));
 }
 static void dense_push(orc_dense *d, double t0, double t1, const double *u0, const double *u1, const double *k) {
     if (d->nsteps == d->cap) {
@@ -550,9 +560,10 @@ static void dense_push(orc_dense *d, double t0, double t1, const double *u0, con
         d->t0 = (double *)realloc(d->t0, sizeof(double) * d->cap); d->t1 = (double *)realloc(d->t1, sizeof(double) * d->cap);
         d->u0 = (double *)realloc(d->u0, sizeof(double) * d->cap * d->n); d->u1 = (double *)realloc(d->u1, sizeof(double) * d->cap * d->n);
         d->k = (double *)realloc(d->k, sizeof(double) * d->cap * d->nk * d->n);
+        d->hfull = (double *)realloc(d->hfull, sizeof(double) * d->cap);
     }
     long s = d->nsteps++;
-    d->t0[s] = t0; d->t1[s] = t1;
+    d->t0[s] = t0; d->t1[s] = t1; d->hfull[s] = t1 - t0;
     memcpy(d->u0 + s * d->n, u0, sizeof(double) * d->n); memcpy(d->u1 + s * d->n, u1, sizeof(double) * d->n);
     memcpy(d->k + s * d->nk * d->n, k, sizeof(double) * d->nk * d->n);
 }
@@ -562,7 +573,7 @@ static void dense_push(orc_dense *d, double t0, double t1, const double *u0, con
  *   u(th) = (1-th) u0 + th u1 + th (th-1) [ (1-2th)(u1-u0) + (th-1) h k1 + th h k2 ]   [upstream-recall, SURVEY §8c]
  * Tsit5 => its own 4th-order interpolant u0 + h sum b_i(th) k_i. */
 static void dense_eval_step(const orc_dense *d, long s, double t, double *y) {
-    int n = d->n; double h = d->t1[s] - d->t0[s]; double th = (h == 0.0) ? 0.0 : (t - d->t0[s]) / h;
+    int n = d->n; double h = d->hfull[s]; double th = (h == 0.0) ? 0.0 : (t - d->t0[s]) / h;
     const double *u0 = d->u0 + s * n, *u1 = d->u1 + s * n, *k = d->k + s * d->nk * n;
     if (d->kind == ORC_STEPPER_TSIT5) {
         double b[7]; tsit5_bweights(th, b);
@@ -995,6 +1006,7 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
 /* =====================================================================================
  * 3. Forward solve (src/concrete_solve.jl:689-770)
  * ===================================================================================== */
+static int time_hits(double t, double target);
 typedef struct { const orc_model *m; const double *p; } fwd_ctx;
 static void fwd_rhs(double *du, const double *u, double t, void *c) { fwd_ctx *f = (fwd_ctx *)c; model_f(f->m, du, u, f->p, t); mm_solve(g_mm_inv, f->m->n, du); }
 
@@ -1054,6 +1066,103 @@ static int dae_consistent_init(const orc_model *m, double *u, const double *p, d
     return st;
 }
 
+/* =====================================================================================
+ * 3b. ContinuousCallback (src/callback_tracking.jl:1-223 forward tracking, :232-479 reverse callbacks; test/Callbacks2/continuous_callbacks.jl)
+ *     save_positions = (false, false); both crossing directions run the same affect (affect_neg! = affect!, the constructor's default); no terminate!.
+ *     Forward [upstream-recall: OrdinaryDiffEq's callback handling, restated in its structure, not in its root finder]: after every accepted step the sign of the condition
+ *     at interp_points = 10 equally spaced points of the step's dense output is compared with its sign at the step's start (right after an event: at 1/100 of the step,
+ *     repeat_nudge); the first bracket is halved 52 times on the dense output; the event time is the bracket's upper end; the step is cut there (the record keeps the
+ *     stages and the length of the full step), u <- affect(u), the derivative is recomputed, the controller's proposal for the next step stands.
+ *     Reverse: the adjoint solve runs piece by piece between the events (each piece a fresh solve: the controller restarts — the reference's PresetTimeCallback keeps it
+ *     running; a tolerance-level difference) and applies at every event, with - / + the limits from below / above, f the right-hand side,
+ *         kappa = lam+ . (a_u f- + a_t - f+) / (c_u . f- + c_t)        lam- = a_u' lam+ - kappa c_u        dp += a_p' lam+ - kappa c_p
+ *     — :375-437 with dgdt :784-819 and implicit_correction! :828-844 for save_positions = (false, false) (Lu_right = 0, no saved left value).  Two terms the reference's
+ *     lines do not carry as read: a_t (its affects do not use t) and kappa c_p — its "Re-compile tape" testset has a condition that depends on p1 and asks 1e-10 of the
+ *     gradient, which needs the term (-kappa c_p = 2.7e-4 there); the restatement follows the mathematics (tests/golden/make_continuous_callbacks.py has the closed forms).
+ * ===================================================================================== */
+static double ev_cond(int kind, const double *u, const double *p, double t) {
+    switch (kind) {
+    case 3: return u[0] - 0.75 * p[0];
+    case 4: return u[0] - 0.3 * t;
+    default: return u[0];
+    }
+}
+static void ev_cond_grad(int kind, int n, int np, const double *u, const double *p, double t, double *gu, double *gp, double *gt) {
+    (void)u; (void)p; (void)t;
+    for (int i = 0; i < n; ++i) gu[i] = 0.0;
+    for (int i = 0; i < np; ++i) gp[i] = 0.0;
+    gu[0] = 1.0; *gt = 0.0;
+    if (kind == 3) gp[0] = -0.75;
+    if (kind == 4) *gt = -0.3;
+}
+static void ev_affect(int kind, int n, double *un, const double *u, const double *p, double t) {
+    for (int i = 0; i < n; ++i) un[i] = u[i];
+    switch (kind) {
+    case 1: un[1] = -p[1] * u[1]; break;
+    case 2: un[0] = u[0] + 3.0; un[1] = u[1] * u[1]; break;
+    case 3: un[0] = u[0] + p[1]; break;
+    case 4: un[1] = -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t; break;
+    default: break;
+    }
+}
+/* out = a_u v + a_t */
+static void ev_affect_jvp(int kind, int n, double *out, const double *u, const double *v, const double *p, double t) {
+    (void)t;
+    for (int i = 0; i < n; ++i) out[i] = v[i];
+    switch (kind) {
+    case 1: out[1] = -p[1] * v[1]; break;
+    case 2: out[1] = 2.0 * u[1] * v[1]; break;
+    case 4: out[1] = -p[1] * v[1] + 0.1; break;
+    default: break;
+    }
+}
+/* lo = a_u' lam, go = a_p' lam */
+static void ev_affect_vjp(int kind, int n, int np, double *lo, double *go, const double *lam, const double *u, const double *p, double t) {
+    (void)t;
+    for (int i = 0; i < n; ++i) lo[i] = lam[i];
+    for (int i = 0; i < np; ++i) go[i] = 0.0;
+    switch (kind) {
+    case 1: lo[1] = -p[1] * lam[1]; go[1] = -u[1] * lam[1]; break;
+    case 2: lo[1] = 2.0 * u[1] * lam[1]; break;
+    case 3: go[1] = lam[0]; break;
+    case 4: lo[1] = -p[1] * lam[1]; go[1] = -(u[1] - 0.3) * lam[1]; break;
+    default: break;
+    }
+}
+typedef struct { const orc_model *m; const double *p; int kind; orc_dense *sol; double cprev, tend; int nudge; } fwd_event_ctx;
+static int fwd_event_cb(orc_integ *I, void *c) {
+    fwd_event_ctx *E = (fwd_event_ctx *)c;
+    const int n = I->n; const double h = I->t - I->tprev;
+    double y[ORC_MM_MAXN];
+    if (h == 0.0) return 0;
+    if (E->nudge) { integ_interp(I, I->tprev + 0.01 * h, y); E->cprev = ev_cond(E->kind, y, E->p, I->tprev + 0.01 * h); E->nudge = 0; }
+    double tha = 0.0, ca = E->cprev, thb = 0.0, cb = 0.0; int found = 0;
+    for (int j = 1; j <= 10 && !found; ++j) {
+        thb = j < 10 ? 0.1 * j : 1.0;
+        if (j < 10) integ_interp(I, I->tprev + thb * h, y); else memcpy(y, I->u, sizeof(double) * n);
+        cb = ev_cond(E->kind, y, E->p, I->tprev + thb * h);
+        if (ca * cb < 0.0 || (cb == 0.0 && ca != 0.0)) found = 1;
+        else { tha = thb; ca = cb; }
+    }
+    if (!found) { E->cprev = cb; return 0; }
+    for (int it = 0; it < 52; ++it) {
+        const double thm = 0.5 * (tha + thb);
+        integ_interp(I, I->tprev + thm * h, y);
+        const double cm = ev_cond(E->kind, y, E->p, I->tprev + thm * h);
+        if (ca * cm < 0.0 || (cm == 0.0 && ca != 0.0)) { thb = thm; cb = cm; } else { tha = thm; ca = cm; }
+    }
+    const double tev = I->tprev + thb * h;
+    if (!(tev < E->tend) || time_hits(tev, E->tend)) { E->cprev = ev_cond(E->kind, I->u, E->p, I->t); return 0; }   /* an event at the end of the span changes nothing that is observed */
+    integ_interp(I, tev, y);
+    orc_dense *d = E->sol; const long s = d->nsteps - 1;          /* the record of this step: pushed just before the callbacks run */
+    d->t1[s] = tev; memcpy(d->u1 + (size_t)s * n, y, sizeof(double) * n);
+    if (d->nev == d->ev_cap) { d->ev_cap = d->ev_cap ? 2 * d->ev_cap : 16; d->ev_s = (long *)realloc(d->ev_s, sizeof(long) * d->ev_cap); }
+    d->ev_s[d->nev++] = s + 1;
+    ev_affect(E->kind, n, I->u, y, E->p, tev);
+    I->t = tev; E->nudge = 1;
+    return 1;
+}
+
 static orc_alg make_alg(const orc_config *cfg) {
     orc_alg a; a.kind = cfg->stepper; a.dt = cfg->dt; a.abstol = cfg->abstol > 0 ? cfg->abstol : 1e-6; a.reltol = cfg->reltol > 0 ? cfg->reltol : 1e-3;
     a.split_G = 0; a.split_coef = 0.0; a.jac = NULL; a.autonomous = 0; a.mass = NULL;
@@ -1083,7 +1192,13 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
         a.split_G = G; a.split_coef = p[2] / (dx * dx);
     }
-    int st = integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, NULL, NULL, 0, sol, nrhs);
+    fwd_event_ctx ev = {m, p, cfg->event_kind, sol, 0.0, tb, 0};
+    if (cfg->event_kind) {
+        if (cfg->event_kind < 1 || cfg->event_kind > 4 || (cfg->stepper != ORC_STEPPER_TSIT5 && cfg->stepper != ORC_STEPPER_ROS23) || g_mm_n == m->n || g_mm_dae || m->n > ORC_MM_MAXN) return -6;
+        if ((cfg->event_kind == 3) != (m->id == ORC_MODEL_RELAX) || (cfg->event_kind != 3 && (m->n != 2 || m->np < 2))) return -6;
+        ev.cprev = ev_cond(cfg->event_kind, u, p, ta); ev.nudge = (ev.cprev == 0.0);
+    }
+    int st = integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, cfg->event_kind ? fwd_event_cb : NULL, &ev, 0, sol, nrhs);
     if (st == 0 && sol->nsteps == 0) {
         /* a span shorter than the solver's time resolution (a checkpoint one ulp below T makes [c, T] such an interval): no step was taken and the solution is its
          * initial value — recorded as ONE step of the span's length with zero slopes, so that dense_eval finds a record (it used to index step -1) */
@@ -1118,6 +1233,9 @@ typedef struct {
     int alg;
     /* semi-explicit DAE: the algebraic parts of the loss jumps, push!(f.dlam_as, (dlam_a, t)) src/adjoint_common.jl:803 — [ndla][n] (zero on the differential entries) and their times */
     double *dla, *dla_t; int ndla;
+    /* ContinuousCallback (section 3b): the reverse solve stands between two events and reads the forward records of that piece only — at an event time the record below
+     * holds the state before the affect, the record above the state after it */
+    int use_win; long win_lo, win_hi;
 } adj_ctx;
 
 /* stored forward value at checkpoint time c (non-dense `sol(c)` at a saved point) */
@@ -1149,6 +1267,12 @@ static int resolve_interval(adj_ctx *A, int cursor, double dt_hint) {
 /* y <- forward state at t: dense interpolant, or checkpointed re-solve
  * (split_states, src/interpolating_adjoint.jl:190-277; src/gauss_adjoint.jl:158-217; src/quadrature_adjoint.jl:63-72) */
 static void fetch_y(adj_ctx *A, double t) {
+    if (A->use_win) {
+        long lo = A->win_lo, hi = A->win_hi;
+        while (lo < hi) { long mid = (lo + hi) / 2; if (t >= A->sol->t1[mid]) lo = mid + 1; else hi = mid; }
+        dense_eval_step(A->sol, lo, t, A->y);
+        return;
+    }
     if (!A->checkpointing) { dense_eval(A->sol, t, A->y, &A->hint); return; }
     double a = A->int_a[A->cursor], b = A->int_b[A->cursor];
     if (!(a <= t && t <= b)) {
@@ -1525,6 +1649,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
     if (cfg->stepper == ORC_STEPPER_ROS23 && cfg->alg == ORC_ALG_BACKSOLVE && g_mm_dae) return -6;   /* Backsolve on the stiff stepper: ODE models (see backsolve_jac; the cost's second-derivative blocks are dropped from W like the model's) */
+    if (cfg->event_kind && (cfg->alg == ORC_ALG_BACKSOLVE || cfg->alg == ORC_ALG_QUADRATURE || cfg->checkpointing || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* section 3b */
     if (g_mm_dae && (cfg->stepper != ORC_STEPPER_ROS23 || g_dae_n != n || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* semi-explicit DAE: Rosenbrock23, discrete losses by cotangent / shift / data */   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
@@ -1596,7 +1721,35 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     orc_dense adjrec; int have_rec = 0;
     if (cfg->alg == ORC_ALG_QUADRATURE) { dense_init(&adjrec, n, cfg->stepper); have_rec = 1; }
     int cb_at_init = (M > 0 && time_hits(cfg->t1, cfg->save_times[M - 1])) && g_recall[ORC_RECALL_PRESET_AT_INIT] != 0.0;
-    st = integrate(rhs, &A, nz, z, cfg->t1, cfg->t0, &alg, tst, nts, adjoint_step_cb, &A, cb_at_init, have_rec ? &adjrec : NULL, nrhs);
+    if (!cfg->event_kind || sol.nev == 0)
+        st = integrate(rhs, &A, nz, z, cfg->t1, cfg->t0, &alg, tst, nts, adjoint_step_cb, &A, cb_at_init, have_rec ? &adjrec : NULL, nrhs);
+    else {
+        /* section 3b: piece e = nev .. 0 lies between event e - 1 (or t0) and event e (or T); the stops of a piece are the loss times inside it */
+        double *pts = (double *)malloc(sizeof(double) * (size_t)(nts + 1));
+        double *w = (double *)calloc((size_t)6 * n + 2 * (size_t)np, sizeof(double)), *ym = w, *yp = w + n, *fm = w + 2 * n, *fp = w + 3 * n, *gu = w + 4 * n, *jf = w + 5 * n, *gp = w + 6 * n, *go = gp + np;
+        A.use_win = 1;
+        for (int e = sol.nev; e >= 0 && st == 0; --e) {
+            const double t_hi = (e == sol.nev) ? cfg->t1 : sol.t0[sol.ev_s[e]], t_lo = (e == 0) ? cfg->t0 : sol.t0[sol.ev_s[e - 1]];
+            A.win_lo = (e == 0) ? 0 : sol.ev_s[e - 1]; A.win_hi = (e == sol.nev) ? sol.nsteps - 1 : sol.ev_s[e] - 1;
+            int npts = 0;
+            for (int i = 0; i < nts; ++i) if (tst[i] >= t_lo && tst[i] <= t_hi) pts[npts++] = tst[i];      /* (a loss time that coincides with an event belongs to the piece above it: it sees the affected state) */
+            st = integrate(rhs, &A, nz, z, t_hi, t_lo, &alg, pts, npts, adjoint_step_cb, &A, e == sol.nev ? cb_at_init : 0, NULL, nrhs);
+            if (e == 0 || st) break;
+            const double tev = t_lo; const long sm = sol.ev_s[e - 1] - 1, sp = sol.ev_s[e - 1];
+            double gt = 0.0, num = 0.0, den = 0.0;
+            dense_eval_step(&sol, sm, tev, ym); dense_eval_step(&sol, sp, tev, yp);
+            model_f(m, fm, ym, p, tev); model_f(m, fp, yp, p, tev);
+            ev_cond_grad(cfg->event_kind, n, np, ym, p, tev, gu, gp, &gt);
+            ev_affect_jvp(cfg->event_kind, n, jf, ym, fm, p, tev);
+            for (int i = 0; i < n; ++i) { num += z[i] * (jf[i] - fp[i]); den += gu[i] * fm[i]; }
+            const double kappa = num / (den + gt);
+            ev_affect_vjp(cfg->event_kind, n, np, A.scratch, go, z, ym, p, tev);       /* scratch[0..n) = a_u' lam+ */
+            for (int i = 0; i < n; ++i) z[i] = A.scratch[i] - kappa * gu[i];
+            double *acc = (cfg->alg == ORC_ALG_INTERPOLATING) ? z + n : A.gauss_acc;
+            for (int i = 0; i < np; ++i) acc[i] += go[i] - kappa * gp[i];
+        }
+        free(pts); free(w);
+    }
 
     /* unpack (src/sensitivity_interface.jl:500-508) */
     memcpy(du0, z, sizeof(double) * n);

@@ -50,6 +50,7 @@ enum {
     ORC_MODEL_DENSELIN = 12, /* u' = A u with A = reshape(p, n, n): np = n^2 (NOT from the reference); dims = {n} */
     ORC_MODEL_PENDULUM = 13, /* `pendulum_eom` of test/Core7/adjoint_param.jl:6-10: dx1 = p1 x2; dx2 = -sin x1 + (-p1 sin x1 + p2 x2); np = 3 (p3 unused, as in the test) */
     ORC_MODEL_LIN1P = 14,    /* `f` of test/Core7/adjoint_param.jl:56-59: du = -u p1 - p2; n = 1, np = 2 */
+    ORC_MODEL_RELAX = 16,    /* du = p1 - u, n = 1, np = 2 (p2 enters through the event only): `f` of the "Re-compile tape" testset, test/Callbacks2/continuous_callbacks.jl:314-327 */
     ORC_MODEL_ROBERDAE = 15  /* `rober` as test/Core3/adjoint.jl:1434-1441 writes it (third row: y1 + y2 + y3 - 1): with orc_set_mass_matrix(diag(1, 1, 0)) the semi-explicit DAE of :1450-1700;
                                 dims[0] = kappa adds -kappa (p1 - 0.04) to the constraint (NOT from the reference: a parameter-dependent constraint, so that the jumps' parameter term is not zero) */
 };
@@ -95,6 +96,12 @@ typedef struct {
                              4: l_i = (i + 1) p_1 u_1 u_n + sin(t_i) u_1 + p_2^2 d_1 u_n   (every argument of the callback in use; np >= 2) */
     int reference_literal;/* 1: the reference's lines where the restatement deliberately deviates: GaussAdjoint / GaussKronrodAdjoint take g_p of a
                              continuous cost with the sign src/gauss_adjoint.jl:753-758 has as written, and drop dgdp_discrete (src/adjoint_common.jl:776 `!isq`) */
+    int event_kind;       /* ContinuousCallback(condition, affect!; save_positions = (false, false)) on the adaptive steppers (src/callback_tracking.jl:232-479, test/Callbacks2/
+                             continuous_callbacks.jl), InterpolatingAdjoint / GaussAdjoint / GaussKronrodAdjoint without checkpointing — adjoint_oracle.c section 3b.  0: none;
+                             1: c = u1, u2 <- -p2 u2 (the bouncing ball, :212-217: "= callback with parameter dependence"; ORC_MODEL_FALLMASS);
+                             2: c = u1, u1 += 3, u2 <- u2^2 (:243-250, the non-linear affect);
+                             3: c = u1 - 3/4 p1, u1 += p2 (:324-327: a condition that depends on a parameter; ORC_MODEL_RELAX);
+                             4: c = u1 - 0.3 t, u2 <- -p2 (u2 - 0.3) + 0.3 + 0.1 t (NOT from the reference: condition and affect depend on t explicitly, so that c_t and a_t are not zero) */
 } orc_config;
 
 int orc_model_sizes(int model, const int dims[4], int *n, int *np);

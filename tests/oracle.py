@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB_PATH = os.path.join(_ORACLE_DIR, "liboracle_adjoint.so")
 
-MODEL = dict(LV=0, LVT=1, LORENZ=2, LINDIAG=3, FALLMASS=4, MLP=5, BRUSS=6, ROBER=7, RING=8, AFFINE3=9, IDXAFF=10, MLP1=11, DENSELIN=12, PENDULUM=13, LIN1P=14, ROBERDAE=15)
+MODEL = dict(LV=0, LVT=1, LORENZ=2, LINDIAG=3, FALLMASS=4, MLP=5, BRUSS=6, ROBER=7, RING=8, AFFINE3=9, IDXAFF=10, MLP1=11, DENSELIN=12, PENDULUM=13, LIN1P=14, ROBERDAE=15, RELAX=16)
 ALG = dict(INTERPOLATING=0, BACKSOLVE=1, GAUSS=2, QUADRATURE=3, GAUSS_KRONROD=4)
 STEPPER = dict(RK4=0, TSIT5=1, ETDRK4=2, ROS23=3)
 LOSS = dict(COTANGENT=0, LSQ_SHIFT=1, LSQ_DATA=2, TEST=3)
@@ -29,7 +29,7 @@ class OrcConfig(C.Structure):
         ("checkpointing", C.c_int), ("nckpt", C.c_int), ("checkpoints", C.POINTER(C.c_double)),
         ("quad_abstol", C.c_double), ("quad_reltol", C.c_double),
         ("no_start", C.c_int), ("cont_cost", C.c_int),
-        ("loss_scale", C.c_double), ("dloss_id", C.c_int), ("reference_literal", C.c_int),
+        ("loss_scale", C.c_double), ("dloss_id", C.c_int), ("reference_literal", C.c_int), ("event_kind", C.c_int),
     ]
 
 
@@ -106,7 +106,7 @@ class Problem:
     def __init__(self, model, alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=1.0, dt=0.01, abstol=1e-6,
                  reltol=1e-3, save_times=(), loss="COTANGENT", loss_shift=0.0, checkpointing=False,
                  checkpoints=None, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, dims=(0, 0, 0, 0), cont_cost=0, loss_scale=0.0, dloss_id=0,
-                 reference_literal=False):
+                 reference_literal=False, event_kind=0):
         self.model = model
         self.dims = tuple(dims)
         self.n, self.np = model_sizes(model, dims)
@@ -127,6 +127,7 @@ class Problem:
         c.no_start = int(no_start)
         c.cont_cost = int(cont_cost)
         c.loss_scale, c.dloss_id, c.reference_literal = float(loss_scale), int(dloss_id), int(bool(reference_literal))
+        c.event_kind = int(event_kind)      # ContinuousCallback of adjoint_oracle.h (1 .. 4)
         self.cfg = c
 
     @property
