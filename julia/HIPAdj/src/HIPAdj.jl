@@ -1,7 +1,7 @@
 """
     HIPAdj
 
-Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 109) — the MI355X-native batched continuous-adjoint
+Thin Julia binding of `libhipadj.so` (C ABI: `include/hipadj.h`, version 110) — the MI355X-native batched continuous-adjoint
 engine.  This package holds ONLY the `ccall` layer and the types a SciMLSensitivity extension dispatches on:
 
   * `HIPBatchedAdjoint(inner; model, device)` — an `AbstractAdjointSensitivityAlgorithm` that wraps one of the reference's
@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, dense_chain_model, declare_dense_chain!, set_mass_matrix!, set_affect!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, dense_chain_model, declare_dense_chain!, set_mass_matrix!, set_affect!, set_continuous_callback!, event_counts, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -39,7 +39,7 @@ function lib()
     if LIB[] == C_NULL
         LIB[] = Libdl.dlopen(libpath(), Libdl.RTLD_NOW | Libdl.RTLD_GLOBAL)
         v = ccall(Libdl.dlsym(LIB[], :hipadj_version), Cint, ())
-        v == 109 || error("libhipadj ABI version $v, this binding was written for 109")
+        v == 110 || error("libhipadj ABI version $v, this binding was written for 110")
     end
     return LIB[]
 end
@@ -351,11 +351,26 @@ as a copy of `u` — and / or `pn` (a copy of `p`) from `u`, `p`, `t` (locals `r
 of ordinary handles, one per span between consecutive event times: `affect_apply` maps the end state of a piece to the start state of the next,
 `affect_vjp` maps `du0` of the upper piece to the extra cotangent at the end of the lower one and returns the parameter term
 (src/callback_tracking.jl:330-452 for a DiscreteCallback).  The Python host mirror (`scimlsensitivity.jl_amd/events.py`) is the executed reference of
-that composition; ContinuousCallbacks stay with the reference's CPU path.
+that composition; a `ContinuousCallback` is a property of the model instead: `set_continuous_callback!`.
 """
 function set_affect!(m::DeviceModel, body)
     s = body === nothing ? nothing : String(body)
     GC.@preserve s check(ccall(sym(:hipadj_model_set_affect), Cint, (Int32, Ptr{UInt8}), m.id, s === nothing ? Ptr{UInt8}(C_NULL) : pointer(s)))
+    return m
+end
+"""
+    set_continuous_callback!(model, condition, affect = nothing; max_events = 0)        # condition === nothing removes it
+
+`ContinuousCallback(condition, affect!; save_positions = (false, false))` as device text (`hipadj_model_set_continuous_callback`; src/callback_tracking.jl:232-479,
+test/Callbacks2/continuous_callbacks.jl): `condition` assigns `c` from `u`, `p`, `t` — the event is its zero crossing, either direction —, `affect` edits `un` (a copy of `u`).
+The bouncing ball: `set_continuous_callback!(m, "c = u[0];", "un[1] = -p[1] * u[1];")`.  Every later handle on the model with `stepper = STEPPER_TSIT5_ADAPTIVE` or
+`STEPPER_ROSENBROCK23_ADAPTIVE` locates the events of each trajectory on the dense output; `ALG_INTERPOLATING`, `ALG_GAUSS` and `ALG_GAUSS_KRONROD` differentiate through them,
+event times included.  `event_counts(handle)` returns the events per trajectory of the last forward solve.
+"""
+function set_continuous_callback!(m::DeviceModel, condition, affect = nothing; max_events::Integer = 0)
+    c = condition === nothing ? nothing : String(condition); a = affect === nothing ? nothing : String(affect)
+    GC.@preserve c a check(ccall(sym(:hipadj_model_set_continuous_callback), Cint, (Int32, Ptr{UInt8}, Ptr{UInt8}, Int32), m.id,
+                                 c === nothing ? Ptr{UInt8}(C_NULL) : pointer(c), a === nothing ? Ptr{UInt8}(C_NULL) : pointer(a), Int32(max_events)))
     return m
 end
 function affect_apply(m::DeviceModel, u::Matrix{Float64}, p::Union{Vector{Float64}, Matrix{Float64}}, t::Real; device::Integer = 0)
@@ -495,6 +510,12 @@ function set_discrete_loss!(model::DeviceModel; dgdu = nothing, dgdp = nothing, 
 end
 
 "`out = forward!(h, u0, p)`: u0 `(n, N)`, p `(np,)` or `(np, N)`; returns `out` `(n, M, N)` = sol(ts) of every trajectory."
+"events per trajectory of the last forward solve of a handle whose model carries a ContinuousCallback (`hipadj_event_counts`)"
+function event_counts(h::Handle)
+    counts = Vector{Int32}(undef, h.N)
+    check(ccall(sym(:hipadj_event_counts), Cint, (Ptr{Cvoid}, Ptr{Int32}), h.ptr, counts), h.ptr)
+    return counts
+end
 function forward!(h::Handle, u0::Matrix{Float64}, p::VecOrMat{Float64}; want_out::Bool = true)
     size(u0) == (h.n, h.N) || throw(DimensionMismatch("u0 must be ($(h.n), $(h.N)), got $(size(u0))"))
     (h.p_shared ? size(p) == (h.np,) : size(p) == (h.np, h.N)) || throw(DimensionMismatch("p has size $(size(p))"))

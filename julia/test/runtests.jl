@@ -6,7 +6,7 @@ using Test, HIPAdj, SciMLSensitivity, OrdinaryDiffEq, Zygote, Random
 
 @testset "layout" begin
     @test HIPAdj.check_layout()
-    @test hipadj_version() == 109
+    @test hipadj_version() == 110
     @test occursin("libhiprtc", runtime_compiler())          # the build toolkit's hiprtc (a Julia process carries no other)
 end
 

@@ -1129,7 +1129,8 @@ static void ev_affect_vjp(int kind, int n, int np, double *lo, double *go, const
     default: break;
     }
 }
-typedef struct { const orc_model *m; const double *p; int kind; orc_dense *sol; double cprev, tend; int nudge; } fwd_event_ctx;
+#define ORC_MAX_EVENTS 4096
+typedef struct { const orc_model *m; const double *p; int kind; orc_dense *sol; double cprev, tend; int nudge, overflow; } fwd_event_ctx;
 static int fwd_event_cb(orc_integ *I, void *c) {
     fwd_event_ctx *E = (fwd_event_ctx *)c;
     const int n = I->n; const double h = I->t - I->tprev;
@@ -1155,6 +1156,7 @@ static int fwd_event_cb(orc_integ *I, void *c) {
     if (!(tev < E->tend) || time_hits(tev, E->tend)) { E->cprev = ev_cond(E->kind, I->u, E->p, I->t); return 0; }   /* an event at the end of the span changes nothing that is observed */
     integ_interp(I, tev, y);
     orc_dense *d = E->sol; const long s = d->nsteps - 1;          /* the record of this step: pushed just before the callbacks run */
+    if (d->nev >= ORC_MAX_EVENTS) { E->overflow = 1; I->t = E->tend; return 0; }      /* an accumulation point of events (a ball that comes to rest): the solve ends with status -7 */
     d->t1[s] = tev; memcpy(d->u1 + (size_t)s * n, y, sizeof(double) * n);
     if (d->nev == d->ev_cap) { d->ev_cap = d->ev_cap ? 2 * d->ev_cap : 16; d->ev_s = (long *)realloc(d->ev_s, sizeof(long) * d->ev_cap); }
     d->ev_s[d->nev++] = s + 1;
@@ -1192,13 +1194,14 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
         a.split_G = G; a.split_coef = p[2] / (dx * dx);
     }
-    fwd_event_ctx ev = {m, p, cfg->event_kind, sol, 0.0, tb, 0};
+    fwd_event_ctx ev = {m, p, cfg->event_kind, sol, 0.0, tb, 0, 0};
     if (cfg->event_kind) {
         if (cfg->event_kind < 1 || cfg->event_kind > 4 || (cfg->stepper != ORC_STEPPER_TSIT5 && cfg->stepper != ORC_STEPPER_ROS23) || g_mm_n == m->n || g_mm_dae || m->n > ORC_MM_MAXN) return -6;
         if ((cfg->event_kind == 3) != (m->id == ORC_MODEL_RELAX) || (cfg->event_kind != 3 && (m->n != 2 || m->np < 2))) return -6;
         ev.cprev = ev_cond(cfg->event_kind, u, p, ta); ev.nudge = (ev.cprev == 0.0);
     }
     int st = integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, cfg->event_kind ? fwd_event_cb : NULL, &ev, 0, sol, nrhs);
+    if (st == 0 && ev.overflow) st = -7;
     if (st == 0 && sol->nsteps == 0) {
         /* a span shorter than the solver's time resolution (a checkpoint one ulp below T makes [c, T] such an interval): no step was taken and the solution is its
          * initial value — recorded as ONE step of the span's length with zero slopes, so that dense_eval finds a record (it used to index step -1) */

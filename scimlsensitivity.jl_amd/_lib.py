@@ -24,6 +24,7 @@ DECLARED_SYMBOLS = (
     "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
     "hipadj_model_set_discrete_loss", "hipadj_model_set_discrete_loss_function", "hipadj_wmodel_set_discrete_loss", "hipadj_set_loss_data", "hipadj_set_loss_data_dev",
     "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride", "hipadj_device_count", "hipadj_wmodel_declare_dense_chain",
+    "hipadj_model_set_continuous_callback", "hipadj_event_counts",
 )
 
 
@@ -114,6 +115,8 @@ def load():
     L.hipadj_wmodel_set_cost.argtypes = [C.c_int32, C.c_char_p]
     L.hipadj_model_set_mass_matrix.argtypes = [C.c_int32, C.POINTER(C.c_double)]
     L.hipadj_model_set_affect.argtypes = [C.c_int32, C.c_char_p]
+    L.hipadj_model_set_continuous_callback.argtypes = [C.c_int32, C.c_char_p, C.c_char_p, C.c_int32]
+    L.hipadj_event_counts.argtypes = [C.c_void_p, C.c_void_p]
     L.hipadj_wmodel_set_affect.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_affect_apply.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.hipadj_affect_vjp.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double),
@@ -214,6 +217,14 @@ def set_model_affect(model_id, body):
     """hipadj_model_set_affect: the DiscreteCallback affect of a runtime-registered model (None removes it)."""
     L = load()
     rc = L.hipadj_model_set_affect(int(model_id), None if body is None else body.encode())
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+
+
+def set_model_continuous_callback(model_id, condition, affect, max_events=0):
+    """hipadj_model_set_continuous_callback: ContinuousCallback(condition, affect!) of a runtime lane model (None, None removes it)."""
+    L = load()
+    rc = L.hipadj_model_set_continuous_callback(int(model_id), None if condition is None else condition.encode(), None if affect is None else affect.encode(), int(max_events))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
 

@@ -45,6 +45,9 @@ struct AdaptGeom {
     int loss_kind, no_start, p_shared, cont_cost;   // loss_kind: hipadj_loss (0 cotangent, 1 lsq_shift, 2 lsq_data, 3 the model's discrete-loss bodies)
     double la, lb; int lflags;                      // as Geom: dgdu = la u + lb c for the kinds that stream a column; bit 0 of lflags drops dgdp_discrete
     int SmaxA;                 // QuadratureAdjoint: capacity (steps) of the dense ADJOINT record; its readers clamp the stored TRUE step count with it
+    // ContinuousCallback (model_has_cond): per trajectory, the index of the first forward record AFTER each event (that record starts at the event time, from the affected
+    // state), ascending in time — ev_s [maxev][Npad] — and the TRUE number of events — nev [Npad]; maxev = 0: no event handling
+    int maxev = 0; int* ev_s = nullptr; int* nev = nullptr;
 };
 
 // Tsit5 coefficients (Tsitouras 2011); same values as oracle/adjoint_oracle.c (order conditions checked there).
@@ -816,10 +819,56 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     const double TINF = 1.7976931348623157e308;
     double ts_next = (outT && ms < g.M) ? save_t[ms] : TINF, tc_next = (ckpt && mc < g.nck) ? ck_t[mc] : TINF;
     auto frhs = [&](double (&du)[N], const double (&uu)[N], double t) { Mo::f(du, uu, pv, t); };
-    auto fcb = [&](double t, double tprev, double (&un)[N], const auto& KK) -> bool {
-            const double h = t - tprev;
+    // ContinuousCallback (model_has_cond; the oracle's section 3b, src/callback_tracking.jl:1-223): the sign of the condition at ten points of the accepted step's dense output
+    // against its sign at the step's start (right after an event: at 1/100 of the step); the first bracket halved 52 times; the step is cut at the bracket's upper end — the
+    // record rescaled to [tprev, t_event] —, u <- affect(u), t <- t_event, and the integrator recomputes the derivative; its proposal for the next step stands
+    double cprev = 0.0; bool nudge = false; int nevl = 0;
+    if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) { cprev = Mo::cond(u, pv, g.t0); nudge = (cprev == 0.0); } }
+    auto fcb = [&](double& t, double tprev, double (&un)[N], const auto& KK) -> bool {
+            double h = t - tprev;
             double c[5][N];
+            bool event = false;
             if constexpr (STEP == 1) ros23_poly<N>(KK, h, c); else tsit5_poly<N>(KK, h, c);
+            if constexpr (model_has_cond<Mo>::value) {
+                if (g.maxev > 0 && h != 0.0) {
+                    double y[N];
+                    if (nudge) { poly_eval<N>(0.01, c, y); cprev = Mo::cond(y, pv, tprev + 0.01 * h); nudge = false; }
+                    double tha = 0.0, ca = cprev, thb = 0.0, cbv = 0.0; bool found = false;
+#pragma unroll 1
+                    for (int j = 1; j <= 10 && !found; ++j) {
+                        thb = j < 10 ? 0.1 * j : 1.0;
+                        if (j < 10) poly_eval<N>(thb, c, y);
+                        else {
+#pragma unroll
+                            for (int q = 0; q < N; ++q) y[q] = un[q]; }
+                        cbv = Mo::cond(y, pv, tprev + thb * h);
+                        if (ca * cbv < 0.0 || (cbv == 0.0 && ca != 0.0)) found = true; else { tha = thb; ca = cbv; }
+                    }
+                    if (!found) cprev = cbv;
+                    else {
+#pragma unroll 1
+                        for (int it = 0; it < 52; ++it) {
+                            const double thm = 0.5 * (tha + thb);
+                            poly_eval<N>(thm, c, y);
+                            const double cm = Mo::cond(y, pv, tprev + thm * h);
+                            if (ca * cm < 0.0 || (cm == 0.0 && ca != 0.0)) { thb = thm; cbv = cm; } else { tha = thm; ca = cm; }
+                        }
+                        const double tev = tprev + thb * h;
+                        if (!(tev < g.t1) || time_hits(tev, g.t1)) cprev = Mo::cond(un, pv, t);      // (an event at the end of the span changes nothing that is observed)
+                        else {
+                            poly_eval<N>(thb, c, y);
+                            double r = thb;
+#pragma unroll
+                            for (int m = 1; m < 5; ++m) {
+#pragma unroll
+                                for (int q = 0; q < N; ++q) c[m][q] *= r;
+                                r *= thb; }
+                            Mo::cc_affect(un, y, pv, tev);
+                            t = tev; h = tev - tprev; nudge = true; event = true;
+                        }
+                    }
+                }
+            }
             if (s < g.Smax) {
                 if (rec) {
                     rec[((long)s * RW + 0) * g.Npad + i] = tprev; rec[((long)s * RW + 1) * g.Npad + i] = t;
@@ -830,6 +879,13 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 }
             } else if (rec) overflow = true;      // (BacksolveAdjoint keeps no dense record: only the step bound g.maxit of the integrator limits it — with max_steps = 0 the reference's maxiters)
             ++s;
+            if constexpr (model_has_cond<Mo>::value) {
+                if (event) {
+                    if (nevl < g.maxev) g.ev_s[(long)nevl * g.Npad + i] = s;
+                    else { overflow = true; t = g.t1; }      // more events than the list holds (an accumulation point of events, or max_events too small): reported, and the solve ends here
+                    ++nevl;
+                }
+            }
             while (ts_next <= t || time_hits(ts_next, t)) {
                 double y[N]; poly_eval<N>((ts_next - tprev) / h, c, y);
 #pragma unroll
@@ -841,7 +897,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = y[j];
                 ++mc; tc_next = mc < g.nck ? ck_t[mc] : TINF; }
             (void)un;
-            return false;
+            return event;
         };
     int na;
     if constexpr (STEP == 1) {
@@ -849,6 +905,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         na = ros23_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.maxit, K, frhs, lin, !Mo::TIME_DEP, fcb);
     } else na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.maxit, K, frhs, fcb);
     nsteps[i] = s;   // the TRUE count, also beyond the capacity: the host sizes the buffers from it (flag bit 4 marks the overflow)
+    if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) g.nev[i] = nevl; }
     if (yT) {
 #pragma unroll
         for (int j = 0; j < N; ++j) yT[(long)j * g.Npad + i] = u[j]; }
@@ -871,7 +928,11 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 template <class Mo, bool PF = (HIPADJ_TS5_PREFETCH != 0)> struct FwdCursor {
     static constexpr int N = Mo::N, RW = 2 + 5 * Mo::N;
     const double* rec; long Npad, i; int ns, sc, lc;
+    int smin = 0;            // lowest record the walk may reach (events: the first record of the piece the reverse solve stands in; a stage time that rounds one ulp below the
+                             // event time must not read the state from before the affect)
     double ta, tb, c[5][Mo::N];
+    // the reverse solve crosses an event downward: onto record s (the step the event cut short, which ends at the event time), with the piece below as the new range
+    HIPADJ_HD void below(int s, int smin_) { sc = s; smin = smin_; ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i]; }
     // PF (off by default, see the macro): the reverse sweeps walk downward and the 64 lanes of a wave change records at different step attempts, so most
     // attempts of the wave wait for SOME lane's 5 n coefficient loads (SQ_WAIT_ANY is a third of the wave cycles, profiles/r3_tsit5_counters.txt).  With PF
     // the cursor also issues the loads of record s - 1 into a second register set when it arrives on record s.  It did not pay: the extra registers and
@@ -892,7 +953,7 @@ template <class Mo, bool PF = (HIPADJ_TS5_PREFETCH != 0)> struct FwdCursor {
     // (Measured: fetching the record below one step ahead into a second register set changes the sweep by -2 % .. +7 %:
     // the sweep is bound by the instruction count of a step, not by this round trip.)
     HIPADJ_HD void eval(double t, double (&y)[Mo::N]) {
-        while (t < ta && sc > 0) { --sc; tb = ta; ta = rec[((long)sc * RW + 0) * Npad + i]; }
+        while (t < ta && sc > smin) { --sc; tb = ta; ta = rec[((long)sc * RW + 0) * Npad + i]; }
         while (t > tb && sc < ns - 1) { ++sc; ta = tb; tb = rec[((long)sc * RW + 1) * Npad + i]; }
         if (sc != lc) {
             lc = sc;
@@ -1235,6 +1296,8 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             }
         }
     };
+    // one reverse solve from ta down to tb (the whole span, or — ContinuousCallback — the piece between two events)
+    auto run_piece = [&](double ta_, double tb_, bool at_init) -> int {
     int na;
     if constexpr (STEP == 1) {
         // W = I - gh A(t_n) for the adjoint system z' = A(t) z + b(t):  A_ll = -J(y(t))', A_ml = -f_p(y(t))' (Interpolating), nothing else — so W is block triangular:
@@ -1299,8 +1362,49 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 }
             }
         } lin{pv, cur, {}, {}, 0.0, 0.0, {}};
-        na = ros23_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.maxit, K, rhs, lin, false, cb, pre);
-    } else na = tsit5_integrate<NZ>(z, g.t1, g.t0, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, cb_at_init, 8 * g.maxit, K, rhs, cb, pre);
+        na = ros23_integrate<NZ>(z, ta_, tb_, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, at_init, 8 * g.maxit, K, rhs, lin, false, cb, pre);
+    } else na = tsit5_integrate<NZ>(z, ta_, tb_, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, at_init, 8 * g.maxit, K, rhs, cb, pre);
+    return na;
+    };
+    int na = 0;
+    if constexpr (model_has_cond<Mo>::value && (ALG == 0 || ALG == 2 || ALG == 4) && !CK && CC == 0) {
+        {
+            // ContinuousCallback (the oracle's section 3b; src/callback_tracking.jl:232-479 with save_positions = (false, false)): the reverse solve runs piece by piece between
+            // this trajectory's events (a fresh solve per piece: the controller restarts) and at each event, - / + the limits from below / above,
+            //     kappa = lam+ . (a_u f- + a_t - f+) / (c_u . f- + c_t)      lam- = a_u' lam+ - kappa c_u      dp += a_p' lam+ - kappa c_p
+            // A loss time that coincides with an event is taken at the end of the piece above it (it sees the affected state).
+            // (ONE call site of the integrator: without events the loop runs once over the whole span)
+            constexpr int RWf = 2 + 5 * N;
+            const int nevl = g.maxev > 0 ? (g.nev[i] < g.maxev ? g.nev[i] : g.maxev) : 0;
+            cur.smin = nevl > 0 ? g.ev_s[(long)(nevl - 1) * g.Npad + i] : 0;
+#pragma unroll 1
+            for (int e = nevl; e >= 0; --e) {
+                const double t_hi = (e == nevl) ? g.t1 : rec[((long)g.ev_s[(long)e * g.Npad + i] * RWf + 0) * g.Npad + i];
+                const int sp = e > 0 ? g.ev_s[(long)(e - 1) * g.Npad + i] : 0;
+                const double t_lo = e > 0 ? rec[((long)sp * RWf + 0) * g.Npad + i] : g.t0;
+                const int r = run_piece(t_hi, t_lo, e == nevl && cb_at_init);
+                if (r < 0) { na = -1; break; }
+                na += r;
+                if (e == 0) break;
+                double yp[N], ym[N], fm[N], fp[N], gu[N], gp[NP], jf[N], lo[N], go[NP], lamv[N], gt = 0.0;
+                cur.eval(t_lo, yp);
+                cur.below(sp - 1, e >= 2 ? g.ev_s[(long)(e - 2) * g.Npad + i] : 0);
+                cur.eval(t_lo, ym);
+                Mo::f(fm, ym, pv, t_lo); Mo::f(fp, yp, pv, t_lo);
+                Mo::cond_grad(gu, gp, gt, ym, pv, t_lo);
+                Mo::cc_affect_jvp(jf, ym, fm, pv, t_lo);
+                double num = 0.0, den = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) { lamv[j] = z[j]; num += z[j] * (jf[j] - fp[j]); den += gu[j] * fm[j]; }
+                const double kappa = num / (den + gt);
+                Mo::cc_affect_vjp(lo, go, lamv, ym, pv, t_lo);
+#pragma unroll
+                for (int j = 0; j < N; ++j) z[j] = lo[j] - kappa * gu[j];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { if constexpr (ALG == 0) z[N + j] += go[j] - kappa * gp[j]; else gacc[j] += go[j] - kappa * gp[j]; }
+            }
+        }
+    } else na = run_piece(g.t1, g.t0, cb_at_init);
 #pragma unroll
     for (int j = 0; j < N; ++j) lam_out[j] = z[j];
 #pragma unroll

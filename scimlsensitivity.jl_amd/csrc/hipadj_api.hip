@@ -96,6 +96,9 @@ extern "C" int hipadj_wmodel_set_affect(int32_t model_id, const char* affect_bod
 extern "C" int hipadj_model_set_affect(int32_t model_id, const char* affect_body) {
     return user_set_affect(model_id, affect_body, g_create_error);
 }
+extern "C" int hipadj_model_set_continuous_callback(int32_t model_id, const char* condition_body, const char* affect_body, int32_t max_events) {
+    return user_set_continuous_callback(model_id, condition_body, affect_body, max_events, g_create_error);
+}
 
 // ---- DiscreteCallback affects applied between solves (host-level composition of event problems, interface.py) --------------------------------
 // Both calls are synchronous and take HOST pointers: the data of an event is N x (n + np) doubles.  The kernels are compiled for the model with
@@ -269,6 +272,8 @@ static void free_all(hipadj_handle* h) {
                     h->d_qb, h->d_partial, h->d_io_a, h->d_du0, h->d_dp, h->d_knots, h->d_adj, h->d_fknots, h->d_fadj, h->d_c1, h->d_ticket, h->d_prev_ck, h->d_save_of_knot,
                     h->d_ckpt_of_knot, h->d_seg_bounds, h->d_flag, h->d_rs_t, h->d_rs_h, h->d_rs_te, h->d_rs_save, h->d_rs_ck, h->d_gtile, h->d_rec, h->d_save_t, h->d_ck_t, h->d_tstops, h->d_nsteps, h->d_arec, h->d_nsteps_adj, h->d_mq_pool, h->d_mq_norm, h->d_mq_panels, h->d_mq_ids, h->d_tbuf, h->d_tcnt, h->d_fev_knot, h->d_fev_save, h->d_fev_ckpt, h->d_wscr, h->d_ldata, h->d_lpart, h->d_lval, h->d_og_i, h->d_og_h, h->d_og_tile};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->d_ev_s) (void)hipFree(h->d_ev_s);
+    if (h->d_nev) (void)hipFree(h->d_nev);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
     if (h->umod_alt) (void)hipModuleUnload(h->umod_alt);
@@ -338,6 +343,11 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
             A(dev_alloc(h, &h->d_rec, (size_t)h->rec_cap * RW * Np));
         }
         A(dev_alloc(h, &h->d_nsteps, (size_t)Np));
+        h->maxev = plan_user_events(cfg->model);      // a ContinuousCallback: the event lists of the trajectories (written by the forward kernel, read by the reverse kernel)
+        if (h->maxev > 0) {
+            A(dev_alloc(h, &h->d_ev_s, (size_t)h->maxev * Np)); A(dev_alloc(h, &h->d_nev, (size_t)Np));
+            if (rc == HIPADJ_OK && !HT(hipMemset(h->d_nev, 0, sizeof(int) * (size_t)Np), "memset")) rc = HIPADJ_ERR_HIP;
+        }
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // dense adjoint solution: the reverse solve also stops at every loss time
             A(dev_alloc(h, &h->d_nsteps_adj, (size_t)Np));
             h->SmaxA = 2 * (h->auto_steps ? (int)h->rec_cap : P.Smax) + h->M + 16;
@@ -361,6 +371,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = (h->auto_steps && cfg->alg != HIPADJ_ALG_BACKSOLVE) ? (int)h->rec_cap : P.Smax; ag.maxit = h->auto_steps ? HIPADJ_AUTO_MAXITERS : P.Smax; ag.nck = P.nck; ag.SmaxI = P.SmaxI; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
         ag.abstol = cfg->abstol; ag.reltol = cfg->reltol; ag.loss_shift = cfg->loss_shift; ag.loss_kind = cfg->loss_kind;
         ag.no_start = cfg->no_start; ag.p_shared = cfg->p_shared; ag.cont_cost = cfg->cont_cost;
+        ag.maxev = h->maxev; ag.ev_s = h->d_ev_s; ag.nev = h->d_nev;
     } else if (P.wide) {
         // workgroup-per-trajectory family of runtime models (hipadj_wide.hpp): trajectory-major knots, Backsolve checkpoints, Quadrature records
         h->wide = true;
@@ -811,9 +822,18 @@ extern "C" int hipadj_synchronize(hipadj_handle* h) {
     HIP_TRY(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
         HIP_TRY(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
-        if (flag & 4) HIPADJ_FAIL(h, HIPADJ_ERR_MAXITERS, "the adaptive %s solve exceeded its step capacity (record capacity %d, step bound %d) on at least one trajectory, or a semi-explicit DAE found no consistent initial state (raise max_steps or loosen tolerances)", h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE ? "Rosenbrock23" : "Tsit5", h->ag.Smax, h->ag.maxit);
+        if (flag & 4) HIPADJ_FAIL(h, HIPADJ_ERR_MAXITERS, "the adaptive %s solve exceeded its step capacity (record capacity %d, step bound %d) on at least one trajectory, or a semi-explicit DAE found no consistent initial state, or a ContinuousCallback fired more often than the max_events it was registered with (raise max_steps or loosen tolerances)", h->cfg.stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE ? "Rosenbrock23" : "Tsit5", h->ag.Smax, h->ag.maxit);
         HIPADJ_FAIL(h, HIPADJ_ERR_NONFINITE, "non-finite sensitivities (flag %d): a trajectory diverged", flag);
     }
+    return HIPADJ_OK;
+}
+
+// events per trajectory of the last forward solve of a handle whose model carries a ContinuousCallback (host pointer, [ntraj]; synchronous)
+extern "C" int hipadj_event_counts(hipadj_handle* h, int32_t* counts) {
+    if (!h || !counts) return HIPADJ_ERR_INVALID_ARG;
+    if (h->multi || h->maxev <= 0 || !h->d_nev) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_event_counts: the handle's model carries no ContinuousCallback (hipadj_model_set_continuous_callback), or the handle spans several devices");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(counts, h->d_nev, sizeof(int32_t) * (size_t)h->N, hipMemcpyDeviceToHost));
     return HIPADJ_OK;
 }
 

@@ -108,7 +108,10 @@ typedef bool (*plan_user_wide_fn)(int32_t);   // is this runtime model one of th
 inline plan_user_wide_fn& plan_user_wide_hook() { static plan_user_wide_fn f = nullptr; return f; }
 typedef bool (*plan_user_dae_fn)(int32_t);    // does this runtime model carry a SINGULAR mass matrix (semi-explicit DAE, hipadj_model_set_mass_matrix)?
 inline plan_user_dae_fn& plan_user_dae_hook() { static plan_user_dae_fn f = nullptr; return f; }
+typedef int (*plan_user_events_fn)(int32_t);  // capacity of the per-trajectory event list when this runtime model carries a ContinuousCallback (hipadj_model_set_continuous_callback), else 0
+inline plan_user_events_fn& plan_user_events_hook() { static plan_user_events_fn f = nullptr; return f; }
 inline bool plan_user_model(int m) { return m >= HIPADJ_MODEL_USER_BASE; }
+inline int plan_user_events(int32_t model) { return (plan_user_model(model) && plan_user_events_hook()) ? plan_user_events_hook()(model) : 0; }
 inline bool plan_small_model(int m) { return (m >= HIPADJ_MODEL_LV && m <= HIPADJ_MODEL_FALLMASS) || plan_user_model(m); }
 
 inline int plan_model_sizes(int32_t model, const int32_t dims[4], int32_t* n, int32_t* np) {
@@ -235,6 +238,14 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     if (cfg->stepper != HIPADJ_STEPPER_RK4_FIXED && cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ETDRK4_FIXED && cfg->stepper != HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) { err = "unknown stepper"; return HIPADJ_ERR_INVALID_ARG; }
     if (plan_user_model(cfg->model) && plan_user_dae_hook() && plan_user_dae_hook()(cfg->model)) {      // M u' = f with a singular M (src/adjoint_common.jl:117-135, 790-803)
         if (cfg->stepper != HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) { err = "the model's mass matrix is singular (a semi-explicit DAE): HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE integrates it in mass-matrix form; the explicit steppers cannot"; return HIPADJ_ERR_UNSUPPORTED; }
+    }
+    if (plan_user_events(cfg->model) > 0) {      // a ContinuousCallback (src/callback_tracking.jl:232-479): detected on the dense output of the adaptive steppers, per trajectory
+        if (cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) { err = "the model carries a ContinuousCallback: events are located on the dense output of the adaptive steppers (HIPADJ_STEPPER_TSIT5_ADAPTIVE, HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->alg != HIPADJ_ALG_INTERPOLATING && cfg->alg != HIPADJ_ALG_GAUSS && cfg->alg != HIPADJ_ALG_GAUSS_KRONROD) { err = "ContinuousCallback: Interpolating-, Gauss- and GaussKronrodAdjoint (the reverse solve runs piece by piece between the events of each trajectory)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->checkpointing) { err = "ContinuousCallback: checkpointing = true is not offered (the event list indexes the dense forward record)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "ContinuousCallback: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (cfg->loss_kind == HIPADJ_LOSS_MODEL) { err = "ContinuousCallback: discrete losses by cotangents, HIPADJ_LOSS_LSQ_SHIFT or HIPADJ_LOSS_LSQ_DATA (the reference refuses dgdp with callbacks, src/callback_tracking.jl:289-290)"; return HIPADJ_ERR_UNSUPPORTED; }
+        if (plan_user_dae_hook() && plan_user_dae_hook()(cfg->model)) { err = "ContinuousCallback on a semi-explicit DAE is not offered"; return HIPADJ_ERR_UNSUPPORTED; }
     }
     if (cfg->stepper == HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) {   // the stiff stepper of the lane family (hipadj_adaptive.hpp ros23_integrate): planned like adaptive Tsit5 below
         if (!plan_small_model(cfg->model) || P.wide) { err = "Rosenbrock23 is available for the lane-per-trajectory models (n <= 8)"; return HIPADJ_ERR_UNSUPPORTED; }

@@ -50,6 +50,8 @@ struct UserModelSrc {
     bool has_dloss = false;
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
     std::string affect;       // DiscreteCallback affect body (hipadj_model_set_affect): modifies un (pre-set to u) from u, p, t; empty = identity
+    std::string cc_cond, cc_affect;   // ContinuousCallback (hipadj_model_set_continuous_callback): the condition body assigns `c` from u, p, t; the affect body edits un (pre-set to u)
+    int cc_maxev = 0;                 // ... and the capacity of the per-trajectory event list
     bool cols = true;         // the VJP bodies compile for Cols<G> (column bundles); cleared by user_compile when they do not
     bool has_mm = false;      // constant non-singular mass matrix (hipadj_model_set_mass_matrix): minv = M^{-1}, row-major n x n
     double minv[64] = {0};
@@ -381,6 +383,31 @@ inline std::string user_model_struct(const UserModelSrc& m) {
       << "            for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
       << "            affect_t<Dual<NP>>(du_, dp_, uu, pp, Dual<NP>(t));\n"
       << "            for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * du_[i].d[j]; for (int k = 0; k < NP; ++k) s += gp[k] * dp_[k].d[j]; go[j] = s; } }\n    }\n";
+    if (!m.cc_cond.empty()) {
+        // ContinuousCallback(condition, affect!) (hipadj_model_set_continuous_callback; hipadj_adaptive.hpp "events", src/callback_tracking.jl:232-479): the condition and the affect
+        // compile for double and for dual numbers — c_u, c_p, c_t, the directional derivative a_u v + a_t and the products a_u' lam, a_p' lam of the reverse jump
+        o << "    static constexpr bool HAS_COND = true;\n"
+          << "    template <class real> HIPADJ_HD static real cond_t(const real (&u)[N], const real (&p)[NP], real t) {\n        (void)u; (void)p; (void)t; real c = real(0.0);\n" << m.cc_cond << "\n        return c;\n    }\n"
+          << "    HIPADJ_HD static double cond(const double (&u)[N], const double (&p)[NP], double t) { return cond_t<double>(u, p, t); }\n"
+          << "    HIPADJ_HD static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        {   Dual<N> uu[N], pp[NP];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
+          << "            const Dual<N> c = cond_t<Dual<N>>(uu, pp, Dual<N>(t));\n            for (int j = 0; j < N; ++j) gu[j] = c.d[j]; }\n"
+          << "        {   Dual<NP> uu[N], pp[NP];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
+          << "            const Dual<NP> c = cond_t<Dual<NP>>(uu, pp, Dual<NP>(t));\n            for (int j = 0; j < NP; ++j) gp[j] = c.d[j]; }\n"
+          << "        {   Dual<1> uu[N], pp[NP];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<1>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<1>(p[j]);\n"
+          << "            const Dual<1> c = cond_t<Dual<1>>(uu, pp, Dual<1>::seed(t, 0));\n            gt = c.d[0]; }\n    }\n"
+          << "    template <class real> HIPADJ_HD static void cc_affect_t(real (&un)[N], const real (&u)[N], const real (&p)[NP], real t) {\n"
+          << "        (void)u; (void)p; (void)t;\n        for (int i = 0; i < N; ++i) un[i] = u[i];\n" << m.cc_affect << "\n    }\n"
+          << "    HIPADJ_HD static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t) { cc_affect_t<double>(un, u, p, t); }\n"
+          << "    HIPADJ_HD static void cc_affect_jvp(double (&out)[N], const double (&u)[N], const double (&v)[N], const double (&p)[NP], double t) {\n"
+          << "        Dual<1> uu[N], pp[NP], un[N];\n        for (int j = 0; j < N; ++j) { uu[j] = Dual<1>(u[j]); uu[j].d[0] = v[j]; }\n        for (int j = 0; j < NP; ++j) pp[j] = Dual<1>(p[j]);\n"
+          << "        cc_affect_t<Dual<1>>(un, uu, pp, Dual<1>::seed(t, 0));\n        for (int j = 0; j < N; ++j) out[j] = un[j].d[0];\n    }\n"
+          << "    HIPADJ_HD static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        {   Dual<N> uu[N], pp[NP], un[N];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
+          << "            cc_affect_t<Dual<N>>(un, uu, pp, Dual<N>(t));\n            for (int j = 0; j < N; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * un[i].d[j]; lo[j] = s; } }\n"
+          << "        {   Dual<NP> uu[N], pp[NP], un[N];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
+          << "            cc_affect_t<Dual<NP>>(un, uu, pp, Dual<NP>(t));\n            for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * un[i].d[j]; go[j] = s; } }\n    }\n";
+    }
     if (m.has_dloss) {
         // discrete loss on the device (hipadj_model_set_discrete_loss[_function]; HIPADJ_LOSS_MODEL): dgdu_discrete(out, u, p, t_i, i) / dgdp_discrete(out, u, p, t_i, i) of
         // ReverseLossCallback (src/adjoint_common.jl:771-779) with d = the data column of this (trajectory, loss time)
@@ -670,6 +697,30 @@ inline int user_set_affect(int32_t model, const char* body, std::string& err) {
     R.models[idx].affect = body ? body : ""; R.models[idx].rev++;
     return HIPADJ_OK;
 }
+// ContinuousCallback(condition, affect!; save_positions = (false, false)) of a runtime lane model (src/callback_tracking.jl:232-479; test/Callbacks2/continuous_callbacks.jl):
+// condition_body assigns `c` from u, p, t; affect_body edits un[0..n) (a copy of u) from u, p, t; both NULL removes the callback
+inline int user_set_continuous_callback(int32_t model, const char* cond, const char* affect, int32_t max_events, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_continuous_callback: unknown model id (callbacks are attached to runtime-registered models)"; return HIPADJ_ERR_INVALID_ARG; }
+    UserModelSrc& m = R.models[idx];
+    const bool hc = cond && *cond, ha = affect && *affect;
+    if (!hc && !ha) { m.cc_cond.clear(); m.cc_affect.clear(); m.cc_maxev = 0; m.rev++; return HIPADJ_OK; }
+    if (!hc) { err = "hipadj_model_set_continuous_callback: a condition body is needed (it assigns `c`; the event is its zero crossing)"; return HIPADJ_ERR_INVALID_ARG; }
+    if (m.wide) { err = "hipadj_model_set_continuous_callback: offered for the lane-per-trajectory models (hipadj_model_register); a wide model takes preset-time events (hipadj_wmodel_set_affect)"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (m.has_mm || m.dae) { err = "hipadj_model_set_continuous_callback: not offered on a model with a mass matrix"; return HIPADJ_ERR_UNSUPPORTED; }
+    if (max_events < 0 || max_events > 4096) { err = "hipadj_model_set_continuous_callback: max_events in 0 .. 4096 (0 = 64)"; return HIPADJ_ERR_INVALID_ARG; }
+    if (ha && std::string(affect).find("pn[") != std::string::npos) { err = "hipadj_model_set_continuous_callback: the affect of a ContinuousCallback edits the state (un); parameter-changing affects are offered at preset times (hipadj_model_set_affect)"; return HIPADJ_ERR_UNSUPPORTED; }
+    m.cc_cond = cond; m.cc_affect = ha ? affect : ""; m.cc_maxev = max_events > 0 ? max_events : 64; m.rev++;
+    return HIPADJ_OK;
+}
+inline int user_model_events(int32_t model) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    return (idx >= 0 && idx < (int)R.models.size() && !R.models[idx].cc_cond.empty()) ? R.models[idx].cc_maxev : 0;
+}
 // wide models: the affect and its reverse callback as text (no dual numbers at n up to 4096); both NULL removes them
 inline int user_set_wide_affect(int32_t model, const char* body, const char* vjp_body, std::string& err) {
     UserRegistry& R = user_registry();
@@ -715,6 +766,7 @@ inline int user_set_mass_matrix(int32_t model, const double* M, std::string& err
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_mass_matrix: unknown model id"; return HIPADJ_ERR_INVALID_ARG; }
     UserModelSrc& m = R.models[idx];
     if (!M) { if (m.has_mm || m.dae) { m.has_mm = false; m.dae = false; m.rev++; } return HIPADJ_OK; }
+    if (!m.cc_cond.empty()) { err = "hipadj_model_set_mass_matrix: the model carries a ContinuousCallback, which is not offered together with a mass matrix"; return HIPADJ_ERR_UNSUPPORTED; }
     if (m.wide || m.n > 8) {   // minv[64] / a[8][16] below are sized for the lane family (n <= 8); the wide kernels never consult has_mm
         err = "hipadj_model_set_mass_matrix: mass matrices are implemented for lane-family runtime models (n <= 8) only, not for wide models (hipadj_wmodel_register)";
         return HIPADJ_ERR_UNSUPPORTED;
@@ -825,6 +877,7 @@ inline int user_register(const char* name, int32_t n, int32_t np, const char* f,
     plan_user_sizes_hook() = &user_model_sizes;
     plan_user_segcap_hook() = &user_seg_cap;
     plan_user_dae_hook() = &user_model_is_dae;
+    plan_user_events_hook() = &user_model_events;
     return HIPADJ_OK;
 }
 

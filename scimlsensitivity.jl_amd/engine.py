@@ -197,6 +197,12 @@ class Engine:
     def synchronize(self):
         self._check(self._L.hipadj_synchronize(self._h))
 
+    def event_counts(self):
+        """Events per trajectory of the last forward solve (a model with a ContinuousCallback: DeviceFunction.set_continuous_callback)."""
+        out = np.zeros(self.N, dtype=np.int32)
+        self._check(self._L.hipadj_event_counts(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def stats(self):
         st = HipadjStats()
         st.struct_size = C.sizeof(HipadjStats)

@@ -116,15 +116,48 @@ template <int KAPPA, int MIX = 0> struct EmuRoberDAE {      // MIX = 1 (id + 206
         dg[2] = u[1] * u[2] * l0 - u[1] * u[2] * l1;
     }
 };
+// TEST-ONLY: the ContinuousCallback problems of the oracle (adjoint_oracle.h event_kind; test/Callbacks2/continuous_callbacks.jl): the falling mass with a condition and an affect,
+// written out by hand the way the generator of hipadj_user.hpp derives them from the registered bodies.  Model id = HIPADJ_MODEL_USER_BASE + 300 + KIND (KIND 1: the bouncing
+// ball; 4: the moving floor, condition and affect with explicit t) and + 303 (EmuRelax, kind 3: the condition depends on a parameter).
+template <int KIND> struct EmuBall {
+    static constexpr int N = 2, NP = 2;
+    static constexpr bool TIME_DEP = false, HAS_COLS = false, HAS_COND = true;
+    static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) { du[0] = u[1]; du[1] = -p[0]; }
+    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dl[0] = 0.0; dl[1] = l[0]; }
+    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dg[0] = -l[1]; dg[1] = 0.0; }
+    static double cond(const double (&u)[N], const double (&)[NP], double t) { return KIND == 4 ? u[0] - 0.3 * t : u[0]; }
+    static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, const double (&)[N], const double (&)[NP], double) { gu[0] = 1.0; gu[1] = 0.0; gp[0] = 0.0; gp[1] = 0.0; gt = KIND == 4 ? -0.3 : 0.0; }
+    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t) { un[0] = u[0]; un[1] = KIND == 4 ? -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t : -p[1] * u[1]; }
+    static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&p)[NP], double) { out[0] = v[0]; out[1] = -p[1] * v[1] + (KIND == 4 ? 0.1 : 0.0); }
+    static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double) {
+        lo[0] = lam[0]; lo[1] = -p[1] * lam[1]; go[0] = 0.0; go[1] = -(u[1] - (KIND == 4 ? 0.3 : 0.0)) * lam[1];
+    }
+};
+struct EmuRelax {
+    static constexpr int N = 1, NP = 2;
+    static constexpr bool TIME_DEP = false, HAS_COLS = false, HAS_COND = true;
+    static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) { du[0] = p[0] - u[0]; }
+    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dl[0] = -l[0]; }
+    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dg[0] = l[0]; dg[1] = 0.0; }
+    static double cond(const double (&u)[N], const double (&p)[NP], double) { return u[0] - 0.75 * p[0]; }
+    static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, const double (&)[N], const double (&)[NP], double) { gu[0] = 1.0; gp[0] = -0.75; gp[1] = 0.0; gt = 0.0; }
+    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double) { un[0] = u[0] + p[1]; }
+    static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&)[NP], double) { out[0] = v[0]; }
+    static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&)[N], const double (&)[NP], double) { lo[0] = lam[0]; go[0] = 0.0; go[1] = lam[0]; }
+};
 static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
     const int nn = model - HIPADJ_MODEL_USER_BASE;
     if (nn >= 203 && nn <= 206) { *n = 3; *np = 3; return HIPADJ_OK; }
+    if (nn == 301 || nn == 304) { *n = 2; *np = 2; return HIPADJ_OK; }
+    if (nn == 303) { *n = 1; *np = 2; return HIPADJ_OK; }
     if (nn != 4 && nn != 105) return HIPADJ_ERR_INVALID_ARG;
     *n = nn % 100; *np = nn % 100 + 1;
     return HIPADJ_OK;
 }
 static bool emu_user_dae(int32_t model) { return model >= HIPADJ_MODEL_USER_BASE + 204 && model <= HIPADJ_MODEL_USER_BASE + 206; }
-static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, plan_user_dae_hook() = &emu_user_dae, true);
+static constexpr int EMU_MAXEV = 16;
+static int emu_user_events(int32_t model) { const int nn = model - HIPADJ_MODEL_USER_BASE; return (nn == 301 || nn == 303 || nn == 304) ? EMU_MAXEV : 0; }
+static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, plan_user_dae_hook() = &emu_user_dae, plan_user_events_hook() = &emu_user_events, true);
 
 template <class Mo>
 static void compose(const Plan& P, const std::vector<double>& segbuf, double* du0, std::vector<double>& dp_traj) {
@@ -403,12 +436,14 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     std::vector<double> rec(ALG != 1 ? (size_t)(CK ? P.SmaxI : P.Smax) * RW * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np), ckpt((size_t)P.nck * N * Np);
     std::vector<double> cotT(cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
     std::vector<int> nsteps((size_t)Np, 0);
+    std::vector<int> ev_s(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * Np : 0), nev(model_has_cond<Mo>::value ? (size_t)Np : 0);      // ContinuousCallback: the event lists (hipadj_api.hip d_ev_s / d_nev)
+    if (model_has_cond<Mo>::value) { g.maxev = EMU_MAXEV; g.ev_s = ev_s.data(); g.nev = nev.data(); }
     int flag = 0;
     std::vector<double> kbuf((size_t)KS_ROWS * (2 * N + NP)), kfbuf((size_t)KS_ROWS * N);   // stage storage of one lane (LDS columns on the device), stride 1 here
     for (long i = 0; i < P.N; ++i)
         forward_tsit5_lane<Mo, STEP>(g, i, u0, p, (rec.empty() || CK) ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(),
                                P.ck_times.data(), ckpt.empty() ? nullptr : ckpt.data(), yT.data(), &flag, kbuf.data(), 1);
-    if (nsteps_out) for (long i = 0; i < P.N; ++i) nsteps_out[i] = nsteps[i];
+    if (nsteps_out) for (long i = 0; i < P.N; ++i) nsteps_out[i] = model_has_cond<Mo>::value ? nev[i] : nsteps[i];      // (a model with events reports its event counts there)
     if (flag & 4) return HIPADJ_ERR_MAXITERS;
     if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
     if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
@@ -494,7 +529,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 
 // Build units (tests/emu.py compiles them in parallel): EMU_UNIT undefined = everything in one translation unit (the variant builds
 // of test_emu_parity.py); EMU_UNIT = 0 = the C entry points, the per-model dispatchers declared `extern template`;
-// EMU_UNIT = 1..11 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
+// EMU_UNIT = 1..14 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
 #ifndef EMU_UNIT
 #define EMU_UNIT -1
 #endif
@@ -525,6 +560,9 @@ extern template int dispatch_mode<EmuRober>(const hipadj_config*, const Plan&, c
 extern template int dispatch_mode<EmuRoberDAE<0>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRoberDAE<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRoberDAE<5, 1>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuBall<1>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuBall<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuRelax>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 1
 template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 2
@@ -547,6 +585,12 @@ template int dispatch_mode<EmuRoberDAE<0>>(const hipadj_config*, const Plan&, co
 template int dispatch_mode<EmuRoberDAE<5>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 11
 template int dispatch_mode<EmuRoberDAE<5, 1>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 12
+template int dispatch_mode<EmuBall<1>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 13
+template int dispatch_mode<EmuBall<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 14
+template int dispatch_mode<EmuRelax>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #endif
 
 #if EMU_UNIT <= 0
@@ -575,6 +619,9 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     case HIPADJ_MODEL_USER_BASE + 204: return dispatch_mode<EmuRoberDAE<0>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 205: return dispatch_mode<EmuRoberDAE<5>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 206: return dispatch_mode<EmuRoberDAE<5, 1>>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 301: return dispatch_mode<EmuBall<1>>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 304: return dispatch_mode<EmuBall<4>>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 303: return dispatch_mode<EmuRelax>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

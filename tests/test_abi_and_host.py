@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(sa):
     assert set(names) == set(_lib.DECLARED_SYMBOLS)
     for nm in names:
         assert hasattr(L, nm), nm
-    assert L.hipadj_version() == 109
+    assert L.hipadj_version() == 110
     assert L.hipadj_status_string(-2).decode().startswith("no usable HIP device")
 
 
@@ -442,7 +442,7 @@ def test_c_host_compiles_against_the_header_and_fails_loudly_without_a_device(sa
     sa.load_library()
     exe = _build_host_demo(sa, tmp_path)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
-    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 109" in r.stdout
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and "version 110" in r.stdout
 
 
 def test_c_stiff_dae_example_compiles_and_fails_loudly_without_a_device(sa, tmp_path):

@@ -1,0 +1,209 @@
+"""ContinuousCallback without a GPU: the oracle's restatement (oracle/adjoint_oracle.c section 3b) against CLOSED-FORM gradients, the device lane bodies (compiled for the
+host, tests/emu) against the oracle, the registration entry point and the planner's refusals, and the runtime kernels through hiprtc.
+
+Reference: src/callback_tracking.jl:1-223 (forward tracking), :232-479 (reverse callbacks, the implicit correction for the event time), test/Callbacks2/continuous_callbacks.jl
+(the bouncing ball: u0 = [5, 0], tspan (0, 2.5), p = [9.8, 0.8], saveat 0.5, abstol = reltol = 1e-12; its bar: rtol 1e-5 against ForwardDiff, :140-145).
+The closed forms (tests/golden/make_continuous_callbacks.py) are exact: piecewise ballistic flights, event times as roots of quadratics, differentiated by dual numbers."""
+import ctypes as C
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import emu as E
+import oracle as O
+import user_models as UM
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ALGS = [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")]
+CASES = {"ball": (1, "FALLMASS", "emu_ball"), "ball_long": (1, "FALLMASS", "emu_ball"), "ball_mse": (2, "FALLMASS", None), "relax": (3, "RELAX", "emu_relax"),
+         "moving": (4, "FALLMASS", "emu_ball_moving")}
+TS5, ROS = 1, 3
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(HERE, "golden", "continuous_callbacks.json")) as f:
+        return json.load(f)
+
+
+def relc(a, b):
+    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12 * np.max(np.abs(b)))))
+
+
+def relmax(du0, dp, g):
+    """error of the whole gradient against its largest entry (an entry that is 1e-5 of the others is not asked to 1e-5 of itself from a second-order stepper)"""
+    a = np.concatenate([np.ravel(du0), np.ravel(dp)]); b = np.concatenate([np.ravel(g["du0"]), np.ravel(g["dp"])])
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+def oracle_run(g, omodel, kind, oalg, stepper="TSIT5", tol=1e-12, mse=False):
+    ts = np.asarray(g["ts"])
+    pr = O.Problem(omodel, alg=oalg, stepper=stepper, t0=g["tspan"][0], t1=g["tspan"][1], dt=0.0, abstol=tol, reltol=tol, save_times=ts, event_kind=kind,
+                   loss="LSQ_SHIFT" if mse else "COTANGENT", loss_shift=1.0 if mse else 0.0)
+    return pr.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), None if mse else np.ones((len(ts), len(g["u0"]))))
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_oracle_against_the_closed_forms(gold, case, alg, oalg):
+    """the pin of the restatement: every term of the event jump — a_u' lam, the event-time term with c_u, c_t, a_t, and the parameter terms a_p' lam and kappa c_p — is needed by
+    at least one of these numbers (relax: -kappa c_p = 2.7e-4 of a gradient entry asked to 1e-10 by the reference, :342-346)"""
+    kind, omodel, _ = CASES[case]; g = gold[case]
+    du0, dp, out = oracle_run(g, omodel, kind, oalg, mse=(case == "ball_mse"))
+    bar = 2e-9 if case == "relax" else 1e-11
+    assert relc(du0, g["du0"]) < bar and relc(dp, g["dp"]) < bar
+    if "u_at_ts" in g:
+        assert np.max(np.abs(out - np.asarray(g["u_at_ts"]))) < 1e-11
+
+
+def test_the_reference_records_the_relax_gradient(gold):
+    """test/Callbacks2/continuous_callbacks.jl:342 holds the numbers of its own finite-difference run as a comment"""
+    assert np.allclose(gold["relax"]["dp"], [0.9999546000702386, 0.00018159971904994378], rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("case", ["ball", "relax"])
+def test_oracle_rosenbrock23(gold, case):
+    kind, omodel, _ = CASES[case]; g = gold[case]
+    du0, dp, _ = oracle_run(g, omodel, kind, "INTERPOLATING", stepper="ROS23", tol=1e-9)
+    assert relmax(du0, dp, g) < 1e-5
+
+
+def test_oracle_without_crossings_is_the_plain_solve():
+    ts = np.array([0.5, 1.0, 2.0]); u0 = np.array([50.0, 3.0]); p = np.array([9.8, 0.8]); d = np.ones((3, 2))
+    kw = dict(alg="INTERPOLATING", stepper="TSIT5", t0=0.0, t1=2.0, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts)
+    a = O.Problem("FALLMASS", **kw).adjoint(u0, p, d); b = O.Problem("FALLMASS", event_kind=1, **kw).adjoint(u0, p, d)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_oracle_refusals_and_the_ball_that_comes_to_rest():
+    ts = np.array([1.0, 2.0]); u0 = np.array([5.0, 0.0]); p = np.array([9.8, 0.8]); d = np.ones((2, 2))
+    kw = dict(t0=0.0, t1=2.0, dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, event_kind=1)
+    for bad in (dict(alg="BACKSOLVE", stepper="TSIT5"), dict(alg="QUADRATURE", stepper="TSIT5"), dict(alg="INTERPOLATING", stepper="TSIT5", checkpointing=True),
+                dict(alg="INTERPOLATING", stepper="TSIT5", cont_cost=1)):
+        with pytest.raises(RuntimeError, match="rc=-6"):
+            O.Problem("FALLMASS", **{**kw, **bad}).adjoint(u0, p, d)
+    with pytest.raises(RuntimeError, match="rc=-6"):
+        O.Problem("FALLMASS", alg="INTERPOLATING", stepper="RK4", **{**kw, "dt": 0.01}).adjoint(u0, p, d)
+    with pytest.raises(RuntimeError, match="rc=-6"):          # event 3 is written for the one-state model
+        O.Problem("FALLMASS", alg="INTERPOLATING", stepper="TSIT5", **{**kw, "event_kind": 3}).adjoint(u0, p, d)
+    # restitution 0.5 from height 1: the bounces accumulate at t = 1.355 < 4.  The solve must END: with flights below the time resolution the ball passes through the floor (as
+    # it does in the reference's solver) or the event bound reports -7; either way not an endless loop
+    try:
+        O.Problem("FALLMASS", alg="INTERPOLATING", stepper="TSIT5", **{**kw, "t1": 4.0, "save_times": np.array([1.0, 4.0])}).adjoint(np.array([1.0, 0.0]), np.array([9.8, 0.5]), d)
+    except RuntimeError as e:
+        assert "rc=-7" in str(e)
+
+
+# ---- the device lane bodies on the host ----------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case", ["ball", "ball_long", "relax", "moving"])
+def test_lane_bodies_against_the_oracle_and_the_closed_forms(gold, case, alg, oalg):
+    kind, omodel, emodel = CASES[case]; g = gold[case]; ts = np.asarray(g["ts"]); n = len(g["u0"])
+    cfg = E.make_config(emodel, alg, 1, g["tspan"][0], g["tspan"][1], 0.0, ts, stepper=TS5, abstol=1e-12, reltol=1e-12, max_steps=4000)
+    du0, dp, out = E.forward_adjoint(cfg, n, len(g["p"]), [g["u0"]], g["p"], np.ones((1, len(ts), n)))
+    rdu0, rdp, rout = oracle_run(g, omodel, kind, oalg)
+    # two representations of one dense output (monomial record / stage form) locate the event to ~1 ulp of each other
+    assert relc(du0[0], rdu0) < 1e-11 and relc(dp, rdp) < 1e-11 and np.max(np.abs(out[0] - rout)) < 1e-11
+    bar = 2e-9 if case == "relax" else 1e-11
+    assert relc(du0[0], g["du0"]) < bar and relc(dp, g["dp"]) < bar
+
+
+@pytest.mark.parametrize("alg,oalg", [ALGS[0], ALGS[1]])
+@pytest.mark.parametrize("case", ["ball", "relax"])
+def test_lane_bodies_rosenbrock23(gold, case, alg, oalg):
+    kind, omodel, emodel = CASES[case]; g = gold[case]; ts = np.asarray(g["ts"]); n = len(g["u0"])
+    cfg = E.make_config(emodel, alg, 1, g["tspan"][0], g["tspan"][1], 0.0, ts, stepper=ROS, abstol=1e-9, reltol=1e-9, max_steps=20000)
+    du0, dp, out = E.forward_adjoint(cfg, n, len(g["p"]), [g["u0"]], g["p"], np.ones((1, len(ts), n)))
+    rdu0, rdp, rout = oracle_run(g, omodel, kind, oalg, stepper="ROS23", tol=1e-9)
+    assert relc(du0[0], rdu0) < 1e-9 and relc(dp, rdp) < 1e-9 and np.max(np.abs(out[0] - rout)) < 1e-9
+    assert relmax(du0[0], dp, g) < 1e-5
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_lane_bodies_ensemble_with_per_trajectory_events(alg, oalg):
+    """every trajectory its own event times and its own number of events (2 .. 7); per-trajectory parameters, random cotangents, loss times off any grid"""
+    rng = np.random.default_rng(5)
+    N, T = 40, 4.0
+    u0 = np.stack([rng.uniform(2.0, 9.0, N), rng.uniform(-1.0, 1.0, N)], axis=1)
+    p = np.stack([9.8 * (1 + 0.1 * rng.uniform(-1, 1, N)), rng.uniform(0.8, 0.9, N)], axis=1)
+    ts = np.array([0.3, 1.0, 1.7, 2.2, 3.1, 4.0]); d = rng.standard_normal((N, len(ts), 2))
+    cfg = E.make_config("emu_ball", alg, N, 0.0, T, 0.0, ts, stepper=TS5, abstol=1e-10, reltol=1e-10, max_steps=4000, p_shared=False)
+    du0, dp, out = E.forward_adjoint(cfg, 2, 2, u0, p, d)
+    ref = O.Problem("FALLMASS", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, event_kind=1)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, d)
+    assert np.max(np.abs(out - rout)) < 1e-9
+    sc = np.maximum(np.abs(rdu0), 1e-3 * np.abs(rdu0).max(axis=1, keepdims=True)); scp = np.maximum(np.abs(rdp), 1e-3 * np.abs(rdp).max(axis=1, keepdims=True))
+    assert np.max(np.abs(du0 - rdu0) / sc) < 1e-8 and np.max(np.abs(dp - rdp) / scp) < 1e-8
+
+
+def test_lane_bodies_event_list_overflow_and_refusals():
+    ts = np.array([1.0, 4.0]); d = np.ones((1, 2, 2))
+    cfg = E.make_config("emu_ball", "interpolating", 1, 0.0, 4.0, 0.0, ts, stepper=TS5, abstol=1e-9, reltol=1e-9, max_steps=4000)
+    with pytest.raises(RuntimeError, match="rc=-7"):          # dropped from 0.1 with restitution 0.95: 24 bounces before t = 4, more than the list holds (16 in the emulator)
+        E.forward_adjoint(cfg, 2, 2, [[0.1, 0.0]], [9.8, 0.95], d)
+    for bad in (dict(alg="backsolve"), dict(alg="quadrature"), dict(alg="interpolating", checkpointing=True), dict(alg="interpolating", cont_cost=1),
+                dict(alg="interpolating", stepper=0, dt=0.01)):
+        kw = dict(alg="interpolating", stepper=TS5, dt=0.0, checkpointing=False, cont_cost=0); kw.update(bad)
+        cfg = E.make_config("emu_ball", kw["alg"], 1, 0.0, 4.0, kw["dt"], ts, stepper=kw["stepper"], abstol=1e-9, reltol=1e-9, checkpointing=kw["checkpointing"], cont_cost=kw["cont_cost"])
+        with pytest.raises(RuntimeError, match="rc=-6"):
+            E.forward_adjoint(cfg, 2, 2, [[5.0, 0.0]], [9.8, 0.8], d)
+
+
+# ---- the C ABI without a device ------------------------------------------------------------------------------------------------------------------------------------------
+def test_registration_entry_point_and_its_refusals():
+    from scimlsensitivity_jl_amd import _lib
+    m = UM.BALL
+    mid = _lib.register_model("cc_host_ball", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+    _lib.set_model_continuous_callback(mid, "c = u[0];", "un[1] = -p[1] * u[1];", 8)
+    _lib.set_model_continuous_callback(mid, "c = u[0];", None)                      # a condition alone: the identity affect (the reference's "callbacks with no effect", :188-193)
+    with pytest.raises(_lib.HipadjError) as ei:
+        _lib.set_model_continuous_callback(mid, None, "un[1] = 0.0;")
+    assert ei.value.status == _lib.ERR_INVALID_ARG and "condition" in str(ei.value)
+    with pytest.raises(_lib.HipadjError) as ei:
+        _lib.set_model_continuous_callback(mid, "c = u[0];", "pn[0] = 2.0 * p[0];")
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "parameter-changing" in str(ei.value)
+    with pytest.raises(_lib.HipadjError) as ei:
+        _lib.set_model_continuous_callback(mid, "c = u[0];", None, -1)
+    assert ei.value.status == _lib.ERR_INVALID_ARG
+    with pytest.raises(_lib.HipadjError) as ei:
+        _lib.set_model_mass_matrix(mid, 2, [[2.0, 0.0], [0.0, 1.0]])
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "ContinuousCallback" in str(ei.value)
+    with pytest.raises(_lib.HipadjError):
+        _lib.set_model_continuous_callback(12345678, "c = u[0];", None)
+    _lib.set_model_continuous_callback(mid, None, None)                              # removed: the mass matrix is accepted again
+    _lib.set_model_mass_matrix(mid, 2, [[2.0, 0.0], [0.0, 1.0]])
+    with pytest.raises(_lib.HipadjError) as ei:
+        _lib.set_model_continuous_callback(mid, "c = u[0];", None)
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "mass matrix" in str(ei.value)
+
+
+@pytest.mark.parametrize("kind,auto,alg,stepper", [(1, False, "interpolating", TS5), (2, True, "gauss", TS5), (3, True, "gausskronrod", ROS), (4, False, "interpolating", ROS)])
+def test_runtime_kernels_compile_without_a_device_and_are_clean(tmp_path, monkeypatch, kind, auto, alg, stepper):
+    """k_forward_tsit5<U, STEP> with the event search and k_adjoint_tsit5<U, ALG, 0, false, STEP> with the piecewise reverse solve and the jump, condition and affect from text
+    (every derivative by dual numbers), through hiprtc; the spill-placement check on what it produced; and the planner's refusals for such a model"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "tools"))
+    import isa_lint
+    from scimlsensitivity_jl_amd import _lib
+    m, cond, aff = UM.EVENTS[kind]
+    name = f"cc_lint_{kind}_{int(auto)}_{alg}_{stepper}"
+    mid = _lib.register_model(name, m["n"], m["np"], m["f"], None if auto else m["vjp"], None if auto else m["vjp_p"])
+    _lib.set_model_continuous_callback(mid, cond, aff, 8)
+    monkeypatch.setenv("HIPADJ_RTC_DUMP", str(tmp_path))
+    L = _lib.load()
+    cfg = E.make_config(name, alg, 53, 0.0, 2.5, 0.0, [0.5, 1.0, 2.5], stepper=stepper, abstol=1e-8, reltol=1e-8)
+    assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+    objs = glob.glob(str(tmp_path / "*.hsaco"))
+    assert objs
+    for o in objs:
+        assert isa_lint.lint(o) == []
+    for bad, word in ((dict(alg="backsolve"), "Interpolating-, Gauss-"), (dict(alg="quadrature"), "Interpolating-, Gauss-"), (dict(checkpointing=True), "checkpointing"),
+                      (dict(cont_cost=1), "continuous cost"), (dict(stepper=0, dt=0.01), "adaptive steppers")):
+        kw = dict(alg=alg, stepper=stepper, dt=0.0, checkpointing=False, cont_cost=0); kw.update(bad)
+        cfg = E.make_config(name, kw["alg"], 53, 0.0, 2.5, kw["dt"], [0.5, 1.0, 2.5], stepper=kw["stepper"], abstol=1e-8, reltol=1e-8, checkpointing=kw["checkpointing"], cont_cost=kw["cont_cost"])
+        assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.ERR_UNSUPPORTED and word in L.hipadj_last_error(None).decode()

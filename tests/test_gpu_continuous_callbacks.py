@@ -1,0 +1,173 @@
+"""ContinuousCallback on the device (`-m gpu`): hipadj_model_set_continuous_callback through the host mirror (`DeviceFunction.set_continuous_callback`) — the reference's
+test/Callbacks2/continuous_callbacks.jl (the bouncing ball and its relatives; src/callback_tracking.jl:232-479) on the adaptive lane steppers.
+
+  * the reference's own problems as runtime models (condition and affect as text, every derivative of the jump by dual numbers): against the CLOSED-FORM gradients of
+    tests/golden/continuous_callbacks.json at the reference's bar (rtol 1e-5, :140-145; the "Re-compile tape" problem 1e-10 at tolerances 1e-14, :342-346 — here 1e-8 at the
+    tolerances the device takes, 1e-12) and against the oracle;
+  * an ensemble in which every trajectory has its own event times and its own NUMBER of events: all trajectories against the oracle, event counts against the closed form;
+  * Rosenbrock23 as the stepper; f-only models (VJPs by dual numbers);
+  * the event list overflowing its capacity: reported, not silently truncated;
+  * what the library refuses for a model with a ContinuousCallback.
+Tolerances: the device and the oracle locate an event on two representations of the same dense output (monomial record / stage form) and restart the reverse controller
+at it; they agree to a fraction of the solver tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import user_models as UM
+from test_gpu_parity import rel
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ALGS = [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")]
+CASES = {"ball": (1, "FALLMASS"), "ball_long": (1, "FALLMASS"), "ball_mse": (2, "FALLMASS"), "relax": (3, "RELAX"), "moving": (4, "FALLMASS")}
+_registered = {}
+
+
+def relc(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12 * np.max(np.abs(b)))))      # (component-wise; a gradient entry that is exactly zero is held to the vector's scale)
+
+
+def sens(sa, alg):
+    return {"interpolating": sa.InterpolatingAdjoint(), "gauss": sa.GaussAdjoint(), "gausskronrod": sa.GaussKronrodAdjoint()}[alg]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(HERE, "golden", "continuous_callbacks.json")) as f:
+        return json.load(f)
+
+
+def model(sa, kind, auto=False, max_events=0):
+    key = (kind, auto, max_events)
+    if key not in _registered:
+        m, cond, aff = UM.EVENTS[kind]
+        f = sa.DeviceFunction(f"cc_kind{kind}_{int(auto)}_{max_events}", m["n"], m["np"], m["f"], None if auto else m["vjp"], None if auto else m["vjp_p"])
+        f.set_continuous_callback(cond, aff, max_events)
+        _registered[key] = f
+    return _registered[key]
+
+
+def run(sa, f, g, alg, stepper, tol, mse=False, u0=None, p=None):
+    ts = np.asarray(g["ts"]); n = len(g["u0"])
+    u0 = np.asarray([g["u0"]]) if u0 is None else u0
+    p = np.asarray(g["p"]) if p is None else p
+    pr = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], tuple(g["tspan"]), p if p.ndim == 1 else p[0]), u0, None if p.ndim == 1 else p)
+    kw = dict(dgdu_discrete=sa.LsqShift(1.0)) if mse else {}
+    sol = sa.solve(pr, stepper, saveat=ts, sensealg=sens(sa, alg), abstol=tol, reltol=tol, **kw)
+    if mse:
+        du0, dp = sa.adjoint_sensitivities(sol, stepper, t=ts)
+    else:
+        du0, dp = sa.adjoint_sensitivities(sol, stepper, t=ts, dgdu_discrete=np.ones((len(u0), len(ts), n)))
+    ne = sol.engine.event_counts()
+    out = np.array(sol.u)
+    sol.engine.close()
+    return du0, dp, out, ne
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case", ["ball", "ball_long", "ball_mse", "relax", "moving"])
+def test_reference_problems_against_the_closed_forms_and_the_oracle(sa, gold, case, alg, oalg):
+    kind, omodel = CASES[case]; g = gold[case]; mse = case == "ball_mse"
+    du0, dp, out, ne = run(sa, model(sa, kind), g, alg, sa.Tsit5(), 1e-12, mse=mse)
+    assert ne.tolist() == [len(g["event_times"])]
+    bar = 1e-8 if case == "relax" else 1e-9          # (relax: an exponential solved at 1e-12; the others are polynomials in t, exact for the stepper)
+    assert relc(du0[0], g["du0"]) < bar and relc(dp, g["dp"]) < bar
+    ts = np.asarray(g["ts"])
+    ref = O.Problem(omodel, alg=oalg, stepper="TSIT5", t0=g["tspan"][0], t1=g["tspan"][1], dt=0.0, abstol=1e-12, reltol=1e-12, save_times=ts, event_kind=kind,
+                    loss="LSQ_SHIFT" if mse else "COTANGENT", loss_shift=1.0 if mse else 0.0)
+    rdu0, rdp, rout = ref.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), None if mse else np.ones((len(ts), len(g["u0"]))))[:3]
+    assert rel(out[0], rout) < 1e-10 and relc(du0[0], rdu0) < 1e-9 and relc(dp, rdp) < 1e-9
+    if "u_at_ts" in g:
+        assert np.max(np.abs(out[0] - np.asarray(g["u_at_ts"]))) < 1e-9
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+def test_an_ensemble_where_every_trajectory_has_its_own_events(sa, alg, oalg):
+    """300 balls dropped from 2 .. 9 with restitution 0.8 .. 0.9 over (0, 4) — none comes to rest before 4: the bounces of such a ball accumulate at t1 + 2 v1 e / (g (1 - e)) > 5.7 —:
+    two to seven bounces each, at times no two trajectories share"""
+    rng = np.random.default_rng(5)
+    N, T = 300, 4.0
+    u0 = np.stack([rng.uniform(2.0, 9.0, N), rng.uniform(-1.0, 1.0, N)], axis=1)
+    p = np.stack([9.8 * (1 + 0.1 * rng.uniform(-1, 1, N)), rng.uniform(0.8, 0.9, N)], axis=1)
+    ts = np.array([0.3, 1.0, 1.7, 2.2, 3.1, 4.0])
+    d = rng.standard_normal((N, len(ts), 2))
+    f = model(sa, 1)
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, T), p[0]), u0, p), sa.Tsit5(), saveat=ts, sensealg=sens(sa, alg), abstol=1e-10, reltol=1e-10)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=d)
+    ne = sol.engine.event_counts(); out = np.array(sol.u)
+    sol.engine.close()
+    ref = O.Problem("FALLMASS", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, event_kind=1)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, d)
+    assert len(set(ne.tolist())) >= 3 and ne.min() >= 1
+    assert rel(out, rout) < 1e-8
+    sc = np.maximum(np.abs(rdu0), 1e-3 * np.abs(rdu0).max(axis=1, keepdims=True)); scp = np.maximum(np.abs(rdp), 1e-3 * np.abs(rdp).max(axis=1, keepdims=True))
+    assert np.max(np.abs(du0 - rdu0) / sc) < 1e-6 and np.max(np.abs(dp - rdp) / scp) < 1e-6
+    # the number of bounces in closed form: flight k lasts 2 v_k / g with v_{k+1} = e v_k
+    for i in range(0, N, 7):
+        x, v, gg, e = u0[i, 0], u0[i, 1], p[i, 0], p[i, 1]
+        t = (v + np.sqrt(v * v + 2 * gg * x)) / gg; vk = e * np.sqrt(v * v + 2 * gg * x); k = 0
+        while t < T and k < 100:
+            k += 1; t += 2 * vk / gg; vk *= e
+        assert ne[i] == k
+
+
+@pytest.mark.parametrize("alg,oalg", [ALGS[0], ALGS[1]])
+@pytest.mark.parametrize("case", ["ball", "relax"])
+def test_rosenbrock23_and_dual_number_vjps(sa, gold, case, alg, oalg):
+    kind, omodel = CASES[case]; g = gold[case]
+    du0, dp, out, ne = run(sa, model(sa, kind, auto=True), g, alg, sa.Rosenbrock23(), 1e-9)
+    assert ne.tolist() == [len(g["event_times"])]
+    a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g["du0"], g["dp"]])
+    assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-5            # the reference's bar, :140-145, on the whole gradient (relax: du0 is 5e-5 of dp[0])
+    ts = np.asarray(g["ts"])
+    ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=g["tspan"][0], t1=g["tspan"][1], dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, event_kind=kind)
+    rdu0, rdp, rout = ref.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), np.ones((len(ts), len(g["u0"]))))[:3]
+    assert rel(out[0], rout) < 1e-8 and relc(du0[0], rdu0) < 1e-6 and relc(dp, rdp) < 1e-6
+
+
+def test_more_events_than_the_list_holds_is_an_error(sa, gold):
+    g = gold["ball_long"]                     # four bounces
+    with pytest.raises(Exception) as ei:
+        run(sa, model(sa, 1, max_events=2), g, "interpolating", sa.Tsit5(), 1e-10)
+    assert "max_events" in str(ei.value)
+    du0, dp, out, ne = run(sa, model(sa, 1, max_events=4), g, "interpolating", sa.Tsit5(), 1e-10)
+    assert ne.tolist() == [4] and relc(dp, g["dp"]) < 1e-7
+
+
+def test_a_model_without_crossings_equals_the_model_without_the_callback(sa):
+    """the ball thrown upward from 50 never reaches the floor within (0, 2): the callback must change nothing, bit for bit"""
+    m = UM.BALL
+    ts = np.array([0.5, 1.0, 2.0]); u0 = np.array([[50.0, 3.0]]); p = np.array([9.8, 0.8]); d = np.ones((1, 3, 2))
+    res = []
+    for cc in (False, True):
+        f = sa.DeviceFunction(f"cc_none_{int(cc)}", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+        if cc:
+            f.set_continuous_callback("c = u[0];", "un[1] = -p[1] * u[1];")
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 2.0), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.InterpolatingAdjoint(), abstol=1e-9, reltol=1e-9)
+        res.append(sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=d) + (np.array(sol.u),))
+        if cc:
+            assert sol.engine.event_counts().tolist() == [0]
+        sol.engine.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
+def test_refusals(sa, gold):
+    from scimlsensitivity_jl_amd import _lib
+    g = gold["ball"]; f = model(sa, 1); ts = np.asarray(g["ts"]); u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
+    pr = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], tuple(g["tspan"]), p), u0)
+    for stepper, alg, kw, word in ((sa.Tsit5(), sa.BacksolveAdjoint(), {}, "Interpolating-, Gauss-"), (sa.Tsit5(), sa.QuadratureAdjoint(), {}, "Interpolating-, Gauss-"),
+                                   (sa.Tsit5(), sa.InterpolatingAdjoint(checkpointing=True), {}, "checkpointing"), (sa.RK4(), sa.InterpolatingAdjoint(), dict(dt=0.01), "adaptive steppers")):
+        with pytest.raises(_lib.HipadjError) as ei:
+            sa.solve(pr, stepper, saveat=ts, sensealg=alg, abstol=1e-8, reltol=1e-8, **kw)
+        assert ei.value.status == _lib.ERR_UNSUPPORTED and word in str(ei.value)
+    with pytest.raises(_lib.HipadjError):
+        f.set_mass_matrix([[2.0, 0.0], [0.0, 1.0]])
+    with pytest.raises(_lib.HipadjError):
+        model(sa, 1).set_continuous_callback("c = u[0];", "pn[0] = 2.0 * p[0];")
+    f.set_continuous_callback("c = u[0];", "un[1] = -p[1] * u[1];")          # (the failed call left the callback as it was — restore explicitly all the same)

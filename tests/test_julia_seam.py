@@ -54,7 +54,7 @@ def test_julia_struct_text_matches_header():
     c_offs = {m.group(1): int(m.group(2)) for m in re.finditer(r"O_(\w+) = (\d+)", c_src)}
     assert [c_offs[f] for f in c_fields] == offs                       # the C replay asserts THESE against offsetof() at compile time
     assert int(re.search(r"const CONFIG_SIZE = (\d+)", jl).group(1)) == int(re.search(r"CONFIG_SIZE = (\d+) \}", c_src).group(1))
-    assert "v == 109" in jl and "#define HIPADJ_VERSION 109" in hdr
+    assert "v == 110" in jl and "#define HIPADJ_VERSION 110" in hdr
 
 
 def test_julia_call_sequence_from_c_fails_loudly_without_a_device(tmp_path):
@@ -64,7 +64,7 @@ def test_julia_call_sequence_from_c_fails_loudly_without_a_device(tmp_path):
         pytest.skip("a GPU is present: the GPU variant of this test runs the sequence for real")
     exe = _build(sa, tmp_path)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
-    assert r.returncode == 1 and "hipadj status -2" in r.stderr and "no usable HIP device" in r.stderr and "version 109" in r.stdout
+    assert r.returncode == 1 and "hipadj status -2" in r.stderr and "no usable HIP device" in r.stderr and "version 110" in r.stdout
 
 
 @pytest.mark.gpu
@@ -128,7 +128,7 @@ def test_julia_model_calls_from_c(tmp_path):
     sa.build_extension()
     exe = _build_model_calls(sa, tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True)
-    assert "singular -6" in r.stdout and "semi_explicit 0" in r.stdout and "version 109" in r.stdout
+    assert "singular -6" in r.stdout and "semi_explicit 0" in r.stdout and "version 110" in r.stdout
     if not os.path.exists("/dev/kfd"):
         assert r.returncode == 1 and "hipadj status -2" in r.stderr and "no usable HIP device" in r.stderr
         return

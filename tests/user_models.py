@@ -64,3 +64,21 @@ ROBERDAE_MIX_F = ("const real a = -p[0]*u[0] + p[2]*u[1]*u[2]; const real b = p[
                   "du[0] = 2.0*a + 0.3*b; du[1] = 0.1*a + 0.5*b; du[2] = u[0] + u[1] + u[2] - 1.0 - 5.0*(p[0] - 0.04);")
 """roberdae_kappa(5) with its differential rows mixed by Md = [2 0.3; 0.1 0.5] and the mass matrix [Md 0; 0 0]: the same trajectory, a non-trivial M'[diff, diff] in the loss jumps
 and off-diagonal mass entries in W (oracle: ROBERDAE with dims = (5, 1)).  f only: VJPs by dual numbers."""
+
+# ContinuousCallback problems (oracle: event_kind of oracle/adjoint_oracle.h; test/Callbacks2/continuous_callbacks.jl)
+BALL = dict(  # `fiip` of test/Callbacks2/continuous_callbacks.jl:10-14 (oracle: ORC_MODEL_FALLMASS); p2 enters through the affect only
+    n=2, np=2,
+    f="du[0] = u[1]; du[1] = -p[0];",
+    vjp="out[0] = 0.0; out[1] = lam[0];",
+    vjp_p="out[0] = -lam[1]; out[1] = 0.0;")
+RELAX = dict(  # `f` of the "Re-compile tape" testset, :320 (oracle: ORC_MODEL_RELAX)
+    n=1, np=2,
+    f="du[0] = p[0] - u[0];",
+    vjp="out[0] = -lam[0];",
+    vjp_p="out[0] = lam[0]; out[1] = 0.0;")
+EVENTS = {  # event_kind -> (model, condition body, affect body)
+    1: (BALL, "c = u[0];", "un[1] = -p[1] * u[1];"),                               # :212-217
+    2: (BALL, "c = u[0];", "un[0] = u[0] + 3.0; un[1] = u[1] * u[1];"),            # :243-250
+    3: (RELAX, "c = u[0] - 0.75 * p[0];", "un[0] = u[0] + p[1];"),                 # :324-327
+    4: (BALL, "c = u[0] - 0.3 * t;", "un[1] = -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t;"),   # NOT from the reference: explicit t in both
+}
