@@ -7,7 +7,7 @@ from ._lib import HipadjError, model_sizes, load as load_library, LIB_PATH
 from .sensitivity_algorithms import (AbstractSensitivityAlgorithm, AbstractAdjointSensitivityAlgorithm, DeviceVJP,
                                      InterpolatingAdjoint, BacksolveAdjoint, QuadratureAdjoint, GaussAdjoint, GaussKronrodAdjoint,
                                      ischeckpointing)
-from .problems import (RK4, ETDRK4, Tsit5, Rosenbrock23, DeviceFunction, WideDeviceFunction, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, LsqData, ModelLoss, HalfSquaredSum, PresetTimeCallback,
+from .problems import (RK4, ETDRK4, Tsit5, Rosenbrock23, DeviceFunction, WideDeviceFunction, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, LsqData, ModelLoss, HalfSquaredSum, PresetTimeCallback, ContinuousCallback,
                        FirstStateSquaredPlusFirstParam, ModelCost)
 from .engine import Engine
 from .interface import solve, adjoint_sensitivities, concrete_solve_adjoint, make_autograd_function
@@ -21,6 +21,6 @@ __all__ = [
     "HipadjError", "model_sizes", "load_library", "LIB_PATH", "AbstractSensitivityAlgorithm",
     "AbstractAdjointSensitivityAlgorithm", "DeviceVJP", "InterpolatingAdjoint", "BacksolveAdjoint",
     "QuadratureAdjoint", "GaussAdjoint", "GaussKronrodAdjoint", "ischeckpointing", "RK4", "ETDRK4", "Tsit5", "Rosenbrock23", "DeviceFunction", "WideDeviceFunction", "ODEProblem", "EnsembleProblem",
-    "EnsembleSolution", "LsqShift", "LsqData", "ModelLoss", "HalfSquaredSum", "FirstStateSquaredPlusFirstParam", "ModelCost", "Engine", "solve", "adjoint_sensitivities", "concrete_solve_adjoint",
+    "EnsembleSolution", "ContinuousCallback", "LsqShift", "LsqData", "ModelLoss", "HalfSquaredSum", "FirstStateSquaredPlusFirstParam", "ModelCost", "Engine", "solve", "adjoint_sensitivities", "concrete_solve_adjoint",
     "make_autograd_function", "shard_range", "allreduce_dp", "gather_du0", "comm_unique_id", "init_native_allreduce", "build_extension",
 ]

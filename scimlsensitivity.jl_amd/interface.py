@@ -14,7 +14,9 @@ import numpy as np
 from . import _lib
 from .engine import Engine
 from .problems import (RK4, ETDRK4, Tsit5, Rosenbrock23, ODEProblem, EnsembleProblem, EnsembleSolution, LsqShift, LsqData, ModelLoss, HalfSquaredSum,
-                       FirstStateSquaredPlusFirstParam, ModelCost)
+                       FirstStateSquaredPlusFirstParam, ModelCost, ContinuousCallback)
+
+_attached_callbacks = {}      # model id -> the ContinuousCallback solve(...) attached last
 from .sensitivity_algorithms import (AbstractAdjointSensitivityAlgorithm, InterpolatingAdjoint, BacksolveAdjoint,
                                      QuadratureAdjoint, GaussAdjoint, GaussKronrodAdjoint, ischeckpointing)
 
@@ -104,6 +106,14 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
     hipadj_config.family, csrc/hipadj_route.hpp; `sol.extra["mfma_routed"]` says so); False — the family the model was registered for; True — raise unless routed."""
     if mfma not in (None, True, False):
         raise ValueError("mfma must be None (the library selects the kernel family), True (insist on the FP64-MFMA family) or False (the family the model was registered for)")
+    if isinstance(callback, ContinuousCallback):      # a property of the model on the device: events located per trajectory inside the kernels (DESIGN.md section 4.12)
+        mid = _lib.MODEL[ensprob.prob.f]
+        if mid < _lib.MODEL_USER_BASE:
+            raise ValueError("ContinuousCallback needs a runtime lane model (DeviceFunction): condition and affect are compiled next to its right-hand side")
+        if _attached_callbacks.get(mid) != callback:      # (re-attaching bumps the model's revision: a new code object)
+            _lib.set_model_continuous_callback(mid, callback.condition, callback.affect, callback.max_events)
+            _attached_callbacks[mid] = callback
+        callback = None
     if callback is not None:       # DiscreteCallback at preset times: a chain of ordinary pieces (events.py)
         from . import events
         return events.solve_with_events(solve, _save_times, ensprob, alg, callback, dt=dt, saveat=saveat, sensealg=sensealg, dgdu_discrete=dgdu_discrete, checkpoints=checkpoints,

@@ -460,6 +460,38 @@ def test_c_stiff_dae_example_compiles_and_fails_loudly_without_a_device(sa, tmp_
     assert r.returncode == 1 and "hipadj_create" in r.stderr and "no usable HIP device" in r.stderr
 
 
+def test_c_bouncing_ball_example_compiles_and_fails_loudly_without_a_device(sa, tmp_path):
+    """examples/bouncing_ball_demo.c (the reference's ContinuousCallback problem through the C ABI: f, condition and affect as text): strict C99 against include/hipadj.h;
+    registration and hipadj_model_set_continuous_callback succeed without a device, hipadj_create reports HIPADJ_ERR_NO_DEVICE."""
+    import subprocess
+    sa.load_library()
+    exe = str(tmp_path / "bouncing_ball_demo")
+    libdir = os.path.dirname(sa.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "bouncing_ball_demo.c"),
+                           "-o", exe, "-L" + libdir, "-lhipadj", "-Wl,-rpath," + libdir, "-lm"])
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a device is present: the GPU suite runs the example (tests/test_gpu_continuous_callbacks.py)")
+    r = subprocess.run([exe, "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "hipadj_create" in r.stderr and "no usable HIP device" in r.stderr
+
+
+def test_solve_attaches_a_continuous_callback_to_the_model(sa, monkeypatch):
+    """solve(...; callback = ContinuousCallback(condition, affect)): the host mirror hands the two bodies to hipadj_model_set_continuous_callback ONCE per (model, callback) and
+    refuses compiled-in models (no text to compile the bodies next to)"""
+    from scimlsensitivity_jl_amd import _lib, interface
+    calls = []
+    monkeypatch.setattr(_lib, "set_model_continuous_callback", lambda *a: calls.append(a))
+    monkeypatch.setattr(interface, "Engine", _StubEngine)
+    f = sa.DeviceFunction("cc_host_mirror", 2, 2, "du[0] = u[1]; du[1] = -p[0];")
+    cb = sa.ContinuousCallback("c = u[0];", "un[1] = -p[1] * u[1];", 32)
+    u0 = np.array([[5.0, 0.0]]); p = np.array([9.8, 0.8])
+    for _ in range(2):
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 2.5), p), u0), sa.Tsit5(), saveat=[0.5, 2.5], sensealg=sa.InterpolatingAdjoint(), abstol=1e-8, reltol=1e-8, callback=cb)
+    assert calls == [(f.id, "c = u[0];", "un[1] = -p[1] * u[1];", 32)]
+    with pytest.raises(ValueError, match="runtime lane model"):
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem("fallmass", u0[0], (0.0, 2.5), p), u0), sa.Tsit5(), saveat=[0.5, 2.5], sensealg=sa.InterpolatingAdjoint(), abstol=1e-8, reltol=1e-8, callback=cb)
+
+
 class _StubEngine:
     """Stands in for the device handle (which needs a GPU) so that the HOST logic of interface.py — argument mapping, saving rules,
     cotangent packing, dgdp_discrete, error paths — runs in the CPU suite.  It records the configuration it was created with and

@@ -171,3 +171,47 @@ def test_refusals(sa, gold):
     with pytest.raises(_lib.HipadjError):
         model(sa, 1).set_continuous_callback("c = u[0];", "pn[0] = 2.0 * p[0];")
     f.set_continuous_callback("c = u[0];", "un[1] = -p[1] * u[1];")          # (the failed call left the callback as it was — restore explicitly all the same)
+
+
+def test_the_solve_keyword_attaches_the_callback(sa, gold):
+    """solve(...; callback = ContinuousCallback(condition, affect!)) as the reference writes it (test/Callbacks2/continuous_callbacks.jl:37-45)"""
+    g = gold["ball"]; m = UM.BALL; ts = np.asarray(g["ts"]); u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
+    f = sa.DeviceFunction("cc_keyword_ball", m["n"], m["np"], m["f"])                 # f only: VJPs by dual numbers
+    cb = sa.ContinuousCallback("c = u[0];", "un[1] = -p[1] * u[1];")
+    for _ in range(2):                                                                # (the second solve finds the callback attached: no new code object)
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], tuple(g["tspan"]), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.InterpolatingAdjoint(), abstol=1e-12, reltol=1e-12, callback=cb)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=np.ones((1, len(ts), 2)))
+        assert sol.engine.event_counts().tolist() == [1]
+        sol.engine.close()
+        assert relc(du0[0], g["du0"]) < 1e-9 and relc(dp, g["dp"]) < 1e-9
+    with pytest.raises(ValueError):
+        sa.solve(sa.EnsembleProblem(sa.ODEProblem("fallmass", u0[0], tuple(g["tspan"]), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.InterpolatingAdjoint(), abstol=1e-8, reltol=1e-8, callback=cb)
+
+
+@pytest.mark.parametrize("alg", [0, 2, 4])
+def test_c_example_of_the_bouncing_ball_matches_the_closed_form(sa, gold, tmp_path, alg):
+    """examples/bouncing_ball_demo.c: plain C against include/hipadj.h — hipadj_model_register (f only), hipadj_model_set_continuous_callback, a Tsit5 handle, host-pointer
+    forward / event counts / adjoint; trajectory 0 is the reference's problem."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe, libdir = str(tmp_path / "bouncing_ball_demo"), os.path.dirname(sa.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "bouncing_ball_demo.c"),
+                           "-o", exe, "-L" + libdir, "-lhipadj", "-Wl,-rpath," + libdir, "-lm"])
+    r = subprocess.run([exe, "5", str(alg)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    val = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.strip().split("\n")}
+    g = gold["ball"]
+    assert relc(val["du0"], g["du0"]) < 1e-9 and relc(val["dp"], g["dp"]) < 1e-9
+    assert np.max(np.abs(val["u_at_2.5"] - np.asarray(g["u_at_ts"])[-1])) < 1e-9
+    assert val["events"].tolist() == [1, 1, 1, 1, 1] and val["rk4_on_the_callback"][0] == -6
+    assert np.all(np.isfinite(val["dp_last"])) and relc(val["dp_last"], val["dp"]) > 1e-3
+
+
+def test_python_example_of_the_bouncing_ball(sa, gold):
+    import subprocess, sys
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "bouncing_ball.py"), "256"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    dev = [l for l in r.stdout.splitlines() if l.startswith("device")][0]
+    nums = [float(x) for x in dev.replace("[", " ").replace("]", " ").replace(",", " ").split() if x.replace(".", "").replace("-", "").replace("e", "").replace("+", "").isdigit()]
+    assert relc(nums[:2], gold["ball"]["du0"]) < 1e-6 and relc(nums[2:4], gold["ball"]["dp"]) < 1e-6
