@@ -696,6 +696,28 @@ def other_configs(sa, torch):
     except Exception as e:
         _mark("Rosenbrock23: Robertson at the stiff rates")
         out.append(dict(config="Rosenbrock23: Robertson at the stiff rates", error=repr(e)))
+    # ContinuousCallback (round 6): the reference's bouncing ball (test/Callbacks2/continuous_callbacks.jl:10-14, 212-217) as an ensemble in which every trajectory has its own bounces;
+    # f, condition and affect as text (hiprtc), adaptive Tsit5 at 1e-6 (scripts/r6/bench_continuous_callback.py has the full table, also without the callback)
+    try:
+        ball = sa.DeviceFunction("ball_bench_line", 2, 2, "du[0] = u[1]; du[1] = -p[0];", "out[0] = 0.0; out[1] = lam[0];", "out[0] = -lam[1]; out[1] = 0.0;")
+        ball.set_continuous_callback("c = u[0];", "un[1] = -p[1] * u[1];")
+        Nb = 65536
+        ub = np.stack([rng.uniform(2.0, 9.0, Nb), rng.uniform(-1.0, 1.0, Nb)], axis=1)
+        pb = np.stack([9.8 * (1 + 0.1 * rng.uniform(-1, 1, Nb)), rng.uniform(0.8, 0.9, Nb)], axis=1)
+        tsb = np.array([0.3, 1.0, 1.7, 2.2, 3.1, 4.0]); db = rng.standard_normal((Nb, len(tsb), 2))
+        for alg in ("interpolating", "gauss"):
+            eng = sa.Engine(ball.name, alg, Nb, 0.0, 4.0, 0.0, save_times=tsb, loss_kind=0, p_shared=False, stepper=1, abstol=1e-6, reltol=1e-6)
+            ms, kms, st = run(eng, ub, pb, db, 3)
+            ne = eng.event_counts()
+            _mark("ContinuousCallback: bouncing balls")
+            out.append(dict(config=f"ContinuousCallback (round 6): {Nb} bouncing balls dropped from 2 .. 9 with restitution 0.8 .. 0.9 over (0, 4), runtime model with condition and affect as text, adaptive Tsit5 1e-6, {alg}",
+                            forward_ms=st["forward_ms_last"], reverse_ms=ms, main_kernel_ms=kms, gradients_per_s=Nb / ((st["forward_ms_last"] + ms) * 1e-3),
+                            events_per_trajectory=dict(min=int(ne.min()), mean=float(ne.mean()), max=int(ne.max())),
+                            roofline=dict(bound="one wave's instruction stream (per-lane step control and event search)", note="adaptive per-lane stepping: no fixed byte or flop count per launch")))
+            eng.close()
+    except Exception as e:
+        _mark("ContinuousCallback: bouncing balls")
+        out.append(dict(config="ContinuousCallback: bouncing balls", error=repr(e)))
     return out
 
 
