@@ -9,7 +9,7 @@
 # Every case targets one [upstream-recall] assumption of the oracle (DESIGN.md §5 table): the behaviour lives in OrdinaryDiffEq /
 # DiffEqCallbacks / QuadGK, which are not vendored in the reference tree, so the oracle restates it from the published algorithms
 # and only a run of the real packages can confirm it.
-using SciMLSensitivity, OrdinaryDiffEq, JSON
+using SciMLSensitivity, OrdinaryDiffEq, JSON, Zygote
 
 lorenz!(du, u, p, t) = (du[1] = p[1] * (u[2] - u[1]); du[2] = u[1] * (p[2] - u[3]) - u[2]; du[3] = u[1] * u[2] - p[3] * u[3]; nothing)   # test/Core3/adjoint.jl:1160-1166
 lv!(du, u, p, t) = (du[1] = p[1] * u[1] - p[2] * u[1] * u[2]; du[2] = -p[3] * u[2] + p[4] * u[1] * u[2]; nothing)                     # test/Core3/user_vjp.jl:6-10
@@ -218,6 +218,39 @@ let Mdae = [1.0 0 0; 0 1.0 0; 0 0 0], p = [0.04, 3.0e7, 1.0e4], ts = [50.0, 100.
                           "ts" => ts, "u0" => [1.0, 0.0, 1.0], "p" => p, "mass_matrix" => [collect(Mdae[i, :]) for i in 1:3], "du0" => collect(du0), "dp" => vec(collect(dp)),
                           "forward_steps" => length(sol.t) - 1, "out" => [collect(sol(t)) for t in ts],
                           "targets" => "mass-matrix Rosenbrock23, BrownFullBasicInit, the DAE loss jump and its parameter term, re-initialised algebraic adjoints"))
+    end
+end
+
+# (12) (round 6) ContinuousCallback, test/Callbacks2/continuous_callbacks.jl: the bouncing ball with save_positions = (false, false) (:219-224) and the "Re-compile tape" problem
+#      (:314-346) whose condition depends on a parameter: pins the event location (the event time itself is recorded), the reverse jump with its event-time term and — the one
+#      term the closed forms need that a reading of src/callback_tracking.jl:375-437 does not find — kappa c_p (adjoint_oracle.c section 3b).
+function ball!(du, u, p, t)
+    du[1] = u[2]; du[2] = -p[1]
+    return nothing
+end
+relax!(du, u, p, t) = (du[1] = p[1] - u[1]; nothing)
+let
+    dg1(out, u, p, t, i) = (out .= 1)
+    event_times = Float64[]
+    cond_ball(u, t, integrator) = u[1]
+    aff_ball!(integrator) = (push!(event_times, integrator.t); integrator.u[2] = -integrator.p[2] * integrator.u[2])
+    cond_relax(u, t, integrator) = u[1] - 3 // 4 * integrator.p[1]
+    aff_relax!(integrator) = (push!(event_times, integrator.t); integrator.u[1] += integrator.p[2])
+    for (model, f!, u0, p, tspan, ts, cond, aff!, kind) in (("FALLMASS", ball!, [5.0, 0.0], [9.8, 0.8], (0.0, 2.5), collect(0.0:0.5:2.5), cond_ball, aff_ball!, 1),
+                                                           ("FALLMASS", ball!, [5.0, 0.0], [9.8, 0.8], (0.0, 5.0), collect(0.0:0.5:5.0), cond_ball, aff_ball!, 1),
+                                                           ("RELAX", relax!, [0.0], [100.0, 50.0], (0.0, 10.0), [10.0], cond_relax, aff_relax!, 3))
+        cb = ContinuousCallback(cond, aff!, save_positions = (false, false))
+        prob = ODEProblem(f!, u0, tspan, p)
+        for (nm, sa) in (("INTERPOLATING", InterpolatingAdjoint()), ("GAUSS", GaussAdjoint()), ("BACKSOLVE", BacksolveAdjoint()))
+            empty!(event_times)
+            sol = solve(prob, Tsit5(); callback = cb, abstol = 1e-12, reltol = 1e-12, saveat = ts)
+            ev = copy(event_times)
+            du0, dp = Zygote.gradient((u0_, p_) -> sum(Array(solve(prob, Tsit5(); u0 = u0_, p = p_, callback = cb, abstol = 1e-12, reltol = 1e-12, saveat = ts, sensealg = sa))), u0, p)
+            push!(cases, Dict("name" => "continuous_callback_$(model)_$(tspan[2])_$nm", "kind" => "continuous_callback", "model" => model, "event_kind" => kind, "alg" => nm, "stepper" => "TSIT5",
+                              "tspan" => collect(tspan), "abstol" => 1e-12, "reltol" => 1e-12, "ts" => ts, "u0" => u0, "p" => p, "du0" => collect(du0), "dp" => collect(dp),
+                              "event_times" => ev, "out" => [collect(sol(t)) for t in ts],
+                              "targets" => "event location on the dense output, the event-time term of the reverse jump, kappa c_p (RELAX), Backsolve through events (not built here)"))
+        end
     end
 end
 
