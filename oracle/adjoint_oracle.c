@@ -1652,7 +1652,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
     if (cfg->stepper == ORC_STEPPER_ROS23 && cfg->alg == ORC_ALG_BACKSOLVE && g_mm_dae) return -6;   /* Backsolve on the stiff stepper: ODE models (see backsolve_jac; the cost's second-derivative blocks are dropped from W like the model's) */
-    if (cfg->event_kind && (cfg->alg == ORC_ALG_BACKSOLVE || cfg->alg == ORC_ALG_QUADRATURE || cfg->checkpointing || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* section 3b */
+    if (cfg->event_kind && (cfg->alg == ORC_ALG_QUADRATURE || (cfg->checkpointing && cfg->alg != ORC_ALG_BACKSOLVE) || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* section 3b */
     if (g_mm_dae && (cfg->stepper != ORC_STEPPER_ROS23 || g_dae_n != n || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* semi-explicit DAE: Rosenbrock23, discrete losses by cotangent / shift / data */   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
@@ -1730,7 +1730,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
         /* section 3b: piece e = nev .. 0 lies between event e - 1 (or t0) and event e (or T); the stops of a piece are the loss times inside it */
         double *pts = (double *)malloc(sizeof(double) * (size_t)(nts + 1));
         double *w = (double *)calloc((size_t)6 * n + 2 * (size_t)np, sizeof(double)), *ym = w, *yp = w + n, *fm = w + 2 * n, *fp = w + 3 * n, *gu = w + 4 * n, *jf = w + 5 * n, *gp = w + 6 * n, *go = gp + np;
-        A.use_win = 1;
+        A.use_win = (cfg->alg != ORC_ALG_BACKSOLVE);
         for (int e = sol.nev; e >= 0 && st == 0; --e) {
             const double t_hi = (e == sol.nev) ? cfg->t1 : sol.t0[sol.ev_s[e]], t_lo = (e == 0) ? cfg->t0 : sol.t0[sol.ev_s[e - 1]];
             A.win_lo = (e == 0) ? 0 : sol.ev_s[e - 1]; A.win_hi = (e == sol.nev) ? sol.nsteps - 1 : sol.ev_s[e] - 1;
@@ -1741,6 +1741,9 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             const double tev = t_lo; const long sm = sol.ev_s[e - 1] - 1, sp = sol.ev_s[e - 1];
             double gt = 0.0, num = 0.0, den = 0.0;
             dense_eval_step(&sol, sm, tev, ym); dense_eval_step(&sol, sp, tev, yp);
+            if (cfg->alg == ORC_ALG_BACKSOLVE) {      /* y+ is the backsolved state; the y block goes on from the stored left state (copy_to_integrator!, src/callback_tracking.jl:377) */
+                memcpy(yp, z + n + np, sizeof(double) * n); memcpy(z + n + np, ym, sizeof(double) * n);
+            }
             model_f(m, fm, ym, p, tev); model_f(m, fp, yp, p, tev);
             ev_cond_grad(cfg->event_kind, n, np, ym, p, tev, gu, gp, &gt);
             ev_affect_jvp(cfg->event_kind, n, jf, ym, fm, p, tev);
@@ -1748,7 +1751,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             const double kappa = num / (den + gt);
             ev_affect_vjp(cfg->event_kind, n, np, A.scratch, go, z, ym, p, tev);       /* scratch[0..n) = a_u' lam+ */
             for (int i = 0; i < n; ++i) z[i] = A.scratch[i] - kappa * gu[i];
-            double *acc = (cfg->alg == ORC_ALG_INTERPOLATING) ? z + n : A.gauss_acc;
+            double *acc = (cfg->alg == ORC_ALG_INTERPOLATING || cfg->alg == ORC_ALG_BACKSOLVE) ? z + n : A.gauss_acc;
             for (int i = 0; i < np; ++i) acc[i] += go[i] - kappa * gp[i];
         }
         free(pts); free(w);

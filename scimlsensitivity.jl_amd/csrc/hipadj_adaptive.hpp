@@ -47,7 +47,9 @@ struct AdaptGeom {
     int SmaxA;                 // QuadratureAdjoint: capacity (steps) of the dense ADJOINT record; its readers clamp the stored TRUE step count with it
     // ContinuousCallback (model_has_cond): per trajectory, the index of the first forward record AFTER each event (that record starts at the event time, from the affected
     // state), ascending in time — ev_s [maxev][Npad] — and the TRUE number of events — nev [Npad]; maxev = 0: no event handling
-    int maxev = 0; int* ev_s = nullptr; int* nev = nullptr;
+    // ... the event times ev_t [maxev][Npad] and the states just BEFORE the affect ev_ul [maxev][n][Npad] (BacksolveAdjoint keeps no forward record: at an event its
+    // backsolved state is overwritten with the stored left state, as at a checkpoint — src/callback_tracking.jl:377 copy_to_integrator!)
+    int maxev = 0; int* ev_s = nullptr; int* nev = nullptr; double* ev_t = nullptr; double* ev_ul = nullptr;
 };
 
 // Tsit5 coefficients (Tsitouras 2011); same values as oracle/adjoint_oracle.c (order conditions checked there).
@@ -828,6 +830,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             double h = t - tprev;
             double c[5][N];
             bool event = false;
+            double uleft[model_has_cond<Mo>::value ? N : 1];
             if constexpr (STEP == 1) ros23_poly<N>(KK, h, c); else tsit5_poly<N>(KK, h, c);
             if constexpr (model_has_cond<Mo>::value) {
                 if (g.maxev > 0 && h != 0.0) {
@@ -864,6 +867,8 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                                 for (int q = 0; q < N; ++q) c[m][q] *= r;
                                 r *= thb; }
                             Mo::cc_affect(un, y, pv, tev);
+#pragma unroll
+                            for (int q = 0; q < N; ++q) uleft[q] = y[q];
                             t = tev; h = tev - tprev; nudge = true; event = true;
                         }
                     }
@@ -881,7 +886,11 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             ++s;
             if constexpr (model_has_cond<Mo>::value) {
                 if (event) {
-                    if (nevl < g.maxev) g.ev_s[(long)nevl * g.Npad + i] = s;
+                    if (nevl < g.maxev) {
+                        g.ev_s[(long)nevl * g.Npad + i] = s; g.ev_t[(long)nevl * g.Npad + i] = t;
+#pragma unroll
+                        for (int q = 0; q < N; ++q) g.ev_ul[((long)nevl * N + q) * g.Npad + i] = uleft[q];
+                    }
                     else { overflow = true; t = g.t1; }      // more events than the list holds (an accumulation point of events, or max_events too small): reported, and the solve ends here
                     ++nevl;
                 }
@@ -1367,29 +1376,34 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     return na;
     };
     int na = 0;
-    if constexpr (model_has_cond<Mo>::value && (ALG == 0 || ALG == 2 || ALG == 4) && !CK && CC == 0) {
+    if constexpr (model_has_cond<Mo>::value && (ALG == 0 || ALG == 1 || ALG == 2 || ALG == 4) && !CK && CC == 0) {
         {
             // ContinuousCallback (the oracle's section 3b; src/callback_tracking.jl:232-479 with save_positions = (false, false)): the reverse solve runs piece by piece between
             // this trajectory's events (a fresh solve per piece: the controller restarts) and at each event, - / + the limits from below / above,
             //     kappa = lam+ . (a_u f- + a_t - f+) / (c_u . f- + c_t)      lam- = a_u' lam+ - kappa c_u      dp += a_p' lam+ - kappa c_p
             // A loss time that coincides with an event is taken at the end of the piece above it (it sees the affected state).
             // (ONE call site of the integrator: without events the loop runs once over the whole span)
-            constexpr int RWf = 2 + 5 * N;
+            // BacksolveAdjoint (z = [lam; mu; y], no forward record): y+ is the backsolved state, y- the left state the forward solve stored; the y block goes on from y-
             const int nevl = g.maxev > 0 ? (g.nev[i] < g.maxev ? g.nev[i] : g.maxev) : 0;
-            cur.smin = nevl > 0 ? g.ev_s[(long)(nevl - 1) * g.Npad + i] : 0;
+            if constexpr (ALG != 1) cur.smin = nevl > 0 ? g.ev_s[(long)(nevl - 1) * g.Npad + i] : 0;
 #pragma unroll 1
             for (int e = nevl; e >= 0; --e) {
-                const double t_hi = (e == nevl) ? g.t1 : rec[((long)g.ev_s[(long)e * g.Npad + i] * RWf + 0) * g.Npad + i];
-                const int sp = e > 0 ? g.ev_s[(long)(e - 1) * g.Npad + i] : 0;
-                const double t_lo = e > 0 ? rec[((long)sp * RWf + 0) * g.Npad + i] : g.t0;
+                const double t_hi = (e == nevl) ? g.t1 : g.ev_t[(long)e * g.Npad + i];
+                const double t_lo = e > 0 ? g.ev_t[(long)(e - 1) * g.Npad + i] : g.t0;
                 const int r = run_piece(t_hi, t_lo, e == nevl && cb_at_init);
                 if (r < 0) { na = -1; break; }
                 na += r;
                 if (e == 0) break;
                 double yp[N], ym[N], fm[N], fp[N], gu[N], gp[NP], jf[N], lo[N], go[NP], lamv[N], gt = 0.0;
-                cur.eval(t_lo, yp);
-                cur.below(sp - 1, e >= 2 ? g.ev_s[(long)(e - 2) * g.Npad + i] : 0);
-                cur.eval(t_lo, ym);
+                if constexpr (ALG == 1) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { yp[j] = z[N + NP + j]; ym[j] = g.ev_ul[((long)(e - 1) * N + j) * g.Npad + i]; z[N + NP + j] = ym[j]; }
+                } else {
+                    const int sp = g.ev_s[(long)(e - 1) * g.Npad + i];
+                    cur.eval(t_lo, yp);
+                    cur.below(sp - 1, e >= 2 ? g.ev_s[(long)(e - 2) * g.Npad + i] : 0);
+                    cur.eval(t_lo, ym);
+                }
                 Mo::f(fm, ym, pv, t_lo); Mo::f(fp, yp, pv, t_lo);
                 Mo::cond_grad(gu, gp, gt, ym, pv, t_lo);
                 Mo::cc_affect_jvp(jf, ym, fm, pv, t_lo);
@@ -1401,7 +1415,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
                 for (int j = 0; j < N; ++j) z[j] = lo[j] - kappa * gu[j];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) { if constexpr (ALG == 0) z[N + j] += go[j] - kappa * gp[j]; else gacc[j] += go[j] - kappa * gp[j]; }
+                for (int j = 0; j < NP; ++j) { if constexpr (ALG == 0 || ALG == 1) z[N + j] += go[j] - kappa * gp[j]; else gacc[j] += go[j] - kappa * gp[j]; }
             }
         }
     } else na = run_piece(g.t1, g.t0, cb_at_init);

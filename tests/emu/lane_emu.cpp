@@ -437,7 +437,8 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     std::vector<double> cotT(cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
     std::vector<int> nsteps((size_t)Np, 0);
     std::vector<int> ev_s(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * Np : 0), nev(model_has_cond<Mo>::value ? (size_t)Np : 0);      // ContinuousCallback: the event lists (hipadj_api.hip d_ev_s / d_nev)
-    if (model_has_cond<Mo>::value) { g.maxev = EMU_MAXEV; g.ev_s = ev_s.data(); g.nev = nev.data(); }
+    std::vector<double> ev_t(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * Np : 0), ev_ul(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * N * Np : 0);
+    if (model_has_cond<Mo>::value) { g.maxev = EMU_MAXEV; g.ev_s = ev_s.data(); g.nev = nev.data(); g.ev_t = ev_t.data(); g.ev_ul = ev_ul.data(); }
     int flag = 0;
     std::vector<double> kbuf((size_t)KS_ROWS * (2 * N + NP)), kfbuf((size_t)KS_ROWS * N);   // stage storage of one lane (LDS columns on the device), stride 1 here
     for (long i = 0; i < P.N; ++i)

@@ -22,7 +22,7 @@ from test_gpu_parity import rel
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-ALGS = [("interpolating", "INTERPOLATING"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")]
+ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")]
 CASES = {"ball": (1, "FALLMASS"), "ball_long": (1, "FALLMASS"), "ball_mse": (2, "FALLMASS"), "relax": (3, "RELAX"), "moving": (4, "FALLMASS")}
 _registered = {}
 
@@ -33,7 +33,7 @@ def relc(a, b):
 
 
 def sens(sa, alg):
-    return {"interpolating": sa.InterpolatingAdjoint(), "gauss": sa.GaussAdjoint(), "gausskronrod": sa.GaussKronrodAdjoint()}[alg]
+    return {"interpolating": sa.InterpolatingAdjoint(), "backsolve": sa.BacksolveAdjoint(checkpointing=False), "gauss": sa.GaussAdjoint(), "gausskronrod": sa.GaussKronrodAdjoint()}[alg]
 
 
 @pytest.fixture(scope="module")
@@ -116,7 +116,7 @@ def test_an_ensemble_where_every_trajectory_has_its_own_events(sa, alg, oalg):
         assert ne[i] == k
 
 
-@pytest.mark.parametrize("alg,oalg", [ALGS[0], ALGS[1]])
+@pytest.mark.parametrize("alg,oalg", ALGS[:3])
 @pytest.mark.parametrize("case", ["ball", "relax"])
 def test_rosenbrock23_and_dual_number_vjps(sa, gold, case, alg, oalg):
     kind, omodel = CASES[case]; g = gold[case]
@@ -128,6 +128,19 @@ def test_rosenbrock23_and_dual_number_vjps(sa, gold, case, alg, oalg):
     ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=g["tspan"][0], t1=g["tspan"][1], dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, event_kind=kind)
     rdu0, rdp, rout = ref.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), np.ones((len(ts), len(g["u0"]))))[:3]
     assert rel(out[0], rout) < 1e-8 and relc(du0[0], rdu0) < 1e-6 and relc(dp, rdp) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["ball", "ball_long", "relax"])
+def test_backsolve_with_checkpoints_through_events(sa, gold, case):
+    """BacksolveAdjoint() as the reference's callback tests call it (checkpointing = true, the default; test/Callbacks2/continuous_callbacks.jl:46-57): the backsolved state is
+    overwritten at the checkpoints (the save times) and, with the stored left state, at every event"""
+    kind, omodel = CASES[case]; g = gold[case]; ts = np.asarray(g["ts"]); n = len(g["u0"])
+    u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model(sa, kind), u0[0], tuple(g["tspan"]), p), u0), sa.Tsit5(), saveat=ts, sensealg=sa.BacksolveAdjoint(), abstol=1e-12, reltol=1e-12)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=np.ones((1, len(ts), n)))
+    sol.engine.close()
+    a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g["du0"], g["dp"]])
+    assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-9
 
 
 def test_more_events_than_the_list_holds_is_an_error(sa, gold):
@@ -161,7 +174,7 @@ def test_refusals(sa, gold):
     from scimlsensitivity_jl_amd import _lib
     g = gold["ball"]; f = model(sa, 1); ts = np.asarray(g["ts"]); u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
     pr = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], tuple(g["tspan"]), p), u0)
-    for stepper, alg, kw, word in ((sa.Tsit5(), sa.BacksolveAdjoint(), {}, "Interpolating-, Gauss-"), (sa.Tsit5(), sa.QuadratureAdjoint(), {}, "Interpolating-, Gauss-"),
+    for stepper, alg, kw, word in ((sa.Tsit5(), sa.QuadratureAdjoint(), {}, "Interpolating-, Backsolve-, Gauss-"), (sa.Tsit5(), sa.GaussAdjoint(checkpointing=True), {}, "checkpointing"),
                                    (sa.Tsit5(), sa.InterpolatingAdjoint(checkpointing=True), {}, "checkpointing"), (sa.RK4(), sa.InterpolatingAdjoint(), dict(dt=0.01), "adaptive steppers")):
         with pytest.raises(_lib.HipadjError) as ei:
             sa.solve(pr, stepper, saveat=ts, sensealg=alg, abstol=1e-8, reltol=1e-8, **kw)
