@@ -1652,7 +1652,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
     if (cfg->stepper == ORC_STEPPER_ROS23 && cfg->alg == ORC_ALG_BACKSOLVE && g_mm_dae) return -6;   /* Backsolve on the stiff stepper: ODE models (see backsolve_jac; the cost's second-derivative blocks are dropped from W like the model's) */
-    if (cfg->event_kind && (cfg->alg == ORC_ALG_QUADRATURE || (cfg->checkpointing && cfg->alg != ORC_ALG_BACKSOLVE) || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* section 3b */
+    if (cfg->event_kind && ((cfg->checkpointing && cfg->alg != ORC_ALG_BACKSOLVE) || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* section 3b */
     if (g_mm_dae && (cfg->stepper != ORC_STEPPER_ROS23 || g_dae_n != n || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* semi-explicit DAE: Rosenbrock23, discrete losses by cotangent / shift / data */   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
@@ -1736,7 +1736,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             A.win_lo = (e == 0) ? 0 : sol.ev_s[e - 1]; A.win_hi = (e == sol.nev) ? sol.nsteps - 1 : sol.ev_s[e] - 1;
             int npts = 0;
             for (int i = 0; i < nts; ++i) if (tst[i] >= t_lo && tst[i] <= t_hi) pts[npts++] = tst[i];      /* (a loss time that coincides with an event belongs to the piece above it: it sees the affected state) */
-            st = integrate(rhs, &A, nz, z, t_hi, t_lo, &alg, pts, npts, adjoint_step_cb, &A, e == sol.nev ? cb_at_init : 0, NULL, nrhs);
+            st = integrate(rhs, &A, nz, z, t_hi, t_lo, &alg, pts, npts, adjoint_step_cb, &A, e == sol.nev ? cb_at_init : 0, have_rec ? &adjrec : NULL, nrhs);
             if (e == 0 || st) break;
             const double tev = t_lo; const long sm = sol.ev_s[e - 1] - 1, sp = sol.ev_s[e - 1];
             double gt = 0.0, num = 0.0, den = 0.0;
@@ -1751,10 +1751,11 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             const double kappa = num / (den + gt);
             ev_affect_vjp(cfg->event_kind, n, np, A.scratch, go, z, ym, p, tev);       /* scratch[0..n) = a_u' lam+ */
             for (int i = 0; i < n; ++i) z[i] = A.scratch[i] - kappa * gu[i];
-            double *acc = (cfg->alg == ORC_ALG_INTERPOLATING || cfg->alg == ORC_ALG_BACKSOLVE) ? z + n : A.gauss_acc;
+            double *acc = (cfg->alg == ORC_ALG_INTERPOLATING || cfg->alg == ORC_ALG_BACKSOLVE) ? z + n : (cfg->alg == ORC_ALG_QUADRATURE ? A.dgp_acc : A.gauss_acc);
             for (int i = 0; i < np; ++i) acc[i] += go[i] - kappa * gp[i];
         }
         free(pts); free(w);
+        A.use_win = 0;      /* (the quadrature pass below reads the whole forward solution; its nodes are interior points of parts that end at the events) */
     }
 
     /* unpack (src/sensitivity_interface.jl:500-508) */
@@ -1768,12 +1769,19 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
         double *seg = (double *)malloc(sizeof(double) * np); long nev = 0;
         double atol = cfg->quad_abstol > 0 ? cfg->quad_abstol : 1e-6, rtol = cfg->quad_reltol > 0 ? cfg->quad_reltol : 1e-3;
         memset(dp, 0, sizeof(double) * np);
-        if (M == 0) { quadgk_vec(quad_integrand, &Q, np, cfg->t0, cfg->t1, atol, rtol, dp, &nev); }
+        /* section 3b: lam and y jump at the events — an interval is split there, every part integrated on its own with the interval's tolerances */
+#define QUAD_INTERVAL(a_, b_) do { double pa_ = (a_); const double pb_ = (b_); int ke_ = 0; \
+            for (;;) { while (cfg->event_kind && ke_ < sol.nev && !(sol.t0[sol.ev_s[ke_]] > pa_)) ++ke_; \
+                const double pe_ = (cfg->event_kind && ke_ < sol.nev && sol.t0[sol.ev_s[ke_]] < pb_) ? sol.t0[sol.ev_s[ke_]] : pb_; \
+                quadgk_vec(quad_integrand, &Q, np, pa_, pe_, atol, rtol, seg, &nev); for (int j_ = 0; j_ < np; ++j_) dp[j_] += seg[j_]; \
+                if (pe_ < pb_) pa_ = pe_; else break; } } while (0)
+        if (M == 0) QUAD_INTERVAL(cfg->t0, cfg->t1);
         else {
-            if (cfg->save_times[M - 1] != cfg->t1) { quadgk_vec(quad_integrand, &Q, np, cfg->save_times[M - 1], cfg->t1, atol, rtol, seg, &nev); for (int i = 0; i < np; ++i) dp[i] += seg[i]; }
-            for (int i = M - 2; i >= 0; --i) { quadgk_vec(quad_integrand, &Q, np, cfg->save_times[i], cfg->save_times[i + 1], atol, rtol, seg, &nev); for (int j = 0; j < np; ++j) dp[j] += seg[j]; }
-            if (cfg->save_times[0] != cfg->t0) { quadgk_vec(quad_integrand, &Q, np, cfg->t0, cfg->save_times[0], atol, rtol, seg, &nev); for (int i = 0; i < np; ++i) dp[i] += seg[i]; }
+            if (cfg->save_times[M - 1] != cfg->t1) QUAD_INTERVAL(cfg->save_times[M - 1], cfg->t1);
+            for (int i = M - 2; i >= 0; --i) QUAD_INTERVAL(cfg->save_times[i], cfg->save_times[i + 1]);
+            if (cfg->save_times[0] != cfg->t0) QUAD_INTERVAL(cfg->t0, cfg->save_times[0]);
         }
+#undef QUAD_INTERVAL
         if (nrhs) *nrhs += nev;
         for (int i = 0; i < np; ++i) dp[i] += A.dgp_acc[i];                                  /* res .+= dgdp_cache at every loss time */
         free(seg); free(Q.lam);

@@ -1376,7 +1376,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     return na;
     };
     int na = 0;
-    if constexpr (model_has_cond<Mo>::value && (ALG == 0 || ALG == 1 || ALG == 2 || ALG == 4) && !CK && CC == 0) {
+    if constexpr (model_has_cond<Mo>::value && !CK && CC == 0) {
         {
             // ContinuousCallback (the oracle's section 3b; src/callback_tracking.jl:232-479 with save_positions = (false, false)): the reverse solve runs piece by piece between
             // this trajectory's events (a fresh solve per piece: the controller restarts) and at each event, - / + the limits from below / above,
@@ -1485,6 +1485,20 @@ HIPADJ_HD void quad_gk_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             for (int j = 0; j < NP; ++j) out[j] += gp[j];
         }
     };
+    // ContinuousCallback: lam (and y) jump at this trajectory's events — the interval is split there and every part integrated on its own (the nodes of the rule are interior
+    // points: no evaluation lands on a jump); the parts share the interval's tolerances
+    double acc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+    const double b_all = b;                 // (the intervals are handed over ascending: a < b, hipadj_plan.hpp)
+    int ke = 0, nevl = 0;
+    if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) nevl = g.nev[i] < g.maxev ? g.nev[i] : g.maxev; }
+#pragma unroll 1
+    for (;;) {
+    if constexpr (model_has_cond<Mo>::value) {
+        while (ke < nevl && !(g.ev_t[(long)ke * g.Npad + i] > a)) ++ke;      // events at or below the part's start
+        b = (ke < nevl && g.ev_t[(long)ke * g.Npad + i] < b_all) ? g.ev_t[(long)ke * g.Npad + i] : b_all;
+    }
     double sa[MAXSEG], sb[MAXSEG], sE[MAXSEG], sI[MAXSEG][NP];
     double I[NP];
     int ns = 1;
@@ -1511,7 +1525,14 @@ HIPADJ_HD void quad_gk_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         sa[ns] = mid; sb[ns] = wb; sE[ns] = E2;
         ++ns;
     }
-    for (int j = 0; j < NP; ++j) { double s = 0.0; for (int q = 0; q < ns; ++q) s += sI[q][j]; res[j] = s; }
+    for (int j = 0; j < NP; ++j) { double s = 0.0; for (int q = 0; q < ns; ++q) s += sI[q][j]; acc[j] += s; }
+    if constexpr (model_has_cond<Mo>::value) {
+        if (b < b_all) { a = b; continue; }
+    }
+    break;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) res[j] = acc[j];
 }
 
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
@@ -1544,7 +1565,7 @@ __global__ void __launch_bounds__(64) k_adjoint_tsit5(AdaptGeom g, const double*
                                         ks + KS_ROWS * AdjNZ<Mo, ALG>::value * 64 + threadIdx.x, CK ? const_cast<double*>(rec) : nullptr);
 #pragma unroll
     for (int j = 0; j < Mo::N; ++j) du0[i * Mo::N + j] = lam[j];
-    if (ALG != 3 || model_has_dloss<Mo>::value || model_dae<Mo>::value) {   // QuadratureAdjoint: k_quad_sum writes dp_traj from the quadrature (and ADDS to it for a model with discrete-loss bodies or a semi-explicit DAE, whose loss jumps leave their parameter term here)
+    if (ALG != 3 || model_has_dloss<Mo>::value || model_dae<Mo>::value || model_has_cond<Mo>::value) {   // QuadratureAdjoint: k_quad_sum writes dp_traj from the quadrature (and ADDS to it for a model with discrete-loss bodies or a semi-explicit DAE, whose loss jumps leave their parameter term here)
 #pragma unroll
         for (int j = 0; j < Mo::NP; ++j) dp_traj[(long)j * g.Npad + i] = mu[j]; }
 }

@@ -1087,7 +1087,7 @@ static int user_adjoint_run(hipadj_handle* h, const double* d_cot, double* d_du0
             const double atol = h->cfg.quad_abstol > 0 ? h->cfg.quad_abstol : 1e-6, rtol = h->cfg.quad_reltol > 0 ? h->cfg.quad_reltol : 1e-3;
             TRY(usig<decltype(&k_quad_gk_tsit5<ModelLV, 0>)>::launch(h, h->uf_gk, dim3(waves, (unsigned)h->nq), dim3(WAVE), h->ag, p, (const double*)h->d_rec, (const int*)h->d_nsteps, (const double*)h->d_arec,
                         (const int*)h->d_nsteps_adj, (const double*)h->d_qa, (const double*)h->d_qb, atol, rtol, h->d_qres));
-            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj, (h->cfg.loss_kind == HIPADJ_LOSS_MODEL || h->dae) ? 1 : 0);
+            hipLaunchKernelGGL(k_quad_sum, dim3(waves), dim3(WAVE), 0, h->stream, h->N, h->Npad, h->np, h->nq, (const double*)h->d_qres, h->d_dp_traj, (h->cfg.loss_kind == HIPADJ_LOSS_MODEL || h->dae || h->maxev > 0) ? 1 : 0);      // (a ContinuousCallback: the event jumps' parameter terms are already in dp_traj)
             HIP_TRY(h, hipGetLastError());
         }
     } else if (h->offgrid) {

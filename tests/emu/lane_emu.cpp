@@ -461,7 +461,7 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
         for (int j = 0; j < N; ++j) du0[i * N + j] = lam[j];
         if (ALG == 3) {   // k_quad_gk_tsit5 + k_quad_sum
             if (flag & 4) return HIPADJ_ERR_MAXITERS;
-            if (!model_dae<Mo>::value) for (int j = 0; j < NP; ++j) mu[j] = 0.0;      // (k_quad_sum with add = 1 for a semi-explicit DAE: the loss jumps' parameter term is already there)
+            if (!model_dae<Mo>::value && !model_has_cond<Mo>::value) for (int j = 0; j < NP; ++j) mu[j] = 0.0;      // (k_quad_sum with add = 1 for a semi-explicit DAE: the loss jumps' parameter term is already there)
             for (int q = 0; q < P.nq; ++q) {
                 double res[NP];
                 quad_gk_tsit5_lane<Mo, 128, CC>(g, i, p, rec.data(), nsteps.data(), arec.data(), nsteps_adj.data(), P.qa[q], P.qb[q], qatol, qrtol, res);

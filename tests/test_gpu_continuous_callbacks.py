@@ -22,7 +22,8 @@ from test_gpu_parity import rel
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD")]
+ALGS = [("interpolating", "INTERPOLATING"), ("backsolve", "BACKSOLVE"), ("gauss", "GAUSS"), ("gausskronrod", "GAUSS_KRONROD"), ("quadrature", "QUADRATURE")]
+QTOL = dict(quad_abstol=1e-14, quad_reltol=1e-12)
 CASES = {"ball": (1, "FALLMASS"), "ball_long": (1, "FALLMASS"), "ball_mse": (2, "FALLMASS"), "relax": (3, "RELAX"), "moving": (4, "FALLMASS")}
 _registered = {}
 
@@ -33,7 +34,8 @@ def relc(a, b):
 
 
 def sens(sa, alg):
-    return {"interpolating": sa.InterpolatingAdjoint(), "backsolve": sa.BacksolveAdjoint(checkpointing=False), "gauss": sa.GaussAdjoint(), "gausskronrod": sa.GaussKronrodAdjoint()}[alg]
+    return {"interpolating": sa.InterpolatingAdjoint(), "backsolve": sa.BacksolveAdjoint(checkpointing=False), "gauss": sa.GaussAdjoint(), "gausskronrod": sa.GaussKronrodAdjoint(),
+            "quadrature": sa.QuadratureAdjoint(abstol=1e-14, reltol=1e-12)}[alg]
 
 
 @pytest.fixture(scope="module")
@@ -79,7 +81,7 @@ def test_reference_problems_against_the_closed_forms_and_the_oracle(sa, gold, ca
     assert relc(du0[0], g["du0"]) < bar and relc(dp, g["dp"]) < bar
     ts = np.asarray(g["ts"])
     ref = O.Problem(omodel, alg=oalg, stepper="TSIT5", t0=g["tspan"][0], t1=g["tspan"][1], dt=0.0, abstol=1e-12, reltol=1e-12, save_times=ts, event_kind=kind,
-                    loss="LSQ_SHIFT" if mse else "COTANGENT", loss_shift=1.0 if mse else 0.0)
+                    loss="LSQ_SHIFT" if mse else "COTANGENT", loss_shift=1.0 if mse else 0.0, **QTOL)
     rdu0, rdp, rout = ref.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), None if mse else np.ones((len(ts), len(g["u0"]))))[:3]
     assert rel(out[0], rout) < 1e-10 and relc(du0[0], rdu0) < 1e-9 and relc(dp, rdp) < 1e-9
     if "u_at_ts" in g:
@@ -101,7 +103,7 @@ def test_an_ensemble_where_every_trajectory_has_its_own_events(sa, alg, oalg):
     du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=d)
     ne = sol.engine.event_counts(); out = np.array(sol.u)
     sol.engine.close()
-    ref = O.Problem("FALLMASS", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, event_kind=1)
+    ref = O.Problem("FALLMASS", alg=oalg, stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, event_kind=1, **QTOL)
     rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, d)
     assert len(set(ne.tolist())) >= 3 and ne.min() >= 1
     assert rel(out, rout) < 1e-8
@@ -116,7 +118,7 @@ def test_an_ensemble_where_every_trajectory_has_its_own_events(sa, alg, oalg):
         assert ne[i] == k
 
 
-@pytest.mark.parametrize("alg,oalg", ALGS[:3])
+@pytest.mark.parametrize("alg,oalg", [ALGS[0], ALGS[1], ALGS[2], ALGS[4]])
 @pytest.mark.parametrize("case", ["ball", "relax"])
 def test_rosenbrock23_and_dual_number_vjps(sa, gold, case, alg, oalg):
     kind, omodel = CASES[case]; g = gold[case]
@@ -125,7 +127,7 @@ def test_rosenbrock23_and_dual_number_vjps(sa, gold, case, alg, oalg):
     a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g["du0"], g["dp"]])
     assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-5            # the reference's bar, :140-145, on the whole gradient (relax: du0 is 5e-5 of dp[0])
     ts = np.asarray(g["ts"])
-    ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=g["tspan"][0], t1=g["tspan"][1], dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, event_kind=kind)
+    ref = O.Problem(omodel, alg=oalg, stepper="ROS23", t0=g["tspan"][0], t1=g["tspan"][1], dt=0.0, abstol=1e-9, reltol=1e-9, save_times=ts, event_kind=kind, **QTOL)
     rdu0, rdp, rout = ref.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), np.ones((len(ts), len(g["u0"]))))[:3]
     assert rel(out[0], rout) < 1e-8 and relc(du0[0], rdu0) < 1e-6 and relc(dp, rdp) < 1e-6
 
@@ -174,7 +176,7 @@ def test_refusals(sa, gold):
     from scimlsensitivity_jl_amd import _lib
     g = gold["ball"]; f = model(sa, 1); ts = np.asarray(g["ts"]); u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
     pr = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], tuple(g["tspan"]), p), u0)
-    for stepper, alg, kw, word in ((sa.Tsit5(), sa.QuadratureAdjoint(), {}, "Interpolating-, Backsolve-, Gauss-"), (sa.Tsit5(), sa.GaussAdjoint(checkpointing=True), {}, "checkpointing"),
+    for stepper, alg, kw, word in ((sa.Tsit5(), sa.GaussAdjoint(checkpointing=True), {}, "checkpointing"),
                                    (sa.Tsit5(), sa.InterpolatingAdjoint(checkpointing=True), {}, "checkpointing"), (sa.RK4(), sa.InterpolatingAdjoint(), dict(dt=0.01), "adaptive steppers")):
         with pytest.raises(_lib.HipadjError) as ei:
             sa.solve(pr, stepper, saveat=ts, sensealg=alg, abstol=1e-8, reltol=1e-8, **kw)
