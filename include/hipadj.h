@@ -255,7 +255,7 @@ int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
 /* ContinuousCallback(condition, affect!; save_positions = (false, false)) on a runtime lane model  (src/callback_tracking.jl:1-223 forward tracking, :232-479 reverse callbacks;
  * test/Callbacks2/continuous_callbacks.jl — the bouncing ball).  Every handle created on the model afterwards, on HIPADJ_STEPPER_TSIT5_ADAPTIVE or
  * HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE, locates the zero crossings of the condition on the dense output of each accepted step, PER TRAJECTORY (either direction: affect_neg! =
- * affect!), cuts the step there, applies the affect and goes on; the reverse solve of Interpolating- / Backsolve- / Gauss- / GaussKronrodAdjoint runs piece by piece between the events
+ * affect!), cuts the step there, applies the affect and goes on; the reverse solve of every sensealg (Interpolating-, Backsolve-, Gauss-, GaussKronrod-, QuadratureAdjoint) runs piece by piece between the events
  * of each trajectory and applies, at each of them, the jump with the event-time term:
  *     kappa = lam+ . (a_u f- + a_t - f+) / (c_u . f- + c_t)      lam- = a_u' lam+ - kappa c_u      dp += a_p' lam+ - kappa c_p
  *   condition_body  assigns `c` from u[0..N), p[0..NP), t       e.g. "c = u[0];"  or  "c = u[0] - 0.75 * p[0];"
@@ -264,7 +264,8 @@ int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
  * Both bodies are compiled for double and for dual numbers (declare locals `real`); every derivative of the jump comes from them.  Both NULL removes the callback.
  * BacksolveAdjoint (the algorithm the reference's callback tests lean on, also with checkpointing = true, its default): the forward solve stores every event's time and left
  * state; the backsolved state is overwritten with it at the event, as at a checkpoint.
- * Refused with HIPADJ_ERR_UNSUPPORTED at hipadj_create: the fixed-step steppers, QuadratureAdjoint, checkpointing = true on Interpolating / Gauss, continuous costs, HIPADJ_LOSS_MODEL;
+ * QuadratureAdjoint: the dense adjoint record runs through the jumps; its quadrature intervals are split at each trajectory's events.
+ * Refused with HIPADJ_ERR_UNSUPPORTED at hipadj_create: the fixed-step steppers, checkpointing = true on Interpolating / Gauss, continuous costs, HIPADJ_LOSS_MODEL;
  * here: wide models, models with a mass matrix, affects that edit the parameters (pn).  Not offered: terminate!, save_positions = (true, true) — outputs and losses live at
  * the save times only; a save time that coincides with an event sees the affected state. */
 int hipadj_model_set_continuous_callback(int32_t model_id, const char *condition_body, const char *affect_body, int32_t max_events);

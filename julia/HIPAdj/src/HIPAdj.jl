@@ -364,8 +364,7 @@ end
 `ContinuousCallback(condition, affect!; save_positions = (false, false))` as device text (`hipadj_model_set_continuous_callback`; src/callback_tracking.jl:232-479,
 test/Callbacks2/continuous_callbacks.jl): `condition` assigns `c` from `u`, `p`, `t` — the event is its zero crossing, either direction —, `affect` edits `un` (a copy of `u`).
 The bouncing ball: `set_continuous_callback!(m, "c = u[0];", "un[1] = -p[1] * u[1];")`.  Every later handle on the model with `stepper = STEPPER_TSIT5_ADAPTIVE` or
-`STEPPER_ROSENBROCK23_ADAPTIVE` locates the events of each trajectory on the dense output; `ALG_INTERPOLATING`, `ALG_GAUSS` and `ALG_GAUSS_KRONROD` differentiate through them,
-event times included.  `event_counts(handle)` returns the events per trajectory of the last forward solve.
+`STEPPER_ROSENBROCK23_ADAPTIVE` locates the events of each trajectory on the dense output; every sensealg differentiates through them, event times included.  `event_counts(handle)` returns the events per trajectory of the last forward solve.
 """
 function set_continuous_callback!(m::DeviceModel, condition, affect = nothing; max_events::Integer = 0)
     c = condition === nothing ? nothing : String(condition); a = affect === nothing ? nothing : String(affect)
