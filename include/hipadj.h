@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 110 /* 0.1.8: + hipadj_model_set_continuous_callback, hipadj_event_counts (ContinuousCallback on the adaptive lane steppers); additive, no struct changed. History of 109 and earlier: docs/ABI_HISTORY.md */
+#define HIPADJ_VERSION 110 /* 0.1.8: + hipadj_model_set_continuous_callback, hipadj_event_counts, hipadj_event_states, hipadj_set_event_cotangents (ContinuousCallback on the adaptive lane steppers); additive, no struct changed. History of 109 and earlier: docs/ABI_HISTORY.md */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -266,11 +266,23 @@ int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
  * state; the backsolved state is overwritten with it at the event, as at a checkpoint.
  * QuadratureAdjoint: the dense adjoint record runs through the jumps; its quadrature intervals are split at each trajectory's events.
  * Refused with HIPADJ_ERR_UNSUPPORTED at hipadj_create: the fixed-step steppers, checkpointing = true on Interpolating / Gauss, continuous costs, HIPADJ_LOSS_MODEL;
- * here: wide models, models with a mass matrix, affects that edit the parameters (pn).  Not offered: terminate!, save_positions = (true, true) — outputs and losses live at
- * the save times only; a save time that coincides with an event sees the affected state. */
+ * here: wide models, models with a mass matrix, affects that edit the parameters (pn).  Not offered: terminate!.  A save time that coincides with an event sees the affected
+ * state; save_positions = (true, true): hipadj_event_states / hipadj_set_event_cotangents below. */
 int hipadj_model_set_continuous_callback(int32_t model_id, const char *condition_body, const char *affect_body, int32_t max_events);
 /* events per trajectory of the handle's last forward solve: counts[ntraj], host pointer, synchronous.  HIPADJ_ERR_UNSUPPORTED when the model carries no ContinuousCallback. */
 int hipadj_event_counts(hipadj_handle *h, int32_t *counts);
+/* save_positions = (true, true) — the constructor's default, and the setting of most of the reference's callback tests (test/Callbacks2/continuous_callbacks.jl:200-250): the
+ * solution also holds the state just before and just after every affect, and a loss may take them.  Outputs and losses of a handle live at the save times; the saved event
+ * states are a second, ragged set handed over by these two calls (max_events as the model was registered with, 0 = 64):
+ *   hipadj_event_states        t [ntraj][max_events], ul, ur [ntraj][max_events][n] of the last forward solve: event times, states before / after the affect (host pointers, any
+ *                              may be NULL; entries beyond a trajectory's event count are zero; synchronous)
+ *   hipadj_set_event_cotangents  dl, dr [ntraj][max_events][n]: the cotangents of the caller's loss at those states, used by every following hipadj_adjoint* call (host pointers;
+ *                              either may be NULL = zero, both NULL removes them; entries beyond a trajectory's event count are ignored).  The reverse jump then reads
+ *                              kappa = [lam+ . (a_u f- + a_t - f+) + dr . (a_u f- + a_t) + dl . f-] / (c_u . f- + c_t),  lam- = a_u' (lam+ + dr) + dl - kappa c_u,
+ *                              dp += a_p' (lam+ + dr) - kappa c_p  (src/callback_tracking.jl:385-401, 439-452: the saved states move with the event time).
+ * HIPADJ_ERR_UNSUPPORTED when the model carries no ContinuousCallback; hipadj_event_states before the first forward solve: HIPADJ_ERR_STATE. */
+int hipadj_event_states(hipadj_handle *h, double *t, double *ul, double *ur);
+int hipadj_set_event_cotangents(hipadj_handle *h, const double *dl, const double *dr);
 /* The same for a wide model (hipadj_wmodel_register; ABI 108, round 5): dual numbers do not scale to 4096 states, so the reverse callback comes as text too.
  * Both bodies are SERIAL code run by one thread per trajectory (an event happens a handful of times per solve), over plain arrays:
  *   affect_body      edits un[0..N) / pn[0..NP) — copies of u / p on entry — from u, p, t

@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, dense_chain_model, declare_dense_chain!, set_mass_matrix!, set_affect!, set_continuous_callback!, event_counts, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, dense_chain_model, declare_dense_chain!, set_mass_matrix!, set_affect!, set_continuous_callback!, event_counts, event_states, set_event_cotangents!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -514,6 +514,22 @@ function event_counts(h::Handle)
     counts = Vector{Int32}(undef, h.N)
     check(ccall(sym(:hipadj_event_counts), Cint, (Ptr{Cvoid}, Ptr{Int32}), h.ptr, counts), h.ptr)
     return counts
+end
+"""
+    event_states(h; max_events = 64) -> (t, ul, ur)        set_event_cotangents!(h, dl, dr)
+
+`save_positions = (true, true)`: the event times `(max_events, N)` and the states just before / after the affect `(n, max_events, N)` of the last forward solve
+(`hipadj_event_states`), and the cotangents of a loss on them for the following `adjoint!` calls (`hipadj_set_event_cotangents`; `nothing` = zero).
+"""
+function event_states(h::Handle; max_events::Integer = 64)
+    t = zeros(Float64, max_events, h.N); ul = zeros(Float64, h.n, max_events, h.N); ur = similar(ul)     # column-major == the ABI's [N][max_events][n]
+    check(ccall(sym(:hipadj_event_states), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h.ptr, t, ul, ur), h.ptr)
+    return t, ul, ur
+end
+function set_event_cotangents!(h::Handle, dl::Union{Nothing, Array{Float64, 3}}, dr::Union{Nothing, Array{Float64, 3}})
+    pl = dl === nothing ? Ptr{Float64}(C_NULL) : pointer(dl); pr = dr === nothing ? Ptr{Float64}(C_NULL) : pointer(dr)
+    GC.@preserve dl dr check(ccall(sym(:hipadj_set_event_cotangents), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h.ptr, pl, pr), h.ptr)
+    return h
 end
 function forward!(h::Handle, u0::Matrix{Float64}, p::VecOrMat{Float64}; want_out::Bool = true)
     size(u0) == (h.n, h.N) || throw(DimensionMismatch("u0 must be ($(h.n), $(h.N)), got $(size(u0))"))

@@ -1747,10 +1747,16 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             model_f(m, fm, ym, p, tev); model_f(m, fp, yp, p, tev);
             ev_cond_grad(cfg->event_kind, n, np, ym, p, tev, gu, gp, &gt);
             ev_affect_jvp(cfg->event_kind, n, jf, ym, fm, p, tev);
-            for (int i = 0; i < n; ++i) { num += z[i] * (jf[i] - fp[i]); den += gu[i] * fm[i]; }
+            /* a loss on the SAVED event states (save_positions = (true, true)): with dl / dr its cotangents at u- / u+ (they sit AT the event time and move with it along f-
+             * resp. a_u f- + a_t),  kappa = [lam+ . (a_u f- + a_t - f+) + dr . (a_u f- + a_t) + dl . f-] / (c_u . f- + c_t),  lam- = a_u' (lam+ + dr) + dl - kappa c_u,
+             * dp += a_p' (lam+ + dr) - kappa c_p   (src/callback_tracking.jl:385-401, 439-452) */
+            const int ek = e - 1;
+            const double *dlk = (cfg->ev_dl && ek < cfg->ev_max) ? cfg->ev_dl + (size_t)ek * n : NULL, *drk = (cfg->ev_dr && ek < cfg->ev_max) ? cfg->ev_dr + (size_t)ek * n : NULL;
+            for (int i = 0; i < n; ++i) { num += z[i] * (jf[i] - fp[i]) + (drk ? drk[i] * jf[i] : 0.0) + (dlk ? dlk[i] * fm[i] : 0.0); den += gu[i] * fm[i]; }
             const double kappa = num / (den + gt);
-            ev_affect_vjp(cfg->event_kind, n, np, A.scratch, go, z, ym, p, tev);       /* scratch[0..n) = a_u' lam+ */
-            for (int i = 0; i < n; ++i) z[i] = A.scratch[i] - kappa * gu[i];
+            if (drk) for (int i = 0; i < n; ++i) z[i] += drk[i];
+            ev_affect_vjp(cfg->event_kind, n, np, A.scratch, go, z, ym, p, tev);       /* scratch[0..n) = a_u' (lam+ + dr) */
+            for (int i = 0; i < n; ++i) z[i] = A.scratch[i] + (dlk ? dlk[i] : 0.0) - kappa * gu[i];
             double *acc = (cfg->alg == ORC_ALG_INTERPOLATING || cfg->alg == ORC_ALG_BACKSOLVE) ? z + n : (cfg->alg == ORC_ALG_QUADRATURE ? A.dgp_acc : A.gauss_acc);
             for (int i = 0; i < np; ++i) acc[i] += go[i] - kappa * gp[i];
         }
@@ -1817,6 +1823,23 @@ int orc_forward(const orc_config *cfg, const double *u0, const double *p, double
     if (nsteps) *nsteps = sol.nsteps;
     dense_free(&sol); free(u); free(m.work);
     return st;
+}
+
+int orc_event_states(const orc_config *cfg, const double *u0, const double *p, int cap, double *t, double *ul, double *ur) {
+    orc_model m; if (model_init(&m, cfg->model, cfg->dims)) return -1;
+    if (!cfg->event_kind) return -6;
+    orc_dense sol; double *u = (double *)malloc(sizeof(double) * m.n); memcpy(u, u0, sizeof(double) * m.n);
+    long nrhs = 0;
+    int st = forward_dense(&m, cfg, p, cfg->t0, cfg->t1, u, 0.0, &sol, &nrhs);
+    int ne = sol.nev;
+    if (!st) for (int k = 0; k < ne && k < cap; ++k) {
+        const long sp = sol.ev_s[k]; const double tev = sol.t0[sp];
+        if (t) t[k] = tev;
+        if (ul) dense_eval_step(&sol, sp - 1, tev, ul + (size_t)k * m.n);
+        if (ur) dense_eval_step(&sol, sp, tev, ur + (size_t)k * m.n);
+    }
+    dense_free(&sol); free(u);
+    return st ? st : ne;
 }
 
 int orc_adjoint(const orc_config *cfg, const double *u0, const double *p, const double *dLdu,

@@ -102,6 +102,9 @@ typedef struct {
                              2: c = u1, u1 += 3, u2 <- u2^2 (:243-250, the non-linear affect);
                              3: c = u1 - 3/4 p1, u1 += p2 (:324-327: a condition that depends on a parameter; ORC_MODEL_RELAX);
                              4: c = u1 - 0.3 t, u2 <- -p2 (u2 - 0.3) + 0.3 + 0.1 t (NOT from the reference: condition and affect depend on t explicitly, so that c_t and a_t are not zero) */
+    int ev_max;           /* save_positions = (true, true) of the ContinuousCallback: a loss on the saved event states — ev_dl / ev_dr [ev_max][n], its cotangents at the state just
+                             before / after the affect of event k (NULL = zero; events beyond ev_max carry none); src/callback_tracking.jl:385-401, 439-452 */
+    const double *ev_dl, *ev_dr;
 } orc_config;
 
 int orc_model_sizes(int model, const int dims[4], int *n, int *np);
@@ -115,6 +118,10 @@ int orc_set_mass_matrix(int n, const double *M);
 
 /* forward solve of ONE trajectory; out[M][n] = sol(save_times) (src/concrete_solve.jl:718-727) */
 int orc_forward(const orc_config *cfg, const double *u0, const double *p, double *out, long *nsteps);
+
+/* the events of ONE trajectory's forward solve (event_kind != 0): times t[cap], states before / after the affect ul / ur [cap][n]; returns the number of events (<= cap are
+   written) or a negative status */
+int orc_event_states(const orc_config *cfg, const double *u0, const double *p, int cap, double *t, double *ul, double *ur);
 
 /* forward + adjoint of ONE trajectory. dLdu: [M][n] cotangents, or the data block of ORC_LOSS_LSQ_DATA / ORC_LOSS_TEST, or NULL (LSQ_SHIFT; TEST without data).
    du0[n], dp[np] (row vector of src/sensitivity_interface.jl:500-508), out[M][n] (may be NULL). */

@@ -50,6 +50,9 @@ struct AdaptGeom {
     // ... the event times ev_t [maxev][Npad] and the states just BEFORE the affect ev_ul [maxev][n][Npad] (BacksolveAdjoint keeps no forward record: at an event its
     // backsolved state is overwritten with the stored left state, as at a checkpoint — src/callback_tracking.jl:377 copy_to_integrator!)
     int maxev = 0; int* ev_s = nullptr; int* nev = nullptr; double* ev_t = nullptr; double* ev_ul = nullptr;
+    // save_positions = (true, true): the states just AFTER the affect, ev_ur [maxev][n][Npad] (hipadj_event_states hands t, u-, u+ to the caller), and the caller's cotangents of
+    // a loss on the saved event states, ev_dl / ev_dr [maxev][n][Npad] (hipadj_set_event_cotangents; nullptr = none)
+    double* ev_ur = nullptr; const double* ev_dl = nullptr; const double* ev_dr = nullptr;
 };
 
 // Tsit5 coefficients (Tsitouras 2011); same values as oracle/adjoint_oracle.c (order conditions checked there).
@@ -889,7 +892,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     if (nevl < g.maxev) {
                         g.ev_s[(long)nevl * g.Npad + i] = s; g.ev_t[(long)nevl * g.Npad + i] = t;
 #pragma unroll
-                        for (int q = 0; q < N; ++q) g.ev_ul[((long)nevl * N + q) * g.Npad + i] = uleft[q];
+                        for (int q = 0; q < N; ++q) { g.ev_ul[((long)nevl * N + q) * g.Npad + i] = uleft[q]; g.ev_ur[((long)nevl * N + q) * g.Npad + i] = un[q]; }
                     }
                     else { overflow = true; t = g.t1; }      // more events than the list holds (an accumulation point of events, or max_events too small): reported, and the solve ends here
                     ++nevl;
@@ -1407,13 +1410,19 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 Mo::f(fm, ym, pv, t_lo); Mo::f(fp, yp, pv, t_lo);
                 Mo::cond_grad(gu, gp, gt, ym, pv, t_lo);
                 Mo::cc_affect_jvp(jf, ym, fm, pv, t_lo);
-                double num = 0.0, den = 0.0;
+                // a loss on the SAVED event states (save_positions = (true, true), src/callback_tracking.jl:385-401, 439-452): with dl / dr its cotangents at u- / u+,
+                //     kappa = [lam+ . (a_u f- + a_t - f+) + dr . (a_u f- + a_t) + dl . f-] / (c_u . f- + c_t)      lam- = a_u' (lam+ + dr) + dl - kappa c_u      dp += a_p' (lam+ + dr) - kappa c_p
+                // (the saved states sit AT the event time: they move with it along f- resp. a_u f- + a_t, not along the later flow)
+                double num = 0.0, den = 0.0, dlv[N];
 #pragma unroll
-                for (int j = 0; j < N; ++j) { lamv[j] = z[j]; num += z[j] * (jf[j] - fp[j]); den += gu[j] * fm[j]; }
+                for (int j = 0; j < N; ++j) {
+                    const double drj = g.ev_dr ? g.ev_dr[((long)(e - 1) * N + j) * g.Npad + i] : 0.0;
+                    dlv[j] = g.ev_dl ? g.ev_dl[((long)(e - 1) * N + j) * g.Npad + i] : 0.0;
+                    lamv[j] = z[j] + drj; num += z[j] * (jf[j] - fp[j]) + drj * jf[j] + dlv[j] * fm[j]; den += gu[j] * fm[j]; }
                 const double kappa = num / (den + gt);
                 Mo::cc_affect_vjp(lo, go, lamv, ym, pv, t_lo);
 #pragma unroll
-                for (int j = 0; j < N; ++j) z[j] = lo[j] - kappa * gu[j];
+                for (int j = 0; j < N; ++j) z[j] = lo[j] + dlv[j] - kappa * gu[j];
 #pragma unroll
                 for (int j = 0; j < NP; ++j) { if constexpr (ALG == 0 || ALG == 1) z[N + j] += go[j] - kappa * gp[j]; else gacc[j] += go[j] - kappa * gp[j]; }
             }

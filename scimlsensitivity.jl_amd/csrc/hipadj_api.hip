@@ -276,6 +276,9 @@ static void free_all(hipadj_handle* h) {
     if (h->d_nev) (void)hipFree(h->d_nev);
     if (h->d_ev_t) (void)hipFree(h->d_ev_t);
     if (h->d_ev_ul) (void)hipFree(h->d_ev_ul);
+    if (h->d_ev_ur) (void)hipFree(h->d_ev_ur);
+    if (h->d_ev_dl) (void)hipFree(h->d_ev_dl);
+    if (h->d_ev_dr) (void)hipFree(h->d_ev_dr);
     if (h->d_save_rev && h->d_save_rev != h->d_save_of_knot) (void)hipFree(h->d_save_rev);
     if (h->umod) (void)hipModuleUnload(h->umod);
     if (h->umod_alt) (void)hipModuleUnload(h->umod_alt);
@@ -348,7 +351,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         h->maxev = plan_user_events(cfg->model);      // a ContinuousCallback: the event lists of the trajectories (written by the forward kernel, read by the reverse kernel)
         if (h->maxev > 0) {
             A(dev_alloc(h, &h->d_ev_s, (size_t)h->maxev * Np)); A(dev_alloc(h, &h->d_nev, (size_t)Np));
-            A(dev_alloc(h, &h->d_ev_t, (size_t)h->maxev * Np)); A(dev_alloc(h, &h->d_ev_ul, (size_t)h->maxev * n * Np));
+            A(dev_alloc(h, &h->d_ev_t, (size_t)h->maxev * Np)); A(dev_alloc(h, &h->d_ev_ul, (size_t)h->maxev * n * Np)); A(dev_alloc(h, &h->d_ev_ur, (size_t)h->maxev * n * Np));
             if (rc == HIPADJ_OK && !HT(hipMemset(h->d_nev, 0, sizeof(int) * (size_t)Np), "memset")) rc = HIPADJ_ERR_HIP;
         }
         if (cfg->alg == HIPADJ_ALG_QUADRATURE) {   // dense adjoint solution: the reverse solve also stops at every loss time
@@ -374,7 +377,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = (h->auto_steps && cfg->alg != HIPADJ_ALG_BACKSOLVE) ? (int)h->rec_cap : P.Smax; ag.maxit = h->auto_steps ? HIPADJ_AUTO_MAXITERS : P.Smax; ag.nck = P.nck; ag.SmaxI = P.SmaxI; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
         ag.abstol = cfg->abstol; ag.reltol = cfg->reltol; ag.loss_shift = cfg->loss_shift; ag.loss_kind = cfg->loss_kind;
         ag.no_start = cfg->no_start; ag.p_shared = cfg->p_shared; ag.cont_cost = cfg->cont_cost;
-        ag.maxev = h->maxev; ag.ev_s = h->d_ev_s; ag.nev = h->d_nev; ag.ev_t = h->d_ev_t; ag.ev_ul = h->d_ev_ul;
+        ag.maxev = h->maxev; ag.ev_s = h->d_ev_s; ag.nev = h->d_nev; ag.ev_t = h->d_ev_t; ag.ev_ul = h->d_ev_ul; ag.ev_ur = h->d_ev_ur;
     } else if (P.wide) {
         // workgroup-per-trajectory family of runtime models (hipadj_wide.hpp): trajectory-major knots, Backsolve checkpoints, Quadrature records
         h->wide = true;
@@ -837,6 +840,50 @@ extern "C" int hipadj_event_counts(hipadj_handle* h, int32_t* counts) {
     if (h->multi || h->maxev <= 0 || !h->d_nev) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_event_counts: the handle's model carries no ContinuousCallback (hipadj_model_set_continuous_callback), or the handle spans several devices");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(counts, h->d_nev, sizeof(int32_t) * (size_t)h->N, hipMemcpyDeviceToHost));
+    return HIPADJ_OK;
+}
+
+// save_positions = (true, true) of a ContinuousCallback: the event times and the states just before / after the affect of the last forward solve — t [ntraj][max_events],
+// ul, ur [ntraj][max_events][n] (host pointers, any may be NULL; entries beyond a trajectory's event count are zero; synchronous)
+extern "C" int hipadj_event_states(hipadj_handle* h, double* t, double* ul, double* ur) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->multi || h->maxev <= 0 || !h->d_nev) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_event_states: the handle's model carries no ContinuousCallback (hipadj_model_set_continuous_callback), or the handle spans several devices");
+    if (!h->have_forward) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_event_states: no forward solve yet");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const long Np = h->Npad; const int n = h->n, me = h->maxev;
+    std::vector<int> ne((size_t)Np);
+    HIP_TRY(h, hipMemcpy(ne.data(), h->d_nev, sizeof(int) * (size_t)Np, hipMemcpyDeviceToHost));
+    std::vector<double> buf((size_t)me * n * Np);
+    if (t) {
+        HIP_TRY(h, hipMemcpy(buf.data(), h->d_ev_t, sizeof(double) * (size_t)me * Np, hipMemcpyDeviceToHost));
+        for (long i = 0; i < h->N; ++i) for (int k = 0; k < me; ++k) t[i * me + k] = k < ne[i] ? buf[(size_t)k * Np + i] : 0.0;
+    }
+    for (int side = 0; side < 2; ++side) {
+        double* dst = side ? ur : ul;
+        if (!dst) continue;
+        HIP_TRY(h, hipMemcpy(buf.data(), side ? h->d_ev_ur : h->d_ev_ul, sizeof(double) * (size_t)me * n * Np, hipMemcpyDeviceToHost));
+        for (long i = 0; i < h->N; ++i) for (int k = 0; k < me; ++k) for (int j = 0; j < n; ++j) dst[((size_t)i * me + k) * n + j] = k < ne[i] ? buf[((size_t)k * n + j) * Np + i] : 0.0;
+    }
+    return HIPADJ_OK;
+}
+// cotangents of a loss on the saved event states for the following reverse passes: dl (at u-), dr (at u+), [ntraj][max_events][n] host pointers (entries beyond a trajectory's
+// event count are ignored); either may be NULL (= zero); both NULL removes them
+extern "C" int hipadj_set_event_cotangents(hipadj_handle* h, const double* dl, const double* dr) {
+    if (!h) return HIPADJ_ERR_INVALID_ARG;
+    if (h->multi || h->maxev <= 0 || !h->d_nev) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_set_event_cotangents: the handle's model carries no ContinuousCallback (hipadj_model_set_continuous_callback), or the handle spans several devices");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const long Np = h->Npad; const int n = h->n, me = h->maxev;
+    const size_t cnt = (size_t)me * n * Np;
+    std::vector<double> buf(cnt);
+    for (int side = 0; side < 2; ++side) {
+        const double* src = side ? dr : dl; double** dev = side ? &h->d_ev_dr : &h->d_ev_dl;
+        if (!src) { if (side) h->ag.ev_dr = nullptr; else h->ag.ev_dl = nullptr; continue; }
+        if (!*dev) TRY(dev_alloc(h, dev, cnt));
+        std::fill(buf.begin(), buf.end(), 0.0);
+        for (long i = 0; i < h->N; ++i) for (int k = 0; k < me; ++k) for (int j = 0; j < n; ++j) buf[((size_t)k * n + j) * Np + i] = src[((size_t)i * me + k) * n + j];
+        HIP_TRY(h, hipMemcpy(*dev, buf.data(), sizeof(double) * cnt, hipMemcpyHostToDevice));
+        if (side) h->ag.ev_dr = *dev; else h->ag.ev_dl = *dev;
+    }
     return HIPADJ_OK;
 }
 

@@ -203,6 +203,20 @@ class Engine:
         self._check(self._L.hipadj_event_counts(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def event_states(self, max_events=64):
+        """save_positions = (true, true): (t [N][max_events], u_left, u_right [N][max_events][n], counts [N]) of the last forward solve — the event times and the states just
+        before / after the affect (zero beyond a trajectory's count).  `max_events` as given to set_continuous_callback (0 / default: 64)."""
+        me = int(max_events) or 64
+        t = np.zeros((self.N, me)); ul = np.zeros((self.N, me, self.n)); ur = np.zeros((self.N, me, self.n))
+        self._check(self._L.hipadj_event_states(self._h, t.ctypes.data_as(C.c_void_p), ul.ctypes.data_as(C.c_void_p), ur.ctypes.data_as(C.c_void_p)))
+        return t, ul, ur, self.event_counts()
+
+    def set_event_cotangents(self, dl=None, dr=None):
+        """Cotangents of the caller's loss at the saved event states, [N][max_events][n] each (None = zero; both None removes them), for the following adjoint calls."""
+        self._ev_cot = tuple(None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (dl, dr))
+        P = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        self._check(self._L.hipadj_set_event_cotangents(self._h, P(self._ev_cot[0]), P(self._ev_cot[1])))
+
     def stats(self):
         st = HipadjStats()
         st.struct_size = C.sizeof(HipadjStats)

@@ -88,6 +88,28 @@ def make_config(model, alg, ntraj, t0, t1, dt, save_times, loss_kind=0, loss_shi
     return c
 
 
+EMU_MAXEV = 16      # capacity of the emulator's event lists (lane_emu.cpp)
+
+
+def set_event_cotangents(dl=None, dr=None):
+    """test hook of lane_emu.cpp: cotangents at the saved event states for the following forward_adjoint calls, [N][EMU_MAXEV][n] each (None = zero); returns the arrays to keep alive"""
+    keep = tuple(None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (dl, dr))
+    P = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    L = lib(); L.emu_set_event_cotangents.argtypes = [C.c_void_p, C.c_void_p]; L.emu_set_event_cotangents.restype = None
+    L.emu_set_event_cotangents(P(keep[0]), P(keep[1]))
+    return keep
+
+
+def set_event_output(N=None, n=None):
+    """test hook: the following forward_adjoint calls write [N][EMU_MAXEV][1 + 2 n] = (t, u-, u+) per event into the returned array (None: switch off)"""
+    L = lib(); L.emu_set_event_output.argtypes = [C.c_void_p]; L.emu_set_event_output.restype = None
+    if N is None:
+        L.emu_set_event_output(None); return None
+    out = np.zeros((N, EMU_MAXEV, 1 + 2 * n))
+    L.emu_set_event_output(out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def forward_adjoint(cfg, n, npar, u0, p, dLdu=None):
     u0 = np.ascontiguousarray(u0, dtype=np.float64)
     p = np.ascontiguousarray(p, dtype=np.float64)

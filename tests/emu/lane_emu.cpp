@@ -156,6 +156,12 @@ static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
 }
 static bool emu_user_dae(int32_t model) { return model >= HIPADJ_MODEL_USER_BASE + 204 && model <= HIPADJ_MODEL_USER_BASE + 206; }
 static constexpr int EMU_MAXEV = 16;
+// cotangents of a loss on the saved event states ([EMU_MAXEV][n][Npad] in the device layout, or nullptr): ONE definition, in the unit with the entry points
+#if !defined(EMU_UNIT) || EMU_UNIT <= 0
+const double *g_emu_ev_dl = nullptr, *g_emu_ev_dr = nullptr; double* g_emu_ev_out = nullptr;
+#else
+extern const double *g_emu_ev_dl, *g_emu_ev_dr; extern double* g_emu_ev_out;
+#endif
 static int emu_user_events(int32_t model) { const int nn = model - HIPADJ_MODEL_USER_BASE; return (nn == 301 || nn == 303 || nn == 304) ? EMU_MAXEV : 0; }
 static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, plan_user_dae_hook() = &emu_user_dae, plan_user_events_hook() = &emu_user_events, true);
 
@@ -438,13 +444,30 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     std::vector<int> nsteps((size_t)Np, 0);
     std::vector<int> ev_s(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * Np : 0), nev(model_has_cond<Mo>::value ? (size_t)Np : 0);      // ContinuousCallback: the event lists (hipadj_api.hip d_ev_s / d_nev)
     std::vector<double> ev_t(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * Np : 0), ev_ul(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * N * Np : 0);
-    if (model_has_cond<Mo>::value) { g.maxev = EMU_MAXEV; g.ev_s = ev_s.data(); g.nev = nev.data(); g.ev_t = ev_t.data(); g.ev_ul = ev_ul.data(); }
+    std::vector<double> ev_ur(ev_ul.size());
+    if (model_has_cond<Mo>::value) { g.maxev = EMU_MAXEV; g.ev_s = ev_s.data(); g.nev = nev.data(); g.ev_t = ev_t.data(); g.ev_ul = ev_ul.data(); g.ev_ur = ev_ur.data();
+                                   }
+    std::vector<double> ev_dl, ev_dr;      // test hook (emu_set_event_cotangents): cotangents at the saved event states, [N][EMU_MAXEV][n] as hipadj_set_event_cotangents takes them
+    if (model_has_cond<Mo>::value) for (int side = 0; side < 2; ++side) {
+        const double* src = side ? g_emu_ev_dr : g_emu_ev_dl; if (!src) continue;
+        std::vector<double>& dst = side ? ev_dr : ev_dl; dst.assign((size_t)EMU_MAXEV * N * Np, 0.0);
+        for (long i = 0; i < P.N; ++i) for (int k = 0; k < EMU_MAXEV; ++k) for (int j = 0; j < N; ++j) dst[((size_t)k * N + j) * Np + i] = src[((size_t)i * EMU_MAXEV + k) * N + j];
+        if (side) g.ev_dr = dst.data(); else g.ev_dl = dst.data();
+    }
+    // (... and emu_set_event_output: the event times and states handed back, [N][EMU_MAXEV][1 + 2 n] = t, u-, u+, filled after the forward loop below)
     int flag = 0;
     std::vector<double> kbuf((size_t)KS_ROWS * (2 * N + NP)), kfbuf((size_t)KS_ROWS * N);   // stage storage of one lane (LDS columns on the device), stride 1 here
     for (long i = 0; i < P.N; ++i)
         forward_tsit5_lane<Mo, STEP>(g, i, u0, p, (rec.empty() || CK) ? nullptr : rec.data(), nsteps.data(), P.save_times.data(), outT.data(),
                                P.ck_times.data(), ckpt.empty() ? nullptr : ckpt.data(), yT.data(), &flag, kbuf.data(), 1);
     if (nsteps_out) for (long i = 0; i < P.N; ++i) nsteps_out[i] = model_has_cond<Mo>::value ? nev[i] : nsteps[i];      // (a model with events reports its event counts there)
+    if (model_has_cond<Mo>::value && g_emu_ev_out)
+        for (long i = 0; i < P.N; ++i) for (int k = 0; k < EMU_MAXEV; ++k) {
+            double* o = g_emu_ev_out + ((size_t)i * EMU_MAXEV + k) * (1 + 2 * N);
+            const bool live = k < nev[i];
+            o[0] = live ? ev_t[(size_t)k * Np + i] : 0.0;
+            for (int j = 0; j < N; ++j) { o[1 + j] = live ? ev_ul[((size_t)k * N + j) * Np + i] : 0.0; o[1 + N + j] = live ? ev_ur[((size_t)k * N + j) * Np + i] : 0.0; }
+        }
     if (flag & 4) return HIPADJ_ERR_MAXITERS;
     if (out) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) out[i * P.M * N + c] = outT[(size_t)c * Np + i];
     if (!cotT.empty()) for (long i = 0; i < P.N; ++i) for (int c = 0; c < P.M * N; ++c) cotT[(size_t)c * Np + i] = dLdu[i * P.M * N + c];
@@ -598,6 +621,8 @@ template int dispatch_mode<EmuRelax>(const hipadj_config*, const Plan&, const do
 static std::string g_err;
 extern "C" const char* emu_last_error() { return g_err.c_str(); }
 
+extern "C" void emu_set_event_cotangents(const double* dl, const double* dr) { g_emu_ev_dl = dl; g_emu_ev_dr = dr; }
+extern "C" void emu_set_event_output(double* out) { g_emu_ev_out = out; }
 extern "C" int emu_plan(const hipadj_config* cfg, int* nseg, int* seg_bounds /*[cap]*/, int cap, int* nck, int* nq) {
     Plan P; const int rc = make_plan(cfg, P, g_err); if (rc) return rc;
     *nseg = P.nseg; *nck = P.nck; *nq = P.nq;

@@ -8,6 +8,7 @@ the solve plays in /root/reference/test/Callbacks2/continuous_callbacks.jl:129-1
   ball_mse    condition u1, affect u1 += 3, u2 <- u2^2, G = sum((1 - u)^2) / 2 (:239-250)
   relax       du = p1 - u, u0 = [0], tspan (0, 10), p = [100, 50], condition u - 3/4 p1, affect u += p2, G = u(10) (:314-338; the reference's comment holds the answer,
               [0.9999546000702386, 0.00018159971904994378], :342)
+  *_saved     the same with save_positions = (true, true) (the constructor's default; :200-217, 239-250): the loss also takes the state just before and just after each affect
   moving      NOT from the reference: the ball on a floor that rises with 0.3 t, condition u1 - 0.3 t, affect u2 <- -p2 (u2 - 0.3) + 0.3 + 0.1 t — condition and affect
               depend on t explicitly
 
@@ -55,11 +56,11 @@ def seeds(vals):
     return [D(v, np.eye(K)[i]) for i, v in enumerate(vals)]
 
 
-def ballistic(kind, u0, p, T, ts, loss):
+def ballistic(kind, u0, p, T, ts, loss, save_positions=False):
     """x'' = -g between events; kind 1: floor at 0, v <- -e v; kind 2: x += 3, v <- v^2; kind 4: floor 0.3 t, v <- -e (v - 0.3) + 0.3 + 0.1 t"""
     x, v, g, e = seeds([u0[0], u0[1], p[0], p[1]])
     tb = D(0.0, np.zeros(4))                    # start time of the current piece
-    G = D(0.0, np.zeros(4)); out = []; events = []
+    G = D(0.0, np.zeros(4)); out = []; events = []; ev_states = []
     k = 0
     while True:
         # next root of x + v s - g s^2 / 2 - floor(tb + s) = 0, s > 0
@@ -84,8 +85,12 @@ def ballistic(kind, u0, p, T, ts, loss):
         if kind == 1: x, v = xm, -e * vm
         elif kind == 2: x, v = xm + 3.0, vm * vm
         else: x, v = xm, -e * (vm - 0.3) + 0.3 + 0.1 * te
+        if save_positions:                        # save_positions = (true, true): the solution also holds the state just before and just after the affect (:202, 207, 215, 222)
+            G = G + loss(xm, vm) + loss(x, v)
+            ev_states.append([[xm.v, vm.v], [x.v, v.v]])
         tb = te
-    return dict(u0=list(u0), p=list(p), tspan=[0.0, T], ts=list(ts), kind=kind, u_at_ts=out, event_times=events, G=G.v, du0=G.g[:2].tolist(), dp=G.g[2:].tolist())
+    return dict(u0=list(u0), p=list(p), tspan=[0.0, T], ts=list(ts), kind=kind, u_at_ts=out, event_times=events, G=G.v, du0=G.g[:2].tolist(), dp=G.g[2:].tolist(),
+                **(dict(event_states=ev_states) if save_positions else {}))
 
 
 def relax():
@@ -108,6 +113,11 @@ if __name__ == "__main__":
         ball_mse=ballistic(2, [5.0, 0.0], [9.8, 0.8], 2.5, ts, mse),
         relax=relax(),
         moving=ballistic(4, [5.0, 0.0], [9.8, 0.8], 4.0, np.arange(0.0, 4.0 + 1e-12, 0.5).tolist(), ssum),
+        # save_positions = (true, true), the constructor's default and the setting of most of the reference's testsets: g also sums the saved event states
+        ball_saved=ballistic(1, [5.0, 0.0], [9.8, 0.8], 2.5, ts, ssum, save_positions=True),                 # "= callback with parameter dependence and save", :212-217
+        ball_long_saved=ballistic(1, [5.0, 0.0], [9.8, 0.8], 5.0, np.arange(0.0, 5.0 + 1e-12, 0.5).tolist(), ssum, save_positions=True),
+        ball_mse_saved=ballistic(2, [5.0, 0.0], [9.8, 0.8], 2.5, ts, mse, save_positions=True),            # "callback with non-linear affect", MSE loss, :239-250
+        moving_saved=ballistic(4, [5.0, 0.0], [9.8, 0.8], 4.0, np.arange(0.0, 4.0 + 1e-12, 0.5).tolist(), ssum, save_positions=True),
         source="tests/golden/make_continuous_callbacks.py: closed forms differentiated with dual numbers")
     json.dump(out, open(os.path.join(HERE, "continuous_callbacks.json"), "w"), indent=1)
     print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk != "u_at_ts"} if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))

@@ -30,6 +30,7 @@ class OrcConfig(C.Structure):
         ("quad_abstol", C.c_double), ("quad_reltol", C.c_double),
         ("no_start", C.c_int), ("cont_cost", C.c_int),
         ("loss_scale", C.c_double), ("dloss_id", C.c_int), ("reference_literal", C.c_int), ("event_kind", C.c_int),
+        ("ev_max", C.c_int), ("ev_dl", C.POINTER(C.c_double)), ("ev_dr", C.POINTER(C.c_double)),
     ]
 
 
@@ -129,6 +130,23 @@ class Problem:
         c.loss_scale, c.dloss_id, c.reference_literal = float(loss_scale), int(dloss_id), int(bool(reference_literal))
         c.event_kind = int(event_kind)      # ContinuousCallback of adjoint_oracle.h (1 .. 4)
         self.cfg = c
+
+    def set_event_cotangents(self, dl=None, dr=None):
+        """cotangents of a loss on the saved event states (save_positions = (true, true)): dl / dr [ev_max][n] at the state before / after the affect of event k"""
+        self._evd = (None if dl is None else _arr(np.asarray(dl, dtype=np.float64)), None if dr is None else _arr(np.asarray(dr, dtype=np.float64)))
+        k = [x.shape[0] for x in self._evd if x is not None]
+        self.cfg.ev_max = min(k) if k else 0
+        self.cfg.ev_dl = _p(self._evd[0]) if self._evd[0] is not None else None
+        self.cfg.ev_dr = _p(self._evd[1]) if self._evd[1] is not None else None
+        return self
+
+    def event_states(self, u0, p, cap=64):
+        u0, p = _arr(u0), _arr(p)
+        t, ul, ur = np.zeros(cap), np.zeros((cap, self.n)), np.zeros((cap, self.n))
+        ne = lib().orc_event_states(C.byref(self.cfg), _p(u0), _p(p), cap, _p(t), _p(ul), _p(ur))
+        if ne < 0:
+            raise RuntimeError(f"orc_event_states rc={ne}")
+        return t[:ne], ul[:ne], ur[:ne]
 
     @property
     def M(self):

@@ -169,6 +169,41 @@ def test_lane_bodies_event_list_overflow_and_refusals():
             E.forward_adjoint(cfg, 2, 2, [[5.0, 0.0]], [9.8, 0.8], d)
 
 
+# ---- save_positions = (true, true): a loss on the saved event states ---------------------------------------------------------------------------------------------------
+SAVED = {"ball_saved": (1, "emu_ball"), "ball_long_saved": (1, "emu_ball"), "ball_mse_saved": (2, None), "moving_saved": (4, "emu_ball_moving")}
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case", sorted(SAVED))
+def test_loss_on_the_saved_event_states(gold, case, alg, oalg):
+    """the constructor's default and the setting of most of the reference's testsets (test/Callbacks2/continuous_callbacks.jl:200-217, 239-250): g also takes the state just before
+    and just after every affect.  Event states and gradients against the closed forms: oracle (every sensealg), lane bodies (where the emulator has the model)"""
+    kind, emodel = SAVED[case]; g = gold[case]; ts = np.asarray(g["ts"]); n = 2; mse = "mse" in case
+    es = np.asarray(g["event_states"]); ne = len(es)
+    pr = O.Problem("FALLMASS", alg=oalg, stepper="TSIT5", t0=g["tspan"][0], t1=g["tspan"][1], dt=0.0, abstol=1e-12, reltol=1e-12, save_times=ts, event_kind=kind,
+                   loss="LSQ_SHIFT" if mse else "COTANGENT", loss_shift=1.0 if mse else 0.0, **QTOL)
+    t, ul, ur = pr.event_states(np.asarray(g["u0"]), np.asarray(g["p"]))
+    assert len(t) == ne and np.max(np.abs(t - np.asarray(g["event_times"]))) < 1e-12 and np.max(np.abs(ul - es[:, 0])) < 1e-10 and np.max(np.abs(ur - es[:, 1])) < 1e-10
+    dl, dr = ((ul - 1.0), (ur - 1.0)) if mse else (np.ones((ne, n)), np.ones((ne, n)))
+    pr.set_event_cotangents(dl, dr)
+    du0, dp, _ = pr.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), None if mse else np.ones((len(ts), n)))
+    assert relmax(du0, dp, g) < 1e-11
+    assert relmax(du0, dp, gold[case[:-6]]) > 1e-3          # (the saved states do carry weight: the gradient without them is another one)
+    if emodel is None:
+        return
+    cfg = E.make_config(emodel, alg, 1, g["tspan"][0], g["tspan"][1], 0.0, ts, stepper=TS5, abstol=1e-12, reltol=1e-12, max_steps=4000, **QTOL)
+    evo = E.set_event_output(1, n)
+    pad = lambda a: np.concatenate([a, np.zeros((E.EMU_MAXEV - ne, n))])[None]
+    keep = E.set_event_cotangents(pad(dl), pad(dr))
+    try:
+        edu0, edp, _ = E.forward_adjoint(cfg, n, 2, [g["u0"]], g["p"], np.ones((1, len(ts), n)))
+    finally:
+        E.set_event_cotangents(None, None); E.set_event_output(None)
+    del keep
+    assert np.max(np.abs(evo[0, :ne, 0] - t)) < 1e-12 and np.max(np.abs(evo[0, :ne, 1:1 + n] - ul)) < 1e-10 and np.max(np.abs(evo[0, :ne, 1 + n:] - ur)) < 1e-10 and np.all(evo[0, ne:] == 0.0)
+    assert relmax(edu0[0], edp, g) < 1e-11 and relc(edu0[0], du0) < 1e-10 and relc(edp, dp) < 1e-10
+
+
 # ---- the C ABI without a device ------------------------------------------------------------------------------------------------------------------------------------------
 def test_registration_entry_point_and_its_refusals():
     from scimlsensitivity_jl_amd import _lib

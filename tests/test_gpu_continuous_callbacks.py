@@ -230,3 +230,61 @@ def test_python_example_of_the_bouncing_ball(sa, gold):
     dev = [l for l in r.stdout.splitlines() if l.startswith("device")][0]
     nums = [float(x) for x in dev.replace("[", " ").replace("]", " ").replace(",", " ").split() if x.replace(".", "").replace("-", "").replace("e", "").replace("+", "").isdigit()]
     assert relc(nums[:2], gold["ball"]["du0"]) < 1e-6 and relc(nums[2:4], gold["ball"]["dp"]) < 1e-6
+
+
+SAVED = {"ball_saved": 1, "ball_long_saved": 1, "ball_mse_saved": 2, "moving_saved": 4}
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case", sorted(SAVED))
+def test_loss_on_the_saved_event_states(sa, gold, case, alg, oalg):
+    """save_positions = (true, true) — the constructor's default, the setting of most of the reference's testsets (test/Callbacks2/continuous_callbacks.jl:200-217, 239-250): the loss
+    also takes the state just before and just after every affect.  hipadj_event_states hands them over, hipadj_set_event_cotangents takes the loss's cotangents there; event
+    states and gradients against the closed forms, every sensealg"""
+    kind = SAVED[case]; g = gold[case]; ts = np.asarray(g["ts"]); n = 2; mse = "mse" in case
+    es = np.asarray(g["event_states"]); ne = len(es)
+    u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
+    kw = dict(dgdu_discrete=sa.LsqShift(1.0)) if mse else {}
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model(sa, kind), u0[0], tuple(g["tspan"]), p), u0), sa.Tsit5(), saveat=ts, sensealg=sens(sa, alg), abstol=1e-12, reltol=1e-12, **kw)
+    t, ul, ur, cnt = sol.engine.event_states()
+    assert cnt.tolist() == [ne] and np.max(np.abs(t[0, :ne] - np.asarray(g["event_times"]))) < 1e-11
+    assert np.max(np.abs(ul[0, :ne] - es[:, 0])) < 1e-9 and np.max(np.abs(ur[0, :ne] - es[:, 1])) < 1e-9 and np.all(ul[0, ne:] == 0.0)
+    dl = np.zeros_like(ul); dr = np.zeros_like(ur)
+    dl[0, :ne] = (ul[0, :ne] - 1.0) if mse else 1.0; dr[0, :ne] = (ur[0, :ne] - 1.0) if mse else 1.0
+    sol.engine.set_event_cotangents(dl, dr)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts) if mse else sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=np.ones((1, len(ts), n)))
+    a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g["du0"], g["dp"]])
+    assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-9
+    sol.engine.set_event_cotangents(None, None)                                   # removed: the gradient of the loss at the save times alone
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts) if mse else sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=np.ones((1, len(ts), n)))
+    sol.engine.close()
+    g0 = gold[case[:-6]]
+    a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g0["du0"], g0["dp"]])
+    assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-9
+
+
+def test_saved_event_states_of_an_ensemble(sa):
+    """per-trajectory event counts: the ragged set of saved states, one row per trajectory, zero beyond its count; u+ = affect(u-), c(u-) = 0; the loss sum over all saved states
+    against the oracle for a sample"""
+    rng = np.random.default_rng(9)
+    N, T = 200, 4.0
+    u0 = np.stack([rng.uniform(2.0, 9.0, N), rng.uniform(-1.0, 1.0, N)], axis=1)
+    p = np.stack([9.8 * (1 + 0.1 * rng.uniform(-1, 1, N)), rng.uniform(0.8, 0.9, N)], axis=1)
+    ts = np.array([0.3, 1.7, 4.0]); d = rng.standard_normal((N, len(ts), 2))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model(sa, 1), u0[0], (0.0, T), p[0]), u0, p), sa.Tsit5(), saveat=ts, sensealg=sa.InterpolatingAdjoint(), abstol=1e-10, reltol=1e-10)
+    t, ul, ur, cnt = sol.engine.event_states()
+    assert cnt.min() >= 1 and cnt.max() <= 8 and len(set(cnt.tolist())) >= 3
+    for i in range(N):
+        k = cnt[i]
+        assert np.all(np.diff(t[i, :k]) > 0) and np.all(t[i, k:] == 0.0) and np.max(np.abs(ul[i, :k, 0])) < 1e-9          # on the floor, in order
+        assert np.max(np.abs(ur[i, :k, 1] + p[i, 1] * ul[i, :k, 1])) < 1e-12 and np.all(ur[i, :k, 0] == ul[i, :k, 0])      # u+ = affect(u-)
+    w = rng.standard_normal(ul.shape); v = rng.standard_normal(ur.shape)
+    sol.engine.set_event_cotangents(w, v)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=d)
+    sol.engine.close()
+    for i in range(0, N, 17):
+        ref = O.Problem("FALLMASS", alg="INTERPOLATING", stepper="TSIT5", t0=0.0, t1=T, dt=0.0, abstol=1e-10, reltol=1e-10, save_times=ts, event_kind=1)
+        ref.set_event_cotangents(w[i, :cnt[i]], v[i, :cnt[i]])
+        rdu0, rdp, _ = ref.adjoint(u0[i], p[i], d[i])
+        a = np.concatenate([du0[i], dp[i]]); b = np.concatenate([rdu0, rdp])
+        assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-7
