@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 110 /* 0.1.8: + hipadj_model_set_continuous_callback, hipadj_event_counts, hipadj_event_states, hipadj_set_event_cotangents (ContinuousCallback on the adaptive lane steppers); additive, no struct changed. History of 109 and earlier: docs/ABI_HISTORY.md */
+#define HIPADJ_VERSION 110 /* 0.1.8: + hipadj_model_set_continuous_callback, hipadj_model_set_vector_continuous_callback, hipadj_event_counts, hipadj_event_states, hipadj_set_event_cotangents (ContinuousCallback on the adaptive lane steppers); additive, no struct changed. History of 109 and earlier: docs/ABI_HISTORY.md */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -269,6 +269,13 @@ int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
  * here: wide models, models with a mass matrix, affects that edit the parameters (pn).  Not offered: terminate!.  A save time that coincides with an event sees the affected
  * state; save_positions = (true, true): hipadj_event_states / hipadj_set_event_cotangents below. */
 int hipadj_model_set_continuous_callback(int32_t model_id, const char *condition_body, const char *affect_body, int32_t max_events);
+/* VectorContinuousCallback(condition, affect!, len) (test/Callbacks2/vector_continuous_callbacks.jl): ncond conditions (1 .. 8) watched together; the event is the first zero
+ * crossing of any of them, and the affect sees which one fired.
+ *   condition_body  assigns out[0 .. ncond)                 e.g. "out[0] = u[0]; out[1] = (u[2] - 10.0) * u[2];"
+ *   affect_body     edits un from u, p, t and `idx` (int)   e.g. "if (idx == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3];"
+ * Everything else as hipadj_model_set_continuous_callback (which is the case ncond = 1, `c` an alias of out[0]).  Components that cross in the same tenth of a step: the lowest index
+ * fires; the simultaneous fire of several components (the reference's event_idx mask, :118-230) is not merged into one event. */
+int hipadj_model_set_vector_continuous_callback(int32_t model_id, int32_t ncond, const char *condition_body, const char *affect_body, int32_t max_events);
 /* events per trajectory of the handle's last forward solve: counts[ntraj], host pointer, synchronous.  HIPADJ_ERR_UNSUPPORTED when the model carries no ContinuousCallback. */
 int hipadj_event_counts(hipadj_handle *h, int32_t *counts);
 /* save_positions = (true, true) — the constructor's default, and the setting of most of the reference's callback tests (test/Callbacks2/continuous_callbacks.jl:200-250): the

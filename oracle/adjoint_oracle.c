@@ -70,6 +70,7 @@ static int model_init(orc_model *m, int id, const int dims[4]) {
     case ORC_MODEL_PENDULUM: m->n = 2; m->np = 3; break;
     case ORC_MODEL_LIN1P: m->n = 1; m->np = 2; break;
     case ORC_MODEL_RELAX: m->n = 1; m->np = 2; break;
+    case ORC_MODEL_BALL2D: m->n = 4; m->np = 2; break;
     case ORC_MODEL_ROBERDAE: m->n = 3; m->np = 3; break;
     default: return -1;
     }
@@ -136,6 +137,9 @@ static void model_f(const orc_model *m, double *du, const double *u, const doubl
         break;
     case ORC_MODEL_RELAX:    /* test/Callbacks2/continuous_callbacks.jl:320 */
         du[0] = p[0] - u[0];
+        break;
+    case ORC_MODEL_BALL2D:   /* test/Callbacks2/vector_continuous_callbacks.jl:10-16 */
+        du[0] = u[1]; du[1] = -p[0]; du[2] = u[3]; du[3] = 0.0;
         break;
     case ORC_MODEL_AFFINE3: /* `foo` of the mass-matrix test, test/Core3/adjoint.jl:1315-1321: du = A u + p; du[2] += sum(p), A = [1 2 3; 4 5 6; 7 8 9] */
         du[0] = 1.0 * u[0] + 2.0 * u[1] + 3.0 * u[2] + p[0];
@@ -273,6 +277,10 @@ static void model_vjp(const orc_model *m, double *dlam, double *dgrad, const dou
     case ORC_MODEL_RELAX:
         if (dlam) dlam[0] = -lam[0];
         if (dgrad) { dgrad[0] = lam[0]; dgrad[1] = 0.0; }
+        break;
+    case ORC_MODEL_BALL2D:
+        if (dlam) { dlam[0] = 0.0; dlam[1] = lam[0]; dlam[2] = 0.0; dlam[3] = lam[2]; }
+        if (dgrad) { dgrad[0] = -lam[1]; dgrad[1] = 0.0; }
         break;
     case ORC_MODEL_AFFINE3:
         if (dlam) {
@@ -530,7 +538,7 @@ typedef struct {
     double *u0, *u1;       /* [nsteps][n] */
     double *k;             /* [nsteps][nk][n]; RK4: k[0]=f(u0,t0), k[1]=f(u1,t1) (FSAL pair) ; Tsit5: 7 stages */
     double *hfull;         /* length of the step the stages belong to: t1 - t0, except on a step a ContinuousCallback cut short (t1 = the event time; section 3b) */
-    long *ev_s; int nev, ev_cap;   /* events of the solve, ascending in time: ev_s[k] = index of the first record AFTER event k (it starts at the event time, from the affected state) */
+    long *ev_s; int *ev_k; int nev, ev_cap;   /* events of the solve, ascending in time: ev_s[k] = index of the first record AFTER event k (it starts at the event time, from the affected state) */
 } orc_dense;
 
 /* Dense solutions are recycled per thread: an ensemble run would otherwise grow and free ~100 KB of arrays per trajectory on
@@ -552,7 +560,7 @@ static void dense_free(orc_dense *d) {
     if (d->cap > 0)
         for (int i = 0; i < ORC_DENSE_POOL; ++i)
             if (tls_pool_used[i] == 0) { tls_pool[i] = *d; tls_pool_used[i] = 1; memset(d, 0, sizeof(*d)); return; }
-    free(d->t0); free(d->t1); free(d->u0); free(d->u1); free(d->k); free(d->hfull); free(d->ev_s); memset(d, 0, sizeof(*d));
+    free(d->t0); free(d->t1); free(d->u0); free(d->u1); free(d->k); free(d->hfull); free(d->ev_s); free(d->ev_k); memset(d, 0, sizeof(*d));
 }
 static void dense_push(orc_dense *d, double t0, double t1, const double *u0, const double *u1, const double *k) {
     if (d->nsteps == d->cap) {
@@ -1080,44 +1088,58 @@ static int dae_consistent_init(const orc_model *m, double *u, const double *p, d
  *     lines do not carry as read: a_t (its affects do not use t) and kappa c_p — its "Re-compile tape" testset has a condition that depends on p1 and asks 1e-10 of the
  *     gradient, which needs the term (-kappa c_p = 2.7e-4 there); the restatement follows the mathematics (tests/golden/make_continuous_callbacks.py has the closed forms).
  * ===================================================================================== */
-static double ev_cond(int kind, const double *u, const double *p, double t) {
+#define ORC_MAXCOND 2
+static int ev_ncond(int kind) { return kind >= 5 ? 2 : 1; }
+static void ev_cond(int kind, double *out, const double *u, const double *p, double t) {
     switch (kind) {
-    case 3: return u[0] - 0.75 * p[0];
-    case 4: return u[0] - 0.3 * t;
-    default: return u[0];
+    case 3: out[0] = u[0] - 0.75 * p[0]; break;
+    case 4: out[0] = u[0] - 0.3 * t; break;
+    case 5: out[0] = u[0]; out[1] = (u[2] - 10.0) * u[2]; break;
+    case 6: out[0] = sin(t); out[1] = cos(t); break;
+    default: out[0] = u[0]; break;
     }
 }
-static void ev_cond_grad(int kind, int n, int np, const double *u, const double *p, double t, double *gu, double *gp, double *gt) {
-    (void)u; (void)p; (void)t;
+/* gradient of component k */
+static void ev_cond_grad(int kind, int k, int n, int np, const double *u, const double *p, double t, double *gu, double *gp, double *gt) {
+    (void)p;
     for (int i = 0; i < n; ++i) gu[i] = 0.0;
     for (int i = 0; i < np; ++i) gp[i] = 0.0;
-    gu[0] = 1.0; *gt = 0.0;
-    if (kind == 3) gp[0] = -0.75;
-    if (kind == 4) *gt = -0.3;
+    *gt = 0.0;
+    switch (kind) {
+    case 3: gu[0] = 1.0; gp[0] = -0.75; break;
+    case 4: gu[0] = 1.0; *gt = -0.3; break;
+    case 5: if (k == 0) gu[0] = 1.0; else gu[2] = 2.0 * u[2] - 10.0; break;
+    case 6: *gt = (k == 0) ? cos(t) : -sin(t); break;
+    default: gu[0] = 1.0; break;
+    }
 }
-static void ev_affect(int kind, int n, double *un, const double *u, const double *p, double t) {
+static void ev_affect(int kind, int k, int n, double *un, const double *u, const double *p, double t) {
     for (int i = 0; i < n; ++i) un[i] = u[i];
     switch (kind) {
     case 1: un[1] = -p[1] * u[1]; break;
     case 2: un[0] = u[0] + 3.0; un[1] = u[1] * u[1]; break;
     case 3: un[0] = u[0] + p[1]; break;
     case 4: un[1] = -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t; break;
+    case 5: if (k == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3]; break;
+    case 6: un[0] = 0.5; un[1] = 1.0; un[2] = 0.0; un[3] = 0.0; break;
     default: break;
     }
 }
 /* out = a_u v + a_t */
-static void ev_affect_jvp(int kind, int n, double *out, const double *u, const double *v, const double *p, double t) {
+static void ev_affect_jvp(int kind, int k, int n, double *out, const double *u, const double *v, const double *p, double t) {
     (void)t;
     for (int i = 0; i < n; ++i) out[i] = v[i];
     switch (kind) {
     case 1: out[1] = -p[1] * v[1]; break;
     case 2: out[1] = 2.0 * u[1] * v[1]; break;
     case 4: out[1] = -p[1] * v[1] + 0.1; break;
+    case 5: if (k == 0) out[1] = -p[1] * v[1]; else out[3] = -p[1] * v[3]; break;
+    case 6: for (int i = 0; i < n; ++i) out[i] = 0.0; break;
     default: break;
     }
 }
 /* lo = a_u' lam, go = a_p' lam */
-static void ev_affect_vjp(int kind, int n, int np, double *lo, double *go, const double *lam, const double *u, const double *p, double t) {
+static void ev_affect_vjp(int kind, int k, int n, int np, double *lo, double *go, const double *lam, const double *u, const double *p, double t) {
     (void)t;
     for (int i = 0; i < n; ++i) lo[i] = lam[i];
     for (int i = 0; i < np; ++i) go[i] = 0.0;
@@ -1126,41 +1148,46 @@ static void ev_affect_vjp(int kind, int n, int np, double *lo, double *go, const
     case 2: lo[1] = 2.0 * u[1] * lam[1]; break;
     case 3: go[1] = lam[0]; break;
     case 4: lo[1] = -p[1] * lam[1]; go[1] = -(u[1] - 0.3) * lam[1]; break;
+    case 5: if (k == 0) { lo[1] = -p[1] * lam[1]; go[1] = -u[1] * lam[1]; } else { lo[3] = -p[1] * lam[3]; go[1] = -u[3] * lam[3]; } break;
+    case 6: for (int i = 0; i < n; ++i) lo[i] = 0.0; break;
     default: break;
     }
 }
 #define ORC_MAX_EVENTS 4096
-typedef struct { const orc_model *m; const double *p; int kind; orc_dense *sol; double cprev, tend; int nudge, overflow; } fwd_event_ctx;
+typedef struct { const orc_model *m; const double *p; int kind; orc_dense *sol; double cprev[ORC_MAXCOND], tend; int nudge, overflow; } fwd_event_ctx;
 static int fwd_event_cb(orc_integ *I, void *c) {
     fwd_event_ctx *E = (fwd_event_ctx *)c;
-    const int n = I->n; const double h = I->t - I->tprev;
-    double y[ORC_MM_MAXN];
+    const int n = I->n, nc = ev_ncond(E->kind); const double h = I->t - I->tprev;
+    double y[ORC_MM_MAXN], cv[ORC_MAXCOND], ca[ORC_MAXCOND];
     if (h == 0.0) return 0;
-    if (E->nudge) { integ_interp(I, I->tprev + 0.01 * h, y); E->cprev = ev_cond(E->kind, y, E->p, I->tprev + 0.01 * h); E->nudge = 0; }
-    double tha = 0.0, ca = E->cprev, thb = 0.0, cb = 0.0; int found = 0;
-    for (int j = 1; j <= 10 && !found; ++j) {
+    if (E->nudge) { integ_interp(I, I->tprev + 0.01 * h, y); ev_cond(E->kind, E->cprev, y, E->p, I->tprev + 0.01 * h); E->nudge = 0; }
+    double tha = 0.0, thb = 0.0, cak = 0.0; int kx = -1;
+    for (int k = 0; k < nc; ++k) ca[k] = E->cprev[k];
+    for (int j = 1; j <= 10 && kx < 0; ++j) {
         thb = j < 10 ? 0.1 * j : 1.0;
         if (j < 10) integ_interp(I, I->tprev + thb * h, y); else memcpy(y, I->u, sizeof(double) * n);
-        cb = ev_cond(E->kind, y, E->p, I->tprev + thb * h);
-        if (ca * cb < 0.0 || (cb == 0.0 && ca != 0.0)) found = 1;
-        else { tha = thb; ca = cb; }
+        ev_cond(E->kind, cv, y, E->p, I->tprev + thb * h);
+        for (int k = 0; k < nc; ++k) if (kx < 0 && (ca[k] * cv[k] < 0.0 || (cv[k] == 0.0 && ca[k] != 0.0))) { kx = k; cak = ca[k]; }      /* the lowest component that crosses in this tenth */
+        if (kx < 0) { tha = thb; for (int k = 0; k < nc; ++k) ca[k] = cv[k]; }
     }
-    if (!found) { E->cprev = cb; return 0; }
+    if (kx < 0) { for (int k = 0; k < nc; ++k) E->cprev[k] = cv[k]; return 0; }
     for (int it = 0; it < 52; ++it) {
         const double thm = 0.5 * (tha + thb);
         integ_interp(I, I->tprev + thm * h, y);
-        const double cm = ev_cond(E->kind, y, E->p, I->tprev + thm * h);
-        if (ca * cm < 0.0 || (cm == 0.0 && ca != 0.0)) { thb = thm; cb = cm; } else { tha = thm; ca = cm; }
+        ev_cond(E->kind, cv, y, E->p, I->tprev + thm * h);
+        const double cm = cv[kx];
+        if (cak * cm < 0.0 || (cm == 0.0 && cak != 0.0)) thb = thm; else { tha = thm; cak = cm; }
     }
     const double tev = I->tprev + thb * h;
-    if (!(tev < E->tend) || time_hits(tev, E->tend)) { E->cprev = ev_cond(E->kind, I->u, E->p, I->t); return 0; }   /* an event at the end of the span changes nothing that is observed */
+    if (!(tev < E->tend) || time_hits(tev, E->tend)) { ev_cond(E->kind, E->cprev, I->u, E->p, I->t); return 0; }   /* an event at the end of the span changes nothing that is observed */
     integ_interp(I, tev, y);
     orc_dense *d = E->sol; const long s = d->nsteps - 1;          /* the record of this step: pushed just before the callbacks run */
     if (d->nev >= ORC_MAX_EVENTS) { E->overflow = 1; I->t = E->tend; return 0; }      /* an accumulation point of events (a ball that comes to rest): the solve ends with status -7 */
     d->t1[s] = tev; memcpy(d->u1 + (size_t)s * n, y, sizeof(double) * n);
-    if (d->nev == d->ev_cap) { d->ev_cap = d->ev_cap ? 2 * d->ev_cap : 16; d->ev_s = (long *)realloc(d->ev_s, sizeof(long) * d->ev_cap); }
+    if (d->nev == d->ev_cap) { d->ev_cap = d->ev_cap ? 2 * d->ev_cap : 16; d->ev_s = (long *)realloc(d->ev_s, sizeof(long) * d->ev_cap); d->ev_k = (int *)realloc(d->ev_k, sizeof(int) * d->ev_cap); }
+    d->ev_k[d->nev] = kx;
     d->ev_s[d->nev++] = s + 1;
-    ev_affect(E->kind, n, I->u, y, E->p, tev);
+    ev_affect(E->kind, kx, n, I->u, y, E->p, tev);
     I->t = tev; E->nudge = 1;
     return 1;
 }
@@ -1194,11 +1221,12 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
         a.split_G = G; a.split_coef = p[2] / (dx * dx);
     }
-    fwd_event_ctx ev = {m, p, cfg->event_kind, sol, 0.0, tb, 0, 0};
+    fwd_event_ctx ev; memset(&ev, 0, sizeof(ev)); ev.m = m; ev.p = p; ev.kind = cfg->event_kind; ev.sol = sol; ev.tend = tb;
     if (cfg->event_kind) {
-        if (cfg->event_kind < 1 || cfg->event_kind > 4 || (cfg->stepper != ORC_STEPPER_TSIT5 && cfg->stepper != ORC_STEPPER_ROS23) || g_mm_n == m->n || g_mm_dae || m->n > ORC_MM_MAXN) return -6;
-        if ((cfg->event_kind == 3) != (m->id == ORC_MODEL_RELAX) || (cfg->event_kind != 3 && (m->n != 2 || m->np < 2))) return -6;
-        ev.cprev = ev_cond(cfg->event_kind, u, p, ta); ev.nudge = (ev.cprev == 0.0);
+        if (cfg->event_kind < 1 || cfg->event_kind > 6 || (cfg->stepper != ORC_STEPPER_TSIT5 && cfg->stepper != ORC_STEPPER_ROS23) || g_mm_n == m->n || g_mm_dae || m->n > ORC_MM_MAXN) return -6;
+        if ((cfg->event_kind == 3) != (m->id == ORC_MODEL_RELAX) || (cfg->event_kind >= 5) != (m->id == ORC_MODEL_BALL2D) || (cfg->event_kind != 3 && cfg->event_kind < 5 && (m->n != 2 || m->np < 2))) return -6;
+        ev_cond(cfg->event_kind, ev.cprev, u, p, ta);
+        for (int k = 0; k < ev_ncond(cfg->event_kind); ++k) if (ev.cprev[k] == 0.0) ev.nudge = 1;
     }
     int st = integrate(fwd_rhs, &fc, m->n, u, ta, tb, &a, NULL, 0, cfg->event_kind ? fwd_event_cb : NULL, &ev, 0, sol, nrhs);
     if (st == 0 && ev.overflow) st = -7;
@@ -1745,8 +1773,9 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
                 memcpy(yp, z + n + np, sizeof(double) * n); memcpy(z + n + np, ym, sizeof(double) * n);
             }
             model_f(m, fm, ym, p, tev); model_f(m, fp, yp, p, tev);
-            ev_cond_grad(cfg->event_kind, n, np, ym, p, tev, gu, gp, &gt);
-            ev_affect_jvp(cfg->event_kind, n, jf, ym, fm, p, tev);
+            const int kx = sol.ev_k[e - 1];      /* the component that fired (0 for a scalar condition) */
+            ev_cond_grad(cfg->event_kind, kx, n, np, ym, p, tev, gu, gp, &gt);
+            ev_affect_jvp(cfg->event_kind, kx, n, jf, ym, fm, p, tev);
             /* a loss on the SAVED event states (save_positions = (true, true)): with dl / dr its cotangents at u- / u+ (they sit AT the event time and move with it along f-
              * resp. a_u f- + a_t),  kappa = [lam+ . (a_u f- + a_t - f+) + dr . (a_u f- + a_t) + dl . f-] / (c_u . f- + c_t),  lam- = a_u' (lam+ + dr) + dl - kappa c_u,
              * dp += a_p' (lam+ + dr) - kappa c_p   (src/callback_tracking.jl:385-401, 439-452) */
@@ -1755,7 +1784,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             for (int i = 0; i < n; ++i) { num += z[i] * (jf[i] - fp[i]) + (drk ? drk[i] * jf[i] : 0.0) + (dlk ? dlk[i] * fm[i] : 0.0); den += gu[i] * fm[i]; }
             const double kappa = num / (den + gt);
             if (drk) for (int i = 0; i < n; ++i) z[i] += drk[i];
-            ev_affect_vjp(cfg->event_kind, n, np, A.scratch, go, z, ym, p, tev);       /* scratch[0..n) = a_u' (lam+ + dr) */
+            ev_affect_vjp(cfg->event_kind, kx, n, np, A.scratch, go, z, ym, p, tev);       /* scratch[0..n) = a_u' (lam+ + dr) */
             for (int i = 0; i < n; ++i) z[i] = A.scratch[i] + (dlk ? dlk[i] : 0.0) - kappa * gu[i];
             double *acc = (cfg->alg == ORC_ALG_INTERPOLATING || cfg->alg == ORC_ALG_BACKSOLVE) ? z + n : (cfg->alg == ORC_ALG_QUADRATURE ? A.dgp_acc : A.gauss_acc);
             for (int i = 0; i < np; ++i) acc[i] += go[i] - kappa * gp[i];

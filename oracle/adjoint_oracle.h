@@ -51,6 +51,7 @@ enum {
     ORC_MODEL_PENDULUM = 13, /* `pendulum_eom` of test/Core7/adjoint_param.jl:6-10: dx1 = p1 x2; dx2 = -sin x1 + (-p1 sin x1 + p2 x2); np = 3 (p3 unused, as in the test) */
     ORC_MODEL_LIN1P = 14,    /* `f` of test/Core7/adjoint_param.jl:56-59: du = -u p1 - p2; n = 1, np = 2 */
     ORC_MODEL_RELAX = 16,    /* du = p1 - u, n = 1, np = 2 (p2 enters through the event only): `f` of the "Re-compile tape" testset, test/Callbacks2/continuous_callbacks.jl:314-327 */
+    ORC_MODEL_BALL2D = 17,   /* du = [u2, -p1, u4, 0], n = 4, np = 2: `f` of test/Callbacks2/vector_continuous_callbacks.jl:10-16 (p2: the restitution of the affects) */
     ORC_MODEL_ROBERDAE = 15  /* `rober` as test/Core3/adjoint.jl:1434-1441 writes it (third row: y1 + y2 + y3 - 1): with orc_set_mass_matrix(diag(1, 1, 0)) the semi-explicit DAE of :1450-1700;
                                 dims[0] = kappa adds -kappa (p1 - 0.04) to the constraint (NOT from the reference: a parameter-dependent constraint, so that the jumps' parameter term is not zero) */
 };
@@ -101,7 +102,10 @@ typedef struct {
                              1: c = u1, u2 <- -p2 u2 (the bouncing ball, :212-217: "= callback with parameter dependence"; ORC_MODEL_FALLMASS);
                              2: c = u1, u1 += 3, u2 <- u2^2 (:243-250, the non-linear affect);
                              3: c = u1 - 3/4 p1, u1 += p2 (:324-327: a condition that depends on a parameter; ORC_MODEL_RELAX);
-                             4: c = u1 - 0.3 t, u2 <- -p2 (u2 - 0.3) + 0.3 + 0.1 t (NOT from the reference: condition and affect depend on t explicitly, so that c_t and a_t are not zero) */
+                             4: c = u1 - 0.3 t, u2 <- -p2 (u2 - 0.3) + 0.3 + 0.1 t (NOT from the reference: condition and affect depend on t explicitly, so that c_t and a_t are not zero);
+                             VectorContinuousCallback (a vector of conditions; the affect sees which component fired; ORC_MODEL_BALL2D):
+                             5: out = [u1, (u3 - 10) u3]; component 1: u2 <- -p2 u2, component 2: u4 <- -p2 u4 (test/Callbacks2/vector_continuous_callbacks.jl:80-96);
+                             6: out = [sin t, cos t]; either: u <- [0.5, 1, 0, 0] (:100-116: conditions that depend on time only, an affect whose Jacobian is zero) */
     int ev_max;           /* save_positions = (true, true) of the ContinuousCallback: a loss on the saved event states — ev_dl / ev_dr [ev_max][n], its cotangents at the state just
                              before / after the affect of event k (NULL = zero; events beyond ev_max carry none); src/callback_tracking.jl:385-401, 439-452 */
     const double *ev_dl, *ev_dr;

@@ -24,7 +24,7 @@ DECLARED_SYMBOLS = (
     "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
     "hipadj_model_set_discrete_loss", "hipadj_model_set_discrete_loss_function", "hipadj_wmodel_set_discrete_loss", "hipadj_set_loss_data", "hipadj_set_loss_data_dev",
     "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride", "hipadj_device_count", "hipadj_wmodel_declare_dense_chain",
-    "hipadj_model_set_continuous_callback", "hipadj_event_counts", "hipadj_event_states", "hipadj_set_event_cotangents",
+    "hipadj_model_set_continuous_callback", "hipadj_model_set_vector_continuous_callback", "hipadj_event_counts", "hipadj_event_states", "hipadj_set_event_cotangents",
 )
 
 
@@ -117,6 +117,7 @@ def load():
     L.hipadj_model_set_affect.argtypes = [C.c_int32, C.c_char_p]
     L.hipadj_model_set_continuous_callback.argtypes = [C.c_int32, C.c_char_p, C.c_char_p, C.c_int32]
     L.hipadj_event_counts.argtypes = [C.c_void_p, C.c_void_p]
+    L.hipadj_model_set_vector_continuous_callback.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32]
     L.hipadj_event_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hipadj_set_event_cotangents.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hipadj_wmodel_set_affect.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
@@ -223,10 +224,14 @@ def set_model_affect(model_id, body):
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
 
 
-def set_model_continuous_callback(model_id, condition, affect, max_events=0):
-    """hipadj_model_set_continuous_callback: ContinuousCallback(condition, affect!) of a runtime lane model (None, None removes it)."""
+def set_model_continuous_callback(model_id, condition, affect, max_events=0, ncond=1):
+    """hipadj_model_set_continuous_callback / hipadj_model_set_vector_continuous_callback (ncond > 1): the callback of a runtime lane model (None, None removes it)."""
     L = load()
-    rc = L.hipadj_model_set_continuous_callback(int(model_id), None if condition is None else condition.encode(), None if affect is None else affect.encode(), int(max_events))
+    enc = lambda s: None if s is None else s.encode()
+    if int(ncond) > 1:
+        rc = L.hipadj_model_set_vector_continuous_callback(int(model_id), int(ncond), enc(condition), enc(affect), int(max_events))
+    else:
+        rc = L.hipadj_model_set_continuous_callback(int(model_id), enc(condition), enc(affect), int(max_events))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
 

@@ -53,6 +53,7 @@ struct AdaptGeom {
     // save_positions = (true, true): the states just AFTER the affect, ev_ur [maxev][n][Npad] (hipadj_event_states hands t, u-, u+ to the caller), and the caller's cotangents of
     // a loss on the saved event states, ev_dl / ev_dr [maxev][n][Npad] (hipadj_set_event_cotangents; nullptr = none)
     double* ev_ur = nullptr; const double* ev_dl = nullptr; const double* ev_dr = nullptr;
+    int* ev_k = nullptr;       // which component of a VectorContinuousCallback fired, [maxev][Npad] (0 for a scalar condition)
 };
 
 // Tsit5 coefficients (Tsitouras 2011); same values as oracle/adjoint_oracle.c (order conditions checked there).
@@ -827,8 +828,12 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     // ContinuousCallback (model_has_cond; the oracle's section 3b, src/callback_tracking.jl:1-223): the sign of the condition at ten points of the accepted step's dense output
     // against its sign at the step's start (right after an event: at 1/100 of the step); the first bracket halved 52 times; the step is cut at the bracket's upper end — the
     // record rescaled to [tprev, t_event] —, u <- affect(u), t <- t_event, and the integrator recomputes the derivative; its proposal for the next step stands
-    double cprev = 0.0; bool nudge = false; int nevl = 0;
-    if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) { cprev = Mo::cond(u, pv, g.t0); nudge = (cprev == 0.0); } }
+    // VectorContinuousCallback (Mo::NCOND > 1: `out[k] = ...` in the condition body, `idx` in the affect body): the scan watches every component; the event is the FIRST crossing
+    // of the step, of the lowest component among those that cross in the same tenth (simultaneous fires of several components are not merged: DESIGN.md section 4.12)
+    constexpr int NC = model_ncond<Mo>::value;
+    double cprev[NC]; bool nudge = false; int nevl = 0, evk = 0;
+    for (int k = 0; k < NC; ++k) cprev[k] = 0.0;
+    if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) { Mo::cond(cprev, u, pv, g.t0); for (int k = 0; k < NC; ++k) nudge = nudge || (cprev[k] == 0.0); } }
     auto fcb = [&](double& t, double tprev, double (&un)[N], const auto& KK) -> bool {
             double h = t - tprev;
             double c[5][N];
@@ -837,30 +842,41 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             if constexpr (STEP == 1) ros23_poly<N>(KK, h, c); else tsit5_poly<N>(KK, h, c);
             if constexpr (model_has_cond<Mo>::value) {
                 if (g.maxev > 0 && h != 0.0) {
-                    double y[N];
-                    if (nudge) { poly_eval<N>(0.01, c, y); cprev = Mo::cond(y, pv, tprev + 0.01 * h); nudge = false; }
-                    double tha = 0.0, ca = cprev, thb = 0.0, cbv = 0.0; bool found = false;
+                    double y[N], cv[NC], ca[NC];
+                    if (nudge) { poly_eval<N>(0.01, c, y); Mo::cond(cprev, y, pv, tprev + 0.01 * h); nudge = false; }
+                    double tha = 0.0, thb = 0.0, cak = 0.0; int kx = -1;
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) ca[k] = cprev[k];
 #pragma unroll 1
-                    for (int j = 1; j <= 10 && !found; ++j) {
+                    for (int j = 1; j <= 10 && kx < 0; ++j) {
                         thb = j < 10 ? 0.1 * j : 1.0;
                         if (j < 10) poly_eval<N>(thb, c, y);
                         else {
 #pragma unroll
                             for (int q = 0; q < N; ++q) y[q] = un[q]; }
-                        cbv = Mo::cond(y, pv, tprev + thb * h);
-                        if (ca * cbv < 0.0 || (cbv == 0.0 && ca != 0.0)) found = true; else { tha = thb; ca = cbv; }
+                        Mo::cond(cv, y, pv, tprev + thb * h);
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) if (kx < 0 && (ca[k] * cv[k] < 0.0 || (cv[k] == 0.0 && ca[k] != 0.0))) { kx = k; cak = ca[k]; }
+                        if (kx < 0) { tha = thb;
+#pragma unroll
+                            for (int k = 0; k < NC; ++k) ca[k] = cv[k]; }
                     }
-                    if (!found) cprev = cbv;
-                    else {
+                    if (kx < 0) {
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) cprev[k] = cv[k];
+                    } else {
 #pragma unroll 1
                         for (int it = 0; it < 52; ++it) {
                             const double thm = 0.5 * (tha + thb);
                             poly_eval<N>(thm, c, y);
-                            const double cm = Mo::cond(y, pv, tprev + thm * h);
-                            if (ca * cm < 0.0 || (cm == 0.0 && ca != 0.0)) { thb = thm; cbv = cm; } else { tha = thm; ca = cm; }
+                            Mo::cond(cv, y, pv, tprev + thm * h);
+                            double cm = cv[0];
+#pragma unroll
+                            for (int k = 1; k < NC; ++k) cm = (k == kx) ? cv[k] : cm;
+                            if (cak * cm < 0.0 || (cm == 0.0 && cak != 0.0)) thb = thm; else { tha = thm; cak = cm; }
                         }
                         const double tev = tprev + thb * h;
-                        if (!(tev < g.t1) || time_hits(tev, g.t1)) cprev = Mo::cond(un, pv, t);      // (an event at the end of the span changes nothing that is observed)
+                        if (!(tev < g.t1) || time_hits(tev, g.t1)) Mo::cond(cprev, un, pv, t);      // (an event at the end of the span changes nothing that is observed)
                         else {
                             poly_eval<N>(thb, c, y);
                             double r = thb;
@@ -869,10 +885,10 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
                                 for (int q = 0; q < N; ++q) c[m][q] *= r;
                                 r *= thb; }
-                            Mo::cc_affect(un, y, pv, tev);
+                            Mo::cc_affect(un, y, pv, tev, kx);
 #pragma unroll
                             for (int q = 0; q < N; ++q) uleft[q] = y[q];
-                            t = tev; h = tev - tprev; nudge = true; event = true;
+                            t = tev; h = tev - tprev; nudge = true; event = true; evk = kx;
                         }
                     }
                 }
@@ -890,7 +906,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             if constexpr (model_has_cond<Mo>::value) {
                 if (event) {
                     if (nevl < g.maxev) {
-                        g.ev_s[(long)nevl * g.Npad + i] = s; g.ev_t[(long)nevl * g.Npad + i] = t;
+                        g.ev_s[(long)nevl * g.Npad + i] = s; g.ev_t[(long)nevl * g.Npad + i] = t; g.ev_k[(long)nevl * g.Npad + i] = evk;
 #pragma unroll
                         for (int q = 0; q < N; ++q) { g.ev_ul[((long)nevl * N + q) * g.Npad + i] = uleft[q]; g.ev_ur[((long)nevl * N + q) * g.Npad + i] = un[q]; }
                     }
@@ -1407,9 +1423,10 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     cur.below(sp - 1, e >= 2 ? g.ev_s[(long)(e - 2) * g.Npad + i] : 0);
                     cur.eval(t_lo, ym);
                 }
+                const int kx = g.ev_k[(long)(e - 1) * g.Npad + i];      // the component that fired (0 for a scalar condition)
                 Mo::f(fm, ym, pv, t_lo); Mo::f(fp, yp, pv, t_lo);
-                Mo::cond_grad(gu, gp, gt, ym, pv, t_lo);
-                Mo::cc_affect_jvp(jf, ym, fm, pv, t_lo);
+                Mo::cond_grad(gu, gp, gt, kx, ym, pv, t_lo);
+                Mo::cc_affect_jvp(jf, ym, fm, pv, t_lo, kx);
                 // a loss on the SAVED event states (save_positions = (true, true), src/callback_tracking.jl:385-401, 439-452): with dl / dr its cotangents at u- / u+,
                 //     kappa = [lam+ . (a_u f- + a_t - f+) + dr . (a_u f- + a_t) + dl . f-] / (c_u . f- + c_t)      lam- = a_u' (lam+ + dr) + dl - kappa c_u      dp += a_p' (lam+ + dr) - kappa c_p
                 // (the saved states sit AT the event time: they move with it along f- resp. a_u f- + a_t, not along the later flow)
@@ -1420,7 +1437,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     dlv[j] = g.ev_dl ? g.ev_dl[((long)(e - 1) * N + j) * g.Npad + i] : 0.0;
                     lamv[j] = z[j] + drj; num += z[j] * (jf[j] - fp[j]) + drj * jf[j] + dlv[j] * fm[j]; den += gu[j] * fm[j]; }
                 const double kappa = num / (den + gt);
-                Mo::cc_affect_vjp(lo, go, lamv, ym, pv, t_lo);
+                Mo::cc_affect_vjp(lo, go, lamv, ym, pv, t_lo, kx);
 #pragma unroll
                 for (int j = 0; j < N; ++j) z[j] = lo[j] + dlv[j] - kappa * gu[j];
 #pragma unroll

@@ -99,6 +99,9 @@ extern "C" int hipadj_model_set_affect(int32_t model_id, const char* affect_body
 extern "C" int hipadj_model_set_continuous_callback(int32_t model_id, const char* condition_body, const char* affect_body, int32_t max_events) {
     return user_set_continuous_callback(model_id, condition_body, affect_body, max_events, g_create_error);
 }
+extern "C" int hipadj_model_set_vector_continuous_callback(int32_t model_id, int32_t ncond, const char* condition_body, const char* affect_body, int32_t max_events) {
+    return user_set_continuous_callback(model_id, condition_body, affect_body, max_events, g_create_error, ncond);
+}
 
 // ---- DiscreteCallback affects applied between solves (host-level composition of event problems, interface.py) --------------------------------
 // Both calls are synchronous and take HOST pointers: the data of an event is N x (n + np) doubles.  The kernels are compiled for the model with
@@ -274,6 +277,7 @@ static void free_all(hipadj_handle* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_ev_s) (void)hipFree(h->d_ev_s);
     if (h->d_nev) (void)hipFree(h->d_nev);
+    if (h->d_ev_k) (void)hipFree(h->d_ev_k);
     if (h->d_ev_t) (void)hipFree(h->d_ev_t);
     if (h->d_ev_ul) (void)hipFree(h->d_ev_ul);
     if (h->d_ev_ur) (void)hipFree(h->d_ev_ur);
@@ -350,7 +354,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         A(dev_alloc(h, &h->d_nsteps, (size_t)Np));
         h->maxev = plan_user_events(cfg->model);      // a ContinuousCallback: the event lists of the trajectories (written by the forward kernel, read by the reverse kernel)
         if (h->maxev > 0) {
-            A(dev_alloc(h, &h->d_ev_s, (size_t)h->maxev * Np)); A(dev_alloc(h, &h->d_nev, (size_t)Np));
+            A(dev_alloc(h, &h->d_ev_s, (size_t)h->maxev * Np)); A(dev_alloc(h, &h->d_nev, (size_t)Np)); A(dev_alloc(h, &h->d_ev_k, (size_t)h->maxev * Np));
             A(dev_alloc(h, &h->d_ev_t, (size_t)h->maxev * Np)); A(dev_alloc(h, &h->d_ev_ul, (size_t)h->maxev * n * Np)); A(dev_alloc(h, &h->d_ev_ur, (size_t)h->maxev * n * Np));
             if (rc == HIPADJ_OK && !HT(hipMemset(h->d_nev, 0, sizeof(int) * (size_t)Np), "memset")) rc = HIPADJ_ERR_HIP;
         }
@@ -377,7 +381,7 @@ extern "C" int hipadj_create(const hipadj_config* cfg, hipadj_handle** out) {
         ag.N = h->N; ag.Npad = Np; ag.M = h->M; ag.Smax = (h->auto_steps && cfg->alg != HIPADJ_ALG_BACKSOLVE) ? (int)h->rec_cap : P.Smax; ag.maxit = h->auto_steps ? HIPADJ_AUTO_MAXITERS : P.Smax; ag.nck = P.nck; ag.SmaxI = P.SmaxI; ag.t0 = cfg->t0; ag.t1 = cfg->t1; ag.dt0 = cfg->dt;
         ag.abstol = cfg->abstol; ag.reltol = cfg->reltol; ag.loss_shift = cfg->loss_shift; ag.loss_kind = cfg->loss_kind;
         ag.no_start = cfg->no_start; ag.p_shared = cfg->p_shared; ag.cont_cost = cfg->cont_cost;
-        ag.maxev = h->maxev; ag.ev_s = h->d_ev_s; ag.nev = h->d_nev; ag.ev_t = h->d_ev_t; ag.ev_ul = h->d_ev_ul; ag.ev_ur = h->d_ev_ur;
+        ag.maxev = h->maxev; ag.ev_s = h->d_ev_s; ag.nev = h->d_nev; ag.ev_t = h->d_ev_t; ag.ev_ul = h->d_ev_ul; ag.ev_ur = h->d_ev_ur; ag.ev_k = h->d_ev_k;
     } else if (P.wide) {
         // workgroup-per-trajectory family of runtime models (hipadj_wide.hpp): trajectory-major knots, Backsolve checkpoints, Quadrature records
         h->wide = true;

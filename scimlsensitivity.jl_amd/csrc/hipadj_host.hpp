@@ -85,7 +85,7 @@ struct hipadj_handle {
     bool no_ops = false; // HIPADJ_NO_OPS=1: the generic vjp_u / vjp_p form of the multi-column step also for models with stage operators (A/B study)
     double *d_rec = nullptr, *d_save_t = nullptr, *d_ck_t = nullptr, *d_tstops = nullptr, *d_arec = nullptr;
     int *d_nsteps = nullptr, *d_nsteps_adj = nullptr, ntstops = 0, SmaxA = 0;
-    int *d_ev_s = nullptr, *d_nev = nullptr, maxev = 0; double *d_ev_t = nullptr, *d_ev_ul = nullptr, *d_ev_ur = nullptr, *d_ev_dl = nullptr, *d_ev_dr = nullptr;      // ContinuousCallback of a runtime model: per-trajectory event lists (AdaptGeom::ev_s / nev), capacity maxev
+    int *d_ev_s = nullptr, *d_nev = nullptr, *d_ev_k = nullptr, maxev = 0; double *d_ev_t = nullptr, *d_ev_ul = nullptr, *d_ev_ur = nullptr, *d_ev_dl = nullptr, *d_ev_dr = nullptr;      // ContinuousCallback of a runtime model: per-trajectory event lists (AdaptGeom::ev_s / nev), capacity maxev
     bool auto_steps = false;              // max_steps == 0: record capacity sized from a counting pass of the forward solve
     long rec_cap = 0;                     // accepted steps the record buffer(s) currently hold per trajectory
     unsigned* d_ticket = nullptr;

@@ -51,7 +51,7 @@ struct UserModelSrc {
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
     std::string affect;       // DiscreteCallback affect body (hipadj_model_set_affect): modifies un (pre-set to u) from u, p, t; empty = identity
     std::string cc_cond, cc_affect;   // ContinuousCallback (hipadj_model_set_continuous_callback): the condition body assigns `c` from u, p, t; the affect body edits un (pre-set to u)
-    int cc_maxev = 0;                 // ... and the capacity of the per-trajectory event list
+    int cc_maxev = 0, cc_ncond = 1;   // ... the capacity of the per-trajectory event list, and the components of the condition (VectorContinuousCallback: `out[k]`, `idx`)
     bool cols = true;         // the VJP bodies compile for Cols<G> (column bundles); cleared by user_compile when they do not
     bool has_mm = false;      // constant non-singular mass matrix (hipadj_model_set_mass_matrix): minv = M^{-1}, row-major n x n
     double minv[64] = {0};
@@ -386,27 +386,29 @@ inline std::string user_model_struct(const UserModelSrc& m) {
     if (!m.cc_cond.empty()) {
         // ContinuousCallback(condition, affect!) (hipadj_model_set_continuous_callback; hipadj_adaptive.hpp "events", src/callback_tracking.jl:232-479): the condition and the affect
         // compile for double and for dual numbers — c_u, c_p, c_t, the directional derivative a_u v + a_t and the products a_u' lam, a_p' lam of the reverse jump
-        o << "    static constexpr bool HAS_COND = true;\n"
-          << "    template <class real> HIPADJ_HD static real cond_t(const real (&u)[N], const real (&p)[NP], real t) {\n        (void)u; (void)p; (void)t; real c = real(0.0);\n" << m.cc_cond << "\n        return c;\n    }\n"
-          << "    HIPADJ_HD static double cond(const double (&u)[N], const double (&p)[NP], double t) { return cond_t<double>(u, p, t); }\n"
-          << "    HIPADJ_HD static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, const double (&u)[N], const double (&p)[NP], double t) {\n"
-          << "        {   Dual<N> uu[N], pp[NP];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
-          << "            const Dual<N> c = cond_t<Dual<N>>(uu, pp, Dual<N>(t));\n            for (int j = 0; j < N; ++j) gu[j] = c.d[j]; }\n"
-          << "        {   Dual<NP> uu[N], pp[NP];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
-          << "            const Dual<NP> c = cond_t<Dual<NP>>(uu, pp, Dual<NP>(t));\n            for (int j = 0; j < NP; ++j) gp[j] = c.d[j]; }\n"
-          << "        {   Dual<1> uu[N], pp[NP];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<1>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<1>(p[j]);\n"
-          << "            const Dual<1> c = cond_t<Dual<1>>(uu, pp, Dual<1>::seed(t, 0));\n            gt = c.d[0]; }\n    }\n"
-          << "    template <class real> HIPADJ_HD static void cc_affect_t(real (&un)[N], const real (&u)[N], const real (&p)[NP], real t) {\n"
-          << "        (void)u; (void)p; (void)t;\n        for (int i = 0; i < N; ++i) un[i] = u[i];\n" << m.cc_affect << "\n    }\n"
-          << "    HIPADJ_HD static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t) { cc_affect_t<double>(un, u, p, t); }\n"
-          << "    HIPADJ_HD static void cc_affect_jvp(double (&out)[N], const double (&u)[N], const double (&v)[N], const double (&p)[NP], double t) {\n"
+        // (a VectorContinuousCallback: NCOND components `out[k]`, the affect sees the index `idx` of the one that fired; a scalar condition is NCOND = 1 with `c` an alias of out[0])
+        o << "    static constexpr bool HAS_COND = true;\n    static constexpr int NCOND = " << (m.cc_ncond > 0 ? m.cc_ncond : 1) << ";\n"
+          << "    template <class real> HIPADJ_HD static void cond_t(real (&out)[NCOND], const real (&u)[N], const real (&p)[NP], real t) {\n        (void)u; (void)p; (void)t;\n"
+          << "        for (int k = 0; k < NCOND; ++k) out[k] = real(0.0);\n        real& c = out[0]; (void)c;\n" << m.cc_cond << "\n    }\n"
+          << "    HIPADJ_HD static void cond(double (&out)[NCOND], const double (&u)[N], const double (&p)[NP], double t) { cond_t<double>(out, u, p, t); }\n"
+          << "    HIPADJ_HD static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, int k, const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        {   Dual<N> uu[N], pp[NP], o[NCOND];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
+          << "            cond_t<Dual<N>>(o, uu, pp, Dual<N>(t));\n            for (int j = 0; j < N; ++j) { double v = 0.0; for (int q = 0; q < NCOND; ++q) v = (q == k) ? o[q].d[j] : v; gu[j] = v; } }\n"
+          << "        {   Dual<NP> uu[N], pp[NP], o[NCOND];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
+          << "            cond_t<Dual<NP>>(o, uu, pp, Dual<NP>(t));\n            for (int j = 0; j < NP; ++j) { double v = 0.0; for (int q = 0; q < NCOND; ++q) v = (q == k) ? o[q].d[j] : v; gp[j] = v; } }\n"
+          << "        {   Dual<1> uu[N], pp[NP], o[NCOND];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<1>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<1>(p[j]);\n"
+          << "            cond_t<Dual<1>>(o, uu, pp, Dual<1>::seed(t, 0));\n            double v = 0.0; for (int q = 0; q < NCOND; ++q) v = (q == k) ? o[q].d[0] : v; gt = v; }\n    }\n"
+          << "    template <class real> HIPADJ_HD static void cc_affect_t(real (&un)[N], const real (&u)[N], const real (&p)[NP], real t, int idx) {\n"
+          << "        (void)u; (void)p; (void)t; (void)idx;\n        for (int i = 0; i < N; ++i) un[i] = u[i];\n" << m.cc_affect << "\n    }\n"
+          << "    HIPADJ_HD static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t, int idx) { cc_affect_t<double>(un, u, p, t, idx); }\n"
+          << "    HIPADJ_HD static void cc_affect_jvp(double (&out)[N], const double (&u)[N], const double (&v)[N], const double (&p)[NP], double t, int idx) {\n"
           << "        Dual<1> uu[N], pp[NP], un[N];\n        for (int j = 0; j < N; ++j) { uu[j] = Dual<1>(u[j]); uu[j].d[0] = v[j]; }\n        for (int j = 0; j < NP; ++j) pp[j] = Dual<1>(p[j]);\n"
-          << "        cc_affect_t<Dual<1>>(un, uu, pp, Dual<1>::seed(t, 0));\n        for (int j = 0; j < N; ++j) out[j] = un[j].d[0];\n    }\n"
-          << "    HIPADJ_HD static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t) {\n"
+          << "        cc_affect_t<Dual<1>>(un, uu, pp, Dual<1>::seed(t, 0), idx);\n        for (int j = 0; j < N; ++j) out[j] = un[j].d[0];\n    }\n"
+          << "    HIPADJ_HD static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double t, int idx) {\n"
           << "        {   Dual<N> uu[N], pp[NP], un[N];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<N>::seed(u[j], j);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<N>(p[j]);\n"
-          << "            cc_affect_t<Dual<N>>(un, uu, pp, Dual<N>(t));\n            for (int j = 0; j < N; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * un[i].d[j]; lo[j] = s; } }\n"
+          << "            cc_affect_t<Dual<N>>(un, uu, pp, Dual<N>(t), idx);\n            for (int j = 0; j < N; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * un[i].d[j]; lo[j] = s; } }\n"
           << "        {   Dual<NP> uu[N], pp[NP], un[N];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<NP>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<NP>::seed(p[j], j);\n"
-          << "            cc_affect_t<Dual<NP>>(un, uu, pp, Dual<NP>(t));\n            for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * un[i].d[j]; go[j] = s; } }\n    }\n";
+          << "            cc_affect_t<Dual<NP>>(un, uu, pp, Dual<NP>(t), idx);\n            for (int j = 0; j < NP; ++j) { double s = 0.0; for (int i = 0; i < N; ++i) s += lam[i] * un[i].d[j]; go[j] = s; } }\n    }\n";
     }
     if (m.has_dloss) {
         // discrete loss on the device (hipadj_model_set_discrete_loss[_function]; HIPADJ_LOSS_MODEL): dgdu_discrete(out, u, p, t_i, i) / dgdp_discrete(out, u, p, t_i, i) of
@@ -699,7 +701,7 @@ inline int user_set_affect(int32_t model, const char* body, std::string& err) {
 }
 // ContinuousCallback(condition, affect!; save_positions = (false, false)) of a runtime lane model (src/callback_tracking.jl:232-479; test/Callbacks2/continuous_callbacks.jl):
 // condition_body assigns `c` from u, p, t; affect_body edits un[0..n) (a copy of u) from u, p, t; both NULL removes the callback
-inline int user_set_continuous_callback(int32_t model, const char* cond, const char* affect, int32_t max_events, std::string& err) {
+inline int user_set_continuous_callback(int32_t model, const char* cond, const char* affect, int32_t max_events, std::string& err, int32_t ncond = 1) {
     UserRegistry& R = user_registry();
     std::lock_guard<std::mutex> lk(R.mu);
     const int idx = model - HIPADJ_MODEL_USER_BASE;
@@ -712,7 +714,8 @@ inline int user_set_continuous_callback(int32_t model, const char* cond, const c
     if (m.has_mm || m.dae) { err = "hipadj_model_set_continuous_callback: not offered on a model with a mass matrix"; return HIPADJ_ERR_UNSUPPORTED; }
     if (max_events < 0 || max_events > 4096) { err = "hipadj_model_set_continuous_callback: max_events in 0 .. 4096 (0 = 64)"; return HIPADJ_ERR_INVALID_ARG; }
     if (ha && std::string(affect).find("pn[") != std::string::npos) { err = "hipadj_model_set_continuous_callback: the affect of a ContinuousCallback edits the state (un); parameter-changing affects are offered at preset times (hipadj_model_set_affect)"; return HIPADJ_ERR_UNSUPPORTED; }
-    m.cc_cond = cond; m.cc_affect = ha ? affect : ""; m.cc_maxev = max_events > 0 ? max_events : 64; m.rev++;
+    if (ncond < 1 || ncond > 8) { err = "hipadj_model_set_vector_continuous_callback: 1 .. 8 condition components"; return HIPADJ_ERR_INVALID_ARG; }
+    m.cc_cond = cond; m.cc_affect = ha ? affect : ""; m.cc_maxev = max_events > 0 ? max_events : 64; m.cc_ncond = ncond; m.rev++;
     return HIPADJ_OK;
 }
 inline int user_model_events(int32_t model) {

@@ -120,36 +120,59 @@ template <int KAPPA, int MIX = 0> struct EmuRoberDAE {      // MIX = 1 (id + 206
 // written out by hand the way the generator of hipadj_user.hpp derives them from the registered bodies.  Model id = HIPADJ_MODEL_USER_BASE + 300 + KIND (KIND 1: the bouncing
 // ball; 4: the moving floor, condition and affect with explicit t) and + 303 (EmuRelax, kind 3: the condition depends on a parameter).
 template <int KIND> struct EmuBall {
-    static constexpr int N = 2, NP = 2;
+    static constexpr int N = 2, NP = 2, NCOND = 1;
     static constexpr bool TIME_DEP = false, HAS_COLS = false, HAS_COND = true;
     static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) { du[0] = u[1]; du[1] = -p[0]; }
     static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dl[0] = 0.0; dl[1] = l[0]; }
     static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dg[0] = -l[1]; dg[1] = 0.0; }
-    static double cond(const double (&u)[N], const double (&)[NP], double t) { return KIND == 4 ? u[0] - 0.3 * t : u[0]; }
-    static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, const double (&)[N], const double (&)[NP], double) { gu[0] = 1.0; gu[1] = 0.0; gp[0] = 0.0; gp[1] = 0.0; gt = KIND == 4 ? -0.3 : 0.0; }
-    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t) { un[0] = u[0]; un[1] = KIND == 4 ? -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t : -p[1] * u[1]; }
-    static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&p)[NP], double) { out[0] = v[0]; out[1] = -p[1] * v[1] + (KIND == 4 ? 0.1 : 0.0); }
-    static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double) {
+    static void cond(double (&out)[NCOND], const double (&u)[N], const double (&)[NP], double t) { out[0] = KIND == 4 ? u[0] - 0.3 * t : u[0]; }
+    static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, int, const double (&)[N], const double (&)[NP], double) { gu[0] = 1.0; gu[1] = 0.0; gp[0] = 0.0; gp[1] = 0.0; gt = KIND == 4 ? -0.3 : 0.0; }
+    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t, int) { un[0] = u[0]; un[1] = KIND == 4 ? -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t : -p[1] * u[1]; }
+    static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&p)[NP], double, int) { out[0] = v[0]; out[1] = -p[1] * v[1] + (KIND == 4 ? 0.1 : 0.0); }
+    static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double, int) {
         lo[0] = lam[0]; lo[1] = -p[1] * lam[1]; go[0] = 0.0; go[1] = -(u[1] - (KIND == 4 ? 0.3 : 0.0)) * lam[1];
     }
 };
 struct EmuRelax {
-    static constexpr int N = 1, NP = 2;
+    static constexpr int N = 1, NP = 2, NCOND = 1;
     static constexpr bool TIME_DEP = false, HAS_COLS = false, HAS_COND = true;
     static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) { du[0] = p[0] - u[0]; }
     static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dl[0] = -l[0]; }
     static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dg[0] = l[0]; dg[1] = 0.0; }
-    static double cond(const double (&u)[N], const double (&p)[NP], double) { return u[0] - 0.75 * p[0]; }
-    static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, const double (&)[N], const double (&)[NP], double) { gu[0] = 1.0; gp[0] = -0.75; gp[1] = 0.0; gt = 0.0; }
-    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double) { un[0] = u[0] + p[1]; }
-    static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&)[NP], double) { out[0] = v[0]; }
-    static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&)[N], const double (&)[NP], double) { lo[0] = lam[0]; go[0] = 0.0; go[1] = lam[0]; }
+    static void cond(double (&out)[NCOND], const double (&u)[N], const double (&p)[NP], double) { out[0] = u[0] - 0.75 * p[0]; }
+    static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, int, const double (&)[N], const double (&)[NP], double) { gu[0] = 1.0; gp[0] = -0.75; gp[1] = 0.0; gt = 0.0; }
+    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double, int) { un[0] = u[0] + p[1]; }
+    static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&)[NP], double, int) { out[0] = v[0]; }
+    static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&)[N], const double (&)[NP], double, int) { lo[0] = lam[0]; go[0] = 0.0; go[1] = lam[0]; }
+};
+// TEST-ONLY: the VectorContinuousCallback problem of test/Callbacks2/vector_continuous_callbacks.jl:10-16, 80-96 (oracle: ORC_MODEL_BALL2D, event_kind 5): a ball that falls in
+// x and drifts in y between two walls; condition out = [u1, (u3 - 10) u3]; component 0 reflects u2, component 1 reflects u4, both with restitution p2.  Model id = USER_BASE + 305.
+struct EmuBall2D {
+    static constexpr int N = 4, NP = 2, NCOND = 2;
+    static constexpr bool TIME_DEP = false, HAS_COLS = false, HAS_COND = true;
+    static void f(double (&du)[N], const double (&u)[N], const double (&p)[NP], double) { du[0] = u[1]; du[1] = -p[0]; du[2] = u[3]; du[3] = 0.0; }
+    static void vjp_u(double (&dl)[N], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dl[0] = 0.0; dl[1] = l[0]; dl[2] = 0.0; dl[3] = l[2]; }
+    static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dg[0] = -l[1]; dg[1] = 0.0; }
+    static void cond(double (&out)[NCOND], const double (&u)[N], const double (&)[NP], double) { out[0] = u[0]; out[1] = (u[2] - 10.0) * u[2]; }
+    static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, int k, const double (&u)[N], const double (&)[NP], double) {
+        for (int j = 0; j < N; ++j) gu[j] = 0.0;
+        gp[0] = 0.0; gp[1] = 0.0; gt = 0.0;
+        if (k == 0) gu[0] = 1.0; else gu[2] = 2.0 * u[2] - 10.0;
+    }
+    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double, int k) { for (int j = 0; j < N; ++j) un[j] = u[j]; if (k == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3]; }
+    static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&p)[NP], double, int k) { for (int j = 0; j < N; ++j) out[j] = v[j]; if (k == 0) out[1] = -p[1] * v[1]; else out[3] = -p[1] * v[3]; }
+    static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double, int k) {
+        for (int j = 0; j < N; ++j) lo[j] = lam[j];
+        go[0] = 0.0;
+        if (k == 0) { lo[1] = -p[1] * lam[1]; go[1] = -u[1] * lam[1]; } else { lo[3] = -p[1] * lam[3]; go[1] = -u[3] * lam[3]; }
+    }
 };
 static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
     const int nn = model - HIPADJ_MODEL_USER_BASE;
     if (nn >= 203 && nn <= 206) { *n = 3; *np = 3; return HIPADJ_OK; }
     if (nn == 301 || nn == 304) { *n = 2; *np = 2; return HIPADJ_OK; }
     if (nn == 303) { *n = 1; *np = 2; return HIPADJ_OK; }
+    if (nn == 305) { *n = 4; *np = 2; return HIPADJ_OK; }
     if (nn != 4 && nn != 105) return HIPADJ_ERR_INVALID_ARG;
     *n = nn % 100; *np = nn % 100 + 1;
     return HIPADJ_OK;
@@ -162,7 +185,7 @@ const double *g_emu_ev_dl = nullptr, *g_emu_ev_dr = nullptr; double* g_emu_ev_ou
 #else
 extern const double *g_emu_ev_dl, *g_emu_ev_dr; extern double* g_emu_ev_out;
 #endif
-static int emu_user_events(int32_t model) { const int nn = model - HIPADJ_MODEL_USER_BASE; return (nn == 301 || nn == 303 || nn == 304) ? EMU_MAXEV : 0; }
+static int emu_user_events(int32_t model) { const int nn = model - HIPADJ_MODEL_USER_BASE; return (nn == 301 || nn == 303 || nn == 304 || nn == 305) ? EMU_MAXEV : 0; }
 static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, plan_user_dae_hook() = &emu_user_dae, plan_user_events_hook() = &emu_user_events, true);
 
 template <class Mo>
@@ -442,10 +465,10 @@ static int run_adaptive(const hipadj_config* cfg, const Plan& P, const double* u
     std::vector<double> rec(ALG != 1 ? (size_t)(CK ? P.SmaxI : P.Smax) * RW * Np : 0), outT((size_t)P.M * N * Np), yT((size_t)N * Np), ckpt((size_t)P.nck * N * Np);
     std::vector<double> cotT(cfg->loss_kind != HIPADJ_LOSS_LSQ_SHIFT ? (size_t)P.M * N * Np : 0), dp_traj((size_t)NP * Np, 0.0);
     std::vector<int> nsteps((size_t)Np, 0);
-    std::vector<int> ev_s(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * Np : 0), nev(model_has_cond<Mo>::value ? (size_t)Np : 0);      // ContinuousCallback: the event lists (hipadj_api.hip d_ev_s / d_nev)
+    std::vector<int> ev_s(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * Np : 0), nev(model_has_cond<Mo>::value ? (size_t)Np : 0), ev_k(ev_s.size());      // ContinuousCallback: the event lists (hipadj_api.hip d_ev_s / d_nev)
     std::vector<double> ev_t(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * Np : 0), ev_ul(model_has_cond<Mo>::value ? (size_t)EMU_MAXEV * N * Np : 0);
     std::vector<double> ev_ur(ev_ul.size());
-    if (model_has_cond<Mo>::value) { g.maxev = EMU_MAXEV; g.ev_s = ev_s.data(); g.nev = nev.data(); g.ev_t = ev_t.data(); g.ev_ul = ev_ul.data(); g.ev_ur = ev_ur.data();
+    if (model_has_cond<Mo>::value) { g.maxev = EMU_MAXEV; g.ev_s = ev_s.data(); g.nev = nev.data(); g.ev_t = ev_t.data(); g.ev_ul = ev_ul.data(); g.ev_ur = ev_ur.data(); g.ev_k = ev_k.data();
                                    }
     std::vector<double> ev_dl, ev_dr;      // test hook (emu_set_event_cotangents): cotangents at the saved event states, [N][EMU_MAXEV][n] as hipadj_set_event_cotangents takes them
     if (model_has_cond<Mo>::value) for (int side = 0; side < 2; ++side) {
@@ -553,7 +576,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 
 // Build units (tests/emu.py compiles them in parallel): EMU_UNIT undefined = everything in one translation unit (the variant builds
 // of test_emu_parity.py); EMU_UNIT = 0 = the C entry points, the per-model dispatchers declared `extern template`;
-// EMU_UNIT = 1..14 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
+// EMU_UNIT = 1..15 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
 #ifndef EMU_UNIT
 #define EMU_UNIT -1
 #endif
@@ -587,6 +610,7 @@ extern template int dispatch_mode<EmuRoberDAE<5, 1>>(const hipadj_config*, const
 extern template int dispatch_mode<EmuBall<1>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuBall<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRelax>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuBall2D>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 1
 template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 2
@@ -615,6 +639,8 @@ template int dispatch_mode<EmuBall<1>>(const hipadj_config*, const Plan&, const 
 template int dispatch_mode<EmuBall<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 14
 template int dispatch_mode<EmuRelax>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 15
+template int dispatch_mode<EmuBall2D>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #endif
 
 #if EMU_UNIT <= 0
@@ -648,6 +674,7 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     case HIPADJ_MODEL_USER_BASE + 301: return dispatch_mode<EmuBall<1>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 304: return dispatch_mode<EmuBall<4>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 303: return dispatch_mode<EmuRelax>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 305: return dispatch_mode<EmuBall2D>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

@@ -9,6 +9,9 @@ the solve plays in /root/reference/test/Callbacks2/continuous_callbacks.jl:129-1
   relax       du = p1 - u, u0 = [0], tspan (0, 10), p = [100, 50], condition u - 3/4 p1, affect u += p2, G = u(10) (:314-338; the reference's comment holds the answer,
               [0.9999546000702386, 0.00018159971904994378], :342)
   *_saved     the same with save_positions = (true, true) (the constructor's default; :200-217, 239-250): the loss also takes the state just before and just after each affect
+  walls       VectorContinuousCallback (test/Callbacks2/vector_continuous_callbacks.jl:10-25, 79-96): du = [u2, -p1, u4, 0], out = [u1, (u3 - 10) u3], component 1 reflects u2,
+              component 2 reflects u4; MSE loss; u0 = [50, 0, 0, 2.01], tspan (0, 10), p = [9.8, 0.9]
+  clock       the same model with out = [sin t, cos t] and the affect u <- [0.5, 1, 0, 0] (:100-116): conditions that depend on time only, an affect with a zero Jacobian
   moving      NOT from the reference: the ball on a floor that rises with 0.3 t, condition u1 - 0.3 t, affect u2 <- -p2 (u2 - 0.3) + 0.3 + 0.1 t — condition and affect
               depend on t explicitly
 
@@ -93,6 +96,56 @@ def ballistic(kind, u0, p, T, ts, loss, save_positions=False):
                 **(dict(event_states=ev_states) if save_positions else {}))
 
 
+def ball2d(kind, u0, p, T, ts, save_positions=False):
+    """du = [u2, -p1, u4, 0] (test/Callbacks2/vector_continuous_callbacks.jl:10-16), MSE loss sum((1 - u)^2) / 2 (:79).  kind 5: out = [u1, (u3 - 10) u3], component 1 reflects
+    u2, component 2 reflects u4, both with restitution p2 (:80-96); kind 6: out = [sin t, cos t], either resets u to [0.5, 1, 0, 0] (:100-116)"""
+    x, v, y, w, g, e = seeds([u0[0], u0[1], u0[2], u0[3], p[0], p[1]])
+    K = 6
+    tb = D(0.0, np.zeros(K)); G = D(0.0, np.zeros(K)); out = []; events = []; ev_states = []; ev_idx = []
+    loss = lambda a, b, c, d: 0.5 * ((1.0 - a) * (1.0 - a) + (1.0 - b) * (1.0 - b) + (1.0 - c) * (1.0 - c) + (1.0 - d) * (1.0 - d))
+    k = 0
+    while True:
+        cands = []
+        if kind == 5:
+            disc = v * v + 2.0 * g * x
+            if disc.v >= 0:
+                sx = (v + dsqrt(disc)) / g
+                if sx.v <= 1e-12: sx = 2.0 * v / g
+                if sx.v > 1e-12: cands.append((sx, 0))
+            if w.v > 0: sy = (10.0 - y) / w
+            elif w.v < 0: sy = (0.0 - y) / w
+            else: sy = None
+            if sy is not None and sy.v <= 1e-12 and w.v != 0:      # standing on a wall right after its event: the other wall
+                sy = (10.0 - y) / w if w.v > 0 else (0.0 - y) / w
+            if sy is not None and sy.v > 1e-12: cands.append((sy, 1))
+        else:
+            m = math.floor(tb.v / (math.pi / 2) + 1e-9) + 1
+            cands.append((D(m * math.pi / 2, np.zeros(K)) - tb, 0 if m % 2 == 0 else 1))      # sin t = 0 at even multiples of pi / 2, cos t = 0 at odd ones
+        s, idx = min(cands, key=lambda c: c[0].v) if cands else (None, None)
+        te = tb + s if s is not None else None
+        while k < len(ts) and (te is None or ts[k] < te.v or te.v >= T):
+            if ts[k] > T: break
+            d = ts[k] - tb
+            st = (x + v * d - 0.5 * g * d * d, v - g * d, y + w * d, w)
+            out.append([q.v if isinstance(q, D) else q for q in st])
+            G = G + loss(*st)
+            k += 1
+        if te is None or te.v >= T or k >= len(ts):
+            break
+        left = (x + v * s - 0.5 * g * s * s, v - g * s, y + w * s, w)
+        events.append(te.v); ev_idx.append(idx)
+        if kind == 5:
+            x, v, y, w = (left[0], -e * left[1], left[2], left[3]) if idx == 0 else (left[0], left[1], left[2], -e * left[3])
+        else:
+            x, v, y, w = [D(c, np.zeros(K)) for c in (0.5, 1.0, 0.0, 0.0)]
+        if save_positions:
+            G = G + loss(*left) + loss(x, v, y, w)
+            ev_states.append([[q.v for q in left], [x.v, v.v, y.v, w.v]])
+        tb = te
+    return dict(u0=list(u0), p=list(p), tspan=[0.0, T], ts=list(ts), kind=kind, u_at_ts=out, event_times=events, event_components=ev_idx, G=G.v, du0=G.g[:4].tolist(), dp=G.g[4:].tolist(),
+                **(dict(event_states=ev_states) if save_positions else {}))
+
+
 def relax():
     u0v, pv, T = [0.0], [100.0, 50.0], 10.0
     u0, a, m = seeds([u0v[0], pv[0], pv[1]])
@@ -118,6 +171,11 @@ if __name__ == "__main__":
         ball_long_saved=ballistic(1, [5.0, 0.0], [9.8, 0.8], 5.0, np.arange(0.0, 5.0 + 1e-12, 0.5).tolist(), ssum, save_positions=True),
         ball_mse_saved=ballistic(2, [5.0, 0.0], [9.8, 0.8], 2.5, ts, mse, save_positions=True),            # "callback with non-linear affect", MSE loss, :239-250
         moving_saved=ballistic(4, [5.0, 0.0], [9.8, 0.8], 4.0, np.arange(0.0, 4.0 + 1e-12, 0.5).tolist(), ssum, save_positions=True),
+        # VectorContinuousCallback, test/Callbacks2/vector_continuous_callbacks.jl: u0 = [50, 0, 0, 2.01], tspan (0, 10), p = [9.8, 0.9] (:23-25), saveat 0.5
+        walls=ball2d(5, [50.0, 0.0, 0.0, 2.01], [9.8, 0.9], 10.0, np.arange(0.0, 10.0 + 1e-12, 0.5).tolist()),
+        walls_saved=ball2d(5, [50.0, 0.0, 0.0, 2.01], [9.8, 0.9], 10.0, np.arange(0.0, 10.0 + 1e-12, 0.5).tolist(), save_positions=True),
+        clock=ball2d(6, [50.0, 0.0, 0.0, 2.01], [9.8, 0.9], 10.0, np.arange(0.0, 10.0 + 1e-12, 0.5).tolist()),
+        clock_saved=ball2d(6, [50.0, 0.0, 0.0, 2.01], [9.8, 0.9], 10.0, np.arange(0.0, 10.0 + 1e-12, 0.5).tolist(), save_positions=True),
         source="tests/golden/make_continuous_callbacks.py: closed forms differentiated with dual numbers")
     json.dump(out, open(os.path.join(HERE, "continuous_callbacks.json"), "w"), indent=1)
     print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk != "u_at_ts"} if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB_PATH = os.path.join(_ORACLE_DIR, "liboracle_adjoint.so")
 
-MODEL = dict(LV=0, LVT=1, LORENZ=2, LINDIAG=3, FALLMASS=4, MLP=5, BRUSS=6, ROBER=7, RING=8, AFFINE3=9, IDXAFF=10, MLP1=11, DENSELIN=12, PENDULUM=13, LIN1P=14, ROBERDAE=15, RELAX=16)
+MODEL = dict(LV=0, LVT=1, LORENZ=2, LINDIAG=3, FALLMASS=4, MLP=5, BRUSS=6, ROBER=7, RING=8, AFFINE3=9, IDXAFF=10, MLP1=11, DENSELIN=12, PENDULUM=13, LIN1P=14, ROBERDAE=15, RELAX=16, BALL2D=17)
 ALG = dict(INTERPOLATING=0, BACKSOLVE=1, GAUSS=2, QUADRATURE=3, GAUSS_KRONROD=4)
 STEPPER = dict(RK4=0, TSIT5=1, ETDRK4=2, ROS23=3)
 LOSS = dict(COTANGENT=0, LSQ_SHIFT=1, LSQ_DATA=2, TEST=3)

@@ -204,6 +204,53 @@ def test_loss_on_the_saved_event_states(gold, case, alg, oalg):
     assert relmax(edu0[0], edp, g) < 1e-11 and relc(edu0[0], du0) < 1e-10 and relc(edp, dp) < 1e-10
 
 
+# ---- VectorContinuousCallback ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case,kind", [("walls", 5), ("walls_saved", 5), ("clock", 6), ("clock_saved", 6)])
+def test_vector_callback_against_the_closed_forms(gold, case, kind, alg, oalg):
+    """test/Callbacks2/vector_continuous_callbacks.jl: a vector of conditions, the affect sees which one fired — the ball between two walls (:80-96: components fire in the order
+    0, 1, 0) and conditions that depend on time only with an affect whose Jacobian is zero (:100-116: six events, alternating components); MSE loss, with and without the saved
+    event states (the testsets use the default save_positions = (true, true)).  Oracle (every sensealg) and — the walls — the lane bodies"""
+    g = gold[case]; ts = np.asarray(g["ts"]); n = 4; saved = case.endswith("_saved")
+    pr = O.Problem("BALL2D", alg=oalg, stepper="TSIT5", t0=0.0, t1=10.0, dt=0.0, abstol=1e-12, reltol=1e-12, save_times=ts, event_kind=kind, loss="LSQ_SHIFT", loss_shift=1.0, **QTOL)
+    t, ul, ur = pr.event_states(np.asarray(g["u0"]), np.asarray(g["p"]))
+    assert len(t) == len(g["event_times"]) and np.max(np.abs(t - np.asarray(g["event_times"]))) < 1e-11
+    if saved:
+        es = np.asarray(g["event_states"])
+        assert np.max(np.abs(ul - es[:, 0])) < 1e-9 and np.max(np.abs(ur - es[:, 1])) < 1e-9
+        pr.set_event_cotangents(ul - 1.0, ur - 1.0)
+    du0, dp, out = pr.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), None)
+    assert relmax(du0, dp, g) < 1e-11 and np.max(np.abs(out - np.asarray(g["u_at_ts"]))) < 1e-10
+    if kind != 5:
+        return
+    ne = len(t)
+    cfg = E.make_config("emu_ball2d", alg, 1, 0.0, 10.0, 0.0, ts, loss_kind=1, loss_shift=1.0, stepper=TS5, abstol=1e-12, reltol=1e-12, max_steps=4000, **QTOL)
+    pad = lambda a: np.concatenate([a, np.zeros((E.EMU_MAXEV - ne, n))])[None]
+    keep = E.set_event_cotangents(pad(ul - 1.0), pad(ur - 1.0)) if saved else None
+    try:
+        edu0, edp, eout = E.forward_adjoint(cfg, n, 2, [g["u0"]], g["p"])
+    finally:
+        E.set_event_cotangents(None, None)
+    del keep
+    assert relmax(edu0[0], edp, g) < 1e-11 and relc(edu0[0], du0) < 1e-10 and relc(edp, dp) < 1e-10 and np.max(np.abs(eout[0] - out)) < 1e-10
+
+
+def test_vector_callback_registration_and_kernels(tmp_path, monkeypatch):
+    """hipadj_model_set_vector_continuous_callback: `out[k]` in the condition body, `idx` in the affect body; ncond outside 1 .. 8 refused; the kernels through hiprtc"""
+    from scimlsensitivity_jl_amd import _lib
+    for kind in (5, 6):
+        m, nc, cond, aff = UM.VECTOR_EVENTS[kind]
+        mid = _lib.register_model(f"cc_vec_lint_{kind}", m["n"], m["np"], m["f"], m["vjp"], m["vjp_p"])
+        with pytest.raises(_lib.HipadjError) as ei:
+            _lib.set_model_continuous_callback(mid, cond, aff, 0, 9)
+        assert ei.value.status == _lib.ERR_INVALID_ARG
+        _lib.set_model_continuous_callback(mid, cond, aff, 8, nc)
+        L = _lib.load()
+        for alg, stepper in (("interpolating", TS5), ("backsolve", ROS), ("quadrature", TS5)):
+            cfg = E.make_config(f"cc_vec_lint_{kind}", alg, 53, 0.0, 10.0, 0.0, [0.5, 5.0, 10.0], loss_kind=1, loss_shift=1.0, stepper=stepper, abstol=1e-8, reltol=1e-8)
+            assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+
+
 # ---- the C ABI without a device ------------------------------------------------------------------------------------------------------------------------------------------
 def test_registration_entry_point_and_its_refusals():
     from scimlsensitivity_jl_amd import _lib

@@ -288,3 +288,36 @@ def test_saved_event_states_of_an_ensemble(sa):
         rdu0, rdp, _ = ref.adjoint(u0[i], p[i], d[i])
         a = np.concatenate([du0[i], dp[i]]); b = np.concatenate([rdu0, rdp])
         assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-7
+
+
+def vmodel(sa, kind, auto=False):
+    key = ("vec", kind, auto)
+    if key not in _registered:
+        m, nc, cond, aff = UM.VECTOR_EVENTS[kind]
+        f = sa.DeviceFunction(f"cc_vec{kind}_{int(auto)}", m["n"], m["np"], m["f"], None if auto else m["vjp"], None if auto else m["vjp_p"])
+        f.set_continuous_callback(cond, aff, 0, ncond=nc)
+        _registered[key] = f
+    return _registered[key]
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case,kind", [("walls", 5), ("walls_saved", 5), ("clock", 6), ("clock_saved", 6)])
+def test_vector_callback_against_the_closed_forms(sa, gold, case, kind, alg, oalg):
+    """VectorContinuousCallback (test/Callbacks2/vector_continuous_callbacks.jl:80-116): the ball between two walls and the time-only conditions, condition and affect as text
+    (`out[k]`, `idx`), MSE loss with and without the saved event states: event times, which component fired, states and gradients against the closed forms, every sensealg"""
+    g = gold[case]; ts = np.asarray(g["ts"]); saved = case.endswith("_saved"); ne = len(g["event_times"])
+    u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(vmodel(sa, kind, auto=(alg == "gauss")), u0[0], (0.0, 10.0), p), u0), sa.Tsit5(), saveat=ts, sensealg=sens(sa, alg), abstol=1e-12, reltol=1e-12,
+                   dgdu_discrete=sa.LsqShift(1.0))
+    t, ul, ur, cnt = sol.engine.event_states()
+    assert cnt.tolist() == [ne] and np.max(np.abs(t[0, :ne] - np.asarray(g["event_times"]))) < 1e-10
+    assert np.max(np.abs(np.array(sol.u)[0] - np.asarray(g["u_at_ts"]))) < 1e-9
+    if saved:
+        es = np.asarray(g["event_states"])
+        assert np.max(np.abs(ul[0, :ne] - es[:, 0])) < 1e-9 and np.max(np.abs(ur[0, :ne] - es[:, 1])) < 1e-9
+        dl = np.zeros_like(ul); dr = np.zeros_like(ur); dl[0, :ne] = ul[0, :ne] - 1.0; dr[0, :ne] = ur[0, :ne] - 1.0
+        sol.engine.set_event_cotangents(dl, dr)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts)
+    sol.engine.close()
+    a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g["du0"], g["dp"]])
+    assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-9

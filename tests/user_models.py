@@ -82,3 +82,12 @@ EVENTS = {  # event_kind -> (model, condition body, affect body)
     3: (RELAX, "c = u[0] - 0.75 * p[0];", "un[0] = u[0] + p[1];"),                 # :324-327
     4: (BALL, "c = u[0] - 0.3 * t;", "un[1] = -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t;"),   # NOT from the reference: explicit t in both
 }
+BALL2D = dict(  # `f` of test/Callbacks2/vector_continuous_callbacks.jl:10-16 (oracle: ORC_MODEL_BALL2D)
+    n=4, np=2,
+    f="du[0] = u[1]; du[1] = -p[0]; du[2] = u[3]; du[3] = 0.0;",
+    vjp="out[0] = 0.0; out[1] = lam[0]; out[2] = 0.0; out[3] = lam[2];",
+    vjp_p="out[0] = -lam[1]; out[1] = 0.0;")
+VECTOR_EVENTS = {  # event_kind -> (model, ncond, condition body, affect body)
+    5: (BALL2D, 2, "out[0] = u[0]; out[1] = (u[2] - 10.0) * u[2];", "if (idx == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3];"),      # :80-96
+    6: (BALL2D, 2, "out[0] = sin(t); out[1] = cos(t);", "un[0] = 0.5; un[1] = 1.0; un[2] = 0.0; un[3] = 0.0;"),                          # :100-116
+}
