@@ -538,7 +538,8 @@ typedef struct {
     double *u0, *u1;       /* [nsteps][n] */
     double *k;             /* [nsteps][nk][n]; RK4: k[0]=f(u0,t0), k[1]=f(u1,t1) (FSAL pair) ; Tsit5: 7 stages */
     double *hfull;         /* length of the step the stages belong to: t1 - t0, except on a step a ContinuousCallback cut short (t1 = the event time; section 3b) */
-    long *ev_s; int *ev_k; int nev, ev_cap;   /* events of the solve, ascending in time: ev_s[k] = index of the first record AFTER event k (it starts at the event time, from the affected state) */
+    long *ev_s; int *ev_k; int nev, ev_cap;
+    int terminated;        /* terminate!: the last event ended the solve */   /* events of the solve, ascending in time: ev_s[k] = index of the first record AFTER event k (it starts at the event time, from the affected state) */
 } orc_dense;
 
 /* Dense solutions are recycled per thread: an ensemble run would otherwise grow and free ~100 KB of arrays per trajectory on
@@ -552,7 +553,7 @@ static void dense_init(orc_dense *d, int n, int kind) {
     int nk = (kind == ORC_STEPPER_TSIT5) ? 7 : 2;      /* (Rosenbrock23: k1, k2) */
     for (int i = 0; i < ORC_DENSE_POOL; ++i)
         if (tls_pool_used[i] == 1 && tls_pool[i].n == n && tls_pool[i].nk == nk) {
-            *d = tls_pool[i]; tls_pool_used[i] = 0; d->kind = kind; d->nsteps = 0; d->nev = 0; return;
+            *d = tls_pool[i]; tls_pool_used[i] = 0; d->kind = kind; d->nsteps = 0; d->nev = 0; d->terminated = 0; return;
         }
     memset(d, 0, sizeof(*d)); d->n = n; d->kind = kind; d->nk = nk;
 }
@@ -614,6 +615,9 @@ static void dense_eval(const orc_dense *d, double t, double *y, long *hint) {
     if (hint) *hint = lo;
     dense_eval_step(d, lo, t, y);
 }
+
+/* time of event k of a solution (section 3b): the start of the record after it — or, for the event that terminated the solve, the end of the last record */
+static double dense_event_time(const orc_dense *d, int k) { return d->ev_s[k] < d->nsteps ? d->t0[d->ev_s[k]] : d->t1[d->nsteps - 1]; }
 
 /* integrator state handed to post-step callbacks (the `integrator` of DiffEq callbacks) */
 typedef struct orc_integ {
@@ -1089,7 +1093,8 @@ static int dae_consistent_init(const orc_model *m, double *u, const double *p, d
  *     gradient, which needs the term (-kappa c_p = 2.7e-4 there); the restatement follows the mathematics (tests/golden/make_continuous_callbacks.py has the closed forms).
  * ===================================================================================== */
 #define ORC_MAXCOND 2
-static int ev_ncond(int kind) { return kind >= 5 ? 2 : 1; }
+static int ev_ncond(int kind) { return (kind == 5 || kind == 6) ? 2 : 1; }
+static int ev_terminates(int kind) { return kind == 7; }
 static void ev_cond(int kind, double *out, const double *u, const double *p, double t) {
     switch (kind) {
     case 3: out[0] = u[0] - 0.75 * p[0]; break;
@@ -1115,6 +1120,7 @@ static void ev_cond_grad(int kind, int k, int n, int np, const double *u, const 
 }
 static void ev_affect(int kind, int k, int n, double *un, const double *u, const double *p, double t) {
     for (int i = 0; i < n; ++i) un[i] = u[i];
+    if (kind == 7) kind = 1;
     switch (kind) {
     case 1: un[1] = -p[1] * u[1]; break;
     case 2: un[0] = u[0] + 3.0; un[1] = u[1] * u[1]; break;
@@ -1129,6 +1135,7 @@ static void ev_affect(int kind, int k, int n, double *un, const double *u, const
 static void ev_affect_jvp(int kind, int k, int n, double *out, const double *u, const double *v, const double *p, double t) {
     (void)t;
     for (int i = 0; i < n; ++i) out[i] = v[i];
+    if (kind == 7) kind = 1;
     switch (kind) {
     case 1: out[1] = -p[1] * v[1]; break;
     case 2: out[1] = 2.0 * u[1] * v[1]; break;
@@ -1143,6 +1150,7 @@ static void ev_affect_vjp(int kind, int k, int n, int np, double *lo, double *go
     (void)t;
     for (int i = 0; i < n; ++i) lo[i] = lam[i];
     for (int i = 0; i < np; ++i) go[i] = 0.0;
+    if (kind == 7) kind = 1;
     switch (kind) {
     case 1: lo[1] = -p[1] * lam[1]; go[1] = -u[1] * lam[1]; break;
     case 2: lo[1] = 2.0 * u[1] * lam[1]; break;
@@ -1189,6 +1197,7 @@ static int fwd_event_cb(orc_integ *I, void *c) {
     d->ev_s[d->nev++] = s + 1;
     ev_affect(E->kind, kx, n, I->u, y, E->p, tev);
     I->t = tev; E->nudge = 1;
+    if (ev_terminates(E->kind)) { d->terminated = 1; I->t = E->tend; }      /* terminate!: the integrator's loop ends; the solution's last record ends at the event */
     return 1;
 }
 
@@ -1223,8 +1232,8 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
     }
     fwd_event_ctx ev; memset(&ev, 0, sizeof(ev)); ev.m = m; ev.p = p; ev.kind = cfg->event_kind; ev.sol = sol; ev.tend = tb;
     if (cfg->event_kind) {
-        if (cfg->event_kind < 1 || cfg->event_kind > 6 || (cfg->stepper != ORC_STEPPER_TSIT5 && cfg->stepper != ORC_STEPPER_ROS23) || g_mm_n == m->n || g_mm_dae || m->n > ORC_MM_MAXN) return -6;
-        if ((cfg->event_kind == 3) != (m->id == ORC_MODEL_RELAX) || (cfg->event_kind >= 5) != (m->id == ORC_MODEL_BALL2D) || (cfg->event_kind != 3 && cfg->event_kind < 5 && (m->n != 2 || m->np < 2))) return -6;
+        if (cfg->event_kind < 1 || cfg->event_kind > 7 || (cfg->stepper != ORC_STEPPER_TSIT5 && cfg->stepper != ORC_STEPPER_ROS23) || g_mm_n == m->n || g_mm_dae || m->n > ORC_MM_MAXN) return -6;
+        if ((cfg->event_kind == 3) != (m->id == ORC_MODEL_RELAX) || (cfg->event_kind == 5 || cfg->event_kind == 6) != (m->id == ORC_MODEL_BALL2D) || ((cfg->event_kind == 1 || cfg->event_kind == 2 || cfg->event_kind == 4 || cfg->event_kind == 7) && (m->n != 2 || m->np < 2))) return -6;
         ev_cond(cfg->event_kind, ev.cprev, u, p, ta);
         for (int k = 0; k < ev_ncond(cfg->event_kind); ++k) if (ev.cprev[k] == 0.0) ev.nudge = 1;
     }
@@ -1688,7 +1697,8 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     int st = forward_dense(m, cfg, p, cfg->t0, cfg->t1, uend, 0.0, &sol, nrhs);
     if (st) { dense_free(&sol); free(uend); return st; }
     long hint = -1;
-    if (out) for (int i = 0; i < M; ++i) dense_eval(&sol, cfg->save_times[i], out + (size_t)i * n, &hint);
+    const double t_term = sol.terminated ? sol.t1[sol.nsteps - 1] : 0.0;      /* terminate!: the solution ends there; later save times hold the final state and carry no loss */
+    if (out) for (int i = 0; i < M; ++i) { if (sol.terminated && cfg->save_times[i] > t_term) memcpy(out + (size_t)i * n, uend, sizeof(double) * n); else dense_eval(&sol, cfg->save_times[i], out + (size_t)i * n, &hint); }
     /* checkpoints: default = sol.t of the saveat solve = save_times (+ endpoints forced: concrete_solve.jl:695-700) */
     int nck = 0; double *ck_t = NULL, *ck_u = NULL;
     int use_ckpt = cfg->checkpointing && cfg->alg != ORC_ALG_QUADRATURE;
@@ -1699,7 +1709,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
         for (int i = 0; i < nsrc; ++i) ck_t[nck++] = src[i];
         if (ck_t[nck - 1] < cfg->t1) ck_t[nck++] = cfg->t1;
         ck_u = (double *)malloc(sizeof(double) * (size_t)nck * n);
-        for (int i = 0; i < nck; ++i) dense_eval(&sol, ck_t[i], ck_u + (size_t)i * n, &hint);
+        for (int i = 0; i < nck; ++i) { if (sol.terminated && ck_t[i] > t_term) memcpy(ck_u + (size_t)i * n, uend, sizeof(double) * n); else dense_eval(&sol, ck_t[i], ck_u + (size_t)i * n, &hint); }
     }
     clock_gettime(CLOCK_MONOTONIC, &c1);
 
@@ -1759,16 +1769,22 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
         double *pts = (double *)malloc(sizeof(double) * (size_t)(nts + 1));
         double *w = (double *)calloc((size_t)6 * n + 2 * (size_t)np, sizeof(double)), *ym = w, *yp = w + n, *fm = w + 2 * n, *fp = w + 3 * n, *gu = w + 4 * n, *jf = w + 5 * n, *gp = w + 6 * n, *go = gp + np;
         A.use_win = (cfg->alg != ORC_ALG_BACKSOLVE);
+        if (sol.terminated) {      /* terminate!: nothing lies above the last event — the piece (t*, T) is skipped (lam = 0), loss and checkpoint times above t* are passed over */
+            while (A.cur_time >= 1 && cfg->save_times[A.cur_time - 1] > t_term && !time_hits(cfg->save_times[A.cur_time - 1], t_term)) A.cur_time -= 1;
+            while (cfg->alg == ORC_ALG_BACKSOLVE && A.bs_cur >= 1 && ck_t && ck_t[A.bs_cur - 1] > t_term) A.bs_cur -= 1;
+        }
         for (int e = sol.nev; e >= 0 && st == 0; --e) {
-            const double t_hi = (e == sol.nev) ? cfg->t1 : sol.t0[sol.ev_s[e]], t_lo = (e == 0) ? cfg->t0 : sol.t0[sol.ev_s[e - 1]];
-            A.win_lo = (e == 0) ? 0 : sol.ev_s[e - 1]; A.win_hi = (e == sol.nev) ? sol.nsteps - 1 : sol.ev_s[e] - 1;
+            const double t_hi = (e == sol.nev) ? cfg->t1 : dense_event_time(&sol, e), t_lo = (e == 0) ? cfg->t0 : dense_event_time(&sol, e - 1);
+            A.win_lo = (e == 0) ? 0 : sol.ev_s[e - 1]; A.win_hi = (e == sol.nev) ? sol.nsteps - 1 : sol.ev_s[e] - 1;      /* (never used for the skipped piece above a terminating event) */
             int npts = 0;
             for (int i = 0; i < nts; ++i) if (tst[i] >= t_lo && tst[i] <= t_hi) pts[npts++] = tst[i];      /* (a loss time that coincides with an event belongs to the piece above it: it sees the affected state) */
-            st = integrate(rhs, &A, nz, z, t_hi, t_lo, &alg, pts, npts, adjoint_step_cb, &A, e == sol.nev ? cb_at_init : 0, have_rec ? &adjrec : NULL, nrhs);
+            if (!(sol.terminated && e == sol.nev))
+                st = integrate(rhs, &A, nz, z, t_hi, t_lo, &alg, pts, npts, adjoint_step_cb, &A, e == sol.nev ? cb_at_init : 0, have_rec ? &adjrec : NULL, nrhs);
             if (e == 0 || st) break;
             const double tev = t_lo; const long sm = sol.ev_s[e - 1] - 1, sp = sol.ev_s[e - 1];
             double gt = 0.0, num = 0.0, den = 0.0;
-            dense_eval_step(&sol, sm, tev, ym); dense_eval_step(&sol, sp, tev, yp);
+            dense_eval_step(&sol, sm, tev, ym);
+            if (sp < sol.nsteps) dense_eval_step(&sol, sp, tev, yp); else memcpy(yp, uend, sizeof(double) * n);      /* (the terminating event: the state after it is the solve's final state) */
             if (cfg->alg == ORC_ALG_BACKSOLVE) {      /* y+ is the backsolved state; the y block goes on from the stored left state (copy_to_integrator!, src/callback_tracking.jl:377) */
                 memcpy(yp, z + n + np, sizeof(double) * n); memcpy(z + n + np, ym, sizeof(double) * n);
             }
@@ -1806,10 +1822,11 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
         memset(dp, 0, sizeof(double) * np);
         /* section 3b: lam and y jump at the events — an interval is split there, every part integrated on its own with the interval's tolerances */
 #define QUAD_INTERVAL(a_, b_) do { double pa_ = (a_); const double pb_ = (b_); int ke_ = 0; \
-            for (;;) { while (cfg->event_kind && ke_ < sol.nev && !(sol.t0[sol.ev_s[ke_]] > pa_)) ++ke_; \
-                const double pe_ = (cfg->event_kind && ke_ < sol.nev && sol.t0[sol.ev_s[ke_]] < pb_) ? sol.t0[sol.ev_s[ke_]] : pb_; \
+            if (sol.terminated && !(pa_ < t_term)) break;      /* (terminate!: lam = 0 above the last event) */ \
+            for (;;) { while (cfg->event_kind && ke_ < sol.nev && !(dense_event_time(&sol, ke_) > pa_)) ++ke_; \
+                const double pe_ = (cfg->event_kind && ke_ < sol.nev && dense_event_time(&sol, ke_) < pb_) ? dense_event_time(&sol, ke_) : pb_; \
                 quadgk_vec(quad_integrand, &Q, np, pa_, pe_, atol, rtol, seg, &nev); for (int j_ = 0; j_ < np; ++j_) dp[j_] += seg[j_]; \
-                if (pe_ < pb_) pa_ = pe_; else break; } } while (0)
+                if (pe_ < pb_ && !(sol.terminated && !(pe_ < t_term))) pa_ = pe_; else break; } } while (0)
         if (M == 0) QUAD_INTERVAL(cfg->t0, cfg->t1);
         else {
             if (cfg->save_times[M - 1] != cfg->t1) QUAD_INTERVAL(cfg->save_times[M - 1], cfg->t1);
@@ -1848,7 +1865,7 @@ int orc_forward(const orc_config *cfg, const double *u0, const double *p, double
     long nrhs = 0;
     int st = forward_dense(&m, cfg, p, cfg->t0, cfg->t1, u, 0.0, &sol, &nrhs);
     long hint = -1;
-    if (!st && out) for (int i = 0; i < cfg->nsave; ++i) dense_eval(&sol, cfg->save_times[i], out + (size_t)i * m.n, &hint);
+    if (!st && out) for (int i = 0; i < cfg->nsave; ++i) { if (sol.terminated && cfg->save_times[i] > sol.t1[sol.nsteps - 1]) memcpy(out + (size_t)i * m.n, u, sizeof(double) * m.n); else dense_eval(&sol, cfg->save_times[i], out + (size_t)i * m.n, &hint); }
     if (nsteps) *nsteps = sol.nsteps;
     dense_free(&sol); free(u); free(m.work);
     return st;
@@ -1862,10 +1879,10 @@ int orc_event_states(const orc_config *cfg, const double *u0, const double *p, i
     int st = forward_dense(&m, cfg, p, cfg->t0, cfg->t1, u, 0.0, &sol, &nrhs);
     int ne = sol.nev;
     if (!st) for (int k = 0; k < ne && k < cap; ++k) {
-        const long sp = sol.ev_s[k]; const double tev = sol.t0[sp];
+        const long sp = sol.ev_s[k]; const double tev = dense_event_time(&sol, k);
         if (t) t[k] = tev;
         if (ul) dense_eval_step(&sol, sp - 1, tev, ul + (size_t)k * m.n);
-        if (ur) dense_eval_step(&sol, sp, tev, ur + (size_t)k * m.n);
+        if (ur) { if (sp < sol.nsteps) dense_eval_step(&sol, sp, tev, ur + (size_t)k * m.n); else memcpy(ur + (size_t)k * m.n, u, sizeof(double) * m.n); }
     }
     dense_free(&sol); free(u);
     return st ? st : ne;

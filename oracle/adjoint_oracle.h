@@ -103,6 +103,8 @@ typedef struct {
                              2: c = u1, u1 += 3, u2 <- u2^2 (:243-250, the non-linear affect);
                              3: c = u1 - 3/4 p1, u1 += p2 (:324-327: a condition that depends on a parameter; ORC_MODEL_RELAX);
                              4: c = u1 - 0.3 t, u2 <- -p2 (u2 - 0.3) + 0.3 + 0.1 t (NOT from the reference: condition and affect depend on t explicitly, so that c_t and a_t are not zero);
+                             7: event 1 with terminate!(integrator) in the affect (test/Callbacks2/continuous_callbacks.jl:226-236): the solve ends at the first bounce; save
+                                times after it hold the final state and carry no loss;
                              VectorContinuousCallback (a vector of conditions; the affect sees which component fired; ORC_MODEL_BALL2D):
                              5: out = [u1, (u3 - 10) u3]; component 1: u2 <- -p2 u2, component 2: u4 <- -p2 u4 (test/Callbacks2/vector_continuous_callbacks.jl:80-96);
                              6: out = [sin t, cos t]; either: u <- [0.5, 1, 0, 0] (:100-116: conditions that depend on time only, an affect whose Jacobian is zero) */

@@ -831,7 +831,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     // VectorContinuousCallback (Mo::NCOND > 1: `out[k] = ...` in the condition body, `idx` in the affect body): the scan watches every component; the event is the FIRST crossing
     // of the step, of the lowest component among those that cross in the same tenth (simultaneous fires of several components are not merged: DESIGN.md section 4.12)
     constexpr int NC = model_ncond<Mo>::value;
-    double cprev[NC]; bool nudge = false; int nevl = 0, evk = 0;
+    double cprev[NC]; bool nudge = false, terminated = false; int nevl = 0, evk = 0;
     for (int k = 0; k < NC; ++k) cprev[k] = 0.0;
     if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) { Mo::cond(cprev, u, pv, g.t0); for (int k = 0; k < NC; ++k) nudge = nudge || (cprev[k] == 0.0); } }
     auto fcb = [&](double& t, double tprev, double (&un)[N], const auto& KK) -> bool {
@@ -885,10 +885,12 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
 #pragma unroll
                                 for (int q = 0; q < N; ++q) c[m][q] *= r;
                                 r *= thb; }
-                            Mo::cc_affect(un, y, pv, tev, kx);
+                            // terminate!(integrator) (the affect body set `terminate`): the event is recorded with bit 8 of its component index, the lane's solve ends here, the save and
+                            // checkpoint times after it hold the state after the affect
+                            terminated = Mo::cc_affect(un, y, pv, tev, kx);
 #pragma unroll
                             for (int q = 0; q < N; ++q) uleft[q] = y[q];
-                            t = tev; h = tev - tprev; nudge = true; event = true; evk = kx;
+                            t = tev; h = tev - tprev; nudge = true; event = true; evk = kx | (terminated ? 256 : 0);
                         }
                     }
                 }
@@ -925,6 +927,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = y[j];
                 ++mc; tc_next = mc < g.nck ? ck_t[mc] : TINF; }
             (void)un;
+            if constexpr (model_has_cond<Mo>::value) { if (terminated) t = g.t1; }      // (after the step's save / checkpoint times were served up to the event: the integrator's loop ends)
             return event;
         };
     int na;
@@ -933,7 +936,19 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         na = ros23_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.maxit, K, frhs, lin, !Mo::TIME_DEP, fcb);
     } else na = tsit5_integrate<N>(u, g.t0, g.t1, g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.maxit, K, frhs, fcb);
     nsteps[i] = s;   // the TRUE count, also beyond the capacity: the host sizes the buffers from it (flag bit 4 marks the overflow)
-    if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) g.nev[i] = nevl; }
+    if constexpr (model_has_cond<Mo>::value) {
+        if (g.maxev > 0) g.nev[i] = nevl;
+        if (terminated) {      // the reference's solution ends at the event; here every later save / checkpoint time holds the final state (their cotangents are ignored by the reverse pass)
+            while (outT && ms < g.M) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) outT[((long)ms * N + j) * g.Npad + i] = u[j];
+                ++ms; }
+            while (ckpt && mc < g.nck) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) ckpt[((long)mc * N + j) * g.Npad + i] = u[j];
+                ++mc; }
+        }
+    }
     if (yT) {
 #pragma unroll
         for (int j = 0; j < N; ++j) yT[(long)j * g.Npad + i] = u[j]; }
@@ -1405,13 +1420,24 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             // BacksolveAdjoint (z = [lam; mu; y], no forward record): y+ is the backsolved state, y- the left state the forward solve stored; the y block goes on from y-
             const int nevl = g.maxev > 0 ? (g.nev[i] < g.maxev ? g.nev[i] : g.maxev) : 0;
             if constexpr (ALG != 1) cur.smin = nevl > 0 ? g.ev_s[(long)(nevl - 1) * g.Npad + i] : 0;
+            // terminate!: the last event ended the lane's forward solve — nothing lies above it: the piece (t*, T) is skipped (lam = 0 there), the loss and checkpoint times above t*
+            // are passed over, and the jump at t* sees lam+ = 0 (the loss on the final state arrives as the event's dr, hipadj_set_event_cotangents)
+            const bool term = nevl > 0 && (g.ev_k[(long)(nevl - 1) * g.Npad + i] & 256) != 0;
+            if (term) {
+                const double tte = g.ev_t[(long)(nevl - 1) * g.Npad + i];
+                while (cur_time >= 1 && save_t[cur_time - 1] > tte && !time_hits(save_t[cur_time - 1], tte)) --cur_time;
+                t_loss = cur_time >= 1 ? save_t[cur_time - 1] : 0.0;
+                if (ALG == 1 && ckpt) { while (bs_cur >= 1 && ck_t[bs_cur - 1] > tte) --bs_cur; t_ck = bs_cur >= 1 ? ck_t[bs_cur - 1] : 0.0; }
+            }
 #pragma unroll 1
             for (int e = nevl; e >= 0; --e) {
                 const double t_hi = (e == nevl) ? g.t1 : g.ev_t[(long)e * g.Npad + i];
                 const double t_lo = e > 0 ? g.ev_t[(long)(e - 1) * g.Npad + i] : g.t0;
+                if (!(term && e == nevl)) {
                 const int r = run_piece(t_hi, t_lo, e == nevl && cb_at_init);
                 if (r < 0) { na = -1; break; }
                 na += r;
+                }
                 if (e == 0) break;
                 double yp[N], ym[N], fm[N], fp[N], gu[N], gp[NP], jf[N], lo[N], go[NP], lamv[N], gt = 0.0;
                 if constexpr (ALG == 1) {
@@ -1423,7 +1449,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                     cur.below(sp - 1, e >= 2 ? g.ev_s[(long)(e - 2) * g.Npad + i] : 0);
                     cur.eval(t_lo, ym);
                 }
-                const int kx = g.ev_k[(long)(e - 1) * g.Npad + i];      // the component that fired (0 for a scalar condition)
+                const int kx = g.ev_k[(long)(e - 1) * g.Npad + i] & 255;      // the component that fired (0 for a scalar condition)
                 Mo::f(fm, ym, pv, t_lo); Mo::f(fp, yp, pv, t_lo);
                 Mo::cond_grad(gu, gp, gt, kx, ym, pv, t_lo);
                 Mo::cc_affect_jvp(jf, ym, fm, pv, t_lo, kx);
@@ -1516,14 +1542,22 @@ HIPADJ_HD void quad_gk_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     double acc[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) acc[j] = 0.0;
-    const double b_all = b;                 // (the intervals are handed over ascending: a < b, hipadj_plan.hpp)
+    // (the intervals are handed over ascending: a < b, hipadj_plan.hpp)
     int ke = 0, nevl = 0;
     if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) nevl = g.nev[i] < g.maxev ? g.nev[i] : g.maxev; }
+    double b_cap = b;                        // terminate!: lam = 0 above the event that ended the lane's solve (and no adjoint record exists there)
+    if constexpr (model_has_cond<Mo>::value) {
+        if (nevl > 0 && (g.ev_k[(long)(nevl - 1) * g.Npad + i] & 256)) { const double tte = g.ev_t[(long)(nevl - 1) * g.Npad + i]; if (tte < b_cap) b_cap = tte; }
+        if (!(a < b_cap)) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) res[j] = 0.0;
+            return; }
+    }
 #pragma unroll 1
     for (;;) {
     if constexpr (model_has_cond<Mo>::value) {
         while (ke < nevl && !(g.ev_t[(long)ke * g.Npad + i] > a)) ++ke;      // events at or below the part's start
-        b = (ke < nevl && g.ev_t[(long)ke * g.Npad + i] < b_all) ? g.ev_t[(long)ke * g.Npad + i] : b_all;
+        b = (ke < nevl && g.ev_t[(long)ke * g.Npad + i] < b_cap) ? g.ev_t[(long)ke * g.Npad + i] : b_cap;
     }
     double sa[MAXSEG], sb[MAXSEG], sE[MAXSEG], sI[MAXSEG][NP];
     double I[NP];
@@ -1553,7 +1587,7 @@ HIPADJ_HD void quad_gk_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     }
     for (int j = 0; j < NP; ++j) { double s = 0.0; for (int q = 0; q < ns; ++q) s += sI[q][j]; acc[j] += s; }
     if constexpr (model_has_cond<Mo>::value) {
-        if (b < b_all) { a = b; continue; }
+        if (b < b_cap) { a = b; continue; }
     }
     break;
     }

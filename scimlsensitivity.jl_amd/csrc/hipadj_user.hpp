@@ -398,9 +398,10 @@ inline std::string user_model_struct(const UserModelSrc& m) {
           << "            cond_t<Dual<NP>>(o, uu, pp, Dual<NP>(t));\n            for (int j = 0; j < NP; ++j) { double v = 0.0; for (int q = 0; q < NCOND; ++q) v = (q == k) ? o[q].d[j] : v; gp[j] = v; } }\n"
           << "        {   Dual<1> uu[N], pp[NP], o[NCOND];\n            for (int j = 0; j < N; ++j) uu[j] = Dual<1>(u[j]);\n            for (int j = 0; j < NP; ++j) pp[j] = Dual<1>(p[j]);\n"
           << "            cond_t<Dual<1>>(o, uu, pp, Dual<1>::seed(t, 0));\n            double v = 0.0; for (int q = 0; q < NCOND; ++q) v = (q == k) ? o[q].d[0] : v; gt = v; }\n    }\n"
-          << "    template <class real> HIPADJ_HD static void cc_affect_t(real (&un)[N], const real (&u)[N], const real (&p)[NP], real t, int idx) {\n"
-          << "        (void)u; (void)p; (void)t; (void)idx;\n        for (int i = 0; i < N; ++i) un[i] = u[i];\n" << m.cc_affect << "\n    }\n"
-          << "    HIPADJ_HD static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t, int idx) { cc_affect_t<double>(un, u, p, t, idx); }\n"
+          // (`terminate = true;` in the affect body: terminate!(integrator) — the trajectory's solve ends at this event)
+          << "    template <class real> HIPADJ_HD static bool cc_affect_t(real (&un)[N], const real (&u)[N], const real (&p)[NP], real t, int idx) {\n"
+          << "        (void)u; (void)p; (void)t; (void)idx; bool terminate = false;\n        for (int i = 0; i < N; ++i) un[i] = u[i];\n" << m.cc_affect << "\n        return terminate;\n    }\n"
+          << "    HIPADJ_HD static bool cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t, int idx) { return cc_affect_t<double>(un, u, p, t, idx); }\n"
           << "    HIPADJ_HD static void cc_affect_jvp(double (&out)[N], const double (&u)[N], const double (&v)[N], const double (&p)[NP], double t, int idx) {\n"
           << "        Dual<1> uu[N], pp[NP], un[N];\n        for (int j = 0; j < N; ++j) { uu[j] = Dual<1>(u[j]); uu[j].d[0] = v[j]; }\n        for (int j = 0; j < NP; ++j) pp[j] = Dual<1>(p[j]);\n"
           << "        cc_affect_t<Dual<1>>(un, uu, pp, Dual<1>::seed(t, 0), idx);\n        for (int j = 0; j < N; ++j) out[j] = un[j].d[0];\n    }\n"

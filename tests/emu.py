@@ -15,7 +15,7 @@ _CSRC = os.path.join(_ROOT, "scimlsensitivity.jl_amd", "csrc")
 
 
 def build(force=False):
-    """Sixteen translation units (-DEMU_UNIT=0..15: entry points + one unit per model) compiled in parallel, then linked."""
+    """Seventeen translation units (-DEMU_UNIT=0..16: entry points + one unit per model) compiled in parallel, then linked."""
     from concurrent.futures import ThreadPoolExecutor
     deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("hipadj_lane.hpp", "hipadj_models.hpp", "hipadj_plan.hpp", "hipadj_adaptive.hpp")]
     def stale():
@@ -35,7 +35,7 @@ def build(force=False):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-DEMU_UNIT={k}", "-c", _SRC, "-o", obj])
             return obj
         with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-            objs = list(pool.map(unit, range(16)))
+            objs = list(pool.map(unit, range(17)))
         subprocess.check_call(["g++", "-shared", "-fPIC", "-o", _LIB + ".tmp"] + objs)
         os.replace(_LIB + ".tmp", _LIB)
     return _LIB
@@ -43,7 +43,7 @@ def build(force=False):
 
 _lib = None
 _EMU_ONLY = {"emu_ring4": 4, "emu_ring5mm": 105, "emu_rober": 203, "emu_roberdae": 204, "emu_roberdae_kappa": 205, "emu_roberdae_mix": 206,
-             "emu_ball": 301, "emu_relax": 303, "emu_ball_moving": 304, "emu_ball2d": 305}      # test-only models of lane_emu.cpp (offset from MODEL_USER_BASE)
+             "emu_ball": 301, "emu_relax": 303, "emu_ball_moving": 304, "emu_ball2d": 305, "emu_ball_terminate": 307}      # test-only models of lane_emu.cpp (offset from MODEL_USER_BASE)
 
 
 def ring_mm_inverse(n):

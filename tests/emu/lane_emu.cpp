@@ -127,7 +127,7 @@ template <int KIND> struct EmuBall {
     static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dg[0] = -l[1]; dg[1] = 0.0; }
     static void cond(double (&out)[NCOND], const double (&u)[N], const double (&)[NP], double t) { out[0] = KIND == 4 ? u[0] - 0.3 * t : u[0]; }
     static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, int, const double (&)[N], const double (&)[NP], double) { gu[0] = 1.0; gu[1] = 0.0; gp[0] = 0.0; gp[1] = 0.0; gt = KIND == 4 ? -0.3 : 0.0; }
-    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t, int) { un[0] = u[0]; un[1] = KIND == 4 ? -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t : -p[1] * u[1]; }
+    static bool cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double t, int) { un[0] = u[0]; un[1] = KIND == 4 ? -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t : -p[1] * u[1]; return KIND == 7; }      // KIND 7: kind 1 with terminate!
     static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&p)[NP], double, int) { out[0] = v[0]; out[1] = -p[1] * v[1] + (KIND == 4 ? 0.1 : 0.0); }
     static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double, int) {
         lo[0] = lam[0]; lo[1] = -p[1] * lam[1]; go[0] = 0.0; go[1] = -(u[1] - (KIND == 4 ? 0.3 : 0.0)) * lam[1];
@@ -141,7 +141,7 @@ struct EmuRelax {
     static void vjp_p(double (&dg)[NP], const double (&l)[N], const double (&)[N], const double (&)[NP], double) { dg[0] = l[0]; dg[1] = 0.0; }
     static void cond(double (&out)[NCOND], const double (&u)[N], const double (&p)[NP], double) { out[0] = u[0] - 0.75 * p[0]; }
     static void cond_grad(double (&gu)[N], double (&gp)[NP], double& gt, int, const double (&)[N], const double (&)[NP], double) { gu[0] = 1.0; gp[0] = -0.75; gp[1] = 0.0; gt = 0.0; }
-    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double, int) { un[0] = u[0] + p[1]; }
+    static bool cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double, int) { un[0] = u[0] + p[1]; return false; }
     static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&)[NP], double, int) { out[0] = v[0]; }
     static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&)[N], const double (&)[NP], double, int) { lo[0] = lam[0]; go[0] = 0.0; go[1] = lam[0]; }
 };
@@ -159,7 +159,7 @@ struct EmuBall2D {
         gp[0] = 0.0; gp[1] = 0.0; gt = 0.0;
         if (k == 0) gu[0] = 1.0; else gu[2] = 2.0 * u[2] - 10.0;
     }
-    static void cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double, int k) { for (int j = 0; j < N; ++j) un[j] = u[j]; if (k == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3]; }
+    static bool cc_affect(double (&un)[N], const double (&u)[N], const double (&p)[NP], double, int k) { for (int j = 0; j < N; ++j) un[j] = u[j]; if (k == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3]; return false; }
     static void cc_affect_jvp(double (&out)[N], const double (&)[N], const double (&v)[N], const double (&p)[NP], double, int k) { for (int j = 0; j < N; ++j) out[j] = v[j]; if (k == 0) out[1] = -p[1] * v[1]; else out[3] = -p[1] * v[3]; }
     static void cc_affect_vjp(double (&lo)[N], double (&go)[NP], const double (&lam)[N], const double (&u)[N], const double (&p)[NP], double, int k) {
         for (int j = 0; j < N; ++j) lo[j] = lam[j];
@@ -170,7 +170,7 @@ struct EmuBall2D {
 static int emu_user_sizes(int32_t model, int32_t* n, int32_t* np) {
     const int nn = model - HIPADJ_MODEL_USER_BASE;
     if (nn >= 203 && nn <= 206) { *n = 3; *np = 3; return HIPADJ_OK; }
-    if (nn == 301 || nn == 304) { *n = 2; *np = 2; return HIPADJ_OK; }
+    if (nn == 301 || nn == 304 || nn == 307) { *n = 2; *np = 2; return HIPADJ_OK; }
     if (nn == 303) { *n = 1; *np = 2; return HIPADJ_OK; }
     if (nn == 305) { *n = 4; *np = 2; return HIPADJ_OK; }
     if (nn != 4 && nn != 105) return HIPADJ_ERR_INVALID_ARG;
@@ -185,7 +185,7 @@ const double *g_emu_ev_dl = nullptr, *g_emu_ev_dr = nullptr; double* g_emu_ev_ou
 #else
 extern const double *g_emu_ev_dl, *g_emu_ev_dr; extern double* g_emu_ev_out;
 #endif
-static int emu_user_events(int32_t model) { const int nn = model - HIPADJ_MODEL_USER_BASE; return (nn == 301 || nn == 303 || nn == 304 || nn == 305) ? EMU_MAXEV : 0; }
+static int emu_user_events(int32_t model) { const int nn = model - HIPADJ_MODEL_USER_BASE; return (nn == 301 || nn == 303 || nn == 304 || nn == 305 || nn == 307) ? EMU_MAXEV : 0; }
 static const bool g_hook_set = (plan_user_sizes_hook() = &emu_user_sizes, plan_user_dae_hook() = &emu_user_dae, plan_user_events_hook() = &emu_user_events, true);
 
 template <class Mo>
@@ -576,7 +576,7 @@ static int dispatch_adaptive(const hipadj_config* cfg, const Plan& P, const doub
 
 // Build units (tests/emu.py compiles them in parallel): EMU_UNIT undefined = everything in one translation unit (the variant builds
 // of test_emu_parity.py); EMU_UNIT = 0 = the C entry points, the per-model dispatchers declared `extern template`;
-// EMU_UNIT = 1..15 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
+// EMU_UNIT = 1..16 = the explicit instantiation of ONE model's dispatcher (all lane bodies of that model).
 #ifndef EMU_UNIT
 #define EMU_UNIT -1
 #endif
@@ -611,6 +611,7 @@ extern template int dispatch_mode<EmuBall<1>>(const hipadj_config*, const Plan&,
 extern template int dispatch_mode<EmuBall<4>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuRelax>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 extern template int dispatch_mode<EmuBall2D>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+extern template int dispatch_mode<EmuBall<7>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 1
 template int dispatch_mode<ModelLV>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 2
@@ -641,6 +642,8 @@ template int dispatch_mode<EmuBall<4>>(const hipadj_config*, const Plan&, const 
 template int dispatch_mode<EmuRelax>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #elif EMU_UNIT == 15
 template int dispatch_mode<EmuBall2D>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
+#elif EMU_UNIT == 16
+template int dispatch_mode<EmuBall<7>>(const hipadj_config*, const Plan&, const double*, const double*, const double*, double*, double*, double*);
 #endif
 
 #if EMU_UNIT <= 0
@@ -675,6 +678,7 @@ extern "C" int emu_forward_adjoint(const hipadj_config* cfg, const double* u0, c
     case HIPADJ_MODEL_USER_BASE + 304: return dispatch_mode<EmuBall<4>>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 303: return dispatch_mode<EmuRelax>(cfg, P, u0, p, dLdu, du0, dp, out);
     case HIPADJ_MODEL_USER_BASE + 305: return dispatch_mode<EmuBall2D>(cfg, P, u0, p, dLdu, du0, dp, out);
+    case HIPADJ_MODEL_USER_BASE + 307: return dispatch_mode<EmuBall<7>>(cfg, P, u0, p, dLdu, du0, dp, out);
     default: g_err = "no emulation for this model"; return HIPADJ_ERR_UNSUPPORTED;
     }
 }

@@ -59,7 +59,7 @@ def seeds(vals):
     return [D(v, np.eye(K)[i]) for i, v in enumerate(vals)]
 
 
-def ballistic(kind, u0, p, T, ts, loss, save_positions=False):
+def ballistic(kind, u0, p, T, ts, loss, save_positions=False, terminate=False):
     """x'' = -g between events; kind 1: floor at 0, v <- -e v; kind 2: x += 3, v <- v^2; kind 4: floor 0.3 t, v <- -e (v - 0.3) + 0.3 + 0.1 t"""
     x, v, g, e = seeds([u0[0], u0[1], p[0], p[1]])
     tb = D(0.0, np.zeros(4))                    # start time of the current piece
@@ -92,8 +92,12 @@ def ballistic(kind, u0, p, T, ts, loss, save_positions=False):
             G = G + loss(xm, vm) + loss(x, v)
             ev_states.append([[xm.v, vm.v], [x.v, v.v]])
         tb = te
+        if terminate:                             # terminate!(integrator): the solution ends here (:226-236); the save times after it carry no loss
+            if not save_positions:
+                ev_states.append([[xm.v, vm.v], [x.v, v.v]])
+            break
     return dict(u0=list(u0), p=list(p), tspan=[0.0, T], ts=list(ts), kind=kind, u_at_ts=out, event_times=events, G=G.v, du0=G.g[:2].tolist(), dp=G.g[2:].tolist(),
-                **(dict(event_states=ev_states) if save_positions else {}))
+                **(dict(event_states=ev_states) if save_positions or terminate else {}))
 
 
 def ball2d(kind, u0, p, T, ts, save_positions=False):
@@ -171,6 +175,10 @@ if __name__ == "__main__":
         ball_long_saved=ballistic(1, [5.0, 0.0], [9.8, 0.8], 5.0, np.arange(0.0, 5.0 + 1e-12, 0.5).tolist(), ssum, save_positions=True),
         ball_mse_saved=ballistic(2, [5.0, 0.0], [9.8, 0.8], 2.5, ts, mse, save_positions=True),            # "callback with non-linear affect", MSE loss, :239-250
         moving_saved=ballistic(4, [5.0, 0.0], [9.8, 0.8], 4.0, np.arange(0.0, 4.0 + 1e-12, 0.5).tolist(), ssum, save_positions=True),
+        # terminate!: "= callback with terminate" (:226-236) — the loss takes the save times before the bounce; with save_positions also the two states at it (the second one
+        # is the solution's last point)
+        ball_terminate=ballistic(1, [5.0, 0.0], [9.8, 0.8], 2.5, ts, ssum, terminate=True),
+        ball_terminate_saved=ballistic(1, [5.0, 0.0], [9.8, 0.8], 2.5, ts, ssum, save_positions=True, terminate=True),
         # VectorContinuousCallback, test/Callbacks2/vector_continuous_callbacks.jl: u0 = [50, 0, 0, 2.01], tspan (0, 10), p = [9.8, 0.9] (:23-25), saveat 0.5
         walls=ball2d(5, [50.0, 0.0, 0.0, 2.01], [9.8, 0.9], 10.0, np.arange(0.0, 10.0 + 1e-12, 0.5).tolist()),
         walls_saved=ball2d(5, [50.0, 0.0, 0.0, 2.01], [9.8, 0.9], 10.0, np.arange(0.0, 10.0 + 1e-12, 0.5).tolist(), save_positions=True),

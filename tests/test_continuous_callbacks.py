@@ -251,6 +251,43 @@ def test_vector_callback_registration_and_kernels(tmp_path, monkeypatch):
             assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
 
 
+# ---- terminate! --------------------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case", ["ball_terminate", "ball_terminate_saved"])
+def test_terminate_against_the_closed_forms(gold, case, alg, oalg):
+    """terminate!(integrator) in the affect (test/Callbacks2/continuous_callbacks.jl:226-236, "= callback with terminate"): the trajectory's solve ends at the bounce; the save times
+    after it hold the final state and carry no loss; the reverse solve starts at the event with lam+ = 0 (the loss on the final state arrives as the event's right cotangent).
+    Oracle and lane bodies, every sensealg, against the closed forms"""
+    g = gold[case]; ts = np.asarray(g["ts"]); n = 2; saved = case.endswith("_saved"); es = np.asarray(g["event_states"]); nb = len(g["u_at_ts"])
+    pr = O.Problem("FALLMASS", alg=oalg, stepper="TSIT5", t0=0.0, t1=2.5, dt=0.0, abstol=1e-12, reltol=1e-12, save_times=ts, event_kind=7, **QTOL)
+    t, ul, ur = pr.event_states(np.asarray(g["u0"]), np.asarray(g["p"]))
+    assert len(t) == 1 and abs(t[0] - g["event_times"][0]) < 1e-12 and np.max(np.abs(ul - es[:, 0])) < 1e-10 and np.max(np.abs(ur - es[:, 1])) < 1e-10
+    if saved:
+        pr.set_event_cotangents(np.ones((1, n)), np.ones((1, n)))
+    du0, dp, out = pr.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), np.ones((len(ts), n)))
+    assert relmax(du0, dp, g) < 1e-12 and np.max(np.abs(out[:nb] - np.asarray(g["u_at_ts"]))) < 1e-11 and np.max(np.abs(out[nb:] - es[0, 1])) < 1e-10
+    cfg = E.make_config("emu_ball_terminate", alg, 1, 0.0, 2.5, 0.0, ts, stepper=TS5, abstol=1e-12, reltol=1e-12, max_steps=4000, **QTOL)
+    pad = lambda a: np.concatenate([a, np.zeros((E.EMU_MAXEV - 1, n))])[None]
+    keep = E.set_event_cotangents(pad(np.ones((1, n))), pad(np.ones((1, n)))) if saved else None
+    try:
+        edu0, edp, eout = E.forward_adjoint(cfg, n, 2, [g["u0"]], g["p"], np.ones((1, len(ts), n)))
+    finally:
+        E.set_event_cotangents(None, None)
+    del keep
+    assert relmax(edu0[0], edp, g) < 1e-12 and np.max(np.abs(eout[0] - out)) < 1e-11
+
+
+def test_terminate_with_checkpointed_backsolve(gold):
+    g = gold["ball_terminate"]; ts = np.asarray(g["ts"]); n = 2
+    for ck in (None, [0.3, 0.9, 1.7, 2.2]):
+        pr = O.Problem("FALLMASS", alg="BACKSOLVE", stepper="TSIT5", t0=0.0, t1=2.5, dt=0.0, abstol=1e-12, reltol=1e-12, save_times=ts, event_kind=7, checkpointing=True, checkpoints=ck)
+        du0, dp, _ = pr.adjoint(np.asarray(g["u0"]), np.asarray(g["p"]), np.ones((len(ts), n)))
+        assert relmax(du0, dp, g) < 1e-12
+        cfg = E.make_config("emu_ball_terminate", "backsolve", 1, 0.0, 2.5, 0.0, ts, stepper=TS5, abstol=1e-12, reltol=1e-12, max_steps=4000, checkpointing=True, checkpoints=ck)
+        edu0, edp, _ = E.forward_adjoint(cfg, n, 2, [g["u0"]], g["p"], np.ones((1, len(ts), n)))
+        assert relmax(edu0[0], edp, g) < 1e-12
+
+
 # ---- the C ABI without a device ------------------------------------------------------------------------------------------------------------------------------------------
 def test_registration_entry_point_and_its_refusals():
     from scimlsensitivity_jl_amd import _lib
@@ -279,7 +316,7 @@ def test_registration_entry_point_and_its_refusals():
     assert ei.value.status == _lib.ERR_UNSUPPORTED and "mass matrix" in str(ei.value)
 
 
-@pytest.mark.parametrize("kind,auto,alg,stepper", [(1, False, "interpolating", TS5), (2, True, "gauss", TS5), (3, True, "gausskronrod", ROS), (4, False, "interpolating", ROS), (1, True, "backsolve", TS5), (4, False, "backsolve", ROS), (1, False, "quadrature", TS5), (3, True, "quadrature", ROS)])
+@pytest.mark.parametrize("kind,auto,alg,stepper", [(1, False, "interpolating", TS5), (2, True, "gauss", TS5), (3, True, "gausskronrod", ROS), (4, False, "interpolating", ROS), (1, True, "backsolve", TS5), (4, False, "backsolve", ROS), (1, False, "quadrature", TS5), (3, True, "quadrature", ROS), (7, True, "interpolating", TS5), (7, False, "quadrature", ROS)])
 def test_runtime_kernels_compile_without_a_device_and_are_clean(tmp_path, monkeypatch, kind, auto, alg, stepper):
     """k_forward_tsit5<U, STEP> with the event search and k_adjoint_tsit5<U, ALG, 0, false, STEP> with the piecewise reverse solve and the jump, condition and affect from text
     (every derivative by dual numbers), through hiprtc; the spill-placement check on what it produced; and the planner's refusals for such a model"""

@@ -321,3 +321,26 @@ def test_vector_callback_against_the_closed_forms(sa, gold, case, kind, alg, oal
     sol.engine.close()
     a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g["du0"], g["dp"]])
     assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-9
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("case", ["ball_terminate", "ball_terminate_saved"])
+def test_terminate_against_the_closed_forms(sa, gold, case, alg, oalg):
+    """terminate!(integrator) (test/Callbacks2/continuous_callbacks.jl:226-236): `terminate = true;` in the affect body ends the trajectory's solve at the event; later save
+    times hold the final state and carry no loss.  One terminating and one ordinary trajectory side by side would not share a closed form: an ensemble of two balls dropped
+    from 5 and 6, both terminating at their own first bounce"""
+    g = gold[case]; ts = np.asarray(g["ts"]); n = 2; saved = case.endswith("_saved"); es = np.asarray(g["event_states"]); nb = len(g["u_at_ts"])
+    u0 = np.asarray([g["u0"], [6.0, 0.0]]); p = np.asarray(g["p"])
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model(sa, 7), u0[0], (0.0, 2.5), p), u0, np.tile(p, (2, 1))), sa.Tsit5(), saveat=ts, sensealg=sens(sa, alg), abstol=1e-12, reltol=1e-12)
+    t, ul, ur, cnt = sol.engine.event_states()
+    assert cnt.tolist() == [1, 1] and abs(t[0, 0] - g["event_times"][0]) < 1e-11 and abs(t[1, 0] - np.sqrt(12.0 / 9.8)) < 1e-11
+    out = np.array(sol.u)
+    assert np.max(np.abs(out[0, :nb] - np.asarray(g["u_at_ts"]))) < 1e-10 and np.max(np.abs(out[0, nb:] - es[0, 1])) < 1e-9 and np.max(np.abs(ur[0, 0] - es[0, 1])) < 1e-9
+    if saved:
+        dl = np.zeros_like(ul); dr = np.zeros_like(ur); dl[:, 0] = 1.0; dr[:, 0] = 1.0
+        sol.engine.set_event_cotangents(dl, dr)
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=np.ones((2, len(ts), n)))
+    sol.engine.close()
+    a = np.concatenate([du0[0], dp[0]]); b = np.concatenate([g["du0"], g["dp"]])
+    assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-9
+    assert np.all(np.isfinite(du0[1])) and np.all(np.isfinite(dp[1])) and abs(dp[1, 0] - dp[0, 0]) > 1e-3

@@ -80,6 +80,7 @@ EVENTS = {  # event_kind -> (model, condition body, affect body)
     1: (BALL, "c = u[0];", "un[1] = -p[1] * u[1];"),                               # :212-217
     2: (BALL, "c = u[0];", "un[0] = u[0] + 3.0; un[1] = u[1] * u[1];"),            # :243-250
     3: (RELAX, "c = u[0] - 0.75 * p[0];", "un[0] = u[0] + p[1];"),                 # :324-327
+    7: (BALL, "c = u[0];", "un[1] = -p[1] * u[1]; terminate = true;"),           # :226-236: the affect of event 1 with terminate!(integrator)
     4: (BALL, "c = u[0] - 0.3 * t;", "un[1] = -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t;"),   # NOT from the reference: explicit t in both
 }
 BALL2D = dict(  # `f` of test/Callbacks2/vector_continuous_callbacks.jl:10-16 (oracle: ORC_MODEL_BALL2D)
