@@ -343,4 +343,6 @@ def test_terminate_against_the_closed_forms(sa, gold, case, alg, oalg):
     sol.engine.close()
     a = np.concatenate([du0[0], dp[0]]); b = np.concatenate([g["du0"], g["dp"]])
     assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-9
-    assert np.all(np.isfinite(du0[1])) and np.all(np.isfinite(dp[1])) and abs(dp[1, 0] - dp[0, 0]) > 1e-3
+    assert np.all(np.isfinite(du0[1])) and np.all(np.isfinite(dp[1]))
+    if saved:
+        assert abs(dp[1, 1] - dp[0, 1]) > 1e-3          # (the second ball hits the floor faster: another d/d restitution of the saved state after the bounce)
