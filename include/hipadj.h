@@ -260,13 +260,15 @@ int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
  *     kappa = lam+ . (a_u f- + a_t - f+) / (c_u . f- + c_t)      lam- = a_u' lam+ - kappa c_u      dp += a_p' lam+ - kappa c_p
  *   condition_body  assigns `c` from u[0..N), p[0..NP), t       e.g. "c = u[0];"  or  "c = u[0] - 0.75 * p[0];"
  *   affect_body     edits un[0..N) — a copy of u on entry — from u, p, t (NULL or "": the identity)       e.g. "un[1] = -p[1] * u[1];"
+ *                   `terminate = true;` in it is terminate!(integrator): THAT trajectory's solve ends at the event; its later save times hold the final state and carry no
+ *                   loss (the loss on the solution's last point: the event's dr, hipadj_set_event_cotangents)
  *   max_events      capacity of the event list of one trajectory (0 = 64); a trajectory with more events fails the forward call with HIPADJ_ERR_MAXITERS
  * Both bodies are compiled for double and for dual numbers (declare locals `real`); every derivative of the jump comes from them.  Both NULL removes the callback.
  * BacksolveAdjoint (the algorithm the reference's callback tests lean on, also with checkpointing = true, its default): the forward solve stores every event's time and left
  * state; the backsolved state is overwritten with it at the event, as at a checkpoint.
  * QuadratureAdjoint: the dense adjoint record runs through the jumps; its quadrature intervals are split at each trajectory's events.
  * Refused with HIPADJ_ERR_UNSUPPORTED at hipadj_create: the fixed-step steppers, checkpointing = true on Interpolating / Gauss, continuous costs, HIPADJ_LOSS_MODEL;
- * here: wide models, models with a mass matrix, affects that edit the parameters (pn).  Not offered: terminate!.  A save time that coincides with an event sees the affected
+ * here: wide models, models with a mass matrix, affects that edit the parameters (pn).  A save time that coincides with an event sees the affected
  * state; save_positions = (true, true): hipadj_event_states / hipadj_set_event_cotangents below. */
 int hipadj_model_set_continuous_callback(int32_t model_id, const char *condition_body, const char *affect_body, int32_t max_events);
 /* VectorContinuousCallback(condition, affect!, len) (test/Callbacks2/vector_continuous_callbacks.jl): ncond conditions (1 .. 8) watched together; the event is the first zero
