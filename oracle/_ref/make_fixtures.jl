@@ -239,17 +239,18 @@ let
     for (model, f!, u0, p, tspan, ts, cond, aff!, kind) in (("FALLMASS", ball!, [5.0, 0.0], [9.8, 0.8], (0.0, 2.5), collect(0.0:0.5:2.5), cond_ball, aff_ball!, 1),
                                                            ("FALLMASS", ball!, [5.0, 0.0], [9.8, 0.8], (0.0, 5.0), collect(0.0:0.5:5.0), cond_ball, aff_ball!, 1),
                                                            ("RELAX", relax!, [0.0], [100.0, 50.0], (0.0, 10.0), [10.0], cond_relax, aff_relax!, 3))
-        cb = ContinuousCallback(cond, aff!, save_positions = (false, false))
         prob = ODEProblem(f!, u0, tspan, p)
-        for (nm, sa) in (("INTERPOLATING", InterpolatingAdjoint()), ("GAUSS", GaussAdjoint()), ("BACKSOLVE", BacksolveAdjoint()))
+        for saved in (false, true), (nm, sa) in (("INTERPOLATING", InterpolatingAdjoint()), ("GAUSS", GaussAdjoint()), ("BACKSOLVE", BacksolveAdjoint()), ("QUADRATURE", QuadratureAdjoint(abstol = 1e-14, reltol = 1e-12)))
+            # saved: save_positions = (true, true), the constructor's default — sum(sol) then also takes the state just before and just after every affect
+            cb = ContinuousCallback(cond, aff!, save_positions = (saved, saved))
             empty!(event_times)
             sol = solve(prob, Tsit5(); callback = cb, abstol = 1e-12, reltol = 1e-12, saveat = ts)
             ev = copy(event_times)
             du0, dp = Zygote.gradient((u0_, p_) -> sum(Array(solve(prob, Tsit5(); u0 = u0_, p = p_, callback = cb, abstol = 1e-12, reltol = 1e-12, saveat = ts, sensealg = sa))), u0, p)
-            push!(cases, Dict("name" => "continuous_callback_$(model)_$(tspan[2])_$nm", "kind" => "continuous_callback", "model" => model, "event_kind" => kind, "alg" => nm, "stepper" => "TSIT5",
+            push!(cases, Dict("name" => "continuous_callback_$(model)_$(tspan[2])_$(nm)$(saved ? "_saved" : "")", "kind" => "continuous_callback", "model" => model, "event_kind" => kind, "alg" => nm, "stepper" => "TSIT5",
                               "tspan" => collect(tspan), "abstol" => 1e-12, "reltol" => 1e-12, "ts" => ts, "u0" => u0, "p" => p, "du0" => collect(du0), "dp" => collect(dp),
-                              "event_times" => ev, "out" => [collect(sol(t)) for t in ts],
-                              "targets" => "event location on the dense output, the event-time term of the reverse jump, kappa c_p (RELAX), Backsolve through events (not built here)"))
+                              "event_times" => ev, "save_positions" => saved, "out" => [collect(sol(t)) for t in ts],
+                              "targets" => "event location on the dense output, the event-time term of the reverse jump, kappa c_p (RELAX), the saved event states' share of it (saved)"))
         end
     end
 end

@@ -125,17 +125,22 @@ def test_oracle_semi_explicit_dae_matches_the_reference(case):
     assert np.max(np.abs(dp - np.asarray(case["dp"])) / np.abs(case["dp"])) < 1e-5 and np.max(np.abs(du0 - np.asarray(case["du0"]))) < 1e-6, case["targets"]
 
 
-CC_CASES = [c for c in ALL if c.get("kind") == "continuous_callback" and c["alg"] != "BACKSOLVE"]      # (BacksolveAdjoint through events: refused here)
+CC_CASES = [c for c in ALL if c.get("kind") == "continuous_callback"]
 
 
 @pytest.mark.skipif(not CC_CASES, reason="tests/golden/reference_fixtures.json absent (or written by an older make_fixtures.jl): ContinuousCallback is pinned to closed forms only (tests/test_continuous_callbacks.py)")
 @pytest.mark.parametrize("case", CC_CASES, ids=[c["name"] for c in CC_CASES])
 def test_oracle_continuous_callback_matches_the_reference(case):
-    """the bouncing ball and the parameter-dependent condition of test/Callbacks2/continuous_callbacks.jl (group (12) of oracle/_ref/make_fixtures.jl): the saved states (they see the
-    event times to 1e-12), du0 and dp — the latter decides whether the reference carries the kappa c_p term the closed forms ask for"""
+    """the bouncing ball and the parameter-dependent condition of test/Callbacks2/continuous_callbacks.jl (group (12) of oracle/_ref/make_fixtures.jl), save_positions (false, false)
+    and (true, true): the event times (to 1e-12), the states at the save times, du0 and dp — the latter decides whether the reference carries the kappa c_p term the closed forms
+    ask for"""
     ts = np.asarray(case["ts"]); n = len(case["u0"])
     pr = O.Problem(case["model"], alg=case["alg"], stepper="TSIT5", t0=case["tspan"][0], t1=case["tspan"][1], dt=0.0, abstol=case["abstol"], reltol=case["reltol"], save_times=ts,
-                   loss="COTANGENT", event_kind=case["event_kind"])
+                   loss="COTANGENT", event_kind=case["event_kind"], quad_abstol=1e-14, quad_reltol=1e-12)
+    t, ul, ur = pr.event_states(case["u0"], case["p"])
+    assert len(t) == len(case["event_times"]) and np.max(np.abs(t - np.asarray(case["event_times"]))) < 1e-10, case["targets"]
+    if case.get("save_positions"):
+        pr.set_event_cotangents(np.ones((len(t), n)), np.ones((len(t), n)))      # g = sum(sol): cotangent 1 on every saved state
     du0, dp, out = pr.adjoint(case["u0"], case["p"], np.ones((len(ts), n)))
     assert rel(out, np.asarray(case["out"])) < 1e-9, case["targets"]
     assert np.max(np.abs(du0 - np.asarray(case["du0"]))) < 1e-7 * np.max(np.abs(case["du0"])) and np.max(np.abs(dp - np.asarray(case["dp"]))) < 1e-7 * np.max(np.abs(case["dp"])), case["targets"]
