@@ -2,7 +2,7 @@
 #   HIPADJ_LIBRARY=/path/to/libhipadj.so julia --project=julia/test julia/test/runtests.jl
 # Not executed in the build image (no Julia there).  Mirrors test/Core3/adjoint.jl:1157-1241 (Lorenz, dg = u - 2) on a matrix-state
 # problem and compares the device gradients with the reference's own CPU adjoint at rtol 1e-6 (BASELINE.json north_star).
-using Test, HIPAdj, SciMLSensitivity, OrdinaryDiffEq, Zygote, Random
+using Test, HIPAdj, SciMLSensitivity, OrdinaryDiffEq, Zygote, Random, ForwardDiff
 
 @testset "layout" begin
     @test HIPAdj.check_layout()
@@ -94,6 +94,39 @@ end
     end
     @test_throws Exception HIPAdj.hip_solve(ODEProblem((dU, U, p, t) -> nothing, repeat([1.0, 0.0, 0.0], 1, 4), (0.0, 1.0), p), Tsit5(),
                                             HIPBatchedAdjoint(InterpolatingAdjoint(); model = m); saveat = [1.0])      # a DAE model on an explicit stepper: refused by name
+end
+
+@testset "ContinuousCallback: the bouncing ball (test/Callbacks2/continuous_callbacks.jl:10-24, 212-224)" begin
+    ball(du, u, p, t) = (du[1] = u[2]; du[2] = -p[1]; nothing)
+    u0 = [5.0, 0.0]; p = [9.8, 0.8]; ts = collect(0.0:0.5:2.5)
+    condition(u, t, integrator) = u[1]
+    affect!(integrator) = (integrator.u[2] = -integrator.p[2] * integrator.u[2])
+    cb = ContinuousCallback(condition, affect!, save_positions = (false, false))
+    g(θ) = sum(Array(solve(ODEProblem(ball, θ[1:2], (0.0, 2.5), θ[3:4]), Tsit5(); callback = cb, abstol = 1.0e-12, reltol = 1.0e-12, saveat = ts)))
+    dref = ForwardDiff.gradient(g, [u0; p])                                                # the reference's own yardstick (:129-139)
+    m = register_model("ball_jl", 2, 2; f = "du[0] = u[1]; du[1] = -p[0];")              # VJPs by dual numbers
+    set_continuous_callback!(m, "c = u[0];", "un[1] = -p[1] * u[1];")
+    dg_ones(out, u, p, t, i) = (out .= 1)
+    for inner in (InterpolatingAdjoint(), BacksolveAdjoint(), GaussAdjoint(), GaussKronrodAdjoint(), QuadratureAdjoint(abstol = 1.0e-14, reltol = 1.0e-12))
+        dev = HIPBatchedAdjoint(inner; model = m)
+        cols = ODEProblem((dU, U, p, t) -> nothing, repeat(u0, 1, 4), (0.0, 2.5), p)
+        sol = HIPAdj.hip_solve(cols, Tsit5(), dev; saveat = ts, abstol = 1.0e-12, reltol = 1.0e-12)
+        @test all(event_counts(sol.handle) .== 1)
+        du0, dp = adjoint_sensitivities(sol, Tsit5(); sensealg = dev, dgdu_discrete = dg_ones)
+        @test isapprox(du0[:, 1], dref[1:2]; rtol = 1e-5) && isapprox(dp ./ 4, dref[3:4]; rtol = 1e-5)      # the reference's bar (:140-145)
+    end
+    # save_positions = (true, true), the constructor's default: the saved event states come from event_states, their cotangents go back through set_event_cotangents!
+    cb2 = ContinuousCallback(condition, affect!)
+    g2(θ) = sum(Array(solve(ODEProblem(ball, θ[1:2], (0.0, 2.5), θ[3:4]), Tsit5(); callback = cb2, abstol = 1.0e-12, reltol = 1.0e-12, saveat = ts)))
+    dref2 = ForwardDiff.gradient(g2, [u0; p])
+    dev = HIPBatchedAdjoint(InterpolatingAdjoint(); model = m)
+    sol = HIPAdj.hip_solve(ODEProblem((dU, U, p, t) -> nothing, repeat(u0, 1, 1), (0.0, 2.5), p), Tsit5(), dev; saveat = ts, abstol = 1.0e-12, reltol = 1.0e-12)
+    tev, ul, ur = event_states(sol.handle)
+    @test isapprox(tev[1, 1], sqrt(2 * 5 / 9.8); atol = 1e-10) && abs(ul[1, 1, 1]) < 1e-9 && isapprox(ur[2, 1, 1], -0.8 * ul[2, 1, 1]; atol = 1e-12)
+    dl = zeros(size(ul)); dr = zeros(size(ur)); dl[:, 1, 1] .= 1; dr[:, 1, 1] .= 1
+    set_event_cotangents!(sol.handle, dl, dr)
+    du0, dp = adjoint_sensitivities(sol, Tsit5(); sensealg = dev, dgdu_discrete = dg_ones)
+    @test isapprox(du0[:, 1], dref2[1:2]; rtol = 1e-5) && isapprox(dp, dref2[3:4]; rtol = 1e-5)
 end
 
 # ---- wide runtime models (ABI 106): the Julia emitter writes the same SPMD text as the Python host's (tests/golden/dense_chain_bodies.json), and the
