@@ -487,7 +487,7 @@ def test_solve_attaches_a_continuous_callback_to_the_model(sa, monkeypatch):
     u0 = np.array([[5.0, 0.0]]); p = np.array([9.8, 0.8])
     for _ in range(2):
         sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, u0[0], (0.0, 2.5), p), u0), sa.Tsit5(), saveat=[0.5, 2.5], sensealg=sa.InterpolatingAdjoint(), abstol=1e-8, reltol=1e-8, callback=cb)
-    assert calls == [(f.id, "c = u[0];", "un[1] = -p[1] * u[1];", 32)]
+    assert calls == [(f.id, "c = u[0];", "un[1] = -p[1] * u[1];", 32, 1)]          # (..., max_events, ncond)
     with pytest.raises(ValueError, match="runtime lane model"):
         sa.solve(sa.EnsembleProblem(sa.ODEProblem("fallmass", u0[0], (0.0, 2.5), p), u0), sa.Tsit5(), saveat=[0.5, 2.5], sensealg=sa.InterpolatingAdjoint(), abstol=1e-8, reltol=1e-8, callback=cb)
 
