@@ -1276,6 +1276,9 @@ typedef struct {
     /* ContinuousCallback (section 3b): the reverse solve stands between two events and reads the forward records of that piece only — at an event time the record below
      * holds the state before the affect, the record above the state after it */
     int use_win; long win_lo, win_hi;
+    /* ... with checkpointing = true: a checkpoint interval is re-solved only as far as the current piece reaches — from the state just after the piece's lower event (piece_u0)
+     * or the checkpoint, to the piece's upper event or the next checkpoint; no event lies inside a re-solve, and none is searched for */
+    int piece_on; double piece_lo, piece_hi; const double *piece_u0;
 } adj_ctx;
 
 /* stored forward value at checkpoint time c (non-dense `sol(c)` at a saved point) */
@@ -1298,7 +1301,14 @@ static int resolve_interval(adj_ctx *A, int cursor, double dt_hint) {
     double *y0 = (double *)malloc(sizeof(double) * A->n);
     ckpt_value(A, A->int_a[cursor], y0);
     if (A->cpsol_valid) dense_free(&A->cpsol);
-    int st = forward_dense(A->m, A->cfg, A->p, A->int_a[cursor], A->int_b[cursor], y0, dt_hint, &A->cpsol, A->nrhs);
+    double ia = A->int_a[cursor], ib = A->int_b[cursor];
+    orc_config cnoev = *A->cfg; const orc_config *rcfg = A->cfg;
+    if (A->piece_on) {
+        if (A->piece_u0 && A->piece_lo > ia) { ia = A->piece_lo; memcpy(y0, A->piece_u0, sizeof(double) * A->n); }
+        if (A->piece_hi < ib) ib = A->piece_hi;
+        cnoev.event_kind = 0; rcfg = &cnoev;
+    }
+    int st = forward_dense(A->m, rcfg, A->p, ia, ib, y0, dt_hint, &A->cpsol, A->nrhs);
     A->cpsol_valid = 1; A->cursor = cursor; A->cphint = -1;
     free(y0);
     return st;
@@ -1315,7 +1325,7 @@ static void fetch_y(adj_ctx *A, double t) {
     }
     if (!A->checkpointing) { dense_eval(A->sol, t, A->y, &A->hint); return; }
     double a = A->int_a[A->cursor], b = A->int_b[A->cursor];
-    if (!(a <= t && t <= b)) {
+    if (!A->cpsol_valid || !(a <= t && t <= b)) {
         int c = findcursor(A, t);
         double dtl = 0;
         if (A->cpsol_valid && A->cpsol.nsteps > 0) { long s = A->cpsol.nsteps - 1; dtl = fabs(A->cpsol.t1[s] - A->cpsol.t0[s]); }
@@ -1689,7 +1699,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
     if (cfg->alg == ORC_ALG_GAUSS_KRONROD && np > ORC_MAXNP_COST) return -6;
     if (cost_has_gp(cfg->cont_cost) && np > ORC_MAXNP_COST) return -6;
     if (cfg->stepper == ORC_STEPPER_ROS23 && cfg->alg == ORC_ALG_BACKSOLVE && g_mm_dae) return -6;   /* Backsolve on the stiff stepper: ODE models (see backsolve_jac; the cost's second-derivative blocks are dropped from W like the model's) */
-    if (cfg->event_kind && ((cfg->checkpointing && cfg->alg != ORC_ALG_BACKSOLVE) || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* section 3b */
+    if (cfg->event_kind && (cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* section 3b */
     if (g_mm_dae && (cfg->stepper != ORC_STEPPER_ROS23 || g_dae_n != n || cfg->cont_cost != 0 || cfg->loss_kind == ORC_LOSS_TEST)) return -6;   /* semi-explicit DAE: Rosenbrock23, discrete losses by cotangent / shift / data */   /* the backsolved system is not affine in its state; see adjoint_oracle.h */
     clock_gettime(CLOCK_MONOTONIC, &c0);
     /* ---- forward solve (src/concrete_solve.jl:689-707): dense; `out` = sol(ts) by interpolation (:718-727) ---- */
@@ -1724,7 +1734,8 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
         A.checkpointing = 1; A.nint = nck - 1;
         A.int_a = (double *)malloc(sizeof(double) * A.nint); A.int_b = (double *)malloc(sizeof(double) * A.nint);
         for (int i = 0; i < A.nint; ++i) { A.int_a[i] = ck_t[i]; A.int_b[i] = ck_t[i + 1]; }
-        resolve_interval(&A, A.nint - 1, 0.0);                      /* eager last-interval re-solve :88-92 */
+        if (!cfg->event_kind || sol.nev == 0) resolve_interval(&A, A.nint - 1, 0.0);                      /* eager last-interval re-solve :88-92 (with events: the first read of the top piece re-solves) */
+        else A.cursor = A.nint - 1;
     } else if (use_ckpt) {
         A.checkpointing = 1;
     }
@@ -1768,13 +1779,16 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
         /* section 3b: piece e = nev .. 0 lies between event e - 1 (or t0) and event e (or T); the stops of a piece are the loss times inside it */
         double *pts = (double *)malloc(sizeof(double) * (size_t)(nts + 1));
         double *w = (double *)calloc((size_t)6 * n + 2 * (size_t)np, sizeof(double)), *ym = w, *yp = w + n, *fm = w + 2 * n, *fp = w + 3 * n, *gu = w + 4 * n, *jf = w + 5 * n, *gp = w + 6 * n, *go = gp + np;
-        A.use_win = (cfg->alg != ORC_ALG_BACKSOLVE);
+        A.use_win = (cfg->alg != ORC_ALG_BACKSOLVE) && !A.checkpointing;
+        double *ev_ur = (double *)calloc((size_t)(sol.nev > 0 ? sol.nev : 1) * n, sizeof(double));      /* the states just after the affects: where a piece's re-solves start */
+        for (int k = 0; k < sol.nev; ++k) { if (sol.ev_s[k] < sol.nsteps) dense_eval_step(&sol, sol.ev_s[k], dense_event_time(&sol, k), ev_ur + (size_t)k * n); else memcpy(ev_ur + (size_t)k * n, uend, sizeof(double) * n); }
         if (sol.terminated) {      /* terminate!: nothing lies above the last event — the piece (t*, T) is skipped (lam = 0), loss and checkpoint times above t* are passed over */
             while (A.cur_time >= 1 && cfg->save_times[A.cur_time - 1] > t_term && !time_hits(cfg->save_times[A.cur_time - 1], t_term)) A.cur_time -= 1;
             while (cfg->alg == ORC_ALG_BACKSOLVE && A.bs_cur >= 1 && ck_t && ck_t[A.bs_cur - 1] > t_term) A.bs_cur -= 1;
         }
         for (int e = sol.nev; e >= 0 && st == 0; --e) {
             const double t_hi = (e == sol.nev) ? cfg->t1 : dense_event_time(&sol, e), t_lo = (e == 0) ? cfg->t0 : dense_event_time(&sol, e - 1);
+            if (A.checkpointing && cfg->alg != ORC_ALG_BACKSOLVE) { A.piece_on = 1; A.piece_lo = t_lo; A.piece_hi = t_hi; A.piece_u0 = e > 0 ? ev_ur + (size_t)(e - 1) * n : NULL; A.cpsol_valid ? (dense_free(&A.cpsol), A.cpsol_valid = 0) : 0; }
             A.win_lo = (e == 0) ? 0 : sol.ev_s[e - 1]; A.win_hi = (e == sol.nev) ? sol.nsteps - 1 : sol.ev_s[e] - 1;      /* (never used for the skipped piece above a terminating event) */
             int npts = 0;
             for (int i = 0; i < nts; ++i) if (tst[i] >= t_lo && tst[i] <= t_hi) pts[npts++] = tst[i];      /* (a loss time that coincides with an event belongs to the piece above it: it sees the affected state) */
@@ -1805,7 +1819,7 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             double *acc = (cfg->alg == ORC_ALG_INTERPOLATING || cfg->alg == ORC_ALG_BACKSOLVE) ? z + n : (cfg->alg == ORC_ALG_QUADRATURE ? A.dgp_acc : A.gauss_acc);
             for (int i = 0; i < np; ++i) acc[i] += go[i] - kappa * gp[i];
         }
-        free(pts); free(w);
+        free(pts); free(w); free(ev_ur);
         A.use_win = 0;      /* (the quadrature pass below reads the whole forward solution; its nodes are interior points of parts that end at the events) */
     }
 

@@ -983,7 +983,7 @@ template <class Mo, bool PF = (HIPADJ_TS5_PREFETCH != 0)> struct FwdCursor {
     // (PF = false: the quadrature lanes, which jump between nodes.)
     double pc[PF ? 5 : 1][PF ? Mo::N : 1]; int pn;
     HIPADJ_HD void init(const double* r, long np, long ii, int nsteps) {
-        rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; lc = -1; pn = -2;
+        rec = r; Npad = np; i = ii; ns = nsteps; sc = nsteps - 1; lc = -1; pn = -2; smin = 0;
         ta = rec[((long)sc * RW + 0) * Npad + i]; tb = rec[((long)sc * RW + 1) * Npad + i];
     }
     // position the cursor on the step containing t by bisection (quadrature lanes start anywhere in [t0, T])
@@ -1090,12 +1090,26 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                                                           //  kernel — LinDiag, GaussKronrod — came back with the spill placement tests/tools/isa_lint.py flags)
     int icur = g.nck - 2;            // CK: checkpoint interval the cursor's records belong to
     bool ck_overflow = false;
+    // ContinuousCallback with checkpointing = true: a checkpoint interval is re-solved only as far as the current PIECE (between two of this trajectory's events) reaches — from
+    // the state just after the piece's lower event (stored by the forward lane, ev_ur) or the checkpoint, to the piece's upper event or the next checkpoint: no event lies inside
+    // a re-solve and none is searched for
+    int pc_ev = -1; double pc_lo = g.t0, pc_hi = g.t1;
+    if constexpr (model_has_cond<Mo>::value && CK) {
+        if (g.maxev > 0) { const int ne0 = g.nev[i] < g.maxev ? g.nev[i] : g.maxev; if (ne0 > 0) { pc_ev = ne0 - 1; pc_lo = g.ev_t[(long)pc_ev * g.Npad + i]; } }
+    }
     auto resolve = [&](int j, double dt_hint) {
         constexpr int RW = 2 + 5 * N;
         KSF KF = ts5_make_rows<KSF>(kfbase, kstride);
         double uu[N];
+        double rta = ck_t[j], rtb = ck_t[j + 1];
 #pragma unroll
         for (int jj = 0; jj < N; ++jj) uu[jj] = ckpt[((long)j * N + jj) * g.Npad + i];
+        if constexpr (model_has_cond<Mo>::value && CK) {
+            if (pc_ev >= 0 && pc_lo > rta) { rta = pc_lo;
+#pragma unroll
+                for (int jj = 0; jj < N; ++jj) uu[jj] = g.ev_ur[((long)pc_ev * N + jj) * g.Npad + i]; }
+            if (pc_hi < rtb) rtb = pc_hi;
+        }
         int sl = 0;
         auto frhs = [&](double (&du)[N], const double (&u_)[N], double t) { Mo::f(du, u_, pv, t); };
         auto fcb = [&](double t, double tprev, double (&un)[N], const auto& KK) -> bool {
@@ -1115,8 +1129,8 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         int nr;
         if constexpr (STEP == 1) {      // the interval re-solved with the forward problem's own stepper (src/interpolating_adjoint.jl:245-251); a DAE's checkpoint is a consistent state already
             RosLinFwd<Mo> flin(pv);
-            nr = ros23_integrate<N>(uu, ck_t[j], ck_t[j + 1], dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF, frhs, flin, !Mo::TIME_DEP, fcb);
-        } else nr = tsit5_integrate<N>(uu, ck_t[j], ck_t[j + 1], dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF, frhs, fcb);
+            nr = ros23_integrate<N>(uu, rta, rtb, dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF, frhs, flin, !Mo::TIME_DEP, fcb);
+        } else nr = tsit5_integrate<N>(uu, rta, rtb, dt_hint > 0 ? dt_hint : g.dt0, g.abstol, g.reltol, nullptr, 0, false, g.SmaxI, KF, frhs, fcb);
         if (nr < 0) ck_overflow = true;
         cur.init(lrec, g.Npad, i, sl < g.SmaxI ? sl : g.SmaxI);
         icur = j;
@@ -1410,7 +1424,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     return na;
     };
     int na = 0;
-    if constexpr (model_has_cond<Mo>::value && !CK && CC == 0) {
+    if constexpr (model_has_cond<Mo>::value && CC == 0) {
         {
             // ContinuousCallback (the oracle's section 3b; src/callback_tracking.jl:232-479 with save_positions = (false, false)): the reverse solve runs piece by piece between
             // this trajectory's events (a fresh solve per piece: the controller restarts) and at each event, - / + the limits from below / above,
@@ -1419,7 +1433,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
             // (ONE call site of the integrator: without events the loop runs once over the whole span)
             // BacksolveAdjoint (z = [lam; mu; y], no forward record): y+ is the backsolved state, y- the left state the forward solve stored; the y block goes on from y-
             const int nevl = g.maxev > 0 ? (g.nev[i] < g.maxev ? g.nev[i] : g.maxev) : 0;
-            if constexpr (ALG != 1) cur.smin = nevl > 0 ? g.ev_s[(long)(nevl - 1) * g.Npad + i] : 0;
+            if constexpr (ALG != 1 && !CK) cur.smin = nevl > 0 ? g.ev_s[(long)(nevl - 1) * g.Npad + i] : 0;
             // terminate!: the last event ended the lane's forward solve — nothing lies above it: the piece (t*, T) is skipped (lam = 0 there), the loss and checkpoint times above t*
             // are passed over, and the jump at t* sees lam+ = 0 (the loss on the final state arrives as the event's dr, hipadj_set_event_cotangents)
             const bool term = nevl > 0 && (g.ev_k[(long)(nevl - 1) * g.Npad + i] & 256) != 0;
@@ -1443,6 +1457,15 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 if constexpr (ALG == 1) {
 #pragma unroll
                     for (int j = 0; j < N; ++j) { yp[j] = z[N + NP + j]; ym[j] = g.ev_ul[((long)(e - 1) * N + j) * g.Npad + i]; z[N + NP + j] = ym[j]; }
+                } else if constexpr (CK) {
+                    // checkpointing = true: the two limits as the forward lane stored them; the interval around the event is re-solved for the piece below it
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { yp[j] = g.ev_ur[((long)(e - 1) * N + j) * g.Npad + i]; ym[j] = g.ev_ul[((long)(e - 1) * N + j) * g.Npad + i]; }
+                    pc_hi = t_lo; pc_ev = e - 2; pc_lo = e >= 2 ? g.ev_t[(long)(e - 2) * g.Npad + i] : g.t0;
+                    int jv = icur;
+                    while (jv > 0 && !(t_lo > ck_t[jv])) --jv;
+                    while (jv < g.nck - 2 && t_lo > ck_t[jv + 1]) ++jv;
+                    resolve(jv, 0.0);
                 } else {
                     const int sp = g.ev_s[(long)(e - 1) * g.Npad + i];
                     cur.eval(t_lo, yp);

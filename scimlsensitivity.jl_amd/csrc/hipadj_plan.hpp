@@ -241,7 +241,6 @@ inline int make_plan(const hipadj_config* cfg, Plan& P, std::string& err) {
     }
     if (plan_user_events(cfg->model) > 0) {      // a ContinuousCallback (src/callback_tracking.jl:232-479): detected on the dense output of the adaptive steppers, per trajectory
         if (cfg->stepper != HIPADJ_STEPPER_TSIT5_ADAPTIVE && cfg->stepper != HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE) { err = "the model carries a ContinuousCallback: events are located on the dense output of the adaptive steppers (HIPADJ_STEPPER_TSIT5_ADAPTIVE, HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE)"; return HIPADJ_ERR_UNSUPPORTED; }
-        if (cfg->checkpointing && cfg->alg != HIPADJ_ALG_BACKSOLVE) { err = "ContinuousCallback: checkpointing = true is offered for BacksolveAdjoint only (Interpolating / Gauss: the event list indexes the dense forward record)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->cont_cost != HIPADJ_CCOST_NONE) { err = "ContinuousCallback: no continuous cost"; return HIPADJ_ERR_UNSUPPORTED; }
         if (cfg->loss_kind == HIPADJ_LOSS_MODEL) { err = "ContinuousCallback: discrete losses by cotangents, HIPADJ_LOSS_LSQ_SHIFT or HIPADJ_LOSS_LSQ_DATA (the reference refuses dgdp with callbacks, src/callback_tracking.jl:289-290)"; return HIPADJ_ERR_UNSUPPORTED; }
         if (plan_user_dae_hook() && plan_user_dae_hook()(cfg->model)) { err = "ContinuousCallback on a semi-explicit DAE is not offered"; return HIPADJ_ERR_UNSUPPORTED; }

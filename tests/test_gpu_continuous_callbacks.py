@@ -176,8 +176,7 @@ def test_refusals(sa, gold):
     from scimlsensitivity_jl_amd import _lib
     g = gold["ball"]; f = model(sa, 1); ts = np.asarray(g["ts"]); u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
     pr = sa.EnsembleProblem(sa.ODEProblem(f, u0[0], tuple(g["tspan"]), p), u0)
-    for stepper, alg, kw, word in ((sa.Tsit5(), sa.GaussAdjoint(checkpointing=True), {}, "checkpointing"),
-                                   (sa.Tsit5(), sa.InterpolatingAdjoint(checkpointing=True), {}, "checkpointing"), (sa.RK4(), sa.InterpolatingAdjoint(), dict(dt=0.01), "adaptive steppers")):
+    for stepper, alg, kw, word in ((sa.RK4(), sa.InterpolatingAdjoint(), dict(dt=0.01), "adaptive steppers"),):
         with pytest.raises(_lib.HipadjError) as ei:
             sa.solve(pr, stepper, saveat=ts, sensealg=alg, abstol=1e-8, reltol=1e-8, **kw)
         assert ei.value.status == _lib.ERR_UNSUPPORTED and word in str(ei.value)
@@ -346,3 +345,19 @@ def test_terminate_against_the_closed_forms(sa, gold, case, alg, oalg):
     assert np.all(np.isfinite(du0[1])) and np.all(np.isfinite(dp[1]))
     if saved:
         assert abs(dp[1, 1] - dp[0, 1]) > 1e-3          # (the second ball hits the floor faster: another d/d restitution of the saved state after the bounce)
+
+
+@pytest.mark.parametrize("alg", ["interpolating", "gauss", "gausskronrod"])
+@pytest.mark.parametrize("case", ["ball", "ball_long", "relax", "moving", "ball_terminate"])
+def test_checkpointed_interpolating_and_gauss_through_events(sa, gold, case, alg):
+    """InterpolatingAdjoint(checkpointing = true) — du03 of the reference's callback tests (test/Callbacks2/continuous_callbacks.jl:99-110) — and the checkpointed Gauss sweeps
+    through events: default checkpoints (the save times) and a list, against the closed forms"""
+    kind = {"ball": 1, "ball_long": 1, "relax": 3, "moving": 4, "ball_terminate": 7}[case]; g = gold[case]; ts = np.asarray(g["ts"]); n = len(g["u0"])
+    u0 = np.asarray([g["u0"]]); p = np.asarray(g["p"])
+    inner = {"interpolating": sa.InterpolatingAdjoint, "gauss": sa.GaussAdjoint, "gausskronrod": sa.GaussKronrodAdjoint}[alg](checkpointing=True)
+    for ck in (None, [0.2, 0.9, 1.1, 2.4]):
+        sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model(sa, kind), u0[0], tuple(g["tspan"]), p), u0), sa.Tsit5(), saveat=ts, sensealg=inner, abstol=1e-12, reltol=1e-12, checkpoints=ck)
+        du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=np.ones((1, len(ts), n)))
+        sol.engine.close()
+        a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g["du0"], g["dp"]])
+        assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < (1e-8 if case == "relax" else 1e-9)
