@@ -267,7 +267,9 @@ int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
  * BacksolveAdjoint (the algorithm the reference's callback tests lean on, also with checkpointing = true, its default): the forward solve stores every event's time and left
  * state; the backsolved state is overwritten with it at the event, as at a checkpoint.
  * QuadratureAdjoint: the dense adjoint record runs through the jumps; its quadrature intervals are split at each trajectory's events.
- * Refused with HIPADJ_ERR_UNSUPPORTED at hipadj_create: the fixed-step steppers, checkpointing = true on Interpolating / Gauss, continuous costs, HIPADJ_LOSS_MODEL;
+ * checkpointing = true (Interpolating / Gauss / GaussKronrod): a checkpoint interval is re-solved only as far as the piece between two events reaches, from the stored state
+ * after the lower event.
+ * Refused with HIPADJ_ERR_UNSUPPORTED at hipadj_create: the fixed-step steppers, continuous costs, HIPADJ_LOSS_MODEL;
  * here: wide models, models with a mass matrix, affects that edit the parameters (pn).  A save time that coincides with an event sees the affected
  * state; save_positions = (true, true): hipadj_event_states / hipadj_set_event_cotangents below. */
 int hipadj_model_set_continuous_callback(int32_t model_id, const char *condition_body, const char *affect_body, int32_t max_events);
