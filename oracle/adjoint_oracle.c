@@ -1169,23 +1169,32 @@ static int fwd_event_cb(orc_integ *I, void *c) {
     double y[ORC_MM_MAXN], cv[ORC_MAXCOND], ca[ORC_MAXCOND];
     if (h == 0.0) return 0;
     if (E->nudge) { integ_interp(I, I->tprev + 0.01 * h, y); ev_cond(E->kind, E->cprev, y, E->p, I->tprev + 0.01 * h); E->nudge = 0; }
-    double tha = 0.0, thb = 0.0, cak = 0.0; int kx = -1;
+    double tha = 0.0, thb = 0.0; int kx = -1, any = 0;
     for (int k = 0; k < nc; ++k) ca[k] = E->cprev[k];
-    for (int j = 1; j <= 10 && kx < 0; ++j) {
+    for (int j = 1; j <= 10 && !any; ++j) {
         thb = j < 10 ? 0.1 * j : 1.0;
         if (j < 10) integ_interp(I, I->tprev + thb * h, y); else memcpy(y, I->u, sizeof(double) * n);
         ev_cond(E->kind, cv, y, E->p, I->tprev + thb * h);
-        for (int k = 0; k < nc; ++k) if (kx < 0 && (ca[k] * cv[k] < 0.0 || (cv[k] == 0.0 && ca[k] != 0.0))) { kx = k; cak = ca[k]; }      /* the lowest component that crosses in this tenth */
-        if (kx < 0) { tha = thb; for (int k = 0; k < nc; ++k) ca[k] = cv[k]; }
+        for (int k = 0; k < nc; ++k) if (ca[k] * cv[k] < 0.0 || (cv[k] == 0.0 && ca[k] != 0.0)) any = 1;
+        if (!any) { tha = thb; for (int k = 0; k < nc; ++k) ca[k] = cv[k]; }
     }
-    if (kx < 0) { for (int k = 0; k < nc; ++k) E->cprev[k] = cv[k]; return 0; }
-    for (int it = 0; it < 52; ++it) {
-        const double thm = 0.5 * (tha + thb);
-        integ_interp(I, I->tprev + thm * h, y);
-        ev_cond(E->kind, cv, y, E->p, I->tprev + thm * h);
-        const double cm = cv[kx];
-        if (cak * cm < 0.0 || (cm == 0.0 && cak != 0.0)) thb = thm; else { tha = thm; cak = cm; }
-    }
+    if (!any) { for (int k = 0; k < nc; ++k) E->cprev[k] = cv[k]; return 0; }
+    /* every component that crosses in this tenth is bisected on its own; the EARLIEST root is the event (ties: the lowest component) */
+    { double best = 2.0, cend[ORC_MAXCOND];
+      for (int k = 0; k < nc; ++k) cend[k] = cv[k];
+      for (int k = 0; k < nc; ++k) {
+          if (!(ca[k] * cend[k] < 0.0 || (cend[k] == 0.0 && ca[k] != 0.0))) continue;
+          double lo = tha, hi = thb, cl = ca[k];
+          for (int it = 0; it < 52; ++it) {
+              const double thm = 0.5 * (lo + hi);
+              integ_interp(I, I->tprev + thm * h, y);
+              ev_cond(E->kind, cv, y, E->p, I->tprev + thm * h);
+              const double cm = cv[k];
+              if (cl * cm < 0.0 || (cm == 0.0 && cl != 0.0)) hi = thm; else { lo = thm; cl = cm; }
+          }
+          if (hi < best) { best = hi; kx = k; }
+      }
+      thb = best; }
     const double tev = I->tprev + thb * h;
     if (!(tev < E->tend) || time_hits(tev, E->tend)) { ev_cond(E->kind, E->cprev, I->u, E->p, I->t); return 0; }   /* an event at the end of the span changes nothing that is observed */
     integ_interp(I, tev, y);

@@ -828,8 +828,8 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     // ContinuousCallback (model_has_cond; the oracle's section 3b, src/callback_tracking.jl:1-223): the sign of the condition at ten points of the accepted step's dense output
     // against its sign at the step's start (right after an event: at 1/100 of the step); the first bracket halved 52 times; the step is cut at the bracket's upper end — the
     // record rescaled to [tprev, t_event] —, u <- affect(u), t <- t_event, and the integrator recomputes the derivative; its proposal for the next step stands
-    // VectorContinuousCallback (Mo::NCOND > 1: `out[k] = ...` in the condition body, `idx` in the affect body): the scan watches every component; the event is the FIRST crossing
-    // of the step, of the lowest component among those that cross in the same tenth (simultaneous fires of several components are not merged: DESIGN.md section 4.12)
+    // VectorContinuousCallback (Mo::NCOND > 1: `out[k] = ...` in the condition body, `idx` in the affect body): the scan watches every component; in the first tenth of the step where any of them
+    // crosses, each crossing component is bisected on its own and the EARLIEST root is the event (simultaneous fires of several components are not merged: DESIGN.md section 4.12)
     constexpr int NC = model_ncond<Mo>::value;
     double cprev[NC]; bool nudge = false, terminated = false; int nevl = 0, evk = 0;
     for (int k = 0; k < NC; ++k) cprev[k] = 0.0;
@@ -844,11 +844,11 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 if (g.maxev > 0 && h != 0.0) {
                     double y[N], cv[NC], ca[NC];
                     if (nudge) { poly_eval<N>(0.01, c, y); Mo::cond(cprev, y, pv, tprev + 0.01 * h); nudge = false; }
-                    double tha = 0.0, thb = 0.0, cak = 0.0; int kx = -1;
+                    double tha = 0.0, thb = 0.0; int kx = -1; bool any = false;
 #pragma unroll
                     for (int k = 0; k < NC; ++k) ca[k] = cprev[k];
 #pragma unroll 1
-                    for (int j = 1; j <= 10 && kx < 0; ++j) {
+                    for (int j = 1; j <= 10 && !any; ++j) {
                         thb = j < 10 ? 0.1 * j : 1.0;
                         if (j < 10) poly_eval<N>(thb, c, y);
                         else {
@@ -856,25 +856,39 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                             for (int q = 0; q < N; ++q) y[q] = un[q]; }
                         Mo::cond(cv, y, pv, tprev + thb * h);
 #pragma unroll
-                        for (int k = 0; k < NC; ++k) if (kx < 0 && (ca[k] * cv[k] < 0.0 || (cv[k] == 0.0 && ca[k] != 0.0))) { kx = k; cak = ca[k]; }
-                        if (kx < 0) { tha = thb;
+                        for (int k = 0; k < NC; ++k) any = any || (ca[k] * cv[k] < 0.0 || (cv[k] == 0.0 && ca[k] != 0.0));
+                        if (!any) { tha = thb;
 #pragma unroll
                             for (int k = 0; k < NC; ++k) ca[k] = cv[k]; }
                     }
-                    if (kx < 0) {
+                    if (!any) {
 #pragma unroll
                         for (int k = 0; k < NC; ++k) cprev[k] = cv[k];
                     } else {
-#pragma unroll 1
-                        for (int it = 0; it < 52; ++it) {
-                            const double thm = 0.5 * (tha + thb);
-                            poly_eval<N>(thm, c, y);
-                            Mo::cond(cv, y, pv, tprev + thm * h);
-                            double cm = cv[0];
+                        // every component that crosses in this tenth is bisected on its own; the EARLIEST root is the event (ties: the lowest component)
+                        double best = 2.0, cend[NC];
 #pragma unroll
-                            for (int k = 1; k < NC; ++k) cm = (k == kx) ? cv[k] : cm;
-                            if (cak * cm < 0.0 || (cm == 0.0 && cak != 0.0)) thb = thm; else { tha = thm; cak = cm; }
+                        for (int k = 0; k < NC; ++k) cend[k] = cv[k];
+#pragma unroll 1
+                        for (int k = 0; k < NC; ++k) {
+                            double cak = ca[0], cek = cend[0];
+#pragma unroll
+                            for (int q = 1; q < NC; ++q) { cak = (q == k) ? ca[q] : cak; cek = (q == k) ? cend[q] : cek; }
+                            if (!(cak * cek < 0.0 || (cek == 0.0 && cak != 0.0))) continue;
+                            double lo = tha, hi = thb;
+#pragma unroll 1
+                            for (int it = 0; it < 52; ++it) {
+                                const double thm = 0.5 * (lo + hi);
+                                poly_eval<N>(thm, c, y);
+                                Mo::cond(cv, y, pv, tprev + thm * h);
+                                double cm = cv[0];
+#pragma unroll
+                                for (int q = 1; q < NC; ++q) cm = (q == k) ? cv[q] : cm;
+                                if (cak * cm < 0.0 || (cm == 0.0 && cak != 0.0)) hi = thm; else { lo = thm; cak = cm; }
+                            }
+                            if (hi < best) { best = hi; kx = k; }
                         }
+                        thb = best;
                         const double tev = tprev + thb * h;
                         if (!(tev < g.t1) || time_hits(tev, g.t1)) Mo::cond(cprev, un, pv, t);      // (an event at the end of the span changes nothing that is observed)
                         else {

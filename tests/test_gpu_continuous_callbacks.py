@@ -361,3 +361,62 @@ def test_checkpointed_interpolating_and_gauss_through_events(sa, gold, case, alg
         sol.engine.close()
         a = np.concatenate([du0[0], np.ravel(dp)]); b = np.concatenate([g["du0"], g["dp"]])
         assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < (1e-8 if case == "relax" else 1e-9)
+
+
+# ---- randomized differential test: the callback path over its configuration space, device vs oracle ---------------------------------------------------------------------
+def _random_event_case(rng):
+    kind = int(rng.choice([1, 1, 2, 4, 5, 7]))
+    alg = ALGS[int(rng.integers(len(ALGS)))]
+    stepper = "ROS23" if rng.uniform() < 0.3 else "TSIT5"
+    ck = bool(rng.uniform() < 0.35) and alg[0] != "quadrature"
+    tol = float(10.0 ** rng.uniform(-11, -8)) if stepper == "TSIT5" else float(10.0 ** rng.uniform(-9, -7))
+    N = int(rng.integers(1, 40))
+    if kind == 5:
+        T = float(rng.uniform(6.0, 10.0))
+        u0 = np.stack([rng.uniform(20.0, 60.0, N), rng.uniform(-2.0, 2.0, N), rng.uniform(1.0, 9.0, N), rng.uniform(0.5, 2.5, N) * rng.choice([-1.0, 1.0], N)], axis=1)
+    else:
+        T = float(rng.uniform(2.0, 4.0))
+        u0 = np.stack([rng.uniform(2.0, 9.0, N), rng.uniform(-1.0, 1.0, N)], axis=1)
+        if kind == 4:
+            u0[:, 0] += 1.0
+    p = np.stack([9.8 * (1 + 0.1 * rng.uniform(-1, 1, N)), rng.uniform(0.8, 0.9, N)], axis=1)
+    M = int(rng.integers(1, 7))
+    ts = np.sort(rng.uniform(0.05 * T, T, M)); ts[-1] = T if rng.uniform() < 0.5 else ts[-1]
+    saved = bool(rng.uniform() < 0.5)
+    return dict(kind=kind, alg=alg, stepper=stepper, ck=ck, tol=tol, N=N, T=T, u0=u0, p=p, ts=ts, saved=saved)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_events_device_vs_oracle(sa, seed):
+    """random problems of the callback path — event kind (scalar, non-linear affect, explicit t, two components, terminating), sensealg, stepper, checkpointing, tolerances, ensemble
+    size, per-trajectory states and parameters, loss times anywhere, random cotangents at the save times and (half of the cases) at the saved event states — device against the
+    oracle, every trajectory.  A case whose event count differs between the two (an event within rounding of the end of the span) is skipped, not failed"""
+    rng = np.random.default_rng(7000 + seed)
+    c = _random_event_case(rng)
+    kind, (alg, oalg), N, n = c["kind"], c["alg"], c["N"], c["u0"].shape[1]
+    f = vmodel(sa, 5) if kind == 5 else model(sa, kind)
+    stepper = sa.Rosenbrock23() if c["stepper"] == "ROS23" else sa.Tsit5()
+    inner = sens(sa, alg) if not c["ck"] else {"interpolating": sa.InterpolatingAdjoint, "gauss": sa.GaussAdjoint, "gausskronrod": sa.GaussKronrodAdjoint, "backsolve": sa.BacksolveAdjoint}[alg](checkpointing=True)
+    d = rng.standard_normal((N, len(c["ts"]), n))
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(f, c["u0"][0], (0.0, c["T"]), c["p"][0]), c["u0"], c["p"]), stepper, saveat=c["ts"], sensealg=inner, abstol=c["tol"], reltol=c["tol"])
+    t, ul, ur, cnt = sol.engine.event_states()
+    w = rng.standard_normal(ul.shape); v = rng.standard_normal(ur.shape)
+    if c["saved"]:
+        sol.engine.set_event_cotangents(w, v)
+    du0, dp = sa.adjoint_sensitivities(sol, stepper, t=c["ts"], dgdu_discrete=d)
+    out = np.array(sol.u)
+    sol.engine.close()
+    omodel = "BALL2D" if kind == 5 else "FALLMASS"
+    for i in range(N):
+        ref = O.Problem(omodel, alg=oalg, stepper=c["stepper"], t0=0.0, t1=c["T"], dt=0.0, abstol=c["tol"], reltol=c["tol"], save_times=c["ts"], event_kind=kind, checkpointing=c["ck"], **QTOL)
+        rt, rul, rur = ref.event_states(c["u0"][i], c["p"][i])
+        if len(rt) != cnt[i]:
+            pytest.skip(f"trajectory {i}: {cnt[i]} events on the device, {len(rt)} in the oracle (an event within rounding of a decision)")
+        assert np.max(np.abs(t[i, :cnt[i]] - rt), initial=0.0) < 1e-6
+        if c["saved"]:
+            ref.set_event_cotangents(w[i, :cnt[i]], v[i, :cnt[i]])
+        rdu0, rdp, rout = ref.adjoint(c["u0"][i], c["p"][i], d[i])
+        a = np.concatenate([du0[i], dp[i]]); b = np.concatenate([rdu0, rdp])
+        bar = 1e-5 if c["stepper"] == "ROS23" else 1e-6
+        assert np.max(np.abs(a - b)) <= bar * np.max(np.abs(b)), (seed, i, c["kind"], alg, c["stepper"], c["ck"], c["saved"])      # (a terminating event ahead of every loss time: both are exactly zero)
+        assert np.max(np.abs(out[i] - rout)) < 1e-5 * max(1.0, np.max(np.abs(rout)))
