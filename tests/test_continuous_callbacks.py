@@ -303,6 +303,49 @@ def test_terminate_with_checkpointed_backsolve(gold):
         assert relmax(edu0[0], edp, g) < 1e-12
 
 
+# ---- randomized differential test of the lane bodies (the GPU suite runs the same over the whole configuration space on the device) ---------------------------------------
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_lane_bodies_vs_oracle(seed):
+    """random problems — event kind, sensealg, stepper, checkpointing, tolerance, states, parameters, loss times, cotangents at the save times and at the saved event states —:
+    the lane bodies against the oracle, event for event and trajectory for trajectory.  (This test found the rule "the lowest component wins" losing an earlier crossing of
+    another component within the same tenth of a step.)"""
+    rng = np.random.default_rng(9100 + seed)
+    kind = int(rng.choice([1, 3, 4, 5, 5, 7]))
+    emodel, omodel, n = {1: ("emu_ball", "FALLMASS", 2), 3: ("emu_relax", "RELAX", 1), 4: ("emu_ball_moving", "FALLMASS", 2), 5: ("emu_ball2d", "BALL2D", 4), 7: ("emu_ball_terminate", "FALLMASS", 2)}[kind]
+    alg, oalg = ALGS[int(rng.integers(len(ALGS)))]
+    ros = rng.uniform() < 0.3
+    ck = bool(rng.uniform() < 0.35) and alg != "quadrature"
+    tol = float(10.0 ** (rng.uniform(-9, -7) if ros else rng.uniform(-11, -8)))
+    N = int(rng.integers(1, 7))
+    if kind == 5:
+        T = float(rng.uniform(6.0, 10.0))
+        u0 = np.stack([rng.uniform(20.0, 60.0, N), rng.uniform(-2.0, 2.0, N), rng.uniform(1.0, 9.0, N), rng.uniform(0.5, 2.5, N) * rng.choice([-1.0, 1.0], N)], axis=1)
+    elif kind == 3:
+        T = float(rng.uniform(2.0, 10.0)); u0 = rng.uniform(0.0, 20.0, (N, 1))
+    else:
+        T = float(rng.uniform(2.0, 4.0)); u0 = np.stack([rng.uniform(2.0, 9.0, N) + (1.0 if kind == 4 else 0.0), rng.uniform(-1.0, 1.0, N)], axis=1)
+    p = np.stack([100.0 * (1 + 0.1 * rng.uniform(-1, 1, N)), 50.0 * (1 + 0.2 * rng.uniform(-1, 1, N))], axis=1) if kind == 3 else np.stack([9.8 * (1 + 0.1 * rng.uniform(-1, 1, N)), rng.uniform(0.8, 0.9, N)], axis=1)
+    ts = np.sort(rng.uniform(0.05 * T, T, int(rng.integers(1, 6)))); d = rng.standard_normal((N, len(ts), n))
+    w = rng.standard_normal((N, E.EMU_MAXEV, n)); v = rng.standard_normal((N, E.EMU_MAXEV, n))
+    cfg = E.make_config(emodel, alg, N, 0.0, T, 0.0, ts, stepper=ROS if ros else TS5, abstol=tol, reltol=tol, max_steps=20000, p_shared=False, checkpointing=ck, **QTOL)
+    evo = E.set_event_output(N, n); keep = E.set_event_cotangents(w, v)
+    try:
+        du0, dp, out = E.forward_adjoint(cfg, n, 2, u0, p, d)
+    finally:
+        E.set_event_cotangents(None, None); E.set_event_output(None)
+    del keep
+    for i in range(N):
+        ref = O.Problem(omodel, alg=oalg, stepper="ROS23" if ros else "TSIT5", t0=0.0, t1=T, dt=0.0, abstol=tol, reltol=tol, save_times=ts, event_kind=kind, checkpointing=ck, **QTOL)
+        rt, rul, rur = ref.event_states(u0[i], p[i])
+        ne = int(np.sum(evo[i, :, 0] != 0.0))
+        assert ne == len(rt) and np.max(np.abs(evo[i, :ne, 0] - rt), initial=0.0) < 1e-6, (seed, i, kind)
+        ref.set_event_cotangents(w[i, :ne], v[i, :ne])
+        rdu0, rdp, rout = ref.adjoint(u0[i], p[i], d[i])
+        a = np.concatenate([du0[i], dp[i]]); b = np.concatenate([rdu0, rdp])
+        assert np.max(np.abs(a - b)) <= (1e-5 if ros else 1e-6) * np.max(np.abs(b)), (seed, i, kind, alg, ros, ck)
+        assert np.max(np.abs(out[i] - rout)) < 1e-5 * max(1.0, np.max(np.abs(rout)))
+
+
 # ---- the C ABI without a device ------------------------------------------------------------------------------------------------------------------------------------------
 def test_registration_entry_point_and_its_refusals():
     from scimlsensitivity_jl_amd import _lib

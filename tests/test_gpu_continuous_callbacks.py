@@ -365,28 +365,33 @@ def test_checkpointed_interpolating_and_gauss_through_events(sa, gold, case, alg
 
 # ---- randomized differential test: the callback path over its configuration space, device vs oracle ---------------------------------------------------------------------
 def _random_event_case(rng):
-    kind = int(rng.choice([1, 1, 2, 4, 5, 7]))
+    kind = int(rng.choice([1, 1, 2, 3, 4, 5, 5, 6, 7]))
     alg = ALGS[int(rng.integers(len(ALGS)))]
     stepper = "ROS23" if rng.uniform() < 0.3 else "TSIT5"
     ck = bool(rng.uniform() < 0.35) and alg[0] != "quadrature"
     tol = float(10.0 ** rng.uniform(-11, -8)) if stepper == "TSIT5" else float(10.0 ** rng.uniform(-9, -7))
     N = int(rng.integers(1, 40))
-    if kind == 5:
+    if kind in (5, 6):
         T = float(rng.uniform(6.0, 10.0))
         u0 = np.stack([rng.uniform(20.0, 60.0, N), rng.uniform(-2.0, 2.0, N), rng.uniform(1.0, 9.0, N), rng.uniform(0.5, 2.5, N) * rng.choice([-1.0, 1.0], N)], axis=1)
+    elif kind == 3:
+        T = float(rng.uniform(2.0, 10.0))
+        u0 = rng.uniform(0.0, 20.0, (N, 1))
     else:
         T = float(rng.uniform(2.0, 4.0))
         u0 = np.stack([rng.uniform(2.0, 9.0, N), rng.uniform(-1.0, 1.0, N)], axis=1)
         if kind == 4:
             u0[:, 0] += 1.0
     p = np.stack([9.8 * (1 + 0.1 * rng.uniform(-1, 1, N)), rng.uniform(0.8, 0.9, N)], axis=1)
+    if kind == 3:
+        p = np.stack([100.0 * (1 + 0.1 * rng.uniform(-1, 1, N)), 50.0 * (1 + 0.2 * rng.uniform(-1, 1, N))], axis=1)
     M = int(rng.integers(1, 7))
     ts = np.sort(rng.uniform(0.05 * T, T, M)); ts[-1] = T if rng.uniform() < 0.5 else ts[-1]
     saved = bool(rng.uniform() < 0.5)
     return dict(kind=kind, alg=alg, stepper=stepper, ck=ck, tol=tol, N=N, T=T, u0=u0, p=p, ts=ts, saved=saved)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(96))
 def test_fuzz_events_device_vs_oracle(sa, seed):
     """random problems of the callback path — event kind (scalar, non-linear affect, explicit t, two components, terminating), sensealg, stepper, checkpointing, tolerances, ensemble
     size, per-trajectory states and parameters, loss times anywhere, random cotangents at the save times and (half of the cases) at the saved event states — device against the
@@ -394,7 +399,7 @@ def test_fuzz_events_device_vs_oracle(sa, seed):
     rng = np.random.default_rng(7000 + seed)
     c = _random_event_case(rng)
     kind, (alg, oalg), N, n = c["kind"], c["alg"], c["N"], c["u0"].shape[1]
-    f = vmodel(sa, 5) if kind == 5 else model(sa, kind)
+    f = vmodel(sa, kind) if kind in (5, 6) else model(sa, kind)
     stepper = sa.Rosenbrock23() if c["stepper"] == "ROS23" else sa.Tsit5()
     inner = sens(sa, alg) if not c["ck"] else {"interpolating": sa.InterpolatingAdjoint, "gauss": sa.GaussAdjoint, "gausskronrod": sa.GaussKronrodAdjoint, "backsolve": sa.BacksolveAdjoint}[alg](checkpointing=True)
     d = rng.standard_normal((N, len(c["ts"]), n))
@@ -406,7 +411,7 @@ def test_fuzz_events_device_vs_oracle(sa, seed):
     du0, dp = sa.adjoint_sensitivities(sol, stepper, t=c["ts"], dgdu_discrete=d)
     out = np.array(sol.u)
     sol.engine.close()
-    omodel = "BALL2D" if kind == 5 else "FALLMASS"
+    omodel = "BALL2D" if kind in (5, 6) else ("RELAX" if kind == 3 else "FALLMASS")
     for i in range(N):
         ref = O.Problem(omodel, alg=oalg, stepper=c["stepper"], t0=0.0, t1=c["T"], dt=0.0, abstol=c["tol"], reltol=c["tol"], save_times=c["ts"], event_kind=kind, checkpointing=c["ck"], **QTOL)
         rt, rul, rur = ref.event_states(c["u0"][i], c["p"][i])
