@@ -88,6 +88,7 @@ int orc_model_sizes(int model, const int dims[4], int *n, int *np) {
  *                  time for every stage — a step that ends exactly at the switch sees the forcing of its interior, as with a tstop at 1.1 — and the knot derivative f(u_k)
  *                  takes the forcing of the step that starts at the knot.  (The classic steppers evaluate `t >= 1.1` at the stage time, docs/src/examples/pde/brusselator.md:85.) */
 static __thread int tls_skip_lin = 0, tls_force_t_on = 0;
+static __thread double tls_exit_dt = 0.0;      /* integrate(): the controller's state at exit, for a solve that continues it (section 3b) */
 static __thread double tls_force_t = 0.0;
 
 /* Brusselator forcing term (docs/src/examples/pde/brusselator.md:85) */
@@ -823,13 +824,15 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
     else I.dt = I.tdir * fabs(alg->dt);
     I.dtcache = I.dt;
     long guard = 0;
+    double dt_asked = 0.0; int clipped = 0;      /* the step the controller asked for before a stop clipped it */
     while (I.tdir * I.t < I.tdir * tend) {
         if (++guard > 200000000L) { status = -2; break; }
         while (its < nts && I.tdir * ts[its] <= I.tdir * I.t + 100 * DBL_EPSILON * fmax(fabs(I.t), fabs(ts[its]))) ++its;
         if (its >= nts) break;
         double tstop = ts[its];
         double dt = adaptive ? I.dt : I.dtcache;
-        if (fabs(dt) > fabs(tstop - I.t)) dt = tstop - I.t;
+        dt_asked = dt; clipped = fabs(dt) > fabs(tstop - I.t);
+        if (clipped) dt = tstop - I.t;
         /* avoid a sliver step: if the remainder after this step would be within roundoff, land on the tstop */
         if (fabs((I.t + dt) - tstop) < 100 * DBL_EPSILON * fmax(fabs(I.t + dt), fabs(tstop))) dt = tstop - I.t;
         memcpy(I.uprev, I.u, sizeof(double) * n);
@@ -1009,6 +1012,7 @@ static int integrate(orc_rhs rhs, void *ctx, int n, double *u, double tstart, do
             if (cb(&I, cbctx)) { if (etd) { tls_force_t_on = 1; tls_force_t = I.t + 0.5 * I.dtcache; } rhs(I.fsal, I.u, I.t, ctx); I.nrhs++; tls_force_t_on = 0; }
         }
     }
+    tls_exit_dt = clipped ? fmax(fabs(I.dt), fabs(dt_asked)) : fabs(I.dt);      /* its last proposal — or, when the end of the span cut the last step short, the larger of that and the step it had asked for */
     if (nrhs_out) *nrhs_out += I.nrhs;
     if (getenv("ORC_TRACE_STEPS")) fprintf(stderr, "orc integrate: %s accepted %ld rejected %ld rhs %ld\n", I.tdir < 0 ? "reverse" : "forward", I.naccept, I.nreject, I.nrhs);   /* debugging aid: step statistics */
     free(ts); free(buf); free(eb); free(rw); free(rpiv);
@@ -1801,8 +1805,11 @@ static int adjoint_one(const orc_model *m, const orc_config *cfg, const double *
             A.win_lo = (e == 0) ? 0 : sol.ev_s[e - 1]; A.win_hi = (e == sol.nev) ? sol.nsteps - 1 : sol.ev_s[e] - 1;      /* (never used for the skipped piece above a terminating event) */
             int npts = 0;
             for (int i = 0; i < nts; ++i) if (tst[i] >= t_lo && tst[i] <= t_hi) pts[npts++] = tst[i];      /* (a loss time that coincides with an event belongs to the piece above it: it sees the affected state) */
-            if (!(sol.terminated && e == sol.nev))
+            if (!(sol.terminated && e == sol.nev)) {
+                /* the reverse solve does not restart its step size at an event (the reference's runs through them): a piece starts from the proposal the piece above ended with */
                 st = integrate(rhs, &A, nz, z, t_hi, t_lo, &alg, pts, npts, adjoint_step_cb, &A, e == sol.nev ? cb_at_init : 0, have_rec ? &adjrec : NULL, nrhs);
+                if (tls_exit_dt > 0.0) alg.dt = tls_exit_dt;
+            }
             if (e == 0 || st) break;
             const double tev = t_lo; const long sm = sol.ev_s[e - 1] - 1, sp = sol.ev_s[e - 1];
             double gt = 0.0, num = 0.0, den = 0.0;

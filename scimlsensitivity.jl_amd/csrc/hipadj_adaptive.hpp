@@ -285,7 +285,7 @@ HIPADJ_HD void tsit5_stage_regs(KS& K, double (&w)[NZ], double h, double t, Rhs&
 template <int NZ, class KS, class Rhs, class Cb, class Pre = NoPre, class Red = TS5LaneNorm>
 HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, double dt_hint, double abstol, double reltol,
                               const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps,
-                              KS& K, Rhs&& rhs, Cb&& cb, Pre&& pre = NoPre(), Red red = Red()) {
+                              KS& K, Rhs&& rhs, Cb&& cb, Pre&& pre = NoPre(), Red red = Red(), double* dt_io = nullptr) {
     const double ncomp = red.count(NZ);
     const double EPS = 2.220446049250313e-16;
     const double tdir = tend >= tstart ? 1.0 : -1.0;
@@ -309,6 +309,7 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
     }
     bool need_k0 = true, first = true;
     double dt = 0.0, lqold = -9.21034037197618272;   // log qold, qold = 1e-4
+    double dt_asked = 0.0; bool clipped = false;      // (the step the controller asked for before a stop clipped it: handed to the caller with the final proposal, dt_io)
     int its = 0, naccept = 0, guard = 0;
     double ts_cur = ntstops > 0 ? tstops[0] : tend;
 #pragma unroll 1
@@ -351,7 +352,8 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
         double tstop = tend;
         if (its < ntstops && tdir * ts_cur < tdir * tend) tstop = ts_cur;
         double h = dt;
-        if (habs(h) > habs(tstop - t)) h = tstop - t;
+        dt_asked = dt; clipped = habs(h) > habs(tstop - t);
+        if (clipped) h = tstop - t;
         if (habs((t + h) - tstop) < 100.0 * EPS * hmax2(habs(t + h), habs(tstop))) h = tstop - t;
 #pragma unroll
         for (int i = 0; i < NZ; ++i) K.set(KS_UPREV, i, u[i]);
@@ -504,6 +506,9 @@ HIPADJ_HD int tsit5_integrate(double (&u)[NZ], double tstart, double tend, doubl
             }
         }
     }
+    // dt_io: the controller's state for a solve that CONTINUES this one (the reverse pieces between the events of a ContinuousCallback): its last proposal — or, when the
+    // last step was cut short by the end of the span, the larger of that and the step it had asked for
+    if (dt_io) *dt_io = clipped ? hmax2(habs(dt), habs(dt_asked)) : habs(dt);
     return naccept;
 }
 
@@ -595,7 +600,7 @@ template <class T> struct ros_noref<T&&> { using type = T; };
 template <int NZ, class KS, class Rhs, class Lin, class Cb, class Pre = NoPre>
 HIPADJ_HD int ros23_integrate(double (&u)[NZ], double tstart, double tend, double dt_hint, double abstol, double reltol,
                               const double* __restrict__ tstops, int ntstops, bool cb_at_init, int max_steps,
-                              KS& K, Rhs&& rhs, Lin&& lin, bool autonomous, Cb&& cb, Pre&& pre = NoPre()) {
+                              KS& K, Rhs&& rhs, Lin&& lin, bool autonomous, Cb&& cb, Pre&& pre = NoPre(), double* dt_io = nullptr) {
     const double EPS = 2.220446049250313e-16;
     const double tdir = tend >= tstart ? 1.0 : -1.0;
     double t = tstart, tprev = tstart;
@@ -607,6 +612,7 @@ HIPADJ_HD int ros23_integrate(double (&u)[NZ], double tstart, double tend, doubl
     }
     bool need_k0 = true, first = true;
     double dt = 0.0, lqold = -9.21034037197618272;   // log qold, qold = 1e-4
+    double dt_asked = 0.0; bool clipped = false;      // (the step the controller asked for before a stop clipped it: handed to the caller with the final proposal, dt_io)
     int its = 0, naccept = 0, guard = 0;
     double ts_cur = ntstops > 0 ? tstops[0] : tend;
 #pragma unroll 1
@@ -645,7 +651,8 @@ HIPADJ_HD int ros23_integrate(double (&u)[NZ], double tstart, double tend, doubl
         double tstop = tend;
         if (its < ntstops && tdir * ts_cur < tdir * tend) tstop = ts_cur;
         double h = dt;
-        if (habs(h) > habs(tstop - t)) h = tstop - t;
+        dt_asked = dt; clipped = habs(h) > habs(tstop - t);
+        if (clipped) h = tstop - t;
         if (habs((t + h) - tstop) < 100.0 * EPS * hmax2(habs(t + h), habs(tstop))) h = tstop - t;
 #pragma unroll
         for (int i = 0; i < NZ; ++i) K.set(KS_UPREV, i, u[i]);
@@ -727,6 +734,9 @@ HIPADJ_HD int ros23_integrate(double (&u)[NZ], double tstart, double tend, doubl
             dt = h / hmin2(5.0, ts5_exp((7.0 / 20.0) * lE) / 0.9);
         }
     }
+    // dt_io: the controller's state for a solve that CONTINUES this one (the reverse pieces between the events of a ContinuousCallback): its last proposal — or, when the
+    // last step was cut short by the end of the span, the larger of that and the step it had asked for
+    if (dt_io) *dt_io = clipped ? hmax2(habs(dt), habs(dt_asked)) : habs(dt);
     return naccept;
 }
 
@@ -1368,7 +1378,9 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
         }
     };
     // one reverse solve from ta down to tb (the whole span, or — ContinuousCallback — the piece between two events)
+    double dt_carry = 0.0;      // the controller's proposal at the end of the piece above (events: the reverse solve does not restart its step size at an event, like the reference's)
     auto run_piece = [&](double ta_, double tb_, bool at_init) -> int {
+    const double dt_first = dt_carry > 0.0 ? dt_carry : g.dt0;
     int na;
     if constexpr (STEP == 1) {
         // W = I - gh A(t_n) for the adjoint system z' = A(t) z + b(t):  A_ll = -J(y(t))', A_ml = -f_p(y(t))' (Interpolating), nothing else — so W is block triangular:
@@ -1433,8 +1445,8 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                 }
             }
         } lin{pv, cur, {}, {}, 0.0, 0.0, {}};
-        na = ros23_integrate<NZ>(z, ta_, tb_, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, at_init, 8 * g.maxit, K, rhs, lin, false, cb, pre);
-    } else na = tsit5_integrate<NZ>(z, ta_, tb_, g.dt0, g.abstol, g.reltol, tstops_desc, ntstops, at_init, 8 * g.maxit, K, rhs, cb, pre);
+        na = ros23_integrate<NZ>(z, ta_, tb_, dt_first, g.abstol, g.reltol, tstops_desc, ntstops, at_init, 8 * g.maxit, K, rhs, lin, false, cb, pre, model_has_cond<Mo>::value ? &dt_carry : nullptr);
+    } else na = tsit5_integrate<NZ>(z, ta_, tb_, dt_first, g.abstol, g.reltol, tstops_desc, ntstops, at_init, 8 * g.maxit, K, rhs, cb, pre, TS5LaneNorm(), model_has_cond<Mo>::value ? &dt_carry : nullptr);
     return na;
     };
     int na = 0;
