@@ -1089,8 +1089,8 @@ static int dae_consistent_init(const orc_model *m, double *u, const double *p, d
  *     at interp_points = 10 equally spaced points of the step's dense output is compared with its sign at the step's start (right after an event: at 1/100 of the step,
  *     repeat_nudge); the first bracket is halved 52 times on the dense output; the event time is the bracket's upper end; the step is cut there (the record keeps the
  *     stages and the length of the full step), u <- affect(u), the derivative is recomputed, the controller's proposal for the next step stands.
- *     Reverse: the adjoint solve runs piece by piece between the events (each piece a fresh solve: the controller restarts — the reference's PresetTimeCallback keeps it
- *     running; a tolerance-level difference) and applies at every event, with - / + the limits from below / above, f the right-hand side,
+ *     Reverse: the adjoint solve runs piece by piece between the events (a piece starts from the step size the piece above ended with, as the reference's one solve runs
+ *     through its PresetTimeCallbacks; the controller's error memory starts fresh: a tolerance-level difference) and applies at every event, with - / + the limits from below / above, f the right-hand side,
  *         kappa = lam+ . (a_u f- + a_t - f+) / (c_u . f- + c_t)        lam- = a_u' lam+ - kappa c_u        dp += a_p' lam+ - kappa c_p
  *     — :375-437 with dgdt :784-819 and implicit_correction! :828-844 for save_positions = (false, false) (Lu_right = 0, no saved left value).  Two terms the reference's
  *     lines do not carry as read: a_t (its affects do not use t) and kappa c_p — its "Re-compile tape" testset has a condition that depends on p1 and asks 1e-10 of the

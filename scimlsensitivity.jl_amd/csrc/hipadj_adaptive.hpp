@@ -1453,7 +1453,7 @@ HIPADJ_HD void adjoint_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     if constexpr (model_has_cond<Mo>::value && CC == 0) {
         {
             // ContinuousCallback (the oracle's section 3b; src/callback_tracking.jl:232-479 with save_positions = (false, false)): the reverse solve runs piece by piece between
-            // this trajectory's events (a fresh solve per piece: the controller restarts) and at each event, - / + the limits from below / above,
+            // this trajectory's events (a piece starts from the step size the piece above ended with, dt_carry) and at each event, - / + the limits from below / above,
             //     kappa = lam+ . (a_u f- + a_t - f+) / (c_u . f- + c_t)      lam- = a_u' lam+ - kappa c_u      dp += a_p' lam+ - kappa c_p
             // A loss time that coincides with an event is taken at the end of the piece above it (it sees the affected state).
             // (ONE call site of the integrator: without events the loop runs once over the whole span)
