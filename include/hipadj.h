@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 110 /* 0.1.8: + hipadj_model_set_continuous_callback, hipadj_model_set_vector_continuous_callback, hipadj_event_counts, hipadj_event_states, hipadj_set_event_cotangents (ContinuousCallback on the adaptive lane steppers); additive, no struct changed. History of 109 and earlier: docs/ABI_HISTORY.md */
+#define HIPADJ_VERSION 110 /* 0.1.8: + hipadj_model_set_continuous_callback, hipadj_model_set_vector_continuous_callback, hipadj_event_counts, hipadj_event_states, hipadj_event_components, hipadj_set_event_cotangents (ContinuousCallback on the adaptive lane steppers); additive, no struct changed. History of 109 and earlier: docs/ABI_HISTORY.md */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -293,6 +293,9 @@ int hipadj_event_counts(hipadj_handle *h, int32_t *counts);
  *                              dp += a_p' (lam+ + dr) - kappa c_p  (src/callback_tracking.jl:385-401, 439-452: the saved states move with the event time).
  * HIPADJ_ERR_UNSUPPORTED when the model carries no ContinuousCallback; hipadj_event_states before the first forward solve: HIPADJ_ERR_STATE. */
 int hipadj_event_states(hipadj_handle *h, double *t, double *ul, double *ur);
+/* which component of a VectorContinuousCallback fired at each event of the last forward solve (the reference's event_idx): idx [ntraj][max_events], 0 for a scalar condition,
+ * + 256 when the event terminated the trajectory's solve, -1 beyond a trajectory's event count.  Host pointer, synchronous; status as hipadj_event_states. */
+int hipadj_event_components(hipadj_handle *h, int32_t *idx);
 int hipadj_set_event_cotangents(hipadj_handle *h, const double *dl, const double *dr);
 /* The same for a wide model (hipadj_wmodel_register; ABI 108, round 5): dual numbers do not scale to 4096 states, so the reverse callback comes as text too.
  * Both bodies are SERIAL code run by one thread per trajectory (an event happens a handful of times per solve), over plain arrays:

@@ -25,7 +25,7 @@ module HIPAdj
 import Libdl
 using SciMLBase: SciMLBase
 
-export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, dense_chain_model, declare_dense_chain!, set_mass_matrix!, set_affect!, set_continuous_callback!, event_counts, event_states, set_event_cotangents!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
+export HIPBatchedAdjoint, HIPAdjSolution, DeviceModel, builtin_model, register_model, register_wide_model, set_wide_cost!, dense_chain_bodies, dense_chain_model, declare_dense_chain!, set_mass_matrix!, set_affect!, set_continuous_callback!, event_counts, event_states, event_components, set_event_cotangents!, affect_apply, affect_vjp, Handle, forward!, adjoint!, hip_solve, ensemble_u0_p, hipadj_version, runtime_compiler
 
 # ---------------------------------------------------------------------------------------------------------------------
 # library
@@ -529,6 +529,12 @@ function event_states(h::Handle; max_events::Integer = 64)
     t = zeros(Float64, max_events, h.N); ul = zeros(Float64, h.n, max_events, h.N); ur = similar(ul)     # column-major == the ABI's [N][max_events][n]
     check(ccall(sym(:hipadj_event_states), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h.ptr, t, ul, ur), h.ptr)
     return t, ul, ur
+end
+"which component of a VectorContinuousCallback fired at each event, `(max_events, N)`: 0 for a scalar condition, + 256 = the event terminated the trajectory, -1 beyond the count (`hipadj_event_components`)"
+function event_components(h::Handle; max_events::Integer = 64)
+    idx = Matrix{Int32}(undef, max_events, h.N)
+    check(ccall(sym(:hipadj_event_components), Cint, (Ptr{Cvoid}, Ptr{Int32}), h.ptr, idx), h.ptr)
+    return idx
 end
 function set_event_cotangents!(h::Handle, dl::Union{Nothing, Array{Float64, 3}}, dr::Union{Nothing, Array{Float64, 3}})
     pl = dl === nothing ? Ptr{Float64}(C_NULL) : pointer(dl); pr = dr === nothing ? Ptr{Float64}(C_NULL) : pointer(dr)

@@ -24,7 +24,7 @@ DECLARED_SYMBOLS = (
     "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
     "hipadj_model_set_discrete_loss", "hipadj_model_set_discrete_loss_function", "hipadj_wmodel_set_discrete_loss", "hipadj_set_loss_data", "hipadj_set_loss_data_dev",
     "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride", "hipadj_device_count", "hipadj_wmodel_declare_dense_chain",
-    "hipadj_model_set_continuous_callback", "hipadj_model_set_vector_continuous_callback", "hipadj_event_counts", "hipadj_event_states", "hipadj_set_event_cotangents",
+    "hipadj_model_set_continuous_callback", "hipadj_model_set_vector_continuous_callback", "hipadj_event_counts", "hipadj_event_states", "hipadj_event_components", "hipadj_set_event_cotangents",
 )
 
 
@@ -120,6 +120,7 @@ def load():
     L.hipadj_model_set_vector_continuous_callback.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32]
     L.hipadj_event_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hipadj_set_event_cotangents.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hipadj_event_components.argtypes = [C.c_void_p, C.c_void_p]
     L.hipadj_wmodel_set_affect.argtypes = [C.c_int32, C.c_char_p, C.c_char_p]
     L.hipadj_affect_apply.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.hipadj_affect_vjp.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_double, C.POINTER(C.c_double),

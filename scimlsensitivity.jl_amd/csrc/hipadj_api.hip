@@ -870,6 +870,20 @@ extern "C" int hipadj_event_states(hipadj_handle* h, double* t, double* ul, doub
     }
     return HIPADJ_OK;
 }
+// which component of a VectorContinuousCallback fired at each event of the last forward solve (0 for a scalar condition; + 256: the event terminated the trajectory's solve):
+// idx [ntraj][max_events], host pointer, -1 beyond a trajectory's event count; synchronous
+extern "C" int hipadj_event_components(hipadj_handle* h, int32_t* idx) {
+    if (!h || !idx) return HIPADJ_ERR_INVALID_ARG;
+    if (h->multi || h->maxev <= 0 || !h->d_nev) HIPADJ_FAIL(h, HIPADJ_ERR_UNSUPPORTED, "hipadj_event_components: the handle's model carries no ContinuousCallback (hipadj_model_set_continuous_callback), or the handle spans several devices");
+    if (!h->have_forward) HIPADJ_FAIL(h, HIPADJ_ERR_STATE, "hipadj_event_components: no forward solve yet");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const long Np = h->Npad; const int me = h->maxev;
+    std::vector<int> ne((size_t)Np), buf((size_t)me * Np);
+    HIP_TRY(h, hipMemcpy(ne.data(), h->d_nev, sizeof(int) * (size_t)Np, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(buf.data(), h->d_ev_k, sizeof(int) * (size_t)me * Np, hipMemcpyDeviceToHost));
+    for (long i = 0; i < h->N; ++i) for (int k = 0; k < me; ++k) idx[i * me + k] = k < ne[i] ? buf[(size_t)k * Np + i] : -1;
+    return HIPADJ_OK;
+}
 // cotangents of a loss on the saved event states for the following reverse passes: dl (at u-), dr (at u+), [ntraj][max_events][n] host pointers (entries beyond a trajectory's
 // event count are ignored); either may be NULL (= zero); both NULL removes them
 extern "C" int hipadj_set_event_cotangents(hipadj_handle* h, const double* dl, const double* dr) {

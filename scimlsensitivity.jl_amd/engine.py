@@ -211,6 +211,13 @@ class Engine:
         self._check(self._L.hipadj_event_states(self._h, t.ctypes.data_as(C.c_void_p), ul.ctypes.data_as(C.c_void_p), ur.ctypes.data_as(C.c_void_p)))
         return t, ul, ur, self.event_counts()
 
+    def event_components(self, max_events=64):
+        """Which component of a VectorContinuousCallback fired at each event (the reference's event_idx): [N][max_events] ints, 0 for a scalar condition, + 256 when the event
+        terminated the trajectory, -1 beyond a trajectory's count."""
+        idx = np.zeros((self.N, int(max_events) or 64), dtype=np.int32)
+        self._check(self._L.hipadj_event_components(self._h, idx.ctypes.data_as(C.c_void_p)))
+        return idx
+
     def set_event_cotangents(self, dl=None, dr=None):
         """Cotangents of the caller's loss at the saved event states, [N][max_events][n] each (None = zero; both None removes them), for the following adjoint calls."""
         self._ev_cot = tuple(None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (dl, dr))

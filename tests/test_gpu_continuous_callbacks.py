@@ -310,6 +310,8 @@ def test_vector_callback_against_the_closed_forms(sa, gold, case, kind, alg, oal
                    dgdu_discrete=sa.LsqShift(1.0))
     t, ul, ur, cnt = sol.engine.event_states()
     assert cnt.tolist() == [ne] and np.max(np.abs(t[0, :ne] - np.asarray(g["event_times"]))) < 1e-10
+    comp = sol.engine.event_components()
+    assert comp[0, :ne].tolist() == g["event_components"] and np.all(comp[0, ne:] == -1)          # which component fired, in order (the reference's event_idx)
     assert np.max(np.abs(np.array(sol.u)[0] - np.asarray(g["u_at_ts"]))) < 1e-9
     if saved:
         es = np.asarray(g["event_states"])
@@ -333,6 +335,7 @@ def test_terminate_against_the_closed_forms(sa, gold, case, alg, oalg):
     sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(model(sa, 7), u0[0], (0.0, 2.5), p), u0, np.tile(p, (2, 1))), sa.Tsit5(), saveat=ts, sensealg=sens(sa, alg), abstol=1e-12, reltol=1e-12)
     t, ul, ur, cnt = sol.engine.event_states()
     assert cnt.tolist() == [1, 1] and abs(t[0, 0] - g["event_times"][0]) < 1e-11 and abs(t[1, 0] - np.sqrt(12.0 / 9.8)) < 1e-11
+    assert sol.engine.event_components()[:, 0].tolist() == [256, 256]                               # component 0, terminating
     out = np.array(sol.u)
     assert np.max(np.abs(out[0, :nb] - np.asarray(g["u_at_ts"]))) < 1e-10 and np.max(np.abs(out[0, nb:] - es[0, 1])) < 1e-9 and np.max(np.abs(ur[0, 0] - es[0, 1])) < 1e-9
     if saved:
