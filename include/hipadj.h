@@ -252,11 +252,23 @@ int hipadj_model_set_mass_matrix(int32_t model_id, const double *M);
  * other than (false, false) — the host mirror defines the value saved AT an event time as the right limit. */
 int hipadj_model_set_affect(int32_t model_id, const char *affect_body);
 
-/* ContinuousCallback(condition, affect!; save_positions = (false, false)) on a runtime lane model  (src/callback_tracking.jl:1-223 forward tracking, :232-479 reverse callbacks;
+/* The same for a wide model (hipadj_wmodel_register; ABI 108, round 5): dual numbers do not scale to 4096 states, so the reverse callback comes as text too.
+ * Both bodies are SERIAL code run by one thread per trajectory (an event happens a handful of times per solve), over plain arrays:
+ *   affect_body      edits un[0..N) / pn[0..NP) — copies of u / p on entry — from u, p, t
+ *   affect_vjp_body  edits lo[0..N) / go[0..NP) — copies of lam / gp on entry, i.e. the reverse callback of the identity — from lam, gp, u, p, t, so that
+ *                    lo = (dun/du)' lam + (dpn/du)' gp,  go = (dun/dp)' lam + (dpn/dp)' gp.  "" = the affect's Jacobian is the identity (a constant dose).
+ * e.g. affect "for (int i = 0; i < N; ++i) un[i] += p[1] / 8.0 * sin(u[i]);"  with  vjp "for (int i = 0; i < N; ++i) { lo[i] = lam[i] * (1.0 + p[1] / 8.0 * cos(u[i])); go[1] += lam[i] * sin(u[i]) / 8.0; }".
+ * Both NULL removes the affect.  hipadj_affect_apply / hipadj_affect_vjp below serve both families. */
+int hipadj_wmodel_set_affect(int32_t model_id, const char *affect_body, const char *affect_vjp_body);
+int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, double *out, double *p_out);
+int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, const double *lam,
+                      const double *gp, double *lam_out, double *gp_out);
+
+/* ContinuousCallback(condition, affect!) on a runtime lane model  (src/callback_tracking.jl:1-223 forward tracking, :232-479 reverse callbacks;
  * test/Callbacks2/continuous_callbacks.jl — the bouncing ball).  Every handle created on the model afterwards, on HIPADJ_STEPPER_TSIT5_ADAPTIVE or
  * HIPADJ_STEPPER_ROSENBROCK23_ADAPTIVE, locates the zero crossings of the condition on the dense output of each accepted step, PER TRAJECTORY (either direction: affect_neg! =
- * affect!), cuts the step there, applies the affect and goes on; the reverse solve of every sensealg (Interpolating-, Backsolve-, Gauss-, GaussKronrod-, QuadratureAdjoint) runs piece by piece between the events
- * of each trajectory and applies, at each of them, the jump with the event-time term:
+ * affect!), cuts the step there, applies the affect and goes on; the reverse solve of every sensealg (Interpolating-,
+ * Backsolve-, Gauss-, GaussKronrod-, QuadratureAdjoint) runs piece by piece between the events of each trajectory and applies, at each of them, the jump with the event-time term:
  *     kappa = lam+ . (a_u f- + a_t - f+) / (c_u . f- + c_t)      lam- = a_u' lam+ - kappa c_u      dp += a_p' lam+ - kappa c_p
  *   condition_body  assigns `c` from u[0..N), p[0..NP), t       e.g. "c = u[0];"  or  "c = u[0] - 0.75 * p[0];"
  *   affect_body     edits un[0..N) — a copy of u on entry — from u, p, t (NULL or "": the identity)       e.g. "un[1] = -p[1] * u[1];"
@@ -277,8 +289,9 @@ int hipadj_model_set_continuous_callback(int32_t model_id, const char *condition
  * crossing of any of them, and the affect sees which one fired.
  *   condition_body  assigns out[0 .. ncond)                 e.g. "out[0] = u[0]; out[1] = (u[2] - 10.0) * u[2];"
  *   affect_body     edits un from u, p, t and `idx` (int)   e.g. "if (idx == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3];"
- * Everything else as hipadj_model_set_continuous_callback (which is the case ncond = 1, `c` an alias of out[0]).  Components that cross in the same tenth of a step: the lowest index
- * fires; the simultaneous fire of several components (the reference's event_idx mask, :118-230) is not merged into one event. */
+ * Everything else as hipadj_model_set_continuous_callback (which is the case ncond = 1, `c` an alias of out[0]).  Components that cross in the same tenth of
+ * a step are each located on their own and the earliest root is the event; the SIMULTANEOUS fire of several components (the reference's event_idx mask, :118-230) is not merged
+ * into one event: the lowest index fires. */
 int hipadj_model_set_vector_continuous_callback(int32_t model_id, int32_t ncond, const char *condition_body, const char *affect_body, int32_t max_events);
 /* events per trajectory of the handle's last forward solve: counts[ntraj], host pointer, synchronous.  HIPADJ_ERR_UNSUPPORTED when the model carries no ContinuousCallback. */
 int hipadj_event_counts(hipadj_handle *h, int32_t *counts);
@@ -297,17 +310,6 @@ int hipadj_event_states(hipadj_handle *h, double *t, double *ul, double *ur);
  * + 256 when the event terminated the trajectory's solve, -1 beyond a trajectory's event count.  Host pointer, synchronous; status as hipadj_event_states. */
 int hipadj_event_components(hipadj_handle *h, int32_t *idx);
 int hipadj_set_event_cotangents(hipadj_handle *h, const double *dl, const double *dr);
-/* The same for a wide model (hipadj_wmodel_register; ABI 108, round 5): dual numbers do not scale to 4096 states, so the reverse callback comes as text too.
- * Both bodies are SERIAL code run by one thread per trajectory (an event happens a handful of times per solve), over plain arrays:
- *   affect_body      edits un[0..N) / pn[0..NP) — copies of u / p on entry — from u, p, t
- *   affect_vjp_body  edits lo[0..N) / go[0..NP) — copies of lam / gp on entry, i.e. the reverse callback of the identity — from lam, gp, u, p, t, so that
- *                    lo = (dun/du)' lam + (dpn/du)' gp,  go = (dun/dp)' lam + (dpn/dp)' gp.  "" = the affect's Jacobian is the identity (a constant dose).
- * e.g. affect "for (int i = 0; i < N; ++i) un[i] += p[1] / 8.0 * sin(u[i]);"  with  vjp "for (int i = 0; i < N; ++i) { lo[i] = lam[i] * (1.0 + p[1] / 8.0 * cos(u[i])); go[1] += lam[i] * sin(u[i]) / 8.0; }".
- * Both NULL removes the affect.  hipadj_affect_apply / hipadj_affect_vjp below serve both families. */
-int hipadj_wmodel_set_affect(int32_t model_id, const char *affect_body, const char *affect_vjp_body);
-int hipadj_affect_apply(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, double *out, double *p_out);
-int hipadj_affect_vjp(int32_t model_id, int32_t device, int64_t N, const double *u, const double *p, int32_t p_shared, double t, const double *lam,
-                      const double *gp, double *lam_out, double *gp_out);
 /* Wide runtime models — more than 8 states or more than 32 parameters (up to n = 4096 states): the workgroup-per-trajectory family
  * (csrc/hipadj_wide.hpp).  ONE workgroup of `threads` threads integrates one trajectory; the stage state, the stage adjoint and the VJP
  * output are tiles in LDS, threads own the components tid, tid + threads, ...  The model is TWO bodies of HIP C++, run by every thread
