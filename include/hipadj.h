@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPADJ_VERSION 110 /* 0.1.8: + hipadj_model_set_continuous_callback, hipadj_model_set_vector_continuous_callback, hipadj_event_counts, hipadj_event_states, hipadj_event_components, hipadj_set_event_cotangents (ContinuousCallback on the adaptive lane steppers); additive, no struct changed. History of 109 and earlier: docs/ABI_HISTORY.md */
+#define HIPADJ_VERSION 110 /* 0.1.8: + hipadj_model_set_continuous_callback, hipadj_model_set_vector_continuous_callback, hipadj_model_set_callback_direction, hipadj_event_counts, hipadj_event_states, hipadj_event_components, hipadj_set_event_cotangents (ContinuousCallback on the adaptive lane steppers); additive, no struct changed. History of 109 and earlier: docs/ABI_HISTORY.md */
 
 typedef enum {
     HIPADJ_OK = 0,
@@ -293,6 +293,9 @@ int hipadj_model_set_continuous_callback(int32_t model_id, const char *condition
  * a step are each located on their own and the earliest root is the event; the SIMULTANEOUS fire of several components (the reference's event_idx mask, :118-230) is not merged
  * into one event: the lowest index fires. */
 int hipadj_model_set_vector_continuous_callback(int32_t model_id, int32_t ncond, const char *condition_body, const char *affect_body, int32_t max_events);
+/* ContinuousCallback(condition, affect!, affect_neg!) with one of the two affects `nothing`: direction +1 = only upcrossings of the condition fire (negative to positive: affect!
+ * with affect_neg! = nothing), -1 = only downcrossings, 0 = both (the default: affect_neg! = affect!).  For a callback set before; applies to every handle created afterwards. */
+int hipadj_model_set_callback_direction(int32_t model_id, int32_t direction);
 /* events per trajectory of the handle's last forward solve: counts[ntraj], host pointer, synchronous.  HIPADJ_ERR_UNSUPPORTED when the model carries no ContinuousCallback. */
 int hipadj_event_counts(hipadj_handle *h, int32_t *counts);
 /* save_positions = (true, true) — the constructor's default, and the setting of most of the reference's callback tests (test/Callbacks2/continuous_callbacks.jl:200-250): the

@@ -366,7 +366,7 @@ test/Callbacks2/continuous_callbacks.jl): `condition` assigns `c` from `u`, `p`,
 The bouncing ball: `set_continuous_callback!(m, "c = u[0];", "un[1] = -p[1] * u[1];")`.  Every later handle on the model with `stepper = STEPPER_TSIT5_ADAPTIVE` or
 `STEPPER_ROSENBROCK23_ADAPTIVE` locates the events of each trajectory on the dense output; every sensealg differentiates through them, event times included.  `event_counts(handle)` returns the events per trajectory of the last forward solve.
 """
-function set_continuous_callback!(m::DeviceModel, condition, affect = nothing; max_events::Integer = 0, ncond::Integer = 1)
+function set_continuous_callback!(m::DeviceModel, condition, affect = nothing; max_events::Integer = 0, ncond::Integer = 1, direction::Integer = 0)
     c = condition === nothing ? nothing : String(condition); a = affect === nothing ? nothing : String(affect)
     pc = c === nothing ? Ptr{UInt8}(C_NULL) : pointer(c); pa = a === nothing ? Ptr{UInt8}(C_NULL) : pointer(a)
     if ncond > 1        # VectorContinuousCallback(condition, affect!, ncond): `out[k]` in the condition body, `idx` in the affect body
@@ -374,6 +374,8 @@ function set_continuous_callback!(m::DeviceModel, condition, affect = nothing; m
     else
         GC.@preserve c a check(ccall(sym(:hipadj_model_set_continuous_callback), Cint, (Int32, Ptr{UInt8}, Ptr{UInt8}, Int32), m.id, pc, pa, Int32(max_events)))
     end
+    # direction = +1: only upcrossings fire (ContinuousCallback(condition, affect!, nothing)), -1: only downcrossings
+    direction != 0 && c !== nothing && check(ccall(sym(:hipadj_model_set_callback_direction), Cint, (Int32, Int32), m.id, Int32(direction)))
     return m
 end
 function affect_apply(m::DeviceModel, u::Matrix{Float64}, p::Union{Vector{Float64}, Matrix{Float64}}, t::Real; device::Integer = 0)

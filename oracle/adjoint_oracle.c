@@ -1105,7 +1105,7 @@ static void ev_cond(int kind, double *out, const double *u, const double *p, dou
     case 4: out[0] = u[0] - 0.3 * t; break;
     case 5: out[0] = u[0]; out[1] = (u[2] - 10.0) * u[2]; break;
     case 6: out[0] = sin(t); out[1] = cos(t); break;
-    default: out[0] = u[0]; break;
+    default: out[0] = u[0]; break;      /* (1, 2, 7, 8) */
     }
 }
 /* gradient of component k */
@@ -1132,6 +1132,7 @@ static void ev_affect(int kind, int k, int n, double *un, const double *u, const
     case 4: un[1] = -p[1] * (u[1] - 0.3) + 0.3 + 0.1 * t; break;
     case 5: if (k == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3]; break;
     case 6: un[0] = 0.5; un[1] = 1.0; un[2] = 0.0; un[3] = 0.0; break;
+    case 8: un[1] = p[2] * u[1]; break;
     default: break;
     }
 }
@@ -1146,6 +1147,7 @@ static void ev_affect_jvp(int kind, int k, int n, double *out, const double *u, 
     case 4: out[1] = -p[1] * v[1] + 0.1; break;
     case 5: if (k == 0) out[1] = -p[1] * v[1]; else out[3] = -p[1] * v[3]; break;
     case 6: for (int i = 0; i < n; ++i) out[i] = 0.0; break;
+    case 8: out[1] = p[2] * v[1]; break;
     default: break;
     }
 }
@@ -1162,11 +1164,14 @@ static void ev_affect_vjp(int kind, int k, int n, int np, double *lo, double *go
     case 4: lo[1] = -p[1] * lam[1]; go[1] = -(u[1] - 0.3) * lam[1]; break;
     case 5: if (k == 0) { lo[1] = -p[1] * lam[1]; go[1] = -u[1] * lam[1]; } else { lo[3] = -p[1] * lam[3]; go[1] = -u[3] * lam[3]; } break;
     case 6: for (int i = 0; i < n; ++i) lo[i] = 0.0; break;
+    case 8: lo[1] = p[2] * lam[1]; go[2] = u[1] * lam[1]; break;
     default: break;
     }
 }
 #define ORC_MAX_EVENTS 4096
-typedef struct { const orc_model *m; const double *p; int kind; orc_dense *sol; double cprev[ORC_MAXCOND], tend; int nudge, overflow; } fwd_event_ctx;
+typedef struct { const orc_model *m; const double *p; int kind; orc_dense *sol; double cprev[ORC_MAXCOND], tend; int nudge, overflow, dir; } fwd_event_ctx;
+/* does the condition cross from a to b in a direction that fires (dir: 0 both, +1 upward, -1 downward)? */
+static int ev_crosses(double a, double b, int dir) { return (a * b < 0.0 || (b == 0.0 && a != 0.0)) && (dir == 0 || (dir > 0 ? a < 0.0 : a > 0.0)); }
 static int fwd_event_cb(orc_integ *I, void *c) {
     fwd_event_ctx *E = (fwd_event_ctx *)c;
     const int n = I->n, nc = ev_ncond(E->kind); const double h = I->t - I->tprev;
@@ -1179,7 +1184,7 @@ static int fwd_event_cb(orc_integ *I, void *c) {
         thb = j < 10 ? 0.1 * j : 1.0;
         if (j < 10) integ_interp(I, I->tprev + thb * h, y); else memcpy(y, I->u, sizeof(double) * n);
         ev_cond(E->kind, cv, y, E->p, I->tprev + thb * h);
-        for (int k = 0; k < nc; ++k) if (ca[k] * cv[k] < 0.0 || (cv[k] == 0.0 && ca[k] != 0.0)) any = 1;
+        for (int k = 0; k < nc; ++k) if (ev_crosses(ca[k], cv[k], E->dir)) any = 1;
         if (!any) { tha = thb; for (int k = 0; k < nc; ++k) ca[k] = cv[k]; }
     }
     if (!any) { for (int k = 0; k < nc; ++k) E->cprev[k] = cv[k]; return 0; }
@@ -1187,7 +1192,7 @@ static int fwd_event_cb(orc_integ *I, void *c) {
     { double best = 2.0, cend[ORC_MAXCOND];
       for (int k = 0; k < nc; ++k) cend[k] = cv[k];
       for (int k = 0; k < nc; ++k) {
-          if (!(ca[k] * cend[k] < 0.0 || (cend[k] == 0.0 && ca[k] != 0.0))) continue;
+          if (!ev_crosses(ca[k], cend[k], E->dir)) continue;
           double lo = tha, hi = thb, cl = ca[k];
           for (int it = 0; it < 52; ++it) {
               const double thm = 0.5 * (lo + hi);
@@ -1243,10 +1248,10 @@ static int forward_dense(const orc_model *m, const orc_config *cfg, const double
         int G = m->dims[0]; double dx = 1.0 / (G - 1);
         a.split_G = G; a.split_coef = p[2] / (dx * dx);
     }
-    fwd_event_ctx ev; memset(&ev, 0, sizeof(ev)); ev.m = m; ev.p = p; ev.kind = cfg->event_kind; ev.sol = sol; ev.tend = tb;
+    fwd_event_ctx ev; memset(&ev, 0, sizeof(ev)); ev.m = m; ev.p = p; ev.kind = cfg->event_kind; ev.sol = sol; ev.tend = tb; ev.dir = cfg->event_dir;
     if (cfg->event_kind) {
-        if (cfg->event_kind < 1 || cfg->event_kind > 7 || (cfg->stepper != ORC_STEPPER_TSIT5 && cfg->stepper != ORC_STEPPER_ROS23) || g_mm_n == m->n || g_mm_dae || m->n > ORC_MM_MAXN) return -6;
-        if ((cfg->event_kind == 3) != (m->id == ORC_MODEL_RELAX) || (cfg->event_kind == 5 || cfg->event_kind == 6) != (m->id == ORC_MODEL_BALL2D) || ((cfg->event_kind == 1 || cfg->event_kind == 2 || cfg->event_kind == 4 || cfg->event_kind == 7) && (m->n != 2 || m->np < 2))) return -6;
+        if (cfg->event_kind < 1 || cfg->event_kind > 8 || cfg->event_dir < -1 || cfg->event_dir > 1 || (cfg->stepper != ORC_STEPPER_TSIT5 && cfg->stepper != ORC_STEPPER_ROS23) || g_mm_n == m->n || g_mm_dae || m->n > ORC_MM_MAXN) return -6;
+        if ((cfg->event_kind == 3) != (m->id == ORC_MODEL_RELAX) || (cfg->event_kind == 5 || cfg->event_kind == 6) != (m->id == ORC_MODEL_BALL2D) || (cfg->event_kind == 8 && m->id != ORC_MODEL_PENDULUM) || ((cfg->event_kind == 1 || cfg->event_kind == 2 || cfg->event_kind == 4 || cfg->event_kind == 7) && (m->n != 2 || m->np < 2))) return -6;
         ev_cond(cfg->event_kind, ev.cprev, u, p, ta);
         for (int k = 0; k < ev_ncond(cfg->event_kind); ++k) if (ev.cprev[k] == 0.0) ev.nudge = 1;
     }

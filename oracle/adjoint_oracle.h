@@ -105,12 +105,15 @@ typedef struct {
                              4: c = u1 - 0.3 t, u2 <- -p2 (u2 - 0.3) + 0.3 + 0.1 t (NOT from the reference: condition and affect depend on t explicitly, so that c_t and a_t are not zero);
                              7: event 1 with terminate!(integrator) in the affect (test/Callbacks2/continuous_callbacks.jl:226-236): the solve ends at the first bounce; save
                                 times after it hold the final state and carry no loss;
+                             8: ORC_MODEL_PENDULUM, c = u1 (the angle), u2 <- p3 u2 (NOT from the reference: an oscillating state whose condition is crossed in both directions — the
+                                problem for event_dir);
                              VectorContinuousCallback (a vector of conditions; the affect sees which component fired; ORC_MODEL_BALL2D):
                              5: out = [u1, (u3 - 10) u3]; component 1: u2 <- -p2 u2, component 2: u4 <- -p2 u4 (test/Callbacks2/vector_continuous_callbacks.jl:80-96);
                              6: out = [sin t, cos t]; either: u <- [0.5, 1, 0, 0] (:100-116: conditions that depend on time only, an affect whose Jacobian is zero) */
     int ev_max;           /* save_positions = (true, true) of the ContinuousCallback: a loss on the saved event states — ev_dl / ev_dr [ev_max][n], its cotangents at the state just
                              before / after the affect of event k (NULL = zero; events beyond ev_max carry none); src/callback_tracking.jl:385-401, 439-452 */
     const double *ev_dl, *ev_dr;
+    int event_dir;        /* which crossings fire: 0 both (affect_neg! = affect!, the constructor's default), +1 upcrossings only (affect! with affect_neg! = nothing), -1 downcrossings only */
 } orc_config;
 
 int orc_model_sizes(int model, const int dims[4], int *n, int *np);

@@ -24,7 +24,7 @@ DECLARED_SYMBOLS = (
     "hipadj_comm_count", "hipadj_comm_selfcheck", "hipadj_comm_overlap",
     "hipadj_model_set_discrete_loss", "hipadj_model_set_discrete_loss_function", "hipadj_wmodel_set_discrete_loss", "hipadj_set_loss_data", "hipadj_set_loss_data_dev",
     "hipadj_loss_value", "hipadj_loss_value_dev", "hipadj_adjoint_dev_soa", "hipadj_soa_stride", "hipadj_device_count", "hipadj_wmodel_declare_dense_chain",
-    "hipadj_model_set_continuous_callback", "hipadj_model_set_vector_continuous_callback", "hipadj_event_counts", "hipadj_event_states", "hipadj_event_components", "hipadj_set_event_cotangents",
+    "hipadj_model_set_continuous_callback", "hipadj_model_set_vector_continuous_callback", "hipadj_model_set_callback_direction", "hipadj_event_counts", "hipadj_event_states", "hipadj_event_components", "hipadj_set_event_cotangents",
 )
 
 
@@ -118,6 +118,7 @@ def load():
     L.hipadj_model_set_continuous_callback.argtypes = [C.c_int32, C.c_char_p, C.c_char_p, C.c_int32]
     L.hipadj_event_counts.argtypes = [C.c_void_p, C.c_void_p]
     L.hipadj_model_set_vector_continuous_callback.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32]
+    L.hipadj_model_set_callback_direction.argtypes = [C.c_int32, C.c_int32]
     L.hipadj_event_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hipadj_set_event_cotangents.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hipadj_event_components.argtypes = [C.c_void_p, C.c_void_p]
@@ -221,6 +222,14 @@ def set_model_affect(model_id, body):
     """hipadj_model_set_affect: the DiscreteCallback affect of a runtime-registered model (None removes it)."""
     L = load()
     rc = L.hipadj_model_set_affect(int(model_id), None if body is None else body.encode())
+    if rc != OK:
+        raise HipadjError(rc, L.hipadj_last_error(None).decode())
+
+
+def set_model_callback_direction(model_id, direction):
+    """hipadj_model_set_callback_direction: +1 only upcrossings fire (affect_neg! = nothing), -1 only downcrossings, 0 both."""
+    L = load()
+    rc = L.hipadj_model_set_callback_direction(int(model_id), int(direction))
     if rc != OK:
         raise HipadjError(rc, L.hipadj_last_error(None).decode())
 

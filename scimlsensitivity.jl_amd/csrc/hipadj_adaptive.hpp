@@ -841,6 +841,8 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
     // VectorContinuousCallback (Mo::NCOND > 1: `out[k] = ...` in the condition body, `idx` in the affect body): the scan watches every component; in the first tenth of the step where any of them
     // crosses, each crossing component is bisected on its own and the EARLIEST root is the event (simultaneous fires of several components are not merged: DESIGN.md section 4.12)
     constexpr int NC = model_ncond<Mo>::value;
+    constexpr int CDIR = model_cdir<Mo>::value;      // 0: both directions fire; +1 / -1: only crossings upward / downward (hipadj_model_set_callback_direction)
+    auto crosses = [](double a, double b) -> bool { return (a * b < 0.0 || (b == 0.0 && a != 0.0)) && (CDIR == 0 || (CDIR > 0 ? a < 0.0 : a > 0.0)); };
     double cprev[NC]; bool nudge = false, terminated = false; int nevl = 0, evk = 0;
     for (int k = 0; k < NC; ++k) cprev[k] = 0.0;
     if constexpr (model_has_cond<Mo>::value) { if (g.maxev > 0) { Mo::cond(cprev, u, pv, g.t0); for (int k = 0; k < NC; ++k) nudge = nudge || (cprev[k] == 0.0); } }
@@ -866,7 +868,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                             for (int q = 0; q < N; ++q) y[q] = un[q]; }
                         Mo::cond(cv, y, pv, tprev + thb * h);
 #pragma unroll
-                        for (int k = 0; k < NC; ++k) any = any || (ca[k] * cv[k] < 0.0 || (cv[k] == 0.0 && ca[k] != 0.0));
+                        for (int k = 0; k < NC; ++k) any = any || crosses(ca[k], cv[k]);
                         if (!any) { tha = thb;
 #pragma unroll
                             for (int k = 0; k < NC; ++k) ca[k] = cv[k]; }
@@ -884,7 +886,7 @@ HIPADJ_HD void forward_tsit5_lane(const AdaptGeom& g, long i, const double* __re
                             double cak = ca[0], cek = cend[0];
 #pragma unroll
                             for (int q = 1; q < NC; ++q) { cak = (q == k) ? ca[q] : cak; cek = (q == k) ? cend[q] : cek; }
-                            if (!(cak * cek < 0.0 || (cek == 0.0 && cak != 0.0))) continue;
+                            if (!crosses(cak, cek)) continue;
                             double lo = tha, hi = thb;
 #pragma unroll 1
                             for (int it = 0; it < 52; ++it) {

@@ -99,6 +99,9 @@ extern "C" int hipadj_model_set_affect(int32_t model_id, const char* affect_body
 extern "C" int hipadj_model_set_continuous_callback(int32_t model_id, const char* condition_body, const char* affect_body, int32_t max_events) {
     return user_set_continuous_callback(model_id, condition_body, affect_body, max_events, g_create_error);
 }
+extern "C" int hipadj_model_set_callback_direction(int32_t model_id, int32_t direction) {
+    return user_set_callback_direction(model_id, direction, g_create_error);
+}
 extern "C" int hipadj_model_set_vector_continuous_callback(int32_t model_id, int32_t ncond, const char* condition_body, const char* affect_body, int32_t max_events) {
     return user_set_continuous_callback(model_id, condition_body, affect_body, max_events, g_create_error, ncond);
 }

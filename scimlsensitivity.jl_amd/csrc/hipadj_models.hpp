@@ -115,6 +115,8 @@ template <class Mo, class = void> struct model_has_cond { static constexpr bool 
 template <class Mo> struct model_has_cond<Mo, decltype((void)Mo::HAS_COND)> { static constexpr bool value = Mo::HAS_COND; };
 template <class Mo, class = void> struct model_ncond { static constexpr int value = 1; };      // components of the condition (VectorContinuousCallback: > 1)
 template <class Mo> struct model_ncond<Mo, decltype((void)Mo::NCOND)> { static constexpr int value = Mo::NCOND; };
+template <class Mo, class = void> struct model_cdir { static constexpr int value = 0; };       // which crossings fire: 0 both, +1 upcrossings only (affect_neg! = nothing), -1 downcrossings only
+template <class Mo> struct model_cdir<Mo, decltype((void)Mo::CDIR)> { static constexpr int value = Mo::CDIR; };
 // Bundle width for n states and NC columns: at most ELEMS doubles per bundle vector (seven such vectors are live in an RK4 step), the columns spread
 // evenly over the fewest bundles.  The sweeps bundle only when ONE bundle holds all columns (NB == 1: n <= 4 for InterpolatingAdjoint at 24 elements,
 // n <= 5 for the lambda-only GaussAdjoint step at 32): with two or more bundles the (u, p, t)-dependent work is repeated per bundle and the measured

@@ -51,6 +51,7 @@ struct UserModelSrc {
     bool auto_vjp = false;    // only f was given: vjp_u / vjp_p by forward-mode dual numbers (hipadj_dual.hpp)
     std::string affect;       // DiscreteCallback affect body (hipadj_model_set_affect): modifies un (pre-set to u) from u, p, t; empty = identity
     std::string cc_cond, cc_affect;   // ContinuousCallback (hipadj_model_set_continuous_callback): the condition body assigns `c` from u, p, t; the affect body edits un (pre-set to u)
+    int cc_dir = 0;                   // which crossings fire: 0 both, +1 upcrossings only, -1 downcrossings only (hipadj_model_set_callback_direction)
     int cc_maxev = 0, cc_ncond = 1;   // ... the capacity of the per-trajectory event list, and the components of the condition (VectorContinuousCallback: `out[k]`, `idx`)
     bool cols = true;         // the VJP bodies compile for Cols<G> (column bundles); cleared by user_compile when they do not
     bool has_mm = false;      // constant non-singular mass matrix (hipadj_model_set_mass_matrix): minv = M^{-1}, row-major n x n
@@ -387,7 +388,7 @@ inline std::string user_model_struct(const UserModelSrc& m) {
         // ContinuousCallback(condition, affect!) (hipadj_model_set_continuous_callback; hipadj_adaptive.hpp "events", src/callback_tracking.jl:232-479): the condition and the affect
         // compile for double and for dual numbers — c_u, c_p, c_t, the directional derivative a_u v + a_t and the products a_u' lam, a_p' lam of the reverse jump
         // (a VectorContinuousCallback: NCOND components `out[k]`, the affect sees the index `idx` of the one that fired; a scalar condition is NCOND = 1 with `c` an alias of out[0])
-        o << "    static constexpr bool HAS_COND = true;\n    static constexpr int NCOND = " << (m.cc_ncond > 0 ? m.cc_ncond : 1) << ";\n"
+        o << "    static constexpr bool HAS_COND = true;\n    static constexpr int NCOND = " << (m.cc_ncond > 0 ? m.cc_ncond : 1) << ", CDIR = " << m.cc_dir << ";\n"
           << "    template <class real> HIPADJ_HD static void cond_t(real (&out)[NCOND], const real (&u)[N], const real (&p)[NP], real t) {\n        (void)u; (void)p; (void)t;\n"
           << "        for (int k = 0; k < NCOND; ++k) out[k] = real(0.0);\n        real& c = out[0]; (void)c;\n" << m.cc_cond << "\n    }\n"
           << "    HIPADJ_HD static void cond(double (&out)[NCOND], const double (&u)[N], const double (&p)[NP], double t) { cond_t<double>(out, u, p, t); }\n"
@@ -709,7 +710,7 @@ inline int user_set_continuous_callback(int32_t model, const char* cond, const c
     if (idx < 0 || idx >= (int)R.models.size()) { err = "hipadj_model_set_continuous_callback: unknown model id (callbacks are attached to runtime-registered models)"; return HIPADJ_ERR_INVALID_ARG; }
     UserModelSrc& m = R.models[idx];
     const bool hc = cond && *cond, ha = affect && *affect;
-    if (!hc && !ha) { m.cc_cond.clear(); m.cc_affect.clear(); m.cc_maxev = 0; m.rev++; return HIPADJ_OK; }
+    if (!hc && !ha) { m.cc_cond.clear(); m.cc_affect.clear(); m.cc_maxev = 0; m.cc_dir = 0; m.rev++; return HIPADJ_OK; }
     if (!hc) { err = "hipadj_model_set_continuous_callback: a condition body is needed (it assigns `c`; the event is its zero crossing)"; return HIPADJ_ERR_INVALID_ARG; }
     if (m.wide) { err = "hipadj_model_set_continuous_callback: offered for the lane-per-trajectory models (hipadj_model_register); a wide model takes preset-time events (hipadj_wmodel_set_affect)"; return HIPADJ_ERR_UNSUPPORTED; }
     if (m.has_mm || m.dae) { err = "hipadj_model_set_continuous_callback: not offered on a model with a mass matrix"; return HIPADJ_ERR_UNSUPPORTED; }
@@ -717,6 +718,16 @@ inline int user_set_continuous_callback(int32_t model, const char* cond, const c
     if (ha && std::string(affect).find("pn[") != std::string::npos) { err = "hipadj_model_set_continuous_callback: the affect of a ContinuousCallback edits the state (un); parameter-changing affects are offered at preset times (hipadj_model_set_affect)"; return HIPADJ_ERR_UNSUPPORTED; }
     if (ncond < 1 || ncond > 8) { err = "hipadj_model_set_vector_continuous_callback: 1 .. 8 condition components"; return HIPADJ_ERR_INVALID_ARG; }
     m.cc_cond = cond; m.cc_affect = ha ? affect : ""; m.cc_maxev = max_events > 0 ? max_events : 64; m.cc_ncond = ncond; m.rev++;
+    return HIPADJ_OK;
+}
+// ContinuousCallback(condition, affect!, affect_neg!) with one of the two affects `nothing`: +1 = only upcrossings fire (affect_neg! = nothing), -1 = only downcrossings, 0 = both
+inline int user_set_callback_direction(int32_t model, int32_t direction, std::string& err) {
+    UserRegistry& R = user_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const int idx = model - HIPADJ_MODEL_USER_BASE;
+    if (idx < 0 || idx >= (int)R.models.size() || R.models[idx].cc_cond.empty()) { err = "hipadj_model_set_callback_direction: the model carries no ContinuousCallback (hipadj_model_set_continuous_callback first)"; return HIPADJ_ERR_INVALID_ARG; }
+    if (direction < -1 || direction > 1) { err = "hipadj_model_set_callback_direction: direction is -1 (downcrossings), 0 (both) or +1 (upcrossings)"; return HIPADJ_ERR_INVALID_ARG; }
+    R.models[idx].cc_dir = direction; R.models[idx].rev++;
     return HIPADJ_OK;
 }
 inline int user_model_events(int32_t model) {

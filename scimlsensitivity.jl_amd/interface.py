@@ -112,6 +112,8 @@ def solve(ensprob, alg=RK4(), *, dt=None, saveat=None, sensealg=InterpolatingAdj
             raise ValueError("ContinuousCallback needs a runtime lane model (DeviceFunction): condition and affect are compiled next to its right-hand side")
         if _attached_callbacks.get(mid) != callback:      # (re-attaching bumps the model's revision: a new code object)
             _lib.set_model_continuous_callback(mid, callback.condition, callback.affect, callback.max_events, callback.ncond)
+            if callback.direction:
+                _lib.set_model_callback_direction(mid, callback.direction)
             _attached_callbacks[mid] = callback
         callback = None
     if callback is not None:       # DiscreteCallback at preset times: a chain of ordinary pieces (events.py)

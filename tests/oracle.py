@@ -30,7 +30,7 @@ class OrcConfig(C.Structure):
         ("quad_abstol", C.c_double), ("quad_reltol", C.c_double),
         ("no_start", C.c_int), ("cont_cost", C.c_int),
         ("loss_scale", C.c_double), ("dloss_id", C.c_int), ("reference_literal", C.c_int), ("event_kind", C.c_int),
-        ("ev_max", C.c_int), ("ev_dl", C.POINTER(C.c_double)), ("ev_dr", C.POINTER(C.c_double)),
+        ("ev_max", C.c_int), ("ev_dl", C.POINTER(C.c_double)), ("ev_dr", C.POINTER(C.c_double)), ("event_dir", C.c_int),
     ]
 
 
@@ -107,7 +107,7 @@ class Problem:
     def __init__(self, model, alg="INTERPOLATING", stepper="RK4", t0=0.0, t1=1.0, dt=0.01, abstol=1e-6,
                  reltol=1e-3, save_times=(), loss="COTANGENT", loss_shift=0.0, checkpointing=False,
                  checkpoints=None, quad_abstol=1e-6, quad_reltol=1e-3, no_start=False, dims=(0, 0, 0, 0), cont_cost=0, loss_scale=0.0, dloss_id=0,
-                 reference_literal=False, event_kind=0):
+                 reference_literal=False, event_kind=0, event_dir=0):
         self.model = model
         self.dims = tuple(dims)
         self.n, self.np = model_sizes(model, dims)
@@ -128,7 +128,8 @@ class Problem:
         c.no_start = int(no_start)
         c.cont_cost = int(cont_cost)
         c.loss_scale, c.dloss_id, c.reference_literal = float(loss_scale), int(dloss_id), int(bool(reference_literal))
-        c.event_kind = int(event_kind)      # ContinuousCallback of adjoint_oracle.h (1 .. 4)
+        c.event_kind = int(event_kind)      # ContinuousCallback of adjoint_oracle.h
+        c.event_dir = int(event_dir)        # 0 both directions, +1 upcrossings only, -1 downcrossings only
         self.cfg = c
 
     def set_event_cotangents(self, dl=None, dr=None):

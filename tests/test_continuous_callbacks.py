@@ -346,6 +346,43 @@ def test_fuzz_lane_bodies_vs_oracle(seed):
         assert np.max(np.abs(out[i] - rout)) < 1e-5 * max(1.0, np.max(np.abs(rout)))
 
 
+# ---- ContinuousCallback(condition, affect!, affect_neg!) with one affect `nothing`: only one crossing direction fires --------------------------------------------------
+@pytest.mark.parametrize("direction,nev", [(0, 3), (1, 1), (-1, 2)])
+def test_oracle_direction_against_finite_differences(direction, nev):
+    """the damped pendulum (ORC_MODEL_PENDULUM) with c = angle, affect u2 <- p3 u2: the angle crosses zero downward, upward, downward within (0, 8).  Which crossings fire, and
+    the gradient against central differences of the oracle's own forward solve (an independent check of the reverse jump: 1e-8 is the differences' precision)"""
+    u0 = np.array([1.2, 0.0]); p = np.array([1.0, -0.1, 0.8]); ts = np.array([2.0, 5.0, 8.0]); d = np.array([[1.0, -0.5], [0.3, 0.7], [-1.0, 0.4]])
+    kw = dict(alg="INTERPOLATING", stepper="TSIT5", t0=0.0, t1=8.0, dt=0.0, save_times=ts, event_kind=8, event_dir=direction)
+    pr = O.Problem("PENDULUM", abstol=1e-12, reltol=1e-12, **kw)
+    t, ul, ur = pr.event_states(u0, p)
+    assert len(t) == nev and (direction == 0 or np.all(np.sign(ul[:, 1]) == direction))          # (p1 > 0: the angle rises where u2 > 0)
+    du0, dp, _ = pr.adjoint(u0, p, d)
+    fine = O.Problem("PENDULUM", abstol=1e-13, reltol=1e-13, **kw)
+    G = lambda a, b: float(np.sum(fine.forward(a, b)[0] * d))
+    fd = [(G(u0 + e, p) - G(u0 - e, p)) / 2e-6 for e in 1e-6 * np.eye(2)] + [(G(u0, p + e) - G(u0, p - e)) / 2e-6 for e in 1e-6 * np.eye(3)]
+    assert np.max(np.abs(np.concatenate([du0, dp]) - fd)) < 2e-7
+    for oalg in ("BACKSOLVE", "GAUSS", "QUADRATURE"):
+        a = O.Problem("PENDULUM", abstol=1e-12, reltol=1e-12, **{**kw, "alg": oalg}, **QTOL).adjoint(u0, p, d)
+        assert relc(a[0], du0) < 1e-7 and relc(a[1], dp) < 1e-7
+
+
+def test_direction_registration_and_kernels():
+    from scimlsensitivity_jl_amd import _lib
+    m, cond, aff = UM.EVENTS[8]
+    mid = _lib.register_model("cc_dir_host", m["n"], m["np"], m["f"])
+    with pytest.raises(_lib.HipadjError) as ei:
+        _lib.set_model_callback_direction(mid, 1)                       # no callback yet
+    assert ei.value.status == _lib.ERR_INVALID_ARG
+    _lib.set_model_continuous_callback(mid, cond, aff, 8)
+    with pytest.raises(_lib.HipadjError):
+        _lib.set_model_callback_direction(mid, 2)
+    L = _lib.load()
+    for direction in (1, -1, 0):
+        _lib.set_model_callback_direction(mid, direction)
+        cfg = E.make_config("cc_dir_host", "interpolating", 53, 0.0, 8.0, 0.0, [2.0, 8.0], stepper=TS5, abstol=1e-8, reltol=1e-8)
+        assert L.hipadj_model_check_config(C.byref(cfg)) == _lib.OK, L.hipadj_last_error(None)
+
+
 # ---- the C ABI without a device ------------------------------------------------------------------------------------------------------------------------------------------
 def test_registration_entry_point_and_its_refusals():
     from scimlsensitivity_jl_amd import _lib

@@ -428,3 +428,31 @@ def test_fuzz_events_device_vs_oracle(sa, seed):
         bar = 1e-5 if c["stepper"] == "ROS23" else 1e-6
         assert np.max(np.abs(a - b)) <= bar * np.max(np.abs(b)), (seed, i, c["kind"], alg, c["stepper"], c["ck"], c["saved"])      # (a terminating event ahead of every loss time: both are exactly zero)
         assert np.max(np.abs(out[i] - rout)) < 1e-5 * max(1.0, np.max(np.abs(rout)))
+
+
+@pytest.mark.parametrize("alg,oalg", ALGS)
+@pytest.mark.parametrize("direction,nev", [(0, 3), (1, 1), (-1, 2)])
+def test_callback_direction(sa, direction, nev, alg, oalg):
+    """ContinuousCallback(condition, affect!, affect_neg!) with one affect `nothing` (hipadj_model_set_callback_direction): the damped pendulum, c = angle, affect u2 <- p3 u2 —
+    the angle crosses zero downward, upward, downward within (0, 8); which crossings fire and the gradients, an ensemble of perturbed pendulums against the oracle (whose
+    gradient for this problem is checked against finite differences in the CPU suite)"""
+    rng = np.random.default_rng(3)
+    N = 24
+    u0 = np.array([1.2, 0.0]) + 0.05 * rng.standard_normal((N, 2)); p = np.array([1.0, -0.1, 0.8]) * (1 + 0.02 * rng.standard_normal((N, 3)))
+    u0[0] = [1.2, 0.0]; p[0] = [1.0, -0.1, 0.8]
+    ts = np.array([2.0, 5.0, 8.0]); d = rng.standard_normal((N, 3, 2))
+    m, cond, aff = UM.EVENTS[8]
+    key = ("dir", direction)
+    if key not in _registered:
+        f = sa.DeviceFunction(f"cc_pendulum_dir{direction + 1}", m["n"], m["np"], m["f"])
+        f.set_continuous_callback(cond, aff, direction=direction)
+        _registered[key] = f
+    sol = sa.solve(sa.EnsembleProblem(sa.ODEProblem(_registered[key], u0[0], (0.0, 8.0), p[0]), u0, p), sa.Tsit5(), saveat=ts, sensealg=sens(sa, alg), abstol=1e-11, reltol=1e-11)
+    t, ul, ur, cnt = sol.engine.event_states()
+    assert cnt[0] == nev and (direction == 0 or np.all(np.sign(ul[0, :nev, 1]) == direction))
+    du0, dp = sa.adjoint_sensitivities(sol, sa.Tsit5(), t=ts, dgdu_discrete=d)
+    sol.engine.close()
+    ref = O.Problem("PENDULUM", alg=oalg, stepper="TSIT5", t0=0.0, t1=8.0, dt=0.0, abstol=1e-11, reltol=1e-11, save_times=ts, event_kind=8, event_dir=direction, **QTOL)
+    rdu0, rdp, rout, _ = ref.adjoint_ensemble(u0, p, d)
+    a = np.concatenate([du0, dp], axis=1); b = np.concatenate([rdu0, rdp], axis=1)
+    assert np.max(np.abs(a - b) / np.max(np.abs(b), axis=1, keepdims=True)) < 1e-6

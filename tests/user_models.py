@@ -92,3 +92,7 @@ VECTOR_EVENTS = {  # event_kind -> (model, ncond, condition body, affect body)
     5: (BALL2D, 2, "out[0] = u[0]; out[1] = (u[2] - 10.0) * u[2];", "if (idx == 0) un[1] = -p[1] * u[1]; else un[3] = -p[1] * u[3];"),      # :80-96
     6: (BALL2D, 2, "out[0] = sin(t); out[1] = cos(t);", "un[0] = 0.5; un[1] = 1.0; un[2] = 0.0; un[3] = 0.0;"),                          # :100-116
 }
+PENDULUM = dict(  # `pendulum_eom` of test/Core7/adjoint_param.jl:6-10 (oracle: ORC_MODEL_PENDULUM); p3 enters through the affect of event 8 only
+    n=2, np=3,
+    f="du[0] = p[0] * u[1]; du[1] = -sin(u[0]) + (-p[0] * sin(u[0]) + p[1] * u[1]);")
+EVENTS[8] = (PENDULUM, "c = u[0];", "un[1] = p[2] * u[1];")      # NOT from the reference: an oscillating state, the condition crossed in both directions (the problem for `direction`)
